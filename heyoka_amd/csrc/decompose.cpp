@@ -1,0 +1,624 @@
+// Taylor decomposition implementation. See decompose.hpp for the reference citations.
+#include "decompose.hpp"
+
+#include <algorithm>
+#include <cassert>
+#include <charconv>
+#include <cmath>
+#include <deque>
+#include <limits>
+#include <optional>
+#include <set>
+#include <unordered_map>
+#include <unordered_set>
+
+namespace heyoka_amd
+{
+
+std::uint32_t uname_to_index(const std::string &s)
+{
+    assert(s.size() > 2u && s[0] == 'u' && s[1] == '_');
+    std::uint32_t value = 0;
+    const auto ret = std::from_chars(s.data() + 2, s.data() + s.size(), value);
+    if (ret.ec != std::errc{} || ret.ptr != s.data() + s.size()) {
+        throw std::invalid_argument("Cannot extract a u variable index from the string '" + s + "'");
+    }
+    return value;
+}
+
+namespace
+{
+
+std::string uname(std::size_t i)
+{
+    return "u_" + std::to_string(i);
+}
+
+bool is_negative_one(const expression &e)
+{
+    return e.is_number() && e.num() == -1;
+}
+
+bool is_kind(const expression &e, func_kind k)
+{
+    return e.is_func() && e.fn().kind() == k;
+}
+
+// Apply a branch transformation to every expression of a vector with a common cache.
+std::vector<expression> transform_all(const std::vector<expression> &v_ex,
+                                      const std::function<expression(const expression &)> &tfunc)
+{
+    ptr_ex_map cache;
+    std::vector<expression> ret;
+    ret.reserve(v_ex.size());
+    for (const auto &e : v_ex) {
+        ret.push_back(traverse_transform_nodes(cache, e, {}, tfunc));
+    }
+    return ret;
+}
+
+// x**y -> exp(y*log(x)) if y is not a number (reference: src/taylor_01.cpp:806-840).
+std::vector<expression> pow_to_explog(const std::vector<expression> &v_ex)
+{
+    return transform_all(v_ex, [](const expression &ex) {
+        const auto &f = ex.fn();
+        if (f.kind() == func_kind::pow && !f.args()[1].is_number()) {
+            // NOTE: no constant folding for the log of a numerical base.
+            return exp(f.args()[1] * detail::make_func(func_kind::log, {f.args()[0]}));
+        }
+        return ex;
+    });
+}
+
+// Sums with negated terms -> subtractions (reference: src/math/sum.cpp:461-544).
+std::vector<expression> sum_to_sub(const std::vector<expression> &v_ex)
+{
+    return transform_all(v_ex, [](const expression &ex) {
+        const auto &fn = ex.fn();
+        if (fn.kind() != func_kind::sum) {
+            return ex;
+        }
+
+        auto new_args(fn.args());
+        const auto fpart = [](const expression &arg) {
+            if (is_kind(arg, func_kind::prod) && arg.fn().args().size() >= 2u && arg.fn().args()[0].is_number()) {
+                return !is_negative_one(arg.fn().args()[0]);
+            }
+            return true;
+        };
+        const auto it = std::stable_partition(new_args.begin(), new_args.end(), fpart);
+
+        if (it == new_args.end()) {
+            return ex;
+        }
+
+        std::vector<expression> sub_args;
+        for (auto cit = it; cit != new_args.end(); ++cit) {
+            const auto &f = cit->fn();
+            std::vector<expression> tmp_args(f.args().begin() + 1, f.args().end());
+            sub_args.push_back(prod(std::move(tmp_args)));
+        }
+
+        auto st = sum(std::move(sub_args));
+
+        if (it == new_args.begin()) {
+            return prod({expression{-1.}, std::move(st)});
+        }
+
+        new_args.erase(it, new_args.end());
+        auto mend = sum(std::move(new_args));
+        return detail::sub(std::move(mend), std::move(st));
+    });
+}
+
+// Re-organise a long associative function into nested invocations with at most 'split' arguments
+// (reference: include/heyoka/detail/udf_split.hpp:49-100).
+expression udf_split(const expression &e, func_kind k, std::uint32_t split)
+{
+    assert(split >= 2u);
+    auto cur = e;
+    while (true) {
+        if (!is_kind(cur, k) || cur.fn().args().size() <= split) {
+            return cur;
+        }
+
+        std::vector<expression> ret_seq, tmp;
+        for (const auto &arg : cur.fn().args()) {
+            tmp.push_back(arg);
+            if (tmp.size() == split) {
+                ret_seq.push_back(detail::make_func(k, std::move(tmp)));
+                tmp.clear();
+            }
+        }
+        if (!tmp.empty()) {
+            if (tmp.size() == 1u) {
+                ret_seq.push_back(std::move(tmp[0]));
+            } else {
+                ret_seq.push_back(detail::make_func(k, std::move(tmp)));
+            }
+        }
+        cur = detail::make_func(k, std::move(ret_seq));
+    }
+}
+
+// Reference: src/expression_basic.cpp:1177-1196 (split on 8).
+std::vector<expression> split_sums_for_decompose(const std::vector<expression> &v_ex)
+{
+    return transform_all(v_ex, [](const expression &ex) { return udf_split(ex, func_kind::sum, 8); });
+}
+
+// Reference: src/expression_basic.cpp:1198-1213.
+std::vector<expression> split_prods_for_decompose(const std::vector<expression> &v_ex, std::uint32_t split)
+{
+    return transform_all(v_ex, [split](const expression &ex) { return udf_split(ex, func_kind::prod, split); });
+}
+
+// sum({x**2, y**2, ...}) -> sum_sq({x, y, ...}) (reference: src/math/sum.cpp:385-455).
+std::vector<expression> sums_to_sum_sqs_for_decompose(const std::vector<expression> &v_ex)
+{
+    return transform_all(v_ex, [](const expression &ex) {
+        if (!is_kind(ex, func_kind::sum)) {
+            return ex;
+        }
+        std::vector<expression> new_args;
+        for (const auto &arg : ex.fn().args()) {
+            if (is_kind(arg, func_kind::pow) && arg.fn().args()[1].is_number() && arg.fn().args()[1].num() == 2) {
+                new_args.push_back(arg.fn().args()[0]);
+            } else {
+                return ex;
+            }
+        }
+        return detail::sum_sq(std::move(new_args));
+    });
+}
+
+// prod with pow(., -1) factors -> div (reference: src/math/prod.cpp:753-908).
+std::vector<expression> prod_to_div_taylor_diff(const std::vector<expression> &v_ex)
+{
+    return transform_all(v_ex, [](const expression &ex) {
+        if (!is_kind(ex, func_kind::prod)) {
+            return ex;
+        }
+
+        // true -> keep in the numerator.
+        const auto fpart = [](const expression &e) {
+            if (!is_kind(e, func_kind::pow)) {
+                return true;
+            }
+            const auto &expo = e.fn().args()[1];
+            return !(expo.is_number() && expo.num() == -1);
+        };
+
+        auto new_args(ex.fn().args());
+        const auto it = std::stable_partition(new_args.begin(), new_args.end(), fpart);
+        if (it == new_args.end()) {
+            return ex;
+        }
+
+        std::vector<expression> div_args;
+        for (auto cit = it; cit != new_args.end(); ++cit) {
+            const auto &f = cit->fn();
+            div_args.push_back(pow(f.args()[0], expression{-f.args()[1].num()}));
+        }
+        auto divisor = prod(std::move(div_args));
+
+        new_args.erase(it, new_args.end());
+        auto num = prod(std::move(new_args));
+
+        return detail::div(std::move(num), std::move(divisor));
+    });
+}
+
+// Decomposition of a single function whose arguments have already been decomposed
+// (reference: func_taylor_decompose_impl(), src/func.cpp:392-420; sin/cos custom
+// decompositions src/math/sin.cpp:115-133, src/math/cos.cpp:116-134).
+std::size_t func_taylor_decompose(expression f_ex, taylor_dc_t &dc)
+{
+    const auto &f = f_ex.fn();
+
+    if (f.kind() == func_kind::sin || f.kind() == func_kind::cos) {
+        const auto other = (f.kind() == func_kind::sin) ? func_kind::cos : func_kind::sin;
+        // NOTE: the argument cannot be a number here (constant folding at construction), thus
+        // building the partner function directly never folds.
+        dc.emplace_back(detail::make_func(other, {f.args()[0]}), std::vector<std::uint32_t>{});
+        dc.emplace_back(std::move(f_ex), std::vector<std::uint32_t>{});
+
+        (dc.end() - 2)->second.push_back(static_cast<std::uint32_t>(dc.size() - 1u));
+        (dc.end() - 1)->second.push_back(static_cast<std::uint32_t>(dc.size() - 2u));
+
+        return dc.size() - 1u;
+    }
+
+    const auto ret = dc.size();
+    dc.emplace_back(std::move(f_ex), std::vector<std::uint32_t>{});
+    return ret;
+}
+
+// Iterative post-order decomposition with a pointer cache
+// (reference: expression_decompose_impl(), src/expression_decompose.cpp:43-210).
+std::optional<std::size_t> taylor_decompose(std::unordered_map<const void *, std::size_t> &func_map,
+                                            const expression &e, taylor_dc_t &dc)
+{
+    std::vector<std::pair<const expression *, bool>> stack;
+    std::vector<std::optional<std::optional<std::size_t>>> out_stack;
+
+    stack.emplace_back(&e, false);
+
+    while (!stack.empty()) {
+        const auto [cur_ex, visited] = stack.back();
+        stack.pop_back();
+
+        if (cur_ex->is_func()) {
+            const auto &f = cur_ex->fn();
+            const auto *f_id = f.get_ptr();
+
+            if (!visited) {
+                if (const auto it = func_map.find(f_id); it != func_map.end()) {
+                    out_stack.emplace_back(std::optional<std::size_t>{it->second});
+                    continue;
+                }
+            }
+
+            if (visited) {
+                std::vector<expression> new_args;
+                const auto n_args = f.args().size();
+                new_args.reserve(n_args);
+                for (std::size_t i = 0; i < n_args; ++i) {
+                    assert(!out_stack.empty() && out_stack.back());
+                    const auto opt_idx = *out_stack.back();
+                    if (opt_idx) {
+                        new_args.emplace_back(uname(*opt_idx));
+                    } else {
+                        new_args.push_back(f.args()[i]);
+                    }
+                    out_stack.pop_back();
+                }
+
+                const auto ret = func_taylor_decompose(expression{f.copy_with_new_args(std::move(new_args))}, dc);
+                if (ret == 0u || ret >= dc.size()) {
+                    throw std::invalid_argument("Invalid value returned by the Taylor decomposition of a function");
+                }
+
+                func_map.emplace(f_id, ret);
+
+                assert(!out_stack.empty() && !out_stack.back());
+                out_stack.back().emplace(std::optional<std::size_t>{ret});
+            } else {
+                stack.emplace_back(cur_ex, true);
+                for (const auto &ex : f.args()) {
+                    stack.emplace_back(&ex, false);
+                }
+                out_stack.emplace_back();
+            }
+        } else {
+            out_stack.emplace_back(std::optional<std::size_t>{});
+        }
+    }
+
+    assert(out_stack.size() == 1u && out_stack.back());
+    return *out_stack.back();
+}
+
+std::uint32_t remap_uidx(const std::unordered_map<std::string, std::string> &m, std::uint32_t idx)
+{
+    const auto it = m.find(uname(idx));
+    assert(it != m.end());
+    return uname_to_index(it->second);
+}
+
+// Common subexpression elimination (reference: taylor_decompose_cse(), src/taylor_01.cpp:315-443).
+// NOTE: hidden deps are not considered when comparing subexpressions.
+taylor_dc_t taylor_decompose_cse(const taylor_dc_t &v_ex, std::size_t n_eq)
+{
+    assert(v_ex.size() >= n_eq * 2u);
+
+    taylor_dc_t new_dc;
+    std::unordered_map<expression, std::size_t, expression_hash> ex_map;
+    std::unordered_map<std::string, std::string> uvars_rename;
+    ptr_ex_map cache;
+
+    for (std::size_t i = 0; i < n_eq; ++i) {
+        new_dc.push_back(v_ex[i]);
+        uvars_rename.emplace(uname(i), uname(i));
+    }
+
+    for (auto i = n_eq; i < v_ex.size() - n_eq; ++i) {
+        const auto &[orig_ex, orig_deps] = v_ex[i];
+
+        auto new_ex = rename_variables(cache, orig_ex, uvars_rename);
+        // NOTE: the cache is keyed on node identity, and each element of v_ex is a distinct
+        // top-level node renamed with a *growing* map: clear the cache between elements.
+        cache.clear();
+
+        if (const auto it = ex_map.find(new_ex); it == ex_map.end()) {
+            new_dc.emplace_back(new_ex, orig_deps);
+            ex_map.emplace(std::move(new_ex), new_dc.size() - 1u);
+            uvars_rename.emplace(uname(i), uname(new_dc.size() - 1u));
+        } else {
+            uvars_rename.emplace(uname(i), uname(it->second));
+        }
+    }
+
+    for (auto i = v_ex.size() - n_eq; i < v_ex.size(); ++i) {
+        const auto &[orig_ex, orig_deps] = v_ex[i];
+        assert(!orig_ex.is_func() && orig_deps.empty());
+        new_dc.emplace_back(rename_variables(cache, orig_ex, uvars_rename), orig_deps);
+        cache.clear();
+    }
+
+    for (auto &[_, deps] : new_dc) {
+        for (auto &idx : deps) {
+            idx = remap_uidx(uvars_rename, idx);
+        }
+    }
+
+    return new_dc;
+}
+
+// Breadth-first (Kahn) topological re-sort (reference: taylor_sort_dc(), src/taylor_01.cpp:454-645).
+taylor_dc_t taylor_sort_dc(const taylor_dc_t &dc, std::size_t n_eq)
+{
+    assert(dc.size() >= n_eq * 2u);
+
+    // Vertex 0 = root, vertex i + 1 = u variable i.
+    const auto n_vert = dc.size() - n_eq + 1u;
+    std::vector<std::vector<std::size_t>> out_edges(n_vert);
+    std::vector<std::size_t> in_degree(n_vert, 0);
+
+    const auto add_edge = [&](std::size_t from, std::size_t to) {
+        out_edges[from].push_back(to);
+        ++in_degree[to];
+    };
+
+    for (std::size_t i = 0; i < n_eq; ++i) {
+        add_edge(0, i + 1u);
+    }
+
+    for (auto i = n_eq; i < dc.size() - n_eq; ++i) {
+        const auto vars = get_variables(dc[i].first);
+        if (vars.empty()) {
+            add_edge(0, i + 1u);
+        } else {
+            for (const auto &var : vars) {
+                add_edge(uname_to_index(var) + 1u, i + 1u);
+            }
+        }
+    }
+
+    std::vector<std::size_t> v_idx;
+    std::deque<std::size_t> tmp;
+    tmp.push_back(0);
+
+    while (!tmp.empty()) {
+        const auto v = tmp.front();
+        tmp.pop_front();
+        v_idx.push_back(v);
+
+        // NOTE: out edges processed in order of target vertex.
+        auto targets = out_edges[v];
+        std::sort(targets.begin(), targets.end());
+
+        for (const auto t : targets) {
+            assert(in_degree[t] > 0u);
+            if (--in_degree[t] == 0u) {
+                tmp.push_back(t);
+            }
+        }
+    }
+
+    assert(v_idx.size() == n_vert);
+
+    for (std::size_t i = 0; i + 1u < v_idx.size(); ++i) {
+        v_idx[i] = v_idx[i + 1u] - 1u;
+    }
+    v_idx.resize(dc.size());
+    for (auto i = dc.size() - n_eq; i < dc.size(); ++i) {
+        v_idx[i] = i;
+    }
+
+    std::unordered_map<std::string, std::string> remap;
+    for (std::size_t i = 0; i < n_eq; ++i) {
+        assert(v_idx[i] == i);
+        remap.emplace(uname(i), uname(i));
+    }
+    for (auto i = n_eq; i < v_idx.size() - n_eq; ++i) {
+        remap.emplace(uname(v_idx[i]), uname(i));
+    }
+
+    taylor_dc_t retval;
+    retval.reserve(dc.size());
+    for (const auto idx : v_idx) {
+        const auto &[ex, deps] = dc[idx];
+        ptr_ex_map cache;
+        auto new_ex = rename_variables(cache, ex, remap);
+        std::vector<std::uint32_t> new_deps;
+        new_deps.reserve(deps.size());
+        for (const auto d : deps) {
+            new_deps.push_back(remap_uidx(remap, d));
+        }
+        retval.emplace_back(std::move(new_ex), std::move(new_deps));
+    }
+
+    return retval;
+}
+
+} // namespace
+
+void validate_ode_sys(const std::vector<std::pair<expression, expression>> &sys)
+{
+    if (sys.empty()) {
+        throw std::invalid_argument("Cannot integrate a system of zero equations");
+    }
+
+    std::vector<expression> sys_rhs;
+    std::unordered_set<std::string> lhs_vars_set;
+
+    for (const auto &[lhs, rhs] : sys) {
+        sys_rhs.push_back(rhs);
+        if (!lhs.is_variable()) {
+            throw std::invalid_argument("Invalid system of differential equations detected: the "
+                                        "left-hand side contains the expression '"
+                                        + lhs.to_string() + "', which is not a variable");
+        }
+        const auto &name = lhs.var_name();
+        if (name.rfind("__", 0) == 0) {
+            throw std::invalid_argument("Invalid system of differential equations detected: the variable '" + name
+                                        + "' appears in the left-hand side, but variables beginning with '__' are "
+                                          "reserved for internal use");
+        }
+        if (!lhs_vars_set.insert(name).second) {
+            throw std::invalid_argument("Invalid system of differential equations detected: the variable '" + name
+                                        + "' appears in the left-hand side twice");
+        }
+    }
+
+    for (const auto &var : get_variables(sys_rhs)) {
+        if (lhs_vars_set.count(var) == 0u) {
+            throw std::invalid_argument("Invalid system of differential equations detected: the variable '" + var
+                                        + "' appears in the right-hand side but not in the left-hand side");
+        }
+    }
+}
+
+taylor_dc_t taylor_decompose_sys(const std::vector<std::pair<expression, expression>> &sys)
+{
+    const auto n_eq = sys.size();
+
+    std::unordered_map<std::string, std::string> repl_map;
+    for (std::size_t i = 0; i < n_eq; ++i) {
+        repl_map.emplace(sys[i].first.var_name(), uname(i));
+    }
+
+    std::vector<expression> all_ex;
+    all_ex.reserve(n_eq);
+    for (const auto &[lhs, rhs] : sys) {
+        all_ex.push_back(rhs);
+    }
+
+    all_ex = pow_to_explog(all_ex);
+    all_ex = sum_to_sub(all_ex);
+    all_ex = split_sums_for_decompose(all_ex);
+    all_ex = sums_to_sum_sqs_for_decompose(all_ex);
+    all_ex = prod_to_div_taylor_diff(all_ex);
+    all_ex = split_prods_for_decompose(all_ex, 2);
+
+    all_ex = rename_variables(all_ex, repl_map);
+
+    taylor_dc_t u_vars_defs;
+    u_vars_defs.reserve(n_eq);
+    for (const auto &[lhs, rhs] : sys) {
+        u_vars_defs.emplace_back(lhs, std::vector<std::uint32_t>{});
+    }
+
+    taylor_dc_t outs;
+    outs.reserve(n_eq);
+
+    std::unordered_map<const void *, std::size_t> func_map;
+    for (std::size_t i = 0; i < n_eq; ++i) {
+        const auto &ex = all_ex[i];
+        if (const auto dres = taylor_decompose(func_map, ex, u_vars_defs)) {
+            outs.emplace_back(expression{uname(*dres)}, std::vector<std::uint32_t>{});
+        } else {
+            outs.emplace_back(ex, std::vector<std::uint32_t>{});
+        }
+    }
+
+    u_vars_defs.insert(u_vars_defs.end(), outs.begin(), outs.end());
+
+    u_vars_defs = taylor_decompose_cse(u_vars_defs, n_eq);
+    u_vars_defs = taylor_sort_dc(u_vars_defs, n_eq);
+
+    // NOTE: sincos_combine_taylor() (src/detail/sincos_combine.cpp) only selects a fused
+    // sin+cos evaluation at order 0: it does not change the structure of the decomposition. The
+    // HIP emitter always evaluates sin/cos pairs with sincos().
+
+    // Numbers -> num_identity (reference: src/taylor_01.cpp:788-804).
+    for (auto i = n_eq; i < u_vars_defs.size() - n_eq; ++i) {
+        auto &[ex, deps] = u_vars_defs[i];
+        if (ex.is_number()) {
+            ex = detail::num_identity(ex);
+            deps.clear();
+        }
+    }
+
+    return u_vars_defs;
+}
+
+namespace
+{
+
+operand make_operand(const expression &e)
+{
+    operand op;
+    if (e.is_number()) {
+        op.type = operand::kind::num;
+        op.value = e.num();
+    } else if (e.is_param()) {
+        op.type = operand::kind::par;
+        op.idx = e.par_idx();
+    } else if (e.is_variable()) {
+        op.type = operand::kind::uvar;
+        op.idx = uname_to_index(e.var_name());
+    } else {
+        throw std::invalid_argument("Invalid operand in a Taylor decomposition: '" + e.to_string() + "'");
+    }
+    return op;
+}
+
+} // namespace
+
+taylor_program make_program(const taylor_dc_t &dc, std::uint32_t n_eq)
+{
+    assert(dc.size() >= 2u * n_eq);
+
+    taylor_program prog;
+    prog.n_eq = n_eq;
+    prog.n_u = static_cast<std::uint32_t>(dc.size() - n_eq);
+
+    std::vector<expression> all;
+    for (std::size_t i = n_eq; i < dc.size(); ++i) {
+        all.push_back(dc[i].first);
+    }
+    prog.n_par = get_param_size(all);
+    prog.time_dependent = is_time_dependent(all);
+
+    for (std::size_t i = n_eq; i < prog.n_u; ++i) {
+        const auto &[ex, deps] = dc[i];
+        if (!ex.is_func()) {
+            throw std::invalid_argument("Invalid Taylor decomposition: the definition of a u variable is not a function");
+        }
+        dc_node n;
+        n.kind = ex.fn().kind();
+        for (const auto &a : ex.fn().args()) {
+            n.args.push_back(make_operand(a));
+            if (n.args.back().type == operand::kind::uvar && n.args.back().idx >= i) {
+                throw std::invalid_argument("Invalid Taylor decomposition: forward reference to a u variable");
+            }
+        }
+        n.deps = deps;
+        prog.nodes.push_back(std::move(n));
+    }
+
+    for (std::size_t i = prog.n_u; i < dc.size(); ++i) {
+        prog.sv_defs.push_back(make_operand(dc[i].first));
+    }
+
+    return prog;
+}
+
+std::uint32_t taylor_order_from_tol(double tol)
+{
+    auto order_f = std::ceil(-std::log(tol) / 2 + 1);
+    if (!std::isfinite(order_f)) {
+        throw std::invalid_argument(
+            "The computation of the Taylor order in an adaptive Taylor stepper produced a non-finite value");
+    }
+    order_f = std::max(2., order_f);
+    if (order_f > static_cast<double>(std::numeric_limits<std::uint32_t>::max())) {
+        throw std::overflow_error("The computation of the Taylor order in an adaptive Taylor stepper resulted "
+                                  "in an overflow condition");
+    }
+    return static_cast<std::uint32_t>(order_f);
+}
+
+} // namespace heyoka_amd

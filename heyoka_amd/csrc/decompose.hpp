@@ -1,0 +1,62 @@
+// Taylor decomposition of an ODE system into elementary subexpressions ("u variables").
+//
+// Reference semantics: taylor_decompose_sys() and its rewrite pipeline,
+// src/taylor_01.cpp:848-1008 (+ CSE :315-443, BFS topological sort :454-645),
+// src/math/sum.cpp:428-544, src/math/prod.cpp:736-908, src/expression_basic.cpp:1177-1231,
+// include/heyoka/detail/udf_split.hpp:49-100, src/expression_decompose.cpp:43-210.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "expression.hpp"
+
+namespace heyoka_amd
+{
+
+// Same shape as the reference's taylor_dc_t (include/heyoka/detail/fwd_decl.hpp:63):
+// first n_eq entries = state variables, middle = one elementary function each (+ hidden deps),
+// last n_eq entries = definitions of the derivatives of the state variables.
+using taylor_dc_t = std::vector<std::pair<expression, std::vector<std::uint32_t>>>;
+
+taylor_dc_t taylor_decompose_sys(const std::vector<std::pair<expression, expression>> &sys);
+
+// Reference: detail::validate_ode_sys() (src/detail/validate_ode_sys.cpp).
+void validate_ode_sys(const std::vector<std::pair<expression, expression>> &sys);
+
+// Parse the index out of a "u_123" variable name.
+std::uint32_t uname_to_index(const std::string &);
+
+// --- Flattened, backend-facing form of a decomposition. ---
+struct operand {
+    enum class kind : std::uint8_t { uvar = 0, num = 1, par = 2 };
+    kind type = kind::num;
+    std::uint32_t idx = 0; // u-variable index or parameter index.
+    double value = 0;      // numerical value (type == num).
+};
+
+struct dc_node {
+    func_kind kind;
+    std::vector<operand> args;
+    std::vector<std::uint32_t> deps; // hidden dependencies (u-variable indices).
+};
+
+struct taylor_program {
+    std::uint32_t n_eq = 0;
+    std::uint32_t n_u = 0;
+    std::uint32_t n_par = 0;
+    bool time_dependent = false;
+    // nodes[i] defines u variable n_eq + i.
+    std::vector<dc_node> nodes;
+    // sv_defs[i] = definition of the time derivative of state variable i.
+    std::vector<operand> sv_defs;
+};
+
+taylor_program make_program(const taylor_dc_t &dc, std::uint32_t n_eq);
+
+// Order of the Taylor method from the tolerance (reference: include/heyoka/detail/taylor_common.hpp:165-191).
+std::uint32_t taylor_order_from_tol(double tol);
+
+} // namespace heyoka_amd

@@ -1,0 +1,563 @@
+// Expression system implementation. See expression.hpp for the reference citations.
+#include "expression.hpp"
+
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <cstring>
+#include <optional>
+#include <set>
+#include <sstream>
+#include <iomanip>
+
+namespace heyoka_amd
+{
+
+const char *func_kind_name(func_kind k)
+{
+    switch (k) {
+        case func_kind::sum:
+            return "sum";
+        case func_kind::prod:
+            return "prod";
+        case func_kind::pow:
+            return "pow";
+        case func_kind::sub:
+            return "sub";
+        case func_kind::div:
+            return "div";
+        case func_kind::sum_sq:
+            return "sum_sq";
+        case func_kind::sin:
+            return "sin";
+        case func_kind::cos:
+            return "cos";
+        case func_kind::exp:
+            return "exp";
+        case func_kind::log:
+            return "log";
+        case func_kind::time:
+            return "time";
+        case func_kind::num_identity:
+            return "num_identity";
+    }
+    return "?";
+}
+
+namespace
+{
+
+inline void hash_combine(std::size_t &seed, std::size_t v)
+{
+    seed ^= v + 0x9e3779b97f4a7c15ull + (seed << 6) + (seed >> 2);
+}
+
+std::size_t hash_double(double x)
+{
+    // +0 and -0 compare equal: hash them identically.
+    if (x == 0) {
+        x = 0;
+    }
+    std::uint64_t bits = 0;
+    std::memcpy(&bits, &x, sizeof(bits));
+    return std::hash<std::uint64_t>{}(bits);
+}
+
+} // namespace
+
+func::func(func_kind k, std::vector<expression> args)
+{
+    auto node = std::make_shared<func_node>();
+    node->kind = k;
+    node->args = std::move(args);
+    std::size_t h = std::hash<int>{}(static_cast<int>(k) + 17);
+    for (const auto &a : node->args) {
+        hash_combine(h, a.hash());
+    }
+    node->hash = h;
+    m_ptr = std::move(node);
+}
+
+func func::copy_with_new_args(std::vector<expression> new_args) const
+{
+    return func(kind(), std::move(new_args));
+}
+
+std::size_t expression::hash() const
+{
+    switch (m_value.index()) {
+        case 0u:
+            return hash_double(num());
+        case 1u:
+            return std::hash<std::string>{}(var_name()) ^ 0x51ed270b;
+        case 2u:
+            return std::hash<std::uint32_t>{}(par_idx()) ^ 0x2545f491;
+        default:
+            return fn().hash();
+    }
+}
+
+bool operator==(const expression &a, const expression &b)
+{
+    if (a.value().index() != b.value().index()) {
+        return false;
+    }
+    switch (a.value().index()) {
+        case 0u: {
+            // NOTE: nan numbers compare equal to each other, so that CSE is well-behaved
+            // (reference: number equality in src/number.cpp).
+            const auto x = a.num(), y = b.num();
+            return x == y || (std::isnan(x) && std::isnan(y));
+        }
+        case 1u:
+            return a.var_name() == b.var_name();
+        case 2u:
+            return a.par_idx() == b.par_idx();
+        default: {
+            const auto &fa = a.fn();
+            const auto &fb = b.fn();
+            if (fa.get_ptr() == fb.get_ptr()) {
+                return true;
+            }
+            if (fa.hash() != fb.hash() || fa.kind() != fb.kind() || fa.args().size() != fb.args().size()) {
+                return false;
+            }
+            for (std::size_t i = 0; i < fa.args().size(); ++i) {
+                if (!(fa.args()[i] == fb.args()[i])) {
+                    return false;
+                }
+            }
+            return true;
+        }
+    }
+}
+
+std::string expression::to_string() const
+{
+    std::ostringstream oss;
+    switch (m_value.index()) {
+        case 0u:
+            oss << std::setprecision(17) << num();
+            break;
+        case 1u:
+            oss << var_name();
+            break;
+        case 2u:
+            oss << "p" << par_idx();
+            break;
+        default: {
+            const auto &f = fn();
+            oss << func_kind_name(f.kind()) << '(';
+            for (std::size_t i = 0; i < f.args().size(); ++i) {
+                if (i != 0u) {
+                    oss << ", ";
+                }
+                oss << f.args()[i].to_string();
+            }
+            oss << ')';
+        }
+    }
+    return oss.str();
+}
+
+namespace detail
+{
+
+expression make_func(func_kind k, std::vector<expression> args)
+{
+    return expression{func(k, std::move(args))};
+}
+
+expression sub(expression a, expression b)
+{
+    return make_func(func_kind::sub, {std::move(a), std::move(b)});
+}
+
+expression div(expression a, expression b)
+{
+    return make_func(func_kind::div, {std::move(a), std::move(b)});
+}
+
+expression sum_sq(std::vector<expression> args)
+{
+    return make_func(func_kind::sum_sq, std::move(args));
+}
+
+expression num_identity(expression e)
+{
+    return make_func(func_kind::num_identity, {std::move(e)});
+}
+
+} // namespace detail
+
+const expression time = detail::make_func(func_kind::time, {});
+
+// --- Operators (reference: src/expression_ops.cpp:34-91). ---
+expression operator+(expression e)
+{
+    return e;
+}
+
+expression operator-(const expression &e)
+{
+    if (e.is_number()) {
+        return expression{-e.num()};
+    }
+    return prod({expression{-1.}, e});
+}
+
+expression operator+(const expression &a, const expression &b)
+{
+    if (a.is_number() && b.is_number()) {
+        return expression{a.num() + b.num()};
+    }
+    return sum({a, b});
+}
+
+expression operator-(const expression &a, const expression &b)
+{
+    if (a.is_number() && b.is_number()) {
+        return expression{a.num() - b.num()};
+    }
+    return a + -b;
+}
+
+expression operator*(const expression &a, const expression &b)
+{
+    if (a.is_number() && b.is_number()) {
+        return expression{a.num() * b.num()};
+    }
+    return prod({a, b});
+}
+
+expression operator/(const expression &a, const expression &b)
+{
+    if (a.is_number() && b.is_number()) {
+        return expression{a.num() / b.num()};
+    }
+    return prod({a, pow(b, expression{-1.})});
+}
+
+// Reference: src/math/sum.cpp:548-601.
+expression sum(std::vector<expression> args)
+{
+    // Numbers to the end, fold them left to right.
+    const auto n_end_it
+        = std::stable_partition(args.begin(), args.end(), [](const expression &ex) { return !ex.is_number(); });
+
+    if (n_end_it != args.end()) {
+        for (auto it = n_end_it + 1; it != args.end(); ++it) {
+            *n_end_it = expression{n_end_it->num() + it->num()};
+        }
+        args.erase(n_end_it + 1, args.end());
+
+        if (n_end_it->num() == 0) {
+            if (args.size() == 1u) {
+                return std::move(*n_end_it);
+            }
+            args.pop_back();
+        }
+    }
+
+    if (args.empty()) {
+        return expression{0.};
+    }
+    if (args.size() == 1u) {
+        return std::move(args[0]);
+    }
+
+    // Numbers to the front (semi-canonical form).
+    std::stable_partition(args.begin(), args.end(), [](const expression &ex) { return ex.is_number(); });
+
+    return detail::make_func(func_kind::sum, std::move(args));
+}
+
+// Reference: src/math/prod.cpp:913-973.
+expression prod(std::vector<expression> args)
+{
+    const auto n_end_it
+        = std::stable_partition(args.begin(), args.end(), [](const expression &ex) { return !ex.is_number(); });
+
+    if (n_end_it != args.end()) {
+        for (auto it = n_end_it + 1; it != args.end(); ++it) {
+            *n_end_it = expression{n_end_it->num() * it->num()};
+        }
+        args.erase(n_end_it + 1, args.end());
+
+        if (n_end_it->num() == 1) {
+            if (args.size() == 1u) {
+                return std::move(*n_end_it);
+            }
+            args.pop_back();
+        } else if (n_end_it->num() == 0) {
+            return std::move(*n_end_it);
+        }
+    }
+
+    if (args.empty()) {
+        return expression{1.};
+    }
+    if (args.size() == 1u) {
+        return std::move(args[0]);
+    }
+
+    std::stable_partition(args.begin(), args.end(), [](const expression &ex) { return ex.is_number(); });
+
+    return detail::make_func(func_kind::prod, std::move(args));
+}
+
+// Reference: src/math/pow.cpp:1024-1062.
+expression pow(const expression &b, const expression &e)
+{
+    if (b.is_number() && e.is_number()) {
+        return expression{std::pow(b.num(), e.num())};
+    }
+    if (e.is_number()) {
+        if (e.num() == 0) {
+            return expression{1.};
+        }
+        if (e.num() == 1) {
+            return b;
+        }
+    }
+    return detail::make_func(func_kind::pow, {b, e});
+}
+
+// Reference: src/math/sqrt.cpp:16-19.
+expression sqrt(const expression &e)
+{
+    return pow(e, expression{.5});
+}
+
+expression square(const expression &e)
+{
+    return pow(e, expression{2.});
+}
+
+// Reference: src/math/sin.cpp:381-395, src/math/cos.cpp:381-395.
+expression sin(expression e)
+{
+    if (e.is_number()) {
+        return expression{std::sin(e.num())};
+    }
+    return detail::make_func(func_kind::sin, {std::move(e)});
+}
+
+expression cos(expression e)
+{
+    if (e.is_number()) {
+        return expression{std::cos(e.num())};
+    }
+    return detail::make_func(func_kind::cos, {std::move(e)});
+}
+
+expression exp(expression e)
+{
+    if (e.is_number()) {
+        return expression{std::exp(e.num())};
+    }
+    return detail::make_func(func_kind::exp, {std::move(e)});
+}
+
+expression log(expression e)
+{
+    if (e.is_number()) {
+        return expression{std::log(e.num())};
+    }
+    return detail::make_func(func_kind::log, {std::move(e)});
+}
+
+// --- Traversal. ---
+// Iterative post-order traversal replicating the visiting order of the reference
+// (src/detail/ex_traversal.cpp:35-180): arguments are pushed on the stack in order and thus
+// visited last-to-first; results are popped so that the argument order is preserved.
+expression traverse_transform_nodes(ptr_ex_map &cache, const expression &e,
+                                    const std::function<expression(const expression &)> &leaf_tfunc,
+                                    const std::function<expression(const expression &)> &branch_tfunc)
+{
+    std::vector<std::pair<const expression *, bool>> stack;
+    std::vector<std::optional<expression>> out_stack;
+
+    stack.emplace_back(&e, false);
+
+    while (!stack.empty()) {
+        const auto [cur_ex, visited] = stack.back();
+        stack.pop_back();
+
+        if (cur_ex->is_func()) {
+            const auto &f = cur_ex->fn();
+            const auto *f_id = f.get_ptr();
+
+            if (!visited) {
+                if (const auto it = cache.find(f_id); it != cache.end()) {
+                    out_stack.emplace_back(it->second);
+                    continue;
+                }
+            }
+
+            if (visited) {
+                std::vector<expression> new_args;
+                const auto n_args = f.args().size();
+                new_args.reserve(n_args);
+                for (std::size_t i = 0; i < n_args; ++i) {
+                    assert(!out_stack.empty() && out_stack.back());
+                    new_args.push_back(std::move(*out_stack.back()));
+                    out_stack.pop_back();
+                }
+
+                // Avoid creating a new node if no argument changed identity.
+                bool same = true;
+                for (std::size_t i = 0; i < n_args && same; ++i) {
+                    const auto &oa = f.args()[i];
+                    const auto &na = new_args[i];
+                    if (oa.is_func() && na.is_func()) {
+                        same = (oa.fn().get_ptr() == na.fn().get_ptr());
+                    } else if (oa.is_func() != na.is_func()) {
+                        same = false;
+                    } else {
+                        same = (oa == na);
+                    }
+                }
+
+                auto ex_copy = same ? *cur_ex : expression{f.copy_with_new_args(std::move(new_args))};
+
+                if (branch_tfunc) {
+                    ex_copy = branch_tfunc(ex_copy);
+                }
+
+                cache.emplace(f_id, ex_copy);
+
+                assert(!out_stack.empty() && !out_stack.back());
+                out_stack.back().emplace(std::move(ex_copy));
+            } else {
+                stack.emplace_back(cur_ex, true);
+                for (const auto &ex : f.args()) {
+                    stack.emplace_back(&ex, false);
+                }
+                out_stack.emplace_back();
+            }
+        } else {
+            out_stack.emplace_back(leaf_tfunc ? leaf_tfunc(*cur_ex) : *cur_ex);
+        }
+    }
+
+    assert(out_stack.size() == 1u && out_stack.back());
+    return std::move(*out_stack.back());
+}
+
+namespace
+{
+
+void visit_leaves(std::set<const void *> &seen, const expression &e, const std::function<void(const expression &)> &vf)
+{
+    std::vector<const expression *> stack{&e};
+    while (!stack.empty()) {
+        const auto *cur = stack.back();
+        stack.pop_back();
+        if (cur->is_func()) {
+            const auto &f = cur->fn();
+            if (!seen.insert(f.get_ptr()).second) {
+                continue;
+            }
+            for (const auto &a : f.args()) {
+                stack.push_back(&a);
+            }
+        } else {
+            vf(*cur);
+        }
+    }
+}
+
+} // namespace
+
+std::vector<std::string> get_variables(const std::vector<expression> &v_ex)
+{
+    std::set<std::string> s;
+    std::set<const void *> seen;
+    for (const auto &e : v_ex) {
+        visit_leaves(seen, e, [&s](const expression &l) {
+            if (l.is_variable()) {
+                s.insert(l.var_name());
+            }
+        });
+    }
+    return {s.begin(), s.end()};
+}
+
+std::vector<std::string> get_variables(const expression &e)
+{
+    return get_variables(std::vector<expression>{e});
+}
+
+expression rename_variables(ptr_ex_map &cache, const expression &e,
+                            const std::unordered_map<std::string, std::string> &repl)
+{
+    return traverse_transform_nodes(
+        cache, e,
+        [&repl](const expression &l) {
+            if (l.is_variable()) {
+                if (const auto it = repl.find(l.var_name()); it != repl.end()) {
+                    return expression{it->second};
+                }
+            }
+            return l;
+        },
+        {});
+}
+
+std::vector<expression> rename_variables(const std::vector<expression> &v_ex,
+                                         const std::unordered_map<std::string, std::string> &repl)
+{
+    ptr_ex_map cache;
+    std::vector<expression> ret;
+    ret.reserve(v_ex.size());
+    for (const auto &e : v_ex) {
+        ret.push_back(rename_variables(cache, e, repl));
+    }
+    return ret;
+}
+
+std::uint32_t get_param_size(const std::vector<expression> &v_ex)
+{
+    std::uint32_t ret = 0;
+    std::set<const void *> seen;
+    for (const auto &e : v_ex) {
+        visit_leaves(seen, e, [&ret](const expression &l) {
+            if (l.is_param()) {
+                if (l.par_idx() == UINT32_MAX) {
+                    throw std::overflow_error("Overflow detected in get_param_size()");
+                }
+                ret = std::max(ret, l.par_idx() + 1u);
+            }
+        });
+    }
+    return ret;
+}
+
+bool is_time_dependent(const std::vector<expression> &v_ex)
+{
+    std::set<const void *> seen;
+    std::vector<const expression *> stack;
+    for (const auto &e : v_ex) {
+        stack.push_back(&e);
+    }
+    while (!stack.empty()) {
+        const auto *cur = stack.back();
+        stack.pop_back();
+        if (cur->is_func()) {
+            const auto &f = cur->fn();
+            if (f.kind() == func_kind::time) {
+                return true;
+            }
+            if (!seen.insert(f.get_ptr()).second) {
+                continue;
+            }
+            for (const auto &a : f.args()) {
+                stack.push_back(&a);
+            }
+        }
+    }
+    return false;
+}
+
+} // namespace heyoka_amd
