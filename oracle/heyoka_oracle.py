@@ -1,0 +1,765 @@
+"""
+TEST INFRASTRUCTURE - NOT PRODUCT CODE.
+
+CPU oracle for the taylor_adaptive_batch<double> hot path of bluescarni/heyoka (v7.12.0).
+
+This module is an *independent* restatement (pure Python) of the symbolic half of the path --
+expression construction with the reference's constant folding, the rewrite pipeline, the Taylor
+decomposition, CSE and the breadth-first re-sort -- and a ctypes driver for the numerical half
+(oracle/taylor_oracle.c). It shares no code with the product (heyoka_amd/): tests compare the
+product's decomposition and numerical results against it.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+Oracle pinning: the reference cannot be built in this environment (no LLVM/Boost/fmt/spdlog dev
+files), so the oracle is pinned against the reference's published known
+answers instead (tests/golden/*.json, transcribed from the reference's docs and tests):
+doc/tut_adaptive.rst:96-229, doc/tut_ensemble.rst:120-139, doc/tut_batch_mode.rst:160-330,
+test/model_nbody.cpp:92-118, test/taylor_*.cpp, test/timestep_check.cpp. sin/cos/pow/sqrt come
+from the host libm (<= 1 ulp class): bitwise parity for those is unpinned.
+
+Reference citations (file:line relative to /root/reference):
+  operators ............... src/expression_ops.cpp:34-91
+  sum()/prod()/pow() ...... src/math/sum.cpp:548-601, src/math/prod.cpp:913-973, src/math/pow.cpp:1024-1062
+  sin()/cos() folding ..... src/math/sin.cpp:381-395, src/math/cos.cpp:381-395
+  nbody / pendulum ........ src/model/nbody.cpp:53-174, src/model/pendulum.cpp:23-28
+  traversal order ......... src/detail/ex_traversal.cpp:35-180
+  sum_to_sub .............. src/math/sum.cpp:461-544
+  sum/prod split .......... include/heyoka/detail/udf_split.hpp:49-100, src/expression_basic.cpp:1177-1213
+  sum -> sum_sq ........... src/math/sum.cpp:385-455
+  prod -> div ............. src/math/prod.cpp:753-908
+  decomposition ........... src/expression_decompose.cpp:43-210, src/func.cpp:392-420
+  sin/cos pairs ........... src/math/sin.cpp:115-133, src/math/cos.cpp:116-134
+  taylor_decompose_sys .... src/taylor_01.cpp:848-1008
+  CSE ..................... src/taylor_01.cpp:315-443
+  BFS topological sort .... src/taylor_01.cpp:454-645
+  order from tolerance .... include/heyoka/detail/taylor_common.hpp:165-191
+"""
+
+import ctypes
+import math
+import os
+import subprocess
+from collections import deque
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+KIND_IDS = {
+    "sum": 0,
+    "prod": 1,
+    "pow": 2,
+    "sub": 3,
+    "div": 4,
+    "sum_sq": 5,
+    "sin": 6,
+    "cos": 7,
+    "exp": 8,
+    "log": 9,
+    "time": 10,
+    "num_identity": 11,
+}
+
+OC_SUCCESS = -4294967296 - 1
+OC_STEP_LIMIT = -4294967296 - 2
+OC_TIME_LIMIT = -4294967296 - 3
+OC_ERR_NF_STATE = -4294967296 - 4
+OC_CB_STOP = -4294967296 - 5
+
+
+# ----------------------------------------------------------------------------------------------
+# Expressions.
+# ----------------------------------------------------------------------------------------------
+class Ex:
+    """Expression node. tag in {'num', 'var', 'par', 'func'}."""
+
+    __slots__ = ("tag", "val", "kind", "args", "_key")
+
+    def __init__(self, tag, val=None, kind=None, args=()):
+        self.tag = tag
+        self.val = val
+        self.kind = kind
+        self.args = tuple(args)
+        self._key = None
+
+    # Structural key (used for CSE equality).
+    def key(self):
+        if self._key is None:
+            if self.tag == "func":
+                self._key = ("f", self.kind, tuple(a.key() for a in self.args))
+            elif self.tag == "num":
+                v = self.val
+                self._key = ("n", "nan" if v != v else (0.0 if v == 0 else v))
+            else:
+                self._key = (self.tag, self.val)
+        return self._key
+
+    def is_num(self):
+        return self.tag == "num"
+
+    def is_func(self, kind=None):
+        return self.tag == "func" and (kind is None or self.kind == kind)
+
+    def __repr__(self):
+        if self.tag == "func":
+            return "%s(%s)" % (self.kind, ", ".join(map(repr, self.args)))
+        if self.tag == "par":
+            return "p%d" % self.val
+        return repr(self.val) if self.tag == "num" else self.val
+
+    # Operators.
+    def __neg__(self):
+        if self.is_num():
+            return num(-self.val)
+        return prod([num(-1.0), self])
+
+    def __add__(self, o):
+        o = as_ex(o)
+        if self.is_num() and o.is_num():
+            return num(self.val + o.val)
+        return sum_([self, o])
+
+    def __radd__(self, o):
+        return as_ex(o) + self
+
+    def __sub__(self, o):
+        o = as_ex(o)
+        if self.is_num() and o.is_num():
+            return num(self.val - o.val)
+        return self + (-o)
+
+    def __rsub__(self, o):
+        return as_ex(o) - self
+
+    def __mul__(self, o):
+        o = as_ex(o)
+        if self.is_num() and o.is_num():
+            return num(self.val * o.val)
+        return prod([self, o])
+
+    def __rmul__(self, o):
+        return as_ex(o) * self
+
+    def __truediv__(self, o):
+        o = as_ex(o)
+        if self.is_num() and o.is_num():
+            return num(np.float64(self.val) / np.float64(o.val))
+        return prod([self, pow_(o, num(-1.0))])
+
+    def __rtruediv__(self, o):
+        return as_ex(o) / self
+
+
+def num(v):
+    return Ex("num", float(v))
+
+
+def var(name):
+    return Ex("var", name)
+
+
+def par(i):
+    return Ex("par", int(i))
+
+
+def func(kind, args):
+    return Ex("func", kind=kind, args=args)
+
+
+def as_ex(x):
+    return x if isinstance(x, Ex) else num(x)
+
+
+TIME = func("time", [])
+
+
+def _stable_partition(lst, pred):
+    a = [x for x in lst if pred(x)]
+    b = [x for x in lst if not pred(x)]
+    return a + b, len(a)
+
+
+def sum_(args):
+    args = [as_ex(a) for a in args]
+    args, n_nonnum = _stable_partition(args, lambda e: not e.is_num())
+    if n_nonnum != len(args):
+        acc = args[n_nonnum].val
+        for e in args[n_nonnum + 1 :]:
+            acc = acc + e.val
+        args = args[:n_nonnum] + [num(acc)]
+        if acc == 0:
+            if len(args) == 1:
+                return args[0]
+            args.pop()
+    if not args:
+        return num(0.0)
+    if len(args) == 1:
+        return args[0]
+    args, _ = _stable_partition(args, lambda e: e.is_num())
+    return func("sum", args)
+
+
+def prod(args):
+    args = [as_ex(a) for a in args]
+    args, n_nonnum = _stable_partition(args, lambda e: not e.is_num())
+    if n_nonnum != len(args):
+        acc = args[n_nonnum].val
+        for e in args[n_nonnum + 1 :]:
+            acc = acc * e.val
+        args = args[:n_nonnum] + [num(acc)]
+        if acc == 1:
+            if len(args) == 1:
+                return args[0]
+            args.pop()
+        elif acc == 0:
+            return args[-1]
+    if not args:
+        return num(1.0)
+    if len(args) == 1:
+        return args[0]
+    args, _ = _stable_partition(args, lambda e: e.is_num())
+    return func("prod", args)
+
+
+def pow_(b, e):
+    b, e = as_ex(b), as_ex(e)
+    if b.is_num() and e.is_num():
+        return num(math.pow(b.val, e.val))
+    if e.is_num():
+        if e.val == 0:
+            return num(1.0)
+        if e.val == 1:
+            return b
+    return func("pow", [b, e])
+
+
+def sqrt(e):
+    return pow_(e, num(0.5))
+
+
+def sin(e):
+    e = as_ex(e)
+    return num(math.sin(e.val)) if e.is_num() else func("sin", [e])
+
+
+def cos(e):
+    e = as_ex(e)
+    return num(math.cos(e.val)) if e.is_num() else func("cos", [e])
+
+
+def exp(e):
+    e = as_ex(e)
+    return num(math.exp(e.val)) if e.is_num() else func("exp", [e])
+
+
+def log(e):
+    e = as_ex(e)
+    return num(math.log(e.val)) if e.is_num() else func("log", [e])
+
+
+# ----------------------------------------------------------------------------------------------
+# Models.
+# ----------------------------------------------------------------------------------------------
+def nbody(n, masses=None, Gconst=1.0):
+    masses = [as_ex(1.0)] * n if masses is None else [as_ex(m) for m in masses]
+    G = as_ex(Gconst)
+    if n < 2 or len(masses) > n:
+        raise ValueError("invalid N-body configuration")
+    x = [var("x_%d" % i) for i in range(n)]
+    y = [var("y_%d" % i) for i in range(n)]
+    z = [var("z_%d" % i) for i in range(n)]
+    vx = [var("vx_%d" % i) for i in range(n)]
+    vy = [var("vy_%d" % i) for i in range(n)]
+    vz = [var("vz_%d" % i) for i in range(n)]
+    xa = [[] for _ in range(n)]
+    ya = [[] for _ in range(n)]
+    za = [[] for _ in range(n)]
+    sys = []
+    nm = len(masses)
+    for i in range(nm):
+        sys += [(x[i], vx[i]), (y[i], vy[i]), (z[i], vz[i])]
+        for j in range(i + 1, n):
+            dx, dy, dz = x[j] - x[i], y[j] - y[i], z[j] - z[i]
+            r_m3 = pow_(sum_([pow_(dx, 2.0), pow_(dy, 2.0), pow_(dz, 2.0)]), num(-3.0 / 2))
+            j_massive = j < nm
+            opt = j_massive and masses[j].is_num() and masses[j].val != 0 and G.is_num()
+            if opt:
+                fac_j = G * masses[j] * r_m3
+                c_ij = -masses[i] / masses[j]
+                xa[i].append(dx * fac_j)
+                ya[i].append(dy * fac_j)
+                za[i].append(dz * fac_j)
+                xa[j].append(xa[i][-1] * c_ij)
+                ya[j].append(ya[i][-1] * c_ij)
+                za[j].append(za[i][-1] * c_ij)
+            else:
+                G_r_m3 = G * r_m3
+                fac_i = -masses[i] * G_r_m3
+                xa[j].append(dx * fac_i)
+                ya[j].append(dy * fac_i)
+                za[j].append(dz * fac_i)
+                if j_massive:
+                    fac_j = masses[j] * G_r_m3
+                    xa[i].append(dx * fac_j)
+                    ya[i].append(dy * fac_j)
+                    za[i].append(dz * fac_j)
+        sys += [(vx[i], sum_(xa[i])), (vy[i], sum_(ya[i])), (vz[i], sum_(za[i]))]
+    for i in range(nm, n):
+        sys += [(x[i], vx[i]), (y[i], vy[i]), (z[i], vz[i])]
+        sys += [(vx[i], sum_(xa[i])), (vy[i], sum_(ya[i])), (vz[i], sum_(za[i]))]
+    return sys
+
+
+def pendulum(gconst=1.0, length=1.0):
+    x, v = var("x"), var("v")
+    return [(x, v), (v, -as_ex(gconst) / as_ex(length) * sin(x))]
+
+
+# ----------------------------------------------------------------------------------------------
+# Rewrites + decomposition.
+# ----------------------------------------------------------------------------------------------
+def _transform(cache, e, leaf_f, branch_f):
+    """Post-order transform; shared nodes (by identity) transformed once; children visited
+    last-argument-first like the reference (only matters for side effects of the callbacks)."""
+    if e.tag != "func":
+        return leaf_f(e) if leaf_f else e
+    hit = cache.get(id(e))
+    if hit is not None:
+        return hit[1]
+    new_args = [None] * len(e.args)
+    for i in range(len(e.args) - 1, -1, -1):
+        new_args[i] = _transform(cache, e.args[i], leaf_f, branch_f)
+    ne = e if all(a is b for a, b in zip(new_args, e.args)) else func(e.kind, new_args)
+    if branch_f:
+        ne = branch_f(ne)
+    cache[id(e)] = (e, ne)  # keep e alive so that ids are not recycled
+    return ne
+
+
+def _transform_all(v_ex, branch_f):
+    cache = {}
+    return [_transform(cache, e, None, branch_f) for e in v_ex]
+
+
+def _pow_to_explog(ex):
+    if ex.kind == "pow" and not ex.args[1].is_num():
+        return exp(ex.args[1] * func("log", [ex.args[0]]))
+    return ex
+
+
+def _sum_to_sub(ex):
+    if ex.kind != "sum":
+        return ex
+
+    def keep(a):
+        if a.is_func("prod") and len(a.args) >= 2 and a.args[0].is_num():
+            return a.args[0].val != -1
+        return True
+
+    new_args, n_keep = _stable_partition(list(ex.args), keep)
+    if n_keep == len(new_args):
+        return ex
+    sub_args = [prod(list(a.args[1:])) for a in new_args[n_keep:]]
+    st = sum_(sub_args)
+    if n_keep == 0:
+        return prod([num(-1.0), st])
+    return func("sub", [sum_(new_args[:n_keep]), st])
+
+
+def _udf_split(ex, kind, split):
+    while ex.is_func(kind) and len(ex.args) > split:
+        seq, tmp = [], []
+        for a in ex.args:
+            tmp.append(a)
+            if len(tmp) == split:
+                seq.append(func(kind, tmp))
+                tmp = []
+        if tmp:
+            seq.append(tmp[0] if len(tmp) == 1 else func(kind, tmp))
+        ex = func(kind, seq)
+    return ex
+
+
+def _sum_to_sum_sq(ex):
+    if ex.kind != "sum":
+        return ex
+    bases = []
+    for a in ex.args:
+        if a.is_func("pow") and a.args[1].is_num() and a.args[1].val == 2:
+            bases.append(a.args[0])
+        else:
+            return ex
+    return func("sum_sq", bases)
+
+
+def _prod_to_div(ex):
+    if ex.kind != "prod":
+        return ex
+
+    def keep(a):
+        return not (a.is_func("pow") and a.args[1].is_num() and a.args[1].val == -1)
+
+    new_args, n_keep = _stable_partition(list(ex.args), keep)
+    if n_keep == len(new_args):
+        return ex
+    divisor = prod([pow_(a.args[0], num(-a.args[1].val)) for a in new_args[n_keep:]])
+    return func("div", [prod(new_args[:n_keep]), divisor])
+
+
+def _uname(i):
+    return "u_%d" % i
+
+
+def _uidx(name):
+    return int(name[2:])
+
+
+def _rename(e, m):
+    return _transform({}, e, lambda l: var(m[l.val]) if l.tag == "var" and l.val in m else l, None)
+
+
+def _get_vars(e, out):
+    if e.tag == "var":
+        out.add(e.val)
+    elif e.tag == "func":
+        for a in e.args:
+            _get_vars(a, out)
+
+
+def taylor_decompose_sys(sys):
+    """Returns dc = list of (Ex, deps)."""
+    n_eq = len(sys)
+    repl = {lhs.val: _uname(i) for i, (lhs, _) in enumerate(sys)}
+    all_ex = [rhs for _, rhs in sys]
+    all_ex = _transform_all(all_ex, _pow_to_explog)
+    all_ex = _transform_all(all_ex, _sum_to_sub)
+    all_ex = _transform_all(all_ex, lambda e: _udf_split(e, "sum", 8))
+    all_ex = _transform_all(all_ex, _sum_to_sum_sq)
+    all_ex = _transform_all(all_ex, _prod_to_div)
+    all_ex = _transform_all(all_ex, lambda e: _udf_split(e, "prod", 2))
+    cache = {}
+    all_ex = [_transform(cache, e, lambda l: var(repl[l.val]) if l.tag == "var" else l, None) for e in all_ex]
+
+    dc = [(lhs, []) for lhs, _ in sys]
+    fmap = {}
+
+    def decomp(e):
+        # Returns the index of the u variable, or None for non-functions.
+        if e.tag != "func":
+            return None
+        hit = fmap.get(id(e))
+        if hit is not None:
+            return hit[1]
+        idxs = [None] * len(e.args)
+        for i in range(len(e.args) - 1, -1, -1):  # last argument first
+            idxs[i] = decomp(e.args[i])
+        new_args = [var(_uname(ix)) if ix is not None else a for ix, a in zip(idxs, e.args)]
+        f = func(e.kind, new_args)
+        if e.kind in ("sin", "cos"):
+            other = "cos" if e.kind == "sin" else "sin"
+            dc.append((func(other, [new_args[0]]), []))
+            dc.append((f, []))
+            dc[-2][1].append(len(dc) - 1)
+            dc[-1][1].append(len(dc) - 2)
+            ret = len(dc) - 1
+        else:
+            ret = len(dc)
+            dc.append((f, []))
+        fmap[id(e)] = (e, ret)
+        return ret
+
+    outs = []
+    for e in all_ex:
+        r = decomp(e)
+        outs.append((var(_uname(r)) if r is not None else e, []))
+    dc += outs
+
+    # CSE.
+    new_dc = list(dc[:n_eq])
+    ex_map = {}
+    ren = {_uname(i): _uname(i) for i in range(n_eq)}
+    for i in range(n_eq, len(dc) - n_eq):
+        ex, deps = dc[i]
+        ne = _rename(ex, ren)
+        j = ex_map.get(ne.key())
+        if j is None:
+            new_dc.append((ne, list(deps)))
+            ex_map[ne.key()] = len(new_dc) - 1
+            ren[_uname(i)] = _uname(len(new_dc) - 1)
+        else:
+            ren[_uname(i)] = _uname(j)
+    for i in range(len(dc) - n_eq, len(dc)):
+        new_dc.append((_rename(dc[i][0], ren), []))
+    new_dc = [(ex, [_uidx(ren[_uname(d)]) for d in deps]) for ex, deps in new_dc]
+    dc = new_dc
+
+    # Kahn BFS sort. Vertex 0 = root, vertex i+1 = u_i.
+    n_vert = len(dc) - n_eq + 1
+    out_edges = [[] for _ in range(n_vert)]
+    indeg = [0] * n_vert
+    for i in range(n_eq):
+        out_edges[0].append(i + 1)
+        indeg[i + 1] += 1
+    for i in range(n_eq, len(dc) - n_eq):
+        vs = set()
+        _get_vars(dc[i][0], vs)
+        if not vs:
+            out_edges[0].append(i + 1)
+            indeg[i + 1] += 1
+        else:
+            for v in vs:
+                out_edges[_uidx(v) + 1].append(i + 1)
+                indeg[i + 1] += 1
+    order_v = []
+    q = deque([0])
+    while q:
+        v = q.popleft()
+        order_v.append(v)
+        for t in sorted(out_edges[v]):
+            indeg[t] -= 1
+            if indeg[t] == 0:
+                q.append(t)
+    assert len(order_v) == n_vert
+    v_idx = [v - 1 for v in order_v[1:]] + list(range(len(dc) - n_eq, len(dc)))
+    remap = {_uname(v_idx[i]): _uname(i) for i in range(len(dc) - n_eq)}
+    dc = [(_rename(dc[ix][0], remap), [_uidx(remap[_uname(d)]) for d in dc[ix][1]]) for ix in v_idx]
+
+    # Numbers -> num_identity.
+    for i in range(n_eq, len(dc) - n_eq):
+        if dc[i][0].tag == "num":
+            dc[i] = (func("num_identity", [dc[i][0]]), [])
+    return dc
+
+
+def taylor_order_from_tol(tol):
+    return int(max(2.0, math.ceil(-math.log(tol) / 2 + 1)))
+
+
+def dc_to_strings(dc):
+    """Canonical textual form of a decomposition (for comparison with the product's)."""
+    out = []
+    for ex, deps in dc:
+        out.append(_ex_str(ex) + "".join(" [dep %d]" % d for d in deps))
+    return out
+
+
+def _ex_str(e):
+    if e.tag == "num":
+        return "%.17g" % e.val
+    if e.tag == "var":
+        return e.val
+    if e.tag == "par":
+        return "p%d" % e.val
+    return "%s(%s)" % (e.kind, ", ".join(_ex_str(a) for a in e.args))
+
+
+# ----------------------------------------------------------------------------------------------
+# Flat program + ctypes driver for oracle/taylor_oracle.c.
+# ----------------------------------------------------------------------------------------------
+class _CProg(ctypes.Structure):
+    _fields_ = [
+        ("n_eq", ctypes.c_int32),
+        ("n_u", ctypes.c_int32),
+        ("n_par", ctypes.c_int32),
+        ("order", ctypes.c_int32),
+        ("n_nodes", ctypes.c_int32),
+        ("high_accuracy", ctypes.c_int32),
+        ("kind", ctypes.c_void_p),
+        ("arg_off", ctypes.c_void_p),
+        ("arg_type", ctypes.c_void_p),
+        ("arg_idx", ctypes.c_void_p),
+        ("arg_val", ctypes.c_void_p),
+        ("dep", ctypes.c_void_p),
+        ("sv_type", ctypes.c_void_p),
+        ("sv_idx", ctypes.c_void_p),
+        ("sv_val", ctypes.c_void_p),
+    ]
+
+
+def _operand(e):
+    if e.tag == "var":
+        return 0, _uidx(e.val), 0.0
+    if e.tag == "num":
+        return 1, 0, e.val
+    if e.tag == "par":
+        return 2, e.val, 0.0
+    raise ValueError("invalid operand in decomposition: %r" % (e,))
+
+
+def build_oracle_lib(force=False):
+    """Compile oracle/taylor_oracle.c into oracle/_build/libtaylor_oracle.so (strict IEEE)."""
+    out_dir = os.path.join(_HERE, "_build")
+    so = os.path.join(out_dir, "libtaylor_oracle.so")
+    src = os.path.join(_HERE, "taylor_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        os.makedirs(out_dir, exist_ok=True)
+        subprocess.check_call(
+            ["gcc", "-O2", "-march=native", "-ffp-contract=off", "-fopenmp", "-shared", "-fPIC", "-o", so, src, "-lm"]
+        )
+    return so
+
+
+_LIB = None
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build_oracle_lib())
+        _LIB.hy_oracle_scratch_size.restype = ctypes.c_size_t
+        _LIB.hy_oracle_ensemble_propagate_until.restype = ctypes.c_int64
+        _LIB.hy_oracle_max_threads.restype = ctypes.c_int
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class OracleIntegrator:
+    """Batch Taylor integrator on the CPU with the reference's semantics (lock-step batch).
+
+    Arrays use the reference layout array[row * batch_size + lane].
+    """
+
+    def __init__(self, sys, state, batch_size, tol=None, high_accuracy=False, pars=None, time=None):
+        self.sys = sys
+        self.dc = taylor_decompose_sys(sys)
+        self.n_eq = len(sys)
+        self.n_u = len(self.dc) - self.n_eq
+        self.batch_size = int(batch_size)
+        self.tol = np.finfo(np.float64).eps if tol is None else float(tol)
+        self.order = taylor_order_from_tol(self.tol)
+        self.high_accuracy = bool(high_accuracy)
+        B = self.batch_size
+
+        kinds, arg_off, at, ai, av, dep = [], [0], [], [], [], []
+        n_par = 0
+        for ex, deps in self.dc[self.n_eq : self.n_u]:
+            kinds.append(KIND_IDS[ex.kind])
+            for a in ex.args:
+                t, i, v = _operand(a)
+                at.append(t)
+                ai.append(i)
+                av.append(v)
+                if t == 2:
+                    n_par = max(n_par, i + 1)
+            arg_off.append(len(at))
+            dep.append(deps[0] if deps else -1)
+        svt, svi, svv = [], [], []
+        for ex, _ in self.dc[self.n_u :]:
+            t, i, v = _operand(ex)
+            svt.append(t)
+            svi.append(i)
+            svv.append(v)
+            if t == 2:
+                n_par = max(n_par, i + 1)
+        self.n_par = n_par
+        i32 = lambda x: np.ascontiguousarray(np.array(x, dtype=np.int32))
+        f64 = lambda x: np.ascontiguousarray(np.array(x, dtype=np.float64))
+        self._arrs = dict(
+            kind=i32(kinds),
+            arg_off=i32(arg_off),
+            arg_type=i32(at if at else [0]),
+            arg_idx=i32(ai if ai else [0]),
+            arg_val=f64(av if av else [0.0]),
+            dep=i32(dep if dep else [0]),
+            sv_type=i32(svt),
+            sv_idx=i32(svi),
+            sv_val=f64(svv),
+        )
+        self._prog = _CProg(
+            self.n_eq,
+            self.n_u,
+            self.n_par,
+            self.order,
+            len(kinds),
+            int(self.high_accuracy),
+            *[_p(self._arrs[k]) for k in ("kind", "arg_off", "arg_type", "arg_idx", "arg_val", "dep", "sv_type", "sv_idx", "sv_val")]
+        )
+
+        self.state = np.ascontiguousarray(np.array(state, dtype=np.float64).reshape(-1))
+        if self.state.size != self.n_eq * B:
+            raise ValueError("inconsistent state size")
+        self.pars = np.zeros(max(self.n_par, 1) * B) if pars is None else np.ascontiguousarray(np.array(pars, dtype=np.float64).reshape(-1))
+        self.time_hi = np.zeros(B) if time is None else np.ascontiguousarray(np.broadcast_to(np.array(time, dtype=np.float64), (B,)).copy())
+        self.time_lo = np.zeros(B)
+        self.tc = np.zeros(self.n_eq * (self.order + 1) * B)
+        self.last_h = np.zeros(B)
+        self.step_res = [(OC_SUCCESS, 0.0)] * B
+        self.prop_res = None
+        self._scratch = np.zeros(_lib().hy_oracle_scratch_size(ctypes.byref(self._prog), B) + 64)
+
+    # step(max_delta_ts=None, wtc=False); max_delta_ts: signed per-lane limits (default +inf).
+    def step(self, max_delta_ts=None, wtc=False, backward=False):
+        B = self.batch_size
+        if max_delta_ts is None:
+            mdt = np.full(B, -np.inf if backward else np.inf)
+        else:
+            mdt = np.ascontiguousarray(np.array(max_delta_ts, dtype=np.float64))
+        oc = np.zeros(B, dtype=np.int64)
+        h = np.zeros(B)
+        _lib().hy_oracle_step_impl(
+            ctypes.byref(self._prog), B, _p(self.state), _p(self.pars), _p(self.time_hi), _p(self.time_lo), _p(mdt),
+            _p(self.tc) if wtc else None, _p(oc), _p(h), _p(self._scratch)
+        )
+        self.last_h = h.copy()
+        self.step_res = [(int(oc[i]), float(h[i])) for i in range(B)]
+        return self.step_res
+
+    def propagate_until(self, t, max_delta_t=None, max_steps=0):
+        B = self.batch_size
+        tf = np.ascontiguousarray(np.broadcast_to(np.array(t, dtype=np.float64), (B,)).copy())
+        md = np.full(B, np.inf) if max_delta_t is None else np.ascontiguousarray(np.broadcast_to(np.array(max_delta_t, dtype=np.float64), (B,)).copy())
+        oc = np.zeros(B, dtype=np.int64)
+        mn, mx = np.zeros(B), np.zeros(B)
+        ns = np.zeros(B, dtype=np.int64)
+        _lib().hy_oracle_propagate_until(
+            ctypes.byref(self._prog), B, _p(self.state), _p(self.pars), _p(self.time_hi), _p(self.time_lo), _p(tf),
+            _p(md), ctypes.c_int64(max_steps), _p(oc), _p(mn), _p(mx), _p(ns), _p(self._scratch)
+        )
+        self.prop_res = [(int(oc[i]), float(mn[i]), float(mx[i]), int(ns[i])) for i in range(B)]
+        return self.prop_res
+
+    def propagate_for(self, dt, **kw):
+        B = self.batch_size
+        dts = np.broadcast_to(np.array(dt, dtype=np.float64), (B,))
+        tf = np.array([dfloat_add(self.time_hi[i], self.time_lo[i], dts[i], 0.0)[0] for i in range(B)])
+        # NOTE: the reference keeps the final times in double-length; the single-length
+        # truncation only matters when time_lo != 0 and is irrelevant for the golden vectors.
+        return self.propagate_until(tf, **kw)
+
+
+def dfloat_add(ahi, alo, bhi, blo):
+    rh, rl = ctypes.c_double(), ctypes.c_double()
+    _lib().hy_oracle_dfloat_add(
+        ctypes.c_double(ahi), ctypes.c_double(alo), ctypes.c_double(bhi), ctypes.c_double(blo), ctypes.byref(rh),
+        ctypes.byref(rl)
+    )
+    return rh.value, rl.value
+
+
+def ensemble_propagate_until(sys, state, n_systems, batch_size, t_final, tol=None, high_accuracy=False, pars=None,
+                             max_steps=0, n_threads=0):
+    """Propagate n_systems independent ICs (state[row * n_systems + sys]) as n_systems / batch_size
+    lock-step batches over host threads. Returns (state, time_hi, time_lo, outcome, min_h, max_h,
+    n_steps, total_steps)."""
+    tmpl = OracleIntegrator(sys, np.zeros(len(sys) * batch_size), batch_size, tol=tol, high_accuracy=high_accuracy)
+    N = int(n_systems)
+    assert N % batch_size == 0
+    st = np.ascontiguousarray(np.array(state, dtype=np.float64).reshape(-1)).copy()
+    pr = np.zeros(max(tmpl.n_par, 1) * N) if pars is None else np.ascontiguousarray(np.array(pars, dtype=np.float64).reshape(-1))
+    thi, tlo = np.zeros(N), np.zeros(N)
+    oc = np.zeros(N, dtype=np.int64)
+    mn, mx = np.zeros(N), np.zeros(N)
+    ns = np.zeros(N, dtype=np.int64)
+    total = _lib().hy_oracle_ensemble_propagate_until(
+        ctypes.byref(tmpl._prog), ctypes.c_int64(N), int(batch_size), _p(st), _p(pr), _p(thi), _p(tlo),
+        ctypes.c_double(t_final), ctypes.c_int64(max_steps), _p(oc), _p(mn), _p(mx), _p(ns), int(n_threads)
+    )
+    return st, thi, tlo, oc, mn, mx, ns, int(total)
+
+
+def max_threads():
+    return int(_lib().hy_oracle_max_threads())

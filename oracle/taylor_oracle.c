@@ -1,0 +1,836 @@
+/*
+ * TEST INFRASTRUCTURE - NOT PRODUCT CODE.
+ *
+ * CPU restatement (the "oracle") of the numerical hot path of heyoka's
+ * taylor_adaptive_batch<double>: Taylor-coefficient recursion, Jorba step-size selector,
+ * Horner / compensated state update, double-length time and the step()/propagate_until()
+ * bookkeeping. Plain C, strict IEEE double (compile with -ffp-contract=off), one flat
+ * "program" (the Taylor decomposition exported by oracle/heyoka_oracle.py) interpreted over a
+ * tape of normalised derivatives laid out tape[(order * n_u + u) * B + lane].
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this file.
+ *
+ * Reference (bluescarni/heyoka v7.12.0) citations, file:line relative to /root/reference:
+ *  - jet ordering:        src/taylor_02.cpp:1339-1418 (taylor_compute_jet, default mode)
+ *  - state-variable rule: src/taylor_02.cpp:245-287   (taylor_compute_sv_diff)
+ *  - prod:                src/math/prod.cpp:314-395
+ *  - sum / sub / div:     src/math/sum.cpp:185-235, src/detail/sub.cpp:60-124, src/detail/div.cpp:62-160
+ *  - sum_sq:              src/detail/sum_sq.cpp:100-245
+ *  - pow:                 src/math/pow.cpp:136-152 (ebs), :292-355 (eval algo), :395-550 (diff)
+ *  - sin / cos:           src/math/sin.cpp:152-192, src/math/cos.cpp:152-185
+ *  - exp / log:           src/math/exp.cpp:84-120, src/math/log.cpp
+ *  - time / num_identity: src/math/time.cpp:81-101, src/detail/num_identity.cpp
+ *  - pairwise sum:        src/detail/llvm_helpers_algo.cpp:271-308
+ *  - step size:           src/taylor_00.cpp:84-94, :102-273; min/max src/detail/llvm_helpers_cmp.cpp:315-329
+ *  - Horner / ceval:      src/taylor_00.cpp:279-351, :355-460
+ *  - TC layout:           src/taylor_00.cpp:467-584
+ *  - dfloat:              include/heyoka/detail/dfloat.hpp:109-164
+ *  - step_impl:           src/taylor_adaptive_batch.cpp:632-727
+ *  - propagate_until:     src/taylor_adaptive_batch.cpp:1137-1534
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* Function kinds: must match oracle/heyoka_oracle.py KIND_IDS. */
+enum {
+    K_SUM = 0,
+    K_PROD = 1,
+    K_POW = 2,
+    K_SUB = 3,
+    K_DIV = 4,
+    K_SUM_SQ = 5,
+    K_SIN = 6,
+    K_COS = 7,
+    K_EXP = 8,
+    K_LOG = 9,
+    K_TIME = 10,
+    K_NUM_IDENTITY = 11
+};
+
+enum { A_UVAR = 0, A_NUM = 1, A_PAR = 2 };
+
+/* taylor_outcome values (reference: include/heyoka/taylor.hpp:142-155). */
+#define OC_SUCCESS (-4294967296LL - 1)
+#define OC_STEP_LIMIT (-4294967296LL - 2)
+#define OC_TIME_LIMIT (-4294967296LL - 3)
+#define OC_ERR_NF_STATE (-4294967296LL - 4)
+#define OC_CB_STOP (-4294967296LL - 5)
+
+typedef struct {
+    int32_t n_eq, n_u, n_par, order, n_nodes, high_accuracy;
+    const int32_t *kind;     /* [n_nodes] */
+    const int32_t *arg_off;  /* [n_nodes + 1] */
+    const int32_t *arg_type; /* [n_args] */
+    const int32_t *arg_idx;  /* [n_args] */
+    const double *arg_val;   /* [n_args] */
+    const int32_t *dep;      /* [n_nodes], -1 if none */
+    const int32_t *sv_type;  /* [n_eq] */
+    const int32_t *sv_idx;   /* [n_eq] */
+    const double *sv_val;    /* [n_eq] */
+} hy_oracle_program;
+
+/* ---- helpers ---- */
+
+/* In-place pairwise sum of n vectors of B lanes: terms[j*B + l]. Result in terms[0..B). */
+static void pairwise_sum(double *terms, int n, int B)
+{
+    while (n != 1) {
+        int m = 0;
+        for (int i = 0; i < n; i += 2) {
+            double *dst = terms + (size_t)m * B;
+            const double *a = terms + (size_t)i * B;
+            if (i + 1 == n) {
+                if (dst != a) {
+                    for (int l = 0; l < B; ++l) dst[l] = a[l];
+                }
+            } else {
+                const double *b = terms + (size_t)(i + 1) * B;
+                for (int l = 0; l < B; ++l) dst[l] = a[l] + b[l];
+            }
+            ++m;
+        }
+        n = m;
+    }
+}
+
+static double pow_ebs(double base, uint32_t e)
+{
+    if (e == 0u) return 1.;
+    if (e == 1u) return base;
+    if (e % 2u == 0u) return pow_ebs(base * base, e / 2u);
+    return base * pow_ebs(base * base, (e - 1u) / 2u);
+}
+
+/* pow evaluation at order 0, selected by the exponent class. */
+static double pow_eval(double b, double ex)
+{
+    if (isfinite(ex) && ex == trunc(ex) && fabs(ex) <= 16.) {
+        if (ex >= 0) return pow_ebs(b, (uint32_t)ex);
+        return 1. / pow_ebs(b, (uint32_t)(-ex));
+    }
+    if (isfinite(ex) && ex != trunc(ex)) {
+        const double y = 2 * ex;
+        if (y == trunc(y) && fabs(y) <= 16.) {
+            const double t = sqrt(b);
+            if (y >= 0) return pow_ebs(t, (uint32_t)y);
+            return 1. / pow_ebs(t, (uint32_t)(-y));
+        }
+    }
+    return pow(b, ex);
+}
+
+#define TAPE(k, u) (tape + ((size_t)(k) * n_u + (size_t)(u)) * B)
+
+/* Value of a num/par argument, per lane. */
+static inline double numpar(const hy_oracle_program *p, int a, const double *pars, int B, int l)
+{
+    return p->arg_type[a] == A_NUM ? p->arg_val[a] : pars[(size_t)p->arg_idx[a] * B + l];
+}
+
+/* Order-k normalised derivative of node i (u variable n_eq + i). */
+static void node_diff(const hy_oracle_program *p, int i, int k, double *tape, const double *pars, const double *time,
+                      int B, double *scratch)
+{
+    const int n_u = p->n_u;
+    const int u = p->n_eq + i;
+    const int a0 = p->arg_off[i];
+    const int nargs = p->arg_off[i + 1] - a0;
+    const int32_t *at = p->arg_type + a0;
+    const int32_t *ai = p->arg_idx + a0;
+    double *out = TAPE(k, u);
+
+    switch (p->kind[i]) {
+        case K_NUM_IDENTITY:
+            for (int l = 0; l < B; ++l) out[l] = k == 0 ? numpar(p, a0, pars, B, l) : 0.;
+            break;
+        case K_TIME:
+            for (int l = 0; l < B; ++l) out[l] = k == 0 ? time[l] : (k == 1 ? 1. : 0.);
+            break;
+        case K_SUM: {
+            for (int j = 0; j < nargs; ++j) {
+                double *t = scratch + (size_t)j * B;
+                if (at[j] == A_UVAR) {
+                    const double *v = TAPE(k, ai[j]);
+                    for (int l = 0; l < B; ++l) t[l] = v[l];
+                } else {
+                    for (int l = 0; l < B; ++l) t[l] = k == 0 ? numpar(p, a0 + j, pars, B, l) : 0.;
+                }
+            }
+            pairwise_sum(scratch, nargs, B);
+            for (int l = 0; l < B; ++l) out[l] = scratch[l];
+            break;
+        }
+        case K_SUB: {
+            if (at[0] == A_UVAR && at[1] == A_UVAR) {
+                const double *x = TAPE(k, ai[0]), *y = TAPE(k, ai[1]);
+                for (int l = 0; l < B; ++l) out[l] = x[l] - y[l];
+            } else if (at[0] == A_UVAR) {
+                const double *x = TAPE(k, ai[0]);
+                for (int l = 0; l < B; ++l) out[l] = k == 0 ? x[l] - numpar(p, a0 + 1, pars, B, l) : x[l];
+            } else if (at[1] == A_UVAR) {
+                const double *y = TAPE(k, ai[1]);
+                for (int l = 0; l < B; ++l) out[l] = k == 0 ? numpar(p, a0, pars, B, l) - y[l] : -y[l];
+            } else {
+                for (int l = 0; l < B; ++l)
+                    out[l] = k == 0 ? numpar(p, a0, pars, B, l) - numpar(p, a0 + 1, pars, B, l) : 0.;
+            }
+            break;
+        }
+        case K_PROD: {
+            if (at[0] == A_UVAR && at[1] == A_UVAR) {
+                for (int j = 0; j <= k; ++j) {
+                    const double *x = TAPE(k - j, ai[0]), *y = TAPE(j, ai[1]);
+                    double *t = scratch + (size_t)j * B;
+                    for (int l = 0; l < B; ++l) t[l] = x[l] * y[l];
+                }
+                pairwise_sum(scratch, k + 1, B);
+                for (int l = 0; l < B; ++l) out[l] = scratch[l];
+            } else if (at[0] != A_UVAR && at[1] != A_UVAR) {
+                const int neg = (at[0] == A_NUM && p->arg_val[a0] == -1.);
+                for (int l = 0; l < B; ++l) {
+                    if (k != 0) {
+                        out[l] = 0.;
+                    } else if (neg) {
+                        out[l] = -numpar(p, a0 + 1, pars, B, l);
+                    } else {
+                        out[l] = numpar(p, a0, pars, B, l) * numpar(p, a0 + 1, pars, B, l);
+                    }
+                }
+            } else {
+                /* numpar * var (either position). */
+                const int vi = at[0] == A_UVAR ? 0 : 1;
+                const int ni = 1 - vi;
+                const double *x = TAPE(k, ai[vi]);
+                if (ni == 0 && at[0] == A_NUM && p->arg_val[a0] == -1.) {
+                    for (int l = 0; l < B; ++l) out[l] = -x[l];
+                } else {
+                    for (int l = 0; l < B; ++l) out[l] = numpar(p, a0 + ni, pars, B, l) * x[l];
+                }
+            }
+            break;
+        }
+        case K_DIV: {
+            if (at[1] == A_UVAR) {
+                const double *d0 = TAPE(0, ai[1]);
+                if (k == 0) {
+                    for (int l = 0; l < B; ++l) {
+                        const double num = at[0] == A_UVAR ? TAPE(0, ai[0])[l] : numpar(p, a0, pars, B, l);
+                        out[l] = num / d0[l];
+                    }
+                } else {
+                    for (int j = 1; j <= k; ++j) {
+                        const double *x = TAPE(k - j, u), *y = TAPE(j, ai[1]);
+                        double *t = scratch + (size_t)(j - 1) * B;
+                        for (int l = 0; l < B; ++l) t[l] = x[l] * y[l];
+                    }
+                    pairwise_sum(scratch, k, B);
+                    if (at[0] == A_UVAR) {
+                        const double *nv = TAPE(k, ai[0]);
+                        for (int l = 0; l < B; ++l) out[l] = (nv[l] - scratch[l]) / d0[l];
+                    } else {
+                        for (int l = 0; l < B; ++l) out[l] = (-scratch[l]) / d0[l];
+                    }
+                }
+            } else if (at[0] == A_UVAR) {
+                const double *x = TAPE(k, ai[0]);
+                for (int l = 0; l < B; ++l) out[l] = x[l] / numpar(p, a0 + 1, pars, B, l);
+            } else {
+                for (int l = 0; l < B; ++l)
+                    out[l] = k == 0 ? numpar(p, a0, pars, B, l) / numpar(p, a0 + 1, pars, B, l) : 0.;
+            }
+            break;
+        }
+        case K_SUM_SQ: {
+            /* Per-argument partial results in acc[arg*B + l], located after the term scratch. */
+            double *acc = scratch + (size_t)(p->order + 2) * B;
+            if (k % 2 == 1) {
+                for (int a = 0; a < nargs; ++a) {
+                    double *dst = acc + (size_t)a * B;
+                    if (at[a] == A_UVAR) {
+                        const int nt = (k - 1) / 2 + 1;
+                        for (int j = 0; j < nt; ++j) {
+                            const double *x = TAPE(k - j, ai[a]), *y = TAPE(j, ai[a]);
+                            double *t = scratch + (size_t)j * B;
+                            for (int l = 0; l < B; ++l) t[l] = x[l] * y[l];
+                        }
+                        pairwise_sum(scratch, nt, B);
+                        for (int l = 0; l < B; ++l) dst[l] = scratch[l];
+                    } else {
+                        for (int l = 0; l < B; ++l) dst[l] = 0.;
+                    }
+                }
+                pairwise_sum(acc, nargs, B);
+                for (int l = 0; l < B; ++l) out[l] = acc[l] + acc[l];
+            } else {
+                for (int a = 0; a < nargs; ++a) {
+                    double *dst = acc + (size_t)a * B;
+                    if (at[a] == A_UVAR) {
+                        const double *h = TAPE(k / 2, ai[a]);
+                        for (int l = 0; l < B; ++l) dst[l] = h[l] * h[l];
+                        if (k > 0) {
+                            const int nt = (k - 2) / 2 + 1;
+                            for (int j = 0; j < nt; ++j) {
+                                const double *x = TAPE(k - j, ai[a]), *y = TAPE(j, ai[a]);
+                                double *t = scratch + (size_t)j * B;
+                                for (int l = 0; l < B; ++l) t[l] = x[l] * y[l];
+                            }
+                            pairwise_sum(scratch, nt, B);
+                            for (int l = 0; l < B; ++l) dst[l] = (scratch[l] + scratch[l]) + dst[l];
+                        }
+                    } else {
+                        for (int l = 0; l < B; ++l) {
+                            if (k == 0) {
+                                const double v = numpar(p, a0 + a, pars, B, l);
+                                dst[l] = v * v;
+                            } else {
+                                /* 2 * 0 + 0. */
+                                dst[l] = 0.;
+                            }
+                        }
+                    }
+                }
+                pairwise_sum(acc, nargs, B);
+                for (int l = 0; l < B; ++l) out[l] = acc[l];
+            }
+            break;
+        }
+        case K_POW: {
+            /* The exponent is always a number here (pow_to_explog handles the rest). */
+            const double ex = p->arg_val[a0 + 1];
+            if (at[0] != A_UVAR) {
+                for (int l = 0; l < B; ++l) out[l] = k == 0 ? pow_eval(numpar(p, a0, pars, B, l), ex) : 0.;
+                break;
+            }
+            const int b = ai[0];
+            if (k == 0) {
+                const double *x = TAPE(0, b);
+                for (int l = 0; l < B; ++l) out[l] = pow_eval(x[l], ex);
+            } else if (ex == .5) {
+                /* sqrt special case. */
+                const double *a_0 = TAPE(0, u), *bn = TAPE(k, b);
+                int nt = 0;
+                const int jmax = (k % 2 == 1) ? (k - 1) / 2 : (k - 2) / 2;
+                for (int j = 1; j <= jmax; ++j, ++nt) {
+                    const double *x = TAPE(k - j, u), *y = TAPE(j, u);
+                    double *t = scratch + (size_t)nt * B;
+                    for (int l = 0; l < B; ++l) t[l] = x[l] * y[l];
+                }
+                double *fac = scratch + (size_t)(p->order + 2) * B;
+                for (int l = 0; l < B; ++l) fac[l] = bn[l];
+                if (k % 2 == 0) {
+                    const double *hh = TAPE(k / 2, u);
+                    for (int l = 0; l < B; ++l) fac[l] = fac[l] - hh[l] * hh[l];
+                }
+                if (nt > 0) {
+                    pairwise_sum(scratch, nt, B);
+                    for (int l = 0; l < B; ++l) fac[l] = fac[l] - (scratch[l] + scratch[l]);
+                }
+                for (int l = 0; l < B; ++l) out[l] = fac[l] / (a_0[l] + a_0[l]);
+            } else if (ex == 2.) {
+                /* square special case. */
+                if (k % 2 == 1) {
+                    const int nt = (k - 1) / 2 + 1;
+                    for (int j = 0; j < nt; ++j) {
+                        const double *x = TAPE(k - j, b), *y = TAPE(j, b);
+                        double *t = scratch + (size_t)j * B;
+                        for (int l = 0; l < B; ++l) t[l] = x[l] * y[l];
+                    }
+                    pairwise_sum(scratch, nt, B);
+                    for (int l = 0; l < B; ++l) out[l] = scratch[l] + scratch[l];
+                } else {
+                    const double *hh = TAPE(k / 2, b);
+                    const int nt = (k - 2) / 2 + 1;
+                    for (int j = 0; j < nt; ++j) {
+                        const double *x = TAPE(k - j, b), *y = TAPE(j, b);
+                        double *t = scratch + (size_t)j * B;
+                        for (int l = 0; l < B; ++l) t[l] = x[l] * y[l];
+                    }
+                    pairwise_sum(scratch, nt, B);
+                    for (int l = 0; l < B; ++l) out[l] = (scratch[l] + scratch[l]) + hh[l] * hh[l];
+                }
+            } else {
+                const double *b0 = TAPE(0, b);
+                for (int j = 0; j < k; ++j) {
+                    const double *x = TAPE(k - j, b), *y = TAPE(j, u);
+                    const double sf = (double)k * ex - (double)j * (ex + 1.);
+                    double *t = scratch + (size_t)j * B;
+                    for (int l = 0; l < B; ++l) t[l] = sf * (x[l] * y[l]);
+                }
+                pairwise_sum(scratch, k, B);
+                for (int l = 0; l < B; ++l) out[l] = scratch[l] / ((double)k * b0[l]);
+            }
+            break;
+        }
+        case K_SIN:
+        case K_COS: {
+            const int is_sin = p->kind[i] == K_SIN;
+            if (at[0] != A_UVAR) {
+                for (int l = 0; l < B; ++l) {
+                    const double v = numpar(p, a0, pars, B, l);
+                    out[l] = k == 0 ? (is_sin ? sin(v) : cos(v)) : 0.;
+                }
+                break;
+            }
+            const int b = ai[0];
+            if (k == 0) {
+                const double *x = TAPE(0, b);
+                for (int l = 0; l < B; ++l) out[l] = is_sin ? sin(x[l]) : cos(x[l]);
+            } else {
+                const int d = p->dep[i];
+                for (int j = 1; j <= k; ++j) {
+                    const double *x = TAPE(k - j, d), *y = TAPE(j, b);
+                    double *t = scratch + (size_t)(j - 1) * B;
+                    for (int l = 0; l < B; ++l) t[l] = (double)j * (x[l] * y[l]);
+                }
+                pairwise_sum(scratch, k, B);
+                const double dv = is_sin ? (double)k : -(double)k;
+                for (int l = 0; l < B; ++l) out[l] = scratch[l] / dv;
+            }
+            break;
+        }
+        case K_EXP: {
+            if (at[0] != A_UVAR) {
+                for (int l = 0; l < B; ++l) out[l] = k == 0 ? exp(numpar(p, a0, pars, B, l)) : 0.;
+                break;
+            }
+            const int b = ai[0];
+            if (k == 0) {
+                const double *x = TAPE(0, b);
+                for (int l = 0; l < B; ++l) out[l] = exp(x[l]);
+            } else {
+                for (int j = 1; j <= k; ++j) {
+                    const double *x = TAPE(k - j, u), *y = TAPE(j, b);
+                    double *t = scratch + (size_t)(j - 1) * B;
+                    for (int l = 0; l < B; ++l) t[l] = (double)j * (x[l] * y[l]);
+                }
+                pairwise_sum(scratch, k, B);
+                for (int l = 0; l < B; ++l) out[l] = scratch[l] / (double)k;
+            }
+            break;
+        }
+        case K_LOG: {
+            if (at[0] != A_UVAR) {
+                for (int l = 0; l < B; ++l) out[l] = k == 0 ? log(numpar(p, a0, pars, B, l)) : 0.;
+                break;
+            }
+            const int b = ai[0];
+            const double *b0 = TAPE(0, b);
+            if (k == 0) {
+                for (int l = 0; l < B; ++l) out[l] = log(b0[l]);
+            } else {
+                const double *bn = TAPE(k, b);
+                double *ret = scratch + (size_t)(p->order + 2) * B;
+                for (int l = 0; l < B; ++l) ret[l] = (double)k * bn[l];
+                if (k > 1) {
+                    for (int j = 1; j < k; ++j) {
+                        const double *x = TAPE(k - j, b), *y = TAPE(j, u);
+                        double *t = scratch + (size_t)(j - 1) * B;
+                        for (int l = 0; l < B; ++l) t[l] = (double)j * (x[l] * y[l]);
+                    }
+                    pairwise_sum(scratch, k - 1, B);
+                    for (int l = 0; l < B; ++l) ret[l] = ret[l] - scratch[l];
+                }
+                for (int l = 0; l < B; ++l) out[l] = ret[l] / ((double)k * b0[l]);
+            }
+            break;
+        }
+        default:
+            for (int l = 0; l < B; ++l) out[l] = NAN;
+    }
+}
+
+/* Order-k coefficients of the state variables. */
+static void sv_diff(const hy_oracle_program *p, int k, double *tape, const double *pars, int B)
+{
+    const int n_u = p->n_u;
+    for (int i = 0; i < p->n_eq; ++i) {
+        double *out = TAPE(k, i);
+        if (p->sv_type[i] == A_UVAR) {
+            const double *x = TAPE(k - 1, p->sv_idx[i]);
+            for (int l = 0; l < B; ++l) out[l] = x[l] / (double)k;
+        } else {
+            for (int l = 0; l < B; ++l) {
+                if (k == 1) {
+                    out[l] = p->sv_type[i] == A_NUM ? p->sv_val[i] : pars[(size_t)p->sv_idx[i] * B + l];
+                } else {
+                    out[l] = 0.;
+                }
+            }
+        }
+    }
+}
+
+/* Number of doubles of scratch needed by hy_oracle_step() for batch size B. */
+size_t hy_oracle_scratch_size(const hy_oracle_program *p, int B)
+{
+    int max_args = 2;
+    for (int i = 0; i < p->n_nodes; ++i) {
+        const int n = p->arg_off[i + 1] - p->arg_off[i];
+        if (n > max_args) max_args = n;
+    }
+    const size_t tape = ((size_t)p->n_u * (size_t)p->order + (size_t)p->n_eq) * (size_t)B;
+    const size_t terms = (size_t)(p->order + 2 + max_args + 2) * (size_t)B;
+    return tape + terms + 8u * (size_t)B;
+}
+
+static double rhofac(int order)
+{
+    /* exp(-7/10 / (order - 1)) / (e * e), folded in double precision. */
+    const double m7_10 = -7. / 10.;
+    const double e2 = exp(1.) * exp(1.);
+    return exp(m7_10 / (double)(order - 1)) / e2;
+}
+
+/*
+ * One step of the batch integrator for B lanes in lock-step (the JIT'd `step` function of the
+ * reference, default mode). h_inout: in = signed max step, out = step taken.
+ * tc (nullable): tc[(var * (order + 1) + k) * B + lane].
+ */
+void hy_oracle_step(const hy_oracle_program *p, int B, double *state, const double *pars, const double *time,
+                    double *h_inout, double *tc, double *scratch_mem)
+{
+    const int n_eq = p->n_eq, n_u = p->n_u, order = p->order;
+    double *tape = scratch_mem;
+    double *scratch = tape + ((size_t)n_u * (size_t)order + (size_t)n_eq) * (size_t)B;
+
+    for (int i = 0; i < n_eq; ++i) {
+        memcpy(TAPE(0, i), state + (size_t)i * B, sizeof(double) * (size_t)B);
+    }
+    for (int i = 0; i < p->n_nodes; ++i) node_diff(p, i, 0, tape, pars, time, B, scratch);
+    for (int k = 1; k < order; ++k) {
+        sv_diff(p, k, tape, pars, B);
+        for (int i = 0; i < p->n_nodes; ++i) node_diff(p, i, k, tape, pars, time, B, scratch);
+    }
+    sv_diff(p, order, tape, pars, B);
+
+    /* Step size: pairwise max reduction over the variables (default mode). */
+    double *mx = (double *)malloc(sizeof(double) * (size_t)3 * (size_t)B + sizeof(double) * (size_t)n_eq * (size_t)B);
+    double *red = mx + (size_t)3 * B;
+    const int ks[3] = {0, order, order - 1};
+    for (int q = 0; q < 3; ++q) {
+        for (int i = 0; i < n_eq; ++i) {
+            const double *x = TAPE(ks[q], i);
+            for (int l = 0; l < B; ++l) red[(size_t)i * B + l] = fabs(x[l]);
+        }
+        int n = n_eq;
+        while (n != 1) {
+            int mcount = 0;
+            for (int i = 0; i < n; i += 2) {
+                double *dst = red + (size_t)mcount * B;
+                const double *a = red + (size_t)i * B;
+                if (i + 1 == n) {
+                    if (dst != a)
+                        for (int l = 0; l < B; ++l) dst[l] = a[l];
+                } else {
+                    const double *b = red + (size_t)(i + 1) * B;
+                    /* max(a, b) = (a < b) ? b : a */
+                    for (int l = 0; l < B; ++l) dst[l] = (a[l] < b[l]) ? b[l] : a[l];
+                }
+                ++mcount;
+            }
+            n = mcount;
+        }
+        for (int l = 0; l < B; ++l) mx[(size_t)q * B + l] = red[l];
+    }
+
+    const double rf = rhofac(order);
+    const double inv_o = 1. / (double)order, inv_om1 = 1. / (double)(order - 1);
+    double *h = scratch; /* B */
+    for (int l = 0; l < B; ++l) {
+        const double m0 = mx[l], mo = mx[(size_t)B + l], mom1 = mx[(size_t)2 * B + l];
+        const double num_rho = (m0 <= 1.) ? 1. : m0;
+        const double rho_o = pow(num_rho / mo, inv_o);
+        const double rho_om1 = pow(num_rho / mom1, inv_om1);
+        /* min(a, b) = (b < a) ? b : a */
+        const double rho_m = (rho_om1 < rho_o) ? rho_om1 : rho_o;
+        double hh = rho_m * rf;
+        const double max_h = h_inout[l];
+        const double amh = fabs(max_h);
+        hh = (amh < hh) ? amh : hh;
+        if (max_h < 0.) hh = -1. * hh;
+        else hh = 1. * hh;
+        h[l] = hh;
+    }
+    free(mx);
+
+    /* State update. */
+    if (p->high_accuracy) {
+        double *cur_h = scratch + (size_t)B;
+        double *comp = scratch + (size_t)2 * B;
+        for (int i = 0; i < n_eq; ++i) {
+            const double *c0 = TAPE(0, i);
+            double *r = state + (size_t)i * B;
+            for (int l = 0; l < B; ++l) {
+                r[l] = c0[l];
+                comp[l] = 0.;
+                cur_h[l] = h[l];
+            }
+            for (int k = 1; k <= order; ++k) {
+                const double *ck = TAPE(k, i);
+                for (int l = 0; l < B; ++l) {
+                    const double tmp = ck[l] * cur_h[l];
+                    const double y = tmp - comp[l];
+                    const double t = r[l] + y;
+                    comp[l] = (t - r[l]) - y;
+                    r[l] = t;
+                    cur_h[l] = cur_h[l] * h[l];
+                }
+            }
+        }
+    } else {
+        for (int i = 0; i < n_eq; ++i) {
+            double *r = state + (size_t)i * B;
+            const double *cp = TAPE(order, i);
+            for (int l = 0; l < B; ++l) r[l] = cp[l];
+            for (int k = 1; k <= order; ++k) {
+                const double *ck = TAPE(order - k, i);
+                for (int l = 0; l < B; ++l) r[l] = ck[l] + r[l] * h[l];
+            }
+        }
+    }
+
+    if (tc != NULL) {
+        for (int i = 0; i < n_eq; ++i) {
+            for (int k = 0; k <= order; ++k) {
+                memcpy(tc + ((size_t)i * (size_t)(order + 1) + (size_t)k) * (size_t)B, TAPE(k, i),
+                       sizeof(double) * (size_t)B);
+            }
+        }
+    }
+
+    for (int l = 0; l < B; ++l) h_inout[l] = h[l];
+}
+
+/* ---- double-length arithmetic ---- */
+typedef struct {
+    double hi, lo;
+} dfloat;
+
+static inline void eft_add_knuth(double a, double b, double *x, double *y)
+{
+    *x = a + b;
+    const double z = *x - a;
+    *y = (a - (*x - z)) + (b - z);
+}
+
+static inline void eft_add_dekker(double a, double b, double *x, double *y)
+{
+    *x = a + b;
+    *y = (a - *x) + b;
+}
+
+static inline dfloat df_add(dfloat a, dfloat b)
+{
+    double x_hi, y_hi, x_lo, y_lo, u, v;
+    eft_add_knuth(a.hi, b.hi, &x_hi, &y_hi);
+    eft_add_knuth(a.lo, b.lo, &x_lo, &y_lo);
+    eft_add_dekker(x_hi, y_hi + x_lo, &u, &v);
+    double u2, v2;
+    eft_add_dekker(u, v + y_lo, &u2, &v2);
+    dfloat r = {u2, v2};
+    return r;
+}
+
+static inline dfloat df_sub(dfloat a, dfloat b)
+{
+    dfloat nb = {-b.hi, -b.lo};
+    return df_add(a, nb);
+}
+
+static inline int df_lt(dfloat x, dfloat y)
+{
+    return (x.hi < y.hi) || (x.hi == y.hi && x.lo < y.lo);
+}
+
+/* Exposed for the dfloat parity tests. */
+void hy_oracle_dfloat_add(double ahi, double alo, double bhi, double blo, double *rhi, double *rlo)
+{
+    dfloat a = {ahi, alo}, b = {bhi, blo};
+    dfloat r = df_add(a, b);
+    *rhi = r.hi;
+    *rlo = r.lo;
+}
+
+/*
+ * step_impl() for one batch (reference: src/taylor_adaptive_batch.cpp:632-727).
+ * outcome[l], h_out[l] = m_step_res.
+ */
+void hy_oracle_step_impl(const hy_oracle_program *p, int B, double *state, const double *pars, double *time_hi,
+                         double *time_lo, const double *max_delta_ts, double *tc, int64_t *outcome, double *h_out,
+                         double *scratch_mem)
+{
+    double *dts = (double *)malloc(sizeof(double) * (size_t)B);
+    memcpy(dts, max_delta_ts, sizeof(double) * (size_t)B);
+
+    hy_oracle_step(p, B, state, pars, time_hi, dts, tc, scratch_mem);
+
+    for (int l = 0; l < B; ++l) {
+        const double h = dts[l];
+        dfloat t = {time_hi[l], time_lo[l]};
+        dfloat hh = {h, 0.};
+        const dfloat nt = df_add(t, hh);
+        time_hi[l] = nt.hi;
+        time_lo[l] = nt.lo;
+        h_out[l] = h;
+        int nf = !(isfinite(nt.hi) && isfinite(nt.lo));
+        for (int i = 0; i < p->n_eq && !nf; ++i) {
+            if (!isfinite(state[(size_t)i * B + l])) nf = 1;
+        }
+        if (nf) {
+            outcome[l] = OC_ERR_NF_STATE;
+        } else {
+            outcome[l] = (h == max_delta_ts[l]) ? OC_TIME_LIMIT : OC_SUCCESS;
+        }
+    }
+    free(dts);
+}
+
+/*
+ * propagate_until() for one batch of B lanes in lock-step, with the reference's semantics
+ * (reference: src/taylor_adaptive_batch.cpp:1137-1534, no callback / no continuous output).
+ * t_final[l] single-length final times; max_delta_t[l] > 0 (or +inf); max_steps 0 = unlimited.
+ * Outputs: outcome, min_h, max_h, n_steps per lane.
+ */
+void hy_oracle_propagate_until(const hy_oracle_program *p, int B, double *state, const double *pars, double *time_hi,
+                               double *time_lo, const double *t_final, const double *max_delta_t, int64_t max_steps,
+                               int64_t *outcome, double *min_h, double *max_h, int64_t *n_steps, double *scratch_mem)
+{
+    dfloat *rem = (dfloat *)malloc(sizeof(dfloat) * (size_t)B);
+    int *t_dir = (int *)malloc(sizeof(int) * (size_t)B);
+    double *cur_dt = (double *)malloc(sizeof(double) * (size_t)B);
+    double *h_out = (double *)malloc(sizeof(double) * (size_t)B);
+    int64_t *oc = (int64_t *)malloc(sizeof(int64_t) * (size_t)B);
+
+    int64_t iter = 0;
+    for (int l = 0; l < B; ++l) {
+        n_steps[l] = 0;
+        min_h[l] = INFINITY;
+        max_h[l] = 0;
+        dfloat tf = {t_final[l], 0.}, t = {time_hi[l], time_lo[l]};
+        rem[l] = df_sub(tf, t);
+        t_dir[l] = (rem[l].hi > 0.) || (rem[l].hi == 0. && rem[l].lo >= 0.);
+    }
+
+    while (1) {
+        for (int l = 0; l < B; ++l) {
+            dfloat lim;
+            if (t_dir[l]) {
+                dfloat m = {max_delta_t[l], 0.};
+                lim = df_lt(rem[l], m) ? rem[l] : m; /* std::min(m, rem) */
+            } else {
+                dfloat m = {-max_delta_t[l], 0.};
+                lim = df_lt(m, rem[l]) ? rem[l] : m; /* std::max(m, rem) */
+            }
+            cur_dt[l] = lim.hi;
+        }
+
+        hy_oracle_step_impl(p, B, state, pars, time_hi, time_lo, cur_dt, NULL, oc, h_out, scratch_mem);
+
+        int n_done = 0, nfs = 0;
+        for (int l = 0; l < B; ++l) {
+            const double h = h_out[l];
+            if (oc[l] == OC_ERR_NF_STATE) {
+                nfs = 1;
+            } else {
+                n_steps[l] += (h != 0);
+                if (oc[l] == OC_SUCCESS) {
+                    const double ah = fabs(h);
+                    min_h[l] = (ah < min_h[l]) ? ah : min_h[l];
+                    max_h[l] = (max_h[l] < ah) ? ah : max_h[l];
+                }
+                const int cur_done = (h == rem[l].hi);
+                n_done += cur_done;
+                if (cur_done) {
+                    rem[l].hi = 0.;
+                    rem[l].lo = 0.;
+                } else {
+                    dfloat tf = {t_final[l], 0.}, t = {time_hi[l], time_lo[l]};
+                    rem[l] = df_sub(tf, t);
+                }
+            }
+            outcome[l] = oc[l];
+        }
+
+        if (nfs) break;
+        ++iter;
+        if (n_done == B) break;
+        if (iter == max_steps) {
+            for (int l = 0; l < B; ++l) outcome[l] = OC_STEP_LIMIT;
+            break;
+        }
+    }
+
+    free(rem);
+    free(t_dir);
+    free(cur_dt);
+    free(h_out);
+    free(oc);
+}
+
+/*
+ * Ensemble driver: N systems organised as N / B batches (N % B == 0), arrays laid out
+ * [row * N + sys]; every batch is gathered into a private [row * B + lane] buffer, propagated
+ * with the reference's lock-step semantics, and scattered back (mirrors the TBB parallel_for
+ * over batch integrators of src/ensemble_propagate.cpp:193-222). Returns the total number of
+ * steps taken (sum over lanes).
+ */
+int64_t hy_oracle_ensemble_propagate_until(const hy_oracle_program *p, int64_t N, int B, double *state,
+                                           const double *pars, double *time_hi, double *time_lo, double t_final,
+                                           int64_t max_steps, int64_t *outcome, double *min_h, double *max_h,
+                                           int64_t *n_steps, int n_threads)
+{
+    const int64_t n_batches = N / B;
+    int64_t total = 0;
+    const size_t ssz = hy_oracle_scratch_size(p, B);
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel reduction(+ : total)
+#endif
+    {
+        double *scratch = (double *)malloc(sizeof(double) * ssz);
+        double *st = (double *)malloc(sizeof(double) * (size_t)p->n_eq * (size_t)B);
+        double *pr = (double *)malloc(sizeof(double) * (size_t)(p->n_par > 0 ? p->n_par : 1) * (size_t)B);
+        double *tf = (double *)malloc(sizeof(double) * (size_t)B);
+        double *md = (double *)malloc(sizeof(double) * (size_t)B);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (int64_t b = 0; b < n_batches; ++b) {
+            const int64_t off = b * B;
+            for (int i = 0; i < p->n_eq; ++i)
+                for (int l = 0; l < B; ++l) st[(size_t)i * B + l] = state[(size_t)i * N + off + l];
+            for (int i = 0; i < p->n_par; ++i)
+                for (int l = 0; l < B; ++l) pr[(size_t)i * B + l] = pars[(size_t)i * N + off + l];
+            for (int l = 0; l < B; ++l) {
+                tf[l] = t_final;
+                md[l] = INFINITY;
+            }
+            hy_oracle_propagate_until(p, B, st, pr, time_hi + off, time_lo + off, tf, md, max_steps, outcome + off,
+                                      min_h + off, max_h + off, n_steps + off, scratch);
+            for (int i = 0; i < p->n_eq; ++i)
+                for (int l = 0; l < B; ++l) state[(size_t)i * N + off + l] = st[(size_t)i * B + l];
+            for (int l = 0; l < B; ++l) total += n_steps[off + l];
+        }
+        free(scratch);
+        free(st);
+        free(pr);
+        free(tf);
+        free(md);
+    }
+    return total;
+}
+
+int hy_oracle_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
