@@ -1,0 +1,247 @@
+#!/usr/bin/env python
+"""Headline benchmark: ODE systems x steps / sec (fp64) for the outer-Solar-System ensemble.
+
+Metric / workload (BASELINE.json): `model::nbody` outer Solar System 6-body, fp64, tol = eps
+(order 20), high_accuracy = true, 1 048 576 perturbed ICs per MI355X
+(benchmark/outer_ss_long_term_batch.cpp of the reference with --perturb 1e-12 --seed 42), propagated
+with the device-resident `propagate_until()`.
+
+One bench "step" = one propagate_until(t + DT) over the whole ensemble (every system takes its own
+adaptive Taylor steps). value = sum over systems of Taylor steps taken (h != 0, like m_ts_count in
+src/taylor_adaptive_batch.cpp:1417) / wall time, aggregated over all ranks (weak scaling: every rank
+integrates `--systems` independent ICs, different seeds; the only collective on the path is the
+final all_gather of the states, the `ensemble_propagate_*` contract).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (n_eq, n_u, B_tape bytes / system-step, F_alg flop / system-step)  (order 20)
+    "outer_ss": (36, 234, 8 * (2 * 36 + 6) + 16 * 234 * 20, 5.7e4),
+    "two_body": (12, 21, 8 * (2 * 12 + 6) + 16 * 21 * 20, 4.1e3),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_PEAK_TFLOPS = 78.6  # vector FP64
+
+
+def make_integrator(hy, configs, workload, n_systems, seed):
+    if workload == "outer_ss":
+        sys_ = hy.model.nbody(6, masses=configs.OUTER_SS_MASSES, Gconst=configs.OUTER_SS_G)
+        st = configs.outer_ss_state(n_systems, perturb=1e-12, seed=seed)
+        ta = hy.taylor_adaptive_batch(sys_, None, n_systems, high_accuracy=True)
+        dt = 4.0  # years per bench step
+    else:
+        sys_ = hy.model.nbody(2, masses=[1.0, 0.0])
+        st = configs.two_body_state(n_systems, perturb=1e-12, seed=seed)
+        ta = hy.taylor_adaptive_batch(sys_, None, n_systems, high_accuracy=False)
+        dt = 5.0
+    return ta, st, dt
+
+
+def cpu_baseline(workload, dt, target_seconds=15.0):
+    """The oracle (C restatement, OpenMP over SIMD-width batches like the reference's
+    TBB-over-batches ensemble) timed on this host on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import heyoka_oracle as ho
+    from heyoka_amd import configs
+
+    width = 8
+    threads = ho.max_threads()
+    if workload == "outer_ss":
+        osys = ho.nbody(6, masses=configs.OUTER_SS_MASSES, Gconst=configs.OUTER_SS_G)
+        gen = lambda n: configs.outer_ss_state(n, perturb=1e-12, seed=42)
+        ha = True
+    else:
+        osys = ho.nbody(2, masses=[1.0, 0.0])
+        gen = lambda n: configs.two_body_state(n, perturb=1e-12, seed=42)
+        ha = False
+    # Calibration run, then a sample sized for ~target_seconds.
+    n0 = width * threads
+    t0 = time.perf_counter()
+    *_, tot = ho.ensemble_propagate_until(osys, gen(n0), n0, width, dt, high_accuracy=ha)
+    el = time.perf_counter() - t0
+    rate = tot / max(el, 1e-9)
+    n = int(max(n0, min(262144, (rate * target_seconds / max(tot / n0, 1.0)) // (width * threads) * width * threads)))
+    t0 = time.perf_counter()
+    *_, tot = ho.ensemble_propagate_until(osys, gen(n), n, width, dt, high_accuracy=ha)
+    el = time.perf_counter() - t0
+    return {
+        "value": tot / el,
+        "unit": "system-steps/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "%d %s systems propagated to t=%g (%d system-steps) in %.1f s; oracle C interpreter, "
+        "batch width %d, %d OpenMP threads, gcc -O2 -march=native -ffp-contract=off" % (n, workload, dt, tot, el, width, threads),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--systems", type=int, default=1048576, help="systems per GPU")
+    ap.add_argument("--workload", default="outer_ss", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl")
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if distributed else 0)
+
+    import heyoka_amd as hy
+    from heyoka_amd import configs
+    from heyoka_amd import ensemble as hens
+
+    if distributed:
+        # One process per GPU: each process sees its GPU as the current torch device; the
+        # integrator is created on that ordinal.
+        pass
+
+    n = args.systems
+    t_build = time.perf_counter()
+    ta, st, dt = make_integrator(hy, configs, args.workload, n, seed=42 + rank)
+    if distributed and local_rank != 0:
+        # Re-create on the right device ordinal.
+        ta = hy.taylor_adaptive_batch(ta._sys, None, n, high_accuracy=ta.high_accuracy, device=local_rank)
+    build_s = time.perf_counter() - t_build
+
+    # Inputs resident in HBM before the timed region; kernels on torch's current stream so that
+    # torch.cuda.Event (HIP events) brackets them.
+    ta.set_stream(torch.cuda.current_stream().cuda_stream)
+    view = torch.as_tensor(ta.device_array("state"), device=dev)
+    view.copy_(torch.from_numpy(st))
+    torch.cuda.synchronize()
+    ta.mark_device_modified()
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    t_cur = 0.0
+    for _ in range(args.warmup):
+        t_cur += dt
+        ta.propagate_until(t_cur)
+    barrier()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # Step counters live on the device: accumulate them with a device-side reduction per call (same
+    # stream, no host synchronisation inside the timed region).
+    nsteps_view = torch.as_tensor(ta.device_array("n_steps"), device=dev)
+    steps_acc = torch.zeros(args.steps, dtype=torch.int64, device=dev)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        t_cur += dt
+        ev[k][0].record()
+        ta.propagate_until(t_cur)
+        ev[k][1].record()
+        steps_acc[k] = nsteps_view.sum()
+    gathered = None
+    if distributed:
+        # ensemble_propagate_*: the only exchange on the path is the gather of the final states.
+        gathered = hens.all_gather_states(view)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    # Per-launch kernel durations (HIP events on the launch stream) and step counts.
+    kern_ms = [a.elapsed_time(b) for a, b in ev]
+    steps_per_call_all = steps_acc.cpu().numpy().astype(np.float64)
+    steps_per_call = float(steps_per_call_all.mean())
+
+    oc, mn, mx, ns = ta.propagate_res_arrays()
+    ok = bool(np.all(oc == int(hy.taylor_outcome.time_limit)))
+
+    local_steps = float(steps_per_call_all.sum())
+    local = torch.tensor([elapsed, local_steps, float(np.mean(kern_ms))], dtype=torch.float64, device=dev)
+    if distributed:
+        mx_t = local.clone()
+        dist.all_reduce(mx_t, op=dist.ReduceOp.MAX)
+        sm_t = local.clone()
+        dist.all_reduce(sm_t, op=dist.ReduceOp.SUM)
+        elapsed_max = float(mx_t[0])
+        total_steps = float(sm_t[1])
+    else:
+        elapsed_max = elapsed
+        total_steps = local_steps
+
+    if rank == 0:
+        n_eq, n_u, b_tape, f_alg = WORKLOADS[args.workload]
+        value = total_steps / elapsed_max
+        k_ms = float(np.mean(kern_ms))
+        per_launch_steps = float(steps_per_call)
+        achieved_gbs = b_tape * per_launch_steps / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "ODE systems x steps/sec (fp64)",
+            "value": value,
+            "unit": "system-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "%s: %d perturbed ICs per GPU (perturb 1e-12, mt19937 seed 42+rank), tol=eps (order 20), "
+                "high_accuracy=%s, propagate_until in increments of %g time units"
+                % (args.workload, n, str(bool(ta.high_accuracy)).lower(), dt),
+                "systems_per_gpu": n,
+                "taylor_order": ta.order,
+                "n_eq": n_eq,
+                "n_uvars": n_u,
+                "system_steps_per_launch": per_launch_steps,
+                "all_outcomes_time_limit": ok,
+                "integrator_build_s": build_s,
+                "hiprtc_compile_s": ta.compile_seconds,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved_gbs,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved_gbs / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": "hy_taylor",
+                "kernel_ms_avg": k_ms,
+                "algorithmic_bytes_per_system_step": b_tape,
+                "fp64_valu_frac": f_alg * per_launch_steps / (k_ms * 1e-3) / (FP64_PEAK_TFLOPS * 1e12),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, dt, args.cpu_seconds)
+        print(json.dumps(out))
+
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,639 @@
+"""heyoka_amd: MI355X-native batch Taylor integrator with heyoka's interface.
+
+Python host layer over the C ABI (include/heyoka_amd.h). Names, argument meaning and error
+behaviour mirror the reference's C++ interface for this path (bluescarni/heyoka v7.12.0:
+include/heyoka/expression.hpp, include/heyoka/taylor.hpp:781-1121,
+include/heyoka/ensemble_propagate.hpp:222-271, include/heyoka/model/nbody.hpp) in the shape of its
+Python bindings (properties `state`, `time`, `step_res`, ...), so that parity tests read like the
+reference's own tests. All numerical work happens in generated HIP kernels on the GPU: there is no
+CPU fallback in this package.
+"""
+
+import ctypes
+import enum
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, raise_for, check_handle, take_str
+
+__all__ = [
+    "expression",
+    "make_vars",
+    "par",
+    "time",
+    "sin",
+    "cos",
+    "exp",
+    "log",
+    "sqrt",
+    "pow",
+    "sum",
+    "prod",
+    "model",
+    "taylor_outcome",
+    "taylor_adaptive_batch",
+    "taylor_decompose_sys",
+    "ensemble_propagate_until_batch",
+    "ensemble_propagate_for_batch",
+    "device_count",
+    "version",
+]
+
+_builtin_sum = sum
+_builtin_pow = pow
+
+
+def version():
+    return take_str(lib.hy_version())
+
+
+def device_count():
+    return int(lib.hy_device_count())
+
+
+class taylor_outcome(enum.IntEnum):
+    """include/heyoka/taylor.hpp:142-155."""
+
+    success = -4294967296 - 1
+    step_limit = -4294967296 - 2
+    time_limit = -4294967296 - 3
+    err_nf_state = -4294967296 - 4
+    cb_stop = -4294967296 - 5
+
+
+def _outcome(v):
+    try:
+        return taylor_outcome(int(v))
+    except ValueError:
+        return int(v)
+
+
+class expression:
+    """Symbolic expression (include/heyoka/expression.hpp:73-118)."""
+
+    __slots__ = ("_h",)
+
+    def __init__(self, x=0.0, _handle=None):
+        if _handle is not None:
+            self._h = _handle
+        elif isinstance(x, expression):
+            raise TypeError("copy-construct expressions by assignment")
+        elif isinstance(x, str):
+            self._h = check_handle(lib.hy_expr_var(x.encode()))
+        else:
+            self._h = check_handle(lib.hy_expr_num(float(x)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib.hy_expr_free(h)
+            self._h = None
+
+    @staticmethod
+    def _wrap(h):
+        return expression(_handle=check_handle(h))
+
+    def __repr__(self):
+        return take_str(lib.hy_expr_str(self._h))
+
+    def __neg__(self):
+        return expression._wrap(lib.hy_expr_neg(self._h))
+
+    def __pos__(self):
+        return self
+
+    def __add__(self, o):
+        return _bin(lib.hy_expr_add, self, o)
+
+    def __radd__(self, o):
+        return _bin(lib.hy_expr_add, o, self)
+
+    def __sub__(self, o):
+        return _bin(lib.hy_expr_sub, self, o)
+
+    def __rsub__(self, o):
+        return _bin(lib.hy_expr_sub, o, self)
+
+    def __mul__(self, o):
+        return _bin(lib.hy_expr_mul, self, o)
+
+    def __rmul__(self, o):
+        return _bin(lib.hy_expr_mul, o, self)
+
+    def __truediv__(self, o):
+        return _bin(lib.hy_expr_div, self, o)
+
+    def __rtruediv__(self, o):
+        return _bin(lib.hy_expr_div, o, self)
+
+    def __pow__(self, o):
+        return _bin(lib.hy_expr_pow, self, o)
+
+
+def _as_ex(x):
+    return x if isinstance(x, expression) else expression(x)
+
+
+def _bin(fn, a, b):
+    # NOTE: keep the (possibly temporary) operands alive across the C call.
+    a, b = _as_ex(a), _as_ex(b)
+    return expression._wrap(fn(a._h, b._h))
+
+
+def _un(fn, a):
+    a = _as_ex(a)
+    return expression._wrap(fn(a._h))
+
+
+def make_vars(*names):
+    """make_vars("x", "v") (include/heyoka/expression.hpp)."""
+    vs = [expression(n) for n in names]
+    return vs[0] if len(vs) == 1 else vs
+
+
+class _Par:
+    """par[i] (include/heyoka/param.hpp)."""
+
+    def __getitem__(self, i):
+        return expression._wrap(lib.hy_expr_par(int(i)))
+
+
+par = _Par()
+time = expression._wrap(lib.hy_expr_time())
+
+
+def sin(e):
+    return _un(lib.hy_expr_sin, e)
+
+
+def cos(e):
+    return _un(lib.hy_expr_cos, e)
+
+
+def exp(e):
+    return _un(lib.hy_expr_exp, e)
+
+
+def log(e):
+    return _un(lib.hy_expr_log, e)
+
+
+def sqrt(e):
+    return _un(lib.hy_expr_sqrt, e)
+
+
+def pow(b, e):  # noqa: A001 - mirrors heyoka::pow
+    return _bin(lib.hy_expr_pow, b, e)
+
+
+def _handle_array(exs):
+    exs = [_as_ex(e) for e in exs]
+    arr = (ctypes.c_void_p * max(len(exs), 1))(*[e._h for e in exs])
+    return exs, arr
+
+
+def sum(args):  # noqa: A001 - mirrors heyoka::sum
+    exs, arr = _handle_array(args)
+    return expression._wrap(lib.hy_expr_sum(arr, len(exs)))
+
+
+def prod(args):
+    exs, arr = _handle_array(args)
+    return expression._wrap(lib.hy_expr_prod(arr, len(exs)))
+
+
+class _Sys:
+    """Owned hy_sys handle built from a list of (lhs, rhs) pairs."""
+
+    def __init__(self, sys=None, _handle=None):
+        if _handle is not None:
+            self._h = _handle
+            return
+        self._h = check_handle(lib.hy_sys_new())
+        for lhs, rhs in sys:
+            lhs, rhs = _as_ex(lhs), _as_ex(rhs)  # keep temporaries alive across the C call
+            raise_for(lib.hy_sys_add(self._h, lhs._h, rhs._h))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib.hy_sys_free(h)
+            self._h = None
+
+    def __len__(self):
+        return int(lib.hy_sys_size(self._h))
+
+
+def _to_sys(sys):
+    return sys if isinstance(sys, _Sys) else _Sys(sys)
+
+
+class model:
+    """heyoka::model (include/heyoka/model/nbody.hpp:73-78, model/pendulum.hpp)."""
+
+    @staticmethod
+    def nbody(n, masses=None, Gconst=1.0):
+        if masses is None:
+            h = lib.hy_model_nbody(int(n), None, 0, float(Gconst))
+        else:
+            m = np.ascontiguousarray(np.asarray(masses, dtype=np.float64))
+            h = lib.hy_model_nbody(int(n), m.ctypes.data, m.size, float(Gconst))
+        return _Sys(_handle=check_handle(h))
+
+    @staticmethod
+    def pendulum(gconst=1.0, length=1.0):
+        return _Sys(_handle=check_handle(lib.hy_model_pendulum(float(gconst), float(length))))
+
+
+def taylor_decompose_sys(sys):
+    """taylor_decompose_sys() (src/taylor_01.cpp:848-1008) -> list of textual entries."""
+    s = _to_sys(sys)
+    txt = take_str(check_handle(lib.hy_sys_decomposition_str(s._h)))
+    return txt.rstrip("\n").split("\n")
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+class _DeviceArray:
+    """Zero-copy view of one of the integrator's device arrays (for torch.as_tensor / cupy)."""
+
+    def __init__(self, ptr, shape, owner, typestr="<f8"):
+        self._owner = owner
+        self.__cuda_array_interface__ = {
+            "shape": tuple(int(s) for s in shape),
+            "typestr": typestr,
+            "data": (int(ptr), False),
+            "version": 2,
+            "strides": None,
+        }
+
+
+class taylor_adaptive_batch:
+    """taylor_adaptive_batch<double> (include/heyoka/taylor.hpp:781-1121) on MI355X.
+
+    `batch_size` is the number of systems integrated concurrently (one GPU lane each).
+    Arrays are exposed with shape (rows, batch_size), i.e. the reference's flat layout
+    array[row * batch_size + lane].
+    """
+
+    def __init__(self, sys, state=None, batch_size=None, *, tol=None, high_accuracy=False, compact_mode=False,
+                 parallel_mode=False, pars=None, time=None, device=0, _handle=None, **ignored_llvm_kwargs):
+        # LLVM-only keyword arguments of the reference (opt_level, fast_math, force_avx512,
+        # slp_vectorize, code_model, parjit) are accepted and ignored.
+        for k in ignored_llvm_kwargs:
+            if k not in ("opt_level", "fast_math", "force_avx512", "slp_vectorize", "code_model", "parjit", "mname"):
+                raise TypeError("unexpected keyword argument '%s'" % k)
+        if _handle is not None:
+            self._h = _handle
+            self._sys = sys
+            return
+        self._sys = _to_sys(sys)
+        if state is None:
+            st = np.zeros(0)
+        else:
+            st = _f64(state)
+            if batch_size is None:
+                if st.ndim != 2:
+                    raise ValueError("batch_size must be given unless the state is a 2D (n_eq, batch_size) array")
+                batch_size = st.shape[1]
+            st = st.reshape(-1)
+        if batch_size is None:
+            raise ValueError("batch_size must be specified")
+        cfg = _lib.TabConfig()
+        cfg.tol = 0.0 if tol is None else float(tol)
+        cfg.high_accuracy = int(bool(high_accuracy))
+        cfg.compact_mode = int(bool(compact_mode))
+        cfg.parallel_mode = int(bool(parallel_mode))
+        keep = []
+        if pars is not None:
+            p = _f64(pars).reshape(-1)
+            keep.append(p)
+            cfg.pars = p.ctypes.data
+            cfg.n_pars = p.size
+        if time is not None:
+            t = _f64(time).reshape(-1)
+            keep.append(t)
+            cfg.time = t.ctypes.data
+            cfg.n_time = t.size
+        cfg.device = int(device)
+        if tol is not None and float(tol) == 0.0:
+            cfg.tol = 0.0
+        self._h = check_handle(
+            lib.hy_tab_create(self._sys._h, st.ctypes.data if st.size else None, st.size, int(batch_size),
+                              ctypes.byref(cfg))
+        )
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib.hy_tab_free(h)
+            self._h = None
+
+    def __copy__(self):
+        return taylor_adaptive_batch(self._sys, _handle=check_handle(lib.hy_tab_copy(self._h)))
+
+    def __deepcopy__(self, memo):
+        return self.__copy__()
+
+    copy = __copy__
+
+    # ---- read-only properties ----
+    @property
+    def batch_size(self):
+        return int(lib.hy_tab_get_batch_size(self._h))
+
+    @property
+    def order(self):
+        return int(lib.hy_tab_get_order(self._h))
+
+    @property
+    def dim(self):
+        return int(lib.hy_tab_get_dim(self._h))
+
+    @property
+    def n_pars(self):
+        return int(lib.hy_tab_get_n_pars(self._h))
+
+    @property
+    def n_uvars(self):
+        return int(lib.hy_tab_get_n_uvars(self._h))
+
+    @property
+    def tol(self):
+        return float(lib.hy_tab_get_tol(self._h))
+
+    @property
+    def high_accuracy(self):
+        return bool(lib.hy_tab_get_high_accuracy(self._h))
+
+    @property
+    def compact_mode(self):
+        return bool(lib.hy_tab_get_compact_mode(self._h))
+
+    @property
+    def compile_seconds(self):
+        return float(lib.hy_tab_get_compile_seconds(self._h))
+
+    @property
+    def hip_source(self):
+        return take_str(lib.hy_tab_get_hip_source(self._h))
+
+    @property
+    def decomposition(self):
+        return take_str(lib.hy_tab_get_decomposition_str(self._h)).rstrip("\n").split("\n")
+
+    # ---- state / time / pars ----
+    @property
+    def state(self):
+        out = np.empty((self.dim, self.batch_size))
+        raise_for(lib.hy_tab_get_state(self._h, out.ctypes.data))
+        return out
+
+    @state.setter
+    def state(self, v):
+        a = _f64(v).reshape(-1)
+        if a.size != self.dim * self.batch_size:
+            raise ValueError("invalid state size")
+        raise_for(lib.hy_tab_set_state(self._h, a.ctypes.data))
+
+    @property
+    def pars(self):
+        out = np.empty((self.n_pars, self.batch_size))
+        if out.size:
+            raise_for(lib.hy_tab_get_pars(self._h, out.ctypes.data))
+        return out
+
+    @pars.setter
+    def pars(self, v):
+        a = _f64(v).reshape(-1)
+        if a.size != self.n_pars * self.batch_size:
+            raise ValueError("invalid pars size")
+        if a.size:
+            raise_for(lib.hy_tab_set_pars(self._h, a.ctypes.data))
+
+    @property
+    def dtime(self):
+        hi, lo = np.empty(self.batch_size), np.empty(self.batch_size)
+        raise_for(lib.hy_tab_get_dtime(self._h, hi.ctypes.data, lo.ctypes.data))
+        return hi, lo
+
+    @dtime.setter
+    def dtime(self, v):
+        hi, lo = v
+        hi, lo = _f64(hi).reshape(-1), _f64(lo).reshape(-1)
+        raise_for(lib.hy_tab_set_dtime(self._h, hi.ctypes.data, lo.ctypes.data, hi.size))
+
+    @property
+    def time(self):
+        return self.dtime[0]
+
+    @time.setter
+    def time(self, v):
+        t = _f64(v).reshape(-1)
+        raise_for(lib.hy_tab_set_time(self._h, t.ctypes.data, t.size))
+
+    def set_time(self, v):
+        self.time = v
+
+    def set_dtime(self, hi, lo):
+        self.dtime = (hi, lo)
+
+    @property
+    def tc(self):
+        out = np.empty((self.dim, self.order + 1, self.batch_size))
+        raise_for(lib.hy_tab_get_tc(self._h, out.ctypes.data))
+        return out
+
+    @property
+    def last_h(self):
+        out = np.empty(self.batch_size)
+        raise_for(lib.hy_tab_get_last_h(self._h, out.ctypes.data))
+        return out
+
+    def update_d_output(self, t, rel_time=False):
+        tt = _f64(t).reshape(-1)
+        out = np.empty((self.dim, self.batch_size))
+        raise_for(lib.hy_tab_update_d_output(self._h, tt.ctypes.data, tt.size, int(bool(rel_time)), out.ctypes.data))
+        return out
+
+    # ---- stepping ----
+    def step(self, max_delta_t=None, write_tc=False):
+        if max_delta_t is None:
+            raise_for(lib.hy_tab_step(self._h, int(bool(write_tc))))
+        else:
+            m = _f64(max_delta_t).reshape(-1)
+            raise_for(lib.hy_tab_step_limited(self._h, m.ctypes.data, m.size, int(bool(write_tc))))
+
+    def step_backward(self, write_tc=False):
+        raise_for(lib.hy_tab_step_backward(self._h, int(bool(write_tc))))
+
+    @property
+    def step_res(self):
+        n = self.batch_size
+        oc = np.empty(n, dtype=np.int64)
+        h = np.empty(n)
+        raise_for(lib.hy_tab_get_step_res(self._h, oc.ctypes.data, h.ctypes.data))
+        return [(_outcome(oc[i]), float(h[i])) for i in range(n)]
+
+    def _propagate(self, fn, t, max_steps, max_delta_t, callback, write_tc, c_output):
+        tt = _f64(t).reshape(-1)
+        if max_delta_t is None:
+            mptr, mn, mkeep = None, 0, None
+        else:
+            mkeep = _f64(max_delta_t).reshape(-1)
+            mptr, mn = mkeep.ctypes.data, mkeep.size
+        err = []
+        if callback is not None:
+
+            def _tramp(_tab, _data):
+                try:
+                    return 1 if callback(self) else 0
+                except BaseException as e:  # propagate Python exceptions out of the C frame
+                    err.append(e)
+                    return 0
+
+            cb = _lib.STEP_CALLBACK(_tramp)
+        else:
+            cb = None
+        rc = fn(self._h, tt.ctypes.data, tt.size, int(max_steps), mptr, mn,
+                ctypes.cast(cb, ctypes.c_void_p) if cb is not None else None, None, int(bool(write_tc)),
+                int(bool(c_output)))
+        if err:
+            raise err[0]
+        raise_for(rc)
+        return callback
+
+    def propagate_until(self, t, max_steps=0, max_delta_t=None, callback=None, write_tc=False, c_output=False):
+        return self._propagate(lib.hy_tab_propagate_until, t, max_steps, max_delta_t, callback, write_tc, c_output)
+
+    def propagate_for(self, delta_t, max_steps=0, max_delta_t=None, callback=None, write_tc=False, c_output=False):
+        return self._propagate(lib.hy_tab_propagate_for, delta_t, max_steps, max_delta_t, callback, write_tc, c_output)
+
+    def propagate_grid(self, grid, max_steps=0, max_delta_t=None, callback=None):
+        g = _f64(grid)
+        if g.ndim == 1:
+            g = np.repeat(g[:, None], self.batch_size, axis=1)
+        g = np.ascontiguousarray(g)
+        n_grid = g.shape[0]
+        out = np.empty((n_grid, self.dim, self.batch_size))
+        if max_delta_t is None:
+            mptr, mn, mkeep = None, 0, None
+        else:
+            mkeep = _f64(max_delta_t).reshape(-1)
+            mptr, mn = mkeep.ctypes.data, mkeep.size
+        err = []
+        cb = None
+        if callback is not None:
+
+            def _tramp(_tab, _data):
+                try:
+                    return 1 if callback(self) else 0
+                except BaseException as e:
+                    err.append(e)
+                    return 0
+
+            cb = _lib.STEP_CALLBACK(_tramp)
+        rc = lib.hy_tab_propagate_grid(self._h, g.ctypes.data, n_grid, int(max_steps), mptr, mn,
+                                       ctypes.cast(cb, ctypes.c_void_p) if cb is not None else None, None,
+                                       out.ctypes.data)
+        if err:
+            raise err[0]
+        raise_for(rc)
+        return callback, out
+
+    @property
+    def propagate_res(self):
+        n = self.batch_size
+        oc = np.empty(n, dtype=np.int64)
+        mn, mx = np.empty(n), np.empty(n)
+        ns = np.empty(n, dtype=np.uint64)
+        raise_for(lib.hy_tab_get_propagate_res(self._h, oc.ctypes.data, mn.ctypes.data, mx.ctypes.data, ns.ctypes.data))
+        return [(_outcome(oc[i]), float(mn[i]), float(mx[i]), int(ns[i])) for i in range(n)]
+
+    def propagate_res_arrays(self):
+        """(outcome, min_h, max_h, n_steps) as numpy arrays (cheap for 10^6 lanes)."""
+        n = self.batch_size
+        oc = np.empty(n, dtype=np.int64)
+        mn, mx = np.empty(n), np.empty(n)
+        ns = np.empty(n, dtype=np.uint64)
+        raise_for(lib.hy_tab_get_propagate_res(self._h, oc.ctypes.data, mn.ctypes.data, mx.ctypes.data, ns.ctypes.data))
+        return oc, mn, mx, ns
+
+    # ---- device-resident access (MI355X extension) ----
+    _BUFS = {"state": 0, "pars": 1, "time_hi": 2, "time_lo": 3, "tc": 4, "n_steps": 5, "outcome": 6, "last_h": 7}
+
+    def device_array(self, which):
+        """Zero-copy __cuda_array_interface__ view of a device array: 'state' (dim, N),
+        'pars' (n_pars, N), 'time_hi' (N,), 'time_lo' (N,), 'tc' (dim, order + 1, N)."""
+        ptr = check_handle(lib.hy_tab_device_ptr(self._h, self._BUFS[which]))
+        N = self.batch_size
+        shape = {
+            "state": (self.dim, N),
+            "pars": (self.n_pars, N),
+            "time_hi": (N,),
+            "time_lo": (N,),
+            "tc": (self.dim, self.order + 1, N),
+            "n_steps": (N,),
+            "outcome": (N,),
+            "last_h": (N,),
+        }[which]
+        return _DeviceArray(ptr, shape, self, "<i8" if which in ("n_steps", "outcome") else "<f8")
+
+    def mark_device_modified(self):
+        raise_for(lib.hy_tab_mark_device_modified(self._h))
+
+    def set_stream(self, stream_ptr):
+        raise_for(lib.hy_tab_set_stream(self._h, ctypes.c_void_p(int(stream_ptr) if stream_ptr else 0)))
+
+    def synchronize(self):
+        raise_for(lib.hy_tab_synchronize(self._h))
+
+    @property
+    def last_total_steps(self):
+        return int(lib.hy_tab_get_last_total_steps(self._h))
+
+    def raw_step(self, d_state, d_pars, d_time, d_h, d_tc, n_systems):
+        """Stepper function-pointer ABI on caller-owned device buffers (integers = device addresses)."""
+        raise_for(lib.hy_tab_raw_step(self._h, int(d_state), int(d_pars) if d_pars else None, int(d_time), int(d_h),
+                                      int(d_tc) if d_tc else None, int(n_systems)))
+
+
+def _ensemble(fn, ta, t, n_iter, gen, max_steps, n_devices):
+    if n_iter <= 0:
+        raise ValueError("Cannot perform an ensemble propagate if the number of iterations is zero")
+    err = []
+
+    def _gen(tab_handle, i, _data):
+        # Wrap the raw handle (not owned) so that gen can use the integrator interface.
+        view = taylor_adaptive_batch(ta._sys, _handle=tab_handle)
+        try:
+            gen(view, int(i))
+            return 0
+        except BaseException as e:
+            err.append(e)
+            return 1
+        finally:
+            view._h = None  # do not free: owned by the library
+
+    cgen = _lib.ENSEMBLE_GEN(_gen)
+    out = (ctypes.c_void_p * n_iter)()
+    rc = fn(ta._h, float(t), int(n_iter), ctypes.cast(cgen, ctypes.c_void_p), None, int(max_steps), int(n_devices), out)
+    if err:
+        raise err[0]
+    raise_for(rc)
+    return [taylor_adaptive_batch(ta._sys, _handle=out[i]) for i in range(n_iter)]
+
+
+def ensemble_propagate_until_batch(ta, t, n_iter, gen, max_steps=0, n_devices=0):
+    """ensemble_propagate_until_batch() (include/heyoka/ensemble_propagate.hpp:222-237).
+
+    gen(ta_copy, i) modifies the copy in place (the reference's generator returns the copy)."""
+    return _ensemble(lib.hy_ensemble_propagate_until_batch, ta, t, n_iter, gen, max_steps, n_devices)
+
+
+def ensemble_propagate_for_batch(ta, delta_t, n_iter, gen, max_steps=0, n_devices=0):
+    """ensemble_propagate_for_batch() (include/heyoka/ensemble_propagate.hpp:239-254)."""
+    return _ensemble(lib.hy_ensemble_propagate_for_batch, ta, delta_t, n_iter, gen, max_steps, n_devices)

@@ -1,0 +1,184 @@
+"""ctypes loader for libheyoka_amd.so (the C ABI declared in include/heyoka_amd.h).
+
+The library is the product: there is no Python/CPU fallback. If it is missing the import fails
+loudly; if it loads but no MI355X is visible, every operation that needs the device raises.
+"""
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libheyoka_amd.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "heyoka_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "or `make -C heyoka_amd/csrc` (there is no CPU fallback for the MI355X path)." % LIB_PATH
+    )
+
+lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+
+c_void_p = ctypes.c_void_p
+c_char_p = ctypes.c_char_p
+c_double = ctypes.c_double
+c_int = ctypes.c_int
+c_size_t = ctypes.c_size_t
+c_uint32 = ctypes.c_uint32
+c_uint64 = ctypes.c_uint64
+c_int64 = ctypes.c_int64
+dptr = ctypes.POINTER(c_double)
+
+
+class TabConfig(ctypes.Structure):
+    _fields_ = [
+        ("tol", c_double),
+        ("high_accuracy", c_int),
+        ("compact_mode", c_int),
+        ("parallel_mode", c_int),
+        ("pars", c_void_p),
+        ("n_pars", c_size_t),
+        ("time", c_void_p),
+        ("n_time", c_size_t),
+        ("device", c_int),
+    ]
+
+
+STEP_CALLBACK = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p)
+ENSEMBLE_GEN = ctypes.CFUNCTYPE(c_int, c_void_p, c_size_t, c_void_p)
+
+# (name, restype, argtypes): every symbol declared in include/heyoka_amd.h.
+SIGNATURES = [
+    ("hy_last_error", c_char_p, []),
+    ("hy_last_error_code", c_int, []),
+    ("hy_free_str", None, [c_void_p]),
+    ("hy_version", c_void_p, []),
+    ("hy_device_count", c_int, []),
+    ("hy_expr_var", c_void_p, [c_char_p]),
+    ("hy_expr_num", c_void_p, [c_double]),
+    ("hy_expr_par", c_void_p, [c_uint32]),
+    ("hy_expr_time", c_void_p, []),
+    ("hy_expr_neg", c_void_p, [c_void_p]),
+    ("hy_expr_add", c_void_p, [c_void_p, c_void_p]),
+    ("hy_expr_sub", c_void_p, [c_void_p, c_void_p]),
+    ("hy_expr_mul", c_void_p, [c_void_p, c_void_p]),
+    ("hy_expr_div", c_void_p, [c_void_p, c_void_p]),
+    ("hy_expr_pow", c_void_p, [c_void_p, c_void_p]),
+    ("hy_expr_sqrt", c_void_p, [c_void_p]),
+    ("hy_expr_sin", c_void_p, [c_void_p]),
+    ("hy_expr_cos", c_void_p, [c_void_p]),
+    ("hy_expr_exp", c_void_p, [c_void_p]),
+    ("hy_expr_log", c_void_p, [c_void_p]),
+    ("hy_expr_sum", c_void_p, [c_void_p, c_size_t]),
+    ("hy_expr_prod", c_void_p, [c_void_p, c_size_t]),
+    ("hy_expr_free", None, [c_void_p]),
+    ("hy_expr_str", c_void_p, [c_void_p]),
+    ("hy_sys_new", c_void_p, []),
+    ("hy_sys_add", c_int, [c_void_p, c_void_p, c_void_p]),
+    ("hy_sys_size", c_size_t, [c_void_p]),
+    ("hy_sys_free", None, [c_void_p]),
+    ("hy_model_nbody", c_void_p, [c_uint32, c_void_p, c_size_t, c_double]),
+    ("hy_model_pendulum", c_void_p, [c_double, c_double]),
+    ("hy_sys_decomposition_str", c_void_p, [c_void_p]),
+    ("hy_tab_create", c_void_p, [c_void_p, c_void_p, c_size_t, c_uint32, c_void_p]),
+    ("hy_tab_copy", c_void_p, [c_void_p]),
+    ("hy_tab_free", None, [c_void_p]),
+    ("hy_tab_get_batch_size", c_uint32, [c_void_p]),
+    ("hy_tab_get_order", c_uint32, [c_void_p]),
+    ("hy_tab_get_dim", c_uint32, [c_void_p]),
+    ("hy_tab_get_n_pars", c_uint32, [c_void_p]),
+    ("hy_tab_get_n_uvars", c_uint32, [c_void_p]),
+    ("hy_tab_get_tol", c_double, [c_void_p]),
+    ("hy_tab_get_high_accuracy", c_int, [c_void_p]),
+    ("hy_tab_get_compact_mode", c_int, [c_void_p]),
+    ("hy_tab_get_compile_seconds", c_double, [c_void_p]),
+    ("hy_tab_get_hip_source", c_void_p, [c_void_p]),
+    ("hy_tab_get_decomposition_str", c_void_p, [c_void_p]),
+    ("hy_tab_get_state", c_int, [c_void_p, c_void_p]),
+    ("hy_tab_set_state", c_int, [c_void_p, c_void_p]),
+    ("hy_tab_get_pars", c_int, [c_void_p, c_void_p]),
+    ("hy_tab_set_pars", c_int, [c_void_p, c_void_p]),
+    ("hy_tab_get_dtime", c_int, [c_void_p, c_void_p, c_void_p]),
+    ("hy_tab_set_time", c_int, [c_void_p, c_void_p, c_size_t]),
+    ("hy_tab_set_dtime", c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    ("hy_tab_get_tc", c_int, [c_void_p, c_void_p]),
+    ("hy_tab_get_last_h", c_int, [c_void_p, c_void_p]),
+    ("hy_tab_update_d_output", c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    ("hy_tab_step", c_int, [c_void_p, c_int]),
+    ("hy_tab_step_backward", c_int, [c_void_p, c_int]),
+    ("hy_tab_step_limited", c_int, [c_void_p, c_void_p, c_size_t, c_int]),
+    ("hy_tab_get_step_res", c_int, [c_void_p, c_void_p, c_void_p]),
+    (
+        "hy_tab_propagate_until",
+        c_int,
+        [c_void_p, c_void_p, c_size_t, c_uint64, c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_int],
+    ),
+    (
+        "hy_tab_propagate_for",
+        c_int,
+        [c_void_p, c_void_p, c_size_t, c_uint64, c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_int],
+    ),
+    (
+        "hy_tab_propagate_grid",
+        c_int,
+        [c_void_p, c_void_p, c_size_t, c_uint64, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p],
+    ),
+    ("hy_tab_get_propagate_res", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("hy_tab_device_ptr", c_void_p, [c_void_p, c_int]),
+    ("hy_tab_mark_device_modified", c_int, [c_void_p]),
+    ("hy_tab_set_stream", c_int, [c_void_p, c_void_p]),
+    ("hy_tab_synchronize", c_int, [c_void_p]),
+    ("hy_tab_get_last_total_steps", c_uint64, [c_void_p]),
+    ("hy_tab_raw_step", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64]),
+    (
+        "hy_ensemble_propagate_until_batch",
+        c_int,
+        [c_void_p, c_double, c_size_t, c_void_p, c_void_p, c_uint64, c_int, c_void_p],
+    ),
+    (
+        "hy_ensemble_propagate_for_batch",
+        c_int,
+        [c_void_p, c_double, c_size_t, c_void_p, c_void_p, c_uint64, c_int, c_void_p],
+    ),
+]
+
+for _name, _res, _args in SIGNATURES:
+    _f = getattr(lib, _name)  # raises AttributeError if a declared symbol is not exported
+    _f.restype = _res
+    _f.argtypes = _args
+
+
+def take_str(ptr):
+    """Convert a malloc'd C string returned by the library into str and free it."""
+    if not ptr:
+        return None
+    s = ctypes.cast(ptr, c_char_p).value.decode()
+    lib.hy_free_str(ptr)
+    return s
+
+
+class NotImplementedErrorHY(NotImplementedError):
+    """heyoka::not_implemented_error."""
+
+
+def last_error():
+    return lib.hy_last_error().decode()
+
+
+def raise_for(code):
+    """Map a HY_ERR_* code to the Python exception matching the reference's C++ exception."""
+    if code == 0:
+        return
+    msg = last_error()
+    if code == 1:
+        raise ValueError(msg)  # std::invalid_argument
+    if code == 2:
+        raise OverflowError(msg)  # std::overflow_error
+    if code == 3:
+        raise NotImplementedErrorHY(msg)
+    raise RuntimeError(msg)
+
+
+def check_handle(h):
+    if not h:
+        raise_for(lib.hy_last_error_code() or 4)
+    return h

@@ -1,0 +1,639 @@
+// C ABI of the MI355X batch Taylor integrator. See include/heyoka_amd.h.
+#include "../../include/heyoka_amd.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <exception>
+#include <limits>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include <hip/hiprtc.h>
+
+#include "decompose.hpp"
+#include "ensemble.hpp"
+#include "expression.hpp"
+#include "hip_backend.hpp"
+#include "model.hpp"
+#include "taylor_adaptive_batch.hpp"
+
+using namespace heyoka_amd;
+
+struct hy_expr_s {
+    expression ex;
+};
+
+struct hy_sys_s {
+    std::vector<std::pair<expression, expression>> sys;
+};
+
+struct hy_tab_s {
+    detail::tab_core core;
+};
+
+namespace
+{
+
+thread_local std::string last_error;
+thread_local int last_error_code = HY_OK;
+
+int handle_exception_impl();
+
+int handle_exception()
+{
+    last_error_code = handle_exception_impl();
+    return last_error_code;
+}
+
+int handle_exception_impl()
+{
+    try {
+        throw;
+    } catch (const not_implemented_error &e) {
+        last_error = e.what();
+        return HY_ERR_NOT_IMPLEMENTED;
+    } catch (const std::invalid_argument &e) {
+        last_error = e.what();
+        return HY_ERR_INVALID_ARGUMENT;
+    } catch (const std::overflow_error &e) {
+        last_error = e.what();
+        return HY_ERR_OVERFLOW;
+    } catch (const std::exception &e) {
+        last_error = e.what();
+        return HY_ERR_RUNTIME;
+    } catch (...) {
+        last_error = "unknown exception";
+        return HY_ERR_RUNTIME;
+    }
+}
+
+char *dup_str(const std::string &s)
+{
+    auto *p = static_cast<char *>(std::malloc(s.size() + 1u));
+    if (p != nullptr) {
+        std::memcpy(p, s.c_str(), s.size() + 1u);
+    }
+    return p;
+}
+
+template <typename F>
+hy_expr make_expr(const F &f)
+{
+    try {
+        return new hy_expr_s{f()};
+    } catch (...) {
+        handle_exception();
+        return nullptr;
+    }
+}
+
+template <typename F>
+int guarded(const F &f)
+{
+    try {
+        f();
+        return HY_OK;
+    } catch (...) {
+        return handle_exception();
+    }
+}
+
+std::string dc_to_string(const taylor_dc_t &dc)
+{
+    std::ostringstream oss;
+    for (std::size_t i = 0; i < dc.size(); ++i) {
+        oss << dc[i].first.to_string();
+        for (const auto d : dc[i].second) {
+            oss << " [dep " << d << "]";
+        }
+        oss << '\n';
+    }
+    return oss.str();
+}
+
+std::vector<double> vec_from(const double *p, std::size_t n)
+{
+    if (p == nullptr || n == 0u) {
+        return {};
+    }
+    return std::vector<double>(p, p + n);
+}
+
+// Expand a (pointer, n) kw::max_delta_t argument: 0 -> none, 1 -> splat, else as is.
+std::vector<double> expand_mdt(const double *p, std::size_t n, std::uint32_t batch_size)
+{
+    if (p == nullptr || n == 0u) {
+        return {};
+    }
+    if (n == 1u) {
+        return std::vector<double>(batch_size, p[0]);
+    }
+    return std::vector<double>(p, p + n);
+}
+
+detail::tab_core::cb_t wrap_cb(hy_tab tab, hy_step_callback cb, void *cb_data)
+{
+    if (cb == nullptr) {
+        return {};
+    }
+    return [tab, cb, cb_data]() { return cb(tab, cb_data) != 0; };
+}
+
+} // namespace
+
+extern "C" {
+
+const char *hy_last_error(void)
+{
+    return last_error.c_str();
+}
+
+int hy_last_error_code(void)
+{
+    return last_error_code;
+}
+
+void hy_free_str(char *s)
+{
+    std::free(s);
+}
+
+char *hy_version(void)
+{
+    int major = 0, minor = 0;
+    hiprtcVersion(&major, &minor);
+    return dup_str("heyoka_amd 0.1.0; target gfx950; hiprtc " + std::to_string(major) + "." + std::to_string(minor));
+}
+
+int hy_device_count(void)
+{
+    return hip_device_count();
+}
+
+// ---- expressions ----
+hy_expr hy_expr_var(const char *name)
+{
+    return make_expr([&] { return expression{std::string(name)}; });
+}
+hy_expr hy_expr_num(double v)
+{
+    return make_expr([&] { return expression{v}; });
+}
+hy_expr hy_expr_par(uint32_t i)
+{
+    return make_expr([&] { return par[i]; });
+}
+hy_expr hy_expr_time(void)
+{
+    return make_expr([&] { return heyoka_amd::time; });
+}
+hy_expr hy_expr_neg(hy_expr a)
+{
+    return make_expr([&] { return -a->ex; });
+}
+hy_expr hy_expr_add(hy_expr a, hy_expr b)
+{
+    return make_expr([&] { return a->ex + b->ex; });
+}
+hy_expr hy_expr_sub(hy_expr a, hy_expr b)
+{
+    return make_expr([&] { return a->ex - b->ex; });
+}
+hy_expr hy_expr_mul(hy_expr a, hy_expr b)
+{
+    return make_expr([&] { return a->ex * b->ex; });
+}
+hy_expr hy_expr_div(hy_expr a, hy_expr b)
+{
+    return make_expr([&] { return a->ex / b->ex; });
+}
+hy_expr hy_expr_pow(hy_expr a, hy_expr b)
+{
+    return make_expr([&] { return pow(a->ex, b->ex); });
+}
+hy_expr hy_expr_sqrt(hy_expr a)
+{
+    return make_expr([&] { return sqrt(a->ex); });
+}
+hy_expr hy_expr_sin(hy_expr a)
+{
+    return make_expr([&] { return sin(a->ex); });
+}
+hy_expr hy_expr_cos(hy_expr a)
+{
+    return make_expr([&] { return cos(a->ex); });
+}
+hy_expr hy_expr_exp(hy_expr a)
+{
+    return make_expr([&] { return exp(a->ex); });
+}
+hy_expr hy_expr_log(hy_expr a)
+{
+    return make_expr([&] { return log(a->ex); });
+}
+hy_expr hy_expr_sum(const hy_expr *v, size_t n)
+{
+    return make_expr([&] {
+        std::vector<expression> args;
+        for (size_t i = 0; i < n; ++i) {
+            args.push_back(v[i]->ex);
+        }
+        return sum(std::move(args));
+    });
+}
+hy_expr hy_expr_prod(const hy_expr *v, size_t n)
+{
+    return make_expr([&] {
+        std::vector<expression> args;
+        for (size_t i = 0; i < n; ++i) {
+            args.push_back(v[i]->ex);
+        }
+        return prod(std::move(args));
+    });
+}
+void hy_expr_free(hy_expr e)
+{
+    delete e;
+}
+char *hy_expr_str(hy_expr e)
+{
+    return dup_str(e->ex.to_string());
+}
+
+// ---- systems ----
+hy_sys hy_sys_new(void)
+{
+    return new hy_sys_s{};
+}
+int hy_sys_add(hy_sys s, hy_expr lhs, hy_expr rhs)
+{
+    return guarded([&] { s->sys.emplace_back(lhs->ex, rhs->ex); });
+}
+size_t hy_sys_size(hy_sys s)
+{
+    return s->sys.size();
+}
+void hy_sys_free(hy_sys s)
+{
+    delete s;
+}
+hy_sys hy_model_nbody(uint32_t n, const double *masses, size_t n_masses, double Gconst)
+{
+    try {
+        std::vector<expression> mv;
+        if (masses == nullptr) {
+            mv.resize(n, expression{1.});
+        } else {
+            for (size_t i = 0; i < n_masses; ++i) {
+                mv.emplace_back(masses[i]);
+            }
+        }
+        return new hy_sys_s{model::detail::nbody_impl(n, expression{Gconst}, mv)};
+    } catch (...) {
+        handle_exception();
+        return nullptr;
+    }
+}
+hy_sys hy_model_pendulum(double gconst, double length)
+{
+    try {
+        return new hy_sys_s{model::detail::pendulum_impl(expression{gconst}, expression{length})};
+    } catch (...) {
+        handle_exception();
+        return nullptr;
+    }
+}
+char *hy_sys_decomposition_str(hy_sys s)
+{
+    try {
+        validate_ode_sys(s->sys);
+        return dup_str(dc_to_string(taylor_decompose_sys(s->sys)));
+    } catch (...) {
+        handle_exception();
+        return nullptr;
+    }
+}
+
+// ---- integrator ----
+hy_tab hy_tab_create(hy_sys sys, const double *state, size_t n_state, uint32_t batch_size, const hy_tab_config *cfg)
+{
+    try {
+        detail::tab_core::config c;
+        if (cfg != nullptr) {
+            if (cfg->tol != 0) {
+                c.tol = cfg->tol;
+            }
+            c.high_accuracy = cfg->high_accuracy != 0;
+            c.compact_mode = cfg->compact_mode != 0;
+            c.parallel_mode = cfg->parallel_mode != 0;
+            c.pars = vec_from(cfg->pars, cfg->n_pars);
+            c.time = vec_from(cfg->time, cfg->n_time);
+            c.time_is_scalar = (cfg->n_time == 1u && batch_size != 1u) || (cfg->n_time == 1u);
+            c.device = cfg->device;
+        }
+        return new hy_tab_s{detail::tab_core(sys->sys, vec_from(state, n_state), batch_size, std::move(c))};
+    } catch (...) {
+        handle_exception();
+        return nullptr;
+    }
+}
+hy_tab hy_tab_copy(hy_tab t)
+{
+    try {
+        return new hy_tab_s{detail::tab_core(t->core)};
+    } catch (...) {
+        handle_exception();
+        return nullptr;
+    }
+}
+void hy_tab_free(hy_tab t)
+{
+    delete t;
+}
+
+uint32_t hy_tab_get_batch_size(hy_tab t)
+{
+    return t->core.get_batch_size();
+}
+uint32_t hy_tab_get_order(hy_tab t)
+{
+    return t->core.get_order();
+}
+uint32_t hy_tab_get_dim(hy_tab t)
+{
+    return t->core.get_dim();
+}
+uint32_t hy_tab_get_n_pars(hy_tab t)
+{
+    return t->core.get_program().n_par;
+}
+uint32_t hy_tab_get_n_uvars(hy_tab t)
+{
+    return t->core.get_program().n_u;
+}
+double hy_tab_get_tol(hy_tab t)
+{
+    return t->core.get_tol();
+}
+int hy_tab_get_high_accuracy(hy_tab t)
+{
+    return t->core.get_high_accuracy() ? 1 : 0;
+}
+int hy_tab_get_compact_mode(hy_tab t)
+{
+    return t->core.get_compact_mode() ? 1 : 0;
+}
+double hy_tab_get_compile_seconds(hy_tab t)
+{
+    return t->core.get_compile_seconds();
+}
+char *hy_tab_get_hip_source(hy_tab t)
+{
+    return dup_str(t->core.get_hip_source());
+}
+char *hy_tab_get_decomposition_str(hy_tab t)
+{
+    return dup_str(dc_to_string(t->core.get_decomposition()));
+}
+
+int hy_tab_get_state(hy_tab t, double *out)
+{
+    return guarded([&] {
+        const auto &s = t->core.get_state();
+        std::memcpy(out, s.data(), s.size() * sizeof(double));
+    });
+}
+int hy_tab_set_state(hy_tab t, const double *in)
+{
+    return guarded([&] {
+        const auto n = static_cast<std::size_t>(t->core.get_dim()) * t->core.get_batch_size();
+        auto *p = t->core.get_state_data();
+        std::memcpy(p, in, n * sizeof(double));
+    });
+}
+int hy_tab_get_pars(hy_tab t, double *out)
+{
+    return guarded([&] {
+        const auto &s = t->core.get_pars();
+        std::memcpy(out, s.data(), s.size() * sizeof(double));
+    });
+}
+int hy_tab_set_pars(hy_tab t, const double *in)
+{
+    return guarded([&] {
+        const auto n = t->core.get_pars().size();
+        auto *p = t->core.get_pars_data();
+        std::memcpy(p, in, n * sizeof(double));
+    });
+}
+int hy_tab_get_dtime(hy_tab t, double *hi, double *lo)
+{
+    return guarded([&] {
+        const auto p = t->core.get_dtime();
+        std::memcpy(hi, p.first.data(), p.first.size() * sizeof(double));
+        if (lo != nullptr) {
+            std::memcpy(lo, p.second.data(), p.second.size() * sizeof(double));
+        }
+    });
+}
+int hy_tab_set_time(hy_tab t, const double *tm, size_t n)
+{
+    return guarded([&] {
+        if (n == 1u) {
+            t->core.set_time(tm[0]);
+        } else {
+            t->core.set_time(vec_from(tm, n));
+        }
+    });
+}
+int hy_tab_set_dtime(hy_tab t, const double *hi, const double *lo, size_t n)
+{
+    return guarded([&] {
+        if (n == 1u) {
+            t->core.set_dtime(hi[0], lo[0]);
+        } else {
+            t->core.set_dtime(vec_from(hi, n), vec_from(lo, n));
+        }
+    });
+}
+int hy_tab_get_tc(hy_tab t, double *out)
+{
+    return guarded([&] {
+        const auto &s = t->core.get_tc();
+        std::memcpy(out, s.data(), s.size() * sizeof(double));
+    });
+}
+int hy_tab_get_last_h(hy_tab t, double *out)
+{
+    return guarded([&] {
+        const auto &s = t->core.get_last_h();
+        std::memcpy(out, s.data(), s.size() * sizeof(double));
+    });
+}
+int hy_tab_update_d_output(hy_tab t, const double *tm, size_t n, int rel_time, double *out)
+{
+    return guarded([&] {
+        const auto &s = (n == 1u) ? t->core.update_d_output(tm[0], rel_time != 0)
+                                  : t->core.update_d_output(vec_from(tm, n), rel_time != 0);
+        std::memcpy(out, s.data(), s.size() * sizeof(double));
+    });
+}
+
+int hy_tab_step(hy_tab t, int wtc)
+{
+    return guarded([&] { t->core.step(wtc != 0); });
+}
+int hy_tab_step_backward(hy_tab t, int wtc)
+{
+    return guarded([&] { t->core.step_backward(wtc != 0); });
+}
+int hy_tab_step_limited(hy_tab t, const double *mdts, size_t n, int wtc)
+{
+    return guarded([&] { t->core.step(vec_from(mdts, n), wtc != 0); });
+}
+int hy_tab_get_step_res(hy_tab t, int64_t *outcome, double *h)
+{
+    return guarded([&] {
+        const auto &r = t->core.get_step_res();
+        for (std::size_t i = 0; i < r.size(); ++i) {
+            outcome[i] = static_cast<int64_t>(std::get<0>(r[i]));
+            h[i] = std::get<1>(r[i]);
+        }
+    });
+}
+
+int hy_tab_propagate_until(hy_tab t, const double *ts, size_t n_ts, uint64_t max_steps, const double *mdts,
+                           size_t n_mdt, hy_step_callback cb, void *cb_data, int wtc, int c_out)
+{
+    return guarded([&] {
+        t->core.propagate_until(vec_from(ts, n_ts), static_cast<std::size_t>(max_steps),
+                                expand_mdt(mdts, n_mdt, t->core.get_batch_size()), wrap_cb(t, cb, cb_data), wtc != 0,
+                                c_out != 0);
+    });
+}
+int hy_tab_propagate_for(hy_tab t, const double *dts, size_t n_dts, uint64_t max_steps, const double *mdts,
+                         size_t n_mdt, hy_step_callback cb, void *cb_data, int wtc, int c_out)
+{
+    return guarded([&] {
+        t->core.propagate_for(vec_from(dts, n_dts), static_cast<std::size_t>(max_steps),
+                              expand_mdt(mdts, n_mdt, t->core.get_batch_size()), wrap_cb(t, cb, cb_data), wtc != 0,
+                              c_out != 0);
+    });
+}
+int hy_tab_propagate_grid(hy_tab t, const double *grid, size_t n_grid, uint64_t max_steps, const double *mdts,
+                          size_t n_mdt, hy_step_callback cb, void *cb_data, double *out)
+{
+    return guarded([&] {
+        const auto bs = t->core.get_batch_size();
+        auto ret = t->core.propagate_grid(vec_from(grid, n_grid * bs), static_cast<std::size_t>(max_steps),
+                                          expand_mdt(mdts, n_mdt, bs), wrap_cb(t, cb, cb_data));
+        std::memcpy(out, ret.data(), ret.size() * sizeof(double));
+    });
+}
+int hy_tab_get_propagate_res(hy_tab t, int64_t *outcome, double *min_h, double *max_h, uint64_t *n_steps)
+{
+    return guarded([&] {
+        const auto &r = t->core.get_propagate_res();
+        for (std::size_t i = 0; i < r.size(); ++i) {
+            outcome[i] = static_cast<int64_t>(std::get<0>(r[i]));
+            min_h[i] = std::get<1>(r[i]);
+            max_h[i] = std::get<2>(r[i]);
+            n_steps[i] = std::get<3>(r[i]);
+        }
+    });
+}
+
+void *hy_tab_device_ptr(hy_tab t, int which)
+{
+    try {
+        switch (which) {
+            case HY_BUF_STATE:
+                return t->core.device_state();
+            case HY_BUF_PARS:
+                return t->core.device_pars();
+            case HY_BUF_TIME_HI:
+                return t->core.device_time_hi();
+            case HY_BUF_TIME_LO:
+                return t->core.device_time_lo();
+            case HY_BUF_TC:
+                return t->core.device_tc();
+            case HY_BUF_N_STEPS:
+                return t->core.device_aux(0);
+            case HY_BUF_OUTCOME:
+                return t->core.device_aux(1);
+            case HY_BUF_LAST_H:
+                return t->core.device_aux(2);
+            default:
+                throw std::invalid_argument("Invalid device buffer identifier: " + std::to_string(which));
+        }
+    } catch (...) {
+        handle_exception();
+        return nullptr;
+    }
+}
+int hy_tab_mark_device_modified(hy_tab t)
+{
+    return guarded([&] { t->core.mark_device_modified(); });
+}
+int hy_tab_set_stream(hy_tab t, void *s)
+{
+    return guarded([&] { t->core.set_stream(s); });
+}
+int hy_tab_synchronize(hy_tab t)
+{
+    return guarded([&] { t->core.synchronize(); });
+}
+uint64_t hy_tab_get_last_total_steps(hy_tab t)
+{
+    try {
+        return t->core.get_last_total_steps();
+    } catch (...) {
+        handle_exception();
+        return 0;
+    }
+}
+int hy_tab_raw_step(hy_tab t, double *d_state, const double *d_pars, const double *d_time, double *d_h, double *d_tc,
+                    uint64_t n)
+{
+    return guarded([&] { t->core.raw_step(d_state, d_pars, d_time, d_h, d_tc, n); });
+}
+
+static int ensemble_impl(hy_tab ta, double tm, size_t n_iter, hy_ensemble_gen gen, void *gen_data, uint64_t max_steps,
+                         int n_devices, hy_tab *out, detail::ensemble_kind kind)
+{
+    return guarded([&] {
+        // NOTE: the generator receives a full-blown handle so that it can use the whole C API.
+        std::vector<hy_tab> handles;
+        auto res = detail::ensemble_propagate_core(
+            ta->core, tm, n_iter,
+            [&](detail::tab_core &c, std::size_t i) {
+                if (gen != nullptr) {
+                    hy_tab_s tmp{std::move(c)};
+                    const auto rc = gen(&tmp, i, gen_data);
+                    c = std::move(tmp.core);
+                    if (rc != 0) {
+                        throw std::runtime_error("The generator of an ensemble propagation returned the error code "
+                                                 + std::to_string(rc) + " at iteration " + std::to_string(i));
+                    }
+                }
+            },
+            static_cast<std::size_t>(max_steps), n_devices, kind);
+        for (std::size_t i = 0; i < n_iter; ++i) {
+            out[i] = new hy_tab_s{std::move(res[i])};
+        }
+    });
+}
+
+int hy_ensemble_propagate_until_batch(hy_tab ta, double tm, size_t n_iter, hy_ensemble_gen gen, void *gen_data,
+                                      uint64_t max_steps, int n_devices, hy_tab *out)
+{
+    return ensemble_impl(ta, tm, n_iter, gen, gen_data, max_steps, n_devices, out, detail::ensemble_kind::until);
+}
+int hy_ensemble_propagate_for_batch(hy_tab ta, double dt, size_t n_iter, hy_ensemble_gen gen, void *gen_data,
+                                    uint64_t max_steps, int n_devices, hy_tab *out)
+{
+    return ensemble_impl(ta, dt, n_iter, gen, gen_data, max_steps, n_devices, out, detail::ensemble_kind::for_);
+}
+
+} // extern "C"

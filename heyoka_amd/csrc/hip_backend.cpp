@@ -1,0 +1,277 @@
+// hiprtc + HIP module runtime. See hip_backend.hpp.
+#include "hip_backend.hpp"
+
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <stdexcept>
+#include <unordered_map>
+
+#include <hip/hip_runtime_api.h>
+#include <hip/hiprtc.h>
+
+namespace heyoka_amd
+{
+
+namespace
+{
+
+void hip_check(hipError_t err, const char *what)
+{
+    if (err != hipSuccess) {
+        throw std::runtime_error(std::string("HIP error in ") + what + ": " + hipGetErrorString(err));
+    }
+}
+
+void rtc_check(hiprtcResult res, const char *what, const std::string &log = {})
+{
+    if (res != HIPRTC_SUCCESS) {
+        throw std::runtime_error(std::string("hiprtc error in ") + what + ": " + hiprtcGetErrorString(res)
+                                 + (log.empty() ? std::string{} : "\n" + log));
+    }
+}
+
+std::mutex cache_mutex;
+std::unordered_map<std::string, std::shared_ptr<const compiled_module>> module_cache;
+
+} // namespace
+
+std::shared_ptr<const compiled_module> hiprtc_compile(const emitted_module &m)
+{
+    {
+        std::lock_guard lock(cache_mutex);
+        if (const auto it = module_cache.find(m.source); it != module_cache.end()) {
+            return it->second;
+        }
+    }
+
+    const auto t0 = std::chrono::steady_clock::now();
+
+    hiprtcProgram prog = nullptr;
+    rtc_check(hiprtcCreateProgram(&prog, m.source.c_str(), "heyoka_amd_taylor.hip", 0, nullptr, nullptr),
+              "hiprtcCreateProgram");
+
+    // NOTE: contraction into FMA is allowed (the reference enables the 'contract' fast-math flag,
+    // src/llvm_state.cpp:843-845); nothing else is relaxed.
+    std::vector<const char *> opts = {"--offload-arch=gfx950", "-O3", "-ffp-contract=fast", "-std=c++17"};
+    const char *extra = std::getenv("HEYOKA_AMD_HIPRTC_FLAGS");
+    std::vector<std::string> extra_store;
+    if (extra != nullptr) {
+        std::string s(extra);
+        std::size_t pos = 0;
+        while (pos < s.size()) {
+            const auto next = s.find(' ', pos);
+            const auto tok = s.substr(pos, next == std::string::npos ? std::string::npos : next - pos);
+            if (!tok.empty()) {
+                extra_store.push_back(tok);
+            }
+            if (next == std::string::npos) {
+                break;
+            }
+            pos = next + 1u;
+        }
+        for (const auto &t : extra_store) {
+            opts.push_back(t.c_str());
+        }
+    }
+
+    const auto cres = hiprtcCompileProgram(prog, static_cast<int>(opts.size()), opts.data());
+
+    std::string log;
+    std::size_t log_size = 0;
+    if (hiprtcGetProgramLogSize(prog, &log_size) == HIPRTC_SUCCESS && log_size > 1u) {
+        log.resize(log_size);
+        hiprtcGetProgramLog(prog, log.data());
+    }
+
+    if (cres != HIPRTC_SUCCESS) {
+        hiprtcDestroyProgram(&prog);
+        rtc_check(cres, "hiprtcCompileProgram", log);
+    }
+
+    std::size_t code_size = 0;
+    rtc_check(hiprtcGetCodeSize(prog, &code_size), "hiprtcGetCodeSize");
+    auto ret = std::make_shared<compiled_module>();
+    ret->code.resize(code_size);
+    rtc_check(hiprtcGetCode(prog, ret->code.data()), "hiprtcGetCode");
+    hiprtcDestroyProgram(&prog);
+
+    ret->meta = m;
+    ret->log = std::move(log);
+    ret->compile_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+
+    std::lock_guard lock(cache_mutex);
+    module_cache.emplace(m.source, ret);
+    return ret;
+}
+
+int hip_device_count()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        return 0;
+    }
+    return n;
+}
+
+struct device_module::impl {
+    std::shared_ptr<const compiled_module> cm;
+    int device = 0;
+    hipModule_t mod = nullptr;
+    hipFunction_t fn_taylor = nullptr;
+    hipFunction_t fn_dout = nullptr;
+    hipStream_t stream = nullptr;
+};
+
+device_module::device_module(std::shared_ptr<const compiled_module> cm, int device) : m_impl(std::make_unique<impl>())
+{
+    if (hip_device_count() <= device) {
+        throw std::runtime_error("heyoka_amd: no HIP device " + std::to_string(device)
+                                 + " is available (the MI355X/gfx950 code path has no CPU fallback)");
+    }
+    m_impl->cm = std::move(cm);
+    m_impl->device = device;
+    hip_check(hipSetDevice(device), "hipSetDevice");
+    hip_check(hipModuleLoadData(&m_impl->mod, m_impl->cm->code.data()), "hipModuleLoadData");
+    hip_check(hipModuleGetFunction(&m_impl->fn_taylor, m_impl->mod, m_impl->cm->meta.kernel_name.c_str()),
+              "hipModuleGetFunction(taylor)");
+    hip_check(hipModuleGetFunction(&m_impl->fn_dout, m_impl->mod, m_impl->cm->meta.dout_name.c_str()),
+              "hipModuleGetFunction(dout)");
+}
+
+device_module::~device_module()
+{
+    if (m_impl && m_impl->mod != nullptr) {
+        (void)hipModuleUnload(m_impl->mod);
+    }
+}
+
+int device_module::device() const
+{
+    return m_impl->device;
+}
+
+void device_module::set_stream(void *s)
+{
+    m_impl->stream = static_cast<hipStream_t>(s);
+}
+
+void *device_module::stream() const
+{
+    return m_impl->stream;
+}
+
+void device_module::launch_taylor(const hy_kargs &args)
+{
+    if (args.N == 0u) {
+        return;
+    }
+    hip_check(hipSetDevice(m_impl->device), "hipSetDevice");
+    const auto &meta = m_impl->cm->meta;
+    const std::uint64_t threads = args.N * meta.lanes_per_system;
+    const auto bs = static_cast<std::uint64_t>(meta.block_size);
+    const auto grid = (threads + bs - 1u) / bs;
+    if (grid > 0x7fffffffull) {
+        throw std::overflow_error("heyoka_amd: grid size overflow");
+    }
+
+    hy_kargs a = args;
+    std::size_t sz = sizeof(a);
+    void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+    hip_check(hipModuleLaunchKernel(m_impl->fn_taylor, static_cast<unsigned>(grid), 1, 1,
+                                    static_cast<unsigned>(bs), 1, 1, meta.lds_bytes, m_impl->stream, nullptr, config),
+              "hipModuleLaunchKernel(taylor)");
+}
+
+void device_module::launch_dout(double *out, const double *tc, const double *hs, std::uint64_t N)
+{
+    if (N == 0u) {
+        return;
+    }
+    hip_check(hipSetDevice(m_impl->device), "hipSetDevice");
+    struct {
+        double *out;
+        const double *tc;
+        const double *hs;
+        unsigned long long N;
+    } a{out, tc, hs, N};
+    std::size_t sz = sizeof(a);
+    void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+    const auto grid = (N + 255u) / 256u;
+    hip_check(hipModuleLaunchKernel(m_impl->fn_dout, static_cast<unsigned>(grid), 1, 1, 256, 1, 1, 0, m_impl->stream,
+                                    nullptr, config),
+              "hipModuleLaunchKernel(dout)");
+}
+
+void device_module::synchronize()
+{
+    hip_check(hipSetDevice(m_impl->device), "hipSetDevice");
+    hip_check(hipStreamSynchronize(m_impl->stream), "hipStreamSynchronize");
+}
+
+device_buffer::device_buffer(std::size_t bytes, int device) : m_bytes(bytes), m_device(device)
+{
+    if (bytes != 0u) {
+        hip_check(hipSetDevice(device), "hipSetDevice");
+        hip_check(hipMalloc(&m_ptr, bytes), "hipMalloc");
+    }
+}
+
+device_buffer::~device_buffer()
+{
+    if (m_ptr != nullptr) {
+        (void)hipFree(m_ptr);
+    }
+}
+
+device_buffer::device_buffer(device_buffer &&o) noexcept : m_ptr(o.m_ptr), m_bytes(o.m_bytes), m_device(o.m_device)
+{
+    o.m_ptr = nullptr;
+    o.m_bytes = 0;
+}
+
+device_buffer &device_buffer::operator=(device_buffer &&o) noexcept
+{
+    if (this != &o) {
+        if (m_ptr != nullptr) {
+            (void)hipFree(m_ptr);
+        }
+        m_ptr = o.m_ptr;
+        m_bytes = o.m_bytes;
+        m_device = o.m_device;
+        o.m_ptr = nullptr;
+        o.m_bytes = 0;
+    }
+    return *this;
+}
+
+void device_buffer::upload(const void *src, std::size_t bytes, void *stream)
+{
+    if (bytes == 0u) {
+        return;
+    }
+    hip_check(hipMemcpyAsync(m_ptr, src, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)),
+              "hipMemcpyAsync(H2D)");
+}
+
+void device_buffer::download(void *dst, std::size_t bytes, void *stream) const
+{
+    if (bytes == 0u) {
+        return;
+    }
+    hip_check(hipMemcpyAsync(dst, m_ptr, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)),
+              "hipMemcpyAsync(D2H)");
+    hip_check(hipStreamSynchronize(static_cast<hipStream_t>(stream)), "hipStreamSynchronize");
+}
+
+void device_buffer::zero(void *stream)
+{
+    if (m_bytes == 0u) {
+        return;
+    }
+    hip_check(hipMemsetAsync(m_ptr, 0, m_bytes, static_cast<hipStream_t>(stream)), "hipMemsetAsync");
+}
+
+} // namespace heyoka_amd

@@ -1,0 +1,90 @@
+// hiprtc + HIP module runtime for the generated Taylor kernels.
+//
+// Plays the role of the reference's JIT layer (llvm_state::compile() / jit_lookup(),
+// src/llvm_state.cpp:1507, :1606) for the HIP source modules produced by hip_emit.cpp.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "hip_emit.hpp"
+
+namespace heyoka_amd
+{
+
+// A compiled (device-independent) code object for gfx950.
+struct compiled_module {
+    emitted_module meta;
+    std::vector<char> code;
+    std::string log;
+    double compile_seconds = 0;
+};
+
+// Compile HIP source with hiprtc for gfx950. Works without a GPU (used by the CPU build check).
+// Results are cached in-process by source text.
+std::shared_ptr<const compiled_module> hiprtc_compile(const emitted_module &m);
+
+// Number of visible HIP devices (0 if no GPU / no driver).
+int hip_device_count();
+
+// A module loaded on a specific device + the buffers of one integrator.
+class device_module
+{
+    struct impl;
+    std::unique_ptr<impl> m_impl;
+
+public:
+    device_module(std::shared_ptr<const compiled_module>, int device);
+    ~device_module();
+    device_module(const device_module &) = delete;
+    device_module &operator=(const device_module &) = delete;
+
+    [[nodiscard]] int device() const;
+    void set_stream(void *hip_stream);
+    [[nodiscard]] void *stream() const;
+
+    // Launch the stepper over N systems.
+    void launch_taylor(const hy_kargs &args);
+    // Launch the dense-output kernel.
+    void launch_dout(double *out, const double *tc, const double *hs, std::uint64_t N);
+    void synchronize();
+};
+
+// Thin RAII device buffer.
+class device_buffer
+{
+    void *m_ptr = nullptr;
+    std::size_t m_bytes = 0;
+    int m_device = 0;
+
+public:
+    device_buffer() = default;
+    device_buffer(std::size_t bytes, int device);
+    ~device_buffer();
+    device_buffer(device_buffer &&) noexcept;
+    device_buffer &operator=(device_buffer &&) noexcept;
+    device_buffer(const device_buffer &) = delete;
+    device_buffer &operator=(const device_buffer &) = delete;
+
+    [[nodiscard]] void *get() const
+    {
+        return m_ptr;
+    }
+    template <typename T>
+    [[nodiscard]] T *as() const
+    {
+        return static_cast<T *>(m_ptr);
+    }
+    [[nodiscard]] std::size_t bytes() const
+    {
+        return m_bytes;
+    }
+    void upload(const void *src, std::size_t bytes, void *stream);
+    void download(void *dst, std::size_t bytes, void *stream) const;
+    void zero(void *stream);
+};
+
+} // namespace heyoka_amd

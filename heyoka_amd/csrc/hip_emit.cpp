@@ -1,0 +1,794 @@
+// HIP source generation. See hip_emit.hpp.
+//
+// The arithmetic emitted for each node follows the "default mode" formulas of the reference
+// (products first, then a pairwise sum; citations next to each rule) so that results agree with
+// heyoka's CPU path up to FMA contraction and the <= 1 ulp elementary functions.
+#include "hip_emit.hpp"
+
+#include <cassert>
+#include <cmath>
+#include <cstdio>
+#include <sstream>
+#include <stdexcept>
+
+namespace heyoka_amd
+{
+
+std::string fp_literal(double x)
+{
+    if (std::isnan(x)) {
+        return "__builtin_nan(\"\")";
+    }
+    if (std::isinf(x)) {
+        return x > 0 ? "__builtin_inf()" : "(-__builtin_inf())";
+    }
+    char buf[64];
+    std::snprintf(buf, sizeof(buf), "%a", x);
+    std::string s(buf);
+    if (x < 0 || (x == 0 && std::signbit(x))) {
+        return "(" + s + ")";
+    }
+    return s;
+}
+
+namespace
+{
+
+// Common device-side prelude: argument block, double-length arithmetic, helpers.
+const char *prelude = R"HIP(
+typedef unsigned long long u64;
+typedef long long i64;
+
+struct hy_kargs {
+    double *state;
+    const double *pars;
+    double *time_hi;
+    double *time_lo;
+    const double *lim;
+    const double *tfin_hi;
+    const double *tfin_lo;
+    double *last_h;
+    i64 *outcome;
+    double *min_h;
+    double *max_h;
+    u64 *n_steps;
+    double *tc;
+    u64 N;
+    u64 max_steps;
+    int mode;
+    int pad;
+    unsigned int *counters;
+};
+
+#define HY_OC_SUCCESS (-4294967296LL - 1)
+#define HY_OC_STEP_LIMIT (-4294967296LL - 2)
+#define HY_OC_TIME_LIMIT (-4294967296LL - 3)
+#define HY_OC_ERR_NF_STATE (-4294967296LL - 4)
+
+// Double-length (hi, lo) arithmetic: Knuth / Dekker error-free transformations
+// (reference: include/heyoka/detail/dfloat.hpp:109-164). No multiplications are involved, hence
+// FMA contraction cannot alter these sequences; reassociation is never enabled.
+struct hy_df {
+    double hi, lo;
+};
+
+__device__ __forceinline__ hy_df hy_df_add(hy_df a, hy_df b)
+{
+    const double x_hi = a.hi + b.hi;
+    const double z_hi = x_hi - a.hi;
+    const double y_hi = (a.hi - (x_hi - z_hi)) + (b.hi - z_hi);
+    const double x_lo = a.lo + b.lo;
+    const double z_lo = x_lo - a.lo;
+    const double y_lo = (a.lo - (x_lo - z_lo)) + (b.lo - z_lo);
+    const double w = y_hi + x_lo;
+    const double u = x_hi + w;
+    const double v = (x_hi - u) + w;
+    const double w2 = v + y_lo;
+    hy_df r;
+    r.hi = u + w2;
+    r.lo = (u - r.hi) + w2;
+    return r;
+}
+
+__device__ __forceinline__ hy_df hy_df_sub(hy_df a, hy_df b)
+{
+    hy_df nb;
+    nb.hi = -b.hi;
+    nb.lo = -b.lo;
+    return hy_df_add(a, nb);
+}
+
+__device__ __forceinline__ bool hy_df_lt(hy_df x, hy_df y)
+{
+    return (x.hi < y.hi) || (x.hi == y.hi && x.lo < y.lo);
+}
+
+// max(a, b) = (a < b) ? b : a and min(a, b) = (b < a) ? b : a
+// (reference: src/detail/llvm_helpers_cmp.cpp:315-329; NaN handling is part of the semantics).
+__device__ __forceinline__ double hy_max(double a, double b)
+{
+    return (a < b) ? b : a;
+}
+__device__ __forceinline__ double hy_min(double a, double b)
+{
+    return (b < a) ? b : a;
+}
+
+__device__ __forceinline__ bool hy_finite(double x)
+{
+    return __builtin_isfinite(x);
+}
+)HIP";
+
+struct ssa_emitter {
+    const taylor_program &p;
+    std::uint32_t order;
+    std::ostringstream os;
+    std::uint64_t counter = 0;
+    std::uint64_t n_stmt = 0;
+    // vals[k * n_u + u]: name (or literal) of the order-k coefficient of u variable u.
+    std::vector<std::string> vals;
+
+    ssa_emitter(const taylor_program &prog, std::uint32_t ord)
+        : p(prog), order(ord), vals(static_cast<std::size_t>(prog.n_u) * (ord + 1u))
+    {
+    }
+
+    std::string &val(std::uint32_t u, std::uint32_t k)
+    {
+        return vals[static_cast<std::size_t>(k) * p.n_u + u];
+    }
+
+    std::string def(const std::string &expr)
+    {
+        const auto name = "t" + std::to_string(counter++);
+        os << "const double " << name << " = " << expr << ";\n";
+        ++n_stmt;
+        return name;
+    }
+
+    // Pairwise reduction (reference: src/detail/llvm_helpers_algo.cpp:271-308).
+    std::string pairwise(std::vector<std::string> v, const char *op)
+    {
+        assert(!v.empty());
+        while (v.size() != 1u) {
+            std::vector<std::string> nv;
+            for (std::size_t i = 0; i < v.size(); i += 2u) {
+                if (i + 1u == v.size()) {
+                    nv.push_back(v[i]);
+                } else {
+                    nv.push_back(def(v[i] + " " + op + " " + v[i + 1u]));
+                }
+            }
+            v.swap(nv);
+        }
+        return v[0];
+    }
+
+    std::string pairwise_sum(std::vector<std::string> v)
+    {
+        return pairwise(std::move(v), "+");
+    }
+
+    static std::string numpar(const operand &o)
+    {
+        assert(o.type != operand::kind::uvar);
+        if (o.type == operand::kind::num) {
+            return fp_literal(o.value);
+        }
+        return "par_" + std::to_string(o.idx);
+    }
+
+    static bool is_var(const operand &o)
+    {
+        return o.type == operand::kind::uvar;
+    }
+
+    static std::string mul(const std::string &a, const std::string &b)
+    {
+        return a + " * " + b;
+    }
+
+    // Exponentiation by squaring (reference: pow_ebs(), src/math/pow.cpp:136-152).
+    std::string pow_ebs(const std::string &base, std::uint32_t e)
+    {
+        if (e == 0u) {
+            return "1.0";
+        }
+        if (e == 1u) {
+            return base;
+        }
+        const auto sq = def(mul(base, base));
+        if (e % 2u == 0u) {
+            return pow_ebs(sq, e / 2u);
+        }
+        const auto tmp = pow_ebs(sq, (e - 1u) / 2u);
+        return def(mul(base, tmp));
+    }
+
+    // Order-0 evaluation of pow (reference: get_pow_eval_algo(), src/math/pow.cpp:292-355).
+    std::string pow_eval(const std::string &b, double ex)
+    {
+        if (std::isfinite(ex) && ex == std::trunc(ex) && std::abs(ex) <= 16.) {
+            if (ex >= 0) {
+                return pow_ebs(b, static_cast<std::uint32_t>(ex));
+            }
+            const auto tmp = pow_ebs(b, static_cast<std::uint32_t>(-ex));
+            return def("1.0 / " + tmp);
+        }
+        if (std::isfinite(ex) && ex != std::trunc(ex)) {
+            const auto y = 2 * ex;
+            if (y == std::trunc(y) && std::abs(y) <= 16.) {
+                const auto sq = def("sqrt(" + b + ")");
+                if (y >= 0) {
+                    return pow_ebs(sq, static_cast<std::uint32_t>(y));
+                }
+                const auto tmp = pow_ebs(sq, static_cast<std::uint32_t>(-y));
+                return def("1.0 / " + tmp);
+            }
+        }
+        return def("pow(" + b + ", " + fp_literal(ex) + ")");
+    }
+
+    // Emit the order-k coefficient of node i.
+    void node(std::uint32_t i, std::uint32_t k)
+    {
+        const auto &n = p.nodes[i];
+        const auto u = p.n_eq + i;
+        auto &out = val(u, k);
+        const auto &a = n.args;
+
+        switch (n.kind) {
+            case func_kind::num_identity:
+                out = (k == 0u) ? numpar(a[0]) : "0.0";
+                break;
+            case func_kind::time:
+                // Reference: src/math/time.cpp:81-101.
+                out = (k == 0u) ? "t_hi" : (k == 1u ? "1.0" : "0.0");
+                break;
+            case func_kind::sum: {
+                // Reference: src/math/sum.cpp:185-235.
+                std::vector<std::string> terms;
+                for (const auto &o : a) {
+                    if (is_var(o)) {
+                        terms.push_back(val(o.idx, k));
+                    } else {
+                        terms.push_back(k == 0u ? numpar(o) : "0.0");
+                    }
+                }
+                out = pairwise_sum(std::move(terms));
+                break;
+            }
+            case func_kind::sub: {
+                // Reference: src/detail/sub.cpp:60-124.
+                if (is_var(a[0]) && is_var(a[1])) {
+                    out = def(val(a[0].idx, k) + " - " + val(a[1].idx, k));
+                } else if (is_var(a[0])) {
+                    out = (k == 0u) ? def(val(a[0].idx, 0) + " - " + numpar(a[1])) : val(a[0].idx, k);
+                } else if (is_var(a[1])) {
+                    out = (k == 0u) ? def(numpar(a[0]) + " - " + val(a[1].idx, 0)) : def("-" + val(a[1].idx, k));
+                } else {
+                    out = (k == 0u) ? def(numpar(a[0]) + " - " + numpar(a[1])) : "0.0";
+                }
+                break;
+            }
+            case func_kind::prod: {
+                // Reference: src/math/prod.cpp:314-395.
+                if (a.size() != 2u) {
+                    throw std::invalid_argument("The Taylor derivative of a product can be computed only for "
+                                                "products of 2 terms");
+                }
+                if (is_var(a[0]) && is_var(a[1])) {
+                    std::vector<std::string> terms;
+                    for (std::uint32_t j = 0; j <= k; ++j) {
+                        terms.push_back(def(mul(val(a[0].idx, k - j), val(a[1].idx, j))));
+                    }
+                    out = pairwise_sum(std::move(terms));
+                } else if (!is_var(a[0]) && !is_var(a[1])) {
+                    if (k != 0u) {
+                        out = "0.0";
+                    } else if (a[0].type == operand::kind::num && a[0].value == -1.) {
+                        out = def("-" + numpar(a[1]));
+                    } else {
+                        out = def(mul(numpar(a[0]), numpar(a[1])));
+                    }
+                } else {
+                    const auto &v = is_var(a[0]) ? a[0] : a[1];
+                    const auto &c = is_var(a[0]) ? a[1] : a[0];
+                    if (&c == &a[0] && c.type == operand::kind::num && c.value == -1.) {
+                        out = def("-" + val(v.idx, k));
+                    } else {
+                        out = def(mul(numpar(c), val(v.idx, k)));
+                    }
+                }
+                break;
+            }
+            case func_kind::div: {
+                // Reference: src/detail/div.cpp:62-160.
+                if (is_var(a[1])) {
+                    if (k == 0u) {
+                        const auto num = is_var(a[0]) ? val(a[0].idx, 0) : numpar(a[0]);
+                        out = def(num + " / " + val(a[1].idx, 0));
+                    } else {
+                        std::vector<std::string> terms;
+                        for (std::uint32_t j = 1; j <= k; ++j) {
+                            terms.push_back(def(mul(val(u, k - j), val(a[1].idx, j))));
+                        }
+                        const auto acc = pairwise_sum(std::move(terms));
+                        if (is_var(a[0])) {
+                            out = def("(" + val(a[0].idx, k) + " - " + acc + ") / " + val(a[1].idx, 0));
+                        } else {
+                            out = def("(-" + acc + ") / " + val(a[1].idx, 0));
+                        }
+                    }
+                } else if (is_var(a[0])) {
+                    out = def(val(a[0].idx, k) + " / " + numpar(a[1]));
+                } else {
+                    out = (k == 0u) ? def(numpar(a[0]) + " / " + numpar(a[1])) : "0.0";
+                }
+                break;
+            }
+            case func_kind::sum_sq: {
+                // Reference: src/detail/sum_sq.cpp:100-245.
+                std::vector<std::string> tmp;
+                if (k % 2u == 1u) {
+                    for (const auto &o : a) {
+                        if (is_var(o)) {
+                            std::vector<std::string> terms;
+                            for (std::uint32_t j = 0; j <= (k - 1u) / 2u; ++j) {
+                                terms.push_back(def(mul(val(o.idx, k - j), val(o.idx, j))));
+                            }
+                            tmp.push_back(pairwise_sum(std::move(terms)));
+                        } else {
+                            tmp.emplace_back("0.0");
+                        }
+                    }
+                    const auto s = pairwise_sum(std::move(tmp));
+                    out = def(s + " + " + s);
+                } else {
+                    for (const auto &o : a) {
+                        if (is_var(o)) {
+                            const auto &hv = val(o.idx, k / 2u);
+                            auto sq = def(mul(hv, hv));
+                            if (k > 0u) {
+                                std::vector<std::string> terms;
+                                for (std::uint32_t j = 0; j <= (k - 2u) / 2u; ++j) {
+                                    terms.push_back(def(mul(val(o.idx, k - j), val(o.idx, j))));
+                                }
+                                const auto ps = pairwise_sum(std::move(terms));
+                                const auto ps2 = def(ps + " + " + ps);
+                                sq = def(ps2 + " + " + sq);
+                            }
+                            tmp.push_back(std::move(sq));
+                        } else if (k == 0u) {
+                            tmp.push_back(def(mul(numpar(o), numpar(o))));
+                        } else {
+                            tmp.emplace_back("0.0");
+                        }
+                    }
+                    out = pairwise_sum(std::move(tmp));
+                }
+                break;
+            }
+            case func_kind::pow: {
+                // Reference: src/math/pow.cpp:395-550.
+                if (a[1].type != operand::kind::num) {
+                    throw std::invalid_argument("An invalid argument type was encountered while trying to build "
+                                                "the Taylor derivative of a pow()");
+                }
+                const auto ex = a[1].value;
+                if (!is_var(a[0])) {
+                    out = (k == 0u) ? pow_eval(numpar(a[0]), ex) : "0.0";
+                    break;
+                }
+                const auto b = a[0].idx;
+                if (k == 0u) {
+                    out = pow_eval(val(b, 0), ex);
+                } else if (ex == .5) {
+                    // sqrt() special case.
+                    const auto dv = def(val(u, 0) + " + " + val(u, 0));
+                    std::string fac = val(b, k);
+                    std::vector<std::string> terms;
+                    const auto jmax = (k % 2u == 1u) ? (k - 1u) / 2u : (k - 2u) / 2u;
+                    for (std::uint32_t j = 1; j <= jmax; ++j) {
+                        terms.push_back(def(mul(val(u, k - j), val(u, j))));
+                    }
+                    if (k % 2u == 0u) {
+                        const auto &hv = val(u, k / 2u);
+                        const auto sq = def(mul(hv, hv));
+                        fac = def(fac + " - " + sq);
+                    }
+                    if (!terms.empty()) {
+                        const auto ps = pairwise_sum(std::move(terms));
+                        const auto ps2 = def(ps + " + " + ps);
+                        fac = def(fac + " - " + ps2);
+                    }
+                    out = def(fac + " / " + dv);
+                } else if (ex == 2.) {
+                    // square() special case.
+                    std::vector<std::string> terms;
+                    if (k % 2u == 1u) {
+                        for (std::uint32_t j = 0; j <= (k - 1u) / 2u; ++j) {
+                            terms.push_back(def(mul(val(b, k - j), val(b, j))));
+                        }
+                        const auto ps = pairwise_sum(std::move(terms));
+                        out = def(ps + " + " + ps);
+                    } else {
+                        const auto &hv = val(b, k / 2u);
+                        const auto sq = def(mul(hv, hv));
+                        for (std::uint32_t j = 0; j <= (k - 2u) / 2u; ++j) {
+                            terms.push_back(def(mul(val(b, k - j), val(b, j))));
+                        }
+                        const auto ps = pairwise_sum(std::move(terms));
+                        const auto ps2 = def(ps + " + " + ps);
+                        out = def(ps2 + " + " + sq);
+                    }
+                } else {
+                    std::vector<std::string> terms;
+                    for (std::uint32_t j = 0; j < k; ++j) {
+                        // Scalar factor folded in double like the reference's IR constants:
+                        // order * alpha - j * (alpha + 1).
+                        const double sf = static_cast<double>(k) * ex - static_cast<double>(j) * (ex + 1.);
+                        const auto pr = def(mul(val(b, k - j), val(u, j)));
+                        terms.push_back(def(mul(fp_literal(sf), pr)));
+                    }
+                    const auto acc = pairwise_sum(std::move(terms));
+                    const auto dv = def(mul(fp_literal(static_cast<double>(k)), val(b, 0)));
+                    out = def(acc + " / " + dv);
+                }
+                break;
+            }
+            case func_kind::sin:
+            case func_kind::cos: {
+                // Reference: src/math/sin.cpp:152-192, src/math/cos.cpp:152-185.
+                const bool is_sin = n.kind == func_kind::sin;
+                if (!is_var(a[0])) {
+                    out = (k == 0u) ? def(std::string(is_sin ? "sin(" : "cos(") + numpar(a[0]) + ")") : "0.0";
+                    break;
+                }
+                const auto b = a[0].idx;
+                if (k == 0u) {
+                    out = def(std::string(is_sin ? "sin(" : "cos(") + val(b, 0) + ")");
+                } else {
+                    if (n.deps.size() != 1u) {
+                        throw std::invalid_argument("A hidden dependency vector of size 1 is expected in order to "
+                                                    "compute the Taylor derivative of the sine/cosine");
+                    }
+                    const auto d = n.deps[0];
+                    std::vector<std::string> terms;
+                    for (std::uint32_t j = 1; j <= k; ++j) {
+                        const auto pr = def(mul(val(d, k - j), val(b, j)));
+                        terms.push_back(def(mul(fp_literal(static_cast<double>(j)), pr)));
+                    }
+                    const auto acc = pairwise_sum(std::move(terms));
+                    out = def(acc + " / " + fp_literal(is_sin ? static_cast<double>(k) : -static_cast<double>(k)));
+                }
+                break;
+            }
+            case func_kind::exp: {
+                // Reference: src/math/exp.cpp:84-120.
+                if (!is_var(a[0])) {
+                    out = (k == 0u) ? def("exp(" + numpar(a[0]) + ")") : "0.0";
+                    break;
+                }
+                const auto b = a[0].idx;
+                if (k == 0u) {
+                    out = def("exp(" + val(b, 0) + ")");
+                } else {
+                    std::vector<std::string> terms;
+                    for (std::uint32_t j = 1; j <= k; ++j) {
+                        const auto pr = def(mul(val(u, k - j), val(b, j)));
+                        terms.push_back(def(mul(fp_literal(static_cast<double>(j)), pr)));
+                    }
+                    const auto acc = pairwise_sum(std::move(terms));
+                    out = def(acc + " / " + fp_literal(static_cast<double>(k)));
+                }
+                break;
+            }
+            case func_kind::log: {
+                // Reference: src/math/log.cpp (taylor_diff_log_impl).
+                if (!is_var(a[0])) {
+                    out = (k == 0u) ? def("log(" + numpar(a[0]) + ")") : "0.0";
+                    break;
+                }
+                const auto b = a[0].idx;
+                if (k == 0u) {
+                    out = def("log(" + val(b, 0) + ")");
+                } else {
+                    const auto kf = fp_literal(static_cast<double>(k));
+                    const auto nb0 = def(mul(kf, val(b, 0)));
+                    auto ret = def(mul(kf, val(b, k)));
+                    if (k > 1u) {
+                        std::vector<std::string> terms;
+                        for (std::uint32_t j = 1; j < k; ++j) {
+                            const auto pr = def(mul(val(b, k - j), val(u, j)));
+                            terms.push_back(def(mul(fp_literal(static_cast<double>(j)), pr)));
+                        }
+                        const auto acc = pairwise_sum(std::move(terms));
+                        ret = def(ret + " - " + acc);
+                    }
+                    out = def(ret + " / " + nb0);
+                }
+                break;
+            }
+        }
+    }
+
+    // Order-k coefficient of state variable i (reference: taylor_compute_sv_diff(),
+    // src/taylor_02.cpp:245-287: true division by the order).
+    void sv(std::uint32_t i, std::uint32_t k)
+    {
+        assert(k > 0u);
+        const auto &d = p.sv_defs[i];
+        auto &out = val(i, k);
+        if (d.type == operand::kind::uvar) {
+            out = def(val(d.idx, k - 1u) + " / " + fp_literal(static_cast<double>(k)));
+        } else {
+            out = (k == 1u) ? numpar(d) : "0.0";
+        }
+    }
+};
+
+// Scaling + safety factor of the step-size selector, folded on the host in double precision
+// (reference: taylor_determine_h_rhofac(), src/taylor_00.cpp:84-94).
+double rhofac(std::uint32_t order)
+{
+    const double m7_10 = -7. / 10.;
+    const double e2 = std::exp(1.) * std::exp(1.);
+    return std::exp(m7_10 / static_cast<double>(order - 1u)) / e2;
+}
+
+// Emit the dense-output kernel (reference: taylor_add_d_out_function(), src/taylor_01.cpp:1015-1185).
+void emit_dout(std::ostringstream &os, const taylor_program &p, const emit_options &opts)
+{
+    const auto n_eq = p.n_eq;
+    const auto order = opts.order;
+    os << "extern \"C\" __global__ void __launch_bounds__(256) hy_dout(double *out, const double *tc, const double "
+          "*hs, u64 N)\n{\n";
+    os << "const u64 s = (u64)blockIdx.x * 256u + threadIdx.x;\nif (s >= N) return;\n";
+    os << "const double h = hs[s];\n";
+    os << "for (unsigned i = 0; i < " << n_eq << "u; ++i) {\n";
+    os << "const double *c = tc + ((u64)i * " << (order + 1u) << "u) * N + s;\n";
+    if (opts.high_accuracy) {
+        // Compensated summation (reference: src/taylor_01.cpp:1074-1134).
+        os << "double res = c[0], comp = 0.0, cur_h = h;\n";
+        os << "for (unsigned k = 1; k <= " << order << "u; ++k) {\n";
+        os << "const double tmp = c[(u64)k * N] * cur_h;\nconst double y = tmp - comp;\nconst double t = res + y;\n";
+        os << "comp = (t - res) - y;\nres = t;\ncur_h = cur_h * h;\n}\n";
+    } else {
+        os << "double res = c[(u64)" << order << "u * N];\n";
+        os << "for (unsigned k = 1; k <= " << order << "u; ++k) {\n";
+        os << "res = c[(u64)(" << order << "u - k) * N] + res * h;\n}\n";
+    }
+    os << "out[(u64)i * N + s] = res;\n}\n}\n";
+}
+
+// One system per lane, fully unrolled SSA code (the GPU analogue of the reference's default mode,
+// taylor_compute_jet() src/taylor_02.cpp:1339-1418).
+emitted_module emit_unrolled(const taylor_program &p, const emit_options &opts)
+{
+    const auto n_eq = p.n_eq;
+    const auto order = opts.order;
+    const auto bs = opts.block_size;
+
+    ssa_emitter e(p, order);
+    auto &os = e.os;
+
+    os << prelude;
+
+    emit_dout(os, p, opts);
+
+    os << "extern \"C\" __global__ void __launch_bounds__(" << bs << ") hy_taylor(const hy_kargs a)\n{\n";
+    os << "const u64 s = (u64)blockIdx.x * " << bs << "u + threadIdx.x;\n";
+    os << "if (s >= a.N) return;\n";
+    os << "const u64 N = a.N;\n";
+    os << "double t_hi = a.time_hi[s], t_lo = a.time_lo[s];\n";
+    for (std::uint32_t i = 0; i < p.n_par; ++i) {
+        os << "const double par_" << i << " = a.pars[(u64)" << i << "u * N + s];\n";
+    }
+    for (std::uint32_t i = 0; i < n_eq; ++i) {
+        os << "double x" << i << " = a.state[(u64)" << i << "u * N + s];\n";
+    }
+    os << "double *const jet = a.tc + s;\n";
+    os << R"HIP(
+hy_df tfin, rem;
+tfin.hi = 0.0; tfin.lo = 0.0; rem.hi = 0.0; rem.lo = 0.0;
+bool t_dir = true;
+double mdt = __builtin_inf();
+double step_lim = 0.0;
+if (a.mode == 1) {
+    tfin.hi = a.tfin_hi[s];
+    tfin.lo = a.tfin_lo[s];
+    hy_df tcur; tcur.hi = t_hi; tcur.lo = t_lo;
+    rem = hy_df_sub(tfin, tcur);
+    t_dir = (rem.hi > 0.0) || (rem.hi == 0.0 && rem.lo >= 0.0);
+    if (a.lim != nullptr) mdt = a.lim[s];
+} else {
+    step_lim = a.lim[s];
+}
+u64 n_steps = 0, iter = 0;
+double min_h = __builtin_inf(), max_h = 0.0, last_h = 0.0;
+i64 outcome = HY_OC_SUCCESS;
+for (;;) {
+// Time limit for this step (reference: src/taylor_adaptive_batch.cpp:1378-1387).
+double lim;
+if (a.mode == 1) {
+    hy_df m; m.lo = 0.0;
+    if (t_dir) { m.hi = mdt; lim = hy_df_lt(rem, m) ? rem.hi : m.hi; }
+    else { m.hi = -mdt; lim = hy_df_lt(m, rem) ? rem.hi : m.hi; }
+} else {
+    lim = step_lim;
+}
+)HIP";
+
+    // ---- Jet of normalised derivatives. ----
+    for (std::uint32_t i = 0; i < n_eq; ++i) {
+        e.val(i, 0) = "x" + std::to_string(i);
+    }
+    const auto store_sv = [&](std::uint32_t i, std::uint32_t k) {
+        os << "jet[(u64)" << (static_cast<std::uint64_t>(i) * (order + 1u) + k) << "u * N] = " << e.val(i, k)
+           << ";\n";
+    };
+    for (std::uint32_t i = 0; i < n_eq; ++i) {
+        store_sv(i, 0);
+    }
+    for (std::uint32_t i = 0; i < p.nodes.size(); ++i) {
+        e.node(i, 0);
+    }
+    for (std::uint32_t k = 1; k < order; ++k) {
+        for (std::uint32_t i = 0; i < n_eq; ++i) {
+            e.sv(i, k);
+            store_sv(i, k);
+        }
+        for (std::uint32_t i = 0; i < p.nodes.size(); ++i) {
+            e.node(i, k);
+        }
+    }
+    for (std::uint32_t i = 0; i < n_eq; ++i) {
+        e.sv(i, order);
+        store_sv(i, order);
+    }
+
+    // ---- Step size (reference: taylor_determine_h(), src/taylor_00.cpp:102-273). ----
+    const auto max_abs = [&](std::uint32_t k) {
+        std::vector<std::string> v;
+        for (std::uint32_t i = 0; i < n_eq; ++i) {
+            v.push_back(e.def("fabs(" + e.val(i, k) + ")"));
+        }
+        while (v.size() != 1u) {
+            std::vector<std::string> nv;
+            for (std::size_t i = 0; i < v.size(); i += 2u) {
+                if (i + 1u == v.size()) {
+                    nv.push_back(v[i]);
+                } else {
+                    nv.push_back(e.def("hy_max(" + v[i] + ", " + v[i + 1u] + ")"));
+                }
+            }
+            v.swap(nv);
+        }
+        return v[0];
+    };
+    const auto m0 = max_abs(0), mo = max_abs(order), mom1 = max_abs(order - 1u);
+    os << "const double num_rho = (" << m0 << " <= 1.0) ? 1.0 : " << m0 << ";\n";
+    os << "const double rho_o = pow(num_rho / " << mo << ", " << fp_literal(1. / static_cast<double>(order))
+       << ");\n";
+    os << "const double rho_om1 = pow(num_rho / " << mom1 << ", "
+       << fp_literal(1. / static_cast<double>(order - 1u)) << ");\n";
+    os << "const double rho_m = hy_min(rho_o, rho_om1);\n";
+    os << "double h = rho_m * " << fp_literal(rhofac(order)) << ";\n";
+    os << "h = hy_min(h, fabs(lim));\n";
+    os << "h = (lim < 0.0) ? -h : h;\n";
+
+    // ---- State update: reload the coefficients from the jet buffer. ----
+    // NOTE: the memory clobber prevents the compiler from forwarding the stored coefficients (which
+    // would keep (order + 1) * n_eq values live in registers across the whole step).
+    os << "asm volatile(\"\" ::: \"memory\");\n";
+    if (opts.high_accuracy) {
+        // Compensated summation (reference: taylor_run_ceval(), src/taylor_00.cpp:355-460).
+        for (std::uint32_t i = 0; i < n_eq; ++i) {
+            os << "{\nconst double *c = jet + (u64)" << (static_cast<std::uint64_t>(i) * (order + 1u))
+               << "u * N;\n";
+            os << "double res = c[0], comp = 0.0, cur_h = h;\n";
+            os << "#pragma unroll\nfor (unsigned k = 1; k <= " << order << "u; ++k) {\n";
+            os << "const double tmp = c[(u64)k * N] * cur_h;\nconst double y = tmp - comp;\nconst double t = res + "
+                  "y;\n";
+            os << "comp = (t - res) - y;\nres = t;\ncur_h = cur_h * h;\n}\n";
+            os << "x" << i << " = res;\n}\n";
+        }
+    } else {
+        // Horner (reference: taylor_run_multihorner(), src/taylor_00.cpp:279-351).
+        for (std::uint32_t i = 0; i < n_eq; ++i) {
+            os << "{\nconst double *c = jet + (u64)" << (static_cast<std::uint64_t>(i) * (order + 1u))
+               << "u * N;\n";
+            os << "double res = c[(u64)" << order << "u * N];\n";
+            os << "#pragma unroll\nfor (unsigned k = 1; k <= " << order << "u; ++k) {\n";
+            os << "res = c[(u64)(" << order << "u - k) * N] + res * h;\n}\n";
+            os << "x" << i << " = res;\n}\n";
+        }
+    }
+
+    // ---- Bookkeeping (reference: src/taylor_adaptive_batch.cpp:702-727, :1402-1460). ----
+    os << R"HIP(
+{
+    hy_df tcur; tcur.hi = t_hi; tcur.lo = t_lo;
+    hy_df hh; hh.hi = h; hh.lo = 0.0;
+    const hy_df nt = hy_df_add(tcur, hh);
+    t_hi = nt.hi; t_lo = nt.lo;
+}
+last_h = h;
+bool nf = !(hy_finite(t_hi) && hy_finite(t_lo));
+)HIP";
+    for (std::uint32_t i = 0; i < n_eq; ++i) {
+        os << "nf = nf || !hy_finite(x" << i << ");\n";
+    }
+    os << R"HIP(
+if (nf) {
+    outcome = HY_OC_ERR_NF_STATE;
+    atomicAdd(a.counters, 1u);
+    break;
+}
+outcome = (h == lim) ? HY_OC_TIME_LIMIT : HY_OC_SUCCESS;
+if (a.mode != 1) break;
+n_steps += (h != 0.0) ? 1u : 0u;
+if (outcome == HY_OC_SUCCESS) {
+    const double ah = fabs(h);
+    min_h = hy_min(min_h, ah);
+    max_h = hy_max(max_h, ah);
+}
+if (h == rem.hi) break;
+{
+    hy_df tcur; tcur.hi = t_hi; tcur.lo = t_lo;
+    rem = hy_df_sub(tfin, tcur);
+}
+++iter;
+if (iter == a.max_steps) { outcome = HY_OC_STEP_LIMIT; break; }
+}
+)HIP";
+    for (std::uint32_t i = 0; i < n_eq; ++i) {
+        os << "a.state[(u64)" << i << "u * N + s] = x" << i << ";\n";
+    }
+    os << R"HIP(
+if (a.mode != 2) {
+    a.time_hi[s] = t_hi;
+    a.time_lo[s] = t_lo;
+} else {
+    // Raw stepper ABI: the step taken is returned through the (in/out) limits array.
+    const_cast<double *>(a.lim)[s] = last_h;
+}
+a.last_h[s] = last_h;
+a.outcome[s] = outcome;
+if (a.mode == 1) {
+    a.min_h[s] = min_h;
+    a.max_h[s] = max_h;
+    a.n_steps[s] = n_steps;
+}
+}
+)HIP";
+
+    emitted_module ret;
+    ret.source = os.str();
+    ret.kernel_name = "hy_taylor";
+    ret.dout_name = "hy_dout";
+    ret.block_size = bs;
+    ret.lanes_per_system = 1;
+    ret.mode = emit_mode::unrolled;
+    ret.n_statements = e.n_stmt;
+    return ret;
+}
+
+} // namespace
+
+emitted_module emit_hip_module(const taylor_program &prog, const emit_options &opts)
+{
+    if (opts.order < 2u) {
+        throw std::invalid_argument("The Taylor order must be at least 2");
+    }
+    switch (opts.mode) {
+        case emit_mode::unrolled:
+            return emit_unrolled(prog, opts);
+        default:
+            throw not_implemented_error("The requested code generation mode is not implemented yet");
+    }
+}
+
+} // namespace heyoka_amd

@@ -1,0 +1,67 @@
+// HIP source generation for the batch Taylor stepper (gfx950 / CDNA4).
+//
+// Replaces the LLVM IR emission of the reference (taylor_add_adaptive_step(),
+// src/taylor_00.cpp:712-865; taylor_compute_jet(), src/taylor_02.cpp:1307-1419; the per-node
+// taylor_diff() rules under src/math/*.cpp) with generation of a HIP source module that is
+// compiled at run time with hiprtc. One system per lane ("unrolled" mode) or one system per group
+// of L lanes with the jets of the nonlinear sub-DAGs resident in registers ("cluster" mode).
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "decompose.hpp"
+
+namespace heyoka_amd
+{
+
+// Kernel argument block. Must match the struct emitted in the generated source.
+struct hy_kargs {
+    double *state;            // [n_eq * N] rw
+    const double *pars;       // [n_par * N]
+    double *time_hi;          // [N] rw
+    double *time_lo;          // [N] rw
+    const double *lim;        // step mode: signed max step [N]; propagate mode: max_delta_t > 0 [N] or null
+    const double *tfin_hi;    // propagate mode: final times (double-length) [N]
+    const double *tfin_lo;    // [N]
+    double *last_h;           // [N] out
+    long long *outcome;       // [N] out (taylor_outcome)
+    double *min_h;            // [N] out (propagate mode)
+    double *max_h;            // [N] out (propagate mode)
+    unsigned long long *n_steps; // [N] out (propagate mode)
+    double *tc;               // [n_eq * (order + 1) * N] jet scratch == Taylor coefficients output
+    unsigned long long N;     // number of systems
+    unsigned long long max_steps; // propagate mode: 0 = unlimited
+    int mode;                 // 0 = single step, 1 = propagate_until
+    int pad;
+    unsigned int *counters;   // [4] device counters: [0] lanes with non-finite state, [1] total steps lo, ...
+};
+
+enum class emit_mode { unrolled, cluster, table };
+
+struct emit_options {
+    std::uint32_t order = 20;
+    bool high_accuracy = false;
+    emit_mode mode = emit_mode::unrolled;
+    std::uint32_t block_size = 256;
+};
+
+struct emitted_module {
+    std::string source;
+    std::string kernel_name; // step / propagate kernel
+    std::string dout_name;   // dense-output kernel
+    std::uint32_t block_size = 256;
+    std::uint32_t lanes_per_system = 1;
+    std::uint32_t lds_bytes = 0;
+    emit_mode mode = emit_mode::unrolled;
+    // Statistics (logged like the reference logs decomposition sizes).
+    std::uint64_t n_statements = 0;
+};
+
+emitted_module emit_hip_module(const taylor_program &prog, const emit_options &opts);
+
+// Format a double as a C++17 hexadecimal floating-point literal (exact round trip).
+std::string fp_literal(double);
+
+} // namespace heyoka_amd

@@ -1,0 +1,999 @@
+// Host driver of the MI355X batch Taylor integrator. See taylor_adaptive_batch.hpp.
+#include "taylor_adaptive_batch.hpp"
+
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+
+#include "dfloat.hpp"
+#include "hip_backend.hpp"
+#include "hip_emit.hpp"
+
+namespace heyoka_amd::detail
+{
+
+namespace
+{
+
+std::string fp_to_string(double x)
+{
+    char buf[64];
+    std::snprintf(buf, sizeof(buf), "%.17g", x);
+    return buf;
+}
+
+emit_mode choose_mode()
+{
+    if (const char *m = std::getenv("HEYOKA_AMD_EMIT_MODE")) {
+        const std::string s(m);
+        if (s == "unrolled") {
+            return emit_mode::unrolled;
+        }
+        if (s == "cluster") {
+            return emit_mode::cluster;
+        }
+        if (s == "table") {
+            return emit_mode::table;
+        }
+    }
+    return emit_mode::unrolled;
+}
+
+} // namespace
+
+struct tab_core::impl {
+    sys_t sys;
+    taylor_dc_t dc;
+    taylor_program prog;
+    std::uint32_t order = 0;
+    double tol = 0;
+    bool high_accuracy = false;
+    bool compact_mode = false;
+    std::uint32_t N = 0; // batch size == number of systems.
+    std::uint32_t dim = 0;
+    int device = 0;
+
+    emitted_module emitted;
+    std::shared_ptr<const compiled_module> cmod;
+
+    // Host mirrors (mutable: refreshed lazily from const getters).
+    mutable std::vector<double> state, pars, time_hi, time_lo, tc, last_h, d_out;
+    mutable std::vector<std::tuple<taylor_outcome, double>> step_res;
+    mutable std::vector<std::tuple<taylor_outcome, double, double, std::size_t>> prop_res;
+
+    // Device side (created lazily at the first operation needing the GPU).
+    mutable std::unique_ptr<device_module> dmod;
+    mutable device_buffer d_state, d_pars, d_thi, d_tlo, d_lim, d_tfhi, d_tflo, d_lasth, d_outcome, d_minh, d_maxh,
+        d_nsteps, d_tc, d_counters, d_dout, d_douth;
+    mutable void *stream = nullptr;
+
+    // Synchronisation state.
+    mutable bool host_newer = true;      // state/pars/time on the host must be uploaded.
+    mutable bool dev_newer = false;      // state/time on the device must be downloaded.
+    mutable bool tc_dev_newer = false;   // tc on the device is newer than the host mirror.
+    mutable bool lasth_dev_newer = false;
+    mutable bool step_res_dev_newer = false;
+    mutable bool prop_res_dev_newer = false;
+    bool sticky_host_ptr = false; // a mutable host pointer was handed out: sync eagerly.
+    std::uint64_t last_total_steps = 0;
+    // Set by the lock-step propagate loop to override the device outcomes.
+    mutable std::optional<taylor_outcome> prop_res_override;
+
+    void ensure_device() const
+    {
+        if (dmod) {
+            return;
+        }
+        dmod = std::make_unique<device_module>(cmod, device);
+        dmod->set_stream(stream);
+        const auto n = static_cast<std::size_t>(N);
+        const auto dsz = sizeof(double);
+        d_state = device_buffer(state.size() * dsz, device);
+        d_pars = device_buffer(pars.size() * dsz, device);
+        d_thi = device_buffer(n * dsz, device);
+        d_tlo = device_buffer(n * dsz, device);
+        d_lim = device_buffer(n * dsz, device);
+        d_tfhi = device_buffer(n * dsz, device);
+        d_tflo = device_buffer(n * dsz, device);
+        d_lasth = device_buffer(n * dsz, device);
+        d_outcome = device_buffer(n * sizeof(long long), device);
+        d_minh = device_buffer(n * dsz, device);
+        d_maxh = device_buffer(n * dsz, device);
+        d_nsteps = device_buffer(n * sizeof(unsigned long long), device);
+        d_tc = device_buffer(static_cast<std::size_t>(dim) * (order + 1u) * n * dsz, device);
+        d_counters = device_buffer(16u * sizeof(unsigned), device);
+        host_newer = true;
+    }
+
+    void to_device() const
+    {
+        ensure_device();
+        if (host_newer) {
+            d_state.upload(state.data(), state.size() * sizeof(double), stream);
+            d_pars.upload(pars.data(), pars.size() * sizeof(double), stream);
+            d_thi.upload(time_hi.data(), time_hi.size() * sizeof(double), stream);
+            d_tlo.upload(time_lo.data(), time_lo.size() * sizeof(double), stream);
+            host_newer = false;
+        }
+    }
+
+    void to_host() const
+    {
+        if (dev_newer) {
+            d_state.download(state.data(), state.size() * sizeof(double), stream);
+            d_thi.download(time_hi.data(), time_hi.size() * sizeof(double), stream);
+            d_tlo.download(time_lo.data(), time_lo.size() * sizeof(double), stream);
+            dev_newer = false;
+        }
+    }
+
+    void times_to_host() const
+    {
+        if (dev_newer) {
+            d_thi.download(time_hi.data(), time_hi.size() * sizeof(double), stream);
+            d_tlo.download(time_lo.data(), time_lo.size() * sizeof(double), stream);
+        }
+    }
+
+    void after_kernel()
+    {
+        dev_newer = true;
+        tc_dev_newer = true;
+        lasth_dev_newer = true;
+        if (sticky_host_ptr) {
+            to_host();
+        }
+    }
+
+    void before_kernel()
+    {
+        if (sticky_host_ptr) {
+            // The user may have written through a previously-obtained pointer.
+            host_newer = true;
+        }
+        to_device();
+    }
+
+    hy_kargs base_args() const
+    {
+        hy_kargs a{};
+        a.state = d_state.as<double>();
+        a.pars = d_pars.as<double>();
+        a.time_hi = d_thi.as<double>();
+        a.time_lo = d_tlo.as<double>();
+        a.lim = d_lim.as<double>();
+        a.tfin_hi = d_tfhi.as<double>();
+        a.tfin_lo = d_tflo.as<double>();
+        a.last_h = d_lasth.as<double>();
+        a.outcome = d_outcome.as<long long>();
+        a.min_h = d_minh.as<double>();
+        a.max_h = d_maxh.as<double>();
+        a.n_steps = d_nsteps.as<unsigned long long>();
+        a.tc = d_tc.as<double>();
+        a.N = N;
+        a.max_steps = 0;
+        a.mode = 0;
+        a.counters = d_counters.as<unsigned>();
+        return a;
+    }
+
+    // One lock-step sweep: a single step for every lane with the per-lane signed limits 'lims'.
+    void run_step(const std::vector<double> &lims)
+    {
+        before_kernel();
+        d_lim.upload(lims.data(), lims.size() * sizeof(double), stream);
+        d_counters.zero(stream);
+        auto a = base_args();
+        a.mode = 0;
+        dmod->launch_taylor(a);
+        after_kernel();
+        step_res_dev_newer = true;
+    }
+
+    void fetch_step_res() const
+    {
+        if (!step_res_dev_newer) {
+            return;
+        }
+        std::vector<long long> oc(N);
+        std::vector<double> h(N);
+        d_outcome.download(oc.data(), oc.size() * sizeof(long long), stream);
+        d_lasth.download(h.data(), h.size() * sizeof(double), stream);
+        for (std::uint32_t i = 0; i < N; ++i) {
+            step_res[i] = std::tuple{static_cast<taylor_outcome>(oc[i]), h[i]};
+        }
+        last_h = h;
+        lasth_dev_newer = false;
+        step_res_dev_newer = false;
+    }
+
+    void fetch_prop_res() const
+    {
+        if (!prop_res_dev_newer) {
+            return;
+        }
+        std::vector<long long> oc(N);
+        std::vector<double> mn(N), mx(N);
+        std::vector<unsigned long long> ns(N);
+        d_outcome.download(oc.data(), oc.size() * sizeof(long long), stream);
+        d_minh.download(mn.data(), mn.size() * sizeof(double), stream);
+        d_maxh.download(mx.data(), mx.size() * sizeof(double), stream);
+        d_nsteps.download(ns.data(), ns.size() * sizeof(unsigned long long), stream);
+        for (std::uint32_t i = 0; i < N; ++i) {
+            prop_res[i] = std::tuple{static_cast<taylor_outcome>(oc[i]), mn[i], mx[i], static_cast<std::size_t>(ns[i])};
+        }
+        prop_res_dev_newer = false;
+    }
+};
+
+// Reference: finalise_ctor_impl(), src/taylor_adaptive_batch.cpp:78-427.
+tab_core::tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_size, config cfg)
+    : m_impl(std::make_unique<impl>())
+{
+    auto &d = *m_impl;
+
+    validate_ode_sys(sys);
+
+    d.N = batch_size;
+    d.high_accuracy = cfg.high_accuracy;
+    d.compact_mode = cfg.compact_mode;
+    d.device = cfg.device;
+
+    if (d.N == 0u) {
+        throw std::invalid_argument("The batch size in an adaptive Taylor integrator cannot be zero");
+    }
+
+    if (state.size() % d.N != 0u) {
+        throw std::invalid_argument("Invalid size detected in the initialization of an adaptive Taylor "
+                                    "integrator: the state vector has a size of "
+                                    + std::to_string(state.size()) + ", which is not a multiple of the batch size ("
+                                    + std::to_string(d.N) + ")");
+    }
+
+    if (state.empty()) {
+        state.resize(sys.size() * static_cast<std::size_t>(d.N));
+    }
+
+    if (state.size() / d.N != sys.size()) {
+        throw std::invalid_argument("Inconsistent sizes detected in the initialization of an adaptive Taylor "
+                                    "integrator: the state vector has a dimension of "
+                                    + std::to_string(state.size() / d.N) + " and a batch size of "
+                                    + std::to_string(d.N) + ", while the number of equations is "
+                                    + std::to_string(sys.size()));
+    }
+
+    // Time.
+    if (cfg.time.empty()) {
+        d.time_hi.assign(d.N, 0.);
+    } else if (cfg.time_is_scalar) {
+        d.time_hi.assign(d.N, cfg.time[0]);
+    } else {
+        d.time_hi = std::move(cfg.time);
+    }
+    if (d.time_hi.size() != d.N) {
+        throw std::invalid_argument("Invalid size detected in the initialization of an adaptive Taylor "
+                                    "integrator: the time vector has a size of "
+                                    + std::to_string(d.time_hi.size()) + ", which is not equal to the batch size ("
+                                    + std::to_string(d.N) + ")");
+    }
+    d.time_lo.assign(d.N, 0.);
+
+    if (cfg.tol && (!std::isfinite(*cfg.tol) || *cfg.tol < 0)) {
+        throw std::invalid_argument("The tolerance in an adaptive Taylor integrator must be finite and positive, "
+                                    "but it is "
+                                    + fp_to_string(*cfg.tol) + " instead");
+    }
+
+    if (cfg.parallel_mode && !cfg.compact_mode) {
+        throw std::invalid_argument("Parallel mode can be activated only in conjunction with compact mode");
+    }
+
+    d.tol = cfg.tol ? *cfg.tol : std::numeric_limits<double>::epsilon();
+    d.dim = static_cast<std::uint32_t>(sys.size());
+    d.state = std::move(state);
+
+    // Decomposition + flattened program.
+    d.dc = taylor_decompose_sys(sys);
+    d.prog = make_program(d.dc, d.dim);
+
+    // Parameters.
+    const auto tot_n_pars = d.prog.n_par;
+    const auto pars_req = static_cast<std::size_t>(tot_n_pars) * d.N;
+    if (cfg.pars.empty()) {
+        cfg.pars.resize(pars_req);
+    } else if (cfg.pars.size() != pars_req) {
+        throw std::invalid_argument("Invalid number of parameter values passed to the constructor of an adaptive "
+                                    "Taylor integrator in batch mode: "
+                                    + std::to_string(cfg.pars.size())
+                                    + " parameter value(s) were passed, but the ODE system contains "
+                                    + std::to_string(tot_n_pars) + " parameter(s) (in batches of "
+                                    + std::to_string(d.N) + ")");
+    }
+    d.pars = std::move(cfg.pars);
+
+    d.order = taylor_order_from_tol(d.tol);
+
+    // Index-range checks (the generated code indexes with 64-bit integers, but the public
+    // interface shares the 32-bit batch size of the reference).
+    if (static_cast<std::uint64_t>(d.dim) * (d.order + 1u) > std::numeric_limits<std::uint32_t>::max()) {
+        throw std::overflow_error(
+            "An overflow condition was detected in the computation of a jet of Taylor derivatives");
+    }
+
+    // Code generation + hiprtc compilation (works without a GPU).
+    emit_options eo;
+    eo.order = d.order;
+    eo.high_accuracy = d.high_accuracy;
+    eo.mode = choose_mode();
+    d.emitted = emit_hip_module(d.prog, eo);
+    d.cmod = hiprtc_compile(d.emitted);
+
+    d.sys = std::move(sys);
+    d.last_h.assign(d.N, 0.);
+    d.d_out.assign(static_cast<std::size_t>(d.dim) * d.N, 0.);
+    d.step_res.assign(d.N, std::tuple{taylor_outcome::success, 0.});
+    d.prop_res.assign(d.N, std::tuple{taylor_outcome::success, 0., 0., std::size_t(0)});
+}
+
+tab_core::tab_core(const tab_core &o) : m_impl(std::make_unique<impl>())
+{
+    const auto &s = *o.m_impl;
+    // Bring the host mirrors of the source up to date, then deep-copy them. The compiled module
+    // is shared (reference: shared_ptr<ta_jit_data>, include/heyoka/detail/i_data.hpp:125).
+    s.to_host();
+    s.fetch_step_res();
+    s.fetch_prop_res();
+    if (s.lasth_dev_newer) {
+        s.d_lasth.download(s.last_h.data(), s.last_h.size() * sizeof(double), s.stream);
+        s.lasth_dev_newer = false;
+    }
+    if (s.tc_dev_newer && s.dmod) {
+        s.tc.resize(static_cast<std::size_t>(s.dim) * (s.order + 1u) * s.N);
+        s.d_tc.download(s.tc.data(), s.tc.size() * sizeof(double), s.stream);
+        s.tc_dev_newer = false;
+    }
+    auto &d = *m_impl;
+    d.sys = s.sys;
+    d.dc = s.dc;
+    d.prog = s.prog;
+    d.order = s.order;
+    d.tol = s.tol;
+    d.high_accuracy = s.high_accuracy;
+    d.compact_mode = s.compact_mode;
+    d.N = s.N;
+    d.dim = s.dim;
+    d.device = s.device;
+    d.emitted = s.emitted;
+    d.cmod = s.cmod;
+    d.state = s.state;
+    d.pars = s.pars;
+    d.time_hi = s.time_hi;
+    d.time_lo = s.time_lo;
+    d.tc = s.tc;
+    d.last_h = s.last_h;
+    d.d_out = s.d_out;
+    d.step_res = s.step_res;
+    d.prop_res = s.prop_res;
+    d.stream = s.stream;
+    d.last_total_steps = s.last_total_steps;
+    d.host_newer = true;
+}
+
+tab_core::tab_core(tab_core &&) noexcept = default;
+
+tab_core &tab_core::operator=(const tab_core &o)
+{
+    if (this != &o) {
+        *this = tab_core(o);
+    }
+    return *this;
+}
+
+tab_core &tab_core::operator=(tab_core &&) noexcept = default;
+
+tab_core::~tab_core() = default;
+
+const taylor_dc_t &tab_core::get_decomposition() const
+{
+    return m_impl->dc;
+}
+const taylor_program &tab_core::get_program() const
+{
+    return m_impl->prog;
+}
+std::uint32_t tab_core::get_batch_size() const
+{
+    return m_impl->N;
+}
+std::uint32_t tab_core::get_order() const
+{
+    return m_impl->order;
+}
+double tab_core::get_tol() const
+{
+    return m_impl->tol;
+}
+bool tab_core::get_high_accuracy() const
+{
+    return m_impl->high_accuracy;
+}
+bool tab_core::get_compact_mode() const
+{
+    return m_impl->compact_mode;
+}
+std::uint32_t tab_core::get_dim() const
+{
+    return m_impl->dim;
+}
+const tab_core::sys_t &tab_core::get_sys() const
+{
+    return m_impl->sys;
+}
+int tab_core::get_device() const
+{
+    return m_impl->device;
+}
+const std::string &tab_core::get_hip_source() const
+{
+    return m_impl->emitted.source;
+}
+double tab_core::get_compile_seconds() const
+{
+    return m_impl->cmod->compile_seconds;
+}
+
+const std::vector<double> &tab_core::get_time() const
+{
+    m_impl->to_host();
+    return m_impl->time_hi;
+}
+
+std::pair<const std::vector<double> &, const std::vector<double> &> tab_core::get_dtime() const
+{
+    m_impl->to_host();
+    return {m_impl->time_hi, m_impl->time_lo};
+}
+
+void tab_core::set_time(const std::vector<double> &t)
+{
+    auto &d = *m_impl;
+    if (t.size() != d.N) {
+        throw std::invalid_argument("Invalid number of new times specified in a Taylor integrator in batch mode: the "
+                                    "batch size is "
+                                    + std::to_string(d.N) + ", but the number of specified times is "
+                                    + std::to_string(t.size()));
+    }
+    d.to_host();
+    d.time_hi = t;
+    std::fill(d.time_lo.begin(), d.time_lo.end(), 0.);
+    d.host_newer = true;
+}
+
+void tab_core::set_time(double t)
+{
+    auto &d = *m_impl;
+    d.to_host();
+    std::fill(d.time_hi.begin(), d.time_hi.end(), t);
+    std::fill(d.time_lo.begin(), d.time_lo.end(), 0.);
+    d.host_newer = true;
+}
+
+void tab_core::set_dtime(const std::vector<double> &hi, const std::vector<double> &lo)
+{
+    auto &d = *m_impl;
+    if (hi.size() != d.N || lo.size() != d.N) {
+        throw std::invalid_argument("Invalid number of new times specified in a Taylor integrator in batch mode: the "
+                                    "batch size is "
+                                    + std::to_string(d.N) + ", but the number of specified times is ("
+                                    + std::to_string(hi.size()) + ", " + std::to_string(lo.size()) + ")");
+    }
+    d.to_host();
+    for (std::uint32_t i = 0; i < d.N; ++i) {
+        // Normalise (reference: normalise(), include/heyoka/detail/dfloat.hpp:125-139).
+        const auto [u, v] = eft_add_dekker(hi[i], lo[i]);
+        d.time_hi[i] = u;
+        d.time_lo[i] = v;
+    }
+    d.host_newer = true;
+}
+
+void tab_core::set_dtime(double hi, double lo)
+{
+    auto &d = *m_impl;
+    set_dtime(std::vector<double>(d.N, hi), std::vector<double>(d.N, lo));
+}
+
+const std::vector<double> &tab_core::get_state() const
+{
+    m_impl->to_host();
+    return m_impl->state;
+}
+
+double *tab_core::get_state_data()
+{
+    auto &d = *m_impl;
+    d.to_host();
+    d.host_newer = true;
+    d.sticky_host_ptr = true;
+    return d.state.data();
+}
+
+const std::vector<double> &tab_core::get_pars() const
+{
+    return m_impl->pars;
+}
+
+double *tab_core::get_pars_data()
+{
+    auto &d = *m_impl;
+    d.to_host();
+    d.host_newer = true;
+    d.sticky_host_ptr = true;
+    return d.pars.data();
+}
+
+const std::vector<double> &tab_core::get_tc() const
+{
+    auto &d = *m_impl;
+    const auto sz = static_cast<std::size_t>(d.dim) * (d.order + 1u) * d.N;
+    if (d.tc.size() != sz) {
+        d.tc.assign(sz, 0.);
+    }
+    if (d.tc_dev_newer && d.dmod) {
+        d.d_tc.download(d.tc.data(), sz * sizeof(double), d.stream);
+        d.tc_dev_newer = false;
+    }
+    return d.tc;
+}
+
+const std::vector<double> &tab_core::get_last_h() const
+{
+    auto &d = *m_impl;
+    if (d.lasth_dev_newer && d.dmod) {
+        d.d_lasth.download(d.last_h.data(), d.last_h.size() * sizeof(double), d.stream);
+        d.lasth_dev_newer = false;
+    }
+    return d.last_h;
+}
+
+const std::vector<double> &tab_core::get_d_output() const
+{
+    return m_impl->d_out;
+}
+
+// Reference: update_d_output(), src/taylor_adaptive_batch.cpp:2251-2327.
+const std::vector<double> &tab_core::update_d_output(const std::vector<double> &t, bool rel_time)
+{
+    auto &d = *m_impl;
+    if (t.size() != d.N) {
+        throw std::invalid_argument("Invalid number of time coordinates specified for the dense output in a Taylor "
+                                    "integrator in batch mode: the batch size is "
+                                    + std::to_string(d.N) + ", but the number of time coordinates is "
+                                    + std::to_string(t.size()));
+    }
+    d.ensure_device();
+    std::vector<double> hs(d.N);
+    if (rel_time) {
+        hs = t;
+    } else {
+        d.times_to_host();
+        const auto &lh = get_last_h();
+        for (std::uint32_t i = 0; i < d.N; ++i) {
+            // h' = t - (t_now - last_h), in double-length arithmetic.
+            const auto t0 = dfloat(d.time_hi[i], d.time_lo[i]) - lh[i];
+            hs[i] = static_cast<double>(dfloat(t[i]) - t0);
+        }
+    }
+    if (d.d_dout.bytes() == 0u) {
+        d.d_dout = device_buffer(d.d_out.size() * sizeof(double), d.device);
+        d.d_douth = device_buffer(static_cast<std::size_t>(d.N) * sizeof(double), d.device);
+    }
+    d.d_douth.upload(hs.data(), hs.size() * sizeof(double), d.stream);
+    d.dmod->launch_dout(d.d_dout.as<double>(), d.d_tc.as<double>(), d.d_douth.as<double>(), d.N);
+    d.d_dout.download(d.d_out.data(), d.d_out.size() * sizeof(double), d.stream);
+    return d.d_out;
+}
+
+const std::vector<double> &tab_core::update_d_output(double t, bool rel_time)
+{
+    return update_d_output(std::vector<double>(m_impl->N, t), rel_time);
+}
+
+const std::vector<std::tuple<taylor_outcome, double>> &tab_core::get_step_res() const
+{
+    m_impl->fetch_step_res();
+    return m_impl->step_res;
+}
+
+const std::vector<std::tuple<taylor_outcome, double, double, std::size_t>> &tab_core::get_propagate_res() const
+{
+    auto &d = *m_impl;
+    d.fetch_prop_res();
+    if (d.prop_res_override) {
+        for (auto &r : d.prop_res) {
+            std::get<0>(r) = *d.prop_res_override;
+        }
+        d.prop_res_override.reset();
+    }
+    return d.prop_res;
+}
+
+// ---- stepping (reference: src/taylor_adaptive_batch.cpp:1039-1080) ----
+void tab_core::step(bool)
+{
+    m_impl->run_step(std::vector<double>(m_impl->N, std::numeric_limits<double>::infinity()));
+}
+
+void tab_core::step_backward(bool)
+{
+    m_impl->run_step(std::vector<double>(m_impl->N, -std::numeric_limits<double>::infinity()));
+}
+
+void tab_core::step(const std::vector<double> &max_delta_ts, bool)
+{
+    auto &d = *m_impl;
+    if (max_delta_ts.size() != d.N) {
+        throw std::invalid_argument("Invalid number of max timesteps specified in a Taylor integrator in batch mode: "
+                                    "the batch size is "
+                                    + std::to_string(d.N) + ", but the number of specified timesteps is "
+                                    + std::to_string(max_delta_ts.size()));
+    }
+    if (std::any_of(max_delta_ts.begin(), max_delta_ts.end(), [](double x) { return std::isnan(x); })) {
+        throw std::invalid_argument("Cannot invoke the step() function of an adaptive Taylor integrator in batch "
+                                    "mode if one of the max timesteps is nan");
+    }
+    d.run_step(max_delta_ts);
+}
+
+// Reference: propagate_for_impl(), src/taylor_adaptive_batch.cpp:1082-1118.
+void tab_core::propagate_for(const std::vector<double> &delta_ts, std::size_t max_steps,
+                             const std::vector<double> &max_delta_ts, const cb_t &cb, bool wtc, bool c_out)
+{
+    auto &d = *m_impl;
+    if (delta_ts.size() != 1u && delta_ts.size() != d.N) {
+        throw std::invalid_argument("Invalid number of time intervals specified in a Taylor integrator in batch "
+                                    "mode: the batch size is "
+                                    + std::to_string(d.N) + ", but the number of specified time intervals is "
+                                    + std::to_string(delta_ts.size()));
+    }
+    d.times_to_host();
+    std::vector<double> ts(2u * static_cast<std::size_t>(d.N));
+    for (std::uint32_t i = 0; i < d.N; ++i) {
+        const auto dt = delta_ts.size() == 1u ? delta_ts[0] : delta_ts[i];
+        const auto tf = dfloat(d.time_hi[i], d.time_lo[i]) + dt;
+        ts[i] = tf.hi;
+        ts[d.N + i] = tf.lo;
+    }
+    // NOTE: a vector of size 2 * N carries double-length final times.
+    propagate_until(ts, max_steps, max_delta_ts, cb, wtc, c_out);
+}
+
+// Reference: propagate_until_impl(), src/taylor_adaptive_batch.cpp:1137-1534.
+void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_steps,
+                               const std::vector<double> &max_delta_ts, const cb_t &cb, bool, bool c_out)
+{
+    auto &d = *m_impl;
+    const auto N = d.N;
+
+    std::vector<double> tf_hi(N), tf_lo(N, 0.);
+    if (ts_.size() == 1u) {
+        std::fill(tf_hi.begin(), tf_hi.end(), ts_[0]);
+    } else if (ts_.size() == N) {
+        tf_hi = ts_;
+    } else if (ts_.size() == 2u * static_cast<std::size_t>(N)) {
+        std::copy(ts_.begin(), ts_.begin() + N, tf_hi.begin());
+        std::copy(ts_.begin() + N, ts_.end(), tf_lo.begin());
+    } else {
+        throw std::invalid_argument("Invalid number of time limits specified in a Taylor integrator in batch mode: "
+                                    "the batch size is "
+                                    + std::to_string(N) + ", but the number of specified time limits is "
+                                    + std::to_string(ts_.size()));
+    }
+
+    d.times_to_host();
+    const auto nonfinite = [](double t) { return !std::isfinite(t); };
+    if (std::any_of(d.time_hi.begin(), d.time_hi.end(), nonfinite)
+        || std::any_of(d.time_lo.begin(), d.time_lo.end(), nonfinite)) {
+        throw std::invalid_argument("Cannot invoke the propagate_until() function of an adaptive Taylor integrator "
+                                    "in batch mode if one of the current times is not finite");
+    }
+    if (std::any_of(tf_hi.begin(), tf_hi.end(), nonfinite) || std::any_of(tf_lo.begin(), tf_lo.end(), nonfinite)) {
+        throw std::invalid_argument("A non-finite time was passed to the propagate_until() function of an adaptive "
+                                    "Taylor integrator in batch mode");
+    }
+    if (!max_delta_ts.empty() && max_delta_ts.size() != N) {
+        throw std::invalid_argument("Invalid number of max timesteps specified in a Taylor integrator in batch mode: "
+                                    "the batch size is "
+                                    + std::to_string(N) + ", but the number of specified timesteps is "
+                                    + std::to_string(max_delta_ts.size()));
+    }
+    for (const auto dt : max_delta_ts) {
+        if (std::isnan(dt)) {
+            throw std::invalid_argument("A nan max_delta_t was passed to the propagate_until() function of an "
+                                        "adaptive Taylor integrator in batch mode");
+        }
+        if (dt <= 0) {
+            throw std::invalid_argument("A non-positive max_delta_t was passed to the propagate_until() function of "
+                                        "an adaptive Taylor integrator in batch mode");
+        }
+    }
+    if (c_out) {
+        throw not_implemented_error("Continuous output (kw::c_output) is not implemented in the MI355X batch "
+                                    "integrator");
+    }
+
+    std::vector<dfloat> rem(N);
+    for (std::uint32_t i = 0; i < N; ++i) {
+        rem[i] = dfloat(tf_hi[i], tf_lo[i]) - dfloat(d.time_hi[i], d.time_lo[i]);
+        if (!isfinite(rem[i])) {
+            throw std::invalid_argument("The final time passed to the propagate_until() function of an adaptive "
+                                        "Taylor integrator in batch mode results in an overflow condition");
+        }
+    }
+
+    d.prop_res_override.reset();
+
+    if (!cb) {
+        // Device-resident propagation: every lane runs its own adaptive loop to completion
+        // (or to max_steps) inside a single kernel launch.
+        d.before_kernel();
+        d.d_tfhi.upload(tf_hi.data(), tf_hi.size() * sizeof(double), d.stream);
+        d.d_tflo.upload(tf_lo.data(), tf_lo.size() * sizeof(double), d.stream);
+        d.d_counters.zero(d.stream);
+        auto a = d.base_args();
+        if (max_delta_ts.empty()) {
+            a.lim = nullptr;
+        } else {
+            d.d_lim.upload(max_delta_ts.data(), max_delta_ts.size() * sizeof(double), d.stream);
+        }
+        a.mode = 1;
+        a.max_steps = max_steps;
+        d.dmod->launch_taylor(a);
+        d.after_kernel();
+        d.prop_res_dev_newer = true;
+        d.step_res_dev_newer = false;
+        return;
+    }
+
+    // Lock-step propagation with a callback executed after every sweep: the reference's loop,
+    // one single-step kernel launch per iteration.
+    std::vector<int> t_dir(N);
+    std::vector<std::size_t> ts_count(N, 0);
+    std::vector<double> min_abs_h(N, std::numeric_limits<double>::infinity()), max_abs_h(N, 0.);
+    std::vector<double> cur_max(N);
+    for (std::uint32_t i = 0; i < N; ++i) {
+        t_dir[i] = rem[i] >= dfloat(0.);
+    }
+    const auto pinf = std::numeric_limits<double>::infinity();
+    std::size_t iter_counter = 0;
+
+    while (true) {
+        for (std::uint32_t i = 0; i < N; ++i) {
+            const auto mdt = max_delta_ts.empty() ? pinf : max_delta_ts[i];
+            const auto dt_limit = t_dir[i] != 0 ? std::min(dfloat(mdt), rem[i]) : std::max(dfloat(-mdt), rem[i]);
+            cur_max[i] = static_cast<double>(dt_limit);
+        }
+
+        d.run_step(cur_max);
+        d.fetch_step_res();
+        d.to_host();
+
+        std::uint32_t n_done = 0;
+        bool nfs_detected = false;
+        for (std::uint32_t i = 0; i < N; ++i) {
+            const auto [oc, h] = d.step_res[i];
+            if (oc == taylor_outcome::err_nf_state) {
+                nfs_detected = true;
+            } else {
+                ts_count[i] += static_cast<std::size_t>(h != 0);
+                if (oc == taylor_outcome::success) {
+                    const auto abs_h = std::abs(h);
+                    min_abs_h[i] = std::min(min_abs_h[i], abs_h);
+                    max_abs_h[i] = std::max(max_abs_h[i], abs_h);
+                }
+                const auto cur_done = (h == static_cast<double>(rem[i]));
+                n_done += cur_done;
+                if (cur_done) {
+                    rem[i] = dfloat(0.);
+                } else {
+                    rem[i] = dfloat(tf_hi[i], tf_lo[i]) - dfloat(d.time_hi[i], d.time_lo[i]);
+                }
+            }
+            d.prop_res[i] = std::tuple{oc, min_abs_h[i], max_abs_h[i], ts_count[i]};
+        }
+        d.prop_res_dev_newer = false;
+
+        if (nfs_detected) {
+            return;
+        }
+
+        ++iter_counter;
+
+        const auto thi_copy = d.time_hi;
+        const auto tlo_copy = d.time_lo;
+        const auto ret_cb = cb();
+        d.to_host();
+        if (d.time_hi != thi_copy || d.time_lo != tlo_copy) {
+            throw std::runtime_error("The invocation of the callback passed to propagate_until() resulted in the "
+                                     "alteration of the time coordinate of the integrator - this is not supported");
+        }
+        if (!ret_cb) {
+            for (auto &r : d.prop_res) {
+                std::get<0>(r) = taylor_outcome::cb_stop;
+            }
+            return;
+        }
+
+        if (n_done == N) {
+            return;
+        }
+
+        if (iter_counter == max_steps) {
+            for (auto &r : d.prop_res) {
+                std::get<0>(r) = taylor_outcome::step_limit;
+            }
+            return;
+        }
+    }
+}
+
+std::vector<double> tab_core::propagate_grid(std::vector<double>, std::size_t, const std::vector<double> &,
+                                             const cb_t &)
+{
+    throw not_implemented_error("propagate_grid() is not implemented yet in the MI355X batch integrator");
+}
+
+double *tab_core::device_state()
+{
+    m_impl->to_device();
+    return m_impl->d_state.as<double>();
+}
+double *tab_core::device_pars()
+{
+    m_impl->to_device();
+    return m_impl->d_pars.as<double>();
+}
+double *tab_core::device_time_hi()
+{
+    m_impl->to_device();
+    return m_impl->d_thi.as<double>();
+}
+double *tab_core::device_time_lo()
+{
+    m_impl->to_device();
+    return m_impl->d_tlo.as<double>();
+}
+double *tab_core::device_tc()
+{
+    m_impl->ensure_device();
+    return m_impl->d_tc.as<double>();
+}
+
+void *tab_core::device_aux(int which)
+{
+    m_impl->ensure_device();
+    switch (which) {
+        case 0:
+            return m_impl->d_nsteps.get();
+        case 1:
+            return m_impl->d_outcome.get();
+        default:
+            return m_impl->d_lasth.get();
+    }
+}
+
+void tab_core::mark_device_modified()
+{
+    m_impl->to_device();
+    m_impl->dev_newer = true;
+}
+
+void tab_core::set_stream(void *s)
+{
+    m_impl->stream = s;
+    if (m_impl->dmod) {
+        m_impl->dmod->set_stream(s);
+    }
+}
+
+void tab_core::set_device(int device)
+{
+    auto &d = *m_impl;
+    if (device == d.device) {
+        return;
+    }
+    // Bring everything back to the host, drop the device objects, switch.
+    d.to_host();
+    d.fetch_step_res();
+    d.fetch_prop_res();
+    (void)get_last_h();
+    if (d.tc_dev_newer && d.dmod) {
+        (void)get_tc();
+    }
+    d.dmod.reset();
+    d.d_state = {};
+    d.d_pars = {};
+    d.d_thi = {};
+    d.d_tlo = {};
+    d.d_lim = {};
+    d.d_tfhi = {};
+    d.d_tflo = {};
+    d.d_lasth = {};
+    d.d_outcome = {};
+    d.d_minh = {};
+    d.d_maxh = {};
+    d.d_nsteps = {};
+    d.d_tc = {};
+    d.d_counters = {};
+    d.d_dout = {};
+    d.d_douth = {};
+    d.device = device;
+    d.host_newer = true;
+    d.dev_newer = false;
+    d.tc_dev_newer = false;
+    d.lasth_dev_newer = false;
+}
+
+void tab_core::synchronize()
+{
+    if (m_impl->dmod) {
+        m_impl->dmod->synchronize();
+    }
+}
+
+std::uint64_t tab_core::get_last_total_steps() const
+{
+    auto &d = *m_impl;
+    d.fetch_prop_res();
+    std::uint64_t tot = 0;
+    for (const auto &r : d.prop_res) {
+        tot += std::get<3>(r);
+    }
+    return tot;
+}
+
+void tab_core::raw_step(double *d_state, const double *d_pars, const double *d_time, double *d_h, double *d_tc,
+                        std::uint64_t n_systems)
+{
+    auto &d = *m_impl;
+    d.ensure_device();
+    // Scratch for the outputs the raw ABI does not expose.
+    device_buffer tlo(n_systems * sizeof(double), d.device), oc(n_systems * sizeof(long long), d.device),
+        lh(n_systems * sizeof(double), d.device);
+    device_buffer tc_scratch;
+    tlo.zero(d.stream);
+    hy_kargs a{};
+    a.state = d_state;
+    a.pars = d_pars;
+    // NOTE: mode 2 does not write the time back (the caller advances it, like step_impl() in the reference).
+    a.time_hi = const_cast<double *>(d_time);
+    a.time_lo = tlo.as<double>();
+    a.lim = d_h;
+    a.last_h = lh.as<double>();
+    a.outcome = oc.as<long long>();
+    if (d_tc == nullptr) {
+        tc_scratch = device_buffer(static_cast<std::size_t>(d.dim) * (d.order + 1u) * n_systems * sizeof(double),
+                                   d.device);
+        a.tc = tc_scratch.as<double>();
+    } else {
+        a.tc = d_tc;
+    }
+    a.N = n_systems;
+    a.mode = 2;
+    a.counters = d.d_counters.as<unsigned>();
+    d.dmod->launch_taylor(a);
+    d.dmod->synchronize();
+}
+
+std::vector<double> make_vector_from(double x)
+{
+    return {x};
+}
+
+} // namespace heyoka_amd::detail

@@ -1,0 +1,442 @@
+// Drop-in counterpart of heyoka::taylor_adaptive_batch<double> running on MI355X.
+//
+// Reference interface: include/heyoka/taylor.hpp:781-1121 (class), :142-155 (taylor_outcome),
+// src/taylor_adaptive_batch.cpp:78-427 (construction), :632-727 (step), :1082-1534 (propagate_for/until),
+// :2251-2327 (update_d_output). "batch_size" is the number of systems integrated concurrently: the
+// SIMD width of the reference becomes the number of GPU lanes here (10^6 and beyond).
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <functional>
+#include <initializer_list>
+#include <limits>
+#include <memory>
+#include <optional>
+#include <tuple>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "decompose.hpp"
+#include "expression.hpp"
+#include "kw.hpp"
+
+namespace heyoka_amd
+{
+
+// Reference: include/heyoka/taylor.hpp:142-155.
+enum class taylor_outcome : std::int64_t {
+    success = -4294967296ll - 1,
+    step_limit = -4294967296ll - 2,
+    time_limit = -4294967296ll - 3,
+    err_nf_state = -4294967296ll - 4,
+    cb_stop = -4294967296ll - 5
+};
+
+template <typename T>
+class taylor_adaptive_batch;
+
+// Type-erased step callback: bool(taylor_adaptive_batch<double> &)
+// (reference: include/heyoka/step_callback.hpp:59-62).
+template <typename T>
+using step_callback_batch = std::function<bool(taylor_adaptive_batch<T> &)>;
+
+namespace detail
+{
+
+// Non-template implementation of the fp64 batch integrator.
+class tab_core
+{
+public:
+    using sys_t = std::vector<std::pair<expression, expression>>;
+
+    struct config {
+        std::optional<double> tol;
+        bool high_accuracy = false;
+        bool compact_mode = false;
+        bool parallel_mode = false;
+        std::vector<double> pars;
+        std::vector<double> time; // empty -> zeros; size 1 -> splat; else size == batch_size.
+        bool time_is_scalar = false;
+        int device = 0;
+    };
+
+    tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_size, config cfg);
+    tab_core(const tab_core &);
+    tab_core(tab_core &&) noexcept;
+    tab_core &operator=(const tab_core &);
+    tab_core &operator=(tab_core &&) noexcept;
+    ~tab_core();
+
+    // ---- getters ----
+    [[nodiscard]] const taylor_dc_t &get_decomposition() const;
+    [[nodiscard]] const taylor_program &get_program() const;
+    [[nodiscard]] std::uint32_t get_batch_size() const;
+    [[nodiscard]] std::uint32_t get_order() const;
+    [[nodiscard]] double get_tol() const;
+    [[nodiscard]] bool get_high_accuracy() const;
+    [[nodiscard]] bool get_compact_mode() const;
+    [[nodiscard]] std::uint32_t get_dim() const;
+    [[nodiscard]] const sys_t &get_sys() const;
+    [[nodiscard]] int get_device() const;
+    [[nodiscard]] const std::string &get_hip_source() const;
+    [[nodiscard]] double get_compile_seconds() const;
+
+    [[nodiscard]] const std::vector<double> &get_time() const;
+    [[nodiscard]] std::pair<const std::vector<double> &, const std::vector<double> &> get_dtime() const;
+    void set_time(const std::vector<double> &);
+    void set_time(double);
+    void set_dtime(const std::vector<double> &, const std::vector<double> &);
+    void set_dtime(double, double);
+
+    [[nodiscard]] const std::vector<double> &get_state() const;
+    [[nodiscard]] double *get_state_data();
+    [[nodiscard]] const std::vector<double> &get_pars() const;
+    [[nodiscard]] double *get_pars_data();
+    [[nodiscard]] const std::vector<double> &get_tc() const;
+    [[nodiscard]] const std::vector<double> &get_last_h() const;
+    [[nodiscard]] const std::vector<double> &get_d_output() const;
+    const std::vector<double> &update_d_output(const std::vector<double> &, bool rel_time);
+    const std::vector<double> &update_d_output(double, bool rel_time);
+
+    [[nodiscard]] const std::vector<std::tuple<taylor_outcome, double>> &get_step_res() const;
+    [[nodiscard]] const std::vector<std::tuple<taylor_outcome, double, double, std::size_t>> &get_propagate_res() const;
+
+    // ---- stepping ----
+    void step(bool wtc);
+    void step_backward(bool wtc);
+    void step(const std::vector<double> &max_delta_ts, bool wtc);
+
+    using cb_t = std::function<bool()>;
+    // ts: final times (size 1 = scalar splat, else batch_size); max_delta_ts: empty or batch_size.
+    void propagate_until(const std::vector<double> &ts, std::size_t max_steps, const std::vector<double> &max_delta_ts,
+                         const cb_t &cb, bool wtc, bool c_out);
+    void propagate_for(const std::vector<double> &delta_ts, std::size_t max_steps,
+                       const std::vector<double> &max_delta_ts, const cb_t &cb, bool wtc, bool c_out);
+    std::vector<double> propagate_grid(std::vector<double> grid, std::size_t max_steps,
+                                       const std::vector<double> &max_delta_ts, const cb_t &cb);
+
+    // ---- device-resident access (MI355X extension, used by the ensemble / benchmark paths) ----
+    // Raw device pointers to the SoA arrays (array[row * batch_size + lane]). Calling any of these
+    // makes the device copy authoritative until a host getter is used again.
+    double *device_state();
+    double *device_pars();
+    double *device_time_hi();
+    double *device_time_lo();
+    double *device_tc();
+    // 0: n_steps (uint64), 1: outcome (int64), 2: last_h (double).
+    void *device_aux(int which);
+    // Mark the device copies as modified by the caller (e.g. initial conditions written by a kernel).
+    void mark_device_modified();
+    void set_stream(void *hip_stream);
+    // Move the integrator to another HIP device (device buffers are re-created lazily).
+    void set_device(int device);
+    void synchronize();
+    // Total number of integration steps taken by the last propagate_*() call (sum over lanes).
+    [[nodiscard]] std::uint64_t get_last_total_steps() const;
+    // Stepper function-pointer ABI of the reference (include/heyoka/detail/ta_jit_data.hpp:35-44)
+    // on caller-provided device buffers: state rw, h in = signed max step, out = step taken.
+    void raw_step(double *d_state, const double *d_pars, const double *d_time, double *d_h, double *d_tc,
+                  std::uint64_t n_systems);
+
+private:
+    struct impl;
+    std::unique_ptr<impl> m_impl;
+};
+
+std::vector<double> make_vector_from(double x);
+
+} // namespace detail
+
+template <>
+class taylor_adaptive_batch<double>
+{
+    detail::tab_core m_core;
+
+    template <typename... KwArgs>
+    static detail::tab_core::config make_config(const KwArgs &...kw_args)
+    {
+        static_assert(kw::all_named_v<KwArgs...>,
+                      "Only named arguments (kw::name = value) can follow the batch size in the constructor");
+        detail::tab_core::config cfg;
+        if constexpr (kw::has_v<kw::tol_tag, KwArgs...>) {
+            const auto tol = static_cast<double>(kw::get(kw::tol, 0., kw_args...));
+            // NOTE: tol == 0 is interpreted as undefined (reference: taylor.hpp:838-846).
+            if (tol != 0) {
+                cfg.tol = tol;
+            }
+        }
+        cfg.high_accuracy = static_cast<bool>(kw::get(kw::high_accuracy, false, kw_args...));
+        cfg.compact_mode = static_cast<bool>(kw::get(kw::compact_mode, false, kw_args...));
+        cfg.parallel_mode = static_cast<bool>(kw::get(kw::parallel_mode, false, kw_args...));
+        cfg.device = static_cast<int>(kw::get(kw::device, 0, kw_args...));
+        if constexpr (kw::has_v<kw::pars_tag, KwArgs...>) {
+            for (const auto &x : kw::get(kw::pars, 0, kw_args...)) {
+                cfg.pars.push_back(static_cast<double>(x));
+            }
+        }
+        if constexpr (kw::has_v<kw::time_tag, KwArgs...>) {
+            using time_t = std::decay_t<decltype(kw::get(kw::time, 0, kw_args...))>;
+            if constexpr (std::is_arithmetic_v<time_t>) {
+                cfg.time = {static_cast<double>(kw::get(kw::time, 0, kw_args...))};
+                cfg.time_is_scalar = true;
+            } else {
+                for (const auto &x : kw::get(kw::time, 0, kw_args...)) {
+                    cfg.time.push_back(static_cast<double>(x));
+                }
+            }
+        }
+        static_assert(!kw::has_v<kw::t_events_tag, KwArgs...> && !kw::has_v<kw::nt_events_tag, KwArgs...>,
+                      "Event detection is not available in the MI355X batch integrator");
+        return cfg;
+    }
+
+    template <typename... KwArgs>
+    auto propagate_common_ops(const KwArgs &...kw_args)
+    {
+        static_assert(kw::all_named_v<KwArgs...>);
+        const auto max_steps = static_cast<std::size_t>(kw::get(kw::max_steps, 0, kw_args...));
+        std::vector<double> max_delta_ts;
+        if constexpr (kw::has_v<kw::max_delta_t_tag, KwArgs...>) {
+            using mdt_t = std::decay_t<decltype(kw::get(kw::max_delta_t, 0, kw_args...))>;
+            if constexpr (std::is_arithmetic_v<mdt_t>) {
+                max_delta_ts.assign(get_batch_size(), static_cast<double>(kw::get(kw::max_delta_t, 0, kw_args...)));
+            } else {
+                for (const auto &x : kw::get(kw::max_delta_t, 0, kw_args...)) {
+                    max_delta_ts.push_back(static_cast<double>(x));
+                }
+            }
+        }
+        detail::tab_core::cb_t cb;
+        step_callback_batch<double> user_cb;
+        if constexpr (kw::has_v<kw::callback_tag, KwArgs...>) {
+            user_cb = kw::get(kw::callback, 0, kw_args...);
+            if (user_cb) {
+                cb = [this, user_cb]() mutable { return user_cb(*this); };
+            }
+        }
+        const auto wtc = static_cast<bool>(kw::get(kw::write_tc, false, kw_args...));
+        const auto c_out = static_cast<bool>(kw::get(kw::c_output, false, kw_args...));
+        return std::tuple{max_steps, std::move(max_delta_ts), std::move(cb), std::move(user_cb), wtc, c_out};
+    }
+
+public:
+    using sys_t = detail::tab_core::sys_t;
+
+    template <typename... KwArgs>
+    taylor_adaptive_batch(sys_t sys, std::vector<double> state, std::uint32_t batch_size, const KwArgs &...kw_args)
+        : m_core(std::move(sys), std::move(state), batch_size, make_config(kw_args...))
+    {
+    }
+    template <typename... KwArgs>
+    taylor_adaptive_batch(sys_t sys, std::initializer_list<double> state, std::uint32_t batch_size,
+                          const KwArgs &...kw_args)
+        : taylor_adaptive_batch(std::move(sys), std::vector<double>(state), batch_size, kw_args...)
+    {
+    }
+    // Construction without an initial state (zero-initialised, reference: taylor.hpp:917-929).
+    template <typename... KwArgs>
+    taylor_adaptive_batch(sys_t sys, std::uint32_t batch_size, const KwArgs &...kw_args)
+        : taylor_adaptive_batch(std::move(sys), std::vector<double>{}, batch_size, kw_args...)
+    {
+    }
+
+    [[nodiscard]] const taylor_dc_t &get_decomposition() const
+    {
+        return m_core.get_decomposition();
+    }
+    [[nodiscard]] std::uint32_t get_batch_size() const
+    {
+        return m_core.get_batch_size();
+    }
+    [[nodiscard]] std::uint32_t get_order() const
+    {
+        return m_core.get_order();
+    }
+    [[nodiscard]] double get_tol() const
+    {
+        return m_core.get_tol();
+    }
+    [[nodiscard]] bool get_high_accuracy() const
+    {
+        return m_core.get_high_accuracy();
+    }
+    [[nodiscard]] bool get_compact_mode() const
+    {
+        return m_core.get_compact_mode();
+    }
+    [[nodiscard]] std::uint32_t get_dim() const
+    {
+        return m_core.get_dim();
+    }
+    [[nodiscard]] std::uint32_t get_n_orig_sv() const noexcept
+    {
+        return m_core.get_dim();
+    }
+    [[nodiscard]] const sys_t &get_sys() const noexcept
+    {
+        return m_core.get_sys();
+    }
+    [[nodiscard]] bool with_events() const
+    {
+        return false;
+    }
+    [[nodiscard]] bool is_variational() const noexcept
+    {
+        return false;
+    }
+
+    [[nodiscard]] const std::vector<double> &get_time() const
+    {
+        return m_core.get_time();
+    }
+    [[nodiscard]] const double *get_time_data() const
+    {
+        return m_core.get_time().data();
+    }
+    void set_time(const std::vector<double> &t)
+    {
+        m_core.set_time(t);
+    }
+    void set_time(double t)
+    {
+        m_core.set_time(t);
+    }
+    [[nodiscard]] std::pair<const std::vector<double> &, const std::vector<double> &> get_dtime() const
+    {
+        return m_core.get_dtime();
+    }
+    [[nodiscard]] std::pair<const double *, const double *> get_dtime_data() const
+    {
+        const auto p = m_core.get_dtime();
+        return {p.first.data(), p.second.data()};
+    }
+    void set_dtime(const std::vector<double> &hi, const std::vector<double> &lo)
+    {
+        m_core.set_dtime(hi, lo);
+    }
+    void set_dtime(double hi, double lo)
+    {
+        m_core.set_dtime(hi, lo);
+    }
+
+    [[nodiscard]] const std::vector<double> &get_state() const
+    {
+        return m_core.get_state();
+    }
+    [[nodiscard]] const double *get_state_data() const
+    {
+        return m_core.get_state().data();
+    }
+    [[nodiscard]] double *get_state_data()
+    {
+        return m_core.get_state_data();
+    }
+    [[nodiscard]] const std::vector<double> &get_pars() const
+    {
+        return m_core.get_pars();
+    }
+    [[nodiscard]] const double *get_pars_data() const
+    {
+        return m_core.get_pars().data();
+    }
+    [[nodiscard]] double *get_pars_data()
+    {
+        return m_core.get_pars_data();
+    }
+    [[nodiscard]] const std::vector<double> &get_tc() const
+    {
+        return m_core.get_tc();
+    }
+    [[nodiscard]] const std::vector<double> &get_last_h() const
+    {
+        return m_core.get_last_h();
+    }
+    [[nodiscard]] const std::vector<double> &get_d_output() const
+    {
+        return m_core.get_d_output();
+    }
+    const std::vector<double> &update_d_output(const std::vector<double> &t, bool rel_time = false)
+    {
+        return m_core.update_d_output(t, rel_time);
+    }
+    const std::vector<double> &update_d_output(double t, bool rel_time = false)
+    {
+        return m_core.update_d_output(t, rel_time);
+    }
+
+    void step(bool wtc = false)
+    {
+        m_core.step(wtc);
+    }
+    void step_backward(bool wtc = false)
+    {
+        m_core.step_backward(wtc);
+    }
+    void step(const std::vector<double> &max_delta_ts, bool wtc = false)
+    {
+        m_core.step(max_delta_ts, wtc);
+    }
+    [[nodiscard]] const std::vector<std::tuple<taylor_outcome, double>> &get_step_res() const
+    {
+        return m_core.get_step_res();
+    }
+    [[nodiscard]] const std::vector<std::tuple<taylor_outcome, double, double, std::size_t>> &get_propagate_res() const
+    {
+        return m_core.get_propagate_res();
+    }
+
+    // NOTE: the first element of the returned tuple (continuous output) is always empty: kw::c_output = true
+    // throws not_implemented_error.
+    template <typename... KwArgs>
+    std::tuple<std::nullopt_t, step_callback_batch<double>> propagate_until(const std::vector<double> &ts,
+                                                                           const KwArgs &...kw_args)
+    {
+        auto [max_steps, mdts, cb, user_cb, wtc, c_out] = propagate_common_ops(kw_args...);
+        m_core.propagate_until(ts, max_steps, mdts, cb, wtc, c_out);
+        return {std::nullopt, std::move(user_cb)};
+    }
+    template <typename... KwArgs>
+    std::tuple<std::nullopt_t, step_callback_batch<double>> propagate_until(double t, const KwArgs &...kw_args)
+    {
+        auto [max_steps, mdts, cb, user_cb, wtc, c_out] = propagate_common_ops(kw_args...);
+        m_core.propagate_until(std::vector<double>{t}, max_steps, mdts, cb, wtc, c_out);
+        return {std::nullopt, std::move(user_cb)};
+    }
+    template <typename... KwArgs>
+    std::tuple<std::nullopt_t, step_callback_batch<double>> propagate_for(const std::vector<double> &dts,
+                                                                         const KwArgs &...kw_args)
+    {
+        auto [max_steps, mdts, cb, user_cb, wtc, c_out] = propagate_common_ops(kw_args...);
+        m_core.propagate_for(dts, max_steps, mdts, cb, wtc, c_out);
+        return {std::nullopt, std::move(user_cb)};
+    }
+    template <typename... KwArgs>
+    std::tuple<std::nullopt_t, step_callback_batch<double>> propagate_for(double dt, const KwArgs &...kw_args)
+    {
+        auto [max_steps, mdts, cb, user_cb, wtc, c_out] = propagate_common_ops(kw_args...);
+        m_core.propagate_for(std::vector<double>{dt}, max_steps, mdts, cb, wtc, c_out);
+        return {std::nullopt, std::move(user_cb)};
+    }
+    template <typename... KwArgs>
+    std::tuple<step_callback_batch<double>, std::vector<double>> propagate_grid(std::vector<double> grid,
+                                                                               const KwArgs &...kw_args)
+    {
+        auto [max_steps, mdts, cb, user_cb, wtc, c_out] = propagate_common_ops(kw_args...);
+        auto ret = m_core.propagate_grid(std::move(grid), max_steps, mdts, cb);
+        return {std::move(user_cb), std::move(ret)};
+    }
+
+    // MI355X extensions.
+    [[nodiscard]] detail::tab_core &core()
+    {
+        return m_core;
+    }
+    [[nodiscard]] const detail::tab_core &core() const
+    {
+        return m_core;
+    }
+};
+
+} // namespace heyoka_amd

@@ -1,0 +1,70 @@
+"""Multi-GPU ensemble propagation: one process per GPU (torch.distributed; backend "nccl" is RCCL
+over xGMI on MI355X, "gloo" on CPU for tests).
+
+The reference's ensemble_propagate_*_batch() (src/ensemble_propagate.cpp:193-297) runs n_iter
+independent propagations inside a TBB parallel_for. Here the independent initial conditions are
+sharded contiguously across ranks, every rank integrates its shard with no communication, and the
+only collective is the gather of the final states (plus outcomes / step counters)."""
+
+import numpy as np
+
+
+def shard_bounds(n_total, rank, world_size):
+    """Contiguous partition of range(n_total) (sizes differ by at most one)."""
+    base, rem = divmod(int(n_total), int(world_size))
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    return lo, hi
+
+
+def all_gather_states(local, group=None):
+    """Gather (rows, n_local) tensors from every rank into a (rows, n_total) tensor on every rank
+    (ranks may own different numbers of systems)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return local
+    world = dist.get_world_size(group)
+    n_local = torch.tensor([local.shape[-1]], dtype=torch.int64, device=local.device)
+    sizes = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(sizes, n_local, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    rows = local.shape[0] if local.dim() == 2 else 1
+    loc2 = local.reshape(rows, -1)
+    if len(set(sizes)) == 1:
+        # One bulk collective: gather contiguous [world, rows, n] then stitch lanes.
+        out = torch.empty((world,) + tuple(loc2.shape), dtype=loc2.dtype, device=loc2.device)
+        dist.all_gather_into_tensor(out, loc2.contiguous(), group=group)
+        res = out.permute(1, 0, 2).reshape(rows, -1)
+    else:
+        nmax = max(sizes)
+        pad = torch.zeros((rows, nmax), dtype=loc2.dtype, device=loc2.device)
+        pad[:, : loc2.shape[1]] = loc2
+        bufs = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(bufs, pad, group=group)
+        res = torch.cat([b[:, :s] for b, s in zip(bufs, sizes)], dim=1)
+    return res if local.dim() == 2 else res.reshape(-1)
+
+
+def ensemble_propagate_until_sharded(make_integrator, global_state, t_final, group=None, max_steps=0, device=None):
+    """Propagate global_state (n_eq, n_total; host array, identical on all ranks) to t_final:
+    rank r integrates lanes shard_bounds(n_total, r, world) and all ranks receive the gathered final
+    state, outcomes and step counts. make_integrator(n_local) -> taylor_adaptive_batch."""
+    import torch
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    n_total = global_state.shape[1]
+    lo, hi = shard_bounds(n_total, rank, world)
+    ta = make_integrator(hi - lo)
+    ta.state = np.ascontiguousarray(global_state[:, lo:hi])
+    ta.propagate_until(t_final, max_steps=max_steps)
+    oc, mn, mx, ns = ta.propagate_res_arrays()
+    dev = device if device is not None else torch.device("cpu")
+    st = torch.as_tensor(ta.state).to(dev)
+    meta = torch.as_tensor(np.stack([oc.astype(np.float64), ns.astype(np.float64)])).to(dev)
+    return ta, all_gather_states(st, group), all_gather_states(meta, group)

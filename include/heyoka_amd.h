@@ -1,0 +1,226 @@
+/*
+ * heyoka_amd C ABI: the drop-in boundary of the MI355X batch Taylor integrator.
+ *
+ * Every entry point replaces (and is named after) a piece of the public C++ interface of
+ * bluescarni/heyoka v7.12.0 on the taylor_adaptive_batch<double> / ensemble_propagate_* path; the
+ * reference interface each one stands for is cited as file:line relative to the reference tree.
+ * Plain pointers and sizes only: no C++ or torch types cross this boundary.
+ *
+ * Conventions
+ *  - All per-system arrays use the reference's batch layout array[row * batch_size + lane]
+ *    (src/taylor_adaptive_batch.cpp:679, src/taylor_00.cpp:574-575, :835).
+ *  - Functions returning int return 0 on success, otherwise one of the HY_ERR_* codes; the message
+ *    (identical to the exception message of the reference where one exists) is available from
+ *    hy_last_error() on the calling thread.
+ *  - Functions returning a handle return NULL on error.
+ *  - Pointers named d_* are device (HBM) pointers; everything else is host memory.
+ */
+#ifndef HEYOKA_AMD_H
+#define HEYOKA_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HY_OK 0
+#define HY_ERR_INVALID_ARGUMENT 1 /* std::invalid_argument in the reference */
+#define HY_ERR_OVERFLOW 2         /* std::overflow_error */
+#define HY_ERR_NOT_IMPLEMENTED 3  /* heyoka::not_implemented_error (include/heyoka/exceptions.hpp) */
+#define HY_ERR_RUNTIME 4          /* std::runtime_error / HIP / hiprtc failures */
+
+/* taylor_outcome (include/heyoka/taylor.hpp:142-155). */
+#define HY_OUTCOME_SUCCESS (-4294967296LL - 1)
+#define HY_OUTCOME_STEP_LIMIT (-4294967296LL - 2)
+#define HY_OUTCOME_TIME_LIMIT (-4294967296LL - 3)
+#define HY_OUTCOME_ERR_NF_STATE (-4294967296LL - 4)
+#define HY_OUTCOME_CB_STOP (-4294967296LL - 5)
+
+const char *hy_last_error(void);
+/* HY_ERR_* code of the last failed call on the calling thread (for functions returning handles). */
+int hy_last_error_code(void);
+void hy_free_str(char *);
+/* Library/toolchain information: "heyoka_amd <version>; gfx950; hiprtc <ver>". Caller frees. */
+char *hy_version(void);
+/* Number of visible HIP devices (0 without a GPU). */
+int hy_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Expressions (include/heyoka/expression.hpp:73-118; operators src/expression_ops.cpp:34-91).
+ * Handles are owned by the caller and released with hy_expr_free(). Functions never consume
+ * their arguments.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct hy_expr_s *hy_expr;
+
+hy_expr hy_expr_var(const char *name);    /* expression{variable{name}}   expression.hpp:73 */
+hy_expr hy_expr_num(double value);        /* expression{number{value}}    number.hpp */
+hy_expr hy_expr_par(uint32_t index);      /* par[index]                   param.hpp */
+hy_expr hy_expr_time(void);               /* heyoka::time                 math/time.hpp */
+hy_expr hy_expr_neg(hy_expr);             /* operator-(e)                 expression_ops.cpp:45-52 */
+hy_expr hy_expr_add(hy_expr, hy_expr);    /* operator+                    expression_ops.cpp:55-62 */
+hy_expr hy_expr_sub(hy_expr, hy_expr);    /* operator-                    expression_ops.cpp:65-72 */
+hy_expr hy_expr_mul(hy_expr, hy_expr);    /* operator*                    expression_ops.cpp:75-82 */
+hy_expr hy_expr_div(hy_expr, hy_expr);    /* operator/                    expression_ops.cpp:85-91 */
+hy_expr hy_expr_pow(hy_expr, hy_expr);    /* pow()                        src/math/pow.cpp:1066 */
+hy_expr hy_expr_sqrt(hy_expr);            /* sqrt()                       src/math/sqrt.cpp:16 */
+hy_expr hy_expr_sin(hy_expr);             /* sin()                        src/math/sin.cpp:406 */
+hy_expr hy_expr_cos(hy_expr);             /* cos()                        src/math/cos.cpp:406 */
+hy_expr hy_expr_exp(hy_expr);             /* exp()                        src/math/exp.cpp */
+hy_expr hy_expr_log(hy_expr);             /* log()                        src/math/log.cpp */
+hy_expr hy_expr_sum(const hy_expr *, size_t n);  /* sum(vector)           src/math/sum.cpp:548 */
+hy_expr hy_expr_prod(const hy_expr *, size_t n); /* prod(vector)          src/math/prod.cpp:913 */
+void hy_expr_free(hy_expr);
+char *hy_expr_str(hy_expr); /* caller frees with hy_free_str() */
+
+/* ------------------------------------------------------------------------------------------------
+ * ODE systems: std::vector<std::pair<expression, expression>> (prime(x) = rhs).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct hy_sys_s *hy_sys;
+
+hy_sys hy_sys_new(void);
+int hy_sys_add(hy_sys, hy_expr lhs, hy_expr rhs); /* prime(lhs) = rhs */
+size_t hy_sys_size(hy_sys);
+void hy_sys_free(hy_sys);
+/* model::nbody(n, kw::masses, kw::Gconst) (include/heyoka/model/nbody.hpp:73-78, src/model/nbody.cpp:53-174).
+ * masses == NULL -> all masses equal to 1 (n_masses ignored). */
+hy_sys hy_model_nbody(uint32_t n, const double *masses, size_t n_masses, double Gconst);
+/* model::pendulum(kw::gconst, kw::length) (src/model/pendulum.cpp:23-28). */
+hy_sys hy_model_pendulum(double gconst, double length);
+/* taylor_decompose_sys() (src/taylor_01.cpp:848-1008): one line per entry of the decomposition,
+ * "u_i = ..." textual form with hidden dependencies. Caller frees with hy_free_str(). */
+char *hy_sys_decomposition_str(hy_sys);
+
+/* ------------------------------------------------------------------------------------------------
+ * taylor_adaptive_batch<double> (include/heyoka/taylor.hpp:781-1121).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct hy_tab_s *hy_tab;
+
+/* Keyword arguments of the constructor (taylor.hpp:814-821, :905-941). */
+typedef struct {
+    double tol;            /* kw::tol; 0 -> default (machine epsilon) */
+    int high_accuracy;     /* kw::high_accuracy */
+    int compact_mode;      /* kw::compact_mode (accepted; code generation mode is chosen internally) */
+    int parallel_mode;     /* kw::parallel_mode (validated like the reference, otherwise ignored) */
+    const double *pars;    /* kw::pars, n_pars values (NULL -> zeros) */
+    size_t n_pars;
+    const double *time;    /* kw::time: NULL -> 0; n_time == 1 -> scalar splat; else batch_size values */
+    size_t n_time;
+    int device;            /* HIP device ordinal (MI355X extension) */
+} hy_tab_config;
+
+/* Constructor (taylor.hpp:905-941 -> finalise_ctor_impl(), src/taylor_adaptive_batch.cpp:78-427).
+ * state: n_state = n_eq * batch_size values, or n_state == 0 for a zero-initialised state.
+ * Performs decomposition, HIP code generation and hiprtc compilation; does not need a GPU. */
+hy_tab hy_tab_create(hy_sys sys, const double *state, size_t n_state, uint32_t batch_size, const hy_tab_config *cfg);
+hy_tab hy_tab_copy(hy_tab);  /* copy constructor (taylor.hpp:943) */
+void hy_tab_free(hy_tab);
+
+/* Getters (taylor.hpp:951-1029). */
+uint32_t hy_tab_get_batch_size(hy_tab);
+uint32_t hy_tab_get_order(hy_tab);
+uint32_t hy_tab_get_dim(hy_tab);
+uint32_t hy_tab_get_n_pars(hy_tab);   /* number of runtime parameters per system */
+uint32_t hy_tab_get_n_uvars(hy_tab);  /* size of the decomposition minus n_eq */
+double hy_tab_get_tol(hy_tab);
+int hy_tab_get_high_accuracy(hy_tab);
+int hy_tab_get_compact_mode(hy_tab);
+double hy_tab_get_compile_seconds(hy_tab);
+char *hy_tab_get_hip_source(hy_tab);  /* generated HIP module (cf. llvm_state::get_ir()); caller frees */
+char *hy_tab_get_decomposition_str(hy_tab);
+
+int hy_tab_get_state(hy_tab, double *out);                 /* get_state()        n_eq * batch_size */
+int hy_tab_set_state(hy_tab, const double *in);            /* writes through get_state_data() */
+int hy_tab_get_pars(hy_tab, double *out);                  /* get_pars() */
+int hy_tab_set_pars(hy_tab, const double *in);             /* writes through get_pars_data() */
+int hy_tab_get_dtime(hy_tab, double *hi, double *lo);      /* get_dtime()        batch_size each; lo may be NULL */
+int hy_tab_set_time(hy_tab, const double *t, size_t n);    /* set_time(): n == 1 scalar, else batch_size */
+int hy_tab_set_dtime(hy_tab, const double *hi, const double *lo, size_t n); /* set_dtime() */
+int hy_tab_get_tc(hy_tab, double *out);                    /* get_tc()           n_eq * (order + 1) * batch_size */
+int hy_tab_get_last_h(hy_tab, double *out);                /* get_last_h() */
+/* update_d_output(t, rel_time) (src/taylor_adaptive_batch.cpp:2251-2327): n == 1 scalar, else batch_size. */
+int hy_tab_update_d_output(hy_tab, const double *t, size_t n, int rel_time, double *out);
+
+/* step() / step_backward() / step(max_delta_ts) (taylor.hpp:1001-1003; step_impl()
+ * src/taylor_adaptive_batch.cpp:632-727). */
+int hy_tab_step(hy_tab, int write_tc);
+int hy_tab_step_backward(hy_tab, int write_tc);
+int hy_tab_step_limited(hy_tab, const double *max_delta_ts, size_t n, int write_tc);
+int hy_tab_get_step_res(hy_tab, int64_t *outcome, double *h); /* get_step_res() */
+
+/* Step callback: bool(taylor_adaptive_batch &) (include/heyoka/step_callback.hpp:59-62).
+ * Return non-zero to continue, 0 to stop (outcome cb_stop). */
+typedef int (*hy_step_callback)(hy_tab, void *user_data);
+
+/* propagate_until() / propagate_for() (taylor.hpp:1064-1107; propagate_until_impl()
+ * src/taylor_adaptive_batch.cpp:1137-1534, propagate_for_impl() :1082-1118).
+ *  ts / n_ts ............ final times (durations for propagate_for): n_ts == 1 scalar, else batch_size
+ *  max_steps ............ kw::max_steps (0 = unlimited)
+ *  max_delta_ts / n_mdt . kw::max_delta_t: n_mdt == 0 none, 1 scalar, else batch_size
+ *  cb ................... kw::callback (NULL = none). Without a callback the whole propagation runs
+ *                         device-resident in one kernel launch; with a callback the reference's
+ *                         lock-step loop is used (one launch per step, callback on the host).
+ *  write_tc, c_output ... kw::write_tc, kw::c_output (c_output != 0 -> HY_ERR_NOT_IMPLEMENTED) */
+int hy_tab_propagate_until(hy_tab, const double *ts, size_t n_ts, uint64_t max_steps, const double *max_delta_ts,
+                           size_t n_mdt, hy_step_callback cb, void *cb_data, int write_tc, int c_output);
+int hy_tab_propagate_for(hy_tab, const double *dts, size_t n_dts, uint64_t max_steps, const double *max_delta_ts,
+                         size_t n_mdt, hy_step_callback cb, void *cb_data, int write_tc, int c_output);
+/* propagate_grid() (taylor.hpp:1113-1119; propagate_grid_impl() src/taylor_adaptive_batch.cpp:1546-2055).
+ * grid: n_grid * batch_size values laid out grid[point * batch_size + lane];
+ * out: n_grid * n_eq * batch_size values (NaN where not reached). */
+int hy_tab_propagate_grid(hy_tab, const double *grid, size_t n_grid, uint64_t max_steps, const double *max_delta_ts,
+                          size_t n_mdt, hy_step_callback cb, void *cb_data, double *out);
+/* get_propagate_res(): (outcome, min |h|, max |h|, n_steps) per lane. */
+int hy_tab_get_propagate_res(hy_tab, int64_t *outcome, double *min_h, double *max_h, uint64_t *n_steps);
+
+/* ------------------------------------------------------------------------------------------------
+ * Device-resident access (MI355X extension; the reference has no device boundary).
+ * --------------------------------------------------------------------------------------------- */
+#define HY_BUF_STATE 0   /* double[n_eq * batch_size] */
+#define HY_BUF_PARS 1    /* double[n_pars * batch_size] */
+#define HY_BUF_TIME_HI 2 /* double[batch_size] */
+#define HY_BUF_TIME_LO 3 /* double[batch_size] */
+#define HY_BUF_TC 4      /* double[n_eq * (order + 1) * batch_size] */
+#define HY_BUF_N_STEPS 5 /* uint64[batch_size]: step counters of the last propagate_*() */
+#define HY_BUF_OUTCOME 6 /* int64[batch_size]: taylor_outcome of the last step()/propagate_*() */
+#define HY_BUF_LAST_H 7  /* double[batch_size] */
+/* Device pointer of one of the SoA arrays of the integrator (uploads pending host changes first). */
+void *hy_tab_device_ptr(hy_tab, int which);
+/* Tell the integrator that the caller wrote to the device arrays. */
+int hy_tab_mark_device_modified(hy_tab);
+/* Run all subsequent kernels/copies on the given hipStream_t (NULL = default stream). */
+int hy_tab_set_stream(hy_tab, void *hip_stream);
+int hy_tab_synchronize(hy_tab);
+/* Sum over lanes of the step counters of the last propagate_*() call. */
+uint64_t hy_tab_get_last_total_steps(hy_tab);
+
+/* Stepper function-pointer ABI of the reference
+ * (`void step(T *state, const T *pars, const T *time, T *h, T *tc)`,
+ *  include/heyoka/detail/ta_jit_data.hpp:35-44, looked up at src/taylor_adaptive_batch.cpp:2391-2393)
+ * on caller-owned device buffers holding n_systems systems:
+ *   d_state rw [n_eq * n], d_pars [n_pars * n] (may be NULL if no parameters), d_time [n] (hi part),
+ *   d_h in: signed max step (+-inf allowed), out: step taken [n], d_tc nullable [n_eq * (order+1) * n].
+ * No error channel for numerical failures (non-finite results are the caller's to detect). */
+int hy_tab_raw_step(hy_tab, double *d_state, const double *d_pars, const double *d_time, double *d_h, double *d_tc,
+                    uint64_t n_systems);
+
+/* ------------------------------------------------------------------------------------------------
+ * ensemble_propagate_until_batch() (include/heyoka/ensemble_propagate.hpp:222-237,
+ * src/ensemble_propagate.cpp:193-222): n_iter independent propagations of copies of `ta`.
+ *  gen(ta_copy, iteration, user_data): sets the initial conditions of the copy (on the host),
+ *      returns 0 on success. Invoked serially on the calling thread.
+ *  Iterations are distributed round-robin over `n_devices` HIP devices (0 = all visible), one host
+ *  thread per device. The propagated copies are returned in out[0..n_iter) (caller frees each with
+ *  hy_tab_free()). */
+typedef int (*hy_ensemble_gen)(hy_tab ta_copy, size_t iteration, void *user_data);
+int hy_ensemble_propagate_until_batch(hy_tab ta, double t, size_t n_iter, hy_ensemble_gen gen, void *gen_data,
+                                      uint64_t max_steps, int n_devices, hy_tab *out);
+int hy_ensemble_propagate_for_batch(hy_tab ta, double delta_t, size_t n_iter, hy_ensemble_gen gen, void *gen_data,
+                                    uint64_t max_steps, int n_devices, hy_tab *out);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

@@ -1,0 +1,95 @@
+"""C-ABI library: loads, exports every symbol declared in include/heyoka_amd.h, and its host-side
+logic (construction, validation, code generation, hiprtc compilation for gfx950) works without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import heyoka_amd as hy
+from heyoka_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "heyoka_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(hy_[a-z_0-9]+)\s*\(", txt)) - {"hy_step_callback", "hy_ensemble_gen"})
+
+
+def test_every_declared_symbol_is_exported():
+    syms = header_symbols()
+    assert len(syms) > 60
+    declared_in_py = {s[0] for s in _lib.SIGNATURES}
+    for s in syms:
+        assert hasattr(_lib.lib, s), "missing export: " + s
+        assert s in declared_in_py, "ctypes signature missing for " + s
+    assert declared_in_py <= set(syms)
+
+
+def test_version_and_no_gpu_behaviour():
+    assert "gfx950" in hy.version()
+    if hy.device_count() == 0:
+        x, v = hy.make_vars("x", "v")
+        ta = hy.taylor_adaptive_batch([(x, v), (v, -9.8 * hy.sin(x))], [[0.05] * 2, [0.025] * 2], 2)
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            ta.step()
+
+
+def test_construction_getters_and_codegen():
+    x, v = hy.make_vars("x", "v")
+    sys = [(x, v), (v, hy.cos(hy.time) - hy.par[0] * v - hy.sin(x))]
+    ta = hy.taylor_adaptive_batch(sys, [[0.01, 0.02, 0.03, 0.04], [1.85, 1.86, 1.87, 1.88]], 4,
+                                  pars=[0.10, 0.11, 0.12, 0.13], opt_level=3, fast_math=False)
+    assert ta.order == 20 and ta.dim == 2 and ta.batch_size == 4 and ta.n_pars == 1
+    assert ta.tol == np.finfo(float).eps and not ta.high_accuracy and not ta.compact_mode
+    assert np.array_equal(ta.state, [[0.01, 0.02, 0.03, 0.04], [1.85, 1.86, 1.87, 1.88]])
+    assert np.array_equal(ta.pars, [[0.10, 0.11, 0.12, 0.13]])
+    assert np.array_equal(ta.time, np.zeros(4))
+    src = ta.hip_source
+    assert "extern \"C\" __global__" in src and "hy_taylor" in src and "hy_dout" in src
+    assert ta.compile_seconds > 0  # hiprtc produced a gfx950 code object
+    # Orders from tolerances (reference: taylor_order_from_tol, taylor_common.hpp:165-191).
+    for tol, order in ((1.0, 2), (0.5, 2), (0.1, 3), (1e-9, 12), (1e-15, 19)):
+        t2 = hy.taylor_adaptive_batch([(x, v), (v, -x)], [[0.0], [1.0]], 1, tol=tol)
+        assert t2.order == order
+    # Zero-initialised state, scalar / vector time.
+    t3 = hy.taylor_adaptive_batch([(x, v), (v, -x)], None, 3, time=2.5)
+    assert np.array_equal(t3.state, np.zeros((2, 3))) and np.array_equal(t3.time, [2.5] * 3)
+    t3.time = [1.0, 2.0, 3.0]
+    assert np.array_equal(t3.time, [1.0, 2.0, 3.0])
+    t3.dtime = ([1.0, 2.0, 3.0], [1e-20, 0.0, -1e-20])
+    assert np.array_equal(t3.dtime[1], [1e-20, 0.0, -1e-20])
+    t3.state = np.arange(6.0).reshape(2, 3)
+    c = t3.copy()
+    assert np.array_equal(c.state, np.arange(6.0).reshape(2, 3)) and np.array_equal(c.time, [1.0, 2.0, 3.0])
+
+
+def test_constructor_error_messages():
+    """Messages checked verbatim by the reference's tests (test/taylor_adaptive_batch.cpp:955-1016)."""
+    x, v = hy.make_vars("x", "v")
+    sys = [(x, v), (v, -x)]
+    with pytest.raises(ValueError, match="The batch size in an adaptive Taylor integrator cannot be zero"):
+        hy.taylor_adaptive_batch(sys, [0.0, 1.0], 0)
+    with pytest.raises(ValueError, match=r"the state vector has a size of 3, which is not a multiple of the batch size \(2\)"):
+        hy.taylor_adaptive_batch(sys, [0.0, 1.0, 2.0], 2)
+    with pytest.raises(ValueError, match="the state vector has a dimension of 1 and a batch size of 2, while the number of equations is 2"):
+        hy.taylor_adaptive_batch(sys, [0.0, 1.0], 2)
+    with pytest.raises(ValueError, match=r"the time vector has a size of 3, which is not equal to the batch size \(2\)"):
+        hy.taylor_adaptive_batch(sys, [0.0, 1.0, 2.0, 3.0], 2, time=[0.0, 1.0, 2.0])
+    with pytest.raises(ValueError, match="The tolerance in an adaptive Taylor integrator must be finite and positive, but it is -1 instead"):
+        hy.taylor_adaptive_batch(sys, [0.0, 1.0], 1, tol=-1.0)
+    with pytest.raises(ValueError, match="Parallel mode can be activated only in conjunction with compact mode"):
+        hy.taylor_adaptive_batch(sys, [0.0, 1.0], 1, parallel_mode=True)
+    with pytest.raises(ValueError, match=r"3 parameter value\(s\) were passed, but the ODE system contains 1 parameter\(s\) \(in batches of 2\)"):
+        hy.taylor_adaptive_batch([(x, v), (v, -hy.par[0] * x)], [0.0, 0.0, 1.0, 1.0], 2, pars=[1.0, 2.0, 3.0])
+
+
+def test_codegen_compiles_for_benchmark_dags():
+    """HIP generation + hiprtc compilation (no GPU needed) for the small benchmark DAGs."""
+    ta = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), None, 64)
+    assert ta.n_uvars == 21 and ta.dim == 12
+    ta = hy.taylor_adaptive_batch(hy.model.pendulum(gconst=9.8), None, 64, high_accuracy=True)
+    assert ta.n_uvars == 5

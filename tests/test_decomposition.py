@@ -1,0 +1,104 @@
+"""Product host logic (C++ expression system + decomposition, through the C ABI) against the
+independent Python restatement in oracle/heyoka_oracle.py and the reference's structure pins."""
+from collections import Counter
+
+import numpy as np
+import pytest
+
+import heyoka_amd as hy
+import heyoka_oracle as ho
+
+M = [1.00000597682, 1 / 1047.355, 1 / 3501.6, 1 / 22869.0, 1 / 19314.0, 7.4074074e-09]
+G = 0.01720209895 * 0.01720209895 * 365 * 365
+
+
+def kinds(lines, n_eq):
+    return Counter(l.split("(")[0] for l in lines[n_eq:-n_eq])
+
+
+def test_outer_ss_pins(golden):
+    g = golden["outer_ss_decomposition"]
+    dc = hy.taylor_decompose_sys(hy.model.nbody(6, masses=M, Gconst=G))
+    assert len(dc) == g["size"]
+    c = kinds(dc, 36)
+    assert (c["sum_sq"], c["sum"], c["sub"]) == (g["sum_sq"], g["sum"], g["sub"])
+    assert c["pow"] == 15 and c["prod"] == 105
+
+
+@pytest.mark.parametrize(
+    "name,prod_sys,ora_sys",
+    [
+        ("outer_ss", lambda: hy.model.nbody(6, masses=M, Gconst=G), lambda: ho.nbody(6, masses=M, Gconst=G)),
+        ("two_body", lambda: hy.model.nbody(2, masses=[1.0, 0.0]), lambda: ho.nbody(2, masses=[1.0, 0.0])),
+        ("nbody3", lambda: hy.model.nbody(3), lambda: ho.nbody(3)),
+        ("nbody9_massless", lambda: hy.model.nbody(9, masses=[1.0, 2.0, 0.5]), lambda: ho.nbody(9, masses=[1.0, 2.0, 0.5])),
+        ("pendulum", lambda: hy.model.pendulum(gconst=9.8), lambda: ho.pendulum(gconst=9.8)),
+    ],
+)
+def test_decomposition_identical_to_oracle(name, prod_sys, ora_sys):
+    got = hy.taylor_decompose_sys(prod_sys())
+    exp = ho.dc_to_strings(ho.taylor_decompose_sys(ora_sys()))
+    assert got == exp
+
+
+def test_decomposition_nbody64_matches_oracle():
+    got = hy.taylor_decompose_sys(hy.model.nbody(64))
+    exp = ho.dc_to_strings(ho.taylor_decompose_sys(ho.nbody(64)))
+    assert len(got) == 18663 + 384
+    assert got == exp
+
+
+def test_expression_rules_match_oracle():
+    """Canonicalisation / constant folding (reference: src/expression_ops.cpp:45-91,
+    src/math/prod.cpp:913-973, src/math/sum.cpp:548-601, src/math/pow.cpp:1024-1062)."""
+    x, y, z = hy.make_vars("x", "y", "z")
+    ox, oy, oz = ho.var("x"), ho.var("y"), ho.var("z")
+    cases = [
+        (lambda: x - y, lambda: ox - oy),
+        (lambda: x / y, lambda: ox / oy),
+        (lambda: 2.0 * x * 3.0, lambda: 2.0 * ox * 3.0),
+        (lambda: hy.prod([x, 2.0, y, 0.5]), lambda: ho.prod([ox, 2.0, oy, 0.5])),
+        (lambda: hy.prod([x, 0.0, y]), lambda: ho.prod([ox, 0.0, oy])),
+        (lambda: hy.sum([x, 1.0, y, -1.0]), lambda: ho.sum_([ox, 1.0, oy, -1.0])),
+        (lambda: hy.pow(x, 0.0), lambda: ho.pow_(ox, 0.0)),
+        (lambda: hy.pow(x, 1.0), lambda: ho.pow_(ox, 1.0)),
+        (lambda: hy.pow(hy.expression(2.0), 3.0), lambda: ho.pow_(ho.num(2.0), 3.0)),
+        (lambda: -(x * y), lambda: -(ox * oy)),
+        (lambda: hy.sin(hy.expression(0.5)), lambda: ho.sin(0.5)),
+        (lambda: hy.sqrt(x + z), lambda: ho.sqrt(ox + oz)),
+    ]
+    for p, o in cases:
+        assert repr(p()) == ho._ex_str(o())
+
+
+def test_rewrites_and_sincos_pairs():
+    x, v = hy.make_vars("x", "v")
+    ox, ov = ho.var("x"), ho.var("v")
+    sysp = [(x, v + hy.cos(x) * hy.sin(x)), (v, hy.exp(x) / v - hy.log(v) + hy.pow(x, -1.0) * hy.pow(v, -1.0) * x)]
+    syso = [(ox, ov + ho.cos(ox) * ho.sin(ox)),
+            (ov, ho.exp(ox) / ov - ho.log(ov) + ho.pow_(ox, -1.0) * ho.pow_(ov, -1.0) * ox)]
+    got = hy.taylor_decompose_sys(sysp)
+    assert got == ho.dc_to_strings(ho.taylor_decompose_sys(syso))
+    assert any(l.startswith("div(") for l in got)
+    # Long sums are split in groups of 8, sums of squares are recognised.
+    vs = hy.make_vars(*["x%d" % i for i in range(20)])
+    ovs = [ho.var("x%d" % i) for i in range(20)]
+    sysp = [(vs[i], hy.sum([vv * vv for vv in vs]) + hy.sum(vs)) for i in range(20)]
+    syso = [(ovs[i], ho.sum_([vv * vv for vv in ovs]) + ho.sum_(ovs)) for i in range(20)]
+    got = hy.taylor_decompose_sys(sysp)
+    assert got == ho.dc_to_strings(ho.taylor_decompose_sys(syso))
+    assert max(l.count("u_") for l in got if l.startswith("sum(")) <= 8
+
+
+def test_validate_ode_sys_messages():
+    x, v = hy.make_vars("x", "v")
+    with pytest.raises(ValueError, match="Cannot integrate a system of zero equations"):
+        hy.taylor_decompose_sys([])
+    with pytest.raises(ValueError, match="appears in the left-hand side twice"):
+        hy.taylor_decompose_sys([(x, v), (x, v)])
+    with pytest.raises(ValueError, match="appears in the right-hand side but not in the left-hand side"):
+        hy.taylor_decompose_sys([(x, v)])
+    with pytest.raises(ValueError, match="which is not a variable"):
+        hy.taylor_decompose_sys([(x + v, v), (v, x)])
+    with pytest.raises(ValueError, match="at least 2 bodies are needed"):
+        hy.model.nbody(1)

@@ -1,0 +1,317 @@
+"""Parity of the HIP path (through the C ABI) against the oracle on the same seeded inputs.
+
+Tolerances follow the reference's own tests: single step from identical
+state - h within 1e4 eps, state within 1e5 eps (test/two_body_batch.cpp:118-150); after a
+propagation - 1e3..1e5 eps depending on the number of steps (test/taylor_adaptive_batch.cpp:105-146)."""
+import numpy as np
+import pytest
+
+import heyoka_amd as hy
+import heyoka_oracle as ho
+from heyoka_amd import configs
+from conftest import EPS, sig_close
+
+pytestmark = pytest.mark.gpu
+
+OC = hy.taylor_outcome
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))
+
+
+def pendulum_p():
+    x, v = hy.make_vars("x", "v")
+    return [(x, v), (v, -9.8 * hy.sin(x))]
+
+
+def pendulum_o():
+    x, v = ho.var("x"), ho.var("v")
+    return [(x, v), (v, -9.8 * ho.sin(x))]
+
+
+def forced_p():
+    x, v = hy.make_vars("x", "v")
+    return [(x, v), (v, hy.cos(hy.time) - hy.par[0] * v - hy.sin(x))]
+
+
+def forced_o():
+    x, v = ho.var("x"), ho.var("v")
+    return [(x, v), (v, ho.cos(ho.TIME) - ho.par(0) * v - ho.sin(x))]
+
+
+def test_device_is_mi355x():
+    assert hy.device_count() >= 1
+
+
+def test_pendulum_golden_first_step(golden):
+    g = golden["pendulum_scalar"]
+    ta = hy.taylor_adaptive_batch(pendulum_p(), [[g["ic"][0]], [g["ic"][1]]], 1)
+    ta.step()
+    (oc, h), = ta.step_res
+    assert oc == OC.success
+    assert abs(h - g["step1"]["h"]) <= 1e2 * EPS
+    assert ta.time[0] == h
+    assert rel_err(ta.state[:, 0], g["step1"]["state"]) <= 1e3 * EPS
+    ta.step_backward()
+    assert sig_close(ta.step_res[0][1], g["step_backward_h_6digits"])
+
+
+def test_batch_mode_tutorial_golden(golden):
+    """The full doc/tut_batch_mode.rst session on the GPU (config 1 of BASELINE.json)."""
+    g = golden["batch_mode_forced_pendulum"]
+    ta = hy.taylor_adaptive_batch(forced_p(), [g["x0"], g["v0"]], 4, pars=g["alpha"])
+    ta.step()
+    res = ta.step_res
+    assert all(oc == OC.success for oc, _ in res)
+    assert sig_close([h for _, h in res], g["step1"]["h"])
+    assert sig_close(ta.state[0], g["step1"]["x"]) and sig_close(ta.state[1], g["step1"]["v"], 7)
+    assert sig_close(ta.time, g["step1"]["h"])
+
+    ta.step(g["step_clamped"]["max_delta_t"])
+    res = ta.step_res
+    assert all(oc == OC.time_limit for oc, _ in res)
+    assert [h for _, h in res] == g["step_clamped"]["max_delta_t"]
+    assert sig_close(ta.state[0], g["step_clamped"]["x"]) and sig_close(ta.state[1], g["step_clamped"]["v"])
+
+    pf = g["propagate_for"]
+    ta.propagate_for(pf["dt"])
+    res = ta.propagate_res
+    assert [r[3] for r in res] == pf["steps"]
+    assert all(r[0] == OC.time_limit for r in res)
+    assert sig_close([r[1] for r in res], pf["min_h"]) and sig_close([r[2] for r in res], pf["max_h"])
+    assert sig_close(ta.state[0], pf["x"]) and sig_close(ta.state[1], pf["v"])
+    assert sig_close(ta.time, pf["time"], 7)
+
+    pu = g["propagate_until"]
+    ta.propagate_until(pu["t"])
+    res = ta.propagate_res
+    assert [r[3] for r in res] == pu["steps"]
+    assert sig_close([r[1] for r in res], pu["min_h"]) and sig_close([r[2] for r in res], pu["max_h"])
+    assert sig_close(ta.state[0], pu["x"]) and sig_close(ta.state[1], pu["v"], 5)
+    assert list(ta.time) == pu["t"]
+
+    ta.step(write_tc=True)
+    tc = ta.tc
+    assert sig_close(tc[0], g["step_wtc_tc_x"], 6) and sig_close(tc[1], g["step_wtc_tc_v"], 6)
+    d = ta.update_d_output(g["dense_output"]["t"])
+    assert sig_close(d[0], g["dense_output"]["x"]) and sig_close(d[1], g["dense_output"]["v"])
+
+
+@pytest.mark.parametrize("ha", [False, True])
+def test_single_step_parity_forced_pendulum(ha):
+    rng = np.random.RandomState(3)
+    n = 1000
+    st = np.stack([rng.uniform(-1, 1, n), rng.uniform(-2, 2, n)])
+    pars = rng.uniform(0.05, 0.2, n)
+    t0 = rng.uniform(0, 10, n)
+    ta = hy.taylor_adaptive_batch(forced_p(), st, n, pars=pars, time=t0, high_accuracy=ha)
+    ora = ho.OracleIntegrator(forced_o(), st, n, pars=pars, time=t0, high_accuracy=ha)
+    ta.step(write_tc=True)
+    ora.step(wtc=True)
+    h_g = np.array([h for _, h in ta.step_res])
+    h_o = np.array([h for _, h in ora.step_res])
+    assert np.max(np.abs(h_g - h_o) / np.abs(h_o)) <= 1e4 * EPS
+    assert rel_err(ta.state, ora.state.reshape(2, n)) <= 1e5 * EPS
+    assert [oc for oc, _ in ta.step_res] == [oc for oc, _ in ora.step_res]
+    hi, lo = ta.dtime
+    assert rel_err(hi, ora.time_hi) <= 1e4 * EPS
+    tc_o = ora.tc.reshape(2, ora.order + 1, n)
+    scale = np.max(np.abs(tc_o), axis=2, keepdims=True) + 1e-300
+    assert np.max(np.abs(ta.tc - tc_o) / scale) <= 1e5 * EPS
+
+
+def test_two_body_stepwise_and_kepler_invariants():
+    """cf. test/two_body_batch.cpp:53-200: 200 steps, each compared with a re-run from the same
+    pre-step state; orbital energy / angular momentum conserved."""
+    n = 64
+    st = configs.two_body_state(n, perturb=0.05, seed=11)
+    sys_p, sys_o = hy.model.nbody(2, masses=[1.0, 0.0]), ho.nbody(2, masses=[1.0, 0.0])
+    ta = hy.taylor_adaptive_batch(sys_p, st, n)
+    s0 = ta.state
+
+    def invariants(s):
+        r = s[6:9] - s[0:3]
+        v = s[9:12] - s[3:6]
+        en = 0.5 * (v * v).sum(0) - 1.0 / np.sqrt((r * r).sum(0))
+        lz = r[0] * v[1] - r[1] * v[0]
+        return en, lz
+
+    e0, l0 = invariants(s0)
+    for _ in range(200):
+        pre = ta.state
+        pre_t = ta.time
+        ora = ho.OracleIntegrator(sys_o, pre, n, time=pre_t)
+        ta.step()
+        ora.step()
+        h_g = np.array([h for _, h in ta.step_res])
+        h_o = np.array([h for _, h in ora.step_res])
+        assert np.max(np.abs(h_g - h_o) / np.abs(h_o)) <= 1e4 * EPS
+        assert rel_err(ta.state, ora.state.reshape(12, n)) <= 1e5 * EPS
+    e1, l1 = invariants(ta.state)
+    assert np.max(np.abs((e1 - e0) / e0)) <= 1e4 * EPS
+    assert np.max(np.abs((l1 - l0) / l0)) <= 1e4 * EPS
+
+
+@pytest.mark.parametrize("ha", [False, True])
+def test_propagate_until_parity_two_body(ha):
+    n = 4096
+    st = configs.two_body_state(n, perturb=1e-2, seed=5)
+    ta = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), st, n, high_accuracy=ha)
+    ta.propagate_until(50.0)
+    oc, mn, mx, ns = ta.propagate_res_arrays()
+    ref, thi, tlo, oc_o, mn_o, mx_o, ns_o, tot = ho.ensemble_propagate_until(
+        ho.nbody(2, masses=[1.0, 0.0]), st, n, 8, 50.0, high_accuracy=ha)
+    assert np.all(oc == int(OC.time_limit)) and np.all(oc_o == ho.OC_TIME_LIMIT)
+    assert np.all(ta.time == 50.0)
+    # Step counts can differ by +-1 on rare lanes (h differs in the last ulps).
+    assert np.max(np.abs(ns.astype(np.int64) - ns_o)) <= 1
+    assert ta.last_total_steps == int(ns.sum())
+    assert rel_err(ta.state, ref.reshape(12, n)) <= 2e4 * EPS
+    assert np.max(np.abs(mn - mn_o) / mn_o) <= 1e-6 and np.max(np.abs(mx - mx_o) / mx_o) <= 1e-6
+
+
+def test_propagate_backward_limits_and_max_steps():
+    n = 256
+    rng = np.random.RandomState(9)
+    st = np.stack([rng.uniform(-0.5, 0.5, n), rng.uniform(-0.5, 0.5, n)])
+    ta = hy.taylor_adaptive_batch(pendulum_p(), st, n)
+    ora = ho.OracleIntegrator(pendulum_o(), st, n)
+    # Per-lane final times, forward and backward, with a max_delta_t clamp.
+    tf = rng.uniform(-5, 5, n)
+    ta.propagate_until(tf, max_delta_t=0.11)
+    ora.propagate_until(tf, max_delta_t=0.11)
+    res_g, res_o = ta.propagate_res, ora.prop_res
+    assert [r[0] for r in res_g] == [r[0] for r in res_o]
+    assert max(abs(a[3] - b[3]) for a, b in zip(res_g, res_o)) <= 1
+    assert np.array_equal(ta.time, tf)
+    assert rel_err(ta.state, ora.state.reshape(2, n)) <= 1e4 * EPS
+    # max_steps -> step_limit for lanes that are not done.
+    ta.propagate_until(tf + 100.0, max_steps=3)
+    res = ta.propagate_res
+    assert all(r[0] == OC.step_limit and r[3] == 3 for r in res)
+    # Zero-length propagation: time_limit, zero steps.
+    t_now = ta.time
+    ta.propagate_until(t_now)
+    assert all(r[0] == OC.time_limit and r[3] == 0 for r in ta.propagate_res)
+
+
+def test_callback_lockstep_matches_reference_loop():
+    n = 8
+    rng = np.random.RandomState(1)
+    st = np.stack([rng.uniform(-0.5, 0.5, n), rng.uniform(-0.5, 0.5, n)])
+    ta = hy.taylor_adaptive_batch(pendulum_p(), st, n)
+    ora = ho.OracleIntegrator(pendulum_o(), st, n)
+    calls = []
+
+    def cb(t):
+        calls.append(t.time.copy())
+        return True
+
+    ta.propagate_until(3.0, callback=cb)
+    ora.propagate_until(3.0)
+    assert [r[0] for r in ta.propagate_res] == [r[0] for r in ora.prop_res]
+    assert [r[3] for r in ta.propagate_res] == [r[3] for r in ora.prop_res]
+    # One callback per lock-step iteration = max step count over the batch.
+    assert len(calls) == max(r[3] for r in ora.prop_res)
+    assert rel_err(ta.state, ora.state.reshape(2, n)) <= 1e4 * EPS
+    # cb returning False -> cb_stop for all lanes after one iteration.
+    ta.propagate_until(6.0, callback=lambda t: False)
+    assert all(r[0] == OC.cb_stop for r in ta.propagate_res)
+
+
+def test_nonfinite_state_is_reported_per_lane():
+    x, v = hy.make_vars("x", "v")
+    # x' = x^2 blows up in finite time for x0 > 0 (t* = 1/x0): lanes 0/1 explode before t = 3.
+    sys = [(x, x * x), (v, -v)]
+    st = [[1.0, 0.5, -1.0, 0.0], [1.0, 1.0, 1.0, 1.0]]
+    ta = hy.taylor_adaptive_batch(sys, st, 4)
+    ta.propagate_until(3.0, max_steps=20000)
+    res = ta.propagate_res
+    assert res[2][0] == OC.time_limit and res[3][0] == OC.time_limit
+    assert res[0][0] in (OC.err_nf_state, OC.step_limit) and res[1][0] in (OC.err_nf_state, OC.step_limit)
+
+
+def test_outer_ss_step_selector_identity_and_energy(outer_ss_golden):
+    """test/timestep_check.cpp:25-95 (h reproduces Jorba's formula from the TCs) and
+    test/model_nbody.cpp:112-118 (energy conserved after propagate_until(100))."""
+    n = 128
+    st = configs.outer_ss_state(n, perturb=1e-10, seed=42)
+    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    ta = hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True)
+    ora = ho.OracleIntegrator(ho.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True)
+    p = ta.order
+    for _ in range(3):
+        ta.step(write_tc=True)
+        ora.step(wtc=True)
+        tc = ta.tc
+        m0 = np.max(np.abs(tc[:, 0, :]), axis=0)
+        mp = np.max(np.abs(tc[:, p, :]), axis=0)
+        mp1 = np.max(np.abs(tc[:, p - 1, :]), axis=0)
+        num = np.where(m0 <= 1, 1.0, m0)
+        rho = np.minimum((num / mp) ** (1.0 / p), (num / mp1) ** (1.0 / (p - 1)))
+        h_formula = rho * np.exp(-0.7 / (p - 1)) / np.e ** 2
+        h_g = ta.last_h
+        assert np.max(np.abs(h_g - h_formula) / h_formula) <= 100 * EPS
+        h_o = np.array([h for _, h in ora.step_res])
+        assert np.max(np.abs(h_g - h_o) / h_o) <= 1e4 * EPS
+        assert rel_err(ta.state, ora.state.reshape(36, n)) <= 1e5 * EPS
+    e0 = configs.nbody_energy(st, M, G)
+    ta.propagate_until(100.0)
+    assert all(r[0] == OC.time_limit for r in ta.propagate_res)
+    e1 = configs.nbody_energy(ta.state, M, G)
+    assert np.max(np.abs((e1 - e0) / e0)) <= 100 * EPS
+
+
+def test_raw_step_abi():
+    import torch
+
+    n = 512
+    st = configs.two_body_state(n, perturb=1e-2, seed=2)
+    ta = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), st, n)
+    ora = ho.OracleIntegrator(ho.nbody(2, masses=[1.0, 0.0]), st, n)
+    dev = torch.device("cuda:0")
+    d_state = torch.tensor(st, device=dev, dtype=torch.float64).contiguous()
+    d_time = torch.zeros(n, device=dev, dtype=torch.float64)
+    d_h = torch.full((n,), float("inf"), device=dev, dtype=torch.float64)
+    d_tc = torch.zeros((12, ta.order + 1, n), device=dev, dtype=torch.float64)
+    torch.cuda.synchronize()
+    ta.raw_step(d_state.data_ptr(), 0, d_time.data_ptr(), d_h.data_ptr(), d_tc.data_ptr(), n)
+    ora.step(wtc=True)
+    h_o = np.array([h for _, h in ora.step_res])
+    assert np.max(np.abs(d_h.cpu().numpy() - h_o) / h_o) <= 1e4 * EPS
+    assert rel_err(d_state.cpu().numpy(), ora.state.reshape(12, n)) <= 1e5 * EPS
+    assert np.array_equal(d_tc[:, 0, :].cpu().numpy(), st)
+
+
+def test_device_array_views_and_ensemble():
+    import torch
+
+    n = 1024
+    st = configs.two_body_state(n, perturb=1e-2, seed=21)
+    ta = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), None, n)
+    # Write the ICs directly into the device-resident state through a zero-copy torch view.
+    view = torch.as_tensor(ta.device_array("state"), device="cuda:0")
+    view.copy_(torch.tensor(st, dtype=torch.float64))
+    torch.cuda.synchronize()
+    ta.mark_device_modified()
+    ta.propagate_until(5.0)
+    ref, *_ = ho.ensemble_propagate_until(ho.nbody(2, masses=[1.0, 0.0]), st, n, 8, 5.0)
+    assert rel_err(ta.state, ref.reshape(12, n)) <= 1e4 * EPS
+    assert rel_err(view.cpu().numpy(), ref.reshape(12, n)) <= 1e4 * EPS
+
+    # ensemble_propagate_until_batch: bitwise equal to a serial propagate_until on the same object
+    # (test/ensemble_propagate.cpp:419-420).
+    tmpl = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), None, 256)
+    chunks = [st[:, i * 256:(i + 1) * 256] for i in range(4)]
+
+    def gen(tc, i):
+        tc.state = chunks[i]
+
+    out = hy.ensemble_propagate_until_batch(tmpl, 5.0, 4, gen)
+    for i, o in enumerate(out):
+        serial = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), chunks[i], 256)
+        serial.propagate_until(5.0)
+        assert np.array_equal(o.state, serial.state)
+        assert np.array_equal(o.state, ta.state[:, i * 256:(i + 1) * 256])

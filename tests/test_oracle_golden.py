@@ -1,0 +1,142 @@
+"""The oracle (oracle/) against the reference's own published known answers (tests/golden/).
+
+This pins the oracle: the reference cannot be built here, so its tutorial console
+outputs and test literals are the golden vectors."""
+import numpy as np
+import pytest
+
+import heyoka_oracle as ho
+from conftest import sig_close, EPS
+
+
+def pendulum():
+    x, v = ho.var("x"), ho.var("v")
+    return [(x, v), (v, -9.8 * ho.sin(x))]
+
+
+def test_pendulum_first_step_17_digits(golden):
+    g = golden["pendulum_scalar"]
+    ta = ho.OracleIntegrator(pendulum(), g["ic"], 1)
+    assert ta.order == g["order"]
+    (oc, h), = ta.step()
+    assert oc == ho.OC_SUCCESS
+    # Printed with 17 significant digits by the reference: must round-trip to a few ulps
+    # (sin/cos/pow of the host libm are the only unpinned ingredients).
+    assert abs(h - g["step1"]["h"]) <= 4 * EPS * abs(h)
+    assert abs(ta.time_hi[0] - g["step1"]["time"]) <= 4 * EPS
+    assert np.all(np.abs(ta.state - np.array(g["step1"]["state"])) <= 8 * EPS * np.abs(ta.state))
+    (oc, h), = ta.step(backward=True)
+    assert sig_close(h, g["step_backward_h_6digits"])
+
+
+def test_pendulum_propagate_sequence(golden):
+    g = golden["pendulum_scalar"]
+    ta = ho.OracleIntegrator(pendulum(), g["ic"], 1)
+    for key, call in (("propagate_for_5", lambda: ta.propagate_for(5.0)),
+                      ("then_propagate_until_20", lambda: ta.propagate_until(20.0)),
+                      ("then_propagate_until_0", lambda: ta.propagate_until(0.0))):
+        (oc, mn, mx, ns), = call()
+        assert oc == ho.OC_TIME_LIMIT
+        assert ns == g[key]["steps"]
+        assert sig_close(mn, g[key]["min_h"]) and sig_close(mx, g[key]["max_h"])
+        assert ta.time_hi[0] == g[key]["time"]
+
+
+def test_readme_pendulum(golden):
+    g = golden["readme_pendulum"]
+    ta = ho.OracleIntegrator(pendulum(), g["ic"], 1)
+    ta.propagate_for(10.0)
+    assert sig_close(ta.state[0], g["propagate_for_10"]["x"])
+    assert sig_close(ta.state[1], g["propagate_for_10"]["v"])
+
+
+def test_ensemble_member_9(golden):
+    g = golden["ensemble_member_9"]
+    ta = ho.OracleIntegrator(pendulum(), g["ic"], 1)
+    (oc, mn, mx, ns), = ta.propagate_until(20.0)
+    e = g["propagate_until_20"]
+    assert oc == ho.OC_TIME_LIMIT and ns == e["steps"]
+    assert sig_close(mn, e["min_h"]) and sig_close(mx, e["max_h"])
+    # 124 steps of accumulated libm-level differences: the printed 17 digits agree to ~1e-13.
+    assert np.all(np.abs(ta.state - np.array(e["state"])) <= 1e-12)
+
+
+def forced(batch=4):
+    x, v = ho.var("x"), ho.var("v")
+    return [(x, v), (v, ho.cos(ho.TIME) - ho.par(0) * v - ho.sin(x))]
+
+
+def test_batch_mode_tutorial(golden):
+    g = golden["batch_mode_forced_pendulum"]
+    ta = ho.OracleIntegrator(forced(), [g["x0"], g["v0"]], 4, pars=g["alpha"])
+    res = ta.step()
+    assert all(oc == ho.OC_SUCCESS for oc, _ in res)
+    assert sig_close([h for _, h in res], g["step1"]["h"])
+    st = ta.state.reshape(2, 4)
+    assert sig_close(st[0], g["step1"]["x"]) and sig_close(st[1], g["step1"]["v"], 7)
+
+    res = ta.step(g["step_clamped"]["max_delta_t"])
+    assert all(oc == ho.OC_TIME_LIMIT for oc, _ in res)
+    assert [h for _, h in res] == g["step_clamped"]["max_delta_t"]
+    st = ta.state.reshape(2, 4)
+    assert sig_close(st[0], g["step_clamped"]["x"]) and sig_close(st[1], g["step_clamped"]["v"])
+    assert sig_close(ta.time_hi, g["step_clamped"]["time"])
+
+    pf = g["propagate_for"]
+    res = ta.propagate_for(pf["dt"])
+    assert [r[3] for r in res] == pf["steps"]
+    assert all(r[0] == ho.OC_TIME_LIMIT for r in res)
+    assert sig_close([r[1] for r in res], pf["min_h"]) and sig_close([r[2] for r in res], pf["max_h"])
+    st = ta.state.reshape(2, 4)
+    assert sig_close(st[0], pf["x"]) and sig_close(st[1], pf["v"])
+    assert sig_close(ta.time_hi, pf["time"], 7)
+
+    pu = g["propagate_until"]
+    res = ta.propagate_until(pu["t"])
+    assert [r[3] for r in res] == pu["steps"]
+    assert sig_close([r[1] for r in res], pu["min_h"]) and sig_close([r[2] for r in res], pu["max_h"])
+    st = ta.state.reshape(2, 4)
+    assert sig_close(st[0], pu["x"]) and sig_close(st[1], pu["v"], 5)
+    assert list(ta.time_hi) == pu["t"]
+
+    # Taylor coefficients of the next step (tc[var][order][lane]).
+    ta.step(wtc=True)
+    tc = ta.tc.reshape(2, ta.order + 1, 4)
+    assert sig_close(tc[0], g["step_wtc_tc_x"], 6)
+    assert sig_close(tc[1], g["step_wtc_tc_v"], 6)
+
+
+def test_outer_ss_structure(golden):
+    from collections import Counter
+
+    g = golden["outer_ss_decomposition"]
+    m = [1.00000597682, 1 / 1047.355, 1 / 3501.6, 1 / 22869.0, 1 / 19314.0, 7.4074074e-09]
+    G = 0.01720209895 * 0.01720209895 * 365 * 365
+    dc = ho.taylor_decompose_sys(ho.nbody(6, masses=m, Gconst=G))
+    assert len(dc) == g["size"]
+    c = Counter(e.kind for e, _ in dc[36:-36])
+    assert c["sum_sq"] == g["sum_sq"] and c["sum"] == g["sum"] and c["sub"] == g["sub"]
+
+
+def test_dfloat_matches_exact_arithmetic():
+    from fractions import Fraction
+
+    rng = np.random.RandomState(0)
+    for _ in range(200):
+        a = rng.uniform(-1e6, 1e6)
+        b = rng.uniform(-1, 1) * 10.0 ** rng.randint(-20, 3)
+        al = a * EPS * rng.uniform(-0.4, 0.4)
+        hi, lo = ho.dfloat_add(a, al, b, 0.0)
+        exact = Fraction(a) + Fraction(al) + Fraction(b)
+        err = abs(Fraction(hi) + Fraction(lo) - exact)
+        assert err <= abs(exact) * Fraction(EPS) ** 2 * 8 + Fraction(1, 10**320)
+
+
+def test_harmonic_oscillator_long_time_analytic():
+    """x' = v, v' = -x over 1e4 time units vs v0 * sin(t) (cf. test/dfloat_time.cpp:168-250)."""
+    x, v = ho.var("x"), ho.var("v")
+    ta = ho.OracleIntegrator([(x, v), (v, -x)], [[0.0, 0.0], [1.0, 1.0 + 1e-3]], 2)
+    ta.propagate_until([1e4, 1.1e4])
+    st = ta.state.reshape(2, 2)
+    exact = np.array([np.sin(1e4), (1.0 + 1e-3) * np.sin(1.1e4)])
+    assert np.all(np.abs(st[0] - exact) <= 1e-11)
