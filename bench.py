@@ -169,7 +169,8 @@ def main():
     elapsed = time.perf_counter() - t0
 
     # Per-launch kernel durations (HIP events on the launch stream) and step counts.
-    kern_ms = [a.elapsed_time(b) for a, b in ev]
+    call_ms = [a.elapsed_time(b) for a, b in ev]  # torch events around the whole call (incl. small copies)
+    kern_ms = list(ta.kernel_ms_history(args.steps))  # HIP events recorded right around each launch
     steps_per_call_all = steps_acc.cpu().numpy().astype(np.float64)
     steps_per_call = float(steps_per_call_all.mean())
 
@@ -230,6 +231,7 @@ def main():
                 "traffic": None,
                 "kernel": "hy_taylor",
                 "kernel_ms_avg": k_ms,
+                "call_ms_avg": float(np.mean(call_ms)),
                 "algorithmic_bytes_per_system_step": b_tape,
                 "fp64_valu_frac": f_alg * per_launch_steps / (k_ms * 1e-3) / (FP64_PEAK_TFLOPS * 1e12),
             },

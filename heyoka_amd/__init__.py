@@ -595,6 +595,12 @@ class taylor_adaptive_batch:
     def last_total_steps(self):
         return int(lib.hy_tab_get_last_total_steps(self._h))
 
+    def kernel_ms_history(self, n=64):
+        """Durations (ms) of the last n stepper kernels, from HIP events on the launch stream."""
+        out = np.empty(int(n))
+        k = int(lib.hy_tab_get_kernel_ms_history(self._h, out.ctypes.data, int(n)))
+        return out[:k]
+
     def raw_step(self, d_state, d_pars, d_time, d_h, d_tc, n_systems):
         """Stepper function-pointer ABI on caller-owned device buffers (integers = device addresses)."""
         raise_for(lib.hy_tab_raw_step(self._h, int(d_state), int(d_pars) if d_pars else None, int(d_time), int(d_h),

@@ -128,6 +128,7 @@ SIGNATURES = [
     ("hy_tab_set_stream", c_int, [c_void_p, c_void_p]),
     ("hy_tab_synchronize", c_int, [c_void_p]),
     ("hy_tab_get_last_total_steps", c_uint64, [c_void_p]),
+    ("hy_tab_get_kernel_ms_history", c_size_t, [c_void_p, c_void_p, c_size_t]),
     ("hy_tab_raw_step", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64]),
     (
         "hy_ensemble_propagate_until_batch",

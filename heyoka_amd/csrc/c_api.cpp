@@ -593,6 +593,19 @@ uint64_t hy_tab_get_last_total_steps(hy_tab t)
         return 0;
     }
 }
+size_t hy_tab_get_kernel_ms_history(hy_tab t, double *out, size_t n)
+{
+    try {
+        const auto v = t->core.get_kernel_ms_history(n);
+        for (std::size_t i = 0; i < v.size(); ++i) {
+            out[i] = v[i];
+        }
+        return v.size();
+    } catch (...) {
+        handle_exception();
+        return 0;
+    }
+}
 int hy_tab_raw_step(hy_tab t, double *d_state, const double *d_pars, const double *d_time, double *d_h, double *d_tc,
                     uint64_t n)
 {

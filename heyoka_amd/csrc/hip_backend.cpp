@@ -1,6 +1,7 @@
 // hiprtc + HIP module runtime. See hip_backend.hpp.
 #include "hip_backend.hpp"
 
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -123,6 +124,10 @@ struct device_module::impl {
     hipFunction_t fn_taylor = nullptr;
     hipFunction_t fn_dout = nullptr;
     hipStream_t stream = nullptr;
+    // Ring of HIP event pairs bracketing the stepper launches.
+    static constexpr int n_ev = 64;
+    hipEvent_t ev_start[n_ev] = {}, ev_stop[n_ev] = {};
+    std::uint64_t n_launches = 0;
 };
 
 device_module::device_module(std::shared_ptr<const compiled_module> cm, int device) : m_impl(std::make_unique<impl>())
@@ -139,11 +144,19 @@ device_module::device_module(std::shared_ptr<const compiled_module> cm, int devi
               "hipModuleGetFunction(taylor)");
     hip_check(hipModuleGetFunction(&m_impl->fn_dout, m_impl->mod, m_impl->cm->meta.dout_name.c_str()),
               "hipModuleGetFunction(dout)");
+    for (int i = 0; i < impl::n_ev; ++i) {
+        hip_check(hipEventCreate(&m_impl->ev_start[i]), "hipEventCreate");
+        hip_check(hipEventCreate(&m_impl->ev_stop[i]), "hipEventCreate");
+    }
 }
 
 device_module::~device_module()
 {
     if (m_impl && m_impl->mod != nullptr) {
+        for (int i = 0; i < impl::n_ev; ++i) {
+            (void)hipEventDestroy(m_impl->ev_start[i]);
+            (void)hipEventDestroy(m_impl->ev_stop[i]);
+        }
         (void)hipModuleUnload(m_impl->mod);
     }
 }
@@ -180,9 +193,29 @@ void device_module::launch_taylor(const hy_kargs &args)
     hy_kargs a = args;
     std::size_t sz = sizeof(a);
     void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+    // HIP events on the launch stream bracket exactly the kernel (used for the roofline figure).
+    const auto slot = static_cast<int>(m_impl->n_launches % impl::n_ev);
+    hip_check(hipEventRecord(m_impl->ev_start[slot], m_impl->stream), "hipEventRecord");
     hip_check(hipModuleLaunchKernel(m_impl->fn_taylor, static_cast<unsigned>(grid), 1, 1,
                                     static_cast<unsigned>(bs), 1, 1, meta.lds_bytes, m_impl->stream, nullptr, config),
               "hipModuleLaunchKernel(taylor)");
+    hip_check(hipEventRecord(m_impl->ev_stop[slot], m_impl->stream), "hipEventRecord");
+    ++m_impl->n_launches;
+}
+
+std::vector<double> device_module::kernel_ms_history(std::size_t n)
+{
+    std::vector<double> ret;
+    hip_check(hipSetDevice(m_impl->device), "hipSetDevice");
+    n = std::min<std::size_t>({n, static_cast<std::size_t>(impl::n_ev), static_cast<std::size_t>(m_impl->n_launches)});
+    for (std::size_t i = 0; i < n; ++i) {
+        const auto slot = static_cast<int>((m_impl->n_launches - n + i) % impl::n_ev);
+        hip_check(hipEventSynchronize(m_impl->ev_stop[slot]), "hipEventSynchronize");
+        float ms = 0;
+        hip_check(hipEventElapsedTime(&ms, m_impl->ev_start[slot], m_impl->ev_stop[slot]), "hipEventElapsedTime");
+        ret.push_back(static_cast<double>(ms));
+    }
+    return ret;
 }
 
 void device_module::launch_dout(double *out, const double *tc, const double *hs, std::uint64_t N)

@@ -48,6 +48,9 @@ public:
 
     // Launch the stepper over N systems.
     void launch_taylor(const hy_kargs &args);
+    // Durations (ms) of the last n stepper kernels, oldest first, from HIP events recorded on the launch
+    // stream right around each launch (at most 64 are kept); synchronises on their completion.
+    std::vector<double> kernel_ms_history(std::size_t n);
     // Launch the dense-output kernel.
     void launch_dout(double *out, const double *tc, const double *hs, std::uint64_t N);
     void synchronize();

@@ -958,6 +958,14 @@ std::uint64_t tab_core::get_last_total_steps() const
     return tot;
 }
 
+std::vector<double> tab_core::get_kernel_ms_history(std::size_t n) const
+{
+    if (!m_impl->dmod) {
+        return {};
+    }
+    return m_impl->dmod->kernel_ms_history(n);
+}
+
 void tab_core::raw_step(double *d_state, const double *d_pars, const double *d_time, double *d_h, double *d_tc,
                         std::uint64_t n_systems)
 {

@@ -135,6 +135,8 @@ public:
     void synchronize();
     // Total number of integration steps taken by the last propagate_*() call (sum over lanes).
     [[nodiscard]] std::uint64_t get_last_total_steps() const;
+    // Durations (ms) of the last n stepper kernel launches (HIP events on the launch stream).
+    [[nodiscard]] std::vector<double> get_kernel_ms_history(std::size_t n) const;
     // Stepper function-pointer ABI of the reference (include/heyoka/detail/ta_jit_data.hpp:35-44)
     // on caller-provided device buffers: state rw, h in = signed max step, out = step taken.
     void raw_step(double *d_state, const double *d_pars, const double *d_time, double *d_h, double *d_tc,

@@ -194,6 +194,9 @@ int hy_tab_set_stream(hy_tab, void *hip_stream);
 int hy_tab_synchronize(hy_tab);
 /* Sum over lanes of the step counters of the last propagate_*() call. */
 uint64_t hy_tab_get_last_total_steps(hy_tab);
+/* Durations (ms) of the last (at most) n stepper-kernel launches, oldest first, measured with HIP
+ * events recorded on the launch stream immediately around each launch. Returns the count written. */
+size_t hy_tab_get_kernel_ms_history(hy_tab, double *out, size_t n);
 
 /* Stepper function-pointer ABI of the reference
  * (`void step(T *state, const T *pars, const T *time, T *h, T *tc)`,
