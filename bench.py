@@ -66,16 +66,29 @@ def cpu_baseline(workload, dt, target_seconds=15.0):
         osys = ho.nbody(2, masses=[1.0, 0.0])
         gen = lambda n: configs.two_body_state(n, perturb=1e-12, seed=42)
         ha = False
-    # Calibration run, then a sample sized for ~target_seconds.
-    n0 = width * threads
-    t0 = time.perf_counter()
-    *_, tot = ho.ensemble_propagate_until(osys, gen(n0), n0, width, dt, high_accuracy=ha)
-    el = time.perf_counter() - t0
-    rate = tot / max(el, 1e-9)
-    n = int(max(n0, min(262144, (rate * target_seconds / max(tot / n0, 1.0)) // (width * threads) * width * threads)))
-    t0 = time.perf_counter()
-    *_, tot = ho.ensemble_propagate_until(osys, gen(n), n, width, dt, high_accuracy=ha)
-    el = time.perf_counter() - t0
+    # Bounded sample: a fixed set of systems propagated further and further (t += dt per call, exactly
+    # like the GPU bench steps) until ~target_seconds of CPU work have been spent.
+    n = width * threads * 64
+    st = gen(n)
+    tmpl = ho.OracleIntegrator(osys, np.zeros(len(osys) * width), width, high_accuracy=ha)
+    import ctypes as _ct
+
+    thi, tlo = np.zeros(n), np.zeros(n)
+    oc = np.zeros(n, dtype=np.int64)
+    mn, mx = np.zeros(n), np.zeros(n)
+    ns = np.zeros(n, dtype=np.int64)
+    pr = np.zeros(max(tmpl.n_par, 1) * n)
+    st = np.ascontiguousarray(st.reshape(-1))
+    tot, el, t_cur, calls = 0, 0.0, 0.0, 0
+    while el < target_seconds and calls < 10000:
+        t_cur += dt
+        t0 = time.perf_counter()
+        tot += int(ho._lib().hy_oracle_ensemble_propagate_until(
+            _ct.byref(tmpl._prog), _ct.c_int64(n), width, ho._p(st), ho._p(pr), ho._p(thi), ho._p(tlo),
+            _ct.c_double(t_cur), _ct.c_int64(0), ho._p(oc), ho._p(mn), ho._p(mx), ho._p(ns), threads))
+        el += time.perf_counter() - t0
+        calls += 1
+    dt = t_cur
     return {
         "value": tot / el,
         "unit": "system-steps/s",
