@@ -128,6 +128,10 @@ struct device_module::impl {
     static constexpr int n_ev = 64;
     hipEvent_t ev_start[n_ev] = {}, ev_stop[n_ev] = {};
     std::uint64_t n_launches = 0;
+    // Persistent (cluster mode) launches: resident grid size and jet scratch.
+    unsigned max_grid = 0;
+    void *scratch = nullptr;
+    std::size_t scratch_bytes = 0;
 };
 
 device_module::device_module(std::shared_ptr<const compiled_module> cm, int device) : m_impl(std::make_unique<impl>())
@@ -144,6 +148,19 @@ device_module::device_module(std::shared_ptr<const compiled_module> cm, int devi
               "hipModuleGetFunction(taylor)");
     hip_check(hipModuleGetFunction(&m_impl->fn_dout, m_impl->mod, m_impl->cm->meta.dout_name.c_str()),
               "hipModuleGetFunction(dout)");
+    if (m_impl->cm->meta.persistent) {
+        int n_cu = 0, per_cu = 0;
+        hip_check(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device),
+                  "hipDeviceGetAttribute");
+        hip_check(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(
+                      &per_cu, m_impl->fn_taylor, static_cast<int>(m_impl->cm->meta.block_size),
+                      m_impl->cm->meta.lds_bytes),
+                  "hipModuleOccupancyMaxActiveBlocksPerMultiprocessor");
+        if (const char *env = std::getenv("HEYOKA_AMD_BLOCKS_PER_CU")) {
+            per_cu = std::max(1, std::atoi(env));
+        }
+        m_impl->max_grid = static_cast<unsigned>(std::max(1, n_cu) * std::max(1, per_cu));
+    }
     for (int i = 0; i < impl::n_ev; ++i) {
         hip_check(hipEventCreate(&m_impl->ev_start[i]), "hipEventCreate");
         hip_check(hipEventCreate(&m_impl->ev_stop[i]), "hipEventCreate");
@@ -156,6 +173,9 @@ device_module::~device_module()
         for (int i = 0; i < impl::n_ev; ++i) {
             (void)hipEventDestroy(m_impl->ev_start[i]);
             (void)hipEventDestroy(m_impl->ev_stop[i]);
+        }
+        if (m_impl->scratch != nullptr) {
+            (void)hipFree(m_impl->scratch);
         }
         (void)hipModuleUnload(m_impl->mod);
     }
@@ -185,12 +205,27 @@ void device_module::launch_taylor(const hy_kargs &args)
     const auto &meta = m_impl->cm->meta;
     const std::uint64_t threads = args.N * meta.lanes_per_system;
     const auto bs = static_cast<std::uint64_t>(meta.block_size);
-    const auto grid = (threads + bs - 1u) / bs;
+    auto grid = (threads + bs - 1u) / bs;
     if (grid > 0x7fffffffull) {
         throw std::overflow_error("heyoka_amd: grid size overflow");
     }
 
     hy_kargs a = args;
+    if (meta.persistent) {
+        // Persistent blocks pulling work from a device-side queue: the grid covers the machine once,
+        // and the jet scratch is sized by the number of resident waves.
+        grid = std::min<std::uint64_t>(grid, m_impl->max_grid);
+        const auto need = static_cast<std::size_t>(grid) * (bs / 64u) * meta.scratch_per_wave * sizeof(double);
+        if (need > m_impl->scratch_bytes) {
+            if (m_impl->scratch != nullptr) {
+                hip_check(hipFree(m_impl->scratch), "hipFree");
+                m_impl->scratch = nullptr;
+            }
+            hip_check(hipMalloc(&m_impl->scratch, need), "hipMalloc(scratch)");
+            m_impl->scratch_bytes = need;
+        }
+        a.scratch = static_cast<double *>(m_impl->scratch);
+    }
     std::size_t sz = sizeof(a);
     void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
     // HIP events on the launch stream bracket exactly the kernel (used for the roofline figure).

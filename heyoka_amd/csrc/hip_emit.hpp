@@ -35,7 +35,8 @@ struct hy_kargs {
     unsigned long long max_steps; // propagate mode: 0 = unlimited
     int mode;                 // 0 = single step, 1 = propagate_until
     int pad;
-    unsigned int *counters;   // [4] device counters: [0] lanes with non-finite state, [1] total steps lo, ...
+    unsigned int *counters;   // [16] device counters: [0] lanes with non-finite state, [1] work-queue head
+    double *scratch;          // cluster mode: jet scratch, scratch_per_wave doubles per resident wave
 };
 
 enum class emit_mode { unrolled, cluster, table };
@@ -57,6 +58,10 @@ struct emitted_module {
     emit_mode mode = emit_mode::unrolled;
     // Statistics (logged like the reference logs decomposition sizes).
     std::uint64_t n_statements = 0;
+    std::string notes;
+    // Cluster mode: doubles of jet scratch needed per resident wave.
+    std::uint64_t scratch_per_wave = 0;
+    bool persistent = false;
 };
 
 emitted_module emit_hip_module(const taylor_program &prog, const emit_options &opts);

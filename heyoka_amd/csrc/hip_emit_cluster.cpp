@@ -1,0 +1,992 @@
+// "Cluster" code generation mode: one ODE system per group of L lanes, jets resident in registers.
+//
+// The Taylor recursion of a nonlinear node (product, sum of squares, pow, sin/cos, ...) at order k
+// reads *all* lower orders of its operands: for an N-body system that history (15 pairs x 6 jets x
+// 20 orders for the outer Solar System) cannot live in the registers of a single lane, and parking
+// it in HBM makes the step bandwidth-bound at a small fraction of the FP64 rate. This generator
+// instead partitions the decomposition (reference: taylor_dc_t, src/taylor_01.cpp:848-1008) into
+//
+//   * clusters - connected components under "history" edges (a nonlinear node and the operands whose
+//     full history it needs). All clusters must be isomorphic (one code path, SIMT-friendly); each
+//     cluster is owned by one lane of the system's lane group and keeps its jets in that lane's VGPRs;
+//   * glue - linear nodes (sums, differences, products by constants) and the state-variable
+//     recursion x^[k] = rhs^[k-1] / k, which only ever need *current-order* values. These are
+//     exchanged between the lanes of a group through a per-system LDS slab holding the order-k
+//     coefficient of every exported u variable, and are evaluated in SIMT "rounds" driven by small
+//     per-lane slot tables.
+//
+// Per-order flow: state-variable recursion -> clusters -> glue levels, separated by wave-level LDS
+// synchronisations (a system never spans wavefronts, hence no s_barrier). The state-variable jets go to
+// a small per-wave scratch (L2 / Infinity-Cache resident, laid out [order][system][variable] so that
+// a wave's accesses are contiguous), are reduced for the step-size selector with wavefront shuffles,
+// and are read back for the Horner / compensated update. Blocks are persistent and pull groups of
+// systems from a device-side work queue, so that the scratch is proportional to the number of
+// resident waves rather than to the number of systems.
+//
+// The arithmetic of every node is emitted by the same ssa_emitter as the unrolled mode (reference
+// formulas cited in hip_emit_detail.hpp).
+#include <algorithm>
+#include <map>
+#include <numeric>
+#include <set>
+
+#include "hip_emit_detail.hpp"
+
+namespace heyoka_amd
+{
+
+namespace
+{
+
+using emit_detail::ssa_emitter;
+
+bool is_var(const operand &o)
+{
+    return o.type == operand::kind::uvar;
+}
+
+// u variables whose *full history* node n needs (besides, possibly, its own).
+std::vector<std::uint32_t> history_operands(const dc_node &n)
+{
+    std::vector<std::uint32_t> ret;
+    const auto &a = n.args;
+    switch (n.kind) {
+        case func_kind::prod:
+            if (a.size() == 2u && is_var(a[0]) && is_var(a[1])) {
+                ret = {a[0].idx, a[1].idx};
+            }
+            break;
+        case func_kind::div:
+            if (is_var(a[1])) {
+                ret = {a[1].idx};
+            }
+            break;
+        case func_kind::sum_sq:
+            for (const auto &o : a) {
+                if (is_var(o)) {
+                    ret.push_back(o.idx);
+                }
+            }
+            break;
+        case func_kind::pow:
+            // NOTE: sqrt only needs the current order of its base, but it always needs its own history:
+            // keep things simple and treat the base as a history operand in all cases.
+            if (is_var(a[0])) {
+                ret = {a[0].idx};
+            }
+            break;
+        case func_kind::sin:
+        case func_kind::cos:
+            if (is_var(a[0])) {
+                ret = {a[0].idx};
+                for (const auto d : n.deps) {
+                    ret.push_back(d);
+                }
+            }
+            break;
+        case func_kind::exp:
+        case func_kind::log:
+            if (is_var(a[0])) {
+                ret = {a[0].idx};
+            }
+            break;
+        default:
+            break;
+    }
+    return ret;
+}
+
+// Kinds that can be evaluated as glue (only current-order operand values).
+bool is_glue_kind(const dc_node &n)
+{
+    switch (n.kind) {
+        case func_kind::sum:
+        case func_kind::sub:
+        case func_kind::num_identity:
+        case func_kind::time:
+            return true;
+        case func_kind::prod:
+            return n.args.size() == 2u && !(is_var(n.args[0]) && is_var(n.args[1]));
+        case func_kind::div:
+            return !is_var(n.args[1]);
+        default:
+            return history_operands(n).empty();
+    }
+}
+
+struct union_find {
+    std::vector<std::uint32_t> p;
+    explicit union_find(std::size_t n) : p(n)
+    {
+        std::iota(p.begin(), p.end(), 0u);
+    }
+    std::uint32_t find(std::uint32_t x)
+    {
+        while (p[x] != x) {
+            p[x] = p[p[x]];
+            x = p[x];
+        }
+        return x;
+    }
+    void unite(std::uint32_t a, std::uint32_t b)
+    {
+        a = find(a);
+        b = find(b);
+        if (a != b) {
+            p[std::max(a, b)] = std::min(a, b);
+        }
+    }
+};
+
+struct glue_group {
+    std::uint32_t level = 0;
+    std::string key;
+    std::vector<std::uint32_t> nodes; // u indices
+};
+
+struct cluster_plan {
+    std::uint32_t n_eq = 0, n_u = 0, L = 1, spw = 64;
+    std::vector<std::vector<std::uint32_t>> clusters; // member u indices (ascending), all isomorphic
+    std::vector<int> cluster_of;                      // per u: cluster id or -1
+    std::uint32_t cluster_level = 1;
+    // Template-relative descriptions.
+    std::vector<std::vector<std::uint32_t>> ext_u;   // [cluster][e] -> u index of the e-th external input
+    std::vector<std::pair<std::uint32_t, std::uint32_t>> cst_pos; // (template position, arg index) of per-lane constants
+    std::vector<std::vector<double>> cst_val;         // [cluster][slot]
+    std::vector<std::uint32_t> out_pos;               // template positions whose value is exported
+    std::vector<int> slot_of;                         // per u: LDS slot or -1
+    std::uint32_t n_slots = 0, n_dummy = 0;
+    std::vector<glue_group> groups;                   // sorted by level
+    std::uint32_t max_level = 0;
+    std::vector<std::uint32_t> lvl;                   // per u
+};
+
+// Build the plan; returns an empty string on success, otherwise the reason why cluster mode is not applicable.
+std::string make_plan(const taylor_program &p, std::uint32_t order, cluster_plan &pl)
+{
+    const auto n_eq = p.n_eq, n_u = p.n_u;
+    pl.n_eq = n_eq;
+    pl.n_u = n_u;
+
+    // 1. History edges -> clusters.
+    union_find uf(n_u);
+    std::vector<char> in_h(n_u, 0);
+    for (std::uint32_t i = 0; i < p.nodes.size(); ++i) {
+        const auto u = n_eq + i;
+        const auto hs = history_operands(p.nodes[i]);
+        for (const auto h : hs) {
+            if (h < n_eq) {
+                return "a state variable is a history operand of a nonlinear function";
+            }
+            uf.unite(u, h);
+            in_h[u] = 1;
+            in_h[h] = 1;
+        }
+    }
+    pl.cluster_of.assign(n_u, -1);
+    std::map<std::uint32_t, int> root_to_cluster;
+    for (std::uint32_t u = n_eq; u < n_u; ++u) {
+        if (in_h[u] == 0) {
+            continue;
+        }
+        const auto r = uf.find(u);
+        auto it = root_to_cluster.find(r);
+        if (it == root_to_cluster.end()) {
+            it = root_to_cluster.emplace(r, static_cast<int>(pl.clusters.size())).first;
+            pl.clusters.emplace_back();
+        }
+        pl.cluster_of[u] = it->second;
+    }
+    if (pl.clusters.size() < 2u) {
+        return "fewer than 2 clusters";
+    }
+    if (pl.clusters.size() > 64u) {
+        return "more than 64 clusters (a system would span several wavefronts)";
+    }
+
+    // 2. Absorb single-source linear nodes into their source cluster.
+    for (std::uint32_t i = 0; i < p.nodes.size(); ++i) {
+        const auto u = n_eq + i;
+        if (pl.cluster_of[u] != -1 || !is_glue_kind(p.nodes[i])) {
+            continue;
+        }
+        int src = -2;
+        for (const auto &o : p.nodes[i].args) {
+            if (!is_var(o)) {
+                continue;
+            }
+            const auto c = o.idx < n_eq ? -1 : pl.cluster_of[o.idx];
+            if (src == -2) {
+                src = c;
+            } else if (src != c) {
+                src = -1;
+            }
+        }
+        if (src >= 0) {
+            pl.cluster_of[u] = src;
+        }
+    }
+    for (std::uint32_t u = n_eq; u < n_u; ++u) {
+        if (pl.cluster_of[u] >= 0) {
+            pl.clusters[static_cast<std::size_t>(pl.cluster_of[u])].push_back(u);
+        }
+    }
+
+    // Glue nodes must be of a kind evaluable from current-order values.
+    for (std::uint32_t i = 0; i < p.nodes.size(); ++i) {
+        if (pl.cluster_of[n_eq + i] == -1 && !is_glue_kind(p.nodes[i])) {
+            return std::string("unsupported glue node kind: ") + func_kind_name(p.nodes[i].kind);
+        }
+    }
+
+    // 3. Levels on the contracted graph. lvl of state variables = 0; a cluster runs as a unit.
+    //    First pass: levels of glue nodes and provisional cluster levels, iterated to a fixed point
+    //    (the graph is a DAG unless a cluster depends on itself through glue).
+    const auto nc = pl.clusters.size();
+    std::vector<std::uint32_t> clvl(nc, 1u);
+    pl.lvl.assign(n_u, 0u);
+    bool changed = true;
+    std::uint32_t iters = 0;
+    while (changed) {
+        changed = false;
+        if (++iters > n_u + 2u) {
+            return "cyclic dependency between a cluster and glue nodes";
+        }
+        for (std::uint32_t i = 0; i < p.nodes.size(); ++i) {
+            const auto u = n_eq + i;
+            const auto c = pl.cluster_of[u];
+            std::uint32_t need = 1;
+            for (const auto &o : p.nodes[i].args) {
+                if (!is_var(o)) {
+                    continue;
+                }
+                const auto oc = o.idx < n_eq ? -1 : pl.cluster_of[o.idx];
+                if (c >= 0 && oc == c) {
+                    continue;
+                }
+                const auto ol = (oc >= 0) ? clvl[static_cast<std::size_t>(oc)] : pl.lvl[o.idx];
+                need = std::max(need, ol + 1u);
+            }
+            if (c >= 0) {
+                if (need > clvl[static_cast<std::size_t>(c)]) {
+                    clvl[static_cast<std::size_t>(c)] = need;
+                    changed = true;
+                }
+            } else if (need != pl.lvl[u]) {
+                pl.lvl[u] = need;
+                changed = true;
+            }
+        }
+    }
+    for (std::size_t c = 1; c < nc; ++c) {
+        if (clvl[c] != clvl[0]) {
+            return "clusters at different dependency levels";
+        }
+    }
+    pl.cluster_level = clvl[0];
+    for (std::uint32_t u = n_eq; u < n_u; ++u) {
+        if (pl.cluster_of[u] >= 0) {
+            pl.lvl[u] = pl.cluster_level;
+        }
+    }
+    pl.max_level = *std::max_element(pl.lvl.begin(), pl.lvl.end());
+
+    // 4. Which cluster members are read from outside their cluster (glue, other clusters, sv rules)?
+    std::vector<char> exported(n_u, 0);
+    for (std::uint32_t i = 0; i < p.nodes.size(); ++i) {
+        const auto c = pl.cluster_of[n_eq + i];
+        for (const auto &o : p.nodes[i].args) {
+            if (is_var(o) && o.idx >= n_eq && pl.cluster_of[o.idx] >= 0 && pl.cluster_of[o.idx] != c) {
+                exported[o.idx] = 1;
+            }
+        }
+    }
+    for (const auto &d : p.sv_defs) {
+        if (is_var(d) && d.idx >= n_eq && pl.cluster_of[d.idx] >= 0) {
+            exported[d.idx] = 1;
+        }
+    }
+
+    // 5. Isomorphism check + template-relative tables.
+    const auto &t0 = pl.clusters[0];
+    pl.ext_u.assign(nc, {});
+    pl.cst_val.assign(nc, {});
+    std::vector<std::string> sigs(nc);
+    // Numerical operands that must be identical (they select the code shape).
+    const auto structural_number = [](const dc_node &n, std::size_t a) {
+        if (n.kind == func_kind::pow && a == 1u) {
+            return true;
+        }
+        if (n.kind == func_kind::prod && a == 0u && n.args[0].type == operand::kind::num && n.args[0].value == -1.) {
+            return true;
+        }
+        return false;
+    };
+    std::vector<std::vector<std::pair<std::uint32_t, std::uint32_t>>> num_pos(nc);
+    std::vector<std::vector<double>> num_val(nc);
+    for (std::size_t c = 0; c < nc; ++c) {
+        const auto &mem = pl.clusters[c];
+        if (mem.size() != t0.size()) {
+            return "clusters are not isomorphic (different sizes)";
+        }
+        std::map<std::uint32_t, std::uint32_t> pos_of, ext_of;
+        for (std::uint32_t q = 0; q < mem.size(); ++q) {
+            pos_of[mem[q]] = q;
+        }
+        std::ostringstream sig;
+        for (std::uint32_t q = 0; q < mem.size(); ++q) {
+            const auto &n = p.nodes[mem[q] - n_eq];
+            sig << func_kind_name(n.kind) << (exported[mem[q]] != 0 ? "!" : "") << '(';
+            for (std::size_t a = 0; a < n.args.size(); ++a) {
+                const auto &o = n.args[a];
+                if (is_var(o)) {
+                    if (const auto it = pos_of.find(o.idx); it != pos_of.end()) {
+                        sig << 'm' << it->second;
+                    } else {
+                        auto it2 = ext_of.find(o.idx);
+                        if (it2 == ext_of.end()) {
+                            it2 = ext_of.emplace(o.idx, static_cast<std::uint32_t>(pl.ext_u[c].size())).first;
+                            pl.ext_u[c].push_back(o.idx);
+                        }
+                        sig << 'e' << it2->second;
+                    }
+                } else if (o.type == operand::kind::par) {
+                    sig << 'p' << o.idx;
+                } else if (structural_number(n, a)) {
+                    sig << 'n' << fp_literal(o.value);
+                } else {
+                    sig << 'c';
+                    num_pos[c].emplace_back(q, static_cast<std::uint32_t>(a));
+                    num_val[c].push_back(o.value);
+                }
+                sig << ',';
+            }
+            sig << ")[";
+            for (const auto d : n.deps) {
+                const auto it = pos_of.find(d);
+                if (it == pos_of.end()) {
+                    return "hidden dependency outside of its cluster";
+                }
+                sig << it->second << ',';
+            }
+            sig << ']';
+        }
+        sigs[c] = sig.str();
+        if (sigs[c] != sigs[0]) {
+            return "clusters are not isomorphic";
+        }
+    }
+    // Constants: literal if identical across clusters, otherwise a per-lane table entry.
+    for (std::size_t j = 0; j < num_pos[0].size(); ++j) {
+        bool same = true;
+        for (std::size_t c = 1; c < nc; ++c) {
+            const auto a = num_val[c][j], b = num_val[0][j];
+            if (!(a == b || (std::isnan(a) && std::isnan(b))) || std::signbit(a) != std::signbit(b)) {
+                same = false;
+            }
+        }
+        if (!same) {
+            pl.cst_pos.push_back(num_pos[0][j]);
+            for (std::size_t c = 0; c < nc; ++c) {
+                pl.cst_val[c].push_back(num_val[c][j]);
+            }
+        }
+    }
+    for (std::uint32_t q = 0; q < t0.size(); ++q) {
+        if (exported[t0[q]] != 0) {
+            pl.out_pos.push_back(q);
+        }
+    }
+
+    // 6. Lane-group width.
+    pl.L = 2;
+    while (pl.L < nc) {
+        pl.L *= 2u;
+    }
+    pl.spw = 64u / pl.L;
+
+    // Register estimate: members whose history is needed keep `order` doubles alive.
+    std::set<std::uint32_t> stored;
+    for (const auto u : t0) {
+        const auto &n = p.nodes[u - n_eq];
+        for (const auto h : history_operands(n)) {
+            stored.insert(h);
+        }
+        switch (n.kind) {
+            case func_kind::pow:
+            case func_kind::div:
+            case func_kind::sin:
+            case func_kind::cos:
+            case func_kind::exp:
+            case func_kind::log:
+                if (!history_operands(n).empty()) {
+                    stored.insert(u);
+                }
+                break;
+            default:
+                break;
+        }
+    }
+    if (stored.size() * order * 2u > 420u) {
+        return "the jets of a cluster do not fit in the register file";
+    }
+
+    // 7. LDS slots: state variables, exported cluster members, glue nodes; then dummies.
+    pl.slot_of.assign(n_u, -1);
+    std::uint32_t ns = 0;
+    for (std::uint32_t i = 0; i < n_eq; ++i) {
+        pl.slot_of[i] = static_cast<int>(ns++);
+    }
+    for (std::size_t c = 0; c < nc; ++c) {
+        for (const auto q : pl.out_pos) {
+            pl.slot_of[pl.clusters[c][q]] = static_cast<int>(ns++);
+        }
+    }
+    for (std::uint32_t u = n_eq; u < n_u; ++u) {
+        if (pl.cluster_of[u] == -1) {
+            pl.slot_of[u] = static_cast<int>(ns++);
+        }
+    }
+    pl.n_slots = ns;
+
+    // 8. Glue groups: per level, per shape.
+    std::map<std::pair<std::uint32_t, std::string>, std::size_t> gidx;
+    for (std::uint32_t i = 0; i < p.nodes.size(); ++i) {
+        const auto u = n_eq + i;
+        if (pl.cluster_of[u] != -1) {
+            continue;
+        }
+        const auto &n = p.nodes[i];
+        std::ostringstream key;
+        key << func_kind_name(n.kind);
+        for (std::size_t a = 0; a < n.args.size(); ++a) {
+            const auto &o = n.args[a];
+            if (is_var(o)) {
+                key << "v";
+            } else if (o.type == operand::kind::par) {
+                key << "p" << o.idx;
+            } else if (structural_number(n, a)) {
+                key << "n" << fp_literal(o.value);
+            } else {
+                key << "c";
+            }
+        }
+        const auto k = std::make_pair(pl.lvl[u], key.str());
+        auto it = gidx.find(k);
+        if (it == gidx.end()) {
+            it = gidx.emplace(k, pl.groups.size()).first;
+            pl.groups.emplace_back();
+            pl.groups.back().level = pl.lvl[u];
+            pl.groups.back().key = key.str();
+        }
+        pl.groups[it->second].nodes.push_back(u);
+    }
+    std::stable_sort(pl.groups.begin(), pl.groups.end(),
+                     [](const glue_group &a, const glue_group &b) { return a.level < b.level; });
+
+    return {};
+}
+
+} // namespace
+
+// Returns a module with an empty source (and the reason in why_not) if cluster mode is not applicable.
+emitted_module emit_cluster_or_empty(const taylor_program &p, const emit_options &opts, std::string &why_not)
+{
+    using emit_detail::prelude;
+    using emit_detail::rhofac;
+
+    emitted_module ret;
+    cluster_plan pl;
+    why_not = make_plan(p, opts.order, pl);
+    if (!why_not.empty()) {
+        return ret;
+    }
+
+    const auto n_eq = p.n_eq, order = opts.order, L = pl.L, spw = pl.spw;
+    const std::uint32_t bs = 256, wpb = bs / 64u;
+    const auto nc = static_cast<std::uint32_t>(pl.clusters.size());
+    const auto &t0 = pl.clusters[0];
+    const auto n_ext = static_cast<std::uint32_t>(pl.ext_u[0].size());
+    const auto n_out = static_cast<std::uint32_t>(pl.out_pos.size());
+    const auto n_cst = static_cast<std::uint32_t>(pl.cst_pos.size());
+    const auto sv_rounds = (n_eq + L - 1u) / L;
+    const auto n_col = sv_rounds * L;
+
+    // Dummy slots for idle lanes (they replicate real work and write to slots nobody reads).
+    std::uint32_t max_round_outputs = std::max<std::uint32_t>(n_out, 1u);
+    const auto dummy_base = pl.n_slots;
+    const auto n_slots_tot = pl.n_slots + max_round_outputs;
+    // Pad the per-system slab to an odd number of doubles (bank spreading between the systems of a wave).
+    const auto slab_stride = n_slots_tot | 1u;
+
+    // ---- per-lane tables (unsigned short slots, double constants) ----
+    std::vector<std::vector<std::uint32_t>> utbl; // each entry: L values
+    std::vector<std::vector<double>> dtbl;
+    const auto add_utbl = [&](std::vector<std::uint32_t> v) {
+        utbl.push_back(std::move(v));
+        return utbl.size() - 1u;
+    };
+    const auto add_dtbl = [&](std::vector<double> v) {
+        dtbl.push_back(std::move(v));
+        return dtbl.size() - 1u;
+    };
+
+    ssa_emitter e(p, order);
+    auto &os = e.os;
+    // The body is emitted into a separate stream first, because the tables it needs are only known
+    // once the whole body has been generated.
+    std::ostringstream body;
+
+    // Cluster tables.
+    std::vector<std::size_t> ext_tbl(n_ext), out_tbl(n_out), cst_tbl(n_cst);
+    for (std::uint32_t x = 0; x < n_ext; ++x) {
+        std::vector<std::uint32_t> v(L);
+        for (std::uint32_t l = 0; l < L; ++l) {
+            const auto c = l < nc ? l : 0u;
+            v[l] = static_cast<std::uint32_t>(pl.slot_of[pl.ext_u[c][x]]);
+        }
+        ext_tbl[x] = add_utbl(std::move(v));
+    }
+    for (std::uint32_t x = 0; x < n_out; ++x) {
+        std::vector<std::uint32_t> v(L);
+        for (std::uint32_t l = 0; l < L; ++l) {
+            v[l] = l < nc ? static_cast<std::uint32_t>(pl.slot_of[pl.clusters[l][pl.out_pos[x]]]) : dummy_base + x;
+        }
+        out_tbl[x] = add_utbl(std::move(v));
+    }
+    for (std::uint32_t x = 0; x < n_cst; ++x) {
+        std::vector<double> v(L);
+        for (std::uint32_t l = 0; l < L; ++l) {
+            v[l] = pl.cst_val[l < nc ? l : 0u][x];
+        }
+        cst_tbl[x] = add_dtbl(std::move(v));
+        const auto [q, a] = pl.cst_pos[x];
+        e.numpar_override[&p.nodes[t0[q] - n_eq].args[a]] = "ccst" + std::to_string(x);
+    }
+
+    // State-variable rounds: variable index of lane l in round r is r * L + l (clamped for padding lanes).
+    struct sv_round {
+        std::size_t in_tbl = 0, out_tbl = 0, cst_tbl = 0;
+        bool all_var = true, any_var = false;
+    };
+    std::vector<sv_round> svr(sv_rounds);
+    for (std::uint32_t r = 0; r < sv_rounds; ++r) {
+        std::vector<std::uint32_t> vin(L), vout(L);
+        std::vector<double> vc(L, 0.);
+        for (std::uint32_t l = 0; l < L; ++l) {
+            const auto i = r * L + l;
+            const auto ii = i < n_eq ? i : r * L; // padding lanes replicate the first variable of the round
+            const auto &d = p.sv_defs[ii];
+            if (d.type == operand::kind::uvar) {
+                vin[l] = static_cast<std::uint32_t>(pl.slot_of[d.idx]);
+                svr[r].any_var = true;
+            } else {
+                vin[l] = 0;
+                svr[r].all_var = false;
+                if (d.type == operand::kind::par) {
+                    return ret.notes = "param", why_not = "state variable defined by a runtime parameter", ret;
+                }
+                vc[l] = d.value;
+            }
+            vout[l] = i < n_eq ? static_cast<std::uint32_t>(pl.slot_of[i]) : dummy_base;
+        }
+        if (svr[r].any_var && !svr[r].all_var) {
+            why_not = "mixed constant / variable state-variable definitions in one round";
+            return ret;
+        }
+        svr[r].in_tbl = add_utbl(std::move(vin));
+        svr[r].out_tbl = add_utbl(std::move(vout));
+        svr[r].cst_tbl = add_dtbl(std::move(vc));
+    }
+
+    // ---- emission helpers ----
+    const auto sync = [&]() { os << "HY_WSYNC();\n"; };
+    const auto utname = [](std::size_t t) { return "ut" + std::to_string(t); };
+    const auto dtname = [](std::size_t t) { return "dt" + std::to_string(t); };
+
+    // Glue group emission at order k: rounds over the nodes of the group.
+    struct glue_round_tbls {
+        std::vector<std::size_t> arg_tbl; // per arg: utbl (var) or dtbl (const) index
+        std::size_t out_tbl = 0;
+    };
+    std::vector<std::vector<glue_round_tbls>> glue_tbls(pl.groups.size());
+    for (std::size_t g = 0; g < pl.groups.size(); ++g) {
+        const auto &grp = pl.groups[g];
+        const auto n_nodes = static_cast<std::uint32_t>(grp.nodes.size());
+        const auto rounds = (n_nodes + L - 1u) / L;
+        const auto &n0 = p.nodes[grp.nodes[0] - n_eq];
+        for (std::uint32_t r = 0; r < rounds; ++r) {
+            glue_round_tbls rt;
+            for (std::size_t a = 0; a < n0.args.size(); ++a) {
+                if (is_var(n0.args[a])) {
+                    std::vector<std::uint32_t> v(L);
+                    for (std::uint32_t l = 0; l < L; ++l) {
+                        const auto j = r * L + l;
+                        const auto u = grp.nodes[j < n_nodes ? j : r * L];
+                        v[l] = static_cast<std::uint32_t>(pl.slot_of[p.nodes[u - n_eq].args[a].idx]);
+                    }
+                    rt.arg_tbl.push_back(add_utbl(std::move(v)));
+                } else if (n0.args[a].type == operand::kind::num) {
+                    std::vector<double> v(L);
+                    for (std::uint32_t l = 0; l < L; ++l) {
+                        const auto j = r * L + l;
+                        const auto u = grp.nodes[j < n_nodes ? j : r * L];
+                        v[l] = p.nodes[u - n_eq].args[a].value;
+                    }
+                    rt.arg_tbl.push_back(add_dtbl(std::move(v)));
+                } else {
+                    rt.arg_tbl.push_back(0);
+                }
+            }
+            std::vector<std::uint32_t> v(L);
+            for (std::uint32_t l = 0; l < L; ++l) {
+                const auto j = r * L + l;
+                v[l] = j < n_nodes ? static_cast<std::uint32_t>(pl.slot_of[grp.nodes[j]]) : dummy_base;
+            }
+            rt.out_tbl = add_utbl(std::move(v));
+            glue_tbls[g].push_back(std::move(rt));
+        }
+    }
+
+    // Emit one glue group at order k by temporarily aliasing the first node of each round: the node
+    // rule is emitted once per round with operands read from the slab through the lane's tables.
+    const auto emit_glue_group = [&](std::size_t g, std::uint32_t k) {
+        const auto &grp = pl.groups[g];
+        const auto rep = grp.nodes[0];
+        const auto &n0 = p.nodes[rep - n_eq];
+        for (std::size_t r = 0; r < glue_tbls[g].size(); ++r) {
+            const auto &rt = glue_tbls[g][r];
+            std::map<const operand *, std::string> saved = e.numpar_override;
+            std::vector<std::pair<std::uint32_t, std::string>> saved_vals;
+            for (std::size_t a = 0; a < n0.args.size(); ++a) {
+                const auto &o = n0.args[a];
+                if (is_var(o)) {
+                    const auto nm = e.def("slab[" + utname(rt.arg_tbl[a]) + "]");
+                    saved_vals.emplace_back(o.idx, e.val(o.idx, k));
+                    e.val(o.idx, k) = nm;
+                } else if (o.type == operand::kind::num) {
+                    e.numpar_override[&o] = dtname(rt.arg_tbl[a]);
+                }
+            }
+            // NOTE: structural numbers (-1 of a negation) keep their literal value; constants are
+            // read from the per-lane table only at the orders where the rule uses them.
+            if (n0.kind == func_kind::prod && n0.args[0].type == operand::kind::num && n0.args[0].value == -1.) {
+                e.numpar_override.erase(&n0.args[0]);
+            }
+            e.node(rep - n_eq, k);
+            os << "slab[" << utname(rt.out_tbl) << "] = " << e.val(rep, k) << ";\n";
+            // Restore.
+            for (auto it = saved_vals.rbegin(); it != saved_vals.rend(); ++it) {
+                e.val(it->first, k) = it->second;
+            }
+            e.numpar_override = std::move(saved);
+        }
+    };
+
+    // Cluster code at order k.
+    const auto emit_cluster = [&](std::uint32_t k) {
+        for (std::uint32_t x = 0; x < n_ext; ++x) {
+            e.val(pl.ext_u[0][x], k) = e.def("slab[" + utname(ext_tbl[x]) + "]");
+        }
+        for (const auto u : t0) {
+            e.node(u - n_eq, k);
+        }
+        for (std::uint32_t x = 0; x < n_out; ++x) {
+            os << "slab[" << utname(out_tbl[x]) << "] = " << e.val(t0[pl.out_pos[x]], k) << ";\n";
+        }
+    };
+
+    // All the levels of order k (k < order).
+    const auto emit_levels = [&](std::uint32_t k) {
+        for (std::uint32_t lev = 1; lev <= pl.max_level; ++lev) {
+            if (lev == pl.cluster_level) {
+                emit_cluster(k);
+            }
+            for (std::size_t g = 0; g < pl.groups.size(); ++g) {
+                if (pl.groups[g].level == lev) {
+                    emit_glue_group(g, k);
+                }
+            }
+            sync();
+        }
+    };
+
+    const auto jet_off = [&](std::uint32_t k, std::uint32_t r) {
+        // jetw[(k * spw + q) * n_col + r * L + l]
+        return "jetl[" + std::to_string(static_cast<std::uint64_t>(k) * spw * n_col + static_cast<std::uint64_t>(r) * L)
+               + "]";
+    };
+
+    // ===================== kernel body =====================
+    // Order 0: publish the state.
+    for (std::uint32_t r = 0; r < sv_rounds; ++r) {
+        os << "slab[" << utname(svr[r].out_tbl) << "] = xs" << r << ";\n";
+        os << jet_off(0, r) << " = xs" << r << ";\n";
+    }
+    {
+        std::string m = "fabs(xs0)";
+        os << "double m0 = fabs(xs0);\n";
+        for (std::uint32_t r = 1; r < sv_rounds; ++r) {
+            os << "if (svalid" << r << ") m0 = hy_max(m0, fabs(xs" << r << "));\n";
+        }
+        (void)m;
+    }
+    sync();
+    emit_levels(0);
+    os << "double mo = 0.0, mom1 = 0.0;\n";
+    for (std::uint32_t k = 1; k <= order; ++k) {
+        // State-variable recursion: read rhs^[k-1], sync, write x^[k].
+        std::vector<std::string> rhs(sv_rounds);
+        for (std::uint32_t r = 0; r < sv_rounds; ++r) {
+            if (svr[r].any_var) {
+                rhs[r] = e.def("slab[" + utname(svr[r].in_tbl) + "]");
+            }
+        }
+        sync();
+        for (std::uint32_t r = 0; r < sv_rounds; ++r) {
+            std::string xv;
+            if (svr[r].any_var) {
+                xv = e.def(rhs[r] + " / " + fp_literal(static_cast<double>(k)));
+            } else {
+                xv = (k == 1u) ? dtname(svr[r].cst_tbl) : std::string("0.0");
+            }
+            os << "slab[" << utname(svr[r].out_tbl) << "] = " << xv << ";\n";
+            os << jet_off(k, r) << " = " << xv << ";\n";
+            if (k == order - 1u || k == order) {
+                const char *acc = (k == order) ? "mo" : "mom1";
+                if (r == 0u) {
+                    os << acc << " = fabs(" << xv << ");\n";
+                } else {
+                    os << "if (svalid" << r << ") " << acc << " = hy_max(" << acc << ", fabs(" << xv << "));\n";
+                }
+            }
+        }
+        sync();
+        if (k < order) {
+            emit_levels(k);
+        }
+    }
+    body << os.str();
+    os.str("");
+    os.clear();
+
+    // ===================== module text =====================
+    std::ostringstream src;
+    src << prelude;
+    emit_detail::emit_dout(src, p, opts);
+
+    src << "#define HY_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); "
+           "__builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\"); } while (0)\n";
+    src << "__constant__ unsigned short hy_utbl[" << std::max<std::size_t>(utbl.size(), 1u) * L << "] = {";
+    for (const auto &v : utbl) {
+        for (const auto x : v) {
+            src << x << ",";
+        }
+    }
+    src << "};\n";
+    src << "__constant__ double hy_dtbl[" << std::max<std::size_t>(dtbl.size(), 1u) * L << "] = {";
+    for (const auto &v : dtbl) {
+        for (const auto x : v) {
+            src << fp_literal(x) << ",";
+        }
+    }
+    src << "};\n";
+
+    src << "extern \"C\" __global__ void __launch_bounds__(" << bs << ") hy_taylor(const hy_kargs a)\n{\n";
+    src << "__shared__ double lds_slab[" << static_cast<std::uint64_t>(wpb) * spw * slab_stride << "];\n";
+    src << "const unsigned lane = threadIdx.x & 63u;\nconst unsigned wib = threadIdx.x >> 6;\n";
+    src << "const unsigned l = lane % " << L << "u;\nconst unsigned q = lane / " << L << "u;\n";
+    src << "const u64 N = a.N;\n";
+    src << "double *const slab = lds_slab + (wib * " << spw << "u + q) * " << slab_stride << "u;\n";
+    src << "const u64 gwave = (u64)blockIdx.x * " << wpb << "u + wib;\n";
+    src << "double *const jetw = a.scratch + gwave * " << static_cast<std::uint64_t>(order + 1u) * spw * n_col
+        << "ull;\n";
+    src << "double *const jetl = jetw + q * " << n_col << "u + l;\n";
+    // Per-lane table entries (loop invariant).
+    for (std::size_t t = 0; t < utbl.size(); ++t) {
+        src << "const unsigned ut" << t << " = hy_utbl[" << t * L << "u + l];\n";
+    }
+    for (std::size_t t = 0; t < dtbl.size(); ++t) {
+        src << "const double dt" << t << " = hy_dtbl[" << t * L << "u + l];\n";
+    }
+    for (std::uint32_t x = 0; x < n_cst; ++x) {
+        src << "const double ccst" << x << " = dt" << cst_tbl[x] << ";\n";
+    }
+    for (std::uint32_t r = 0; r < sv_rounds; ++r) {
+        src << "const bool svalid" << r << " = (" << r * L << "u + l) < " << n_eq << "u;\n";
+        src << "const unsigned svi" << r << " = svalid" << r << " ? (" << r * L << "u + l) : " << r * L << "u;\n";
+    }
+    src << R"HIP(
+for (;;) {
+// Pull the next group of systems from the device-side work queue.
+u64 base = 0;
+if (lane == 0u) base = atomicAdd((u64 *)(a.counters + 2), (u64)SPW);
+base = __shfl(base, 0, 64);
+if (base >= N) break;
+// NOTE: lanes beyond the end of the ensemble replicate the last system (no side effects).
+const bool live = (base + q) < N;
+const u64 s = live ? (base + q) : (N - 1u);
+double t_hi = a.time_hi[s], t_lo = a.time_lo[s];
+)HIP";
+    for (std::uint32_t i = 0; i < p.n_par; ++i) {
+        src << "const double par_" << i << " = a.pars[(u64)" << i << "u * N + s];\n";
+    }
+    for (std::uint32_t r = 0; r < sv_rounds; ++r) {
+        src << "double xs" << r << " = a.state[(u64)svi" << r << " * N + s];\n";
+    }
+    src << R"HIP(
+hy_df tfin, rem;
+tfin.hi = 0.0; tfin.lo = 0.0; rem.hi = 0.0; rem.lo = 0.0;
+bool t_dir = true;
+double mdt = __builtin_inf();
+double step_lim = 0.0;
+if (a.mode == 1) {
+    tfin.hi = a.tfin_hi[s];
+    tfin.lo = a.tfin_lo[s];
+    hy_df tcur; tcur.hi = t_hi; tcur.lo = t_lo;
+    rem = hy_df_sub(tfin, tcur);
+    t_dir = (rem.hi > 0.0) || (rem.hi == 0.0 && rem.lo >= 0.0);
+    if (a.lim != nullptr) mdt = a.lim[s];
+} else {
+    step_lim = a.lim[s];
+}
+u64 n_steps = 0, iter = 0;
+double min_h = __builtin_inf(), max_h = 0.0, last_h = 0.0;
+i64 outcome = HY_OC_SUCCESS;
+for (;;) {
+double lim;
+if (a.mode == 1) {
+    hy_df m; m.lo = 0.0;
+    if (t_dir) { m.hi = mdt; lim = hy_df_lt(rem, m) ? rem.hi : m.hi; }
+    else { m.hi = -mdt; lim = hy_df_lt(m, rem) ? rem.hi : m.hi; }
+} else {
+    lim = step_lim;
+}
+)HIP";
+    src << body.str();
+
+    // Step size: reduce the partial maxima over the lanes of the group with wavefront shuffles.
+    for (std::uint32_t m = 1; m < L; m *= 2u) {
+        src << "m0 = hy_max(m0, __shfl_xor(m0, " << m << ", 64));\n";
+        src << "mo = hy_max(mo, __shfl_xor(mo, " << m << ", 64));\n";
+        src << "mom1 = hy_max(mom1, __shfl_xor(mom1, " << m << ", 64));\n";
+    }
+    src << "const double num_rho = (m0 <= 1.0) ? 1.0 : m0;\n";
+    src << "const double rho_o = pow(num_rho / mo, " << fp_literal(1. / static_cast<double>(order)) << ");\n";
+    src << "const double rho_om1 = pow(num_rho / mom1, " << fp_literal(1. / static_cast<double>(order - 1u))
+        << ");\n";
+    src << "const double rho_m = hy_min(rho_o, rho_om1);\n";
+    src << "double h = rho_m * " << fp_literal(rhofac(order)) << ";\n";
+    src << "h = hy_min(h, fabs(lim));\nh = (lim < 0.0) ? -h : h;\n";
+
+    // State update from the scratch jets.
+    src << "asm volatile(\"\" ::: \"memory\");\n";
+    const auto kstride = static_cast<std::uint64_t>(spw) * n_col;
+    for (std::uint32_t r = 0; r < sv_rounds; ++r) {
+        src << "{\nconst double *c = jetl + " << static_cast<std::uint64_t>(r) * L << "u;\n";
+        if (opts.high_accuracy) {
+            src << "double res = c[0], comp = 0.0, cur_h = h;\n#pragma unroll\n";
+            src << "for (unsigned k = 1; k <= " << order << "u; ++k) {\n";
+            src << "const double tmp = c[(u64)k * " << kstride << "u] * cur_h;\nconst double y = tmp - comp;\n";
+            src << "const double t = res + y;\ncomp = (t - res) - y;\nres = t;\ncur_h = cur_h * h;\n}\n";
+        } else {
+            src << "double res = c[(u64)" << order << "u * " << kstride << "u];\n#pragma unroll\n";
+            src << "for (unsigned k = 1; k <= " << order << "u; ++k) {\n";
+            src << "res = c[(u64)(" << order << "u - k) * " << kstride << "u] + res * h;\n}\n";
+        }
+        src << "xs" << r << " = res;\n}\n";
+    }
+    src << R"HIP(
+{
+    hy_df tcur; tcur.hi = t_hi; tcur.lo = t_lo;
+    hy_df hh; hh.hi = h; hh.lo = 0.0;
+    const hy_df nt = hy_df_add(tcur, hh);
+    t_hi = nt.hi; t_lo = nt.lo;
+}
+last_h = h;
+int nfi = !(hy_finite(t_hi) && hy_finite(t_lo)) ? 1 : 0;
+)HIP";
+    for (std::uint32_t r = 0; r < sv_rounds; ++r) {
+        src << "if (svalid" << r << " && !hy_finite(xs" << r << ")) nfi = 1;\n";
+    }
+    for (std::uint32_t m = 1; m < L; m *= 2u) {
+        src << "nfi |= __shfl_xor(nfi, " << m << ", 64);\n";
+    }
+    src << R"HIP(
+// The coefficients of the step just taken, in the reference's layout, if requested.
+if (a.tc != nullptr && live) {
+)HIP";
+    for (std::uint32_t r = 0; r < sv_rounds; ++r) {
+        src << "if (svalid" << r << ") {\nconst double *c = jetl + " << static_cast<std::uint64_t>(r) * L
+            << "u;\nfor (unsigned k = 0; k <= " << order << "u; ++k) a.tc[((u64)svi" << r << " * "
+            << (order + 1u) << "u + k) * N + s] = c[(u64)k * " << kstride << "u];\n}\n";
+    }
+    src << R"HIP(
+}
+if (nfi != 0) {
+    outcome = HY_OC_ERR_NF_STATE;
+    if (l == 0u && live) atomicAdd(a.counters, 1u);
+    break;
+}
+outcome = (h == lim) ? HY_OC_TIME_LIMIT : HY_OC_SUCCESS;
+if (a.mode != 1) break;
+n_steps += (h != 0.0) ? 1u : 0u;
+if (outcome == HY_OC_SUCCESS) {
+    const double ah = fabs(h);
+    min_h = hy_min(min_h, ah);
+    max_h = hy_max(max_h, ah);
+}
+if (h == rem.hi) break;
+{
+    hy_df tcur; tcur.hi = t_hi; tcur.lo = t_lo;
+    rem = hy_df_sub(tfin, tcur);
+}
+++iter;
+if (iter == a.max_steps) { outcome = HY_OC_STEP_LIMIT; break; }
+}
+)HIP";
+    for (std::uint32_t r = 0; r < sv_rounds; ++r) {
+        src << "if (svalid" << r << " && live) a.state[(u64)svi" << r << " * N + s] = xs" << r << ";\n";
+    }
+    src << R"HIP(
+if (l == 0u && live) {
+    if (a.mode != 2) {
+        a.time_hi[s] = t_hi;
+        a.time_lo[s] = t_lo;
+    } else {
+        const_cast<double *>(a.lim)[s] = last_h;
+    }
+    a.last_h[s] = last_h;
+    a.outcome[s] = outcome;
+    if (a.mode == 1) {
+        a.min_h[s] = min_h;
+        a.max_h[s] = max_h;
+        a.n_steps[s] = n_steps;
+    }
+}
+}
+}
+)HIP";
+
+    auto text = src.str();
+    // SPW macro used by the work-queue code.
+    const std::string spw_def = "#define SPW " + std::to_string(spw) + "u\n";
+    ret.source = spw_def + text;
+    ret.kernel_name = "hy_taylor";
+    ret.dout_name = "hy_dout";
+    ret.block_size = bs;
+    ret.lanes_per_system = L;
+    ret.lds_bytes = 0;
+    ret.mode = emit_mode::cluster;
+    ret.n_statements = e.n_stmt;
+    ret.scratch_per_wave = static_cast<std::uint64_t>(order + 1u) * spw * n_col;
+    ret.persistent = true;
+    ret.notes = "cluster mode: " + std::to_string(nc) + " clusters of " + std::to_string(t0.size())
+                + " nodes, L=" + std::to_string(L) + ", " + std::to_string(pl.n_slots) + " LDS slots, "
+                + std::to_string(pl.groups.size()) + " glue groups, " + std::to_string(utbl.size())
+                + " slot tables";
+    (void)n_slots_tot;
+    return ret;
+}
+
+} // namespace heyoka_amd

@@ -1,0 +1,445 @@
+// Internal pieces shared by the HIP code generators (hip_emit.cpp, hip_emit_cluster.cpp).
+#pragma once
+
+#include <cassert>
+#include <cmath>
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "hip_emit.hpp"
+
+namespace heyoka_amd::emit_detail
+{
+
+// Common device-side prelude: argument block, double-length arithmetic, helpers.
+extern const char *const prelude;
+
+// Scaling + safety factor of the step-size selector, folded on the host in double precision.
+double rhofac(std::uint32_t order);
+
+// Dense-output kernel.
+void emit_dout(std::ostringstream &os, const taylor_program &p, const emit_options &opts);
+
+struct ssa_emitter {
+    const taylor_program &p;
+    std::uint32_t order;
+    std::ostringstream os;
+    std::uint64_t counter = 0;
+    std::uint64_t n_stmt = 0;
+    // vals[k * n_u + u]: name (or literal) of the order-k coefficient of u variable u.
+    std::vector<std::string> vals;
+
+    ssa_emitter(const taylor_program &prog, std::uint32_t ord)
+        : p(prog), order(ord), vals(static_cast<std::size_t>(prog.n_u) * (ord + 1u))
+    {
+    }
+
+    std::string &val(std::uint32_t u, std::uint32_t k)
+    {
+        return vals[static_cast<std::size_t>(k) * p.n_u + u];
+    }
+
+    std::string def(const std::string &expr)
+    {
+        const auto name = "t" + std::to_string(counter++);
+        os << "const double " << name << " = " << expr << ";\n";
+        ++n_stmt;
+        return name;
+    }
+
+    // Pairwise reduction (reference: src/detail/llvm_helpers_algo.cpp:271-308).
+    std::string pairwise(std::vector<std::string> v, const char *op)
+    {
+        assert(!v.empty());
+        while (v.size() != 1u) {
+            std::vector<std::string> nv;
+            for (std::size_t i = 0; i < v.size(); i += 2u) {
+                if (i + 1u == v.size()) {
+                    nv.push_back(v[i]);
+                } else {
+                    nv.push_back(def(v[i] + " " + op + " " + v[i + 1u]));
+                }
+            }
+            v.swap(nv);
+        }
+        return v[0];
+    }
+
+    std::string pairwise_sum(std::vector<std::string> v)
+    {
+        return pairwise(std::move(v), "+");
+    }
+
+    // Optional replacement names for specific numerical operands (keyed by address of the operand in
+    // the program): used by the cluster generator for constants that differ between isomorphic clusters.
+    std::map<const operand *, std::string> numpar_override;
+
+    std::string numpar(const operand &o) const
+    {
+        assert(o.type != operand::kind::uvar);
+        if (const auto it = numpar_override.find(&o); it != numpar_override.end()) {
+            return it->second;
+        }
+        if (o.type == operand::kind::num) {
+            return fp_literal(o.value);
+        }
+        return "par_" + std::to_string(o.idx);
+    }
+
+    static bool is_var(const operand &o)
+    {
+        return o.type == operand::kind::uvar;
+    }
+
+    static std::string mul(const std::string &a, const std::string &b)
+    {
+        return a + " * " + b;
+    }
+
+    // Exponentiation by squaring (reference: pow_ebs(), src/math/pow.cpp:136-152).
+    std::string pow_ebs(const std::string &base, std::uint32_t e)
+    {
+        if (e == 0u) {
+            return "1.0";
+        }
+        if (e == 1u) {
+            return base;
+        }
+        const auto sq = def(mul(base, base));
+        if (e % 2u == 0u) {
+            return pow_ebs(sq, e / 2u);
+        }
+        const auto tmp = pow_ebs(sq, (e - 1u) / 2u);
+        return def(mul(base, tmp));
+    }
+
+    // Order-0 evaluation of pow (reference: get_pow_eval_algo(), src/math/pow.cpp:292-355).
+    std::string pow_eval(const std::string &b, double ex)
+    {
+        if (std::isfinite(ex) && ex == std::trunc(ex) && std::abs(ex) <= 16.) {
+            if (ex >= 0) {
+                return pow_ebs(b, static_cast<std::uint32_t>(ex));
+            }
+            const auto tmp = pow_ebs(b, static_cast<std::uint32_t>(-ex));
+            return def("1.0 / " + tmp);
+        }
+        if (std::isfinite(ex) && ex != std::trunc(ex)) {
+            const auto y = 2 * ex;
+            if (y == std::trunc(y) && std::abs(y) <= 16.) {
+                const auto sq = def("sqrt(" + b + ")");
+                if (y >= 0) {
+                    return pow_ebs(sq, static_cast<std::uint32_t>(y));
+                }
+                const auto tmp = pow_ebs(sq, static_cast<std::uint32_t>(-y));
+                return def("1.0 / " + tmp);
+            }
+        }
+        return def("pow(" + b + ", " + fp_literal(ex) + ")");
+    }
+
+    // Emit the order-k coefficient of node i.
+    void node(std::uint32_t i, std::uint32_t k)
+    {
+        const auto &n = p.nodes[i];
+        const auto u = p.n_eq + i;
+        auto &out = val(u, k);
+        const auto &a = n.args;
+
+        switch (n.kind) {
+            case func_kind::num_identity:
+                out = (k == 0u) ? numpar(a[0]) : "0.0";
+                break;
+            case func_kind::time:
+                // Reference: src/math/time.cpp:81-101.
+                out = (k == 0u) ? "t_hi" : (k == 1u ? "1.0" : "0.0");
+                break;
+            case func_kind::sum: {
+                // Reference: src/math/sum.cpp:185-235.
+                std::vector<std::string> terms;
+                for (const auto &o : a) {
+                    if (is_var(o)) {
+                        terms.push_back(val(o.idx, k));
+                    } else {
+                        terms.push_back(k == 0u ? numpar(o) : "0.0");
+                    }
+                }
+                out = pairwise_sum(std::move(terms));
+                break;
+            }
+            case func_kind::sub: {
+                // Reference: src/detail/sub.cpp:60-124.
+                if (is_var(a[0]) && is_var(a[1])) {
+                    out = def(val(a[0].idx, k) + " - " + val(a[1].idx, k));
+                } else if (is_var(a[0])) {
+                    out = (k == 0u) ? def(val(a[0].idx, 0) + " - " + numpar(a[1])) : val(a[0].idx, k);
+                } else if (is_var(a[1])) {
+                    out = (k == 0u) ? def(numpar(a[0]) + " - " + val(a[1].idx, 0)) : def("-" + val(a[1].idx, k));
+                } else {
+                    out = (k == 0u) ? def(numpar(a[0]) + " - " + numpar(a[1])) : "0.0";
+                }
+                break;
+            }
+            case func_kind::prod: {
+                // Reference: src/math/prod.cpp:314-395.
+                if (a.size() != 2u) {
+                    throw std::invalid_argument("The Taylor derivative of a product can be computed only for "
+                                                "products of 2 terms");
+                }
+                if (is_var(a[0]) && is_var(a[1])) {
+                    std::vector<std::string> terms;
+                    for (std::uint32_t j = 0; j <= k; ++j) {
+                        terms.push_back(def(mul(val(a[0].idx, k - j), val(a[1].idx, j))));
+                    }
+                    out = pairwise_sum(std::move(terms));
+                } else if (!is_var(a[0]) && !is_var(a[1])) {
+                    if (k != 0u) {
+                        out = "0.0";
+                    } else if (a[0].type == operand::kind::num && a[0].value == -1.) {
+                        out = def("-" + numpar(a[1]));
+                    } else {
+                        out = def(mul(numpar(a[0]), numpar(a[1])));
+                    }
+                } else {
+                    const auto &v = is_var(a[0]) ? a[0] : a[1];
+                    const auto &c = is_var(a[0]) ? a[1] : a[0];
+                    if (&c == &a[0] && c.type == operand::kind::num && c.value == -1.) {
+                        out = def("-" + val(v.idx, k));
+                    } else {
+                        out = def(mul(numpar(c), val(v.idx, k)));
+                    }
+                }
+                break;
+            }
+            case func_kind::div: {
+                // Reference: src/detail/div.cpp:62-160.
+                if (is_var(a[1])) {
+                    if (k == 0u) {
+                        const auto num = is_var(a[0]) ? val(a[0].idx, 0) : numpar(a[0]);
+                        out = def(num + " / " + val(a[1].idx, 0));
+                    } else {
+                        std::vector<std::string> terms;
+                        for (std::uint32_t j = 1; j <= k; ++j) {
+                            terms.push_back(def(mul(val(u, k - j), val(a[1].idx, j))));
+                        }
+                        const auto acc = pairwise_sum(std::move(terms));
+                        if (is_var(a[0])) {
+                            out = def("(" + val(a[0].idx, k) + " - " + acc + ") / " + val(a[1].idx, 0));
+                        } else {
+                            out = def("(-" + acc + ") / " + val(a[1].idx, 0));
+                        }
+                    }
+                } else if (is_var(a[0])) {
+                    out = def(val(a[0].idx, k) + " / " + numpar(a[1]));
+                } else {
+                    out = (k == 0u) ? def(numpar(a[0]) + " / " + numpar(a[1])) : "0.0";
+                }
+                break;
+            }
+            case func_kind::sum_sq: {
+                // Reference: src/detail/sum_sq.cpp:100-245.
+                std::vector<std::string> tmp;
+                if (k % 2u == 1u) {
+                    for (const auto &o : a) {
+                        if (is_var(o)) {
+                            std::vector<std::string> terms;
+                            for (std::uint32_t j = 0; j <= (k - 1u) / 2u; ++j) {
+                                terms.push_back(def(mul(val(o.idx, k - j), val(o.idx, j))));
+                            }
+                            tmp.push_back(pairwise_sum(std::move(terms)));
+                        } else {
+                            tmp.emplace_back("0.0");
+                        }
+                    }
+                    const auto s = pairwise_sum(std::move(tmp));
+                    out = def(s + " + " + s);
+                } else {
+                    for (const auto &o : a) {
+                        if (is_var(o)) {
+                            const auto &hv = val(o.idx, k / 2u);
+                            auto sq = def(mul(hv, hv));
+                            if (k > 0u) {
+                                std::vector<std::string> terms;
+                                for (std::uint32_t j = 0; j <= (k - 2u) / 2u; ++j) {
+                                    terms.push_back(def(mul(val(o.idx, k - j), val(o.idx, j))));
+                                }
+                                const auto ps = pairwise_sum(std::move(terms));
+                                const auto ps2 = def(ps + " + " + ps);
+                                sq = def(ps2 + " + " + sq);
+                            }
+                            tmp.push_back(std::move(sq));
+                        } else if (k == 0u) {
+                            tmp.push_back(def(mul(numpar(o), numpar(o))));
+                        } else {
+                            tmp.emplace_back("0.0");
+                        }
+                    }
+                    out = pairwise_sum(std::move(tmp));
+                }
+                break;
+            }
+            case func_kind::pow: {
+                // Reference: src/math/pow.cpp:395-550.
+                if (a[1].type != operand::kind::num) {
+                    throw std::invalid_argument("An invalid argument type was encountered while trying to build "
+                                                "the Taylor derivative of a pow()");
+                }
+                const auto ex = a[1].value;
+                if (!is_var(a[0])) {
+                    out = (k == 0u) ? pow_eval(numpar(a[0]), ex) : "0.0";
+                    break;
+                }
+                const auto b = a[0].idx;
+                if (k == 0u) {
+                    out = pow_eval(val(b, 0), ex);
+                } else if (ex == .5) {
+                    // sqrt() special case.
+                    const auto dv = def(val(u, 0) + " + " + val(u, 0));
+                    std::string fac = val(b, k);
+                    std::vector<std::string> terms;
+                    const auto jmax = (k % 2u == 1u) ? (k - 1u) / 2u : (k - 2u) / 2u;
+                    for (std::uint32_t j = 1; j <= jmax; ++j) {
+                        terms.push_back(def(mul(val(u, k - j), val(u, j))));
+                    }
+                    if (k % 2u == 0u) {
+                        const auto &hv = val(u, k / 2u);
+                        const auto sq = def(mul(hv, hv));
+                        fac = def(fac + " - " + sq);
+                    }
+                    if (!terms.empty()) {
+                        const auto ps = pairwise_sum(std::move(terms));
+                        const auto ps2 = def(ps + " + " + ps);
+                        fac = def(fac + " - " + ps2);
+                    }
+                    out = def(fac + " / " + dv);
+                } else if (ex == 2.) {
+                    // square() special case.
+                    std::vector<std::string> terms;
+                    if (k % 2u == 1u) {
+                        for (std::uint32_t j = 0; j <= (k - 1u) / 2u; ++j) {
+                            terms.push_back(def(mul(val(b, k - j), val(b, j))));
+                        }
+                        const auto ps = pairwise_sum(std::move(terms));
+                        out = def(ps + " + " + ps);
+                    } else {
+                        const auto &hv = val(b, k / 2u);
+                        const auto sq = def(mul(hv, hv));
+                        for (std::uint32_t j = 0; j <= (k - 2u) / 2u; ++j) {
+                            terms.push_back(def(mul(val(b, k - j), val(b, j))));
+                        }
+                        const auto ps = pairwise_sum(std::move(terms));
+                        const auto ps2 = def(ps + " + " + ps);
+                        out = def(ps2 + " + " + sq);
+                    }
+                } else {
+                    std::vector<std::string> terms;
+                    for (std::uint32_t j = 0; j < k; ++j) {
+                        // Scalar factor folded in double like the reference's IR constants:
+                        // order * alpha - j * (alpha + 1).
+                        const double sf = static_cast<double>(k) * ex - static_cast<double>(j) * (ex + 1.);
+                        const auto pr = def(mul(val(b, k - j), val(u, j)));
+                        terms.push_back(def(mul(fp_literal(sf), pr)));
+                    }
+                    const auto acc = pairwise_sum(std::move(terms));
+                    const auto dv = def(mul(fp_literal(static_cast<double>(k)), val(b, 0)));
+                    out = def(acc + " / " + dv);
+                }
+                break;
+            }
+            case func_kind::sin:
+            case func_kind::cos: {
+                // Reference: src/math/sin.cpp:152-192, src/math/cos.cpp:152-185.
+                const bool is_sin = n.kind == func_kind::sin;
+                if (!is_var(a[0])) {
+                    out = (k == 0u) ? def(std::string(is_sin ? "sin(" : "cos(") + numpar(a[0]) + ")") : "0.0";
+                    break;
+                }
+                const auto b = a[0].idx;
+                if (k == 0u) {
+                    out = def(std::string(is_sin ? "sin(" : "cos(") + val(b, 0) + ")");
+                } else {
+                    if (n.deps.size() != 1u) {
+                        throw std::invalid_argument("A hidden dependency vector of size 1 is expected in order to "
+                                                    "compute the Taylor derivative of the sine/cosine");
+                    }
+                    const auto d = n.deps[0];
+                    std::vector<std::string> terms;
+                    for (std::uint32_t j = 1; j <= k; ++j) {
+                        const auto pr = def(mul(val(d, k - j), val(b, j)));
+                        terms.push_back(def(mul(fp_literal(static_cast<double>(j)), pr)));
+                    }
+                    const auto acc = pairwise_sum(std::move(terms));
+                    out = def(acc + " / " + fp_literal(is_sin ? static_cast<double>(k) : -static_cast<double>(k)));
+                }
+                break;
+            }
+            case func_kind::exp: {
+                // Reference: src/math/exp.cpp:84-120.
+                if (!is_var(a[0])) {
+                    out = (k == 0u) ? def("exp(" + numpar(a[0]) + ")") : "0.0";
+                    break;
+                }
+                const auto b = a[0].idx;
+                if (k == 0u) {
+                    out = def("exp(" + val(b, 0) + ")");
+                } else {
+                    std::vector<std::string> terms;
+                    for (std::uint32_t j = 1; j <= k; ++j) {
+                        const auto pr = def(mul(val(u, k - j), val(b, j)));
+                        terms.push_back(def(mul(fp_literal(static_cast<double>(j)), pr)));
+                    }
+                    const auto acc = pairwise_sum(std::move(terms));
+                    out = def(acc + " / " + fp_literal(static_cast<double>(k)));
+                }
+                break;
+            }
+            case func_kind::log: {
+                // Reference: src/math/log.cpp (taylor_diff_log_impl).
+                if (!is_var(a[0])) {
+                    out = (k == 0u) ? def("log(" + numpar(a[0]) + ")") : "0.0";
+                    break;
+                }
+                const auto b = a[0].idx;
+                if (k == 0u) {
+                    out = def("log(" + val(b, 0) + ")");
+                } else {
+                    const auto kf = fp_literal(static_cast<double>(k));
+                    const auto nb0 = def(mul(kf, val(b, 0)));
+                    auto ret = def(mul(kf, val(b, k)));
+                    if (k > 1u) {
+                        std::vector<std::string> terms;
+                        for (std::uint32_t j = 1; j < k; ++j) {
+                            const auto pr = def(mul(val(b, k - j), val(u, j)));
+                            terms.push_back(def(mul(fp_literal(static_cast<double>(j)), pr)));
+                        }
+                        const auto acc = pairwise_sum(std::move(terms));
+                        ret = def(ret + " - " + acc);
+                    }
+                    out = def(ret + " / " + nb0);
+                }
+                break;
+            }
+        }
+    }
+
+    // Order-k coefficient of state variable i (reference: taylor_compute_sv_diff(),
+    // src/taylor_02.cpp:245-287: true division by the order).
+    void sv(std::uint32_t i, std::uint32_t k)
+    {
+        assert(k > 0u);
+        const auto &d = p.sv_defs[i];
+        auto &out = val(i, k);
+        if (d.type == operand::kind::uvar) {
+            out = def(val(d.idx, k - 1u) + " / " + fp_literal(static_cast<double>(k)));
+        } else {
+            out = (k == 1u) ? numpar(d) : "0.0";
+        }
+    }
+};
+
+} // namespace heyoka_amd::emit_detail

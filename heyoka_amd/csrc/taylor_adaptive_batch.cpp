@@ -42,7 +42,7 @@ emit_mode choose_mode()
             return emit_mode::table;
         }
     }
-    return emit_mode::unrolled;
+    return emit_mode::cluster;
 }
 
 } // namespace
@@ -85,6 +85,18 @@ struct tab_core::impl {
     // Set by the lock-step propagate loop to override the device outcomes.
     mutable std::optional<taylor_outcome> prop_res_override;
 
+    [[nodiscard]] bool is_cluster() const
+    {
+        return emitted.mode == emit_mode::cluster;
+    }
+
+    void ensure_tc() const
+    {
+        if (d_tc.bytes() == 0u) {
+            d_tc = device_buffer(static_cast<std::size_t>(dim) * (order + 1u) * N * sizeof(double), device);
+        }
+    }
+
     void ensure_device() const
     {
         if (dmod) {
@@ -106,7 +118,10 @@ struct tab_core::impl {
         d_minh = device_buffer(n * dsz, device);
         d_maxh = device_buffer(n * dsz, device);
         d_nsteps = device_buffer(n * sizeof(unsigned long long), device);
-        d_tc = device_buffer(static_cast<std::size_t>(dim) * (order + 1u) * n * dsz, device);
+        if (!is_cluster()) {
+            // Unrolled mode: the tc buffer doubles as the jet scratch of the kernel.
+            ensure_tc();
+        }
         d_counters = device_buffer(16u * sizeof(unsigned), device);
         host_newer = true;
     }
@@ -175,7 +190,7 @@ struct tab_core::impl {
         a.min_h = d_minh.as<double>();
         a.max_h = d_maxh.as<double>();
         a.n_steps = d_nsteps.as<unsigned long long>();
-        a.tc = d_tc.as<double>();
+        a.tc = is_cluster() ? nullptr : d_tc.as<double>();
         a.N = N;
         a.max_steps = 0;
         a.mode = 0;
@@ -184,12 +199,16 @@ struct tab_core::impl {
     }
 
     // One lock-step sweep: a single step for every lane with the per-lane signed limits 'lims'.
-    void run_step(const std::vector<double> &lims)
+    void run_step(const std::vector<double> &lims, bool wtc)
     {
         before_kernel();
         d_lim.upload(lims.data(), lims.size() * sizeof(double), stream);
         d_counters.zero(stream);
         auto a = base_args();
+        if (wtc && is_cluster()) {
+            ensure_tc();
+            a.tc = d_tc.as<double>();
+        }
         a.mode = 0;
         dmod->launch_taylor(a);
         after_kernel();
@@ -353,7 +372,7 @@ tab_core::tab_core(const tab_core &o) : m_impl(std::make_unique<impl>())
         s.d_lasth.download(s.last_h.data(), s.last_h.size() * sizeof(double), s.stream);
         s.lasth_dev_newer = false;
     }
-    if (s.tc_dev_newer && s.dmod) {
+    if (s.tc_dev_newer && s.dmod && s.d_tc.bytes() != 0u) {
         s.tc.resize(static_cast<std::size_t>(s.dim) * (s.order + 1u) * s.N);
         s.d_tc.download(s.tc.data(), s.tc.size() * sizeof(double), s.stream);
         s.tc_dev_newer = false;
@@ -545,7 +564,7 @@ const std::vector<double> &tab_core::get_tc() const
     if (d.tc.size() != sz) {
         d.tc.assign(sz, 0.);
     }
-    if (d.tc_dev_newer && d.dmod) {
+    if (d.tc_dev_newer && d.dmod && d.d_tc.bytes() != 0u) {
         d.d_tc.download(d.tc.data(), sz * sizeof(double), d.stream);
         d.tc_dev_newer = false;
     }
@@ -578,6 +597,7 @@ const std::vector<double> &tab_core::update_d_output(const std::vector<double> &
                                     + std::to_string(t.size()));
     }
     d.ensure_device();
+    d.ensure_tc();
     std::vector<double> hs(d.N);
     if (rel_time) {
         hs = t;
@@ -625,17 +645,17 @@ const std::vector<std::tuple<taylor_outcome, double, double, std::size_t>> &tab_
 }
 
 // ---- stepping (reference: src/taylor_adaptive_batch.cpp:1039-1080) ----
-void tab_core::step(bool)
+void tab_core::step(bool wtc)
 {
-    m_impl->run_step(std::vector<double>(m_impl->N, std::numeric_limits<double>::infinity()));
+    m_impl->run_step(std::vector<double>(m_impl->N, std::numeric_limits<double>::infinity()), wtc);
 }
 
-void tab_core::step_backward(bool)
+void tab_core::step_backward(bool wtc)
 {
-    m_impl->run_step(std::vector<double>(m_impl->N, -std::numeric_limits<double>::infinity()));
+    m_impl->run_step(std::vector<double>(m_impl->N, -std::numeric_limits<double>::infinity()), wtc);
 }
 
-void tab_core::step(const std::vector<double> &max_delta_ts, bool)
+void tab_core::step(const std::vector<double> &max_delta_ts, bool wtc)
 {
     auto &d = *m_impl;
     if (max_delta_ts.size() != d.N) {
@@ -648,7 +668,7 @@ void tab_core::step(const std::vector<double> &max_delta_ts, bool)
         throw std::invalid_argument("Cannot invoke the step() function of an adaptive Taylor integrator in batch "
                                     "mode if one of the max timesteps is nan");
     }
-    d.run_step(max_delta_ts);
+    d.run_step(max_delta_ts, wtc);
 }
 
 // Reference: propagate_for_impl(), src/taylor_adaptive_batch.cpp:1082-1118.
@@ -676,7 +696,7 @@ void tab_core::propagate_for(const std::vector<double> &delta_ts, std::size_t ma
 
 // Reference: propagate_until_impl(), src/taylor_adaptive_batch.cpp:1137-1534.
 void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_steps,
-                               const std::vector<double> &max_delta_ts, const cb_t &cb, bool, bool c_out)
+                               const std::vector<double> &max_delta_ts, const cb_t &cb, bool wtc, bool c_out)
 {
     auto &d = *m_impl;
     const auto N = d.N;
@@ -752,6 +772,10 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
         } else {
             d.d_lim.upload(max_delta_ts.data(), max_delta_ts.size() * sizeof(double), d.stream);
         }
+        if (wtc && d.is_cluster()) {
+            d.ensure_tc();
+            a.tc = d.d_tc.as<double>();
+        }
         a.mode = 1;
         a.max_steps = max_steps;
         d.dmod->launch_taylor(a);
@@ -780,7 +804,7 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
             cur_max[i] = static_cast<double>(dt_limit);
         }
 
-        d.run_step(cur_max);
+        d.run_step(cur_max, wtc);
         d.fetch_step_res();
         d.to_host();
 
@@ -872,6 +896,7 @@ double *tab_core::device_time_lo()
 double *tab_core::device_tc()
 {
     m_impl->ensure_device();
+    m_impl->ensure_tc();
     return m_impl->d_tc.as<double>();
 }
 
@@ -985,7 +1010,8 @@ void tab_core::raw_step(double *d_state, const double *d_pars, const double *d_t
     a.lim = d_h;
     a.last_h = lh.as<double>();
     a.outcome = oc.as<long long>();
-    if (d_tc == nullptr) {
+    d.d_counters.zero(d.stream);
+    if (d_tc == nullptr && !d.is_cluster()) {
         tc_scratch = device_buffer(static_cast<std::size_t>(d.dim) * (d.order + 1u) * n_systems * sizeof(double),
                                    d.device);
         a.tc = tc_scratch.as<double>();

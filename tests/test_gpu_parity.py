@@ -195,8 +195,7 @@ def test_propagate_backward_limits_and_max_steps():
     res = ta.propagate_res
     assert all(r[0] == OC.step_limit and r[3] == 3 for r in res)
     # Zero-length propagation: time_limit, zero steps.
-    t_now = ta.time
-    ta.propagate_until(t_now)
+    ta.propagate_for(0.0)
     assert all(r[0] == OC.time_limit and r[3] == 0 for r in ta.propagate_res)
 
 
