@@ -34,9 +34,9 @@ def all_gather_states(local, group=None):
     loc2 = local.reshape(rows, -1)
     if len(set(sizes)) == 1:
         # One bulk collective: gather contiguous [world, rows, n] then stitch lanes.
-        out = torch.empty((world,) + tuple(loc2.shape), dtype=loc2.dtype, device=loc2.device)
+        out = torch.empty((world * rows, loc2.shape[1]), dtype=loc2.dtype, device=loc2.device)
         dist.all_gather_into_tensor(out, loc2.contiguous(), group=group)
-        res = out.permute(1, 0, 2).reshape(rows, -1)
+        res = out.view(world, rows, -1).permute(1, 0, 2).reshape(rows, -1)
     else:
         nmax = max(sizes)
         pad = torch.zeros((rows, nmax), dtype=loc2.dtype, device=loc2.device)

@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""Summarise rocprofv3 (rocpd sqlite) outputs into the small text/JSON files kept under profiles/.
+
+usage: python profiles/summarize_rocprof.py <out_prefix> <ktrace.db> [<pmc_fetch.db> <pmc_write.db>]
+Writes <out_prefix>_kernel_stats.txt (per-kernel calls / total / avg / min / max, like
+`rocprofv3 --kernel-trace --stats`) and, if counter databases are given, <out_prefix>_pmc.json with
+the per-dispatch FETCH_SIZE / WRITE_SIZE of the stepper kernel (KiB, as reported) and the derived HBM
+traffic per launch."""
+import json
+import sqlite3
+import sys
+
+
+def kernel_stats(path):
+    cur = sqlite3.connect(path).cursor()
+    rows = list(cur.execute(
+        "select name, count(*), sum(end - start), avg(end - start), min(end - start), max(end - start) "
+        "from kernels group by name order by 3 desc"))
+    tot = sum(r[2] for r in rows) or 1
+    lines = ["%-64s %6s %14s %14s %14s %14s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "pct")]
+    for r in rows[:12]:
+        lines.append("%-64s %6d %14d %14.0f %14d %14d %6.2f%%" % (r[0][:64], r[1], r[2], r[3], r[4], r[5], 100.0 * r[2] / tot))
+    return "\n".join(lines), rows
+
+
+def counters(path, kernel="hy_taylor"):
+    cur = sqlite3.connect(path).cursor()
+    return list(cur.execute(
+        "select dispatch_id, counter_name, value, vgpr_count, accum_vgpr_count, sgpr_count, lds_block_size, "
+        "scratch_size, grid_size, workgroup_size, end - start from counters_collection where kernel_name = ? "
+        "order by dispatch_id", (kernel,)))
+
+
+def main():
+    prefix, ktrace = sys.argv[1], sys.argv[2]
+    txt, rows = kernel_stats(ktrace)
+    with open(prefix + "_kernel_stats.txt", "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats (rocpd database summarised by profiles/summarize_rocprof.py)\n")
+        f.write(txt + "\n")
+    print(txt)
+    if len(sys.argv) >= 5:
+        fe, wr = counters(sys.argv[3]), counters(sys.argv[4])
+        out = {
+            "note": "FETCH_SIZE / WRITE_SIZE in KiB as reported by rocprofv3 (separate --pmc passes, no tracing "
+                    "domains). MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads 1/2 of the bytes of a wide (16 B/lane) "
+                    "coalesced stream; this kernel uses 8 B/lane accesses, for which the counter is uncalibrated, so "
+                    "both the raw and the doubled figure are given. Infinity-Cache hits are counted.",
+            "dispatches": [],
+        }
+        for a, b in zip(fe, wr):
+            out["dispatches"].append({
+                "dispatch_id": a[0], "fetch_kib": a[2], "write_kib": b[2], "vgpr": a[3], "agpr": a[4], "sgpr": a[5],
+                "lds_bytes": a[6], "scratch_bytes_per_lane": a[7], "grid": a[8], "workgroup": a[9],
+                "duration_ns_fetch_pass": a[10], "duration_ns_write_pass": b[10],
+            })
+        timed = out["dispatches"][1:] or out["dispatches"]
+        n = len(timed)
+        fetch = sum(d["fetch_kib"] for d in timed) / n * 1024.0
+        write = sum(d["write_kib"] for d in timed) / n * 1024.0
+        out["per_launch_avg"] = {
+            "fetch_bytes_raw": fetch, "fetch_bytes_x2": 2 * fetch, "write_bytes": write,
+            "traffic_bytes_raw": fetch + write, "traffic_bytes_fetch_x2": 2 * fetch + write,
+            "kernel_ns": sum(d["duration_ns_fetch_pass"] for d in timed) / n,
+        }
+        with open(prefix + "_pmc.json", "w") as f:
+            json.dump(out, f, indent=1)
+        print(json.dumps(out["per_launch_avg"], indent=1))
+
+
+if __name__ == "__main__":
+    main()
