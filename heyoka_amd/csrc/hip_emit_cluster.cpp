@@ -26,10 +26,12 @@
 // The arithmetic of every node is emitted by the same ssa_emitter as the unrolled mode (reference
 // formulas cited in hip_emit_detail.hpp).
 #include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <numeric>
 #include <set>
 
+#include "hip_emit_cluster_plan.hpp"
 #include "hip_emit_detail.hpp"
 
 namespace heyoka_amd
@@ -40,10 +42,9 @@ namespace
 
 using emit_detail::ssa_emitter;
 
-bool is_var(const operand &o)
-{
-    return o.type == operand::kind::uvar;
-}
+using cluster_detail::cluster_plan;
+using cluster_detail::glue_group;
+using cluster_detail::is_var;
 
 // u variables whose *full history* node n needs (besides, possibly, its own).
 std::vector<std::uint32_t> history_operands(const dc_node &n)
@@ -138,31 +139,10 @@ struct union_find {
     }
 };
 
-struct glue_group {
-    std::uint32_t level = 0;
-    std::string key;
-    std::vector<std::uint32_t> nodes; // u indices
-};
-
-struct cluster_plan {
-    std::uint32_t n_eq = 0, n_u = 0, L = 1, spw = 64;
-    std::vector<std::vector<std::uint32_t>> clusters; // member u indices (ascending), all isomorphic
-    std::vector<int> cluster_of;                      // per u: cluster id or -1
-    std::uint32_t cluster_level = 1;
-    // Template-relative descriptions.
-    std::vector<std::vector<std::uint32_t>> ext_u;   // [cluster][e] -> u index of the e-th external input
-    std::vector<std::pair<std::uint32_t, std::uint32_t>> cst_pos; // (template position, arg index) of per-lane constants
-    std::vector<std::vector<double>> cst_val;         // [cluster][slot]
-    std::vector<std::uint32_t> out_pos;               // template positions whose value is exported
-    std::vector<int> slot_of;                         // per u: LDS slot or -1
-    std::uint32_t n_slots = 0, n_dummy = 0;
-    std::vector<glue_group> groups;                   // sorted by level
-    std::uint32_t max_level = 0;
-    std::vector<std::uint32_t> lvl;                   // per u
-};
+} // namespace
 
 // Build the plan; returns an empty string on success, otherwise the reason why cluster mode is not applicable.
-std::string make_plan(const taylor_program &p, std::uint32_t order, cluster_plan &pl)
+std::string cluster_detail::make_plan(const taylor_program &p, std::uint32_t order, cluster_plan &pl)
 {
     const auto n_eq = p.n_eq, n_u = p.n_u;
     pl.n_eq = n_eq;
@@ -487,17 +467,16 @@ std::string make_plan(const taylor_program &p, std::uint32_t order, cluster_plan
     return {};
 }
 
-} // namespace
-
+// Version 1 of the cluster kernel: separate state-variable phase, 4 LDS synchronisations per order.
 // Returns a module with an empty source (and the reason in why_not) if cluster mode is not applicable.
-emitted_module emit_cluster_or_empty(const taylor_program &p, const emit_options &opts, std::string &why_not)
+emitted_module emit_cluster_v1(const taylor_program &p, const emit_options &opts, std::string &why_not)
 {
     using emit_detail::prelude;
     using emit_detail::rhofac;
 
     emitted_module ret;
     cluster_plan pl;
-    why_not = make_plan(p, opts.order, pl);
+    why_not = cluster_detail::make_plan(p, opts.order, pl);
     if (!why_not.empty()) {
         return ret;
     }
@@ -987,6 +966,28 @@ if (l == 0u && live) {
                 + " slot tables";
     (void)n_slots_tot;
     return ret;
+}
+
+//V2_PLACEHOLDER
+
+emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts, std::string &why_not);
+
+// Returns a module with an empty source (and the reason in why_not) if cluster mode is not applicable.
+emitted_module emit_cluster_or_empty(const taylor_program &p, const emit_options &opts, std::string &why_not)
+{
+    if (std::getenv("HEYOKA_AMD_CLUSTER_V1") == nullptr) {
+        std::string why2;
+        auto m = emit_cluster_v2(p, opts, why2);
+        if (!m.source.empty()) {
+            return m;
+        }
+        auto m1 = emit_cluster_v1(p, opts, why_not);
+        if (!m1.source.empty()) {
+            m1.notes += " (pipelined cluster kernel not applicable: " + why2 + ")";
+        }
+        return m1;
+    }
+    return emit_cluster_v1(p, opts, why_not);
 }
 
 } // namespace heyoka_amd

@@ -1,0 +1,596 @@
+// Cluster code generation, version 2: software-pipelined orders.
+//
+// Same partition as hip_emit_cluster.cpp (clusters in registers, glue through an LDS slab), with the
+// per-order critical path shortened:
+//   * state-variable recursions are *fused* into the glue round that produces their right-hand side
+//     (x^[k+1] = rhs^[k] / (k + 1) is computed by the lane that just computed rhs^[k]; chains such as
+//     x' = v, v' = a ride along), so that an order needs one LDS synchronisation per dependency level
+//     (2 for N-body systems) instead of two extra ones for a separate state-variable phase;
+//   * the LDS slab is double-buffered by order parity (no write-after-read hazards between orders);
+//   * the history part of every convolution of order k + 1 (terms without order-(k+1) operands) is
+//     emitted at the end of order k, where it overlaps the latency of the glue exchange; only the
+//     1-2 terms involving new coefficients remain on the critical path (ssa_emitter::node_partial /
+//     node_finish). Sums are FMA chains;
+//   * divisions by the (constant) order use the exact FMA-based sequence ssa_emitter::div_const().
+#include <algorithm>
+#include <map>
+#include <set>
+
+#include "hip_emit_cluster_plan.hpp"
+#include "hip_emit_detail.hpp"
+
+namespace heyoka_amd
+{
+
+emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts, std::string &why_not)
+{
+    using cluster_detail::cluster_plan;
+    using cluster_detail::is_var;
+    using emit_detail::prelude;
+    using emit_detail::rhofac;
+    using emit_detail::ssa_emitter;
+
+    emitted_module ret;
+    cluster_plan pl;
+    why_not = cluster_detail::make_plan(p, opts.order, pl);
+    if (!why_not.empty()) {
+        return ret;
+    }
+
+    const auto n_eq = p.n_eq, order = opts.order, L = pl.L, spw = pl.spw;
+    const std::uint32_t bs = 256, wpb = bs / 64u;
+    const auto nc = static_cast<std::uint32_t>(pl.clusters.size());
+    const auto &t0 = pl.clusters[0];
+    const auto n_ext = static_cast<std::uint32_t>(pl.ext_u[0].size());
+    const auto n_out = static_cast<std::uint32_t>(pl.out_pos.size());
+    const auto n_cst = static_cast<std::uint32_t>(pl.cst_pos.size());
+
+    // ---- 1. Anchor every state variable to the glue node at the root of its rhs chain. ----
+    // anchor[i] = glue u variable, depth[i] >= 1.
+    std::vector<int> anchor(n_eq, -1);
+    std::vector<std::uint32_t> depth(n_eq, 0);
+    for (std::uint32_t i = 0; i < n_eq; ++i) {
+        std::uint32_t cur = i, d = 0;
+        std::set<std::uint32_t> seen;
+        for (;;) {
+            if (!seen.insert(cur).second) {
+                why_not = "cyclic chain of state-variable definitions";
+                return ret;
+            }
+            const auto &def = p.sv_defs[cur];
+            ++d;
+            if (def.type != operand::kind::uvar) {
+                why_not = "a state variable is defined by a constant or a parameter";
+                return ret;
+            }
+            if (def.idx < n_eq) {
+                cur = def.idx;
+                continue;
+            }
+            if (pl.cluster_of[def.idx] != -1) {
+                why_not = "a state variable is defined directly by a cluster member";
+                return ret;
+            }
+            anchor[i] = static_cast<int>(def.idx);
+            depth[i] = d;
+            break;
+        }
+    }
+    // att[u] = state variables anchored at glue node u, sorted by depth.
+    std::map<std::uint32_t, std::vector<std::uint32_t>> att;
+    for (std::uint32_t i = 0; i < n_eq; ++i) {
+        att[static_cast<std::uint32_t>(anchor[i])].push_back(i);
+    }
+    for (auto &[u, v] : att) {
+        std::sort(v.begin(), v.end(), [&](std::uint32_t a, std::uint32_t b) { return depth[a] < depth[b]; });
+        for (std::size_t j = 0; j < v.size(); ++j) {
+            // Chain shape: depths 1, 2, 3, ... each defined by the previous one (or by the anchor).
+            if (depth[v[j]] != j + 1u) {
+                why_not = "branching state-variable chains";
+                return ret;
+            }
+            const auto &def = p.sv_defs[v[j]];
+            const auto expect = (j == 0u) ? u : v[j - 1u];
+            if (def.idx != expect) {
+                why_not = "branching state-variable chains";
+                return ret;
+            }
+        }
+    }
+    // All the nodes of a glue group must carry the same number of attached variables.
+    std::vector<std::uint32_t> grp_natt(pl.groups.size(), 0);
+    for (std::size_t g = 0; g < pl.groups.size(); ++g) {
+        const auto &nodes = pl.groups[g].nodes;
+        const auto it0 = att.find(nodes[0]);
+        const auto n0 = it0 == att.end() ? 0u : static_cast<std::uint32_t>(it0->second.size());
+        for (const auto u : nodes) {
+            const auto it = att.find(u);
+            const auto n = it == att.end() ? 0u : static_cast<std::uint32_t>(it->second.size());
+            if (n != n0) {
+                why_not = "glue nodes of one group with different state-variable chains";
+                return ret;
+            }
+        }
+        grp_natt[g] = n0;
+    }
+
+    // ---- 2. LDS layout: every slot double-buffered by order parity. ----
+    const std::uint32_t max_round_outputs = std::max<std::uint32_t>(n_out, 1u);
+    const auto dummy_base = pl.n_slots;
+    const auto n_slots_tot = pl.n_slots + max_round_outputs;
+    const auto buf_stride = n_slots_tot;                 // doubles between the two parity buffers
+    const auto slab_stride = (2u * n_slots_tot) | 1u;    // doubles per system
+
+    // ---- 3. Tables. ----
+    std::vector<std::vector<std::uint32_t>> utbl;
+    std::vector<std::vector<double>> dtbl;
+    const auto add_utbl = [&](std::vector<std::uint32_t> v) {
+        // Deduplicate identical tables.
+        for (std::size_t t = 0; t < utbl.size(); ++t) {
+            if (utbl[t] == v) {
+                return t;
+            }
+        }
+        utbl.push_back(std::move(v));
+        return utbl.size() - 1u;
+    };
+    const auto add_dtbl = [&](std::vector<double> v) {
+        dtbl.push_back(std::move(v));
+        return dtbl.size() - 1u;
+    };
+    const auto utname = [](std::size_t t) { return "ut" + std::to_string(t); };
+    const auto dtname = [](std::size_t t) { return "dt" + std::to_string(t); };
+
+    ssa_emitter e(p, order);
+    auto &os = e.os;
+
+    std::vector<std::size_t> ext_tbl(n_ext), out_tbl(n_out), cst_tbl(n_cst);
+    for (std::uint32_t x = 0; x < n_ext; ++x) {
+        std::vector<std::uint32_t> v(L);
+        for (std::uint32_t l = 0; l < L; ++l) {
+            v[l] = static_cast<std::uint32_t>(pl.slot_of[pl.ext_u[l < nc ? l : 0u][x]]);
+        }
+        ext_tbl[x] = add_utbl(std::move(v));
+    }
+    for (std::uint32_t x = 0; x < n_out; ++x) {
+        std::vector<std::uint32_t> v(L);
+        for (std::uint32_t l = 0; l < L; ++l) {
+            v[l] = l < nc ? static_cast<std::uint32_t>(pl.slot_of[pl.clusters[l][pl.out_pos[x]]]) : dummy_base + x;
+        }
+        out_tbl[x] = add_utbl(std::move(v));
+    }
+    for (std::uint32_t x = 0; x < n_cst; ++x) {
+        std::vector<double> v(L);
+        for (std::uint32_t l = 0; l < L; ++l) {
+            v[l] = pl.cst_val[l < nc ? l : 0u][x];
+        }
+        cst_tbl[x] = add_dtbl(std::move(v));
+        const auto [q, a] = pl.cst_pos[x];
+        e.numpar_override[&p.nodes[t0[q] - n_eq].args[a]] = "ccst" + std::to_string(x);
+    }
+
+    // Glue rounds (+ the owner slots of the attached state variables).
+    struct owner_slot {
+        std::size_t out_tbl = 0;  // slab slot of the state variable
+        std::size_t var_tbl = 0;  // state-variable index (for the global state array)
+        std::uint32_t col = 0;    // jet column block (col * L + l)
+        std::vector<std::string> xname; // SSA names of the coefficients, by order
+    };
+    struct glue_round {
+        std::vector<std::size_t> arg_tbl;
+        std::size_t out_tbl = 0;
+        std::uint32_t n_valid = 0; // lanes l < n_valid own a real node
+        bool exported = true;
+        std::vector<owner_slot> owners;
+    };
+    std::vector<std::vector<glue_round>> rounds(pl.groups.size());
+    std::uint32_t n_own = 0;
+    // A glue node needs a slab slot only if somebody reads it through the slab.
+    std::vector<char> glue_read(p.n_u, 0);
+    for (const auto &n : p.nodes) {
+        for (const auto &o : n.args) {
+            if (is_var(o)) {
+                glue_read[o.idx] = 1;
+            }
+        }
+    }
+    for (std::size_t g = 0; g < pl.groups.size(); ++g) {
+        const auto &grp = pl.groups[g];
+        const auto n_nodes = static_cast<std::uint32_t>(grp.nodes.size());
+        const auto n_rounds = (n_nodes + L - 1u) / L;
+        const auto &n0 = p.nodes[grp.nodes[0] - n_eq];
+        for (std::uint32_t r = 0; r < n_rounds; ++r) {
+            glue_round gr;
+            gr.n_valid = std::min(L, n_nodes - r * L);
+            const auto node_of = [&](std::uint32_t l) {
+                const auto j = r * L + l;
+                return grp.nodes[j < n_nodes ? j : r * L];
+            };
+            for (std::size_t a = 0; a < n0.args.size(); ++a) {
+                if (is_var(n0.args[a])) {
+                    std::vector<std::uint32_t> v(L);
+                    for (std::uint32_t l = 0; l < L; ++l) {
+                        v[l] = static_cast<std::uint32_t>(pl.slot_of[p.nodes[node_of(l) - n_eq].args[a].idx]);
+                    }
+                    gr.arg_tbl.push_back(add_utbl(std::move(v)));
+                } else if (n0.args[a].type == operand::kind::num) {
+                    std::vector<double> v(L);
+                    for (std::uint32_t l = 0; l < L; ++l) {
+                        v[l] = p.nodes[node_of(l) - n_eq].args[a].value;
+                    }
+                    gr.arg_tbl.push_back(add_dtbl(std::move(v)));
+                } else {
+                    gr.arg_tbl.push_back(0);
+                }
+            }
+            bool any_read = false;
+            std::vector<std::uint32_t> v(L);
+            for (std::uint32_t l = 0; l < L; ++l) {
+                const auto j = r * L + l;
+                v[l] = j < n_nodes ? static_cast<std::uint32_t>(pl.slot_of[grp.nodes[j]]) : dummy_base;
+                any_read = any_read || (j < n_nodes && glue_read[grp.nodes[j]] != 0);
+            }
+            gr.exported = any_read;
+            gr.out_tbl = add_utbl(std::move(v));
+            for (std::uint32_t a = 0; a < grp_natt[g]; ++a) {
+                owner_slot ow;
+                std::vector<std::uint32_t> vs(L), vv(L);
+                for (std::uint32_t l = 0; l < L; ++l) {
+                    const auto var = att.at(node_of(l))[a];
+                    vs[l] = (r * L + l < n_nodes) ? static_cast<std::uint32_t>(pl.slot_of[var]) : dummy_base;
+                    vv[l] = var;
+                }
+                ow.out_tbl = add_utbl(std::move(vs));
+                ow.var_tbl = add_utbl(std::move(vv));
+                ow.col = n_own++;
+                ow.xname.resize(order + 1u);
+                gr.owners.push_back(std::move(ow));
+            }
+            rounds[g].push_back(std::move(gr));
+        }
+    }
+    if (n_own == 0u) {
+        why_not = "no state variable could be attached to a glue round";
+        return ret;
+    }
+    const auto n_col = n_own * L;
+
+    // ---- 4. Emission helpers. ----
+    const auto slabk = [&](std::uint32_t k, const std::string &tbl) {
+        // Parity buffer of order k.
+        return (k % 2u == 0u) ? ("slab[" + tbl + "]") : ("slab[" + tbl + " + " + std::to_string(buf_stride) + "u]");
+    };
+    const auto jet_at = [&](std::uint32_t k, std::uint32_t col) {
+        return "jetl[" + std::to_string(static_cast<std::uint64_t>(k) * spw * n_col + static_cast<std::uint64_t>(col) * L)
+               + "]";
+    };
+    const auto sync = [&]() { os << "HY_WSYNC();\n"; };
+
+    // Owner-slot bookkeeping when a new coefficient of a state variable is produced.
+    const auto publish_sv = [&](owner_slot &ow, std::uint32_t k, const std::string &name, const std::string &valid) {
+        ow.xname[k] = name;
+        os << slabk(k, utname(ow.out_tbl)) << " = " << name << ";\n";
+        os << jet_at(k, ow.col) << " = " << name << ";\n";
+        const char *acc = (k == 0u) ? "m0" : (k == order ? "mo" : (k == order - 1u ? "mom1" : nullptr));
+        if (acc != nullptr) {
+            os << "if (" << valid << ") " << acc << " = hy_max(" << acc << ", fabs(" << name << "));\n";
+        }
+    };
+
+    const auto emit_glue_round = [&](std::size_t g, std::uint32_t r, std::uint32_t k) {
+        const auto &grp = pl.groups[g];
+        auto &gr = rounds[g][r];
+        const auto rep = grp.nodes[0];
+        const auto &n0 = p.nodes[rep - n_eq];
+        const auto saved = e.numpar_override;
+        std::vector<std::pair<std::uint32_t, std::string>> saved_vals;
+        for (std::size_t a = 0; a < n0.args.size(); ++a) {
+            const auto &o = n0.args[a];
+            if (is_var(o)) {
+                const auto nm = e.def(slabk(k, utname(gr.arg_tbl[a])));
+                saved_vals.emplace_back(o.idx, e.val(o.idx, k));
+                e.val(o.idx, k) = nm;
+            } else if (o.type == operand::kind::num) {
+                e.numpar_override[&o] = dtname(gr.arg_tbl[a]);
+            }
+        }
+        if (n0.kind == func_kind::prod && n0.args[0].type == operand::kind::num && n0.args[0].value == -1.) {
+            e.numpar_override.erase(&n0.args[0]);
+        }
+        e.node(rep - n_eq, k);
+        const auto gval = e.val(rep, k);
+        if (gr.exported) {
+            os << slabk(k, utname(gr.out_tbl)) << " = " << gval << ";\n";
+        }
+        for (auto it = saved_vals.rbegin(); it != saved_vals.rend(); ++it) {
+            e.val(it->first, k) = it->second;
+        }
+        e.numpar_override = saved;
+
+        // Fused state-variable recursion: x^[k+1] = src^[k] / (k + 1).
+        const auto valid = "ovalid" + std::to_string(gr.owners.empty() ? 0u : gr.owners[0].col);
+        for (std::size_t a = 0; a < gr.owners.size(); ++a) {
+            const auto src = (a == 0u) ? gval : gr.owners[a - 1u].xname[k];
+            const auto x = e.div_const(src, k + 1u);
+            publish_sv(gr.owners[a], k + 1u, x, "ovalid" + std::to_string(gr.owners[a].col));
+        }
+        (void)valid;
+    };
+
+    const auto emit_cluster = [&](std::uint32_t k) {
+        for (std::uint32_t x = 0; x < n_ext; ++x) {
+            e.val(pl.ext_u[0][x], k) = e.def(slabk(k, utname(ext_tbl[x])));
+        }
+        for (const auto u : t0) {
+            e.node_finish(u - n_eq, k);
+        }
+        for (std::uint32_t x = 0; x < n_out; ++x) {
+            os << slabk(k, utname(out_tbl[x])) << " = " << e.val(t0[pl.out_pos[x]], k) << ";\n";
+        }
+    };
+
+    // ===================== step body =====================
+    os << "double m0 = 0.0, mo = 0.0, mom1 = 0.0;\n";
+    for (auto &rg : rounds) {
+        for (auto &gr : rg) {
+            for (auto &ow : gr.owners) {
+                publish_sv(ow, 0, "xs" + std::to_string(ow.col), "ovalid" + std::to_string(ow.col));
+            }
+        }
+    }
+    sync();
+    for (std::uint32_t k = 0; k < order; ++k) {
+        for (std::uint32_t lev = 1; lev <= pl.max_level; ++lev) {
+            if (lev == pl.cluster_level) {
+                emit_cluster(k);
+            }
+            for (std::size_t g = 0; g < pl.groups.size(); ++g) {
+                if (pl.groups[g].level == lev) {
+                    for (std::uint32_t r = 0; r < rounds[g].size(); ++r) {
+                        emit_glue_round(g, r, k);
+                    }
+                }
+            }
+            if (lev == pl.max_level && k + 1u < order) {
+                // History part of the next order's convolutions: overlaps the exchange latency.
+                for (const auto u : t0) {
+                    e.node_partial(u - n_eq, k + 1u);
+                }
+            }
+            sync();
+        }
+    }
+    const auto body = os.str();
+    os.str("");
+    os.clear();
+
+    // ===================== module text =====================
+    std::ostringstream src;
+    src << "#define SPW " << spw << "u\n";
+    src << prelude;
+    emit_detail::emit_dout(src, p, opts);
+    src << "#define HY_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); "
+           "__builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\"); } while (0)\n";
+    src << "__constant__ unsigned short hy_utbl[" << std::max<std::size_t>(utbl.size(), 1u) * L << "] = {";
+    for (const auto &v : utbl) {
+        for (const auto x : v) {
+            if (x > 65535u) {
+                why_not = "slot / variable index overflow in the lane tables";
+                return ret;
+            }
+            src << x << ",";
+        }
+    }
+    src << "};\n__constant__ double hy_dtbl[" << std::max<std::size_t>(dtbl.size(), 1u) * L << "] = {";
+    for (const auto &v : dtbl) {
+        for (const auto x : v) {
+            src << fp_literal(x) << ",";
+        }
+    }
+    src << "};\n";
+
+    src << "extern \"C\" __global__ void __launch_bounds__(" << bs << ") hy_taylor(const hy_kargs a)\n{\n";
+    src << "__shared__ double lds_slab[" << static_cast<std::uint64_t>(wpb) * spw * slab_stride << "];\n";
+    src << "const unsigned lane = threadIdx.x & 63u;\nconst unsigned wib = threadIdx.x >> 6;\n";
+    src << "const unsigned l = lane % " << L << "u;\nconst unsigned q = lane / " << L << "u;\n";
+    src << "const u64 N = a.N;\n";
+    src << "double *const slab = lds_slab + (wib * " << spw << "u + q) * " << slab_stride << "u;\n";
+    src << "const u64 gwave = (u64)blockIdx.x * " << wpb << "u + wib;\n";
+    src << "double *const jetw = a.scratch + gwave * " << static_cast<std::uint64_t>(order + 1u) * spw * n_col
+        << "ull;\n";
+    src << "double *const jetl = jetw + q * " << n_col << "u + l;\n";
+    for (std::size_t t = 0; t < utbl.size(); ++t) {
+        src << "const unsigned ut" << t << " = hy_utbl[" << t * L << "u + l];\n";
+    }
+    for (std::size_t t = 0; t < dtbl.size(); ++t) {
+        src << "const double dt" << t << " = hy_dtbl[" << t * L << "u + l];\n";
+    }
+    for (std::uint32_t x = 0; x < n_cst; ++x) {
+        src << "const double ccst" << x << " = dt" << cst_tbl[x] << ";\n";
+    }
+    for (const auto &rg : rounds) {
+        for (const auto &gr : rg) {
+            for (const auto &ow : gr.owners) {
+                src << "const bool ovalid" << ow.col << " = l < " << gr.n_valid << "u;\n";
+            }
+        }
+    }
+    src << R"HIP(
+for (;;) {
+// Pull the next group of systems from the device-side work queue.
+u64 base = 0;
+if (lane == 0u) base = atomicAdd((u64 *)(a.counters + 2), (u64)SPW);
+base = __shfl(base, 0, 64);
+if (base >= N) break;
+// NOTE: lanes beyond the end of the ensemble replicate the last system (no side effects).
+const bool live = (base + q) < N;
+const u64 s = live ? (base + q) : (N - 1u);
+double t_hi = a.time_hi[s], t_lo = a.time_lo[s];
+)HIP";
+    for (std::uint32_t i = 0; i < p.n_par; ++i) {
+        src << "const double par_" << i << " = a.pars[(u64)" << i << "u * N + s];\n";
+    }
+    for (const auto &rg : rounds) {
+        for (const auto &gr : rg) {
+            for (const auto &ow : gr.owners) {
+                src << "double xs" << ow.col << " = a.state[(u64)" << utname(ow.var_tbl) << " * N + s];\n";
+            }
+        }
+    }
+    src << R"HIP(
+hy_df tfin, rem;
+tfin.hi = 0.0; tfin.lo = 0.0; rem.hi = 0.0; rem.lo = 0.0;
+bool t_dir = true;
+double mdt = __builtin_inf();
+double step_lim = 0.0;
+if (a.mode == 1) {
+    tfin.hi = a.tfin_hi[s];
+    tfin.lo = a.tfin_lo[s];
+    hy_df tcur; tcur.hi = t_hi; tcur.lo = t_lo;
+    rem = hy_df_sub(tfin, tcur);
+    t_dir = (rem.hi > 0.0) || (rem.hi == 0.0 && rem.lo >= 0.0);
+    if (a.lim != nullptr) mdt = a.lim[s];
+} else {
+    step_lim = a.lim[s];
+}
+u64 n_steps = 0, iter = 0;
+double min_h = __builtin_inf(), max_h = 0.0, last_h = 0.0;
+i64 outcome = HY_OC_SUCCESS;
+for (;;) {
+double lim;
+if (a.mode == 1) {
+    hy_df m; m.lo = 0.0;
+    if (t_dir) { m.hi = mdt; lim = hy_df_lt(rem, m) ? rem.hi : m.hi; }
+    else { m.hi = -mdt; lim = hy_df_lt(m, rem) ? rem.hi : m.hi; }
+} else {
+    lim = step_lim;
+}
+)HIP";
+    src << body;
+
+    for (std::uint32_t m = 1; m < L; m *= 2u) {
+        src << "m0 = hy_max(m0, __shfl_xor(m0, " << m << ", 64));\n";
+        src << "mo = hy_max(mo, __shfl_xor(mo, " << m << ", 64));\n";
+        src << "mom1 = hy_max(mom1, __shfl_xor(mom1, " << m << ", 64));\n";
+    }
+    src << "const double num_rho = (m0 <= 1.0) ? 1.0 : m0;\n";
+    src << "const double rho_o = pow(num_rho / mo, " << fp_literal(1. / static_cast<double>(order)) << ");\n";
+    src << "const double rho_om1 = pow(num_rho / mom1, " << fp_literal(1. / static_cast<double>(order - 1u))
+        << ");\n";
+    src << "const double rho_m = hy_min(rho_o, rho_om1);\n";
+    src << "double h = rho_m * " << fp_literal(rhofac(order)) << ";\n";
+    src << "h = hy_min(h, fabs(lim));\nh = (lim < 0.0) ? -h : h;\n";
+
+    src << "asm volatile(\"\" ::: \"memory\");\n";
+    const auto kstride = static_cast<std::uint64_t>(spw) * n_col;
+    for (std::uint32_t c = 0; c < n_own; ++c) {
+        src << "{\nconst double *c = jetl + " << static_cast<std::uint64_t>(c) * L << "u;\n";
+        if (opts.high_accuracy) {
+            src << "double res = c[0], comp = 0.0, cur_h = h;\n#pragma unroll\n";
+            src << "for (unsigned k = 1; k <= " << order << "u; ++k) {\n";
+            src << "const double tmp = c[(u64)k * " << kstride << "u] * cur_h;\nconst double y = tmp - comp;\n";
+            src << "const double t = res + y;\ncomp = (t - res) - y;\nres = t;\ncur_h = cur_h * h;\n}\n";
+        } else {
+            src << "double res = c[(u64)" << order << "u * " << kstride << "u];\n#pragma unroll\n";
+            src << "for (unsigned k = 1; k <= " << order << "u; ++k) {\n";
+            src << "res = c[(u64)(" << order << "u - k) * " << kstride << "u] + res * h;\n}\n";
+        }
+        src << "xs" << c << " = res;\n}\n";
+    }
+    src << R"HIP(
+{
+    hy_df tcur; tcur.hi = t_hi; tcur.lo = t_lo;
+    hy_df hh; hh.hi = h; hh.lo = 0.0;
+    const hy_df nt = hy_df_add(tcur, hh);
+    t_hi = nt.hi; t_lo = nt.lo;
+}
+last_h = h;
+int nfi = !(hy_finite(t_hi) && hy_finite(t_lo)) ? 1 : 0;
+)HIP";
+    for (std::uint32_t c = 0; c < n_own; ++c) {
+        src << "if (ovalid" << c << " && !hy_finite(xs" << c << ")) nfi = 1;\n";
+    }
+    for (std::uint32_t m = 1; m < L; m *= 2u) {
+        src << "nfi |= __shfl_xor(nfi, " << m << ", 64);\n";
+    }
+    src << "if (a.tc != nullptr && live) {\n";
+    for (const auto &rg : rounds) {
+        for (const auto &gr : rg) {
+            for (const auto &ow : gr.owners) {
+                src << "if (ovalid" << ow.col << ") {\nconst double *c = jetl + "
+                    << static_cast<std::uint64_t>(ow.col) * L << "u;\nfor (unsigned k = 0; k <= " << order
+                    << "u; ++k) a.tc[((u64)" << utname(ow.var_tbl) << " * " << (order + 1u)
+                    << "u + k) * N + s] = c[(u64)k * " << kstride << "u];\n}\n";
+            }
+        }
+    }
+    src << R"HIP(
+}
+if (nfi != 0) {
+    outcome = HY_OC_ERR_NF_STATE;
+    if (l == 0u && live) atomicAdd(a.counters, 1u);
+    break;
+}
+outcome = (h == lim) ? HY_OC_TIME_LIMIT : HY_OC_SUCCESS;
+if (a.mode != 1) break;
+n_steps += (h != 0.0) ? 1u : 0u;
+if (outcome == HY_OC_SUCCESS) {
+    const double ah = fabs(h);
+    min_h = hy_min(min_h, ah);
+    max_h = hy_max(max_h, ah);
+}
+if (h == rem.hi) break;
+{
+    hy_df tcur; tcur.hi = t_hi; tcur.lo = t_lo;
+    rem = hy_df_sub(tfin, tcur);
+}
+++iter;
+if (iter == a.max_steps) { outcome = HY_OC_STEP_LIMIT; break; }
+}
+)HIP";
+    for (const auto &rg : rounds) {
+        for (const auto &gr : rg) {
+            for (const auto &ow : gr.owners) {
+                src << "if (ovalid" << ow.col << " && live) a.state[(u64)" << utname(ow.var_tbl) << " * N + s] = xs"
+                    << ow.col << ";\n";
+            }
+        }
+    }
+    src << R"HIP(
+if (l == 0u && live) {
+    if (a.mode != 2) {
+        a.time_hi[s] = t_hi;
+        a.time_lo[s] = t_lo;
+    } else {
+        const_cast<double *>(a.lim)[s] = last_h;
+    }
+    a.last_h[s] = last_h;
+    a.outcome[s] = outcome;
+    if (a.mode == 1) {
+        a.min_h[s] = min_h;
+        a.max_h[s] = max_h;
+        a.n_steps[s] = n_steps;
+    }
+}
+}
+}
+)HIP";
+
+    ret.source = src.str();
+    ret.kernel_name = "hy_taylor";
+    ret.dout_name = "hy_dout";
+    ret.block_size = bs;
+    ret.lanes_per_system = L;
+    ret.lds_bytes = 0;
+    ret.mode = emit_mode::cluster;
+    ret.n_statements = e.n_stmt;
+    ret.scratch_per_wave = static_cast<std::uint64_t>(order + 1u) * spw * n_col;
+    ret.persistent = true;
+    ret.notes = "cluster mode v2 (pipelined): " + std::to_string(nc) + " clusters of " + std::to_string(t0.size())
+                + " nodes, L=" + std::to_string(L) + ", " + std::to_string(pl.n_slots) + " LDS slots x2, "
+                + std::to_string(n_own) + " state-variable owner slots, " + std::to_string(utbl.size())
+                + " slot tables";
+    return ret;
+}
+
+} // namespace heyoka_amd

@@ -440,6 +440,160 @@ struct ssa_emitter {
             out = (k == 1u) ? numpar(d) : "0.0";
         }
     }
+
+    // ---------------------------------------------------------------------------------------------
+    // Software-pipelined ("split") evaluation, used by the cluster generator.
+    //
+    // The order-k coefficient of a convolution-type node is split into a *history part* (all terms
+    // that involve only coefficients of order < k, which are available one full phase earlier) and a
+    // short *finish* (the 1-2 terms containing order-k operands). The history part is accumulated
+    // with an FMA chain (like the running sums of the reference's compact mode,
+    // src/math/prod.cpp:686-698) and can be scheduled under the latency of the LDS exchange.
+    // ---------------------------------------------------------------------------------------------
+    std::map<std::pair<std::uint32_t, std::uint32_t>, std::string> partials;
+
+    // acc += a * b as a chain (contracted into an FMA by -ffp-contract=fast).
+    std::string chain(const std::string &acc, const std::string &a, const std::string &b)
+    {
+        if (acc.empty()) {
+            return def(mul(a, b));
+        }
+        return def(a + " * " + b + " + " + acc);
+    }
+
+    // Is the split form implemented for node i?
+    bool can_split(std::uint32_t i) const
+    {
+        const auto &n = p.nodes[i];
+        const auto &a = n.args;
+        switch (n.kind) {
+            case func_kind::prod:
+                return a.size() == 2u && is_var(a[0]) && is_var(a[1]);
+            case func_kind::sum_sq:
+                for (const auto &o : a) {
+                    if (!is_var(o)) {
+                        return false;
+                    }
+                }
+                return true;
+            case func_kind::pow:
+                return is_var(a[0]) && a[1].type == operand::kind::num && a[1].value != .5 && a[1].value != 2.;
+            default:
+                return false;
+        }
+    }
+
+    // History part of the order-k coefficient of node i (k >= 2): needs orders 1..k-1 of the operands
+    // (and of the node itself, for pow). No-op if the node is not splittable or k < 2.
+    void node_partial(std::uint32_t i, std::uint32_t k)
+    {
+        if (k < 2u || !can_split(i)) {
+            return;
+        }
+        const auto &n = p.nodes[i];
+        const auto u = p.n_eq + i;
+        const auto &a = n.args;
+        std::string acc;
+        switch (n.kind) {
+            case func_kind::prod:
+                for (std::uint32_t j = 1; j < k; ++j) {
+                    acc = chain(acc, val(a[0].idx, k - j), val(a[1].idx, j));
+                }
+                break;
+            case func_kind::sum_sq: {
+                // Sum over the arguments of sum_{j=1}^{jmax} b^[k-j] b^[j] (to be doubled) ...
+                const auto jmax = (k % 2u == 1u) ? (k - 1u) / 2u : (k - 2u) / 2u;
+                for (const auto &o : a) {
+                    for (std::uint32_t j = 1; j <= jmax; ++j) {
+                        acc = chain(acc, val(o.idx, k - j), val(o.idx, j));
+                    }
+                }
+                // ... and, for even orders, the sum of the squares of the middle coefficients.
+                if (k % 2u == 0u) {
+                    std::string sq;
+                    for (const auto &o : a) {
+                        sq = chain(sq, val(o.idx, k / 2u), val(o.idx, k / 2u));
+                    }
+                    partials[{i, k + 0x10000u}] = sq;
+                }
+                break;
+            }
+            case func_kind::pow: {
+                const auto ex = a[1].value;
+                for (std::uint32_t j = 1; j < k; ++j) {
+                    const double sf = static_cast<double>(k) * ex - static_cast<double>(j) * (ex + 1.);
+                    const auto pr = def(mul(val(a[0].idx, k - j), val(u, j)));
+                    acc = chain(acc, fp_literal(sf), pr);
+                }
+                break;
+            }
+            default:
+                break;
+        }
+        partials[{i, k}] = acc;
+    }
+
+    // Order-k coefficient of node i using the history part emitted earlier (falls back to node()).
+    void node_finish(std::uint32_t i, std::uint32_t k)
+    {
+        const auto it = partials.find({i, k});
+        if (it == partials.end()) {
+            node(i, k);
+            return;
+        }
+        const auto &n = p.nodes[i];
+        const auto u = p.n_eq + i;
+        const auto &a = n.args;
+        auto acc = it->second;
+        auto &out = val(u, k);
+        switch (n.kind) {
+            case func_kind::prod:
+                acc = chain(acc, val(a[0].idx, k), val(a[1].idx, 0));
+                out = chain(acc, val(a[0].idx, 0), val(a[1].idx, k));
+                break;
+            case func_kind::sum_sq: {
+                for (const auto &o : a) {
+                    acc = chain(acc, val(o.idx, k), val(o.idx, 0));
+                }
+                const auto dbl = def(acc + " + " + acc);
+                if (k % 2u == 0u) {
+                    out = def(dbl + " + " + partials.at({i, k + 0x10000u}));
+                } else {
+                    out = dbl;
+                }
+                break;
+            }
+            case func_kind::pow: {
+                const auto ex = a[1].value;
+                const double sf = static_cast<double>(k) * ex;
+                const auto pr = def(mul(val(a[0].idx, k), val(u, 0)));
+                acc = chain(acc, fp_literal(sf), pr);
+                const auto dv = def(mul(fp_literal(static_cast<double>(k)), val(a[0].idx, 0)));
+                out = def(acc + " / " + dv);
+                break;
+            }
+            default:
+                break;
+        }
+    }
+
+    // x / d for a small integer constant d > 0 without a division: q = RN(x * r), r = RN(1 / d);
+    // rem = x - q * d (exact, FMA); result = RN(q + rem * r). By Markstein's theorem the result is the
+    // correctly-rounded quotient, i.e. bit-identical to IEEE x / d (outside of the subnormal range).
+    std::string div_const(const std::string &x, std::uint32_t d)
+    {
+        if (d == 1u) {
+            return x;
+        }
+        if ((d & (d - 1u)) == 0u) {
+            // Power of two: the multiplication by the reciprocal is exact.
+            return def(mul(x, fp_literal(1. / static_cast<double>(d))));
+        }
+        const auto r = fp_literal(1. / static_cast<double>(d));
+        const auto q = def(mul(x, r));
+        const auto rem = def("__builtin_fma(" + fp_literal(-static_cast<double>(d)) + ", " + q + ", " + x + ")");
+        return def("__builtin_fma(" + rem + ", " + r + ", " + q + ")");
+    }
 };
 
 } // namespace heyoka_amd::emit_detail
