@@ -152,10 +152,15 @@ device_module::device_module(std::shared_ptr<const compiled_module> cm, int devi
         int n_cu = 0, per_cu = 0;
         hip_check(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device),
                   "hipDeviceGetAttribute");
-        hip_check(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(
-                      &per_cu, m_impl->fn_taylor, static_cast<int>(m_impl->cm->meta.block_size),
-                      m_impl->cm->meta.lds_bytes),
-                  "hipModuleOccupancyMaxActiveBlocksPerMultiprocessor");
+        if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, m_impl->fn_taylor,
+                                                               static_cast<int>(m_impl->cm->meta.block_size),
+                                                               m_impl->cm->meta.lds_bytes)
+            != hipSuccess) {
+            // The occupancy query is advisory (and known to be unreliable for register-heavy kernels): the
+            // cluster kernels use the whole register file, i.e. one 256-thread block per CU.
+            (void)hipGetLastError();
+            per_cu = 1;
+        }
         if (const char *env = std::getenv("HEYOKA_AMD_BLOCKS_PER_CU")) {
             per_cu = std::max(1, std::atoi(env));
         }

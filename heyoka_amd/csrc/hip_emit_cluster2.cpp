@@ -353,9 +353,11 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
             }
             if (lev == pl.max_level && k + 1u < order) {
                 // History part of the next order's convolutions: overlaps the exchange latency.
+                std::vector<std::uint32_t> ids;
                 for (const auto u : t0) {
-                    e.node_partial(u - n_eq, k + 1u);
+                    ids.push_back(u - n_eq);
                 }
+                e.emit_partials(ids, k + 1u);
             }
             sync();
         }

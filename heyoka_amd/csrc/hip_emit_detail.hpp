@@ -483,38 +483,35 @@ struct ssa_emitter {
         }
     }
 
-    // History part of the order-k coefficient of node i (k >= 2): needs orders 1..k-1 of the operands
-    // (and of the node itself, for pow). No-op if the node is not splittable or k < 2.
-    void node_partial(std::uint32_t i, std::uint32_t k)
+    // One term of a history chain: scale * (a * b) (no scaling if scale is empty).
+    struct chain_term {
+        std::string a, b, scale;
+    };
+
+    // Terms of the history part of the order-k coefficient of node i (k >= 2): orders 1..k-1 of the
+    // operands (and of the node itself, for pow). sq receives the "middle squares" of sum_sq at even orders.
+    void partial_terms(std::uint32_t i, std::uint32_t k, std::vector<chain_term> &main, std::vector<chain_term> &sq)
     {
-        if (k < 2u || !can_split(i)) {
-            return;
-        }
         const auto &n = p.nodes[i];
         const auto u = p.n_eq + i;
         const auto &a = n.args;
-        std::string acc;
         switch (n.kind) {
             case func_kind::prod:
                 for (std::uint32_t j = 1; j < k; ++j) {
-                    acc = chain(acc, val(a[0].idx, k - j), val(a[1].idx, j));
+                    main.push_back({val(a[0].idx, k - j), val(a[1].idx, j), {}});
                 }
                 break;
             case func_kind::sum_sq: {
-                // Sum over the arguments of sum_{j=1}^{jmax} b^[k-j] b^[j] (to be doubled) ...
                 const auto jmax = (k % 2u == 1u) ? (k - 1u) / 2u : (k - 2u) / 2u;
-                for (const auto &o : a) {
-                    for (std::uint32_t j = 1; j <= jmax; ++j) {
-                        acc = chain(acc, val(o.idx, k - j), val(o.idx, j));
+                for (std::uint32_t j = 1; j <= jmax; ++j) {
+                    for (const auto &o : a) {
+                        main.push_back({val(o.idx, k - j), val(o.idx, j), {}});
                     }
                 }
-                // ... and, for even orders, the sum of the squares of the middle coefficients.
                 if (k % 2u == 0u) {
-                    std::string sq;
                     for (const auto &o : a) {
-                        sq = chain(sq, val(o.idx, k / 2u), val(o.idx, k / 2u));
+                        sq.push_back({val(o.idx, k / 2u), val(o.idx, k / 2u), {}});
                     }
-                    partials[{i, k + 0x10000u}] = sq;
                 }
                 break;
             }
@@ -522,15 +519,68 @@ struct ssa_emitter {
                 const auto ex = a[1].value;
                 for (std::uint32_t j = 1; j < k; ++j) {
                     const double sf = static_cast<double>(k) * ex - static_cast<double>(j) * (ex + 1.);
-                    const auto pr = def(mul(val(a[0].idx, k - j), val(u, j)));
-                    acc = chain(acc, fp_literal(sf), pr);
+                    main.push_back({val(a[0].idx, k - j), val(u, j), fp_literal(sf)});
                 }
                 break;
             }
             default:
                 break;
         }
-        partials[{i, k}] = acc;
+    }
+
+    // Emit the history parts of order k for a set of nodes, interleaving the FMA chains of the different
+    // nodes term by term (independent chains back to back hide the FP64 FMA latency at one wave per SIMD).
+    void emit_partials(const std::vector<std::uint32_t> &node_ids, std::uint32_t k)
+    {
+        if (k < 2u) {
+            return;
+        }
+        struct chain_state {
+            std::uint32_t node;
+            bool is_sq;
+            std::vector<chain_term> terms;
+            std::string acc;
+        };
+        std::vector<chain_state> chains;
+        for (const auto i : node_ids) {
+            if (!can_split(i)) {
+                continue;
+            }
+            std::vector<chain_term> main, sq;
+            partial_terms(i, k, main, sq);
+            // NOTE: long chains are split in two interleaved accumulators.
+            chains.push_back({i, false, std::move(main), {}});
+            if (!sq.empty()) {
+                chains.push_back({i, true, std::move(sq), {}});
+            }
+        }
+        std::size_t max_len = 0;
+        for (const auto &c : chains) {
+            max_len = std::max(max_len, c.terms.size());
+        }
+        for (std::size_t t = 0; t < max_len; ++t) {
+            for (auto &c : chains) {
+                if (t >= c.terms.size()) {
+                    continue;
+                }
+                const auto &tm = c.terms[t];
+                if (tm.scale.empty()) {
+                    c.acc = chain(c.acc, tm.a, tm.b);
+                } else {
+                    const auto pr = def(mul(tm.a, tm.b));
+                    c.acc = chain(c.acc, tm.scale, pr);
+                }
+            }
+        }
+        for (auto &c : chains) {
+            partials[{c.node, c.is_sq ? (k + 0x10000u) : k}] = c.acc;
+        }
+    }
+
+    // History part of a single node (non-interleaved form).
+    void node_partial(std::uint32_t i, std::uint32_t k)
+    {
+        emit_partials({i}, k);
     }
 
     // Order-k coefficient of node i using the history part emitted earlier (falls back to node()).
