@@ -221,7 +221,7 @@ void device_module::launch_taylor(const hy_kargs &args)
         // and the jet scratch is sized by the number of resident waves.
         grid = std::min<std::uint64_t>(grid, m_impl->max_grid);
         const auto need = static_cast<std::size_t>(grid) * (bs / 64u) * meta.scratch_per_wave * sizeof(double);
-        if (need > m_impl->scratch_bytes) {
+        if (need > m_impl->scratch_bytes && need != 0u) {
             if (m_impl->scratch != nullptr) {
                 hip_check(hipFree(m_impl->scratch), "hipFree");
                 m_impl->scratch = nullptr;

@@ -754,8 +754,7 @@ emitted_module emit_cluster_v1(const taylor_program &p, const emit_options &opts
     src << prelude;
     emit_detail::emit_dout(src, p, opts);
 
-    src << "#define HY_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); "
-           "__builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\"); } while (0)\n";
+    src << emit_detail::wsync_macro;
     src << "__constant__ unsigned short hy_utbl[" << std::max<std::size_t>(utbl.size(), 1u) * L << "] = {";
     for (const auto &v : utbl) {
         for (const auto x : v) {

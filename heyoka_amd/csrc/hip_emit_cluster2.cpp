@@ -13,6 +13,7 @@
 //     node_finish). Sums are FMA chains;
 //   * divisions by the (constant) order use the exact FMA-based sequence ssa_emitter::div_const().
 #include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <set>
 
@@ -173,7 +174,9 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     struct owner_slot {
         std::size_t out_tbl = 0;  // slab slot of the state variable
         std::size_t var_tbl = 0;  // state-variable index (for the global state array)
-        std::uint32_t col = 0;    // jet column block (col * L + l)
+        std::uint32_t col = 0;    // owner slot id
+        std::uint32_t cbase = 0;  // first jet column of the slot (columns are compressed: one per valid lane)
+        std::uint32_t n_valid = 0;
         std::vector<std::string> xname; // SSA names of the coefficients, by order
     };
     struct glue_round {
@@ -184,7 +187,7 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         std::vector<owner_slot> owners;
     };
     std::vector<std::vector<glue_round>> rounds(pl.groups.size());
-    std::uint32_t n_own = 0;
+    std::uint32_t n_own = 0, n_col_acc = 0;
     // A glue node needs a slab slot only if somebody reads it through the slab.
     std::vector<char> glue_read(p.n_u, 0);
     for (const auto &n : p.nodes) {
@@ -243,6 +246,9 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
                 ow.out_tbl = add_utbl(std::move(vs));
                 ow.var_tbl = add_utbl(std::move(vv));
                 ow.col = n_own++;
+                ow.cbase = n_col_acc;
+                ow.n_valid = gr.n_valid;
+                n_col_acc += gr.n_valid;
                 ow.xname.resize(order + 1u);
                 gr.owners.push_back(std::move(ow));
             }
@@ -253,7 +259,14 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         why_not = "no state variable could be attached to a glue round";
         return ret;
     }
-    const auto n_col = n_own * L;
+    const auto n_col = n_col_acc;
+    // Jets of the state variables: [order][system of the wave][column], per wave. Kept in LDS when the
+    // block's slab + jets fit in the 160 KB of a CU (the kernel occupies a whole CU anyway: 512 registers
+    // per lane), otherwise in a per-wave global scratch.
+    const auto jet_doubles_per_wave = static_cast<std::uint64_t>(order + 1u) * spw * n_col;
+    const auto lds_doubles_slab = static_cast<std::uint64_t>(wpb) * spw * ((2u * (pl.n_slots + std::max<std::uint32_t>(n_out, 1u))) | 1u);
+    const bool jet_lds = (lds_doubles_slab + wpb * jet_doubles_per_wave) * 8u <= 160u * 1024u
+                         && std::getenv("HEYOKA_AMD_JET_GLOBAL") == nullptr;
 
     // ---- 4. Emission helpers. ----
     const auto slabk = [&](std::uint32_t k, const std::string &tbl) {
@@ -261,8 +274,7 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         return (k % 2u == 0u) ? ("slab[" + tbl + "]") : ("slab[" + tbl + " + " + std::to_string(buf_stride) + "u]");
     };
     const auto jet_at = [&](std::uint32_t k, std::uint32_t col) {
-        return "jetl[" + std::to_string(static_cast<std::uint64_t>(k) * spw * n_col + static_cast<std::uint64_t>(col) * L)
-               + "]";
+        return "jc" + std::to_string(col) + "[" + std::to_string(static_cast<std::uint64_t>(k) * spw * n_col) + "]";
     };
     const auto sync = [&]() { os << "HY_WSYNC();\n"; };
 
@@ -270,6 +282,9 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     const auto publish_sv = [&](owner_slot &ow, std::uint32_t k, const std::string &name, const std::string &valid) {
         ow.xname[k] = name;
         os << slabk(k, utname(ow.out_tbl)) << " = " << name << ";\n";
+        if (ow.n_valid < L) {
+            os << "if (" << valid << ") ";
+        }
         os << jet_at(k, ow.col) << " = " << name << ";\n";
         const char *acc = (k == 0u) ? "m0" : (k == order ? "mo" : (k == order - 1u ? "mom1" : nullptr));
         if (acc != nullptr) {
@@ -371,8 +386,7 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     src << "#define SPW " << spw << "u\n";
     src << prelude;
     emit_detail::emit_dout(src, p, opts);
-    src << "#define HY_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); "
-           "__builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\"); } while (0)\n";
+    src << emit_detail::wsync_macro;
     src << "__constant__ unsigned short hy_utbl[" << std::max<std::size_t>(utbl.size(), 1u) * L << "] = {";
     for (const auto &v : utbl) {
         for (const auto x : v) {
@@ -398,9 +412,12 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     src << "const u64 N = a.N;\n";
     src << "double *const slab = lds_slab + (wib * " << spw << "u + q) * " << slab_stride << "u;\n";
     src << "const u64 gwave = (u64)blockIdx.x * " << wpb << "u + wib;\n";
-    src << "double *const jetw = a.scratch + gwave * " << static_cast<std::uint64_t>(order + 1u) * spw * n_col
-        << "ull;\n";
-    src << "double *const jetl = jetw + q * " << n_col << "u + l;\n";
+    if (jet_lds) {
+        src << "__shared__ double lds_jet[" << wpb * jet_doubles_per_wave << "];\n";
+        src << "double *const jetw = lds_jet + wib * " << jet_doubles_per_wave << "u;\n";
+    } else {
+        src << "double *const jetw = a.scratch + gwave * " << jet_doubles_per_wave << "ull;\n";
+    }
     for (std::size_t t = 0; t < utbl.size(); ++t) {
         src << "const unsigned ut" << t << " = hy_utbl[" << t * L << "u + l];\n";
     }
@@ -414,6 +431,8 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         for (const auto &gr : rg) {
             for (const auto &ow : gr.owners) {
                 src << "const bool ovalid" << ow.col << " = l < " << gr.n_valid << "u;\n";
+                src << "double *const jc" << ow.col << " = jetw + q * " << n_col << "u + " << ow.cbase << "u + (ovalid"
+                    << ow.col << " ? l : 0u);\n";
             }
         }
     }
@@ -486,7 +505,7 @@ if (a.mode == 1) {
     src << "asm volatile(\"\" ::: \"memory\");\n";
     const auto kstride = static_cast<std::uint64_t>(spw) * n_col;
     for (std::uint32_t c = 0; c < n_own; ++c) {
-        src << "{\nconst double *c = jetl + " << static_cast<std::uint64_t>(c) * L << "u;\n";
+        src << "{\nconst double *c = jc" << c << ";\n";
         if (opts.high_accuracy) {
             src << "double res = c[0], comp = 0.0, cur_h = h;\n#pragma unroll\n";
             src << "for (unsigned k = 1; k <= " << order << "u; ++k) {\n";
@@ -519,8 +538,8 @@ int nfi = !(hy_finite(t_hi) && hy_finite(t_lo)) ? 1 : 0;
     for (const auto &rg : rounds) {
         for (const auto &gr : rg) {
             for (const auto &ow : gr.owners) {
-                src << "if (ovalid" << ow.col << ") {\nconst double *c = jetl + "
-                    << static_cast<std::uint64_t>(ow.col) * L << "u;\nfor (unsigned k = 0; k <= " << order
+                src << "if (ovalid" << ow.col << ") {\nconst double *c = jc" << ow.col
+                    << ";\nfor (unsigned k = 0; k <= " << order
                     << "u; ++k) a.tc[((u64)" << utname(ow.var_tbl) << " * " << (order + 1u)
                     << "u + k) * N + s] = c[(u64)k * " << kstride << "u];\n}\n";
             }
@@ -586,12 +605,12 @@ if (l == 0u && live) {
     ret.lds_bytes = 0;
     ret.mode = emit_mode::cluster;
     ret.n_statements = e.n_stmt;
-    ret.scratch_per_wave = static_cast<std::uint64_t>(order + 1u) * spw * n_col;
+    ret.scratch_per_wave = jet_lds ? 0u : jet_doubles_per_wave;
     ret.persistent = true;
     ret.notes = "cluster mode v2 (pipelined): " + std::to_string(nc) + " clusters of " + std::to_string(t0.size())
                 + " nodes, L=" + std::to_string(L) + ", " + std::to_string(pl.n_slots) + " LDS slots x2, "
                 + std::to_string(n_own) + " state-variable owner slots, " + std::to_string(utbl.size())
-                + " slot tables";
+                + " slot tables, jets in " + (jet_lds ? "LDS" : "global scratch");
     return ret;
 }
 

@@ -20,6 +20,17 @@ namespace heyoka_amd::emit_detail
 // Common device-side prelude: argument block, double-length arithmetic, helpers.
 extern const char *const prelude;
 
+// Synchronisation of the LDS exchange between the lanes of ONE wavefront (a system never spans
+// wavefronts). The LDS pipeline executes the DS instructions of a wave in issue order, so a ds_write by
+// one lane is visible to a later ds_read of any lane of the same wave without any hardware wait: all
+// that is needed is that the *compiler* neither reorders LDS accesses across the point nor keeps slab
+// values cached in registers. A memory fence here (even at wavefront scope) makes the compiler drain
+// *all* outstanding memory operations (s_waitcnt vmcnt(0)), including the global jet-scratch stores,
+// 40-80 times per step - measured: 72 % of the wave cycles parked in s_waitcnt.
+inline constexpr const char *wsync_macro
+    = "#define HY_WSYNC() do { asm volatile(\"\" ::: \"memory\"); __builtin_amdgcn_wave_barrier(); "
+      "asm volatile(\"\" ::: \"memory\"); } while (0)\n";
+
 // Scaling + safety factor of the step-size selector, folded on the host in double precision.
 double rhofac(std::uint32_t order);
 
