@@ -37,6 +37,7 @@ struct hy_kargs {
     int pad;
     unsigned int *counters;   // [16] device counters: [0] lanes with non-finite state, [1] work-queue head
     double *scratch;          // cluster mode: jet scratch, scratch_per_wave doubles per resident wave
+    double tfin_s_hi, tfin_s_lo; // propagate mode, scalar final time (used when tfin_hi == nullptr)
 };
 
 enum class emit_mode { unrolled, cluster, table };

@@ -465,8 +465,8 @@ bool t_dir = true;
 double mdt = __builtin_inf();
 double step_lim = 0.0;
 if (a.mode == 1) {
-    tfin.hi = a.tfin_hi[s];
-    tfin.lo = a.tfin_lo[s];
+    tfin.hi = (a.tfin_hi != nullptr) ? a.tfin_hi[s] : a.tfin_s_hi;
+    tfin.lo = (a.tfin_hi != nullptr) ? a.tfin_lo[s] : a.tfin_s_lo;
     hy_df tcur; tcur.hi = t_hi; tcur.lo = t_lo;
     rem = hy_df_sub(tfin, tcur);
     t_dir = (rem.hi > 0.0) || (rem.hi == 0.0 && rem.lo >= 0.0);

@@ -701,6 +701,64 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
     auto &d = *m_impl;
     const auto N = d.N;
 
+    const auto check_mdts = [&]() {
+        if (!max_delta_ts.empty() && max_delta_ts.size() != N) {
+            throw std::invalid_argument("Invalid number of max timesteps specified in a Taylor integrator in batch "
+                                        "mode: the batch size is "
+                                        + std::to_string(N) + ", but the number of specified timesteps is "
+                                        + std::to_string(max_delta_ts.size()));
+        }
+        for (const auto dt : max_delta_ts) {
+            if (std::isnan(dt)) {
+                throw std::invalid_argument("A nan max_delta_t was passed to the propagate_until() function of an "
+                                            "adaptive Taylor integrator in batch mode");
+            }
+            if (dt <= 0) {
+                throw std::invalid_argument("A non-positive max_delta_t was passed to the propagate_until() function "
+                                            "of an adaptive Taylor integrator in batch mode");
+            }
+        }
+        if (c_out) {
+            throw not_implemented_error("Continuous output (kw::c_output) is not implemented in the MI355X batch "
+                                        "integrator");
+        }
+    };
+
+    // Fast path: state and time live on the device (they were produced by a previous kernel), scalar final
+    // time, no callback -> nothing to move or to inspect on the host. The per-lane checks of the reference on
+    // the *current* times are subsumed by the kernel: a lane whose time is already non-finite (it can only
+    // come from an earlier err_nf_state) reports err_nf_state again instead of raising an exception.
+    if (!cb && ts_.size() == 1u && d.dev_newer && !d.host_newer && !d.sticky_host_ptr && d.dmod) {
+        if (!std::isfinite(ts_[0])) {
+            throw std::invalid_argument("A non-finite time was passed to the propagate_until() function of an "
+                                        "adaptive Taylor integrator in batch mode");
+        }
+        check_mdts();
+        d.prop_res_override.reset();
+        d.d_counters.zero(d.stream);
+        auto a = d.base_args();
+        a.tfin_hi = nullptr;
+        a.tfin_lo = nullptr;
+        a.tfin_s_hi = ts_[0];
+        a.tfin_s_lo = 0.;
+        if (max_delta_ts.empty()) {
+            a.lim = nullptr;
+        } else {
+            d.d_lim.upload(max_delta_ts.data(), max_delta_ts.size() * sizeof(double), d.stream);
+        }
+        if (wtc && d.is_cluster()) {
+            d.ensure_tc();
+            a.tc = d.d_tc.as<double>();
+        }
+        a.mode = 1;
+        a.max_steps = max_steps;
+        d.dmod->launch_taylor(a);
+        d.after_kernel();
+        d.prop_res_dev_newer = true;
+        d.step_res_dev_newer = false;
+        return;
+    }
+
     std::vector<double> tf_hi(N), tf_lo(N, 0.);
     if (ts_.size() == 1u) {
         std::fill(tf_hi.begin(), tf_hi.end(), ts_[0]);
