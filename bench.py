@@ -99,6 +99,29 @@ def cpu_baseline(workload, dt, target_seconds=15.0):
     }
 
 
+def kernel_sha(ta):
+    import hashlib
+
+    return hashlib.sha256(ta.hip_source.encode()).hexdigest()[:16]
+
+
+def pmc_traffic(sha, n_systems):
+    """HBM traffic per launch of the stepper kernel from the committed rocprofv3 PMC summaries
+    (profiles/*_pmc.json, separate --pmc FETCH_SIZE / WRITE_SIZE passes): only used if the summary was
+    taken on exactly this kernel (same generated source) and ensemble size."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if d.get("kernel_sha256") == sha and d.get("systems_per_gpu") == n_systems:
+            return d["per_launch_avg"]["traffic_bytes_raw"], os.path.basename(path)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -209,6 +232,7 @@ def main():
         k_ms = float(np.mean(kern_ms))
         per_launch_steps = float(steps_per_call)
         achieved_gbs = b_tape * per_launch_steps / (k_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(kernel_sha(ta), n)
         out = {
             "metric": "ODE systems x steps/sec (fp64)",
             "value": value,
@@ -234,6 +258,7 @@ def main():
                 "all_outcomes_time_limit": ok,
                 "integrator_build_s": build_s,
                 "hiprtc_compile_s": ta.compile_seconds,
+                "kernel_sha256": kernel_sha(ta),
             },
             "roofline": {
                 "bound": "hbm",
@@ -241,7 +266,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "kernel": "hy_taylor",
                 "kernel_ms_avg": k_ms,
                 "call_ms_avg": float(np.mean(call_ms)),

@@ -417,8 +417,11 @@ std::string cluster_detail::make_plan(const taylor_program &p, std::uint32_t ord
     for (std::uint32_t i = 0; i < n_eq; ++i) {
         pl.slot_of[i] = static_cast<int>(ns++);
     }
-    for (std::size_t c = 0; c < nc; ++c) {
-        for (const auto q : pl.out_pos) {
+    // NOTE: output-major numbering: the lanes of a group (one cluster each) write *consecutive* slots for a
+    // given output, i.e. distinct LDS banks (cluster-major numbering gave a stride of n_out doubles between
+    // lanes and 2-way bank conflicts on every ds_write_b64).
+    for (const auto q : pl.out_pos) {
+        for (std::size_t c = 0; c < nc; ++c) {
             pl.slot_of[pl.clusters[c][q]] = static_cast<int>(ns++);
         }
     }

@@ -115,6 +115,27 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         grp_natt[g] = n0;
     }
 
+    // Renumber the slab slots of the state variables in owner order (group, round, chain position, lane), so
+    // that the lanes publishing new coefficients write consecutive slots (distinct LDS banks).
+    {
+        std::uint32_t next = 0;
+        for (std::size_t g = 0; g < pl.groups.size(); ++g) {
+            const auto &nodes = pl.groups[g].nodes;
+            const auto n_nodes = static_cast<std::uint32_t>(nodes.size());
+            for (std::uint32_t r = 0; r * L < n_nodes; ++r) {
+                for (std::uint32_t a = 0; a < grp_natt[g]; ++a) {
+                    for (std::uint32_t l = 0; l < L && r * L + l < n_nodes; ++l) {
+                        pl.slot_of[att.at(nodes[r * L + l])[a]] = static_cast<int>(next++);
+                    }
+                }
+            }
+        }
+        if (next != n_eq) {
+            why_not = "internal error: state-variable slots";
+            return ret;
+        }
+    }
+
     // ---- 2. LDS layout: every slot double-buffered by order parity. ----
     const std::uint32_t max_round_outputs = std::max<std::uint32_t>(n_out, 1u);
     const auto dummy_base = pl.n_slots;

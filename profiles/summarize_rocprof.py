@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Summarise rocprofv3 (rocpd sqlite) outputs into the small text/JSON files kept under profiles/.
 
-usage: python profiles/summarize_rocprof.py <out_prefix> <ktrace.db> [<pmc_fetch.db> <pmc_write.db>]
+usage: python profiles/summarize_rocprof.py <out_prefix> <ktrace.db> [<pmc_fetch.db> <pmc_write.db> [<bench.log>]]
 Writes <out_prefix>_kernel_stats.txt (per-kernel calls / total / avg / min / max, like
 `rocprofv3 --kernel-trace --stats`) and, if counter databases are given, <out_prefix>_pmc.json with
 the per-dispatch FETCH_SIZE / WRITE_SIZE of the stepper kernel (KiB, as reported) and the derived HBM
@@ -62,6 +62,14 @@ def main():
             "traffic_bytes_raw": fetch + write, "traffic_bytes_fetch_x2": 2 * fetch + write,
             "kernel_ns": sum(d["duration_ns_fetch_pass"] for d in timed) / n,
         }
+        if len(sys.argv) >= 6:
+            # The bench JSON line printed by the profiled command identifies the kernel and the workload.
+            for line in open(sys.argv[5]):
+                if line.startswith("{"):
+                    b = json.loads(line)
+                    out["kernel_sha256"] = b["config"].get("kernel_sha256")
+                    out["systems_per_gpu"] = b["config"].get("systems_per_gpu")
+                    out["bench_line_of_profiled_run"] = b
         with open(prefix + "_pmc.json", "w") as f:
             json.dump(out, f, indent=1)
         print(json.dumps(out["per_launch_avg"], indent=1))
