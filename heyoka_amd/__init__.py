@@ -382,6 +382,11 @@ class taylor_adaptive_batch:
         return take_str(lib.hy_tab_get_hip_source(self._h))
 
     @property
+    def hip_source_mode(self):
+        """Which code generator produced the kernels ("unrolled", "cluster ...", "table ...")."""
+        return take_str(lib.hy_tab_get_codegen_info(self._h))
+
+    @property
     def decomposition(self):
         return take_str(lib.hy_tab_get_decomposition_str(self._h)).rstrip("\n").split("\n")
 

@@ -93,6 +93,7 @@ SIGNATURES = [
     ("hy_tab_get_compile_seconds", c_double, [c_void_p]),
     ("hy_tab_get_hip_source", c_void_p, [c_void_p]),
     ("hy_tab_get_decomposition_str", c_void_p, [c_void_p]),
+    ("hy_tab_get_codegen_info", c_void_p, [c_void_p]),
     ("hy_tab_get_state", c_int, [c_void_p, c_void_p]),
     ("hy_tab_set_state", c_int, [c_void_p, c_void_p]),
     ("hy_tab_get_pars", c_int, [c_void_p, c_void_p]),

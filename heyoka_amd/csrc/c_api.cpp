@@ -392,6 +392,10 @@ char *hy_tab_get_hip_source(hy_tab t)
 {
     return dup_str(t->core.get_hip_source());
 }
+char *hy_tab_get_codegen_info(hy_tab t)
+{
+    return dup_str(t->core.get_codegen_info());
+}
 char *hy_tab_get_decomposition_str(hy_tab t)
 {
     return dup_str(dc_to_string(t->core.get_decomposition()));

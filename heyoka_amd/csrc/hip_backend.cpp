@@ -220,6 +220,17 @@ void device_module::launch_taylor(const hy_kargs &args)
         // Persistent blocks pulling work from a device-side queue: the grid covers the machine once,
         // and the jet scratch is sized by the number of resident waves.
         grid = std::min<std::uint64_t>(grid, m_impl->max_grid);
+        if (meta.scratch_per_wave != 0u) {
+            // Bound the scratch (table mode keeps the whole tape of every resident thread in HBM):
+            // 48 GiB by default out of the 288 GB of an MI355X.
+            double budget_gib = 48.;
+            if (const char *env = std::getenv("HEYOKA_AMD_SCRATCH_GIB")) {
+                budget_gib = std::max(0.25, std::atof(env));
+            }
+            const auto per_block = static_cast<double>(bs / 64u) * static_cast<double>(meta.scratch_per_wave) * 8.;
+            const auto max_blocks = static_cast<std::uint64_t>(budget_gib * 1073741824. / per_block);
+            grid = std::max<std::uint64_t>(1u, std::min<std::uint64_t>(grid, max_blocks));
+        }
         const auto need = static_cast<std::size_t>(grid) * (bs / 64u) * meta.scratch_per_wave * sizeof(double);
         if (need > m_impl->scratch_bytes && need != 0u) {
             if (m_impl->scratch != nullptr) {

@@ -372,6 +372,7 @@ if (a.mode == 1) {
 } // namespace emit_detail
 
 emitted_module emit_cluster_or_empty(const taylor_program &, const emit_options &, std::string &why_not);
+emitted_module emit_table(const taylor_program &, const emit_options &);
 
 emitted_module emit_hip_module(const taylor_program &prog, const emit_options &opts)
 {
@@ -385,13 +386,17 @@ emitted_module emit_hip_module(const taylor_program &prog, const emit_options &o
             std::string why;
             auto m = emit_cluster_or_empty(prog, opts, why);
             if (m.source.empty()) {
-                // Not applicable to this DAG: fall back to the generic one-system-per-lane code.
-                auto u = emit_detail::emit_unrolled(prog, opts);
-                u.notes = "cluster mode not applicable: " + why;
+                // Not applicable to this DAG: fall back to the generic one-system-per-lane code, unrolled
+                // for small decompositions (registers), table-driven for large ones (bounded code size, the
+                // reason compact mode exists in the reference).
+                auto u = (prog.nodes.size() > 150u) ? emit_table(prog, opts) : emit_detail::emit_unrolled(prog, opts);
+                u.notes += (u.notes.empty() ? "" : "; ") + ("cluster mode not applicable: " + why);
                 return u;
             }
             return m;
         }
+        case emit_mode::table:
+            return emit_table(prog, opts);
         default:
             throw not_implemented_error("The requested code generation mode is not implemented yet");
     }

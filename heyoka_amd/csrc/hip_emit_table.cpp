@@ -1,0 +1,539 @@
+// "Table" code generation mode: the GPU analogue of the reference's compact mode
+// (taylor_compute_jet_compact_mode(), src/taylor_02.cpp:1194-1260; per-node taylor_c_diff_func
+// functions driven by index tables, src/taylor_02.cpp:560-614).
+//
+// Used for decompositions that are too large to unroll and that do not fit the cluster scheme
+// (e.g. model::nbody(64): 18 663 u variables). One system per lane; the code is a fixed set of
+// per-node-kind device functions (one per elementary function, the "plugin" layer of the reference,
+// include/heyoka/func.hpp:117-147) interpreted over node tables stored in the module; control flow is
+// wave-uniform (all lanes process the same node), so table reads are scalar loads. The tape of
+// normalised derivatives lives in HBM, laid out tape[(order * n_u + u) * T + thread] (coalesced: one
+// 512-byte line per wave access), sized by the number of resident threads T: persistent blocks walk the
+// ensemble with a grid stride. Sums are accumulated as running sums in increasing j (the reference's
+// compact-mode order, e.g. src/math/prod.cpp:686-698).
+//
+// This mode is HBM-bound by construction (every convolution term reads two tape entries); it exists for
+// coverage (BASELINE config 5), not for speed.
+#include <sstream>
+
+#include "hip_emit_detail.hpp"
+
+namespace heyoka_amd
+{
+
+namespace
+{
+
+const char *table_device_code = R"HIP(
+// Node tables (one entry per u variable that is not a state variable).
+#define K_SUM 0
+#define K_PROD 1
+#define K_POW 2
+#define K_SUB 3
+#define K_DIV 4
+#define K_SUM_SQ 5
+#define K_SIN 6
+#define K_COS 7
+#define K_EXP 8
+#define K_LOG 9
+#define K_TIME 10
+#define K_NUM_IDENTITY 11
+#define A_UVAR 0
+#define A_NUM 1
+#define A_PAR 2
+
+struct hy_tctx {
+    double *tape;      // this thread's column of the tape
+    u64 T;             // tape stride between consecutive (order, u) entries
+    const double *pars;
+    u64 N, s;
+    double t_hi;
+};
+
+__device__ __forceinline__ double &hy_tp(const hy_tctx &c, unsigned k, unsigned u)
+{
+    return c.tape[((u64)k * HY_N_U + u) * c.T];
+}
+
+__device__ __forceinline__ double hy_numpar(const hy_tctx &c, unsigned a)
+{
+    return hy_arg_type[a] == A_NUM ? hy_arg_val[a] : c.pars[(u64)hy_arg_idx[a] * c.N + c.s];
+}
+
+__device__ double hy_pow_ebs(double base, unsigned e)
+{
+    // Exponentiation by squaring (src/math/pow.cpp:136-152): iterative form reproducing the association of
+    // the recursive definition, b0 * (b1 * (b2 * ... * base_final)).
+    if (e == 0u) return 1.0;
+    double pend[6];
+    int np = 0;
+    while (e > 1u) {
+        if (e % 2u == 1u) {
+            pend[np++] = base;
+            e = (e - 1u) / 2u;
+        } else {
+            e /= 2u;
+        }
+        base = base * base;
+    }
+    double r = base;
+    for (int i = np - 1; i >= 0; --i) r = pend[i] * r;
+    return r;
+}
+
+__device__ double hy_pow_eval(double b, double ex)
+{
+    // get_pow_eval_algo(), src/math/pow.cpp:292-355.
+    if (__builtin_isfinite(ex) && ex == trunc(ex) && fabs(ex) <= 16.0) {
+        if (ex >= 0.0) return hy_pow_ebs(b, (unsigned)ex);
+        return 1.0 / hy_pow_ebs(b, (unsigned)(-ex));
+    }
+    if (__builtin_isfinite(ex) && ex != trunc(ex)) {
+        const double y = 2.0 * ex;
+        if (y == trunc(y) && fabs(y) <= 16.0) {
+            const double t = sqrt(b);
+            if (y >= 0.0) return hy_pow_ebs(t, (unsigned)y);
+            return 1.0 / hy_pow_ebs(t, (unsigned)(-y));
+        }
+    }
+    return pow(b, ex);
+}
+
+// ---- one device function per elementary function (the reference's taylor_c_diff_func layer) ----
+__device__ double hy_diff_sum(const hy_tctx &c, unsigned a0, unsigned nargs, unsigned k)
+{
+    double acc = 0.0;
+    for (unsigned j = 0; j < nargs; ++j) {
+        const unsigned a = a0 + j;
+        const double v = (hy_arg_type[a] == A_UVAR) ? hy_tp(c, k, hy_arg_idx[a]) : (k == 0u ? hy_numpar(c, a) : 0.0);
+        acc = (j == 0u) ? v : acc + v;
+    }
+    return acc;
+}
+
+__device__ double hy_diff_sub(const hy_tctx &c, unsigned a0, unsigned k)
+{
+    const bool v0 = hy_arg_type[a0] == A_UVAR, v1 = hy_arg_type[a0 + 1u] == A_UVAR;
+    if (v0 && v1) return hy_tp(c, k, hy_arg_idx[a0]) - hy_tp(c, k, hy_arg_idx[a0 + 1u]);
+    if (v0) return k == 0u ? hy_tp(c, 0, hy_arg_idx[a0]) - hy_numpar(c, a0 + 1u) : hy_tp(c, k, hy_arg_idx[a0]);
+    if (v1) return k == 0u ? hy_numpar(c, a0) - hy_tp(c, 0, hy_arg_idx[a0 + 1u]) : -hy_tp(c, k, hy_arg_idx[a0 + 1u]);
+    return k == 0u ? hy_numpar(c, a0) - hy_numpar(c, a0 + 1u) : 0.0;
+}
+
+__device__ double hy_diff_prod(const hy_tctx &c, unsigned a0, unsigned k)
+{
+    const bool v0 = hy_arg_type[a0] == A_UVAR, v1 = hy_arg_type[a0 + 1u] == A_UVAR;
+    if (v0 && v1) {
+        const unsigned b = hy_arg_idx[a0], d = hy_arg_idx[a0 + 1u];
+        double acc = 0.0;
+        for (unsigned j = 0; j <= k; ++j) acc += hy_tp(c, k - j, b) * hy_tp(c, j, d);
+        return acc;
+    }
+    if (!v0 && !v1) {
+        if (k != 0u) return 0.0;
+        if (hy_arg_type[a0] == A_NUM && hy_arg_val[a0] == -1.0) return -hy_numpar(c, a0 + 1u);
+        return hy_numpar(c, a0) * hy_numpar(c, a0 + 1u);
+    }
+    const unsigned av = v0 ? a0 : a0 + 1u, an = v0 ? a0 + 1u : a0;
+    const double x = hy_tp(c, k, hy_arg_idx[av]);
+    if (an == a0 && hy_arg_type[a0] == A_NUM && hy_arg_val[a0] == -1.0) return -x;
+    return hy_numpar(c, an) * x;
+}
+
+__device__ double hy_diff_div(const hy_tctx &c, unsigned a0, unsigned u, unsigned k)
+{
+    const bool v0 = hy_arg_type[a0] == A_UVAR, v1 = hy_arg_type[a0 + 1u] == A_UVAR;
+    if (v1) {
+        const unsigned d = hy_arg_idx[a0 + 1u];
+        if (k == 0u) return (v0 ? hy_tp(c, 0, hy_arg_idx[a0]) : hy_numpar(c, a0)) / hy_tp(c, 0, d);
+        double acc = 0.0;
+        for (unsigned j = 1; j <= k; ++j) acc += hy_tp(c, k - j, u) * hy_tp(c, j, d);
+        if (v0) return (hy_tp(c, k, hy_arg_idx[a0]) - acc) / hy_tp(c, 0, d);
+        return (-acc) / hy_tp(c, 0, d);
+    }
+    if (v0) return hy_tp(c, k, hy_arg_idx[a0]) / hy_numpar(c, a0 + 1u);
+    return k == 0u ? hy_numpar(c, a0) / hy_numpar(c, a0 + 1u) : 0.0;
+}
+
+__device__ double hy_diff_sum_sq(const hy_tctx &c, unsigned a0, unsigned nargs, unsigned k)
+{
+    double tot = 0.0;
+    for (unsigned q = 0; q < nargs; ++q) {
+        const unsigned a = a0 + q;
+        double term;
+        if (hy_arg_type[a] == A_UVAR) {
+            const unsigned b = hy_arg_idx[a];
+            double acc = 0.0;
+            if (k % 2u == 1u) {
+                for (unsigned j = 0; j <= (k - 1u) / 2u; ++j) acc += hy_tp(c, k - j, b) * hy_tp(c, j, b);
+                term = acc;
+            } else {
+                for (unsigned j = 0; k > 0u && j <= (k - 2u) / 2u; ++j) acc += hy_tp(c, k - j, b) * hy_tp(c, j, b);
+                const double hv = hy_tp(c, k / 2u, b);
+                term = (k > 0u) ? (acc + acc) + hv * hv : hv * hv;
+            }
+        } else {
+            const double v = (k == 0u) ? hy_numpar(c, a) : 0.0;
+            term = v * v;
+        }
+        tot = (q == 0u) ? term : tot + term;
+    }
+    return (k % 2u == 1u) ? tot + tot : tot;
+}
+
+__device__ double hy_diff_pow(const hy_tctx &c, unsigned a0, unsigned u, unsigned k)
+{
+    const double ex = hy_arg_val[a0 + 1u];
+    if (hy_arg_type[a0] != A_UVAR) return k == 0u ? hy_pow_eval(hy_numpar(c, a0), ex) : 0.0;
+    const unsigned b = hy_arg_idx[a0];
+    if (k == 0u) return hy_pow_eval(hy_tp(c, 0, b), ex);
+    if (ex == 0.5) {
+        // sqrt (src/math/pow.cpp:432-474).
+        const double a_0 = hy_tp(c, 0, u);
+        double fac = hy_tp(c, k, b), acc = 0.0;
+        const unsigned jmax = (k % 2u == 1u) ? (k - 1u) / 2u : (k - 2u) / 2u;
+        for (unsigned j = 1; j <= jmax; ++j) acc += hy_tp(c, k - j, u) * hy_tp(c, j, u);
+        if (k % 2u == 0u) {
+            const double hv = hy_tp(c, k / 2u, u);
+            fac = fac - hv * hv;
+        }
+        if (jmax >= 1u) fac = fac - (acc + acc);
+        return fac / (a_0 + a_0);
+    }
+    if (ex == 2.0) {
+        // square (src/math/pow.cpp:395-430).
+        double acc = 0.0;
+        if (k % 2u == 1u) {
+            for (unsigned j = 0; j <= (k - 1u) / 2u; ++j) acc += hy_tp(c, k - j, b) * hy_tp(c, j, b);
+            return acc + acc;
+        }
+        for (unsigned j = 0; j <= (k - 2u) / 2u; ++j) acc += hy_tp(c, k - j, b) * hy_tp(c, j, b);
+        const double hv = hy_tp(c, k / 2u, b);
+        return (acc + acc) + hv * hv;
+    }
+    double acc = 0.0;
+    for (unsigned j = 0; j < k; ++j) {
+        const double sf = (double)k * ex - (double)j * (ex + 1.0);
+        acc += sf * (hy_tp(c, k - j, b) * hy_tp(c, j, u));
+    }
+    return acc / ((double)k * hy_tp(c, 0, b));
+}
+
+__device__ double hy_diff_sincos(const hy_tctx &c, unsigned a0, unsigned dep, unsigned k, bool is_sin)
+{
+    if (hy_arg_type[a0] != A_UVAR) {
+        const double v = hy_numpar(c, a0);
+        return k == 0u ? (is_sin ? sin(v) : cos(v)) : 0.0;
+    }
+    const unsigned b = hy_arg_idx[a0];
+    if (k == 0u) return is_sin ? sin(hy_tp(c, 0, b)) : cos(hy_tp(c, 0, b));
+    double acc = 0.0;
+    for (unsigned j = 1; j <= k; ++j) acc += (double)j * (hy_tp(c, k - j, dep) * hy_tp(c, j, b));
+    return acc / (is_sin ? (double)k : -(double)k);
+}
+
+__device__ double hy_diff_exp(const hy_tctx &c, unsigned a0, unsigned u, unsigned k)
+{
+    if (hy_arg_type[a0] != A_UVAR) return k == 0u ? exp(hy_numpar(c, a0)) : 0.0;
+    const unsigned b = hy_arg_idx[a0];
+    if (k == 0u) return exp(hy_tp(c, 0, b));
+    double acc = 0.0;
+    for (unsigned j = 1; j <= k; ++j) acc += (double)j * (hy_tp(c, k - j, u) * hy_tp(c, j, b));
+    return acc / (double)k;
+}
+
+__device__ double hy_diff_log(const hy_tctx &c, unsigned a0, unsigned u, unsigned k)
+{
+    if (hy_arg_type[a0] != A_UVAR) return k == 0u ? log(hy_numpar(c, a0)) : 0.0;
+    const unsigned b = hy_arg_idx[a0];
+    if (k == 0u) return log(hy_tp(c, 0, b));
+    double ret = (double)k * hy_tp(c, k, b);
+    if (k > 1u) {
+        double acc = 0.0;
+        for (unsigned j = 1; j < k; ++j) acc += (double)j * (hy_tp(c, k - j, b) * hy_tp(c, j, u));
+        ret = ret - acc;
+    }
+    return ret / ((double)k * hy_tp(c, 0, b));
+}
+
+// Order-k coefficients of all the u variables that are not state variables.
+__device__ void hy_nodes_order(const hy_tctx &c, unsigned k)
+{
+    for (unsigned i = 0; i < HY_N_NODES; ++i) {
+        const unsigned u = HY_N_EQ + i;
+        const unsigned a0 = hy_arg_off[i], nargs = hy_arg_off[i + 1u] - a0;
+        double v;
+        switch (hy_kind[i]) {
+            case K_SUM: v = hy_diff_sum(c, a0, nargs, k); break;
+            case K_PROD: v = hy_diff_prod(c, a0, k); break;
+            case K_POW: v = hy_diff_pow(c, a0, u, k); break;
+            case K_SUB: v = hy_diff_sub(c, a0, k); break;
+            case K_DIV: v = hy_diff_div(c, a0, u, k); break;
+            case K_SUM_SQ: v = hy_diff_sum_sq(c, a0, nargs, k); break;
+            case K_SIN: v = hy_diff_sincos(c, a0, hy_dep[i], k, true); break;
+            case K_COS: v = hy_diff_sincos(c, a0, hy_dep[i], k, false); break;
+            case K_EXP: v = hy_diff_exp(c, a0, u, k); break;
+            case K_LOG: v = hy_diff_log(c, a0, u, k); break;
+            case K_TIME: v = (k == 0u) ? c.t_hi : (k == 1u ? 1.0 : 0.0); break;
+            default: v = (k == 0u) ? hy_numpar(c, a0) : 0.0; break;
+        }
+        hy_tp(c, k, u) = v;
+    }
+}
+
+// Order-k coefficients of the state variables (taylor_compute_sv_diff(), src/taylor_02.cpp:245-287).
+__device__ void hy_sv_order(const hy_tctx &c, unsigned k)
+{
+    for (unsigned i = 0; i < HY_N_EQ; ++i) {
+        double v;
+        if (hy_sv_type[i] == A_UVAR) {
+            v = hy_tp(c, k - 1u, hy_sv_idx[i]) / (double)k;
+        } else if (k == 1u) {
+            v = hy_sv_type[i] == A_NUM ? hy_sv_val[i] : c.pars[(u64)hy_sv_idx[i] * c.N + c.s];
+        } else {
+            v = 0.0;
+        }
+        hy_tp(c, k, i) = v;
+    }
+}
+
+// NOTE: latency-bound on the HBM tape: ask for >= 4 waves per SIMD (<= 128 VGPRs).
+extern "C" __global__ void __launch_bounds__(256, 4) hy_taylor(const hy_kargs a)
+{
+    const u64 T = (u64)gridDim.x * 256u;
+    const u64 tid = (u64)blockIdx.x * 256u + threadIdx.x;
+    const u64 N = a.N;
+    hy_tctx c;
+    c.tape = a.scratch + tid;
+    c.T = T;
+    c.pars = a.pars;
+    c.N = N;
+    for (u64 s = tid; s < N; s += T) {
+        c.s = s;
+        double t_hi = a.time_hi[s], t_lo = a.time_lo[s];
+        hy_df tfin, rem;
+        tfin.hi = 0.0; tfin.lo = 0.0; rem.hi = 0.0; rem.lo = 0.0;
+        bool t_dir = true;
+        double mdt = __builtin_inf();
+        double step_lim = 0.0;
+        if (a.mode == 1) {
+            tfin.hi = (a.tfin_hi != nullptr) ? a.tfin_hi[s] : a.tfin_s_hi;
+            tfin.lo = (a.tfin_hi != nullptr) ? a.tfin_lo[s] : a.tfin_s_lo;
+            hy_df tcur; tcur.hi = t_hi; tcur.lo = t_lo;
+            rem = hy_df_sub(tfin, tcur);
+            t_dir = (rem.hi > 0.0) || (rem.hi == 0.0 && rem.lo >= 0.0);
+            if (a.lim != nullptr) mdt = a.lim[s];
+        } else {
+            step_lim = a.lim[s];
+        }
+        // The order-0 row of the tape doubles as the current state.
+        for (unsigned i = 0; i < HY_N_EQ; ++i) hy_tp(c, 0, i) = a.state[(u64)i * N + s];
+        u64 n_steps = 0, iter = 0;
+        double min_h = __builtin_inf(), max_h = 0.0, last_h = 0.0;
+        i64 outcome = HY_OC_SUCCESS;
+        for (;;) {
+            double lim;
+            if (a.mode == 1) {
+                hy_df m; m.lo = 0.0;
+                if (t_dir) { m.hi = mdt; lim = hy_df_lt(rem, m) ? rem.hi : m.hi; }
+                else { m.hi = -mdt; lim = hy_df_lt(m, rem) ? rem.hi : m.hi; }
+            } else {
+                lim = step_lim;
+            }
+            c.t_hi = t_hi;
+            hy_nodes_order(c, 0);
+            for (unsigned k = 1; k < HY_ORDER; ++k) {
+                hy_sv_order(c, k);
+                hy_nodes_order(c, k);
+            }
+            hy_sv_order(c, HY_ORDER);
+
+            // Step size (taylor_determine_h(), compact-mode reduction order, src/taylor_00.cpp:154-167).
+            double m0 = fabs(hy_tp(c, 0, 0)), mo = fabs(hy_tp(c, HY_ORDER, 0)), mom1 = fabs(hy_tp(c, HY_ORDER - 1u, 0));
+            for (unsigned i = 1; i < HY_N_EQ; ++i) {
+                m0 = hy_max(m0, fabs(hy_tp(c, 0, i)));
+                mo = hy_max(mo, fabs(hy_tp(c, HY_ORDER, i)));
+                mom1 = hy_max(mom1, fabs(hy_tp(c, HY_ORDER - 1u, i)));
+            }
+            const double num_rho = (m0 <= 1.0) ? 1.0 : m0;
+            const double rho_o = pow(num_rho / mo, 1.0 / (double)HY_ORDER);
+            const double rho_om1 = pow(num_rho / mom1, 1.0 / (double)(HY_ORDER - 1u));
+            const double rho_m = hy_min(rho_o, rho_om1);
+            double h = rho_m * HY_RHOFAC;
+            h = hy_min(h, fabs(lim));
+            h = (lim < 0.0) ? -h : h;
+
+            if (a.tc != nullptr) {
+                for (unsigned i = 0; i < HY_N_EQ; ++i)
+                    for (unsigned k = 0; k <= HY_ORDER; ++k)
+                        a.tc[((u64)i * (HY_ORDER + 1u) + k) * N + s] = hy_tp(c, k, i);
+            }
+
+            bool nf = false;
+            for (unsigned i = 0; i < HY_N_EQ; ++i) {
+                double res;
+#if HY_HIGH_ACCURACY
+                res = hy_tp(c, 0, i);
+                double comp = 0.0, cur_h = h;
+                for (unsigned k = 1; k <= HY_ORDER; ++k) {
+                    const double tmp = hy_tp(c, k, i) * cur_h;
+                    const double y = tmp - comp;
+                    const double t = res + y;
+                    comp = (t - res) - y;
+                    res = t;
+                    cur_h = cur_h * h;
+                }
+#else
+                res = hy_tp(c, HY_ORDER, i);
+                for (unsigned k = 1; k <= HY_ORDER; ++k) res = hy_tp(c, HY_ORDER - k, i) + res * h;
+#endif
+                hy_tp(c, 0, i) = res;
+                nf = nf || !hy_finite(res);
+            }
+            {
+                hy_df tcur; tcur.hi = t_hi; tcur.lo = t_lo;
+                hy_df hh; hh.hi = h; hh.lo = 0.0;
+                const hy_df nt = hy_df_add(tcur, hh);
+                t_hi = nt.hi; t_lo = nt.lo;
+            }
+            last_h = h;
+            nf = nf || !(hy_finite(t_hi) && hy_finite(t_lo));
+            if (nf) {
+                outcome = HY_OC_ERR_NF_STATE;
+                atomicAdd(a.counters, 1u);
+                break;
+            }
+            outcome = (h == lim) ? HY_OC_TIME_LIMIT : HY_OC_SUCCESS;
+            if (a.mode != 1) break;
+            n_steps += (h != 0.0) ? 1u : 0u;
+            if (outcome == HY_OC_SUCCESS) {
+                const double ah = fabs(h);
+                min_h = hy_min(min_h, ah);
+                max_h = hy_max(max_h, ah);
+            }
+            if (h == rem.hi) break;
+            {
+                hy_df tcur; tcur.hi = t_hi; tcur.lo = t_lo;
+                rem = hy_df_sub(tfin, tcur);
+            }
+            ++iter;
+            if (iter == a.max_steps) { outcome = HY_OC_STEP_LIMIT; break; }
+        }
+        for (unsigned i = 0; i < HY_N_EQ; ++i) a.state[(u64)i * N + s] = hy_tp(c, 0, i);
+        if (a.mode != 2) {
+            a.time_hi[s] = t_hi;
+            a.time_lo[s] = t_lo;
+        } else {
+            const_cast<double *>(a.lim)[s] = last_h;
+        }
+        a.last_h[s] = last_h;
+        a.outcome[s] = outcome;
+        if (a.mode == 1) {
+            a.min_h[s] = min_h;
+            a.max_h[s] = max_h;
+            a.n_steps[s] = n_steps;
+        }
+    }
+}
+)HIP";
+
+int kind_id(func_kind k)
+{
+    switch (k) {
+        case func_kind::sum:
+            return 0;
+        case func_kind::prod:
+            return 1;
+        case func_kind::pow:
+            return 2;
+        case func_kind::sub:
+            return 3;
+        case func_kind::div:
+            return 4;
+        case func_kind::sum_sq:
+            return 5;
+        case func_kind::sin:
+            return 6;
+        case func_kind::cos:
+            return 7;
+        case func_kind::exp:
+            return 8;
+        case func_kind::log:
+            return 9;
+        case func_kind::time:
+            return 10;
+        default:
+            return 11;
+    }
+}
+
+} // namespace
+
+emitted_module emit_table(const taylor_program &p, const emit_options &opts)
+{
+    std::ostringstream src;
+    src << emit_detail::prelude;
+    emit_detail::emit_dout(src, p, opts);
+
+    src << "#define HY_N_EQ " << p.n_eq << "u\n#define HY_N_U " << p.n_u << "u\n#define HY_N_NODES " << p.nodes.size()
+        << "u\n#define HY_ORDER " << opts.order << "u\n#define HY_HIGH_ACCURACY " << (opts.high_accuracy ? 1 : 0)
+        << "\n#define HY_RHOFAC " << fp_literal(emit_detail::rhofac(opts.order)) << "\n";
+
+    std::ostringstream kind, off, at, ai, av, dep;
+    std::size_t n_args = 0;
+    off << "0,";
+    for (const auto &n : p.nodes) {
+        kind << kind_id(n.kind) << ",";
+        if (n.kind == func_kind::prod && n.args.size() != 2u) {
+            throw std::invalid_argument("The Taylor derivative of a product can be computed only for products of 2 "
+                                        "terms");
+        }
+        if (n.kind == func_kind::pow && n.args[1].type != operand::kind::num) {
+            throw std::invalid_argument("An invalid argument type was encountered while trying to build the Taylor "
+                                        "derivative of a pow()");
+        }
+        for (const auto &o : n.args) {
+            at << static_cast<int>(o.type) << ",";
+            ai << o.idx << ",";
+            av << fp_literal(o.type == operand::kind::num ? o.value : 0.) << ",";
+            ++n_args;
+        }
+        off << n_args << ",";
+        dep << (n.deps.empty() ? 0u : n.deps[0]) << ",";
+    }
+    src << "__device__ const unsigned char hy_kind[] = {" << kind.str() << "0};\n";
+    src << "__device__ const unsigned hy_arg_off[] = {" << off.str() << "0};\n";
+    src << "__device__ const unsigned char hy_arg_type[] = {" << at.str() << "0};\n";
+    src << "__device__ const unsigned hy_arg_idx[] = {" << ai.str() << "0};\n";
+    src << "__device__ const double hy_arg_val[] = {" << av.str() << "0.0};\n";
+    src << "__device__ const unsigned hy_dep[] = {" << dep.str() << "0};\n";
+    src << "__device__ const unsigned char hy_sv_type[] = {";
+    for (const auto &d : p.sv_defs) {
+        src << static_cast<int>(d.type) << ",";
+    }
+    src << "0};\n__device__ const unsigned hy_sv_idx[] = {";
+    for (const auto &d : p.sv_defs) {
+        src << d.idx << ",";
+    }
+    src << "0};\n__device__ const double hy_sv_val[] = {";
+    for (const auto &d : p.sv_defs) {
+        src << fp_literal(d.type == operand::kind::num ? d.value : 0.) << ",";
+    }
+    src << "0.0};\n";
+    src << table_device_code;
+
+    emitted_module ret;
+    ret.source = src.str();
+    ret.kernel_name = "hy_taylor";
+    ret.dout_name = "hy_dout";
+    ret.block_size = 256;
+    ret.lanes_per_system = 1;
+    ret.mode = emit_mode::table;
+    ret.persistent = true;
+    // One tape column per resident *thread*: (n_u * order + n_eq) doubles, i.e. 64x that per wave.
+    ret.scratch_per_wave = (static_cast<std::uint64_t>(p.n_u) * opts.order + p.n_eq) * 64u;
+    ret.notes = "table mode: " + std::to_string(p.nodes.size()) + " nodes interpreted from tables, tape in HBM";
+    return ret;
+}
+
+} // namespace heyoka_amd

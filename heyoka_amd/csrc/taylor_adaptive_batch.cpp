@@ -462,6 +462,14 @@ const std::string &tab_core::get_hip_source() const
 {
     return m_impl->emitted.source;
 }
+std::string tab_core::get_codegen_info() const
+{
+    const auto &m = m_impl->emitted;
+    const char *mode = m.mode == emit_mode::cluster ? "cluster" : (m.mode == emit_mode::table ? "table" : "unrolled");
+    return std::string(mode) + " [lanes per system: " + std::to_string(m.lanes_per_system)
+           + ", statements: " + std::to_string(m.n_statements) + "] " + m.notes;
+}
+
 double tab_core::get_compile_seconds() const
 {
     return m_impl->cmod->compile_seconds;

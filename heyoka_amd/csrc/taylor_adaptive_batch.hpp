@@ -82,6 +82,8 @@ public:
     [[nodiscard]] int get_device() const;
     [[nodiscard]] const std::string &get_hip_source() const;
     [[nodiscard]] double get_compile_seconds() const;
+    // "unrolled" / "cluster ..." / "table ...": which code generator was selected, and why.
+    [[nodiscard]] std::string get_codegen_info() const;
 
     [[nodiscard]] const std::vector<double> &get_time() const;
     [[nodiscard]] std::pair<const std::vector<double> &, const std::vector<double> &> get_dtime() const;

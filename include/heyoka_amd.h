@@ -129,6 +129,8 @@ int hy_tab_get_compact_mode(hy_tab);
 double hy_tab_get_compile_seconds(hy_tab);
 char *hy_tab_get_hip_source(hy_tab);  /* generated HIP module (cf. llvm_state::get_ir()); caller frees */
 char *hy_tab_get_decomposition_str(hy_tab);
+/* Description of the code generation mode chosen for this system ("unrolled", "cluster ...", "table ..."). Caller frees. */
+char *hy_tab_get_codegen_info(hy_tab);
 
 int hy_tab_get_state(hy_tab, double *out);                 /* get_state()        n_eq * batch_size */
 int hy_tab_set_state(hy_tab, const double *in);            /* writes through get_state_data() */

@@ -476,7 +476,8 @@ size_t hy_oracle_scratch_size(const hy_oracle_program *p, int B)
     }
     const size_t tape = ((size_t)p->n_u * (size_t)p->order + (size_t)p->n_eq) * (size_t)B;
     const size_t terms = (size_t)(p->order + 2 + max_args + 2) * (size_t)B;
-    return tape + terms + 8u * (size_t)B;
+    /* + reduction area of the step-size selector (n_eq + 3) * B and the step_impl() copy of the limits. */
+    return tape + terms + 8u * (size_t)B + ((size_t)p->n_eq + 4u) * (size_t)B;
 }
 
 static double rhofac(int order)
@@ -510,7 +511,8 @@ void hy_oracle_step(const hy_oracle_program *p, int B, double *state, const doub
     sv_diff(p, order, tape, pars, B);
 
     /* Step size: pairwise max reduction over the variables (default mode). */
-    double *mx = (double *)malloc(sizeof(double) * (size_t)3 * (size_t)B + sizeof(double) * (size_t)n_eq * (size_t)B);
+    /* Per-step temporaries live at the end of the caller-provided scratch (no allocation in the hot path). */
+    double *mx = scratch_mem + hy_oracle_scratch_size(p, B) - ((size_t)n_eq + 4u) * (size_t)B;
     double *red = mx + (size_t)3 * B;
     const int ks[3] = {0, order, order - 1};
     for (int q = 0; q < 3; ++q) {
@@ -557,7 +559,6 @@ void hy_oracle_step(const hy_oracle_program *p, int B, double *state, const doub
         else hh = 1. * hh;
         h[l] = hh;
     }
-    free(mx);
 
     /* State update. */
     if (p->high_accuracy) {
@@ -665,7 +666,7 @@ void hy_oracle_step_impl(const hy_oracle_program *p, int B, double *state, const
                          double *time_lo, const double *max_delta_ts, double *tc, int64_t *outcome, double *h_out,
                          double *scratch_mem)
 {
-    double *dts = (double *)malloc(sizeof(double) * (size_t)B);
+    double *dts = scratch_mem + hy_oracle_scratch_size(p, B) - (size_t)B;
     memcpy(dts, max_delta_ts, sizeof(double) * (size_t)B);
 
     hy_oracle_step(p, B, state, pars, time_hi, dts, tc, scratch_mem);
@@ -688,7 +689,6 @@ void hy_oracle_step_impl(const hy_oracle_program *p, int B, double *state, const
             outcome[l] = (h == max_delta_ts[l]) ? OC_TIME_LIMIT : OC_SUCCESS;
         }
     }
-    free(dts);
 }
 
 /*

@@ -319,3 +319,86 @@ def test_device_array_views_and_ensemble():
         serial.propagate_until(5.0)
         assert np.array_equal(o.state, serial.state)
         assert np.array_equal(o.state, ta.state[:, i * 256:(i + 1) * 256])
+
+
+def _nbody_parity(n_bodies, n_sys, n_steps, expect_mode, t_final=None, env_mode=None, tol=1e5):
+    import os
+
+    st = configs.plummer_nbody_state(n_bodies, n_sys, seed=77, jitter=1e-6)
+    old = os.environ.get("HEYOKA_AMD_EMIT_MODE")
+    if env_mode is not None:
+        os.environ["HEYOKA_AMD_EMIT_MODE"] = env_mode
+    try:
+        ta = hy.taylor_adaptive_batch(hy.model.nbody(n_bodies), st, n_sys)
+    finally:
+        if env_mode is not None:
+            if old is None:
+                del os.environ["HEYOKA_AMD_EMIT_MODE"]
+            else:
+                os.environ["HEYOKA_AMD_EMIT_MODE"] = old
+    assert expect_mode in ta.hip_source_mode, ta.hip_source_mode
+    ora = ho.OracleIntegrator(ho.nbody(n_bodies), st, n_sys)
+    for _ in range(n_steps):
+        ta.step(write_tc=True)
+        ora.step(wtc=True)
+        h_g = np.array([h for _, h in ta.step_res])
+        h_o = np.array([h for _, h in ora.step_res])
+        assert np.max(np.abs(h_g - h_o) / h_o) <= 1e6 * EPS
+        assert rel_err(ta.state, ora.state.reshape(6 * n_bodies, n_sys)) <= tol * EPS
+    tc_o = ora.tc.reshape(6 * n_bodies, ora.order + 1, n_sys)
+    scale = np.max(np.abs(tc_o), axis=2, keepdims=True) + 1e-300
+    assert np.max(np.abs(ta.tc - tc_o) / scale) <= 1e7 * EPS
+    if t_final is not None:
+        ta.propagate_until(t_final)
+        ora.propagate_until(t_final)
+        assert all(r[0] == OC.time_limit for r in ta.propagate_res)
+        assert max(abs(a[3] - b[3]) for a, b in zip(ta.propagate_res, ora.prop_res)) <= 1
+        assert rel_err(ta.state, ora.state.reshape(6 * n_bodies, n_sys)) <= 1e7 * EPS
+    return ta
+
+
+def test_cluster_mode_nbody8_default_masses():
+    """28 isomorphic pair clusters, L = 32 lanes per system, reaction terms through sub/neg glue."""
+    _nbody_parity(8, 96, 3, "cluster", t_final=0.05)
+
+
+def test_table_mode_small_dag_forced():
+    """Table (compact-mode analogue) kernels on a DAG that would normally be unrolled."""
+    _nbody_parity(3, 200, 3, "table", t_final=0.1, env_mode="table")
+
+
+def test_table_mode_nbody12_automatic():
+    """66 clusters (> 64 lanes): automatic fallback to the table-driven kernel."""
+    _nbody_parity(12, 64, 2, "table", t_final=0.02)
+
+
+def test_config5_nbody64_table_mode():
+    """BASELINE config 5 DAG (18 663 u variables) at a reduced ensemble size: parity vs the oracle."""
+    ta = _nbody_parity(64, 64, 1, "table")
+    assert ta.n_uvars == 18663
+
+
+def test_unrolled_vs_cluster_v1_vs_v2_same_results():
+    """The three code generators agree with each other on the outer Solar System (same inputs)."""
+    import os
+
+    n = 64
+    st = configs.outer_ss_state(n, perturb=1e-8, seed=3)
+    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    res = {}
+    for name, env in (("v2", {}), ("v1", {"HEYOKA_AMD_CLUSTER_V1": "1"}), ("table", {"HEYOKA_AMD_EMIT_MODE": "table"})):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            ta = hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+        ta.propagate_until(20.0)
+        res[name] = (ta.state, np.array([r[3] for r in ta.propagate_res]))
+    for name in ("v1", "table"):
+        assert rel_err(res[name][0], res["v2"][0]) <= 1e5 * EPS
+        assert np.max(np.abs(res[name][1] - res["v2"][1])) <= 1
