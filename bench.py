@@ -30,7 +30,10 @@ WORKLOADS = {
     # name: (n_eq, n_u, B_tape bytes / system-step, F_alg flop / system-step)  (order 20)
     "outer_ss": (36, 234, 8 * (2 * 36 + 6) + 16 * 234 * 20, 5.7e4),
     "two_body": (12, 21, 8 * (2 * 12 + 6) + 16 * 21 * 20, 4.1e3),
+    "nbody64": (384, 18663, 8 * (2 * 384 + 6) + 16 * 18663 * 20, 6.9e6),
 }
+# Default ensemble sizes of the BASELINE.json configurations (systems per GPU).
+DEFAULT_SYSTEMS = {"outer_ss": 1048576, "two_body": 4194304, "nbody64": 65536}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_PEAK_TFLOPS = 78.6  # vector FP64
 
@@ -41,6 +44,11 @@ def make_integrator(hy, configs, workload, n_systems, seed):
         st = configs.outer_ss_state(n_systems, perturb=1e-12, seed=seed)
         ta = hy.taylor_adaptive_batch(sys_, None, n_systems, high_accuracy=True)
         dt = 4.0  # years per bench step
+    elif workload == "nbody64":
+        sys_ = hy.model.nbody(64)
+        st = configs.plummer_nbody_state(64, n_systems, seed=1234 + seed)
+        ta = hy.taylor_adaptive_batch(sys_, None, n_systems, high_accuracy=False)
+        dt = 0.03
     else:
         sys_ = hy.model.nbody(2, masses=[1.0, 0.0])
         st = configs.two_body_state(n_systems, perturb=1e-12, seed=seed)
@@ -62,13 +70,17 @@ def cpu_baseline(workload, dt, target_seconds=15.0):
         osys = ho.nbody(6, masses=configs.OUTER_SS_MASSES, Gconst=configs.OUTER_SS_G)
         gen = lambda n: configs.outer_ss_state(n, perturb=1e-12, seed=42)
         ha = True
+    elif workload == "nbody64":
+        osys = ho.nbody(64)
+        gen = lambda n: configs.plummer_nbody_state(64, n, seed=1234 + 42)
+        ha = False
     else:
         osys = ho.nbody(2, masses=[1.0, 0.0])
         gen = lambda n: configs.two_body_state(n, perturb=1e-12, seed=42)
         ha = False
     # Bounded sample: a fixed set of systems propagated further and further (t += dt per call, exactly
     # like the GPU bench steps) until ~target_seconds of CPU work have been spent.
-    n = width * threads * 64
+    n = width * threads * (1 if workload == "nbody64" else 64)
     st = gen(n)
     tmpl = ho.OracleIntegrator(osys, np.zeros(len(osys) * width), width, high_accuracy=ha)
     import ctypes as _ct
@@ -127,7 +139,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--systems", type=int, default=1048576, help="systems per GPU")
+    ap.add_argument("--systems", type=int, default=0, help="systems per GPU (default: the BASELINE.json size)")
     ap.add_argument("--workload", default="outer_ss", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -158,7 +170,7 @@ def main():
         # integrator is created on that ordinal.
         pass
 
-    n = args.systems
+    n = args.systems if args.systems > 0 else DEFAULT_SYSTEMS[args.workload]
     t_build = time.perf_counter()
     ta, st, dt = make_integrator(hy, configs, args.workload, n, seed=42 + rank)
     if distributed and local_rank != 0:
