@@ -123,6 +123,7 @@ struct device_module::impl {
     hipModule_t mod = nullptr;
     hipFunction_t fn_taylor = nullptr;
     hipFunction_t fn_dout = nullptr;
+    hipFunction_t fn_taylor_tc = nullptr; // optional variant writing the Taylor coefficients
     hipStream_t stream = nullptr;
     // Ring of HIP event pairs bracketing the stepper launches.
     static constexpr int n_ev = 64;
@@ -148,6 +149,10 @@ device_module::device_module(std::shared_ptr<const compiled_module> cm, int devi
               "hipModuleGetFunction(taylor)");
     hip_check(hipModuleGetFunction(&m_impl->fn_dout, m_impl->mod, m_impl->cm->meta.dout_name.c_str()),
               "hipModuleGetFunction(dout)");
+    if (!m_impl->cm->meta.tc_kernel_name.empty()) {
+        hip_check(hipModuleGetFunction(&m_impl->fn_taylor_tc, m_impl->mod, m_impl->cm->meta.tc_kernel_name.c_str()),
+                  "hipModuleGetFunction(taylor_tc)");
+    }
     if (m_impl->cm->meta.persistent) {
         int n_cu = 0, per_cu = 0;
         hip_check(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device),
@@ -224,6 +229,13 @@ void device_module::launch_taylor(const hy_kargs &args)
             // Bound the scratch (table mode keeps the whole tape of every resident thread in HBM):
             // 48 GiB by default out of the 288 GB of an MI355X.
             double budget_gib = 48.;
+            {
+                // Default: 60 % of the free device memory (288 GB of HBM3E on an MI355X).
+                std::size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b != 0u) {
+                    budget_gib = 0.6 * static_cast<double>(free_b + m_impl->scratch_bytes) / 1073741824.;
+                }
+            }
             if (const char *env = std::getenv("HEYOKA_AMD_SCRATCH_GIB")) {
                 budget_gib = std::max(0.25, std::atof(env));
             }
@@ -247,7 +259,9 @@ void device_module::launch_taylor(const hy_kargs &args)
     // HIP events on the launch stream bracket exactly the kernel (used for the roofline figure).
     const auto slot = static_cast<int>(m_impl->n_launches % impl::n_ev);
     hip_check(hipEventRecord(m_impl->ev_start[slot], m_impl->stream), "hipEventRecord");
-    hip_check(hipModuleLaunchKernel(m_impl->fn_taylor, static_cast<unsigned>(grid), 1, 1,
+    // Kernels with register-resident jets come with a second variant used when the caller wants the TCs.
+    const auto fn = (a.tc != nullptr && m_impl->fn_taylor_tc != nullptr) ? m_impl->fn_taylor_tc : m_impl->fn_taylor;
+    hip_check(hipModuleLaunchKernel(fn, static_cast<unsigned>(grid), 1, 1,
                                     static_cast<unsigned>(bs), 1, 1, meta.lds_bytes, m_impl->stream, nullptr, config),
               "hipModuleLaunchKernel(taylor)");
     hip_check(hipEventRecord(m_impl->ev_stop[slot], m_impl->stream), "hipEventRecord");

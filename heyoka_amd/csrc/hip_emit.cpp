@@ -9,6 +9,8 @@
 #include <cassert>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <functional>
 #include <sstream>
 #include <stdexcept>
 
@@ -158,7 +160,11 @@ void emit_dout(std::ostringstream &os, const taylor_program &p, const emit_optio
 
 // One system per lane, fully unrolled SSA code (the GPU analogue of the reference's default mode,
 // taylor_compute_jet() src/taylor_02.cpp:1339-1418).
-emitted_module emit_unrolled(const taylor_program &p, const emit_options &opts)
+// One stepper kernel. reg_jets = false: the jets of the state variables go through the tc buffer (always
+// needed, also serves kw::write_tc). reg_jets = true: they stay in SSA values (registers); state variables
+// defined by other state variables (x' = v) are re-derived in the final evaluation instead of being stored.
+std::string emit_unrolled_kernel(const taylor_program &p, const emit_options &opts, const std::string &kname,
+                                 bool reg_jets, std::uint64_t &n_stmt)
 {
     const auto n_eq = p.n_eq;
     const auto order = opts.order;
@@ -167,11 +173,7 @@ emitted_module emit_unrolled(const taylor_program &p, const emit_options &opts)
     ssa_emitter e(p, order);
     auto &os = e.os;
 
-    os << prelude;
-
-    emit_dout(os, p, opts);
-
-    os << "extern \"C\" __global__ void __launch_bounds__(" << bs << ") hy_taylor(const hy_kargs a)\n{\n";
+    os << "extern \"C\" __global__ void __launch_bounds__(" << bs << ") " << kname << "(const hy_kargs a)\n{\n";
     os << "const u64 s = (u64)blockIdx.x * " << bs << "u + threadIdx.x;\n";
     os << "if (s >= a.N) return;\n";
     os << "const u64 N = a.N;\n";
@@ -181,8 +183,13 @@ emitted_module emit_unrolled(const taylor_program &p, const emit_options &opts)
     }
     for (std::uint32_t i = 0; i < n_eq; ++i) {
         os << "double x" << i << " = a.state[(u64)" << i << "u * N + s];\n";
+        if (reg_jets) {
+            os << "double x" << i << "n = 0.0;\n";
+        }
     }
-    os << "double *const jet = a.tc + s;\n";
+    if (!reg_jets) {
+        os << "double *const jet = a.tc + s;\n";
+    }
     os << R"HIP(
 hy_df tfin, rem;
 tfin.hi = 0.0; tfin.lo = 0.0; rem.hi = 0.0; rem.lo = 0.0;
@@ -219,6 +226,9 @@ if (a.mode == 1) {
         e.val(i, 0) = "x" + std::to_string(i);
     }
     const auto store_sv = [&](std::uint32_t i, std::uint32_t k) {
+        if (reg_jets) {
+            return;
+        }
         os << "jet[(u64)" << (static_cast<std::uint64_t>(i) * (order + 1u) + k) << "u * N] = " << e.val(i, k)
            << ";\n";
     };
@@ -272,32 +282,70 @@ if (a.mode == 1) {
     os << "h = hy_min(h, fabs(lim));\n";
     os << "h = (lim < 0.0) ? -h : h;\n";
 
-    // ---- State update: reload the coefficients from the jet buffer. ----
-    // NOTE: the memory clobber prevents the compiler from forwarding the stored coefficients (which
-    // would keep (order + 1) * n_eq values live in registers across the whole step).
-    os << "asm volatile(\"\" ::: \"memory\");\n";
-    if (opts.high_accuracy) {
-        // Compensated summation (reference: taylor_run_ceval(), src/taylor_00.cpp:355-460).
+    if (reg_jets) {
+        // ---- State update straight from the SSA coefficients. ----
+        // Coefficient k of state variable i: re-derived from the defining state variable when x' = v.
+        std::function<std::string(std::uint32_t, std::uint32_t)> coef = [&](std::uint32_t i, std::uint32_t k) {
+            const auto &d = p.sv_defs[i];
+            if (k > 0u && d.type == operand::kind::uvar && d.idx < n_eq) {
+                return e.div_const(coef(d.idx, k - 1u), k);
+            }
+            return e.val(i, k);
+        };
         for (std::uint32_t i = 0; i < n_eq; ++i) {
-            os << "{\nconst double *c = jet + (u64)" << (static_cast<std::uint64_t>(i) * (order + 1u))
-               << "u * N;\n";
-            os << "double res = c[0], comp = 0.0, cur_h = h;\n";
-            os << "#pragma unroll\nfor (unsigned k = 1; k <= " << order << "u; ++k) {\n";
-            os << "const double tmp = c[(u64)k * N] * cur_h;\nconst double y = tmp - comp;\nconst double t = res + "
-                  "y;\n";
-            os << "comp = (t - res) - y;\nres = t;\ncur_h = cur_h * h;\n}\n";
-            os << "x" << i << " = res;\n}\n";
+            if (opts.high_accuracy) {
+                os << "{\ndouble res = " << coef(i, 0) << ", comp = 0.0, cur_h = h;\n";
+                for (std::uint32_t k = 1; k <= order; ++k) {
+                    const auto c = coef(i, k);
+                    os << "{\nconst double tmp = " << c << " * cur_h;\nconst double y = tmp - comp;\n";
+                    os << "const double t = res + y;\ncomp = (t - res) - y;\nres = t;\ncur_h = cur_h * h;\n}\n";
+                }
+                os << "x" << i << "n = res;\n}\n";
+            } else {
+                // NOTE: coefficients are named before the block so that the chain is a pure Horner recursion.
+                std::vector<std::string> cs;
+                for (std::uint32_t k = 0; k <= order; ++k) {
+                    cs.push_back(coef(i, k));
+                }
+                os << "{\ndouble res = " << cs[order] << ";\n";
+                for (std::uint32_t k = 1; k <= order; ++k) {
+                    os << "res = " << cs[order - k] << " + res * h;\n";
+                }
+                os << "x" << i << "n = res;\n}\n";
+            }
+        }
+        for (std::uint32_t i = 0; i < n_eq; ++i) {
+            os << "x" << i << " = x" << i << "n;\n";
         }
     } else {
-        // Horner (reference: taylor_run_multihorner(), src/taylor_00.cpp:279-351).
-        for (std::uint32_t i = 0; i < n_eq; ++i) {
-            os << "{\nconst double *c = jet + (u64)" << (static_cast<std::uint64_t>(i) * (order + 1u))
-               << "u * N;\n";
-            os << "double res = c[(u64)" << order << "u * N];\n";
-            os << "#pragma unroll\nfor (unsigned k = 1; k <= " << order << "u; ++k) {\n";
-            os << "res = c[(u64)(" << order << "u - k) * N] + res * h;\n}\n";
-            os << "x" << i << " = res;\n}\n";
+        // ---- State update: reload the coefficients from the jet buffer. ----
+        // NOTE: the memory clobber prevents the compiler from forwarding the stored coefficients (which
+        // would keep (order + 1) * n_eq values live in registers across the whole step).
+        os << "asm volatile(\"\" ::: \"memory\");\n";
+        if (opts.high_accuracy) {
+            // Compensated summation (reference: taylor_run_ceval(), src/taylor_00.cpp:355-460).
+            for (std::uint32_t i = 0; i < n_eq; ++i) {
+                os << "{\nconst double *c = jet + (u64)" << (static_cast<std::uint64_t>(i) * (order + 1u))
+                   << "u * N;\n";
+                os << "double res = c[0], comp = 0.0, cur_h = h;\n";
+                os << "#pragma unroll\nfor (unsigned k = 1; k <= " << order << "u; ++k) {\n";
+                os << "const double tmp = c[(u64)k * N] * cur_h;\nconst double y = tmp - comp;\nconst double t = res + "
+                      "y;\n";
+                os << "comp = (t - res) - y;\nres = t;\ncur_h = cur_h * h;\n}\n";
+                os << "x" << i << " = res;\n}\n";
+            }
+        } else {
+            // Horner (reference: taylor_run_multihorner(), src/taylor_00.cpp:279-351).
+            for (std::uint32_t i = 0; i < n_eq; ++i) {
+                os << "{\nconst double *c = jet + (u64)" << (static_cast<std::uint64_t>(i) * (order + 1u))
+                   << "u * N;\n";
+                os << "double res = c[(u64)" << order << "u * N];\n";
+                os << "#pragma unroll\nfor (unsigned k = 1; k <= " << order << "u; ++k) {\n";
+                os << "res = c[(u64)(" << order << "u - k) * N] + res * h;\n}\n";
+                os << "x" << i << " = res;\n}\n";
+            }
         }
+
     }
 
     // ---- Bookkeeping (reference: src/taylor_adaptive_batch.cpp:702-727, :1402-1460). ----
@@ -358,14 +406,92 @@ if (a.mode == 1) {
 }
 )HIP";
 
+    n_stmt += e.n_stmt;
+    return os.str();
+}
+
+// Estimate (in doubles) of what a lane must keep alive in register-jet mode: the jets of the state variables
+// that are neither constant nor defined by another state variable, plus the history of the operands of the
+// nonlinear nodes.
+std::uint64_t reg_jet_estimate(const taylor_program &p, std::uint32_t order)
+{
+    std::uint64_t n = 0;
+    for (const auto &d : p.sv_defs) {
+        if (d.type == operand::kind::uvar && d.idx >= p.n_eq) {
+            n += order + 1u;
+        }
+    }
+    std::vector<char> hist(p.n_u, 0);
+    for (std::uint32_t i = 0; i < p.nodes.size(); ++i) {
+        const auto &nd = p.nodes[i];
+        const auto &a = nd.args;
+        const auto mark = [&](const operand &o) {
+            if (o.type == operand::kind::uvar) {
+                hist[o.idx] = 1;
+            }
+        };
+        switch (nd.kind) {
+            case func_kind::prod:
+                if (a.size() == 2u && a[0].type == operand::kind::uvar && a[1].type == operand::kind::uvar) {
+                    mark(a[0]);
+                    mark(a[1]);
+                }
+                break;
+            case func_kind::sum_sq:
+                for (const auto &o : a) {
+                    mark(o);
+                }
+                break;
+            case func_kind::pow:
+            case func_kind::exp:
+            case func_kind::log:
+            case func_kind::sin:
+            case func_kind::cos:
+                if (a[0].type == operand::kind::uvar) {
+                    mark(a[0]);
+                    hist[p.n_eq + i] = 1;
+                }
+                break;
+            case func_kind::div:
+                if (a[1].type == operand::kind::uvar) {
+                    mark(a[1]);
+                    hist[p.n_eq + i] = 1;
+                }
+                break;
+            default:
+                break;
+        }
+    }
+    for (const auto h : hist) {
+        n += (h != 0) ? order : 0u;
+    }
+    return n;
+}
+
+emitted_module emit_unrolled(const taylor_program &p, const emit_options &opts)
+{
+    std::ostringstream src;
+    src << prelude;
+    emit_dout(src, p, opts);
+
     emitted_module ret;
-    ret.source = os.str();
+    // Register-resident jets when they fit comfortably in the 512 VGPR+AGPR of a lane.
+    const bool reg_jets = reg_jet_estimate(p, opts.order) <= 200u && std::getenv("HEYOKA_AMD_NO_REG_JETS") == nullptr;
+    if (reg_jets) {
+        src << emit_unrolled_kernel(p, opts, "hy_taylor", true, ret.n_statements);
+        src << emit_unrolled_kernel(p, opts, "hy_taylor_tc", false, ret.n_statements);
+        ret.tc_kernel_name = "hy_taylor_tc";
+        ret.tc_optional = true;
+        ret.notes = "register-resident state jets (+ tc variant)";
+    } else {
+        src << emit_unrolled_kernel(p, opts, "hy_taylor", false, ret.n_statements);
+    }
+    ret.source = src.str();
     ret.kernel_name = "hy_taylor";
     ret.dout_name = "hy_dout";
-    ret.block_size = bs;
+    ret.block_size = opts.block_size;
     ret.lanes_per_system = 1;
     ret.mode = emit_mode::unrolled;
-    ret.n_statements = e.n_stmt;
     return ret;
 }
 

@@ -53,6 +53,8 @@ struct emitted_module {
     std::string source;
     std::string kernel_name; // step / propagate kernel
     std::string dout_name;   // dense-output kernel
+    std::string tc_kernel_name; // optional variant of the stepper that writes the Taylor coefficients
+    bool tc_optional = false;   // the main kernel works with a.tc == nullptr
     std::uint32_t block_size = 256;
     std::uint32_t lanes_per_system = 1;
     std::uint32_t lds_bytes = 0;

@@ -962,6 +962,7 @@ if (l == 0u && live) {
     ret.n_statements = e.n_stmt;
     ret.scratch_per_wave = static_cast<std::uint64_t>(order + 1u) * spw * n_col;
     ret.persistent = true;
+    ret.tc_optional = true;
     ret.notes = "cluster mode: " + std::to_string(nc) + " clusters of " + std::to_string(t0.size())
                 + " nodes, L=" + std::to_string(L) + ", " + std::to_string(pl.n_slots) + " LDS slots, "
                 + std::to_string(pl.groups.size()) + " glue groups, " + std::to_string(utbl.size())

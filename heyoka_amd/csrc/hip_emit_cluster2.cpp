@@ -628,6 +628,7 @@ if (l == 0u && live) {
     ret.n_statements = e.n_stmt;
     ret.scratch_per_wave = jet_lds ? 0u : jet_doubles_per_wave;
     ret.persistent = true;
+    ret.tc_optional = true;
     ret.notes = "cluster mode v2 (pipelined): " + std::to_string(nc) + " clusters of " + std::to_string(t0.size())
                 + " nodes, L=" + std::to_string(L) + ", " + std::to_string(pl.n_slots) + " LDS slots x2, "
                 + std::to_string(n_own) + " state-variable owner slots, " + std::to_string(utbl.size())

@@ -530,6 +530,7 @@ emitted_module emit_table(const taylor_program &p, const emit_options &opts)
     ret.lanes_per_system = 1;
     ret.mode = emit_mode::table;
     ret.persistent = true;
+    ret.tc_optional = true;
     // One tape column per resident *thread*: (n_u * order + n_eq) doubles, i.e. 64x that per wave.
     ret.scratch_per_wave = (static_cast<std::uint64_t>(p.n_u) * opts.order + p.n_eq) * 64u;
     ret.notes = "table mode: " + std::to_string(p.nodes.size()) + " nodes interpreted from tables, tape in HBM";

@@ -87,7 +87,9 @@ struct tab_core::impl {
 
     [[nodiscard]] bool is_cluster() const
     {
-        return emitted.mode == emit_mode::cluster;
+        // NOTE: true whenever the stepper does not need the tc buffer as its jet scratch (cluster / table
+        // kernels, unrolled kernels with register-resident jets): tc is then written only on request.
+        return emitted.tc_optional;
     }
 
     void ensure_tc() const
