@@ -191,17 +191,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    t_cur = 0.0
-    for _ in range(args.warmup):
-        t_cur += dt
-        ta.propagate_until(t_cur)
-    barrier()
-
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     # Step counters live on the device: accumulate them with a device-side reduction per call (same
     # stream, no host synchronisation inside the timed region).
     nsteps_view = torch.as_tensor(ta.device_array("n_steps"), device=dev)
-    steps_acc = torch.zeros(args.steps, dtype=torch.int64, device=dev)
+    steps_acc = torch.zeros(max(args.steps, args.warmup, 1), dtype=torch.int64, device=dev)
+    t_cur = 0.0
+    for k in range(args.warmup):
+        # NOTE: the warmup runs the complete step, reduction included (the first use of a torch kernel
+        # costs ~20 ms of lazy code loading).
+        t_cur += dt
+        ta.propagate_until(t_cur)
+        steps_acc[k] = nsteps_view.sum()
+    barrier()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    steps_acc.zero_()
     t0 = time.perf_counter()
     for k in range(args.steps):
         t_cur += dt
@@ -219,7 +223,7 @@ def main():
     # Per-launch kernel durations (HIP events on the launch stream) and step counts.
     call_ms = [a.elapsed_time(b) for a, b in ev]  # torch events around the whole call (incl. small copies)
     kern_ms = list(ta.kernel_ms_history(args.steps))  # HIP events recorded right around each launch
-    steps_per_call_all = steps_acc.cpu().numpy().astype(np.float64)
+    steps_per_call_all = steps_acc[: args.steps].cpu().numpy().astype(np.float64)
     steps_per_call = float(steps_per_call_all.mean())
 
     oc, mn, mx, ns = ta.propagate_res_arrays()
