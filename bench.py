@@ -38,21 +38,21 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_PEAK_TFLOPS = 78.6  # vector FP64
 
 
-def make_integrator(hy, configs, workload, n_systems, seed):
+def make_integrator(hy, configs, workload, n_systems, seed, device=0):
     if workload == "outer_ss":
         sys_ = hy.model.nbody(6, masses=configs.OUTER_SS_MASSES, Gconst=configs.OUTER_SS_G)
         st = configs.outer_ss_state(n_systems, perturb=1e-12, seed=seed)
-        ta = hy.taylor_adaptive_batch(sys_, None, n_systems, high_accuracy=True)
+        ta = hy.taylor_adaptive_batch(sys_, None, n_systems, high_accuracy=True, device=device)
         dt = 4.0  # years per bench step
     elif workload == "nbody64":
         sys_ = hy.model.nbody(64)
         st = configs.plummer_nbody_state(64, n_systems, seed=1234 + seed)
-        ta = hy.taylor_adaptive_batch(sys_, None, n_systems, high_accuracy=False)
+        ta = hy.taylor_adaptive_batch(sys_, None, n_systems, high_accuracy=False, device=device)
         dt = 0.03
     else:
         sys_ = hy.model.nbody(2, masses=[1.0, 0.0])
         st = configs.two_body_state(n_systems, perturb=1e-12, seed=seed)
-        ta = hy.taylor_adaptive_batch(sys_, None, n_systems, high_accuracy=False)
+        ta = hy.taylor_adaptive_batch(sys_, None, n_systems, high_accuracy=False, device=device)
         dt = 5.0
     return ta, st, dt
 
@@ -143,6 +143,9 @@ def main():
     ap.add_argument("--workload", default="outer_ss", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="debug: all ranks share GPU 0 (use with --backend gloo to exercise the N > 1 path on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -155,27 +158,22 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl")
+        dev_index = 0 if args.single_device else local_rank
+        torch.cuda.set_device(dev_index)
+        dist.init_process_group(backend=args.backend)
     else:
+        dev_index = 0
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if distributed else 0)
+    dev = torch.device("cuda", dev_index)
 
     import heyoka_amd as hy
     from heyoka_amd import configs
     from heyoka_amd import ensemble as hens
 
-    if distributed:
-        # One process per GPU: each process sees its GPU as the current torch device; the
-        # integrator is created on that ordinal.
-        pass
-
     n = args.systems if args.systems > 0 else DEFAULT_SYSTEMS[args.workload]
     t_build = time.perf_counter()
-    ta, st, dt = make_integrator(hy, configs, args.workload, n, seed=42 + rank)
-    if distributed and local_rank != 0:
-        # Re-create on the right device ordinal.
-        ta = hy.taylor_adaptive_batch(ta._sys, None, n, high_accuracy=ta.high_accuracy, device=local_rank)
+    # One process per GPU: the integrator lives on this rank's device ordinal.
+    ta, st, dt = make_integrator(hy, configs, args.workload, n, seed=42 + rank, device=dev_index)
     build_s = time.perf_counter() - t_build
 
     # Inputs resident in HBM before the timed region; kernels on torch's current stream so that
