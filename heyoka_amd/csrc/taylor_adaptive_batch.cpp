@@ -935,10 +935,232 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
     }
 }
 
-std::vector<double> tab_core::propagate_grid(std::vector<double>, std::size_t, const std::vector<double> &,
-                                             const cb_t &)
+// Reference: propagate_grid_impl(), src/taylor_adaptive_batch.cpp:1546-2055. Host-driven lock-step loop:
+// single-step kernel launches (always with the Taylor coefficients) interleaved with dense-output launches.
+// grid[point * N + lane]; return value ret[(point * dim + var) * N + lane], NaN where not reached.
+std::vector<double> tab_core::propagate_grid(std::vector<double> grid, std::size_t max_steps,
+                                             const std::vector<double> &max_delta_ts_, const cb_t &cb)
 {
-    throw not_implemented_error("propagate_grid() is not implemented yet in the MI355X batch integrator");
+    auto &d = *m_impl;
+    const auto N = d.N;
+    const auto dim = d.dim;
+    const auto pinf = std::numeric_limits<double>::infinity();
+
+    if (grid.empty()) {
+        throw std::invalid_argument(
+            "Cannot invoke propagate_grid() in an adaptive Taylor integrator in batch mode if the time grid is empty");
+    }
+    if (grid.size() % N != 0u) {
+        throw std::invalid_argument("Invalid grid size detected in propagate_grid() in an adaptive Taylor integrator "
+                                    "in batch mode: the grid has a size of "
+                                    + std::to_string(grid.size()) + ", which is not a multiple of the batch size ("
+                                    + std::to_string(N) + ")");
+    }
+    const std::vector<double> max_delta_ts = max_delta_ts_.empty() ? std::vector<double>(N, pinf) : max_delta_ts_;
+    if (max_delta_ts.size() != N) {
+        throw std::invalid_argument("Invalid number of max timesteps specified in a Taylor integrator in batch mode: "
+                                    "the batch size is "
+                                    + std::to_string(N) + ", but the number of specified timesteps is "
+                                    + std::to_string(max_delta_ts.size()));
+    }
+    for (const auto dt : max_delta_ts) {
+        if (std::isnan(dt)) {
+            throw std::invalid_argument("A nan max_delta_t was passed to the propagate_grid() function of an adaptive "
+                                        "Taylor integrator in batch mode");
+        }
+        if (dt <= 0) {
+            throw std::invalid_argument("A non-positive max_delta_t was passed to the propagate_grid() function of an "
+                                        "adaptive Taylor integrator in batch mode");
+        }
+    }
+
+    const auto n_grid_points = grid.size() / N;
+    const auto *const gp = grid.data();
+    const auto is_nf = [](double t) { return !std::isfinite(t); };
+    const char *nf_err_msg
+        = "A non-finite time value was passed to propagate_grid() in an adaptive Taylor integrator in batch mode";
+    const char *ig_err_msg = "A non-monotonic time grid was passed to propagate_grid() in an adaptive "
+                             "Taylor integrator in batch mode";
+    if (std::any_of(gp, gp + N, is_nf)) {
+        throw std::invalid_argument(nf_err_msg);
+    }
+    if (n_grid_points > 1u) {
+        if (std::any_of(gp + N, gp + 2u * N, is_nf)) {
+            throw std::invalid_argument(nf_err_msg);
+        }
+        if (gp[N] == gp[0]) {
+            throw std::invalid_argument(ig_err_msg);
+        }
+        const auto grid_direction = gp[N] > gp[0];
+        for (std::uint32_t i = 1; i < N; ++i) {
+            if ((gp[N + i] > gp[i]) != grid_direction) {
+                throw std::invalid_argument(ig_err_msg);
+            }
+        }
+        for (std::size_t k = 2; k < n_grid_points; ++k) {
+            for (std::uint32_t i = 0; i < N; ++i) {
+                const auto t = gp[k * N + i];
+                if (is_nf(t)) {
+                    throw std::invalid_argument(nf_err_msg);
+                }
+                if ((t > gp[(k - 1u) * N + i]) != grid_direction) {
+                    throw std::invalid_argument(ig_err_msg);
+                }
+            }
+        }
+    }
+    d.to_host();
+    for (std::uint32_t i = 0; i < N; ++i) {
+        if (d.time_hi[i] != gp[i]) {
+            throw std::invalid_argument("When invoking propagate_grid(), the first element of the time grid "
+                                        "must match the current time coordinate - however, the first element of the "
+                                        "time grid at batch index "
+                                        + std::to_string(i) + " has a value of " + fp_to_string(gp[i])
+                                        + ", while the current time coordinate is " + fp_to_string(d.time_hi[i]));
+        }
+    }
+
+    std::vector<double> retval(grid.size() * dim, std::numeric_limits<double>::quiet_NaN());
+    std::vector<double> pgrid_tmp(gp, gp + N);
+
+    // Propagate up to the first grid point (absorbs the low part of the double-length time).
+    propagate_until(pgrid_tmp, max_steps, max_delta_ts, {}, true, false);
+    d.fetch_prop_res();
+    if (std::any_of(d.prop_res.begin(), d.prop_res.end(),
+                    [](const auto &t) { return std::get<0>(t) != taylor_outcome::time_limit; })) {
+        for (auto &[oc, min_h, max_h, ts_count] : d.prop_res) {
+            (void)oc;
+            min_h = pinf;
+            max_h = 0;
+            ts_count = 0;
+        }
+        return retval;
+    }
+    d.to_host();
+    std::copy(d.state.begin(), d.state.end(), retval.begin());
+
+    std::vector<dfloat> rem(N), t0(N), t1(N);
+    std::vector<int> t_dir(N);
+    for (std::uint32_t i = 0; i < N; ++i) {
+        rem[i] = dfloat(gp[(n_grid_points - 1u) * N + i]) - dfloat(d.time_hi[i], d.time_lo[i]);
+        if (!isfinite(rem[i])) {
+            throw std::invalid_argument("The final time passed to the propagate_grid() function of an adaptive Taylor "
+                                        "integrator in batch mode results in an overflow condition");
+        }
+        t_dir[i] = rem[i] >= dfloat(0.);
+    }
+    std::size_t iter_counter = 0;
+    std::vector<std::size_t> ts_count(N, 0), cur_grid_idx(N, 1);
+    std::vector<double> min_abs_h(N, pinf), max_abs_h(N, 0.);
+    std::vector<unsigned> dflags(N);
+    const auto cont_cond = [&]() {
+        return std::any_of(cur_grid_idx.begin(), cur_grid_idx.end(), [&](auto idx) { return idx < n_grid_points; });
+    };
+    const auto cb_time_errmsg = "The invocation of the callback passed to propagate_grid() resulted in the alteration "
+                                "of the time coordinate of the integrator - this is not supported";
+
+    while (cont_cond()) {
+        const auto &lh = get_last_h();
+        for (std::uint32_t i = 0; i < N; ++i) {
+            const dfloat cur_time(d.time_hi[i], d.time_lo[i]), cmp = cur_time - lh[i];
+            t0[i] = std::min(cur_time, cmp);
+            t1[i] = std::max(cur_time, cmp);
+        }
+        std::fill(dflags.begin(), dflags.end(), 1u);
+        while (true) {
+            std::uint32_t counter = 0;
+            for (std::uint32_t i = 0; i < N; ++i) {
+                const auto gidx = cur_grid_idx[i];
+                if (dflags[i] != 0u && gidx < n_grid_points) {
+                    const auto idx = gidx * N + i;
+                    const auto d_avail = (dfloat(gp[idx]) >= t0[i] && dfloat(gp[idx]) <= t1[i]) || (rem[i] == dfloat(0.));
+                    dflags[i] = d_avail ? 1u : 0u;
+                    counter += d_avail ? 1u : 0u;
+                    pgrid_tmp[i] = gp[idx];
+                } else {
+                    dflags[i] = 0;
+                }
+            }
+            if (counter == 0u) {
+                break;
+            }
+            const auto &dout = update_d_output(pgrid_tmp, false);
+            for (std::uint32_t i = 0; i < N; ++i) {
+                if (dflags[i] != 0u) {
+                    const auto gidx = cur_grid_idx[i];
+                    for (std::uint32_t j = 0; j < dim; ++j) {
+                        retval[gidx * N * dim + static_cast<std::size_t>(j) * N + i] = dout[static_cast<std::size_t>(j) * N + i];
+                    }
+                    ++cur_grid_idx[i];
+                }
+            }
+            if (!cont_cond()) {
+                break;
+            }
+        }
+        if (!cont_cond()) {
+            break;
+        }
+        if (std::any_of(d.prop_res.begin(), d.prop_res.end(), [](const auto &t) {
+                const auto oc = std::get<0>(t);
+                return oc == taylor_outcome::cb_stop || oc == taylor_outcome::step_limit;
+            })) {
+            break;
+        }
+        for (std::uint32_t i = 0; i < N; ++i) {
+            const auto dt_limit
+                = t_dir[i] != 0 ? std::min(dfloat(max_delta_ts[i]), rem[i]) : std::max(dfloat(-max_delta_ts[i]), rem[i]);
+            pgrid_tmp[i] = static_cast<double>(dt_limit);
+        }
+        d.run_step(pgrid_tmp, true);
+        d.fetch_step_res();
+        d.to_host();
+
+        bool nfs_detected = false;
+        for (std::uint32_t i = 0; i < N; ++i) {
+            const auto [oc, h] = d.step_res[i];
+            if (oc == taylor_outcome::err_nf_state) {
+                nfs_detected = true;
+            } else {
+                ts_count[i] += static_cast<std::size_t>(h != 0);
+                if (oc == taylor_outcome::success) {
+                    const auto abs_h = std::abs(h);
+                    min_abs_h[i] = std::min(min_abs_h[i], abs_h);
+                    max_abs_h[i] = std::max(max_abs_h[i], abs_h);
+                }
+                if (h == static_cast<double>(rem[i])) {
+                    rem[i] = dfloat(0.);
+                } else {
+                    rem[i] = dfloat(gp[(n_grid_points - 1u) * N + i]) - dfloat(d.time_hi[i], d.time_lo[i]);
+                }
+            }
+            d.prop_res[i] = std::tuple{oc, min_abs_h[i], max_abs_h[i], ts_count[i]};
+        }
+        d.prop_res_dev_newer = false;
+        if (nfs_detected) {
+            break;
+        }
+        ++iter_counter;
+        bool cb_ok = true;
+        if (cb) {
+            const auto thi_copy = d.time_hi, tlo_copy = d.time_lo;
+            cb_ok = cb();
+            d.to_host();
+            if (d.time_hi != thi_copy || d.time_lo != tlo_copy) {
+                throw std::runtime_error(cb_time_errmsg);
+            }
+        }
+        if (!cb_ok) {
+            for (auto &t : d.prop_res) {
+                std::get<0>(t) = taylor_outcome::cb_stop;
+            }
+        } else if (iter_counter == max_steps) {
+            for (auto &t : d.prop_res) {
+                std::get<0>(t) = taylor_outcome::step_limit;
+            }
+        }
+    }
+    return retval;
 }
 
 double *tab_core::device_state()

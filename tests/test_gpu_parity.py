@@ -402,3 +402,43 @@ def test_unrolled_vs_cluster_v1_vs_v2_same_results():
     for name in ("v1", "table"):
         assert rel_err(res[name][0], res["v2"][0]) <= 1e5 * EPS
         assert np.max(np.abs(res[name][1] - res["v2"][1])) <= 1
+
+
+def test_propagate_grid():
+    """propagate_grid() (src/taylor_adaptive_batch.cpp:1546-2055): doc/tut_adaptive.rst:324-325 known answer,
+    agreement with direct propagation to every grid point, per-lane grids, error paths."""
+    ta = hy.taylor_adaptive_batch(pendulum_p(), [[0.05] * 3, [0.025] * 3], 3)
+    grid = np.linspace(0.0, 1.0, 11)
+    _, out = ta.propagate_grid(grid)
+    assert out.shape == (11, 2, 3)
+    assert sig_close(out[4, 0, 0], 0.0232578) and sig_close(out[4, 1, 0], -0.14078)
+    assert np.array_equal(out[0], [[0.05] * 3, [0.025] * 3])
+    assert all(r[0] == OC.time_limit for r in ta.propagate_res)
+    assert np.array_equal(ta.time, [1.0] * 3)
+    assert rel_err(ta.state, out[-1]) <= 10 * EPS
+    # Every grid point agrees with a direct propagate_until() from the initial conditions.
+    for k in (1, 5, 10):
+        tb = hy.taylor_adaptive_batch(pendulum_p(), [[0.05] * 3, [0.025] * 3], 3)
+        tb.propagate_until(float(grid[k]))
+        assert rel_err(out[k], tb.state) <= 100 * EPS
+    # Per-lane grids (different spacing per lane), backward in time, with the oracle as cross-check.
+    n = 4
+    rng = np.random.RandomState(4)
+    st = np.stack([rng.uniform(-0.5, 0.5, n), rng.uniform(-0.5, 0.5, n)])
+    g2 = -np.outer(np.arange(6.0), np.array([0.3, 0.5, 0.7, 1.1]))
+    tc_ = hy.taylor_adaptive_batch(pendulum_p(), st, n)
+    _, out2 = tc_.propagate_grid(g2)
+    for k in range(1, 6):
+        ora = ho.OracleIntegrator(pendulum_o(), st, n)
+        ora.propagate_until(g2[k])
+        assert rel_err(out2[k], ora.state.reshape(2, n)) <= 1e3 * EPS
+    # Error paths (messages of the reference).
+    with pytest.raises(ValueError, match="non-monotonic time grid"):
+        tc_.propagate_grid(np.outer([-5.5, -6.0, -5.8], np.ones(n)) * np.array([0.3, 0.5, 0.7, 1.1]) / 0.3 * 0.3)
+    with pytest.raises(ValueError, match="must match the current time coordinate"):
+        tc_.propagate_grid(np.outer([0.0, 1.0], np.ones(n)))
+    # max_steps -> step_limit, unreached grid points are NaN.
+    td = hy.taylor_adaptive_batch(pendulum_p(), [[0.05], [0.025]], 1)
+    _, out3 = td.propagate_grid(np.linspace(0.0, 10.0, 11), max_steps=2)
+    assert td.propagate_res[0][0] == OC.step_limit
+    assert np.isnan(out3[-1]).all() and not np.isnan(out3[0]).any()
