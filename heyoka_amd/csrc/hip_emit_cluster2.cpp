@@ -353,7 +353,26 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         (void)valid;
     };
 
+    // NOTE: the history chains of order k can be emitted in several parts: the first one at the end of
+    // order k - 1 (it overlaps the glue exchange), the others at the beginning of the cluster phase of
+    // order k. Measured on gfx950 (outer-SS, 1 048 576 systems): 18.11 ms per launch for 1, 2 and 3 parts
+    // - the chains only touch registers, so the compiler's scheduler already moves them across the
+    // compiler-only HY_WSYNC barrier. Hence the default of a single part.
+    const std::uint32_t n_parts = [&]() -> std::uint32_t {
+        if (const char *ev = std::getenv("HEYOKA_AMD_PARTIAL_SPLIT")) {
+            return std::max(1, std::atoi(ev));
+        }
+        return 1u;
+    }();
+    std::vector<std::uint32_t> t0_ids;
+    for (const auto u : t0) {
+        t0_ids.push_back(u - n_eq);
+    }
+
     const auto emit_cluster = [&](std::uint32_t k) {
+        for (std::uint32_t part = 1; part < n_parts; ++part) {
+            e.emit_partials(t0_ids, k, part, n_parts);
+        }
         for (std::uint32_t x = 0; x < n_ext; ++x) {
             e.val(pl.ext_u[0][x], k) = e.def(slabk(k, utname(ext_tbl[x])));
         }
@@ -389,11 +408,7 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
             }
             if (lev == pl.max_level && k + 1u < order) {
                 // History part of the next order's convolutions: overlaps the exchange latency.
-                std::vector<std::uint32_t> ids;
-                for (const auto u : t0) {
-                    ids.push_back(u - n_eq);
-                }
-                e.emit_partials(ids, k + 1u);
+                e.emit_partials(t0_ids, k + 1u, 0, n_parts);
             }
             sync();
         }

@@ -541,35 +541,46 @@ struct ssa_emitter {
 
     // Emit the history parts of order k for a set of nodes, interleaving the FMA chains of the different
     // nodes term by term (independent chains back to back hide the FP64 FMA latency at one wave per SIMD).
-    void emit_partials(const std::vector<std::uint32_t> &node_ids, std::uint32_t k)
+    // NOTE: the interleaved chains can be emitted in several parts (part = 0 .. n_parts - 1), so
+    // that the caller can spread the history work over different latency windows. The accumulators
+    // are carried from one part to the next in pending_chains.
+    struct chain_state {
+        std::uint32_t node;
+        bool is_sq;
+        std::vector<chain_term> terms;
+        std::string acc;
+    };
+    std::map<std::uint32_t, std::vector<chain_state>> pending_chains;
+
+    void emit_partials(const std::vector<std::uint32_t> &node_ids, std::uint32_t k, std::uint32_t part = 0,
+                       std::uint32_t n_parts = 1)
     {
         if (k < 2u) {
             return;
         }
-        struct chain_state {
-            std::uint32_t node;
-            bool is_sq;
-            std::vector<chain_term> terms;
-            std::string acc;
-        };
-        std::vector<chain_state> chains;
-        for (const auto i : node_ids) {
-            if (!can_split(i)) {
-                continue;
+        if (part == 0u) {
+            std::vector<chain_state> chains;
+            for (const auto i : node_ids) {
+                if (!can_split(i)) {
+                    continue;
+                }
+                std::vector<chain_term> main, sq;
+                partial_terms(i, k, main, sq);
+                chains.push_back({i, false, std::move(main), {}});
+                if (!sq.empty()) {
+                    chains.push_back({i, true, std::move(sq), {}});
+                }
             }
-            std::vector<chain_term> main, sq;
-            partial_terms(i, k, main, sq);
-            // NOTE: long chains are split in two interleaved accumulators.
-            chains.push_back({i, false, std::move(main), {}});
-            if (!sq.empty()) {
-                chains.push_back({i, true, std::move(sq), {}});
-            }
+            pending_chains[k] = std::move(chains);
         }
+        auto &chains = pending_chains[k];
         std::size_t max_len = 0;
         for (const auto &c : chains) {
             max_len = std::max(max_len, c.terms.size());
         }
-        for (std::size_t t = 0; t < max_len; ++t) {
+        const auto t_begin = max_len * part / n_parts;
+        const auto t_end = max_len * (part + 1u) / n_parts;
+        for (std::size_t t = t_begin; t < t_end; ++t) {
             for (auto &c : chains) {
                 if (t >= c.terms.size()) {
                     continue;
@@ -583,8 +594,11 @@ struct ssa_emitter {
                 }
             }
         }
-        for (auto &c : chains) {
-            partials[{c.node, c.is_sq ? (k + 0x10000u) : k}] = c.acc;
+        if (part + 1u == n_parts) {
+            for (auto &c : chains) {
+                partials[{c.node, c.is_sq ? (k + 0x10000u) : k}] = c.acc;
+            }
+            pending_chains.erase(k);
         }
     }
 

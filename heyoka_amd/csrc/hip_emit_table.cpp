@@ -7,9 +7,11 @@
 // per-node-kind device functions (one per elementary function, the "plugin" layer of the reference,
 // include/heyoka/func.hpp:117-147) interpreted over node tables stored in the module; control flow is
 // wave-uniform (all lanes process the same node), so table reads are scalar loads. The tape of
-// normalised derivatives lives in HBM, laid out tape[(order * n_u + u) * T + thread] (coalesced: one
-// 512-byte line per wave access), sized by the number of resident threads T: persistent blocks walk the
-// ensemble with a grid stride. Sums are accumulated as running sums in increasing j (the reference's
+// normalised derivatives lives in HBM in one tile per resident wave, laid out
+// tile[(u * (order + 1) + k) * 64 + lane]: one 512-byte line per wave access, and all the orders of a u
+// variable are contiguous (10.5 KB), so that a convolution walks two short contiguous runs (few pages,
+// L2-friendly) instead of striding over the whole allocation. Persistent blocks walk the ensemble with a
+// grid stride. Sums are accumulated as running sums in increasing j (the reference's
 // compact-mode order, e.g. src/math/prod.cpp:686-698).
 //
 // This mode is HBM-bound by construction (every convolution term reads two tape entries); it exists for
@@ -43,8 +45,8 @@ const char *table_device_code = R"HIP(
 #define A_PAR 2
 
 struct hy_tctx {
-    double *tape;      // this thread's column of the tape
-    u64 T;             // tape stride between consecutive (order, u) entries
+    double *tape;      // this lane's column of the wave's tape tile
+    u64 T;             // total number of resident threads
     const double *pars;
     u64 N, s;
     double t_hi;
@@ -52,7 +54,7 @@ struct hy_tctx {
 
 __device__ __forceinline__ double &hy_tp(const hy_tctx &c, unsigned k, unsigned u)
 {
-    return c.tape[((u64)k * HY_N_U + u) * c.T];
+    return c.tape[((u64)u * (HY_ORDER + 1u) + k) * 64u];
 }
 
 __device__ __forceinline__ double hy_numpar(const hy_tctx &c, unsigned a)
@@ -304,7 +306,7 @@ extern "C" __global__ void __launch_bounds__(256, 4) hy_taylor(const hy_kargs a)
     const u64 tid = (u64)blockIdx.x * 256u + threadIdx.x;
     const u64 N = a.N;
     hy_tctx c;
-    c.tape = a.scratch + tid;
+    c.tape = a.scratch + (tid >> 6) * ((u64)HY_N_U * (HY_ORDER + 1u) * 64u) + (tid & 63u);
     c.T = T;
     c.pars = a.pars;
     c.N = N;
@@ -531,8 +533,8 @@ emitted_module emit_table(const taylor_program &p, const emit_options &opts)
     ret.mode = emit_mode::table;
     ret.persistent = true;
     ret.tc_optional = true;
-    // One tape column per resident *thread*: (n_u * order + n_eq) doubles, i.e. 64x that per wave.
-    ret.scratch_per_wave = (static_cast<std::uint64_t>(p.n_u) * opts.order + p.n_eq) * 64u;
+    // One tape tile per resident wave: n_u * (order + 1) rows of 64 doubles.
+    ret.scratch_per_wave = static_cast<std::uint64_t>(p.n_u) * (opts.order + 1u) * 64u;
     ret.notes = "table mode: " + std::to_string(p.nodes.size()) + " nodes interpreted from tables, tape in HBM";
     return ret;
 }
