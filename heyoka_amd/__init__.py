@@ -18,6 +18,8 @@ from . import _lib
 from ._lib import lib, raise_for, check_handle, take_str
 
 __all__ = [
+    "cfunc",
+    "continuous_output_batch",
     "expression",
     "make_vars",
     "par",
@@ -224,6 +226,14 @@ class _Sys:
     def __len__(self):
         return int(lib.hy_sys_size(self._h))
 
+    @property
+    def vars(self):
+        """The state variables (lhs of each equation), in order."""
+        n = len(self)
+        arr = (ctypes.c_void_p * n)()
+        raise_for(lib.hy_sys_get_vars(self._h, arr))
+        return [expression(_handle=check_handle(arr[i])) for i in range(n)]
+
 
 def _to_sys(sys):
     return sys if isinstance(sys, _Sys) else _Sys(sys)
@@ -233,17 +243,52 @@ class model:
     """heyoka::model (include/heyoka/model/nbody.hpp:73-78, model/pendulum.hpp)."""
 
     @staticmethod
-    def nbody(n, masses=None, Gconst=1.0):
+    def _nbody_args(masses, Gconst):
+        """Masses / G as expressions (numbers or par[i]); returns (array, n, G handle, keep-alive list)."""
+        keep = []
         if masses is None:
-            h = lib.hy_model_nbody(int(n), None, 0, float(Gconst))
+            arr, n = None, 0
         else:
-            m = np.ascontiguousarray(np.asarray(masses, dtype=np.float64))
-            h = lib.hy_model_nbody(int(n), m.ctypes.data, m.size, float(Gconst))
+            ms = [_as_ex(m) for m in masses]
+            keep.extend(ms)
+            arr = (ctypes.c_void_p * len(ms))(*[m._h for m in ms])
+            n = len(ms)
+        g = _as_ex(Gconst)
+        keep.append(g)
+        return arr, n, g._h, keep
+
+    @staticmethod
+    def nbody(n, masses=None, Gconst=1.0):
+        numeric = not isinstance(Gconst, expression) and (
+            masses is None or not any(isinstance(m, expression) for m in masses))
+        if numeric:
+            if masses is None:
+                h = lib.hy_model_nbody(int(n), None, 0, float(Gconst))
+            else:
+                m = np.ascontiguousarray(np.asarray(masses, dtype=np.float64))
+                h = lib.hy_model_nbody(int(n), m.ctypes.data, m.size, float(Gconst))
+        else:
+            arr, nm, g, _keep = model._nbody_args(masses, Gconst)
+            h = lib.hy_model_nbody_ex(int(n), arr, nm, g)
         return _Sys(_handle=check_handle(h))
+
+    @staticmethod
+    def nbody_energy(n, masses=None, Gconst=1.0):
+        arr, nm, g, _keep = model._nbody_args(masses, Gconst)
+        return expression(_handle=check_handle(lib.hy_model_nbody_energy(int(n), arr, nm, g)))
+
+    @staticmethod
+    def nbody_potential(n, masses=None, Gconst=1.0):
+        arr, nm, g, _keep = model._nbody_args(masses, Gconst)
+        return expression(_handle=check_handle(lib.hy_model_nbody_potential(int(n), arr, nm, g)))
 
     @staticmethod
     def pendulum(gconst=1.0, length=1.0):
         return _Sys(_handle=check_handle(lib.hy_model_pendulum(float(gconst), float(length))))
+
+    @staticmethod
+    def pendulum_energy(gconst=1.0, length=1.0):
+        return expression(_handle=check_handle(lib.hy_model_pendulum_energy(float(gconst), float(length))))
 
 
 def taylor_decompose_sys(sys):
@@ -269,6 +314,158 @@ class _DeviceArray:
             "version": 2,
             "strides": None,
         }
+
+    @property
+    def ptr(self):
+        """Raw device address (int)."""
+        return self.__cuda_array_interface__["data"][0]
+
+    @property
+    def shape(self):
+        return self.__cuda_array_interface__["shape"]
+
+
+class cfunc:
+    """cfunc<double> (reference: include/heyoka/expression.hpp:735-970): compiled evaluation of ``fn(vars)``
+    over many input columns - one HIP kernel, one lane per evaluation. Arrays are row-major
+    ``inputs[var, eval]`` (the reference's 2D call operator), i.e. the integrator's SoA state layout.
+
+    ``cf(inputs, pars=None, time=None)`` works on host arrays; ``cf.eval_device(out_ptr, in_ptr, ...)`` works
+    on device pointers (e.g. ``ta.device_array("state").ptr``) without any host round trip."""
+
+    def __init__(self, fn, vars, device=0, **_ignored):
+        fs = [_as_ex(f) for f in fn]
+        vs = [_as_ex(v) for v in vars]
+        fa = (ctypes.c_void_p * len(fs))(*[f._h for f in fs])
+        va = (ctypes.c_void_p * len(vs))(*[v._h for v in vs])
+        self._h = check_handle(lib.hy_cfunc_new(fa, len(fs), va, len(vs), int(device)))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.hy_cfunc_free(h)
+
+    @property
+    def nparams(self):
+        return int(lib.hy_cfunc_get_nparams(self._h))
+
+    @property
+    def nvars(self):
+        return int(lib.hy_cfunc_get_nvars(self._h))
+
+    @property
+    def nouts(self):
+        return int(lib.hy_cfunc_get_nouts(self._h))
+
+    @property
+    def is_time_dependent(self):
+        return bool(lib.hy_cfunc_is_time_dependent(self._h))
+
+    @property
+    def dc(self):
+        return take_str(check_handle(lib.hy_cfunc_decomposition_str(self._h))).rstrip("\n").split("\n")
+
+    @property
+    def hip_source(self):
+        return take_str(check_handle(lib.hy_cfunc_get_hip_source(self._h)))
+
+    def set_stream(self, stream_ptr):
+        raise_for(lib.hy_cfunc_set_stream(self._h, ctypes.c_void_p(stream_ptr)))
+
+    def __call__(self, inputs, pars=None, time=None):
+        x = _f64(inputs)
+        single = x.ndim == 1
+        nev = 1 if single else x.shape[1]
+        out = np.empty(self.nouts if single else (self.nouts, nev))
+        p = None if pars is None else _f64(pars)
+        t = None if time is None else _f64(time).reshape(-1)
+        raise_for(lib.hy_cfunc_eval(self._h, out.ctypes.data, out.size, x.ctypes.data, x.size,
+                                    None if p is None else p.ctypes.data, 0 if p is None else p.size,
+                                    None if t is None else t.ctypes.data, 0 if t is None else t.size))
+        return out
+
+    def eval_device(self, d_out, d_in, nevals, d_pars=None, d_time=None):
+        """All pointers are device addresses (ints); asynchronous on the cfunc's stream."""
+        raise_for(lib.hy_cfunc_eval_device(self._h, ctypes.c_void_p(d_out), ctypes.c_void_p(d_in),
+                                           ctypes.c_void_p(d_pars) if d_pars else None,
+                                           ctypes.c_void_p(d_time) if d_time else None, int(nevals)))
+
+
+class continuous_output_batch:
+    """continuous_output_batch<double> (reference: include/heyoka/continuous_output.hpp:151-204): returned
+    by propagate_for/until(c_output=True). Coefficients and times live in HBM; ``co(t)`` launches one kernel."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self._output = None
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.hy_cout_free(h)
+
+    def __copy__(self):
+        return continuous_output_batch(check_handle(lib.hy_cout_clone(self._h)))
+
+    def __deepcopy__(self, memo):
+        return self.__copy__()
+
+    @property
+    def batch_size(self):
+        return int(lib.hy_cout_get_batch_size(self._h))
+
+    @property
+    def dim(self):
+        return int(lib.hy_cout_get_dim(self._h))
+
+    @property
+    def order(self):
+        return int(lib.hy_cout_get_order(self._h))
+
+    @property
+    def n_steps(self):
+        n = ctypes.c_size_t()
+        raise_for(lib.hy_cout_get_n_steps(self._h, ctypes.byref(n)))
+        return int(n.value)
+
+    @property
+    def bounds(self):
+        lb, ub = np.empty(self.batch_size), np.empty(self.batch_size)
+        raise_for(lib.hy_cout_get_bounds(self._h, lb.ctypes.data, ub.ctypes.data))
+        return lb, ub
+
+    @property
+    def times(self):
+        """(n_steps + 2, batch_size): the last row is the +-inf padding, as in the reference."""
+        hi = np.empty((self.n_steps + 2, self.batch_size))
+        raise_for(lib.hy_cout_get_times(self._h, hi.ctypes.data, None))
+        return hi
+
+    @property
+    def tcs(self):
+        """(n_steps, dim, order + 1, batch_size)."""
+        out = np.empty((self.n_steps, self.dim, self.order + 1, self.batch_size))
+        raise_for(lib.hy_cout_get_tcs(self._h, out.ctypes.data))
+        return out
+
+    @property
+    def output(self):
+        return self._output
+
+    def __call__(self, tm):
+        """tm: scalar or array of batch_size target times -> (dim, batch_size)."""
+        t = _f64(tm).reshape(-1)
+        out = np.empty((self.dim, self.batch_size))
+        raise_for(lib.hy_cout_eval(self._h, t.ctypes.data, t.size, out.ctypes.data))
+        self._output = out
+        return out
+
+    def eval_device(self, d_tm_ptr, d_out_ptr):
+        """Device pointers (ints): target times [batch_size] -> output [dim * batch_size]; asynchronous."""
+        raise_for(lib.hy_cout_eval_device(self._h, ctypes.c_void_p(d_tm_ptr), ctypes.c_void_p(d_out_ptr)))
+
+    def __repr__(self):
+        return _lib.take_str(lib.hy_cout_to_string(self._h))
 
 
 class taylor_adaptive_batch:
@@ -509,7 +706,14 @@ class taylor_adaptive_batch:
         if err:
             raise err[0]
         raise_for(rc)
-        return callback
+        c_out = None
+        if c_output:
+            h = ctypes.c_void_p()
+            raise_for(lib.hy_tab_take_c_output(self._h, ctypes.byref(h)))
+            if h.value:
+                c_out = continuous_output_batch(h.value)
+        # NOTE: like the reference's Python binding: (continuous output or None, callback).
+        return c_out, callback
 
     def propagate_until(self, t, max_steps=0, max_delta_t=None, callback=None, write_tc=False, c_output=False):
         return self._propagate(lib.hy_tab_propagate_until, t, max_steps, max_delta_t, callback, write_tc, c_output)

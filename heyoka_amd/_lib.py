@@ -124,6 +124,35 @@ SIGNATURES = [
         [c_void_p, c_void_p, c_size_t, c_uint64, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p],
     ),
     ("hy_tab_get_propagate_res", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("hy_model_nbody_ex", c_void_p, [c_uint32, c_void_p, c_size_t, c_void_p]),
+    ("hy_model_nbody_energy", c_void_p, [c_uint32, c_void_p, c_size_t, c_void_p]),
+    ("hy_model_nbody_potential", c_void_p, [c_uint32, c_void_p, c_size_t, c_void_p]),
+    ("hy_model_pendulum_energy", c_void_p, [c_double, c_double]),
+    ("hy_sys_get_vars", c_int, [c_void_p, c_void_p]),
+    ("hy_cfunc_new", c_void_p, [c_void_p, c_size_t, c_void_p, c_size_t, c_int]),
+    ("hy_cfunc_free", None, [c_void_p]),
+    ("hy_cfunc_get_nparams", c_uint32, [c_void_p]),
+    ("hy_cfunc_get_nvars", c_uint32, [c_void_p]),
+    ("hy_cfunc_get_nouts", c_uint32, [c_void_p]),
+    ("hy_cfunc_is_time_dependent", c_int, [c_void_p]),
+    ("hy_cfunc_decomposition_str", c_void_p, [c_void_p]),
+    ("hy_cfunc_get_hip_source", c_void_p, [c_void_p]),
+    ("hy_cfunc_set_stream", c_int, [c_void_p, c_void_p]),
+    ("hy_cfunc_eval", c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t]),
+    ("hy_cfunc_eval_device", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64]),
+    ("hy_tab_take_c_output", c_int, [c_void_p, c_void_p]),
+    ("hy_cout_free", None, [c_void_p]),
+    ("hy_cout_clone", c_void_p, [c_void_p]),
+    ("hy_cout_eval", c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    ("hy_cout_eval_device", c_int, [c_void_p, c_void_p, c_void_p]),
+    ("hy_cout_get_batch_size", c_uint32, [c_void_p]),
+    ("hy_cout_get_dim", c_uint32, [c_void_p]),
+    ("hy_cout_get_order", c_uint32, [c_void_p]),
+    ("hy_cout_get_n_steps", c_int, [c_void_p, c_void_p]),
+    ("hy_cout_get_bounds", c_int, [c_void_p, c_void_p, c_void_p]),
+    ("hy_cout_get_times", c_int, [c_void_p, c_void_p, c_void_p]),
+    ("hy_cout_get_tcs", c_int, [c_void_p, c_void_p]),
+    ("hy_cout_to_string", c_void_p, [c_void_p]),
     ("hy_tab_device_ptr", c_void_p, [c_void_p, c_int]),
     ("hy_tab_mark_device_modified", c_int, [c_void_p]),
     ("hy_tab_set_stream", c_int, [c_void_p, c_void_p]),

@@ -11,6 +11,7 @@
 
 #include <hip/hiprtc.h>
 
+#include "cfunc.hpp"
 #include "decompose.hpp"
 #include "ensemble.hpp"
 #include "expression.hpp"
@@ -30,6 +31,14 @@ struct hy_sys_s {
 
 struct hy_tab_s {
     detail::tab_core core;
+};
+
+struct hy_cout_s {
+    detail::c_out_core core;
+};
+
+struct hy_cfunc_s {
+    detail::cfunc_core core;
 };
 
 namespace
@@ -295,6 +304,61 @@ hy_sys hy_model_nbody(uint32_t n, const double *masses, size_t n_masses, double 
         return nullptr;
     }
 }
+namespace
+{
+
+std::pair<expression, std::vector<expression>> model_args(uint32_t n, const hy_expr *masses, size_t n_masses,
+                                                          hy_expr Gconst)
+{
+    std::vector<expression> mv;
+    if (masses == nullptr) {
+        mv.resize(n, expression{1.});
+    } else {
+        for (size_t i = 0; i < n_masses; ++i) {
+            mv.push_back(masses[i]->ex);
+        }
+    }
+    return {Gconst == nullptr ? expression{1.} : Gconst->ex, std::move(mv)};
+}
+
+} // namespace
+
+hy_sys hy_model_nbody_ex(uint32_t n, const hy_expr *masses, size_t n_masses, hy_expr Gconst)
+{
+    try {
+        auto [G, mv] = model_args(n, masses, n_masses, Gconst);
+        return new hy_sys_s{model::detail::nbody_impl(n, G, mv)};
+    } catch (...) {
+        handle_exception();
+        return nullptr;
+    }
+}
+hy_expr hy_model_nbody_energy(uint32_t n, const hy_expr *masses, size_t n_masses, hy_expr Gconst)
+{
+    return make_expr([&] {
+        auto [G, mv] = model_args(n, masses, n_masses, Gconst);
+        return model::detail::nbody_energy_impl(n, G, mv);
+    });
+}
+hy_expr hy_model_nbody_potential(uint32_t n, const hy_expr *masses, size_t n_masses, hy_expr Gconst)
+{
+    return make_expr([&] {
+        auto [G, mv] = model_args(n, masses, n_masses, Gconst);
+        return model::detail::nbody_potential_impl(n, G, mv);
+    });
+}
+hy_expr hy_model_pendulum_energy(double gconst, double length)
+{
+    return make_expr([&] { return model::detail::pendulum_energy_impl(expression{gconst}, expression{length}); });
+}
+int hy_sys_get_vars(hy_sys s, hy_expr *out)
+{
+    return guarded([&] {
+        for (std::size_t i = 0; i < s->sys.size(); ++i) {
+            out[i] = new hy_expr_s{s->sys[i].first};
+        }
+    });
+}
 hy_sys hy_model_pendulum(double gconst, double length)
 {
     try {
@@ -524,6 +588,162 @@ int hy_tab_propagate_for(hy_tab t, const double *dts, size_t n_dts, uint64_t max
                               expand_mdt(mdts, n_mdt, t->core.get_batch_size()), wrap_cb(t, cb, cb_data), wtc != 0,
                               c_out != 0);
     });
+}
+int hy_tab_take_c_output(hy_tab t, hy_cout *out)
+{
+    return guarded([&] {
+        *out = nullptr;
+        auto c = t->core.take_c_output();
+        if (c) {
+            *out = new hy_cout_s{std::move(*c)};
+        }
+    });
+}
+void hy_cout_free(hy_cout c)
+{
+    delete c;
+}
+hy_cout hy_cout_clone(hy_cout c)
+{
+    try {
+        return new hy_cout_s{c->core};
+    } catch (...) {
+        handle_exception();
+        return nullptr;
+    }
+}
+int hy_cout_eval(hy_cout c, const double *tm, size_t n_tm, double *out)
+{
+    return guarded([&] {
+        const auto &r = (n_tm == 1u && c->core.get_batch_size() != 1u) ? c->core.call(tm[0])
+                                                                       : c->core.call(vec_from(tm, n_tm));
+        std::memcpy(out, r.data(), r.size() * sizeof(double));
+    });
+}
+int hy_cout_eval_device(hy_cout c, const double *d_tm, double *d_out)
+{
+    return guarded([&] { c->core.call_device(d_tm, d_out); });
+}
+uint32_t hy_cout_get_batch_size(hy_cout c)
+{
+    return c->core.get_batch_size();
+}
+uint32_t hy_cout_get_dim(hy_cout c)
+{
+    return c->core.get_dim();
+}
+uint32_t hy_cout_get_order(hy_cout c)
+{
+    return c->core.get_order();
+}
+int hy_cout_get_n_steps(hy_cout c, size_t *n)
+{
+    return guarded([&] { *n = c->core.get_n_steps(); });
+}
+int hy_cout_get_bounds(hy_cout c, double *lb, double *ub)
+{
+    return guarded([&] {
+        const auto [l, u] = c->core.get_bounds();
+        std::memcpy(lb, l.data(), l.size() * sizeof(double));
+        std::memcpy(ub, u.data(), u.size() * sizeof(double));
+    });
+}
+int hy_cout_get_times(hy_cout c, double *hi, double *lo)
+{
+    return guarded([&] {
+        const auto &h = c->core.get_times();
+        std::memcpy(hi, h.data(), h.size() * sizeof(double));
+        if (lo != nullptr) {
+            const auto &l = c->core.get_times_lo();
+            std::memcpy(lo, l.data(), l.size() * sizeof(double));
+        }
+    });
+}
+int hy_cout_get_tcs(hy_cout c, double *out)
+{
+    return guarded([&] {
+        const auto &t = c->core.get_tcs();
+        std::memcpy(out, t.data(), t.size() * sizeof(double));
+    });
+}
+char *hy_cout_to_string(hy_cout c)
+{
+    try {
+        std::ostringstream oss;
+        c->core.stream_to(oss);
+        return dup_str(oss.str());
+    } catch (...) {
+        handle_exception();
+        return nullptr;
+    }
+}
+hy_cfunc hy_cfunc_new(const hy_expr *fn, size_t n_fn, const hy_expr *vars, size_t n_vars, int device)
+{
+    try {
+        std::vector<expression> f, v;
+        for (size_t i = 0; i < n_fn; ++i) {
+            f.push_back(fn[i]->ex);
+        }
+        for (size_t i = 0; i < n_vars; ++i) {
+            v.push_back(vars[i]->ex);
+        }
+        return new hy_cfunc_s{detail::cfunc_core(std::move(f), std::move(v), device)};
+    } catch (...) {
+        handle_exception();
+        return nullptr;
+    }
+}
+void hy_cfunc_free(hy_cfunc c)
+{
+    delete c;
+}
+uint32_t hy_cfunc_get_nparams(hy_cfunc c)
+{
+    return c->core.get_nparams();
+}
+uint32_t hy_cfunc_get_nvars(hy_cfunc c)
+{
+    return c->core.get_nvars();
+}
+uint32_t hy_cfunc_get_nouts(hy_cfunc c)
+{
+    return c->core.get_nouts();
+}
+int hy_cfunc_is_time_dependent(hy_cfunc c)
+{
+    return c->core.is_time_dependent() ? 1 : 0;
+}
+char *hy_cfunc_decomposition_str(hy_cfunc c)
+{
+    try {
+        return dup_str(dc_to_string(c->core.get_dc()));
+    } catch (...) {
+        handle_exception();
+        return nullptr;
+    }
+}
+char *hy_cfunc_get_hip_source(hy_cfunc c)
+{
+    try {
+        return dup_str(c->core.get_hip_source());
+    } catch (...) {
+        handle_exception();
+        return nullptr;
+    }
+}
+int hy_cfunc_set_stream(hy_cfunc c, void *stream)
+{
+    return guarded([&] { c->core.set_stream(stream); });
+}
+int hy_cfunc_eval(hy_cfunc c, double *out, size_t out_size, const double *in, size_t in_size, const double *pars,
+                  size_t pars_size, const double *time, size_t time_size)
+{
+    return guarded([&] { c->core.call_host(out, out_size, in, in_size, pars, pars_size, time, time_size); });
+}
+int hy_cfunc_eval_device(hy_cfunc c, double *d_out, const double *d_in, const double *d_pars, const double *d_time,
+                         uint64_t nevals)
+{
+    return guarded([&] { c->core.call_device(d_out, d_in, d_pars, d_time, nevals); });
 }
 int hy_tab_propagate_grid(hy_tab t, const double *grid, size_t n_grid, uint64_t max_steps, const double *mdts,
                           size_t n_mdt, hy_step_callback cb, void *cb_data, double *out)

@@ -236,8 +236,10 @@ std::size_t func_taylor_decompose(expression f_ex, taylor_dc_t &dc)
 
 // Iterative post-order decomposition with a pointer cache
 // (reference: expression_decompose_impl(), src/expression_decompose.cpp:43-210).
+// NOTE: with taylor = false every function is appended as-is (decomposition of a compiled function,
+// src/func.cpp:360-390: no partner functions / hidden dependencies).
 std::optional<std::size_t> taylor_decompose(std::unordered_map<const void *, std::size_t> &func_map,
-                                            const expression &e, taylor_dc_t &dc)
+                                            const expression &e, taylor_dc_t &dc, bool taylor = true)
 {
     std::vector<std::pair<const expression *, bool>> stack;
     std::vector<std::optional<std::optional<std::size_t>>> out_stack;
@@ -274,7 +276,14 @@ std::optional<std::size_t> taylor_decompose(std::unordered_map<const void *, std
                     out_stack.pop_back();
                 }
 
-                const auto ret = func_taylor_decompose(expression{f.copy_with_new_args(std::move(new_args))}, dc);
+                std::size_t ret = 0;
+                if (taylor) {
+                    ret = func_taylor_decompose(expression{f.copy_with_new_args(std::move(new_args))}, dc);
+                } else {
+                    ret = dc.size();
+                    dc.emplace_back(expression{f.copy_with_new_args(std::move(new_args))},
+                                    std::vector<std::uint32_t>{});
+                }
                 if (ret == 0u || ret >= dc.size()) {
                     throw std::invalid_argument("Invalid value returned by the Taylor decomposition of a function");
                 }
@@ -308,9 +317,11 @@ std::uint32_t remap_uidx(const std::unordered_map<std::string, std::string> &m, 
 
 // Common subexpression elimination (reference: taylor_decompose_cse(), src/taylor_01.cpp:315-443).
 // NOTE: hidden deps are not considered when comparing subexpressions.
-taylor_dc_t taylor_decompose_cse(const taylor_dc_t &v_ex, std::size_t n_eq)
+// NOTE: n_eq leading variable entries, n_outs trailing definitions (n_outs == n_eq in a Taylor decomposition;
+// the decomposition of a compiled function has nvars / nouts instead, src/expression_cfunc.cpp:198-300).
+taylor_dc_t taylor_decompose_cse(const taylor_dc_t &v_ex, std::size_t n_eq, std::size_t n_outs)
 {
-    assert(v_ex.size() >= n_eq * 2u);
+    assert(v_ex.size() >= n_eq + n_outs);
 
     taylor_dc_t new_dc;
     std::unordered_map<expression, std::size_t, expression_hash> ex_map;
@@ -322,7 +333,7 @@ taylor_dc_t taylor_decompose_cse(const taylor_dc_t &v_ex, std::size_t n_eq)
         uvars_rename.emplace(uname(i), uname(i));
     }
 
-    for (auto i = n_eq; i < v_ex.size() - n_eq; ++i) {
+    for (auto i = n_eq; i < v_ex.size() - n_outs; ++i) {
         const auto &[orig_ex, orig_deps] = v_ex[i];
 
         auto new_ex = rename_variables(cache, orig_ex, uvars_rename);
@@ -339,7 +350,7 @@ taylor_dc_t taylor_decompose_cse(const taylor_dc_t &v_ex, std::size_t n_eq)
         }
     }
 
-    for (auto i = v_ex.size() - n_eq; i < v_ex.size(); ++i) {
+    for (auto i = v_ex.size() - n_outs; i < v_ex.size(); ++i) {
         const auto &[orig_ex, orig_deps] = v_ex[i];
         assert(!orig_ex.is_func() && orig_deps.empty());
         new_dc.emplace_back(rename_variables(cache, orig_ex, uvars_rename), orig_deps);
@@ -356,12 +367,12 @@ taylor_dc_t taylor_decompose_cse(const taylor_dc_t &v_ex, std::size_t n_eq)
 }
 
 // Breadth-first (Kahn) topological re-sort (reference: taylor_sort_dc(), src/taylor_01.cpp:454-645).
-taylor_dc_t taylor_sort_dc(const taylor_dc_t &dc, std::size_t n_eq)
+taylor_dc_t taylor_sort_dc(const taylor_dc_t &dc, std::size_t n_eq, std::size_t n_outs)
 {
-    assert(dc.size() >= n_eq * 2u);
+    assert(dc.size() >= n_eq + n_outs);
 
     // Vertex 0 = root, vertex i + 1 = u variable i.
-    const auto n_vert = dc.size() - n_eq + 1u;
+    const auto n_vert = dc.size() - n_outs + 1u;
     std::vector<std::vector<std::size_t>> out_edges(n_vert);
     std::vector<std::size_t> in_degree(n_vert, 0);
 
@@ -374,7 +385,7 @@ taylor_dc_t taylor_sort_dc(const taylor_dc_t &dc, std::size_t n_eq)
         add_edge(0, i + 1u);
     }
 
-    for (auto i = n_eq; i < dc.size() - n_eq; ++i) {
+    for (auto i = n_eq; i < dc.size() - n_outs; ++i) {
         const auto vars = get_variables(dc[i].first);
         if (vars.empty()) {
             add_edge(0, i + 1u);
@@ -412,7 +423,7 @@ taylor_dc_t taylor_sort_dc(const taylor_dc_t &dc, std::size_t n_eq)
         v_idx[i] = v_idx[i + 1u] - 1u;
     }
     v_idx.resize(dc.size());
-    for (auto i = dc.size() - n_eq; i < dc.size(); ++i) {
+    for (auto i = dc.size() - n_outs; i < dc.size(); ++i) {
         v_idx[i] = i;
     }
 
@@ -421,7 +432,7 @@ taylor_dc_t taylor_sort_dc(const taylor_dc_t &dc, std::size_t n_eq)
         assert(v_idx[i] == i);
         remap.emplace(uname(i), uname(i));
     }
-    for (auto i = n_eq; i < v_idx.size() - n_eq; ++i) {
+    for (auto i = n_eq; i < v_idx.size() - n_outs; ++i) {
         remap.emplace(uname(v_idx[i]), uname(i));
     }
 
@@ -525,8 +536,8 @@ taylor_dc_t taylor_decompose_sys(const std::vector<std::pair<expression, express
 
     u_vars_defs.insert(u_vars_defs.end(), outs.begin(), outs.end());
 
-    u_vars_defs = taylor_decompose_cse(u_vars_defs, n_eq);
-    u_vars_defs = taylor_sort_dc(u_vars_defs, n_eq);
+    u_vars_defs = taylor_decompose_cse(u_vars_defs, n_eq, n_eq);
+    u_vars_defs = taylor_sort_dc(u_vars_defs, n_eq, n_eq);
 
     // NOTE: sincos_combine_taylor() (src/detail/sincos_combine.cpp) only selects a fused
     // sin+cos evaluation at order 0: it does not change the structure of the decomposition. The
@@ -542,6 +553,77 @@ taylor_dc_t taylor_decompose_sys(const std::vector<std::pair<expression, express
     }
 
     return u_vars_defs;
+}
+
+// Reference: function_decompose(), src/expression_cfunc.cpp:723-900.
+// NOTE: products are split in binary form (the reference uses groups of 8 here and evaluates them as a
+// pairwise product tree): same values up to the association of the multiplications.
+taylor_dc_t function_decompose(const std::vector<expression> &v_ex_, const std::vector<expression> &vars)
+{
+    if (v_ex_.empty()) {
+        throw std::invalid_argument("Cannot decompose a function with no outputs");
+    }
+
+    std::unordered_set<std::string> var_set;
+    for (const auto &ex : vars) {
+        if (ex.is_variable()) {
+            if (!var_set.emplace(ex.var_name()).second) {
+                throw std::invalid_argument("Error in the decomposition of a function: the variable '" + ex.var_name()
+                                            + "' appears in the user-provided list of variables twice");
+            }
+        } else {
+            throw std::invalid_argument("Error in the decomposition of a function: the user-provided list of "
+                                        "variables contains the expression '"
+                                        + ex.to_string() + "', which is not a variable");
+        }
+    }
+    for (const auto &var : get_variables(v_ex_)) {
+        if (var_set.find(var) == var_set.end()) {
+            throw std::invalid_argument("Error in the decomposition of a function: the variable '" + var
+                                        + "' appears in the function but not in the user-provided list of variables");
+        }
+    }
+
+    const auto nvars = vars.size();
+    const auto nouts = v_ex_.size();
+
+    std::unordered_map<std::string, std::string> repl_map;
+    for (std::size_t i = 0; i < nvars; ++i) {
+        repl_map.emplace(vars[i].var_name(), uname(i));
+    }
+
+    auto v_ex = sum_to_sub(v_ex_);
+    v_ex = split_sums_for_decompose(v_ex);
+    v_ex = sums_to_sum_sqs_for_decompose(v_ex);
+    v_ex = prod_to_div_taylor_diff(v_ex);
+    v_ex = split_prods_for_decompose(v_ex, 2);
+    v_ex = rename_variables(v_ex, repl_map);
+
+    taylor_dc_t ret;
+    for (const auto &var : vars) {
+        ret.emplace_back(var, std::vector<std::uint32_t>{});
+    }
+    taylor_dc_t outs;
+    std::unordered_map<const void *, std::size_t> func_map;
+    for (const auto &ex : v_ex) {
+        if (const auto dres = taylor_decompose(func_map, ex, ret, false)) {
+            outs.emplace_back(expression{uname(*dres)}, std::vector<std::uint32_t>{});
+        } else {
+            outs.emplace_back(ex, std::vector<std::uint32_t>{});
+        }
+    }
+    ret.insert(ret.end(), outs.begin(), outs.end());
+
+    ret = taylor_decompose_cse(ret, nvars, nouts);
+    ret = taylor_sort_dc(ret, nvars, nouts);
+
+    for (auto i = nvars; i < ret.size() - nouts; ++i) {
+        auto &[ex, deps] = ret[i];
+        if (ex.is_number()) {
+            ex = detail::num_identity(ex);
+        }
+    }
+    return ret;
 }
 
 namespace
@@ -567,13 +649,14 @@ operand make_operand(const expression &e)
 
 } // namespace
 
-taylor_program make_program(const taylor_dc_t &dc, std::uint32_t n_eq)
+taylor_program make_program(const taylor_dc_t &dc, std::uint32_t n_eq, std::uint32_t n_outs_)
 {
-    assert(dc.size() >= 2u * n_eq);
+    const auto n_outs = (n_outs_ == std::numeric_limits<std::uint32_t>::max()) ? n_eq : n_outs_;
+    assert(dc.size() >= static_cast<std::size_t>(n_eq) + n_outs);
 
     taylor_program prog;
     prog.n_eq = n_eq;
-    prog.n_u = static_cast<std::uint32_t>(dc.size() - n_eq);
+    prog.n_u = static_cast<std::uint32_t>(dc.size() - n_outs);
 
     std::vector<expression> all;
     for (std::size_t i = n_eq; i < dc.size(); ++i) {

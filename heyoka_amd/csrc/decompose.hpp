@@ -7,6 +7,7 @@
 #pragma once
 
 #include <cstdint>
+#include <limits>
 #include <string>
 #include <utility>
 #include <vector>
@@ -22,6 +23,10 @@ namespace heyoka_amd
 using taylor_dc_t = std::vector<std::pair<expression, std::vector<std::uint32_t>>>;
 
 taylor_dc_t taylor_decompose_sys(const std::vector<std::pair<expression, expression>> &sys);
+
+// Decomposition of a vector function of the variables `vars` (reference: function_decompose(),
+// src/expression_cfunc.cpp:723-900): vars.size() leading entries, fn.size() trailing definitions.
+taylor_dc_t function_decompose(const std::vector<expression> &fn, const std::vector<expression> &vars);
 
 // Reference: detail::validate_ode_sys() (src/detail/validate_ode_sys.cpp).
 void validate_ode_sys(const std::vector<std::pair<expression, expression>> &sys);
@@ -54,7 +59,9 @@ struct taylor_program {
     std::vector<operand> sv_defs;
 };
 
-taylor_program make_program(const taylor_dc_t &dc, std::uint32_t n_eq);
+// NOTE: n_outs = number of trailing definitions (defaults to n_eq, i.e. a Taylor decomposition).
+taylor_program make_program(const taylor_dc_t &dc, std::uint32_t n_eq,
+                            std::uint32_t n_outs = std::numeric_limits<std::uint32_t>::max());
 
 // Order of the Taylor method from the tolerance (reference: include/heyoka/detail/taylor_common.hpp:165-191).
 std::uint32_t taylor_order_from_tol(double tol);

@@ -6,8 +6,13 @@
 // layer (heyoka_amd/ensemble.py), one process per GPU.
 #pragma once
 
+#include <algorithm>
 #include <cstddef>
+#include <exception>
 #include <functional>
+#include <optional>
+#include <thread>
+#include <type_traits>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -31,52 +36,159 @@ int ensemble_visible_devices();
 
 } // namespace detail
 
-// Reference signature: ensemble_propagate_until_batch(ta, t, n_iter, gen, kw...) with
+// Reference signatures: ensemble_propagate_{until,for,grid}_batch(ta, t | delta_t | grid, n_iter, gen, kw...)
+// (include/heyoka/ensemble_propagate.hpp:222-271) with
 // gen: taylor_adaptive_batch<T>(taylor_adaptive_batch<T>, std::size_t), invoked here serially on the
 // calling thread (the reference may invoke it concurrently, src/ensemble_propagate.cpp:45-49).
-// Returns one (integrator, callback) tuple per iteration; the continuous-output slot of the
-// reference's return type is not available (see kw::c_output). kw::device selects the number of HIP
-// devices to spread the iterations over (0 = all visible).
+// Accepted kwargs: max_steps, max_delta_t, callback, write_tc, c_output (not for grid), plus the MI355X
+// extension kw::device = number of HIP devices to spread the iterations over (0 = all visible).
+// Return values as in the reference: one (integrator, optional<continuous_output_batch>, callback)
+// tuple per iteration, or (integrator, callback, grid output) for the grid variant.
+//
+// Without callback / continuous output every iteration is a single device-resident kernel: all the
+// launches are issued asynchronously and synchronised once at the end. Otherwise the propagation is a
+// host-driven lock-step loop, and the iterations are distributed over one host thread per device.
 namespace detail
 {
 
-template <bool Until, typename Gen, typename... KwArgs>
-std::vector<std::tuple<taylor_adaptive_batch<double>, step_callback_batch<double>>>
-ensemble_propagate_tmpl(const taylor_adaptive_batch<double> &ta, double t, std::size_t n_iter, const Gen &gen,
-                        const KwArgs &...kw_args)
+enum class ensemble_tmpl_kind { until, for_, grid };
+
+template <typename F>
+void ensemble_run_per_device(std::size_t n_iter, int n_dev, const F &f)
+{
+    const auto n_thr = static_cast<std::size_t>(std::max(1, n_dev));
+    if (n_thr == 1u || n_iter == 1u) {
+        for (std::size_t i = 0; i < n_iter; ++i) {
+            f(i);
+        }
+        return;
+    }
+    std::vector<std::exception_ptr> errs(n_thr);
+    std::vector<std::thread> thr;
+    for (std::size_t d = 0; d < n_thr; ++d) {
+        thr.emplace_back([&, d]() {
+            try {
+                for (std::size_t i = d; i < n_iter; i += n_thr) {
+                    f(i);
+                }
+            } catch (...) {
+                errs[d] = std::current_exception();
+            }
+        });
+    }
+    for (auto &t : thr) {
+        t.join();
+    }
+    for (auto &e : errs) {
+        if (e) {
+            std::rethrow_exception(e);
+        }
+    }
+}
+
+template <ensemble_tmpl_kind Kind, typename TimeArg, typename Gen, typename... KwArgs>
+auto ensemble_propagate_tmpl(const taylor_adaptive_batch<double> &ta, const TimeArg &t, std::size_t n_iter,
+                             const Gen &gen, const KwArgs &...kw_args)
 {
     static_assert(kw::all_named_v<KwArgs...>);
+    constexpr bool is_grid = (Kind == ensemble_tmpl_kind::grid);
+    static_assert(!is_grid || (!kw::has_v<kw::c_output_tag, KwArgs...> && !kw::has_v<kw::write_tc_tag, KwArgs...>),
+                  "kw::c_output and kw::write_tc are not accepted by ensemble_propagate_grid_batch()");
     if (n_iter == 0u) {
-        throw std::invalid_argument(std::string("Cannot perform an ensemble propagate_") + (Until ? "until" : "for")
+        throw std::invalid_argument(std::string("Cannot perform an ensemble propagate_")
+                                    + (Kind == ensemble_tmpl_kind::until ? "until"
+                                                                         : (is_grid ? "grid" : "for"))
                                     + "() if the number of iterations is zero");
     }
+    const auto batch_size = ta.get_batch_size();
     const auto max_steps = static_cast<std::size_t>(kw::get(kw::max_steps, 0, kw_args...));
+    std::vector<double> max_delta_ts;
+    if constexpr (kw::has_v<kw::max_delta_t_tag, KwArgs...>) {
+        using mdt_t = std::decay_t<decltype(kw::get(kw::max_delta_t, 0, kw_args...))>;
+        if constexpr (std::is_arithmetic_v<mdt_t>) {
+            max_delta_ts.assign(batch_size, static_cast<double>(kw::get(kw::max_delta_t, 0, kw_args...)));
+        } else {
+            for (const auto &x : kw::get(kw::max_delta_t, 0, kw_args...)) {
+                max_delta_ts.push_back(static_cast<double>(x));
+            }
+        }
+    }
+    step_callback_batch<double> cb;
+    if constexpr (kw::has_v<kw::callback_tag, KwArgs...>) {
+        cb = kw::get(kw::callback, 0, kw_args...);
+    }
+    const auto wtc = static_cast<bool>(kw::get(kw::write_tc, false, kw_args...));
+    const auto c_out = static_cast<bool>(kw::get(kw::c_output, false, kw_args...));
     auto n_dev = static_cast<int>(kw::get(kw::device, 0, kw_args...));
     const auto visible = ensemble_visible_devices();
     if (n_dev <= 0 || n_dev > visible) {
         n_dev = visible;
     }
 
-    std::vector<std::tuple<taylor_adaptive_batch<double>, step_callback_batch<double>>> ret;
-    ret.reserve(n_iter);
+    // Generate the integrators (serially) and pin them to their devices.
+    std::vector<taylor_adaptive_batch<double>> tas;
+    tas.reserve(n_iter);
     for (std::size_t i = 0; i < n_iter; ++i) {
-        ret.emplace_back(gen(ta, i), step_callback_batch<double>{});
+        tas.push_back(gen(ta, i));
         if (n_dev > 0) {
-            std::get<0>(ret.back()).core().set_device(static_cast<int>(i % static_cast<std::size_t>(n_dev)));
+            tas.back().core().set_device(static_cast<int>(i % static_cast<std::size_t>(n_dev)));
         }
     }
-    // Asynchronous launches (one device-resident propagation per iteration), then one sync each.
-    for (auto &r : ret) {
-        if constexpr (Until) {
-            std::get<0>(r).propagate_until(t, kw::max_steps = max_steps);
+
+    if constexpr (is_grid) {
+        // Splat out the time grid (src/ensemble_propagate.cpp:266-273).
+        std::vector<double> grid;
+        grid.reserve(t.size() * batch_size);
+        for (const auto gval : t) {
+            for (std::uint32_t i = 0; i < batch_size; ++i) {
+                grid.push_back(static_cast<double>(gval));
+            }
+        }
+        std::vector<std::tuple<step_callback_batch<double>, std::vector<double>>> res(n_iter);
+        ensemble_run_per_device(n_iter, n_dev, [&](std::size_t i) {
+            res[i] = tas[i].propagate_grid(grid, kw::max_steps = max_steps, kw::max_delta_t = max_delta_ts,
+                                           kw::callback = cb);
+        });
+        std::vector<std::tuple<taylor_adaptive_batch<double>, step_callback_batch<double>, std::vector<double>>> ret;
+        ret.reserve(n_iter);
+        for (std::size_t i = 0; i < n_iter; ++i) {
+            ret.emplace_back(std::move(tas[i]), std::move(std::get<0>(res[i])), std::move(std::get<1>(res[i])));
+        }
+        return ret;
+    } else {
+        using res_t = std::tuple<std::optional<continuous_output_batch<double>>, step_callback_batch<double>>;
+        std::vector<res_t> res(n_iter);
+        const auto run = [&](std::size_t i) {
+            if constexpr (Kind == ensemble_tmpl_kind::until) {
+                res[i] = tas[i].propagate_until(static_cast<double>(t), kw::max_steps = max_steps,
+                                                kw::max_delta_t = max_delta_ts, kw::callback = cb,
+                                                kw::write_tc = wtc, kw::c_output = c_out);
+            } else {
+                res[i] = tas[i].propagate_for(static_cast<double>(t), kw::max_steps = max_steps,
+                                              kw::max_delta_t = max_delta_ts, kw::callback = cb, kw::write_tc = wtc,
+                                              kw::c_output = c_out);
+            }
+        };
+        if (!cb && !c_out) {
+            // Asynchronous launches (one device-resident propagation per iteration), then one sync each.
+            for (std::size_t i = 0; i < n_iter; ++i) {
+                run(i);
+            }
+            for (auto &x : tas) {
+                x.core().synchronize();
+            }
         } else {
-            std::get<0>(r).propagate_for(t, kw::max_steps = max_steps);
+            ensemble_run_per_device(n_iter, n_dev, run);
         }
+        std::vector<std::tuple<taylor_adaptive_batch<double>, std::optional<continuous_output_batch<double>>,
+                               step_callback_batch<double>>>
+            ret;
+        ret.reserve(n_iter);
+        for (std::size_t i = 0; i < n_iter; ++i) {
+            ret.emplace_back(std::move(tas[i]), std::move(std::get<0>(res[i])), std::move(std::get<1>(res[i])));
+        }
+        return ret;
     }
-    for (auto &r : ret) {
-        std::get<0>(r).core().synchronize();
-    }
-    return ret;
 }
 
 } // namespace detail
@@ -85,14 +197,21 @@ template <typename Gen, typename... KwArgs>
 auto ensemble_propagate_until_batch(const taylor_adaptive_batch<double> &ta, double t, std::size_t n_iter,
                                     const Gen &gen, const KwArgs &...kw_args)
 {
-    return detail::ensemble_propagate_tmpl<true>(ta, t, n_iter, gen, kw_args...);
+    return detail::ensemble_propagate_tmpl<detail::ensemble_tmpl_kind::until>(ta, t, n_iter, gen, kw_args...);
 }
 
 template <typename Gen, typename... KwArgs>
 auto ensemble_propagate_for_batch(const taylor_adaptive_batch<double> &ta, double delta_t, std::size_t n_iter,
                                   const Gen &gen, const KwArgs &...kw_args)
 {
-    return detail::ensemble_propagate_tmpl<false>(ta, delta_t, n_iter, gen, kw_args...);
+    return detail::ensemble_propagate_tmpl<detail::ensemble_tmpl_kind::for_>(ta, delta_t, n_iter, gen, kw_args...);
+}
+
+template <typename Gen, typename... KwArgs>
+auto ensemble_propagate_grid_batch(const taylor_adaptive_batch<double> &ta, const std::vector<double> &grid,
+                                   std::size_t n_iter, const Gen &gen, const KwArgs &...kw_args)
+{
+    return detail::ensemble_propagate_tmpl<detail::ensemble_tmpl_kind::grid>(ta, grid, n_iter, gen, kw_args...);
 }
 
 } // namespace heyoka_amd

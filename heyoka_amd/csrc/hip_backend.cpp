@@ -309,6 +309,78 @@ void device_module::synchronize()
     hip_check(hipStreamSynchronize(m_impl->stream), "hipStreamSynchronize");
 }
 
+struct aux_module::impl {
+    std::shared_ptr<const compiled_module> cm;
+    int device = 0;
+    hipModule_t mod = nullptr;
+    std::unordered_map<std::string, hipFunction_t> fns;
+};
+
+aux_module::aux_module(std::shared_ptr<const compiled_module> cm, int device) : m_impl(std::make_unique<impl>())
+{
+    m_impl->cm = std::move(cm);
+    m_impl->device = device;
+    hip_check(hipSetDevice(device), "hipSetDevice");
+    hip_check(hipModuleLoadData(&m_impl->mod, m_impl->cm->code.data()), "hipModuleLoadData");
+}
+
+aux_module::~aux_module()
+{
+    if (m_impl && m_impl->mod != nullptr) {
+        (void)hipSetDevice(m_impl->device);
+        (void)hipModuleUnload(m_impl->mod);
+    }
+}
+
+int aux_module::device() const
+{
+    return m_impl->device;
+}
+
+void aux_module::launch(const char *name, std::uint64_t n_threads, unsigned block, const void *args,
+                        std::size_t args_size, void *stream)
+{
+    if (n_threads == 0u) {
+        return;
+    }
+    hip_check(hipSetDevice(m_impl->device), "hipSetDevice");
+    auto it = m_impl->fns.find(name);
+    if (it == m_impl->fns.end()) {
+        hipFunction_t fn = nullptr;
+        hip_check(hipModuleGetFunction(&fn, m_impl->mod, name), "hipModuleGetFunction(aux)");
+        it = m_impl->fns.emplace(name, fn).first;
+    }
+    std::size_t sz = args_size;
+    void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<void *>(args), HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz,
+                      HIP_LAUNCH_PARAM_END};
+    const auto grid = (n_threads + block - 1u) / block;
+    hip_check(hipModuleLaunchKernel(it->second, static_cast<unsigned>(grid), 1, 1, block, 1, 1, 0,
+                                    static_cast<hipStream_t>(stream), nullptr, config),
+              "hipModuleLaunchKernel(aux)");
+}
+
+std::shared_ptr<const compiled_module> hiprtc_compile_source(const std::string &source)
+{
+    emitted_module m;
+    m.source = source;
+    return hiprtc_compile(m);
+}
+
+void device_copy(void *dst, const void *src, std::size_t bytes, int device, void *stream)
+{
+    if (bytes == 0u) {
+        return;
+    }
+    hip_check(hipSetDevice(device), "hipSetDevice");
+    hip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, static_cast<hipStream_t>(stream)), "hipMemcpyAsync");
+}
+
+void stream_synchronize(int device, void *stream)
+{
+    hip_check(hipSetDevice(device), "hipSetDevice");
+    hip_check(hipStreamSynchronize(static_cast<hipStream_t>(stream)), "hipStreamSynchronize");
+}
+
 device_buffer::device_buffer(std::size_t bytes, int device) : m_bytes(bytes), m_device(device)
 {
     if (bytes != 0u) {

@@ -56,6 +56,32 @@ public:
     void synchronize();
 };
 
+// A generic hiprtc module loaded on a device: used for the auxiliary kernels (continuous output,
+// compiled functions) that live outside the stepper module. Kernels take a single struct argument.
+class aux_module
+{
+    struct impl;
+    std::unique_ptr<impl> m_impl;
+
+public:
+    aux_module(std::shared_ptr<const compiled_module>, int device);
+    ~aux_module();
+    aux_module(const aux_module &) = delete;
+    aux_module &operator=(const aux_module &) = delete;
+
+    [[nodiscard]] int device() const;
+    // Launch kernel `name` with n_threads threads in blocks of `block`, passing the args_size bytes at args.
+    void launch(const char *name, std::uint64_t n_threads, unsigned block, const void *args, std::size_t args_size,
+                void *stream);
+};
+
+// Plain source -> code object helper for the auxiliary modules (cached like hiprtc_compile()).
+std::shared_ptr<const compiled_module> hiprtc_compile_source(const std::string &source);
+
+// Device-to-device / host copies on a stream + stream synchronisation, for code that does not include HIP headers.
+void device_copy(void *dst, const void *src, std::size_t bytes, int device, void *stream);
+void stream_synchronize(int device, void *stream);
+
 // Thin RAII device buffer.
 class device_buffer
 {

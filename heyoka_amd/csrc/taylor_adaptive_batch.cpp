@@ -84,6 +84,8 @@ struct tab_core::impl {
     std::uint64_t last_total_steps = 0;
     // Set by the lock-step propagate loop to override the device outcomes.
     mutable std::optional<taylor_outcome> prop_res_override;
+    // Continuous output produced by the last propagate_for/until() with c_output = true.
+    std::optional<c_out_core> last_c_out;
 
     [[nodiscard]] bool is_cluster() const
     {
@@ -728,17 +730,14 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
                                             "of an adaptive Taylor integrator in batch mode");
             }
         }
-        if (c_out) {
-            throw not_implemented_error("Continuous output (kw::c_output) is not implemented in the MI355X batch "
-                                        "integrator");
-        }
     };
 
     // Fast path: state and time live on the device (they were produced by a previous kernel), scalar final
     // time, no callback -> nothing to move or to inspect on the host. The per-lane checks of the reference on
     // the *current* times are subsumed by the kernel: a lane whose time is already non-finite (it can only
     // come from an earlier err_nf_state) reports err_nf_state again instead of raising an exception.
-    if (!cb && ts_.size() == 1u && d.dev_newer && !d.host_newer && !d.sticky_host_ptr && d.dmod) {
+    d.last_c_out.reset();
+    if (!cb && !c_out && ts_.size() == 1u && d.dev_newer && !d.host_newer && !d.sticky_host_ptr && d.dmod) {
         if (!std::isfinite(ts_[0])) {
             throw std::invalid_argument("A non-finite time was passed to the propagate_until() function of an "
                                         "adaptive Taylor integrator in batch mode");
@@ -811,11 +810,6 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
                                         "an adaptive Taylor integrator in batch mode");
         }
     }
-    if (c_out) {
-        throw not_implemented_error("Continuous output (kw::c_output) is not implemented in the MI355X batch "
-                                    "integrator");
-    }
-
     std::vector<dfloat> rem(N);
     for (std::uint32_t i = 0; i < N; ++i) {
         rem[i] = dfloat(tf_hi[i], tf_lo[i]) - dfloat(d.time_hi[i], d.time_lo[i]);
@@ -827,7 +821,7 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
 
     d.prop_res_override.reset();
 
-    if (!cb) {
+    if (!cb && !c_out) {
         // Device-resident propagation: every lane runs its own adaptive loop to completion
         // (or to max_steps) inside a single kernel launch.
         d.before_kernel();
@@ -853,8 +847,16 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
         return;
     }
 
-    // Lock-step propagation with a callback executed after every sweep: the reference's loop,
-    // one single-step kernel launch per iteration.
+    // Lock-step propagation with a callback executed after every sweep and/or the recording of the
+    // continuous output: the reference's loop, one single-step kernel launch per iteration.
+    // If c_out is true, we always need to write the Taylor coefficients (:1243-1244).
+    wtc = wtc || c_out;
+    std::unique_ptr<c_out_builder> cob;
+    if (c_out) {
+        d.ensure_device();
+        cob = std::make_unique<c_out_builder>(N, d.order, d.dim, d.high_accuracy, d.device, d.stream, d.time_hi,
+                                              d.time_lo);
+    }
     std::vector<int> t_dir(N);
     std::vector<std::size_t> ts_count(N, 0);
     std::vector<double> min_abs_h(N, std::numeric_limits<double>::infinity()), max_abs_h(N, 0.);
@@ -901,28 +903,44 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
         }
         d.prop_res_dev_newer = false;
 
+        const auto make_c_out = [&]() {
+            if (cob) {
+                d.last_c_out = cob->finish(t_dir);
+            }
+        };
+
         if (nfs_detected) {
+            make_c_out();
             return;
+        }
+
+        // Update the continuous output data (:1470).
+        if (cob) {
+            cob->append(d.d_tc.as<double>(), d.time_hi, d.time_lo);
         }
 
         ++iter_counter;
 
-        const auto thi_copy = d.time_hi;
-        const auto tlo_copy = d.time_lo;
-        const auto ret_cb = cb();
-        d.to_host();
-        if (d.time_hi != thi_copy || d.time_lo != tlo_copy) {
-            throw std::runtime_error("The invocation of the callback passed to propagate_until() resulted in the "
-                                     "alteration of the time coordinate of the integrator - this is not supported");
-        }
-        if (!ret_cb) {
-            for (auto &r : d.prop_res) {
-                std::get<0>(r) = taylor_outcome::cb_stop;
+        if (cb) {
+            const auto thi_copy = d.time_hi;
+            const auto tlo_copy = d.time_lo;
+            const auto ret_cb = cb();
+            d.to_host();
+            if (d.time_hi != thi_copy || d.time_lo != tlo_copy) {
+                throw std::runtime_error("The invocation of the callback passed to propagate_until() resulted in the "
+                                         "alteration of the time coordinate of the integrator - this is not supported");
             }
-            return;
+            if (!ret_cb) {
+                for (auto &r : d.prop_res) {
+                    std::get<0>(r) = taylor_outcome::cb_stop;
+                }
+                make_c_out();
+                return;
+            }
         }
 
         if (n_done == N) {
+            make_c_out();
             return;
         }
 
@@ -930,9 +948,17 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
             for (auto &r : d.prop_res) {
                 std::get<0>(r) = taylor_outcome::step_limit;
             }
+            make_c_out();
             return;
         }
     }
+}
+
+std::optional<c_out_core> tab_core::take_c_output()
+{
+    auto ret = std::move(m_impl->last_c_out);
+    m_impl->last_c_out.reset();
+    return ret;
 }
 
 // Reference: propagate_grid_impl(), src/taylor_adaptive_batch.cpp:1546-2055. Host-driven lock-step loop:

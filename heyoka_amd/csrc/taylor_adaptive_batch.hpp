@@ -18,6 +18,7 @@
 #include <utility>
 #include <vector>
 
+#include "continuous_output.hpp"
 #include "decompose.hpp"
 #include "expression.hpp"
 #include "kw.hpp"
@@ -118,6 +119,9 @@ public:
                        const std::vector<double> &max_delta_ts, const cb_t &cb, bool wtc, bool c_out);
     std::vector<double> propagate_grid(std::vector<double> grid, std::size_t max_steps,
                                        const std::vector<double> &max_delta_ts, const cb_t &cb);
+    // The continuous output recorded by the last propagate_for/until() invoked with c_out = true
+    // (empty if no step was taken); the object is moved out.
+    std::optional<c_out_core> take_c_output();
 
     // ---- device-resident access (MI355X extension, used by the ensemble / benchmark paths) ----
     // Raw device pointers to the SoA arrays (array[row * batch_size + lane]). Calling any of these
@@ -391,37 +395,47 @@ public:
         return m_core.get_propagate_res();
     }
 
-    // NOTE: the first element of the returned tuple (continuous output) is always empty: kw::c_output = true
-    // throws not_implemented_error.
+    // NOTE: as in the reference (taylor.hpp:1064-1107), the first element of the returned tuple is the
+    // continuous output object if kw::c_output = true was passed (and at least one step was taken).
+    std::optional<continuous_output_batch<double>> make_c_out()
+    {
+        auto c = m_core.take_c_output();
+        if (c) {
+            return continuous_output_batch<double>(std::move(*c));
+        }
+        return std::nullopt;
+    }
+
+public:
     template <typename... KwArgs>
-    std::tuple<std::nullopt_t, step_callback_batch<double>> propagate_until(const std::vector<double> &ts,
+    std::tuple<std::optional<continuous_output_batch<double>>, step_callback_batch<double>> propagate_until(const std::vector<double> &ts,
                                                                            const KwArgs &...kw_args)
     {
         auto [max_steps, mdts, cb, user_cb, wtc, c_out] = propagate_common_ops(kw_args...);
         m_core.propagate_until(ts, max_steps, mdts, cb, wtc, c_out);
-        return {std::nullopt, std::move(user_cb)};
+        return {make_c_out(), std::move(user_cb)};
     }
     template <typename... KwArgs>
-    std::tuple<std::nullopt_t, step_callback_batch<double>> propagate_until(double t, const KwArgs &...kw_args)
+    std::tuple<std::optional<continuous_output_batch<double>>, step_callback_batch<double>> propagate_until(double t, const KwArgs &...kw_args)
     {
         auto [max_steps, mdts, cb, user_cb, wtc, c_out] = propagate_common_ops(kw_args...);
         m_core.propagate_until(std::vector<double>{t}, max_steps, mdts, cb, wtc, c_out);
-        return {std::nullopt, std::move(user_cb)};
+        return {make_c_out(), std::move(user_cb)};
     }
     template <typename... KwArgs>
-    std::tuple<std::nullopt_t, step_callback_batch<double>> propagate_for(const std::vector<double> &dts,
+    std::tuple<std::optional<continuous_output_batch<double>>, step_callback_batch<double>> propagate_for(const std::vector<double> &dts,
                                                                          const KwArgs &...kw_args)
     {
         auto [max_steps, mdts, cb, user_cb, wtc, c_out] = propagate_common_ops(kw_args...);
         m_core.propagate_for(dts, max_steps, mdts, cb, wtc, c_out);
-        return {std::nullopt, std::move(user_cb)};
+        return {make_c_out(), std::move(user_cb)};
     }
     template <typename... KwArgs>
-    std::tuple<std::nullopt_t, step_callback_batch<double>> propagate_for(double dt, const KwArgs &...kw_args)
+    std::tuple<std::optional<continuous_output_batch<double>>, step_callback_batch<double>> propagate_for(double dt, const KwArgs &...kw_args)
     {
         auto [max_steps, mdts, cb, user_cb, wtc, c_out] = propagate_common_ops(kw_args...);
         m_core.propagate_for(std::vector<double>{dt}, max_steps, mdts, cb, wtc, c_out);
-        return {std::nullopt, std::move(user_cb)};
+        return {make_c_out(), std::move(user_cb)};
     }
     template <typename... KwArgs>
     std::tuple<step_callback_batch<double>, std::vector<double>> propagate_grid(std::vector<double> grid,

@@ -88,6 +88,18 @@ void hy_sys_free(hy_sys);
 hy_sys hy_model_nbody(uint32_t n, const double *masses, size_t n_masses, double Gconst);
 /* model::pendulum(kw::gconst, kw::length) (src/model/pendulum.cpp:23-28). */
 hy_sys hy_model_pendulum(double gconst, double length);
+/* General form of model::nbody(): masses and Gconst as expressions (numbers or par[i]; runtime parameters
+ * select the non-grouped branch src/model/nbody.cpp:131-150). masses == NULL -> all 1; Gconst == NULL -> 1. */
+hy_sys hy_model_nbody_ex(uint32_t n, const hy_expr *masses, size_t n_masses, hy_expr Gconst);
+/* model::nbody_energy() / nbody_potential() (include/heyoka/model/nbody.hpp:80-92, src/model/nbody.cpp:176-235),
+ * model::pendulum_energy() (src/model/pendulum.cpp:31-36): expressions of the state variables
+ * x_i, y_i, z_i, vx_i, vy_i, vz_i (resp. x, v), ready for hy_cfunc_new(). */
+hy_expr hy_model_nbody_energy(uint32_t n, const hy_expr *masses, size_t n_masses, hy_expr Gconst);
+hy_expr hy_model_nbody_potential(uint32_t n, const hy_expr *masses, size_t n_masses, hy_expr Gconst);
+hy_expr hy_model_pendulum_energy(double gconst, double length);
+/* The state variables of a system, in order (the lhs of each equation); out[hy_sys_size()] receives new
+ * handles owned by the caller. */
+int hy_sys_get_vars(hy_sys, hy_expr *out);
 /* taylor_decompose_sys() (src/taylor_01.cpp:848-1008): one line per entry of the decomposition,
  * "u_i = ..." textual form with hidden dependencies. Caller frees with hy_free_str(). */
 char *hy_sys_decomposition_str(hy_sys);
@@ -163,11 +175,43 @@ typedef int (*hy_step_callback)(hy_tab, void *user_data);
  *  cb ................... kw::callback (NULL = none). Without a callback the whole propagation runs
  *                         device-resident in one kernel launch; with a callback the reference's
  *                         lock-step loop is used (one launch per step, callback on the host).
- *  write_tc, c_output ... kw::write_tc, kw::c_output (c_output != 0 -> HY_ERR_NOT_IMPLEMENTED) */
+ *  write_tc, c_output ... kw::write_tc, kw::c_output. With c_output != 0 the lock-step loop is used as well and
+ *                         the continuous output object is retrieved with hy_tab_take_c_output(). */
 int hy_tab_propagate_until(hy_tab, const double *ts, size_t n_ts, uint64_t max_steps, const double *max_delta_ts,
                            size_t n_mdt, hy_step_callback cb, void *cb_data, int write_tc, int c_output);
 int hy_tab_propagate_for(hy_tab, const double *dts, size_t n_dts, uint64_t max_steps, const double *max_delta_ts,
                          size_t n_mdt, hy_step_callback cb, void *cb_data, int write_tc, int c_output);
+/* ------------------------------------------------------------------------------------------------
+ * continuous_output_batch<double> (include/heyoka/continuous_output.hpp:151-204,
+ * src/continuous_output.cpp:602-1236): the optional<continuous_output_batch> slot of the tuple returned
+ * by propagate_for/until(). Coefficients and times stay in HBM; evaluation is one kernel launch. */
+typedef struct hy_cout_s *hy_cout;
+/* Moves the continuous output recorded by the last propagate_for/until(c_output != 0) into *out
+ * (*out = NULL if no step was taken, like the empty optional of the reference). Free with hy_cout_free(). */
+int hy_tab_take_c_output(hy_tab, hy_cout *out);
+void hy_cout_free(hy_cout);
+/* Copy (the device data is shared, the output buffers are not). */
+hy_cout hy_cout_clone(hy_cout);
+/* operator()(T) (n_tm == 1), operator()(const std::vector<T> &) (n_tm == batch_size; any other size is
+ * an error). out receives get_output(): n_eq * batch_size values, out[var * batch_size + lane]. */
+int hy_cout_eval(hy_cout, const double *tm, size_t n_tm, double *out);
+/* MI355X extension: target times d_tm[batch_size] and d_out[n_eq * batch_size] in device memory;
+ * asynchronous on the integrator's stream. */
+int hy_cout_eval_device(hy_cout, const double *d_tm, double *d_out);
+uint32_t hy_cout_get_batch_size(hy_cout);
+uint32_t hy_cout_get_dim(hy_cout);
+uint32_t hy_cout_get_order(hy_cout);
+/* get_n_steps() (padding excluded). */
+int hy_cout_get_n_steps(hy_cout, size_t *n_steps);
+/* get_bounds(): lb[batch_size], ub[batch_size]. */
+int hy_cout_get_bounds(hy_cout, double *lb, double *ub);
+/* get_times(): (n_steps + 2) * batch_size values (last row = +-inf padding); lo may be NULL. */
+int hy_cout_get_times(hy_cout, double *hi, double *lo);
+/* get_tcs(): n_steps * n_eq * (order + 1) * batch_size values, downloaded from the device. */
+int hy_cout_get_tcs(hy_cout, double *out);
+/* operator<<: malloc'ed string, free with hy_free_str(). */
+char *hy_cout_to_string(hy_cout);
+
 /* propagate_grid() (taylor.hpp:1113-1119; propagate_grid_impl() src/taylor_adaptive_batch.cpp:1546-2055).
  * grid: n_grid * batch_size values laid out grid[point * batch_size + lane];
  * out: n_grid * n_eq * batch_size values (NaN where not reached). */
@@ -209,6 +253,32 @@ size_t hy_tab_get_kernel_ms_history(hy_tab, double *out, size_t n);
  * No error channel for numerical failures (non-finite results are the caller's to detect). */
 int hy_tab_raw_step(hy_tab, double *d_state, const double *d_pars, const double *d_time, double *d_h, double *d_tc,
                     uint64_t n_systems);
+
+/* ------------------------------------------------------------------------------------------------
+ * cfunc<double> (include/heyoka/expression.hpp:735-970, src/cfunc_class.cpp, function_decompose()
+ * src/expression_cfunc.cpp:723-900): compiled evaluation of fn(vars) over many input columns.
+ * One HIP kernel, one lane per evaluation, on SoA arrays in[var * nevals + eval] (the row-major 2D
+ * layout of the reference's multi-evaluation call operator, which is also the integrator's state
+ * layout: the device-side invariant monitor of an ensemble is hy_cfunc_eval_device() on
+ * hy_tab_device_ptr(HY_BUF_STATE)). */
+typedef struct hy_cfunc_s *hy_cfunc;
+hy_cfunc hy_cfunc_new(const hy_expr *fn, size_t n_fn, const hy_expr *vars, size_t n_vars, int device);
+void hy_cfunc_free(hy_cfunc);
+uint32_t hy_cfunc_get_nparams(hy_cfunc);
+uint32_t hy_cfunc_get_nvars(hy_cfunc);
+uint32_t hy_cfunc_get_nouts(hy_cfunc);
+int hy_cfunc_is_time_dependent(hy_cfunc);
+/* get_dc() in textual form / generated HIP source; caller frees with hy_free_str(). */
+char *hy_cfunc_decomposition_str(hy_cfunc);
+char *hy_cfunc_get_hip_source(hy_cfunc);
+int hy_cfunc_set_stream(hy_cfunc, void *hip_stream);
+/* Call operator on host arrays: out_size = nouts * nevals, in_size = nvars * nevals, pars
+ * (nparams * nevals; NULL if none), time (nevals; NULL if none). */
+int hy_cfunc_eval(hy_cfunc, double *out, size_t out_size, const double *in, size_t in_size, const double *pars,
+                  size_t pars_size, const double *time, size_t time_size);
+/* Same on device-resident arrays, asynchronous on the stream. */
+int hy_cfunc_eval_device(hy_cfunc, double *d_out, const double *d_in, const double *d_pars, const double *d_time,
+                         uint64_t nevals);
 
 /* ------------------------------------------------------------------------------------------------
  * ensemble_propagate_until_batch() (include/heyoka/ensemble_propagate.hpp:222-237,

@@ -10,6 +10,8 @@
 #include <tuple>
 #include <vector>
 
+#include <sstream>
+
 #include "../../heyoka_amd/csrc/ensemble.hpp"
 #include "../../heyoka_amd/csrc/model.hpp"
 #include "../../heyoka_amd/csrc/taylor_adaptive_batch.hpp"
@@ -63,6 +65,29 @@ int main(int argc, char **argv)
     auto tad = taylor_adaptive_batch<double>{sys2, std::vector<double>(12u * 8u, 0.), 8u, kw::high_accuracy = true,
                                              kw::tol = 1e-12, kw::compact_mode = false, kw::fast_math = false};
     REQUIRE(tad.get_order() == 15u && tad.get_high_accuracy());
+
+    // Default-constructed continuous output (test/c_output.cpp:306-331).
+    {
+        continuous_output_batch<double> co;
+        REQUIRE(co.get_output().empty() && co.get_times().empty() && co.get_tcs().empty());
+        REQUIRE(co.get_batch_size() == 0u);
+        int n_thrown = 0;
+        const auto expect = [&](auto &&f) {
+            try {
+                f();
+            } catch (const std::invalid_argument &e) {
+                n_thrown += std::string(e.what()) == "Cannot use a default-constructed continuous_output_batch object";
+            }
+        };
+        expect([&]() { co(0.); });
+        expect([&]() { co(std::vector<double>{0., 0.}); });
+        expect([&]() { co.get_bounds(); });
+        expect([&]() { co.get_n_steps(); });
+        REQUIRE(n_thrown == 4);
+        std::ostringstream oss;
+        oss << co;
+        REQUIRE(oss.str().find("Default-constructed continuous_output_batch") != std::string::npos);
+    }
 
     if (!with_gpu) {
         std::puts("CPU-only checks OK");
@@ -126,6 +151,116 @@ int main(int argc, char **argv)
     REQUIRE(std::abs(last.get_state()[1] - 0.12257736827306077) < 1e-12);
     REQUIRE(std::abs(last.get_state()[3] - 0.24068377640981869) < 1e-12);
     REQUIRE(std::get<3>(last.get_propagate_res()[1]) == 124u);
+
+    // Every kwarg of the reference is forwarded; the continuous output slot is filled on request.
+    auto ret2 = ensemble_propagate_for_batch(tp, 2., 3, gen, kw::c_output = true, kw::max_delta_t = 0.5,
+                                             kw::write_tc = true);
+    REQUIRE(ret2.size() == 3u && std::get<1>(ret2[2]).has_value());
+    REQUIRE(std::get<1>(ret2[2])->get_n_steps() >= 4u);
+    auto retg = ensemble_propagate_grid_batch(tp, std::vector<double>{0., 0.4, 0.8}, 3, gen);
+    REQUIRE(retg.size() == 3u && std::get<2>(retg[0]).size() == 3u * 2u * 2u);
+    {
+        // doc/tut_adaptive.rst:324-325: x(0.4) = 0.0232578, v(0.4) = -0.14078 for the IC (0.05, 0.025).
+        const auto &g = std::get<2>(retg[0]);
+        REQUIRE(close6(g[(1u * 2u + 0u) * 2u + 0u], 0.0232578) && close6(g[(1u * 2u + 1u) * 2u + 0u], -0.14078));
+    }
+
+    // ---- continuous output (test/c_output.cpp:289-560): harmonic oscillator, analytical solution, ----
+    // ---- agreement with propagate_grid(), bounds, error messages, backward integration.          ----
+    for (const bool ha : {false, true}) {
+        const auto bs = 5u;
+        std::vector<double> ic(2u * bs), final_tm(bs);
+        for (auto i = 0u; i < bs; ++i) {
+            ic[i] = 0.01 + i / 100.;
+            ic[bs + i] = 1.02 + i / 100.;
+            final_tm[i] = 10. + i / 10.;
+        }
+        auto tc = taylor_adaptive_batch<double>{{prime(x) = v, prime(v) = -x}, ic, bs, kw::high_accuracy = ha};
+        auto [d_out, cbk] = tc.propagate_until(final_tm, kw::c_output = true);
+        REQUIRE(d_out.has_value());
+        REQUIRE(d_out->get_batch_size() == bs && d_out->get_output().size() == 2u * bs);
+        REQUIRE(d_out->get_times().size() == (d_out->get_n_steps() + 2u) * bs);
+        REQUIRE(d_out->get_tcs().size() == d_out->get_n_steps() * 2u * 21u * bs);
+        const auto [lb, ub] = d_out->get_bounds();
+        for (auto j = 0u; j < bs; ++j) {
+            REQUIRE(lb[j] == 0. && ub[j] == final_tm[j]);
+        }
+        // Analytical solution at interior, boundary and (slightly) extrapolated times.
+        for (const double frac : {0., 0.113, 0.5, 0.977, 1., 1.001, -0.001}) {
+            std::vector<double> tm(bs);
+            for (auto j = 0u; j < bs; ++j) {
+                tm[j] = frac * final_tm[j];
+            }
+            (*d_out)(tm);
+            for (auto j = 0u; j < bs; ++j) {
+                const auto ex = ic[j] * std::cos(tm[j]) + ic[bs + j] * std::sin(tm[j]);
+                const auto ev = -ic[j] * std::sin(tm[j]) + ic[bs + j] * std::cos(tm[j]);
+                REQUIRE(std::abs(d_out->get_output()[j] - ex) < 1e-13);
+                REQUIRE(std::abs(d_out->get_output()[bs + j] - ev) < 1e-13);
+            }
+        }
+        // Scalar-time overload.
+        (*d_out)(3.3);
+        for (auto j = 0u; j < bs; ++j) {
+            REQUIRE(std::abs(d_out->get_output()[j] - (ic[j] * std::cos(3.3) + ic[bs + j] * std::sin(3.3))) < 1e-13);
+        }
+        // Agreement with propagate_grid() on a batch grid.
+        auto tg = taylor_adaptive_batch<double>{{prime(x) = v, prime(v) = -x}, ic, bs, kw::high_accuracy = ha};
+        const auto n_points = 7u;
+        std::vector<double> grid(n_points * bs);
+        for (auto i = 0u; i < n_points; ++i) {
+            for (auto j = 0u; j < bs; ++j) {
+                grid[i * bs + j] = final_tm[j] * i / (n_points - 1u);
+            }
+        }
+        auto [gcb, grid_out] = tg.propagate_grid(grid);
+        for (auto i = 0u; i < n_points; ++i) {
+            (*d_out)(grid.data() + i * bs);
+            for (auto j = 0u; j < 2u * bs; ++j) {
+                const auto a = d_out->get_output()[j], b = grid_out[2u * i * bs + j];
+                REQUIRE(std::abs(a - b) <= 100. * 2.3e-16 * std::max(1., std::abs(b)));
+            }
+        }
+        // Copies share the device data and evaluate independently.
+        auto co3 = *d_out;
+        co3(1.5);
+        REQUIRE(std::abs(co3.get_output()[0] - (ic[0] * std::cos(1.5) + ic[bs] * std::sin(1.5))) < 1e-13);
+        // Error messages.
+        bool thrown = false;
+        try {
+            (*d_out)(std::vector<double>(bs + 1u, 0.));
+        } catch (const std::invalid_argument &e) {
+            thrown = std::string(e.what()).find("the vector size is 6, but a size of 5 was expected instead")
+                     != std::string::npos;
+        }
+        REQUIRE(thrown);
+        thrown = false;
+        try {
+            (*d_out)(std::numeric_limits<double>::infinity());
+        } catch (const std::invalid_argument &e) {
+            thrown = std::string(e.what())
+                     == "Cannot compute the continuous output in batch mode at the non-finite time inf";
+        }
+        REQUIRE(thrown);
+        std::ostringstream oss;
+        oss << *d_out;
+        REQUIRE(oss.str().find("forward") != std::string::npos && oss.str().find("N of steps") != std::string::npos);
+
+        // Backward in time from the final state.
+        auto [d_back, cb2] = tc.propagate_until(0., kw::c_output = true);
+        REQUIRE(d_back.has_value());
+        std::ostringstream oss2;
+        oss2 << *d_back;
+        REQUIRE(oss2.str().find("backward") != std::string::npos);
+        (*d_back)(2.5);
+        for (auto j = 0u; j < bs; ++j) {
+            REQUIRE(std::abs(d_back->get_output()[j] - (ic[j] * std::cos(2.5) + ic[bs + j] * std::sin(2.5))) < 1e-12);
+        }
+        // No step taken -> empty optional (src/taylor_adaptive_batch.cpp:1278-1282).
+        tc.get_state_data()[bs] = std::numeric_limits<double>::infinity();
+        auto [d_none, cb3] = tc.propagate_until(10., kw::c_output = true);
+        REQUIRE(!d_none.has_value());
+    }
 
     std::puts("GPU checks OK");
     return 0;

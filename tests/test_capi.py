@@ -93,3 +93,33 @@ def test_codegen_compiles_for_benchmark_dags():
     assert ta.n_uvars == 21 and ta.dim == 12
     ta = hy.taylor_adaptive_batch(hy.model.pendulum(gconst=9.8), None, 64, high_accuracy=True)
     assert ta.n_uvars == 5
+
+
+def test_cfunc_host_logic_without_gpu():
+    """cfunc<double> construction (function_decompose(), src/expression_cfunc.cpp:723-900): decomposition
+    structure, properties, error messages, and the generated kernel compiles for gfx950."""
+    x, v = hy.make_vars("x", "v")
+    cf = hy.cfunc([x * hy.par[1] + hy.cos(hy.time), v * v, x], [x, v])
+    assert (cf.nvars, cf.nouts, cf.nparams, cf.is_time_dependent) == (2, 3, 2, True)
+    dc = cf.dc
+    assert dc[:2] == ["x", "v"] and len(dc) == 2 + 5 + 3
+    # Outputs: u variables or (here) a direct reference to an input variable.
+    assert dc[-1] == "u_0" and dc[-3].startswith("u_")
+    assert "hy_cfunc" in cf.hip_source and "cos(" in cf.hip_source
+    # model::nbody_energy: 3 bodies -> 3 pairs.
+    sys3 = hy.model.nbody(3)
+    en = hy.cfunc([hy.model.nbody_energy(3, masses=[1.0, 2.0, 3.0], Gconst=0.5)], sys3.vars)
+    assert en.nvars == 18 and en.nouts == 1 and en.nparams == 0 and not en.is_time_dependent
+    assert sum("sum_sq" in l for l in en.dc) == 3 + 3
+    with pytest.raises(ValueError, match="appears in the function but not in the user-provided list of variables"):
+        hy.cfunc([x + v], [x])
+    with pytest.raises(ValueError, match="appears in the user-provided list of variables twice"):
+        hy.cfunc([x + v], [x, v, x])
+    with pytest.raises(ValueError, match="which is not a variable"):
+        hy.cfunc([x + v], [x, v + 1.0])
+    with pytest.raises(ValueError, match="Cannot decompose a function with no outputs"):
+        hy.cfunc([], [x])
+    # Runtime masses switch model::nbody to the non-grouped branch (src/model/nbody.cpp:131-150).
+    sp = hy.model.nbody(2, masses=[hy.par[0], hy.par[1]])
+    dcs = hy.taylor_decompose_sys(sp)
+    assert any("p0" in l for l in dcs) and any("p1" in l for l in dcs)

@@ -442,3 +442,120 @@ def test_propagate_grid():
     _, out3 = td.propagate_grid(np.linspace(0.0, 10.0, 11), max_steps=2)
     assert td.propagate_res[0][0] == OC.step_limit
     assert np.isnan(out3[-1]).all() and not np.isnan(out3[0]).any()
+
+
+def test_continuous_output():
+    """kw::c_output (src/taylor_adaptive_batch.cpp:1243-1346, src/continuous_output.cpp:602-1236), modelled on
+    test/c_output.cpp:289-560: agreement with the oracle's propagation to arbitrary times, with
+    propagate_grid(), bounds / padding / tcs bookkeeping, error messages, device-side evaluation."""
+    import copy
+
+    n = 6
+    rng = np.random.RandomState(11)
+    st = np.stack([rng.uniform(-0.5, 0.5, n), rng.uniform(-0.5, 0.5, n)])
+    tf = 3.0 + 0.25 * np.arange(n)
+    for ha in (False, True):
+        ta = hy.taylor_adaptive_batch(pendulum_p(), st, n, high_accuracy=ha)
+        co, cb = ta.propagate_until(tf, c_output=True)
+        assert cb is None and co is not None
+        assert co.batch_size == n and co.dim == 2 and co.order == 20
+        ns = co.n_steps
+        assert ns == max(r[3] for r in ta.propagate_res)
+        times = co.times
+        assert times.shape == (ns + 2, n) and np.all(times[0] == 0.0) and np.all(np.isposinf(times[-1]))
+        lb, ub = co.bounds
+        assert np.array_equal(lb, np.zeros(n)) and np.array_equal(ub, tf)
+        # Lanes which finish early repeat their final time (zero-length steps) up to the padding row.
+        assert np.all(np.diff(times[:-1], axis=0) >= 0.0)
+        tcs = co.tcs
+        assert tcs.shape == (ns, 2, 21, n)
+        assert np.array_equal(tcs[0, :, 0, :], st)
+        # Arbitrary target times vs an independent oracle propagation.
+        for frac in (0.0, 0.21, 0.5, 0.83, 1.0):
+            tm = frac * tf
+            out = co(tm)
+            ora = ho.OracleIntegrator(pendulum_o(), st, n, high_accuracy=ha)
+            ora.propagate_until(tm)
+            assert rel_err(out, ora.state.reshape(2, n)) <= 1e3 * EPS
+            assert co.output is out
+        # Scalar time and agreement with propagate_grid().
+        tg = hy.taylor_adaptive_batch(pendulum_p(), st, n, high_accuracy=ha)
+        grid = np.linspace(0.0, 3.0, 7)
+        _, gout = tg.propagate_grid(grid)
+        for k, t in enumerate(grid):
+            assert rel_err(co(float(t)), gout[k]) <= 100 * EPS
+        # Copies share the device data.
+        co2 = copy.copy(co)
+        assert np.array_equal(co2(1.25), co(1.25))
+        # Device-side evaluation on caller-owned buffers.
+        import torch
+
+        d_tm = torch.full((n,), 1.25, dtype=torch.float64, device="cuda")
+        d_out = torch.empty((2, n), dtype=torch.float64, device="cuda")
+        co.eval_device(d_tm.data_ptr(), d_out.data_ptr())
+        ta.synchronize()
+        torch.cuda.synchronize()
+        assert np.array_equal(d_out.cpu().numpy(), co(1.25))
+        with pytest.raises(ValueError, match="the vector size is 7, but a size of 6 was expected instead"):
+            co(np.zeros(n + 1))
+        with pytest.raises(ValueError, match="at the non-finite time"):
+            co(float("nan"))
+        assert "forward" in repr(co) and "N of steps  : %d" % ns in repr(co)
+        # Backward, with a callback and max_delta_t at the same time.
+        calls = []
+        co_b, cb_b = ta.propagate_for(-tf, c_output=True, max_delta_t=0.05, callback=lambda t: calls.append(1) or True)
+        assert co_b.n_steps == len(calls) and co_b.n_steps >= 60 and "backward" in repr(co_b)
+        assert rel_err(co_b(0.0), st) <= 1e3 * EPS
+    # No step taken -> no continuous output (empty optional in the reference).
+    bad = st.copy()
+    bad[1, 0] = np.inf
+    tb = hy.taylor_adaptive_batch(pendulum_p(), bad, n)
+    co_n, _ = tb.propagate_until(1.0, c_output=True)
+    assert co_n is None and tb.propagate_res[0][0] == OC.err_nf_state
+
+
+def test_cfunc_values_and_device_side_energy_monitor():
+    """cfunc<double> on the device: values against numpy, parameters and time,
+    and model::nbody_energy evaluated directly on the integrator's device-resident state
+    (test/model_nbody.cpp:112-118: relative energy drift <= 100 eps over propagate_until(100))."""
+    import torch
+
+    rng = np.random.RandomState(5)
+    x, v = hy.make_vars("x", "v")
+    cf = hy.cfunc([x * hy.par[1] + hy.cos(hy.time) - hy.par[0], hy.exp(v) * hy.sin(x) / (1.0 + v * v),
+                   hy.pow(x * x + 1.0, -1.5) + hy.log(2.0 + v * v), x], [x, v])
+    nev = 1000
+    inp, pars, tm = rng.uniform(-1, 1, (2, nev)), rng.uniform(-1, 1, (2, nev)), rng.uniform(0, 10, nev)
+    out = cf(inp, pars=pars, time=tm)
+    X, V = inp
+    exp = np.stack([X * pars[1] + np.cos(tm) - pars[0], np.exp(V) * np.sin(X) / (1.0 + V * V),
+                    (X * X + 1.0) ** -1.5 + np.log(2.0 + V * V), X])
+    assert out.shape == (4, nev) and rel_err(out, exp) <= 8 * EPS
+    # Single evaluation overload.
+    o1 = cf(inp[:, 0], pars=pars[:, 0], time=tm[0])
+    assert o1.shape == (4,) and np.array_equal(o1, out[:, 0])
+    with pytest.raises(ValueError, match="An array of parameter values must be passed"):
+        cf(inp, time=tm)
+    with pytest.raises(ValueError, match="time value"):
+        cf(inp[:, 0], pars=pars[:, 0])
+    with pytest.raises(ValueError, match="Invalid inputs array passed to a cfunc"):
+        cf(inp[:1, 0], pars=pars[:, 0], time=tm[0])
+
+    # Energy monitor on the outer Solar System ensemble, no host round trip for the state.
+    n = 256
+    st = configs.outer_ss_state(n, perturb=1e-12, seed=42)
+    masses, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    sys_ = hy.model.nbody(6, masses=masses, Gconst=G)
+    en = hy.cfunc([hy.model.nbody_energy(6, masses=masses, Gconst=G)], sys_.vars)
+    ta = hy.taylor_adaptive_batch(sys_, st, n, high_accuracy=True)
+    d_e0 = torch.empty(n, dtype=torch.float64, device="cuda")
+    d_e1 = torch.empty(n, dtype=torch.float64, device="cuda")
+    en.eval_device(d_e0.data_ptr(), ta.device_array("state").ptr, n)
+    ta.propagate_until(100.0)
+    en.eval_device(d_e1.data_ptr(), ta.device_array("state").ptr, n)
+    ta.synchronize()
+    torch.cuda.synchronize()
+    e0, e1 = d_e0.cpu().numpy(), d_e1.cpu().numpy()
+    assert rel_err(e0, configs.nbody_energy(st, masses, G)) <= 16 * EPS
+    assert np.max(np.abs((e1 - e0) / e0)) <= 100 * EPS
+    assert rel_err(e1, configs.nbody_energy(ta.state, masses, G)) <= 16 * EPS
