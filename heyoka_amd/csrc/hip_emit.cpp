@@ -499,6 +499,7 @@ emitted_module emit_unrolled(const taylor_program &p, const emit_options &opts)
 
 emitted_module emit_cluster_or_empty(const taylor_program &, const emit_options &, std::string &why_not);
 emitted_module emit_table(const taylor_program &, const emit_options &);
+emitted_module emit_block(const taylor_program &, const emit_options &, std::string &why_not);
 
 emitted_module emit_hip_module(const taylor_program &prog, const emit_options &opts)
 {
@@ -511,6 +512,16 @@ emitted_module emit_hip_module(const taylor_program &prog, const emit_options &o
         case emit_mode::cluster: {
             std::string why;
             auto m = emit_cluster_or_empty(prog, opts, why);
+            if (m.source.empty() && why.rfind("more than 64 clusters", 0) == 0) {
+                // Too many clusters for one wavefront: one system per workgroup, if the workgroup's lanes
+                // can be kept reasonably busy.
+                std::string why_b;
+                auto b = emit_block(prog, opts, why_b);
+                if (!b.source.empty() && b.n_clusters >= 128u) {
+                    return b;
+                }
+                why += why_b.empty() ? "; block mode: fewer than 128 clusters" : ("; block mode: " + why_b);
+            }
             if (m.source.empty()) {
                 // Not applicable to this DAG: fall back to the generic one-system-per-lane code, unrolled
                 // for small decompositions (registers), table-driven for large ones (bounded code size, the
@@ -523,6 +534,14 @@ emitted_module emit_hip_module(const taylor_program &prog, const emit_options &o
         }
         case emit_mode::table:
             return emit_table(prog, opts);
+        case emit_mode::block: {
+            std::string why;
+            auto b = emit_block(prog, opts, why);
+            if (b.source.empty()) {
+                throw std::invalid_argument("Block mode is not applicable to this system: " + why);
+            }
+            return b;
+        }
         default:
             throw not_implemented_error("The requested code generation mode is not implemented yet");
     }

@@ -40,7 +40,7 @@ struct hy_kargs {
     double tfin_s_hi, tfin_s_lo; // propagate mode, scalar final time (used when tfin_hi == nullptr)
 };
 
-enum class emit_mode { unrolled, cluster, table };
+enum class emit_mode { unrolled, cluster, table, block };
 
 struct emit_options {
     std::uint32_t order = 20;
@@ -57,6 +57,7 @@ struct emitted_module {
     bool tc_optional = false;   // the main kernel works with a.tc == nullptr
     std::uint32_t block_size = 256;
     std::uint32_t lanes_per_system = 1;
+    std::uint32_t n_clusters = 0; // cluster / block modes
     std::uint32_t lds_bytes = 0;
     emit_mode mode = emit_mode::unrolled;
     // Statistics (logged like the reference logs decomposition sizes).

@@ -142,7 +142,8 @@ struct union_find {
 } // namespace
 
 // Build the plan; returns an empty string on success, otherwise the reason why cluster mode is not applicable.
-std::string cluster_detail::make_plan(const taylor_program &p, std::uint32_t order, cluster_plan &pl)
+std::string cluster_detail::make_plan(const taylor_program &p, std::uint32_t order, cluster_plan &pl,
+                                      const plan_limits &lim)
 {
     const auto n_eq = p.n_eq, n_u = p.n_u;
     pl.n_eq = n_eq;
@@ -180,8 +181,8 @@ std::string cluster_detail::make_plan(const taylor_program &p, std::uint32_t ord
     if (pl.clusters.size() < 2u) {
         return "fewer than 2 clusters";
     }
-    if (pl.clusters.size() > 64u) {
-        return "more than 64 clusters (a system would span several wavefronts)";
+    if (pl.clusters.size() > lim.max_clusters) {
+        return "more than " + std::to_string(lim.max_clusters) + " clusters";
     }
 
     // 2. Absorb single-source linear nodes into their source cluster.
@@ -380,7 +381,7 @@ std::string cluster_detail::make_plan(const taylor_program &p, std::uint32_t ord
 
     // 6. Lane-group width.
     pl.L = 2;
-    while (pl.L < nc) {
+    while (pl.L < nc && pl.L < 64u) {
         pl.L *= 2u;
     }
     pl.spw = 64u / pl.L;
@@ -407,8 +408,13 @@ std::string cluster_detail::make_plan(const taylor_program &p, std::uint32_t ord
                 break;
         }
     }
-    if (stored.size() * order * 2u > 420u) {
+    if (lim.jets_in_registers && stored.size() * order * 2u > 420u) {
         return "the jets of a cluster do not fit in the register file";
+    }
+    for (std::uint32_t q = 0; q < t0.size(); ++q) {
+        if (stored.count(t0[q]) != 0u) {
+            pl.stored_pos.push_back(q);
+        }
     }
 
     // 7. LDS slots: state variables, exported cluster members, glue nodes; then dummies.

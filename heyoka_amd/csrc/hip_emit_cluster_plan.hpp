@@ -32,10 +32,20 @@ struct cluster_plan {
     std::vector<glue_group> groups;                   // sorted by level
     std::uint32_t max_level = 0;
     std::vector<std::uint32_t> lvl;                   // per u
+    // Template positions of the members whose lower-order coefficients are read by a recurrence
+    // (they must be kept for the whole step: in registers, or on a tape).
+    std::vector<std::uint32_t> stored_pos;
+};
+
+// Limits of the target kernel shape: wave mode (one system per group of <= 64 lanes, jets in registers) or
+// block mode (one system per workgroup, any number of clusters, jets on a tape).
+struct plan_limits {
+    std::uint32_t max_clusters = 64;
+    bool jets_in_registers = true;
 };
 
 // Build the plan; returns an empty string on success, otherwise the reason why cluster mode is not applicable.
-std::string make_plan(const taylor_program &p, std::uint32_t order, cluster_plan &pl);
+std::string make_plan(const taylor_program &p, std::uint32_t order, cluster_plan &pl, const plan_limits &lim = {});
 
 inline bool is_var(const operand &o)
 {

@@ -41,6 +41,9 @@ emit_mode choose_mode()
         if (s == "table") {
             return emit_mode::table;
         }
+        if (s == "block") {
+            return emit_mode::block;
+        }
     }
     return emit_mode::cluster;
 }
@@ -469,7 +472,9 @@ const std::string &tab_core::get_hip_source() const
 std::string tab_core::get_codegen_info() const
 {
     const auto &m = m_impl->emitted;
-    const char *mode = m.mode == emit_mode::cluster ? "cluster" : (m.mode == emit_mode::table ? "table" : "unrolled");
+    const char *mode = m.mode == emit_mode::cluster
+                           ? "cluster"
+                           : (m.mode == emit_mode::table ? "table" : (m.mode == emit_mode::block ? "block" : "unrolled"));
     return std::string(mode) + " [lanes per system: " + std::to_string(m.lanes_per_system)
            + ", statements: " + std::to_string(m.n_statements) + "] " + m.notes;
 }

@@ -373,9 +373,36 @@ def test_table_mode_nbody12_automatic():
 
 
 def test_config5_nbody64_table_mode():
-    """BASELINE config 5 DAG (18 663 u variables) at a reduced ensemble size: parity vs the oracle."""
-    ta = _nbody_parity(64, 64, 1, "table")
+    """BASELINE config 5 DAG (18 663 u variables) at a reduced ensemble size: parity vs the oracle
+    (table-driven kernel, one system per lane)."""
+    ta = _nbody_parity(64, 64, 1, "table", env_mode="table")
     assert ta.n_uvars == 18663
+
+
+def test_block_mode_nbody20_forced_and_nbody64_automatic():
+    """Block mode (one system per workgroup, cluster jets on a coalesced tape): 190 clusters (forced; fewer
+    lanes than a workgroup would normally select table mode is not the case here: >= 128 clusters), a
+    propagation with per-lane step counts, and the BASELINE config 5 DAG where it is the default."""
+    ta = _nbody_parity(20, 24, 2, "block", t_final=0.02)
+    assert "190 clusters" in ta.hip_source_mode
+    # More systems than workgroups in flight + high accuracy (compensated summation update).
+    import os
+
+    os.environ["HEYOKA_AMD_EMIT_MODE"] = "block"
+    try:
+        st = configs.plummer_nbody_state(9, 700, seed=5, jitter=1e-6)
+        tb = hy.taylor_adaptive_batch(hy.model.nbody(9), st, 700, high_accuracy=True)
+    finally:
+        del os.environ["HEYOKA_AMD_EMIT_MODE"]
+    assert "block" in tb.hip_source_mode
+    ora = ho.OracleIntegrator(ho.nbody(9), st, 700, high_accuracy=True)
+    tb.propagate_until(0.05)
+    ora.propagate_until(0.05)
+    assert all(r[0] == OC.time_limit for r in tb.propagate_res)
+    assert max(abs(a[3] - b[3]) for a, b in zip(tb.propagate_res, ora.prop_res)) <= 1
+    assert rel_err(tb.state, ora.state.reshape(54, 700)) <= 1e7 * EPS
+    tc = _nbody_parity(64, 8, 1, "block")
+    assert tc.n_uvars == 18663 and "2016 clusters" in tc.hip_source_mode
 
 
 def test_unrolled_vs_cluster_v1_vs_v2_same_results():
