@@ -86,10 +86,11 @@ class expression:
         else:
             self._h = check_handle(lib.hy_expr_num(float(x)))
 
-    def __del__(self):
+    def __del__(self, _free=lib.hy_expr_free):
+        # NOTE: the free function is bound at definition time (module globals may be gone at shutdown).
         h = getattr(self, "_h", None)
         if h:
-            lib.hy_expr_free(h)
+            _free(h)
             self._h = None
 
     @staticmethod
@@ -217,10 +218,10 @@ class _Sys:
             lhs, rhs = _as_ex(lhs), _as_ex(rhs)  # keep temporaries alive across the C call
             raise_for(lib.hy_sys_add(self._h, lhs._h, rhs._h))
 
-    def __del__(self):
+    def __del__(self, _free=lib.hy_sys_free):
         h = getattr(self, "_h", None)
         if h:
-            lib.hy_sys_free(h)
+            _free(h)
             self._h = None
 
     def __len__(self):
@@ -340,10 +341,10 @@ class cfunc:
         va = (ctypes.c_void_p * len(vs))(*[v._h for v in vs])
         self._h = check_handle(lib.hy_cfunc_new(fa, len(fs), va, len(vs), int(device)))
 
-    def __del__(self):
+    def __del__(self, _free=lib.hy_cfunc_free):
         h, self._h = getattr(self, "_h", None), None
         if h:
-            lib.hy_cfunc_free(h)
+            _free(h)
 
     @property
     def nparams(self):
@@ -399,10 +400,10 @@ class continuous_output_batch:
         self._h = handle
         self._output = None
 
-    def __del__(self):
+    def __del__(self, _free=lib.hy_cout_free):
         h, self._h = getattr(self, "_h", None), None
         if h:
-            lib.hy_cout_free(h)
+            _free(h)
 
     def __copy__(self):
         return continuous_output_batch(check_handle(lib.hy_cout_clone(self._h)))
@@ -523,10 +524,10 @@ class taylor_adaptive_batch:
                               ctypes.byref(cfg))
         )
 
-    def __del__(self):
+    def __del__(self, _free=lib.hy_tab_free):
         h = getattr(self, "_h", None)
         if h:
-            lib.hy_tab_free(h)
+            _free(h)
             self._h = None
 
     def __copy__(self):

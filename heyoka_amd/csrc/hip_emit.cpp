@@ -513,14 +513,19 @@ emitted_module emit_hip_module(const taylor_program &prog, const emit_options &o
             std::string why;
             auto m = emit_cluster_or_empty(prog, opts, why);
             if (m.source.empty() && why.rfind("more than 64 clusters", 0) == 0) {
-                // Too many clusters for one wavefront: one system per workgroup, if the workgroup's lanes
-                // can be kept reasonably busy.
+                // Too many clusters for one wavefront: one system per workgroup.
                 std::string why_b;
+                // Measured on an MI355X: block mode beats the table-driven one-lane-per-system kernels by 5x
+                // (nbody(12), 66 clusters) to 44x (nbody(64)) - it is used whenever it is applicable.
+                std::uint32_t block_min_clusters = 0;
+                if (const char *ev = std::getenv("HEYOKA_AMD_BLOCK_MIN_CLUSTERS")) {
+                    block_min_clusters = static_cast<std::uint32_t>(std::max(0, std::atoi(ev)));
+                }
                 auto b = emit_block(prog, opts, why_b);
-                if (!b.source.empty() && b.n_clusters >= 128u) {
+                if (!b.source.empty() && b.n_clusters >= block_min_clusters) {
                     return b;
                 }
-                why += why_b.empty() ? "; block mode: fewer than 128 clusters" : ("; block mode: " + why_b);
+                why += why_b.empty() ? "; block mode: too few clusters" : ("; block mode: " + why_b);
             }
             if (m.source.empty()) {
                 // Not applicable to this DAG: fall back to the generic one-system-per-lane code, unrolled

@@ -58,7 +58,22 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
     }
 
     const auto n_eq = p.n_eq, order = opts.order;
-    const std::uint32_t bs = 256;
+    // Workgroup size: 256 lanes = one wavefront per SIMD with the whole register file (512 VGPRs) for the
+    // history of the cluster being processed.
+    std::uint32_t bs = 256;
+    {
+        // Small cluster counts: do not park lanes (several smaller workgroups fit on a compute unit).
+        const auto nc0 = static_cast<std::uint32_t>(pl.clusters.size());
+        if (nc0 <= 128u) {
+            bs = 128;
+        }
+    }
+    if (const char *ev = std::getenv("HEYOKA_AMD_BLOCK_SIZE")) {
+        const auto v = std::atoi(ev);
+        if (v == 128 || v == 256 || v == 512 || v == 1024) {
+            bs = static_cast<std::uint32_t>(v);
+        }
+    }
     const auto nc = static_cast<std::uint32_t>(pl.clusters.size());
     const auto ncp = (nc + 63u) / 64u * 64u;
     const auto &t0 = pl.clusters[0];
@@ -73,10 +88,78 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         why_not = "the jets of a cluster do not fit in the register file";
         return ret;
     }
-    const std::uint64_t lds_bytes = static_cast<std::uint64_t>(n_slots) * 8u + 64u;
-    if (lds_bytes > 150u * 1024u) {
+    // Stored members which are linear functions of external inputs only (e.g. the coordinate differences of
+    // an N-body pair) are not written to the tape: their lower-order coefficients are recomputed from the
+    // jets of the external inputs, which are kept in LDS (ejet[m * n_ej + e]). This removes 3 of the 5 tape
+    // streams of the N-body clusters (HEYOKA_AMD_BLOCK_NO_RECOMPUTE=1 disables it, for A/B measurements).
+    std::vector<char> recomp(n_sto, 0);
+    std::vector<char> ext_used(n_ext, 0);
+    std::vector<std::uint32_t> ej_slots; // distinct slab slots of the external inputs with LDS jets
+    std::vector<std::uint32_t> ej_index; // [x * nc + c] -> index into ej_slots
+    if (std::getenv("HEYOKA_AMD_BLOCK_NO_RECOMPUTE") == nullptr) {
+        std::map<std::uint32_t, std::uint32_t> ext_pos;
+        for (std::uint32_t x = 0; x < n_ext; ++x) {
+            ext_pos[pl.ext_u[0][x]] = x;
+        }
+        for (std::uint32_t s = 0; s < n_sto; ++s) {
+            const auto &n = p.nodes[t0[pl.stored_pos[s]] - n_eq];
+            bool ok = (n.kind == func_kind::sub || n.kind == func_kind::sum
+                       || (n.kind == func_kind::prod && n.args.size() == 2u && !is_var(n.args[0])));
+            bool any_var = false;
+            for (const auto &o : n.args) {
+                if (is_var(o)) {
+                    any_var = true;
+                    ok = ok && ext_pos.count(o.idx) != 0u;
+                }
+            }
+            if (ok && any_var) {
+                recomp[s] = 1;
+                for (const auto &o : n.args) {
+                    if (is_var(o)) {
+                        ext_used[ext_pos[o.idx]] = 1;
+                    }
+                }
+            }
+        }
+        std::map<std::uint32_t, std::uint32_t> slot_to_ej;
+        ej_index.assign(static_cast<std::size_t>(n_ext) * nc, 0u);
+        for (std::uint32_t x = 0; x < n_ext; ++x) {
+            if (ext_used[x] == 0) {
+                continue;
+            }
+            for (std::uint32_t c = 0; c < nc; ++c) {
+                const auto slot = static_cast<std::uint32_t>(pl.slot_of[pl.ext_u[c][x]]);
+                auto it = slot_to_ej.find(slot);
+                if (it == slot_to_ej.end()) {
+                    it = slot_to_ej.emplace(slot, static_cast<std::uint32_t>(ej_slots.size())).first;
+                    ej_slots.push_back(slot);
+                }
+                ej_index[static_cast<std::size_t>(x) * nc + c] = it->second;
+            }
+        }
+    }
+    auto n_ej = static_cast<std::uint32_t>(ej_slots.size());
+    const auto lds_for = [&](std::uint32_t nej) {
+        return static_cast<std::uint64_t>(n_slots) * 8u + static_cast<std::uint64_t>(nej) * (order - 1u) * 8u + 128u;
+    };
+    if (lds_for(n_ej) > 150u * 1024u) {
+        // No room for the jets of the external inputs: everything goes through the tape.
+        std::fill(recomp.begin(), recomp.end(), 0);
+        std::fill(ext_used.begin(), ext_used.end(), 0);
+        ej_slots.clear();
+        n_ej = 0;
+    }
+    if (lds_for(n_ej) > 150u * 1024u) {
         why_not = "the exchange slab does not fit in LDS";
         return ret;
+    }
+    // Tape rows: only the members which are not recomputed.
+    std::vector<std::uint32_t> tape_row(n_sto, 0u);
+    std::uint32_t n_tape = 0;
+    for (std::uint32_t s = 0; s < n_sto; ++s) {
+        if (recomp[s] == 0) {
+            tape_row[s] = n_tape++;
+        }
     }
     for (const auto &d : p.sv_defs) {
         if (d.type == operand::kind::uvar && pl.slot_of[d.idx] < 0) {
@@ -126,6 +209,8 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
             }
         }
         emit_dtbl("hy_cst", dv);
+        emit_utbl("hy_extj", n_ej != 0u ? ej_index : std::vector<std::uint32_t>{});
+        emit_utbl("hy_ejs", ej_slots);
     }
     // Glue groups: per argument a table of slots (variables) or of values (non-structural numbers).
     for (std::size_t g = 0; g < pl.groups.size(); ++g) {
@@ -184,69 +269,215 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
     }
     const auto sync = [&]() { os << "__syncthreads();\n"; };
 
-    const auto emit_cluster = [&](std::uint32_t k) {
-        os << "for (unsigned c = tid; c < " << nc << "u; c += " << bs << "u) {\n";
-        os << "double *const tp = tape + c;\n";
-        for (std::uint32_t x = 0; x < n_cst; ++x) {
-            os << "const double ccst" << x << " = hy_cst[" << static_cast<std::uint64_t>(x) * nc << "u + c];\n";
+    // Cluster phase at order k: a rolled loop over the clusters of the lane. The loads of a cluster (slot
+    // indices, per-cluster constants, tape history) can be software-pipelined, i.e. requested one round ahead:
+    //   pf_mode 0 - no pipelining: everything is loaded at the top of the round (default);
+    //   pf_mode 1 - only the slot indices / constants are requested one round ahead;
+    //   pf_mode 2 - the tape history as well.
+    // Measured on an MI355X (nbody64, 65 536 systems): mode 0 8.4e5, mode 2 5.0e5 system-steps/s - the
+    // loop-carried copies of the history push the kernel over the 512-VGPR budget and the spill traffic
+    // costs more than the latency it hides.
+    const auto n_iter = (nc + bs - 1u) / bs;
+    const bool glue_fence = std::getenv("HEYOKA_AMD_BLOCK_GLUE_FENCE") != nullptr;
+    const int pf_mode = [&]() {
+        if (n_iter <= 1u) {
+            return 0;
         }
-        // History of the stored members.
+        if (const char *ev = std::getenv("HEYOKA_AMD_BLOCK_PREFETCH")) {
+            return std::max(0, std::min(2, std::atoi(ev)));
+        }
+        return 0;
+    }();
+    const std::uint32_t sched_every = [&]() -> std::uint32_t {
+        if (const char *ev = std::getenv("HEYOKA_AMD_BLOCK_SCHED")) {
+            return static_cast<std::uint32_t>(std::max(1, std::atoi(ev)));
+        }
+        return 4u;
+    }();
+    const auto emit_cluster = [&](std::uint32_t k) {
+        if (n_ej != 0u && k + 1u < order) {
+            // Record the order-k coefficients of the external inputs (read back from order k + 1 on).
+            os << "for (unsigned e = tid; e < " << n_ej << "u; e += " << bs << "u) ejet["
+               << static_cast<std::uint64_t>(k) * n_ej << "u + e] = slab[hy_ejs[e]];\n";
+        }
+        // Names of the per-cluster loads: (variable name, type, load expression in terms of `cc`).
+        struct pf {
+            std::string name, type, expr;
+            bool carried = false; // requested one round ahead
+        };
+        std::vector<pf> loads;
+        for (std::uint32_t x = 0; x < n_cst; ++x) {
+            loads.push_back({"ccst" + std::to_string(x), "double",
+                             "hy_cst[" + std::to_string(static_cast<std::uint64_t>(x) * nc) + "u + cc]"});
+        }
+        for (std::uint32_t x = 0; x < n_ext; ++x) {
+            loads.push_back({"ie" + std::to_string(x), "unsigned",
+                             "hy_ext[" + std::to_string(static_cast<std::uint64_t>(x) * nc) + "u + cc]"});
+        }
+        for (std::uint32_t x = 0; x < n_out; ++x) {
+            loads.push_back({"io" + std::to_string(x), "unsigned",
+                             "hy_out[" + std::to_string(static_cast<std::uint64_t>(x) * nc) + "u + cc]"});
+        }
+        if (n_ej != 0u && k > 0u) {
+            for (std::uint32_t x = 0; x < n_ext; ++x) {
+                if (ext_used[x] != 0) {
+                    loads.push_back({"ej" + std::to_string(x), "unsigned",
+                                     "hy_extj[" + std::to_string(static_cast<std::uint64_t>(x) * nc) + "u + cc]"});
+                }
+            }
+        }
         for (std::uint32_t s = 0; s < n_sto; ++s) {
+            if (recomp[s] != 0) {
+                continue;
+            }
             const auto u = t0[pl.stored_pos[s]];
             for (std::uint32_t m = 0; m < k; ++m) {
                 const auto nm = "h" + std::to_string(s) + "_" + std::to_string(m);
-                os << "const double " << nm << " = tp[" << (static_cast<std::uint64_t>(s) * order + m) * ncp << "u];\n";
+                loads.push_back({nm, "double",
+                                 "tape[" + std::to_string((static_cast<std::uint64_t>(tape_row[s]) * order + m) * ncp)
+                                     + "u + cc]",
+                                 pf_mode == 2});
                 e.val(u, m) = nm;
             }
         }
+        for (auto &l : loads) {
+            if (l.type != "double" || l.name.rfind("ccst", 0) == 0) {
+                l.carried = pf_mode >= 1;
+            }
+        }
+        // Prologue: carried loads of the first cluster of the lane (clamped: the idle lanes of a partial last
+        // round replicate the last cluster and do not write anything).
+        os << "{\n";
+        os << "unsigned c = tid;\n";
+        for (const auto &l : loads) {
+            if (l.carried) {
+                os << l.type << " " << l.name << ";\n";
+            }
+        }
+        os << "{\nconst unsigned cc = c < " << nc << "u ? c : " << nc - 1u << "u;\n";
+        for (const auto &l : loads) {
+            if (l.carried) {
+                os << l.name << " = " << l.expr << ";\n";
+            }
+        }
+        os << "}\n";
+        os << "#pragma nounroll\n";
+        os << "for (unsigned it = 0; it < " << n_iter << "u; ++it, c += " << bs << "u) {\n";
+        os << "const bool live = c < " << nc << "u;\n";
+        os << "const unsigned cw = live ? c : " << nc - 1u << "u;\n";
+        for (const auto &l : loads) {
+            if (!l.carried) {
+                auto ex = l.expr;
+                const auto pos = ex.rfind("cc]");
+                ex.replace(pos, 2, "cw");
+                os << "const " << l.type << " " << l.name << " = " << ex << ";\n";
+            }
+        }
+        if (pf_mode != 0) {
+            os << "const unsigned cc = (c + " << bs << "u) < " << nc << "u ? (c + " << bs << "u) : " << nc - 1u
+               << "u;\n";
+            for (const auto &l : loads) {
+                if (l.carried) {
+                    os << "const " << l.type << " n_" << l.name << " = " << l.expr << ";\n";
+                }
+            }
+        }
+        // Lower-order coefficients recomputed from the LDS jets of the external inputs.
+        if (n_ej != 0u && k > 0u) {
+            for (std::uint32_t m = 0; m < k; ++m) {
+                for (std::uint32_t x = 0; x < n_ext; ++x) {
+                    if (ext_used[x] != 0) {
+                        e.val(pl.ext_u[0][x], m)
+                            = e.def("ejet[" + std::to_string(static_cast<std::uint64_t>(m) * n_ej) + "u + ej"
+                                    + std::to_string(x) + "]");
+                    }
+                }
+                for (std::uint32_t s = 0; s < n_sto; ++s) {
+                    if (recomp[s] != 0) {
+                        e.node(t0[pl.stored_pos[s]] - n_eq, m);
+                    }
+                }
+                // NOTE: without a fence the scheduler hoists all the LDS reads of the inputs' jets to the top
+                // (2 * 3 * k live doubles on top of the history itself): hundreds of spilled registers.
+                if (m % sched_every == sched_every - 1u) {
+                    os << "__builtin_amdgcn_sched_barrier(0);\n";
+                }
+            }
+            os << "__builtin_amdgcn_sched_barrier(0);\n";
+        }
         for (std::uint32_t x = 0; x < n_ext; ++x) {
-            e.val(pl.ext_u[0][x], k)
-                = e.def("slab[hy_ext[" + std::to_string(static_cast<std::uint64_t>(x) * nc) + "u + c]]");
+            e.val(pl.ext_u[0][x], k) = e.def("slab[ie" + std::to_string(x) + "]");
         }
         for (const auto u : t0) {
             e.node(u - n_eq, k);
         }
+        os << "if (live) {\n";
         if (k + 1u < order) {
             for (std::uint32_t s = 0; s < n_sto; ++s) {
-                os << "tp[" << (static_cast<std::uint64_t>(s) * order + k) * ncp
-                   << "u] = " << e.val(t0[pl.stored_pos[s]], k) << ";\n";
+                if (recomp[s] == 0) {
+                    os << "tape[" << (static_cast<std::uint64_t>(tape_row[s]) * order + k) * ncp
+                       << "u + cw] = " << e.val(t0[pl.stored_pos[s]], k) << ";\n";
+                }
             }
         }
         for (std::uint32_t x = 0; x < n_out; ++x) {
-            os << "slab[hy_out[" << static_cast<std::uint64_t>(x) * nc << "u + c]] = " << e.val(t0[pl.out_pos[x]], k)
-               << ";\n";
+            os << "slab[io" << x << "] = " << e.val(t0[pl.out_pos[x]], k) << ";\n";
         }
         os << "}\n";
+        for (const auto &l : loads) {
+            if (l.carried) {
+                os << l.name << " = n_" << l.name << ";\n";
+            }
+        }
+        os << "}\n}\n";
     };
 
+    // Glue group at order k: branch-free rounds (clamped node index, the result of an idle lane goes to a dummy
+    // slot), so that all the groups of a level form one basic block and their table / LDS loads overlap.
     const auto emit_glue_group = [&](std::size_t g, std::uint32_t k) {
         const auto &grp = pl.groups[g];
         const auto rep = grp.nodes[0];
         const auto &n0 = p.nodes[rep - n_eq];
         const auto gn = "hy_g" + std::to_string(g);
-        os << "for (unsigned j = tid; j < " << grp.nodes.size() << "u; j += " << bs << "u) {\n";
-        const auto saved = e.numpar_override;
-        std::vector<std::pair<std::uint32_t, std::string>> saved_vals;
-        for (std::size_t a = 0; a < n0.args.size(); ++a) {
-            const auto &o = n0.args[a];
-            if (is_var(o)) {
-                const auto nm = e.def("slab[" + gn + "_a" + std::to_string(a) + "[j]]");
-                saved_vals.emplace_back(o.idx, e.val(o.idx, k));
-                e.val(o.idx, k) = nm;
-            } else if (o.type == operand::kind::num) {
-                e.numpar_override[&o] = gn + "_a" + std::to_string(a) + "[j]";
+        const auto ng = static_cast<std::uint32_t>(grp.nodes.size());
+        for (std::uint32_t r = 0; r * bs < ng; ++r) {
+            os << "{\nconst unsigned jr = tid + " << r * bs << "u;\n";
+            const bool partial = (r + 1u) * bs > ng;
+            if (glue_fence) {
+                os << "__builtin_amdgcn_sched_barrier(0);\n";
             }
+            if (partial) {
+                os << "const bool ok = jr < " << ng << "u;\nconst unsigned j = ok ? jr : " << ng - 1u << "u;\n";
+            } else {
+                os << "const unsigned j = jr;\n";
+            }
+            const auto saved = e.numpar_override;
+            std::vector<std::pair<std::uint32_t, std::string>> saved_vals;
+            for (std::size_t a = 0; a < n0.args.size(); ++a) {
+                const auto &o = n0.args[a];
+                if (is_var(o)) {
+                    const auto nm = e.def("slab[" + gn + "_a" + std::to_string(a) + "[j]]");
+                    saved_vals.emplace_back(o.idx, e.val(o.idx, k));
+                    e.val(o.idx, k) = nm;
+                } else if (o.type == operand::kind::num) {
+                    e.numpar_override[&o] = gn + "_a" + std::to_string(a) + "[j]";
+                }
+            }
+            if (n0.kind == func_kind::prod && n0.args[0].type == operand::kind::num && n0.args[0].value == -1.) {
+                e.numpar_override.erase(&n0.args[0]);
+            }
+            e.node(rep - n_eq, k);
+            if (partial) {
+                os << "slab[ok ? (unsigned)" << gn << "_o[j] : " << n_slots << "u] = " << e.val(rep, k) << ";\n";
+            } else {
+                os << "slab[" << gn << "_o[j]] = " << e.val(rep, k) << ";\n";
+            }
+            for (auto it = saved_vals.rbegin(); it != saved_vals.rend(); ++it) {
+                e.val(it->first, k) = it->second;
+            }
+            e.numpar_override = saved;
+            os << "}\n";
         }
-        if (n0.kind == func_kind::prod && n0.args[0].type == operand::kind::num && n0.args[0].value == -1.) {
-            e.numpar_override.erase(&n0.args[0]);
-        }
-        e.node(rep - n_eq, k);
-        os << "slab[" << gn << "_o[j]] = " << e.val(rep, k) << ";\n";
-        for (auto it = saved_vals.rbegin(); it != saved_vals.rend(); ++it) {
-            e.val(it->first, k) = it->second;
-        }
-        e.numpar_override = saved;
-        os << "}\n";
     };
 
     const auto sv_rounds = (n_eq + bs - 1u) / bs;
@@ -303,7 +534,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
     os.clear();
 
     // Scratch per workgroup: tape + state jets.
-    const std::uint64_t tape_doubles = static_cast<std::uint64_t>(n_sto) * order * ncp;
+    const std::uint64_t tape_doubles = static_cast<std::uint64_t>(n_tape) * order * ncp;
     const std::uint64_t sjet_doubles = (static_cast<std::uint64_t>(order) + 1u) * n_eq;
     const std::uint64_t per_block = (tape_doubles + sjet_doubles + 63u) / 64u * 64u;
     const std::uint32_t wpb = bs / 64u;
@@ -314,7 +545,10 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
     emit_detail::emit_dout(src, p, opts);
     src << tbl.str();
     src << "extern \"C\" __global__ void __launch_bounds__(" << bs << ") hy_taylor(const hy_kargs a)\n{\n";
-    src << "__shared__ double slab[" << n_slots << "];\n";
+    src << "__shared__ double slab[" << n_slots + 1u << "];\n";
+    if (n_ej != 0u) {
+        src << "__shared__ double ejet[" << static_cast<std::uint64_t>(n_ej) * (order - 1u) << "];\n";
+    }
     src << "__shared__ double red[3 * " << wpb << "];\n__shared__ u64 sh_base;\n__shared__ int sh_nfi;\n";
     src << "const unsigned tid = threadIdx.x;\nconst u64 N = a.N;\n";
     // Per-lane buffer of the updated state values (lane = state variable, strided).
@@ -476,8 +710,9 @@ if (tid == 0u) {
     ret.persistent = true;
     ret.tc_optional = true;
     ret.notes = "block mode: one system per workgroup of " + std::to_string(bs) + " lanes, " + std::to_string(nc)
-                + " clusters of " + std::to_string(t0.size()) + " nodes (" + std::to_string(n_sto)
-                + " members on the tape), " + std::to_string(pl.groups.size()) + " glue groups, "
+                + " clusters of " + std::to_string(t0.size()) + " nodes (" + std::to_string(n_tape)
+                + " members on the tape, " + std::to_string(n_sto - n_tape) + " recomputed from " + std::to_string(n_ej)
+                + " LDS-resident input jets), " + std::to_string(pl.groups.size()) + " glue groups, "
                 + std::to_string(n_slots) + " LDS slots, tape " + std::to_string(per_block * 8u / 1024u)
                 + " KiB per workgroup";
     return ret;

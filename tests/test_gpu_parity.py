@@ -367,9 +367,11 @@ def test_table_mode_small_dag_forced():
     _nbody_parity(3, 200, 3, "table", t_final=0.1, env_mode="table")
 
 
-def test_table_mode_nbody12_automatic():
-    """66 clusters (> 64 lanes): automatic fallback to the table-driven kernel."""
-    _nbody_parity(12, 64, 2, "table", t_final=0.02)
+def test_nbody12_block_automatic_and_table_forced():
+    """66 clusters (> 64 lanes): one system per workgroup (block mode, 128 lanes); the table-driven
+    one-lane-per-system kernel remains available (HEYOKA_AMD_EMIT_MODE=table) and agrees."""
+    _nbody_parity(12, 64, 2, "block", t_final=0.02)
+    _nbody_parity(12, 64, 2, "table", t_final=0.02, env_mode="table")
 
 
 def test_config5_nbody64_table_mode():
@@ -380,9 +382,9 @@ def test_config5_nbody64_table_mode():
 
 
 def test_block_mode_nbody20_forced_and_nbody64_automatic():
-    """Block mode (one system per workgroup, cluster jets on a coalesced tape): 190 clusters (forced; fewer
-    lanes than a workgroup would normally select table mode is not the case here: >= 128 clusters), a
-    propagation with per-lane step counts, and the BASELINE config 5 DAG where it is the default."""
+    """Block mode (one system per workgroup, cluster jets on a coalesced tape): 190 clusters, a forced
+    instance on a DAG that normally runs in wave-cluster mode with more systems than workgroups in flight
+    and the compensated update, and the BASELINE config 5 DAG (2016 clusters)."""
     ta = _nbody_parity(20, 24, 2, "block", t_final=0.02)
     assert "190 clusters" in ta.hip_source_mode
     # More systems than workgroups in flight + high accuracy (compensated summation update).
