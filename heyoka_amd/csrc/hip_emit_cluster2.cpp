@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <map>
 #include <set>
+#include <tuple>
 
 #include "hip_emit_cluster_plan.hpp"
 #include "hip_emit_detail.hpp"
@@ -146,14 +147,18 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     // ---- 3. Tables. ----
     std::vector<std::vector<std::uint32_t>> utbl;
     std::vector<std::vector<double>> dtbl;
-    const auto add_utbl = [&](std::vector<std::uint32_t> v) {
+    // NOTE: tables of slab slots and tables of state-variable indices are kept apart (the slot tables are
+    // renumbered by the bank-conflict optimiser below).
+    std::vector<char> utbl_is_slot;
+    const auto add_utbl = [&](std::vector<std::uint32_t> v, bool is_slot = true) {
         // Deduplicate identical tables.
         for (std::size_t t = 0; t < utbl.size(); ++t) {
-            if (utbl[t] == v) {
+            if (utbl[t] == v && (utbl_is_slot[t] != 0) == is_slot) {
                 return t;
             }
         }
         utbl.push_back(std::move(v));
+        utbl_is_slot.push_back(is_slot ? 1 : 0);
         return utbl.size() - 1u;
     };
     const auto add_dtbl = [&](std::vector<double> v) {
@@ -265,7 +270,7 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
                     vv[l] = var;
                 }
                 ow.out_tbl = add_utbl(std::move(vs));
-                ow.var_tbl = add_utbl(std::move(vv));
+                ow.var_tbl = add_utbl(std::move(vv), false);
                 ow.col = n_own++;
                 ow.cbase = n_col_acc;
                 ow.n_valid = gr.n_valid;
@@ -313,7 +318,22 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         }
     };
 
-    const auto emit_glue_round = [&](std::size_t g, std::uint32_t r, std::uint32_t k) {
+    // A glue round is emitted in two halves: the LDS reads of the operands, and the computation (node rule,
+    // export, fused state-variable recursions). In overlap mode independent FMA work is placed in between.
+    const auto emit_glue_reads = [&](std::size_t g, std::uint32_t r, std::uint32_t k) {
+        const auto &grp = pl.groups[g];
+        auto &gr = rounds[g][r];
+        const auto &n0 = p.nodes[grp.nodes[0] - n_eq];
+        std::vector<std::string> names(n0.args.size());
+        for (std::size_t a = 0; a < n0.args.size(); ++a) {
+            if (is_var(n0.args[a])) {
+                names[a] = e.def(slabk(k, utname(gr.arg_tbl[a])));
+            }
+        }
+        return names;
+    };
+    const auto emit_glue_compute = [&](std::size_t g, std::uint32_t r, std::uint32_t k,
+                                       const std::vector<std::string> &names) {
         const auto &grp = pl.groups[g];
         auto &gr = rounds[g][r];
         const auto rep = grp.nodes[0];
@@ -323,9 +343,8 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         for (std::size_t a = 0; a < n0.args.size(); ++a) {
             const auto &o = n0.args[a];
             if (is_var(o)) {
-                const auto nm = e.def(slabk(k, utname(gr.arg_tbl[a])));
                 saved_vals.emplace_back(o.idx, e.val(o.idx, k));
-                e.val(o.idx, k) = nm;
+                e.val(o.idx, k) = names[a];
             } else if (o.type == operand::kind::num) {
                 e.numpar_override[&o] = dtname(gr.arg_tbl[a]);
             }
@@ -344,13 +363,14 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         e.numpar_override = saved;
 
         // Fused state-variable recursion: x^[k+1] = src^[k] / (k + 1).
-        const auto valid = "ovalid" + std::to_string(gr.owners.empty() ? 0u : gr.owners[0].col);
         for (std::size_t a = 0; a < gr.owners.size(); ++a) {
             const auto src = (a == 0u) ? gval : gr.owners[a - 1u].xname[k];
             const auto x = e.div_const(src, k + 1u);
             publish_sv(gr.owners[a], k + 1u, x, "ovalid" + std::to_string(gr.owners[a].col));
         }
-        (void)valid;
+    };
+    const auto emit_glue_round = [&](std::size_t g, std::uint32_t r, std::uint32_t k) {
+        emit_glue_compute(g, r, k, emit_glue_reads(g, r, k));
     };
 
     // NOTE: the history chains of order k can be emitted in several parts: the first one at the end of
@@ -369,12 +389,36 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         t0_ids.push_back(u - n_eq);
     }
 
+    // Explicit overlap of the LDS exchange latency (the workgroup runs one wavefront per SIMD, nobody else
+    // hides it): in both exchange regions of an order the LDS reads are issued first, then - fenced by
+    // scheduling barriers - a chunk of history-chain FMAs which do not depend on them, then the dependent
+    // computation. The chunks are (ssa_emitter::emit_partials_sel): in the cluster region of order k the second
+    // half of the early terms of order k + 1; in the last glue region of order k the late terms of order k + 1
+    // and the first half of the early terms of order k + 2. HEYOKA_AMD_V2_OVERLAP=0 restores the previous
+    // schedule (whole history chain of order k + 1 at the end of order k, placement left to the compiler).
+    const bool overlap = [&]() {
+        if (const char *ev = std::getenv("HEYOKA_AMD_V2_OVERLAP")) {
+            return std::atoi(ev) != 0;
+        }
+        return true;
+    }();
+    if (const char *ev = std::getenv("HEYOKA_AMD_V2_EARLY_A_PCT")) {
+        e.early_a_pct = static_cast<std::size_t>(std::max(0, std::min(100, std::atoi(ev))));
+    }
+    const auto sched_fence = [&]() { os << "__builtin_amdgcn_sched_barrier(0);\n"; };
+    using psel = ssa_emitter::part_sel;
+
     const auto emit_cluster = [&](std::uint32_t k) {
         for (std::uint32_t part = 1; part < n_parts; ++part) {
             e.emit_partials(t0_ids, k, part, n_parts);
         }
         for (std::uint32_t x = 0; x < n_ext; ++x) {
             e.val(pl.ext_u[0][x], k) = e.def(slabk(k, utname(ext_tbl[x])));
+        }
+        if (overlap) {
+            sched_fence();
+            e.emit_partials_sel(t0_ids, k + 1u, psel::early_b);
+            sched_fence();
         }
         for (const auto u : t0) {
             e.node_finish(u - n_eq, k);
@@ -399,16 +443,36 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
             if (lev == pl.cluster_level) {
                 emit_cluster(k);
             }
-            for (std::size_t g = 0; g < pl.groups.size(); ++g) {
-                if (pl.groups[g].level == lev) {
-                    for (std::uint32_t r = 0; r < rounds[g].size(); ++r) {
-                        emit_glue_round(g, r, k);
+            const bool last = (lev == pl.max_level);
+            if (overlap && last) {
+                // Reads of all the rounds of the level first, then the independent chunk, then the computations.
+                std::vector<std::tuple<std::size_t, std::uint32_t, std::vector<std::string>>> pend;
+                for (std::size_t g = 0; g < pl.groups.size(); ++g) {
+                    if (pl.groups[g].level == lev) {
+                        for (std::uint32_t r = 0; r < rounds[g].size(); ++r) {
+                            pend.emplace_back(g, r, emit_glue_reads(g, r, k));
+                        }
                     }
                 }
-            }
-            if (lev == pl.max_level && k + 1u < order) {
-                // History part of the next order's convolutions: overlaps the exchange latency.
-                e.emit_partials(t0_ids, k + 1u, 0, n_parts);
+                sched_fence();
+                e.emit_partials_sel(t0_ids, k + 1u, psel::late);
+                e.emit_partials_sel(t0_ids, k + 2u, psel::early_a);
+                sched_fence();
+                for (const auto &[g, r, names] : pend) {
+                    emit_glue_compute(g, r, k, names);
+                }
+            } else {
+                for (std::size_t g = 0; g < pl.groups.size(); ++g) {
+                    if (pl.groups[g].level == lev) {
+                        for (std::uint32_t r = 0; r < rounds[g].size(); ++r) {
+                            emit_glue_round(g, r, k);
+                        }
+                    }
+                }
+                if (!overlap && last && k + 1u < order) {
+                    // History part of the next order's convolutions: overlaps the exchange latency.
+                    e.emit_partials(t0_ids, k + 1u, 0, n_parts);
+                }
             }
             sync();
         }
@@ -416,6 +480,12 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     const auto body = os.str();
     os.str("");
     os.clear();
+
+    // NOTE: a local search over slot permutations minimising the LDS bank conflicts of the gather-type reads
+    // was tried and removed: it lowered SQ_LDS_BANK_CONFLICT by 9 % with no change in kernel time. A
+    // microbenchmark on gfx950 shows why: a single wavefront issues one ds_read_b64 per 6.6 clk whatever the
+    // pattern (consecutive, 2-way conflicting, strided groups), only a 64-way same-bank pattern is slower
+    // (34.6 clk); the cost of the LDS traffic here is the issue slots of its ~620 instructions per step.
 
     // ===================== module text =====================
     std::ostringstream src;

@@ -602,6 +602,136 @@ struct ssa_emitter {
         }
     }
 
+    // ---- Selective emission of the history chains (explicit overlap with LDS latency windows) ----
+    // The terms of the order-K history chain of a node are classified as
+    //   late  - they involve an order-(K-1) coefficient (available only once order K-1 is complete),
+    //   early - both coefficients have order <= K-2 (available one full order earlier);
+    // the early terms are further split in two halves (early_a / early_b). The caller emits the three
+    // selections at three different points of the schedule (see hip_emit_cluster2.cpp); the accumulators
+    // are carried in pending_sel and published to `partials` when the last selection has been emitted.
+    // NOTE: the order of accumulation within a chain is early terms first, then late terms.
+    enum class part_sel { early_a = 0, early_b = 1, late = 2 };
+
+    struct idx_term {
+        std::uint32_t ua, ka, ub, kb;
+        std::string scale;
+    };
+    struct sel_chain {
+        std::uint32_t node;
+        bool is_sq;
+        std::vector<idx_term> early, late;
+        std::string acc;
+    };
+    struct sel_state {
+        std::vector<sel_chain> chains;
+        unsigned done_mask = 0;
+    };
+    std::map<std::uint32_t, sel_state> pending_sel;
+    // Percentage of the early terms emitted with the early_a selection.
+    std::size_t early_a_pct = 50;
+
+    void emit_partials_sel(const std::vector<std::uint32_t> &node_ids, std::uint32_t K, part_sel sel)
+    {
+        if (K < 2u || K >= order) {
+            return;
+        }
+        auto it = pending_sel.find(K);
+        if (it == pending_sel.end()) {
+            sel_state st;
+            for (const auto i : node_ids) {
+                if (!can_split(i)) {
+                    continue;
+                }
+                const auto &n = p.nodes[i];
+                const auto u = p.n_eq + i;
+                const auto &a = n.args;
+                sel_chain mainc{i, false, {}, {}, {}}, sqc{i, true, {}, {}, {}};
+                const auto add = [&](sel_chain &c, idx_term t) {
+                    ((t.ka == K - 1u || t.kb == K - 1u) ? c.late : c.early).push_back(std::move(t));
+                };
+                switch (n.kind) {
+                    case func_kind::prod:
+                        for (std::uint32_t j = 1; j < K; ++j) {
+                            add(mainc, {a[0].idx, K - j, a[1].idx, j, {}});
+                        }
+                        break;
+                    case func_kind::sum_sq: {
+                        const auto jmax = (K % 2u == 1u) ? (K - 1u) / 2u : (K - 2u) / 2u;
+                        for (std::uint32_t j = 1; j <= jmax; ++j) {
+                            for (const auto &o : a) {
+                                add(mainc, {o.idx, K - j, o.idx, j, {}});
+                            }
+                        }
+                        if (K % 2u == 0u) {
+                            for (const auto &o : a) {
+                                add(sqc, {o.idx, K / 2u, o.idx, K / 2u, {}});
+                            }
+                        }
+                        break;
+                    }
+                    case func_kind::pow: {
+                        const auto ex = a[1].value;
+                        for (std::uint32_t j = 1; j < K; ++j) {
+                            const double sf = static_cast<double>(K) * ex - static_cast<double>(j) * (ex + 1.);
+                            add(mainc, {a[0].idx, K - j, u, j, fp_literal(sf)});
+                        }
+                        break;
+                    }
+                    default:
+                        break;
+                }
+                const bool has_sq = !sqc.early.empty() || !sqc.late.empty();
+                st.chains.push_back(std::move(mainc));
+                if (has_sq) {
+                    st.chains.push_back(std::move(sqc));
+                }
+            }
+            it = pending_sel.emplace(K, std::move(st)).first;
+        }
+        auto &st = it->second;
+        // Interleave the chains term by term.
+        const auto range_of = [&](const sel_chain &c) -> std::pair<std::size_t, std::size_t> {
+            switch (sel) {
+                case part_sel::early_a:
+                    return {0u, c.early.size() * early_a_pct / 100u};
+                case part_sel::early_b:
+                    return {c.early.size() * early_a_pct / 100u, c.early.size()};
+                default:
+                    return {0u, c.late.size()};
+            }
+        };
+        std::size_t max_len = 0;
+        for (const auto &c : st.chains) {
+            const auto [b, e] = range_of(c);
+            max_len = std::max(max_len, e - b);
+        }
+        for (std::size_t t = 0; t < max_len; ++t) {
+            for (auto &c : st.chains) {
+                const auto [b, e] = range_of(c);
+                if (b + t >= e) {
+                    continue;
+                }
+                const auto &tm = (sel == part_sel::late) ? c.late[b + t] : c.early[b + t];
+                const auto &va = val(tm.ua, tm.ka);
+                const auto &vb = val(tm.ub, tm.kb);
+                assert(!va.empty() && !vb.empty());
+                if (tm.scale.empty()) {
+                    c.acc = chain(c.acc, va, vb);
+                } else {
+                    const auto pr = def(mul(va, vb));
+                    c.acc = chain(c.acc, tm.scale, pr);
+                }
+            }
+        }
+        st.done_mask |= 1u << static_cast<unsigned>(sel);
+        if (st.done_mask == 7u) {
+            for (auto &c : st.chains) {
+                partials[{c.node, c.is_sq ? (K + 0x10000u) : K}] = c.acc;
+            }
+            pending_sel.erase(it);
+        }
+    }
+
     // History part of a single node (non-interleaved form).
     void node_partial(std::uint32_t i, std::uint32_t k)
     {
