@@ -405,6 +405,12 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     if (const char *ev = std::getenv("HEYOKA_AMD_V2_EARLY_A_PCT")) {
         e.early_a_pct = static_cast<std::size_t>(std::max(0, std::min(100, std::atoi(ev))));
     }
+    const bool fence2 = [&]() {
+        if (const char *ev = std::getenv("HEYOKA_AMD_V2_FENCE2")) {
+            return std::atoi(ev) != 0;
+        }
+        return true;
+    }();
     const auto sched_fence = [&]() { os << "__builtin_amdgcn_sched_barrier(0);\n"; };
     using psel = ssa_emitter::part_sel;
 
@@ -418,7 +424,9 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         if (overlap) {
             sched_fence();
             e.emit_partials_sel(t0_ids, k + 1u, psel::early_b);
-            sched_fence();
+            if (fence2) {
+                sched_fence();
+            }
         }
         for (const auto u : t0) {
             e.node_finish(u - n_eq, k);
@@ -457,7 +465,9 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
                 sched_fence();
                 e.emit_partials_sel(t0_ids, k + 1u, psel::late);
                 e.emit_partials_sel(t0_ids, k + 2u, psel::early_a);
-                sched_fence();
+                if (fence2) {
+                    sched_fence();
+                }
                 for (const auto &[g, r, names] : pend) {
                     emit_glue_compute(g, r, k, names);
                 }
