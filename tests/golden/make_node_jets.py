@@ -1,0 +1,113 @@
+#!/usr/bin/env python
+"""Generates tests/golden/node_jets.json: closed-form Taylor coefficients (orders 0..3) of small coupled
+systems exercising every elementary function of the hot path, in the style of the reference's per-function
+tests (test/taylor_pow.cpp:573-700, test/taylor_sum_sq.cpp, test/taylor_sincos.cpp, test/taylor_div.cpp, ...:
+batch size 3, tol = .1 -> order 3, state {2, 5, 1, 3, 4, 6}, jets compared with the analytic derivatives).
+
+The expected values come from the calculus identities for z' = Phi(z):
+    z1 = Phi,  z2 = J z1 / 2,  z3 = (H[z1, z1] + 2 J z2) / 6
+with hand-written Jacobians J and Hessians H - no recurrence of the oracle or of the product is involved.
+The inputs are the reference's literals; where a reference test uses the same system its file:line is given.
+
+    python tests/golden/make_node_jets.py > tests/golden/node_jets.json
+"""
+import json
+import math
+
+import numpy as np
+
+X0 = [2.0, 5.0, 1.0]
+Y0 = [3.0, 4.0, 6.0]
+
+
+def jets(phi, jac, hess, z0):
+    z0 = np.array(z0, dtype=float)
+    z1 = np.array(phi(z0))
+    J = np.array(jac(z0))
+    H = np.array(hess(z0))
+    z2 = J @ z1 / 2.0
+    z3 = (np.einsum("ijk,j,k->i", H, z1, z1) + 2.0 * (J @ z2)) / 6.0
+    return [z0.tolist(), z1.tolist(), z2.tolist(), z3.tolist()]
+
+
+def Z(n):
+    return [[[0.0] * n for _ in range(n)] for _ in range(n)]
+
+
+CASES = []
+
+
+def case(name, sys, source, phi, jac, hess, pars=None, time=None):
+    CASES.append(dict(name=name, sys=sys, source=source, phi=phi, jac=jac, hess=hess, pars=pars, time=time))
+
+
+# 1. pow with fractional exponents (test/taylor_pow.cpp:573-641).
+def _pow(a, b):
+    def hess(z):
+        h = Z(2)
+        h[0][1][1] = a * (a - 1) * z[1] ** (a - 2)
+        h[1][0][0] = b * (b - 1) * z[0] ** (b - 2)
+        return h
+    return (lambda z: [z[1] ** a, z[0] ** b],
+            lambda z: [[0, a * z[1] ** (a - 1)], [b * z[0] ** (b - 1), 0]], hess)
+
+
+case("pow_3_2__m1_3", ["pow(y, 3/2)", "pow(x, -1/3)"], "test/taylor_pow.cpp:573-641", *_pow(1.5, -1.0 / 3.0))
+case("pow_par_exponents", ["pow(y, par[0])", "pow(x, par[1])"], "test/taylor_pow.cpp:643-700", *_pow(1.5, -1.0 / 3.0),
+     pars=[[1.5] * 3, [-1.0 / 3.0] * 3])
+case("pow_m3_2__2", ["pow(y, -3/2)", "pow(x, 2)"], "src/math/pow.cpp:292-355 (neg_small_half / square paths)",
+     *_pow(-1.5, 2.0))
+case("sqrt", ["sqrt(y)", "sqrt(x)"], "test/taylor_sqrt.cpp", *_pow(0.5, 0.5))
+
+# 2. Products, quotients, linear combinations.
+case("prod_var_var", ["x * y", "y * x * x"], "test/taylor_mul.cpp / taylor_prod.cpp",
+     lambda z: [z[0] * z[1], z[1] * z[0] * z[0]],
+     lambda z: [[z[1], z[0]], [2 * z[0] * z[1], z[0] * z[0]]],
+     lambda z: [[[0, 1], [1, 0]], [[2 * z[1], 2 * z[0]], [2 * z[0], 0]]])
+case("prod_num_var_neg", ["-2 * y", "-x"], "test/taylor_neg.cpp",
+     lambda z: [-2 * z[1], -z[0]], lambda z: [[0, -2], [-1, 0]], lambda z: Z(2))
+case("div", ["x / y", "1.5 / x"], "test/taylor_div.cpp",
+     lambda z: [z[0] / z[1], 1.5 / z[0]],
+     lambda z: [[1 / z[1], -z[0] / z[1] ** 2], [-1.5 / z[0] ** 2, 0]],
+     lambda z: [[[0, -1 / z[1] ** 2], [-1 / z[1] ** 2, 2 * z[0] / z[1] ** 3]], [[3.0 / z[0] ** 3, 0], [0, 0]]])
+case("sum_sub", ["x - y", "x + y + 2"], "test/taylor_sub.cpp / taylor_sum.cpp",
+     lambda z: [z[0] - z[1], z[0] + z[1] + 2], lambda z: [[1, -1], [1, 1]], lambda z: Z(2))
+case("sum_sq", ["x*x + y*y", "x*x + y*y + 9"], "test/taylor_sum_sq.cpp",
+     lambda z: [z[0] ** 2 + z[1] ** 2, z[0] ** 2 + z[1] ** 2 + 9],
+     lambda z: [[2 * z[0], 2 * z[1]], [2 * z[0], 2 * z[1]]],
+     lambda z: [[[2, 0], [0, 2]], [[2, 0], [0, 2]]])
+
+# 3. Transcendental functions.
+case("sin_cos", ["sin(y)", "cos(x)"], "test/taylor_sincos.cpp",
+     lambda z: [math.sin(z[1]), math.cos(z[0])],
+     lambda z: [[0, math.cos(z[1])], [-math.sin(z[0]), 0]],
+     lambda z: [[[0, 0], [0, -math.sin(z[1])]], [[-math.cos(z[0]), 0], [0, 0]]])
+case("exp_log", ["exp(0.1 * y)", "log(x)"], "test/taylor_exp.cpp / taylor_log.cpp",
+     lambda z: [math.exp(0.1 * z[1]), math.log(z[0])],
+     lambda z: [[0, 0.1 * math.exp(0.1 * z[1])], [1 / z[0], 0]],
+     lambda z: [[[0, 0], [0, 0.01 * math.exp(0.1 * z[1])]], [[-1 / z[0] ** 2, 0], [0, 0]]])
+
+# 4. Explicit time dependence (z = (x, y, t), t' = 1; test/taylor_time.cpp).
+case("time", ["time + y", "x * time"], "test/taylor_time.cpp",
+     lambda z: [z[2] + z[1], z[0] * z[2], 1.0],
+     lambda z: [[0, 1, 1], [z[2], 0, z[0]], [0, 0, 0]],
+     lambda z: [Z(3)[0], [[0, 0, 1], [0, 0, 0], [1, 0, 0]], Z(3)[0]],
+     time=[0.5, -1.25, 3.0])
+
+
+def main():
+    out = {"note": "closed-form jets, see make_node_jets.py; jets[lane][order][variable]", "tol": 0.1, "order": 3,
+           "state": [X0, Y0], "cases": []}
+    for c in CASES:
+        lanes = []
+        for l in range(3):
+            z0 = [X0[l], Y0[l]] + ([c["time"][l]] if c["time"] else [])
+            j = jets(c["phi"], c["jac"], c["hess"], z0)
+            lanes.append([row[:2] for row in j])
+        out["cases"].append({"name": c["name"], "sys": c["sys"], "source": c["source"], "pars": c["pars"],
+                             "time": c["time"], "jets": lanes})
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,87 @@
+"""Per-function Taylor coefficients against closed-form derivatives (tests/golden/node_jets.json), in the
+style of the reference's per-function tests (test/taylor_pow.cpp:573-700 etc.: batch 3, tol = .1 -> order 3,
+`approximately()` = 100 eps). Pins the recurrences of the oracle (CPU) and of the HIP path (GPU) for every
+elementary function of the hot path independently of each other."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import heyoka_oracle as ho
+from conftest import EPS
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "node_jets.json")) as _f:
+    G = json.load(_f)
+
+
+def build(m, name):
+    """The systems of make_node_jets.py for expression module m (oracle or product)."""
+    if m is ho:
+        x, y, t = m.var("x"), m.var("y"), m.func("time", [])
+        P = m.par
+        powf, sqrt = m.pow_, m.sqrt
+    else:
+        x, y = m.make_vars("x", "y")
+        t, P = m.time, lambda i: m.par[i]
+        powf, sqrt = m.pow, m.sqrt
+    rhs = {
+        "pow_3_2__m1_3": (powf(y, 1.5), powf(x, -1.0 / 3.0)),
+        "pow_par_exponents": (powf(y, P(0)), powf(x, P(1))),
+        "pow_m3_2__2": (powf(y, -1.5), powf(x, 2.0)),
+        "sqrt": (sqrt(y), sqrt(x)),
+        "prod_var_var": (x * y, y * x * x),
+        "prod_num_var_neg": (-2.0 * y, -x),
+        "div": (x / y, 1.5 / x),
+        "sum_sub": (x - y, x + y + 2.0),
+        "sum_sq": (x * x + y * y, x * x + y * y + 9.0),
+        "sin_cos": (m.sin(y), m.cos(x)),
+        "exp_log": (m.exp(0.1 * y), m.log(x)),
+        "time": (t + y, x * t),
+    }[name]
+    return [(x, rhs[0]), (y, rhs[1])]
+
+
+def check(tc, case):
+    # tc[var][order][lane] vs jets[lane][order][var]
+    exp = np.transpose(np.array(case["jets"]), (2, 1, 0))
+    err = np.abs(tc - exp) / np.maximum(np.abs(exp), 1e-300)
+    err[exp == 0] = np.abs(tc)[exp == 0]
+    assert np.max(err) <= 100 * EPS, (case["name"], float(np.max(err)))
+
+
+@pytest.mark.parametrize("case", G["cases"], ids=[c["name"] for c in G["cases"]])
+def test_oracle_node_jets(case):
+    ta = ho.OracleIntegrator(build(ho, case["name"]), G["state"], 3, tol=G["tol"], pars=case["pars"],
+                             time=case["time"])
+    assert ta.order == G["order"]
+    ta.step(wtc=True)
+    check(ta.tc.reshape(2, G["order"] + 1, 3), case)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["default", "table"])
+def test_gpu_node_jets(mode):
+    import heyoka_amd as hy
+
+    old = os.environ.get("HEYOKA_AMD_EMIT_MODE")
+    if mode == "table":
+        os.environ["HEYOKA_AMD_EMIT_MODE"] = "table"
+    try:
+        for case in G["cases"]:
+            kw = {}
+            if case["pars"] is not None:
+                kw["pars"] = case["pars"]
+            if case["time"] is not None:
+                kw["time"] = case["time"]
+            ta = hy.taylor_adaptive_batch(build(hy, case["name"]), G["state"], 3, tol=G["tol"], **kw)
+            assert ta.order == G["order"]
+            ta.step(write_tc=True)
+            check(np.asarray(ta.tc).reshape(2, G["order"] + 1, 3), case)
+    finally:
+        if mode == "table":
+            if old is None:
+                del os.environ["HEYOKA_AMD_EMIT_MODE"]
+            else:
+                os.environ["HEYOKA_AMD_EMIT_MODE"] = old
