@@ -881,7 +881,7 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
 
         d.run_step(cur_max, wtc);
         d.fetch_step_res();
-        d.to_host();
+        d.times_to_host(); // NOTE: the state stays on the device (fetched lazily by the getters).
 
         std::uint32_t n_done = 0;
         bool nfs_detected = false;
@@ -930,7 +930,7 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
             const auto thi_copy = d.time_hi;
             const auto tlo_copy = d.time_lo;
             const auto ret_cb = cb();
-            d.to_host();
+            d.times_to_host(); // NOTE: the state stays on the device (fetched lazily by the getters).
             if (d.time_hi != thi_copy || d.time_lo != tlo_copy) {
                 throw std::runtime_error("The invocation of the callback passed to propagate_until() resulted in the "
                                          "alteration of the time coordinate of the integrator - this is not supported");
@@ -1145,7 +1145,7 @@ std::vector<double> tab_core::propagate_grid(std::vector<double> grid, std::size
         }
         d.run_step(pgrid_tmp, true);
         d.fetch_step_res();
-        d.to_host();
+        d.times_to_host(); // NOTE: the state stays on the device (fetched lazily by the getters).
 
         bool nfs_detected = false;
         for (std::uint32_t i = 0; i < N; ++i) {
@@ -1176,7 +1176,7 @@ std::vector<double> tab_core::propagate_grid(std::vector<double> grid, std::size
         if (cb) {
             const auto thi_copy = d.time_hi, tlo_copy = d.time_lo;
             cb_ok = cb();
-            d.to_host();
+            d.times_to_host(); // NOTE: the state stays on the device (fetched lazily by the getters).
             if (d.time_hi != thi_copy || d.time_lo != tlo_copy) {
                 throw std::runtime_error(cb_time_errmsg);
             }
