@@ -29,6 +29,18 @@ __all__ = [
     "exp",
     "log",
     "sqrt",
+    "tan",
+    "tanh",
+    "sinh",
+    "cosh",
+    "asin",
+    "acos",
+    "atan",
+    "asinh",
+    "acosh",
+    "atanh",
+    "erf",
+    "sigmoid",
     "pow",
     "sum",
     "prod",
@@ -184,6 +196,54 @@ def log(e):
 
 def sqrt(e):
     return _un(lib.hy_expr_sqrt, e)
+
+
+def tan(e):
+    return _un(lib.hy_expr_tan, e)
+
+
+def tanh(e):
+    return _un(lib.hy_expr_tanh, e)
+
+
+def sinh(e):
+    return _un(lib.hy_expr_sinh, e)
+
+
+def cosh(e):
+    return _un(lib.hy_expr_cosh, e)
+
+
+def asin(e):
+    return _un(lib.hy_expr_asin, e)
+
+
+def acos(e):
+    return _un(lib.hy_expr_acos, e)
+
+
+def atan(e):
+    return _un(lib.hy_expr_atan, e)
+
+
+def asinh(e):
+    return _un(lib.hy_expr_asinh, e)
+
+
+def acosh(e):
+    return _un(lib.hy_expr_acosh, e)
+
+
+def atanh(e):
+    return _un(lib.hy_expr_atanh, e)
+
+
+def erf(e):
+    return _un(lib.hy_expr_erf, e)
+
+
+def sigmoid(e):
+    return _un(lib.hy_expr_sigmoid, e)
 
 
 def pow(b, e):  # noqa: A001 - mirrors heyoka::pow

@@ -68,6 +68,18 @@ SIGNATURES = [
     ("hy_expr_cos", c_void_p, [c_void_p]),
     ("hy_expr_exp", c_void_p, [c_void_p]),
     ("hy_expr_log", c_void_p, [c_void_p]),
+    ("hy_expr_tan", c_void_p, [c_void_p]),
+    ("hy_expr_tanh", c_void_p, [c_void_p]),
+    ("hy_expr_sinh", c_void_p, [c_void_p]),
+    ("hy_expr_cosh", c_void_p, [c_void_p]),
+    ("hy_expr_asin", c_void_p, [c_void_p]),
+    ("hy_expr_acos", c_void_p, [c_void_p]),
+    ("hy_expr_atan", c_void_p, [c_void_p]),
+    ("hy_expr_asinh", c_void_p, [c_void_p]),
+    ("hy_expr_acosh", c_void_p, [c_void_p]),
+    ("hy_expr_atanh", c_void_p, [c_void_p]),
+    ("hy_expr_erf", c_void_p, [c_void_p]),
+    ("hy_expr_sigmoid", c_void_p, [c_void_p]),
     ("hy_expr_sum", c_void_p, [c_void_p, c_size_t]),
     ("hy_expr_prod", c_void_p, [c_void_p, c_size_t]),
     ("hy_expr_free", None, [c_void_p]),

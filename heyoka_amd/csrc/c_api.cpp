@@ -241,6 +241,54 @@ hy_expr hy_expr_log(hy_expr a)
 {
     return make_expr([&] { return log(a->ex); });
 }
+hy_expr hy_expr_tan(hy_expr a)
+{
+    return make_expr([&] { return tan(a->ex); });
+}
+hy_expr hy_expr_tanh(hy_expr a)
+{
+    return make_expr([&] { return tanh(a->ex); });
+}
+hy_expr hy_expr_sinh(hy_expr a)
+{
+    return make_expr([&] { return sinh(a->ex); });
+}
+hy_expr hy_expr_cosh(hy_expr a)
+{
+    return make_expr([&] { return cosh(a->ex); });
+}
+hy_expr hy_expr_asin(hy_expr a)
+{
+    return make_expr([&] { return asin(a->ex); });
+}
+hy_expr hy_expr_acos(hy_expr a)
+{
+    return make_expr([&] { return acos(a->ex); });
+}
+hy_expr hy_expr_atan(hy_expr a)
+{
+    return make_expr([&] { return atan(a->ex); });
+}
+hy_expr hy_expr_asinh(hy_expr a)
+{
+    return make_expr([&] { return asinh(a->ex); });
+}
+hy_expr hy_expr_acosh(hy_expr a)
+{
+    return make_expr([&] { return acosh(a->ex); });
+}
+hy_expr hy_expr_atanh(hy_expr a)
+{
+    return make_expr([&] { return atanh(a->ex); });
+}
+hy_expr hy_expr_erf(hy_expr a)
+{
+    return make_expr([&] { return erf(a->ex); });
+}
+hy_expr hy_expr_sigmoid(hy_expr a)
+{
+    return make_expr([&] { return sigmoid(a->ex); });
+}
 hy_expr hy_expr_sum(const hy_expr *v, size_t n)
 {
     return make_expr([&] {

@@ -229,6 +229,70 @@ std::size_t func_taylor_decompose(expression f_ex, taylor_dc_t &dc)
         return dc.size() - 1u;
     }
 
+    const auto u32 = [](std::size_t x) { return static_cast<std::uint32_t>(x); };
+    const auto uvar = [&](std::size_t i) { return expression{uname(i)}; };
+    const auto &arg = f.args().empty() ? f_ex : f.args()[0];
+
+    switch (f.kind()) {
+        case func_kind::tan:
+        case func_kind::tanh:
+        case func_kind::sigmoid: {
+            // f(b) followed by its square, on which it depends
+            // (src/math/tan.cpp:69-85, src/math/tanh.cpp:76-92, src/math/sigmoid.cpp:102-118).
+            dc.emplace_back(f_ex, std::vector<std::uint32_t>{});
+            const auto i = dc.size() - 1u;
+            dc.emplace_back(pow(uvar(i), expression{2.}), std::vector<std::uint32_t>{});
+            dc[i].second.push_back(u32(i + 1u));
+            return i;
+        }
+        case func_kind::sinh:
+        case func_kind::cosh: {
+            // Mutually-dependent pair, partner first (src/math/sinh.cpp:75-93, src/math/cosh.cpp:75-93).
+            const auto other = (f.kind() == func_kind::sinh) ? func_kind::cosh : func_kind::sinh;
+            dc.emplace_back(detail::make_func(other, {arg}), std::vector<std::uint32_t>{});
+            dc.emplace_back(f_ex, std::vector<std::uint32_t>{});
+            (dc.end() - 2)->second.push_back(u32(dc.size() - 1u));
+            (dc.end() - 1)->second.push_back(u32(dc.size() - 2u));
+            return dc.size() - 1u;
+        }
+        case func_kind::asin:
+        case func_kind::acos:
+        case func_kind::asinh:
+        case func_kind::acosh: {
+            // b^2 -> (1 - b^2 | 1 + b^2 | b^2 - 1) -> sqrt -> f(b), which depends on the square root
+            // (src/math/asin.cpp:77-108, acos.cpp:77-108, asinh.cpp:76-101, acosh.cpp:76-101).
+            dc.emplace_back(pow(arg, expression{2.}), std::vector<std::uint32_t>{});
+            const auto sq = uvar(dc.size() - 1u);
+            if (f.kind() == func_kind::asin || f.kind() == func_kind::acos) {
+                dc.emplace_back(detail::make_func(func_kind::sub, {expression{1.}, sq}), std::vector<std::uint32_t>{});
+            } else if (f.kind() == func_kind::asinh) {
+                dc.emplace_back(expression{1.} + sq, std::vector<std::uint32_t>{});
+            } else {
+                dc.emplace_back(sq - expression{1.}, std::vector<std::uint32_t>{});
+            }
+            dc.emplace_back(sqrt(uvar(dc.size() - 1u)), std::vector<std::uint32_t>{});
+            dc.emplace_back(f_ex, std::vector<std::uint32_t>{u32(dc.size() - 1u)});
+            return dc.size() - 1u;
+        }
+        case func_kind::atan:
+        case func_kind::atanh: {
+            // b^2 -> f(b), which depends on it (src/math/atan.cpp:74-91, atanh.cpp:74-91).
+            dc.emplace_back(pow(arg, expression{2.}), std::vector<std::uint32_t>{});
+            dc.emplace_back(f_ex, std::vector<std::uint32_t>{u32(dc.size() - 1u)});
+            return dc.size() - 1u;
+        }
+        case func_kind::erf: {
+            // b^2 -> -b^2 -> exp(-b^2) -> erf(b), which depends on the exponential (src/math/erf.cpp:81-105).
+            dc.emplace_back(pow(arg, expression{2.}), std::vector<std::uint32_t>{});
+            dc.emplace_back(-uvar(dc.size() - 1u), std::vector<std::uint32_t>{});
+            dc.emplace_back(exp(uvar(dc.size() - 1u)), std::vector<std::uint32_t>{});
+            dc.emplace_back(f_ex, std::vector<std::uint32_t>{u32(dc.size() - 1u)});
+            return dc.size() - 1u;
+        }
+        default:
+            break;
+    }
+
     const auto ret = dc.size();
     dc.emplace_back(std::move(f_ex), std::vector<std::uint32_t>{});
     return ret;

@@ -40,6 +40,30 @@ const char *func_kind_name(func_kind k)
             return "time";
         case func_kind::num_identity:
             return "num_identity";
+        case func_kind::tan:
+            return "tan";
+        case func_kind::tanh:
+            return "tanh";
+        case func_kind::sinh:
+            return "sinh";
+        case func_kind::cosh:
+            return "cosh";
+        case func_kind::asin:
+            return "asin";
+        case func_kind::acos:
+            return "acos";
+        case func_kind::atan:
+            return "atan";
+        case func_kind::asinh:
+            return "asinh";
+        case func_kind::acosh:
+            return "acosh";
+        case func_kind::atanh:
+            return "atanh";
+        case func_kind::erf:
+            return "erf";
+        case func_kind::sigmoid:
+            return "sigmoid";
     }
     return "?";
 }
@@ -366,6 +390,33 @@ expression log(expression e)
     }
     return detail::make_func(func_kind::log, {std::move(e)});
 }
+
+// Unary elementary functions: constant folding on numbers, otherwise a function node
+// (reference: src/math/tan.cpp etc., e.g. the number overloads at src/math/tan.cpp:230-245).
+#define HEYOKA_AMD_UNARY_FUNC(name, eval)                                                                              \
+    expression name(expression e)                                                                                      \
+    {                                                                                                                  \
+        if (e.is_number()) {                                                                                           \
+            const double x = e.num();                                                                                  \
+            return expression{eval};                                                                                   \
+        }                                                                                                              \
+        return detail::make_func(func_kind::name, {std::move(e)});                                                     \
+    }
+
+HEYOKA_AMD_UNARY_FUNC(tan, std::tan(x))
+HEYOKA_AMD_UNARY_FUNC(tanh, std::tanh(x))
+HEYOKA_AMD_UNARY_FUNC(sinh, std::sinh(x))
+HEYOKA_AMD_UNARY_FUNC(cosh, std::cosh(x))
+HEYOKA_AMD_UNARY_FUNC(asin, std::asin(x))
+HEYOKA_AMD_UNARY_FUNC(acos, std::acos(x))
+HEYOKA_AMD_UNARY_FUNC(atan, std::atan(x))
+HEYOKA_AMD_UNARY_FUNC(asinh, std::asinh(x))
+HEYOKA_AMD_UNARY_FUNC(acosh, std::acosh(x))
+HEYOKA_AMD_UNARY_FUNC(atanh, std::atanh(x))
+HEYOKA_AMD_UNARY_FUNC(erf, std::erf(x))
+HEYOKA_AMD_UNARY_FUNC(sigmoid, 1. / (1. + std::exp(-x)))
+
+#undef HEYOKA_AMD_UNARY_FUNC
 
 // --- Traversal. ---
 // Iterative post-order traversal replicating the visiting order of the reference

@@ -40,7 +40,21 @@ enum class func_kind : std::uint8_t {
     exp,
     log,
     time,
-    num_identity
+    num_identity,
+    // Elementary functions beyond the N-body set (reference: src/math/{tan,tanh,sinh,cosh,asin,acos,atan,
+    // asinh,acosh,atanh,erf,sigmoid}.cpp).
+    tan,
+    tanh,
+    sinh,
+    cosh,
+    asin,
+    acos,
+    atan,
+    asinh,
+    acosh,
+    atanh,
+    erf,
+    sigmoid
 };
 
 const char *func_kind_name(func_kind);
@@ -184,6 +198,18 @@ expression sin(expression);
 expression cos(expression);
 expression exp(expression);
 expression log(expression);
+expression tan(expression);
+expression tanh(expression);
+expression sinh(expression);
+expression cosh(expression);
+expression asin(expression);
+expression acos(expression);
+expression atan(expression);
+expression asinh(expression);
+expression acosh(expression);
+expression atanh(expression);
+expression erf(expression);
+expression sigmoid(expression);
 
 namespace detail
 {

@@ -91,6 +91,26 @@ std::vector<std::uint32_t> history_operands(const dc_node &n)
                 ret = {a[0].idx};
             }
             break;
+        case func_kind::tan:
+        case func_kind::tanh:
+        case func_kind::sinh:
+        case func_kind::cosh:
+        case func_kind::erf:
+        case func_kind::sigmoid:
+        case func_kind::asin:
+        case func_kind::acos:
+        case func_kind::atan:
+        case func_kind::asinh:
+        case func_kind::acosh:
+        case func_kind::atanh:
+            // Argument + hidden dependency (the functions' own histories are added by the planner).
+            if (is_var(a[0])) {
+                ret = {a[0].idx};
+                for (const auto d : n.deps) {
+                    ret.push_back(d);
+                }
+            }
+            break;
         default:
             break;
     }
@@ -400,6 +420,13 @@ std::string cluster_detail::make_plan(const taylor_program &p, std::uint32_t ord
             case func_kind::cos:
             case func_kind::exp:
             case func_kind::log:
+            case func_kind::sigmoid:
+            case func_kind::asin:
+            case func_kind::acos:
+            case func_kind::atan:
+            case func_kind::asinh:
+            case func_kind::acosh:
+            case func_kind::atanh:
                 if (!history_operands(n).empty()) {
                     stored.insert(u);
                 }

@@ -435,6 +435,117 @@ struct ssa_emitter {
                 }
                 break;
             }
+            case func_kind::tan:
+            case func_kind::tanh:
+            case func_kind::sinh:
+            case func_kind::cosh:
+            case func_kind::erf:
+            case func_kind::sigmoid: {
+                // "Forward" rules: k a^[k] = sum_{j=1..k} j X^[k-j] b^[j], with
+                //   tan:  a^[k] = b^[k] + S/k, X = a^2 (hidden dep)            src/math/tan.cpp:105-131
+                //   tanh: a^[k] = b^[k] - S/k, X = a^2                          src/math/tanh.cpp
+                //   sinh / cosh: a^[k] = S/k, X = the partner function           src/math/sinh.cpp, cosh.cpp
+                //   erf:  a^[k] = 2/sqrt(pi) S/k, X = exp(-b^2)                  src/math/erf.cpp
+                //   sigmoid: a^[k] = S/k, X = a - a^2                            src/math/sigmoid.cpp:150-172
+                const auto fname = std::string(func_kind_name(n.kind));
+                const auto order0 = [&](const std::string &x) {
+                    return n.kind == func_kind::sigmoid ? def("1.0 / (1.0 + exp(-(" + x + ")))") : def(fname + "(" + x + ")");
+                };
+                if (!is_var(a[0])) {
+                    out = (k == 0u) ? order0(numpar(a[0])) : "0.0";
+                    break;
+                }
+                const auto b = a[0].idx;
+                if (k == 0u) {
+                    out = order0(val(b, 0));
+                    break;
+                }
+                if (n.deps.size() != 1u) {
+                    throw std::invalid_argument("A hidden dependency vector of size 1 is expected in order to compute "
+                                                "the Taylor derivative of " + fname);
+                }
+                const auto d = n.deps[0];
+                std::vector<std::string> terms;
+                for (std::uint32_t j = 1; j <= k; ++j) {
+                    std::string x = val(d, k - j);
+                    if (n.kind == func_kind::sigmoid) {
+                        x = def(val(u, k - j) + " - " + x);
+                    }
+                    const auto pr = def(mul(x, val(b, j)));
+                    terms.push_back(def(mul(fp_literal(static_cast<double>(j)), pr)));
+                }
+                const auto acc = def(pairwise_sum(std::move(terms)) + " / " + fp_literal(static_cast<double>(k)));
+                if (n.kind == func_kind::tan) {
+                    out = def(val(b, k) + " + " + acc);
+                } else if (n.kind == func_kind::tanh) {
+                    out = def(val(b, k) + " - " + acc);
+                } else if (n.kind == func_kind::erf) {
+                    // 2 / sqrt(pi)
+                    out = def(mul(fp_literal(1.1283791670955125738961589031215451716881012586580), acc));
+                } else {
+                    out = acc;
+                }
+                break;
+            }
+            case func_kind::asin:
+            case func_kind::acos:
+            case func_kind::atan:
+            case func_kind::asinh:
+            case func_kind::acosh:
+            case func_kind::atanh: {
+                // "Inverse" rules: a^[k] = (k b^[k] -+ sum_{j=1..k-1} j c^[k-j] a^[j]) / (k D), with c the hidden dep and
+                //   asin:  D = c0 = sqrt(1 - b0^2), minus            src/math/asin.cpp:140-178
+                //   acos:  D = -c0, plus                              src/math/acos.cpp:140-178
+                //   atan:  D = 1 + c0 (c = b^2), minus                src/math/atan.cpp:125-164
+                //   atanh: D = 1 - c0 (c = b^2), plus                 src/math/atanh.cpp:125-164
+                //   asinh: D = c0 = sqrt(1 + b0^2), minus             src/math/asinh.cpp:135-170
+                //   acosh: D = c0 = sqrt(b0^2 - 1), minus             src/math/acosh.cpp
+                const auto fname = std::string(func_kind_name(n.kind));
+                if (!is_var(a[0])) {
+                    out = (k == 0u) ? def(fname + "(" + numpar(a[0]) + ")") : "0.0";
+                    break;
+                }
+                const auto b = a[0].idx;
+                if (k == 0u) {
+                    out = def(fname + "(" + val(b, 0) + ")");
+                    break;
+                }
+                if (n.deps.size() != 1u) {
+                    throw std::invalid_argument("A hidden dependency vector of size 1 is expected in order to compute "
+                                                "the Taylor derivative of " + fname);
+                }
+                const auto d = n.deps[0];
+                std::string D;
+                switch (n.kind) {
+                    case func_kind::acos:
+                        D = def("-" + val(d, 0));
+                        break;
+                    case func_kind::atan:
+                        D = def(val(d, 0) + " + 1.0");
+                        break;
+                    case func_kind::atanh:
+                        D = def("1.0 - " + val(d, 0));
+                        break;
+                    default:
+                        D = val(d, 0);
+                        break;
+                }
+                if (k == 1u) {
+                    out = def(val(b, 1) + " / " + D);
+                    break;
+                }
+                const bool plus = (n.kind == func_kind::acos || n.kind == func_kind::atanh);
+                const auto kf = fp_literal(static_cast<double>(k));
+                auto ret = def(mul(kf, val(b, k)));
+                std::vector<std::string> terms;
+                for (std::uint32_t j = 1; j < k; ++j) {
+                    const auto pr = def(mul(val(d, k - j), val(u, j)));
+                    terms.push_back(def(mul(fp_literal(static_cast<double>(j)), pr)));
+                }
+                ret = def(ret + (plus ? " + " : " - ") + pairwise_sum(std::move(terms)));
+                out = def(ret + " / " + def(mul(kf, D)));
+                break;
+            }
         }
     }
 

@@ -40,6 +40,18 @@ const char *table_device_code = R"HIP(
 #define K_LOG 9
 #define K_TIME 10
 #define K_NUM_IDENTITY 11
+#define K_TAN 12
+#define K_TANH 13
+#define K_SINH 14
+#define K_COSH 15
+#define K_ERF 16
+#define K_SIGMOID 17
+#define K_ASIN 18
+#define K_ACOS 19
+#define K_ATAN 20
+#define K_ASINH 21
+#define K_ACOSH 22
+#define K_ATANH 23
 #define A_UVAR 0
 #define A_NUM 1
 #define A_PAR 2
@@ -258,6 +270,59 @@ __device__ double hy_diff_log(const hy_tctx &c, unsigned a0, unsigned u, unsigne
     return ret / ((double)k * hy_tp(c, 0, b));
 }
 
+__device__ double hy_unary0(unsigned kind, double x)
+{
+    switch (kind) {
+        case K_TAN: return tan(x);
+        case K_TANH: return tanh(x);
+        case K_SINH: return sinh(x);
+        case K_COSH: return cosh(x);
+        case K_ERF: return erf(x);
+        case K_SIGMOID: return 1.0 / (1.0 + exp(-x));
+        case K_ASIN: return asin(x);
+        case K_ACOS: return acos(x);
+        case K_ATAN: return atan(x);
+        case K_ASINH: return asinh(x);
+        case K_ACOSH: return acosh(x);
+        default: return atanh(x);
+    }
+}
+
+// tan, tanh, sinh, cosh, erf, sigmoid: k a^[k] = sum_{j=1..k} j X^[k-j] b^[j] (see ssa_emitter::node()).
+__device__ double hy_diff_fwd(const hy_tctx &c, unsigned kind, unsigned a0, unsigned u, unsigned dep, unsigned k)
+{
+    if (hy_arg_type[a0] != A_UVAR) return k == 0u ? hy_unary0(kind, hy_numpar(c, a0)) : 0.0;
+    const unsigned b = hy_arg_idx[a0];
+    if (k == 0u) return hy_unary0(kind, hy_tp(c, 0, b));
+    double acc = 0.0;
+    for (unsigned j = 1; j <= k; ++j) {
+        double x = hy_tp(c, k - j, dep);
+        if (kind == K_SIGMOID) x = hy_tp(c, k - j, u) - x;
+        acc += (double)j * (x * hy_tp(c, j, b));
+    }
+    acc = acc / (double)k;
+    if (kind == K_TAN) return hy_tp(c, k, b) + acc;
+    if (kind == K_TANH) return hy_tp(c, k, b) - acc;
+    if (kind == K_ERF) return 0x1.20dd750429b6dp+0 * acc;
+    return acc;
+}
+
+// asin, acos, atan, asinh, acosh, atanh: a^[k] = (k b^[k] -+ sum_{j=1..k-1} j c^[k-j] a^[j]) / (k D).
+__device__ double hy_diff_inv(const hy_tctx &c, unsigned kind, unsigned a0, unsigned u, unsigned dep, unsigned k)
+{
+    if (hy_arg_type[a0] != A_UVAR) return k == 0u ? hy_unary0(kind, hy_numpar(c, a0)) : 0.0;
+    const unsigned b = hy_arg_idx[a0];
+    if (k == 0u) return hy_unary0(kind, hy_tp(c, 0, b));
+    const double c0 = hy_tp(c, 0, dep);
+    const double D = (kind == K_ACOS) ? -c0 : (kind == K_ATAN ? (c0 + 1.0) : (kind == K_ATANH ? (1.0 - c0) : c0));
+    if (k == 1u) return hy_tp(c, 1, b) / D;
+    double acc = 0.0;
+    for (unsigned j = 1; j < k; ++j) acc += (double)j * (hy_tp(c, k - j, dep) * hy_tp(c, j, u));
+    double ret = (double)k * hy_tp(c, k, b);
+    ret = (kind == K_ACOS || kind == K_ATANH) ? (ret + acc) : (ret - acc);
+    return ret / ((double)k * D);
+}
+
 // Order-k coefficients of all the u variables that are not state variables.
 __device__ void hy_nodes_order(const hy_tctx &c, unsigned k)
 {
@@ -277,6 +342,10 @@ __device__ void hy_nodes_order(const hy_tctx &c, unsigned k)
             case K_EXP: v = hy_diff_exp(c, a0, u, k); break;
             case K_LOG: v = hy_diff_log(c, a0, u, k); break;
             case K_TIME: v = (k == 0u) ? c.t_hi : (k == 1u ? 1.0 : 0.0); break;
+            case K_TAN: case K_TANH: case K_SINH: case K_COSH: case K_ERF: case K_SIGMOID:
+                v = hy_diff_fwd(c, hy_kind[i], a0, u, hy_dep[i], k); break;
+            case K_ASIN: case K_ACOS: case K_ATAN: case K_ASINH: case K_ACOSH: case K_ATANH:
+                v = hy_diff_inv(c, hy_kind[i], a0, u, hy_dep[i], k); break;
             default: v = (k == 0u) ? hy_numpar(c, a0) : 0.0; break;
         }
         hy_tp(c, k, u) = v;
@@ -464,6 +533,30 @@ int kind_id(func_kind k)
             return 9;
         case func_kind::time:
             return 10;
+        case func_kind::tan:
+            return 12;
+        case func_kind::tanh:
+            return 13;
+        case func_kind::sinh:
+            return 14;
+        case func_kind::cosh:
+            return 15;
+        case func_kind::erf:
+            return 16;
+        case func_kind::sigmoid:
+            return 17;
+        case func_kind::asin:
+            return 18;
+        case func_kind::acos:
+            return 19;
+        case func_kind::atan:
+            return 20;
+        case func_kind::asinh:
+            return 21;
+        case func_kind::acosh:
+            return 22;
+        case func_kind::atanh:
+            return 23;
         default:
             return 11;
     }

@@ -69,6 +69,20 @@ hy_expr hy_expr_sin(hy_expr);             /* sin()                        src/ma
 hy_expr hy_expr_cos(hy_expr);             /* cos()                        src/math/cos.cpp:406 */
 hy_expr hy_expr_exp(hy_expr);             /* exp()                        src/math/exp.cpp */
 hy_expr hy_expr_log(hy_expr);             /* log()                        src/math/log.cpp */
+/* Elementary functions beyond the N-body set (include/heyoka/math/{tan,tanh,sinh,cosh,asin,acos,atan,asinh,
+ * acosh,atanh,erf,sigmoid}.hpp; Taylor rules src/math/<name>.cpp). */
+hy_expr hy_expr_tan(hy_expr);
+hy_expr hy_expr_tanh(hy_expr);
+hy_expr hy_expr_sinh(hy_expr);
+hy_expr hy_expr_cosh(hy_expr);
+hy_expr hy_expr_asin(hy_expr);
+hy_expr hy_expr_acos(hy_expr);
+hy_expr hy_expr_atan(hy_expr);
+hy_expr hy_expr_asinh(hy_expr);
+hy_expr hy_expr_acosh(hy_expr);
+hy_expr hy_expr_atanh(hy_expr);
+hy_expr hy_expr_erf(hy_expr);
+hy_expr hy_expr_sigmoid(hy_expr);
 hy_expr hy_expr_sum(const hy_expr *, size_t n);  /* sum(vector)           src/math/sum.cpp:548 */
 hy_expr hy_expr_prod(const hy_expr *, size_t n); /* prod(vector)          src/math/prod.cpp:913 */
 void hy_expr_free(hy_expr);

@@ -59,6 +59,18 @@ KIND_IDS = {
     "log": 9,
     "time": 10,
     "num_identity": 11,
+    "tan": 12,
+    "tanh": 13,
+    "sinh": 14,
+    "cosh": 15,
+    "erf": 16,
+    "sigmoid": 17,
+    "asin": 18,
+    "acos": 19,
+    "atan": 20,
+    "asinh": 21,
+    "acosh": 22,
+    "atanh": 23,
 }
 
 OC_SUCCESS = -4294967296 - 1
@@ -256,6 +268,30 @@ def exp(e):
 def log(e):
     e = as_ex(e)
     return num(math.log(e.val)) if e.is_num() else func("log", [e])
+
+
+def _unary(name, ev):
+    def f(e):
+        e = as_ex(e)
+        return num(ev(e.val)) if e.is_num() else func(name, [e])
+
+    f.__name__ = name
+    return f
+
+
+# Elementary functions beyond the N-body set (reference: src/math/{tan,tanh,...}.cpp).
+tan = _unary("tan", math.tan)
+tanh = _unary("tanh", math.tanh)
+sinh = _unary("sinh", math.sinh)
+cosh = _unary("cosh", math.cosh)
+asin = _unary("asin", math.asin)
+acos = _unary("acos", math.acos)
+atan = _unary("atan", math.atan)
+asinh = _unary("asinh", math.asinh)
+acosh = _unary("acosh", math.acosh)
+atanh = _unary("atanh", math.atanh)
+erf = _unary("erf", math.erf)
+sigmoid = _unary("sigmoid", lambda x: 1.0 / (1.0 + math.exp(-x)))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -456,12 +492,41 @@ def taylor_decompose_sys(sys):
             idxs[i] = decomp(e.args[i])
         new_args = [var(_uname(ix)) if ix is not None else a for ix, a in zip(idxs, e.args)]
         f = func(e.kind, new_args)
-        if e.kind in ("sin", "cos"):
-            other = "cos" if e.kind == "sin" else "sin"
-            dc.append((func(other, [new_args[0]]), []))
+        pairs = {"sin": "cos", "cos": "sin", "sinh": "cosh", "cosh": "sinh"}
+        if e.kind in pairs:
+            dc.append((func(pairs[e.kind], [new_args[0]]), []))
             dc.append((f, []))
             dc[-2][1].append(len(dc) - 1)
             dc[-1][1].append(len(dc) - 2)
+            ret = len(dc) - 1
+        elif e.kind in ("tan", "tanh", "sigmoid"):
+            # f(b), then its square on which it depends (src/math/tan.cpp:69-85).
+            dc.append((f, []))
+            ret = len(dc) - 1
+            dc.append((pow_(var(_uname(ret)), num(2.0)), []))
+            dc[ret][1].append(ret + 1)
+        elif e.kind in ("asin", "acos", "asinh", "acosh"):
+            # b^2 -> 1 - b^2 | 1 + b^2 | b^2 - 1 -> sqrt -> f(b) depending on the square root (src/math/asin.cpp:77-108).
+            dc.append((pow_(new_args[0], num(2.0)), []))
+            sq = var(_uname(len(dc) - 1))
+            if e.kind in ("asin", "acos"):
+                dc.append((func("sub", [num(1.0), sq]), []))
+            elif e.kind == "asinh":
+                dc.append((num(1.0) + sq, []))
+            else:
+                dc.append((sq - num(1.0), []))
+            dc.append((sqrt(var(_uname(len(dc) - 1))), []))
+            dc.append((f, [len(dc) - 1]))
+            ret = len(dc) - 1
+        elif e.kind in ("atan", "atanh"):
+            dc.append((pow_(new_args[0], num(2.0)), []))
+            dc.append((f, [len(dc) - 1]))
+            ret = len(dc) - 1
+        elif e.kind == "erf":
+            dc.append((pow_(new_args[0], num(2.0)), []))
+            dc.append((-var(_uname(len(dc) - 1)), []))
+            dc.append((exp(var(_uname(len(dc) - 1))), []))
+            dc.append((f, [len(dc) - 1]))
             ret = len(dc) - 1
         else:
             ret = len(dc)

@@ -50,7 +50,19 @@ enum {
     K_EXP = 8,
     K_LOG = 9,
     K_TIME = 10,
-    K_NUM_IDENTITY = 11
+    K_NUM_IDENTITY = 11,
+    K_TAN = 12,
+    K_TANH = 13,
+    K_SINH = 14,
+    K_COSH = 15,
+    K_ERF = 16,
+    K_SIGMOID = 17,
+    K_ASIN = 18,
+    K_ACOS = 19,
+    K_ATAN = 20,
+    K_ASINH = 21,
+    K_ACOSH = 22,
+    K_ATANH = 23
 };
 
 enum { A_UVAR = 0, A_NUM = 1, A_PAR = 2 };
@@ -123,6 +135,25 @@ static double pow_eval(double b, double ex)
         }
     }
     return pow(b, ex);
+}
+
+/* Order-0 value of the unary functions beyond the N-body set. */
+static double unary0(int kind, double x)
+{
+    switch (kind) {
+        case K_TAN: return tan(x);
+        case K_TANH: return tanh(x);
+        case K_SINH: return sinh(x);
+        case K_COSH: return cosh(x);
+        case K_ERF: return erf(x);
+        case K_SIGMOID: return 1. / (1. + exp(-x));
+        case K_ASIN: return asin(x);
+        case K_ACOS: return acos(x);
+        case K_ATAN: return atan(x);
+        case K_ASINH: return asinh(x);
+        case K_ACOSH: return acosh(x);
+        default: return atanh(x);
+    }
 }
 
 #define TAPE(k, u) (tape + ((size_t)(k) * n_u + (size_t)(u)) * B)
@@ -437,6 +468,88 @@ static void node_diff(const hy_oracle_program *p, int i, int k, double *tape, co
                     for (int l = 0; l < B; ++l) ret[l] = ret[l] - scratch[l];
                 }
                 for (int l = 0; l < B; ++l) out[l] = ret[l] / ((double)k * b0[l]);
+            }
+            break;
+        }
+        case K_TAN:
+        case K_TANH:
+        case K_SINH:
+        case K_COSH:
+        case K_ERF:
+        case K_SIGMOID: {
+            /* Forward rules (src/math/tan.cpp:105-131, tanh.cpp, sinh.cpp, cosh.cpp, erf.cpp, sigmoid.cpp:150-172):
+             * k a^[k] = pairwise_sum_j(j * (X^[k-j] * b^[j])), X = hidden dependency (a - a^2 for the sigmoid). */
+            const int kind = p->kind[i];
+            if (at[0] != A_UVAR) {
+                for (int l = 0; l < B; ++l) out[l] = k == 0 ? unary0(kind, numpar(p, a0, pars, B, l)) : 0.;
+                break;
+            }
+            const int b = ai[0];
+            if (k == 0) {
+                const double *x = TAPE(0, b);
+                for (int l = 0; l < B; ++l) out[l] = unary0(kind, x[l]);
+                break;
+            }
+            const int d = p->dep[i];
+            for (int j = 1; j <= k; ++j) {
+                const double *x = TAPE(k - j, d), *y = TAPE(j, b), *self = TAPE(k - j, u);
+                double *t = scratch + (size_t)(j - 1) * B;
+                for (int l = 0; l < B; ++l) {
+                    const double xv = kind == K_SIGMOID ? (self[l] - x[l]) : x[l];
+                    t[l] = (double)j * (xv * y[l]);
+                }
+            }
+            pairwise_sum(scratch, k, B);
+            {
+                const double *bk = TAPE(k, b);
+                for (int l = 0; l < B; ++l) {
+                    const double acc = scratch[l] / (double)k;
+                    out[l] = kind == K_TAN ? (bk[l] + acc)
+                                           : (kind == K_TANH ? (bk[l] - acc)
+                                                             : (kind == K_ERF ? 1.1283791670955126 * acc : acc));
+                }
+            }
+            break;
+        }
+        case K_ASIN:
+        case K_ACOS:
+        case K_ATAN:
+        case K_ASINH:
+        case K_ACOSH:
+        case K_ATANH: {
+            /* Inverse rules (src/math/asin.cpp:140-178, acos.cpp, atan.cpp:125-164, atanh.cpp, asinh.cpp, acosh.cpp):
+             * a^[k] = (k b^[k] -+ pairwise_sum_{j<k}(j * (c^[k-j] * a^[j]))) / (k D). */
+            const int kind = p->kind[i];
+            if (at[0] != A_UVAR) {
+                for (int l = 0; l < B; ++l) out[l] = k == 0 ? unary0(kind, numpar(p, a0, pars, B, l)) : 0.;
+                break;
+            }
+            const int b = ai[0];
+            if (k == 0) {
+                const double *x = TAPE(0, b);
+                for (int l = 0; l < B; ++l) out[l] = unary0(kind, x[l]);
+                break;
+            }
+            const int d = p->dep[i];
+            const double *c0 = TAPE(0, d), *bk = TAPE(k, b);
+            double *D = scratch + (size_t)(p->order + 2) * B;
+            for (int l = 0; l < B; ++l) {
+                D[l] = kind == K_ACOS ? -c0[l] : (kind == K_ATAN ? (c0[l] + 1.) : (kind == K_ATANH ? (1. - c0[l]) : c0[l]));
+            }
+            if (k == 1) {
+                for (int l = 0; l < B; ++l) out[l] = bk[l] / D[l];
+                break;
+            }
+            for (int j = 1; j < k; ++j) {
+                const double *x = TAPE(k - j, d), *y = TAPE(j, u);
+                double *t = scratch + (size_t)(j - 1) * B;
+                for (int l = 0; l < B; ++l) t[l] = (double)j * (x[l] * y[l]);
+            }
+            pairwise_sum(scratch, k - 1, B);
+            for (int l = 0; l < B; ++l) {
+                double ret = (double)k * bk[l];
+                ret = (kind == K_ACOS || kind == K_ATANH) ? (ret + scratch[l]) : (ret - scratch[l]);
+                out[l] = ret / ((double)k * D[l]);
             }
             break;
         }

@@ -87,6 +87,38 @@ case("exp_log", ["exp(0.1 * y)", "log(x)"], "test/taylor_exp.cpp / taylor_log.cp
      lambda z: [[0, 0.1 * math.exp(0.1 * z[1])], [1 / z[0], 0]],
      lambda z: [[[0, 0], [0, 0.01 * math.exp(0.1 * z[1])]], [[-1 / z[0] ** 2, 0], [0, 0]]])
 
+# 3b. Elementary functions beyond the N-body set (test/taylor_{tan,tanh,sinhcosh,asin,acos,atan,asinh,acosh,
+# atanh,erf,sigmoid}.cpp): x' = f(a*y + c), y' = f(a*x + c).
+def _unary(f, d1, d2, a=0.1, c=0.0):
+    def hess(z):
+        h = Z(2)
+        h[0][1][1] = a * a * d2(a * z[1] + c)
+        h[1][0][0] = a * a * d2(a * z[0] + c)
+        return h
+    return (lambda z: [f(a * z[1] + c), f(a * z[0] + c)],
+            lambda z: [[0, a * d1(a * z[1] + c)], [a * d1(a * z[0] + c), 0]], hess)
+
+
+_sig = lambda x: 1.0 / (1.0 + math.exp(-x))
+_SQPI = 2.0 / math.sqrt(math.pi)
+UNARY = {
+    "tan": (math.tan, lambda x: 1 + math.tan(x) ** 2, lambda x: 2 * math.tan(x) * (1 + math.tan(x) ** 2), 0.1, 0.0),
+    "tanh": (math.tanh, lambda x: 1 - math.tanh(x) ** 2, lambda x: -2 * math.tanh(x) * (1 - math.tanh(x) ** 2), 0.1, 0.0),
+    "sinh": (math.sinh, math.cosh, math.sinh, 0.1, 0.0),
+    "cosh": (math.cosh, math.sinh, math.cosh, 0.1, 0.0),
+    "asin": (math.asin, lambda x: (1 - x * x) ** -0.5, lambda x: x * (1 - x * x) ** -1.5, 0.1, 0.0),
+    "acos": (math.acos, lambda x: -((1 - x * x) ** -0.5), lambda x: -x * (1 - x * x) ** -1.5, 0.1, 0.0),
+    "atan": (math.atan, lambda x: 1 / (1 + x * x), lambda x: -2 * x / (1 + x * x) ** 2, 0.1, 0.0),
+    "asinh": (math.asinh, lambda x: (1 + x * x) ** -0.5, lambda x: -x * (1 + x * x) ** -1.5, 0.1, 0.0),
+    "acosh": (math.acosh, lambda x: (x * x - 1) ** -0.5, lambda x: -x * (x * x - 1) ** -1.5, 1.0, 0.5),
+    "atanh": (math.atanh, lambda x: 1 / (1 - x * x), lambda x: 2 * x / (1 - x * x) ** 2, 0.1, 0.0),
+    "erf": (math.erf, lambda x: _SQPI * math.exp(-x * x), lambda x: -2 * x * _SQPI * math.exp(-x * x), 0.1, 0.0),
+    "sigmoid": (_sig, lambda x: _sig(x) * (1 - _sig(x)), lambda x: _sig(x) * (1 - _sig(x)) * (1 - 2 * _sig(x)), 0.1, 0.0),
+}
+for _n, (_f, _d1, _d2, _a, _c) in UNARY.items():
+    case("unary_" + _n, ["%s(%g*y + %g)" % (_n, _a, _c), "%s(%g*x + %g)" % (_n, _a, _c)],
+         "test/taylor_%s.cpp (closed forms)" % _n, *_unary(_f, _d1, _d2, _a, _c))
+
 # 4. Explicit time dependence (z = (x, y, t), t' = 1; test/taylor_time.cpp).
 case("time", ["time + y", "x * time"], "test/taylor_time.cpp",
      lambda z: [z[2] + z[1], z[0] * z[2], 1.0],

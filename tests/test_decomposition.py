@@ -102,3 +102,20 @@ def test_validate_ode_sys_messages():
         hy.taylor_decompose_sys([(x + v, v), (v, x)])
     with pytest.raises(ValueError, match="at least 2 bodies are needed"):
         hy.model.nbody(1)
+
+
+UNARY = "tan tanh sinh cosh asin acos atan asinh acosh atanh erf sigmoid".split()
+
+
+@pytest.mark.parametrize("fn", UNARY)
+def test_unary_function_decompositions_match_oracle(fn):
+    """Hidden-dependency structures of the functions beyond the N-body set (src/math/tan.cpp:69-85,
+    sinh.cpp:75-93, asin.cpp:77-108, atan.cpp:74-91, erf.cpp:81-105, sigmoid.cpp:102-118)."""
+    x, y = hy.make_vars("x", "y")
+    ox, oy = ho.var("x"), ho.var("y")
+    got = hy.taylor_decompose_sys([(x, getattr(hy, fn)(y) + 0.5 * x), (y, getattr(hy, fn)(0.3 * x) * getattr(hy, fn)(y))])
+    exp = ho.dc_to_strings(ho.taylor_decompose_sys(
+        [(ox, getattr(ho, fn)(oy) + 0.5 * ox), (oy, getattr(ho, fn)(0.3 * ox) * getattr(ho, fn)(oy))]))
+    assert got == exp
+    # Constant folding at construction.
+    assert str(getattr(hy, fn)(hy.expression(0.25) if fn != "acosh" else hy.expression(1.5)))[:1] in "0123456789-"

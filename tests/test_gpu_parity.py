@@ -588,3 +588,34 @@ def test_cfunc_values_and_device_side_energy_monitor():
     assert rel_err(e0, configs.nbody_energy(st, masses, G)) <= 16 * EPS
     assert np.max(np.abs((e1 - e0) / e0)) <= 100 * EPS
     assert rel_err(e1, configs.nbody_energy(ta.state, masses, G)) <= 16 * EPS
+
+
+@pytest.mark.parametrize("fn", "tan tanh sinh cosh asin acos atan asinh acosh atanh erf sigmoid".split())
+def test_unary_functions_full_order_step_parity(fn):
+    """Order-20 recurrences of the elementary functions beyond the N-body set: one full step and a short
+    propagation of a coupled system vs the oracle (the order <= 3 coefficients are pinned by closed forms in
+    tests/test_node_jets.py)."""
+    n = 37
+    rng = np.random.RandomState(sum(map(ord, fn)))
+    lo, hi = (1.2, 1.8) if fn == "acosh" else (-0.6, 0.6)
+    st = np.stack([rng.uniform(lo, hi, n), rng.uniform(lo, hi, n)])
+    x, y = hy.make_vars("x", "y")
+    ox, oy = ho.var("x"), ho.var("y")
+    c = 1.5 if fn == "acosh" else 0.0
+    # Damped coupling keeps the arguments inside the domains of asin/acos/atanh/acosh.
+    sys_p = [(x, 0.3 * getattr(hy, fn)(y) - 0.4 * (x - c)), (y, -0.3 * getattr(hy, fn)(x) * hy.cos(y) - 0.4 * (y - c))]
+    sys_o = [(ox, 0.3 * getattr(ho, fn)(oy) - 0.4 * (ox - c)), (oy, -0.3 * getattr(ho, fn)(ox) * ho.cos(oy) - 0.4 * (oy - c))]
+    ta = hy.taylor_adaptive_batch(sys_p, st, n)
+    ora = ho.OracleIntegrator(sys_o, st, n)
+    ta.step(write_tc=True)
+    ora.step(wtc=True)
+    h_g = np.array([h for _, h in ta.step_res])
+    h_o = np.array([h for _, h in ora.step_res])
+    assert np.max(np.abs(h_g - h_o) / np.abs(h_o)) <= 1e6 * EPS
+    tc_o = ora.tc.reshape(2, ora.order + 1, n)
+    scale = np.max(np.abs(tc_o), axis=2, keepdims=True) + 1e-300
+    assert np.max(np.abs(np.asarray(ta.tc).reshape(2, 21, n) - tc_o) / scale) <= 1e6 * EPS
+    assert rel_err(ta.state, ora.state.reshape(2, n)) <= 1e5 * EPS
+    ta.propagate_until(0.8)
+    ora.propagate_until(0.8)
+    assert rel_err(ta.state, ora.state.reshape(2, n)) <= 1e6 * EPS

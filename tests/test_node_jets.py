@@ -26,6 +26,11 @@ def build(m, name):
         x, y = m.make_vars("x", "y")
         t, P = m.time, lambda i: m.par[i]
         powf, sqrt = m.pow, m.sqrt
+    if name.startswith("unary_"):
+        fn = name[len("unary_"):]
+        a, c = (1.0, 0.5) if fn == "acosh" else (0.1, 0.0)
+        f = getattr(m, fn)
+        return [(x, f(a * y + c) if c else f(a * y)), (y, f(a * x + c) if c else f(a * x))]
     rhs = {
         "pow_3_2__m1_3": (powf(y, 1.5), powf(x, -1.0 / 3.0)),
         "pow_par_exponents": (powf(y, P(0)), powf(x, P(1))),
