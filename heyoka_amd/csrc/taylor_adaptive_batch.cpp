@@ -14,6 +14,7 @@
 #include "dfloat.hpp"
 #include "hip_backend.hpp"
 #include "hip_emit.hpp"
+#include "hip_emit_detail.hpp"
 
 namespace heyoka_amd::detail
 {
@@ -89,6 +90,8 @@ struct tab_core::impl {
     mutable std::optional<taylor_outcome> prop_res_override;
     // Continuous output produced by the last propagate_for/until() with c_output = true.
     std::optional<c_out_core> last_c_out;
+    // Post-step kernel of the device-resident propagate_grid() loop (created on first use).
+    mutable std::unique_ptr<aux_module> grid_mod;
 
     [[nodiscard]] bool is_cluster() const
     {
@@ -206,10 +209,17 @@ struct tab_core::impl {
     }
 
     // One lock-step sweep: a single step for every lane with the per-lane signed limits 'lims'.
+    // NOTE: lims == nullptr -> the step limits are already in d_lim (device-driven loops).
     void run_step(const std::vector<double> &lims, bool wtc)
     {
+        run_step_impl(&lims, wtc);
+    }
+    void run_step_impl(const std::vector<double> *lims, bool wtc)
+    {
         before_kernel();
-        d_lim.upload(lims.data(), lims.size() * sizeof(double), stream);
+        if (lims != nullptr) {
+            d_lim.upload(lims->data(), lims->size() * sizeof(double), stream);
+        }
         d_counters.zero(stream);
         auto a = base_args();
         if (wtc && is_cluster()) {
@@ -966,6 +976,219 @@ std::optional<c_out_core> tab_core::take_c_output()
     return ret;
 }
 
+namespace
+{
+
+struct grid_kargs {
+    const double *grid;
+    double *out;
+    const double *tc;
+    const double *thi;
+    const double *tlo;
+    const double *last_h;
+    const long long *outcome;
+    double *rem_hi;
+    double *rem_lo;
+    const double *mdt;
+    const int *t_dir;
+    double *lim;
+    unsigned *gidx;
+    double *min_h;
+    double *max_h;
+    unsigned long long *n_steps;
+    unsigned *counters;
+    unsigned long long N;
+    unsigned n_grid;
+};
+
+// Post-step kernel of the device-resident propagate_grid() loop: the per-lane body of the reference's loop
+// (src/taylor_adaptive_batch.cpp:1760-2040) - step counters, remaining time, dense output at every grid
+// point inside the step just taken (h' = t_grid - (t_now - last_h) in double-length arithmetic, Horner or
+// compensated summation as in taylor_add_d_out_function()), limit of the next step.
+std::string make_grid_source(std::uint32_t order, std::uint32_t dim, bool ha)
+{
+    std::ostringstream src;
+    src << emit_detail::prelude;
+    src << "#define HY_ORDER " << order << "u\n#define HY_DIM " << dim << "u\n#define HY_HA " << (ha ? 1 : 0) << "\n";
+    src << R"HIP(
+struct hy_grid_args {
+    const double *grid;
+    double *out;
+    const double *tc;
+    const double *thi;
+    const double *tlo;
+    const double *last_h;
+    const i64 *outcome;
+    double *rem_hi;
+    double *rem_lo;
+    const double *mdt;
+    const int *t_dir;
+    double *lim;
+    unsigned *gidx;
+    double *min_h;
+    double *max_h;
+    u64 *n_steps;
+    unsigned *counters;
+    u64 N;
+    unsigned n_grid;
+};
+
+extern "C" __global__ void __launch_bounds__(256) hy_grid_post(const hy_grid_args a)
+{
+    const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+    const u64 N = a.N;
+    if (i >= N) return;
+    const i64 oc = a.outcome[i];
+    const double h = a.last_h[i];
+    if (oc == HY_OC_ERR_NF_STATE) {
+        atomicAdd(a.counters + 1, 1u);
+        return;
+    }
+    a.n_steps[i] += (h != 0.0) ? 1u : 0u;
+    if (oc == HY_OC_SUCCESS) {
+        const double ah = fabs(h);
+        a.min_h[i] = hy_min(a.min_h[i], ah);
+        a.max_h[i] = hy_max(a.max_h[i], ah);
+    }
+    hy_df tcur; tcur.hi = a.thi[i]; tcur.lo = a.tlo[i];
+    hy_df rem; rem.hi = a.rem_hi[i]; rem.lo = a.rem_lo[i];
+    const unsigned ng = a.n_grid;
+    if (h == rem.hi) {
+        rem.hi = 0.0; rem.lo = 0.0;
+    } else {
+        hy_df tl; tl.hi = a.grid[(u64)(ng - 1u) * N + i]; tl.lo = 0.0;
+        rem = hy_df_sub(tl, tcur);
+    }
+    a.rem_hi[i] = rem.hi; a.rem_lo[i] = rem.lo;
+    // Time interval covered by the step, and the start of the step for the dense output.
+    hy_df hh; hh.hi = h; hh.lo = 0.0;
+    const hy_df tstart = hy_df_sub(tcur, hh);
+    const bool fwd = !hy_df_lt(tcur, tstart);
+    const hy_df t0 = fwd ? tstart : tcur, t1 = fwd ? tcur : tstart;
+    const bool done_lane = (rem.hi == 0.0 && rem.lo == 0.0);
+    unsigned g = a.gidx[i];
+    while (g < ng) {
+        hy_df tg; tg.hi = a.grid[(u64)g * N + i]; tg.lo = 0.0;
+        const bool avail = (!hy_df_lt(tg, t0) && !hy_df_lt(t1, tg)) || done_lane;
+        if (!avail) break;
+        const double hd = hy_df_sub(tg, tstart).hi;
+        for (unsigned v = 0; v < HY_DIM; ++v) {
+            const double *c = a.tc + (u64)v * (HY_ORDER + 1u) * N + i;
+#if HY_HA
+            double res = c[0], comp = 0.0, cur_h = hd;
+            for (unsigned k = 1; k <= HY_ORDER; ++k) {
+                const double tmp = c[(u64)k * N] * cur_h;
+                const double y = tmp - comp;
+                const double t = res + y;
+                comp = (t - res) - y;
+                res = t;
+                cur_h = cur_h * hd;
+            }
+#else
+            double res = c[(u64)HY_ORDER * N];
+            for (unsigned k = 1; k <= HY_ORDER; ++k) {
+                res = c[(u64)(HY_ORDER - k) * N] + res * hd;
+            }
+#endif
+            a.out[((u64)g * HY_DIM + v) * N + i] = res;
+        }
+        ++g;
+    }
+    a.gidx[i] = g;
+    // Limit of the next step.
+    hy_df m; m.lo = 0.0;
+    double lim;
+    if (a.t_dir[i] != 0) { m.hi = a.mdt[i]; lim = hy_df_lt(rem, m) ? rem.hi : m.hi; }
+    else { m.hi = -a.mdt[i]; lim = hy_df_lt(m, rem) ? rem.hi : m.hi; }
+    a.lim[i] = lim;
+    if (g < ng) atomicAdd(a.counters, 1u);
+}
+)HIP";
+    return src.str();
+}
+
+} // namespace
+
+void tab_core::propagate_grid_device_loop(const std::vector<double> &grid, std::vector<double> &retval,
+                                          const std::vector<dfloat> &rem, const std::vector<int> &t_dir,
+                                          const std::vector<double> &max_delta_ts, std::size_t max_steps)
+{
+    auto &d = *m_impl;
+    const auto N = d.N;
+    const auto dim = d.dim;
+    const auto n_grid = static_cast<std::uint32_t>(grid.size() / N);
+    const auto pinf = std::numeric_limits<double>::infinity();
+    const auto dsz = sizeof(double);
+
+    d.ensure_device();
+    d.ensure_tc();
+    if (!d.grid_mod) {
+        d.grid_mod = std::make_unique<aux_module>(hiprtc_compile_source(make_grid_source(d.order, dim, d.high_accuracy)),
+                                                  d.device);
+    }
+
+    device_buffer b_grid(grid.size() * dsz, d.device), b_out(retval.size() * dsz, d.device);
+    device_buffer b_rem_hi(N * dsz, d.device), b_rem_lo(N * dsz, d.device), b_mdt(N * dsz, d.device);
+    device_buffer b_tdir(N * sizeof(int), d.device), b_gidx(N * sizeof(unsigned), d.device), b_cnt(4u * sizeof(unsigned), d.device);
+    b_grid.upload(grid.data(), grid.size() * dsz, d.stream);
+    // Row 0 = current state, everything else NaN until reached.
+    b_out.upload(retval.data(), retval.size() * dsz, d.stream);
+    std::vector<double> rhi(N), rlo(N), lim(N), mn(N, pinf), mx(N, 0.);
+    std::vector<unsigned> gidx(N, 1u);
+    std::vector<unsigned long long> ns(N, 0u);
+    for (std::uint32_t i = 0; i < N; ++i) {
+        rhi[i] = rem[i].hi;
+        rlo[i] = rem[i].lo;
+        const auto dt_limit
+            = t_dir[i] != 0 ? std::min(dfloat(max_delta_ts[i]), rem[i]) : std::max(dfloat(-max_delta_ts[i]), rem[i]);
+        lim[i] = static_cast<double>(dt_limit);
+    }
+    b_rem_hi.upload(rhi.data(), N * dsz, d.stream);
+    b_rem_lo.upload(rlo.data(), N * dsz, d.stream);
+    b_mdt.upload(max_delta_ts.data(), N * dsz, d.stream);
+    b_tdir.upload(t_dir.data(), N * sizeof(int), d.stream);
+    b_gidx.upload(gidx.data(), N * sizeof(unsigned), d.stream);
+    d.d_lim.upload(lim.data(), N * dsz, d.stream);
+    d.d_minh.upload(mn.data(), N * dsz, d.stream);
+    d.d_maxh.upload(mx.data(), N * dsz, d.stream);
+    d.d_nsteps.upload(ns.data(), N * sizeof(unsigned long long), d.stream);
+
+    d.prop_res_override.reset();
+    std::size_t iter_counter = 0;
+    bool any_step = false;
+    while (n_grid > 1u) {
+        d.run_step_impl(nullptr, true);
+        any_step = true;
+        b_cnt.zero(d.stream);
+        const grid_kargs a{b_grid.as<double>(),    b_out.as<double>(),     d.d_tc.as<double>(),   d.d_thi.as<double>(),
+                           d.d_tlo.as<double>(),   d.d_lasth.as<double>(), d.d_outcome.as<long long>(),
+                           b_rem_hi.as<double>(),  b_rem_lo.as<double>(),  b_mdt.as<double>(),    b_tdir.as<int>(),
+                           d.d_lim.as<double>(),   b_gidx.as<unsigned>(),  d.d_minh.as<double>(), d.d_maxh.as<double>(),
+                           d.d_nsteps.as<unsigned long long>(), b_cnt.as<unsigned>(), N, n_grid};
+        d.grid_mod->launch("hy_grid_post", N, 256, &a, sizeof(a), d.stream);
+        unsigned cnt[2] = {0, 0};
+        b_cnt.download(cnt, sizeof(cnt), d.stream);
+        if (cnt[1] != 0u) {
+            // A non-finite state was detected: stop (the outcomes of the last step are reported).
+            break;
+        }
+        ++iter_counter;
+        if (cnt[0] == 0u) {
+            break;
+        }
+        if (iter_counter == max_steps) {
+            d.prop_res_override = taylor_outcome::step_limit;
+            break;
+        }
+    }
+    if (any_step) {
+        // Outcomes of the last sweep + the accumulated statistics live on the device.
+        d.prop_res_dev_newer = true;
+        d.step_res_dev_newer = true;
+    }
+    b_out.download(retval.data(), retval.size() * dsz, d.stream);
+}
+
 // Reference: propagate_grid_impl(), src/taylor_adaptive_batch.cpp:1546-2055. Host-driven lock-step loop:
 // single-step kernel launches (always with the Taylor coefficients) interleaved with dense-output launches.
 // grid[point * N + lane]; return value ret[(point * dim + var) * N + lane], NaN where not reached.
@@ -1079,6 +1302,14 @@ std::vector<double> tab_core::propagate_grid(std::vector<double> grid, std::size
                                         "integrator in batch mode results in an overflow condition");
         }
         t_dir[i] = rem[i] >= dfloat(0.);
+    }
+
+    if (!cb && std::getenv("HEYOKA_AMD_GRID_HOST_LOOP") == nullptr) {
+        // Device-resident lock-step loop: the step kernel and a post-step kernel (bookkeeping of the reference's
+        // loop, dense output at the grid points covered by the step, next step limit) alternate without any
+        // per-lane host work; the host only reads two counters per sweep.
+        propagate_grid_device_loop(grid, retval, rem, t_dir, max_delta_ts, max_steps);
+        return retval;
     }
     std::size_t iter_counter = 0;
     std::vector<std::size_t> ts_count(N, 0), cur_grid_idx(N, 1);

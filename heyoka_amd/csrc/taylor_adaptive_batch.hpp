@@ -21,6 +21,7 @@
 
 #include "continuous_output.hpp"
 #include "decompose.hpp"
+#include "dfloat.hpp"
 #include "expression.hpp"
 #include "kw.hpp"
 
@@ -120,6 +121,10 @@ public:
                        const std::vector<double> &max_delta_ts, const cb_t &cb, bool wtc, bool c_out);
     std::vector<double> propagate_grid(std::vector<double> grid, std::size_t max_steps,
                                        const std::vector<double> &max_delta_ts, const cb_t &cb);
+    // Device-resident loop of propagate_grid() (no callback): see taylor_adaptive_batch.cpp.
+    void propagate_grid_device_loop(const std::vector<double> &grid, std::vector<double> &retval,
+                                    const std::vector<dfloat> &rem, const std::vector<int> &t_dir,
+                                    const std::vector<double> &max_delta_ts, std::size_t max_steps);
     // The continuous output recorded by the last propagate_for/until() invoked with c_out = true
     // (empty if no step was taken); the object is moved out.
     std::optional<c_out_core> take_c_output();

@@ -619,3 +619,38 @@ def test_unary_functions_full_order_step_parity(fn):
     ta.propagate_until(0.8)
     ora.propagate_until(0.8)
     assert rel_err(ta.state, ora.state.reshape(2, n)) <= 1e6 * EPS
+
+
+def test_propagate_grid_device_loop_equals_host_loop():
+    """The device-resident propagate_grid() loop (step kernel + post-step kernel, no per-lane host work) gives
+    the same samples, states and propagate_res as the host-driven transcription of the reference's loop
+    (HEYOKA_AMD_GRID_HOST_LOOP=1), forward and backward, with max_delta_t and max_steps."""
+    import os
+
+    n = 300
+    st = configs.outer_ss_state(n, perturb=1e-6, seed=9)
+    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    grid = np.outer(np.linspace(0.0, 30.0, 13), np.ones(n)) * (1.0 + 0.01 * np.arange(n) / n)
+    res = {}
+    for name in ("device", "host"):
+        if name == "host":
+            os.environ["HEYOKA_AMD_GRID_HOST_LOOP"] = "1"
+        try:
+            ta = hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True)
+            _, out = ta.propagate_grid(grid, max_delta_t=3.0)
+            pr1 = ta.propagate_res
+            _, out_b = ta.propagate_grid(grid[::-1].copy())
+            pr2 = ta.propagate_res
+            tb = hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True)
+            _, out_c = tb.propagate_grid(grid, max_steps=3)
+            res[name] = (out, pr1, out_b, pr2, ta.state.copy(), out_c, tb.propagate_res)
+        finally:
+            os.environ.pop("HEYOKA_AMD_GRID_HOST_LOOP", None)
+    d, h = res["device"], res["host"]
+    assert np.array_equal(d[0], h[0]) and np.array_equal(d[2], h[2]) and np.array_equal(d[4], h[4])
+    assert d[1] == h[1] and d[3] == h[3] and d[6] == h[6]
+    assert np.array_equal(np.isnan(d[5]), np.isnan(h[5])) and np.array_equal(np.nan_to_num(d[5]), np.nan_to_num(h[5]))
+    assert all(r[0] == OC.step_limit for r in d[6]) and np.isnan(d[5][-1]).all()
+    assert all(r[0] == OC.time_limit for r in d[1]) and not np.isnan(d[0]).any()
+    # Back at the start after the backward grid: energy-level agreement with the initial state.
+    assert rel_err(d[4], st) <= 1e-9
