@@ -814,6 +814,20 @@ class taylor_adaptive_batch:
         raise_for(rc)
         return callback, out
 
+    def propagate_grid_device(self, grid, out_ptr, max_steps=0, max_delta_t=None):
+        """propagate_grid() with the samples written to a caller-owned device buffer (``out_ptr``: device address of
+        n_grid * dim * batch_size doubles, layout [point, var, lane]); ``grid``: 1-D (shared by all the lanes) or
+        (n_grid, batch_size). Nothing of that size is materialised on the host."""
+        g = np.ascontiguousarray(_f64(grid))
+        scalar = g.ndim == 1
+        if max_delta_t is None:
+            mptr, mn, mkeep = None, 0, None
+        else:
+            mkeep = _f64(max_delta_t).reshape(-1)
+            mptr, mn = mkeep.ctypes.data, mkeep.size
+        raise_for(lib.hy_tab_propagate_grid_device(self._h, g.ctypes.data, g.shape[0], int(scalar), int(max_steps),
+                                                   mptr, mn, ctypes.c_void_p(int(out_ptr))))
+
     @property
     def propagate_res(self):
         n = self.batch_size

@@ -135,6 +135,7 @@ SIGNATURES = [
         c_int,
         [c_void_p, c_void_p, c_size_t, c_uint64, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p],
     ),
+    ("hy_tab_propagate_grid_device", c_int, [c_void_p, c_void_p, c_size_t, c_int, c_uint64, c_void_p, c_size_t, c_void_p]),
     ("hy_tab_get_propagate_res", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("hy_model_nbody_ex", c_void_p, [c_uint32, c_void_p, c_size_t, c_void_p]),
     ("hy_model_nbody_energy", c_void_p, [c_uint32, c_void_p, c_size_t, c_void_p]),

@@ -803,6 +803,26 @@ int hy_tab_propagate_grid(hy_tab t, const double *grid, size_t n_grid, uint64_t 
         std::memcpy(out, ret.data(), ret.size() * sizeof(double));
     });
 }
+int hy_tab_propagate_grid_device(hy_tab t, const double *grid, size_t n_grid, int scalar_grid, uint64_t max_steps,
+                                 const double *mdts, size_t n_mdt, double *d_out)
+{
+    return guarded([&] {
+        const auto bs = t->core.get_batch_size();
+        std::vector<double> g;
+        if (scalar_grid != 0) {
+            g.reserve(n_grid * bs);
+            for (size_t k = 0; k < n_grid; ++k) {
+                g.insert(g.end(), bs, grid[k]);
+            }
+        } else {
+            g = vec_from(grid, n_grid * bs);
+        }
+        if (d_out == nullptr) {
+            throw std::invalid_argument("hy_tab_propagate_grid_device(): the device output pointer is null");
+        }
+        t->core.propagate_grid(std::move(g), static_cast<std::size_t>(max_steps), expand_mdt(mdts, n_mdt, bs), {}, d_out);
+    });
+}
 int hy_tab_get_propagate_res(hy_tab t, int64_t *outcome, double *min_h, double *max_h, uint64_t *n_steps)
 {
     return guarded([&] {

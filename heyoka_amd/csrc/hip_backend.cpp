@@ -375,6 +375,15 @@ void device_copy(void *dst, const void *src, std::size_t bytes, int device, void
     hip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, static_cast<hipStream_t>(stream)), "hipMemcpyAsync");
 }
 
+void device_fill_bytes(void *dst, int value, std::size_t bytes, int device, void *stream)
+{
+    if (bytes == 0u) {
+        return;
+    }
+    hip_check(hipSetDevice(device), "hipSetDevice");
+    hip_check(hipMemsetAsync(dst, value, bytes, static_cast<hipStream_t>(stream)), "hipMemsetAsync");
+}
+
 void stream_synchronize(int device, void *stream)
 {
     hip_check(hipSetDevice(device), "hipSetDevice");

@@ -81,6 +81,7 @@ std::shared_ptr<const compiled_module> hiprtc_compile_source(const std::string &
 // Device-to-device / host copies on a stream + stream synchronisation, for code that does not include HIP headers.
 void device_copy(void *dst, const void *src, std::size_t bytes, int device, void *stream);
 void stream_synchronize(int device, void *stream);
+void device_fill_bytes(void *dst, int value, std::size_t bytes, int device, void *stream);
 
 // Thin RAII device buffer.
 class device_buffer

@@ -1111,7 +1111,8 @@ extern "C" __global__ void __launch_bounds__(256) hy_grid_post(const hy_grid_arg
 
 void tab_core::propagate_grid_device_loop(const std::vector<double> &grid, std::vector<double> &retval,
                                           const std::vector<dfloat> &rem, const std::vector<int> &t_dir,
-                                          const std::vector<double> &max_delta_ts, std::size_t max_steps)
+                                          const std::vector<double> &max_delta_ts, std::size_t max_steps,
+                                          double *d_out)
 {
     auto &d = *m_impl;
     const auto N = d.N;
@@ -1127,12 +1128,21 @@ void tab_core::propagate_grid_device_loop(const std::vector<double> &grid, std::
                                                   d.device);
     }
 
-    device_buffer b_grid(grid.size() * dsz, d.device), b_out(retval.size() * dsz, d.device);
+    const auto out_doubles = grid.size() * dim;
+    device_buffer b_grid(grid.size() * dsz, d.device), b_out(d_out != nullptr ? 0u : out_doubles * dsz, d.device);
+    double *const out_ptr = d_out != nullptr ? d_out : b_out.as<double>();
     device_buffer b_rem_hi(N * dsz, d.device), b_rem_lo(N * dsz, d.device), b_mdt(N * dsz, d.device);
     device_buffer b_tdir(N * sizeof(int), d.device), b_gidx(N * sizeof(unsigned), d.device), b_cnt(4u * sizeof(unsigned), d.device);
     b_grid.upload(grid.data(), grid.size() * dsz, d.stream);
     // Row 0 = current state, everything else NaN until reached.
-    b_out.upload(retval.data(), retval.size() * dsz, d.stream);
+    if (d_out == nullptr) {
+        b_out.upload(retval.data(), retval.size() * dsz, d.stream);
+    } else {
+        // NOTE: the all-ones byte pattern is a (quiet) NaN.
+        device_fill_bytes(out_ptr, 0xFF, out_doubles * dsz, d.device, d.stream);
+        d.to_device();
+        device_copy(out_ptr, d.d_state.get(), static_cast<std::size_t>(dim) * N * dsz, d.device, d.stream);
+    }
     std::vector<double> rhi(N), rlo(N), lim(N), mn(N, pinf), mx(N, 0.);
     std::vector<unsigned> gidx(N, 1u);
     std::vector<unsigned long long> ns(N, 0u);
@@ -1160,7 +1170,7 @@ void tab_core::propagate_grid_device_loop(const std::vector<double> &grid, std::
         d.run_step_impl(nullptr, true);
         any_step = true;
         b_cnt.zero(d.stream);
-        const grid_kargs a{b_grid.as<double>(),    b_out.as<double>(),     d.d_tc.as<double>(),   d.d_thi.as<double>(),
+        const grid_kargs a{b_grid.as<double>(),    out_ptr,     d.d_tc.as<double>(),   d.d_thi.as<double>(),
                            d.d_tlo.as<double>(),   d.d_lasth.as<double>(), d.d_outcome.as<long long>(),
                            b_rem_hi.as<double>(),  b_rem_lo.as<double>(),  b_mdt.as<double>(),    b_tdir.as<int>(),
                            d.d_lim.as<double>(),   b_gidx.as<unsigned>(),  d.d_minh.as<double>(), d.d_maxh.as<double>(),
@@ -1186,14 +1196,18 @@ void tab_core::propagate_grid_device_loop(const std::vector<double> &grid, std::
         d.prop_res_dev_newer = true;
         d.step_res_dev_newer = true;
     }
-    b_out.download(retval.data(), retval.size() * dsz, d.stream);
+    if (d_out == nullptr) {
+        b_out.download(retval.data(), retval.size() * dsz, d.stream);
+    } else {
+        stream_synchronize(d.device, d.stream);
+    }
 }
 
 // Reference: propagate_grid_impl(), src/taylor_adaptive_batch.cpp:1546-2055. Host-driven lock-step loop:
 // single-step kernel launches (always with the Taylor coefficients) interleaved with dense-output launches.
 // grid[point * N + lane]; return value ret[(point * dim + var) * N + lane], NaN where not reached.
 std::vector<double> tab_core::propagate_grid(std::vector<double> grid, std::size_t max_steps,
-                                             const std::vector<double> &max_delta_ts_, const cb_t &cb)
+                                             const std::vector<double> &max_delta_ts_, const cb_t &cb, double *d_out)
 {
     auto &d = *m_impl;
     const auto N = d.N;
@@ -1274,7 +1288,12 @@ std::vector<double> tab_core::propagate_grid(std::vector<double> grid, std::size
         }
     }
 
-    std::vector<double> retval(grid.size() * dim, std::numeric_limits<double>::quiet_NaN());
+    // NOTE: with a caller-provided device output (MI355X extension, no callback) nothing of size n_grid * dim * N
+    // is ever materialised on the host: the samples go straight to d_out and an empty vector is returned.
+    if (d_out != nullptr && cb) {
+        throw std::invalid_argument("propagate_grid() with a device output buffer does not support callbacks");
+    }
+    std::vector<double> retval(d_out != nullptr ? 0u : grid.size() * dim, std::numeric_limits<double>::quiet_NaN());
     std::vector<double> pgrid_tmp(gp, gp + N);
 
     // Propagate up to the first grid point (absorbs the low part of the double-length time).
@@ -1290,8 +1309,12 @@ std::vector<double> tab_core::propagate_grid(std::vector<double> grid, std::size
         }
         return retval;
     }
-    d.to_host();
-    std::copy(d.state.begin(), d.state.end(), retval.begin());
+    if (d_out == nullptr) {
+        d.to_host();
+        std::copy(d.state.begin(), d.state.end(), retval.begin());
+    } else {
+        d.times_to_host();
+    }
 
     std::vector<dfloat> rem(N), t0(N), t1(N);
     std::vector<int> t_dir(N);
@@ -1304,11 +1327,11 @@ std::vector<double> tab_core::propagate_grid(std::vector<double> grid, std::size
         t_dir[i] = rem[i] >= dfloat(0.);
     }
 
-    if (!cb && std::getenv("HEYOKA_AMD_GRID_HOST_LOOP") == nullptr) {
+    if (d_out != nullptr || (!cb && std::getenv("HEYOKA_AMD_GRID_HOST_LOOP") == nullptr)) {
         // Device-resident lock-step loop: the step kernel and a post-step kernel (bookkeeping of the reference's
         // loop, dense output at the grid points covered by the step, next step limit) alternate without any
         // per-lane host work; the host only reads two counters per sweep.
-        propagate_grid_device_loop(grid, retval, rem, t_dir, max_delta_ts, max_steps);
+        propagate_grid_device_loop(grid, retval, rem, t_dir, max_delta_ts, max_steps, d_out);
         return retval;
     }
     std::size_t iter_counter = 0;

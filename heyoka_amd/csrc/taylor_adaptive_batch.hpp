@@ -120,11 +120,13 @@ public:
     void propagate_for(const std::vector<double> &delta_ts, std::size_t max_steps,
                        const std::vector<double> &max_delta_ts, const cb_t &cb, bool wtc, bool c_out);
     std::vector<double> propagate_grid(std::vector<double> grid, std::size_t max_steps,
-                                       const std::vector<double> &max_delta_ts, const cb_t &cb);
+                                       const std::vector<double> &max_delta_ts, const cb_t &cb,
+                                       double *d_out = nullptr);
     // Device-resident loop of propagate_grid() (no callback): see taylor_adaptive_batch.cpp.
     void propagate_grid_device_loop(const std::vector<double> &grid, std::vector<double> &retval,
                                     const std::vector<dfloat> &rem, const std::vector<int> &t_dir,
-                                    const std::vector<double> &max_delta_ts, std::size_t max_steps);
+                                    const std::vector<double> &max_delta_ts, std::size_t max_steps,
+                                    double *d_out = nullptr);
     // The continuous output recorded by the last propagate_for/until() invoked with c_out = true
     // (empty if no step was taken); the object is moved out.
     std::optional<c_out_core> take_c_output();

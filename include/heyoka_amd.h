@@ -231,6 +231,12 @@ char *hy_cout_to_string(hy_cout);
  * out: n_grid * n_eq * batch_size values (NaN where not reached). */
 int hy_tab_propagate_grid(hy_tab, const double *grid, size_t n_grid, uint64_t max_steps, const double *max_delta_ts,
                           size_t n_mdt, hy_step_callback cb, void *cb_data, double *out);
+/* MI355X extension of propagate_grid() for ensemble-scale batches: the n_grid * n_eq * batch_size samples are
+ * written to a caller-owned device buffer d_out (same layout as above) instead of a host vector; no callback.
+ * scalar_grid != 0: grid holds n_grid values used by every lane (the splat of ensemble_propagate_grid_batch(),
+ * src/ensemble_propagate.cpp:266-273), otherwise n_grid * batch_size values. */
+int hy_tab_propagate_grid_device(hy_tab, const double *grid, size_t n_grid, int scalar_grid, uint64_t max_steps,
+                                 const double *max_delta_ts, size_t n_mdt, double *d_out);
 /* get_propagate_res(): (outcome, min |h|, max |h|, n_steps) per lane. */
 int hy_tab_get_propagate_res(hy_tab, int64_t *outcome, double *min_h, double *max_h, uint64_t *n_steps);
 

@@ -654,3 +654,20 @@ def test_propagate_grid_device_loop_equals_host_loop():
     assert all(r[0] == OC.time_limit for r in d[1]) and not np.isnan(d[0]).any()
     # Back at the start after the backward grid: energy-level agreement with the initial state.
     assert rel_err(d[4], st) <= 1e-9
+
+
+def test_propagate_grid_device_output():
+    """hy_tab_propagate_grid_device(): samples written straight to a caller-owned device buffer."""
+    import torch
+
+    n = 128
+    st = configs.two_body_state(n, perturb=1e-3, seed=4)
+    grid = np.linspace(0.0, 6.0, 9)
+    ta = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), st, n)
+    _, ref = ta.propagate_grid(grid)
+    tb = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), st, n)
+    d_out = torch.empty((9, 12, n), dtype=torch.float64, device="cuda")
+    tb.propagate_grid_device(grid, d_out.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out.cpu().numpy(), ref)
+    assert tb.propagate_res == ta.propagate_res and np.array_equal(tb.state, ta.state)
