@@ -11,6 +11,7 @@ CPU fallback in this package.
 
 import ctypes
 import enum
+import weakref
 
 import numpy as np
 
@@ -47,6 +48,9 @@ __all__ = [
     "model",
     "taylor_outcome",
     "taylor_adaptive_batch",
+    "event_direction",
+    "nt_event",
+    "t_event",
     "taylor_decompose_sys",
     "ensemble_propagate_until_batch",
     "ensemble_propagate_for_batch",
@@ -529,6 +533,37 @@ class continuous_output_batch:
         return _lib.take_str(lib.hy_cout_to_string(self._h))
 
 
+class event_direction(enum.IntEnum):
+    """heyoka::event_direction (include/heyoka/events.hpp)."""
+
+    negative = -1
+    any = 0
+    positive = 1
+
+
+class nt_event:
+    """nt_event_batch<double> (include/heyoka/events.hpp): ``callback(ta, time, d_sgn, batch_idx)``."""
+
+    def __init__(self, eq, callback, direction=event_direction.any):
+        if callback is None:
+            raise ValueError("Cannot construct a non-terminal event with an empty callback")
+        self.eq, self.callback, self.direction = _as_ex(eq), callback, event_direction(direction)
+
+
+class t_event:
+    """t_event_batch<double> (include/heyoka/events.hpp): ``callback(ta, d_sgn, batch_idx) -> bool`` (False stops the
+    propagation; no callback: always stop); ``cooldown < 0``: deduced automatically."""
+
+    def __init__(self, eq, callback=None, direction=event_direction.any, cooldown=-1.0):
+        self.eq, self.callback, self.direction = _as_ex(eq), callback, event_direction(direction)
+        self.cooldown = float(cooldown)
+
+
+# Integrator objects by handle address: the C callbacks receive the handle of the integrator they run on (which may
+# be a copy of the one the events were defined for).
+_TAB_REGISTRY = weakref.WeakValueDictionary()
+
+
 class taylor_adaptive_batch:
     """taylor_adaptive_batch<double> (include/heyoka/taylor.hpp:781-1121) on MI355X.
 
@@ -538,15 +573,19 @@ class taylor_adaptive_batch:
     """
 
     def __init__(self, sys, state=None, batch_size=None, *, tol=None, high_accuracy=False, compact_mode=False,
-                 parallel_mode=False, pars=None, time=None, device=0, _handle=None, **ignored_llvm_kwargs):
+                 parallel_mode=False, pars=None, time=None, device=0, t_events=(), nt_events=(), _handle=None,
+                 _events=None, **ignored_llvm_kwargs):
         # LLVM-only keyword arguments of the reference (opt_level, fast_math, force_avx512,
         # slp_vectorize, code_model, parjit) are accepted and ignored.
         for k in ignored_llvm_kwargs:
             if k not in ("opt_level", "fast_math", "force_avx512", "slp_vectorize", "code_model", "parjit", "mname"):
                 raise TypeError("unexpected keyword argument '%s'" % k)
+        self._cb_errors = []
         if _handle is not None:
             self._h = _handle
             self._sys = sys
+            self._events = _events
+            _TAB_REGISTRY[int(self._h)] = self
             return
         self._sys = _to_sys(sys)
         if state is None:
@@ -579,10 +618,80 @@ class taylor_adaptive_batch:
         cfg.device = int(device)
         if tol is not None and float(tol) == 0.0:
             cfg.tol = 0.0
-        self._h = check_handle(
-            lib.hy_tab_create(self._sys._h, st.ctypes.data if st.size else None, st.size, int(batch_size),
-                              ctypes.byref(cfg))
-        )
+        t_events, nt_events = list(t_events), list(nt_events)
+        self._events = None
+        if t_events or nt_events:
+            # C trampolines: look the Python integrator up by handle, record exceptions (re-raised after the C call).
+            def make_nt(ev):
+                def tramp(handle, tm, d_sgn, idx, _user):
+                    ta = _TAB_REGISTRY.get(int(handle))
+                    try:
+                        ev.callback(ta, float(tm), int(d_sgn), int(idx))
+                    except BaseException as e:
+                        if ta is not None:
+                            ta._cb_errors.append(e)
+                return _lib.NT_EVENT_CB(tramp)
+
+            def make_t(ev):
+                if ev.callback is None:
+                    return ctypes.cast(None, _lib.T_EVENT_CB)
+
+                def tramp(handle, d_sgn, idx, _user):
+                    ta = _TAB_REGISTRY.get(int(handle))
+                    try:
+                        return 1 if ev.callback(ta, int(d_sgn), int(idx)) else 0
+                    except BaseException as e:
+                        if ta is not None:
+                            ta._cb_errors.append(e)
+                        return 0
+                return _lib.T_EVENT_CB(tramp)
+
+            te_arr = (_lib.TEvent * max(len(t_events), 1))()
+            nte_arr = (_lib.NtEvent * max(len(nt_events), 1))()
+            cbs = []
+            for k, ev in enumerate(t_events):
+                cb = make_t(ev)
+                cbs.append(cb)
+                te_arr[k] = _lib.TEvent(ev.eq._h, cb, None, int(ev.direction), ev.cooldown)
+            for k, ev in enumerate(nt_events):
+                cb = make_nt(ev)
+                cbs.append(cb)
+                nte_arr[k] = _lib.NtEvent(ev.eq._h, cb, None, int(ev.direction))
+            self._events = (t_events, nt_events, cbs)
+            self._h = check_handle(
+                lib.hy_tab_create_with_events(self._sys._h, st.ctypes.data if st.size else None, st.size,
+                                              int(batch_size), ctypes.byref(cfg), te_arr, len(t_events), nte_arr,
+                                              len(nt_events)))
+        else:
+            self._h = check_handle(
+                lib.hy_tab_create(self._sys._h, st.ctypes.data if st.size else None, st.size, int(batch_size),
+                                  ctypes.byref(cfg))
+            )
+        _TAB_REGISTRY[int(self._h)] = self
+
+    def _raise_cb_errors(self):
+        if self._cb_errors:
+            e = self._cb_errors[0]
+            self._cb_errors = []
+            raise e
+
+    @property
+    def with_events(self):
+        return bool(lib.hy_tab_with_events(self._h))
+
+    def reset_cooldowns(self, batch_idx=None):
+        raise_for(lib.hy_tab_reset_cooldowns(self._h, -1 if batch_idx is None else int(batch_idx)))
+
+    @property
+    def te_cooldowns(self):
+        """Per lane, per terminal event: None or (elapsed, duration)."""
+        n_te = len(self._events[0]) if self._events else 0
+        n = self.batch_size
+        first, second = np.zeros(max(n * n_te, 1)), np.zeros(max(n * n_te, 1))
+        active = np.zeros(max(n * n_te, 1), dtype=np.int32)
+        raise_for(lib.hy_tab_get_te_cooldowns(self._h, first.ctypes.data, second.ctypes.data, active.ctypes.data))
+        return [[(float(first[i * n_te + e]), float(second[i * n_te + e])) if active[i * n_te + e] else None
+                 for e in range(n_te)] for i in range(n)]
 
     def __del__(self, _free=lib.hy_tab_free):
         h = getattr(self, "_h", None)
@@ -591,7 +700,7 @@ class taylor_adaptive_batch:
             self._h = None
 
     def __copy__(self):
-        return taylor_adaptive_batch(self._sys, _handle=check_handle(lib.hy_tab_copy(self._h)))
+        return taylor_adaptive_batch(self._sys, _handle=check_handle(lib.hy_tab_copy(self._h)), _events=self._events)
 
     def __deepcopy__(self, memo):
         return self.__copy__()
@@ -725,13 +834,19 @@ class taylor_adaptive_batch:
     # ---- stepping ----
     def step(self, max_delta_t=None, write_tc=False):
         if max_delta_t is None:
-            raise_for(lib.hy_tab_step(self._h, int(bool(write_tc))))
+            rc = lib.hy_tab_step(self._h, int(bool(write_tc)))
+            self._raise_cb_errors()
+            raise_for(rc)
         else:
             m = _f64(max_delta_t).reshape(-1)
-            raise_for(lib.hy_tab_step_limited(self._h, m.ctypes.data, m.size, int(bool(write_tc))))
+            rc = lib.hy_tab_step_limited(self._h, m.ctypes.data, m.size, int(bool(write_tc)))
+            self._raise_cb_errors()
+            raise_for(rc)
 
     def step_backward(self, write_tc=False):
-        raise_for(lib.hy_tab_step_backward(self._h, int(bool(write_tc))))
+        rc = lib.hy_tab_step_backward(self._h, int(bool(write_tc)))
+        self._raise_cb_errors()
+        raise_for(rc)
 
     @property
     def step_res(self):
@@ -766,6 +881,7 @@ class taylor_adaptive_batch:
                 int(bool(c_output)))
         if err:
             raise err[0]
+        self._raise_cb_errors()
         raise_for(rc)
         c_out = None
         if c_output:
@@ -811,6 +927,7 @@ class taylor_adaptive_batch:
                                        out.ctypes.data)
         if err:
             raise err[0]
+        self._raise_cb_errors()
         raise_for(rc)
         return callback, out
 

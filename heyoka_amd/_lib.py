@@ -44,6 +44,21 @@ class TabConfig(ctypes.Structure):
 
 
 STEP_CALLBACK = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p)
+NT_EVENT_CB = ctypes.CFUNCTYPE(None, c_void_p, c_double, c_int, c_uint32, c_void_p)
+T_EVENT_CB = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, c_uint32, c_void_p)
+
+
+class NtEvent(ctypes.Structure):
+    """hy_nt_event (include/heyoka_amd.h)."""
+
+    _fields_ = [("eq", c_void_p), ("cb", NT_EVENT_CB), ("user", c_void_p), ("direction", c_int)]
+
+
+class TEvent(ctypes.Structure):
+    """hy_t_event (include/heyoka_amd.h)."""
+
+    _fields_ = [("eq", c_void_p), ("cb", T_EVENT_CB), ("user", c_void_p), ("direction", c_int), ("cooldown", c_double)]
+
 ENSEMBLE_GEN = ctypes.CFUNCTYPE(c_int, c_void_p, c_size_t, c_void_p)
 
 # (name, restype, argtypes): every symbol declared in include/heyoka_amd.h.
@@ -92,6 +107,11 @@ SIGNATURES = [
     ("hy_model_pendulum", c_void_p, [c_double, c_double]),
     ("hy_sys_decomposition_str", c_void_p, [c_void_p]),
     ("hy_tab_create", c_void_p, [c_void_p, c_void_p, c_size_t, c_uint32, c_void_p]),
+    ("hy_tab_create_with_events", c_void_p,
+     [c_void_p, c_void_p, c_size_t, c_uint32, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t]),
+    ("hy_tab_with_events", c_int, [c_void_p]),
+    ("hy_tab_reset_cooldowns", c_int, [c_void_p, ctypes.c_int64]),
+    ("hy_tab_get_te_cooldowns", c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     ("hy_tab_copy", c_void_p, [c_void_p]),
     ("hy_tab_free", None, [c_void_p]),
     ("hy_tab_get_batch_size", c_uint32, [c_void_p]),

@@ -430,8 +430,41 @@ char *hy_sys_decomposition_str(hy_sys s)
 // ---- integrator ----
 hy_tab hy_tab_create(hy_sys sys, const double *state, size_t n_state, uint32_t batch_size, const hy_tab_config *cfg)
 {
+    return hy_tab_create_with_events(sys, state, n_state, batch_size, cfg, nullptr, 0, nullptr, 0);
+}
+hy_tab hy_tab_create_with_events(hy_sys sys, const double *state, size_t n_state, uint32_t batch_size,
+                                 const hy_tab_config *cfg, const hy_t_event *tes, size_t n_tes, const hy_nt_event *ntes,
+                                 size_t n_ntes)
+{
     try {
         detail::tab_core::config c;
+        for (size_t i = 0; i < n_tes; ++i) {
+            detail::core_t_event e;
+            e.eq = tes[i].eq->ex;
+            e.dir = static_cast<event_direction>(tes[i].direction);
+            e.cooldown = tes[i].cooldown;
+            if (tes[i].cb != nullptr) {
+                const auto cb = tes[i].cb;
+                auto *const user = tes[i].user;
+                e.callback = [cb, user](void *ctx, int d_sgn, std::uint32_t idx) {
+                    return cb(static_cast<hy_tab>(ctx), d_sgn, idx, user) != 0;
+                };
+            }
+            c.t_events.push_back(std::move(e));
+        }
+        for (size_t i = 0; i < n_ntes; ++i) {
+            detail::core_nt_event e;
+            e.eq = ntes[i].eq->ex;
+            e.dir = static_cast<event_direction>(ntes[i].direction);
+            if (ntes[i].cb != nullptr) {
+                const auto cb = ntes[i].cb;
+                auto *const user = ntes[i].user;
+                e.callback = [cb, user](void *ctx, double tm, int d_sgn, std::uint32_t idx) {
+                    cb(static_cast<hy_tab>(ctx), tm, d_sgn, idx, user);
+                };
+            }
+            c.nt_events.push_back(std::move(e));
+        }
         if (cfg != nullptr) {
             if (cfg->tol != 0) {
                 c.tol = cfg->tol;
@@ -444,16 +477,49 @@ hy_tab hy_tab_create(hy_sys sys, const double *state, size_t n_state, uint32_t b
             c.time_is_scalar = (cfg->n_time == 1u && batch_size != 1u) || (cfg->n_time == 1u);
             c.device = cfg->device;
         }
-        return new hy_tab_s{detail::tab_core(sys->sys, vec_from(state, n_state), batch_size, std::move(c))};
+        auto *ret = new hy_tab_s{detail::tab_core(sys->sys, vec_from(state, n_state), batch_size, std::move(c))};
+        // The event callbacks receive the handle itself.
+        ret->core.set_callback_context(ret);
+        return ret;
     } catch (...) {
         handle_exception();
         return nullptr;
     }
 }
+int hy_tab_with_events(hy_tab t)
+{
+    return t->core.with_events() ? 1 : 0;
+}
+int hy_tab_reset_cooldowns(hy_tab t, int64_t batch_idx)
+{
+    return guarded([&] {
+        if (batch_idx < 0) {
+            t->core.reset_cooldowns();
+        } else {
+            t->core.reset_cooldowns(static_cast<std::uint32_t>(batch_idx));
+        }
+    });
+}
+int hy_tab_get_te_cooldowns(hy_tab t, double *first, double *second, int *active)
+{
+    return guarded([&] {
+        const auto &cds = t->core.get_te_cooldowns();
+        for (std::size_t i = 0; i < cds.size(); ++i) {
+            for (std::size_t e = 0; e < cds[i].size(); ++e) {
+                const auto k = i * cds[i].size() + e;
+                active[k] = cds[i][e] ? 1 : 0;
+                first[k] = cds[i][e] ? cds[i][e]->first : 0.;
+                second[k] = cds[i][e] ? cds[i][e]->second : 0.;
+            }
+        }
+    });
+}
 hy_tab hy_tab_copy(hy_tab t)
 {
     try {
-        return new hy_tab_s{detail::tab_core(t->core)};
+        auto *ret = new hy_tab_s{detail::tab_core(t->core)};
+        ret->core.set_callback_context(ret);
+        return ret;
     } catch (...) {
         handle_exception();
         return nullptr;

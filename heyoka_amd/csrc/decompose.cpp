@@ -557,7 +557,18 @@ void validate_ode_sys(const std::vector<std::pair<expression, expression>> &sys)
 
 taylor_dc_t taylor_decompose_sys(const std::vector<std::pair<expression, expression>> &sys)
 {
+    std::vector<std::uint32_t> dummy;
+    return taylor_decompose_sys(sys, {}, dummy);
+}
+
+// Reference: taylor_decompose_sys(sys, sv_funcs), src/taylor_01.cpp:848-1008. The extra functions are decomposed
+// after the right-hand sides; here they ride along as additional trailing entries through CSE and sorting (which
+// renumber them) and are stripped at the end.
+taylor_dc_t taylor_decompose_sys(const std::vector<std::pair<expression, expression>> &sys,
+                                 const std::vector<expression> &sv_funcs, std::vector<std::uint32_t> &sv_funcs_dc)
+{
     const auto n_eq = sys.size();
+    const auto n_sv = sv_funcs.size();
 
     std::unordered_map<std::string, std::string> repl_map;
     for (std::size_t i = 0; i < n_eq; ++i) {
@@ -569,6 +580,7 @@ taylor_dc_t taylor_decompose_sys(const std::vector<std::pair<expression, express
     for (const auto &[lhs, rhs] : sys) {
         all_ex.push_back(rhs);
     }
+    all_ex.insert(all_ex.end(), sv_funcs.begin(), sv_funcs.end());
 
     all_ex = pow_to_explog(all_ex);
     all_ex = sum_to_sub(all_ex);
@@ -598,10 +610,27 @@ taylor_dc_t taylor_decompose_sys(const std::vector<std::pair<expression, express
         }
     }
 
+    for (std::size_t i = n_eq; i < all_ex.size(); ++i) {
+        const auto &ex = all_ex[i];
+        if (ex.is_variable()) {
+            outs.emplace_back(ex, std::vector<std::uint32_t>{});
+        } else if (const auto dres = taylor_decompose(func_map, ex, u_vars_defs)) {
+            outs.emplace_back(expression{uname(*dres)}, std::vector<std::uint32_t>{});
+        } else {
+            throw std::invalid_argument("The extra functions in a Taylor decomposition cannot be constants or parameters");
+        }
+    }
+
     u_vars_defs.insert(u_vars_defs.end(), outs.begin(), outs.end());
 
-    u_vars_defs = taylor_decompose_cse(u_vars_defs, n_eq, n_eq);
-    u_vars_defs = taylor_sort_dc(u_vars_defs, n_eq, n_eq);
+    u_vars_defs = taylor_decompose_cse(u_vars_defs, n_eq, n_eq + n_sv);
+    u_vars_defs = taylor_sort_dc(u_vars_defs, n_eq, n_eq + n_sv);
+
+    sv_funcs_dc.clear();
+    for (std::size_t i = u_vars_defs.size() - n_sv; i < u_vars_defs.size(); ++i) {
+        sv_funcs_dc.push_back(uname_to_index(u_vars_defs[i].first.var_name()));
+    }
+    u_vars_defs.resize(u_vars_defs.size() - n_sv);
 
     // NOTE: sincos_combine_taylor() (src/detail/sincos_combine.cpp) only selects a fused
     // sin+cos evaluation at order 0: it does not change the structure of the decomposition. The

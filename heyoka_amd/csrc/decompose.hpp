@@ -23,6 +23,10 @@ namespace heyoka_amd
 using taylor_dc_t = std::vector<std::pair<expression, std::vector<std::uint32_t>>>;
 
 taylor_dc_t taylor_decompose_sys(const std::vector<std::pair<expression, expression>> &sys);
+// With extra functions of the state (e.g. event equations): sv_funcs_dc receives the index of the u variable holding
+// each of them (reference: src/taylor_01.cpp:848-1008, second return value).
+taylor_dc_t taylor_decompose_sys(const std::vector<std::pair<expression, expression>> &sys,
+                                 const std::vector<expression> &sv_funcs, std::vector<std::uint32_t> &sv_funcs_dc);
 
 // Decomposition of a vector function of the variables `vars` (reference: function_decompose(),
 // src/expression_cfunc.cpp:723-900): vars.size() leading entries, fn.size() trailing definitions.
@@ -57,6 +61,8 @@ struct taylor_program {
     std::vector<dc_node> nodes;
     // sv_defs[i] = definition of the time derivative of state variable i.
     std::vector<operand> sv_defs;
+    // u variables holding the event equations (terminal events first), empty if no events.
+    std::vector<std::uint32_t> ev_u;
 };
 
 // NOTE: n_outs = number of trailing definitions (defaults to n_eq, i.e. a Taylor decomposition).

@@ -1,0 +1,78 @@
+// Event detection for the batch integrator.
+//
+// Reference: include/heyoka/events.hpp (t_event_batch / nt_event_batch), src/detail/event_detection.cpp
+// (ed_data_batch<T>::detect_events(), :1733-2173), src/taylor_adaptive_batch.cpp:727-1030 (the event branch of
+// step_impl()). The reference detects events on the host, one batch lane after the other, with JIT-compiled
+// helpers for the polynomial translations. Here the detection runs on the device, one lane per system:
+// fast exclusion check (interval Horner enclosure), Collins-Akritas root isolation with Descartes' rule on
+// the translated polynomials, bracketed root finding, direction filter and terminal-event cooldowns; the
+// (few) detected events are then copied to the host, which runs the reference's sequential logic (ordering,
+// step truncation at the first terminal event, callbacks, cooldown bookkeeping, outcomes).
+#pragma once
+
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <optional>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "expression.hpp"
+
+namespace heyoka_amd
+{
+
+enum class event_direction : int { negative = -1, any = 0, positive = 1 };
+
+namespace detail
+{
+
+// Type-erased events as stored in the integrator core. ctx is the address of the user-facing integrator object
+// (taylor_adaptive_batch<double> *, or the C handle), supplied at call time.
+struct core_nt_event {
+    expression eq;
+    std::function<void(void *ctx, double time, int d_sgn, std::uint32_t batch_idx)> callback;
+    event_direction dir = event_direction::any;
+};
+
+struct core_t_event {
+    expression eq;
+    std::function<bool(void *ctx, int d_sgn, std::uint32_t batch_idx)> callback; // empty -> always stop
+    event_direction dir = event_direction::any;
+    double cooldown = -1; // < 0: deduced automatically (taylor_deduce_cooldown())
+};
+
+// One detected event of a lane: (event index, root (time from the beginning of the step), sign of the time
+// derivative of the event equation, absolute value of the derivative).
+struct detected_event {
+    std::uint32_t idx;
+    double root;
+    int d_sgn;
+    double abs_der;
+};
+
+// HIP source of the detection kernel for a given Taylor order.
+std::string make_event_detection_source(std::uint32_t order);
+
+// Maximum number of events of one class (terminal / non-terminal) recorded per lane and step.
+inline constexpr std::uint32_t max_detected_per_lane = 16;
+
+struct ed_kargs {
+    const double *ev_tc;      // [(event * (order + 1) + k) * N + lane], terminal events first
+    const double *h;          // [N] step taken
+    const double *g_eps;      // [N]
+    const int *dirs;          // [n_te + n_nte]
+    const double *cd_first;   // [n_te * N] terminal-event cooldowns (valid if cd_active != 0)
+    const double *cd_second;  // [n_te * N]
+    const int *cd_active;     // [n_te * N]
+    double *out;              // [2][N][max_detected][4]: idx, root, d_sgn, abs_der
+    unsigned *counts;         // [2][N]
+    unsigned *flags;          // [0] = number of lanes whose list overflowed / whose isolation failed
+    unsigned long long N;
+    unsigned n_te, n_nte;
+};
+
+} // namespace detail
+
+} // namespace heyoka_amd

@@ -62,6 +62,8 @@ struct hy_kargs {
     unsigned int *counters;
     double *scratch;
     double tfin_s_hi, tfin_s_lo;
+    double *ev_tc;
+    double *max_abs_state;
 };
 
 #define HY_OC_SUCCESS (-4294967296LL - 1)

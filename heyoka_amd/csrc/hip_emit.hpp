@@ -33,11 +33,15 @@ struct hy_kargs {
     double *tc;               // [n_eq * (order + 1) * N] jet scratch == Taylor coefficients output
     unsigned long long N;     // number of systems
     unsigned long long max_steps; // propagate mode: 0 = unlimited
-    int mode;                 // 0 = single step, 1 = propagate_until
+    int mode;                 // 0 = single step, 1 = propagate_until, 2 = raw step, 4 = step with events
     int pad;
     unsigned int *counters;   // [16] device counters: [0] lanes with non-finite state, [1] work-queue head
     double *scratch;          // cluster mode: jet scratch, scratch_per_wave doubles per resident wave
     double tfin_s_hi, tfin_s_lo; // propagate mode, scalar final time (used when tfin_hi == nullptr)
+    // mode 4 (stepper with events, no state update): Taylor coefficients of the event equations
+    // [(event * (order + 1) + k) * N + system] and max_i |x_i| per system.
+    double *ev_tc;
+    double *max_abs_state;
 };
 
 enum class emit_mode { unrolled, cluster, table, block };

@@ -418,6 +418,11 @@ extern "C" __global__ void __launch_bounds__(256, 4) hy_taylor(const hy_kargs a)
                 hy_nodes_order(c, k);
             }
             hy_sv_order(c, HY_ORDER);
+#if HY_N_EV > 0
+            // The event equations need the order-p coefficients of the u variables as well
+            // (src/taylor_02.cpp:1016-1190).
+            hy_nodes_order(c, HY_ORDER);
+#endif
 
             // Step size (taylor_determine_h(), compact-mode reduction order, src/taylor_00.cpp:154-167).
             double m0 = fabs(hy_tp(c, 0, 0)), mo = fabs(hy_tp(c, HY_ORDER, 0)), mom1 = fabs(hy_tp(c, HY_ORDER - 1u, 0));
@@ -438,6 +443,20 @@ extern "C" __global__ void __launch_bounds__(256, 4) hy_taylor(const hy_kargs a)
                 for (unsigned i = 0; i < HY_N_EQ; ++i)
                     for (unsigned k = 0; k <= HY_ORDER; ++k)
                         a.tc[((u64)i * (HY_ORDER + 1u) + k) * N + s] = hy_tp(c, k, i);
+            }
+
+            if (a.mode == 4) {
+                // Stepper with events (taylor_add_adaptive_step_with_events(), src/taylor_00.cpp:592-710): jets of the
+                // event equations, max |x_i| and the step size; the state is updated later, by the dense-output
+                // kernel, at the (possibly truncated) step decided by the event-detection logic.
+#if HY_N_EV > 0
+                for (unsigned e = 0; e < HY_N_EV; ++e)
+                    for (unsigned k = 0; k <= HY_ORDER; ++k)
+                        a.ev_tc[((u64)e * (HY_ORDER + 1u) + k) * N + s] = hy_tp(c, k, hy_ev_u[e]);
+#endif
+                a.max_abs_state[s] = m0;
+                last_h = h;
+                break;
             }
 
             bool nf = false;
@@ -489,6 +508,10 @@ extern "C" __global__ void __launch_bounds__(256, 4) hy_taylor(const hy_kargs a)
             }
             ++iter;
             if (iter == a.max_steps) { outcome = HY_OC_STEP_LIMIT; break; }
+        }
+        if (a.mode == 4) {
+            a.last_h[s] = last_h;
+            continue;
         }
         for (unsigned i = 0; i < HY_N_EQ; ++i) a.state[(u64)i * N + s] = hy_tp(c, 0, i);
         if (a.mode != 2) {
@@ -572,7 +595,13 @@ emitted_module emit_table(const taylor_program &p, const emit_options &opts)
 
     src << "#define HY_N_EQ " << p.n_eq << "u\n#define HY_N_U " << p.n_u << "u\n#define HY_N_NODES " << p.nodes.size()
         << "u\n#define HY_ORDER " << opts.order << "u\n#define HY_HIGH_ACCURACY " << (opts.high_accuracy ? 1 : 0)
-        << "\n#define HY_RHOFAC " << fp_literal(emit_detail::rhofac(opts.order)) << "\n";
+        << "\n#define HY_RHOFAC " << fp_literal(emit_detail::rhofac(opts.order)) << "\n#define HY_N_EV " << p.ev_u.size()
+        << "\n";
+    src << "__device__ const unsigned hy_ev_u[] = {";
+    for (const auto u : p.ev_u) {
+        src << u << ",";
+    }
+    src << "0};\n";
 
     std::ostringstream kind, off, at, ai, av, dep;
     std::size_t n_args = 0;

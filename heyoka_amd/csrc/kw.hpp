@@ -65,6 +65,9 @@ HEYOKA_AMD_KWARG(max_delta_t);
 HEYOKA_AMD_KWARG(callback);
 HEYOKA_AMD_KWARG(write_tc);
 HEYOKA_AMD_KWARG(c_output);
+// Events (reference: include/heyoka/events.hpp:87-100).
+HEYOKA_AMD_KWARG(direction);
+HEYOKA_AMD_KWARG(cooldown);
 // Models.
 HEYOKA_AMD_KWARG(masses);
 HEYOKA_AMD_KWARG(Gconst);

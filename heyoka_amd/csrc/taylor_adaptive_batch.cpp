@@ -93,6 +93,34 @@ struct tab_core::impl {
     // Post-step kernel of the device-resident propagate_grid() loop (created on first use).
     mutable std::unique_ptr<aux_module> grid_mod;
 
+    // ---- event detection (see event_detection.hpp) ----
+    std::vector<core_t_event> tes;
+    std::vector<core_nt_event> ntes;
+    // te_cooldowns[lane][event]: (time elapsed since the trigger, cooldown duration).
+    std::vector<std::vector<std::optional<std::pair<double, double>>>> te_cooldowns;
+    void *cb_ctx = nullptr;
+    mutable std::unique_ptr<aux_module> ed_mod;
+    mutable device_buffer d_ev_tc, d_mas, d_geps, d_dirs, d_cd_first, d_cd_second, d_cd_active, d_ed_out, d_ed_counts,
+        d_ed_flags;
+    std::uint64_t ed_failures = 0;
+
+    [[nodiscard]] bool has_events() const
+    {
+        return !tes.empty() || !ntes.empty();
+    }
+    void step_with_events(const std::vector<double> &lims, bool wtc);
+    // One lock-step sweep for the propagate_*() loops: afterwards step_res and the times are on the host.
+    void lockstep_sweep(const std::vector<double> &lims, bool wtc)
+    {
+        if (has_events()) {
+            step_with_events(lims, wtc);
+        } else {
+            run_step(lims, wtc);
+            fetch_step_res();
+            times_to_host();
+        }
+    }
+
     [[nodiscard]] bool is_cluster() const
     {
         // NOTE: true whenever the stepper does not need the tc buffer as its jet scratch (cluster / table
@@ -334,9 +362,37 @@ tab_core::tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_siz
     d.dim = static_cast<std::uint32_t>(sys.size());
     d.state = std::move(state);
 
-    // Decomposition + flattened program.
-    d.dc = taylor_decompose_sys(sys);
-    d.prog = make_program(d.dc, d.dim);
+    // Decomposition + flattened program (with the event equations as extra functions, terminal events first,
+    // reference: src/taylor_adaptive_batch.cpp:280-330).
+    d.tes = std::move(cfg.t_events);
+    d.ntes = std::move(cfg.nt_events);
+    if (d.has_events()) {
+        for (const auto &ev : d.tes) {
+            if (!std::isfinite(ev.cooldown)) {
+                throw std::invalid_argument("Cannot set a non-finite cooldown value for a terminal event");
+            }
+        }
+        for (const auto &ev : d.ntes) {
+            if (!ev.callback) {
+                throw std::invalid_argument("Cannot construct a non-terminal event with an empty callback");
+            }
+        }
+        std::vector<expression> ev_eqs;
+        for (const auto &ev : d.tes) {
+            ev_eqs.push_back(ev.eq);
+        }
+        for (const auto &ev : d.ntes) {
+            ev_eqs.push_back(ev.eq);
+        }
+        std::vector<std::uint32_t> ev_u;
+        d.dc = taylor_decompose_sys(sys, ev_eqs, ev_u);
+        d.prog = make_program(d.dc, d.dim);
+        d.prog.ev_u = std::move(ev_u);
+        d.te_cooldowns.assign(d.N, std::vector<std::optional<std::pair<double, double>>>(d.tes.size()));
+    } else {
+        d.dc = taylor_decompose_sys(sys);
+        d.prog = make_program(d.dc, d.dim);
+    }
 
     // Parameters.
     const auto tot_n_pars = d.prog.n_par;
@@ -366,7 +422,8 @@ tab_core::tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_siz
     emit_options eo;
     eo.order = d.order;
     eo.high_accuracy = d.high_accuracy;
-    eo.mode = choose_mode();
+    // NOTE: the stepper with events (mode 4) is implemented by the table-driven kernel.
+    eo.mode = d.has_events() ? emit_mode::table : choose_mode();
     d.emitted = emit_hip_module(d.prog, eo);
     d.cmod = hiprtc_compile(d.emitted);
 
@@ -418,6 +475,9 @@ tab_core::tab_core(const tab_core &o) : m_impl(std::make_unique<impl>())
     d.prop_res = s.prop_res;
     d.stream = s.stream;
     d.last_total_steps = s.last_total_steps;
+    d.tes = s.tes;
+    d.ntes = s.ntes;
+    d.te_cooldowns = s.te_cooldowns;
     d.host_newer = true;
 }
 
@@ -671,15 +731,314 @@ const std::vector<std::tuple<taylor_outcome, double, double, std::size_t>> &tab_
     return d.prop_res;
 }
 
+// ---- events ----
+bool tab_core::with_events() const
+{
+    return m_impl->has_events();
+}
+const std::vector<core_t_event> &tab_core::get_t_events() const
+{
+    if (!m_impl->has_events()) {
+        throw std::invalid_argument("No events were defined for this integrator");
+    }
+    return m_impl->tes;
+}
+const std::vector<core_nt_event> &tab_core::get_nt_events() const
+{
+    if (!m_impl->has_events()) {
+        throw std::invalid_argument("No events were defined for this integrator");
+    }
+    return m_impl->ntes;
+}
+const std::vector<std::vector<std::optional<std::pair<double, double>>>> &tab_core::get_te_cooldowns() const
+{
+    if (!m_impl->has_events()) {
+        throw std::invalid_argument("No events were defined for this integrator");
+    }
+    return m_impl->te_cooldowns;
+}
+void tab_core::reset_cooldowns()
+{
+    for (std::uint32_t i = 0; i < m_impl->N; ++i) {
+        reset_cooldowns(i);
+    }
+}
+void tab_core::reset_cooldowns(std::uint32_t i)
+{
+    if (!m_impl->has_events()) {
+        throw std::invalid_argument("No events were defined for this integrator");
+    }
+    if (i >= m_impl->N) {
+        throw std::invalid_argument("Cannot reset the cooldowns at batch index " + std::to_string(i)
+                                    + ": the batch size for this integrator is only " + std::to_string(m_impl->N));
+    }
+    for (auto &cd : m_impl->te_cooldowns[i]) {
+        cd.reset();
+    }
+}
+void tab_core::set_callback_context(void *ctx)
+{
+    m_impl->cb_ctx = ctx;
+}
+
+// One step with event detection: the event branch of step_impl(), src/taylor_adaptive_batch.cpp:727-1030.
+// Device: stepper with events (jets of the state and of the event equations, step size, no state update), event
+// detection kernel, dense-output kernel for the state update at the (possibly truncated) step. Host: the
+// reference's sequential per-lane logic on the few detected events.
+void tab_core::impl::step_with_events(const std::vector<double> &lims, bool wtc)
+{
+    (void)wtc; // The Taylor coefficients are always written by the stepper with events (:756-757).
+    const auto n = static_cast<std::size_t>(N);
+    const auto dsz = sizeof(double);
+    const auto n_te = static_cast<std::uint32_t>(tes.size()), n_nte = static_cast<std::uint32_t>(ntes.size());
+    const auto n_ev = n_te + n_nte;
+    constexpr auto maxd = max_detected_per_lane;
+
+    before_kernel();
+    ensure_tc();
+    if (d_ev_tc.bytes() == 0u) {
+        d_ev_tc = device_buffer(static_cast<std::size_t>(n_ev) * (order + 1u) * n * dsz, device);
+        d_mas = device_buffer(n * dsz, device);
+        d_geps = device_buffer(n * dsz, device);
+        d_dirs = device_buffer(std::max<std::size_t>(n_ev, 1u) * sizeof(int), device);
+        const auto ncd = std::max<std::size_t>(n_te, 1u) * n;
+        d_cd_first = device_buffer(ncd * dsz, device);
+        d_cd_second = device_buffer(ncd * dsz, device);
+        d_cd_active = device_buffer(ncd * sizeof(int), device);
+        d_ed_out = device_buffer(2u * n * maxd * 4u * dsz, device);
+        d_ed_counts = device_buffer(2u * n * sizeof(unsigned), device);
+        d_ed_flags = device_buffer(4u * sizeof(unsigned), device);
+        std::vector<int> dirs;
+        for (const auto &ev : tes) {
+            dirs.push_back(static_cast<int>(ev.dir));
+        }
+        for (const auto &ev : ntes) {
+            dirs.push_back(static_cast<int>(ev.dir));
+        }
+        d_dirs.upload(dirs.data(), dirs.size() * sizeof(int), stream);
+        ed_mod = std::make_unique<aux_module>(hiprtc_compile_source(make_event_detection_source(order)), device);
+    }
+
+    // 1. Stepper with events.
+    d_lim.upload(lims.data(), n * dsz, stream);
+    d_counters.zero(stream);
+    auto a = base_args();
+    a.tc = d_tc.as<double>();
+    a.ev_tc = d_ev_tc.as<double>();
+    a.max_abs_state = d_mas.as<double>();
+    a.mode = 4;
+    dmod->launch_taylor(a);
+
+    // 2. Maximum error on the Taylor series of the event equations (:744-767).
+    std::vector<double> mas(n), g_eps(n), hs(n);
+    d_mas.download(mas.data(), n * dsz, stream);
+    d_lasth.download(hs.data(), n * dsz, stream);
+    constexpr auto eps = std::numeric_limits<double>::epsilon();
+    for (std::size_t i = 0; i < n; ++i) {
+        if (std::isfinite(mas[i])) {
+            const auto max_r_size = (mas[i] < 1) ? tol : (tol * mas[i]);
+            g_eps[i] = (max_r_size < eps * mas[i]) ? (eps * mas[i]) : max_r_size;
+        } else {
+            g_eps[i] = std::numeric_limits<double>::infinity();
+        }
+    }
+    d_geps.upload(g_eps.data(), n * dsz, stream);
+
+    // 3. Event detection on the device.
+    if (n_te != 0u) {
+        std::vector<double> cf(static_cast<std::size_t>(n_te) * n, 0.), cs(static_cast<std::size_t>(n_te) * n, 0.);
+        std::vector<int> ca(static_cast<std::size_t>(n_te) * n, 0);
+        for (std::size_t i = 0; i < n; ++i) {
+            for (std::uint32_t e = 0; e < n_te; ++e) {
+                if (const auto &cd = te_cooldowns[i][e]) {
+                    cf[e * n + i] = cd->first;
+                    cs[e * n + i] = cd->second;
+                    ca[e * n + i] = 1;
+                }
+            }
+        }
+        d_cd_first.upload(cf.data(), cf.size() * dsz, stream);
+        d_cd_second.upload(cs.data(), cs.size() * dsz, stream);
+        d_cd_active.upload(ca.data(), ca.size() * sizeof(int), stream);
+    }
+    d_ed_flags.zero(stream);
+    const ed_kargs ea{d_ev_tc.as<double>(),   d_lasth.as<double>(),     d_geps.as<double>(),     d_dirs.as<int>(),
+                      d_cd_first.as<double>(), d_cd_second.as<double>(), d_cd_active.as<int>(),   d_ed_out.as<double>(),
+                      d_ed_counts.as<unsigned>(), d_ed_flags.as<unsigned>(), N, n_te, n_nte};
+    ed_mod->launch("hy_detect_events", N, 64, &ea, sizeof(ea), stream);
+    std::vector<unsigned> counts(2u * n);
+    std::vector<double> ed_out(2u * n * maxd * 4u);
+    unsigned flags[1] = {0};
+    d_ed_counts.download(counts.data(), counts.size() * sizeof(unsigned), stream);
+    d_ed_flags.download(flags, sizeof(flags), stream);
+    if (std::any_of(counts.begin(), counts.end(), [](unsigned c) { return c != 0u; })) {
+        d_ed_out.download(ed_out.data(), ed_out.size() * dsz, stream);
+    }
+    ed_failures += flags[0];
+
+    // Per-lane lists, sorted by the absolute value of the trigger time (:771-778).
+    std::vector<std::vector<detected_event>> d_tes(n), d_ntes(n);
+    const auto fetch = [&](std::size_t cls, std::size_t i, std::vector<detected_event> &out) {
+        for (unsigned c = 0; c < counts[cls * n + i]; ++c) {
+            const auto *r = ed_out.data() + ((cls * n + i) * maxd + c) * 4u;
+            out.push_back({static_cast<std::uint32_t>(r[0]), r[1], static_cast<int>(r[2]), r[3]});
+        }
+        std::stable_sort(out.begin(), out.end(),
+                         [](const auto &x, const auto &y) { return std::abs(x.root) < std::abs(y.root); });
+    };
+    for (std::size_t i = 0; i < n; ++i) {
+        fetch(0, i, d_tes[i]);
+        fetch(1, i, d_ntes[i]);
+        if (!d_tes[i].empty()) {
+            // Truncate the step at the first terminal event.
+            hs[i] = d_tes[i][0].root;
+        }
+    }
+
+    // 4. State update via dense output at the final step sizes (:781), then back to the host: the callbacks may
+    //    read and write state and parameters.
+    if (d_dout.bytes() == 0u) {
+        d_dout = device_buffer(d_out.size() * dsz, device);
+        d_douth = device_buffer(n * dsz, device);
+    }
+    d_douth.upload(hs.data(), n * dsz, stream);
+    dmod->launch_dout(d_state.as<double>(), d_tc.as<double>(), d_douth.as<double>(), N);
+    d_state.download(state.data(), state.size() * dsz, stream);
+    tc_dev_newer = true;
+    dev_newer = false;
+    // NOTE: from here on the host copies are authoritative (they are uploaded again by the next kernel).
+    host_newer = true;
+    step_res_dev_newer = false;
+    lasth_dev_newer = false;
+
+    std::vector<std::pair<std::uint32_t, std::exception_ptr>> cb_eptrs;
+    std::vector<double> thi_copy(n), tlo_copy(n);
+    for (std::uint32_t i = 0; i < N; ++i) {
+        const auto h = hs[i];
+        const auto new_time = dfloat(time_hi[i], time_lo[i]) + h;
+        time_hi[i] = new_time.hi;
+        time_lo[i] = new_time.lo;
+        thi_copy[i] = new_time.hi;
+        tlo_copy[i] = new_time.lo;
+        last_h[i] = h;
+
+        bool nf = !isfinite(new_time);
+        for (std::uint32_t v = 0; v < dim && !nf; ++v) {
+            nf = !std::isfinite(state[static_cast<std::size_t>(v) * n + i]);
+        }
+        if (nf) {
+            step_res[i] = std::tuple{taylor_outcome::err_nf_state, h};
+            continue;
+        }
+
+        // Update the cooldowns (:822-835).
+        for (auto &cd : te_cooldowns[i]) {
+            if (cd) {
+                const auto tmp = cd->first + h;
+                if (std::abs(tmp) >= cd->second) {
+                    cd.reset();
+                } else {
+                    cd->first = tmp;
+                }
+            }
+        }
+
+        // Non-terminal events triggering before the first terminal event (:837-871).
+        bool nt_cb_exception = false;
+        for (const auto &ev : d_ntes[i]) {
+            if (!d_tes[i].empty() && !(std::abs(ev.root) < std::abs(h))) {
+                break;
+            }
+            try {
+                ntes[ev.idx].callback(cb_ctx, static_cast<double>(new_time - last_h[i] + ev.root), ev.d_sgn, i);
+            } catch (...) {
+                cb_eptrs.emplace_back(i, std::current_exception());
+                nt_cb_exception = true;
+                break;
+            }
+        }
+        if (nt_cb_exception) {
+            continue;
+        }
+
+        // The first terminal event (:875-908).
+        bool te_cb_ret = false;
+        if (!d_tes[i].empty()) {
+            const auto &ev = d_tes[i][0];
+            auto &te = tes[ev.idx];
+            if (te.cooldown >= 0) {
+                te_cooldowns[i][ev.idx].emplace(0., te.cooldown);
+            } else {
+                // taylor_deduce_cooldown(), src/detail/event_detection.cpp:519-550.
+                auto cd = g_eps[i] / ev.abs_der * 10;
+                if (!std::isfinite(cd)) {
+                    cd = 0;
+                }
+                te_cooldowns[i][ev.idx].emplace(0., cd);
+            }
+            if (te.callback) {
+                try {
+                    te_cb_ret = te.callback(cb_ctx, ev.d_sgn, i);
+                } catch (...) {
+                    cb_eptrs.emplace_back(i, std::current_exception());
+                    continue;
+                }
+            }
+            const auto ev_idx = static_cast<std::int64_t>(ev.idx);
+            step_res[i] = std::tuple{static_cast<taylor_outcome>(te_cb_ret ? ev_idx : (-ev_idx - 1)), h};
+        } else {
+            step_res[i] = std::tuple{h == lims[i] ? taylor_outcome::time_limit : taylor_outcome::success, h};
+        }
+    }
+
+    if (!cb_eptrs.empty()) {
+        if (cb_eptrs.size() == 1u) {
+            std::rethrow_exception(cb_eptrs[0].second);
+        }
+        std::string exc_msg = "Two or more exceptions were raised during the execution of event callbacks in a "
+                              "batch integrator:\n\n";
+        for (auto &[i, eptr] : cb_eptrs) {
+            exc_msg += "Batch index #" + std::to_string(i) + ":\n";
+            try {
+                std::rethrow_exception(eptr);
+            } catch (const std::exception &ex) {
+                exc_msg += std::string("    Exception message: ") + ex.what() + "\n";
+            } catch (...) {
+                exc_msg += "    Exception type: unknown\n    Exception message: unknown\n";
+            }
+            exc_msg += '\n';
+        }
+        throw std::runtime_error(exc_msg);
+    }
+    for (std::uint32_t i = 0; i < N; ++i) {
+        const auto same = [](double x, double y) { return x == y || (std::isnan(x) && std::isnan(y)); };
+        if (!same(time_hi[i], thi_copy[i]) || !same(time_lo[i], tlo_copy[i])) {
+            throw std::runtime_error("The invocation of one or more event callbacks resulted in the alteration of the "
+                                     "time coordinate of the integrator at the batch index "
+                                     + std::to_string(i) + " - this is not supported");
+        }
+    }
+}
+
 // ---- stepping (reference: src/taylor_adaptive_batch.cpp:1039-1080) ----
 void tab_core::step(bool wtc)
 {
-    m_impl->run_step(std::vector<double>(m_impl->N, std::numeric_limits<double>::infinity()), wtc);
+    const std::vector<double> lims(m_impl->N, std::numeric_limits<double>::infinity());
+    if (m_impl->has_events()) {
+        m_impl->step_with_events(lims, wtc);
+    } else {
+        m_impl->run_step(lims, wtc);
+    }
 }
 
 void tab_core::step_backward(bool wtc)
 {
-    m_impl->run_step(std::vector<double>(m_impl->N, -std::numeric_limits<double>::infinity()), wtc);
+    const std::vector<double> lims(m_impl->N, -std::numeric_limits<double>::infinity());
+    if (m_impl->has_events()) {
+        m_impl->step_with_events(lims, wtc);
+    } else {
+        m_impl->run_step(lims, wtc);
+    }
 }
 
 void tab_core::step(const std::vector<double> &max_delta_ts, bool wtc)
@@ -695,7 +1054,11 @@ void tab_core::step(const std::vector<double> &max_delta_ts, bool wtc)
         throw std::invalid_argument("Cannot invoke the step() function of an adaptive Taylor integrator in batch "
                                     "mode if one of the max timesteps is nan");
     }
-    d.run_step(max_delta_ts, wtc);
+    if (d.has_events()) {
+        d.step_with_events(max_delta_ts, wtc);
+    } else {
+        d.run_step(max_delta_ts, wtc);
+    }
 }
 
 // Reference: propagate_for_impl(), src/taylor_adaptive_batch.cpp:1082-1118.
@@ -752,7 +1115,8 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
     // the *current* times are subsumed by the kernel: a lane whose time is already non-finite (it can only
     // come from an earlier err_nf_state) reports err_nf_state again instead of raising an exception.
     d.last_c_out.reset();
-    if (!cb && !c_out && ts_.size() == 1u && d.dev_newer && !d.host_newer && !d.sticky_host_ptr && d.dmod) {
+    if (!cb && !c_out && !d.has_events() && ts_.size() == 1u && d.dev_newer && !d.host_newer && !d.sticky_host_ptr
+        && d.dmod) {
         if (!std::isfinite(ts_[0])) {
             throw std::invalid_argument("A non-finite time was passed to the propagate_until() function of an "
                                         "adaptive Taylor integrator in batch mode");
@@ -836,7 +1200,7 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
 
     d.prop_res_override.reset();
 
-    if (!cb && !c_out) {
+    if (!cb && !c_out && !d.has_events()) {
         // Device-resident propagation: every lane runs its own adaptive loop to completion
         // (or to max_steps) inside a single kernel launch.
         d.before_kernel();
@@ -889,12 +1253,10 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
             cur_max[i] = static_cast<double>(dt_limit);
         }
 
-        d.run_step(cur_max, wtc);
-        d.fetch_step_res();
-        d.times_to_host(); // NOTE: the state stays on the device (fetched lazily by the getters).
+        d.lockstep_sweep(cur_max, wtc); // NOTE: the state stays on the device (fetched lazily by the getters).
 
         std::uint32_t n_done = 0;
-        bool nfs_detected = false;
+        bool nfs_detected = false, ste_detected = false;
         for (std::uint32_t i = 0; i < N; ++i) {
             const auto [oc, h] = d.step_res[i];
             if (oc == taylor_outcome::err_nf_state) {
@@ -906,6 +1268,8 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
                     min_abs_h[i] = std::min(min_abs_h[i], abs_h);
                     max_abs_h[i] = std::max(max_abs_h[i], abs_h);
                 }
+                // Stopping terminal event (:1411).
+                ste_detected = ste_detected || (oc > taylor_outcome::success && oc < taylor_outcome{0});
                 const auto cur_done = (h == static_cast<double>(rem[i]));
                 n_done += cur_done;
                 if (cur_done) {
@@ -954,7 +1318,7 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
             }
         }
 
-        if (n_done == N) {
+        if (n_done == N || ste_detected) {
             make_c_out();
             return;
         }
@@ -1327,7 +1691,10 @@ std::vector<double> tab_core::propagate_grid(std::vector<double> grid, std::size
         t_dir[i] = rem[i] >= dfloat(0.);
     }
 
-    if (d_out != nullptr || (!cb && std::getenv("HEYOKA_AMD_GRID_HOST_LOOP") == nullptr)) {
+    if (d_out != nullptr && d.has_events()) {
+        throw std::invalid_argument("propagate_grid() with a device output buffer does not support events");
+    }
+    if (d_out != nullptr || (!cb && !d.has_events() && std::getenv("HEYOKA_AMD_GRID_HOST_LOOP") == nullptr)) {
         // Device-resident lock-step loop: the step kernel and a post-step kernel (bookkeeping of the reference's
         // loop, dense output at the grid points covered by the step, next step limit) alternate without any
         // per-lane host work; the host only reads two counters per sweep.
@@ -1388,7 +1755,9 @@ std::vector<double> tab_core::propagate_grid(std::vector<double> grid, std::size
         }
         if (std::any_of(d.prop_res.begin(), d.prop_res.end(), [](const auto &t) {
                 const auto oc = std::get<0>(t);
-                return oc == taylor_outcome::cb_stop || oc == taylor_outcome::step_limit;
+                // NOTE: stopping terminal events interrupt the propagation as well (:1903-1908).
+                return oc == taylor_outcome::cb_stop || (oc > taylor_outcome::success && oc < taylor_outcome{0})
+                       || oc == taylor_outcome::step_limit;
             })) {
             break;
         }
@@ -1397,9 +1766,7 @@ std::vector<double> tab_core::propagate_grid(std::vector<double> grid, std::size
                 = t_dir[i] != 0 ? std::min(dfloat(max_delta_ts[i]), rem[i]) : std::max(dfloat(-max_delta_ts[i]), rem[i]);
             pgrid_tmp[i] = static_cast<double>(dt_limit);
         }
-        d.run_step(pgrid_tmp, true);
-        d.fetch_step_res();
-        d.times_to_host(); // NOTE: the state stays on the device (fetched lazily by the getters).
+        d.lockstep_sweep(pgrid_tmp, true); // NOTE: the state stays on the device (fetched lazily by the getters).
 
         bool nfs_detected = false;
         for (std::uint32_t i = 0; i < N; ++i) {

@@ -6,6 +6,7 @@
 // SIMD width of the reference becomes the number of GPU lanes here (10^6 and beyond).
 #pragma once
 
+#include <cmath>
 #include <cstddef>
 #include <cstdint>
 #include <functional>
@@ -13,6 +14,7 @@
 #include <limits>
 #include <memory>
 #include <optional>
+#include <stdexcept>
 #include <span>
 #include <tuple>
 #include <type_traits>
@@ -22,6 +24,7 @@
 #include "continuous_output.hpp"
 #include "decompose.hpp"
 #include "dfloat.hpp"
+#include "event_detection.hpp"
 #include "expression.hpp"
 #include "kw.hpp"
 
@@ -63,6 +66,9 @@ public:
         std::vector<double> time; // empty -> zeros; size 1 -> splat; else size == batch_size.
         bool time_is_scalar = false;
         int device = 0;
+        // Event detection (reference: kw::t_events / kw::nt_events, include/heyoka/taylor.hpp:814-821).
+        std::vector<core_t_event> t_events;
+        std::vector<core_nt_event> nt_events;
     };
 
     tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_size, config cfg);
@@ -127,6 +133,15 @@ public:
                                     const std::vector<dfloat> &rem, const std::vector<int> &t_dir,
                                     const std::vector<double> &max_delta_ts, std::size_t max_steps,
                                     double *d_out = nullptr);
+    // ---- events (reference: taylor.hpp:1008-1014) ----
+    [[nodiscard]] bool with_events() const;
+    [[nodiscard]] const std::vector<core_t_event> &get_t_events() const;
+    [[nodiscard]] const std::vector<core_nt_event> &get_nt_events() const;
+    [[nodiscard]] const std::vector<std::vector<std::optional<std::pair<double, double>>>> &get_te_cooldowns() const;
+    void reset_cooldowns();
+    void reset_cooldowns(std::uint32_t batch_idx);
+    // Opaque pointer handed to the event callbacks (the address of the user-facing integrator object).
+    void set_callback_context(void *ctx);
     // The continuous output recorded by the last propagate_for/until() invoked with c_out = true
     // (empty if no step was taken); the object is moved out.
     std::optional<c_out_core> take_c_output();
@@ -164,6 +179,103 @@ private:
 std::vector<double> make_vector_from(double x);
 
 } // namespace detail
+
+// Event classes of the batch integrator (reference: nt_event_batch<T> / t_event_batch<T>,
+// include/heyoka/events.hpp:52-325). Callback signatures as in the reference:
+//   non-terminal: void(taylor_adaptive_batch<T> &, T time, int d_sgn, std::uint32_t batch_idx)
+//   terminal:     bool(taylor_adaptive_batch<T> &, int d_sgn, std::uint32_t batch_idx) (false -> stop).
+template <typename T>
+class nt_event_batch
+{
+public:
+    using callback_t = std::function<void(taylor_adaptive_batch<T> &, T, int, std::uint32_t)>;
+
+private:
+    expression m_eq;
+    callback_t m_cb;
+    event_direction m_dir = event_direction::any;
+
+public:
+    template <typename... KwArgs>
+    explicit nt_event_batch(expression e, callback_t cb, const KwArgs &...kw_args)
+        : m_eq(std::move(e)), m_cb(std::move(cb)),
+          m_dir(static_cast<event_direction>(kw::get(kw::direction, event_direction::any, kw_args...)))
+    {
+        static_assert(kw::all_named_v<KwArgs...>);
+        if (!m_cb) {
+            throw std::invalid_argument("Cannot construct a non-terminal event with an empty callback");
+        }
+        check_dir();
+    }
+    [[nodiscard]] const expression &get_expression() const
+    {
+        return m_eq;
+    }
+    [[nodiscard]] const callback_t &get_callback() const
+    {
+        return m_cb;
+    }
+    [[nodiscard]] event_direction get_direction() const
+    {
+        return m_dir;
+    }
+
+private:
+    void check_dir() const
+    {
+        if (m_dir != event_direction::any && m_dir != event_direction::positive && m_dir != event_direction::negative) {
+            throw std::invalid_argument("Invalid value selected for the direction of a non-terminal event");
+        }
+    }
+};
+
+template <typename T>
+class t_event_batch
+{
+public:
+    using callback_t = std::function<bool(taylor_adaptive_batch<T> &, int, std::uint32_t)>;
+
+private:
+    expression m_eq;
+    callback_t m_cb;
+    event_direction m_dir = event_direction::any;
+    T m_cooldown = -1;
+
+public:
+    template <typename... KwArgs>
+    explicit t_event_batch(expression e, const KwArgs &...kw_args)
+        : m_eq(std::move(e)),
+          m_dir(static_cast<event_direction>(kw::get(kw::direction, event_direction::any, kw_args...))),
+          m_cooldown(static_cast<T>(kw::get(kw::cooldown, -1., kw_args...)))
+    {
+        static_assert(kw::all_named_v<KwArgs...>);
+        if constexpr (kw::has_v<kw::callback_tag, KwArgs...>) {
+            m_cb = kw::get(kw::callback, 0, kw_args...);
+        }
+        if (m_dir != event_direction::any && m_dir != event_direction::positive && m_dir != event_direction::negative) {
+            throw std::invalid_argument("Invalid value selected for the direction of a terminal event");
+        }
+        if (!std::isfinite(m_cooldown)) {
+            throw std::invalid_argument("Cannot set a non-finite cooldown value for a terminal event");
+        }
+    }
+    [[nodiscard]] const expression &get_expression() const
+    {
+        return m_eq;
+    }
+    [[nodiscard]] const callback_t &get_callback() const
+    {
+        return m_cb;
+    }
+    [[nodiscard]] event_direction get_direction() const
+    {
+        return m_dir;
+    }
+    [[nodiscard]] T get_cooldown() const
+    {
+        return m_cooldown;
+    }
+};
 
 template <>
 class taylor_adaptive_batch<double>
@@ -203,8 +315,35 @@ class taylor_adaptive_batch<double>
                 }
             }
         }
-        static_assert(!kw::has_v<kw::t_events_tag, KwArgs...> && !kw::has_v<kw::nt_events_tag, KwArgs...>,
-                      "Event detection is not available in the MI355X batch integrator");
+        // Events: the callbacks are type-erased; the integrator object is handed to them through the context pointer
+        // set by every stepping / propagation member.
+        using self_t = taylor_adaptive_batch<double>;
+        if constexpr (kw::has_v<kw::t_events_tag, KwArgs...>) {
+            for (const auto &ev : kw::get(kw::t_events, 0, kw_args...)) {
+                detail::core_t_event ce;
+                ce.eq = ev.get_expression();
+                ce.dir = ev.get_direction();
+                ce.cooldown = ev.get_cooldown();
+                if (const auto &cb = ev.get_callback()) {
+                    ce.callback = [cb](void *ctx, int d_sgn, std::uint32_t idx) {
+                        return cb(*static_cast<self_t *>(ctx), d_sgn, idx);
+                    };
+                }
+                cfg.t_events.push_back(std::move(ce));
+            }
+        }
+        if constexpr (kw::has_v<kw::nt_events_tag, KwArgs...>) {
+            for (const auto &ev : kw::get(kw::nt_events, 0, kw_args...)) {
+                detail::core_nt_event ce;
+                ce.eq = ev.get_expression();
+                ce.dir = ev.get_direction();
+                const auto &cb = ev.get_callback();
+                ce.callback = [cb](void *ctx, double tm, int d_sgn, std::uint32_t idx) {
+                    cb(*static_cast<self_t *>(ctx), tm, d_sgn, idx);
+                };
+                cfg.nt_events.push_back(std::move(ce));
+            }
+        }
         return cfg;
     }
 
@@ -296,7 +435,19 @@ public:
     }
     [[nodiscard]] bool with_events() const
     {
-        return false;
+        return m_core.with_events();
+    }
+    void reset_cooldowns()
+    {
+        m_core.reset_cooldowns();
+    }
+    void reset_cooldowns(std::uint32_t i)
+    {
+        m_core.reset_cooldowns(i);
+    }
+    [[nodiscard]] const std::vector<std::vector<std::optional<std::pair<double, double>>>> &get_te_cooldowns() const
+    {
+        return m_core.get_te_cooldowns();
     }
     [[nodiscard]] bool is_variational() const noexcept
     {
@@ -393,14 +544,17 @@ public:
 
     void step(bool wtc = false)
     {
+        m_core.set_callback_context(this);
         m_core.step(wtc);
     }
     void step_backward(bool wtc = false)
     {
+        m_core.set_callback_context(this);
         m_core.step_backward(wtc);
     }
     void step(const std::vector<double> &max_delta_ts, bool wtc = false)
     {
+        m_core.set_callback_context(this);
         m_core.step(max_delta_ts, wtc);
     }
     [[nodiscard]] const std::vector<std::tuple<taylor_outcome, double>> &get_step_res() const
@@ -429,6 +583,7 @@ public:
                                                                            const KwArgs &...kw_args)
     {
         auto [max_steps, mdts, cb, user_cb, wtc, c_out] = propagate_common_ops(kw_args...);
+        m_core.set_callback_context(this);
         m_core.propagate_until(ts, max_steps, mdts, cb, wtc, c_out);
         return {make_c_out(), std::move(user_cb)};
     }
@@ -436,6 +591,7 @@ public:
     std::tuple<std::optional<continuous_output_batch<double>>, step_callback_batch<double>> propagate_until(double t, const KwArgs &...kw_args)
     {
         auto [max_steps, mdts, cb, user_cb, wtc, c_out] = propagate_common_ops(kw_args...);
+        m_core.set_callback_context(this);
         m_core.propagate_until(std::vector<double>{t}, max_steps, mdts, cb, wtc, c_out);
         return {make_c_out(), std::move(user_cb)};
     }
@@ -444,6 +600,7 @@ public:
                                                                          const KwArgs &...kw_args)
     {
         auto [max_steps, mdts, cb, user_cb, wtc, c_out] = propagate_common_ops(kw_args...);
+        m_core.set_callback_context(this);
         m_core.propagate_for(dts, max_steps, mdts, cb, wtc, c_out);
         return {make_c_out(), std::move(user_cb)};
     }
@@ -451,6 +608,7 @@ public:
     std::tuple<std::optional<continuous_output_batch<double>>, step_callback_batch<double>> propagate_for(double dt, const KwArgs &...kw_args)
     {
         auto [max_steps, mdts, cb, user_cb, wtc, c_out] = propagate_common_ops(kw_args...);
+        m_core.set_callback_context(this);
         m_core.propagate_for(std::vector<double>{dt}, max_steps, mdts, cb, wtc, c_out);
         return {make_c_out(), std::move(user_cb)};
     }
@@ -459,6 +617,7 @@ public:
                                                                                const KwArgs &...kw_args)
     {
         auto [max_steps, mdts, cb, user_cb, wtc, c_out] = propagate_common_ops(kw_args...);
+        m_core.set_callback_context(this);
         auto ret = m_core.propagate_grid(std::move(grid), max_steps, mdts, cb);
         return {std::move(user_cb), std::move(ret)};
     }

@@ -140,6 +140,37 @@ typedef struct {
  * state: n_state = n_eq * batch_size values, or n_state == 0 for a zero-initialised state.
  * Performs decomposition, HIP code generation and hiprtc compilation; does not need a GPU. */
 hy_tab hy_tab_create(hy_sys sys, const double *state, size_t n_state, uint32_t batch_size, const hy_tab_config *cfg);
+/* Event detection (kw::t_events / kw::nt_events, include/heyoka/events.hpp:52-325; detection
+ * src/detail/event_detection.cpp:1733-2173; event branch of step_impl() src/taylor_adaptive_batch.cpp:727-1030).
+ * direction: -1 negative, 0 any, +1 positive (event_direction). Callbacks run on the host, one lane at a time:
+ *   non-terminal: cb(integrator, trigger time, sign of d(eq)/dt, batch index, user)
+ *   terminal:     cb(...) returns non-zero to continue, zero to stop the propagation; cb == NULL always stops.
+ *   cooldown < 0 -> deduced automatically (taylor_deduce_cooldown()).
+ * Outcomes follow the reference: step outcome = event index (continuing) or -index - 1 (stopping). */
+typedef void (*hy_nt_event_cb)(hy_tab, double time, int d_sgn, uint32_t batch_idx, void *user);
+typedef int (*hy_t_event_cb)(hy_tab, int d_sgn, uint32_t batch_idx, void *user);
+typedef struct {
+    hy_expr eq;
+    hy_nt_event_cb cb;
+    void *user;
+    int direction;
+} hy_nt_event;
+typedef struct {
+    hy_expr eq;
+    hy_t_event_cb cb;
+    void *user;
+    int direction;
+    double cooldown;
+} hy_t_event;
+hy_tab hy_tab_create_with_events(hy_sys sys, const double *state, size_t n_state, uint32_t batch_size,
+                                 const hy_tab_config *cfg, const hy_t_event *t_events, size_t n_t_events,
+                                 const hy_nt_event *nt_events, size_t n_nt_events);
+int hy_tab_with_events(hy_tab);
+/* reset_cooldowns(): batch_idx < 0 -> all the lanes. */
+int hy_tab_reset_cooldowns(hy_tab, int64_t batch_idx);
+/* get_te_cooldowns(): [batch_size * n_t_events] arrays indexed [lane * n_t_events + event]; active != 0 where a
+ * cooldown is in progress, (first, second) = (elapsed, duration). */
+int hy_tab_get_te_cooldowns(hy_tab, double *first, double *second, int *active);
 hy_tab hy_tab_copy(hy_tab);  /* copy constructor (taylor.hpp:943) */
 void hy_tab_free(hy_tab);
 

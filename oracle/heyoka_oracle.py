@@ -463,11 +463,13 @@ def _get_vars(e, out):
             _get_vars(a, out)
 
 
-def taylor_decompose_sys(sys):
-    """Returns dc = list of (Ex, deps)."""
+def taylor_decompose_sys(sys, sv_funcs=None):
+    """Returns dc = list of (Ex, deps); with sv_funcs (extra functions of the state, e.g. event equations,
+    src/taylor_01.cpp:848-1008) returns (dc, sv_funcs_dc) with the u-variable index of each function."""
     n_eq = len(sys)
+    n_sv = 0 if sv_funcs is None else len(sv_funcs)
     repl = {lhs.val: _uname(i) for i, (lhs, _) in enumerate(sys)}
-    all_ex = [rhs for _, rhs in sys]
+    all_ex = [rhs for _, rhs in sys] + ([] if sv_funcs is None else [as_ex(f) for f in sv_funcs])
     all_ex = _transform_all(all_ex, _pow_to_explog)
     all_ex = _transform_all(all_ex, _sum_to_sub)
     all_ex = _transform_all(all_ex, lambda e: _udf_split(e, "sum", 8))
@@ -535,16 +537,27 @@ def taylor_decompose_sys(sys):
         return ret
 
     outs = []
-    for e in all_ex:
+    for e in all_ex[:n_eq]:
         r = decomp(e)
         outs.append((var(_uname(r)) if r is not None else e, []))
+    # Extra functions: decomposed after the right-hand sides; they ride along as additional trailing
+    # entries through CSE and sorting (which renumber them) and are stripped at the end.
+    for e in all_ex[n_eq:]:
+        if e.tag == "var":
+            outs.append((e, []))
+        else:
+            r = decomp(e)
+            if r is None:
+                raise ValueError("The extra functions in a Taylor decomposition cannot be constants or parameters")
+            outs.append((var(_uname(r)), []))
     dc += outs
+    n_outs = n_eq + n_sv
 
     # CSE.
     new_dc = list(dc[:n_eq])
     ex_map = {}
     ren = {_uname(i): _uname(i) for i in range(n_eq)}
-    for i in range(n_eq, len(dc) - n_eq):
+    for i in range(n_eq, len(dc) - n_outs):
         ex, deps = dc[i]
         ne = _rename(ex, ren)
         j = ex_map.get(ne.key())
@@ -554,19 +567,19 @@ def taylor_decompose_sys(sys):
             ren[_uname(i)] = _uname(len(new_dc) - 1)
         else:
             ren[_uname(i)] = _uname(j)
-    for i in range(len(dc) - n_eq, len(dc)):
+    for i in range(len(dc) - n_outs, len(dc)):
         new_dc.append((_rename(dc[i][0], ren), []))
     new_dc = [(ex, [_uidx(ren[_uname(d)]) for d in deps]) for ex, deps in new_dc]
     dc = new_dc
 
     # Kahn BFS sort. Vertex 0 = root, vertex i+1 = u_i.
-    n_vert = len(dc) - n_eq + 1
+    n_vert = len(dc) - n_outs + 1
     out_edges = [[] for _ in range(n_vert)]
     indeg = [0] * n_vert
     for i in range(n_eq):
         out_edges[0].append(i + 1)
         indeg[i + 1] += 1
-    for i in range(n_eq, len(dc) - n_eq):
+    for i in range(n_eq, len(dc) - n_outs):
         vs = set()
         _get_vars(dc[i][0], vs)
         if not vs:
@@ -586,15 +599,18 @@ def taylor_decompose_sys(sys):
             if indeg[t] == 0:
                 q.append(t)
     assert len(order_v) == n_vert
-    v_idx = [v - 1 for v in order_v[1:]] + list(range(len(dc) - n_eq, len(dc)))
-    remap = {_uname(v_idx[i]): _uname(i) for i in range(len(dc) - n_eq)}
+    v_idx = [v - 1 for v in order_v[1:]] + list(range(len(dc) - n_outs, len(dc)))
+    remap = {_uname(v_idx[i]): _uname(i) for i in range(len(dc) - n_outs)}
     dc = [(_rename(dc[ix][0], remap), [_uidx(remap[_uname(d)]) for d in dc[ix][1]]) for ix in v_idx]
 
     # Numbers -> num_identity.
-    for i in range(n_eq, len(dc) - n_eq):
+    for i in range(n_eq, len(dc) - n_outs):
         if dc[i][0].tag == "num":
             dc[i] = (func("num_identity", [dc[i][0]]), [])
-    return dc
+    if sv_funcs is None:
+        return dc
+    sv_funcs_dc = [_uidx(ex.val) for ex, _ in dc[len(dc) - n_sv:]] if n_sv else []
+    return dc[: len(dc) - n_sv], sv_funcs_dc
 
 
 def taylor_order_from_tol(tol):
@@ -673,6 +689,7 @@ def _lib():
     if _LIB is None:
         _LIB = ctypes.CDLL(build_oracle_lib())
         _LIB.hy_oracle_scratch_size.restype = ctypes.c_size_t
+        _LIB.hy_oracle_scratch_size_e.restype = ctypes.c_size_t
         _LIB.hy_oracle_ensemble_propagate_until.restype = ctypes.c_int64
         _LIB.hy_oracle_max_threads.restype = ctypes.c_int
     return _LIB
@@ -698,7 +715,21 @@ class OracleIntegrator:
         self.order = taylor_order_from_tol(self.tol)
         self.high_accuracy = bool(high_accuracy)
         B = self.batch_size
+        self._build_program()
 
+        self.state = np.ascontiguousarray(np.array(state, dtype=np.float64).reshape(-1))
+        if self.state.size != self.n_eq * B:
+            raise ValueError("inconsistent state size")
+        self.pars = np.zeros(max(self.n_par, 1) * B) if pars is None else np.ascontiguousarray(np.array(pars, dtype=np.float64).reshape(-1))
+        self.time_hi = np.zeros(B) if time is None else np.ascontiguousarray(np.broadcast_to(np.array(time, dtype=np.float64), (B,)).copy())
+        self.time_lo = np.zeros(B)
+        self.tc = np.zeros(self.n_eq * (self.order + 1) * B)
+        self.last_h = np.zeros(B)
+        self.step_res = [(OC_SUCCESS, 0.0)] * B
+        self.prop_res = None
+        self._scratch = np.zeros(_lib().hy_oracle_scratch_size(ctypes.byref(self._prog), B) + 64)
+
+    def _build_program(self):
         kinds, arg_off, at, ai, av, dep = [], [0], [], [], [], []
         n_par = 0
         for ex, deps in self.dc[self.n_eq : self.n_u]:
@@ -743,18 +774,6 @@ class OracleIntegrator:
             int(self.high_accuracy),
             *[_p(self._arrs[k]) for k in ("kind", "arg_off", "arg_type", "arg_idx", "arg_val", "dep", "sv_type", "sv_idx", "sv_val")]
         )
-
-        self.state = np.ascontiguousarray(np.array(state, dtype=np.float64).reshape(-1))
-        if self.state.size != self.n_eq * B:
-            raise ValueError("inconsistent state size")
-        self.pars = np.zeros(max(self.n_par, 1) * B) if pars is None else np.ascontiguousarray(np.array(pars, dtype=np.float64).reshape(-1))
-        self.time_hi = np.zeros(B) if time is None else np.ascontiguousarray(np.broadcast_to(np.array(time, dtype=np.float64), (B,)).copy())
-        self.time_lo = np.zeros(B)
-        self.tc = np.zeros(self.n_eq * (self.order + 1) * B)
-        self.last_h = np.zeros(B)
-        self.step_res = [(OC_SUCCESS, 0.0)] * B
-        self.prop_res = None
-        self._scratch = np.zeros(_lib().hy_oracle_scratch_size(ctypes.byref(self._prog), B) + 64)
 
     # step(max_delta_ts=None, wtc=False); max_delta_ts: signed per-lane limits (default +inf).
     def step(self, max_delta_ts=None, wtc=False, backward=False):
@@ -828,3 +847,350 @@ def ensemble_propagate_until(sys, state, n_systems, batch_size, t_final, tol=Non
 
 def max_threads():
     return int(_lib().hy_oracle_max_threads())
+
+
+# ----------------------------------------------------------------------------------------------
+# Event detection (reference: src/detail/event_detection.cpp, src/taylor_adaptive_batch.cpp:727-1030,
+# include/heyoka/events.hpp). Test infrastructure, like the rest of this module.
+# ----------------------------------------------------------------------------------------------
+DIR_ANY, DIR_POSITIVE, DIR_NEGATIVE = 0, 1, -1
+
+
+class nt_event:
+    """Non-terminal event: callback(ta, time, d_sgn, batch_idx)."""
+
+    def __init__(self, eq, callback, direction=DIR_ANY):
+        self.eq, self.callback, self.direction = as_ex(eq), callback, int(direction)
+
+
+class t_event:
+    """Terminal event: callback(ta, d_sgn, batch_idx) -> bool (None: always stop); cooldown < 0 = automatic."""
+
+    def __init__(self, eq, callback=None, direction=DIR_ANY, cooldown=-1.0):
+        self.eq, self.callback, self.direction, self.cooldown = as_ex(eq), callback, int(direction), float(cooldown)
+
+
+def _poly_rescale(a, scal):
+    out, cur = [], 1.0
+    for c in a:
+        out.append(c * cur)
+        cur *= scal
+    return out
+
+
+def _poly_rescale_p2(a):
+    n = len(a) - 1
+    out, cur = [0.0] * (n + 1), 1.0
+    for i in range(n + 1):
+        out[n - i] = cur * a[n - i]
+        cur *= 2.0
+    return out
+
+
+def _poly_translate_1(a):
+    n = len(a) - 1
+    out = [0.0] * (n + 1)
+    for i in range(n + 1):
+        for j in range(i + 1):
+            out[j] += float(math.comb(i, j)) * a[i]
+    return out
+
+
+def _sgn(x):
+    return (0.0 < x) - (x < 0.0)
+
+
+def _count_sign_changes(a):
+    n_sc, last = 0, 0
+    for i, c in enumerate(a):
+        if i == 0:
+            last = _sgn(c)
+            continue
+        s = _sgn(c)
+        if last != 0 and s + last == 0:
+            n_sc += 1
+        if s != 0:
+            last = s
+    return n_sc
+
+
+def _poly_eval(a, x):
+    r = a[-1]
+    for c in reversed(a[:-1]):
+        r = c + r * x
+    return r
+
+
+def _poly_eval_1(a, x):
+    n = len(a) - 1
+    r = a[n] * n
+    for i in range(1, n):
+        r = a[n - i] * (n - i) + r * x
+    return r
+
+
+def _fex_check(a, h):
+    """Interval Horner enclosure of the polynomial over [0, h]: True if it excludes zero."""
+    lo_h, hi_h = (h, 0.0) if h < 0 else (0.0, h)
+    lo = hi = a[-1]
+    for c in reversed(a[:-1]):
+        ps = (lo * lo_h, lo * hi_h, hi * lo_h, hi * hi_h)
+        lo, hi = min(ps) + c, max(ps) + c
+    return _sgn(lo) == _sgn(hi) and _sgn(lo) != 0
+
+
+def _bracketed_root(a, lb, ub):
+    """Root of the polynomial in [lb, ub] with a sign change (the reference uses TOMS 748 with an eps
+    tolerance and returns the midpoint of the final bracket, src/detail/event_detection.cpp:307-394;
+    here: bisection to the last bit, same bracket-midpoint convention)."""
+    if math.isfinite(lb) and math.isfinite(ub) and ub > lb:
+        ub = float(np.nextafter(ub, lb))
+    flb, fub = _poly_eval(a, lb), _poly_eval(a, ub)
+    if flb == 0.0:
+        return lb, 0
+    if fub == 0.0:
+        return ub, 0
+    for _ in range(200):
+        mid = lb / 2 + ub / 2
+        if mid <= lb or mid >= ub:
+            break
+        fm = _poly_eval(a, mid)
+        if fm == 0.0:
+            return mid, 0
+        if (fm < 0) == (flb < 0):
+            lb, flb = mid, fm
+        else:
+            ub, fub = mid, fm
+    return lb / 2 + ub / 2, 0
+
+
+def detect_events(poly, h, g_eps, events, is_terminal, cooldowns, order):
+    """Per-lane detection for one class of events. poly[e] = Taylor coefficients of event e.
+    Returns the list of (idx, root, d_sgn[, abs_der])."""
+    out = []
+    if not (math.isfinite(h) and math.isfinite(g_eps)) or h == 0:
+        return out
+    for i, ev in enumerate(events):
+        ptr = [float(c) for c in poly[i]]
+        if _fex_check(ptr, h):
+            continue
+
+        def add(root):
+            if not math.isfinite(root):
+                return
+            if abs(root) >= abs(h):
+                root = float(np.nextafter(h, 0.0))
+            der = _poly_eval_1(ptr, root)
+            if not math.isfinite(der):
+                return
+            d_sgn = _sgn(der)
+            if ev.direction == DIR_ANY or d_sgn == ev.direction:
+                out.append((i, root, d_sgn, abs(der)) if is_terminal else (i, root, d_sgn))
+
+        lb_offset = 0.0
+        if is_terminal and cooldowns[i] is not None:
+            first, second = cooldowns[i]
+            lb_offset = ((second - first) if h >= 0 else (second + first)) / abs(h)
+        if lb_offset >= 1:
+            continue
+        wlist = [(0.0, 1.0, _poly_rescale(ptr, h))]
+        isol = []
+        failed = False
+        while wlist:
+            lb, ub, tmp = wlist.pop()
+            if tmp[0] == 0 and all(math.isfinite(c) for c in tmp[1:]):
+                if not (is_terminal and lb < lb_offset):
+                    add(lb * h)
+            n_sc = _count_sign_changes(_poly_translate_1(list(reversed(tmp))))
+            if n_sc == 1:
+                isol.append([lb, ub])
+            elif n_sc > 1:
+                tmp1 = _poly_rescale_p2(tmp)
+                tmp2 = _poly_translate_1(tmp1)
+                mid = lb / 2 + ub / 2
+                if lb_offset < mid:
+                    wlist.append((lb, mid, tmp1))
+                wlist.append((mid, ub, tmp2))
+            if len(wlist) > 250 or len(isol) > order:
+                failed = True
+                break
+        if not isol or failed:
+            continue
+        tmp1 = _poly_rescale(ptr, h)
+        for lb, ub in isol:
+            if is_terminal and lb < lb_offset:
+                lb = lb_offset
+                if not (_poly_eval(tmp1, lb) * _poly_eval(tmp1, ub) < 0):
+                    continue
+            root, cflag = _bracketed_root(tmp1, lb, ub)
+            if cflag == 0:
+                add(root * h)
+    return out
+
+
+class OracleEventIntegrator(OracleIntegrator):
+    """OracleIntegrator + event detection: step(), propagate_until/for() with the reference's semantics
+    (lock-step batch, outcomes: >= 0 continuing terminal event, (success, 0) stopping terminal event)."""
+
+    def __init__(self, sys, state, batch_size, t_events=(), nt_events=(), **kw):
+        super().__init__(sys, state, batch_size, **kw)
+        self.t_events, self.nt_events = list(t_events), list(nt_events)
+        evs = [e.eq for e in self.t_events] + [e.eq for e in self.nt_events]
+        dc, ev_u = taylor_decompose_sys(sys, evs)
+        assert dc_to_strings(dc)[: self.n_eq] == dc_to_strings(self.dc)[: self.n_eq]
+        # Rebuild the program on the decomposition that includes the event equations.
+        self._rebuild(dc)
+        self._ev_u = np.ascontiguousarray(np.array(ev_u, dtype=np.int32))
+        B = self.batch_size
+        self._ev_tc = np.zeros(max(len(evs), 1) * (self.order + 1) * B)
+        self._mas = np.zeros(B)
+        self._scratch = np.zeros(_lib().hy_oracle_scratch_size_e(ctypes.byref(self._prog), B) + 64)
+        self.te_cooldowns = [[None] * len(self.t_events) for _ in range(B)]
+        _lib().hy_oracle_scratch_size_e.restype = ctypes.c_size_t
+
+    def _rebuild(self, dc):
+        st, pars, thi = self.state.copy(), self.pars.copy(), self.time_hi.copy()
+        sysv = self.sys
+        self.dc = dc
+        self.n_u = len(dc) - self.n_eq
+        OracleIntegrator._build_program(self)
+        self.state, self.time_hi = st, thi
+        if pars.size == self.pars.size:
+            self.pars = pars
+        self.sys = sysv
+
+    def _dense(self, i, h):
+        """Dense output of lane i at h from the Taylor coefficients."""
+        B, p = self.batch_size, self.order
+        tc = self.tc.reshape(self.n_eq, p + 1, B)[:, :, i]
+        out = np.empty(self.n_eq)
+        for v in range(self.n_eq):
+            if self.high_accuracy:
+                res, comp, cur_h = tc[v, 0], 0.0, h
+                for k in range(1, p + 1):
+                    tmp = tc[v, k] * cur_h
+                    y = tmp - comp
+                    t = res + y
+                    comp = (t - res) - y
+                    res = t
+                    cur_h = cur_h * h
+            else:
+                res = tc[v, p]
+                for k in range(1, p + 1):
+                    res = tc[v, p - k] + res * h
+            out[v] = res
+        return out
+
+    def step(self, max_delta_ts=None, wtc=False, backward=False):
+        B, p = self.batch_size, self.order
+        if max_delta_ts is None:
+            mdt = np.full(B, -np.inf if backward else np.inf)
+        else:
+            mdt = np.ascontiguousarray(np.array(max_delta_ts, dtype=np.float64))
+        h = mdt.copy()
+        n_te, n_ev = len(self.t_events), len(self.t_events) + len(self.nt_events)
+        _lib().hy_oracle_step_e(
+            ctypes.byref(self._prog), B, _p(self.state), _p(self.pars), _p(self.time_hi), _p(h), _p(self.tc),
+            _p(self._ev_u), n_ev, _p(self._ev_tc), _p(self._mas), _p(self._scratch))
+        ev_tc = self._ev_tc.reshape(max(n_ev, 1), p + 1, B)
+        eps = np.finfo(np.float64).eps
+        res = []
+        st = self.state.reshape(self.n_eq, B)
+        for i in range(B):
+            mas = self._mas[i]
+            if math.isfinite(mas):
+                max_r = self.tol if mas < 1 else self.tol * mas
+                g_eps = eps * mas if max_r < eps * mas else max_r
+            else:
+                g_eps = math.inf
+            hi = float(h[i])
+            d_tes = detect_events(ev_tc[:n_te, :, i], hi, g_eps, self.t_events, True, self.te_cooldowns[i], p)
+            d_ntes = detect_events(ev_tc[n_te:n_ev, :, i], hi, g_eps, self.nt_events, False, None, p)
+            d_tes.sort(key=lambda e: abs(e[1]))
+            d_ntes.sort(key=lambda e: abs(e[1]))
+            if d_tes:
+                hi = d_tes[0][1]
+            st[:, i] = self._dense(i, hi)
+            nt = dfloat_add(self.time_hi[i], self.time_lo[i], hi, 0.0)
+            self.time_hi[i], self.time_lo[i] = nt
+            self.last_h[i] = hi
+            if not (math.isfinite(nt[0]) and math.isfinite(nt[1]) and np.all(np.isfinite(st[:, i]))):
+                res.append((OC_ERR_NF_STATE, hi))
+                continue
+            for k, cd in enumerate(self.te_cooldowns[i]):
+                if cd is not None:
+                    tmp = cd[0] + hi
+                    self.te_cooldowns[i][k] = None if abs(tmp) >= cd[1] else (tmp, cd[1])
+            for ev in d_ntes:
+                if d_tes and not (abs(ev[1]) < abs(hi)):
+                    break
+                # new_time - last_h + root, in double-length arithmetic.
+                t0 = dfloat_add(nt[0], nt[1], -hi, 0.0)
+                t_ev = dfloat_add(t0[0], t0[1], ev[1], 0.0)[0]
+                self.nt_events[ev[0]].callback(self, t_ev, ev[2], i)
+            te_cb_ret = False
+            if d_tes:
+                idx = d_tes[0][0]
+                te = self.t_events[idx]
+                cd = te.cooldown if te.cooldown >= 0 else (g_eps / d_tes[0][3] * 10 if math.isfinite(g_eps / d_tes[0][3] * 10) else 0.0)
+                self.te_cooldowns[i][idx] = (0.0, cd)
+                if te.callback is not None:
+                    te_cb_ret = bool(te.callback(self, d_tes[0][2], i))
+                res.append((idx if te_cb_ret else (-idx - 1), hi))
+            else:
+                res.append((OC_TIME_LIMIT if hi == mdt[i] else OC_SUCCESS, hi))
+        self.step_res = res
+        return res
+
+    def propagate_until(self, t, max_delta_t=None, max_steps=0):
+        B = self.batch_size
+        tf = np.broadcast_to(np.array(t, dtype=np.float64), (B,)).copy()
+        md = np.full(B, np.inf) if max_delta_t is None else np.broadcast_to(np.array(max_delta_t, dtype=np.float64), (B,)).copy()
+
+        def rem_of(i):
+            return dfloat_add(tf[i], 0.0, -self.time_hi[i], -self.time_lo[i])
+
+        rem = [rem_of(i) for i in range(B)]
+        t_dir = [r[0] > 0 or (r[0] == 0 and r[1] >= 0) for r in rem]
+        ts_count, mn, mx = [0] * B, [math.inf] * B, [0.0] * B
+        it = 0
+        while True:
+            lims = np.empty(B)
+            for i in range(B):
+                r = rem[i]
+                if t_dir[i]:
+                    lims[i] = r[0] if (r[0] < md[i] or (r[0] == md[i] and r[1] < 0)) else md[i]
+                else:
+                    lims[i] = r[0] if (-md[i] < r[0] or (-md[i] == r[0] and 0 < r[1])) else -md[i]
+            res = self.step(lims)
+            n_done, nfs, ste = 0, False, False
+            pr = []
+            for i, (oc, h) in enumerate(res):
+                if oc == OC_ERR_NF_STATE:
+                    nfs = True
+                else:
+                    ts_count[i] += int(h != 0)
+                    if oc == OC_SUCCESS:
+                        mn[i], mx[i] = min(mn[i], abs(h)), max(mx[i], abs(h))
+                    ste = ste or (OC_SUCCESS < oc < 0)
+                    if h == rem[i][0]:
+                        n_done += 1
+                        rem[i] = (0.0, 0.0)
+                    else:
+                        rem[i] = rem_of(i)
+                pr.append((oc, mn[i], mx[i], ts_count[i]))
+            self.prop_res = pr
+            if nfs:
+                return pr
+            it += 1
+            if n_done == B or ste:
+                return pr
+            if it == max_steps:
+                self.prop_res = [(OC_STEP_LIMIT,) + r[1:] for r in pr]
+                return self.prop_res
+
+    def propagate_for(self, dt, **kw):
+        B = self.batch_size
+        dts = np.broadcast_to(np.array(dt, dtype=np.float64), (B,))
+        tf = np.array([dfloat_add(self.time_hi[i], self.time_lo[i], dts[i], 0.0)[0] for i in range(B)])
+        return self.propagate_until(tf, **kw)

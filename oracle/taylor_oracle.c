@@ -593,6 +593,12 @@ size_t hy_oracle_scratch_size(const hy_oracle_program *p, int B)
     return tape + terms + 8u * (size_t)B + ((size_t)p->n_eq + 4u) * (size_t)B;
 }
 
+/* Same for hy_oracle_step_e() (full order for every u variable). */
+size_t hy_oracle_scratch_size_e(const hy_oracle_program *p, int B)
+{
+    return hy_oracle_scratch_size(p, B) + ((size_t)p->n_u + 8u) * (size_t)B;
+}
+
 static double rhofac(int order)
 {
     /* exp(-7/10 / (order - 1)) / (e * e), folded in double precision. */
@@ -606,12 +612,15 @@ static double rhofac(int order)
  * reference, default mode). h_inout: in = signed max step, out = step taken.
  * tc (nullable): tc[(var * (order + 1) + k) * B + lane].
  */
-void hy_oracle_step(const hy_oracle_program *p, int B, double *state, const double *pars, const double *time,
-                    double *h_inout, double *tc, double *scratch_mem)
+static void step_core(const hy_oracle_program *p, int B, double *state, const double *pars, const double *time,
+                      double *h_inout, double *tc, double *scratch_mem, int with_events, const int32_t *ev_u, int n_ev,
+                      double *ev_tc, double *max_abs_state)
 {
     const int n_eq = p->n_eq, n_u = p->n_u, order = p->order;
     double *tape = scratch_mem;
-    double *scratch = tape + ((size_t)n_u * (size_t)order + (size_t)n_eq) * (size_t)B;
+    /* NOTE: with events the order-p coefficients of all the u variables are needed (src/taylor_02.cpp:1016-1190). */
+    const size_t tape_rows = with_events ? (size_t)n_u * (size_t)(order + 1) : ((size_t)n_u * (size_t)order + (size_t)n_eq);
+    double *scratch = tape + tape_rows * (size_t)B;
 
     for (int i = 0; i < n_eq; ++i) {
         memcpy(TAPE(0, i), state + (size_t)i * B, sizeof(double) * (size_t)B);
@@ -622,10 +631,14 @@ void hy_oracle_step(const hy_oracle_program *p, int B, double *state, const doub
         for (int i = 0; i < p->n_nodes; ++i) node_diff(p, i, k, tape, pars, time, B, scratch);
     }
     sv_diff(p, order, tape, pars, B);
+    if (with_events) {
+        for (int i = 0; i < p->n_nodes; ++i) node_diff(p, i, order, tape, pars, time, B, scratch);
+    }
 
     /* Step size: pairwise max reduction over the variables (default mode). */
     /* Per-step temporaries live at the end of the caller-provided scratch (no allocation in the hot path). */
-    double *mx = scratch_mem + hy_oracle_scratch_size(p, B) - ((size_t)n_eq + 4u) * (size_t)B;
+    double *mx = scratch_mem + (with_events ? hy_oracle_scratch_size_e(p, B) : hy_oracle_scratch_size(p, B))
+                 - ((size_t)n_eq + 4u) * (size_t)B;
     double *red = mx + (size_t)3 * B;
     const int ks[3] = {0, order, order - 1};
     for (int q = 0; q < 3; ++q) {
@@ -673,8 +686,16 @@ void hy_oracle_step(const hy_oracle_program *p, int B, double *state, const doub
         h[l] = hh;
     }
 
-    /* State update. */
-    if (p->high_accuracy) {
+    if (with_events) {
+        /* step_e: no state update (the caller truncates the step at the first terminal event). */
+        for (int l = 0; l < B; ++l) max_abs_state[l] = mx[l];
+        for (int e = 0; e < n_ev; ++e) {
+            for (int k = 0; k <= order; ++k) {
+                memcpy(ev_tc + ((size_t)e * (size_t)(order + 1) + (size_t)k) * (size_t)B, TAPE(k, ev_u[e]),
+                       sizeof(double) * (size_t)B);
+            }
+        }
+    } else if (p->high_accuracy) {
         double *cur_h = scratch + (size_t)B;
         double *comp = scratch + (size_t)2 * B;
         for (int i = 0; i < n_eq; ++i) {
@@ -719,6 +740,24 @@ void hy_oracle_step(const hy_oracle_program *p, int B, double *state, const doub
     }
 
     for (int l = 0; l < B; ++l) h_inout[l] = h[l];
+}
+
+void hy_oracle_step(const hy_oracle_program *p, int B, double *state, const double *pars, const double *time,
+                    double *h_inout, double *tc, double *scratch_mem)
+{
+    step_core(p, B, state, pars, time, h_inout, tc, scratch_mem, 0, NULL, 0, NULL, NULL);
+}
+
+/*
+ * The stepper with events of the reference (taylor_add_adaptive_step_with_events(), src/taylor_00.cpp:592-710):
+ * jets of the state variables (tc) and of the event equations (ev_tc[(event * (order + 1) + k) * B + lane], u variables
+ * ev_u), step size and max |x_i|; the state is NOT updated.
+ */
+void hy_oracle_step_e(const hy_oracle_program *p, int B, const double *state, const double *pars, const double *time,
+                      double *h_inout, double *tc, const int32_t *ev_u, int n_ev, double *ev_tc, double *max_abs_state,
+                      double *scratch_mem)
+{
+    step_core(p, B, (double *)state, pars, time, h_inout, tc, scratch_mem, 1, ev_u, n_ev, ev_tc, max_abs_state);
 }
 
 /* ---- double-length arithmetic ---- */

@@ -671,3 +671,113 @@ def test_propagate_grid_device_output():
     torch.cuda.synchronize()
     assert np.array_equal(d_out.cpu().numpy(), ref)
     assert tb.propagate_res == ta.propagate_res and np.array_equal(tb.state, ta.state)
+
+
+# ---- event detection (doc/tut_events.rst; test/taylor_t_event.cpp, taylor_nt_event.cpp) ----
+def test_events_tutorial_known_answers(golden):
+    """The tutorial session of doc/tut_events.rst on the HIP path: non-terminal event times to machine precision,
+    direction filter, two close events in chronological order, terminal event with a parameter-toggling callback
+    followed by propagate_grid()."""
+    g = golden["events_tutorial"]
+    x, v = hy.make_vars("x", "v")
+    sys_ = [(x, v), (v, -9.8 * hy.sin(x))]
+    times, xs = [], []
+
+    def cb(ta, t, d_sgn, idx):
+        times.append(t)
+        xs.append(ta.update_d_output(t)[0, 0])
+
+    ta = hy.taylor_adaptive_batch(sys_, [[g["ic"][0]], [g["ic"][1]]], 1, nt_events=[hy.nt_event(v, cb)])
+    assert ta.with_events and "table" in ta.hip_source_mode
+    ta.propagate_until(5.0)
+    assert np.max(np.abs(np.array(times) - np.array(g["event_times"]))) <= 8 * EPS
+    assert np.max(np.abs(np.array(xs) - np.array(g["x_at_events"]))) <= 1e-15
+    assert all(r[0] == OC.time_limit for r in ta.propagate_res)
+    times.clear()
+    ta = hy.taylor_adaptive_batch(sys_, [[g["ic"][0]], [g["ic"][1]]], 1,
+                                  nt_events=[hy.nt_event(v, lambda ta, t, d, i: times.append(t),
+                                                         direction=hy.event_direction.positive)])
+    ta.propagate_until(5.0)
+    assert np.max(np.abs(np.array(times) - np.array(g["event_times_positive_direction"]))) <= 8 * EPS
+    log = []
+    ta = hy.taylor_adaptive_batch(sys_, [[g["ic"][0]], [g["ic"][1]]], 1, nt_events=[
+        hy.nt_event(v, lambda ta, t, d, i: log.append((0, t))),
+        hy.nt_event(v * v - 1e-12, lambda ta, t, d, i: log.append((1, t)))])
+    ta.propagate_until(5.0)
+    seq = g["two_events"]["sequence"]
+    assert [e for e, _ in log] == [e for e, _ in seq]
+    assert np.max(np.abs(np.array([t for _, t in log]) - np.array([t for _, t in seq]))) <= 2e-11
+
+    # Terminal event toggling the drag coefficient.
+    gt = g["terminal_drag_toggle"]
+
+    def toggle(ta, d_sgn, idx):
+        p = ta.pars
+        ta.pars = np.where(p == 0, 1.0, 0.0)
+        return True
+
+    ta = hy.taylor_adaptive_batch([(x, v), (v, -9.8 * hy.sin(x) - hy.par[0] * v)], [[gt["ic"][0]], [gt["ic"][1]]], 1,
+                                  t_events=[hy.t_event(v, toggle)], pars=[0.0])
+    while True:
+        ta.step()
+        oc, h = ta.step_res[0]
+        if oc != OC.success:
+            break
+    assert int(oc) == gt["first_event_outcome"] and ta.pars[0, 0] == 1.0 and abs(ta.state[1, 0]) <= 1e-15
+    assert ta.te_cooldowns[0][0] is not None
+    ta.propagate_until(1.0)
+    _, out = ta.propagate_grid(np.array(gt["grid"], dtype=float))
+    assert ta.time[0] == gt["final_time"]
+    assert np.max(np.abs(out[:, :, 0] - np.array(gt["grid_states"]))) <= 1e-13
+
+
+def test_events_batch_vs_oracle():
+    """Batch of pendulums with different amplitudes: terminal + non-terminal events, lane by lane against the oracle
+    (event times, signs, order, step outcomes, cooldowns, stopping terminal events in propagate_until)."""
+    n = 7
+    amp = np.linspace(0.05, 1.2, n)
+    st = np.stack([-amp, np.zeros(n)])
+    x, v = hy.make_vars("x", "v")
+    ox, ov = ho.var("x"), ho.var("v")
+    log_p, log_o = [], []
+    te_p, te_o = [], []
+    ta = hy.taylor_adaptive_batch(
+        [(x, v), (v, -9.8 * hy.sin(x))], st, n,
+        nt_events=[hy.nt_event(v, lambda ta, t, d, i: log_p.append((i, 0, t, d))),
+                   hy.nt_event(x, lambda ta, t, d, i: log_p.append((i, 1, t, d)), direction=hy.event_direction.negative)],
+        t_events=[hy.t_event(x * x + v * v - 1e-3, lambda ta, d, i: te_p.append((i, d)) or True, cooldown=0.05)])
+    ora = ho.OracleEventIntegrator(
+        [(ox, ov), (ov, -9.8 * ho.sin(ox))], st, n,
+        nt_events=[ho.nt_event(ov, lambda ta, t, d, i: log_o.append((i, 0, t, d))),
+                   ho.nt_event(ox, lambda ta, t, d, i: log_o.append((i, 1, t, d)), direction=ho.DIR_NEGATIVE)],
+        t_events=[ho.t_event(ox * ox + ov * ov - 1e-3, lambda ta, d, i: te_o.append((i, d)) or True, cooldown=0.05)])
+    for _ in range(12):
+        ta.step()
+        ora.step()
+        assert [int(oc) for oc, _ in ta.step_res] == [oc for oc, _ in ora.step_res]
+        h_p = np.array([h for _, h in ta.step_res])
+        h_o = np.array([h for _, h in ora.step_res])
+        assert np.max(np.abs(h_p - h_o) / np.abs(h_o)) <= 1e6 * EPS
+        assert rel_err(ta.state, ora.state.reshape(2, n)) <= 1e5 * EPS
+    assert [(a[0], a[1], a[3]) for a in log_p] == [(a[0], a[1], a[3]) for a in log_o] and len(log_p) > 10
+    assert np.max(np.abs(np.array([a[2] for a in log_p]) - np.array([a[2] for a in log_o]))) <= 1e-12
+    assert te_p == te_o
+    cd_p, cd_o = ta.te_cooldowns, ora.te_cooldowns
+    for i in range(n):
+        assert (cd_p[i][0] is None) == (cd_o[i][0] is None)
+    # A stopping terminal event interrupts propagate_until() for the whole batch (outcome = -index - 1).
+    stop = hy.taylor_adaptive_batch([(x, v), (v, -9.8 * hy.sin(x))], st, n, t_events=[hy.t_event(v - 0.3)])
+    stop_o = ho.OracleEventIntegrator([(ox, ov), (ov, -9.8 * ho.sin(ox))], st, n, t_events=[ho.t_event(ov - 0.3)])
+    stop.propagate_until(10.0)
+    stop_o.propagate_until(10.0)
+    assert [int(r[0]) for r in stop.propagate_res] == [r[0] for r in stop_o.prop_res]
+    assert any(int(r[0]) == -1 for r in stop.propagate_res)
+    assert rel_err(stop.state, stop_o.state.reshape(2, n)) <= 1e5 * EPS
+    assert np.max(np.abs(stop.time - stop_o.time_hi)) <= 1e-13
+    # Exceptions raised by Python callbacks surface after the call.
+    def boom(ta, t, d, i):
+        raise RuntimeError("boom")
+
+    tb = hy.taylor_adaptive_batch([(x, v), (v, -9.8 * hy.sin(x))], st, n, nt_events=[hy.nt_event(v, boom)])
+    with pytest.raises(RuntimeError, match="boom"):
+        tb.step()

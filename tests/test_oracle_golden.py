@@ -140,3 +140,61 @@ def test_harmonic_oscillator_long_time_analytic():
     st = ta.state.reshape(2, 2)
     exact = np.array([np.sin(1e4), (1.0 + 1e-3) * np.sin(1.1e4)])
     assert np.all(np.abs(st[0] - exact) <= 1e-11)
+
+
+# ---- event detection (doc/tut_events.rst) ----
+def _pend():
+    x, v = ho.var("x"), ho.var("v")
+    return x, v, [(x, v), (v, -9.8 * ho.sin(x))]
+
+
+def test_events_tutorial_nt_events(golden):
+    g = golden["events_tutorial"]
+    x, v, sys_ = _pend()
+    times, xs = [], []
+
+    def cb(ta, t, d_sgn, idx):
+        times.append(t)
+
+    ta = ho.OracleEventIntegrator(sys_, g["ic"], 1, nt_events=[ho.nt_event(v, cb)])
+    ta.propagate_until(5.0)
+    assert len(times) == len(g["event_times"])
+    # "accurate to machine precision" (doc/tut_events.rst:166-170): a few ulps on times of order 1.
+    assert np.max(np.abs(np.array(times) - np.array(g["event_times"]))) <= 8 * EPS
+    times.clear()
+    ta = ho.OracleEventIntegrator(sys_, g["ic"], 1, nt_events=[ho.nt_event(v, cb, direction=ho.DIR_POSITIVE)])
+    ta.propagate_until(5.0)
+    assert np.max(np.abs(np.array(times) - np.array(g["event_times_positive_direction"]))) <= 8 * EPS
+    # Two close events: chronological processing within a step.
+    log = []
+    e0 = ho.nt_event(v, lambda ta, t, d, i: log.append((0, t)))
+    e1 = ho.nt_event(v * v - 1e-12, lambda ta, t, d, i: log.append((1, t)))
+    ta = ho.OracleEventIntegrator(sys_, g["ic"], 1, nt_events=[e0, e1])
+    ta.propagate_until(5.0)
+    seq = g["two_events"]["sequence"]
+    assert [e for e, _ in log] == [e for e, _ in seq]
+    # v*v - 1e-12 has two roots 4e-6 apart around each zero of v: conditioned to ~1e-11 in time.
+    assert np.max(np.abs(np.array([t for _, t in log]) - np.array([t for _, t in seq]))) <= 2e-11
+
+
+def test_events_tutorial_terminal_event(golden):
+    g = golden["events_tutorial"]["terminal_drag_toggle"]
+    x, v = ho.var("x"), ho.var("v")
+
+    def toggle(ta, d_sgn, idx):
+        ta.pars[0] = 1.0 if ta.pars[0] == 0 else 0.0
+        return True
+
+    ta = ho.OracleEventIntegrator([(x, v), (v, -9.8 * ho.sin(x) - ho.par(0) * v)], g["ic"], 1,
+                                  t_events=[ho.t_event(v, toggle)], pars=[0.0])
+    while True:
+        (oc, h), = ta.step()
+        if oc != ho.OC_SUCCESS:
+            break
+    assert oc == g["first_event_outcome"] and ta.pars[0] == 1.0
+    assert abs(ta.state[1]) <= 1e-15  # stopped at v = 0
+    ta.propagate_until(1.0)
+    for tg, exp in zip(g["grid"], g["grid_states"]):
+        ta.propagate_until(float(tg))
+        assert ta.time_hi[0] == tg
+        assert np.max(np.abs(ta.state - np.array(exp))) <= 1e-13
