@@ -89,6 +89,31 @@ int main(int argc, char **argv)
         REQUIRE(oss.str().find("Default-constructed continuous_output_batch") != std::string::npos);
     }
 
+    // Events: construction as in tutorial/event_basic.cpp (batch flavour of the classes, include/heyoka/events.hpp).
+    std::vector<double> zero_vel_times;
+    nt_event_batch<double> ev(v, [&zero_vel_times](taylor_adaptive_batch<double> &, double tm, int, std::uint32_t) {
+        zero_vel_times.push_back(tm);
+    });
+    t_event_batch<double> tev(
+        x - 0.04,
+        kw::callback = [](taylor_adaptive_batch<double> &t, int, std::uint32_t i) { return t.get_time()[i] < 2.; },
+        kw::direction = event_direction::positive, kw::cooldown = 0.01);
+    auto tae = taylor_adaptive_batch<double>{{prime(x) = v, prime(v) = -9.8 * sin(x)},
+                                             std::vector<double>{-0.05, 0.},
+                                             1u,
+                                             kw::nt_events = {ev},
+                                             kw::t_events = {tev}};
+    REQUIRE(tae.with_events() && tae.get_te_cooldowns().size() == 1u && !tae.get_te_cooldowns()[0][0].has_value());
+    {
+        bool thrown = false;
+        try {
+            nt_event_batch<double> bad(v, nt_event_batch<double>::callback_t{});
+        } catch (const std::invalid_argument &e) {
+            thrown = std::string(e.what()) == "Cannot construct a non-terminal event with an empty callback";
+        }
+        REQUIRE(thrown);
+    }
+
     if (!with_gpu) {
         std::puts("CPU-only checks OK");
         return 0;
@@ -260,6 +285,22 @@ int main(int argc, char **argv)
         tc.get_state_data()[bs] = std::numeric_limits<double>::infinity();
         auto [d_none, cb3] = tc.propagate_until(10., kw::c_output = true);
         REQUIRE(!d_none.has_value());
+    }
+
+    // ---- events (doc/tut_events.rst:156-162: event times to machine precision) ----
+    tae.propagate_until(1.5);
+    REQUIRE(zero_vel_times.size() == 2u && zero_vel_times[0] == 0.
+            && std::abs(zero_vel_times[1] - 1.003701787940065) < 1e-15);
+    // The terminal event x = 0.04 (upwards) continues until t >= 2, then stops the propagation.
+    tae.propagate_until(10.);
+    {
+        const auto oc = std::get<0>(tae.get_propagate_res()[0]);
+        REQUIRE(static_cast<std::int64_t>(oc) == -1);
+        REQUIRE(tae.get_time()[0] > 2. && tae.get_time()[0] < 3.1);
+        REQUIRE(std::abs(tae.get_state()[0] - 0.04) < 1e-15);
+        REQUIRE(tae.get_te_cooldowns()[0][0].has_value());
+        tae.reset_cooldowns();
+        REQUIRE(!tae.get_te_cooldowns()[0][0].has_value());
     }
 
     std::puts("GPU checks OK");
