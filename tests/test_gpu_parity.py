@@ -781,3 +781,31 @@ def test_events_batch_vs_oracle():
     tb = hy.taylor_adaptive_batch([(x, v), (v, -9.8 * hy.sin(x))], st, n, nt_events=[hy.nt_event(v, boom)])
     with pytest.raises(RuntimeError, match="boom"):
         tb.step()
+
+
+def test_block_mode_nonuniform_masses_and_massless_bodies():
+    """Block mode with per-cluster constants (distinct masses -> G*m_j factors in the hy_cst table) and with
+    massless particles (clusters of two shapes are not isomorphic -> table-mode fallback), vs the oracle."""
+    nb, n = 13, 40
+    masses = [1.0 + 0.1 * i for i in range(nb)]
+    st = configs.plummer_nbody_state(nb, n, seed=21, jitter=1e-6)
+    ta = hy.taylor_adaptive_batch(hy.model.nbody(nb, masses=masses, Gconst=0.9), st, n)
+    assert "block" in ta.hip_source_mode and "78 clusters" in ta.hip_source_mode
+    ora = ho.OracleIntegrator(ho.nbody(nb, masses=masses, Gconst=0.9), st, n)
+    for _ in range(2):
+        ta.step()
+        ora.step()
+        assert rel_err(ta.state, ora.state.reshape(6 * nb, n)) <= 1e5 * EPS
+    ta.propagate_until(0.02)
+    ora.propagate_until(0.02)
+    assert max(abs(a[3] - b[3]) for a, b in zip(ta.propagate_res, ora.prop_res)) <= 1
+    assert rel_err(ta.state, ora.state.reshape(6 * nb, n)) <= 1e7 * EPS
+    # 12 massive + 2 massless bodies: the massive-massive and massive-massless pairs have different shapes.
+    nb2 = 14
+    m2 = [1.0] * 12
+    st2 = configs.plummer_nbody_state(nb2, 16, seed=22, jitter=1e-6)
+    tb = hy.taylor_adaptive_batch(hy.model.nbody(nb2, masses=m2), st2, 16)
+    ob = ho.OracleIntegrator(ho.nbody(nb2, masses=m2), st2, 16)
+    tb.step()
+    ob.step()
+    assert rel_err(tb.state, ob.state.reshape(6 * nb2, 16)) <= 1e5 * EPS
