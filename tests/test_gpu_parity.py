@@ -809,3 +809,78 @@ def test_block_mode_nonuniform_masses_and_massless_bodies():
     tb.step()
     ob.step()
     assert rel_err(tb.state, ob.state.reshape(6 * nb2, 16)) <= 1e5 * EPS
+
+
+def _random_system(m, rng, n_var=3):
+    """The same pseudo-random ODE system through expression module m (product or oracle)."""
+    if m is ho:
+        vs = [m.var("x%d" % i) for i in range(n_var)]
+        par, tm, powf = m.par, m.func("time", []), m.pow_
+    else:
+        vs = list(m.make_vars(*["x%d" % i for i in range(n_var)]))
+        par, tm, powf = (lambda i: m.par[i]), m.time, m.pow
+    unary = [m.sin, m.cos, lambda e: m.exp(0.3 * e), lambda e: m.log(2.0 + e * e), m.tanh, m.atan, m.sigmoid,
+             lambda e: powf(1.5 + e * e, -1.5), lambda e: powf(e, 2.0), lambda e: m.sqrt(1.0 + e * e), m.sinh, m.erf]
+
+    def leaf():
+        k = rng.randint(0, 6)
+        if k < 4:
+            return vs[rng.randint(0, n_var)]
+        if k == 4:
+            return par(rng.randint(0, 2))
+        return tm
+
+    def tree(depth):
+        if depth == 0:
+            return leaf()
+        k = rng.randint(0, 7)
+        if k == 0:
+            return tree(depth - 1) + tree(depth - 1)
+        if k == 1:
+            return tree(depth - 1) - float(rng.randint(1, 4)) * tree(depth - 1)
+        if k == 2:
+            return tree(depth - 1) * tree(depth - 1)
+        if k == 3:
+            return tree(depth - 1) / (2.0 + powf(tree(depth - 1), 2.0))
+        if k == 4:
+            return float(rng.uniform(-1.5, 1.5)) * tree(depth - 1)
+        return unary[rng.randint(0, len(unary))](tree(depth - 1))
+
+    return [(v, 0.3 * tree(3) - 0.2 * v) for v in vs]
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5, 7, 8, 9])
+def test_random_systems_all_code_paths_vs_oracle(seed):
+    """Pseudo-random ODE systems over the whole function set (shared subexpressions, parameters, explicit time): the
+    default code generator and the table-driven one against the oracle - decomposition, one full step with
+    Taylor coefficients, a short propagation."""
+    import os
+
+    n = 33
+    rs = np.random.RandomState(100 + seed)
+    st = rs.uniform(-0.7, 0.7, (3, n))
+    pars = rs.uniform(-0.5, 0.5, (2, n))
+    t0 = rs.uniform(0.0, 2.0, n)
+    sys_o = _random_system(ho, np.random.RandomState(seed))
+    for mode in ("default", "table"):
+        if mode == "table":
+            os.environ["HEYOKA_AMD_EMIT_MODE"] = "table"
+        try:
+            sys_p = _random_system(hy, np.random.RandomState(seed))
+            ta = hy.taylor_adaptive_batch(sys_p, st, n, pars=pars, time=t0)
+        finally:
+            os.environ.pop("HEYOKA_AMD_EMIT_MODE", None)
+        assert hy.taylor_decompose_sys(sys_p) == ho.dc_to_strings(ho.taylor_decompose_sys(sys_o))
+        ora = ho.OracleIntegrator(sys_o, st, n, pars=pars, time=t0)
+        ta.step(write_tc=True)
+        ora.step(wtc=True)
+        h_g = np.array([h for _, h in ta.step_res])
+        h_o = np.array([h for _, h in ora.step_res])
+        assert np.max(np.abs(h_g - h_o) / np.abs(h_o)) <= 1e6 * EPS
+        tc_o = ora.tc.reshape(3, ora.order + 1, n)
+        scale = np.max(np.abs(tc_o), axis=2, keepdims=True) + 1e-300
+        assert np.max(np.abs(np.asarray(ta.tc).reshape(3, 21, n) - tc_o) / scale) <= 1e6 * EPS
+        assert rel_err(ta.state, ora.state.reshape(3, n)) <= 1e5 * EPS
+        ta.propagate_for(0.5)
+        ora.propagate_for(0.5)
+        assert rel_err(ta.state, ora.state.reshape(3, n)) <= 1e6 * EPS
