@@ -846,7 +846,8 @@ def _random_system(m, rng, n_var=3):
             return float(rng.uniform(-1.5, 1.5)) * tree(depth - 1)
         return unary[rng.randint(0, len(unary))](tree(depth - 1))
 
-    return [(v, 0.3 * tree(3) - 0.2 * v) for v in vs]
+    # NOTE: both runtime parameters appear in every system (fixed size of the pars array).
+    return [(v, 0.3 * tree(3) - 0.2 * v + 1e-3 * (par(0) - par(1))) for v in vs]
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5, 7, 8, 9])
