@@ -284,6 +284,22 @@ if (a.mode == 1) {
     os << "h = hy_min(h, fabs(lim));\n";
     os << "h = (lim < 0.0) ? -h : h;\n";
 
+    if (!p.ev_u.empty() && !reg_jets) {
+        // ---- Stepper with events (mode 4; taylor_add_adaptive_step_with_events(), src/taylor_00.cpp:592-710): the
+        // order-p coefficients of the u variables (src/taylor_02.cpp:1016-1190), the jets of the event equations,
+        // max |x_i| and the step size; the state is updated later by the dense-output kernel.
+        os << "if (a.mode == 4) {\n";
+        for (std::uint32_t i = 0; i < p.nodes.size(); ++i) {
+            e.node(i, order);
+        }
+        for (std::size_t ev = 0; ev < p.ev_u.size(); ++ev) {
+            for (std::uint32_t k = 0; k <= order; ++k) {
+                os << "a.ev_tc[(u64)" << (ev * (order + 1u) + k) << "u * N + s] = " << e.val(p.ev_u[ev], k) << ";\n";
+            }
+        }
+        os << "a.max_abs_state[s] = " << m0 << ";\nlast_h = h;\nbreak;\n}\n";
+    }
+
     if (reg_jets) {
         // ---- State update straight from the SSA coefficients. ----
         // Coefficient k of state variable i: re-derived from the defining state variable when x' = v.
@@ -387,6 +403,9 @@ if (h == rem.hi) break;
 if (iter == a.max_steps) { outcome = HY_OC_STEP_LIMIT; break; }
 }
 )HIP";
+    if (!p.ev_u.empty() && !reg_jets) {
+        os << "if (a.mode == 4) {\na.last_h[s] = last_h;\nreturn;\n}\n";
+    }
     for (std::uint32_t i = 0; i < n_eq; ++i) {
         os << "a.state[(u64)" << i << "u * N + s] = x" << i << ";\n";
     }
@@ -478,7 +497,9 @@ emitted_module emit_unrolled(const taylor_program &p, const emit_options &opts)
 
     emitted_module ret;
     // Register-resident jets when they fit comfortably in the 512 VGPR+AGPR of a lane.
-    const bool reg_jets = reg_jet_estimate(p, opts.order) <= 200u && std::getenv("HEYOKA_AMD_NO_REG_JETS") == nullptr;
+    // NOTE: the stepper with events needs the Taylor coefficients in memory (event detection, dense output).
+    const bool reg_jets = p.ev_u.empty() && reg_jet_estimate(p, opts.order) <= 200u
+                          && std::getenv("HEYOKA_AMD_NO_REG_JETS") == nullptr;
     if (reg_jets) {
         src << emit_unrolled_kernel(p, opts, "hy_taylor", true, ret.n_statements);
         src << emit_unrolled_kernel(p, opts, "hy_taylor_tc", false, ret.n_statements);

@@ -422,8 +422,14 @@ tab_core::tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_siz
     emit_options eo;
     eo.order = d.order;
     eo.high_accuracy = d.high_accuracy;
-    // NOTE: the stepper with events (mode 4) is implemented by the table-driven kernel.
-    eo.mode = d.has_events() ? emit_mode::table : choose_mode();
+    // NOTE: the stepper with events (mode 4) is implemented by the one-system-per-lane kernels: fully unrolled for
+    // small decompositions, table-driven otherwise (HEYOKA_AMD_EMIT_MODE=table forces the latter).
+    if (d.has_events()) {
+        eo.mode = (d.prog.nodes.size() > 150u || choose_mode() == emit_mode::table) ? emit_mode::table
+                                                                                   : emit_mode::unrolled;
+    } else {
+        eo.mode = choose_mode();
+    }
     d.emitted = emit_hip_module(d.prog, eo);
     d.cmod = hiprtc_compile(d.emitted);
 

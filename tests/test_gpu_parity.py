@@ -674,10 +674,13 @@ def test_propagate_grid_device_output():
 
 
 # ---- event detection (doc/tut_events.rst; test/taylor_t_event.cpp, taylor_nt_event.cpp) ----
-def test_events_tutorial_known_answers(golden):
-    """The tutorial session of doc/tut_events.rst on the HIP path: non-terminal event times to machine precision,
-    direction filter, two close events in chronological order, terminal event with a parameter-toggling callback
-    followed by propagate_grid()."""
+@pytest.mark.parametrize("mode", ["unrolled", "table"])
+def test_events_tutorial_known_answers(golden, mode, monkeypatch):
+    """The tutorial session of doc/tut_events.rst on the HIP path (both steppers with events: fully unrolled and
+    table-driven): non-terminal event times to machine precision, direction filter, two close events in
+    chronological order, terminal event with a parameter-toggling callback followed by propagate_grid()."""
+    if mode == "table":
+        monkeypatch.setenv("HEYOKA_AMD_EMIT_MODE", "table")
     g = golden["events_tutorial"]
     x, v = hy.make_vars("x", "v")
     sys_ = [(x, v), (v, -9.8 * hy.sin(x))]
@@ -688,7 +691,7 @@ def test_events_tutorial_known_answers(golden):
         xs.append(ta.update_d_output(t)[0, 0])
 
     ta = hy.taylor_adaptive_batch(sys_, [[g["ic"][0]], [g["ic"][1]]], 1, nt_events=[hy.nt_event(v, cb)])
-    assert ta.with_events and "table" in ta.hip_source_mode
+    assert ta.with_events and mode in ta.hip_source_mode
     ta.propagate_until(5.0)
     assert np.max(np.abs(np.array(times) - np.array(g["event_times"]))) <= 8 * EPS
     assert np.max(np.abs(np.array(xs) - np.array(g["x_at_events"]))) <= 1e-15
