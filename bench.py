@@ -218,11 +218,15 @@ def main():
     # (heyoka_amd/ensemble.py, RCCL all-gather over xGMI) is exercised here, outside of the timed region.
     gathered = None
     gather_ms = None
+    gather_err = None
     if distributed:
-        tg = time.perf_counter()
-        gathered = hens.all_gather_states(view)
-        torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - tg) * 1e3
+        try:
+            tg = time.perf_counter()
+            gathered = hens.all_gather_states(view)
+            torch.cuda.synchronize()
+            gather_ms = (time.perf_counter() - tg) * 1e3
+        except Exception as e:  # the optional collective must never cost the measurement
+            gather_err = "%s: %s" % (type(e).__name__, e)
 
     # Per-launch kernel durations (HIP events on the launch stream) and step counts.
     call_ms = [a.elapsed_time(b) for a, b in ev]  # torch events around the whole call (incl. small copies)
@@ -280,6 +284,7 @@ def main():
                 "hiprtc_compile_s": ta.compile_seconds,
                 "kernel_sha256": kernel_sha(ta),
                 "untimed_final_state_all_gather_ms": gather_ms,
+                "untimed_final_state_all_gather_error": gather_err,
             },
             "roofline": {
                 "bound": "hbm",
