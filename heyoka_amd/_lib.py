@@ -162,6 +162,7 @@ SIGNATURES = [
     ("hy_model_nbody_potential", c_void_p, [c_uint32, c_void_p, c_size_t, c_void_p]),
     ("hy_model_pendulum_energy", c_void_p, [c_double, c_double]),
     ("hy_sys_get_vars", c_int, [c_void_p, c_void_p]),
+    ("hy_compile_aux_kernels", c_int, [c_uint32, c_uint32, c_int]),
     ("hy_cfunc_new", c_void_p, [c_void_p, c_size_t, c_void_p, c_size_t, c_int]),
     ("hy_cfunc_free", None, [c_void_p]),
     ("hy_cfunc_get_nparams", c_uint32, [c_void_p]),

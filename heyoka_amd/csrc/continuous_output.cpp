@@ -43,6 +43,8 @@ std::string fp_str(double x)
     return oss.str();
 }
 
+} // namespace
+
 // The evaluation kernel. One lane per batch element:
 // - upper_bound over the lane's column of the (hi, lo) times (src/continuous_output.cpp:700-800; the last
 //   row is the +-inf padding which makes the search well defined),
@@ -125,8 +127,6 @@ extern "C" __global__ void __launch_bounds__(256) hy_c_out(const hy_cout_args a)
 )HIP";
     return src.str();
 }
-
-} // namespace
 
 struct c_out_core::data {
     std::uint32_t N = 0, order = 0, dim = 0;

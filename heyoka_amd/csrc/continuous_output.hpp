@@ -19,6 +19,7 @@
 #include <memory>
 #include <optional>
 #include <ostream>
+#include <string>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -75,6 +76,9 @@ public:
     [[nodiscard]] std::uint32_t get_order() const;
     void stream_to(std::ostream &) const;
 };
+
+// HIP source of the evaluation kernel (exposed for the build-time compilation check).
+std::string make_cout_source(std::uint32_t order, std::uint32_t dim, bool high_accuracy);
 
 // Accumulates the per-sweep data during propagate_until().
 class c_out_builder

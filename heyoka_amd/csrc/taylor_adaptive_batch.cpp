@@ -1371,6 +1371,8 @@ struct grid_kargs {
     unsigned n_grid;
 };
 
+} // namespace
+
 // Post-step kernel of the device-resident propagate_grid() loop: the per-lane body of the reference's loop
 // (src/taylor_adaptive_batch.cpp:1760-2040) - step counters, remaining time, dense output at every grid
 // point inside the step just taken (h' = t_grid - (t_now - last_h) in double-length arithmetic, Horner or
@@ -1476,8 +1478,6 @@ extern "C" __global__ void __launch_bounds__(256) hy_grid_post(const hy_grid_arg
 )HIP";
     return src.str();
 }
-
-} // namespace
 
 void tab_core::propagate_grid_device_loop(const std::vector<double> &grid, std::vector<double> &retval,
                                           const std::vector<dfloat> &rem, const std::vector<int> &t_dir,

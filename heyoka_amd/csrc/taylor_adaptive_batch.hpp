@@ -178,6 +178,10 @@ private:
 
 std::vector<double> make_vector_from(double x);
 
+// HIP source of the post-step kernel of the device-resident propagate_grid() loop (exposed for the build-time
+// compilation check).
+std::string make_grid_source(std::uint32_t order, std::uint32_t dim, bool high_accuracy);
+
 } // namespace detail
 
 // Event classes of the batch integrator (reference: nt_event_batch<T> / t_event_batch<T>,

@@ -305,6 +305,11 @@ size_t hy_tab_get_kernel_ms_history(hy_tab, double *out, size_t n);
 int hy_tab_raw_step(hy_tab, double *d_state, const double *d_pars, const double *d_time, double *d_h, double *d_tc,
                     uint64_t n_systems);
 
+/* Build-time check: hiprtc-compiles for gfx950 the auxiliary kernels that are otherwise compiled at first use on a
+ * GPU (continuous output, propagate_grid post-step, event detection) for the given order / dimension; does not need
+ * a GPU. Returns HY_OK or an error code (hy_last_error()). */
+int hy_compile_aux_kernels(uint32_t order, uint32_t dim, int high_accuracy);
+
 /* ------------------------------------------------------------------------------------------------
  * cfunc<double> (include/heyoka/expression.hpp:735-970, src/cfunc_class.cpp, function_decompose()
  * src/expression_cfunc.cpp:723-900): compiled evaluation of fn(vars) over many input columns.

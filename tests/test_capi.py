@@ -123,3 +123,10 @@ def test_cfunc_host_logic_without_gpu():
     sp = hy.model.nbody(2, masses=[hy.par[0], hy.par[1]])
     dcs = hy.taylor_decompose_sys(sp)
     assert any("p0" in l for l in dcs) and any("p1" in l for l in dcs)
+
+
+def test_aux_kernels_compile_for_gfx950():
+    """The auxiliary kernels compiled at first use on a GPU (continuous output, propagate_grid post-step, event
+    detection) build for gfx950 with hiprtc on the CPU-only box."""
+    for order, dim, ha in ((20, 36, 1), (3, 2, 0)):
+        _lib.raise_for(_lib.lib.hy_compile_aux_kernels(order, dim, ha))
