@@ -888,3 +888,56 @@ def test_random_systems_all_code_paths_vs_oracle(seed):
         ta.propagate_for(0.5)
         ora.propagate_for(0.5)
         assert rel_err(ta.state, ora.state.reshape(3, n)) <= 1e6 * EPS
+
+
+def test_full_size_invariants_baseline_configs():
+    """BASELINE.json's full sizes through size-independent properties (no oracle at this scale): energy conservation
+    evaluated on the device by compiled functions (test/model_nbody.cpp:112-118: <= 100 eps over the propagation),
+    time reversibility (propagate forth and back), every lane ends exactly on the requested time."""
+    import torch
+
+    def energy_monitor(sys_, expr, n):
+        cf = hy.cfunc([expr], sys_.vars)
+        buf = torch.empty(n, dtype=torch.float64, device="cuda")
+        return cf, buf
+
+    def run(name, sys_, energy_expr, st, t_final, drift_tol, rev_tol, **kw):
+        n = st.shape[1]
+        ta = hy.taylor_adaptive_batch(sys_, None, n, **kw)
+        view = torch.as_tensor(ta.device_array("state"), device="cuda")
+        view.copy_(torch.from_numpy(st))
+        torch.cuda.synchronize()
+        ta.mark_device_modified()
+        cf, e0 = energy_monitor(sys_, energy_expr, n)
+        e1 = torch.empty_like(e0)
+        cf.eval_device(e0.data_ptr(), ta.device_array("state").ptr, n)
+        ta.propagate_until(t_final)
+        cf.eval_device(e1.data_ptr(), ta.device_array("state").ptr, n)
+        ta.synchronize()
+        torch.cuda.synchronize()
+        drift = float(((e1 - e0) / e0).abs().max())
+        oc = torch.as_tensor(ta.device_array("outcome"), device="cuda")
+        assert bool((oc == int(OC.time_limit)).all()), name
+        thi = torch.as_tensor(ta.device_array("time_hi"), device="cuda")
+        assert bool((thi == t_final).all()), name
+        steps = int(torch.as_tensor(ta.device_array("n_steps"), device="cuda").sum())
+        assert drift <= drift_tol, (name, drift)
+        ta.propagate_until(0.0)
+        ta.synchronize()
+        back = torch.as_tensor(ta.device_array("state"), device="cuda")
+        ref = torch.from_numpy(st).cuda()
+        rev = float(((back - ref).abs() / ref.abs().clamp(min=1.0)).max())
+        assert rev <= rev_tol, (name, rev)
+        return steps
+
+    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    n = 1048576
+    steps = run("outer_ss", hy.model.nbody(6, masses=M, Gconst=G), hy.model.nbody_energy(6, masses=M, Gconst=G),
+                configs.outer_ss_state(n, perturb=1e-12, seed=42), 20.0, 100 * EPS, 1e-11, high_accuracy=True)
+    assert steps > 20 * n
+    n = 4194304
+    run("two_body", hy.model.nbody(2, masses=[1.0, 0.0]), hy.model.nbody_energy(2, masses=[1.0, 1e-300]),
+        configs.two_body_state(n, perturb=1e-12, seed=42), 50.0, 1e3 * EPS, 1e-11)
+    n = 65536
+    run("nbody64", hy.model.nbody(64), hy.model.nbody_energy(64), configs.plummer_nbody_state(64, n, seed=1234 + 42),
+        0.03, 1e3 * EPS, 1e-10)
