@@ -278,7 +278,6 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
     // loop-carried copies of the history push the kernel over the 512-VGPR budget and the spill traffic
     // costs more than the latency it hides.
     const auto n_iter = (nc + bs - 1u) / bs;
-    const bool glue_fence = std::getenv("HEYOKA_AMD_BLOCK_GLUE_FENCE") != nullptr;
     const int pf_mode = [&]() {
         if (n_iter <= 1u) {
             return 0;
@@ -443,9 +442,6 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         for (std::uint32_t r = 0; r * bs < ng; ++r) {
             os << "{\nconst unsigned jr = tid + " << r * bs << "u;\n";
             const bool partial = (r + 1u) * bs > ng;
-            if (glue_fence) {
-                os << "__builtin_amdgcn_sched_barrier(0);\n";
-            }
             if (partial) {
                 os << "const bool ok = jr < " << ng << "u;\nconst unsigned j = ok ? jr : " << ng - 1u << "u;\n";
             } else {
