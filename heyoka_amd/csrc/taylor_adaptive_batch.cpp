@@ -29,6 +29,29 @@ std::string fp_to_string(double x)
     return buf;
 }
 
+// Argument block of the post-step kernels (hy_grid_post / hy_until_post, see make_grid_source()).
+struct grid_kargs {
+    const double *grid;
+    double *out;
+    const double *tc;
+    const double *thi;
+    const double *tlo;
+    const double *last_h;
+    const long long *outcome;
+    double *rem_hi;
+    double *rem_lo;
+    const double *mdt;
+    const int *t_dir;
+    double *lim;
+    unsigned *gidx;
+    double *min_h;
+    double *max_h;
+    unsigned long long *n_steps;
+    unsigned *counters;
+    unsigned long long N;
+    unsigned n_grid;
+};
+
 emit_mode choose_mode()
 {
     if (const char *m = std::getenv("HEYOKA_AMD_EMIT_MODE")) {
@@ -103,6 +126,9 @@ struct tab_core::impl {
     mutable device_buffer d_ev_tc, d_mas, d_geps, d_dirs, d_cd_first, d_cd_second, d_cd_active, d_ed_out, d_ed_counts,
         d_ed_flags;
     std::uint64_t ed_failures = 0;
+    // Incremented by set_time() / set_dtime(): lets the device-driven loops detect callbacks that touch the time
+    // coordinate without moving the times to the host after every sweep.
+    std::uint64_t time_gen = 0;
 
     [[nodiscard]] bool has_events() const
     {
@@ -585,6 +611,7 @@ void tab_core::set_time(const std::vector<double> &t)
     d.time_hi = t;
     std::fill(d.time_lo.begin(), d.time_lo.end(), 0.);
     d.host_newer = true;
+    ++d.time_gen;
 }
 
 void tab_core::set_time(double t)
@@ -594,6 +621,7 @@ void tab_core::set_time(double t)
     std::fill(d.time_hi.begin(), d.time_hi.end(), t);
     std::fill(d.time_lo.begin(), d.time_lo.end(), 0.);
     d.host_newer = true;
+    ++d.time_gen;
 }
 
 void tab_core::set_dtime(const std::vector<double> &hi, const std::vector<double> &lo)
@@ -613,6 +641,7 @@ void tab_core::set_dtime(const std::vector<double> &hi, const std::vector<double
         d.time_lo[i] = v;
     }
     d.host_newer = true;
+    ++d.time_gen;
 }
 
 void tab_core::set_dtime(double hi, double lo)
@@ -1252,6 +1281,92 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
     const auto pinf = std::numeric_limits<double>::infinity();
     std::size_t iter_counter = 0;
 
+    if (!d.has_events() && std::getenv("HEYOKA_AMD_LOCKSTEP_HOST_LOOP") == nullptr) {
+        // Device-driven loop: the per-lane bookkeeping runs in a post-step kernel, the host reads two counters per
+        // sweep, runs the callback and (for the continuous output) appends the coefficients device-to-device.
+        d.ensure_device();
+        d.ensure_tc();
+        if (!d.grid_mod) {
+            d.grid_mod = std::make_unique<aux_module>(
+                hiprtc_compile_source(make_grid_source(d.order, d.dim, d.high_accuracy)), d.device);
+        }
+        const auto dsz = sizeof(double);
+        device_buffer b_rem_hi(N * dsz, d.device), b_rem_lo(N * dsz, d.device), b_mdt(N * dsz, d.device);
+        device_buffer b_tdir(N * sizeof(int), d.device), b_cnt(4u * sizeof(unsigned), d.device);
+        std::vector<double> rhi(N), rlo(N), mdts(N);
+        const std::vector<unsigned long long> ns0(N, 0u);
+        for (std::uint32_t i = 0; i < N; ++i) {
+            rhi[i] = rem[i].hi;
+            rlo[i] = rem[i].lo;
+            mdts[i] = max_delta_ts.empty() ? pinf : max_delta_ts[i];
+            const auto dt_limit
+                = t_dir[i] != 0 ? std::min(dfloat(mdts[i]), rem[i]) : std::max(dfloat(-mdts[i]), rem[i]);
+            cur_max[i] = static_cast<double>(dt_limit);
+        }
+        b_rem_hi.upload(rhi.data(), N * dsz, d.stream);
+        b_rem_lo.upload(rlo.data(), N * dsz, d.stream);
+        b_mdt.upload(mdts.data(), N * dsz, d.stream);
+        b_tdir.upload(t_dir.data(), N * sizeof(int), d.stream);
+        d.d_tfhi.upload(tf_hi.data(), N * dsz, d.stream);
+        d.d_tflo.upload(tf_lo.data(), N * dsz, d.stream);
+        d.d_lim.upload(cur_max.data(), N * dsz, d.stream);
+        d.d_minh.upload(min_abs_h.data(), N * dsz, d.stream);
+        d.d_maxh.upload(max_abs_h.data(), N * dsz, d.stream);
+        d.d_nsteps.upload(ns0.data(), N * sizeof(unsigned long long), d.stream);
+        const auto make_c_out = [&]() {
+            if (cob) {
+                d.last_c_out = cob->finish(t_dir);
+            }
+        };
+        while (true) {
+            d.run_step_impl(nullptr, wtc);
+            b_cnt.zero(d.stream);
+            const grid_kargs a{d.d_tfhi.as<double>(), d.d_tflo.as<double>(), nullptr, d.d_thi.as<double>(),
+                               d.d_tlo.as<double>(), d.d_lasth.as<double>(), d.d_outcome.as<long long>(),
+                               b_rem_hi.as<double>(), b_rem_lo.as<double>(), b_mdt.as<double>(), b_tdir.as<int>(),
+                               d.d_lim.as<double>(), nullptr, d.d_minh.as<double>(), d.d_maxh.as<double>(),
+                               d.d_nsteps.as<unsigned long long>(), b_cnt.as<unsigned>(), N, 0u};
+            d.grid_mod->launch("hy_until_post", N, 256, &a, sizeof(a), d.stream);
+            unsigned cnt[2] = {0, 0};
+            b_cnt.download(cnt, sizeof(cnt), d.stream);
+            // Outcomes of the last sweep + accumulated statistics: on the device.
+            d.prop_res_dev_newer = true;
+            d.step_res_dev_newer = true;
+            if (cnt[1] != 0u) {
+                make_c_out();
+                return;
+            }
+            if (cob) {
+                d.times_to_host();
+                cob->append(d.d_tc.as<double>(), d.time_hi, d.time_lo);
+            }
+            ++iter_counter;
+            if (cb) {
+                const auto gen = d.time_gen;
+                const auto ret_cb = cb();
+                if (d.time_gen != gen) {
+                    throw std::runtime_error("The invocation of the callback passed to propagate_until() resulted in "
+                                             "the alteration of the time coordinate of the integrator - this is not "
+                                             "supported");
+                }
+                if (!ret_cb) {
+                    d.prop_res_override = taylor_outcome::cb_stop;
+                    make_c_out();
+                    return;
+                }
+            }
+            if (cnt[0] == N) {
+                make_c_out();
+                return;
+            }
+            if (iter_counter == max_steps) {
+                d.prop_res_override = taylor_outcome::step_limit;
+                make_c_out();
+                return;
+            }
+        }
+    }
+
     while (true) {
         for (std::uint32_t i = 0; i < N; ++i) {
             const auto mdt = max_delta_ts.empty() ? pinf : max_delta_ts[i];
@@ -1349,27 +1464,6 @@ std::optional<c_out_core> tab_core::take_c_output()
 namespace
 {
 
-struct grid_kargs {
-    const double *grid;
-    double *out;
-    const double *tc;
-    const double *thi;
-    const double *tlo;
-    const double *last_h;
-    const long long *outcome;
-    double *rem_hi;
-    double *rem_lo;
-    const double *mdt;
-    const int *t_dir;
-    double *lim;
-    unsigned *gidx;
-    double *min_h;
-    double *max_h;
-    unsigned long long *n_steps;
-    unsigned *counters;
-    unsigned long long N;
-    unsigned n_grid;
-};
 
 } // namespace
 
@@ -1404,6 +1498,44 @@ struct hy_grid_args {
     u64 N;
     unsigned n_grid;
 };
+
+// Post-step kernel of the device-driven propagate_until() lock-step loop (callbacks / continuous output): the
+// per-lane bookkeeping of src/taylor_adaptive_batch.cpp:1395-1440 (step counters, min/max |h|, remaining time, limit of
+// the next step). counters[0] = lanes done in this sweep, counters[1] = lanes with a non-finite state. The final
+// times are in the (double-length) grid row 0: grid[i] = hi, out[i] = lo.
+extern "C" __global__ void __launch_bounds__(256) hy_until_post(const hy_grid_args a)
+{
+    const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+    const u64 N = a.N;
+    if (i >= N) return;
+    const i64 oc = a.outcome[i];
+    const double h = a.last_h[i];
+    if (oc == HY_OC_ERR_NF_STATE) {
+        atomicAdd(a.counters + 1, 1u);
+        return;
+    }
+    a.n_steps[i] += (h != 0.0) ? 1u : 0u;
+    if (oc == HY_OC_SUCCESS) {
+        const double ah = fabs(h);
+        a.min_h[i] = hy_min(a.min_h[i], ah);
+        a.max_h[i] = hy_max(a.max_h[i], ah);
+    }
+    hy_df rem; rem.hi = a.rem_hi[i]; rem.lo = a.rem_lo[i];
+    if (h == rem.hi) {
+        atomicAdd(a.counters, 1u);
+        rem.hi = 0.0; rem.lo = 0.0;
+    } else {
+        hy_df tcur; tcur.hi = a.thi[i]; tcur.lo = a.tlo[i];
+        hy_df tf; tf.hi = a.grid[i]; tf.lo = a.out[i];
+        rem = hy_df_sub(tf, tcur);
+    }
+    a.rem_hi[i] = rem.hi; a.rem_lo[i] = rem.lo;
+    hy_df m; m.lo = 0.0;
+    double lim;
+    if (a.t_dir[i] != 0) { m.hi = a.mdt[i]; lim = hy_df_lt(rem, m) ? rem.hi : m.hi; }
+    else { m.hi = -a.mdt[i]; lim = hy_df_lt(m, rem) ? rem.hi : m.hi; }
+    a.lim[i] = lim;
+}
 
 extern "C" __global__ void __launch_bounds__(256) hy_grid_post(const hy_grid_args a)
 {

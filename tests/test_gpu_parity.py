@@ -941,3 +941,42 @@ def test_full_size_invariants_baseline_configs():
     n = 65536
     run("nbody64", hy.model.nbody(64), hy.model.nbody_energy(64), configs.plummer_nbody_state(64, n, seed=1234 + 42),
         0.03, 1e3 * EPS, 1e-10)
+
+
+def test_lockstep_device_loop_equals_host_loop(monkeypatch):
+    """propagate_until() with a callback / continuous output: the device-driven lock-step loop (post-step kernel, two
+    counters per sweep) reproduces the host transcription of the reference's loop (HEYOKA_AMD_LOCKSTEP_HOST_LOOP=1)
+    bit for bit: states, times, propagate_res, number of callback invocations, cb_stop / step_limit outcomes."""
+    n = 257
+    st = configs.two_body_state(n, perturb=1e-2, seed=12)
+    tf = 3.0 + 0.01 * np.arange(n)
+    res = {}
+    for name in ("device", "host"):
+        if name == "host":
+            monkeypatch.setenv("HEYOKA_AMD_LOCKSTEP_HOST_LOOP", "1")
+        calls = []
+        ta = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), st, n)
+        co, _ = ta.propagate_until(tf, callback=lambda t: calls.append(1) or True, max_delta_t=0.4, c_output=True)
+        r1 = (ta.state.copy(), ta.time.copy(), ta.propagate_res, len(calls), co.n_steps, co(1.7).copy())
+        tb = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), st, n)
+        tb.propagate_until(-5.0, callback=lambda t: len(calls) < r1[3] + 3 or False)
+        r2 = (tb.state.copy(), tb.propagate_res, len(calls))
+        calls.append(1)
+        tc = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), st, n)
+        tc.propagate_for(50.0, callback=lambda t: True, max_steps=4)
+        res[name] = (r1, r2, (tc.state.copy(), tc.propagate_res))
+    d, h = res["device"], res["host"]
+    assert np.array_equal(d[0][0], h[0][0]) and np.array_equal(d[0][1], h[0][1]) and d[0][2] == h[0][2]
+    assert d[0][3] == h[0][3] and d[0][4] == h[0][4] and np.array_equal(d[0][5], h[0][5])
+    assert np.array_equal(d[1][0], h[1][0]) and d[1][1] == h[1][1]
+    assert all(r[0] == OC.cb_stop for r in d[1][1])
+    assert np.array_equal(d[2][0], h[2][0]) and d[2][1] == h[2][1] and all(r[0] == OC.step_limit for r in d[2][1])
+    # A callback altering the time coordinate is rejected.
+    te = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), st, n)
+
+    def bad(t):
+        t.time = np.zeros(n)
+        return True
+
+    with pytest.raises(RuntimeError, match="alteration of the time coordinate"):
+        te.propagate_until(1.0, callback=bad)
