@@ -959,7 +959,7 @@ def test_lockstep_device_loop_equals_host_loop(monkeypatch):
         co, _ = ta.propagate_until(tf, callback=lambda t: calls.append(1) or True, max_delta_t=0.4, c_output=True)
         r1 = (ta.state.copy(), ta.time.copy(), ta.propagate_res, len(calls), co.n_steps, co(1.7).copy())
         tb = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), st, n)
-        tb.propagate_until(-5.0, callback=lambda t: len(calls) < r1[3] + 3 or False)
+        tb.propagate_until(-5.0, callback=lambda t: (calls.append(1) or True) and len(calls) < r1[3] + 3)
         r2 = (tb.state.copy(), tb.propagate_res, len(calls))
         calls.append(1)
         tc = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), st, n)
