@@ -109,6 +109,15 @@ __device__ __forceinline__ bool hy_df_lt(hy_df x, hy_df y)
     return (x.hi < y.hi) || (x.hi == y.hi && x.lo < y.lo);
 }
 
+// x^c for x >= 0, 0 < c < 1: the (1/p)-th roots of the step-size selector (src/taylor_00.cpp:242-252, llvm.pow in
+// the reference). exp(log(x) * c) has the same limits (0 -> 0, +inf -> +inf, nan -> nan) and agrees with pow() to
+// a few ulps (the error of log(x) is scaled by c < 1), for ~160 instructions less per step than the general-purpose
+// device pow().
+__device__ __forceinline__ double hy_root(double x, double c)
+{
+    return exp(log(x) * c);
+}
+
 // max(a, b) = (a < b) ? b : a and min(a, b) = (b < a) ? b : a
 // (reference: src/detail/llvm_helpers_cmp.cpp:315-329; NaN handling is part of the semantics).
 __device__ __forceinline__ double hy_max(double a, double b)
@@ -275,9 +284,9 @@ if (a.mode == 1) {
     };
     const auto m0 = max_abs(0), mo = max_abs(order), mom1 = max_abs(order - 1u);
     os << "const double num_rho = (" << m0 << " <= 1.0) ? 1.0 : " << m0 << ";\n";
-    os << "const double rho_o = pow(num_rho / " << mo << ", " << fp_literal(1. / static_cast<double>(order))
+    os << "const double rho_o = hy_root(num_rho / " << mo << ", " << fp_literal(1. / static_cast<double>(order))
        << ");\n";
-    os << "const double rho_om1 = pow(num_rho / " << mom1 << ", "
+    os << "const double rho_om1 = hy_root(num_rho / " << mom1 << ", "
        << fp_literal(1. / static_cast<double>(order - 1u)) << ");\n";
     os << "const double rho_m = hy_min(rho_o, rho_om1);\n";
     os << "double h = rho_m * " << fp_literal(rhofac(order)) << ";\n";

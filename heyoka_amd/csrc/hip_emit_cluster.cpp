@@ -886,8 +886,8 @@ if (a.mode == 1) {
         src << "mom1 = hy_max(mom1, __shfl_xor(mom1, " << m << ", 64));\n";
     }
     src << "const double num_rho = (m0 <= 1.0) ? 1.0 : m0;\n";
-    src << "const double rho_o = pow(num_rho / mo, " << fp_literal(1. / static_cast<double>(order)) << ");\n";
-    src << "const double rho_om1 = pow(num_rho / mom1, " << fp_literal(1. / static_cast<double>(order - 1u))
+    src << "const double rho_o = hy_root(num_rho / mo, " << fp_literal(1. / static_cast<double>(order)) << ");\n";
+    src << "const double rho_om1 = hy_root(num_rho / mom1, " << fp_literal(1. / static_cast<double>(order - 1u))
         << ");\n";
     src << "const double rho_m = hy_min(rho_o, rho_om1);\n";
     src << "double h = rho_m * " << fp_literal(rhofac(order)) << ";\n";

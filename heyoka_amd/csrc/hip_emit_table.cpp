@@ -432,8 +432,8 @@ extern "C" __global__ void __launch_bounds__(256, 4) hy_taylor(const hy_kargs a)
                 mom1 = hy_max(mom1, fabs(hy_tp(c, HY_ORDER - 1u, i)));
             }
             const double num_rho = (m0 <= 1.0) ? 1.0 : m0;
-            const double rho_o = pow(num_rho / mo, 1.0 / (double)HY_ORDER);
-            const double rho_om1 = pow(num_rho / mom1, 1.0 / (double)(HY_ORDER - 1u));
+            const double rho_o = hy_root(num_rho / mo, 1.0 / (double)HY_ORDER);
+            const double rho_om1 = hy_root(num_rho / mom1, 1.0 / (double)(HY_ORDER - 1u));
             const double rho_m = hy_min(rho_o, rho_om1);
             double h = rho_m * HY_RHOFAC;
             h = hy_min(h, fabs(lim));
