@@ -433,6 +433,10 @@ void device_buffer::upload(const void *src, std::size_t bytes, void *stream)
     }
     hip_check(hipMemcpyAsync(m_ptr, src, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)),
               "hipMemcpyAsync(H2D)");
+    // NOTE: the sources are pageable and often temporaries of the caller: an H2D copy from pageable memory may
+    // still be reading the source after hipMemcpyAsync() returns (the runtime can pin it in place), so the copy
+    // is completed here. No upload is on a timed path (the propagate loops are device-driven).
+    hip_check(hipStreamSynchronize(static_cast<hipStream_t>(stream)), "hipStreamSynchronize");
 }
 
 void device_buffer::download(void *dst, std::size_t bytes, void *stream) const

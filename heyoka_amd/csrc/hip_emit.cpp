@@ -106,8 +106,39 @@ __device__ __forceinline__ hy_df hy_df_sub(hy_df a, hy_df b)
 
 __device__ __forceinline__ bool hy_df_lt(hy_df x, hy_df y)
 {
-    return (x.hi < y.hi) || (x.hi == y.hi && x.lo < y.lo);
+    // NOTE: non-short-circuit operators on purpose (three compares and two mask operations, no control flow).
+    return (x.hi < y.hi) | ((x.hi == y.hi) & (x.lo < y.lo));
 }
+
+// End-of-step bookkeeping shared by all the steppers (reference: src/taylor_adaptive_batch.cpp:702-727 for the
+// outcome of a step, :1402-1460 for the propagate loop): non-finite state check, outcome, step counters, min/max
+// step size, remaining time, step limit. Written with selects and ONE (divergent) loop exit instead of a chain of
+// early breaks: see the note on HY_LIBM1 about divergent control flow in kernels under register pressure.
+// NF: the non-finite flag; COUNT: which thread reports it in the error counter.
+#define HY_STEP_TAIL(NF, COUNT)                                                                                        \
+    {                                                                                                                  \
+        const bool hy_nf = (NF);                                                                                       \
+        outcome = hy_nf ? HY_OC_ERR_NF_STATE : ((h == lim) ? HY_OC_TIME_LIMIT : HY_OC_SUCCESS);                       \
+        if (hy_nf & (COUNT)) atomicAdd(a.counters, 1u);                                                                \
+        bool hy_done = hy_nf | (a.mode != 1);                                                                          \
+        n_steps += (!hy_done & (h != 0.0)) ? 1u : 0u;                                                                  \
+        const bool hy_upd = !hy_done & (outcome == HY_OC_SUCCESS);                                                     \
+        const double hy_ah = fabs(h);                                                                                  \
+        min_h = hy_upd ? hy_min(min_h, hy_ah) : min_h;                                                                 \
+        max_h = hy_upd ? hy_max(max_h, hy_ah) : max_h;                                                                 \
+        hy_done |= (h == rem.hi);                                                                                      \
+        {                                                                                                              \
+            hy_df hy_tcur;                                                                                             \
+            hy_tcur.hi = t_hi;                                                                                         \
+            hy_tcur.lo = t_lo;                                                                                         \
+            rem = hy_df_sub(tfin, hy_tcur);                                                                            \
+        }                                                                                                              \
+        ++iter;                                                                                                        \
+        const bool hy_sl = !hy_done & (iter == a.max_steps);                                                           \
+        outcome = hy_sl ? HY_OC_STEP_LIMIT : outcome;                                                                  \
+        hy_done |= hy_sl;                                                                                              \
+        if (hy_done) break;                                                                                            \
+    }
 
 // x^c for x >= 0, 0 < c < 1: the (1/p)-th roots of the step-size selector (src/taylor_00.cpp:242-252, llvm.pow in
 // the reference). exp(log(x) * c) has the same limits (0 -> 0, +inf -> +inf, nan -> nan) and agrees with pow() to
@@ -116,6 +147,38 @@ __device__ __forceinline__ bool hy_df_lt(hy_df x, hy_df y)
 __device__ __forceinline__ double hy_root(double x, double c)
 {
     return exp(log(x) * c);
+}
+
+// Out-of-line calls for the math-library functions with data-dependent control flow in their device implementations
+// (the Payne-Hanek branch of sin/cos/tan, the piecewise ranges of erf, ...). Inlined into a straight-line kernel with
+// several hundred live registers, those divergent if/else regions are where the register allocator splits long live
+// ranges, and with this toolchain (ROCm 7.2) such a split can land in the exec-masked flow block between the two sides
+// of the branch: the copy is then executed only by the lanes which took the first side and the other lanes read
+// stale registers later on (observed as wild jet addresses in a 3500-statement kernel with tan()). As functions of
+// their own, the branches live in a small frame without register pressure and the kernel sees an ordinary call at
+// its current exec mask. One call per function instance and step (order 0 only): the cost is not measurable.
+#define HY_LIBM1(f)                                                                                                    \
+    static __device__ __attribute__((noinline)) double hy_##f(double x)                                                \
+    {                                                                                                                  \
+        return f(x);                                                                                                   \
+    }
+HY_LIBM1(sin)
+HY_LIBM1(cos)
+HY_LIBM1(tan)
+HY_LIBM1(tanh)
+HY_LIBM1(sinh)
+HY_LIBM1(cosh)
+HY_LIBM1(erf)
+HY_LIBM1(asin)
+HY_LIBM1(acos)
+HY_LIBM1(atan)
+HY_LIBM1(asinh)
+HY_LIBM1(acosh)
+HY_LIBM1(atanh)
+#undef HY_LIBM1
+static __device__ __attribute__((noinline)) double hy_pow(double x, double y)
+{
+    return pow(x, y);
 }
 
 // max(a, b) = (a < b) ? b : a and min(a, b) = (b < a) ? b : a
@@ -225,8 +288,11 @@ for (;;) {
 double lim;
 if (a.mode == 1) {
     hy_df m; m.lo = 0.0;
-    if (t_dir) { m.hi = mdt; lim = hy_df_lt(rem, m) ? rem.hi : m.hi; }
-    else { m.hi = -mdt; lim = hy_df_lt(m, rem) ? rem.hi : m.hi; }
+    // NOTE: selects, not an if/else on the (per-lane) direction: see the note on HY_LIBM1.
+    m.hi = t_dir ? mdt : -mdt;
+    const bool lt_fwd = hy_df_lt(rem, m), lt_bwd = hy_df_lt(m, rem);
+    const bool rem_first = (t_dir & lt_fwd) | (!t_dir & lt_bwd);
+    lim = rem_first ? rem.hi : m.hi;
 } else {
     lim = step_lim;
 }
@@ -384,32 +450,13 @@ if (a.mode == 1) {
     t_hi = nt.hi; t_lo = nt.lo;
 }
 last_h = h;
-bool nf = !(hy_finite(t_hi) && hy_finite(t_lo));
+bool nf = !(hy_finite(t_hi) & hy_finite(t_lo));
 )HIP";
     for (std::uint32_t i = 0; i < n_eq; ++i) {
-        os << "nf = nf || !hy_finite(x" << i << ");\n";
+        os << "nf = nf | !hy_finite(x" << i << ");\n";
     }
     os << R"HIP(
-if (nf) {
-    outcome = HY_OC_ERR_NF_STATE;
-    atomicAdd(a.counters, 1u);
-    break;
-}
-outcome = (h == lim) ? HY_OC_TIME_LIMIT : HY_OC_SUCCESS;
-if (a.mode != 1) break;
-n_steps += (h != 0.0) ? 1u : 0u;
-if (outcome == HY_OC_SUCCESS) {
-    const double ah = fabs(h);
-    min_h = hy_min(min_h, ah);
-    max_h = hy_max(max_h, ah);
-}
-if (h == rem.hi) break;
-{
-    hy_df tcur; tcur.hi = t_hi; tcur.lo = t_lo;
-    rem = hy_df_sub(tfin, tcur);
-}
-++iter;
-if (iter == a.max_steps) { outcome = HY_OC_STEP_LIMIT; break; }
+HY_STEP_TAIL(nf, true)
 }
 )HIP";
     if (!p.ev_u.empty() && !reg_jets) {

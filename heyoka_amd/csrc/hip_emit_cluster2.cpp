@@ -597,8 +597,11 @@ for (;;) {
 double lim;
 if (a.mode == 1) {
     hy_df m; m.lo = 0.0;
-    if (t_dir) { m.hi = mdt; lim = hy_df_lt(rem, m) ? rem.hi : m.hi; }
-    else { m.hi = -mdt; lim = hy_df_lt(m, rem) ? rem.hi : m.hi; }
+    // NOTE: selects, not an if/else on the (per-lane) direction: see the note on HY_LIBM1.
+    m.hi = t_dir ? mdt : -mdt;
+    const bool lt_fwd = hy_df_lt(rem, m), lt_bwd = hy_df_lt(m, rem);
+    const bool rem_first = (t_dir & lt_fwd) | (!t_dir & lt_bwd);
+    lim = rem_first ? rem.hi : m.hi;
 } else {
     lim = step_lim;
 }
@@ -663,26 +666,7 @@ int nfi = !(hy_finite(t_hi) && hy_finite(t_lo)) ? 1 : 0;
     }
     src << R"HIP(
 }
-if (nfi != 0) {
-    outcome = HY_OC_ERR_NF_STATE;
-    if (l == 0u && live) atomicAdd(a.counters, 1u);
-    break;
-}
-outcome = (h == lim) ? HY_OC_TIME_LIMIT : HY_OC_SUCCESS;
-if (a.mode != 1) break;
-n_steps += (h != 0.0) ? 1u : 0u;
-if (outcome == HY_OC_SUCCESS) {
-    const double ah = fabs(h);
-    min_h = hy_min(min_h, ah);
-    max_h = hy_max(max_h, ah);
-}
-if (h == rem.hi) break;
-{
-    hy_df tcur; tcur.hi = t_hi; tcur.lo = t_lo;
-    rem = hy_df_sub(tfin, tcur);
-}
-++iter;
-if (iter == a.max_steps) { outcome = HY_OC_STEP_LIMIT; break; }
+HY_STEP_TAIL(nfi != 0, l == 0u && live)
 }
 )HIP";
     for (const auto &rg : rounds) {

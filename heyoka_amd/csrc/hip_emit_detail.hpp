@@ -151,7 +151,7 @@ struct ssa_emitter {
                 return def("1.0 / " + tmp);
             }
         }
-        return def("pow(" + b + ", " + fp_literal(ex) + ")");
+        return def("hy_pow(" + b + ", " + fp_literal(ex) + ")");
     }
 
     // Emit the order-k coefficient of node i.
@@ -367,12 +367,12 @@ struct ssa_emitter {
                 // Reference: src/math/sin.cpp:152-192, src/math/cos.cpp:152-185.
                 const bool is_sin = n.kind == func_kind::sin;
                 if (!is_var(a[0])) {
-                    out = (k == 0u) ? def(std::string(is_sin ? "sin(" : "cos(") + numpar(a[0]) + ")") : "0.0";
+                    out = (k == 0u) ? def(std::string(is_sin ? "hy_sin(" : "hy_cos(") + numpar(a[0]) + ")") : "0.0";
                     break;
                 }
                 const auto b = a[0].idx;
                 if (k == 0u) {
-                    out = def(std::string(is_sin ? "sin(" : "cos(") + val(b, 0) + ")");
+                    out = def(std::string(is_sin ? "hy_sin(" : "hy_cos(") + val(b, 0) + ")");
                 } else {
                     if (n.deps.size() != 1u) {
                         throw std::invalid_argument("A hidden dependency vector of size 1 is expected in order to "
@@ -452,7 +452,7 @@ struct ssa_emitter {
                 //   sigmoid: a^[k] = S/k, X = a - a^2                            src/math/sigmoid.cpp:150-172
                 const auto fname = std::string(func_kind_name(n.kind));
                 const auto order0 = [&](const std::string &x) {
-                    return n.kind == func_kind::sigmoid ? def("1.0 / (1.0 + exp(-(" + x + ")))") : def(fname + "(" + x + ")");
+                    return n.kind == func_kind::sigmoid ? def("1.0 / (1.0 + exp(-(" + x + ")))") : def("hy_" + fname + "(" + x + ")");
                 };
                 if (!is_var(a[0])) {
                     out = (k == 0u) ? order0(numpar(a[0])) : "0.0";
@@ -505,12 +505,12 @@ struct ssa_emitter {
                 //   acosh: D = c0 = sqrt(b0^2 - 1), minus             src/math/acosh.cpp
                 const auto fname = std::string(func_kind_name(n.kind));
                 if (!is_var(a[0])) {
-                    out = (k == 0u) ? def(fname + "(" + numpar(a[0]) + ")") : "0.0";
+                    out = (k == 0u) ? def("hy_" + fname + "(" + numpar(a[0]) + ")") : "0.0";
                     break;
                 }
                 const auto b = a[0].idx;
                 if (k == 0u) {
-                    out = def(fname + "(" + val(b, 0) + ")");
+                    out = def("hy_" + fname + "(" + val(b, 0) + ")");
                     break;
                 }
                 if (n.deps.size() != 1u) {

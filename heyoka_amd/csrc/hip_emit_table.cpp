@@ -110,7 +110,7 @@ __device__ double hy_pow_eval(double b, double ex)
             return 1.0 / hy_pow_ebs(t, (unsigned)(-y));
         }
     }
-    return pow(b, ex);
+    return hy_pow(b, ex);
 }
 
 // ---- one device function per elementary function (the reference's taylor_c_diff_func layer) ----
@@ -237,10 +237,10 @@ __device__ double hy_diff_sincos(const hy_tctx &c, unsigned a0, unsigned dep, un
 {
     if (hy_arg_type[a0] != A_UVAR) {
         const double v = hy_numpar(c, a0);
-        return k == 0u ? (is_sin ? sin(v) : cos(v)) : 0.0;
+        return k == 0u ? (is_sin ? hy_sin(v) : hy_cos(v)) : 0.0;
     }
     const unsigned b = hy_arg_idx[a0];
-    if (k == 0u) return is_sin ? sin(hy_tp(c, 0, b)) : cos(hy_tp(c, 0, b));
+    if (k == 0u) return is_sin ? hy_sin(hy_tp(c, 0, b)) : hy_cos(hy_tp(c, 0, b));
     double acc = 0.0;
     for (unsigned j = 1; j <= k; ++j) acc += (double)j * (hy_tp(c, k - j, dep) * hy_tp(c, j, b));
     return acc / (is_sin ? (double)k : -(double)k);
@@ -273,18 +273,18 @@ __device__ double hy_diff_log(const hy_tctx &c, unsigned a0, unsigned u, unsigne
 __device__ double hy_unary0(unsigned kind, double x)
 {
     switch (kind) {
-        case K_TAN: return tan(x);
-        case K_TANH: return tanh(x);
-        case K_SINH: return sinh(x);
-        case K_COSH: return cosh(x);
-        case K_ERF: return erf(x);
+        case K_TAN: return hy_tan(x);
+        case K_TANH: return hy_tanh(x);
+        case K_SINH: return hy_sinh(x);
+        case K_COSH: return hy_cosh(x);
+        case K_ERF: return hy_erf(x);
         case K_SIGMOID: return 1.0 / (1.0 + exp(-x));
-        case K_ASIN: return asin(x);
-        case K_ACOS: return acos(x);
-        case K_ATAN: return atan(x);
-        case K_ASINH: return asinh(x);
-        case K_ACOSH: return acosh(x);
-        default: return atanh(x);
+        case K_ASIN: return hy_asin(x);
+        case K_ACOS: return hy_acos(x);
+        case K_ATAN: return hy_atan(x);
+        case K_ASINH: return hy_asinh(x);
+        case K_ACOSH: return hy_acosh(x);
+        default: return hy_atanh(x);
     }
 }
 
@@ -406,8 +406,11 @@ extern "C" __global__ void __launch_bounds__(256, 4) hy_taylor(const hy_kargs a)
             double lim;
             if (a.mode == 1) {
                 hy_df m; m.lo = 0.0;
-                if (t_dir) { m.hi = mdt; lim = hy_df_lt(rem, m) ? rem.hi : m.hi; }
-                else { m.hi = -mdt; lim = hy_df_lt(m, rem) ? rem.hi : m.hi; }
+                // NOTE: selects, not an if/else on the (per-lane) direction: see the note on HY_LIBM1.
+                m.hi = t_dir ? mdt : -mdt;
+                const bool lt_fwd = hy_df_lt(rem, m), lt_bwd = hy_df_lt(m, rem);
+                const bool rem_first = (t_dir & lt_fwd) | (!t_dir & lt_bwd);
+                lim = rem_first ? rem.hi : m.hi;
             } else {
                 lim = step_lim;
             }
@@ -478,7 +481,7 @@ extern "C" __global__ void __launch_bounds__(256, 4) hy_taylor(const hy_kargs a)
                 for (unsigned k = 1; k <= HY_ORDER; ++k) res = hy_tp(c, HY_ORDER - k, i) + res * h;
 #endif
                 hy_tp(c, 0, i) = res;
-                nf = nf || !hy_finite(res);
+                nf = nf | !hy_finite(res);
             }
             {
                 hy_df tcur; tcur.hi = t_hi; tcur.lo = t_lo;
@@ -487,27 +490,8 @@ extern "C" __global__ void __launch_bounds__(256, 4) hy_taylor(const hy_kargs a)
                 t_hi = nt.hi; t_lo = nt.lo;
             }
             last_h = h;
-            nf = nf || !(hy_finite(t_hi) && hy_finite(t_lo));
-            if (nf) {
-                outcome = HY_OC_ERR_NF_STATE;
-                atomicAdd(a.counters, 1u);
-                break;
-            }
-            outcome = (h == lim) ? HY_OC_TIME_LIMIT : HY_OC_SUCCESS;
-            if (a.mode != 1) break;
-            n_steps += (h != 0.0) ? 1u : 0u;
-            if (outcome == HY_OC_SUCCESS) {
-                const double ah = fabs(h);
-                min_h = hy_min(min_h, ah);
-                max_h = hy_max(max_h, ah);
-            }
-            if (h == rem.hi) break;
-            {
-                hy_df tcur; tcur.hi = t_hi; tcur.lo = t_lo;
-                rem = hy_df_sub(tfin, tcur);
-            }
-            ++iter;
-            if (iter == a.max_steps) { outcome = HY_OC_STEP_LIMIT; break; }
+            nf = nf | !(hy_finite(t_hi) & hy_finite(t_lo));
+            HY_STEP_TAIL(nf, true)
         }
         if (a.mode == 4) {
             a.last_h[s] = last_h;
