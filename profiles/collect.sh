@@ -22,7 +22,7 @@ for WL in outer_ss two_body nbody64; do
   timeout 600 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pf_$WL" -o pf -- $CMD > "$OUT/pf_$WL.log" 2>&1
   timeout 600 rocprofv3 --pmc WRITE_SIZE -d "$OUT/pw_$WL" -o pw -- $CMD > "$OUT/pw_$WL.log" 2>&1
   python profiles/summarize_rocprof.py "$OUT/${TAG}_$WL" "$(find $OUT/kt_$WL -name '*.db' | head -1)" \
-      "$(find $OUT/pf_$WL -name '*.db' | head -1)" "$(find $OUT/pw_$WL -name '*.db' | head -1)" "$OUT/pf_$WL.log" \
+      "$(find $OUT/pf_$WL -name '*.db' | head -1)" "$(find $OUT/pw_$WL -name '*.db' | head -1)" "$OUT/pf_$WL.log" "$OUT/kt_$WL.log" \
       > "$OUT/summary_$WL.log" 2>&1
   tail -8 "$OUT/summary_$WL.log"
   find "$OUT" -name '*.db' -size +8M -delete

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Summarise rocprofv3 (rocpd sqlite) outputs into the small text/JSON files kept under profiles/.
 
-usage: python profiles/summarize_rocprof.py <out_prefix> <ktrace.db> [<pmc_fetch.db> <pmc_write.db> [<bench.log>]]
+usage: python profiles/summarize_rocprof.py <out_prefix> <ktrace.db> [<pmc_fetch.db> <pmc_write.db> [<pmc_bench.log> [<ktrace_bench.log>]]]
 Writes <out_prefix>_kernel_stats.txt (per-kernel calls / total / avg / min / max, like
 `rocprofv3 --kernel-trace --stats`) and, if counter databases are given, <out_prefix>_pmc.json with
 the per-dispatch FETCH_SIZE / WRITE_SIZE of the stepper kernel (KiB, as reported) and the derived HBM
@@ -20,6 +20,14 @@ def kernel_stats(path):
     lines = ["%-64s %6s %14s %14s %14s %14s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "pct")]
     for r in rows[:12]:
         lines.append("%-64s %6d %14d %14.0f %14d %14d %6.2f%%" % (r[0][:64], r[1], r[2], r[3], r[4], r[5], 100.0 * r[2] / tot))
+    # The stepper launches one by one: the first is the bench's warmup, the others are the timed region whose
+    # average bench.py reports as roofline.kernel_ms_avg (HIP events around the same launches).
+    per = [r[0] for r in cur.execute("select end - start from kernels where name = 'hy_taylor' order by start")]
+    if len(per) > 1:
+        timed = per[1:]
+        lines.append("")
+        lines.append("hy_taylor launches in order (ns): " + " ".join(str(x) for x in per))
+        lines.append("hy_taylor timed launches (all but the warmup launch): n = %d, avg_ns = %.0f" % (len(timed), sum(timed) / len(timed)))
     return "\n".join(lines), rows
 
 
@@ -37,6 +45,13 @@ def main():
     with open(prefix + "_kernel_stats.txt", "w") as f:
         f.write("# rocprofv3 --kernel-trace --stats (rocpd database summarised by profiles/summarize_rocprof.py)\n")
         f.write(txt + "\n")
+        if len(sys.argv) >= 7:
+            # The bench line printed by the traced run itself: its kernel_ms_avg is measured with HIP events.
+            for line in open(sys.argv[6]):
+                if line.startswith("{"):
+                    b = json.loads(line)
+                    f.write("bench.py (same run) roofline.kernel_ms_avg = %.6f ms, value = %.6g %s\n"
+                            % (b["roofline"]["kernel_ms_avg"], b["value"], b["unit"]))
     print(txt)
     if len(sys.argv) >= 5:
         fe, wr = counters(sys.argv[3]), counters(sys.argv[4])
