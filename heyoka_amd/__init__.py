@@ -356,6 +356,96 @@ class model:
         return expression(_handle=check_handle(lib.hy_model_pendulum_energy(float(gconst), float(length))))
 
 
+    # ---- the other point-mass models ----
+    @staticmethod
+    def _ex_array(values):
+        """Sequence of numbers / expressions -> (ctypes array of handles, n, keep-alive list)."""
+        exs = [_as_ex(v) for v in (values if values is not None else [])]
+        arr = (ctypes.c_void_p * len(exs))(*[e._h for e in exs]) if exs else None
+        return arr, len(exs), exs
+
+    @staticmethod
+    def np1body(n, masses=None, Gconst=1.0):
+        """model::np1body() (src/model/nbody.cpp:236-325): n bodies in the frame of body 0."""
+        arr, nm, g, _keep = model._nbody_args(masses, Gconst)
+        return _Sys(_handle=check_handle(lib.hy_model_np1body(int(n), arr, nm, g)))
+
+    @staticmethod
+    def np1body_energy(n, masses=None, Gconst=1.0):
+        arr, nm, g, _keep = model._nbody_args(masses, Gconst)
+        return expression(_handle=check_handle(lib.hy_model_np1body_energy(int(n), arr, nm, g)))
+
+    @staticmethod
+    def np1body_potential(n, masses=None, Gconst=1.0):
+        arr, nm, g, _keep = model._nbody_args(masses, Gconst)
+        return expression(_handle=check_handle(lib.hy_model_np1body_potential(int(n), arr, nm, g)))
+
+    @staticmethod
+    def cr3bp(mu=1e-3):
+        """model::cr3bp() (src/model/cr3bp.cpp): state x, y, z, px, py, pz."""
+        m = _as_ex(mu)
+        return _Sys(_handle=check_handle(lib.hy_model_cr3bp(m._h)))
+
+    @staticmethod
+    def cr3bp_jacobi(mu=1e-3):
+        m = _as_ex(mu)
+        return expression(_handle=check_handle(lib.hy_model_cr3bp_jacobi(m._h)))
+
+    @staticmethod
+    def _fc_call(fn, Gconst, masses, positions, omega=None, with_omega=False, sys_=False):
+        g = _as_ex(Gconst)
+        ma, nm, k1 = model._ex_array(masses)
+        pa, npos, k2 = model._ex_array(positions)
+        args = [g._h, ma, nm, pa, npos]
+        if with_omega:
+            oa, no, k3 = model._ex_array(omega)
+            args += [oa, no]
+        h = check_handle(fn(*args))
+        return _Sys(_handle=h) if sys_ else expression(_handle=h)
+
+    @staticmethod
+    def fixed_centres(Gconst=1.0, masses=(), positions=()):
+        """model::fixed_centres() (src/model/fixed_centres.cpp): state x, y, z, vx, vy, vz."""
+        return model._fc_call(lib.hy_model_fixed_centres, Gconst, masses, positions, sys_=True)
+
+    @staticmethod
+    def fixed_centres_energy(Gconst=1.0, masses=(), positions=()):
+        return model._fc_call(lib.hy_model_fixed_centres_energy, Gconst, masses, positions)
+
+    @staticmethod
+    def fixed_centres_potential(Gconst=1.0, masses=(), positions=()):
+        return model._fc_call(lib.hy_model_fixed_centres_potential, Gconst, masses, positions)
+
+    @staticmethod
+    def rotating(omega=()):
+        """model::rotating() (src/model/rotating.cpp)."""
+        oa, no, _k = model._ex_array(omega)
+        return _Sys(_handle=check_handle(lib.hy_model_rotating(oa, no)))
+
+    @staticmethod
+    def rotating_energy(omega=()):
+        oa, no, _k = model._ex_array(omega)
+        return expression(_handle=check_handle(lib.hy_model_rotating_energy(oa, no)))
+
+    @staticmethod
+    def rotating_potential(omega=()):
+        oa, no, _k = model._ex_array(omega)
+        return expression(_handle=check_handle(lib.hy_model_rotating_potential(oa, no)))
+
+    @staticmethod
+    def mascon(Gconst=1.0, masses=(), positions=(), omega=()):
+        """model::mascon() (src/model/mascon.cpp): fixed centres in a uniformly rotating frame."""
+        return model._fc_call(lib.hy_model_mascon, Gconst, masses, positions, omega, with_omega=True, sys_=True)
+
+    @staticmethod
+    def mascon_energy(Gconst=1.0, masses=(), positions=(), omega=()):
+        return model._fc_call(lib.hy_model_mascon_energy, Gconst, masses, positions, omega, with_omega=True)
+
+    @staticmethod
+    def mascon_potential(Gconst=1.0, masses=(), positions=(), omega=()):
+        return model._fc_call(lib.hy_model_mascon_potential, Gconst, masses, positions, omega, with_omega=True)
+
+
 def taylor_decompose_sys(sys):
     """taylor_decompose_sys() (src/taylor_01.cpp:848-1008) -> list of textual entries."""
     s = _to_sys(sys)

@@ -161,6 +161,20 @@ SIGNATURES = [
     ("hy_model_nbody_energy", c_void_p, [c_uint32, c_void_p, c_size_t, c_void_p]),
     ("hy_model_nbody_potential", c_void_p, [c_uint32, c_void_p, c_size_t, c_void_p]),
     ("hy_model_pendulum_energy", c_void_p, [c_double, c_double]),
+    ("hy_model_np1body", c_void_p, [c_uint32, c_void_p, c_size_t, c_void_p]),
+    ("hy_model_np1body_energy", c_void_p, [c_uint32, c_void_p, c_size_t, c_void_p]),
+    ("hy_model_np1body_potential", c_void_p, [c_uint32, c_void_p, c_size_t, c_void_p]),
+    ("hy_model_cr3bp", c_void_p, [c_void_p]),
+    ("hy_model_cr3bp_jacobi", c_void_p, [c_void_p]),
+    ("hy_model_fixed_centres", c_void_p, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t]),
+    ("hy_model_fixed_centres_energy", c_void_p, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t]),
+    ("hy_model_fixed_centres_potential", c_void_p, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t]),
+    ("hy_model_rotating", c_void_p, [c_void_p, c_size_t]),
+    ("hy_model_rotating_energy", c_void_p, [c_void_p, c_size_t]),
+    ("hy_model_rotating_potential", c_void_p, [c_void_p, c_size_t]),
+    ("hy_model_mascon", c_void_p, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t]),
+    ("hy_model_mascon_energy", c_void_p, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t]),
+    ("hy_model_mascon_potential", c_void_p, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t]),
     ("hy_sys_get_vars", c_int, [c_void_p, c_void_p]),
     ("hy_compile_aux_kernels", c_int, [c_uint32, c_uint32, c_int]),
     ("hy_cfunc_new", c_void_p, [c_void_p, c_size_t, c_void_p, c_size_t, c_int]),

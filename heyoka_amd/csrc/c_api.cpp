@@ -395,6 +395,127 @@ hy_expr hy_model_nbody_potential(uint32_t n, const hy_expr *masses, size_t n_mas
         return model::detail::nbody_potential_impl(n, G, mv);
     });
 }
+extern "C++" {
+namespace
+{
+
+std::vector<expression> expr_vector(const hy_expr *v, size_t n)
+{
+    std::vector<expression> ret;
+    for (size_t i = 0; v != nullptr && i < n; ++i) {
+        ret.push_back(v[i]->ex);
+    }
+    return ret;
+}
+
+template <typename F>
+hy_sys make_sys(F &&f)
+{
+    try {
+        return new hy_sys_s{f()};
+    } catch (...) {
+        handle_exception();
+        return nullptr;
+    }
+}
+
+expression or_default(hy_expr e, double def)
+{
+    return e == nullptr ? expression{def} : e->ex;
+}
+
+} // namespace
+} // extern "C++"
+
+hy_sys hy_model_np1body(uint32_t n, const hy_expr *masses, size_t n_masses, hy_expr Gconst)
+{
+    return make_sys([&] {
+        auto [G, mv] = model_args(n, masses, n_masses, Gconst);
+        return model::detail::np1body_impl(n, G, mv);
+    });
+}
+hy_expr hy_model_np1body_energy(uint32_t n, const hy_expr *masses, size_t n_masses, hy_expr Gconst)
+{
+    return make_expr([&] {
+        auto [G, mv] = model_args(n, masses, n_masses, Gconst);
+        return model::detail::np1body_energy_impl(n, G, mv);
+    });
+}
+hy_expr hy_model_np1body_potential(uint32_t n, const hy_expr *masses, size_t n_masses, hy_expr Gconst)
+{
+    return make_expr([&] {
+        auto [G, mv] = model_args(n, masses, n_masses, Gconst);
+        return model::detail::np1body_potential_impl(n, G, mv);
+    });
+}
+hy_sys hy_model_cr3bp(hy_expr mu)
+{
+    return make_sys([&] { return model::detail::cr3bp_impl(or_default(mu, 1e-3)); });
+}
+hy_expr hy_model_cr3bp_jacobi(hy_expr mu)
+{
+    return make_expr([&] { return model::detail::cr3bp_jacobi_impl(or_default(mu, 1e-3)); });
+}
+hy_sys hy_model_fixed_centres(hy_expr Gconst, const hy_expr *masses, size_t n_masses, const hy_expr *positions,
+                              size_t n_positions)
+{
+    return make_sys([&] {
+        return model::detail::fixed_centres_impl(or_default(Gconst, 1.), expr_vector(masses, n_masses),
+                                                 expr_vector(positions, n_positions));
+    });
+}
+hy_expr hy_model_fixed_centres_energy(hy_expr Gconst, const hy_expr *masses, size_t n_masses, const hy_expr *positions,
+                                      size_t n_positions)
+{
+    return make_expr([&] {
+        return model::detail::fixed_centres_energy_impl(or_default(Gconst, 1.), expr_vector(masses, n_masses),
+                                                        expr_vector(positions, n_positions));
+    });
+}
+hy_expr hy_model_fixed_centres_potential(hy_expr Gconst, const hy_expr *masses, size_t n_masses,
+                                         const hy_expr *positions, size_t n_positions)
+{
+    return make_expr([&] {
+        return model::detail::fixed_centres_potential_impl(or_default(Gconst, 1.), expr_vector(masses, n_masses),
+                                                           expr_vector(positions, n_positions));
+    });
+}
+hy_sys hy_model_rotating(const hy_expr *omega, size_t n_omega)
+{
+    return make_sys([&] { return model::detail::rotating_impl(expr_vector(omega, n_omega)); });
+}
+hy_expr hy_model_rotating_energy(const hy_expr *omega, size_t n_omega)
+{
+    return make_expr([&] { return model::detail::rotating_energy_impl(expr_vector(omega, n_omega)); });
+}
+hy_expr hy_model_rotating_potential(const hy_expr *omega, size_t n_omega)
+{
+    return make_expr([&] { return model::detail::rotating_potential_impl(expr_vector(omega, n_omega)); });
+}
+hy_sys hy_model_mascon(hy_expr Gconst, const hy_expr *masses, size_t n_masses, const hy_expr *positions,
+                       size_t n_positions, const hy_expr *omega, size_t n_omega)
+{
+    return make_sys([&] {
+        return model::detail::mascon_impl(or_default(Gconst, 1.), expr_vector(masses, n_masses),
+                                          expr_vector(positions, n_positions), expr_vector(omega, n_omega));
+    });
+}
+hy_expr hy_model_mascon_energy(hy_expr Gconst, const hy_expr *masses, size_t n_masses, const hy_expr *positions,
+                               size_t n_positions, const hy_expr *omega, size_t n_omega)
+{
+    return make_expr([&] {
+        return model::detail::mascon_energy_impl(or_default(Gconst, 1.), expr_vector(masses, n_masses),
+                                                 expr_vector(positions, n_positions), expr_vector(omega, n_omega));
+    });
+}
+hy_expr hy_model_mascon_potential(hy_expr Gconst, const hy_expr *masses, size_t n_masses, const hy_expr *positions,
+                                  size_t n_positions, const hy_expr *omega, size_t n_omega)
+{
+    return make_expr([&] {
+        return model::detail::mascon_potential_impl(or_default(Gconst, 1.), expr_vector(masses, n_masses),
+                                                    expr_vector(positions, n_positions), expr_vector(omega, n_omega));
+    });
+}
 hy_expr hy_model_pendulum_energy(double gconst, double length)
 {
     return make_expr([&] { return model::detail::pendulum_energy_impl(expression{gconst}, expression{length}); });

@@ -233,6 +233,25 @@ struct par_impl {
 };
 inline constexpr par_impl par{};
 
+// "x"_var, 2_dbl / 1.5_dbl (reference: inline namespace literals, include/heyoka/expression.hpp:122-146).
+inline namespace literals
+{
+
+inline expression operator""_var(const char *s, std::size_t n)
+{
+    return expression{std::string(s, n)};
+}
+inline expression operator""_dbl(long double x)
+{
+    return expression{static_cast<double>(x)};
+}
+inline expression operator""_dbl(unsigned long long n)
+{
+    return expression{static_cast<double>(n)};
+}
+
+} // namespace literals
+
 // make_vars("x", "v") -> array of variable expressions.
 template <typename... Args>
 inline auto make_vars(const Args &...names)

@@ -73,6 +73,9 @@ HEYOKA_AMD_KWARG(masses);
 HEYOKA_AMD_KWARG(Gconst);
 HEYOKA_AMD_KWARG(gconst);
 HEYOKA_AMD_KWARG(length);
+HEYOKA_AMD_KWARG(mu);
+HEYOKA_AMD_KWARG(positions);
+HEYOKA_AMD_KWARG(omega);
 // MI355X-specific extension: select the device ordinal.
 HEYOKA_AMD_KWARG(device);
 

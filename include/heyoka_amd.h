@@ -111,6 +111,35 @@ hy_sys hy_model_nbody_ex(uint32_t n, const hy_expr *masses, size_t n_masses, hy_
 hy_expr hy_model_nbody_energy(uint32_t n, const hy_expr *masses, size_t n_masses, hy_expr Gconst);
 hy_expr hy_model_nbody_potential(uint32_t n, const hy_expr *masses, size_t n_masses, hy_expr Gconst);
 hy_expr hy_model_pendulum_energy(double gconst, double length);
+/* The other point-mass models. Expression arguments are numbers or par[i]; a NULL
+ * Gconst / mu selects the reference's default (1 resp. 1e-3), an empty omega a non-rotating frame.
+ *   model::np1body / np1body_energy / np1body_potential  include/heyoka/model/nbody.hpp:94-120, src/model/nbody.cpp:236-445
+ *   model::cr3bp / cr3bp_jacobi                          include/heyoka/model/cr3bp.hpp:30-64, src/model/cr3bp.cpp
+ *   model::fixed_centres{,_energy,_potential}            include/heyoka/model/fixed_centres.hpp, src/model/fixed_centres.cpp
+ *   model::rotating{,_energy,_potential}                 include/heyoka/model/rotating.hpp, src/model/rotating.cpp
+ *   model::mascon{,_energy,_potential}                   include/heyoka/model/mascon.hpp, src/model/mascon.cpp
+ * State variables: x_i, y_i, z_i, vx_i, vy_i, vz_i (i = 1..n-1) for np1body; x, y, z, px, py, pz for cr3bp;
+ * x, y, z, vx, vy, vz for the others. positions holds 3 entries per mass. */
+hy_sys hy_model_np1body(uint32_t n, const hy_expr *masses, size_t n_masses, hy_expr Gconst);
+hy_expr hy_model_np1body_energy(uint32_t n, const hy_expr *masses, size_t n_masses, hy_expr Gconst);
+hy_expr hy_model_np1body_potential(uint32_t n, const hy_expr *masses, size_t n_masses, hy_expr Gconst);
+hy_sys hy_model_cr3bp(hy_expr mu);
+hy_expr hy_model_cr3bp_jacobi(hy_expr mu);
+hy_sys hy_model_fixed_centres(hy_expr Gconst, const hy_expr *masses, size_t n_masses, const hy_expr *positions,
+                              size_t n_positions);
+hy_expr hy_model_fixed_centres_energy(hy_expr Gconst, const hy_expr *masses, size_t n_masses, const hy_expr *positions,
+                                      size_t n_positions);
+hy_expr hy_model_fixed_centres_potential(hy_expr Gconst, const hy_expr *masses, size_t n_masses,
+                                         const hy_expr *positions, size_t n_positions);
+hy_sys hy_model_rotating(const hy_expr *omega, size_t n_omega);
+hy_expr hy_model_rotating_energy(const hy_expr *omega, size_t n_omega);
+hy_expr hy_model_rotating_potential(const hy_expr *omega, size_t n_omega);
+hy_sys hy_model_mascon(hy_expr Gconst, const hy_expr *masses, size_t n_masses, const hy_expr *positions,
+                       size_t n_positions, const hy_expr *omega, size_t n_omega);
+hy_expr hy_model_mascon_energy(hy_expr Gconst, const hy_expr *masses, size_t n_masses, const hy_expr *positions,
+                               size_t n_positions, const hy_expr *omega, size_t n_omega);
+hy_expr hy_model_mascon_potential(hy_expr Gconst, const hy_expr *masses, size_t n_masses, const hy_expr *positions,
+                                  size_t n_positions, const hy_expr *omega, size_t n_omega);
 /* The state variables of a system, in order (the lhs of each equation); out[hy_sys_size()] receives new
  * handles owned by the caller. */
 int hy_sys_get_vars(hy_sys, hy_expr *out);

@@ -352,6 +352,120 @@ def pendulum(gconst=1.0, length=1.0):
     return [(x, v), (v, -as_ex(gconst) / as_ex(length) * sin(x))]
 
 
+def _r2(dx, dy, dz):
+    return sum_([pow_(dx, 2.0), pow_(dy, 2.0), pow_(dz, 2.0)])
+
+
+def np1body(n, masses=None, Gconst=1.0):
+    """N+1 bodies in the frame of body 0 (reference: src/model/nbody.cpp:236-325)."""
+    masses = [as_ex(1.0)] * n if masses is None else [as_ex(m) for m in masses]
+    G = as_ex(Gconst)
+    if n < 2 or len(masses) > n:
+        raise ValueError("invalid N-body configuration")
+    rng = range(1, n)
+    x = [var("x_%d" % i) for i in rng]
+    y = [var("y_%d" % i) for i in rng]
+    z = [var("z_%d" % i) for i in rng]
+    vx = [var("vx_%d" % i) for i in rng]
+    vy = [var("vy_%d" % i) for i in rng]
+    vz = [var("vz_%d" % i) for i in rng]
+    rm3 = [pow_(_r2(x[i], y[i], z[i]), num(-3.0 / 2)) for i in range(n - 1)]
+    xr3 = [x[i] * rm3[i] for i in range(n - 1)]
+    yr3 = [y[i] * rm3[i] for i in range(n - 1)]
+    zr3 = [z[i] * rm3[i] for i in range(n - 1)]
+    nm = len(masses)
+    sys = []
+    for i in range(n - 1):
+        sys += [(x[i], vx[i]), (y[i], vy[i]), (z[i], vz[i])]
+        m0 = masses[0] if nm > 0 else num(0.0)
+        mi = masses[i + 1] if i + 1 < nm else num(0.0)
+        mu0i = -G * (m0 + mi)
+        ax, ay, az = [mu0i * xr3[i]], [mu0i * yr3[i]], [mu0i * zr3[i]]
+        for j in range(max(nm - 1, 0)):
+            if j == i:
+                continue
+            fwd = j > i
+            dx = x[j] - x[i] if fwd else x[i] - x[j]
+            dy = y[j] - y[i] if fwd else y[i] - y[j]
+            dz = z[j] - z[i] if fwd else z[i] - z[j]
+            drm3 = pow_(_r2(dx, dy, dz), num(-1.5))
+            mu = G * masses[j + 1]
+            tx, ty, tz = mu * (dx * drm3), mu * (dy * drm3), mu * (dz * drm3)
+            ax.append(tx if fwd else -tx)
+            ay.append(ty if fwd else -ty)
+            az.append(tz if fwd else -tz)
+            ax.append(-mu * xr3[j])
+            ay.append(-mu * yr3[j])
+            az.append(-mu * zr3[j])
+        sys += [(vx[i], sum_(ax)), (vy[i], sum_(ay)), (vz[i], sum_(az))]
+    return sys
+
+
+def _cr3bp_check(mu):
+    if mu.is_num() and not (np.isfinite(mu.val) and 0 < mu.val < 0.5):
+        raise ValueError("The 'mu' parameter in a CR3BP must be in the range (0, 0.5)")
+
+
+def cr3bp(mu=1e-3):
+    """Reference: src/model/cr3bp.cpp (state x, y, z, px, py, pz)."""
+    mu = as_ex(mu)
+    _cr3bp_check(mu)
+    px, py, pz, x, y, z = (var(n) for n in ("px", "py", "pz", "x", "y", "z"))
+    d1 = x - mu
+    d2 = d1 + 1.0
+    yz2 = pow_(y, 2.0) + pow_(z, 2.0)
+    r1_2 = pow_(d1, 2.0) + yz2
+    r2_2 = pow_(d2, 2.0) + yz2
+    g1 = (1.0 - mu) * pow_(r1_2, num(-3.0 / 2))
+    g2 = mu * pow_(r2_2, num(-3.0 / 2))
+    g12 = g1 + g2
+    return [(x, px + y), (y, py - x), (z, pz), (px, py - g1 * d1 - g2 * d2), (py, -px - g12 * y), (pz, -g12 * z)]
+
+
+def fixed_centres(Gconst=1.0, masses=(), positions=()):
+    """Reference: src/model/fixed_centres.cpp."""
+    G = as_ex(Gconst)
+    masses = [as_ex(m) for m in masses]
+    positions = [as_ex(p) for p in positions]
+    if len(positions) % 3 != 0 or len(positions) // 3 != len(masses):
+        raise ValueError("invalid fixed centres configuration")
+    x, y, z, vx, vy, vz = (var(n) for n in ("x", "y", "z", "vx", "vy", "vz"))
+    ax, ay, az = [], [], []
+    for i, m in enumerate(masses):
+        dx, dy, dz = positions[3 * i] - x, positions[3 * i + 1] - y, positions[3 * i + 2] - z
+        mrm3 = m * pow_(_r2(dx, dy, dz), num(-1.5))
+        ax.append(dx * mrm3)
+        ay.append(dy * mrm3)
+        az.append(dz * mrm3)
+    return [(x, vx), (y, vy), (z, vz), (vx, G * sum_(ax)), (vy, G * sum_(ay)), (vz, G * sum_(az))]
+
+
+def rotating(omega=()):
+    """Reference: src/model/rotating.cpp."""
+    omega = [as_ex(o) for o in omega]
+    if omega and len(omega) != 3:
+        raise ValueError("invalid angular velocity")
+    x, y, z, vx, vy, vz = (var(n) for n in ("x", "y", "z", "vx", "vy", "vz"))
+    ax, ay, az = [], [], []
+    if omega:
+        p, q, r = omega
+        qx, rx, qy, rz = q * x, r * x, q * y, r * z
+        ax = [q * qx, r * rx, -(p * qy), -(p * rz)]
+        ay = [pow_(p, 2.0) * y, pow_(r, 2.0) * y, -(p * qx), -(q * rz)]
+        az = [pow_(p, 2.0) * z, pow_(q, 2.0) * z, -(p * rx), -(r * qy)]
+        ax.append(num(-2.0) * (q * vz - r * vy))
+        ay.append(num(-2.0) * (r * vx - p * vz))
+        az.append(num(-2.0) * (p * vy - q * vx))
+    return [(x, vx), (y, vy), (z, vz), (vx, sum_(ax)), (vy, sum_(ay)), (vz, sum_(az))]
+
+
+def mascon(Gconst=1.0, masses=(), positions=(), omega=()):
+    """Reference: src/model/mascon.cpp."""
+    fc = fixed_centres(Gconst, masses, positions)
+    rot = rotating(omega)
+    return fc[:3] + [(fc[i][0], fc[i][1] + rot[i][1]) for i in range(3, 6)]
+
+
 # ----------------------------------------------------------------------------------------------
 # Rewrites + decomposition.
 # ----------------------------------------------------------------------------------------------

@@ -12,6 +12,7 @@
 
 #include <sstream>
 
+#include "../../heyoka_amd/csrc/cfunc.hpp"
 #include "../../heyoka_amd/csrc/ensemble.hpp"
 #include "../../heyoka_amd/csrc/model.hpp"
 #include "../../heyoka_amd/csrc/taylor_adaptive_batch.hpp"
@@ -110,6 +111,39 @@ int main(int argc, char **argv)
             nt_event_batch<double> bad(v, nt_event_batch<double>::callback_t{});
         } catch (const std::invalid_argument &e) {
             thrown = std::string(e.what()) == "Cannot construct a non-terminal event with an empty callback";
+        }
+        REQUIRE(thrown);
+    }
+
+    // The other point-mass models, with the call syntax and the decomposition sizes of the reference's tests
+    // (test/model_cr3bp.cpp:41-48, model_rotating.cpp:65-73, :96-107, model_fixed_centres.cpp:70, model_mascon.cpp:287-299,
+    // model_nbody.cpp:492-497).
+    {
+        auto mk = [](auto dyn, std::size_t n_pars = 0) {
+            return taylor_adaptive_batch<double>{dyn, std::vector<double>(dyn.size() * 2u, .5), 2u,
+                                                 kw::pars = std::vector<double>(n_pars * 2u, .1)};
+        };
+        REQUIRE(mk(model::cr3bp()).get_decomposition().size() == 35u);
+        REQUIRE(mk(model::cr3bp(kw::mu = 1e-2)).get_decomposition().size() == 35u);
+        REQUIRE(mk(model::rotating(kw::omega = {.1, .2, .3})).get_decomposition().size() == 49u);
+        REQUIRE(mk(model::rotating(kw::omega = {par[0], par[1], par[2]}), 3).get_decomposition().size() == 52u);
+        REQUIRE(model::rotating_potential() == expression{0.});
+        const std::vector<double> masses{-3e-3}, pos{1e-3, 2e-3, -4e-3}, omega{.1, .11, .12};
+        auto mdyn = model::mascon(kw::masses = masses, kw::positions = pos, kw::Gconst = 1.01, kw::omega = omega);
+        REQUIRE(mk(mdyn).get_decomposition().size() == 64u);
+        auto fdyn = model::fixed_centres(kw::Gconst = 1.02, kw::masses = {1.01}, kw::positions = {1., 2., 3.});
+        REQUIRE(fdyn.size() == 6u && fdyn[3].first == expression{"vx"});
+        const std::vector<double> mss{1.00000597682, 1 / 1047.355, 1 / 3501.6, 1 / 22869., 1 / 19314., 7.4074074e-09};
+        const auto G = 0.01720209895 * 0.01720209895 * 365 * 365;
+        REQUIRE(mk(model::np1body(6, kw::masses = mss, kw::Gconst = G)).get_decomposition().size() == 294u);
+        cfunc<double> cf({model::cr3bp_jacobi()}, {"x"_var, "y"_var, "z"_var, "px"_var, "py"_var, "pz"_var});
+        REQUIRE(cf.get_dc().size() == 28u);
+        bool thrown = false;
+        try {
+            model::cr3bp(kw::mu = -1.);
+        } catch (const std::invalid_argument &e) {
+            thrown = std::string(e.what())
+                     == "The 'mu' parameter in a CR3BP must be in the range (0, 0.5), but a value of -1 was provided instead";
         }
         REQUIRE(thrown);
     }

@@ -1,0 +1,325 @@
+"""The point-mass models beyond model::nbody: np1body, cr3bp, fixed_centres, rotating,
+mascon. CPU part: the product's expression system / decomposition / compiled-function decomposition against the
+sizes the reference's own tests pin (tests/golden/model_structure_pins.json, transcribed from
+test/model_{nbody,cr3bp,fixed_centres,rotating,mascon}.cpp), against the independent Python restatement in
+oracle/heyoka_oracle.py, and the verbatim error messages. GPU part: one full-order step and a propagation vs the
+oracle, and the conservation checks of the reference's tests (energy / Jacobi constant) with the device-side
+compiled functions."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import heyoka_amd as hy
+import heyoka_oracle as ho
+
+EPS = 2.220446049250313e-16
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def pins():
+    with open(os.path.join(HERE, "golden", "model_structure_pins.json")) as f:
+        return json.load(f)
+
+
+def dc_size(sys_):
+    return len(hy.taylor_decompose_sys(sys_))
+
+
+def cfunc_dc_size(ex, vars_):
+    return len(hy.cfunc([ex], vars_).dc)
+
+
+def _masses(kind, M, par, num):
+    return {
+        "numeric": lambda: list(M),
+        "numeric_first5": lambda: list(M[:5]),
+        "par6": lambda: [par(i) for i in range(6)],
+        "par5": lambda: [par(i) for i in range(5)],
+        "par3_num3": lambda: [par(0), par(1), par(2)] + list(M[3:]),
+        "par3_zero_num2": lambda: [par(0), par(1), par(2), 0.0] + list(M[4:]),
+        "default": lambda: None,
+        "zeros": lambda: [0.0] * 6,
+    }[kind]()
+
+
+def _energy_masses(kind, M):
+    # The reference's tests build the energy with the numerical values of the masses.
+    return {
+        "numeric": list(M), "numeric_first5": list(M[:5]), "par6": list(M), "par5": list(M[:5]),
+        "par3_num3": list(M), "par3_zero_num2": list(M[:3]) + [0.0] + list(M[4:]), "default": None, "zeros": [0.0] * 6,
+    }[kind]
+
+
+def _G(pins):
+    a, b = pins["outer_ss"]["Gconst_factors"]
+    return a * a * b * b
+
+
+def test_nbody_and_np1body_structure_pins(pins):
+    M, G = pins["outer_ss"]["masses"], _G(pins)
+    par = lambda i: hy.par[i]
+    vars6 = hy.model.nbody(6).vars
+    for case in pins["nbody6"]:
+        kw = {} if case["masses"] == "default" else {"Gconst": G}
+        if "dc" in case:
+            assert dc_size(hy.model.nbody(6, masses=_masses(case["masses"], M, par, None), **kw)) == case["dc"], case
+        en = hy.model.nbody_energy(6, masses=_energy_masses(case["masses"], M), **kw)
+        assert cfunc_dc_size(en, vars6) == case["cfunc_dc"], case
+    vars5 = hy.model.np1body(6).vars
+    assert [str(v) for v in vars5[:6]] == ["x_1", "y_1", "z_1", "vx_1", "vy_1", "vz_1"] and len(vars5) == 30
+    for case in pins["np1body6"]:
+        kw = {} if case["masses"] == "default" else {"Gconst": G}
+        if "dc" in case:
+            assert dc_size(hy.model.np1body(6, masses=_masses(case["masses"], M, par, None), **kw)) == case["dc"], case
+        en = hy.model.np1body_energy(6, masses=_energy_masses(case["masses"], M), **kw)
+        assert cfunc_dc_size(en, vars5) == case["cfunc_dc"], case
+    # nbody_potential() without massive particles (test/model_nbody.cpp:449-450).
+    # (the reference compares numbers by value: -G * sum({}) is the number -0 == 0).
+    assert float(str(hy.model.nbody_potential(2, masses=[]))) == 0 and float(str(hy.model.nbody_potential(10, masses=[]))) == 0
+
+
+def test_cr3bp_fixed_centres_rotating_mascon_structure_pins(pins):
+    c = pins["cr3bp"]
+    for mu in (None, c["other_mu"]):
+        kw = {} if mu is None else {"mu": mu}
+        s = hy.model.cr3bp(**kw)
+        assert [str(v) for v in s.vars] == c["state_vars"]
+        assert dc_size(s) == c["dc"] and cfunc_dc_size(hy.model.cr3bp_jacobi(**kw), s.vars) == c["cfunc_dc"]
+
+    f = pins["fixed_centres"]
+    rng = np.random.RandomState(0)
+    m = rng.uniform(*f["value_range"], f["n_masses"])
+    pos = rng.uniform(*f["value_range"], 3 * f["n_masses"])
+    s = hy.model.fixed_centres(masses=m, positions=pos)
+    assert dc_size(s) == f["dc"]
+    assert cfunc_dc_size(hy.model.fixed_centres_energy(masses=m, positions=pos), s.vars) == f["cfunc_dc"]
+
+    r = pins["rotating"]
+    s = hy.model.rotating(omega=r["omega"])
+    x, y, z, vx, vy, vz = s.vars
+    kin = 0.5 * (vx * vx + vy * vy + vz * vz)
+    assert dc_size(s) == r["dc"]
+    assert cfunc_dc_size(kin + hy.model.rotating_potential(omega=r["omega"]), s.vars) == r["cfunc_dc"]
+    P = [hy.par[0], hy.par[1], hy.par[2]]
+    assert dc_size(hy.model.rotating(omega=P)) == r["dc_par"]
+    assert cfunc_dc_size(kin + hy.model.rotating_potential(omega=P), s.vars) == r["cfunc_dc_par"]
+    # No rotation: free particle, zero potential (test/model_rotating.cpp:41-62).
+    assert str(hy.model.rotating_potential()) == "0"
+    assert hy.taylor_decompose_sys(hy.model.rotating())[-3:] == ["0", "0", "0"]
+
+    k = pins["mascon"]
+    m1, p1 = m[:1], pos[:3]
+    s = hy.model.mascon(masses=m1, positions=p1, Gconst=k["Gconst"], omega=k["omega"])
+    assert dc_size(s) == k["dc"]
+    en = hy.model.mascon_energy(masses=m1, positions=p1, Gconst=k["Gconst"], omega=k["omega"])
+    assert cfunc_dc_size(en, s.vars) == k["cfunc_dc_energy"]
+    kp = kin + hy.model.mascon_potential(masses=m1, positions=p1, Gconst=k["Gconst"], omega=k["omega"])
+    assert cfunc_dc_size(kp, s.vars) == k["cfunc_dc_kin_plus_potential"]
+
+
+def test_model_error_messages(pins):
+    for mu, msg in pins["cr3bp"]["errors"]:
+        for fn in (hy.model.cr3bp, hy.model.cr3bp_jacobi):
+            with pytest.raises(ValueError) as ei:
+                fn(mu=mu)
+            assert str(ei.value) == msg
+    for m, pos, msg in pins["fixed_centres"]["errors"]:
+        for fn in (hy.model.fixed_centres, hy.model.fixed_centres_energy, hy.model.fixed_centres_potential):
+            with pytest.raises(ValueError) as ei:
+                fn(masses=m, positions=pos)
+            assert str(ei.value) == msg
+    for om, msg in pins["rotating"]["errors"]:
+        for fn in (hy.model.rotating, hy.model.rotating_energy, hy.model.rotating_potential):
+            with pytest.raises(ValueError) as ei:
+                fn(omega=om)
+            assert str(ei.value) == msg
+
+
+def _model_cases():
+    M = [1.00000597682, 1 / 1047.355, 1 / 3501.6, 1 / 22869.0, 1 / 19314.0, 7.4074074e-09]
+    G = 0.01720209895 * 0.01720209895 * 365 * 365
+    rng = np.random.RandomState(3)
+    m = rng.uniform(0.2, 1.0, 7)
+    m /= m.sum()  # total mass 1: the reference tests' initial state (1, 0, 0, 0, 1, 0) is then a near-circular orbit
+    pos = rng.uniform(-0.3, 0.3, 21)
+    om = [0.1, 0.11, 0.12]
+    return {
+        "cr3bp": (lambda: hy.model.cr3bp(), lambda: ho.cr3bp()),
+        "cr3bp_par": (lambda: hy.model.cr3bp(mu=hy.par[0]), lambda: ho.cr3bp(mu=ho.par(0))),
+        "np1body6": (lambda: hy.model.np1body(6, masses=M, Gconst=G), lambda: ho.np1body(6, masses=M, Gconst=G)),
+        "np1body4_par": (lambda: hy.model.np1body(4, masses=[hy.par[0], 1e-3, hy.par[1]]),
+                         lambda: ho.np1body(4, masses=[ho.par(0), 1e-3, ho.par(1)])),
+        "np1body5_massless": (lambda: hy.model.np1body(5, masses=[1.0, 1e-3]), lambda: ho.np1body(5, masses=[1.0, 1e-3])),
+        "fixed_centres7": (lambda: hy.model.fixed_centres(masses=m, positions=pos, Gconst=1.02),
+                           lambda: ho.fixed_centres(masses=m, positions=pos, Gconst=1.02)),
+        "rotating": (lambda: hy.model.rotating(omega=om), lambda: ho.rotating(omega=om)),
+        "rotating_par": (lambda: hy.model.rotating(omega=[hy.par[0], hy.par[1], hy.par[2]]),
+                         lambda: ho.rotating(omega=[ho.par(0), ho.par(1), ho.par(2)])),
+        "rotating_none": (lambda: hy.model.rotating(), lambda: ho.rotating()),
+        "mascon7": (lambda: hy.model.mascon(masses=m, positions=pos, Gconst=1.01, omega=om),
+                    lambda: ho.mascon(masses=m, positions=pos, Gconst=1.01, omega=om)),
+    }
+
+
+@pytest.mark.parametrize("name", sorted(_model_cases()))
+def test_model_decomposition_identical_to_oracle(name):
+    prod, ora = _model_cases()[name]
+    assert hy.taylor_decompose_sys(prod()) == ho.dc_to_strings(ho.taylor_decompose_sys(ora()))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# GPU: the HIP path vs the oracle and the reference tests' conservation checks.
+# ------------------------------------------------------------------------------------------------------------------
+def rel_err(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))
+
+
+def _lanes(base, n, rel, seed):
+    """(len(base), n) initial conditions: lane 0 is the reference test's state, the others are perturbed copies."""
+    rng = np.random.RandomState(seed)
+    b = np.asarray(base, dtype=np.float64)[:, None]
+    st = b + (np.abs(b) + 0.05) * rel * rng.uniform(-1, 1, (b.shape[0], n))
+    st[:, 0] = b[:, 0]
+    return np.ascontiguousarray(st)
+
+
+def _gpu_cases(pins):
+    from heyoka_amd import configs
+
+    M, G = pins["outer_ss"]["masses"], _G(pins)
+    n = 40
+    cr_st = _lanes(pins["cr3bp"]["init_state"], n, 1e-3, 1)
+    fc_st = _lanes(pins["mascon"]["init_state"], n, 1e-2, 2)
+    rot_st = _lanes(pins["rotating"]["init_state"], n, 1e-2, 4)
+    oss = configs.outer_ss_state(n, perturb=1e-6, seed=11, com_shift=False)[6:]
+    npar = lambda vals: np.repeat(np.asarray(vals, dtype=np.float64)[:, None], n, axis=1) * (1 + 1e-3 * np.arange(n) / n)
+    cases = _model_cases()
+    return {
+        # name: (product system, oracle system, state, pars, horizon)
+        "cr3bp": (*cases["cr3bp"], cr_st, None, 5.0),
+        "cr3bp_par": (*cases["cr3bp_par"], cr_st, npar([1e-2]), 5.0),
+        "np1body6": (lambda: hy.model.np1body(6, masses=M, Gconst=G), lambda: ho.np1body(6, masses=M, Gconst=G), oss, None, 30.0),
+        "np1body4_par": (*cases["np1body4_par"], oss[:18], npar([1.0, 3e-4]), 30.0),
+        "fixed_centres7": (*cases["fixed_centres7"], fc_st, None, 5.0),
+        "rotating": (*cases["rotating"], rot_st, None, 5.0),
+        "rotating_par": (*cases["rotating_par"], rot_st, npar([0.1, 0.2, 0.3]), 5.0),
+        "mascon7": (*cases["mascon7"], fc_st, None, 5.0),
+    }
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cr3bp", "cr3bp_par", "np1body6", "np1body4_par", "fixed_centres7", "rotating",
+                                  "rotating_par", "mascon7"])
+def test_models_step_and_propagate_vs_oracle(name, pins):
+    """One full-order step (h, Taylor coefficients, state) and a propagation of every model against the oracle.
+    Tolerances: those of the N-body parity tests (h 1e6 eps, coefficients 1e6 eps of the row maximum, state 1e5 eps
+    after one step, 1e7 eps after the propagation of ~25-150 steps)."""
+    prod, ora, st, pars, T = _gpu_cases(pins)[name]
+    n = st.shape[1]
+    kw = {} if pars is None else {"pars": pars}
+    ta = hy.taylor_adaptive_batch(prod(), st, n, **kw)
+    oi = ho.OracleIntegrator(ora(), st, n, **kw)
+    n_eq = st.shape[0]
+    ta.step(write_tc=True)
+    oi.step(wtc=True)
+    h_g = np.array([h for _, h in ta.step_res])
+    h_o = np.array([h for _, h in oi.step_res])
+    assert all(o == hy.taylor_outcome.success for o, _ in ta.step_res)
+    assert np.max(np.abs(h_g - h_o) / np.abs(h_o)) <= 1e6 * EPS
+    tc_o = oi.tc.reshape(n_eq, oi.order + 1, n)
+    scale = np.max(np.abs(tc_o), axis=2, keepdims=True) + 1e-300
+    assert np.max(np.abs(np.asarray(ta.tc).reshape(n_eq, oi.order + 1, n) - tc_o) / scale) <= 1e6 * EPS
+    assert rel_err(ta.state, oi.state.reshape(n_eq, n)) <= 1e5 * EPS
+    ta.propagate_until(T)
+    oi.propagate_until(T)
+    assert all(r[0] == hy.taylor_outcome.time_limit for r in ta.propagate_res)
+    assert [r[3] for r in ta.propagate_res] == [r[3] for r in oi.prop_res]
+    assert rel_err(ta.state, oi.state.reshape(n_eq, n)) <= 1e7 * EPS
+
+
+def _invariant_drift(sys_, inv_ex, st, T, pars=None, high_accuracy=False):
+    """Relative drift of a compiled-function invariant evaluated on the device-resident state before and after
+    propagate_until(T) (the pattern of test/model_*.cpp: cf(outs, init_state); propagate; cf(outs, state))."""
+    import torch
+
+    n = st.shape[1]
+    kw = {} if pars is None else {"pars": pars}
+    ta = hy.taylor_adaptive_batch(sys_, st, n, high_accuracy=high_accuracy, **kw)
+    cf = hy.cfunc([inv_ex], sys_.vars)
+    e0 = cf(st, **kw)[0]
+    ta.propagate_until(T)
+    assert all(r[0] == hy.taylor_outcome.time_limit for r in ta.propagate_res)
+    e1 = cf(ta.state, **kw)[0]
+    # The same through the device-side entry point (no host round trip of the state).
+    if pars is None:
+        d_e = torch.empty(n, dtype=torch.float64, device="cuda")
+        cf.eval_device(d_e.data_ptr(), ta.device_array("state").ptr, n)
+        ta.synchronize()
+        torch.cuda.synchronize()
+        assert np.array_equal(d_e.cpu().numpy(), e1)
+    return np.max(np.abs((e1 - e0) / e0)), ta
+
+
+@pytest.mark.gpu
+def test_models_conservation_checks_of_the_reference_tests(pins):
+    """The invariants the reference's model tests check, with their horizons and tolerances ('approximately()' = 100
+    eps unless stated): Jacobi constant of the CR3BP (test/model_cr3bp.cpp:41-91), energy in a rotating frame (1000
+    eps, test/model_rotating.cpp:65-126), mascon energy (test/model_mascon.cpp:311-343), energy with 100 fixed
+    centres (test/model_fixed_centres.cpp:112-153), N+1-body energy of the outer Solar System
+    (test/model_nbody.cpp:490-524), and the equivalence of one fixed centre with the two-body problem with one
+    massive body (1000 eps, test/model_fixed_centres.cpp:66-110). Lane 0 holds the reference's initial state, the
+    other lanes perturbed copies."""
+    from heyoka_amd import configs
+
+    n = 32
+    c = pins["cr3bp"]
+    for mu in (c["default_mu"], c["other_mu"]):
+        drift, _ = _invariant_drift(hy.model.cr3bp(mu=mu), hy.model.cr3bp_jacobi(mu=mu), _lanes(c["init_state"], n, 1e-3, 5),
+                                    c["t_final"])
+        assert drift <= c["invariant_tol_eps"] * EPS
+
+    r = pins["rotating"]
+    st = _lanes(r["init_state"], n, 1e-2, 6)
+    drift, _ = _invariant_drift(hy.model.rotating(omega=r["omega"]), hy.model.rotating_energy(omega=r["omega"]), st, r["t_final"])
+    assert drift <= r["invariant_tol_eps"] * EPS
+    P = [hy.par[0], hy.par[1], hy.par[2]]
+    pars = np.repeat(np.asarray(r["omega"])[:, None], n, axis=1)
+    drift, _ = _invariant_drift(hy.model.rotating(omega=P), hy.model.rotating_energy(omega=P), st, r["t_final"], pars=pars)
+    assert drift <= r["invariant_tol_eps"] * EPS
+
+    k = pins["mascon"]
+    rng = np.random.RandomState(0)
+    m1, p1 = rng.uniform(*k["value_range"], 1), rng.uniform(*k["value_range"], 3)
+    args = dict(masses=m1, positions=p1, Gconst=k["Gconst"], omega=k["omega"])
+    drift, _ = _invariant_drift(hy.model.mascon(**args), hy.model.mascon_energy(**args), _lanes(k["init_state"], n, 1e-2, 7),
+                                k["t_final"])
+    assert drift <= k["invariant_tol_eps"] * EPS
+
+    f = pins["fixed_centres"]
+    m = rng.uniform(*f["value_range"], f["n_masses"])
+    pos = rng.uniform(*f["value_range"], 3 * f["n_masses"])
+    drift, ta = _invariant_drift(hy.model.fixed_centres(masses=m, positions=pos),
+                                 hy.model.fixed_centres_energy(masses=m, positions=pos), _lanes(f["init_state"], n, 1e-2, 8),
+                                 f["t_final"])
+    assert drift <= 100 * EPS
+
+    M, G = pins["outer_ss"]["masses"], _G(pins)
+    st = configs.outer_ss_state(n, perturb=1e-9, seed=12, com_shift=False)[6:]
+    drift, _ = _invariant_drift(hy.model.np1body(6, masses=M, Gconst=G), hy.model.np1body_energy(6, masses=M, Gconst=G), st, 100.0)
+    assert drift <= 100 * EPS
+
+    e = f["two_body_equivalence"]
+    cx, cy, cz = e["position"]
+    rel = _lanes([1.0, 0.0, 0.0, 0.1, 1.0, 0.2], n, 1e-2, 9)  # the reference's state relative to the centre
+    fix_st = rel + np.array([cx, cy, cz, 0, 0, 0])[:, None]
+    two_st = np.concatenate([np.repeat(np.array([cx, cy, cz, 0.0, 0.0, 0.0])[:, None], n, axis=1), fix_st])
+    ta_fix = hy.taylor_adaptive_batch(hy.model.fixed_centres(Gconst=e["Gconst"], masses=[e["mass"]], positions=e["position"]), fix_st, n)
+    ta_2bp = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[e["mass"]], Gconst=e["Gconst"]), two_st, n)
+    ta_fix.propagate_until(e["t_final"])
+    ta_2bp.propagate_until(e["t_final"])
+    a, b = ta_fix.state, ta_2bp.state[6:]
+    assert np.max(np.abs(a - b) / np.maximum(np.abs(a), np.abs(b))) <= e["tol_eps"] * EPS
