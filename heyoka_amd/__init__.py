@@ -254,6 +254,16 @@ def pow(b, e):  # noqa: A001 - mirrors heyoka::pow
     return _bin(lib.hy_expr_pow, b, e)
 
 
+def atan2(y, x):
+    """atan2(y, x) (src/math/atan2.cpp:763-786)."""
+    return _bin(lib.hy_expr_atan2, _as_ex(y), x)
+
+
+def kepE(e, M):
+    """Eccentric anomaly E(e, M), E - e sin E = M (src/math/kepE.cpp:801-809)."""
+    return _bin(lib.hy_expr_kepE, _as_ex(e), M)
+
+
 def _handle_array(exs):
     exs = [_as_ex(e) for e in exs]
     arr = (ctypes.c_void_p * max(len(exs), 1))(*[e._h for e in exs])

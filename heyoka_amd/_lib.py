@@ -95,6 +95,8 @@ SIGNATURES = [
     ("hy_expr_atanh", c_void_p, [c_void_p]),
     ("hy_expr_erf", c_void_p, [c_void_p]),
     ("hy_expr_sigmoid", c_void_p, [c_void_p]),
+    ("hy_expr_atan2", c_void_p, [c_void_p, c_void_p]),
+    ("hy_expr_kepE", c_void_p, [c_void_p, c_void_p]),
     ("hy_expr_sum", c_void_p, [c_void_p, c_size_t]),
     ("hy_expr_prod", c_void_p, [c_void_p, c_size_t]),
     ("hy_expr_free", None, [c_void_p]),

@@ -221,6 +221,14 @@ hy_expr hy_expr_pow(hy_expr a, hy_expr b)
 {
     return make_expr([&] { return pow(a->ex, b->ex); });
 }
+hy_expr hy_expr_atan2(hy_expr y, hy_expr x)
+{
+    return make_expr([&] { return atan2(y->ex, x->ex); });
+}
+hy_expr hy_expr_kepE(hy_expr e, hy_expr M)
+{
+    return make_expr([&] { return kepE(e->ex, M->ex); });
+}
 hy_expr hy_expr_sqrt(hy_expr a)
 {
     return make_expr([&] { return sqrt(a->ex); });

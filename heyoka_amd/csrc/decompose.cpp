@@ -289,6 +289,26 @@ std::size_t func_taylor_decompose(expression f_ex, taylor_dc_t &dc)
             dc.emplace_back(f_ex, std::vector<std::uint32_t>{u32(dc.size() - 1u)});
             return dc.size() - 1u;
         }
+        case func_kind::atan2: {
+            // y^2 + x^2 -> atan2(y, x), which depends on it (src/math/atan2.cpp:92-108).
+            dc.emplace_back(detail::sum_sq({f.args()[0], f.args()[1]}), std::vector<std::uint32_t>{});
+            dc.emplace_back(f_ex, std::vector<std::uint32_t>{u32(dc.size() - 1u)});
+            return dc.size() - 1u;
+        }
+        case func_kind::kepE: {
+            // E = kepE(e, M) -> sin(E) -> cos(E) -> e * cos(E); E depends on (e cos E, sin E), in this order, and
+            // sin / cos on each other (src/math/kepE.cpp:100-135).
+            const auto ecc = f.args()[0];
+            dc.emplace_back(f_ex, std::vector<std::uint32_t>{});
+            const auto iE = dc.size() - 1u;
+            dc.emplace_back(sin(uvar(iE)), std::vector<std::uint32_t>{});
+            dc.emplace_back(cos(uvar(iE)), std::vector<std::uint32_t>{});
+            dc.emplace_back(ecc * uvar(iE + 2u), std::vector<std::uint32_t>{});
+            dc[iE].second = {u32(iE + 3u), u32(iE + 1u)};
+            dc[iE + 1u].second.push_back(u32(iE + 2u));
+            dc[iE + 2u].second.push_back(u32(iE + 1u));
+            return iE;
+        }
         default:
             break;
     }

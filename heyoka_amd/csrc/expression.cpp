@@ -54,6 +54,10 @@ const char *func_kind_name(func_kind k)
             return "acos";
         case func_kind::atan:
             return "atan";
+        case func_kind::atan2:
+            return "atan2";
+        case func_kind::kepE:
+            return "kepE";
         case func_kind::asinh:
             return "asinh";
         case func_kind::acosh:
@@ -417,6 +421,24 @@ HEYOKA_AMD_UNARY_FUNC(erf, std::erf(x))
 HEYOKA_AMD_UNARY_FUNC(sigmoid, 1. / (1. + std::exp(-x)))
 
 #undef HEYOKA_AMD_UNARY_FUNC
+
+// Reference: src/math/atan2.cpp:763-786 (two numbers fold).
+expression atan2(expression y, expression x)
+{
+    if (y.is_number() && x.is_number()) {
+        return expression{std::atan2(y.num(), x.num())};
+    }
+    return detail::make_func(func_kind::atan2, {std::move(y), std::move(x)});
+}
+
+// Reference: src/math/kepE.cpp:801-809 (zero eccentricity: E = M; no other folding).
+expression kepE(expression e, expression M)
+{
+    if (e.is_number() && e.num() == 0) {
+        return M;
+    }
+    return detail::make_func(func_kind::kepE, {std::move(e), std::move(M)});
+}
 
 // --- Traversal. ---
 // Iterative post-order traversal replicating the visiting order of the reference

@@ -54,7 +54,10 @@ enum class func_kind : std::uint8_t {
     acosh,
     atanh,
     erf,
-    sigmoid
+    sigmoid,
+    // Two-argument functions (reference: src/math/atan2.cpp, src/math/kepE.cpp).
+    atan2,
+    kepE
 };
 
 const char *func_kind_name(func_kind);
@@ -210,6 +213,10 @@ expression acosh(expression);
 expression atanh(expression);
 expression erf(expression);
 expression sigmoid(expression);
+// atan2(y, x) (src/math/atan2.cpp:763-786) and the eccentric anomaly E(e, M), E - e sin E = M
+// (src/math/kepE.cpp:801-809).
+expression atan2(expression y, expression x);
+expression kepE(expression e, expression M);
 
 namespace detail
 {

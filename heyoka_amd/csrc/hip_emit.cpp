@@ -181,6 +181,102 @@ static __device__ __attribute__((noinline)) double hy_pow(double x, double y)
     return pow(x, y);
 }
 
+static __device__ __attribute__((noinline)) double hy_atan2(double y, double x)
+{
+    return atan2(y, x);
+}
+
+// Inverse of Kepler's equation for the eccentric anomaly: E - e sin E = M (reference: llvm_add_inv_kep_E(),
+// src/detail/llvm_helpers_celmec.cpp:181-466). Invalid eccentricities (nan, < 0, >= 1) give nan; M is reduced to
+// [0, 2 pi) in double-length arithmetic (llvm_trig_arg_reduce(), :140-177, on top of the Dekker / NTL procedures of
+// src/detail/llvm_helpers_dl.cpp:130-281); third-order initial guess in e; Newton-Raphson iterations safeguarded by
+// bisection on a bracketing interval, stopped when |f(E)| or the bracket are below 4 eps, nan after 20 iterations
+// without convergence. One lane per system: every lane stops at its own convergence (the scalar flavour of the
+// reference; its batch flavour keeps iterating all the lanes until the slowest has converged, which moves the
+// others by rounding errors at most).
+static __device__ __attribute__((noinline)) double hy_kepE(double ecc_in, double M_in)
+{
+#pragma clang fp contract(off)
+    const double qnan = __builtin_nan("");
+    const bool ecc_invalid = !(ecc_in >= 0.0) | (ecc_in >= 1.0);
+    const double ecc = ecc_invalid ? qnan : ecc_in;
+
+    // ---- M mod 2 pi: x - y * floor(x / y) in double-length arithmetic.
+    const double y_hi = 0x1.921fb54442d18p+2, y_lo = 0x1.1a62633145c07p-52;
+    const double twopi_prev = 0x1.921fb54442d17p+2; // the double preceding 2 pi
+    double M;
+    {
+        // x / y (div2()).
+        const double c = M_in / y_hi;
+        const double u = c * y_hi, uu = fma(c, y_hi, -u);
+        double cc = M_in - u;
+        cc = cc - uu;
+        cc = cc + 0.0;
+        cc = cc - c * y_lo;
+        cc = cc / y_hi;
+        const double q_hi = c + cc, q_lo = (c - q_hi) + cc;
+        // floor().
+        const double fhi = floor(q_hi);
+        const double flo = (fhi == q_hi) ? floor(q_lo) : 0.0;
+        const double fl_hi = fhi + flo, fl_lo = (fhi - fl_hi) + flo;
+        // y * floor (mul2()).
+        const double pc = y_hi * fl_hi;
+        double pcc = fma(y_hi, fl_hi, -pc);
+        pcc = (y_hi * fl_lo + y_lo * fl_hi) + pcc;
+        const double p_hi = pc + pcc, p_lo = (pc - p_hi) + pcc;
+        // x - y * floor.
+        hy_df xx, yy;
+        xx.hi = M_in;
+        xx.lo = 0.0;
+        yy.hi = -p_hi;
+        yy.lo = -p_lo;
+        M = hy_df_add(xx, yy).hi;
+        M = (M < 0.0) ? 0.0 : M;
+        M = (twopi_prev < M) ? twopi_prev : M;
+    }
+
+    // ---- Initial guess: E = M + e sin M + e^2 sin M cos M + e^3 sin M (3/2 cos^2 M - 1/2).
+    double sE = sin(M), cE = cos(M);
+    double E;
+    {
+        const double e_sin = ecc * sE, e_cos = ecc * cE, e2 = ecc * ecc, cos2 = cE * cE;
+        const double ig1 = (M + e_sin) + e_sin * e_cos;
+        const double ig2 = (e2 * e_sin) * (1.5 * cos2 - 0.5);
+        E = ig1 + ig2;
+    }
+    double lb = 0.0, ub = twopi_prev;
+    E = (E < lb) ? lb : E;
+    E = (ub < E) ? ub : E;
+    sE = sin(E);
+    cE = cos(E);
+    double fE = (E - M) - ecc * sE;
+
+    const double tol = 4.0 * 0x1p-52;
+    bool not_converged = false;
+    unsigned it = 0;
+    for (;;) {
+        // Bracket update from the sign of f(E) (0 for nan: the bracket collapses and the loop ends).
+        const int sgn = (0.0 < fE) - (fE < 0.0);
+        const double n_ub = (sgn >= 0) ? E : ub, n_lb = (sgn <= 0) ? E : lb;
+        ub = n_ub;
+        lb = n_lb;
+        not_converged = (fabs(fE) > tol) & ((ub - lb) > tol);
+        if (!(it < 20u) | !not_converged) {
+            break;
+        }
+        // Newton-Raphson step, replaced by a bisection when it leaves the bracket.
+        double nE = E - fE / (1.0 - ecc * cE);
+        nE = (nE > ub) ? 0.5 * (E + ub) : nE;
+        nE = (nE < lb) ? 0.5 * (E + lb) : nE;
+        E = nE;
+        sE = sin(E);
+        cE = cos(E);
+        fE = (E - M) - ecc * sE;
+        ++it;
+    }
+    return (it == 20u && not_converged) ? qnan : E;
+}
+
 // max(a, b) = (a < b) ? b : a and min(a, b) = (b < a) ? b : a
 // (reference: src/detail/llvm_helpers_cmp.cpp:315-329; NaN handling is part of the semantics).
 __device__ __forceinline__ double hy_max(double a, double b)

@@ -549,6 +549,98 @@ struct ssa_emitter {
                 out = def(ret + " / " + def(mul(kf, D)));
                 break;
             }
+            case func_kind::atan2: {
+                // a = atan2(b, c), d = b^2 + c^2 (hidden dependency). Reference: src/math/atan2.cpp:113-330:
+                //   a^[k] = (k (c^[0] b^[k] - b^[0] c^[k]) + sum_{j=1..k-1} j (c^[k-j] b^[j] - b^[k-j] c^[j] - d^[k-j] a^[j]))
+                //           / (k d^[0]),
+                // with the terms of a constant argument dropped.
+                const bool vy = is_var(a[0]), vx = is_var(a[1]);
+                const auto arg0 = [&](const operand &o) { return is_var(o) ? val(o.idx, 0) : numpar(o); };
+                if (k == 0u) {
+                    out = def("hy_atan2(" + arg0(a[0]) + ", " + arg0(a[1]) + ")");
+                    break;
+                }
+                if (!vy && !vx) {
+                    out = "0.0";
+                    break;
+                }
+                const auto d = n.deps.at(0);
+                const auto kf = fp_literal(static_cast<double>(k));
+                const auto divisor = def(mul(kf, val(d, 0)));
+                std::string dividend;
+                if (vy && vx) {
+                    const auto b = a[0].idx, c = a[1].idx;
+                    const auto t1 = def(mul(val(c, 0), val(b, k)));
+                    const auto t2 = def(mul(val(b, 0), val(c, k)));
+                    dividend = def(mul(kf, def(t1 + " - " + t2)));
+                } else if (vy) {
+                    dividend = def(mul(kf, def(mul(numpar(a[1]), val(a[0].idx, k)))));
+                } else {
+                    dividend = def(mul(fp_literal(-static_cast<double>(k)), def(mul(numpar(a[0]), val(a[1].idx, k)))));
+                }
+                if (k > 1u) {
+                    std::vector<std::string> terms;
+                    for (std::uint32_t j = 1; j < k; ++j) {
+                        const auto t3 = def(mul(val(d, k - j), val(u, j)));
+                        if (vy && vx) {
+                            const auto b = a[0].idx, c = a[1].idx;
+                            const auto t1 = def(mul(val(c, k - j), val(b, j)));
+                            const auto t2 = def(mul(val(b, k - j), val(c, j)));
+                            const auto t = def(def(t1 + " - " + t2) + " - " + t3);
+                            terms.push_back(def(mul(fp_literal(static_cast<double>(j)), t)));
+                        } else {
+                            terms.push_back(def(mul(fp_literal(-static_cast<double>(j)), t3)));
+                        }
+                    }
+                    dividend = def(dividend + " + " + pairwise_sum(std::move(terms)));
+                }
+                out = def(dividend + " / " + divisor);
+                break;
+            }
+            case func_kind::kepE: {
+                // a = E(e, M) with E - e sin E = M; hidden dependencies c = e cos(a), d = sin(a), in this order.
+                // Reference: src/math/kepE.cpp:140-355:
+                //   a^[k] = (k (e^[k] d^[0] + M^[k]) + sum_{j=1..k-1} j (c^[k-j] a^[j] + d^[k-j] e^[j])) / (k (1 - c^[0])),
+                // with the terms of a constant argument dropped.
+                const bool ve = is_var(a[0]), vm = is_var(a[1]);
+                const auto arg0 = [&](const operand &o) { return is_var(o) ? val(o.idx, 0) : numpar(o); };
+                if (k == 0u) {
+                    out = def("hy_kepE(" + arg0(a[0]) + ", " + arg0(a[1]) + ")");
+                    break;
+                }
+                if (!ve && !vm) {
+                    out = "0.0";
+                    break;
+                }
+                const auto c = n.deps.at(0), d = n.deps.at(1);
+                const auto kf = fp_literal(static_cast<double>(k));
+                const auto divisor = def(mul(kf, def("1.0 - " + val(c, 0))));
+                std::string dividend;
+                if (ve && vm) {
+                    const auto t = def(def(mul(val(a[0].idx, k), val(d, 0))) + " + " + val(a[1].idx, k));
+                    dividend = def(mul(kf, t));
+                } else if (ve) {
+                    dividend = def(mul(kf, def(mul(val(a[0].idx, k), val(d, 0)))));
+                } else {
+                    dividend = def(mul(kf, val(a[1].idx, k)));
+                }
+                if (k > 1u) {
+                    std::vector<std::string> terms;
+                    for (std::uint32_t j = 1; j < k; ++j) {
+                        const auto jf = fp_literal(static_cast<double>(j));
+                        const auto ca = def(mul(val(c, k - j), val(u, j)));
+                        if (ve) {
+                            const auto de = def(mul(val(d, k - j), val(a[0].idx, j)));
+                            terms.push_back(def(mul(jf, def(ca + " + " + de))));
+                        } else {
+                            terms.push_back(def(mul(jf, ca)));
+                        }
+                    }
+                    dividend = def(dividend + " + " + pairwise_sum(std::move(terms)));
+                }
+                out = def(dividend + " / " + divisor);
+                break;
+            }
         }
     }
 

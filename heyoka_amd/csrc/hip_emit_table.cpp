@@ -52,6 +52,8 @@ const char *table_device_code = R"HIP(
 #define K_ASINH 21
 #define K_ACOSH 22
 #define K_ATANH 23
+#define K_ATAN2 24
+#define K_KEPE 25
 #define A_UVAR 0
 #define A_NUM 1
 #define A_PAR 2
@@ -323,6 +325,61 @@ __device__ double hy_diff_inv(const hy_tctx &c, unsigned kind, unsigned a0, unsi
     return ret / ((double)k * D);
 }
 
+// atan2(b, c) with d = b^2 + c^2 (see ssa_emitter::node(); src/math/atan2.cpp:113-330).
+__device__ double hy_diff_atan2(const hy_tctx &c, unsigned a0, unsigned u, unsigned d, unsigned k)
+{
+    const bool vy = hy_arg_type[a0] == A_UVAR, vx = hy_arg_type[a0 + 1u] == A_UVAR;
+    const unsigned iy = hy_arg_idx[a0], ix = hy_arg_idx[a0 + 1u];
+    if (k == 0u) return hy_atan2(vy ? hy_tp(c, 0, iy) : hy_numpar(c, a0), vx ? hy_tp(c, 0, ix) : hy_numpar(c, a0 + 1u));
+    if (!vy && !vx) return 0.0;
+    const double kf = (double)k;
+    double dividend;
+    if (vy && vx) {
+        dividend = kf * (hy_tp(c, 0, ix) * hy_tp(c, k, iy) - hy_tp(c, 0, iy) * hy_tp(c, k, ix));
+    } else if (vy) {
+        dividend = kf * (hy_numpar(c, a0 + 1u) * hy_tp(c, k, iy));
+    } else {
+        dividend = -kf * (hy_numpar(c, a0) * hy_tp(c, k, ix));
+    }
+    double acc = 0.0;
+    for (unsigned j = 1; j < k; ++j) {
+        const double t3 = hy_tp(c, k - j, d) * hy_tp(c, j, u);
+        if (vy && vx) {
+            acc += (double)j * ((hy_tp(c, k - j, ix) * hy_tp(c, j, iy) - hy_tp(c, k - j, iy) * hy_tp(c, j, ix)) - t3);
+        } else {
+            acc += -(double)j * t3;
+        }
+    }
+    if (k > 1u) dividend += acc;
+    return dividend / (kf * hy_tp(c, 0, d));
+}
+
+// E = kepE(e, M) with the hidden dependencies dc = e cos E, dd = sin E (src/math/kepE.cpp:140-355).
+__device__ double hy_diff_kepE(const hy_tctx &c, unsigned a0, unsigned u, unsigned dc, unsigned dd, unsigned k)
+{
+    const bool ve = hy_arg_type[a0] == A_UVAR, vm = hy_arg_type[a0 + 1u] == A_UVAR;
+    const unsigned ie = hy_arg_idx[a0], im = hy_arg_idx[a0 + 1u];
+    if (k == 0u) return hy_kepE(ve ? hy_tp(c, 0, ie) : hy_numpar(c, a0), vm ? hy_tp(c, 0, im) : hy_numpar(c, a0 + 1u));
+    if (!ve && !vm) return 0.0;
+    const double kf = (double)k;
+    double dividend;
+    if (ve && vm) {
+        dividend = kf * (hy_tp(c, k, ie) * hy_tp(c, 0, dd) + hy_tp(c, k, im));
+    } else if (ve) {
+        dividend = kf * (hy_tp(c, k, ie) * hy_tp(c, 0, dd));
+    } else {
+        dividend = kf * hy_tp(c, k, im);
+    }
+    double acc = 0.0;
+    for (unsigned j = 1; j < k; ++j) {
+        double t = hy_tp(c, k - j, dc) * hy_tp(c, j, u);
+        if (ve) t += hy_tp(c, k - j, dd) * hy_tp(c, j, ie);
+        acc += (double)j * t;
+    }
+    if (k > 1u) dividend += acc;
+    return dividend / (kf * (1.0 - hy_tp(c, 0, dc)));
+}
+
 // Order-k coefficients of all the u variables that are not state variables.
 __device__ void hy_nodes_order(const hy_tctx &c, unsigned k)
 {
@@ -346,6 +403,8 @@ __device__ void hy_nodes_order(const hy_tctx &c, unsigned k)
                 v = hy_diff_fwd(c, hy_kind[i], a0, u, hy_dep[i], k); break;
             case K_ASIN: case K_ACOS: case K_ATAN: case K_ASINH: case K_ACOSH: case K_ATANH:
                 v = hy_diff_inv(c, hy_kind[i], a0, u, hy_dep[i], k); break;
+            case K_ATAN2: v = hy_diff_atan2(c, a0, u, hy_dep[i], k); break;
+            case K_KEPE: v = hy_diff_kepE(c, a0, u, hy_dep[i], hy_dep2[i], k); break;
             default: v = (k == 0u) ? hy_numpar(c, a0) : 0.0; break;
         }
         hy_tp(c, k, u) = v;
@@ -564,6 +623,10 @@ int kind_id(func_kind k)
             return 22;
         case func_kind::atanh:
             return 23;
+        case func_kind::atan2:
+            return 24;
+        case func_kind::kepE:
+            return 25;
         default:
             return 11;
     }
@@ -587,7 +650,7 @@ emitted_module emit_table(const taylor_program &p, const emit_options &opts)
     }
     src << "0};\n";
 
-    std::ostringstream kind, off, at, ai, av, dep;
+    std::ostringstream kind, off, at, ai, av, dep, dep2;
     std::size_t n_args = 0;
     off << "0,";
     for (const auto &n : p.nodes) {
@@ -608,6 +671,7 @@ emitted_module emit_table(const taylor_program &p, const emit_options &opts)
         }
         off << n_args << ",";
         dep << (n.deps.empty() ? 0u : n.deps[0]) << ",";
+        dep2 << (n.deps.size() < 2u ? 0u : n.deps[1]) << ",";
     }
     src << "__device__ const unsigned char hy_kind[] = {" << kind.str() << "0};\n";
     src << "__device__ const unsigned hy_arg_off[] = {" << off.str() << "0};\n";
@@ -615,6 +679,7 @@ emitted_module emit_table(const taylor_program &p, const emit_options &opts)
     src << "__device__ const unsigned hy_arg_idx[] = {" << ai.str() << "0};\n";
     src << "__device__ const double hy_arg_val[] = {" << av.str() << "0.0};\n";
     src << "__device__ const unsigned hy_dep[] = {" << dep.str() << "0};\n";
+    src << "__device__ const unsigned hy_dep2[] = {" << dep2.str() << "0};\n";
     src << "__device__ const unsigned char hy_sv_type[] = {";
     for (const auto &d : p.sv_defs) {
         src << static_cast<int>(d.type) << ",";

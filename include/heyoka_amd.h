@@ -83,6 +83,8 @@ hy_expr hy_expr_acosh(hy_expr);
 hy_expr hy_expr_atanh(hy_expr);
 hy_expr hy_expr_erf(hy_expr);
 hy_expr hy_expr_sigmoid(hy_expr);
+hy_expr hy_expr_atan2(hy_expr y, hy_expr x); /* atan2(y, x)                  src/math/atan2.cpp:763 */
+hy_expr hy_expr_kepE(hy_expr e, hy_expr M);  /* eccentric anomaly E(e, M)    src/math/kepE.cpp:801 */
 hy_expr hy_expr_sum(const hy_expr *, size_t n);  /* sum(vector)           src/math/sum.cpp:548 */
 hy_expr hy_expr_prod(const hy_expr *, size_t n); /* prod(vector)          src/math/prod.cpp:913 */
 void hy_expr_free(hy_expr);

@@ -71,6 +71,8 @@ KIND_IDS = {
     "asinh": 21,
     "acosh": 22,
     "atanh": 23,
+    "atan2": 24,
+    "kepE": 25,
 }
 
 OC_SUCCESS = -4294967296 - 1
@@ -292,6 +294,27 @@ acosh = _unary("acosh", math.acosh)
 atanh = _unary("atanh", math.atanh)
 erf = _unary("erf", math.erf)
 sigmoid = _unary("sigmoid", lambda x: 1.0 / (1.0 + math.exp(-x)))
+
+
+def atan2(y, x):
+    """Reference: src/math/atan2.cpp:763-786 (two numbers fold)."""
+    y, x = as_ex(y), as_ex(x)
+    if y.is_num() and x.is_num():
+        return num(math.atan2(y.val, x.val))
+    return func("atan2", [y, x])
+
+
+def inv_kep_E(ecc, M):
+    """The oracle's Kepler solver (C restatement of llvm_add_inv_kep_E())."""
+    return _lib().hy_oracle_inv_kep_E(float(ecc), float(M))
+
+
+def kepE(e, M):
+    """Eccentric anomaly (src/math/kepE.cpp:801-809): zero eccentricity gives M, nothing else folds."""
+    e, M = as_ex(e), as_ex(M)
+    if e.is_num() and e.val == 0:
+        return M
+    return func("kepE", [e, M])
 
 
 # ----------------------------------------------------------------------------------------------
@@ -638,6 +661,22 @@ def taylor_decompose_sys(sys, sv_funcs=None):
             dc.append((pow_(new_args[0], num(2.0)), []))
             dc.append((f, [len(dc) - 1]))
             ret = len(dc) - 1
+        elif e.kind == "atan2":
+            # y^2 + x^2 -> atan2(y, x) depending on it (src/math/atan2.cpp:92-108).
+            dc.append((func("sum_sq", [new_args[0], new_args[1]]), []))
+            dc.append((f, [len(dc) - 1]))
+            ret = len(dc) - 1
+        elif e.kind == "kepE":
+            # E -> sin E -> cos E -> e cos E; E depends on (e cos E, sin E) (src/math/kepE.cpp:100-135).
+            dc.append((f, []))
+            ret = len(dc) - 1
+            uE = var(_uname(ret))
+            dc.append((sin(uE), []))
+            dc.append((cos(uE), []))
+            dc.append((new_args[0] * var(_uname(ret + 2)), []))
+            dc[ret][1].extend([ret + 3, ret + 1])
+            dc[ret + 1][1].append(ret + 2)
+            dc[ret + 2][1].append(ret + 1)
         elif e.kind == "erf":
             dc.append((pow_(new_args[0], num(2.0)), []))
             dc.append((-var(_uname(len(dc) - 1)), []))
@@ -769,6 +808,7 @@ class _CProg(ctypes.Structure):
         ("sv_type", ctypes.c_void_p),
         ("sv_idx", ctypes.c_void_p),
         ("sv_val", ctypes.c_void_p),
+        ("dep2", ctypes.c_void_p),
     ]
 
 
@@ -806,6 +846,8 @@ def _lib():
         _LIB.hy_oracle_scratch_size_e.restype = ctypes.c_size_t
         _LIB.hy_oracle_ensemble_propagate_until.restype = ctypes.c_int64
         _LIB.hy_oracle_max_threads.restype = ctypes.c_int
+        _LIB.hy_oracle_inv_kep_E.restype = ctypes.c_double
+        _LIB.hy_oracle_inv_kep_E.argtypes = [ctypes.c_double, ctypes.c_double]
     return _LIB
 
 
@@ -844,7 +886,7 @@ class OracleIntegrator:
         self._scratch = np.zeros(_lib().hy_oracle_scratch_size(ctypes.byref(self._prog), B) + 64)
 
     def _build_program(self):
-        kinds, arg_off, at, ai, av, dep = [], [0], [], [], [], []
+        kinds, arg_off, at, ai, av, dep, dep2 = [], [0], [], [], [], [], []
         n_par = 0
         for ex, deps in self.dc[self.n_eq : self.n_u]:
             kinds.append(KIND_IDS[ex.kind])
@@ -857,6 +899,7 @@ class OracleIntegrator:
                     n_par = max(n_par, i + 1)
             arg_off.append(len(at))
             dep.append(deps[0] if deps else -1)
+            dep2.append(deps[1] if len(deps) > 1 else -1)
         svt, svi, svv = [], [], []
         for ex, _ in self.dc[self.n_u :]:
             t, i, v = _operand(ex)
@@ -875,6 +918,7 @@ class OracleIntegrator:
             arg_idx=i32(ai if ai else [0]),
             arg_val=f64(av if av else [0.0]),
             dep=i32(dep if dep else [0]),
+            dep2=i32(dep2 if dep2 else [0]),
             sv_type=i32(svt),
             sv_idx=i32(svi),
             sv_val=f64(svv),
@@ -886,7 +930,7 @@ class OracleIntegrator:
             self.order,
             len(kinds),
             int(self.high_accuracy),
-            *[_p(self._arrs[k]) for k in ("kind", "arg_off", "arg_type", "arg_idx", "arg_val", "dep", "sv_type", "sv_idx", "sv_val")]
+            *[_p(self._arrs[k]) for k in ("kind", "arg_off", "arg_type", "arg_idx", "arg_val", "dep", "sv_type", "sv_idx", "sv_val", "dep2")]
         )
 
     # step(max_delta_ts=None, wtc=False); max_delta_ts: signed per-lane limits (default +inf).

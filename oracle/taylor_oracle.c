@@ -62,7 +62,9 @@ enum {
     K_ATAN = 20,
     K_ASINH = 21,
     K_ACOSH = 22,
-    K_ATANH = 23
+    K_ATANH = 23,
+    K_ATAN2 = 24,
+    K_KEPE = 25
 };
 
 enum { A_UVAR = 0, A_NUM = 1, A_PAR = 2 };
@@ -85,6 +87,7 @@ typedef struct {
     const int32_t *sv_type;  /* [n_eq] */
     const int32_t *sv_idx;   /* [n_eq] */
     const double *sv_val;    /* [n_eq] */
+    const int32_t *dep2;     /* [n_nodes], second hidden dependency (kepE), -1 if none */
 } hy_oracle_program;
 
 /* ---- helpers ---- */
@@ -154,6 +157,95 @@ static double unary0(int kind, double x)
         case K_ACOSH: return acosh(x);
         default: return atanh(x);
     }
+}
+
+/* Inverse of Kepler's equation E - e sin E = M (llvm_add_inv_kep_E(), src/detail/llvm_helpers_celmec.cpp:181-466, scalar
+ * flavour: every lane iterates until its own convergence). Double-length reduction of M to [0, 2 pi)
+ * (llvm_trig_arg_reduce(), :140-177; div2 / floor / mul2 / add of src/detail/llvm_helpers_dl.cpp:57-281), third-order
+ * initial guess, Newton-Raphson safeguarded by bisection, absolute tolerance 4 eps on f(E) and on the bracket, 20
+ * iterations at most (then nan). */
+static double inv_kep_E(double ecc_in, double M_in)
+{
+    const double ecc = (!(ecc_in >= 0.) || ecc_in >= 1.) ? NAN : ecc_in;
+
+    const double y_hi = 6.283185307179586, y_lo = 2.4492935982947064e-16;
+    const double twopi_prev = nextafter(y_hi, 0.);
+    /* x / y. */
+    const double c = M_in / y_hi;
+    const double u = c * y_hi, uu = fma(c, y_hi, -u);
+    double cc = M_in - u;
+    cc = cc - uu;
+    cc = cc + 0.;
+    cc = cc - c * y_lo;
+    cc = cc / y_hi;
+    const double q_hi = c + cc, q_lo = (c - q_hi) + cc;
+    /* floor. */
+    const double fhi = floor(q_hi);
+    const double flo = (fhi == q_hi) ? floor(q_lo) : 0.;
+    const double fl_hi = fhi + flo, fl_lo = (fhi - fl_hi) + flo;
+    /* y * floor. */
+    const double pc = y_hi * fl_hi;
+    double pcc = fma(y_hi, fl_hi, -pc);
+    pcc = (y_hi * fl_lo + y_lo * fl_hi) + pcc;
+    const double p_hi = pc + pcc, p_lo = (pc - p_hi) + pcc;
+    /* x - y * floor (llvm_dl_add(), :57-92, with the second operand negated). */
+    double M;
+    {
+        const double x_hi = M_in, x_lo = 0., yh = -p_hi, yl = -p_lo;
+        const double S = x_hi + yh, T = x_lo + yl;
+        double e = S - x_hi, f = T - x_lo;
+        double t1 = S - e;
+        t1 = x_hi - t1;
+        double s_ = yh - e;
+        s_ = s_ + t1;
+        t1 = T - f;
+        t1 = x_lo - t1;
+        double t = yl - f;
+        t = t + t1;
+        s_ = s_ + T;
+        const double H = S + s_;
+        double h = S - H;
+        h = h + s_;
+        h = h + t;
+        M = H + h;
+    }
+    M = (M < 0.) ? 0. : M;
+    M = (twopi_prev < M) ? twopi_prev : M;
+
+    double sE = sin(M), cE = cos(M);
+    const double e_sin = ecc * sE, e_cos = ecc * cE, e2 = ecc * ecc, cos2 = cE * cE;
+    double E = ((M + e_sin) + e_sin * e_cos) + (e2 * e_sin) * (1.5 * cos2 - 0.5);
+    double lb = 0., ub = twopi_prev;
+    E = (E < lb) ? lb : E;
+    E = (ub < E) ? ub : E;
+    sE = sin(E);
+    cE = cos(E);
+    double fE = (E - M) - ecc * sE;
+    const double tol = 4. * 2.220446049250313e-16;
+    int it = 0, not_converged = 0;
+    for (;;) {
+        const int sgn = (0. < fE) - (fE < 0.);
+        const double n_ub = (sgn >= 0) ? E : ub, n_lb = (sgn <= 0) ? E : lb;
+        ub = n_ub;
+        lb = n_lb;
+        not_converged = (fabs(fE) > tol) && ((ub - lb) > tol);
+        if (!(it < 20) || !not_converged) break;
+        double nE = E - fE / (1. - ecc * cE);
+        nE = (nE > ub) ? 0.5 * (E + ub) : nE;
+        nE = (nE < lb) ? 0.5 * (E + lb) : nE;
+        E = nE;
+        sE = sin(E);
+        cE = cos(E);
+        fE = (E - M) - ecc * sE;
+        ++it;
+    }
+    return (it == 20 && not_converged) ? NAN : E;
+}
+
+/* Exported for the tests (known answers of the Kepler solver). */
+double hy_oracle_inv_kep_E(double ecc, double M)
+{
+    return inv_kep_E(ecc, M);
 }
 
 #define TAPE(k, u) (tape + ((size_t)(k) * n_u + (size_t)(u)) * B)
@@ -551,6 +643,108 @@ static void node_diff(const hy_oracle_program *p, int i, int k, double *tape, co
                 ret = (kind == K_ACOS || kind == K_ATANH) ? (ret + scratch[l]) : (ret - scratch[l]);
                 out[l] = ret / ((double)k * D[l]);
             }
+            break;
+        }
+        case K_ATAN2: {
+            /* a = atan2(b, c), d = b^2 + c^2 (src/math/atan2.cpp:113-330):
+             * a^[k] = (k (c^[0] b^[k] - b^[0] c^[k]) + pairwise_sum_{j=1..k-1} j (c^[k-j] b^[j] - b^[k-j] c^[j] - d^[k-j] a^[j]))
+             *         / (k d^[0]); constant arguments drop their terms. */
+            const int vy = at[0] == A_UVAR, vx = at[1] == A_UVAR;
+            if (k == 0) {
+                for (int l = 0; l < B; ++l) {
+                    const double y = vy ? TAPE(0, ai[0])[l] : numpar(p, a0, pars, B, l);
+                    const double x = vx ? TAPE(0, ai[1])[l] : numpar(p, a0 + 1, pars, B, l);
+                    out[l] = atan2(y, x);
+                }
+                break;
+            }
+            if (!vy && !vx) {
+                for (int l = 0; l < B; ++l) out[l] = 0.;
+                break;
+            }
+            const int d = p->dep[i];
+            const double n = (double)k;
+            double *dividend = scratch + (size_t)(p->order + 2) * B;
+            for (int l = 0; l < B; ++l) {
+                if (vy && vx) {
+                    double t = TAPE(0, ai[1])[l] * TAPE(k, ai[0])[l];
+                    t = t - TAPE(0, ai[0])[l] * TAPE(k, ai[1])[l];
+                    dividend[l] = n * t;
+                } else if (vy) {
+                    dividend[l] = n * (numpar(p, a0 + 1, pars, B, l) * TAPE(k, ai[0])[l]);
+                } else {
+                    dividend[l] = -n * (numpar(p, a0, pars, B, l) * TAPE(k, ai[1])[l]);
+                }
+            }
+            if (k > 1) {
+                for (int j = 1; j < k; ++j) {
+                    double *t = scratch + (size_t)(j - 1) * B;
+                    const double *dnj = TAPE(k - j, d), *aj = TAPE(j, u);
+                    for (int l = 0; l < B; ++l) {
+                        const double t3 = dnj[l] * aj[l];
+                        if (vy && vx) {
+                            const double t1 = TAPE(k - j, ai[1])[l] * TAPE(j, ai[0])[l];
+                            const double t2 = TAPE(k - j, ai[0])[l] * TAPE(j, ai[1])[l];
+                            t[l] = (double)j * ((t1 - t2) - t3);
+                        } else {
+                            t[l] = -(double)j * t3;
+                        }
+                    }
+                }
+                pairwise_sum(scratch, k - 1, B);
+                for (int l = 0; l < B; ++l) dividend[l] = dividend[l] + scratch[l];
+            }
+            for (int l = 0; l < B; ++l) out[l] = dividend[l] / (n * TAPE(0, d)[l]);
+            break;
+        }
+        case K_KEPE: {
+            /* a = E(e, M), c = e cos(a) (dep), d = sin(a) (dep2) (src/math/kepE.cpp:140-355):
+             * a^[k] = (k (e^[k] d^[0] + M^[k]) + pairwise_sum_{j=1..k-1} j (c^[k-j] a^[j] + d^[k-j] e^[j])) / (k (1 - c^[0])). */
+            const int ve = at[0] == A_UVAR, vm = at[1] == A_UVAR;
+            if (k == 0) {
+                for (int l = 0; l < B; ++l) {
+                    const double e = ve ? TAPE(0, ai[0])[l] : numpar(p, a0, pars, B, l);
+                    const double M = vm ? TAPE(0, ai[1])[l] : numpar(p, a0 + 1, pars, B, l);
+                    out[l] = inv_kep_E(e, M);
+                }
+                break;
+            }
+            if (!ve && !vm) {
+                for (int l = 0; l < B; ++l) out[l] = 0.;
+                break;
+            }
+            const int c = p->dep[i], d = p->dep2[i];
+            const double n = (double)k;
+            double *dividend = scratch + (size_t)(p->order + 2) * B;
+            for (int l = 0; l < B; ++l) {
+                if (ve && vm) {
+                    double t = TAPE(k, ai[0])[l] * TAPE(0, d)[l];
+                    t = t + TAPE(k, ai[1])[l];
+                    dividend[l] = n * t;
+                } else if (ve) {
+                    dividend[l] = n * (TAPE(k, ai[0])[l] * TAPE(0, d)[l]);
+                } else {
+                    dividend[l] = n * TAPE(k, ai[1])[l];
+                }
+            }
+            if (k > 1) {
+                for (int j = 1; j < k; ++j) {
+                    double *t = scratch + (size_t)(j - 1) * B;
+                    const double *cnj = TAPE(k - j, c), *aj = TAPE(j, u);
+                    for (int l = 0; l < B; ++l) {
+                        if (ve) {
+                            double tmp = TAPE(k - j, d)[l] * TAPE(j, ai[0])[l];
+                            tmp = cnj[l] * aj[l] + tmp;
+                            t[l] = (double)j * tmp;
+                        } else {
+                            t[l] = (double)j * (cnj[l] * aj[l]);
+                        }
+                    }
+                }
+                pairwise_sum(scratch, k - 1, B);
+                for (int l = 0; l < B; ++l) dividend[l] = dividend[l] + scratch[l];
+            }
+            for (int l = 0; l < B; ++l) out[l] = dividend[l] / (n * (1. - TAPE(0, c)[l]));
             break;
         }
         default:

@@ -119,6 +119,75 @@ for _n, (_f, _d1, _d2, _a, _c) in UNARY.items():
     case("unary_" + _n, ["%s(%g*y + %g)" % (_n, _a, _c), "%s(%g*x + %g)" % (_n, _a, _c)],
          "test/taylor_%s.cpp (closed forms)" % _n, *_unary(_f, _d1, _d2, _a, _c))
 
+# 3b. Two-argument functions: atan2 (test/taylor_atan2.cpp) and the eccentric anomaly kepE (test/taylor_kepE.cpp).
+# g(p, q) with partials (g_p, g_q, g_pp, g_pq, g_qq); each right-hand side is g(a*z[i] + c, b*z[j] + d) with linear
+# inner maps (a == 0 or b == 0: constant argument).
+def _two_arg(g, parts, rows):
+    # rows[r] = (i, a, c, j, b, d): phi_r = g(a*z[i] + c, b*z[j] + d)
+    def args(z, r):
+        i, a, c, j, b, d = rows[r]
+        return a * z[i] + c, b * z[j] + d
+
+    def phi(z):
+        return [g(*args(z, r)) for r in range(2)]
+
+    def jac(z):
+        J = [[0.0, 0.0], [0.0, 0.0]]
+        for r in range(2):
+            i, a, c, j, b, d = rows[r]
+            gp, gq = parts(*args(z, r))[:2]
+            J[r][i] += a * gp
+            J[r][j] += b * gq
+        return J
+
+    def hess(z):
+        H = Z(2)
+        for r in range(2):
+            i, a, c, j, b, d = rows[r]
+            _, _, gpp, gpq, gqq = parts(*args(z, r))
+            H[r][i][i] += a * a * gpp
+            H[r][j][j] += b * b * gqq
+            H[r][i][j] += a * b * gpq
+            H[r][j][i] += a * b * gpq
+        return H
+
+    return phi, jac, hess
+
+
+def _atan2_parts(y, x):
+    r2 = x * x + y * y
+    return x / r2, -y / r2, -2 * x * y / r2 ** 2, (y * y - x * x) / r2 ** 2, 2 * x * y / r2 ** 2
+
+
+def _kep_solve(e, M):
+    # Independent of the oracle's solver: bracketing root finder on the reduced anomaly + Newton polishing.
+    from scipy.optimize import brentq
+
+    Mr = math.fmod(M, 2 * math.pi)
+    Mr = Mr + 2 * math.pi if Mr < 0 else Mr
+    E = brentq(lambda E: E - e * math.sin(E) - Mr, 0.0, 2 * math.pi, xtol=1e-15, rtol=1e-15)
+    for _ in range(3):
+        E -= (E - e * math.sin(E) - Mr) / (1 - e * math.cos(E))
+    return E
+
+
+def _kep_parts(e, M):
+    E = _kep_solve(e, M)
+    s, c = math.sin(E), math.cos(E)
+    D = 1.0 / (1.0 - e * c)
+    # (E_e, E_M, E_ee, E_eM, E_MM)
+    return s * D, D, D * D * s * (2 * c - e * s * s * D), D * D * (c - e * s * s * D), -e * s * D ** 3
+
+
+case("atan2_var_var", ["atan2(y, x)", "atan2(x, y)"], "test/taylor_atan2.cpp (closed forms)",
+     *_two_arg(math.atan2, _atan2_parts, [(1, 1.0, 0.0, 0, 1.0, 0.0), (0, 1.0, 0.0, 1, 1.0, 0.0)]))
+case("atan2_var_num", ["atan2(y, 1.5)", "atan2(0.3, x)"], "test/taylor_atan2.cpp (closed forms)",
+     *_two_arg(math.atan2, _atan2_parts, [(1, 1.0, 0.0, 0, 0.0, 1.5), (1, 0.0, 0.3, 0, 1.0, 0.0)]))
+case("kepE_var_var", ["kepE(0.1*x, y)", "kepE(0.05*y, x)"], "test/taylor_kepE.cpp (closed forms)",
+     *_two_arg(_kep_solve, _kep_parts, [(0, 0.1, 0.0, 1, 1.0, 0.0), (1, 0.05, 0.0, 0, 1.0, 0.0)]))
+case("kepE_num_var", ["kepE(0.3, y)", "kepE(0.05*x, 0.4)"], "test/taylor_kepE.cpp (closed forms)",
+     *_two_arg(_kep_solve, _kep_parts, [(0, 0.0, 0.3, 1, 1.0, 0.0), (0, 0.05, 0.0, 1, 0.0, 0.4)]))
+
 # 4. Explicit time dependence (z = (x, y, t), t' = 1; test/taylor_time.cpp).
 case("time", ["time + y", "x * time"], "test/taylor_time.cpp",
      lambda z: [z[2] + z[1], z[0] * z[2], 1.0],

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def header_symbols():
     txt = open(os.path.join(ROOT, "include", "heyoka_amd.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(hy_[a-z_0-9]+)\s*\(", txt)) - {"hy_step_callback", "hy_ensemble_gen"})
+    return sorted(set(re.findall(r"\b(hy_[A-Za-z_0-9]+)\s*\(", txt)) - {"hy_step_callback", "hy_ensemble_gen"})
 
 
 def test_every_declared_symbol_is_exported():

@@ -621,6 +621,65 @@ def test_unary_functions_full_order_step_parity(fn):
     assert rel_err(ta.state, ora.state.reshape(2, n)) <= 1e6 * EPS
 
 
+@pytest.mark.parametrize("mode", ["unrolled", "table"])
+def test_atan2_kepE_full_order_step_parity(mode):
+    """atan2 and kepE in all the argument combinations (variable / number / parameter), order 20: one full step and a
+    propagation vs the oracle, in the unrolled and in the interpreted (table) stepper. The order <= 3 coefficients
+    are pinned by closed forms in tests/test_node_jets.py; the Kepler solver is the restatement of
+    llvm_add_inv_kep_E() (src/detail/llvm_helpers_celmec.cpp:181-466) on both sides (device function hy_kepE in the
+    generated module vs oracle/taylor_oracle.c)."""
+    import os
+
+    def build(m, x, y, t, par):
+        return [
+            (x, 0.3 * m.atan2(y, 1.0 + x * x) - 0.4 * x + 0.1 * m.sin(m.kepE(0.3 + 0.2 * m.sin(y), 2.0 * x + t))
+             + 0.1 * m.atan2(y, 1.5) + 0.1 * m.atan2(par, x + 2.0)),
+            (y, -0.3 * m.atan2(x, y + 3.0) - 0.4 * y + 0.2 * m.cos(m.kepE(0.6, y)) - 0.2 * m.kepE(0.1 + 0.05 * m.cos(x), 0.7)),
+        ]
+
+    n = 45
+    rng = np.random.RandomState(77)
+    st = np.stack([rng.uniform(-0.8, 0.8, n), rng.uniform(-0.8, 0.8, n)])
+    pars = rng.uniform(0.2, 0.5, (1, n))
+    x, y = hy.make_vars("x", "y")
+    os.environ["HEYOKA_AMD_EMIT_MODE"] = mode
+    try:
+        ta = hy.taylor_adaptive_batch(build(hy, x, y, hy.time, hy.par[0]), st, n, pars=pars)
+    finally:
+        del os.environ["HEYOKA_AMD_EMIT_MODE"]
+    assert ta.hip_source_mode.startswith(mode)
+    ora = ho.OracleIntegrator(build(ho, ho.var("x"), ho.var("y"), ho.func("time", []), ho.par(0)), st, n, pars=pars)
+    ta.step(write_tc=True)
+    ora.step(wtc=True)
+    h_g = np.array([h for _, h in ta.step_res])
+    h_o = np.array([h for _, h in ora.step_res])
+    assert np.max(np.abs(h_g - h_o) / np.abs(h_o)) <= 1e6 * EPS
+    tc_o = ora.tc.reshape(2, ora.order + 1, n)
+    scale = np.max(np.abs(tc_o), axis=2, keepdims=True) + 1e-300
+    assert np.max(np.abs(np.asarray(ta.tc).reshape(2, 21, n) - tc_o) / scale) <= 1e6 * EPS
+    assert rel_err(ta.state, ora.state.reshape(2, n)) <= 1e5 * EPS
+    ta.propagate_until(2.5)
+    ora.propagate_until(2.5)
+    assert [r[3] for r in ta.propagate_res] == [r[3] for r in ora.prop_res]
+    assert rel_err(ta.state, ora.state.reshape(2, n)) <= 1e6 * EPS
+
+    # The Kepler solver itself: E - e sin E = M mod 2 pi to a few ulps, nan for invalid eccentricities
+    # (test/kepE.cpp:296-373 checks the same residual at 1000 eps).
+    e, M = hy.make_vars("e", "M")
+    cf = hy.cfunc([hy.kepE(e, M)], [e, M])
+    ecc = np.concatenate([rng.uniform(0, 0.99, 500), [0.0, 0.999999, 1.0, -0.1, np.nan]])
+    Mv = np.concatenate([rng.uniform(-40, 40, 500), [0.3, 1e-9, 0.3, 0.3, 0.3]])
+    E = cf(np.stack([ecc, Mv]))[0]
+    assert np.all(np.isnan(E[-3:])) and np.all(np.isfinite(E[:-3]))
+    ok = slice(0, -3)
+    Mr = np.mod(Mv[ok], 2 * np.pi)
+    res = E[ok] - ecc[ok] * np.sin(E[ok]) - Mr
+    res = np.minimum(np.abs(res), np.abs(np.abs(res) - 2 * np.pi))
+    assert np.max(res) <= 1000 * EPS * 2 * np.pi
+    E_o = np.array([ho.inv_kep_E(a, b) for a, b in zip(ecc[ok], Mv[ok])])
+    assert np.max(np.abs(E[ok] - E_o)) <= 64 * EPS * 2 * np.pi
+
+
 def test_propagate_grid_device_loop_equals_host_loop():
     """The device-resident propagate_grid() loop (step kernel + post-step kernel, no per-lane host work) gives
     the same samples, states and propagate_res as the host-driven transcription of the reference's loop

@@ -44,6 +44,10 @@ def build(m, name):
         "sin_cos": (m.sin(y), m.cos(x)),
         "exp_log": (m.exp(0.1 * y), m.log(x)),
         "time": (t + y, x * t),
+        "atan2_var_var": (m.atan2(y, x), m.atan2(x, y)),
+        "atan2_var_num": (m.atan2(y, 1.5), m.atan2(0.3, x)),
+        "kepE_var_var": (m.kepE(0.1 * x, y), m.kepE(0.05 * y, x)),
+        "kepE_num_var": (m.kepE(0.3, y), m.kepE(0.05 * x, 0.4)),
     }[name]
     return [(x, rhs[0]), (y, rhs[1])]
 
