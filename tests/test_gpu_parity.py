@@ -680,6 +680,38 @@ def test_atan2_kepE_full_order_step_parity(mode):
     assert np.max(np.abs(E[ok] - E_o)) <= 64 * EPS * 2 * np.pi
 
 
+def test_kepE_stark_problem_known_answer_on_gpu(golden):
+    """The reference's known answer for an integration through kepE (test/kepE.cpp:194-239, Stark problem in Delaunay
+    elements, propagate_until(250)): lane 0 carries the reference's initial state and must reproduce its final state
+    to 100 eps (mean anomaly through sin / cos at 1e4 eps); the other lanes are perturbed copies compared with the
+    oracle."""
+    from test_oracle_golden import stark_delaunay
+
+    g = golden["kepE_stark"]
+    n = 24
+    L0, G0, H0, E0, g0, h0 = g["init_state_LGH_E_gh"]
+    l0 = E0 - np.sqrt(1 - G0 * G0 / (L0 * L0)) * np.sin(E0)
+    rng = np.random.RandomState(8)
+    st = np.array([L0, G0, H0, l0, g0, h0])[:, None] * (1.0 + 1e-4 * rng.uniform(-1, 1, (6, n)))
+    st[:, 0] = [L0, G0, H0, l0, g0, h0]
+    ta = hy.taylor_adaptive_batch(stark_delaunay(hy, g["eps"]), st, n)
+    ora = ho.OracleIntegrator(stark_delaunay(ho, g["eps"]), st, n)
+    ta.propagate_until(g["t_final"])
+    ora.propagate_until(g["t_final"])
+    assert all(r[0] == OC.time_limit for r in ta.propagate_res)
+    s = ta.state
+    for got, exp in zip([s[0, 0], s[1, 0], s[2, 0], s[4, 0], s[5, 0]], g["final_L_G_H_g_h"]):
+        assert abs(got - exp) <= g["tol_eps"] * EPS * abs(exp)
+    fL, fG, fE = s[0, 0], s[1, 0], g["final_E"]
+    l_exp = fE - np.sqrt(1 - fG * fG / (fL * fL)) * np.sin(fE)
+    assert abs(np.sin(s[3, 0]) - np.sin(l_exp)) <= g["tol_eps_angle_l"] * EPS * abs(np.sin(l_exp))
+    assert abs(np.cos(s[3, 0]) - np.cos(l_exp)) <= g["tol_eps_angle_l"] * EPS * abs(np.cos(l_exp))
+    so = ora.state.reshape(6, n)
+    # Actions and slow angles: 1e4 eps; the fast angle l accumulates the rounding of L over 250 time units.
+    assert rel_err(s[[0, 1, 2, 4, 5]], so[[0, 1, 2, 4, 5]]) <= 1e4 * EPS
+    assert np.max(np.abs(s[3] - so[3])) <= 1e5 * EPS * np.max(np.abs(so[3]))
+
+
 def test_propagate_grid_device_loop_equals_host_loop():
     """The device-resident propagate_grid() loop (step kernel + post-step kernel, no per-lane host work) gives
     the same samples, states and propagate_res as the host-driven transcription of the reference's loop

@@ -198,3 +198,49 @@ def test_events_tutorial_terminal_event(golden):
         ta.propagate_until(float(tg))
         assert ta.time_hi[0] == tg
         assert np.max(np.abs(ta.state - np.array(exp))) <= 1e-13
+
+
+def stark_delaunay(m, eps):
+    """Hamilton's equations of the Stark problem in Delaunay elements with the eccentric anomaly E = kepE(e, l)
+    (the system of test/kepE.cpp:194-239, with the partial derivatives of the Hamiltonian written out by hand)."""
+    if m is ho:
+        L, G, H, l, g, h = (m.var(n) for n in ("L", "G", "H", "l", "g", "h"))
+        powf, sqrt = m.pow_, m.sqrt
+    else:
+        L, G, H, l, g, h = m.make_vars("L", "G", "H", "l", "g", "h")
+        powf, sqrt = m.pow, m.sqrt
+    e = sqrt(1.0 - G * G / (L * L))
+    E = m.kepE(e, l)
+    sE, cE, sg, cg = m.sin(E), m.cos(E), m.sin(g), m.cos(g)
+    A = sqrt(1.0 - H * H / (G * G))
+    B = L * (cE - e) * sg + G * sE * cg
+    den = 1.0 / (1.0 - e * cE)
+    E_l, E_e = den, sE * den
+    e_L, e_G = (G * G / (L * L * L)) / e, -(G / (L * L)) / e
+    B_E = G * cE * cg - L * sE * sg
+    A_H, A_G = -(H / (G * G)) / A, (H * H / (G * G * G)) / A
+    dH_dl = -eps * L * A * B_E * E_l
+    dH_dg = -eps * L * A * (L * (cE - e) * cg - G * sE * sg)
+    dH_dL = powf(L, -3.0) - eps * A * B - eps * L * A * ((cE - e) * sg + B_E * E_e * e_L - L * sg * e_L)
+    dH_dG = -eps * L * B * A_G - eps * L * A * (sE * cg + B_E * E_e * e_G - L * sg * e_G)
+    dH_dH = -eps * L * B * A_H
+    return [(L, -dH_dl), (G, -dH_dg), (H, 0.0 * L), (l, dH_dL), (g, dH_dG), (h, dH_dH)]
+
+
+def test_kepE_stark_problem_known_answer(golden):
+    """Known answer held by the reference for an integration through kepE (test/kepE.cpp:194-239): state after
+    propagate_until(250) to 100 eps (the mean anomaly through sin / cos at 1e4 eps)."""
+    g = golden["kepE_stark"]
+    L0, G0, H0, E0, g0, h0 = g["init_state_LGH_E_gh"]
+    l0 = E0 - np.sqrt(1 - G0 * G0 / (L0 * L0)) * np.sin(E0)
+    st = np.array([L0, G0, H0, l0, g0, h0])[:, None]
+    oi = ho.OracleIntegrator(stark_delaunay(ho, g["eps"]), st, 1)
+    oi.propagate_until(g["t_final"])
+    assert oi.prop_res[0][0] == ho.OC_TIME_LIMIT
+    s = oi.state
+    for got, exp in zip([s[0], s[1], s[2], s[4], s[5]], g["final_L_G_H_g_h"]):
+        assert abs(got - exp) <= g["tol_eps"] * EPS * abs(exp)
+    fL, fG, fE = s[0], s[1], g["final_E"]
+    l_exp = fE - np.sqrt(1 - fG * fG / (fL * fL)) * np.sin(fE)
+    assert abs(np.sin(s[3]) - np.sin(l_exp)) <= g["tol_eps_angle_l"] * EPS * abs(np.sin(l_exp))
+    assert abs(np.cos(s[3]) - np.cos(l_exp)) <= g["tol_eps_angle_l"] * EPS * abs(np.cos(l_exp))
