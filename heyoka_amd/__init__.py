@@ -264,6 +264,57 @@ def kepE(e, M):
     return _bin(lib.hy_expr_kepE, _as_ex(e), M)
 
 
+def relu(x, slope=0.0):
+    """relu(x, slope) = x > 0 ? x : slope * x (src/math/relu.cpp:580-590)."""
+    x = _as_ex(x)
+    return expression._wrap(check_handle(lib.hy_expr_relu(x._h, float(slope))))
+
+
+def relup(x, slope=0.0):
+    """Derivative of relu (src/math/relu.cpp:592-602)."""
+    x = _as_ex(x)
+    return expression._wrap(check_handle(lib.hy_expr_relup(x._h, float(slope))))
+
+
+def leaky_relu(slope):
+    return lambda x: relu(x, slope)
+
+
+def leaky_relup(slope):
+    return lambda x: relup(x, slope)
+
+
+def select(cond, t, f):
+    """select(c, t, f) = c != 0 ? t : f (src/math/select.cpp:267-270)."""
+    c, t, f = _as_ex(cond), _as_ex(t), _as_ex(f)
+    return expression._wrap(lib.hy_expr_select(c._h, t._h, f._h))
+
+
+def _logical(is_and, args):
+    exs = [_as_ex(a) for a in args]
+    arr = (ctypes.c_void_p * len(exs))(*[e._h for e in exs]) if exs else None
+    return expression._wrap(lib.hy_expr_logical(is_and, arr, len(exs)))
+
+
+def logical_and(args):
+    return _logical(1, args)
+
+
+def logical_or(args):
+    return _logical(0, args)
+
+
+def _rel(op):
+    def f(a, b):
+        a, b = _as_ex(a), _as_ex(b)
+        return expression._wrap(lib.hy_expr_rel(op, a._h, b._h))
+
+    return f
+
+
+eq, neq, lt, gt, lte, gte = (_rel(i) for i in range(6))
+
+
 def _handle_array(exs):
     exs = [_as_ex(e) for e in exs]
     arr = (ctypes.c_void_p * max(len(exs), 1))(*[e._h for e in exs])

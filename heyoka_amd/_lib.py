@@ -97,6 +97,11 @@ SIGNATURES = [
     ("hy_expr_sigmoid", c_void_p, [c_void_p]),
     ("hy_expr_atan2", c_void_p, [c_void_p, c_void_p]),
     ("hy_expr_kepE", c_void_p, [c_void_p, c_void_p]),
+    ("hy_expr_relu", c_void_p, [c_void_p, c_double]),
+    ("hy_expr_relup", c_void_p, [c_void_p, c_double]),
+    ("hy_expr_select", c_void_p, [c_void_p, c_void_p, c_void_p]),
+    ("hy_expr_logical", c_void_p, [c_int, c_void_p, c_size_t]),
+    ("hy_expr_rel", c_void_p, [c_int, c_void_p, c_void_p]),
     ("hy_expr_sum", c_void_p, [c_void_p, c_size_t]),
     ("hy_expr_prod", c_void_p, [c_void_p, c_size_t]),
     ("hy_expr_free", None, [c_void_p]),

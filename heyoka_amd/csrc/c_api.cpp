@@ -229,6 +229,49 @@ hy_expr hy_expr_kepE(hy_expr e, hy_expr M)
 {
     return make_expr([&] { return kepE(e->ex, M->ex); });
 }
+hy_expr hy_expr_relu(hy_expr x, double slope)
+{
+    return make_expr([&] { return relu(x->ex, slope); });
+}
+hy_expr hy_expr_relup(hy_expr x, double slope)
+{
+    return make_expr([&] { return relup(x->ex, slope); });
+}
+hy_expr hy_expr_select(hy_expr c, hy_expr t, hy_expr f)
+{
+    return make_expr([&] { return select(c->ex, t->ex, f->ex); });
+}
+hy_expr hy_expr_logical(int is_and, const hy_expr *args, size_t n)
+{
+    return make_expr([&] {
+        std::vector<expression> v;
+        for (size_t i = 0; i < n; ++i) {
+            v.push_back(args[i]->ex);
+        }
+        return is_and != 0 ? logical_and(std::move(v)) : logical_or(std::move(v));
+    });
+}
+hy_expr hy_expr_rel(int op, hy_expr a, hy_expr b)
+{
+    return make_expr([&] {
+        switch (op) {
+            case 0:
+                return eq(a->ex, b->ex);
+            case 1:
+                return neq(a->ex, b->ex);
+            case 2:
+                return lt(a->ex, b->ex);
+            case 3:
+                return gt(a->ex, b->ex);
+            case 4:
+                return lte(a->ex, b->ex);
+            case 5:
+                return gte(a->ex, b->ex);
+            default:
+                throw std::invalid_argument("Invalid relational operator code: " + std::to_string(op));
+        }
+    });
+}
 hy_expr hy_expr_sqrt(hy_expr a)
 {
     return make_expr([&] { return sqrt(a->ex); });

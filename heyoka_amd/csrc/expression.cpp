@@ -58,6 +58,28 @@ const char *func_kind_name(func_kind k)
             return "atan2";
         case func_kind::kepE:
             return "kepE";
+        case func_kind::relu:
+            return "relu";
+        case func_kind::relup:
+            return "relup";
+        case func_kind::select:
+            return "select";
+        case func_kind::logical_and:
+            return "logical_and";
+        case func_kind::logical_or:
+            return "logical_or";
+        case func_kind::rel_eq:
+            return "rel_eq";
+        case func_kind::rel_neq:
+            return "rel_neq";
+        case func_kind::rel_lt:
+            return "rel_lt";
+        case func_kind::rel_gt:
+            return "rel_gt";
+        case func_kind::rel_lte:
+            return "rel_lte";
+        case func_kind::rel_gte:
+            return "rel_gte";
         case func_kind::asinh:
             return "asinh";
         case func_kind::acosh:
@@ -439,6 +461,94 @@ expression kepE(expression e, expression M)
     }
     return detail::make_func(func_kind::kepE, {std::move(e), std::move(M)});
 }
+
+namespace
+{
+
+// Reference: relu_slope_check(), src/math/relu.cpp:52-59.
+void relu_slope_check(double slope)
+{
+    if (!std::isfinite(slope) || slope < 0) {
+        std::ostringstream oss;
+        oss << "The slope parameter for a leaky ReLU must be finite and non-negative, but the value " << slope
+            << " was provided instead";
+        throw std::invalid_argument(oss.str());
+    }
+}
+
+} // namespace
+
+// Reference: src/math/relu.cpp:580-602 (numbers fold).
+expression relu(expression x, double slope)
+{
+    relu_slope_check(slope);
+    if (x.is_number()) {
+        return expression{x.num() > 0 ? x.num() : slope * x.num()};
+    }
+    return detail::make_func(func_kind::relu, {std::move(x), expression{slope}});
+}
+
+expression relup(expression x, double slope)
+{
+    relu_slope_check(slope);
+    if (x.is_number()) {
+        return expression{x.num() > 0 ? 1. : slope};
+    }
+    return detail::make_func(func_kind::relup, {std::move(x), expression{slope}});
+}
+
+leaky_relu::leaky_relu(double s) : slope(s)
+{
+    relu_slope_check(s);
+}
+
+leaky_relup::leaky_relup(double s) : slope(s)
+{
+    relu_slope_check(s);
+}
+
+// Reference: src/math/select.cpp:267-270 (no folding).
+expression select(expression cond, expression t, expression f)
+{
+    return detail::make_func(func_kind::select, {std::move(cond), std::move(t), std::move(f)});
+}
+
+// Reference: src/math/logical.cpp:314-338.
+expression logical_and(std::vector<expression> args)
+{
+    if (args.empty()) {
+        return expression{1.};
+    }
+    if (args.size() == 1u) {
+        return std::move(args[0]);
+    }
+    return detail::make_func(func_kind::logical_and, std::move(args));
+}
+
+expression logical_or(std::vector<expression> args)
+{
+    if (args.empty()) {
+        return expression{0.};
+    }
+    if (args.size() == 1u) {
+        return std::move(args[0]);
+    }
+    return detail::make_func(func_kind::logical_or, std::move(args));
+}
+
+// Reference: src/math/relational.cpp:343-354 (no folding).
+#define HEYOKA_AMD_REL_FUNC(name)                                                                                      \
+    expression name(expression a, expression b)                                                                        \
+    {                                                                                                                  \
+        return detail::make_func(func_kind::rel_##name, {std::move(a), std::move(b)});                                 \
+    }
+HEYOKA_AMD_REL_FUNC(eq)
+HEYOKA_AMD_REL_FUNC(neq)
+HEYOKA_AMD_REL_FUNC(lt)
+HEYOKA_AMD_REL_FUNC(gt)
+HEYOKA_AMD_REL_FUNC(lte)
+HEYOKA_AMD_REL_FUNC(gte)
+#undef HEYOKA_AMD_REL_FUNC
 
 // --- Traversal. ---
 // Iterative post-order traversal replicating the visiting order of the reference

@@ -57,7 +57,20 @@ enum class func_kind : std::uint8_t {
     sigmoid,
     // Two-argument functions (reference: src/math/atan2.cpp, src/math/kepE.cpp).
     atan2,
-    kepE
+    kepE,
+    // Piecewise functions (reference: src/math/{relu,select,relational,logical}.cpp). relu / relup carry the slope
+    // of the leaky variants as a second (numerical) argument.
+    relu,
+    relup,
+    select,
+    logical_and,
+    logical_or,
+    rel_eq,
+    rel_neq,
+    rel_lt,
+    rel_gt,
+    rel_lte,
+    rel_gte
 };
 
 const char *func_kind_name(func_kind);
@@ -217,6 +230,36 @@ expression sigmoid(expression);
 // (src/math/kepE.cpp:801-809).
 expression atan2(expression y, expression x);
 expression kepE(expression e, expression M);
+// relu(x, slope) = x > 0 ? x : slope * x and its derivative relup (src/math/relu.cpp:580-602); leaky_relu(slope)(x).
+expression relu(expression x, double slope = 0.);
+expression relup(expression x, double slope = 0.);
+struct leaky_relu {
+    double slope;
+    explicit leaky_relu(double s);
+    expression operator()(expression x) const
+    {
+        return relu(std::move(x), slope);
+    }
+};
+struct leaky_relup {
+    double slope;
+    explicit leaky_relup(double s);
+    expression operator()(expression x) const
+    {
+        return relup(std::move(x), slope);
+    }
+};
+// select(c, t, f) = c != 0 ? t : f (src/math/select.cpp:267-270), logical_and / logical_or of the truth values
+// (src/math/logical.cpp:314-338), comparisons returning 1 / 0 (src/math/relational.cpp:343-354).
+expression select(expression cond, expression t, expression f);
+expression logical_and(std::vector<expression> args);
+expression logical_or(std::vector<expression> args);
+expression eq(expression, expression);
+expression neq(expression, expression);
+expression lt(expression, expression);
+expression gt(expression, expression);
+expression lte(expression, expression);
+expression gte(expression, expression);
 
 namespace detail
 {

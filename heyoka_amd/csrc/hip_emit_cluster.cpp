@@ -173,9 +173,9 @@ std::string cluster_detail::make_plan(const taylor_program &p, std::uint32_t ord
     union_find uf(n_u);
     std::vector<char> in_h(n_u, 0);
     for (std::uint32_t i = 0; i < p.nodes.size(); ++i) {
-        if (p.nodes[i].kind == func_kind::atan2 || p.nodes[i].kind == func_kind::kepE) {
-            // Served by the unrolled / table steppers.
-            return "two-argument transcendental function (atan2 / kepE)";
+        if (p.nodes[i].kind >= func_kind::atan2) {
+            // atan2, kepE and the piecewise functions: served by the unrolled / table steppers.
+            return std::string("function served by the unrolled / table steppers: ") + func_kind_name(p.nodes[i].kind);
         }
         const auto u = n_eq + i;
         const auto hs = history_operands(p.nodes[i]);

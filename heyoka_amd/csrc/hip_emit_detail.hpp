@@ -549,6 +549,71 @@ struct ssa_emitter {
                 out = def(ret + " / " + def(mul(kf, D)));
                 break;
             }
+            case func_kind::relu:
+            case func_kind::relup: {
+                // relu(b)^[k] = b^[0] > 0 ? b^[k] : slope * b^[k] (all orders), relup(b)^[0] = b^[0] > 0 ? 1 : slope and 0
+                // beyond (src/math/relu.cpp:144-178, :392-424).
+                const auto slope = a.at(1).value;
+                const auto pick = [&](const std::string &c, const std::string &x) {
+                    if (n.kind == func_kind::relup) {
+                        return def("(" + c + " > 0.0) ? 1.0 : " + fp_literal(slope));
+                    }
+                    return slope == 0. ? def("(" + c + " > 0.0) ? " + x + " : 0.0")
+                                       : def("(" + c + " > 0.0) ? " + x + " : " + def(mul(fp_literal(slope), x)));
+                };
+                if (!is_var(a[0])) {
+                    out = (k == 0u) ? pick(numpar(a[0]), numpar(a[0])) : "0.0";
+                } else if (n.kind == func_kind::relup) {
+                    out = (k == 0u) ? pick(val(a[0].idx, 0), "") : "0.0";
+                } else {
+                    out = pick(val(a[0].idx, 0), val(a[0].idx, k));
+                }
+                break;
+            }
+            case func_kind::select: {
+                // select(c, t, f)^[k] = c^[0] != 0 ? t^[k] : f^[k] (src/math/select.cpp:88-131).
+                const auto arg_k = [&](const operand &o) {
+                    return is_var(o) ? val(o.idx, k) : (k == 0u ? numpar(o) : std::string("0.0"));
+                };
+                const auto c0 = is_var(a[0]) ? val(a[0].idx, 0) : numpar(a[0]);
+                out = def("(" + c0 + " != 0.0) ? " + arg_k(a.at(1)) + " : " + arg_k(a.at(2)));
+                break;
+            }
+            case func_kind::logical_and:
+            case func_kind::logical_or:
+            case func_kind::rel_eq:
+            case func_kind::rel_neq:
+            case func_kind::rel_lt:
+            case func_kind::rel_gt:
+            case func_kind::rel_lte:
+            case func_kind::rel_gte: {
+                // Truth values 1 / 0 at order 0, zero beyond (src/math/relational.cpp:197-238, logical.cpp:93-127, :266-300).
+                if (k != 0u) {
+                    out = "0.0";
+                    break;
+                }
+                const auto arg0 = [&](const operand &o) { return is_var(o) ? val(o.idx, 0) : numpar(o); };
+                std::string e;
+                if (n.kind == func_kind::logical_and || n.kind == func_kind::logical_or) {
+                    for (std::size_t i = 0; i < a.size(); ++i) {
+                        e += (i == 0u ? "" : (n.kind == func_kind::logical_and ? " & " : " | "));
+                        e += "(" + arg0(a[i]) + " != 0.0)";
+                    }
+                } else {
+                    // NOTE: "neq" is an ordered comparison in the reference (false if an operand is nan).
+                    const auto x = arg0(a.at(0)), y = arg0(a.at(1));
+                    switch (n.kind) {
+                        case func_kind::rel_eq: e = x + " == " + y; break;
+                        case func_kind::rel_neq: e = "(" + x + " < " + y + ") | (" + x + " > " + y + ")"; break;
+                        case func_kind::rel_lt: e = x + " < " + y; break;
+                        case func_kind::rel_gt: e = x + " > " + y; break;
+                        case func_kind::rel_lte: e = x + " <= " + y; break;
+                        default: e = x + " >= " + y; break;
+                    }
+                }
+                out = def("(" + e + ") ? 1.0 : 0.0");
+                break;
+            }
             case func_kind::atan2: {
                 // a = atan2(b, c), d = b^2 + c^2 (hidden dependency). Reference: src/math/atan2.cpp:113-330:
                 //   a^[k] = (k (c^[0] b^[k] - b^[0] c^[k]) + sum_{j=1..k-1} j (c^[k-j] b^[j] - b^[k-j] c^[j] - d^[k-j] a^[j]))

@@ -54,6 +54,17 @@ const char *table_device_code = R"HIP(
 #define K_ATANH 23
 #define K_ATAN2 24
 #define K_KEPE 25
+#define K_RELU 26
+#define K_RELUP 27
+#define K_SELECT 28
+#define K_LAND 29
+#define K_LOR 30
+#define K_REL_EQ 31
+#define K_REL_NEQ 32
+#define K_REL_LT 33
+#define K_REL_GT 34
+#define K_REL_LTE 35
+#define K_REL_GTE 36
 #define A_UVAR 0
 #define A_NUM 1
 #define A_PAR 2
@@ -380,6 +391,41 @@ __device__ double hy_diff_kepE(const hy_tctx &c, unsigned a0, unsigned u, unsign
     return dividend / (kf * (1.0 - hy_tp(c, 0, dc)));
 }
 
+// Piecewise functions (see ssa_emitter::node(); src/math/{relu,select,relational,logical}.cpp).
+__device__ double hy_diff_piecewise(const hy_tctx &c, unsigned kind, unsigned a0, unsigned nargs, unsigned k)
+{
+    const auto arg0 = [&](unsigned a) { return hy_arg_type[a] == A_UVAR ? hy_tp(c, 0, hy_arg_idx[a]) : hy_numpar(c, a); };
+    const auto argk = [&](unsigned a) {
+        return hy_arg_type[a] == A_UVAR ? hy_tp(c, k, hy_arg_idx[a]) : (k == 0u ? hy_numpar(c, a) : 0.0);
+    };
+    if (kind == K_RELU) {
+        const double x = argk(a0);
+        return (arg0(a0) > 0.0) ? x : hy_arg_val[a0 + 1u] * x;
+    }
+    if (kind == K_RELUP) return (k == 0u) ? ((arg0(a0) > 0.0) ? 1.0 : hy_arg_val[a0 + 1u]) : 0.0;
+    if (kind == K_SELECT) return (arg0(a0) != 0.0) ? argk(a0 + 1u) : argk(a0 + 2u);
+    if (k != 0u) return 0.0;
+    bool r;
+    if (kind == K_LAND || kind == K_LOR) {
+        r = (kind == K_LAND);
+        for (unsigned j = 0; j < nargs; ++j) {
+            const bool t = arg0(a0 + j) != 0.0;
+            r = (kind == K_LAND) ? (r & t) : (r | t);
+        }
+    } else {
+        const double x = arg0(a0), y = arg0(a0 + 1u);
+        switch (kind) {
+            case K_REL_EQ: r = x == y; break;
+            case K_REL_NEQ: r = (x < y) | (x > y); break;
+            case K_REL_LT: r = x < y; break;
+            case K_REL_GT: r = x > y; break;
+            case K_REL_LTE: r = x <= y; break;
+            default: r = x >= y; break;
+        }
+    }
+    return r ? 1.0 : 0.0;
+}
+
 // Order-k coefficients of all the u variables that are not state variables.
 __device__ void hy_nodes_order(const hy_tctx &c, unsigned k)
 {
@@ -405,6 +451,9 @@ __device__ void hy_nodes_order(const hy_tctx &c, unsigned k)
                 v = hy_diff_inv(c, hy_kind[i], a0, u, hy_dep[i], k); break;
             case K_ATAN2: v = hy_diff_atan2(c, a0, u, hy_dep[i], k); break;
             case K_KEPE: v = hy_diff_kepE(c, a0, u, hy_dep[i], hy_dep2[i], k); break;
+            case K_RELU: case K_RELUP: case K_SELECT: case K_LAND: case K_LOR: case K_REL_EQ: case K_REL_NEQ:
+            case K_REL_LT: case K_REL_GT: case K_REL_LTE: case K_REL_GTE:
+                v = hy_diff_piecewise(c, hy_kind[i], a0, nargs, k); break;
             default: v = (k == 0u) ? hy_numpar(c, a0) : 0.0; break;
         }
         hy_tp(c, k, u) = v;
@@ -627,6 +676,28 @@ int kind_id(func_kind k)
             return 24;
         case func_kind::kepE:
             return 25;
+        case func_kind::relu:
+            return 26;
+        case func_kind::relup:
+            return 27;
+        case func_kind::select:
+            return 28;
+        case func_kind::logical_and:
+            return 29;
+        case func_kind::logical_or:
+            return 30;
+        case func_kind::rel_eq:
+            return 31;
+        case func_kind::rel_neq:
+            return 32;
+        case func_kind::rel_lt:
+            return 33;
+        case func_kind::rel_gt:
+            return 34;
+        case func_kind::rel_lte:
+            return 35;
+        case func_kind::rel_gte:
+            return 36;
         default:
             return 11;
     }

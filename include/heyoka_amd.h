@@ -85,6 +85,14 @@ hy_expr hy_expr_erf(hy_expr);
 hy_expr hy_expr_sigmoid(hy_expr);
 hy_expr hy_expr_atan2(hy_expr y, hy_expr x); /* atan2(y, x)                  src/math/atan2.cpp:763 */
 hy_expr hy_expr_kepE(hy_expr e, hy_expr M);  /* eccentric anomaly E(e, M)    src/math/kepE.cpp:801 */
+/* Piecewise functions: relu / relup with the slope of the leaky variants (src/math/relu.cpp:580-602), select(c, t, f)
+ * (src/math/select.cpp:267), logical_and (is_and != 0) / logical_or (src/math/logical.cpp:314-338), comparisons
+ * op = 0..5 -> eq, neq, lt, gt, lte, gte (src/math/relational.cpp:343-354). */
+hy_expr hy_expr_relu(hy_expr x, double slope);
+hy_expr hy_expr_relup(hy_expr x, double slope);
+hy_expr hy_expr_select(hy_expr cond, hy_expr t, hy_expr f);
+hy_expr hy_expr_logical(int is_and, const hy_expr *args, size_t n);
+hy_expr hy_expr_rel(int op, hy_expr a, hy_expr b);
 hy_expr hy_expr_sum(const hy_expr *, size_t n);  /* sum(vector)           src/math/sum.cpp:548 */
 hy_expr hy_expr_prod(const hy_expr *, size_t n); /* prod(vector)          src/math/prod.cpp:913 */
 void hy_expr_free(hy_expr);

@@ -73,6 +73,17 @@ KIND_IDS = {
     "atanh": 23,
     "atan2": 24,
     "kepE": 25,
+    "relu": 26,
+    "relup": 27,
+    "select": 28,
+    "logical_and": 29,
+    "logical_or": 30,
+    "rel_eq": 31,
+    "rel_neq": 32,
+    "rel_lt": 33,
+    "rel_gt": 34,
+    "rel_lte": 35,
+    "rel_gte": 36,
 }
 
 OC_SUCCESS = -4294967296 - 1
@@ -302,6 +313,56 @@ def atan2(y, x):
     if y.is_num() and x.is_num():
         return num(math.atan2(y.val, x.val))
     return func("atan2", [y, x])
+
+
+def relu(x, slope=0.0):
+    """relu(x, slope) = x > 0 ? x : slope * x; the slope is kept as a second, numerical argument
+    (reference: src/math/relu.cpp:580-590)."""
+    x = as_ex(x)
+    if not (math.isfinite(slope) and slope >= 0):
+        raise ValueError("invalid slope")
+    if x.is_num():
+        return num(x.val if x.val > 0 else slope * x.val)
+    return func("relu", [x, num(float(slope))])
+
+
+def relup(x, slope=0.0):
+    """Derivative of relu (src/math/relu.cpp:592-602)."""
+    x = as_ex(x)
+    if not (math.isfinite(slope) and slope >= 0):
+        raise ValueError("invalid slope")
+    if x.is_num():
+        return num(1.0 if x.val > 0 else float(slope))
+    return func("relup", [x, num(float(slope))])
+
+
+def select(cond, t, f):
+    """select(c, t, f) = c != 0 ? t : f (src/math/select.cpp:267-270)."""
+    return func("select", [as_ex(cond), as_ex(t), as_ex(f)])
+
+
+def logical_and(args):
+    """src/math/logical.cpp:314-325."""
+    args = [as_ex(a) for a in args]
+    return num(1.0) if not args else (args[0] if len(args) == 1 else func("logical_and", args))
+
+
+def logical_or(args):
+    """src/math/logical.cpp:327-338."""
+    args = [as_ex(a) for a in args]
+    return num(0.0) if not args else (args[0] if len(args) == 1 else func("logical_or", args))
+
+
+def _rel(name):
+    def f(a, b):
+        return func("rel_" + name, [as_ex(a), as_ex(b)])
+
+    f.__name__ = name
+    return f
+
+
+# Comparisons returning 1 / 0 (src/math/relational.cpp:343-354).
+eq, neq, lt, gt, lte, gte = (_rel(n) for n in ("eq", "neq", "lt", "gt", "lte", "gte"))
 
 
 def inv_kep_E(ecc, M):

@@ -64,7 +64,18 @@ enum {
     K_ACOSH = 22,
     K_ATANH = 23,
     K_ATAN2 = 24,
-    K_KEPE = 25
+    K_KEPE = 25,
+    K_RELU = 26,
+    K_RELUP = 27,
+    K_SELECT = 28,
+    K_LAND = 29,
+    K_LOR = 30,
+    K_REL_EQ = 31,
+    K_REL_NEQ = 32,
+    K_REL_LT = 33,
+    K_REL_GT = 34,
+    K_REL_LTE = 35,
+    K_REL_GTE = 36
 };
 
 enum { A_UVAR = 0, A_NUM = 1, A_PAR = 2 };
@@ -745,6 +756,60 @@ static void node_diff(const hy_oracle_program *p, int i, int k, double *tape, co
                 for (int l = 0; l < B; ++l) dividend[l] = dividend[l] + scratch[l];
             }
             for (int l = 0; l < B; ++l) out[l] = dividend[l] / (n * (1. - TAPE(0, c)[l]));
+            break;
+        }
+        case K_RELU:
+        case K_RELUP:
+        case K_SELECT:
+        case K_LAND:
+        case K_LOR:
+        case K_REL_EQ:
+        case K_REL_NEQ:
+        case K_REL_LT:
+        case K_REL_GT:
+        case K_REL_LTE:
+        case K_REL_GTE: {
+            /* Piecewise functions (src/math/relu.cpp:144-178, :392-424; select.cpp:88-131; relational.cpp:197-238;
+             * logical.cpp:93-127): the branch is chosen by the order-0 values; truth values are 1 / 0 at order 0 and 0
+             * beyond; relu / select pick the order-k coefficient of the chosen branch. */
+            const int kind = p->kind[i];
+            for (int l = 0; l < B; ++l) {
+#define ARG0(j) (at[j] == A_UVAR ? TAPE(0, ai[j])[l] : numpar(p, a0 + (j), pars, B, l))
+#define ARGK(j) (at[j] == A_UVAR ? TAPE(k, ai[j])[l] : (k == 0 ? numpar(p, a0 + (j), pars, B, l) : 0.))
+                double r;
+                if (kind == K_RELU) {
+                    const double x = ARGK(0);
+                    r = (ARG0(0) > 0.) ? x : p->arg_val[a0 + 1] * x;
+                } else if (kind == K_RELUP) {
+                    r = (k == 0) ? ((ARG0(0) > 0.) ? 1. : p->arg_val[a0 + 1]) : 0.;
+                } else if (kind == K_SELECT) {
+                    r = (ARG0(0) != 0.) ? ARGK(1) : ARGK(2);
+                } else if (k != 0) {
+                    r = 0.;
+                } else if (kind == K_LAND || kind == K_LOR) {
+                    int t = (kind == K_LAND);
+                    for (int j = 0; j < nargs; ++j) {
+                        const int nz = ARG0(j) != 0.;
+                        t = (kind == K_LAND) ? (t && nz) : (t || nz);
+                    }
+                    r = t ? 1. : 0.;
+                } else {
+                    const double x = ARG0(0), y = ARG0(1);
+                    int t;
+                    switch (kind) {
+                        case K_REL_EQ: t = x == y; break;
+                        case K_REL_NEQ: t = (x < y) || (x > y); break; /* ordered: false with a nan operand */
+                        case K_REL_LT: t = x < y; break;
+                        case K_REL_GT: t = x > y; break;
+                        case K_REL_LTE: t = x <= y; break;
+                        default: t = x >= y; break;
+                    }
+                    r = t ? 1. : 0.;
+                }
+                out[l] = r;
+#undef ARG0
+#undef ARGK
+            }
             break;
         }
         default:

@@ -188,6 +188,42 @@ case("kepE_var_var", ["kepE(0.1*x, y)", "kepE(0.05*y, x)"], "test/taylor_kepE.cp
 case("kepE_num_var", ["kepE(0.3, y)", "kepE(0.05*x, 0.4)"], "test/taylor_kepE.cpp (closed forms)",
      *_two_arg(_kep_solve, _kep_parts, [(0, 0.0, 0.3, 1, 1.0, 0.0), (0, 0.05, 0.0, 1, 0.0, 0.4)]))
 
+# 3c. Piecewise functions (test/relu.cpp, test/select.cpp, test/relational.cpp, test/logical.cpp): the branch is fixed
+# by the state, inside a branch the right-hand side is a polynomial of degree <= 2.
+def _relu_case():
+    s0 = lambda z: 1.0 if z[1] - 4.5 > 0 else 0.0
+    s1 = lambda z: 1.0 if z[0] - 3.0 > 0 else 0.01
+    return (lambda z: [s0(z) * (z[1] - 4.5), s1(z) * (z[0] - 3.0)],
+            lambda z: [[0, s0(z)], [s1(z), 0]], lambda z: Z(2))
+
+
+def _relup_select_case():
+    s = lambda z: 1.0 if z[1] - 4.5 > 0 else 0.1
+    prod = lambda z: z[0] > z[1]
+
+    def hess(z):
+        h = Z(2)
+        if prod(z):
+            h[1][0][1] = h[1][1][0] = 1.0
+        return h
+    return (lambda z: [s(z) * z[0], z[0] * z[1] if prod(z) else z[0] + z[1]],
+            lambda z: [[s(z), 0], [z[1], z[0]] if prod(z) else [1, 1]], hess)
+
+
+def _logical_rel_case():
+    c0 = lambda z: 1.0 if (z[0] < 3 and z[1] >= 3.5) else 0.0
+    c1 = lambda z: 1.0 if (z[0] == 5 or z[1] <= 3) else 0.0
+    c2 = lambda z: 1.0 if z[0] != 1 else 0.0
+    return (lambda z: [c0(z) + 0.5 * z[1], c1(z) * z[0] + c2(z)],
+            lambda z: [[0, 0.5], [c1(z), 0]], lambda z: Z(2))
+
+
+case("relu_leaky", ["relu(y - 4.5)", "leaky_relu(0.01)(x - 3)"], "test/relu.cpp (closed forms)", *_relu_case())
+case("relup_select", ["relup(y - 4.5, 0.1) * x", "select(gt(x, y), x * y, x + y)"],
+     "test/relu.cpp, test/select.cpp (closed forms)", *_relup_select_case())
+case("logical_rel", ["logical_and({lt(x, 3), gte(y, 3.5)}) + 0.5 * y", "logical_or({eq(x, 5), lte(y, 3)}) * x + neq(x, 1)"],
+     "test/logical.cpp, test/relational.cpp (closed forms)", *_logical_rel_case())
+
 # 4. Explicit time dependence (z = (x, y, t), t' = 1; test/taylor_time.cpp).
 case("time", ["time + y", "x * time"], "test/taylor_time.cpp",
      lambda z: [z[2] + z[1], z[0] * z[2], 1.0],

@@ -147,3 +147,34 @@ def test_two_argument_functions_atan2_kepE():
     got = hy.taylor_decompose_sys(build(hy, x, y, hy.time, hy.par[0]))
     exp = ho.dc_to_strings(ho.taylor_decompose_sys(build(ho, ox, oy, ho.func("time", []), ho.par(0))))
     assert got == exp
+
+
+def piecewise_system(m, x, y, t, par):
+    """relu / relup (plain and leaky), select, all the comparisons, logical_and / logical_or, with variable, number,
+    parameter and time arguments."""
+    return [
+        (x, m.relu(y - 0.1) - m.relu(x, 0.01) + 0.2 * m.relup(y + par, 0.1) + m.select(m.gt(x, y), 0.3 * y, -0.2 * x * y) - 0.3 * x),
+        (y, m.select(m.logical_and([m.lt(x, 0.5), m.gte(y, -0.5), m.neq(x, 2.0)]), m.sin(x), m.cos(y)) - 0.4 * y
+         + 0.1 * m.logical_or([m.lte(x, -0.3), m.eq(y, 7.0)]) + 0.05 * m.select(t, 1.0, 2.0)),
+    ]
+
+
+def test_piecewise_functions():
+    """relu / relup / select / relational / logical (src/math/{relu,select,relational,logical}.cpp): construction rules
+    (folding of numbers, degenerate logical_and / logical_or, slope validation message) and identity of the
+    decomposition with the independent restatement."""
+    x, y = hy.make_vars("x", "y")
+    assert str(hy.relu(-2.0, 0.5)) == "-1" and str(hy.relu(3.0)) == "3" and str(hy.relup(3.0)) == "1"
+    assert float(str(hy.relup(-3.0, 0.25))) == 0.25
+    assert str(hy.logical_and([])) == "1" and str(hy.logical_or([])) == "0" and str(hy.logical_or([x])) == "x"
+    assert str(hy.leaky_relu(0.1)(x)) == str(hy.relu(x, 0.1)) and str(hy.leaky_relup(0.1)(x)) == str(hy.relup(x, 0.1))
+    # No folding for select / comparisons (src/math/select.cpp:267-270, relational.cpp:343-347).
+    assert str(hy.select(1.0, 2.0, 3.0)).startswith("select(") and str(hy.lt(1.0, 2.0)).startswith("rel_lt(")
+    for bad in (-1.0, float("inf"), float("nan")):
+        with pytest.raises(ValueError, match="The slope parameter for a leaky ReLU must be finite and non-negative"):
+            hy.relu(x, bad)
+        with pytest.raises(ValueError, match="The slope parameter for a leaky ReLU must be finite and non-negative"):
+            hy.relup(x, bad)
+    got = hy.taylor_decompose_sys(piecewise_system(hy, x, y, hy.time, hy.par[0]))
+    exp = ho.dc_to_strings(ho.taylor_decompose_sys(piecewise_system(ho, ho.var("x"), ho.var("y"), ho.func("time", []), ho.par(0))))
+    assert got == exp

@@ -680,6 +680,45 @@ def test_atan2_kepE_full_order_step_parity(mode):
     assert np.max(np.abs(E[ok] - E_o)) <= 64 * EPS * 2 * np.pi
 
 
+@pytest.mark.parametrize("mode", ["unrolled", "table"])
+def test_piecewise_functions_full_order_step_parity(mode):
+    """relu / relup / select / comparisons / logical_and / logical_or at order 20, in the unrolled and in the table
+    stepper: one full step (h, Taylor coefficients, state) and a propagation vs the oracle. Lanes whose branch
+    conditions flip inside the propagation are part of the test (both sides pick the branch from the order-0 values
+    at the beginning of each step, as the reference does)."""
+    import os
+
+    from test_decomposition import piecewise_system
+
+    n = 64
+    rng = np.random.RandomState(3)
+    st = np.stack([rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)])
+    pars = rng.uniform(-0.2, 0.2, (1, n))
+    x, y = hy.make_vars("x", "y")
+    os.environ["HEYOKA_AMD_EMIT_MODE"] = mode
+    try:
+        ta = hy.taylor_adaptive_batch(piecewise_system(hy, x, y, hy.time, hy.par[0]), st, n, pars=pars)
+    finally:
+        del os.environ["HEYOKA_AMD_EMIT_MODE"]
+    assert ta.hip_source_mode.startswith(mode)
+    ora = ho.OracleIntegrator(piecewise_system(ho, ho.var("x"), ho.var("y"), ho.func("time", []), ho.par(0)), st, n, pars=pars)
+    ta.step(write_tc=True)
+    ora.step(wtc=True)
+    h_g = np.array([h for _, h in ta.step_res])
+    h_o = np.array([h for _, h in ora.step_res])
+    assert np.max(np.abs(h_g - h_o) / np.abs(h_o)) <= 1e6 * EPS
+    tc_o = ora.tc.reshape(2, ora.order + 1, n)
+    scale = np.max(np.abs(tc_o), axis=2, keepdims=True) + 1e-300
+    assert np.max(np.abs(np.asarray(ta.tc).reshape(2, 21, n) - tc_o) / scale) <= 1e6 * EPS
+    assert rel_err(ta.state, ora.state.reshape(2, n)) <= 1e5 * EPS
+    # A propagation across branch switches: a lane whose state lands within rounding of a switching surface may take
+    # a different branch on the two sides; all the other lanes must agree.
+    ta.propagate_until(1.0)
+    ora.propagate_until(1.0)
+    err = np.max(np.abs(ta.state - ora.state.reshape(2, n)) / np.maximum(1.0, np.abs(ora.state.reshape(2, n))), axis=0)
+    assert np.sum(err > 1e6 * EPS) <= 1
+
+
 def test_kepE_stark_problem_known_answer_on_gpu(golden):
     """The reference's known answer for an integration through kepE (test/kepE.cpp:194-239, Stark problem in Delaunay
     elements, propagate_until(250)): lane 0 carries the reference's initial state and must reproduce its final state

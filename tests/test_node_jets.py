@@ -48,6 +48,10 @@ def build(m, name):
         "atan2_var_num": (m.atan2(y, 1.5), m.atan2(0.3, x)),
         "kepE_var_var": (m.kepE(0.1 * x, y), m.kepE(0.05 * y, x)),
         "kepE_num_var": (m.kepE(0.3, y), m.kepE(0.05 * x, 0.4)),
+        "relu_leaky": (m.relu(y - 4.5), m.relu(x - 3.0, 0.01)),
+        "relup_select": (m.relup(y - 4.5, 0.1) * x, m.select(m.gt(x, y), x * y, x + y)),
+        "logical_rel": (m.logical_and([m.lt(x, 3.0), m.gte(y, 3.5)]) + 0.5 * y,
+                        m.logical_or([m.eq(x, 5.0), m.lte(y, 3.0)]) * x + m.neq(x, 1.0)),
     }[name]
     return [(x, rhs[0]), (y, rhs[1])]
 
