@@ -51,6 +51,8 @@ struct emit_options {
     bool high_accuracy = false;
     emit_mode mode = emit_mode::unrolled;
     std::uint32_t block_size = 256;
+    // Number of systems integrated at the same time (0: unknown); steers latency- vs throughput-oriented variants.
+    std::uint64_t batch_size = 0;
 };
 
 struct emitted_module {

@@ -448,6 +448,7 @@ tab_core::tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_siz
     emit_options eo;
     eo.order = d.order;
     eo.high_accuracy = d.high_accuracy;
+    eo.batch_size = d.N;
     // NOTE: the stepper with events (mode 4) is implemented by the one-system-per-lane kernels: fully unrolled for
     // small decompositions, table-driven otherwise (HEYOKA_AMD_EMIT_MODE=table forces the latter).
     if (d.has_events()) {

@@ -362,9 +362,20 @@ def test_cluster_mode_nbody8_default_masses():
     _nbody_parity(8, 96, 3, "cluster", t_final=0.05)
 
 
-def test_table_mode_small_dag_forced():
-    """Table (compact-mode analogue) kernels on a DAG that would normally be unrolled."""
-    _nbody_parity(3, 200, 3, "table", t_final=0.1, env_mode="table")
+@pytest.mark.parametrize("variant", ["wave-level", "tape in HBM"])
+def test_table_mode_small_dag_forced(variant, monkeypatch):
+    """Table (compact-mode analogue) kernels on a DAG that would normally be unrolled, in both variants: one system per
+    wavefront with the tape in LDS (the default for batches of up to 32 768 systems) and one system per lane with the
+    tape in HBM (HEYOKA_AMD_TABLE_LDS=0, the default for larger batches)."""
+    monkeypatch.setenv("HEYOKA_AMD_TABLE_LDS", "1" if variant == "wave-level" else "0")
+    ta = _nbody_parity(3, 200, 3, "table", t_final=0.1, env_mode="table")
+    assert variant in ta.hip_source_mode
+    if variant == "wave-level":
+        # The default choice depends on the batch size.
+        monkeypatch.delenv("HEYOKA_AMD_TABLE_LDS")
+        monkeypatch.setenv("HEYOKA_AMD_EMIT_MODE", "table")
+        assert "wave-level" in hy.taylor_adaptive_batch(hy.model.nbody(3), None, 32768).hip_source_mode
+        assert "tape in HBM" in hy.taylor_adaptive_batch(hy.model.nbody(3), None, 32832).hip_source_mode
 
 
 def test_nbody12_block_automatic_and_table_forced():
