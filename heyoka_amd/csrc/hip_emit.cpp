@@ -675,6 +675,7 @@ emitted_module emit_unrolled(const taylor_program &p, const emit_options &opts)
 emitted_module emit_cluster_or_empty(const taylor_program &, const emit_options &, std::string &why_not);
 emitted_module emit_table(const taylor_program &, const emit_options &);
 emitted_module emit_block(const taylor_program &, const emit_options &, std::string &why_not);
+bool add_state_aliases(const taylor_program &, taylor_program &);
 
 emitted_module emit_hip_module(const taylor_program &prog, const emit_options &opts)
 {
@@ -687,6 +688,25 @@ emitted_module emit_hip_module(const taylor_program &prog, const emit_options &o
         case emit_mode::cluster: {
             std::string why;
             auto m = emit_cluster_or_empty(prog, opts, why);
+            if (m.source.empty() && why.rfind("a state variable is a history operand", 0) == 0
+                && std::getenv("HEYOKA_AMD_NO_STATE_ALIASES") == nullptr) {
+                // Retry with alias u variables for those state variables (see add_state_aliases()).
+                taylor_program aliased;
+                if (add_state_aliases(prog, aliased)) {
+                    auto o2 = opts;
+                    std::string why2;
+                    auto m2 = emit_cluster_or_empty(aliased, o2, why2);
+                    if (m2.source.empty() && why2.rfind("more than 64 clusters", 0) == 0) {
+                        std::string why_b;
+                        m2 = emit_block(aliased, o2, why_b);
+                    }
+                    if (!m2.source.empty()) {
+                        m2.notes += "; state variables in history-operand position aliased by u variables";
+                        return m2;
+                    }
+                    why += "; with state-variable aliases: " + why2;
+                }
+            }
             if (m.source.empty() && why.rfind("more than 64 clusters", 0) == 0) {
                 // Too many clusters for one wavefront: one system per workgroup.
                 std::string why_b;

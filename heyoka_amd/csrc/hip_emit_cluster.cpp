@@ -162,6 +162,109 @@ struct union_find {
 } // namespace
 
 // Build the plan; returns an empty string on success, otherwise the reason why cluster mode is not applicable.
+// State variables as history operands. The planner groups a nonlinear node with the u variables whose whole history it
+// needs; a *state variable* in that position (model::np1body: |r_i|^2 = sum_sq(x_i, y_i, z_i), x_i * |r_i|^-3) cannot be
+// a member of a cluster. This transformation
+//   - gives every state variable s read by a cluster member a glue copy g_s = sum(s),
+//   - gives every state variable in history position an alias a_s = g_s - z_s (z_s: a constant-zero node of its own),
+//     an ordinary cluster member with the shape of the coordinate differences of a pair cluster, and
+//   - rewires the members to g_s / a_s,
+// so that heliocentric and pair clusters are isomorphic and sit at the same dependency level (both read level-1 glue).
+// The values are unchanged (s + nothing, s - 0). Returns false if the program needs no alias.
+bool add_state_aliases(const taylor_program &p, taylor_program &out)
+{
+    const auto n_eq = p.n_eq;
+    // Cluster members: nodes with history operands, and the u variables in history position.
+    std::vector<char> member(p.n_u, 0);
+    std::set<std::uint32_t> hist_sv;
+    for (std::uint32_t i = 0; i < p.nodes.size(); ++i) {
+        const auto hs = history_operands(p.nodes[i]);
+        if (!hs.empty()) {
+            member[n_eq + i] = 1;
+        }
+        for (const auto h : hs) {
+            if (h < n_eq) {
+                hist_sv.insert(h);
+            } else {
+                member[h] = 1;
+            }
+        }
+    }
+    if (hist_sv.empty()) {
+        return false;
+    }
+    // State variables read by members (in any position).
+    std::set<std::uint32_t> used_sv(hist_sv.begin(), hist_sv.end());
+    for (std::uint32_t i = 0; i < p.nodes.size(); ++i) {
+        if (member[n_eq + i] != 0) {
+            for (const auto &o : p.nodes[i].args) {
+                if (o.type == operand::kind::uvar && o.idx < n_eq) {
+                    used_sv.insert(o.idx);
+                }
+            }
+        }
+    }
+
+    out = p;
+    out.nodes.clear();
+    std::map<std::uint32_t, std::uint32_t> copy_of, alias_of;
+    std::uint32_t next = n_eq;
+    const auto uvar = [](std::uint32_t u) { return operand{operand::kind::uvar, u, 0.}; };
+    for (const auto sv : used_sv) {
+        dc_node g;
+        g.kind = func_kind::sum;
+        g.args.push_back(uvar(sv));
+        out.nodes.push_back(g);
+        copy_of[sv] = next++;
+    }
+    for (const auto sv : hist_sv) {
+        dc_node z;
+        z.kind = func_kind::num_identity;
+        z.args.push_back(operand{operand::kind::num, 0u, 0.});
+        out.nodes.push_back(z);
+        dc_node a;
+        a.kind = func_kind::sub;
+        a.args.push_back(uvar(copy_of.at(sv)));
+        a.args.push_back(uvar(next));
+        out.nodes.push_back(a);
+        alias_of[sv] = next + 1u;
+        next += 2u;
+    }
+    const auto m = next - n_eq;
+    const auto shift = [&](std::uint32_t u) { return u < n_eq ? u : u + m; };
+    for (std::uint32_t i = 0; i < p.nodes.size(); ++i) {
+        auto nn = p.nodes[i];
+        const auto hs = history_operands(p.nodes[i]);
+        const bool is_member = member[n_eq + i] != 0;
+        for (auto &o : nn.args) {
+            if (o.type != operand::kind::uvar) {
+                continue;
+            }
+            if (o.idx >= n_eq) {
+                o.idx = shift(o.idx);
+            } else if (std::find(hs.begin(), hs.end(), o.idx) != hs.end()) {
+                o.idx = alias_of.at(o.idx);
+            } else if (is_member) {
+                o.idx = copy_of.at(o.idx);
+            }
+        }
+        for (auto &d : nn.deps) {
+            d = shift(d);
+        }
+        out.nodes.push_back(std::move(nn));
+    }
+    for (auto &d : out.sv_defs) {
+        if (d.type == operand::kind::uvar) {
+            d.idx = shift(d.idx);
+        }
+    }
+    for (auto &e : out.ev_u) {
+        e = shift(e);
+    }
+    out.n_u = p.n_u + m;
+    return true;
+}
+
 std::string cluster_detail::make_plan(const taylor_program &p, std::uint32_t order, cluster_plan &pl,
                                       const plan_limits &lim)
 {

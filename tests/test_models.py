@@ -222,6 +222,10 @@ def test_models_step_and_propagate_vs_oracle(name, pins):
     n = st.shape[1]
     kw = {} if pars is None else {"pars": pars}
     ta = hy.taylor_adaptive_batch(prod(), st, n, **kw)
+    if name == "np1body6":
+        # State variables in history-operand position (|r_i|^2 = sum_sq(x_i, y_i, z_i)) are aliased by u variables so that
+        # the wave-cluster stepper applies (add_state_aliases(), heyoka_amd/csrc/hip_emit_cluster.cpp).
+        assert ta.hip_source_mode.startswith("cluster") and "aliased" in ta.hip_source_mode
     oi = ho.OracleIntegrator(ora(), st, n, **kw)
     n_eq = st.shape[0]
     ta.step(write_tc=True)
@@ -327,3 +331,27 @@ def test_models_conservation_checks_of_the_reference_tests(pins):
     assert np.max(np.abs(a[:, 0] - b[:, 0]) / np.maximum(np.abs(a[:, 0]), np.abs(b[:, 0]))) <= e["tol_eps"] * EPS
     for sl in (slice(0, 3), slice(3, 6)):
         assert np.max(np.linalg.norm(a[sl] - b[sl], axis=0) / np.linalg.norm(b[sl], axis=0)) <= e["tol_eps"] * EPS
+
+
+@pytest.mark.gpu
+def test_np1body_cluster_stepper_equals_table_stepper(pins, monkeypatch):
+    """model::np1body through the wave-cluster stepper (with the state-variable aliases) and through the table stepper
+    (HEYOKA_AMD_NO_STATE_ALIASES=1): same step counts, states within 1e5 eps, with the compensated update as well."""
+    from heyoka_amd import configs
+
+    M, G = pins["outer_ss"]["masses"], _G(pins)
+    n = 128
+    st = configs.outer_ss_state(n, perturb=1e-6, seed=5, com_shift=False)[6:]
+    for ha in (False, True):
+        res = {}
+        for which in ("cluster", "table"):
+            if which == "table":
+                monkeypatch.setenv("HEYOKA_AMD_NO_STATE_ALIASES", "1")
+            else:
+                monkeypatch.delenv("HEYOKA_AMD_NO_STATE_ALIASES", raising=False)
+            ta = hy.taylor_adaptive_batch(hy.model.np1body(6, masses=M, Gconst=G), st, n, high_accuracy=ha)
+            assert ta.hip_source_mode.startswith(which), ta.hip_source_mode
+            ta.propagate_until(50.0)
+            res[which] = (ta.state.copy(), [r[3] for r in ta.propagate_res])
+        assert res["cluster"][1] == res["table"][1]
+        assert rel_err(res["cluster"][0], res["table"][0]) <= 1e5 * EPS
