@@ -265,9 +265,40 @@ bool add_state_aliases(const taylor_program &p, taylor_program &out)
     return true;
 }
 
+namespace
+{
+
+std::string make_plan_impl(const taylor_program &p, std::uint32_t order, cluster_plan &pl,
+                           const cluster_detail::plan_limits &lim);
+
+} // namespace
+
 std::string cluster_detail::make_plan(const taylor_program &p, std::uint32_t order, cluster_plan &pl,
                                       const plan_limits &lim)
 {
+    auto why = make_plan_impl(p, order, pl, lim);
+    if (lim.absorb_linear && why.rfind("clusters are not isomorphic", 0) == 0) {
+        // E.g. model::np1body with unit masses: the heliocentric clusters feed scaling products of their own, the pair
+        // clusters do not. Without the absorption those products are glue and the clusters are isomorphic again.
+        auto lim2 = lim;
+        lim2.absorb_linear = false;
+        cluster_plan pl2;
+        const auto why2 = make_plan_impl(p, order, pl2, lim2);
+        if (why2.empty()) {
+            pl = std::move(pl2);
+            return why2;
+        }
+    }
+    return why;
+}
+
+namespace
+{
+
+std::string make_plan_impl(const taylor_program &p, std::uint32_t order, cluster_plan &pl,
+                           const cluster_detail::plan_limits &lim)
+{
+    using cluster_detail::glue_group;
     const auto n_eq = p.n_eq, n_u = p.n_u;
     pl.n_eq = n_eq;
     pl.n_u = n_u;
@@ -315,7 +346,7 @@ std::string cluster_detail::make_plan(const taylor_program &p, std::uint32_t ord
     // 2. Absorb single-source linear nodes into their source cluster.
     for (std::uint32_t i = 0; i < p.nodes.size(); ++i) {
         const auto u = n_eq + i;
-        if (pl.cluster_of[u] != -1 || !is_glue_kind(p.nodes[i])) {
+        if (!lim.absorb_linear || pl.cluster_of[u] != -1 || !is_glue_kind(p.nodes[i])) {
             continue;
         }
         int src = -2;
@@ -609,6 +640,8 @@ std::string cluster_detail::make_plan(const taylor_program &p, std::uint32_t ord
 
     return {};
 }
+
+} // namespace
 
 // Version 1 of the cluster kernel: separate state-variable phase, 4 LDS synchronisations per order.
 // Returns a module with an empty source (and the reason in why_not) if cluster mode is not applicable.

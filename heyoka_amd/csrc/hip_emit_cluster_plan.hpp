@@ -42,6 +42,9 @@ struct cluster_plan {
 struct plan_limits {
     std::uint32_t max_clusters = 64;
     bool jets_in_registers = true;
+    // Absorb the linear nodes fed by a single cluster into that cluster (fewer glue rounds). Switched off by
+    // make_plan() on a second attempt when the absorption makes otherwise isomorphic clusters differ.
+    bool absorb_linear = true;
 };
 
 // Build the plan; returns an empty string on success, otherwise the reason why cluster mode is not applicable.
