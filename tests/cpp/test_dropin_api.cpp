@@ -148,6 +148,31 @@ int main(int argc, char **argv)
         REQUIRE(thrown);
     }
 
+    // Two-argument and piecewise functions with the reference's spelling; decomposition sizes pinned by
+    // test/kepE.cpp:183-192, test/atan2.cpp:159-167, test/taylor_atan2.cpp:62-73.
+    {
+        auto [xx, yy] = make_vars("x", "y");
+        auto mk2 = [](std::vector<std::pair<expression, expression>> dyn) {
+            return taylor_adaptive_batch<double>{std::move(dyn), std::vector<double>{.1, .2, .3, .4}, 2u, kw::tol = 1.};
+        };
+        REQUIRE(mk2({prime(xx) = cos(kepE(xx, yy)) + sin(kepE(xx, yy)) + kepE(xx, yy), prime(yy) = xx}).get_decomposition().size()
+                == 10u);
+        REQUIRE(mk2({prime(xx) = atan2(yy, xx) + (pow(yy, 2_dbl) + pow(xx, 2_dbl)), prime(yy) = xx}).get_decomposition().size() == 7u);
+        REQUIRE(mk2({prime(xx) = atan2(xx, yy), prime(yy) = pow(xx, 2_dbl) + pow(yy, 2_dbl)}).get_decomposition().size() == 6u);
+        REQUIRE(kepE(0_dbl, xx) == xx);
+        auto pw = mk2({prime(xx) = relu(yy) - leaky_relu(.01)(xx) + select(gt(xx, yy), xx, yy * relup(xx, .1)),
+                       prime(yy) = logical_and({lt(xx, .5_dbl), gte(yy, -.5_dbl)}) - logical_or({eq(xx, yy), neq(xx, 1_dbl), lte(yy, xx)})});
+        REQUIRE(pw.get_decomposition().size() > 10u);
+        bool thrown = false;
+        try {
+            relu(xx, -1.);
+        } catch (const std::invalid_argument &e) {
+            thrown = std::string(e.what())
+                     == "The slope parameter for a leaky ReLU must be finite and non-negative, but the value -1 was provided instead";
+        }
+        REQUIRE(thrown);
+    }
+
     if (!with_gpu) {
         std::puts("CPU-only checks OK");
         return 0;
