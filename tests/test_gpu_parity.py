@@ -955,7 +955,7 @@ def test_block_mode_nonuniform_masses_and_massless_bodies():
     assert rel_err(tb.state, ob.state.reshape(6 * nb2, 16)) <= 1e5 * EPS
 
 
-def _random_system(m, rng, n_var=3):
+def _random_system(m, rng, n_var=3, extended=False):
     """The same pseudo-random ODE system through expression module m (product or oracle)."""
     if m is ho:
         vs = [m.var("x%d" % i) for i in range(n_var)]
@@ -965,6 +965,13 @@ def _random_system(m, rng, n_var=3):
         par, tm, powf = (lambda i: m.par[i]), m.time, m.pow
     unary = [m.sin, m.cos, lambda e: m.exp(0.3 * e), lambda e: m.log(2.0 + e * e), m.tanh, m.atan, m.sigmoid,
              lambda e: powf(1.5 + e * e, -1.5), lambda e: powf(e, 2.0), lambda e: m.sqrt(1.0 + e * e), m.sinh, m.erf]
+    if extended:
+        # Two-argument and piecewise functions (bounded / smooth enough for a step-by-step comparison).
+        unary += [lambda e: m.relu(e, 0.1), lambda e: m.relup(e, 0.2) * e]
+        binary = [lambda a, b: m.atan2(a, 1.5 + b * b), lambda a, b: m.atan2(0.7, a) * b,
+                  lambda a, b: m.sin(m.kepE(0.6 * m.sigmoid(a), b)), lambda a, b: m.cos(m.kepE(0.3, a + b)),
+                  lambda a, b: m.select(m.gt(a, b), a, 0.5 * b), lambda a, b: m.select(m.logical_and([m.lt(a, 0.3), m.gte(b, -0.3)]), a * b, a - b),
+                  lambda a, b: m.logical_or([m.lte(a, b), m.neq(a, 1.0)]) * a + m.eq(b, 2.0)]
 
     def leaf():
         k = rng.randint(0, 6)
@@ -988,13 +995,18 @@ def _random_system(m, rng, n_var=3):
             return tree(depth - 1) / (2.0 + powf(tree(depth - 1), 2.0))
         if k == 4:
             return float(rng.uniform(-1.5, 1.5)) * tree(depth - 1)
+        if extended and k == 5:
+            return binary[rng.randint(0, len(binary))](tree(depth - 1), tree(depth - 1))
         return unary[rng.randint(0, len(unary))](tree(depth - 1))
 
     # NOTE: both runtime parameters appear in every system (fixed size of the pars array).
     return [(v, 0.3 * tree(3) - 0.2 * v + 1e-3 * (par(0) - par(1))) for v in vs]
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5, 7, 8, 9])
+EXT_SEEDS = [1000 + i for i in range(12)]
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5, 7, 8, 9] + EXT_SEEDS)
 def test_random_systems_all_code_paths_vs_oracle(seed):
     """Pseudo-random ODE systems over the whole function set (shared subexpressions, parameters, explicit time): the
     default code generator and the table-driven one against the oracle - decomposition, one full step with
@@ -1006,12 +1018,13 @@ def test_random_systems_all_code_paths_vs_oracle(seed):
     st = rs.uniform(-0.7, 0.7, (3, n))
     pars = rs.uniform(-0.5, 0.5, (2, n))
     t0 = rs.uniform(0.0, 2.0, n)
-    sys_o = _random_system(ho, np.random.RandomState(seed))
+    ext = seed >= 1000
+    sys_o = _random_system(ho, np.random.RandomState(seed), extended=ext)
     for mode in ("default", "table"):
         if mode == "table":
             os.environ["HEYOKA_AMD_EMIT_MODE"] = "table"
         try:
-            sys_p = _random_system(hy, np.random.RandomState(seed))
+            sys_p = _random_system(hy, np.random.RandomState(seed), extended=ext)
             ta = hy.taylor_adaptive_batch(sys_p, st, n, pars=pars, time=t0)
         finally:
             os.environ.pop("HEYOKA_AMD_EMIT_MODE", None)
