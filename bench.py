@@ -256,7 +256,21 @@ def main():
         k_ms = float(np.mean(kern_ms))
         per_launch_steps = float(steps_per_call)
         achieved_gbs = b_tape * per_launch_steps / (k_ms * 1e-3) / 1e9
+        achieved_tflops = f_alg * per_launch_steps / (k_ms * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic(kernel_sha(ta), n)
+        # Which ceiling binds. The tape model B_tape describes a stepper that streams its jets through HBM
+        # (block / table modes). The cluster and register-resident steppers keep the jets on chip: their measured HBM
+        # traffic is a fraction of a percent of the peak and the binding ceiling is the FP64 arithmetic rate (78.6
+        # TFLOP/s vector = matrix peak for f64 on MI355X; the recurrences have no dense contraction, MFMA itself is
+        # unused) - reported under the contract's "mfma" label with the algorithmic flop count F_alg.
+        hbm_util = (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else min(1.0, achieved_gbs / HBM_PEAK_GBS)
+        compute_bound = achieved_tflops / FP64_PEAK_TFLOPS > hbm_util
+        if compute_bound:
+            roof = {"bound": "mfma", "achieved": achieved_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved_tflops / FP64_PEAK_TFLOPS}
+        else:
+            roof = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved_gbs / HBM_PEAK_GBS}
         out = {
             "metric": "ODE systems x steps/sec (fp64)",
             "value": value,
@@ -287,18 +301,18 @@ def main():
                 "untimed_final_state_all_gather_error": gather_err,
             },
             "roofline": {
-                "bound": "hbm",
-                "achieved": achieved_gbs,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved_gbs / HBM_PEAK_GBS,
+                **roof,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "kernel": "hy_taylor",
                 "kernel_ms_avg": k_ms,
                 "call_ms_avg": float(np.mean(call_ms)),
+                "algorithmic_flop_per_system_step": f_alg,
                 "algorithmic_bytes_per_system_step": b_tape,
-                "fp64_valu_frac": f_alg * per_launch_steps / (k_ms * 1e-3) / (FP64_PEAK_TFLOPS * 1e12),
+                # Both views, whichever binds.
+                "fp64_valu_frac": achieved_tflops / FP64_PEAK_TFLOPS,
+                "hbm_tape_model_frac": achieved_gbs / HBM_PEAK_GBS,
+                "hbm_measured_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
