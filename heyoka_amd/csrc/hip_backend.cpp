@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <stdexcept>
 #include <unordered_map>
@@ -117,6 +118,34 @@ int hip_device_count()
     return n;
 }
 
+namespace
+{
+
+// Loaded code objects, per (device, compiled module), kept for the lifetime of the process. Integrators built from the
+// same system share the hipModule_t (construction does not reload it), and nothing is ever unloaded: with this toolchain
+// (ROCm 7.2) a process that loads and unloads many run-time modules and then runs the first kernels of another HIP
+// client (PyTorch's lazily-loaded kernels) intermittently took a GPU memory fault inside that client's kernel; keeping
+// the modules resident removes the unloads from the picture. The code objects are a few tens of KB each.
+std::mutex loaded_mutex;
+std::map<std::pair<int, const compiled_module *>, std::pair<hipModule_t, std::shared_ptr<const compiled_module>>>
+    loaded_modules;
+
+hipModule_t load_module_cached(const std::shared_ptr<const compiled_module> &cm, int device)
+{
+    std::lock_guard lock(loaded_mutex);
+    const auto key = std::make_pair(device, cm.get());
+    if (const auto it = loaded_modules.find(key); it != loaded_modules.end()) {
+        return it->second.first;
+    }
+    hip_check(hipSetDevice(device), "hipSetDevice");
+    hipModule_t mod = nullptr;
+    hip_check(hipModuleLoadData(&mod, cm->code.data()), "hipModuleLoadData");
+    loaded_modules.emplace(key, std::make_pair(mod, cm));
+    return mod;
+}
+
+} // namespace
+
 struct device_module::impl {
     std::shared_ptr<const compiled_module> cm;
     int device = 0;
@@ -144,7 +173,7 @@ device_module::device_module(std::shared_ptr<const compiled_module> cm, int devi
     m_impl->cm = std::move(cm);
     m_impl->device = device;
     hip_check(hipSetDevice(device), "hipSetDevice");
-    hip_check(hipModuleLoadData(&m_impl->mod, m_impl->cm->code.data()), "hipModuleLoadData");
+    m_impl->mod = load_module_cached(m_impl->cm, device);
     hip_check(hipModuleGetFunction(&m_impl->fn_taylor, m_impl->mod, m_impl->cm->meta.kernel_name.c_str()),
               "hipModuleGetFunction(taylor)");
     hip_check(hipModuleGetFunction(&m_impl->fn_dout, m_impl->mod, m_impl->cm->meta.dout_name.c_str()),
@@ -187,7 +216,7 @@ device_module::~device_module()
         if (m_impl->scratch != nullptr) {
             (void)hipFree(m_impl->scratch);
         }
-        (void)hipModuleUnload(m_impl->mod);
+        // NOTE: the module stays loaded (see load_module_cached()).
     }
 }
 
@@ -321,16 +350,11 @@ aux_module::aux_module(std::shared_ptr<const compiled_module> cm, int device) : 
     m_impl->cm = std::move(cm);
     m_impl->device = device;
     hip_check(hipSetDevice(device), "hipSetDevice");
-    hip_check(hipModuleLoadData(&m_impl->mod, m_impl->cm->code.data()), "hipModuleLoadData");
+    m_impl->mod = load_module_cached(m_impl->cm, device);
 }
 
-aux_module::~aux_module()
-{
-    if (m_impl && m_impl->mod != nullptr) {
-        (void)hipSetDevice(m_impl->device);
-        (void)hipModuleUnload(m_impl->mod);
-    }
-}
+// NOTE: the module stays loaded (see load_module_cached()).
+aux_module::~aux_module() = default;
 
 int aux_module::device() const
 {
