@@ -507,6 +507,16 @@ class model:
         return model._fc_call(lib.hy_model_mascon_potential, Gconst, masses, positions, omega, with_omega=True)
 
 
+def hiprtc_compile(source):
+    """Compile a HIP source with hiprtc and the options of the steppers (works without a GPU); returns the code object."""
+    n = ctypes.c_size_t(0)
+    src = source.encode()
+    raise_for(lib.hy_hiprtc_compile(src, None, ctypes.byref(n)))
+    buf = ctypes.create_string_buffer(n.value)
+    raise_for(lib.hy_hiprtc_compile(src, buf, ctypes.byref(n)))
+    return buf.raw[: n.value]
+
+
 def taylor_decompose_sys(sys):
     """taylor_decompose_sys() (src/taylor_01.cpp:848-1008) -> list of textual entries."""
     s = _to_sys(sys)
@@ -898,6 +908,15 @@ class taylor_adaptive_batch:
     @property
     def hip_source(self):
         return take_str(lib.hy_tab_get_hip_source(self._h))
+
+    @property
+    def code_object(self):
+        """The gfx950 code object of the stepper module (bytes), e.g. for llvm-objdump."""
+        n = ctypes.c_size_t(0)
+        raise_for(lib.hy_tab_get_code_object(self._h, None, ctypes.byref(n)))
+        buf = ctypes.create_string_buffer(n.value)
+        raise_for(lib.hy_tab_get_code_object(self._h, buf, ctypes.byref(n)))
+        return buf.raw[: n.value]
 
     @property
     def hip_source_mode(self):

@@ -133,6 +133,8 @@ SIGNATURES = [
     ("hy_tab_get_hip_source", c_void_p, [c_void_p]),
     ("hy_tab_get_decomposition_str", c_void_p, [c_void_p]),
     ("hy_tab_get_codegen_info", c_void_p, [c_void_p]),
+    ("hy_tab_get_code_object", c_int, [c_void_p, c_void_p, c_void_p]),
+    ("hy_hiprtc_compile", c_int, [c_char_p, c_void_p, c_void_p]),
     ("hy_tab_get_state", c_int, [c_void_p, c_void_p]),
     ("hy_tab_set_state", c_int, [c_void_p, c_void_p]),
     ("hy_tab_get_pars", c_int, [c_void_p, c_void_p]),

@@ -742,6 +742,32 @@ char *hy_tab_get_hip_source(hy_tab t)
 {
     return dup_str(t->core.get_hip_source());
 }
+int hy_tab_get_code_object(hy_tab t, void *out, size_t *size)
+{
+    return guarded([&] {
+        const auto &co = t->core.get_code_object();
+        if (out != nullptr) {
+            if (*size < co.size()) {
+                throw std::invalid_argument("hy_tab_get_code_object(): the output buffer is too small");
+            }
+            std::memcpy(out, co.data(), co.size());
+        }
+        *size = co.size();
+    });
+}
+int hy_hiprtc_compile(const char *source, void *out, size_t *size)
+{
+    return guarded([&] {
+        const auto cm = hiprtc_compile_source(source);
+        if (out != nullptr) {
+            if (*size < cm->code.size()) {
+                throw std::invalid_argument("hy_hiprtc_compile(): the output buffer is too small");
+            }
+            std::memcpy(out, cm->code.data(), cm->code.size());
+        }
+        *size = cm->code.size();
+    });
+}
 char *hy_tab_get_codegen_info(hy_tab t)
 {
     return dup_str(t->core.get_codegen_info());

@@ -568,6 +568,11 @@ int tab_core::get_device() const
 {
     return m_impl->device;
 }
+const std::vector<char> &tab_core::get_code_object() const
+{
+    return m_impl->cmod->code;
+}
+
 const std::string &tab_core::get_hip_source() const
 {
     return m_impl->emitted.source;

@@ -90,6 +90,8 @@ public:
     [[nodiscard]] const sys_t &get_sys() const;
     [[nodiscard]] int get_device() const;
     [[nodiscard]] const std::string &get_hip_source() const;
+    // The gfx950 code object of the stepper module (the counterpart of llvm_state::get_object_code()).
+    [[nodiscard]] const std::vector<char> &get_code_object() const;
     [[nodiscard]] double get_compile_seconds() const;
     // "unrolled" / "cluster ..." / "table ...": which code generator was selected, and why.
     [[nodiscard]] std::string get_codegen_info() const;

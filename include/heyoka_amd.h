@@ -227,6 +227,11 @@ char *hy_tab_get_hip_source(hy_tab);  /* generated HIP module (cf. llvm_state::g
 char *hy_tab_get_decomposition_str(hy_tab);
 /* Description of the code generation mode chosen for this system ("unrolled", "cluster ...", "table ..."). Caller frees. */
 char *hy_tab_get_codegen_info(hy_tab);
+/* The gfx950 code object of the stepper module (cf. llvm_state::get_object_code(), include/heyoka/llvm_state.hpp) and a
+ * plain hiprtc compilation of a HIP source with the options of the steppers (for offline inspection: disassembly, the
+ * code-generation checks of tests/test_codegen_hazards.py). Two-call convention: out == NULL -> *size receives the size. */
+int hy_tab_get_code_object(hy_tab, void *out, size_t *size);
+int hy_hiprtc_compile(const char *source, void *out, size_t *size);
 
 int hy_tab_get_state(hy_tab, double *out);                 /* get_state()        n_eq * batch_size */
 int hy_tab_set_state(hy_tab, const double *in);            /* writes through get_state_data() */
