@@ -63,3 +63,48 @@ def test_detector_fires_on_the_configuration_that_exposed_the_hazard():
     if not hz:
         pytest.skip("this toolchain no longer produces the pattern for the inlined variant")
     assert any(h[0] == "hy_taylor" and "v_accvgpr_write" in h[3] or "scratch_store" in h[3] for h in hz)
+
+
+def test_detector_on_synthetic_disassembly():
+    """The pattern matcher itself, on hand-written listings: copies ahead of the exec restore at the target of an
+    s_cbranch_execz are reported; the same copies after the restore, or at the target of an s_cbranch_execnz (an outlined
+    first side, entered with its own mask), are not."""
+    def listing(body):
+        lines = ["0000000000001000 <hy_taylor>:"]
+        addr = 0x1000
+        for ins in body:
+            tgt = ""
+            if isinstance(ins, tuple):
+                ins, off = ins
+                tgt = " <hy_taylor+0x%x>" % off
+            lines.append("\t%-58s // %012X: 00000000%s" % (ins, addr, tgt))
+            addr += 4
+        return "\n".join(lines) + "\n"
+
+    bad = listing([
+        "s_and_saveexec_b64 s[2:3], vcc",
+        ("s_cbranch_execz 3", 0x10),         # skips the first side
+        "v_add_f64 v[0:1], v[0:1], v[2:3]",  # first side
+        "v_mul_f64 v[0:1], v[0:1], v[2:3]",
+        "s_waitcnt vmcnt(0)",                # +0x10: flow block
+        "v_accvgpr_write_b32 a3, v9",        # live-range split under the stale mask
+        "s_mov_b32 s4, s5",
+        "s_andn2_saveexec_b64 s[2:3], s[4:5]",
+        "s_endpgm",
+    ])
+    hz = codegen_check.scan_disassembly(bad)
+    assert hz == [("hy_taylor", "0x1010", 1, "v_accvgpr_write_b32 a3, v9")]
+
+    good = bad.replace("v_accvgpr_write_b32 a3, v9", "s_nop 0")
+    assert codegen_check.scan_disassembly(good) == []
+    after = listing([
+        "s_and_saveexec_b64 s[2:3], vcc",
+        ("s_cbranch_execz 2", 0xc),
+        "v_add_f64 v[0:1], v[0:1], v[2:3]",
+        "s_or_b64 exec, exec, s[2:3]",       # +0xc: exec restored first
+        "v_accvgpr_write_b32 a3, v9",
+        "s_endpgm",
+    ])
+    assert codegen_check.scan_disassembly(after) == []
+    outlined = bad.replace("s_cbranch_execz 3", "s_cbranch_execnz 3")
+    assert codegen_check.scan_disassembly(outlined) == []
