@@ -178,3 +178,55 @@ def test_piecewise_functions():
     got = hy.taylor_decompose_sys(piecewise_system(hy, x, y, hy.time, hy.par[0]))
     exp = ho.dc_to_strings(ho.taylor_decompose_sys(piecewise_system(ho, ho.var("x"), ho.var("y"), ho.func("time", []), ho.par(0))))
     assert got == exp
+
+
+def test_reference_decomposition_size_pins():
+    """Sizes (and extra-function indices) pinned by the reference's own tests, tests/golden/decomposition_pins.json: CSE
+    across the hidden dependencies of every unary function, sin/cos and sinh/cosh pairs, pow_to_explog, and
+    taylor_decompose_sys() with extra functions (the event equations' path) - product and oracle."""
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "decomposition_pins.json")) as f:
+        pins = json.load(f)
+
+    def env(m):
+        if m is ho:
+            x, y = m.var("x"), m.var("y")
+            d = {"pow": m.pow_, "par": m.par}
+        else:
+            x, y = m.make_vars("x", "y")
+            d = {"pow": m.pow, "par": lambda i: m.par[i]}
+        for fn in "sqrt exp erf sigmoid tan tanh acos acosh asin asinh atan atanh sin cos sinh cosh".split():
+            d[fn] = getattr(m, fn)
+        d.update(x=x, y=y, s=x + y)
+        return d
+
+    def size(m, sys_):
+        return len(hy.taylor_decompose_sys(sys_)) if m is hy else len(ho.taylor_decompose_sys(sys_))
+
+    for m in (hy, ho):
+        e = env(m)
+        x, y = e["x"], e["y"]
+        for c in pins["unary_cse"]:
+            assert size(m, [(x, eval(c["rhs_x"], {}, e)), (y, x)]) == c["size"], (m.__name__, c)
+        for c in pins["pairs"]:
+            s_, c_ = (m.sin, m.cos) if c["name"] == "sincos" else (m.sinh, m.cosh)
+            rhs = (s_(x) + c_(y)) + (s_(y) + c_(x))
+            assert size(m, [(x, rhs), (y, rhs)]) == c["size"], (m.__name__, c)
+        t1 = x + e["pow"](y, e["par"](0))
+        t2, t3 = e["pow"](x, t1), e["pow"](t1, e["par"](1))
+        assert size(m, [(x, (t1 * t2) / t3), (y, t1)]) == pins["pow_to_explog"]["size"]
+
+    # Extra functions: the oracle exposes the indices; the product's integrator with the same functions as event
+    # equations must report a decomposition of the same size.
+    for c in pins["sv_funcs"]:
+        eo = env(ho)
+        sys_o = [(eo[lhs], eval(rhs, {}, eo)) for lhs, rhs in c["sys"]]
+        dc, sv = ho.taylor_decompose_sys(sys_o, [eval(f, {}, eo) for f in c["funcs"]])
+        assert len(dc) == c["size"] and list(sv) == c["sv_funcs_dc"], c
+        ep = env(hy)
+        sys_p = [(ep[lhs], eval(rhs, {}, ep)) for lhs, rhs in c["sys"]]
+        evs = [hy.nt_event(eval(f, {}, ep), lambda *a: None) for f in c["funcs"]]
+        ta = hy.taylor_adaptive_batch(sys_p, None, 2, nt_events=evs)
+        assert len(ta.decomposition) == c["size"], c
