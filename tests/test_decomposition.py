@@ -218,6 +218,23 @@ def test_reference_decomposition_size_pins():
         t2, t3 = e["pow"](x, t1), e["pow"](t1, e["par"](1))
         assert size(m, [(x, (t1 * t2) / t3), (y, t1)]) == pins["pow_to_explog"]["size"]
 
+    # Rewrites applied by the decomposition: prod({3, y^-1, x^-1.5}) -> div with one negative-exponent pow left;
+    # sum({1, -x, -y}) -> sub(1, sum(x, y)).
+    for m in (hy, ho):
+        e = env(m)
+        x, y = e["x"], e["y"]
+        systems = {
+            "prod_to_div": [(x, m.prod([3.0, e["pow"](y, -1.0), e["pow"](x, -1.5)])), (y, x)],
+            "sum_to_sub": [(x, (m.sum if m is hy else m.sum_)([1.0, m.prod([-1.0, x]), m.prod([-1.0, y])])), (y, x)],
+        }
+        for c in pins["rewrites"]:
+            dc = hy.taylor_decompose_sys(systems[c["name"]]) if m is hy else ho.dc_to_strings(ho.taylor_decompose_sys(systems[c["name"]]))
+            assert len(dc) == c["size"], (m.__name__, c)
+            k = Counter(l.split("(")[0] for l in dc)
+            assert all(k[n] == v for n, v in c["counts"].items()), (m.__name__, c, k)
+        assert any(l.startswith("pow(") and l.rstrip(")").split(", ")[-1].startswith("-") for l in
+                   (hy.taylor_decompose_sys(systems["prod_to_div"]) if m is hy else ho.dc_to_strings(ho.taylor_decompose_sys(systems["prod_to_div"]))))
+
     # Extra functions: the oracle exposes the indices; the product's integrator with the same functions as event
     # equations must report a decomposition of the same size.
     for c in pins["sv_funcs"]:
