@@ -1727,7 +1727,7 @@ std::vector<double> tab_core::propagate_grid(std::vector<double> grid, std::size
             "Cannot invoke propagate_grid() in an adaptive Taylor integrator in batch mode if the time grid is empty");
     }
     if (grid.size() % N != 0u) {
-        throw std::invalid_argument("Invalid grid size detected in propagate_grid() in an adaptive Taylor integrator "
+        throw std::invalid_argument("Invalid grid size detected in propagate_grid() for an adaptive Taylor integrator "
                                     "in batch mode: the grid has a size of "
                                     + std::to_string(grid.size()) + ", which is not a multiple of the batch size ("
                                     + std::to_string(N) + ")");

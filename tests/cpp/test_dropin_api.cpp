@@ -61,6 +61,26 @@ int main(int argc, char **argv)
     REQUIRE(ta.get_tol() == std::numeric_limits<double>::epsilon());
     REQUIRE(ta.get_decomposition().size() == 12u);
 
+    // propagate_grid() argument validation, verbatim messages (test/taylor_adaptive_batch.cpp:174-190).
+    {
+        const auto expect_msg = [&](std::vector<double> grid, const std::string &msg) {
+            bool ok = false;
+            try {
+                ta.propagate_grid(std::move(grid));
+            } catch (const std::invalid_argument &e) {
+                ok = msg == e.what();
+            }
+            REQUIRE(ok);
+        };
+        expect_msg({}, "Cannot invoke propagate_grid() in an adaptive Taylor integrator in batch mode if the time grid is empty");
+        for (const auto n : {1u, 2u, 5u}) {
+            expect_msg(std::vector<double>(n, 1.),
+                       "Invalid grid size detected in propagate_grid() for an adaptive Taylor integrator in batch mode: "
+                       "the grid has a size of "
+                           + std::to_string(n) + ", which is not a multiple of the batch size (4)");
+        }
+    }
+
     // kwargs accepted like the reference's (LLVM-only ones are ignored).
     auto sys2 = model::nbody(2, kw::masses = {1., 0.});
     auto tad = taylor_adaptive_batch<double>{sys2, std::vector<double>(12u * 8u, 0.), 8u, kw::high_accuracy = true,
