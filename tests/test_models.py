@@ -154,6 +154,7 @@ def _model_cases():
                          lambda: ho.np1body(4, masses=[ho.par(0), 1e-3, ho.par(1)])),
         "np1body5_massless": (lambda: hy.model.np1body(5, masses=[1.0, 1e-3]), lambda: ho.np1body(5, masses=[1.0, 1e-3])),
         "np1body8_default": (lambda: hy.model.np1body(8), lambda: ho.np1body(8)),
+        "np1body13_default": (lambda: hy.model.np1body(13), lambda: ho.np1body(13)),
         "fixed_centres7": (lambda: hy.model.fixed_centres(masses=m, positions=pos, Gconst=1.02),
                            lambda: ho.fixed_centres(masses=m, positions=pos, Gconst=1.02)),
         "rotating": (lambda: hy.model.rotating(omega=om), lambda: ho.rotating(omega=om)),
@@ -215,6 +216,8 @@ def _gpu_cases(pins):
         "np1body4_par": (*cases["np1body4_par"], oss[:18], npar([1.0, 3e-4]), 30.0),
         # Unit masses: the planner needs its second attempt (no absorption of the scaling products) on top of the aliases.
         "np1body8_default": (*cases["np1body8_default"], _relative_plummer(8, n), None, 0.5),
+        # 78 clusters (> 64 lanes): one system per workgroup (block mode) on the aliased program.
+        "np1body13_default": (*cases["np1body13_default"], _relative_plummer(13, n), None, 0.2),
         "fixed_centres7": (*cases["fixed_centres7"], fc_st, None, 5.0),
         "rotating": (*cases["rotating"], rot_st, None, 5.0),
         "rotating_par": (*cases["rotating_par"], rot_st, npar([0.1, 0.2, 0.3]), 5.0),
@@ -223,7 +226,8 @@ def _gpu_cases(pins):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["cr3bp", "cr3bp_par", "np1body6", "np1body4_par", "np1body8_default", "fixed_centres7",
+@pytest.mark.parametrize("name", ["cr3bp", "cr3bp_par", "np1body6", "np1body4_par", "np1body8_default", "np1body13_default",
+                                  "fixed_centres7",
                                   "rotating", "rotating_par", "mascon7"])
 def test_models_step_and_propagate_vs_oracle(name, pins):
     """One full-order step (h, Taylor coefficients, state) and a propagation of every model against the oracle.
@@ -233,6 +237,8 @@ def test_models_step_and_propagate_vs_oracle(name, pins):
     n = st.shape[1]
     kw = {} if pars is None else {"pars": pars}
     ta = hy.taylor_adaptive_batch(prod(), st, n, **kw)
+    if name == "np1body13_default":
+        assert ta.hip_source_mode.startswith("block") and "aliased" in ta.hip_source_mode
     if name in ("np1body6", "np1body8_default"):
         # State variables in history-operand position (|r_i|^2 = sum_sq(x_i, y_i, z_i)) are aliased by u variables so that
         # the wave-cluster stepper applies (add_state_aliases(), heyoka_amd/csrc/hip_emit_cluster.cpp).
