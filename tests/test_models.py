@@ -138,6 +138,9 @@ def test_model_error_messages(pins):
             assert str(ei.value) == msg
 
 
+_M8 = [1.0, 1e-3, 2e-3, 3e-4, 5e-4, 1e-5, 2e-5, 3e-5]
+
+
 def _model_cases():
     M = [1.00000597682, 1 / 1047.355, 1 / 3501.6, 1 / 22869.0, 1 / 19314.0, 7.4074074e-09]
     G = 0.01720209895 * 0.01720209895 * 365 * 365
@@ -155,6 +158,7 @@ def _model_cases():
         "np1body5_massless": (lambda: hy.model.np1body(5, masses=[1.0, 1e-3]), lambda: ho.np1body(5, masses=[1.0, 1e-3])),
         "np1body8_default": (lambda: hy.model.np1body(8), lambda: ho.np1body(8)),
         "np1body13_default": (lambda: hy.model.np1body(13), lambda: ho.np1body(13)),
+        "np1body8_masses": (lambda: hy.model.np1body(8, masses=_M8), lambda: ho.np1body(8, masses=_M8)),
         "fixed_centres7": (lambda: hy.model.fixed_centres(masses=m, positions=pos, Gconst=1.02),
                            lambda: ho.fixed_centres(masses=m, positions=pos, Gconst=1.02)),
         "rotating": (lambda: hy.model.rotating(omega=om), lambda: ho.rotating(omega=om)),
@@ -216,6 +220,9 @@ def _gpu_cases(pins):
         "np1body4_par": (*cases["np1body4_par"], oss[:18], npar([1.0, 3e-4]), 30.0),
         # Unit masses: the planner needs its second attempt (no absorption of the scaling products) on top of the aliases.
         "np1body8_default": (*cases["np1body8_default"], _relative_plummer(8, n), None, 0.5),
+        # The first-generation cluster kernel (separate state-variable rounds) on aliased programs.
+        "np1body8_masses": (*cases["np1body8_masses"], _relative_plummer(8, n), None, 0.5),
+        "np1body5_massless": (*cases["np1body5_massless"], _relative_plummer(5, n), None, 0.5),
         # 78 clusters (> 64 lanes): one system per workgroup (block mode) on the aliased program.
         "np1body13_default": (*cases["np1body13_default"], _relative_plummer(13, n), None, 0.2),
         "fixed_centres7": (*cases["fixed_centres7"], fc_st, None, 5.0),
@@ -227,7 +234,7 @@ def _gpu_cases(pins):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["cr3bp", "cr3bp_par", "np1body6", "np1body4_par", "np1body8_default", "np1body13_default",
-                                  "fixed_centres7",
+                                  "np1body8_masses", "np1body5_massless", "fixed_centres7",
                                   "rotating", "rotating_par", "mascon7"])
 def test_models_step_and_propagate_vs_oracle(name, pins):
     """One full-order step (h, Taylor coefficients, state) and a propagation of every model against the oracle.
@@ -237,6 +244,9 @@ def test_models_step_and_propagate_vs_oracle(name, pins):
     n = st.shape[1]
     kw = {} if pars is None else {"pars": pars}
     ta = hy.taylor_adaptive_batch(prod(), st, n, **kw)
+    if name in ("np1body8_masses", "np1body5_massless"):
+        m_ = ta.hip_source_mode
+        assert m_.startswith("cluster") and "v2" not in m_.split(";")[0] and "aliased" in m_
     if name == "np1body13_default":
         assert ta.hip_source_mode.startswith("block") and "aliased" in ta.hip_source_mode
     if name in ("np1body6", "np1body8_default"):
