@@ -16,8 +16,8 @@ std::vector<tab_core> ensemble_propagate_core(const tab_core &ta, double t, std:
                                               std::size_t max_steps, int n_devices, ensemble_kind kind)
 {
     if (n_iter == 0u) {
-        throw std::invalid_argument("Cannot perform an ensemble propagate_" + std::string(kind == ensemble_kind::until ? "until" : "for")
-                                    + "() if the number of iterations is zero");
+        // Reference: an empty result (test/ensemble_propagate.cpp:90-99).
+        return {};
     }
 
     const auto visible = hip_device_count();

@@ -94,12 +94,7 @@ auto ensemble_propagate_tmpl(const taylor_adaptive_batch<double> &ta, const Time
     constexpr bool is_grid = (Kind == ensemble_tmpl_kind::grid);
     static_assert(!is_grid || (!kw::has_v<kw::c_output_tag, KwArgs...> && !kw::has_v<kw::write_tc_tag, KwArgs...>),
                   "kw::c_output and kw::write_tc are not accepted by ensemble_propagate_grid_batch()");
-    if (n_iter == 0u) {
-        throw std::invalid_argument(std::string("Cannot perform an ensemble propagate_")
-                                    + (Kind == ensemble_tmpl_kind::until ? "until"
-                                                                         : (is_grid ? "grid" : "for"))
-                                    + "() if the number of iterations is zero");
-    }
+    // NOTE: zero iterations: an empty result (test/ensemble_propagate.cpp:90-99).
     const auto batch_size = ta.get_batch_size();
     const auto max_steps = static_cast<std::size_t>(kw::get(kw::max_steps, 0, kw_args...));
     std::vector<double> max_delta_ts;

@@ -81,6 +81,17 @@ int main(int argc, char **argv)
         }
     }
 
+    // Zero iterations: empty results, the generator is never called (test/ensemble_propagate.cpp:90-99, :307-315).
+    {
+        const auto gen = [](taylor_adaptive_batch<double> tint, std::size_t) {
+            std::abort();
+            return tint;
+        };
+        REQUIRE(ensemble_propagate_until_batch(ta, 20., 0u, gen).empty());
+        REQUIRE(ensemble_propagate_for_batch(ta, 20., 0u, gen, kw::max_steps = 10u).empty());
+        REQUIRE(ensemble_propagate_grid_batch(ta, std::vector<double>{0., 1.}, 0u, gen).empty());
+    }
+
     // kwargs accepted like the reference's (LLVM-only ones are ignored).
     auto sys2 = model::nbody(2, kw::masses = {1., 0.});
     auto tad = taylor_adaptive_batch<double>{sys2, std::vector<double>(12u * 8u, 0.), 8u, kw::high_accuracy = true,
