@@ -12,6 +12,9 @@
 #include <functional>
 #include <initializer_list>
 #include <limits>
+#include <locale>
+#include <ostream>
+#include <sstream>
 #include <memory>
 #include <optional>
 #include <stdexcept>
@@ -638,5 +641,45 @@ public:
         return m_core;
     }
 };
+
+// Human-readable summary (reference: taylor_adaptive_batch_stream_impl(), src/taylor_stream_ops.cpp:110-170): the same
+// fields and labels, plus the code generator that produced the device kernels.
+template <typename T>
+inline std::ostream &operator<<(std::ostream &os, const taylor_adaptive_batch<T> &ta)
+{
+    std::ostringstream oss;
+    oss.imbue(std::locale::classic());
+    oss << std::boolalpha;
+    oss.precision(std::numeric_limits<T>::max_digits10);
+    const auto list = [&oss](const char *label, const std::vector<T> &v) {
+        oss << label << '[';
+        for (std::size_t i = 0; i < v.size(); ++i) {
+            oss << v[i] << (i + 1u == v.size() ? "" : ", ");
+        }
+        oss << "]\n";
+    };
+    oss << "C++ datatype            : double\n";
+    oss << "Tolerance               : " << ta.get_tol() << '\n';
+    oss << "High accuracy           : " << ta.get_high_accuracy() << '\n';
+    oss << "Compact mode            : " << ta.get_compact_mode() << '\n';
+    oss << "Taylor order            : " << ta.get_order() << '\n';
+    oss << "Dimension               : " << ta.get_dim() << '\n';
+    oss << "Batch size              : " << ta.get_batch_size() << '\n';
+    list("Time                    : ", ta.get_time());
+    list("State                   : ", ta.get_state());
+    if (!ta.get_pars().empty()) {
+        list("Parameters              : ", ta.get_pars());
+    }
+    if (ta.with_events()) {
+        if (!ta.core().get_t_events().empty()) {
+            oss << "N of terminal events    : " << ta.core().get_t_events().size() << '\n';
+        }
+        if (!ta.core().get_nt_events().empty()) {
+            oss << "N of non-terminal events: " << ta.core().get_nt_events().size() << '\n';
+        }
+    }
+    oss << "Code generator (gfx950) : " << ta.core().get_codegen_info() << '\n';
+    return os << oss.str();
+}
 
 } // namespace heyoka_amd

@@ -146,6 +146,22 @@ int main(int argc, char **argv)
         REQUIRE(thrown);
     }
 
+    // operator<< (test/taylor_adaptive_batch.cpp:1268-1345).
+    {
+        std::ostringstream oss;
+        oss << ta;
+        const auto out = oss.str();
+        for (const char *field : {"Tolerance", "Dimension", "Batch size", "Parameters", "High accuracy", "Compact mode", "Taylor order"}) {
+            REQUIRE(out.find(field) != std::string::npos);
+        }
+        REQUIRE(out.find("events") == std::string::npos);
+        std::ostringstream oss2;
+        oss2 << tae;
+        REQUIRE(oss2.str().find("N of terminal events    : 1") != std::string::npos);
+        REQUIRE(oss2.str().find("N of non-terminal events: 1") != std::string::npos);
+        REQUIRE(oss2.str().find("Parameters") == std::string::npos);
+    }
+
     // The other point-mass models, with the call syntax and the decomposition sizes of the reference's tests
     // (test/model_cr3bp.cpp:41-48, model_rotating.cpp:65-73, :96-107, model_fixed_centres.cpp:70, model_mascon.cpp:287-299,
     // model_nbody.cpp:492-497).
