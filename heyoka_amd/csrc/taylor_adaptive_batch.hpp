@@ -290,6 +290,8 @@ template <>
 class taylor_adaptive_batch<double>
 {
     detail::tab_core m_core;
+    std::vector<t_event_batch<double>> m_t_events;
+    std::vector<nt_event_batch<double>> m_nt_events;
 
     template <typename... KwArgs>
     static detail::tab_core::config make_config(const KwArgs &...kw_args)
@@ -392,6 +394,17 @@ public:
     taylor_adaptive_batch(sys_t sys, std::vector<double> state, std::uint32_t batch_size, const KwArgs &...kw_args)
         : m_core(std::move(sys), std::move(state), batch_size, make_config(kw_args...))
     {
+        // The user-facing event objects, for get_t_events() / get_nt_events() (include/heyoka/taylor.hpp:1009-1024).
+        if constexpr (kw::has_v<kw::t_events_tag, KwArgs...>) {
+            for (const auto &ev : kw::get(kw::t_events, 0, kw_args...)) {
+                m_t_events.push_back(ev);
+            }
+        }
+        if constexpr (kw::has_v<kw::nt_events_tag, KwArgs...>) {
+            for (const auto &ev : kw::get(kw::nt_events, 0, kw_args...)) {
+                m_nt_events.push_back(ev);
+            }
+        }
     }
     template <typename... KwArgs>
     taylor_adaptive_batch(sys_t sys, std::initializer_list<double> state, std::uint32_t batch_size,
@@ -409,6 +422,14 @@ public:
     [[nodiscard]] const taylor_dc_t &get_decomposition() const
     {
         return m_core.get_decomposition();
+    }
+    [[nodiscard]] const std::vector<t_event_batch<double>> &get_t_events() const
+    {
+        return m_t_events;
+    }
+    [[nodiscard]] const std::vector<nt_event_batch<double>> &get_nt_events() const
+    {
+        return m_nt_events;
     }
     [[nodiscard]] std::uint32_t get_batch_size() const
     {
@@ -671,11 +692,11 @@ inline std::ostream &operator<<(std::ostream &os, const taylor_adaptive_batch<T>
         list("Parameters              : ", ta.get_pars());
     }
     if (ta.with_events()) {
-        if (!ta.core().get_t_events().empty()) {
-            oss << "N of terminal events    : " << ta.core().get_t_events().size() << '\n';
+        if (!ta.get_t_events().empty()) {
+            oss << "N of terminal events    : " << ta.get_t_events().size() << '\n';
         }
-        if (!ta.core().get_nt_events().empty()) {
-            oss << "N of non-terminal events: " << ta.core().get_nt_events().size() << '\n';
+        if (!ta.get_nt_events().empty()) {
+            oss << "N of non-terminal events: " << ta.get_nt_events().size() << '\n';
         }
     }
     oss << "Code generator (gfx950) : " << ta.core().get_codegen_info() << '\n';

@@ -160,6 +160,9 @@ int main(int argc, char **argv)
         REQUIRE(oss2.str().find("N of terminal events    : 1") != std::string::npos);
         REQUIRE(oss2.str().find("N of non-terminal events: 1") != std::string::npos);
         REQUIRE(oss2.str().find("Parameters") == std::string::npos);
+        REQUIRE(tae.get_t_events().size() == 1u && tae.get_nt_events().size() == 1u && ta.get_t_events().empty());
+        REQUIRE(tae.get_t_events()[0].get_direction() == event_direction::positive
+                && tae.get_t_events()[0].get_cooldown() == 0.01);
     }
 
     // The other point-mass models, with the call syntax and the decomposition sizes of the reference's tests
