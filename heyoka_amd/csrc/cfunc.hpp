@@ -120,6 +120,20 @@ public:
     {
         return m_core.is_time_dependent();
     }
+    // Reference getters without a counterpart on the device (include/heyoka/expression.hpp:735-970): the evaluation is
+    // always one lane per evaluation, in double precision, with the function fully unrolled.
+    [[nodiscard]] bool get_parallel_mode() const
+    {
+        return false;
+    }
+    [[nodiscard]] bool get_compact_mode() const
+    {
+        return false;
+    }
+    [[nodiscard]] bool get_high_accuracy() const
+    {
+        return false;
+    }
 
     // Evaluation over host vectors. Single evaluation: inputs.size() == nvars; multiple evaluations:
     // inputs.size() == nvars * nevals with the row-major layout inputs[var * nevals + eval] (the 2D
