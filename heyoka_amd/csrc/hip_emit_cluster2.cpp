@@ -40,7 +40,11 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     }
 
     const auto n_eq = p.n_eq, order = opts.order, L = pl.L, spw = pl.spw;
-    const std::uint32_t bs = 256, wpb = bs / 64u;
+    // NOTE: HEYOKA_AMD_V2_BS=512 (two wavefronts per SIMD, 256 registers per lane) is an experiment knob.
+    const std::uint32_t bs = std::getenv("HEYOKA_AMD_V2_BS") != nullptr
+                                 ? static_cast<std::uint32_t>(std::atoi(std::getenv("HEYOKA_AMD_V2_BS")))
+                                 : 256u;
+    const std::uint32_t wpb = bs / 64u;
     const auto nc = static_cast<std::uint32_t>(pl.clusters.size());
     const auto &t0 = pl.clusters[0];
     const auto n_ext = static_cast<std::uint32_t>(pl.ext_u[0].size());
@@ -285,11 +289,17 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         why_not = "no state variable could be attached to a glue round";
         return ret;
     }
+    // Columns of the state-variable jets: one per state variable (owner slots are compressed: only the valid lanes
+    // of a slot own a column) plus one dummy column per system which absorbs the stores of the idle lanes of a
+    // partially filled slot - they replicate the node of a valid lane, so every statement of the step body is
+    // unconditional (no exec-mask manipulation inside the step loop).
     const auto n_col = n_col_acc;
+    const auto n_colp = n_col + 1u;
+    const auto n_hslots = (n_col + L - 1u) / L; // lane slots of the final Horner / compensated evaluation
     // Jets of the state variables: [order][system of the wave][column], per wave. Kept in LDS when the
     // block's slab + jets fit in the 160 KB of a CU (the kernel occupies a whole CU anyway: 512 registers
     // per lane), otherwise in a per-wave global scratch.
-    const auto jet_doubles_per_wave = static_cast<std::uint64_t>(order + 1u) * spw * n_col;
+    const auto jet_doubles_per_wave = static_cast<std::uint64_t>(order + 1u) * spw * n_colp;
     const auto lds_doubles_slab = static_cast<std::uint64_t>(wpb) * spw * ((2u * (pl.n_slots + std::max<std::uint32_t>(n_out, 1u))) | 1u);
     const bool jet_lds = (lds_doubles_slab + wpb * jet_doubles_per_wave) * 8u <= 160u * 1024u
                          && std::getenv("HEYOKA_AMD_JET_GLOBAL") == nullptr;
@@ -300,21 +310,22 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         return (k % 2u == 0u) ? ("slab[" + tbl + "]") : ("slab[" + tbl + " + " + std::to_string(buf_stride) + "u]");
     };
     const auto jet_at = [&](std::uint32_t k, std::uint32_t col) {
-        return "jc" + std::to_string(col) + "[" + std::to_string(static_cast<std::uint64_t>(k) * spw * n_col) + "]";
+        return "jc" + std::to_string(col) + "[" + std::to_string(static_cast<std::uint64_t>(k) * spw * n_colp) + "]";
     };
     const auto sync = [&]() { os << "HY_WSYNC();\n"; };
 
     // Owner-slot bookkeeping when a new coefficient of a state variable is produced.
-    const auto publish_sv = [&](owner_slot &ow, std::uint32_t k, const std::string &name, const std::string &valid) {
+    const auto publish_sv = [&](owner_slot &ow, std::uint32_t k, const std::string &name) {
         ow.xname[k] = name;
         os << slabk(k, utname(ow.out_tbl)) << " = " << name << ";\n";
-        if (ow.n_valid < L) {
-            os << "if (" << valid << ") ";
+        if (k != 0u) {
+            // (The order-0 row of the jets *is* the current state: written by the update of the previous step.)
+            os << jet_at(k, ow.col) << " = " << name << ";\n";
         }
-        os << jet_at(k, ow.col) << " = " << name << ";\n";
+        // NOTE: the idle lanes of a partially filled slot hold a copy of a valid lane's coefficient: harmless in a maximum.
         const char *acc = (k == 0u) ? "m0" : (k == order ? "mo" : (k == order - 1u ? "mom1" : nullptr));
         if (acc != nullptr) {
-            os << "if (" << valid << ") " << acc << " = hy_max(" << acc << ", fabs(" << name << "));\n";
+            os << acc << " = hy_max(" << acc << ", fabs(" << name << "));\n";
         }
     };
 
@@ -366,7 +377,7 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         for (std::size_t a = 0; a < gr.owners.size(); ++a) {
             const auto src = (a == 0u) ? gval : gr.owners[a - 1u].xname[k];
             const auto x = e.div_const(src, k + 1u);
-            publish_sv(gr.owners[a], k + 1u, x, "ovalid" + std::to_string(gr.owners[a].col));
+            publish_sv(gr.owners[a], k + 1u, x);
         }
     };
     const auto emit_glue_round = [&](std::size_t g, std::uint32_t r, std::uint32_t k) {
@@ -441,7 +452,8 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     for (auto &rg : rounds) {
         for (auto &gr : rg) {
             for (auto &ow : gr.owners) {
-                publish_sv(ow, 0, "xs" + std::to_string(ow.col), "ovalid" + std::to_string(ow.col));
+                os << "const double xs" << ow.col << " = jr" << ow.col << "[0];\n";
+                publish_sv(ow, 0, "xs" + std::to_string(ow.col));
             }
         }
     }
@@ -547,10 +559,18 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         for (const auto &gr : rg) {
             for (const auto &ow : gr.owners) {
                 src << "const bool ovalid" << ow.col << " = l < " << gr.n_valid << "u;\n";
-                src << "double *const jc" << ow.col << " = jetw + q * " << n_col << "u + " << ow.cbase << "u + (ovalid"
-                    << ow.col << " ? l : 0u);\n";
+                src << "double *const jc" << ow.col << " = jetw + q * " << n_colp << "u + (ovalid" << ow.col << " ? "
+                    << ow.cbase << "u + l : " << n_col << "u);\n";
+                // The current state (order-0 row) is read from the column of the replicated variable by the idle lanes.
+                src << "const double *const jr" << ow.col << " = jetw + q * " << n_colp << "u + " << ow.cbase
+                    << "u + (ovalid" << ow.col << " ? l : 0u);\n";
             }
         }
+    }
+    // Lane slots of the final evaluation: slot h, lane l <-> jet column h * L + l (dummy column beyond the last one).
+    for (std::uint32_t h = 0; h < n_hslots; ++h) {
+        src << "double *const hc" << h << " = jetw + q * " << n_colp << "u + ((" << h * L << "u + l < " << n_col << "u) ? "
+            << h * L << "u + l : " << n_col << "u);\n";
     }
     src << R"HIP(
 for (;;) {
@@ -570,10 +590,11 @@ double t_hi = a.time_hi[s], t_lo = a.time_lo[s];
     for (const auto &rg : rounds) {
         for (const auto &gr : rg) {
             for (const auto &ow : gr.owners) {
-                src << "double xs" << ow.col << " = a.state[(u64)" << utname(ow.var_tbl) << " * N + s];\n";
+                src << jet_at(0, ow.col) << " = a.state[(u64)" << utname(ow.var_tbl) << " * N + s];\n";
             }
         }
     }
+    src << "HY_WSYNC();\n" << (jet_lds ? "" : "__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, \"wavefront\");\n");
     src << R"HIP(
 hy_df tfin, rem;
 tfin.hi = 0.0; tfin.lo = 0.0; rem.hi = 0.0; rem.lo = 0.0;
@@ -593,6 +614,14 @@ if (a.mode == 1) {
 u64 n_steps = 0, iter = 0;
 double min_h = __builtin_inf(), max_h = 0.0, last_h = 0.0;
 i64 outcome = HY_OC_SUCCESS;
+// NOTE: the step loop is left by the whole wavefront at once (wave-uniform exit): a system which has reached its final
+// time keeps executing steps of length zero with all its bookkeeping frozen by selects (fin) until the other
+// systems of the wavefront are done - a wavefront executes an iteration as long as one of its lanes is active
+// anyway. With a per-lane exit the loop-carried values of the lanes which have left live across several
+// hundred live registers of the remaining ones, which is where this toolchain's live-range splitting goes
+// wrong (DESIGN.md, toolchain notes).
+bool fin = false;
+int nf_seen = 0;
 for (;;) {
 double lim;
 if (a.mode == 1) {
@@ -605,6 +634,7 @@ if (a.mode == 1) {
 } else {
     lim = step_lim;
 }
+lim = fin ? 0.0 : lim;
 )HIP";
     src << body;
 
@@ -622,9 +652,16 @@ if (a.mode == 1) {
     src << "h = hy_min(h, fabs(lim));\nh = (lim < 0.0) ? -h : h;\n";
 
     src << "asm volatile(\"\" ::: \"memory\");\n";
-    const auto kstride = static_cast<std::uint64_t>(spw) * n_col;
-    for (std::uint32_t c = 0; c < n_own; ++c) {
-        src << "{\nconst double *c = jc" << c << ";\n";
+    // NOTE: with the jets in global scratch the lanes exchange them through memory: wavefront-scope fences.
+    const char *jet_fence = jet_lds ? "" : "__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, \"wavefront\");\n";
+    src << jet_fence;
+    // Final evaluation of the Taylor series of the state variables (taylor_run_multihorner() / taylor_run_ceval(),
+    // src/taylor_00.cpp:279-460). The jets live in LDS (or in the per-wave scratch), so the evaluation is spread
+    // evenly over the lanes of the group: slot h, lane l <-> column h * L + l, ceil(n_eq / L) slots instead of
+    // one per owner slot (3 instead of 4 for the 36 variables of the outer Solar System on 16 lanes).
+    const auto kstride = static_cast<std::uint64_t>(spw) * n_colp;
+    for (std::uint32_t c = 0; c < n_hslots; ++c) {
+        src << "double xn" << c << ";\n{\nconst double *c = hc" << c << ";\n";
         if (opts.high_accuracy) {
             src << "double res = c[0], comp = 0.0, cur_h = h;\n#pragma unroll\n";
             src << "for (unsigned k = 1; k <= " << order << "u; ++k) {\n";
@@ -635,45 +672,91 @@ if (a.mode == 1) {
             src << "for (unsigned k = 1; k <= " << order << "u; ++k) {\n";
             src << "res = c[(u64)(" << order << "u - k) * " << kstride << "u] + res * h;\n}\n";
         }
-        src << "xs" << c << " = res;\n}\n";
+        src << "xn" << c << " = res;\n}\n";
     }
     src << R"HIP(
+double nt_hi, nt_lo;
 {
     hy_df tcur; tcur.hi = t_hi; tcur.lo = t_lo;
     hy_df hh; hh.hi = h; hh.lo = 0.0;
     const hy_df nt = hy_df_add(tcur, hh);
-    t_hi = nt.hi; t_lo = nt.lo;
+    nt_hi = nt.hi; nt_lo = nt.lo;
 }
-last_h = h;
-int nfi = !(hy_finite(t_hi) && hy_finite(t_lo)) ? 1 : 0;
+int nfi = !(hy_finite(nt_hi) && hy_finite(nt_lo)) ? 1 : 0;
 )HIP";
-    for (std::uint32_t c = 0; c < n_own; ++c) {
-        src << "if (ovalid" << c << " && !hy_finite(xs" << c << ")) nfi = 1;\n";
+    for (std::uint32_t c = 0; c < n_hslots; ++c) {
+        // (The dummy column holds finite copies.)
+        src << "nfi |= !hy_finite(xn" << c << ") ? 1 : 0;\n";
     }
     for (std::uint32_t m = 1; m < L; m *= 2u) {
         src << "nfi |= __shfl_xor(nfi, " << m << ", 64);\n";
     }
-    src << "if (a.tc != nullptr && live) {\n";
+    // Taylor coefficients on request (wave-uniform branch). NOTE: every lane stores: the idle lanes of a partially filled
+    // owner slot replicate the variable of a valid lane and the lanes beyond the end of the ensemble replicate the
+    // last system, so their stores write the same values to the same addresses - no divergent region in the step
+    // loop (see the toolchain notes in DESIGN.md). A rolled loop with a running pointer: unrolled, the (order + 1)
+    // store addresses per owner slot are invariants of the step loop and get hoisted into registers (84 x 64 bit for
+    // the outer Solar System) for a path that only runs when the caller asks for the coefficients.
+    src << "if (a.tc != nullptr) {\n";
     for (const auto &rg : rounds) {
         for (const auto &gr : rg) {
             for (const auto &ow : gr.owners) {
-                src << "if (ovalid" << ow.col << ") {\nconst double *c = jc" << ow.col
-                    << ";\nfor (unsigned k = 0; k <= " << order
-                    << "u; ++k) a.tc[((u64)" << utname(ow.var_tbl) << " * " << (order + 1u)
-                    << "u + k) * N + s] = c[(u64)k * " << kstride << "u];\n}\n";
+                src << "{\nconst double *c = jr" << ow.col << ";\ndouble *tcp = a.tc + ((u64)" << utname(ow.var_tbl)
+                    << " * " << (order + 1u) << "u) * N + s;\n"
+                    << "#pragma nounroll\nfor (unsigned k = 0; k <= " << order << "u; ++k) {\n*tcp = c[(u64)k * "
+                    << kstride << "u];\ntcp += N;\n}\n}\n";
             }
         }
     }
+    src << "}\n";
+    // The new state becomes the order-0 row of the jets (read back by the owner lanes at the top of the next step).
+    src << "HY_WSYNC();\n" << jet_fence;
+    for (std::uint32_t c = 0; c < n_hslots; ++c) {
+        // (A zero-length step leaves the state untouched bit by bit: x + 0 * ... = x also in the compensated sum.)
+        src << "hc" << c << "[0] = fin ? hc" << c << "[0] : xn" << c << ";\n";
+    }
+    src << "HY_WSYNC();\n" << jet_fence;
     src << R"HIP(
+{
+    // Bookkeeping of the reference's step() / propagate_until() loops (src/taylor_adaptive_batch.cpp:632-727,
+    // :1395-1520) on values frozen once the system is done.
+    const bool nf = nfi != 0;
+    const i64 oc_new = nf ? HY_OC_ERR_NF_STATE : ((h == lim) ? HY_OC_TIME_LIMIT : HY_OC_SUCCESS);
+    bool done = nf | (a.mode != 1);
+    const u64 ns_new = n_steps + ((!done & (h != 0.0)) ? 1u : 0u);
+    const bool upd = !done & (oc_new == HY_OC_SUCCESS);
+    const double ah = fabs(h);
+    const double mn_new = upd ? hy_min(min_h, ah) : min_h;
+    const double mx_new = upd ? hy_max(max_h, ah) : max_h;
+    done |= (h == rem.hi);
+    hy_df tnew; tnew.hi = nt_hi; tnew.lo = nt_lo;
+    const hy_df rem_new = hy_df_sub(tfin, tnew);
+    const u64 it_new = iter + 1u;
+    const bool sl = !done & (it_new == a.max_steps);
+    const i64 oc_fin = sl ? HY_OC_STEP_LIMIT : oc_new;
+    done |= sl;
+    nf_seen |= (!fin & nf) ? 1 : 0;
+    t_hi = fin ? t_hi : nt_hi;
+    t_lo = fin ? t_lo : nt_lo;
+    last_h = fin ? last_h : h;
+    outcome = fin ? outcome : oc_fin;
+    n_steps = fin ? n_steps : ns_new;
+    min_h = fin ? min_h : mn_new;
+    max_h = fin ? max_h : mx_new;
+    rem.hi = fin ? rem.hi : rem_new.hi;
+    rem.lo = fin ? rem.lo : rem_new.lo;
+    iter = fin ? iter : it_new;
+    fin = fin | done;
 }
-HY_STEP_TAIL(nfi != 0, l == 0u && live)
+if (__builtin_amdgcn_ballot_w64(!fin) == 0ull) break;
 }
+if (nf_seen != 0 && l == 0u && live) atomicAdd(a.counters, 1u);
 )HIP";
     for (const auto &rg : rounds) {
         for (const auto &gr : rg) {
             for (const auto &ow : gr.owners) {
-                src << "if (ovalid" << ow.col << " && live) a.state[(u64)" << utname(ow.var_tbl) << " * N + s] = xs"
-                    << ow.col << ";\n";
+                src << "if (ovalid" << ow.col << " && live) a.state[(u64)" << utname(ow.var_tbl) << " * N + s] = "
+                    << jet_at(0, ow.col) << ";\n";
             }
         }
     }

@@ -1,0 +1,2 @@
+mkdir -p gpurun_out/exp
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_models.py -x -q -m gpu -k "outer_ss or cluster or nbody8 or models or random_systems or write_tc or tutorial or device_array or full_size" > gpurun_out/exp/t3.log 2>&1; tail -5 gpurun_out/exp/t3.log
