@@ -39,14 +39,175 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         return ret;
     }
 
-    const auto n_eq = p.n_eq, order = opts.order, L = pl.L, spw = pl.spw;
-    // NOTE: HEYOKA_AMD_V2_BS=512 (two wavefronts per SIMD, 256 registers per lane) is an experiment knob.
-    const std::uint32_t bs = std::getenv("HEYOKA_AMD_V2_BS") != nullptr
-                                 ? static_cast<std::uint32_t>(std::atoi(std::getenv("HEYOKA_AMD_V2_BS")))
-                                 : 256u;
-    const std::uint32_t wpb = bs / 64u;
+    const auto n_eq = p.n_eq, order = opts.order;
     const auto nc = static_cast<std::uint32_t>(pl.clusters.size());
     const auto &t0 = pl.clusters[0];
+
+    // ---- 0. Lane-pair variant ("v3"): point-mass pair clusters {d_0, d_1, d_2 = coordinate differences,
+    // sum_sq(d_0, d_1, d_2), pow(sum_sq, alpha), [c * pow], d_i * pow, [c_i * (d_i * pow)]} are split over TWO lanes:
+    // lane A owns d_0, d_1 (their products and squares), lane B owns d_2, the sum of squares and the pow recurrence.
+    // Each lane keeps 4 coefficient histories instead of 5 + and the kernel fits in 256 registers, i.e. two wavefronts
+    // per SIMD: with one wavefront per SIMD every instruction of the stream - LDS, scalar, register copies - costs an
+    // issue slot of the FP64 pipe (profiles/ubench/issue_rate.hip), with two they overlap with the other wavefront's
+    // arithmetic. The two lanes run ONE instruction stream: the chains are matched so that the same FMA is useful
+    // work on both lanes with different register contents (see emit_pair_order below).
+    struct pair_pattern {
+        bool ok = false;
+        std::uint32_t d[3] = {}, sq = 0, pw = 0, pr[3] = {};
+        int sc = -1, rx[3] = {-1, -1, -1};
+        double ex = 0;
+        // External inputs of the three differences: template ext indices (minuend, subtrahend).
+        std::uint32_t de[3][2] = {};
+    } pp;
+    {
+        const auto npos = static_cast<std::uint32_t>(t0.size());
+        std::map<std::uint32_t, std::uint32_t> pos_of, ext_of;
+        for (std::uint32_t q = 0; q < npos; ++q) {
+            pos_of[t0[q]] = q;
+        }
+        // Template ext numbering exactly as in make_plan() (first encounter, members in order, arguments in order).
+        for (std::uint32_t q = 0; q < npos; ++q) {
+            for (const auto &o : p.nodes[t0[q] - n_eq].args) {
+                if (is_var(o) && pos_of.count(o.idx) == 0u && ext_of.count(o.idx) == 0u) {
+                    const auto e = static_cast<std::uint32_t>(ext_of.size());
+                    ext_of[o.idx] = e;
+                }
+            }
+        }
+        const auto node_at = [&](std::uint32_t q) -> const dc_node & { return p.nodes[t0[q] - n_eq]; };
+        const auto member = [&](const operand &o) { return is_var(o) && pos_of.count(o.idx) != 0u; };
+        int q_pw = -1, n_pw = 0;
+        for (std::uint32_t q = 0; q < npos; ++q) {
+            const auto &n = node_at(q);
+            if (n.kind == func_kind::pow && member(n.args[0]) && n.args[1].type == operand::kind::num
+                && n.args[1].value != .5 && n.args[1].value != 2.) {
+                q_pw = static_cast<int>(q);
+                ++n_pw;
+            }
+        }
+        bool ok = n_pw == 1;
+        std::vector<char> used(npos, 0);
+        if (ok) {
+            pp.pw = static_cast<std::uint32_t>(q_pw);
+            pp.ex = node_at(pp.pw).args[1].value;
+            used[pp.pw] = 1;
+            pp.sq = pos_of.at(node_at(pp.pw).args[0].idx);
+            const auto &ns = node_at(pp.sq);
+            ok = ns.kind == func_kind::sum_sq && ns.args.size() == 3u && used[pp.sq] == 0;
+            used[pp.sq] = 1;
+            for (std::uint32_t c = 0; ok && c < 3u; ++c) {
+                ok = member(ns.args[c]);
+                if (!ok) {
+                    break;
+                }
+                pp.d[c] = pos_of.at(ns.args[c].idx);
+                const auto &nd = node_at(pp.d[c]);
+                ok = used[pp.d[c]] == 0 && nd.kind == func_kind::sub && nd.args.size() == 2u && is_var(nd.args[0])
+                     && is_var(nd.args[1]) && !member(nd.args[0]) && !member(nd.args[1]);
+                if (ok) {
+                    used[pp.d[c]] = 1;
+                    pp.de[c][0] = ext_of.at(nd.args[0].idx);
+                    pp.de[c][1] = ext_of.at(nd.args[1].idx);
+                }
+            }
+        }
+        // Scaling of the pow (G * m_j * r^-3).
+        for (std::uint32_t q = 0; ok && q < npos; ++q) {
+            const auto &n = node_at(q);
+            if (used[q] == 0 && n.kind == func_kind::prod && n.args.size() == 2u && n.args[0].type == operand::kind::num
+                && !(n.args[0].value == -1.) && member(n.args[1]) && pos_of.at(n.args[1].idx) == pp.pw) {
+                if (pp.sc != -1) {
+                    ok = false;
+                }
+                pp.sc = static_cast<int>(q);
+                used[q] = 1;
+            }
+        }
+        const auto q_r = pp.sc >= 0 ? static_cast<std::uint32_t>(pp.sc) : pp.pw;
+        bool have_pr[3] = {false, false, false};
+        for (std::uint32_t q = 0; ok && q < npos; ++q) {
+            const auto &n = node_at(q);
+            if (used[q] != 0 || n.kind != func_kind::prod || n.args.size() != 2u || !member(n.args[0]) || !member(n.args[1])) {
+                continue;
+            }
+            const auto a0 = pos_of.at(n.args[0].idx), a1 = pos_of.at(n.args[1].idx);
+            const auto dq = (a0 == q_r) ? a1 : (a1 == q_r ? a0 : npos);
+            for (std::uint32_t c = 0; c < 3u; ++c) {
+                if (dq == pp.d[c] && !have_pr[c]) {
+                    pp.pr[c] = q;
+                    have_pr[c] = true;
+                    used[q] = 1;
+                }
+            }
+        }
+        ok = ok && have_pr[0] && have_pr[1] && have_pr[2];
+        for (std::uint32_t q = 0; ok && q < npos; ++q) {
+            const auto &n = node_at(q);
+            if (used[q] != 0) {
+                continue;
+            }
+            bool hit = false;
+            if (n.kind == func_kind::prod && n.args.size() == 2u && n.args[0].type == operand::kind::num
+                && !(n.args[0].value == -1.) && member(n.args[1])) {
+                for (std::uint32_t c = 0; c < 3u; ++c) {
+                    if (pos_of.at(n.args[1].idx) == pp.pr[c] && pp.rx[c] == -1) {
+                        pp.rx[c] = static_cast<int>(q);
+                        used[q] = 1;
+                        hit = true;
+                    }
+                }
+            }
+            ok = hit;
+        }
+        // Only the products (and their scalings) may be read from outside.
+        for (const auto q : pl.out_pos) {
+            bool fine = false;
+            for (std::uint32_t c = 0; c < 3u; ++c) {
+                fine = fine || q == pp.pr[c] || (pp.rx[c] >= 0 && q == static_cast<std::uint32_t>(pp.rx[c]));
+            }
+            ok = ok && fine;
+        }
+        ok = ok && ((pp.rx[0] >= 0) == (pp.rx[1] >= 0)) && ((pp.rx[0] >= 0) == (pp.rx[2] >= 0));
+        const char *ev = std::getenv("HEYOKA_AMD_PAIR_SPLIT");
+        pp.ok = ok && 2u * nc <= 64u && p.n_par == 0u && !(ev != nullptr && std::atoi(ev) == 0);
+    }
+    const bool pair_split = pp.ok;
+    if (pair_split) {
+        pl.L = 2;
+        while (pl.L < 2u * nc) {
+            pl.L *= 2u;
+        }
+        pl.spw = 64u / pl.L;
+        // Slab slots of the cluster outputs in lane order: the lanes of a group write consecutive doubles (distinct LDS
+        // banks). d_0 * sa / d_2 * sa alternate (lane = 2 * pair + role), d_1 * sa is written by the A lanes only.
+        std::uint32_t ns = n_eq;
+        std::fill(pl.slot_of.begin() + n_eq, pl.slot_of.end(), -1);
+        const auto number = [&](const auto &member_of_lane, std::uint32_t n_lanes) {
+            for (std::uint32_t l = 0; l < n_lanes; ++l) {
+                pl.slot_of[member_of_lane(l)] = static_cast<int>(ns++);
+            }
+        };
+        number([&](std::uint32_t l) { return pl.clusters[l / 2u][pp.pr[(l & 1u) != 0u ? 2u : 0u]]; }, 2u * nc);
+        number([&](std::uint32_t c) { return pl.clusters[c][pp.pr[1]]; }, nc);
+        if (pp.rx[0] >= 0) {
+            number([&](std::uint32_t l) {
+                return pl.clusters[l / 2u][static_cast<std::uint32_t>(pp.rx[(l & 1u) != 0u ? 2u : 0u])];
+            }, 2u * nc);
+            number([&](std::uint32_t c) { return pl.clusters[c][static_cast<std::uint32_t>(pp.rx[1])]; }, nc);
+        }
+        for (std::uint32_t u = n_eq; u < p.n_u; ++u) {
+            if (pl.cluster_of[u] == -1) {
+                pl.slot_of[u] = static_cast<int>(ns++);
+            }
+        }
+        pl.n_slots = ns;
+    }
+    const auto L = pl.L, spw = pl.spw;
+    // NOTE: HEYOKA_AMD_V2_BS overrides the block size (experiments). Lane pairs: 512 threads = two wavefronts per SIMD.
+    const std::uint32_t bs = std::getenv("HEYOKA_AMD_V2_BS") != nullptr
+                                 ? static_cast<std::uint32_t>(std::atoi(std::getenv("HEYOKA_AMD_V2_BS")))
+                                 : (pair_split ? 512u : 256u);
+    const std::uint32_t wpb = bs / 64u;
     const auto n_ext = static_cast<std::uint32_t>(pl.ext_u[0].size());
     const auto n_out = static_cast<std::uint32_t>(pl.out_pos.size());
     const auto n_cst = static_cast<std::uint32_t>(pl.cst_pos.size());
@@ -142,7 +303,7 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     }
 
     // ---- 2. LDS layout: every slot double-buffered by order parity. ----
-    const std::uint32_t max_round_outputs = std::max<std::uint32_t>(n_out, 1u);
+    const std::uint32_t max_round_outputs = std::max<std::uint32_t>(n_out, 4u);
     const auto dummy_base = pl.n_slots;
     const auto n_slots_tot = pl.n_slots + max_round_outputs;
     const auto buf_stride = n_slots_tot;                 // doubles between the two parity buffers
@@ -175,22 +336,74 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     ssa_emitter e(p, order);
     auto &os = e.os;
 
+    // Lane-pair variant: lane l = 2 * pair + role (role 0 = A: d_0, d_1; role 1 = B: d_2 and the pow); the lanes
+    // beyond the last pair replicate pair 0 and write to dummy slots.
+    struct pair_tables {
+        std::size_t s0 = 0, s1 = 0, p0 = 0, p1 = 0, os = 0, op = 0, rs = 0, rp = 0, csc = 0, crs = 0, crp = 0;
+    } pt;
+    if (pair_split) {
+        const auto slot_or = [&](std::uint32_t u, std::uint32_t dflt) {
+            return pl.slot_of[u] >= 0 ? static_cast<std::uint32_t>(pl.slot_of[u]) : dflt;
+        };
+        std::vector<std::uint32_t> s0(L), s1(L), p0(L), p1(L), os_(L), op(L), rs(L), rp(L);
+        std::vector<double> csc(L, 1.), crs(L, 0.), crp(L, 0.);
+        for (std::uint32_t l = 0; l < L; ++l) {
+            const bool valid = l / 2u < nc;
+            const auto c = valid ? l / 2u : 0u;
+            const bool rb = (l & 1u) != 0u;
+            const auto ds = rb ? 2u : 0u;
+            const auto &cl = pl.clusters[c];
+            const auto ext = [&](std::uint32_t dc, std::uint32_t a) {
+                return static_cast<std::uint32_t>(pl.slot_of[pl.ext_u[c][pp.de[dc][a]]]);
+            };
+            s0[l] = ext(ds, 0);
+            s1[l] = ext(ds, 1);
+            p0[l] = rb ? s0[l] : ext(1, 0);
+            p1[l] = rb ? s0[l] : ext(1, 1);
+            os_[l] = valid ? slot_or(cl[pp.pr[ds]], dummy_base) : dummy_base;
+            op[l] = (valid && !rb) ? slot_or(cl[pp.pr[1]], dummy_base + 1u) : dummy_base + 1u;
+            if (pp.rx[0] >= 0) {
+                rs[l] = valid ? slot_or(cl[static_cast<std::uint32_t>(pp.rx[ds])], dummy_base + 2u) : dummy_base + 2u;
+                rp[l] = (valid && !rb) ? slot_or(cl[static_cast<std::uint32_t>(pp.rx[1])], dummy_base + 3u) : dummy_base + 3u;
+                crs[l] = p.nodes[cl[static_cast<std::uint32_t>(pp.rx[ds])] - n_eq].args[0].value;
+                crp[l] = rb ? 0. : p.nodes[cl[static_cast<std::uint32_t>(pp.rx[1])] - n_eq].args[0].value;
+            }
+            if (pp.sc >= 0) {
+                csc[l] = p.nodes[cl[static_cast<std::uint32_t>(pp.sc)] - n_eq].args[0].value;
+            }
+        }
+        pt.s0 = add_utbl(std::move(s0));
+        pt.s1 = add_utbl(std::move(s1));
+        pt.p0 = add_utbl(std::move(p0));
+        pt.p1 = add_utbl(std::move(p1));
+        pt.os = add_utbl(std::move(os_));
+        pt.op = add_utbl(std::move(op));
+        if (pp.rx[0] >= 0) {
+            pt.rs = add_utbl(std::move(rs));
+            pt.rp = add_utbl(std::move(rp));
+            pt.crs = add_dtbl(std::move(crs));
+            pt.crp = add_dtbl(std::move(crp));
+        }
+        if (pp.sc >= 0) {
+            pt.csc = add_dtbl(std::move(csc));
+        }
+    }
     std::vector<std::size_t> ext_tbl(n_ext), out_tbl(n_out), cst_tbl(n_cst);
-    for (std::uint32_t x = 0; x < n_ext; ++x) {
+    for (std::uint32_t x = 0; !pair_split && x < n_ext; ++x) {
         std::vector<std::uint32_t> v(L);
         for (std::uint32_t l = 0; l < L; ++l) {
             v[l] = static_cast<std::uint32_t>(pl.slot_of[pl.ext_u[l < nc ? l : 0u][x]]);
         }
         ext_tbl[x] = add_utbl(std::move(v));
     }
-    for (std::uint32_t x = 0; x < n_out; ++x) {
+    for (std::uint32_t x = 0; !pair_split && x < n_out; ++x) {
         std::vector<std::uint32_t> v(L);
         for (std::uint32_t l = 0; l < L; ++l) {
             v[l] = l < nc ? static_cast<std::uint32_t>(pl.slot_of[pl.clusters[l][pl.out_pos[x]]]) : dummy_base + x;
         }
         out_tbl[x] = add_utbl(std::move(v));
     }
-    for (std::uint32_t x = 0; x < n_cst; ++x) {
+    for (std::uint32_t x = 0; !pair_split && x < n_cst; ++x) {
         std::vector<double> v(L);
         for (std::uint32_t l = 0; l < L; ++l) {
             v[l] = pl.cst_val[l < nc ? l : 0u][x];
@@ -208,6 +421,7 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         std::uint32_t cbase = 0;  // first jet column of the slot (columns are compressed: one per valid lane)
         std::uint32_t n_valid = 0;
         std::vector<std::string> xname; // SSA names of the coefficients, by order
+        bool slab_needed = true;        // is one of the variables of the slot read through the slab?
     };
     struct glue_round {
         std::vector<std::size_t> arg_tbl;
@@ -280,6 +494,10 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
                 ow.n_valid = gr.n_valid;
                 n_col_acc += gr.n_valid;
                 ow.xname.resize(order + 1u);
+                ow.slab_needed = false;
+                for (std::uint32_t l = 0; l < L && r * L + l < n_nodes; ++l) {
+                    ow.slab_needed = ow.slab_needed || glue_read[att.at(grp.nodes[r * L + l])[a]] != 0;
+                }
                 gr.owners.push_back(std::move(ow));
             }
             rounds[g].push_back(std::move(gr));
@@ -300,9 +518,24 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     // block's slab + jets fit in the 160 KB of a CU (the kernel occupies a whole CU anyway: 512 registers
     // per lane), otherwise in a per-wave global scratch.
     const auto jet_doubles_per_wave = static_cast<std::uint64_t>(order + 1u) * spw * n_colp;
-    const auto lds_doubles_slab = static_cast<std::uint64_t>(wpb) * spw * ((2u * (pl.n_slots + std::max<std::uint32_t>(n_out, 1u))) | 1u);
+    const auto lds_doubles_slab = static_cast<std::uint64_t>(wpb) * spw * ((2u * (pl.n_slots + std::max<std::uint32_t>(n_out, 4u))) | 1u);
     const bool jet_lds = (lds_doubles_slab + wpb * jet_doubles_per_wave) * 8u <= 160u * 1024u
                          && std::getenv("HEYOKA_AMD_JET_GLOBAL") == nullptr;
+
+    // Merged schedule (lane-pair variant, one glue level after the clusters): round k = cluster(k) + glue(k-1),
+    // one LDS synchronisation per order instead of two.
+    const bool merged = [&]() {
+        if (!pair_split || pl.cluster_level != 1u || pl.max_level != 2u) {
+            return false;
+        }
+        for (const auto &g : pl.groups) {
+            if (g.level != 2u) {
+                return false;
+            }
+        }
+        const char *ev = std::getenv("HEYOKA_AMD_V3_MERGED");
+        return !(ev != nullptr && std::atoi(ev) == 0);
+    }();
 
     // ---- 4. Emission helpers. ----
     const auto slabk = [&](std::uint32_t k, const std::string &tbl) {
@@ -317,7 +550,9 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     // Owner-slot bookkeeping when a new coefficient of a state variable is produced.
     const auto publish_sv = [&](owner_slot &ow, std::uint32_t k, const std::string &name) {
         ow.xname[k] = name;
-        os << slabk(k, utname(ow.out_tbl)) << " = " << name << ";\n";
+        if (ow.slab_needed) {
+            os << slabk(k, utname(ow.out_tbl)) << " = " << name << ";\n";
+        }
         if (k != 0u) {
             // (The order-0 row of the jets *is* the current state: written by the update of the previous step.)
             os << jet_at(k, ow.col) << " = " << name << ";\n";
@@ -373,11 +608,18 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         }
         e.numpar_override = saved;
 
-        // Fused state-variable recursion: x^[k+1] = src^[k] / (k + 1).
+        // Fused state-variable recursion: x^[k+1] = src^[k] / (k + 1). In the merged schedule the a-th variable of
+        // the chain runs a orders ahead (x^[k+1+a] from the coefficient of order k + a of its predecessor, which
+        // the same lane has just produced): a position is then known one exchange earlier than the acceleration
+        // of the same order, which is what lets cluster(k+1) and glue(k) share one round.
         for (std::size_t a = 0; a < gr.owners.size(); ++a) {
-            const auto src = (a == 0u) ? gval : gr.owners[a - 1u].xname[k];
-            const auto x = e.div_const(src, k + 1u);
-            publish_sv(gr.owners[a], k + 1u, x);
+            const auto ord = k + 1u + (merged ? static_cast<std::uint32_t>(a) : 0u);
+            if (ord > order) {
+                continue;
+            }
+            const auto src = (a == 0u) ? gval : gr.owners[a - 1u].xname[ord - 1u];
+            const auto x = e.div_const(src, ord);
+            publish_sv(gr.owners[a], ord, x);
         }
     };
     const auto emit_glue_round = [&](std::size_t g, std::uint32_t r, std::uint32_t k) {
@@ -425,7 +667,126 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     const auto sched_fence = [&]() { os << "__builtin_amdgcn_sched_barrier(0);\n"; };
     using psel = ssa_emitter::part_sel;
 
+    // ---- Lane-pair cluster program ----
+    // Coefficient histories of a lane (SSA names by order), role A | role B:
+    //   aS: d_0 | d_2          aP: d_1 | b = sum of squares          aR: sa = (scaled) pow, both lanes
+    //   aRp: d_1 (a copy) | j * sa_j
+    // Convolution chains of order k (same FMA stream on both lanes), history part = indices 1 .. k-1:
+    //   c1 = sum aP[k-j] aR[j]   (A: d_1 * sa,  B: S1 = sum b[k-j] sa[j] of the pow recurrence)
+    //   c2 = sum aP[k-j] aRp[j]  (A: the order-k coefficient of d_1^2, B: S2 = sum b[k-j] j sa[j])
+    //   c3 = sum aS[k-j] aR[j]   (d_0 * sa | d_2 * sa)
+    //   c4 = sum_{j <= jmax} aS[k-j] aS[j] (+ the middle square): d_0^2 | d_2^2
+    // The pow recurrence (src/math/pow.cpp:517-549) k b_0 a_k = sum_{j<k} (k alpha - j (alpha + 1)) b_{k-j} a_j is linear
+    // in a: it is run directly on sa = c a, as alpha k S1 - (alpha + 1) S2.
+    // Per order the two lanes exchange (DPP quad_perm [1,0,3,2], no LDS): the partial sums of squares, then sa_k.
+    std::vector<std::string> aP(order + 1u), aR(order + 1u), aRp(order + 1u), aS(order + 1u);
+    std::string hc1, hc2, hc3, hc4, hmid;
+    const bool has_rx = pp.rx[0] >= 0;
+    std::string rb1; // 1 / b_0 (lane B)
+    const auto emit_pair_reads = [&](std::uint32_t k) {
+        const auto rd = [&](std::size_t t) { return e.def(slabk(k, utname(t))); };
+        return std::vector<std::string>{rd(pt.s0), rd(pt.s1), rd(pt.p0), rd(pt.p1)};
+    };
+    const auto emit_pair_compute = [&](std::uint32_t k, const std::vector<std::string> &rdv) {
+        using emit_detail::ssa_emitter;
+        const auto &es0 = rdv[0], &es1 = rdv[1], &ep0 = rdv[2], &ep1 = rdv[3];
+        aS[k] = e.def(es0 + " - " + es1);
+        const auto dP = e.def(ep0 + " - " + ep1);
+        std::string sqS, sqy;
+        if (k == 0u) {
+            sqS = e.def(ssa_emitter::mul(aS[0], aS[0]));
+            sqy = e.def(ssa_emitter::mul(dP, dP));
+        } else {
+            const auto acc4 = e.chain(hc4, aS[k], aS[0]);
+            const auto dbl = e.def(acc4 + " + " + acc4);
+            sqS = (k % 2u == 0u) ? e.def(dbl + " + " + hmid) : dbl;
+            const auto dP2 = e.def(dP + " + " + dP);
+            sqy = e.chain(hc2, dP2, aP[0]);
+        }
+        // NOTE: role-dependent values are formed arithmetically with the lane constants fA / fB (1.0 on the lanes of
+        // the role, 0.0 on the others) instead of selects (two v_cndmask per double): lane B reads the same slot twice
+        // for the second difference, so that its dP is an exact zero.
+        const auto mine = e.def("__builtin_fma(fA, " + sqy + ", " + sqS + ")");
+        const auto oth = e.def("hy_swap1(" + mine + ")");
+        const auto r2 = e.def(mine + " + " + oth);
+        aP[k] = e.def("__builtin_fma(fB, " + r2 + ", " + dP + ")");
+        std::string c1a;
+        if (k == 0u) {
+            // NOTE: the sum of squares is the same on both lanes: each of them evaluates the pow itself.
+            const auto a0 = e.pow_eval(r2, pp.ex);
+            aR[0] = pp.sc >= 0 ? e.def(ssa_emitter::mul(dtname(pt.csc), a0)) : a0;
+            // (Zero on lane A: its quotient below is then an exact zero and sa_k = own + partner's.)
+            rb1 = e.def("isB ? (1.0 / " + aP[0] + ") : 0.0");
+        } else {
+            c1a = e.chain(hc1, aP[k], aR[0]);
+            std::string num;
+            if (hc2.empty()) {
+                num = e.def(ssa_emitter::mul(fp_literal(pp.ex * static_cast<double>(k)), c1a));
+            } else {
+                const auto t = e.def(ssa_emitter::mul(fp_literal(-(pp.ex + 1.)), hc2));
+                num = e.def(fp_literal(pp.ex * static_cast<double>(k)) + " * " + c1a + " + " + t);
+            }
+            // Division by k * b_0 (src/math/pow.cpp:546-549) without a division sequence on the critical path:
+            // q0 = num * r, r = RN(1 / b_0) * RN(1 / k); residual rem = num - dv * q0 (exact, FMA); q = q0 + rem * r
+            // (Markstein: the correctly-rounded quotient unless r is off by more than an ulp in a halfway case).
+            const auto dv = e.def(ssa_emitter::mul(fp_literal(static_cast<double>(k)), aP[0]));
+            const auto rk = (k == 1u) ? rb1 : e.def(ssa_emitter::mul(rb1, fp_literal(1. / static_cast<double>(k))));
+            const auto q0 = e.def(ssa_emitter::mul(num, rk));
+            const auto rem = e.def("__builtin_fma(-" + dv + ", " + q0 + ", " + num + ")");
+            const auto sab = e.def("__builtin_fma(" + rem + ", " + rk + ", " + q0 + ")");
+            const auto sao = e.def("hy_swap1(" + sab + ")");
+            aR[k] = e.def(sab + " + " + sao);
+        }
+        if (k >= 1u && k + 2u <= order) {
+            const auto t = e.def(ssa_emitter::mul("fB", aR[k]));
+            aRp[k] = e.def("__builtin_fma(" + fp_literal(static_cast<double>(k)) + ", " + t + ", " + dP + ")");
+        }
+        std::string prS, prP;
+        if (k == 0u) {
+            prS = e.def(ssa_emitter::mul(aS[0], aR[0]));
+            prP = e.def(ssa_emitter::mul(aP[0], aR[0]));
+        } else {
+            prS = e.chain(e.chain(hc3, aS[k], aR[0]), aS[0], aR[k]);
+            prP = e.chain(c1a, aP[0], aR[k]);
+        }
+        os << slabk(k, utname(pt.os)) << " = " << prS << ";\n";
+        os << slabk(k, utname(pt.op)) << " = " << prP << ";\n";
+        if (has_rx) {
+            const auto rS = e.def(ssa_emitter::mul(dtname(pt.crs), prS));
+            const auto rP = e.def(ssa_emitter::mul(dtname(pt.crp), prP));
+            os << slabk(k, utname(pt.rs)) << " = " << rS << ";\n";
+            os << slabk(k, utname(pt.rp)) << " = " << rP << ";\n";
+        }
+        // History parts of order K = k + 1 (indices 1 .. k), the four chains interleaved term by term.
+        hc1.clear();
+        hc2.clear();
+        hc3.clear();
+        hc4.clear();
+        hmid.clear();
+        const auto K = k + 1u;
+        if (K < order && K >= 2u) {
+            const auto jmax = (K % 2u == 1u) ? (K - 1u) / 2u : (K - 2u) / 2u;
+            for (std::uint32_t j = 1; j < K; ++j) {
+                hc1 = e.chain(hc1, aP[K - j], aR[j]);
+                hc2 = e.chain(hc2, aP[K - j], aRp[j]);
+                hc3 = e.chain(hc3, aS[K - j], aR[j]);
+                if (j <= jmax) {
+                    hc4 = e.chain(hc4, aS[K - j], aS[j]);
+                }
+            }
+            if (K % 2u == 0u) {
+                hmid = e.def(ssa_emitter::mul(aS[K / 2u], aS[K / 2u]));
+            }
+        }
+    };
+
+    const auto emit_pair_order = [&](std::uint32_t k) { emit_pair_compute(k, emit_pair_reads(k)); };
+
     const auto emit_cluster = [&](std::uint32_t k) {
+        if (pair_split) {
+            emit_pair_order(k);
+            return;
+        }
         for (std::uint32_t part = 1; part < n_parts; ++part) {
             e.emit_partials(t0_ids, k, part, n_parts);
         }
@@ -457,8 +818,41 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
             }
         }
     }
+    if (merged) {
+        // Orders 1 .. a of the a-th variable of a chain follow from the state alone.
+        for (auto &rg : rounds) {
+            for (auto &gr : rg) {
+                for (std::size_t a = 1; a < gr.owners.size(); ++a) {
+                    for (std::uint32_t j = 1; j <= a && j <= order; ++j) {
+                        publish_sv(gr.owners[a], j, e.div_const(gr.owners[a - 1u].xname[j - 1u], j));
+                    }
+                }
+            }
+        }
+    }
     sync();
-    for (std::uint32_t k = 0; k < order; ++k) {
+    for (std::uint32_t k = 0; merged && k <= order; ++k) {
+        std::vector<std::string> prd;
+        if (k < order) {
+            prd = emit_pair_reads(k);
+        }
+        std::vector<std::tuple<std::size_t, std::uint32_t, std::vector<std::string>>> pend;
+        if (k >= 1u) {
+            for (std::size_t g = 0; g < pl.groups.size(); ++g) {
+                for (std::uint32_t r = 0; r < rounds[g].size(); ++r) {
+                    pend.emplace_back(g, r, emit_glue_reads(g, r, k - 1u));
+                }
+            }
+        }
+        if (k < order) {
+            emit_pair_compute(k, prd);
+        }
+        for (const auto &[g, r, names] : pend) {
+            emit_glue_compute(g, r, k - 1u, names);
+        }
+        sync();
+    }
+    for (std::uint32_t k = 0; !merged && k < order; ++k) {
         for (std::uint32_t lev = 1; lev <= pl.max_level; ++lev) {
             if (lev == pl.cluster_level) {
                 emit_cluster(k);
@@ -474,11 +868,13 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
                         }
                     }
                 }
-                sched_fence();
-                e.emit_partials_sel(t0_ids, k + 1u, psel::late);
-                e.emit_partials_sel(t0_ids, k + 2u, psel::early_a);
-                if (fence2) {
+                if (!pair_split) {
                     sched_fence();
+                    e.emit_partials_sel(t0_ids, k + 1u, psel::late);
+                    e.emit_partials_sel(t0_ids, k + 2u, psel::early_a);
+                    if (fence2) {
+                        sched_fence();
+                    }
                 }
                 for (const auto &[g, r, names] : pend) {
                     emit_glue_compute(g, r, k, names);
@@ -491,7 +887,7 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
                         }
                     }
                 }
-                if (!overlap && last && k + 1u < order) {
+                if (!pair_split && !overlap && last && k + 1u < order) {
                     // History part of the next order's convolutions: overlaps the exchange latency.
                     e.emit_partials(t0_ids, k + 1u, 0, n_parts);
                 }
@@ -515,6 +911,18 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     src << prelude;
     emit_detail::emit_dout(src, p, opts);
     src << emit_detail::wsync_macro;
+    if (pair_split) {
+        // Exchange between the two lanes of a pair: DPP quad_perm [1,0,3,2] on the two halves of the double.
+        src << R"HIP(
+__device__ __forceinline__ double hy_swap1(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+)HIP";
+    }
     src << "__constant__ unsigned short hy_utbl[" << std::max<std::size_t>(utbl.size(), 1u) * L << "] = {";
     for (const auto &v : utbl) {
         for (const auto x : v) {
@@ -538,6 +946,9 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     src << "const unsigned lane = threadIdx.x & 63u;\nconst unsigned wib = threadIdx.x >> 6;\n";
     src << "const unsigned l = lane % " << L << "u;\nconst unsigned q = lane / " << L << "u;\n";
     src << "const u64 N = a.N;\n";
+    if (pair_split) {
+        src << "const bool isB = (lane & 1u) != 0u;\nconst double fB = isB ? 1.0 : 0.0, fA = isB ? 0.0 : 1.0;\n";
+    }
     src << "double *const slab = lds_slab + (wib * " << spw << "u + q) * " << slab_stride << "u;\n";
     src << "const u64 gwave = (u64)blockIdx.x * " << wpb << "u + wib;\n";
     if (jet_lds) {
@@ -791,7 +1202,8 @@ if (l == 0u && live) {
     ret.scratch_per_wave = jet_lds ? 0u : jet_doubles_per_wave;
     ret.persistent = true;
     ret.tc_optional = true;
-    ret.notes = "cluster mode v2 (pipelined): " + std::to_string(nc) + " clusters of " + std::to_string(t0.size())
+    ret.notes = std::string(pair_split ? "cluster mode v3 (lane pairs, 2 wavefronts per SIMD): " : "cluster mode v2 (pipelined): ")
+                + std::to_string(nc) + " clusters of " + std::to_string(t0.size())
                 + " nodes, L=" + std::to_string(L) + ", " + std::to_string(pl.n_slots) + " LDS slots x2, "
                 + std::to_string(n_own) + " state-variable owner slots, " + std::to_string(utbl.size())
                 + " slot tables, jets in " + (jet_lds ? "LDS" : "global scratch");
