@@ -83,3 +83,46 @@ def scan_disassembly(text):
 
 def scan_code_object(code_object):
     return scan_disassembly(disassemble(code_object))
+
+
+def kernel_resources(code_object, kernel="hy_taylor"):
+    """Register / LDS / scratch usage of a kernel from the metadata notes of its code object (llvm-readelf --notes):
+    {"vgpr", "agpr", "sgpr", "vgpr_spill", "sgpr_spill", "scratch_bytes_per_lane", "lds_bytes", "waves_per_simd"}.
+    The register file of a gfx950 SIMD holds 512 registers per lane (VGPR + AGPR, allocation granule 8)."""
+    objdump = find_objdump()
+    if objdump is None:
+        return None
+    readelf = os.path.join(os.path.dirname(objdump), "llvm-readelf")
+    if not os.path.exists(readelf):
+        return None
+    with tempfile.NamedTemporaryFile(suffix=".co") as f:
+        f.write(code_object)
+        f.flush()
+        text = subprocess.run([readelf, "--notes", f.name], check=True, capture_output=True, text=True).stdout
+    # One YAML-ish block per kernel, fields sorted alphabetically; .name sits in the middle of its block.
+    blocks = re.split(r"\n\s+- \.agpr_count:", "\n" + text)
+    for b in blocks[1:]:
+        b = ".agpr_count:" + b
+        m = re.search(r"\.name:\s+(\S+)", b)
+        if not m or m.group(1) != kernel:
+            continue
+
+        def field(name):
+            mm = re.search(r"\." + name + r":\s+(\d+)", b)
+            return int(mm.group(1)) if mm else None
+
+        vg, ag = field("vgpr_count"), field("agpr_count")
+        # NOTE: on gfx90a+ .vgpr_count is the unified total (ArchVGPR + AGPR).
+        alloc = ((vg + 7) // 8) * 8 if vg else None
+        return {
+            "vgpr_total": vg,
+            "agpr": ag,
+            "arch_vgpr": (vg - ag) if (vg is not None and ag is not None) else None,
+            "sgpr": field("sgpr_count"),
+            "vgpr_spill": field("vgpr_spill_count"),
+            "sgpr_spill": field("sgpr_spill_count"),
+            "scratch_bytes_per_lane": field("private_segment_fixed_size"),
+            "lds_bytes": field("group_segment_fixed_size"),
+            "waves_per_simd_by_registers": min(8, 512 // alloc) if alloc else None,
+        }
+    return None

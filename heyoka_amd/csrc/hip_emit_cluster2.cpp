@@ -169,7 +169,10 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         }
         ok = ok && ((pp.rx[0] >= 0) == (pp.rx[1] >= 0)) && ((pp.rx[0] >= 0) == (pp.rx[2] >= 0));
         const char *ev = std::getenv("HEYOKA_AMD_PAIR_SPLIT");
-        pp.ok = ok && 2u * nc <= 64u && p.n_par == 0u && !(ev != nullptr && std::atoi(ev) == 0);
+        // NOTE: at most 16 pairs (two systems per wavefront). With 17 .. 32 pairs (one system per wavefront, e.g.
+        // model::np1body(8)) the generated kernel did not terminate on the hardware (round 2, not yet understood):
+        // those systems stay on the one-lane-per-cluster kernel.
+        pp.ok = ok && 2u * nc <= 32u && p.n_par == 0u && !(ev != nullptr && std::atoi(ev) == 0);
     }
     const bool pair_split = pp.ok;
     if (pair_split) {
@@ -670,7 +673,7 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     // ---- Lane-pair cluster program ----
     // Coefficient histories of a lane (SSA names by order), role A | role B:
     //   aS: d_0 | d_2          aP: d_1 | b = sum of squares          aR: sa = (scaled) pow, both lanes
-    //   aRp: d_1 (a copy) | j * sa_j
+    //   aRp: d_1 (a copy) | -(alpha + 1) j sa_j
     // Convolution chains of order k (same FMA stream on both lanes), history part = indices 1 .. k-1:
     //   c1 = sum aP[k-j] aR[j]   (A: d_1 * sa,  B: S1 = sum b[k-j] sa[j] of the pow recurrence)
     //   c2 = sum aP[k-j] aRp[j]  (A: the order-k coefficient of d_1^2, B: S2 = sum b[k-j] j sa[j])
@@ -682,7 +685,8 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     std::vector<std::string> aP(order + 1u), aR(order + 1u), aRp(order + 1u), aS(order + 1u);
     std::string hc1, hc2, hc3, hc4, hmid;
     const bool has_rx = pp.rx[0] >= 0;
-    std::string rb1; // 1 / b_0 (lane B)
+    std::string rb1;   // 1 / b_0 (lane B)
+    std::string ap0x2; // 2 aP[0]
     const auto emit_pair_reads = [&](std::uint32_t k) {
         const auto rd = [&](std::size_t t) { return e.def(slabk(k, utname(t))); };
         return std::vector<std::string>{rd(pt.s0), rd(pt.s1), rd(pt.p0), rd(pt.p1)};
@@ -698,10 +702,9 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
             sqy = e.def(ssa_emitter::mul(dP, dP));
         } else {
             const auto acc4 = e.chain(hc4, aS[k], aS[0]);
-            const auto dbl = e.def(acc4 + " + " + acc4);
-            sqS = (k % 2u == 0u) ? e.def(dbl + " + " + hmid) : dbl;
-            const auto dP2 = e.def(dP + " + " + dP);
-            sqy = e.chain(hc2, dP2, aP[0]);
+            sqS = (k % 2u == 0u) ? e.def("__builtin_fma(2.0, " + acc4 + ", " + hmid + ")") : e.def(acc4 + " + " + acc4);
+            // (A: 2 d_1[k] d_1[0] on top of the symmetric history sum; ap0x2 = 2 aP[0].)
+            sqy = e.chain(hc2, dP, ap0x2);
         }
         // NOTE: role-dependent values are formed arithmetically with the lane constants fA / fB (1.0 on the lanes of
         // the role, 0.0 on the others) instead of selects (two v_cndmask per double): lane B reads the same slot twice
@@ -717,14 +720,15 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
             aR[0] = pp.sc >= 0 ? e.def(ssa_emitter::mul(dtname(pt.csc), a0)) : a0;
             // (Zero on lane A: its quotient below is then an exact zero and sa_k = own + partner's.)
             rb1 = e.def("isB ? (1.0 / " + aP[0] + ") : 0.0");
+            ap0x2 = e.def(aP[0] + " + " + aP[0]);
         } else {
             c1a = e.chain(hc1, aP[k], aR[0]);
+            // NOTE: lane B keeps -(alpha + 1) j sa_j in aRp, so that its c2 chain is -(alpha + 1) S2 right away.
             std::string num;
             if (hc2.empty()) {
                 num = e.def(ssa_emitter::mul(fp_literal(pp.ex * static_cast<double>(k)), c1a));
             } else {
-                const auto t = e.def(ssa_emitter::mul(fp_literal(-(pp.ex + 1.)), hc2));
-                num = e.def(fp_literal(pp.ex * static_cast<double>(k)) + " * " + c1a + " + " + t);
+                num = e.def(fp_literal(pp.ex * static_cast<double>(k)) + " * " + c1a + " + " + hc2);
             }
             // Division by k * b_0 (src/math/pow.cpp:546-549) without a division sequence on the critical path:
             // q0 = num * r, r = RN(1 / b_0) * RN(1 / k); residual rem = num - dv * q0 (exact, FMA); q = q0 + rem * r
@@ -739,7 +743,7 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         }
         if (k >= 1u && k + 2u <= order) {
             const auto t = e.def(ssa_emitter::mul("fB", aR[k]));
-            aRp[k] = e.def("__builtin_fma(" + fp_literal(static_cast<double>(k)) + ", " + t + ", " + dP + ")");
+            aRp[k] = e.def("__builtin_fma(" + fp_literal(-(pp.ex + 1.) * static_cast<double>(k)) + ", " + t + ", " + dP + ")");
         }
         std::string prS, prP;
         if (k == 0u) {
@@ -988,7 +992,9 @@ for (;;) {
 // Pull the next group of systems from the device-side work queue.
 u64 base = 0;
 if (lane == 0u) base = atomicAdd((u64 *)(a.counters + 2), (u64)SPW);
-base = __shfl(base, 0, 64);
+// NOTE: through readfirstlane the queue position is a scalar for the compiler and the exit of the work loop a
+// wave-uniform branch (a shuffle leaves it "divergent": exec-mask bookkeeping around the whole step loop).
+base = ((u64)__builtin_amdgcn_readfirstlane((unsigned)(base >> 32)) << 32) | (u64)__builtin_amdgcn_readfirstlane((unsigned)base);
 if (base >= N) break;
 // NOTE: lanes beyond the end of the ensemble replicate the last system (no side effects).
 const bool live = (base + q) < N;
