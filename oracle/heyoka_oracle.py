@@ -883,16 +883,35 @@ def _operand(e):
     raise ValueError("invalid operand in decomposition: %r" % (e,))
 
 
+def cpu_tag():
+    """Fingerprint of the host CPU's instruction-set flags: libraries built with -march=native on one machine are
+    rebuilt on a different one (the repository snapshot, built files included, travels to the GPU box)."""
+    import hashlib
+
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    return hashlib.sha256(" ".join(sorted(line.split(":", 1)[1].split())).encode()).hexdigest()[:12]
+    except OSError:
+        pass
+    return "unknown"
+
+
 def build_oracle_lib(force=False):
     """Compile oracle/taylor_oracle.c into oracle/_build/libtaylor_oracle.so (strict IEEE)."""
     out_dir = os.path.join(_HERE, "_build")
     so = os.path.join(out_dir, "libtaylor_oracle.so")
+    stamp = so + ".cpu"
     src = os.path.join(_HERE, "taylor_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    same_cpu = os.path.exists(stamp) and open(stamp).read().strip() == cpu_tag()
+    if force or not same_cpu or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
         os.makedirs(out_dir, exist_ok=True)
         subprocess.check_call(
             ["gcc", "-O2", "-march=native", "-ffp-contract=off", "-fopenmp", "-shared", "-fPIC", "-o", so, src, "-lm"]
         )
+        with open(stamp, "w") as f:
+            f.write(cpu_tag())
     return so
 
 

@@ -871,6 +871,21 @@ static double rhofac(int order)
  * reference, default mode). h_inout: in = signed max step, out = step taken.
  * tc (nullable): tc[(var * (order + 1) + k) * B + lane].
  */
+/* Optional compiled replacement of the interpreter for the computation of the jet (oracle/compiled_baseline.py): a
+ * generated, fully unrolled, vectorised function which fills the tape of one batch of hook_B systems with exactly
+ * the operations of node_diff() / sv_diff(). Process-wide; used by the CPU baseline of bench.py and checked against
+ * the interpreter bit by bit in tests/test_oracle_golden.py. */
+typedef void (*hy_jet_hook_t)(const double *state, const double *pars, const double *time, double *tape);
+static hy_jet_hook_t g_jet_hook = NULL;
+static int g_hook_B = 0, g_hook_nu = 0, g_hook_order = 0;
+void hy_oracle_set_jet_hook(hy_jet_hook_t f, int B, int n_u, int order)
+{
+    g_jet_hook = f;
+    g_hook_B = B;
+    g_hook_nu = n_u;
+    g_hook_order = order;
+}
+
 static void step_core(const hy_oracle_program *p, int B, double *state, const double *pars, const double *time,
                       double *h_inout, double *tc, double *scratch_mem, int with_events, const int32_t *ev_u, int n_ev,
                       double *ev_tc, double *max_abs_state)
@@ -881,17 +896,21 @@ static void step_core(const hy_oracle_program *p, int B, double *state, const do
     const size_t tape_rows = with_events ? (size_t)n_u * (size_t)(order + 1) : ((size_t)n_u * (size_t)order + (size_t)n_eq);
     double *scratch = tape + tape_rows * (size_t)B;
 
-    for (int i = 0; i < n_eq; ++i) {
-        memcpy(TAPE(0, i), state + (size_t)i * B, sizeof(double) * (size_t)B);
-    }
-    for (int i = 0; i < p->n_nodes; ++i) node_diff(p, i, 0, tape, pars, time, B, scratch);
-    for (int k = 1; k < order; ++k) {
-        sv_diff(p, k, tape, pars, B);
-        for (int i = 0; i < p->n_nodes; ++i) node_diff(p, i, k, tape, pars, time, B, scratch);
-    }
-    sv_diff(p, order, tape, pars, B);
-    if (with_events) {
-        for (int i = 0; i < p->n_nodes; ++i) node_diff(p, i, order, tape, pars, time, B, scratch);
+    if (g_jet_hook != NULL && !with_events && B == g_hook_B && n_u == g_hook_nu && order == g_hook_order) {
+        g_jet_hook(state, pars, time, tape);
+    } else {
+        for (int i = 0; i < n_eq; ++i) {
+            memcpy(TAPE(0, i), state + (size_t)i * B, sizeof(double) * (size_t)B);
+        }
+        for (int i = 0; i < p->n_nodes; ++i) node_diff(p, i, 0, tape, pars, time, B, scratch);
+        for (int k = 1; k < order; ++k) {
+            sv_diff(p, k, tape, pars, B);
+            for (int i = 0; i < p->n_nodes; ++i) node_diff(p, i, k, tape, pars, time, B, scratch);
+        }
+        sv_diff(p, order, tape, pars, B);
+        if (with_events) {
+            for (int i = 0; i < p->n_nodes; ++i) node_diff(p, i, order, tape, pars, time, B, scratch);
+        }
     }
 
     /* Step size: pairwise max reduction over the variables (default mode). */

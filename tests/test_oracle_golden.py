@@ -244,3 +244,39 @@ def test_kepE_stark_problem_known_answer(golden):
     l_exp = fE - np.sqrt(1 - fG * fG / (fL * fL)) * np.sin(fE)
     assert abs(np.sin(s[3]) - np.sin(l_exp)) <= g["tol_eps_angle_l"] * EPS * abs(np.sin(l_exp))
     assert abs(np.cos(s[3]) - np.cos(l_exp)) <= g["tol_eps_angle_l"] * EPS * abs(np.cos(l_exp))
+
+
+@pytest.mark.parametrize("which", ["outer_ss", "two_body"])
+def test_compiled_cpu_baseline_is_bit_identical_to_the_interpreter(which):
+    """The CPU baseline timed by bench.py (oracle/compiled_baseline.py: straight-line, 8-wide vectorised C generated from
+    the oracle's decomposition, the stand-in for the reference's default-mode SIMD JIT, src/taylor_02.cpp:1339-1418) built
+    strictly (-ffp-contract=off) reproduces the interpreter bit by bit: steps with Taylor coefficients and a propagation;
+    the fast build (-O3, contraction on, like the reference's LLVM builder flags) stays within 1e3 eps of it."""
+    import compiled_baseline as cb
+    from heyoka_amd import configs
+
+    if which == "outer_ss":
+        sysd = ho.nbody(6, masses=configs.OUTER_SS_MASSES, Gconst=configs.OUTER_SS_G)
+        st, ha, T = configs.outer_ss_state(8, perturb=1e-6, seed=1), True, 30.0
+    else:
+        sysd = ho.nbody(2, masses=[1.0, 0.0])
+        st, ha, T = configs.two_body_state(8, perturb=1e-3, seed=2), False, 20.0
+    a = ho.OracleIntegrator(sysd, st, 8, high_accuracy=ha)
+    b = ho.OracleIntegrator(sysd, st, 8, high_accuracy=ha)
+    c = ho.OracleIntegrator(sysd, st, 8, high_accuracy=ha)
+    for _ in range(3):
+        a.step(wtc=True)
+    a.propagate_until(T)
+    try:
+        cb.install(b, fast=False)
+        for _ in range(3):
+            b.step(wtc=True)
+        b.propagate_until(T)
+        cb.install(c, fast=True)
+        c.propagate_until(T)
+    finally:
+        cb.uninstall()
+    assert np.array_equal(a.tc, b.tc) and np.array_equal(a.state, b.state)
+    assert [r[3] for r in a.prop_res] == [r[3] for r in b.prop_res]
+    eps = np.finfo(float).eps
+    assert np.max(np.abs(c.state - a.state) / np.maximum(1.0, np.abs(a.state))) <= 1e3 * eps
