@@ -242,6 +242,11 @@ def main():
             gathered = hens.all_gather_states(view)
             torch.cuda.synchronize()
             gather_ms = (time.perf_counter() - tg) * 1e3
+            # Every rank must hold the final state of all the N x systems ICs, its own shard in place.
+            if tuple(gathered.shape) != (view.shape[0], world * n):
+                raise RuntimeError("gathered shape %s, expected %s" % (tuple(gathered.shape), (view.shape[0], world * n)))
+            if not torch.equal(gathered[:, rank * n:(rank + 1) * n], view):
+                raise RuntimeError("the gathered state does not contain this rank's shard at its place")
         except Exception as e:  # the optional collective must never cost the measurement
             gather_err = "%s: %s" % (type(e).__name__, e)
 
@@ -322,6 +327,8 @@ def main():
                 "hiprtc_compile_s": ta.compile_seconds,
                 "kernel_sha256": kernel_sha(ta),
                 "untimed_final_state_all_gather_ms": gather_ms,
+                "gathered_systems": (int(gathered.shape[1]) if gathered is not None else None),
+                "gathered_bytes_per_rank": (int(gathered.numel()) * 8 if gathered is not None else None),
                 "untimed_final_state_all_gather_error": gather_err,
             },
             "roofline": {

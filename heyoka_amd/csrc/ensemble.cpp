@@ -1,6 +1,10 @@
 // Ensemble driver. See ensemble.hpp.
 #include "ensemble.hpp"
 
+#include <exception>
+#include <optional>
+#include <thread>
+
 #include "hip_backend.hpp"
 
 namespace heyoka_amd::detail
@@ -28,25 +32,55 @@ std::vector<tab_core> ensemble_propagate_core(const tab_core &ta, double t, std:
         throw std::runtime_error("heyoka_amd: no HIP device is available for ensemble propagation");
     }
 
-    std::vector<tab_core> ret;
-    ret.reserve(n_iter);
-    for (std::size_t i = 0; i < n_iter; ++i) {
-        ret.emplace_back(ta);
-        gen(ret.back(), i);
-        ret.back().set_device(static_cast<int>(i % static_cast<std::size_t>(n_devices)));
-    }
-
-    // Asynchronous launches: one device-resident propagation per iteration.
+    // One host thread per device (the reference runs the iterations inside a TBB parallel_for,
+    // src/ensemble_propagate.cpp:203-219, and documents that the generator is invoked concurrently): thread d copies
+    // the template integrator, runs the generator, uploads and launches the device-resident propagation of the
+    // iterations i = d, d + n_devices, ... on device d, so that neither the generator nor the uploads of one device
+    // wait for another device. Results keep the iteration order.
+    std::vector<std::optional<tab_core>> slots(n_iter);
+    std::vector<std::exception_ptr> errors(static_cast<std::size_t>(n_devices));
     const std::vector<double> ts{t};
-    for (auto &c : ret) {
-        if (kind == ensemble_kind::until) {
-            c.propagate_until(ts, max_steps, {}, {}, false, false);
-        } else {
-            c.propagate_for(ts, max_steps, {}, {}, false, false);
+    const auto worker = [&](int dev) {
+        try {
+            for (std::size_t i = static_cast<std::size_t>(dev); i < n_iter; i += static_cast<std::size_t>(n_devices)) {
+                slots[i].emplace(ta);
+                gen(*slots[i], i);
+                slots[i]->set_device(dev);
+                // Asynchronous launch: one device-resident propagation per iteration.
+                if (kind == ensemble_kind::until) {
+                    slots[i]->propagate_until(ts, max_steps, {}, {}, false, false);
+                } else {
+                    slots[i]->propagate_for(ts, max_steps, {}, {}, false, false);
+                }
+            }
+            for (std::size_t i = static_cast<std::size_t>(dev); i < n_iter; i += static_cast<std::size_t>(n_devices)) {
+                slots[i]->synchronize();
+            }
+        } catch (...) {
+            errors[static_cast<std::size_t>(dev)] = std::current_exception();
+        }
+    };
+    if (n_devices == 1) {
+        worker(0);
+    } else {
+        std::vector<std::thread> threads;
+        threads.reserve(static_cast<std::size_t>(n_devices));
+        for (int d = 0; d < n_devices; ++d) {
+            threads.emplace_back(worker, d);
+        }
+        for (auto &th : threads) {
+            th.join();
         }
     }
-    for (auto &c : ret) {
-        c.synchronize();
+    for (const auto &ep : errors) {
+        if (ep) {
+            std::rethrow_exception(ep);
+        }
+    }
+    std::vector<tab_core> ret;
+    ret.reserve(n_iter);
+    for (auto &sl : slots) {
+        ret.emplace_back(std::move(*sl));
     }
     return ret;
 }

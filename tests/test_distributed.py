@@ -80,3 +80,66 @@ def test_sharded_ensemble_gather_world2(n_total):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _gpu_worker(rank, world, port, n_total, t_final, q):
+    """One rank of the sharded ensemble with REAL integrators; all the ranks share GPU 0 (the single-GPU stand-in for
+    one-process-per-GPU: same code path as bench.py --gpus N --single-device, gloo instead of RCCL)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import heyoka_amd as hy
+        from heyoka_amd import configs
+
+        M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+        g = configs.outer_ss_state(n_total, perturb=1e-8, seed=17)
+        mk = lambda n: hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), None, n, high_accuracy=True, device=0)
+        ta, st, meta = hens.ensemble_propagate_until_sharded(mk, g, t_final)
+        lo, hi = hens.shard_bounds(n_total, rank, world)
+        assert ta.batch_size == hi - lo and st.shape == (36, n_total) and meta.shape == (2, n_total)
+        q.put((rank, st.numpy().copy(), meta.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_total", [256, 250])
+def test_sharded_ensemble_real_integrators_two_ranks_one_gpu(n_total):
+    """ensemble_propagate_until_sharded() with real integrators on 2 ranks (both on GPU 0): every rank receives the
+    same gathered state; it is bit-identical to a single-process run over the whole ensemble (systems are independent,
+    the reference's test/ensemble_propagate.cpp:419-420 pattern) and agrees with the oracle."""
+    import sys
+
+    import heyoka_amd as hy
+    from heyoka_amd import configs
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import heyoka_oracle as ho
+
+    t_final = 12.0
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, n_total, t_final, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+    assert all(p.exitcode == 0 for p in procs)
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+
+    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    g = configs.outer_ss_state(n_total, perturb=1e-8, seed=17)
+    ta = hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), g, n_total, high_accuracy=True)
+    ta.propagate_until(t_final)
+    assert np.array_equal(ta.state, res[0][1])
+    oc, _, _, ns = ta.propagate_res_arrays()
+    assert np.array_equal(res[0][2][0], oc.astype(np.float64)) and np.array_equal(res[0][2][1], ns.astype(np.float64))
+
+    n_o = (n_total // 8) * 8
+    ref, *_ = ho.ensemble_propagate_until(ho.nbody(6, masses=M, Gconst=G), g[:, :n_o], n_o, 8, t_final, high_accuracy=True)
+    ref = ref.reshape(36, n_o)
+    eps = np.finfo(float).eps
+    assert np.max(np.abs(res[0][1][:, :n_o] - ref) / np.maximum(1.0, np.abs(ref))) <= 1e5 * eps
