@@ -147,7 +147,8 @@ def pmc_traffic(sha, n_systems):
         except (OSError, ValueError):
             continue
         if d.get("kernel_sha256") == sha and d.get("systems_per_gpu") == n_systems:
-            return d["per_launch_avg"]["traffic_bytes_raw"], os.path.basename(path)
+            # Calibrated on known-byte streams (profiles/r02_pmc_calibration.json): traffic = 2 x FETCH_SIZE + WRITE_SIZE.
+            return d["per_launch_avg"]["traffic_bytes_fetch_x2"], os.path.basename(path)
     return None, None
 
 
@@ -289,7 +290,11 @@ def main():
         # traffic is a fraction of a percent of the peak and the binding ceiling is the FP64 arithmetic rate (78.6
         # TFLOP/s vector = matrix peak for f64 on MI355X; the recurrences have no dense contraction, MFMA itself is
         # unused) - reported under the contract's "mfma" label with the algorithmic flop count F_alg.
-        hbm_util = (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else min(1.0, achieved_gbs / HBM_PEAK_GBS)
+        # Without a counter file for this exact kernel: the cluster / register-resident steppers keep their jets on chip
+        # (FP64-bound), the block / table steppers stream them through HBM (tape model).
+        mode_str = ta.hip_source_mode
+        on_chip = mode_str.startswith("cluster") or "jets in registers" in mode_str or mode_str.startswith("unrolled")
+        hbm_util = (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else (0.0 if on_chip else min(1.0, achieved_gbs / HBM_PEAK_GBS))
         compute_bound = achieved_tflops / FP64_PEAK_TFLOPS > hbm_util
         if compute_bound:
             # NOTE: "fp64_valu" = the FP64 *vector* rate (16 lanes x FMA per clock and SIMD = 78.6 TFLOP/s at 2.4 GHz;

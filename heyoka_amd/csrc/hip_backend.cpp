@@ -42,9 +42,15 @@ std::unordered_map<std::string, std::shared_ptr<const compiled_module>> module_c
 
 std::shared_ptr<const compiled_module> hiprtc_compile(const emitted_module &m)
 {
+    // NOTE: the extra compiler flags (HEYOKA_AMD_HIPRTC_FLAGS, e.g. "-ffp-contract=off" in the parity tests) are part
+    // of the cache key.
+    const std::string cache_key = [&]() {
+        const char *ex = std::getenv("HEYOKA_AMD_HIPRTC_FLAGS");
+        return (ex != nullptr ? std::string(ex) + "\n" : std::string{}) + m.source;
+    }();
     {
         std::lock_guard lock(cache_mutex);
-        if (const auto it = module_cache.find(m.source); it != module_cache.end()) {
+        if (const auto it = module_cache.find(cache_key); it != module_cache.end()) {
             return it->second;
         }
     }
@@ -105,7 +111,7 @@ std::shared_ptr<const compiled_module> hiprtc_compile(const emitted_module &m)
     ret->compile_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
     std::lock_guard lock(cache_mutex);
-    module_cache.emplace(m.source, ret);
+    module_cache.emplace(cache_key, ret);
     return ret;
 }
 

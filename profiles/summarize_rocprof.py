@@ -57,9 +57,10 @@ def main():
         fe, wr = counters(sys.argv[3]), counters(sys.argv[4])
         out = {
             "note": "FETCH_SIZE / WRITE_SIZE in KiB as reported by rocprofv3 (separate --pmc passes, no tracing "
-                    "domains). MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads 1/2 of the bytes of a wide (16 B/lane) "
-                    "coalesced stream; this kernel uses 8 B/lane accesses, for which the counter is uncalibrated, so "
-                    "both the raw and the doubled figure are given. Infinity-Cache hits are counted.",
+                    "domains). Calibration on known-byte streams (profiles/r02_pmc_calibration.json, "
+                    "profiles/ubench/stream8.hip): on gfx950 FETCH_SIZE reads 1/2 of the bytes for 8 B/lane as well as for "
+                    "16 B/lane coalesced reads (factor 2.000), WRITE_SIZE is exact (factor 1.000): HBM traffic = "
+                    "2 x FETCH_SIZE + WRITE_SIZE (traffic_bytes_fetch_x2). Infinity-Cache hits are counted.",
             "dispatches": [],
         }
         for a, b in zip(fe, wr):
@@ -85,6 +86,9 @@ def main():
                     out["kernel_sha256"] = b["config"].get("kernel_sha256")
                     out["systems_per_gpu"] = b["config"].get("systems_per_gpu")
                     out["bench_line_of_profiled_run"] = b
+                    # Registers / spills / scratch / LDS from the metadata notes of the code object (the per-dispatch
+                    # "vgpr" / "agpr" columns of rocprofv3 above are what the tool reports: ArchVGPR granules, no AGPRs).
+                    out["kernel_resources_from_code_object"] = b.get("roofline", {}).get("kernel_resources")
         with open(prefix + "_pmc.json", "w") as f:
             json.dump(out, f, indent=1)
         print(json.dumps(out["per_launch_avg"], indent=1))

@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""Writes tests/golden/reference_node_tests.json: the per-node known answers the reference's own tests assert,
+transcribed case by case (system, initial state, batch size, tolerance -> order, and the REQUIRE(jet[i] == ...) expressions
+evaluated here in double precision exactly as written in the test). Data only: no reference source is copied.
+
+jet layout of the reference's tc_to_jet(): jet[(k * n_eq + var) * batch + lane].
+
+  pow_frac      test/taylor_pow.cpp:575-640       x' = pow(y, 3/2), y' = pow(x, -1/3), batch 3, tol .1 (order 3)
+  sum_sq_vars   test/taylor_sum_sq.cpp:435-497    x' = sum_sq(y, x, 1), y' = sum_sq(x, y, 2), batch 3, tol .1
+  prod_vars     test/taylor_prod.cpp:977-1022     x' = x * y, y' = y * x, batch 3, tol .1
+"""
+import json
+import os
+from math import pow as P
+
+
+def pow_frac():
+    j = [2., 5., 1., 3., 4., 6.] + [0.] * 18
+    for l in range(3):
+        j[6 + l] = P(j[3 + l], 3. / 2)
+        j[9 + l] = P(j[l], -1. / 3)
+        j[12 + l] = 1. / 2 * 3. / 2 * P(j[3 + l], 1. / 2) * j[9 + l]
+        j[15 + l] = 1. / 2 * -1. / 3 * P(j[l], -4. / 3) * j[6 + l]
+        j[18 + l] = 1. / 6 * 3. / 2 * (1. / 2 * P(j[3 + l], -1. / 2) * j[9 + l] * j[9 + l] + P(j[3 + l], 1. / 2) * 2 * j[15 + l])
+        j[21 + l] = 1. / 6 * -1. / 3 * (-4. / 3 * P(j[l], -7. / 3) * j[6 + l] * j[6 + l] + P(j[l], -4. / 3) * 2 * j[12 + l])
+    return {"source": "test/taylor_pow.cpp:575-640", "system": "pow_frac", "state": j[:6], "batch": 3, "tol": .1, "jet": j}
+
+
+def sum_sq_vars():
+    j = [2., 4., 3., 3., 5., 6.] + [0.] * 18
+    for l in range(3):
+        j[6 + l] = j[3 + l] * j[3 + l] + j[l] * j[l] + 1
+        j[9 + l] = j[3 + l] * j[3 + l] + j[l] * j[l] + 4
+        j[12 + l] = j[3 + l] * j[9 + l] + j[l] * j[6 + l]
+        j[15 + l] = j[3 + l] * j[9 + l] + j[l] * j[6 + l]
+        j[18 + l] = 1. / 3 * (j[9 + l] * j[9 + l] + j[3 + l] * 2 * j[15 + l] + j[6 + l] * j[6 + l] + j[l] * 2 * j[12 + l])
+        j[21 + l] = j[18 + l]
+    return {"source": "test/taylor_sum_sq.cpp:435-497", "system": "sum_sq_vars", "state": j[:6], "batch": 3, "tol": .1, "jet": j}
+
+
+def prod_vars():
+    j = [2., 1., 3., 3., -4., 6.] + [0.] * 18
+    x0, y0 = j[:3], j[3:6]
+    for l in range(3):
+        j[6 + l] = x0[l] * y0[l]
+        j[9 + l] = j[6 + l]
+        j[12 + l] = 1. / 2 * (j[6 + l] * y0[l] + j[9 + l] * x0[l])
+        j[15 + l] = j[12 + l]
+        j[18 + l] = 1 / 6. * (2 * j[12 + l] * y0[l] + 2 * j[6 + l] * j[9 + l] + 2 * x0[l] * j[15 + l])
+        j[21 + l] = j[18 + l]
+    return {"source": "test/taylor_prod.cpp:977-1022", "system": "prod_vars", "state": j[:6], "batch": 3, "tol": .1, "jet": j}
+
+
+if __name__ == "__main__":
+    out = {"note": __doc__, "cases": [pow_frac(), sum_sq_vars(), prod_vars()],
+           "tolerance": "the reference's approximately(): 100 eps relative"}
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_node_tests.json"), "w") as f:
+        json.dump(out, f, indent=1)

@@ -1134,3 +1134,43 @@ def test_lockstep_device_loop_equals_host_loop(monkeypatch):
 
     with pytest.raises(RuntimeError, match="alteration of the time coordinate"):
         te.propagate_until(1.0, callback=bad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["two_body_unrolled", "outer_ss_cluster_v3", "outer_ss_cluster_v2"])
+def test_contraction_off_build_meets_the_reference_tolerances(which, monkeypatch):
+    """The stated slack of the parity tests on h (1e6 eps) and on the Taylor coefficients is FMA contraction (allowed
+    by the reference too, src/llvm_state.cpp:843-845) and nothing else: the same kernels built with
+    -ffp-contract=off (test-only build, HEYOKA_AMD_HIPRTC_FLAGS) meet the reference's own tolerances against the
+    strict-IEEE oracle from identical states - h to 1e4 eps, every Taylor coefficient to 1e5 eps of the largest
+    coefficient of its order IN ITS LANE (not of the row maximum over the lanes), states to 1e5 eps
+    (test/two_body_batch.cpp:118-150)."""
+    monkeypatch.setenv("HEYOKA_AMD_HIPRTC_FLAGS", "-ffp-contract=off")
+    n = 64
+    if which == "two_body_unrolled":
+        st = configs.two_body_state(n, perturb=1e-3, seed=21)
+        sys_g, sys_o, ha = hy.model.nbody(2, masses=[1.0, 0.0]), ho.nbody(2, masses=[1.0, 0.0]), False
+    else:
+        M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+        st = configs.outer_ss_state(n, perturb=1e-6, seed=22)
+        sys_g, sys_o, ha = hy.model.nbody(6, masses=M, Gconst=G), ho.nbody(6, masses=M, Gconst=G), True
+        if which.endswith("v2"):
+            monkeypatch.setenv("HEYOKA_AMD_PAIR_SPLIT", "0")
+    ta = hy.taylor_adaptive_batch(sys_g, st, n, high_accuracy=ha)
+    if which.startswith("outer_ss"):
+        assert ("v3" in ta.hip_source_mode) == which.endswith("v3"), ta.hip_source_mode
+    ora = ho.OracleIntegrator(sys_o, st, n, high_accuracy=ha)
+    n_eq, p = st.shape[0], ta.order
+    for _ in range(4):
+        # Identical states at the beginning of every step.
+        ta.state = ora.state.reshape(n_eq, n)
+        ta.step(write_tc=True)
+        ora.step(wtc=True)
+        h_g = np.array([h for _, h in ta.step_res])
+        h_o = np.array([h for _, h in ora.step_res])
+        assert np.max(np.abs(h_g - h_o) / np.abs(h_o)) <= 1e4 * EPS
+        tc_g = np.asarray(ta.tc).reshape(n_eq, p + 1, n)
+        tc_o = ora.tc.reshape(n_eq, p + 1, n)
+        scale = np.max(np.abs(tc_o), axis=0, keepdims=True)  # per order and per lane
+        assert np.max(np.abs(tc_g - tc_o) / scale) <= 1e5 * EPS
+        assert rel_err(ta.state, ora.state.reshape(n_eq, n)) <= 1e5 * EPS

@@ -98,3 +98,63 @@ def test_gpu_node_jets(mode):
                 del os.environ["HEYOKA_AMD_EMIT_MODE"]
             else:
                 os.environ["HEYOKA_AMD_EMIT_MODE"] = old
+
+
+# ---- The reference's own literal expectations (tests/golden/reference_node_tests.json, transcribed from
+# test/taylor_pow.cpp:575-640, test/taylor_sum_sq.cpp:435-497, test/taylor_prod.cpp:977-1022 by
+# tests/golden/make_reference_node_tests.py) ----
+with open(os.path.join(HERE, "golden", "reference_node_tests.json")) as _f:
+    R = json.load(_f)
+
+
+def build_ref(m, name):
+    if m is ho:
+        x, y = m.var("x"), m.var("y")
+        powf, sum_sq = m.pow_, lambda a: m.func("sum_sq", [m.as_ex(v) for v in a])
+    else:
+        x, y = m.make_vars("x", "y")
+        powf, sum_sq = m.pow, getattr(m, "sum_sq", None)
+    if name == "pow_frac":
+        return [(x, powf(y, 3.0 / 2.0)), (y, powf(x, -1.0 / 3.0))]
+    if name == "prod_vars":
+        return [(x, x * y), (y, y * x)]
+    if name == "sum_sq_vars":
+        # (sum_to_sum_sq() builds the sum_sq nodes out of the sums of squares, src/math/sum_sq.cpp.)
+        return [(x, y * y + x * x + 1.0), (y, x * x + y * y + 4.0)]
+    raise KeyError(name)
+
+
+def check_ref(tc, case, n_ord):
+    # tc[var][order][lane] vs jet[(k * 2 + var) * 3 + lane]
+    exp = np.array(case["jet"]).reshape(n_ord, 2, 3).transpose(1, 0, 2)
+    err = np.abs(tc[:, :n_ord, :] - exp) / np.maximum(np.abs(exp), 1e-300)
+    assert np.max(err) <= 100 * EPS, (case["system"], float(np.max(err)))
+
+
+@pytest.mark.parametrize("case", R["cases"], ids=[c["system"] for c in R["cases"]])
+def test_oracle_reference_literal_node_expectations(case):
+    st = np.array(case["state"])
+    ta = ho.OracleIntegrator(build_ref(ho, case["system"]), st, case["batch"], tol=case["tol"])
+    ta.step(wtc=True)
+    check_ref(ta.tc.reshape(2, ta.order + 1, 3), case, len(case["jet"]) // 6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["default", "table"])
+def test_gpu_reference_literal_node_expectations(mode):
+    import heyoka_amd as hy
+
+    old = os.environ.get("HEYOKA_AMD_EMIT_MODE")
+    if mode == "table":
+        os.environ["HEYOKA_AMD_EMIT_MODE"] = "table"
+    try:
+        for case in R["cases"]:
+            ta = hy.taylor_adaptive_batch(build_ref(hy, case["system"]), np.array(case["state"]), case["batch"], tol=case["tol"])
+            ta.step(write_tc=True)
+            check_ref(np.asarray(ta.tc).reshape(2, ta.order + 1, 3), case, len(case["jet"]) // 6)
+    finally:
+        if mode == "table":
+            if old is None:
+                del os.environ["HEYOKA_AMD_EMIT_MODE"]
+            else:
+                os.environ["HEYOKA_AMD_EMIT_MODE"] = old
