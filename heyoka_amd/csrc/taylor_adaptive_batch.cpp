@@ -456,6 +456,14 @@ tab_core::tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_siz
                                                                                    : emit_mode::unrolled;
     } else {
         eo.mode = choose_mode();
+        // kw::compact_mode = true selects the analogue of the reference's compact mode (src/taylor_02.cpp:1194-1260):
+        // the table-driven stepper - one device function per elementary function, rolled loops, running sums like
+        // src/math/prod.cpp:686-698 - instead of unrolled / clustered straight-line code (code size and compile time
+        // independent of the order). Decompositions beyond 2000 nodes keep the automatic choice (block / table: both
+        // tape-based), and HEYOKA_AMD_EMIT_MODE still overrides.
+        if (d.compact_mode && std::getenv("HEYOKA_AMD_EMIT_MODE") == nullptr && d.prog.nodes.size() <= 2000u) {
+            eo.mode = emit_mode::table;
+        }
     }
     d.emitted = emit_hip_module(d.prog, eo);
     d.cmod = hiprtc_compile(d.emitted);
@@ -1241,7 +1249,17 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
 
     d.prop_res_override.reset();
 
-    if (!cb && !c_out && !d.has_events()) {
+    // Opt-in: the reference's batch-wide semantics (src/taylor_adaptive_batch.cpp:1404-1407, :1462-1467, :1516): a
+    // non-finite lane stops the whole batch at that iteration, max_steps counts lock-step iterations of the batch and
+    // the lanes which are done keep taking zero-length steps. HEYOKA_AMD_REFERENCE_BATCH_SEMANTICS=1 routes
+    // propagate_until() / propagate_for() through the lock-step loop (one step of every lane per sweep), which
+    // implements exactly that; by default every lane runs its own loop on the device (known deviations).
+    const bool ref_semantics = [&]() {
+        const char *ev = std::getenv("HEYOKA_AMD_REFERENCE_BATCH_SEMANTICS");
+        return ev != nullptr && std::atoi(ev) != 0;
+    }();
+
+    if (!cb && !c_out && !d.has_events() && !ref_semantics) {
         // Device-resident propagation: every lane runs its own adaptive loop to completion
         // (or to max_steps) inside a single kernel launch.
         d.before_kernel();

@@ -43,6 +43,34 @@ enum class taylor_outcome : std::int64_t {
     cb_stop = -4294967296ll - 5
 };
 
+// Human-readable outcome ("taylor_outcome::success", "taylor_outcome::terminal_event_2 (stopping)", ...): the output
+// format of the reference's operator<< (src/taylor_stream_ops.cpp:244-266), which its tutorials print.
+inline std::ostream &operator<<(std::ostream &os, taylor_outcome oc)
+{
+    switch (oc) {
+        case taylor_outcome::success:
+            return os << "taylor_outcome::success";
+        case taylor_outcome::step_limit:
+            return os << "taylor_outcome::step_limit";
+        case taylor_outcome::time_limit:
+            return os << "taylor_outcome::time_limit";
+        case taylor_outcome::err_nf_state:
+            return os << "taylor_outcome::err_nf_state";
+        case taylor_outcome::cb_stop:
+            return os << "taylor_outcome::cb_stop";
+        default:
+            break;
+    }
+    const auto v = static_cast<std::int64_t>(oc);
+    if (v >= 0) {
+        return os << "taylor_outcome::terminal_event_" << v << " (continuing)";
+    }
+    if (oc > taylor_outcome::success) {
+        return os << "taylor_outcome::terminal_event_" << (-v - 1) << " (stopping)";
+    }
+    return os << "taylor_outcome::??";
+}
+
 template <typename T>
 class taylor_adaptive_batch;
 

@@ -34,3 +34,37 @@ def test_cpp_api_tutorial_sessions_on_gpu():
     out = subprocess.run([EXE, "gpu"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr + out.stdout
     assert "GPU checks OK" in out.stdout
+
+
+EXE2 = os.path.join(ROOT, "heyoka_amd", "csrc", "_build", "test_reference_includes")
+
+
+def _build_ref_includes():
+    """tests/cpp/test_reference_includes.cpp uses the reference's include layout (<heyoka/heyoka.hpp>, <heyoka/taylor.hpp>,
+    <heyoka/kw.hpp>, <heyoka/model/nbody.hpp>) and namespace (heyoka::) unchanged: only -I include -lheyoka_amd."""
+    src = os.path.join(ROOT, "tests", "cpp", "test_reference_includes.cpp")
+    lib = os.path.join(ROOT, "heyoka_amd", "libheyoka_amd.so")
+    if os.path.exists(EXE2) and os.path.getmtime(EXE2) > max(os.path.getmtime(src), os.path.getmtime(lib)):
+        return
+    os.makedirs(os.path.dirname(EXE2), exist_ok=True)
+    subprocess.check_call(
+        ["g++", "-std=c++20", "-O1", "-I" + os.path.join(ROOT, "include"), src, "-o", EXE2,
+         "-L" + os.path.join(ROOT, "heyoka_amd"), "-lheyoka_amd", "-Wl,-rpath," + os.path.join(ROOT, "heyoka_amd"),
+         "-Wl,-rpath,/opt/rocm/lib"])
+
+
+def test_reference_include_layout_and_namespace_compile_unchanged():
+    _build_ref_includes()
+    out = subprocess.run([EXE2], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "reference include layout OK" in out.stdout and "order 20 22 36" in out.stdout
+
+
+@pytest.mark.gpu
+def test_reference_include_layout_runs_the_tutorial_calls_on_gpu():
+    _build_ref_includes()
+    out = subprocess.run([EXE2, "gpu"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr + out.stdout
+    # The first step of the four pendulums succeeds (outcomes printed in the reference's format).
+    assert "GPU OK" in out.stdout and "Batch index 0: (taylor_outcome::success, 0.1" in out.stdout
+    assert "taylor_outcome::time_limit" in out.stdout

@@ -1174,3 +1174,53 @@ def test_contraction_off_build_meets_the_reference_tolerances(which, monkeypatch
         scale = np.max(np.abs(tc_o), axis=0, keepdims=True)  # per order and per lane
         assert np.max(np.abs(tc_g - tc_o) / scale) <= 1e5 * EPS
         assert rel_err(ta.state, ora.state.reshape(n_eq, n)) <= 1e5 * EPS
+
+
+@pytest.mark.gpu
+def test_reference_batch_semantics_opt_in(monkeypatch):
+    """HEYOKA_AMD_REFERENCE_BATCH_SEMANTICS=1: a non-finite lane stops the whole batch at that iteration and max_steps
+    counts lock-step iterations of the batch (src/taylor_adaptive_batch.cpp:1404-1407, :1462-1467, :1516) - outcomes,
+    step counters and times of every lane are those of the oracle's lock-step loop, also for the healthy lanes of a batch
+    with a diverging one (by default each lane runs its own loop on the device: DESIGN.md, known deviations)."""
+    monkeypatch.setenv("HEYOKA_AMD_REFERENCE_BATCH_SEMANTICS", "1")
+    x, v = hy.make_vars("x", "v")
+    ox, ov = ho.var("x"), ho.var("v")
+    st = np.array([[1.0, 0.5, -1.0, 0.0], [1.0, 1.0, 1.0, 1.0]])
+    for max_steps, t_end in ((0, 3.0), (7, 3.0), (0, 0.4)):
+        ta = hy.taylor_adaptive_batch([(x, x * x), (v, -v)], st, 4)
+        ora = ho.OracleIntegrator([(ox, ox * ox), (ov, -1.0 * ov)], st, 4)
+        ta.propagate_until(t_end, max_steps=max_steps)
+        ora.propagate_until(t_end, max_steps=max_steps)
+        got, ref = ta.propagate_res, ora.prop_res
+        assert [int(r[0]) for r in got] == [int(r[0]) for r in ref]
+        assert [int(r[3]) for r in got] == [int(r[3]) for r in ref]
+        # (Times of the healthy lanes: in the step which produces the non-finite state the step size of the diverging
+        # lane itself depends on the order in which NaNs enter the max() reductions of the selector.)
+        ok_l = np.all(np.isfinite(ora.state.reshape(2, 4)), axis=0)
+        assert np.allclose(np.asarray(ta.time)[ok_l], ora.time_hi[ok_l], rtol=1e-12, atol=0)
+        fin = np.isfinite(ora.state)
+        assert np.array_equal(np.isfinite(ta.state.reshape(-1)), fin)
+        assert np.allclose(ta.state.reshape(-1)[fin], ora.state[fin], rtol=1e-10)
+    # Every lane reports the step limit (per-batch counter), unlike the per-lane default.
+    ta = hy.taylor_adaptive_batch([(x, x * x), (v, -v)], [[-1.0, -2.0, -1.0, 0.0], [1.0, 1.0, 1.0, 1.0]], 4)
+    ta.propagate_until(50.0, max_steps=3)
+    assert all(r[0] == OC.step_limit for r in ta.propagate_res)
+
+
+@pytest.mark.gpu
+def test_compact_mode_kwarg_selects_the_table_stepper():
+    """kw::compact_mode = true (include/heyoka/kw.hpp) is honoured: the table-driven stepper (the analogue of
+    src/taylor_02.cpp:1194-1260) instead of straight-line code, same results as the default mode and as the oracle."""
+    n = 32
+    st = configs.two_body_state(n, perturb=1e-3, seed=5)
+    sys_g = hy.model.nbody(2, masses=[1.0, 0.0])
+    a = hy.taylor_adaptive_batch(sys_g, st, n, compact_mode=True)
+    b = hy.taylor_adaptive_batch(sys_g, st, n)
+    assert a.compact_mode and not b.compact_mode
+    assert a.hip_source_mode.startswith("table") and not b.hip_source_mode.startswith("table")
+    ora = ho.OracleIntegrator(ho.nbody(2, masses=[1.0, 0.0]), st, n)
+    for ta in (a, b):
+        ta.propagate_until(7.0)
+    ora.propagate_until(7.0)
+    assert rel_err(a.state, ora.state.reshape(12, n)) <= 1e5 * EPS
+    assert rel_err(a.state, b.state) <= 1e5 * EPS
