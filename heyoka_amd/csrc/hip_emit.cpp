@@ -425,11 +425,27 @@ if (a.mode == 1) {
         store_sv(i, order);
     }
 
+    // Integrators with events: every step is a step with events (mode 4), which needs the order-p coefficients of the u
+    // variables (src/taylor_02.cpp:1016-1190) - and the event equations take part in the norms of the step-size
+    // selector (taylor_determine_h() iterates up to n_eq + n_sv_funcs, src/taylor_00.cpp:209-219), so that the step
+    // stays inside the convergence radius of their Taylor series as well.
+    const bool ev_norms = !p.ev_u.empty() && !reg_jets;
+    if (ev_norms) {
+        for (std::uint32_t i = 0; i < p.nodes.size(); ++i) {
+            e.node(i, order);
+        }
+    }
+
     // ---- Step size (reference: taylor_determine_h(), src/taylor_00.cpp:102-273). ----
     const auto max_abs = [&](std::uint32_t k) {
         std::vector<std::string> v;
         for (std::uint32_t i = 0; i < n_eq; ++i) {
             v.push_back(e.def("fabs(" + e.val(i, k) + ")"));
+        }
+        if (ev_norms) {
+            for (const auto u : p.ev_u) {
+                v.push_back(e.def("fabs(" + e.val(u, k) + ")"));
+            }
         }
         while (v.size() != 1u) {
             std::vector<std::string> nv;
@@ -460,9 +476,6 @@ if (a.mode == 1) {
         // order-p coefficients of the u variables (src/taylor_02.cpp:1016-1190), the jets of the event equations,
         // max |x_i| and the step size; the state is updated later by the dense-output kernel.
         os << "if (a.mode == 4) {\n";
-        for (std::uint32_t i = 0; i < p.nodes.size(); ++i) {
-            e.node(i, order);
-        }
         for (std::size_t ev = 0; ev < p.ev_u.size(); ++ev) {
             for (std::uint32_t k = 0; k <= order; ++k) {
                 os << "a.ev_tc[(u64)" << (ev * (order + 1u) + k) << "u * N + s] = " << e.val(p.ev_u[ev], k) << ";\n";

@@ -567,6 +567,15 @@ extern "C" __global__ void __launch_bounds__(256, 4) hy_taylor(const hy_kargs a)
                 mo = hy_max(mo, fabs(hy_tp(c, HY_ORDER, i)));
                 mom1 = hy_max(mom1, fabs(hy_tp(c, HY_ORDER - 1u, i)));
             }
+#if HY_N_EV > 0
+            // The event equations take part in the three norms (taylor_determine_h() iterates up to n_eq + n_sv_funcs,
+            // src/taylor_00.cpp:209-219): the step stays inside the convergence radius of their Taylor series too.
+            for (unsigned e = 0; e < HY_N_EV; ++e) {
+                m0 = hy_max(m0, fabs(hy_tp(c, 0, hy_ev_u[e])));
+                mo = hy_max(mo, fabs(hy_tp(c, HY_ORDER, hy_ev_u[e])));
+                mom1 = hy_max(mom1, fabs(hy_tp(c, HY_ORDER - 1u, hy_ev_u[e])));
+            }
+#endif
             const double num_rho = (m0 <= 1.0) ? 1.0 : m0;
             const double rho_o = hy_root(num_rho / mo, 1.0 / (double)HY_ORDER);
             const double rho_om1 = hy_root(num_rho / mom1, 1.0 / (double)(HY_ORDER - 1u));
@@ -739,6 +748,14 @@ extern "C" __global__ void __launch_bounds__(64) hy_taylor(const hy_kargs a)
                 mo = hy_max(mo, fabs(hy_tp(c, HY_ORDER, i)));
                 mom1 = hy_max(mom1, fabs(hy_tp(c, HY_ORDER - 1u, i)));
             }
+#if HY_N_EV > 0
+            // (The event equations take part in the norms, src/taylor_00.cpp:209-219.)
+            for (unsigned e = lane; e < HY_N_EV; e += 64u) {
+                m0 = hy_max(m0, fabs(hy_tp(c, 0, hy_ev_u[e])));
+                mo = hy_max(mo, fabs(hy_tp(c, HY_ORDER, hy_ev_u[e])));
+                mom1 = hy_max(mom1, fabs(hy_tp(c, HY_ORDER - 1u, hy_ev_u[e])));
+            }
+#endif
             m0 = hy_wave_max(m0);
             mo = hy_wave_max(mo);
             mom1 = hy_wave_max(mom1);

@@ -855,7 +855,8 @@ size_t hy_oracle_scratch_size(const hy_oracle_program *p, int B)
 /* Same for hy_oracle_step_e() (full order for every u variable). */
 size_t hy_oracle_scratch_size_e(const hy_oracle_program *p, int B)
 {
-    return hy_oracle_scratch_size(p, B) + ((size_t)p->n_u + 8u) * (size_t)B;
+    /* (+ n_u rows: the event equations take part in the reductions of the step-size selector.) */
+    return hy_oracle_scratch_size(p, B) + (2u * (size_t)p->n_u + 8u) * (size_t)B;
 }
 
 static double rhofac(int order)
@@ -915,16 +916,19 @@ static void step_core(const hy_oracle_program *p, int B, double *state, const do
 
     /* Step size: pairwise max reduction over the variables (default mode). */
     /* Per-step temporaries live at the end of the caller-provided scratch (no allocation in the hot path). */
+    /* With events the event equations take part in the three norms: taylor_determine_h() iterates up to
+     * n_eq + n_sv_funcs (src/taylor_00.cpp:209-219), state variables first, then the event equations in order. */
+    const int n_red = n_eq + (with_events ? n_ev : 0);
     double *mx = scratch_mem + (with_events ? hy_oracle_scratch_size_e(p, B) : hy_oracle_scratch_size(p, B))
-                 - ((size_t)n_eq + 4u) * (size_t)B;
+                 - ((size_t)n_eq + (with_events ? (size_t)n_u : 0u) + 4u) * (size_t)B;
     double *red = mx + (size_t)3 * B;
     const int ks[3] = {0, order, order - 1};
     for (int q = 0; q < 3; ++q) {
-        for (int i = 0; i < n_eq; ++i) {
-            const double *x = TAPE(ks[q], i);
+        for (int i = 0; i < n_red; ++i) {
+            const double *x = TAPE(ks[q], i < n_eq ? i : ev_u[i - n_eq]);
             for (int l = 0; l < B; ++l) red[(size_t)i * B + l] = fabs(x[l]);
         }
-        int n = n_eq;
+        int n = n_red;
         while (n != 1) {
             int mcount = 0;
             for (int i = 0; i < n; i += 2) {

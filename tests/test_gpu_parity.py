@@ -1224,3 +1224,36 @@ def test_compact_mode_kwarg_selects_the_table_stepper():
     ora.propagate_until(7.0)
     assert rel_err(a.state, ora.state.reshape(12, n)) <= 1e5 * EPS
     assert rel_err(a.state, b.state) <= 1e5 * EPS
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["unrolled", "table"])
+def test_event_equations_take_part_in_the_step_size_selector(mode, monkeypatch):
+    """taylor_determine_h() of the stepper with events iterates over the state variables AND the event equations
+    (src/taylor_00.cpp:209-219, :693): with a fast-oscillating event function g = sin(40 x) the step must stay inside the
+    convergence radius of g's Taylor series - the step sizes are those of the oracle (which follows the reference) and
+    about 40 times smaller than those of the same system without the event; every zero crossing is reported."""
+    if mode == "table":
+        monkeypatch.setenv("HEYOKA_AMD_EMIT_MODE", "table")
+    n = 4
+    st = np.stack([np.linspace(0.1, 0.4, n), np.linspace(1.0, 1.3, n)])
+    x, v = hy.make_vars("x", "v")
+    ox, ov = ho.var("x"), ho.var("v")
+    log_p, log_o = [], []
+    ta = hy.taylor_adaptive_batch([(x, v), (v, -x)], st, n,
+                                  nt_events=[hy.nt_event(hy.sin(40.0 * x), lambda ta, t, d, i: log_p.append((i, t, d)))])
+    ora = ho.OracleEventIntegrator([(ox, ov), (ov, -1.0 * ox)], st, n,
+                                   nt_events=[ho.nt_event(ho.sin(40.0 * ox), lambda ta, t, d, i: log_o.append((i, t, d)))])
+    plain = hy.taylor_adaptive_batch([(x, v), (v, -x)], st, n)
+    plain.step()
+    h_plain = np.array([h for _, h in plain.step_res])
+    for _ in range(30):
+        ta.step()
+        ora.step()
+        h_p = np.array([h for _, h in ta.step_res])
+        h_o = np.array([h for _, h in ora.step_res])
+        assert np.max(np.abs(h_p - h_o) / np.abs(h_o)) <= 1e6 * EPS
+        assert np.all(h_p < 0.2 * h_plain)
+    assert len(log_p) == len(log_o) and len(log_p) >= 8
+    assert [(a[0], a[2]) for a in log_p] == [(a[0], a[2]) for a in log_o]
+    assert np.max(np.abs(np.array([a[1] for a in log_p]) - np.array([a[1] for a in log_o]))) <= 1e-12
