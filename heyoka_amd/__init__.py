@@ -902,6 +902,11 @@ class taylor_adaptive_batch:
         return bool(lib.hy_tab_get_compact_mode(self._h))
 
     @property
+    def event_detection_failures(self):
+        """Lane-steps in which the device-side event detection overflowed its fixed-size lists (events may have been dropped)."""
+        return int(lib.hy_tab_get_event_detection_failures(self._h))
+
+    @property
     def compile_seconds(self):
         return float(lib.hy_tab_get_compile_seconds(self._h))
 

@@ -129,6 +129,7 @@ SIGNATURES = [
     ("hy_tab_get_tol", c_double, [c_void_p]),
     ("hy_tab_get_high_accuracy", c_int, [c_void_p]),
     ("hy_tab_get_compact_mode", c_int, [c_void_p]),
+    ("hy_tab_get_event_detection_failures", ctypes.c_ulonglong, [c_void_p]),
     ("hy_tab_get_compile_seconds", c_double, [c_void_p]),
     ("hy_tab_get_hip_source", c_void_p, [c_void_p]),
     ("hy_tab_get_decomposition_str", c_void_p, [c_void_p]),

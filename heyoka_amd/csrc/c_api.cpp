@@ -730,6 +730,11 @@ int hy_tab_get_high_accuracy(hy_tab t)
 {
     return t->core.get_high_accuracy() ? 1 : 0;
 }
+unsigned long long hy_tab_get_event_detection_failures(hy_tab t)
+{
+    return t->core.get_event_detection_failures();
+}
+
 int hy_tab_get_compact_mode(hy_tab t)
 {
     return t->core.get_compact_mode() ? 1 : 0;

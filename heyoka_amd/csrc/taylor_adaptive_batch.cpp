@@ -126,6 +126,8 @@ struct tab_core::impl {
     mutable device_buffer d_ev_tc, d_mas, d_geps, d_dirs, d_cd_first, d_cd_second, d_cd_active, d_ed_out, d_ed_counts,
         d_ed_flags;
     std::uint64_t ed_failures = 0;
+    // Set by propagate_for() only: propagate_until() then accepts 2 * N double-length (hi, lo) final times.
+    bool dl_times_ok = false;
     // Incremented by set_time() / set_dtime(): lets the device-driven loops detect callbacks that touch the time
     // coordinate without moving the times to the host after every sweep.
     std::uint64_t time_gen = 0;
@@ -560,6 +562,11 @@ bool tab_core::get_high_accuracy() const
 {
     return m_impl->high_accuracy;
 }
+std::uint64_t tab_core::get_event_detection_failures() const
+{
+    return m_impl->ed_failures;
+}
+
 bool tab_core::get_compact_mode() const
 {
     return m_impl->compact_mode;
@@ -923,7 +930,18 @@ void tab_core::impl::step_with_events(const std::vector<double> &lims, bool wtc)
     if (std::any_of(counts.begin(), counts.end(), [](unsigned c) { return c != 0u; })) {
         d_ed_out.download(ed_out.data(), ed_out.size() * dsz, stream);
     }
-    ed_failures += flags[0];
+    if (flags[0] != 0u) {
+        // The per-lane lists of detected events / the work list of the root isolation are of fixed size on the device
+        // (16 events per class and lane, 64 intervals): an overflow drops events. The reference has no fixed cap and
+        // logs a warning when the isolation fails; here the count is kept (get_event_detection_failures()) and the
+        // first occurrence is reported on stderr.
+        if (ed_failures == 0u) {
+            std::fprintf(stderr, "heyoka_amd: warning: event detection overflow in %u lane(s) (more than 16 events of one "
+                                 "class in a step, or root isolation work list exhausted): events may have been "
+                                 "dropped - reduce the step (max_delta_t) around dense clusters of events\n", flags[0]);
+        }
+        ed_failures += flags[0];
+    }
 
     // Per-lane lists, sorted by the absolute value of the trigger time (:771-778).
     std::vector<std::vector<detected_event>> d_tes(n), d_ntes(n);
@@ -961,7 +979,12 @@ void tab_core::impl::step_with_events(const std::vector<double> &lims, bool wtc)
     lasth_dev_newer = false;
 
     std::vector<std::pair<std::uint32_t, std::exception_ptr>> cb_eptrs;
+    // NOTE: the new times and the non-finite flags of ALL the lanes are taken before any callback runs (the reference
+    // snapshots m_time_copy / m_nf_detected first, src/taylor_adaptive_batch.cpp:825-835, :844): a callback of lane i
+    // which touches the time or the state of a later lane neither changes that lane's time update nor defeats the
+    // "callback altered the time" check.
     std::vector<double> thi_copy(n), tlo_copy(n);
+    std::vector<char> nf_all(n, 0);
     for (std::uint32_t i = 0; i < N; ++i) {
         const auto h = hs[i];
         const auto new_time = dfloat(time_hi[i], time_lo[i]) + h;
@@ -970,11 +993,16 @@ void tab_core::impl::step_with_events(const std::vector<double> &lims, bool wtc)
         thi_copy[i] = new_time.hi;
         tlo_copy[i] = new_time.lo;
         last_h[i] = h;
-
         bool nf = !isfinite(new_time);
         for (std::uint32_t v = 0; v < dim && !nf; ++v) {
             nf = !std::isfinite(state[static_cast<std::size_t>(v) * n + i]);
         }
+        nf_all[i] = nf ? 1 : 0;
+    }
+    for (std::uint32_t i = 0; i < N; ++i) {
+        const auto h = hs[i];
+        const auto new_time = dfloat(thi_copy[i], tlo_copy[i]);
+        const bool nf = nf_all[i] != 0;
         if (nf) {
             step_res[i] = std::tuple{taylor_outcome::err_nf_state, h};
             continue;
@@ -1129,7 +1157,19 @@ void tab_core::propagate_for(const std::vector<double> &delta_ts, std::size_t ma
         ts[i] = tf.hi;
         ts[d.N + i] = tf.lo;
     }
-    // NOTE: a vector of size 2 * N carries double-length final times.
+    // NOTE: double-length final times travel as a vector of size 2 * N: a form accepted only from here (a public
+    // propagate_until() call with any size other than N throws like the reference).
+    struct dl_guard {
+        bool &flag;
+        explicit dl_guard(bool &f) : flag(f)
+        {
+            flag = true;
+        }
+        ~dl_guard()
+        {
+            flag = false;
+        }
+    } guard(d.dl_times_ok);
     propagate_until(ts, max_steps, max_delta_ts, cb, wtc, c_out);
 }
 
@@ -1201,7 +1241,7 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
         std::fill(tf_hi.begin(), tf_hi.end(), ts_[0]);
     } else if (ts_.size() == N) {
         tf_hi = ts_;
-    } else if (ts_.size() == 2u * static_cast<std::size_t>(N)) {
+    } else if (d.dl_times_ok && ts_.size() == 2u * static_cast<std::size_t>(N)) {
         std::copy(ts_.begin(), ts_.begin() + N, tf_hi.begin());
         std::copy(ts_.begin() + N, ts_.end(), tf_lo.begin());
     } else {
@@ -2062,6 +2102,22 @@ void tab_core::set_device(int device)
     d.d_counters = {};
     d.d_dout = {};
     d.d_douth = {};
+    // The auxiliary modules (event detection, post-step kernels of the lock-step loops) and the event buffers belong to
+    // the old device as well: they are recreated on first use. A caller-provided stream belonged to the old device:
+    // back to the default stream of the new one (set_stream() again if needed).
+    d.ed_mod.reset();
+    d.grid_mod.reset();
+    d.d_ev_tc = {};
+    d.d_mas = {};
+    d.d_geps = {};
+    d.d_dirs = {};
+    d.d_cd_first = {};
+    d.d_cd_second = {};
+    d.d_cd_active = {};
+    d.d_ed_out = {};
+    d.d_ed_counts = {};
+    d.d_ed_flags = {};
+    d.stream = nullptr;
     d.device = device;
     d.host_newer = true;
     d.dev_newer = false;

@@ -117,6 +117,8 @@ public:
     [[nodiscard]] double get_tol() const;
     [[nodiscard]] bool get_high_accuracy() const;
     [[nodiscard]] bool get_compact_mode() const;
+    // Number of lane-steps in which the device-side event detection overflowed its fixed-size lists (events dropped).
+    [[nodiscard]] std::uint64_t get_event_detection_failures() const;
     [[nodiscard]] std::uint32_t get_dim() const;
     [[nodiscard]] const sys_t &get_sys() const;
     [[nodiscard]] int get_device() const;
@@ -478,6 +480,11 @@ public:
     [[nodiscard]] bool get_compact_mode() const
     {
         return m_core.get_compact_mode();
+    }
+    // (Not in the reference: the device-side event detection works on fixed-size per-lane lists.)
+    [[nodiscard]] std::uint64_t get_event_detection_failures() const
+    {
+        return m_core.get_event_detection_failures();
     }
     [[nodiscard]] std::uint32_t get_dim() const
     {

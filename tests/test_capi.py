@@ -130,3 +130,15 @@ def test_aux_kernels_compile_for_gfx950():
     detection) build for gfx950 with hiprtc on the CPU-only box."""
     for order, dim, ha in ((20, 36, 1), (3, 2, 0)):
         _lib.raise_for(_lib.lib.hy_compile_aux_kernels(order, dim, ha))
+
+
+def test_propagate_until_rejects_time_vectors_of_the_wrong_size():
+    """Any number of final times other than the batch size throws like the reference (src/taylor_adaptive_batch.cpp:
+    propagate_until_impl()); in particular 2 * batch_size values are NOT read as double-length times (that form is private
+    to propagate_for())."""
+    import heyoka_amd as hy
+
+    ta = hy.taylor_adaptive_batch(hy.model.pendulum(), None, 4)
+    for n in (3, 8, 5):
+        with pytest.raises(ValueError, match="the number of specified time limits is %d" % n):
+            ta.propagate_until([1.0] * n)
