@@ -148,7 +148,10 @@ def pmc_traffic(sha, n_systems):
             continue
         if d.get("kernel_sha256") == sha and d.get("systems_per_gpu") == n_systems:
             # Calibrated on known-byte streams (profiles/r02_pmc_calibration.json): traffic = 2 x FETCH_SIZE + WRITE_SIZE.
-            return d["per_launch_avg"]["traffic_bytes_fetch_x2"], os.path.basename(path)
+            # Per system-step of the profiled launches (adaptive step counts differ from launch to launch).
+            steps = d.get("bench_line_of_profiled_run", {}).get("config", {}).get("system_steps_per_launch")
+            if steps:
+                return d["per_launch_avg"]["traffic_bytes_fetch_x2"] / steps, os.path.basename(path)
     return None, None
 
 
@@ -284,7 +287,8 @@ def main():
         per_launch_steps = float(steps_per_call)
         achieved_gbs = b_tape * per_launch_steps / (k_ms * 1e-3) / 1e9
         achieved_tflops = f_alg * per_launch_steps / (k_ms * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic(kernel_sha(ta), n)
+        traffic_per_step, traffic_src = pmc_traffic(kernel_sha(ta), n)
+        traffic = traffic_per_step * per_launch_steps if traffic_per_step else None
         # Which ceiling binds. The tape model B_tape describes a stepper that streams its jets through HBM
         # (block / table modes). The cluster and register-resident steppers keep the jets on chip: their measured HBM
         # traffic is a fraction of a percent of the peak and the binding ceiling is the FP64 arithmetic rate (78.6
@@ -345,6 +349,11 @@ def main():
                 "call_ms_avg": float(np.mean(call_ms)),
                 "algorithmic_flop_per_system_step": f_alg,
                 "algorithmic_bytes_per_system_step": b_tape,
+                # Launch by launch: adaptive step counts make the launches differ (and, for one system per workgroup,
+                # the launch cannot end before its slowest system: see steps_per_system_last_launch).
+                "per_launch": [{"kernel_ms": float(k), "system_steps": float(s_)} for k, s_ in zip(kern_ms, steps_per_call_all)],
+                "steps_per_system_last_launch": {"mean": float(ns.mean()), "max": int(ns.max()), "min": int(ns.min()),
+                                                 "p99": float(np.percentile(ns, 99))},
                 "algorithmic_counts_source": "heyoka_amd/roofline.py on the decomposition of this integrator "
                 "(%d u variables, order %d)" % (n_u, ta.order),
                 # Round-1 basis (SURVEY 8d estimate of F_alg), for continuity only.
