@@ -333,8 +333,10 @@ void emit_dout(std::ostringstream &os, const taylor_program &p, const emit_optio
 // One stepper kernel. reg_jets = false: the jets of the state variables go through the tc buffer (always
 // needed, also serves kw::write_tc). reg_jets = true: they stay in SSA values (registers); state variables
 // defined by other state variables (x' = v) are re-derived in the final evaluation instead of being stored.
+// stream_tc (with reg_jets): the Taylor coefficients are additionally streamed to a.tc as they are produced (stores
+// only, nothing is read back): the write_tc / continuous-output / propagate_grid variant of a register-resident stepper.
 std::string emit_unrolled_kernel(const taylor_program &p, const emit_options &opts, const std::string &kname,
-                                 bool reg_jets, std::uint64_t &n_stmt)
+                                 bool reg_jets, std::uint64_t &n_stmt, bool stream_tc = false)
 {
     const auto n_eq = p.n_eq;
     const auto order = opts.order;
@@ -357,7 +359,9 @@ std::string emit_unrolled_kernel(const taylor_program &p, const emit_options &op
             os << "double x" << i << "n = 0.0;\n";
         }
     }
-    if (!reg_jets) {
+    if (stream_tc) {
+        os << "double *jet = a.tc + s;\n";
+    } else if (!reg_jets) {
         os << "double *const jet = a.tc + s;\n";
     }
     os << R"HIP(
@@ -393,13 +397,18 @@ if (a.mode == 1) {
     lim = step_lim;
 }
 )HIP";
+    if (stream_tc) {
+        // NOTE: the (order + 1) * n_eq store addresses are invariants of the step loop: left alone, the compiler hoists
+        // all of them into registers (2 per address). Laundering the base pointer once per step makes them per-step values.
+        os << "asm volatile(\"\" : \"+v\"(jet));\n";
+    }
 
     // ---- Jet of normalised derivatives. ----
     for (std::uint32_t i = 0; i < n_eq; ++i) {
         e.val(i, 0) = "x" + std::to_string(i);
     }
     const auto store_sv = [&](std::uint32_t i, std::uint32_t k) {
-        if (reg_jets) {
+        if (reg_jets && !stream_tc) {
             return;
         }
         os << "jet[(u64)" << (static_cast<std::uint64_t>(i) * (order + 1u) + k) << "u * N] = " << e.val(i, k)
@@ -667,10 +676,12 @@ emitted_module emit_unrolled(const taylor_program &p, const emit_options &opts)
                           && std::getenv("HEYOKA_AMD_NO_REG_JETS") == nullptr;
     if (reg_jets) {
         src << emit_unrolled_kernel(p, opts, "hy_taylor", true, ret.n_statements);
-        src << emit_unrolled_kernel(p, opts, "hy_taylor_tc", false, ret.n_statements);
+        // NOTE: the variant serving write_tc streams the coefficients out of the same register-resident code (round 1
+        // went through the jets-in-memory kernel: 512 registers, 790 spilled dwords for the two-body problem).
+        src << emit_unrolled_kernel(p, opts, "hy_taylor_tc", true, ret.n_statements, true);
         ret.tc_kernel_name = "hy_taylor_tc";
         ret.tc_optional = true;
-        ret.notes = "register-resident state jets (+ tc variant)";
+        ret.notes = "register-resident state jets (+ variant streaming the Taylor coefficients out)";
     } else {
         src << emit_unrolled_kernel(p, opts, "hy_taylor", false, ret.n_statements);
     }
