@@ -51,123 +51,10 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     // issue slot of the FP64 pipe (profiles/ubench/issue_rate.hip), with two they overlap with the other wavefront's
     // arithmetic. The two lanes run ONE instruction stream: the chains are matched so that the same FMA is useful
     // work on both lanes with different register contents (see emit_pair_order below).
-    struct pair_pattern {
-        bool ok = false;
-        std::uint32_t d[3] = {}, sq = 0, pw = 0, pr[3] = {};
-        int sc = -1, rx[3] = {-1, -1, -1};
-        double ex = 0;
-        // External inputs of the three differences: template ext indices (minuend, subtrahend).
-        std::uint32_t de[3][2] = {};
-    } pp;
+    cluster_detail::pair_pattern pp;
+    cluster_detail::detect_pair_pattern(p, pl, pp);
     {
-        const auto npos = static_cast<std::uint32_t>(t0.size());
-        std::map<std::uint32_t, std::uint32_t> pos_of, ext_of;
-        for (std::uint32_t q = 0; q < npos; ++q) {
-            pos_of[t0[q]] = q;
-        }
-        // Template ext numbering exactly as in make_plan() (first encounter, members in order, arguments in order).
-        for (std::uint32_t q = 0; q < npos; ++q) {
-            for (const auto &o : p.nodes[t0[q] - n_eq].args) {
-                if (is_var(o) && pos_of.count(o.idx) == 0u && ext_of.count(o.idx) == 0u) {
-                    const auto e = static_cast<std::uint32_t>(ext_of.size());
-                    ext_of[o.idx] = e;
-                }
-            }
-        }
-        const auto node_at = [&](std::uint32_t q) -> const dc_node & { return p.nodes[t0[q] - n_eq]; };
-        const auto member = [&](const operand &o) { return is_var(o) && pos_of.count(o.idx) != 0u; };
-        int q_pw = -1, n_pw = 0;
-        for (std::uint32_t q = 0; q < npos; ++q) {
-            const auto &n = node_at(q);
-            if (n.kind == func_kind::pow && member(n.args[0]) && n.args[1].type == operand::kind::num
-                && n.args[1].value != .5 && n.args[1].value != 2.) {
-                q_pw = static_cast<int>(q);
-                ++n_pw;
-            }
-        }
-        bool ok = n_pw == 1;
-        std::vector<char> used(npos, 0);
-        if (ok) {
-            pp.pw = static_cast<std::uint32_t>(q_pw);
-            pp.ex = node_at(pp.pw).args[1].value;
-            used[pp.pw] = 1;
-            pp.sq = pos_of.at(node_at(pp.pw).args[0].idx);
-            const auto &ns = node_at(pp.sq);
-            ok = ns.kind == func_kind::sum_sq && ns.args.size() == 3u && used[pp.sq] == 0;
-            used[pp.sq] = 1;
-            for (std::uint32_t c = 0; ok && c < 3u; ++c) {
-                ok = member(ns.args[c]);
-                if (!ok) {
-                    break;
-                }
-                pp.d[c] = pos_of.at(ns.args[c].idx);
-                const auto &nd = node_at(pp.d[c]);
-                ok = used[pp.d[c]] == 0 && nd.kind == func_kind::sub && nd.args.size() == 2u && is_var(nd.args[0])
-                     && is_var(nd.args[1]) && !member(nd.args[0]) && !member(nd.args[1]);
-                if (ok) {
-                    used[pp.d[c]] = 1;
-                    pp.de[c][0] = ext_of.at(nd.args[0].idx);
-                    pp.de[c][1] = ext_of.at(nd.args[1].idx);
-                }
-            }
-        }
-        // Scaling of the pow (G * m_j * r^-3).
-        for (std::uint32_t q = 0; ok && q < npos; ++q) {
-            const auto &n = node_at(q);
-            if (used[q] == 0 && n.kind == func_kind::prod && n.args.size() == 2u && n.args[0].type == operand::kind::num
-                && !(n.args[0].value == -1.) && member(n.args[1]) && pos_of.at(n.args[1].idx) == pp.pw) {
-                if (pp.sc != -1) {
-                    ok = false;
-                }
-                pp.sc = static_cast<int>(q);
-                used[q] = 1;
-            }
-        }
-        const auto q_r = pp.sc >= 0 ? static_cast<std::uint32_t>(pp.sc) : pp.pw;
-        bool have_pr[3] = {false, false, false};
-        for (std::uint32_t q = 0; ok && q < npos; ++q) {
-            const auto &n = node_at(q);
-            if (used[q] != 0 || n.kind != func_kind::prod || n.args.size() != 2u || !member(n.args[0]) || !member(n.args[1])) {
-                continue;
-            }
-            const auto a0 = pos_of.at(n.args[0].idx), a1 = pos_of.at(n.args[1].idx);
-            const auto dq = (a0 == q_r) ? a1 : (a1 == q_r ? a0 : npos);
-            for (std::uint32_t c = 0; c < 3u; ++c) {
-                if (dq == pp.d[c] && !have_pr[c]) {
-                    pp.pr[c] = q;
-                    have_pr[c] = true;
-                    used[q] = 1;
-                }
-            }
-        }
-        ok = ok && have_pr[0] && have_pr[1] && have_pr[2];
-        for (std::uint32_t q = 0; ok && q < npos; ++q) {
-            const auto &n = node_at(q);
-            if (used[q] != 0) {
-                continue;
-            }
-            bool hit = false;
-            if (n.kind == func_kind::prod && n.args.size() == 2u && n.args[0].type == operand::kind::num
-                && !(n.args[0].value == -1.) && member(n.args[1])) {
-                for (std::uint32_t c = 0; c < 3u; ++c) {
-                    if (pos_of.at(n.args[1].idx) == pp.pr[c] && pp.rx[c] == -1) {
-                        pp.rx[c] = static_cast<int>(q);
-                        used[q] = 1;
-                        hit = true;
-                    }
-                }
-            }
-            ok = hit;
-        }
-        // Only the products (and their scalings) may be read from outside.
-        for (const auto q : pl.out_pos) {
-            bool fine = false;
-            for (std::uint32_t c = 0; c < 3u; ++c) {
-                fine = fine || q == pp.pr[c] || (pp.rx[c] >= 0 && q == static_cast<std::uint32_t>(pp.rx[c]));
-            }
-            ok = ok && fine;
-        }
-        ok = ok && ((pp.rx[0] >= 0) == (pp.rx[1] >= 0)) && ((pp.rx[0] >= 0) == (pp.rx[2] >= 0));
+        const bool ok = pp.ok;
         const char *ev = std::getenv("HEYOKA_AMD_PAIR_SPLIT");
         // NOTE: at most 16 pairs (two systems per wavefront). With 17 .. 32 pairs (one system per wavefront, e.g.
         // model::np1body(8)) the generated kernel did not terminate on the hardware (round 2, not yet understood):
