@@ -69,6 +69,28 @@ struct taylor_program {
 taylor_program make_program(const taylor_dc_t &dc, std::uint32_t n_eq,
                             std::uint32_t n_outs = std::numeric_limits<std::uint32_t>::max());
 
+// u variables which do not depend on the state or on time: every argument is a number, a parameter or another constant
+// u variable (e.g. -par[0], par[0] + par[1] in models with runtime masses). All their Taylor coefficients beyond order 0
+// vanish: a product with such a factor is linear in the other one.
+inline std::vector<char> constant_uvars(const taylor_program &p)
+{
+    std::vector<char> c(p.n_u, 0);
+    for (std::size_t i = 0; i < p.nodes.size(); ++i) {
+        const auto &n = p.nodes[i];
+        if (n.kind == func_kind::time || !n.deps.empty()) {
+            continue;
+        }
+        bool all_const = true;
+        for (const auto &o : n.args) {
+            if (o.type == operand::kind::uvar && (o.idx < p.n_eq || c[o.idx] == 0)) {
+                all_const = false;
+            }
+        }
+        c[p.n_eq + i] = all_const ? 1 : 0;
+    }
+    return c;
+}
+
 // Order of the Taylor method from the tolerance (reference: include/heyoka/detail/taylor_common.hpp:165-191).
 std::uint32_t taylor_order_from_tol(double tol);
 

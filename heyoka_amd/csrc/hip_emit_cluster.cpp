@@ -47,13 +47,18 @@ using cluster_detail::glue_group;
 using cluster_detail::is_var;
 
 // u variables whose *full history* node n needs (besides, possibly, its own).
-std::vector<std::uint32_t> history_operands(const dc_node &n)
+// NOTE: cu (optional) = constant u variables (constant_uvars()): a product with a constant factor is linear in the other
+// one and needs no history (ssa_emitter::node evaluates it as c^[0] * x^[k]). Used by the wave-cluster planner only.
+std::vector<std::uint32_t> history_operands(const dc_node &n, const std::vector<char> *cu = nullptr)
 {
     std::vector<std::uint32_t> ret;
     const auto &a = n.args;
     switch (n.kind) {
         case func_kind::prod:
             if (a.size() == 2u && is_var(a[0]) && is_var(a[1])) {
+                if (cu != nullptr && ((*cu)[a[0].idx] != 0 || (*cu)[a[1].idx] != 0)) {
+                    break;
+                }
                 ret = {a[0].idx, a[1].idx};
             }
             break;
@@ -118,7 +123,7 @@ std::vector<std::uint32_t> history_operands(const dc_node &n)
 }
 
 // Kinds that can be evaluated as glue (only current-order operand values).
-bool is_glue_kind(const dc_node &n)
+bool is_glue_kind(const dc_node &n, const std::vector<char> *cu = nullptr)
 {
     switch (n.kind) {
         case func_kind::sum:
@@ -127,11 +132,14 @@ bool is_glue_kind(const dc_node &n)
         case func_kind::time:
             return true;
         case func_kind::prod:
-            return n.args.size() == 2u && !(is_var(n.args[0]) && is_var(n.args[1]));
+            if (n.args.size() == 2u && is_var(n.args[0]) && is_var(n.args[1])) {
+                return cu != nullptr && ((*cu)[n.args[0].idx] != 0 || (*cu)[n.args[1].idx] != 0);
+            }
+            return n.args.size() == 2u;
         case func_kind::div:
             return !is_var(n.args[1]);
         default:
-            return history_operands(n).empty();
+            return history_operands(n, cu).empty();
     }
 }
 
@@ -302,6 +310,10 @@ std::string make_plan_impl(const taylor_program &p, std::uint32_t order, cluster
     const auto n_eq = p.n_eq, n_u = p.n_u;
     pl.n_eq = n_eq;
     pl.n_u = n_u;
+    // Constant u variables: only the wave-cluster generators (ssa_emitter-based) evaluate products with a constant
+    // factor linearly; the block planner keeps the general treatment.
+    const auto cu_store = constant_uvars(p);
+    const std::vector<char> *cu = lim.jets_in_registers ? &cu_store : nullptr;
 
     // 1. History edges -> clusters.
     union_find uf(n_u);
@@ -312,7 +324,7 @@ std::string make_plan_impl(const taylor_program &p, std::uint32_t order, cluster
             return std::string("function served by the unrolled / table steppers: ") + func_kind_name(p.nodes[i].kind);
         }
         const auto u = n_eq + i;
-        const auto hs = history_operands(p.nodes[i]);
+        const auto hs = history_operands(p.nodes[i], cu);
         for (const auto h : hs) {
             if (h < n_eq) {
                 return "a state variable is a history operand of a nonlinear function";
@@ -346,7 +358,7 @@ std::string make_plan_impl(const taylor_program &p, std::uint32_t order, cluster
     // 2. Absorb single-source linear nodes into their source cluster.
     for (std::uint32_t i = 0; i < p.nodes.size(); ++i) {
         const auto u = n_eq + i;
-        if (!lim.absorb_linear || pl.cluster_of[u] != -1 || !is_glue_kind(p.nodes[i])) {
+        if (!lim.absorb_linear || pl.cluster_of[u] != -1 || !is_glue_kind(p.nodes[i], cu)) {
             continue;
         }
         int src = -2;
@@ -373,7 +385,7 @@ std::string make_plan_impl(const taylor_program &p, std::uint32_t order, cluster
 
     // Glue nodes must be of a kind evaluable from current-order values.
     for (std::uint32_t i = 0; i < p.nodes.size(); ++i) {
-        if (pl.cluster_of[n_eq + i] == -1 && !is_glue_kind(p.nodes[i])) {
+        if (pl.cluster_of[n_eq + i] == -1 && !is_glue_kind(p.nodes[i], cu)) {
             return std::string("unsupported glue node kind: ") + func_kind_name(p.nodes[i].kind);
         }
     }
@@ -461,8 +473,9 @@ std::string make_plan_impl(const taylor_program &p, std::uint32_t order, cluster
         }
         return false;
     };
-    std::vector<std::vector<std::pair<std::uint32_t, std::uint32_t>>> num_pos(nc);
+    std::vector<std::vector<std::pair<std::uint32_t, std::uint32_t>>> num_pos(nc), par_pos(nc);
     std::vector<std::vector<double>> num_val(nc);
+    std::vector<std::vector<std::uint32_t>> par_idx(nc);
     for (std::size_t c = 0; c < nc; ++c) {
         const auto &mem = pl.clusters[c];
         if (mem.size() != t0.size()) {
@@ -490,7 +503,14 @@ std::string make_plan_impl(const taylor_program &p, std::uint32_t order, cluster
                         sig << 'e' << it2->second;
                     }
                 } else if (o.type == operand::kind::par) {
-                    sig << 'p' << o.idx;
+                    // Parameters: identical index across the clusters -> plain name, otherwise a per-lane table.
+                    if (lim.generic_pars) {
+                        sig << 'P';
+                        par_pos[c].emplace_back(q, static_cast<std::uint32_t>(a));
+                        par_idx[c].push_back(o.idx);
+                    } else {
+                        sig << 'p' << o.idx;
+                    }
                 } else if (structural_number(n, a)) {
                     sig << 'n' << fp_literal(o.value);
                 } else {
@@ -531,6 +551,19 @@ std::string make_plan_impl(const taylor_program &p, std::uint32_t order, cluster
             }
         }
     }
+    pl.par_idx.assign(nc, {});
+    for (std::size_t j = 0; j < par_pos[0].size(); ++j) {
+        bool same = true;
+        for (std::size_t c = 1; c < nc; ++c) {
+            same = same && par_idx[c][j] == par_idx[0][j];
+        }
+        if (!same) {
+            pl.par_pos.push_back(par_pos[0][j]);
+            for (std::size_t c = 0; c < nc; ++c) {
+                pl.par_idx[c].push_back(par_idx[c][j]);
+            }
+        }
+    }
     for (std::uint32_t q = 0; q < t0.size(); ++q) {
         if (exported[t0[q]] != 0) {
             pl.out_pos.push_back(q);
@@ -548,7 +581,7 @@ std::string make_plan_impl(const taylor_program &p, std::uint32_t order, cluster
     std::set<std::uint32_t> stored;
     for (const auto u : t0) {
         const auto &n = p.nodes[u - n_eq];
-        for (const auto h : history_operands(n)) {
+        for (const auto h : history_operands(n, cu)) {
             stored.insert(h);
         }
         switch (n.kind) {
@@ -565,7 +598,7 @@ std::string make_plan_impl(const taylor_program &p, std::uint32_t order, cluster
             case func_kind::asinh:
             case func_kind::acosh:
             case func_kind::atanh:
-                if (!history_operands(n).empty()) {
+                if (!history_operands(n, cu).empty()) {
                     stored.insert(u);
                 }
                 break;
@@ -616,9 +649,16 @@ std::string make_plan_impl(const taylor_program &p, std::uint32_t order, cluster
         for (std::size_t a = 0; a < n.args.size(); ++a) {
             const auto &o = n.args[a];
             if (is_var(o)) {
-                key << "v";
+                // (Constant factors of products are part of the shape: they select the linear rule.)
+                key << ((cu != nullptr && n.kind == func_kind::prod && (*cu)[o.idx] != 0) ? "k" : "v");
             } else if (o.type == operand::kind::par) {
-                key << "p" << o.idx;
+                // (Per-lane parameter tables in the pipelined generator; the first-generation one checks gpar_generic.)
+                if (lim.generic_pars) {
+                    key << "P";
+                    pl.glue_has_par = true;
+                } else {
+                    key << "p" << o.idx;
+                }
             } else if (structural_number(n, a)) {
                 key << "n" << fp_literal(o.value);
             } else {
@@ -805,6 +845,10 @@ emitted_module emit_cluster_v1(const taylor_program &p, const emit_options &opts
 
     // Emit one glue group at order k by temporarily aliasing the first node of each round: the node
     // rule is emitted once per round with operands read from the slab through the lane's tables.
+    // Constant operands (constant_uvars()): the value a round has read at order 0 is the one the linear rule
+    // c^[0] * x^[k] of ssa_emitter::node() uses at every order (same position in all the nodes of a group: the shape key
+    // of a group does not distinguish them, so const-ness is checked over the whole group).
+    std::map<std::tuple<std::size_t, std::size_t, std::size_t>, std::string> glue_c0;
     const auto emit_glue_group = [&](std::size_t g, std::uint32_t k) {
         const auto &grp = pl.groups[g];
         const auto rep = grp.nodes[0];
@@ -813,12 +857,21 @@ emitted_module emit_cluster_v1(const taylor_program &p, const emit_options &opts
             const auto &rt = glue_tbls[g][r];
             std::map<const operand *, std::string> saved = e.numpar_override;
             std::vector<std::pair<std::uint32_t, std::string>> saved_vals;
+            std::vector<std::pair<std::uint32_t, std::string>> saved_vals0;
             for (std::size_t a = 0; a < n0.args.size(); ++a) {
                 const auto &o = n0.args[a];
                 if (is_var(o)) {
                     const auto nm = e.def("slab[" + utname(rt.arg_tbl[a]) + "]");
                     saved_vals.emplace_back(o.idx, e.val(o.idx, k));
                     e.val(o.idx, k) = nm;
+                    if (e.cu[o.idx] != 0) {
+                        if (k == 0u) {
+                            glue_c0[{g, r, a}] = nm;
+                        } else {
+                            saved_vals0.emplace_back(o.idx, e.val(o.idx, 0));
+                            e.val(o.idx, 0) = glue_c0.at({g, r, a});
+                        }
+                    }
                 } else if (o.type == operand::kind::num) {
                     e.numpar_override[&o] = dtname(rt.arg_tbl[a]);
                 }
@@ -833,6 +886,9 @@ emitted_module emit_cluster_v1(const taylor_program &p, const emit_options &opts
             // Restore.
             for (auto it = saved_vals.rbegin(); it != saved_vals.rend(); ++it) {
                 e.val(it->first, k) = it->second;
+            }
+            for (auto it = saved_vals0.rbegin(); it != saved_vals0.rend(); ++it) {
+                e.val(it->first, 0) = it->second;
             }
             e.numpar_override = std::move(saved);
         }

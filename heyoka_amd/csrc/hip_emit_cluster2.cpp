@@ -34,10 +34,15 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
 
     emitted_module ret;
     cluster_plan pl;
-    why_not = cluster_detail::make_plan(p, opts.order, pl);
+    // Parameter operands are per-lane values here (e.g. kw::masses = par[...]: the pair clusters differ only by the
+    // indices of the parameters they read).
+    cluster_detail::plan_limits plim;
+    plim.generic_pars = true;
+    why_not = cluster_detail::make_plan(p, opts.order, pl, plim);
     if (!why_not.empty()) {
         return ret;
     }
+    const auto cu = constant_uvars(p);
 
     const auto n_eq = p.n_eq, order = opts.order;
     const auto nc = static_cast<std::uint32_t>(pl.clusters.size());
@@ -302,6 +307,23 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         const auto [q, a] = pl.cst_pos[x];
         e.numpar_override[&p.nodes[t0[q] - n_eq].args[a]] = "ccst" + std::to_string(x);
     }
+    // Per-lane parameters: tables of parameter indices; the values are loaded when a group of systems is picked up.
+    std::vector<std::size_t> lane_par_tbls;
+    const auto lane_par = [&](std::vector<std::uint32_t> idx) {
+        const auto t = add_utbl(std::move(idx), false);
+        if (std::find(lane_par_tbls.begin(), lane_par_tbls.end(), t) == lane_par_tbls.end()) {
+            lane_par_tbls.push_back(t);
+        }
+        return "lp" + std::to_string(t);
+    };
+    for (std::size_t x = 0; !pair_split && x < pl.par_pos.size(); ++x) {
+        std::vector<std::uint32_t> v(L);
+        for (std::uint32_t l = 0; l < L; ++l) {
+            v[l] = pl.par_idx[l < nc ? l : 0u][x];
+        }
+        const auto [q, a] = pl.par_pos[x];
+        e.numpar_override[&p.nodes[t0[q] - n_eq].args[a]] = lane_par(std::move(v));
+    }
 
     // Glue rounds (+ the owner slots of the attached state variables).
     struct owner_slot {
@@ -319,6 +341,8 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         std::uint32_t n_valid = 0; // lanes l < n_valid own a real node
         bool exported = true;
         std::vector<owner_slot> owners;
+        std::vector<std::string> par_name; // per-lane parameter value names, by argument (empty: none)
+        std::vector<std::string> c0name;   // names of the constant operands read at order 0, by argument
     };
     std::vector<std::vector<glue_round>> rounds(pl.groups.size());
     std::uint32_t n_own = 0, n_col_acc = 0;
@@ -357,6 +381,13 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
                     }
                     gr.arg_tbl.push_back(add_dtbl(std::move(v)));
                 } else {
+                    // Parameter: per-lane index (the nodes of a group may read different parameters).
+                    std::vector<std::uint32_t> v(L);
+                    for (std::uint32_t l = 0; l < L; ++l) {
+                        v[l] = p.nodes[node_of(l) - n_eq].args[a].idx;
+                    }
+                    gr.par_name.resize(n0.args.size());
+                    gr.par_name[a] = lane_par(std::move(v));
                     gr.arg_tbl.push_back(0);
                 }
             }
@@ -475,14 +506,26 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         const auto rep = grp.nodes[0];
         const auto &n0 = p.nodes[rep - n_eq];
         const auto saved = e.numpar_override;
-        std::vector<std::pair<std::uint32_t, std::string>> saved_vals;
+        std::vector<std::pair<std::uint32_t, std::string>> saved_vals, saved_vals0;
         for (std::size_t a = 0; a < n0.args.size(); ++a) {
             const auto &o = n0.args[a];
             if (is_var(o)) {
                 saved_vals.emplace_back(o.idx, e.val(o.idx, k));
                 e.val(o.idx, k) = names[a];
+                // Constant operand: the linear rule of ssa_emitter::node() uses the value read at order 0.
+                if (cu[o.idx] != 0) {
+                    if (k == 0u) {
+                        gr.c0name.resize(n0.args.size());
+                        gr.c0name[a] = names[a];
+                    } else {
+                        saved_vals0.emplace_back(o.idx, e.val(o.idx, 0));
+                        e.val(o.idx, 0) = gr.c0name.at(a);
+                    }
+                }
             } else if (o.type == operand::kind::num) {
                 e.numpar_override[&o] = dtname(gr.arg_tbl[a]);
+            } else if (a < gr.par_name.size() && !gr.par_name[a].empty()) {
+                e.numpar_override[&o] = gr.par_name[a];
             }
         }
         if (n0.kind == func_kind::prod && n0.args[0].type == operand::kind::num && n0.args[0].value == -1.) {
@@ -490,11 +533,16 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         }
         e.node(rep - n_eq, k);
         const auto gval = e.val(rep, k);
+        // NOTE: constant nodes are exported at every order too (zeros beyond order 0): a reader whose template position
+        // pairs the constant with a variable in another cluster reads it at every order.
         if (gr.exported) {
             os << slabk(k, utname(gr.out_tbl)) << " = " << gval << ";\n";
         }
         for (auto it = saved_vals.rbegin(); it != saved_vals.rend(); ++it) {
             e.val(it->first, k) = it->second;
+        }
+        for (auto it = saved_vals0.rbegin(); it != saved_vals0.rend(); ++it) {
+            e.val(it->first, 0) = it->second;
         }
         e.numpar_override = saved;
 
@@ -673,6 +721,14 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
 
     const auto emit_pair_order = [&](std::uint32_t k) { emit_pair_compute(k, emit_pair_reads(k)); };
 
+    // External inputs which are constant u variables in EVERY cluster (isomorphic clusters may pair a constant with a
+    // variable: the heliocentric alias x_i - 0 and the pair difference x_j - x_i of model::np1body).
+    std::vector<char> ext_const(n_ext, 1);
+    for (std::uint32_t x = 0; x < n_ext; ++x) {
+        for (std::size_t c = 0; c < nc; ++c) {
+            ext_const[x] = (ext_const[x] != 0 && cu[pl.ext_u[c][x]] != 0) ? 1 : 0;
+        }
+    }
     const auto emit_cluster = [&](std::uint32_t k) {
         if (pair_split) {
             emit_pair_order(k);
@@ -682,6 +738,11 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
             e.emit_partials(t0_ids, k, part, n_parts);
         }
         for (std::uint32_t x = 0; x < n_ext; ++x) {
+            if (ext_const[x] != 0 && k > 0u) {
+                // A constant input of every cluster (e.g. -par[i]): read once, at order 0.
+                e.val(pl.ext_u[0][x], k) = "0.0";
+                continue;
+            }
             e.val(pl.ext_u[0][x], k) = e.def(slabk(k, utname(ext_tbl[x])));
         }
         if (overlap) {
@@ -890,6 +951,9 @@ double t_hi = a.time_hi[s], t_lo = a.time_lo[s];
 )HIP";
     for (std::uint32_t i = 0; i < p.n_par; ++i) {
         src << "const double par_" << i << " = a.pars[(u64)" << i << "u * N + s];\n";
+    }
+    for (const auto t : lane_par_tbls) {
+        src << "const double lp" << t << " = a.pars[(u64)" << utname(t) << " * N + s];\n";
     }
     for (const auto &rg : rounds) {
         for (const auto &gr : rg) {

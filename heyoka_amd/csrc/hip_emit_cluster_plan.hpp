@@ -27,6 +27,12 @@ struct cluster_plan {
     std::vector<std::vector<std::uint32_t>> ext_u;   // [cluster][e] -> u index of the e-th external input
     std::vector<std::pair<std::uint32_t, std::uint32_t>> cst_pos; // (template position, arg index) of per-lane constants
     std::vector<std::vector<double>> cst_val;         // [cluster][slot]
+    // Parameter operands of the members whose index differs between the clusters: (template position, arg index)
+    // and, per cluster, the parameter indices (loaded per lane).
+    std::vector<std::pair<std::uint32_t, std::uint32_t>> par_pos;
+    std::vector<std::vector<std::uint32_t>> par_idx;
+    // A glue node has a parameter operand (glue groups are keyed by shape, the parameter index is per lane).
+    bool glue_has_par = false;
     std::vector<std::uint32_t> out_pos;               // template positions whose value is exported
     std::vector<int> slot_of;                         // per u: LDS slot or -1
     std::uint32_t n_slots = 0, n_dummy = 0;
@@ -46,6 +52,9 @@ struct plan_limits {
     // Absorb the linear nodes fed by a single cluster into that cluster (fewer glue rounds). Switched off by
     // make_plan() on a second attempt when the absorption makes otherwise isomorphic clusters differ.
     bool absorb_linear = true;
+    // Parameter operands as per-lane values (the index may differ between isomorphic clusters / the nodes of a glue
+    // group: cluster_plan::par_pos / par_idx, glue_has_par). Off: the index is part of the shape.
+    bool generic_pars = false;
 };
 
 // Build the plan; returns an empty string on success, otherwise the reason why cluster mode is not applicable.

@@ -46,8 +46,11 @@ struct ssa_emitter {
     // vals[k * n_u + u]: name (or literal) of the order-k coefficient of u variable u.
     std::vector<std::string> vals;
 
+    // Constant u variables (constant_uvars(), decompose.hpp).
+    std::vector<char> cu;
+
     ssa_emitter(const taylor_program &prog, std::uint32_t ord)
-        : p(prog), order(ord), vals(static_cast<std::size_t>(prog.n_u) * (ord + 1u))
+        : p(prog), order(ord), vals(static_cast<std::size_t>(prog.n_u) * (ord + 1u)), cu(constant_uvars(prog))
     {
     }
 
@@ -202,7 +205,17 @@ struct ssa_emitter {
                     throw std::invalid_argument("The Taylor derivative of a product can be computed only for "
                                                 "products of 2 terms");
                 }
-                if (is_var(a[0]) && is_var(a[1])) {
+                if (is_var(a[0]) && is_var(a[1]) && (cu[a[0].idx] != 0 || cu[a[1].idx] != 0)) {
+                    // A constant factor (all its coefficients beyond order 0 are zero): the convolution reduces to
+                    // c^[0] * x^[k] - the other k products of the reference's formula are exact zeros.
+                    if (cu[a[0].idx] != 0 && cu[a[1].idx] != 0) {
+                        out = (k == 0u) ? def(mul(val(a[0].idx, 0), val(a[1].idx, 0))) : "0.0";
+                    } else {
+                        const auto &c = (cu[a[0].idx] != 0) ? a[0] : a[1];
+                        const auto &v = (cu[a[0].idx] != 0) ? a[1] : a[0];
+                        out = def(mul(val(c.idx, 0), val(v.idx, k)));
+                    }
+                } else if (is_var(a[0]) && is_var(a[1])) {
                     std::vector<std::string> terms;
                     for (std::uint32_t j = 0; j <= k; ++j) {
                         terms.push_back(def(mul(val(a[0].idx, k - j), val(a[1].idx, j))));
@@ -753,7 +766,7 @@ struct ssa_emitter {
         const auto &a = n.args;
         switch (n.kind) {
             case func_kind::prod:
-                return a.size() == 2u && is_var(a[0]) && is_var(a[1]);
+                return a.size() == 2u && is_var(a[0]) && is_var(a[1]) && cu[a[0].idx] == 0 && cu[a[1].idx] == 0;
             case func_kind::sum_sq:
                 for (const auto &o : a) {
                     if (!is_var(o)) {

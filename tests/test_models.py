@@ -249,6 +249,10 @@ def test_models_step_and_propagate_vs_oracle(name, pins):
         assert m_.startswith("cluster") and "v2" not in m_.split(";")[0] and "aliased" in m_
     if name == "np1body13_default":
         assert ta.hip_source_mode.startswith("block") and "aliased" in ta.hip_source_mode
+    if name == "np1body4_par":
+        # Runtime masses: constant u variables (m_0 + m_i, -m_i ...) are recognised, products with them are linear, and
+        # the system leaves the 21 000-statement unrolled kernel for the wave-cluster stepper.
+        assert ta.hip_source_mode.startswith("cluster")
     if name in ("np1body6", "np1body8_default"):
         # State variables in history-operand position (|r_i|^2 = sum_sq(x_i, y_i, z_i)) are aliased by u variables so that
         # the wave-cluster stepper applies (add_state_aliases(), heyoka_amd/csrc/hip_emit_cluster.cpp).
@@ -382,3 +386,40 @@ def test_np1body_cluster_stepper_equals_table_stepper(pins, monkeypatch):
             res[which] = (ta.state.copy(), [r[3] for r in ta.propagate_res])
         assert res["cluster"][1] == res["table"][1]
         assert rel_err(res["cluster"][0], res["table"][0]) <= 1e5 * EPS
+
+
+@pytest.mark.gpu
+def test_nbody_with_parameter_masses_runs_on_the_cluster_kernel():
+    """model::nbody with kw::masses = par[...] (the non-grouped branch of src/model/nbody.cpp:131-150): the pair clusters
+    differ only by the indices of the parameters they read (per-lane parameter tables) and by constant u variables
+    (-par[i]) in linear position: wave-cluster stepper instead of the table-driven one; results = those of the oracle and of
+    the same system with numerical masses."""
+    from heyoka_amd import configs
+
+    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    n = 48
+    st = configs.outer_ss_state(n, perturb=1e-6, seed=13)
+    pars = np.repeat(np.asarray(M, dtype=np.float64)[:, None], n, axis=1)
+    pars[1:] *= 1 + 1e-3 * np.arange(n) / n  # different planet masses in every system
+    ta = hy.taylor_adaptive_batch(hy.model.nbody(6, masses=[hy.par[i] for i in range(6)], Gconst=G), st, n, pars=pars,
+                                  high_accuracy=True)
+    assert ta.hip_source_mode.startswith("cluster") and "v2" in ta.hip_source_mode, ta.hip_source_mode
+    oi = ho.OracleIntegrator(ho.nbody(6, masses=[ho.par(i) for i in range(6)], Gconst=G), st, n, pars=pars,
+                             high_accuracy=True)
+    ta.step(write_tc=True)
+    oi.step(wtc=True)
+    h_g = np.array([h for _, h in ta.step_res])
+    h_o = np.array([h for _, h in oi.step_res])
+    assert np.max(np.abs(h_g - h_o) / np.abs(h_o)) <= 1e6 * EPS
+    tc_o = oi.tc.reshape(36, oi.order + 1, n)
+    scale = np.max(np.abs(tc_o), axis=0, keepdims=True)
+    assert np.max(np.abs(np.asarray(ta.tc).reshape(36, oi.order + 1, n) - tc_o) / scale) <= 1e6 * EPS
+    assert rel_err(ta.state, oi.state.reshape(36, n)) <= 1e5 * EPS
+    ta.propagate_until(25.0)
+    oi.propagate_until(25.0)
+    assert rel_err(ta.state, oi.state.reshape(36, n)) <= 1e7 * EPS
+    # Lane 0 carries the nominal masses: same trajectory as the numerical-mass system (cluster v3).
+    tn = hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True)
+    tn.step()
+    tn.propagate_until(25.0)
+    assert rel_err(ta.state[:, 0], tn.state[:, 0]) <= 1e7 * EPS
