@@ -700,6 +700,7 @@ emitted_module emit_cluster_or_empty(const taylor_program &, const emit_options 
 emitted_module emit_table(const taylor_program &, const emit_options &);
 emitted_module emit_block(const taylor_program &, const emit_options &, std::string &why_not);
 bool add_state_aliases(const taylor_program &, taylor_program &);
+bool pad_clusters(const taylor_program &, std::uint32_t, taylor_program &);
 
 emitted_module emit_hip_module(const taylor_program &prog, const emit_options &opts)
 {
@@ -729,6 +730,22 @@ emitted_module emit_hip_module(const taylor_program &prog, const emit_options &o
                         return m2;
                     }
                     why += "; with state-variable aliases: " + why2;
+                }
+            }
+            if (m.source.empty() && why.rfind("clusters are not isomorphic", 0) == 0
+                && std::getenv("HEYOKA_AMD_NO_CLUSTER_PADDING") == nullptr) {
+                // Clusters which are sub-shapes of the largest one (test particles next to massive bodies): pad them
+                // in the internal program (see pad_clusters()).
+                taylor_program padded;
+                if (pad_clusters(prog, opts.order, padded)) {
+                    std::string why2;
+                    auto m2 = emit_cluster_or_empty(padded, opts, why2);
+                    if (!m2.source.empty()) {
+                        m2.notes += "; clusters of " + std::to_string(padded.n_u - prog.n_u)
+                                    + " missing members padded to the shape of the largest one";
+                        return m2;
+                    }
+                    why += "; with padded clusters: " + why2;
                 }
             }
             if (m.source.empty() && why.rfind("more than 64 clusters", 0) == 0) {

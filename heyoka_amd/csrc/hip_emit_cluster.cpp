@@ -27,6 +27,8 @@
 // formulas cited in hip_emit_detail.hpp).
 #include <algorithm>
 #include <cstdlib>
+#include <functional>
+#include <limits>
 #include <map>
 #include <numeric>
 #include <set>
@@ -281,6 +283,250 @@ std::string make_plan_impl(const taylor_program &p, std::uint32_t order, cluster
 
 } // namespace
 
+// Clusters of different shapes. When every cluster is a *sub-shape* of the largest one (model::nbody with massless
+// bodies: the pairs with a test particle lack the three reaction products of the massive-massive pairs), the smaller
+// clusters are padded in the INTERNAL program (the user-visible decomposition is untouched, like add_state_aliases())
+// with the members they lack - same kinds and operands as in the template, results nobody reads - so that all the
+// clusters are isomorphic and the wave-cluster steppers apply instead of the table-driven one. The embedding of a
+// cluster into the template is found by backtracking over the (small) member lists: kinds, argument structure
+// (member -> member edges, consistent external inputs, structural numbers) and hidden dependencies must match.
+// Returns false if the program is not of that kind.
+bool pad_clusters(const taylor_program &p, std::uint32_t order, taylor_program &out)
+{
+    using cluster_detail::cluster_plan;
+    cluster_plan pl;
+    const auto why = make_plan_impl(p, order, pl, cluster_detail::plan_limits{});
+    if (why.rfind("clusters are not isomorphic", 0) != 0 || pl.clusters.size() < 2u) {
+        return false;
+    }
+    const auto n_eq = p.n_eq;
+    const auto nc = pl.clusters.size();
+    std::size_t tmax = 0;
+    for (std::size_t c = 1; c < nc; ++c) {
+        if (pl.clusters[c].size() > pl.clusters[tmax].size()) {
+            tmax = c;
+        }
+    }
+    const auto &T = pl.clusters[tmax];
+    std::map<std::uint32_t, std::uint32_t> tpos;
+    for (std::uint32_t q = 0; q < T.size(); ++q) {
+        tpos[T[q]] = q;
+    }
+    const auto structural_number = [](const dc_node &n, std::size_t a) {
+        return (n.kind == func_kind::pow && a == 1u)
+               || (n.kind == func_kind::prod && a == 0u && n.args[0].type == operand::kind::num && n.args[0].value == -1.);
+    };
+    constexpr auto none = std::numeric_limits<std::uint32_t>::max();
+
+    // New members get provisional indices p.n_u, p.n_u + 1, ... and an anchor: the (old) u variable after which they are
+    // inserted, so that the members of a padded cluster come in the order of the template (the planner compares the
+    // clusters member by member, in ascending order of their indices).
+    std::vector<dc_node> new_nodes;
+    std::vector<std::uint32_t> anchor_of; // per new node: old u variable it follows (none: before the first node)
+    std::uint32_t next_u = p.n_u;
+    bool padded_any = false;
+    for (std::size_t c = 0; c < nc; ++c) {
+        if (c == tmax) {
+            continue;
+        }
+        const auto &S = pl.clusters[c];
+        std::map<std::uint32_t, std::uint32_t> spos;
+        for (std::uint32_t q = 0; q < S.size(); ++q) {
+            spos[S[q]] = q;
+        }
+        std::vector<std::uint32_t> f(S.size(), none);      // S position -> T position
+        std::vector<char> used(T.size(), 0);
+        std::map<std::uint32_t, std::uint32_t> ext_t2s, ext_s2t; // external inputs: T's u <-> S's u
+        std::uint64_t budget = 200000;
+        // Try to map S[i], S[i+1], ... (ascending u: the arguments of a member precede it).
+        std::function<bool(std::size_t)> rec = [&](std::size_t i) -> bool {
+            if (i == S.size()) {
+                return true;
+            }
+            if (budget-- == 0u) {
+                return false;
+            }
+            const auto &ns = p.nodes[S[i] - n_eq];
+            for (std::uint32_t q = 0; q < T.size(); ++q) {
+                const auto &nt = p.nodes[T[q] - n_eq];
+                if (used[q] != 0 || nt.kind != ns.kind || nt.args.size() != ns.args.size() || nt.deps.size() != ns.deps.size()) {
+                    continue;
+                }
+                bool ok = true;
+                std::vector<std::pair<std::uint32_t, std::uint32_t>> added; // tentative external pairs (T u, S u)
+                for (std::size_t a = 0; ok && a < ns.args.size(); ++a) {
+                    const auto &so = ns.args[a], &to = nt.args[a];
+                    if (so.type != to.type) {
+                        ok = false;
+                    } else if (is_var(so)) {
+                        const auto it_t = tpos.find(to.idx);
+                        const auto it_s = spos.find(so.idx);
+                        if ((it_t == tpos.end()) != (it_s == spos.end())) {
+                            ok = false;
+                        } else if (it_t != tpos.end()) {
+                            ok = f[it_s->second] == it_t->second;
+                        } else {
+                            const auto e1 = ext_t2s.find(to.idx);
+                            const auto e2 = ext_s2t.find(so.idx);
+                            if (e1 != ext_t2s.end() || e2 != ext_s2t.end()) {
+                                ok = e1 != ext_t2s.end() && e2 != ext_s2t.end() && e1->second == so.idx && e2->second == to.idx;
+                            } else {
+                                ext_t2s[to.idx] = so.idx;
+                                ext_s2t[so.idx] = to.idx;
+                                added.emplace_back(to.idx, so.idx);
+                            }
+                        }
+                    } else if (so.type == operand::kind::num) {
+                        if (structural_number(nt, a) || structural_number(ns, a)) {
+                            ok = so.value == to.value;
+                        }
+                    }
+                }
+                for (std::size_t d = 0; ok && d < ns.deps.size(); ++d) {
+                    const auto it_t = tpos.find(nt.deps[d]);
+                    const auto it_s = spos.find(ns.deps[d]);
+                    ok = it_t != tpos.end() && it_s != spos.end() && f[it_s->second] == it_t->second;
+                }
+                if (ok) {
+                    f[i] = q;
+                    used[q] = 1;
+                    if (rec(i + 1u)) {
+                        return true;
+                    }
+                    used[q] = 0;
+                    f[i] = none;
+                }
+                for (const auto &[tu, su] : added) {
+                    ext_t2s.erase(tu);
+                    ext_s2t.erase(su);
+                }
+            }
+            return false;
+        };
+        if (!rec(0)) {
+            return false;
+        }
+        // Members of the template the cluster lacks: appended to the program, in template order.
+        std::vector<std::uint32_t> inv(T.size(), none); // T position -> u variable of this cluster
+        for (std::size_t i = 0; i < S.size(); ++i) {
+            inv[f[i]] = S[i];
+        }
+        std::uint32_t fallback_ext = none;
+        for (const auto &[su, tu] : ext_s2t) {
+            (void)tu;
+            fallback_ext = su;
+            break;
+        }
+        for (std::uint32_t q = 0; q < T.size(); ++q) {
+            if (inv[q] != none) {
+                continue;
+            }
+            auto nn = p.nodes[T[q] - n_eq];
+            for (auto &o : nn.args) {
+                if (o.type != operand::kind::uvar) {
+                    continue;
+                }
+                if (const auto it = tpos.find(o.idx); it != tpos.end()) {
+                    if (inv[it->second] == none) {
+                        return false; // (template order is topological: cannot happen)
+                    }
+                    o.idx = inv[it->second];
+                } else if (const auto e = ext_t2s.find(o.idx); e != ext_t2s.end()) {
+                    o.idx = e->second;
+                } else if (fallback_ext != none) {
+                    o.idx = fallback_ext;
+                } else {
+                    return false;
+                }
+            }
+            for (auto &d : nn.deps) {
+                const auto it = tpos.find(d);
+                if (it == tpos.end() || inv[it->second] == none) {
+                    return false;
+                }
+                d = inv[it->second];
+            }
+            // Anchor: the member at the previous template position (or its anchor, if that one is new as well).
+            std::uint32_t anc = none;
+            if (q > 0u) {
+                const auto prev = inv[q - 1u];
+                anc = prev < p.n_u ? prev : anchor_of[prev - p.n_u];
+            } else if (!S.empty() && S[0] > n_eq) {
+                anc = S[0] - 1u;
+            }
+            new_nodes.push_back(std::move(nn));
+            anchor_of.push_back(anc);
+            inv[q] = next_u++;
+            padded_any = true;
+        }
+    }
+    if (!padded_any) {
+        return false;
+    }
+    // Rebuild the program with the new members at their places; remap every u-variable index.
+    std::vector<std::uint32_t> new_idx(next_u, none);
+    std::vector<const dc_node *> order_nodes;
+    std::vector<std::uint32_t> order_old; // provisional / old index of the nodes in the new order
+    const auto place_after = [&](std::uint32_t anc) {
+        for (std::size_t j = 0; j < new_nodes.size(); ++j) {
+            if (anchor_of[j] == anc) {
+                order_nodes.push_back(&new_nodes[j]);
+                order_old.push_back(p.n_u + static_cast<std::uint32_t>(j));
+            }
+        }
+    };
+    place_after(none);
+    for (std::uint32_t u = n_eq; u < p.n_u; ++u) {
+        order_nodes.push_back(&p.nodes[u - n_eq]);
+        order_old.push_back(u);
+        place_after(u);
+    }
+    // NOTE: members anchored at a state variable (a cluster whose first member directly follows the state) land first.
+    for (std::uint32_t i = 0; i < n_eq; ++i) {
+        new_idx[i] = i;
+    }
+    for (std::size_t j = 0; j < order_old.size(); ++j) {
+        new_idx[order_old[j]] = n_eq + static_cast<std::uint32_t>(j);
+    }
+    for (std::size_t j = 0; j < new_nodes.size(); ++j) {
+        if (new_idx[p.n_u + j] == none) {
+            return false; // anchored at something which is not a node (cannot happen for anchors >= n_eq)
+        }
+    }
+    out = p;
+    out.nodes.clear();
+    for (const auto *np : order_nodes) {
+        auto nn = *np;
+        for (auto &o : nn.args) {
+            if (o.type == operand::kind::uvar) {
+                o.idx = new_idx[o.idx];
+            }
+        }
+        for (auto &d : nn.deps) {
+            d = new_idx[d];
+        }
+        out.nodes.push_back(std::move(nn));
+    }
+    for (auto &d : out.sv_defs) {
+        if (d.type == operand::kind::uvar) {
+            d.idx = new_idx[d.idx];
+        }
+    }
+    for (auto &e : out.ev_u) {
+        e = new_idx[e];
+    }
+    out.n_u = next_u;
+    // Arguments must precede their users.
+    for (std::size_t j = 0; j < out.nodes.size(); ++j) {
+        for (const auto &o : out.nodes[j].args) {
+            if (o.type == operand::kind::uvar && o.idx >= n_eq + j) {
+                return false;
+            }
+        }
+    }
+    return true;
+}
+
 std::string cluster_detail::make_plan(const taylor_program &p, std::uint32_t order, cluster_plan &pl,
                                       const plan_limits &lim)
 {
@@ -488,7 +734,9 @@ std::string make_plan_impl(const taylor_program &p, std::uint32_t order, cluster
         std::ostringstream sig;
         for (std::uint32_t q = 0; q < mem.size(); ++q) {
             const auto &n = p.nodes[mem[q] - n_eq];
-            sig << func_kind_name(n.kind) << (exported[mem[q]] != 0 ? "!" : "") << '(';
+            // NOTE: whether a member is read from outside is not part of the shape: a position is exported if it is in
+            // any cluster (clusters padded by pad_clusters() carry members nobody reads).
+            sig << func_kind_name(n.kind) << '(';
             for (std::size_t a = 0; a < n.args.size(); ++a) {
                 const auto &o = n.args[a];
                 if (is_var(o)) {
@@ -565,7 +813,11 @@ std::string make_plan_impl(const taylor_program &p, std::uint32_t order, cluster
         }
     }
     for (std::uint32_t q = 0; q < t0.size(); ++q) {
-        if (exported[t0[q]] != 0) {
+        bool any = false;
+        for (std::size_t c = 0; c < nc; ++c) {
+            any = any || exported[pl.clusters[c][q]] != 0;
+        }
+        if (any) {
             pl.out_pos.push_back(q);
         }
     }

@@ -423,3 +423,34 @@ def test_nbody_with_parameter_masses_runs_on_the_cluster_kernel():
     tn.step()
     tn.propagate_until(25.0)
     assert rel_err(ta.state[:, 0], tn.state[:, 0]) <= 1e7 * EPS
+
+
+@pytest.mark.gpu
+def test_test_particles_next_to_parameter_masses_padded_clusters():
+    """model::nbody(6, masses = par[0..3]): two test particles next to four massive bodies. The massive - test-particle pair
+    clusters lack the products acting on the (massless) partner: they are padded in the internal program to the shape of
+    the massive - massive clusters (pad_clusters(), subgraph embedding) and the system runs on the wave-cluster stepper
+    instead of the table-driven one; results = the oracle's on the user-visible (unpadded) decomposition."""
+    from heyoka_amd import configs
+
+    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    n = 40
+    st = configs.outer_ss_state(n, perturb=1e-6, seed=19)
+    pars = np.repeat(np.asarray(M[:4], dtype=np.float64)[:, None], n, axis=1)
+    sys_g = hy.model.nbody(6, masses=[hy.par[i] for i in range(4)], Gconst=G)
+    sys_o = ho.nbody(6, masses=[ho.par(i) for i in range(4)], Gconst=G)
+    assert hy.taylor_decompose_sys(sys_g) == ho.dc_to_strings(ho.taylor_decompose_sys(sys_o))
+    ta = hy.taylor_adaptive_batch(sys_g, st, n, pars=pars, high_accuracy=True)
+    assert ta.hip_source_mode.startswith("cluster") and "padded" in ta.hip_source_mode, ta.hip_source_mode
+    oi = ho.OracleIntegrator(sys_o, st, n, pars=pars, high_accuracy=True)
+    ta.step(write_tc=True)
+    oi.step(wtc=True)
+    h_g = np.array([h for _, h in ta.step_res])
+    h_o = np.array([h for _, h in oi.step_res])
+    assert np.max(np.abs(h_g - h_o) / np.abs(h_o)) <= 1e6 * EPS
+    tc_o = oi.tc.reshape(36, oi.order + 1, n)
+    scale = np.max(np.abs(tc_o), axis=0, keepdims=True)
+    assert np.max(np.abs(np.asarray(ta.tc).reshape(36, oi.order + 1, n) - tc_o) / scale) <= 1e6 * EPS
+    ta.propagate_until(25.0)
+    oi.propagate_until(25.0)
+    assert rel_err(ta.state, oi.state.reshape(36, n)) <= 1e7 * EPS
