@@ -64,7 +64,9 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         // NOTE: at most 16 pairs (two systems per wavefront). With 17 .. 32 pairs (one system per wavefront, e.g.
         // model::np1body(8)) the generated kernel did not terminate on the hardware (round 2, not yet understood):
         // those systems stay on the one-lane-per-cluster kernel.
-        pp.ok = ok && 2u * nc <= 32u && p.n_par == 0u && !(ev != nullptr && std::atoi(ev) == 0);
+        const char *evm = std::getenv("HEYOKA_AMD_PAIR_SPLIT_MAX_LANES"); // (experiments: 64)
+        const auto max_lanes = evm != nullptr ? static_cast<std::uint32_t>(std::atoi(evm)) : 32u;
+        pp.ok = ok && 2u * nc <= max_lanes && p.n_par == 0u && !(ev != nullptr && std::atoi(ev) == 0);
     }
     const bool pair_split = pp.ok;
     if (pair_split) {

@@ -1283,3 +1283,50 @@ def test_wave_role_kernel_v4_opt_in_matches_the_default_kernel(monkeypatch):
     ora.step()
     ora.propagate_until(30.0)
     assert rel_err(a.state, ora.state.reshape(36, n)) <= 1e6 * EPS
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["v3", "v2", "v4"])
+def test_cluster_kernels_loop_control_semantics(kernel, monkeypatch):
+    """The wave-uniform step loop of the cluster kernels (a finished system keeps taking zero-length steps with frozen
+    bookkeeping until the other systems of its wavefront / workgroup are done): per-lane final times forward and backward
+    with a max_delta_t clamp, max_steps, zero-length propagation, the raw step - against the oracle, for the lane-pair
+    (v3), one-lane-per-cluster (v2) and wave-role (v4) variants."""
+    if kernel == "v2":
+        monkeypatch.setenv("HEYOKA_AMD_PAIR_SPLIT", "0")
+    if kernel == "v4":
+        monkeypatch.setenv("HEYOKA_AMD_WAVE_ROLES", "1")
+    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    n = 22  # ragged: the last wavefront / workgroup holds replicas
+    rng = np.random.RandomState(31)
+    st = configs.outer_ss_state(n, perturb=1e-7, seed=23)
+    ta = hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True)
+    assert kernel in ta.hip_source_mode
+    ora = ho.OracleIntegrator(ho.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True)
+    # Very different final times inside one wavefront (systems finish after 0 ... ~40 steps), both directions.
+    tf = rng.uniform(-30.0, 30.0, n)
+    tf[3] = 0.0
+    ta.propagate_until(tf, max_delta_t=0.9)
+    ora.propagate_until(tf, max_delta_t=0.9)
+    assert [int(r[0]) for r in ta.propagate_res] == [int(r[0]) for r in ora.prop_res]
+    assert max(abs(int(a[3]) - int(b[3])) for a, b in zip(ta.propagate_res, ora.prop_res)) <= 1
+    assert np.array_equal(ta.time, tf)
+    assert rel_err(ta.state, ora.state.reshape(36, n)) <= 1e6 * EPS
+    mn_g = np.array([r[1] for r in ta.propagate_res])[tf != 0]
+    mn_o = np.array([r[1] for r in ora.prop_res])[tf != 0]
+    assert np.max(np.abs(mn_g - mn_o) / mn_o) <= 1e-6
+    # max_steps: every lane which is not done reports the step limit after exactly 3 steps (per-lane counter).
+    ta.propagate_until(tf + 200.0, max_steps=3)
+    assert all(r[0] == OC.step_limit and r[3] == 3 for r in ta.propagate_res)
+    # Zero-length propagation.
+    ta.propagate_for(0.0)
+    assert all(r[0] == OC.time_limit and r[3] == 0 for r in ta.propagate_res)
+    # Single steps with per-lane limits (some negative, one zero).
+    ora2 = ho.OracleIntegrator(ho.nbody(6, masses=M, Gconst=G), ta.state, n, high_accuracy=True, time=ta.time)
+    lims = rng.uniform(-0.5, 0.5, n)
+    lims[5] = 0.0
+    ta.step(lims)
+    ora2.step(max_delta_ts=lims)
+    assert [int(o) for o, _ in ta.step_res] == [int(o) for o, _ in ora2.step_res]
+    assert np.allclose([h for _, h in ta.step_res], [h for _, h in ora2.step_res], rtol=1e-9, atol=0)
+    assert rel_err(ta.state, ora2.state.reshape(36, n)) <= 1e5 * EPS
