@@ -46,7 +46,7 @@ std::shared_ptr<const compiled_module> hiprtc_compile(const emitted_module &m)
     // of the cache key.
     const std::string cache_key = [&]() {
         const char *ex = std::getenv("HEYOKA_AMD_HIPRTC_FLAGS");
-        return (ex != nullptr ? std::string(ex) + "\n" : std::string{}) + m.source;
+        return (ex != nullptr ? std::string(ex) + "\n" : std::string{}) + m.compile_flags + "\n" + m.source;
     }();
     {
         std::lock_guard lock(cache_mutex);
@@ -66,8 +66,9 @@ std::shared_ptr<const compiled_module> hiprtc_compile(const emitted_module &m)
     std::vector<const char *> opts = {"--offload-arch=gfx950", "-O3", "-ffp-contract=fast", "-std=c++17"};
     const char *extra = std::getenv("HEYOKA_AMD_HIPRTC_FLAGS");
     std::vector<std::string> extra_store;
-    if (extra != nullptr) {
-        std::string s(extra);
+    if (extra != nullptr || !m.compile_flags.empty()) {
+        // (Module flags first: the environment can override them.)
+        std::string s = m.compile_flags + " " + (extra != nullptr ? extra : "");
         std::size_t pos = 0;
         while (pos < s.size()) {
             const auto next = s.find(' ', pos);

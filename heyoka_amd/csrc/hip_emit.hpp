@@ -72,6 +72,8 @@ struct emitted_module {
     // Cluster mode: doubles of jet scratch needed per resident wave.
     std::uint64_t scratch_per_wave = 0;
     bool persistent = false;
+    // Extra hiprtc options of the module (space separated), on top of the common ones.
+    std::string compile_flags;
 };
 
 emitted_module emit_hip_module(const taylor_program &prog, const emit_options &opts);

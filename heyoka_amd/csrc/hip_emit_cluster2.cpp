@@ -238,6 +238,57 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     struct pair_tables {
         std::size_t s0 = 0, s1 = 0, p0 = 0, p1 = 0, os = 0, op = 0, rs = 0, rp = 0, csc = 0, crs = 0, crp = 0;
     } pt;
+    // Reaction fusion (lane-pair variant): the members c * pr of a cluster (the reaction on the second body of the pair)
+    // are not computed / exported by the cluster lanes: the glue sums which read them read the direct product pr instead
+    // and multiply it by a per-lane coefficient (c, or 1.0 where the sum reads the direct product itself: exact, so the
+    // rounding sequence of every term is the one of the separate node). Two LDS stores less per order and lane.
+    // rx_fused[u] = 1 for the fused members; rx_src[u] = the product they scale.
+    std::vector<char> rx_fused(p.n_u, 0);
+    std::vector<std::uint32_t> rx_src(p.n_u, 0);
+    bool fuse_rx = false;
+    if (pair_split && pp.rx[0] >= 0) {
+        const char *ev = std::getenv("HEYOKA_AMD_V3_FUSE_RX");
+        fuse_rx = !(ev != nullptr && std::atoi(ev) == 0);
+        for (std::size_t c = 0; c < nc; ++c) {
+            for (std::uint32_t i = 0; i < 3u; ++i) {
+                const auto u = pl.clusters[c][static_cast<std::uint32_t>(pp.rx[i])];
+                rx_fused[u] = 1;
+                rx_src[u] = pl.clusters[c][pp.pr[i]];
+            }
+        }
+        std::vector<char> in_sum_group(p.n_u, 0);
+        for (const auto &g : pl.groups) {
+            const auto &n0 = p.nodes[g.nodes[0] - n_eq];
+            const bool all_var = std::all_of(n0.args.begin(), n0.args.end(), [](const operand &o) { return is_var(o); });
+            if (n0.kind == func_kind::sum && all_var) {
+                for (const auto u : g.nodes) {
+                    in_sum_group[u] = 1;
+                }
+            }
+        }
+        for (std::uint32_t u = n_eq; fuse_rx && u < p.n_u; ++u) {
+            for (const auto &o : p.nodes[u - n_eq].args) {
+                if (is_var(o) && rx_fused[o.idx] != 0 && in_sum_group[u] == 0) {
+                    fuse_rx = false;
+                }
+            }
+        }
+        for (const auto &d : p.sv_defs) {
+            if (is_var(d) && rx_fused[d.idx] != 0) {
+                fuse_rx = false;
+            }
+        }
+        if (!fuse_rx) {
+            std::fill(rx_fused.begin(), rx_fused.end(), 0);
+        }
+    }
+    // Slab slot through which a product pr travels (its own, or - when only its reaction was exported - that one's).
+    const auto pr_slot = [&](std::uint32_t pr_u, std::uint32_t rx_u, std::uint32_t dflt) {
+        if (pl.slot_of[pr_u] >= 0) {
+            return static_cast<std::uint32_t>(pl.slot_of[pr_u]);
+        }
+        return (fuse_rx && pl.slot_of[rx_u] >= 0) ? static_cast<std::uint32_t>(pl.slot_of[rx_u]) : dflt;
+    };
     if (pair_split) {
         const auto slot_or = [&](std::uint32_t u, std::uint32_t dflt) {
             return pl.slot_of[u] >= 0 ? static_cast<std::uint32_t>(pl.slot_of[u]) : dflt;
@@ -257,9 +308,15 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
             s1[l] = ext(ds, 1);
             p0[l] = rb ? s0[l] : ext(1, 0);
             p1[l] = rb ? s0[l] : ext(1, 1);
-            os_[l] = valid ? slot_or(cl[pp.pr[ds]], dummy_base) : dummy_base;
-            op[l] = (valid && !rb) ? slot_or(cl[pp.pr[1]], dummy_base + 1u) : dummy_base + 1u;
-            if (pp.rx[0] >= 0) {
+            if (fuse_rx) {
+                os_[l] = valid ? pr_slot(cl[pp.pr[ds]], cl[static_cast<std::uint32_t>(pp.rx[ds])], dummy_base) : dummy_base;
+                op[l] = (valid && !rb) ? pr_slot(cl[pp.pr[1]], cl[static_cast<std::uint32_t>(pp.rx[1])], dummy_base + 1u)
+                                       : dummy_base + 1u;
+            } else {
+                os_[l] = valid ? slot_or(cl[pp.pr[ds]], dummy_base) : dummy_base;
+                op[l] = (valid && !rb) ? slot_or(cl[pp.pr[1]], dummy_base + 1u) : dummy_base + 1u;
+            }
+            if (pp.rx[0] >= 0 && !fuse_rx) {
                 rs[l] = valid ? slot_or(cl[static_cast<std::uint32_t>(pp.rx[ds])], dummy_base + 2u) : dummy_base + 2u;
                 rp[l] = (valid && !rb) ? slot_or(cl[static_cast<std::uint32_t>(pp.rx[1])], dummy_base + 3u) : dummy_base + 3u;
                 crs[l] = p.nodes[cl[static_cast<std::uint32_t>(pp.rx[ds])] - n_eq].args[0].value;
@@ -275,7 +332,7 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         pt.p1 = add_utbl(std::move(p1));
         pt.os = add_utbl(std::move(os_));
         pt.op = add_utbl(std::move(op));
-        if (pp.rx[0] >= 0) {
+        if (pp.rx[0] >= 0 && !fuse_rx) {
             pt.rs = add_utbl(std::move(rs));
             pt.rp = add_utbl(std::move(rp));
             pt.crs = add_dtbl(std::move(crs));
@@ -345,6 +402,7 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         std::vector<owner_slot> owners;
         std::vector<std::string> par_name; // per-lane parameter value names, by argument (empty: none)
         std::vector<std::string> c0name;   // names of the constant operands read at order 0, by argument
+        std::vector<std::size_t> coef_tbl; // reaction fusion: per-lane coefficient tables, by argument (empty: not fused)
     };
     std::vector<std::vector<glue_round>> rounds(pl.groups.size());
     std::uint32_t n_own = 0, n_col_acc = 0;
@@ -369,8 +427,28 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
                 const auto j = r * L + l;
                 return grp.nodes[j < n_nodes ? j : r * L];
             };
+            bool round_fused = false;
+            for (std::uint32_t l = 0; fuse_rx && l < L; ++l) {
+                for (const auto &o : p.nodes[node_of(l) - n_eq].args) {
+                    round_fused = round_fused || (is_var(o) && rx_fused[o.idx] != 0);
+                }
+            }
             for (std::size_t a = 0; a < n0.args.size(); ++a) {
-                if (is_var(n0.args[a])) {
+                if (is_var(n0.args[a]) && round_fused) {
+                    std::vector<std::uint32_t> v(L);
+                    std::vector<double> cf(L, 1.);
+                    for (std::uint32_t l = 0; l < L; ++l) {
+                        const auto ua = p.nodes[node_of(l) - n_eq].args[a].idx;
+                        if (rx_fused[ua] != 0) {
+                            v[l] = pr_slot(rx_src[ua], ua, 0);
+                            cf[l] = p.nodes[ua - n_eq].args[0].value;
+                        } else {
+                            v[l] = static_cast<std::uint32_t>(pl.slot_of[ua]);
+                        }
+                    }
+                    gr.arg_tbl.push_back(add_utbl(std::move(v)));
+                    gr.coef_tbl.push_back(add_dtbl(std::move(cf)));
+                } else if (is_var(n0.args[a])) {
                     std::vector<std::uint32_t> v(L);
                     for (std::uint32_t l = 0; l < L; ++l) {
                         v[l] = static_cast<std::uint32_t>(pl.slot_of[p.nodes[node_of(l) - n_eq].args[a].idx]);
@@ -509,7 +587,35 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         const auto &n0 = p.nodes[rep - n_eq];
         const auto saved = e.numpar_override;
         std::vector<std::pair<std::uint32_t, std::string>> saved_vals, saved_vals0;
-        for (std::size_t a = 0; a < n0.args.size(); ++a) {
+        std::string fused_val;
+        if (!gr.coef_tbl.empty()) {
+            // Sum of scaled products, pairwise like the sum rule: ((t0 + t1) + (t2 + t3)) + ..., t_i = c_i * p_i, the
+            // first product of every pair fused into the addition.
+            std::vector<std::string> terms;
+            for (std::size_t a = 0; a + 1u < names.size(); a += 2u) {
+                const auto m = e.def(ssa_emitter::mul(dtname(gr.coef_tbl[a + 1u]), names[a + 1u]));
+                terms.push_back(e.def("__builtin_fma(" + dtname(gr.coef_tbl[a]) + ", " + names[a] + ", " + m + ")"));
+            }
+            const bool odd = names.size() % 2u == 1u;
+            while (terms.size() > 1u) {
+                std::vector<std::string> nt;
+                for (std::size_t i = 0; i + 1u < terms.size(); i += 2u) {
+                    nt.push_back(e.def(terms[i] + " + " + terms[i + 1u]));
+                }
+                if (terms.size() % 2u == 1u) {
+                    nt.push_back(terms.back());
+                }
+                terms = std::move(nt);
+            }
+            if (odd) {
+                const auto a = names.size() - 1u;
+                fused_val = terms.empty() ? e.def(ssa_emitter::mul(dtname(gr.coef_tbl[a]), names[a]))
+                                          : e.def("__builtin_fma(" + dtname(gr.coef_tbl[a]) + ", " + names[a] + ", " + terms[0] + ")");
+            } else {
+                fused_val = terms[0];
+            }
+        }
+        for (std::size_t a = 0; fused_val.empty() && a < n0.args.size(); ++a) {
             const auto &o = n0.args[a];
             if (is_var(o)) {
                 saved_vals.emplace_back(o.idx, e.val(o.idx, k));
@@ -533,8 +639,10 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         if (n0.kind == func_kind::prod && n0.args[0].type == operand::kind::num && n0.args[0].value == -1.) {
             e.numpar_override.erase(&n0.args[0]);
         }
-        e.node(rep - n_eq, k);
-        const auto gval = e.val(rep, k);
+        if (fused_val.empty()) {
+            e.node(rep - n_eq, k);
+        }
+        const auto gval = fused_val.empty() ? e.val(rep, k) : fused_val;
         // NOTE: constant nodes are exported at every order too (zeros beyond order 0): a reader whose template position
         // pairs the constant with a variable in another cluster reads it at every order.
         if (gr.exported) {
@@ -623,6 +731,11 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     std::string hc1, hc2, hc3, hc4, hmid;
     const bool has_rx = pp.rx[0] >= 0;
     std::string rb1;   // 1 / b_0 (lane B)
+    // (Experiment switch: the previous formulation, q = num / (k b_0) with r = RN(1 / b_0) RN(1 / k).)
+    const bool div_by_kb0 = [&]() {
+        const char *ev = std::getenv("HEYOKA_AMD_V3_DIV_KB0");
+        return ev != nullptr && std::atoi(ev) != 0;
+    }();
     std::string ap0x2; // 2 aP[0]
     const auto emit_pair_reads = [&](std::uint32_t k) {
         const auto rd = [&](std::size_t t) { return e.def(slabk(k, utname(t))); };
@@ -668,13 +781,23 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
                 num = e.def(fp_literal(pp.ex * static_cast<double>(k)) + " * " + c1a + " + " + hc2);
             }
             // Division by k * b_0 (src/math/pow.cpp:546-549) without a division sequence on the critical path:
-            // q0 = num * r, r = RN(1 / b_0) * RN(1 / k); residual rem = num - dv * q0 (exact, FMA); q = q0 + rem * r
-            // (Markstein: the correctly-rounded quotient unless r is off by more than an ulp in a halfway case).
-            const auto dv = e.def(ssa_emitter::mul(fp_literal(static_cast<double>(k)), aP[0]));
-            const auto rk = (k == 1u) ? rb1 : e.def(ssa_emitter::mul(rb1, fp_literal(1. / static_cast<double>(k))));
-            const auto q0 = e.def(ssa_emitter::mul(num, rk));
-            const auto rem = e.def("__builtin_fma(-" + dv + ", " + q0 + ", " + num + ")");
-            const auto sab = e.def("__builtin_fma(" + rem + ", " + rk + ", " + q0 + ")");
+            // n = num * RN(1 / k), q0 = n * r with r = RN(1 / b_0); residual rem = n - b_0 * q0 (exact, FMA);
+            // q = q0 + rem * r (Markstein: the correctly-rounded n / b_0 unless r is off by more than an ulp in a
+            // halfway case; n itself carries the rounding of the scaling by 1 / k, so q is within 1.5 ulp of the
+            // quotient num / (k b_0) the reference rounds once).
+            std::string sab;
+            if (div_by_kb0) {
+                const auto dv = e.def(ssa_emitter::mul(fp_literal(static_cast<double>(k)), aP[0]));
+                const auto rk = (k == 1u) ? rb1 : e.def(ssa_emitter::mul(rb1, fp_literal(1. / static_cast<double>(k))));
+                const auto q0 = e.def(ssa_emitter::mul(num, rk));
+                const auto rem = e.def("__builtin_fma(-" + dv + ", " + q0 + ", " + num + ")");
+                sab = e.def("__builtin_fma(" + rem + ", " + rk + ", " + q0 + ")");
+            } else {
+                const auto nk = (k == 1u) ? num : e.def(ssa_emitter::mul(num, fp_literal(1. / static_cast<double>(k))));
+                const auto q0 = e.def(ssa_emitter::mul(nk, rb1));
+                const auto rem = e.def("__builtin_fma(-" + aP[0] + ", " + q0 + ", " + nk + ")");
+                sab = e.def("__builtin_fma(" + rem + ", " + rb1 + ", " + q0 + ")");
+            }
             const auto sao = e.def("hy_swap1(" + sab + ")");
             aR[k] = e.def(sab + " + " + sao);
         }
@@ -692,7 +815,7 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         }
         os << slabk(k, utname(pt.os)) << " = " << prS << ";\n";
         os << slabk(k, utname(pt.op)) << " = " << prP << ";\n";
-        if (has_rx) {
+        if (has_rx && !fuse_rx) {
             const auto rS = e.def(ssa_emitter::mul(dtname(pt.crs), prS));
             const auto rP = e.def(ssa_emitter::mul(dtname(pt.crp), prP));
             os << slabk(k, utname(pt.rs)) << " = " << rS << ";\n";
@@ -865,6 +988,16 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     src << prelude;
     emit_detail::emit_dout(src, p, opts);
     src << emit_detail::wsync_macro;
+    src << R"HIP(
+template <int CTRL>
+__device__ __forceinline__ double hy_dpp(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+)HIP";
     if (pair_split) {
         // Exchange between the two lanes of a pair: DPP quad_perm [1,0,3,2] on the two halves of the double.
         src << R"HIP(
@@ -1008,10 +1141,28 @@ lim = fin ? 0.0 : lim;
 )HIP";
     src << body;
 
+    // Maximum over the lanes of the system: DPP stages where a DPP pattern yields an all-reduce step (xor 1, xor 2 within
+    // quads; rotations by 4 and 8 within rows of 16 lanes once the quads are uniform), ds_bpermute for the others.
     for (std::uint32_t m = 1; m < L; m *= 2u) {
-        src << "m0 = hy_max(m0, __shfl_xor(m0, " << m << ", 64));\n";
-        src << "mo = hy_max(mo, __shfl_xor(mo, " << m << ", 64));\n";
-        src << "mom1 = hy_max(mom1, __shfl_xor(mom1, " << m << ", 64));\n";
+        const auto ex = [&](const char *v) -> std::string {
+            const bool dpp_ok = std::getenv("HEYOKA_AMD_NO_DPP_REDUCE") == nullptr;
+            if (dpp_ok && m == 1u) {
+                return std::string("hy_dpp<0xB1>(") + v + ")";
+            }
+            if (dpp_ok && m == 2u) {
+                return std::string("hy_dpp<0x4E>(") + v + ")";
+            }
+            if (dpp_ok && m == 4u && L % 16u == 0u) {
+                return std::string("hy_dpp<0x124>(") + v + ")";
+            }
+            if (dpp_ok && m == 8u && L % 16u == 0u) {
+                return std::string("hy_dpp<0x128>(") + v + ")";
+            }
+            return std::string("__shfl_xor(") + v + ", " + std::to_string(m) + ", 64)";
+        };
+        src << "m0 = hy_max(m0, " << ex("m0") << ");\n";
+        src << "mo = hy_max(mo, " << ex("mo") << ");\n";
+        src << "mom1 = hy_max(mom1, " << ex("mom1") << ");\n";
     }
     src << "const double num_rho = (m0 <= 1.0) ? 1.0 : m0;\n";
     src << "const double rho_o = hy_root(num_rho / mo, " << fp_literal(1. / static_cast<double>(order)) << ");\n";
@@ -1058,8 +1209,13 @@ int nfi = !(hy_finite(nt_hi) && hy_finite(nt_lo)) ? 1 : 0;
         // (The dummy column holds finite copies.)
         src << "nfi |= !hy_finite(xn" << c << ") ? 1 : 0;\n";
     }
-    for (std::uint32_t m = 1; m < L; m *= 2u) {
-        src << "nfi |= __shfl_xor(nfi, " << m << ", 64);\n";
+    // Any lane of the system: one ballot, then the bits of the system's lanes.
+    src << "{\nconst u64 nfb = __builtin_amdgcn_ballot_w64(nfi != 0);\n";
+    if (L == 64u) {
+        src << "nfi = (nfb != 0ull) ? 1 : 0;\n}\n";
+    } else {
+        src << "nfi = (((nfb >> ((threadIdx.x & 63u) & " << (64u - L) << "u)) & " << ((std::uint64_t(1) << L) - 1u)
+            << "ull) != 0ull) ? 1 : 0;\n}\n";
     }
     // Taylor coefficients on request (wave-uniform branch). NOTE: every lane stores: the idle lanes of a partially filled
     // owner slot replicate the variable of a valid lane and the lanes beyond the end of the ensemble replicate the
@@ -1160,6 +1316,13 @@ if (l == 0u && live) {
     ret.n_statements = e.n_stmt;
     ret.scratch_per_wave = jet_lds ? 0u : jet_doubles_per_wave;
     ret.persistent = true;
+    if (pair_split) {
+        // NOTE: MachineLICM hoists the materialisation of ~50 fp64 literals (1 / k, the polynomial constants of the
+        // step-size selector) out of the step loop into SGPR pairs: pointers and masks are then spilled to VGPR lanes and
+        // come back through 186 v_readlane_b32 per step (VALU issue slots). Without it: 20, and 7 % fewer VALU
+        // instructions in the loop (measured: +2 % system-steps/s, profiles/experiments/run17.sh).
+        ret.compile_flags = "-mllvm -disable-machine-licm";
+    }
     ret.tc_optional = true;
     ret.notes = std::string(pair_split ? "cluster mode v3 (lane pairs, 2 wavefronts per SIMD): " : "cluster mode v2 (pipelined): ")
                 + std::to_string(nc) + " clusters of " + std::to_string(t0.size())
