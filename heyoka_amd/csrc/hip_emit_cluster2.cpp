@@ -561,7 +561,7 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         // NOTE: the idle lanes of a partially filled slot hold a copy of a valid lane's coefficient: harmless in a maximum.
         const char *acc = (k == 0u) ? "m0" : (k == order ? "mo" : (k == order - 1u ? "mom1" : nullptr));
         if (acc != nullptr) {
-            os << acc << " = hy_max(" << acc << ", fabs(" << name << "));\n";
+            os << acc << " = hy_nmax(" << acc << ", fabs(" << name << "));\n";
         }
     };
 
@@ -736,6 +736,15 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         const char *ev = std::getenv("HEYOKA_AMD_V3_DIV_KB0");
         return ev != nullptr && std::atoi(ev) != 0;
     }();
+    // Normalised pow recurrence (default): lane B keeps b_k / b_0 (k >= 1) instead of b_k, one multiplication by
+    // RN(1 / b_0) folded into the FMA which forms the lane's aP[k]; the recurrence k b_0 a_k = sum(...) then needs no
+    // division: a_k = alpha S1 - (alpha + 1) S2 / k on the normalised sums. The new coefficient goes to both lanes of
+    // the pair with one DPP broadcast from the odd lane. HEYOKA_AMD_V3_POW_DIV=1: the previous formulation (quotient by
+    // b_0 with a Markstein correction, within 1.5 ulp of the reference's single division).
+    const bool pow_norm = [&]() {
+        const char *ev = std::getenv("HEYOKA_AMD_V3_POW_DIV");
+        return !(ev != nullptr && std::atoi(ev) != 0) && !div_by_kb0;
+    }();
     std::string ap0x2; // 2 aP[0]
     const auto emit_pair_reads = [&](std::uint32_t k) {
         const auto rd = [&](std::size_t t) { return e.def(slabk(k, utname(t))); };
@@ -762,7 +771,7 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         const auto mine = e.def("__builtin_fma(fA, " + sqy + ", " + sqS + ")");
         const auto oth = e.def("hy_swap1(" + mine + ")");
         const auto r2 = e.def(mine + " + " + oth);
-        aP[k] = e.def("__builtin_fma(fB, " + r2 + ", " + dP + ")");
+        aP[k] = e.def("__builtin_fma(" + std::string((pow_norm && k >= 1u) ? "rb1n" : "fB") + ", " + r2 + ", " + dP + ")");
         std::string c1a;
         if (k == 0u) {
             // NOTE: the sum of squares is the same on both lanes: each of them evaluates the pow itself.
@@ -770,11 +779,25 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
             aR[0] = pp.sc >= 0 ? e.def(ssa_emitter::mul(dtname(pt.csc), a0)) : a0;
             // (Zero on lane A: its quotient below is then an exact zero and sa_k = own + partner's.)
             rb1 = e.def("isB ? (1.0 / " + aP[0] + ") : 0.0");
+            if (pow_norm) {
+                os << "const double rb1n = " << rb1 << ";\n";
+            }
             ap0x2 = e.def(aP[0] + " + " + aP[0]);
         } else {
             c1a = e.chain(hc1, aP[k], aR[0]);
             // NOTE: lane B keeps -(alpha + 1) j sa_j in aRp, so that its c2 chain is -(alpha + 1) S2 right away.
             std::string num;
+            if (pow_norm) {
+                const auto m = e.def(ssa_emitter::mul(fp_literal(pp.ex), c1a));
+                const auto sab = hc2.empty() ? m
+                                             : e.def("__builtin_fma(" + hc2 + ", " + fp_literal(1. / static_cast<double>(k)) + ", " + m + ")");
+                // (Masked to the B lanes: the value doubles as the operand of aRp below.)
+                const auto t = e.def(ssa_emitter::mul("fB", sab));
+                aR[k] = e.def("hy_dpp<0xF5>(" + t + ")");
+                if (k + 2u <= order) {
+                    aRp[k] = e.def("__builtin_fma(" + fp_literal(-(pp.ex + 1.) * static_cast<double>(k)) + ", " + t + ", " + dP + ")");
+                }
+            } else {
             if (hc2.empty()) {
                 num = e.def(ssa_emitter::mul(fp_literal(pp.ex * static_cast<double>(k)), c1a));
             } else {
@@ -800,8 +823,9 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
             }
             const auto sao = e.def("hy_swap1(" + sab + ")");
             aR[k] = e.def(sab + " + " + sao);
+            }
         }
-        if (k >= 1u && k + 2u <= order) {
+        if (!pow_norm && k >= 1u && k + 2u <= order) {
             const auto t = e.def(ssa_emitter::mul("fB", aR[k]));
             aRp[k] = e.def("__builtin_fma(" + fp_literal(-(pp.ex + 1.) * static_cast<double>(k)) + ", " + t + ", " + dP + ")");
         }
@@ -985,10 +1009,27 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     // ===================== module text =====================
     std::ostringstream src;
     src << "#define SPW " << spw << "u\n";
+    if (std::getenv("HEYOKA_AMD_NO_NMAX") != nullptr) {
+        src << "#define HY_NO_NMAX 1\n";
+    }
     src << prelude;
     emit_detail::emit_dout(src, p, opts);
     src << emit_detail::wsync_macro;
     src << R"HIP(
+// Maximum of the norm accumulators. They start from 0.0 and (a < b) ? b : a never selects a NaN b: the first operand
+// is never a NaN, and for such operands the IEEE maximum (one instruction: it returns the non-NaN operand) is the same
+// function as the comparison + select of hy_max(). (Written as the instruction itself: fmax() would first canonicalise
+// every operand which comes out of a lane exchange, one more v_max_f64 each.)
+__device__ __forceinline__ double hy_nmax(double a, double b)
+{
+#if defined(HY_NO_NMAX)
+    return hy_max(a, b);
+#else
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#endif
+}
 template <int CTRL>
 __device__ __forceinline__ double hy_dpp(double x)
 {
@@ -1160,15 +1201,23 @@ lim = fin ? 0.0 : lim;
             }
             return std::string("__shfl_xor(") + v + ", " + std::to_string(m) + ", 64)";
         };
-        src << "m0 = hy_max(m0, " << ex("m0") << ");\n";
-        src << "mo = hy_max(mo, " << ex("mo") << ");\n";
-        src << "mom1 = hy_max(mom1, " << ex("mom1") << ");\n";
+        src << "m0 = hy_nmax(m0, " << ex("m0") << ");\n";
+        src << "mo = hy_nmax(mo, " << ex("mo") << ");\n";
+        src << "mom1 = hy_nmax(mom1, " << ex("mom1") << ");\n";
     }
     src << "const double num_rho = (m0 <= 1.0) ? 1.0 : m0;\n";
-    src << "const double rho_o = hy_root(num_rho / mo, " << fp_literal(1. / static_cast<double>(order)) << ");\n";
-    src << "const double rho_om1 = hy_root(num_rho / mom1, " << fp_literal(1. / static_cast<double>(order - 1u))
-        << ");\n";
-    src << "const double rho_m = hy_min(rho_o, rho_om1);\n";
+    // NOTE: rho = exp(log(x) / order) (hy_root): the minimum of the two estimates is taken on the exponents (exp is
+    // monotone and keeps NaNs: the same selection as min(rho_o, rho_om1), src/taylor_02.cpp:1050-1072, one exp less).
+    if (std::getenv("HEYOKA_AMD_RHO_2EXP") != nullptr) {
+        src << "const double rho_o = hy_root(num_rho / mo, " << fp_literal(1. / static_cast<double>(order)) << ");\n";
+        src << "const double rho_om1 = hy_root(num_rho / mom1, " << fp_literal(1. / static_cast<double>(order - 1u))
+            << ");\n";
+        src << "const double rho_m = hy_min(rho_o, rho_om1);\n";
+    } else {
+    src << "const double lr_o = log(num_rho / mo) * " << fp_literal(1. / static_cast<double>(order)) << ";\n";
+    src << "const double lr_om1 = log(num_rho / mom1) * " << fp_literal(1. / static_cast<double>(order - 1u)) << ";\n";
+    src << "const double rho_m = exp(hy_min(lr_o, lr_om1));\n";
+    }
     src << "double h = rho_m * " << fp_literal(rhofac(order)) << ";\n";
     src << "h = hy_min(h, fabs(lim));\nh = (lim < 0.0) ? -h : h;\n";
 
