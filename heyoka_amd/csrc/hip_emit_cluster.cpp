@@ -312,10 +312,8 @@ bool pad_clusters(const taylor_program &p, std::uint32_t order, taylor_program &
     for (std::uint32_t q = 0; q < T.size(); ++q) {
         tpos[T[q]] = q;
     }
-    const auto structural_number = [](const dc_node &n, std::size_t a) {
-        return (n.kind == func_kind::pow && a == 1u)
-               || (n.kind == func_kind::prod && a == 0u && n.args[0].type == operand::kind::num && n.args[0].value == -1.);
-    };
+    // (Like the cluster signatures of make_plan(): a factor -1 is an ordinary per-cluster constant.)
+    const auto structural_number = [](const dc_node &n, std::size_t a) { return n.kind == func_kind::pow && a == 1u; };
     constexpr auto none = std::numeric_limits<std::uint32_t>::max();
 
     // New members get provisional indices p.n_u, p.n_u + 1, ... and an anchor: the (old) u variable after which they are
@@ -759,9 +757,13 @@ std::string make_plan_impl(const taylor_program &p, std::uint32_t order, cluster
                     } else {
                         sig << 'p' << o.idx;
                     }
-                } else if (structural_number(n, a)) {
+                } else if (n.kind == func_kind::pow && a == 1u) {
                     sig << 'n' << fp_literal(o.value);
                 } else {
+                    // NOTE: a factor -1 (a negation in the decomposition) is an ordinary constant here: -G m_i is -1 for a
+                    // unit mass in G = 1 units and something else for the other bodies. Identical across the clusters ->
+                    // it stays in the node (and the emitter negates); otherwise it becomes a per-lane constant and the
+                    // emitter multiplies (ssa_emitter::node() checks for an override before taking the shortcut).
                     sig << 'c';
                     num_pos[c].emplace_back(q, static_cast<std::uint32_t>(a));
                     num_val[c].push_back(o.value);

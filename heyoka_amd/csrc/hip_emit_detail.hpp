@@ -232,7 +232,7 @@ struct ssa_emitter {
                 } else {
                     const auto &v = is_var(a[0]) ? a[0] : a[1];
                     const auto &c = is_var(a[0]) ? a[1] : a[0];
-                    if (&c == &a[0] && c.type == operand::kind::num && c.value == -1.) {
+                    if (&c == &a[0] && c.type == operand::kind::num && c.value == -1. && numpar_override.count(&c) == 0u) {
                         out = def("-" + val(v.idx, k));
                     } else {
                         out = def(mul(numpar(c), val(v.idx, k)));

@@ -454,3 +454,43 @@ def test_test_particles_next_to_parameter_masses_padded_clusters():
     ta.propagate_until(25.0)
     oi.propagate_until(25.0)
     assert rel_err(ta.state, oi.state.reshape(36, n)) <= 1e7 * EPS
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("masses", [[1.0, 3e-4, 1e-4, 5e-5, 0.0, 0.0], [1.0, 1e-3, 0.0]])
+def test_test_particles_next_to_numeric_masses_with_a_unit_mass(masses):
+    """model::nbody() with numeric masses, G = 1 and a unit-mass primary: -G m_0 is then the literal -1, which the
+    decomposition shows as a negation in the pairs of body 0 with the test particles, next to ordinary factors in the
+    other pairs. The planner treats the factor as a per-cluster constant (not as part of the cluster shape), so that
+    the clusters are isomorphic and the system runs on the wave-cluster stepper."""
+    nb = len(masses)
+    n = 24
+    rng = np.random.default_rng(5)
+    st = np.zeros((6 * nb, n))
+    for b in range(nb):
+        r = 1.0 + 1.7 * b
+        ph = rng.uniform(0, 2 * np.pi, n)
+        vc = np.sqrt(1.0 / r) if b > 0 else 0.0
+        st[6 * b + 0] = r * np.cos(ph) if b > 0 else 0.0
+        st[6 * b + 1] = r * np.sin(ph) if b > 0 else 0.0
+        st[6 * b + 2] = 0.01 * rng.standard_normal(n)
+        st[6 * b + 3] = -vc * np.sin(ph)
+        st[6 * b + 4] = vc * np.cos(ph)
+        st[6 * b + 5] = 0.001 * rng.standard_normal(n)
+    sys_g = hy.model.nbody(nb, masses=masses, Gconst=1.0)
+    sys_o = ho.nbody(nb, masses=masses, Gconst=1.0)
+    assert hy.taylor_decompose_sys(sys_g) == ho.dc_to_strings(ho.taylor_decompose_sys(sys_o))
+    ta = hy.taylor_adaptive_batch(sys_g, st, n, high_accuracy=True)
+    assert ta.hip_source_mode.startswith("cluster"), ta.hip_source_mode
+    oi = ho.OracleIntegrator(sys_o, st, n, high_accuracy=True)
+    ta.step(write_tc=True)
+    oi.step(wtc=True)
+    h_g = np.array([h for _, h in ta.step_res])
+    h_o = np.array([h for _, h in oi.step_res])
+    assert np.max(np.abs(h_g - h_o) / np.abs(h_o)) <= 1e6 * EPS
+    tc_o = oi.tc.reshape(6 * nb, oi.order + 1, n)
+    scale = np.max(np.abs(tc_o), axis=0, keepdims=True)
+    assert np.max(np.abs(np.asarray(ta.tc).reshape(6 * nb, oi.order + 1, n) - tc_o) / scale) <= 1e6 * EPS
+    ta.propagate_until(10.0)
+    oi.propagate_until(10.0)
+    assert rel_err(ta.state, oi.state.reshape(6 * nb, n)) <= 1e7 * EPS
