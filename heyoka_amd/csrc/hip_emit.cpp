@@ -64,6 +64,7 @@ struct hy_kargs {
     double tfin_s_hi, tfin_s_lo;
     double *ev_tc;
     double *max_abs_state;
+    double *sel_norms;
 };
 
 #define HY_OC_SUCCESS (-4294967296LL - 1)
@@ -695,6 +696,125 @@ emitted_module emit_unrolled(const taylor_program &p, const emit_options &opts)
 }
 
 } // namespace emit_detail
+
+// Jets of the event equations from the jets of the state variables (see hip_emit.hpp). The part of the decomposition the
+// event equations depend on is run order by order, one system per lane, with the coefficients of the state variables
+// loaded from a.tc instead of being produced by the recursion x^[k+1] = f^[k] / (k + 1) - the elementary-function rules
+// (and hence the coefficients) are the ones of the stepper with events of the one-system-per-lane kernels. The norms of
+// the step-size selector are those of the state variables (a.sel_norms, written by the cluster stepper in mode 4)
+// extended to the event equations (taylor_determine_h() iterates up to n_eq + n_sv_funcs, src/taylor_00.cpp:209-219).
+emitted_module emit_event_jets(const taylor_program &p, const emit_options &opts, std::string &why_not)
+{
+    using emit_detail::ssa_emitter;
+    emitted_module ret;
+    const auto n_eq = p.n_eq;
+    const auto order = opts.order;
+    if (p.ev_u.empty()) {
+        why_not = "no event equations";
+        return ret;
+    }
+    // Nodes needed by the event equations (transitive closure over the arguments and the hidden dependencies).
+    std::vector<char> need(p.n_u, 0);
+    for (const auto u : p.ev_u) {
+        need[u] = 1;
+    }
+    for (std::uint32_t u = p.n_u; u-- > n_eq;) {
+        if (need[u] == 0) {
+            continue;
+        }
+        const auto &n = p.nodes[u - n_eq];
+        for (const auto &o : n.args) {
+            if (o.type == operand::kind::uvar) {
+                need[o.idx] = 1;
+            }
+        }
+        for (const auto d : n.deps) {
+            need[d] = 1;
+        }
+    }
+    std::uint32_t n_nodes = 0, n_sv = 0;
+    for (std::uint32_t u = 0; u < p.n_u; ++u) {
+        if (need[u] != 0) {
+            (u < n_eq ? n_sv : n_nodes) += 1u;
+        }
+    }
+    // NOTE: straight-line code with the histories in registers, like the unrolled stepper.
+    std::uint32_t max_nodes = 40;
+    if (const char *ev = std::getenv("HEYOKA_AMD_EV_JETS_MAX_NODES")) {
+        max_nodes = static_cast<std::uint32_t>(std::max(0, std::atoi(ev)));
+    }
+    if (n_nodes > max_nodes) {
+        why_not = "the event equations depend on " + std::to_string(n_nodes) + " nodes of the decomposition (limit: "
+                  + std::to_string(max_nodes) + ")";
+        return ret;
+    }
+
+    ssa_emitter e(p, order);
+    auto &os = e.os;
+    os << "extern \"C\" __global__ void __launch_bounds__(256) hy_ev_jets(const hy_kargs a)\n{\n";
+    os << "const u64 N = a.N;\nconst u64 s = (u64)blockIdx.x * 256u + threadIdx.x;\nif (s >= N) return;\n";
+    std::vector<char> par_used(p.n_par, 0);
+    for (std::uint32_t u = n_eq; u < p.n_u; ++u) {
+        if (need[u] != 0) {
+            for (const auto &o : p.nodes[u - n_eq].args) {
+                if (o.type == operand::kind::par) {
+                    par_used[o.idx] = 1;
+                }
+            }
+        }
+    }
+    for (std::uint32_t i = 0; i < p.n_par; ++i) {
+        if (par_used[i] != 0) {
+            os << "const double par_" << i << " = a.pars[(u64)" << i << "u * N + s];\n";
+        }
+    }
+    os << "const double *const jet = a.tc + s;\n";
+    for (std::uint32_t k = 0; k <= order; ++k) {
+        for (std::uint32_t i = 0; i < n_eq; ++i) {
+            if (need[i] != 0) {
+                e.val(i, k) = e.def("jet[(u64)" + std::to_string(static_cast<std::uint64_t>(i) * (order + 1u) + k) + "u * N]");
+            }
+        }
+        for (std::uint32_t u = n_eq; u < p.n_u; ++u) {
+            if (need[u] != 0) {
+                e.node(u - n_eq, k);
+            }
+        }
+        for (std::size_t ev = 0; ev < p.ev_u.size(); ++ev) {
+            os << "a.ev_tc[(u64)" << (ev * (order + 1u) + k) << "u * N + s] = " << e.val(p.ev_u[ev], k) << ";\n";
+        }
+    }
+    // Norms: state variables first, then the event equations, combined like the pairwise maximum of the stepper with
+    // events (the maximum of non-NaN values does not depend on the order of the comparisons).
+    const auto ext = [&](const std::string &base, std::uint32_t k) {
+        auto m = e.def(base);
+        for (const auto u : p.ev_u) {
+            m = e.def("hy_max(" + m + ", fabs(" + e.val(u, k) + "))");
+        }
+        return m;
+    };
+    const auto m0 = ext("a.sel_norms[s]", 0), mo = ext("a.sel_norms[N + s]", order), mom1 = ext("a.sel_norms[2u * N + s]", order - 1u);
+    os << "const double num_rho = (" << m0 << " <= 1.0) ? 1.0 : " << m0 << ";\n";
+    os << "const double rho_o = hy_root(num_rho / " << mo << ", " << fp_literal(1. / static_cast<double>(order)) << ");\n";
+    os << "const double rho_om1 = hy_root(num_rho / " << mom1 << ", " << fp_literal(1. / static_cast<double>(order - 1u))
+       << ");\n";
+    os << "const double rho_m = hy_min(rho_o, rho_om1);\n";
+    os << "double h = rho_m * " << fp_literal(emit_detail::rhofac(order)) << ";\n";
+    os << "const double lim = a.lim[s];\nh = hy_min(h, fabs(lim));\nh = (lim < 0.0) ? -h : h;\n";
+    os << "a.last_h[s] = h;\na.max_abs_state[s] = " << m0 << ";\n}\n";
+
+    std::ostringstream src;
+    src << emit_detail::prelude << os.str();
+    ret.source = src.str();
+    ret.kernel_name = "hy_ev_jets";
+    ret.block_size = 256;
+    ret.lanes_per_system = 1;
+    ret.mode = emit_mode::unrolled;
+    ret.n_statements = e.n_stmt;
+    ret.notes = "jets of " + std::to_string(p.ev_u.size()) + " event equation(s) from the jets of " + std::to_string(n_sv)
+                + " state variable(s), " + std::to_string(n_nodes) + " nodes";
+    return ret;
+}
 
 emitted_module emit_cluster_or_empty(const taylor_program &, const emit_options &, std::string &why_not);
 emitted_module emit_table(const taylor_program &, const emit_options &);

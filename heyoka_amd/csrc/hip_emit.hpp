@@ -42,6 +42,10 @@ struct hy_kargs {
     // [(event * (order + 1) + k) * N + system] and max_i |x_i| per system.
     double *ev_tc;
     double *max_abs_state;
+    // mode 4 on the wave-cluster steppers (jets of the state variables to tc, no state update): the three norms of the
+    // step-size selector over the state variables, [3 * N] = max |x^[0]|, max |x^[p]|, max |x^[p-1]| per system. The
+    // jets of the event equations and the final step size are computed from tc by hy_ev_jets (emit_event_jets()).
+    double *sel_norms;
 };
 
 enum class emit_mode { unrolled, cluster, table, block };
@@ -74,9 +78,18 @@ struct emitted_module {
     bool persistent = false;
     // Extra hiprtc options of the module (space separated), on top of the common ones.
     std::string compile_flags;
+    // The stepper implements mode 4 in its cluster form (see hy_kargs::sel_norms).
+    bool cluster_mode4 = false;
 };
 
 emitted_module emit_hip_module(const taylor_program &prog, const emit_options &opts);
+
+// Companion of the wave-cluster steppers for integrators with events: kernel hy_ev_jets, one system per lane - the jets
+// of the event equations from the jets of the state variables in a.tc (only the part of the decomposition the event
+// equations depend on), the norms of the step-size selector extended to the event equations and the final step size.
+// prog is the decomposition of the system *with* the event equations (prog.ev_u). Returns a module with an empty source
+// (and the reason in why_not) when the event equations need too much of the decomposition.
+emitted_module emit_event_jets(const taylor_program &prog, const emit_options &opts, std::string &why_not);
 
 // Format a double as a C++17 hexadecimal floating-point literal (exact round trip).
 std::string fp_literal(double);

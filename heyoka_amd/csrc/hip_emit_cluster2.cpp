@@ -1205,6 +1205,10 @@ lim = fin ? 0.0 : lim;
         src << "mo = hy_nmax(mo, " << ex("mo") << ");\n";
         src << "mom1 = hy_nmax(mom1, " << ex("mom1") << ");\n";
     }
+    // Mode 4 (stepper with events): the norms over the state variables go to the kernel which extends them to the event
+    // equations (hy_ev_jets). A wave-uniform branch; every lane of the system stores the same values.
+    src << "const bool nostate = a.mode == 4;\n";
+    src << "if (nostate) {\na.sel_norms[s] = m0;\na.sel_norms[N + s] = mo;\na.sel_norms[2u * N + s] = mom1;\n}\n";
     src << "const double num_rho = (m0 <= 1.0) ? 1.0 : m0;\n";
     // NOTE: rho = exp(log(x) / order) (hy_root): the minimum of the two estimates is taken on the exponents (exp is
     // monotone and keeps NaNs: the same selection as min(rho_o, rho_om1), src/taylor_02.cpp:1050-1072, one exp less).
@@ -1288,7 +1292,7 @@ int nfi = !(hy_finite(nt_hi) && hy_finite(nt_lo)) ? 1 : 0;
     src << "HY_WSYNC();\n" << jet_fence;
     for (std::uint32_t c = 0; c < n_hslots; ++c) {
         // (A zero-length step leaves the state untouched bit by bit: x + 0 * ... = x also in the compensated sum.)
-        src << "hc" << c << "[0] = fin ? hc" << c << "[0] : xn" << c << ";\n";
+        src << "hc" << c << "[0] = (fin | nostate) ? hc" << c << "[0] : xn" << c << ";\n";
     }
     src << "HY_WSYNC();\n" << jet_fence;
     src << R"HIP(
@@ -1310,9 +1314,9 @@ int nfi = !(hy_finite(nt_hi) && hy_finite(nt_lo)) ? 1 : 0;
     const bool sl = !done & (it_new == a.max_steps);
     const i64 oc_fin = sl ? HY_OC_STEP_LIMIT : oc_new;
     done |= sl;
-    nf_seen |= (!fin & nf) ? 1 : 0;
-    t_hi = fin ? t_hi : nt_hi;
-    t_lo = fin ? t_lo : nt_lo;
+    nf_seen |= (!fin & nf & !nostate) ? 1 : 0;
+    t_hi = (fin | nostate) ? t_hi : nt_hi;
+    t_lo = (fin | nostate) ? t_lo : nt_lo;
     last_h = fin ? last_h : h;
     outcome = fin ? outcome : oc_fin;
     n_steps = fin ? n_steps : ns_new;
@@ -1373,6 +1377,7 @@ if (l == 0u && live) {
         ret.compile_flags = "-mllvm -disable-machine-licm";
     }
     ret.tc_optional = true;
+    ret.cluster_mode4 = true;
     ret.notes = std::string(pair_split ? "cluster mode v3 (lane pairs, 2 wavefronts per SIMD): " : "cluster mode v2 (pipelined): ")
                 + std::to_string(nc) + " clusters of " + std::to_string(t0.size())
                 + " nodes, L=" + std::to_string(L) + ", " + std::to_string(pl.n_slots) + " LDS slots x2, "

@@ -126,6 +126,14 @@ struct tab_core::impl {
     mutable device_buffer d_ev_tc, d_mas, d_geps, d_dirs, d_cd_first, d_cd_second, d_cd_active, d_ed_out, d_ed_counts,
         d_ed_flags;
     std::uint64_t ed_failures = 0;
+    // Events on the wave-cluster steppers: the main stepper is built from the system alone and runs in mode 4 (jets of
+    // the state variables, no update); hy_ev_jets (emit_event_jets()) derives the jets of the event equations and the
+    // final step size from them.
+    bool cluster_events = false;
+    emitted_module ev_emitted;
+    std::shared_ptr<const compiled_module> ev_cmod;
+    mutable std::unique_ptr<aux_module> evj_mod;
+    mutable device_buffer d_selnorms;
     // Set by propagate_for() only: propagate_until() then accepts 2 * N double-length (hi, lo) final times.
     bool dl_times_ok = false;
     // Incremented by set_time() / set_dtime(): lets the device-driven loops detect callbacks that touch the time
@@ -456,6 +464,27 @@ tab_core::tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_siz
     if (d.has_events()) {
         eo.mode = (d.prog.nodes.size() > 150u || choose_mode() == emit_mode::table) ? emit_mode::table
                                                                                    : emit_mode::unrolled;
+        // Wave-cluster stepper for the system itself + the event equations from its jets, when both apply (event
+        // equations which depend on a small part of the decomposition: distances, coordinates, angles, ...).
+        // HEYOKA_AMD_EVENTS_ON_CLUSTER=0: always the one-system-per-lane steppers with events.
+        const char *evc = std::getenv("HEYOKA_AMD_EVENTS_ON_CLUSTER");
+        if (choose_mode() == emit_mode::cluster && !(evc != nullptr && std::atoi(evc) == 0)) {
+            const auto prog0 = make_program(taylor_decompose_sys(sys), d.dim);
+            auto eo2 = eo;
+            eo2.mode = emit_mode::cluster;
+            auto m = emit_hip_module(prog0, eo2);
+            std::string why;
+            if (m.cluster_mode4) {
+                auto evm = emit_event_jets(d.prog, eo, why);
+                if (!evm.source.empty()) {
+                    d.cluster_events = true;
+                    d.emitted = std::move(m);
+                    d.emitted.notes += "; events: " + evm.notes;
+                    d.ev_emitted = std::move(evm);
+                    d.ev_cmod = hiprtc_compile(d.ev_emitted);
+                }
+            }
+        }
     } else {
         eo.mode = choose_mode();
         // kw::compact_mode = true selects the analogue of the reference's compact mode (src/taylor_02.cpp:1194-1260):
@@ -467,7 +496,9 @@ tab_core::tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_siz
             eo.mode = emit_mode::table;
         }
     }
-    d.emitted = emit_hip_module(d.prog, eo);
+    if (!d.cluster_events) {
+        d.emitted = emit_hip_module(d.prog, eo);
+    }
     d.cmod = hiprtc_compile(d.emitted);
 
     d.sys = std::move(sys);
@@ -507,6 +538,9 @@ tab_core::tab_core(const tab_core &o) : m_impl(std::make_unique<impl>())
     d.device = s.device;
     d.emitted = s.emitted;
     d.cmod = s.cmod;
+    d.cluster_events = s.cluster_events;
+    d.ev_emitted = s.ev_emitted;
+    d.ev_cmod = s.ev_cmod;
     d.state = s.state;
     d.pars = s.pars;
     d.time_hi = s.time_hi;
@@ -883,7 +917,18 @@ void tab_core::impl::step_with_events(const std::vector<double> &lims, bool wtc)
     a.ev_tc = d_ev_tc.as<double>();
     a.max_abs_state = d_mas.as<double>();
     a.mode = 4;
+    if (cluster_events) {
+        if (d_selnorms.bytes() == 0u) {
+            d_selnorms = device_buffer(3u * n * dsz, device);
+            evj_mod = std::make_unique<aux_module>(ev_cmod, device);
+        }
+        a.sel_norms = d_selnorms.as<double>();
+    }
     dmod->launch_taylor(a);
+    if (cluster_events) {
+        // Jets of the event equations, extended norms and final step sizes from the jets of the state variables.
+        evj_mod->launch("hy_ev_jets", N, 256, &a, sizeof(a), stream);
+    }
 
     // 2. Maximum error on the Taylor series of the event equations (:744-767).
     std::vector<double> mas(n), g_eps(n), hs(n);
@@ -2107,6 +2152,8 @@ void tab_core::set_device(int device)
     // back to the default stream of the new one (set_stream() again if needed).
     d.ed_mod.reset();
     d.grid_mod.reset();
+    d.evj_mod.reset();
+    d.d_selnorms = {};
     d.d_ev_tc = {};
     d.d_mas = {};
     d.d_geps = {};

@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""Cost of a lock-step step() with events on a large outer-SS ensemble: wave-cluster stepper + hy_ev_jets vs the
+one-system-per-lane stepper with events vs an event-free step(). usage: events_scale.py [--systems N] [--steps K]"""
+import argparse, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import heyoka_amd as hy
+from heyoka_amd import configs
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--systems", type=int, default=262144)
+ap.add_argument("--steps", type=int, default=6)
+ap.add_argument("--skip-lane-stepper", action="store_true")
+args = ap.parse_args()
+M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+n = args.systems
+st = configs.outer_ss_state(n, perturb=1e-6, seed=42)
+sys_ = hy.model.nbody(6, masses=M, Gconst=G)
+
+
+def events(log):
+    x1, y1, z1, x2, y2, z2 = hy.make_vars("x_1", "y_1", "z_1", "x_2", "y_2", "z_2")
+    d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2) - 81.0
+    return [hy.nt_event(d2, lambda ta, t, d, i: log.append((i, t)), direction=hy.event_direction.negative)]
+
+
+def run(tag, **kw):
+    log = []
+    ta = hy.taylor_adaptive_batch(sys_, st, n, high_accuracy=True, **(dict(nt_events=events(log)) if kw.get("ev") else {}))
+    ta.step()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ta.step()
+    el = (time.perf_counter() - t0) / args.steps
+    print(json.dumps({"tag": tag, "systems": n, "s_per_step": el, "system_steps_per_s": n / el,
+                      "events_seen": len(log), "mode": ta.hip_source_mode[:70]}), flush=True)
+
+
+run("no events")
+run("events on the cluster stepper", ev=True)
+if not args.skip_lane_stepper:
+    os.environ["HEYOKA_AMD_EVENTS_ON_CLUSTER"] = "0"
+    run("events on the one-system-per-lane stepper", ev=True)

@@ -1330,3 +1330,59 @@ def test_cluster_kernels_loop_control_semantics(kernel, monkeypatch):
     assert [int(o) for o, _ in ta.step_res] == [int(o) for o, _ in ora2.step_res]
     assert np.allclose([h for _, h in ta.step_res], [h for _, h in ora2.step_res], rtol=1e-9, atol=0)
     assert rel_err(ta.state, ora2.state.reshape(36, n)) <= 1e5 * EPS
+
+
+def _outer_ss_event_setup(m, log, te_log):
+    """Events on the outer Solar System through expression module m (product or oracle): radial velocity of Jupiter
+    (non-terminal, both directions), Saturn crossing y = 0 upwards (non-terminal), Jupiter - Saturn distance falling
+    below 9 AU (terminal, callback keeps going)."""
+    mk = (lambda s: m.var(s)) if m is ho else (lambda s: m.make_vars(s)[0] if isinstance(m.make_vars(s), (list, tuple)) else m.make_vars(s))
+    x1, y1, z1, vx1, vy1, vz1 = [mk(s + "_1") for s in ("x", "y", "z", "vx", "vy", "vz")]
+    x2, y2, z2 = [mk(s + "_2") for s in ("x", "y", "z")]
+    pos = m.DIR_POSITIVE if m is ho else m.event_direction.positive
+    neg = m.DIR_NEGATIVE if m is ho else m.event_direction.negative
+    nt = [m.nt_event(x1 * vx1 + y1 * vy1 + z1 * vz1, lambda ta, t, d, i: log.append((i, 0, t, d))),
+          m.nt_event(y2, lambda ta, t, d, i: log.append((i, 1, t, d)), direction=pos)]
+    d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2) - 81.0
+    te = [m.t_event(d2, lambda ta, d, i: te_log.append((i, d)) or True, direction=neg)]
+    return nt, te
+
+
+@pytest.mark.gpu
+def test_events_on_the_cluster_stepper_vs_oracle(monkeypatch):
+    """Integrators with events whose system runs on a wave-cluster stepper: the stepper computes the jets of the state
+    variables only (mode 4, no update), hy_ev_jets derives the jets of the event equations and the final step size from
+    them. Step by step against the oracle's stepper with events (outcomes, step sizes, states, event times / signs /
+    order), and against the one-system-per-lane stepper with events of the product."""
+    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    n = 10
+    st = configs.outer_ss_state(n, perturb=1e-3, seed=11)
+    log_p, te_p, log_o, te_o, log_q, te_q = [], [], [], [], [], []
+    nt_p, te_ev_p = _outer_ss_event_setup(hy, log_p, te_p)
+    ta = hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True, nt_events=nt_p,
+                                  t_events=te_ev_p)
+    assert ta.hip_source_mode.startswith("cluster") and "events:" in ta.hip_source_mode, ta.hip_source_mode
+    nt_o, te_ev_o = _outer_ss_event_setup(ho, log_o, te_o)
+    ora = ho.OracleEventIntegrator(ho.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True, nt_events=nt_o,
+                                   t_events=te_ev_o)
+    monkeypatch.setenv("HEYOKA_AMD_EVENTS_ON_CLUSTER", "0")
+    nt_q, te_ev_q = _outer_ss_event_setup(hy, log_q, te_q)
+    tq = hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True, nt_events=nt_q,
+                                  t_events=te_ev_q)
+    assert not tq.hip_source_mode.startswith("cluster")
+    for _ in range(45):
+        ta.step()
+        ora.step()
+        tq.step()
+        assert [int(oc) for oc, _ in ta.step_res] == [oc for oc, _ in ora.step_res]
+        assert [int(oc) for oc, _ in ta.step_res] == [int(oc) for oc, _ in tq.step_res]
+        h_p = np.array([h for _, h in ta.step_res])
+        h_o = np.array([h for _, h in ora.step_res])
+        assert np.max(np.abs(h_p - h_o) / np.abs(h_o)) <= 1e6 * EPS
+        assert rel_err(ta.state, ora.state.reshape(36, n)) <= 1e6 * EPS
+        assert rel_err(ta.state, tq.state) <= 1e6 * EPS
+    assert len(log_p) >= 3 * n and len(te_p) >= n
+    assert [(a[0], a[1], a[3]) for a in log_p] == [(a[0], a[1], a[3]) for a in log_o]
+    assert np.max(np.abs(np.array([a[2] for a in log_p]) - np.array([a[2] for a in log_o]))) <= 1e-10
+    assert te_p == te_o and te_p == te_q
+    assert [(a[0], a[1], a[3]) for a in log_p] == [(a[0], a[1], a[3]) for a in log_q]
