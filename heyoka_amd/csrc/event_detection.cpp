@@ -47,6 +47,29 @@ struct hy_ed_args {
     unsigned *flags;
     u64 N;
     unsigned n_te, n_nte;
+    const double *mas;
+    double *g_eps_out;
+    double tol;
+};
+
+struct hy_ep_args {
+    const double *h;
+    const double *ed_out;
+    const unsigned *counts;
+    double *dout_h;
+    const double *g_eps;
+    const double *state;
+    double *time_hi, *time_lo;
+    const double *lim;
+    double *cd_first, *cd_second;
+    int *cd_active;
+    i64 *outcome;
+    double *last_h;
+    double *rec;
+    u64 *cursor;
+    const double *upd;
+    u64 N;
+    unsigned n_te, n_nte, dim, n_cd, n_oc, pad;
 };
 
 __device__ __forceinline__ int hy_sgn(double x)
@@ -157,7 +180,22 @@ extern "C" __global__ void __launch_bounds__(64) hy_detect_events(const hy_ed_ar
     if (j >= N) return;
     a.counts[j] = 0u;
     a.counts[N + j] = 0u;
-    const double h = a.h[j], g_eps = a.g_eps[j];
+    const double h = a.h[j];
+    double g_eps;
+    if (a.mas != nullptr) {
+        // Maximum error on the Taylor series of the event equations (src/taylor_adaptive_batch.cpp:744-767).
+        const double mas = a.mas[j];
+        const double eps = 0x1p-52;
+        if (hy_finite(mas)) {
+            const double max_r_size = (mas < 1.0) ? a.tol : (a.tol * mas);
+            g_eps = (max_r_size < eps * mas) ? (eps * mas) : max_r_size;
+        } else {
+            g_eps = __builtin_inf();
+        }
+        a.g_eps_out[j] = g_eps;
+    } else {
+        g_eps = a.g_eps[j];
+    }
     if (!hy_finite(h) || !hy_finite(g_eps) || h == 0.0) return;
 
     double ptr[HY_P], tmp[HY_P], tmp1[HY_P], tmp2[HY_P];
@@ -269,6 +307,98 @@ extern "C" __global__ void __launch_bounds__(64) hy_detect_events(const hy_ed_ar
             }
             add_event(hy_bracketed_root(tmp1, lb, ub) * h);
         }
+    }
+}
+
+// Step sizes of the state update: the step is truncated at the first terminal event of the lane - the one with the
+// smallest |root|, the earliest detected among equals like the stable sort of the reference
+// (src/taylor_adaptive_batch.cpp:771-781). Also: the size of the record buffer hy_ev_post needs.
+extern "C" __global__ void __launch_bounds__(256) hy_ev_pre(const hy_ep_args a)
+{
+    const u64 j = (u64)blockIdx.x * 256u + threadIdx.x;
+    const u64 N = a.N;
+    if (j >= N) return;
+    const unsigned c_te = a.counts[j], c_nte = a.counts[N + j];
+    double h = a.h[j];
+    if (c_te != 0u) {
+        const double *r = a.ed_out + (j * HY_MAXD) * 4u;
+        double best = r[1];
+        for (unsigned c = 1; c < c_te; ++c) {
+            const double root = r[c * 4u + 1u];
+            if (fabs(root) < fabs(best)) best = root;
+        }
+        h = best;
+    }
+    a.dout_h[j] = h;
+    if (c_te + c_nte != 0u) atomicAdd(a.cursor, (u64)(8u + 4u * (c_te + c_nte)));
+}
+
+// After the state update (:783-835 and the parts of :837-1030 which do not depend on callbacks).
+extern "C" __global__ void __launch_bounds__(256) hy_ev_post(const hy_ep_args a)
+{
+    const u64 j = (u64)blockIdx.x * 256u + threadIdx.x;
+    const u64 N = a.N;
+    if (j >= N) return;
+    const double h = a.dout_h[j];
+    hy_df tcur; tcur.hi = a.time_hi[j]; tcur.lo = a.time_lo[j];
+    hy_df hh; hh.hi = h; hh.lo = 0.0;
+    const hy_df nt = hy_df_add(tcur, hh);
+    a.time_hi[j] = nt.hi;
+    a.time_lo[j] = nt.lo;
+    a.last_h[j] = h;
+    bool nf = !(hy_finite(nt.hi) && hy_finite(nt.lo));
+    for (unsigned v = 0; v < a.dim; ++v) nf = nf | !hy_finite(a.state[(u64)v * N + j]);
+    if (nf) {
+        a.outcome[j] = HY_OC_ERR_NF_STATE;
+        return;
+    }
+    // Cooldowns (:822-835).
+    for (unsigned e = 0; e < a.n_te; ++e) {
+        const u64 p = (u64)e * N + j;
+        if (a.cd_active[p] != 0) {
+            const double tmp = a.cd_first[p] + h;
+            if (fabs(tmp) >= a.cd_second[p]) {
+                a.cd_active[p] = 0;
+            } else {
+                a.cd_first[p] = tmp;
+            }
+        }
+    }
+    // (The outcome of a lane with a terminal event is set by the host once its callback has run.)
+    a.outcome[j] = (h == a.lim[j]) ? HY_OC_TIME_LIMIT : HY_OC_SUCCESS;
+    const unsigned c_te = a.counts[j], c_nte = a.counts[N + j];
+    if (c_te + c_nte == 0u) return;
+    const u64 off = atomicAdd(a.cursor + 1, (u64)(8u + 4u * (c_te + c_nte)));
+    double *r = a.rec + off;
+    r[0] = (double)j;
+    r[1] = (double)c_te;
+    r[2] = (double)c_nte;
+    r[3] = a.g_eps[j];
+    r[4] = h;
+    r[5] = nt.hi;
+    r[6] = nt.lo;
+    r[7] = 0.0;
+    r += 8;
+    for (unsigned cls = 0; cls < 2u; ++cls) {
+        const unsigned cnt = cls == 0u ? c_te : c_nte;
+        const double *src = a.ed_out + (((u64)cls * N + j) * HY_MAXD) * 4u;
+        for (unsigned c = 0; c < cnt * 4u; ++c) r[c] = src[c];
+        r += cnt * 4u;
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(256) hy_ev_scatter(const hy_ep_args a)
+{
+    const u64 j = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (j < a.n_cd) {
+        const double *u = a.upd + j * 3u;
+        const u64 p = (u64)u[0];
+        a.cd_first[p] = u[1];
+        a.cd_second[p] = u[2];
+        a.cd_active[p] = 1;
+    } else if (j < (u64)a.n_cd + a.n_oc) {
+        const double *u = a.upd + (u64)a.n_cd * 3u + (j - a.n_cd) * 2u;
+        a.outcome[(u64)u[0]] = (i64)u[1];
     }
 }
 )HIP";

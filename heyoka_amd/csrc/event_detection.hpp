@@ -71,6 +71,37 @@ struct ed_kargs {
     unsigned *flags;          // [0] = number of lanes whose list overflowed / whose isolation failed
     unsigned long long N;
     unsigned n_te, n_nte;
+    // Device-side error bound of the Taylor series of the event equations (src/taylor_adaptive_batch.cpp:744-767):
+    // when mas != nullptr, g_eps is computed from max |x_i| and the tolerance and written to g_eps_out.
+    const double *mas;
+    double *g_eps_out;
+    double tol;
+};
+
+// Per-lane bookkeeping of a step with events on the device (src/taylor_adaptive_batch.cpp:771-1030): hy_ev_pre
+// (truncation of the step at the first terminal event, size of the record buffer), the dense-output kernel, hy_ev_post
+// (time update, non-finite check, cooldown update, outcomes, compaction of the lanes with events into records),
+// hy_ev_scatter (cooldowns / outcomes set by the host for the lanes whose terminal events triggered).
+// Record of a lane with events: 8 doubles (lane, n_te, n_nte, g_eps, h, new time hi, new time lo, 0) followed by
+// 4 doubles per event (idx, root, d_sgn, |derivative|), terminal events first, in detection order.
+struct ep_kargs {
+    const double *h;          // [N] step sizes of the stepper
+    const double *ed_out;
+    const unsigned *counts;
+    double *dout_h;           // [N] final step sizes
+    const double *g_eps;      // [N]
+    const double *state;      // [dim * N], after the update
+    double *time_hi, *time_lo;
+    const double *lim;
+    double *cd_first, *cd_second;
+    int *cd_active;
+    long long *outcome;
+    double *last_h;
+    double *rec;
+    unsigned long long *cursor; // [0] record doubles needed (hy_ev_pre), [1] record doubles written (hy_ev_post)
+    const double *upd;          // hy_ev_scatter: n_cd x (position, first, second) then n_oc x (lane, outcome)
+    unsigned long long N;
+    unsigned n_te, n_nte, dim, n_cd, n_oc, pad;
 };
 
 } // namespace detail

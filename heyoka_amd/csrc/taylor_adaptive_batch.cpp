@@ -120,7 +120,7 @@ struct tab_core::impl {
     std::vector<core_t_event> tes;
     std::vector<core_nt_event> ntes;
     // te_cooldowns[lane][event]: (time elapsed since the trigger, cooldown duration).
-    std::vector<std::vector<std::optional<std::pair<double, double>>>> te_cooldowns;
+    mutable std::vector<std::vector<std::optional<std::pair<double, double>>>> te_cooldowns;
     void *cb_ctx = nullptr;
     mutable std::unique_ptr<aux_module> ed_mod;
     mutable device_buffer d_ev_tc, d_mas, d_geps, d_dirs, d_cd_first, d_cd_second, d_cd_active, d_ed_out, d_ed_counts,
@@ -145,11 +145,25 @@ struct tab_core::impl {
         return !tes.empty() || !ntes.empty();
     }
     void step_with_events(const std::vector<double> &lims, bool wtc);
+    void step_with_events_host(const std::vector<double> &lims);
+    void step_with_events_device(const std::vector<double> &lims);
+    void ensure_event_buffers();
+    void launch_event_stepper(const std::vector<double> &lims);
+    unsigned launch_event_detection(bool device_g_eps);
+    // Terminal-event cooldowns: the device arrays (d_cd_*) are authoritative between steps with events (updated by
+    // hy_ev_post / hy_ev_scatter); te_cooldowns is the lazily synchronised host mirror.
+    mutable bool cd_dev_newer = false;
+    bool cd_host_newer = true;
+    void cooldowns_to_host() const;
+    void cooldowns_to_device();
+    mutable device_buffer d_ev_cursor, d_ev_rec, d_ev_upd;
     // One lock-step sweep for the propagate_*() loops: afterwards step_res and the times are on the host.
     void lockstep_sweep(const std::vector<double> &lims, bool wtc)
     {
         if (has_events()) {
             step_with_events(lims, wtc);
+            fetch_step_res();
+            times_to_host();
         } else {
             run_step(lims, wtc);
             fetch_step_res();
@@ -554,6 +568,7 @@ tab_core::tab_core(const tab_core &o) : m_impl(std::make_unique<impl>())
     d.last_total_steps = s.last_total_steps;
     d.tes = s.tes;
     d.ntes = s.ntes;
+    s.cooldowns_to_host();
     d.te_cooldowns = s.te_cooldowns;
     d.host_newer = true;
 }
@@ -845,6 +860,7 @@ const std::vector<std::vector<std::optional<std::pair<double, double>>>> &tab_co
     if (!m_impl->has_events()) {
         throw std::invalid_argument("No events were defined for this integrator");
     }
+    m_impl->cooldowns_to_host();
     return m_impl->te_cooldowns;
 }
 void tab_core::reset_cooldowns()
@@ -862,9 +878,11 @@ void tab_core::reset_cooldowns(std::uint32_t i)
         throw std::invalid_argument("Cannot reset the cooldowns at batch index " + std::to_string(i)
                                     + ": the batch size for this integrator is only " + std::to_string(m_impl->N));
     }
+    m_impl->cooldowns_to_host();
     for (auto &cd : m_impl->te_cooldowns[i]) {
         cd.reset();
     }
+    m_impl->cd_host_newer = true;
 }
 void tab_core::set_callback_context(void *ctx)
 {
@@ -875,16 +893,63 @@ void tab_core::set_callback_context(void *ctx)
 // Device: stepper with events (jets of the state and of the event equations, step size, no state update), event
 // detection kernel, dense-output kernel for the state update at the (possibly truncated) step. Host: the
 // reference's sequential per-lane logic on the few detected events.
-void tab_core::impl::step_with_events(const std::vector<double> &lims, bool wtc)
+void tab_core::impl::cooldowns_to_host() const
 {
-    (void)wtc; // The Taylor coefficients are always written by the stepper with events (:756-757).
+    if (!cd_dev_newer) {
+        return;
+    }
+    const auto n = static_cast<std::size_t>(N);
+    const auto n_te = tes.size();
+    std::vector<double> cf(n_te * n), cs(n_te * n);
+    std::vector<int> ca(n_te * n);
+    d_cd_first.download(cf.data(), cf.size() * sizeof(double), stream);
+    d_cd_second.download(cs.data(), cs.size() * sizeof(double), stream);
+    d_cd_active.download(ca.data(), ca.size() * sizeof(int), stream);
+    for (std::size_t i = 0; i < n; ++i) {
+        for (std::size_t e = 0; e < n_te; ++e) {
+            if (ca[e * n + i] != 0) {
+                te_cooldowns[i][e].emplace(cf[e * n + i], cs[e * n + i]);
+            } else {
+                te_cooldowns[i][e].reset();
+            }
+        }
+    }
+    cd_dev_newer = false;
+}
+
+void tab_core::impl::cooldowns_to_device()
+{
+    if (!cd_host_newer || tes.empty()) {
+        cd_host_newer = false;
+        return;
+    }
+    cooldowns_to_host();
+    const auto n = static_cast<std::size_t>(N);
+    const auto n_te = tes.size();
+    std::vector<double> cf(n_te * n, 0.), cs(n_te * n, 0.);
+    std::vector<int> ca(n_te * n, 0);
+    for (std::size_t i = 0; i < n; ++i) {
+        for (std::size_t e = 0; e < n_te; ++e) {
+            if (const auto &cd = te_cooldowns[i][e]) {
+                cf[e * n + i] = cd->first;
+                cs[e * n + i] = cd->second;
+                ca[e * n + i] = 1;
+            }
+        }
+    }
+    d_cd_first.upload(cf.data(), cf.size() * sizeof(double), stream);
+    d_cd_second.upload(cs.data(), cs.size() * sizeof(double), stream);
+    d_cd_active.upload(ca.data(), ca.size() * sizeof(int), stream);
+    cd_host_newer = false;
+}
+
+void tab_core::impl::ensure_event_buffers()
+{
     const auto n = static_cast<std::size_t>(N);
     const auto dsz = sizeof(double);
     const auto n_te = static_cast<std::uint32_t>(tes.size()), n_nte = static_cast<std::uint32_t>(ntes.size());
     const auto n_ev = n_te + n_nte;
     constexpr auto maxd = max_detected_per_lane;
-
-    before_kernel();
     ensure_tc();
     if (d_ev_tc.bytes() == 0u) {
         d_ev_tc = device_buffer(static_cast<std::size_t>(n_ev) * (order + 1u) * n * dsz, device);
@@ -898,6 +963,7 @@ void tab_core::impl::step_with_events(const std::vector<double> &lims, bool wtc)
         d_ed_out = device_buffer(2u * n * maxd * 4u * dsz, device);
         d_ed_counts = device_buffer(2u * n * sizeof(unsigned), device);
         d_ed_flags = device_buffer(4u * sizeof(unsigned), device);
+        d_ev_cursor = device_buffer(2u * sizeof(unsigned long long), device);
         std::vector<int> dirs;
         for (const auto &ev : tes) {
             dirs.push_back(static_cast<int>(ev.dir));
@@ -907,9 +973,19 @@ void tab_core::impl::step_with_events(const std::vector<double> &lims, bool wtc)
         }
         d_dirs.upload(dirs.data(), dirs.size() * sizeof(int), stream);
         ed_mod = std::make_unique<aux_module>(hiprtc_compile_source(make_event_detection_source(order)), device);
+        cd_host_newer = true;
     }
+    if (d_dout.bytes() == 0u) {
+        d_dout = device_buffer(d_out.size() * dsz, device);
+        d_douth = device_buffer(n * dsz, device);
+    }
+}
 
-    // 1. Stepper with events.
+// Stepper with events: jets of the state and of the event equations, step sizes, max |x_i|, no state update.
+void tab_core::impl::launch_event_stepper(const std::vector<double> &lims)
+{
+    const auto n = static_cast<std::size_t>(N);
+    const auto dsz = sizeof(double);
     d_lim.upload(lims.data(), n * dsz, stream);
     d_counters.zero(stream);
     auto a = base_args();
@@ -929,6 +1005,264 @@ void tab_core::impl::step_with_events(const std::vector<double> &lims, bool wtc)
         // Jets of the event equations, extended norms and final step sizes from the jets of the state variables.
         evj_mod->launch("hy_ev_jets", N, 256, &a, sizeof(a), stream);
     }
+}
+
+// Event detection on the device; returns the number of lanes whose event lists overflowed / whose root isolation failed.
+unsigned tab_core::impl::launch_event_detection(bool device_g_eps)
+{
+    const auto n_te = static_cast<std::uint32_t>(tes.size()), n_nte = static_cast<std::uint32_t>(ntes.size());
+    d_ed_flags.zero(stream);
+    const ed_kargs ea{d_ev_tc.as<double>(),   d_lasth.as<double>(),     d_geps.as<double>(),     d_dirs.as<int>(),
+                      d_cd_first.as<double>(), d_cd_second.as<double>(), d_cd_active.as<int>(),   d_ed_out.as<double>(),
+                      d_ed_counts.as<unsigned>(), d_ed_flags.as<unsigned>(), N, n_te, n_nte,
+                      device_g_eps ? d_mas.as<double>() : nullptr, d_geps.as<double>(), tol};
+    ed_mod->launch("hy_detect_events", N, 64, &ea, sizeof(ea), stream);
+    return 0;
+}
+
+void tab_core::impl::step_with_events(const std::vector<double> &lims, bool wtc)
+{
+    (void)wtc; // The Taylor coefficients are always written by the stepper with events (:756-757).
+    // HEYOKA_AMD_EVENTS_HOST_LOGIC=1: the per-lane bookkeeping of every lane on the host (the first implementation).
+    const char *ev = std::getenv("HEYOKA_AMD_EVENTS_HOST_LOGIC");
+    if (ev != nullptr && std::atoi(ev) != 0) {
+        step_with_events_host(lims);
+    } else {
+        step_with_events_device(lims);
+    }
+}
+
+namespace
+{
+
+void report_ed_failures(std::uint64_t &ed_failures, unsigned flags)
+{
+    if (flags != 0u) {
+        // The per-lane lists of detected events / the work list of the root isolation are of fixed size on the device
+        // (16 events per class and lane, 64 intervals): an overflow drops events. The reference has no fixed cap and
+        // logs a warning when the isolation fails; here the count is kept (get_event_detection_failures()) and the
+        // first occurrence is reported on stderr.
+        if (ed_failures == 0u) {
+            std::fprintf(stderr, "heyoka_amd: warning: event detection overflow in %u lane(s) (more than 16 events of one "
+                                 "class in a step, or root isolation work list exhausted): events may have been "
+                                 "dropped - reduce the step (max_delta_t) around dense clusters of events\n", flags);
+        }
+        ed_failures += flags;
+    }
+}
+
+[[noreturn]] void throw_callback_exceptions(std::vector<std::pair<std::uint32_t, std::exception_ptr>> &cb_eptrs)
+{
+    if (cb_eptrs.size() == 1u) {
+        std::rethrow_exception(cb_eptrs[0].second);
+    }
+    std::string exc_msg = "Two or more exceptions were raised during the execution of event callbacks in a "
+                          "batch integrator:\n\n";
+    for (auto &[i, eptr] : cb_eptrs) {
+        exc_msg += "Batch index #" + std::to_string(i) + ":\n";
+        try {
+            std::rethrow_exception(eptr);
+        } catch (const std::exception &ex) {
+            exc_msg += std::string("    Exception message: ") + ex.what() + "\n";
+        } catch (...) {
+            exc_msg += "    Exception type: unknown\n    Exception message: unknown\n";
+        }
+        exc_msg += '\n';
+    }
+    throw std::runtime_error(exc_msg);
+}
+
+} // namespace
+
+// One step with events, per-lane bookkeeping on the device: only the lanes with detected events reach the host (compact
+// records), which runs the callbacks and the logic that depends on them (src/taylor_adaptive_batch.cpp:837-1030) in
+// the order of the batch index; state, times, step sizes, outcomes and cooldowns stay on the device.
+void tab_core::impl::step_with_events_device(const std::vector<double> &lims)
+{
+    const auto n = static_cast<std::size_t>(N);
+    const auto dsz = sizeof(double);
+    const auto n_te = static_cast<std::uint32_t>(tes.size()), n_nte = static_cast<std::uint32_t>(ntes.size());
+
+    before_kernel();
+    ensure_event_buffers();
+    cooldowns_to_device();
+
+    launch_event_stepper(lims);
+    launch_event_detection(true);
+
+    ep_kargs pa{};
+    pa.h = d_lasth.as<double>();
+    pa.ed_out = d_ed_out.as<double>();
+    pa.counts = d_ed_counts.as<unsigned>();
+    pa.dout_h = d_douth.as<double>();
+    pa.g_eps = d_geps.as<double>();
+    pa.state = d_state.as<double>();
+    pa.time_hi = d_thi.as<double>();
+    pa.time_lo = d_tlo.as<double>();
+    pa.lim = d_lim.as<double>();
+    pa.cd_first = d_cd_first.as<double>();
+    pa.cd_second = d_cd_second.as<double>();
+    pa.cd_active = d_cd_active.as<int>();
+    pa.outcome = d_outcome.as<long long>();
+    pa.last_h = d_lasth.as<double>();
+    pa.cursor = d_ev_cursor.as<unsigned long long>();
+    pa.N = N;
+    pa.n_te = n_te;
+    pa.n_nte = n_nte;
+    pa.dim = dim;
+    d_ev_cursor.zero(stream);
+    ed_mod->launch("hy_ev_pre", N, 256, &pa, sizeof(pa), stream);
+    unsigned flags[1] = {0};
+    unsigned long long cur[2] = {0, 0};
+    d_ed_flags.download(flags, sizeof(flags), stream);
+    d_ev_cursor.download(cur, sizeof(cur), stream);
+    report_ed_failures(ed_failures, flags[0]);
+    if (cur[0] * dsz > d_ev_rec.bytes()) {
+        d_ev_rec = device_buffer(static_cast<std::size_t>(cur[0] + cur[0] / 2u + 1024u) * dsz, device);
+    }
+    pa.rec = d_ev_rec.as<double>();
+
+    // State update via dense output at the final step sizes (:781), then times / non-finite check / cooldowns /
+    // outcomes / records.
+    dmod->launch_dout(d_state.as<double>(), d_tc.as<double>(), d_douth.as<double>(), N);
+    ed_mod->launch("hy_ev_post", N, 256, &pa, sizeof(pa), stream);
+    std::vector<double> rec;
+    if (cur[0] != 0u) {
+        d_ev_cursor.download(cur, sizeof(cur), stream);
+        rec.resize(cur[1]);
+        if (cur[1] != 0u) {
+            d_ev_rec.download(rec.data(), rec.size() * dsz, stream);
+        }
+    } else {
+        stream_synchronize(device, stream);
+    }
+    host_newer = false;
+    after_kernel();
+    step_res_dev_newer = true;
+    cd_dev_newer = n_te != 0u;
+
+    // Records -> per-lane lists, in the order of the batch index.
+    struct lane_rec {
+        std::uint32_t lane;
+        double g_eps, h, thi, tlo;
+        std::vector<detected_event> tes, ntes;
+    };
+    std::vector<lane_rec> recs;
+    for (std::size_t p = 0; p < rec.size();) {
+        const auto *r = rec.data() + p;
+        lane_rec lr{static_cast<std::uint32_t>(r[0]), r[3], r[4], r[5], r[6], {}, {}};
+        const auto c_te = static_cast<unsigned>(r[1]), c_nte = static_cast<unsigned>(r[2]);
+        const auto *e = r + 8;
+        for (unsigned c = 0; c < c_te + c_nte; ++c, e += 4) {
+            (c < c_te ? lr.tes : lr.ntes).push_back({static_cast<std::uint32_t>(e[0]), e[1], static_cast<int>(e[2]), e[3]});
+        }
+        p += 8u + 4u * (c_te + c_nte);
+        recs.push_back(std::move(lr));
+    }
+    std::sort(recs.begin(), recs.end(), [](const auto &x, const auto &y) { return x.lane < y.lane; });
+
+    std::vector<std::pair<std::uint32_t, std::exception_ptr>> cb_eptrs;
+    std::vector<double> upd_cd, upd_oc;
+    const auto gen = time_gen;
+    for (auto &lr : recs) {
+        const auto by_root = [](const auto &x, const auto &y) { return std::abs(x.root) < std::abs(y.root); };
+        std::stable_sort(lr.tes.begin(), lr.tes.end(), by_root);
+        std::stable_sort(lr.ntes.begin(), lr.ntes.end(), by_root);
+        const auto i = lr.lane;
+        const auto h = lr.h;
+        const auto new_time = dfloat(lr.thi, lr.tlo);
+
+        // Non-terminal events triggering before the first terminal event (:837-871).
+        bool nt_cb_exception = false;
+        for (const auto &ev : lr.ntes) {
+            if (!lr.tes.empty() && !(std::abs(ev.root) < std::abs(h))) {
+                break;
+            }
+            try {
+                ntes[ev.idx].callback(cb_ctx, static_cast<double>(new_time - h + ev.root), ev.d_sgn, i);
+            } catch (...) {
+                cb_eptrs.emplace_back(i, std::current_exception());
+                nt_cb_exception = true;
+                break;
+            }
+        }
+        if (nt_cb_exception || lr.tes.empty()) {
+            continue;
+        }
+
+        // The first terminal event (:875-908).
+        const auto &ev = lr.tes[0];
+        auto &te = tes[ev.idx];
+        auto cd = te.cooldown;
+        if (!(cd >= 0)) {
+            // taylor_deduce_cooldown(), src/detail/event_detection.cpp:519-550.
+            cd = lr.g_eps / ev.abs_der * 10;
+            if (!std::isfinite(cd)) {
+                cd = 0;
+            }
+        }
+        upd_cd.insert(upd_cd.end(), {static_cast<double>(static_cast<std::size_t>(ev.idx) * n + i), 0., cd});
+        bool te_cb_ret = false;
+        if (te.callback) {
+            try {
+                te_cb_ret = te.callback(cb_ctx, ev.d_sgn, i);
+            } catch (...) {
+                cb_eptrs.emplace_back(i, std::current_exception());
+                continue;
+            }
+        }
+        const auto ev_idx = static_cast<std::int64_t>(ev.idx);
+        upd_oc.insert(upd_oc.end(), {static_cast<double>(i), static_cast<double>(te_cb_ret ? ev_idx : (-ev_idx - 1))});
+    }
+    if (!upd_cd.empty() || !upd_oc.empty()) {
+        // NOTE: a callback may have moved the host mirrors ahead (mutable getters): the device arrays touched here
+        // (cooldowns, outcomes) are not among those it can reach.
+        std::vector<double> upd(upd_cd);
+        upd.insert(upd.end(), upd_oc.begin(), upd_oc.end());
+        if (upd.size() * dsz > d_ev_upd.bytes()) {
+            d_ev_upd = device_buffer((upd.size() * 2u + 64u) * dsz, device);
+        }
+        d_ev_upd.upload(upd.data(), upd.size() * dsz, stream);
+        pa.upd = d_ev_upd.as<double>();
+        pa.n_cd = static_cast<unsigned>(upd_cd.size() / 3u);
+        pa.n_oc = static_cast<unsigned>(upd_oc.size() / 2u);
+        ed_mod->launch("hy_ev_scatter", pa.n_cd + pa.n_oc, 256, &pa, sizeof(pa), stream);
+        stream_synchronize(device, stream);
+    }
+
+    if (!cb_eptrs.empty()) {
+        throw_callback_exceptions(cb_eptrs);
+    }
+    if (time_gen != gen) {
+        // A callback went through set_time() / set_dtime(): compare the host mirror with the times of the device.
+        std::vector<double> thi(n), tlo(n);
+        d_thi.download(thi.data(), n * dsz, stream);
+        d_tlo.download(tlo.data(), n * dsz, stream);
+        for (std::uint32_t i = 0; i < N; ++i) {
+            const auto same = [](double x, double y) { return x == y || (std::isnan(x) && std::isnan(y)); };
+            if (!same(time_hi[i], thi[i]) || !same(time_lo[i], tlo[i])) {
+                throw std::runtime_error("The invocation of one or more event callbacks resulted in the alteration of the "
+                                         "time coordinate of the integrator at the batch index "
+                                         + std::to_string(i) + " - this is not supported");
+            }
+        }
+    }
+}
+
+// The first implementation: every lane goes through the host (kept as a cross-check, HEYOKA_AMD_EVENTS_HOST_LOGIC=1).
+void tab_core::impl::step_with_events_host(const std::vector<double> &lims)
+{
+    const auto n = static_cast<std::size_t>(N);
+    const auto dsz = sizeof(double);
+    const auto n_te = static_cast<std::uint32_t>(tes.size());
+    constexpr auto maxd = max_detected_per_lane;
+
+    before_kernel();
+    ensure_event_buffers();
+    cooldowns_to_host();
+
+    // 1. Stepper with events.
+    launch_event_stepper(lims);
 
     // 2. Maximum error on the Taylor series of the event equations (:744-767).
     std::vector<double> mas(n), g_eps(n), hs(n);
@@ -946,27 +1280,10 @@ void tab_core::impl::step_with_events(const std::vector<double> &lims, bool wtc)
     d_geps.upload(g_eps.data(), n * dsz, stream);
 
     // 3. Event detection on the device.
-    if (n_te != 0u) {
-        std::vector<double> cf(static_cast<std::size_t>(n_te) * n, 0.), cs(static_cast<std::size_t>(n_te) * n, 0.);
-        std::vector<int> ca(static_cast<std::size_t>(n_te) * n, 0);
-        for (std::size_t i = 0; i < n; ++i) {
-            for (std::uint32_t e = 0; e < n_te; ++e) {
-                if (const auto &cd = te_cooldowns[i][e]) {
-                    cf[e * n + i] = cd->first;
-                    cs[e * n + i] = cd->second;
-                    ca[e * n + i] = 1;
-                }
-            }
-        }
-        d_cd_first.upload(cf.data(), cf.size() * dsz, stream);
-        d_cd_second.upload(cs.data(), cs.size() * dsz, stream);
-        d_cd_active.upload(ca.data(), ca.size() * sizeof(int), stream);
-    }
-    d_ed_flags.zero(stream);
-    const ed_kargs ea{d_ev_tc.as<double>(),   d_lasth.as<double>(),     d_geps.as<double>(),     d_dirs.as<int>(),
-                      d_cd_first.as<double>(), d_cd_second.as<double>(), d_cd_active.as<int>(),   d_ed_out.as<double>(),
-                      d_ed_counts.as<unsigned>(), d_ed_flags.as<unsigned>(), N, n_te, n_nte};
-    ed_mod->launch("hy_detect_events", N, 64, &ea, sizeof(ea), stream);
+    cd_host_newer = true;
+    cooldowns_to_device();
+    cd_host_newer = true; // (the host copy stays authoritative in this variant)
+    launch_event_detection(false);
     std::vector<unsigned> counts(2u * n);
     std::vector<double> ed_out(2u * n * maxd * 4u);
     unsigned flags[1] = {0};
@@ -975,18 +1292,8 @@ void tab_core::impl::step_with_events(const std::vector<double> &lims, bool wtc)
     if (std::any_of(counts.begin(), counts.end(), [](unsigned c) { return c != 0u; })) {
         d_ed_out.download(ed_out.data(), ed_out.size() * dsz, stream);
     }
-    if (flags[0] != 0u) {
-        // The per-lane lists of detected events / the work list of the root isolation are of fixed size on the device
-        // (16 events per class and lane, 64 intervals): an overflow drops events. The reference has no fixed cap and
-        // logs a warning when the isolation fails; here the count is kept (get_event_detection_failures()) and the
-        // first occurrence is reported on stderr.
-        if (ed_failures == 0u) {
-            std::fprintf(stderr, "heyoka_amd: warning: event detection overflow in %u lane(s) (more than 16 events of one "
-                                 "class in a step, or root isolation work list exhausted): events may have been "
-                                 "dropped - reduce the step (max_delta_t) around dense clusters of events\n", flags[0]);
-        }
-        ed_failures += flags[0];
-    }
+    report_ed_failures(ed_failures, flags[0]);
+    (void)n_te;
 
     // Per-lane lists, sorted by the absolute value of the trigger time (:771-778).
     std::vector<std::vector<detected_event>> d_tes(n), d_ntes(n);
@@ -1009,10 +1316,6 @@ void tab_core::impl::step_with_events(const std::vector<double> &lims, bool wtc)
 
     // 4. State update via dense output at the final step sizes (:781), then back to the host: the callbacks may
     //    read and write state and parameters.
-    if (d_dout.bytes() == 0u) {
-        d_dout = device_buffer(d_out.size() * dsz, device);
-        d_douth = device_buffer(n * dsz, device);
-    }
     d_douth.upload(hs.data(), n * dsz, stream);
     dmod->launch_dout(d_state.as<double>(), d_tc.as<double>(), d_douth.as<double>(), N);
     d_state.download(state.data(), state.size() * dsz, stream);
@@ -1114,23 +1417,7 @@ void tab_core::impl::step_with_events(const std::vector<double> &lims, bool wtc)
     }
 
     if (!cb_eptrs.empty()) {
-        if (cb_eptrs.size() == 1u) {
-            std::rethrow_exception(cb_eptrs[0].second);
-        }
-        std::string exc_msg = "Two or more exceptions were raised during the execution of event callbacks in a "
-                              "batch integrator:\n\n";
-        for (auto &[i, eptr] : cb_eptrs) {
-            exc_msg += "Batch index #" + std::to_string(i) + ":\n";
-            try {
-                std::rethrow_exception(eptr);
-            } catch (const std::exception &ex) {
-                exc_msg += std::string("    Exception message: ") + ex.what() + "\n";
-            } catch (...) {
-                exc_msg += "    Exception type: unknown\n    Exception message: unknown\n";
-            }
-            exc_msg += '\n';
-        }
-        throw std::runtime_error(exc_msg);
+        throw_callback_exceptions(cb_eptrs);
     }
     for (std::uint32_t i = 0; i < N; ++i) {
         const auto same = [](double x, double y) { return x == y || (std::isnan(x) && std::isnan(y)); };
@@ -2126,6 +2413,7 @@ void tab_core::set_device(int device)
     d.to_host();
     d.fetch_step_res();
     d.fetch_prop_res();
+    d.cooldowns_to_host();
     (void)get_last_h();
     if (d.tc_dev_newer && d.dmod) {
         (void)get_tc();
@@ -2154,6 +2442,10 @@ void tab_core::set_device(int device)
     d.grid_mod.reset();
     d.evj_mod.reset();
     d.d_selnorms = {};
+    d.d_ev_cursor = {};
+    d.d_ev_rec = {};
+    d.d_ev_upd = {};
+    d.cd_host_newer = true;
     d.d_ev_tc = {};
     d.d_mas = {};
     d.d_geps = {};
