@@ -57,6 +57,9 @@ struct emit_options {
     std::uint32_t block_size = 256;
     // Number of systems integrated at the same time (0: unknown); steers latency- vs throughput-oriented variants.
     std::uint64_t batch_size = 0;
+    // Wave-cluster steppers: emit the stepper of an integrator with events - every launch is a mode-4 step (jets of the
+    // state variables to a.tc, selector norms to a.sel_norms, no state update; emitted_module::cluster_mode4).
+    bool event_stepper = false;
 };
 
 struct emitted_module {

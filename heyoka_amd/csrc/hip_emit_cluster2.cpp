@@ -69,6 +69,7 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         pp.ok = ok && 2u * nc <= max_lanes && p.n_par == 0u && !(ev != nullptr && std::atoi(ev) == 0);
     }
     const bool pair_split = pp.ok;
+    const bool m4 = opts.event_stepper;
     if (pair_split) {
         pl.L = 2;
         while (pl.L < 2u * nc) {
@@ -1009,6 +1010,7 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     // ===================== module text =====================
     std::ostringstream src;
     src << "#define SPW " << spw << "u\n#define HY_WPB " << wpb << "u\n";
+    src << "#define HY_M4 " << (m4 ? 1 : 0) << "\n";
     src << "#define HY_NO_STATIC " << (std::getenv("HEYOKA_AMD_NO_STATIC_SCHEDULE") != nullptr ? 1 : 0) << "\n";
     if (std::getenv("HEYOKA_AMD_NO_NMAX") != nullptr) {
         src << "#define HY_NO_NMAX 1\n";
@@ -1060,6 +1062,25 @@ __device__ __forceinline__ double hy_swap1(double x)
                 return ret;
             }
             src << x << ",";
+        }
+    }
+    src << "};\n";
+    {
+        // Jet column of every state variable.
+        std::vector<std::uint32_t> col_of(n_eq, 0);
+        for (const auto &rg : rounds) {
+            for (const auto &gr : rg) {
+                for (const auto &ow : gr.owners) {
+                    const auto &vv = utbl[ow.var_tbl];
+                    for (std::uint32_t l2 = 0; l2 < ow.n_valid; ++l2) {
+                        col_of[vv[l2]] = ow.cbase + l2;
+                    }
+                }
+            }
+        }
+        src << "__constant__ unsigned short hy_col_of_var[" << n_eq << "] = {";
+        for (const auto c : col_of) {
+            src << c << ",";
         }
     }
     src << "};\n__constant__ double hy_dtbl[" << std::max<std::size_t>(dtbl.size(), 1u) * L << "] = {";
@@ -1124,6 +1145,9 @@ u64 hy_it = 0;
 for (;;) {
 u64 base = 0;
 if (hy_static) {
+    // (Exit decided per workgroup: the cooperative store of the Taylor coefficients below has workgroup barriers. A
+    // wavefront beyond the end of the ensemble in a live workgroup replicates the last system, without side effects.)
+    if (HY_M4 && (hy_it * (u64)gridDim.x + blockIdx.x) * (HY_WPB * SPW) >= N) break;
     base = (hy_it * hy_waves + gwave) * SPW;
     ++hy_it;
 } else {
@@ -1132,7 +1156,7 @@ if (hy_static) {
 // NOTE: through readfirstlane the position is a scalar for the compiler and the exit of the work loop a wave-uniform
 // branch (a shuffle / the wavefront index leave it "divergent": exec-mask bookkeeping around the whole step loop).
 base = ((u64)__builtin_amdgcn_readfirstlane((unsigned)(base >> 32)) << 32) | (u64)__builtin_amdgcn_readfirstlane((unsigned)base);
-if (base >= N) break;
+if (!(HY_M4 && hy_static) && base >= N) break;
 // NOTE: lanes beyond the end of the ensemble replicate the last system (no side effects).
 const bool live = (base + q) < N;
 const u64 s = live ? (base + q) : (N - 1u);
@@ -1220,8 +1244,12 @@ lim = fin ? 0.0 : lim;
     }
     // Mode 4 (stepper with events): the norms over the state variables go to the kernel which extends them to the event
     // equations (hy_ev_jets). A wave-uniform branch; every lane of the system stores the same values.
-    src << "const bool nostate = a.mode == 4;\n";
-    src << "if (nostate) {\na.sel_norms[s] = m0;\na.sel_norms[N + s] = mo;\na.sel_norms[2u * N + s] = mom1;\n}\n";
+    // (A separate specialisation of the kernel - opts.event_stepper - so that the propagation kernel is not touched: the
+    // extra code, although never executed there, costs it spills in the step loop.)
+    src << "const bool nostate = " << (m4 ? "true" : "false") << ";\n";
+    if (m4) {
+        src << "a.sel_norms[s] = m0;\na.sel_norms[N + s] = mo;\na.sel_norms[2u * N + s] = mom1;\n";
+    }
     src << "const double num_rho = (m0 <= 1.0) ? 1.0 : m0;\n";
     // NOTE: rho = exp(log(x) / order) (hy_root): the minimum of the two estimates is taken on the exponents (exp is
     // monotone and keeps NaNs: the same selection as min(rho_o, rho_om1), src/taylor_02.cpp:1050-1072, one exp less).
@@ -1248,6 +1276,11 @@ lim = fin ? 0.0 : lim;
     // one per owner slot (3 instead of 4 for the 36 variables of the outer Solar System on 16 lanes).
     const auto kstride = static_cast<std::uint64_t>(spw) * n_colp;
     for (std::uint32_t c = 0; c < n_hslots; ++c) {
+        if (m4) {
+            // (No state update in the stepper with events.)
+            src << "const double xn" << c << " = hc" << c << "[0];\n";
+            continue;
+        }
         src << "double xn" << c << ";\n{\nconst double *c = hc" << c << ";\n";
         if (opts.high_accuracy) {
             src << "double res = c[0], comp = 0.0, cur_h = h;\n#pragma unroll\n";
@@ -1289,7 +1322,7 @@ int nfi = !(hy_finite(nt_hi) && hy_finite(nt_lo)) ? 1 : 0;
     // loop (see the toolchain notes in DESIGN.md). A rolled loop with a running pointer: unrolled, the (order + 1)
     // store addresses per owner slot are invariants of the step loop and get hoisted into registers (84 x 64 bit for
     // the outer Solar System) for a path that only runs when the caller asks for the coefficients.
-    src << "if (a.tc != nullptr) {\n";
+    src << (jet_lds ? "if (a.tc != nullptr && !nostate) {\n" : "if (a.tc != nullptr) {\n");
     for (const auto &rg : rounds) {
         for (const auto &gr : rg) {
             for (const auto &ow : gr.owners) {
@@ -1344,6 +1377,24 @@ if (__builtin_amdgcn_ballot_w64(!fin) == 0ull) break;
 }
 if (nf_seen != 0 && l == 0u && live) atomicAdd(a.counters, 1u);
 )HIP";
+    if (jet_lds && m4) {
+        // Mode 4: the Taylor coefficients of the workgroup's systems (consecutive under the static schedule) leave through
+        // a cooperative store - [variable][order] rows of HY_WPB * SPW consecutive systems, whole 128-byte lines for the
+        // 16 systems of the lane-pair kernel - instead of 16-byte pieces per wavefront (the per-wavefront stores make
+        // the 1 048 576-system stepper with events transaction bound: 8 ms instead of 3).
+        const auto spb = wpb * spw;
+        src << "{\n__syncthreads();\n";
+        src << "const u64 bs0 = base - (u64)wib * SPW;\n";
+        src << "for (unsigned idx = threadIdx.x; idx < " << n_eq * (order + 1u) * spb << "u; idx += " << bs << "u) {\n";
+        src << "const unsigned sy = idx % " << spb << "u, row = idx / " << spb << "u;\n";
+        src << "const unsigned var = row / " << (order + 1u) << "u, k = row % " << (order + 1u) << "u;\n";
+        src << "const u64 sg = bs0 + sy;\n";
+        src << "const double val = lds_jet[(sy / SPW) * " << jet_doubles_per_wave << "u + k * " << spw * n_colp
+            << "u + (sy % SPW) * " << n_colp << "u + hy_col_of_var[var]];\n";
+        src << "if (sg < N) a.tc[(u64)row * N + sg] = val;\n}\n__syncthreads();\n}\n";
+    }
+    src << R"HIP(
+)HIP";
     for (const auto &rg : rounds) {
         for (const auto &gr : rg) {
             for (const auto &ow : gr.owners) {
@@ -1390,7 +1441,7 @@ if (l == 0u && live) {
         ret.compile_flags = "-mllvm -disable-machine-licm";
     }
     ret.tc_optional = true;
-    ret.cluster_mode4 = true;
+    ret.cluster_mode4 = m4;
     ret.notes = std::string(pair_split ? "cluster mode v3 (lane pairs, 2 wavefronts per SIMD): " : "cluster mode v2 (pipelined): ")
                 + std::to_string(nc) + " clusters of " + std::to_string(t0.size())
                 + " nodes, L=" + std::to_string(L) + ", " + std::to_string(pl.n_slots) + " LDS slots x2, "

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cassert>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -286,6 +287,28 @@ struct tab_core::impl {
         return a;
     }
 
+    // step() / step_backward(): the limits are +-infinity for every lane - kept in two vectors built once, uploaded only
+    // when d_lim does not hold them already (8 MB per call for 1 048 576 systems otherwise).
+    std::vector<double> lims_pinf, lims_ninf;
+    const double *d_lim_src = nullptr;
+    const std::vector<double> &inf_lims(bool forward)
+    {
+        auto &v = forward ? lims_pinf : lims_ninf;
+        if (v.size() != N) {
+            v.assign(N, forward ? std::numeric_limits<double>::infinity() : -std::numeric_limits<double>::infinity());
+        }
+        return v;
+    }
+    void upload_lims(const std::vector<double> &lims)
+    {
+        const bool cached = lims.data() == lims_pinf.data() || lims.data() == lims_ninf.data();
+        if (cached && lims.data() == d_lim_src) {
+            return;
+        }
+        d_lim.upload(lims.data(), lims.size() * sizeof(double), stream);
+        d_lim_src = cached ? lims.data() : nullptr;
+    }
+
     // One lock-step sweep: a single step for every lane with the per-lane signed limits 'lims'.
     // NOTE: lims == nullptr -> the step limits are already in d_lim (device-driven loops).
     void run_step(const std::vector<double> &lims, bool wtc)
@@ -296,7 +319,9 @@ struct tab_core::impl {
     {
         before_kernel();
         if (lims != nullptr) {
-            d_lim.upload(lims->data(), lims->size() * sizeof(double), stream);
+            upload_lims(*lims);
+        } else {
+            d_lim_src = nullptr;
         }
         d_counters.zero(stream);
         auto a = base_args();
@@ -486,6 +511,7 @@ tab_core::tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_siz
             const auto prog0 = make_program(taylor_decompose_sys(sys), d.dim);
             auto eo2 = eo;
             eo2.mode = emit_mode::cluster;
+            eo2.event_stepper = true;
             auto m = emit_hip_module(prog0, eo2);
             std::string why;
             if (m.cluster_mode4) {
@@ -986,7 +1012,7 @@ void tab_core::impl::launch_event_stepper(const std::vector<double> &lims)
 {
     const auto n = static_cast<std::size_t>(N);
     const auto dsz = sizeof(double);
-    d_lim.upload(lims.data(), n * dsz, stream);
+    upload_lims(lims);
     d_counters.zero(stream);
     auto a = base_args();
     a.tc = d_tc.as<double>();
@@ -1083,12 +1109,26 @@ void tab_core::impl::step_with_events_device(const std::vector<double> &lims)
     const auto dsz = sizeof(double);
     const auto n_te = static_cast<std::uint32_t>(tes.size()), n_nte = static_cast<std::uint32_t>(ntes.size());
 
+    // HEYOKA_AMD_EVENTS_TIMING=1: wall-clock time of the phases (with a stream synchronisation after each of them).
+    static const bool timing = std::getenv("HEYOKA_AMD_EVENTS_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    const auto lap = [&](const char *what) {
+        if (timing) {
+            stream_synchronize(device, stream);
+            const auto now = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[events] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+            t_last = now;
+        }
+    };
     before_kernel();
     ensure_event_buffers();
     cooldowns_to_device();
+    lap("upload / buffers");
 
     launch_event_stepper(lims);
+    lap("stepper (+ event jets)");
     launch_event_detection(true);
+    lap("detection");
 
     ep_kargs pa{};
     pa.h = d_lasth.as<double>();
@@ -1117,6 +1157,7 @@ void tab_core::impl::step_with_events_device(const std::vector<double> &lims)
     d_ed_flags.download(flags, sizeof(flags), stream);
     d_ev_cursor.download(cur, sizeof(cur), stream);
     report_ed_failures(ed_failures, flags[0]);
+    lap("pre + flags to host");
     if (cur[0] * dsz > d_ev_rec.bytes()) {
         d_ev_rec = device_buffer(static_cast<std::size_t>(cur[0] + cur[0] / 2u + 1024u) * dsz, device);
     }
@@ -1136,6 +1177,7 @@ void tab_core::impl::step_with_events_device(const std::vector<double> &lims)
     } else {
         stream_synchronize(device, stream);
     }
+    lap("dout + post + records");
     host_newer = false;
     after_kernel();
     step_res_dev_newer = true;
@@ -1432,7 +1474,7 @@ void tab_core::impl::step_with_events_host(const std::vector<double> &lims)
 // ---- stepping (reference: src/taylor_adaptive_batch.cpp:1039-1080) ----
 void tab_core::step(bool wtc)
 {
-    const std::vector<double> lims(m_impl->N, std::numeric_limits<double>::infinity());
+    const auto &lims = m_impl->inf_lims(true);
     if (m_impl->has_events()) {
         m_impl->step_with_events(lims, wtc);
     } else {
@@ -1442,7 +1484,7 @@ void tab_core::step(bool wtc)
 
 void tab_core::step_backward(bool wtc)
 {
-    const std::vector<double> lims(m_impl->N, -std::numeric_limits<double>::infinity());
+    const auto &lims = m_impl->inf_lims(false);
     if (m_impl->has_events()) {
         m_impl->step_with_events(lims, wtc);
     } else {
@@ -1554,6 +1596,7 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
             a.lim = nullptr;
         } else {
             d.d_lim.upload(max_delta_ts.data(), max_delta_ts.size() * sizeof(double), d.stream);
+            d.d_lim_src = nullptr;
         }
         if (wtc && d.is_cluster()) {
             d.ensure_tc();
@@ -1643,6 +1686,7 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
             a.lim = nullptr;
         } else {
             d.d_lim.upload(max_delta_ts.data(), max_delta_ts.size() * sizeof(double), d.stream);
+            d.d_lim_src = nullptr;
         }
         if (wtc && d.is_cluster()) {
             d.ensure_tc();
@@ -1706,6 +1750,7 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
         d.d_tfhi.upload(tf_hi.data(), N * dsz, d.stream);
         d.d_tflo.upload(tf_lo.data(), N * dsz, d.stream);
         d.d_lim.upload(cur_max.data(), N * dsz, d.stream);
+        d.d_lim_src = nullptr;
         d.d_minh.upload(min_abs_h.data(), N * dsz, d.stream);
         d.d_maxh.upload(max_abs_h.data(), N * dsz, d.stream);
         d.d_nsteps.upload(ns0.data(), N * sizeof(unsigned long long), d.stream);
@@ -2057,6 +2102,7 @@ void tab_core::propagate_grid_device_loop(const std::vector<double> &grid, std::
     b_tdir.upload(t_dir.data(), N * sizeof(int), d.stream);
     b_gidx.upload(gidx.data(), N * sizeof(unsigned), d.stream);
     d.d_lim.upload(lim.data(), N * dsz, d.stream);
+    d.d_lim_src = nullptr;
     d.d_minh.upload(mn.data(), N * dsz, d.stream);
     d.d_maxh.upload(mx.data(), N * dsz, d.stream);
     d.d_nsteps.upload(ns.data(), N * sizeof(unsigned long long), d.stream);
@@ -2424,6 +2470,7 @@ void tab_core::set_device(int device)
     d.d_thi = {};
     d.d_tlo = {};
     d.d_lim = {};
+    d.d_lim_src = nullptr;
     d.d_tfhi = {};
     d.d_tflo = {};
     d.d_lasth = {};

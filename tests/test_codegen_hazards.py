@@ -24,7 +24,11 @@ def _cases():
     pw = [(x, hy.atan2(y, 1.5 + x * x) - hy.relu(x, 0.1) + hy.sin(hy.kepE(0.3, y)) + hy.erf(x * y)),
           (y, hy.select(hy.gt(x, y), hy.tanh(x), -y) - 0.5 * y + hy.asin(0.3 * hy.sin(x)))]
     ev = [hy.nt_event(y, lambda *a: None)]
+    x1, x2 = hy.make_vars("x_1", "x_2")
+    ev_ss = [hy.nt_event((x1 - x2) * (x1 - x2) - 4.0, lambda *a: None)]
     return {
+        "outer_ss_cluster_event_stepper": (lambda: hy.model.nbody(6, masses=M, Gconst=G),
+                                           {"high_accuracy": True, "nt_events": ev_ss}, {}, "events:"),
         "outer_ss_cluster_v2": (lambda: hy.model.nbody(6, masses=M, Gconst=G), {"high_accuracy": True}, {}, "cluster"),
         "outer_ss_cluster_v1": (lambda: hy.model.nbody(6, masses=M, Gconst=G), {}, {"HEYOKA_AMD_CLUSTER_V1": "1"}, "cluster"),
         "np1body_aliased": (lambda: hy.model.np1body(6, masses=M, Gconst=G), {}, {}, "cluster"),
