@@ -147,9 +147,15 @@ struct tab_core::impl {
     }
     void step_with_events(const std::vector<double> &lims, bool wtc);
     void step_with_events_host(const std::vector<double> &lims);
-    void step_with_events_device(const std::vector<double> &lims);
+    // (lims == nullptr: the step limits are already in d_lim - device-driven loops.)
+    void step_with_events_device(const std::vector<double> *lims);
+    [[nodiscard]] static bool events_host_logic()
+    {
+        const char *ev = std::getenv("HEYOKA_AMD_EVENTS_HOST_LOGIC");
+        return ev != nullptr && std::atoi(ev) != 0;
+    }
     void ensure_event_buffers();
-    void launch_event_stepper(const std::vector<double> &lims);
+    void launch_event_stepper(const std::vector<double> *lims);
     unsigned launch_event_detection(bool device_g_eps);
     // Terminal-event cooldowns: the device arrays (d_cd_*) are authoritative between steps with events (updated by
     // hy_ev_post / hy_ev_scatter); te_cooldowns is the lazily synchronised host mirror.
@@ -1008,11 +1014,15 @@ void tab_core::impl::ensure_event_buffers()
 }
 
 // Stepper with events: jets of the state and of the event equations, step sizes, max |x_i|, no state update.
-void tab_core::impl::launch_event_stepper(const std::vector<double> &lims)
+void tab_core::impl::launch_event_stepper(const std::vector<double> *lims)
 {
     const auto n = static_cast<std::size_t>(N);
     const auto dsz = sizeof(double);
-    upload_lims(lims);
+    if (lims != nullptr) {
+        upload_lims(*lims);
+    } else {
+        d_lim_src = nullptr;
+    }
     d_counters.zero(stream);
     auto a = base_args();
     a.tc = d_tc.as<double>();
@@ -1050,11 +1060,10 @@ void tab_core::impl::step_with_events(const std::vector<double> &lims, bool wtc)
 {
     (void)wtc; // The Taylor coefficients are always written by the stepper with events (:756-757).
     // HEYOKA_AMD_EVENTS_HOST_LOGIC=1: the per-lane bookkeeping of every lane on the host (the first implementation).
-    const char *ev = std::getenv("HEYOKA_AMD_EVENTS_HOST_LOGIC");
-    if (ev != nullptr && std::atoi(ev) != 0) {
+    if (events_host_logic()) {
         step_with_events_host(lims);
     } else {
-        step_with_events_device(lims);
+        step_with_events_device(&lims);
     }
 }
 
@@ -1103,7 +1112,7 @@ void report_ed_failures(std::uint64_t &ed_failures, unsigned flags)
 // One step with events, per-lane bookkeeping on the device: only the lanes with detected events reach the host (compact
 // records), which runs the callbacks and the logic that depends on them (src/taylor_adaptive_batch.cpp:837-1030) in
 // the order of the batch index; state, times, step sizes, outcomes and cooldowns stay on the device.
-void tab_core::impl::step_with_events_device(const std::vector<double> &lims)
+void tab_core::impl::step_with_events_device(const std::vector<double> *lims)
 {
     const auto n = static_cast<std::size_t>(N);
     const auto dsz = sizeof(double);
@@ -1304,7 +1313,7 @@ void tab_core::impl::step_with_events_host(const std::vector<double> &lims)
     cooldowns_to_host();
 
     // 1. Stepper with events.
-    launch_event_stepper(lims);
+    launch_event_stepper(&lims);
 
     // 2. Maximum error on the Taylor series of the event equations (:744-767).
     std::vector<double> mas(n), g_eps(n), hs(n);
@@ -1721,7 +1730,7 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
     const auto pinf = std::numeric_limits<double>::infinity();
     std::size_t iter_counter = 0;
 
-    if (!d.has_events() && std::getenv("HEYOKA_AMD_LOCKSTEP_HOST_LOOP") == nullptr) {
+    if ((!d.has_events() || !impl::events_host_logic()) && std::getenv("HEYOKA_AMD_LOCKSTEP_HOST_LOOP") == nullptr) {
         // Device-driven loop: the per-lane bookkeeping runs in a post-step kernel, the host reads two counters per
         // sweep, runs the callback and (for the continuous output) appends the coefficients device-to-device.
         d.ensure_device();
@@ -1760,7 +1769,12 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
             }
         };
         while (true) {
-            d.run_step_impl(nullptr, wtc);
+            if (d.has_events()) {
+                // (Callbacks of the events run inside: state, times, outcomes and cooldowns stay on the device.)
+                d.step_with_events_device(nullptr);
+            } else {
+                d.run_step_impl(nullptr, wtc);
+            }
             b_cnt.zero(d.stream);
             const grid_kargs a{d.d_tfhi.as<double>(), d.d_tflo.as<double>(), nullptr, d.d_thi.as<double>(),
                                d.d_tlo.as<double>(), d.d_lasth.as<double>(), d.d_outcome.as<long long>(),
@@ -1768,7 +1782,7 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
                                d.d_lim.as<double>(), nullptr, d.d_minh.as<double>(), d.d_maxh.as<double>(),
                                d.d_nsteps.as<unsigned long long>(), b_cnt.as<unsigned>(), N, 0u};
             d.grid_mod->launch("hy_until_post", N, 256, &a, sizeof(a), d.stream);
-            unsigned cnt[2] = {0, 0};
+            unsigned cnt[3] = {0, 0, 0};
             b_cnt.download(cnt, sizeof(cnt), d.stream);
             // Outcomes of the last sweep + accumulated statistics: on the device.
             d.prop_res_dev_newer = true;
@@ -1796,7 +1810,8 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
                     return;
                 }
             }
-            if (cnt[0] == N) {
+            // (cnt[2]: lanes stopped by a terminal event - the propagation of the whole batch ends, :1411, :1429.)
+            if (cnt[0] == N || cnt[2] != 0u) {
                 make_c_out();
                 return;
             }
@@ -1961,6 +1976,8 @@ extern "C" __global__ void __launch_bounds__(256) hy_until_post(const hy_grid_ar
         a.min_h[i] = hy_min(a.min_h[i], ah);
         a.max_h[i] = hy_max(a.max_h[i], ah);
     }
+    // Stopping terminal event: outcome -index - 1 (src/taylor_adaptive_batch.cpp:1411).
+    if (oc > HY_OC_SUCCESS && oc < 0) atomicAdd(a.counters + 2, 1u);
     hy_df rem; rem.hi = a.rem_hi[i]; rem.lo = a.rem_lo[i];
     if (h == rem.hi) {
         atomicAdd(a.counters, 1u);

@@ -12,6 +12,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--systems", type=int, default=262144)
 ap.add_argument("--steps", type=int, default=6)
 ap.add_argument("--skip-lane-stepper", action="store_true")
+ap.add_argument("--d2", type=float, default=81.0, help="squared Jupiter - Saturn distance of the event")
+ap.add_argument("--propagate", type=float, default=0.0, help="also time propagate_until(T)")
 args = ap.parse_args()
 M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
 n = args.systems
@@ -21,7 +23,7 @@ sys_ = hy.model.nbody(6, masses=M, Gconst=G)
 
 def events(log):
     x1, y1, z1, x2, y2, z2 = hy.make_vars("x_1", "y_1", "z_1", "x_2", "y_2", "z_2")
-    d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2) - 81.0
+    d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2) - args.d2
     return [hy.nt_event(d2, lambda ta, t, d, i: log.append((i, t)), direction=hy.event_direction.negative)]
 
 
@@ -35,8 +37,16 @@ def run(tag, **kw):
         ta.step()
     _ = ta.time  # (step() without events returns before the kernel has finished: the getter synchronises)
     el = (time.perf_counter() - t0) / args.steps
-    print(json.dumps({"tag": tag, "systems": n, "s_per_step": el, "system_steps_per_s": n / el,
-                      "events_seen": len(log), "mode": ta.hip_source_mode[:70]}), flush=True)
+    out = {"tag": tag, "systems": n, "s_per_step": el, "system_steps_per_s": n / el, "events_seen": len(log),
+           "mode": ta.hip_source_mode[:70]}
+    if args.propagate > 0:
+        t0 = time.perf_counter()
+        ta.propagate_until(float(ta.time[0]) + args.propagate)
+        res = ta.propagate_res_arrays()
+        el = time.perf_counter() - t0
+        out.update({"propagate_s": el, "propagate_steps": float(res[3].sum()), "propagate_system_steps_per_s": float(res[3].sum()) / el,
+                    "events_seen_total": len(log)})
+    print(json.dumps(out), flush=True)
 
 
 run("no events")
