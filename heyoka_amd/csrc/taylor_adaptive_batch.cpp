@@ -2012,6 +2012,8 @@ extern "C" __global__ void __launch_bounds__(256) hy_grid_post(const hy_grid_arg
         a.min_h[i] = hy_min(a.min_h[i], ah);
         a.max_h[i] = hy_max(a.max_h[i], ah);
     }
+    // Stopping terminal event: outcome -index - 1 (:1903-1908).
+    if (oc > HY_OC_SUCCESS && oc < 0) atomicAdd(a.counters + 2, 1u);
     hy_df tcur; tcur.hi = a.thi[i]; tcur.lo = a.tlo[i];
     hy_df rem; rem.hi = a.rem_hi[i]; rem.lo = a.rem_lo[i];
     const unsigned ng = a.n_grid;
@@ -2128,7 +2130,11 @@ void tab_core::propagate_grid_device_loop(const std::vector<double> &grid, std::
     std::size_t iter_counter = 0;
     bool any_step = false;
     while (n_grid > 1u) {
-        d.run_step_impl(nullptr, true);
+        if (d.has_events()) {
+            d.step_with_events_device(nullptr);
+        } else {
+            d.run_step_impl(nullptr, true);
+        }
         any_step = true;
         b_cnt.zero(d.stream);
         const grid_kargs a{b_grid.as<double>(),    out_ptr,     d.d_tc.as<double>(),   d.d_thi.as<double>(),
@@ -2137,14 +2143,15 @@ void tab_core::propagate_grid_device_loop(const std::vector<double> &grid, std::
                            d.d_lim.as<double>(),   b_gidx.as<unsigned>(),  d.d_minh.as<double>(), d.d_maxh.as<double>(),
                            d.d_nsteps.as<unsigned long long>(), b_cnt.as<unsigned>(), N, n_grid};
         d.grid_mod->launch("hy_grid_post", N, 256, &a, sizeof(a), d.stream);
-        unsigned cnt[2] = {0, 0};
+        unsigned cnt[3] = {0, 0, 0};
         b_cnt.download(cnt, sizeof(cnt), d.stream);
         if (cnt[1] != 0u) {
             // A non-finite state was detected: stop (the outcomes of the last step are reported).
             break;
         }
         ++iter_counter;
-        if (cnt[0] == 0u) {
+        // (cnt[2]: lanes stopped by a terminal event - they interrupt the propagation of the whole batch.)
+        if (cnt[0] == 0u || cnt[2] != 0u) {
             break;
         }
         if (iter_counter == max_steps) {
@@ -2288,10 +2295,8 @@ std::vector<double> tab_core::propagate_grid(std::vector<double> grid, std::size
         t_dir[i] = rem[i] >= dfloat(0.);
     }
 
-    if (d_out != nullptr && d.has_events()) {
-        throw std::invalid_argument("propagate_grid() with a device output buffer does not support events");
-    }
-    if (d_out != nullptr || (!cb && !d.has_events() && std::getenv("HEYOKA_AMD_GRID_HOST_LOOP") == nullptr)) {
+    if (d_out != nullptr
+        || (!cb && (!d.has_events() || !impl::events_host_logic()) && std::getenv("HEYOKA_AMD_GRID_HOST_LOOP") == nullptr)) {
         // Device-resident lock-step loop: the step kernel and a post-step kernel (bookkeeping of the reference's
         // loop, dense output at the grid points covered by the step, next step limit) alternate without any
         // per-lane host work; the host only reads two counters per sweep.

@@ -1386,3 +1386,28 @@ def test_events_on_the_cluster_stepper_vs_oracle(monkeypatch):
     assert np.max(np.abs(np.array([a[2] for a in log_p]) - np.array([a[2] for a in log_o]))) <= 1e-10
     assert te_p == te_o and te_p == te_q
     assert [(a[0], a[1], a[3]) for a in log_p] == [(a[0], a[1], a[3]) for a in log_q]
+    # propagate_until() / propagate_grid() with events: the device-driven lock-step loops with the step with events as
+    # their sweep, against the oracle's host loop (propagate_until) and against the product's own host loops with the
+    # per-lane bookkeeping on the host (HEYOKA_AMD_EVENTS_HOST_LOGIC=1, on the one-system-per-lane stepper).
+    t_end = float(np.max(ora.time_hi)) + 12.0
+    ta.propagate_until(t_end)
+    ora.propagate_until(t_end)
+    monkeypatch.setenv("HEYOKA_AMD_EVENTS_HOST_LOGIC", "1")
+    tq.propagate_until(t_end)
+    monkeypatch.delenv("HEYOKA_AMD_EVENTS_HOST_LOGIC")
+    assert [int(r[0]) for r in ta.propagate_res] == [r[0] for r in ora.prop_res]
+    assert [int(r[0]) for r in ta.propagate_res] == [int(r[0]) for r in tq.propagate_res]
+    assert max(abs(a[3] - b[3]) for a, b in zip(ta.propagate_res, ora.prop_res)) <= 1
+    assert rel_err(ta.state, ora.state.reshape(36, n)) <= 1e7 * EPS
+    assert rel_err(ta.state, tq.state) <= 1e7 * EPS
+    assert [(a[0], a[1], a[3]) for a in log_p] == [(a[0], a[1], a[3]) for a in log_o]
+    assert [(a[0], a[1], a[3]) for a in log_p] == [(a[0], a[1], a[3]) for a in log_q]
+    assert te_p == te_o and te_p == te_q
+    grid = np.repeat(t_end + np.array([0.0, 1.5, 3.0, 7.0])[:, None], n, axis=1)
+    _, out_p = ta.propagate_grid(grid)
+    monkeypatch.setenv("HEYOKA_AMD_EVENTS_HOST_LOGIC", "1")
+    _, out_q = tq.propagate_grid(grid)
+    monkeypatch.delenv("HEYOKA_AMD_EVENTS_HOST_LOGIC")
+    assert rel_err(np.asarray(out_p), np.asarray(out_q)) <= 1e7 * EPS
+    assert [int(r[0]) for r in ta.propagate_res] == [int(r[0]) for r in tq.propagate_res]
+    assert [(a[0], a[1], a[3]) for a in log_p] == [(a[0], a[1], a[3]) for a in log_q]
