@@ -142,3 +142,37 @@ def test_propagate_until_rejects_time_vectors_of_the_wrong_size():
     for n in (3, 8, 5):
         with pytest.raises(ValueError, match="the number of specified time limits is %d" % n):
             ta.propagate_until([1.0] * n)
+
+
+def test_event_integrators_pick_the_cluster_stepper_when_the_event_equations_are_small(monkeypatch):
+    """Integrators with events: the wave-cluster stepper (built from the system alone, mode-4 specialisation) + hy_ev_jets
+    when the right-hand side qualifies and the event equations depend on a small part of the decomposition - including an
+    event equation which IS a state variable; otherwise (event equations which need most of the decomposition, systems
+    without a cluster structure, HEYOKA_AMD_EVENTS_ON_CLUSTER=0) the one-system-per-lane steppers with events."""
+    from heyoka_amd import configs
+
+    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    sys_ = hy.model.nbody(6, masses=M, Gconst=G)
+    x1, y1, vx1, x2 = hy.make_vars("x_1", "y_1", "vx_1", "x_2")
+    cb = lambda *a: None
+    ta = hy.taylor_adaptive_batch(sys_, None, 8, high_accuracy=True,
+                                  nt_events=[hy.nt_event((x1 - x2) * (x1 - x2) - 4.0, cb), hy.nt_event(y1, cb)],
+                                  t_events=[hy.t_event(x1 * vx1)])
+    mode = ta.hip_source_mode
+    assert mode.startswith("cluster") and "events: jets of 3 event equation(s)" in mode, mode
+    src = ta.hip_source
+    assert "a.sel_norms[s] = m0" in src and "__syncthreads" in src  # the mode-4 specialisation, cooperative tc store
+    # The plain integrator of the same system keeps the propagation kernel (no mode-4 code in it).
+    tb = hy.taylor_adaptive_batch(sys_, None, 8, high_accuracy=True)
+    assert "sel_norms[s]" not in tb.hip_source and tb.hip_source_mode.startswith("cluster")
+    # An event equation that needs most of the decomposition: the energy of the system.
+    en = hy.model.nbody_energy(6, masses=M, Gconst=G)
+    tc = hy.taylor_adaptive_batch(sys_, None, 8, high_accuracy=True, nt_events=[hy.nt_event(en + 1.0, cb)])
+    assert not tc.hip_source_mode.startswith("cluster"), tc.hip_source_mode
+    # No cluster structure: the pendulum stays on the unrolled stepper with events.
+    x, v = hy.make_vars("x", "v")
+    tp = hy.taylor_adaptive_batch([(x, v), (v, -9.8 * hy.sin(x))], None, 4, nt_events=[hy.nt_event(v, cb)])
+    assert tp.hip_source_mode.startswith("unrolled")
+    monkeypatch.setenv("HEYOKA_AMD_EVENTS_ON_CLUSTER", "0")
+    td = hy.taylor_adaptive_batch(sys_, None, 8, high_accuracy=True, nt_events=[hy.nt_event(y1, cb)])
+    assert not td.hip_source_mode.startswith("cluster")
