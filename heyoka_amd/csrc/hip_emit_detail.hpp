@@ -1072,12 +1072,14 @@ struct ssa_emitter {
     // x / d for a small integer constant d > 0 without a division: q = RN(x * r), r = RN(1 / d);
     // rem = x - q * d (exact, FMA); result = RN(q + rem * r). By Markstein's theorem the result is the
     // correctly-rounded quotient, i.e. bit-identical to IEEE x / d (outside of the subnormal range).
+    // (recip_div: the lane-pair kernel's choice - one multiplication by RN(1 / d), within 1 ulp.)
+    bool recip_div = false;
     std::string div_const(const std::string &x, std::uint32_t d)
     {
         if (d == 1u) {
             return x;
         }
-        if ((d & (d - 1u)) == 0u) {
+        if ((d & (d - 1u)) == 0u || recip_div) {
             // Power of two: the multiplication by the reciprocal is exact.
             return def(mul(x, fp_literal(1. / static_cast<double>(d))));
         }
