@@ -237,6 +237,7 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     // the exact 3-operation sequence (60 VALU instructions per step, +2.1 % system-steps/s; the strict-contraction parity
     // test passes its 1e4 / 1e5 eps bounds with it). HEYOKA_AMD_V3_EXACT_DIV=1 restores the correctly-rounded quotient.
     e.recip_div = pair_split && std::getenv("HEYOKA_AMD_V3_EXACT_DIV") == nullptr;
+    e.enable_pow_rcp();
 
     // Lane-pair variant: lane l = 2 * pair + role (role 0 = A: d_0, d_1; role 1 = B: d_2 and the pow); the lanes
     // beyond the last pair replicate pair 0 and write to dummy slots.

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdint>
 #include <functional>
+#include <cstdlib>
 #include <map>
 #include <sstream>
 #include <stdexcept>
@@ -370,8 +371,7 @@ struct ssa_emitter {
                         terms.push_back(def(mul(fp_literal(sf), pr)));
                     }
                     const auto acc = pairwise_sum(std::move(terms));
-                    const auto dv = def(mul(fp_literal(static_cast<double>(k)), val(b, 0)));
-                    out = def(acc + " / " + dv);
+                    out = pow_quotient(u, b, acc, k);
                 }
                 break;
             }
@@ -1060,13 +1060,40 @@ struct ssa_emitter {
                 const double sf = static_cast<double>(k) * ex;
                 const auto pr = def(mul(val(a[0].idx, k), val(u, 0)));
                 acc = chain(acc, fp_literal(sf), pr);
-                const auto dv = def(mul(fp_literal(static_cast<double>(k)), val(a[0].idx, 0)));
-                out = def(acc + " / " + dv);
+                out = pow_quotient(u, a[0].idx, acc, k);
                 break;
             }
             default:
                 break;
         }
+    }
+
+    // Quotient acc / (k b_0) of the pow recurrence (src/math/pow.cpp:546-549) without a division sequence per order
+    // (~13 instructions on gfx950): r = RN(1 / b_0) once per step and node, then q0 = acc * r_k with r_k = r * RN(1 / k),
+    // the exact residual rem = acc - (k b_0) q0 (FMA) and q = q0 + rem * r_k (Markstein: the correctly-rounded quotient
+    // unless r_k is off by more than an ulp in a halfway case). Opt-in of the emitters whose step body is ONE scope (the
+    // reciprocal is defined at the first use and read at every later order): enable_pow_rcp(); HEYOKA_AMD_EXACT_POW_DIV=1
+    // keeps the plain division.
+    bool pow_rcp = false;
+    void enable_pow_rcp()
+    {
+        pow_rcp = std::getenv("HEYOKA_AMD_EXACT_POW_DIV") == nullptr;
+    }
+    std::map<std::uint32_t, std::string> pow_r0;
+    std::string pow_quotient(std::uint32_t u, std::uint32_t b, const std::string &acc, std::uint32_t k)
+    {
+        const auto dv = def(mul(fp_literal(static_cast<double>(k)), val(b, 0)));
+        if (!pow_rcp) {
+            return def(acc + " / " + dv);
+        }
+        auto &r = pow_r0[u];
+        if (r.empty()) {
+            r = def("1.0 / " + val(b, 0));
+        }
+        const auto rk = (k == 1u) ? r : def(mul(r, fp_literal(1. / static_cast<double>(k))));
+        const auto q0 = def(mul(acc, rk));
+        const auto rem = def("__builtin_fma(-" + dv + ", " + q0 + ", " + acc + ")");
+        return def("__builtin_fma(" + rem + ", " + rk + ", " + q0 + ")");
     }
 
     // x / d for a small integer constant d > 0 without a division: q = RN(x * r), r = RN(1 / d);
