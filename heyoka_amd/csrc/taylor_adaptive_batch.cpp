@@ -161,6 +161,10 @@ struct tab_core::impl {
     // hy_ev_post / hy_ev_scatter); te_cooldowns is the lazily synchronised host mirror.
     mutable bool cd_dev_newer = false;
     bool cd_host_newer = true;
+    // Cooldowns set by the terminal events of the step being processed (position, first, second), not yet on the device:
+    // a callback which reads or resets the cooldowns sees them (the reference sets the cooldown before it invokes the
+    // callback, src/taylor_adaptive_batch.cpp:875-890).
+    mutable std::vector<double> pending_cd;
     void cooldowns_to_host() const;
     void cooldowns_to_device();
     mutable device_buffer d_ev_cursor, d_ev_rec, d_ev_upd;
@@ -946,6 +950,10 @@ void tab_core::impl::cooldowns_to_host() const
             }
         }
     }
+    for (std::size_t q = 0; q + 2u < pending_cd.size(); q += 3u) {
+        const auto pos = static_cast<std::size_t>(pending_cd[q]);
+        te_cooldowns[pos % n][pos / n].emplace(pending_cd[q + 1u], pending_cd[q + 2u]);
+    }
     cd_dev_newer = false;
 }
 
@@ -1213,7 +1221,9 @@ void tab_core::impl::step_with_events_device(const std::vector<double> *lims)
     std::sort(recs.begin(), recs.end(), [](const auto &x, const auto &y) { return x.lane < y.lane; });
 
     std::vector<std::pair<std::uint32_t, std::exception_ptr>> cb_eptrs;
-    std::vector<double> upd_cd, upd_oc;
+    auto &upd_cd = pending_cd;
+    upd_cd.clear();
+    std::vector<double> upd_oc;
     const auto gen = time_gen;
     for (auto &lr : recs) {
         const auto by_root = [](const auto &x, const auto &y) { return std::abs(x.root) < std::abs(y.root); };
@@ -1253,6 +1263,10 @@ void tab_core::impl::step_with_events_device(const std::vector<double> *lims)
             }
         }
         upd_cd.insert(upd_cd.end(), {static_cast<double>(static_cast<std::size_t>(ev.idx) * n + i), 0., cd});
+        if (!cd_dev_newer) {
+            // (An earlier callback of this step moved the cooldowns to the host: the mirror is the authoritative copy.)
+            te_cooldowns[i][ev.idx].emplace(0., cd);
+        }
         bool te_cb_ret = false;
         if (te.callback) {
             try {
@@ -1280,6 +1294,7 @@ void tab_core::impl::step_with_events_device(const std::vector<double> *lims)
         ed_mod->launch("hy_ev_scatter", pa.n_cd + pa.n_oc, 256, &pa, sizeof(pa), stream);
         stream_synchronize(device, stream);
     }
+    pending_cd.clear();
 
     if (!cb_eptrs.empty()) {
         throw_callback_exceptions(cb_eptrs);
