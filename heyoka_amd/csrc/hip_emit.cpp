@@ -822,6 +822,7 @@ emitted_module emit_table(const taylor_program &, const emit_options &);
 emitted_module emit_block(const taylor_program &, const emit_options &, std::string &why_not);
 bool add_state_aliases(const taylor_program &, taylor_program &);
 bool pad_clusters(const taylor_program &, std::uint32_t, taylor_program &);
+bool insert_unit_scalings(const taylor_program &, taylor_program &);
 
 emitted_module emit_hip_module(const taylor_program &prog, const emit_options &opts)
 {
@@ -867,6 +868,25 @@ emitted_module emit_hip_module(const taylor_program &prog, const emit_options &o
                         return m2;
                     }
                     why += "; with padded clusters: " + why2;
+                }
+                // Clusters which differ by an elided unit factor (unit masses next to other masses / test particles).
+                taylor_program scaled_p;
+                if (insert_unit_scalings(prog, scaled_p)) {
+                    std::string why3;
+                    auto m3 = emit_cluster_or_empty(scaled_p, opts, why3);
+                    const taylor_program *base = &scaled_p;
+                    taylor_program padded2;
+                    if (m3.source.empty() && why3.rfind("clusters are not isomorphic", 0) == 0
+                        && pad_clusters(scaled_p, opts.order, padded2)) {
+                        m3 = emit_cluster_or_empty(padded2, opts, why3);
+                        base = &padded2;
+                    }
+                    if (!m3.source.empty()) {
+                        m3.notes += "; " + std::to_string(base->n_u - prog.n_u)
+                                    + " members added to the internal program (unit scalings of elided factors, padding)";
+                        return m3;
+                    }
+                    why += "; with unit scalings: " + why3;
                 }
             }
             if (m.source.empty() && why.rfind("more than 64 clusters", 0) == 0) {

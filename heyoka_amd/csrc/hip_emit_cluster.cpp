@@ -283,6 +283,98 @@ std::string make_plan_impl(const taylor_program &p, std::uint32_t order, cluster
 
 } // namespace
 
+// Clusters which differ by an *elided unit factor*. model::nbody() scales r^-3 by G m_j before the three products of a
+// pair; when that factor is exactly 1 (unit masses in G = 1 units) the scaling node is not there and the products read the
+// pow directly, while the pairs of the same system with another factor (-G m_i = -1 towards a test particle, other
+// masses) keep it: the pair clusters are then neither isomorphic nor sub-shapes of each other. This pass restores the
+// missing member in the INTERNAL program (the user-visible decomposition is untouched): every pow node which is read by
+// products with a variable factor but by no scaling product `c * pow`, in a program where other pow nodes are read
+// through such a scaling, gets `s = 1.0 * pow` right behind it, and its product readers read s (x * 1.0 is exact: no
+// value changes). Returns false if there is nothing of that kind.
+bool insert_unit_scalings(const taylor_program &p, taylor_program &out)
+{
+    const auto n_eq = p.n_eq;
+    constexpr auto none = std::numeric_limits<std::uint32_t>::max();
+    std::vector<char> is_pow(p.n_u, 0), scaled(p.n_u, 0), direct(p.n_u, 0);
+    for (std::uint32_t u = n_eq; u < p.n_u; ++u) {
+        const auto &n = p.nodes[u - n_eq];
+        is_pow[u] = (n.kind == func_kind::pow && n.args.size() == 2u && is_var(n.args[0])) ? 1 : 0;
+    }
+    for (const auto &n : p.nodes) {
+        if (n.kind != func_kind::prod || n.args.size() != 2u) {
+            continue;
+        }
+        for (std::size_t a = 0; a < 2u; ++a) {
+            const auto &o = n.args[a], &other = n.args[1u - a];
+            if (is_var(o) && is_pow[o.idx] != 0) {
+                if (other.type == operand::kind::num || other.type == operand::kind::par) {
+                    scaled[o.idx] = 1;
+                } else if (is_var(other)) {
+                    direct[o.idx] = 1;
+                }
+            }
+        }
+    }
+    bool any_scaled = false, any_todo = false;
+    for (std::uint32_t u = n_eq; u < p.n_u; ++u) {
+        any_scaled = any_scaled || scaled[u] != 0;
+        any_todo = any_todo || (direct[u] != 0 && scaled[u] == 0);
+    }
+    if (!any_scaled || !any_todo) {
+        return false;
+    }
+    // New index of every old u variable: one slot is inserted behind each pow node to be scaled.
+    std::vector<std::uint32_t> new_idx(p.n_u, none), scal_idx(p.n_u, none);
+    std::uint32_t next = n_eq;
+    for (std::uint32_t i = 0; i < n_eq; ++i) {
+        new_idx[i] = i;
+    }
+    for (std::uint32_t u = n_eq; u < p.n_u; ++u) {
+        new_idx[u] = next++;
+        if (direct[u] != 0 && scaled[u] == 0) {
+            scal_idx[u] = next++;
+        }
+    }
+    out = p;
+    out.nodes.clear();
+    for (std::uint32_t u = n_eq; u < p.n_u; ++u) {
+        auto nn = p.nodes[u - n_eq];
+        const bool var_prod = nn.kind == func_kind::prod && nn.args.size() == 2u && is_var(nn.args[0]) && is_var(nn.args[1]);
+        for (auto &o : nn.args) {
+            if (o.type == operand::kind::uvar) {
+                // (Only the products with a variable factor are rewired: other readers of the pow keep reading it.)
+                o.idx = (var_prod && scal_idx[o.idx] != none) ? scal_idx[o.idx] : new_idx[o.idx];
+            }
+        }
+        for (auto &d : nn.deps) {
+            d = new_idx[d];
+        }
+        out.nodes.push_back(std::move(nn));
+        if (scal_idx[u] != none) {
+            dc_node sc;
+            sc.kind = func_kind::prod;
+            operand one;
+            one.type = operand::kind::num;
+            one.value = 1.;
+            operand src;
+            src.type = operand::kind::uvar;
+            src.idx = new_idx[u];
+            sc.args = {one, src};
+            out.nodes.push_back(std::move(sc));
+        }
+    }
+    for (auto &d : out.sv_defs) {
+        if (d.type == operand::kind::uvar) {
+            d.idx = new_idx[d.idx];
+        }
+    }
+    for (auto &e : out.ev_u) {
+        e = new_idx[e];
+    }
+    out.n_u = next;
+    return true;
+}
+
 // Clusters of different shapes. When every cluster is a *sub-shape* of the largest one (model::nbody with massless
 // bodies: the pairs with a test particle lack the three reaction products of the massive-massive pairs), the smaller
 // clusters are padded in the INTERNAL program (the user-visible decomposition is untouched, like add_state_aliases())

@@ -457,8 +457,12 @@ def test_test_particles_next_to_parameter_masses_padded_clusters():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("masses", [[1.0, 3e-4, 1e-4, 5e-5, 0.0, 0.0], [1.0, 1e-3, 0.0]])
-def test_test_particles_next_to_numeric_masses_with_a_unit_mass(masses):
+@pytest.mark.parametrize("masses,t_end,expect", [([1.0, 3e-4, 1e-4, 5e-5, 0.0, 0.0], 10.0, ""), ([1.0, 1e-3, 0.0], 10.0, ""),
+                                                  # Unit factors G m_j = 1 are elided by the model (the products read r^-3
+                                                  # directly) next to pairs which keep their scaling: insert_unit_scalings().
+                                                  ([1.0, 1.0, 1.0, 1.0, 0.0, 0.0], 2.0, "unit scalings"),
+                                                  ([1.0, 2.0, 1.0, 0.0], 2.0, "unit scalings")])
+def test_test_particles_next_to_numeric_masses_with_a_unit_mass(masses, t_end, expect):
     """model::nbody() with numeric masses, G = 1 and a unit-mass primary: -G m_0 is then the literal -1, which the
     decomposition shows as a negation in the pairs of body 0 with the test particles, next to ordinary factors in the
     other pairs. The planner treats the factor as a per-cluster constant (not as part of the cluster shape), so that
@@ -481,7 +485,7 @@ def test_test_particles_next_to_numeric_masses_with_a_unit_mass(masses):
     sys_o = ho.nbody(nb, masses=masses, Gconst=1.0)
     assert hy.taylor_decompose_sys(sys_g) == ho.dc_to_strings(ho.taylor_decompose_sys(sys_o))
     ta = hy.taylor_adaptive_batch(sys_g, st, n, high_accuracy=True)
-    assert ta.hip_source_mode.startswith("cluster"), ta.hip_source_mode
+    assert ta.hip_source_mode.startswith("cluster") and expect in ta.hip_source_mode, ta.hip_source_mode
     oi = ho.OracleIntegrator(sys_o, st, n, high_accuracy=True)
     ta.step(write_tc=True)
     oi.step(wtc=True)
@@ -495,6 +499,6 @@ def test_test_particles_next_to_numeric_masses_with_a_unit_mass(masses):
     # same 1.2e6 - 1.4e6 eps at order 18 on the wave-cluster and on the fully unrolled stepper
     # (profiles/experiments/dbg5.py), the step sizes agree to 1e6 eps.
     assert np.max(np.abs(np.asarray(ta.tc).reshape(6 * nb, oi.order + 1, n) - tc_o) / scale) <= 1e7 * EPS
-    ta.propagate_until(10.0)
-    oi.propagate_until(10.0)
+    ta.propagate_until(t_end)
+    oi.propagate_until(t_end)
     assert rel_err(ta.state, oi.state.reshape(6 * nb, n)) <= 1e7 * EPS
