@@ -915,6 +915,13 @@ class taylor_adaptive_batch:
         return take_str(lib.hy_tab_get_hip_source(self._h))
 
     @property
+    def internal_program(self):
+        """The rewritten internal program the stepper was generated from (list of strings: nodes, then the definitions of
+        the state derivatives), or [] when the code was generated from the decomposition itself."""
+        txt = take_str(lib.hy_tab_get_internal_program(self._h)).rstrip("\n")
+        return txt.split("\n") if txt else []
+
+    @property
     def code_object(self):
         """The gfx950 code object of the stepper module (bytes), e.g. for llvm-objdump."""
         n = ctypes.c_size_t(0)

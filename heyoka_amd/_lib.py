@@ -132,6 +132,7 @@ SIGNATURES = [
     ("hy_tab_get_event_detection_failures", ctypes.c_ulonglong, [c_void_p]),
     ("hy_tab_get_compile_seconds", c_double, [c_void_p]),
     ("hy_tab_get_hip_source", c_void_p, [c_void_p]),
+    ("hy_tab_get_internal_program", c_void_p, [c_void_p]),
     ("hy_tab_get_decomposition_str", c_void_p, [c_void_p]),
     ("hy_tab_get_codegen_info", c_void_p, [c_void_p]),
     ("hy_tab_get_code_object", c_int, [c_void_p, c_void_p, c_void_p]),

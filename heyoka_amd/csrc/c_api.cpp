@@ -747,6 +747,10 @@ char *hy_tab_get_hip_source(hy_tab t)
 {
     return dup_str(t->core.get_hip_source());
 }
+char *hy_tab_get_internal_program(hy_tab t)
+{
+    return dup_str(t->core.get_internal_program());
+}
 int hy_tab_get_code_object(hy_tab t, void *out, size_t *size)
 {
     return guarded([&] {

@@ -824,6 +824,44 @@ bool add_state_aliases(const taylor_program &, taylor_program &);
 bool pad_clusters(const taylor_program &, std::uint32_t, taylor_program &);
 bool insert_unit_scalings(const taylor_program &, taylor_program &);
 
+std::string program_to_string(const taylor_program &p)
+{
+    std::ostringstream oss;
+    const auto op = [&](const operand &o) {
+        char buf[64];
+        switch (o.type) {
+            case operand::kind::uvar:
+                oss << "u_" << o.idx;
+                break;
+            case operand::kind::num:
+                std::snprintf(buf, sizeof(buf), "%.17g", o.value);
+                oss << buf;
+                break;
+            default:
+                oss << "p" << o.idx;
+        }
+    };
+    for (const auto &n : p.nodes) {
+        oss << func_kind_name(n.kind) << '(';
+        for (std::size_t a = 0; a < n.args.size(); ++a) {
+            if (a != 0u) {
+                oss << ", ";
+            }
+            op(n.args[a]);
+        }
+        oss << ')';
+        for (const auto d : n.deps) {
+            oss << " [dep " << d << "]";
+        }
+        oss << '\n';
+    }
+    for (const auto &d : p.sv_defs) {
+        op(d);
+        oss << '\n';
+    }
+    return oss.str();
+}
+
 emitted_module emit_hip_module(const taylor_program &prog, const emit_options &opts)
 {
     if (opts.order < 2u) {
@@ -849,6 +887,7 @@ emitted_module emit_hip_module(const taylor_program &prog, const emit_options &o
                     }
                     if (!m2.source.empty()) {
                         m2.notes += "; state variables in history-operand position aliased by u variables";
+                        m2.internal_program = program_to_string(aliased);
                         return m2;
                     }
                     why += "; with state-variable aliases: " + why2;
@@ -865,6 +904,7 @@ emitted_module emit_hip_module(const taylor_program &prog, const emit_options &o
                     if (!m2.source.empty()) {
                         m2.notes += "; clusters of " + std::to_string(padded.n_u - prog.n_u)
                                     + " missing members padded to the shape of the largest one";
+                        m2.internal_program = program_to_string(padded);
                         return m2;
                     }
                     why += "; with padded clusters: " + why2;
@@ -884,6 +924,7 @@ emitted_module emit_hip_module(const taylor_program &prog, const emit_options &o
                     if (!m3.source.empty()) {
                         m3.notes += "; " + std::to_string(base->n_u - prog.n_u)
                                     + " members added to the internal program (unit scalings of elided factors, padding)";
+                        m3.internal_program = program_to_string(*base);
                         return m3;
                     }
                     why += "; with unit scalings: " + why3;

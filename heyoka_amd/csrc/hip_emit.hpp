@@ -83,7 +83,15 @@ struct emitted_module {
     std::string compile_flags;
     // The stepper implements mode 4 in its cluster form (see hy_kargs::sel_norms).
     bool cluster_mode4 = false;
+    // When the code was generated from a rewritten INTERNAL program (state-variable aliases, padded clusters, restored unit
+    // scalings - the user-visible decomposition is never touched): its text, one node per line in the format of the
+    // decomposition strings, then the definitions of the state derivatives. Lets the tests run the oracle's interpreter
+    // on the rewritten program and check that the rewrites do not change a single bit of the jets.
+    std::string internal_program;
 };
+
+// Textual form of a flattened program (see emitted_module::internal_program).
+std::string program_to_string(const taylor_program &);
 
 emitted_module emit_hip_module(const taylor_program &prog, const emit_options &opts);
 

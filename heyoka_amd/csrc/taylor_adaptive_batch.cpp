@@ -677,6 +677,10 @@ const std::string &tab_core::get_hip_source() const
 {
     return m_impl->emitted.source;
 }
+const std::string &tab_core::get_internal_program() const
+{
+    return m_impl->emitted.internal_program;
+}
 std::string tab_core::get_codegen_info() const
 {
     const auto &m = m_impl->emitted;

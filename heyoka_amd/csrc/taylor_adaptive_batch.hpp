@@ -123,6 +123,8 @@ public:
     [[nodiscard]] const sys_t &get_sys() const;
     [[nodiscard]] int get_device() const;
     [[nodiscard]] const std::string &get_hip_source() const;
+    // Text of the rewritten internal program the stepper was generated from (empty: the decomposition itself).
+    [[nodiscard]] const std::string &get_internal_program() const;
     // The gfx950 code object of the stepper module (the counterpart of llvm_state::get_object_code()).
     [[nodiscard]] const std::vector<char> &get_code_object() const;
     [[nodiscard]] double get_compile_seconds() const;

@@ -228,6 +228,11 @@ unsigned long long hy_tab_get_event_detection_failures(hy_tab);
 double hy_tab_get_compile_seconds(hy_tab);
 char *hy_tab_get_hip_source(hy_tab);  /* generated HIP module (cf. llvm_state::get_ir()); caller frees */
 char *hy_tab_get_decomposition_str(hy_tab);
+/* No reference counterpart: the rewritten INTERNAL program the stepper was generated from when the planner of the
+ * wave-cluster kernels changed it (state-variable aliases, padded clusters, restored unit scalings; the decomposition the
+ * user sees is never touched) - one node per line in the format of hy_tab_get_decomposition_str(), then the definitions
+ * of the state derivatives; an empty string otherwise. For tests: the rewrites must not change the jets. Caller frees. */
+char *hy_tab_get_internal_program(hy_tab);
 /* Description of the code generation mode chosen for this system ("unrolled", "cluster ...", "table ..."). Caller frees. */
 char *hy_tab_get_codegen_info(hy_tab);
 /* The gfx950 code object of the stepper module (cf. llvm_state::get_object_code(), include/heyoka/llvm_state.hpp) and a

@@ -502,3 +502,73 @@ def test_test_particles_next_to_numeric_masses_with_a_unit_mass(masses, t_end, e
     ta.propagate_until(t_end)
     oi.propagate_until(t_end)
     assert rel_err(ta.state, oi.state.reshape(6 * nb, n)) <= 1e7 * EPS
+
+
+def _oracle_on_program(monkeypatch, lines, n_eq, st, n, **kw):
+    """The oracle's interpreter on an explicit flattened program (the text of taylor_adaptive_batch.internal_program:
+    one node per line, then the definitions of the state derivatives)."""
+    import re
+
+    def operand(t):
+        t = t.strip()
+        if t.startswith("u_"):
+            return ho.var(t)
+        if re.fullmatch(r"p\d+", t):
+            return ho.par(int(t[1:]))
+        return ho.num(float(t))
+
+    dc = [(ho.var("u_%d" % i), []) for i in range(n_eq)]
+    for ln in lines[: len(lines) - n_eq]:
+        m = re.fullmatch(r"(\w+)\((.*?)\)((?: \[dep \d+\])*)", ln)
+        assert m, ln
+        deps = [int(d) for d in re.findall(r"\[dep (\d+)\]", m.group(3))]
+        dc.append((ho.func(m.group(1), [operand(t) for t in m.group(2).split(",")]), deps))
+    for ln in lines[len(lines) - n_eq :]:
+        dc.append((operand(ln), []))
+    monkeypatch.setattr(ho, "taylor_decompose_sys", lambda sys, sv_funcs=None: dc)
+    try:
+        return ho.OracleIntegrator([None] * n_eq, st, n, **kw)
+    finally:
+        monkeypatch.undo()
+
+
+@pytest.mark.parametrize("case", ["unit_scalings", "unit_scalings_padded", "padded_par_masses", "state_aliases"])
+def test_planner_rewrites_of_the_internal_program_do_not_change_the_jets(case, monkeypatch):
+    """The planner of the wave-cluster kernels may rewrite the INTERNAL program (never the decomposition the user sees):
+    alias u variables for state variables in history-operand position (add_state_aliases()), padding of clusters which
+    are sub-shapes of the largest one (pad_clusters()), unit scalings restored where the model elided a factor 1
+    (insert_unit_scalings()). The rewritten program is exposed as text; the oracle's interpreter runs it next to the
+    original decomposition: the Taylor coefficients of the state variables, the step size and the new state must be
+    IDENTICAL, bit for bit (the added nodes are exact copies / x - 0 / x * 1.0, or are read by nobody)."""
+    from heyoka_amd import configs
+
+    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    n, pars = 6, None
+    if case == "unit_scalings":
+        sys_g, sys_o = hy.model.nbody(4, masses=[1.0, 2.0, 1.0, 0.0]), ho.nbody(4, masses=[1.0, 2.0, 1.0, 0.0])
+    elif case == "unit_scalings_padded":
+        m = [1.0, 1.0, 1.0, 1.0, 0.0, 0.0]
+        sys_g, sys_o = hy.model.nbody(6, masses=m), ho.nbody(6, masses=m)
+    elif case == "padded_par_masses":
+        sys_g = hy.model.nbody(6, masses=[hy.par[i] for i in range(4)], Gconst=G)
+        sys_o = ho.nbody(6, masses=[ho.par(i) for i in range(4)], Gconst=G)
+        pars = np.repeat(np.asarray(M[:4], dtype=np.float64)[:, None], n, axis=1)
+    else:
+        sys_g, sys_o = hy.model.np1body(6, masses=M, Gconst=G), ho.np1body(6, masses=M, Gconst=G)
+    n_eq = len(sys_o)
+    rng = np.random.default_rng(3)
+    st = rng.uniform(-1.0, 1.0, (n_eq, n)) + np.arange(n_eq)[:, None] * 0.37
+    kw = {"high_accuracy": True}
+    if pars is not None:
+        kw["pars"] = pars
+    ta = hy.taylor_adaptive_batch(sys_g, st, n, **kw)
+    prog = ta.internal_program
+    assert ta.hip_source_mode.startswith("cluster") and len(prog) > len(ta.decomposition) - n_eq, ta.hip_source_mode
+    plain = ho.OracleIntegrator(sys_o, st, n, **kw)
+    rewritten = _oracle_on_program(monkeypatch, prog, n_eq, st, n, **kw)
+    assert rewritten.n_u > plain.n_u
+    plain.step(wtc=True)
+    rewritten.step(wtc=True)
+    assert plain.step_res == rewritten.step_res
+    assert np.array_equal(plain.tc, rewritten.tc) and np.array_equal(plain.state, rewritten.state)
+    assert np.array_equal(plain.time_hi, rewritten.time_hi)
