@@ -1016,7 +1016,8 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     std::ostringstream src;
     src << "#define SPW " << spw << "u\n#define HY_WPB " << wpb << "u\n";
     src << "#define HY_M4 " << (m4 ? 1 : 0) << "\n";
-    src << "#define HY_NO_STATIC " << (std::getenv("HEYOKA_AMD_NO_STATIC_SCHEDULE") != nullptr ? 1 : 0) << "\n";
+    // (The stepper with events always uses the static schedule: its cooperative store has workgroup barriers.)
+    src << "#define HY_NO_STATIC " << ((!m4 && std::getenv("HEYOKA_AMD_NO_STATIC_SCHEDULE") != nullptr) ? 1 : 0) << "\n";
     if (std::getenv("HEYOKA_AMD_NO_NMAX") != nullptr) {
         src << "#define HY_NO_NMAX 1\n";
     }
