@@ -37,6 +37,13 @@ std::vector<tab_core> ensemble_propagate_core(const tab_core &ta, double t, std:
     // the template integrator, runs the generator, uploads and launches the device-resident propagation of the
     // iterations i = d, d + n_devices, ... on device d, so that neither the generator nor the uploads of one device
     // wait for another device. Results keep the iteration order.
+    // The copy constructor brings the (mutable, lazily synchronised) host mirrors of its source up to date before it
+    // copies them. The worker threads below all copy `ta` concurrently: one throwaway copy on the calling thread
+    // leaves nothing for them to synchronise, so that their copies only READ the template.
+    if (n_devices > 1) {
+        const tab_core synced(ta);
+        (void)synced;
+    }
     std::vector<std::optional<tab_core>> slots(n_iter);
     std::vector<std::exception_ptr> errors(static_cast<std::size_t>(n_devices));
     const std::vector<double> ts{t};

@@ -770,6 +770,8 @@ emitted_module emit_event_jets(const taylor_program &p, const emit_options &opts
         }
     }
     os << "const double *const jet = a.tc + s;\n";
+    // (The order-0 rule of func_kind::time reads the time coordinate by this name: an event equation like time - 0.5.)
+    os << "const double t_hi = a.time_hi[s];\n(void)t_hi;\n";
     for (std::uint32_t k = 0; k <= order; ++k) {
         for (std::uint32_t i = 0; i < n_eq; ++i) {
             if (need[i] != 0) {

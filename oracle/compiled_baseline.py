@@ -272,9 +272,13 @@ def install(oi, fast):
     lib = ctypes.CDLL(so)
     _KEEP.append(lib)
     fn = ctypes.cast(lib.hy_jet_hook, ctypes.c_void_p)
-    ho._lib().hy_oracle_set_jet_hook(fn, ctypes.c_int(W), ctypes.c_int(oi.n_u), ctypes.c_int(oi.order))
+    lib_o = ho._lib()
+    lib_o.hy_oracle_program_hash.restype = ctypes.c_uint64
+    # (Keyed on the content of the program: another oracle program with the same batch width / n_u / order keeps the
+    # interpreter.)
+    lib_o.hy_oracle_set_jet_hook(fn, ctypes.c_int(W), ctypes.c_uint64(lib_o.hy_oracle_program_hash(oi.program_ptr())))
     return secs
 
 
 def uninstall():
-    ho._lib().hy_oracle_set_jet_hook(ctypes.c_void_p(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0))
+    ho._lib().hy_oracle_set_jet_hook(ctypes.c_void_p(0), ctypes.c_int(0), ctypes.c_uint64(0))

@@ -1013,6 +1013,10 @@ class OracleIntegrator:
             *[_p(self._arrs[k]) for k in ("kind", "arg_off", "arg_type", "arg_idx", "arg_val", "dep", "sv_type", "sv_idx", "sv_val", "dep2")]
         )
 
+    def program_ptr(self):
+        """Pointer to the C program structure (hy_oracle_program) of this integrator."""
+        return ctypes.byref(self._prog)
+
     # step(max_delta_ts=None, wtc=False); max_delta_ts: signed per-lane limits (default +inf).
     def step(self, max_delta_ts=None, wtc=False, backward=False):
         B = self.batch_size

@@ -878,13 +878,66 @@ static double rhofac(int order)
  * the interpreter bit by bit in tests/test_oracle_golden.py. */
 typedef void (*hy_jet_hook_t)(const double *state, const double *pars, const double *time, double *tape);
 static hy_jet_hook_t g_jet_hook = NULL;
-static int g_hook_B = 0, g_hook_nu = 0, g_hook_order = 0;
-void hy_oracle_set_jet_hook(hy_jet_hook_t f, int B, int n_u, int order)
+static int g_hook_B = 0;
+static uint64_t g_hook_hash = 0;
+
+/* Content hash of a program (FNV-1a over sizes, node kinds, arguments, hidden dependencies and the definitions of the
+ * state variables): the compiled jet function is only used for the program it was generated from, not for any program
+ * which happens to share (batch width, n_u, order) with it. */
+uint64_t hy_oracle_program_hash(const hy_oracle_program *p)
+{
+    uint64_t h = 1469598103934665603ull;
+#define HY_FNV(ptr, nbytes)                                                                                           \
+    do {                                                                                                              \
+        const unsigned char *q_ = (const unsigned char *)(ptr);                                                       \
+        for (size_t i_ = 0; i_ < (size_t)(nbytes); ++i_) {                                                            \
+            h ^= q_[i_];                                                                                              \
+            h *= 1099511628211ull;                                                                                    \
+        }                                                                                                             \
+    } while (0)
+    HY_FNV(&p->n_eq, sizeof(int32_t) * 6);
+    const int32_t n_args = p->arg_off[p->n_nodes];
+    HY_FNV(p->kind, sizeof(int32_t) * (size_t)p->n_nodes);
+    HY_FNV(p->arg_off, sizeof(int32_t) * (size_t)(p->n_nodes + 1));
+    HY_FNV(p->arg_type, sizeof(int32_t) * (size_t)n_args);
+    HY_FNV(p->arg_idx, sizeof(int32_t) * (size_t)n_args);
+    HY_FNV(p->arg_val, sizeof(double) * (size_t)n_args);
+    HY_FNV(p->dep, sizeof(int32_t) * (size_t)p->n_nodes);
+    HY_FNV(p->dep2, sizeof(int32_t) * (size_t)p->n_nodes);
+    HY_FNV(p->sv_type, sizeof(int32_t) * (size_t)p->n_eq);
+    HY_FNV(p->sv_idx, sizeof(int32_t) * (size_t)p->n_eq);
+    HY_FNV(p->sv_val, sizeof(double) * (size_t)p->n_eq);
+#undef HY_FNV
+    return h;
+}
+
+static volatile uint64_t g_hook_gen = 0;
+void hy_oracle_set_jet_hook(hy_jet_hook_t f, int B, uint64_t program_hash)
 {
     g_jet_hook = f;
     g_hook_B = B;
-    g_hook_nu = n_u;
-    g_hook_order = order;
+    g_hook_hash = program_hash;
+    ++g_hook_gen;
+}
+
+/* Does the installed hook belong to program p? (The hash is computed once per thread, program object and installation.) */
+static int jet_hook_matches(const hy_oracle_program *p, int B)
+{
+    static _Thread_local const hy_oracle_program *tl_p = NULL;
+    static _Thread_local uint64_t tl_gen = 0;
+    static _Thread_local int32_t tl_nu = 0, tl_nn = 0;
+    static _Thread_local int tl_match = 0;
+    if (g_jet_hook == NULL || B != g_hook_B) {
+        return 0;
+    }
+    if (p != tl_p || tl_gen != g_hook_gen || tl_nu != p->n_u || tl_nn != p->n_nodes) {
+        tl_p = p;
+        tl_gen = g_hook_gen;
+        tl_nu = p->n_u;
+        tl_nn = p->n_nodes;
+        tl_match = hy_oracle_program_hash(p) == g_hook_hash;
+    }
+    return tl_match;
 }
 
 static void step_core(const hy_oracle_program *p, int B, double *state, const double *pars, const double *time,
@@ -897,7 +950,7 @@ static void step_core(const hy_oracle_program *p, int B, double *state, const do
     const size_t tape_rows = with_events ? (size_t)n_u * (size_t)(order + 1) : ((size_t)n_u * (size_t)order + (size_t)n_eq);
     double *scratch = tape + tape_rows * (size_t)B;
 
-    if (g_jet_hook != NULL && !with_events && B == g_hook_B && n_u == g_hook_nu && order == g_hook_order) {
+    if (!with_events && jet_hook_matches(p, B)) {
         g_jet_hook(state, pars, time, tape);
     } else {
         for (int i = 0; i < n_eq; ++i) {

@@ -1348,6 +1348,53 @@ def _outer_ss_event_setup(m, log, te_log):
     return nt, te
 
 
+def test_time_dependent_event_on_the_cluster_event_stepper_builds():
+    """(CPU: hiprtc cross-compiles.) An event equation which depends on the time coordinate next to a system which runs
+    on the wave-cluster stepper: hy_ev_jets evaluates func_kind::time and needs the time of the lane (round-2 advisor
+    finding: the constructor threw 'use of undeclared identifier t_hi')."""
+    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    x1 = hy.make_vars("x_1")
+    x1 = x1[0] if isinstance(x1, (list, tuple)) else x1
+    for ev in (hy.time - 0.5, x1 - hy.cos(hy.time)):
+        ta = hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), None, 8, high_accuracy=True,
+                                      nt_events=[hy.nt_event(ev, lambda *a: None)])
+        assert ta.hip_source_mode.startswith("cluster") and "events:" in ta.hip_source_mode, ta.hip_source_mode
+
+
+@pytest.mark.gpu
+def test_time_dependent_events_on_the_cluster_stepper_vs_oracle():
+    """Time-triggered events (time - t0, x_1 - 5 cos(time / 3)) on the outer Solar System: mode-4 cluster stepper +
+    hy_ev_jets against the oracle's stepper with events."""
+    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    n = 6
+    st = configs.outer_ss_state(n, perturb=1e-3, seed=5)
+    logs = {}
+
+    def setup(m, key):
+        log = logs.setdefault(key, [])
+        x1 = m.var("x_1") if m is ho else hy.make_vars("x_1")
+        x1 = x1[0] if isinstance(x1, (list, tuple)) else x1
+        t = m.TIME if m is ho else m.time
+        return [m.nt_event(t - 0.7, lambda ta, tm, d, i: log.append((i, 0, tm, d))),
+                m.nt_event(x1 - 5.0 * m.cos(t / 3.0), lambda ta, tm, d, i: log.append((i, 1, tm, d)))]
+
+    ta = hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True, nt_events=setup(hy, "p"))
+    assert ta.hip_source_mode.startswith("cluster") and "events:" in ta.hip_source_mode, ta.hip_source_mode
+    ora = ho.OracleEventIntegrator(ho.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True, nt_events=setup(ho, "o"))
+    for _ in range(25):
+        ta.step()
+        ora.step()
+        assert [int(oc) for oc, _ in ta.step_res] == [oc for oc, _ in ora.step_res]
+        h_p = np.array([h for _, h in ta.step_res])
+        h_o = np.array([h for _, h in ora.step_res])
+        assert np.max(np.abs(h_p - h_o) / np.abs(h_o)) <= 1e6 * EPS
+        assert rel_err(ta.state, ora.state.reshape(36, n)) <= 1e6 * EPS
+    lp, lo = logs["p"], logs["o"]
+    assert len(lp) >= n and [(a[0], a[1], a[3]) for a in lp] == [(a[0], a[1], a[3]) for a in lo]
+    assert np.max(np.abs(np.array([a[2] for a in lp]) - np.array([a[2] for a in lo]))) <= 1e-10
+    assert all(abs(a[2] - 0.7) <= 1e-14 for a in lp if a[1] == 0)
+
+
 @pytest.mark.gpu
 def test_events_on_the_cluster_stepper_vs_oracle(monkeypatch):
     """Integrators with events whose system runs on a wave-cluster stepper: the stepper computes the jets of the state

@@ -280,3 +280,25 @@ def test_compiled_cpu_baseline_is_bit_identical_to_the_interpreter(which):
     assert [r[3] for r in a.prop_res] == [r[3] for r in b.prop_res]
     eps = np.finfo(float).eps
     assert np.max(np.abs(c.state - a.state) / np.maximum(1.0, np.abs(a.state))) <= 1e3 * eps
+
+
+def test_compiled_jet_hook_is_keyed_on_the_program():
+    """The compiled jet function installed for one oracle program is not used by another program with the same batch
+    width, number of u variables and order (round-2 advisor finding: the hook was matched on those three numbers only)."""
+    import compiled_baseline as cb
+
+    st = np.tile(np.array([1.0, 0.3, -0.2, 0.1, 0.0, 0.0, 0.0, 0.0, 0.0, 0.1, 0.9, 0.05])[:, None], (1, 8)).copy()
+    st += 1e-3 * np.arange(8)[None, :]
+    s1 = ho.nbody(2, masses=[1.0, 0.0])
+    s2 = ho.nbody(2, masses=[1.5, 0.0])
+    ref = ho.OracleIntegrator(s2, st, 8)
+    ref.step(wtc=True)
+    a = ho.OracleIntegrator(s1, st, 8)
+    b = ho.OracleIntegrator(s2, st, 8)
+    assert (a.n_u, a.order) == (b.n_u, b.order)
+    try:
+        cb.install(a, fast=False)
+        b.step(wtc=True)
+    finally:
+        cb.uninstall()
+    assert np.array_equal(b.tc, ref.tc) and np.array_equal(b.state, ref.state)
