@@ -1048,6 +1048,47 @@ __device__ __forceinline__ double hy_dpp(double x)
     return __hiloint2double(hi, lo);
 }
 )HIP";
+    // Logarithm of the step-size selector (packed tail): the three arguments (max(1, |x|_inf), |x^[p]|_inf, |x^[p-1]|_inf)
+    // sit on three lanes of a quad and share ONE evaluation - written out here (45 VALU instructions) instead of the
+    // device library's log() (95: double-double arithmetic for < 1 ulp), since three of those were a sixth of the serial
+    // tail of a step. frexp, m in [sqrt(1/2), sqrt(2)), z = (m - 1) / (m + 1) by reciprocal + two Newton steps + one
+    // residual correction, log m = 2 z + z^3 P(z^2) with the Taylor coefficients 2 / (2 n + 1) up to z^21 (|z| <= 0.1716:
+    // the first neglected term is 2e-17 relative), e ln 2 added in two pieces. Error ~1.5 ulp; the roots of the selector
+    // scale it by 1 / p. 0 -> -inf, +inf -> +inf, nan -> nan like log().
+    src << R"HIP(
+__device__ __forceinline__ double hy_sel_log(double x)
+{
+    double m = __builtin_amdgcn_frexp_mant(x);
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool lo = m < 0x1.6a09e667f3bcdp-1;
+    m = m * (lo ? 2.0 : 1.0);
+    e -= lo ? 1 : 0;
+    const double num = m - 1.0, den = m + 1.0;
+    double r = __builtin_amdgcn_rcp(den);
+    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+    double z = num * r;
+    z = __builtin_fma(__builtin_fma(-den, z, num), r, z);
+    const double w = z * z;
+    double p = 0x1.8618618618618p-4;
+    p = __builtin_fma(p, w, 0x1.af286bca1af28p-4);
+    p = __builtin_fma(p, w, 0x1.e1e1e1e1e1e1ep-4);
+    p = __builtin_fma(p, w, 0x1.1111111111111p-3);
+    p = __builtin_fma(p, w, 0x1.3b13b13b13b14p-3);
+    p = __builtin_fma(p, w, 0x1.745d1745d1746p-3);
+    p = __builtin_fma(p, w, 0x1.c71c71c71c71cp-3);
+    p = __builtin_fma(p, w, 0x1.2492492492492p-2);
+    p = __builtin_fma(p, w, 0x1.999999999999ap-2);
+    p = __builtin_fma(p, w, 0x1.5555555555555p-1);
+    const double ed = (double)e;
+    double res = __builtin_fma(ed, 0x1.abc9e3b39803fp-56, (z * w) * p);
+    res = __builtin_fma(2.0, z, res);
+    res = __builtin_fma(ed, 0x1.62e42fefa39efp-1, res);
+    res = (x == 0.0) ? -__builtin_inf() : res;
+    res = (x == __builtin_inf()) ? x : res;
+    return res;
+}
+)HIP";
     if (pair_split) {
         // Exchange between the two lanes of a pair: DPP quad_perm [1,0,3,2] on the two halves of the double.
         src << R"HIP(
@@ -1227,50 +1268,81 @@ lim = fin ? 0.0 : lim;
 
     // Maximum over the lanes of the system: DPP stages where a DPP pattern yields an all-reduce step (xor 1, xor 2 within
     // quads; rotations by 4 and 8 within rows of 16 lanes once the quads are uniform), ds_bpermute for the others.
+    // Packed tail (L >= 4): after the two stages inside the quads the three norms move to three lanes of every quad
+    // (lane & 3 = 0: |x|, 1: |x^[p]|, 2 and 3: |x^[p-1]|) and the remaining stages reduce ONE value instead of three;
+    // the logarithm of the selector is then evaluated once, on the packed lanes (hy_sel_log above).
+    const bool packed_tail = L >= 4u && std::getenv("HEYOKA_AMD_NO_PACKED_TAIL") == nullptr;
+    const auto red_ex = [&](std::uint32_t m, const char *v) -> std::string {
+        const bool dpp_ok = std::getenv("HEYOKA_AMD_NO_DPP_REDUCE") == nullptr;
+        if (dpp_ok && m == 1u) {
+            return std::string("hy_dpp<0xB1>(") + v + ")";
+        }
+        if (dpp_ok && m == 2u) {
+            return std::string("hy_dpp<0x4E>(") + v + ")";
+        }
+        if (dpp_ok && m == 4u && L % 16u == 0u) {
+            return std::string("hy_dpp<0x124>(") + v + ")";
+        }
+        if (dpp_ok && m == 8u && L % 16u == 0u) {
+            return std::string("hy_dpp<0x128>(") + v + ")";
+        }
+        return std::string("__shfl_xor(") + v + ", " + std::to_string(m) + ", 64)";
+    };
     for (std::uint32_t m = 1; m < L; m *= 2u) {
-        const auto ex = [&](const char *v) -> std::string {
-            const bool dpp_ok = std::getenv("HEYOKA_AMD_NO_DPP_REDUCE") == nullptr;
-            if (dpp_ok && m == 1u) {
-                return std::string("hy_dpp<0xB1>(") + v + ")";
-            }
-            if (dpp_ok && m == 2u) {
-                return std::string("hy_dpp<0x4E>(") + v + ")";
-            }
-            if (dpp_ok && m == 4u && L % 16u == 0u) {
-                return std::string("hy_dpp<0x124>(") + v + ")";
-            }
-            if (dpp_ok && m == 8u && L % 16u == 0u) {
-                return std::string("hy_dpp<0x128>(") + v + ")";
-            }
-            return std::string("__shfl_xor(") + v + ", " + std::to_string(m) + ", 64)";
-        };
-        src << "m0 = hy_nmax(m0, " << ex("m0") << ");\n";
-        src << "mo = hy_nmax(mo, " << ex("mo") << ");\n";
-        src << "mom1 = hy_nmax(mom1, " << ex("mom1") << ");\n";
+        if (packed_tail && m == 4u) {
+            break;
+        }
+        src << "m0 = hy_nmax(m0, " << red_ex(m, "m0") << ");\n";
+        src << "mo = hy_nmax(mo, " << red_ex(m, "mo") << ");\n";
+        src << "mom1 = hy_nmax(mom1, " << red_ex(m, "mom1") << ");\n";
+    }
+    if (packed_tail) {
+        src << "const bool hy_q0 = (lane & 3u) == 0u, hy_q1 = (lane & 3u) == 1u;\n";
+        src << "double nv = hy_q0 ? m0 : (hy_q1 ? mo : mom1);\n";
+        for (std::uint32_t m = 4; m < L; m *= 2u) {
+            src << "nv = hy_nmax(nv, " << red_ex(m, "nv") << ");\n";
+        }
     }
     // Mode 4 (stepper with events): the norms over the state variables go to the kernel which extends them to the event
     // equations (hy_ev_jets). A wave-uniform branch; every lane of the system stores the same values.
     // (A separate specialisation of the kernel - opts.event_stepper - so that the propagation kernel is not touched: the
     // extra code, although never executed there, costs it spills in the step loop.)
     src << "const bool nostate = " << (m4 ? "true" : "false") << ";\n";
-    if (m4) {
+    if (m4 && packed_tail) {
+        // (Every lane stores: lane & 3 selects the row, the lanes of a system write identical values.)
+        src << "a.sel_norms[(u64)(((lane & 3u) < 2u) ? (lane & 3u) : 2u) * N + s] = nv;\n";
+    } else if (m4) {
         src << "a.sel_norms[s] = m0;\na.sel_norms[N + s] = mo;\na.sel_norms[2u * N + s] = mom1;\n";
     }
-    src << "const double num_rho = (m0 <= 1.0) ? 1.0 : m0;\n";
     // NOTE: rho = exp(log(x) / order) (hy_root): the minimum of the two estimates is taken on the exponents (exp is
     // monotone and keeps NaNs: the same selection as min(rho_o, rho_om1), src/taylor_02.cpp:1050-1072, one exp less).
-    if (std::getenv("HEYOKA_AMD_RHO_2EXP") != nullptr) {
-        src << "const double rho_o = hy_root(num_rho / mo, " << fp_literal(1. / static_cast<double>(order)) << ");\n";
-        src << "const double rho_om1 = hy_root(num_rho / mom1, " << fp_literal(1. / static_cast<double>(order - 1u))
-            << ");\n";
-        src << "const double rho_m = hy_min(rho_o, rho_om1);\n";
+    if (packed_tail) {
+        // log(num / m) = log(num) - log(m): no quotients (0 -> +inf, inf -> -inf, inf - inf -> nan as for the quotient).
+        src << "const double nw = (hy_q0 & (nv <= 1.0)) ? 1.0 : nv;\n";
+        src << "const double lg = hy_sel_log(nw);\n";
+        src << "const double lg0 = hy_dpp<0x00>(lg), lg1 = hy_dpp<0x55>(lg), lg2 = hy_dpp<0xAA>(lg);\n";
+        src << "const double lr_o = (lg0 - lg1) * " << fp_literal(1. / static_cast<double>(order)) << ";\n";
+        src << "const double lr_om1 = (lg0 - lg2) * " << fp_literal(1. / static_cast<double>(order - 1u)) << ";\n";
+        src << "const double rho_m = exp(hy_min(lr_o, lr_om1));\n";
     } else {
-    src << "const double lr_o = log(num_rho / mo) * " << fp_literal(1. / static_cast<double>(order)) << ";\n";
-    src << "const double lr_om1 = log(num_rho / mom1) * " << fp_literal(1. / static_cast<double>(order - 1u)) << ";\n";
-    src << "const double rho_m = exp(hy_min(lr_o, lr_om1));\n";
+        src << "const double num_rho = (m0 <= 1.0) ? 1.0 : m0;\n";
+        if (std::getenv("HEYOKA_AMD_RHO_2EXP") != nullptr) {
+            src << "const double rho_o = hy_root(num_rho / mo, " << fp_literal(1. / static_cast<double>(order)) << ");\n";
+            src << "const double rho_om1 = hy_root(num_rho / mom1, " << fp_literal(1. / static_cast<double>(order - 1u))
+                << ");\n";
+            src << "const double rho_m = hy_min(rho_o, rho_om1);\n";
+        } else {
+            src << "const double lr_o = log(num_rho / mo) * " << fp_literal(1. / static_cast<double>(order)) << ";\n";
+            src << "const double lr_om1 = log(num_rho / mom1) * " << fp_literal(1. / static_cast<double>(order - 1u)) << ";\n";
+            src << "const double rho_m = exp(hy_min(lr_o, lr_om1));\n";
+        }
     }
     src << "double h = rho_m * " << fp_literal(rhofac(order)) << ";\n";
     src << "h = hy_min(h, fabs(lim));\nh = (lim < 0.0) ? -h : h;\n";
+    // A system which is done takes steps of length EXACTLY zero (lim = 0 gives that unless the selector produced a nan):
+    // the double-length time, the remaining time, the state and the step counters then reproduce themselves bit by bit,
+    // and only the values which a zero-length step would overwrite need a select below (last_h, outcome).
+    src << "h = fin ? 0.0 : h;\n";
 
     src << "asm volatile(\"\" ::: \"memory\");\n";
     // NOTE: with the jets in global scratch the lanes exchange them through memory: wavefront-scope fences.
@@ -1367,16 +1439,17 @@ int nfi = !(hy_finite(nt_hi) && hy_finite(nt_lo)) ? 1 : 0;
     const i64 oc_fin = sl ? HY_OC_STEP_LIMIT : oc_new;
     done |= sl;
     nf_seen |= (!fin & nf & !nostate) ? 1 : 0;
-    t_hi = (fin | nostate) ? t_hi : nt_hi;
-    t_lo = (fin | nostate) ? t_lo : nt_lo;
+    // (fin: h = 0, hence nt = t, rem_new = rem, ns_new = n_steps, no min / max update - see above.)
+    t_hi = nostate ? t_hi : nt_hi;
+    t_lo = nostate ? t_lo : nt_lo;
     last_h = fin ? last_h : h;
     outcome = fin ? outcome : oc_fin;
-    n_steps = fin ? n_steps : ns_new;
-    min_h = fin ? min_h : mn_new;
-    max_h = fin ? max_h : mx_new;
-    rem.hi = fin ? rem.hi : rem_new.hi;
-    rem.lo = fin ? rem.lo : rem_new.lo;
-    iter = fin ? iter : it_new;
+    n_steps = ns_new;
+    min_h = mn_new;
+    max_h = mx_new;
+    rem.hi = rem_new.hi;
+    rem.lo = rem_new.lo;
+    iter = it_new;
     fin = fin | done;
 }
 if (__builtin_amdgcn_ballot_w64(!fin) == 0ull) break;
