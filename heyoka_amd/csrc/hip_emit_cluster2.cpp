@@ -58,18 +58,43 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     // work on both lanes with different register contents (see emit_pair_order below).
     cluster_detail::pair_pattern pp;
     cluster_detail::detect_pair_pattern(p, pl, pp);
+    const bool pp_shape_ok = pp.ok;
     {
         const bool ok = pp.ok;
         const char *ev = std::getenv("HEYOKA_AMD_PAIR_SPLIT");
-        // NOTE: at most 16 pairs (two systems per wavefront). With 17 .. 32 pairs (one system per wavefront, e.g.
-        // model::np1body(8)) the generated kernel did not terminate on the hardware (round 2, not yet understood):
-        // those systems stay on the one-lane-per-cluster kernel.
-        const char *evm = std::getenv("HEYOKA_AMD_PAIR_SPLIT_MAX_LANES"); // (experiments: 64)
-        const auto max_lanes = evm != nullptr ? static_cast<std::uint32_t>(std::atoi(evm)) : 32u;
+        // NOTE: up to 32 pairs. With 17 .. 32 pairs there is one system per wavefront (64 lanes per system); in round 2
+        // that variant did not terminate on the hardware: a finished system kept taking steps whose length was only
+        // clamped to zero (a nan from the selector of a non-finite state survives the clamp), fixed by forcing h = 0.
+        const char *evm = std::getenv("HEYOKA_AMD_PAIR_SPLIT_MAX_LANES");
+        const auto max_lanes = evm != nullptr ? static_cast<std::uint32_t>(std::atoi(evm)) : 64u;
         pp.ok = ok && 2u * nc <= max_lanes && p.n_par == 0u && !(ev != nullptr && std::atoi(ev) == 0);
     }
-    const bool pair_split = pp.ok;
     const bool m4 = opts.event_stepper;
+    // ---- 0b. One lane per pair, two wavefronts per SIMD ("v5"): the lane-pair split halves the histories a lane keeps
+    // (4 x 20 doubles) so that the kernel fits in 256 registers, but every piece of work outside the convolution
+    // chains - the role union of the finishing operations, the glue round, the serial tail of the step - is then paid
+    // per TWO systems of a wavefront. Five histories (d_0, d_1, d_2, b / b_0, sa) of 19 entries fit in 256 registers as
+    // well once the pow recurrence stops keeping j * sa_j: with T_j = sum_{i >= j} p_i (p_i = b_{k-i} sa_i) the weighted
+    // sum is a sum of suffix sums, S2 = sum_j j p_j = sum_j T_j - one FMA and one addition per term, like the two FMAs
+    // of the weighted form, and no sixth history. One lane per pair: 16 lanes per system for the 15 pairs of the outer
+    // Solar System, FOUR systems per wavefront, no role union and no lane exchanges inside a pair. The jets of the
+    // state variables of 32 systems per CU do not fit in LDS (199 KB): only the velocity-type variables (the ones
+    // defined by a glue node) are stored, the coefficients of the position-type ones (x' = v) are re-derived in the final
+    // evaluation as x^[k] = v^[k-1] * RN(1 / k) - the very operation which produced them.
+    const bool one_lane = [&]() {
+        const char *ev = std::getenv("HEYOKA_AMD_ONE_LANE");
+        if (ev == nullptr || std::atoi(ev) == 0) {
+            return false;
+        }
+        return pp_shape_ok && p.n_par == 0u && !m4 && nc <= 64u && std::getenv("HEYOKA_AMD_V3_EXACT_DIV") == nullptr
+               && std::getenv("HEYOKA_AMD_V3_POW_DIV") == nullptr;
+    }();
+    if (one_lane) {
+        pp.ok = false;
+    }
+    const bool pair_split = pp.ok;
+    // (Shared by the two pair-pattern kernels: fused reactions, merged schedule, reciprocal-based divisions.)
+    const bool pairk = pair_split || one_lane;
     if (pair_split) {
         pl.L = 2;
         while (pl.L < 2u * nc) {
@@ -100,11 +125,39 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         }
         pl.n_slots = ns;
     }
+    if (one_lane) {
+        pl.L = 4;
+        while (pl.L < nc) {
+            pl.L *= 2u;
+        }
+        pl.spw = 64u / pl.L;
+        // Outputs in lane order, one run of consecutive slots per product.
+        std::uint32_t ns = n_eq;
+        std::fill(pl.slot_of.begin() + n_eq, pl.slot_of.end(), -1);
+        // ([pair][product]: the three output slots of a lane are consecutive, one address register per lane; the lanes of
+        // a group write with a stride of 3 doubles - distinct banks.)
+        for (std::uint32_t c = 0; c < nc; ++c) {
+            for (std::uint32_t i = 0; i < 3u; ++i) {
+                pl.slot_of[pl.clusters[c][pp.pr[i]]] = static_cast<int>(ns++);
+            }
+        }
+        for (std::uint32_t c = 0; pp.rx[0] >= 0 && c < nc; ++c) {
+            for (std::uint32_t i = 0; i < 3u; ++i) {
+                pl.slot_of[pl.clusters[c][static_cast<std::uint32_t>(pp.rx[i])]] = static_cast<int>(ns++);
+            }
+        }
+        for (std::uint32_t u = n_eq; u < p.n_u; ++u) {
+            if (pl.cluster_of[u] == -1) {
+                pl.slot_of[u] = static_cast<int>(ns++);
+            }
+        }
+        pl.n_slots = ns;
+    }
     const auto L = pl.L, spw = pl.spw;
     // NOTE: HEYOKA_AMD_V2_BS overrides the block size (experiments). Lane pairs: 512 threads = two wavefronts per SIMD.
     const std::uint32_t bs = std::getenv("HEYOKA_AMD_V2_BS") != nullptr
                                  ? static_cast<std::uint32_t>(std::atoi(std::getenv("HEYOKA_AMD_V2_BS")))
-                                 : (pair_split ? 512u : 256u);
+                                 : (pairk ? 512u : 256u);
     const std::uint32_t wpb = bs / 64u;
     const auto n_ext = static_cast<std::uint32_t>(pl.ext_u[0].size());
     const auto n_out = static_cast<std::uint32_t>(pl.out_pos.size());
@@ -200,50 +253,6 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         }
     }
 
-    // ---- 2. LDS layout: every slot double-buffered by order parity. ----
-    const std::uint32_t max_round_outputs = std::max<std::uint32_t>(n_out, 4u);
-    const auto dummy_base = pl.n_slots;
-    const auto n_slots_tot = pl.n_slots + max_round_outputs;
-    const auto buf_stride = n_slots_tot;                 // doubles between the two parity buffers
-    const auto slab_stride = (2u * n_slots_tot) | 1u;    // doubles per system
-
-    // ---- 3. Tables. ----
-    std::vector<std::vector<std::uint32_t>> utbl;
-    std::vector<std::vector<double>> dtbl;
-    // NOTE: tables of slab slots and tables of state-variable indices are kept apart (the slot tables are
-    // renumbered by the bank-conflict optimiser below).
-    std::vector<char> utbl_is_slot;
-    const auto add_utbl = [&](std::vector<std::uint32_t> v, bool is_slot = true) {
-        // Deduplicate identical tables.
-        for (std::size_t t = 0; t < utbl.size(); ++t) {
-            if (utbl[t] == v && (utbl_is_slot[t] != 0) == is_slot) {
-                return t;
-            }
-        }
-        utbl.push_back(std::move(v));
-        utbl_is_slot.push_back(is_slot ? 1 : 0);
-        return utbl.size() - 1u;
-    };
-    const auto add_dtbl = [&](std::vector<double> v) {
-        dtbl.push_back(std::move(v));
-        return dtbl.size() - 1u;
-    };
-    const auto utname = [](std::size_t t) { return "ut" + std::to_string(t); };
-    const auto dtname = [](std::size_t t) { return "dt" + std::to_string(t); };
-
-    ssa_emitter e(p, order);
-    auto &os = e.os;
-    // Lane-pair kernel: x^[k+1] = f^[k] * RN(1 / (k + 1)) - one multiplication, within 1 ulp of the quotient - instead of
-    // the exact 3-operation sequence (60 VALU instructions per step, +2.1 % system-steps/s; the strict-contraction parity
-    // test passes its 1e4 / 1e5 eps bounds with it). HEYOKA_AMD_V3_EXACT_DIV=1 restores the correctly-rounded quotient.
-    e.recip_div = pair_split && std::getenv("HEYOKA_AMD_V3_EXACT_DIV") == nullptr;
-    e.enable_pow_rcp();
-
-    // Lane-pair variant: lane l = 2 * pair + role (role 0 = A: d_0, d_1; role 1 = B: d_2 and the pow); the lanes
-    // beyond the last pair replicate pair 0 and write to dummy slots.
-    struct pair_tables {
-        std::size_t s0 = 0, s1 = 0, p0 = 0, p1 = 0, os = 0, op = 0, rs = 0, rp = 0, csc = 0, crs = 0, crp = 0;
-    } pt;
     // Reaction fusion (lane-pair variant): the members c * pr of a cluster (the reaction on the second body of the pair)
     // are not computed / exported by the cluster lanes: the glue sums which read them read the direct product pr instead
     // and multiply it by a per-lane coefficient (c, or 1.0 where the sum reads the direct product itself: exact, so the
@@ -252,7 +261,7 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     std::vector<char> rx_fused(p.n_u, 0);
     std::vector<std::uint32_t> rx_src(p.n_u, 0);
     bool fuse_rx = false;
-    if (pair_split && pp.rx[0] >= 0) {
+    if (pairk && pp.rx[0] >= 0) {
         const char *ev = std::getenv("HEYOKA_AMD_V3_FUSE_RX");
         fuse_rx = !(ev != nullptr && std::atoi(ev) == 0);
         for (std::size_t c = 0; c < nc; ++c) {
@@ -288,6 +297,126 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
             std::fill(rx_fused.begin(), rx_fused.end(), 0);
         }
     }
+    // A glue node / state variable needs a slab slot only if somebody reads it through the slab.
+    std::vector<char> glue_read(p.n_u, 0);
+    for (const auto &n : p.nodes) {
+        for (const auto &o : n.args) {
+            if (is_var(o)) {
+                glue_read[o.idx] = 1;
+            }
+        }
+    }
+    if (one_lane) {
+        // 32 systems per CU: the slab only keeps the slots which are read through it (positions, products, glue nodes
+        // with readers): 63 instead of 144 for the outer Solar System.
+        for (std::size_t g = 0; g < pl.groups.size(); ++g) {
+            if (grp_natt[g] > 2u) {
+                why_not = "one-lane pair kernel: state-variable chains longer than two";
+                return ret;
+            }
+        }
+        std::vector<int> remap(pl.n_slots, -1);
+        std::uint32_t ns = 0;
+        const auto keep = [&](std::uint32_t u) {
+            if (pl.slot_of[u] < 0) {
+                return false;
+            }
+            if (pl.cluster_of[u] != -1) {
+                // Cluster outputs: the direct products, or - when only the reaction was exported - that one.
+                if (fuse_rx && rx_fused[u] != 0) {
+                    return pl.slot_of[rx_src[u]] < 0;
+                }
+                return true;
+            }
+            return glue_read[u] != 0;
+        };
+        // (The kept slots keep their relative order.)
+        std::vector<char> kept(p.n_u, 0);
+        std::vector<std::pair<int, std::uint32_t>> order_v;
+        for (std::uint32_t u = 0; u < p.n_u; ++u) {
+            kept[u] = keep(u) ? 1 : 0;
+            if (kept[u] != 0) {
+                order_v.emplace_back(pl.slot_of[u], u);
+            }
+        }
+        std::sort(order_v.begin(), order_v.end());
+        for (std::uint32_t u = 0; u < p.n_u; ++u) {
+            if (kept[u] == 0) {
+                pl.slot_of[u] = -1;
+            }
+        }
+        for (const auto &[old_slot, u] : order_v) {
+            (void)old_slot;
+            pl.slot_of[u] = static_cast<int>(ns++);
+        }
+        pl.n_slots = ns;
+    }
+
+    // ---- 2. LDS layout: every slot double-buffered by order parity. ----
+    const std::uint32_t max_round_outputs = std::max<std::uint32_t>(n_out, 4u);
+    const auto dummy_base = pl.n_slots;
+    const auto n_slots_tot = pl.n_slots + max_round_outputs;
+    const auto buf_stride = n_slots_tot;                 // doubles between the two parity buffers
+    const auto slab_stride = (2u * n_slots_tot) | 1u;    // doubles per system
+
+    // ---- 3. Tables. ----
+    std::vector<std::vector<std::uint32_t>> utbl;
+    std::vector<std::vector<double>> dtbl;
+    // NOTE: tables of slab slots and tables of state-variable indices are kept apart (the slot tables are
+    // renumbered by the bank-conflict optimiser below).
+    std::vector<char> utbl_is_slot;
+    // utexpr[t]: how the kernel refers to the per-lane value of table t - a register loaded at the top of the kernel
+    // ("ut<t>"), or (one-lane pair kernel, where every register counts) an earlier table plus a constant when the two
+    // differ by the same amount on every lane (the three coordinates of a body, the three products of a pair: the
+    // constant folds into the offset field of the LDS instruction).
+    std::vector<std::string> utexpr;
+    const auto add_utbl = [&](std::vector<std::uint32_t> v, bool is_slot = true) {
+        // Deduplicate identical tables.
+        for (std::size_t t = 0; t < utbl.size(); ++t) {
+            if (utbl[t] == v && (utbl_is_slot[t] != 0) == is_slot) {
+                return t;
+            }
+        }
+        std::string ex = "ut" + std::to_string(utbl.size());
+        for (std::size_t t = 0; one_lane && is_slot && t < utbl.size(); ++t) {
+            if (utbl_is_slot[t] == 0 || utexpr[t] != "ut" + std::to_string(t)) {
+                continue;
+            }
+            const auto d = static_cast<std::int64_t>(v[0]) - static_cast<std::int64_t>(utbl[t][0]);
+            bool affine = true;
+            for (std::size_t l2 = 0; l2 < v.size(); ++l2) {
+                affine = affine && (static_cast<std::int64_t>(v[l2]) - static_cast<std::int64_t>(utbl[t][l2]) == d);
+            }
+            if (affine) {
+                ex = "(ut" + std::to_string(t) + (d >= 0 ? " + " : " - ") + std::to_string(d >= 0 ? d : -d) + "u)";
+                break;
+            }
+        }
+        utexpr.push_back(std::move(ex));
+        utbl.push_back(std::move(v));
+        utbl_is_slot.push_back(is_slot ? 1 : 0);
+        return utbl.size() - 1u;
+    };
+    const auto add_dtbl = [&](std::vector<double> v) {
+        dtbl.push_back(std::move(v));
+        return dtbl.size() - 1u;
+    };
+    const auto utname = [&](std::size_t t) { return utexpr[t]; };
+    const auto dtname = [](std::size_t t) { return "dt" + std::to_string(t); };
+
+    ssa_emitter e(p, order);
+    auto &os = e.os;
+    // Lane-pair kernel: x^[k+1] = f^[k] * RN(1 / (k + 1)) - one multiplication, within 1 ulp of the quotient - instead of
+    // the exact 3-operation sequence (60 VALU instructions per step, +2.1 % system-steps/s; the strict-contraction parity
+    // test passes its 1e4 / 1e5 eps bounds with it). HEYOKA_AMD_V3_EXACT_DIV=1 restores the correctly-rounded quotient.
+    e.recip_div = pairk && std::getenv("HEYOKA_AMD_V3_EXACT_DIV") == nullptr;
+    e.enable_pow_rcp();
+
+    // Lane-pair variant: lane l = 2 * pair + role (role 0 = A: d_0, d_1; role 1 = B: d_2 and the pow); the lanes
+    // beyond the last pair replicate pair 0 and write to dummy slots.
+    struct pair_tables {
+        std::size_t s0 = 0, s1 = 0, p0 = 0, p1 = 0, os = 0, op = 0, rs = 0, rp = 0, csc = 0, crs = 0, crp = 0;
+    } pt;
     // Slab slot through which a product pr travels (its own, or - when only its reaction was exported - that one's).
     const auto pr_slot = [&](std::uint32_t pr_u, std::uint32_t rx_u, std::uint32_t dflt) {
         if (pl.slot_of[pr_u] >= 0) {
@@ -348,22 +477,55 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
             pt.csc = add_dtbl(std::move(csc));
         }
     }
+    // One-lane pair kernel: lane l = pair l (the lanes beyond the last pair replicate pair 0 and write to dummy slots).
+    struct single_tables {
+        std::size_t s[3][2] = {}, o[3] = {}, csc = 0;
+    } st1;
+    if (one_lane) {
+        if (!fuse_rx && pp.rx[0] >= 0) {
+            why_not = "one-lane pair kernel: the reaction products cannot be fused into the sums";
+            return ret;
+        }
+        std::vector<double> csc(L, 1.);
+        for (std::uint32_t i = 0; i < 3u; ++i) {
+            std::vector<std::uint32_t> s0(L), s1(L), o(L);
+            for (std::uint32_t l = 0; l < L; ++l) {
+                const bool valid = l < nc;
+                const auto c = valid ? l : 0u;
+                const auto &cl = pl.clusters[c];
+                s0[l] = static_cast<std::uint32_t>(pl.slot_of[pl.ext_u[c][pp.de[i][0]]]);
+                s1[l] = static_cast<std::uint32_t>(pl.slot_of[pl.ext_u[c][pp.de[i][1]]]);
+                o[l] = valid ? pr_slot(cl[pp.pr[i]], pp.rx[0] >= 0 ? cl[static_cast<std::uint32_t>(pp.rx[i])] : cl[pp.pr[i]],
+                                       dummy_base + i)
+                             : dummy_base + i;
+                if (pp.sc >= 0) {
+                    csc[l] = p.nodes[cl[static_cast<std::uint32_t>(pp.sc)] - n_eq].args[0].value;
+                }
+            }
+            st1.s[i][0] = add_utbl(std::move(s0));
+            st1.s[i][1] = add_utbl(std::move(s1));
+            st1.o[i] = add_utbl(std::move(o));
+        }
+        if (pp.sc >= 0) {
+            st1.csc = add_dtbl(std::move(csc));
+        }
+    }
     std::vector<std::size_t> ext_tbl(n_ext), out_tbl(n_out), cst_tbl(n_cst);
-    for (std::uint32_t x = 0; !pair_split && x < n_ext; ++x) {
+    for (std::uint32_t x = 0; !pairk && x < n_ext; ++x) {
         std::vector<std::uint32_t> v(L);
         for (std::uint32_t l = 0; l < L; ++l) {
             v[l] = static_cast<std::uint32_t>(pl.slot_of[pl.ext_u[l < nc ? l : 0u][x]]);
         }
         ext_tbl[x] = add_utbl(std::move(v));
     }
-    for (std::uint32_t x = 0; !pair_split && x < n_out; ++x) {
+    for (std::uint32_t x = 0; !pairk && x < n_out; ++x) {
         std::vector<std::uint32_t> v(L);
         for (std::uint32_t l = 0; l < L; ++l) {
             v[l] = l < nc ? static_cast<std::uint32_t>(pl.slot_of[pl.clusters[l][pl.out_pos[x]]]) : dummy_base + x;
         }
         out_tbl[x] = add_utbl(std::move(v));
     }
-    for (std::uint32_t x = 0; !pair_split && x < n_cst; ++x) {
+    for (std::uint32_t x = 0; !pairk && x < n_cst; ++x) {
         std::vector<double> v(L);
         for (std::uint32_t l = 0; l < L; ++l) {
             v[l] = pl.cst_val[l < nc ? l : 0u][x];
@@ -381,7 +543,7 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         }
         return "lp" + std::to_string(t);
     };
-    for (std::size_t x = 0; !pair_split && x < pl.par_pos.size(); ++x) {
+    for (std::size_t x = 0; !pairk && x < pl.par_pos.size(); ++x) {
         std::vector<std::uint32_t> v(L);
         for (std::uint32_t l = 0; l < L; ++l) {
             v[l] = pl.par_idx[l < nc ? l : 0u][x];
@@ -399,6 +561,11 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         std::uint32_t n_valid = 0;
         std::vector<std::string> xname; // SSA names of the coefficients, by order
         bool slab_needed = true;        // is one of the variables of the slot read through the slab?
+        // One-lane pair kernel: the second variable of a chain (x' = v) keeps no jet column: its coefficients are
+        // re-derived from the column of the first one (parent) in the final evaluation; cbase then counts the
+        // order-0 entries of the derived variables (their current values).
+        bool derived = false;
+        std::uint32_t parent = 0; // owner slot id of the variable it is derived from
     };
     struct glue_round {
         std::vector<std::size_t> arg_tbl;
@@ -411,16 +578,7 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         std::vector<std::size_t> coef_tbl; // reaction fusion: per-lane coefficient tables, by argument (empty: not fused)
     };
     std::vector<std::vector<glue_round>> rounds(pl.groups.size());
-    std::uint32_t n_own = 0, n_col_acc = 0;
-    // A glue node needs a slab slot only if somebody reads it through the slab.
-    std::vector<char> glue_read(p.n_u, 0);
-    for (const auto &n : p.nodes) {
-        for (const auto &o : n.args) {
-            if (is_var(o)) {
-                glue_read[o.idx] = 1;
-            }
-        }
-    }
+    std::uint32_t n_own = 0, n_col_acc = 0, n_dcol_acc = 0;
     for (std::size_t g = 0; g < pl.groups.size(); ++g) {
         const auto &grp = pl.groups[g];
         const auto n_nodes = static_cast<std::uint32_t>(grp.nodes.size());
@@ -481,7 +639,7 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
             std::vector<std::uint32_t> v(L);
             for (std::uint32_t l = 0; l < L; ++l) {
                 const auto j = r * L + l;
-                v[l] = j < n_nodes ? static_cast<std::uint32_t>(pl.slot_of[grp.nodes[j]]) : dummy_base;
+                v[l] = (j < n_nodes && pl.slot_of[grp.nodes[j]] >= 0) ? static_cast<std::uint32_t>(pl.slot_of[grp.nodes[j]]) : dummy_base;
                 any_read = any_read || (j < n_nodes && glue_read[grp.nodes[j]] != 0);
             }
             gr.exported = any_read;
@@ -491,15 +649,22 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
                 std::vector<std::uint32_t> vs(L), vv(L);
                 for (std::uint32_t l = 0; l < L; ++l) {
                     const auto var = att.at(node_of(l))[a];
-                    vs[l] = (r * L + l < n_nodes) ? static_cast<std::uint32_t>(pl.slot_of[var]) : dummy_base;
+                    vs[l] = (r * L + l < n_nodes && pl.slot_of[var] >= 0) ? static_cast<std::uint32_t>(pl.slot_of[var]) : dummy_base;
                     vv[l] = var;
                 }
                 ow.out_tbl = add_utbl(std::move(vs));
                 ow.var_tbl = add_utbl(std::move(vv), false);
                 ow.col = n_own++;
-                ow.cbase = n_col_acc;
                 ow.n_valid = gr.n_valid;
-                n_col_acc += gr.n_valid;
+                if (one_lane && a >= 1u) {
+                    ow.derived = true;
+                    ow.parent = gr.owners[a - 1u].col;
+                    ow.cbase = n_dcol_acc;
+                    n_dcol_acc += gr.n_valid;
+                } else {
+                    ow.cbase = n_col_acc;
+                    n_col_acc += gr.n_valid;
+                }
                 ow.xname.resize(order + 1u);
                 ow.slab_needed = false;
                 for (std::uint32_t l = 0; l < L && r * L + l < n_nodes; ++l) {
@@ -520,11 +685,15 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     // unconditional (no exec-mask manipulation inside the step loop).
     const auto n_col = n_col_acc;
     const auto n_colp = n_col + 1u;
+    // (One-lane pair kernel: current values of the derived variables, [system of the wave][entry] + one dummy entry.)
+    const auto n_dcol = n_dcol_acc;
+    const auto n_dcolp = n_dcol + 1u;
     const auto n_hslots = (n_col + L - 1u) / L; // lane slots of the final Horner / compensated evaluation
     // Jets of the state variables: [order][system of the wave][column], per wave. Kept in LDS when the
     // block's slab + jets fit in the 160 KB of a CU (the kernel occupies a whole CU anyway: 512 registers
     // per lane), otherwise in a per-wave global scratch.
-    const auto jet_doubles_per_wave = static_cast<std::uint64_t>(order + 1u) * spw * n_colp;
+    const auto jet_rows_doubles = static_cast<std::uint64_t>(order + 1u) * spw * n_colp;
+    const auto jet_doubles_per_wave = jet_rows_doubles + (one_lane ? static_cast<std::uint64_t>(spw) * n_dcolp : 0u);
     const auto lds_doubles_slab = static_cast<std::uint64_t>(wpb) * spw * ((2u * (pl.n_slots + std::max<std::uint32_t>(n_out, 4u))) | 1u);
     const bool jet_lds = (lds_doubles_slab + wpb * jet_doubles_per_wave) * 8u <= 160u * 1024u
                          && std::getenv("HEYOKA_AMD_JET_GLOBAL") == nullptr;
@@ -532,7 +701,7 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     // Merged schedule (lane-pair variant, one glue level after the clusters): round k = cluster(k) + glue(k-1),
     // one LDS synchronisation per order instead of two.
     const bool merged = [&]() {
-        if (!pair_split || pl.cluster_level != 1u || pl.max_level != 2u) {
+        if (!pairk || pl.cluster_level != 1u || pl.max_level != 2u) {
             return false;
         }
         for (const auto &g : pl.groups) {
@@ -543,6 +712,10 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         const char *ev = std::getenv("HEYOKA_AMD_V3_MERGED");
         return !(ev != nullptr && std::atoi(ev) == 0);
     }();
+    if (one_lane && !merged) {
+        why_not = "one-lane pair kernel: the merged schedule does not apply";
+        return ret;
+    }
 
     // ---- 4. Emission helpers. ----
     const auto slabk = [&](std::uint32_t k, const std::string &tbl) {
@@ -553,6 +726,14 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         return "jc" + std::to_string(col) + "[" + std::to_string(static_cast<std::uint64_t>(k) * spw * n_colp) + "]";
     };
     const auto sync = [&]() { os << "HY_WSYNC();\n"; };
+    // Where the current value (order 0) of the variables of an owner slot lives: read side (the idle lanes of a partially
+    // filled slot read the entry of a valid lane) and write side (... and write to the dummy entry).
+    const auto row0_r = [&](const owner_slot &ow) {
+        return (ow.derived ? "x0r" : "jr") + std::to_string(ow.col) + "[0]";
+    };
+    const auto row0_w = [&](const owner_slot &ow) {
+        return (ow.derived ? "x0c" : "jc") + std::to_string(ow.col) + "[0]";
+    };
 
     // Owner-slot bookkeeping when a new coefficient of a state variable is produced.
     const auto publish_sv = [&](owner_slot &ow, std::uint32_t k, const std::string &name) {
@@ -560,7 +741,7 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         if (ow.slab_needed) {
             os << slabk(k, utname(ow.out_tbl)) << " = " << name << ";\n";
         }
-        if (k != 0u) {
+        if (k != 0u && !ow.derived) {
             // (The order-0 row of the jets *is* the current state: written by the update of the previous step.)
             os << jet_at(k, ow.col) << " = " << name << ";\n";
         }
@@ -876,6 +1057,104 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
 
     const auto emit_pair_order = [&](std::uint32_t k) { emit_pair_compute(k, emit_pair_reads(k)); };
 
+    // ---- One-lane pair program ("v5") ----
+    // Histories of a lane (SSA names by order): sD[i] = d_i (i = 0, 1, 2), sB = b_k / b_0 (k >= 1; b = sum of squares),
+    // sA = sa = (scaled) pow. Chains of order k, history part = indices 1 .. k-1:
+    //   q_i = sum_{j <= jmax} d_i[k-j] d_i[j]                      (half of the symmetric sum of d_i^2, see below)
+    //   T   = sum_j sB[k-j] sA[j]                                  (S1 of the pow recurrence)
+    //   U   = sum of the suffix sums of T's terms = sum_j j sB[k-j] sA[j]   (S2; terms taken in the order j = k-1 .. 1)
+    //   c_i = sum_j d_i[k-j] sA[j]                                 (d_i * sa)
+    // b_k = 2 (q_0 + q_1 + q_2) (+ the middle squares at even orders): the factor 2 is exact, so the HALF sum
+    // bh = (q_0 + 0.5 mid_0) + ... is formed instead and the doubling is folded into the normalisation constant
+    // rb2 = 2 RN(1 / b_0). a_k = alpha (T + sB[k] a_0) - ((alpha + 1) / k) U (src/math/pow.cpp:517-549 divided by k b_0).
+    std::vector<std::string> sD[3], sB(order + 1u), sA(order + 1u);
+    for (auto &v : sD) {
+        v.resize(order + 1u);
+    }
+    std::string hq[3], hm[3], hcx[3], hT, hU;
+    const auto emit_single_reads = [&](std::uint32_t k) {
+        std::vector<std::string> r;
+        for (std::uint32_t i = 0; i < 3u; ++i) {
+            r.push_back(e.def(slabk(k, utname(st1.s[i][0]))));
+            r.push_back(e.def(slabk(k, utname(st1.s[i][1]))));
+        }
+        return r;
+    };
+    const auto emit_single_compute = [&](std::uint32_t k, const std::vector<std::string> &rdv) {
+        using emit_detail::ssa_emitter;
+        for (std::uint32_t i = 0; i < 3u; ++i) {
+            sD[i][k] = e.def(rdv[2u * i] + " - " + rdv[2u * i + 1u]);
+        }
+        std::string pr[3];
+        if (k == 0u) {
+            // (Products rounded one by one, summed pairwise like the reference's sum_sq: src/detail/sum_sq.cpp:120-245.)
+            std::string sq[3];
+            for (std::uint32_t i = 0; i < 3u; ++i) {
+                sq[i] = e.def(ssa_emitter::mul(sD[i][0], sD[i][0]));
+            }
+            const auto s01 = e.def(sq[0] + " + " + sq[1]);
+            const auto r2 = e.def(s01 + " + " + sq[2]);
+            sB[0] = r2;
+            const auto a0 = e.pow_eval(r2, pp.ex);
+            sA[0] = pp.sc >= 0 ? e.def(ssa_emitter::mul(dtname(st1.csc), a0)) : a0;
+            const auto rb = e.def("1.0 / " + r2);
+            os << "const double rb2 = " << rb << " + " << rb << ";\n";
+            for (std::uint32_t i = 0; i < 3u; ++i) {
+                pr[i] = e.def(ssa_emitter::mul(sD[i][0], sA[0]));
+            }
+        } else {
+            std::string q[3];
+            for (std::uint32_t i = 0; i < 3u; ++i) {
+                q[i] = e.chain(hq[i], sD[i][k], sD[i][0]);
+                if (k % 2u == 0u) {
+                    q[i] = e.def("__builtin_fma(0.5, " + hm[i] + ", " + q[i] + ")");
+                }
+            }
+            const auto q01 = e.def(q[0] + " + " + q[1]);
+            const auto bh = e.def(q01 + " + " + q[2]);
+            sB[k] = e.def(ssa_emitter::mul("rb2", bh));
+            const auto c1a = e.chain(hT, sB[k], sA[0]);
+            const auto m = e.def(ssa_emitter::mul(fp_literal(pp.ex), c1a));
+            sA[k] = hU.empty() ? m
+                               : e.def("__builtin_fma(" + hU + ", " + fp_literal(-(pp.ex + 1.) / static_cast<double>(k)) + ", " + m + ")");
+            for (std::uint32_t i = 0; i < 3u; ++i) {
+                pr[i] = e.chain(e.chain(hcx[i], sD[i][k], sA[0]), sD[i][0], sA[k]);
+            }
+        }
+        for (std::uint32_t i = 0; i < 3u; ++i) {
+            os << slabk(k, utname(st1.o[i])) << " = " << pr[i] << ";\n";
+        }
+        // History parts of order K = k + 1 (indices 1 .. k), the eight chains interleaved term by term.
+        for (std::uint32_t i = 0; i < 3u; ++i) {
+            hq[i].clear();
+            hm[i].clear();
+            hcx[i].clear();
+        }
+        hT.clear();
+        hU.clear();
+        const auto K = k + 1u;
+        if (K < order && K >= 2u) {
+            const auto jmax = (K % 2u == 1u) ? (K - 1u) / 2u : (K - 2u) / 2u;
+            for (std::uint32_t j = 1; j < K; ++j) {
+                // (T / U take their terms in the order j = K-1 .. 1: the first term enters U K-1 times, the last one once.)
+                const auto jd = K - j;
+                hT = e.chain(hT, sB[K - jd], sA[jd]);
+                hU = hU.empty() ? hT : e.def(hU + " + " + hT);
+                for (std::uint32_t i = 0; i < 3u; ++i) {
+                    hcx[i] = e.chain(hcx[i], sD[i][K - j], sA[j]);
+                    if (j <= jmax) {
+                        hq[i] = e.chain(hq[i], sD[i][K - j], sD[i][j]);
+                    }
+                }
+            }
+            if (K % 2u == 0u) {
+                for (std::uint32_t i = 0; i < 3u; ++i) {
+                    hm[i] = e.def(ssa_emitter::mul(sD[i][K / 2u], sD[i][K / 2u]));
+                }
+            }
+        }
+    };
+
     // External inputs which are constant u variables in EVERY cluster (isomorphic clusters may pair a constant with a
     // variable: the heliocentric alias x_i - 0 and the pair difference x_j - x_i of model::np1body).
     std::vector<char> ext_const(n_ext, 1);
@@ -920,7 +1199,7 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     for (auto &rg : rounds) {
         for (auto &gr : rg) {
             for (auto &ow : gr.owners) {
-                os << "const double xs" << ow.col << " = jr" << ow.col << "[0];\n";
+                os << "const double xs" << ow.col << " = " << row0_r(ow) << ";\n";
                 publish_sv(ow, 0, "xs" + std::to_string(ow.col));
             }
         }
@@ -941,7 +1220,7 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     for (std::uint32_t k = 0; merged && k <= order; ++k) {
         std::vector<std::string> prd;
         if (k < order) {
-            prd = emit_pair_reads(k);
+            prd = one_lane ? emit_single_reads(k) : emit_pair_reads(k);
         }
         std::vector<std::tuple<std::size_t, std::uint32_t, std::vector<std::string>>> pend;
         if (k >= 1u) {
@@ -952,7 +1231,11 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
             }
         }
         if (k < order) {
-            emit_pair_compute(k, prd);
+            if (one_lane) {
+                emit_single_compute(k, prd);
+            } else {
+                emit_pair_compute(k, prd);
+            }
         }
         for (const auto &[g, r, names] : pend) {
             emit_glue_compute(g, r, k - 1u, names);
@@ -1130,6 +1413,12 @@ __device__ __forceinline__ double hy_swap1(double x)
             src << c << ",";
         }
     }
+    if (one_lane) {
+        src << "};\n__constant__ double hy_rk[" << (order + 1u) << "] = {0.0,";
+        for (std::uint32_t k = 1; k <= order; ++k) {
+            src << fp_literal(1. / static_cast<double>(k)) << ",";
+        }
+    }
     src << "};\n__constant__ double hy_dtbl[" << std::max<std::size_t>(dtbl.size(), 1u) * L << "] = {";
     for (const auto &v : dtbl) {
         for (const auto x : v) {
@@ -1155,7 +1444,9 @@ __device__ __forceinline__ double hy_swap1(double x)
         src << "double *const jetw = a.scratch + gwave * " << jet_doubles_per_wave << "ull;\n";
     }
     for (std::size_t t = 0; t < utbl.size(); ++t) {
-        src << "const unsigned ut" << t << " = hy_utbl[" << t * L << "u + l];\n";
+        if (utexpr[t] == "ut" + std::to_string(t)) {
+            src << "const unsigned ut" << t << " = hy_utbl[" << t * L << "u + l];\n";
+        }
     }
     for (std::size_t t = 0; t < dtbl.size(); ++t) {
         src << "const double dt" << t << " = hy_dtbl[" << t * L << "u + l];\n";
@@ -1167,6 +1458,14 @@ __device__ __forceinline__ double hy_swap1(double x)
         for (const auto &gr : rg) {
             for (const auto &ow : gr.owners) {
                 src << "const bool ovalid" << ow.col << " = l < " << gr.n_valid << "u;\n";
+                if (ow.derived) {
+                    // (Current values of the derived variables: after the jet rows of the wavefront.)
+                    src << "double *const x0c" << ow.col << " = jetw + " << jet_rows_doubles << "u + q * " << n_dcolp
+                        << "u + (ovalid" << ow.col << " ? " << ow.cbase << "u + l : " << n_dcol << "u);\n";
+                    src << "const double *const x0r" << ow.col << " = jetw + " << jet_rows_doubles << "u + q * " << n_dcolp
+                        << "u + " << ow.cbase << "u + (ovalid" << ow.col << " ? l : 0u);\n";
+                    continue;
+                }
                 src << "double *const jc" << ow.col << " = jetw + q * " << n_colp << "u + (ovalid" << ow.col << " ? "
                     << ow.cbase << "u + l : " << n_col << "u);\n";
                 // The current state (order-0 row) is read from the column of the replicated variable by the idle lanes.
@@ -1176,7 +1475,7 @@ __device__ __forceinline__ double hy_swap1(double x)
         }
     }
     // Lane slots of the final evaluation: slot h, lane l <-> jet column h * L + l (dummy column beyond the last one).
-    for (std::uint32_t h = 0; h < n_hslots; ++h) {
+    for (std::uint32_t h = 0; !one_lane && h < n_hslots; ++h) {
         src << "double *const hc" << h << " = jetw + q * " << n_colp << "u + ((" << h * L << "u + l < " << n_col << "u) ? "
             << h * L << "u + l : " << n_col << "u);\n";
     }
@@ -1218,7 +1517,7 @@ double t_hi = a.time_hi[s], t_lo = a.time_lo[s];
     for (const auto &rg : rounds) {
         for (const auto &gr : rg) {
             for (const auto &ow : gr.owners) {
-                src << jet_at(0, ow.col) << " = a.state[(u64)" << utname(ow.var_tbl) << " * N + s];\n";
+                src << row0_w(ow) << " = a.state[(u64)hy_utbl[" << ow.var_tbl * L << "u + l] * N + s];\n";
             }
         }
     }
@@ -1353,7 +1652,52 @@ lim = fin ? 0.0 : lim;
     // evenly over the lanes of the group: slot h, lane l <-> column h * L + l, ceil(n_eq / L) slots instead of
     // one per owner slot (3 instead of 4 for the 36 variables of the outer Solar System on 16 lanes).
     const auto kstride = static_cast<std::uint64_t>(spw) * n_colp;
-    for (std::uint32_t c = 0; c < n_hslots; ++c) {
+    // (name of the new value, where the current value is read, where the new one goes)
+    std::vector<std::tuple<std::string, std::string, std::string>> upd;
+    if (one_lane) {
+        // One pass per owner slot: the variables with a jet column, and the derived ones (x' = v) whose coefficients are
+        // formed on the fly from the parent's column, x^[k] = v^[k-1] * RN(1 / k) - bit for bit the published coefficient
+        // (ssa_emitter::div_const() in its reciprocal form). Every pass is one instruction stream without selects.
+        for (const auto &rg : rounds) {
+            for (const auto &gr : rg) {
+                for (const auto &ow : gr.owners) {
+                    const auto xn = "xn" + std::to_string(ow.col);
+                    const auto src_col = "jr" + std::to_string(ow.derived ? ow.parent : ow.col);
+                    const auto coef = [&](std::uint32_t k) -> std::string {
+                        if (!ow.derived) {
+                            return src_col + "[" + std::to_string(k * kstride) + "]";
+                        }
+                        if (k == 0u) {
+                            return row0_r(ow);
+                        }
+                        return "(" + src_col + "[" + std::to_string((k - 1u) * kstride) + "] * "
+                               + fp_literal(1. / static_cast<double>(k)) + ")";
+                    };
+                    src << "double " << xn << ";\n{\n";
+                    if (opts.high_accuracy) {
+                        src << "double res = " << coef(0) << ", comp = 0.0, cur_h = h;\n";
+                        for (std::uint32_t k = 1; k <= order; ++k) {
+                            src << "{\nconst double ck = " << coef(k) << ";\nconst double tmp = ck * cur_h;\n"
+                                << "const double y = tmp - comp;\nconst double t = res + y;\ncomp = (t - res) - y;\nres = t;\n";
+                            if (k < order) {
+                                src << "cur_h = cur_h * h;\n";
+                            }
+                            src << "}\n";
+                        }
+                    } else {
+                        src << "double res = " << coef(order) << ";\n";
+                        for (std::uint32_t k = 1; k <= order; ++k) {
+                            src << "res = " << coef(order - k) << " + res * h;\n";
+                        }
+                    }
+                    src << xn << " = res;\n}\n";
+                    upd.emplace_back(xn, row0_r(ow), row0_w(ow));
+                }
+            }
+        }
+    }
+    for (std::uint32_t c = 0; !one_lane && c < n_hslots; ++c) {
+        upd.emplace_back("xn" + std::to_string(c), "hc" + std::to_string(c) + "[0]", "hc" + std::to_string(c) + "[0]");
         if (m4) {
             // (No state update in the stepper with events.)
             src << "const double xn" << c << " = hc" << c << "[0];\n";
@@ -1382,9 +1726,9 @@ double nt_hi, nt_lo;
 }
 int nfi = !(hy_finite(nt_hi) && hy_finite(nt_lo)) ? 1 : 0;
 )HIP";
-    for (std::uint32_t c = 0; c < n_hslots; ++c) {
+    for (const auto &u3 : upd) {
         // (The dummy column holds finite copies.)
-        src << "nfi |= !hy_finite(xn" << c << ") ? 1 : 0;\n";
+        src << "nfi |= !hy_finite(" << std::get<0>(u3) << ") ? 1 : 0;\n";
     }
     // Any lane of the system: one ballot, then the bits of the system's lanes.
     src << "{\nconst u64 nfb = __builtin_amdgcn_ballot_w64(nfi != 0);\n";
@@ -1404,8 +1748,15 @@ int nfi = !(hy_finite(nt_hi) && hy_finite(nt_lo)) ? 1 : 0;
     for (const auto &rg : rounds) {
         for (const auto &gr : rg) {
             for (const auto &ow : gr.owners) {
-                src << "{\nconst double *c = jr" << ow.col << ";\ndouble *tcp = a.tc + ((u64)" << utname(ow.var_tbl)
-                    << " * " << (order + 1u) << "u) * N + s;\n"
+                if (ow.derived) {
+                    src << "{\nconst double *c = jr" << ow.parent << ";\ndouble *tcp = a.tc + ((u64)hy_utbl[" << ow.var_tbl * L
+                        << "u + l] * " << (order + 1u) << "u) * N + s;\n*tcp = " << row0_r(ow) << ";\ntcp += N;\n"
+                        << "#pragma nounroll\nfor (unsigned k = 1; k <= " << order << "u; ++k) {\n*tcp = c[(u64)(k - 1u) * "
+                        << kstride << "u] * hy_rk[k];\ntcp += N;\n}\n}\n";
+                    continue;
+                }
+                src << "{\nconst double *c = jr" << ow.col << ";\ndouble *tcp = a.tc + ((u64)hy_utbl[" << ow.var_tbl * L
+                    << "u + l] * " << (order + 1u) << "u) * N + s;\n"
                     << "#pragma nounroll\nfor (unsigned k = 0; k <= " << order << "u; ++k) {\n*tcp = c[(u64)k * "
                     << kstride << "u];\ntcp += N;\n}\n}\n";
             }
@@ -1414,9 +1765,9 @@ int nfi = !(hy_finite(nt_hi) && hy_finite(nt_lo)) ? 1 : 0;
     src << "}\n";
     // The new state becomes the order-0 row of the jets (read back by the owner lanes at the top of the next step).
     src << "HY_WSYNC();\n" << jet_fence;
-    for (std::uint32_t c = 0; c < n_hslots; ++c) {
+    for (const auto &u3 : upd) {
         // (A zero-length step leaves the state untouched bit by bit: x + 0 * ... = x also in the compensated sum.)
-        src << "hc" << c << "[0] = (fin | nostate) ? hc" << c << "[0] : xn" << c << ";\n";
+        src << std::get<2>(u3) << " = (fin | nostate) ? " << std::get<1>(u3) << " : " << std::get<0>(u3) << ";\n";
     }
     src << "HY_WSYNC();\n" << jet_fence;
     src << R"HIP(
@@ -1477,8 +1828,8 @@ if (nf_seen != 0 && l == 0u && live) atomicAdd(a.counters, 1u);
     for (const auto &rg : rounds) {
         for (const auto &gr : rg) {
             for (const auto &ow : gr.owners) {
-                src << "if (ovalid" << ow.col << " && live) a.state[(u64)" << utname(ow.var_tbl) << " * N + s] = "
-                    << jet_at(0, ow.col) << ";\n";
+                src << "if (ovalid" << ow.col << " && live) a.state[(u64)hy_utbl[" << ow.var_tbl * L << "u + l] * N + s] = "
+                    << row0_w(ow) << ";\n";
             }
         }
     }
@@ -1512,7 +1863,7 @@ if (l == 0u && live) {
     ret.n_statements = e.n_stmt;
     ret.scratch_per_wave = jet_lds ? 0u : jet_doubles_per_wave;
     ret.persistent = true;
-    if (pair_split) {
+    if (pairk) {
         // NOTE: MachineLICM hoists the materialisation of ~50 fp64 literals (1 / k, the polynomial constants of the
         // step-size selector) out of the step loop into SGPR pairs: pointers and masks are then spilled to VGPR lanes and
         // come back through 186 v_readlane_b32 per step (VALU issue slots). Without it: 20, and 7 % fewer VALU
@@ -1521,7 +1872,8 @@ if (l == 0u && live) {
     }
     ret.tc_optional = true;
     ret.cluster_mode4 = m4;
-    ret.notes = std::string(pair_split ? "cluster mode v3 (lane pairs, 2 wavefronts per SIMD): " : "cluster mode v2 (pipelined): ")
+    ret.notes = std::string(one_lane ? "cluster mode v5 (one lane per pair, 2 wavefronts per SIMD): "
+                                     : (pair_split ? "cluster mode v3 (lane pairs, 2 wavefronts per SIMD): " : "cluster mode v2 (pipelined): "))
                 + std::to_string(nc) + " clusters of " + std::to_string(t0.size())
                 + " nodes, L=" + std::to_string(L) + ", " + std::to_string(pl.n_slots) + " LDS slots x2, "
                 + std::to_string(n_own) + " state-variable owner slots, " + std::to_string(utbl.size())

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import heyoka_amd as hy
-from heyoka_amd import _lib
+from heyoka_amd import _lib, configs
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -176,3 +176,16 @@ def test_event_integrators_pick_the_cluster_stepper_when_the_event_equations_are
     monkeypatch.setenv("HEYOKA_AMD_EVENTS_ON_CLUSTER", "0")
     td = hy.taylor_adaptive_batch(sys_, None, 8, high_accuracy=True, nt_events=[hy.nt_event(y1, cb)])
     assert not td.hip_source_mode.startswith("cluster")
+
+
+def test_time_dependent_event_on_the_cluster_event_stepper_builds():
+    """(CPU: hiprtc cross-compiles.) An event equation which depends on the time coordinate next to a system which runs
+    on the wave-cluster stepper: hy_ev_jets evaluates func_kind::time and needs the time of the lane (round-2 advisor
+    finding: the constructor threw 'use of undeclared identifier t_hi')."""
+    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    x1 = hy.make_vars("x_1")
+    x1 = x1[0] if isinstance(x1, (list, tuple)) else x1
+    for ev in (hy.time - 0.5, x1 - hy.cos(hy.time)):
+        ta = hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), None, 8, high_accuracy=True,
+                                      nt_events=[hy.nt_event(ev, lambda *a: None)])
+        assert ta.hip_source_mode.startswith("cluster") and "events:" in ta.hip_source_mode, ta.hip_source_mode

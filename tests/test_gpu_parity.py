@@ -362,6 +362,42 @@ def test_cluster_mode_nbody8_default_masses():
     _nbody_parity(8, 96, 3, "cluster", t_final=0.05)
 
 
+@pytest.mark.parametrize("n_bodies", [7, 8])
+def test_lane_pair_kernel_one_system_per_wavefront(n_bodies):
+    """17 .. 32 pair clusters (model::nbody(7), nbody(8) with numerical masses): the lane-pair kernel with ONE system per
+    wavefront (64 lanes per system). In round 2 this variant did not terminate on the hardware and was gated off; with
+    the zero-length steps of a finished system forced to h = 0 exactly it runs: steps, a step-limited and a complete
+    propagation against the oracle."""
+    n = 24
+    rng = np.random.RandomState(3)
+    masses = [1.0] + [1e-3 * (i + 1) for i in range(n_bodies - 1)]
+    st = np.zeros((6 * n_bodies, n))
+    for b in range(1, n_bodies):
+        r = 1.0 + 0.7 * b
+        ph = rng.uniform(0, 2 * np.pi, n)
+        v = 1.0 / np.sqrt(r)
+        st[6 * b + 0], st[6 * b + 1], st[6 * b + 2] = r * np.cos(ph), r * np.sin(ph), 0.01 * rng.randn(n)
+        st[6 * b + 3], st[6 * b + 4], st[6 * b + 5] = -v * np.sin(ph), v * np.cos(ph), 0.01 * rng.randn(n)
+    ta = hy.taylor_adaptive_batch(hy.model.nbody(n_bodies, masses=masses), st, n, high_accuracy=True)
+    assert "lanes per system: 64" in ta.hip_source_mode and "v3" in ta.hip_source_mode, ta.hip_source_mode
+    ora = ho.OracleIntegrator(ho.nbody(n_bodies, masses=masses), st.reshape(-1), n, high_accuracy=True)
+    for _ in range(3):
+        ta.step()
+        ora.step()
+        h_g = np.array([h for _, h in ta.step_res])
+        h_o = np.array([h for _, h in ora.step_res])
+        assert np.max(np.abs(h_g - h_o) / h_o) <= 1e6 * EPS
+        assert rel_err(ta.state, ora.state.reshape(6 * n_bodies, n)) <= 1e5 * EPS
+    ta.propagate_until(40.0, max_steps=4)
+    ora.propagate_until(40.0, max_steps=4)
+    assert [(int(r[0]), r[3]) for r in ta.propagate_res] == [(r[0], r[3]) for r in ora.prop_res]
+    ta.propagate_until(8.0)
+    ora.propagate_until(8.0)
+    assert all(r[0] == OC.time_limit for r in ta.propagate_res)
+    assert max(abs(a[3] - b[3]) for a, b in zip(ta.propagate_res, ora.prop_res)) <= 1
+    assert rel_err(ta.state, ora.state.reshape(6 * n_bodies, n)) <= 1e6 * EPS
+
+
 @pytest.mark.parametrize("variant", ["wave-level", "tape in HBM"])
 def test_table_mode_small_dag_forced(variant, monkeypatch):
     """Table (compact-mode analogue) kernels on a DAG that would normally be unrolled, in both variants: one system per
@@ -1346,19 +1382,6 @@ def _outer_ss_event_setup(m, log, te_log):
     d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2) - 81.0
     te = [m.t_event(d2, lambda ta, d, i: te_log.append((i, d)) or True, direction=neg)]
     return nt, te
-
-
-def test_time_dependent_event_on_the_cluster_event_stepper_builds():
-    """(CPU: hiprtc cross-compiles.) An event equation which depends on the time coordinate next to a system which runs
-    on the wave-cluster stepper: hy_ev_jets evaluates func_kind::time and needs the time of the lane (round-2 advisor
-    finding: the constructor threw 'use of undeclared identifier t_hi')."""
-    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
-    x1 = hy.make_vars("x_1")
-    x1 = x1[0] if isinstance(x1, (list, tuple)) else x1
-    for ev in (hy.time - 0.5, x1 - hy.cos(hy.time)):
-        ta = hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), None, 8, high_accuracy=True,
-                                      nt_events=[hy.nt_event(ev, lambda *a: None)])
-        assert ta.hip_source_mode.startswith("cluster") and "events:" in ta.hip_source_mode, ta.hip_source_mode
 
 
 @pytest.mark.gpu
