@@ -155,6 +155,207 @@ def pmc_traffic(sha, n_systems):
     return None, None
 
 
+def run_workload(ctx, workload, n, steps, warmup):
+    """One timed leg: `warmup` untimed + `steps` timed propagate_until() calls over n systems per GPU. Returns the bench
+    line of the leg on rank 0 (None elsewhere)."""
+    torch, hy, configs, hens, dist = ctx["torch"], ctx["hy"], ctx["configs"], ctx["hens"], ctx["dist"]
+    rank, world, distributed, dev, dev_index = ctx["rank"], ctx["world"], ctx["distributed"], ctx["dev"], ctx["dev_index"]
+    out = None
+    t_build = time.perf_counter()
+    # One process per GPU: the integrator lives on this rank's device ordinal.
+    ta, st, dt = make_integrator(hy, configs, workload, n, seed=42 + rank, device=dev_index)
+    build_s = time.perf_counter() - t_build
+
+    # Inputs resident in HBM before the timed region; kernels on torch's current stream so that
+    # torch.cuda.Event (HIP events) brackets them.
+    ta.set_stream(torch.cuda.current_stream().cuda_stream)
+    view = torch.as_tensor(ta.device_array("state"), device=dev)
+    view.copy_(torch.from_numpy(st))
+    torch.cuda.synchronize()
+    ta.mark_device_modified()
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # Step counters live on the device: accumulate them with a device-side reduction per call (same
+    # stream, no host synchronisation inside the timed region).
+    nsteps_view = torch.as_tensor(ta.device_array("n_steps"), device=dev)
+    steps_acc = torch.zeros(max(steps, warmup, 1), dtype=torch.int64, device=dev)
+    t_cur = 0.0
+    for k in range(warmup):
+        # NOTE: the warmup runs the complete step, reduction included (the first use of a torch kernel
+        # costs ~20 ms of lazy code loading).
+        t_cur += dt
+        ta.propagate_until(t_cur)
+        steps_acc[k] = nsteps_view.sum()
+    barrier()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    steps_acc.zero_()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        t_cur += dt
+        ev[k][0].record()
+        ta.propagate_until(t_cur)
+        ev[k][1].record()
+        steps_acc[k] = nsteps_view.sum()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # Shader clock right after the timed region (the FP64-dense steppers are power limited: 2.0 - 2.4 GHz depending on the
+    # kernel and the box; the sustained value during a launch is in profiles/*_sq_counters.json, GRBM_GUI_ACTIVE).
+    try:
+        sclk_mhz = int(torch.cuda.clock_rate(dev))
+    except Exception:
+        sclk_mhz = None
+    # The path partitions with no exchange step (independent systems, the reference's ensemble is a
+    # parallel_for over copies, src/ensemble_propagate.cpp:203-219): the optional gather of the final states
+    # (heyoka_amd/ensemble.py, RCCL all-gather over xGMI) is exercised here, outside of the timed region.
+    gathered = None
+    gather_ms = None
+    gather_err = None
+    if distributed:
+        try:
+            tg = time.perf_counter()
+            gathered = hens.all_gather_states(view)
+            torch.cuda.synchronize()
+            gather_ms = (time.perf_counter() - tg) * 1e3
+            # Every rank must hold the final state of all the N x systems ICs, its own shard in place.
+            if tuple(gathered.shape) != (view.shape[0], world * n):
+                raise RuntimeError("gathered shape %s, expected %s" % (tuple(gathered.shape), (view.shape[0], world * n)))
+            if not torch.equal(gathered[:, rank * n:(rank + 1) * n], view):
+                raise RuntimeError("the gathered state does not contain this rank's shard at its place")
+        except Exception as e:  # the optional collective must never cost the measurement
+            gather_err = "%s: %s" % (type(e).__name__, e)
+
+    # Per-launch kernel durations (HIP events on the launch stream) and step counts.
+    call_ms = [a.elapsed_time(b) for a, b in ev]  # torch events around the whole call (incl. small copies)
+    kern_ms = list(ta.kernel_ms_history(steps))  # HIP events recorded right around each launch
+    steps_per_call_all = steps_acc[: steps].cpu().numpy().astype(np.float64)
+    steps_per_call = float(steps_per_call_all.mean())
+
+    oc, mn, mx, ns = ta.propagate_res_arrays()
+    ok = bool(np.all(oc == int(hy.taylor_outcome.time_limit)))
+
+    local_steps = float(steps_per_call_all.sum())
+    local = torch.tensor([elapsed, local_steps, float(np.mean(kern_ms))], dtype=torch.float64, device=dev)
+    if distributed:
+        mx_t = local.clone()
+        dist.all_reduce(mx_t, op=dist.ReduceOp.MAX)
+        sm_t = local.clone()
+        dist.all_reduce(sm_t, op=dist.ReduceOp.SUM)
+        elapsed_max = float(mx_t[0])
+        total_steps = float(sm_t[1])
+    else:
+        elapsed_max = elapsed
+        total_steps = local_steps
+
+    if rank == 0:
+        from heyoka_amd import codegen_check, roofline
+
+        n_eq, n_u = ta.dim, ta.n_uvars
+        f_alg, b_tape = roofline.counts_for(ta)
+        f_survey = WORKLOADS[workload]
+        value = total_steps / elapsed_max
+        k_ms = float(np.mean(kern_ms))
+        per_launch_steps = float(steps_per_call)
+        achieved_gbs = b_tape * per_launch_steps / (k_ms * 1e-3) / 1e9
+        achieved_tflops = f_alg * per_launch_steps / (k_ms * 1e-3) / 1e12
+        traffic_per_step, traffic_src = pmc_traffic(kernel_sha(ta), n)
+        traffic = traffic_per_step * per_launch_steps if traffic_per_step else None
+        # Which ceiling binds. The tape model B_tape (SURVEY 8d) describes a stepper that streams its jets through HBM
+        # (block / table modes). The cluster and register-resident steppers keep the jets on chip: their measured HBM
+        # traffic is a fraction of a percent of the peak and the binding ceiling is the FP64 arithmetic rate (78.6
+        # TFLOP/s vector = matrix peak for f64 on MI355X; the recurrences have no dense contraction, MFMA itself is
+        # unused) - reported under the contract's "mfma" label with the algorithmic flop count F_alg.
+        # Without a counter file for this exact kernel: the cluster / register-resident steppers keep their jets on chip
+        # (FP64-bound), the block / table steppers stream them through HBM (tape model).
+        mode_str = ta.hip_source_mode
+        on_chip = mode_str.startswith("cluster") or "jets in registers" in mode_str or mode_str.startswith("unrolled")
+        on_chip = on_chip and "global scratch" not in mode_str
+        hbm_util = (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else (0.0 if on_chip else min(1.0, achieved_gbs / HBM_PEAK_GBS))
+        compute_bound = achieved_tflops / FP64_PEAK_TFLOPS > hbm_util
+        # (How the binding ceiling was decided: from counter traffic of this very kernel, or - without a matching summary
+        # under profiles/ - from where the generator keeps the jets.)
+        bound_basis = ("measured: HBM traffic of this kernel from %s" % traffic_src) if traffic else (
+            "by construction: the jets of this stepper live in %s (no counter summary for this kernel under profiles/)"
+            % ("LDS / registers, HBM only sees the state" if on_chip else "an HBM tape (B_tape model)"))
+        if compute_bound:
+            # NOTE: "fp64_valu" = the FP64 *vector* rate (16 lanes x FMA per clock and SIMD = 78.6 TFLOP/s at 2.4 GHz;
+            # equal to the f64 matrix peak of gfx950, which is why the contract files it under the "mfma" ceiling -
+            # MFMA itself is unused: the recurrences are elementwise).
+            roof = {"bound": "fp64_valu", "bound_contract_class": "mfma", "achieved": achieved_tflops,
+                    "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / FP64_PEAK_TFLOPS}
+        else:
+            roof = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved_gbs / HBM_PEAK_GBS}
+        out = {
+            "metric": "ODE systems x steps/sec (fp64)",
+            "value": value,
+            "unit": "system-steps/s",
+            "n_gpus": world,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": elapsed_max / steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "%s: %d perturbed ICs per GPU (perturb 1e-12, mt19937 seed 42+rank), tol=eps (order 20), "
+                "high_accuracy=%s, propagate_until in increments of %g time units"
+                % (workload, n, str(bool(ta.high_accuracy)).lower(), dt),
+                "systems_per_gpu": n,
+                "taylor_order": ta.order,
+                "n_eq": n_eq,
+                "n_uvars": n_u,
+                "system_steps_per_launch": per_launch_steps,
+                "all_outcomes_time_limit": ok,
+                "integrator_build_s": build_s,
+                "hiprtc_compile_s": ta.compile_seconds,
+                "kernel_sha256": kernel_sha(ta),
+                "untimed_final_state_all_gather_ms": gather_ms,
+                "gathered_systems": (int(gathered.shape[1]) if gathered is not None else None),
+                "gathered_bytes_per_rank": (int(gathered.numel()) * 8 if gathered is not None else None),
+                "untimed_final_state_all_gather_error": gather_err,
+            },
+            "roofline": {
+                **roof,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
+                "bound_basis": bound_basis,
+                "sclk_mhz_after_timed_region": sclk_mhz,
+                "kernel": "hy_taylor",
+                "kernel_ms_avg": k_ms,
+                "call_ms_avg": float(np.mean(call_ms)),
+                "algorithmic_flop_per_system_step": f_alg,
+                "algorithmic_bytes_per_system_step": b_tape,
+                # Launch by launch: adaptive step counts make the launches differ (and, for one system per workgroup,
+                # the launch cannot end before its slowest system: see steps_per_system_last_launch).
+                "per_launch": [{"kernel_ms": float(k), "system_steps": float(s_)} for k, s_ in zip(kern_ms, steps_per_call_all)],
+                "steps_per_system_last_launch": {"mean": float(ns.mean()), "max": int(ns.max()), "min": int(ns.min()),
+                                                 "p99": float(np.percentile(ns, 99))},
+                "algorithmic_counts_source": "heyoka_amd/roofline.py on the decomposition of this integrator "
+                "(%d u variables, order %d)" % (n_u, ta.order),
+                # Round-1 basis (SURVEY 8d estimate of F_alg), for continuity only.
+                "fp64_valu_frac_survey_falg": f_survey * per_launch_steps / (k_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                "kernel_resources": codegen_check.kernel_resources(ta.code_object),
+                "kernel_mode": ta.hip_source_mode,
+                # Both views, whichever binds.
+                "fp64_valu_frac": achieved_tflops / FP64_PEAK_TFLOPS,
+                "hbm_tape_model_frac": achieved_gbs / HBM_PEAK_GBS,
+                "hbm_measured_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            },
+        }
+        out["_dt"] = dt
+
+    del ta, view, nsteps_view
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,6 +364,8 @@ def main():
     ap.add_argument("--systems", type=int, default=0, help="systems per GPU (default: the BASELINE.json size)")
     ap.add_argument("--workload", default="outer_ss", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-workloads", action="store_true",
+                    help="skip the short two-body / N = 64 legs which follow the outer-Solar-System measurement at N = 1")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI)")
     ap.add_argument("--single-device", action="store_true",
@@ -191,183 +394,27 @@ def main():
     from heyoka_amd import configs
     from heyoka_amd import ensemble as hens
 
+    ctx = dict(torch=torch, hy=hy, configs=configs, hens=hens, dist=(dist if distributed else None), rank=rank, world=world,
+               distributed=distributed, dev=dev, dev_index=dev_index)
     n = args.systems if args.systems > 0 else DEFAULT_SYSTEMS[args.workload]
-    t_build = time.perf_counter()
-    # One process per GPU: the integrator lives on this rank's device ordinal.
-    ta, st, dt = make_integrator(hy, configs, args.workload, n, seed=42 + rank, device=dev_index)
-    build_s = time.perf_counter() - t_build
-
-    # Inputs resident in HBM before the timed region; kernels on torch's current stream so that
-    # torch.cuda.Event (HIP events) brackets them.
-    ta.set_stream(torch.cuda.current_stream().cuda_stream)
-    view = torch.as_tensor(ta.device_array("state"), device=dev)
-    view.copy_(torch.from_numpy(st))
-    torch.cuda.synchronize()
-    ta.mark_device_modified()
-
-    def barrier():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # Step counters live on the device: accumulate them with a device-side reduction per call (same
-    # stream, no host synchronisation inside the timed region).
-    nsteps_view = torch.as_tensor(ta.device_array("n_steps"), device=dev)
-    steps_acc = torch.zeros(max(args.steps, args.warmup, 1), dtype=torch.int64, device=dev)
-    t_cur = 0.0
-    for k in range(args.warmup):
-        # NOTE: the warmup runs the complete step, reduction included (the first use of a torch kernel
-        # costs ~20 ms of lazy code loading).
-        t_cur += dt
-        ta.propagate_until(t_cur)
-        steps_acc[k] = nsteps_view.sum()
-    barrier()
-
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    steps_acc.zero_()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        t_cur += dt
-        ev[k][0].record()
-        ta.propagate_until(t_cur)
-        ev[k][1].record()
-        steps_acc[k] = nsteps_view.sum()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    # The path partitions with no exchange step (independent systems, the reference's ensemble is a
-    # parallel_for over copies, src/ensemble_propagate.cpp:203-219): the optional gather of the final states
-    # (heyoka_amd/ensemble.py, RCCL all-gather over xGMI) is exercised here, outside of the timed region.
-    gathered = None
-    gather_ms = None
-    gather_err = None
-    if distributed:
-        try:
-            tg = time.perf_counter()
-            gathered = hens.all_gather_states(view)
-            torch.cuda.synchronize()
-            gather_ms = (time.perf_counter() - tg) * 1e3
-            # Every rank must hold the final state of all the N x systems ICs, its own shard in place.
-            if tuple(gathered.shape) != (view.shape[0], world * n):
-                raise RuntimeError("gathered shape %s, expected %s" % (tuple(gathered.shape), (view.shape[0], world * n)))
-            if not torch.equal(gathered[:, rank * n:(rank + 1) * n], view):
-                raise RuntimeError("the gathered state does not contain this rank's shard at its place")
-        except Exception as e:  # the optional collective must never cost the measurement
-            gather_err = "%s: %s" % (type(e).__name__, e)
-
-    # Per-launch kernel durations (HIP events on the launch stream) and step counts.
-    call_ms = [a.elapsed_time(b) for a, b in ev]  # torch events around the whole call (incl. small copies)
-    kern_ms = list(ta.kernel_ms_history(args.steps))  # HIP events recorded right around each launch
-    steps_per_call_all = steps_acc[: args.steps].cpu().numpy().astype(np.float64)
-    steps_per_call = float(steps_per_call_all.mean())
-
-    oc, mn, mx, ns = ta.propagate_res_arrays()
-    ok = bool(np.all(oc == int(hy.taylor_outcome.time_limit)))
-
-    local_steps = float(steps_per_call_all.sum())
-    local = torch.tensor([elapsed, local_steps, float(np.mean(kern_ms))], dtype=torch.float64, device=dev)
-    if distributed:
-        mx_t = local.clone()
-        dist.all_reduce(mx_t, op=dist.ReduceOp.MAX)
-        sm_t = local.clone()
-        dist.all_reduce(sm_t, op=dist.ReduceOp.SUM)
-        elapsed_max = float(mx_t[0])
-        total_steps = float(sm_t[1])
-    else:
-        elapsed_max = elapsed
-        total_steps = local_steps
-
+    out = run_workload(ctx, args.workload, n, args.steps, args.warmup)
     if rank == 0:
-        from heyoka_amd import codegen_check, roofline
-
-        n_eq, n_u = ta.dim, ta.n_uvars
-        f_alg, b_tape = roofline.counts_for(ta)
-        f_survey = WORKLOADS[args.workload]
-        value = total_steps / elapsed_max
-        k_ms = float(np.mean(kern_ms))
-        per_launch_steps = float(steps_per_call)
-        achieved_gbs = b_tape * per_launch_steps / (k_ms * 1e-3) / 1e9
-        achieved_tflops = f_alg * per_launch_steps / (k_ms * 1e-3) / 1e12
-        traffic_per_step, traffic_src = pmc_traffic(kernel_sha(ta), n)
-        traffic = traffic_per_step * per_launch_steps if traffic_per_step else None
-        # Which ceiling binds. The tape model B_tape describes a stepper that streams its jets through HBM
-        # (block / table modes). The cluster and register-resident steppers keep the jets on chip: their measured HBM
-        # traffic is a fraction of a percent of the peak and the binding ceiling is the FP64 arithmetic rate (78.6
-        # TFLOP/s vector = matrix peak for f64 on MI355X; the recurrences have no dense contraction, MFMA itself is
-        # unused) - reported under the contract's "mfma" label with the algorithmic flop count F_alg.
-        # Without a counter file for this exact kernel: the cluster / register-resident steppers keep their jets on chip
-        # (FP64-bound), the block / table steppers stream them through HBM (tape model).
-        mode_str = ta.hip_source_mode
-        on_chip = mode_str.startswith("cluster") or "jets in registers" in mode_str or mode_str.startswith("unrolled")
-        hbm_util = (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else (0.0 if on_chip else min(1.0, achieved_gbs / HBM_PEAK_GBS))
-        compute_bound = achieved_tflops / FP64_PEAK_TFLOPS > hbm_util
-        if compute_bound:
-            # NOTE: "fp64_valu" = the FP64 *vector* rate (16 lanes x FMA per clock and SIMD = 78.6 TFLOP/s at 2.4 GHz;
-            # equal to the f64 matrix peak of gfx950, which is why the contract files it under the "mfma" ceiling -
-            # MFMA itself is unused: the recurrences are elementwise).
-            roof = {"bound": "fp64_valu", "bound_contract_class": "mfma", "achieved": achieved_tflops,
-                    "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / FP64_PEAK_TFLOPS}
-        else:
-            roof = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved_gbs / HBM_PEAK_GBS}
-        out = {
-            "metric": "ODE systems x steps/sec (fp64)",
-            "value": value,
-            "unit": "system-steps/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed_max / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {
-                "workload": "%s: %d perturbed ICs per GPU (perturb 1e-12, mt19937 seed 42+rank), tol=eps (order 20), "
-                "high_accuracy=%s, propagate_until in increments of %g time units"
-                % (args.workload, n, str(bool(ta.high_accuracy)).lower(), dt),
-                "systems_per_gpu": n,
-                "taylor_order": ta.order,
-                "n_eq": n_eq,
-                "n_uvars": n_u,
-                "system_steps_per_launch": per_launch_steps,
-                "all_outcomes_time_limit": ok,
-                "integrator_build_s": build_s,
-                "hiprtc_compile_s": ta.compile_seconds,
-                "kernel_sha256": kernel_sha(ta),
-                "untimed_final_state_all_gather_ms": gather_ms,
-                "gathered_systems": (int(gathered.shape[1]) if gathered is not None else None),
-                "gathered_bytes_per_rank": (int(gathered.numel()) * 8 if gathered is not None else None),
-                "untimed_final_state_all_gather_error": gather_err,
-            },
-            "roofline": {
-                **roof,
-                "traffic": traffic,
-                "traffic_source": traffic_src,
-                "kernel": "hy_taylor",
-                "kernel_ms_avg": k_ms,
-                "call_ms_avg": float(np.mean(call_ms)),
-                "algorithmic_flop_per_system_step": f_alg,
-                "algorithmic_bytes_per_system_step": b_tape,
-                # Launch by launch: adaptive step counts make the launches differ (and, for one system per workgroup,
-                # the launch cannot end before its slowest system: see steps_per_system_last_launch).
-                "per_launch": [{"kernel_ms": float(k), "system_steps": float(s_)} for k, s_ in zip(kern_ms, steps_per_call_all)],
-                "steps_per_system_last_launch": {"mean": float(ns.mean()), "max": int(ns.max()), "min": int(ns.min()),
-                                                 "p99": float(np.percentile(ns, 99))},
-                "algorithmic_counts_source": "heyoka_amd/roofline.py on the decomposition of this integrator "
-                "(%d u variables, order %d)" % (n_u, ta.order),
-                # Round-1 basis (SURVEY 8d estimate of F_alg), for continuity only.
-                "fp64_valu_frac_survey_falg": f_survey * per_launch_steps / (k_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-                "kernel_resources": codegen_check.kernel_resources(ta.code_object),
-                "kernel_mode": ta.hip_source_mode,
-                # Both views, whichever binds.
-                "fp64_valu_frac": achieved_tflops / FP64_PEAK_TFLOPS,
-                "hbm_tape_model_frac": achieved_gbs / HBM_PEAK_GBS,
-                "hbm_measured_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-            },
-        }
+        if world == 1 and not args.no_extra_workloads and args.workload == "outer_ss":
+            # The other two single-GPU measurement points of BASELINE.json (configs 3 and 5) as short legs of the same run,
+            # each with its own roofline: the two-body problem (small DAG, jets in registers: FP64-bound) and
+            # model::nbody(64) (block mode, jets on a tape: HBM-bound, counter traffic when a matching summary is
+            # committed).
+            extra = []
+            for wl, st_, wu_ in (("two_body", 4, 2), ("nbody64", 2, 1)):
+                try:
+                    r = run_workload(ctx, wl, DEFAULT_SYSTEMS[wl], st_, wu_)
+                    extra.append({k: r[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline")})
+                except Exception as e:  # an auxiliary leg must never cost the headline line
+                    extra.append({"config": {"workload": wl}, "error": "%s: %s" % (type(e).__name__, e)})
+            out["extra_workloads"] = extra
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, dt, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(args.workload, out.pop("_dt"), args.cpu_seconds)
+        out.pop("_dt", None)
         print(json.dumps(out))
 
     if distributed:

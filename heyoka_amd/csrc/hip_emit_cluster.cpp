@@ -1533,21 +1533,12 @@ if (l == 0u && live) {
 //V2_PLACEHOLDER
 
 emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts, std::string &why_not);
-emitted_module emit_cluster_v4(const taylor_program &p, const emit_options &opts, std::string &why_not);
 
 // Returns a module with an empty source (and the reason in why_not) if cluster mode is not applicable.
 emitted_module emit_cluster_or_empty(const taylor_program &p, const emit_options &opts, std::string &why_not)
 {
     if (std::getenv("HEYOKA_AMD_CLUSTER_V1") == nullptr) {
         std::string why2;
-        // The wave-role kernel (v4, hip_emit_cluster4.cpp) for point-mass pair systems; HEYOKA_AMD_WAVE_ROLES=0/1.
-        if (const char *ev = std::getenv("HEYOKA_AMD_WAVE_ROLES"); ev != nullptr && std::atoi(ev) != 0) {
-            std::string why4;
-            auto m4 = emit_cluster_v4(p, opts, why4);
-            if (!m4.source.empty()) {
-                return m4;
-            }
-        }
         auto m = emit_cluster_v2(p, opts, why2);
         if (!m.source.empty()) {
             return m;

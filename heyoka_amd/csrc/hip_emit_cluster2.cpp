@@ -24,7 +24,11 @@
 namespace heyoka_amd
 {
 
-emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts, std::string &why_not)
+namespace
+{
+
+emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options &opts, std::string &why_not, bool allow_one_lane,
+                                    bool &one_lane_jets_in_lds)
 {
     using cluster_detail::cluster_plan;
     using cluster_detail::is_var;
@@ -83,7 +87,7 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     // evaluation as x^[k] = v^[k-1] * RN(1 / k) - the very operation which produced them.
     const bool one_lane = [&]() {
         const char *ev = std::getenv("HEYOKA_AMD_ONE_LANE");
-        if (ev == nullptr || std::atoi(ev) == 0) {
+        if (!allow_one_lane || (ev != nullptr && std::atoi(ev) == 0)) {
             return false;
         }
         return pp_shape_ok && p.n_par == 0u && !m4 && nc <= 64u && std::getenv("HEYOKA_AMD_V3_EXACT_DIV") == nullptr
@@ -134,8 +138,9 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         // Outputs in lane order, one run of consecutive slots per product.
         std::uint32_t ns = n_eq;
         std::fill(pl.slot_of.begin() + n_eq, pl.slot_of.end(), -1);
-        // ([pair][product]: the three output slots of a lane are consecutive, one address register per lane; the lanes of
-        // a group write with a stride of 3 doubles - distinct banks.)
+        // (Numbered again after the compaction below: [lane][product] with a stride of 3 doubles between the lanes of a
+        // group - the 16 lanes which a ds_write_b64 services together hit 16 different bank pairs -, the reactions in a
+        // second region of the same shape.)
         for (std::uint32_t c = 0; c < nc; ++c) {
             for (std::uint32_t i = 0; i < 3u; ++i) {
                 pl.slot_of[pl.clusters[c][pp.pr[i]]] = static_cast<int>(ns++);
@@ -263,7 +268,9 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     bool fuse_rx = false;
     if (pairk && pp.rx[0] >= 0) {
         const char *ev = std::getenv("HEYOKA_AMD_V3_FUSE_RX");
-        fuse_rx = !(ev != nullptr && std::atoi(ev) == 0);
+        // (One-lane pair kernel: the reactions are computed and exported by the pair lane - the slab of a system is
+        // single-buffered there and has room for them - so that the sums need no per-lane coefficients: 20 registers.)
+        fuse_rx = !(ev != nullptr && std::atoi(ev) == 0) && !one_lane;
         for (std::size_t c = 0; c < nc; ++c) {
             for (std::uint32_t i = 0; i < 3u; ++i) {
                 const auto u = pl.clusters[c][static_cast<std::uint32_t>(pp.rx[i])];
@@ -306,6 +313,9 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
             }
         }
     }
+    std::vector<std::uint32_t> lane_pr, lane_rx; // one-lane pair kernel: output slot triples of the lanes
+    std::uint32_t slab_stride_opt = 0;
+    std::uint64_t bank_cost = 0;
     if (one_lane) {
         // 32 systems per CU: the slab only keeps the slots which are read through it (positions, products, glue nodes
         // with readers): 63 instead of 144 for the outer Solar System.
@@ -347,17 +357,162 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         }
         for (const auto &[old_slot, u] : order_v) {
             (void)old_slot;
-            pl.slot_of[u] = static_cast<int>(ns++);
+            if (pl.cluster_of[u] == -1) {
+                pl.slot_of[u] = static_cast<int>(ns++);
+            }
         }
+        // Cluster outputs: every lane (the idle ones too) owns 3 + 3 slots, read or not: lane l keeps its products in the
+        // slots out_base + 3 * lane_pr[l] + i and its reactions in rx_base + 3 * lane_rx[l] + i, where lane_pr / lane_rx are
+        // permutations of the lanes. The kernel is within 25 % of the LDS throughput, so the permutations and the
+        // distance between the slabs of two systems are chosen to minimise the bank conflicts of the exchange (a small
+        // deterministic local search over the access patterns of a step; the model is the one of the microarchitecture
+        // guide: a ds_read_b64 services the lanes 0-31 / 32-63 together, bank pair = double index mod 32, every further
+        // distinct address on a bank pair costs a cycle; a ds_write_b64 services 16 consecutive lanes, double index mod 16).
+        const auto out_base = ns;
+        const auto rx_base = out_base + 3u * pl.L;
+        lane_pr.resize(pl.L);
+        lane_rx.resize(pl.L);
+        for (std::uint32_t l = 0; l < pl.L; ++l) {
+            lane_pr[l] = lane_rx[l] = l;
+        }
+        ns = out_base + 3u * pl.L * (pp.rx[0] >= 0 ? 2u : 1u);
+        const auto assign = [&]() {
+            for (std::uint32_t c = 0; c < nc; ++c) {
+                for (std::uint32_t i = 0; i < 3u; ++i) {
+                    pl.slot_of[pl.clusters[c][pp.pr[i]]] = static_cast<int>(out_base + 3u * lane_pr[c] + i);
+                    if (pp.rx[0] >= 0) {
+                        pl.slot_of[pl.clusters[c][static_cast<std::uint32_t>(pp.rx[i])]] = static_cast<int>(rx_base + 3u * lane_rx[c] + i);
+                    }
+                }
+            }
+        };
+        // Read patterns of a step: per LDS read instruction, the u variable every lane of a group reads.
+        std::vector<std::vector<std::uint32_t>> rd_pat;
+        for (std::uint32_t i = 0; i < 3u; ++i) {
+            for (std::uint32_t sd = 0; sd < 2u; ++sd) {
+                std::vector<std::uint32_t> v(pl.L);
+                for (std::uint32_t l = 0; l < pl.L; ++l) {
+                    v[l] = pl.ext_u[l < nc ? l : 0u][pp.de[i][sd]];
+                }
+                rd_pat.push_back(std::move(v));
+            }
+        }
+        for (const auto &grp : pl.groups) {
+            const auto n_nodes = static_cast<std::uint32_t>(grp.nodes.size());
+            const auto &n0 = p.nodes[grp.nodes[0] - n_eq];
+            for (std::uint32_t r = 0; r * pl.L < n_nodes; ++r) {
+                for (std::size_t a = 0; a < n0.args.size(); ++a) {
+                    if (!is_var(n0.args[a])) {
+                        continue;
+                    }
+                    std::vector<std::uint32_t> v(pl.L);
+                    for (std::uint32_t l = 0; l < pl.L; ++l) {
+                        const auto j = r * pl.L + l;
+                        v[l] = p.nodes[grp.nodes[j < n_nodes ? j : r * pl.L] - n_eq].args[a].idx;
+                    }
+                    rd_pat.push_back(std::move(v));
+                }
+            }
+        }
+        const auto cost = [&](std::uint32_t stride) {
+            std::uint64_t tot = 0;
+            const auto spw_ = 64u / pl.L;
+            // Reads: two groups of 32 lanes.
+            for (const auto &v : rd_pat) {
+                for (std::uint32_t g = 0; g < 2u; ++g) {
+                    std::map<std::uint32_t, std::set<std::uint32_t>> banks;
+                    for (std::uint32_t lane = 32u * g; lane < 32u * g + 32u; ++lane) {
+                        const auto q = (lane / pl.L) % spw_, l = lane % pl.L;
+                        const auto a = q * stride + static_cast<std::uint32_t>(std::max(0, pl.slot_of[v[l]]));
+                        banks[a % 32u].insert(a);
+                    }
+                    std::size_t mx = 1;
+                    for (const auto &[b, st_] : banks) {
+                        mx = std::max(mx, st_.size());
+                    }
+                    tot += mx - 1u;
+                }
+            }
+            // Writes of the outputs: four groups of 16 lanes, three coordinates, two kinds.
+            for (std::uint32_t kind = 0; kind < (pp.rx[0] >= 0 ? 2u : 1u); ++kind) {
+                for (std::uint32_t g = 0; g < 4u; ++g) {
+                    std::map<std::uint32_t, std::set<std::uint32_t>> banks;
+                    for (std::uint32_t lane = 16u * g; lane < 16u * g + 16u; ++lane) {
+                        const auto q = (lane / pl.L) % spw_, l = lane % pl.L;
+                        const auto a = q * stride + (kind == 0u ? out_base + 3u * lane_pr[l] : rx_base + 3u * lane_rx[l]);
+                        banks[a % 16u].insert(a);
+                    }
+                    std::size_t mx = 1;
+                    for (const auto &[b, st_] : banks) {
+                        mx = std::max(mx, st_.size());
+                    }
+                    tot += 3u * 2u * (mx - 1u); // (a conflicting store costs two LDS cycles more, three coordinates)
+                }
+            }
+            return tot;
+        };
+        // Total slots incl. the dummy area (as computed below).
+        const auto n_tot_est = ns + std::max<std::uint32_t>(static_cast<std::uint32_t>(pl.out_pos.size()), 6u);
+        assign();
+        slab_stride_opt = n_tot_est;
+        auto best = cost(slab_stride_opt);
+        for (std::uint32_t st_ = n_tot_est; st_ < n_tot_est + 32u; ++st_) {
+            if (const auto c = cost(st_); c < best) {
+                best = c;
+                slab_stride_opt = st_;
+            }
+        }
+        if (std::getenv("HEYOKA_AMD_V5_NO_BANK_SEARCH") == nullptr) {
+            std::uint64_t rng = 0x9E3779B97F4A7C15ull;
+            const auto next = [&]() {
+                rng ^= rng << 13;
+                rng ^= rng >> 7;
+                rng ^= rng << 17;
+                return rng;
+            };
+            for (int it = 0; it < 4000 && best != 0u; ++it) {
+                auto &perm = (pp.rx[0] >= 0 && (next() & 1u) != 0u) ? lane_rx : lane_pr;
+                const auto i1 = static_cast<std::uint32_t>(next() % pl.L), i2 = static_cast<std::uint32_t>(next() % pl.L);
+                if (i1 == i2) {
+                    continue;
+                }
+                std::swap(perm[i1], perm[i2]);
+                assign();
+                auto c = cost(slab_stride_opt);
+                auto cs = slab_stride_opt;
+                if (it % 16 == 0) {
+                    for (std::uint32_t st_ = n_tot_est; st_ < n_tot_est + 32u; ++st_) {
+                        if (const auto c2 = cost(st_); c2 < c) {
+                            c = c2;
+                            cs = st_;
+                        }
+                    }
+                }
+                if (c <= best) {
+                    best = c;
+                    slab_stride_opt = cs;
+                } else {
+                    std::swap(perm[i1], perm[i2]);
+                }
+            }
+            assign();
+        }
+        bank_cost = best;
         pl.n_slots = ns;
     }
 
     // ---- 2. LDS layout: every slot double-buffered by order parity. ----
-    const std::uint32_t max_round_outputs = std::max<std::uint32_t>(n_out, 4u);
+    const std::uint32_t max_round_outputs = std::max<std::uint32_t>(n_out, one_lane ? 6u : 4u);
     const auto dummy_base = pl.n_slots;
     const auto n_slots_tot = pl.n_slots + max_round_outputs;
-    const auto buf_stride = n_slots_tot;                 // doubles between the two parity buffers
-    const auto slab_stride = (2u * n_slots_tot) | 1u;    // doubles per system
+    // One-lane pair kernel: ONE buffer. A system never spans wavefronts and the LDS instructions of a wavefront complete
+    // in order, so a round may overwrite what it has read as long as its reads come first in the instruction stream -
+    // which is how the merged schedule is emitted: reads of x^[k] and of the products of order k-1, then the stores of
+    // the products of order k and of x^[k+1] (the stores may alias the loads as far as the compiler knows: it keeps
+    // their order).
+    const auto buf_stride = one_lane ? 0u : n_slots_tot; // doubles between the two parity buffers
+    // (One buffer; the stride comes out of the bank-conflict search above.)
+    const auto slab_stride = one_lane ? std::max(slab_stride_opt, n_slots_tot) : ((2u * n_slots_tot) | 1u); // doubles per system
 
     // ---- 3. Tables. ----
     std::vector<std::vector<std::uint32_t>> utbl;
@@ -402,7 +557,11 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         return dtbl.size() - 1u;
     };
     const auto utname = [&](std::size_t t) { return utexpr[t]; };
-    const auto dtname = [](std::size_t t) { return "dt" + std::to_string(t); };
+    // (One-lane pair kernel: the per-lane constants live in LDS and are read where they are used - one address register
+    // for all of them instead of two registers each.)
+    const auto dtname = [&](std::size_t t) {
+        return one_lane ? ("dtl[" + std::to_string(t * L) + "]") : ("dt" + std::to_string(t));
+    };
 
     ssa_emitter e(p, order);
     auto &os = e.os;
@@ -479,25 +638,31 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     }
     // One-lane pair kernel: lane l = pair l (the lanes beyond the last pair replicate pair 0 and write to dummy slots).
     struct single_tables {
-        std::size_t s[3][2] = {}, o[3] = {}, csc = 0;
+        std::size_t s[3][2] = {}, o[3] = {}, r[3] = {}, csc = 0, crs = 0;
     } st1;
     if (one_lane) {
-        if (!fuse_rx && pp.rx[0] >= 0) {
-            why_not = "one-lane pair kernel: the reaction products cannot be fused into the sums";
-            return ret;
-        }
-        std::vector<double> csc(L, 1.);
+        std::vector<double> csc(L, 1.), crs(L, 0.);
         for (std::uint32_t i = 0; i < 3u; ++i) {
-            std::vector<std::uint32_t> s0(L), s1(L), o(L);
+            std::vector<std::uint32_t> s0(L), s1(L), o(L), r(L);
             for (std::uint32_t l = 0; l < L; ++l) {
                 const bool valid = l < nc;
                 const auto c = valid ? l : 0u;
                 const auto &cl = pl.clusters[c];
                 s0[l] = static_cast<std::uint32_t>(pl.slot_of[pl.ext_u[c][pp.de[i][0]]]);
                 s1[l] = static_cast<std::uint32_t>(pl.slot_of[pl.ext_u[c][pp.de[i][1]]]);
-                o[l] = valid ? pr_slot(cl[pp.pr[i]], pp.rx[0] >= 0 ? cl[static_cast<std::uint32_t>(pp.rx[i])] : cl[pp.pr[i]],
-                                       dummy_base + i)
-                             : dummy_base + i;
+                // (Every lane owns its output slots, the idle ones too: slot = first slot of pair 0 + 3 * lane + i.)
+                o[l] = static_cast<std::uint32_t>(pl.slot_of[pl.clusters[0][pp.pr[i]]]) - 3u * lane_pr[0] + 3u * lane_pr[l];
+                if (pp.rx[0] >= 0) {
+                    const auto ru = cl[static_cast<std::uint32_t>(pp.rx[i])];
+                    r[l] = static_cast<std::uint32_t>(pl.slot_of[pl.clusters[0][static_cast<std::uint32_t>(pp.rx[i])]]) - 3u * lane_rx[0]
+                           + 3u * lane_rx[l];
+                    const auto cv = p.nodes[ru - n_eq].args[0].value;
+                    if (i > 0u && cv != crs[l]) {
+                        why_not = "one-lane pair kernel: the reaction coefficients of a pair differ between the coordinates";
+                        return ret;
+                    }
+                    crs[l] = cv;
+                }
                 if (pp.sc >= 0) {
                     csc[l] = p.nodes[cl[static_cast<std::uint32_t>(pp.sc)] - n_eq].args[0].value;
                 }
@@ -505,9 +670,15 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
             st1.s[i][0] = add_utbl(std::move(s0));
             st1.s[i][1] = add_utbl(std::move(s1));
             st1.o[i] = add_utbl(std::move(o));
+            if (pp.rx[0] >= 0) {
+                st1.r[i] = add_utbl(std::move(r));
+            }
         }
         if (pp.sc >= 0) {
             st1.csc = add_dtbl(std::move(csc));
+        }
+        if (pp.rx[0] >= 0) {
+            st1.crs = add_dtbl(std::move(crs));
         }
     }
     std::vector<std::size_t> ext_tbl(n_ext), out_tbl(n_out), cst_tbl(n_cst);
@@ -684,17 +855,20 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     // partially filled slot - they replicate the node of a valid lane, so every statement of the step body is
     // unconditional (no exec-mask manipulation inside the step loop).
     const auto n_col = n_col_acc;
-    const auto n_colp = n_col + 1u;
+    // (One-lane pair kernel: no dummy column - the idle lanes of a partially filled slot store to the entry they
+    // replicate - and a row is laid out [owner slot][system][lane]: the 32 lanes which a ds_read_b64 services together
+    // (two systems) then touch 32 consecutive doubles, i.e. every bank once.)
+    const auto n_colp = one_lane ? n_col : n_col + 1u;
     // (One-lane pair kernel: current values of the derived variables, [system of the wave][entry] + one dummy entry.)
     const auto n_dcol = n_dcol_acc;
-    const auto n_dcolp = n_dcol + 1u;
+    const auto n_dcolp = one_lane ? n_dcol : n_dcol + 1u;
     const auto n_hslots = (n_col + L - 1u) / L; // lane slots of the final Horner / compensated evaluation
     // Jets of the state variables: [order][system of the wave][column], per wave. Kept in LDS when the
     // block's slab + jets fit in the 160 KB of a CU (the kernel occupies a whole CU anyway: 512 registers
     // per lane), otherwise in a per-wave global scratch.
     const auto jet_rows_doubles = static_cast<std::uint64_t>(order + 1u) * spw * n_colp;
     const auto jet_doubles_per_wave = jet_rows_doubles + (one_lane ? static_cast<std::uint64_t>(spw) * n_dcolp : 0u);
-    const auto lds_doubles_slab = static_cast<std::uint64_t>(wpb) * spw * ((2u * (pl.n_slots + std::max<std::uint32_t>(n_out, 4u))) | 1u);
+    const auto lds_doubles_slab = static_cast<std::uint64_t>(wpb) * spw * slab_stride;
     const bool jet_lds = (lds_doubles_slab + wpb * jet_doubles_per_wave) * 8u <= 160u * 1024u
                          && std::getenv("HEYOKA_AMD_JET_GLOBAL") == nullptr;
 
@@ -720,7 +894,8 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     // ---- 4. Emission helpers. ----
     const auto slabk = [&](std::uint32_t k, const std::string &tbl) {
         // Parity buffer of order k.
-        return (k % 2u == 0u) ? ("slab[" + tbl + "]") : ("slab[" + tbl + " + " + std::to_string(buf_stride) + "u]");
+        return (k % 2u == 0u || buf_stride == 0u) ? ("slab[" + tbl + "]")
+                                                  : ("slab[" + tbl + " + " + std::to_string(buf_stride) + "u]");
     };
     const auto jet_at = [&](std::uint32_t k, std::uint32_t col) {
         return "jc" + std::to_string(col) + "[" + std::to_string(static_cast<std::uint64_t>(k) * spw * n_colp) + "]";
@@ -1072,6 +1247,17 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         v.resize(order + 1u);
     }
     std::string hq[3], hm[3], hcx[3], hT, hU;
+    // (Accumulators of the next order, started by emit_single_early().)
+    std::string nq[3], nm[3], ncx[3];
+    // (Only up to order early_kmax: at the high orders all the histories are live and the extra accumulators spill.
+    // Measured on the outer Solar System, 1 048 576 systems: 6.99e8 system-steps/s without the split, 6.99e8 / 6.91e8 /
+    // 6.98e8 / 6.90e8 with early_kmax = 8 / 12 / 14 / 16 - the other wavefront of the SIMD already covers the exchange -,
+    // hence off by default; HEYOKA_AMD_V5_EARLY_KMAX for experiments.)
+    const bool early_on = std::getenv("HEYOKA_AMD_V5_NO_EARLY") == nullptr;
+    const std::uint32_t early_kmax = std::getenv("HEYOKA_AMD_V5_EARLY_KMAX") != nullptr
+                                         ? static_cast<std::uint32_t>(std::atoi(std::getenv("HEYOKA_AMD_V5_EARLY_KMAX")))
+                                         : 0u;
+    bool early_split = false; // (the flag of the order being emitted)
     const auto emit_single_reads = [&](std::uint32_t k) {
         std::vector<std::string> r;
         for (std::uint32_t i = 0; i < 3u; ++i) {
@@ -1124,15 +1310,26 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         for (std::uint32_t i = 0; i < 3u; ++i) {
             os << slabk(k, utname(st1.o[i])) << " = " << pr[i] << ";\n";
         }
-        // History parts of order K = k + 1 (indices 1 .. k), the eight chains interleaved term by term.
+        for (std::uint32_t i = 0; pp.rx[0] >= 0 && i < 3u; ++i) {
+            // (The reaction on the second body of the pair: c * (d_i * sa), src/model/nbody.cpp:113-130.)
+            const auto rxv = e.def(ssa_emitter::mul("crs_r", pr[i]));
+            os << slabk(k, utname(st1.r[i])) << " = " << rxv << ";\n";
+        }
+        // History parts of order K = k + 1: the early terms (both indices <= k - 1) were accumulated before this
+        // finishing, under the latency of the LDS reads (emit_single_early()); here the late ones - the terms with an
+        // order-k coefficient - and the T / U chains of the pow recurrence, whose first term is the newest one.
         for (std::uint32_t i = 0; i < 3u; ++i) {
-            hq[i].clear();
-            hm[i].clear();
-            hcx[i].clear();
+            hq[i] = nq[i];
+            hm[i] = nm[i];
+            hcx[i] = ncx[i];
+            nq[i].clear();
+            nm[i].clear();
+            ncx[i].clear();
         }
         hT.clear();
         hU.clear();
         const auto K = k + 1u;
+        early_split = early_on && K <= early_kmax;
         if (K < order && K >= 2u) {
             const auto jmax = (K % 2u == 1u) ? (K - 1u) / 2u : (K - 2u) / 2u;
             for (std::uint32_t j = 1; j < K; ++j) {
@@ -1140,17 +1337,44 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
                 const auto jd = K - j;
                 hT = e.chain(hT, sB[K - jd], sA[jd]);
                 hU = hU.empty() ? hT : e.def(hU + " + " + hT);
-                for (std::uint32_t i = 0; i < 3u; ++i) {
-                    hcx[i] = e.chain(hcx[i], sD[i][K - j], sA[j]);
-                    if (j <= jmax) {
-                        hq[i] = e.chain(hq[i], sD[i][K - j], sD[i][j]);
+                if (j == 1u || j == K - 1u || !early_split) {
+                    for (std::uint32_t i = 0; i < 3u; ++i) {
+                        hcx[i] = e.chain(hcx[i], sD[i][K - j], sA[j]);
+                        if (j <= jmax) {
+                            hq[i] = e.chain(hq[i], sD[i][K - j], sD[i][j]);
+                        }
                     }
                 }
             }
-            if (K % 2u == 0u) {
+            if (K % 2u == 0u && (K / 2u == k || !early_split)) {
                 for (std::uint32_t i = 0; i < 3u; ++i) {
                     hm[i] = e.def(ssa_emitter::mul(sD[i][K / 2u], sD[i][K / 2u]));
                 }
+            }
+        }
+    };
+    // Early terms of the history chains of order K = k + 1 (operand indices 2 .. k - 1 on both sides): they only need
+    // coefficients of order < k, so they are emitted between the LDS reads of round k and the finishing operations which
+    // consume them - a few hundred cycles of independent FMAs where the wavefront would otherwise wait for the exchange.
+    const auto emit_single_early = [&](std::uint32_t k) {
+        using emit_detail::ssa_emitter;
+        const auto K = k + 1u;
+        early_split = early_on && K <= early_kmax;
+        if (!early_split || K >= order || K < 4u) {
+            return;
+        }
+        const auto jmax = (K % 2u == 1u) ? (K - 1u) / 2u : (K - 2u) / 2u;
+        for (std::uint32_t j = 2; j + 1u < K; ++j) {
+            for (std::uint32_t i = 0; i < 3u; ++i) {
+                ncx[i] = e.chain(ncx[i], sD[i][K - j], sA[j]);
+                if (j <= jmax) {
+                    nq[i] = e.chain(nq[i], sD[i][K - j], sD[i][j]);
+                }
+            }
+        }
+        if (K % 2u == 0u && K / 2u < k) {
+            for (std::uint32_t i = 0; i < 3u; ++i) {
+                nm[i] = e.def(ssa_emitter::mul(sD[i][K / 2u], sD[i][K / 2u]));
             }
         }
     };
@@ -1204,13 +1428,21 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
             }
         }
     }
+    // (One-lane pair kernel, single-buffered slab: the order-1 coefficients go to the slab once the order-0 ones have
+    // been read, i.e. after the reads of round 0.)
+    std::vector<std::tuple<owner_slot *, std::uint32_t, std::string>> deferred_pub;
     if (merged) {
         // Orders 1 .. a of the a-th variable of a chain follow from the state alone.
         for (auto &rg : rounds) {
             for (auto &gr : rg) {
                 for (std::size_t a = 1; a < gr.owners.size(); ++a) {
                     for (std::uint32_t j = 1; j <= a && j <= order; ++j) {
-                        publish_sv(gr.owners[a], j, e.div_const(gr.owners[a - 1u].xname[j - 1u], j));
+                        const auto x = e.div_const(gr.owners[a - 1u].xname[j - 1u], j);
+                        if (one_lane) {
+                            deferred_pub.emplace_back(&gr.owners[a], j, x);
+                        } else {
+                            publish_sv(gr.owners[a], j, x);
+                        }
                     }
                 }
             }
@@ -1222,6 +1454,11 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
         if (k < order) {
             prd = one_lane ? emit_single_reads(k) : emit_pair_reads(k);
         }
+        if (k == 0u) {
+            for (auto &[ow, j, x] : deferred_pub) {
+                publish_sv(*ow, j, x);
+            }
+        }
         std::vector<std::tuple<std::size_t, std::uint32_t, std::vector<std::string>>> pend;
         if (k >= 1u) {
             for (std::size_t g = 0; g < pl.groups.size(); ++g) {
@@ -1230,12 +1467,34 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
                 }
             }
         }
-        if (k < order) {
-            if (one_lane) {
-                emit_single_compute(k, prd);
-            } else {
-                emit_pair_compute(k, prd);
+        if (one_lane) {
+            // Round k of the one-lane kernel: LDS reads | early chains of order k + 1 (independent of the reads) | glue of
+            // order k - 1 (consumes its ten operands right away: 20 registers which would otherwise stay live across
+            // the finishing operations of the pairs) | finishing of order k, stores, late chains.
+            static const bool glue_first = std::getenv("HEYOKA_AMD_V5_GLUE_LAST") == nullptr;
+            sched_fence();
+            if (k < order) {
+                emit_single_early(k);
+                sched_fence();
             }
+            for (const auto &[g, r, names] : pend) {
+                if (glue_first) {
+                    emit_glue_compute(g, r, k - 1u, names);
+                }
+            }
+            if (k < order) {
+                emit_single_compute(k, prd);
+            }
+            for (const auto &[g, r, names] : pend) {
+                if (!glue_first) {
+                    emit_glue_compute(g, r, k - 1u, names);
+                }
+            }
+            sync();
+            continue;
+        }
+        if (k < order) {
+            emit_pair_compute(k, prd);
         }
         for (const auto &[g, r, names] : pend) {
             emit_glue_compute(g, r, k - 1u, names);
@@ -1436,6 +1695,9 @@ __device__ __forceinline__ double hy_swap1(double x)
         src << "const bool isB = (lane & 1u) != 0u;\nconst double fB = isB ? 1.0 : 0.0, fA = isB ? 0.0 : 1.0;\n";
     }
     src << "double *const slab = lds_slab + (wib * " << spw << "u + q) * " << slab_stride << "u;\n";
+    if (one_lane) {
+        src << "__shared__ double lds_bk[" << wpb * spw * 16u << "];\ndouble *const bk = lds_bk + (wib * " << spw << "u + q) * 16u;\n";
+    }
     src << "const u64 gwave = (u64)blockIdx.x * " << wpb << "u + wib;\n";
     if (jet_lds) {
         src << "__shared__ double lds_jet[" << wpb * jet_doubles_per_wave << "];\n";
@@ -1448,10 +1710,18 @@ __device__ __forceinline__ double hy_swap1(double x)
             src << "const unsigned ut" << t << " = hy_utbl[" << t * L << "u + l];\n";
         }
     }
-    for (std::size_t t = 0; t < dtbl.size(); ++t) {
+    if (one_lane) {
+        src << "__shared__ double lds_dt[" << std::max<std::size_t>(dtbl.size(), 1u) * L << "];\n";
+        src << "for (unsigned i = threadIdx.x; i < " << dtbl.size() * L << "u; i += " << bs << "u) lds_dt[i] = hy_dtbl[i];\n";
+        src << "__syncthreads();\nconst double *const dtl = lds_dt + l;\n";
+        if (pp.rx[0] >= 0) {
+            src << "const double crs_r = hy_dtbl[" << st1.crs * L << "u + l];\n";
+        }
+    }
+    for (std::size_t t = 0; !one_lane && t < dtbl.size(); ++t) {
         src << "const double dt" << t << " = hy_dtbl[" << t * L << "u + l];\n";
     }
-    for (std::uint32_t x = 0; x < n_cst; ++x) {
+    for (std::uint32_t x = 0; !pairk && x < n_cst; ++x) {
         src << "const double ccst" << x << " = dt" << cst_tbl[x] << ";\n";
     }
     for (const auto &rg : rounds) {
@@ -1459,11 +1729,18 @@ __device__ __forceinline__ double hy_swap1(double x)
             for (const auto &ow : gr.owners) {
                 src << "const bool ovalid" << ow.col << " = l < " << gr.n_valid << "u;\n";
                 if (ow.derived) {
-                    // (Current values of the derived variables: after the jet rows of the wavefront.)
-                    src << "double *const x0c" << ow.col << " = jetw + " << jet_rows_doubles << "u + q * " << n_dcolp
-                        << "u + (ovalid" << ow.col << " ? " << ow.cbase << "u + l : " << n_dcol << "u);\n";
-                    src << "const double *const x0r" << ow.col << " = jetw + " << jet_rows_doubles << "u + q * " << n_dcolp
-                        << "u + " << ow.cbase << "u + (ovalid" << ow.col << " ? l : 0u);\n";
+                    // (Current values of the derived variables: after the jet rows of the wavefront. One pointer for
+                    // reading and writing: the idle lanes of a partially filled slot replicate the work of lane 0 bit by
+                    // bit and store the same values to the same entry.)
+                    src << "double *const x0c" << ow.col << " = jetw + " << jet_rows_doubles + static_cast<std::uint64_t>(spw) * ow.cbase
+                        << "u + q * " << ow.n_valid << "u + (ovalid" << ow.col << " ? l : 0u);\n";
+                    src << "const double *const x0r" << ow.col << " = x0c" << ow.col << ";\n";
+                    continue;
+                }
+                if (one_lane) {
+                    src << "double *const jc" << ow.col << " = jetw + " << static_cast<std::uint64_t>(spw) * ow.cbase << "u + q * "
+                        << ow.n_valid << "u + (ovalid" << ow.col << " ? l : 0u);\n";
+                    src << "const double *const jr" << ow.col << " = jc" << ow.col << ";\n";
                     continue;
                 }
                 src << "double *const jc" << ow.col << " = jetw + q * " << n_colp << "u + (ovalid" << ow.col << " ? "
@@ -1549,20 +1826,39 @@ i64 outcome = HY_OC_SUCCESS;
 // wrong (DESIGN.md, toolchain notes).
 bool fin = false;
 int nf_seen = 0;
-for (;;) {
-double lim;
-if (a.mode == 1) {
-    hy_df m; m.lo = 0.0;
-    // NOTE: selects, not an if/else on the (per-lane) direction: see the note on HY_LIBM1.
-    m.hi = t_dir ? mdt : -mdt;
-    const bool lt_fwd = hy_df_lt(rem, m), lt_bwd = hy_df_lt(m, rem);
-    const bool rem_first = (t_dir & lt_fwd) | (!t_dir & lt_bwd);
-    lim = rem_first ? rem.hi : m.hi;
-} else {
-    lim = step_lim;
-}
-lim = fin ? 0.0 : lim;
 )HIP";
+    // One-lane pair kernel: the per-system bookkeeping of the step loop (times, limits, counters, outcome: 30 registers
+    // which nothing reads during the 20 orders) is parked in LDS between the tails of two steps - written at the end of
+    // a tail, read back at the beginning of the next one - instead of being spilled to scratch by the register
+    // allocator, whose reloads are scattered over the tail and each wait for a round trip through the vector memory
+    // path. Every lane of a system holds the same values and stores them to the same address.
+    const bool bk_lds = one_lane && std::getenv("HEYOKA_AMD_NO_BK_LDS") == nullptr;
+    const char *bk_fields_d[] = {"t_hi", "t_lo", "tfin.hi", "tfin.lo", "rem.hi", "rem.lo", "mdt", "step_lim", "min_h", "max_h", "last_h"};
+    const auto bk_store = [&]() {
+        std::uint32_t f = 0;
+        for (const auto *nm : bk_fields_d) {
+            src << "bk[" << f++ << "] = " << nm << ";\n";
+        }
+        src << "bk[" << f++ << "] = __longlong_as_double((long long)n_steps);\n";
+        src << "bk[" << f++ << "] = __longlong_as_double((long long)iter);\n";
+        src << "bk[" << f++ << "] = __longlong_as_double((long long)outcome);\n";
+        src << "bk[" << f++ << "] = __longlong_as_double((long long)((t_dir ? 1 : 0) | (nf_seen != 0 ? 2 : 0)));\n";
+    };
+    const auto bk_load = [&]() {
+        std::uint32_t f = 0;
+        for (const auto *nm : bk_fields_d) {
+            src << nm << " = bk[" << f++ << "];\n";
+        }
+        src << "n_steps = (u64)__double_as_longlong(bk[" << f++ << "]);\n";
+        src << "iter = (u64)__double_as_longlong(bk[" << f++ << "]);\n";
+        src << "outcome = (i64)__double_as_longlong(bk[" << f++ << "]);\n";
+        src << "{\nconst long long fl = __double_as_longlong(bk[" << f++ << "]);\nt_dir = (fl & 1) != 0;\nnf_seen = (fl & 2) != 0 ? 1 : 0;\n}\n";
+    };
+    if (bk_lds) {
+        bk_store();
+        src << "HY_WSYNC();\n";
+    }
+    src << "for (;;) {\n";
     src << body;
 
     // Maximum over the lanes of the system: DPP stages where a DPP pattern yields an all-reduce step (xor 1, xor 2 within
@@ -1636,6 +1932,25 @@ lim = fin ? 0.0 : lim;
             src << "const double rho_m = exp(hy_min(lr_o, lr_om1));\n";
         }
     }
+    if (bk_lds) {
+        bk_load();
+    }
+    // The limit of this step (remaining time / maximum step). NOTE: computed here, next to its only use, and not at the
+    // top of the step: its inputs then do not have to be live (or reloaded) before the 20 orders.
+    src << R"HIP(
+double lim;
+if (a.mode == 1) {
+    hy_df m; m.lo = 0.0;
+    // NOTE: selects, not an if/else on the (per-lane) direction: see the note on HY_LIBM1.
+    m.hi = t_dir ? mdt : -mdt;
+    const bool lt_fwd = hy_df_lt(rem, m), lt_bwd = hy_df_lt(m, rem);
+    const bool rem_first = (t_dir & lt_fwd) | (!t_dir & lt_bwd);
+    lim = rem_first ? rem.hi : m.hi;
+} else {
+    lim = step_lim;
+}
+lim = fin ? 0.0 : lim;
+)HIP";
     src << "double h = rho_m * " << fp_literal(rhofac(order)) << ";\n";
     src << "h = hy_min(h, fabs(lim));\nh = (lim < 0.0) ? -h : h;\n";
     // A system which is done takes steps of length EXACTLY zero (lim = 0 gives that unless the selector produced a nan):
@@ -1803,6 +2118,11 @@ int nfi = !(hy_finite(nt_hi) && hy_finite(nt_lo)) ? 1 : 0;
     iter = it_new;
     fin = fin | done;
 }
+)HIP";
+    if (bk_lds) {
+        bk_store();
+    }
+    src << R"HIP(
 if (__builtin_amdgcn_ballot_w64(!fin) == 0ull) break;
 }
 if (nf_seen != 0 && l == 0u && live) atomicAdd(a.counters, 1u);
@@ -1869,9 +2189,15 @@ if (l == 0u && live) {
         // come back through 186 v_readlane_b32 per step (VALU issue slots). Without it: 20, and 7 % fewer VALU
         // instructions in the loop (measured: +2 % system-steps/s, profiles/experiments/run17.sh).
         ret.compile_flags = "-mllvm -disable-machine-licm";
+        if (one_lane) {
+            // NOTE: no merging of LDS accesses: on gfx950 a ds_read2_b64 is serviced at half the rate of two ds_read_b64
+            // (8 against 2 x 2 LDS cycles per wavefront) and this kernel is within 25 % of the LDS throughput.
+            ret.compile_flags += " -Xclang -target-feature -Xclang -load-store-opt -mllvm -amdgpu-load-store-vectorizer=0";
+        }
     }
     ret.tc_optional = true;
     ret.cluster_mode4 = m4;
+    one_lane_jets_in_lds = one_lane && jet_lds;
     ret.notes = std::string(one_lane ? "cluster mode v5 (one lane per pair, 2 wavefronts per SIMD): "
                                      : (pair_split ? "cluster mode v3 (lane pairs, 2 wavefronts per SIMD): " : "cluster mode v2 (pipelined): "))
                 + std::to_string(nc) + " clusters of " + std::to_string(t0.size())
@@ -1879,6 +2205,22 @@ if (l == 0u && live) {
                 + std::to_string(n_own) + " state-variable owner slots, " + std::to_string(utbl.size())
                 + " slot tables, jets in " + (jet_lds ? "LDS" : "global scratch");
     return ret;
+}
+
+} // namespace
+
+emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts, std::string &why_not)
+{
+    // The one-lane pair kernel first (pair-pattern systems without runtime parameters, not the stepper with events); if
+    // its shape requirements fail or the jets of its systems do not fit in LDS, the lane-pair / pipelined kernels.
+    bool in_lds = false;
+    std::string why1;
+    auto ret = emit_cluster_v2_impl(p, opts, why1, true, in_lds);
+    if (why1.empty() && (in_lds || ret.notes.find("cluster mode v5") == std::string::npos)) {
+        why_not.clear();
+        return ret;
+    }
+    return emit_cluster_v2_impl(p, opts, why_not, false, in_lds);
 }
 
 } // namespace heyoka_amd

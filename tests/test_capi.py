@@ -161,7 +161,7 @@ def test_event_integrators_pick_the_cluster_stepper_when_the_event_equations_are
     mode = ta.hip_source_mode
     assert mode.startswith("cluster") and "events: jets of 3 event equation(s)" in mode, mode
     src = ta.hip_source
-    assert "a.sel_norms[s] = m0" in src and "__syncthreads" in src  # the mode-4 specialisation, cooperative tc store
+    assert "a.sel_norms[" in src and "__syncthreads" in src  # the mode-4 specialisation, cooperative tc store
     # The plain integrator of the same system keeps the propagation kernel (no mode-4 code in it).
     tb = hy.taylor_adaptive_batch(sys_, None, 8, high_accuracy=True)
     assert "sel_norms[s]" not in tb.hip_source and tb.hip_source_mode.startswith("cluster")

@@ -29,7 +29,13 @@ def _cases():
     return {
         "outer_ss_cluster_event_stepper": (lambda: hy.model.nbody(6, masses=M, Gconst=G),
                                            {"high_accuracy": True, "nt_events": ev_ss}, {}, "events:"),
-        "outer_ss_cluster_v2": (lambda: hy.model.nbody(6, masses=M, Gconst=G), {"high_accuracy": True}, {}, "cluster"),
+        "outer_ss_cluster_v5": (lambda: hy.model.nbody(6, masses=M, Gconst=G), {"high_accuracy": True}, {}, "v5"),
+        "outer_ss_cluster_v3": (lambda: hy.model.nbody(6, masses=M, Gconst=G), {"high_accuracy": True},
+                                {"HEYOKA_AMD_ONE_LANE": "0"}, "v3"),
+        "outer_ss_cluster_v2": (lambda: hy.model.nbody(6, masses=M, Gconst=G), {"high_accuracy": True},
+                                {"HEYOKA_AMD_ONE_LANE": "0", "HEYOKA_AMD_PAIR_SPLIT": "0"}, "v2"),
+        "nbody8_v5_two_systems_per_wavefront": (lambda: hy.model.nbody(8, masses=[1.0, 1e-3, 2e-3, 3e-3, 4e-3, 5e-3, 6e-3, 7e-3]),
+                                                {}, {}, "v5"),
         "outer_ss_cluster_v1": (lambda: hy.model.nbody(6, masses=M, Gconst=G), {}, {"HEYOKA_AMD_CLUSTER_V1": "1"}, "cluster"),
         "np1body_aliased": (lambda: hy.model.np1body(6, masses=M, Gconst=G), {}, {}, "cluster"),
         "two_body_register_jets": (lambda: hy.model.nbody(2, masses=[1.0, 0.0]), {}, {}, "unrolled"),

@@ -321,6 +321,16 @@ def test_device_array_views_and_ensemble():
         assert np.array_equal(o.state, ta.state[:, i * 256:(i + 1) * 256])
 
 
+def _select_cluster_kernel(monkeypatch, kernel):
+    """Generator selection for the tests (construction-time): v5 = one lane per pair (default), v3 = lane pairs,
+    v2 = pipelined one-lane-per-cluster kernel at one wavefront per SIMD."""
+    assert kernel in ("v5", "v3", "v2")
+    if kernel in ("v3", "v2"):
+        monkeypatch.setenv("HEYOKA_AMD_ONE_LANE", "0")
+    if kernel == "v2":
+        monkeypatch.setenv("HEYOKA_AMD_PAIR_SPLIT", "0")
+
+
 def _nbody_parity(n_bodies, n_sys, n_steps, expect_mode, t_final=None, env_mode=None, tol=1e5):
     import os
 
@@ -362,12 +372,14 @@ def test_cluster_mode_nbody8_default_masses():
     _nbody_parity(8, 96, 3, "cluster", t_final=0.05)
 
 
+@pytest.mark.parametrize("kernel", ["v5", "v3"])
 @pytest.mark.parametrize("n_bodies", [7, 8])
-def test_lane_pair_kernel_one_system_per_wavefront(n_bodies):
-    """17 .. 32 pair clusters (model::nbody(7), nbody(8) with numerical masses): the lane-pair kernel with ONE system per
-    wavefront (64 lanes per system). In round 2 this variant did not terminate on the hardware and was gated off; with
-    the zero-length steps of a finished system forced to h = 0 exactly it runs: steps, a step-limited and a complete
-    propagation against the oracle."""
+def test_pair_kernels_with_17_to_32_pairs(n_bodies, kernel, monkeypatch):
+    """17 .. 32 pair clusters (model::nbody(7), nbody(8) with numerical masses): the one-lane-per-pair kernel with 32 lanes
+    per system (two systems per wavefront) and the lane-pair kernel with ONE system per wavefront (64 lanes per system).
+    In round 2 the latter did not terminate on the hardware and was gated off; with the zero-length steps of a finished
+    system forced to h = 0 exactly it runs: steps, a step-limited and a complete propagation against the oracle."""
+    _select_cluster_kernel(monkeypatch, kernel)
     n = 24
     rng = np.random.RandomState(3)
     masses = [1.0] + [1e-3 * (i + 1) for i in range(n_bodies - 1)]
@@ -379,7 +391,8 @@ def test_lane_pair_kernel_one_system_per_wavefront(n_bodies):
         st[6 * b + 0], st[6 * b + 1], st[6 * b + 2] = r * np.cos(ph), r * np.sin(ph), 0.01 * rng.randn(n)
         st[6 * b + 3], st[6 * b + 4], st[6 * b + 5] = -v * np.sin(ph), v * np.cos(ph), 0.01 * rng.randn(n)
     ta = hy.taylor_adaptive_batch(hy.model.nbody(n_bodies, masses=masses), st, n, high_accuracy=True)
-    assert "lanes per system: 64" in ta.hip_source_mode and "v3" in ta.hip_source_mode, ta.hip_source_mode
+    lanes = 32 if kernel == "v5" else 64
+    assert "lanes per system: %d" % lanes in ta.hip_source_mode and kernel in ta.hip_source_mode, ta.hip_source_mode
     ora = ho.OracleIntegrator(ho.nbody(n_bodies, masses=masses), st.reshape(-1), n, high_accuracy=True)
     for _ in range(3):
         ta.step()
@@ -1173,7 +1186,7 @@ def test_lockstep_device_loop_equals_host_loop(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which", ["two_body_unrolled", "outer_ss_cluster_v3", "outer_ss_cluster_v2"])
+@pytest.mark.parametrize("which", ["two_body_unrolled", "outer_ss_cluster_v5", "outer_ss_cluster_v3", "outer_ss_cluster_v2"])
 def test_contraction_off_build_meets_the_reference_tolerances(which, monkeypatch):
     """The stated slack of the parity tests on h (1e6 eps) and on the Taylor coefficients is FMA contraction (allowed
     by the reference too, src/llvm_state.cpp:843-845) and nothing else: the same kernels built with
@@ -1190,11 +1203,10 @@ def test_contraction_off_build_meets_the_reference_tolerances(which, monkeypatch
         M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
         st = configs.outer_ss_state(n, perturb=1e-6, seed=22)
         sys_g, sys_o, ha = hy.model.nbody(6, masses=M, Gconst=G), ho.nbody(6, masses=M, Gconst=G), True
-        if which.endswith("v2"):
-            monkeypatch.setenv("HEYOKA_AMD_PAIR_SPLIT", "0")
+        _select_cluster_kernel(monkeypatch, which[-2:])
     ta = hy.taylor_adaptive_batch(sys_g, st, n, high_accuracy=ha)
     if which.startswith("outer_ss"):
-        assert ("v3" in ta.hip_source_mode) == which.endswith("v3"), ta.hip_source_mode
+        assert which[-2:] in ta.hip_source_mode, ta.hip_source_mode
     ora = ho.OracleIntegrator(sys_o, st, n, high_accuracy=ha)
     n_eq, p = st.shape[0], ta.order
     for _ in range(4):
@@ -1296,42 +1308,45 @@ def test_event_equations_take_part_in_the_step_size_selector(mode, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_wave_role_kernel_v4_opt_in_matches_the_default_kernel(monkeypatch):
-    """The wave-role variant of the cluster kernel (hip_emit_cluster4.cpp, HEYOKA_AMD_WAVE_ROLES=1: the two roles of a pair
-    cluster on two wavefronts of a workgroup, exchange through LDS + barriers; measured 14 % slower than the lane-pair
-    kernel, kept as an opt-in) agrees with the default kernel and with the oracle, also for a ragged last workgroup."""
+@pytest.mark.parametrize("kernel,contract", [("v5", True), ("v5", False), ("v3", True), ("v3", False), ("v2", True)])
+def test_bench_length_parity_on_4096_systems(kernel, contract, monkeypatch):
+    """The headline kernels over one bench-sized launch (propagate_until(60 yr), ~80 Taylor steps per system) on 4 096
+    perturbed outer Solar Systems against the oracle's ensemble driver, lane by lane: identical outcomes, step counts
+    within +-1 (and equal for all but a handful of lanes), final states, and the smallest / largest step of every lane.
+    Default build: 1e6 eps on the states (test/taylor_adaptive_batch.cpp:105-146 style), 1e-6 on the step sizes; built with
+    -ffp-contract=off (the oracle's arithmetic): 1e5 eps (test/two_body_batch.cpp:118-150)."""
+    _select_cluster_kernel(monkeypatch, kernel)
+    if not contract:
+        monkeypatch.setenv("HEYOKA_AMD_HIPRTC_FLAGS", "-ffp-contract=off")
     M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
-    for n in (6, 64):
-        st = configs.outer_ss_state(n, perturb=1e-8, seed=9)
-        monkeypatch.setenv("HEYOKA_AMD_WAVE_ROLES", "1")
-        a = hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True)
-        monkeypatch.delenv("HEYOKA_AMD_WAVE_ROLES")
-        b = hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True)
-        assert "v4" in a.hip_source_mode and "v3" in b.hip_source_mode
-        a.step(write_tc=True)
-        b.step(write_tc=True)
-        assert rel_err(np.asarray(a.tc), np.asarray(b.tc)) <= 1e5 * EPS
-        a.propagate_until(30.0)
-        b.propagate_until(30.0)
-        assert [r[3] for r in a.propagate_res] == [r[3] for r in b.propagate_res]
-        assert rel_err(a.state, b.state) <= 1e5 * EPS
-    ora = ho.OracleIntegrator(ho.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True)
-    ora.step()
-    ora.propagate_until(30.0)
-    assert rel_err(a.state, ora.state.reshape(36, n)) <= 1e6 * EPS
+    n = 4096
+    st = configs.outer_ss_state(n, perturb=1e-6, seed=77)
+    ta = hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True)
+    assert kernel in ta.hip_source_mode, ta.hip_source_mode
+    ta.propagate_until(60.0)
+    ref, thi, tlo, oc, mn, mx, ns, total = ho.ensemble_propagate_until(ho.nbody(6, masses=M, Gconst=G), st, n, 8, 60.0,
+                                                                       high_accuracy=True)
+    oc_g, mn_g, mx_g, ns_g = ta.propagate_res_arrays()
+    assert np.array_equal(np.asarray(oc_g, dtype=np.int64), oc) and np.all(oc == int(OC.time_limit))
+    assert np.array_equal(ta.time, thi) and np.all(thi == 60.0)
+    dn = np.abs(np.asarray(ns_g, dtype=np.int64) - ns)
+    assert dn.max() <= 1 and np.count_nonzero(dn) <= n // 100, (dn.max(), np.count_nonzero(dn))
+    assert 70 <= ns.mean() <= 95
+    tol = 1e6 if contract else 1e5
+    assert rel_err(ta.state, ref.reshape(36, n)) <= tol * EPS
+    same = dn == 0
+    assert np.max(np.abs(np.asarray(mn_g)[same] - mn[same]) / mn[same]) <= 1e-6
+    assert np.max(np.abs(np.asarray(mx_g)[same] - mx[same]) / mx[same]) <= 1e-6
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kernel", ["v3", "v2", "v4"])
+@pytest.mark.parametrize("kernel", ["v5", "v3", "v2"])
 def test_cluster_kernels_loop_control_semantics(kernel, monkeypatch):
     """The wave-uniform step loop of the cluster kernels (a finished system keeps taking zero-length steps with frozen
-    bookkeeping until the other systems of its wavefront / workgroup are done): per-lane final times forward and backward
-    with a max_delta_t clamp, max_steps, zero-length propagation, the raw step - against the oracle, for the lane-pair
-    (v3), one-lane-per-cluster (v2) and wave-role (v4) variants."""
-    if kernel == "v2":
-        monkeypatch.setenv("HEYOKA_AMD_PAIR_SPLIT", "0")
-    if kernel == "v4":
-        monkeypatch.setenv("HEYOKA_AMD_WAVE_ROLES", "1")
+    bookkeeping until the other systems of its wavefront are done): per-lane final times forward and backward with a
+    max_delta_t clamp, max_steps, zero-length propagation, the raw step - against the oracle, for the one-lane-per-pair
+    kernel (v5, the default), the lane-pair kernel (v3) and the pipelined one-lane-per-cluster kernel (v2)."""
+    _select_cluster_kernel(monkeypatch, kernel)
     M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
     n = 22  # ragged: the last wavefront / workgroup holds replicas
     rng = np.random.RandomState(31)
