@@ -725,6 +725,15 @@ class t_event:
 _TAB_REGISTRY = weakref.WeakValueDictionary()
 
 
+def _enum_arg(name, value, table):
+    if isinstance(value, int) and not isinstance(value, bool) and value in table.values():
+        return value
+    if value not in table:
+        raise ValueError("invalid value %r for the keyword argument '%s' (expected one of %s)"
+                         % (value, name, sorted(k for k in table if k is not None)))
+    return table[value]
+
+
 class taylor_adaptive_batch:
     """taylor_adaptive_batch<double> (include/heyoka/taylor.hpp:781-1121) on MI355X.
 
@@ -734,8 +743,12 @@ class taylor_adaptive_batch:
     """
 
     def __init__(self, sys, state=None, batch_size=None, *, tol=None, high_accuracy=False, compact_mode=False,
-                 parallel_mode=False, pars=None, time=None, device=0, t_events=(), nt_events=(), _handle=None,
+                 parallel_mode=False, pars=None, time=None, device=0, t_events=(), nt_events=(), emitter=None,
+                 cluster_kernel=None, exact_division=False, events_on_cluster=None, batch_semantics=None, _handle=None,
                  _events=None, **ignored_llvm_kwargs):
+        # MI355X extensions (hy_tab_config, include/heyoka_amd.h): emitter in (None, "unrolled", "cluster", "table",
+        # "block"); cluster_kernel in (None, "v5", "v3", "v2", "v1"); exact_division; events_on_cluster (None / False);
+        # batch_semantics in (None = "reference", "lockstep", "per_lane").
         # LLVM-only keyword arguments of the reference (opt_level, fast_math, force_avx512,
         # slp_vectorize, code_model, parjit) are accepted and ignored.
         for k in ignored_llvm_kwargs:
@@ -777,6 +790,12 @@ class taylor_adaptive_batch:
             cfg.time = t.ctypes.data
             cfg.n_time = t.size
         cfg.device = int(device)
+        cfg.emitter = _enum_arg("emitter", emitter, {None: 0, "auto": 0, "unrolled": 1, "cluster": 2, "table": 3, "block": 4})
+        cfg.cluster_kernel = _enum_arg("cluster_kernel", cluster_kernel, {None: 0, "auto": 0, "v5": 5, "v3": 3, "v2": 2, "v1": 1})
+        cfg.exact_division = int(bool(exact_division))
+        cfg.events_on_cluster = 1 if events_on_cluster is False else 0
+        cfg.batch_semantics = _enum_arg("batch_semantics", batch_semantics,
+                                        {None: 0, "reference": 0, "lockstep": 1, "per_lane": 2})
         if tol is not None and float(tol) == 0.0:
             cfg.tol = 0.0
         t_events, nt_events = list(t_events), list(nt_events)

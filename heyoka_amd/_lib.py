@@ -40,6 +40,11 @@ class TabConfig(ctypes.Structure):
         ("time", c_void_p),
         ("n_time", c_size_t),
         ("device", c_int),
+        ("emitter", c_int),
+        ("cluster_kernel", c_int),
+        ("exact_division", c_int),
+        ("events_on_cluster", c_int),
+        ("batch_semantics", c_int),
     ]
 
 

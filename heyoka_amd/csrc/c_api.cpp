@@ -648,6 +648,11 @@ hy_tab hy_tab_create_with_events(hy_sys sys, const double *state, size_t n_state
             c.time = vec_from(cfg->time, cfg->n_time);
             c.time_is_scalar = (cfg->n_time == 1u && batch_size != 1u) || (cfg->n_time == 1u);
             c.device = cfg->device;
+            c.emitter = cfg->emitter;
+            c.cluster_kernel = cfg->cluster_kernel;
+            c.exact_division = cfg->exact_division != 0;
+            c.events_on_cluster = cfg->events_on_cluster;
+            c.batch_semantics = cfg->batch_semantics;
         }
         auto *ret = new hy_tab_s{detail::tab_core(sys->sys, vec_from(state, n_state), batch_size, std::move(c))};
         // The event callbacks receive the handle itself.

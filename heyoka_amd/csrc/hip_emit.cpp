@@ -345,7 +345,7 @@ std::string emit_unrolled_kernel(const taylor_program &p, const emit_options &op
 
     ssa_emitter e(p, order);
     auto &os = e.os;
-    e.enable_pow_rcp();
+    e.enable_pow_rcp(!opts.exact_division);
 
     os << "extern \"C\" __global__ void __launch_bounds__(" << bs << ") " << kname << "(const hy_kargs a)\n{\n";
     os << "const u64 s = (u64)blockIdx.x * " << bs << "u + threadIdx.x;\n";

@@ -60,6 +60,13 @@ struct emit_options {
     // Wave-cluster steppers: emit the stepper of an integrator with events - every launch is a mode-4 step (jets of the
     // state variables to a.tc, selector norms to a.sel_norms, no state update; emitted_module::cluster_mode4).
     bool event_stepper = false;
+    // Wave-cluster generator (kw::cluster_kernel / hy_tab_config::cluster_kernel): 0 = automatic - the first one which
+    // applies out of 5 (one lane per pair cluster, two wavefronts per SIMD), 3 (lane pairs), 2 (one lane per cluster,
+    // pipelined orders), 1 (first generation) -, otherwise the search starts at the given generator.
+    int cluster_kernel = 0;
+    // Correctly rounded quotients in the recurrences of the pair kernels (division by the order, quotient of the pow
+    // recurrence) instead of the reciprocal forms (within 1 ulp of them): kw::exact_division.
+    bool exact_division = false;
 };
 
 struct emitted_module {

@@ -71,7 +71,8 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
         // clamped to zero (a nan from the selector of a non-finite state survives the clamp), fixed by forcing h = 0.
         const char *evm = std::getenv("HEYOKA_AMD_PAIR_SPLIT_MAX_LANES");
         const auto max_lanes = evm != nullptr ? static_cast<std::uint32_t>(std::atoi(evm)) : 64u;
-        pp.ok = ok && 2u * nc <= max_lanes && p.n_par == 0u && !(ev != nullptr && std::atoi(ev) == 0);
+        pp.ok = ok && 2u * nc <= max_lanes && p.n_par == 0u && !(ev != nullptr && std::atoi(ev) == 0)
+                && (opts.cluster_kernel == 0 || opts.cluster_kernel >= 3);
     }
     const bool m4 = opts.event_stepper;
     // ---- 0b. One lane per pair, two wavefronts per SIMD ("v5"): the lane-pair split halves the histories a lane keeps
@@ -90,8 +91,9 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
         if (!allow_one_lane || (ev != nullptr && std::atoi(ev) == 0)) {
             return false;
         }
-        return pp_shape_ok && p.n_par == 0u && !m4 && nc <= 64u && std::getenv("HEYOKA_AMD_V3_EXACT_DIV") == nullptr
-               && std::getenv("HEYOKA_AMD_V3_POW_DIV") == nullptr;
+        // (The derived position jets rely on the reciprocal form of the division by the order.)
+        return pp_shape_ok && p.n_par == 0u && !m4 && nc <= 64u && !opts.exact_division
+               && std::getenv("HEYOKA_AMD_V3_EXACT_DIV") == nullptr && std::getenv("HEYOKA_AMD_V3_POW_DIV") == nullptr;
     }();
     if (one_lane) {
         pp.ok = false;
@@ -568,8 +570,8 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     // Lane-pair kernel: x^[k+1] = f^[k] * RN(1 / (k + 1)) - one multiplication, within 1 ulp of the quotient - instead of
     // the exact 3-operation sequence (60 VALU instructions per step, +2.1 % system-steps/s; the strict-contraction parity
     // test passes its 1e4 / 1e5 eps bounds with it). HEYOKA_AMD_V3_EXACT_DIV=1 restores the correctly-rounded quotient.
-    e.recip_div = pairk && std::getenv("HEYOKA_AMD_V3_EXACT_DIV") == nullptr;
-    e.enable_pow_rcp();
+    e.recip_div = pairk && !opts.exact_division && std::getenv("HEYOKA_AMD_V3_EXACT_DIV") == nullptr;
+    e.enable_pow_rcp(!opts.exact_division);
 
     // Lane-pair variant: lane l = 2 * pair + role (role 0 = A: d_0, d_1; role 1 = B: d_2 and the pow); the lanes
     // beyond the last pair replicate pair 0 and write to dummy slots.
@@ -1105,7 +1107,7 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     // b_0 with a Markstein correction, within 1.5 ulp of the reference's single division).
     const bool pow_norm = [&]() {
         const char *ev = std::getenv("HEYOKA_AMD_V3_POW_DIV");
-        return !(ev != nullptr && std::atoi(ev) != 0) && !div_by_kb0;
+        return !(ev != nullptr && std::atoi(ev) != 0) && !div_by_kb0 && !opts.exact_division;
     }();
     std::string ap0x2; // 2 aP[0]
     const auto emit_pair_reads = [&](std::uint32_t k) {
@@ -1970,43 +1972,82 @@ lim = fin ? 0.0 : lim;
     // (name of the new value, where the current value is read, where the new one goes)
     std::vector<std::tuple<std::string, std::string, std::string>> upd;
     if (one_lane) {
-        // One pass per owner slot: the variables with a jet column, and the derived ones (x' = v) whose coefficients are
-        // formed on the fly from the parent's column, x^[k] = v^[k-1] * RN(1 / k) - bit for bit the published coefficient
-        // (ssa_emitter::div_const() in its reciprocal form). Every pass is one instruction stream without selects.
+        // One pass per glue round: the variable with a jet column (v) and the one derived from it (x' = v), whose
+        // coefficients are formed on the fly from the same column, x^[k] = v^[k-1] * RN(1 / k) - bit for bit the published
+        // coefficient (ssa_emitter::div_const() in its reciprocal form). Both sums of a lane share the loads of the column
+        // (one LDS read per order) and the powers of h; every pass is one instruction stream without selects.
         for (const auto &rg : rounds) {
             for (const auto &gr : rg) {
                 for (const auto &ow : gr.owners) {
+                    if (ow.derived) {
+                        continue;
+                    }
+                    // The variables derived from this one (at most one: chains of length <= 2).
+                    const owner_slot *dv = nullptr;
+                    for (const auto &o2 : gr.owners) {
+                        if (o2.derived && o2.parent == ow.col) {
+                            dv = &o2;
+                        }
+                    }
                     const auto xn = "xn" + std::to_string(ow.col);
-                    const auto src_col = "jr" + std::to_string(ow.derived ? ow.parent : ow.col);
-                    const auto coef = [&](std::uint32_t k) -> std::string {
-                        if (!ow.derived) {
-                            return src_col + "[" + std::to_string(k * kstride) + "]";
-                        }
-                        if (k == 0u) {
-                            return row0_r(ow);
-                        }
-                        return "(" + src_col + "[" + std::to_string((k - 1u) * kstride) + "] * "
-                               + fp_literal(1. / static_cast<double>(k)) + ")";
-                    };
-                    src << "double " << xn << ";\n{\n";
+                    const auto xd = dv != nullptr ? "xn" + std::to_string(dv->col) : std::string{};
+                    const auto colp = "jr" + std::to_string(ow.col);
+                    src << "double " << xn << ";\n";
+                    if (dv != nullptr) {
+                        src << "double " << xd << ";\n";
+                    }
+                    src << "{\n";
                     if (opts.high_accuracy) {
-                        src << "double res = " << coef(0) << ", comp = 0.0, cur_h = h;\n";
+                        src << "double cprev = " << colp << "[0];\ndouble res = cprev, comp = 0.0, cur_h = h;\n";
+                        if (dv != nullptr) {
+                            src << "double resd = " << row0_r(*dv) << ", compd = 0.0;\n";
+                        }
                         for (std::uint32_t k = 1; k <= order; ++k) {
-                            src << "{\nconst double ck = " << coef(k) << ";\nconst double tmp = ck * cur_h;\n"
-                                << "const double y = tmp - comp;\nconst double t = res + y;\ncomp = (t - res) - y;\nres = t;\n";
+                            src << "{\nconst double ck = " << colp << "[" << k * kstride << "];\n";
+                            if (dv != nullptr) {
+                                src << "const double cd = cprev * " << fp_literal(1. / static_cast<double>(k)) << ";\n"
+                                    << "const double tmpd = cd * cur_h;\nconst double yd = tmpd - compd;\n"
+                                    << "const double td = resd + yd;\ncompd = (td - resd) - yd;\nresd = td;\n";
+                            }
+                            src << "const double tmp = ck * cur_h;\nconst double y = tmp - comp;\nconst double t = res + y;\n"
+                                << "comp = (t - res) - y;\nres = t;\ncprev = ck;\n";
                             if (k < order) {
                                 src << "cur_h = cur_h * h;\n";
                             }
                             src << "}\n";
                         }
                     } else {
-                        src << "double res = " << coef(order) << ";\n";
+                        // Horner from the highest order down: the derived series needs the column shifted by one.
+                        src << "double res = " << colp << "[" << order * kstride << "];\n";
+                        if (dv != nullptr) {
+                            src << "double resd = " << colp << "[" << (order - 1u) * kstride << "] * "
+                                << fp_literal(1. / static_cast<double>(order)) << ";\n";
+                        }
                         for (std::uint32_t k = 1; k <= order; ++k) {
-                            src << "res = " << coef(order - k) << " + res * h;\n";
+                            const auto kk = order - k;
+                            src << "res = " << colp << "[" << kk * kstride << "] + res * h;\n";
+                        }
+                        if (dv != nullptr) {
+                            for (std::uint32_t k = 1; k <= order; ++k) {
+                                const auto kk = order - k;
+                                if (kk >= 1u) {
+                                    src << "resd = (" << colp << "[" << (kk - 1u) * kstride << "] * "
+                                        << fp_literal(1. / static_cast<double>(kk)) << ") + resd * h;\n";
+                                } else {
+                                    src << "resd = " << row0_r(*dv) << " + resd * h;\n";
+                                }
+                            }
                         }
                     }
-                    src << xn << " = res;\n}\n";
+                    src << xn << " = res;\n";
+                    if (dv != nullptr) {
+                        src << xd << " = resd;\n";
+                    }
+                    src << "}\n";
                     upd.emplace_back(xn, row0_r(ow), row0_w(ow));
+                    if (dv != nullptr) {
+                        upd.emplace_back(xd, row0_r(*dv), row0_w(*dv));
+                    }
                 }
             }
         }
@@ -2203,7 +2244,8 @@ if (l == 0u && live) {
                 + std::to_string(nc) + " clusters of " + std::to_string(t0.size())
                 + " nodes, L=" + std::to_string(L) + ", " + std::to_string(pl.n_slots) + " LDS slots x2, "
                 + std::to_string(n_own) + " state-variable owner slots, " + std::to_string(utbl.size())
-                + " slot tables, jets in " + (jet_lds ? "LDS" : "global scratch");
+                + " slot tables, jets in " + (jet_lds ? "LDS" : "global scratch")
+                + (one_lane ? ", slab layout: " + std::to_string(bank_cost) + " conflict cycles per step in the model" : std::string{});
     return ret;
 }
 
@@ -2215,7 +2257,8 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
     // its shape requirements fail or the jets of its systems do not fit in LDS, the lane-pair / pipelined kernels.
     bool in_lds = false;
     std::string why1;
-    auto ret = emit_cluster_v2_impl(p, opts, why1, true, in_lds);
+    const bool try_one_lane = opts.cluster_kernel == 0 || opts.cluster_kernel == 5;
+    auto ret = emit_cluster_v2_impl(p, opts, why1, try_one_lane, in_lds);
     if (why1.empty() && (in_lds || ret.notes.find("cluster mode v5") == std::string::npos)) {
         why_not.clear();
         return ret;

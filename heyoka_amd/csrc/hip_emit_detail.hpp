@@ -1075,9 +1075,9 @@ struct ssa_emitter {
     // reciprocal is defined at the first use and read at every later order): enable_pow_rcp(); HEYOKA_AMD_EXACT_POW_DIV=1
     // keeps the plain division.
     bool pow_rcp = false;
-    void enable_pow_rcp()
+    void enable_pow_rcp(bool on = true)
     {
-        pow_rcp = std::getenv("HEYOKA_AMD_EXACT_POW_DIV") == nullptr;
+        pow_rcp = on && std::getenv("HEYOKA_AMD_EXACT_POW_DIV") == nullptr;
     }
     std::map<std::uint32_t, std::string> pow_r0;
     std::string pow_quotient(std::uint32_t u, std::uint32_t b, const std::string &acc, std::uint32_t k)

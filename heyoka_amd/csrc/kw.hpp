@@ -76,8 +76,16 @@ HEYOKA_AMD_KWARG(length);
 HEYOKA_AMD_KWARG(mu);
 HEYOKA_AMD_KWARG(positions);
 HEYOKA_AMD_KWARG(omega);
-// MI355X-specific extension: select the device ordinal.
+// MI355X-specific extensions: the device ordinal, the code generator (emitter: 0 automatic, 1 unrolled, 2 wave-cluster,
+// 3 table, 4 block; cluster_kernel: 0 automatic, 5 / 3 / 2 / 1), correctly rounded quotients in the recurrences, the
+// steppers used with events, and the outcome semantics of propagate_for / propagate_until (0 reference, 1 lock-step loop,
+// 2 per lane) - see tab_core::config.
 HEYOKA_AMD_KWARG(device);
+HEYOKA_AMD_KWARG(emitter);
+HEYOKA_AMD_KWARG(cluster_kernel);
+HEYOKA_AMD_KWARG(exact_division);
+HEYOKA_AMD_KWARG(events_on_cluster);
+HEYOKA_AMD_KWARG(batch_semantics);
 
 #undef HEYOKA_AMD_KWARG
 

@@ -53,24 +53,20 @@ struct grid_kargs {
     unsigned n_grid;
 };
 
-emit_mode choose_mode()
+// Code generator from the configuration field (0 automatic: the wave-cluster generator is tried first and falls back
+// by itself, see emit_hip_module()).
+emit_mode choose_mode(int emitter)
 {
-    if (const char *m = std::getenv("HEYOKA_AMD_EMIT_MODE")) {
-        const std::string s(m);
-        if (s == "unrolled") {
+    switch (emitter) {
+        case 1:
             return emit_mode::unrolled;
-        }
-        if (s == "cluster") {
-            return emit_mode::cluster;
-        }
-        if (s == "table") {
+        case 3:
             return emit_mode::table;
-        }
-        if (s == "block") {
+        case 4:
             return emit_mode::block;
-        }
+        default:
+            return emit_mode::cluster;
     }
-    return emit_mode::cluster;
 }
 
 } // namespace
@@ -83,6 +79,10 @@ struct tab_core::impl {
     double tol = 0;
     bool high_accuracy = false;
     bool compact_mode = false;
+    // MI355X extensions of the configuration (tab_core::config): code generator, cluster generator, exact divisions,
+    // steppers used with events, outcome semantics of propagate_for / propagate_until.
+    int emitter = 0, cluster_kernel = 0, events_on_cluster = 0, batch_semantics = 0;
+    bool exact_division = false;
     std::uint32_t N = 0; // batch size == number of systems.
     std::uint32_t dim = 0;
     int device = 0;
@@ -112,6 +112,33 @@ struct tab_core::impl {
     std::uint64_t last_total_steps = 0;
     // Set by the lock-step propagate loop to override the device outcomes.
     mutable std::optional<taylor_outcome> prop_res_override;
+    // Reference outcome semantics on the device-resident propagation (config::batch_semantics == 0): snapshot of the
+    // state / times taken before the launch (a batch in which a lane goes non-finite is rolled back and re-run through
+    // the lock-step loop: src/taylor_adaptive_batch.cpp:1404-1407, :1462-1467) and the flag which makes a step-limited
+    // batch report step_limit in every lane (:1516) when its results are fetched.
+    mutable device_buffer snap_state, snap_thi, snap_tlo;
+    mutable bool fix_step_limit = false;
+    bool force_lockstep = false;
+    void snapshot_for_rollback()
+    {
+        const auto sb = d_state.bytes(), tb = d_thi.bytes();
+        if (snap_state.bytes() != sb) {
+            snap_state = device_buffer(sb, device);
+            snap_thi = device_buffer(tb, device);
+            snap_tlo = device_buffer(tb, device);
+        }
+        device_copy(snap_state.get(), d_state.get(), sb, device, stream);
+        device_copy(snap_thi.get(), d_thi.get(), tb, device, stream);
+        device_copy(snap_tlo.get(), d_tlo.get(), tb, device, stream);
+    }
+    void rollback_to_snapshot()
+    {
+        device_copy(d_state.get(), snap_state.get(), d_state.bytes(), device, stream);
+        device_copy(d_thi.get(), snap_thi.get(), d_thi.bytes(), device, stream);
+        device_copy(d_tlo.get(), snap_tlo.get(), d_tlo.bytes(), device, stream);
+        dev_newer = true;
+        host_newer = false;
+    }
     // Continuous output produced by the last propagate_for/until() with c_output = true.
     std::optional<c_out_core> last_c_out;
     // Post-step kernel of the device-resident propagate_grid() loop (created on first use).
@@ -374,6 +401,17 @@ struct tab_core::impl {
         d_minh.download(mn.data(), mn.size() * sizeof(double), stream);
         d_maxh.download(mx.data(), mx.size() * sizeof(double), stream);
         d_nsteps.download(ns.data(), ns.size() * sizeof(unsigned long long), stream);
+        if (fix_step_limit) {
+            // The reference stops the whole batch when the iteration counter reaches max_steps and reports step_limit in
+            // EVERY lane (src/taylor_adaptive_batch.cpp:1516): the lanes which were done earlier took zero-length steps
+            // in the meantime, so their states, times and counters are what the device-resident loop left.
+            fix_step_limit = false;
+            const auto sl = static_cast<long long>(taylor_outcome::step_limit);
+            if (std::find(oc.begin(), oc.end(), sl) != oc.end()) {
+                std::fill(oc.begin(), oc.end(), sl);
+                d_outcome.upload(oc.data(), oc.size() * sizeof(long long), stream);
+            }
+        }
         for (std::uint32_t i = 0; i < N; ++i) {
             prop_res[i] = std::tuple{static_cast<taylor_outcome>(oc[i]), mn[i], mx[i], static_cast<std::size_t>(ns[i])};
         }
@@ -393,6 +431,42 @@ tab_core::tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_siz
     d.high_accuracy = cfg.high_accuracy;
     d.compact_mode = cfg.compact_mode;
     d.device = cfg.device;
+    d.emitter = cfg.emitter;
+    d.cluster_kernel = cfg.cluster_kernel;
+    d.exact_division = cfg.exact_division;
+    d.events_on_cluster = cfg.events_on_cluster;
+    d.batch_semantics = cfg.batch_semantics;
+    if (d.emitter < 0 || d.emitter > 4) {
+        throw std::invalid_argument("Invalid code generator selected in an adaptive Taylor integrator in batch mode: "
+                                    + std::to_string(d.emitter) + " (0 automatic, 1 unrolled, 2 cluster, 3 table, 4 block)");
+    }
+    if (d.cluster_kernel != 0 && d.cluster_kernel != 5 && d.cluster_kernel != 3 && d.cluster_kernel != 2
+        && d.cluster_kernel != 1) {
+        throw std::invalid_argument("Invalid wave-cluster generator selected in an adaptive Taylor integrator in batch mode: "
+                                    + std::to_string(d.cluster_kernel) + " (0 automatic, or 5, 3, 2, 1)");
+    }
+    if (d.batch_semantics < 0 || d.batch_semantics > 2) {
+        throw std::invalid_argument("Invalid batch semantics selected in an adaptive Taylor integrator in batch mode: "
+                                    + std::to_string(d.batch_semantics) + " (0 reference, 1 lock-step loop, 2 per lane)");
+    }
+    // Developer overrides from the environment (experiments and the test matrix): they map onto the same fields.
+    if (const char *m = std::getenv("HEYOKA_AMD_EMIT_MODE")) {
+        const std::string ms(m);
+        d.emitter = ms == "unrolled" ? 1 : (ms == "cluster" ? 2 : (ms == "table" ? 3 : (ms == "block" ? 4 : d.emitter)));
+    }
+    if (const char *ev = std::getenv("HEYOKA_AMD_ONE_LANE"); ev != nullptr && std::atoi(ev) == 0 && d.cluster_kernel == 0) {
+        d.cluster_kernel = 3;
+    }
+    if (const char *ev = std::getenv("HEYOKA_AMD_PAIR_SPLIT"); ev != nullptr && std::atoi(ev) == 0
+        && (d.cluster_kernel == 0 || d.cluster_kernel == 3)) {
+        d.cluster_kernel = 2;
+    }
+    if (const char *ev = std::getenv("HEYOKA_AMD_EVENTS_ON_CLUSTER"); ev != nullptr && std::atoi(ev) == 0) {
+        d.events_on_cluster = 1;
+    }
+    if (const char *ev = std::getenv("HEYOKA_AMD_REFERENCE_BATCH_SEMANTICS"); ev != nullptr && std::atoi(ev) != 0) {
+        d.batch_semantics = 1;
+    }
 
     if (d.N == 0u) {
         throw std::invalid_argument("The batch size in an adaptive Taylor integrator cannot be zero");
@@ -508,16 +582,17 @@ tab_core::tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_siz
     eo.order = d.order;
     eo.high_accuracy = d.high_accuracy;
     eo.batch_size = d.N;
+    eo.cluster_kernel = d.cluster_kernel;
+    eo.exact_division = d.exact_division;
     // NOTE: the stepper with events (mode 4) is implemented by the one-system-per-lane kernels: fully unrolled for
     // small decompositions, table-driven otherwise (HEYOKA_AMD_EMIT_MODE=table forces the latter).
     if (d.has_events()) {
-        eo.mode = (d.prog.nodes.size() > 150u || choose_mode() == emit_mode::table) ? emit_mode::table
-                                                                                   : emit_mode::unrolled;
+        eo.mode = (d.prog.nodes.size() > 150u || choose_mode(d.emitter) == emit_mode::table) ? emit_mode::table
+                                                                                            : emit_mode::unrolled;
         // Wave-cluster stepper for the system itself + the event equations from its jets, when both apply (event
         // equations which depend on a small part of the decomposition: distances, coordinates, angles, ...).
         // HEYOKA_AMD_EVENTS_ON_CLUSTER=0: always the one-system-per-lane steppers with events.
-        const char *evc = std::getenv("HEYOKA_AMD_EVENTS_ON_CLUSTER");
-        if (choose_mode() == emit_mode::cluster && !(evc != nullptr && std::atoi(evc) == 0)) {
+        if (choose_mode(d.emitter) == emit_mode::cluster && d.events_on_cluster == 0) {
             const auto prog0 = make_program(taylor_decompose_sys(sys), d.dim);
             auto eo2 = eo;
             eo2.mode = emit_mode::cluster;
@@ -536,13 +611,13 @@ tab_core::tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_siz
             }
         }
     } else {
-        eo.mode = choose_mode();
+        eo.mode = choose_mode(d.emitter);
         // kw::compact_mode = true selects the analogue of the reference's compact mode (src/taylor_02.cpp:1194-1260):
         // the table-driven stepper - one device function per elementary function, rolled loops, running sums like
         // src/math/prod.cpp:686-698 - instead of unrolled / clustered straight-line code (code size and compile time
         // independent of the order). Decompositions beyond 2000 nodes keep the automatic choice (block / table: both
         // tape-based), and HEYOKA_AMD_EMIT_MODE still overrides.
-        if (d.compact_mode && std::getenv("HEYOKA_AMD_EMIT_MODE") == nullptr && d.prog.nodes.size() <= 2000u) {
+        if (d.compact_mode && d.emitter == 0 && d.prog.nodes.size() <= 2000u) {
             eo.mode = emit_mode::table;
         }
     }
@@ -583,6 +658,11 @@ tab_core::tab_core(const tab_core &o) : m_impl(std::make_unique<impl>())
     d.tol = s.tol;
     d.high_accuracy = s.high_accuracy;
     d.compact_mode = s.compact_mode;
+    d.emitter = s.emitter;
+    d.cluster_kernel = s.cluster_kernel;
+    d.exact_division = s.exact_division;
+    d.events_on_cluster = s.events_on_cluster;
+    d.batch_semantics = s.batch_semantics;
     d.N = s.N;
     d.dim = s.dim;
     d.device = s.device;
@@ -872,6 +952,7 @@ const std::vector<std::tuple<taylor_outcome, double, double, std::size_t>> &tab_
             std::get<0>(r) = *d.prop_res_override;
         }
         d.prop_res_override.reset();
+    d.fix_step_limit = false;
     }
     return d.prop_res;
 }
@@ -1541,6 +1622,45 @@ void tab_core::step(const std::vector<double> &max_delta_ts, bool wtc)
 }
 
 // Reference: propagate_for_impl(), src/taylor_adaptive_batch.cpp:1082-1118.
+// Reference outcomes on the device-resident propagation (config::batch_semantics == 0, the default). In the reference
+// every iteration of propagate_until() steps ALL the lanes of the batch; a lane which produces a non-finite state stops
+// the whole batch at that iteration (src/taylor_adaptive_batch.cpp:1404-1407, :1462-1467) and max_steps counts iterations of
+// the batch (:1516). The device-resident loop runs every lane on its own. Its results are the reference's whenever no lane
+// goes non-finite (finished lanes take zero-length steps in the reference: nothing changes) up to the outcome of a
+// step-limited batch, which is fixed when the results are fetched (impl::fetch_prop_res()). A batch WITH a non-finite
+// lane - an error path - is rolled back to the snapshot taken before the launch and re-run through the lock-step loop,
+// which implements the reference's semantics iteration by iteration.
+void tab_core::finish_device_propagate(const std::vector<double> &ts, std::size_t max_steps,
+                                       const std::vector<double> &max_delta_ts, bool wtc)
+{
+    auto &d = *m_impl;
+    if (d.batch_semantics != 0) {
+        return;
+    }
+    d.fix_step_limit = max_steps != 0u;
+    unsigned nf = 0;
+    // (One 4-byte download per call: it waits for the launch, i.e. propagate_*() is synchronous in this mode;
+    // batch_semantics = 2 keeps the fully asynchronous per-lane behaviour.)
+    d.d_counters.download(&nf, sizeof(unsigned), d.stream);
+    if (nf == 0u) {
+        return;
+    }
+    d.fix_step_limit = false;
+    d.rollback_to_snapshot();
+    struct flag_guard {
+        bool &f;
+        explicit flag_guard(bool &x) : f(x)
+        {
+            f = true;
+        }
+        ~flag_guard()
+        {
+            f = false;
+        }
+    } guard(d.force_lockstep);
+    propagate_until(ts, max_steps, max_delta_ts, {}, wtc, false);
+}
+
 void tab_core::propagate_for(const std::vector<double> &delta_ts, std::size_t max_steps,
                              const std::vector<double> &max_delta_ts, const cb_t &cb, bool wtc, bool c_out)
 {
@@ -1607,13 +1727,14 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
     // come from an earlier err_nf_state) reports err_nf_state again instead of raising an exception.
     d.last_c_out.reset();
     if (!cb && !c_out && !d.has_events() && ts_.size() == 1u && d.dev_newer && !d.host_newer && !d.sticky_host_ptr
-        && d.dmod) {
+        && d.dmod && d.batch_semantics != 1 && !d.force_lockstep) {
         if (!std::isfinite(ts_[0])) {
             throw std::invalid_argument("A non-finite time was passed to the propagate_until() function of an "
                                         "adaptive Taylor integrator in batch mode");
         }
         check_mdts();
         d.prop_res_override.reset();
+    d.fix_step_limit = false;
         d.d_counters.zero(d.stream);
         auto a = d.base_args();
         a.tfin_hi = nullptr;
@@ -1632,10 +1753,14 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
         }
         a.mode = 1;
         a.max_steps = max_steps;
+        if (d.batch_semantics == 0) {
+            d.snapshot_for_rollback();
+        }
         d.dmod->launch_taylor(a);
         d.after_kernel();
         d.prop_res_dev_newer = true;
         d.step_res_dev_newer = false;
+        finish_device_propagate(ts_, max_steps, max_delta_ts, wtc);
         return;
     }
 
@@ -1691,16 +1816,14 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
     }
 
     d.prop_res_override.reset();
+    d.fix_step_limit = false;
 
     // Opt-in: the reference's batch-wide semantics (src/taylor_adaptive_batch.cpp:1404-1407, :1462-1467, :1516): a
     // non-finite lane stops the whole batch at that iteration, max_steps counts lock-step iterations of the batch and
     // the lanes which are done keep taking zero-length steps. HEYOKA_AMD_REFERENCE_BATCH_SEMANTICS=1 routes
     // propagate_until() / propagate_for() through the lock-step loop (one step of every lane per sweep), which
     // implements exactly that; by default every lane runs its own loop on the device (known deviations).
-    const bool ref_semantics = [&]() {
-        const char *ev = std::getenv("HEYOKA_AMD_REFERENCE_BATCH_SEMANTICS");
-        return ev != nullptr && std::atoi(ev) != 0;
-    }();
+    const bool ref_semantics = d.batch_semantics == 1 || d.force_lockstep;
 
     if (!cb && !c_out && !d.has_events() && !ref_semantics) {
         // Device-resident propagation: every lane runs its own adaptive loop to completion
@@ -1722,10 +1845,14 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
         }
         a.mode = 1;
         a.max_steps = max_steps;
+        if (d.batch_semantics == 0) {
+            d.snapshot_for_rollback();
+        }
         d.dmod->launch_taylor(a);
         d.after_kernel();
         d.prop_res_dev_newer = true;
         d.step_res_dev_newer = false;
+        finish_device_propagate(ts_, max_steps, max_delta_ts, wtc);
         return;
     }
 
@@ -2146,6 +2273,7 @@ void tab_core::propagate_grid_device_loop(const std::vector<double> &grid, std::
     d.d_nsteps.upload(ns.data(), N * sizeof(unsigned long long), d.stream);
 
     d.prop_res_override.reset();
+    d.fix_step_limit = false;
     std::size_t iter_counter = 0;
     bool any_step = false;
     while (n_grid > 1u) {

@@ -100,6 +100,23 @@ public:
         // Event detection (reference: kw::t_events / kw::nt_events, include/heyoka/taylor.hpp:814-821).
         std::vector<core_t_event> t_events;
         std::vector<core_nt_event> nt_events;
+        // ---- MI355X extensions (kw::emitter, kw::cluster_kernel, kw::exact_division, kw::events_on_cluster,
+        // kw::batch_semantics; hy_tab_config carries the same fields). ----
+        // Code generator: 0 automatic, 1 unrolled, 2 wave-cluster, 3 table, 4 block.
+        int emitter = 0;
+        // Wave-cluster generator: 0 automatic, or 5 / 3 / 2 / 1 (see emit_options::cluster_kernel).
+        int cluster_kernel = 0;
+        bool exact_division = false;
+        // Events next to a system which qualifies for a wave-cluster stepper: 0 automatic (cluster stepper + hy_ev_jets when
+        // the event equations are small), 1 always the one-system-per-lane steppers with events.
+        int events_on_cluster = 0;
+        // Outcomes of propagate_for / propagate_until when a lane produces a non-finite state or max_steps is hit:
+        //   0 (default) the reference's batch-wide results (src/taylor_adaptive_batch.cpp:1404-1407, :1462-1467, :1516),
+        //     obtained on the device-resident path: a step-limited batch reports step_limit in every lane, and a batch
+        //     with a non-finite lane is rolled back and re-run through the lock-step loop;
+        //   1 always the lock-step loop (one launch per iteration of the batch);
+        //   2 per-lane results of the device-resident path (every lane stops on its own), no snapshot, no host sync.
+        int batch_semantics = 0;
     };
 
     tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_size, config cfg);
@@ -158,6 +175,8 @@ public:
 
     using cb_t = std::function<bool()>;
     // ts: final times (size 1 = scalar splat, else batch_size); max_delta_ts: empty or batch_size.
+    void finish_device_propagate(const std::vector<double> &ts, std::size_t max_steps, const std::vector<double> &max_delta_ts,
+                                 bool wtc);
     void propagate_until(const std::vector<double> &ts, std::size_t max_steps, const std::vector<double> &max_delta_ts,
                          const cb_t &cb, bool wtc, bool c_out);
     void propagate_for(const std::vector<double> &delta_ts, std::size_t max_steps,
@@ -340,6 +359,11 @@ class taylor_adaptive_batch<double>
         }
         cfg.high_accuracy = static_cast<bool>(kw::get(kw::high_accuracy, false, kw_args...));
         cfg.compact_mode = static_cast<bool>(kw::get(kw::compact_mode, false, kw_args...));
+        cfg.emitter = static_cast<int>(kw::get(kw::emitter, 0, kw_args...));
+        cfg.cluster_kernel = static_cast<int>(kw::get(kw::cluster_kernel, 0, kw_args...));
+        cfg.exact_division = static_cast<bool>(kw::get(kw::exact_division, false, kw_args...));
+        cfg.events_on_cluster = static_cast<int>(kw::get(kw::events_on_cluster, 0, kw_args...));
+        cfg.batch_semantics = static_cast<int>(kw::get(kw::batch_semantics, 0, kw_args...));
         cfg.parallel_mode = static_cast<bool>(kw::get(kw::parallel_mode, false, kw_args...));
         cfg.device = static_cast<int>(kw::get(kw::device, 0, kw_args...));
         if constexpr (kw::has_v<kw::pars_tag, KwArgs...>) {

@@ -173,6 +173,14 @@ typedef struct {
     const double *time;    /* kw::time: NULL -> 0; n_time == 1 -> scalar splat; else batch_size values */
     size_t n_time;
     int device;            /* HIP device ordinal (MI355X extension) */
+    /* MI355X extensions; 0 = default everywhere (a zero-initialised structure behaves like the reference). */
+    int emitter;           /* code generator: 0 automatic, 1 unrolled, 2 wave-cluster, 3 table (the compact-mode analogue), 4 block */
+    int cluster_kernel;    /* wave-cluster generator: 0 automatic, 5 one lane per pair, 3 lane pairs, 2 pipelined, 1 first generation */
+    int exact_division;    /* != 0: correctly rounded quotients in the recurrences of the pair kernels (default: reciprocal forms, within 1 ulp) */
+    int events_on_cluster; /* 0 automatic; 1: integrators with events always use the one-system-per-lane steppers */
+    int batch_semantics;   /* propagate_for/until when a lane goes non-finite or max_steps is hit: 0 the reference's batch-wide
+                            * outcomes (src/taylor_adaptive_batch.cpp:1404-1407, :1462-1467, :1516), 1 always the lock-step loop,
+                            * 2 per-lane outcomes of the device-resident path (no snapshot, fully asynchronous) */
 } hy_tab_config;
 
 /* Constructor (taylor.hpp:905-941 -> finalise_ctor_impl(), src/taylor_adaptive_batch.cpp:78-427).

@@ -224,11 +224,14 @@ def test_callback_lockstep_matches_reference_loop():
 
 
 def test_nonfinite_state_is_reported_per_lane():
+    """batch_semantics = "per_lane" (the fully asynchronous device-resident path): a lane which produces a non-finite
+    state stops itself, the other lanes reach their final time. (The default reproduces the reference, where the whole
+    batch stops at that iteration: test_reference_batch_semantics.)"""
     x, v = hy.make_vars("x", "v")
     # x' = x^2 blows up in finite time for x0 > 0 (t* = 1/x0): lanes 0/1 explode before t = 3.
     sys = [(x, x * x), (v, -v)]
     st = [[1.0, 0.5, -1.0, 0.0], [1.0, 1.0, 1.0, 1.0]]
-    ta = hy.taylor_adaptive_batch(sys, st, 4)
+    ta = hy.taylor_adaptive_batch(sys, st, 4, batch_semantics="per_lane")
     ta.propagate_until(3.0, max_steps=20000)
     res = ta.propagate_res
     assert res[2][0] == OC.time_limit and res[3][0] == OC.time_limit
@@ -1225,17 +1228,18 @@ def test_contraction_off_build_meets_the_reference_tolerances(which, monkeypatch
 
 
 @pytest.mark.gpu
-def test_reference_batch_semantics_opt_in(monkeypatch):
-    """HEYOKA_AMD_REFERENCE_BATCH_SEMANTICS=1: a non-finite lane stops the whole batch at that iteration and max_steps
-    counts lock-step iterations of the batch (src/taylor_adaptive_batch.cpp:1404-1407, :1462-1467, :1516) - outcomes,
-    step counters and times of every lane are those of the oracle's lock-step loop, also for the healthy lanes of a batch
-    with a diverging one (by default each lane runs its own loop on the device: DESIGN.md, known deviations)."""
-    monkeypatch.setenv("HEYOKA_AMD_REFERENCE_BATCH_SEMANTICS", "1")
+@pytest.mark.parametrize("semantics", [None, "lockstep"])
+def test_reference_batch_semantics(semantics):
+    """Default (batch_semantics = "reference", device-resident lanes + fix-ups) and "lockstep" (always the lock-step
+    loop): a non-finite lane stops the whole batch at that iteration and max_steps counts iterations of the batch
+    (src/taylor_adaptive_batch.cpp:1404-1407, :1462-1467, :1516) - outcomes, step counters and times of every lane are
+    those of the oracle's lock-step loop, also for the healthy lanes of a batch with a diverging one. No environment
+    variable involved: the switch is a constructor argument (hy_tab_config::batch_semantics, kw::batch_semantics)."""
     x, v = hy.make_vars("x", "v")
     ox, ov = ho.var("x"), ho.var("v")
     st = np.array([[1.0, 0.5, -1.0, 0.0], [1.0, 1.0, 1.0, 1.0]])
     for max_steps, t_end in ((0, 3.0), (7, 3.0), (0, 0.4)):
-        ta = hy.taylor_adaptive_batch([(x, x * x), (v, -v)], st, 4)
+        ta = hy.taylor_adaptive_batch([(x, x * x), (v, -v)], st, 4, batch_semantics=semantics)
         ora = ho.OracleIntegrator([(ox, ox * ox), (ov, -1.0 * ov)], st, 4)
         ta.propagate_until(t_end, max_steps=max_steps)
         ora.propagate_until(t_end, max_steps=max_steps)
@@ -1249,10 +1253,28 @@ def test_reference_batch_semantics_opt_in(monkeypatch):
         assert np.all(np.isfinite(ta.state[:, ok_l]))
         assert np.all(ok_l) or not np.all(np.isfinite(ta.state[:, ~ok_l]))
         assert np.allclose(ta.state[:, ok_l], ora.state.reshape(2, 4)[:, ok_l], rtol=1e-10)
-    # Every lane reports the step limit (per-batch counter), unlike the per-lane default.
-    ta = hy.taylor_adaptive_batch([(x, x * x), (v, -v)], [[-1.0, -2.0, -1.0, 0.0], [1.0, 1.0, 1.0, 1.0]], 4)
+    # Every lane reports the step limit (per-batch counter) ...
+    ta = hy.taylor_adaptive_batch([(x, x * x), (v, -v)], [[-1.0, -2.0, -1.0, 0.0], [1.0, 1.0, 1.0, 1.0]], 4,
+                                  batch_semantics=semantics)
     ta.propagate_until(50.0, max_steps=3)
     assert all(r[0] == OC.step_limit for r in ta.propagate_res)
+    if semantics is None:
+        # (The device-side outcome array is brought in line too.)
+        import torch
+
+        assert bool(torch.all(torch.as_tensor(ta.device_array("outcome"), device="cuda") == int(OC.step_limit)))
+    # ... unlike the per-lane results of the fully asynchronous device-resident path (batch_semantics = "per_lane"): lanes
+    # which reach their final time report time_limit, the others the step limit.
+    st2 = np.array([[-1.0, -2.0, -1.0, 0.0], [1.0, 1.0, 1.0, 1.0]])
+    tb = hy.taylor_adaptive_batch([(x, x * x), (v, -v)], st2, 4, batch_semantics="per_lane")
+    tb.propagate_until([50.0, 50.0, 50.0, 1e-3], max_steps=3)
+    oc = [r[0] for r in tb.propagate_res]
+    assert oc[3] == OC.time_limit and all(o == OC.step_limit for o in oc[:3])
+    tc = hy.taylor_adaptive_batch([(x, x * x), (v, -v)], st2, 4, batch_semantics=semantics)
+    tc.propagate_until([50.0, 50.0, 50.0, 1e-3], max_steps=3)
+    assert all(r[0] == OC.step_limit for r in tc.propagate_res)
+    assert [r[3] for r in tc.propagate_res] == [r[3] for r in tb.propagate_res]
+    assert np.array_equal(tc.state, tb.state) and np.array_equal(tc.time, tb.time)
 
 
 @pytest.mark.gpu
