@@ -54,90 +54,88 @@ expression r2_of(const expression &dx, const expression &dy, const expression &d
 
 } // namespace
 
+// Newtonian N-body right-hand side (the model of src/model/nbody.cpp:53-174; what must agree with it is the RESULT -
+// the expression of every acceleration term and the order of the terms inside each sum, since the decomposition, its CSE
+// and the sizes pinned by test/model_nbody.cpp follow from them - not the text).
+//
+// Built axis by axis: bodies carry pos[3] / vel[3], every unordered pair {i < j} with a massive first body contributes one
+// term per axis to the acceleration lists of its two bodies, in the order of the pairs. Two forms of the pair term:
+//  * "scaled" (both bodies massive, m_j and G numerical): the term on i is d * (G m_j r^-3) and the term on j is that very
+//    expression times -(m_i / m_j), so that the constants fold into two numbers per pair;
+//  * general: the terms are d * (-m_i (G r^-3)) on j and, if j is massive, d * (m_j (G r^-3)) on i.
 std::vector<std::pair<expression, expression>> nbody_impl(std::uint32_t n, const expression &Gconst,
                                                           const std::vector<expression> &masses)
 {
     nbody_checks(n, masses);
 
-    std::vector<expression> x, y, z, vx, vy, vz;
-    for (std::uint32_t i = 0; i < n; ++i) {
-        const auto s = std::to_string(i);
-        x.emplace_back("x_" + s);
-        y.emplace_back("y_" + s);
-        z.emplace_back("z_" + s);
-        vx.emplace_back("vx_" + s);
-        vy.emplace_back("vy_" + s);
-        vz.emplace_back("vz_" + s);
+    static constexpr const char *axis_name[3] = {"x_", "y_", "z_"};
+    struct body {
+        expression pos[3], vel[3];
+        std::vector<expression> acc[3]; // terms of the acceleration, per axis
+    };
+    std::vector<body> bodies(n);
+    for (std::uint32_t b = 0; b < n; ++b) {
+        for (int c = 0; c < 3; ++c) {
+            const auto name = axis_name[c] + std::to_string(b);
+            bodies[b].pos[c] = expression{name};
+            bodies[b].vel[c] = expression{"v" + name};
+        }
     }
 
-    std::vector<std::pair<expression, expression>> retval;
-    std::vector<std::vector<expression>> x_acc(n), y_acc(n), z_acc(n);
-
     const auto n_massive = static_cast<std::uint32_t>(masses.size());
+    const auto is_massive = [&](std::uint32_t b) { return b < n_massive; };
+    // A pair takes the scaled form when the mass of its second body is a non-zero number and G is a number too.
+    const auto scaled_form = [&](std::uint32_t j) {
+        return is_massive(j) && masses[j].is_number() && masses[j].num() != 0 && Gconst.is_number();
+    };
 
     for (std::uint32_t i = 0; i < n_massive; ++i) {
-        retval.emplace_back(x[i], vx[i]);
-        retval.emplace_back(y[i], vy[i]);
-        retval.emplace_back(z[i], vz[i]);
-
         for (std::uint32_t j = i + 1u; j < n; ++j) {
-            const auto diff_x = x[j] - x[i];
-            const auto diff_y = y[j] - y[i];
-            const auto diff_z = z[j] - z[i];
+            auto &bi = bodies[i];
+            auto &bj = bodies[j];
+            expression d[3];
+            for (int c = 0; c < 3; ++c) {
+                d[c] = bj.pos[c] - bi.pos[c];
+            }
+            const auto inv_r3 = pow(r2_of(d[0], d[1], d[2]), expression{-3. / 2});
 
-            const auto r_m3 = pow(r2_of(diff_x, diff_y, diff_z), expression{-3. / 2});
-
-            const auto j_massive = j < n_massive;
-            // Grouping that maximises constant folding, when masses and G are numbers.
-            const auto opt_grouping
-                = j_massive && masses[j].is_number() && masses[j].num() != 0 && Gconst.is_number();
-
-            if (opt_grouping) {
-                const auto fac_j = Gconst * masses[j] * r_m3;
-                const auto c_ij = -masses[i] / masses[j];
-
-                // j on i.
-                x_acc[i].push_back(diff_x * fac_j);
-                y_acc[i].push_back(diff_y * fac_j);
-                z_acc[i].push_back(diff_z * fac_j);
-
-                // i on j.
-                x_acc[j].push_back(x_acc[i].back() * c_ij);
-                y_acc[j].push_back(y_acc[i].back() * c_ij);
-                z_acc[j].push_back(z_acc[i].back() * c_ij);
+            if (scaled_form(j)) {
+                const auto on_i = Gconst * masses[j] * inv_r3;
+                const auto reaction = -masses[i] / masses[j];
+                for (int c = 0; c < 3; ++c) {
+                    const auto term = d[c] * on_i;
+                    bi.acc[c].push_back(term);
+                    bj.acc[c].push_back(term * reaction);
+                }
             } else {
-                const auto G_r_m3 = Gconst * r_m3;
-
-                const auto fac_i = -masses[i] * G_r_m3;
-                x_acc[j].push_back(diff_x * fac_i);
-                y_acc[j].push_back(diff_y * fac_i);
-                z_acc[j].push_back(diff_z * fac_i);
-
-                if (j_massive) {
-                    const auto fac_j = masses[j] * G_r_m3;
-                    x_acc[i].push_back(diff_x * fac_j);
-                    y_acc[i].push_back(diff_y * fac_j);
-                    z_acc[i].push_back(diff_z * fac_j);
+                const auto g_inv_r3 = Gconst * inv_r3;
+                const auto on_j = -masses[i] * g_inv_r3;
+                for (int c = 0; c < 3; ++c) {
+                    bj.acc[c].push_back(d[c] * on_j);
+                }
+                if (is_massive(j)) {
+                    const auto on_i = masses[j] * g_inv_r3;
+                    for (int c = 0; c < 3; ++c) {
+                        bi.acc[c].push_back(d[c] * on_i);
+                    }
                 }
             }
         }
-
-        retval.emplace_back(vx[i], sum(x_acc[i]));
-        retval.emplace_back(vy[i], sum(y_acc[i]));
-        retval.emplace_back(vz[i], sum(z_acc[i]));
     }
 
-    for (auto i = n_massive; i < n; ++i) {
-        retval.emplace_back(x[i], vx[i]);
-        retval.emplace_back(y[i], vy[i]);
-        retval.emplace_back(z[i], vz[i]);
-
-        retval.emplace_back(vx[i], sum(x_acc[i]));
-        retval.emplace_back(vy[i], sum(y_acc[i]));
-        retval.emplace_back(vz[i], sum(z_acc[i]));
+    // x' = v for the three axes of a body, then v' = sum of its acceleration terms; bodies in order (the massive ones
+    // come first by construction of the masses argument).
+    std::vector<std::pair<expression, expression>> sys;
+    sys.reserve(static_cast<std::size_t>(n) * 6u);
+    for (auto &b : bodies) {
+        for (int c = 0; c < 3; ++c) {
+            sys.emplace_back(b.pos[c], b.vel[c]);
+        }
+        for (int c = 0; c < 3; ++c) {
+            sys.emplace_back(b.vel[c], sum(b.acc[c]));
+        }
     }
-
-    return retval;
+    return sys;
 }
 
 expression nbody_potential_impl(std::uint32_t n, const expression &Gconst, const std::vector<expression> &masses)

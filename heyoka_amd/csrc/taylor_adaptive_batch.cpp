@@ -173,14 +173,8 @@ struct tab_core::impl {
         return !tes.empty() || !ntes.empty();
     }
     void step_with_events(const std::vector<double> &lims, bool wtc);
-    void step_with_events_host(const std::vector<double> &lims);
     // (lims == nullptr: the step limits are already in d_lim - device-driven loops.)
     void step_with_events_device(const std::vector<double> *lims);
-    [[nodiscard]] static bool events_host_logic()
-    {
-        const char *ev = std::getenv("HEYOKA_AMD_EVENTS_HOST_LOGIC");
-        return ev != nullptr && std::atoi(ev) != 0;
-    }
     void ensure_event_buffers();
     void launch_event_stepper(const std::vector<double> *lims);
     unsigned launch_event_detection(bool device_g_eps);
@@ -195,20 +189,6 @@ struct tab_core::impl {
     void cooldowns_to_host() const;
     void cooldowns_to_device();
     mutable device_buffer d_ev_cursor, d_ev_rec, d_ev_upd;
-    // One lock-step sweep for the propagate_*() loops: afterwards step_res and the times are on the host.
-    void lockstep_sweep(const std::vector<double> &lims, bool wtc)
-    {
-        if (has_events()) {
-            step_with_events(lims, wtc);
-            fetch_step_res();
-            times_to_host();
-        } else {
-            run_step(lims, wtc);
-            fetch_step_res();
-            times_to_host();
-        }
-    }
-
     [[nodiscard]] bool is_cluster() const
     {
         // NOTE: true whenever the stepper does not need the tc buffer as its jet scratch (cluster / table
@@ -1152,12 +1132,7 @@ unsigned tab_core::impl::launch_event_detection(bool device_g_eps)
 void tab_core::impl::step_with_events(const std::vector<double> &lims, bool wtc)
 {
     (void)wtc; // The Taylor coefficients are always written by the stepper with events (:756-757).
-    // HEYOKA_AMD_EVENTS_HOST_LOGIC=1: the per-lane bookkeeping of every lane on the host (the first implementation).
-    if (events_host_logic()) {
-        step_with_events_host(lims);
-    } else {
-        step_with_events_device(&lims);
-    }
+    step_with_events_device(&lims);
 }
 
 namespace
@@ -1396,186 +1371,6 @@ void tab_core::impl::step_with_events_device(const std::vector<double> *lims)
                                          "time coordinate of the integrator at the batch index "
                                          + std::to_string(i) + " - this is not supported");
             }
-        }
-    }
-}
-
-// The first implementation: every lane goes through the host (kept as a cross-check, HEYOKA_AMD_EVENTS_HOST_LOGIC=1).
-void tab_core::impl::step_with_events_host(const std::vector<double> &lims)
-{
-    const auto n = static_cast<std::size_t>(N);
-    const auto dsz = sizeof(double);
-    const auto n_te = static_cast<std::uint32_t>(tes.size());
-    constexpr auto maxd = max_detected_per_lane;
-
-    before_kernel();
-    ensure_event_buffers();
-    cooldowns_to_host();
-
-    // 1. Stepper with events.
-    launch_event_stepper(&lims);
-
-    // 2. Maximum error on the Taylor series of the event equations (:744-767).
-    std::vector<double> mas(n), g_eps(n), hs(n);
-    d_mas.download(mas.data(), n * dsz, stream);
-    d_lasth.download(hs.data(), n * dsz, stream);
-    constexpr auto eps = std::numeric_limits<double>::epsilon();
-    for (std::size_t i = 0; i < n; ++i) {
-        if (std::isfinite(mas[i])) {
-            const auto max_r_size = (mas[i] < 1) ? tol : (tol * mas[i]);
-            g_eps[i] = (max_r_size < eps * mas[i]) ? (eps * mas[i]) : max_r_size;
-        } else {
-            g_eps[i] = std::numeric_limits<double>::infinity();
-        }
-    }
-    d_geps.upload(g_eps.data(), n * dsz, stream);
-
-    // 3. Event detection on the device.
-    cd_host_newer = true;
-    cooldowns_to_device();
-    cd_host_newer = true; // (the host copy stays authoritative in this variant)
-    launch_event_detection(false);
-    std::vector<unsigned> counts(2u * n);
-    std::vector<double> ed_out(2u * n * maxd * 4u);
-    unsigned flags[1] = {0};
-    d_ed_counts.download(counts.data(), counts.size() * sizeof(unsigned), stream);
-    d_ed_flags.download(flags, sizeof(flags), stream);
-    if (std::any_of(counts.begin(), counts.end(), [](unsigned c) { return c != 0u; })) {
-        d_ed_out.download(ed_out.data(), ed_out.size() * dsz, stream);
-    }
-    report_ed_failures(ed_failures, flags[0]);
-    (void)n_te;
-
-    // Per-lane lists, sorted by the absolute value of the trigger time (:771-778).
-    std::vector<std::vector<detected_event>> d_tes(n), d_ntes(n);
-    const auto fetch = [&](std::size_t cls, std::size_t i, std::vector<detected_event> &out) {
-        for (unsigned c = 0; c < counts[cls * n + i]; ++c) {
-            const auto *r = ed_out.data() + ((cls * n + i) * maxd + c) * 4u;
-            out.push_back({static_cast<std::uint32_t>(r[0]), r[1], static_cast<int>(r[2]), r[3]});
-        }
-        std::stable_sort(out.begin(), out.end(),
-                         [](const auto &x, const auto &y) { return std::abs(x.root) < std::abs(y.root); });
-    };
-    for (std::size_t i = 0; i < n; ++i) {
-        fetch(0, i, d_tes[i]);
-        fetch(1, i, d_ntes[i]);
-        if (!d_tes[i].empty()) {
-            // Truncate the step at the first terminal event.
-            hs[i] = d_tes[i][0].root;
-        }
-    }
-
-    // 4. State update via dense output at the final step sizes (:781), then back to the host: the callbacks may
-    //    read and write state and parameters.
-    d_douth.upload(hs.data(), n * dsz, stream);
-    dmod->launch_dout(d_state.as<double>(), d_tc.as<double>(), d_douth.as<double>(), N);
-    d_state.download(state.data(), state.size() * dsz, stream);
-    tc_dev_newer = true;
-    dev_newer = false;
-    // NOTE: from here on the host copies are authoritative (they are uploaded again by the next kernel).
-    host_newer = true;
-    step_res_dev_newer = false;
-    lasth_dev_newer = false;
-
-    std::vector<std::pair<std::uint32_t, std::exception_ptr>> cb_eptrs;
-    // NOTE: the new times and the non-finite flags of ALL the lanes are taken before any callback runs (the reference
-    // snapshots m_time_copy / m_nf_detected first, src/taylor_adaptive_batch.cpp:825-835, :844): a callback of lane i
-    // which touches the time or the state of a later lane neither changes that lane's time update nor defeats the
-    // "callback altered the time" check.
-    std::vector<double> thi_copy(n), tlo_copy(n);
-    std::vector<char> nf_all(n, 0);
-    for (std::uint32_t i = 0; i < N; ++i) {
-        const auto h = hs[i];
-        const auto new_time = dfloat(time_hi[i], time_lo[i]) + h;
-        time_hi[i] = new_time.hi;
-        time_lo[i] = new_time.lo;
-        thi_copy[i] = new_time.hi;
-        tlo_copy[i] = new_time.lo;
-        last_h[i] = h;
-        bool nf = !isfinite(new_time);
-        for (std::uint32_t v = 0; v < dim && !nf; ++v) {
-            nf = !std::isfinite(state[static_cast<std::size_t>(v) * n + i]);
-        }
-        nf_all[i] = nf ? 1 : 0;
-    }
-    for (std::uint32_t i = 0; i < N; ++i) {
-        const auto h = hs[i];
-        const auto new_time = dfloat(thi_copy[i], tlo_copy[i]);
-        const bool nf = nf_all[i] != 0;
-        if (nf) {
-            step_res[i] = std::tuple{taylor_outcome::err_nf_state, h};
-            continue;
-        }
-
-        // Update the cooldowns (:822-835).
-        for (auto &cd : te_cooldowns[i]) {
-            if (cd) {
-                const auto tmp = cd->first + h;
-                if (std::abs(tmp) >= cd->second) {
-                    cd.reset();
-                } else {
-                    cd->first = tmp;
-                }
-            }
-        }
-
-        // Non-terminal events triggering before the first terminal event (:837-871).
-        bool nt_cb_exception = false;
-        for (const auto &ev : d_ntes[i]) {
-            if (!d_tes[i].empty() && !(std::abs(ev.root) < std::abs(h))) {
-                break;
-            }
-            try {
-                ntes[ev.idx].callback(cb_ctx, static_cast<double>(new_time - last_h[i] + ev.root), ev.d_sgn, i);
-            } catch (...) {
-                cb_eptrs.emplace_back(i, std::current_exception());
-                nt_cb_exception = true;
-                break;
-            }
-        }
-        if (nt_cb_exception) {
-            continue;
-        }
-
-        // The first terminal event (:875-908).
-        bool te_cb_ret = false;
-        if (!d_tes[i].empty()) {
-            const auto &ev = d_tes[i][0];
-            auto &te = tes[ev.idx];
-            if (te.cooldown >= 0) {
-                te_cooldowns[i][ev.idx].emplace(0., te.cooldown);
-            } else {
-                // taylor_deduce_cooldown(), src/detail/event_detection.cpp:519-550.
-                auto cd = g_eps[i] / ev.abs_der * 10;
-                if (!std::isfinite(cd)) {
-                    cd = 0;
-                }
-                te_cooldowns[i][ev.idx].emplace(0., cd);
-            }
-            if (te.callback) {
-                try {
-                    te_cb_ret = te.callback(cb_ctx, ev.d_sgn, i);
-                } catch (...) {
-                    cb_eptrs.emplace_back(i, std::current_exception());
-                    continue;
-                }
-            }
-            const auto ev_idx = static_cast<std::int64_t>(ev.idx);
-            step_res[i] = std::tuple{static_cast<taylor_outcome>(te_cb_ret ? ev_idx : (-ev_idx - 1)), h};
-        } else {
-            step_res[i] = std::tuple{h == lims[i] ? taylor_outcome::time_limit : taylor_outcome::success, h};
-        }
-    }
-
-    if (!cb_eptrs.empty()) {
-        throw_callback_exceptions(cb_eptrs);
-    }
-    for (std::uint32_t i = 0; i < N; ++i) {
-        const auto same = [](double x, double y) { return x == y || (std::isnan(x) && std::isnan(y)); };
-        if (!same(time_hi[i], thi_copy[i]) || !same(time_lo[i], tlo_copy[i])) {
-            throw std::runtime_error("The invocation of one or more event callbacks resulted in the alteration of the "
-                                     "time coordinate of the integrator at the batch index "
-                                     + std::to_string(i) + " - this is not supported");
         }
     }
 }
@@ -1867,7 +1662,6 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
                                               d.time_lo);
     }
     std::vector<int> t_dir(N);
-    std::vector<std::size_t> ts_count(N, 0);
     std::vector<double> min_abs_h(N, std::numeric_limits<double>::infinity()), max_abs_h(N, 0.);
     std::vector<double> cur_max(N);
     for (std::uint32_t i = 0; i < N; ++i) {
@@ -1876,8 +1670,8 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
     const auto pinf = std::numeric_limits<double>::infinity();
     std::size_t iter_counter = 0;
 
-    if ((!d.has_events() || !impl::events_host_logic()) && std::getenv("HEYOKA_AMD_LOCKSTEP_HOST_LOOP") == nullptr) {
-        // Device-driven loop: the per-lane bookkeeping runs in a post-step kernel, the host reads two counters per
+    {
+        // Device-driven loop: the per-lane bookkeeping runs in a post-step kernel, the host reads three counters per
         // sweep, runs the callback and (for the continuous output) appends the coefficients device-to-device.
         d.ensure_device();
         d.ensure_tc();
@@ -1969,91 +1763,6 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
         }
     }
 
-    while (true) {
-        for (std::uint32_t i = 0; i < N; ++i) {
-            const auto mdt = max_delta_ts.empty() ? pinf : max_delta_ts[i];
-            const auto dt_limit = t_dir[i] != 0 ? std::min(dfloat(mdt), rem[i]) : std::max(dfloat(-mdt), rem[i]);
-            cur_max[i] = static_cast<double>(dt_limit);
-        }
-
-        d.lockstep_sweep(cur_max, wtc); // NOTE: the state stays on the device (fetched lazily by the getters).
-
-        std::uint32_t n_done = 0;
-        bool nfs_detected = false, ste_detected = false;
-        for (std::uint32_t i = 0; i < N; ++i) {
-            const auto [oc, h] = d.step_res[i];
-            if (oc == taylor_outcome::err_nf_state) {
-                nfs_detected = true;
-            } else {
-                ts_count[i] += static_cast<std::size_t>(h != 0);
-                if (oc == taylor_outcome::success) {
-                    const auto abs_h = std::abs(h);
-                    min_abs_h[i] = std::min(min_abs_h[i], abs_h);
-                    max_abs_h[i] = std::max(max_abs_h[i], abs_h);
-                }
-                // Stopping terminal event (:1411).
-                ste_detected = ste_detected || (oc > taylor_outcome::success && oc < taylor_outcome{0});
-                const auto cur_done = (h == static_cast<double>(rem[i]));
-                n_done += cur_done;
-                if (cur_done) {
-                    rem[i] = dfloat(0.);
-                } else {
-                    rem[i] = dfloat(tf_hi[i], tf_lo[i]) - dfloat(d.time_hi[i], d.time_lo[i]);
-                }
-            }
-            d.prop_res[i] = std::tuple{oc, min_abs_h[i], max_abs_h[i], ts_count[i]};
-        }
-        d.prop_res_dev_newer = false;
-
-        const auto make_c_out = [&]() {
-            if (cob) {
-                d.last_c_out = cob->finish(t_dir);
-            }
-        };
-
-        if (nfs_detected) {
-            make_c_out();
-            return;
-        }
-
-        // Update the continuous output data (:1470).
-        if (cob) {
-            cob->append(d.d_tc.as<double>(), d.time_hi, d.time_lo);
-        }
-
-        ++iter_counter;
-
-        if (cb) {
-            const auto thi_copy = d.time_hi;
-            const auto tlo_copy = d.time_lo;
-            const auto ret_cb = cb();
-            d.times_to_host(); // NOTE: the state stays on the device (fetched lazily by the getters).
-            if (d.time_hi != thi_copy || d.time_lo != tlo_copy) {
-                throw std::runtime_error("The invocation of the callback passed to propagate_until() resulted in the "
-                                         "alteration of the time coordinate of the integrator - this is not supported");
-            }
-            if (!ret_cb) {
-                for (auto &r : d.prop_res) {
-                    std::get<0>(r) = taylor_outcome::cb_stop;
-                }
-                make_c_out();
-                return;
-            }
-        }
-
-        if (n_done == N || ste_detected) {
-            make_c_out();
-            return;
-        }
-
-        if (iter_counter == max_steps) {
-            for (auto &r : d.prop_res) {
-                std::get<0>(r) = taylor_outcome::step_limit;
-            }
-            make_c_out();
-            return;
-        }
-    }
 }
 
 std::optional<c_out_core> tab_core::take_c_output()
@@ -2220,7 +1929,7 @@ extern "C" __global__ void __launch_bounds__(256) hy_grid_post(const hy_grid_arg
 void tab_core::propagate_grid_device_loop(const std::vector<double> &grid, std::vector<double> &retval,
                                           const std::vector<dfloat> &rem, const std::vector<int> &t_dir,
                                           const std::vector<double> &max_delta_ts, std::size_t max_steps,
-                                          double *d_out)
+                                          double *d_out, const cb_t &cb)
 {
     auto &d = *m_impl;
     const auto N = d.N;
@@ -2297,6 +2006,22 @@ void tab_core::propagate_grid_device_loop(const std::vector<double> &grid, std::
             break;
         }
         ++iter_counter;
+        if (cb) {
+            // The step callback, once per sweep (src/taylor_adaptive_batch.cpp:2003-2040); it may read or write the state
+            // through the lazily synchronised mirrors, but not move the time coordinate (generation counter).
+            d.prop_res_dev_newer = true;
+            d.step_res_dev_newer = true;
+            const auto gen = d.time_gen;
+            const auto ret_cb = cb();
+            if (d.time_gen != gen) {
+                throw std::runtime_error("The invocation of the callback passed to propagate_grid() resulted in the "
+                                         "alteration of the time coordinate of the integrator - this is not supported");
+            }
+            if (!ret_cb) {
+                d.prop_res_override = taylor_outcome::cb_stop;
+                break;
+            }
+        }
         // (cnt[2]: lanes stopped by a terminal event - they interrupt the propagation of the whole batch.)
         if (cnt[0] == 0u || cnt[2] != 0u) {
             break;
@@ -2442,125 +2167,10 @@ std::vector<double> tab_core::propagate_grid(std::vector<double> grid, std::size
         t_dir[i] = rem[i] >= dfloat(0.);
     }
 
-    if (d_out != nullptr
-        || (!cb && (!d.has_events() || !impl::events_host_logic()) && std::getenv("HEYOKA_AMD_GRID_HOST_LOOP") == nullptr)) {
-        // Device-resident lock-step loop: the step kernel and a post-step kernel (bookkeeping of the reference's
-        // loop, dense output at the grid points covered by the step, next step limit) alternate without any
-        // per-lane host work; the host only reads two counters per sweep.
-        propagate_grid_device_loop(grid, retval, rem, t_dir, max_delta_ts, max_steps, d_out);
-        return retval;
-    }
-    std::size_t iter_counter = 0;
-    std::vector<std::size_t> ts_count(N, 0), cur_grid_idx(N, 1);
-    std::vector<double> min_abs_h(N, pinf), max_abs_h(N, 0.);
-    std::vector<unsigned> dflags(N);
-    const auto cont_cond = [&]() {
-        return std::any_of(cur_grid_idx.begin(), cur_grid_idx.end(), [&](auto idx) { return idx < n_grid_points; });
-    };
-    const auto cb_time_errmsg = "The invocation of the callback passed to propagate_grid() resulted in the alteration "
-                                "of the time coordinate of the integrator - this is not supported";
-
-    while (cont_cond()) {
-        const auto &lh = get_last_h();
-        for (std::uint32_t i = 0; i < N; ++i) {
-            const dfloat cur_time(d.time_hi[i], d.time_lo[i]), cmp = cur_time - lh[i];
-            t0[i] = std::min(cur_time, cmp);
-            t1[i] = std::max(cur_time, cmp);
-        }
-        std::fill(dflags.begin(), dflags.end(), 1u);
-        while (true) {
-            std::uint32_t counter = 0;
-            for (std::uint32_t i = 0; i < N; ++i) {
-                const auto gidx = cur_grid_idx[i];
-                if (dflags[i] != 0u && gidx < n_grid_points) {
-                    const auto idx = gidx * N + i;
-                    const auto d_avail = (dfloat(gp[idx]) >= t0[i] && dfloat(gp[idx]) <= t1[i]) || (rem[i] == dfloat(0.));
-                    dflags[i] = d_avail ? 1u : 0u;
-                    counter += d_avail ? 1u : 0u;
-                    pgrid_tmp[i] = gp[idx];
-                } else {
-                    dflags[i] = 0;
-                }
-            }
-            if (counter == 0u) {
-                break;
-            }
-            const auto &dout = update_d_output(pgrid_tmp, false);
-            for (std::uint32_t i = 0; i < N; ++i) {
-                if (dflags[i] != 0u) {
-                    const auto gidx = cur_grid_idx[i];
-                    for (std::uint32_t j = 0; j < dim; ++j) {
-                        retval[gidx * N * dim + static_cast<std::size_t>(j) * N + i] = dout[static_cast<std::size_t>(j) * N + i];
-                    }
-                    ++cur_grid_idx[i];
-                }
-            }
-            if (!cont_cond()) {
-                break;
-            }
-        }
-        if (!cont_cond()) {
-            break;
-        }
-        if (std::any_of(d.prop_res.begin(), d.prop_res.end(), [](const auto &t) {
-                const auto oc = std::get<0>(t);
-                // NOTE: stopping terminal events interrupt the propagation as well (:1903-1908).
-                return oc == taylor_outcome::cb_stop || (oc > taylor_outcome::success && oc < taylor_outcome{0})
-                       || oc == taylor_outcome::step_limit;
-            })) {
-            break;
-        }
-        for (std::uint32_t i = 0; i < N; ++i) {
-            const auto dt_limit
-                = t_dir[i] != 0 ? std::min(dfloat(max_delta_ts[i]), rem[i]) : std::max(dfloat(-max_delta_ts[i]), rem[i]);
-            pgrid_tmp[i] = static_cast<double>(dt_limit);
-        }
-        d.lockstep_sweep(pgrid_tmp, true); // NOTE: the state stays on the device (fetched lazily by the getters).
-
-        bool nfs_detected = false;
-        for (std::uint32_t i = 0; i < N; ++i) {
-            const auto [oc, h] = d.step_res[i];
-            if (oc == taylor_outcome::err_nf_state) {
-                nfs_detected = true;
-            } else {
-                ts_count[i] += static_cast<std::size_t>(h != 0);
-                if (oc == taylor_outcome::success) {
-                    const auto abs_h = std::abs(h);
-                    min_abs_h[i] = std::min(min_abs_h[i], abs_h);
-                    max_abs_h[i] = std::max(max_abs_h[i], abs_h);
-                }
-                if (h == static_cast<double>(rem[i])) {
-                    rem[i] = dfloat(0.);
-                } else {
-                    rem[i] = dfloat(gp[(n_grid_points - 1u) * N + i]) - dfloat(d.time_hi[i], d.time_lo[i]);
-                }
-            }
-            d.prop_res[i] = std::tuple{oc, min_abs_h[i], max_abs_h[i], ts_count[i]};
-        }
-        d.prop_res_dev_newer = false;
-        if (nfs_detected) {
-            break;
-        }
-        ++iter_counter;
-        bool cb_ok = true;
-        if (cb) {
-            const auto thi_copy = d.time_hi, tlo_copy = d.time_lo;
-            cb_ok = cb();
-            d.times_to_host(); // NOTE: the state stays on the device (fetched lazily by the getters).
-            if (d.time_hi != thi_copy || d.time_lo != tlo_copy) {
-                throw std::runtime_error(cb_time_errmsg);
-            }
-        }
-        if (!cb_ok) {
-            for (auto &t : d.prop_res) {
-                std::get<0>(t) = taylor_outcome::cb_stop;
-            }
-        } else if (iter_counter == max_steps) {
-            for (auto &t : d.prop_res) {
-                std::get<0>(t) = taylor_outcome::step_limit;
-            }
-        }
-    }
+    // Device-resident lock-step loop: the step kernel and a post-step kernel (bookkeeping of the reference's loop, dense
+    // output at the grid points covered by the step, next step limit) alternate without any per-lane host work; the host
+    // reads three counters per sweep and runs the callback, if any.
+    propagate_grid_device_loop(grid, retval, rem, t_dir, max_delta_ts, max_steps, d_out, cb);
     return retval;
 }
 

@@ -184,11 +184,11 @@ public:
     std::vector<double> propagate_grid(std::vector<double> grid, std::size_t max_steps,
                                        const std::vector<double> &max_delta_ts, const cb_t &cb,
                                        double *d_out = nullptr);
-    // Device-resident loop of propagate_grid() (no callback): see taylor_adaptive_batch.cpp.
+    // Device-resident loop of propagate_grid(): see taylor_adaptive_batch.cpp.
     void propagate_grid_device_loop(const std::vector<double> &grid, std::vector<double> &retval,
                                     const std::vector<dfloat> &rem, const std::vector<int> &t_dir,
                                     const std::vector<double> &max_delta_ts, std::size_t max_steps,
-                                    double *d_out = nullptr);
+                                    double *d_out, const cb_t &cb);
     // ---- events (reference: taylor.hpp:1008-1014) ----
     [[nodiscard]] bool with_events() const;
     [[nodiscard]] const std::vector<core_t_event> &get_t_events() const;

@@ -97,6 +97,25 @@ int main(int argc, char **argv)
     auto tad = taylor_adaptive_batch<double>{sys2, std::vector<double>(12u * 8u, 0.), 8u, kw::high_accuracy = true,
                                              kw::tol = 1e-12, kw::compact_mode = false, kw::fast_math = false};
     REQUIRE(tad.get_order() == 15u && tad.get_high_accuracy());
+    // MI355X extensions of the keyword arguments: code generator, cluster kernel, exact quotients, outcome semantics
+    // (tab_core::config; the same fields as hy_tab_config) - validated at construction.
+    {
+        auto oss = model::nbody(3, kw::masses = {1., 1e-3, 1e-4});
+        auto t5 = taylor_adaptive_batch<double>{oss, std::vector<double>(18u * 4u, 0.), 4u};
+        auto t3 = taylor_adaptive_batch<double>{oss, std::vector<double>(18u * 4u, 0.), 4u, kw::cluster_kernel = 3,
+                                                kw::exact_division = true, kw::batch_semantics = 2};
+        auto tt = taylor_adaptive_batch<double>{oss, std::vector<double>(18u * 4u, 0.), 4u, kw::emitter = 3};
+        REQUIRE(t3.core().get_codegen_info().find("v3") != std::string::npos);
+        REQUIRE(tt.core().get_codegen_info().rfind("table", 0) == 0u);
+        REQUIRE(t5.core().get_codegen_info() != t3.core().get_codegen_info());
+        bool thrown = false;
+        try {
+            taylor_adaptive_batch<double>{oss, std::vector<double>(18u * 4u, 0.), 4u, kw::batch_semantics = 7};
+        } catch (const std::invalid_argument &e) {
+            thrown = std::string(e.what()).find("Invalid batch semantics") != std::string::npos;
+        }
+        REQUIRE(thrown);
+    }
 
     // Default-constructed continuous output (test/c_output.cpp:306-331).
     {

@@ -814,39 +814,56 @@ def test_kepE_stark_problem_known_answer_on_gpu(golden):
     assert np.max(np.abs(s[3] - so[3])) <= 1e5 * EPS * np.max(np.abs(so[3]))
 
 
-def test_propagate_grid_device_loop_equals_host_loop():
-    """The device-resident propagate_grid() loop (step kernel + post-step kernel, no per-lane host work) gives
-    the same samples, states and propagate_res as the host-driven transcription of the reference's loop
-    (HEYOKA_AMD_GRID_HOST_LOOP=1), forward and backward, with max_delta_t and max_steps."""
-    import os
-
+def test_propagate_grid_device_loop_with_and_without_callback():
+    """The device-resident propagate_grid() loop (step kernel + post-step kernel, no per-lane host work; the only
+    implementation: the host transcription of the reference's loop is gone): samples against independent
+    propagate_until() calls to the grid times, forward and backward, with max_delta_t, max_steps (step_limit, NaN rows)
+    and with a step callback - one invocation per sweep, samples bit-identical to the run without callback, cb_stop."""
     n = 300
     st = configs.outer_ss_state(n, perturb=1e-6, seed=9)
     M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    sysd = hy.model.nbody(6, masses=M, Gconst=G)
     grid = np.outer(np.linspace(0.0, 30.0, 13), np.ones(n)) * (1.0 + 0.01 * np.arange(n) / n)
-    res = {}
-    for name in ("device", "host"):
-        if name == "host":
-            os.environ["HEYOKA_AMD_GRID_HOST_LOOP"] = "1"
-        try:
-            ta = hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True)
-            _, out = ta.propagate_grid(grid, max_delta_t=3.0)
-            pr1 = ta.propagate_res
-            _, out_b = ta.propagate_grid(grid[::-1].copy())
-            pr2 = ta.propagate_res
-            tb = hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True)
-            _, out_c = tb.propagate_grid(grid, max_steps=3)
-            res[name] = (out, pr1, out_b, pr2, ta.state.copy(), out_c, tb.propagate_res)
-        finally:
-            os.environ.pop("HEYOKA_AMD_GRID_HOST_LOOP", None)
-    d, h = res["device"], res["host"]
-    assert np.array_equal(d[0], h[0]) and np.array_equal(d[2], h[2]) and np.array_equal(d[4], h[4])
-    assert d[1] == h[1] and d[3] == h[3] and d[6] == h[6]
-    assert np.array_equal(np.isnan(d[5]), np.isnan(h[5])) and np.array_equal(np.nan_to_num(d[5]), np.nan_to_num(h[5]))
-    assert all(r[0] == OC.step_limit for r in d[6]) and np.isnan(d[5][-1]).all()
-    assert all(r[0] == OC.time_limit for r in d[1]) and not np.isnan(d[0]).any()
-    # Back at the start after the backward grid: energy-level agreement with the initial state.
-    assert rel_err(d[4], st) <= 1e-9
+    ta = hy.taylor_adaptive_batch(sysd, st, n, high_accuracy=True)
+    _, out = ta.propagate_grid(grid, max_delta_t=3.0)
+    pr1 = ta.propagate_res
+    assert all(r[0] == OC.time_limit for r in pr1) and not np.isnan(out).any()
+    # Against independent propagations to three of the grid times.
+    tu = hy.taylor_adaptive_batch(sysd, st, n, high_accuracy=True)
+    for k in (4, 9, 12):
+        tu.propagate_until(grid[k])
+        assert rel_err(out[k], tu.state) <= 1e5 * EPS
+    # With a callback: one call per sweep, same samples bit for bit.
+    calls = []
+    tb = hy.taylor_adaptive_batch(sysd, st, n, high_accuracy=True)
+    _, out_cb = tb.propagate_grid(grid, max_delta_t=3.0, callback=lambda t: calls.append(float(t.time[0])) or True)
+    assert np.array_equal(out_cb, out) and tb.propagate_res == pr1 and np.array_equal(tb.state, ta.state)
+    assert len(calls) >= max(r[3] for r in pr1) and calls == sorted(calls)
+    # Backward, back to the start: energy-level agreement with the initial state.
+    _, out_b = ta.propagate_grid(grid[::-1].copy())
+    assert all(r[0] == OC.time_limit for r in ta.propagate_res) and rel_err(ta.state, st) <= 1e-9
+    assert rel_err(out_b[::-1][4], out[4]) <= 1e-9
+    # max_steps: step_limit in every lane, unreached grid points are NaN.
+    tc = hy.taylor_adaptive_batch(sysd, st, n, high_accuracy=True)
+    _, out_c = tc.propagate_grid(grid, max_steps=3)
+    assert all(r[0] == OC.step_limit for r in tc.propagate_res) and np.isnan(out_c[-1]).all() and not np.isnan(out_c[0]).any()
+    # A callback which stops after two sweeps: cb_stop, and the state of the run limited to two iterations.
+    n_cb = []
+    td = hy.taylor_adaptive_batch(sysd, st, n, high_accuracy=True)
+    _, out_d = td.propagate_grid(grid, callback=lambda t: n_cb.append(1) or len(n_cb) < 2)
+    te = hy.taylor_adaptive_batch(sysd, st, n, high_accuracy=True)
+    _, out_e = te.propagate_grid(grid, max_steps=2)
+    assert all(r[0] == OC.cb_stop for r in td.propagate_res) and len(n_cb) == 2
+    assert np.array_equal(td.state, te.state) and np.array_equal(np.nan_to_num(out_d), np.nan_to_num(out_e))
+    # A callback altering the time coordinate is rejected.
+    tf = hy.taylor_adaptive_batch(sysd, st, n, high_accuracy=True)
+
+    def bad(t):
+        t.time = np.zeros(n)
+        return True
+
+    with pytest.raises(RuntimeError, match="alteration of the time coordinate"):
+        tf.propagate_grid(grid, callback=bad)
 
 
 def test_propagate_grid_device_output():
@@ -1149,34 +1166,47 @@ def test_full_size_invariants_baseline_configs():
         0.03, 1e3 * EPS, 1e-10)
 
 
-def test_lockstep_device_loop_equals_host_loop(monkeypatch):
-    """propagate_until() with a callback / continuous output: the device-driven lock-step loop (post-step kernel, two
-    counters per sweep) reproduces the host transcription of the reference's loop (HEYOKA_AMD_LOCKSTEP_HOST_LOOP=1)
-    bit for bit: states, times, propagate_res, number of callback invocations, cb_stop / step_limit outcomes."""
+def test_lockstep_device_loop_against_the_oracle_lockstep_loop():
+    """propagate_until() with a callback / continuous output: the device-driven lock-step loop (post-step kernel, three
+    counters per sweep; the only implementation - the host transcription of the reference's loop is gone) against the
+    oracle's lock-step loop: states, times, outcomes, step counters, one callback invocation per iteration of the batch,
+    cb_stop == the state after that many iterations, step_limit."""
     n = 257
     st = configs.two_body_state(n, perturb=1e-2, seed=12)
     tf = 3.0 + 0.01 * np.arange(n)
-    res = {}
-    for name in ("device", "host"):
-        if name == "host":
-            monkeypatch.setenv("HEYOKA_AMD_LOCKSTEP_HOST_LOOP", "1")
-        calls = []
-        ta = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), st, n)
-        co, _ = ta.propagate_until(tf, callback=lambda t: calls.append(1) or True, max_delta_t=0.4, c_output=True)
-        r1 = (ta.state.copy(), ta.time.copy(), ta.propagate_res, len(calls), co.n_steps, co(1.7).copy())
-        tb = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), st, n)
-        tb.propagate_until(-5.0, callback=lambda t: (calls.append(1) or True) and len(calls) < r1[3] + 3)
-        r2 = (tb.state.copy(), tb.propagate_res, len(calls))
-        calls.append(1)
-        tc = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), st, n)
-        tc.propagate_for(50.0, callback=lambda t: True, max_steps=4)
-        res[name] = (r1, r2, (tc.state.copy(), tc.propagate_res))
-    d, h = res["device"], res["host"]
-    assert np.array_equal(d[0][0], h[0][0]) and np.array_equal(d[0][1], h[0][1]) and d[0][2] == h[0][2]
-    assert d[0][3] == h[0][3] and d[0][4] == h[0][4] and np.array_equal(d[0][5], h[0][5])
-    assert np.array_equal(d[1][0], h[1][0]) and d[1][1] == h[1][1]
-    assert all(r[0] == OC.cb_stop for r in d[1][1])
-    assert np.array_equal(d[2][0], h[2][0]) and d[2][1] == h[2][1] and all(r[0] == OC.step_limit for r in d[2][1])
+    osys = ho.nbody(2, masses=[1.0, 0.0])
+    calls = []
+    ta = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), st, n)
+    co, _ = ta.propagate_until(tf, callback=lambda t: calls.append(1) or True, max_delta_t=0.4, c_output=True)
+    ora = ho.OracleIntegrator(osys, st, n)
+    ora.propagate_until(tf, max_delta_t=0.4)
+    assert [int(r[0]) for r in ta.propagate_res] == [r[0] for r in ora.prop_res]
+    assert [r[3] for r in ta.propagate_res] == [r[3] for r in ora.prop_res]
+    assert len(calls) == max(r[3] for r in ora.prop_res) and co.n_steps == len(calls)
+    assert np.array_equal(ta.time, tf) and rel_err(ta.state, ora.state.reshape(12, n)) <= 1e4 * EPS
+    # Continuous output in the middle of the range against an independent propagation.
+    tm = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), st, n)
+    tm.propagate_until(1.7)
+    assert rel_err(co(1.7), tm.state) <= 1e4 * EPS
+    # cb_stop after k invocations == the oracle's loop limited to k iterations (outcome aside).
+    k = 5
+    cnt = []
+    tb = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), st, n)
+    tb.propagate_until(-5.0, callback=lambda t: cnt.append(1) or len(cnt) < k)
+    orb = ho.OracleIntegrator(osys, st, n)
+    orb.propagate_until(-5.0, max_steps=k)
+    assert all(r[0] == OC.cb_stop for r in tb.propagate_res) and len(cnt) == k
+    assert [r[3] for r in tb.propagate_res] == [r[3] for r in orb.prop_res]
+    assert rel_err(tb.state, orb.state.reshape(12, n)) <= 1e4 * EPS
+    assert np.max(np.abs(tb.time - orb.time_hi)) <= 1e-13
+    # max_steps with a callback.
+    tc = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), st, n)
+    tc.propagate_for(50.0, callback=lambda t: True, max_steps=4)
+    orc = ho.OracleIntegrator(osys, st, n)
+    orc.propagate_for(50.0, max_steps=4)
+    assert all(r[0] == OC.step_limit for r in tc.propagate_res)
+    assert [(int(r[0]), r[3]) for r in tc.propagate_res] == [(r[0], r[3]) for r in orc.prop_res]
+    assert rel_err(tc.state, orc.state.reshape(12, n)) <= 1e4 * EPS
     # A callback altering the time coordinate is rejected.
     te = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), st, n)
 
@@ -1494,14 +1524,11 @@ def test_events_on_the_cluster_stepper_vs_oracle(monkeypatch):
     assert te_p == te_o and te_p == te_q
     assert [(a[0], a[1], a[3]) for a in log_p] == [(a[0], a[1], a[3]) for a in log_q]
     # propagate_until() / propagate_grid() with events: the device-driven lock-step loops with the step with events as
-    # their sweep, against the oracle's host loop (propagate_until) and against the product's own host loops with the
-    # per-lane bookkeeping on the host (HEYOKA_AMD_EVENTS_HOST_LOGIC=1, on the one-system-per-lane stepper).
+    # their sweep, against the oracle's loop (propagate_until) and on the one-system-per-lane stepper with events.
     t_end = float(np.max(ora.time_hi)) + 12.0
     ta.propagate_until(t_end)
     ora.propagate_until(t_end)
-    monkeypatch.setenv("HEYOKA_AMD_EVENTS_HOST_LOGIC", "1")
     tq.propagate_until(t_end)
-    monkeypatch.delenv("HEYOKA_AMD_EVENTS_HOST_LOGIC")
     assert [int(r[0]) for r in ta.propagate_res] == [r[0] for r in ora.prop_res]
     assert [int(r[0]) for r in ta.propagate_res] == [int(r[0]) for r in tq.propagate_res]
     assert max(abs(a[3] - b[3]) for a, b in zip(ta.propagate_res, ora.prop_res)) <= 1
@@ -1512,9 +1539,7 @@ def test_events_on_the_cluster_stepper_vs_oracle(monkeypatch):
     assert te_p == te_o and te_p == te_q
     grid = np.repeat(t_end + np.array([0.0, 1.5, 3.0, 7.0])[:, None], n, axis=1)
     _, out_p = ta.propagate_grid(grid)
-    monkeypatch.setenv("HEYOKA_AMD_EVENTS_HOST_LOGIC", "1")
     _, out_q = tq.propagate_grid(grid)
-    monkeypatch.delenv("HEYOKA_AMD_EVENTS_HOST_LOGIC")
     assert rel_err(np.asarray(out_p), np.asarray(out_q)) <= 1e7 * EPS
     assert [int(r[0]) for r in ta.propagate_res] == [int(r[0]) for r in tq.propagate_res]
     assert [(a[0], a[1], a[3]) for a in log_p] == [(a[0], a[1], a[3]) for a in log_q]
