@@ -1057,6 +1057,44 @@ class taylor_adaptive_batch:
         raise_for(lib.hy_tab_get_step_res(self._h, oc.ctypes.data, h.ctypes.data))
         return [(_outcome(oc[i]), float(h[i])) for i in range(n)]
 
+    def _callback_descs(self, callback, err):
+        """kw::callback: one callback - any callable taking the integrator and returning a truth value, optionally with a
+        pre_hook(integrator) method (include/heyoka/step_callback.hpp:46-62) - or a list / tuple of them (a callback set:
+        all run at every step, the results are and-ed). Returns (array of hy_step_callback_desc or None, count, keepalive)."""
+        if callback is None:
+            return None, 0, None
+        cbs = list(callback) if isinstance(callback, (list, tuple)) else [callback]
+        for c in cbs:
+            if c is None or not callable(c):
+                raise ValueError("Cannot construct a callback set containing one or more empty callbacks"
+                                 if len(cbs) > 1 or isinstance(callback, (list, tuple)) else "the step callback must be callable")
+        arr = (_lib.StepCallbackDesc * len(cbs))()
+        keep = []
+
+        def make(c):
+            def call(_tab, _data):
+                try:
+                    return 1 if c(self) else 0
+                except BaseException as e:  # propagate Python exceptions out of the C frame
+                    err.append(e)
+                    return 0
+
+            def pre(_tab, _data):
+                try:
+                    c.pre_hook(self)
+                except BaseException as e:
+                    err.append(e)
+
+            f_call = _lib.STEP_CALLBACK(call)
+            f_pre = _lib.STEP_PRE_HOOK(pre) if hasattr(c, "pre_hook") else _lib.STEP_PRE_HOOK()
+            keep.extend((f_call, f_pre))
+            return f_call, f_pre
+
+        for i, c in enumerate(cbs):
+            arr[i].call, arr[i].pre_hook = make(c)
+            arr[i].user_data = None
+        return arr, len(cbs), keep
+
     def _propagate(self, fn, t, max_steps, max_delta_t, callback, write_tc, c_output):
         tt = _f64(t).reshape(-1)
         if max_delta_t is None:
@@ -1065,21 +1103,11 @@ class taylor_adaptive_batch:
             mkeep = _f64(max_delta_t).reshape(-1)
             mptr, mn = mkeep.ctypes.data, mkeep.size
         err = []
-        if callback is not None:
-
-            def _tramp(_tab, _data):
-                try:
-                    return 1 if callback(self) else 0
-                except BaseException as e:  # propagate Python exceptions out of the C frame
-                    err.append(e)
-                    return 0
-
-            cb = _lib.STEP_CALLBACK(_tramp)
-        else:
-            cb = None
-        rc = fn(self._h, tt.ctypes.data, tt.size, int(max_steps), mptr, mn,
-                ctypes.cast(cb, ctypes.c_void_p) if cb is not None else None, None, int(bool(write_tc)),
-                int(bool(c_output)))
+        descs, n_cbs, keep = self._callback_descs(callback, err)
+        fn_cbs = lib.hy_tab_propagate_until_cbs if fn is lib.hy_tab_propagate_until else lib.hy_tab_propagate_for_cbs
+        rc = fn_cbs(self._h, tt.ctypes.data, tt.size, int(max_steps), mptr, mn, descs, n_cbs, int(bool(write_tc)),
+                    int(bool(c_output)))
+        del keep
         if err:
             raise err[0]
         self._raise_cb_errors()
@@ -1112,20 +1140,10 @@ class taylor_adaptive_batch:
             mkeep = _f64(max_delta_t).reshape(-1)
             mptr, mn = mkeep.ctypes.data, mkeep.size
         err = []
-        cb = None
-        if callback is not None:
-
-            def _tramp(_tab, _data):
-                try:
-                    return 1 if callback(self) else 0
-                except BaseException as e:
-                    err.append(e)
-                    return 0
-
-            cb = _lib.STEP_CALLBACK(_tramp)
-        rc = lib.hy_tab_propagate_grid(self._h, g.ctypes.data, n_grid, int(max_steps), mptr, mn,
-                                       ctypes.cast(cb, ctypes.c_void_p) if cb is not None else None, None,
-                                       out.ctypes.data)
+        descs, n_cbs, keep = self._callback_descs(callback, err)
+        rc = lib.hy_tab_propagate_grid_cbs(self._h, g.ctypes.data, n_grid, int(max_steps), mptr, mn, descs, n_cbs,
+                                           out.ctypes.data)
+        del keep
         if err:
             raise err[0]
         self._raise_cb_errors()

@@ -49,6 +49,13 @@ class TabConfig(ctypes.Structure):
 
 
 STEP_CALLBACK = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p)
+STEP_PRE_HOOK = ctypes.CFUNCTYPE(None, c_void_p, c_void_p)
+
+
+class StepCallbackDesc(ctypes.Structure):
+    """hy_step_callback_desc (include/heyoka_amd.h)."""
+
+    _fields_ = [("call", STEP_CALLBACK), ("pre_hook", STEP_PRE_HOOK), ("user_data", c_void_p)]
 NT_EVENT_CB = ctypes.CFUNCTYPE(None, c_void_p, c_double, c_int, c_uint32, c_void_p)
 T_EVENT_CB = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, c_uint32, c_void_p)
 
@@ -165,6 +172,21 @@ SIGNATURES = [
         "hy_tab_propagate_for",
         c_int,
         [c_void_p, c_void_p, c_size_t, c_uint64, c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_int],
+    ),
+    (
+        "hy_tab_propagate_until_cbs",
+        c_int,
+        [c_void_p, c_void_p, c_size_t, c_uint64, c_void_p, c_size_t, c_void_p, c_size_t, c_int, c_int],
+    ),
+    (
+        "hy_tab_propagate_for_cbs",
+        c_int,
+        [c_void_p, c_void_p, c_size_t, c_uint64, c_void_p, c_size_t, c_void_p, c_size_t, c_int, c_int],
+    ),
+    (
+        "hy_tab_propagate_grid_cbs",
+        c_int,
+        [c_void_p, c_void_p, c_size_t, c_uint64, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p],
     ),
     (
         "hy_tab_propagate_grid",

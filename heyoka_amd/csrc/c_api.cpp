@@ -149,6 +149,36 @@ detail::tab_core::cb_t wrap_cb(hy_tab tab, hy_step_callback cb, void *cb_data)
     return [tab, cb, cb_data]() { return cb(tab, cb_data) != 0; };
 }
 
+// A set of C step callbacks with optional pre-hooks (hy_step_callback_desc): every member runs at every step, the
+// results are and-ed (src/step_callback.cpp:108-127). Returns the pair (call, pre_hook) for the core.
+std::pair<detail::tab_core::cb_t, detail::tab_core::pre_t> wrap_cbs(hy_tab tab, const hy_step_callback_desc *cbs, size_t n_cbs)
+{
+    if (n_cbs == 0u || (n_cbs == 1u && cbs[0].call == nullptr)) {
+        return {};
+    }
+    std::vector<hy_step_callback_desc> v(cbs, cbs + n_cbs);
+    for (const auto &c : v) {
+        if (c.call == nullptr) {
+            throw std::invalid_argument("Cannot construct a callback set containing one or more empty callbacks");
+        }
+    }
+    detail::tab_core::cb_t call = [tab, v]() {
+        bool ret = true;
+        for (const auto &c : v) {
+            ret = (c.call(tab, c.user_data) != 0) && ret;
+        }
+        return ret;
+    };
+    detail::tab_core::pre_t pre = [tab, v]() {
+        for (const auto &c : v) {
+            if (c.pre_hook != nullptr) {
+                c.pre_hook(tab, c.user_data);
+            }
+        }
+    };
+    return {std::move(call), std::move(pre)};
+}
+
 } // namespace
 
 extern "C" {
@@ -913,6 +943,35 @@ int hy_tab_propagate_for(hy_tab t, const double *dts, size_t n_dts, uint64_t max
         t->core.propagate_for(vec_from(dts, n_dts), static_cast<std::size_t>(max_steps),
                               expand_mdt(mdts, n_mdt, t->core.get_batch_size()), wrap_cb(t, cb, cb_data), wtc != 0,
                               c_out != 0);
+    });
+}
+int hy_tab_propagate_until_cbs(hy_tab t, const double *ts, size_t n_ts, uint64_t max_steps, const double *mdts, size_t n_mdt,
+                               const hy_step_callback_desc *cbs, size_t n_cbs, int wtc, int c_out)
+{
+    return guarded([&] {
+        auto [call, pre] = wrap_cbs(t, cbs, n_cbs);
+        t->core.propagate_until(vec_from(ts, n_ts), static_cast<std::size_t>(max_steps),
+                                expand_mdt(mdts, n_mdt, t->core.get_batch_size()), call, wtc != 0, c_out != 0, pre);
+    });
+}
+int hy_tab_propagate_for_cbs(hy_tab t, const double *dts, size_t n_dts, uint64_t max_steps, const double *mdts, size_t n_mdt,
+                             const hy_step_callback_desc *cbs, size_t n_cbs, int wtc, int c_out)
+{
+    return guarded([&] {
+        auto [call, pre] = wrap_cbs(t, cbs, n_cbs);
+        t->core.propagate_for(vec_from(dts, n_dts), static_cast<std::size_t>(max_steps),
+                              expand_mdt(mdts, n_mdt, t->core.get_batch_size()), call, wtc != 0, c_out != 0, pre);
+    });
+}
+int hy_tab_propagate_grid_cbs(hy_tab t, const double *grid, size_t n_grid, uint64_t max_steps, const double *mdts,
+                              size_t n_mdt, const hy_step_callback_desc *cbs, size_t n_cbs, double *out)
+{
+    return guarded([&] {
+        const auto bs = t->core.get_batch_size();
+        auto [call, pre] = wrap_cbs(t, cbs, n_cbs);
+        auto ret = t->core.propagate_grid(vec_from(grid, n_grid * bs), static_cast<std::size_t>(max_steps),
+                                          expand_mdt(mdts, n_mdt, bs), call, nullptr, pre);
+        std::memcpy(out, ret.data(), ret.size() * sizeof(double));
     });
 }
 int hy_tab_take_c_output(hy_tab t, hy_cout *out)

@@ -1457,7 +1457,8 @@ void tab_core::finish_device_propagate(const std::vector<double> &ts, std::size_
 }
 
 void tab_core::propagate_for(const std::vector<double> &delta_ts, std::size_t max_steps,
-                             const std::vector<double> &max_delta_ts, const cb_t &cb, bool wtc, bool c_out)
+                             const std::vector<double> &max_delta_ts, const cb_t &cb, bool wtc, bool c_out,
+                             const pre_t &pre)
 {
     auto &d = *m_impl;
     if (delta_ts.size() != 1u && delta_ts.size() != d.N) {
@@ -1487,12 +1488,13 @@ void tab_core::propagate_for(const std::vector<double> &delta_ts, std::size_t ma
             flag = false;
         }
     } guard(d.dl_times_ok);
-    propagate_until(ts, max_steps, max_delta_ts, cb, wtc, c_out);
+    propagate_until(ts, max_steps, max_delta_ts, cb, wtc, c_out, pre);
 }
 
 // Reference: propagate_until_impl(), src/taylor_adaptive_batch.cpp:1137-1534.
 void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_steps,
-                               const std::vector<double> &max_delta_ts, const cb_t &cb, bool wtc, bool c_out)
+                               const std::vector<double> &max_delta_ts, const cb_t &cb, bool wtc, bool c_out,
+                               const pre_t &pre)
 {
     auto &d = *m_impl;
     const auto N = d.N;
@@ -1653,6 +1655,16 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
 
     // Lock-step propagation with a callback executed after every sweep and/or the recording of the
     // continuous output: the reference's loop, one single-step kernel launch per iteration.
+    // The pre_hook() of the step callback, once, before the first step (src/taylor_adaptive_batch.cpp:1356-1365).
+    if (cb && pre) {
+        const auto gen = d.time_gen;
+        pre();
+        if (d.time_gen != gen) {
+            throw std::runtime_error("The invocation of the callback passed to propagate_until() resulted in the "
+                                     "alteration of the time coordinate of the integrator - this is not supported");
+        }
+        // (The hook may have changed the state: the remaining times only depend on the times.)
+    }
     // If c_out is true, we always need to write the Taylor coefficients (:1243-1244).
     wtc = wtc || c_out;
     std::unique_ptr<c_out_builder> cob;
@@ -2047,7 +2059,8 @@ void tab_core::propagate_grid_device_loop(const std::vector<double> &grid, std::
 // single-step kernel launches (always with the Taylor coefficients) interleaved with dense-output launches.
 // grid[point * N + lane]; return value ret[(point * dim + var) * N + lane], NaN where not reached.
 std::vector<double> tab_core::propagate_grid(std::vector<double> grid, std::size_t max_steps,
-                                             const std::vector<double> &max_delta_ts_, const cb_t &cb, double *d_out)
+                                             const std::vector<double> &max_delta_ts_, const cb_t &cb, double *d_out,
+                                             const pre_t &pre)
 {
     auto &d = *m_impl;
     const auto N = d.N;
@@ -2167,6 +2180,15 @@ std::vector<double> tab_core::propagate_grid(std::vector<double> grid, std::size
         t_dir[i] = rem[i] >= dfloat(0.);
     }
 
+    // The pre_hook() of the step callback (src/taylor_adaptive_batch.cpp:1782-1791).
+    if (cb && pre) {
+        const auto gen = d.time_gen;
+        pre();
+        if (d.time_gen != gen) {
+            throw std::runtime_error("The invocation of the callback passed to propagate_grid() resulted in the "
+                                     "alteration of the time coordinate of the integrator - this is not supported");
+        }
+    }
     // Device-resident lock-step loop: the step kernel and a post-step kernel (bookkeeping of the reference's loop, dense
     // output at the grid points covered by the step, next step limit) alternate without any per-lane host work; the host
     // reads three counters per sweep and runs the callback, if any.

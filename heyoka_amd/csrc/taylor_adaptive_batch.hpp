@@ -30,6 +30,7 @@
 #include "event_detection.hpp"
 #include "expression.hpp"
 #include "kw.hpp"
+#include "step_callback.hpp"
 
 namespace heyoka_amd
 {
@@ -74,10 +75,12 @@ inline std::ostream &operator<<(std::ostream &os, taylor_outcome oc)
 template <typename T>
 class taylor_adaptive_batch;
 
-// Type-erased step callback: bool(taylor_adaptive_batch<double> &)
-// (reference: include/heyoka/step_callback.hpp:59-62).
+// Type-erased step callback bool(taylor_adaptive_batch<T> &) with the optional pre_hook() member, and sets of them
+// (reference: include/heyoka/step_callback.hpp:46-62, :139-185) - step_callback.hpp.
 template <typename T>
-using step_callback_batch = std::function<bool(taylor_adaptive_batch<T> &)>;
+using step_callback_batch = detail::step_cb_wrap<taylor_adaptive_batch<T>>;
+template <typename T>
+using step_callback_batch_set = detail::step_cb_set<taylor_adaptive_batch<T>>;
 
 namespace detail
 {
@@ -177,13 +180,18 @@ public:
     // ts: final times (size 1 = scalar splat, else batch_size); max_delta_ts: empty or batch_size.
     void finish_device_propagate(const std::vector<double> &ts, std::size_t max_steps, const std::vector<double> &max_delta_ts,
                                  bool wtc);
+    // pre: the pre_hook() of the step callback (include/heyoka/step_callback.hpp:46-62), run once after the validation of
+    // the arguments and before the first step (src/taylor_adaptive_batch.cpp:1356-1365, :1782-1791); it must not move the
+    // time coordinate.
+    using pre_t = std::function<void()>;
     void propagate_until(const std::vector<double> &ts, std::size_t max_steps, const std::vector<double> &max_delta_ts,
-                         const cb_t &cb, bool wtc, bool c_out);
+                         const cb_t &cb, bool wtc, bool c_out, const pre_t &pre = {});
     void propagate_for(const std::vector<double> &delta_ts, std::size_t max_steps,
-                       const std::vector<double> &max_delta_ts, const cb_t &cb, bool wtc, bool c_out);
+                       const std::vector<double> &max_delta_ts, const cb_t &cb, bool wtc, bool c_out,
+                       const pre_t &pre = {});
     std::vector<double> propagate_grid(std::vector<double> grid, std::size_t max_steps,
                                        const std::vector<double> &max_delta_ts, const cb_t &cb,
-                                       double *d_out = nullptr);
+                                       double *d_out = nullptr, const pre_t &pre = {});
     // Device-resident loop of propagate_grid(): see taylor_adaptive_batch.cpp.
     void propagate_grid_device_loop(const std::vector<double> &grid, std::vector<double> &retval,
                                     const std::vector<dfloat> &rem, const std::vector<int> &t_dir,
@@ -430,17 +438,32 @@ class taylor_adaptive_batch<double>
                 }
             }
         }
-        detail::tab_core::cb_t cb;
-        step_callback_batch<double> user_cb;
+        // kw::callback: one callback (anything a step_callback_batch can be built from), or a range of callbacks, which
+        // becomes a step_callback_batch_set (parse_propagate_cb(), include/heyoka/taylor.hpp:237-260). The callback object
+        // lives in a shared holder for the duration of the call: the core invokes it through `cb` / `pre`, and the very
+        // same object - with whatever state it accumulated - is handed back to the caller.
+        auto user_cb = std::make_shared<step_callback_batch<double>>();
         if constexpr (kw::has_v<kw::callback_tag, KwArgs...>) {
-            user_cb = kw::get(kw::callback, 0, kw_args...);
-            if (user_cb) {
-                cb = [this, user_cb]() mutable { return user_cb(*this); };
+            using cb_arg_t = std::decay_t<decltype(kw::get(kw::callback, 0, kw_args...))>;
+            if constexpr (std::is_constructible_v<step_callback_batch<double>, const cb_arg_t &>) {
+                *user_cb = step_callback_batch<double>(kw::get(kw::callback, 0, kw_args...));
+            } else {
+                std::vector<step_callback_batch<double>> v;
+                for (const auto &x : kw::get(kw::callback, 0, kw_args...)) {
+                    v.emplace_back(x);
+                }
+                *user_cb = step_callback_batch<double>(step_callback_batch_set<double>(std::move(v)));
             }
+        }
+        detail::tab_core::cb_t cb;
+        detail::tab_core::pre_t pre;
+        if (*user_cb) {
+            cb = [this, user_cb]() { return (*user_cb)(*this); };
+            pre = [this, user_cb]() { user_cb->pre_hook(*this); };
         }
         const auto wtc = static_cast<bool>(kw::get(kw::write_tc, false, kw_args...));
         const auto c_out = static_cast<bool>(kw::get(kw::c_output, false, kw_args...));
-        return std::tuple{max_steps, std::move(max_delta_ts), std::move(cb), std::move(user_cb), wtc, c_out};
+        return std::tuple{max_steps, std::move(max_delta_ts), std::move(cb), std::move(user_cb), wtc, c_out, std::move(pre)};
     }
 
 public:
@@ -673,44 +696,44 @@ public:
     std::tuple<std::optional<continuous_output_batch<double>>, step_callback_batch<double>> propagate_until(const std::vector<double> &ts,
                                                                            const KwArgs &...kw_args)
     {
-        auto [max_steps, mdts, cb, user_cb, wtc, c_out] = propagate_common_ops(kw_args...);
+        auto [max_steps, mdts, cb, user_cb, wtc, c_out, pre] = propagate_common_ops(kw_args...);
         m_core.set_callback_context(this);
-        m_core.propagate_until(ts, max_steps, mdts, cb, wtc, c_out);
-        return {make_c_out(), std::move(user_cb)};
+        m_core.propagate_until(ts, max_steps, mdts, cb, wtc, c_out, pre);
+        return {make_c_out(), std::move(*user_cb)};
     }
     template <typename... KwArgs>
     std::tuple<std::optional<continuous_output_batch<double>>, step_callback_batch<double>> propagate_until(double t, const KwArgs &...kw_args)
     {
-        auto [max_steps, mdts, cb, user_cb, wtc, c_out] = propagate_common_ops(kw_args...);
+        auto [max_steps, mdts, cb, user_cb, wtc, c_out, pre] = propagate_common_ops(kw_args...);
         m_core.set_callback_context(this);
-        m_core.propagate_until(std::vector<double>{t}, max_steps, mdts, cb, wtc, c_out);
-        return {make_c_out(), std::move(user_cb)};
+        m_core.propagate_until(std::vector<double>{t}, max_steps, mdts, cb, wtc, c_out, pre);
+        return {make_c_out(), std::move(*user_cb)};
     }
     template <typename... KwArgs>
     std::tuple<std::optional<continuous_output_batch<double>>, step_callback_batch<double>> propagate_for(const std::vector<double> &dts,
                                                                          const KwArgs &...kw_args)
     {
-        auto [max_steps, mdts, cb, user_cb, wtc, c_out] = propagate_common_ops(kw_args...);
+        auto [max_steps, mdts, cb, user_cb, wtc, c_out, pre] = propagate_common_ops(kw_args...);
         m_core.set_callback_context(this);
-        m_core.propagate_for(dts, max_steps, mdts, cb, wtc, c_out);
-        return {make_c_out(), std::move(user_cb)};
+        m_core.propagate_for(dts, max_steps, mdts, cb, wtc, c_out, pre);
+        return {make_c_out(), std::move(*user_cb)};
     }
     template <typename... KwArgs>
     std::tuple<std::optional<continuous_output_batch<double>>, step_callback_batch<double>> propagate_for(double dt, const KwArgs &...kw_args)
     {
-        auto [max_steps, mdts, cb, user_cb, wtc, c_out] = propagate_common_ops(kw_args...);
+        auto [max_steps, mdts, cb, user_cb, wtc, c_out, pre] = propagate_common_ops(kw_args...);
         m_core.set_callback_context(this);
-        m_core.propagate_for(std::vector<double>{dt}, max_steps, mdts, cb, wtc, c_out);
-        return {make_c_out(), std::move(user_cb)};
+        m_core.propagate_for(std::vector<double>{dt}, max_steps, mdts, cb, wtc, c_out, pre);
+        return {make_c_out(), std::move(*user_cb)};
     }
     template <typename... KwArgs>
     std::tuple<step_callback_batch<double>, std::vector<double>> propagate_grid(std::vector<double> grid,
                                                                                const KwArgs &...kw_args)
     {
-        auto [max_steps, mdts, cb, user_cb, wtc, c_out] = propagate_common_ops(kw_args...);
+        auto [max_steps, mdts, cb, user_cb, wtc, c_out, pre] = propagate_common_ops(kw_args...);
         m_core.set_callback_context(this);
-        auto ret = m_core.propagate_grid(std::move(grid), max_steps, mdts, cb);
-        return {std::move(user_cb), std::move(ret)};
+        auto ret = m_core.propagate_grid(std::move(grid), max_steps, mdts, cb, nullptr, pre);
+        return {std::move(*user_cb), std::move(ret)};
     }
 
     // MI355X extensions.

@@ -286,6 +286,24 @@ int hy_tab_propagate_until(hy_tab, const double *ts, size_t n_ts, uint64_t max_s
                            size_t n_mdt, hy_step_callback cb, void *cb_data, int write_tc, int c_output);
 int hy_tab_propagate_for(hy_tab, const double *dts, size_t n_dts, uint64_t max_steps, const double *max_delta_ts,
                          size_t n_mdt, hy_step_callback cb, void *cb_data, int write_tc, int c_output);
+/* The full step-callback protocol (include/heyoka/step_callback.hpp:46-62, :139-185): a callback may provide a
+ * pre_hook(), run once after the validation of the arguments and before the first step
+ * (src/taylor_adaptive_batch.cpp:1356-1365, :1782-1791; it must not move the time coordinate), and kw::callback accepts a
+ * range of callbacks, which form a set: every member runs at every step and the results are and-ed
+ * (src/step_callback.cpp:108-127); a NULL `call` inside a set of more than one member is an error
+ * ("Cannot construct a callback set containing one or more empty callbacks"), n_cbs == 0 means no callback. */
+typedef void (*hy_step_pre_hook)(hy_tab, void *user_data);
+typedef struct {
+    hy_step_callback call;
+    hy_step_pre_hook pre_hook; /* NULL: the default no-op */
+    void *user_data;
+} hy_step_callback_desc;
+int hy_tab_propagate_until_cbs(hy_tab, const double *ts, size_t n_ts, uint64_t max_steps, const double *max_delta_ts,
+                               size_t n_mdt, const hy_step_callback_desc *cbs, size_t n_cbs, int write_tc, int c_output);
+int hy_tab_propagate_for_cbs(hy_tab, const double *dts, size_t n_dts, uint64_t max_steps, const double *max_delta_ts,
+                             size_t n_mdt, const hy_step_callback_desc *cbs, size_t n_cbs, int write_tc, int c_output);
+int hy_tab_propagate_grid_cbs(hy_tab, const double *grid, size_t n_grid, uint64_t max_steps, const double *max_delta_ts,
+                              size_t n_mdt, const hy_step_callback_desc *cbs, size_t n_cbs, double *out);
 /* ------------------------------------------------------------------------------------------------
  * continuous_output_batch<double> (include/heyoka/continuous_output.hpp:151-204,
  * src/continuous_output.cpp:602-1236): the optional<continuous_output_batch> slot of the tuple returned

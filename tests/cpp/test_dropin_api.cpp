@@ -285,6 +285,80 @@ int main(int argc, char **argv)
         return t.get_time()[0] < 10.;
     });
     REQUIRE(n_cb > 0 && ta.get_time()[0] == 1.);
+    // Step callbacks with pre_hook(), ranges of callbacks, and the callback handed back with its state
+    // (include/heyoka/step_callback.hpp:46-62; src/taylor_adaptive_batch.cpp:1356-1365).
+    {
+        struct counting_cb {
+            int n_pre = 0, n_call = 0;
+            bool operator()(taylor_adaptive_batch<double> &)
+            {
+                ++n_call;
+                return true;
+            }
+            void pre_hook(taylor_adaptive_batch<double> &t)
+            {
+                ++n_pre;
+                t.get_state_data()[1] = 0.25; // a pre_hook may set the state up ...
+            }
+        };
+        ta.set_time(0.);
+        auto [co1, cb1] = ta.propagate_until(0.5, kw::callback = counting_cb{});
+        const auto *p1 = cb1.extract<counting_cb>();
+        REQUIRE(p1 != nullptr && p1->n_pre == 1 && p1->n_call > 0 && !co1);
+        // A reference wrapper: the caller's own object is updated.
+        counting_cb mine;
+        ta.propagate_for(0.5, kw::callback = std::ref(mine));
+        REQUIRE(mine.n_pre == 1 && mine.n_call > 0);
+        // A range of callbacks -> a callback set: every member runs at every step, the results are and-ed.
+        int n_a = 0, n_b = 0;
+        std::vector<step_callback_batch<double>> cbs;
+        cbs.emplace_back([&n_a](taylor_adaptive_batch<double> &) { return ++n_a < 3; });
+        cbs.emplace_back([&n_b](taylor_adaptive_batch<double> &) {
+            ++n_b;
+            return true;
+        });
+        cbs.emplace_back(counting_cb{});
+        auto [co2, cb2] = ta.propagate_for(50., kw::callback = cbs);
+        REQUIRE(n_a == 3 && n_b == 3 && std::get<0>(ta.get_propagate_res()[0]) == taylor_outcome::cb_stop);
+        auto *set2 = cb2.extract<step_callback_batch_set<double>>();
+        REQUIRE(set2 != nullptr && set2->size() == 3u && (*set2)[2].extract<counting_cb>()->n_pre == 1);
+        REQUIRE((*set2)[2].extract<counting_cb>()->n_call == 3);
+        // propagate_grid() runs the hook too; a pre_hook which moves the time is rejected.
+        ta.set_time(0.);
+        counting_cb gcb;
+        ta.propagate_grid(std::vector<double>{0., 0., 0., 0., .1, .1, .1, .1, .2, .2, .2, .2}, kw::callback = std::ref(gcb));
+        REQUIRE(gcb.n_pre == 1 && gcb.n_call >= 1);
+        struct bad_hook {
+            bool operator()(taylor_adaptive_batch<double> &)
+            {
+                return true;
+            }
+            void pre_hook(taylor_adaptive_batch<double> &t)
+            {
+                t.set_time(42.);
+            }
+        };
+        bool thrown = false;
+        try {
+            ta.propagate_for(1., kw::callback = bad_hook{});
+        } catch (const std::runtime_error &e) {
+            thrown = std::string(e.what()).find("alteration of the time coordinate") != std::string::npos;
+        }
+        REQUIRE(thrown);
+        // Empty callbacks: a set cannot hold them; an empty std::function is "no callback".
+        bool thrown2 = false;
+        try {
+            step_callback_batch_set<double>{step_callback_batch<double>{}};
+        } catch (const std::invalid_argument &e) {
+            thrown2 = std::string(e.what()) == "Cannot construct a callback set containing one or more empty callbacks";
+        }
+        REQUIRE(thrown2);
+        ta.set_time(0.);
+        auto [co3, cb3] = ta.propagate_for(.1, kw::callback = std::function<bool(taylor_adaptive_batch<double> &)>{});
+        REQUIRE(!cb3);
+        ta.get_state_data()[1] = 0.01;
+        ta.set_time(1.);
+    }
     ta.propagate_until(100., kw::max_steps = 2u);
     REQUIRE(std::get<0>(ta.get_propagate_res()[0]) == taylor_outcome::step_limit);
 
