@@ -21,6 +21,11 @@ import os
 import sys
 import time
 
+# The CPU baseline runs one OpenMP worker per PHYSICAL core (two SMT siblings thrash the L2-resident tape of a batch):
+# ask the OpenMP runtime to place the workers on distinct cores before anything loads it.
+os.environ.setdefault("OMP_PLACES", "cores")
+os.environ.setdefault("OMP_PROC_BIND", "spread")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -61,6 +66,38 @@ def make_integrator(hy, configs, workload, n_systems, seed, device=0):
     return ta, st, dt
 
 
+def physical_cores(hw_threads):
+    """Number of physical cores of this host (distinct (package, core) pairs of /proc/cpuinfo), capped by the OpenMP
+    thread limit; falls back to the hardware threads."""
+    try:
+        cores = set()
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if core is not None:
+                        cores.add((phys, core))
+                    phys = core = None
+        if core is not None:
+            cores.add((phys, core))
+        n = len(cores)
+        # (Containers: the affinity mask may be narrower than the machine.)
+        n = min(n, len(os.sched_getaffinity(0))) if n else 0
+        return max(1, min(n, hw_threads)) if n else hw_threads
+    except Exception:
+        return hw_threads
+
+
+# (Taken at import: once the OpenMP runtime has bound the primary thread to its place, the affinity mask of this process
+# no longer shows the machine.)
+HW_THREADS_AT_START = len(os.sched_getaffinity(0))
+PHYSICAL_CORES_AT_START = physical_cores(HW_THREADS_AT_START)
+
+
 def cpu_baseline(workload, dt, target_seconds=15.0):
     """The oracle (C restatement, OpenMP over SIMD-width batches like the reference's
     TBB-over-batches ensemble) timed on this host on a bounded sample of the same workload."""
@@ -69,7 +106,8 @@ def cpu_baseline(workload, dt, target_seconds=15.0):
     from heyoka_amd import configs
 
     width = 8
-    threads = ho.max_threads()
+    hw_threads = max(ho.max_threads(), HW_THREADS_AT_START)
+    threads = min(PHYSICAL_CORES_AT_START, hw_threads)
     if workload == "outer_ss":
         osys = ho.nbody(6, masses=configs.OUTER_SS_MASSES, Gconst=configs.OUTER_SS_G)
         gen = lambda n: configs.outer_ss_state(n, perturb=1e-12, seed=42)
@@ -120,11 +158,13 @@ def cpu_baseline(workload, dt, target_seconds=15.0):
         "value": tot / el,
         "unit": "system-steps/s",
         "cores": threads,
+        "threads": threads,
+        "hw_threads": hw_threads,
         "kind": "port",
-        "per_thread": tot / el / threads,
+        "per_core": tot / el / threads,
         "sample": "%d %s systems propagated to t=%g (%d system-steps) in %.1f s; %s; batch width %d (lock-step batches like "
-        "the reference's batch mode), one OpenMP worker per hardware thread (%d) over batches"
-        % (n, workload, dt, tot, el, how, width, threads),
+        "the reference's batch mode), one OpenMP worker per physical core (%d cores, %d hardware threads; OMP_PLACES=cores) "
+        "over batches" % (n, workload, dt, tot, el, how, width, threads, hw_threads),
     }
 
 
@@ -408,7 +448,10 @@ def main():
             for wl, st_, wu_ in (("two_body", 4, 2), ("nbody64", 2, 1)):
                 try:
                     r = run_workload(ctx, wl, DEFAULT_SYSTEMS[wl], st_, wu_)
-                    extra.append({k: r[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline")})
+                    leg = {k: r[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline")}
+                    if wl == "two_body" and not args.no_cpu_baseline:
+                        leg["cpu_baseline"] = cpu_baseline(wl, r["_dt"], 5.0)
+                    extra.append(leg)
                 except Exception as e:  # an auxiliary leg must never cost the headline line
                     extra.append({"config": {"workload": wl}, "error": "%s: %s" % (type(e).__name__, e)})
             out["extra_workloads"] = extra

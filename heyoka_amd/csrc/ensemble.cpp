@@ -24,13 +24,21 @@ std::vector<tab_core> ensemble_propagate_core(const tab_core &ta, double t, std:
         return {};
     }
 
+    // n_devices: number of HIP devices (0: all the visible ones), one host thread per device; a NEGATIVE value -k asks
+    // for k host threads spread round-robin over the visible devices (more workers than devices: how the threaded path
+    // runs on a single-GPU box; also useful when the generator is expensive).
     const auto visible = hip_device_count();
-    if (n_devices <= 0 || n_devices > visible) {
-        n_devices = visible;
-    }
-    if (n_devices <= 0) {
+    if (visible <= 0) {
         throw std::runtime_error("heyoka_amd: no HIP device is available for ensemble propagation");
     }
+    int n_workers = 0;
+    if (n_devices < 0) {
+        n_workers = -n_devices;
+    } else {
+        n_workers = (n_devices == 0 || n_devices > visible) ? visible : n_devices;
+    }
+    const auto device_of = [visible](int worker) { return worker % visible; };
+    n_devices = n_workers;
 
     // One host thread per device (the reference runs the iterations inside a TBB parallel_for,
     // src/ensemble_propagate.cpp:203-219, and documents that the generator is invoked concurrently): thread d copies
@@ -52,7 +60,7 @@ std::vector<tab_core> ensemble_propagate_core(const tab_core &ta, double t, std:
             for (std::size_t i = static_cast<std::size_t>(dev); i < n_iter; i += static_cast<std::size_t>(n_devices)) {
                 slots[i].emplace(ta);
                 gen(*slots[i], i);
-                slots[i]->set_device(dev);
+                slots[i]->set_device(device_of(dev));
                 // Asynchronous launch: one device-resident propagation per iteration.
                 if (kind == ensemble_kind::until) {
                     slots[i]->propagate_until(ts, max_steps, {}, {}, false, false);

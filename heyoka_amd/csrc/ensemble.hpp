@@ -114,10 +114,20 @@ auto ensemble_propagate_tmpl(const taylor_adaptive_batch<double> &ta, const Time
     }
     const auto wtc = static_cast<bool>(kw::get(kw::write_tc, false, kw_args...));
     const auto c_out = static_cast<bool>(kw::get(kw::c_output, false, kw_args...));
+    // kw::device = number of HIP devices to use (0: all the visible ones; one host thread per device). A NEGATIVE value
+    // -k asks for k host threads spread round-robin over the visible devices - more workers than devices: the threaded
+    // path on a single-GPU box, and a way to overlap expensive generators / callbacks.
     auto n_dev = static_cast<int>(kw::get(kw::device, 0, kw_args...));
     const auto visible = ensemble_visible_devices();
-    if (n_dev <= 0 || n_dev > visible) {
+    int n_workers = 0;
+    if (n_dev < 0) {
+        n_workers = -n_dev;
         n_dev = visible;
+    } else {
+        if (n_dev == 0 || n_dev > visible) {
+            n_dev = visible;
+        }
+        n_workers = n_dev;
     }
 
     // Generate the integrators (serially) and pin them to their devices.
@@ -126,9 +136,11 @@ auto ensemble_propagate_tmpl(const taylor_adaptive_batch<double> &ta, const Time
     for (std::size_t i = 0; i < n_iter; ++i) {
         tas.push_back(gen(ta, i));
         if (n_dev > 0) {
-            tas.back().core().set_device(static_cast<int>(i % static_cast<std::size_t>(n_dev)));
+            const auto worker = i % static_cast<std::size_t>(std::max(1, n_workers));
+            tas.back().core().set_device(static_cast<int>(worker % static_cast<std::size_t>(n_dev)));
         }
     }
+    n_dev = n_workers; // (below: the number of worker threads)
 
     if constexpr (is_grid) {
         // Splat out the time grid (src/ensemble_propagate.cpp:266-273).
@@ -164,8 +176,8 @@ auto ensemble_propagate_tmpl(const taylor_adaptive_batch<double> &ta, const Time
                                               kw::c_output = c_out);
             }
         };
-        if (!cb && !c_out) {
-            // Asynchronous launches (one device-resident propagation per iteration), then one sync each.
+        if (!cb && !c_out && n_dev <= 1) {
+            // One device: the device-resident propagations of the iterations, one after the other.
             for (std::size_t i = 0; i < n_iter; ++i) {
                 run(i);
             }

@@ -50,7 +50,12 @@ def all_gather_states(local, group=None):
 def ensemble_propagate_until_sharded(make_integrator, global_state, t_final, group=None, max_steps=0, device=None):
     """Propagate global_state (n_eq, n_total; host array, identical on all ranks) to t_final:
     rank r integrates lanes shard_bounds(n_total, r, world) and all ranks receive the gathered final
-    state, outcomes and step counts. make_integrator(n_local) -> taylor_adaptive_batch."""
+    state (float64, (n_eq, n_total)) and a (2, n_total) int64 tensor of outcomes and step counts.
+    make_integrator(n_local) -> taylor_adaptive_batch.
+
+    device: the torch device of the collective. With a CUDA device (backend "nccl" = RCCL over xGMI) the final state,
+    outcomes and step counters are gathered straight from the integrator's device arrays (zero-copy views, no host
+    staging); with None / CPU (backend "gloo", the tests) they go through the host mirrors."""
     import torch
     import torch.distributed as dist
 
@@ -63,8 +68,15 @@ def ensemble_propagate_until_sharded(make_integrator, global_state, t_final, gro
     ta = make_integrator(hi - lo)
     ta.state = np.ascontiguousarray(global_state[:, lo:hi])
     ta.propagate_until(t_final, max_steps=max_steps)
+    # (Fetching the results first also brings the device-side outcome array in line with the reference's batch-wide
+    # outcomes, see tab_core::config::batch_semantics.)
     oc, mn, mx, ns = ta.propagate_res_arrays()
-    dev = device if device is not None else torch.device("cpu")
-    st = torch.as_tensor(ta.state).to(dev)
-    meta = torch.as_tensor(np.stack([oc.astype(np.float64), ns.astype(np.float64)])).to(dev)
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    if dev.type == "cuda" and hasattr(ta, "device_array"):
+        st = torch.as_tensor(ta.device_array("state"), device=dev)
+        meta = torch.stack([torch.as_tensor(ta.device_array("outcome"), device=dev),
+                            torch.as_tensor(ta.device_array("n_steps"), device=dev)])
+    else:
+        st = torch.as_tensor(np.asarray(ta.state)).to(dev)
+        meta = torch.as_tensor(np.stack([np.asarray(oc, dtype=np.int64), np.asarray(ns).astype(np.int64)])).to(dev)
     return ta, all_gather_states(st, group), all_gather_states(meta, group)

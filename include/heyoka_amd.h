@@ -420,8 +420,9 @@ int hy_cfunc_eval_device(hy_cfunc, double *d_out, const double *d_in, const doub
  *  gen(ta_copy, iteration, user_data): sets the initial conditions of the copy (on the host),
  *      returns 0 on success. Invoked serially on the calling thread.
  *  Iterations are distributed round-robin over `n_devices` HIP devices (0 = all visible), one host
- *  thread per device. The propagated copies are returned in out[0..n_iter) (caller frees each with
- *  hy_tab_free()). */
+ *  thread per device; n_devices = -k: k host threads spread round-robin over the visible devices (more
+ *  workers than devices). The propagated copies are returned in out[0..n_iter) (caller frees each with
+ *  hy_tab_free()); every copy lives on the device which propagated it and its getters fetch from there. */
 typedef int (*hy_ensemble_gen)(hy_tab ta_copy, size_t iteration, void *user_data);
 int hy_ensemble_propagate_until_batch(hy_tab ta, double t, size_t n_iter, hy_ensemble_gen gen, void *gen_data,
                                       uint64_t max_steps, int n_devices, hy_tab *out);

@@ -379,6 +379,22 @@ int main(int argc, char **argv)
     REQUIRE(std::abs(last.get_state()[3] - 0.24068377640981869) < 1e-12);
     REQUIRE(std::get<3>(last.get_propagate_res()[1]) == 124u);
 
+    // Several host threads (kw::device = -3: three workers spread round-robin over the visible devices, here one): the
+    // threaded path of the ensemble driver gives bitwise the results of the serial one, with and without callbacks.
+    {
+        auto ret_t = ensemble_propagate_until_batch(tp, 20., 5, gen, kw::device = -3);
+        REQUIRE(ret_t.size() == 5u);
+        for (auto i = 0u; i < 5u; ++i) {
+            REQUIRE(std::get<0>(ret_t[i]).get_state() == std::get<0>(ret[i]).get_state());
+            REQUIRE(std::get<0>(ret_t[i]).get_propagate_res() == std::get<0>(ret[i]).get_propagate_res());
+        }
+        auto ret_c = ensemble_propagate_until_batch(
+            tp, 20., 5, gen, kw::device = -2, kw::callback = [](taylor_adaptive_batch<double> &) { return true; });
+        for (auto i = 0u; i < 5u; ++i) {
+            REQUIRE(std::get<0>(ret_c[i]).get_state() == std::get<0>(ret[i]).get_state());
+        }
+    }
+
     // Every kwarg of the reference is forwarded; the continuous output slot is filled on request.
     auto ret2 = ensemble_propagate_for_batch(tp, 2., 3, gen, kw::c_output = true, kw::max_delta_t = 0.5,
                                              kw::write_tc = true);

@@ -136,7 +136,16 @@ def test_sharded_ensemble_real_integrators_two_ranks_one_gpu(n_total):
     ta.propagate_until(t_final)
     assert np.array_equal(ta.state, res[0][1])
     oc, _, _, ns = ta.propagate_res_arrays()
-    assert np.array_equal(res[0][2][0], oc.astype(np.float64)) and np.array_equal(res[0][2][1], ns.astype(np.float64))
+    assert res[0][2].dtype == np.int64
+    assert np.array_equal(res[0][2][0], oc.astype(np.int64)) and np.array_equal(res[0][2][1], ns.astype(np.int64))
+    # The same driver in one process with the collective on the device: final state, outcomes and step counters come
+    # straight from the integrator's device arrays (the path the RCCL ranks of bench.py / a multi-GPU job take).
+    import torch
+
+    mk = lambda n: hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), None, n, high_accuracy=True, device=0)
+    _, st_d, meta_d = hens.ensemble_propagate_until_sharded(mk, g, t_final, device="cuda:0")
+    assert st_d.is_cuda and meta_d.is_cuda and meta_d.dtype == torch.int64
+    assert np.array_equal(st_d.cpu().numpy(), res[0][1]) and np.array_equal(meta_d.cpu().numpy(), res[0][2])
 
     n_o = (n_total // 8) * 8
     ref, *_ = ho.ensemble_propagate_until(ho.nbody(6, masses=M, Gconst=G), g[:, :n_o], n_o, 8, t_final, high_accuracy=True)

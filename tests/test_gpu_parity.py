@@ -317,6 +317,11 @@ def test_device_array_views_and_ensemble():
         tc.state = chunks[i]
 
     out = hy.ensemble_propagate_until_batch(tmpl, 5.0, 4, gen)
+    # The threaded core (csrc/ensemble.cpp: one host thread per device; n_devices = -3: three workers mapped round-robin
+    # onto the visible devices, i.e. all onto GPU 0 here) returns the same objects bit for bit.
+    out_t = hy.ensemble_propagate_until_batch(tmpl, 5.0, 4, gen, n_devices=-3)
+    assert len(out_t) == len(out) and all(np.array_equal(a.state, b.state) and a.propagate_res == b.propagate_res
+                                          for a, b in zip(out_t, out))
     for i, o in enumerate(out):
         serial = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), chunks[i], 256)
         serial.propagate_until(5.0)
