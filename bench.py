@@ -92,10 +92,35 @@ def physical_cores(hw_threads):
         return hw_threads
 
 
+def cgroup_cpu_quota():
+    """CPU quota of this container in CPUs (cgroup v2 cpu.max / v1 cfs quota), or None if unlimited. More runnable
+    threads than the quota are throttled by the kernel: the GPU boxes of this pool expose 256 hardware threads of two
+    EPYC 9575F to a container whose quota is 16 CPUs - 128 workers there measured 3.6e4 system-steps/s each, i.e. the
+    2.9e5 per CPU of the quota which 16 workers reach directly."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            p = float(f.read())
+        return None if q <= 0 else q / p
+    except Exception:
+        return None
+
+
 # (Taken at import: once the OpenMP runtime has bound the primary thread to its place, the affinity mask of this process
 # no longer shows the machine.)
 HW_THREADS_AT_START = len(os.sched_getaffinity(0))
+CPU_QUOTA = cgroup_cpu_quota()
 PHYSICAL_CORES_AT_START = physical_cores(HW_THREADS_AT_START)
+if CPU_QUOTA is not None:
+    # One worker per CPU the container may actually use.
+    PHYSICAL_CORES_AT_START = max(1, min(PHYSICAL_CORES_AT_START, int(CPU_QUOTA + 0.5)))
 
 
 def cpu_baseline(workload, dt, target_seconds=15.0):
@@ -160,11 +185,13 @@ def cpu_baseline(workload, dt, target_seconds=15.0):
         "cores": threads,
         "threads": threads,
         "hw_threads": hw_threads,
+        "cgroup_cpu_quota": CPU_QUOTA,
         "kind": "port",
         "per_core": tot / el / threads,
         "sample": "%d %s systems propagated to t=%g (%d system-steps) in %.1f s; %s; batch width %d (lock-step batches like "
-        "the reference's batch mode), one OpenMP worker per physical core (%d cores, %d hardware threads; OMP_PLACES=cores) "
-        "over batches" % (n, workload, dt, tot, el, how, width, threads, hw_threads),
+        "the reference's batch mode), one OpenMP worker per usable physical core (%d workers; %d hardware threads visible, cgroup "
+        "CPU quota %s; OMP_PLACES=cores) over batches" % (n, workload, dt, tot, el, how, width, threads, hw_threads,
+                                                          "%.1f CPUs" % CPU_QUOTA if CPU_QUOTA is not None else "none"),
     }
 
 

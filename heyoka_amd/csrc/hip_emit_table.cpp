@@ -141,8 +141,45 @@ __device__ double hy_pow_eval(double b, double ex)
 }
 
 // ---- one device function per elementary function (the reference's taylor_c_diff_func layer) ----
+// pairwise_sum() of the reference (src/detail/llvm_helpers.cpp: adjacent terms are added two by two until one value is
+// left; a term without a partner moves up unchanged) for up to 8 terms - the arguments of sum() and sum_sq() are added
+// pairwise in the reference's compact mode as well (src/math/sum.cpp:355, src/detail/sum_sq.cpp:371-377), and sums are
+// split into chunks of at most 8 arguments by the decomposition (src/detail/udf_split.hpp:49-100). Compile-time loop
+// bounds: the 8 slots stay in registers.
+__device__ double hy_pairwise8(const double *t, unsigned n)
+{
+    double v[8];
+    bool have[8];
+#pragma unroll
+    for (unsigned i = 0; i < 8u; ++i) {
+        have[i] = i < n;
+        v[i] = have[i] ? t[i] : 0.0;
+    }
+#pragma unroll
+    for (unsigned w = 8u; w > 1u; w /= 2u) {
+#pragma unroll
+        for (unsigned i = 0; i < w / 2u; ++i) {
+            const double a = v[2u * i], b = v[2u * i + 1u];
+            const bool ha = have[2u * i], hb = have[2u * i + 1u];
+            v[i] = hb ? a + b : a;
+            have[i] = ha;
+        }
+    }
+    return v[0];
+}
+
 __device__ double hy_diff_sum(const hy_tctx &c, unsigned a0, unsigned nargs, unsigned k)
 {
+    if (nargs <= 8u) {
+        double t[8];
+#pragma unroll
+        for (unsigned j = 0; j < 8u; ++j) {
+            const unsigned a = a0 + (j < nargs ? j : 0u);
+            t[j] = (hy_arg_type[a] == A_UVAR) ? hy_tp(c, k, hy_arg_idx[a]) : (k == 0u ? hy_numpar(c, a) : 0.0);
+        }
+        return hy_pairwise8(t, nargs);
+    }
+    // (More than 8 terms do not come out of the decomposition; kept for hand-built programs: left to right.)
     double acc = 0.0;
     for (unsigned j = 0; j < nargs; ++j) {
         const unsigned a = a0 + j;
@@ -198,6 +235,8 @@ __device__ double hy_diff_div(const hy_tctx &c, unsigned a0, unsigned u, unsigne
 
 __device__ double hy_diff_sum_sq(const hy_tctx &c, unsigned a0, unsigned nargs, unsigned k)
 {
+    // Per-argument running sums (src/detail/sum_sq.cpp:330-345), then the pairwise sum over the arguments (:371-377).
+    double terms[8];
     double tot = 0.0;
     for (unsigned q = 0; q < nargs; ++q) {
         const unsigned a = a0 + q;
@@ -217,7 +256,17 @@ __device__ double hy_diff_sum_sq(const hy_tctx &c, unsigned a0, unsigned nargs, 
             const double v = (k == 0u) ? hy_numpar(c, a) : 0.0;
             term = v * v;
         }
+        if (nargs <= 8u) {
+            // (A select chain instead of a dynamically indexed store: the slots stay in registers.)
+#pragma unroll
+            for (unsigned i = 0; i < 8u; ++i) {
+                terms[i] = (i == q) ? term : terms[i];
+            }
+        }
         tot = (q == 0u) ? term : tot + term;
+    }
+    if (nargs <= 8u) {
+        tot = hy_pairwise8(terms, nargs);
     }
     return (k % 2u == 1u) ? tot + tot : tot;
 }

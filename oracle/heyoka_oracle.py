@@ -941,7 +941,7 @@ class OracleIntegrator:
     Arrays use the reference layout array[row * batch_size + lane].
     """
 
-    def __init__(self, sys, state, batch_size, tol=None, high_accuracy=False, pars=None, time=None):
+    def __init__(self, sys, state, batch_size, tol=None, high_accuracy=False, pars=None, time=None, compact_mode=False):
         self.sys = sys
         self.dc = taylor_decompose_sys(sys)
         self.n_eq = len(sys)
@@ -950,6 +950,7 @@ class OracleIntegrator:
         self.tol = np.finfo(np.float64).eps if tol is None else float(tol)
         self.order = taylor_order_from_tol(self.tol)
         self.high_accuracy = bool(high_accuracy)
+        self.compact_mode = bool(compact_mode)
         B = self.batch_size
         self._build_program()
 
@@ -1009,7 +1010,9 @@ class OracleIntegrator:
             self.n_par,
             self.order,
             len(kinds),
-            int(self.high_accuracy),
+            # (bit 0: compensated summation; bit 1: the arithmetic of the reference's compact mode - running sums inside
+            # the convolutions, see HY_COMPACT in taylor_oracle.c.)
+            int(self.high_accuracy) | (2 if self.compact_mode else 0),
             *[_p(self._arrs[k]) for k in ("kind", "arg_off", "arg_type", "arg_idx", "arg_val", "dep", "sv_type", "sv_idx", "sv_val", "dep2")]
         )
 

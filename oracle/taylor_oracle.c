@@ -103,6 +103,16 @@ typedef struct {
 
 /* ---- helpers ---- */
 
+/* Arithmetic flavour (bit 1 of hy_oracle_program::high_accuracy; bit 0 is the compensated-summation flag): the
+ * reference's default mode forms the products of a convolution first and adds them with pairwise_sum()
+ * (src/math/prod.cpp:386-395); its COMPACT mode (kw::compact_mode, src/taylor_02.cpp:1194-1260) runs the same terms
+ * through a rolled loop with a running sum which starts from 0, acc = acc + term (src/math/prod.cpp:686-698,
+ * src/math/pow.cpp:905-925, src/math/sin.cpp:314-329, src/detail/sum_sq.cpp:330-345, ...). The terms themselves, the
+ * pairwise sum over the ARGUMENTS of sum / sum_sq (src/math/sum.cpp:355, src/detail/sum_sq.cpp:371-377) and everything
+ * outside the convolutions are the same in both modes. */
+#define HY_COMPACT(p) (((p)->high_accuracy & 2) != 0)
+#define HY_HA(p) (((p)->high_accuracy & 1) != 0)
+
 /* In-place pairwise sum of n vectors of B lanes: terms[j*B + l]. Result in terms[0..B). */
 static void pairwise_sum(double *terms, int n, int B)
 {
@@ -122,6 +132,23 @@ static void pairwise_sum(double *terms, int n, int B)
             ++m;
         }
         n = m;
+    }
+}
+
+/* Sum of the n terms of a convolution (terms[j * B + l], j in loop order), result in terms[0 .. B): pairwise (default mode)
+ * or the running sum from 0 of the reference's compact mode. */
+static void conv_sum(const hy_oracle_program *p, double *terms, int n, int B)
+{
+    if (!HY_COMPACT(p)) {
+        pairwise_sum(terms, n, B);
+        return;
+    }
+    for (int l = 0; l < B; ++l) {
+        double acc = 0.;
+        for (int j = 0; j < n; ++j) {
+            acc = acc + terms[(size_t)j * B + l];
+        }
+        terms[l] = acc;
     }
 }
 
@@ -323,7 +350,7 @@ static void node_diff(const hy_oracle_program *p, int i, int k, double *tape, co
                     double *t = scratch + (size_t)j * B;
                     for (int l = 0; l < B; ++l) t[l] = x[l] * y[l];
                 }
-                pairwise_sum(scratch, k + 1, B);
+                conv_sum(p, scratch, k + 1, B);
                 for (int l = 0; l < B; ++l) out[l] = scratch[l];
             } else if (at[0] != A_UVAR && at[1] != A_UVAR) {
                 const int neg = (at[0] == A_NUM && p->arg_val[a0] == -1.);
@@ -363,7 +390,7 @@ static void node_diff(const hy_oracle_program *p, int i, int k, double *tape, co
                         double *t = scratch + (size_t)(j - 1) * B;
                         for (int l = 0; l < B; ++l) t[l] = x[l] * y[l];
                     }
-                    pairwise_sum(scratch, k, B);
+                    conv_sum(p, scratch, k, B);
                     if (at[0] == A_UVAR) {
                         const double *nv = TAPE(k, ai[0]);
                         for (int l = 0; l < B; ++l) out[l] = (nv[l] - scratch[l]) / d0[l];
@@ -393,7 +420,7 @@ static void node_diff(const hy_oracle_program *p, int i, int k, double *tape, co
                             double *t = scratch + (size_t)j * B;
                             for (int l = 0; l < B; ++l) t[l] = x[l] * y[l];
                         }
-                        pairwise_sum(scratch, nt, B);
+                        conv_sum(p, scratch, nt, B);
                         for (int l = 0; l < B; ++l) dst[l] = scratch[l];
                     } else {
                         for (int l = 0; l < B; ++l) dst[l] = 0.;
@@ -414,7 +441,7 @@ static void node_diff(const hy_oracle_program *p, int i, int k, double *tape, co
                                 double *t = scratch + (size_t)j * B;
                                 for (int l = 0; l < B; ++l) t[l] = x[l] * y[l];
                             }
-                            pairwise_sum(scratch, nt, B);
+                            conv_sum(p, scratch, nt, B);
                             for (int l = 0; l < B; ++l) dst[l] = (scratch[l] + scratch[l]) + dst[l];
                         }
                     } else {
@@ -462,7 +489,7 @@ static void node_diff(const hy_oracle_program *p, int i, int k, double *tape, co
                     for (int l = 0; l < B; ++l) fac[l] = fac[l] - hh[l] * hh[l];
                 }
                 if (nt > 0) {
-                    pairwise_sum(scratch, nt, B);
+                    conv_sum(p, scratch, nt, B);
                     for (int l = 0; l < B; ++l) fac[l] = fac[l] - (scratch[l] + scratch[l]);
                 }
                 for (int l = 0; l < B; ++l) out[l] = fac[l] / (a_0[l] + a_0[l]);
@@ -475,7 +502,7 @@ static void node_diff(const hy_oracle_program *p, int i, int k, double *tape, co
                         double *t = scratch + (size_t)j * B;
                         for (int l = 0; l < B; ++l) t[l] = x[l] * y[l];
                     }
-                    pairwise_sum(scratch, nt, B);
+                    conv_sum(p, scratch, nt, B);
                     for (int l = 0; l < B; ++l) out[l] = scratch[l] + scratch[l];
                 } else {
                     const double *hh = TAPE(k / 2, b);
@@ -485,7 +512,7 @@ static void node_diff(const hy_oracle_program *p, int i, int k, double *tape, co
                         double *t = scratch + (size_t)j * B;
                         for (int l = 0; l < B; ++l) t[l] = x[l] * y[l];
                     }
-                    pairwise_sum(scratch, nt, B);
+                    conv_sum(p, scratch, nt, B);
                     for (int l = 0; l < B; ++l) out[l] = (scratch[l] + scratch[l]) + hh[l] * hh[l];
                 }
             } else {
@@ -496,7 +523,7 @@ static void node_diff(const hy_oracle_program *p, int i, int k, double *tape, co
                     double *t = scratch + (size_t)j * B;
                     for (int l = 0; l < B; ++l) t[l] = sf * (x[l] * y[l]);
                 }
-                pairwise_sum(scratch, k, B);
+                conv_sum(p, scratch, k, B);
                 for (int l = 0; l < B; ++l) out[l] = scratch[l] / ((double)k * b0[l]);
             }
             break;
@@ -522,7 +549,7 @@ static void node_diff(const hy_oracle_program *p, int i, int k, double *tape, co
                     double *t = scratch + (size_t)(j - 1) * B;
                     for (int l = 0; l < B; ++l) t[l] = (double)j * (x[l] * y[l]);
                 }
-                pairwise_sum(scratch, k, B);
+                conv_sum(p, scratch, k, B);
                 const double dv = is_sin ? (double)k : -(double)k;
                 for (int l = 0; l < B; ++l) out[l] = scratch[l] / dv;
             }
@@ -543,7 +570,7 @@ static void node_diff(const hy_oracle_program *p, int i, int k, double *tape, co
                     double *t = scratch + (size_t)(j - 1) * B;
                     for (int l = 0; l < B; ++l) t[l] = (double)j * (x[l] * y[l]);
                 }
-                pairwise_sum(scratch, k, B);
+                conv_sum(p, scratch, k, B);
                 for (int l = 0; l < B; ++l) out[l] = scratch[l] / (double)k;
             }
             break;
@@ -567,7 +594,7 @@ static void node_diff(const hy_oracle_program *p, int i, int k, double *tape, co
                         double *t = scratch + (size_t)(j - 1) * B;
                         for (int l = 0; l < B; ++l) t[l] = (double)j * (x[l] * y[l]);
                     }
-                    pairwise_sum(scratch, k - 1, B);
+                    conv_sum(p, scratch, k - 1, B);
                     for (int l = 0; l < B; ++l) ret[l] = ret[l] - scratch[l];
                 }
                 for (int l = 0; l < B; ++l) out[l] = ret[l] / ((double)k * b0[l]);
@@ -602,7 +629,7 @@ static void node_diff(const hy_oracle_program *p, int i, int k, double *tape, co
                     t[l] = (double)j * (xv * y[l]);
                 }
             }
-            pairwise_sum(scratch, k, B);
+            conv_sum(p, scratch, k, B);
             {
                 const double *bk = TAPE(k, b);
                 for (int l = 0; l < B; ++l) {
@@ -648,7 +675,7 @@ static void node_diff(const hy_oracle_program *p, int i, int k, double *tape, co
                 double *t = scratch + (size_t)(j - 1) * B;
                 for (int l = 0; l < B; ++l) t[l] = (double)j * (x[l] * y[l]);
             }
-            pairwise_sum(scratch, k - 1, B);
+            conv_sum(p, scratch, k - 1, B);
             for (int l = 0; l < B; ++l) {
                 double ret = (double)k * bk[l];
                 ret = (kind == K_ACOS || kind == K_ATANH) ? (ret + scratch[l]) : (ret - scratch[l]);
@@ -702,7 +729,7 @@ static void node_diff(const hy_oracle_program *p, int i, int k, double *tape, co
                         }
                     }
                 }
-                pairwise_sum(scratch, k - 1, B);
+                conv_sum(p, scratch, k - 1, B);
                 for (int l = 0; l < B; ++l) dividend[l] = dividend[l] + scratch[l];
             }
             for (int l = 0; l < B; ++l) out[l] = dividend[l] / (n * TAPE(0, d)[l]);
@@ -752,7 +779,7 @@ static void node_diff(const hy_oracle_program *p, int i, int k, double *tape, co
                         }
                     }
                 }
-                pairwise_sum(scratch, k - 1, B);
+                conv_sum(p, scratch, k - 1, B);
                 for (int l = 0; l < B; ++l) dividend[l] = dividend[l] + scratch[l];
             }
             for (int l = 0; l < B; ++l) out[l] = dividend[l] / (n * (1. - TAPE(0, c)[l]));
@@ -1030,7 +1057,7 @@ static void step_core(const hy_oracle_program *p, int B, double *state, const do
                        sizeof(double) * (size_t)B);
             }
         }
-    } else if (p->high_accuracy) {
+    } else if (HY_HA(p)) {
         double *cur_h = scratch + (size_t)B;
         double *comp = scratch + (size_t)2 * B;
         for (int i = 0; i < n_eq; ++i) {

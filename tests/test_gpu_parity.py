@@ -1375,6 +1375,45 @@ def test_reference_batch_semantics(semantics):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["wave-level", "tape in HBM"])
+def test_compact_mode_has_the_arithmetic_of_the_reference_compact_mode(variant, monkeypatch):
+    """kw::compact_mode = true is a flavour of the ARITHMETIC too: running sums inside the convolutions
+    (src/math/prod.cpp:686-698, src/math/pow.cpp:905-925, src/detail/sum_sq.cpp:330-345), pairwise sums over the arguments
+    of sum() / sum_sq() (src/math/sum.cpp:355). The oracle has the same flavour (OracleIntegrator(compact_mode=True)); built
+    without FMA contraction, the table stepper reproduces its Taylor coefficients BIT FOR BIT from identical states (the
+    N-body right-hand side contains no library function: sqrt and the divisions are correctly rounded on both sides),
+    and differs from the default-mode flavour in the last bits - for both variants of the table kernel."""
+    monkeypatch.setenv("HEYOKA_AMD_HIPRTC_FLAGS", "-ffp-contract=off")
+    monkeypatch.setenv("HEYOKA_AMD_TABLE_LDS", "1" if variant == "wave-level" else "0")
+    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    n = 64
+    for sys_g, sys_o, st, ha in (
+        (hy.model.nbody(6, masses=M, Gconst=G), ho.nbody(6, masses=M, Gconst=G), configs.outer_ss_state(n, perturb=1e-6, seed=2), True),
+        (hy.model.nbody(4), ho.nbody(4), configs.plummer_nbody_state(4, n, seed=5), False),
+    ):
+        ta = hy.taylor_adaptive_batch(sys_g, st, n, high_accuracy=ha, compact_mode=True)
+        assert ta.hip_source_mode.startswith("table") and variant in ta.hip_source_mode, ta.hip_source_mode
+        oc = ho.OracleIntegrator(sys_o, st, n, high_accuracy=ha, compact_mode=True)
+        od = ho.OracleIntegrator(sys_o, st, n, high_accuracy=ha)
+        n_eq, p = st.shape[0], ta.order
+        diff_default = 0
+        for _ in range(3):
+            ta.state = oc.state.reshape(n_eq, n)
+            od.state[:] = oc.state
+            ta.step(write_tc=True)
+            oc.step(wtc=True)
+            od.step(wtc=True)
+            tc_g = np.asarray(ta.tc).reshape(n_eq, p + 1, n)
+            assert np.array_equal(tc_g, oc.tc.reshape(n_eq, p + 1, n))
+            diff_default += np.count_nonzero(tc_g != od.tc.reshape(n_eq, p + 1, n))
+            # (The step size goes through exp(log()) on the device and pow() in the oracle: a few ulps.)
+            h_g = np.array([h for _, h in ta.step_res])
+            h_o = np.array([h for _, h in oc.step_res])
+            assert np.max(np.abs(h_g - h_o) / np.abs(h_o)) <= 16 * EPS
+        assert diff_default > 0
+
+
+@pytest.mark.gpu
 def test_compact_mode_kwarg_selects_the_table_stepper():
     """kw::compact_mode = true (include/heyoka/kw.hpp) is honoured: the table-driven stepper (the analogue of
     src/taylor_02.cpp:1194-1260) instead of straight-line code, same results as the default mode and as the oracle."""
