@@ -1375,6 +1375,26 @@ def test_reference_batch_semantics(semantics):
 
 
 @pytest.mark.gpu
+def test_default_mode_unrolled_kernel_is_bit_identical_to_the_oracle_without_contraction(monkeypatch):
+    """The unrolled generator follows the reference's default-mode operation order (products first, pairwise sums:
+    src/math/prod.cpp:386-395); with kw::exact_division = true (true quotients instead of the reciprocal forms) and built
+    without FMA contraction, its Taylor coefficients of the two-body problem are those of the strict-IEEE oracle BIT FOR
+    BIT from identical states - the 1e5 eps of the other parity tests are contraction and the reciprocal forms only."""
+    monkeypatch.setenv("HEYOKA_AMD_HIPRTC_FLAGS", "-ffp-contract=off")
+    n = 64
+    st = configs.two_body_state(n, perturb=1e-3, seed=21)
+    ta = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), st, n, exact_division=True)
+    assert ta.hip_source_mode.startswith("unrolled"), ta.hip_source_mode
+    ora = ho.OracleIntegrator(ho.nbody(2, masses=[1.0, 0.0]), st, n)
+    for _ in range(4):
+        ta.state = ora.state.reshape(12, n)
+        ta.step(write_tc=True)
+        ora.step(wtc=True)
+        tc_g, tc_o = np.asarray(ta.tc).reshape(12, ta.order + 1, n), ora.tc.reshape(12, ta.order + 1, n)
+        assert np.array_equal(tc_g, tc_o), (np.count_nonzero(tc_g != tc_o), np.max(np.abs(tc_g - tc_o) / (np.abs(tc_o) + 1e-300)))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("variant", ["wave-level", "tape in HBM"])
 def test_compact_mode_has_the_arithmetic_of_the_reference_compact_mode(variant, monkeypatch):
     """kw::compact_mode = true is a flavour of the ARITHMETIC too: running sums inside the convolutions
