@@ -22,9 +22,9 @@ if [ -x $R/profiles/ubench/stream8.bin ]; then
   tail -40 "$OUT/cal.log"
 fi
 for WL in $WLS; do
-  timeout 900 python $R/bench.py --workload $WL --steps 20 --warmup 5 > "$OUT/bench_$WL.log" 2>&1
+  timeout 900 python $R/bench.py --workload $WL --steps 20 --warmup 5 --no-extra-workloads > "$OUT/bench_$WL.log" 2>&1
   tail -1 "$OUT/bench_$WL.log" | cut -c1-200
-  CMD="python $R/bench.py --workload $WL --no-cpu-baseline --steps 4 --warmup 1"
+  CMD="python $R/bench.py --workload $WL --no-cpu-baseline --no-extra-workloads --steps 4 --warmup 1"
   timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/kt_$WL" -o kt -- $CMD > "$OUT/kt_$WL.log" 2>&1
   timeout 600 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pf_$WL" -o pf -- $CMD > "$OUT/pf_$WL.log" 2>&1
   timeout 600 rocprofv3 --pmc WRITE_SIZE -d "$OUT/pw_$WL" -o pw -- $CMD > "$OUT/pw_$WL.log" 2>&1
