@@ -1080,12 +1080,18 @@ def _random_system(m, rng, n_var=3, extended=False):
 EXT_SEEDS = [1000 + i for i in range(12)]
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5, 7, 8, 9] + EXT_SEEDS)
-def test_random_systems_all_code_paths_vs_oracle(seed):
+@pytest.mark.parametrize("seed,contract", [(sd, True) for sd in [0, 1, 2, 3, 4, 5, 7, 8, 9] + EXT_SEEDS]
+                         + [(sd, False) for sd in [0, 1, 2, 3, 5, 8] + EXT_SEEDS[:6]])
+def test_random_systems_all_code_paths_vs_oracle(seed, contract, monkeypatch):
     """Pseudo-random ODE systems over the whole function set (shared subexpressions, parameters, explicit time): the
     default code generator and the table-driven one against the oracle - decomposition, one full step with
-    Taylor coefficients, a short propagation."""
+    Taylor coefficients, a short propagation. contract = False: the same kernels built without FMA contraction and with
+    true quotients, at the reference's tolerances (h 1e4 eps, coefficients 1e5 eps: test/two_body_batch.cpp:118-150)."""
     import os
+
+    if not contract:
+        monkeypatch.setenv("HEYOKA_AMD_HIPRTC_FLAGS", "-ffp-contract=off")
+    h_tol, tc_tol = (1e6, 1e6) if contract else (1e4, 1e5)
 
     n = 33
     rs = np.random.RandomState(100 + seed)
@@ -1099,7 +1105,7 @@ def test_random_systems_all_code_paths_vs_oracle(seed):
             os.environ["HEYOKA_AMD_EMIT_MODE"] = "table"
         try:
             sys_p = _random_system(hy, np.random.RandomState(seed), extended=ext)
-            ta = hy.taylor_adaptive_batch(sys_p, st, n, pars=pars, time=t0)
+            ta = hy.taylor_adaptive_batch(sys_p, st, n, pars=pars, time=t0, exact_division=not contract)
         finally:
             os.environ.pop("HEYOKA_AMD_EMIT_MODE", None)
         assert hy.taylor_decompose_sys(sys_p) == ho.dc_to_strings(ho.taylor_decompose_sys(sys_o))
@@ -1108,10 +1114,10 @@ def test_random_systems_all_code_paths_vs_oracle(seed):
         ora.step(wtc=True)
         h_g = np.array([h for _, h in ta.step_res])
         h_o = np.array([h for _, h in ora.step_res])
-        assert np.max(np.abs(h_g - h_o) / np.abs(h_o)) <= 1e6 * EPS
+        assert np.max(np.abs(h_g - h_o) / np.abs(h_o)) <= h_tol * EPS
         tc_o = ora.tc.reshape(3, ora.order + 1, n)
         scale = np.max(np.abs(tc_o), axis=2, keepdims=True) + 1e-300
-        assert np.max(np.abs(np.asarray(ta.tc).reshape(3, 21, n) - tc_o) / scale) <= 1e6 * EPS
+        assert np.max(np.abs(np.asarray(ta.tc).reshape(3, 21, n) - tc_o) / scale) <= tc_tol * EPS
         assert rel_err(ta.state, ora.state.reshape(3, n)) <= 1e5 * EPS
         ta.propagate_for(0.5)
         ora.propagate_for(0.5)
