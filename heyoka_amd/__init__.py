@@ -744,7 +744,8 @@ class taylor_adaptive_batch:
 
     def __init__(self, sys, state=None, batch_size=None, *, tol=None, high_accuracy=False, compact_mode=False,
                  parallel_mode=False, pars=None, time=None, device=0, t_events=(), nt_events=(), emitter=None,
-                 cluster_kernel=None, exact_division=False, events_on_cluster=None, batch_semantics=None, _handle=None,
+                 cluster_kernel=None, exact_division=False, events_on_cluster=None, batch_semantics=None, sum_order=None,
+                 _handle=None,
                  _events=None, **ignored_llvm_kwargs):
         # MI355X extensions (hy_tab_config, include/heyoka_amd.h): emitter in (None, "unrolled", "cluster", "table",
         # "block"); cluster_kernel in (None, "v5", "v3", "v2", "v1"); exact_division; events_on_cluster (None / False);
@@ -794,6 +795,7 @@ class taylor_adaptive_batch:
         cfg.cluster_kernel = _enum_arg("cluster_kernel", cluster_kernel, {None: 0, "auto": 0, "v5": 5, "v3": 3, "v2": 2, "v1": 1})
         cfg.exact_division = int(bool(exact_division))
         cfg.events_on_cluster = 1 if events_on_cluster is False else 0
+        cfg.sum_order = _enum_arg("sum_order", sum_order, {None: 0, "auto": 0, "pairwise": 1, "running": 2})
         cfg.batch_semantics = _enum_arg("batch_semantics", batch_semantics,
                                         {None: 0, "reference": 0, "lockstep": 1, "per_lane": 2})
         if tol is not None and float(tol) == 0.0:

@@ -44,6 +44,7 @@ class TabConfig(ctypes.Structure):
         ("cluster_kernel", c_int),
         ("exact_division", c_int),
         ("events_on_cluster", c_int),
+        ("sum_order", c_int),
         ("batch_semantics", c_int),
     ]
 

@@ -681,6 +681,7 @@ hy_tab hy_tab_create_with_events(hy_sys sys, const double *state, size_t n_state
             c.emitter = cfg->emitter;
             c.cluster_kernel = cfg->cluster_kernel;
             c.exact_division = cfg->exact_division != 0;
+            c.sum_order = cfg->sum_order;
             c.events_on_cluster = cfg->events_on_cluster;
             c.batch_semantics = cfg->batch_semantics;
         }

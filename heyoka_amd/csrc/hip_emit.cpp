@@ -150,6 +150,48 @@ __device__ __forceinline__ double hy_root(double x, double c)
     return exp(log(x) * c);
 }
 
+// Logarithm of the step-size selector: written out (45 VALU instructions) instead of the device library's log() (95:
+// double-double arithmetic for < 1 ulp) - the selector takes the logarithms of max(1, |x|_inf), |x^[p]|_inf and
+// |x^[p-1]|_inf at every step (no quotients: log(num / m) = log(num) - log(m), with the same limits 0 -> +inf,
+// inf -> -inf, inf - inf -> nan), which was a sixth of the serial tail of a step of the cluster kernels (there the three
+// arguments sit on three lanes of a quad and share ONE evaluation) and 8 % of the two-body stepper. frexp, m in
+// [sqrt(1/2), sqrt(2)), z = (m - 1) / (m + 1) by reciprocal + two Newton steps + one residual correction,
+// log m = 2 z + z^3 P(z^2) with the Taylor coefficients 2 / (2 n + 1) up to z^21 (|z| <= 0.1716: the first neglected term
+// is 2e-17 relative), e ln 2 added in two pieces. Error < 2 ulp (checked against logl on 2e7 arguments); the roots of
+// the selector scale it by 1 / p. 0 -> -inf, +inf -> +inf, nan -> nan like log().
+__device__ __forceinline__ double hy_sel_log(double x)
+{
+    double m = __builtin_amdgcn_frexp_mant(x);
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool lo = m < 0x1.6a09e667f3bcdp-1;
+    m = m * (lo ? 2.0 : 1.0);
+    e -= lo ? 1 : 0;
+    const double num = m - 1.0, den = m + 1.0;
+    double r = __builtin_amdgcn_rcp(den);
+    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+    double z = num * r;
+    z = __builtin_fma(__builtin_fma(-den, z, num), r, z);
+    const double w = z * z;
+    double p = 0x1.8618618618618p-4;
+    p = __builtin_fma(p, w, 0x1.af286bca1af28p-4);
+    p = __builtin_fma(p, w, 0x1.e1e1e1e1e1e1ep-4);
+    p = __builtin_fma(p, w, 0x1.1111111111111p-3);
+    p = __builtin_fma(p, w, 0x1.3b13b13b13b14p-3);
+    p = __builtin_fma(p, w, 0x1.745d1745d1746p-3);
+    p = __builtin_fma(p, w, 0x1.c71c71c71c71cp-3);
+    p = __builtin_fma(p, w, 0x1.2492492492492p-2);
+    p = __builtin_fma(p, w, 0x1.999999999999ap-2);
+    p = __builtin_fma(p, w, 0x1.5555555555555p-1);
+    const double ed = (double)e;
+    double res = __builtin_fma(ed, 0x1.abc9e3b39803fp-56, (z * w) * p);
+    res = __builtin_fma(2.0, z, res);
+    res = __builtin_fma(ed, 0x1.62e42fefa39efp-1, res);
+    res = (x == 0.0) ? -__builtin_inf() : res;
+    res = (x == __builtin_inf()) ? x : res;
+    return res;
+}
+
 // Out-of-line calls for the math-library functions with data-dependent control flow in their device implementations
 // (the Payne-Hanek branch of sin/cos/tan, the piecewise ranges of erf, ...). Inlined into a straight-line kernel with
 // several hundred live registers, those divergent if/else regions are where the register allocator splits long live
@@ -346,6 +388,7 @@ std::string emit_unrolled_kernel(const taylor_program &p, const emit_options &op
     ssa_emitter e(p, order);
     auto &os = e.os;
     e.enable_pow_rcp(!opts.exact_division);
+    e.running_sums = opts.sum_order != 1;
 
     os << "extern \"C\" __global__ void __launch_bounds__(" << bs << ") " << kname << "(const hy_kargs a)\n{\n";
     os << "const u64 s = (u64)blockIdx.x * " << bs << "u + threadIdx.x;\n";
@@ -473,11 +516,13 @@ if (a.mode == 1) {
     };
     const auto m0 = max_abs(0), mo = max_abs(order), mom1 = max_abs(order - 1u);
     os << "const double num_rho = (" << m0 << " <= 1.0) ? 1.0 : " << m0 << ";\n";
-    os << "const double rho_o = hy_root(num_rho / " << mo << ", " << fp_literal(1. / static_cast<double>(order))
-       << ");\n";
-    os << "const double rho_om1 = hy_root(num_rho / " << mom1 << ", "
-       << fp_literal(1. / static_cast<double>(order - 1u)) << ");\n";
-    os << "const double rho_m = hy_min(rho_o, rho_om1);\n";
+    // rho = exp(log(num / m) / order) (the (1/p)-th roots of src/taylor_00.cpp:242-252): the minimum of the two estimates
+    // is taken on the exponents (exp is monotone and keeps nans), the quotients become differences of logarithms.
+    os << "const double lg_num = hy_sel_log(num_rho);\n";
+    os << "const double lr_o = (lg_num - hy_sel_log(" << mo << ")) * " << fp_literal(1. / static_cast<double>(order)) << ";\n";
+    os << "const double lr_om1 = (lg_num - hy_sel_log(" << mom1 << ")) * " << fp_literal(1. / static_cast<double>(order - 1u))
+       << ";\n";
+    os << "const double rho_m = exp(hy_min(lr_o, lr_om1));\n";
     os << "double h = rho_m * " << fp_literal(rhofac(order)) << ";\n";
     os << "h = hy_min(h, fabs(lim));\n";
     os << "h = (lim < 0.0) ? -h : h;\n";
@@ -752,6 +797,8 @@ emitted_module emit_event_jets(const taylor_program &p, const emit_options &opts
 
     ssa_emitter e(p, order);
     auto &os = e.os;
+    // (The same node rules and addition order as the one-system-per-lane stepper with events.)
+    e.running_sums = opts.sum_order != 1;
     os << "extern \"C\" __global__ void __launch_bounds__(256) hy_ev_jets(const hy_kargs a)\n{\n";
     os << "const u64 N = a.N;\nconst u64 s = (u64)blockIdx.x * 256u + threadIdx.x;\nif (s >= N) return;\n";
     std::vector<char> par_used(p.n_par, 0);

@@ -67,6 +67,11 @@ struct emit_options {
     // Correctly rounded quotients in the recurrences of the pair kernels (division by the order, quotient of the pow
     // recurrence) instead of the reciprocal forms (within 1 ulp of them): kw::exact_division.
     bool exact_division = false;
+    // Order of the additions inside the convolutions of the straight-line (unrolled) generator: 0 automatic = 2; 1 = the
+    // reference's default mode (products first, pairwise sum: src/math/prod.cpp:386-395), 2 = the reference's compact mode
+    // (running sum from 0: src/math/prod.cpp:686-698; one FMA per term). kw::sum_order. The table stepper always uses the
+    // running sums, the cluster kernels their own FMA chains.
+    int sum_order = 0;
 };
 
 struct emitted_module {

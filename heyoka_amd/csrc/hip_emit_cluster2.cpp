@@ -1622,47 +1622,7 @@ __device__ __forceinline__ double hy_dpp(double x)
     return __hiloint2double(hi, lo);
 }
 )HIP";
-    // Logarithm of the step-size selector (packed tail): the three arguments (max(1, |x|_inf), |x^[p]|_inf, |x^[p-1]|_inf)
-    // sit on three lanes of a quad and share ONE evaluation - written out here (45 VALU instructions) instead of the
-    // device library's log() (95: double-double arithmetic for < 1 ulp), since three of those were a sixth of the serial
-    // tail of a step. frexp, m in [sqrt(1/2), sqrt(2)), z = (m - 1) / (m + 1) by reciprocal + two Newton steps + one
-    // residual correction, log m = 2 z + z^3 P(z^2) with the Taylor coefficients 2 / (2 n + 1) up to z^21 (|z| <= 0.1716:
-    // the first neglected term is 2e-17 relative), e ln 2 added in two pieces. Error ~1.5 ulp; the roots of the selector
-    // scale it by 1 / p. 0 -> -inf, +inf -> +inf, nan -> nan like log().
-    src << R"HIP(
-__device__ __forceinline__ double hy_sel_log(double x)
-{
-    double m = __builtin_amdgcn_frexp_mant(x);
-    int e = __builtin_amdgcn_frexp_exp(x);
-    const bool lo = m < 0x1.6a09e667f3bcdp-1;
-    m = m * (lo ? 2.0 : 1.0);
-    e -= lo ? 1 : 0;
-    const double num = m - 1.0, den = m + 1.0;
-    double r = __builtin_amdgcn_rcp(den);
-    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
-    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
-    double z = num * r;
-    z = __builtin_fma(__builtin_fma(-den, z, num), r, z);
-    const double w = z * z;
-    double p = 0x1.8618618618618p-4;
-    p = __builtin_fma(p, w, 0x1.af286bca1af28p-4);
-    p = __builtin_fma(p, w, 0x1.e1e1e1e1e1e1ep-4);
-    p = __builtin_fma(p, w, 0x1.1111111111111p-3);
-    p = __builtin_fma(p, w, 0x1.3b13b13b13b14p-3);
-    p = __builtin_fma(p, w, 0x1.745d1745d1746p-3);
-    p = __builtin_fma(p, w, 0x1.c71c71c71c71cp-3);
-    p = __builtin_fma(p, w, 0x1.2492492492492p-2);
-    p = __builtin_fma(p, w, 0x1.999999999999ap-2);
-    p = __builtin_fma(p, w, 0x1.5555555555555p-1);
-    const double ed = (double)e;
-    double res = __builtin_fma(ed, 0x1.abc9e3b39803fp-56, (z * w) * p);
-    res = __builtin_fma(2.0, z, res);
-    res = __builtin_fma(ed, 0x1.62e42fefa39efp-1, res);
-    res = (x == 0.0) ? -__builtin_inf() : res;
-    res = (x == __builtin_inf()) ? x : res;
-    return res;
-}
-)HIP";
+    // (hy_sel_log(): the logarithm of the step-size selector, in the common prelude - hip_emit.cpp.)
     if (pair_split) {
         // Exchange between the two lanes of a pair: DPP quad_perm [1,0,3,2] on the two halves of the double.
         src << R"HIP(

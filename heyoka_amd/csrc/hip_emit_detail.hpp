@@ -91,6 +91,25 @@ struct ssa_emitter {
         return pairwise(std::move(v), "+");
     }
 
+    // Sum of the terms of a CONVOLUTION (the products of a prod / sum_sq / pow / div / sin ... rule, in loop order). The
+    // reference's default mode adds them pairwise (src/math/prod.cpp:386-395); its compact mode accumulates them in a
+    // running sum which starts from 0 (src/math/prod.cpp:686-698). The running sum is the cheaper of the two in
+    // straight-line code: with FMA contraction it is one instruction per term (k + 1 FMAs) where the pairwise tree needs
+    // ~1.5 (k + 1) (half of the products cannot be fused into an addition). emit_options::sum_order selects
+    // (hip_emit.hpp); the sums over the ARGUMENTS of sum() / sum_sq() are pairwise in both modes.
+    bool running_sums = false;
+    std::string conv_sum(std::vector<std::string> v)
+    {
+        if (!running_sums) {
+            return pairwise(std::move(v), "+");
+        }
+        auto acc = v.at(0);
+        for (std::size_t j = 1; j < v.size(); ++j) {
+            acc = def(acc + " + " + v[j]);
+        }
+        return acc;
+    }
+
     // Optional replacement names for specific numerical operands (keyed by address of the operand in
     // the program): used by the cluster generator for constants that differ between isomorphic clusters.
     std::map<const operand *, std::string> numpar_override;
@@ -221,7 +240,7 @@ struct ssa_emitter {
                     for (std::uint32_t j = 0; j <= k; ++j) {
                         terms.push_back(def(mul(val(a[0].idx, k - j), val(a[1].idx, j))));
                     }
-                    out = pairwise_sum(std::move(terms));
+                    out = conv_sum(std::move(terms));
                 } else if (!is_var(a[0]) && !is_var(a[1])) {
                     if (k != 0u) {
                         out = "0.0";
@@ -252,7 +271,7 @@ struct ssa_emitter {
                         for (std::uint32_t j = 1; j <= k; ++j) {
                             terms.push_back(def(mul(val(u, k - j), val(a[1].idx, j))));
                         }
-                        const auto acc = pairwise_sum(std::move(terms));
+                        const auto acc = conv_sum(std::move(terms));
                         if (is_var(a[0])) {
                             out = def("(" + val(a[0].idx, k) + " - " + acc + ") / " + val(a[1].idx, 0));
                         } else {
@@ -276,7 +295,7 @@ struct ssa_emitter {
                             for (std::uint32_t j = 0; j <= (k - 1u) / 2u; ++j) {
                                 terms.push_back(def(mul(val(o.idx, k - j), val(o.idx, j))));
                             }
-                            tmp.push_back(pairwise_sum(std::move(terms)));
+                            tmp.push_back(conv_sum(std::move(terms)));
                         } else {
                             tmp.emplace_back("0.0");
                         }
@@ -293,7 +312,7 @@ struct ssa_emitter {
                                 for (std::uint32_t j = 0; j <= (k - 2u) / 2u; ++j) {
                                     terms.push_back(def(mul(val(o.idx, k - j), val(o.idx, j))));
                                 }
-                                const auto ps = pairwise_sum(std::move(terms));
+                                const auto ps = conv_sum(std::move(terms));
                                 const auto ps2 = def(ps + " + " + ps);
                                 sq = def(ps2 + " + " + sq);
                             }
@@ -337,7 +356,7 @@ struct ssa_emitter {
                         fac = def(fac + " - " + sq);
                     }
                     if (!terms.empty()) {
-                        const auto ps = pairwise_sum(std::move(terms));
+                        const auto ps = conv_sum(std::move(terms));
                         const auto ps2 = def(ps + " + " + ps);
                         fac = def(fac + " - " + ps2);
                     }
@@ -349,7 +368,7 @@ struct ssa_emitter {
                         for (std::uint32_t j = 0; j <= (k - 1u) / 2u; ++j) {
                             terms.push_back(def(mul(val(b, k - j), val(b, j))));
                         }
-                        const auto ps = pairwise_sum(std::move(terms));
+                        const auto ps = conv_sum(std::move(terms));
                         out = def(ps + " + " + ps);
                     } else {
                         const auto &hv = val(b, k / 2u);
@@ -357,7 +376,7 @@ struct ssa_emitter {
                         for (std::uint32_t j = 0; j <= (k - 2u) / 2u; ++j) {
                             terms.push_back(def(mul(val(b, k - j), val(b, j))));
                         }
-                        const auto ps = pairwise_sum(std::move(terms));
+                        const auto ps = conv_sum(std::move(terms));
                         const auto ps2 = def(ps + " + " + ps);
                         out = def(ps2 + " + " + sq);
                     }
@@ -370,7 +389,7 @@ struct ssa_emitter {
                         const auto pr = def(mul(val(b, k - j), val(u, j)));
                         terms.push_back(def(mul(fp_literal(sf), pr)));
                     }
-                    const auto acc = pairwise_sum(std::move(terms));
+                    const auto acc = conv_sum(std::move(terms));
                     out = pow_quotient(u, b, acc, k);
                 }
                 break;
@@ -397,7 +416,7 @@ struct ssa_emitter {
                         const auto pr = def(mul(val(d, k - j), val(b, j)));
                         terms.push_back(def(mul(fp_literal(static_cast<double>(j)), pr)));
                     }
-                    const auto acc = pairwise_sum(std::move(terms));
+                    const auto acc = conv_sum(std::move(terms));
                     // NOTE: division by the (constant) order via the exact FMA sequence of div_const() (bit-identical
                     // to the IEEE quotient); x / (-k) == -(x / k) exactly.
                     const auto q = div_const(acc, k);
@@ -420,7 +439,7 @@ struct ssa_emitter {
                         const auto pr = def(mul(val(u, k - j), val(b, j)));
                         terms.push_back(def(mul(fp_literal(static_cast<double>(j)), pr)));
                     }
-                    const auto acc = pairwise_sum(std::move(terms));
+                    const auto acc = conv_sum(std::move(terms));
                     out = div_const(acc, k);
                 }
                 break;
@@ -444,7 +463,7 @@ struct ssa_emitter {
                             const auto pr = def(mul(val(b, k - j), val(u, j)));
                             terms.push_back(def(mul(fp_literal(static_cast<double>(j)), pr)));
                         }
-                        const auto acc = pairwise_sum(std::move(terms));
+                        const auto acc = conv_sum(std::move(terms));
                         ret = def(ret + " - " + acc);
                     }
                     out = def(ret + " / " + nb0);
@@ -490,7 +509,7 @@ struct ssa_emitter {
                     const auto pr = def(mul(x, val(b, j)));
                     terms.push_back(def(mul(fp_literal(static_cast<double>(j)), pr)));
                 }
-                const auto acc = div_const(pairwise_sum(std::move(terms)), k);
+                const auto acc = div_const(conv_sum(std::move(terms)), k);
                 if (n.kind == func_kind::tan) {
                     out = def(val(b, k) + " + " + acc);
                 } else if (n.kind == func_kind::tanh) {
@@ -558,7 +577,7 @@ struct ssa_emitter {
                     const auto pr = def(mul(val(d, k - j), val(u, j)));
                     terms.push_back(def(mul(fp_literal(static_cast<double>(j)), pr)));
                 }
-                ret = def(ret + (plus ? " + " : " - ") + pairwise_sum(std::move(terms)));
+                ret = def(ret + (plus ? " + " : " - ") + conv_sum(std::move(terms)));
                 out = def(ret + " / " + def(mul(kf, D)));
                 break;
             }
@@ -670,7 +689,7 @@ struct ssa_emitter {
                             terms.push_back(def(mul(fp_literal(-static_cast<double>(j)), t3)));
                         }
                     }
-                    dividend = def(dividend + " + " + pairwise_sum(std::move(terms)));
+                    dividend = def(dividend + " + " + conv_sum(std::move(terms)));
                 }
                 out = def(dividend + " / " + divisor);
                 break;
@@ -714,7 +733,7 @@ struct ssa_emitter {
                             terms.push_back(def(mul(jf, ca)));
                         }
                     }
-                    dividend = def(dividend + " + " + pairwise_sum(std::move(terms)));
+                    dividend = def(dividend + " + " + conv_sum(std::move(terms)));
                 }
                 out = def(dividend + " / " + divisor);
                 break;

@@ -84,6 +84,7 @@ HEYOKA_AMD_KWARG(device);
 HEYOKA_AMD_KWARG(emitter);
 HEYOKA_AMD_KWARG(cluster_kernel);
 HEYOKA_AMD_KWARG(exact_division);
+HEYOKA_AMD_KWARG(sum_order);
 HEYOKA_AMD_KWARG(events_on_cluster);
 HEYOKA_AMD_KWARG(batch_semantics);
 

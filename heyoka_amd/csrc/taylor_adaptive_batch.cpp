@@ -81,7 +81,7 @@ struct tab_core::impl {
     bool compact_mode = false;
     // MI355X extensions of the configuration (tab_core::config): code generator, cluster generator, exact divisions,
     // steppers used with events, outcome semantics of propagate_for / propagate_until.
-    int emitter = 0, cluster_kernel = 0, events_on_cluster = 0, batch_semantics = 0;
+    int emitter = 0, cluster_kernel = 0, events_on_cluster = 0, batch_semantics = 0, sum_order = 0;
     bool exact_division = false;
     std::uint32_t N = 0; // batch size == number of systems.
     std::uint32_t dim = 0;
@@ -414,6 +414,11 @@ tab_core::tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_siz
     d.emitter = cfg.emitter;
     d.cluster_kernel = cfg.cluster_kernel;
     d.exact_division = cfg.exact_division;
+    d.sum_order = cfg.sum_order;
+    if (d.sum_order < 0 || d.sum_order > 2) {
+        throw std::invalid_argument("Invalid order of summation selected in an adaptive Taylor integrator in batch mode: "
+                                    + std::to_string(d.sum_order) + " (0 automatic, 1 pairwise, 2 running sums)");
+    }
     d.events_on_cluster = cfg.events_on_cluster;
     d.batch_semantics = cfg.batch_semantics;
     if (d.emitter < 0 || d.emitter > 4) {
@@ -564,6 +569,7 @@ tab_core::tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_siz
     eo.batch_size = d.N;
     eo.cluster_kernel = d.cluster_kernel;
     eo.exact_division = d.exact_division;
+    eo.sum_order = d.sum_order;
     // NOTE: the stepper with events (mode 4) is implemented by the one-system-per-lane kernels: fully unrolled for
     // small decompositions, table-driven otherwise (HEYOKA_AMD_EMIT_MODE=table forces the latter).
     if (d.has_events()) {
@@ -641,6 +647,7 @@ tab_core::tab_core(const tab_core &o) : m_impl(std::make_unique<impl>())
     d.emitter = s.emitter;
     d.cluster_kernel = s.cluster_kernel;
     d.exact_division = s.exact_division;
+    d.sum_order = s.sum_order;
     d.events_on_cluster = s.events_on_cluster;
     d.batch_semantics = s.batch_semantics;
     d.N = s.N;

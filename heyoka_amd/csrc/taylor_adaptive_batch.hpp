@@ -110,6 +110,9 @@ public:
         // Wave-cluster generator: 0 automatic, or 5 / 3 / 2 / 1 (see emit_options::cluster_kernel).
         int cluster_kernel = 0;
         bool exact_division = false;
+        // Order of the additions inside the convolutions of the unrolled generator: 0 automatic (running sums), 1 the
+        // reference's default mode (pairwise), 2 its compact mode (running sums) - emit_options::sum_order.
+        int sum_order = 0;
         // Events next to a system which qualifies for a wave-cluster stepper: 0 automatic (cluster stepper + hy_ev_jets when
         // the event equations are small), 1 always the one-system-per-lane steppers with events.
         int events_on_cluster = 0;
@@ -370,6 +373,7 @@ class taylor_adaptive_batch<double>
         cfg.emitter = static_cast<int>(kw::get(kw::emitter, 0, kw_args...));
         cfg.cluster_kernel = static_cast<int>(kw::get(kw::cluster_kernel, 0, kw_args...));
         cfg.exact_division = static_cast<bool>(kw::get(kw::exact_division, false, kw_args...));
+        cfg.sum_order = static_cast<int>(kw::get(kw::sum_order, 0, kw_args...));
         cfg.events_on_cluster = static_cast<int>(kw::get(kw::events_on_cluster, 0, kw_args...));
         cfg.batch_semantics = static_cast<int>(kw::get(kw::batch_semantics, 0, kw_args...));
         cfg.parallel_mode = static_cast<bool>(kw::get(kw::parallel_mode, false, kw_args...));

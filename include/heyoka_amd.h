@@ -178,6 +178,8 @@ typedef struct {
     int cluster_kernel;    /* wave-cluster generator: 0 automatic, 5 one lane per pair, 3 lane pairs, 2 pipelined, 1 first generation */
     int exact_division;    /* != 0: correctly rounded quotients in the recurrences of the pair kernels (default: reciprocal forms, within 1 ulp) */
     int events_on_cluster; /* 0 automatic; 1: integrators with events always use the one-system-per-lane steppers */
+    int sum_order;         /* additions inside the convolutions of the unrolled generator: 0 automatic (= 2), 1 the reference's
+                            * default mode (products first, pairwise sum), 2 its compact mode (running sums: one FMA per term) */
     int batch_semantics;   /* propagate_for/until when a lane goes non-finite or max_steps is hit: 0 the reference's batch-wide
                             * outcomes (src/taylor_adaptive_batch.cpp:1404-1407, :1462-1467, :1516), 1 always the lock-step loop,
                             * 2 per-lane outcomes of the device-resident path (no snapshot, fully asynchronous) */

@@ -1313,7 +1313,10 @@ def test_contraction_off_build_meets_the_reference_tolerances(which, monkeypatch
     ta = hy.taylor_adaptive_batch(sys_g, st, n, high_accuracy=ha)
     if which.startswith("outer_ss"):
         assert which[-2:] in ta.hip_source_mode, ta.hip_source_mode
-    ora = ho.OracleIntegrator(sys_o, st, n, high_accuracy=ha)
+    # (The unrolled generator adds the terms of a convolution in the order of the reference's compact mode by default,
+    # kw::sum_order: the oracle of the same flavour. The step size of a near-circular orbit is conditioned like 1e5: the
+    # ulp-level differences between the two flavours alone would move it by more than the 1e4 eps asserted here.)
+    ora = ho.OracleIntegrator(sys_o, st, n, high_accuracy=ha, compact_mode=(which == "two_body_unrolled"))
     n_eq, p = st.shape[0], ta.order
     for _ in range(4):
         # Identical states at the beginning of every step.
@@ -1381,17 +1384,21 @@ def test_reference_batch_semantics(semantics):
 
 
 @pytest.mark.gpu
-def test_default_mode_unrolled_kernel_is_bit_identical_to_the_oracle_without_contraction(monkeypatch):
-    """The unrolled generator follows the reference's default-mode operation order (products first, pairwise sums:
-    src/math/prod.cpp:386-395); with kw::exact_division = true (true quotients instead of the reciprocal forms) and built
-    without FMA contraction, its Taylor coefficients of the two-body problem are those of the strict-IEEE oracle BIT FOR
-    BIT from identical states - the 1e5 eps of the other parity tests are contraction and the reciprocal forms only."""
+@pytest.mark.parametrize("sum_order", ["pairwise", "running"])
+def test_unrolled_kernel_is_bit_identical_to_the_oracle_without_contraction(sum_order, monkeypatch):
+    """The unrolled generator keeps the reference's operation order inside the convolutions, in either of its two forms
+    (kw::sum_order): "pairwise" = the default mode (products first, pairwise sums: src/math/prod.cpp:386-395), "running" =
+    the compact mode (running sums from 0: src/math/prod.cpp:686-698; the generator's default - one FMA per term once
+    contraction is allowed). With kw::exact_division = true (true quotients instead of the reciprocal forms) and built
+    without FMA contraction, its Taylor coefficients of the two-body problem are those of the strict-IEEE oracle of the
+    same flavour BIT FOR BIT from identical states - the 1e5 eps of the other parity tests are contraction and the
+    reciprocal forms only."""
     monkeypatch.setenv("HEYOKA_AMD_HIPRTC_FLAGS", "-ffp-contract=off")
     n = 64
     st = configs.two_body_state(n, perturb=1e-3, seed=21)
-    ta = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), st, n, exact_division=True)
+    ta = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), st, n, exact_division=True, sum_order=sum_order)
     assert ta.hip_source_mode.startswith("unrolled"), ta.hip_source_mode
-    ora = ho.OracleIntegrator(ho.nbody(2, masses=[1.0, 0.0]), st, n)
+    ora = ho.OracleIntegrator(ho.nbody(2, masses=[1.0, 0.0]), st, n, compact_mode=(sum_order == "running"))
     for _ in range(4):
         ta.state = ora.state.reshape(12, n)
         ta.step(write_tc=True)
