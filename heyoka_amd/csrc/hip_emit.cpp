@@ -389,6 +389,10 @@ std::string emit_unrolled_kernel(const taylor_program &p, const emit_options &op
     auto &os = e.os;
     e.enable_pow_rcp(!opts.exact_division);
     e.running_sums = opts.sum_order != 1;
+    // Divisions by the (constant) order: one multiplication by RN(1 / k), within 1 ulp of the quotient (like the pair
+    // kernels), unless kw::exact_division asks for the correctly rounded 3-operation sequence - 120 of them per step of
+    // the two-body problem.
+    e.recip_div = !opts.exact_division;
 
     os << "extern \"C\" __global__ void __launch_bounds__(" << bs << ") " << kname << "(const hy_kargs a)\n{\n";
     os << "const u64 s = (u64)blockIdx.x * " << bs << "u + threadIdx.x;\n";
