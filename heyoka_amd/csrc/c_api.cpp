@@ -1068,7 +1068,7 @@ int hy_compile_aux_kernels(uint32_t order, uint32_t dim, int high_accuracy)
     return guarded([&] {
         hiprtc_compile_source(detail::make_cout_source(order, dim, high_accuracy != 0));
         hiprtc_compile_source(detail::make_grid_source(order, dim, high_accuracy != 0));
-        hiprtc_compile_source(detail::make_event_detection_source(order));
+        hiprtc_compile_source(detail::make_event_detection_source(order, detail::ed_max_detected(order, 1, 1)));
     });
 }
 hy_cfunc hy_cfunc_new(const hy_expr *fn, size_t n_fn, const hy_expr *vars, size_t n_vars, int device)

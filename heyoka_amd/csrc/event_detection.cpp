@@ -1,6 +1,7 @@
 // Event detection kernel. See event_detection.hpp.
 #include "event_detection.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <sstream>
 
@@ -10,12 +11,26 @@
 namespace heyoka_amd::detail
 {
 
-std::string make_event_detection_source(std::uint32_t order)
+std::uint32_t ed_max_detected(std::uint32_t order, std::uint32_t n_te, std::uint32_t n_nte)
+{
+    // An event equation is a polynomial of degree `order` over the step: at most `order` isolating intervals are
+    // accepted (more is a failure of the isolation, src/detail/event_detection.cpp:2082), plus possibly a root exactly
+    // at the beginning of the step.
+    const auto n = std::max<std::uint32_t>(std::max(n_te, n_nte), 1u);
+    return n * (order + 1u);
+}
+
+std::size_t ed_work_list_bytes_per_slot(std::uint32_t order)
+{
+    return static_cast<std::size_t>(ed_work_list_cap + 2u) * (order + 3u) * sizeof(double);
+}
+
+std::string make_event_detection_source(std::uint32_t order, std::uint32_t max_detected)
 {
     std::ostringstream src;
     src << emit_detail::prelude;
-    src << "#define HY_ORDER " << order << "u\n#define HY_P " << (order + 1u) << "u\n#define HY_MAXD "
-        << max_detected_per_lane << "u\n#define HY_WL_CAP 64u\n";
+    src << "#define HY_ORDER " << order << "u\n#define HY_P " << (order + 1u) << "u\n#define HY_MAXD " << max_detected
+        << "u\n#define HY_WL_CAP " << ed_work_list_cap << "u\n";
     // Binomial coefficients for the translation by 1 (exact in double precision up to the orders in use).
     src << "__device__ const double hy_bc[" << (order + 1u) * (order + 1u) << "] = {";
     for (std::uint32_t i = 0; i <= order; ++i) {
@@ -50,6 +65,8 @@ struct hy_ed_args {
     const double *mas;
     double *g_eps_out;
     double tol;
+    double *wl;
+    u64 wl_slots;
 };
 
 struct hy_ep_args {
@@ -148,36 +165,184 @@ __device__ bool hy_fex_check(const double *a, double h)
     return hy_sgn(lo) == hy_sgn(hi) && hy_sgn(lo) != 0;
 }
 
-// Root inside a bracket with a sign change. The reference uses TOMS 748 with an eps tolerance and returns the
-// midpoint of the final bracket (bracketed_root_find(), :307-394); here: bisection down to adjacent doubles.
-__device__ double hy_bracketed_root(const double *a, double lb, double ub)
+// Algorithm 748 (Alefeld, Potra, Shi, ACM TOMS 21(3), 1995, algorithm 4.2): the reference calls Boost.Math's
+// toms748_solve() with eps_tolerance<double>() and a budget of 53 function evaluations (bracketed_root_find(),
+// :307-394). Boost is not part of the reference tree: restated from the published algorithm - a secant step, a
+// quadratic step, then rounds of (inverse cubic or quadratic, the same again, double-length secant, bisection if the
+// bracket did not halve).
+#define HY_T748_EPS 0x1p-52
+#define HY_T748_MAX 1.7976931348623157e308
+#define HY_T748_MIN_DIFF (2.2250738585072014e-308 * 32)
+
+__device__ inline double hy_t748_safe_div(double num, double den, double r)
 {
-    if (hy_finite(lb) && hy_finite(ub) && ub > lb) ub = nextafter(ub, lb);
-    double flb = hy_poly_eval(a, lb);
-    const double fub = hy_poly_eval(a, ub);
-    if (flb == 0.0) return lb;
-    if (fub == 0.0) return ub;
-    for (int it = 0; it < 200; ++it) {
-        const double mid = lb / 2 + ub / 2;
-        if (mid <= lb || mid >= ub) break;
-        const double fm = hy_poly_eval(a, mid);
-        if (fm == 0.0) return mid;
-        if ((fm < 0.0) == (flb < 0.0)) {
-            lb = mid;
-            flb = fm;
-        } else {
-            ub = mid;
-        }
+    if (fabs(den) < 1.0) {
+        if (fabs(den * HY_T748_MAX) <= fabs(num)) return r;
     }
-    return lb / 2 + ub / 2;
+    return num / den;
 }
 
-// One lane per thread (ed_data_batch<T>::detect_events(), :1733-2173).
-extern "C" __global__ void __launch_bounds__(64) hy_detect_events(const hy_ed_args a)
+__device__ inline double hy_t748_secant(double a, double b, double fa, double fb)
 {
-    const u64 j = (u64)blockIdx.x * 64u + threadIdx.x;
+    const double tol = HY_T748_EPS * 5;
+    const double c = a - (fa / (fb - fa)) * (b - a);
+    if (c <= a + fabs(a) * tol || c >= b - fabs(b) * tol) return (a + b) / 2;
+    return c;
+}
+
+__device__ double hy_t748_quadratic(double a, double b, double d, double fa, double fb, double fd, int count)
+{
+    const double B = hy_t748_safe_div(fb - fa, b - a, HY_T748_MAX);
+    double A = hy_t748_safe_div(fd - fb, d - b, HY_T748_MAX);
+    A = hy_t748_safe_div(A - B, d - a, 0.0);
+    if (A == 0.0) return hy_t748_secant(a, b, fa, fb);
+    double c = (hy_sgn(A) * hy_sgn(fa) > 0) ? a : b;
+    for (int i = 0; i < count; ++i) {
+        c -= hy_t748_safe_div(fa + (B + A * (c - b)) * (c - a), B + A * (2 * c - a - b), 1 + c - a);
+    }
+    if (c <= a || c >= b) c = hy_t748_secant(a, b, fa, fb);
+    return c;
+}
+
+__device__ double hy_t748_cubic(double a, double b, double d, double e, double fa, double fb, double fd, double fe)
+{
+    const double q11 = (d - e) * fd / (fe - fd);
+    const double q21 = (b - d) * fb / (fd - fb);
+    const double q31 = (a - b) * fa / (fb - fa);
+    const double d21 = (b - d) * fd / (fd - fb);
+    const double d31 = (a - b) * fb / (fb - fa);
+    const double q22 = (d21 - q11) * fb / (fe - fb);
+    const double q32 = (d31 - q21) * fa / (fd - fa);
+    const double d32 = (d31 - q21) * fd / (fd - fa);
+    const double q33 = (d32 - q22) * fa / (fe - fa);
+    double c = q31 + q32 + q33 + a;
+    if (c <= a || c >= b) c = hy_t748_quadratic(a, b, d, fa, fb, fd, 3);
+    return c;
+}
+
+struct hy_t748_state {
+    double a, b, fa, fb, d, fd;
+};
+
+__device__ inline bool hy_t748_tol(double x, double y)
+{
+    return fabs(x - y) <= 4 * HY_T748_EPS * fmin(fabs(x), fabs(y));
+}
+
+__device__ void hy_t748_bracket(const double *poly, hy_t748_state &s, double c)
+{
+    const double t = HY_T748_EPS * 2;
+    if ((s.b - s.a) < 2 * t * s.a) {
+        c = s.a + (s.b - s.a) / 2;
+    } else if (c <= s.a + fabs(s.a) * t) {
+        c = s.a + fabs(s.a) * t;
+    } else if (c >= s.b - fabs(s.b) * t) {
+        c = s.b - fabs(s.b) * t;
+    }
+    const double fc = hy_poly_eval(poly, c);
+    if (fc == 0.0) {
+        s.a = c;
+        s.fa = 0.0;
+        s.d = 0.0;
+        s.fd = 0.0;
+        return;
+    }
+    if (hy_sgn(s.fa) * hy_sgn(fc) < 0) {
+        s.d = s.b;
+        s.fd = s.fb;
+        s.b = c;
+        s.fb = fc;
+    } else {
+        s.d = s.a;
+        s.fd = s.fa;
+        s.a = c;
+        s.fa = fc;
+    }
+}
+
+__device__ inline bool hy_t748_distinct(const hy_t748_state &s, double fe)
+{
+    return !(fabs(s.fa - s.fb) < HY_T748_MIN_DIFF || fabs(s.fa - s.fd) < HY_T748_MIN_DIFF || fabs(s.fa - fe) < HY_T748_MIN_DIFF
+             || fabs(s.fb - s.fd) < HY_T748_MIN_DIFF || fabs(s.fb - fe) < HY_T748_MIN_DIFF
+             || fabs(s.fd - fe) < HY_T748_MIN_DIFF);
+}
+
+// Root of the polynomial in [lb, ub): the midpoint of the final bracket of TOMS 748 on [lb, prev(ub)]. *flag: 0 = ok,
+// -1 = budget of function evaluations exhausted, 1 = no sign change at the ends (Boost's domain error); the caller
+// ignores the event unless 0, like the reference (:1460-1490).
+__device__ double hy_bracketed_root(const double *poly, double lb, double ub, int *flag)
+{
+    if (hy_finite(lb) && hy_finite(ub) && ub > lb) ub = nextafter(ub, lb);
+    hy_t748_state s;
+    s.a = lb;
+    s.b = ub;
+    s.fa = hy_poly_eval(poly, lb);
+    s.fb = hy_poly_eval(poly, ub);
+    s.d = 0.0;
+    s.fd = 0.0;
+    if (!(lb < ub) || hy_sgn(s.fa) * hy_sgn(s.fb) > 0 || !hy_finite(s.fa) || !hy_finite(s.fb)) {
+        *flag = 1;
+        return 0.0;
+    }
+    int count = 53 - 2;
+    if (!(hy_t748_tol(s.a, s.b) || s.fa == 0.0 || s.fb == 0.0)) {
+        double e = 1e5, fe = 1e5;
+        hy_t748_bracket(poly, s, hy_t748_secant(s.a, s.b, s.fa, s.fb));
+        --count;
+        if (count != 0 && s.fa != 0.0 && !hy_t748_tol(s.a, s.b)) {
+            const double c = hy_t748_quadratic(s.a, s.b, s.d, s.fa, s.fb, s.fd, 2);
+            e = s.d;
+            fe = s.fd;
+            hy_t748_bracket(poly, s, c);
+            --count;
+        }
+        while (count != 0 && s.fa != 0.0 && !hy_t748_tol(s.a, s.b)) {
+            const double a0 = s.a, b0 = s.b;
+            double c = hy_t748_distinct(s, fe) ? hy_t748_cubic(s.a, s.b, s.d, e, s.fa, s.fb, s.fd, fe)
+                                               : hy_t748_quadratic(s.a, s.b, s.d, s.fa, s.fb, s.fd, 2);
+            e = s.d;
+            fe = s.fd;
+            hy_t748_bracket(poly, s, c);
+            if (--count == 0 || s.fa == 0.0 || hy_t748_tol(s.a, s.b)) break;
+            c = hy_t748_distinct(s, fe) ? hy_t748_cubic(s.a, s.b, s.d, e, s.fa, s.fb, s.fd, fe)
+                                        : hy_t748_quadratic(s.a, s.b, s.d, s.fa, s.fb, s.fd, 3);
+            hy_t748_bracket(poly, s, c);
+            if (--count == 0 || s.fa == 0.0 || hy_t748_tol(s.a, s.b)) break;
+            // Double-length secant step from the end with the smaller function value.
+            const bool at_a = fabs(s.fa) < fabs(s.fb);
+            const double u = at_a ? s.a : s.b, fu = at_a ? s.fa : s.fb;
+            c = u - 2 * (fu / (s.fb - s.fa)) * (s.b - s.a);
+            if (fabs(c - u) > (s.b - s.a) / 2) c = s.a + (s.b - s.a) / 2;
+            e = s.d;
+            fe = s.fd;
+            hy_t748_bracket(poly, s, c);
+            if (--count == 0 || s.fa == 0.0 || hy_t748_tol(s.a, s.b)) break;
+            // Bisection if the three steps did not halve the bracket.
+            if ((s.b - s.a) < 0.5 * (b0 - a0)) continue;
+            e = s.d;
+            fe = s.fd;
+            hy_t748_bracket(poly, s, s.a + (s.b - s.a) / 2);
+            --count;
+        }
+    }
+    if (s.fa == 0.0) {
+        s.b = s.a;
+    } else if (s.fb == 0.0) {
+        s.a = s.b;
+    }
+    *flag = (count > 0) ? 0 : -1;
+    return s.a / 2 + s.b / 2;
+}
+
+// Detection for one lane (ed_data_batch<T>::detect_events(), :1733-2173). The working list of the root isolation
+// (interval + rescaled polynomial per entry, at most 250 entries like the reference, :2082) lives in global memory,
+// one column per resident thread ("slot"): entry e, word k of slot s at wl[(e * (HY_P + 2) + k) * S + s], words
+// 0 .. order = coefficients, then lb, ub.
+__device__ void hy_detect_lane(const hy_ed_args &a, const u64 j, const u64 slot)
+{
     const u64 N = a.N;
-    if (j >= N) return;
+    const u64 S = a.wl_slots;
+    double *const wl = a.wl + slot;
     a.counts[j] = 0u;
     a.counts[N + j] = 0u;
     const double h = a.h[j];
@@ -199,7 +364,6 @@ extern "C" __global__ void __launch_bounds__(64) hy_detect_events(const hy_ed_ar
     if (!hy_finite(h) || !hy_finite(g_eps) || h == 0.0) return;
 
     double ptr[HY_P], tmp[HY_P], tmp1[HY_P], tmp2[HY_P];
-    double wl_poly[HY_WL_CAP * HY_P], wl_lb[HY_WL_CAP], wl_ub[HY_WL_CAP];
     double isol_lb[HY_P], isol_ub[HY_P];
 
     const unsigned n_ev = a.n_te + a.n_nte;
@@ -222,7 +386,7 @@ extern "C" __global__ void __launch_bounds__(64) hy_detect_events(const hy_ed_ar
             if (dir != 0 && d_sgn != dir) return;
             const unsigned c = a.counts[(u64)cls * N + j];
             if (c >= HY_MAXD) {
-                atomicAdd(a.flags, 1u);
+                atomicAdd(a.flags + 1, 1u);
                 return;
             }
             out[c * 4u + 0u] = (double)idx;
@@ -240,15 +404,20 @@ extern "C" __global__ void __launch_bounds__(64) hy_detect_events(const hy_ed_ar
         if (lb_offset >= 1.0) continue;
 
         // Working list of (lb, ub, polynomial rescaled to [0, 1]).
-        unsigned n_wl = 1, n_isol = 0;
-        hy_poly_rescale(wl_poly, ptr, h);
-        wl_lb[0] = 0.0;
-        wl_ub[0] = 1.0;
-        bool failed = false;
-        while (n_wl != 0u) {
-            --n_wl;
-            const double lb = wl_lb[n_wl], ub = wl_ub[n_wl];
-            for (unsigned k = 0; k < HY_P; ++k) tmp[k] = wl_poly[n_wl * HY_P + k];
+        // (The first entry - the whole step - never goes through memory.)
+        unsigned n_wl = 0, n_isol = 0;
+        hy_poly_rescale(tmp, ptr, h);
+        double lb = 0.0, ub = 1.0;
+        bool failed = false, first = true;
+        while (first || n_wl != 0u) {
+            if (!first) {
+                --n_wl;
+                const double *top = wl + (u64)n_wl * (HY_P + 2u) * S;
+                lb = top[(u64)HY_P * S];
+                ub = top[(u64)(HY_P + 1u) * S];
+                for (unsigned k = 0; k < HY_P; ++k) tmp[k] = top[(u64)k * S];
+            }
+            first = false;
             // A root exactly at the beginning of the interval.
             if (tmp[0] == 0.0) {
                 bool fin = true;
@@ -272,22 +441,21 @@ extern "C" __global__ void __launch_bounds__(64) hy_detect_events(const hy_ed_ar
                 hy_poly_rescale_p2(tmp1, tmp);
                 hy_poly_translate_1(tmp2, tmp1);
                 const double mid = lb / 2 + ub / 2;
-                if (n_wl + 2u > HY_WL_CAP) {
-                    failed = true;
-                    break;
-                }
                 if (lb_offset < mid) {
-                    for (unsigned k = 0; k < HY_P; ++k) wl_poly[n_wl * HY_P + k] = tmp1[k];
-                    wl_lb[n_wl] = lb;
-                    wl_ub[n_wl] = mid;
+                    double *dst = wl + (u64)n_wl * (HY_P + 2u) * S;
+                    for (unsigned k = 0; k < HY_P; ++k) dst[(u64)k * S] = tmp1[k];
+                    dst[(u64)HY_P * S] = lb;
+                    dst[(u64)(HY_P + 1u) * S] = mid;
                     ++n_wl;
                 }
-                for (unsigned k = 0; k < HY_P; ++k) wl_poly[n_wl * HY_P + k] = tmp2[k];
-                wl_lb[n_wl] = mid;
-                wl_ub[n_wl] = ub;
+                double *dst = wl + (u64)n_wl * (HY_P + 2u) * S;
+                for (unsigned k = 0; k < HY_P; ++k) dst[(u64)k * S] = tmp2[k];
+                dst[(u64)HY_P * S] = mid;
+                dst[(u64)(HY_P + 1u) * S] = ub;
                 ++n_wl;
             }
-            if (n_isol > HY_ORDER) {
+            // (The reference's limits, :2082.)
+            if (n_wl > HY_WL_CAP || n_isol > HY_ORDER) {
                 failed = true;
                 break;
             }
@@ -299,15 +467,28 @@ extern "C" __global__ void __launch_bounds__(64) hy_detect_events(const hy_ed_ar
         if (n_isol == 0u) continue;
         hy_poly_rescale(tmp1, ptr, h);
         for (unsigned q = 0; q < n_isol; ++q) {
-            double lb = isol_lb[q];
-            const double ub = isol_ub[q];
-            if (terminal && lb < lb_offset) {
-                lb = lb_offset;
-                if (!(hy_poly_eval(tmp1, lb) * hy_poly_eval(tmp1, ub) < 0.0)) continue;
+            double rlb = isol_lb[q];
+            const double rub = isol_ub[q];
+            if (terminal && rlb < lb_offset) {
+                rlb = lb_offset;
+                if (!(hy_poly_eval(tmp1, rlb) * hy_poly_eval(tmp1, rub) < 0.0)) continue;
             }
-            add_event(hy_bracketed_root(tmp1, lb, ub) * h);
+            int rflag = 0;
+            const double root = hy_bracketed_root(tmp1, rlb, rub, &rflag);
+            if (rflag == 0) {
+                add_event(root * h);
+            } else {
+                // (The reference logs a warning and ignores the event.)
+                atomicAdd(a.flags + 2, 1u);
+            }
         }
     }
+}
+
+extern "C" __global__ void __launch_bounds__(64) hy_detect_events(const hy_ed_args a)
+{
+    const u64 slot = (u64)blockIdx.x * 64u + threadIdx.x;
+    for (u64 j = slot; j < a.N; j += (u64)gridDim.x * 64u) hy_detect_lane(a, j, slot);
 }
 
 // Step sizes of the state update: the step is truncated at the first terminal event of the lane - the one with the

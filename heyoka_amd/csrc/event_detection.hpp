@@ -10,6 +10,7 @@
 // step truncation at the first terminal event, callbacks, cooldown bookkeeping, outcomes).
 #pragma once
 
+#include <cstddef>
 #include <cstdint>
 #include <functional>
 #include <memory>
@@ -52,11 +53,18 @@ struct detected_event {
     double abs_der;
 };
 
-// HIP source of the detection kernel for a given Taylor order.
-std::string make_event_detection_source(std::uint32_t order);
+// Capacity of the per-lane list of detected events of one class (terminal / non-terminal) in a step: every event
+// equation is a polynomial of degree `order` over the step, so (order + 1) entries per event of the class hold
+// whatever a successful root isolation can produce (the reference's lists are unbounded vectors).
+std::uint32_t ed_max_detected(std::uint32_t order, std::uint32_t n_te, std::uint32_t n_nte);
 
-// Maximum number of events of one class (terminal / non-terminal) recorded per lane and step.
-inline constexpr std::uint32_t max_detected_per_lane = 16;
+// Limit on the working list of the root isolation: the reference's (src/detail/event_detection.cpp:1399, :2082).
+inline constexpr std::uint32_t ed_work_list_cap = 250;
+// Bytes of working list per resident thread ("slot") of hy_detect_events.
+std::size_t ed_work_list_bytes_per_slot(std::uint32_t order);
+
+// HIP source of the detection kernel for a given Taylor order and list capacity.
+std::string make_event_detection_source(std::uint32_t order, std::uint32_t max_detected);
 
 struct ed_kargs {
     const double *ev_tc;      // [(event * (order + 1) + k) * N + lane], terminal events first
@@ -66,9 +74,10 @@ struct ed_kargs {
     const double *cd_first;   // [n_te * N] terminal-event cooldowns (valid if cd_active != 0)
     const double *cd_second;  // [n_te * N]
     const int *cd_active;     // [n_te * N]
-    double *out;              // [2][N][max_detected][4]: idx, root, d_sgn, abs_der
+    double *out;              // [2][N][ed_max_detected()][4]: idx, root, d_sgn, abs_der
     unsigned *counts;         // [2][N]
-    unsigned *flags;          // [0] = number of lanes whose list overflowed / whose isolation failed
+    unsigned *flags;          // [0] root isolations which failed, [1] event lists which overflowed, [2] root findings which
+                              // failed (event, lane) - the reference logs a warning and ignores the event
     unsigned long long N;
     unsigned n_te, n_nte;
     // Device-side error bound of the Taylor series of the event equations (src/taylor_adaptive_batch.cpp:744-767):
@@ -76,6 +85,8 @@ struct ed_kargs {
     const double *mas;
     double *g_eps_out;
     double tol;
+    double *wl;               // working lists of the root isolation, ed_work_list_bytes_per_slot() per launched thread
+    unsigned long long wl_slots; // number of launched threads (grid-stride loop over the lanes)
 };
 
 // Per-lane bookkeeping of a step with events on the device (src/taylor_adaptive_batch.cpp:771-1030): hy_ev_pre

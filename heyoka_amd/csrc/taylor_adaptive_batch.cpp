@@ -152,7 +152,8 @@ struct tab_core::impl {
     void *cb_ctx = nullptr;
     mutable std::unique_ptr<aux_module> ed_mod;
     mutable device_buffer d_ev_tc, d_mas, d_geps, d_dirs, d_cd_first, d_cd_second, d_cd_active, d_ed_out, d_ed_counts,
-        d_ed_flags;
+        d_ed_flags, d_ed_wl;
+    std::uint64_t ed_slots = 0;
     std::uint64_t ed_failures = 0;
     // Events on the wave-cluster steppers: the main stepper is built from the system alone and runs in mode 4 (jets of
     // the state variables, no update); hy_ev_jets (emit_event_jets()) derives the jets of the event equations and the
@@ -1061,7 +1062,7 @@ void tab_core::impl::ensure_event_buffers()
     const auto dsz = sizeof(double);
     const auto n_te = static_cast<std::uint32_t>(tes.size()), n_nte = static_cast<std::uint32_t>(ntes.size());
     const auto n_ev = n_te + n_nte;
-    constexpr auto maxd = max_detected_per_lane;
+    const auto maxd = ed_max_detected(order, n_te, n_nte);
     ensure_tc();
     if (d_ev_tc.bytes() == 0u) {
         d_ev_tc = device_buffer(static_cast<std::size_t>(n_ev) * (order + 1u) * n * dsz, device);
@@ -1075,6 +1076,12 @@ void tab_core::impl::ensure_event_buffers()
         d_ed_out = device_buffer(2u * n * maxd * 4u * dsz, device);
         d_ed_counts = device_buffer(2u * n * sizeof(unsigned), device);
         d_ed_flags = device_buffer(4u * sizeof(unsigned), device);
+        // Working lists of the root isolation: one column per launched thread of hy_detect_events (a grid-stride loop
+        // over the lanes), up to 8 wavefronts per compute unit and 4 GiB in total.
+        const auto per_slot = ed_work_list_bytes_per_slot(order);
+        const std::uint64_t max_slots = std::clamp<std::uint64_t>((std::uint64_t(4) << 30) / per_slot / 64u * 64u, 64u * 256u, 64u * 256u * 8u);
+        ed_slots = std::min<std::uint64_t>((static_cast<std::uint64_t>(n) + 63u) / 64u * 64u, max_slots);
+        d_ed_wl = device_buffer(static_cast<std::size_t>(ed_slots) * per_slot, device);
         d_ev_cursor = device_buffer(2u * sizeof(unsigned long long), device);
         std::vector<int> dirs;
         for (const auto &ev : tes) {
@@ -1084,7 +1091,7 @@ void tab_core::impl::ensure_event_buffers()
             dirs.push_back(static_cast<int>(ev.dir));
         }
         d_dirs.upload(dirs.data(), dirs.size() * sizeof(int), stream);
-        ed_mod = std::make_unique<aux_module>(hiprtc_compile_source(make_event_detection_source(order)), device);
+        ed_mod = std::make_unique<aux_module>(hiprtc_compile_source(make_event_detection_source(order, maxd)), device);
         cd_host_newer = true;
     }
     if (d_dout.bytes() == 0u) {
@@ -1131,8 +1138,9 @@ unsigned tab_core::impl::launch_event_detection(bool device_g_eps)
     const ed_kargs ea{d_ev_tc.as<double>(),   d_lasth.as<double>(),     d_geps.as<double>(),     d_dirs.as<int>(),
                       d_cd_first.as<double>(), d_cd_second.as<double>(), d_cd_active.as<int>(),   d_ed_out.as<double>(),
                       d_ed_counts.as<unsigned>(), d_ed_flags.as<unsigned>(), N, n_te, n_nte,
-                      device_g_eps ? d_mas.as<double>() : nullptr, d_geps.as<double>(), tol};
-    ed_mod->launch("hy_detect_events", N, 64, &ea, sizeof(ea), stream);
+                      device_g_eps ? d_mas.as<double>() : nullptr, d_geps.as<double>(), tol,
+                      d_ed_wl.as<double>(), ed_slots};
+    ed_mod->launch("hy_detect_events", ed_slots, 64, &ea, sizeof(ea), stream);
     return 0;
 }
 
@@ -1145,19 +1153,24 @@ void tab_core::impl::step_with_events(const std::vector<double> &lims, bool wtc)
 namespace
 {
 
-void report_ed_failures(std::uint64_t &ed_failures, unsigned flags)
+void report_ed_failures(std::uint64_t &ed_failures, const unsigned (&flags)[3])
 {
-    if (flags != 0u) {
-        // The per-lane lists of detected events / the work list of the root isolation are of fixed size on the device
-        // (16 events per class and lane, 64 intervals): an overflow drops events. The reference has no fixed cap and
-        // logs a warning when the isolation fails; here the count is kept (get_event_detection_failures()) and the
-        // first occurrence is reported on stderr.
+    const auto total = static_cast<std::uint64_t>(flags[0]) + flags[1] + flags[2];
+    if (total != 0u) {
+        // The reference logs a warning through its logger and ignores the event for the step when the root isolation
+        // exceeds its limits (working list > 250 intervals or more isolating intervals than the order,
+        // src/detail/event_detection.cpp:2082-2090) or when the root finder fails (:2150-2165). Here the count is kept
+        // (get_event_detection_failures()) and the first occurrence is reported on stderr. The list of detected events
+        // of a lane holds (order + 1) entries per event of the class: an overflow cannot come from a successful
+        // isolation and is reported separately.
         if (ed_failures == 0u) {
-            std::fprintf(stderr, "heyoka_amd: warning: event detection overflow in %u lane(s) (more than 16 events of one "
-                                 "class in a step, or root isolation work list exhausted): events may have been "
-                                 "dropped - reduce the step (max_delta_t) around dense clusters of events\n", flags);
+            std::fprintf(stderr,
+                         "heyoka_amd: warning: event detection: %u root isolation(s) failed (working list > 250 or more "
+                         "isolating intervals than the Taylor order), %u root finding(s) failed, %u event list(s) "
+                         "overflowed: the events concerned were ignored in this step\n",
+                         flags[0], flags[2], flags[1]);
         }
-        ed_failures += flags;
+        ed_failures += total;
     }
 }
 
@@ -1236,11 +1249,11 @@ void tab_core::impl::step_with_events_device(const std::vector<double> *lims)
     pa.dim = dim;
     d_ev_cursor.zero(stream);
     ed_mod->launch("hy_ev_pre", N, 256, &pa, sizeof(pa), stream);
-    unsigned flags[1] = {0};
+    unsigned flags[3] = {0, 0, 0};
     unsigned long long cur[2] = {0, 0};
     d_ed_flags.download(flags, sizeof(flags), stream);
     d_ev_cursor.download(cur, sizeof(cur), stream);
-    report_ed_failures(ed_failures, flags[0]);
+    report_ed_failures(ed_failures, flags);
     lap("pre + flags to host");
     if (cur[0] * dsz > d_ev_rec.bytes()) {
         d_ev_rec = device_buffer(static_cast<std::size_t>(cur[0] + cur[0] / 2u + 1024u) * dsz, device);
@@ -2311,6 +2324,7 @@ void tab_core::set_device(int device)
     d.d_ed_out = {};
     d.d_ed_counts = {};
     d.d_ed_flags = {};
+    d.d_ed_wl = {};
     d.stream = nullptr;
     d.device = device;
     d.host_newer = true;

@@ -1184,29 +1184,164 @@ def _fex_check(a, h):
     return _sgn(lo) == _sgn(hi) and _sgn(lo) != 0
 
 
+_T748_EPS = 2.0 ** -52
+_T748_MAX = 1.7976931348623157e308
+_T748_MIN_DIFF = 2.2250738585072014e-308 * 32
+
+
+def _t748_safe_div(num, den, r):
+    """num / den, or r if the quotient would overflow."""
+    if abs(den) < 1:
+        if abs(den * _T748_MAX) <= abs(num):
+            return r
+    return num / den
+
+
+def _t748_secant(a, b, fa, fb):
+    tol = _T748_EPS * 5
+    c = a - (fa / (fb - fa)) * (b - a)
+    if c <= a + abs(a) * tol or c >= b - abs(b) * tol:
+        return (a + b) / 2
+    return c
+
+
+def _t748_quadratic(a, b, d, fa, fb, fd, count):
+    """`count` Newton steps on the quadratic through (a, fa), (b, fb), (d, fd)."""
+    B = _t748_safe_div(fb - fa, b - a, _T748_MAX)
+    A = _t748_safe_div(fd - fb, d - b, _T748_MAX)
+    A = _t748_safe_div(A - B, d - a, 0.0)
+    if A == 0:
+        return _t748_secant(a, b, fa, fb)
+    c = a if _sgn(A) * _sgn(fa) > 0 else b
+    for _ in range(count):
+        c -= _t748_safe_div(fa + (B + A * (c - b)) * (c - a), B + A * (2 * c - a - b), 1 + c - a)
+    if c <= a or c >= b:
+        c = _t748_secant(a, b, fa, fb)
+    return c
+
+
+def _t748_cubic(a, b, d, e, fa, fb, fd, fe):
+    """Inverse cubic interpolation through four points with distinct function values."""
+    q11 = (d - e) * fd / (fe - fd)
+    q21 = (b - d) * fb / (fd - fb)
+    q31 = (a - b) * fa / (fb - fa)
+    d21 = (b - d) * fd / (fd - fb)
+    d31 = (a - b) * fb / (fb - fa)
+    q22 = (d21 - q11) * fb / (fe - fb)
+    q32 = (d31 - q21) * fa / (fd - fa)
+    d32 = (d31 - q21) * fd / (fd - fa)
+    q33 = (d32 - q22) * fa / (fe - fa)
+    c = q31 + q32 + q33 + a
+    if c <= a or c >= b:
+        c = _t748_quadratic(a, b, d, fa, fb, fd, 3)
+    return c
+
+
+def _toms748(f, a, b, fa, fb, count):
+    """Algorithm 748 (Alefeld, Potra, Shi: "Algorithm 748: enclosing zeros of continuous functions", ACM TOMS 21(3),
+    1995, algorithm 4.2) as the reference uses it through Boost.Math's toms748_solve() with eps_tolerance<double>()
+    (src/detail/event_detection.cpp:361-363; Boost is a third-party dependency which is not part of the reference tree,
+    version not pinned by the reference beyond ">= 1.69": restated from the published algorithm). `count` = budget of
+    function evaluations. Returns the final bracket and the budget left."""
+
+    def tol(x, y):
+        return abs(x - y) <= 4 * _T748_EPS * min(abs(x), abs(y))
+
+    st = dict(a=a, b=b, fa=fa, fb=fb, d=0.0, fd=0.0)
+
+    def bracket(c):
+        a, b, fa, fb = st["a"], st["b"], st["fa"], st["fb"]
+        t = _T748_EPS * 2
+        if (b - a) < 2 * t * a:
+            c = a + (b - a) / 2
+        elif c <= a + abs(a) * t:
+            c = a + abs(a) * t
+        elif c >= b - abs(b) * t:
+            c = b - abs(b) * t
+        fc = f(c)
+        if fc == 0:
+            st.update(a=c, fa=0.0, d=0.0, fd=0.0)
+            return
+        if _sgn(fa) * _sgn(fc) < 0:
+            st.update(d=b, fd=fb, b=c, fb=fc)
+        else:
+            st.update(d=a, fd=fa, a=c, fa=fc)
+
+    def distinct():
+        v = (st["fa"], st["fb"], st["fd"], fe)
+        return all(abs(v[i] - v[j]) >= _T748_MIN_DIFF for i in range(4) for j in range(i + 1, 4))
+
+    if tol(a, b) or fa == 0 or fb == 0:
+        if fa == 0:
+            b = a
+        elif fb == 0:
+            a = b
+        return a, b, count
+    e = fe = 1e5
+    # A secant step, then a quadratic one.
+    bracket(_t748_secant(a, b, fa, fb))
+    count -= 1
+    if count and st["fa"] != 0 and not tol(st["a"], st["b"]):
+        c = _t748_quadratic(st["a"], st["b"], st["d"], st["fa"], st["fb"], st["fd"], 2)
+        e, fe = st["d"], st["fd"]
+        bracket(c)
+        count -= 1
+    while count and st["fa"] != 0 and not tol(st["a"], st["b"]):
+        a0, b0 = st["a"], st["b"]
+        if distinct():
+            c = _t748_cubic(st["a"], st["b"], st["d"], e, st["fa"], st["fb"], st["fd"], fe)
+        else:
+            c = _t748_quadratic(st["a"], st["b"], st["d"], st["fa"], st["fb"], st["fd"], 2)
+        e, fe = st["d"], st["fd"]
+        bracket(c)
+        count -= 1
+        if count == 0 or st["fa"] == 0 or tol(st["a"], st["b"]):
+            break
+        if distinct():
+            c = _t748_cubic(st["a"], st["b"], st["d"], e, st["fa"], st["fb"], st["fd"], fe)
+        else:
+            c = _t748_quadratic(st["a"], st["b"], st["d"], st["fa"], st["fb"], st["fd"], 3)
+        bracket(c)
+        count -= 1
+        if count == 0 or st["fa"] == 0 or tol(st["a"], st["b"]):
+            break
+        # Double-length secant step from the endpoint with the smaller function value.
+        a, b, fa, fb = st["a"], st["b"], st["fa"], st["fb"]
+        u, fu = (a, fa) if abs(fa) < abs(fb) else (b, fb)
+        c = u - 2 * (fu / (fb - fa)) * (b - a)
+        if abs(c - u) > (b - a) / 2:
+            c = a + (b - a) / 2
+        e, fe = st["d"], st["fd"]
+        bracket(c)
+        count -= 1
+        if count == 0 or st["fa"] == 0 or tol(st["a"], st["b"]):
+            break
+        # Bisection if the three steps did not halve the bracket.
+        if (st["b"] - st["a"]) < 0.5 * (b0 - a0):
+            continue
+        e, fe = st["d"], st["fd"]
+        bracket(st["a"] + (st["b"] - st["a"]) / 2)
+        count -= 1
+    a, b = st["a"], st["b"]
+    if st["fa"] == 0:
+        b = a
+    elif st["fb"] == 0:
+        a = b
+    return a, b, count
+
+
 def _bracketed_root(a, lb, ub):
-    """Root of the polynomial in [lb, ub] with a sign change (the reference uses TOMS 748 with an eps
-    tolerance and returns the midpoint of the final bracket, src/detail/event_detection.cpp:307-394;
-    here: bisection to the last bit, same bracket-midpoint convention)."""
+    """Root of the polynomial in [lb, ub) (bracketed_root_find(), src/detail/event_detection.cpp:307-394): TOMS 748 with
+    a tolerance of 4 eps and a budget of 53 function evaluations on [lb, prev(ub)]; the result is the midpoint of the
+    final bracket; flag -1 = budget exhausted, flag 1 = no sign change at the ends (the reference gets a domain error
+    out of Boost through errno): the caller ignores the event in both cases."""
     if math.isfinite(lb) and math.isfinite(ub) and ub > lb:
         ub = float(np.nextafter(ub, lb))
     flb, fub = _poly_eval(a, lb), _poly_eval(a, ub)
-    if flb == 0.0:
-        return lb, 0
-    if fub == 0.0:
-        return ub, 0
-    for _ in range(200):
-        mid = lb / 2 + ub / 2
-        if mid <= lb or mid >= ub:
-            break
-        fm = _poly_eval(a, mid)
-        if fm == 0.0:
-            return mid, 0
-        if (fm < 0) == (flb < 0):
-            lb, flb = mid, fm
-        else:
-            ub, fub = mid, fm
-    return lb / 2 + ub / 2, 0
+    if not (lb < ub) or _sgn(flb) * _sgn(fub) > 0 or not (math.isfinite(flb) and math.isfinite(fub)):
+        return 0.0, 1
+    ra, rb, left = _toms748(lambda x: _poly_eval(a, x), lb, ub, flb, fub, 53 - 2)
+    return ra / 2 + rb / 2, (0 if left > 0 else -1)
 
 
 def detect_events(poly, h, g_eps, events, is_terminal, cooldowns, order):

@@ -287,8 +287,17 @@ def test_raw_step_abi():
     h_o = np.array([h for _, h in ora.step_res])
     # NOTE: h is ill-conditioned for near-circular orbits (the order-p coefficients are tiny sums of
     # cancelling terms): 1e6 eps here, while the propagated state agrees to 1e5 eps.
-    assert np.max(np.abs(d_h.cpu().numpy() - h_o) / h_o) <= 1e6 * EPS
-    assert rel_err(d_state.cpu().numpy(), ora.state.reshape(12, n)) <= 1e5 * EPS
+    h_g = d_h.cpu().numpy()
+    assert np.max(np.abs(h_g - h_o) / h_o) <= 1e6 * EPS
+    # The new state against the ORACLE's Taylor polynomials evaluated at the step the device took (a difference of
+    # 1e6 eps in h moves the state by up to ~1e6 eps |v| h / |x| on its own), and the polynomials themselves.
+    tc_o = ora.tc.reshape(12, ta.order + 1, n)
+    st_o = np.zeros((12, n))
+    for k in range(ta.order, -1, -1):
+        st_o = st_o * h_g + tc_o[:, k, :]
+    assert rel_err(d_state.cpu().numpy(), st_o) <= 1e5 * EPS
+    assert rel_err(d_tc.cpu().numpy(), tc_o) <= 1e5 * EPS
+    assert rel_err(d_state.cpu().numpy(), ora.state.reshape(12, n)) <= 1e6 * EPS
     assert np.array_equal(d_tc[:, 0, :].cpu().numpy(), st)
 
 
@@ -999,6 +1008,44 @@ def test_events_batch_vs_oracle():
     tb = hy.taylor_adaptive_batch([(x, v), (v, -9.8 * hy.sin(x))], st, n, nt_events=[hy.nt_event(v, boom)])
     with pytest.raises(RuntimeError, match="boom"):
         tb.step()
+
+
+def test_events_more_than_sixteen_roots_in_one_step_and_failure_counters():
+    """The lists of detected events are sized from the Taylor order and the number of events (round 2: 16 per class and
+    lane, which this case overflowed): x' = 1 and an event equation which is a polynomial with 19 roots inside ONE step,
+    per lane against the oracle; the working list of the root isolation has the reference's limit of 250 intervals
+    (src/detail/event_detection.cpp:2082), the bracket solver is TOMS 748 (:361-363) on both sides."""
+    n = 5
+    nroots = 19
+    x, y = hy.make_vars("x", "y")
+    ox, oy = ho.var("x"), ho.var("y")
+    roots = [0.04 + 0.05 * i for i in range(nroots)]
+
+    def poly(v, one):
+        g = one
+        for r in roots:
+            g = g * (v - r)
+        return g
+
+    st = np.stack([np.linspace(0.0, 0.004, n), np.zeros(n)])
+    log_p, log_o = [], []
+    ta = hy.taylor_adaptive_batch([(x, 1.0 + 0.0 * y), (y, 0.0 * x)], st, n,
+                                  nt_events=[hy.nt_event(poly(x, 1.0 + 0.0 * y), lambda ta, t, d, i: log_p.append((i, t, d)))])
+    ora = ho.OracleEventIntegrator([(ox, 1.0 + 0.0 * oy), (oy, 0.0 * ox)], st, n,
+                                   nt_events=[ho.nt_event(poly(ox, 1.0 + 0.0 * oy), lambda ta, t, d, i: log_o.append((i, t, d)))])
+    ta.step(max_delta_t=[1.0] * n)
+    ora.step(max_delta_ts=[1.0] * n)
+    assert [h for _, h in ta.step_res] == [1.0] * n == [h for _, h in ora.step_res]
+    assert len(log_o) == n * nroots
+    assert sorted((a[0], a[2]) for a in log_p) == sorted((a[0], a[2]) for a in log_o)
+    tp = np.array(sorted((a[0], a[1]) for a in log_p))
+    to = np.array(sorted((a[0], a[1]) for a in log_o))
+    # (Product of 19 factors in floating point: the roots of the computed polynomial sit within ~1e-9 of the exact ones;
+    # GPU and oracle isolate and polish the same polynomial up to the rounding of its coefficients.)
+    assert np.max(np.abs(tp[:, 1] - to[:, 1])) <= 1e-9
+    exact = np.array([r - st[0, i] for i in range(n) for r in roots])
+    assert np.max(np.abs(to[:, 1] - exact)) <= 1e-6
+    assert ta.event_detection_failures == 0
 
 
 def test_block_mode_nonuniform_masses_and_massless_bodies():
