@@ -924,7 +924,7 @@ class taylor_adaptive_batch:
 
     @property
     def event_detection_failures(self):
-        """Lane-steps in which the device-side event detection overflowed its fixed-size lists (events may have been dropped)."""
+        """Events ignored in a step because the root isolation or the root finder failed (the reference logs a warning)."""
         return int(lib.hy_tab_get_event_detection_failures(self._h))
 
     @property

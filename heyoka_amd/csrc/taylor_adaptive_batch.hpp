@@ -140,7 +140,8 @@ public:
     [[nodiscard]] double get_tol() const;
     [[nodiscard]] bool get_high_accuracy() const;
     [[nodiscard]] bool get_compact_mode() const;
-    // Number of lane-steps in which the device-side event detection overflowed its fixed-size lists (events dropped).
+    // Number of events which the device-side detection ignored in a step because the root isolation or the root finder
+    // failed (the reference logs a warning, src/detail/event_detection.cpp:2082-2090).
     [[nodiscard]] std::uint64_t get_event_detection_failures() const;
     [[nodiscard]] std::uint32_t get_dim() const;
     [[nodiscard]] const sys_t &get_sys() const;
@@ -534,7 +535,7 @@ public:
     {
         return m_core.get_compact_mode();
     }
-    // (Not in the reference: the device-side event detection works on fixed-size per-lane lists.)
+    // (Not in the reference, which reports these cases through its logger.)
     [[nodiscard]] std::uint64_t get_event_detection_failures() const
     {
         return m_core.get_event_detection_failures();

@@ -232,8 +232,10 @@ uint32_t hy_tab_get_n_uvars(hy_tab);  /* size of the decomposition minus n_eq */
 double hy_tab_get_tol(hy_tab);
 int hy_tab_get_high_accuracy(hy_tab);
 int hy_tab_get_compact_mode(hy_tab);
-/* No reference counterpart: number of lane-steps in which the device-side event detection (fixed-size per-lane lists; the
- * reference's detect_events(), src/detail/event_detection.cpp:1733-2173, has no cap) overflowed and may have dropped events. */
+/* No reference counterpart: number of (event, lane, step) triples in which the device-side event detection gave up - root
+ * isolation beyond 250 working intervals or more isolating intervals than the order, root finder out of iterations: the
+ * cases in which the reference's detect_events(), src/detail/event_detection.cpp:2082-2090, :2150-2165, logs a warning and
+ * ignores the event for the step. */
 unsigned long long hy_tab_get_event_detection_failures(hy_tab);
 double hy_tab_get_compile_seconds(hy_tab);
 char *hy_tab_get_hip_source(hy_tab);  /* generated HIP module (cf. llvm_state::get_ir()); caller frees */

@@ -1012,39 +1012,42 @@ def test_events_batch_vs_oracle():
 
 def test_events_more_than_sixteen_roots_in_one_step_and_failure_counters():
     """The lists of detected events are sized from the Taylor order and the number of events (round 2: 16 per class and
-    lane, which this case overflowed): x' = 1 and an event equation which is a polynomial with 19 roots inside ONE step,
-    per lane against the oracle; the working list of the root isolation has the reference's limit of 250 intervals
-    (src/detail/event_detection.cpp:2082), the bracket solver is TOMS 748 (:361-363) on both sides."""
+    lane, which this case overflowed): x' = 1 and three event equations which are polynomials with 7 roots each inside
+    ONE step (21 non-terminal events per lane and step), per lane against the oracle; the working list of the root
+    isolation has the reference's limit of 250 intervals (src/detail/event_detection.cpp:2082), the bracket solver is
+    TOMS 748 (:361-363) on both sides."""
     n = 5
-    nroots = 19
     x, y = hy.make_vars("x", "y")
     ox, oy = ho.var("x"), ho.var("y")
-    roots = [0.04 + 0.05 * i for i in range(nroots)]
+    roots = [[0.05 + 0.13 * i + 0.011 * e for i in range(7)] for e in range(3)]
 
-    def poly(v, one):
+    def poly(v, one, rts):
         g = one
-        for r in roots:
+        for r in rts:
             g = g * (v - r)
         return g
 
     st = np.stack([np.linspace(0.0, 0.004, n), np.zeros(n)])
     log_p, log_o = [], []
-    ta = hy.taylor_adaptive_batch([(x, 1.0 + 0.0 * y), (y, 0.0 * x)], st, n,
-                                  nt_events=[hy.nt_event(poly(x, 1.0 + 0.0 * y), lambda ta, t, d, i: log_p.append((i, t, d)))])
-    ora = ho.OracleEventIntegrator([(ox, 1.0 + 0.0 * oy), (oy, 0.0 * ox)], st, n,
-                                   nt_events=[ho.nt_event(poly(ox, 1.0 + 0.0 * oy), lambda ta, t, d, i: log_o.append((i, t, d)))])
+    ta = hy.taylor_adaptive_batch(
+        [(x, 1.0 + 0.0 * y), (y, 0.0 * x)], st, n,
+        nt_events=[hy.nt_event(poly(x, 1.0 + 0.0 * y, roots[e]), lambda ta, t, d, i, e=e: log_p.append((i, e, t, d)))
+                   for e in range(3)])
+    ora = ho.OracleEventIntegrator(
+        [(ox, 1.0 + 0.0 * oy), (oy, 0.0 * ox)], st, n,
+        nt_events=[ho.nt_event(poly(ox, 1.0 + 0.0 * oy, roots[e]), lambda ta, t, d, i, e=e: log_o.append((i, e, t, d)))
+                   for e in range(3)])
     ta.step(max_delta_t=[1.0] * n)
     ora.step(max_delta_ts=[1.0] * n)
     assert [h for _, h in ta.step_res] == [1.0] * n == [h for _, h in ora.step_res]
-    assert len(log_o) == n * nroots
-    assert sorted((a[0], a[2]) for a in log_p) == sorted((a[0], a[2]) for a in log_o)
-    tp = np.array(sorted((a[0], a[1]) for a in log_p))
-    to = np.array(sorted((a[0], a[1]) for a in log_o))
-    # (Product of 19 factors in floating point: the roots of the computed polynomial sit within ~1e-9 of the exact ones;
-    # GPU and oracle isolate and polish the same polynomial up to the rounding of its coefficients.)
-    assert np.max(np.abs(tp[:, 1] - to[:, 1])) <= 1e-9
-    exact = np.array([r - st[0, i] for i in range(n) for r in roots])
-    assert np.max(np.abs(to[:, 1] - exact)) <= 1e-6
+    assert len(log_o) == n * 21
+    # Same events in the same (chronological, per lane) order, same directions.
+    assert [(a[0], a[1], a[3]) for a in log_p] == [(a[0], a[1], a[3]) for a in log_o]
+    tp, to = np.array([a[2] for a in log_p]), np.array([a[2] for a in log_o])
+    assert np.max(np.abs(tp - to)) <= 1e-12
+    exact = {(i, e, k): roots[e][k] - st[0, i] for i in range(n) for e in range(3) for k in range(7)}
+    got = sorted((a[0], a[1], a[2]) for a in log_o)
+    assert np.max(np.abs(np.array([g[2] for g in got]) - np.array([exact[k] for k in sorted(exact)]))) <= 1e-11
     assert ta.event_detection_failures == 0
 
 
