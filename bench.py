@@ -451,7 +451,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dev_index = 0 if args.single_device else local_rank
         torch.cuda.set_device(dev_index)
-        dist.init_process_group(backend=args.backend)
+        if args.backend == "nccl":
+            # Binding the communicator to this rank's device up front: barrier() and the first collective do not have to
+            # guess the device (and RCCL initialises eagerly, before the timed region).
+            dist.init_process_group(backend=args.backend, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=args.backend)
     else:
         dev_index = 0
         torch.cuda.set_device(0)
