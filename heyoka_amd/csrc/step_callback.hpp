@@ -239,4 +239,22 @@ public:
 
 } // namespace detail
 
+// Access to the object stored in a callback wrapper, spelled like the reference's (tanuki) helpers
+// (test/taylor_adaptive_batch.cpp:688-730: value_isa<T>(cb), value_ptr<T>(cb)).
+template <typename T, typename TA>
+[[nodiscard]] bool value_isa(const detail::step_cb_wrap<TA> &w) noexcept
+{
+    return w.template extract<T>() != nullptr;
+}
+template <typename T, typename TA>
+[[nodiscard]] T *value_ptr(detail::step_cb_wrap<TA> &w) noexcept
+{
+    return w.template extract<T>();
+}
+template <typename T, typename TA>
+[[nodiscard]] const T *value_ptr(const detail::step_cb_wrap<TA> &w) noexcept
+{
+    return w.template extract<T>();
+}
+
 } // namespace heyoka_amd

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cassert>
+#include <charconv>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -23,11 +24,13 @@ namespace heyoka_amd::detail
 namespace
 {
 
+// Shortest representation which round-trips, like the reference's fmt::format("{}", x) (fp_to_string(),
+// src/detail/string_conv.cpp:64-80).
 std::string fp_to_string(double x)
 {
     char buf[64];
-    std::snprintf(buf, sizeof(buf), "%.17g", x);
-    return buf;
+    const auto res = std::to_chars(buf, buf + sizeof(buf), x);
+    return std::string(buf, res.ptr);
 }
 
 // Argument block of the post-step kernels (hy_grid_post / hy_until_post, see make_grid_source()).
@@ -620,8 +623,13 @@ tab_core::tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_siz
     d.prop_res.assign(d.N, std::tuple{taylor_outcome::success, 0., 0., std::size_t(0)});
 }
 
-tab_core::tab_core(const tab_core &o) : m_impl(std::make_unique<impl>())
+tab_core::tab_core() noexcept = default;
+
+tab_core::tab_core(const tab_core &o) : m_impl(o.m_impl ? std::make_unique<impl>() : nullptr)
 {
+    if (!o.m_impl) {
+        return;
+    }
     const auto &s = *o.m_impl;
     // Bring the host mirrors of the source up to date, then deep-copy them. The compiled module
     // is shared (reference: shared_ptr<ta_jit_data>, include/heyoka/detail/i_data.hpp:125).
@@ -810,6 +818,21 @@ void tab_core::set_dtime(const std::vector<double> &hi, const std::vector<double
                                     "batch size is "
                                     + std::to_string(d.N) + ", but the number of specified times is ("
                                     + std::to_string(hi.size()) + ", " + std::to_string(lo.size()) + ")");
+    }
+    // Checks on the values before anything is touched (dtime_checks(), include/heyoka/detail/taylor_common.hpp:232-249;
+    // src/taylor_adaptive_batch.cpp:576-580).
+    for (std::uint32_t i = 0; i < d.N; ++i) {
+        if (!std::isfinite(hi[i]) || !std::isfinite(lo[i])) {
+            throw std::invalid_argument("The components of the double-length representation of the time coordinate must "
+                                        "both be finite, but they are "
+                                        + fp_to_string(hi[i]) + " and " + fp_to_string(lo[i]) + " instead");
+        }
+        if (std::abs(hi[i]) < std::abs(lo[i])) {
+            throw std::invalid_argument("The first component of the double-length representation of the time coordinate ("
+                                        + fp_to_string(hi[i])
+                                        + ") must not be smaller in magnitude than the second component ("
+                                        + fp_to_string(lo[i]) + ")");
+        }
     }
     d.to_host();
     for (std::uint32_t i = 0; i < d.N; ++i) {
@@ -2097,6 +2120,13 @@ std::vector<double> tab_core::propagate_grid(std::vector<double> grid, std::size
                                     + std::to_string(grid.size()) + ", which is not a multiple of the batch size ("
                                     + std::to_string(N) + ")");
     }
+    // The current time coordinates (src/taylor_adaptive_batch.cpp:1588-1593).
+    d.times_to_host();
+    if (std::any_of(d.time_hi.begin(), d.time_hi.end(), [](double t) { return !std::isfinite(t); })
+        || std::any_of(d.time_lo.begin(), d.time_lo.end(), [](double t) { return !std::isfinite(t); })) {
+        throw std::invalid_argument("Cannot invoke propagate_grid() in an adaptive Taylor integrator in batch mode if "
+                                    "the current time is not finite");
+    }
     const std::vector<double> max_delta_ts = max_delta_ts_.empty() ? std::vector<double>(N, pinf) : max_delta_ts_;
     if (max_delta_ts.size() != N) {
         throw std::invalid_argument("Invalid number of max timesteps specified in a Taylor integrator in batch mode: "
@@ -2138,13 +2168,13 @@ std::vector<double> tab_core::propagate_grid(std::vector<double> grid, std::size
                 throw std::invalid_argument(ig_err_msg);
             }
         }
+        // (Row by row: finiteness of the whole row first, then the ordering - src/taylor_adaptive_batch.cpp:1652-1661.)
         for (std::size_t k = 2; k < n_grid_points; ++k) {
+            if (std::any_of(gp + k * N, gp + (k + 1u) * N, is_nf)) {
+                throw std::invalid_argument(nf_err_msg);
+            }
             for (std::uint32_t i = 0; i < N; ++i) {
-                const auto t = gp[k * N + i];
-                if (is_nf(t)) {
-                    throw std::invalid_argument(nf_err_msg);
-                }
-                if ((t > gp[(k - 1u) * N + i]) != grid_direction) {
+                if ((gp[k * N + i] > gp[(k - 1u) * N + i]) != grid_direction) {
                     throw std::invalid_argument(ig_err_msg);
                 }
             }

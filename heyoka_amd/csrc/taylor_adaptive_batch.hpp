@@ -125,6 +125,9 @@ public:
         int batch_semantics = 0;
     };
 
+    // Default construction: an empty object which can only be destroyed, assigned to or copied (the reference's
+    // default constructor leaves the integrator in an invalid state, src/taylor_adaptive_batch.cpp:430).
+    tab_core() noexcept;
     tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_size, config cfg);
     tab_core(const tab_core &);
     tab_core(tab_core &&) noexcept;
@@ -428,7 +431,7 @@ class taylor_adaptive_batch<double>
     }
 
     template <typename... KwArgs>
-    auto propagate_common_ops(const KwArgs &...kw_args)
+    auto propagate_common_ops(KwArgs &&...kw_args)
     {
         static_assert(kw::all_named_v<KwArgs...>);
         const auto max_steps = static_cast<std::size_t>(kw::get(kw::max_steps, 0, kw_args...));
@@ -450,12 +453,14 @@ class taylor_adaptive_batch<double>
         auto user_cb = std::make_shared<step_callback_batch<double>>();
         if constexpr (kw::has_v<kw::callback_tag, KwArgs...>) {
             using cb_arg_t = std::decay_t<decltype(kw::get(kw::callback, 0, kw_args...))>;
+            // NOTE: a callback passed as an rvalue (kw::callback = std::move(cb), or a temporary) is MOVED into the holder
+            // and never copied afterwards (test/taylor_adaptive_batch.cpp:497-526, :688-730).
             if constexpr (std::is_constructible_v<step_callback_batch<double>, const cb_arg_t &>) {
-                *user_cb = step_callback_batch<double>(kw::get(kw::callback, 0, kw_args...));
+                *user_cb = step_callback_batch<double>(kw::get(kw::callback, 0, std::forward<KwArgs>(kw_args)...));
             } else {
                 std::vector<step_callback_batch<double>> v;
-                for (const auto &x : kw::get(kw::callback, 0, kw_args...)) {
-                    v.emplace_back(x);
+                for (auto &&x : kw::get(kw::callback, 0, std::forward<KwArgs>(kw_args)...)) {
+                    v.emplace_back(std::forward<decltype(x)>(x));
                 }
                 *user_cb = step_callback_batch<double>(step_callback_batch_set<double>(std::move(v)));
             }
@@ -473,6 +478,10 @@ class taylor_adaptive_batch<double>
 
 public:
     using sys_t = detail::tab_core::sys_t;
+
+    // Default construction leaves the object in an invalid state: only destruction, assignment and copy are allowed
+    // (include/heyoka/taylor.hpp:901, test/taylor_adaptive_batch.cpp:1253-1263).
+    taylor_adaptive_batch() noexcept = default;
 
     template <typename... KwArgs>
     taylor_adaptive_batch(sys_t sys, std::vector<double> state, std::uint32_t batch_size, const KwArgs &...kw_args)
@@ -507,12 +516,15 @@ public:
     {
         return m_core.get_decomposition();
     }
+    // (Both throw "No events were defined for this integrator" without events: src/taylor_adaptive_batch.cpp:2127-2150.)
     [[nodiscard]] const std::vector<t_event_batch<double>> &get_t_events() const
     {
+        (void)m_core.get_t_events();
         return m_t_events;
     }
     [[nodiscard]] const std::vector<nt_event_batch<double>> &get_nt_events() const
     {
+        (void)m_core.get_nt_events();
         return m_nt_events;
     }
     [[nodiscard]] std::uint32_t get_batch_size() const
@@ -699,43 +711,43 @@ public:
 public:
     template <typename... KwArgs>
     std::tuple<std::optional<continuous_output_batch<double>>, step_callback_batch<double>> propagate_until(const std::vector<double> &ts,
-                                                                           const KwArgs &...kw_args)
+                                                                           KwArgs &&...kw_args)
     {
-        auto [max_steps, mdts, cb, user_cb, wtc, c_out, pre] = propagate_common_ops(kw_args...);
+        auto [max_steps, mdts, cb, user_cb, wtc, c_out, pre] = propagate_common_ops(std::forward<KwArgs>(kw_args)...);
         m_core.set_callback_context(this);
         m_core.propagate_until(ts, max_steps, mdts, cb, wtc, c_out, pre);
         return {make_c_out(), std::move(*user_cb)};
     }
     template <typename... KwArgs>
-    std::tuple<std::optional<continuous_output_batch<double>>, step_callback_batch<double>> propagate_until(double t, const KwArgs &...kw_args)
+    std::tuple<std::optional<continuous_output_batch<double>>, step_callback_batch<double>> propagate_until(double t, KwArgs &&...kw_args)
     {
-        auto [max_steps, mdts, cb, user_cb, wtc, c_out, pre] = propagate_common_ops(kw_args...);
+        auto [max_steps, mdts, cb, user_cb, wtc, c_out, pre] = propagate_common_ops(std::forward<KwArgs>(kw_args)...);
         m_core.set_callback_context(this);
         m_core.propagate_until(std::vector<double>{t}, max_steps, mdts, cb, wtc, c_out, pre);
         return {make_c_out(), std::move(*user_cb)};
     }
     template <typename... KwArgs>
     std::tuple<std::optional<continuous_output_batch<double>>, step_callback_batch<double>> propagate_for(const std::vector<double> &dts,
-                                                                         const KwArgs &...kw_args)
+                                                                         KwArgs &&...kw_args)
     {
-        auto [max_steps, mdts, cb, user_cb, wtc, c_out, pre] = propagate_common_ops(kw_args...);
+        auto [max_steps, mdts, cb, user_cb, wtc, c_out, pre] = propagate_common_ops(std::forward<KwArgs>(kw_args)...);
         m_core.set_callback_context(this);
         m_core.propagate_for(dts, max_steps, mdts, cb, wtc, c_out, pre);
         return {make_c_out(), std::move(*user_cb)};
     }
     template <typename... KwArgs>
-    std::tuple<std::optional<continuous_output_batch<double>>, step_callback_batch<double>> propagate_for(double dt, const KwArgs &...kw_args)
+    std::tuple<std::optional<continuous_output_batch<double>>, step_callback_batch<double>> propagate_for(double dt, KwArgs &&...kw_args)
     {
-        auto [max_steps, mdts, cb, user_cb, wtc, c_out, pre] = propagate_common_ops(kw_args...);
+        auto [max_steps, mdts, cb, user_cb, wtc, c_out, pre] = propagate_common_ops(std::forward<KwArgs>(kw_args)...);
         m_core.set_callback_context(this);
         m_core.propagate_for(std::vector<double>{dt}, max_steps, mdts, cb, wtc, c_out, pre);
         return {make_c_out(), std::move(*user_cb)};
     }
     template <typename... KwArgs>
     std::tuple<step_callback_batch<double>, std::vector<double>> propagate_grid(std::vector<double> grid,
-                                                                               const KwArgs &...kw_args)
+                                                                               KwArgs &&...kw_args)
     {
-        auto [max_steps, mdts, cb, user_cb, wtc, c_out, pre] = propagate_common_ops(kw_args...);
+        auto [max_steps, mdts, cb, user_cb, wtc, c_out, pre] = propagate_common_ops(std::forward<KwArgs>(kw_args)...);
         m_core.set_callback_context(this);
         auto ret = m_core.propagate_grid(std::move(grid), max_steps, mdts, cb, nullptr, pre);
         return {std::move(*user_cb), std::move(ret)};

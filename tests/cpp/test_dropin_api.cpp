@@ -179,7 +179,17 @@ int main(int argc, char **argv)
         REQUIRE(oss2.str().find("N of terminal events    : 1") != std::string::npos);
         REQUIRE(oss2.str().find("N of non-terminal events: 1") != std::string::npos);
         REQUIRE(oss2.str().find("Parameters") == std::string::npos);
-        REQUIRE(tae.get_t_events().size() == 1u && tae.get_nt_events().size() == 1u && ta.get_t_events().empty());
+        REQUIRE(tae.get_t_events().size() == 1u && tae.get_nt_events().size() == 1u);
+        {
+            // Without events the getters throw (test/taylor_adaptive_batch.cpp:1441-1452).
+            bool thrown = false;
+            try {
+                (void)ta.get_t_events();
+            } catch (const std::invalid_argument &e) {
+                thrown = std::string(e.what()) == "No events were defined for this integrator";
+            }
+            REQUIRE(thrown);
+        }
         REQUIRE(tae.get_t_events()[0].get_direction() == event_direction::positive
                 && tae.get_t_events()[0].get_cooldown() == 0.01);
     }

@@ -68,3 +68,35 @@ def test_reference_include_layout_runs_the_tutorial_calls_on_gpu():
     # The first step of the four pendulums succeeds (outcomes printed in the reference's format).
     assert "GPU OK" in out.stdout and "Batch index 0: (taylor_outcome::success, 0.1" in out.stdout
     assert "taylor_outcome::time_limit" in out.stdout
+
+
+EXE3 = os.path.join(ROOT, "heyoka_amd", "csrc", "_build", "test_reference_cases")
+
+
+def _build_ref_cases():
+    """tests/cpp/test_reference_cases.cpp: the behaviours pinned by the reference's own unit tests of the batch integrator
+    (test/taylor_adaptive_batch.cpp), restated against the reference's include layout."""
+    src = os.path.join(ROOT, "tests", "cpp", "test_reference_cases.cpp")
+    lib = os.path.join(ROOT, "heyoka_amd", "libheyoka_amd.so")
+    if os.path.exists(EXE3) and os.path.getmtime(EXE3) > max(os.path.getmtime(src), os.path.getmtime(lib)):
+        return
+    os.makedirs(os.path.dirname(EXE3), exist_ok=True)
+    subprocess.check_call(
+        ["g++", "-std=c++20", "-O1", "-I" + os.path.join(ROOT, "include"), src, "-o", EXE3,
+         "-L" + os.path.join(ROOT, "heyoka_amd"), "-lheyoka_amd", "-Wl,-rpath," + os.path.join(ROOT, "heyoka_amd"),
+         "-Wl,-rpath,/opt/rocm/lib"])
+
+
+def test_reference_unit_test_cases_host_side():
+    _build_ref_cases()
+    out = subprocess.run([EXE3], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "host cases OK" in out.stdout
+
+
+@pytest.mark.gpu
+def test_reference_unit_test_cases_on_gpu():
+    _build_ref_cases()
+    out = subprocess.run([EXE3, "gpu"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert "GPU cases OK" in out.stdout
