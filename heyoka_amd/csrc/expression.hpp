@@ -302,11 +302,16 @@ inline expression operator""_dbl(unsigned long long n)
 
 } // namespace literals
 
-// make_vars("x", "v") -> array of variable expressions.
-template <typename... Args>
-inline auto make_vars(const Args &...names)
+// make_vars("x", "v") -> array of variable expressions; make_vars("x") -> a single expression
+// (include/heyoka/expression.hpp:540-549).
+template <typename Arg0, typename... Args>
+inline auto make_vars(const Arg0 &name, const Args &...names)
 {
-    return std::array<expression, sizeof...(Args)>{expression{std::string(names)}...};
+    if constexpr (sizeof...(Args) == 0u) {
+        return expression{std::string(name)};
+    } else {
+        return std::array<expression, sizeof...(Args) + 1u>{expression{std::string(name)}, expression{std::string(names)}...};
+    }
 }
 
 // prime(x) = rhs -> pair(x, rhs).

@@ -271,6 +271,9 @@ private:
     event_direction m_dir = event_direction::any;
 
 public:
+    // Default construction: the event equation 0 with a callback which does nothing
+    // (test/batch_event_detection.cpp:1020-1027).
+    nt_event_batch() : m_eq(0.), m_cb([](taylor_adaptive_batch<T> &, T, int, std::uint32_t) {}) {}
     template <typename... KwArgs>
     explicit nt_event_batch(expression e, callback_t cb, const KwArgs &...kw_args)
         : m_eq(std::move(e)), m_cb(std::move(cb)),
@@ -317,6 +320,9 @@ private:
     T m_cooldown = -1;
 
 public:
+    // Default construction: the event equation 0, no callback, any direction, automatic cooldown
+    // (test/batch_event_detection.cpp:1818-1826).
+    t_event_batch() : m_eq(0.) {}
     template <typename... KwArgs>
     explicit t_event_batch(expression e, const KwArgs &...kw_args)
         : m_eq(std::move(e)),
@@ -478,6 +484,10 @@ class taylor_adaptive_batch<double>
 
 public:
     using sys_t = detail::tab_core::sys_t;
+    // (include/heyoka/taylor.hpp:789-795.)
+    using value_type = double;
+    using nt_event_t = nt_event_batch<double>;
+    using t_event_t = t_event_batch<double>;
 
     // Default construction leaves the object in an invalid state: only destruction, assignment and copy are allowed
     // (include/heyoka/taylor.hpp:901, test/taylor_adaptive_batch.cpp:1253-1263).

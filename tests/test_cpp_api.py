@@ -100,3 +100,34 @@ def test_reference_unit_test_cases_on_gpu():
     out = subprocess.run([EXE3, "gpu"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr + out.stdout
     assert "GPU cases OK" in out.stdout
+
+
+EXE4 = os.path.join(ROOT, "heyoka_amd", "csrc", "_build", "test_reference_event_cases")
+
+
+def _build_ref_event_cases():
+    """tests/cpp/test_reference_event_cases.cpp: behaviours and known answers of test/batch_event_detection.cpp."""
+    src = os.path.join(ROOT, "tests", "cpp", "test_reference_event_cases.cpp")
+    lib = os.path.join(ROOT, "heyoka_amd", "libheyoka_amd.so")
+    if os.path.exists(EXE4) and os.path.getmtime(EXE4) > max(os.path.getmtime(src), os.path.getmtime(lib)):
+        return
+    os.makedirs(os.path.dirname(EXE4), exist_ok=True)
+    subprocess.check_call(
+        ["g++", "-std=c++20", "-O1", "-I" + os.path.join(ROOT, "include"), src, "-o", EXE4,
+         "-L" + os.path.join(ROOT, "heyoka_amd"), "-lheyoka_amd", "-Wl,-rpath," + os.path.join(ROOT, "heyoka_amd"),
+         "-Wl,-rpath,/opt/rocm/lib"])
+
+
+def test_reference_event_detection_cases_host_side():
+    _build_ref_event_cases()
+    out = subprocess.run([EXE4], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "host cases OK" in out.stdout
+
+
+@pytest.mark.gpu
+def test_reference_event_detection_cases_on_gpu():
+    _build_ref_event_cases()
+    out = subprocess.run([EXE4, "gpu"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert "GPU cases OK" in out.stdout
