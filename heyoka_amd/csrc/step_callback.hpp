@@ -16,6 +16,7 @@
 #include <stdexcept>
 #include <string>
 #include <type_traits>
+#include <typeindex>
 #include <typeinfo>
 #include <utility>
 #include <vector>
@@ -241,10 +242,24 @@ public:
 
 // Access to the object stored in a callback wrapper, spelled like the reference's (tanuki) helpers
 // (test/taylor_adaptive_batch.cpp:688-730: value_isa<T>(cb), value_ptr<T>(cb)).
+template <typename TA>
+[[nodiscard]] std::type_index value_type_index(const detail::step_cb_wrap<TA> &w) noexcept
+{
+    return std::type_index(w.value_type());
+}
 template <typename T, typename TA>
 [[nodiscard]] bool value_isa(const detail::step_cb_wrap<TA> &w) noexcept
 {
     return w.template extract<T>() != nullptr;
+}
+template <typename T, typename TA>
+[[nodiscard]] T &value_ref(detail::step_cb_wrap<TA> &w)
+{
+    auto *p = w.template extract<T>();
+    if (p == nullptr) {
+        throw std::runtime_error("Invalid reference to the value stored in a step callback: the stored type is different");
+    }
+    return *p;
 }
 template <typename T, typename TA>
 [[nodiscard]] T *value_ptr(detail::step_cb_wrap<TA> &w) noexcept

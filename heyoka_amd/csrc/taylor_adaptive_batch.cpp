@@ -204,6 +204,9 @@ struct tab_core::impl {
     {
         if (d_tc.bytes() == 0u) {
             d_tc = device_buffer(static_cast<std::size_t>(dim) * (order + 1u) * N * sizeof(double), device);
+            // The Taylor coefficients read as zeros until a step writes them (the reference value-initialises m_tc:
+            // test/taylor_adaptive_batch.cpp:741-746 checks it from a step callback).
+            d_tc.zero(stream);
         }
     }
 
@@ -266,10 +269,15 @@ struct tab_core::impl {
         }
     }
 
-    void after_kernel()
+    // tc_written: the launch was asked to write the Taylor coefficients. The reference's get_tc() holds the coefficients
+    // of the last step taken with write_tc (zeros before the first one, src/taylor_adaptive_batch.cpp:756-760): steppers
+    // which keep their jets in the tc buffer anyway do not count.
+    void after_kernel(bool tc_written = true)
     {
         dev_newer = true;
-        tc_dev_newer = true;
+        if (tc_written) {
+            tc_dev_newer = true;
+        }
         lasth_dev_newer = true;
         if (sticky_host_ptr) {
             to_host();
@@ -352,7 +360,7 @@ struct tab_core::impl {
         }
         a.mode = 0;
         dmod->launch_taylor(a);
-        after_kernel();
+        after_kernel(wtc);
         step_res_dev_newer = true;
     }
 
@@ -1597,7 +1605,7 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
             d.snapshot_for_rollback();
         }
         d.dmod->launch_taylor(a);
-        d.after_kernel();
+        d.after_kernel(wtc);
         d.prop_res_dev_newer = true;
         d.step_res_dev_newer = false;
         finish_device_propagate(ts_, max_steps, max_delta_ts, wtc);
@@ -1689,7 +1697,7 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
             d.snapshot_for_rollback();
         }
         d.dmod->launch_taylor(a);
-        d.after_kernel();
+        d.after_kernel(wtc);
         d.prop_res_dev_newer = true;
         d.step_res_dev_newer = false;
         finish_device_propagate(ts_, max_steps, max_delta_ts, wtc);

@@ -112,6 +112,47 @@ struct counting_cb {
     inline static unsigned n_copies = 0, n_copies_after = 0, n_calls = 0;
 };
 
+// The callables of test/step_callback.cpp:49-78, :362-401.
+bool free_cb(tab &)
+{
+    return true;
+}
+struct two_and_false {
+    bool operator()(tab &ta)
+    {
+        ta.get_state_data()[0] = 2;
+        return false;
+    }
+    void pre_hook(tab &ta)
+    {
+        ta.get_state_data()[0] = 1;
+    }
+};
+struct only_pre_hook {
+    void pre_hook(tab &) {}
+};
+struct sets_length_in_pre_hook {
+    bool operator()(tab &)
+    {
+        return true;
+    }
+    void pre_hook(tab &ta)
+    {
+        ta.get_pars_data()[0] = 1.5;
+        ta.get_pars_data()[1] = 1.5;
+    }
+};
+struct moves_time_in_pre_hook {
+    bool operator()(tab &)
+    {
+        return true;
+    }
+    void pre_hook(tab &ta)
+    {
+        ta.set_time({ta.get_time()[0] + 1, ta.get_time()[1] + 1});
+    }
+};
+
 const std::string ev_time_msg = "The invocation of one or more event callbacks resulted in the alteration of the time "
                                 "coordinate of the integrator at the batch index 0 - this is not supported";
 
@@ -292,6 +333,111 @@ void host_cases()
                     "The final time passed to the propagate_until()" + tail + " results in an overflow condition");
     }
 
+    // test/step_callback.cpp "step_callback basics" (:80-195) for the batch wrapper.
+    {
+        using cb_t = step_callback_batch<double>;
+        auto ta = tab{{prime(x) = 0_dbl, prime(v) = 0_dbl}, {0., 0.}, 1u, kw::tol = 1e-1};
+        {
+            cb_t c;
+            CHECK(!c);
+            THROWS(std::bad_function_call, c(ta));
+            static_assert(std::is_nothrow_swappable_v<cb_t>);
+            static_assert(!std::is_constructible_v<cb_t, void>);
+            static_assert(!std::is_constructible_v<cb_t, int, int>);
+            static_assert(!std::is_constructible_v<cb_t, only_pre_hook>);
+            auto c2 = c;
+            auto c3 = std::move(c);
+            CHECK(!c2 && !c3);
+            cb_t c6 = static_cast<bool (*)(tab &)>(nullptr);
+            cb_t c7 = std::function<bool(tab &)>{};
+            CHECK(!c6 && !c7);
+        }
+        {
+            auto lam = [](auto &) { return true; };
+            cb_t c(lam);
+            CHECK(static_cast<bool>(c) && c(ta));
+            c.pre_hook(ta);
+            CHECK(value_type_index(c) == typeid(decltype(lam)));
+            CHECK(value_ptr<decltype(lam)>(c) != nullptr && value_ptr<decltype(lam)>(std::as_const(c)) != nullptr);
+            cb_t from_ptr(&free_cb), from_fn(free_cb);
+            CHECK(value_type_index(from_ptr) == typeid(decltype(&free_cb)));
+            CHECK(from_ptr(ta) && from_fn(ta));
+            from_ptr.pre_hook(ta);
+            from_fn.pre_hook(ta);
+        }
+        const auto call_then_hook = [&](cb_t c) {
+            CHECK(ta.get_state()[0] == 0.);
+            CHECK(static_cast<bool>(c) && !c(ta));
+            CHECK(ta.get_state()[0] == 2.);
+            c.pre_hook(ta);
+            CHECK(ta.get_state()[0] == 1.);
+            ta.get_state_data()[0] = 0;
+        };
+        call_then_hook(cb_t(two_and_false{}));
+        two_and_false by_ref;
+        call_then_hook(cb_t(std::ref(by_ref)));
+        {
+            cb_t c([](auto &t) {
+                t.get_state_data()[0] = 3;
+                return true;
+            });
+            CHECK(c(ta) && ta.get_state()[0] == 3.);
+            c.pre_hook(ta); // (no pre_hook() member: nothing happens)
+            CHECK(ta.get_state()[0] == 3.);
+            ta.get_state_data()[0] = 0;
+        }
+        {
+            using std::swap;
+            cb_t c1(two_and_false{}), c2;
+            swap(c1, c2);
+            CHECK(static_cast<bool>(c2) && !c1 && value_ptr<two_and_false>(c2) != nullptr);
+        }
+        // "step_callback_set" (:493-545, :660-680): container interface and error messages.
+        {
+            using set_t = step_callback_batch_set<double>;
+            using std::swap;
+            static_assert(std::is_nothrow_swappable_v<set_t>);
+            set_t s0;
+            CHECK(s0.size() == 0u);
+            THROWS_WITH(std::out_of_range, s0[0], "Out of range index 0 when accessing a step callback set of size 0");
+            THROWS_WITH(std::out_of_range, std::as_const(s0)[0],
+                        "Out of range index 0 when accessing a step callback set of size 0");
+            auto s1 = set_t{[](const auto &) { return true; }};
+            CHECK(s1.size() == 1u);
+            (void)s1[0];
+            THROWS_WITH(std::out_of_range, s1[10], "Out of range index 10 when accessing a step callback set of size 1");
+            swap(s0, s1);
+            CHECK(s0.size() == 1u && s1.size() == 0u);
+            auto s3 = s0;
+            auto s4 = std::move(s0);
+            s0 = s4;
+            s1 = std::move(s0);
+            CHECK(s3.size() == 1u && s4.size() == 1u && s1.size() == 1u);
+            const std::string empty_msg = "Cannot construct a callback set containing one or more empty callbacks";
+            THROWS_WITH(std::invalid_argument, (set_t{cb_t{}}), empty_msg);
+            THROWS_WITH(std::invalid_argument, (set_t{cb_t{}, [](const auto &) { return true; }}), empty_msg);
+            THROWS_WITH(std::invalid_argument, (set_t{[](const auto &) { return true; }, cb_t{}}), empty_msg);
+        }
+    }
+
+    // "propagate grid 2" (:768-800), argument checks.
+    {
+        auto ta = tab{pend, {0.05, 0.06, 0.025, 0.026}, 2u};
+        const std::string tail = " function of an adaptive Taylor integrator in batch mode";
+        const auto n_msg = [](int n) {
+            return "Invalid number of max timesteps specified in a Taylor integrator in batch mode: the batch size is 2, but "
+                   "the number of specified timesteps is "
+                   + std::to_string(n);
+        };
+        THROWS_WITH(std::invalid_argument, ta.propagate_grid({10., 11.}, kw::max_delta_t = dvec{1}), n_msg(1));
+        THROWS_WITH(std::invalid_argument, ta.propagate_grid({10., 11.}, kw::max_delta_t = {1., 2., 3.}), n_msg(3));
+        THROWS_WITH(std::invalid_argument,
+                    ta.propagate_grid({10., 11.}, kw::max_delta_t = {1., std::numeric_limits<double>::quiet_NaN()}),
+                    "A nan max_delta_t was passed to the propagate_grid()" + tail);
+        THROWS_WITH(std::invalid_argument, ta.propagate_grid({10., 11.}, kw::max_delta_t = {1., -1.}),
+                    "A non-positive max_delta_t was passed to the propagate_grid()" + tail);
+    }
+
     // "propagate grid" (:162-245), argument checks in the reference's order.
     {
         for (const auto cm : {true, false}) {
@@ -441,6 +587,249 @@ void gpu_cases()
             std::get<1>(ret)(ta);
             CHECK(value_isa<step_callback_batch_set<double>>(std::get<1>(ret)));
         }
+    }
+
+    // test/step_callback.cpp "step_callback pre_hook" (:448-490), batch part: pre_hook() runs before the first step (the
+    // pendulum's length is set there: same trajectory as an integrator constructed with it); a pre_hook() which moves
+    // the time coordinate is reported like a callback doing so.
+    {
+        const auto dyn = model::pendulum(kw::length = par[0]);
+        auto ta0 = tab{dyn, {1., 1.1, 0., 0.1}, 2u};
+        auto ta1 = tab{dyn, {1., 1.1, 0., 0.1}, 2u, kw::pars = {1.5, 1.5}};
+        CHECK((ta0.get_pars() == dvec{0., 0.}));
+        ta0.propagate_until(3., kw::callback = sets_length_in_pre_hook{});
+        ta1.propagate_until(3.);
+        CHECK((ta0.get_pars() == dvec{1.5, 1.5}));
+        CHECK(ta0.get_state() == ta1.get_state());
+        THROWS_WITH(std::runtime_error, ta0.propagate_until(6., kw::callback = moves_time_in_pre_hook{}),
+                    "The invocation of the callback passed to propagate_until() resulted in the alteration of the time "
+                    "coordinate of the integrator - this is not supported");
+        CHECK((ta0.get_time() == dvec{4., 4.}));
+        ta0.set_time(0.);
+        ta0.get_pars_data()[0] = 0.1;
+        ta0.get_pars_data()[1] = 0.1;
+        ta1.set_time(0.);
+        auto [cb0, res0] = ta0.propagate_grid({0., 0., 1., 1., 2., 2.}, kw::callback = sets_length_in_pre_hook{});
+        auto [cb1, res1] = ta1.propagate_grid({0., 0., 1., 1., 2., 2.});
+        CHECK(static_cast<bool>(cb0) && !cb1);
+        CHECK(res0 == res1);
+        CHECK((ta0.get_pars() == dvec{1.5, 1.5}));
+        THROWS_WITH(std::runtime_error,
+                    ta0.propagate_grid({ta0.get_time()[0], ta0.get_time()[1], 4., 4.}, kw::callback = moves_time_in_pre_hook{}),
+                    "The invocation of the callback passed to propagate_grid() resulted in the alteration of the time "
+                    "coordinate of the integrator - this is not supported");
+    }
+
+    // "step_callback_set" (:546-658) and "step_callback range" (:725-790) in propagate_until(): every member runs at
+    // every step, in order, whatever the others return; the pre-hooks run once each; ranges become sets.
+    {
+        using cb_t = step_callback_batch<double>;
+        using set_t = step_callback_batch_set<double>;
+        const auto fresh = [&]() { return tab{model::pendulum(), {1., 1.1, 0., 0.1}, 2u}; };
+        {
+            auto ta = fresh();
+            ta.propagate_until(10., kw::callback = set_t{});
+            CHECK(all_time_limit(ta));
+        }
+        for (const auto stop_first : {0, 1, 2}) {
+            int c1 = 0, c2 = 0;
+            auto ta = fresh();
+            ta.propagate_until(10., kw::callback = set_t{[&, stop_first](const auto &) {
+                                                             CHECK(c1 == c2);
+                                                             ++c1;
+                                                             return stop_first != 1;
+                                                         },
+                                                         [&, stop_first](const auto &) {
+                                                             ++c2;
+                                                             CHECK(c1 == c2);
+                                                             return stop_first != 2;
+                                                         }});
+            CHECK(c1 == c2 && c1 > 0);
+            CHECK(oc(ta, 0) == (stop_first == 0 ? taylor_outcome::time_limit : taylor_outcome::cb_stop));
+            CHECK(stop_first == 0 || c1 == 1);
+        }
+        {
+            struct counted {
+                int *calls, *hooks;
+                bool operator()(tab &)
+                {
+                    ++*calls;
+                    return true;
+                }
+                void pre_hook(tab &)
+                {
+                    CHECK(*hooks == 0);
+                    ++*hooks;
+                }
+            };
+            int a = 0, b = 0, h1 = 0, h2 = 0;
+            auto ta = fresh();
+            ta.propagate_until(10., kw::callback = set_t{counted{&a, &h1}, counted{&b, &h2}});
+            CHECK(all_time_limit(ta) && a == b && a > 0 && h1 == 1 && h2 == 1);
+        }
+        {
+            auto ta = fresh();
+            auto r = ta.propagate_until(10., kw::callback = std::initializer_list<cb_t>{});
+            CHECK(all_time_limit(ta) && static_cast<bool>(std::get<1>(r)) && value_isa<set_t>(std::get<1>(r)));
+            int c1 = 0, c2 = 0;
+            auto r2 = ta.propagate_until(20., kw::callback = {cb_t{[&](const auto &) {
+                                                                  CHECK(c1 == c2);
+                                                                  ++c1;
+                                                                  return true;
+                                                              }},
+                                                              cb_t{[&](const auto &) {
+                                                                  ++c2;
+                                                                  CHECK(c1 == c2);
+                                                                  return true;
+                                                              }}});
+            CHECK(all_time_limit(ta) && c1 == c2 && c1 > 0 && value_isa<set_t>(std::get<1>(r2)));
+            c1 = c2 = 0;
+            auto r3 = ta.propagate_until(30., kw::callback = std::vector<cb_t>{[&](const auto &) {
+                                                                                   ++c1;
+                                                                                   return false;
+                                                                               },
+                                                                               [&](const auto &) {
+                                                                                   ++c2;
+                                                                                   return true;
+                                                                               }});
+            CHECK(oc(ta, 0) == taylor_outcome::cb_stop && c1 == 1 && c2 == 1 && value_isa<set_t>(std::get<1>(r3)));
+        }
+    }
+
+    // "propagate grid" (:246-445): a non-finite lane, a grid of one point, the harmonic oscillator sampled on 1 000 points
+    // per lane (regular and irregular, forwards and backwards) against sin / cos, callbacks moved in and handed back.
+    {
+        auto ta = tab{pend, {0.05, 0.025, 0.051, 0.0251, 0.052, 0.0252, 0.053, 0.0253}, 4u};
+        ta.get_state_data()[0] = inf;
+        auto [cb, ret] = ta.propagate_grid({.0, .0, .0, .0});
+        CHECK(!cb && ret.size() == 8u);
+        CHECK(oc(ta, 0) == taylor_outcome::err_nf_state);
+        for (const auto i : {1, 2, 3}) {
+            CHECK(oc(ta, i) == taylor_outcome::time_limit);
+        }
+        const dvec st{0.05, 0.025, 0.051, 0.0251, 0.052, 0.0252, 0.053, 0.0253};
+        ta = tab{pend, st, 4u};
+        std::tie(cb, ret) = ta.propagate_grid({0., 0., 0., 0.});
+        CHECK(!cb && ret == st);
+        for (auto i = 0u; i < 4u; ++i) {
+            const auto [o, min_h, max_h, ns] = ta.get_propagate_res()[i];
+            CHECK(o == taylor_outcome::time_limit && min_h == inf && max_h == 0 && ns == 0u);
+        }
+        // Deterministic stand-in for the reference's random increments in (0, 0.1).
+        std::uint64_t lcg = 12345;
+        const auto next_inc = [&lcg]() {
+            lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+            return 0.1 * (static_cast<double>(lcg >> 11) + 1.) / 9007199254740994.;
+        };
+        for (const auto sign : {1., -1.}) {
+            for (const auto irregular : {false, true}) {
+                dvec grid(4000u, 0.);
+                for (auto i = 1u; i < 1000u; ++i) {
+                    for (auto j = 0u; j < 4u; ++j) {
+                        grid[i * 4u + j] = irregular ? grid[(i - 1u) * 4u + j] + sign * next_inc()
+                                                     : sign * (i / 100. + j / 10.);
+                    }
+                }
+                ta = tab{osc, {0., 0., 0., 0., 1., 1.1, 1.2, 1.3}, 4u};
+                std::tie(cb, ret) = ta.propagate_grid(grid);
+                CHECK(!cb && ret.size() == 8000u && all_time_limit(ta));
+                const auto tol = (irregular ? (sign > 0 ? 400000. : 800000.) : 10000.) * eps;
+                for (auto j = 0u; j < 4u; ++j) {
+                    CHECK(ta.get_time()[j] == grid[3996u + j]);
+                    for (auto i = 0u; i < 1000u; ++i) {
+                        CHECK(close_to(ret[8u * i + j], (1 + j / 10.) * std::sin(grid[i * 4u + j]), tol));
+                        CHECK(close_to(ret[8u * i + j + 4u], (1 + j / 10.) * std::cos(grid[i * 4u + j]), tol));
+                    }
+                }
+            }
+        }
+        using cb_g = counting_cb<2>;
+        const dvec st2{0., 0.01, 0.02, 0.03, 1., 1.01, 1.02, 1.03};
+        ta = tab{osc, st2, 4};
+        step_callback_batch<double> f_grid(cb_g{});
+        cb_g::n_copies_after = cb_g::n_copies;
+        auto [out_cb, _] = ta.propagate_grid({0., 0., 0., 0., 10., 10., 10., 10., 100., 100., 100., 100.},
+                                             kw::callback = std::move(f_grid));
+        (void)_;
+        out_cb(ta);
+        CHECK(value_isa<cb_g>(out_cb) && cb_g::n_calls > 0u);
+        std::vector<cb_g> cbs(2);
+        cb_g::n_copies_after = cb_g::n_copies;
+        auto r2 = ta.propagate_grid({100., 100., 100., 100., 101., 101., 101., 101., 102., 102., 102., 102.},
+                                    kw::callback = cbs | std::views::transform([](cb_g &c) -> cb_g && { return std::move(c); }));
+        std::get<0>(r2)(ta);
+        CHECK(value_isa<step_callback_batch_set<double>>(std::get<0>(r2)));
+        CHECK(value_isa<cb_g>(value_ref<step_callback_batch_set<double>>(std::get<0>(r2))[0]));
+        const std::string msg = "The invocation of the callback passed to propagate_grid() resulted in the alteration of the "
+                                "time coordinate of the integrator - this is not supported";
+        ta = tab{osc, st2, 4};
+        THROWS_WITH(std::runtime_error,
+                    ta.propagate_grid({0., 0., 0., 0., 10., 10., 10., 10., 100., 100., 100., 100.}, kw::callback = [](auto &t) {
+                        t.set_time(-100.);
+                        return true;
+                    }),
+                    msg);
+        ta = tab{osc, st2, 4};
+        THROWS_WITH(std::runtime_error,
+                    ta.propagate_grid({0., 0., 0., 0., 10., 10., 10., 10., 100., 100., 100., 100.}, kw::callback = [](auto &t) {
+                        t.set_time({t.get_time()[0], -100., t.get_time()[2], t.get_time()[3]});
+                        return true;
+                    }),
+                    msg);
+    }
+
+    // "propagate for_until write_tc" (:733-766): the Taylor coefficients are written only on request.
+    {
+        const auto all_zero = [](tab &t) { return std::ranges::all_of(t.get_tc(), [](double val) { return val == 0.; }); };
+        for (const auto use_for : {false, true}) {
+            auto ta = tab{pend, {0.05, 0.06, 0.025, 0.026}, 2};
+            const auto go = [&](const dvec &ts, bool wtc, bool expect_zero) {
+                const auto cb = [&, expect_zero](tab &t) {
+                    CHECK(all_zero(t) == expect_zero);
+                    return true;
+                };
+                if (use_for) {
+                    ta.propagate_for(ts, kw::write_tc = wtc, kw::callback = cb);
+                } else {
+                    ta.propagate_until(ts, kw::write_tc = wtc, kw::callback = cb);
+                }
+            };
+            go({10., 11.}, false, true);
+            go({20., 21.}, true, false);
+        }
+    }
+
+    // "propagate grid 2" (:802-851) with max_delta_t 100x larger: one callback per iteration, exact grid end points
+    // forwards and backwards, a scalar max_delta_t is the vector with equal entries.
+    {
+        auto ta = tab{pend, {0.05, 0.06, 0.025, 0.026}, 2u};
+        // (:795-800; the check follows the propagation to the first grid point.)
+        const auto lowest = std::numeric_limits<double>::lowest();
+        ta.set_time({0., lowest});
+        THROWS_WITH(std::invalid_argument,
+                    ta.propagate_grid({0., lowest, 1., std::numeric_limits<double>::max()}, kw::max_delta_t = dvec{}),
+                    "The final time passed to the propagate_grid() function of an adaptive Taylor integrator in batch mode "
+                    "results in an overflow condition");
+        ta.set_time({0., 0.});
+        auto counter0 = 0ul, counter1 = 0ul;
+        auto cb = [&](tab &t) {
+            counter0 += t.get_last_h()[0] != 0;
+            counter1 += t.get_last_h()[1] != 0;
+            return true;
+        };
+        auto [cbo, out] = ta.propagate_grid({0., 0., 5., 5.6, 10., 11.}, kw::max_delta_t = dvec{1e-2, 5e-3}, kw::callback = cb);
+        CHECK(static_cast<bool>(cbo) && (ta.get_time() == dvec{10., 11.}) && all_time_limit(ta));
+        CHECK(counter0 == 1000ul && counter1 == 2200ul);
+        std::tie(cbo, out) = ta.propagate_grid({10., 11., 5., 5.6, 1., 1.5}, kw::max_delta_t = dvec{1e-2, 5e-3}, kw::callback = cb);
+        CHECK(static_cast<bool>(cbo) && (ta.get_time() == dvec{1., 1.5}) && all_time_limit(ta));
+        CHECK(counter0 == 1900ul && counter1 == 4100ul);
+        auto ta_copy = ta;
+        ta.set_time(0.);
+        ta_copy.set_time(0.);
+        std::tie(cbo, out) = ta.propagate_grid({0., 0., 5., 5.6, 10., 11.}, kw::max_delta_t = dvec{1e-2, 1e-2});
+        CHECK(!cbo);
+        auto r = ta_copy.propagate_grid({0., 0., 5., 5.6, 10., 11.}, kw::max_delta_t = 1e-2);
+        CHECK(out == std::get<1>(r));
     }
 
     // "cb interrupt" (:853-953).
