@@ -15,6 +15,7 @@
 #include <functional>
 #include <memory>
 #include <optional>
+#include <ostream>
 #include <string>
 #include <utility>
 #include <vector>
@@ -25,6 +26,20 @@ namespace heyoka_amd
 {
 
 enum class event_direction : int { negative = -1, any = 0, positive = 1 };
+
+// (src/nt_event.cpp:42-54.)
+inline std::ostream &operator<<(std::ostream &os, event_direction dir)
+{
+    switch (dir) {
+        case event_direction::any:
+            return os << "event_direction::any";
+        case event_direction::positive:
+            return os << "event_direction::positive";
+        case event_direction::negative:
+            return os << "event_direction::negative";
+    }
+    return os << "event_direction::??";
+}
 
 namespace detail
 {

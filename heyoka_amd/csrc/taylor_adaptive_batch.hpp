@@ -358,6 +358,36 @@ public:
     }
 };
 
+// Summaries of the event objects (src/nt_event.cpp:163-173, src/t_event.cpp:138-152).
+template <typename T>
+inline std::ostream &operator<<(std::ostream &os, const nt_event_batch<T> &e)
+{
+    os << "C++ datatype   : double\n";
+    os << "Event type     : non-terminal\n";
+    os << "Event equation : " << e.get_expression().to_string() << '\n';
+    os << "Event direction: " << e.get_direction() << '\n';
+    return os;
+}
+template <typename T>
+inline std::ostream &operator<<(std::ostream &os, const t_event_batch<T> &e)
+{
+    os << "C++ datatype   : double\n";
+    os << "Event type     : terminal\n";
+    os << "Event equation : " << e.get_expression().to_string() << '\n';
+    os << "Event direction: " << e.get_direction() << '\n';
+    os << "With callback  : " << (e.get_callback() ? "yes" : "no") << '\n';
+    os << "Cooldown       : ";
+    if (e.get_cooldown() < 0) {
+        os << "auto";
+    } else {
+        std::ostringstream oss;
+        oss.precision(17);
+        oss << e.get_cooldown();
+        os << oss.str();
+    }
+    return os << '\n';
+}
+
 template <>
 class taylor_adaptive_batch<double>
 {
@@ -366,7 +396,7 @@ class taylor_adaptive_batch<double>
     std::vector<nt_event_batch<double>> m_nt_events;
 
     template <typename... KwArgs>
-    static detail::tab_core::config make_config(const KwArgs &...kw_args)
+    static detail::tab_core::config make_config(KwArgs &&...kw_args)
     {
         static_assert(kw::all_named_v<KwArgs...>,
                       "Only named arguments (kw::name = value) can follow the batch size in the constructor");
@@ -389,8 +419,15 @@ class taylor_adaptive_batch<double>
         cfg.parallel_mode = static_cast<bool>(kw::get(kw::parallel_mode, false, kw_args...));
         cfg.device = static_cast<int>(kw::get(kw::device, 0, kw_args...));
         if constexpr (kw::has_v<kw::pars_tag, KwArgs...>) {
-            for (const auto &x : kw::get(kw::pars, 0, kw_args...)) {
-                cfg.pars.push_back(static_cast<double>(x));
+            // NOTE: a std::vector<double> handed over as an rvalue is moved all the way into the integrator
+            // (test/taylor_adaptive_batch.cpp:1368-1393).
+            using pars_arg_t = decltype(kw::get(kw::pars, 0, std::forward<KwArgs>(kw_args)...));
+            if constexpr (std::is_same_v<pars_arg_t, std::vector<double> &&>) {
+                cfg.pars = kw::get(kw::pars, 0, std::forward<KwArgs>(kw_args)...);
+            } else {
+                for (const auto &x : kw::get(kw::pars, 0, kw_args...)) {
+                    cfg.pars.push_back(static_cast<double>(x));
+                }
             }
         }
         if constexpr (kw::has_v<kw::time_tag, KwArgs...>) {
@@ -494,8 +531,8 @@ public:
     taylor_adaptive_batch() noexcept = default;
 
     template <typename... KwArgs>
-    taylor_adaptive_batch(sys_t sys, std::vector<double> state, std::uint32_t batch_size, const KwArgs &...kw_args)
-        : m_core(std::move(sys), std::move(state), batch_size, make_config(kw_args...))
+    taylor_adaptive_batch(sys_t sys, std::vector<double> state, std::uint32_t batch_size, KwArgs &&...kw_args)
+        : m_core(std::move(sys), std::move(state), batch_size, make_config(std::forward<KwArgs>(kw_args)...))
     {
         // The user-facing event objects, for get_t_events() / get_nt_events() (include/heyoka/taylor.hpp:1009-1024).
         if constexpr (kw::has_v<kw::t_events_tag, KwArgs...>) {
@@ -511,14 +548,14 @@ public:
     }
     template <typename... KwArgs>
     taylor_adaptive_batch(sys_t sys, std::initializer_list<double> state, std::uint32_t batch_size,
-                          const KwArgs &...kw_args)
-        : taylor_adaptive_batch(std::move(sys), std::vector<double>(state), batch_size, kw_args...)
+                          KwArgs &&...kw_args)
+        : taylor_adaptive_batch(std::move(sys), std::vector<double>(state), batch_size, std::forward<KwArgs>(kw_args)...)
     {
     }
     // Construction without an initial state (zero-initialised, reference: taylor.hpp:917-929).
     template <typename... KwArgs>
-    taylor_adaptive_batch(sys_t sys, std::uint32_t batch_size, const KwArgs &...kw_args)
-        : taylor_adaptive_batch(std::move(sys), std::vector<double>{}, batch_size, kw_args...)
+    taylor_adaptive_batch(sys_t sys, std::uint32_t batch_size, KwArgs &&...kw_args)
+        : taylor_adaptive_batch(std::move(sys), std::vector<double>{}, batch_size, std::forward<KwArgs>(kw_args)...)
     {
     }
 

@@ -9,6 +9,7 @@
 #include <functional>
 #include <limits>
 #include <ranges>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -418,6 +419,41 @@ void host_cases()
             THROWS_WITH(std::invalid_argument, (set_t{cb_t{}, [](const auto &) { return true; }}), empty_msg);
             THROWS_WITH(std::invalid_argument, (set_t{[](const auto &) { return true; }, cb_t{}}), empty_msg);
         }
+    }
+
+    // "taylor move" (:1368-1393): state and parameters handed over as rvalues are not reallocated.
+    {
+        auto init_state = dvec{-1., -1.1, 0., 0.1};
+        auto pars = dvec{9.8, 9.9};
+        const auto *s_data = init_state.data();
+        const auto *p_data = pars.data();
+        auto ta = tab{{prime(x) = v, prime(v) = -par[0] * sin(x)}, std::move(init_state), 2, kw::pars = std::move(pars)};
+        CHECK(s_data == ta.get_state().data());
+        CHECK(p_data == ta.get_pars().data());
+    }
+
+    // "stream output" (:1265-1352): the fields of the summary; the event counts appear only when there are events.
+    {
+        const auto sys = std::vector{prime(x) = v - par[1], prime(v) = -9.8 * sin(x + par[0])};
+        const dvec st{0., 0.01, 0.5, 0.51};
+        const auto text = [](const tab &ta) {
+            std::ostringstream oss;
+            oss << ta;
+            return oss.str();
+        };
+        const auto has = [](const std::string &str, const char *p) { return str.find(p) != std::string::npos; };
+        const auto nt_noop = [](auto &, double, int, std::uint32_t) {};
+        auto str = text(tab{sys, st, 2u, kw::pars = dvec{-1e-4, -1.1e-4, 0, 0}});
+        for (const auto *field : {"Tolerance", "Dimension", "Batch size", "Parameters", "High accuracy", "Compact mode"}) {
+            CHECK(has(str, field));
+        }
+        CHECK(!has(str, "events"));
+        str = text(tab{sys, st, 2u, kw::t_events = {te_t(x)}});
+        CHECK(has(str, "N of terminal events") && has(str, ": 1") && !has(str, "N of non-terminal events"));
+        str = text(tab{sys, st, 2u, kw::nt_events = {nte_t(x, nt_noop)}});
+        CHECK(!has(str, "N of terminal events") && has(str, ": 1") && has(str, "N of non-terminal events"));
+        str = text(tab{sys, st, 2u, kw::t_events = {te_t(x)}, kw::nt_events = {nte_t(x, nt_noop)}});
+        CHECK(has(str, "N of terminal events") && has(str, ": 1") && has(str, "N of non-terminal events"));
     }
 
     // "propagate grid 2" (:768-800), argument checks.

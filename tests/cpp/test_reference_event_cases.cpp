@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <functional>
 #include <limits>
+#include <sstream>
+#include <stdexcept>
 #include <string>
 #include <tuple>
 #include <utility>
@@ -108,6 +110,46 @@ void host_cases()
     ev2 = *&ev2;
     ev2 = ev;
     CHECK(ev2.get_expression() == ex);
+    // test/taylor_nt_event.cpp "taylor nte" (:175-235) and test/taylor_t_event.cpp "taylor te" (:117-226), batch classes:
+    // summaries and constructor checks.
+    {
+        const auto text = [](const auto &e) {
+            std::ostringstream oss;
+            oss << e;
+            return oss.str();
+        };
+        const auto has = [](const std::string &str, const char *p) { return str.find(p) != std::string::npos; };
+        const auto noop = [](auto &, double, int, std::uint32_t) {};
+        const auto eq = v * v - 1e-10;
+        auto str = text(nte_t(eq, noop));
+        CHECK(has(str, "direction::any") && has(str, "non-terminal"));
+        str = text(nte_t(eq, noop, kw::direction = event_direction::positive));
+        CHECK(has(str, "event_direction::positive") && has(str, "non-terminal"));
+        nte_t e0(eq, noop), e1(eq, noop, kw::direction = event_direction::negative);
+        e0 = e1;
+        CHECK(has(text(e0), "event_direction::negative"));
+        const auto throws_with = [](auto &&f, const std::string &msg) {
+            try {
+                f();
+            } catch (const std::invalid_argument &e) {
+                return msg == e.what();
+            }
+            return false;
+        };
+        CHECK(throws_with([&]() { nte_t(eq, nte_t::callback_t{}); },
+                          "Cannot construct a non-terminal event with an empty callback"));
+        CHECK(throws_with([&]() { nte_t(eq, noop, kw::direction = event_direction{50}); },
+                          "Invalid value selected for the direction of a non-terminal event"));
+        str = text(te_t(eq));
+        CHECK(has(str, " event_direction::any") && has(str, " terminal") && has(str, " auto") && has(str, " no"));
+        str = text(te_t(eq, kw::direction = event_direction::negative,
+                        kw::callback = [](auto &, int, std::uint32_t) { return true; }, kw::cooldown = 1));
+        CHECK(has(str, " event_direction::negative") && has(str, " terminal") && has(str, " 1") && has(str, " yes"));
+        CHECK(throws_with([&]() { te_t(eq, kw::cooldown = std::numeric_limits<double>::quiet_NaN()); },
+                          "Cannot set a non-finite cooldown value for a terminal event"));
+        CHECK(throws_with([&]() { te_t(eq, kw::direction = event_direction{50}); },
+                          "Invalid value selected for the direction of a terminal event"));
+    }
     te_t tev(ex);
     auto tev2 = tev;
     tev2 = *&tev2;
@@ -625,6 +667,33 @@ void gpu_cases()
                       })}};
         ta.propagate_until({10., 10., 10., 10.}, kw::max_delta_t = {0.005, 0.005, 0.005, 0.005});
         CHECK(std::ranges::all_of(counter, [](unsigned c) { return c == 1u; }));
+    }
+
+    // test/taylor_t_event.cpp "te open range" (:1142-1181) in batch form: a step covers [0, h): an event exactly at the
+    // end of a limited step belongs to the next step, which then reports it with a step of length zero.
+    {
+        const auto t_ev = 97 / 100000.;
+        const auto t_next = std::nextafter(t_ev, 1.);
+        const dvec st0{-0.25, -0.25, -0.25, -0.25, 0., 0., 0., 0.};
+        auto ta = tab{pend, st0, 4, kw::t_events = {te_t(heyoka::time - t_ev)}};
+        const auto restart_at = [&](double t) {
+            ta.set_time(t);
+            std::copy(st0.begin(), st0.end(), ta.get_state_data());
+            ta.reset_cooldowns();
+        };
+        ta.step(dvec(bs, t_ev));
+        CHECK(all_step_outcomes_are(ta, taylor_outcome::time_limit));
+        restart_at(0.);
+        ta.step(dvec(bs, t_next));
+        CHECK(all_step_outcomes_are(ta, taylor_outcome{-1}));
+        restart_at(t_ev);
+        ta.step();
+        CHECK(all_step_outcomes_are(ta, taylor_outcome{-1}));
+        CHECK(std::ranges::all_of(ta.get_step_res(), [](const auto &r) { return std::get<1>(r) == 0; }));
+        restart_at(t_next);
+        ta.step();
+        CHECK(all_step_outcomes_are(ta, taylor_outcome::success));
+        CHECK(std::ranges::all_of(ta.get_step_res(), [](const auto &r) { return std::get<1>(r) > 0; }));
     }
 
     // "te zero cd mr bug" (:1749-1785): zero cooldown and a callback which stops.
