@@ -118,6 +118,18 @@ def build_ref(m, name):
         return [(x, powf(y, 3.0 / 2.0)), (y, powf(x, -1.0 / 3.0))]
     if name == "prod_vars":
         return [(x, x * y), (y, y * x)]
+    if name == "sincos_vars":
+        return [(x, m.sin(y)), (y, m.cos(x))]
+    if name == "div_vars":
+        return [(x, x / y), (y, y / x)]
+    if name == "sub_vars":
+        return [(x, x - y), (y, y - x)]
+    tm = m.TIME if m is ho else m.time
+    par0 = m.par(0) if m is ho else m.par[0]
+    if name == "time_vars":
+        return [(x, tm + x), (y, x + y)]
+    if name == "sum_vars":
+        return [(x, 2.0 + x + par0 + y), (y, x + y)]
     if name == "sum_sq_vars":
         # (sum_to_sum_sq() builds the sum_sq nodes out of the sums of squares, src/math/sum_sq.cpp.)
         return [(x, y * y + x * x + 1.0), (y, x * x + y * y + 4.0)]
@@ -134,7 +146,12 @@ def check_ref(tc, case, n_ord):
 @pytest.mark.parametrize("case", R["cases"], ids=[c["system"] for c in R["cases"]])
 def test_oracle_reference_literal_node_expectations(case):
     st = np.array(case["state"])
-    ta = ho.OracleIntegrator(build_ref(ho, case["system"]), st, case["batch"], tol=case["tol"])
+    kw = {}
+    if "pars" in case:
+        kw["pars"] = np.array(case["pars"])
+    if "time" in case:
+        kw["time"] = np.array(case["time"])
+    ta = ho.OracleIntegrator(build_ref(ho, case["system"]), st, case["batch"], tol=case["tol"], **kw)
     ta.step(wtc=True)
     check_ref(ta.tc.reshape(2, ta.order + 1, 3), case, len(case["jet"]) // 6)
 
@@ -149,7 +166,13 @@ def test_gpu_reference_literal_node_expectations(mode):
         os.environ["HEYOKA_AMD_EMIT_MODE"] = "table"
     try:
         for case in R["cases"]:
-            ta = hy.taylor_adaptive_batch(build_ref(hy, case["system"]), np.array(case["state"]), case["batch"], tol=case["tol"])
+            kw = {}
+            if "pars" in case:
+                kw["pars"] = np.array(case["pars"])
+            if "time" in case:
+                kw["time"] = np.array(case["time"])
+            ta = hy.taylor_adaptive_batch(build_ref(hy, case["system"]), np.array(case["state"]), case["batch"], tol=case["tol"],
+                                          **kw)
             ta.step(write_tc=True)
             check_ref(np.asarray(ta.tc).reshape(2, ta.order + 1, 3), case, len(case["jet"]) // 6)
     finally:
