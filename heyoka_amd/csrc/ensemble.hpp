@@ -88,7 +88,7 @@ void ensemble_run_per_device(std::size_t n_iter, int n_dev, const F &f)
 
 template <ensemble_tmpl_kind Kind, typename TimeArg, typename Gen, typename... KwArgs>
 auto ensemble_propagate_tmpl(const taylor_adaptive_batch<double> &ta, const TimeArg &t, std::size_t n_iter,
-                             const Gen &gen, const KwArgs &...kw_args)
+                             const Gen &gen, KwArgs &&...kw_args)
 {
     static_assert(kw::all_named_v<KwArgs...>);
     constexpr bool is_grid = (Kind == ensemble_tmpl_kind::grid);
@@ -108,9 +108,11 @@ auto ensemble_propagate_tmpl(const taylor_adaptive_batch<double> &ta, const Time
             }
         }
     }
+    // NOTE: the callback is moved in when it arrives as an rvalue, then copied ONCE per iteration
+    // (test/ensemble_propagate.cpp:380-405).
     step_callback_batch<double> cb;
     if constexpr (kw::has_v<kw::callback_tag, KwArgs...>) {
-        cb = kw::get(kw::callback, 0, kw_args...);
+        cb = step_callback_batch<double>(kw::get(kw::callback, 0, std::forward<KwArgs>(kw_args)...));
     }
     const auto wtc = static_cast<bool>(kw::get(kw::write_tc, false, kw_args...));
     const auto c_out = static_cast<bool>(kw::get(kw::c_output, false, kw_args...));
@@ -200,25 +202,30 @@ auto ensemble_propagate_tmpl(const taylor_adaptive_batch<double> &ta, const Time
 
 } // namespace detail
 
-template <typename Gen, typename... KwArgs>
+// (The reference's call sites name the value type explicitly: ensemble_propagate_until_batch<double>(...),
+// include/heyoka/ensemble_propagate.hpp:222-271.)
+template <typename T = double, typename Gen, typename... KwArgs>
+    requires std::is_same_v<T, double>
 auto ensemble_propagate_until_batch(const taylor_adaptive_batch<double> &ta, double t, std::size_t n_iter,
-                                    const Gen &gen, const KwArgs &...kw_args)
+                                    const Gen &gen, KwArgs &&...kw_args)
 {
-    return detail::ensemble_propagate_tmpl<detail::ensemble_tmpl_kind::until>(ta, t, n_iter, gen, kw_args...);
+    return detail::ensemble_propagate_tmpl<detail::ensemble_tmpl_kind::until>(ta, t, n_iter, gen, std::forward<KwArgs>(kw_args)...);
 }
 
-template <typename Gen, typename... KwArgs>
+template <typename T = double, typename Gen, typename... KwArgs>
+    requires std::is_same_v<T, double>
 auto ensemble_propagate_for_batch(const taylor_adaptive_batch<double> &ta, double delta_t, std::size_t n_iter,
-                                  const Gen &gen, const KwArgs &...kw_args)
+                                  const Gen &gen, KwArgs &&...kw_args)
 {
-    return detail::ensemble_propagate_tmpl<detail::ensemble_tmpl_kind::for_>(ta, delta_t, n_iter, gen, kw_args...);
+    return detail::ensemble_propagate_tmpl<detail::ensemble_tmpl_kind::for_>(ta, delta_t, n_iter, gen, std::forward<KwArgs>(kw_args)...);
 }
 
-template <typename Gen, typename... KwArgs>
+template <typename T = double, typename Gen, typename... KwArgs>
+    requires std::is_same_v<T, double>
 auto ensemble_propagate_grid_batch(const taylor_adaptive_batch<double> &ta, const std::vector<double> &grid,
-                                   std::size_t n_iter, const Gen &gen, const KwArgs &...kw_args)
+                                   std::size_t n_iter, const Gen &gen, KwArgs &&...kw_args)
 {
-    return detail::ensemble_propagate_tmpl<detail::ensemble_tmpl_kind::grid>(ta, grid, n_iter, gen, kw_args...);
+    return detail::ensemble_propagate_tmpl<detail::ensemble_tmpl_kind::grid>(ta, grid, n_iter, gen, std::forward<KwArgs>(kw_args)...);
 }
 
 } // namespace heyoka_amd

@@ -16,6 +16,7 @@
 #include <utility>
 #include <vector>
 
+#include <heyoka/ensemble_propagate.hpp>
 #include <heyoka/heyoka.hpp>
 #include <heyoka/kw.hpp>
 #include <heyoka/model/pendulum.hpp>
@@ -152,6 +153,21 @@ struct moves_time_in_pre_hook {
     {
         ta.set_time({ta.get_time()[0] + 1, ta.get_time()[1] + 1});
     }
+};
+
+// (test/ensemble_propagate.cpp:52-64.)
+struct counting_copies_cb {
+    counting_copies_cb() = default;
+    counting_copies_cb(counting_copies_cb &&) noexcept = default;
+    counting_copies_cb(const counting_copies_cb &)
+    {
+        ++n_copies;
+    }
+    bool operator()(tab &) const
+    {
+        return true;
+    }
+    inline static unsigned long n_copies = 0;
 };
 
 const std::string ev_time_msg = "The invocation of one or more event callbacks resulted in the alteration of the time "
@@ -866,6 +882,82 @@ void gpu_cases()
         CHECK(!cbo);
         auto r = ta_copy.propagate_grid({0., 0., 5., 5.6, 10., 11.}, kw::max_delta_t = 1e-2);
         CHECK(out == std::get<1>(r));
+    }
+
+    // test/ensemble_propagate.cpp "batch propagate until / for / grid" (:355-700): an empty ensemble, one copy of the
+    // callback per iteration, every iteration bitwise equal to the same propagation done serially, continuous output.
+    {
+        using ens_cb = counting_copies_cb;
+        const auto n_iter = 16u;
+        std::vector<dvec> ics(n_iter);
+        std::uint64_t lcg = 99;
+        const auto small = [&lcg]() {
+            lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+            return (static_cast<double>(lcg >> 11) / 9007199254740992. - .5) * 200 * eps;
+        };
+        for (auto &ic : ics) {
+            ic = {small(), small(), 1 + small(), 1 + small()};
+        }
+        const auto gen = [&ics](tab tint, std::size_t i) {
+            std::copy(ics[i].begin(), ics[i].end(), tint.get_state_data());
+            return tint;
+        };
+        auto ta = tab{osc, {0., 0., 1., 1.}, 2u};
+        const auto serial = [&](std::size_t i) {
+            ta.set_time(dvec(2u, 0.));
+            std::copy(ics[i].begin(), ics[i].end(), ta.get_state_data());
+        };
+        auto copies0 = ens_cb::n_copies;
+        CHECK(ensemble_propagate_until_batch<double>(ta, 20, 0, gen, kw::callback = ens_cb{}).empty());
+        CHECK(ensemble_propagate_for_batch<double>(ta, 20, 0, gen, kw::callback = ens_cb{}).empty());
+        CHECK(ens_cb::n_copies == copies0);
+        for (const auto use_for : {false, true}) {
+            // (The template integrator is at t = 0 whenever an ensemble starts from it.)
+            ta = tab{osc, {0., 0., 1., 1.}, 2u};
+            copies0 = ens_cb::n_copies;
+            auto res = use_for ? ensemble_propagate_for_batch<double>(ta, 20, n_iter, gen, kw::callback = ens_cb{})
+                               : ensemble_propagate_until_batch<double>(ta, 20, n_iter, gen, kw::callback = ens_cb{});
+            CHECK(ens_cb::n_copies == copies0 + n_iter);
+            CHECK(res.size() == n_iter);
+            for (auto i = 0u; i < n_iter; ++i) {
+                serial(i);
+                auto [loc_c, loc_cb] = ta.propagate_until(20);
+                CHECK(std::ranges::all_of(std::get<0>(res[i]).get_time(), [](double t) { return close_to(t, 20., 10 * eps); }));
+                CHECK(std::get<0>(res[i]).get_state() == ta.get_state());
+                CHECK(std::get<0>(res[i]).get_propagate_res() == ta.get_propagate_res());
+                CHECK(std::get<1>(res[i]).has_value() == loc_c.has_value());
+                CHECK(static_cast<bool>(std::get<2>(res[i])));
+            }
+            ta = tab{osc, {0., 0., 1., 1.}, 2u};
+            auto res_c = use_for ? ensemble_propagate_for_batch<double>(ta, 20, n_iter, gen, kw::c_output = true)
+                                 : ensemble_propagate_until_batch<double>(ta, 20, n_iter, gen, kw::c_output = true);
+            for (auto i = 0u; i < n_iter; ++i) {
+                serial(i);
+                auto [loc_c, loc_cb] = ta.propagate_until(dvec(2u, 20.), kw::c_output = true);
+                CHECK(std::get<0>(res_c[i]).get_state() == ta.get_state());
+                CHECK((*std::get<1>(res_c[i]))(1.5) == (*loc_c)(1.5));
+                CHECK(!std::get<2>(res_c[i]));
+            }
+        }
+        dvec grid, grid_splat;
+        for (auto i = 0; i <= 20; ++i) {
+            grid.push_back(i);
+            grid_splat.insert(grid_splat.end(), 2u, static_cast<double>(i));
+        }
+        ta = tab{osc, {0., 0., 1., 1.}, 2u};
+        copies0 = ens_cb::n_copies;
+        CHECK(ensemble_propagate_grid_batch<double>(ta, grid, 0, gen, kw::callback = ens_cb{}).empty());
+        CHECK(ens_cb::n_copies == copies0);
+        auto res_g = ensemble_propagate_grid_batch<double>(ta, grid, n_iter, gen, kw::callback = ens_cb{});
+        CHECK(ens_cb::n_copies == copies0 + n_iter && res_g.size() == n_iter);
+        for (auto i = 0u; i < n_iter; ++i) {
+            serial(i);
+            auto [loc_cb, loc_res] = ta.propagate_grid(grid_splat);
+            CHECK(std::get<0>(res_g[i]).get_state() == ta.get_state());
+            CHECK(std::get<0>(res_g[i]).get_propagate_res() == ta.get_propagate_res());
+            CHECK(static_cast<bool>(std::get<1>(res_g[i])));
+            CHECK(std::get<2>(res_g[i]) == loc_res);
+        }
     }
 
     // "cb interrupt" (:853-953).
