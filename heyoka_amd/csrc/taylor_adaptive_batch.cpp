@@ -112,6 +112,11 @@ struct tab_core::impl {
     mutable bool step_res_dev_newer = false;
     mutable bool prop_res_dev_newer = false;
     bool sticky_host_ptr = false; // a mutable host pointer was handed out: sync eagerly.
+    // The C++ interface handed out a reference / pointer to the host mirror of the state or of the times (the
+    // reference's getters return references to members which every step updates in place, and its own benchmark keeps
+    // one across steps: benchmark/outer_ss_long_term_batch.cpp, `const auto &times_v = ta.get_time()`): the mirrors are
+    // refreshed after every kernel from then on.
+    mutable bool sticky_const_refs = false;
     std::uint64_t last_total_steps = 0;
     // Set by the lock-step propagate loop to override the device outcomes.
     mutable std::optional<taylor_outcome> prop_res_override;
@@ -279,7 +284,7 @@ struct tab_core::impl {
             tc_dev_newer = true;
         }
         lasth_dev_newer = true;
-        if (sticky_host_ptr) {
+        if (sticky_host_ptr || sticky_const_refs) {
             to_host();
         }
     }
@@ -857,6 +862,11 @@ void tab_core::set_dtime(double hi, double lo)
 {
     auto &d = *m_impl;
     set_dtime(std::vector<double>(d.N, hi), std::vector<double>(d.N, lo));
+}
+
+void tab_core::hold_host_refs() const
+{
+    m_impl->sticky_const_refs = true;
 }
 
 const std::vector<double> &tab_core::get_state() const

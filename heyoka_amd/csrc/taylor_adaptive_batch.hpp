@@ -166,6 +166,8 @@ public:
     void set_dtime(double, double);
 
     [[nodiscard]] const std::vector<double> &get_state() const;
+    // References to the host mirrors of state / times are being kept by the caller: refresh them after every kernel.
+    void hold_host_refs() const;
     [[nodiscard]] double *get_state_data();
     [[nodiscard]] const std::vector<double> &get_pars() const;
     [[nodiscard]] double *get_pars_data();
@@ -632,12 +634,18 @@ public:
         return false;
     }
 
+    // NOTE: the getters of state and times return references to host mirrors which stay valid AND current across steps,
+    // like the members they stand for in the reference (its benchmark/outer_ss_long_term_batch.cpp keeps
+    // `const auto &times_v = ta.get_time()` across its stepping loop): from the first call on, the mirrors are refreshed
+    // after every kernel. Code which cares about the transfers uses the device views instead.
     [[nodiscard]] const std::vector<double> &get_time() const
     {
+        m_core.hold_host_refs();
         return m_core.get_time();
     }
     [[nodiscard]] const double *get_time_data() const
     {
+        m_core.hold_host_refs();
         return m_core.get_time().data();
     }
     void set_time(const std::vector<double> &t)
@@ -650,6 +658,7 @@ public:
     }
     [[nodiscard]] std::pair<const std::vector<double> &, const std::vector<double> &> get_dtime() const
     {
+        m_core.hold_host_refs();
         return m_core.get_dtime();
     }
     [[nodiscard]] std::pair<const double *, const double *> get_dtime_data() const
@@ -668,10 +677,12 @@ public:
 
     [[nodiscard]] const std::vector<double> &get_state() const
     {
+        m_core.hold_host_refs();
         return m_core.get_state();
     }
     [[nodiscard]] const double *get_state_data() const
     {
+        m_core.hold_host_refs();
         return m_core.get_state().data();
     }
     [[nodiscard]] double *get_state_data()
@@ -810,6 +821,15 @@ public:
         return m_core;
     }
 };
+
+// Class template argument deduction from the type of the initial state (include/heyoka/taylor.hpp:1124-1150,
+// test/taylor_adaptive_batch.cpp:2048-2066): taylor_adaptive_batch({prime(x) = v, ...}, std::vector{0., 1.}, 1u).
+template <typename... KwArgs>
+taylor_adaptive_batch(std::vector<std::pair<expression, expression>>, std::vector<double>, std::uint32_t, KwArgs &&...)
+    -> taylor_adaptive_batch<double>;
+template <typename... KwArgs>
+taylor_adaptive_batch(std::vector<std::pair<expression, expression>>, std::initializer_list<double>, std::uint32_t,
+                      KwArgs &&...) -> taylor_adaptive_batch<double>;
 
 // Human-readable summary (reference: taylor_adaptive_batch_stream_impl(), src/taylor_stream_ops.cpp:110-170): the same
 // fields and labels, plus the code generator that produced the device kernels.

@@ -437,6 +437,19 @@ void host_cases()
         }
     }
 
+    // "ctad" (:2048-2066, :2089-2097): the value type is deduced from the initial state.
+    {
+        auto ta = taylor_adaptive_batch({prime(x) = v, prime(v) = -x}, std::vector{0., 1.}, 1u);
+        static_assert(std::is_same_v<decltype(ta), taylor_adaptive_batch<double>>);
+        CHECK(ta.get_state()[0] == 0 && ta.get_state()[1] == 1);
+        ta = taylor_adaptive_batch({{v, v}, {x, -x}}, std::vector{0., 1.}, 1u);
+        CHECK(ta.get_state()[0] == 0 && ta.get_state()[1] == 1);
+        auto tb = taylor_adaptive_batch({prime(x) = v, prime(v) = -x}, {0., 1.}, 1u);
+        static_assert(std::is_same_v<decltype(tb), taylor_adaptive_batch<double>>);
+        tb = taylor_adaptive_batch({{v, v}, {x, -x}}, {0., 1.}, 1u);
+        CHECK(tb.get_state()[0] == 0 && tb.get_state()[1] == 1);
+    }
+
     // "taylor move" (:1368-1393): state and parameters handed over as rvalues are not reallocated.
     {
         auto init_state = dvec{-1., -1.1, 0., 0.1};
@@ -541,6 +554,25 @@ void gpu_cases()
         return std::ranges::all_of(ta.get_propagate_res(),
                                    [](const auto &t) { return std::get<0>(t) == taylor_outcome::time_limit; });
     };
+
+    // References returned by the getters stay current across steps, like the members they stand for in the reference: its
+    // benchmark/outer_ss_long_term_batch.cpp keeps `const auto &times_v = ta.get_time()` (and an xtensor view over
+    // get_state_data()) across the stepping loop.
+    {
+        auto ta = tab{pend, {0.05, 0.06, 0.025, 0.026}, 2u};
+        const auto &times_v = ta.get_time();
+        const auto &state_v = ta.get_state();
+        const auto *state_p = ta.get_state_data();
+        const auto x0 = state_v[0];
+        auto n = 0;
+        while (std::ranges::any_of(times_v, [](double t) { return t < 1.; })) {
+            ta.step();
+            CHECK(++n < 1000);
+        }
+        CHECK(times_v[0] >= 1. && times_v[1] >= 1. && state_v[0] != x0 && state_p == state_v.data());
+        ta.propagate_until(5.);
+        CHECK(times_v[0] == 5. && times_v[1] == 5.);
+    }
 
     // "propagate trivial" (:446-464).
     {
