@@ -260,7 +260,9 @@ int hy_tab_set_pars(hy_tab, const double *in);             /* writes through get
 int hy_tab_get_dtime(hy_tab, double *hi, double *lo);      /* get_dtime()        batch_size each; lo may be NULL */
 int hy_tab_set_time(hy_tab, const double *t, size_t n);    /* set_time(): n == 1 scalar, else batch_size */
 int hy_tab_set_dtime(hy_tab, const double *hi, const double *lo, size_t n); /* set_dtime() */
-int hy_tab_get_tc(hy_tab, double *out);                    /* get_tc()           n_eq * (order + 1) * batch_size */
+int hy_tab_get_tc(hy_tab, double *out);                    /* get_tc()           n_eq * (order + 1) * batch_size: the
+                                                            * coefficients of the last step taken with write_tc (zeros
+                                                            * before the first one), like the reference's m_tc */
 int hy_tab_get_last_h(hy_tab, double *out);                /* get_last_h() */
 /* update_d_output(t, rel_time) (src/taylor_adaptive_batch.cpp:2251-2327): n == 1 scalar, else batch_size. */
 int hy_tab_update_d_output(hy_tab, const double *t, size_t n, int rel_time, double *out);
