@@ -454,7 +454,12 @@ def main():
         if args.backend == "nccl":
             # Binding the communicator to this rank's device up front: barrier() and the first collective do not have to
             # guess the device (and RCCL initialises eagerly, before the timed region).
-            dist.init_process_group(backend=args.backend, device_id=torch.device("cuda", dev_index))
+            try:
+                dist.init_process_group(backend=args.backend, device_id=torch.device("cuda", dev_index))
+            except Exception:  # (eager initialisation not available / failed: fall back to the lazy one)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                dist.init_process_group(backend=args.backend)
         else:
             dist.init_process_group(backend=args.backend)
     else:
