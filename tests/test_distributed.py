@@ -152,3 +152,37 @@ def test_sharded_ensemble_real_integrators_two_ranks_one_gpu(n_total):
     ref = ref.reshape(36, n_o)
     eps = np.finfo(float).eps
     assert np.max(np.abs(res[0][1][:, :n_o] - ref) / np.maximum(1.0, np.abs(ref))) <= 1e5 * eps
+
+
+@pytest.mark.gpu
+def test_bench_py_two_ranks_on_one_gpu_prints_the_contract_line():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1), with
+    the two ranks sharing GPU 0 and gloo standing in for RCCL: one JSON line from rank 0, whole-job aggregate over both
+    ranks, weak scaling, every rank's systems counted."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    n = 8192
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--systems", str(n), "--single-device", "--backend", "gloo"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"]
+    assert d["unit"] == "system-steps/s" and d["value"] > 0 and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert d["config"]["systems_per_gpu"] == n and "roofline" in d
+    # Both shards did their steps: the whole-job aggregate is twice what rank 0 stepped per launch (the shards differ only
+    # in their seeds), and the untimed gather - when the backend could do it - returned every rank's systems.
+    per_step_total = d["value"] * d["ms_per_step"] * 1e-3
+    assert abs(per_step_total / (2 * d["config"]["system_steps_per_launch"]) - 1) < 0.05
+    if d["config"]["untimed_final_state_all_gather_error"] is None:
+        assert d["config"]["gathered_systems"] == 2 * n
