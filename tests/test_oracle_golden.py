@@ -302,3 +302,51 @@ def test_compiled_jet_hook_is_keyed_on_the_program():
     finally:
         cb.uninstall()
     assert np.array_equal(b.tc, ref.tc) and np.array_equal(b.state, ref.state)
+
+
+def test_bracket_solver_is_algorithm_748_with_the_reference_budget():
+    """oracle/_bracketed_root(): TOMS 748 with Boost's eps_tolerance and 53 evaluations as the reference calls it
+    (src/detail/event_detection.cpp:307-394). Roots of random polynomials with ONE root in [0, 1): agreement with plain
+    bisection to the conditioning of the polynomial, far fewer evaluations, the bracket-midpoint convention, and the two
+    failure flags the caller turns into "event ignored"."""
+    rng = np.random.default_rng(1)
+    evals = []
+    orig = ho._poly_eval
+    try:
+        for _ in range(400):
+            r = rng.uniform(0.01, 0.99)
+            q = np.poly1d([1.0])
+            for _k in range(rng.integers(1, 12)):
+                q = q * np.poly1d([1.0, -rng.uniform(1.2, 5) * rng.choice([-1, 1])])
+            a = [float(c) for c in (np.poly1d([1.0, -r]) * q).coeffs[::-1] * rng.uniform(0.1, 10)]
+            a += [0.0] * (21 - len(a))
+            lb, ub = 0.0, float(np.nextafter(1.0, 0.0))
+            flb = orig(a, lb)
+            for _i in range(200):
+                mid = lb / 2 + ub / 2
+                if mid <= lb or mid >= ub:
+                    break
+                if (orig(a, mid) < 0) == (flb < 0):
+                    lb = mid
+                else:
+                    ub = mid
+            n = [0]
+
+            def counting(aa, x):
+                n[0] += 1
+                return orig(aa, x)
+
+            ho._poly_eval = counting
+            root, flag = ho._bracketed_root(a, 0.0, 1.0)
+            ho._poly_eval = orig
+            evals.append(n[0])
+            assert flag == 0 and n[0] <= 53
+            assert abs(root - (lb / 2 + ub / 2)) <= 1e3 * np.spacing(root)
+            assert abs(root - r) <= 1e-12
+    finally:
+        ho._poly_eval = orig
+    assert np.mean(evals) < 15
+    # No sign change at the ends of the interval: flag 1 (Boost reports a domain error, the event is ignored).
+    assert ho._bracketed_root([1.0, 0.0, 1.0], 0.0, 1.0)[1] == 1
+    # A root exactly at an end is returned as it is.
+    assert ho._bracketed_root([0.0, 1.0], 0.0, 1.0) == (0.0, 0)
