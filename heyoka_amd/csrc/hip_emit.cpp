@@ -876,6 +876,7 @@ emitted_module emit_block(const taylor_program &, const emit_options &, std::str
 bool add_state_aliases(const taylor_program &, taylor_program &);
 bool pad_clusters(const taylor_program &, std::uint32_t, taylor_program &);
 bool insert_unit_scalings(const taylor_program &, taylor_program &);
+bool privatise_cluster_inputs(const taylor_program &, taylor_program &);
 
 std::string program_to_string(const taylor_program &p)
 {
@@ -983,6 +984,59 @@ emitted_module emit_hip_module(const taylor_program &prog, const emit_options &o
                     why += "; with unit scalings: " + why3;
                 }
             }
+            // Clusters which share coordinate differences or have a negation where the others have a difference (fixed
+            // centres / mascons with repeated or zero coordinates): private copies per cluster in the internal program
+            // (see privatise_cluster_inputs()), then - if needed - the unit scalings and the padding on top of it; wave-cluster
+            // kernels, or block mode beyond 64 clusters.
+            const auto try_private_inputs = [&](emitted_module &res) {
+                if (std::getenv("HEYOKA_AMD_NO_PRIVATE_INPUTS") != nullptr) {
+                    return false;
+                }
+                taylor_program priv;
+                if (!privatise_cluster_inputs(prog, priv)) {
+                    return false;
+                }
+                std::vector<taylor_program> variants;
+                variants.push_back(priv);
+                taylor_program tmp;
+                if (insert_unit_scalings(priv, tmp)) {
+                    variants.push_back(tmp);
+                }
+                std::string why_p;
+                for (const auto &v : variants) {
+                    std::string w;
+                    auto mp = emit_cluster_or_empty(v, opts, w);
+                    const taylor_program *base = &v;
+                    taylor_program padded;
+                    if (mp.source.empty() && w.rfind("clusters are not isomorphic", 0) == 0
+                        && pad_clusters(v, opts.order, padded)) {
+                        mp = emit_cluster_or_empty(padded, opts, w);
+                        base = &padded;
+                    }
+                    if (mp.source.empty() && w.rfind("more than 64 clusters", 0) == 0) {
+                        std::string wb;
+                        mp = emit_block(*base, opts, wb);
+                        w += wb.empty() ? "" : ("; block mode: " + wb);
+                    }
+                    if (!mp.source.empty()) {
+                        mp.notes += "; internal program with private coordinate differences per cluster ("
+                                    + std::to_string(static_cast<long long>(base->n_u) - static_cast<long long>(prog.n_u))
+                                    + " members more than the decomposition)";
+                        mp.internal_program = program_to_string(*base);
+                        res = std::move(mp);
+                        return true;
+                    }
+                    why_p = w;
+                }
+                why += "; with private cluster inputs: " + why_p;
+                return false;
+            };
+            if (m.source.empty() && why.find("clusters are not isomorphic") != std::string::npos) {
+                emitted_module mp;
+                if (try_private_inputs(mp)) {
+                    return mp;
+                }
+            }
             if (m.source.empty() && why.rfind("more than 64 clusters", 0) == 0) {
                 // Too many clusters for one wavefront: one system per workgroup.
                 std::string why_b;
@@ -997,6 +1051,12 @@ emitted_module emit_hip_module(const taylor_program &prog, const emit_options &o
                     return b;
                 }
                 why += why_b.empty() ? "; block mode: too few clusters" : ("; block mode: " + why_b);
+                if (why_b.find("clusters are not isomorphic") != std::string::npos) {
+                    emitted_module mp;
+                    if (try_private_inputs(mp)) {
+                        return mp;
+                    }
+                }
             }
             if (m.source.empty()) {
                 // Not applicable to this DAG: fall back to the generic one-system-per-lane code, unrolled

@@ -375,6 +375,210 @@ bool insert_unit_scalings(const taylor_program &p, taylor_program &out)
     return true;
 }
 
+namespace
+{
+
+bool node_of_is_pow(const taylor_program &p, std::uint32_t u)
+{
+    return u >= p.n_eq && p.nodes[u - p.n_eq].kind == func_kind::pow;
+}
+
+} // namespace
+
+// Clusters which SHARE cheap linear members. The sum of squares at the head of a distance cluster reads coordinate
+// differences `c - x` / `x - c` of ONE variable and a number; when several clusters have the same difference (fixed
+// centres / mascons with a repeated coordinate) common-subexpression elimination gives them ONE node, and a coordinate
+// which is zero turns `0 - x` into `-1 * x` (model::fixed_centres with a centre at the origin, a mascon on an axis): the
+// clusters then overlap or differ in the kind of a member, and the cluster planner gives up ("clusters are not
+// isomorphic": table stepper, 100x slower). This pass rewrites the INTERNAL program (the user-visible decomposition is
+// untouched): every sum of squares all of whose arguments are such differences gets PRIVATE copies of them, placed right
+// in front of it in argument order, negations written as `-0.0 - x` (bit for bit the same value as `-1 * x`, signed
+// zeros and NaNs included: -0 - (+0) = -0, -0 - (-0) = +0); the products of the cluster (difference times the -
+// possibly scaled - power of the sum of squares) read the copies; originals which nobody reads any more are dropped.
+// A few redundant subtractions per step buy the cluster kernels. Returns false if nothing of that kind is found.
+bool privatise_cluster_inputs(const taylor_program &p, taylor_program &out)
+{
+    const auto n_eq = p.n_eq;
+    constexpr auto none = std::numeric_limits<std::uint32_t>::max();
+    const auto node_of = [&](std::uint32_t u) -> const dc_node & { return p.nodes[u - n_eq]; };
+    // Cheap linear members: sub(num, var), sub(var, num), prod(-1, var) over a STATE variable or u variable.
+    const auto is_neg = [](const dc_node &n) {
+        return n.kind == func_kind::prod && n.args.size() == 2u && n.args[0].type == operand::kind::num
+               && n.args[0].value == -1. && is_var(n.args[1]);
+    };
+    const auto is_diff = [](const dc_node &n) {
+        return n.kind == func_kind::sub && n.args.size() == 2u
+               && ((n.args[0].type == operand::kind::num && is_var(n.args[1]))
+                   || (is_var(n.args[0]) && n.args[1].type == operand::kind::num));
+    };
+    const auto cheap = [&](std::uint32_t u) { return u >= n_eq && (is_neg(node_of(u)) || is_diff(node_of(u))); };
+
+    // The heads: sums of squares over cheap members only.
+    std::vector<std::uint32_t> heads;
+    std::vector<std::uint32_t> n_head_readers(p.n_u, 0u);
+    for (std::uint32_t u = n_eq; u < p.n_u; ++u) {
+        const auto &n = node_of(u);
+        if (n.kind != func_kind::sum_sq || n.args.empty()) {
+            continue;
+        }
+        bool ok = true;
+        for (const auto &o : n.args) {
+            ok = ok && is_var(o) && cheap(o.idx);
+        }
+        if (ok) {
+            heads.push_back(u);
+            for (const auto &o : n.args) {
+                ++n_head_readers[o.idx];
+            }
+        }
+    }
+    if (heads.size() < 2u) {
+        return false;
+    }
+    bool needed = false;
+    bool any_diff = false;
+    for (const auto h : heads) {
+        for (const auto &o : node_of(h).args) {
+            needed = needed || n_head_readers[o.idx] > 1u || is_neg(node_of(o.idx));
+            any_diff = any_diff || is_diff(node_of(o.idx));
+        }
+    }
+    if (!needed || !any_diff) {
+        return false;
+    }
+    // Which head does a u variable hang off? pow(head, c) and the scalings num * pow / par * pow of it.
+    std::vector<std::uint32_t> head_of(p.n_u, none);
+    for (const auto h : heads) {
+        head_of[h] = h;
+    }
+    for (std::uint32_t u = n_eq; u < p.n_u; ++u) {
+        const auto &n = node_of(u);
+        if (n.kind == func_kind::pow && n.args.size() == 2u && is_var(n.args[0]) && head_of[n.args[0].idx] != none) {
+            head_of[u] = head_of[n.args[0].idx];
+        } else if (n.kind == func_kind::prod && n.args.size() == 2u && !is_var(n.args[0]) && is_var(n.args[1])
+                   && node_of_is_pow(p, n.args[1].idx) && head_of[n.args[1].idx] != none) {
+            head_of[u] = head_of[n.args[1].idx];
+        }
+    }
+    // Private copies: copy_idx[(head, position)] in the new numbering; readers: the head itself and the products
+    // cheap * (pow chain of the head).
+    struct rewire {
+        std::uint32_t node, arg, head, pos;
+    };
+    std::vector<rewire> rw;
+    std::vector<std::uint32_t> other_readers(p.n_u, 0u);
+    for (std::uint32_t u = n_eq; u < p.n_u; ++u) {
+        const auto &n = node_of(u);
+        if (head_of[u] == u) {
+            continue; // (a head: handled below)
+        }
+        for (std::size_t a = 0; a < n.args.size(); ++a) {
+            const auto &o = n.args[a];
+            if (!is_var(o) || !cheap(o.idx) || n_head_readers[o.idx] == 0u) {
+                continue;
+            }
+            bool done = false;
+            if (n.kind == func_kind::prod && n.args.size() == 2u && is_var(n.args[1u - a])) {
+                const auto h = head_of[n.args[1u - a].idx];
+                if (h != none) {
+                    const auto &ha = node_of(h).args;
+                    for (std::uint32_t q = 0; q < ha.size(); ++q) {
+                        if (ha[q].idx == o.idx) {
+                            rw.push_back({u, static_cast<std::uint32_t>(a), h, q});
+                            done = true;
+                            break;
+                        }
+                    }
+                }
+            }
+            if (!done) {
+                ++other_readers[o.idx];
+            }
+        }
+    }
+    for (const auto &d : p.sv_defs) {
+        if (d.type == operand::kind::uvar && d.idx < p.n_u) {
+            ++other_readers[d.idx];
+        }
+    }
+    for (const auto e : p.ev_u) {
+        ++other_readers[e];
+    }
+    // New numbering: the originals which keep a reader stay where they are, the copies of a head go right in front of it.
+    std::vector<std::uint32_t> new_idx(p.n_u, none);
+    std::map<std::pair<std::uint32_t, std::uint32_t>, std::uint32_t> copy_idx;
+    std::uint32_t next = n_eq;
+    for (std::uint32_t i = 0; i < n_eq; ++i) {
+        new_idx[i] = i;
+    }
+    for (std::uint32_t u = n_eq; u < p.n_u; ++u) {
+        if (cheap(u) && n_head_readers[u] != 0u && other_readers[u] == 0u) {
+            continue; // dropped
+        }
+        if (head_of[u] == u) {
+            for (std::uint32_t q = 0; q < node_of(u).args.size(); ++q) {
+                copy_idx[{u, q}] = next++;
+            }
+        }
+        new_idx[u] = next++;
+    }
+    out = p;
+    out.nodes.clear();
+    std::map<std::pair<std::uint32_t, std::uint32_t>, std::pair<std::uint32_t, std::uint32_t>> rw_of;
+    for (const auto &r : rw) {
+        rw_of[{r.node, r.arg}] = {r.head, r.pos};
+    }
+    for (std::uint32_t u = n_eq; u < p.n_u; ++u) {
+        if (new_idx[u] == none) {
+            continue;
+        }
+        auto nn = node_of(u);
+        if (head_of[u] == u) {
+            for (std::uint32_t q = 0; q < nn.args.size(); ++q) {
+                auto c = node_of(nn.args[q].idx);
+                if (is_neg(c)) {
+                    // -1 * x -> -0.0 - x.
+                    const auto var = c.args[1];
+                    c.kind = func_kind::sub;
+                    c.args[0].type = operand::kind::num;
+                    c.args[0].value = -0.;
+                    c.args[1] = var;
+                }
+                for (auto &o : c.args) {
+                    if (o.type == operand::kind::uvar) {
+                        o.idx = new_idx[o.idx];
+                    }
+                }
+                out.nodes.push_back(std::move(c));
+                nn.args[q].idx = copy_idx[{u, q}];
+            }
+        } else {
+            for (std::size_t a = 0; a < nn.args.size(); ++a) {
+                auto &o = nn.args[a];
+                if (o.type != operand::kind::uvar) {
+                    continue;
+                }
+                const auto it = rw_of.find({u, static_cast<std::uint32_t>(a)});
+                o.idx = (it != rw_of.end()) ? copy_idx[it->second] : new_idx[o.idx];
+            }
+        }
+        for (auto &d : nn.deps) {
+            d = new_idx[d];
+        }
+        out.nodes.push_back(std::move(nn));
+    }
+    for (auto &d : out.sv_defs) {
+        if (d.type == operand::kind::uvar) {
+            d.idx = new_idx[d.idx];
+        }
+    }
+    for (auto &e : out.ev_u) {
+        e = new_idx[e];
+    }
+    out.n_u = next;
+    return true;
+}
+
 // Clusters of different shapes. When every cluster is a *sub-shape* of the largest one (model::nbody with massless
 // bodies: the pairs with a test particle lack the three reaction products of the massive-massive pairs), the smaller
 // clusters are padded in the INTERNAL program (the user-visible decomposition is untouched, like add_state_aliases())

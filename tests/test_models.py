@@ -229,13 +229,27 @@ def _gpu_cases(pins):
         "rotating": (*cases["rotating"], rot_st, None, 5.0),
         "rotating_par": (*cases["rotating_par"], rot_st, npar([0.1, 0.2, 0.3]), 5.0),
         "mascon7": (*cases["mascon7"], fc_st, None, 5.0),
+        # Centres at the origin / with repeated and zero coordinates / with G m = 1: shared and negated coordinate
+        # differences, which the planner makes private per cluster (privatise_cluster_inputs()): wave-cluster kernel
+        # (12 centres) and block mode (70 centres) instead of the table stepper. A particle well outside the centres.
+        "fixed_centres12_special": (lambda: hy.model.fixed_centres(Gconst=1.0, masses=_fixed_centres_special(12)[0],
+                                                                   positions=_fixed_centres_special(12)[1]),
+                                    lambda: ho.fixed_centres(Gconst=1.0, masses=_fixed_centres_special(12)[0],
+                                                             positions=_fixed_centres_special(12)[1]),
+                                    _lanes([5.0, 0.3, -0.2, 0.0, 1.0, 0.1], n, 1e-2, 6), None, 30.0),
+        "fixed_centres70_special": (lambda: hy.model.fixed_centres(Gconst=1.0, masses=_fixed_centres_special(70)[0],
+                                                                   positions=_fixed_centres_special(70)[1]),
+                                    lambda: ho.fixed_centres(Gconst=1.0, masses=_fixed_centres_special(70)[0],
+                                                             positions=_fixed_centres_special(70)[1]),
+                                    _lanes([6.0, 0.3, -0.2, 0.0, 2.4, 0.1], n, 1e-2, 7), None, 10.0),
     }
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["cr3bp", "cr3bp_par", "np1body6", "np1body4_par", "np1body8_default", "np1body13_default",
                                   "np1body8_masses", "np1body5_massless", "fixed_centres7",
-                                  "rotating", "rotating_par", "mascon7"])
+                                  "rotating", "rotating_par", "mascon7", "fixed_centres12_special",
+                                  "fixed_centres70_special"])
 @pytest.mark.parametrize("contract", [True, False])
 def test_models_step_and_propagate_vs_oracle(name, pins, contract, monkeypatch):
     """One full-order step (h, Taylor coefficients, state) and a propagation of every model against the oracle.
@@ -257,6 +271,9 @@ def test_models_step_and_propagate_vs_oracle(name, pins, contract, monkeypatch):
         assert m_.startswith("cluster") and "v2" not in m_.split(";")[0] and "aliased" in m_
     if name == "np1body13_default":
         assert ta.hip_source_mode.startswith("block") and "aliased" in ta.hip_source_mode
+    if name.endswith("_special"):
+        assert ta.hip_source_mode.startswith("cluster" if name == "fixed_centres12_special" else "block")
+        assert "private coordinate differences" in ta.hip_source_mode
     if name == "np1body4_par":
         # Runtime masses: constant u variables (m_0 + m_i, -m_i ...) are recognised, products with them are linear, and
         # the system leaves the 21 000-statement unrolled kernel for the wave-cluster stepper.
@@ -540,7 +557,22 @@ def _oracle_on_program(monkeypatch, lines, n_eq, st, n, **kw):
         monkeypatch.undo()
 
 
-@pytest.mark.parametrize("case", ["unit_scalings", "unit_scalings_padded", "padded_par_masses", "state_aliases"])
+def _fixed_centres_special(nc):
+    """Fixed centres with one centre at the origin (0 - x becomes -1 * x), repeated coordinates (shared differences), a
+    zero coordinate elsewhere and one product G m = 1 (elided scaling)."""
+    rng = np.random.default_rng(5)
+    pos = rng.uniform(-2.0, 2.0, (nc, 3))
+    pos[0] = 0.0
+    pos[3, 0] = pos[2, 0]
+    pos[5, 1] = 0.0
+    pos[6, 2] = pos[1, 2]
+    m = rng.uniform(0.1, 1.0, nc)
+    m[0] = 1.0
+    return [float(v) for v in m], [float(v) for v in pos.reshape(-1)]
+
+
+@pytest.mark.parametrize("case", ["unit_scalings", "unit_scalings_padded", "padded_par_masses", "state_aliases",
+                                  "private_inputs_cluster", "private_inputs_block"])
 def test_planner_rewrites_of_the_internal_program_do_not_change_the_jets(case, monkeypatch):
     """The planner of the wave-cluster kernels may rewrite the INTERNAL program (never the decomposition the user sees):
     alias u variables for state variables in history-operand position (add_state_aliases()), padding of clusters which
@@ -561,6 +593,12 @@ def test_planner_rewrites_of_the_internal_program_do_not_change_the_jets(case, m
         sys_g = hy.model.nbody(6, masses=[hy.par[i] for i in range(4)], Gconst=G)
         sys_o = ho.nbody(6, masses=[ho.par(i) for i in range(4)], Gconst=G)
         pars = np.repeat(np.asarray(M[:4], dtype=np.float64)[:, None], n, axis=1)
+    elif case.startswith("private_inputs"):
+        # privatise_cluster_inputs(): private copies of the coordinate differences per distance cluster, -1 * x as
+        # -0.0 - x (+ unit scalings on top): 12 centres -> wave-cluster kernel, 70 -> block mode.
+        mm, pp = _fixed_centres_special(12 if case.endswith("cluster") else 70)
+        sys_g = hy.model.fixed_centres(Gconst=1.0, masses=mm, positions=pp)
+        sys_o = ho.fixed_centres(Gconst=1.0, masses=mm, positions=pp)
     else:
         sys_g, sys_o = hy.model.np1body(6, masses=M, Gconst=G), ho.np1body(6, masses=M, Gconst=G)
     n_eq = len(sys_o)
@@ -571,7 +609,11 @@ def test_planner_rewrites_of_the_internal_program_do_not_change_the_jets(case, m
         kw["pars"] = pars
     ta = hy.taylor_adaptive_batch(sys_g, st, n, **kw)
     prog = ta.internal_program
-    assert ta.hip_source_mode.startswith("cluster") and len(prog) > len(ta.decomposition) - n_eq, ta.hip_source_mode
+    mode = ta.hip_source_mode
+    assert mode.startswith("block" if case == "private_inputs_block" else "cluster"), mode
+    assert len(prog) > len(ta.decomposition) - n_eq, mode
+    if case.startswith("private_inputs"):
+        assert "private coordinate differences" in mode and any(ln.startswith("sub(-0, u_") for ln in prog)
     plain = ho.OracleIntegrator(sys_o, st, n, **kw)
     rewritten = _oracle_on_program(monkeypatch, prog, n_eq, st, n, **kw)
     assert rewritten.n_u > plain.n_u
