@@ -799,10 +799,73 @@ emitted_module emit_event_jets(const taylor_program &p, const emit_options &opts
         return ret;
     }
 
+    // Compact Taylor coefficients (emit_options::compact_tc): the stepper wrote only the order-0 row of the state
+    // variables defined by another state variable; their higher orders are parent^[k-1] / k - a multiplication by
+    // RN(1 / k) like the state recursion of the pair kernels, the correctly rounded quotient under kw::exact_division.
+    const auto derived = [&](std::uint32_t i) {
+        return opts.compact_tc && p.sv_defs[i].type == operand::kind::uvar && p.sv_defs[i].idx < n_eq;
+    };
+    // NOTE: through hy_mul_nc() - a product which is never contracted into an FMA with its consumer: the value must be
+    // the ROUNDED product the stepper would have stored, whatever comes next (x_1 - x_2, the Horner step).
+    const auto derived_coeff = [&](const std::string &parent, std::uint32_t k) {
+        return opts.exact_division ? ("(" + parent + " / " + fp_literal(static_cast<double>(k)) + ")")
+                                   : ("hy_mul_nc(" + parent + ", " + fp_literal(1. / static_cast<double>(k)) + ")");
+    };
+
     ssa_emitter e(p, order);
     auto &os = e.os;
     // (The same node rules and addition order as the one-system-per-lane stepper with events.)
     e.running_sums = opts.sum_order != 1;
+    if (opts.compact_tc) {
+        // (An empty asm statement on the product: with -ffp-contract=fast the backend fuses whatever it can reach, pragmas
+        // or not; a value which went through an asm operand is opaque to it.)
+        os << "__device__ __forceinline__ double hy_mul_nc(double x, double y)\n{\n    double t = x * y;\n"
+              "    asm volatile(\"\" : \"+v\"(t));\n    return t;\n}\n";
+        // hy_dout_c: dense output (state update of a step with events) from the compact coefficients; hy_tc_expand: fills
+        // in the rows the stepper left out, for whoever reads the full array afterwards (get_tc(), update_d_output(),
+        // continuous output, propagate_grid()).
+        os << "__constant__ double hy_rk_c[" << (order + 1u) << "] = {0.0";
+        for (std::uint32_t k = 1; k <= order; ++k) {
+            os << "," << fp_literal(opts.exact_division ? static_cast<double>(k) : 1. / static_cast<double>(k));
+        }
+        os << "};\n__constant__ int hy_tc_parent[" << n_eq << "] = {";
+        for (std::uint32_t i = 0; i < n_eq; ++i) {
+            os << (derived(i) ? static_cast<long long>(p.sv_defs[i].idx) : -1ll) << ",";
+        }
+        os << "};\n";
+        const std::string coeff
+            = opts.exact_division ? "(cp[(u64)(k - 1u) * N] / hy_rk_c[k])" : "hy_mul_nc(cp[(u64)(k - 1u) * N], hy_rk_c[k])";
+        os << "struct hy_doutc_args { double *out; const double *tc; const double *hs; u64 N; };\n";
+        os << "extern \"C\" __global__ void __launch_bounds__(256) hy_dout_c(const hy_doutc_args a)\n{\n";
+        os << "const u64 N = a.N;\nconst u64 s = (u64)blockIdx.x * 256u + threadIdx.x;\nif (s >= N) return;\n";
+        os << "const double h = a.hs[s];\n";
+        os << "for (unsigned i = 0; i < " << n_eq << "u; ++i) {\n";
+        os << "const int par = hy_tc_parent[i];\n";
+        os << "const double *c = a.tc + ((u64)i * " << (order + 1u) << "u) * N + s;\n";
+        os << "const double *cp = a.tc + ((u64)(par < 0 ? i : (unsigned)par) * " << (order + 1u) << "u) * N + s;\n";
+        os << "#define HY_COEFF(k) ((par < 0) ? c[(u64)(k) * N] : " << coeff << ")\n";
+        if (opts.high_accuracy) {
+            os << "double res = c[0], comp = 0.0, cur_h = h;\n";
+            os << "for (unsigned k = 1; k <= " << order << "u; ++k) {\n";
+            os << "const double tmp = HY_COEFF(k) * cur_h;\nconst double y = tmp - comp;\nconst double t = res + y;\n";
+            os << "comp = (t - res) - y;\nres = t;\ncur_h = cur_h * h;\n}\n";
+        } else {
+            os << "double res;\n{\nconst unsigned k = " << order << "u;\nres = HY_COEFF(k);\n}\n";
+            os << "for (unsigned k = " << order - 1u << "u; k >= 1u; --k) {\n";
+            os << "res = HY_COEFF(k) + res * h;\n}\n";
+            os << "res = c[0] + res * h;\n";
+        }
+        os << "#undef HY_COEFF\n";
+        os << "a.out[(u64)i * N + s] = res;\n}\n}\n";
+        os << "extern \"C\" __global__ void __launch_bounds__(256) hy_tc_expand(const hy_doutc_args a)\n{\n";
+        os << "const u64 N = a.N;\nconst u64 s = (u64)blockIdx.x * 256u + threadIdx.x;\nif (s >= N) return;\n";
+        os << "double *tc = a.out;\n";
+        os << "for (unsigned i = 0; i < " << n_eq << "u; ++i) {\n";
+        os << "const int par = hy_tc_parent[i];\nif (par < 0) continue;\n";
+        os << "double *c = tc + ((u64)i * " << (order + 1u) << "u) * N + s;\n";
+        os << "const double *cp = tc + ((u64)(unsigned)par * " << (order + 1u) << "u) * N + s;\n";
+        os << "for (unsigned k = 1; k <= " << order << "u; ++k) c[(u64)k * N] = " << coeff << ";\n}\n}\n";
+    }
     os << "extern \"C\" __global__ void __launch_bounds__(256) hy_ev_jets(const hy_kargs a)\n{\n";
     os << "const u64 N = a.N;\nconst u64 s = (u64)blockIdx.x * 256u + threadIdx.x;\nif (s >= N) return;\n";
     std::vector<char> par_used(p.n_par, 0);
@@ -826,7 +889,17 @@ emitted_module emit_event_jets(const taylor_program &p, const emit_options &opts
     for (std::uint32_t k = 0; k <= order; ++k) {
         for (std::uint32_t i = 0; i < n_eq; ++i) {
             if (need[i] != 0) {
-                e.val(i, k) = e.def("jet[(u64)" + std::to_string(static_cast<std::uint64_t>(i) * (order + 1u) + k) + "u * N]");
+                if (derived(i) && k > 0u) {
+                    // (Compact Taylor coefficients: x^[k] = v^[k-1] / k with the arithmetic of the stepper.)
+                    e.val(i, k) = e.def(derived_coeff("jet[(u64)"
+                                                          + std::to_string(static_cast<std::uint64_t>(p.sv_defs[i].idx) * (order + 1u)
+                                                                           + (k - 1u))
+                                                          + "u * N]",
+                                                      k));
+                } else {
+                    e.val(i, k)
+                        = e.def("jet[(u64)" + std::to_string(static_cast<std::uint64_t>(i) * (order + 1u) + k) + "u * N]");
+                }
             }
         }
         for (std::uint32_t u = n_eq; u < p.n_u; ++u) {

@@ -72,6 +72,9 @@ struct emit_options {
     // (running sum from 0: src/math/prod.cpp:686-698; one FMA per term). kw::sum_order. The table stepper always uses the
     // running sums, the cluster kernels their own FMA chains.
     int sum_order = 0;
+    // emit_event_jets(): the stepper it accompanies leaves out the Taylor coefficients of order >= 1 of the state variables
+    // defined by another state variable (emitted_module::compact_tc): read them as parent^[k-1] / k.
+    bool compact_tc = false;
 };
 
 struct emitted_module {
@@ -95,6 +98,10 @@ struct emitted_module {
     std::string compile_flags;
     // The stepper implements mode 4 in its cluster form (see hy_kargs::sel_norms).
     bool cluster_mode4 = false;
+    // Mode 4 writes a COMPACT set of Taylor coefficients: for a state variable x defined by another state variable
+    // (x' = v) only the order-0 row; x^[k] = v^[k-1] / k is left to the consumers (hy_ev_jets, hy_dout_c, hy_tc_expand in
+    // the module of emit_event_jets()): half of the 6 KB per system of an N-body ensemble never travel.
+    bool compact_tc = false;
     // When the code was generated from a rewritten INTERNAL program (state-variable aliases, padded clusters, restored unit
     // scalings - the user-visible decomposition is never touched): its text, one node per line in the format of the
     // decomposition strings, then the definitions of the state derivatives. Lets the tests run the oracle's interpreter

@@ -873,6 +873,32 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     const auto lds_doubles_slab = static_cast<std::uint64_t>(wpb) * spw * slab_stride;
     const bool jet_lds = (lds_doubles_slab + wpb * jet_doubles_per_wave) * 8u <= 160u * 1024u
                          && std::getenv("HEYOKA_AMD_JET_GLOBAL") == nullptr;
+    // Stepper with events: compact set of Taylor coefficients (see emitted_module::compact_tc) through the cooperative
+    // store of the LDS-resident jets. HEYOKA_AMD_COMPACT_TC=0 switches it off (A/B measurements).
+    const bool compact_tc = [&]() {
+        if (!m4 || !jet_lds || one_lane) {
+            return false;
+        }
+        if (const char *ev = std::getenv("HEYOKA_AMD_COMPACT_TC")) {
+            if (std::atoi(ev) == 0) {
+                return false;
+            }
+        }
+        // (Chains x' = v, v' = a only: the parent of a derived variable is not derived itself.)
+        const auto derived = [&](std::uint32_t var) {
+            return p.sv_defs[var].type == operand::kind::uvar && p.sv_defs[var].idx < n_eq;
+        };
+        bool any = false;
+        for (std::uint32_t var = 0; var < n_eq; ++var) {
+            if (derived(var)) {
+                if (derived(p.sv_defs[var].idx)) {
+                    return false;
+                }
+                any = true;
+            }
+        }
+        return any;
+    }();
 
     // Merged schedule (lane-pair variant, one glue level after the clusters): round k = cluster(k) + glue(k-1),
     // one LDS synchronisation per order instead of two.
@@ -1659,6 +1685,17 @@ __device__ __forceinline__ double hy_swap1(double x)
                 }
             }
         }
+        if (m4) {
+            src << "__constant__ unsigned short hy_tc_rows[" << n_eq * (order + 1u) << "] = {";
+            for (std::uint32_t var = 0; var < n_eq; ++var) {
+                const auto &sd = p.sv_defs[var];
+                const bool derived = compact_tc && sd.type == operand::kind::uvar && sd.idx < n_eq;
+                for (std::uint32_t k = 0; k <= (derived ? 0u : order); ++k) {
+                    src << var * (order + 1u) + k << ",";
+                }
+            }
+            src << "};\n";
+        }
         src << "__constant__ unsigned short hy_col_of_var[" << n_eq << "] = {";
         for (const auto c : col_of) {
             src << c << ",";
@@ -2164,10 +2201,20 @@ if (nf_seen != 0 && l == 0u && live) atomicAdd(a.counters, 1u);
         // 16 systems of the lane-pair kernel - instead of 16-byte pieces per wavefront (the per-wavefront stores make
         // the 1 048 576-system stepper with events transaction bound: 8 ms instead of 3).
         const auto spb = wpb * spw;
+        // Compact set of rows: a state variable defined by another state variable (x' = v) leaves with its order-0 row
+        // only, x^[k] = v^[k-1] / k is derived by the consumers (emitted_module::compact_tc).
+        std::vector<std::uint32_t> tc_rows;
+        for (std::uint32_t var = 0; var < n_eq; ++var) {
+            const auto &sd = p.sv_defs[var];
+            const bool derived = compact_tc && sd.type == operand::kind::uvar && sd.idx < n_eq;
+            for (std::uint32_t k = 0; k <= (derived ? 0u : order); ++k) {
+                tc_rows.push_back(var * (order + 1u) + k);
+            }
+        }
         src << "{\n__syncthreads();\n";
         src << "const u64 bs0 = base - (u64)wib * SPW;\n";
-        src << "for (unsigned idx = threadIdx.x; idx < " << n_eq * (order + 1u) * spb << "u; idx += " << bs << "u) {\n";
-        src << "const unsigned sy = idx % " << spb << "u, row = idx / " << spb << "u;\n";
+        src << "for (unsigned idx = threadIdx.x; idx < " << tc_rows.size() * spb << "u; idx += " << bs << "u) {\n";
+        src << "const unsigned sy = idx % " << spb << "u, row = hy_tc_rows[idx / " << spb << "u];\n";
         src << "const unsigned var = row / " << (order + 1u) << "u, k = row % " << (order + 1u) << "u;\n";
         src << "const u64 sg = bs0 + sy;\n";
         src << "const double val = lds_jet[(sy / SPW) * " << jet_doubles_per_wave << "u + k * " << spw * n_colp
@@ -2228,6 +2275,7 @@ if (l == 0u && live) {
     }
     ret.tc_optional = true;
     ret.cluster_mode4 = m4;
+    ret.compact_tc = compact_tc;
     one_lane_jets_in_lds = one_lane && jet_lds;
     ret.notes = std::string(one_lane ? "cluster mode v5 (one lane per pair, 2 wavefronts per SIMD): "
                                      : (pair_split ? "cluster mode v3 (lane pairs, 2 wavefronts per SIMD): " : "cluster mode v2 (pipelined): "))

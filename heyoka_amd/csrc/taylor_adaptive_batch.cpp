@@ -117,6 +117,11 @@ struct tab_core::impl {
     // one across steps: benchmark/outer_ss_long_term_batch.cpp, `const auto &times_v = ta.get_time()`): the mirrors are
     // refreshed after every kernel from then on.
     mutable bool sticky_const_refs = false;
+    // Stepper with events on the wave-cluster kernels: the Taylor coefficients of order >= 1 of the state variables defined
+    // by another state variable are not written by the stepper (emitted_module::compact_tc); hy_tc_expand fills them in
+    // before anybody reads the full array.
+    mutable bool tc_expand_pending = false;
+    void ensure_tc_expanded() const;
     std::uint64_t last_total_steps = 0;
     // Set by the lock-step propagate loop to override the device outcomes.
     mutable std::optional<taylor_outcome> prop_res_override;
@@ -603,7 +608,9 @@ tab_core::tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_siz
             auto m = emit_hip_module(prog0, eo2);
             std::string why;
             if (m.cluster_mode4) {
-                auto evm = emit_event_jets(d.prog, eo, why);
+                auto eo_ev = eo;
+                eo_ev.compact_tc = m.compact_tc;
+                auto evm = emit_event_jets(d.prog, eo_ev, why);
                 if (!evm.source.empty()) {
                     d.cluster_events = true;
                     d.emitted = std::move(m);
@@ -654,6 +661,7 @@ tab_core::tab_core(const tab_core &o) : m_impl(o.m_impl ? std::make_unique<impl>
         s.lasth_dev_newer = false;
     }
     if (s.tc_dev_newer && s.dmod && s.d_tc.bytes() != 0u) {
+        s.ensure_tc_expanded();
         s.tc.resize(static_cast<std::size_t>(s.dim) * (s.order + 1u) * s.N);
         s.d_tc.download(s.tc.data(), s.tc.size() * sizeof(double), s.stream);
         s.tc_dev_newer = false;
@@ -898,9 +906,25 @@ double *tab_core::get_pars_data()
     return d.pars.data();
 }
 
+void tab_core::impl::ensure_tc_expanded() const
+{
+    if (!tc_expand_pending || !evj_mod) {
+        return;
+    }
+    const struct {
+        double *out;
+        const double *tc;
+        const double *hs;
+        unsigned long long N;
+    } ea{d_tc.as<double>(), d_tc.as<double>(), nullptr, N};
+    evj_mod->launch("hy_tc_expand", N, 256, &ea, sizeof(ea), stream);
+    tc_expand_pending = false;
+}
+
 const std::vector<double> &tab_core::get_tc() const
 {
     auto &d = *m_impl;
+    d.ensure_tc_expanded();
     const auto sz = static_cast<std::size_t>(d.dim) * (d.order + 1u) * d.N;
     if (d.tc.size() != sz) {
         d.tc.assign(sz, 0.);
@@ -956,6 +980,7 @@ const std::vector<double> &tab_core::update_d_output(const std::vector<double> &
         d.d_douth = device_buffer(static_cast<std::size_t>(d.N) * sizeof(double), d.device);
     }
     d.d_douth.upload(hs.data(), hs.size() * sizeof(double), d.stream);
+    d.ensure_tc_expanded();
     d.dmod->launch_dout(d.d_dout.as<double>(), d.d_tc.as<double>(), d.d_douth.as<double>(), d.N);
     d.d_dout.download(d.d_out.data(), d.d_out.size() * sizeof(double), d.stream);
     return d.d_out;
@@ -1165,6 +1190,7 @@ void tab_core::impl::launch_event_stepper(const std::vector<double> *lims)
         a.sel_norms = d_selnorms.as<double>();
     }
     dmod->launch_taylor(a);
+    tc_expand_pending = cluster_events && emitted.compact_tc;
     if (cluster_events) {
         // Jets of the event equations, extended norms and final step sizes from the jets of the state variables.
         evj_mod->launch("hy_ev_jets", N, 256, &a, sizeof(a), stream);
@@ -1303,7 +1329,18 @@ void tab_core::impl::step_with_events_device(const std::vector<double> *lims)
 
     // State update via dense output at the final step sizes (:781), then times / non-finite check / cooldowns /
     // outcomes / records.
-    dmod->launch_dout(d_state.as<double>(), d_tc.as<double>(), d_douth.as<double>(), N);
+    if (tc_expand_pending) {
+        // (Compact Taylor coefficients: the dense output derives the rows the stepper left out.)
+        const struct {
+            double *out;
+            const double *tc;
+            const double *hs;
+            unsigned long long N;
+        } da{d_state.as<double>(), d_tc.as<double>(), d_douth.as<double>(), N};
+        evj_mod->launch("hy_dout_c", N, 256, &da, sizeof(da), stream);
+    } else {
+        dmod->launch_dout(d_state.as<double>(), d_tc.as<double>(), d_douth.as<double>(), N);
+    }
     ed_mod->launch("hy_ev_post", N, 256, &pa, sizeof(pa), stream);
     std::vector<double> rec;
     if (cur[0] != 0u) {
@@ -1806,6 +1843,7 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
             }
             if (cob) {
                 d.times_to_host();
+                d.ensure_tc_expanded();
                 cob->append(d.d_tc.as<double>(), d.time_hi, d.time_lo);
             }
             ++iter_counter;
@@ -2065,6 +2103,7 @@ void tab_core::propagate_grid_device_loop(const std::vector<double> &grid, std::
             d.run_step_impl(nullptr, true);
         }
         any_step = true;
+        d.ensure_tc_expanded();
         b_cnt.zero(d.stream);
         const grid_kargs a{b_grid.as<double>(),    out_ptr,     d.d_tc.as<double>(),   d.d_thi.as<double>(),
                            d.d_tlo.as<double>(),   d.d_lasth.as<double>(), d.d_outcome.as<long long>(),
@@ -2288,6 +2327,7 @@ double *tab_core::device_tc()
 {
     m_impl->ensure_device();
     m_impl->ensure_tc();
+    m_impl->ensure_tc_expanded();
     return m_impl->d_tc.as<double>();
 }
 
@@ -2357,6 +2397,7 @@ void tab_core::set_device(int device)
     d.ed_mod.reset();
     d.grid_mod.reset();
     d.evj_mod.reset();
+    d.tc_expand_pending = false;
     d.d_selnorms = {};
     d.d_ev_cursor = {};
     d.d_ev_rec = {};

@@ -1677,6 +1677,63 @@ def test_time_dependent_events_on_the_cluster_stepper_vs_oracle():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("high_accuracy", [True, False])
+def test_compact_taylor_coefficients_of_the_stepper_with_events_change_nothing(high_accuracy, monkeypatch):
+    """The wave-cluster stepper with events writes a compact set of Taylor coefficients (only the order-0 row of the
+    positions: x^[k] = v^[k-1] / k is derived by hy_ev_jets, by the dense output of the state update and - on demand - by
+    hy_tc_expand). Against the same integrator built with HEYOKA_AMD_COMPACT_TC=0: states, times, step sizes, event
+    records, get_tc(), update_d_output() and propagate_grid() are IDENTICAL bit for bit; get_tc() also against the oracle."""
+    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    n = 37
+    st = configs.outer_ss_state(n, perturb=1e-3, seed=12)
+
+    def build(log, te):
+        nt, tev = _outer_ss_event_setup(hy, log, te)
+        return hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=high_accuracy,
+                                        nt_events=nt, t_events=tev)
+
+    log_c, te_c, log_f, te_f, log_o, te_o = [], [], [], [], [], []
+    tc_ = build(log_c, te_c)
+    monkeypatch.setenv("HEYOKA_AMD_COMPACT_TC", "0")
+    tf = build(log_f, te_f)
+    monkeypatch.delenv("HEYOKA_AMD_COMPACT_TC")
+    assert tc_.hip_source_mode.startswith("cluster") and "hy_tc_rows" in tc_.hip_source
+    # (The full build lists every row in its table, the compact one 18 x 21 + 18 of the 36 x 21.)
+    count = lambda src: len(src.split("hy_tc_rows[")[1].split("{")[1].split("}")[0].strip(",").split(","))
+    assert count(tf.hip_source) == 36 * 21 and count(tc_.hip_source) == 18 * 21 + 18
+    nt_o, te_ev_o = _outer_ss_event_setup(ho, log_o, te_o)
+    ora = ho.OracleEventIntegrator(ho.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=high_accuracy, nt_events=nt_o,
+                                   t_events=te_ev_o)
+    for it in range(30):
+        tc_.step()
+        tf.step()
+        ora.step()
+        assert tc_.step_res == tf.step_res
+        assert np.array_equal(tc_.state, tf.state) and np.array_equal(tc_.time, tf.time)
+        if it % 7 == 0:
+            a, b = np.asarray(tc_.tc), np.asarray(tf.tc)
+            assert np.array_equal(a, b)
+            tco = ora.tc.reshape(36, ora.order + 1, n)
+            scale = np.max(np.abs(tco), axis=2, keepdims=True) + 1e-300
+            assert np.max(np.abs(a.reshape(36, ora.order + 1, n) - tco) / scale) <= 1e6 * EPS
+        if it % 5 == 0:
+            tq = np.asarray(tc_.time) - 0.3 * np.array([h for _, h in tc_.step_res])
+            assert np.array_equal(np.asarray(tc_.update_d_output(tq)), np.asarray(tf.update_d_output(tq)))
+    assert log_c == log_f and te_c == te_f and len(log_c) > 0
+    t0 = float(np.max(tc_.time)) + 5.0
+    tc_.propagate_until(t0)
+    tf.propagate_until(t0)
+    assert np.array_equal(tc_.state, tf.state)
+    grid = np.repeat(t0 + np.array([0.0, 1.5, 3.0, 7.0])[:, None], n, axis=1)
+    _, out_c = tc_.propagate_grid(grid)
+    _, out_f = tf.propagate_grid(grid)
+    assert np.array_equal(np.asarray(out_c), np.asarray(out_f))
+    c_c, _ = tc_.propagate_until(t0 + 12.0, c_output=True)
+    c_f, _ = tf.propagate_until(t0 + 12.0, c_output=True)
+    assert np.array_equal(np.asarray(c_c(t0 + 9.1)), np.asarray(c_f(t0 + 9.1)))
+    assert log_c == log_f and te_c == te_f
+
+
 def test_events_on_the_cluster_stepper_vs_oracle(monkeypatch):
     """Integrators with events whose system runs on a wave-cluster stepper: the stepper computes the jets of the state
     variables only (mode 4, no update), hy_ev_jets derives the jets of the event equations and the final step size from
