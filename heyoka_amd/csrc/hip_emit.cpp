@@ -820,7 +820,7 @@ emitted_module emit_event_jets(const taylor_program &p, const emit_options &opts
         // (An empty asm statement on the product: with -ffp-contract=fast the backend fuses whatever it can reach, pragmas
         // or not; a value which went through an asm operand is opaque to it.)
         os << "__device__ __forceinline__ double hy_mul_nc(double x, double y)\n{\n    double t = x * y;\n"
-              "    asm volatile(\"\" : \"+v\"(t));\n    return t;\n}\n";
+              "    asm(\"\" : \"+v\"(t));\n    return t;\n}\n";
         // hy_dout_c: dense output (state update of a step with events) from the compact coefficients; hy_tc_expand: fills
         // in the rows the stepper left out, for whoever reads the full array afterwards (get_tc(), update_d_output(),
         // continuous output, propagate_grid()).
@@ -836,27 +836,51 @@ emitted_module emit_event_jets(const taylor_program &p, const emit_options &opts
         const std::string coeff
             = opts.exact_division ? "(cp[(u64)(k - 1u) * N] / hy_rk_c[k])" : "hy_mul_nc(cp[(u64)(k - 1u) * N], hy_rk_c[k])";
         os << "struct hy_doutc_args { double *out; const double *tc; const double *hs; u64 N; };\n";
+        // hy_dout_c: ONE pass over the coefficients of every stored variable v updates its own sum and the sum of the
+        // variable x it defines (x' = v: x^[k] = v^[k-1] / k) - the rows of v are read once, with the operations and the
+        // operation order of hy_dout on the full set.
+        os << "__constant__ int hy_tc_child[" << n_eq << "] = {";
+        for (std::uint32_t j = 0; j < n_eq; ++j) {
+            long long child = -1;
+            for (std::uint32_t i = 0; i < n_eq; ++i) {
+                if (derived(i) && p.sv_defs[i].idx == j) {
+                    child = static_cast<long long>(i);
+                }
+            }
+            os << child << ",";
+        }
+        os << "};\n";
+        const std::string xk = opts.exact_division ? "(ck / hy_rk_c[k + 1u])" : "hy_mul_nc(ck, hy_rk_c[k + 1u])";
         os << "extern \"C\" __global__ void __launch_bounds__(256) hy_dout_c(const hy_doutc_args a)\n{\n";
         os << "const u64 N = a.N;\nconst u64 s = (u64)blockIdx.x * 256u + threadIdx.x;\nif (s >= N) return;\n";
         os << "const double h = a.hs[s];\n";
-        os << "for (unsigned i = 0; i < " << n_eq << "u; ++i) {\n";
-        os << "const int par = hy_tc_parent[i];\n";
-        os << "const double *c = a.tc + ((u64)i * " << (order + 1u) << "u) * N + s;\n";
-        os << "const double *cp = a.tc + ((u64)(par < 0 ? i : (unsigned)par) * " << (order + 1u) << "u) * N + s;\n";
-        os << "#define HY_COEFF(k) ((par < 0) ? c[(u64)(k) * N] : " << coeff << ")\n";
+        os << "for (unsigned j = 0; j < " << n_eq << "u; ++j) {\n";
+        os << "if (hy_tc_parent[j] >= 0) continue;\n";
+        os << "const int ch = hy_tc_child[j];\n";
+        os << "const double *c = a.tc + ((u64)j * " << (order + 1u) << "u) * N + s;\n";
+        os << "const double x0 = (ch >= 0) ? a.tc[((u64)(unsigned)(ch < 0 ? 0 : ch) * " << (order + 1u) << "u) * N + s] : 0.0;\n";
         if (opts.high_accuracy) {
-            os << "double res = c[0], comp = 0.0, cur_h = h;\n";
-            os << "for (unsigned k = 1; k <= " << order << "u; ++k) {\n";
-            os << "const double tmp = HY_COEFF(k) * cur_h;\nconst double y = tmp - comp;\nconst double t = res + y;\n";
-            os << "comp = (t - res) - y;\nres = t;\ncur_h = cur_h * h;\n}\n";
+            // (Ascending orders: res = c[0]; res += c[k] * h^k with the compensation of hy_dout.)
+            os << "double ck = c[0];\n";
+            os << "double rv = ck, cv = 0.0, rx = x0, cx = 0.0, cur_h = h;\n";
+            os << "for (unsigned k = 0; k < " << order << "u; ++k) {\n";
+            os << "{\nconst double tmp = " << xk << " * cur_h;\nconst double y = tmp - cx;\nconst double t = rx + y;\n";
+            os << "cx = (t - rx) - y;\nrx = t;\n}\n";
+            os << "ck = c[(u64)(k + 1u) * N];\n";
+            os << "{\nconst double tmp = ck * cur_h;\nconst double y = tmp - cv;\nconst double t = rv + y;\n";
+            os << "cv = (t - rv) - y;\nrv = t;\n}\n";
+            os << "cur_h = cur_h * h;\n}\n";
         } else {
-            os << "double res;\n{\nconst unsigned k = " << order << "u;\nres = HY_COEFF(k);\n}\n";
-            os << "for (unsigned k = " << order - 1u << "u; k >= 1u; --k) {\n";
-            os << "res = HY_COEFF(k) + res * h;\n}\n";
-            os << "res = c[0] + res * h;\n";
+            // (Descending orders: res = c[p]; res = c[k] + res * h.)
+            os << "double ck = c[(u64)" << order << "u * N];\ndouble rv = ck, rx = 0.0;\n";
+            os << "for (unsigned k = " << order - 1u << "u;; --k) {\n";
+            os << "ck = c[(u64)k * N];\nrv = ck + rv * h;\n";
+            os << "rx = (k == " << order - 1u << "u) ? " << xk << " : (" << xk << " + rx * h);\n";
+            os << "if (k == 0u) break;\n}\n";
+            os << "rx = x0 + rx * h;\n";
         }
-        os << "#undef HY_COEFF\n";
-        os << "a.out[(u64)i * N + s] = res;\n}\n}\n";
+        os << "a.out[(u64)j * N + s] = rv;\n";
+        os << "if (ch >= 0) a.out[(u64)(unsigned)ch * N + s] = rx;\n}\n}\n";
         os << "extern \"C\" __global__ void __launch_bounds__(256) hy_tc_expand(const hy_doutc_args a)\n{\n";
         os << "const u64 N = a.N;\nconst u64 s = (u64)blockIdx.x * 256u + threadIdx.x;\nif (s >= N) return;\n";
         os << "double *tc = a.out;\n";
