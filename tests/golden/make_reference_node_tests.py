@@ -13,6 +13,8 @@ jet layout of the reference's tc_to_jet(): jet[(k * n_eq + var) * batch + lane].
   sub_vars      test/taylor_sub.cpp:859-893       x' = x - y, y' = y - x, batch 3, tol .1
   time_vars     test/taylor_time.cpp:196-230      x' = t + x, y' = x + y, batch 3, tol .1, times (-5, 6, -1)
   sum_vars      test/taylor_sum.cpp:154-189       x' = sum(2, x, par[0], y), y' = x + y, batch 3, tol .1, pars (2, -1, 3)
+  no_decomp     test/taylor_no_decomp_sys.cpp:149-184  x' = y, y' = x (no u variables), batch 3, tol .1
+  const_pars    test/taylor_const_sys.cpp:285-318   x' = par[0], y' = par[1], z' = par[2] (n_eq = 3), batch 3, tol .1
 """
 import json
 import os
@@ -127,8 +129,29 @@ def sum_vars():
             "jet": j}
 
 
+def no_decomp():
+    j = [2., 1., 0., -3., 5., 4.] + [0.] * 18
+    for l in range(3):
+        j[6 + l] = j[3 + l]
+        j[9 + l] = j[l]
+        j[12 + l] = j[9 + l] / 2
+        j[15 + l] = j[6 + l] / 2
+        j[18 + l] = 1. / 6 * j[15 + l] * 2
+        j[21 + l] = 1. / 6 * j[12 + l] * 2
+    return {"source": "test/taylor_no_decomp_sys.cpp:149-184", "system": "no_decomp", "state": j[:6], "batch": 3, "tol": .1,
+            "jet": j}
+
+
+def const_pars():
+    st = [2., -2., 0., 3., -3., 0., 4., -4., 0.]
+    pars = [1., 1., 1., -2., -2., -2., 0., 0., 0.]
+    j = st + pars + [0.] * 18
+    return {"source": "test/taylor_const_sys.cpp:285-318", "system": "const_pars", "state": st, "batch": 3, "tol": .1,
+            "pars": pars, "n_eq": 3, "jet": j}
+
+
 if __name__ == "__main__":
-    out = {"note": __doc__, "cases": [pow_frac(), sum_sq_vars(), prod_vars(), sincos_vars(), div_vars(), sub_vars(), time_vars(), sum_vars()],
+    out = {"note": __doc__, "cases": [pow_frac(), sum_sq_vars(), prod_vars(), sincos_vars(), div_vars(), sub_vars(), time_vars(), sum_vars(), no_decomp(), const_pars()],
            "tolerance": "the reference's approximately(): 100 eps relative"}
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_node_tests.json"), "w") as f:
         json.dump(out, f, indent=1)

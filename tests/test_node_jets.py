@@ -130,6 +130,12 @@ def build_ref(m, name):
         return [(x, tm + x), (y, x + y)]
     if name == "sum_vars":
         return [(x, 2.0 + x + par0 + y), (y, x + y)]
+    if name == "no_decomp":
+        return [(x, y), (y, x)]
+    if name == "const_pars":
+        z = m.var("z") if m is ho else m.make_vars("z")[0]
+        pr = (lambda i: m.par(i)) if m is ho else (lambda i: m.par[i])
+        return [(x, pr(0)), (y, pr(1)), (z, pr(2))]
     if name == "sum_sq_vars":
         # (sum_to_sum_sq() builds the sum_sq nodes out of the sums of squares, src/math/sum_sq.cpp.)
         return [(x, y * y + x * x + 1.0), (y, x * x + y * y + 4.0)]
@@ -137,8 +143,8 @@ def build_ref(m, name):
 
 
 def check_ref(tc, case, n_ord):
-    # tc[var][order][lane] vs jet[(k * 2 + var) * 3 + lane]
-    exp = np.array(case["jet"]).reshape(n_ord, 2, 3).transpose(1, 0, 2)
+    # tc[var][order][lane] vs jet[(k * n_eq + var) * 3 + lane]
+    exp = np.array(case["jet"]).reshape(n_ord, case.get("n_eq", 2), 3).transpose(1, 0, 2)
     err = np.abs(tc[:, :n_ord, :] - exp) / np.maximum(np.abs(exp), 1e-300)
     assert np.max(err) <= 100 * EPS, (case["system"], float(np.max(err)))
 
@@ -153,7 +159,8 @@ def test_oracle_reference_literal_node_expectations(case):
         kw["time"] = np.array(case["time"])
     ta = ho.OracleIntegrator(build_ref(ho, case["system"]), st, case["batch"], tol=case["tol"], **kw)
     ta.step(wtc=True)
-    check_ref(ta.tc.reshape(2, ta.order + 1, 3), case, len(case["jet"]) // 6)
+    ne = case.get("n_eq", 2)
+    check_ref(ta.tc.reshape(ne, ta.order + 1, 3), case, len(case["jet"]) // (3 * ne))
 
 
 @pytest.mark.gpu
@@ -174,7 +181,8 @@ def test_gpu_reference_literal_node_expectations(mode):
             ta = hy.taylor_adaptive_batch(build_ref(hy, case["system"]), np.array(case["state"]), case["batch"], tol=case["tol"],
                                           **kw)
             ta.step(write_tc=True)
-            check_ref(np.asarray(ta.tc).reshape(2, ta.order + 1, 3), case, len(case["jet"]) // 6)
+            ne = case.get("n_eq", 2)
+            check_ref(np.asarray(ta.tc).reshape(ne, ta.order + 1, 3), case, len(case["jet"]) // (3 * ne))
     finally:
         if mode == "table":
             if old is None:
