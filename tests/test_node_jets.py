@@ -133,7 +133,8 @@ def build_ref(m, name):
     if name == "no_decomp":
         return [(x, y), (y, x)]
     if name == "const_pars":
-        z = m.var("z") if m is ho else m.make_vars("z")[0]
+        z = m.var("z") if m is ho else m.make_vars("z")
+        z = z[0] if isinstance(z, (list, tuple)) else z
         pr = (lambda i: m.par(i)) if m is ho else (lambda i: m.par[i])
         return [(x, pr(0)), (y, pr(1)), (z, pr(2))]
     if name == "sum_sq_vars":
