@@ -871,7 +871,9 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     const auto jet_rows_doubles = static_cast<std::uint64_t>(order + 1u) * spw * n_colp;
     const auto jet_doubles_per_wave = jet_rows_doubles + (one_lane ? static_cast<std::uint64_t>(spw) * n_dcolp : 0u);
     const auto lds_doubles_slab = static_cast<std::uint64_t>(wpb) * spw * slab_stride;
-    const bool jet_lds = (lds_doubles_slab + wpb * jet_doubles_per_wave) * 8u <= 160u * 1024u
+    // (Mode 4: plus the source table of the cooperative store of the Taylor coefficients, 4 bytes per row.)
+    const auto lds_tc_table_bytes = m4 ? static_cast<std::uint64_t>(n_eq) * (order + 1u) * 4u : 0u;
+    const bool jet_lds = (lds_doubles_slab + wpb * jet_doubles_per_wave) * 8u + lds_tc_table_bytes <= 160u * 1024u
                          && std::getenv("HEYOKA_AMD_JET_GLOBAL") == nullptr;
     // Stepper with events: compact set of Taylor coefficients (see emitted_module::compact_tc) through the cooperative
     // store of the LDS-resident jets. HEYOKA_AMD_COMPACT_TC=0 switches it off (A/B measurements).
@@ -1731,6 +1733,14 @@ __device__ __forceinline__ double hy_swap1(double x)
     if (jet_lds) {
         src << "__shared__ double lds_jet[" << wpb * jet_doubles_per_wave << "];\n";
         src << "double *const jetw = lds_jet + wib * " << jet_doubles_per_wave << "u;\n";
+        if (m4) {
+            // Source table of the cooperative store of the Taylor coefficients: row | jet column << 16.
+            const auto n_rows_max = n_eq * (order + 1u);
+            src << "__shared__ unsigned lds_tcsrc[" << n_rows_max << "];\n";
+            src << "for (unsigned i = threadIdx.x; i < " << n_rows_max << "u; i += " << bs << "u) {\n"
+                << "const unsigned row = hy_tc_rows[i];\nlds_tcsrc[i] = row | ((unsigned)hy_col_of_var[row / "
+                << (order + 1u) << "u] << 16);\n}\n__syncthreads();\n";
+        }
     } else {
         src << "double *const jetw = a.scratch + gwave * " << jet_doubles_per_wave << "ull;\n";
     }
@@ -2211,14 +2221,19 @@ if (nf_seen != 0 && l == 0u && live) atomicAdd(a.counters, 1u);
                 tc_rows.push_back(var * (order + 1u) + k);
             }
         }
+        // NOTE: the (row, jet column) of every stored row comes from a table in LDS (lds_tcsrc, filled once per
+        // workgroup): with the tables in global / constant memory every iteration of this loop issues vector loads BEHIND
+        // the stores of the previous one, and gfx9 counts loads and stores in one in-order counter (vmcnt) - each
+        // iteration then waits for a store acknowledgement (12 iterations: 6 us per group of systems, 1.5 ms of a 4.2 ms
+        // launch on 1 048 576 systems).
         src << "{\n__syncthreads();\n";
         src << "const u64 bs0 = base - (u64)wib * SPW;\n";
         src << "for (unsigned idx = threadIdx.x; idx < " << tc_rows.size() * spb << "u; idx += " << bs << "u) {\n";
-        src << "const unsigned sy = idx % " << spb << "u, row = hy_tc_rows[idx / " << spb << "u];\n";
-        src << "const unsigned var = row / " << (order + 1u) << "u, k = row % " << (order + 1u) << "u;\n";
+        src << "const unsigned sy = idx % " << spb << "u, te = lds_tcsrc[idx / " << spb << "u];\n";
+        src << "const unsigned row = te & 0xffffu, col = te >> 16, k = row % " << (order + 1u) << "u;\n";
         src << "const u64 sg = bs0 + sy;\n";
         src << "const double val = lds_jet[(sy / SPW) * " << jet_doubles_per_wave << "u + k * " << spw * n_colp
-            << "u + (sy % SPW) * " << n_colp << "u + hy_col_of_var[var]];\n";
+            << "u + (sy % SPW) * " << n_colp << "u + col];\n";
         src << "if (sg < N) a.tc[(u64)row * N + sg] = val;\n}\n__syncthreads();\n}\n";
     }
     src << R"HIP(
