@@ -6,10 +6,19 @@
 #include <utility>
 #include <vector>
 
+#include <heyoka/callable.hpp>
+#include <heyoka/exceptions.hpp>
+#include <heyoka/func.hpp>
 #include <heyoka/heyoka.hpp>
 #include <heyoka/kw.hpp>
 #include <heyoka/model/nbody.hpp>
+#include <heyoka/math.hpp>
+#include <heyoka/models.hpp>
+#include <heyoka/number.hpp>
+#include <heyoka/param.hpp>
+#include <heyoka/step_callback.hpp>
 #include <heyoka/taylor.hpp>
+#include <heyoka/variable.hpp>
 
 using namespace heyoka;
 namespace hy = heyoka;
