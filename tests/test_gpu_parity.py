@@ -1740,6 +1740,44 @@ def test_compact_taylor_coefficients_of_the_stepper_with_events_change_nothing(h
     assert log_c == log_f and te_c == te_f
 
 
+def test_events_on_the_pipelined_cluster_stepper_vs_oracle():
+    """Events on a system which runs on the pipelined (v2) wave-cluster stepper - model::np1body(6), heliocentric
+    coordinates: mode 4 with the compact Taylor coefficients and the cooperative store, hy_ev_jets, detection - step by step
+    against the oracle's stepper with events; get_tc() (expanded on demand) against the oracle's coefficients."""
+    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    n = 9
+    st = configs.outer_ss_state(n, perturb=1e-3, seed=21, com_shift=False)
+    st = st[6:] - np.tile(st[:6], (5, 1))
+    log_p, log_o = [], []
+
+    def evs(m, log, var):
+        x1, y1, x2, y2, z1, z2 = [var(s) for s in ("x_1", "y_1", "x_2", "y_2", "z_1", "z_2")]
+        d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2) - 81.0
+        return [m.nt_event(y1, lambda ta, t, d, i: log.append((i, 0, t, d))),
+                m.nt_event(d2, lambda ta, t, d, i: log.append((i, 1, t, d)))]
+
+    pv = lambda s_: (lambda v: v[0] if isinstance(v, (list, tuple)) else v)(hy.make_vars(s_))
+    ta = hy.taylor_adaptive_batch(hy.model.np1body(6, masses=M, Gconst=G), st, n, high_accuracy=True,
+                                  nt_events=evs(hy, log_p, pv))
+    assert ta.hip_source_mode.startswith("cluster") and "events:" in ta.hip_source_mode and "lds_tcsrc" in ta.hip_source
+    ora = ho.OracleEventIntegrator(ho.np1body(6, masses=M, Gconst=G), st, n, high_accuracy=True,
+                                   nt_events=evs(ho, log_o, ho.var))
+    for it in range(40):
+        ta.step()
+        ora.step()
+        assert [int(oc) for oc, _ in ta.step_res] == [oc for oc, _ in ora.step_res]
+        h_p = np.array([h for _, h in ta.step_res])
+        h_o = np.array([h for _, h in ora.step_res])
+        assert np.max(np.abs(h_p - h_o) / np.abs(h_o)) <= 1e6 * EPS
+        assert rel_err(ta.state, ora.state.reshape(30, n)) <= 1e6 * EPS
+        if it % 13 == 0:
+            tco = ora.tc.reshape(30, ora.order + 1, n)
+            scale = np.max(np.abs(tco), axis=2, keepdims=True) + 1e-300
+            assert np.max(np.abs(np.asarray(ta.tc).reshape(30, ora.order + 1, n) - tco) / scale) <= 1e6 * EPS
+    assert len(log_p) > n and [(a[0], a[1], a[3]) for a in log_p] == [(a[0], a[1], a[3]) for a in log_o]
+    assert np.max(np.abs(np.array([a[2] for a in log_p]) - np.array([a[2] for a in log_o]))) <= 1e-10
+
+
 def test_events_on_the_cluster_stepper_vs_oracle(monkeypatch):
     """Integrators with events whose system runs on a wave-cluster stepper: the stepper computes the jets of the state
     variables only (mode 4, no update), hy_ev_jets derives the jets of the event equations and the final step size from
