@@ -1683,8 +1683,8 @@ def test_time_dependent_events_on_the_cluster_stepper_vs_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("high_accuracy", [True, False])
-def test_compact_taylor_coefficients_of_the_stepper_with_events_change_nothing(high_accuracy, monkeypatch):
+@pytest.mark.parametrize("high_accuracy,exact_division", [(True, False), (False, False), (True, True)])
+def test_compact_taylor_coefficients_of_the_stepper_with_events_change_nothing(high_accuracy, exact_division, monkeypatch):
     """The wave-cluster stepper with events writes a compact set of Taylor coefficients (only the order-0 row of the
     positions: x^[k] = v^[k-1] / k is derived by hy_ev_jets, by the dense output of the state update and - on demand - by
     hy_tc_expand). Against the same integrator built with HEYOKA_AMD_COMPACT_TC=0: states, times, step sizes, event
@@ -1696,7 +1696,7 @@ def test_compact_taylor_coefficients_of_the_stepper_with_events_change_nothing(h
     def build(log, te):
         nt, tev = _outer_ss_event_setup(hy, log, te)
         return hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=high_accuracy,
-                                        nt_events=nt, t_events=tev)
+                                        nt_events=nt, t_events=tev, exact_division=exact_division)
 
     log_c, te_c, log_f, te_f, log_o, te_o = [], [], [], [], [], []
     tc_ = build(log_c, te_c)
