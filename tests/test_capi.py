@@ -189,3 +189,28 @@ def test_time_dependent_event_on_the_cluster_event_stepper_builds():
         ta = hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), None, 8, high_accuracy=True,
                                       nt_events=[hy.nt_event(ev, lambda *a: None)])
         assert ta.hip_source_mode.startswith("cluster") and "events:" in ta.hip_source_mode, ta.hip_source_mode
+
+
+def test_time_setters_follow_the_reference_checks_without_a_gpu():
+    """set_dtime() through the C ABI: normalisation of (hi, lo), the reference's argument checks with their messages
+    (include/heyoka/detail/taylor_common.hpp:232-249, test/taylor_adaptive_batch.cpp:1864-1942), nothing modified when a
+    check fails; get_tc() reads zeros before any write_tc step."""
+    import heyoka_amd as hy
+
+    x, v = hy.make_vars("x", "v")
+    ta = hy.taylor_adaptive_batch([(x, v), (v, -9.8 * hy.sin(x))], [[0.0, 0.01], [0.1, 0.11]], 2)
+    eps = np.finfo(float).eps
+    ta.set_dtime([3.0, -7.0], [2.0, 5.0])
+    hi, lo = ta.dtime
+    assert list(hi) == [5.0, -2.0] and list(lo) == [0.0, 0.0]
+    ta.set_dtime([3.0, -3.0], [eps, eps])
+    hi, lo = ta.dtime
+    assert list(hi) == [3.0, -3.0] and list(lo) == [eps, eps]
+    ta.set_dtime([3.0, 4.0], [1.0, 2.0])
+    with pytest.raises(ValueError, match="must both be finite, but they are inf and 1 instead"):
+        ta.set_dtime([np.inf, 1.0], [1.0, 1.0])
+    with pytest.raises(ValueError, match=r"coordinate \(3\) must not be smaller in magnitude than the second component \(4\)"):
+        ta.set_dtime([3.0, 3.0], [4.0, 4.0])
+    hi, lo = ta.dtime
+    assert list(hi) == [4.0, 6.0] and list(lo) == [0.0, 0.0]
+    assert not np.any(ta.tc)
