@@ -574,6 +574,25 @@ void gpu_cases()
         CHECK(times_v[0] == 5. && times_v[1] == 5.);
     }
 
+    // "batch consistency" (:105-160): the forced damped pendulum with per-lane parameters and per-lane initial times,
+    // propagated to per-lane final times; the reference compares with four scalar integrators, here: with four batches
+    // of one (1000 eps).
+    {
+        const dvec st{0.01, 0.02, 0.03, 0.04, 1.85, 1.86, 1.87, 1.88}, pv{0.10, 0.11, 0.12, 0.13};
+        const auto dyn = std::vector{prime(x) = v, prime(v) = cos(heyoka::time) - par[0] * v - sin(x)};
+        auto ta = tab{dyn, st, 4u, kw::pars = pv};
+        ta.set_time({0.1, 0.2, 0.3, 0.4});
+        ta.propagate_until({20, 21, 22, 23});
+        for (auto i = 0u; i < 4u; ++i) {
+            auto t1 = tab{dyn, {st[i], st[4u + i]}, 1u, kw::pars = dvec{pv[i]}};
+            t1.set_time((i + 1) / 10.);
+            t1.propagate_until(20. + i);
+            CHECK(close_to(t1.get_state()[0], ta.get_state()[i], 1000 * eps));
+            CHECK(close_to(t1.get_state()[1], ta.get_state()[4u + i], 1000 * eps));
+            CHECK(t1.get_time()[0] == ta.get_time()[i]);
+        }
+    }
+
     // "propagate trivial" (:446-464).
     {
         auto ta = tab{{prime(x) = v, prime(v) = 1_dbl}, {0, 0, 0.1, 0.1}, 2};
