@@ -92,7 +92,15 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
             return false;
         }
         // (The derived position jets rely on the reciprocal form of the division by the order.)
-        return pp_shape_ok && p.n_par == 0u && !m4 && nc <= 64u && !opts.exact_division
+        // (Stepper with events: this kernel keeps exactly the COMPACT set of Taylor coefficients - velocity-type jets and
+        // the current values of the position-type variables -, see emitted_module::compact_tc; HEYOKA_AMD_V5_EVENTS=0 and
+        // HEYOKA_AMD_COMPACT_TC=0 keep the stepper with events on the lane-pair kernel.)
+        const auto env_off = [](const char *name) {
+            const char *e = std::getenv(name);
+            return e != nullptr && std::atoi(e) == 0;
+        };
+        const bool m4_ok = !m4 || (!env_off("HEYOKA_AMD_V5_EVENTS") && !env_off("HEYOKA_AMD_COMPACT_TC"));
+        return pp_shape_ok && p.n_par == 0u && m4_ok && nc <= 64u && !opts.exact_division
                && std::getenv("HEYOKA_AMD_V3_EXACT_DIV") == nullptr && std::getenv("HEYOKA_AMD_V3_POW_DIV") == nullptr;
     }();
     if (one_lane) {
@@ -872,14 +880,18 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     const auto jet_doubles_per_wave = jet_rows_doubles + (one_lane ? static_cast<std::uint64_t>(spw) * n_dcolp : 0u);
     const auto lds_doubles_slab = static_cast<std::uint64_t>(wpb) * spw * slab_stride;
     // (Mode 4: plus the source table of the cooperative store of the Taylor coefficients, 4 bytes per row.)
-    const auto lds_tc_table_bytes = m4 ? static_cast<std::uint64_t>(n_eq) * (order + 1u) * 4u : 0u;
+    const auto lds_tc_table_bytes = m4 ? static_cast<std::uint64_t>(n_eq) * (order + 1u) * 8u : 0u;
     const bool jet_lds = (lds_doubles_slab + wpb * jet_doubles_per_wave) * 8u + lds_tc_table_bytes <= 160u * 1024u
                          && std::getenv("HEYOKA_AMD_JET_GLOBAL") == nullptr;
     // Stepper with events: compact set of Taylor coefficients (see emitted_module::compact_tc) through the cooperative
     // store of the LDS-resident jets. HEYOKA_AMD_COMPACT_TC=0 switches it off (A/B measurements).
+    std::size_t n_tc_rows = 0; // rows of the mode-4 store (set where its source table is emitted)
     const bool compact_tc = [&]() {
-        if (!m4 || !jet_lds || one_lane) {
+        if (!m4 || !jet_lds) {
             return false;
+        }
+        if (one_lane) {
+            return true;
         }
         if (const char *ev = std::getenv("HEYOKA_AMD_COMPACT_TC")) {
             if (std::atoi(ev) == 0) {
@@ -1688,13 +1700,55 @@ __device__ __forceinline__ double hy_swap1(double x)
             }
         }
         if (m4) {
-            src << "__constant__ unsigned short hy_tc_rows[" << n_eq * (order + 1u) << "] = {";
-            for (std::uint32_t var = 0; var < n_eq; ++var) {
-                const auto &sd = p.sv_defs[var];
-                const bool derived = compact_tc && sd.type == operand::kind::uvar && sd.idx < n_eq;
-                for (std::uint32_t k = 0; k <= (derived ? 0u : order); ++k) {
-                    src << var * (order + 1u) + k << ",";
+            // Source table of the cooperative store of the Taylor coefficients (mode 4): per stored row its index in a.tc
+            // (variable * (order + 1) + k), the offset of its value for the first system of a wavefront inside the jets of
+            // the wavefront, and the stride between the systems of the wavefront. Compact set (emitted_module::compact_tc):
+            // a state variable defined by another state variable (x' = v) leaves with its order-0 row only.
+            struct tc_entry {
+                std::uint64_t row, off, stride;
+            };
+            std::vector<tc_entry> tc_src;
+            if (one_lane) {
+                // (Velocity-type jets [row][owner slot][system][lane]; current values of the derived variables behind them.)
+                for (const auto &rg : rounds) {
+                    for (const auto &gr : rg) {
+                        for (const auto &ow : gr.owners) {
+                            const auto &vv = utbl[ow.var_tbl];
+                            for (std::uint32_t l2 = 0; l2 < ow.n_valid; ++l2) {
+                                const std::uint64_t var = vv[l2];
+                                if (ow.derived) {
+                                    tc_src.push_back({var * (order + 1u), jet_rows_doubles + static_cast<std::uint64_t>(spw) * ow.cbase + l2,
+                                                      ow.n_valid});
+                                } else {
+                                    for (std::uint32_t k = 0; k <= order; ++k) {
+                                        tc_src.push_back({var * (order + 1u) + k,
+                                                          static_cast<std::uint64_t>(k) * spw * n_colp
+                                                              + static_cast<std::uint64_t>(spw) * ow.cbase + l2,
+                                                          ow.n_valid});
+                                    }
+                                }
+                            }
+                        }
+                    }
                 }
+            } else {
+                for (std::uint32_t var = 0; var < n_eq; ++var) {
+                    const auto &sd = p.sv_defs[var];
+                    const bool derived = compact_tc && sd.type == operand::kind::uvar && sd.idx < n_eq;
+                    for (std::uint32_t k = 0; k <= (derived ? 0u : order); ++k) {
+                        tc_src.push_back({static_cast<std::uint64_t>(var) * (order + 1u) + k,
+                                          static_cast<std::uint64_t>(k) * spw * n_colp + col_of[var], n_colp});
+                    }
+                }
+            }
+            n_tc_rows = tc_src.size();
+            src << "__constant__ unsigned long long hy_tc_src[" << std::max<std::size_t>(n_tc_rows, 1u) << "] = {";
+            for (const auto &t : tc_src) {
+                if (t.row >= (1ull << 20) || t.off >= (1ull << 20) || t.stride >= (1ull << 20)) {
+                    why_not = "mode 4: index overflow in the source table of the Taylor coefficients";
+                    return ret;
+                }
+                src << (t.row | (t.off << 20) | (t.stride << 40)) << "ull,";
             }
             src << "};\n";
         }
@@ -1735,11 +1789,9 @@ __device__ __forceinline__ double hy_swap1(double x)
         src << "double *const jetw = lds_jet + wib * " << jet_doubles_per_wave << "u;\n";
         if (m4) {
             // Source table of the cooperative store of the Taylor coefficients: row | jet column << 16.
-            const auto n_rows_max = n_eq * (order + 1u);
-            src << "__shared__ unsigned lds_tcsrc[" << n_rows_max << "];\n";
-            src << "for (unsigned i = threadIdx.x; i < " << n_rows_max << "u; i += " << bs << "u) {\n"
-                << "const unsigned row = hy_tc_rows[i];\nlds_tcsrc[i] = row | ((unsigned)hy_col_of_var[row / "
-                << (order + 1u) << "u] << 16);\n}\n__syncthreads();\n";
+            src << "__shared__ unsigned long long lds_tcsrc[" << std::max<std::size_t>(n_tc_rows, 1u) << "];\n";
+            src << "for (unsigned i = threadIdx.x; i < " << n_tc_rows << "u; i += " << bs
+                << "u) lds_tcsrc[i] = hy_tc_src[i];\n__syncthreads();\n";
         }
     } else {
         src << "double *const jetw = a.scratch + gwave * " << jet_doubles_per_wave << "ull;\n";
@@ -2211,29 +2263,19 @@ if (nf_seen != 0 && l == 0u && live) atomicAdd(a.counters, 1u);
         // 16 systems of the lane-pair kernel - instead of 16-byte pieces per wavefront (the per-wavefront stores make
         // the 1 048 576-system stepper with events transaction bound: 8 ms instead of 3).
         const auto spb = wpb * spw;
-        // Compact set of rows: a state variable defined by another state variable (x' = v) leaves with its order-0 row
-        // only, x^[k] = v^[k-1] / k is derived by the consumers (emitted_module::compact_tc).
-        std::vector<std::uint32_t> tc_rows;
-        for (std::uint32_t var = 0; var < n_eq; ++var) {
-            const auto &sd = p.sv_defs[var];
-            const bool derived = compact_tc && sd.type == operand::kind::uvar && sd.idx < n_eq;
-            for (std::uint32_t k = 0; k <= (derived ? 0u : order); ++k) {
-                tc_rows.push_back(var * (order + 1u) + k);
-            }
-        }
-        // NOTE: the (row, jet column) of every stored row comes from a table in LDS (lds_tcsrc, filled once per
-        // workgroup): with the tables in global / constant memory every iteration of this loop issues vector loads BEHIND
-        // the stores of the previous one, and gfx9 counts loads and stores in one in-order counter (vmcnt) - each
-        // iteration then waits for a store acknowledgement (12 iterations: 6 us per group of systems, 1.5 ms of a 4.2 ms
-        // launch on 1 048 576 systems).
+        // NOTE: the (row, source offset, stride) of every stored row comes from a table in LDS (lds_tcsrc, filled once per
+        // workgroup from hy_tc_src): with the table in global / constant memory every iteration of this loop issues vector
+        // loads BEHIND the stores of the previous one, and gfx9 counts loads and stores in one in-order counter (vmcnt) -
+        // each iteration then waits for a store acknowledgement (12 iterations: 6 us per group of systems, 1.5 ms of a
+        // 4.2 ms launch on 1 048 576 systems).
         src << "{\n__syncthreads();\n";
         src << "const u64 bs0 = base - (u64)wib * SPW;\n";
-        src << "for (unsigned idx = threadIdx.x; idx < " << tc_rows.size() * spb << "u; idx += " << bs << "u) {\n";
-        src << "const unsigned sy = idx % " << spb << "u, te = lds_tcsrc[idx / " << spb << "u];\n";
-        src << "const unsigned row = te & 0xffffu, col = te >> 16, k = row % " << (order + 1u) << "u;\n";
+        src << "for (unsigned idx = threadIdx.x; idx < " << n_tc_rows * spb << "u; idx += " << bs << "u) {\n";
+        src << "const unsigned sy = idx % " << spb << "u;\nconst unsigned long long te = lds_tcsrc[idx / " << spb << "u];\n";
+        src << "const unsigned row = (unsigned)(te & 0xfffffull), off = (unsigned)((te >> 20) & 0xfffffull), sst = "
+               "(unsigned)(te >> 40);\n";
         src << "const u64 sg = bs0 + sy;\n";
-        src << "const double val = lds_jet[(sy / SPW) * " << jet_doubles_per_wave << "u + k * " << spw * n_colp
-            << "u + (sy % SPW) * " << n_colp << "u + col];\n";
+        src << "const double val = lds_jet[(sy / SPW) * " << jet_doubles_per_wave << "u + off + (sy % SPW) * sst];\n";
         src << "if (sg < N) a.tc[(u64)row * N + sg] = val;\n}\n__syncthreads();\n}\n";
     }
     src << R"HIP(

@@ -29,6 +29,9 @@ def _cases():
     return {
         "outer_ss_cluster_event_stepper": (lambda: hy.model.nbody(6, masses=M, Gconst=G),
                                            {"high_accuracy": True, "nt_events": ev_ss}, {}, "events:"),
+        "outer_ss_cluster_event_stepper_v3": (lambda: hy.model.nbody(6, masses=M, Gconst=G),
+                                              {"high_accuracy": True, "nt_events": ev_ss}, {"HEYOKA_AMD_V5_EVENTS": "0"},
+                                              "events:"),
         "outer_ss_cluster_v5": (lambda: hy.model.nbody(6, masses=M, Gconst=G), {"high_accuracy": True}, {}, "v5"),
         "outer_ss_cluster_v3": (lambda: hy.model.nbody(6, masses=M, Gconst=G), {"high_accuracy": True},
                                 {"HEYOKA_AMD_ONE_LANE": "0"}, "v3"),

@@ -1699,13 +1699,16 @@ def test_compact_taylor_coefficients_of_the_stepper_with_events_change_nothing(h
                                         nt_events=nt, t_events=tev, exact_division=exact_division)
 
     log_c, te_c, log_f, te_f, log_o, te_o = [], [], [], [], [], []
+    # (Both on the lane-pair kernel v3: the one-lane kernel v5, the default for this system, has no full variant.)
+    monkeypatch.setenv("HEYOKA_AMD_V5_EVENTS", "0")
     tc_ = build(log_c, te_c)
     monkeypatch.setenv("HEYOKA_AMD_COMPACT_TC", "0")
     tf = build(log_f, te_f)
     monkeypatch.delenv("HEYOKA_AMD_COMPACT_TC")
-    assert tc_.hip_source_mode.startswith("cluster") and "hy_tc_rows" in tc_.hip_source
+    monkeypatch.delenv("HEYOKA_AMD_V5_EVENTS")
+    assert tc_.hip_source_mode.startswith("cluster") and "v3" in tc_.hip_source_mode and "hy_tc_src" in tc_.hip_source
     # (The full build lists every row in its table, the compact one 18 x 21 + 18 of the 36 x 21.)
-    count = lambda src: len(src.split("hy_tc_rows[")[1].split("{")[1].split("}")[0].strip(",").split(","))
+    count = lambda src: int(src.split("hy_tc_src[")[1].split("]")[0])
     assert count(tf.hip_source) == 36 * 21 and count(tc_.hip_source) == 18 * 21 + 18
     nt_o, te_ev_o = _outer_ss_event_setup(ho, log_o, te_o)
     ora = ho.OracleEventIntegrator(ho.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=high_accuracy, nt_events=nt_o,
@@ -1791,6 +1794,8 @@ def test_events_on_the_cluster_stepper_vs_oracle(monkeypatch):
     ta = hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True, nt_events=nt_p,
                                   t_events=te_ev_p)
     assert ta.hip_source_mode.startswith("cluster") and "events:" in ta.hip_source_mode, ta.hip_source_mode
+    # (The stepper with events of this system is the one-lane-per-pair kernel v5 since round 3.)
+    assert "v5" in ta.hip_source_mode
     nt_o, te_ev_o = _outer_ss_event_setup(ho, log_o, te_o)
     ora = ho.OracleEventIntegrator(ho.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True, nt_events=nt_o,
                                    t_events=te_ev_o)
