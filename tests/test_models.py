@@ -622,3 +622,34 @@ def test_planner_rewrites_of_the_internal_program_do_not_change_the_jets(case, m
     assert plain.step_res == rewritten.step_res
     assert np.array_equal(plain.tc, rewritten.tc) and np.array_equal(plain.state, rewritten.state)
     assert np.array_equal(plain.time_hi, rewritten.time_hi)
+
+
+@pytest.mark.gpu
+def test_events_on_a_program_with_private_cluster_inputs():
+    """model::fixed_centres with zero / repeated coordinates (internal program rewritten by privatise_cluster_inputs()) AND
+    events whose equations are exactly the shared / negated differences: the wave-cluster stepper with events on the
+    rewritten program + hy_ev_jets on the decomposition, step by step against the oracle's stepper with events."""
+    mm, pp = _fixed_centres_special(12)
+    n = 11
+    st = _lanes([5.0, 0.3, -0.2, 0.0, 1.0, 0.1], n, 1e-2, 6)
+    log_p, log_o = [], []
+    xg, yg = hy.make_vars("x", "y")
+    xo, yo = ho.var("x"), ho.var("y")
+    ta = hy.taylor_adaptive_batch(hy.model.fixed_centres(Gconst=1.0, masses=mm, positions=pp), st, n,
+                                  nt_events=[hy.nt_event(pp[6] - xg, lambda ta, t, d, i: log_p.append((i, 0, t, d))),
+                                             hy.nt_event(-1.0 * yg, lambda ta, t, d, i: log_p.append((i, 1, t, d)))])
+    assert ta.hip_source_mode.startswith("cluster") and "private coordinate differences" in ta.hip_source_mode
+    assert "events:" in ta.hip_source_mode
+    ora = ho.OracleEventIntegrator(ho.fixed_centres(Gconst=1.0, masses=mm, positions=pp), st, n,
+                                   nt_events=[ho.nt_event(ho.num(pp[6]) - xo, lambda ta, t, d, i: log_o.append((i, 0, t, d))),
+                                              ho.nt_event(ho.num(-1.0) * yo, lambda ta, t, d, i: log_o.append((i, 1, t, d)))])
+    for _ in range(60):
+        ta.step()
+        ora.step()
+        assert [int(oc) for oc, _ in ta.step_res] == [oc for oc, _ in ora.step_res]
+        h_p = np.array([h for _, h in ta.step_res])
+        h_o = np.array([h for _, h in ora.step_res])
+        assert np.max(np.abs(h_p - h_o) / np.abs(h_o)) <= 1e6 * EPS
+        assert rel_err(ta.state, ora.state.reshape(6, n)) <= 1e6 * EPS
+    assert len(log_p) >= n and [(a[0], a[1], a[3]) for a in log_p] == [(a[0], a[1], a[3]) for a in log_o]
+    assert np.max(np.abs(np.array([a[2] for a in log_p]) - np.array([a[2] for a in log_o]))) <= 1e-10
