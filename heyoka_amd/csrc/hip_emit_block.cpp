@@ -172,7 +172,9 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
     const bool wide = n_slots > 65535u;
     const std::string ut = wide ? "unsigned" : "unsigned short";
     std::ostringstream tbl;
+    std::vector<std::pair<std::string, std::size_t>> utbl_list; // (name, entries) of the index tables
     const auto emit_utbl = [&](const std::string &name, const std::vector<std::uint32_t> &v) {
+        utbl_list.emplace_back(name, std::max<std::size_t>(v.size(), 1u));
         tbl << "__device__ const " << ut << " " << name << "[" << std::max<std::size_t>(v.size(), 1u) << "] = {";
         for (const auto x : v) {
             tbl << x << ",";
@@ -260,6 +262,58 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         emit_dtbl("hy_sv_val", val);
     }
 
+    // ---- "v2" cluster phase (point-mass pair clusters): see emit_pair_rounds() below ----
+    // The order loop is ROLLED and the rounds of a lane (its n_iter clusters) are unrolled, so that the coefficients of
+    // order < M of the two members with a recurrence on themselves (r^2 and its power) stay in REGISTERS for the whole
+    // step (2 * M doubles per cluster of the lane); the convolutions are evaluated as index pairs (i, k - i), i < k - i:
+    // the low index from the registers (or, for M <= i, from the tape), the high index from the tape - every tape row
+    // >= M is read once per order instead of every row, and the rows just written are the ones read next (L2).
+    pair_pattern pp;
+    detect_pair_pattern(p, pl, pp);
+    const std::uint32_t v2_T = (order - 1u) / 2u + 1u; // index pairs (slots) of the highest order
+    std::uint32_t v2_M = 0;
+    bool v2 = [&]() {
+        if (const char *ev = std::getenv("HEYOKA_AMD_BLOCK_V2"); ev != nullptr && std::atoi(ev) == 0) {
+            return false;
+        }
+        if (!pp.ok || pp.sc != -1 || pp.rx[0] != -1 || pp.rx[1] != -1 || pp.rx[2] != -1 || n_cst != 0u
+            || !pl.par_pos.empty() || pl.glue_has_par || wide || pl.cluster_level != 1u || n_ej == 0u || n_tape != 2u
+            || n_out != 3u || order < 6u || p.n_par != 0u) {
+            return false;
+        }
+        if (static_cast<std::uint64_t>(n_ej) * order * 8u >= 65536u || (nc + bs - 1u) / bs > 16u) {
+            return false;
+        }
+        for (const auto c : constant_uvars(p)) {
+            if (c != 0) {
+                return false;
+            }
+        }
+        // External inputs: state variables (their order-k values are recorded by the state recursion).
+        for (std::uint32_t c = 0; c < nc; ++c) {
+            for (std::uint32_t x = 0; x < n_ext; ++x) {
+                const auto u = pl.ext_u[c][x];
+                if (u >= n_eq || pl.slot_of[u] != static_cast<int>(u)) {
+                    return false;
+                }
+            }
+        }
+        // Glue: nodes whose order-k rule is the same for every k >= 1.
+        for (const auto &grp : pl.groups) {
+            const auto &n0 = p.nodes[grp.nodes[0] - n_eq];
+            bool ok = false;
+            if (n0.kind == func_kind::sum || n0.kind == func_kind::sub) {
+                ok = true;
+            } else if (n0.kind == func_kind::prod && n0.args.size() == 2u && n0.args[0].type == operand::kind::num
+                       && is_var(n0.args[1])) {
+                ok = true;
+            }
+            if (!ok) {
+                return false;
+            }
+        }
+        return true;
+    }();
     // ---- body ----
     ssa_emitter e(p, order);
     auto &os = e.os;
@@ -477,6 +531,594 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
     };
 
     const auto sv_rounds = (n_eq + bs - 1u) / bs;
+    std::string v2_decl; // kernel-lifetime declarations of the v2 cluster phase
+
+    // The whole step body of the v2 cluster phase (see the eligibility test above). Index pairs ("slots"): at order k
+    // the convolutions of the cluster run over the pairs (i, p = k - i), 0 <= i <= p. Slot 0 pairs the order-0
+    // coefficients with the order-k ones (which are being computed), slots 1 .. floor(k / 2) pair known coefficients;
+    // for an even k the last slot is the middle term (i = p), entered with the weights (1/2, 0) on the symmetric parts.
+    //   r2^[k]  = 2 * sum_i d^[i] . d^[p]                                                   (src/detail/sum_sq.cpp:100-245)
+    //   pw^[k]  = (sum_j (k a - j (a + 1)) r2^[k-j] pw^[j]) / (k r2^[0])                   (src/math/pow.cpp:395-550)
+    //   f_c^[k] = sum_j d_c^[k-j] pw^[j]                                                    (src/math/prod.cpp:314-395)
+    // Data of a slot: r2^[i], pw^[i] from the registers (i < M) or the tape, r2^[p], pw^[p] from the tape, d^[i], d^[p]
+    // recomputed from the jets of the external inputs in LDS (rows stored in REVERSE order, so that the row of p = k - i
+    // is a non-negative constant offset from the row of k). All the tape loads of a round are issued, unconditionally
+    // (rows of slots beyond the last one are clamped to a row which is loaded anyway), one round ahead of their use.
+    const auto emit_pair_rounds_body = [&]() -> bool {
+        const auto R = n_iter;
+        const auto T = v2_T;
+        // Developer experiments (timing only, wrong results): 1 = no slots beyond slot 0, 2 = no glue arithmetic, 3 = no LDS
+        // reads in the slots, 4 = no tape loads in the slots.
+        const int exp_mode = std::getenv("HEYOKA_AMD_BLOCK_EXP") != nullptr ? std::atoi(std::getenv("HEYOKA_AMD_BLOCK_EXP")) : 0;
+        std::uint32_t M = 160u / (4u * R);
+        if (const char *ev = std::getenv("HEYOKA_AMD_BLOCK_CACHE_ROWS")) {
+            M = static_cast<std::uint32_t>(std::max(0, std::atoi(ev)));
+        }
+        M = std::min(T, std::max(2u, M));
+        v2_M = M;
+        int s_sq = -1, s_pw = -1;
+        for (std::uint32_t s = 0; s < n_sto; ++s) {
+            if (recomp[s] == 0 && pl.stored_pos[s] == pp.sq) {
+                s_sq = static_cast<int>(s);
+            }
+            if (recomp[s] == 0 && pl.stored_pos[s] == pp.pw) {
+                s_pw = static_cast<int>(s);
+            }
+        }
+        int io_of[3] = {-1, -1, -1};
+        for (std::uint32_t c = 0; c < 3u; ++c) {
+            for (std::uint32_t x = 0; x < n_out; ++x) {
+                if (pl.out_pos[x] == pp.pr[c]) {
+                    io_of[c] = static_cast<int>(x);
+                }
+            }
+            for (std::uint32_t s = 0; s < n_sto; ++s) {
+                if (pl.stored_pos[s] == pp.d[c] && recomp[s] == 0) {
+                    return false;
+                }
+            }
+        }
+        if (s_sq < 0 || s_pw < 0 || io_of[0] < 0 || io_of[1] < 0 || io_of[2] < 0 || n_ext > 8u) {
+            return false;
+        }
+        const auto arow0 = static_cast<std::uint64_t>(tape_row[static_cast<std::uint32_t>(s_sq)]) * order;
+        const auto brow0 = static_cast<std::uint64_t>(tape_row[static_cast<std::uint32_t>(s_pw)]) * order;
+        const auto rowb = static_cast<std::uint64_t>(ncp) * 8u;
+        const auto P = order;
+        const auto ejrow = static_cast<std::uint64_t>(n_ej) * 8u;         // bytes per row of the input jets
+        const auto ej0b = static_cast<std::uint64_t>(P - 1u) * ejrow;     // row of order 0
+        const double ex = pp.ex, e1 = pp.ex + 1.;
+        const auto U = [](std::uint64_t x) { return std::to_string(x) + "u"; };
+        const auto S = [](std::uint32_t x) { return std::to_string(x); };
+        const auto nm = [&](const char *b, std::uint32_t r) { return std::string(b) + "_" + std::to_string(r); };
+        const auto nm2 = [&](const char *b, std::uint32_t i, std::uint32_t r) {
+            return std::string(b) + "_" + std::to_string(i) + "_" + std::to_string(r);
+        };
+
+        {
+            // State variable -> index of its jet among the LDS-resident input jets (0xffff: not an input of the clusters).
+            std::vector<std::uint32_t> sv_ej(n_eq, 0xffffu);
+            for (std::uint32_t e2 = 0; e2 < n_ej; ++e2) {
+                sv_ej[ej_slots[e2]] = e2;
+            }
+            emit_utbl("hy_sv_ej", sv_ej);
+        }
+        // ---- the descriptors of the clusters: byte offsets (inside a row of the input jets) of the external inputs, two
+        // per word, and the slab slots of the outputs; loaded at the head of the tape loads of a round (a table of
+        // (n_dq + 2) * n_clusters words shared by all the workgroups: L2) - as values which live for the whole kernel they
+        // were spilled, and a scratch reload inside the order loop makes the wavefront wait for ALL its outstanding tape
+        // loads (loads, stores and scratch accesses share one in-order counter).
+        std::ostringstream dc;
+        dc << "#define HY_EJ(off) (*(const double *)((const char *)ejet + (off)))\n";
+        dc << "#define HY_EJW(off) (*(double *)((char *)ejet + (off)))\n";
+        const auto n_dq = (n_ext + 1u) / 2u;
+        {
+            std::vector<std::uint32_t> dsc(static_cast<std::size_t>(n_dq + 2u) * nc, 0u);
+            for (std::uint32_t c = 0; c < nc; ++c) {
+                for (std::uint32_t x = 0; x < n_ext; ++x) {
+                    dsc[static_cast<std::size_t>(x / 2u) * nc + c]
+                        |= (ej_index[static_cast<std::size_t>(x) * nc + c] * 8u) << (16u * (x % 2u));
+                }
+                const auto oslot = [&](int x) {
+                    return static_cast<std::uint32_t>(pl.slot_of[pl.clusters[c][pl.out_pos[static_cast<std::uint32_t>(x)]]]);
+                };
+                dsc[static_cast<std::size_t>(n_dq) * nc + c] = oslot(io_of[0]) | (oslot(io_of[1]) << 16);
+                dsc[static_cast<std::size_t>(n_dq + 1u) * nc + c] = oslot(io_of[2]);
+            }
+            tbl << "__device__ const unsigned hy_dsc[" << dsc.size() << "] = {";
+            for (const auto x : dsc) {
+                tbl << x << ",";
+            }
+            tbl << "};\n";
+        }
+        for (std::uint32_t r = 0; r < R; ++r) {
+            const bool full = static_cast<std::uint64_t>(r + 1u) * bs <= nc;
+            if (!full) {
+                dc << "const bool live_" << r << " = tid + " << r * bs << "u < " << nc << "u;\n";
+            }
+        }
+        // LDS copies of the index tables read at every order (cluster descriptors, glue operands / results, state-variable
+        // definitions), as far as they fit next to the slab and the input jets: a table lookup in front of every LDS access
+        // of the glue phases and of the head of a round is a ~1 us round trip to L2 per dependency level when it is a
+        // global load, ~0.1 us from LDS. Filled once per workgroup (the workgroups are persistent).
+        {
+            std::uint64_t lds_used = (static_cast<std::uint64_t>(n_slots) + 1u) * 8u + static_cast<std::uint64_t>(n_ej) * order * 8u
+                                     + 3u * 8u * (bs / 64u) + 64u;
+            const std::uint64_t lds_cap = 160u * 1024u - 256u;
+            std::ostringstream cp, defs;
+            const auto mirror = [&](const std::string &name, std::size_t n, const char *type, std::uint64_t esz) {
+                if (lds_used + n * esz + 8u > lds_cap) {
+                    return;
+                }
+                lds_used += (n * esz + 7u) / 8u * 8u;
+                dc << "__shared__ " << type << " l_" << name << "[" << n << "];\n";
+                cp << "for (unsigned i_ = tid; i_ < " << n << "u; i_ += " << bs << "u) l_" << name << "[i_] = " << name
+                   << "[i_];\n";
+                defs << "#define " << name << " l_" << name << "\n";
+            };
+            if (std::getenv("HEYOKA_AMD_BLOCK_NO_LDS_TABLES") == nullptr) {
+                mirror("hy_dsc", static_cast<std::size_t>(n_dq + 2u) * nc, "unsigned", 4u);
+                for (const auto &[name, n] : utbl_list) {
+                    if (name.rfind("hy_g", 0) == 0 || name.rfind("hy_sv_", 0) == 0) {
+                        mirror(name, n, "unsigned short", 2u);
+                    }
+                }
+            }
+            dc << cp.str() << "__syncthreads();\n" << defs.str();
+        }
+        v2_decl = dc.str();
+        // Cluster index of the lane in round r and its byte offset inside a tape row; the descriptor loads.
+        const auto lo_only = [&](std::uint32_t r) {
+            const bool full = static_cast<std::uint64_t>(r + 1u) * bs <= nc;
+            os << "unsigned cl_" << r << " = "
+               << (full ? "tid + " + U(r * bs) : "live_" + S(r) + " ? tid + " + U(r * bs) + " : " + U(nc - 1u)) << ";\n";
+            os << "asm volatile(\"\" : \"+v\"(cl_" << r << "));\n";
+            os << "const unsigned lo_" << r << " = cl_" << r << " * 8u;\n";
+        };
+        const auto desc_loads = [&](std::uint32_t r) {
+            const bool full = static_cast<std::uint64_t>(r + 1u) * bs <= nc;
+            // (The empty asm statement keeps the loads where they are: as loop invariants they would be hoisted out of the
+            // order loop and spilled.)
+            os << "unsigned cl_" << r << " = "
+               << (full ? "tid + " + U(r * bs) : "live_" + S(r) + " ? tid + " + U(r * bs) + " : " + U(nc - 1u)) << ";\n";
+            os << "asm volatile(\"\" : \"+v\"(cl_" << r << "));\n";
+            os << "const unsigned lo_" << r << " = cl_" << r << " * 8u;\n";
+            for (std::uint32_t j = 0; j < n_dq + 2u; ++j) {
+                os << "const unsigned dq_" << j << "_" << r << " = hy_dsc[" << U(static_cast<std::uint64_t>(j) * nc) << " + cl_" << r
+                   << "];\n";
+            }
+        };
+
+        const auto unpack = [&](std::uint32_t r) {
+            for (std::uint32_t x = 0; x < n_ext; ++x) {
+                os << "const unsigned ex" << x << " = "
+                   << ((x % 2u == 0u) ? "dq_" + S(x / 2u) + "_" + S(r) + " & 0xffffu" : "dq_" + S(x / 2u) + "_" + S(r) + " >> 16")
+                   << ";\n";
+            }
+            os << "const unsigned dvo0 = dq_" << n_dq << "_" << r << ", dvo1 = dq_" << n_dq + 1u << "_" << r << ";\n";
+        };
+        // d_c of the row at byte offset `row` (an expression): minuend - subtrahend (src/detail/sub.cpp:60-124).
+        const auto diff = [&](const std::string &name, std::uint32_t c, const std::string &row) {
+            os << "const double " << name << " = HY_EJ(" << row << " + ex" << pp.de[c][0] << ") - HY_EJ(" << row << " + ex"
+               << pp.de[c][1] << ");\n";
+        };
+        const auto store_out = [&](std::uint32_t, const std::string v[3]) {
+            os << "slab[dvo0 & 0xffffu] = " << v[0] << ";\n";
+            os << "slab[dvo0 >> 16] = " << v[1] << ";\n";
+            os << "slab[dvo1] = " << v[2] << ";\n";
+        };
+        // NOTE: the idle lanes of a partial last round work on a copy of the last cluster and store the same values to the
+        // same places as the lane which owns it: no predicated stores, i.e. no divergent control flow in the cluster phase
+        // (see the toolchain note on exec-masked regions under register pressure, heyoka_amd/codegen_check.py).
+        const auto is_full = [&](std::uint32_t) { return true; };
+
+        os << "double m0 = 0.0, mo = 0.0, mom1 = 0.0;\n";
+        for (std::uint32_t r = 0; r < sv_rounds; ++r) {
+            os << "{ const unsigned i = tid + " << r * bs << "u; if (i < " << n_eq
+               << "u) m0 = hy_max(m0, fabs(slab[i])); }\n";
+        }
+        for (std::uint32_t r = 0; r < R; ++r) {
+            for (std::uint32_t m = 0; m < M; ++m) {
+                os << "double " << nm2("ca", m, r) << " = 0.0, " << nm2("cb", m, r) << " = 0.0;\n";
+            }
+        }
+
+        // ---- order 0: the node rules of the other modes ----
+        os << "// ---- order 0 ----\n";
+        for (std::uint32_t r = 0; r < R; ++r) {
+            os << "{\n";
+            desc_loads(r);
+            unpack(r);
+            for (std::uint32_t x = 0; x < n_ext; ++x) {
+                e.val(pl.ext_u[0][x], 0) = e.def("HY_EJ(" + U(ej0b) + " + ex" + S(x) + ")");
+            }
+            for (const auto u : t0) {
+                e.node(u - n_eq, 0);
+            }
+            os << nm2("ca", 0, r) << " = " << e.val(t0[pp.sq], 0) << ";\n";
+            os << nm2("cb", 0, r) << " = " << e.val(t0[pp.pw], 0) << ";\n";
+            const std::string v[3] = {e.val(t0[pp.pr[0]], 0), e.val(t0[pp.pr[1]], 0), e.val(t0[pp.pr[2]], 0)};
+            if (!is_full(r)) {
+                os << "if (live_" << r << ") {\n";
+            }
+            store_out(r, v);
+            if (!is_full(r)) {
+                os << "}\n";
+            }
+            os << "}\n";
+        }
+        // The glue groups of a dependency level, STAGED: the nodes of a level do not read each other, but the compiler
+        // cannot know that the slab store of one block does not alias the slab loads of the next one - emitted block by block
+        // (index lookup, operands, sum, store) a level is one chain of ~40 dependent LDS round trips on the single wavefront
+        // of a SIMD. Here: all the index lookups of the level, then all the operand loads, then the arithmetic, then the
+        // stores.
+        const auto glue_level_staged = [&](std::uint32_t lev, std::uint32_t k) {
+            std::string st_idx, st_ld, st_ar, st_wr;
+            const auto take = [&]() {
+                auto t = os.str();
+                os.str("");
+                os.clear();
+                return t;
+            };
+            const auto before = take();
+            for (std::size_t g = 0; g < pl.groups.size(); ++g) {
+                const auto &grp = pl.groups[g];
+                if (grp.level != lev || (exp_mode == 2 && k != 0u)) {
+                    continue;
+                }
+                const auto rep = grp.nodes[0];
+                const auto &n0 = p.nodes[rep - n_eq];
+                const auto gn = "hy_g" + std::to_string(g);
+                const auto ng = static_cast<std::uint32_t>(grp.nodes.size());
+                for (std::uint32_t r = 0; r * bs < ng; ++r) {
+                    const auto tag = "_" + std::to_string(g) + "_" + std::to_string(r) + "_" + std::to_string(k == 0u ? 0 : 1);
+                    const bool partial = (r + 1u) * bs > ng;
+                    os << "const unsigned j" << tag << " = ";
+                    if (partial) {
+                        os << "(tid + " << r * bs << "u < " << ng << "u) ? tid + " << r * bs << "u : " << ng - 1u << "u;\n";
+                    } else {
+                        os << "tid + " << r * bs << "u;\n";
+                    }
+                    for (std::size_t a = 0; a < n0.args.size(); ++a) {
+                        if (is_var(n0.args[a])) {
+                            os << "const unsigned ia" << a << tag << " = " << gn << "_a" << a << "[j" << tag << "];\n";
+                        }
+                    }
+                    os << "const unsigned io" << tag << " = "
+                       << (partial ? "(tid + " + std::to_string(r * bs) + "u < " + std::to_string(ng) + "u) ? (unsigned)" + gn
+                                         + "_o[j" + tag + "] : " + std::to_string(n_slots) + "u"
+                                   : "(unsigned)" + gn + "_o[j" + tag + "]")
+                       << ";\n";
+                    st_idx += take();
+                    const auto saved = e.numpar_override;
+                    std::vector<std::pair<std::uint32_t, std::string>> saved_vals;
+                    for (std::size_t a = 0; a < n0.args.size(); ++a) {
+                        const auto &o = n0.args[a];
+                        if (is_var(o)) {
+                            const auto nm_ = e.def(exp_mode == 5 ? "slab[(ia" + std::to_string(a) + tag + " & 1u) + tid + "
+                                                                       + std::to_string(a * 2u) + "u]"
+                                                                 : "slab[ia" + std::to_string(a) + tag + "]");
+                            saved_vals.emplace_back(o.idx, e.val(o.idx, k));
+                            e.val(o.idx, k) = nm_;
+                        } else if (o.type == operand::kind::num) {
+                            e.numpar_override[&o] = gn + "_a" + std::to_string(a) + "[j" + tag + "]";
+                        }
+                    }
+                    st_ld += take();
+                    if (n0.kind == func_kind::prod && n0.args[0].type == operand::kind::num && n0.args[0].value == -1.) {
+                        e.numpar_override.erase(&n0.args[0]);
+                    }
+                    e.node(rep - n_eq, k);
+                    st_ar += take();
+                    st_wr += "slab[io" + tag + "] = " + e.val(rep, k) + ";\n";
+                    for (auto it = saved_vals.rbegin(); it != saved_vals.rend(); ++it) {
+                        e.val(it->first, k) = it->second;
+                    }
+                    e.numpar_override = saved;
+                }
+            }
+            os << before << "{\n" << st_idx << st_ld << st_ar << st_wr << "}\n";
+        };
+        const auto glue_levels = [&](std::uint32_t k) {
+            for (std::uint32_t lev = 1; lev <= pl.max_level; ++lev) {
+                glue_level_staged(lev, k);
+                sync();
+            }
+        };
+        glue_levels(0);
+        // State-variable recursion (src/taylor_02.cpp:245-287) with the order-(k + 1) values of the external inputs
+        // recorded in LDS. dyn: k is the loop variable.
+        const auto recursion = [&](bool dyn) {
+            os << "{\n";
+            for (std::uint32_t r = 0; r < sv_rounds; ++r) {
+                os << "double xn" << r << " = 0.0;\n";
+                os << "{ const unsigned i = tid + " << r * bs << "u; if (i < " << n_eq << "u) {\n";
+                os << "const unsigned kd_ = hy_sv_kind[i];\n";
+                if (dyn) {
+                    os << "if (kd_ == 0u) xn" << r << " = slab[hy_sv_idx[i]] / (kd + 1.0);\n";
+                } else {
+                    os << "if (kd_ == 0u) xn" << r << " = slab[hy_sv_idx[i]];\n";
+                    os << "else if (kd_ == 1u) xn" << r << " = hy_sv_val[i];\n";
+                    os << "else xn" << r << " = a.pars[(u64)hy_sv_idx[i] * N + s];\n";
+                }
+                os << "} }\n";
+            }
+            sync();
+            for (std::uint32_t r = 0; r < sv_rounds; ++r) {
+                os << "{ const unsigned i = tid + " << r * bs << "u; if (i < " << n_eq << "u) {\n";
+                os << "slab[i] = xn" << r << ";\n";
+                if (dyn) {
+                    os << "sjet[(k + 1u) * " << n_eq << "u + i] = xn" << r << ";\n";
+                    os << "const unsigned ee = hy_sv_ej[i];\n";
+                    os << "if (ee != 0xffffu && k + 1u < " << P << "u) HY_EJW((" << P - 2u << "u - k) * " << U(ejrow)
+                       << " + ee * 8u) = xn" << r << ";\n";
+                    os << "if (k + 1u == " << P << "u) mo = hy_max(mo, fabs(xn" << r << "));\n";
+                    os << "else if (k + 2u == " << P << "u) mom1 = hy_max(mom1, fabs(xn" << r << "));\n";
+                } else {
+                    os << "sjet[" << n_eq << "u + i] = xn" << r << ";\n";
+                    os << "const unsigned ee = hy_sv_ej[i];\n";
+                    os << "if (ee != 0xffffu) HY_EJW(" << U(static_cast<std::uint64_t>(P - 2u) * ejrow) << " + ee * 8u) = xn" << r
+                       << ";\n";
+                }
+                os << "} }\n";
+            }
+            sync();
+            os << "}\n";
+        };
+        recursion(false);
+
+        // ---- orders 1 .. P - 1 ----
+        // Tape registers of slot 1 (set 1 of the pipeline): slot 1 pairs order 1 with order k - 1, whose coefficients the lane
+        // computed itself one order earlier - they are handed over in registers (no load: the head of a group does not
+        // wait for the memory system). NOTE: loading them back right behind their stores is NOT an option: under load
+        // such a load was observed to overtake the store (stale values, runaway step sizes).
+        for (std::uint32_t r = 0; r < R; ++r) {
+            os << "double ap1_" << r << " = 0.0, bp1_" << r << " = 0.0;\n";
+        }
+        os << "#pragma nounroll\nfor (unsigned k = 1; k < " << P << "u; ++k) {\n";
+        os << "const double kd = (double)k;\n";
+        os << "const double c0k = kd * " << fp_literal(ex) << ";\n";
+        os << "const unsigned nm1 = k >> 1;\nconst bool even = (k & 1u) == 0u;\n";
+        os << "const unsigned kbr = (" << P - 1u << "u - k) * " << U(ejrow) << ";\n";
+        os << "const char *const tpa = (const char *)tape + (u64)(" << arow0 << "u + k) * " << rowb << "ull;\n";
+        os << "const char *const tpb = (const char *)tape + (u64)(" << brow0 << "u + k) * " << rowb << "ull;\n";
+        // The cluster phase of order k, SLOT-major: for slot i = 1 .. floor(k / 2) (early exit after the last one) the
+        // rounds 0 .. R - 1 of the lane, with the five accumulators of every round in registers. One software pipeline runs
+        // through the whole (slot, round) sequence of an order:
+        //  * tape loads: those of slot i + 1 (all rounds) are issued, unconditionally, at the head of slot i - rows of
+        //    slots beyond the last one are clamped to rows which are loaded anyway (L1 hits) -, so that an order pays the
+        //    latency of the memory system once (slot 1) and not once per round;
+        //  * LDS reads: the 12 raw values of a step are read before the arithmetic of the previous step (two sets,
+        //    ping-pong): with ONE wavefront per SIMD nothing else covers the LDS latency.
+        const auto raw = [&](std::uint32_t set, std::uint32_t q, std::uint32_t c, std::uint32_t side) {
+            return "w" + S(set) + "_" + S(q) + S(c) + S(side); // q: 0 = row i, 1 = row p
+        };
+        const auto unpack_ex = [&](std::uint32_t r) {
+            for (std::uint32_t x = 0; x < n_ext; ++x) {
+                os << "const unsigned ex" << x << " = "
+                   << ((x % 2u == 0u) ? "dq_" + S(x / 2u) + "_" + S(r) + " & 0xffffu" : "dq_" + S(x / 2u) + "_" + S(r) + " >> 16")
+                   << ";\n";
+            }
+        };
+        // The LDS reads of step (i, r) into set `set` (inside their own scope: the unpacked offsets are temporaries).
+        const auto lds_step = [&](std::uint32_t i, std::uint32_t r, std::uint32_t set) {
+            if (exp_mode == 3) {
+                for (std::uint32_t c = 0; c < 3u; ++c) {
+                    for (std::uint32_t side = 0; side < 2u; ++side) {
+                        os << raw(set, 0, c, side) << " = kd;\n" << raw(set, 1, c, side) << " = c0k;\n";
+                    }
+                }
+                return;
+            }
+            os << "{\n";
+            unpack_ex(r);
+            for (std::uint32_t c = 0; c < 3u; ++c) {
+                for (std::uint32_t side = 0; side < 2u; ++side) {
+                    os << raw(set, 0, c, side) << " = HY_EJ(" << U(static_cast<std::uint64_t>(P - 1u - i) * ejrow) << " + ex"
+                       << pp.de[c][side] << ");\n";
+                    os << raw(set, 1, c, side) << " = HY_EJ(kbr + " << U(static_cast<std::uint64_t>(i) * ejrow) << " + ex"
+                       << pp.de[c][side] << ");\n";
+                }
+            }
+            os << "}\n";
+        };
+        // Rounds per pipeline group (the accumulators, descriptors and tape registers of a group are live at the same
+        // time: R rounds at once do not fit the register file next to the register copies of the low orders).
+        std::uint32_t G = R;
+        if (const char *ev = std::getenv("HEYOKA_AMD_BLOCK_GROUP")) {
+            G = static_cast<std::uint32_t>(std::max(1, std::atoi(ev)));
+        } else if (R > 2u) {
+            G = 2;
+        }
+        G = std::min(G, R);
+        // Depth of the tape-load pipeline, in slots: the loads of slot i + D are issued at the head of slot i. One slot of a
+        // group is G * ~80 instructions, i.e. a fraction of a microsecond, against 1 - 2 us for a load which misses L2.
+        // (Measured on nbody(64), 65 536 systems, rows < 5 in registers: depth 1 / 2 / 3 / 4 with groups of two rounds =
+        // 9.8e5 / 9.7e5 / 8.8e5 / 8.6e5 system-steps/s - the registers of a deeper pipeline cost more than the latency they
+        // hide; the kernel is bound by the instruction issue of its single wavefront per SIMD.)
+        std::uint32_t D = 1;
+        if (const char *ev = std::getenv("HEYOKA_AMD_BLOCK_DEPTH")) {
+            D = static_cast<std::uint32_t>(std::max(1, std::atoi(ev)));
+        }
+        // The tape loads of slot i (rounds r0 .. r1 - 1) into the set i % 2.
+        const auto gname = [&](const char *b, std::uint32_t i, std::uint32_t r) {
+            return std::string(b) + S(i % (D + 1u)) + "_" + S(r);
+        };
+        const auto tape_loads = [&](std::uint32_t i, std::uint32_t r0, std::uint32_t r1) {
+            const auto back = "(u64)(nm1 < " + S(i) + "u ? nm1 : " + S(i) + "u) * " + std::to_string(rowb) + "ull";
+            const auto own = "(u64)(k < " + S(i) + "u ? k : " + S(i) + "u) * " + std::to_string(rowb) + "ull";
+            if (exp_mode == 4) {
+                for (std::uint32_t r = r0; r < r1; ++r) {
+                    os << gname("ap", i, r) << " = kd;\n" << gname("bp", i, r) << " = c0k;\n";
+                    if (i >= M) {
+                        os << gname("al", i, r) << " = kd;\n" << gname("bl", i, r) << " = c0k;\n";
+                    }
+                }
+                return;
+            }
+            for (std::uint32_t r = r0; r < r1; ++r) {
+                os << gname("ap", i, r) << " = *(const double *)(tpa - " << back << " + lo_" << r << ");\n";
+                os << gname("bp", i, r) << " = *(const double *)(tpb - " << back << " + lo_" << r << ");\n";
+                if (i >= M) {
+                    os << gname("al", i, r) << " = *(const double *)((const char *)tape + " << arow0 * rowb << "ull + " << own
+                       << " + lo_" << r << ");\n";
+                    os << gname("bl", i, r) << " = *(const double *)((const char *)tape + " << brow0 * rowb << "ull + " << own
+                       << " + lo_" << r << ");\n";
+                }
+            }
+        };
+        const auto emit_group = [&](std::uint32_t r0, std::uint32_t r1, std::uint32_t gi) {
+            const auto Rg = r1 - r0;
+            const auto step_set = [&](std::uint32_t i, std::uint32_t r) { return ((i - 1u) * Rg + (r - r0)) % 2u; };
+            os << "{\n";
+            // Declarations of the pipeline registers.
+            for (std::uint32_t set = 0; set <= D; ++set) {
+                for (std::uint32_t r = r0; r < r1; ++r) {
+                    std::string d;
+                    if (set != 1u) {
+                        d = "ap" + S(set) + "_" + S(r) + " = 0.0, bp" + S(set) + "_" + S(r) + " = 0.0";
+                    }
+                    if (M < T) {
+                        d += std::string(d.empty() ? "" : ", ") + "al" + S(set) + "_" + S(r) + " = 0.0, bl" + S(set) + "_" + S(r)
+                             + " = 0.0";
+                    }
+                    if (!d.empty()) {
+                        os << "double " << d << ";\n";
+                    }
+                }
+            }
+            for (std::uint32_t set = 0; set < 2u; ++set) {
+                for (std::uint32_t c = 0; c < 3u; ++c) {
+                    for (std::uint32_t side = 0; side < 2u; ++side) {
+                        os << "double " << raw(set, 0, c, side) << " = 0.0, " << raw(set, 1, c, side) << " = 0.0;\n";
+                    }
+                }
+            }
+            // Head: descriptors, the tape loads of slot 1, slot 0 (order-k differences x order-0 ones).
+            for (std::uint32_t r = r0; r < r1; ++r) {
+                desc_loads(r);
+            }
+            for (std::uint32_t i = 2; i <= D && i < T; ++i) {
+                tape_loads(i, r0, r1);
+            }
+            for (std::uint32_t r = r0; r < r1; ++r) {
+                os << "double ssq_" << r << ", spw_" << r << " = 0.0, sf0_" << r << ", sf1_" << r << ", sf2_" << r << ";\n";
+                os << "{\n";
+                unpack_ex(r);
+                for (std::uint32_t c = 0; c < 3u; ++c) {
+                    diff("dk" + S(c), c, "kbr");
+                    diff("dz" + S(c), c, U(ej0b));
+                }
+                os << "ssq_" << r << " = dz0 * dk0;\nssq_" << r << " = __builtin_fma(dz1, dk1, ssq_" << r << ");\nssq_" << r
+                   << " = __builtin_fma(dz2, dk2, ssq_" << r << ");\n";
+                for (std::uint32_t c = 0; c < 3u; ++c) {
+                    os << "sf" << c << "_" << r << " = dk" << c << " * " << nm2("cb", 0, r) << ";\n";
+                }
+                os << "}\n";
+            }
+            if (T > 1u) {
+                lds_step(1, r0, step_set(1, r0));
+                os << "__builtin_amdgcn_sched_barrier(0);\n";
+                os << (exp_mode == 1 ? "if (nm1 > 1000u) {\n" : "if (nm1 != 0u) {\n");
+                for (std::uint32_t i = 1; i < T; ++i) {
+                    os << "{\n";
+                    if (i + D < T) {
+                        tape_loads(i + D, r0, r1);
+                    }
+                    // Weights of the last slot of an even order (middle term): 1/2 on the squares, 0 on the mirrored
+                    // products; scalar factors k a - j (a + 1) of the terms j = i and j = p = k - i.
+                    os << "const bool mid = even & (nm1 == " << i << "u);\n";
+                    os << "const double wq = mid ? 0.5 : 1.0, w2 = mid ? 0.0 : 1.0;\n";
+                    os << "const double ci = c0k - " << fp_literal(static_cast<double>(i) * e1) << ";\n";
+                    os << "const double cp = c0k - (kd - " << fp_literal(static_cast<double>(i)) << ") * " << fp_literal(e1)
+                       << ";\n";
+                    for (std::uint32_t r = r0; r < r1; ++r) {
+                        const auto set = step_set(i, r);
+                        os << "{\n";
+                        if (r + 1u < r1) {
+                            lds_step(i, r + 1u, 1u - set);
+                        } else if (i + 1u < T) {
+                            lds_step(i + 1u, r0, 1u - set);
+                        }
+                        os << "__builtin_amdgcn_sched_barrier(0);\n";
+                        for (std::uint32_t c = 0; c < 3u; ++c) {
+                            os << "const double pi" << c << " = " << raw(set, 0, c, 0) << " - " << raw(set, 0, c, 1) << ";\n";
+                            os << "const double pp" << c << " = " << raw(set, 1, c, 0) << " - " << raw(set, 1, c, 1) << ";\n";
+                        }
+                        const auto ai = i < M ? nm2("ca", i, r) : gname("al", i, r);
+                        const auto bi = i < M ? nm2("cb", i, r) : gname("bl", i, r);
+                        os << "const double bpw = " << gname("bp", i, r) << " * w2;\n";
+                        os << "double sqt = pi0 * pp0;\nsqt = __builtin_fma(pi1, pp1, sqt);\nsqt = __builtin_fma(pi2, pp2, sqt);\n";
+                        os << "ssq_" << r << " = __builtin_fma(wq, sqt, ssq_" << r << ");\n";
+                        os << "spw_" << r << " = __builtin_fma(ci, " << gname("ap", i, r) << " * " << bi << ", spw_" << r << ");\n";
+                        os << "spw_" << r << " = __builtin_fma(cp, " << ai << " * bpw, spw_" << r << ");\n";
+                        for (std::uint32_t c = 0; c < 3u; ++c) {
+                            os << "sf" << c << "_" << r << " = __builtin_fma(pp" << c << ", " << bi << ", sf" << c << "_" << r
+                               << ");\n";
+                            os << "sf" << c << "_" << r << " = __builtin_fma(pi" << c << ", bpw, sf" << c << "_" << r << ");\n";
+                        }
+                        os << "}\n";
+                    }
+                    if (i + 1u < T) {
+                        os << "if (nm1 == " << i << "u) goto hy_done_" << gi << ";\n";
+                    }
+                    os << "}\n";
+                }
+                os << "}\nhy_done_" << gi << ":;\n";
+            }
+            // Slot 0, second half, and the quotient of the pow recurrence (src/math/pow.cpp:546-549); stores; the register
+            // copies of the coefficients of order < M.
+            for (std::uint32_t r = r0; r < r1; ++r) {
+                os << "{\n";
+                unpack_ex(r);
+                os << "const unsigned dvo0 = dq_" << n_dq << "_" << r << ", dvo1 = dq_" << n_dq + 1u << "_" << r << ";\n";
+                for (std::uint32_t c = 0; c < 3u; ++c) {
+                    diff("dz" + S(c), c, U(ej0b));
+                }
+                os << "const double ak = ssq_" << r << " + ssq_" << r << ";\n";
+                os << "const double spw = __builtin_fma(c0k, ak * " << nm2("cb", 0, r) << ", spw_" << r << ");\n";
+                os << "const double bk = spw / (kd * " << nm2("ca", 0, r) << ");\n";
+                for (std::uint32_t c = 0; c < 3u; ++c) {
+                    os << "const double sf" << c << " = __builtin_fma(dz" << c << ", bk, sf" << c << "_" << r << ");\n";
+                }
+                if (!is_full(r)) {
+                    os << "if (live_" << r << ") {\n";
+                }
+                os << "if (k + 1u < " << P << "u) {\n";
+                os << "*(double *)((char *)tape + (u64)(" << arow0 << "u + k) * " << rowb << "ull + lo_" << r << ") = ak;\n";
+                os << "*(double *)((char *)tape + (u64)(" << brow0 << "u + k) * " << rowb << "ull + lo_" << r << ") = bk;\n";
+                os << "}\n";
+                const std::string v[3] = {"sf0", "sf1", "sf2"};
+                store_out(r, v);
+                if (!is_full(r)) {
+                    os << "}\n";
+                }
+                os << "ap1_" << r << " = ak;\nbp1_" << r << " = bk;\n";
+                if (M > 1u) {
+                    os << "if (k < " << M << "u) {\n";
+                    for (std::uint32_t m = 1; m < M; ++m) {
+                        os << nm2("ca", m, r) << " = (k == " << m << "u) ? ak : " << nm2("ca", m, r) << ";\n";
+                        os << nm2("cb", m, r) << " = (k == " << m << "u) ? bk : " << nm2("cb", m, r) << ";\n";
+                    }
+                    os << "}\n";
+                }
+                os << "}\n";
+            }
+            os << "}\n";
+        };
+        for (std::uint32_t r0 = 0, gi = 0; r0 < R; r0 += G, ++gi) {
+            emit_group(r0, std::min(R, r0 + G), gi);
+        }
+        glue_levels(1);
+        recursion(true);
+        os << "}\n";
+        return true;
+    };
+    if (v2) {
+        v2 = emit_pair_rounds_body();
+    }
+
+    if (!v2) {
     os << "double m0 = 0.0, mo = 0.0, mom1 = 0.0;\n";
     // Order 0: the state is already in slab[0 .. n_eq) and sjet[0 .. n_eq) (see the module text).
     for (std::uint32_t r = 0; r < sv_rounds; ++r) {
@@ -525,6 +1167,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         sync();
         os << "}\n";
     }
+    }
     const auto body = os.str();
     os.str("");
     os.clear();
@@ -535,6 +1178,11 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
     const std::uint64_t per_block = (tape_doubles + sjet_doubles + 63u) / 64u * 64u;
     const std::uint32_t wpb = bs / 64u;
 
+    // v2: the order-0 row of the input jets is recorded together with the state (load / update).
+    const std::string ej_rec0
+        = v2 ? "{ const unsigned ee = hy_sv_ej[i]; if (ee != 0xffffu) HY_EJW("
+                   + std::to_string(static_cast<std::uint64_t>(order - 1u) * n_ej * 8u) + "u + ee * 8u) = x; } "
+             : std::string{};
     // ===================== module text =====================
     std::ostringstream src;
     src << prelude;
@@ -543,7 +1191,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
     src << "extern \"C\" __global__ void __launch_bounds__(" << bs << ") hy_taylor(const hy_kargs a)\n{\n";
     src << "__shared__ double slab[" << n_slots + 1u << "];\n";
     if (n_ej != 0u) {
-        src << "__shared__ double ejet[" << static_cast<std::uint64_t>(n_ej) * (order - 1u) << "];\n";
+        src << "__shared__ double ejet[" << static_cast<std::uint64_t>(n_ej) * (v2 ? order : order - 1u) << "];\n";
     }
     src << "__shared__ double red[3 * " << wpb << "];\n__shared__ u64 sh_base;\n__shared__ int sh_nfi;\n";
     src << "const unsigned tid = threadIdx.x;\nconst u64 N = a.N;\n";
@@ -551,6 +1199,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
     src << "double c_new[" << sv_rounds << "];\n";
     src << "double *const tape = a.scratch + (u64)blockIdx.x * " << per_block << "ull;\n";
     src << "double *const sjet = tape + " << tape_doubles << "ull;\n";
+    src << v2_decl;
     src << R"HIP(
 for (;;) {
 // Pull the next system from the device-side work queue.
@@ -565,7 +1214,8 @@ double t_hi = a.time_hi[s], t_lo = a.time_lo[s];
         src << "const double par_" << i << " = a.pars[(u64)" << i << "u * N + s];\n";
     }
     src << "for (unsigned i = tid; i < " << n_eq
-        << "u; i += " << bs << "u) { const double x = a.state[(u64)i * N + s]; slab[i] = x; sjet[i] = x; }\n";
+        << "u; i += " << bs << "u) { const double x = a.state[(u64)i * N + s]; slab[i] = x; sjet[i] = x; " << ej_rec0
+        << "}\n";
     src << R"HIP(
 __syncthreads();
 hy_df tfin, rem;
@@ -651,7 +1301,7 @@ if (!(hy_finite(t_hi) && hy_finite(t_lo))) nfi = 1;
 nfi = __syncthreads_or(nfi);
 )HIP";
     src << "for (unsigned i = tid; i < " << n_eq << "u; i += " << bs << "u) { const double x = c_new[i / " << bs
-        << "u]; slab[i] = x; sjet[i] = x; }\n__syncthreads();\n";
+        << "u]; slab[i] = x; sjet[i] = x; " << ej_rec0 << "}\n__syncthreads();\n";
     src << R"HIP(
 HY_STEP_TAIL(nfi != 0, tid == 0u)
 }
@@ -695,6 +1345,10 @@ if (tid == 0u) {
                 + " LDS-resident input jets), " + std::to_string(pl.groups.size()) + " glue groups, "
                 + std::to_string(n_slots) + " LDS slots, tape " + std::to_string(per_block * 8u / 1024u)
                 + " KiB per workgroup";
+    if (v2) {
+        ret.notes += "; v2 cluster phase: rolled order loop, " + std::to_string(n_iter) + " rounds per lane, rows < "
+                     + std::to_string(v2_M) + " of the tape members in registers";
+    }
     return ret;
 }
 

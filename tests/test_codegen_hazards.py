@@ -43,6 +43,8 @@ def _cases():
         "np1body_aliased": (lambda: hy.model.np1body(6, masses=M, Gconst=G), {}, {}, "cluster"),
         "two_body_register_jets": (lambda: hy.model.nbody(2, masses=[1.0, 0.0]), {}, {}, "unrolled"),
         "nbody12_block": (lambda: hy.model.nbody(12), {}, {}, "block"),
+        "nbody12_block_generic_cluster_phase": (lambda: hy.model.nbody(12), {}, {"HEYOKA_AMD_BLOCK_V2": "0"}, "block"),
+        "nbody64_block_v2": (lambda: hy.model.nbody(64), {}, {}, "v2 cluster phase"),
         "tan_3500_statements": (tan_system, {}, {}, "unrolled"),
         "cr3bp_unrolled": (lambda: hy.model.cr3bp(), {}, {}, "unrolled"),
         "functions_unrolled": (lambda: pw, {}, {}, "unrolled"),
