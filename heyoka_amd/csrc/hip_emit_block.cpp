@@ -611,6 +611,13 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         std::ostringstream dc;
         dc << "#define HY_EJ(off) (*(const double *)((const char *)ejet + (off)))\n";
         dc << "#define HY_EJW(off) (*(double *)((char *)ejet + (off)))\n";
+        // Tape accesses as raw buffer instructions: lane offset in a VGPR, row offset in an SGPR - one instruction per access
+        // (the flat form costs a 64-bit VALU addition per access and two SALU instructions per row).
+        dc << "typedef unsigned hy_u2 __attribute__((ext_vector_type(2)));\n";
+        dc << "const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void *)tape, 0, "
+           << static_cast<std::uint64_t>(n_tape) * order * ncp * 8u << ", 0x00020000);\n";
+        dc << "#define HY_TLD(lo, so) __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(trs, (lo), (so), 0))\n";
+        dc << "#define HY_TST(v, lo, so) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(hy_u2, (v)), trs, (lo), (so), 0)\n";
         const auto n_dq = (n_ext + 1u) / 2u;
         {
             std::vector<std::uint32_t> dsc(static_cast<std::size_t>(n_dq + 2u) * nc, 0u);
@@ -880,8 +887,8 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         os << "const double c0k = kd * " << fp_literal(ex) << ";\n";
         os << "const unsigned nm1 = k >> 1;\nconst bool even = (k & 1u) == 0u;\n";
         os << "const unsigned kbr = (" << P - 1u << "u - k) * " << U(ejrow) << ";\n";
-        os << "const char *const tpa = (const char *)tape + (u64)(" << arow0 << "u + k) * " << rowb << "ull;\n";
-        os << "const char *const tpb = (const char *)tape + (u64)(" << brow0 << "u + k) * " << rowb << "ull;\n";
+        os << "const unsigned tpa = (" << arow0 << "u + k) * " << rowb << "u;\n";
+        os << "const unsigned tpb = (" << brow0 << "u + k) * " << rowb << "u;\n";
         // The cluster phase of order k, SLOT-major: for slot i = 1 .. floor(k / 2) (early exit after the last one) the
         // rounds 0 .. R - 1 of the lane, with the five accumulators of every round in registers. One software pipeline runs
         // through the whole (slot, round) sequence of an order:
@@ -910,17 +917,16 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                 }
                 return;
             }
-            os << "{\n";
-            unpack_ex(r);
+            // (eo*_r: byte offsets of the inputs of the lane's cluster of round r inside a row; kx*_r: the same plus the row of
+            // order k - one register each for the duration of a group, so that every read is "register + constant".)
             for (std::uint32_t c = 0; c < 3u; ++c) {
                 for (std::uint32_t side = 0; side < 2u; ++side) {
-                    os << raw(set, 0, c, side) << " = HY_EJ(" << U(static_cast<std::uint64_t>(P - 1u - i) * ejrow) << " + ex"
-                       << pp.de[c][side] << ");\n";
-                    os << raw(set, 1, c, side) << " = HY_EJ(kbr + " << U(static_cast<std::uint64_t>(i) * ejrow) << " + ex"
-                       << pp.de[c][side] << ");\n";
+                    os << raw(set, 0, c, side) << " = HY_EJ(eo" << pp.de[c][side] << "_" << r << " + "
+                       << U(static_cast<std::uint64_t>(P - 1u - i) * ejrow) << ");\n";
+                    os << raw(set, 1, c, side) << " = HY_EJ(kx" << pp.de[c][side] << "_" << r << " + "
+                       << U(static_cast<std::uint64_t>(i) * ejrow) << ");\n";
                 }
             }
-            os << "}\n";
         };
         // Rounds per pipeline group (the accumulators, descriptors and tape registers of a group are live at the same
         // time: R rounds at once do not fit the register file next to the register copies of the low orders).
@@ -945,8 +951,8 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
             return std::string(b) + S(i % (D + 1u)) + "_" + S(r);
         };
         const auto tape_loads = [&](std::uint32_t i, std::uint32_t r0, std::uint32_t r1) {
-            const auto back = "(u64)(nm1 < " + S(i) + "u ? nm1 : " + S(i) + "u) * " + std::to_string(rowb) + "ull";
-            const auto own = "(u64)(k < " + S(i) + "u ? k : " + S(i) + "u) * " + std::to_string(rowb) + "ull";
+            const auto back = "(nm1 < " + S(i) + "u ? nm1 : " + S(i) + "u) * " + std::to_string(rowb) + "u";
+            const auto own = "(k < " + S(i) + "u ? k : " + S(i) + "u) * " + std::to_string(rowb) + "u";
             if (exp_mode == 4) {
                 for (std::uint32_t r = r0; r < r1; ++r) {
                     os << gname("ap", i, r) << " = kd;\n" << gname("bp", i, r) << " = c0k;\n";
@@ -956,16 +962,19 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                 }
                 return;
             }
+            os << "{\nconst unsigned sa = tpa - " << back << ", sb = tpb - " << back << ";\n";
+            if (i >= M) {
+                os << "const unsigned oa = " << arow0 * rowb << "u + " << own << ", ob = " << brow0 * rowb << "u + " << own << ";\n";
+            }
             for (std::uint32_t r = r0; r < r1; ++r) {
-                os << gname("ap", i, r) << " = *(const double *)(tpa - " << back << " + lo_" << r << ");\n";
-                os << gname("bp", i, r) << " = *(const double *)(tpb - " << back << " + lo_" << r << ");\n";
+                os << gname("ap", i, r) << " = HY_TLD(lo_" << r << ", sa);\n";
+                os << gname("bp", i, r) << " = HY_TLD(lo_" << r << ", sb);\n";
                 if (i >= M) {
-                    os << gname("al", i, r) << " = *(const double *)((const char *)tape + " << arow0 * rowb << "ull + " << own
-                       << " + lo_" << r << ");\n";
-                    os << gname("bl", i, r) << " = *(const double *)((const char *)tape + " << brow0 * rowb << "ull + " << own
-                       << " + lo_" << r << ");\n";
+                    os << gname("al", i, r) << " = HY_TLD(lo_" << r << ", oa);\n";
+                    os << gname("bl", i, r) << " = HY_TLD(lo_" << r << ", ob);\n";
                 }
             }
+            os << "}\n";
         };
         const auto emit_group = [&](std::uint32_t r0, std::uint32_t r1, std::uint32_t gi) {
             const auto Rg = r1 - r0;
@@ -997,6 +1006,15 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
             // Head: descriptors, the tape loads of slot 1, slot 0 (order-k differences x order-0 ones).
             for (std::uint32_t r = r0; r < r1; ++r) {
                 desc_loads(r);
+                for (std::uint32_t x = 0; x < n_ext; ++x) {
+                    // (The optimiser re-derives these from the packed word where they are used - one SDWA addition per read
+                    // of a dynamic row; pinning them in registers was measured: they end up in AGPRs and every read pays a
+                    // copy instead.)
+                    os << "const unsigned eo" << x << "_" << r << " = "
+                       << ((x % 2u == 0u) ? "dq_" + S(x / 2u) + "_" + S(r) + " & 0xffffu" : "dq_" + S(x / 2u) + "_" + S(r) + " >> 16")
+                       << ";\n";
+                    os << "const unsigned kx" << x << "_" << r << " = kbr + eo" << x << "_" << r << ";\n";
+                }
             }
             for (std::uint32_t i = 2; i <= D && i < T; ++i) {
                 tape_loads(i, r0, r1);
@@ -1085,8 +1103,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                     os << "if (live_" << r << ") {\n";
                 }
                 os << "if (k + 1u < " << P << "u) {\n";
-                os << "*(double *)((char *)tape + (u64)(" << arow0 << "u + k) * " << rowb << "ull + lo_" << r << ") = ak;\n";
-                os << "*(double *)((char *)tape + (u64)(" << brow0 << "u + k) * " << rowb << "ull + lo_" << r << ") = bk;\n";
+                os << "HY_TST(ak, lo_" << r << ", tpa);\nHY_TST(bk, lo_" << r << ", tpb);\n";
                 os << "}\n";
                 const std::string v[3] = {"sf0", "sf1", "sf2"};
                 store_out(r, v);
