@@ -264,6 +264,94 @@ def kepE(e, M):
     return _bin(lib.hy_expr_kepE, _as_ex(e), M)
 
 
+def kepF(h, k, lam):
+    """Eccentric longitude F(h, k, lam), F + h cos F - k sin F = lam (src/math/kepF.cpp:1689-1699). Defined through the
+    registry of node rules alone (csrc/builtin_rules.cpp)."""
+    h, k, lam = _as_ex(h), _as_ex(k), _as_ex(lam)
+    return expression._wrap(lib.hy_expr_kepF(h._h, k._h, lam._h))
+
+
+def kepDE(s0, c0, DM):
+    """Difference of eccentric anomalies DE(s0, c0, DM), DE - c0 sin DE + s0 (1 - cos DE) = DM
+    (src/math/kepDE.cpp:113-123). Defined through the registry of node rules alone (csrc/builtin_rules.cpp)."""
+    s0, c0, DM = _as_ex(s0), _as_ex(c0), _as_ex(DM)
+    return expression._wrap(lib.hy_expr_kepDE(s0._h, c0._h, DM._h))
+
+
+def custom_func(name, *args):
+    """f(args) of a function registered with register_node_rule(); not_implemented_error for an unknown name (reference:
+    func.hpp:266-267)."""
+    exs = [_as_ex(a) for a in args]
+    arr = (ctypes.c_void_p * len(exs))(*[e._h for e in exs]) if exs else None
+    return expression._wrap(lib.hy_expr_custom(name.encode(), arr, len(exs)))
+
+
+class _node_rule_desc(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char_p), ("n_args", ctypes.c_uint32), ("n_hidden", ctypes.c_uint32),
+                ("decompose", ctypes.c_void_p), ("ctx", ctypes.c_void_p), ("hidden_deps", ctypes.c_void_p),
+                ("deps", ctypes.c_void_p), ("n_deps", ctypes.c_uint32), ("hip_source", ctypes.c_char_p)]
+
+
+_DECOMPOSE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p),
+                                 ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p))
+_node_rule_keepalive = []
+
+
+def register_node_rule(name, n_args, hip_source, hidden=None, hidden_deps=(), deps=()):
+    """Register an elementary function with its Taylor rule - the counterpart of deriving from func_base in the reference
+    (include/heyoka/func.hpp:94-96, :117-147); see csrc/node_rule.hpp for the contract.
+
+    hidden(self, args, hidden_vars) -> list of expressions: the definitions of the hidden u variables appended behind the
+    node (each ONE elementary function of self, args, hidden_vars[j] with j below its own index); hidden_deps[j]: the
+    hidden dependencies of definition j (indices into that list); deps: those of the node itself, in the order
+    hy_rule_<name>_orderk() reads them. hip_source defines hy_rule_<name>_order0() and hy_rule_<name>_orderk()."""
+    n_hidden = len(hidden_deps) if hidden is not None else 0
+    if hidden is not None and n_hidden == 0:
+        raise ValueError("register_node_rule(): hidden_deps must list one (possibly empty) entry per hidden definition")
+    cb = None
+    if hidden is not None:
+        def tramp(_ctx, self_h, args_p, n, hid_p, out_p):
+            try:
+                res = hidden(_borrow(self_h), [_borrow(args_p[i]) for i in range(n)], [_borrow(hid_p[j]) for j in range(n_hidden)])
+                if len(res) != n_hidden:
+                    return 1
+                for j, e in enumerate(res):
+                    e = _as_ex(e)
+                    # The library takes ownership of what it finds in hidden_out: hand over a copy.
+                    out_p[j] = _clone_handle(e)
+                return 0
+            except Exception:  # noqa: BLE001 - reported as a failed decomposition by the library
+                return 1
+
+        cb = _DECOMPOSE_FN(tramp)
+        _node_rule_keepalive.append(cb)
+    hd = (ctypes.c_int32 * (4 * max(n_hidden, 1)))(*([-1] * (4 * max(n_hidden, 1))))
+    for j, lst in enumerate(hidden_deps):
+        for q, x in enumerate(lst):
+            hd[4 * j + q] = int(x)
+    dp = (ctypes.c_uint32 * max(len(deps), 1))(*[int(x) for x in deps]) if deps else None
+    d = _node_rule_desc(name.encode(), int(n_args), n_hidden, ctypes.cast(cb, ctypes.c_void_p) if cb else None, None,
+                        ctypes.cast(hd, ctypes.c_void_p), ctypes.cast(dp, ctypes.c_void_p) if dp else None, len(deps),
+                        hip_source.encode())
+    raise_for(lib.hy_node_rule_register(ctypes.byref(d)))
+
+
+def _borrow(h):
+    """A Python expression which shares the value of a handle owned by the library (an independent copy: the handle
+    itself is not adopted)."""
+    return expression(_handle=_clone_raw(h))
+
+
+def _clone_raw(h):
+    # x + 0 would fold; the product API has no copy entry point: sum([x]) of one term returns the term itself.
+    arr = (ctypes.c_void_p * 1)(h)
+    return check_handle(lib.hy_expr_sum(arr, 1))
+
+
+def _clone_handle(e):
+    return _clone_raw(e._h)
+
+
 def relu(x, slope=0.0):
     """relu(x, slope) = x > 0 ? x : slope * x (src/math/relu.cpp:580-590)."""
     x = _as_ex(x)

@@ -110,6 +110,10 @@ SIGNATURES = [
     ("hy_expr_sigmoid", c_void_p, [c_void_p]),
     ("hy_expr_atan2", c_void_p, [c_void_p, c_void_p]),
     ("hy_expr_kepE", c_void_p, [c_void_p, c_void_p]),
+    ("hy_expr_kepF", c_void_p, [c_void_p, c_void_p, c_void_p]),
+    ("hy_expr_kepDE", c_void_p, [c_void_p, c_void_p, c_void_p]),
+    ("hy_expr_custom", c_void_p, [c_char_p, c_void_p, c_size_t]),
+    ("hy_node_rule_register", c_int, [c_void_p]),
     ("hy_expr_relu", c_void_p, [c_void_p, c_double]),
     ("hy_expr_relup", c_void_p, [c_void_p, c_double]),
     ("hy_expr_select", c_void_p, [c_void_p, c_void_p, c_void_p]),

@@ -17,6 +17,7 @@
 #include "expression.hpp"
 #include "hip_backend.hpp"
 #include "model.hpp"
+#include "node_rule.hpp"
 #include "taylor_adaptive_batch.hpp"
 
 using namespace heyoka_amd;
@@ -258,6 +259,99 @@ hy_expr hy_expr_atan2(hy_expr y, hy_expr x)
 hy_expr hy_expr_kepE(hy_expr e, hy_expr M)
 {
     return make_expr([&] { return kepE(e->ex, M->ex); });
+}
+hy_expr hy_expr_kepF(hy_expr h, hy_expr k, hy_expr lam)
+{
+    return make_expr([&] { return kepF(h->ex, k->ex, lam->ex); });
+}
+hy_expr hy_expr_kepDE(hy_expr s0, hy_expr c0, hy_expr DM)
+{
+    return make_expr([&] { return kepDE(s0->ex, c0->ex, DM->ex); });
+}
+hy_expr hy_expr_custom(const char *name, const hy_expr *args, size_t n)
+{
+    return make_expr([&] {
+        std::vector<expression> v;
+        for (size_t i = 0; i < n; ++i) {
+            v.push_back(args[i]->ex);
+        }
+        return custom_func(name, std::move(v));
+    });
+}
+int hy_node_rule_register(const hy_node_rule_desc *d)
+{
+    try {
+        if (d == nullptr || d->name == nullptr || d->hip_source == nullptr) {
+            throw std::invalid_argument("hy_node_rule_register(): null descriptor, name or source");
+        }
+        if ((d->n_hidden != 0u) != (d->decompose != nullptr)) {
+            throw std::invalid_argument("hy_node_rule_register(): a decomposition callback is needed iff n_hidden != 0");
+        }
+        node_rule r;
+        r.name = d->name;
+        r.n_args = d->n_args;
+        r.hip_source = d->hip_source;
+        r.deps.assign(d->deps, d->deps + (d->deps == nullptr ? 0u : d->n_deps));
+        for (const auto x : r.deps) {
+            if (x >= d->n_hidden) {
+                throw std::invalid_argument("hy_node_rule_register(): a hidden dependency of the node is out of range");
+            }
+        }
+        if (d->n_hidden != 0u) {
+            const auto n_hidden = d->n_hidden;
+            const auto cb = d->decompose;
+            auto *const ctx = d->ctx;
+            std::vector<std::int32_t> hdeps(static_cast<std::size_t>(n_hidden) * 4u, -1);
+            if (d->hidden_deps != nullptr) {
+                hdeps.assign(d->hidden_deps, d->hidden_deps + static_cast<std::size_t>(n_hidden) * 4u);
+            }
+            const auto rname = r.name;
+            r.decompose = [n_hidden, cb, ctx, hdeps, rname](const expression &self, const std::vector<expression> &args,
+                                                            const std::function<expression(std::uint32_t)> &hidden) {
+                hy_expr_s self_h{self};
+                std::vector<hy_expr_s> arg_h, hid_h;
+                for (const auto &a : args) {
+                    arg_h.push_back(hy_expr_s{a});
+                }
+                for (std::uint32_t j = 0; j < n_hidden; ++j) {
+                    hid_h.push_back(hy_expr_s{hidden(j)});
+                }
+                std::vector<hy_expr> arg_p, hid_p, out(n_hidden, nullptr);
+                for (auto &x : arg_h) {
+                    arg_p.push_back(&x);
+                }
+                for (auto &x : hid_h) {
+                    hid_p.push_back(&x);
+                }
+                const auto rc = cb(ctx, &self_h, arg_p.data(), static_cast<std::uint32_t>(arg_p.size()), hid_p.data(), out.data());
+                std::vector<hidden_def> defs;
+                bool ok = rc == 0;
+                for (std::uint32_t j = 0; j < n_hidden; ++j) {
+                    if (out[j] == nullptr) {
+                        ok = false;
+                        continue;
+                    }
+                    hidden_def hd;
+                    hd.ex = out[j]->ex;
+                    for (unsigned q = 0; q < 4u; ++q) {
+                        if (hdeps[j * 4u + q] >= 0) {
+                            hd.deps.push_back(static_cast<std::uint32_t>(hdeps[j * 4u + q]));
+                        }
+                    }
+                    defs.push_back(std::move(hd));
+                    delete out[j];
+                }
+                if (!ok) {
+                    throw std::invalid_argument("The decomposition callback of the node rule '" + rname + "' failed");
+                }
+                return defs;
+            };
+        }
+        register_node_rule(std::move(r));
+        return HY_OK;
+    } catch (...) {
+        return handle_exception();
+    }
 }
 hy_expr hy_expr_relu(hy_expr x, double slope)
 {

@@ -69,7 +69,7 @@ std::string emit_cfunc_source(const taylor_program &p)
         }
     }
     std::ostringstream src;
-    src << emit_detail::prelude;
+    src << emit_detail::prelude << emit_detail::rules_source(p);
     src << R"HIP(
 struct hy_cf_args {
     double *out;

@@ -48,6 +48,7 @@ struct operand {
 
 struct dc_node {
     func_kind kind;
+    std::uint32_t rule = 0; // id of the node rule (kind == custom)
     std::vector<operand> args;
     std::vector<std::uint32_t> deps; // hidden dependencies (u-variable indices).
 };

@@ -1,5 +1,6 @@
 // Expression system implementation. See expression.hpp for the reference citations.
 #include "expression.hpp"
+#include "node_rule.hpp"
 
 #include <algorithm>
 #include <cassert>
@@ -90,6 +91,8 @@ const char *func_kind_name(func_kind k)
             return "erf";
         case func_kind::sigmoid:
             return "sigmoid";
+        case func_kind::custom:
+            return "custom";
     }
     return "?";
 }
@@ -115,12 +118,13 @@ std::size_t hash_double(double x)
 
 } // namespace
 
-func::func(func_kind k, std::vector<expression> args)
+func::func(func_kind k, std::vector<expression> args, std::uint32_t rule)
 {
     auto node = std::make_shared<func_node>();
     node->kind = k;
     node->args = std::move(args);
-    std::size_t h = std::hash<int>{}(static_cast<int>(k) + 17);
+    node->rule = rule;
+    std::size_t h = std::hash<int>{}(static_cast<int>(k) + 17 + static_cast<int>(rule) * 64);
     for (const auto &a : node->args) {
         hash_combine(h, a.hash());
     }
@@ -130,7 +134,12 @@ func::func(func_kind k, std::vector<expression> args)
 
 func func::copy_with_new_args(std::vector<expression> new_args) const
 {
-    return func(kind(), std::move(new_args));
+    return func(kind(), std::move(new_args), rule());
+}
+
+std::string func::name() const
+{
+    return kind() == func_kind::custom ? get_node_rule(rule()).name : std::string(func_kind_name(kind()));
 }
 
 std::size_t expression::hash() const
@@ -169,7 +178,8 @@ bool operator==(const expression &a, const expression &b)
             if (fa.get_ptr() == fb.get_ptr()) {
                 return true;
             }
-            if (fa.hash() != fb.hash() || fa.kind() != fb.kind() || fa.args().size() != fb.args().size()) {
+            if (fa.hash() != fb.hash() || fa.kind() != fb.kind() || fa.rule() != fb.rule()
+                || fa.args().size() != fb.args().size()) {
                 return false;
             }
             for (std::size_t i = 0; i < fa.args().size(); ++i) {
@@ -197,7 +207,7 @@ std::string expression::to_string() const
             break;
         default: {
             const auto &f = fn();
-            oss << func_kind_name(f.kind()) << '(';
+            oss << f.name() << '(';
             for (std::size_t i = 0; i < f.args().size(); ++i) {
                 if (i != 0u) {
                     oss << ", ";
@@ -551,81 +561,83 @@ HEYOKA_AMD_REL_FUNC(gte)
 #undef HEYOKA_AMD_REL_FUNC
 
 // --- Traversal. ---
-// Iterative post-order traversal replicating the visiting order of the reference
-// (src/detail/ex_traversal.cpp:35-180): arguments are pushed on the stack in order and thus
-// visited last-to-first; results are popped so that the argument order is preserved.
+// The distinct function nodes below root which are not done yet, every node behind its arguments; the arguments of a node
+// are taken from the LAST to the first (this is the order in which the reference numbers the u variables of a
+// decomposition, src/expression_decompose.cpp:43-210, and visits the nodes in its transformations,
+// src/detail/ex_traversal.cpp:35-180). A stack of (node, number of arguments already descended into).
+std::vector<const expression *> function_nodes_postorder(const expression &root,
+                                                         const std::function<bool(const void *)> &is_done)
+{
+    std::vector<const expression *> order;
+    if (!root.is_func() || is_done(root.fn().get_ptr())) {
+        return order;
+    }
+    std::set<const void *> finished;
+    struct frame {
+        const expression *node;
+        std::size_t descended;
+    };
+    std::vector<frame> path{{&root, 0u}};
+    while (!path.empty()) {
+        auto &top = path.back();
+        const auto &args = top.node->fn().args();
+        if (top.descended == args.size()) {
+            finished.insert(top.node->fn().get_ptr());
+            order.push_back(top.node);
+            path.pop_back();
+            continue;
+        }
+        const auto &next = args[args.size() - 1u - top.descended];
+        ++top.descended;
+        if (next.is_func()) {
+            const auto *id = next.fn().get_ptr();
+            if (finished.count(id) == 0u && !is_done(id)) {
+                path.push_back({&next, 0u});
+            }
+        }
+    }
+    return order;
+}
+
+// Bottom-up rebuild: the leaves through leaf_tfunc, every function node (with its rebuilt arguments) through
+// branch_tfunc; a node whose arguments did not change identity is not copied. cache: node identity -> result, shared by
+// the calls which belong together.
 expression traverse_transform_nodes(ptr_ex_map &cache, const expression &e,
                                     const std::function<expression(const expression &)> &leaf_tfunc,
                                     const std::function<expression(const expression &)> &branch_tfunc)
 {
-    std::vector<std::pair<const expression *, bool>> stack;
-    std::vector<std::optional<expression>> out_stack;
-
-    stack.emplace_back(&e, false);
-
-    while (!stack.empty()) {
-        const auto [cur_ex, visited] = stack.back();
-        stack.pop_back();
-
-        if (cur_ex->is_func()) {
-            const auto &f = cur_ex->fn();
-            const auto *f_id = f.get_ptr();
-
-            if (!visited) {
-                if (const auto it = cache.find(f_id); it != cache.end()) {
-                    out_stack.emplace_back(it->second);
-                    continue;
-                }
-            }
-
-            if (visited) {
-                std::vector<expression> new_args;
-                const auto n_args = f.args().size();
-                new_args.reserve(n_args);
-                for (std::size_t i = 0; i < n_args; ++i) {
-                    assert(!out_stack.empty() && out_stack.back());
-                    new_args.push_back(std::move(*out_stack.back()));
-                    out_stack.pop_back();
-                }
-
-                // Avoid creating a new node if no argument changed identity.
-                bool same = true;
-                for (std::size_t i = 0; i < n_args && same; ++i) {
-                    const auto &oa = f.args()[i];
-                    const auto &na = new_args[i];
-                    if (oa.is_func() && na.is_func()) {
-                        same = (oa.fn().get_ptr() == na.fn().get_ptr());
-                    } else if (oa.is_func() != na.is_func()) {
-                        same = false;
-                    } else {
-                        same = (oa == na);
-                    }
-                }
-
-                auto ex_copy = same ? *cur_ex : expression{f.copy_with_new_args(std::move(new_args))};
-
-                if (branch_tfunc) {
-                    ex_copy = branch_tfunc(ex_copy);
-                }
-
-                cache.emplace(f_id, ex_copy);
-
-                assert(!out_stack.empty() && !out_stack.back());
-                out_stack.back().emplace(std::move(ex_copy));
-            } else {
-                stack.emplace_back(cur_ex, true);
-                for (const auto &ex : f.args()) {
-                    stack.emplace_back(&ex, false);
-                }
-                out_stack.emplace_back();
-            }
-        } else {
-            out_stack.emplace_back(leaf_tfunc ? leaf_tfunc(*cur_ex) : *cur_ex);
-        }
+    if (!e.is_func()) {
+        return leaf_tfunc ? leaf_tfunc(e) : e;
     }
-
-    assert(out_stack.size() == 1u && out_stack.back());
-    return std::move(*out_stack.back());
+    const auto rebuilt = [&](const expression &a) -> expression {
+        if (a.is_func()) {
+            return cache.at(a.fn().get_ptr());
+        }
+        return leaf_tfunc ? leaf_tfunc(a) : a;
+    };
+    for (const auto *node : function_nodes_postorder(e, [&cache](const void *id) { return cache.count(id) != 0u; })) {
+        const auto &f = node->fn();
+        std::vector<expression> args;
+        args.reserve(f.args().size());
+        bool untouched = true;
+        for (const auto &a : f.args()) {
+            args.push_back(rebuilt(a));
+            const auto &b = args.back();
+            if (a.is_func() != b.is_func()) {
+                untouched = false;
+            } else if (a.is_func()) {
+                untouched = untouched && a.fn().get_ptr() == b.fn().get_ptr();
+            } else {
+                untouched = untouched && a == b;
+            }
+        }
+        auto result = untouched ? *node : expression{f.copy_with_new_args(std::move(args))};
+        if (branch_tfunc) {
+            result = branch_tfunc(result);
+        }
+        cache.emplace(f.get_ptr(), std::move(result));
+    }
+    return cache.at(e.fn().get_ptr());
 }
 
 namespace

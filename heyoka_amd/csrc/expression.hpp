@@ -70,7 +70,9 @@ enum class func_kind : std::uint8_t {
     rel_lt,
     rel_gt,
     rel_lte,
-    rel_gte
+    rel_gte,
+    // A function defined through the registry of node rules (node_rule.hpp): func::rule() identifies it.
+    custom
 };
 
 const char *func_kind_name(func_kind);
@@ -94,6 +96,7 @@ struct func_node {
     func_kind kind;
     std::vector<expression> args;
     std::size_t hash = 0;
+    std::uint32_t rule = 0; // id of the node rule (kind == custom), 0 otherwise
 };
 
 class func
@@ -101,7 +104,7 @@ class func
     std::shared_ptr<const func_node> m_ptr;
 
 public:
-    func(func_kind, std::vector<expression>);
+    func(func_kind, std::vector<expression>, std::uint32_t rule = 0);
 
     [[nodiscard]] func_kind kind() const
     {
@@ -111,6 +114,12 @@ public:
     {
         return m_ptr->args;
     }
+    [[nodiscard]] std::uint32_t rule() const
+    {
+        return m_ptr->rule;
+    }
+    // Name of the function (func_kind_name() for the built-in kinds, the rule's name for a custom function).
+    [[nodiscard]] std::string name() const;
     // Identity of the node (used by the traversal caches, reference: func::get_ptr()).
     [[nodiscard]] const void *get_ptr() const
     {
@@ -332,6 +341,11 @@ inline prime_wrapper prime(expression e)
 
 // --- Traversal helpers. ---
 using ptr_ex_map = std::unordered_map<const void *, expression>;
+
+// The distinct function nodes below root for which is_done() is false, arguments before the functions which use them, the
+// arguments of a node from the last to the first (the numbering order of the reference's decomposition).
+std::vector<const expression *> function_nodes_postorder(const expression &root,
+                                                         const std::function<bool(const void *)> &is_done);
 
 // Post-order transform of the function nodes of e (children first, in the reference's visiting order:
 // last argument first). Shared nodes are transformed once (reference: src/detail/ex_traversal.cpp:35-180).

@@ -717,7 +717,7 @@ std::uint64_t reg_jet_estimate(const taylor_program &p, std::uint32_t order)
 emitted_module emit_unrolled(const taylor_program &p, const emit_options &opts)
 {
     std::ostringstream src;
-    src << prelude;
+    src << prelude << rules_source(p);
     emit_dout(src, p, opts);
 
     emitted_module ret;
@@ -955,7 +955,7 @@ emitted_module emit_event_jets(const taylor_program &p, const emit_options &opts
     os << "a.last_h[s] = h;\na.max_abs_state[s] = " << m0 << ";\n}\n";
 
     std::ostringstream src;
-    src << emit_detail::prelude << os.str();
+    src << emit_detail::prelude << emit_detail::rules_source(p) << os.str();
     ret.source = src.str();
     ret.kernel_name = "hy_ev_jets";
     ret.block_size = 256;

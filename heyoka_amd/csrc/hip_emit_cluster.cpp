@@ -848,6 +848,11 @@ std::string make_plan_impl(const taylor_program &p, std::uint32_t order, cluster
 {
     using cluster_detail::glue_group;
     const auto n_eq = p.n_eq, n_u = p.n_u;
+    for (const auto &n : p.nodes) {
+        if (n.kind == func_kind::custom) {
+            return "functions defined through node rules run on the straight-line and interpreted steppers";
+        }
+    }
     pl.n_eq = n_eq;
     pl.n_u = n_u;
     // Constant u variables: only the wave-cluster generators (ssa_emitter-based) evaluate products with a constant

@@ -14,12 +14,25 @@
 #include <vector>
 
 #include "hip_emit.hpp"
+#include "node_rule.hpp"
 
 namespace heyoka_amd::emit_detail
 {
 
 // Common device-side prelude: argument block, double-length arithmetic, helpers.
 extern const char *const prelude;
+
+// The device code of the node rules a program uses (node_rule.hpp), to be emitted right behind the prelude.
+inline std::string rules_source(const taylor_program &p)
+{
+    std::vector<std::uint32_t> ids;
+    for (const auto &n : p.nodes) {
+        if (n.kind == func_kind::custom) {
+            ids.push_back(n.rule);
+        }
+    }
+    return node_rules_device_source(ids);
+}
 
 // Synchronisation of the LDS exchange between the lanes of ONE wavefront (a system never spans
 // wavefronts). The LDS pipeline executes the DS instructions of a wave in issue order, so a ds_write by
@@ -692,6 +705,50 @@ struct ssa_emitter {
                     dividend = def(dividend + " + " + conv_sum(std::move(terms)));
                 }
                 out = def(dividend + " / " + divisor);
+                break;
+            }
+            case func_kind::custom: {
+                // A function defined through the registry of node rules (node_rule.hpp): order 0 from the values of the
+                // arguments; order k from jets - here local arrays of the SSA values (the rule is force-inlined with a
+                // constant k: its loops unroll and the arrays dissolve into registers). Arguments: orders 0 .. k (a
+                // number / parameter: order 0 only), the node itself and its hidden dependencies: orders 0 .. k - 1.
+                const auto &rule = get_node_rule(n.rule);
+                const auto uid = std::to_string(counter++);
+                if (k == 0u) {
+                    os << "const double xr" << uid << "[] = {";
+                    for (std::size_t i2 = 0; i2 < a.size(); ++i2) {
+                        os << (i2 == 0u ? "" : ", ") << (is_var(a[i2]) ? val(a[i2].idx, 0) : numpar(a[i2]));
+                    }
+                    os << "};\n";
+                    out = def("hy_rule_" + rule.name + "_order0(xr" + uid + ")");
+                    break;
+                }
+                const auto arr = [&](const std::string &name, const std::function<std::string(std::uint32_t)> &coeff,
+                                     std::uint32_t n_valid) {
+                    os << "const double " << name << "[] = {";
+                    for (std::uint32_t j = 0; j < n_valid; ++j) {
+                        os << (j == 0u ? "" : ", ") << coeff(j);
+                    }
+                    os << "};\n";
+                    return "{" + name + ", 1u, " + std::to_string(n_valid) + "u}";
+                };
+                std::string xj, hj;
+                for (std::size_t i2 = 0; i2 < a.size(); ++i2) {
+                    const auto &o = a[i2];
+                    const auto nm = "xa" + uid + "_" + std::to_string(i2);
+                    xj += (i2 == 0u ? "" : ", ")
+                          + (is_var(o) ? arr(nm, [&](std::uint32_t j) { return val(o.idx, j); }, k + 1u)
+                                       : arr(nm, [&](std::uint32_t) { return numpar(o); }, 1u));
+                }
+                for (std::size_t i2 = 0; i2 < n.deps.size(); ++i2) {
+                    const auto d = n.deps[i2];
+                    hj += (i2 == 0u ? "" : ", ") + arr("ha" + uid + "_" + std::to_string(i2), [&](std::uint32_t j) { return val(d, j); }, k);
+                }
+                const auto self = arr("sa" + uid, [&](std::uint32_t j) { return val(u, j); }, k);
+                os << "const hy_jet xj" << uid << "[] = {" << xj << "};\n";
+                os << "const hy_jet hj" << uid << "[] = {" << (hj.empty() ? "{nullptr, 1u, 0u}" : hj) << "};\n";
+                out = def("hy_rule_" + rule.name + "_orderk(" + std::to_string(k) + "u, hy_jet" + self + ", xj" + uid + ", hj" + uid
+                          + ")");
                 break;
             }
             case func_kind::kepE: {

@@ -69,6 +69,7 @@ const char *table_device_code = R"HIP(
 #define K_REL_GT 34
 #define K_REL_LTE 35
 #define K_REL_GTE 36
+#define K_CUSTOM 37
 #define A_UVAR 0
 #define A_NUM 1
 #define A_PAR 2
@@ -489,6 +490,11 @@ __device__ double hy_diff_piecewise(const hy_tctx &c, unsigned kind, unsigned a0
     return r ? 1.0 : 0.0;
 }
 
+#if defined(HY_HAS_CUSTOM)
+// Functions defined through node rules (node_rule.hpp): generated per module behind this text (see emit_table()).
+__device__ double hy_custom_value(const hy_tctx &c, unsigned i, unsigned a0, unsigned nargs, unsigned u, unsigned k);
+#endif
+
 // Order-k coefficient of node i (u variable HY_N_EQ + i).
 __device__ double hy_node_value(const hy_tctx &c, unsigned i, unsigned k)
 {
@@ -517,6 +523,9 @@ __device__ double hy_node_value(const hy_tctx &c, unsigned i, unsigned k)
             case K_RELU: case K_RELUP: case K_SELECT: case K_LAND: case K_LOR: case K_REL_EQ: case K_REL_NEQ:
             case K_REL_LT: case K_REL_GT: case K_REL_LTE: case K_REL_GTE:
                 v = hy_diff_piecewise(c, hy_kind[i], a0, nargs, k); break;
+#if defined(HY_HAS_CUSTOM)
+            case K_CUSTOM: v = hy_custom_value(c, i, a0, nargs, u, k); break;
+#endif
             default: v = (k == 0u) ? hy_numpar(c, a0) : 0.0; break;
         }
         return v;
@@ -968,6 +977,8 @@ int kind_id(func_kind k)
             return 35;
         case func_kind::rel_gte:
             return 36;
+        case func_kind::custom:
+            return 37;
         default:
             return 11;
     }
@@ -992,7 +1003,7 @@ emitted_module emit_table(const taylor_program &p, const emit_options &opts)
     }
 
     std::ostringstream src;
-    src << emit_detail::prelude;
+    src << emit_detail::prelude << emit_detail::rules_source(p);
     emit_detail::emit_dout(src, p, opts);
     std::uint32_t n_levels = 0;
     if (wave_level) {
@@ -1084,7 +1095,59 @@ emitted_module emit_table(const taylor_program &p, const emit_options &opts)
         src << fp_literal(d.type == operand::kind::num ? d.value : 0.) << ",";
     }
     src << "0.0};\n";
-    src << table_device_code;
+    // Functions defined through node rules: their hidden dependencies (any number), the rule of every node, and the
+    // dispatcher which hands the rule its jets as strided views of the tape.
+    bool has_custom = false;
+    for (const auto &n : p.nodes) {
+        has_custom = has_custom || n.kind == func_kind::custom;
+    }
+    if (has_custom) {
+        std::ostringstream doff, dlist, rof;
+        std::size_t nd = 0;
+        doff << "0,";
+        std::vector<std::uint32_t> used;
+        for (const auto &n : p.nodes) {
+            if (n.kind == func_kind::custom) {
+                for (const auto d : n.deps) {
+                    dlist << d << ",";
+                    ++nd;
+                }
+                if (std::find(used.begin(), used.end(), n.rule) == used.end()) {
+                    used.push_back(n.rule);
+                }
+            }
+            doff << nd << ",";
+            rof << n.rule << ",";
+        }
+        src << "#define HY_HAS_CUSTOM 1\n";
+        src << "__device__ const unsigned hy_cdep_off[] = {" << doff.str() << "0};\n";
+        src << "__device__ const unsigned hy_cdep[] = {" << dlist.str() << "0};\n";
+        src << "__device__ const unsigned hy_rule_of[] = {" << rof.str() << "0};\n";
+        src << table_device_code;
+        const char *stride = wave_level ? "1u" : "64u";
+        src << "__device__ double hy_custom_value(const hy_tctx &c, unsigned i, unsigned a0, unsigned nargs, unsigned u, "
+               "unsigned k)\n{\n";
+        src << "double xv[8];\nhy_jet xj[8], hj[8];\n";
+        src << "for (unsigned a = 0; a < nargs && a < 8u; ++a) {\n"
+               "    if (hy_arg_type[a0 + a] == A_UVAR) {\n"
+               "        xj[a].p = &hy_tp(c, 0, hy_arg_idx[a0 + a]); xj[a].s = " << stride << "; xj[a].n = k + 1u; xv[a] = xj[a].p[0];\n"
+               "    } else {\n"
+               "        xv[a] = hy_numpar(c, a0 + a); xj[a].p = &xv[a]; xj[a].s = 1u; xj[a].n = 1u;\n"
+               "    }\n}\n";
+        src << "const unsigned d0 = hy_cdep_off[i], ndep = hy_cdep_off[i + 1u] - d0;\n";
+        src << "for (unsigned j = 0; j < ndep && j < 8u; ++j) { hj[j].p = &hy_tp(c, 0, hy_cdep[d0 + j]); hj[j].s = " << stride
+            << "; hj[j].n = k; }\n";
+        src << "hy_jet self; self.p = &hy_tp(c, 0, u); self.s = " << stride << "; self.n = k;\n";
+        src << "switch (hy_rule_of[i]) {\n";
+        for (const auto id : used) {
+            const auto &nm = get_node_rule(id).name;
+            src << "case " << id << "u: return (k == 0u) ? hy_rule_" << nm << "_order0(xv) : hy_rule_" << nm
+                << "_orderk(k, self, xj, hj);\n";
+        }
+        src << "default: return 0.0;\n}\n}\n";
+    } else {
+        src << table_device_code;
+    }
 
     emitted_module ret;
     ret.source = src.str();

@@ -93,6 +93,41 @@ hy_expr hy_expr_relup(hy_expr x, double slope);
 hy_expr hy_expr_select(hy_expr cond, hy_expr t, hy_expr f);
 hy_expr hy_expr_logical(int is_and, const hy_expr *args, size_t n);
 hy_expr hy_expr_rel(int op, hy_expr a, hy_expr b);
+/* ---- Node rules: the per-function extension seam (reference: func_base, include/heyoka/func.hpp:94-96, :117-147; a
+ * function without a Taylor rule raises not_implemented_error, func.hpp:266-267 -> HY_ERR_NOT_IMPLEMENTED here).
+ * A rule is the counterpart of a func_base subclass (heyoka_amd/csrc/node_rule.hpp):
+ *   - decompose(): fills hidden_out[0 .. n_hidden) with the definitions of the hidden u variables appended behind the node
+ *     (what a taylor_decompose() override appends by hand); each is ONE elementary function of `self` (the node), its
+ *     arguments and hidden_vars[j], j < own index. Returns 0 on success. The callee owns nothing: every handle it
+ *     creates and stores in hidden_out is released by the library.
+ *   - hidden_deps[4 * j .. 4 * j + 4): the hidden dependencies of hidden definition j (indices into the hidden
+ *     definitions, -1 = none), e.g. sin(self) <-> cos(self);
+ *   - deps[0 .. n_deps): the hidden dependencies of the node itself, in the order hy_rule_<name>_orderk() reads them;
+ *   - hip_source: HIP device code defining
+ *         double hy_rule_<name>_order0(const double *x);
+ *         double hy_rule_<name>_orderk(unsigned k, const hy_jet &a, const hy_jet *x, const hy_jet *h);
+ *     (the taylor_diff() / taylor_c_diff_func() pair of the reference: one text serves the straight-line generator, the
+ *     interpreted steppers and compiled functions). */
+typedef int (*hy_node_rule_decompose_fn)(void *ctx, hy_expr self, const hy_expr *args, uint32_t n_args,
+                                         const hy_expr *hidden_vars, hy_expr *hidden_out);
+typedef struct hy_node_rule_desc {
+    const char *name;
+    uint32_t n_args;
+    uint32_t n_hidden;
+    hy_node_rule_decompose_fn decompose; /* NULL iff n_hidden == 0 */
+    void *ctx;
+    const int32_t *hidden_deps; /* 4 * n_hidden entries, may be NULL if no hidden definition has dependencies */
+    const uint32_t *deps;
+    uint32_t n_deps;
+    const char *hip_source;
+} hy_node_rule_desc;
+int hy_node_rule_register(const hy_node_rule_desc *); /* HY_OK / HY_ERR_INVALID_ARGUMENT (duplicate, malformed) */
+/* f(args) of a registered rule; NULL + HY_ERR_NOT_IMPLEMENTED for an unknown name. */
+hy_expr hy_expr_custom(const char *name, const hy_expr *args, size_t n);
+/* Defined through the registry alone (csrc/builtin_rules.cpp): kepF(h, k, lam), F + h cos F - k sin F = lam
+ * (src/math/kepF.cpp:1689), and kepDE(s0, c0, DM), DE - c0 sin DE + s0 (1 - cos DE) = DM (src/math/kepDE.cpp:113). */
+hy_expr hy_expr_kepF(hy_expr h, hy_expr k, hy_expr lam);
+hy_expr hy_expr_kepDE(hy_expr s0, hy_expr c0, hy_expr DM);
 hy_expr hy_expr_sum(const hy_expr *, size_t n);  /* sum(vector)           src/math/sum.cpp:548 */
 hy_expr hy_expr_prod(const hy_expr *, size_t n); /* prod(vector)          src/math/prod.cpp:913 */
 void hy_expr_free(hy_expr);

@@ -84,6 +84,8 @@ KIND_IDS = {
     "rel_gt": 34,
     "rel_lte": 35,
     "rel_gte": 36,
+    "kepF": 37,
+    "kepDE": 38,
 }
 
 OC_SUCCESS = -4294967296 - 1
@@ -376,6 +378,30 @@ def kepE(e, M):
     if e.is_num() and e.val == 0:
         return M
     return func("kepE", [e, M])
+
+
+def kepF(h, k, lam):
+    """Eccentric longitude F(h, k, lam), F + h cos F - k sin F = lam (src/math/kepF.cpp:1689-1699): h = k = 0 gives lam."""
+    h, k, lam = as_ex(h), as_ex(k), as_ex(lam)
+    if h.is_num() and k.is_num() and h.val == 0 and k.val == 0:
+        return lam
+    return func("kepF", [h, k, lam])
+
+
+def kepDE(s0, c0, DM):
+    """DE(s0, c0, DM), DE - c0 sin DE + s0 (1 - cos DE) = DM (src/math/kepDE.cpp:113-123): s0 = c0 = 0 gives DM."""
+    s0, c0, DM = as_ex(s0), as_ex(c0), as_ex(DM)
+    if s0.is_num() and c0.is_num() and s0.val == 0 and c0.val == 0:
+        return DM
+    return func("kepDE", [s0, c0, DM])
+
+
+def inv_kep_F(h, k, lam):
+    return _lib().hy_oracle_inv_kep_F(float(h), float(k), float(lam))
+
+
+def inv_kep_DE(s0, c0, DM):
+    return _lib().hy_oracle_inv_kep_DE(float(s0), float(c0), float(DM))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -738,6 +764,21 @@ def taylor_decompose_sys(sys, sv_funcs=None):
             dc[ret][1].extend([ret + 3, ret + 1])
             dc[ret + 1][1].append(ret + 2)
             dc[ret + 2][1].append(ret + 1)
+        elif e.kind in ("kepF", "kepDE"):
+            # a -> sin a -> cos a -> (h sin a, k cos a) for kepF (src/math/kepF.cpp:110-156), (c0 cos a, s0 sin a) for
+            # kepDE; a depends on (c, d, sin a, cos a) in this order, sin and cos on each other.
+            dc.append((f, []))
+            ret = len(dc) - 1
+            ua = var(_uname(ret))
+            dc.append((sin(ua), [ret + 2]))
+            dc.append((cos(ua), [ret + 1]))
+            if e.kind == "kepF":
+                dc.append((new_args[0] * var(_uname(ret + 1)), []))
+                dc.append((new_args[1] * var(_uname(ret + 2)), []))
+            else:
+                dc.append((new_args[1] * var(_uname(ret + 2)), []))
+                dc.append((new_args[0] * var(_uname(ret + 1)), []))
+            dc[ret][1].extend([ret + 3, ret + 4, ret + 1, ret + 2])
         elif e.kind == "erf":
             dc.append((pow_(new_args[0], num(2.0)), []))
             dc.append((-var(_uname(len(dc) - 1)), []))
@@ -870,6 +911,8 @@ class _CProg(ctypes.Structure):
         ("sv_idx", ctypes.c_void_p),
         ("sv_val", ctypes.c_void_p),
         ("dep2", ctypes.c_void_p),
+        ("dep3", ctypes.c_void_p),
+        ("dep4", ctypes.c_void_p),
     ]
 
 
@@ -928,6 +971,9 @@ def _lib():
         _LIB.hy_oracle_max_threads.restype = ctypes.c_int
         _LIB.hy_oracle_inv_kep_E.restype = ctypes.c_double
         _LIB.hy_oracle_inv_kep_E.argtypes = [ctypes.c_double, ctypes.c_double]
+        for _n in ("hy_oracle_inv_kep_F", "hy_oracle_inv_kep_DE"):
+            getattr(_LIB, _n).restype = ctypes.c_double
+            getattr(_LIB, _n).argtypes = [ctypes.c_double] * 3
     return _LIB
 
 
@@ -967,7 +1013,7 @@ class OracleIntegrator:
         self._scratch = np.zeros(_lib().hy_oracle_scratch_size(ctypes.byref(self._prog), B) + 64)
 
     def _build_program(self):
-        kinds, arg_off, at, ai, av, dep, dep2 = [], [0], [], [], [], [], []
+        kinds, arg_off, at, ai, av, dep, dep2, dep3, dep4 = [], [0], [], [], [], [], [], [], []
         n_par = 0
         for ex, deps in self.dc[self.n_eq : self.n_u]:
             kinds.append(KIND_IDS[ex.kind])
@@ -981,6 +1027,8 @@ class OracleIntegrator:
             arg_off.append(len(at))
             dep.append(deps[0] if deps else -1)
             dep2.append(deps[1] if len(deps) > 1 else -1)
+            dep3.append(deps[2] if len(deps) > 2 else -1)
+            dep4.append(deps[3] if len(deps) > 3 else -1)
         svt, svi, svv = [], [], []
         for ex, _ in self.dc[self.n_u :]:
             t, i, v = _operand(ex)
@@ -1000,6 +1048,8 @@ class OracleIntegrator:
             arg_val=f64(av if av else [0.0]),
             dep=i32(dep if dep else [0]),
             dep2=i32(dep2 if dep2 else [0]),
+            dep3=i32(dep3 if dep3 else [0]),
+            dep4=i32(dep4 if dep4 else [0]),
             sv_type=i32(svt),
             sv_idx=i32(svi),
             sv_val=f64(svv),
@@ -1013,7 +1063,7 @@ class OracleIntegrator:
             # (bit 0: compensated summation; bit 1: the arithmetic of the reference's compact mode - running sums inside
             # the convolutions, see HY_COMPACT in taylor_oracle.c.)
             int(self.high_accuracy) | (2 if self.compact_mode else 0),
-            *[_p(self._arrs[k]) for k in ("kind", "arg_off", "arg_type", "arg_idx", "arg_val", "dep", "sv_type", "sv_idx", "sv_val", "dep2")]
+            *[_p(self._arrs[k]) for k in ("kind", "arg_off", "arg_type", "arg_idx", "arg_val", "dep", "sv_type", "sv_idx", "sv_val", "dep2", "dep3", "dep4")]
         )
 
     def program_ptr(self):

@@ -75,7 +75,9 @@ enum {
     K_REL_LT = 33,
     K_REL_GT = 34,
     K_REL_LTE = 35,
-    K_REL_GTE = 36
+    K_REL_GTE = 36,
+    K_KEPF = 37,
+    K_KEPDE = 38
 };
 
 enum { A_UVAR = 0, A_NUM = 1, A_PAR = 2 };
@@ -99,6 +101,8 @@ typedef struct {
     const int32_t *sv_idx;   /* [n_eq] */
     const double *sv_val;    /* [n_eq] */
     const int32_t *dep2;     /* [n_nodes], second hidden dependency (kepE), -1 if none */
+    const int32_t *dep3;     /* [n_nodes], third / fourth hidden dependencies (kepF, kepDE), -1 if none */
+    const int32_t *dep4;
 } hy_oracle_program;
 
 /* ---- helpers ---- */
@@ -284,6 +288,128 @@ static double inv_kep_E(double ecc_in, double M_in)
 double hy_oracle_inv_kep_E(double ecc, double M)
 {
     return inv_kep_E(ecc, M);
+}
+
+/* x mod 2 pi in [0, 2 pi) (llvm_trig_arg_reduce(), src/detail/llvm_helpers_celmec.cpp:140-177): the reduction used by
+ * inv_kep_E() above, as a function of its own for the two solvers below. */
+static double reduce_2pi(double x)
+{
+    const double y_hi = 6.283185307179586, y_lo = 2.4492935982947064e-16;
+    const double twopi_prev = nextafter(y_hi, 0.);
+    const double c = x / y_hi;
+    const double u = c * y_hi, uu = fma(c, y_hi, -u);
+    double cc = x - u;
+    cc = cc - uu;
+    cc = cc + 0.;
+    cc = cc - c * y_lo;
+    cc = cc / y_hi;
+    const double q_hi = c + cc, q_lo = (c - q_hi) + cc;
+    const double fhi = floor(q_hi);
+    const double flo = (fhi == q_hi) ? floor(q_lo) : 0.;
+    const double fl_hi = fhi + flo, fl_lo = (fhi - fl_hi) + flo;
+    const double pc = y_hi * fl_hi;
+    double pcc = fma(y_hi, fl_hi, -pc);
+    pcc = (y_hi * fl_lo + y_lo * fl_hi) + pcc;
+    const double p_hi = pc + pcc, p_lo = (pc - p_hi) + pcc;
+    const double x_hi = x, x_lo = 0., yh = -p_hi, yl = -p_lo;
+    const double S = x_hi + yh, T = x_lo + yl;
+    double e = S - x_hi, f = T - x_lo;
+    double t1 = S - e;
+    t1 = x_hi - t1;
+    double s_ = yh - e;
+    s_ = s_ + t1;
+    t1 = T - f;
+    t1 = x_lo - t1;
+    double t = yl - f;
+    t = t + t1;
+    s_ = s_ + T;
+    const double H = S + s_;
+    double h = S - H;
+    h = h + s_;
+    h = h + t;
+    double r = H + h;
+    r = (r < 0.) ? 0. : r;
+    r = (twopi_prev < r) ? twopi_prev : r;
+    return r;
+}
+
+/* Safeguarded Newton-Raphson iteration shared by the eccentric-longitude and delta-eccentric-anomaly solvers
+ * (llvm_add_inv_kep_F() / llvm_add_inv_kep_DE(), src/detail/llvm_helpers_celmec.cpp:540-856, :857-1170): bracket
+ * [-1, 2 pi + 1), absolute tolerance 4 eps on f and on the bracket, 20 iterations at most (then nan), result folded into
+ * [0, 2 pi). which = 0: f(F) = F - lam + h cos F - k sin F (p = h, q = k); which = 1: f(DE) = DE - DM + s0 (1 - cos DE)
+ * - c0 sin DE (p = s0, q = c0). */
+static double kep_newton(int which, double X, double T, double p, double q)
+{
+    const double twopi = 6.283185307179586;
+    double lb = -1., ub = nextafter(twopi + 1., 0.);
+    X = (X < lb) ? lb : X;
+    X = (ub < X) ? ub : X;
+    double sX = sin(X), cX = cos(X);
+#define KEP_F() (which == 0 ? (((X - T) + p * cX) - q * sX) : (((X - T) + p * (1. - cX)) - q * sX))
+#define KEP_DF() (which == 0 ? ((1. - p * sX) - q * cX) : ((1. + p * sX) - q * cX))
+    double fX = KEP_F();
+    const double tol = 4. * 2.220446049250313e-16;
+    int it = 0, not_converged = 0;
+    for (;;) {
+        const int sgn = (0. < fX) - (fX < 0.);
+        const double n_ub = (sgn >= 0) ? X : ub, n_lb = (sgn <= 0) ? X : lb;
+        ub = n_ub;
+        lb = n_lb;
+        not_converged = (fabs(fX) > tol) && ((ub - lb) > tol);
+        if (!(it < 20) || !not_converged) break;
+        double nX = X - fX / KEP_DF();
+        nX = (nX > ub) ? 0.5 * (X + ub) : nX;
+        nX = (nX < lb) ? 0.5 * (X + lb) : nX;
+        X = nX;
+        sX = sin(X);
+        cX = cos(X);
+        fX = KEP_F();
+        ++it;
+    }
+#undef KEP_F
+#undef KEP_DF
+    double ret = (it == 20 && not_converged) ? NAN : X;
+    ret = (ret < 0.) ? twopi + ret : ret;
+    ret = (ret >= twopi) ? ret - twopi : ret;
+    return ret;
+}
+
+static double inv_kep_F(double h_in, double k_in, double lam_in)
+{
+    const double h2 = h_in * h_in, k2 = k_in * k_in;
+    const int invalid = !(h2 + k2 < 1.);
+    const double h = invalid ? NAN : h_in, k = invalid ? NAN : k_in;
+    const double L = reduce_2pi(lam_in);
+    const double sL = sin(L), cL = cos(L);
+    const double ksL_m_hcL = k * sL - h * cL, kcL_p_hsL = k * cL + h * sL;
+    const double ig1 = L + ksL_m_hcL;
+    const double ig2 = (k2 - h2) * (cL * sL);
+    const double ig3 = (h * k) * (sL * sL - cL * cL);
+    const double ig4 = (0.5 * ksL_m_hcL) * ((kcL_p_hsL * kcL_p_hsL + kcL_p_hsL * kcL_p_hsL) - ksL_m_hcL * ksL_m_hcL);
+    return kep_newton(0, (ig1 + ig2) + (ig3 + ig4), L, h, k);
+}
+
+static double inv_kep_DE(double s0_in, double c0_in, double DM_in)
+{
+    const double s2 = s0_in * s0_in, c2 = c0_in * c0_in;
+    const int invalid = !(s2 + c2 < 1.);
+    const double s0 = invalid ? NAN : s0_in, c0 = invalid ? NAN : c0_in;
+    const double DM = reduce_2pi(DM_in);
+    const double sM = sin(DM), cM = cos(DM);
+    const double A = c0 * cM - s0 * sM, Bv = c0 * sM + s0 * cM;
+    const double C = Bv - s0;
+    const double ig1 = DM + C, ig2 = A * C, ig3 = (0.5 * C) * ((A * A + A * A) - C * Bv);
+    return kep_newton(1, (ig1 + ig2) + ig3, DM, s0, c0);
+}
+
+double hy_oracle_inv_kep_F(double h, double k, double lam)
+{
+    return inv_kep_F(h, k, lam);
+}
+
+double hy_oracle_inv_kep_DE(double s0, double c0, double DM)
+{
+    return inv_kep_DE(s0, c0, DM);
 }
 
 #define TAPE(k, u) (tape + ((size_t)(k) * n_u + (size_t)(u)) * B)
@@ -783,6 +909,65 @@ static void node_diff(const hy_oracle_program *p, int i, int k, double *tape, co
                 for (int l = 0; l < B; ++l) dividend[l] = dividend[l] + scratch[l];
             }
             for (int l = 0; l < B; ++l) out[l] = dividend[l] / (n * (1. - TAPE(0, c)[l]));
+            break;
+        }
+        case K_KEPF:
+        case K_KEPDE: {
+            /* a = kepF(h, k, lam) / kepDE(s0, c0, DM) with the hidden dependencies c (dep), d (dep2), e = sin a (dep3),
+             * f = cos a (dep4): c = h e, d = k f (src/math/kepF.cpp:110-156) resp. c = c0 f, d = s0 e. A numerical or
+             * parameter argument has no coefficients beyond order 0. kepF (src/math/kepF.cpp:633-711):
+             *   a^[n] = (n (k^[n] e^[0] - h^[n] f^[0] + lam^[n]) + sum_{j=1..n-1} j (a^[j] (c^[n-j] + d^[n-j]) + k^[j] e^[n-j]
+             *           - h^[j] f^[n-j])) / (n (1 - c^[0] - d^[0]));
+             * kepDE (same derivation from DE - c0 sin DE + s0 (1 - cos DE) = DM):
+             *   a^[n] = (n (DM^[n] - s0^[n] + c0^[n] e^[0] + s0^[n] f^[0]) + sum_{j=1..n-1} j (c0^[j] e^[n-j] + s0^[j] f^[n-j]
+             *           - a^[j] (d^[n-j] - c^[n-j]))) / (n (1 - c^[0] + d^[0])). */
+            const int isF = p->kind[i] == K_KEPF;
+            const int v0 = at[0] == A_UVAR, v1 = at[1] == A_UVAR, v2 = at[2] == A_UVAR;
+            if (k == 0) {
+                for (int l = 0; l < B; ++l) {
+                    const double x0 = v0 ? TAPE(0, ai[0])[l] : numpar(p, a0, pars, B, l);
+                    const double x1 = v1 ? TAPE(0, ai[1])[l] : numpar(p, a0 + 1, pars, B, l);
+                    const double x2 = v2 ? TAPE(0, ai[2])[l] : numpar(p, a0 + 2, pars, B, l);
+                    out[l] = isF ? inv_kep_F(x0, x1, x2) : inv_kep_DE(x0, x1, x2);
+                }
+                break;
+            }
+            const int c = p->dep[i], d = p->dep2[i], e = p->dep3[i], f = p->dep4[i];
+            const double n = (double)k;
+#define XC(arg, ord, l) ((at[arg] == A_UVAR) ? TAPE(ord, ai[arg])[l] : 0.)
+            double *dividend = scratch + (size_t)(p->order + 2) * B;
+            for (int l = 0; l < B; ++l) {
+                if (isF) {
+                    dividend[l] = n * ((XC(1, k, l) * TAPE(0, e)[l] - XC(0, k, l) * TAPE(0, f)[l]) + XC(2, k, l));
+                } else {
+                    dividend[l] = n * (((XC(2, k, l) - XC(0, k, l)) + XC(1, k, l) * TAPE(0, e)[l]) + XC(0, k, l) * TAPE(0, f)[l]);
+                }
+            }
+            if (k > 1) {
+                for (int j = 1; j < k; ++j) {
+                    double *t = scratch + (size_t)(j - 1) * B;
+                    for (int l = 0; l < B; ++l) {
+                        const double aj = TAPE(j, u)[l];
+                        const double cnj = TAPE(k - j, c)[l], dnj = TAPE(k - j, d)[l], enj = TAPE(k - j, e)[l], fnj = TAPE(k - j, f)[l];
+                        if (isF) {
+                            const double t1 = aj * (cnj + dnj);
+                            const double t2 = XC(1, j, l) * enj - XC(0, j, l) * fnj;
+                            t[l] = (double)j * (t1 + t2);
+                        } else {
+                            const double t1 = XC(1, j, l) * enj + XC(0, j, l) * fnj;
+                            const double t2 = aj * (dnj - cnj);
+                            t[l] = (double)j * (t1 - t2);
+                        }
+                    }
+                }
+                conv_sum(p, scratch, k - 1, B);
+                for (int l = 0; l < B; ++l) dividend[l] = dividend[l] + scratch[l];
+            }
+#undef XC
+            for (int l = 0; l < B; ++l) {
+                const double den = isF ? ((1. - TAPE(0, c)[l]) - TAPE(0, d)[l]) : ((1. - TAPE(0, c)[l]) + TAPE(0, d)[l]);
+                out[l] = dividend[l] / (n * den);
+            }
             break;
         }
         case K_RELU:

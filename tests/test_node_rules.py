@@ -1,0 +1,232 @@
+"""The registry of node rules - the per-function extension seam (reference: func_base,
+include/heyoka/func.hpp:94-96, :117-147, not_implemented_error :266-267).
+
+kepF and kepDE exist ONLY as registered rules (heyoka_amd/csrc/builtin_rules.cpp: no generator, planner or decomposition
+pass mentions them). Their jets are checked against tests/golden/kep_rule_jets.json (40-digit numerical differentiation of
+the defining equations, tests/golden/make_kep_rule_jets.py - no recurrence involved) for the oracle (CPU) and for the HIP
+path in the straight-line generator and both interpreted steppers (GPU); steps and propagations against the oracle; a rule
+registered from Python through the C ABI (hy_node_rule_register) runs through the same code paths."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import heyoka_oracle as ho
+from conftest import EPS
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "kep_rule_jets.json")) as _f:
+    G = json.load(_f)
+
+
+def build(m, name):
+    if m is ho:
+        x, y = m.var("x"), m.var("y")
+    else:
+        x, y = m.make_vars("x", "y")
+    F, D = m.kepF, m.kepDE
+    rhs = {
+        "kepF_var_var_var": (F(0.05 * x, 0.04 * y, 0.3 * x + 0.1 * y), F(0.03 * y, 0.06 * x, 0.2 * y)),
+        "kepF_num_mixed": (F(0.3, 0.04 * y, 0.25 * x), F(0.03 * y, 0.2, 1.5) + 0.1 * x),
+        "kepF_num_num_var": (F(0.3, -0.2, 0.2 * y), F(0.05 * x, 0.04 * y, 0.7)),
+        "kepDE_var_var_var": (D(0.05 * x, 0.04 * y, 0.3 * x + 0.1 * y), D(0.03 * y, 0.06 * x, 0.2 * y)),
+        "kepDE_num_mixed": (D(0.3, 0.04 * y, 0.25 * x), D(0.03 * y, -0.2, 0.9) + 0.1 * x),
+        "kepF_of_kepDE": (F(0.05 * x, 0.1, D(0.1, 0.04 * y, 0.2 * x)), 0.2 * y - 0.1 * x),
+    }[name]
+    return [(x, rhs[0]), (y, rhs[1])]
+
+
+def check(tc, case, tol=100):
+    exp = np.transpose(np.array(case["jets"]), (2, 1, 0))  # [var][order][lane]
+    err = np.abs(tc - exp) / np.maximum(np.abs(exp), 1e-300)
+    err[exp == 0] = np.abs(tc)[exp == 0]
+    assert np.max(err) <= tol * EPS, (case["name"], float(np.max(err)) / EPS)
+
+
+@pytest.mark.parametrize("case", G["cases"], ids=[c["name"] for c in G["cases"]])
+def test_oracle_jets_of_the_kepler_rules(case):
+    ta = ho.OracleIntegrator(build(ho, case["name"]), G["state"], 3, tol=G["tol"])
+    assert ta.order == G["order"]
+    ta.step(wtc=True)
+    check(ta.tc.reshape(2, G["order"] + 1, 3), case)
+
+
+def test_solvers_of_the_oracle_satisfy_the_defining_equations():
+    rng = np.random.RandomState(5)
+    for _ in range(200):
+        h, k = rng.uniform(-0.65, 0.65, 2)
+        lam = rng.uniform(-20, 20)
+        F = ho.inv_kep_F(h, k, lam)
+        assert 0 <= F < 2 * np.pi
+        lam_r = np.mod(lam, 2 * np.pi)
+        r = (F + h * np.cos(F) - k * np.sin(F) - lam_r + np.pi) % (2 * np.pi) - np.pi
+        assert abs(r) < 20 * EPS * 2 * np.pi
+        D = ho.inv_kep_DE(h, k, lam)
+        r = (D - k * np.sin(D) + h * (1 - np.cos(D)) - lam_r + np.pi) % (2 * np.pi) - np.pi
+        assert abs(r) < 20 * EPS * 2 * np.pi
+    assert np.isnan(ho.inv_kep_F(0.8, 0.7, 1.0)) and np.isnan(ho.inv_kep_DE(0.8, 0.7, 1.0))
+
+
+def test_decompositions_match_the_oracle_and_the_reference_layout():
+    import heyoka_amd as hy
+
+    for case in G["cases"]:
+        ta = hy.taylor_adaptive_batch(build(hy, case["name"]), None, 3, tol=G["tol"])
+        ora = ho.OracleIntegrator(build(ho, case["name"]), G["state"], 3, tol=G["tol"])
+        assert len(ta.decomposition) == len(ora.dc), case["name"]
+        for a, (ex, deps) in zip(ta.decomposition, ora.dc):
+            kind = a.split("(")[0] if "(" in a else None
+            assert kind == (ex.kind if ex.tag == "func" else None), (case["name"], a)
+            got = [int(t.split("]")[0]) for t in a.split("[dep ")[1:]]
+            assert got == list(deps), (case["name"], a, deps)
+    # kepF(h, k, lam): F, sin F, cos F, h sin F, k cos F behind each other, F reading (h sin F, k cos F, sin F, cos F)
+    # (src/math/kepF.cpp:110-156).
+    x, y = hy.make_vars("x", "y")
+    dc = hy.taylor_adaptive_batch([(x, hy.kepF(x, y, x)), (y, x)], None, 1).decomposition
+    assert dc[2:7] == ["kepF(u_0, u_1, u_0) [dep 5] [dep 6] [dep 3] [dep 4]", "sin(u_2) [dep 4]", "cos(u_2) [dep 3]",
+                       "prod(u_0, u_3)", "prod(u_1, u_4)"], dc
+    # Constant folding at construction (src/math/kepF.cpp:1689-1699, src/math/kepDE.cpp:113-123).
+    assert str(hy.kepF(0.0, 0.0, x)) == "x" and str(hy.kepDE(0.0, 0.0, y)) == "y"
+
+
+def test_registry_error_behaviour_and_a_rule_registered_from_python():
+    import heyoka_amd as hy
+
+    x, y = hy.make_vars("x", "y")
+    with pytest.raises(Exception) as ei:
+        hy.custom_func("no_such_function", x)
+    assert "not implemented" in str(ei.value)
+    with pytest.raises(Exception):
+        hy.custom_func("kepF", x, y)  # wrong number of arguments
+    with pytest.raises(Exception):
+        hy.register_node_rule("kepF", 3, "hy_rule_kepF_order0 hy_rule_kepF_orderk")  # duplicate
+    with pytest.raises(Exception):
+        hy.register_node_rule("sin", 1, "hy_rule_sin_order0 hy_rule_sin_orderk")  # built-in name
+    with pytest.raises(Exception):
+        hy.register_node_rule("incomplete", 1, "static __device__ double hy_rule_incomplete_order0(const double *x);")
+    _register_cube_root()
+    ta = hy.taylor_adaptive_batch([(x, hy.custom_func("cbrt3", y)), (y, -x)], None, 4)
+    dc = ta.decomposition
+    assert dc[2] == "prod(-1, u_0)" and dc[3].startswith("cbrt3(u_1) [dep 4]") and dc[4] == "pow(u_3, 2)", dc
+    assert "hy_rule_cbrt3_orderk" in ta.hip_source
+
+
+_CBRT_DONE = []
+
+
+def _register_cube_root():
+    """a = x^(1/3) as a user rule with one hidden definition, a^2: 3 a^2 a' = x', i.e.
+    a^[k] = (x^[k] - sum_{j=1..k-1} (j / k) ... ) - written with the hidden square s = a^2:
+    k x^[k] = 3 sum_{j=1..k} j a^[j] s^[k-j]  ->  a^[k] = (k x^[k] / 3 - sum_{j=1..k-1} j a^[j] s^[k-j]) / (k s^[0])."""
+    if _CBRT_DONE:
+        return
+    import heyoka_amd as hy
+
+    src = r"""
+static __device__ double hy_rule_cbrt3_order0(const double *x) { return cbrt(x[0]); }
+static __device__ __forceinline__ double hy_rule_cbrt3_orderk(unsigned k, const hy_jet &a, const hy_jet *x, const hy_jet *h)
+{
+    double acc = 0.0;
+    for (unsigned j = 1; j < k; ++j) acc += (double)j * (hy_jc(a, j) * hy_jc(h[0], k - j));
+    return ((double)k * hy_jc(x[0], k) / 3.0 - acc) / ((double)k * hy_jc(h[0], 0));
+}
+"""
+    hy.register_node_rule("cbrt3", 1, src, hidden=lambda self, args, hid: [hy.pow(self, 2.0)], hidden_deps=[[]], deps=[0])
+    _CBRT_DONE.append(1)
+
+
+def _modes():
+    return [("default", {}), ("table-wave", {"HEYOKA_AMD_EMIT_MODE": "table", "HEYOKA_AMD_TABLE_LDS": "1"}),
+            ("table-hbm", {"HEYOKA_AMD_EMIT_MODE": "table", "HEYOKA_AMD_TABLE_LDS": "0"})]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [m[0] for m in _modes()])
+def test_gpu_jets_of_the_kepler_rules(mode, monkeypatch):
+    import heyoka_amd as hy
+
+    for k, v in dict(_modes())[mode].items():
+        monkeypatch.setenv(k, v)
+    for case in G["cases"]:
+        ta = hy.taylor_adaptive_batch(build(hy, case["name"]), G["state"], 3, tol=G["tol"])
+        assert ta.order == G["order"]
+        assert ("table" in ta.hip_source_mode) == (mode != "default"), ta.hip_source_mode
+        ta.step(write_tc=True)
+        # (500 eps: one order-3 coefficient of kepF_of_kepDE is 7e-6, the difference of terms of 1e-2 - with contracted
+        # multiply-adds its relative error is 113 eps on the GPU, 60 in the strict-IEEE oracle.)
+        check(np.asarray(ta.tc).reshape(2, G["order"] + 1, 3), case, tol=500)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [m[0] for m in _modes()])
+def test_gpu_steps_and_propagation_with_the_kepler_rules_vs_oracle(mode, monkeypatch):
+    """Full order (20): steps and a propagation of a system built on both rules, argument kinds mixed, against the oracle:
+    step sizes to 1e4 eps, states to 1e5 eps (the tolerances of the reference's own batch tests,
+    test/two_body_batch.cpp:118-150)."""
+    import heyoka_amd as hy
+
+    for k, v in dict(_modes())[mode].items():
+        monkeypatch.setenv(k, v)
+    n = 96
+    rng = np.random.RandomState(11)
+    st = np.stack([rng.uniform(0.5, 2.5, n), rng.uniform(1.0, 4.0, n), rng.uniform(-0.5, 0.5, n)])
+    pars = np.stack([rng.uniform(0.05, 0.3, n)])
+
+    def sys_of(m):
+        if m is ho:
+            x, y, z = m.var("x"), m.var("y"), m.var("z")
+            p0 = m.par(0)
+        else:
+            x, y, z = m.make_vars("x", "y", "z")
+            p0 = m.par[0]
+        return [(x, m.kepF(0.1 * y, p0, x + z) - 1.0), (y, m.sin(m.kepDE(0.1 * z, 0.2, x)) - 0.3 * y),
+                (z, 0.1 * m.kepF(p0, 0.05, 0.5 * y) - z)]
+
+    ta = hy.taylor_adaptive_batch(sys_of(hy), st, n, pars=pars)
+    ora = ho.OracleIntegrator(sys_of(ho), st.reshape(-1), n, pars=pars.reshape(-1))
+    for _ in range(3):
+        ta.step()
+        ora.step()
+        h_g = np.array([h for _, h in ta.step_res])
+        h_o = np.array([h for _, h in ora.step_res])
+        assert np.max(np.abs(h_g - h_o) / h_o) <= 1e4 * EPS
+        ref = ora.state.reshape(3, n)
+        assert np.max(np.abs(ta.state - ref) / np.maximum(1.0, np.abs(ref))) <= 1e5 * EPS
+    ta.propagate_until(2.0)
+    ora.propagate_until(2.0)
+    assert all(int(r[0]) == ho.OC_TIME_LIMIT for r in ta.propagate_res)
+    assert max(abs(a[3] - b[3]) for a, b in zip(ta.propagate_res, ora.prop_res)) <= 1
+    ref = ora.state.reshape(3, n)
+    assert np.max(np.abs(ta.state - ref) / np.maximum(1.0, np.abs(ref))) <= 1e6 * EPS
+
+
+@pytest.mark.gpu
+def test_gpu_rule_registered_from_python_and_compiled_function():
+    """x' = cbrt3(y), y' = 1 with y(0) = 1: x(t) = x0 + 3/4 ((1 + t)^(4/3) - 1); the same rule inside a compiled
+    function; kepF / kepDE in a compiled function against the oracle's solvers."""
+    import heyoka_amd as hy
+
+    _register_cube_root()
+    x, y = hy.make_vars("x", "y")
+    for env in ({}, {"HEYOKA_AMD_EMIT_MODE": "table"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            ta = hy.taylor_adaptive_batch([(x, hy.custom_func("cbrt3", y)), (y, 1.0 + 0.0 * x)], [[0.0] * 4, [1.0] * 4], 4)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+        ta.propagate_until(1.5)
+        exact = 0.75 * (2.5 ** (4.0 / 3.0) - 1.0)
+        assert np.max(np.abs(ta.state[0] - exact)) <= 100 * EPS * exact
+    cf = hy.cfunc([hy.kepF(0.1 * x, 0.2, y), hy.kepDE(0.3, 0.1 * x, y), hy.custom_func("cbrt3", x + y)], [x, y])
+    inp = np.array([[0.5, 1.5, 2.5, -1.0], [0.3, 2.0, 4.0, 5.5]])
+    out = np.asarray(cf(inp))
+    for l in range(4):
+        assert abs(out[0, l] - ho.inv_kep_F(0.1 * inp[0, l], 0.2, inp[1, l])) <= 50 * EPS * 2 * np.pi
+        assert abs(out[1, l] - ho.inv_kep_DE(0.3, 0.1 * inp[0, l], inp[1, l])) <= 50 * EPS * 2 * np.pi
+        assert abs(out[2, l] - np.cbrt(inp[0, l] + inp[1, l])) <= 10 * EPS * 2
