@@ -298,72 +298,54 @@ expression operator/(const expression &a, const expression &b)
     return prod({a, pow(b, expression{-1.})});
 }
 
-// Reference: src/math/sum.cpp:548-601.
-expression sum(std::vector<expression> args)
+namespace
 {
-    // Numbers to the end, fold them left to right.
-    const auto n_end_it
-        = std::stable_partition(args.begin(), args.end(), [](const expression &ex) { return !ex.is_number(); });
 
-    if (n_end_it != args.end()) {
-        for (auto it = n_end_it + 1; it != args.end(); ++it) {
-            *n_end_it = expression{n_end_it->num() + it->num()};
+// sum() and prod() share their canonical form (src/math/sum.cpp:548-601, src/math/prod.cpp:913-973): the numerical
+// arguments are combined, in their order of appearance, into ONE number which leads the remaining arguments (these keep
+// their order); a number equal to the neutral element is dropped, and for products a zero swallows everything. No
+// arguments left: the neutral element; one: that argument itself, without a function around it.
+expression commutative(func_kind kind, const std::vector<expression> &args, double neutral, bool zero_absorbs,
+                       double (*combine)(double, double))
+{
+    std::vector<expression> rest;
+    rest.reserve(args.size() + 1u);
+    bool any_number = false;
+    double folded = neutral;
+    for (const auto &a : args) {
+        if (a.is_number()) {
+            folded = any_number ? combine(folded, a.num()) : a.num();
+            any_number = true;
+        } else {
+            rest.push_back(a);
         }
-        args.erase(n_end_it + 1, args.end());
-
-        if (n_end_it->num() == 0) {
-            if (args.size() == 1u) {
-                return std::move(*n_end_it);
-            }
-            args.pop_back();
-        }
     }
-
-    if (args.empty()) {
-        return expression{0.};
+    if (any_number && zero_absorbs && folded == 0) {
+        return expression{folded};
     }
-    if (args.size() == 1u) {
-        return std::move(args[0]);
+    const bool keep_number = any_number && !(folded == neutral);
+    if (rest.empty()) {
+        return expression{any_number ? folded : neutral};
     }
-
-    // Numbers to the front (semi-canonical form).
-    std::stable_partition(args.begin(), args.end(), [](const expression &ex) { return ex.is_number(); });
-
-    return detail::make_func(func_kind::sum, std::move(args));
+    if (!keep_number && rest.size() == 1u) {
+        return rest[0];
+    }
+    if (keep_number) {
+        rest.insert(rest.begin(), expression{folded});
+    }
+    return detail::make_func(kind, std::move(rest));
 }
 
-// Reference: src/math/prod.cpp:913-973.
+} // namespace
+
+expression sum(std::vector<expression> args)
+{
+    return commutative(func_kind::sum, args, 0., false, [](double x, double y) { return x + y; });
+}
+
 expression prod(std::vector<expression> args)
 {
-    const auto n_end_it
-        = std::stable_partition(args.begin(), args.end(), [](const expression &ex) { return !ex.is_number(); });
-
-    if (n_end_it != args.end()) {
-        for (auto it = n_end_it + 1; it != args.end(); ++it) {
-            *n_end_it = expression{n_end_it->num() * it->num()};
-        }
-        args.erase(n_end_it + 1, args.end());
-
-        if (n_end_it->num() == 1) {
-            if (args.size() == 1u) {
-                return std::move(*n_end_it);
-            }
-            args.pop_back();
-        } else if (n_end_it->num() == 0) {
-            return std::move(*n_end_it);
-        }
-    }
-
-    if (args.empty()) {
-        return expression{1.};
-    }
-    if (args.size() == 1u) {
-        return std::move(args[0]);
-    }
-
-    std::stable_partition(args.begin(), args.end(), [](const expression &ex) { return ex.is_number(); });
-
-    return detail::make_func(func_kind::prod, std::move(args));
+    return commutative(func_kind::prod, args, 1., true, [](double x, double y) { return x * y; });
 }
 
 // Reference: src/math/pow.cpp:1024-1062.
