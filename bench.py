@@ -413,11 +413,19 @@ def run_workload(ctx, workload, n, steps, warmup):
                 # Both views, whichever binds.
                 "fp64_valu_frac": achieved_tflops / FP64_PEAK_TFLOPS,
                 "hbm_tape_model_frac": achieved_gbs / HBM_PEAK_GBS,
+                # (> 1 in the tape model means the jets never travel: they live in registers / LDS - not skipped work.)
+                "tape_on_chip": bool(on_chip),
                 "hbm_measured_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
             },
         }
         out["_dt"] = dt
 
+    # Any rank's failed gather fails the job (every rank learns it: the exit status is decided in main()).
+    if distributed:
+        flag = torch.tensor([1.0 if gather_err is not None else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        out = {} if out is None else out
+        out["_gather_failed"] = bool(flag.item() != 0.0)
     del ta, view, nsteps_view
     torch.cuda.empty_cache()
     return out
@@ -444,7 +452,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    # (A process group also for ONE rank when the launcher set up a rendezvous - `torch.distributed.run --nproc-per-node 1`:
+    # RCCL's all-gather then runs on a single-GPU box as well; a plain `python bench.py` stays without a group.)
+    distributed = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
     if distributed:
         import torch.distributed as dist
 
@@ -475,6 +485,7 @@ def main():
                distributed=distributed, dev=dev, dev_index=dev_index)
     n = args.systems if args.systems > 0 else DEFAULT_SYSTEMS[args.workload]
     out = run_workload(ctx, args.workload, n, args.steps, args.warmup)
+    gather_failed = bool(out.pop("_gather_failed", False)) if out is not None else False
     if rank == 0:
         if world == 1 and not args.no_extra_workloads and args.workload == "outer_ss":
             # The other two single-GPU measurement points of BASELINE.json (configs 3 and 5) as short legs of the same run,
@@ -486,7 +497,7 @@ def main():
                 try:
                     r = run_workload(ctx, wl, DEFAULT_SYSTEMS[wl], st_, wu_)
                     leg = {k: r[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline")}
-                    if wl == "two_body" and not args.no_cpu_baseline:
+                    if not args.no_cpu_baseline:
                         leg["cpu_baseline"] = cpu_baseline(wl, r["_dt"], 5.0)
                     extra.append(leg)
                 except Exception as e:  # an auxiliary leg must never cost the headline line
@@ -500,6 +511,10 @@ def main():
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if distributed and gather_failed:
+        # The collective of the multi-GPU path is part of what a run with a process group has to prove: the line above
+        # carries the error text, the exit status fails the run.
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -1354,3 +1354,20 @@ def ensemble_propagate_until_batch(ta, t, n_iter, gen, max_steps=0, n_devices=0)
 def ensemble_propagate_for_batch(ta, delta_t, n_iter, gen, max_steps=0, n_devices=0):
     """ensemble_propagate_for_batch() (include/heyoka/ensemble_propagate.hpp:239-254)."""
     return _ensemble(lib.hy_ensemble_propagate_for_batch, ta, delta_t, n_iter, gen, max_steps, n_devices)
+
+
+def ensemble_gather_states(tas, dst_device=0):
+    """The final states of a list of integrators (e.g. the result of ensemble_propagate_*_batch(), each copy on the device
+    which propagated it) gathered into one host array (dim, sum of the batch sizes) - the native gather behind the C ABI
+    (hy_ensemble_gather_states(): RCCL over xGMI between devices, device-to-device copies on one). Returns (array,
+    used_rccl)."""
+    tas = list(tas)
+    if not tas:
+        return np.zeros((0, 0)), False
+    n_total = int(np.sum([t.batch_size for t in tas]))
+    out = np.empty((tas[0].dim, n_total))
+    arr = (ctypes.c_void_p * len(tas))(*[t._h for t in tas])
+    used = ctypes.c_int(0)
+    raise_for(lib.hy_ensemble_gather_states(arr, len(tas), int(dst_device), out.ctypes.data_as(ctypes.c_void_p), out.size, 0,
+                                            ctypes.byref(used)))
+    return out, bool(used.value)

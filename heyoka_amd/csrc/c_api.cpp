@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 
+#include <hip/hip_runtime_api.h>
 #include <hip/hiprtc.h>
 
 #include "cfunc.hpp"
@@ -1379,6 +1380,38 @@ int hy_ensemble_propagate_for_batch(hy_tab ta, double dt, size_t n_iter, hy_ense
                                     uint64_t max_steps, int n_devices, hy_tab *out)
 {
     return ensemble_impl(ta, dt, n_iter, gen, gen_data, max_steps, n_devices, out, detail::ensemble_kind::for_);
+}
+
+int hy_ensemble_gather_states(const hy_tab *tabs, size_t n, int dst_device, double *out, size_t out_doubles,
+                              int out_is_device, int *used_rccl)
+{
+    try {
+        std::vector<detail::tab_core *> cores;
+        for (size_t i = 0; i < n; ++i) {
+            cores.push_back(&tabs[i]->core);
+        }
+        const auto g = detail_gather(cores, dst_device);
+        if (out_doubles < g.dim() * g.n_total()) {
+            throw std::invalid_argument("hy_ensemble_gather_states(): the output buffer holds " + std::to_string(out_doubles)
+                                        + " doubles, " + std::to_string(g.dim() * g.n_total()) + " are needed");
+        }
+        if (used_rccl != nullptr) {
+            *used_rccl = g.used_rccl() ? 1 : 0;
+        }
+        if (g.n_total() != 0u) {
+            if (out_is_device != 0) {
+                if (hipMemcpy(out, g.data(), g.dim() * g.n_total() * sizeof(double), hipMemcpyDeviceToDevice) != hipSuccess) {
+                    throw std::runtime_error("heyoka_amd: copy of the gathered states failed");
+                }
+            } else {
+                const auto h = g.to_host();
+                std::memcpy(out, h.data(), h.size() * sizeof(double));
+            }
+        }
+        return HY_OK;
+    } catch (...) {
+        return handle_exception();
+    }
 }
 
 } // extern "C"

@@ -101,3 +101,197 @@ std::vector<tab_core> ensemble_propagate_core(const tab_core &ta, double t, std:
 }
 
 } // namespace heyoka_amd::detail
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Gather of the final states (see ensemble.hpp).
+// ---------------------------------------------------------------------------------------------------------------------
+#include <dlfcn.h>
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+namespace heyoka_amd
+{
+
+namespace
+{
+
+void hip_ok(hipError_t e, const char *what)
+{
+    if (e != hipSuccess) {
+        throw std::runtime_error(std::string("heyoka_amd: ") + what + " failed: " + hipGetErrorString(e));
+    }
+}
+
+// The handful of RCCL entry points used, resolved at run time (the library is not linked: the single-GPU path has no use
+// for it, and the C ABI must load on machines without it).
+struct rccl_api {
+    using comm_t = void *;
+    int (*CommInitAll)(comm_t *, int, const int *) = nullptr;
+    int (*CommDestroy)(comm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, std::size_t, int, int, comm_t, hipStream_t) = nullptr;
+    int (*Recv)(void *, std::size_t, int, int, comm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+
+const rccl_api &rccl()
+{
+    static const rccl_api api = [] {
+        rccl_api a;
+        void *h = nullptr;
+        for (const auto *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (h != nullptr) {
+                break;
+            }
+        }
+        if (h == nullptr) {
+            return a;
+        }
+        const auto sym = [h](const char *n) { return dlsym(h, n); };
+        a.CommInitAll = reinterpret_cast<decltype(a.CommInitAll)>(sym("ncclCommInitAll"));
+        a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+        a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(sym("ncclGroupStart"));
+        a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(sym("ncclGroupEnd"));
+        a.Send = reinterpret_cast<decltype(a.Send)>(sym("ncclSend"));
+        a.Recv = reinterpret_cast<decltype(a.Recv)>(sym("ncclRecv"));
+        a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+        a.ok = a.CommInitAll != nullptr && a.CommDestroy != nullptr && a.GroupStart != nullptr && a.GroupEnd != nullptr
+               && a.Send != nullptr && a.Recv != nullptr;
+        return a;
+    }();
+    return api;
+}
+
+void nccl_ok(int rc, const char *what)
+{
+    if (rc != 0) {
+        const auto &a = rccl();
+        throw std::runtime_error(std::string("heyoka_amd: RCCL ") + what + " failed: "
+                                 + (a.GetErrorString != nullptr ? std::string(a.GetErrorString(rc)) : std::to_string(rc)));
+    }
+}
+
+// A 2D copy (dim rows of n doubles) into the columns [off, off + n) of the result.
+void place_block(double *dst, std::size_t n_total, std::size_t off, const double *src, std::size_t n, std::size_t dim,
+                 hipStream_t stream)
+{
+    hip_ok(hipMemcpy2DAsync(dst + off, n_total * sizeof(double), src, n * sizeof(double), n * sizeof(double), dim,
+                            hipMemcpyDefault, stream),
+           "hipMemcpy2DAsync (gather)");
+}
+
+} // namespace
+
+ensemble_gathered detail_gather(const std::vector<detail::tab_core *> &tabs, int dst_device)
+{
+    ensemble_gathered g;
+    g.m_device = dst_device;
+    if (tabs.empty()) {
+        return g;
+    }
+    g.m_dim = tabs[0]->get_dim();
+    for (auto *t : tabs) {
+        if (t->get_dim() != g.m_dim) {
+            throw std::invalid_argument("Cannot gather the states of integrators of different dimensions");
+        }
+        t->synchronize();
+        g.m_off.push_back(g.m_total);
+        g.m_total += t->get_batch_size();
+    }
+    g.m_buf = device_buffer(g.m_dim * g.m_total * sizeof(double), dst_device);
+    auto *const out = g.m_buf.as<double>();
+
+    // Which devices take part (the destination is rank 0).
+    std::vector<int> devs{dst_device};
+    for (auto *t : tabs) {
+        if (std::find(devs.begin(), devs.end(), t->get_device()) == devs.end()) {
+            devs.push_back(t->get_device());
+        }
+    }
+    const char *force = std::getenv("HEYOKA_AMD_GATHER_RCCL");
+    const bool want_rccl = force != nullptr ? std::atoi(force) != 0 : devs.size() > 1u;
+    bool done = false;
+    if (want_rccl && rccl().ok) {
+        const auto &a = rccl();
+        const auto nd = static_cast<int>(devs.size());
+        std::vector<rccl_api::comm_t> comms(devs.size(), nullptr);
+        nccl_ok(a.CommInitAll(comms.data(), nd, devs.data()), "ncclCommInitAll");
+        std::vector<hipStream_t> streams(devs.size(), nullptr);
+        std::vector<device_buffer> staging; // contiguous landing blocks on the destination, one per integrator
+        const auto cleanup = [&]() {
+            for (std::size_t d = 0; d < devs.size(); ++d) {
+                (void)hipSetDevice(devs[d]);
+                if (streams[d] != nullptr) {
+                    (void)hipStreamDestroy(streams[d]);
+                }
+                if (comms[d] != nullptr) {
+                    (void)a.CommDestroy(comms[d]);
+                }
+            }
+        };
+        try {
+            for (std::size_t d = 0; d < devs.size(); ++d) {
+                hip_ok(hipSetDevice(devs[d]), "hipSetDevice");
+                hip_ok(hipStreamCreateWithFlags(&streams[d], hipStreamNonBlocking), "hipStreamCreate");
+            }
+            const auto rank_of = [&](int dev) {
+                return static_cast<std::size_t>(std::find(devs.begin(), devs.end(), dev) - devs.begin());
+            };
+            for (auto *t : tabs) {
+                staging.emplace_back(g.m_dim * t->get_batch_size() * sizeof(double), dst_device);
+            }
+            constexpr int nccl_f64 = 8; // ncclFloat64 (ncclDataType_t, nccl.h)
+            nccl_ok(a.GroupStart(), "ncclGroupStart");
+            for (std::size_t i = 0; i < tabs.size(); ++i) {
+                const auto cnt = g.m_dim * tabs[i]->get_batch_size();
+                const auto r = rank_of(tabs[i]->get_device());
+                nccl_ok(a.Send(tabs[i]->device_state(), cnt, nccl_f64, 0, comms[r], streams[r]), "ncclSend");
+                nccl_ok(a.Recv(staging[i].get(), cnt, nccl_f64, static_cast<int>(r), comms[0], streams[0]), "ncclRecv");
+            }
+            nccl_ok(a.GroupEnd(), "ncclGroupEnd");
+            hip_ok(hipSetDevice(dst_device), "hipSetDevice");
+            for (std::size_t i = 0; i < tabs.size(); ++i) {
+                place_block(out, g.m_total, g.m_off[i], staging[i].as<double>(), tabs[i]->get_batch_size(), g.m_dim,
+                            streams[0]);
+            }
+            for (std::size_t d = 0; d < devs.size(); ++d) {
+                hip_ok(hipSetDevice(devs[d]), "hipSetDevice");
+                hip_ok(hipStreamSynchronize(streams[d]), "hipStreamSynchronize");
+            }
+            done = true;
+            g.m_rccl = true;
+        } catch (...) {
+            cleanup();
+            throw;
+        }
+        cleanup();
+    }
+    if (!done) {
+        // Device-to-device copies (unified addressing: the runtime routes peer copies over xGMI).
+        hip_ok(hipSetDevice(dst_device), "hipSetDevice");
+        for (std::size_t i = 0; i < tabs.size(); ++i) {
+            place_block(out, g.m_total, g.m_off[i], static_cast<const double *>(tabs[i]->device_state()),
+                        tabs[i]->get_batch_size(), g.m_dim, nullptr);
+        }
+        hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    }
+    return g;
+}
+
+std::vector<double> ensemble_gathered::to_host() const
+{
+    std::vector<double> ret(m_dim * m_total);
+    if (!ret.empty()) {
+        m_buf.download(ret.data(), ret.size() * sizeof(double), nullptr);
+    }
+    return ret;
+}
+
+} // namespace heyoka_amd

@@ -18,6 +18,7 @@
 #include <tuple>
 #include <vector>
 
+#include "hip_backend.hpp"
 #include "taylor_adaptive_batch.hpp"
 
 namespace heyoka_amd
@@ -35,6 +36,70 @@ std::vector<tab_core> ensemble_propagate_core(const tab_core &ta, double t, std:
 int ensemble_visible_devices();
 
 } // namespace detail
+
+// The final states of the integrators of an ensemble, gathered into ONE buffer on one device:
+// data()[row * n_total() + offset(i) + lane] = state row `row`, lane `lane` of integrator i. The reference's
+// ensemble_propagate_*() leaves its results in host memory next to each other (src/ensemble_propagate.cpp:193-297);
+// here the iterations finish on (up to) 8 devices, and a caller of the drop-in who wants the ensemble in one place asks
+// for it with kw::gather = &g (or ensemble_gather_states() / C ABI hy_ensemble_gather_states()).
+// Transport: RCCL over xGMI (librccl loaded at run time: one communicator per device of the process,
+// ncclSend / ncclRecv of every integrator's state block inside one group, then a strided placement on the destination)
+// when there is more than one device or HEYOKA_AMD_GATHER_RCCL=1; device-to-device copies otherwise (and as the fallback
+// when librccl is not available).
+class ensemble_gathered
+{
+public:
+    ensemble_gathered() = default;
+    [[nodiscard]] const double *data() const
+    {
+        return m_buf.as<double>();
+    }
+    [[nodiscard]] int device() const
+    {
+        return m_device;
+    }
+    [[nodiscard]] std::size_t dim() const
+    {
+        return m_dim;
+    }
+    [[nodiscard]] std::size_t n_total() const
+    {
+        return m_total;
+    }
+    [[nodiscard]] std::size_t offset(std::size_t i) const
+    {
+        return m_off.at(i);
+    }
+    [[nodiscard]] bool used_rccl() const
+    {
+        return m_rccl;
+    }
+    [[nodiscard]] std::vector<double> to_host() const;
+
+private:
+    friend ensemble_gathered detail_gather(const std::vector<detail::tab_core *> &, int);
+    device_buffer m_buf;
+    int m_device = 0;
+    std::size_t m_dim = 0, m_total = 0;
+    std::vector<std::size_t> m_off;
+    bool m_rccl = false;
+};
+ensemble_gathered detail_gather(const std::vector<detail::tab_core *> &, int dst_device);
+
+// Gather the states of a range of integrators (e.g. the first tuple elements of an ensemble_propagate_*_batch() result).
+template <typename Range>
+ensemble_gathered ensemble_gather_states(Range &tas, int dst_device = 0)
+{
+    std::vector<detail::tab_core *> cores;
+    for (auto &x : tas) {
+        if constexpr (requires { x.core(); }) {
+            cores.push_back(&x.core());
+        } else {
+            cores.push_back(&std::get<0>(x).core());
+        }
+    }
+    return detail_gather(cores, dst_device);
+}
 
 // Reference signatures: ensemble_propagate_{until,for,grid}_batch(ta, t | delta_t | grid, n_iter, gen, kw...)
 // (include/heyoka/ensemble_propagate.hpp:222-271) with
@@ -158,6 +223,9 @@ auto ensemble_propagate_tmpl(const taylor_adaptive_batch<double> &ta, const Time
             res[i] = tas[i].propagate_grid(grid, kw::max_steps = max_steps, kw::max_delta_t = max_delta_ts,
                                            kw::callback = cb);
         });
+        if constexpr (kw::has_v<kw::gather_tag, KwArgs...>) {
+            *kw::get(kw::gather, 0, kw_args...) = ensemble_gather_states(tas, 0);
+        }
         std::vector<std::tuple<taylor_adaptive_batch<double>, step_callback_batch<double>, std::vector<double>>> ret;
         ret.reserve(n_iter);
         for (std::size_t i = 0; i < n_iter; ++i) {
@@ -188,6 +256,9 @@ auto ensemble_propagate_tmpl(const taylor_adaptive_batch<double> &ta, const Time
             }
         } else {
             ensemble_run_per_device(n_iter, n_dev, run);
+        }
+        if constexpr (kw::has_v<kw::gather_tag, KwArgs...>) {
+            *kw::get(kw::gather, 0, kw_args...) = ensemble_gather_states(tas, 0);
         }
         std::vector<std::tuple<taylor_adaptive_batch<double>, std::optional<continuous_output_batch<double>>,
                                step_callback_batch<double>>>

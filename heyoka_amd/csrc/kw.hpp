@@ -87,6 +87,9 @@ HEYOKA_AMD_KWARG(exact_division);
 HEYOKA_AMD_KWARG(sum_order);
 HEYOKA_AMD_KWARG(events_on_cluster);
 HEYOKA_AMD_KWARG(batch_semantics);
+// ensemble_propagate_*_batch(): kw::gather = &g (ensemble_gathered *) collects the final states of all the iterations in one
+// buffer on device 0 (RCCL over xGMI between devices, see ensemble.hpp).
+HEYOKA_AMD_KWARG(gather);
 
 #undef HEYOKA_AMD_KWARG
 

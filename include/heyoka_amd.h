@@ -469,6 +469,16 @@ int hy_ensemble_propagate_until_batch(hy_tab ta, double t, size_t n_iter, hy_ens
                                       uint64_t max_steps, int n_devices, hy_tab *out);
 int hy_ensemble_propagate_for_batch(hy_tab ta, double delta_t, size_t n_iter, hy_ensemble_gen gen, void *gen_data,
                                     uint64_t max_steps, int n_devices, hy_tab *out);
+/* The final states of n integrators (e.g. the copies returned above, each on the device which propagated it) gathered
+ * into ONE buffer: out[row * n_total + offset_i + lane], n_total = sum of the batch sizes, offset_i = sum of those of the
+ * integrators before i; out is host memory (out_is_device = 0) or memory of device dst_device. Between devices the
+ * blocks travel through RCCL (librccl loaded at run time: ncclSend / ncclRecv over xGMI inside one group; set
+ * HEYOKA_AMD_GATHER_RCCL=1 to take that route on a single device too, =0 to force plain device-to-device copies, which are
+ * also the fallback when librccl is absent). *used_rccl (may be NULL) reports the route taken. The reference returns the
+ * iterations in host memory of one process (src/ensemble_propagate.cpp:193-297): this is how a caller of the drop-in gets
+ * the 8-GPU ensemble in one place. */
+int hy_ensemble_gather_states(const hy_tab *tabs, size_t n, int dst_device, double *out, size_t out_doubles,
+                              int out_is_device, int *used_rccl);
 
 #ifdef __cplusplus
 }

@@ -405,6 +405,28 @@ int main(int argc, char **argv)
         }
     }
 
+    // kw::gather: the final states of all the iterations in one buffer on device 0 (device-to-device copies on one GPU;
+    // RCCL send / receive between devices - forced on the single device here through HEYOKA_AMD_GATHER_RCCL=1).
+    for (const char *route : {"0", "1"}) {
+        setenv("HEYOKA_AMD_GATHER_RCCL", route, 1);
+        ensemble_gathered g;
+        auto ret_g = ensemble_propagate_until_batch(tp, 20., 5, gen, kw::gather = &g);
+        unsetenv("HEYOKA_AMD_GATHER_RCCL");
+        REQUIRE(g.dim() == 2u && g.n_total() == 5u * tp.get_batch_size());
+        REQUIRE(g.used_rccl() == (route[0] == '1'));
+        const auto h = g.to_host();
+        for (auto i = 0u; i < 5u; ++i) {
+            const auto &st_i = std::get<0>(ret_g[i]).get_state();
+            const auto bs = tp.get_batch_size();
+            for (auto r = 0u; r < 2u; ++r) {
+                for (auto l = 0u; l < bs; ++l) {
+                    REQUIRE(h[r * g.n_total() + g.offset(i) + l] == st_i[r * bs + l]);
+                }
+            }
+            REQUIRE(st_i == std::get<0>(ret[i]).get_state());
+        }
+    }
+
     // Every kwarg of the reference is forwarded; the continuous output slot is filled on request.
     auto ret2 = ensemble_propagate_for_batch(tp, 2., 3, gen, kw::c_output = true, kw::max_delta_t = 0.5,
                                              kw::write_tc = true);

@@ -186,3 +186,74 @@ def test_bench_py_two_ranks_on_one_gpu_prints_the_contract_line():
     assert abs(per_step_total / (2 * d["config"]["system_steps_per_launch"]) - 1) < 0.05
     if d["config"]["untimed_final_state_all_gather_error"] is None:
         assert d["config"]["gathered_systems"] == 2 * n
+
+
+@pytest.mark.gpu
+def test_rccl_executes_on_one_rank_sharded_driver_and_bench():
+    """The collective of the multi-GPU path with the REAL backend: a one-rank `nccl` process group (RCCL) on this GPU -
+    all_gather / all_gather_into_tensor on the integrator's device views through ensemble_propagate_until_sharded(), and
+    bench.py launched the way the driver launches it (`torch.distributed.run --nproc-per-node 1 ... --backend nccl`), whose
+    exit status now fails on a failed gather."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import heyoka_amd as hy
+from heyoka_amd import configs, ensemble as hens
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl"
+M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+g = configs.outer_ss_state(96, perturb=1e-8, seed=17)
+mk = lambda n: hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), None, n, high_accuracy=True, device=0)
+ta, st, meta = hens.ensemble_propagate_until_sharded(mk, g, 6.0, device="cuda:0")
+assert st.is_cuda and st.shape == (36, 96) and meta.dtype == torch.int64
+assert np.array_equal(st.cpu().numpy(), ta.state)
+# Unequal shard sizes take the padded all_gather branch: exercise it with a ragged tensor as well.
+r = hens.all_gather_states(torch.arange(10, dtype=torch.float64, device="cuda:0").reshape(2, 5))
+assert r.shape == (2, 5)
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_ONE_RANK_OK")
+""" % root
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert out.returncode == 0 and "RCCL_ONE_RANK_OK" in out.stdout, out.stderr[-3000:]
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--systems", "8192", "--backend", "nccl", "--no-cpu-baseline", "--no-extra-workloads"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["config"]["untimed_final_state_all_gather_error"] is None
+    assert d["config"]["gathered_systems"] == 8192 and d["config"]["untimed_final_state_all_gather_ms"] is not None
+
+
+@pytest.mark.gpu
+def test_native_gather_behind_the_c_abi_with_and_without_rccl(monkeypatch):
+    """hy_ensemble_gather_states(): the final states of the copies returned by ensemble_propagate_until_batch() in one
+    buffer - by device-to-device copies, and through RCCL (ncclCommInitAll + grouped ncclSend / ncclRecv, forced here on
+    the one device of the box: the route the copies take between the 8 GPUs of a node)."""
+    import heyoka_amd as hy
+    from heyoka_amd import configs
+
+    n, n_iter = 64, 5
+    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    states = [configs.outer_ss_state(n, perturb=1e-8, seed=100 + i) for i in range(n_iter)]
+    ta = hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), states[0], n, high_accuracy=True)
+
+    def gen(copy, i):
+        copy.state = states[i]
+
+    res = hy.ensemble_propagate_until_batch(ta, 4.0, n_iter, gen, n_devices=-2)
+    expect = np.concatenate([r.state for r in res], axis=1)
+    for force, want in (("0", False), ("1", True)):
+        monkeypatch.setenv("HEYOKA_AMD_GATHER_RCCL", force)
+        got, used = hy.ensemble_gather_states(res)
+        assert used is want, (force, used)
+        assert got.shape == (36, n * n_iter) and np.array_equal(got, expect)
