@@ -151,6 +151,12 @@ struct tab_core::impl {
         device_copy(d_tlo.get(), snap_tlo.get(), d_tlo.bytes(), device, stream);
         dev_newer = true;
         host_newer = false;
+        // With a host pointer handed out (get_state_data(), hy_tab_set_state(), the Python state setter) the host mirrors
+        // are refreshed after every launch and re-uploaded before the next one: they hold the state at the END of the
+        // rolled-back propagation, which would overwrite the restored snapshot in the re-run. Bring them back as well.
+        if (sticky_host_ptr || sticky_const_refs) {
+            to_host();
+        }
     }
     // Continuous output produced by the last propagate_for/until() with c_output = true.
     std::optional<c_out_core> last_c_out;
@@ -2391,6 +2397,13 @@ void tab_core::set_device(int device)
     d.d_counters = {};
     d.d_dout = {};
     d.d_douth = {};
+    // (The rollback snapshot lives on the old device too; a pending step-limit fix-up / forced lock-step flag belonged to a
+    // propagation which has been fetched above.)
+    d.snap_state = {};
+    d.snap_thi = {};
+    d.snap_tlo = {};
+    d.fix_step_limit = false;
+    d.force_lockstep = false;
     // The auxiliary modules (event detection, post-step kernels of the lock-step loops) and the event buffers belong to
     // the old device as well: they are recreated on first use. A caller-provided stream belonged to the old device:
     // back to the default stream of the new one (set_stream() again if needed).

@@ -1442,6 +1442,31 @@ def test_reference_batch_semantics(semantics):
 
 
 @pytest.mark.gpu
+def test_rollback_of_a_batch_with_a_nonfinite_lane_when_the_state_was_set_through_the_setter():
+    """Advisor finding (round 3): with the state written through the setter (hy_tab_set_state / ta.state = ..., which keeps
+    the host mirrors in step with the device after every launch) the rollback of a batch with a diverging lane restored
+    the device buffers only - the forced lock-step re-run then uploaded the END state of the rolled-back propagation over
+    the snapshot. The healthy lanes must come out as in the oracle's lock-step loop, exactly like with the state passed to
+    the constructor."""
+    x, v = hy.make_vars("x", "v")
+    ox, ov = ho.var("x"), ho.var("v")
+    st = np.array([[1.0, 0.5, -1.0, 0.0], [1.0, 1.0, 1.0, 1.0]])
+    ref = hy.taylor_adaptive_batch([(x, x * x), (v, -v)], st, 4)
+    ref.propagate_until(3.0)
+    ta = hy.taylor_adaptive_batch([(x, x * x), (v, -v)], np.zeros((2, 4)), 4)
+    ta.state = st  # the setter: sticky host pointer
+    ta.propagate_until(3.0)
+    ora = ho.OracleIntegrator([(ox, ox * ox), (ov, -1.0 * ov)], st, 4)
+    ora.propagate_until(3.0)
+    assert [int(r[0]) for r in ta.propagate_res] == [int(r[0]) for r in ora.prop_res]
+    assert [int(r[3]) for r in ta.propagate_res] == [int(r[3]) for r in ora.prop_res]
+    ok_l = np.all(np.isfinite(ora.state.reshape(2, 4)), axis=0)
+    assert np.array_equal(np.asarray(ta.time)[ok_l], np.asarray(ref.time)[ok_l])
+    assert np.array_equal(ta.state[:, ok_l], ref.state[:, ok_l])
+    assert np.allclose(ta.state[:, ok_l], ora.state.reshape(2, 4)[:, ok_l], rtol=1e-10)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("sum_order", ["pairwise", "running"])
 def test_unrolled_kernel_is_bit_identical_to_the_oracle_without_contraction(sum_order, monkeypatch):
     """The unrolled generator keeps the reference's operation order inside the convolutions, in either of its two forms
