@@ -431,6 +431,47 @@ def run_workload(ctx, workload, n, steps, warmup):
     return out
 
 
+def divergence_leg(ctx, n, t_span=60.0):
+    """Heterogeneous step counts: the headline ensemble is 1e-12-perturbed copies which all take the same
+    number of steps. Here: outer Solar System with 1e-2 relative perturbations and PER-LANE final times T * U(0.5, 1.5), against
+    the same perturbed ensemble with the common final time T; one untimed + two timed launches each, kernel time from the HIP
+    events around the launch. Reference behaviour for comparison: the lanes of a batch run in lock step and idle until the
+    slowest is done (src/taylor_adaptive_batch.cpp:1378-1460)."""
+    torch, hy, configs = ctx["torch"], ctx["hy"], ctx["configs"]
+    sys_ = hy.model.nbody(6, masses=configs.OUTER_SS_MASSES, Gconst=configs.OUTER_SS_G)
+    st = configs.outer_ss_state(n, perturb=1e-2, seed=4242)
+    rng = np.random.RandomState(99)
+    frac = rng.uniform(0.5, 1.5, n)
+    res = {}
+    for name, per_lane in (("uniform", False), ("divergent", True)):
+        ta = hy.taylor_adaptive_batch(sys_, st, n, high_accuracy=True, device=ctx["dev_index"])
+        rates, spread = [], None
+        t_prev = np.zeros(n)
+        for k in range(3):
+            t_fin = t_prev + t_span * (frac if per_lane else 1.0)
+            ta.propagate_until(t_fin if per_lane else float(t_fin[0]))
+            oc, _, _, ns = ta.propagate_res_arrays()
+            ms = list(ta.kernel_ms_history(1))[-1]
+            if k > 0:
+                rates.append(float(ns.sum()) / (ms * 1e-3))
+                spread = [int(ns.min()), float(ns.mean()), int(ns.max())]
+            t_prev = t_fin
+        res[name] = {"value": float(np.mean(rates)), "steps_per_system_min_mean_max": spread,
+                     "all_outcomes_time_limit": bool(np.all(oc == int(hy.taylor_outcome.time_limit)))}
+        del ta
+        torch.cuda.empty_cache()
+    return {
+        "config": {"workload": "outer_ss_divergent: %d ICs, relative perturbation 1e-2, per-lane final times T * U(0.5, 1.5), "
+                               "T = %g; compared with the same ensemble and a common final time" % (n, t_span),
+                   "systems_per_gpu": n},
+        "unit": "system-steps/s", "value": res["divergent"]["value"], "uniform_value": res["uniform"]["value"],
+        "divergent_over_uniform": res["divergent"]["value"] / res["uniform"]["value"],
+        "steps_per_system_min_mean_max": res["divergent"]["steps_per_system_min_mean_max"],
+        "uniform_steps_per_system_min_mean_max": res["uniform"]["steps_per_system_min_mean_max"],
+        "all_outcomes_time_limit": res["divergent"]["all_outcomes_time_limit"] and res["uniform"]["all_outcomes_time_limit"],
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -502,6 +543,10 @@ def main():
                     extra.append(leg)
                 except Exception as e:  # an auxiliary leg must never cost the headline line
                     extra.append({"config": {"workload": wl}, "error": "%s: %s" % (type(e).__name__, e)})
+            try:
+                extra.append(divergence_leg(ctx, DEFAULT_SYSTEMS["outer_ss"]))
+            except Exception as e:
+                extra.append({"config": {"workload": "outer_ss_divergent"}, "error": "%s: %s" % (type(e).__name__, e)})
             out["extra_workloads"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, out.pop("_dt"), args.cpu_seconds)
