@@ -1856,6 +1856,7 @@ __device__ __forceinline__ double hy_swap1(double x)
 const u64 hy_waves = (u64)gridDim.x * HY_WPB;
 const bool hy_static = (a.mode != 1) && (HY_NO_STATIC == 0);
 u64 hy_it = 0;
+bool hy_queue_empty = false;
 for (;;) {
 u64 base = 0;
 if (hy_static) {
@@ -1872,8 +1873,8 @@ if (hy_static) {
 base = ((u64)__builtin_amdgcn_readfirstlane((unsigned)(base >> 32)) << 32) | (u64)__builtin_amdgcn_readfirstlane((unsigned)base);
 if (!(HY_M4 && hy_static) && base >= N) break;
 // NOTE: lanes beyond the end of the ensemble replicate the last system (no side effects).
-const bool live = (base + q) < N;
-const u64 s = live ? (base + q) : (N - 1u);
+bool live = (base + q) < N;
+u64 s = live ? (base + q) : (N - 1u);
 double t_hi = a.time_hi[s], t_lo = a.time_lo[s];
 )HIP";
     for (std::uint32_t i = 0; i < p.n_par; ++i) {
@@ -2249,6 +2250,84 @@ int nfi = !(hy_finite(nt_hi) && hy_finite(nt_lo)) ? 1 : 0;
     fin = fin | done;
 }
 )HIP";
+    // Per-system refill (propagations through the device-side work queue): the step loop is left by the whole wavefront at
+    // once, so a system which reaches its final time early idles - zero-length steps - until the slowest of the SPW
+    // systems of its wavefront is done. With heterogeneous step counts (per-lane final times T * U(0.5, 1.5): 37 .. 127 steps
+    // per system) that costs E[max of 4] / mean = 1.3x: 0.78 of the rate of a uniform ensemble (bench.py, divergence leg).
+    // Here a finished system is retired on the spot - its results stored like at the end of the kernel - and its lanes pull
+    // the next system from the queue: one atomic per system instead of one per wavefront, only behind a wave-uniform test
+    // that some system of the wavefront has just finished. (The reference's lanes idle like the old loop:
+    // src/taylor_adaptive_batch.cpp:1378-1460.)
+    const bool refill = one_lane && !m4 && jet_lds && p.n_par == 0u && lane_par_tbls.empty() && L < 64u
+                        && std::getenv("HEYOKA_AMD_NO_REFILL") == nullptr;
+    if (refill) {
+        src << "if (!hy_static && !hy_queue_empty && __builtin_amdgcn_ballot_w64(fin) != 0ull) {\n";
+        // 1. Retire.
+        for (const auto &rg : rounds) {
+            for (const auto &gr : rg) {
+                for (const auto &ow : gr.owners) {
+                    src << "if (fin && ovalid" << ow.col << " && live) a.state[(u64)hy_utbl[" << ow.var_tbl * L
+                        << "u + l] * N + s] = " << row0_w(ow) << ";\n";
+                }
+            }
+        }
+        src << R"HIP(
+if (fin && l == 0u && live) {
+    a.time_hi[s] = t_hi;
+    a.time_lo[s] = t_lo;
+    a.last_h[s] = last_h;
+    a.outcome[s] = outcome;
+    a.min_h[s] = min_h;
+    a.max_h[s] = max_h;
+    a.n_steps[s] = n_steps;
+    if (nf_seen != 0) atomicAdd(a.counters, 1u);
+}
+// 2. The next system of the queue, for every finished system of the wavefront (its lane 0 asks, the others listen).
+u64 snew = 0;
+if (fin && l == 0u) snew = atomicAdd((u64 *)(a.counters + 2), (u64)1);
+{
+    const int src_lane = (int)((threadIdx.x & 63u) - l);
+    const unsigned lo_ = (unsigned)__shfl((int)(unsigned)snew, src_lane, 64);
+    const unsigned hi_ = (unsigned)__shfl((int)(unsigned)(snew >> 32), src_lane, 64);
+    snew = ((u64)hi_ << 32) | (u64)lo_;
+}
+const bool got = fin && (snew < N);
+// (The queue position only grows: one request beyond the end means that the queue is empty - stop asking.)
+if (__builtin_amdgcn_ballot_w64(fin && !got) != 0ull) hy_queue_empty = true;
+live = fin ? got : live;
+nf_seen = fin ? 0 : nf_seen;
+s = got ? snew : s;
+// 3. Its state, times and limits; a fresh set of counters.
+if (got) {
+    t_hi = a.time_hi[s];
+    t_lo = a.time_lo[s];
+)HIP";
+        for (const auto &rg : rounds) {
+            for (const auto &gr : rg) {
+                for (const auto &ow : gr.owners) {
+                    src << row0_w(ow) << " = a.state[(u64)hy_utbl[" << ow.var_tbl * L << "u + l] * N + s];\n";
+                }
+            }
+        }
+        src << R"HIP(
+    tfin.hi = (a.tfin_hi != nullptr) ? a.tfin_hi[s] : a.tfin_s_hi;
+    tfin.lo = (a.tfin_hi != nullptr) ? a.tfin_lo[s] : a.tfin_s_lo;
+    hy_df tcur; tcur.hi = t_hi; tcur.lo = t_lo;
+    rem = hy_df_sub(tfin, tcur);
+    t_dir = (rem.hi > 0.0) || (rem.hi == 0.0 && rem.lo >= 0.0);
+    mdt = (a.lim != nullptr) ? a.lim[s] : __builtin_inf();
+    n_steps = 0;
+    iter = 0;
+    min_h = __builtin_inf();
+    max_h = 0.0;
+    last_h = 0.0;
+    outcome = HY_OC_SUCCESS;
+    fin = false;
+}
+HY_WSYNC();
+}
+)HIP";
+    }
     if (bk_lds) {
         bk_store();
     }
