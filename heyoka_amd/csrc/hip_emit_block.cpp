@@ -618,19 +618,68 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
            << static_cast<std::uint64_t>(n_tape) * order * ncp * 8u << ", 0x00020000);\n";
         dc << "#define HY_TLD(lo, so) __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(trs, (lo), (so), 0))\n";
         dc << "#define HY_TST(v, lo, so) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(hy_u2, (v)), trs, (lo), (so), 0)\n";
-        const auto n_dq = (n_ext + 1u) / 2u;
-        {
-            std::vector<std::uint32_t> dsc(static_cast<std::size_t>(n_dq + 2u) * nc, 0u);
-            for (std::uint32_t c = 0; c < nc; ++c) {
-                for (std::uint32_t x = 0; x < n_ext; ++x) {
-                    dsc[static_cast<std::size_t>(x / 2u) * nc + c]
-                        |= (ej_index[static_cast<std::size_t>(x) * nc + c] * 8u) << (16u * (x % 2u));
+        // Compact form (2 words per cluster instead of n_ext / 2 + 2) when the tables are affine: the inputs of a cluster are
+        // the coordinates of two bodies whose jets sit at a constant distance from one another ([component][body] layout of
+        // the input jets) and its outputs sit at constant distances too - then one offset per body and one output slot
+        // describe the cluster, the rest are constants which fold into the offset fields of the LDS instructions (and the
+        // three components of a body share ONE address addition per row instead of three).
+        std::vector<std::uint32_t> ex_word(n_ext), ex_shift(n_ext), ex_delta(n_ext, 0u);
+        std::uint32_t out_delta[3] = {0u, 0u, 0u};
+        const auto oslot_of = [&](std::uint32_t c, int x) {
+            return static_cast<std::uint32_t>(pl.slot_of[pl.clusters[c][pl.out_pos[static_cast<std::uint32_t>(x)]]]);
+        };
+        bool compact = n_ext == 6u && std::getenv("HEYOKA_AMD_BLOCK_FULL_DESC") == nullptr;
+        if (compact) {
+            for (std::uint32_t side = 0; side < 2u && compact; ++side) {
+                const auto xb = pp.de[0][side];
+                for (std::uint32_t comp = 0; comp < 3u && compact; ++comp) {
+                    const auto x = pp.de[comp][side];
+                    const auto d0 = static_cast<std::int64_t>(ej_index[static_cast<std::size_t>(x) * nc])
+                                    - static_cast<std::int64_t>(ej_index[static_cast<std::size_t>(xb) * nc]);
+                    for (std::uint32_t c = 0; c < nc && compact; ++c) {
+                        compact = static_cast<std::int64_t>(ej_index[static_cast<std::size_t>(x) * nc + c])
+                                      - static_cast<std::int64_t>(ej_index[static_cast<std::size_t>(xb) * nc + c])
+                                  == d0;
+                    }
+                    compact = compact && d0 >= 0;
+                    ex_word[x] = 0;
+                    ex_shift[x] = 16u * side;
+                    ex_delta[x] = static_cast<std::uint32_t>(d0) * 8u;
                 }
-                const auto oslot = [&](int x) {
-                    return static_cast<std::uint32_t>(pl.slot_of[pl.clusters[c][pl.out_pos[static_cast<std::uint32_t>(x)]]]);
-                };
-                dsc[static_cast<std::size_t>(n_dq) * nc + c] = oslot(io_of[0]) | (oslot(io_of[1]) << 16);
-                dsc[static_cast<std::size_t>(n_dq + 1u) * nc + c] = oslot(io_of[2]);
+            }
+            for (std::uint32_t q = 1; q < 3u && compact; ++q) {
+                const auto d0 = static_cast<std::int64_t>(oslot_of(0, io_of[q])) - static_cast<std::int64_t>(oslot_of(0, io_of[0]));
+                for (std::uint32_t c = 0; c < nc && compact; ++c) {
+                    compact = static_cast<std::int64_t>(oslot_of(c, io_of[q])) - static_cast<std::int64_t>(oslot_of(c, io_of[0])) == d0;
+                }
+                compact = compact && d0 >= 0;
+                out_delta[q] = static_cast<std::uint32_t>(d0);
+            }
+        }
+        if (!compact) {
+            for (std::uint32_t x = 0; x < n_ext; ++x) {
+                ex_word[x] = x / 2u;
+                ex_shift[x] = 16u * (x % 2u);
+                ex_delta[x] = 0;
+            }
+        }
+        const auto n_dq = compact ? 1u : (n_ext + 1u) / 2u;  // words holding input offsets
+        const auto n_dw = compact ? 2u : n_dq + 2u;           // words per cluster
+        {
+            std::vector<std::uint32_t> dsc(static_cast<std::size_t>(n_dw) * nc, 0u);
+            for (std::uint32_t c = 0; c < nc; ++c) {
+                if (compact) {
+                    dsc[c] = (ej_index[static_cast<std::size_t>(pp.de[0][0]) * nc + c] * 8u)
+                             | ((ej_index[static_cast<std::size_t>(pp.de[0][1]) * nc + c] * 8u) << 16);
+                    dsc[static_cast<std::size_t>(nc) + c] = oslot_of(c, io_of[0]);
+                } else {
+                    for (std::uint32_t x = 0; x < n_ext; ++x) {
+                        dsc[static_cast<std::size_t>(x / 2u) * nc + c]
+                            |= (ej_index[static_cast<std::size_t>(x) * nc + c] * 8u) << (16u * (x % 2u));
+                    }
+                    dsc[static_cast<std::size_t>(n_dq) * nc + c] = oslot_of(c, io_of[0]) | (oslot_of(c, io_of[1]) << 16);
+                    dsc[static_cast<std::size_t>(n_dq + 1u) * nc + c] = oslot_of(c, io_of[2]);
+                }
             }
             tbl << "__device__ const unsigned hy_dsc[" << dsc.size() << "] = {";
             for (const auto x : dsc) {
@@ -638,6 +687,24 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
             }
             tbl << "};\n";
         }
+        // The byte offset of input x / the slab slot of output q of the lane's cluster in round r, as expressions.
+        const auto ex_expr = [&](std::uint32_t x, std::uint32_t r) {
+            const auto w = "dq_" + S(ex_word[x]) + "_" + S(r);
+            auto e = ex_shift[x] == 0u ? "(" + w + " & 0xffffu)" : "(" + w + " >> 16)";
+            if (ex_delta[x] != 0u) {
+                e = "(" + e + " + " + U(ex_delta[x]) + ")";
+            }
+            return e;
+        };
+        const auto out_expr = [&](std::uint32_t q, std::uint32_t r) -> std::string {
+            if (compact) {
+                return "(dq_1_" + S(r) + " + " + U(out_delta[q]) + ")";
+            }
+            if (q == 0u) {
+                return "(dq_" + S(n_dq) + "_" + S(r) + " & 0xffffu)";
+            }
+            return q == 1u ? "(dq_" + S(n_dq) + "_" + S(r) + " >> 16)" : "dq_" + S(n_dq + 1u) + "_" + S(r);
+        };
         for (std::uint32_t r = 0; r < R; ++r) {
             const bool full = static_cast<std::uint64_t>(r + 1u) * bs <= nc;
             if (!full) {
@@ -664,7 +731,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                 defs << "#define " << name << " l_" << name << "\n";
             };
             if (std::getenv("HEYOKA_AMD_BLOCK_NO_LDS_TABLES") == nullptr) {
-                mirror("hy_dsc", static_cast<std::size_t>(n_dq + 2u) * nc, "unsigned", 4u);
+                mirror("hy_dsc", static_cast<std::size_t>(n_dw) * nc, "unsigned", 4u);
                 for (const auto &[name, n] : utbl_list) {
                     if (name.rfind("hy_g", 0) == 0 || name.rfind("hy_sv_", 0) == 0) {
                         mirror(name, n, "unsigned short", 2u);
@@ -690,7 +757,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                << (full ? "tid + " + U(r * bs) : "live_" + S(r) + " ? tid + " + U(r * bs) + " : " + U(nc - 1u)) << ";\n";
             os << "asm volatile(\"\" : \"+v\"(cl_" << r << "));\n";
             os << "const unsigned lo_" << r << " = cl_" << r << " * 8u;\n";
-            for (std::uint32_t j = 0; j < n_dq + 2u; ++j) {
+            for (std::uint32_t j = 0; j < n_dw; ++j) {
                 os << "const unsigned dq_" << j << "_" << r << " = hy_dsc[" << U(static_cast<std::uint64_t>(j) * nc) << " + cl_" << r
                    << "];\n";
             }
@@ -698,11 +765,10 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
 
         const auto unpack = [&](std::uint32_t r) {
             for (std::uint32_t x = 0; x < n_ext; ++x) {
-                os << "const unsigned ex" << x << " = "
-                   << ((x % 2u == 0u) ? "dq_" + S(x / 2u) + "_" + S(r) + " & 0xffffu" : "dq_" + S(x / 2u) + "_" + S(r) + " >> 16")
-                   << ";\n";
+                os << "const unsigned ex" << x << " = " << ex_expr(x, r) << ";\n";
             }
-            os << "const unsigned dvo0 = dq_" << n_dq << "_" << r << ", dvo1 = dq_" << n_dq + 1u << "_" << r << ";\n";
+            os << "const unsigned dvo0 = " << out_expr(0, r) << ", dvo1 = " << out_expr(1, r) << ", dvo2 = " << out_expr(2, r)
+               << ";\n";
         };
         // d_c of the row at byte offset `row` (an expression): minuend - subtrahend (src/detail/sub.cpp:60-124).
         const auto diff = [&](const std::string &name, std::uint32_t c, const std::string &row) {
@@ -710,9 +776,9 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                << pp.de[c][1] << ");\n";
         };
         const auto store_out = [&](std::uint32_t, const std::string v[3]) {
-            os << "slab[dvo0 & 0xffffu] = " << v[0] << ";\n";
-            os << "slab[dvo0 >> 16] = " << v[1] << ";\n";
-            os << "slab[dvo1] = " << v[2] << ";\n";
+            os << "slab[dvo0] = " << v[0] << ";\n";
+            os << "slab[dvo1] = " << v[1] << ";\n";
+            os << "slab[dvo2] = " << v[2] << ";\n";
         };
         // NOTE: the idle lanes of a partial last round work on a copy of the last cluster and store the same values to the
         // same places as the lane which owns it: no predicated stores, i.e. no divergent control flow in the cluster phase
@@ -902,9 +968,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         };
         const auto unpack_ex = [&](std::uint32_t r) {
             for (std::uint32_t x = 0; x < n_ext; ++x) {
-                os << "const unsigned ex" << x << " = "
-                   << ((x % 2u == 0u) ? "dq_" + S(x / 2u) + "_" + S(r) + " & 0xffffu" : "dq_" + S(x / 2u) + "_" + S(r) + " >> 16")
-                   << ";\n";
+                os << "const unsigned ex" << x << " = " << ex_expr(x, r) << ";\n";
             }
         };
         // The LDS reads of step (i, r) into set `set` (inside their own scope: the unpacked offsets are temporaries).
@@ -933,8 +997,8 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         std::uint32_t G = R;
         if (const char *ev = std::getenv("HEYOKA_AMD_BLOCK_GROUP")) {
             G = static_cast<std::uint32_t>(std::max(1, std::atoi(ev)));
-        } else if (R > 2u) {
-            G = 2;
+        } else if (R > 4u) {
+            G = 4;
         }
         G = std::min(G, R);
         // Depth of the tape-load pipeline, in slots: the loads of slot i + D are issued at the head of slot i. One slot of a
@@ -1010,9 +1074,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                     // (The optimiser re-derives these from the packed word where they are used - one SDWA addition per read
                     // of a dynamic row; pinning them in registers was measured: they end up in AGPRs and every read pays a
                     // copy instead.)
-                    os << "const unsigned eo" << x << "_" << r << " = "
-                       << ((x % 2u == 0u) ? "dq_" + S(x / 2u) + "_" + S(r) + " & 0xffffu" : "dq_" + S(x / 2u) + "_" + S(r) + " >> 16")
-                       << ";\n";
+                    os << "const unsigned eo" << x << "_" << r << " = " << ex_expr(x, r) << ";\n";
                     os << "const unsigned kx" << x << "_" << r << " = kbr + eo" << x << "_" << r << ";\n";
                 }
             }
@@ -1089,7 +1151,8 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
             for (std::uint32_t r = r0; r < r1; ++r) {
                 os << "{\n";
                 unpack_ex(r);
-                os << "const unsigned dvo0 = dq_" << n_dq << "_" << r << ", dvo1 = dq_" << n_dq + 1u << "_" << r << ";\n";
+                os << "const unsigned dvo0 = " << out_expr(0, r) << ", dvo1 = " << out_expr(1, r) << ", dvo2 = " << out_expr(2, r)
+                   << ";\n";
                 for (std::uint32_t c = 0; c < 3u; ++c) {
                     diff("dz" + S(c), c, U(ej0b));
                 }
@@ -1292,20 +1355,42 @@ if (a.mode == 1) {
         << "u) for (unsigned k = 0; k <= " << order << "u; ++k) a.tc[((u64)i * " << (order + 1u)
         << "u + k) * N + s] = sjet[k * " << n_eq << "u + i];\n}\n";
     src << "int nfi = 0;\n";
-    src << "for (unsigned i = tid; i < " << n_eq << "u; i += " << bs << "u) {\nconst double *c = sjet + i;\n";
-    if (opts.high_accuracy) {
-        src << "double res = c[0], comp = 0.0, cur_h = h;\n";
-        src << "for (unsigned k = 1; k <= " << order << "u; ++k) {\n";
-        src << "const double tmp = c[k * " << n_eq << "u] * cur_h;\nconst double y = tmp - comp;\n";
-        src << "const double t = res + y;\ncomp = (t - res) - y;\nres = t;\ncur_h = cur_h * h;\n}\n";
-    } else {
-        src << "double res = c[" << static_cast<std::uint64_t>(order) * n_eq << "u];\n";
-        src << "for (unsigned k = 1; k <= " << order << "u; ++k) {\n";
-        src << "res = c[(" << order << "u - k) * " << n_eq << "u] + res * h;\n}\n";
+    // NOTE: the coefficients of a state variable are read back from the per-workgroup array in global memory. As a rolled
+    // loop this was ONE load per iteration with a full wait behind it (20 dependent round trips to L2 per state variable and
+    // step: ~30 us of a 260 us step on nbody(64)); written out, all the loads of all the rounds of the lane are issued
+    // before the first operation - the registers of the order loop are free by now. Branch-free: a lane without a state
+    // variable in its last round evaluates a copy of the last variable and the result is ignored.
+    for (std::uint32_t r = 0; r < sv_rounds; ++r) {
+        const bool partial = static_cast<std::uint64_t>(r + 1u) * bs > n_eq;
+        src << "const unsigned hi" << r << " = " << (partial ? "(tid + " + std::to_string(r * bs) + "u < " + std::to_string(n_eq)
+                                                                      + "u) ? tid + " + std::to_string(r * bs) + "u : "
+                                                                      + std::to_string(n_eq - 1u) + "u"
+                                                                : "tid + " + std::to_string(r * bs) + "u")
+            << ";\n";
+        for (std::uint32_t k = 0; k <= order; ++k) {
+            src << "const double hc" << r << "_" << k << " = sjet[" << static_cast<std::uint64_t>(k) * n_eq << "u + hi" << r
+                << "];\n";
+        }
     }
-    src << "if (!hy_finite(res)) nfi = 1;\n";
-    // NOTE: sjet row 0 / slab are rewritten only after every lane is done reading the jets.
-    src << "c_new[i / " << bs << "u] = res;\n}\n";
+    for (std::uint32_t r = 0; r < sv_rounds; ++r) {
+        const auto c = [&](std::uint32_t k) { return "hc" + std::to_string(r) + "_" + std::to_string(k); };
+        src << "{\n";
+        if (opts.high_accuracy) {
+            src << "double res = " << c(0) << ", comp = 0.0, cur_h = h;\n";
+            for (std::uint32_t k = 1; k <= order; ++k) {
+                src << "{\nconst double tmp = " << c(k) << " * cur_h;\nconst double y = tmp - comp;\n";
+                src << "const double t = res + y;\ncomp = (t - res) - y;\nres = t;\ncur_h = cur_h * h;\n}\n";
+            }
+        } else {
+            src << "double res = " << c(order) << ";\n";
+            for (std::uint32_t k = 1; k <= order; ++k) {
+                src << "res = " << c(order - k) << " + res * h;\n";
+            }
+        }
+        src << "if (!hy_finite(res)) nfi = 1;\n";
+        // NOTE: sjet row 0 / slab are rewritten only after every lane is done reading the jets.
+        src << "c_new[" << r << "] = res;\n}\n";
+    }
     src << R"HIP(
 {
     hy_df tcur; tcur.hi = t_hi; tcur.lo = t_lo;
