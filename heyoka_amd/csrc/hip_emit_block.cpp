@@ -711,6 +711,56 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                 dc << "const bool live_" << r << " = tid + " << r * bs << "u < " << nc << "u;\n";
             }
         }
+        // Sums of one dependency level with different numbers of terms (63 accelerations terms per body arrive as sums of
+        // 8 + 8 + ... + 7: seven shapes per level for nbody(64), six of them with 48 nodes on 256 lanes) run as ONE group of
+        // the widest shape, the missing operands read a slot which holds 0.0: the pairwise tree of the padded sum adds
+        // exact zeros where the short one has nothing (same value), and a level is 7 + 2 + 2 lane rounds instead of 21.
+        struct merged_sums {
+            std::vector<std::size_t> groups;
+            std::vector<std::uint32_t> nodes;
+            std::uint32_t nargs = 0;
+        };
+        std::map<std::uint32_t, merged_sums> merged;
+        std::vector<char> group_merged(pl.groups.size(), 0);
+        if (std::getenv("HEYOKA_AMD_BLOCK_NO_MERGE") == nullptr) {
+            for (std::size_t g = 0; g < pl.groups.size(); ++g) {
+                const auto &n0 = p.nodes[pl.groups[g].nodes[0] - n_eq];
+                bool all_var = n0.kind == func_kind::sum && n0.args.size() <= 8u;
+                for (const auto &o : n0.args) {
+                    all_var = all_var && is_var(o);
+                }
+                if (all_var) {
+                    auto &m = merged[pl.groups[g].level];
+                    m.groups.push_back(g);
+                    m.nargs = std::max(m.nargs, static_cast<std::uint32_t>(n0.args.size()));
+                    m.nodes.insert(m.nodes.end(), pl.groups[g].nodes.begin(), pl.groups[g].nodes.end());
+                }
+            }
+            for (auto it = merged.begin(); it != merged.end();) {
+                if (it->second.groups.size() < 2u) {
+                    it = merged.erase(it);
+                } else {
+                    for (const auto g : it->second.groups) {
+                        group_merged[g] = 1;
+                    }
+                    const auto base = "hy_gm" + std::to_string(it->first);
+                    for (std::uint32_t a2 = 0; a2 < it->second.nargs; ++a2) {
+                        std::vector<std::uint32_t> v;
+                        for (const auto u : it->second.nodes) {
+                            const auto &args = p.nodes[u - n_eq].args;
+                            v.push_back(a2 < args.size() ? static_cast<std::uint32_t>(pl.slot_of[args[a2].idx]) : n_slots + 1u);
+                        }
+                        emit_utbl(base + "_a" + std::to_string(a2), v);
+                    }
+                    std::vector<std::uint32_t> v;
+                    for (const auto u : it->second.nodes) {
+                        v.push_back(static_cast<std::uint32_t>(pl.slot_of[u]));
+                    }
+                    emit_utbl(base + "_o", v);
+                    ++it;
+                }
+            }
+        }
         // LDS copies of the index tables read at every order (cluster descriptors, glue operands / results, state-variable
         // definitions), as far as they fit next to the slab and the input jets: a table lookup in front of every LDS access
         // of the glue phases and of the head of a round is a ~1 us round trip to L2 per dependency level when it is a
@@ -733,7 +783,11 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
             if (std::getenv("HEYOKA_AMD_BLOCK_NO_LDS_TABLES") == nullptr) {
                 mirror("hy_dsc", static_cast<std::size_t>(n_dw) * nc, "unsigned", 4u);
                 for (const auto &[name, n] : utbl_list) {
-                    if (name.rfind("hy_g", 0) == 0 || name.rfind("hy_sv_", 0) == 0) {
+                    bool unused = false;
+                    for (std::size_t g = 0; g < pl.groups.size(); ++g) {
+                        unused = unused || (group_merged[g] != 0 && name.rfind("hy_g" + std::to_string(g) + "_", 0) == 0);
+                    }
+                    if (!unused && (name.rfind("hy_g", 0) == 0 || name.rfind("hy_sv_", 0) == 0)) {
                         mirror(name, n, "unsigned short", 2u);
                     }
                 }
@@ -834,9 +888,39 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                 return t;
             };
             const auto before = take();
+            if (const auto mit = merged.find(lev); mit != merged.end() && !(exp_mode == 2 && k != 0u)) {
+                const auto &m = mit->second;
+                const auto gn = "hy_gm" + std::to_string(lev);
+                const auto ng = static_cast<std::uint32_t>(m.nodes.size());
+                for (std::uint32_t r = 0; r * bs < ng; ++r) {
+                    const auto tag = "_m" + std::to_string(lev) + "_" + std::to_string(r) + "_" + std::to_string(k == 0u ? 0 : 1);
+                    const bool partial = (r + 1u) * bs > ng;
+                    const auto inside = "(tid + " + std::to_string(r * bs) + "u < " + std::to_string(ng) + "u)";
+                    os << "const unsigned j" << tag << " = "
+                       << (partial ? inside + " ? tid + " + std::to_string(r * bs) + "u : " + std::to_string(ng - 1u) + "u"
+                                   : "tid + " + std::to_string(r * bs) + "u")
+                       << ";\n";
+                    for (std::uint32_t a2 = 0; a2 < m.nargs; ++a2) {
+                        os << "const unsigned ia" << a2 << tag << " = " << gn << "_a" << a2 << "[j" << tag << "];\n";
+                    }
+                    os << "const unsigned io" << tag << " = "
+                       << (partial ? inside + " ? (unsigned)" + gn + "_o[j" + tag + "] : " + std::to_string(n_slots) + "u"
+                                   : "(unsigned)" + gn + "_o[j" + tag + "]")
+                       << ";\n";
+                    st_idx += take();
+                    std::vector<std::string> terms;
+                    for (std::uint32_t a2 = 0; a2 < m.nargs; ++a2) {
+                        terms.push_back(e.def("slab[ia" + std::to_string(a2) + tag + "]"));
+                    }
+                    st_ld += take();
+                    const auto res = e.pairwise_sum(std::move(terms));
+                    st_ar += take();
+                    st_wr += "slab[io" + tag + "] = " + res + ";\n";
+                }
+            }
             for (std::size_t g = 0; g < pl.groups.size(); ++g) {
                 const auto &grp = pl.groups[g];
-                if (grp.level != lev || (exp_mode == 2 && k != 0u)) {
+                if (grp.level != lev || group_merged[g] != 0 || (exp_mode == 2 && k != 0u)) {
                     continue;
                 }
                 const auto rep = grp.nodes[0];
@@ -1269,7 +1353,9 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
     emit_detail::emit_dout(src, p, opts);
     src << tbl.str();
     src << "extern \"C\" __global__ void __launch_bounds__(" << bs << ") hy_taylor(const hy_kargs a)\n{\n";
-    src << "__shared__ double slab[" << n_slots + 1u << "];\n";
+    // (slab[n_slots]: the slot idle lanes write to; slab[n_slots + 1]: a constant 0.0 - the missing operands of the merged
+    // sums of the v2 glue.)
+    src << "__shared__ double slab[" << n_slots + 2u << "];\n";
     if (n_ej != 0u) {
         src << "__shared__ double ejet[" << static_cast<std::uint64_t>(n_ej) * (v2 ? order : order - 1u) << "];\n";
     }
@@ -1280,6 +1366,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
     src << "double *const tape = a.scratch + (u64)blockIdx.x * " << per_block << "ull;\n";
     src << "double *const sjet = tape + " << tape_doubles << "ull;\n";
     src << v2_decl;
+    src << "if (tid == 0u) slab[" << n_slots + 1u << "] = 0.0;\n";
     src << R"HIP(
 for (;;) {
 // Pull the next system from the device-side work queue.
