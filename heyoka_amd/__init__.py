@@ -1167,13 +1167,15 @@ class taylor_adaptive_batch:
                     return 1 if c(self) else 0
                 except BaseException as e:  # propagate Python exceptions out of the C frame
                     err.append(e)
-                    return 0
+                    return -1  # the other members of the set are not run, the propagation stops
 
             def pre(_tab, _data):
                 try:
                     c.pre_hook(self)
+                    return 0
                 except BaseException as e:
                     err.append(e)
+                    return 1  # the propagation is not started (the reference lets the exception out of propagate_*())
 
             f_call = _lib.STEP_CALLBACK(call)
             f_pre = _lib.STEP_PRE_HOOK(pre) if hasattr(c, "pre_hook") else _lib.STEP_PRE_HOOK()

@@ -50,7 +50,7 @@ class TabConfig(ctypes.Structure):
 
 
 STEP_CALLBACK = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p)
-STEP_PRE_HOOK = ctypes.CFUNCTYPE(None, c_void_p, c_void_p)
+STEP_PRE_HOOK = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p)
 
 
 class StepCallbackDesc(ctypes.Structure):

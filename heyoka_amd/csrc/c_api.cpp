@@ -167,14 +167,20 @@ std::pair<detail::tab_core::cb_t, detail::tab_core::pre_t> wrap_cbs(hy_tab tab, 
     detail::tab_core::cb_t call = [tab, v]() {
         bool ret = true;
         for (const auto &c : v) {
-            ret = (c.call(tab, c.user_data) != 0) && ret;
+            const auto rc = c.call(tab, c.user_data);
+            if (rc < 0) {
+                // An error inside the callback (e.g. a Python exception recorded by the binding): the other members of the
+                // set do not run any more, the propagation stops.
+                return false;
+            }
+            ret = (rc != 0) && ret;
         }
         return ret;
     };
     detail::tab_core::pre_t pre = [tab, v]() {
         for (const auto &c : v) {
-            if (c.pre_hook != nullptr) {
-                c.pre_hook(tab, c.user_data);
+            if (c.pre_hook != nullptr && c.pre_hook(tab, c.user_data) != 0) {
+                throw std::runtime_error("The pre_hook() of a step callback failed: the propagation was not started");
             }
         }
     };

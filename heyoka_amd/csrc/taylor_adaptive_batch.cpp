@@ -300,6 +300,22 @@ struct tab_core::impl {
         }
     }
 
+    // get_tc() holds the coefficients of the last step taken with write_tc (src/taylor_adaptive_batch.cpp:756-760). The
+    // steppers which are not wave-cluster kernels use the tc buffer as their jet scratch on EVERY step: before a launch
+    // without write_tc overwrites it, a pending (lazily downloaded) set of coefficients is brought to the host mirror.
+    void keep_written_tc(bool wtc)
+    {
+        if (wtc || !tc_dev_newer || is_cluster() || !dmod || d_tc.bytes() == 0u) {
+            return;
+        }
+        const auto sz = static_cast<std::size_t>(dim) * (order + 1u) * N;
+        if (tc.size() != sz) {
+            tc.assign(sz, 0.);
+        }
+        d_tc.download(tc.data(), sz * sizeof(double), stream);
+        tc_dev_newer = false;
+    }
+
     void before_kernel()
     {
         if (sticky_host_ptr) {
@@ -369,6 +385,7 @@ struct tab_core::impl {
             d_lim_src = nullptr;
         }
         d_counters.zero(stream);
+        keep_written_tc(wtc);
         auto a = base_args();
         if (wtc && is_cluster()) {
             ensure_tc();
@@ -1654,6 +1671,7 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
         }
         a.mode = 1;
         a.max_steps = max_steps;
+        d.keep_written_tc(wtc);
         if (d.batch_semantics == 0) {
             d.snapshot_for_rollback();
         }
@@ -1746,6 +1764,7 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
         }
         a.mode = 1;
         a.max_steps = max_steps;
+        d.keep_written_tc(wtc);
         if (d.batch_semantics == 0) {
             d.snapshot_for_rollback();
         }

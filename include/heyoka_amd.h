@@ -333,7 +333,11 @@ int hy_tab_propagate_for(hy_tab, const double *dts, size_t n_dts, uint64_t max_s
  * range of callbacks, which form a set: every member runs at every step and the results are and-ed
  * (src/step_callback.cpp:108-127); a NULL `call` inside a set of more than one member is an error
  * ("Cannot construct a callback set containing one or more empty callbacks"), n_cbs == 0 means no callback. */
-typedef void (*hy_step_pre_hook)(hy_tab, void *user_data);
+/* A pre-hook returns 0, or non-zero to abort the propagation before its first step (how an exception thrown by
+ * pre_hook() travels through the C boundary; the reference lets it propagate out of propagate_*()); a `call` member
+ * may return a NEGATIVE value for the same purpose: the remaining members of the set are not run and the propagation
+ * stops like after a `false`. */
+typedef int (*hy_step_pre_hook)(hy_tab, void *user_data);
 typedef struct {
     hy_step_callback call;
     hy_step_pre_hook pre_hook; /* NULL: the default no-op */

@@ -1865,3 +1865,53 @@ def test_events_on_the_cluster_stepper_vs_oracle(monkeypatch):
     assert rel_err(np.asarray(out_p), np.asarray(out_q)) <= 1e7 * EPS
     assert [int(r[0]) for r in ta.propagate_res] == [int(r[0]) for r in tq.propagate_res]
     assert [(a[0], a[1], a[3]) for a in log_p] == [(a[0], a[1], a[3]) for a in log_q]
+
+
+@pytest.mark.gpu
+def test_python_exceptions_in_pre_hook_and_in_a_callback_set_stop_the_propagation():
+    """Advisor findings (round 3): an exception raised by pre_hook() must stop propagate_*() BEFORE the first step (the
+    reference lets it out of propagate_*(), src/taylor_adaptive_batch.cpp:1356-1365) - state and time untouched -, and after
+    an exception in one member of a callback set the other members are not run any more. Also: get_tc() keeps the
+    coefficients of the last step taken with write_tc when later steps run without it (the steppers which use the
+    coefficient buffer as their scratch included)."""
+    x, v = hy.make_vars("x", "v")
+    st = np.array([[0.05, 0.06], [0.025, 0.03]])
+    ta = hy.taylor_adaptive_batch([(x, v), (v, -9.8 * hy.sin(x))], st, 2)
+
+    class Hooked:
+        def __init__(self):
+            self.calls = 0
+
+        def pre_hook(self, t):
+            raise RuntimeError("pre_hook says no")
+
+        def __call__(self, t):
+            self.calls += 1
+            return True
+
+    h = Hooked()
+    with pytest.raises(RuntimeError, match="pre_hook says no"):
+        ta.propagate_until(1.0, callback=h)
+    assert h.calls == 0 and np.array_equal(ta.state, st) and np.all(np.asarray(ta.time) == 0.0)
+
+    seen = []
+
+    def bad(t):
+        seen.append("bad")
+        raise ValueError("callback failed")
+
+    def other(t):
+        seen.append("other")
+        return True
+
+    with pytest.raises(ValueError, match="callback failed"):
+        ta.propagate_until(1.0, callback=[bad, other])
+    assert seen == ["bad"]
+
+    tb = hy.taylor_adaptive_batch([(x, v), (v, -9.8 * hy.sin(x))], st, 2)
+    tb.step(write_tc=True)
+    tb2 = hy.taylor_adaptive_batch([(x, v), (v, -9.8 * hy.sin(x))], st, 2)
+    tb2.step(write_tc=True)
+    ref_tc = np.array(tb2.tc).copy()
+    tb.step()          # no write_tc: must not disturb what get_tc() returns
+    assert np.array_equal(np.asarray(tb.tc), ref_tc)
