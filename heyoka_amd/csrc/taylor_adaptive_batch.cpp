@@ -1166,9 +1166,14 @@ void tab_core::impl::ensure_event_buffers()
         d_ed_counts = device_buffer(2u * n * sizeof(unsigned), device);
         d_ed_flags = device_buffer(4u * sizeof(unsigned), device);
         // Working lists of the root isolation: one column per launched thread of hy_detect_events (a grid-stride loop
-        // over the lanes), up to 8 wavefronts per compute unit and 4 GiB in total.
+        // over the lanes). Sized from what the device keeps in flight, not from the ensemble: at least one wavefront per
+        // compute unit (64 x 256 columns), at most 1 GiB (42 KB per column at order 20: ~25 000 columns; almost every
+        // lane leaves the kernel at the exclusion test and never touches its column) - the previous 4 GiB budget made a
+        // large-N integrator with events fail at allocation where nothing needed the space. The lists of detected events
+        // (d_ed_out) are 2 * N * (order + 1) * max(n_te, n_nte) * 32 B: 1.4 GB per million systems at order 20, the price
+        // of the reference's bound of (order + 1) detections per event and step.
         const auto per_slot = ed_work_list_bytes_per_slot(order);
-        const std::uint64_t max_slots = std::clamp<std::uint64_t>((std::uint64_t(4) << 30) / per_slot / 64u * 64u, 64u * 256u, 64u * 256u * 8u);
+        const std::uint64_t max_slots = std::clamp<std::uint64_t>((std::uint64_t(1) << 30) / per_slot / 64u * 64u, 64u * 256u, 64u * 256u * 8u);
         ed_slots = std::min<std::uint64_t>((static_cast<std::uint64_t>(n) + 63u) / 64u * 64u, max_slots);
         d_ed_wl = device_buffer(static_cast<std::size_t>(ed_slots) * per_slot, device);
         d_ev_cursor = device_buffer(2u * sizeof(unsigned long long), device);
