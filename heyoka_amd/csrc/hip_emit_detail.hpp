@@ -715,12 +715,12 @@ struct ssa_emitter {
                 const auto &rule = get_node_rule(n.rule);
                 const auto uid = std::to_string(counter++);
                 if (k == 0u) {
-                    os << "const double xr" << uid << "[] = {";
+                    // (Out of line, arguments by value: node_rules_device_source().)
+                    std::string call = "hy_rule_" + rule.name + "_value(";
                     for (std::size_t i2 = 0; i2 < a.size(); ++i2) {
-                        os << (i2 == 0u ? "" : ", ") << (is_var(a[i2]) ? val(a[i2].idx, 0) : numpar(a[i2]));
+                        call += (i2 == 0u ? "" : ", ") + (is_var(a[i2]) ? val(a[i2].idx, 0) : numpar(a[i2]));
                     }
-                    os << "};\n";
-                    out = def("hy_rule_" + rule.name + "_order0(xr" + uid + ")");
+                    out = def(call + ")");
                     break;
                 }
                 const auto arr = [&](const std::string &name, const std::function<std::string(std::uint32_t)> &coeff,

@@ -1141,8 +1141,11 @@ emitted_module emit_table(const taylor_program &p, const emit_options &opts)
         src << "switch (hy_rule_of[i]) {\n";
         for (const auto id : used) {
             const auto &nm = get_node_rule(id).name;
-            src << "case " << id << "u: return (k == 0u) ? hy_rule_" << nm << "_order0(xv) : hy_rule_" << nm
-                << "_orderk(k, self, xj, hj);\n";
+            src << "case " << id << "u: return (k == 0u) ? hy_rule_" << nm << "_value(";
+            for (std::uint32_t q = 0; q < get_node_rule(id).n_args; ++q) {
+                src << (q == 0u ? "" : ", ") << "xv[" << q << "]";
+            }
+            src << ") : hy_rule_" << nm << "_orderk(k, self, xj, hj);\n";
         }
         src << "default: return 0.0;\n}\n}\n";
     } else {

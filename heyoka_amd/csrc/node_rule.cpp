@@ -150,7 +150,21 @@ __device__ __forceinline__ double hy_jc(const hy_jet &x, unsigned j)
         }
         if (!dup) {
             done.push_back(id);
-            os << "// rule: " << get_node_rule(id).name << "\n" << get_node_rule(id).hip_source << "\n";
+            const auto &r = get_node_rule(id);
+            os << "// rule: " << r.name << "\n" << r.hip_source << "\n";
+            // What the generators call for order 0: the rule's function behind an out-of-line frame with the arguments by
+            // value. Order-0 rules are where library calls and data-dependent loops live (a Newton iteration, the
+            // large-argument path of sin()): inlined into a stepper with hundreds of live registers they would put
+            // divergent regions into it ("Toolchain notes": live-range splits inside exec-masked blocks).
+            os << "static __device__ __attribute__((noinline)) double hy_rule_" << r.name << "_value(";
+            for (std::uint32_t i = 0; i < r.n_args; ++i) {
+                os << (i == 0u ? "" : ", ") << "double x" << i;
+            }
+            os << ")\n{\n    const double x[] = {";
+            for (std::uint32_t i = 0; i < r.n_args; ++i) {
+                os << (i == 0u ? "" : ", ") << "x" << i;
+            }
+            os << "};\n    return hy_rule_" << r.name << "_order0(x);\n}\n";
         }
     }
     return os.str();

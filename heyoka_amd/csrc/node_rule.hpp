@@ -11,7 +11,9 @@
 //     func_base::taylor_decompose() override encodes by appending to the decomposition by hand;
 //   * hip_source: HIP device code with the two functions every generator calls,
 //         double hy_rule_<name>_order0(const double *x);
-//             x[i] = order-0 value of argument i (a number / parameter argument is passed by value as well);
+//             x[i] = order-0 value of argument i (a number / parameter argument is passed by value as well); the
+//             generators call it through an out-of-line frame (hy_rule_<name>_value(x0, x1, ...), generated): library
+//             calls and data-dependent loops are welcome here and stay out of the stepper's own control flow;
 //         double hy_rule_<name>_orderk(unsigned k, const hy_jet &a, const hy_jet *x, const hy_jet *h);
 //             k >= 1; a = the node's own coefficients (orders 0 .. k - 1), x[i] = coefficients of argument i (orders
 //             0 .. k; a number or parameter has order 0 only), h[j] = coefficients of hidden dependency j (orders

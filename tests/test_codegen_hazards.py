@@ -24,6 +24,9 @@ def _cases():
     pw = [(x, hy.atan2(y, 1.5 + x * x) - hy.relu(x, 0.1) + hy.sin(hy.kepE(0.3, y)) + hy.erf(x * y)),
           (y, hy.select(hy.gt(x, y), hy.tanh(x), -y) - 0.5 * y + hy.asin(0.3 * hy.sin(x)))]
     ev = [hy.nt_event(y, lambda *a: None)]
+    h_, k_, lam_ = hy.make_vars("h", "k", "lam")
+    F_ = hy.kepF(h_, k_, lam_)
+    kep = [(h_, -0.01 * hy.sin(F_)), (k_, 0.02 * hy.cos(F_) + 0.01 * hy.kepDE(0.1 * h_, 0.2 + k_, 0.3 * lam_)), (lam_, 1.0 + 0.1 * h_ * k_)]
     x1, x2 = hy.make_vars("x_1", "x_2")
     ev_ss = [hy.nt_event((x1 - x2) * (x1 - x2) - 4.0, lambda *a: None)]
     return {
@@ -50,6 +53,11 @@ def _cases():
         "functions_unrolled": (lambda: pw, {}, {}, "unrolled"),
         "functions_table_wave_level": (lambda: pw, {}, {"HEYOKA_AMD_EMIT_MODE": "table", "HEYOKA_AMD_TABLE_LDS": "1"}, "wave-level"),
         "functions_table_hbm": (lambda: pw, {}, {"HEYOKA_AMD_EMIT_MODE": "table", "HEYOKA_AMD_TABLE_LDS": "0"}, "tape in HBM"),
+        # Functions defined through the registry of node rules: their order-0 functions (Newton iterations, library calls)
+        # sit behind out-of-line frames (node_rule.cpp).
+        "node_rules_unrolled": (lambda: kep, {}, {}, "unrolled"),
+        "node_rules_table_hbm": (lambda: kep, {}, {"HEYOKA_AMD_EMIT_MODE": "table", "HEYOKA_AMD_TABLE_LDS": "0"}, "tape in HBM"),
+        "node_rules_table_wave_level": (lambda: kep, {}, {"HEYOKA_AMD_EMIT_MODE": "table", "HEYOKA_AMD_TABLE_LDS": "1"}, "wave-level"),
         "events_unrolled": (lambda: pw, {"nt_events": ev}, {}, "unrolled"),
         "events_table": (lambda: pw, {"nt_events": ev}, {"HEYOKA_AMD_EMIT_MODE": "table"}, "table"),
     }

@@ -1657,6 +1657,52 @@ def test_cluster_kernels_loop_control_semantics(kernel, monkeypatch):
     assert rel_err(ta.state, ora2.state.reshape(36, n)) <= 1e5 * EPS
 
 
+@pytest.mark.gpu
+def test_per_system_refill_of_the_one_lane_per_pair_stepper(monkeypatch):
+    """A finished system of the one-lane-per-pair stepper (v5) is retired on the spot and its 16 lanes take the next system
+    of the work queue while the other three systems of the wavefront keep stepping (hip_emit_cluster2.cpp, "refill"; the
+    reference's lanes idle until the slowest lane of the batch is done, src/taylor_adaptive_batch.cpp:1378-1460). With more
+    systems than resident slots (8 192) and very different per-lane final times every slot is refilled several times, at
+    different steps of its neighbours. Independent systems: the results must not depend on the schedule - bit-identical to the
+    same kernel without refill (whole groups of four from the queue) - and agree with the oracle on a sample of lanes drawn from
+    the whole queue."""
+    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    n = 40000 + 3  # ragged tail
+    rng = np.random.RandomState(5)
+    st = configs.outer_ss_state(n, perturb=1e-3, seed=91)
+    tf = rng.uniform(2.0, 45.0, n)
+    tf[rng.randint(0, n, 50)] = 0.0  # systems which are done before their first step
+    sys_ = hy.model.nbody(6, masses=M, Gconst=G)
+    ta = hy.taylor_adaptive_batch(sys_, st, n, high_accuracy=True)
+    assert "v5" in ta.hip_source_mode and "u64 snew" in ta.hip_source
+    ta.propagate_until(tf)
+    monkeypatch.setenv("HEYOKA_AMD_NO_REFILL", "1")
+    tb = hy.taylor_adaptive_batch(sys_, st, n, high_accuracy=True)
+    monkeypatch.delenv("HEYOKA_AMD_NO_REFILL")
+    assert "u64 snew" not in tb.hip_source
+    tb.propagate_until(tf)
+    assert np.array_equal(ta.state, tb.state) and np.array_equal(ta.time, tb.time) and np.array_equal(ta.time, tf)
+    ra, rb = ta.propagate_res_arrays(), tb.propagate_res_arrays()
+    for a, b in zip(ra, rb):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    assert np.all(np.asarray(ra[0]) == int(OC.time_limit))
+    ns = np.asarray(ra[3])
+    assert ns.max() >= 4 * max(1, int(np.median(ns))) // 3 and ns.min() == 0
+    # The oracle on 512 lanes spread over the whole queue (first groups, refilled slots, the ragged tail).
+    idx = np.unique(np.concatenate([np.arange(16), rng.randint(0, n, 480), np.arange(n - 16, n)]))
+    m = len(idx)
+    ora = ho.OracleIntegrator(ho.nbody(6, masses=M, Gconst=G), st.reshape(36, n)[:, idx].copy(), m, high_accuracy=True)
+    ora.propagate_until(tf[idx])
+    assert [int(r[0]) for r in ora.prop_res] == [int(OC.time_limit)] * m
+    dn = np.abs(ns[idx].astype(np.int64) - np.array([int(r[3]) for r in ora.prop_res]))
+    assert dn.max() <= 1 and np.count_nonzero(dn) <= max(2, m // 50)
+    assert rel_err(ta.state[:, idx], ora.state.reshape(36, m)) <= 1e6 * EPS
+    # A second call reuses the queue from the start.
+    ta.propagate_until(tf + 3.0)
+    tb.propagate_until(tf + 3.0)
+    assert np.array_equal(ta.state, tb.state)
+
+
 def _outer_ss_event_setup(m, log, te_log):
     """Events on the outer Solar System through expression module m (product or oracle): radial velocity of Jupiter
     (non-terminal, both directions), Saturn crossing y = 0 upwards (non-terminal), Jupiter - Saturn distance falling
