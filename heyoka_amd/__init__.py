@@ -30,6 +30,8 @@ __all__ = [
     "exp",
     "log",
     "sqrt",
+    "pi",
+    "pi_constant",
     "tan",
     "tanh",
     "sinh",
@@ -276,6 +278,16 @@ def kepDE(s0, c0, DM):
     (src/math/kepDE.cpp:113-123). Defined through the registry of node rules alone (csrc/builtin_rules.cpp)."""
     s0, c0, DM = _as_ex(s0), _as_ex(c0), _as_ex(DM)
     return expression._wrap(lib.hy_expr_kepDE(s0._h, c0._h, DM._h))
+
+
+def pi_constant():
+    """The constant pi as the reference has it (heyoka::pi, include/heyoka/math/constants.hpp:117): a function without
+    arguments which occupies its own u variable (order 0: the value, 0 beyond, src/math/constants.cpp:258-273). A registered
+    node rule (csrc/builtin_rules.cpp). The module attribute `pi` is this expression."""
+    return expression._wrap(lib.hy_expr_pi())
+
+
+pi = pi_constant()
 
 
 def custom_func(name, *args):

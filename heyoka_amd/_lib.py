@@ -113,6 +113,7 @@ SIGNATURES = [
     ("hy_expr_kepF", c_void_p, [c_void_p, c_void_p, c_void_p]),
     ("hy_expr_kepDE", c_void_p, [c_void_p, c_void_p, c_void_p]),
     ("hy_expr_custom", c_void_p, [c_char_p, c_void_p, c_size_t]),
+    ("hy_expr_pi", c_void_p, []),
     ("hy_node_rule_register", c_int, [c_void_p]),
     ("hy_expr_relu", c_void_p, [c_void_p, c_double]),
     ("hy_expr_relup", c_void_p, [c_void_p, c_double]),

@@ -216,6 +216,26 @@ bool register_builtin_rules()
         };
         register_node_rule(std::move(r));
     }
+    {
+        // A constant: no arguments, no hidden dependencies (src/math/constants.cpp:258-273).
+        node_rule r;
+        r.name = "pi";
+        r.n_args = 0;
+        r.decompose = [](const expression &, const std::vector<expression> &, const std::function<expression(std::uint32_t)> &) {
+            return std::vector<hidden_def>{};
+        };
+        r.hip_source = R"HIP(
+static __device__ __forceinline__ double hy_rule_pi_order0(const double *)
+{
+    return 0x1.921fb54442d18p+1;
+}
+static __device__ __forceinline__ double hy_rule_pi_orderk(unsigned, const hy_jet &, const hy_jet *, const hy_jet *)
+{
+    return 0.0;
+}
+)HIP";
+        register_node_rule(std::move(r));
+    }
     return true;
 }
 
@@ -237,6 +257,12 @@ expression kepDE(expression s0, expression c0, expression DM)
 {
     ensure_builtin_rules();
     return custom_func("kepDE", {std::move(s0), std::move(c0), std::move(DM)});
+}
+
+expression pi_constant()
+{
+    ensure_builtin_rules();
+    return custom_func("pi", {});
 }
 
 } // namespace heyoka_amd

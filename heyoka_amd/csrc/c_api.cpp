@@ -275,6 +275,10 @@ hy_expr hy_expr_kepDE(hy_expr s0, hy_expr c0, hy_expr DM)
 {
     return make_expr([&] { return kepDE(s0->ex, c0->ex, DM->ex); });
 }
+hy_expr hy_expr_pi(void)
+{
+    return make_expr([&] { return pi_constant(); });
+}
 hy_expr hy_expr_custom(const char *name, const hy_expr *args, size_t n)
 {
     return make_expr([&] {

@@ -745,7 +745,7 @@ struct ssa_emitter {
                     hj += (i2 == 0u ? "" : ", ") + arr("ha" + uid + "_" + std::to_string(i2), [&](std::uint32_t j) { return val(d, j); }, k);
                 }
                 const auto self = arr("sa" + uid, [&](std::uint32_t j) { return val(u, j); }, k);
-                os << "const hy_jet xj" << uid << "[] = {" << xj << "};\n";
+                os << "const hy_jet xj" << uid << "[] = {" << (xj.empty() ? "{nullptr, 1u, 0u}" : xj) << "};\n";
                 os << "const hy_jet hj" << uid << "[] = {" << (hj.empty() ? "{nullptr, 1u, 0u}" : hj) << "};\n";
                 out = def("hy_rule_" + rule.name + "_orderk(" + std::to_string(k) + "u, hy_jet" + self + ", xj" + uid + ", hj" + uid
                           + ")");

@@ -50,8 +50,9 @@ std::uint32_t register_node_rule(node_rule r)
             throw std::invalid_argument("Cannot register the node rule '" + r.name + "': the name of a built-in function");
         }
     }
-    if (r.n_args == 0u || r.n_args > 8u) {
-        throw std::invalid_argument("A node rule must have between 1 and 8 arguments, but the rule '" + r.name + "' has "
+    // (No arguments: a named constant - reference: the constant class, include/heyoka/math/constants.hpp:75-117.)
+    if (r.n_args > 8u) {
+        throw std::invalid_argument("A node rule can have at most 8 arguments, but the rule '" + r.name + "' has "
                                     + std::to_string(r.n_args));
     }
     for (const auto *fn : {"_order0", "_orderk"}) {
@@ -159,6 +160,10 @@ __device__ __forceinline__ double hy_jc(const hy_jet &x, unsigned j)
             os << "static __device__ __attribute__((noinline)) double hy_rule_" << r.name << "_value(";
             for (std::uint32_t i = 0; i < r.n_args; ++i) {
                 os << (i == 0u ? "" : ", ") << "double x" << i;
+            }
+            if (r.n_args == 0u) {
+                os << ")\n{\n    return hy_rule_" << r.name << "_order0(nullptr);\n}\n";
+                continue;
             }
             os << ")\n{\n    const double x[] = {";
             for (std::uint32_t i = 0; i < r.n_args; ++i) {

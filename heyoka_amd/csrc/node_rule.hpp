@@ -79,6 +79,10 @@ expression custom_func(const std::string &name, std::vector<expression> args);
 void ensure_builtin_rules();
 expression kepF(expression h, expression k, expression lam);
 expression kepDE(expression s0, expression c0, expression DM);
+// The constant pi as a function without arguments which occupies its own u variable, like the reference's
+// heyoka::pi (include/heyoka/math/constants.hpp:48-60, :117; src/math/constants.cpp:258-273: order 0 = the value, 0
+// beyond) - the third function defined through the registry alone.
+expression pi_constant();
 
 // The device-side interface of the rules (struct hy_jet, hy_jc) + the sources of the rules used by a program, for the
 // generators: emitted once per module, behind the prelude.

@@ -3,6 +3,8 @@
 // compile unchanged with -I <repo>/include -lheyoka_amd.
 #pragma once
 #include "../../heyoka_amd/csrc/expression.hpp"
+// (The counterpart of deriving from func_base: a registered node rule.)
+#include "../../heyoka_amd/csrc/node_rule.hpp"
 
 #ifndef HEYOKA_AMD_NAMESPACE_ALIAS
 #define HEYOKA_AMD_NAMESPACE_ALIAS

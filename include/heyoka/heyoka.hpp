@@ -6,6 +6,9 @@
 #include "../../heyoka_amd/csrc/ensemble.hpp"
 #include "../../heyoka_amd/csrc/model.hpp"
 #include "../../heyoka_amd/csrc/cfunc.hpp"
+#include "math/constants.hpp"
+#include "math/kepDE.hpp"
+#include "math/kepF.hpp"
 
 #ifndef HEYOKA_AMD_NAMESPACE_ALIAS
 #define HEYOKA_AMD_NAMESPACE_ALIAS

@@ -9,11 +9,14 @@
 #include <heyoka/math/atan.hpp>
 #include <heyoka/math/atan2.hpp>
 #include <heyoka/math/atanh.hpp>
+#include <heyoka/math/constants.hpp>
 #include <heyoka/math/cos.hpp>
 #include <heyoka/math/cosh.hpp>
 #include <heyoka/math/erf.hpp>
 #include <heyoka/math/exp.hpp>
+#include <heyoka/math/kepDE.hpp>
 #include <heyoka/math/kepE.hpp>
+#include <heyoka/math/kepF.hpp>
 #include <heyoka/math/log.hpp>
 #include <heyoka/math/logical.hpp>
 #include <heyoka/math/pow.hpp>

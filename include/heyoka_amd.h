@@ -128,6 +128,9 @@ hy_expr hy_expr_custom(const char *name, const hy_expr *args, size_t n);
  * (src/math/kepF.cpp:1689), and kepDE(s0, c0, DM), DE - c0 sin DE + s0 (1 - cos DE) = DM (src/math/kepDE.cpp:113). */
 hy_expr hy_expr_kepF(hy_expr h, hy_expr k, hy_expr lam);
 hy_expr hy_expr_kepDE(hy_expr s0, hy_expr c0, hy_expr DM);
+/* heyoka::pi: a constant which is a function without arguments with its own u variable (include/heyoka/math/constants.hpp:117,
+ * src/math/constants.cpp:258-273); a registered rule as well. */
+hy_expr hy_expr_pi(void);
 hy_expr hy_expr_sum(const hy_expr *, size_t n);  /* sum(vector)           src/math/sum.cpp:548 */
 hy_expr hy_expr_prod(const hy_expr *, size_t n); /* prod(vector)          src/math/prod.cpp:913 */
 void hy_expr_free(hy_expr);

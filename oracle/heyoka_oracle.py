@@ -86,6 +86,7 @@ KIND_IDS = {
     "rel_gte": 36,
     "kepF": 37,
     "kepDE": 38,
+    "pi": 39,
 }
 
 OC_SUCCESS = -4294967296 - 1
@@ -199,6 +200,9 @@ def as_ex(x):
 
 
 TIME = func("time", [])
+# heyoka::pi: a function without arguments with its own u variable (include/heyoka/math/constants.hpp:117; order 0 = the
+# value, 0 beyond: src/math/constants.cpp:258-273).
+PI = func("pi", [])
 
 
 def _stable_partition(lst, pred):

@@ -77,7 +77,8 @@ enum {
     K_REL_LTE = 35,
     K_REL_GTE = 36,
     K_KEPF = 37,
-    K_KEPDE = 38
+    K_KEPDE = 38,
+    K_PI = 39
 };
 
 enum { A_UVAR = 0, A_NUM = 1, A_PAR = 2 };
@@ -438,6 +439,10 @@ static void node_diff(const hy_oracle_program *p, int i, int k, double *tape, co
             break;
         case K_TIME:
             for (int l = 0; l < B; ++l) out[l] = k == 0 ? time[l] : (k == 1 ? 1. : 0.);
+            break;
+        case K_PI:
+            /* A constant (src/math/constants.cpp:258-273): the value at order 0, zero beyond. */
+            for (int l = 0; l < B; ++l) out[l] = k == 0 ? 0x1.921fb54442d18p+1 : 0.;
             break;
         case K_SUM: {
             for (int j = 0; j < nargs; ++j) {

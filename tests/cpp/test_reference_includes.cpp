@@ -40,6 +40,15 @@ int main(int argc, char **)
         init_state[10u * batch_size + i] = 29800. + i;
     }
     auto tb = taylor_adaptive_batch<double>{sys, std::move(init_state), batch_size, kw::tol = 1e-18, kw::high_accuracy = true};
+    // <heyoka/math/constants.hpp>, <heyoka/math/kepF.hpp>, <heyoka/math/kepDE.hpp>: heyoka::pi is a function without arguments
+    // with its own u variable; kepF / kepDE bring their hidden dependencies (all three are registered node rules here).
+    auto tk = taylor_adaptive_batch<double>{{prime(x) = kepF(0.1 * x, 0.2_dbl, v + hy::pi), prime(v) = kepDE(0.1_dbl, 0.2 * v, x) - hy::pi * x},
+                                            {0.01, 0.02, 0.03, 0.04, 1.85, 1.86, 1.87, 1.88},
+                                            batch_size};
+    if (tk.get_decomposition().size() != 20u) {
+        std::cout << "unexpected decomposition size " << tk.get_decomposition().size() << '\n';
+        return 1;
+    }
     std::cout << "order " << ta.get_order() << ' ' << tb.get_order() << ' ' << tb.get_decomposition().size() << '\n';
     if (argc > 1) {
         // On a GPU: the tutorial's calls.

@@ -230,3 +230,63 @@ def test_gpu_rule_registered_from_python_and_compiled_function():
         assert abs(out[0, l] - ho.inv_kep_F(0.1 * inp[0, l], 0.2, inp[1, l])) <= 50 * EPS * 2 * np.pi
         assert abs(out[1, l] - ho.inv_kep_DE(0.3, 0.1 * inp[0, l], inp[1, l])) <= 50 * EPS * 2 * np.pi
         assert abs(out[2, l] - np.cbrt(inp[0, l] + inp[1, l])) <= 10 * EPS * 2
+
+
+def _pi_system(m):
+    """x' = v, v' = -pi^2 x (period 2) next to a variable which mixes pi with a parameter and the time."""
+    if m is ho:
+        x, v, w = m.var("x"), m.var("v"), m.var("w")
+        pi, p0, t = m.PI, m.par(0), m.TIME
+    else:
+        x, v, w = m.make_vars("x", "v", "w")
+        pi, p0, t = m.pi, m.par[0], m.time
+    return [(x, v), (v, -(pi * pi) * x), (w, m.sin(pi * t) * p0 + m.cos(w + pi))]
+
+
+def test_pi_is_a_function_without_arguments_with_its_own_u_variable():
+    """heyoka::pi (include/heyoka/math/constants.hpp:117): a func - not a number - whose Taylor rule is (value, 0, 0, ...)
+    (src/math/constants.cpp:258-273). Here: a registered rule without arguments. The decomposition gives it ONE u variable
+    (CSE across its uses), identical to the oracle's restatement; the oracle integrates x'' = -pi^2 x over one period."""
+    import heyoka_amd as hy
+
+    assert str(hy.pi) == "pi()" or "pi" in str(hy.pi)
+    ta = hy.taylor_adaptive_batch(_pi_system(hy), None, 2, pars=np.zeros((1, 2)))
+    dc = ta.decomposition
+    assert sum(1 for a in dc if a.startswith("pi(")) == 1, dc
+    ora = ho.OracleIntegrator(_pi_system(ho), np.array([0.3, 0.3, 0.0, 0.0, 0.1, 0.2]), 2, pars=np.array([0.5, 0.25]))
+    assert len(dc) == len(ora.dc)
+    for a, (ex, deps) in zip(dc, ora.dc):
+        assert (a.split("(")[0] if "(" in a else None) == (ex.kind if ex.tag == "func" else None), (a, ex)
+    ora.propagate_until(2.0)
+    st = ora.state.reshape(3, 2)
+    assert np.max(np.abs(st[0] - 0.3)) <= 200 * EPS and np.max(np.abs(st[1])) <= 200 * EPS * np.pi
+    with pytest.raises(Exception):
+        hy.custom_func("pi", hy.make_vars("x", "y")[0])  # takes no arguments
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [m[0] for m in _modes()])
+def test_gpu_pi_constant_vs_oracle_and_closed_form(mode, monkeypatch):
+    import heyoka_amd as hy
+
+    for k, v in dict(_modes())[mode].items():
+        monkeypatch.setenv(k, v)
+    n = 8
+    rng = np.random.RandomState(3)
+    st = np.stack([rng.uniform(0.1, 1.0, n), rng.uniform(-1.0, 1.0, n), rng.uniform(-0.5, 0.5, n)])
+    pars = rng.uniform(0.1, 0.9, (1, n))
+    ta = hy.taylor_adaptive_batch(_pi_system(hy), st, n, pars=pars)
+    assert ("table" in ta.hip_source_mode) == (mode != "default"), ta.hip_source_mode
+    ora = ho.OracleIntegrator(_pi_system(ho), st.reshape(-1), n, pars=pars.reshape(-1))
+    ta.step()
+    ora.step()
+    assert np.max(np.abs(np.array([h for _, h in ta.step_res]) / np.array([h for _, h in ora.step_res]) - 1.0)) <= 1e4 * EPS
+    ta.propagate_until(2.0)
+    ora.propagate_until(2.0)
+    ref = ora.state.reshape(3, n)
+    assert np.max(np.abs(ta.state - ref) / np.maximum(1.0, np.abs(ref))) <= 1e5 * EPS
+    # One period of the oscillator.
+    assert np.max(np.abs(ta.state[0] - st[0])) <= 1e3 * EPS and np.max(np.abs(ta.state[1] - st[1])) <= 1e3 * EPS * np.pi
+    cf = hy.cfunc([hy.pi * hy.make_vars("x", "y")[0]], list(hy.make_vars("x", "y")))
+    out = np.asarray(cf(np.array([[1.0, 2.0], [0.0, 0.0]])))
+    assert np.array_equal(out[0], np.array([np.pi, 2 * np.pi]))
