@@ -1796,6 +1796,16 @@ __device__ __forceinline__ double hy_swap1(double x)
     } else {
         src << "double *const jetw = a.scratch + gwave * " << jet_doubles_per_wave << "ull;\n";
     }
+    // The lane tables (state variable of every owner slot and lane) are read from LDS: in constant memory every lookup at
+    // the pickup of a group and ahead of every store of its results is a vector load, and gfx9 counts loads and stores in
+    // ONE in-order counter (vmcnt) - the address of each group of stores then waits for the acknowledgement of all the
+    // stores before it (four owner slots: four round trips per group of systems; with the table in LDS: none).
+    if (std::getenv("HEYOKA_AMD_NO_LDS_UTBL") == nullptr) {
+        const auto n_ut = std::max<std::size_t>(utbl.size(), 1u) * L;
+        src << "__shared__ unsigned short lds_utbl[" << n_ut << "];\n";
+        src << "for (unsigned i = threadIdx.x; i < " << n_ut << "u; i += " << bs << "u) lds_utbl[i] = hy_utbl[i];\n";
+        src << "__syncthreads();\n#define hy_utbl lds_utbl\n";
+    }
     for (std::size_t t = 0; t < utbl.size(); ++t) {
         if (utexpr[t] == "ut" + std::to_string(t)) {
             src << "const unsigned ut" << t << " = hy_utbl[" << t * L << "u + l];\n";
