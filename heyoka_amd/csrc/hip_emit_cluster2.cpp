@@ -1630,6 +1630,9 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     std::ostringstream src;
     src << "#define SPW " << spw << "u\n#define HY_WPB " << wpb << "u\n";
     src << "#define HY_M4 " << (m4 ? 1 : 0) << "\n";
+    // (The stepper with events is a specialisation of its own and always runs in mode 4: a compile-time constant there - the
+    // bookkeeping of the propagation mode, ~900 instructions per group of systems around a single step, is not generated.)
+    src << "#define HY_MODE " << (m4 ? "4" : "a.mode") << "\n";
     // (The stepper with events always uses the static schedule: its cooperative store has workgroup barriers.)
     src << "#define HY_NO_STATIC " << ((!m4 && std::getenv("HEYOKA_AMD_NO_STATIC_SCHEDULE") != nullptr) ? 1 : 0) << "\n";
     if (std::getenv("HEYOKA_AMD_NO_NMAX") != nullptr) {
@@ -1864,7 +1867,7 @@ __device__ __forceinline__ double hy_swap1(double x)
 // group): a static interleaved schedule - group = iteration * wavefronts + wavefront - with the same locality and no
 // atomics (a launch of 1 048 576 systems is 524 288 atomics on one address: 3 ms of a 6.5 ms launch).
 const u64 hy_waves = (u64)gridDim.x * HY_WPB;
-const bool hy_static = (a.mode != 1) && (HY_NO_STATIC == 0);
+const bool hy_static = (HY_MODE != 1) && (HY_NO_STATIC == 0);
 u64 hy_it = 0;
 bool hy_queue_empty = false;
 for (;;) {
@@ -1907,7 +1910,7 @@ tfin.hi = 0.0; tfin.lo = 0.0; rem.hi = 0.0; rem.lo = 0.0;
 bool t_dir = true;
 double mdt = __builtin_inf();
 double step_lim = 0.0;
-if (a.mode == 1) {
+if (HY_MODE == 1) {
     tfin.hi = (a.tfin_hi != nullptr) ? a.tfin_hi[s] : a.tfin_s_hi;
     tfin.lo = (a.tfin_hi != nullptr) ? a.tfin_lo[s] : a.tfin_s_lo;
     hy_df tcur; tcur.hi = t_hi; tcur.lo = t_lo;
@@ -2041,7 +2044,7 @@ int nf_seen = 0;
     // top of the step: its inputs then do not have to be live (or reloaded) before the 20 orders.
     src << R"HIP(
 double lim;
-if (a.mode == 1) {
+if (HY_MODE == 1) {
     hy_df m; m.lo = 0.0;
     // NOTE: selects, not an if/else on the (per-lane) direction: see the note on HY_LIBM1.
     m.hi = t_dir ? mdt : -mdt;
@@ -2232,7 +2235,7 @@ int nfi = !(hy_finite(nt_hi) && hy_finite(nt_lo)) ? 1 : 0;
     // :1395-1520) on values frozen once the system is done.
     const bool nf = nfi != 0;
     const i64 oc_new = nf ? HY_OC_ERR_NF_STATE : ((h == lim) ? HY_OC_TIME_LIMIT : HY_OC_SUCCESS);
-    bool done = nf | (a.mode != 1);
+    bool done = nf | (HY_MODE != 1);
     const u64 ns_new = n_steps + ((!done & (h != 0.0)) ? 1u : 0u);
     const bool upd = !done & (oc_new == HY_OC_SUCCESS);
     const double ah = fabs(h);
@@ -2372,6 +2375,10 @@ if (nf_seen != 0 && l == 0u && live) atomicAdd(a.counters, 1u);
     for (const auto &rg : rounds) {
         for (const auto &gr : rg) {
             for (const auto &ow : gr.owners) {
+                if (m4) {
+                    // (The stepper with events leaves the state, the time and the step size to the kernels behind it.)
+                    continue;
+                }
                 src << "if (ovalid" << ow.col << " && live) a.state[(u64)hy_utbl[" << ow.var_tbl * L << "u + l] * N + s] = "
                     << row0_w(ow) << ";\n";
             }
@@ -2379,15 +2386,17 @@ if (nf_seen != 0 && l == 0u && live) atomicAdd(a.counters, 1u);
     }
     src << R"HIP(
 if (l == 0u && live) {
-    if (a.mode != 2) {
-        a.time_hi[s] = t_hi;
-        a.time_lo[s] = t_lo;
-    } else {
-        const_cast<double *>(a.lim)[s] = last_h;
+    if (!HY_M4) {
+        if (HY_MODE != 2) {
+            a.time_hi[s] = t_hi;
+            a.time_lo[s] = t_lo;
+        } else {
+            const_cast<double *>(a.lim)[s] = last_h;
+        }
+        a.last_h[s] = last_h;
     }
-    a.last_h[s] = last_h;
     a.outcome[s] = outcome;
-    if (a.mode == 1) {
+    if (HY_MODE == 1) {
         a.min_h[s] = min_h;
         a.max_h[s] = max_h;
         a.n_steps[s] = n_steps;
