@@ -967,6 +967,102 @@ emitted_module emit_event_jets(const taylor_program &p, const emit_options &opts
     return ret;
 }
 
+bool emit_event_jets_inline(const taylor_program &p, const emit_options &opts,
+                            const std::function<std::string(std::uint32_t, std::uint32_t)> &sv,
+                            const std::function<std::string(std::uint32_t, std::uint32_t, const std::string &)> &ev_store,
+                            std::string &out, std::vector<std::array<std::string, 3>> &norm_terms, std::string &why_not)
+{
+    using emit_detail::ssa_emitter;
+    const auto n_eq = p.n_eq;
+    const auto order = opts.order;
+    if (p.ev_u.empty()) {
+        why_not = "no event equations";
+        return false;
+    }
+    // Nodes needed by the event equations (transitive closure over the arguments and the hidden dependencies).
+    std::vector<char> need(p.n_u, 0);
+    for (const auto u : p.ev_u) {
+        need[u] = 1;
+    }
+    std::uint32_t n_nodes = 0;
+    for (std::uint32_t u = p.n_u; u-- > n_eq;) {
+        if (need[u] == 0) {
+            continue;
+        }
+        ++n_nodes;
+        const auto &n = p.nodes[u - n_eq];
+        if (n.kind == func_kind::custom) {
+            why_not = "an event equation depends on a function defined through a node rule";
+            return false;
+        }
+        for (const auto &o : n.args) {
+            if (o.type == operand::kind::uvar) {
+                need[o.idx] = 1;
+            } else if (o.type == operand::kind::par) {
+                why_not = "an event equation depends on a runtime parameter";
+                return false;
+            }
+        }
+        for (const auto d : n.deps) {
+            need[d] = 1;
+        }
+    }
+    // NOTE: every lane of a system runs these statements (the wavefront of the one-lane-per-pair kernel holds FOUR systems
+    // where hy_ev_jets holds 64: a convolution costs 16 times the lane-time here). What the stepper saves is the
+    // dense-output pass over the Taylor coefficients and the launch of hy_ev_jets, ~1.1 ms per 1 048 576 outer-SS systems; one
+    // nonlinear node (a convolution per order: ~230 multiply-adds) costs ~0.3 ms on that scale. The budget: three nonlinear
+    // nodes (a squared distance, a radial velocity: break-even), any number of linear ones (coordinates, differences,
+    // sums, multiples, the time: practically free).
+    std::uint32_t n_nonlin = 0;
+    for (std::uint32_t u = n_eq; u < p.n_u; ++u) {
+        if (need[u] == 0) {
+            continue;
+        }
+        const auto &n = p.nodes[u - n_eq];
+        bool linear = n.kind == func_kind::sum || n.kind == func_kind::sub || n.kind == func_kind::time;
+        if (n.kind == func_kind::prod) {
+            linear = std::any_of(n.args.begin(), n.args.end(), [](const auto &o) { return o.type != operand::kind::uvar; });
+        }
+        n_nonlin += linear ? 0u : (n.kind == func_kind::sum_sq ? static_cast<std::uint32_t>((n.args.size() + 1u) / 2u) : 1u);
+    }
+    std::uint32_t max_nonlin = 3, max_nodes = 24;
+    if (const char *ev = std::getenv("HEYOKA_AMD_EV_INLINE_MAX_NONLINEAR")) {
+        max_nonlin = static_cast<std::uint32_t>(std::max(0, std::atoi(ev)));
+    }
+    if (n_nonlin > max_nonlin || n_nodes > max_nodes) {
+        why_not = "the event equations depend on " + std::to_string(n_nonlin) + " nonlinear / " + std::to_string(n_nodes)
+                  + " nodes of the decomposition (budget inside the stepper: " + std::to_string(max_nonlin) + " / "
+                  + std::to_string(max_nodes) + ")";
+        return false;
+    }
+    ssa_emitter e(p, order);
+    // (Names of their own: the statements are pasted into the body of another generator.)
+    e.counter = 1000000000ull;
+    // (The node rules and addition order of hy_ev_jets.)
+    e.running_sums = opts.sum_order != 1;
+    for (std::uint32_t k = 0; k <= order; ++k) {
+        for (std::uint32_t i = 0; i < n_eq; ++i) {
+            if (need[i] != 0) {
+                e.val(i, k) = e.def(sv(i, k));
+            }
+        }
+        for (std::uint32_t u = n_eq; u < p.n_u; ++u) {
+            if (need[u] != 0) {
+                e.node(u - n_eq, k);
+            }
+        }
+        for (std::size_t ev = 0; ev < p.ev_u.size(); ++ev) {
+            e.os << ev_store(static_cast<std::uint32_t>(ev), k, e.val(p.ev_u[ev], k));
+        }
+    }
+    norm_terms.clear();
+    for (const auto u : p.ev_u) {
+        norm_terms.push_back({e.val(u, 0), e.val(u, order), e.val(u, order - 1u)});
+    }
+    out = e.os.str();
+    return true;
+}
+
 emitted_module emit_cluster_or_empty(const taylor_program &, const emit_options &, std::string &why_not);
 emitted_module emit_table(const taylor_program &, const emit_options &);
 emitted_module emit_block(const taylor_program &, const emit_options &, std::string &why_not);

@@ -8,6 +8,8 @@
 #pragma once
 
 #include <cstdint>
+#include <array>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -75,6 +77,12 @@ struct emit_options {
     // emit_event_jets(): the stepper it accompanies leaves out the Taylor coefficients of order >= 1 of the state variables
     // defined by another state variable (emitted_module::compact_tc): read them as parent^[k-1] / k.
     bool compact_tc = false;
+    // Stepper with events on the one-lane-per-pair kernel: the decomposition of the system WITH the event equations
+    // (prog.ev_u). When set (integrators without terminal events), the stepper evaluates the event equations itself from
+    // the jets of the state variables in LDS, extends the norms of the step-size selector to them, takes the final step
+    // size and updates the state (emitted_module::events_in_stepper): hy_ev_jets and the dense-output pass over the Taylor
+    // coefficients drop out of a step.
+    const taylor_program *ev_prog = nullptr;
 };
 
 struct emitted_module {
@@ -102,6 +110,8 @@ struct emitted_module {
     // (x' = v) only the order-0 row; x^[k] = v^[k-1] / k is left to the consumers (hy_ev_jets, hy_dout_c, hy_tc_expand in
     // the module of emit_event_jets()): half of the 6 KB per system of an N-body ensemble never travel.
     bool compact_tc = false;
+    // Mode 4 also evaluates the event equations, takes the final step size and updates the state (emit_options::ev_prog).
+    bool events_in_stepper = false;
     // When the code was generated from a rewritten INTERNAL program (state-variable aliases, padded clusters, restored unit
     // scalings - the user-visible decomposition is never touched): its text, one node per line in the format of the
     // decomposition strings, then the definitions of the state derivatives. Lets the tests run the oracle's interpreter
@@ -120,6 +130,17 @@ emitted_module emit_hip_module(const taylor_program &prog, const emit_options &o
 // prog is the decomposition of the system *with* the event equations (prog.ev_u). Returns a module with an empty source
 // (and the reason in why_not) when the event equations need too much of the decomposition.
 emitted_module emit_event_jets(const taylor_program &prog, const emit_options &opts, std::string &why_not);
+
+// The same computation as straight-line statements for use INSIDE a stepper (the one-lane-per-pair kernel in mode 4): sv(i, k)
+// gives the expression of the order-k coefficient of state variable i (every use of a coefficient goes through ONE
+// definition: one LDS read), ev_store(event, k, value) the statement which publishes a coefficient of an event equation.
+// Appends the statements to `out` and returns, per event equation, the names of its coefficients of orders 0, order and
+// order - 1 (for the norms of the step-size selector). Returns false (and the reason) if the event equations depend on
+// too much of the decomposition or on functions defined through node rules.
+bool emit_event_jets_inline(const taylor_program &prog, const emit_options &opts,
+                            const std::function<std::string(std::uint32_t, std::uint32_t)> &sv,
+                            const std::function<std::string(std::uint32_t, std::uint32_t, const std::string &)> &ev_store,
+                            std::string &out, std::vector<std::array<std::string, 3>> &norm_terms, std::string &why_not);
 
 // Format a double as a C++17 hexadecimal floating-point literal (exact round trip).
 std::string fp_literal(double);

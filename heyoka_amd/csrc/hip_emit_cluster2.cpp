@@ -1656,6 +1656,13 @@ __device__ __forceinline__ double hy_nmax(double a, double b)
     return r;
 #endif
 }
+// A product which is never contracted into an FMA with its consumer (the value must be the ROUNDED product).
+__device__ __forceinline__ double hy_mul_nc(double x, double y)
+{
+    double t = x * y;
+    asm("" : "+v"(t));
+    return t;
+}
 template <int CTRL>
 __device__ __forceinline__ double hy_dpp(double x)
 {
@@ -2007,8 +2014,82 @@ int nf_seen = 0;
     // equations (hy_ev_jets). A wave-uniform branch; every lane of the system stores the same values.
     // (A separate specialisation of the kernel - opts.event_stepper - so that the propagation kernel is not touched: the
     // extra code, although never executed there, costs it spills in the step loop.)
-    src << "const bool nostate = " << (m4 ? "true" : "false") << ";\n";
-    if (m4 && packed_tail) {
+    // Event equations inside the stepper (emit_options::ev_prog; one-lane-per-pair kernel, integrators without terminal
+    // events): their jets from the jets of the state variables in LDS - every lane of a system runs the same statements -,
+    // the three norms extended to them, then the ordinary selector, final evaluation and state update of this kernel. What
+    // is left to the kernels behind the stepper: event detection on a.ev_tc, times / outcomes / records (hy_ev_post).
+    bool ev_inline = false;
+    if (m4 && one_lane && jet_lds && packed_tail && opts.ev_prog != nullptr && !opts.exact_division && slab_stride >= n_own * L
+        && std::getenv("HEYOKA_AMD_NO_EVENTS_IN_STEPPER") == nullptr) {
+        struct sv_loc {
+            bool derived = false;
+            std::uint64_t off = 0;
+            std::uint32_t stride = 0;
+            std::uint32_t parent = 0;
+        };
+        std::vector<sv_loc> loc(n_eq);
+        for (const auto &rg : rounds) {
+            for (const auto &gr : rg) {
+                for (const auto &ow : gr.owners) {
+                    const auto &vv = utbl[ow.var_tbl];
+                    for (std::uint32_t l2 = 0; l2 < ow.n_valid; ++l2) {
+                        auto &lc = loc[vv[l2]];
+                        lc.stride = ow.n_valid;
+                        if (ow.derived) {
+                            lc.derived = true;
+                            lc.off = jet_rows_doubles + static_cast<std::uint64_t>(spw) * ow.cbase + l2;
+                            for (const auto &o2 : gr.owners) {
+                                if (o2.col == ow.parent) {
+                                    lc.parent = utbl[o2.var_tbl][l2];
+                                }
+                            }
+                        } else {
+                            lc.off = static_cast<std::uint64_t>(spw) * ow.cbase + l2;
+                        }
+                    }
+                }
+            }
+        }
+        const auto rowst = static_cast<std::uint64_t>(spw) * n_colp;
+        const std::function<std::string(std::uint32_t, std::uint32_t)> sv = [&](std::uint32_t i, std::uint32_t k) -> std::string {
+            const auto &lc = loc[i];
+            if (!lc.derived) {
+                return "jetw[" + std::to_string(k * rowst + lc.off) + "u + q * " + std::to_string(lc.stride) + "u]";
+            }
+            if (k == 0u) {
+                return "jetw[" + std::to_string(lc.off) + "u + q * " + std::to_string(lc.stride) + "u]";
+            }
+            // x^[k] = v^[k-1] * RN(1 / k): the rounded product the stepper itself would publish, kept out of contraction.
+            const auto &pl_ = loc[lc.parent];
+            return "hy_mul_nc(jetw[" + std::to_string((k - 1u) * rowst + pl_.off) + "u + q * " + std::to_string(pl_.stride) + "u], "
+                   + fp_literal(1. / static_cast<double>(k)) + ")";
+        };
+        const std::function<std::string(std::uint32_t, std::uint32_t, const std::string &)> ev_store
+            = [&](std::uint32_t ev, std::uint32_t k, const std::string &v) {
+                  return "a.ev_tc[(u64)" + std::to_string(static_cast<std::uint64_t>(ev) * (order + 1u) + k) + "u * N + s] = " + v + ";\n";
+              };
+        std::string code, why_ev;
+        std::vector<std::array<std::string, 3>> terms;
+        if (emit_event_jets_inline(*opts.ev_prog, opts, sv, ev_store, code, terms, why_ev)) {
+            ev_inline = true;
+            src << "double evm0 = 0.0, evmo = 0.0, evmom1 = 0.0;\n{\n" << code;
+            for (const auto &t3 : terms) {
+                src << "evm0 = hy_max(evm0, fabs(" << t3[0] << "));\nevmo = hy_max(evmo, fabs(" << t3[1]
+                    << "));\nevmom1 = hy_max(evmom1, fabs(" << t3[2] << "));\n";
+            }
+            src << "}\n";
+            src << "nv = hy_nmax(nv, hy_q0 ? evm0 : (hy_q1 ? evmo : evmom1));\n";
+            // (max |x_i| over the state variables and the event equations: the scale of the root finder's tolerance.)
+            src << "a.max_abs_state[s] = hy_dpp<0x00>(nv);\n";
+        }
+    }
+    src << "#define HY_EV_INLINE " << (ev_inline ? 1 : 0) << "\n";
+    src << "const bool nostate = " << ((m4 && !ev_inline) ? "true" : "false") << ";\n";
+    // (The stepper with events never advances the time: hy_ev_post does, from the step size which was finally taken.)
+    src << "const bool notime = " << (m4 ? "true" : "false") << ";\n";
+    if (ev_inline) {
+        // (Nothing to hand over: the norms are complete.)
+    } else if (m4 && packed_tail) {
         // (Every lane stores: lane & 3 selects the row, the lanes of a system write identical values.)
         src << "a.sel_norms[(u64)(((lane & 3u) < 2u) ? (lane & 3u) : 2u) * N + s] = nv;\n";
     } else if (m4) {
@@ -2147,9 +2228,15 @@ lim = fin ? 0.0 : lim;
                         src << xd << " = resd;\n";
                     }
                     src << "}\n";
-                    upd.emplace_back(xn, row0_r(ow), row0_w(ow));
+                    // (Event equations inside the stepper: the order-0 rows stay what they were - the Taylor coefficients
+                    // leave through the cooperative store behind the step - and the new state waits in the slab, which is
+                    // dead between the last order and the next step.)
+                    const auto new_at = [&](const owner_slot &o) {
+                        return ev_inline ? ("slab[" + std::to_string(o.col * L) + "u + l]") : row0_w(o);
+                    };
+                    upd.emplace_back(xn, row0_r(ow), new_at(ow));
                     if (dv != nullptr) {
-                        upd.emplace_back(xd, row0_r(*dv), row0_w(*dv));
+                        upd.emplace_back(xd, row0_r(*dv), new_at(*dv));
                     }
                 }
             }
@@ -2203,7 +2290,7 @@ int nfi = !(hy_finite(nt_hi) && hy_finite(nt_lo)) ? 1 : 0;
     // loop (see the toolchain notes in DESIGN.md). A rolled loop with a running pointer: unrolled, the (order + 1)
     // store addresses per owner slot are invariants of the step loop and get hoisted into registers (84 x 64 bit for
     // the outer Solar System) for a path that only runs when the caller asks for the coefficients.
-    src << (jet_lds ? "if (a.tc != nullptr && !nostate) {\n" : "if (a.tc != nullptr) {\n");
+    src << (jet_lds ? "if (a.tc != nullptr && !HY_M4) {\n" : "if (a.tc != nullptr) {\n");
     for (const auto &rg : rounds) {
         for (const auto &gr : rg) {
             for (const auto &ow : gr.owners) {
@@ -2250,8 +2337,8 @@ int nfi = !(hy_finite(nt_hi) && hy_finite(nt_lo)) ? 1 : 0;
     done |= sl;
     nf_seen |= (!fin & nf & !nostate) ? 1 : 0;
     // (fin: h = 0, hence nt = t, rem_new = rem, ns_new = n_steps, no min / max update - see above.)
-    t_hi = nostate ? t_hi : nt_hi;
-    t_lo = nostate ? t_lo : nt_lo;
+    t_hi = notime ? t_hi : nt_hi;
+    t_lo = notime ? t_lo : nt_lo;
     last_h = fin ? last_h : h;
     outcome = fin ? outcome : oc_fin;
     n_steps = ns_new;
@@ -2375,12 +2462,13 @@ if (nf_seen != 0 && l == 0u && live) atomicAdd(a.counters, 1u);
     for (const auto &rg : rounds) {
         for (const auto &gr : rg) {
             for (const auto &ow : gr.owners) {
-                if (m4) {
-                    // (The stepper with events leaves the state, the time and the step size to the kernels behind it.)
+                if (m4 && !ev_inline) {
+                    // (The stepper with events leaves the state, the time and the step size to the kernels behind it -
+                    // unless it evaluates the event equations itself: then the state is final here.)
                     continue;
                 }
                 src << "if (ovalid" << ow.col << " && live) a.state[(u64)hy_utbl[" << ow.var_tbl * L << "u + l] * N + s] = "
-                    << row0_w(ow) << ";\n";
+                    << (ev_inline ? ("slab[" + std::to_string(ow.col * L) + "u + l]") : row0_w(ow)) << ";\n";
             }
         }
     }
@@ -2393,8 +2481,8 @@ if (l == 0u && live) {
         } else {
             const_cast<double *>(a.lim)[s] = last_h;
         }
-        a.last_h[s] = last_h;
     }
+    if (!HY_M4 || HY_EV_INLINE) a.last_h[s] = last_h;
     a.outcome[s] = outcome;
     if (HY_MODE == 1) {
         a.min_h[s] = min_h;
@@ -2430,6 +2518,7 @@ if (l == 0u && live) {
     }
     ret.tc_optional = true;
     ret.cluster_mode4 = m4;
+    ret.events_in_stepper = ev_inline;
     ret.compact_tc = compact_tc;
     one_lane_jets_in_lds = one_lane && jet_lds;
     ret.notes = std::string(one_lane ? "cluster mode v5 (one lane per pair, 2 wavefronts per SIMD): "
@@ -2438,7 +2527,8 @@ if (l == 0u && live) {
                 + " nodes, L=" + std::to_string(L) + ", " + std::to_string(pl.n_slots) + " LDS slots x2, "
                 + std::to_string(n_own) + " state-variable owner slots, " + std::to_string(utbl.size())
                 + " slot tables, jets in " + (jet_lds ? "LDS" : "global scratch")
-                + (one_lane ? ", slab layout: " + std::to_string(bank_cost) + " conflict cycles per step in the model" : std::string{});
+                + (one_lane ? ", slab layout: " + std::to_string(bank_cost) + " conflict cycles per step in the model" : std::string{})
+                + (ev_inline ? "; event equations, final step size and state update inside the stepper" : "");
     return ret;
 }
 

@@ -628,6 +628,9 @@ tab_core::tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_siz
             auto eo2 = eo;
             eo2.mode = emit_mode::cluster;
             eo2.event_stepper = true;
+            // Without terminal events no step is ever truncated at an event: the stepper can evaluate the event equations
+            // itself, take the final step size and update the state (emit_options::ev_prog).
+            eo2.ev_prog = d.tes.empty() ? &d.prog : nullptr;
             auto m = emit_hip_module(prog0, eo2);
             std::string why;
             if (m.cluster_mode4) {
@@ -1219,7 +1222,7 @@ void tab_core::impl::launch_event_stepper(const std::vector<double> *lims)
     }
     dmod->launch_taylor(a);
     tc_expand_pending = cluster_events && emitted.compact_tc;
-    if (cluster_events) {
+    if (cluster_events && !emitted.events_in_stepper) {
         // Jets of the event equations, extended norms and final step sizes from the jets of the state variables.
         evj_mod->launch("hy_ev_jets", N, 256, &a, sizeof(a), stream);
     }
@@ -1357,7 +1360,10 @@ void tab_core::impl::step_with_events_device(const std::vector<double> *lims)
 
     // State update via dense output at the final step sizes (:781), then times / non-finite check / cooldowns /
     // outcomes / records.
-    if (tc_expand_pending) {
+    if (cluster_events && emitted.events_in_stepper) {
+        // (The stepper evaluated the event equations, took the final step size and updated the state itself; without
+        // terminal events dout_h = h for every lane.)
+    } else if (tc_expand_pending) {
         // (Compact Taylor coefficients: the dense output derives the rows the stepper left out.)
         const struct {
             double *out;

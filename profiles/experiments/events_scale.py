@@ -14,6 +14,8 @@ ap.add_argument("--steps", type=int, default=6)
 ap.add_argument("--skip-lane-stepper", action="store_true")
 ap.add_argument("--d2", type=float, default=81.0, help="squared Jupiter - Saturn distance of the event")
 ap.add_argument("--propagate", type=float, default=0.0, help="also time propagate_until(T)")
+ap.add_argument("--event", default="d2", choices=["d2", "linear"], help="d2: squared Jupiter - Saturn distance (three products); "
+                "linear: Saturn crossing y = 0 (a state variable)")
 args = ap.parse_args()
 M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
 n = args.systems
@@ -24,6 +26,8 @@ sys_ = hy.model.nbody(6, masses=M, Gconst=G)
 def events(log):
     x1, y1, z1, x2, y2, z2 = hy.make_vars("x_1", "y_1", "z_1", "x_2", "y_2", "z_2")
     d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2) - args.d2
+    if args.event == "linear":
+        return [hy.nt_event(y2, lambda ta, t, d, i: log.append((i, t)), direction=hy.event_direction.positive)]
     return [hy.nt_event(d2, lambda ta, t, d, i: log.append((i, t)), direction=hy.event_direction.negative)]
 
 

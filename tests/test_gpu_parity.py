@@ -1720,6 +1720,87 @@ def _outer_ss_event_setup(m, log, te_log):
 
 
 @pytest.mark.gpu
+def test_event_equations_inside_the_stepper_vs_oracle_and_vs_the_event_jet_kernel(monkeypatch):
+    """Integrators WITHOUT terminal events on the one-lane-per-pair stepper: the stepper evaluates the event equations itself
+    (jets of the state variables from LDS), extends the selector norms to them, takes the final step size and updates the
+    state - the reference's step_e (src/taylor_00.cpp:592-710) in one kernel; hy_ev_jets and the dense-output pass are not
+    launched. Against the oracle's stepper with events, step by step, and against the same integrator with the event
+    equations in their own kernel (HEYOKA_AMD_NO_EVENTS_IN_STEPPER=1): outcomes, step sizes, states, events in order, the
+    Taylor coefficients / dense output of the last step (still written by every step), lock-step propagation and grid. An
+    integrator with a terminal event keeps the two-kernel path (its steps can be truncated)."""
+    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    n = 70  # ragged: three wavefronts, the last one partly filled
+    st = configs.outer_ss_state(n, perturb=1e-3, seed=12)
+    logs = {"p": [], "o": [], "q": []}
+
+    def events(m, key):
+        # Saturn crossing y = 0 upwards, Jupiter overtaking Saturn in x, their distance falling below 9 AU: two linear event
+        # equations and one with three products (the budget of the stepper: three nonlinear nodes).
+        log = logs[key]
+        mk = (lambda s_: m.var(s_)) if m is ho else (lambda s_: m.make_vars(s_, "dummy__")[0])
+        x1, y1, z1, x2, y2, z2 = [mk(s_) for s_ in ("x_1", "y_1", "z_1", "x_2", "y_2", "z_2")]
+        d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2) - 81.0
+        pos = m.DIR_POSITIVE if m is ho else m.event_direction.positive
+        neg = m.DIR_NEGATIVE if m is ho else m.event_direction.negative
+        return [m.nt_event(y2, lambda ta, t, d, i: log.append((i, 0, t, d)), direction=pos),
+                m.nt_event(x1 - x2, lambda ta, t, d, i: log.append((i, 1, t, d))),
+                m.nt_event(d2, lambda ta, t, d, i: log.append((i, 2, t, d)), direction=neg)]
+
+    sys_ = hy.model.nbody(6, masses=M, Gconst=G)
+    ta = hy.taylor_adaptive_batch(sys_, st, n, high_accuracy=True, nt_events=events(hy, "p"))
+    assert "v5" in ta.hip_source_mode and "inside the stepper" in ta.hip_source_mode, ta.hip_source_mode
+    monkeypatch.setenv("HEYOKA_AMD_NO_EVENTS_IN_STEPPER", "1")
+    tq = hy.taylor_adaptive_batch(sys_, st, n, high_accuracy=True, nt_events=events(hy, "q"))
+    monkeypatch.delenv("HEYOKA_AMD_NO_EVENTS_IN_STEPPER")
+    assert "v5" in tq.hip_source_mode and "inside the stepper" not in tq.hip_source_mode
+    ora = ho.OracleEventIntegrator(ho.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True, nt_events=events(ho, "o"))
+    for it in range(40):
+        ta.step()
+        ora.step()
+        tq.step()
+        assert [int(oc) for oc, _ in ta.step_res] == [oc for oc, _ in ora.step_res]
+        assert [int(oc) for oc, _ in ta.step_res] == [int(oc) for oc, _ in tq.step_res]
+        h_p = np.array([h for _, h in ta.step_res])
+        h_o = np.array([h for _, h in ora.step_res])
+        h_q = np.array([h for _, h in tq.step_res])
+        assert np.max(np.abs(h_p - h_o) / np.abs(h_o)) <= 1e6 * EPS
+        assert np.max(np.abs(h_p - h_q) / np.abs(h_q)) <= 1e6 * EPS
+        assert rel_err(ta.state, ora.state.reshape(36, n)) <= 1e6 * EPS
+        assert rel_err(ta.state, tq.state) <= 1e6 * EPS
+        assert np.max(np.abs(ta.time - ora.time_hi)) <= 1e-11
+        if it in (0, 17):
+            # The Taylor coefficients of the step which was just taken: dense output half-way back.
+            tm = ta.time - 0.5 * h_p
+            assert rel_err(np.asarray(ta.update_d_output(tm)), np.asarray(tq.update_d_output(tm))) <= 1e6 * EPS
+            assert rel_err(np.asarray(ta.tc), np.asarray(tq.tc)) <= 1e6 * EPS
+    assert len(logs["p"]) >= n
+    assert [(a[0], a[1], a[3]) for a in logs["p"]] == [(a[0], a[1], a[3]) for a in logs["o"]]
+    assert [(a[0], a[1], a[3]) for a in logs["p"]] == [(a[0], a[1], a[3]) for a in logs["q"]]
+    assert np.max(np.abs(np.array([a[2] for a in logs["p"]]) - np.array([a[2] for a in logs["o"]]))) <= 1e-10
+    t_end = float(np.max(ora.time_hi)) + 10.0
+    ta.propagate_until(t_end)
+    ora.propagate_until(t_end)
+    tq.propagate_until(t_end)
+    assert [int(r[0]) for r in ta.propagate_res] == [r[0] for r in ora.prop_res]
+    assert max(abs(a[3] - b[3]) for a, b in zip(ta.propagate_res, ora.prop_res)) <= 1
+    assert rel_err(ta.state, ora.state.reshape(36, n)) <= 1e7 * EPS
+    assert rel_err(ta.state, tq.state) <= 1e7 * EPS
+    assert [(a[0], a[1], a[3]) for a in logs["p"]] == [(a[0], a[1], a[3]) for a in logs["o"]]
+    grid = np.repeat(t_end + np.array([0.0, 1.5, 3.0, 7.0])[:, None], n, axis=1)
+    _, out_p = ta.propagate_grid(grid)
+    _, out_q = tq.propagate_grid(grid)
+    assert rel_err(np.asarray(out_p), np.asarray(out_q)) <= 1e7 * EPS
+    assert [(a[0], a[1], a[3]) for a in logs["p"]] == [(a[0], a[1], a[3]) for a in logs["q"]]
+    # With a terminal event, or with event equations beyond the budget (radial velocity + distance: six products): the
+    # two-kernel path.
+    nt_t, te_t = _outer_ss_event_setup(hy, [], [])
+    tt = hy.taylor_adaptive_batch(sys_, st, n, high_accuracy=True, nt_events=nt_t[1:], t_events=te_t)
+    assert "v5" in tt.hip_source_mode and "inside the stepper" not in tt.hip_source_mode
+    tt = hy.taylor_adaptive_batch(sys_, st, n, high_accuracy=True, nt_events=nt_t + events(hy, "q")[2:])
+    assert "v5" in tt.hip_source_mode and "inside the stepper" not in tt.hip_source_mode
+
+
+@pytest.mark.gpu
 def test_time_dependent_events_on_the_cluster_stepper_vs_oracle():
     """Time-triggered events (time - t0, x_1 - 5 cos(time / 3)) on the outer Solar System: mode-4 cluster stepper +
     hy_ev_jets against the oracle's stepper with events."""
