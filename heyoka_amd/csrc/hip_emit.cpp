@@ -970,7 +970,7 @@ emitted_module emit_event_jets(const taylor_program &p, const emit_options &opts
 bool emit_event_jets_inline(const taylor_program &p, const emit_options &opts,
                             const std::function<std::string(std::uint32_t, std::uint32_t)> &sv,
                             const std::function<std::string(std::uint32_t, std::uint32_t, const std::string &)> &ev_store,
-                            std::string &out, std::vector<std::array<std::string, 3>> &norm_terms, std::string &why_not)
+                            std::string &out, std::vector<std::vector<std::string>> &ev_coeffs, std::string &why_not)
 {
     using emit_detail::ssa_emitter;
     const auto n_eq = p.n_eq;
@@ -1055,9 +1055,13 @@ bool emit_event_jets_inline(const taylor_program &p, const emit_options &opts,
             e.os << ev_store(static_cast<std::uint32_t>(ev), k, e.val(p.ev_u[ev], k));
         }
     }
-    norm_terms.clear();
+    ev_coeffs.clear();
     for (const auto u : p.ev_u) {
-        norm_terms.push_back({e.val(u, 0), e.val(u, order), e.val(u, order - 1u)});
+        std::vector<std::string> c;
+        for (std::uint32_t k = 0; k <= order; ++k) {
+            c.push_back(e.val(u, k));
+        }
+        ev_coeffs.push_back(std::move(c));
     }
     out = e.os.str();
     return true;

@@ -134,13 +134,13 @@ emitted_module emit_event_jets(const taylor_program &prog, const emit_options &o
 // The same computation as straight-line statements for use INSIDE a stepper (the one-lane-per-pair kernel in mode 4): sv(i, k)
 // gives the expression of the order-k coefficient of state variable i (every use of a coefficient goes through ONE
 // definition: one LDS read), ev_store(event, k, value) the statement which publishes a coefficient of an event equation.
-// Appends the statements to `out` and returns, per event equation, the names of its coefficients of orders 0, order and
-// order - 1 (for the norms of the step-size selector). Returns false (and the reason) if the event equations depend on
+// Appends the statements to `out` and returns, per event equation, the names of its coefficients by order (for the norms
+// of the step-size selector and the exclusion test). Returns false (and the reason) if the event equations depend on
 // too much of the decomposition or on functions defined through node rules.
 bool emit_event_jets_inline(const taylor_program &prog, const emit_options &opts,
                             const std::function<std::string(std::uint32_t, std::uint32_t)> &sv,
                             const std::function<std::string(std::uint32_t, std::uint32_t, const std::string &)> &ev_store,
-                            std::string &out, std::vector<std::array<std::string, 3>> &norm_terms, std::string &why_not);
+                            std::string &out, std::vector<std::vector<std::string>> &ev_coeffs, std::string &why_not);
 
 // Format a double as a C++17 hexadecimal floating-point literal (exact round trip).
 std::string fp_literal(double);

@@ -1938,6 +1938,11 @@ i64 outcome = HY_OC_SUCCESS;
 // wrong (DESIGN.md, toolchain notes).
 bool fin = false;
 int nf_seen = 0;
+// (Stepper with events which evaluates the event equations itself: does this system need its Taylor coefficients in
+// memory? See "On-demand Taylor coefficients" below. hy_kargs::pad: bit 0 = store them for every system, bit 1 = store
+// NOTHING but them - the regeneration launch on the snapshot of the state before the step.)
+bool need_tc = true;
+const bool hy_tc_only = HY_M4 && ((a.pad & 2) != 0);
 )HIP";
     // One-lane pair kernel: the per-system bookkeeping of the step loop (times, limits, counters, outcome: 30 registers
     // which nothing reads during the 20 orders) is parked in LDS between the tails of two steps - written at the end of
@@ -2019,6 +2024,7 @@ int nf_seen = 0;
     // the three norms extended to them, then the ordinary selector, final evaluation and state update of this kernel. What
     // is left to the kernels behind the stepper: event detection on a.ev_tc, times / outcomes / records (hy_ev_post).
     bool ev_inline = false;
+    std::vector<std::vector<std::string>> ev_coeffs;
     if (m4 && one_lane && jet_lds && packed_tail && opts.ev_prog != nullptr && !opts.exact_division && slab_stride >= n_own * L
         && std::getenv("HEYOKA_AMD_NO_EVENTS_IN_STEPPER") == nullptr) {
         struct sv_loc {
@@ -2069,15 +2075,15 @@ int nf_seen = 0;
                   return "a.ev_tc[(u64)" + std::to_string(static_cast<std::uint64_t>(ev) * (order + 1u) + k) + "u * N + s] = " + v + ";\n";
               };
         std::string code, why_ev;
-        std::vector<std::array<std::string, 3>> terms;
-        if (emit_event_jets_inline(*opts.ev_prog, opts, sv, ev_store, code, terms, why_ev)) {
+        if (emit_event_jets_inline(*opts.ev_prog, opts, sv, ev_store, code, ev_coeffs, why_ev)) {
             ev_inline = true;
-            src << "double evm0 = 0.0, evmo = 0.0, evmom1 = 0.0;\n{\n" << code;
-            for (const auto &t3 : terms) {
-                src << "evm0 = hy_max(evm0, fabs(" << t3[0] << "));\nevmo = hy_max(evmo, fabs(" << t3[1]
-                    << "));\nevmom1 = hy_max(evmom1, fabs(" << t3[2] << "));\n";
+            // (No scope around the statements: the coefficients of the event equations are read again by the exclusion
+            // test once the step size is known. Their names live in a range of their own.)
+            src << "double evm0 = 0.0, evmo = 0.0, evmom1 = 0.0;\n" << code;
+            for (const auto &c : ev_coeffs) {
+                src << "evm0 = hy_max(evm0, fabs(" << c[0] << "));\nevmo = hy_max(evmo, fabs(" << c[order]
+                    << "));\nevmom1 = hy_max(evmom1, fabs(" << c[order - 1u] << "));\n";
             }
-            src << "}\n";
             src << "nv = hy_nmax(nv, hy_q0 ? evm0 : (hy_q1 ? evmo : evmom1));\n";
             // (max |x_i| over the state variables and the event equations: the scale of the root finder's tolerance.)
             src << "a.max_abs_state[s] = hy_dpp<0x00>(nv);\n";
@@ -2143,6 +2149,30 @@ lim = fin ? 0.0 : lim;
     // the double-length time, the remaining time, the state and the step counters then reproduce themselves bit by bit,
     // and only the values which a zero-length step would overwrite need a select below (last_h, outcome).
     src << "h = fin ? 0.0 : h;\n";
+    if (ev_inline && std::getenv("HEYOKA_AMD_EVENTS_ALL_TC") == nullptr) {
+        // On-demand Taylor coefficients. Behind a step with events nothing reads the coefficients of the state variables
+        // unless an event is detected (its callback may ask for dense output) or the caller asks for them. The stepper
+        // runs the fast exclusion test of the detection (interval Horner enclosure of the event polynomial over the
+        // step, src/detail/event_detection.cpp:704-816) on the jets it has just computed - CONSERVATIVELY: a system counts
+        // as event-free only if the enclosure stays away from zero by 1e-8 of the largest intermediate magnitude, six
+        // orders of magnitude above the rounding differences between this evaluation and the detection kernel's own -
+        // and the workgroup stores its coefficients only if one of its systems may have an event. The integrator keeps
+        // a snapshot of the state before the step: whoever reads coefficients which were not stored gets them from a
+        // second launch on the snapshot (pad = 3), bit-identical.
+        src << "{\nbool maybe = false;\nconst double lo_h = (h < 0.0) ? h : 0.0, hi_h = (h < 0.0) ? 0.0 : h;\n";
+        for (const auto &c : ev_coeffs) {
+            src << "{\ndouble lo = " << c[order] << ", hi = lo, mm = fabs(lo);\n";
+            for (std::uint32_t i = 1; i <= order; ++i) {
+                src << "{\nconst double p0 = lo * lo_h, p1 = lo * hi_h, p2 = hi * lo_h, p3 = hi * hi_h;\n"
+                    << "const double mn = fmin(fmin(p0, p1), fmin(p2, p3)), mx = fmax(fmax(p0, p1), fmax(p2, p3));\n"
+                    << "lo = mn + " << c[order - i] << ";\nhi = mx + " << c[order - i] << ";\n"
+                    << "mm = fmax(mm, fmax(fabs(lo), fabs(hi)));\n}\n";
+            }
+            src << "const bool excl = (((lo > 0.0) & (hi > 0.0)) | ((lo < 0.0) & (hi < 0.0))) & (fmin(fabs(lo), fabs(hi)) > 1e-8 * mm);\n"
+                << "maybe = maybe | !excl;\n}\n";
+        }
+        src << "need_tc = maybe | ((a.pad & 1) != 0);\n}\n";
+    }
 
     src << "asm volatile(\"\" ::: \"memory\");\n";
     // NOTE: with the jets in global scratch the lanes exchange them through memory: wavefront-scope fences.
@@ -2447,7 +2477,10 @@ if (nf_seen != 0 && l == 0u && live) atomicAdd(a.counters, 1u);
         // loads BEHIND the stores of the previous one, and gfx9 counts loads and stores in one in-order counter (vmcnt) -
         // each iteration then waits for a store acknowledgement (12 iterations: 6 us per group of systems, 1.5 ms of a
         // 4.2 ms launch on 1 048 576 systems).
-        src << "{\n__syncthreads();\n";
+        // (Event equations inside the stepper: only if one of the systems of the workgroup needs them - need_tc.)
+        src << "{\nconst int hy_wg_tc = __syncthreads_or(need_tc ? 1 : 0);\n";
+        src << "if (hy_wg_tc == 0 && threadIdx.x == 0u) atomicAdd(a.counters + 4, 1u);\n";
+        src << "if (hy_wg_tc != 0) {\n";
         src << "const u64 bs0 = base - (u64)wib * SPW;\n";
         src << "for (unsigned idx = threadIdx.x; idx < " << n_tc_rows * spb << "u; idx += " << bs << "u) {\n";
         src << "const unsigned sy = idx % " << spb << "u;\nconst unsigned long long te = lds_tcsrc[idx / " << spb << "u];\n";
@@ -2455,7 +2488,7 @@ if (nf_seen != 0 && l == 0u && live) atomicAdd(a.counters, 1u);
                "(unsigned)(te >> 40);\n";
         src << "const u64 sg = bs0 + sy;\n";
         src << "const double val = lds_jet[(sy / SPW) * " << jet_doubles_per_wave << "u + off + (sy % SPW) * sst];\n";
-        src << "if (sg < N) a.tc[(u64)row * N + sg] = val;\n}\n__syncthreads();\n}\n";
+        src << "if (sg < N) a.tc[(u64)row * N + sg] = val;\n}\n}\n__syncthreads();\n}\n";
     }
     src << R"HIP(
 )HIP";
@@ -2467,13 +2500,13 @@ if (nf_seen != 0 && l == 0u && live) atomicAdd(a.counters, 1u);
                     // unless it evaluates the event equations itself: then the state is final here.)
                     continue;
                 }
-                src << "if (ovalid" << ow.col << " && live) a.state[(u64)hy_utbl[" << ow.var_tbl * L << "u + l] * N + s] = "
+                src << "if (ovalid" << ow.col << " && live && !hy_tc_only) a.state[(u64)hy_utbl[" << ow.var_tbl * L << "u + l] * N + s] = "
                     << (ev_inline ? ("slab[" + std::to_string(ow.col * L) + "u + l]") : row0_w(ow)) << ";\n";
             }
         }
     }
     src << R"HIP(
-if (l == 0u && live) {
+if (l == 0u && live && !hy_tc_only) {
     if (!HY_M4) {
         if (HY_MODE != 2) {
             a.time_hi[s] = t_hi;

@@ -122,6 +122,16 @@ struct tab_core::impl {
     // before anybody reads the full array.
     mutable bool tc_expand_pending = false;
     void ensure_tc_expanded() const;
+    // Stepper with events which evaluates the event equations itself (emitted_module::events_in_stepper): the Taylor
+    // coefficients of a step are stored only for the workgroups in which an event may have happened; the state and time
+    // before the step are kept, and whoever reads coefficients which were not stored (get_tc(), update_d_output(),
+    // continuous output, propagate_grid()) triggers a second launch of the stepper on the snapshot which stores nothing
+    // but them (bit-identical: the same kernel on the same input). ev_all_tc: store them in every step (lock-step loops
+    // which consume them step by step).
+    device_buffer evs_state, evs_thi, evs_tlo;
+    mutable bool tc_partial = false;
+    bool ev_all_tc = false;
+    void ensure_tc_complete() const;
     std::uint64_t last_total_steps = 0;
     // Set by the lock-step propagate loop to override the device outcomes.
     mutable std::optional<taylor_outcome> prop_res_override;
@@ -932,8 +942,31 @@ double *tab_core::get_pars_data()
     return d.pars.data();
 }
 
+void tab_core::impl::ensure_tc_complete() const
+{
+    if (!tc_partial) {
+        return;
+    }
+    tc_partial = false;
+    auto &self = const_cast<impl &>(*this);
+    auto a = self.base_args();
+    a.state = evs_state.as<double>();
+    a.time_hi = evs_thi.as<double>();
+    a.time_lo = evs_tlo.as<double>();
+    a.tc = d_tc.as<double>();
+    a.ev_tc = d_ev_tc.as<double>();
+    a.max_abs_state = d_mas.as<double>();
+    a.sel_norms = d_selnorms.as<double>();
+    a.mode = 4;
+    a.pad = 3; // every workgroup stores its coefficients, nothing else is stored
+    self.d_counters.zero(stream);
+    dmod->launch_taylor(a);
+    tc_expand_pending = emitted.compact_tc;
+}
+
 void tab_core::impl::ensure_tc_expanded() const
 {
+    ensure_tc_complete();
     if (!tc_expand_pending || !evj_mod) {
         return;
     }
@@ -1213,6 +1246,21 @@ void tab_core::impl::launch_event_stepper(const std::vector<double> *lims)
     a.ev_tc = d_ev_tc.as<double>();
     a.max_abs_state = d_mas.as<double>();
     a.mode = 4;
+    a.pad = 1;
+    if (cluster_events && emitted.events_in_stepper) {
+        tc_partial = false; // (nobody asked for the coefficients of the previous step: this step replaces them)
+        if (!ev_all_tc) {
+            if (evs_state.bytes() == 0u) {
+                evs_state = device_buffer(d_state.bytes(), device);
+                evs_thi = device_buffer(d_thi.bytes(), device);
+                evs_tlo = device_buffer(d_tlo.bytes(), device);
+            }
+            device_copy(evs_state.get(), d_state.get(), d_state.bytes(), device, stream);
+            device_copy(evs_thi.get(), d_thi.get(), d_thi.bytes(), device, stream);
+            device_copy(evs_tlo.get(), d_tlo.get(), d_tlo.bytes(), device, stream);
+            a.pad = 0;
+        }
+    }
     if (cluster_events) {
         if (d_selnorms.bytes() == 0u) {
             d_selnorms = device_buffer(3u * n * dsz, device);
@@ -1350,6 +1398,12 @@ void tab_core::impl::step_with_events_device(const std::vector<double> *lims)
     unsigned flags[3] = {0, 0, 0};
     unsigned long long cur[2] = {0, 0};
     d_ed_flags.download(flags, sizeof(flags), stream);
+    if (cluster_events && emitted.events_in_stepper && !ev_all_tc) {
+        // (Workgroups of the stepper which did not store their Taylor coefficients.)
+        unsigned cnt[5] = {0, 0, 0, 0, 0};
+        d_counters.download(cnt, sizeof(cnt), stream);
+        tc_partial = cnt[4] != 0u;
+    }
     d_ev_cursor.download(cur, sizeof(cur), stream);
     report_ed_failures(ed_failures, flags);
     lap("pre + flags to host");
@@ -1854,6 +1908,19 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
                 d.last_c_out = cob->finish(t_dir);
             }
         };
+        // (Continuous output consumes the Taylor coefficients of every step.)
+        const struct all_tc_guard {
+            bool &flag;
+            bool old;
+            all_tc_guard(bool &f, bool v) : flag(f), old(f)
+            {
+                flag = v;
+            }
+            ~all_tc_guard()
+            {
+                flag = old;
+            }
+        } tc_guard(d.ev_all_tc, static_cast<bool>(cob));
         while (true) {
             if (d.has_events()) {
                 // (Callbacks of the events run inside: state, times, outcomes and cooldowns stay on the device.)
@@ -2132,6 +2199,15 @@ void tab_core::propagate_grid_device_loop(const std::vector<double> &grid, std::
     d.fix_step_limit = false;
     std::size_t iter_counter = 0;
     bool any_step = false;
+    // (The dense output over the grid consumes the Taylor coefficients of every step.)
+    d.ev_all_tc = true;
+    const struct all_tc_reset {
+        bool &flag;
+        ~all_tc_reset()
+        {
+            flag = false;
+        }
+    } tc_reset{d.ev_all_tc};
     while (n_grid > 1u) {
         if (d.has_events()) {
             d.step_with_events_device(nullptr);
@@ -2441,6 +2517,10 @@ void tab_core::set_device(int device)
     d.grid_mod.reset();
     d.evj_mod.reset();
     d.tc_expand_pending = false;
+    d.tc_partial = false;
+    d.evs_state = {};
+    d.evs_thi = {};
+    d.evs_tlo = {};
     d.d_selnorms = {};
     d.d_ev_cursor = {};
     d.d_ev_rec = {};
