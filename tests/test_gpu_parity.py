@@ -1791,6 +1791,24 @@ def test_event_equations_inside_the_stepper_vs_oracle_and_vs_the_event_jet_kerne
     _, out_q = tq.propagate_grid(grid)
     assert rel_err(np.asarray(out_p), np.asarray(out_q)) <= 1e7 * EPS
     assert [(a[0], a[1], a[3]) for a in logs["p"]] == [(a[0], a[1], a[3]) for a in logs["q"]]
+    # Taylor coefficients on demand: the stepper stores them only for workgroups in which an event may have happened and the
+    # integrator regenerates the rest from its snapshot of the state before the step. (a) The regeneration stores nothing
+    # but the coefficients: a state which was set after the step survives it, and the coefficients are those of the step;
+    # (b) continuous output (every step's coefficients are consumed: stored by every step).
+    ta.step()
+    tq.step()
+    mod = ta.state * (1.0 + 1e-3)
+    ta.state = mod
+    assert rel_err(np.asarray(ta.tc), np.asarray(tq.tc)) <= 1e6 * EPS
+    assert np.array_equal(ta.state, mod)
+    assert rel_err(np.asarray(ta.tc)[:, 0, :], np.asarray(tq.tc)[:, 0, :]) <= 1e6 * EPS
+    ta.state = tq.state
+    t_c = float(np.max(ta.time)) + 6.0
+    co_p, _ = ta.propagate_until(t_c, c_output=True)
+    co_q, _ = tq.propagate_until(t_c, c_output=True)
+    for frac in (0.1, 0.5, 0.9):
+        tm = t_c - 6.0 * frac
+        assert rel_err(np.asarray(co_p(tm)), np.asarray(co_q(tm))) <= 1e7 * EPS
     # With a terminal event, or with event equations beyond the budget (radial velocity + distance: six products): the
     # two-kernel path.
     nt_t, te_t = _outer_ss_event_setup(hy, [], [])
