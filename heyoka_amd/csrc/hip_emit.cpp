@@ -835,7 +835,9 @@ emitted_module emit_event_jets(const taylor_program &p, const emit_options &opts
         os << "};\n";
         const std::string coeff
             = opts.exact_division ? "(cp[(u64)(k - 1u) * N] / hy_rk_c[k])" : "hy_mul_nc(cp[(u64)(k - 1u) * N], hy_rk_c[k])";
-        os << "struct hy_doutc_args { double *out; const double *tc; const double *hs; u64 N; };\n";
+        // (hfull != nullptr: only the lanes whose step was truncated - hs[s] != hfull[s] - are updated: the stepper which
+        // evaluates the event equations itself has already taken the full step everywhere.)
+        os << "struct hy_doutc_args { double *out; const double *tc; const double *hs; u64 N; const double *hfull; };\n";
         // hy_dout_c: ONE pass over the coefficients of every stored variable v updates its own sum and the sum of the
         // variable x it defines (x' = v: x^[k] = v^[k-1] / k) - the rows of v are read once, with the operations and the
         // operation order of hy_dout on the full set.
@@ -854,6 +856,7 @@ emitted_module emit_event_jets(const taylor_program &p, const emit_options &opts
         os << "extern \"C\" __global__ void __launch_bounds__(256) hy_dout_c(const hy_doutc_args a)\n{\n";
         os << "const u64 N = a.N;\nconst u64 s = (u64)blockIdx.x * 256u + threadIdx.x;\nif (s >= N) return;\n";
         os << "const double h = a.hs[s];\n";
+        os << "if (a.hfull != nullptr && h == a.hfull[s]) return;\n";
         os << "for (unsigned j = 0; j < " << n_eq << "u; ++j) {\n";
         os << "if (hy_tc_parent[j] >= 0) continue;\n";
         os << "const int ch = hy_tc_child[j];\n";

@@ -78,7 +78,7 @@ struct emit_options {
     // defined by another state variable (emitted_module::compact_tc): read them as parent^[k-1] / k.
     bool compact_tc = false;
     // Stepper with events on the one-lane-per-pair kernel: the decomposition of the system WITH the event equations
-    // (prog.ev_u). When set (integrators without terminal events), the stepper evaluates the event equations itself from
+    // (prog.ev_u). When set, the stepper evaluates the event equations itself from
     // the jets of the state variables in LDS, extends the norms of the step-size selector to them, takes the final step
     // size and updates the state (emitted_module::events_in_stepper): hy_ev_jets and the dense-output pass over the Taylor
     // coefficients drop out of a step.

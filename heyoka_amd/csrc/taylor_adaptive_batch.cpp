@@ -638,9 +638,10 @@ tab_core::tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_siz
             auto eo2 = eo;
             eo2.mode = emit_mode::cluster;
             eo2.event_stepper = true;
-            // Without terminal events no step is ever truncated at an event: the stepper can evaluate the event equations
-            // itself, take the final step size and update the state (emit_options::ev_prog).
-            eo2.ev_prog = d.tes.empty() ? &d.prog : nullptr;
+            // The stepper may evaluate the event equations itself, take the final step size and update the state
+            // (emit_options::ev_prog); lanes whose step is truncated at a terminal event are redone from the Taylor
+            // coefficients afterwards.
+            eo2.ev_prog = &d.prog;
             auto m = emit_hip_module(prog0, eo2);
             std::string why;
             if (m.cluster_mode4) {
@@ -975,7 +976,8 @@ void tab_core::impl::ensure_tc_expanded() const
         const double *tc;
         const double *hs;
         unsigned long long N;
-    } ea{d_tc.as<double>(), d_tc.as<double>(), nullptr, N};
+        const double *hfull;
+    } ea{d_tc.as<double>(), d_tc.as<double>(), nullptr, N, nullptr};
     evj_mod->launch("hy_tc_expand", N, 256, &ea, sizeof(ea), stream);
     tc_expand_pending = false;
 }
@@ -1415,8 +1417,19 @@ void tab_core::impl::step_with_events_device(const std::vector<double> *lims)
     // State update via dense output at the final step sizes (:781), then times / non-finite check / cooldowns /
     // outcomes / records.
     if (cluster_events && emitted.events_in_stepper) {
-        // (The stepper evaluated the event equations, took the final step size and updated the state itself; without
-        // terminal events dout_h = h for every lane.)
+        // (The stepper evaluated the event equations, took the final step size and updated the state itself.) Lanes whose
+        // step is truncated at a terminal event (dout_h != h) are redone from the Taylor coefficients: their workgroup
+        // stored them - a detected event is an event the stepper's exclusion test could not rule out.
+        if (n_te != 0u) {
+            const struct {
+                double *out;
+                const double *tc;
+                const double *hs;
+                unsigned long long N;
+                const double *hfull;
+            } da{d_state.as<double>(), d_tc.as<double>(), d_douth.as<double>(), N, d_lasth.as<double>()};
+            evj_mod->launch("hy_dout_c", N, 256, &da, sizeof(da), stream);
+        }
     } else if (tc_expand_pending) {
         // (Compact Taylor coefficients: the dense output derives the rows the stepper left out.)
         const struct {
@@ -1424,7 +1437,8 @@ void tab_core::impl::step_with_events_device(const std::vector<double> *lims)
             const double *tc;
             const double *hs;
             unsigned long long N;
-        } da{d_state.as<double>(), d_tc.as<double>(), d_douth.as<double>(), N};
+            const double *hfull;
+        } da{d_state.as<double>(), d_tc.as<double>(), d_douth.as<double>(), N, nullptr};
         evj_mod->launch("hy_dout_c", N, 256, &da, sizeof(da), stream);
     } else {
         dmod->launch_dout(d_state.as<double>(), d_tc.as<double>(), d_douth.as<double>(), N);

@@ -1809,13 +1809,61 @@ def test_event_equations_inside_the_stepper_vs_oracle_and_vs_the_event_jet_kerne
     for frac in (0.1, 0.5, 0.9):
         tm = t_c - 6.0 * frac
         assert rel_err(np.asarray(co_p(tm)), np.asarray(co_q(tm))) <= 1e7 * EPS
-    # With a terminal event, or with event equations beyond the budget (radial velocity + distance: six products): the
-    # two-kernel path.
+    # Event equations beyond the budget (radial velocity + distance: six products): the three-kernel path.
     nt_t, te_t = _outer_ss_event_setup(hy, [], [])
-    tt = hy.taylor_adaptive_batch(sys_, st, n, high_accuracy=True, nt_events=nt_t[1:], t_events=te_t)
-    assert "v5" in tt.hip_source_mode and "inside the stepper" not in tt.hip_source_mode
     tt = hy.taylor_adaptive_batch(sys_, st, n, high_accuracy=True, nt_events=nt_t + events(hy, "q")[2:])
     assert "v5" in tt.hip_source_mode and "inside the stepper" not in tt.hip_source_mode
+
+
+@pytest.mark.gpu
+def test_terminal_events_with_the_event_equations_inside_the_stepper_vs_oracle():
+    """A terminal event truncates the step of ITS lane at the event (src/taylor_adaptive_batch.cpp:771-781): the stepper which
+    evaluates the event equations itself takes the full step everywhere, and the lanes with a terminal event are redone from
+    the Taylor coefficients (their workgroup stored them: a detected event is one the stepper's exclusion test could not
+    rule out). Jupiter - Saturn distance below 9 AU as a terminal event whose callback keeps going (cooldown deduced
+    automatically), two linear non-terminal events; step by step against the oracle."""
+    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    n = 40
+    st = configs.outer_ss_state(n, perturb=1e-3, seed=14)
+    logs = {"p": ([], []), "o": ([], [])}
+
+    def events(m, key):
+        log, te_log = logs[key]
+        mk = (lambda s_: m.var(s_)) if m is ho else (lambda s_: m.make_vars(s_, "dummy__")[0])
+        x1, y1, z1, x2, y2, z2 = [mk(s_) for s_ in ("x_1", "y_1", "z_1", "x_2", "y_2", "z_2")]
+        d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2) - 81.0
+        pos = m.DIR_POSITIVE if m is ho else m.event_direction.positive
+        neg = m.DIR_NEGATIVE if m is ho else m.event_direction.negative
+        nt = [m.nt_event(y2, lambda ta, t, d, i: log.append((i, 0, t, d)), direction=pos),
+              m.nt_event(x1 - x2, lambda ta, t, d, i: log.append((i, 1, t, d)))]
+        te = [m.t_event(d2, lambda ta, d, i: te_log.append((i, d)) or True, direction=neg)]
+        return nt, te
+
+    nt_p, te_p = events(hy, "p")
+    ta = hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True, nt_events=nt_p, t_events=te_p)
+    assert "v5" in ta.hip_source_mode and "inside the stepper" in ta.hip_source_mode, ta.hip_source_mode
+    nt_o, te_o = events(ho, "o")
+    ora = ho.OracleEventIntegrator(ho.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True, nt_events=nt_o, t_events=te_o)
+    seen_te = 0
+    for _ in range(60):
+        ta.step()
+        ora.step()
+        oc_p = [int(oc) for oc, _ in ta.step_res]
+        assert oc_p == [oc for oc, _ in ora.step_res]
+        seen_te += sum(1 for oc in oc_p if oc >= 0)
+        h_p = np.array([h for _, h in ta.step_res])
+        h_o = np.array([h for _, h in ora.step_res])
+        assert np.max(np.abs(h_p - h_o) / np.abs(h_o)) <= 1e6 * EPS
+        assert rel_err(ta.state, ora.state.reshape(36, n)) <= 1e6 * EPS
+        assert np.max(np.abs(ta.time - ora.time_hi)) <= 1e-10
+    assert seen_te >= n // 2 and logs["p"][1] == logs["o"][1]
+    assert [(a[0], a[1], a[3]) for a in logs["p"][0]] == [(a[0], a[1], a[3]) for a in logs["o"][0]]
+    t_end = float(np.max(ora.time_hi)) + 8.0
+    ta.propagate_until(t_end)
+    ora.propagate_until(t_end)
+    assert [int(r[0]) for r in ta.propagate_res] == [r[0] for r in ora.prop_res]
+    assert rel_err(ta.state, ora.state.reshape(36, n)) <= 1e7 * EPS
+    assert logs["p"][1] == logs["o"][1]
 
 
 @pytest.mark.gpu
