@@ -161,6 +161,17 @@ def test_event_integrators_pick_the_cluster_stepper_when_the_event_equations_are
     mode = ta.hip_source_mode
     assert mode.startswith("cluster") and "events: jets of 3 event equation(s)" in mode, mode
     src = ta.hip_source
+    # Round 4: event equations of up to three nonlinear nodes are evaluated by the stepper itself (the jets of the event
+    # equations leave from there, the selector norms stay in registers); the cooperative store of the Taylor coefficients runs
+    # for the workgroups which may have an event.
+    assert "inside the stepper" in mode and "a.ev_tc[" in src and "a.sel_norms[" not in src and "__syncthreads_or" in src
+    monkeypatch.setenv("HEYOKA_AMD_NO_EVENTS_IN_STEPPER", "1")
+    ta2 = hy.taylor_adaptive_batch(sys_, None, 8, high_accuracy=True,
+                                   nt_events=[hy.nt_event((x1 - x2) * (x1 - x2) - 4.0, cb), hy.nt_event(y1, cb)],
+                                   t_events=[hy.t_event(x1 * vx1)])
+    monkeypatch.delenv("HEYOKA_AMD_NO_EVENTS_IN_STEPPER")
+    src = ta2.hip_source
+    assert "inside the stepper" not in ta2.hip_source_mode
     assert "a.sel_norms[" in src and "__syncthreads" in src  # the mode-4 specialisation, cooperative tc store
     # The plain integrator of the same system keeps the propagation kernel (no mode-4 code in it).
     tb = hy.taylor_adaptive_batch(sys_, None, 8, high_accuracy=True)
