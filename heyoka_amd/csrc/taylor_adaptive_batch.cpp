@@ -131,6 +131,9 @@ struct tab_core::impl {
     device_buffer evs_state, evs_thi, evs_tlo;
     mutable bool tc_partial = false;
     bool ev_all_tc = false;
+    // (A caller who read the coefficients of the previous step - a step callback with dense output, say - will probably read
+    // those of the next one: that step stores them all instead of paying for a second launch again.)
+    mutable bool tc_regenerated = false;
     void ensure_tc_complete() const;
     std::uint64_t last_total_steps = 0;
     // Set by the lock-step propagate loop to override the device outcomes.
@@ -949,6 +952,7 @@ void tab_core::impl::ensure_tc_complete() const
         return;
     }
     tc_partial = false;
+    tc_regenerated = true;
     auto &self = const_cast<impl &>(*this);
     auto a = self.base_args();
     a.state = evs_state.as<double>();
@@ -1251,7 +1255,9 @@ void tab_core::impl::launch_event_stepper(const std::vector<double> *lims)
     a.pad = 1;
     if (cluster_events && emitted.events_in_stepper) {
         tc_partial = false; // (nobody asked for the coefficients of the previous step: this step replaces them)
-        if (!ev_all_tc) {
+        const bool all_now = ev_all_tc || tc_regenerated;
+        tc_regenerated = false;
+        if (!all_now) {
             if (evs_state.bytes() == 0u) {
                 evs_state = device_buffer(d_state.bytes(), device);
                 evs_thi = device_buffer(d_thi.bytes(), device);
@@ -1400,8 +1406,8 @@ void tab_core::impl::step_with_events_device(const std::vector<double> *lims)
     unsigned flags[3] = {0, 0, 0};
     unsigned long long cur[2] = {0, 0};
     d_ed_flags.download(flags, sizeof(flags), stream);
-    if (cluster_events && emitted.events_in_stepper && !ev_all_tc) {
-        // (Workgroups of the stepper which did not store their Taylor coefficients.)
+    if (cluster_events && emitted.events_in_stepper) {
+        // (Workgroups of the stepper which did not store their Taylor coefficients: none if it was asked to store all.)
         unsigned cnt[5] = {0, 0, 0, 0, 0};
         d_counters.download(cnt, sizeof(cnt), stream);
         tc_partial = cnt[4] != 0u;

@@ -29,12 +29,20 @@ def _cases():
     kep = [(h_, -0.01 * hy.sin(F_)), (k_, 0.02 * hy.cos(F_) + 0.01 * hy.kepDE(0.1 * h_, 0.2 + k_, 0.3 * lam_)), (lam_, 1.0 + 0.1 * h_ * k_)]
     x1, x2 = hy.make_vars("x_1", "x_2")
     ev_ss = [hy.nt_event((x1 - x2) * (x1 - x2) - 4.0, lambda *a: None)]
+    y1_, y2_, z1_, z2_ = hy.make_vars("y_1", "y_2", "z_1", "z_2")
+    ev_ss3 = [hy.nt_event(y2_, lambda *a: None), hy.nt_event(x1 - x2, lambda *a: None),
+              hy.nt_event((x1 - x2) * (x1 - x2) + (y1_ - y2_) * (y1_ - y2_) + (z1_ - z2_) * (z1_ - z2_) - 81.0, lambda *a: None)]
     return {
         "outer_ss_cluster_event_stepper": (lambda: hy.model.nbody(6, masses=M, Gconst=G),
                                            {"high_accuracy": True, "nt_events": ev_ss}, {}, "events:"),
         "outer_ss_cluster_event_stepper_v3": (lambda: hy.model.nbody(6, masses=M, Gconst=G),
                                               {"high_accuracy": True, "nt_events": ev_ss}, {"HEYOKA_AMD_V5_EVENTS": "0"},
                                               "events:"),
+        # Event equations evaluated inside the stepper (three events, three nonlinear nodes: the budget), exclusion test,
+        # conditional store of the Taylor coefficients.
+        "outer_ss_event_equations_inside_the_stepper": (lambda: hy.model.nbody(6, masses=M, Gconst=G),
+                                                        {"high_accuracy": True, "nt_events": ev_ss3,
+                                                         "t_events": [hy.t_event(x1 - 3.0)]}, {}, "inside the stepper"),
         "outer_ss_cluster_v5": (lambda: hy.model.nbody(6, masses=M, Gconst=G), {"high_accuracy": True}, {}, "v5"),
         "outer_ss_cluster_v3": (lambda: hy.model.nbody(6, masses=M, Gconst=G), {"high_accuracy": True},
                                 {"HEYOKA_AMD_ONE_LANE": "0"}, "v3"),
