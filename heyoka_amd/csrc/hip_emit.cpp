@@ -6,11 +6,13 @@
 #include "hip_emit.hpp"
 #include "hip_emit_detail.hpp"
 
+#include <algorithm>
 #include <cassert>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
+#include <map>
 #include <sstream>
 #include <stdexcept>
 
@@ -973,7 +975,8 @@ emitted_module emit_event_jets(const taylor_program &p, const emit_options &opts
 bool emit_event_jets_inline(const taylor_program &p, const emit_options &opts,
                             const std::function<std::string(std::uint32_t, std::uint32_t)> &sv,
                             const std::function<std::string(std::uint32_t, std::uint32_t, const std::string &)> &ev_store,
-                            std::string &out, std::vector<std::vector<std::string>> &ev_coeffs, std::string &why_not)
+                            std::string &out, std::vector<std::vector<std::string>> &ev_coeffs, std::string &why_not,
+                            ev_lane_hooks *lanes)
 {
     using emit_detail::ssa_emitter;
     const auto n_eq = p.n_eq;
@@ -982,10 +985,13 @@ bool emit_event_jets_inline(const taylor_program &p, const emit_options &opts,
         why_not = "no event equations";
         return false;
     }
-    // Nodes needed by the event equations (transitive closure over the arguments and the hidden dependencies).
+    // Nodes needed by the event equations (transitive closure over the arguments and the hidden dependencies), and how
+    // often each of them is read (by a needed node or as an event equation).
     std::vector<char> need(p.n_u, 0);
+    std::vector<std::uint32_t> uses(p.n_u, 0);
     for (const auto u : p.ev_u) {
         need[u] = 1;
+        ++uses[u];
     }
     std::uint32_t n_nodes = 0;
     for (std::uint32_t u = p.n_u; u-- > n_eq;) {
@@ -1001,6 +1007,7 @@ bool emit_event_jets_inline(const taylor_program &p, const emit_options &opts,
         for (const auto &o : n.args) {
             if (o.type == operand::kind::uvar) {
                 need[o.idx] = 1;
+                ++uses[o.idx];
             } else if (o.type == operand::kind::par) {
                 why_not = "an event equation depends on a runtime parameter";
                 return false;
@@ -1008,17 +1015,171 @@ bool emit_event_jets_inline(const taylor_program &p, const emit_options &opts,
         }
         for (const auto d : n.deps) {
             need[d] = 1;
+            ++uses[d];
         }
     }
+
+    // Sums of isomorphic terms (ev_lane_hooks): which needed nodes are evaluated by lane c of the system for term c. A sum
+    // written with binary operators arrives as a chain, sum(sum(t0, t1), t2): a later sum which adds more terms of the same
+    // shape to the result of an earlier one extends its group.
+    struct lane_group {
+        std::vector<std::uint32_t> roots;               // root of term c
+        std::vector<std::uint32_t> nodes0;              // nodes of term 0 (ascending)
+        std::vector<std::vector<std::uint32_t>> leaves; // [c][p]: state variable at leaf position p of term c
+        std::string sig;
+        // sum node -> (argument position, term) pairs it collects
+        std::map<std::uint32_t, std::vector<std::pair<std::uint32_t, std::uint32_t>>> collect;
+        std::uint32_t last_sum = 0;
+    };
+    std::vector<lane_group> groups;
+    std::vector<int> owner(p.n_u, -1);   // group of a node which belongs to a term (roots included)
+    std::vector<char> skipped(p.n_u, 0); // nodes of the terms c >= 1: never emitted
+    if (lanes != nullptr) {
+        lanes->leaf_vars.clear();
+        lanes->leaf_class.clear();
+        std::vector<std::vector<std::uint32_t>> claimed; // nodes of all the terms accepted so far
+        const auto linear_node = [&](const dc_node &n) {
+            return n.kind == func_kind::sum || n.kind == func_kind::sub
+                   || (n.kind == func_kind::prod
+                       && std::any_of(n.args.begin(), n.args.end(), [](const auto &o) { return o.type != operand::kind::uvar; }));
+        };
+        for (std::uint32_t S = n_eq; S < p.n_u; ++S) {
+            const auto &ns = p.nodes[S - n_eq];
+            const auto m = static_cast<std::uint32_t>(ns.args.size());
+            if (need[S] == 0 || ns.kind != func_kind::sum || m < 2u) {
+                continue;
+            }
+            bool ok = true;
+            int ext = -1; // the group whose running sum is one of the arguments
+            std::vector<std::uint32_t> cand_pos;
+            for (std::uint32_t a = 0; ok && a < m; ++a) {
+                const auto &o = ns.args[a];
+                ok = ok && o.type == operand::kind::uvar && o.idx >= n_eq && uses[o.idx] == 1u;
+                if (!ok) {
+                    break;
+                }
+                int gs = -1;
+                for (std::size_t gi = 0; gi < groups.size(); ++gi) {
+                    if (groups[gi].last_sum == o.idx) {
+                        gs = static_cast<int>(gi);
+                    }
+                }
+                if (gs >= 0) {
+                    ok = ok && ext < 0;
+                    ext = gs;
+                } else {
+                    ok = ok && owner[o.idx] < 0;
+                    cand_pos.push_back(a);
+                }
+                for (std::uint32_t b = a + 1u; b < m; ++b) {
+                    ok = ok && ns.args[a].idx != ns.args[b].idx;
+                }
+            }
+            const auto n_old = ext >= 0 ? static_cast<std::uint32_t>(groups[static_cast<std::size_t>(ext)].roots.size()) : 0u;
+            ok = ok && !cand_pos.empty() && (ext >= 0 || cand_pos.size() >= 2u) && n_old + cand_pos.size() <= lanes->max_terms;
+            if (!ok) {
+                continue;
+            }
+            std::vector<std::string> sigs;
+            std::vector<std::vector<std::uint32_t>> term_nodes, term_leaves;
+            for (std::size_t ci = 0; ok && ci < cand_pos.size(); ++ci) {
+                const auto root = ns.args[cand_pos[ci]].idx;
+                std::vector<std::uint32_t> nodes, leaves;
+                std::map<std::uint32_t, std::uint32_t> refs; // references to the nodes of the term from inside it
+                const std::function<std::string(std::uint32_t)> sig = [&](std::uint32_t u) -> std::string {
+                    if (u < n_eq) {
+                        auto it = std::find(leaves.begin(), leaves.end(), u);
+                        if (it == leaves.end()) {
+                            leaves.push_back(u);
+                            it = leaves.end() - 1;
+                        }
+                        return "s" + std::to_string(lanes->sv_class(u)) + ":" + std::to_string(it - leaves.begin());
+                    }
+                    ++refs[u];
+                    if (const auto it = std::find(nodes.begin(), nodes.end(), u); it != nodes.end()) {
+                        return "r" + std::to_string(it - nodes.begin());
+                    }
+                    const auto &n = p.nodes[u - n_eq];
+                    if (!n.deps.empty() || n.kind == func_kind::time || owner[u] >= 0) {
+                        ok = false;
+                        return "";
+                    }
+                    nodes.push_back(u);
+                    std::string r = std::string(func_kind_name(n.kind)) + "[";
+                    for (const auto &o : n.args) {
+                        if (o.type == operand::kind::par) {
+                            ok = false;
+                        }
+                        r += (o.type == operand::kind::num) ? ("n" + fp_literal(o.value)) : sig(o.idx);
+                        r += ",";
+                    }
+                    return r + "]";
+                };
+                sigs.push_back(sig(root));
+                // Nothing outside the term reads its nodes (the reference of the sum to the root is the first call of sig()).
+                for (const auto u : nodes) {
+                    ok = ok && uses[u] == refs[u];
+                }
+                // (Terms are disjoint.)
+                for (const auto *lst : {&claimed, &term_nodes}) {
+                    for (const auto &tn : *lst) {
+                        for (const auto u : nodes) {
+                            ok = ok && std::find(tn.begin(), tn.end(), u) == tn.end();
+                        }
+                    }
+                }
+                const auto &ref_sig = ext >= 0 ? groups[static_cast<std::size_t>(ext)].sig : sigs[0];
+                ok = ok && sigs.back() == ref_sig && !leaves.empty();
+                std::sort(nodes.begin(), nodes.end());
+                term_nodes.push_back(std::move(nodes));
+                term_leaves.push_back(std::move(leaves));
+            }
+            // A term without a convolution is not worth the lane broadcasts.
+            bool has_conv = ext >= 0;
+            if (ok && ext < 0) {
+                for (const auto u : term_nodes[0]) {
+                    has_conv = has_conv || !linear_node(p.nodes[u - n_eq]);
+                }
+            }
+            if (std::getenv("HEYOKA_AMD_EV_DEBUG") != nullptr) {
+                std::fprintf(stderr, "[event lanes] sum u_%u: %zu new term(s)%s: %s (%s)\n", S, cand_pos.size(),
+                             ext >= 0 ? " added to an earlier sum" : "", (ok && has_conv) ? "side by side" : "no",
+                             sigs.empty() ? "" : sigs.back().c_str());
+            }
+            if (!ok || !has_conv) {
+                continue;
+            }
+            if (ext < 0) {
+                groups.emplace_back();
+                ext = static_cast<int>(groups.size()) - 1;
+                groups.back().sig = sigs[0];
+                groups.back().nodes0 = term_nodes[0];
+            }
+            auto &g = groups[static_cast<std::size_t>(ext)];
+            for (std::size_t ci = 0; ci < cand_pos.size(); ++ci) {
+                const auto c = static_cast<std::uint32_t>(g.roots.size());
+                for (const auto u : term_nodes[ci]) {
+                    owner[u] = ext;
+                    skipped[u] = c >= 1u ? 1 : 0;
+                }
+                g.roots.push_back(ns.args[cand_pos[ci]].idx);
+                g.leaves.push_back(term_leaves[ci]);
+                g.collect[S].emplace_back(cand_pos[ci], c);
+                claimed.push_back(term_nodes[ci]);
+            }
+            g.last_sum = S;
+        }
+    }
+
     // NOTE: every lane of a system runs these statements (the wavefront of the one-lane-per-pair kernel holds FOUR systems
     // where hy_ev_jets holds 64: a convolution costs 16 times the lane-time here). What the stepper saves is the
     // dense-output pass over the Taylor coefficients and the launch of hy_ev_jets, ~1.1 ms per 1 048 576 outer-SS systems; one
     // nonlinear node (a convolution per order: ~230 multiply-adds) costs ~0.3 ms on that scale. The budget: three nonlinear
-    // nodes (a squared distance, a radial velocity: break-even), any number of linear ones (coordinates, differences,
-    // sums, multiples, the time: practically free).
+    // nodes, any number of linear ones (coordinates, differences, sums, multiples, the time: practically free); the terms
+    // of a sum which the lanes evaluate side by side count once (a squared distance AND a radial velocity fit).
     std::uint32_t n_nonlin = 0;
     for (std::uint32_t u = n_eq; u < p.n_u; ++u) {
-        if (need[u] == 0) {
+        if (need[u] == 0 || skipped[u] != 0) {
             continue;
         }
         const auto &n = p.nodes[u - n_eq];
@@ -1028,7 +1189,7 @@ bool emit_event_jets_inline(const taylor_program &p, const emit_options &opts,
         }
         n_nonlin += linear ? 0u : (n.kind == func_kind::sum_sq ? static_cast<std::uint32_t>((n.args.size() + 1u) / 2u) : 1u);
     }
-    std::uint32_t max_nonlin = 3, max_nodes = 24;
+    std::uint32_t max_nonlin = 3, max_nodes = 40;
     if (const char *ev = std::getenv("HEYOKA_AMD_EV_INLINE_MAX_NONLINEAR")) {
         max_nonlin = static_cast<std::uint32_t>(std::max(0, std::atoi(ev)));
     }
@@ -1038,21 +1199,88 @@ bool emit_event_jets_inline(const taylor_program &p, const emit_options &opts,
                   + std::to_string(max_nodes) + ")";
         return false;
     }
+
+    // Leaf positions of the groups, globally numbered; state variables which are (also) read outside the terms.
+    std::vector<std::uint32_t> leaf_base(groups.size(), 0);
+    for (std::size_t gi = 0; gi < groups.size(); ++gi) {
+        leaf_base[gi] = static_cast<std::uint32_t>(lanes->leaf_vars.size());
+        const auto &g = groups[gi];
+        for (std::size_t pp = 0; pp < g.leaves[0].size(); ++pp) {
+            std::vector<std::uint32_t> vars;
+            for (const auto &lv : g.leaves) {
+                vars.push_back(lv[pp]);
+            }
+            lanes->leaf_class.push_back(lanes->sv_class(vars[0]));
+            lanes->leaf_vars.push_back(std::move(vars));
+        }
+    }
+    std::vector<char> scalar_use(n_eq, 0);
+    for (const auto u : p.ev_u) {
+        if (u < n_eq) {
+            scalar_use[u] = 1;
+        }
+    }
+    for (std::uint32_t u = n_eq; u < p.n_u; ++u) {
+        if (need[u] != 0 && owner[u] < 0) {
+            for (const auto &o : p.nodes[u - n_eq].args) {
+                if (o.type == operand::kind::uvar && o.idx < n_eq) {
+                    scalar_use[o.idx] = 1;
+                }
+            }
+        }
+    }
+
     ssa_emitter e(p, order);
     // (Names of their own: the statements are pasted into the body of another generator.)
     e.counter = 1000000000ull;
     // (The node rules and addition order of hy_ev_jets.)
     e.running_sums = opts.sum_order != 1;
+    // lane_vals[position][k]: coefficient k of the state variable this lane holds at a leaf position.
+    std::vector<std::vector<std::string>> lane_vals(lanes != nullptr ? lanes->leaf_vars.size() : 0u,
+                                                    std::vector<std::string>(order + 1u));
+    // (What this lane computed for its term, by group and order: read by every sum of the chain which collects terms.)
+    std::vector<std::vector<std::string>> own_val(groups.size(), std::vector<std::string>(order + 1u));
+    const auto swap_leaves = [&](const lane_group &g, std::uint32_t base, std::uint32_t k) {
+        for (std::size_t pp = 0; pp < g.leaves[0].size(); ++pp) {
+            for (std::uint32_t j = 0; j <= k; ++j) {
+                std::swap(e.val(g.leaves[0][pp], j), lane_vals[base + pp][j]);
+            }
+        }
+    };
     for (std::uint32_t k = 0; k <= order; ++k) {
         for (std::uint32_t i = 0; i < n_eq; ++i) {
-            if (need[i] != 0) {
+            if (need[i] != 0 && scalar_use[i] != 0) {
                 e.val(i, k) = e.def(sv(i, k));
             }
         }
+        for (std::size_t pp = 0; pp < lane_vals.size(); ++pp) {
+            lane_vals[pp][k] = e.def(lanes->sv_lane(static_cast<std::uint32_t>(pp), k, lanes->leaf_class[pp]));
+        }
         for (std::uint32_t u = n_eq; u < p.n_u; ++u) {
-            if (need[u] != 0) {
-                e.node(u - n_eq, k);
+            if (need[u] == 0 || skipped[u] != 0) {
+                continue;
             }
+            if (owner[u] >= 0) {
+                // A node of term 0 of a group: evaluated by every lane on ITS term's state variables.
+                const auto gi = static_cast<std::size_t>(owner[u]);
+                swap_leaves(groups[gi], leaf_base[gi], k);
+                e.node(u - n_eq, k);
+                swap_leaves(groups[gi], leaf_base[gi], k);
+                continue;
+            }
+            for (auto &g : groups) {
+                if (const auto it = g.collect.find(u); it != g.collect.end()) {
+                    // The terms in the order of the arguments: the value of term c is what lane c computed.
+                    if (own_val[&g - groups.data()][k].empty()) {
+                        own_val[&g - groups.data()][k] = e.val(g.roots[0], k);
+                    }
+                    for (const auto &[pos, c] : it->second) {
+                        (void)pos;
+                        e.val(g.roots[c], k) = e.def(lanes->lane_bcast(own_val[&g - groups.data()][k], c));
+                    }
+                }
+            }
+            e.node(u - n_eq, k);
         }
         for (std::size_t ev = 0; ev < p.ev_u.size(); ++ev) {
             e.os << ev_store(static_cast<std::uint32_t>(ev), k, e.val(p.ev_u[ev], k));

@@ -137,10 +137,29 @@ emitted_module emit_event_jets(const taylor_program &prog, const emit_options &o
 // Appends the statements to `out` and returns, per event equation, the names of its coefficients by order (for the norms
 // of the step-size selector and the exclusion test). Returns false (and the reason) if the event equations depend on
 // too much of the decomposition or on functions defined through node rules.
+// Lanes of a system as a vector unit for ISOMORPHIC terms of a sum (optional): the event equations of N-body problems are
+// sums of a few terms of one shape - (x_1 - x_2)^2 + (y_1 - y_2)^2 + (z_1 - z_2)^2, x vx + y vy + z vz - whose convolutions
+// dominate the cost. With these hooks the terms of such a sum are evaluated ONCE, term c by lane c of the system (leaf
+// position p of the shared shape reads the state variable leaf_vars[p][c]), and the sum collects them with lane broadcasts
+// in the order of its arguments - the same operations on the same operands as the term-by-term evaluation, bit for bit.
+struct ev_lane_hooks {
+    // Access class of a state variable (variables of one class are read by the same expression up to an offset).
+    std::function<int(std::uint32_t)> sv_class;
+    // Coefficient k of the state variable which THIS lane holds at leaf position p (class cls).
+    std::function<std::string(std::uint32_t p, std::uint32_t k, int cls)> sv_lane;
+    // Value of v in lane c of the system.
+    std::function<std::string(const std::string &v, std::uint32_t c)> lane_bcast;
+    std::uint32_t max_terms = 4;
+    // Out: per leaf position the state variable of term c (c < number of terms of the sum, <= max_terms), and its class.
+    std::vector<std::vector<std::uint32_t>> leaf_vars;
+    std::vector<int> leaf_class;
+};
+
 bool emit_event_jets_inline(const taylor_program &prog, const emit_options &opts,
                             const std::function<std::string(std::uint32_t, std::uint32_t)> &sv,
                             const std::function<std::string(std::uint32_t, std::uint32_t, const std::string &)> &ev_store,
-                            std::string &out, std::vector<std::vector<std::string>> &ev_coeffs, std::string &why_not);
+                            std::string &out, std::vector<std::vector<std::string>> &ev_coeffs, std::string &why_not,
+                            ev_lane_hooks *lanes = nullptr);
 
 // Format a double as a C++17 hexadecimal floating-point literal (exact round trip).
 std::string fp_literal(double);

@@ -1867,6 +1867,118 @@ __device__ __forceinline__ double hy_swap1(double x)
         src << "double *const hc" << h << " = jetw + q * " << n_colp << "u + ((" << h * L << "u + l < " << n_col << "u) ? "
             << h * L << "u + l : " << n_col << "u);\n";
     }
+    // Event equations inside the stepper (emit_options::ev_prog; one-lane-per-pair kernel): their jets from the jets of the
+    // state variables in LDS - every lane of a system runs the same statements; the terms of a sum of isomorphic terms
+    // (a squared distance, a radial velocity) are evaluated side by side, term c by lane c (ev_lane_hooks) -, the three
+    // norms extended to them, then the ordinary selector, final evaluation and state update of this kernel. What is left
+    // to the kernels behind the stepper: event detection on a.ev_tc, times / outcomes / records (hy_ev_post). The
+    // statements are generated here (their per-lane offsets are declared ahead of the work loop) and pasted into the tail.
+    bool ev_inline = false;
+    std::string ev_code;
+    std::vector<std::vector<std::string>> ev_coeffs;
+    const bool packed_tail_ev = L >= 4u && std::getenv("HEYOKA_AMD_NO_PACKED_TAIL") == nullptr;
+    if (m4 && one_lane && jet_lds && packed_tail_ev && opts.ev_prog != nullptr && !opts.exact_division && slab_stride >= n_own * L
+        && std::getenv("HEYOKA_AMD_NO_EVENTS_IN_STEPPER") == nullptr) {
+        struct sv_loc {
+            bool derived = false;
+            std::uint64_t off = 0;
+            std::uint32_t stride = 0;
+            std::uint32_t parent = 0;
+        };
+        std::vector<sv_loc> loc(n_eq);
+        for (const auto &rg : rounds) {
+            for (const auto &gr : rg) {
+                for (const auto &ow : gr.owners) {
+                    const auto &vv = utbl[ow.var_tbl];
+                    for (std::uint32_t l2 = 0; l2 < ow.n_valid; ++l2) {
+                        auto &lc = loc[vv[l2]];
+                        lc.stride = ow.n_valid;
+                        if (ow.derived) {
+                            lc.derived = true;
+                            lc.off = jet_rows_doubles + static_cast<std::uint64_t>(spw) * ow.cbase + l2;
+                            for (const auto &o2 : gr.owners) {
+                                if (o2.col == ow.parent) {
+                                    lc.parent = utbl[o2.var_tbl][l2];
+                                }
+                            }
+                        } else {
+                            lc.off = static_cast<std::uint64_t>(spw) * ow.cbase + l2;
+                        }
+                    }
+                }
+            }
+        }
+        const auto rowst = static_cast<std::uint64_t>(spw) * n_colp;
+        const std::function<std::string(std::uint32_t, std::uint32_t)> sv = [&](std::uint32_t i, std::uint32_t k) -> std::string {
+            const auto &lc = loc[i];
+            if (!lc.derived) {
+                return "jetw[" + std::to_string(k * rowst + lc.off) + "u + q * " + std::to_string(lc.stride) + "u]";
+            }
+            if (k == 0u) {
+                return "jetw[" + std::to_string(lc.off) + "u + q * " + std::to_string(lc.stride) + "u]";
+            }
+            // x^[k] = v^[k-1] * RN(1 / k): the rounded product the stepper itself would publish, kept out of contraction.
+            const auto &pl_ = loc[lc.parent];
+            return "hy_mul_nc(jetw[" + std::to_string((k - 1u) * rowst + pl_.off) + "u + q * " + std::to_string(pl_.stride) + "u], "
+                   + fp_literal(1. / static_cast<double>(k)) + ")";
+        };
+        const std::function<std::string(std::uint32_t, std::uint32_t, const std::string &)> ev_store
+            = [&](std::uint32_t ev, std::uint32_t k, const std::string &v) {
+                  return "a.ev_tc[(u64)" + std::to_string(static_cast<std::uint64_t>(ev) * (order + 1u) + k) + "u * N + s] = " + v + ";\n";
+              };
+        // Terms of a sum side by side on the lanes of the system: leaf position p of the shared shape is read at a per-lane
+        // offset (evo<p>: the jet column, of the variable itself or - position-type variables - of the variable it is
+        // derived from; evz<p>: the current value of a position-type variable).
+        ev_lane_hooks hooks;
+        hooks.max_terms = std::min<std::uint32_t>(4u, L);
+        hooks.sv_class = [&](std::uint32_t i) { return loc[i].derived ? 1 : 0; };
+        hooks.sv_lane = [&](std::uint32_t pp, std::uint32_t k, int cls) -> std::string {
+            const auto ps = std::to_string(pp);
+            if (cls == 0) {
+                return "jetw[" + std::to_string(k * rowst) + "u + evo" + ps + "]";
+            }
+            if (k == 0u) {
+                return "jetw[evz" + ps + "]";
+            }
+            return "hy_mul_nc(jetw[" + std::to_string((k - 1u) * rowst) + "u + evo" + ps + "], " + fp_literal(1. / static_cast<double>(k)) + ")";
+        };
+        hooks.lane_bcast = [&](const std::string &v, std::uint32_t c) {
+            return "__shfl(" + v + ", (int)((threadIdx.x & " + std::to_string(64u - L) + "u) + " + std::to_string(c) + "u), 64)";
+        };
+        std::string why_ev;
+        const bool use_lanes = std::getenv("HEYOKA_AMD_NO_EVENT_LANES") == nullptr;
+        const bool ev_ok = emit_event_jets_inline(*opts.ev_prog, opts, sv, ev_store, ev_code, ev_coeffs, why_ev, use_lanes ? &hooks : nullptr);
+        if (std::getenv("HEYOKA_AMD_EV_DEBUG") != nullptr) {
+            std::fprintf(stderr, "[events in the stepper] %s%s; %zu leaf positions on the lanes\n", ev_ok ? "yes" : "no: ", why_ev.c_str(),
+                         hooks.leaf_vars.size());
+        }
+        if (ev_ok) {
+            ev_inline = true;
+            // Per-lane offsets of the leaf positions (lanes beyond the last term replicate term 0).
+            const auto pick = [&](const std::vector<std::uint64_t> &v) {
+                std::string r = std::to_string(v[0]) + "u";
+                for (std::size_t c = v.size(); c-- > 1u;) {
+                    r = "(l == " + std::to_string(c) + "u ? " + std::to_string(v[c]) + "u : " + r + ")";
+                }
+                return r;
+            };
+            for (std::size_t pp = 0; use_lanes && pp < hooks.leaf_vars.size(); ++pp) {
+                std::vector<std::uint64_t> off, str_, zoff, zstr;
+                for (const auto var : hooks.leaf_vars[pp]) {
+                    const auto &lc = loc[var];
+                    const auto &src_ = lc.derived ? loc[lc.parent] : lc;
+                    off.push_back(src_.off);
+                    str_.push_back(src_.stride);
+                    zoff.push_back(lc.off);
+                    zstr.push_back(lc.stride);
+                }
+                src << "const unsigned evo" << pp << " = " << pick(off) << " + q * " << pick(str_) << ";\n";
+                if (hooks.leaf_class[pp] == 1) {
+                    src << "const unsigned evz" << pp << " = " << pick(zoff) << " + q * " << pick(zstr) << ";\n";
+                }
+            }
+        }
+    }
     src << R"HIP(
 // Work distribution. Propagation (steps per system differ): a device-side queue, one group of systems at a time (taking
 // chunks of 8 groups per atomic costs 1 % there: consecutive groups no longer run at the same time on neighbouring
@@ -2019,75 +2131,18 @@ const bool hy_tc_only = HY_M4 && ((a.pad & 2) != 0);
     // equations (hy_ev_jets). A wave-uniform branch; every lane of the system stores the same values.
     // (A separate specialisation of the kernel - opts.event_stepper - so that the propagation kernel is not touched: the
     // extra code, although never executed there, costs it spills in the step loop.)
-    // Event equations inside the stepper (emit_options::ev_prog; one-lane-per-pair kernel, integrators without terminal
-    // events): their jets from the jets of the state variables in LDS - every lane of a system runs the same statements -,
-    // the three norms extended to them, then the ordinary selector, final evaluation and state update of this kernel. What
-    // is left to the kernels behind the stepper: event detection on a.ev_tc, times / outcomes / records (hy_ev_post).
-    bool ev_inline = false;
-    std::vector<std::vector<std::string>> ev_coeffs;
-    if (m4 && one_lane && jet_lds && packed_tail && opts.ev_prog != nullptr && !opts.exact_division && slab_stride >= n_own * L
-        && std::getenv("HEYOKA_AMD_NO_EVENTS_IN_STEPPER") == nullptr) {
-        struct sv_loc {
-            bool derived = false;
-            std::uint64_t off = 0;
-            std::uint32_t stride = 0;
-            std::uint32_t parent = 0;
-        };
-        std::vector<sv_loc> loc(n_eq);
-        for (const auto &rg : rounds) {
-            for (const auto &gr : rg) {
-                for (const auto &ow : gr.owners) {
-                    const auto &vv = utbl[ow.var_tbl];
-                    for (std::uint32_t l2 = 0; l2 < ow.n_valid; ++l2) {
-                        auto &lc = loc[vv[l2]];
-                        lc.stride = ow.n_valid;
-                        if (ow.derived) {
-                            lc.derived = true;
-                            lc.off = jet_rows_doubles + static_cast<std::uint64_t>(spw) * ow.cbase + l2;
-                            for (const auto &o2 : gr.owners) {
-                                if (o2.col == ow.parent) {
-                                    lc.parent = utbl[o2.var_tbl][l2];
-                                }
-                            }
-                        } else {
-                            lc.off = static_cast<std::uint64_t>(spw) * ow.cbase + l2;
-                        }
-                    }
-                }
-            }
+    // Event equations inside the stepper: the statements prepared above (ev_code), then the three norms extended to them.
+    if (ev_inline) {
+        // (No scope around the statements: the coefficients of the event equations are read again by the exclusion test once
+        // the step size is known. Their names live in a range of their own.)
+        src << "double evm0 = 0.0, evmo = 0.0, evmom1 = 0.0;\n" << ev_code;
+        for (const auto &c : ev_coeffs) {
+            src << "evm0 = hy_max(evm0, fabs(" << c[0] << "));\nevmo = hy_max(evmo, fabs(" << c[order]
+                << "));\nevmom1 = hy_max(evmom1, fabs(" << c[order - 1u] << "));\n";
         }
-        const auto rowst = static_cast<std::uint64_t>(spw) * n_colp;
-        const std::function<std::string(std::uint32_t, std::uint32_t)> sv = [&](std::uint32_t i, std::uint32_t k) -> std::string {
-            const auto &lc = loc[i];
-            if (!lc.derived) {
-                return "jetw[" + std::to_string(k * rowst + lc.off) + "u + q * " + std::to_string(lc.stride) + "u]";
-            }
-            if (k == 0u) {
-                return "jetw[" + std::to_string(lc.off) + "u + q * " + std::to_string(lc.stride) + "u]";
-            }
-            // x^[k] = v^[k-1] * RN(1 / k): the rounded product the stepper itself would publish, kept out of contraction.
-            const auto &pl_ = loc[lc.parent];
-            return "hy_mul_nc(jetw[" + std::to_string((k - 1u) * rowst + pl_.off) + "u + q * " + std::to_string(pl_.stride) + "u], "
-                   + fp_literal(1. / static_cast<double>(k)) + ")";
-        };
-        const std::function<std::string(std::uint32_t, std::uint32_t, const std::string &)> ev_store
-            = [&](std::uint32_t ev, std::uint32_t k, const std::string &v) {
-                  return "a.ev_tc[(u64)" + std::to_string(static_cast<std::uint64_t>(ev) * (order + 1u) + k) + "u * N + s] = " + v + ";\n";
-              };
-        std::string code, why_ev;
-        if (emit_event_jets_inline(*opts.ev_prog, opts, sv, ev_store, code, ev_coeffs, why_ev)) {
-            ev_inline = true;
-            // (No scope around the statements: the coefficients of the event equations are read again by the exclusion
-            // test once the step size is known. Their names live in a range of their own.)
-            src << "double evm0 = 0.0, evmo = 0.0, evmom1 = 0.0;\n" << code;
-            for (const auto &c : ev_coeffs) {
-                src << "evm0 = hy_max(evm0, fabs(" << c[0] << "));\nevmo = hy_max(evmo, fabs(" << c[order]
-                    << "));\nevmom1 = hy_max(evmom1, fabs(" << c[order - 1u] << "));\n";
-            }
-            src << "nv = hy_nmax(nv, hy_q0 ? evm0 : (hy_q1 ? evmo : evmom1));\n";
-            // (max |x_i| over the state variables and the event equations: the scale of the root finder's tolerance.)
-            src << "a.max_abs_state[s] = hy_dpp<0x00>(nv);\n";
-        }
+        src << "nv = hy_nmax(nv, hy_q0 ? evm0 : (hy_q1 ? evmo : evmom1));\n";
+        // (max |x_i| over the state variables and the event equations: the scale of the root finder's tolerance.)
+        src << "a.max_abs_state[s] = hy_dpp<0x00>(nv);\n";
     }
     src << "#define HY_EV_INLINE " << (ev_inline ? 1 : 0) << "\n";
     src << "const bool nostate = " << ((m4 && !ev_inline) ? "true" : "false") << ";\n";

@@ -1809,9 +1809,15 @@ def test_event_equations_inside_the_stepper_vs_oracle_and_vs_the_event_jet_kerne
     for frac in (0.1, 0.5, 0.9):
         tm = t_c - 6.0 * frac
         assert rel_err(np.asarray(co_p(tm)), np.asarray(co_q(tm))) <= 1e7 * EPS
-    # Event equations beyond the budget (radial velocity + distance: six products): the three-kernel path.
+    # Radial velocity + squared distance: each a sum of three terms of one shape, evaluated side by side by three lanes of
+    # the system - both fit the budget (two convolutions instead of six). Beyond the budget (two more products of unrelated
+    # shape on top): the three-kernel path.
     nt_t, te_t = _outer_ss_event_setup(hy, [], [])
     tt = hy.taylor_adaptive_batch(sys_, st, n, high_accuracy=True, nt_events=nt_t + events(hy, "q")[2:])
+    assert "v5" in tt.hip_source_mode and "inside the stepper" in tt.hip_source_mode
+    xa, ya, vxa = hy.make_vars("x_3", "y_3", "vx_3")
+    more = [hy.nt_event(xa * ya - 1.0, lambda *a: None), hy.nt_event(xa * vxa * ya, lambda *a: None)]
+    tt = hy.taylor_adaptive_batch(sys_, st, n, high_accuracy=True, nt_events=nt_t + events(hy, "q")[2:] + more)
     assert "v5" in tt.hip_source_mode and "inside the stepper" not in tt.hip_source_mode
 
 
