@@ -163,6 +163,7 @@ struct tab_core::impl {
         device_copy(d_thi.get(), snap_thi.get(), d_thi.bytes(), device, stream);
         device_copy(d_tlo.get(), snap_tlo.get(), d_tlo.bytes(), device, stream);
         dev_newer = true;
+        times_fresh = false;
         host_newer = false;
         // With a host pointer handed out (get_state_data(), hy_tab_set_state(), the Python state setter) the host mirrors
         // are refreshed after every launch and re-uploaded before the next one: they hold the state at the END of the
@@ -290,11 +291,15 @@ struct tab_core::impl {
         }
     }
 
+    // (The times alone: 16 B per system where the state is 8 * dim. dev_newer stays set - the state is still pending -
+    // and times_fresh remembers that the mirror of the times is current until the next kernel.)
+    mutable bool times_fresh = false;
     void times_to_host() const
     {
-        if (dev_newer) {
+        if (dev_newer && !times_fresh) {
             d_thi.download(time_hi.data(), time_hi.size() * sizeof(double), stream);
             d_tlo.download(time_lo.data(), time_lo.size() * sizeof(double), stream);
+            times_fresh = true;
         }
     }
 
@@ -304,6 +309,7 @@ struct tab_core::impl {
     void after_kernel(bool tc_written = true)
     {
         dev_newer = true;
+        times_fresh = false;
         if (tc_written) {
             tc_dev_newer = true;
         }
@@ -835,13 +841,14 @@ double tab_core::get_compile_seconds() const
 
 const std::vector<double> &tab_core::get_time() const
 {
-    m_impl->to_host();
+    // (Polling the time after every step - benchmark/outer_ss_long_term_batch.cpp does - must not drag the state along.)
+    m_impl->times_to_host();
     return m_impl->time_hi;
 }
 
 std::pair<const std::vector<double> &, const std::vector<double> &> tab_core::get_dtime() const
 {
-    m_impl->to_host();
+    m_impl->times_to_host();
     return {m_impl->time_hi, m_impl->time_lo};
 }
 
@@ -2480,6 +2487,7 @@ void tab_core::mark_device_modified()
 {
     m_impl->to_device();
     m_impl->dev_newer = true;
+    m_impl->times_fresh = false;
 }
 
 void tab_core::set_stream(void *s)
