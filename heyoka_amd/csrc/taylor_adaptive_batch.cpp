@@ -117,6 +117,7 @@ struct tab_core::impl {
     // one across steps: benchmark/outer_ss_long_term_batch.cpp, `const auto &times_v = ta.get_time()`): the mirrors are
     // refreshed after every kernel from then on.
     mutable bool sticky_const_refs = false;
+    mutable bool sticky_time_refs = false; // (a reference to the times only: the state stays on the device)
     // Stepper with events on the wave-cluster kernels: the Taylor coefficients of order >= 1 of the state variables defined
     // by another state variable are not written by the stepper (emitted_module::compact_tc); hy_tc_expand fills them in
     // before anybody reads the full array.
@@ -170,6 +171,8 @@ struct tab_core::impl {
         // rolled-back propagation, which would overwrite the restored snapshot in the re-run. Bring them back as well.
         if (sticky_host_ptr || sticky_const_refs) {
             to_host();
+        } else if (sticky_time_refs) {
+            times_to_host();
         }
     }
     // Continuous output produced by the last propagate_for/until() with c_output = true.
@@ -316,6 +319,8 @@ struct tab_core::impl {
         lasth_dev_newer = true;
         if (sticky_host_ptr || sticky_const_refs) {
             to_host();
+        } else if (sticky_time_refs) {
+            times_to_host();
         }
     }
 
@@ -922,6 +927,11 @@ void tab_core::set_dtime(double hi, double lo)
 void tab_core::hold_host_refs() const
 {
     m_impl->sticky_const_refs = true;
+}
+
+void tab_core::hold_time_refs() const
+{
+    m_impl->sticky_time_refs = true;
 }
 
 const std::vector<double> &tab_core::get_state() const

@@ -168,6 +168,7 @@ public:
     [[nodiscard]] const std::vector<double> &get_state() const;
     // References to the host mirrors of state / times are being kept by the caller: refresh them after every kernel.
     void hold_host_refs() const;
+    void hold_time_refs() const;
     [[nodiscard]] double *get_state_data();
     [[nodiscard]] const std::vector<double> &get_pars() const;
     [[nodiscard]] double *get_pars_data();
@@ -637,15 +638,16 @@ public:
     // NOTE: the getters of state and times return references to host mirrors which stay valid AND current across steps,
     // like the members they stand for in the reference (its benchmark/outer_ss_long_term_batch.cpp keeps
     // `const auto &times_v = ta.get_time()` across its stepping loop): from the first call on, the mirrors are refreshed
-    // after every kernel. Code which cares about the transfers uses the device views instead.
+    // after every kernel (a reference to the times alone costs 16 B per system and kernel, one to the state the whole state).
+    // Code which cares about the transfers uses the device views instead.
     [[nodiscard]] const std::vector<double> &get_time() const
     {
-        m_core.hold_host_refs();
+        m_core.hold_time_refs();
         return m_core.get_time();
     }
     [[nodiscard]] const double *get_time_data() const
     {
-        m_core.hold_host_refs();
+        m_core.hold_time_refs();
         return m_core.get_time().data();
     }
     void set_time(const std::vector<double> &t)
@@ -658,7 +660,7 @@ public:
     }
     [[nodiscard]] std::pair<const std::vector<double> &, const std::vector<double> &> get_dtime() const
     {
-        m_core.hold_host_refs();
+        m_core.hold_time_refs();
         return m_core.get_dtime();
     }
     [[nodiscard]] std::pair<const double *, const double *> get_dtime_data() const
