@@ -67,6 +67,7 @@ struct hy_ed_args {
     double tol;
     double *wl;
     u64 wl_slots;
+    const double *maybe;
 };
 
 struct hy_ep_args {
@@ -345,6 +346,7 @@ __device__ void hy_detect_lane(const hy_ed_args &a, const u64 j, const u64 slot)
     double *const wl = a.wl + slot;
     a.counts[j] = 0u;
     a.counts[N + j] = 0u;
+    if (a.maybe != nullptr && a.maybe[j] == 0.0) return;
     const double h = a.h[j];
     double g_eps;
     if (a.mas != nullptr) {

@@ -102,6 +102,10 @@ struct ed_kargs {
     double tol;
     double *wl;               // working lists of the root isolation, ed_work_list_bytes_per_slot() per launched thread
     unsigned long long wl_slots; // number of launched threads (grid-stride loop over the lanes)
+    // Optional [N]: 0.0 for the lanes in which the stepper has already ruled out events in this step (its conservative
+    // exclusion test on the jets it computed, emitted_module::events_in_stepper): they are skipped without reading their
+    // event jets.
+    const double *maybe;
 };
 
 // Per-lane bookkeeping of a step with events on the device (src/taylor_adaptive_batch.cpp:771-1030): hy_ev_pre

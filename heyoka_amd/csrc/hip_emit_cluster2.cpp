@@ -2225,7 +2225,7 @@ lim = fin ? 0.0 : lim;
             }
             src << "r = r * ah;\nmaybe0 = maybe0 | !(fabs(" << c[0] << ") > r * 1.00000001);\n}\n";
         }
-        src << "}\nneed_tc = ((a.pad & 1) != 0);\n";
+        src << "}\nneed_tc = ((a.pad & 1) != 0);\nbool ev_possible = false;\n";
         src << "if (__builtin_amdgcn_ballot_w64(maybe0) != 0ull) {\n";
         src << "bool maybe = false;\nconst double lo_h = (h < 0.0) ? h : 0.0, hi_h = (h < 0.0) ? 0.0 : h;\n";
         for (const auto &c : ev_coeffs) {
@@ -2239,7 +2239,11 @@ lim = fin ? 0.0 : lim;
             src << "const bool excl = (((lo > 0.0) & (hi > 0.0)) | ((lo < 0.0) & (hi < 0.0))) & (fmin(fabs(lo), fabs(hi)) > 1e-8 * mm);\n"
                 << "maybe = maybe | !excl;\n}\n";
         }
-        src << "need_tc = need_tc | (maybe & maybe0);\n}\n";
+        src << "ev_possible = maybe & maybe0;\nneed_tc = need_tc | ev_possible;\n}\n";
+        // (For the detection kernel: systems in which no event is possible are skipped without reading their event jets.)
+        src << "a.sel_norms[s] = ev_possible ? 1.0 : 0.0;\n";
+    } else if (ev_inline) {
+        src << "a.sel_norms[s] = 1.0;\n";
     }
 
     src << "asm volatile(\"\" ::: \"memory\");\n";

@@ -1310,7 +1310,10 @@ unsigned tab_core::impl::launch_event_detection(bool device_g_eps)
                       d_cd_first.as<double>(), d_cd_second.as<double>(), d_cd_active.as<int>(),   d_ed_out.as<double>(),
                       d_ed_counts.as<unsigned>(), d_ed_flags.as<unsigned>(), N, n_te, n_nte,
                       device_g_eps ? d_mas.as<double>() : nullptr, d_geps.as<double>(), tol,
-                      d_ed_wl.as<double>(), ed_slots};
+                      d_ed_wl.as<double>(), ed_slots,
+                      // (The stepper which evaluates the event equations itself leaves a flag per system in the buffer of the
+                      // selector norms, which it does not use: 0 = no event possible in this step.)
+                      (cluster_events && emitted.events_in_stepper) ? d_selnorms.as<double>() : nullptr};
     ed_mod->launch("hy_detect_events", ed_slots, 64, &ea, sizeof(ea), stream);
     return 0;
 }
