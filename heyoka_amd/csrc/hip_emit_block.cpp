@@ -590,7 +590,6 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         const double ex = pp.ex, e1 = pp.ex + 1.;
         const auto U = [](std::uint64_t x) { return std::to_string(x) + "u"; };
         const auto S = [](std::uint32_t x) { return std::to_string(x); };
-        const auto nm = [&](const char *b, std::uint32_t r) { return std::string(b) + "_" + std::to_string(r); };
         const auto nm2 = [&](const char *b, std::uint32_t i, std::uint32_t r) {
             return std::string(b) + "_" + std::to_string(i) + "_" + std::to_string(r);
         };
@@ -796,13 +795,6 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         }
         v2_decl = dc.str();
         // Cluster index of the lane in round r and its byte offset inside a tape row; the descriptor loads.
-        const auto lo_only = [&](std::uint32_t r) {
-            const bool full = static_cast<std::uint64_t>(r + 1u) * bs <= nc;
-            os << "unsigned cl_" << r << " = "
-               << (full ? "tid + " + U(r * bs) : "live_" + S(r) + " ? tid + " + U(r * bs) + " : " + U(nc - 1u)) << ";\n";
-            os << "asm volatile(\"\" : \"+v\"(cl_" << r << "));\n";
-            os << "const unsigned lo_" << r << " = cl_" << r << " * 8u;\n";
-        };
         const auto desc_loads = [&](std::uint32_t r) {
             const bool full = static_cast<std::uint64_t>(r + 1u) * bs <= nc;
             // (The empty asm statement keeps the loads where they are: as loop invariants they would be hoisted out of the
