@@ -189,6 +189,41 @@ def test_event_integrators_pick_the_cluster_stepper_when_the_event_equations_are
     assert not td.hip_source_mode.startswith("cluster")
 
 
+def test_isomorphic_terms_of_event_equations_are_evaluated_side_by_side_on_the_lanes():
+    """(CPU: generated source.) Event equations inside the one-lane-per-pair stepper: a sum of terms of one shape over state
+    variables of one access class - a squared distance, a radial velocity, also written as a chain of binary sums - is
+    evaluated once, term c by lane c (per-lane offsets evo<p> / evz<p>, lane broadcasts in the order of the arguments); terms
+    of different shapes, or which share a node, are evaluated one after the other."""
+    from heyoka_amd import configs
+
+    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    sys_ = hy.model.nbody(6, masses=M, Gconst=G)
+    x1, y1, z1, x2, y2, z2, vx1, vy1, vz1 = hy.make_vars("x_1", "y_1", "z_1", "x_2", "y_2", "z_2", "vx_1", "vy_1", "vz_1")
+    cb = lambda *a: None
+
+    def src_of(ev):
+        ta = hy.taylor_adaptive_batch(sys_, None, 8, high_accuracy=True, nt_events=[hy.nt_event(ev, cb)])
+        assert "inside the stepper" in ta.hip_source_mode, ta.hip_source_mode
+        return ta.hip_source
+
+    d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2) - 81.0
+    s = src_of(d2)
+    # Two leaf positions (the two bodies), both position-type variables: offsets of the parent columns + current values.
+    assert s.count("__shfl(") == 3 * 21 and "const unsigned evo1 =" in s and "const unsigned evz1 =" in s and "evo2" not in s
+    s = src_of(x1 * vx1 + y1 * vy1 + z1 * vz1)
+    assert s.count("__shfl(") == 3 * 21 and "const unsigned evz0 =" in s and "const unsigned evz1 =" not in s
+    # Different shapes (a position times a velocity, a position times a position): one after the other.
+    s = src_of(x1 * vx1 + y1 * y2 - 1.0)
+    assert "__shfl(" not in s and "evo0" not in s
+    # Terms which share a node (x_1 - x_2 in both): one after the other.
+    dx = x1 - x2
+    s = src_of(dx * (y1 - y2) + dx * (z1 - z2))
+    assert "__shfl(" not in s
+    # Linear terms only: nothing to gain.
+    s = src_of((x1 - x2) + (y1 - y2) + (z1 - z2))
+    assert "__shfl(" not in s
+
+
 def test_time_dependent_event_on_the_cluster_event_stepper_builds():
     """(CPU: hiprtc cross-compiles.) An event equation which depends on the time coordinate next to a system which runs
     on the wave-cluster stepper: hy_ev_jets evaluates func_kind::time and needs the time of the lane (round-2 advisor
