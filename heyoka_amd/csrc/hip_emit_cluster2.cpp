@@ -1922,8 +1922,14 @@ __device__ __forceinline__ double hy_swap1(double x)
             return "hy_mul_nc(jetw[" + std::to_string((k - 1u) * rowst + pl_.off) + "u + q * " + std::to_string(pl_.stride) + "u], "
                    + fp_literal(1. / static_cast<double>(k)) + ")";
         };
+        // (With the exclusion test below the jets of the event equations are stored behind it, and only by wavefronts in which
+        // an event is possible: the detection kernel does not read the jets of the systems the test has ruled out.)
+        const bool ev_store_late = std::getenv("HEYOKA_AMD_EVENTS_ALL_TC") == nullptr;
         const std::function<std::string(std::uint32_t, std::uint32_t, const std::string &)> ev_store
             = [&](std::uint32_t ev, std::uint32_t k, const std::string &v) {
+                  if (ev_store_late) {
+                      return std::string{};
+                  }
                   return "a.ev_tc[(u64)" + std::to_string(static_cast<std::uint64_t>(ev) * (order + 1u) + k) + "u * N + s] = " + v + ";\n";
               };
         // Terms of a sum side by side on the lanes of the system: leaf position p of the shared shape is read at a per-lane
@@ -2240,8 +2246,16 @@ lim = fin ? 0.0 : lim;
                 << "maybe = maybe | !excl;\n}\n";
         }
         src << "ev_possible = maybe & maybe0;\nneed_tc = need_tc | ev_possible;\n}\n";
-        // (For the detection kernel: systems in which no event is possible are skipped without reading their event jets.)
+        // (For the detection kernel: systems in which no event is possible are skipped without reading their event jets -
+        // which are stored only by the wavefronts that hold such a system.)
         src << "a.sel_norms[s] = ev_possible ? 1.0 : 0.0;\n";
+        src << "if (__builtin_amdgcn_ballot_w64(ev_possible) != 0ull) {\n";
+        for (std::size_t ev = 0; ev < ev_coeffs.size(); ++ev) {
+            for (std::uint32_t k = 0; k <= order; ++k) {
+                src << "a.ev_tc[(u64)" << static_cast<std::uint64_t>(ev) * (order + 1u) + k << "u * N + s] = " << ev_coeffs[ev][k] << ";\n";
+            }
+        }
+        src << "}\n";
     } else if (ev_inline) {
         src << "a.sel_norms[s] = 1.0;\n";
     }
