@@ -795,7 +795,7 @@ emitted_module emit_event_jets(const taylor_program &p, const emit_options &opts
     if (const char *ev = std::getenv("HEYOKA_AMD_EV_JETS_MAX_NODES")) {
         max_nodes = static_cast<std::uint32_t>(std::max(0, std::atoi(ev)));
     }
-    if (n_nodes > max_nodes) {
+    if (n_nodes > max_nodes && !opts.ev_helpers_only) {
         why_not = "the event equations depend on " + std::to_string(n_nodes) + " nodes of the decomposition (limit: "
                   + std::to_string(max_nodes) + ")";
         return ret;
@@ -895,6 +895,17 @@ emitted_module emit_event_jets(const taylor_program &p, const emit_options &opts
         os << "const double *cp = tc + ((u64)(unsigned)par * " << (order + 1u) << "u) * N + s;\n";
         os << "for (unsigned k = 1; k <= " << order << "u; ++k) c[(u64)k * N] = " << coeff << ";\n}\n}\n";
     }
+    if (opts.ev_helpers_only) {
+        std::ostringstream src;
+        src << emit_detail::prelude << os.str();
+        ret.source = src.str();
+        ret.kernel_name = "hy_dout_c";
+        ret.block_size = 256;
+        ret.lanes_per_system = 1;
+        ret.mode = emit_mode::unrolled;
+        ret.notes = std::to_string(p.ev_u.size()) + " event equation(s) evaluated by the stepper";
+        return ret;
+    }
     os << "extern \"C\" __global__ void __launch_bounds__(256) hy_ev_jets(const hy_kargs a)\n{\n";
     os << "const u64 N = a.N;\nconst u64 s = (u64)blockIdx.x * 256u + threadIdx.x;\nif (s >= N) return;\n";
     std::vector<char> par_used(p.n_par, 0);
@@ -976,7 +987,7 @@ bool emit_event_jets_inline(const taylor_program &p, const emit_options &opts,
                             const std::function<std::string(std::uint32_t, std::uint32_t)> &sv,
                             const std::function<std::string(std::uint32_t, std::uint32_t, const std::string &)> &ev_store,
                             std::string &out, std::vector<std::vector<std::string>> &ev_coeffs, std::string &why_not,
-                            ev_lane_hooks *lanes)
+                            ev_lane_hooks *lanes, const std::vector<char> *skip_events)
 {
     using emit_detail::ssa_emitter;
     const auto n_eq = p.n_eq;
@@ -989,9 +1000,12 @@ bool emit_event_jets_inline(const taylor_program &p, const emit_options &opts,
     // often each of them is read (by a needed node or as an event equation).
     std::vector<char> need(p.n_u, 0);
     std::vector<std::uint32_t> uses(p.n_u, 0);
-    for (const auto u : p.ev_u) {
-        need[u] = 1;
-        ++uses[u];
+    const auto skipped_ev = [&](std::size_t ev) { return skip_events != nullptr && (*skip_events)[ev] != 0; };
+    for (std::size_t ev = 0; ev < p.ev_u.size(); ++ev) {
+        if (!skipped_ev(ev)) {
+            need[p.ev_u[ev]] = 1;
+            ++uses[p.ev_u[ev]];
+        }
     }
     std::uint32_t n_nodes = 0;
     for (std::uint32_t u = p.n_u; u-- > n_eq;) {
@@ -1215,9 +1229,9 @@ bool emit_event_jets_inline(const taylor_program &p, const emit_options &opts,
         }
     }
     std::vector<char> scalar_use(n_eq, 0);
-    for (const auto u : p.ev_u) {
-        if (u < n_eq) {
-            scalar_use[u] = 1;
+    for (std::size_t ev = 0; ev < p.ev_u.size(); ++ev) {
+        if (p.ev_u[ev] < n_eq && !skipped_ev(ev)) {
+            scalar_use[p.ev_u[ev]] = 1;
         }
     }
     for (std::uint32_t u = n_eq; u < p.n_u; ++u) {
@@ -1283,18 +1297,92 @@ bool emit_event_jets_inline(const taylor_program &p, const emit_options &opts,
             e.node(u - n_eq, k);
         }
         for (std::size_t ev = 0; ev < p.ev_u.size(); ++ev) {
-            e.os << ev_store(static_cast<std::uint32_t>(ev), k, e.val(p.ev_u[ev], k));
+            if (!skipped_ev(ev)) {
+                e.os << ev_store(static_cast<std::uint32_t>(ev), k, e.val(p.ev_u[ev], k));
+            }
         }
     }
     ev_coeffs.clear();
-    for (const auto u : p.ev_u) {
+    for (std::size_t ev = 0; ev < p.ev_u.size(); ++ev) {
         std::vector<std::string> c;
-        for (std::uint32_t k = 0; k <= order; ++k) {
-            c.push_back(e.val(u, k));
+        for (std::uint32_t k = 0; !skipped_ev(ev) && k <= order; ++k) {
+            c.push_back(e.val(p.ev_u[ev], k));
         }
         ev_coeffs.push_back(std::move(c));
     }
     out = e.os.str();
+    return true;
+}
+
+bool match_pair_distance_event(const taylor_program &p, std::uint32_t u, pair_distance_event &out)
+{
+    const auto n_eq = p.n_eq;
+    if (u < n_eq) {
+        return false;
+    }
+    // Flatten the sums / differences at the top: squares and numeric constants.
+    std::vector<std::uint32_t> sq_args; // the u variable whose square a term is
+    double c = 0;
+    bool ok = true;
+    const std::function<void(std::uint32_t, bool)> term = [&](std::uint32_t v, bool negated) {
+        if (!ok || v < n_eq) {
+            ok = false;
+            return;
+        }
+        const auto &n = p.nodes[v - n_eq];
+        const auto arg = [&](const operand &o, bool neg) {
+            if (o.type == operand::kind::num) {
+                c += neg ? -o.value : o.value;
+            } else if (o.type == operand::kind::uvar) {
+                term(o.idx, neg);
+            } else {
+                ok = false;
+            }
+        };
+        if (n.kind == func_kind::sum) {
+            for (const auto &o : n.args) {
+                arg(o, negated);
+            }
+        } else if (n.kind == func_kind::sub && n.args.size() == 2u) {
+            arg(n.args[0], negated);
+            arg(n.args[1], !negated);
+        } else if (negated) {
+            ok = false; // (a square which is subtracted: not a distance)
+        } else if (n.kind == func_kind::prod && n.args.size() == 2u && n.args[0].type == operand::kind::uvar
+                   && n.args[1].type == operand::kind::uvar && n.args[0].idx == n.args[1].idx) {
+            sq_args.push_back(n.args[0].idx);
+        } else if (n.kind == func_kind::pow && n.args.size() == 2u && n.args[0].type == operand::kind::uvar
+                   && n.args[1].type == operand::kind::num && n.args[1].value == 2.) {
+            sq_args.push_back(n.args[0].idx);
+        } else if (n.kind == func_kind::sum_sq) {
+            for (const auto &o : n.args) {
+                if (o.type == operand::kind::uvar) {
+                    sq_args.push_back(o.idx);
+                } else {
+                    ok = false;
+                }
+            }
+        } else {
+            ok = false;
+        }
+    };
+    term(u, false);
+    if (!ok || sq_args.size() != 3u) {
+        return false;
+    }
+    for (std::size_t i = 0; i < 3u; ++i) {
+        const auto d = sq_args[i];
+        if (d < n_eq) {
+            return false;
+        }
+        const auto &n = p.nodes[d - n_eq];
+        if (n.kind != func_kind::sub || n.args.size() != 2u || n.args[0].type != operand::kind::uvar
+            || n.args[1].type != operand::kind::uvar || n.args[0].idx >= n_eq || n.args[1].idx >= n_eq) {
+            return false;
+        }
+        out.diffs[i] = {n.args[0].idx, n.args[1].idx};
+    }
+    out.c = c;
     return true;
 }
 

@@ -83,6 +83,9 @@ struct emit_options {
     // size and updates the state (emitted_module::events_in_stepper): hy_ev_jets and the dense-output pass over the Taylor
     // coefficients drop out of a step.
     const taylor_program *ev_prog = nullptr;
+    // emit_event_jets(): only the kernels which serve the compact Taylor coefficients (hy_dout_c, hy_tc_expand) - the
+    // stepper evaluates the event equations itself (emitted_module::events_in_stepper).
+    bool ev_helpers_only = false;
 };
 
 struct emitted_module {
@@ -155,11 +158,23 @@ struct ev_lane_hooks {
     std::vector<int> leaf_class;
 };
 
+// skip_events (optional, one flag per event equation): event equations which the caller evaluates by other means - their
+// entry of ev_coeffs stays empty and the nodes only they depend on are not generated.
 bool emit_event_jets_inline(const taylor_program &prog, const emit_options &opts,
                             const std::function<std::string(std::uint32_t, std::uint32_t)> &sv,
                             const std::function<std::string(std::uint32_t, std::uint32_t, const std::string &)> &ev_store,
                             std::string &out, std::vector<std::vector<std::string>> &ev_coeffs, std::string &why_not,
-                            ev_lane_hooks *lanes = nullptr);
+                            ev_lane_hooks *lanes = nullptr, const std::vector<char> *skip_events = nullptr);
+
+// Is the event equation u (a u variable of prog) a squared distance plus a constant,
+//     (a_0 - b_0)^2 + (a_1 - b_1)^2 + (a_2 - b_2)^2 + c,        a_i, b_i state variables,
+// written with products, pow(., 2) or sum_sq and sums / differences in any nesting? The close-encounter events of an
+// N-body problem have this form - and the pair kernels hold the Taylor coefficients of exactly these squared distances.
+struct pair_distance_event {
+    std::array<std::pair<std::uint32_t, std::uint32_t>, 3> diffs; // (a_i, b_i), state variable indices
+    double c = 0;
+};
+bool match_pair_distance_event(const taylor_program &prog, std::uint32_t u, pair_distance_event &out);
 
 // Format a double as a C++17 hexadecimal floating-point literal (exact round trip).
 std::string fp_literal(double);

@@ -1874,6 +1874,8 @@ __device__ __forceinline__ double hy_swap1(double x)
     // to the kernels behind the stepper: event detection on a.ev_tc, times / outcomes / records (hy_ev_post). The
     // statements are generated here (their per-lane offsets are declared ahead of the work loop) and pasted into the tail.
     bool ev_inline = false;
+    // (lane -> (event, constant) of the close-encounter events which the lane of a pair contributes itself.)
+    std::map<std::uint32_t, std::pair<std::uint32_t, double>> pe_lane_ev;
     std::string ev_code;
     std::vector<std::vector<std::string>> ev_coeffs;
     const bool packed_tail_ev = L >= 4u && std::getenv("HEYOKA_AMD_NO_PACKED_TAIL") == nullptr;
@@ -1953,7 +1955,53 @@ __device__ __forceinline__ double hy_swap1(double x)
         };
         std::string why_ev;
         const bool use_lanes = std::getenv("HEYOKA_AMD_NO_EVENT_LANES") == nullptr;
-        const bool ev_ok = emit_event_jets_inline(*opts.ev_prog, opts, sv, ev_store, ev_code, ev_coeffs, why_ev, use_lanes ? &hooks : nullptr);
+        // Close encounters: an event equation |r_i - r_j|^2 + c is, up to the constant, the squared distance whose Taylor
+        // coefficients the lane of the pair (i, j) holds as the history of its pow recurrence (sB: b_k / b_0). Such events are
+        // not evaluated at all: the lane of the pair contributes its history - one event per lane, every lane at the same
+        // time (one exclusion test, one set of stores for ALL of them); order p, which the recursion of the state does not
+        // need, costs one more convolution from the order-p coefficients of the positions.
+        std::vector<char> ev_on_lane(opts.ev_prog->ev_u.size(), 0);
+        if (pairk && ev_store_late && std::getenv("HEYOKA_AMD_NO_PAIR_EVENTS") == nullptr) {
+            for (std::size_t ev = 0; ev < opts.ev_prog->ev_u.size(); ++ev) {
+                pair_distance_event pe;
+                const bool pe_ok = match_pair_distance_event(*opts.ev_prog, opts.ev_prog->ev_u[ev], pe);
+                if (std::getenv("HEYOKA_AMD_EV_DEBUG") != nullptr) {
+                    std::fprintf(stderr, "[pair events] event %zu: %s", ev, pe_ok ? "squared distance" : "other\n");
+                    if (pe_ok) {
+                        std::fprintf(stderr, " (%u,%u) (%u,%u) (%u,%u) + %g\n", pe.diffs[0].first, pe.diffs[0].second, pe.diffs[1].first,
+                                     pe.diffs[1].second, pe.diffs[2].first, pe.diffs[2].second, pe.c);
+                    }
+                }
+                if (!pe_ok) {
+                    continue;
+                }
+                const auto unordered = [](std::pair<std::uint32_t, std::uint32_t> x) {
+                    return x.first < x.second ? x : std::pair<std::uint32_t, std::uint32_t>{x.second, x.first};
+                };
+                std::vector<std::pair<std::uint32_t, std::uint32_t>> want;
+                for (const auto &d : pe.diffs) {
+                    want.push_back(unordered(d));
+                }
+                std::sort(want.begin(), want.end());
+                for (std::uint32_t cl = 0; cl < nc && cl < L; ++cl) {
+                    std::vector<std::pair<std::uint32_t, std::uint32_t>> have;
+                    for (std::uint32_t i = 0; i < 3u; ++i) {
+                        have.push_back(unordered({pl.ext_u[cl][pp.de[i][0]], pl.ext_u[cl][pp.de[i][1]]}));
+                    }
+                    std::sort(have.begin(), have.end());
+                    if (have == want && pe_lane_ev.count(cl) == 0u) {
+                        pe_lane_ev[cl] = {static_cast<std::uint32_t>(ev), pe.c};
+                        ev_on_lane[ev] = 1;
+                        break;
+                    }
+                }
+            }
+        }
+        const bool ev_ok = emit_event_jets_inline(*opts.ev_prog, opts, sv, ev_store, ev_code, ev_coeffs, why_ev,
+                                                  use_lanes ? &hooks : nullptr, &ev_on_lane);
+        if (!ev_ok) {
+            pe_lane_ev.clear();
+        }
         if (std::getenv("HEYOKA_AMD_EV_DEBUG") != nullptr) {
             std::fprintf(stderr, "[events in the stepper] %s%s; %zu leaf positions on the lanes\n", ev_ok ? "yes" : "no: ", why_ev.c_str(),
                          hooks.leaf_vars.size());
@@ -1982,6 +2030,19 @@ __device__ __forceinline__ double hy_swap1(double x)
                 if (hooks.leaf_class[pp] == 1) {
                     src << "const unsigned evz" << pp << " = " << pick(zoff) << " + q * " << pick(zstr) << ";\n";
                 }
+            }
+            if (!pe_lane_ev.empty()) {
+                // Per lane: 1 / 0 (the pair of this lane has an event), the constant of the event equation, the row block of
+                // the event in a.ev_tc (lanes without an event: a block of their own behind the last event).
+                std::string on = "0.0", cst = "0.0", row = std::to_string(opts.ev_prog->ev_u.size()) + "u";
+                for (const auto &[lane_, evc] : pe_lane_ev) {
+                    const auto ls = "(l == " + std::to_string(lane_) + "u ? ";
+                    on = ls + "1.0 : " + on + ")";
+                    cst = ls + fp_literal(evc.second) + " : " + cst + ")";
+                    row = ls + std::to_string(evc.first) + "u : " + row + ")";
+                }
+                src << "const double pe_on = " << on << ";\nconst double pe_c = " << cst << ";\nconst u64 pe_row = (u64)" << row
+                    << " * " << (order + 1u) << "u;\n";
             }
         }
     }
@@ -2095,6 +2156,42 @@ const bool hy_tc_only = HY_M4 && ((a.pad & 2) != 0);
     }
     src << "for (;;) {\n";
     src << body;
+    // Close-encounter events on the lanes of their pairs (pe_lane_ev): g^[0] = b_0 + c, g^[k] = (b_k / b_0) b_0 from the
+    // history of the pow recurrence, g^[p] from one more convolution; folded into the three norms of the lane BEFORE the
+    // reduction over the lanes (masked: a lane without an event contributes nothing).
+    std::vector<std::string> pe_g;
+    if (!pe_lane_ev.empty()) {
+        src << "HY_WSYNC();\n";
+        std::string dK[3];
+        for (std::uint32_t i = 0; i < 3u; ++i) {
+            src << "const double pe_d" << i << " = " << slabk(order, utname(st1.s[i][0])) << " - " << slabk(order, utname(st1.s[i][1]))
+                << ";\n";
+            dK[i] = "pe_d" + std::to_string(i);
+        }
+        // b_p = 2 sum_i (sum_{j < p / 2} d_i[j] d_i[p - j] + 1/2 d_i[p / 2]^2)   (p even: src/detail/sum_sq.cpp:100-245)
+        for (std::uint32_t i = 0; i < 3u; ++i) {
+            src << "double pe_q" << i << " = " << dK[i] << " * " << sD[i][0] << ";\n";
+            for (std::uint32_t j = 1; 2u * j < order; ++j) {
+                src << "pe_q" << i << " = __builtin_fma(" << sD[i][j] << ", " << sD[i][order - j] << ", pe_q" << i << ");\n";
+            }
+            if (order % 2u == 0u) {
+                src << "pe_q" << i << " = __builtin_fma(0.5 * " << sD[i][order / 2u] << ", " << sD[i][order / 2u] << ", pe_q" << i
+                    << ");\n";
+            }
+        }
+        src << "const double pe_bh = (pe_q0 + pe_q1) + pe_q2;\n";
+        pe_g.resize(order + 1u);
+        src << "const double pe_g0 = " << sB[0] << " + pe_c;\n";
+        pe_g[0] = "pe_g0";
+        for (std::uint32_t k = 1; k < order; ++k) {
+            src << "const double pe_g" << k << " = " << sB[k] << " * " << sB[0] << ";\n";
+            pe_g[k] = "pe_g" + std::to_string(k);
+        }
+        src << "const double pe_g" << order << " = pe_bh + pe_bh;\n";
+        pe_g[order] = "pe_g" + std::to_string(order);
+        src << "m0 = hy_nmax(m0, fabs(pe_g0) * pe_on);\nmo = hy_nmax(mo, fabs(pe_g" << order
+            << ") * pe_on);\nmom1 = hy_nmax(mom1, fabs(pe_g" << order - 1u << ") * pe_on);\n";
+    }
 
     // Maximum over the lanes of the system: DPP stages where a DPP pattern yields an all-reduce step (xor 1, xor 2 within
     // quads; rotations by 4 and 8 within rows of 16 lanes once the quads are uniform), ds_bpermute for the others.
@@ -2143,6 +2240,9 @@ const bool hy_tc_only = HY_M4 && ((a.pad & 2) != 0);
         // the step size is known. Their names live in a range of their own.)
         src << "double evm0 = 0.0, evmo = 0.0, evmom1 = 0.0;\n" << ev_code;
         for (const auto &c : ev_coeffs) {
+            if (c.empty()) {
+                continue;
+            }
             src << "evm0 = hy_max(evm0, fabs(" << c[0] << "));\nevmo = hy_max(evmo, fabs(" << c[order]
                 << "));\nevmom1 = hy_max(evmom1, fabs(" << c[order - 1u] << "));\n";
         }
@@ -2223,18 +2323,37 @@ lim = fin ? 0.0 : lim;
         // First a cheaper bound which decides almost every system: |P(t) - c_0| <= sum_k |c_k| |h|^k on the step (20
         // multiply-adds per event equation); the interval enclosure (300 instructions per event equation) runs - behind a
         // wave-uniform branch - only in wavefronts where it leaves a system undecided.
-        src << "bool maybe0 = false;\n{\nconst double ah = fabs(h);\n";
+        src << "bool maybe0 = false, pe_m0 = false;\n{\nconst double ah = fabs(h);\n";
         for (const auto &c : ev_coeffs) {
+            if (c.empty()) {
+                continue;
+            }
             src << "{\ndouble r = fabs(" << c[order] << ");\n";
             for (std::uint32_t k = order - 1u; k >= 1u; --k) {
                 src << "r = r * ah + fabs(" << c[k] << ");\n";
             }
             src << "r = r * ah;\nmaybe0 = maybe0 | !(fabs(" << c[0] << ") > r * 1.00000001);\n}\n";
         }
+        // (The events on the lanes of their pairs: every lane tests ITS event - one instruction stream for all of them.)
+        if (!pe_g.empty()) {
+            src << "{\ndouble r = fabs(" << pe_g[order] << ");\n";
+            for (std::uint32_t k = order - 1u; k >= 1u; --k) {
+                src << "r = r * ah + fabs(" << pe_g[k] << ");\n";
+            }
+            src << "r = r * ah;\npe_m0 = (pe_on != 0.0) & !(fabs(" << pe_g[0] << ") > r * 1.00000001);\n}\n";
+        }
         src << "}\nneed_tc = ((a.pad & 1) != 0);\nbool ev_possible = false;\n";
-        src << "if (__builtin_amdgcn_ballot_w64(maybe0) != 0ull) {\n";
+        // (Any lane of the system: one ballot, then the bits of the system's lanes.)
+        const auto sys_any = [&](const char *v) {
+            return "(((__builtin_amdgcn_ballot_w64(" + std::string(v) + ") >> ((threadIdx.x & 63u) & " + std::to_string(64u - L) + "u)) & "
+                   + std::to_string((std::uint64_t(1) << L) - 1u) + "ull) != 0ull)";
+        };
+        src << "if (__builtin_amdgcn_ballot_w64(maybe0 | pe_m0) != 0ull) {\n";
         src << "bool maybe = false;\nconst double lo_h = (h < 0.0) ? h : 0.0, hi_h = (h < 0.0) ? 0.0 : h;\n";
         for (const auto &c : ev_coeffs) {
+            if (c.empty()) {
+                continue;
+            }
             src << "{\ndouble lo = " << c[order] << ", hi = lo, mm = fabs(lo);\n";
             for (std::uint32_t i = 1; i <= order; ++i) {
                 src << "{\nconst double p0 = lo * lo_h, p1 = lo * hi_h, p2 = hi * lo_h, p3 = hi * hi_h;\n"
@@ -2245,15 +2364,31 @@ lim = fin ? 0.0 : lim;
             src << "const bool excl = (((lo > 0.0) & (hi > 0.0)) | ((lo < 0.0) & (hi < 0.0))) & (fmin(fabs(lo), fabs(hi)) > 1e-8 * mm);\n"
                 << "maybe = maybe | !excl;\n}\n";
         }
-        src << "ev_possible = maybe & maybe0;\nneed_tc = need_tc | ev_possible;\n}\n";
+        src << "bool pe_m = false;\n";
+        if (!pe_g.empty()) {
+            src << "{\ndouble lo = " << pe_g[order] << ", hi = lo, mm = fabs(lo);\n";
+            for (std::uint32_t i = 1; i <= order; ++i) {
+                src << "{\nconst double p0 = lo * lo_h, p1 = lo * hi_h, p2 = hi * lo_h, p3 = hi * hi_h;\n"
+                    << "const double mn = fmin(fmin(p0, p1), fmin(p2, p3)), mx = fmax(fmax(p0, p1), fmax(p2, p3));\n"
+                    << "lo = mn + " << pe_g[order - i] << ";\nhi = mx + " << pe_g[order - i] << ";\n"
+                    << "mm = fmax(mm, fmax(fabs(lo), fabs(hi)));\n}\n";
+            }
+            src << "const bool excl = (((lo > 0.0) & (hi > 0.0)) | ((lo < 0.0) & (hi < 0.0))) & (fmin(fabs(lo), fabs(hi)) > 1e-8 * mm);\n"
+                << "pe_m = pe_m0 & !excl;\n}\n";
+        }
+        src << "ev_possible = (maybe & maybe0) | " << sys_any("pe_m") << ";\nneed_tc = need_tc | ev_possible;\n}\n";
         // (For the detection kernel: systems in which no event is possible are skipped without reading their event jets -
         // which are stored only by the wavefronts that hold such a system.)
         src << "a.sel_norms[s] = ev_possible ? 1.0 : 0.0;\n";
         src << "if (__builtin_amdgcn_ballot_w64(ev_possible) != 0ull) {\n";
         for (std::size_t ev = 0; ev < ev_coeffs.size(); ++ev) {
-            for (std::uint32_t k = 0; k <= order; ++k) {
+            for (std::uint32_t k = 0; !ev_coeffs[ev].empty() && k <= order; ++k) {
                 src << "a.ev_tc[(u64)" << static_cast<std::uint64_t>(ev) * (order + 1u) + k << "u * N + s] = " << ev_coeffs[ev][k] << ";\n";
             }
+        }
+        // (The lanes of the pairs: every lane stores the row of ITS event - lanes without one into the spare block.)
+        for (std::uint32_t k = 0; !pe_g.empty() && k <= order; ++k) {
+            src << "a.ev_tc[(pe_row + " << k << "u) * N + s] = " << pe_g[k] << ";\n";
         }
         src << "}\n";
     } else if (ev_inline) {

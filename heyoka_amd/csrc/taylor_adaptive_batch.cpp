@@ -661,6 +661,8 @@ tab_core::tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_siz
             if (m.cluster_mode4) {
                 auto eo_ev = eo;
                 eo_ev.compact_tc = m.compact_tc;
+                // (Event equations inside the stepper: the companion module only serves the compact Taylor coefficients.)
+                eo_ev.ev_helpers_only = m.events_in_stepper && m.compact_tc;
                 auto evm = emit_event_jets(d.prog, eo_ev, why);
                 if (!evm.source.empty()) {
                     d.cluster_events = true;
@@ -1213,7 +1215,9 @@ void tab_core::impl::ensure_event_buffers()
     const auto maxd = ed_max_detected(order, n_te, n_nte);
     ensure_tc();
     if (d_ev_tc.bytes() == 0u) {
-        d_ev_tc = device_buffer(static_cast<std::size_t>(n_ev) * (order + 1u) * n * dsz, device);
+        // (One spare block: the stepper which takes close-encounter events from the lanes of their pairs lets the lanes
+        // WITHOUT an event store there - every statement unconditional.)
+        d_ev_tc = device_buffer((static_cast<std::size_t>(n_ev) + 1u) * (order + 1u) * n * dsz, device);
         d_mas = device_buffer(n * dsz, device);
         d_geps = device_buffer(n * dsz, device);
         d_dirs = device_buffer(std::max<std::size_t>(n_ev, 1u) * sizeof(int), device);

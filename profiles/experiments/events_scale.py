@@ -14,8 +14,8 @@ ap.add_argument("--steps", type=int, default=6)
 ap.add_argument("--skip-lane-stepper", action="store_true")
 ap.add_argument("--d2", type=float, default=81.0, help="squared Jupiter - Saturn distance of the event")
 ap.add_argument("--propagate", type=float, default=0.0, help="also time propagate_until(T)")
-ap.add_argument("--event", default="d2", choices=["d2", "linear"], help="d2: squared Jupiter - Saturn distance (three products); "
-                "linear: Saturn crossing y = 0 (a state variable)")
+ap.add_argument("--event", default="d2", choices=["d2", "linear", "pairs"], help="d2: squared Jupiter - Saturn distance (three products); "
+                "linear: Saturn crossing y = 0 (a state variable); pairs: the squared distances of all 15 pairs of bodies (close encounters)")
 args = ap.parse_args()
 M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
 n = args.systems
@@ -26,6 +26,16 @@ sys_ = hy.model.nbody(6, masses=M, Gconst=G)
 def events(log):
     x1, y1, z1, x2, y2, z2 = hy.make_vars("x_1", "y_1", "z_1", "x_2", "y_2", "z_2")
     d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2) - args.d2
+    if args.event == "pairs":
+        def pos(b):
+            return hy.make_vars("x_%d" % b, "y_%d" % b, "z_%d" % b)
+        evs = []
+        for a in range(6):
+            for b in range(a + 1, 6):
+                pa, pb = pos(a), pos(b)
+                g = (pa[0] - pb[0]) * (pa[0] - pb[0]) + (pa[1] - pb[1]) * (pa[1] - pb[1]) + (pa[2] - pb[2]) * (pa[2] - pb[2]) - 1.0
+                evs.append(hy.nt_event(g, lambda ta, t, d, i: log.append((i, t)), direction=hy.event_direction.negative))
+        return evs
     if args.event == "linear":
         return [hy.nt_event(y2, lambda ta, t, d, i: log.append((i, t)), direction=hy.event_direction.positive)]
     return [hy.nt_event(d2, lambda ta, t, d, i: log.append((i, t)), direction=hy.event_direction.negative)]

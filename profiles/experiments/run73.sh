@@ -5,7 +5,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 R=$(pwd)
 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "inside_the_stepper or time_dependent or compact_taylor or events" 2>&1 | tail -6
 mkdir -p gpurun_out/r73
-for ev in linear d2; do
+for ev in ${EVS:-linear d2}; do
   cd /tmp && export TMPDIR=/tmp
   timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r73/kt_$ev -o kt -- python $R/profiles/experiments/events_scale.py --systems 1048576 --skip-lane-stepper --steps 6 --event $ev > $R/gpurun_out/r73/run_$ev.log 2>&1
   cd $R

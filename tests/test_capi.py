@@ -159,19 +159,21 @@ def test_event_integrators_pick_the_cluster_stepper_when_the_event_equations_are
                                   nt_events=[hy.nt_event((x1 - x2) * (x1 - x2) - 4.0, cb), hy.nt_event(y1, cb)],
                                   t_events=[hy.t_event(x1 * vx1)])
     mode = ta.hip_source_mode
-    assert mode.startswith("cluster") and "events: jets of 3 event equation(s)" in mode, mode
+    assert mode.startswith("cluster") and "events: 3 event equation(s) evaluated by the stepper" in mode, mode
     src = ta.hip_source
     # Round 4: event equations of up to three nonlinear nodes are evaluated by the stepper itself (the jets of the event
     # equations leave from there, the selector norms stay in registers); the cooperative store of the Taylor coefficients runs
     # for the workgroups which may have an event.
-    assert "inside the stepper" in mode and "a.ev_tc[" in src and "a.sel_norms[" not in src and "__syncthreads_or" in src
+    # (a.sel_norms carries the per-system verdict of the exclusion test to the detection kernel on this path.)
+    assert "inside the stepper" in mode and "a.ev_tc[" in src and "__syncthreads_or" in src
+    assert "a.sel_norms[s] = ev_possible" in src and "a.sel_norms[(u64)" not in src
     monkeypatch.setenv("HEYOKA_AMD_NO_EVENTS_IN_STEPPER", "1")
     ta2 = hy.taylor_adaptive_batch(sys_, None, 8, high_accuracy=True,
                                    nt_events=[hy.nt_event((x1 - x2) * (x1 - x2) - 4.0, cb), hy.nt_event(y1, cb)],
                                    t_events=[hy.t_event(x1 * vx1)])
     monkeypatch.delenv("HEYOKA_AMD_NO_EVENTS_IN_STEPPER")
     src = ta2.hip_source
-    assert "inside the stepper" not in ta2.hip_source_mode
+    assert "inside the stepper" not in ta2.hip_source_mode and "events: jets of 3 event equation(s)" in ta2.hip_source_mode
     assert "a.sel_norms[" in src and "__syncthreads" in src  # the mode-4 specialisation, cooperative tc store
     # The plain integrator of the same system keeps the propagation kernel (no mode-4 code in it).
     tb = hy.taylor_adaptive_batch(sys_, None, 8, high_accuracy=True)
@@ -189,7 +191,7 @@ def test_event_integrators_pick_the_cluster_stepper_when_the_event_equations_are
     assert not td.hip_source_mode.startswith("cluster")
 
 
-def test_isomorphic_terms_of_event_equations_are_evaluated_side_by_side_on_the_lanes():
+def test_isomorphic_terms_of_event_equations_are_evaluated_side_by_side_on_the_lanes(monkeypatch):
     """(CPU: generated source.) Event equations inside the one-lane-per-pair stepper: a sum of terms of one shape over state
     variables of one access class - a squared distance, a radial velocity, also written as a chain of binary sums - is
     evaluated once, term c by lane c (per-lane offsets evo<p> / evz<p>, lane broadcasts in the order of the arguments); terms
@@ -208,8 +210,30 @@ def test_isomorphic_terms_of_event_equations_are_evaluated_side_by_side_on_the_l
 
     d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2) - 81.0
     s = src_of(d2)
+    # The squared distance of two bodies is not evaluated at all: the lane of their pair holds its Taylor coefficients (the
+    # history of the pow recurrence) and contributes them - per-lane switch, constant and row of the event.
+    assert "__shfl(" not in s and "const double pe_on =" in s and "pe_row" in s and "evo0" not in s
+    monkeypatch.setenv("HEYOKA_AMD_NO_PAIR_EVENTS", "1")
+    s = src_of(d2)
+    monkeypatch.delenv("HEYOKA_AMD_NO_PAIR_EVENTS")
     # Two leaf positions (the two bodies), both position-type variables: offsets of the parent columns + current values.
     assert s.count("__shfl(") == 3 * 21 and "const unsigned evo1 =" in s and "const unsigned evz1 =" in s and "evo2" not in s
+    assert "pe_on" not in s
+    # A distance in the plane (two squares) is not a pair distance: two terms side by side.
+    s = src_of((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) - 4.0)
+    assert s.count("__shfl(") == 2 * 21 and "pe_on" not in s
+    # All 15 pair distances of the six bodies at once: one event per lane, nothing evaluated.
+    def pos(b_):
+        return hy.make_vars("x_%d" % b_, "y_%d" % b_, "z_%d" % b_)
+    evs = []
+    for a_ in range(6):
+        for b_ in range(a_ + 1, 6):
+            pa, pb = pos(a_), pos(b_)
+            evs.append(hy.nt_event((pa[0] - pb[0]) * (pa[0] - pb[0]) + (pa[1] - pb[1]) * (pa[1] - pb[1])
+                                   + (pa[2] - pb[2]) * (pa[2] - pb[2]) - 1.0, cb))
+    ta15 = hy.taylor_adaptive_batch(sys_, None, 8, high_accuracy=True, nt_events=evs)
+    assert "inside the stepper" in ta15.hip_source_mode and "15 event equation(s) evaluated by the stepper" in ta15.hip_source_mode
+    assert ta15.hip_source.count("l == ") >= 45 and "__shfl(" not in ta15.hip_source
     s = src_of(x1 * vx1 + y1 * vy1 + z1 * vz1)
     assert s.count("__shfl(") == 3 * 21 and "const unsigned evz0 =" in s and "const unsigned evz1 =" not in s
     # Different shapes (a position times a velocity, a position times a position): one after the other.

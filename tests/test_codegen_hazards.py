@@ -30,6 +30,14 @@ def _cases():
     x1, x2 = hy.make_vars("x_1", "x_2")
     ev_ss = [hy.nt_event((x1 - x2) * (x1 - x2) - 4.0, lambda *a: None)]
     y1_, y2_, z1_, z2_ = hy.make_vars("y_1", "y_2", "z_1", "z_2")
+    def _pos(b_):
+        return hy.make_vars("x_%d" % b_, "y_%d" % b_, "z_%d" % b_)
+    ev_pairs = []
+    for a_ in range(6):
+        for b_ in range(a_ + 1, 6):
+            pa_, pb_ = _pos(a_), _pos(b_)
+            ev_pairs.append(hy.nt_event((pa_[0] - pb_[0]) * (pa_[0] - pb_[0]) + (pa_[1] - pb_[1]) * (pa_[1] - pb_[1])
+                                        + (pa_[2] - pb_[2]) * (pa_[2] - pb_[2]) - 1.0, lambda *a: None))
     ev_ss3 = [hy.nt_event(y2_, lambda *a: None), hy.nt_event(x1 - x2, lambda *a: None),
               hy.nt_event((x1 - x2) * (x1 - x2) + (y1_ - y2_) * (y1_ - y2_) + (z1_ - z2_) * (z1_ - z2_) - 81.0, lambda *a: None)]
     return {
@@ -43,6 +51,9 @@ def _cases():
         "outer_ss_event_equations_inside_the_stepper": (lambda: hy.model.nbody(6, masses=M, Gconst=G),
                                                         {"high_accuracy": True, "nt_events": ev_ss3,
                                                          "t_events": [hy.t_event(x1 - 3.0)]}, {}, "inside the stepper"),
+        # Close-encounter events taken from the lanes of their pairs (all 15 pair distances) next to a generic one.
+        "outer_ss_pair_distance_events_on_the_lanes": (lambda: hy.model.nbody(6, masses=M, Gconst=G),
+                                                       {"high_accuracy": True, "nt_events": ev_pairs + ev_ss3[:1]}, {}, "inside the stepper"),
         "outer_ss_cluster_v5": (lambda: hy.model.nbody(6, masses=M, Gconst=G), {"high_accuracy": True}, {}, "v5"),
         "outer_ss_cluster_v3": (lambda: hy.model.nbody(6, masses=M, Gconst=G), {"high_accuracy": True},
                                 {"HEYOKA_AMD_ONE_LANE": "0"}, "v3"),

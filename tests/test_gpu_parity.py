@@ -1822,6 +1822,88 @@ def test_event_equations_inside_the_stepper_vs_oracle_and_vs_the_event_jet_kerne
 
 
 @pytest.mark.gpu
+def test_close_encounter_events_from_the_pair_lanes_vs_oracle(monkeypatch):
+    """An event equation |r_i - r_j|^2 - R^2 is the squared distance whose Taylor coefficients the lane of the pair (i, j) of
+    the one-lane-per-pair stepper holds anyway (the history of its pow recurrence): such events are not evaluated, the lane
+    contributes its history (order p from one more convolution), tests ITS event and stores ITS row - all pairs at the same
+    time. Sun - Jupiter, Jupiter - Saturn (twice: two radii, the second one goes through the generic statements) and
+    Saturn - Uranus distances next to a linear event, against the oracle step by step and against the same integrator with the
+    events evaluated by the generic statements (HEYOKA_AMD_NO_PAIR_EVENTS=1); a terminal close-encounter event."""
+    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    n = 70
+    st = configs.outer_ss_state(n, perturb=1e-3, seed=15)
+    logs = {"p": [], "o": [], "q": []}
+
+    def events(m, key, terminal=False):
+        log = logs[key]
+        mk = (lambda s_: m.var(s_)) if m is ho else (lambda s_: m.make_vars(s_, "dummy__")[0])
+
+        def d2(a, b, r2):
+            pa = [mk("%s_%d" % (c, a)) for c in "xyz"]
+            pb = [mk("%s_%d" % (c, b)) for c in "xyz"]
+            return (pa[0] - pb[0]) * (pa[0] - pb[0]) + (pa[1] - pb[1]) * (pa[1] - pb[1]) + (pa[2] - pb[2]) * (pa[2] - pb[2]) - r2
+
+        neg = m.DIR_NEGATIVE if m is ho else m.event_direction.negative
+        nt = [m.nt_event(d2(0, 1, 27.0), lambda ta, t, d, i: log.append((i, 0, t, d))),
+              m.nt_event(d2(2, 1, 81.0), lambda ta, t, d, i: log.append((i, 1, t, d)), direction=neg),
+              m.nt_event(mk("y_2"), lambda ta, t, d, i: log.append((i, 2, t, d))),
+              m.nt_event(d2(1, 2, 100.0), lambda ta, t, d, i: log.append((i, 3, t, d))),
+              m.nt_event(d2(2, 3, 160.0), lambda ta, t, d, i: log.append((i, 4, t, d)))]
+        te = [m.t_event(d2(1, 2, 64.0), lambda ta, d, i: log.append((i, 9, 0.0, d)) or True, direction=neg)] if terminal else []
+        return nt, te
+
+    sys_ = hy.model.nbody(6, masses=M, Gconst=G)
+    nt_p, _ = events(hy, "p")
+    ta = hy.taylor_adaptive_batch(sys_, st, n, high_accuracy=True, nt_events=nt_p)
+    assert "inside the stepper" in ta.hip_source_mode and "pe_on" in ta.hip_source, ta.hip_source_mode
+    monkeypatch.setenv("HEYOKA_AMD_NO_PAIR_EVENTS", "1")
+    monkeypatch.setenv("HEYOKA_AMD_EV_INLINE_MAX_NONLINEAR", "8")
+    nt_q, _ = events(hy, "q")
+    tq = hy.taylor_adaptive_batch(sys_, st, n, high_accuracy=True, nt_events=nt_q)
+    monkeypatch.delenv("HEYOKA_AMD_NO_PAIR_EVENTS")
+    monkeypatch.delenv("HEYOKA_AMD_EV_INLINE_MAX_NONLINEAR")
+    assert "inside the stepper" in tq.hip_source_mode and "pe_on" not in tq.hip_source
+    nt_o, _ = events(ho, "o")
+    ora = ho.OracleEventIntegrator(ho.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True, nt_events=nt_o)
+    for it in range(45):
+        ta.step()
+        ora.step()
+        tq.step()
+        assert [int(oc) for oc, _ in ta.step_res] == [oc for oc, _ in ora.step_res]
+        h_p = np.array([h for _, h in ta.step_res])
+        h_o = np.array([h for _, h in ora.step_res])
+        h_q = np.array([h for _, h in tq.step_res])
+        assert np.max(np.abs(h_p - h_o) / np.abs(h_o)) <= 1e6 * EPS
+        assert np.max(np.abs(h_p - h_q) / np.abs(h_q)) <= 1e6 * EPS
+        assert rel_err(ta.state, ora.state.reshape(36, n)) <= 1e6 * EPS
+        if it == 20:
+            assert rel_err(np.asarray(ta.tc), np.asarray(tq.tc)) <= 1e6 * EPS
+    t_end = float(np.max(ora.time_hi)) + 8.0
+    ta.propagate_until(t_end)
+    ora.propagate_until(t_end)
+    tq.propagate_until(t_end)
+    assert rel_err(ta.state, ora.state.reshape(36, n)) <= 1e7 * EPS
+    kinds = {a[1] for a in logs["p"]}
+    assert {0, 1, 2}.issubset(kinds) and len(logs["p"]) >= 2 * n, (kinds, len(logs["p"]))
+    assert [(a[0], a[1], a[3]) for a in logs["p"]] == [(a[0], a[1], a[3]) for a in logs["o"]]
+    assert [(a[0], a[1], a[3]) for a in logs["p"]] == [(a[0], a[1], a[3]) for a in logs["q"]]
+    assert np.max(np.abs(np.array([a[2] for a in logs["p"]]) - np.array([a[2] for a in logs["o"]]))) <= 1e-9
+    # A terminal close-encounter event: the step of its lane is truncated there.
+    logs["p"], logs["o"] = [], []
+    nt_p, te_p = events(hy, "p", terminal=True)
+    tt = hy.taylor_adaptive_batch(sys_, st, n, high_accuracy=True, nt_events=nt_p[:1], t_events=te_p)
+    assert "pe_on" in tt.hip_source
+    nt_o, te_o = events(ho, "o", terminal=True)
+    ot = ho.OracleEventIntegrator(ho.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True, nt_events=nt_o[:1], t_events=te_o)
+    for _ in range(50):
+        tt.step()
+        ot.step()
+        assert [int(oc) for oc, _ in tt.step_res] == [oc for oc, _ in ot.step_res]
+        assert rel_err(tt.state, ot.state.reshape(36, n)) <= 1e6 * EPS
+    assert [(a[0], a[1], a[3]) for a in logs["p"]] == [(a[0], a[1], a[3]) for a in logs["o"]]
+
+
+@pytest.mark.gpu
 def test_terminal_events_with_the_event_equations_inside_the_stepper_vs_oracle():
     """A terminal event truncates the step of ITS lane at the event (src/taylor_adaptive_batch.cpp:771-781): the stepper which
     evaluates the event equations itself takes the full step everywhere, and the lanes with a terminal event are redone from
