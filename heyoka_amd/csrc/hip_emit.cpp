@@ -1206,6 +1206,7 @@ bool emit_event_jets_inline(const taylor_program &p, const emit_options &opts,
     std::uint32_t max_nonlin = 3, max_nodes = 40;
     if (const char *ev = std::getenv("HEYOKA_AMD_EV_INLINE_MAX_NONLINEAR")) {
         max_nonlin = static_cast<std::uint32_t>(std::max(0, std::atoi(ev)));
+        max_nodes = std::max(max_nodes, 12u * max_nonlin);
     }
     if (n_nonlin > max_nonlin || n_nodes > max_nodes) {
         why_not = "the event equations depend on " + std::to_string(n_nonlin) + " nonlinear / " + std::to_string(n_nodes)
@@ -1322,6 +1323,7 @@ bool match_pair_distance_event(const taylor_program &p, std::uint32_t u, pair_di
     }
     // Flatten the sums / differences at the top: squares and numeric constants.
     std::vector<std::uint32_t> sq_args; // the u variable whose square a term is
+    std::vector<bool> sq_neg;           // ... and whether the square is subtracted
     double c = 0;
     bool ok = true;
     const std::function<void(std::uint32_t, bool)> term = [&](std::uint32_t v, bool negated) {
@@ -1346,18 +1348,23 @@ bool match_pair_distance_event(const taylor_program &p, std::uint32_t u, pair_di
         } else if (n.kind == func_kind::sub && n.args.size() == 2u) {
             arg(n.args[0], negated);
             arg(n.args[1], !negated);
-        } else if (negated) {
-            ok = false; // (a square which is subtracted: not a distance)
+        } else if (n.kind == func_kind::prod && n.args.size() == 2u && n.args[0].type == operand::kind::num
+                   && n.args[0].value == -1. && n.args[1].type == operand::kind::uvar) {
+            // (-x is written as -1 * x.)
+            term(n.args[1].idx, !negated);
         } else if (n.kind == func_kind::prod && n.args.size() == 2u && n.args[0].type == operand::kind::uvar
                    && n.args[1].type == operand::kind::uvar && n.args[0].idx == n.args[1].idx) {
             sq_args.push_back(n.args[0].idx);
+            sq_neg.push_back(negated);
         } else if (n.kind == func_kind::pow && n.args.size() == 2u && n.args[0].type == operand::kind::uvar
                    && n.args[1].type == operand::kind::num && n.args[1].value == 2.) {
             sq_args.push_back(n.args[0].idx);
+            sq_neg.push_back(negated);
         } else if (n.kind == func_kind::sum_sq) {
             for (const auto &o : n.args) {
                 if (o.type == operand::kind::uvar) {
                     sq_args.push_back(o.idx);
+                    sq_neg.push_back(negated);
                 } else {
                     ok = false;
                 }
@@ -1367,9 +1374,10 @@ bool match_pair_distance_event(const taylor_program &p, std::uint32_t u, pair_di
         }
     };
     term(u, false);
-    if (!ok || sq_args.size() != 3u) {
+    if (!ok || sq_args.size() != 3u || sq_neg[0] != sq_neg[1] || sq_neg[0] != sq_neg[2]) {
         return false;
     }
+    out.sign = sq_neg[0] ? -1. : 1.;
     for (std::size_t i = 0; i < 3u; ++i) {
         const auto d = sq_args[i];
         if (d < n_eq) {

@@ -167,12 +167,13 @@ bool emit_event_jets_inline(const taylor_program &prog, const emit_options &opts
                             ev_lane_hooks *lanes = nullptr, const std::vector<char> *skip_events = nullptr);
 
 // Is the event equation u (a u variable of prog) a squared distance plus a constant,
-//     (a_0 - b_0)^2 + (a_1 - b_1)^2 + (a_2 - b_2)^2 + c,        a_i, b_i state variables,
+//     +-((a_0 - b_0)^2 + (a_1 - b_1)^2 + (a_2 - b_2)^2) + c,        a_i, b_i state variables,
 // written with products, pow(., 2) or sum_sq and sums / differences in any nesting? The close-encounter events of an
 // N-body problem have this form - and the pair kernels hold the Taylor coefficients of exactly these squared distances.
 struct pair_distance_event {
     std::array<std::pair<std::uint32_t, std::uint32_t>, 3> diffs; // (a_i, b_i), state variable indices
     double c = 0;
+    double sign = 1; // -1: the squares are subtracted, c - |r_i - r_j|^2
 };
 bool match_pair_distance_event(const taylor_program &prog, std::uint32_t u, pair_distance_event &out);
 

@@ -1876,6 +1876,7 @@ __device__ __forceinline__ double hy_swap1(double x)
     bool ev_inline = false;
     // (lane -> (event, constant) of the close-encounter events which the lane of a pair contributes itself.)
     std::map<std::uint32_t, std::pair<std::uint32_t, double>> pe_lane_ev;
+    std::map<std::uint32_t, double> pe_lane_sign; // (-1: the event equation is c - |r_i - r_j|^2)
     std::string ev_code;
     std::vector<std::vector<std::string>> ev_coeffs;
     const bool packed_tail_ev = L >= 4u && std::getenv("HEYOKA_AMD_NO_PACKED_TAIL") == nullptr;
@@ -1991,6 +1992,7 @@ __device__ __forceinline__ double hy_swap1(double x)
                     std::sort(have.begin(), have.end());
                     if (have == want && pe_lane_ev.count(cl) == 0u) {
                         pe_lane_ev[cl] = {static_cast<std::uint32_t>(ev), pe.c};
+                        pe_lane_sign[cl] = pe.sign;
                         ev_on_lane[ev] = 1;
                         break;
                     }
@@ -2037,7 +2039,8 @@ __device__ __forceinline__ double hy_swap1(double x)
                 std::string on = "0.0", cst = "0.0", row = std::to_string(opts.ev_prog->ev_u.size()) + "u";
                 for (const auto &[lane_, evc] : pe_lane_ev) {
                     const auto ls = "(l == " + std::to_string(lane_) + "u ? ";
-                    on = ls + "1.0 : " + on + ")";
+                    // (The switch carries the sign of the squared distance in the event equation: +-1, 0 = no event.)
+                    on = ls + (pe_lane_sign.at(lane_) < 0 ? "-1.0 : " : "1.0 : ") + on + ")";
                     cst = ls + fp_literal(evc.second) + " : " + cst + ")";
                     row = ls + std::to_string(evc.first) + "u : " + row + ")";
                 }
@@ -2181,16 +2184,19 @@ const bool hy_tc_only = HY_M4 && ((a.pad & 2) != 0);
         }
         src << "const double pe_bh = (pe_q0 + pe_q1) + pe_q2;\n";
         pe_g.resize(order + 1u);
-        src << "const double pe_g0 = " << sB[0] << " + pe_c;\n";
+        // (pe_on = +-1 on the lanes with an event: the sign of the squared distance in the event equation - exact. A lane
+        // without an event gets zeros; it stores them into the spare block.)
+        src << "const double pe_b0s = " << sB[0] << " * pe_on;\n";
+        src << "const double pe_g0 = pe_b0s + pe_c;\n";
         pe_g[0] = "pe_g0";
         for (std::uint32_t k = 1; k < order; ++k) {
-            src << "const double pe_g" << k << " = " << sB[k] << " * " << sB[0] << ";\n";
+            src << "const double pe_g" << k << " = " << sB[k] << " * pe_b0s;\n";
             pe_g[k] = "pe_g" + std::to_string(k);
         }
-        src << "const double pe_g" << order << " = pe_bh + pe_bh;\n";
+        src << "const double pe_g" << order << " = (pe_bh + pe_bh) * pe_on;\n";
         pe_g[order] = "pe_g" + std::to_string(order);
-        src << "m0 = hy_nmax(m0, fabs(pe_g0) * pe_on);\nmo = hy_nmax(mo, fabs(pe_g" << order
-            << ") * pe_on);\nmom1 = hy_nmax(mom1, fabs(pe_g" << order - 1u << ") * pe_on);\n";
+        src << "m0 = hy_nmax(m0, fabs(pe_g0));\nmo = hy_nmax(mo, fabs(pe_g" << order
+            << "));\nmom1 = hy_nmax(mom1, fabs(pe_g" << order - 1u << "));\n";
     }
 
     // Maximum over the lanes of the system: DPP stages where a DPP pattern yields an all-reduce step (xor 1, xor 2 within

@@ -223,13 +223,14 @@ def test_isomorphic_terms_of_event_equations_are_evaluated_side_by_side_on_the_l
     s = src_of((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) - 4.0)
     assert s.count("__shfl(") == 2 * 21 and "pe_on" not in s
     # Other spellings of the same event - pow(., 2) (a sum of squares becomes sum_sq in the decomposition), a flat sum, the
-    # bodies the other way round with the constant spread over the expression - are recognised; R^2 - d^2 (the squares are
-    # subtracted) and a "distance" which mixes three bodies are not.
+    # bodies the other way round with the constant spread over the expression, R^2 - d^2 (the lane switch carries the sign) -
+    # are recognised; squares of mixed signs and a "distance" which mixes three bodies are not.
     z3 = hy.make_vars("z_3", "dummy__")[0]
     for ev, lane in ((hy.pow(x1 - x2, 2.0) + hy.pow(y1 - y2, 2.0) + hy.pow(z1 - z2, 2.0) - 81.0, True),
                      (hy.sum([(x1 - x2) * (x1 - x2), (y1 - y2) * (y1 - y2), (z1 - z2) * (z1 - z2)]) - 81.0, True),
                      (81.0 + ((x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1)) - 162.0, True),
-                     (81.0 - ((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2)), False),
+                     (81.0 - ((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2)), True),
+                     ((x1 - x2) * (x1 - x2) - (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2) - 1.0, False),
                      ((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z3) * (z1 - z3) - 81.0, False)):
         assert ("const double pe_on =" in src_of(ev)) == lane
     # All 15 pair distances of the six bodies at once: one event per lane, nothing evaluated.

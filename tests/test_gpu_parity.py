@@ -1848,7 +1848,9 @@ def test_close_encounter_events_from_the_pair_lanes_vs_oracle(monkeypatch):
               m.nt_event(d2(2, 1, 81.0), lambda ta, t, d, i: log.append((i, 1, t, d)), direction=neg),
               m.nt_event(mk("y_2"), lambda ta, t, d, i: log.append((i, 2, t, d))),
               m.nt_event(d2(1, 2, 100.0), lambda ta, t, d, i: log.append((i, 3, t, d))),
-              m.nt_event(d2(2, 3, 160.0), lambda ta, t, d, i: log.append((i, 4, t, d)))]
+              m.nt_event(d2(2, 3, 160.0), lambda ta, t, d, i: log.append((i, 4, t, d))),
+              # (R^2 - d^2: the squares are subtracted - the lane switch carries the sign.)
+              m.nt_event(900.0 - d2(4, 5, 0.0), lambda ta, t, d, i: log.append((i, 5, t, d)))]
         te = [m.t_event(d2(1, 2, 64.0), lambda ta, d, i: log.append((i, 9, 0.0, d)) or True, direction=neg)] if terminal else []
         return nt, te
 
