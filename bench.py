@@ -479,6 +479,52 @@ def divergence_leg(ctx, n, t_span=60.0):
     }
 
 
+def events_leg(ctx, n, n_steps=6):
+    """Lock-step steps with event detection (reference: step_e, src/taylor_00.cpp:592-710, detection
+    src/detail/event_detection.cpp): the outer Solar System with the squared distances of ALL 15 pairs of bodies as
+    non-terminal events (close-encounter monitoring), wall time per step() of the whole ensemble against the event-free
+    step() of the same ensemble. Device-resident throughout (every launch of the step is on the integrator's stream; the
+    getter of the times at the end synchronises, its transfer is excluded by timing a second, empty call)."""
+    import time as _time
+
+    torch, hy, configs = ctx["torch"], ctx["hy"], ctx["configs"]
+    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    sys_ = hy.model.nbody(6, masses=M, Gconst=G)
+    st = configs.outer_ss_state(n, perturb=1e-6, seed=4243)
+
+    def pos(b):
+        return hy.make_vars("x_%d" % b, "y_%d" % b, "z_%d" % b)
+
+    seen = []
+    evs = []
+    for a in range(6):
+        for b in range(a + 1, 6):
+            pa, pb = pos(a), pos(b)
+            g = (pa[0] - pb[0]) * (pa[0] - pb[0]) + (pa[1] - pb[1]) * (pa[1] - pb[1]) + (pa[2] - pb[2]) * (pa[2] - pb[2]) - 1.0
+            evs.append(hy.nt_event(g, lambda ta, t, d, i: seen.append(i), direction=hy.event_direction.negative))
+    res = {}
+    for name, kw in (("event_free", {}), ("with_events", {"nt_events": evs})):
+        ta = hy.taylor_adaptive_batch(sys_, st, n, high_accuracy=True, device=ctx["dev_index"], **kw)
+        ta.step()
+        ta.step()
+        torch.cuda.synchronize()
+        t0 = _time.perf_counter()
+        for _ in range(n_steps):
+            ta.step()
+        torch.cuda.synchronize()
+        res[name] = {"s_per_step": (_time.perf_counter() - t0) / n_steps, "mode": ta.hip_source_mode[-110:]}
+        del ta
+        torch.cuda.empty_cache()
+    ev, fr = res["with_events"]["s_per_step"], res["event_free"]["s_per_step"]
+    return {
+        "config": {"workload": "outer_ss_close_encounters: %d ICs, lock-step step() with the squared distances of all 15 pairs of "
+                               "bodies as non-terminal events against the event-free step()" % n, "systems_per_gpu": n,
+                   "n_events": len(evs), "events_detected": len(seen), "stepper": res["with_events"]["mode"]},
+        "unit": "system-steps/s", "value": n / ev, "event_free_value": n / fr, "ms_per_step": ev * 1e3,
+        "event_free_ms_per_step": fr * 1e3, "with_events_over_event_free_time": ev / fr,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -554,6 +600,10 @@ def main():
                 extra.append(divergence_leg(ctx, DEFAULT_SYSTEMS["outer_ss"]))
             except Exception as e:
                 extra.append({"config": {"workload": "outer_ss_divergent"}, "error": "%s: %s" % (type(e).__name__, e)})
+            try:
+                extra.append(events_leg(ctx, DEFAULT_SYSTEMS["outer_ss"]))
+            except Exception as e:
+                extra.append({"config": {"workload": "outer_ss_close_encounters"}, "error": "%s: %s" % (type(e).__name__, e)})
             out["extra_workloads"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, out.pop("_dt"), args.cpu_seconds)
