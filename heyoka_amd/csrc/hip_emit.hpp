@@ -36,6 +36,9 @@ struct hy_kargs {
     unsigned long long N;     // number of systems
     unsigned long long max_steps; // propagate mode: 0 = unlimited
     int mode;                 // 0 = single step, 1 = propagate_until, 2 = raw step, 4 = step with events
+    // Stepper with events which evaluates the event equations itself (emitted_module::events_in_stepper): bit 0 = every
+    // workgroup stores its Taylor coefficients (otherwise only those in which an event is possible), bit 1 = store NOTHING
+    // but the coefficients (the launch which regenerates them from the snapshot of the state before the step). 0 elsewhere.
     int pad;
     unsigned int *counters;   // [16] device counters: [0] lanes with non-finite state, [1] work-queue head
     double *scratch;          // cluster mode: jet scratch, scratch_per_wave doubles per resident wave
@@ -47,6 +50,8 @@ struct hy_kargs {
     // mode 4 on the wave-cluster steppers (jets of the state variables to tc, no state update): the three norms of the
     // step-size selector over the state variables, [3 * N] = max |x^[0]|, max |x^[p]|, max |x^[p-1]| per system. The
     // jets of the event equations and the final step size are computed from tc by hy_ev_jets (emit_event_jets()).
+    // (With the event equations inside the stepper the first N entries carry its verdict per system for the detection
+    // kernel instead: 0.0 = no event possible in this step.)
     double *sel_norms;
 };
 
