@@ -1,0 +1,71 @@
+"""CPU tests (no GPU): the generated stepper kernels, compiled for the HOST and run under the wavefront emulator of
+tests/emu (fibres with rendezvous at the cross-lane operations), against the oracle. TEST INFRASTRUCTURE: the emulator is
+a checker of the generators' arithmetic and exchange logic in the authoring container - the proof for the hardware stays
+with the -m gpu parity tests, which run the same comparisons through the C ABI on an MI355X."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+
+import emu  # noqa: E402
+import heyoka_oracle as ho  # noqa: E402
+
+import heyoka_amd as hy  # noqa: E402
+from heyoka_amd import configs  # noqa: E402
+
+EPS = 2.220446049250313e-16
+M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+
+
+def rel_err(a, b):
+    return float(np.max(np.abs(a - b) / (np.abs(b) + 1e-300)))
+
+
+def _outer_ss(kernel, monkeypatch=None, **kw):
+    ta = hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), None, 64, high_accuracy=True, cluster_kernel=kernel, **kw)
+    assert kernel in ta.hip_source_mode, ta.hip_source_mode
+    return ta
+
+
+@pytest.mark.parametrize("kernel", ["v5", "v3", "v2"])
+def test_emulated_cluster_kernels_single_step_vs_oracle(kernel):
+    """One Taylor step of 11 perturbed outer Solar Systems (ragged: the last wavefront holds replicas) with the strict
+    (no contraction) host build of the generated source: step sizes to 1e4 eps, states and Taylor coefficients to 1e5 eps
+    of the oracle's - the tolerances of the GPU parity tests built with -ffp-contract=off."""
+    n = 11
+    st = configs.outer_ss_state(n, perturb=1e-6, seed=5)
+    ta = _outer_ss(kernel)
+    k = emu.EmulatedKernel(ta.hip_source)
+    r = k.run(st, np.zeros(n), np.zeros(n), mode=0, lim=np.full(n, np.inf), want_tc_rows=36 * (ta.order + 1))
+    ora = ho.OracleIntegrator(ho.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True)
+    ora.step(wtc=True)
+    h_o = np.array([h for _, h in ora.step_res])
+    assert rel_err(r["last_h"], h_o) <= 1e4 * EPS
+    assert rel_err(r["state"], ora.state.reshape(36, n)) <= 1e5 * EPS
+    assert rel_err(r["time_hi"], ora.time_hi) <= 1e4 * EPS
+    tc_o = ora.tc.reshape(36, ta.order + 1, n)
+    scale = np.max(np.abs(tc_o), axis=2, keepdims=True) + 1e-300
+    assert np.max(np.abs(r["tc"].reshape(tc_o.shape) - tc_o) / scale) <= 1e5 * EPS
+
+
+def test_emulated_v5_propagation_through_the_work_queue_with_refill():
+    """propagate_until() of 37 systems with per-system final times through ONE workgroup (32 systems in flight): the
+    device-side queue, the retire / refill path of the one-lane-per-pair kernel and the frozen bookkeeping of finished
+    systems, lane by lane against the oracle's ensemble driver."""
+    n = 37
+    rng = np.random.RandomState(3)
+    st = configs.outer_ss_state(n, perturb=1e-6, seed=77)
+    tf = 4.0 * rng.uniform(0.2, 1.5, n)
+    ta = _outer_ss("v5")
+    k = emu.EmulatedKernel(ta.hip_source)
+    r = k.run(st, np.zeros(n), np.zeros(n), mode=1, tfin=tf, max_grid=1)
+    ora = ho.OracleIntegrator(ho.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True)
+    ora.propagate_until(tf)
+    assert np.array_equal(r["outcome"], np.array([int(p[0]) for p in ora.prop_res]))
+    assert np.array_equal(r["time_hi"], tf)
+    ns_o = np.array([int(p[3]) for p in ora.prop_res])
+    assert np.abs(r["n_steps"].astype(np.int64) - ns_o).max() <= 1
+    assert rel_err(r["state"], ora.state.reshape(36, n)) <= 1e5 * EPS
