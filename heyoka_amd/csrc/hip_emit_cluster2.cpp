@@ -13,6 +13,7 @@
 //     node_finish). Sums are FMA chains;
 //   * divisions by the (constant) order use the exact FMA-based sequence ssa_emitter::div_const().
 #include <algorithm>
+#include <array>
 #include <cstdlib>
 #include <map>
 #include <set>
@@ -37,6 +38,18 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     using emit_detail::ssa_emitter;
 
     emitted_module ret;
+    // Experiment switches of this generator: ONE environment variable, HEYOKA_AMD_V5_OPTS, a comma-separated list of flags
+    // (profiles/experiments/ab.py compares variants inside one process). Every flag switches OFF one of the round-5 items:
+    //   nomsq     three accumulators for the half sums of squares (one per coordinate) instead of one;
+    //   nopack2   the final evaluation of a partially filled owner slot as a full two-series pass;
+    const auto v5_flag = [](const char *name) {
+        const char *ev = std::getenv("HEYOKA_AMD_V5_OPTS");
+        if (ev == nullptr) {
+            return false;
+        }
+        const std::string s = std::string(",") + ev + ",";
+        return s.find(std::string(",") + name + ",") != std::string::npos;
+    };
     cluster_plan pl;
     // Parameter operands are per-lane values here (e.g. kw::masses = par[...]: the pair clusters differ only by the
     // indices of the parameters they read).
@@ -914,6 +927,40 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
         return any;
     }();
 
+    // Final evaluation of a partially filled owner slot with a derived variable (x' = v; 18 velocity columns on 16 lanes
+    // leave 2): ONE series per lane - the lanes [0, n) sum the velocity columns, the lanes [n, 2 n) the series derived from
+    // them, whose coefficient k is row k - 1 of the same column times RN(1 / k). Both kinds run the same statements: where
+    // the lane's current value lives, where row k of its series starts and which row of the factor table (ones / RN(1 / k))
+    // it reads are per-lane table entries (pk_tbl[owner slot] = the three tables).
+    const auto pack_tail_slot = [&](const owner_slot &ow, const owner_slot *dv) {
+        return one_lane && jet_lds && !m4 && opts.high_accuracy && dv != nullptr && !ow.derived && 2u * ow.n_valid <= L
+               && !v5_flag("nopack2");
+    };
+    std::map<std::uint32_t, std::array<std::size_t, 3>> pk_tbl;
+    for (const auto &rg : rounds) {
+        for (const auto &gr : rg) {
+            for (const auto &ow : gr.owners) {
+                for (const auto &o2 : gr.owners) {
+                    if (!(o2.derived && o2.parent == ow.col && pack_tail_slot(ow, &o2))) {
+                        continue;
+                    }
+                    const auto nv = ow.n_valid;
+                    const auto kst = static_cast<std::uint64_t>(spw) * n_colp;
+                    std::vector<std::uint32_t> tv(L), tj(L), tf(L);
+                    for (std::uint32_t l = 0; l < L; ++l) {
+                        const bool isx = l >= nv && l < 2u * nv;
+                        const auto c = isx ? l - nv : (l < nv ? l : 0u);
+                        tv[l] = static_cast<std::uint32_t>((isx ? jet_rows_doubles + static_cast<std::uint64_t>(spw) * o2.cbase
+                                                                : static_cast<std::uint64_t>(spw) * ow.cbase) + c);
+                        tj[l] = static_cast<std::uint32_t>(static_cast<std::uint64_t>(spw) * ow.cbase + c + (isx ? 0u : kst));
+                        tf[l] = isx ? order + 1u : 0u;
+                    }
+                    pk_tbl[ow.col] = {add_utbl(std::move(tv), false), add_utbl(std::move(tj), false), add_utbl(std::move(tf), false)};
+                }
+            }
+        }
+    }
+
     // Merged schedule (lane-pair variant, one glue level after the clusters): round k = cluster(k) + glue(k-1),
     // one LDS synchronisation per order instead of two.
     const bool merged = [&]() {
@@ -1289,17 +1336,13 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
         v.resize(order + 1u);
     }
     std::string hq[3], hm[3], hcx[3], hT, hU, pow_pre;
-    // (Accumulators of the next order, started by emit_single_early().)
-    std::string nq[3], nm[3], ncx[3];
-    // (Only up to order early_kmax: at the high orders all the histories are live and the extra accumulators spill.
-    // Measured on the outer Solar System, 1 048 576 systems: 6.99e8 system-steps/s without the split, 6.99e8 / 6.91e8 /
-    // 6.98e8 / 6.90e8 with early_kmax = 8 / 12 / 14 / 16 - the other wavefront of the SIMD already covers the exchange -,
-    // hence off by default; HEYOKA_AMD_V5_EARLY_KMAX for experiments.)
-    const bool early_on = std::getenv("HEYOKA_AMD_V5_NO_EARLY") == nullptr;
-    const std::uint32_t early_kmax = std::getenv("HEYOKA_AMD_V5_EARLY_KMAX") != nullptr
-                                         ? static_cast<std::uint32_t>(std::atoi(std::getenv("HEYOKA_AMD_V5_EARLY_KMAX")))
-                                         : 0u;
-    bool early_split = false; // (the flag of the order being emitted)
+    // One accumulator for the half sum of squares bh_k = sum_i (sum_j d_i[k-j] d_i[j] + 1/2 d_i[k/2]^2): the three chains
+    // of the coordinates run into each other - two additions per order and two multiply-adds per even order less, two
+    // accumulators less. (The reference adds the three squares pairwise, src/detail/sum_sq.cpp:120-245: same terms, other
+    // rounding order - inside the stated tolerances like the suffix sums of the pow recurrence.)
+    const bool merged_sq = !v5_flag("nomsq");
+    //   nosc      the selector's logarithm / exponential with literal polynomial constants (hy_sel_log(), exp()).
+    const bool sel_scalar = one_lane && !v5_flag("nosc");
     // Issue priority (s_setprio): raised between the LDS exchange and the end of the finishing operations of a round - the
     // dependent chain which decides how soon the next exchange can start - and lowered for the convolution chains, so
     // that the wavefront which is in its critical section wins the VALU over the one streaming FMAs.
@@ -1343,12 +1386,20 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
             // everything which does not need an order-k input was folded into the history accumulators at the end of the
             // previous round (the middle squares into hq, alpha T - ((alpha + 1) / k) U into pow_pre): what is left is
             // sub -> fma -> add -> add -> fma (sa_k) -> fma (products) -> mul (reactions).
-            std::string q[3];
-            for (std::uint32_t i = 0; i < 3u; ++i) {
-                q[i] = e.chain(hq[i], sD[i][k], sD[i][0]);
+            std::string bh;
+            if (merged_sq) {
+                bh = hq[0];
+                for (std::uint32_t i = 0; i < 3u; ++i) {
+                    bh = e.chain(bh, sD[i][k], sD[i][0]);
+                }
+            } else {
+                std::string q[3];
+                for (std::uint32_t i = 0; i < 3u; ++i) {
+                    q[i] = e.chain(hq[i], sD[i][k], sD[i][0]);
+                }
+                const auto q01 = e.def(q[0] + " + " + q[1]);
+                bh = e.def(q01 + " + " + q[2]);
             }
-            const auto q01 = e.def(q[0] + " + " + q[1]);
-            const auto bh = e.def(q01 + " + " + q[2]);
             // sa_k = alpha (T + (b_k / b_0) sa_0) - ((alpha + 1) / k) U with b_k / b_0 = rb2 bh: alpha rb2 sa_0 is a constant
             // of the step (arbA).
             sA[k] = pow_pre.empty() ? e.def(ssa_emitter::mul(bh, "arbA")) : e.def("__builtin_fma(" + bh + ", arbA, " + pow_pre + ")");
@@ -1369,21 +1420,18 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
             // (End of the latency-critical part of the round: the chains below are bulk work.)
             os << "__builtin_amdgcn_s_setprio(0);\n";
         }
-        // History parts of order K = k + 1: the early terms (both indices <= k - 1) were accumulated before this
-        // finishing, under the latency of the LDS reads (emit_single_early()); here the late ones - the terms with an
-        // order-k coefficient - and the T / U chains of the pow recurrence, whose first term is the newest one.
+        // History parts of order K = k + 1 (terms without an order-K operand) and the T / U chains of the pow recurrence,
+        // whose first term is the newest one. (Accumulating the terms with both indices <= k - 1 ahead of this finishing,
+        // under the latency of the LDS reads, was measured in round 3: +-0 % - the other wavefront of the SIMD covers the
+        // exchange already - and spills at the high orders; removed.)
         for (std::uint32_t i = 0; i < 3u; ++i) {
-            hq[i] = nq[i];
-            hm[i] = nm[i];
-            hcx[i] = ncx[i];
-            nq[i].clear();
-            nm[i].clear();
-            ncx[i].clear();
+            hq[i].clear();
+            hm[i].clear();
+            hcx[i].clear();
         }
         hT.clear();
         hU.clear();
         const auto K = k + 1u;
-        early_split = early_on && K <= early_kmax;
         if (K < order && K >= 2u) {
             const auto jmax = (K % 2u == 1u) ? (K - 1u) / 2u : (K - 2u) / 2u;
             for (std::uint32_t j = 1; j < K; ++j) {
@@ -1391,24 +1439,28 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
                 const auto jd = K - j;
                 hT = e.chain(hT, sB[K - jd], sA[jd]);
                 hU = hU.empty() ? hT : e.def(hU + " + " + hT);
-                if (j == 1u || j == K - 1u || !early_split) {
-                    for (std::uint32_t i = 0; i < 3u; ++i) {
-                        hcx[i] = e.chain(hcx[i], sD[i][K - j], sA[j]);
-                        if (j <= jmax) {
-                            hq[i] = e.chain(hq[i], sD[i][K - j], sD[i][j]);
-                        }
+                for (std::uint32_t i = 0; i < 3u; ++i) {
+                    hcx[i] = e.chain(hcx[i], sD[i][K - j], sA[j]);
+                    if (j <= jmax) {
+                        auto &acc = hq[merged_sq ? 0u : i];
+                        acc = e.chain(acc, sD[i][K - j], sD[i][j]);
                     }
                 }
             }
-            if (K % 2u == 0u && (K / 2u == k || !early_split)) {
+            if (K % 2u == 0u) {
                 for (std::uint32_t i = 0; i < 3u; ++i) {
-                    hm[i] = e.def(ssa_emitter::mul(sD[i][K / 2u], sD[i][K / 2u]));
+                    if (merged_sq) {
+                        // (One running sum of the three middle squares.)
+                        hm[0] = e.chain(i == 0u ? std::string{} : hm[0], sD[i][K / 2u], sD[i][K / 2u]);
+                    } else {
+                        hm[i] = e.def(ssa_emitter::mul(sD[i][K / 2u], sD[i][K / 2u]));
+                    }
                 }
             }
             // Off the critical path of round K: the middle squares join the half sums, the two sums of the pow
             // recurrence are combined.
             if (K % 2u == 0u) {
-                for (std::uint32_t i = 0; i < 3u; ++i) {
+                for (std::uint32_t i = 0; i < (merged_sq ? 1u : 3u); ++i) {
                     hq[i] = hq[i].empty() ? e.def(ssa_emitter::mul("0.5", hm[i]))
                                           : e.def("__builtin_fma(0.5, " + hm[i] + ", " + hq[i] + ")");
                 }
@@ -1419,32 +1471,6 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
             pow_pre.clear();
         }
     };
-    // Early terms of the history chains of order K = k + 1 (operand indices 2 .. k - 1 on both sides): they only need
-    // coefficients of order < k, so they are emitted between the LDS reads of round k and the finishing operations which
-    // consume them - a few hundred cycles of independent FMAs where the wavefront would otherwise wait for the exchange.
-    const auto emit_single_early = [&](std::uint32_t k) {
-        using emit_detail::ssa_emitter;
-        const auto K = k + 1u;
-        early_split = early_on && K <= early_kmax;
-        if (!early_split || K >= order || K < 4u) {
-            return;
-        }
-        const auto jmax = (K % 2u == 1u) ? (K - 1u) / 2u : (K - 2u) / 2u;
-        for (std::uint32_t j = 2; j + 1u < K; ++j) {
-            for (std::uint32_t i = 0; i < 3u; ++i) {
-                ncx[i] = e.chain(ncx[i], sD[i][K - j], sA[j]);
-                if (j <= jmax) {
-                    nq[i] = e.chain(nq[i], sD[i][K - j], sD[i][j]);
-                }
-            }
-        }
-        if (K % 2u == 0u && K / 2u < k) {
-            for (std::uint32_t i = 0; i < 3u; ++i) {
-                nm[i] = e.def(ssa_emitter::mul(sD[i][K / 2u], sD[i][K / 2u]));
-            }
-        }
-    };
-
     // External inputs which are constant u variables in EVERY cluster (isomorphic clusters may pair a constant with a
     // variable: the heliocentric alias x_i - 0 and the pair difference x_j - x_i of model::np1body).
     std::vector<char> ext_const(n_ext, 1);
@@ -1543,7 +1569,6 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
             }
             sched_fence();
             if (k < order) {
-                emit_single_early(k);
                 sched_fence();
             }
             for (const auto &[g, r, names] : pend) {
@@ -1673,6 +1698,83 @@ __device__ __forceinline__ double hy_dpp(double x)
 }
 )HIP";
     // (hy_sel_log(): the logarithm of the step-size selector, in the common prelude - hip_emit.cpp.)
+    if (one_lane) {
+        // The logarithm and the exponential of the selector with their polynomial constants in SCALAR registers. A Horner
+        // step p * w + C with a literal C compiles to v_mov_b32 x 2 (the literal into the destination pair) + v_fmac_f64:
+        // three VALU instructions where v_fma_f64 with C in an SGPR pair is one - VOP3 takes no 64-bit literal, and the
+        // instruction selector prefers the two-address form even when the constant already sits in scalar registers, hence
+        // the instruction is written out (hy_fma_sc). The constants are materialised by s_mov_b32 pairs next to their use
+        // (MachineLICM is off for this module), which issue on the scalar unit next to the other wavefront's arithmetic: 39 VALU instructions per step less (20 in the logarithm, 19 against the device library's
+        // exp(), whose minimax polynomial has the same shape). hy_sel_exp_s(): k = rint(x / ln 2), r = x - k ln 2 in two
+        // pieces, Taylor polynomial of degree 13 on |r| <= 0.347 (truncation 4e-18), ldexp; +inf -> +inf, -inf -> 0, nan -> nan.
+        src << R"HIP(
+#if defined(HY_HOST_EMU)
+#define hy_fma_sc(a, b, c) __builtin_fma((a), (b), (c))
+#else
+// a * b + c with the (uniform) addend c in a scalar register pair: ONE v_fma_f64.
+__device__ __forceinline__ double hy_fma_sc(double a, double b, double c)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+#endif
+__device__ __forceinline__ double hy_sel_log_s(double x)
+{
+    double m = __builtin_amdgcn_frexp_mant(x);
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool lo = m < 0x1.6a09e667f3bcdp-1;
+    m = m * (lo ? 2.0 : 1.0);
+    e -= lo ? 1 : 0;
+    const double num = m - 1.0, den = m + 1.0;
+    double r = __builtin_amdgcn_rcp(den);
+    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+    double z = num * r;
+    z = __builtin_fma(__builtin_fma(-den, z, num), r, z);
+    const double w = z * z;
+    double p = __builtin_fma(w, 0x1.8618618618618p-4, 0x1.af286bca1af28p-4);
+    p = hy_fma_sc(p, w, 0x1.e1e1e1e1e1e1ep-4);
+    p = hy_fma_sc(p, w, 0x1.1111111111111p-3);
+    p = hy_fma_sc(p, w, 0x1.3b13b13b13b14p-3);
+    p = hy_fma_sc(p, w, 0x1.745d1745d1746p-3);
+    p = hy_fma_sc(p, w, 0x1.c71c71c71c71cp-3);
+    p = hy_fma_sc(p, w, 0x1.2492492492492p-2);
+    p = hy_fma_sc(p, w, 0x1.999999999999ap-2);
+    p = hy_fma_sc(p, w, 0x1.5555555555555p-1);
+    const double ed = (double)e;
+    double res = __builtin_fma(ed, 0x1.abc9e3b39803fp-56, (z * w) * p);
+    res = __builtin_fma(2.0, z, res);
+    res = __builtin_fma(ed, 0x1.62e42fefa39efp-1, res);
+    res = (x == 0.0) ? -__builtin_inf() : res;
+    res = (x == __builtin_inf()) ? x : res;
+    return res;
+}
+__device__ __forceinline__ double hy_sel_exp_s(double x)
+{
+    const double kf = __builtin_rint(x * 0x1.71547652b82fep+0);
+    double r = __builtin_fma(kf, -0x1.62e42fefa39efp-1, x);
+    r = __builtin_fma(kf, -0x1.abc9e3b39803fp-56, r);
+    double p = __builtin_fma(r, 0x1.6124613a86d09p-33, 0x1.1eed8eff8d898p-29);
+    p = hy_fma_sc(p, r, 0x1.ae64567f544e4p-26);
+    p = hy_fma_sc(p, r, 0x1.27e4fb7789f5cp-22);
+    p = hy_fma_sc(p, r, 0x1.71de3a556c734p-19);
+    p = hy_fma_sc(p, r, 0x1.a01a01a01a01ap-16);
+    p = hy_fma_sc(p, r, 0x1.a01a01a01a01ap-13);
+    p = hy_fma_sc(p, r, 0x1.6c16c16c16c17p-10);
+    p = hy_fma_sc(p, r, 0x1.1111111111111p-7);
+    p = hy_fma_sc(p, r, 0x1.5555555555555p-5);
+    p = hy_fma_sc(p, r, 0x1.5555555555555p-3);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    double res = ldexp(p, (int)kf);
+    res = (x > 710.0) ? __builtin_inf() : res;
+    res = (x < -746.0) ? 0.0 : res;
+    return res;
+}
+)HIP";
+    }
     if (pair_split) {
         // Exchange between the two lanes of a pair: DPP quad_perm [1,0,3,2] on the two halves of the double.
         src << R"HIP(
@@ -1828,6 +1930,12 @@ __device__ __forceinline__ double hy_swap1(double x)
         if (pp.rx[0] >= 0) {
             src << "const double crs_r = hy_dtbl[" << st1.crs * L << "u + l];\n";
         }
+    }
+    if (!pk_tbl.empty()) {
+        // (Factors of the packed evaluation: row 0 = ones - the series of a variable with a jet column -, row 1 = RN(1 / k).)
+        src << "__shared__ double lds_fac[" << 2u * (order + 1u) << "];\n";
+        src << "for (unsigned i = threadIdx.x; i < " << 2u * (order + 1u) << "u; i += " << bs << "u) lds_fac[i] = (i <= " << order
+            << "u) ? 1.0 : hy_rk[i - " << (order + 1u) << "u];\n__syncthreads();\n";
     }
     for (std::size_t t = 0; !one_lane && t < dtbl.size(); ++t) {
         src << "const double dt" << t << " = hy_dtbl[" << t * L << "u + l];\n";
@@ -2273,11 +2381,11 @@ const bool hy_tc_only = HY_M4 && ((a.pad & 2) != 0);
     if (packed_tail) {
         // log(num / m) = log(num) - log(m): no quotients (0 -> +inf, inf -> -inf, inf - inf -> nan as for the quotient).
         src << "const double nw = (hy_q0 & (nv <= 1.0)) ? 1.0 : nv;\n";
-        src << "const double lg = hy_sel_log(nw);\n";
+        src << "const double lg = " << (sel_scalar ? "hy_sel_log_s" : "hy_sel_log") << "(nw);\n";
         src << "const double lg0 = hy_dpp<0x00>(lg), lg1 = hy_dpp<0x55>(lg), lg2 = hy_dpp<0xAA>(lg);\n";
         src << "const double lr_o = (lg0 - lg1) * " << fp_literal(1. / static_cast<double>(order)) << ";\n";
         src << "const double lr_om1 = (lg0 - lg2) * " << fp_literal(1. / static_cast<double>(order - 1u)) << ";\n";
-        src << "const double rho_m = exp(hy_min(lr_o, lr_om1));\n";
+        src << "const double rho_m = " << (sel_scalar ? "hy_sel_exp_s" : "exp") << "(hy_min(lr_o, lr_om1));\n";
     } else {
         src << "const double num_rho = (m0 <= 1.0) ? 1.0 : m0;\n";
         if (std::getenv("HEYOKA_AMD_RHO_2EXP") != nullptr) {
@@ -2433,6 +2541,36 @@ lim = fin ? 0.0 : lim;
                     const auto xn = "xn" + std::to_string(ow.col);
                     const auto xd = dv != nullptr ? "xn" + std::to_string(dv->col) : std::string{};
                     const auto colp = "jr" + std::to_string(ow.col);
+                    if (dv != nullptr && pk_tbl.count(ow.col) != 0u) {
+                        // A partially filled owner slot (18 velocity columns on 16 lanes leave 2): ONE series per lane - the
+                        // lanes [0, n) sum the velocity columns, the lanes [n, 2 n) the series derived from them, whose
+                        // coefficient k is row k - 1 of the same column times RN(1 / k); both kinds run the same statements, the
+                        // row shift sits in the lane's pointer and the factor (1 or RN(1 / k)) comes from a two-row table in LDS.
+                        // Six instructions per order instead of the ten of the two-series pass which 2 of 16 lanes used.
+                        const auto nv = ow.n_valid;
+                        const auto cs = std::to_string(ow.col);
+                        const auto &tb = pk_tbl.at(ow.col);
+                        // (The current value of the lane's variable: order-0 row of the column / entry of the derived variable.)
+                        src << "double *const pk_v" << cs << " = jetw + q * " << nv << "u + hy_utbl[" << tb[0] * L << "u + l];\n";
+                        src << "double " << xn << ";\n{\n";
+                        // (Row k of the lane's series at pk_j[(k - 1) * stride]: the velocity column from row 1 on, from row 0
+                        // on for the derived series.)
+                        src << "const double *const pk_j = jetw + q * " << nv << "u + hy_utbl[" << tb[1] * L << "u + l];\n";
+                        src << "const double *const pk_f = lds_fac + hy_utbl[" << tb[2] * L << "u + l];\n";
+                        src << "double res = pk_v" << cs << "[0], comp = 0.0, cur_h = h;\n";
+                        for (std::uint32_t k = 1; k <= order; ++k) {
+                            src << "{\nconst double ck = pk_j[" << (k - 1u) * kstride << "] * pk_f[" << k << "];\n"
+                                << "const double tmp = ck * cur_h;\nconst double y = tmp - comp;\nconst double t = res + y;\n"
+                                << "comp = (t - res) - y;\nres = t;\n";
+                            if (k < order) {
+                                src << "cur_h = cur_h * h;\n";
+                            }
+                            src << "}\n";
+                        }
+                        src << xn << " = res;\n}\n";
+                        upd.emplace_back(xn, "pk_v" + cs + "[0]", "pk_v" + cs + "[0]");
+                        continue;
+                    }
                     src << "double " << xn << ";\n";
                     if (dv != nullptr) {
                         src << "double " << xd << ";\n";

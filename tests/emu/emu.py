@@ -81,7 +81,7 @@ def host_source(hip_source):
     src = hip_source
     # Register-class constraints of the amdgcn inline asm ("v": a VGPR) -> an SSE register of the host.
     src = src.replace('"+v"(', '"+x"(')
-    return '#define HY_NO_NMAX 1\n#include "wave_emu.hpp"\n' + _lockstep(src) + _TAIL
+    return '#define HY_NO_NMAX 1\n#define HY_HOST_EMU 1\n#include "wave_emu.hpp"\n' + _lockstep(src) + _TAIL
 
 
 class EmulatedKernel:

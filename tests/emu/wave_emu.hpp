@@ -376,3 +376,4 @@ using std::fmax;
 using std::fmin;
 using std::log;
 using std::sqrt;
+using std::ldexp;
