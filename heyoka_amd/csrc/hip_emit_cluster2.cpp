@@ -14,6 +14,7 @@
 //   * divisions by the (constant) order use the exact FMA-based sequence ssa_emitter::div_const().
 #include <algorithm>
 #include <array>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <set>
@@ -47,7 +48,8 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
         if (ev == nullptr) {
             return false;
         }
-        const std::string s = std::string(",") + ev + ",";
+        std::string s = std::string(",") + ev + ",";
+        std::replace(s.begin(), s.end(), '+', ','); // ('+' separates flags where ',' separates variables: ab.py)
         return s.find(std::string(",") + name + ",") != std::string::npos;
     };
     cluster_plan pl;
@@ -337,6 +339,8 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
         }
     }
     std::vector<std::uint32_t> lane_pr, lane_rx; // one-lane pair kernel: output slot triples of the lanes
+    bool wide_rd = false;                        // ... wide-read layout: slots arranged by consumer (see below)
+    std::vector<std::array<std::uint32_t, 3>> wide_pr, wide_rx; // ... its output slots, per lane and coordinate
     std::uint32_t slab_stride_opt = 0;
     std::uint64_t bank_cost = 0;
     if (one_lane) {
@@ -522,10 +526,384 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
         }
         bank_cost = best;
         pl.n_slots = ns;
+
+        // ---- Wide-read layout (round 5). A wavefront pays ~7 cycles of its own time for every LDS instruction it issues
+        // (profiles/README.md, issue-rate table), and a round of the step reads 6 positions + 2 x 5 sum operands with 16
+        // ds_read_b64. Slots arranged BY CONSUMER make them 10 reads: the three coordinates of a body are adjacent
+        // ([x, y, z, -]: one ds_read_b128 + one ds_read_b64 per body), and the five operands of an acceleration sum are
+        // adjacent ([t0 .. t4, -]: two ds_read_b128 + one ds_read_b64 per sum, pairs (t0, t1), (t2, t3) as the pairwise sum
+        // takes them). A ds_read_b128 moves its 16 bytes per lane at the same LDS-array rate as two ds_read_b64
+        // (MI355X_MICROARCH.md, LDS table). The products / reactions of a pair lane now go to the operand arrays of the
+        // sums which read them: slot = array of (coordinate i, body) + operand index, with the arrays laid out
+        // [coordinate][body] so that the three stores of a lane differ by a constant (one table register for the three).
+        // The unused sixth slot of the arrays of the first two bodies takes the stores of the idle lanes. The order of the
+        // bodies inside a coordinate block, the distance between the blocks and between the slabs of two systems come out
+        // of an exhaustive search with the bank model of the guide (reads in the lane groups of each instruction width).
+        wide_rd = !v5_flag("nowide") && pp.rx[0] >= 0 && pl.groups.size() == 1u;
+        std::vector<std::array<std::uint32_t, 3>> bodies; // position variables (x, y, z) of every body
+        std::vector<std::uint32_t> node_coord, node_rank;   // per node of the glue group
+        std::uint32_t n_rank = 0, n_args = 0;
+        if (wide_rd) {
+            std::map<std::uint32_t, std::pair<std::uint32_t, std::uint32_t>> pos_of; // position variable -> (body, coordinate)
+            for (std::uint32_t c = 0; c < nc && wide_rd; ++c) {
+                for (std::uint32_t sd = 0; sd < 2u; ++sd) {
+                    std::array<std::uint32_t, 3> tr{};
+                    for (std::uint32_t i = 0; i < 3u; ++i) {
+                        tr[i] = pl.ext_u[c][pp.de[i][sd]];
+                    }
+                    auto it = std::find(bodies.begin(), bodies.end(), tr);
+                    if (it == bodies.end()) {
+                        bodies.push_back(tr);
+                        it = bodies.end() - 1;
+                    }
+                    for (std::uint32_t i = 0; i < 3u; ++i) {
+                        const auto key = std::make_pair(static_cast<std::uint32_t>(it - bodies.begin()), i);
+                        const auto ins = pos_of.emplace(tr[i], key);
+                        wide_rd = wide_rd && ins.first->second == key && tr[i] < n_eq && glue_read[tr[i]] != 0;
+                    }
+                }
+            }
+            // The sums: one group, all arguments exported cluster outputs, every output read by exactly one sum.
+            const auto &grp = pl.groups[0];
+            const auto &n0 = p.nodes[grp.nodes[0] - n_eq];
+            n_args = static_cast<std::uint32_t>(n0.args.size());
+            wide_rd = wide_rd && n0.kind == func_kind::sum && n_args >= 2u && n_args <= 6u;
+            std::map<std::uint32_t, std::uint32_t> out_coord; // cluster output -> coordinate
+            std::map<std::uint32_t, std::pair<std::uint32_t, bool>> out_src; // cluster output -> (cluster, is reaction)
+            for (std::uint32_t c = 0; c < nc; ++c) {
+                for (std::uint32_t i = 0; i < 3u; ++i) {
+                    out_coord[pl.clusters[c][pp.pr[i]]] = i;
+                    out_src[pl.clusters[c][pp.pr[i]]] = {c, false};
+                    out_coord[pl.clusters[c][static_cast<std::uint32_t>(pp.rx[i])]] = i;
+                    out_src[pl.clusters[c][static_cast<std::uint32_t>(pp.rx[i])]] = {c, true};
+                }
+            }
+            std::map<std::uint32_t, std::uint32_t> n_readers;
+            node_coord.assign(grp.nodes.size(), 0);
+            node_rank.assign(grp.nodes.size(), 0);
+            // (Signature of a sum: its operands as (cluster, kind) in argument order - the sums of the three coordinates of a
+            // body have the same one.)
+            std::vector<std::vector<std::pair<std::uint32_t, bool>>> sig(grp.nodes.size());
+            for (std::size_t j = 0; j < grp.nodes.size() && wide_rd; ++j) {
+                const auto &nd = p.nodes[grp.nodes[j] - n_eq];
+                wide_rd = wide_rd && nd.args.size() == n_args;
+                for (std::uint32_t a = 0; a < nd.args.size() && wide_rd; ++a) {
+                    const auto &o = nd.args[a];
+                    wide_rd = wide_rd && is_var(o) && out_coord.count(o.idx) != 0u;
+                    if (!wide_rd) {
+                        break;
+                    }
+                    if (a == 0u) {
+                        node_coord[j] = out_coord[o.idx];
+                    }
+                    wide_rd = wide_rd && out_coord[o.idx] == node_coord[j];
+                    ++n_readers[o.idx];
+                    sig[j].push_back(out_src[o.idx]);
+                }
+            }
+            for (const auto &[u, cnt] : n_readers) {
+                (void)u;
+                wide_rd = wide_rd && cnt == 1u;
+            }
+            // Every output which has a slot must have a reader (the others are not stored).
+            for (const auto &[u, src_] : out_src) {
+                (void)src_;
+                wide_rd = wide_rd && (pl.slot_of[u] < 0 || n_readers.count(u) != 0u);
+            }
+            std::vector<std::vector<std::pair<std::uint32_t, bool>>> ranks;
+            for (std::size_t j = 0; j < grp.nodes.size() && wide_rd; ++j) {
+                auto it = std::find(ranks.begin(), ranks.end(), sig[j]);
+                if (it == ranks.end()) {
+                    ranks.push_back(sig[j]);
+                    it = ranks.end() - 1;
+                }
+                node_rank[j] = static_cast<std::uint32_t>(it - ranks.begin());
+            }
+            n_rank = static_cast<std::uint32_t>(ranks.size());
+            // (Three sums per rank, one per coordinate; at least two ranks for the dummy stores.)
+            wide_rd = wide_rd && n_rank >= 2u && grp.nodes.size() == 3u * n_rank;
+            for (std::uint32_t r = 0; r < n_rank && wide_rd; ++r) {
+                std::uint32_t seen = 0;
+                for (std::size_t j = 0; j < grp.nodes.size(); ++j) {
+                    if (node_rank[j] == r) {
+                        seen |= 1u << node_coord[j];
+                    }
+                }
+                wide_rd = wide_rd && seen == 7u;
+            }
+        }
+        if (wide_rd) {
+            const auto W = (n_args + 2u) & ~1u; // slots of an operand array (>= one spare slot, even)
+            const auto nb = static_cast<std::uint32_t>(bodies.size());
+            const auto &grp = pl.groups[0];
+            // Address lists of the LDS instructions of a round (doubles, relative to the slab of the system), per lane of a
+            // system; filled for a given layout by addr_lists().
+            struct lds_op {
+                int width; // 16: ds_read_b128, 8: ds_read_b64, -8: ds_write_b64
+                std::vector<std::uint32_t> addr;
+            };
+            std::vector<std::uint32_t> perm(n_rank);
+            for (std::uint32_t r = 0; r < n_rank; ++r) {
+                perm[r] = r;
+            }
+            std::uint32_t Dd = W * n_rank, pos_base = 0, op_base = 4u * nb;
+            const auto op_slot = [&](std::uint32_t coord, std::uint32_t rank, std::uint32_t a) {
+                return op_base + Dd * coord + W * perm[rank] + a;
+            };
+            const auto out_slot = [&](std::uint32_t u) {
+                // (u: an exported cluster output: the slot of the operand position which reads it.)
+                for (std::size_t j = 0; j < grp.nodes.size(); ++j) {
+                    const auto &nd = p.nodes[grp.nodes[j] - n_eq];
+                    for (std::uint32_t a = 0; a < n_args; ++a) {
+                        if (nd.args[a].idx == u) {
+                            return op_slot(node_coord[j], node_rank[j], a);
+                        }
+                    }
+                }
+                return 0u;
+            };
+            // (Dummy slots of the idle lanes: the spare slot of the arrays of rank 0 (products) and rank 1 (reactions).)
+            const auto dummy_pr = [&](std::uint32_t i) { return op_slot(i, 0, W - 1u); };
+            const auto dummy_rx = [&](std::uint32_t i) { return op_slot(i, 1, W - 1u); };
+            // Which operand position reads the outputs of every cluster (independent of the layout parameters).
+            std::vector<std::array<std::uint32_t, 3>> pr_ref(nc), rx_ref(nc); // (node index j, argument) packed: j * 8 + a
+            for (std::uint32_t c = 0; c < nc; ++c) {
+                for (std::uint32_t i = 0; i < 3u; ++i) {
+                    for (int kind = 0; kind < 2; ++kind) {
+                        const auto u = pl.clusters[c][kind == 0 ? pp.pr[i] : static_cast<std::uint32_t>(pp.rx[i])];
+                        std::uint32_t ref = ~0u;
+                        for (std::size_t j = 0; j < grp.nodes.size(); ++j) {
+                            const auto &nd = p.nodes[grp.nodes[j] - n_eq];
+                            for (std::uint32_t a = 0; a < n_args; ++a) {
+                                if (nd.args[a].idx == u) {
+                                    ref = static_cast<std::uint32_t>(j) * 8u + a;
+                                }
+                            }
+                        }
+                        (kind == 0 ? pr_ref : rx_ref)[c][i] = ref;
+                    }
+                }
+            }
+            // (The three stores of a lane must differ by the block distance: same rank and argument for the three coordinates.)
+            for (std::uint32_t c = 0; c < nc && wide_rd; ++c) {
+                for (const auto *ref : {&pr_ref, &rx_ref}) {
+                    const auto r0 = (*ref)[c][0];
+                    for (std::uint32_t i = 0; i < 3u; ++i) {
+                        const auto ri = (*ref)[c][i];
+                        if (ri == ~0u || r0 == ~0u) {
+                            wide_rd = wide_rd && ri == r0; // (unread outputs: all three or none)
+                            continue;
+                        }
+                        wide_rd = wide_rd && node_coord[ri / 8u] == i && node_rank[ri / 8u] == node_rank[r0 / 8u] && ri % 8u == r0 % 8u;
+                    }
+                }
+            }
+            const auto ref_slot = [&](std::uint32_t ref) { return op_slot(node_coord[ref / 8u], node_rank[ref / 8u], ref % 8u); };
+            const auto addr_lists = [&]() {
+                std::vector<lds_op> ops;
+                // Position reads of the pair lanes: per side a ds_read_b128 (x, y) and a ds_read_b64 (z).
+                for (std::uint32_t sd = 0; sd < 2u; ++sd) {
+                    lds_op o16{16, std::vector<std::uint32_t>(pl.L)}, o8{8, std::vector<std::uint32_t>(pl.L)};
+                    for (std::uint32_t l = 0; l < pl.L; ++l) {
+                        const auto c = l < nc ? l : 0u;
+                        std::array<std::uint32_t, 3> tr{};
+                        for (std::uint32_t i = 0; i < 3u; ++i) {
+                            tr[i] = pl.ext_u[c][pp.de[i][sd]];
+                        }
+                        const auto b = static_cast<std::uint32_t>(std::find(bodies.begin(), bodies.end(), tr) - bodies.begin());
+                        o16.addr[l] = pos_base + 4u * b;
+                        o8.addr[l] = pos_base + 4u * b + 2u;
+                    }
+                    ops.push_back(std::move(o16));
+                    ops.push_back(std::move(o8));
+                }
+                // Operand reads of the glue rounds.
+                const auto n_nodes = static_cast<std::uint32_t>(grp.nodes.size());
+                for (std::uint32_t r = 0; r * pl.L < n_nodes; ++r) {
+                    for (std::uint32_t a = 0; a < n_args; a += 2u) {
+                        lds_op o{a + 1u < n_args ? 16 : 8, std::vector<std::uint32_t>(pl.L)};
+                        for (std::uint32_t l = 0; l < pl.L; ++l) {
+                            const auto j = r * pl.L + l < n_nodes ? r * pl.L + l : r * pl.L;
+                            o.addr[l] = op_slot(node_coord[j], node_rank[j], a);
+                        }
+                        ops.push_back(std::move(o));
+                    }
+                    // The position coefficients which the round publishes.
+                    lds_op ow{-8, std::vector<std::uint32_t>(pl.L)};
+                    for (std::uint32_t l = 0; l < pl.L; ++l) {
+                        if (r * pl.L + l >= n_nodes) {
+                            ow.addr[l] = 4u * nb + 2u * Dd + W * n_rank; // (the dummy area)
+                            continue;
+                        }
+                        const auto j = r * pl.L + l;
+                        // (The position variable attached to the node: second member of its chain.)
+                        const auto &ch = att.at(grp.nodes[j]);
+                        std::uint32_t slot = 0;
+                        for (const auto var : ch) {
+                            for (std::uint32_t b = 0; b < nb; ++b) {
+                                for (std::uint32_t i = 0; i < 3u; ++i) {
+                                    if (bodies[b][i] == var) {
+                                        slot = pos_base + 4u * b + i;
+                                    }
+                                }
+                            }
+                        }
+                        ow.addr[l] = slot;
+                    }
+                    ops.push_back(std::move(ow));
+                }
+                // Stores of the products and of the reactions.
+                for (int kind = 0; kind < 2; ++kind) {
+                    for (std::uint32_t i = 0; i < 3u; ++i) {
+                        lds_op o{-8, std::vector<std::uint32_t>(pl.L)};
+                        for (std::uint32_t l = 0; l < pl.L; ++l) {
+                            const auto ref = l < nc ? (kind == 0 ? pr_ref : rx_ref)[l][i] : ~0u;
+                            o.addr[l] = ref != ~0u ? ref_slot(ref) : (kind == 0 ? dummy_pr(i) : dummy_rx(i));
+                        }
+                        ops.push_back(std::move(o));
+                    }
+                }
+                return ops;
+            };
+            // Bank model (MI355X_MICROARCH.md, LDS): lane groups per instruction width, banks of 4 bytes; identical addresses
+            // broadcast, every further distinct address on a busy bank costs the group one more LDS cycle.
+            static const std::vector<std::vector<std::uint32_t>> grp128 = [] {
+                std::vector<std::vector<std::uint32_t>> g(4);
+                const std::uint32_t r0[] = {0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27};
+                const std::uint32_t r1[] = {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31};
+                for (const auto x : r0) {
+                    g[0].push_back(x);
+                    g[2].push_back(x + 32u);
+                }
+                for (const auto x : r1) {
+                    g[1].push_back(x);
+                    g[3].push_back(x + 32u);
+                }
+                return g;
+            }();
+            const auto wcost = [&](const std::vector<lds_op> &ops, std::uint32_t stride) {
+                std::uint64_t tot = 0;
+                const auto spw_ = 64u / pl.L;
+                const auto lane_addr = [&](const lds_op &o, std::uint32_t lane) {
+                    return ((lane / pl.L) % spw_) * stride + o.addr[lane % pl.L];
+                };
+                for (const auto &o : ops) {
+                    const auto n_banks = o.width < 0 ? 32u : 64u;
+                    const auto dwords = o.width == 16 ? 4u : 2u;
+                    std::vector<std::vector<std::uint32_t>> groups;
+                    if (o.width == 16) {
+                        groups = grp128;
+                    } else if (o.width == 8) {
+                        groups.assign(2, {});
+                        for (std::uint32_t l = 0; l < 64u; ++l) {
+                            groups[l / 32u].push_back(l);
+                        }
+                    } else {
+                        groups.assign(4, {});
+                        for (std::uint32_t l = 0; l < 64u; ++l) {
+                            groups[l / 16u].push_back(l);
+                        }
+                    }
+                    for (const auto &g : groups) {
+                        std::map<std::uint32_t, std::set<std::uint32_t>> banks;
+                        for (const auto lane : g) {
+                            const auto a = lane_addr(o, lane);
+                            for (std::uint32_t d = 0; d < dwords; ++d) {
+                                banks[(2u * a + d) % n_banks].insert(a);
+                            }
+                        }
+                        std::size_t mx = 1;
+                        for (const auto &[b, st_] : banks) {
+                            (void)b;
+                            mx = std::max(mx, st_.size());
+                        }
+                        tot += (mx - 1u) * (o.width < 0 ? 2u : 1u);
+                    }
+                }
+                return tot;
+            };
+            if (wide_rd) {
+                // Exhaustive over the order of the bodies inside a coordinate block (n_rank! <= 720), a few block distances
+                // and the even slab strides of one bank period.
+                std::uint64_t best_c = ~std::uint64_t(0);
+                auto best_perm = perm;
+                std::uint32_t best_D = Dd, best_stride = 0;
+                std::vector<std::uint32_t> pm(n_rank);
+                for (std::uint32_t r = 0; r < n_rank; ++r) {
+                    pm[r] = r;
+                }
+                // (+ 2: the dummy area behind the arrays - idle lanes of a partially filled glue round publish there.)
+                const auto total_for = [&](std::uint32_t D_) { return 4u * nb + 2u * D_ + W * n_rank + 2u; };
+                const bool full = n_rank <= 6u && !v5_flag("nobanksearch");
+                do {
+                    perm = pm;
+                    for (std::uint32_t D_ = W * n_rank; D_ <= W * n_rank + (full ? 8u : 0u); D_ += 2u) {
+                        Dd = D_;
+                        const auto ops = addr_lists();
+                        const auto tot = total_for(D_);
+                        for (std::uint32_t st_ = (tot + 1u) & ~1u; st_ < ((tot + 1u) & ~1u) + 32u; st_ += 2u) {
+                            // (The dead slab also parks the new state of the stepper with events: >= n_own * L slots.)
+                            const auto c = wcost(ops, st_);
+                            if (c < best_c) {
+                                best_c = c;
+                                best_perm = pm;
+                                best_D = D_;
+                                best_stride = st_;
+                            }
+                        }
+                    }
+                } while (full && std::next_permutation(pm.begin(), pm.end()) && best_c != 0u);
+                perm = best_perm;
+                Dd = best_D;
+                slab_stride_opt = best_stride;
+                bank_cost = best_c;
+                if (v5_flag("bankdbg")) {
+                    const auto ops = addr_lists();
+                    std::fprintf(stderr, "wide layout: D = %u, stride = %u, cost = %llu, perm =", Dd, best_stride,
+                                 static_cast<unsigned long long>(best_c));
+                    for (const auto x : perm) {
+                        std::fprintf(stderr, " %u", x);
+                    }
+                    std::fprintf(stderr, "\n");
+                    for (const auto &o : ops) {
+                        std::fprintf(stderr, "  width %d cost %llu addr:", o.width,
+                                     static_cast<unsigned long long>(wcost(std::vector<lds_op>{o}, best_stride)));
+                        for (const auto x : o.addr) {
+                            std::fprintf(stderr, " %u", x);
+                        }
+                        std::fprintf(stderr, "\n");
+                    }
+                }
+                // The slots.
+                std::fill(pl.slot_of.begin(), pl.slot_of.end(), -1);
+                for (std::uint32_t b = 0; b < nb; ++b) {
+                    for (std::uint32_t i = 0; i < 3u; ++i) {
+                        pl.slot_of[bodies[b][i]] = static_cast<int>(pos_base + 4u * b + i);
+                    }
+                }
+                wide_pr.assign(pl.L, {});
+                wide_rx.assign(pl.L, {});
+                for (std::uint32_t l = 0; l < pl.L; ++l) {
+                    for (std::uint32_t i = 0; i < 3u; ++i) {
+                        const auto rp = l < nc ? pr_ref[l][i] : ~0u, rr = l < nc ? rx_ref[l][i] : ~0u;
+                        wide_pr[l][i] = rp != ~0u ? ref_slot(rp) : dummy_pr(i);
+                        wide_rx[l][i] = rr != ~0u ? ref_slot(rr) : dummy_rx(i);
+                        if (l < nc && rp != ~0u) {
+                            pl.slot_of[pl.clusters[l][pp.pr[i]]] = static_cast<int>(wide_pr[l][i]);
+                        }
+                        if (l < nc && rr != ~0u) {
+                            pl.slot_of[pl.clusters[l][static_cast<std::uint32_t>(pp.rx[i])]] = static_cast<int>(wide_rx[l][i]);
+                        }
+                    }
+                }
+                pl.n_slots = total_for(Dd) - 2u;
+                (void)out_slot;
+            }
+        }
     }
 
     // ---- 2. LDS layout: every slot double-buffered by order parity. ----
-    const std::uint32_t max_round_outputs = std::max<std::uint32_t>(n_out, one_lane ? 6u : 4u);
+    const std::uint32_t max_round_outputs = wide_rd ? 2u : std::max<std::uint32_t>(n_out, one_lane ? 6u : 4u);
     const auto dummy_base = pl.n_slots;
     const auto n_slots_tot = pl.n_slots + max_round_outputs;
     // One-lane pair kernel: ONE buffer. A system never spans wavefronts and the LDS instructions of a wavefront complete
@@ -674,11 +1052,13 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
                 s0[l] = static_cast<std::uint32_t>(pl.slot_of[pl.ext_u[c][pp.de[i][0]]]);
                 s1[l] = static_cast<std::uint32_t>(pl.slot_of[pl.ext_u[c][pp.de[i][1]]]);
                 // (Every lane owns its output slots, the idle ones too: slot = first slot of pair 0 + 3 * lane + i.)
-                o[l] = static_cast<std::uint32_t>(pl.slot_of[pl.clusters[0][pp.pr[i]]]) - 3u * lane_pr[0] + 3u * lane_pr[l];
+                o[l] = wide_rd ? wide_pr[l][i]
+                               : static_cast<std::uint32_t>(pl.slot_of[pl.clusters[0][pp.pr[i]]]) - 3u * lane_pr[0] + 3u * lane_pr[l];
                 if (pp.rx[0] >= 0) {
                     const auto ru = cl[static_cast<std::uint32_t>(pp.rx[i])];
-                    r[l] = static_cast<std::uint32_t>(pl.slot_of[pl.clusters[0][static_cast<std::uint32_t>(pp.rx[i])]]) - 3u * lane_rx[0]
-                           + 3u * lane_rx[l];
+                    r[l] = wide_rd ? wide_rx[l][i]
+                                   : static_cast<std::uint32_t>(pl.slot_of[pl.clusters[0][static_cast<std::uint32_t>(pp.rx[i])]])
+                                         - 3u * lane_rx[0] + 3u * lane_rx[l];
                     const auto cv = p.nodes[ru - n_eq].args[0].value;
                     if (i > 0u && cv != crs[l]) {
                         why_not = "one-lane pair kernel: the reaction coefficients of a pair differ between the coordinates";
@@ -1016,6 +1396,14 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
         }
     };
 
+    // A 16-byte LDS read of two adjacent slots (wide-read layout: the table entries are even, the slab is 16-byte aligned).
+    std::uint32_t n_wide = 0;
+    const auto wide_read = [&](const std::string &tbl) {
+        const auto nm = "w" + std::to_string(n_wide++);
+        os << "const hy_d2 " << nm << " = *reinterpret_cast<const hy_d2 *>(slab + " << tbl << ");\n";
+        ++e.n_stmt;
+        return nm;
+    };
     // A glue round is emitted in two halves: the LDS reads of the operands, and the computation (node rule,
     // export, fused state-variable recursions). In overlap mode independent FMA work is placed in between.
     const auto emit_glue_reads = [&](std::size_t g, std::uint32_t r, std::uint32_t k) {
@@ -1024,6 +1412,14 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
         const auto &n0 = p.nodes[grp.nodes[0] - n_eq];
         std::vector<std::string> names(n0.args.size());
         for (std::size_t a = 0; a < n0.args.size(); ++a) {
+            if (wide_rd && a + 1u < n0.args.size() && a % 2u == 0u) {
+                // (Operands a, a + 1 of the sum: adjacent slots of the node's operand array.)
+                const auto w = wide_read(utname(gr.arg_tbl[a]));
+                names[a] = w + ".x";
+                names[a + 1u] = w + ".y";
+                ++a;
+                continue;
+            }
             if (is_var(n0.args[a])) {
                 names[a] = e.def(slabk(k, utname(gr.arg_tbl[a])));
             }
@@ -1336,6 +1732,17 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
         v.resize(order + 1u);
     }
     std::string hq[3], hm[3], hcx[3], hT, hU, pow_pre;
+    std::string nq[3], nm[3], ncx[3]; // (early terms of the next order, see emit_single_early())
+    // Sensitivity experiment (profiles/experiments/sensitivity.py): HEYOKA_AMD_V5_PAD = "chain:dep:st:ld:salu" adds that many
+    // dummy instructions of each kind to every order - independent FMAs in the chain section, dependent FMAs, LDS stores
+    // and LDS reads in the dependent section, scalar no-ops - without touching the results: the slope of the step time
+    // against each count says which resource the kernel is bound by.
+    unsigned pad_chain = 0, pad_dep = 0, pad_st = 0, pad_ld = 0, pad_salu = 0;
+    if (const char *ev = std::getenv("HEYOKA_AMD_V5_PAD")) {
+        std::sscanf(ev, "%u:%u:%u:%u:%u", &pad_chain, &pad_dep, &pad_st, &pad_ld, &pad_salu);
+    }
+    const bool any_pad = (pad_chain | pad_dep | pad_st | pad_ld | pad_salu) != 0u;
+    bool early_done = false;
     // One accumulator for the half sum of squares bh_k = sum_i (sum_j d_i[k-j] d_i[j] + 1/2 d_i[k/2]^2): the three chains
     // of the coordinates run into each other - two additions per order and two multiply-adds per even order less, two
     // accumulators less. (The reference adds the three squares pairwise, src/detail/sum_sq.cpp:120-245: same terms, other
@@ -1343,6 +1750,22 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     const bool merged_sq = !v5_flag("nomsq");
     //   nosc      the selector's logarithm / exponential with literal polynomial constants (hy_sel_log(), exp()).
     const bool sel_scalar = one_lane && !v5_flag("nosc");
+    //   noilv     no interleaving of the early chain terms of order k + 1 with the dependent operations of round k
+    //             (HEYOKA_AMD_V5_ILV = "kmin:kmax:barriers" sets the range of rounds and the scheduling fences);
+    // (Measured: 7.35e8 without, 7.21e8 ... 7.30e8 with it over any range of rounds, profiles/r05_ab_interleaved_early_terms.log:
+    // OFF unless HEYOKA_AMD_V5_ILV asks for it.)
+    std::uint32_t ilv_kmin = 3, ilv_kmax = 0;
+    bool ilv_fences = true;
+    if (v5_flag("noilv")) {
+        ilv_kmax = 0;
+    } else if (const char *ev = std::getenv("HEYOKA_AMD_V5_ILV")) {
+        unsigned a_ = 0, b_ = 0, c_ = 1;
+        if (std::sscanf(ev, "%u:%u:%u", &a_, &b_, &c_) >= 2) {
+            ilv_kmin = a_;
+            ilv_kmax = b_;
+            ilv_fences = c_ != 0u;
+        }
+    }
     // Issue priority (s_setprio): raised between the LDS exchange and the end of the finishing operations of a round - the
     // dependent chain which decides how soon the next exchange can start - and lowered for the convolution chains, so
     // that the wavefront which is in its critical section wins the VALU over the one streaming FMAs.
@@ -1351,10 +1774,22 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     const int prio_mode = std::getenv("HEYOKA_AMD_V5_PRIO") != nullptr ? std::atoi(std::getenv("HEYOKA_AMD_V5_PRIO")) : 2;
     const bool prio_switch = prio_mode != 0;
     const auto emit_single_reads = [&](std::uint32_t k) {
-        std::vector<std::string> r;
+        std::vector<std::string> r(6);
+        if (wide_rd) {
+            // (x, y) of the two bodies with one ds_read_b128 each, then the two z.
+            for (std::uint32_t sd = 0; sd < 2u; ++sd) {
+                const auto w = wide_read(utname(st1.s[0][sd]));
+                r[0u + sd] = w + ".x";
+                r[2u + sd] = w + ".y";
+            }
+            for (std::uint32_t sd = 0; sd < 2u; ++sd) {
+                r[4u + sd] = e.def(slabk(k, utname(st1.s[2][sd])));
+            }
+            return r;
+        }
         for (std::uint32_t i = 0; i < 3u; ++i) {
-            r.push_back(e.def(slabk(k, utname(st1.s[i][0]))));
-            r.push_back(e.def(slabk(k, utname(st1.s[i][1]))));
+            r[2u * i] = e.def(slabk(k, utname(st1.s[i][0])));
+            r[2u * i + 1u] = e.def(slabk(k, utname(st1.s[i][1])));
         }
         return r;
     };
@@ -1416,18 +1851,78 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
             const auto rxv = e.def(ssa_emitter::mul("crs_r", pr[i]));
             os << slabk(k, utname(st1.r[i])) << " = " << rxv << ";\n";
         }
+        if (any_pad && k >= 1u) {
+            for (unsigned i = 0; i < pad_dep; ++i) {
+                os << "asm volatile(\"v_fma_f64 %0, %0, %0, %0\" : \"+v\"(hy_pad0));\n";
+            }
+            // (Written-out LDS stores of the first product to its own slot once more: same value, same address. The
+            // compiler's lgkmcnt bookkeeping stays conservative: LDS operations complete in order.)
+            for (unsigned i = 0; i < pad_st; ++i) {
+                os << "asm volatile(\"ds_write_b64 %0, %1\" ::\"v\"((unsigned)(unsigned long long)&" << slabk(k, utname(st1.o[0]))
+                   << "), \"v\"(" << pr[0] << ") : \"memory\");\n";
+            }
+            (void)pad_ld;
+            for (unsigned i = 0; i < pad_salu; ++i) {
+                os << "asm volatile(\"s_nop 0\");\n";
+            }
+        }
         if (prio_switch) {
             // (End of the latency-critical part of the round: the chains below are bulk work.)
             os << "__builtin_amdgcn_s_setprio(0);\n";
         }
-        // History parts of order K = k + 1 (terms without an order-K operand) and the T / U chains of the pow recurrence,
-        // whose first term is the newest one. (Accumulating the terms with both indices <= k - 1 ahead of this finishing,
-        // under the latency of the LDS reads, was measured in round 3: +-0 % - the other wavefront of the SIMD covers the
-        // exchange already - and spills at the high orders; removed.)
+        if (any_pad && k >= 1u) {
+            for (unsigned i = 0; i < pad_chain; ++i) {
+                os << "asm volatile(\"v_fma_f64 %0, %0, %0, %0\" : \"+v\"(hy_pad" << (1u + i % 4u) << "));\n";
+            }
+        }
+    };
+    // Early terms of the chains of order K = k + 1: the products with both indices <= k - 1, which need nothing of round k.
+    // They are INTERLEAVED with the dependent operations of the round (interleave_round() below): the finishing
+    // operations and the glue sums are chains of dependent FP64 operations, one result per ~8 cycles, and the wavefront
+    // which runs them holds the issue priority - the early terms fill its idle issue slots with work that had to be done
+    // anyway. (Round 3 tried the early terms as a BLOCK between the LDS reads and the finishing: +-0 %, the reads are
+    // hoisted above the chains of the previous order by the compiler anyway; the gain is in the dependent section.)
+    // T / U of the pow recurrence start with the newest coefficient and stay behind the finishing.
+    const auto emit_single_early = [&](std::uint32_t k) {
+        const auto K = k + 1u;
         for (std::uint32_t i = 0; i < 3u; ++i) {
-            hq[i].clear();
-            hm[i].clear();
-            hcx[i].clear();
+            nq[i].clear();
+            nm[i].clear();
+            ncx[i].clear();
+        }
+        early_done = false;
+        if (!(K < order && K >= 4u && k >= ilv_kmin && k <= ilv_kmax)) {
+            return;
+        }
+        early_done = true;
+        const auto jmax = (K % 2u == 1u) ? (K - 1u) / 2u : (K - 2u) / 2u;
+        for (std::uint32_t j = 2; j + 2u <= K; ++j) {
+            for (std::uint32_t i = 0; i < 3u; ++i) {
+                ncx[i] = e.chain(ncx[i], sD[i][K - j], sA[j]);
+                if (j <= jmax) {
+                    auto &acc = nq[merged_sq ? 0u : i];
+                    acc = e.chain(acc, sD[i][K - j], sD[i][j]);
+                }
+            }
+        }
+        if (K % 2u == 0u) {
+            for (std::uint32_t i = 0; i < 3u; ++i) {
+                if (merged_sq) {
+                    nm[0] = e.chain(i == 0u ? std::string{} : nm[0], sD[i][K / 2u], sD[i][K / 2u]);
+                } else {
+                    nm[i] = e.def(ssa_emitter::mul(sD[i][K / 2u], sD[i][K / 2u]));
+                }
+            }
+        }
+    };
+    const auto emit_single_history = [&](std::uint32_t k) {
+        using emit_detail::ssa_emitter;
+        // History parts of order K = k + 1 (terms without an order-K operand) and the T / U chains of the pow recurrence,
+        // whose first term is the newest one; on top of the early terms where those were accumulated during the round.
+        for (std::uint32_t i = 0; i < 3u; ++i) {
+            hq[i] = early_done ? nq[i] : std::string{};
+            hm[i] = early_done ? nm[i] : std::string{};
+            hcx[i] = early_done ? ncx[i] : std::string{};
         }
         hT.clear();
         hU.clear();
@@ -1439,6 +1934,9 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
                 const auto jd = K - j;
                 hT = e.chain(hT, sB[K - jd], sA[jd]);
                 hU = hU.empty() ? hT : e.def(hU + " + " + hT);
+                if (early_done && j >= 2u && j + 2u <= K) {
+                    continue;
+                }
                 for (std::uint32_t i = 0; i < 3u; ++i) {
                     hcx[i] = e.chain(hcx[i], sD[i][K - j], sA[j]);
                     if (j <= jmax) {
@@ -1447,7 +1945,7 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
                     }
                 }
             }
-            if (K % 2u == 0u) {
+            if (K % 2u == 0u && !early_done) {
                 for (std::uint32_t i = 0; i < 3u; ++i) {
                     if (merged_sq) {
                         // (One running sum of the three middle squares.)
@@ -1512,6 +2010,9 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
 
     // ===================== step body =====================
     os << "double m0 = 0.0, mo = 0.0, mom1 = 0.0;\n";
+    if (one_lane && std::getenv("HEYOKA_AMD_V5_PAD") != nullptr) {
+        os << "double hy_pad0 = 1.0, hy_pad1 = 1.0, hy_pad2 = 1.0, hy_pad3 = 1.0, hy_pad4 = 1.0;\n";
+    }
     for (auto &rg : rounds) {
         for (auto &gr : rg) {
             for (auto &ow : gr.owners) {
@@ -1571,18 +2072,65 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
             if (k < order) {
                 sched_fence();
             }
-            for (const auto &[g, r, names] : pend) {
-                if (glue_first) {
-                    emit_glue_compute(g, r, k - 1u, names);
+            // (The statements of a part of the round as text: the stream is swapped for the duration of f.)
+            const auto capture = [&](const auto &f) {
+                const auto before = os.str();
+                os.str("");
+                os.clear();
+                f();
+                auto txt = os.str();
+                os.str(before);
+                os.seekp(0, std::ios_base::end);
+                return txt;
+            };
+            const auto critical = [&]() {
+                for (const auto &[g, r, names] : pend) {
+                    if (glue_first) {
+                        emit_glue_compute(g, r, k - 1u, names);
+                    }
+                }
+                if (k < order) {
+                    emit_single_compute(k, prd);
+                }
+                for (const auto &[g, r, names] : pend) {
+                    if (!glue_first) {
+                        emit_glue_compute(g, r, k - 1u, names);
+                    }
+                }
+            };
+            std::string early_txt;
+            if (k < order) {
+                early_txt = capture([&]() { emit_single_early(k); });
+            }
+            if (early_txt.empty()) {
+                critical();
+            } else {
+                // Interleave: the early terms spread evenly behind the statements of the dependent section.
+                const auto split = [](const std::string &t) {
+                    std::vector<std::string> v;
+                    std::size_t a_ = 0;
+                    while (a_ < t.size()) {
+                        const auto b_ = t.find('\n', a_);
+                        v.push_back(t.substr(a_, b_ - a_));
+                        a_ = b_ + 1u;
+                    }
+                    return v;
+                };
+                const auto la = split(capture(critical)), lb = split(early_txt);
+                std::size_t nb_done = 0;
+                for (std::size_t i = 0; i < la.size(); ++i) {
+                    os << la[i] << "\n";
+                    const auto upto = (i + 1u) * lb.size() / la.size();
+                    for (; nb_done < upto; ++nb_done) {
+                        os << lb[nb_done] << "\n";
+                    }
+                    if (ilv_fences && i % 2u == 1u) {
+                        os << "__builtin_amdgcn_sched_barrier(0);\n";
+                    }
                 }
             }
             if (k < order) {
-                emit_single_compute(k, prd);
-            }
-            for (const auto &[g, r, names] : pend) {
-                if (!glue_first) {
-                    emit_glue_compute(g, r, k - 1u, names);
-                }
+                emit_single_history(k);
             }
             if (prio_switch && k == order && prio_mode != 2) {
                 os << "__builtin_amdgcn_s_setprio(0);\n";
@@ -1698,6 +2246,11 @@ __device__ __forceinline__ double hy_dpp(double x)
 }
 )HIP";
     // (hy_sel_log(): the logarithm of the step-size selector, in the common prelude - hip_emit.cpp.)
+    if (wide_rd) {
+        // (The native vector type: a load of HIP's double2 - a struct - is taken apart into two 8-byte loads by SROA.)
+        src << "#if defined(HY_HOST_EMU)\nstruct hy_d2 {\n    double x, y;\n};\n#else\n"
+               "typedef double hy_d2 __attribute__((ext_vector_type(2)));\n#endif\n";
+    }
     if (one_lane) {
         // The logarithm and the exponential of the selector with their polynomial constants in SCALAR registers. A Horner
         // step p * w + C with a literal C compiles to v_mov_b32 x 2 (the literal into the destination pair) + v_fmac_f64:
@@ -1884,7 +2437,8 @@ __device__ __forceinline__ double hy_swap1(double x)
     src << "};\n";
 
     src << "extern \"C\" __global__ void __launch_bounds__(" << bs << ") hy_taylor(const hy_kargs a)\n{\n";
-    src << "__shared__ double lds_slab[" << static_cast<std::uint64_t>(wpb) * spw * slab_stride << "];\n";
+    src << "__shared__ " << (wide_rd ? "__attribute__((aligned(16))) " : "") << "double lds_slab["
+        << static_cast<std::uint64_t>(wpb) * spw * slab_stride << "];\n";
     src << "const unsigned lane = threadIdx.x & 63u;\nconst unsigned wib = threadIdx.x >> 6;\n";
     src << "const unsigned l = lane % " << L << "u;\nconst unsigned q = lane / " << L << "u;\n";
     src << "const u64 N = a.N;\n";

@@ -42,7 +42,7 @@ def _lockstep(src):
     kernels rely on every lane having READ a slot before any lane overwrites it. The fibres of the emulator run one after
     the other between rendezvous points, so a rendezvous goes in front of every LDS store - except inside blocks whose
     condition is not wave-uniform (the pickup of a new system by the lanes of a finished one: no exchange in there)."""
-    lds = set(re.findall(r"__shared__\s+[\w ]+?\s+(\w+)\[", src))
+    lds = set(re.findall(r"__shared__\s+(?:__attribute__\(\([^)]*\)\)\)\s+)?[\w ]+?\s+(\w+)\[", src))
     decl = re.compile(r"^\s*(?:const\s+)?double\s*\*\s*(?:const\s+)?(\w+)\s*=\s*([^;]*);", re.M)
     grew = True
     while grew:
