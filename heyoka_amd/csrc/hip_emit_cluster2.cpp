@@ -16,6 +16,7 @@
 #include <array>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <map>
 #include <set>
 #include <tuple>
@@ -340,6 +341,10 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     }
     std::vector<std::uint32_t> lane_pr, lane_rx; // one-lane pair kernel: output slot triples of the lanes
     bool wide_rd = false;                        // ... wide-read layout: slots arranged by consumer (see below)
+    // ... velocity exchange: the pair lanes take the coordinate differences from the velocity jets, d^[k] = (v_a^[k-1] - v_b^[k-1])
+    // RN(1 / k), and no position coefficient is published (see below). vx_col[l] = first jet column of the two bodies of lane l.
+    bool vexch = false;
+    std::vector<std::array<std::uint32_t, 2>> vx_col;
     std::vector<std::array<std::uint32_t, 3>> wide_pr, wide_rx; // ... its output slots, per lane and coordinate
     std::uint32_t slab_stride_opt = 0;
     std::uint64_t bank_cost = 0;
@@ -632,6 +637,51 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
                 wide_rd = wide_rd && seen == 7u;
             }
         }
+        // Velocity exchange (round 5). An LDS store is the most expensive instruction of this kernel: 35-40 cycles of the
+        // issuing wavefront's time against 5.6 for an FMA (profiles/r05_sensitivity_marginal_costs.log: the store path of
+        // a CU moves one ds_write_b64 of a wavefront per ~6 cycles and all eight wavefronts queue on it), and a round stores
+        // 3 products + 3 reactions + 2 velocity coefficients (jets) + 2 position coefficients (slab). The position
+        // coefficient is the velocity coefficient times RN(1 / (k + 1)): the pair lanes read the velocity jets of their
+        // two bodies instead and form d^[k] = (v_a^[k-1] - v_b^[k-1]) RN(1 / k) themselves (one multiplication per
+        // coordinate; the order-0 differences come from the current positions), so that the glue lanes neither compute
+        // nor store x^[k+1]: 8 stores per round instead of 10. (Rounded once after the subtraction instead of once per body
+        // before it: the same quantity to rounding, more accurate where the velocities are close.) Requires the jet
+        // columns of the three coordinates of a body to be adjacent: the rows are laid out [system][column] here.
+        if (wide_rd && !m4 && !v5_flag("novx")) {
+            // Jet column of a velocity variable = index of its glue node in the group (owner slots are filled in that order).
+            const auto &grp = pl.groups[0];
+            std::map<std::uint32_t, std::uint32_t> col_of_pos; // position variable -> jet column of its velocity
+            for (std::size_t j = 0; j < grp.nodes.size(); ++j) {
+                const auto it = att.find(grp.nodes[j]);
+                if (it != att.end() && it->second.size() == 2u) {
+                    col_of_pos[it->second[1]] = static_cast<std::uint32_t>(j);
+                }
+            }
+            vexch = true;
+            std::vector<std::uint32_t> body_col(bodies.size(), 0);
+            for (std::size_t b = 0; b < bodies.size() && vexch; ++b) {
+                for (std::uint32_t i = 0; i < 3u; ++i) {
+                    const auto it = col_of_pos.find(bodies[b][i]);
+                    vexch = vexch && it != col_of_pos.end() && (i == 0u || it->second == body_col[b] + i);
+                    if (vexch && i == 0u) {
+                        body_col[b] = it->second;
+                    }
+                }
+            }
+            if (vexch) {
+                vx_col.assign(pl.L, {});
+                for (std::uint32_t l = 0; l < pl.L; ++l) {
+                    const auto c = l < nc ? l : 0u;
+                    for (std::uint32_t sd = 0; sd < 2u; ++sd) {
+                        std::array<std::uint32_t, 3> tr{};
+                        for (std::uint32_t i = 0; i < 3u; ++i) {
+                            tr[i] = pl.ext_u[c][pp.de[i][sd]];
+                        }
+                        vx_col[l][sd] = body_col[static_cast<std::size_t>(std::find(bodies.begin(), bodies.end(), tr) - bodies.begin())];
+                    }
+                }
+            }
+        }
         if (wide_rd) {
             const auto W = (n_args + 2u) & ~1u; // slots of an operand array (>= one spare slot, even)
             const auto nb = static_cast<std::uint32_t>(bodies.size());
@@ -646,7 +696,9 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
             for (std::uint32_t r = 0; r < n_rank; ++r) {
                 perm[r] = r;
             }
-            std::uint32_t Dd = W * n_rank, pos_base = 0, op_base = 4u * nb;
+            // (Velocity exchange: no position slots.)
+            const auto pos_sz = vexch ? 0u : 4u * nb;
+            std::uint32_t Dd = W * n_rank, pos_base = 0, op_base = pos_sz;
             const auto op_slot = [&](std::uint32_t coord, std::uint32_t rank, std::uint32_t a) {
                 return op_base + Dd * coord + W * perm[rank] + a;
             };
@@ -702,7 +754,7 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
             const auto addr_lists = [&]() {
                 std::vector<lds_op> ops;
                 // Position reads of the pair lanes: per side a ds_read_b128 (x, y) and a ds_read_b64 (z).
-                for (std::uint32_t sd = 0; sd < 2u; ++sd) {
+                for (std::uint32_t sd = 0; sd < (vexch ? 0u : 2u); ++sd) {
                     lds_op o16{16, std::vector<std::uint32_t>(pl.L)}, o8{8, std::vector<std::uint32_t>(pl.L)};
                     for (std::uint32_t l = 0; l < pl.L; ++l) {
                         const auto c = l < nc ? l : 0u;
@@ -729,10 +781,13 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
                         ops.push_back(std::move(o));
                     }
                     // The position coefficients which the round publishes.
+                    if (vexch) {
+                        continue;
+                    }
                     lds_op ow{-8, std::vector<std::uint32_t>(pl.L)};
                     for (std::uint32_t l = 0; l < pl.L; ++l) {
                         if (r * pl.L + l >= n_nodes) {
-                            ow.addr[l] = 4u * nb + 2u * Dd + W * n_rank; // (the dummy area)
+                            ow.addr[l] = pos_sz + 2u * Dd + W * n_rank; // (the dummy area)
                             continue;
                         }
                         const auto j = r * pl.L + l;
@@ -833,7 +888,7 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
                     pm[r] = r;
                 }
                 // (+ 2: the dummy area behind the arrays - idle lanes of a partially filled glue round publish there.)
-                const auto total_for = [&](std::uint32_t D_) { return 4u * nb + 2u * D_ + W * n_rank + 2u; };
+                const auto total_for = [&](std::uint32_t D_) { return pos_sz + 2u * D_ + W * n_rank + 2u; };
                 const bool full = n_rank <= 6u && !v5_flag("nobanksearch");
                 do {
                     perm = pm;
@@ -876,7 +931,7 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
                 }
                 // The slots.
                 std::fill(pl.slot_of.begin(), pl.slot_of.end(), -1);
-                for (std::uint32_t b = 0; b < nb; ++b) {
+                for (std::uint32_t b = 0; b < nb && !vexch; ++b) {
                     for (std::uint32_t i = 0; i < 3u; ++i) {
                         pl.slot_of[bodies[b][i]] = static_cast<int>(pos_base + 4u * b + i);
                     }
@@ -900,6 +955,7 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
                 (void)out_slot;
             }
         }
+        vexch = vexch && wide_rd;
     }
 
     // ---- 2. LDS layout: every slot double-buffered by order parity. ----
@@ -1049,8 +1105,14 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
                 const bool valid = l < nc;
                 const auto c = valid ? l : 0u;
                 const auto &cl = pl.clusters[c];
-                s0[l] = static_cast<std::uint32_t>(pl.slot_of[pl.ext_u[c][pp.de[i][0]]]);
-                s1[l] = static_cast<std::uint32_t>(pl.slot_of[pl.ext_u[c][pp.de[i][1]]]);
+                if (vexch) {
+                    // (Velocity exchange: the jet columns of the two bodies instead of slab slots.)
+                    s0[l] = vx_col[l][0] + i;
+                    s1[l] = vx_col[l][1] + i;
+                } else {
+                    s0[l] = static_cast<std::uint32_t>(pl.slot_of[pl.ext_u[c][pp.de[i][0]]]);
+                    s1[l] = static_cast<std::uint32_t>(pl.slot_of[pl.ext_u[c][pp.de[i][1]]]);
+                }
                 // (Every lane owns its output slots, the idle ones too: slot = first slot of pair 0 + 3 * lane + i.)
                 o[l] = wide_rd ? wide_pr[l][i]
                                : static_cast<std::uint32_t>(pl.slot_of[pl.clusters[0][pp.pr[i]]]) - 3u * lane_pr[0] + 3u * lane_pr[l];
@@ -1244,6 +1306,8 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
                 for (std::uint32_t l = 0; l < L && r * L + l < n_nodes; ++l) {
                     ow.slab_needed = ow.slab_needed || glue_read[att.at(grp.nodes[r * L + l])[a]] != 0;
                 }
+                // (Velocity exchange: nobody reads a position coefficient - the compiler drops the unused ones.)
+                ow.slab_needed = ow.slab_needed && !vexch;
                 gr.owners.push_back(std::move(ow));
             }
             rounds[g].push_back(std::move(gr));
@@ -1266,6 +1330,14 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     const auto n_dcol = n_dcol_acc;
     const auto n_dcolp = one_lane ? n_dcol : n_dcol + 1u;
     const auto n_hslots = (n_col + L - 1u) / L; // lane slots of the final Horner / compensated evaluation
+    // Position of an owner slot inside a row of the jets (one-lane pair kernel): rows are [owner slot][system][lane] - the 32
+    // lanes which a ds_read_b64 services together touch 32 consecutive doubles - or, with the velocity exchange,
+    // [system][column] - the three coordinates of a body adjacent. jet_off: first entry of the slot for the first system
+    // of the wavefront, jet_sys: distance between two systems.
+    const auto jet_off = [&](const owner_slot &ow) -> std::uint64_t {
+        return vexch ? ow.cbase : static_cast<std::uint64_t>(spw) * ow.cbase;
+    };
+    const auto jet_sys = [&](const owner_slot &ow) -> std::uint32_t { return vexch ? (ow.derived ? n_dcol : n_col) : ow.n_valid; };
     // Jets of the state variables: [order][system of the wave][column], per wave. Kept in LDS when the
     // block's slab + jets fit in the 160 KB of a CU (the kernel occupies a whole CU anyway: 512 registers
     // per lane), otherwise in a per-wave global scratch.
@@ -1276,6 +1348,10 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     const auto lds_tc_table_bytes = m4 ? static_cast<std::uint64_t>(n_eq) * (order + 1u) * 8u : 0u;
     const bool jet_lds = (lds_doubles_slab + wpb * jet_doubles_per_wave) * 8u + lds_tc_table_bytes <= 160u * 1024u
                          && std::getenv("HEYOKA_AMD_JET_GLOBAL") == nullptr;
+    if (vexch && (!jet_lds || n_dcol != n_col)) {
+        why_not = "one-lane pair kernel: the velocity exchange needs the jets in LDS and one position per velocity";
+        return ret;
+    }
     // Stepper with events: compact set of Taylor coefficients (see emitted_module::compact_tc) through the cooperative
     // store of the LDS-resident jets. HEYOKA_AMD_COMPACT_TC=0 switches it off (A/B measurements).
     std::size_t n_tc_rows = 0; // rows of the mode-4 store (set where its source table is emitted)
@@ -1330,9 +1406,8 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
                     for (std::uint32_t l = 0; l < L; ++l) {
                         const bool isx = l >= nv && l < 2u * nv;
                         const auto c = isx ? l - nv : (l < nv ? l : 0u);
-                        tv[l] = static_cast<std::uint32_t>((isx ? jet_rows_doubles + static_cast<std::uint64_t>(spw) * o2.cbase
-                                                                : static_cast<std::uint64_t>(spw) * ow.cbase) + c);
-                        tj[l] = static_cast<std::uint32_t>(static_cast<std::uint64_t>(spw) * ow.cbase + c + (isx ? 0u : kst));
+                        tv[l] = static_cast<std::uint32_t>((isx ? jet_rows_doubles + jet_off(o2) : jet_off(ow)) + c);
+                        tj[l] = static_cast<std::uint32_t>(jet_off(ow) + c + (isx ? 0u : kst));
                         tf[l] = isx ? order + 1u : 0u;
                     }
                     pk_tbl[ow.col] = {add_utbl(std::move(tv), false), add_utbl(std::move(tj), false), add_utbl(std::move(tf), false)};
@@ -1733,6 +1808,11 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     }
     std::string hq[3], hm[3], hcx[3], hT, hU, pow_pre;
     std::string nq[3], nm[3], ncx[3]; // (early terms of the next order, see emit_single_early())
+    // (Tried in round 5 and removed: the stores of a round spread over the convolution chains which follow it instead of a
+    // burst at the end of the dependent section - the eight wavefronts of a CU queue on one LDS store path -: -1.6 %,
+    // profiles/r05_ab_spread_stores.log; the early chain terms of order k + 1 interleaved with the dependent operations of
+    // round k: -1 %, profiles/r05_ab_interleaved_early_terms.log.)
+    const auto emit_store = [&](const std::string &stmt) { os << stmt; };
     // Sensitivity experiment (profiles/experiments/sensitivity.py): HEYOKA_AMD_V5_PAD = "chain:dep:st:ld:salu" adds that many
     // dummy instructions of each kind to every order - independent FMAs in the chain section, dependent FMAs, LDS stores
     // and LDS reads in the dependent section, scalar no-ops - without touching the results: the slope of the step time
@@ -1742,7 +1822,6 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
         std::sscanf(ev, "%u:%u:%u:%u:%u", &pad_chain, &pad_dep, &pad_st, &pad_ld, &pad_salu);
     }
     const bool any_pad = (pad_chain | pad_dep | pad_st | pad_ld | pad_salu) != 0u;
-    bool early_done = false;
     // One accumulator for the half sum of squares bh_k = sum_i (sum_j d_i[k-j] d_i[j] + 1/2 d_i[k/2]^2): the three chains
     // of the coordinates run into each other - two additions per order and two multiply-adds per even order less, two
     // accumulators less. (The reference adds the three squares pairwise, src/detail/sum_sq.cpp:120-245: same terms, other
@@ -1750,22 +1829,6 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     const bool merged_sq = !v5_flag("nomsq");
     //   nosc      the selector's logarithm / exponential with literal polynomial constants (hy_sel_log(), exp()).
     const bool sel_scalar = one_lane && !v5_flag("nosc");
-    //   noilv     no interleaving of the early chain terms of order k + 1 with the dependent operations of round k
-    //             (HEYOKA_AMD_V5_ILV = "kmin:kmax:barriers" sets the range of rounds and the scheduling fences);
-    // (Measured: 7.35e8 without, 7.21e8 ... 7.30e8 with it over any range of rounds, profiles/r05_ab_interleaved_early_terms.log:
-    // OFF unless HEYOKA_AMD_V5_ILV asks for it.)
-    std::uint32_t ilv_kmin = 3, ilv_kmax = 0;
-    bool ilv_fences = true;
-    if (v5_flag("noilv")) {
-        ilv_kmax = 0;
-    } else if (const char *ev = std::getenv("HEYOKA_AMD_V5_ILV")) {
-        unsigned a_ = 0, b_ = 0, c_ = 1;
-        if (std::sscanf(ev, "%u:%u:%u", &a_, &b_, &c_) >= 2) {
-            ilv_kmin = a_;
-            ilv_kmax = b_;
-            ilv_fences = c_ != 0u;
-        }
-    }
     // Issue priority (s_setprio): raised between the LDS exchange and the end of the finishing operations of a round - the
     // dependent chain which decides how soon the next exchange can start - and lowered for the convolution chains, so
     // that the wavefront which is in its critical section wins the VALU over the one streaming FMAs.
@@ -1775,6 +1838,17 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     const bool prio_switch = prio_mode != 0;
     const auto emit_single_reads = [&](std::uint32_t k) {
         std::vector<std::string> r(6);
+        if (vexch) {
+            // The velocity coefficients of order k - 1 of the two bodies (row k - 1 of the jets; order 0: their current
+            // positions, behind the rows).
+            const auto row = k == 0u ? jet_rows_doubles : static_cast<std::uint64_t>(k - 1u) * spw * n_colp;
+            for (std::uint32_t i = 0; i < 3u; ++i) {
+                for (std::uint32_t sd = 0; sd < 2u; ++sd) {
+                    r[2u * i + sd] = e.def("jetq[" + utname(st1.s[i][sd]) + " + " + std::to_string(row) + "u]");
+                }
+            }
+            return r;
+        }
         if (wide_rd) {
             // (x, y) of the two bodies with one ds_read_b128 each, then the two z.
             for (std::uint32_t sd = 0; sd < 2u; ++sd) {
@@ -1797,6 +1871,10 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
         using emit_detail::ssa_emitter;
         for (std::uint32_t i = 0; i < 3u; ++i) {
             sD[i][k] = e.def(rdv[2u * i] + " - " + rdv[2u * i + 1u]);
+            if (vexch && k >= 2u) {
+                // (d^[k] = (v_a^[k-1] - v_b^[k-1]) RN(1 / k).)
+                sD[i][k] = e.def(ssa_emitter::mul(sD[i][k], fp_literal(1. / static_cast<double>(k))));
+            }
         }
         std::string pr[3];
         if (k == 0u) {
@@ -1844,12 +1922,12 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
             }
         }
         for (std::uint32_t i = 0; i < 3u; ++i) {
-            os << slabk(k, utname(st1.o[i])) << " = " << pr[i] << ";\n";
+            emit_store(slabk(k, utname(st1.o[i])) + " = " + pr[i] + ";\n");
         }
         for (std::uint32_t i = 0; pp.rx[0] >= 0 && i < 3u; ++i) {
             // (The reaction on the second body of the pair: c * (d_i * sa), src/model/nbody.cpp:113-130.)
             const auto rxv = e.def(ssa_emitter::mul("crs_r", pr[i]));
-            os << slabk(k, utname(st1.r[i])) << " = " << rxv << ";\n";
+            emit_store(slabk(k, utname(st1.r[i])) + " = " + rxv + ";\n");
         }
         if (any_pad && k >= 1u) {
             for (unsigned i = 0; i < pad_dep; ++i) {
@@ -1857,11 +1935,22 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
             }
             // (Written-out LDS stores of the first product to its own slot once more: same value, same address. The
             // compiler's lgkmcnt bookkeeping stays conservative: LDS operations complete in order.)
-            for (unsigned i = 0; i < pad_st; ++i) {
+            for (unsigned i = 0; i < pad_st % 100u; ++i) {
                 os << "asm volatile(\"ds_write_b64 %0, %1\" ::\"v\"((unsigned)(unsigned long long)&" << slabk(k, utname(st1.o[0]))
                    << "), \"v\"(" << pr[0] << ") : \"memory\");\n";
             }
-            (void)pad_ld;
+            // (pad_st >= 100: 16-byte stores - the first product and its neighbour in the array written back as a pair.)
+            for (unsigned i = 0; i < pad_st / 100u; ++i) {
+                os << "{\nhy_d2 hy_pv;\nhy_pv.x = " << pr[0] << ";\nhy_pv.y = " << pr[0] << ";\n"
+                   << "asm volatile(\"ds_write_b128 %0, %1\" ::\"v\"((unsigned)(unsigned long long)(slab + (" << dummy_base
+                   << "u & ~1u))), \"v\"(hy_pv) : \"memory\");\n}\n";
+            }
+            // (LDS reads of the velocity coefficients of the previous order once more, summed into a dummy: the reads of
+            // this round cannot be shared with them - the wave barrier between the rounds is a memory clobber.)
+            for (unsigned i = 0; vexch && k >= 2u && i < pad_ld && i < 6u; ++i) {
+                os << "hy_pad4 = hy_pad4 + jetq[" << utname(st1.s[i % 3u][i / 3u]) << " + "
+                   << static_cast<std::uint64_t>(k - 2u) * spw * n_colp << "u];\n";
+            }
             for (unsigned i = 0; i < pad_salu; ++i) {
                 os << "asm volatile(\"s_nop 0\");\n";
             }
@@ -1876,53 +1965,14 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
             }
         }
     };
-    // Early terms of the chains of order K = k + 1: the products with both indices <= k - 1, which need nothing of round k.
-    // They are INTERLEAVED with the dependent operations of the round (interleave_round() below): the finishing
-    // operations and the glue sums are chains of dependent FP64 operations, one result per ~8 cycles, and the wavefront
-    // which runs them holds the issue priority - the early terms fill its idle issue slots with work that had to be done
-    // anyway. (Round 3 tried the early terms as a BLOCK between the LDS reads and the finishing: +-0 %, the reads are
-    // hoisted above the chains of the previous order by the compiler anyway; the gain is in the dependent section.)
-    // T / U of the pow recurrence start with the newest coefficient and stay behind the finishing.
-    const auto emit_single_early = [&](std::uint32_t k) {
-        const auto K = k + 1u;
-        for (std::uint32_t i = 0; i < 3u; ++i) {
-            nq[i].clear();
-            nm[i].clear();
-            ncx[i].clear();
-        }
-        early_done = false;
-        if (!(K < order && K >= 4u && k >= ilv_kmin && k <= ilv_kmax)) {
-            return;
-        }
-        early_done = true;
-        const auto jmax = (K % 2u == 1u) ? (K - 1u) / 2u : (K - 2u) / 2u;
-        for (std::uint32_t j = 2; j + 2u <= K; ++j) {
-            for (std::uint32_t i = 0; i < 3u; ++i) {
-                ncx[i] = e.chain(ncx[i], sD[i][K - j], sA[j]);
-                if (j <= jmax) {
-                    auto &acc = nq[merged_sq ? 0u : i];
-                    acc = e.chain(acc, sD[i][K - j], sD[i][j]);
-                }
-            }
-        }
-        if (K % 2u == 0u) {
-            for (std::uint32_t i = 0; i < 3u; ++i) {
-                if (merged_sq) {
-                    nm[0] = e.chain(i == 0u ? std::string{} : nm[0], sD[i][K / 2u], sD[i][K / 2u]);
-                } else {
-                    nm[i] = e.def(ssa_emitter::mul(sD[i][K / 2u], sD[i][K / 2u]));
-                }
-            }
-        }
-    };
     const auto emit_single_history = [&](std::uint32_t k) {
         using emit_detail::ssa_emitter;
         // History parts of order K = k + 1 (terms without an order-K operand) and the T / U chains of the pow recurrence,
-        // whose first term is the newest one; on top of the early terms where those were accumulated during the round.
+        // whose first term is the newest one.
         for (std::uint32_t i = 0; i < 3u; ++i) {
-            hq[i] = early_done ? nq[i] : std::string{};
-            hm[i] = early_done ? nm[i] : std::string{};
-            hcx[i] = early_done ? ncx[i] : std::string{};
+            hq[i].clear();
+            hm[i].clear();
+            hcx[i].clear();
         }
         hT.clear();
         hU.clear();
@@ -1934,9 +1984,6 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
                 const auto jd = K - j;
                 hT = e.chain(hT, sB[K - jd], sA[jd]);
                 hU = hU.empty() ? hT : e.def(hU + " + " + hT);
-                if (early_done && j >= 2u && j + 2u <= K) {
-                    continue;
-                }
                 for (std::uint32_t i = 0; i < 3u; ++i) {
                     hcx[i] = e.chain(hcx[i], sD[i][K - j], sA[j]);
                     if (j <= jmax) {
@@ -1945,7 +1992,7 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
                     }
                 }
             }
-            if (K % 2u == 0u && !early_done) {
+            if (K % 2u == 0u) {
                 for (std::uint32_t i = 0; i < 3u; ++i) {
                     if (merged_sq) {
                         // (One running sum of the three middle squares.)
@@ -2072,61 +2119,17 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
             if (k < order) {
                 sched_fence();
             }
-            // (The statements of a part of the round as text: the stream is swapped for the duration of f.)
-            const auto capture = [&](const auto &f) {
-                const auto before = os.str();
-                os.str("");
-                os.clear();
-                f();
-                auto txt = os.str();
-                os.str(before);
-                os.seekp(0, std::ios_base::end);
-                return txt;
-            };
-            const auto critical = [&]() {
-                for (const auto &[g, r, names] : pend) {
-                    if (glue_first) {
-                        emit_glue_compute(g, r, k - 1u, names);
-                    }
+            for (const auto &[g, r, names] : pend) {
+                if (glue_first) {
+                    emit_glue_compute(g, r, k - 1u, names);
                 }
-                if (k < order) {
-                    emit_single_compute(k, prd);
-                }
-                for (const auto &[g, r, names] : pend) {
-                    if (!glue_first) {
-                        emit_glue_compute(g, r, k - 1u, names);
-                    }
-                }
-            };
-            std::string early_txt;
-            if (k < order) {
-                early_txt = capture([&]() { emit_single_early(k); });
             }
-            if (early_txt.empty()) {
-                critical();
-            } else {
-                // Interleave: the early terms spread evenly behind the statements of the dependent section.
-                const auto split = [](const std::string &t) {
-                    std::vector<std::string> v;
-                    std::size_t a_ = 0;
-                    while (a_ < t.size()) {
-                        const auto b_ = t.find('\n', a_);
-                        v.push_back(t.substr(a_, b_ - a_));
-                        a_ = b_ + 1u;
-                    }
-                    return v;
-                };
-                const auto la = split(capture(critical)), lb = split(early_txt);
-                std::size_t nb_done = 0;
-                for (std::size_t i = 0; i < la.size(); ++i) {
-                    os << la[i] << "\n";
-                    const auto upto = (i + 1u) * lb.size() / la.size();
-                    for (; nb_done < upto; ++nb_done) {
-                        os << lb[nb_done] << "\n";
-                    }
-                    if (ilv_fences && i % 2u == 1u) {
-                        os << "__builtin_amdgcn_sched_barrier(0);\n";
-                    }
+            if (k < order) {
+                emit_single_compute(k, prd);
+            }
+            for (const auto &[g, r, names] : pend) {
+                if (!glue_first) {
+                    emit_glue_compute(g, r, k - 1u, names);
                 }
             }
             if (k < order) {
@@ -2188,6 +2191,9 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
             }
             sync();
         }
+    }
+    if (one_lane && std::getenv("HEYOKA_AMD_V5_PAD") != nullptr) {
+        os << "asm volatile(\"\" ::\"v\"(hy_pad4));\n";
     }
     const auto body = os.str();
     os.str("");
@@ -2382,14 +2388,11 @@ __device__ __forceinline__ double hy_swap1(double x)
                             for (std::uint32_t l2 = 0; l2 < ow.n_valid; ++l2) {
                                 const std::uint64_t var = vv[l2];
                                 if (ow.derived) {
-                                    tc_src.push_back({var * (order + 1u), jet_rows_doubles + static_cast<std::uint64_t>(spw) * ow.cbase + l2,
-                                                      ow.n_valid});
+                                    tc_src.push_back({var * (order + 1u), jet_rows_doubles + jet_off(ow) + l2, jet_sys(ow)});
                                 } else {
                                     for (std::uint32_t k = 0; k <= order; ++k) {
                                         tc_src.push_back({var * (order + 1u) + k,
-                                                          static_cast<std::uint64_t>(k) * spw * n_colp
-                                                              + static_cast<std::uint64_t>(spw) * ow.cbase + l2,
-                                                          ow.n_valid});
+                                                          static_cast<std::uint64_t>(k) * spw * n_colp + jet_off(ow) + l2, jet_sys(ow)});
                                     }
                                 }
                             }
@@ -2449,10 +2452,15 @@ __device__ __forceinline__ double hy_swap1(double x)
     if (one_lane) {
         src << "__shared__ double lds_bk[" << wpb * spw * 16u << "];\ndouble *const bk = lds_bk + (wib * " << spw << "u + q) * 16u;\n";
     }
+    const bool vexch_decl = vexch;
     src << "const u64 gwave = (u64)blockIdx.x * " << wpb << "u + wib;\n";
     if (jet_lds) {
         src << "__shared__ double lds_jet[" << wpb * jet_doubles_per_wave << "];\n";
         src << "double *const jetw = lds_jet + wib * " << jet_doubles_per_wave << "u;\n";
+        if (vexch_decl) {
+            // (The rows of the system of this lane: [system][column].)
+            src << "const double *const jetq = jetw + q * " << n_col << "u;\n";
+        }
         if (m4) {
             // Source table of the cooperative store of the Taylor coefficients: row | jet column << 16.
             src << "__shared__ unsigned long long lds_tcsrc[" << std::max<std::size_t>(n_tc_rows, 1u) << "];\n";
@@ -2505,14 +2513,14 @@ __device__ __forceinline__ double hy_swap1(double x)
                     // (Current values of the derived variables: after the jet rows of the wavefront. One pointer for
                     // reading and writing: the idle lanes of a partially filled slot replicate the work of lane 0 bit by
                     // bit and store the same values to the same entry.)
-                    src << "double *const x0c" << ow.col << " = jetw + " << jet_rows_doubles + static_cast<std::uint64_t>(spw) * ow.cbase
-                        << "u + q * " << ow.n_valid << "u + (ovalid" << ow.col << " ? l : 0u);\n";
+                    src << "double *const x0c" << ow.col << " = jetw + " << jet_rows_doubles + jet_off(ow) << "u + q * " << jet_sys(ow)
+                        << "u + (ovalid" << ow.col << " ? l : 0u);\n";
                     src << "const double *const x0r" << ow.col << " = x0c" << ow.col << ";\n";
                     continue;
                 }
                 if (one_lane) {
-                    src << "double *const jc" << ow.col << " = jetw + " << static_cast<std::uint64_t>(spw) * ow.cbase << "u + q * "
-                        << ow.n_valid << "u + (ovalid" << ow.col << " ? l : 0u);\n";
+                    src << "double *const jc" << ow.col << " = jetw + " << jet_off(ow) << "u + q * " << jet_sys(ow) << "u + (ovalid"
+                        << ow.col << " ? l : 0u);\n";
                     src << "const double *const jr" << ow.col << " = jc" << ow.col << ";\n";
                     continue;
                 }
@@ -2557,17 +2565,17 @@ __device__ __forceinline__ double hy_swap1(double x)
                     const auto &vv = utbl[ow.var_tbl];
                     for (std::uint32_t l2 = 0; l2 < ow.n_valid; ++l2) {
                         auto &lc = loc[vv[l2]];
-                        lc.stride = ow.n_valid;
+                        lc.stride = jet_sys(ow);
                         if (ow.derived) {
                             lc.derived = true;
-                            lc.off = jet_rows_doubles + static_cast<std::uint64_t>(spw) * ow.cbase + l2;
+                            lc.off = jet_rows_doubles + jet_off(ow) + l2;
                             for (const auto &o2 : gr.owners) {
                                 if (o2.col == ow.parent) {
                                     lc.parent = utbl[o2.var_tbl][l2];
                                 }
                             }
                         } else {
-                            lc.off = static_cast<std::uint64_t>(spw) * ow.cbase + l2;
+                            lc.off = jet_off(ow) + l2;
                         }
                     }
                 }
@@ -2795,10 +2803,20 @@ const bool hy_tc_only = HY_M4 && ((a.pad & 2) != 0);
     // path. Every lane of a system holds the same values and stores them to the same address.
     const bool bk_lds = one_lane && std::getenv("HEYOKA_AMD_NO_BK_LDS") == nullptr;
     const char *bk_fields_d[] = {"t_hi", "t_lo", "tfin.hi", "tfin.lo", "rem.hi", "rem.lo", "mdt", "step_lim", "min_h", "max_h", "last_h"};
-    const auto bk_store = [&]() {
+    // (which = 0: every field; 1: the fields a step changes; 2: the others - final time and limits, which only change when a
+    // system is picked up: an LDS store is the most expensive instruction of the kernel.)
+    const auto bk_store = [&](int which = 0) {
         std::uint32_t f = 0;
         for (const auto *nm : bk_fields_d) {
-            src << "bk[" << f++ << "] = " << nm << ";\n";
+            const std::string n_ = nm;
+            const bool constant = n_ == "tfin.hi" || n_ == "tfin.lo" || n_ == "mdt" || n_ == "step_lim";
+            if (which == 0 || (which == 1) != constant) {
+                src << "bk[" << f << "] = " << nm << ";\n";
+            }
+            ++f;
+        }
+        if (which == 2) {
+            return;
         }
         src << "bk[" << f++ << "] = __longlong_as_double((long long)n_steps);\n";
         src << "bk[" << f++ << "] = __longlong_as_double((long long)iter);\n";
@@ -3101,15 +3119,14 @@ lim = fin ? 0.0 : lim;
                         // coefficient k is row k - 1 of the same column times RN(1 / k); both kinds run the same statements, the
                         // row shift sits in the lane's pointer and the factor (1 or RN(1 / k)) comes from a two-row table in LDS.
                         // Six instructions per order instead of the ten of the two-series pass which 2 of 16 lanes used.
-                        const auto nv = ow.n_valid;
                         const auto cs = std::to_string(ow.col);
                         const auto &tb = pk_tbl.at(ow.col);
                         // (The current value of the lane's variable: order-0 row of the column / entry of the derived variable.)
-                        src << "double *const pk_v" << cs << " = jetw + q * " << nv << "u + hy_utbl[" << tb[0] * L << "u + l];\n";
+                        src << "double *const pk_v" << cs << " = jetw + q * " << jet_sys(ow) << "u + hy_utbl[" << tb[0] * L << "u + l];\n";
                         src << "double " << xn << ";\n{\n";
                         // (Row k of the lane's series at pk_j[(k - 1) * stride]: the velocity column from row 1 on, from row 0
                         // on for the derived series.)
-                        src << "const double *const pk_j = jetw + q * " << nv << "u + hy_utbl[" << tb[1] * L << "u + l];\n";
+                        src << "const double *const pk_j = jetw + q * " << jet_sys(ow) << "u + hy_utbl[" << tb[1] * L << "u + l];\n";
                         src << "const double *const pk_f = lds_fac + hy_utbl[" << tb[2] * L << "u + l];\n";
                         src << "double res = pk_v" << cs << "[0], comp = 0.0, cur_h = h;\n";
                         for (std::uint32_t k = 1; k <= order; ++k) {
@@ -3374,11 +3391,14 @@ if (got) {
     fin = false;
 }
 HY_WSYNC();
-}
 )HIP";
+        if (bk_lds) {
+            bk_store(2);
+        }
+        src << "}\n";
     }
     if (bk_lds) {
-        bk_store();
+        bk_store(1);
     }
     src << R"HIP(
 if (__builtin_amdgcn_ballot_w64(!fin) == 0ull) break;

@@ -47,6 +47,8 @@ def step_loop_counts(code_object):
             cls = ("valu" if op.startswith("v_") else "lds" if op.startswith("ds_") else "salu" if op.startswith("s_") and not op.startswith("s_waitcnt") and not op.startswith("s_nop")
                    else "wait" if op.startswith("s_waitcnt") else "vmem" if op.startswith(("global_", "scratch_", "buffer_", "flat_")) else "other")
             cnt[cls] += 1
+            if cls == "lds":
+                cnt["lds_write" if "write" in op else "lds_read"] += 1
             if cls == "valu":
                 cnt["valu_fp64" if "_f64" in op else "valu_other"] += 1
     return dict(cnt)

@@ -13,8 +13,7 @@ from heyoka_amd import configs
 n = 1048576
 sys_ = hy.model.nbody(6, masses=configs.OUTER_SS_MASSES, Gconst=configs.OUTER_SS_G)
 st = configs.outer_ss_state(n, perturb=1e-12, seed=42)
-variants = [("base", "0:0:0:0:0"), ("chain+8", "8:0:0:0:0"), ("chain+16", "16:0:0:0:0"), ("dep+4", "0:4:0:0:0"), ("dep+8", "0:8:0:0:0"),
-            ("st+2", "0:0:2:0:0"), ("st+4", "0:0:4:0:0"), ("salu+8", "0:0:0:0:8"), ("salu+16", "0:0:0:0:16")]
+variants = [("base", "0:0:0:0:0"), ("st+2", "0:0:2:0:0"), ("st+4", "0:0:4:0:0"), ("st128+1", "0:0:100:0:0"), ("st128+2", "0:0:200:0:0"), ("st128+4", "0:0:400:0:0")]
 tas = []
 for name, pad in variants:
     os.environ["HEYOKA_AMD_V5_PAD"] = pad
