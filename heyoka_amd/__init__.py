@@ -339,7 +339,11 @@ def register_node_rule(name, n_args, hip_source, hidden=None, hidden_deps=(), de
         _node_rule_keepalive.append(cb)
     hd = (ctypes.c_int32 * (4 * max(n_hidden, 1)))(*([-1] * (4 * max(n_hidden, 1))))
     for j, lst in enumerate(hidden_deps):
+        if len(lst) > 4:
+            raise ValueError("register_node_rule(): a hidden definition can depend on at most 4 other hidden variables")
         for q, x in enumerate(lst):
+            if not 0 <= int(x) < n_hidden:
+                raise ValueError("register_node_rule(): an entry of hidden_deps is out of range")
             hd[4 * j + q] = int(x)
     dp = (ctypes.c_uint32 * max(len(deps), 1))(*[int(x) for x in deps]) if deps else None
     d = _node_rule_desc(name.encode(), int(n_args), n_hidden, ctypes.cast(cb, ctypes.c_void_p) if cb else None, None,
@@ -1368,6 +1372,25 @@ def ensemble_propagate_until_batch(ta, t, n_iter, gen, max_steps=0, n_devices=0)
 def ensemble_propagate_for_batch(ta, delta_t, n_iter, gen, max_steps=0, n_devices=0):
     """ensemble_propagate_for_batch() (include/heyoka/ensemble_propagate.hpp:239-254)."""
     return _ensemble(lib.hy_ensemble_propagate_for_batch, ta, delta_t, n_iter, gen, max_steps, n_devices)
+
+
+def ensemble_gather_results(tas, dst_device=0):
+    """Everything the propagated copies hold, gathered in one piece (hy_ensemble_gather_results()): a dict with "state"
+    (dim, n_total), "time_hi", "time_lo", "outcome" (int64), "n_steps" (uint64), "min_h", "max_h" (n_total each) and
+    "used_rccl"."""
+    tas = list(tas)
+    if not tas:
+        return {"state": np.zeros((0, 0)), "used_rccl": False}
+    n_total = int(np.sum([t.batch_size for t in tas]))
+    dim = tas[0].dim
+    out = np.empty((dim + 6, n_total))
+    arr = (ctypes.c_void_p * len(tas))(*[t._h for t in tas])
+    used = ctypes.c_int(0)
+    raise_for(lib.hy_ensemble_gather_results(arr, len(tas), int(dst_device), out.ctypes.data_as(ctypes.c_void_p), out.size, 0,
+                                             ctypes.byref(used)))
+    return {"state": out[:dim].copy(), "time_hi": out[dim].copy(), "time_lo": out[dim + 1].copy(),
+            "outcome": out[dim + 2].copy().view(np.int64), "n_steps": out[dim + 3].copy().view(np.uint64),
+            "min_h": out[dim + 4].copy(), "max_h": out[dim + 5].copy(), "used_rccl": bool(used.value)}
 
 
 def ensemble_gather_states(tas, dst_device=0):

@@ -263,6 +263,7 @@ SIGNATURES = [
         [c_void_p, c_double, c_size_t, c_void_p, c_void_p, c_uint64, c_int, c_void_p],
     ),
     ("hy_ensemble_gather_states", c_int, [c_void_p, c_size_t, c_int, c_void_p, c_size_t, c_int, c_void_p]),
+    ("hy_ensemble_gather_results", c_int, [c_void_p, c_size_t, c_int, c_void_p, c_size_t, c_int, c_void_p]),
 ]
 
 for _name, _res, _args in SIGNATURES:

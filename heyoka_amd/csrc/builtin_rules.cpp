@@ -168,6 +168,13 @@ static __device__ __forceinline__ double hy_rule_kepDE_orderk(unsigned n, const 
 }
 )HIP";
 
+// A product node as it stands: operator*() folds 0 * x and 1 * x into a number / the bare variable, and a hidden definition
+// must be ONE function of leaves (kepF(0.0, k, lam), kepF(1.0, k, lam) ... used to break the decomposition).
+expression unfolded_prod(const expression &a, const expression &b)
+{
+    return detail::make_func(func_kind::prod, {a, b});
+}
+
 bool both_zero(const std::vector<expression> &a)
 {
     return a[0].is_number() && a[1].is_number() && a[0].num() == 0. && a[1].num() == 0.;
@@ -182,7 +189,7 @@ bool register_builtin_rules()
         r.n_args = 3;
         r.decompose = [](const expression &self, const std::vector<expression> &args,
                          const std::function<expression(std::uint32_t)> &hidden) {
-            return std::vector<hidden_def>{{sin(self), {1u}}, {cos(self), {0u}}, {args[0] * hidden(0), {}}, {args[1] * hidden(1), {}}};
+            return std::vector<hidden_def>{{sin(self), {1u}}, {cos(self), {0u}}, {unfolded_prod(args[0], hidden(0)), {}}, {unfolded_prod(args[1], hidden(1)), {}}};
         };
         r.deps = {2u, 3u, 0u, 1u};
         r.hip_source = std::string(kep_common) + kepF_src;
@@ -202,7 +209,7 @@ bool register_builtin_rules()
         r.n_args = 3;
         r.decompose = [](const expression &self, const std::vector<expression> &args,
                          const std::function<expression(std::uint32_t)> &hidden) {
-            return std::vector<hidden_def>{{sin(self), {1u}}, {cos(self), {0u}}, {args[1] * hidden(1), {}}, {args[0] * hidden(0), {}}};
+            return std::vector<hidden_def>{{sin(self), {1u}}, {cos(self), {0u}}, {unfolded_prod(args[1], hidden(1)), {}}, {unfolded_prod(args[0], hidden(0)), {}}};
         };
         r.deps = {2u, 3u, 0u, 1u};
         r.hip_source = std::string(kep_common) + kepDE_src;
@@ -243,8 +250,21 @@ static __device__ __forceinline__ double hy_rule_pi_orderk(unsigned, const hy_je
 
 void ensure_builtin_rules()
 {
-    static const bool done = register_builtin_rules();
-    (void)done;
+    // (register_node_rule() calls this first, and the registration of the built-ins goes through register_node_rule():
+    // the nested call on the registering thread returns at once.)
+    thread_local bool busy = false;
+    if (busy) {
+        return;
+    }
+    busy = true;
+    try {
+        static const bool done = register_builtin_rules();
+        (void)done;
+    } catch (...) {
+        busy = false;
+        throw;
+    }
+    busy = false;
 }
 
 expression kepF(expression h, expression k, expression lam)

@@ -315,6 +315,12 @@ int hy_node_rule_register(const hy_node_rule_desc *d)
             std::vector<std::int32_t> hdeps(static_cast<std::size_t>(n_hidden) * 4u, -1);
             if (d->hidden_deps != nullptr) {
                 hdeps.assign(d->hidden_deps, d->hidden_deps + static_cast<std::size_t>(n_hidden) * 4u);
+                // (At most 4 dependencies per hidden definition, -1 = unused: checked here, not at the first decomposition.)
+                for (const auto x : hdeps) {
+                    if (x < -1 || x >= static_cast<std::int32_t>(n_hidden)) {
+                        throw std::invalid_argument("hy_node_rule_register(): an entry of hidden_deps is out of range");
+                    }
+                }
             }
             const auto rname = r.name;
             r.decompose = [n_hidden, cb, ctx, hdeps, rname](const expression &self, const std::vector<expression> &args,
@@ -1415,6 +1421,39 @@ int hy_ensemble_gather_states(const hy_tab *tabs, size_t n, int dst_device, doub
                 }
             } else {
                 const auto h = g.to_host();
+                std::memcpy(out, h.data(), h.size() * sizeof(double));
+            }
+        }
+        return HY_OK;
+    } catch (...) {
+        return handle_exception();
+    }
+}
+
+int hy_ensemble_gather_results(const hy_tab *tabs, size_t n, int dst_device, double *out, size_t out_words, int out_is_device,
+                               int *used_rccl)
+{
+    try {
+        std::vector<detail::tab_core *> cores;
+        for (size_t i = 0; i < n; ++i) {
+            cores.push_back(&tabs[i]->core);
+        }
+        const auto g = detail_gather(cores, dst_device);
+        const auto need = g.n_rows() * g.n_total();
+        if (out_words < need) {
+            throw std::invalid_argument("hy_ensemble_gather_results(): the output buffer holds " + std::to_string(out_words)
+                                        + " 8-byte words, " + std::to_string(need) + " are needed");
+        }
+        if (used_rccl != nullptr) {
+            *used_rccl = g.used_rccl() ? 1 : 0;
+        }
+        if (g.n_total() != 0u) {
+            if (out_is_device != 0) {
+                if (hipMemcpy(out, g.data(), need * sizeof(double), hipMemcpyDeviceToDevice) != hipSuccess) {
+                    throw std::runtime_error("heyoka_amd: copy of the gathered results failed");
+                }
+            } else {
+                const auto h = g.all_to_host();
                 std::memcpy(out, h.data(), h.size() * sizeof(double));
             }
         }

@@ -313,6 +313,17 @@ std::size_t append_function(const expression &f_ex, taylor_dc_t &dc)
                     }
                     deps.push_back(static_cast<std::uint32_t>(base + 1u + j));
                 }
+                // (A hidden definition is ONE elementary function of leaves: a rule which builds it with the folding operators
+                // can end up with a number or a bare variable - 0 * x, 1 * x.)
+                bool leaves_only = d.ex.is_func();
+                for (std::size_t q = 0; leaves_only && q < d.ex.fn().args().size(); ++q) {
+                    leaves_only = !d.ex.fn().args()[q].is_func();
+                }
+                if (!leaves_only) {
+                    throw std::invalid_argument("The decomposition of the node rule '" + rule.name
+                                                + "' returned a hidden definition which is not one function of variables, numbers and "
+                                                  "parameters (folded by an operator? build it with make_func())");
+                }
                 dc.emplace_back(d.ex, std::move(deps));
             }
             for (const auto j : rule.deps) {

@@ -111,6 +111,9 @@ std::vector<tab_core> ensemble_propagate_core(const tab_core &ta, double t, std:
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <string>
 
 namespace heyoka_amd
@@ -189,6 +192,51 @@ void place_block(double *dst, std::size_t n_total, std::size_t off, const double
 
 } // namespace
 
+namespace
+{
+
+// RCCL communicators are expensive to create (hundreds of ms on 8 GPUs): one set per list of devices, kept for the
+// lifetime of the process.
+struct comm_cache {
+    std::mutex mtx;
+    std::map<std::vector<int>, std::vector<rccl_api::comm_t>> comms;
+};
+comm_cache &comm_store()
+{
+    static comm_cache c;
+    return c;
+}
+std::vector<rccl_api::comm_t> comms_for(const std::vector<int> &devs)
+{
+    auto &c = comm_store();
+    std::lock_guard<std::mutex> lock(c.mtx);
+    auto it = c.comms.find(devs);
+    if (it == c.comms.end()) {
+        std::vector<rccl_api::comm_t> v(devs.size(), nullptr);
+        nccl_ok(rccl().CommInitAll(v.data(), static_cast<int>(devs.size()), devs.data()), "ncclCommInitAll");
+        it = c.comms.emplace(devs, std::move(v)).first;
+    }
+    return it->second;
+}
+
+// (The caller's current device is put back on every way out.)
+struct device_restore {
+    int dev = 0;
+    bool ok = false;
+    device_restore()
+    {
+        ok = hipGetDevice(&dev) == hipSuccess;
+    }
+    ~device_restore()
+    {
+        if (ok) {
+            (void)hipSetDevice(dev);
+        }
+    }
+};
+
+} // namespace
+
 ensemble_gathered detail_gather(const std::vector<detail::tab_core *> &tabs, int dst_device)
 {
     ensemble_gathered g;
@@ -196,16 +244,28 @@ ensemble_gathered detail_gather(const std::vector<detail::tab_core *> &tabs, int
     if (tabs.empty()) {
         return g;
     }
+    const device_restore restore;
     g.m_dim = tabs[0]->get_dim();
+    const auto n_rows = g.m_dim + detail::tab_core::n_result_rows;
     for (auto *t : tabs) {
         if (t->get_dim() != g.m_dim) {
             throw std::invalid_argument("Cannot gather the states of integrators of different dimensions");
         }
-        t->synchronize();
         g.m_off.push_back(g.m_total);
         g.m_total += t->get_batch_size();
     }
-    g.m_buf = device_buffer(g.m_dim * g.m_total * sizeof(double), dst_device);
+    // 1. Every integrator packs its state, times and propagation records into one block on ITS device (copies on its own
+    // stream, uploads of host-side records included); only then are the integrators synchronised - the transfers below
+    // run on other streams and must not start before the blocks are complete.
+    std::vector<device_buffer> packs;
+    for (auto *t : tabs) {
+        packs.emplace_back(n_rows * t->get_batch_size() * sizeof(double), t->get_device());
+        t->pack_results(packs.back().as<double>());
+    }
+    for (auto *t : tabs) {
+        t->synchronize();
+    }
+    g.m_buf = device_buffer(n_rows * g.m_total * sizeof(double), dst_device);
     auto *const out = g.m_buf.as<double>();
 
     // Which devices take part (the destination is rank 0).
@@ -220,9 +280,7 @@ ensemble_gathered detail_gather(const std::vector<detail::tab_core *> &tabs, int
     bool done = false;
     if (want_rccl && rccl().ok) {
         const auto &a = rccl();
-        const auto nd = static_cast<int>(devs.size());
-        std::vector<rccl_api::comm_t> comms(devs.size(), nullptr);
-        nccl_ok(a.CommInitAll(comms.data(), nd, devs.data()), "ncclCommInitAll");
+        const auto comms = comms_for(devs);
         std::vector<hipStream_t> streams(devs.size(), nullptr);
         std::vector<device_buffer> staging; // contiguous landing blocks on the destination, one per integrator
         const auto cleanup = [&]() {
@@ -230,9 +288,6 @@ ensemble_gathered detail_gather(const std::vector<detail::tab_core *> &tabs, int
                 (void)hipSetDevice(devs[d]);
                 if (streams[d] != nullptr) {
                     (void)hipStreamDestroy(streams[d]);
-                }
-                if (comms[d] != nullptr) {
-                    (void)a.CommDestroy(comms[d]);
                 }
             }
         };
@@ -245,21 +300,21 @@ ensemble_gathered detail_gather(const std::vector<detail::tab_core *> &tabs, int
                 return static_cast<std::size_t>(std::find(devs.begin(), devs.end(), dev) - devs.begin());
             };
             for (auto *t : tabs) {
-                staging.emplace_back(g.m_dim * t->get_batch_size() * sizeof(double), dst_device);
+                staging.emplace_back(n_rows * t->get_batch_size() * sizeof(double), dst_device);
             }
             constexpr int nccl_f64 = 8; // ncclFloat64 (ncclDataType_t, nccl.h)
             nccl_ok(a.GroupStart(), "ncclGroupStart");
             for (std::size_t i = 0; i < tabs.size(); ++i) {
-                const auto cnt = g.m_dim * tabs[i]->get_batch_size();
+                const auto cnt = n_rows * tabs[i]->get_batch_size();
                 const auto r = rank_of(tabs[i]->get_device());
-                nccl_ok(a.Send(tabs[i]->device_state(), cnt, nccl_f64, 0, comms[r], streams[r]), "ncclSend");
+                nccl_ok(a.Send(packs[i].get(), cnt, nccl_f64, 0, comms[r], streams[r]), "ncclSend");
                 nccl_ok(a.Recv(staging[i].get(), cnt, nccl_f64, static_cast<int>(r), comms[0], streams[0]), "ncclRecv");
             }
             nccl_ok(a.GroupEnd(), "ncclGroupEnd");
+            // (The placements follow the receives on the destination's stream.)
             hip_ok(hipSetDevice(dst_device), "hipSetDevice");
             for (std::size_t i = 0; i < tabs.size(); ++i) {
-                place_block(out, g.m_total, g.m_off[i], staging[i].as<double>(), tabs[i]->get_batch_size(), g.m_dim,
-                            streams[0]);
+                place_block(out, g.m_total, g.m_off[i], staging[i].as<double>(), tabs[i]->get_batch_size(), n_rows, streams[0]);
             }
             for (std::size_t d = 0; d < devs.size(); ++d) {
                 hip_ok(hipSetDevice(devs[d]), "hipSetDevice");
@@ -274,15 +329,72 @@ ensemble_gathered detail_gather(const std::vector<detail::tab_core *> &tabs, int
         cleanup();
     }
     if (!done) {
-        // Device-to-device copies (unified addressing: the runtime routes peer copies over xGMI).
+        // Device-to-device copies (unified addressing: the runtime routes peer copies over xGMI), all of them on ONE stream
+        // of the destination device, which is then synchronised.
         hip_ok(hipSetDevice(dst_device), "hipSetDevice");
-        for (std::size_t i = 0; i < tabs.size(); ++i) {
-            place_block(out, g.m_total, g.m_off[i], static_cast<const double *>(tabs[i]->device_state()),
-                        tabs[i]->get_batch_size(), g.m_dim, nullptr);
+        hipStream_t st = nullptr;
+        hip_ok(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
+        try {
+            for (std::size_t i = 0; i < tabs.size(); ++i) {
+                hip_ok(hipSetDevice(dst_device), "hipSetDevice");
+                place_block(out, g.m_total, g.m_off[i], packs[i].as<double>(), tabs[i]->get_batch_size(), n_rows, st);
+            }
+            hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize");
+        } catch (...) {
+            (void)hipStreamDestroy(st);
+            throw;
         }
-        hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        (void)hipStreamDestroy(st);
     }
     return g;
+}
+
+std::vector<double> ensemble_gathered::all_to_host() const
+{
+    std::vector<double> ret(n_rows() * m_total);
+    if (!ret.empty()) {
+        m_buf.download(ret.data(), ret.size() * sizeof(double), nullptr);
+    }
+    return ret;
+}
+
+namespace
+{
+
+std::vector<double> row_to_host(const device_buffer &buf, std::size_t first_row, std::size_t n_rows_, std::size_t n_total)
+{
+    std::vector<double> ret(n_rows_ * n_total);
+    if (!ret.empty()) {
+        hip_ok(hipMemcpy(ret.data(), buf.as<double>() + first_row * n_total, ret.size() * sizeof(double), hipMemcpyDeviceToHost),
+               "hipMemcpy (gathered records)");
+    }
+    return ret;
+}
+
+} // namespace
+
+std::vector<double> ensemble_gathered::times_hi() const
+{
+    return row_to_host(m_buf, m_dim + time_hi, 1, m_total);
+}
+
+std::vector<double> ensemble_gathered::times_lo() const
+{
+    return row_to_host(m_buf, m_dim + time_lo, 1, m_total);
+}
+
+std::vector<std::tuple<taylor_outcome, double, double, std::size_t>> ensemble_gathered::propagate_res() const
+{
+    const auto raw = row_to_host(m_buf, m_dim + outcome, 4, m_total);
+    std::vector<std::tuple<taylor_outcome, double, double, std::size_t>> ret(m_total);
+    for (std::size_t i = 0; i < m_total; ++i) {
+        long long oc = 0;
+        unsigned long long ns = 0;
+        std::memcpy(&oc, &raw[i], sizeof(oc));
+        std::memcpy(&ns, &raw[m_total + i], sizeof(ns));
+        ret[i] = std::tuple{static_cast<taylor_outcome>(oc), raw[2u * m_total + i], raw[3u * m_total + i], static_cast<std::size_t>(ns)};
+    }
+    return ret;
 }
 
 std::vector<double> ensemble_gathered::to_host() const

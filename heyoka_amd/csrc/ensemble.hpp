@@ -50,10 +50,29 @@ class ensemble_gathered
 {
 public:
     ensemble_gathered() = default;
+    // The gathered buffer: (dim + 6) rows of n_total 8-byte words, [row * n_total + offset_i + lane]. Rows [0, dim): the
+    // states (data() alone is the states-only view of earlier rounds); then time_hi, time_lo, outcome (int64), number
+    // of steps (uint64), min |h|, max |h| of the last propagation - what the reference's returned integrators hold
+    // (src/ensemble_propagate.cpp:193-297: m_state, m_time_hi / m_time_lo, m_prop_res).
+    enum row : std::size_t { time_hi = 0, time_lo = 1, outcome = 2, n_steps = 3, min_h = 4, max_h = 5, n_result_rows = 6 };
     [[nodiscard]] const double *data() const
     {
         return m_buf.as<double>();
     }
+    [[nodiscard]] std::size_t n_rows() const
+    {
+        return m_dim + n_result_rows;
+    }
+    // (Device pointer to one of the record rows.)
+    [[nodiscard]] const double *result_row(row r) const
+    {
+        return m_buf.as<double>() + (m_dim + static_cast<std::size_t>(r)) * m_total;
+    }
+    // Host copies: everything ((dim + 6) * n_total words), or the records alone as typed vectors.
+    [[nodiscard]] std::vector<double> all_to_host() const;
+    [[nodiscard]] std::vector<double> times_hi() const;
+    [[nodiscard]] std::vector<double> times_lo() const;
+    [[nodiscard]] std::vector<std::tuple<taylor_outcome, double, double, std::size_t>> propagate_res() const;
     [[nodiscard]] int device() const
     {
         return m_device;

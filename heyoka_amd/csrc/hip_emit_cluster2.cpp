@@ -542,8 +542,8 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
         // sums which read them: slot = array of (coordinate i, body) + operand index, with the arrays laid out
         // [coordinate][body] so that the three stores of a lane differ by a constant (one table register for the three).
         // The unused sixth slot of the arrays of the first two bodies takes the stores of the idle lanes. The order of the
-        // bodies inside a coordinate block, the distance between the blocks and between the slabs of two systems come out
-        // of an exhaustive search with the bank model of the guide (reads in the lane groups of each instruction width).
+        // distance between the slabs of two systems comes out of a scan with the bank model of the guide (reads in the lane
+        // groups of each instruction width).
         wide_rd = !v5_flag("nowide") && pp.rx[0] >= 0 && pl.groups.size() == 1u;
         std::vector<std::array<std::uint32_t, 3>> bodies; // position variables (x, y, z) of every body
         std::vector<std::uint32_t> node_coord, node_rank;   // per node of the glue group
@@ -889,7 +889,11 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
                 }
                 // (+ 2: the dummy area behind the arrays - idle lanes of a partially filled glue round publish there.)
                 const auto total_for = [&](std::uint32_t D_) { return pos_sz + 2u * D_ + W * n_rank + 2u; };
-                const bool full = n_rank <= 6u && !v5_flag("nobanksearch");
+                // (An exhaustive search over the order of the bodies inside a block and a few block distances - 720 x 5 x 16 layouts,
+                // 6.5 s per integrator - found nothing the slab stride alone does not give: every layout keeps one two-way
+                // conflict per store, and the kernel time does not move, profiles/r05_ab_velocity_exchange.log, "nobanksearch".
+                // The LDS time of this kernel follows the BYTES it moves. Only the stride is scanned.)
+                const bool full = false;
                 do {
                     perm = pm;
                     for (std::uint32_t D_ = W * n_rank; D_ <= W * n_rank + (full ? 8u : 0u); D_ += 2u) {
@@ -1807,7 +1811,6 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
         v.resize(order + 1u);
     }
     std::string hq[3], hm[3], hcx[3], hT, hU, pow_pre;
-    std::string nq[3], nm[3], ncx[3]; // (early terms of the next order, see emit_single_early())
     // (Tried in round 5 and removed: the stores of a round spread over the convolution chains which follow it instead of a
     // burst at the end of the dependent section - the eight wavefronts of a CU queue on one LDS store path -: -1.6 %,
     // profiles/r05_ab_spread_stores.log; the early chain terms of order k + 1 interleaved with the dependent operations of

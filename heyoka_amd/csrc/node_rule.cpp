@@ -42,6 +42,9 @@ bool valid_identifier(const std::string &s)
 
 std::uint32_t register_node_rule(node_rule r)
 {
+    // The built-in rules (kepF, kepDE, pi) go in first, whoever registers first: a user rule of one of those names must be
+    // refused HERE - registered ahead of them it would make the built-in registration throw on every later use.
+    ensure_builtin_rules();
     if (!valid_identifier(r.name)) {
         throw std::invalid_argument("Invalid name for a node rule: '" + r.name + "' is not an identifier");
     }

@@ -2500,6 +2500,44 @@ void *tab_core::device_aux(int which)
     }
 }
 
+void tab_core::pack_results(double *dst)
+{
+    auto &d = *m_impl;
+    d.to_device();
+    const auto n = static_cast<std::size_t>(d.N), w = sizeof(double);
+    // The results of the last propagation: on the device after a device-resident propagation (a step-limited batch first
+    // gets the reference's batch-wide outcome, see fetch_prop_res()), otherwise uploaded from the host records.
+    if (d.prop_res_dev_newer && d.fix_step_limit) {
+        d.fetch_prop_res();
+    }
+    if (!d.prop_res_dev_newer) {
+        std::vector<long long> oc(n);
+        std::vector<double> mn(n), mx(n);
+        std::vector<unsigned long long> ns(n);
+        for (std::size_t i = 0; i < n; ++i) {
+            const auto &[o, a, b, c] = d.prop_res[i];
+            oc[i] = static_cast<long long>(o);
+            mn[i] = a;
+            mx[i] = b;
+            ns[i] = static_cast<unsigned long long>(c);
+        }
+        d.d_outcome.upload(oc.data(), n * w, d.stream);
+        d.d_minh.upload(mn.data(), n * w, d.stream);
+        d.d_maxh.upload(mx.data(), n * w, d.stream);
+        d.d_nsteps.upload(ns.data(), n * w, d.stream);
+    }
+    const auto cp = [&](std::size_t row, const void *src, std::size_t rows) {
+        device_copy(dst + row * n, src, rows * n * w, d.device, d.stream);
+    };
+    cp(0, d.d_state.get(), d.dim);
+    cp(d.dim, d.d_thi.get(), 1);
+    cp(d.dim + 1u, d.d_tlo.get(), 1);
+    cp(d.dim + 2u, d.d_outcome.get(), 1);
+    cp(d.dim + 3u, d.d_nsteps.get(), 1);
+    cp(d.dim + 4u, d.d_minh.get(), 1);
+    cp(d.dim + 5u, d.d_maxh.get(), 1);
+}
+
 void tab_core::mark_device_modified()
 {
     m_impl->to_device();

@@ -230,6 +230,12 @@ public:
     double *device_tc();
     // 0: n_steps (uint64), 1: outcome (int64), 2: last_h (double).
     void *device_aux(int which);
+    // Everything a propagation leaves behind, packed into ONE device buffer of (dim + 6) rows of batch_size 8-byte words
+    // (on this integrator's device, copies enqueued on its stream): the state rows, then time_hi, time_lo, outcome (int64),
+    // number of steps (uint64), min |h|, max |h| - what the ensemble gather moves between devices in one piece
+    // (reference: ensemble_propagate_*() returns whole integrators, src/ensemble_propagate.cpp:193-297).
+    static constexpr std::size_t n_result_rows = 6;
+    void pack_results(double *d_dst);
     // Mark the device copies as modified by the caller (e.g. initial conditions written by a kernel).
     void mark_device_modified();
     void set_stream(void *hip_stream);

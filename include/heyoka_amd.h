@@ -486,6 +486,14 @@ int hy_ensemble_propagate_for_batch(hy_tab ta, double delta_t, size_t n_iter, hy
  * the 8-GPU ensemble in one place. */
 int hy_ensemble_gather_states(const hy_tab *tabs, size_t n, int dst_device, double *out, size_t out_doubles,
                               int out_is_device, int *used_rccl);
+/* The same gather with everything the reference's returned integrators hold (src/ensemble_propagate.cpp:193-297: m_state,
+ * m_time_hi / m_time_lo, m_prop_res): out receives (dim + 6) rows of n_total 8-byte words, out[row * n_total + offset_i +
+ * lane] - the dim state rows, then time_hi, time_lo (doubles), the outcome of the last propagation (int64_t), its number
+ * of steps (uint64_t), min |h| and max |h| (doubles). Each integrator sends ONE packed block; the RCCL communicators are
+ * created once per list of devices and kept. */
+#define HY_GATHER_RESULT_ROWS 6
+int hy_ensemble_gather_results(const hy_tab *tabs, size_t n, int dst_device, double *out, size_t out_words, int out_is_device,
+                               int *used_rccl);
 
 #ifdef __cplusplus
 }

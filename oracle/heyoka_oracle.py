@@ -776,12 +776,14 @@ def taylor_decompose_sys(sys, sv_funcs=None):
             ua = var(_uname(ret))
             dc.append((sin(ua), [ret + 2]))
             dc.append((cos(ua), [ret + 1]))
+            # (Product nodes as they stand: the folding operator* of the reference, src/math/kepF.cpp:131-134, turns
+            # 0 * x / 1 * x into a number / the bare variable - not a valid entry of a decomposition.)
             if e.kind == "kepF":
-                dc.append((new_args[0] * var(_uname(ret + 1)), []))
-                dc.append((new_args[1] * var(_uname(ret + 2)), []))
+                dc.append((func("prod", [new_args[0], var(_uname(ret + 1))]), []))
+                dc.append((func("prod", [new_args[1], var(_uname(ret + 2))]), []))
             else:
-                dc.append((new_args[1] * var(_uname(ret + 2)), []))
-                dc.append((new_args[0] * var(_uname(ret + 1)), []))
+                dc.append((func("prod", [new_args[1], var(_uname(ret + 2))]), []))
+                dc.append((func("prod", [new_args[0], var(_uname(ret + 1))]), []))
             dc[ret][1].extend([ret + 3, ret + 4, ret + 1, ret + 2])
         elif e.kind == "erf":
             dc.append((pow_(new_args[0], num(2.0)), []))

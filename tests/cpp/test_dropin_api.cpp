@@ -425,6 +425,18 @@ int main(int argc, char **argv)
             }
             REQUIRE(st_i == std::get<0>(ret[i]).get_state());
         }
+        // The records which travel with the states: times (hi, lo), outcomes, step counts, min / max |h|.
+        const auto thi = g.times_hi(), tlo = g.times_lo();
+        const auto pres = g.propagate_res();
+        REQUIRE(thi.size() == g.n_total());
+        for (auto i = 0u; i < 5u; ++i) {
+            const auto &ta_i = std::get<0>(ret_g[i]);
+            for (auto l = 0u; l < tp.get_batch_size(); ++l) {
+                REQUIRE(thi[g.offset(i) + l] == ta_i.get_dtime().first[l]);
+                REQUIRE(tlo[g.offset(i) + l] == ta_i.get_dtime().second[l]);
+                REQUIRE(pres[g.offset(i) + l] == ta_i.get_propagate_res()[l]);
+            }
+        }
     }
 
     // Every kwarg of the reference is forwarded; the continuous output slot is filled on request.

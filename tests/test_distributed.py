@@ -257,3 +257,14 @@ def test_native_gather_behind_the_c_abi_with_and_without_rccl(monkeypatch):
         got, used = hy.ensemble_gather_states(res)
         assert used is want, (force, used)
         assert got.shape == (36, n * n_iter) and np.array_equal(got, expect)
+        # Everything SURVEY 8(e) names in one packed block per integrator: states, double-length times, the records of the
+        # propagation (src/ensemble_propagate.cpp:193-297 returns whole integrators).
+        full = hy.ensemble_gather_results(res)
+        assert full["used_rccl"] is want and np.array_equal(full["state"], expect)
+        assert np.array_equal(full["time_hi"], np.concatenate([np.asarray(r.dtime[0]) for r in res]))
+        assert np.array_equal(full["time_lo"], np.concatenate([np.asarray(r.dtime[1]) for r in res]))
+        pr = [p_ for r in res for p_ in r.propagate_res]
+        assert np.array_equal(full["outcome"], np.array([int(p_[0]) for p_ in pr], dtype=np.int64))
+        assert np.array_equal(full["min_h"], np.array([p_[1] for p_ in pr])) and np.array_equal(full["max_h"], np.array([p_[2] for p_ in pr]))
+        assert np.array_equal(full["n_steps"].astype(np.int64), np.array([int(p_[3]) for p_ in pr]))
+        assert np.all(full["time_hi"] == 4.0) and np.all(full["n_steps"] > 0)

@@ -112,6 +112,47 @@ def test_registry_error_behaviour_and_a_rule_registered_from_python():
     assert "hy_rule_cbrt3_orderk" in ta.hip_source
 
 
+def test_numeric_zero_and_one_arguments_of_the_kepler_rules_and_folded_hidden_definitions():
+    """Advisor findings (round 4). (1) The hidden definitions h sin F, k cos F (s0 sin DE, c0 cos DE) were built with the
+    folding operator*: with h or k the NUMBER 0 or 1 the product folded into a number / a bare u variable and
+    taylor_decompose failed ('std::get: wrong index for variant'). They are product nodes as they stand now: the
+    decomposition has the reference's five entries per function and equals the oracle's. (2) A user rule whose callback
+    returns a folded definition gets a clear error. (3) hidden_deps with more than four entries / out of range is refused at
+    registration."""
+    import heyoka_amd as hy
+
+    x, v = hy.make_vars("x", "v")
+    ox, ov = ho.var("x"), ho.var("v")
+    for fn, ofn, args, oargs in (
+        (hy.kepF, ho.kepF, (0.0, v, x), (0.0, ov, ox)), (hy.kepF, ho.kepF, (1.0, v, x), (1.0, ov, ox)),
+        (hy.kepF, ho.kepF, (v, 0.0, x), (ov, 0.0, ox)), (hy.kepF, ho.kepF, (v, 1.0, x), (ov, 1.0, ox)),
+        (hy.kepDE, ho.kepDE, (x, 0.0, v), (ox, 0.0, ov)), (hy.kepDE, ho.kepDE, (1.0, x, v), (1.0, ox, ov)),
+    ):
+        ta = hy.taylor_adaptive_batch([(x, fn(*args)), (v, -x)], None, 2)
+        ora = ho.OracleIntegrator([(ox, ofn(*oargs)), (ov, -1.0 * ox)], np.zeros(4), 2)
+        dc = ta.decomposition
+        assert len(dc) == len(ora.dc), (args, dc)
+        kinds = [a.split("(")[0] for a in dc if "(" in a]
+        assert kinds.count("prod") >= 2 and kinds.count("sin") == 1 and kinds.count("cos") == 1, dc
+    src = r"""
+static __device__ double hy_rule_foldme_order0(const double *x) { return x[0]; }
+static __device__ __forceinline__ double hy_rule_foldme_orderk(unsigned k, const hy_jet &a, const hy_jet *x, const hy_jet *h)
+{
+    return hy_jc(x[0], k);
+}
+"""
+    hy.register_node_rule("foldme", 1, src, hidden=lambda self, args, hid: [1.0 * self], hidden_deps=[[]], deps=[0])
+    with pytest.raises(Exception) as ei:
+        hy.taylor_adaptive_batch([(x, hy.custom_func("foldme", v)), (v, -x)], None, 2)
+    assert "not one function" in str(ei.value)
+    with pytest.raises(ValueError):
+        hy.register_node_rule("toomany", 1, src.replace("foldme", "toomany"), hidden=lambda s_, a_, h_: [hy.sin(s_)],
+                              hidden_deps=[[0, 0, 0, 0, 0]], deps=[0])
+    with pytest.raises(ValueError):
+        hy.register_node_rule("outofrange", 1, src.replace("foldme", "outofrange"), hidden=lambda s_, a_, h_: [hy.sin(s_)],
+                              hidden_deps=[[3]], deps=[0])
+
+
 _CBRT_DONE = []
 
 
