@@ -210,7 +210,12 @@ char *hy_version(void)
 {
     int major = 0, minor = 0;
     hiprtcVersion(&major, &minor);
-    return dup_str("heyoka_amd 0.1.0; target gfx950; hiprtc " + std::to_string(major) + "." + std::to_string(minor));
+    // (The HIP runtime's own version as well: the kernels are compiled by whatever hiprtc the box carries - ROCm 7.2 in the
+    // authoring container, 7.0.x on the driver's GPU boxes - and the bench line records it.)
+    int rt = 0;
+    (void)hipRuntimeGetVersion(&rt);
+    return dup_str("heyoka_amd 0.1.0; target gfx950; hiprtc " + std::to_string(major) + "." + std::to_string(minor)
+                   + "; hip runtime " + std::to_string(rt));
 }
 
 int hy_device_count(void)

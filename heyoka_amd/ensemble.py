@@ -50,7 +50,9 @@ def all_gather_states(local, group=None):
 def ensemble_propagate_until_sharded(make_integrator, global_state, t_final, group=None, max_steps=0, device=None):
     """Propagate global_state (n_eq, n_total; host array, identical on all ranks) to t_final:
     rank r integrates lanes shard_bounds(n_total, r, world) and all ranks receive the gathered final
-    state (float64, (n_eq, n_total)) and a (2, n_total) int64 tensor of outcomes and step counts.
+    state (float64, (n_eq, n_total)), a (2, n_total) int64 tensor of outcomes and step counts and a (4, n_total) float64
+    tensor of the double-length times and of the smallest / largest step sizes (time_hi, time_lo, min |h|, max |h|) -
+    everything the reference's returned integrators hold (src/ensemble_propagate.cpp:193-297).
     make_integrator(n_local) -> taylor_adaptive_batch.
 
     device: the torch device of the collective. With a CUDA device (backend "nccl" = RCCL over xGMI) the final state,
@@ -72,11 +74,16 @@ def ensemble_propagate_until_sharded(make_integrator, global_state, t_final, gro
     # outcomes, see tab_core::config::batch_semantics.)
     oc, mn, mx, ns = ta.propagate_res_arrays()
     dev = torch.device(device) if device is not None else torch.device("cpu")
+    thi, tlo = ta.dtime if hasattr(ta, "dtime") else (np.asarray(ta.time), np.zeros(hi - lo))
+    rec_h = np.stack([np.asarray(thi, dtype=np.float64), np.asarray(tlo, dtype=np.float64), np.asarray(mn, dtype=np.float64),
+                      np.asarray(mx, dtype=np.float64)])
     if dev.type == "cuda" and hasattr(ta, "device_array"):
         st = torch.as_tensor(ta.device_array("state"), device=dev)
         meta = torch.stack([torch.as_tensor(ta.device_array("outcome"), device=dev),
                             torch.as_tensor(ta.device_array("n_steps"), device=dev)])
+        rec = torch.as_tensor(rec_h).to(dev)
     else:
         st = torch.as_tensor(np.asarray(ta.state)).to(dev)
         meta = torch.as_tensor(np.stack([np.asarray(oc, dtype=np.int64), np.asarray(ns).astype(np.int64)])).to(dev)
-    return ta, all_gather_states(st, group), all_gather_states(meta, group)
+        rec = torch.as_tensor(rec_h).to(dev)
+    return ta, all_gather_states(st, group), all_gather_states(meta, group), all_gather_states(rec, group)

@@ -33,11 +33,13 @@ class _FakeIntegrator:
 
     def propagate_until(self, t, max_steps=0):
         self.state = self.state * 2.0 + t
+        # (Double-length time and step-size records which depend on the lane, so that the gather is checked per system.)
+        self.dtime = (np.full(self.n, float(t)), self.state[0] * 1e-20)
 
     def propagate_res_arrays(self):
         oc = np.full(self.n, -4294967299, dtype=np.int64)
         ns = (np.arange(self.n) % 5 + 10).astype(np.uint64)
-        return oc, np.zeros(self.n), np.zeros(self.n), ns
+        return oc, self.state[1] * 1e-3, self.state[2] * 1e-2, ns
 
 
 def _free_port():
@@ -54,10 +56,15 @@ def _worker(rank, world, port, n_total, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         g = np.arange(3 * n_total, dtype=np.float64).reshape(3, n_total)
-        ta, st, meta = hens.ensemble_propagate_until_sharded(lambda n: _FakeIntegrator(n), g, 7.0)
+        ta, st, meta, rec = hens.ensemble_propagate_until_sharded(lambda n: _FakeIntegrator(n), g, 7.0)
         lo, hi = hens.shard_bounds(n_total, rank, world)
-        ok = bool(np.array_equal(st.numpy(), g * 2.0 + 7.0)) and ta.n == hi - lo
+        fin = g * 2.0 + 7.0
+        ok = bool(np.array_equal(st.numpy(), fin)) and ta.n == hi - lo
         ok = ok and meta.shape == (2, n_total) and bool(np.all(meta[0].numpy() == -4294967299))
+        # The records of SURVEY 8(e): times (hi, lo), min / max |h| of every system, in the order of the systems.
+        ok = ok and rec.shape == (4, n_total) and bool(np.all(rec[0].numpy() == 7.0))
+        ok = ok and bool(np.array_equal(rec[1].numpy(), fin[0] * 1e-20)) and bool(np.array_equal(rec[2].numpy(), fin[1] * 1e-3))
+        ok = ok and bool(np.array_equal(rec[3].numpy(), fin[2] * 1e-2))
         # Equal-size fast path (all_gather_into_tensor) and ragged path.
         loc = torch.full((2, 4 if n_total % world == 0 else 3 + rank), float(rank))
         gathered = hens.all_gather_states(loc)
@@ -95,9 +102,10 @@ def _gpu_worker(rank, world, port, n_total, t_final, q):
         M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
         g = configs.outer_ss_state(n_total, perturb=1e-8, seed=17)
         mk = lambda n: hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), None, n, high_accuracy=True, device=0)
-        ta, st, meta = hens.ensemble_propagate_until_sharded(mk, g, t_final)
+        ta, st, meta, rec = hens.ensemble_propagate_until_sharded(mk, g, t_final)
         lo, hi = hens.shard_bounds(n_total, rank, world)
         assert ta.batch_size == hi - lo and st.shape == (36, n_total) and meta.shape == (2, n_total)
+        assert rec.shape == (4, n_total) and bool((rec[0] == t_final).all()) and bool((rec[2] > 0).all()) and bool((rec[3] >= rec[2]).all())
         q.put((rank, st.numpy().copy(), meta.numpy().copy()))
     finally:
         dist.destroy_process_group()
@@ -143,7 +151,7 @@ def test_sharded_ensemble_real_integrators_two_ranks_one_gpu(n_total):
     import torch
 
     mk = lambda n: hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), None, n, high_accuracy=True, device=0)
-    _, st_d, meta_d = hens.ensemble_propagate_until_sharded(mk, g, t_final, device="cuda:0")
+    _, st_d, meta_d, rec_d = hens.ensemble_propagate_until_sharded(mk, g, t_final, device="cuda:0")
     assert st_d.is_cuda and meta_d.is_cuda and meta_d.dtype == torch.int64
     assert np.array_equal(st_d.cpu().numpy(), res[0][1]) and np.array_equal(meta_d.cpu().numpy(), res[0][2])
 
@@ -210,7 +218,7 @@ assert dist.get_backend() == "nccl"
 M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
 g = configs.outer_ss_state(96, perturb=1e-8, seed=17)
 mk = lambda n: hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), None, n, high_accuracy=True, device=0)
-ta, st, meta = hens.ensemble_propagate_until_sharded(mk, g, 6.0, device="cuda:0")
+ta, st, meta, rec = hens.ensemble_propagate_until_sharded(mk, g, 6.0, device="cuda:0")
 assert st.is_cuda and st.shape == (36, 96) and meta.dtype == torch.int64
 assert np.array_equal(st.cpu().numpy(), ta.state)
 # Unequal shard sizes take the padded all_gather branch: exercise it with a ragged tensor as well.

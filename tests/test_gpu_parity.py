@@ -348,7 +348,7 @@ def _select_cluster_kernel(monkeypatch, kernel):
         monkeypatch.setenv("HEYOKA_AMD_PAIR_SPLIT", "0")
 
 
-def _nbody_parity(n_bodies, n_sys, n_steps, expect_mode, t_final=None, env_mode=None, tol=1e5):
+def _nbody_parity(n_bodies, n_sys, n_steps, expect_mode, t_final=None, env_mode=None, tol=1e5, tc_tol=1e6):
     import os
 
     st = configs.plummer_nbody_state(n_bodies, n_sys, seed=77, jitter=1e-6)
@@ -374,7 +374,7 @@ def _nbody_parity(n_bodies, n_sys, n_steps, expect_mode, t_final=None, env_mode=
         assert rel_err(ta.state, ora.state.reshape(6 * n_bodies, n_sys)) <= tol * EPS
     tc_o = ora.tc.reshape(6 * n_bodies, ora.order + 1, n_sys)
     scale = np.max(np.abs(tc_o), axis=2, keepdims=True) + 1e-300
-    assert np.max(np.abs(ta.tc - tc_o) / scale) <= 1e7 * EPS
+    assert np.max(np.abs(ta.tc - tc_o) / scale) <= tc_tol * EPS
     if t_final is not None:
         ta.propagate_until(t_final)
         ora.propagate_until(t_final)
@@ -1608,6 +1608,35 @@ def test_bench_length_parity_on_4096_systems(kernel, contract, monkeypatch):
     assert 70 <= ns.mean() <= 95
     tol = 1e6 if contract else 1e5
     assert rel_err(ta.state, ref.reshape(36, n)) <= tol * EPS
+    same = dn == 0
+    assert np.max(np.abs(np.asarray(mn_g)[same] - mn[same]) / mn[same]) <= 1e-6
+    assert np.max(np.abs(np.asarray(mx_g)[same] - mx[same]) / mx[same]) <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("contract", [True, False], ids=["default-build", "no-contraction"])
+def test_bench_length_parity_nbody64_block_v2(contract, monkeypatch):
+    """Config 5's benchmarked kernel (block mode, v2 cluster phase) over a bench-sized launch: 768 Plummer spheres of 64
+    bodies - three times the workgroups a launch keeps in flight, so that the work queue hands every workgroup several
+    systems - through propagate_until(0.055) (~34 Taylor steps per system, what a bench launch runs), lane by lane against
+    the oracle's ensemble driver: identical outcomes and end times, step counts within +-1 on at most 1 % of the systems,
+    states to 1e6 eps (1e5 eps built with -ffp-contract=off, the oracle's arithmetic), smallest / largest steps to 1e-6.
+    (Tolerances: test/two_body_batch.cpp:118-150; the tape: src/taylor_02.cpp:1194-1260.)"""
+    if not contract:
+        monkeypatch.setenv("HEYOKA_AMD_HIPRTC_FLAGS", "-ffp-contract=off")
+    n, t_final = 768, 0.055
+    st = configs.plummer_nbody_state(64, n, seed=77, jitter=1e-6)
+    ta = hy.taylor_adaptive_batch(hy.model.nbody(64), st, n)
+    assert "block" in ta.hip_source_mode and "v2 cluster phase" in ta.hip_source_mode, ta.hip_source_mode
+    ta.propagate_until(t_final)
+    ref, thi, tlo, oc, mn, mx, ns, total = ho.ensemble_propagate_until(ho.nbody(64), st, n, 8, t_final)
+    oc_g, mn_g, mx_g, ns_g = ta.propagate_res_arrays()
+    assert np.array_equal(np.asarray(oc_g, dtype=np.int64), oc) and np.all(oc == int(OC.time_limit))
+    assert np.array_equal(ta.time, thi) and np.all(thi == t_final)
+    dn = np.abs(np.asarray(ns_g, dtype=np.int64) - ns)
+    assert dn.max() <= 1 and np.count_nonzero(dn) <= n // 100, (dn.max(), np.count_nonzero(dn))
+    assert 25 <= ns.mean() <= 45, ns.mean()
+    assert rel_err(ta.state, ref.reshape(384, n)) <= (1e6 if contract else 1e5) * EPS
     same = dn == 0
     assert np.max(np.abs(np.asarray(mn_g)[same] - mn[same]) / mn[same]) <= 1e-6
     assert np.max(np.abs(np.asarray(mx_g)[same] - mx[same]) / mx[same]) <= 1e-6
