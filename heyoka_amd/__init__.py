@@ -58,6 +58,7 @@ __all__ = [
     "ensemble_propagate_for_batch",
     "device_count",
     "version",
+    "native_event_counter",
 ]
 
 _builtin_sum = sum
@@ -806,6 +807,19 @@ class event_direction(enum.IntEnum):
     positive = 1
 
 
+class native_event_counter:
+    """A callback which lives in the library (hy_event_counter_nt / hy_event_counter_t of the C ABI) and only counts its
+    invocations - for ensembles in which 10^5 events fire per step and a Python callback per event would be the only thing
+    measured. ``.value``: the count; as a terminal callback it always continues."""
+
+    def __init__(self):
+        self._c = ctypes.c_uint64(0)
+
+    @property
+    def value(self):
+        return int(self._c.value)
+
+
 class nt_event:
     """nt_event_batch<double> (include/heyoka/events.hpp): ``callback(ta, time, d_sgn, batch_idx)``."""
 
@@ -909,6 +923,9 @@ class taylor_adaptive_batch:
         if t_events or nt_events:
             # C trampolines: look the Python integrator up by handle, record exceptions (re-raised after the C call).
             def make_nt(ev):
+                if isinstance(ev.callback, native_event_counter):
+                    return ctypes.cast(lib.hy_event_counter_nt, _lib.NT_EVENT_CB)
+
                 def tramp(handle, tm, d_sgn, idx, _user):
                     ta = _TAB_REGISTRY.get(int(handle))
                     try:
@@ -921,6 +938,8 @@ class taylor_adaptive_batch:
             def make_t(ev):
                 if ev.callback is None:
                     return ctypes.cast(None, _lib.T_EVENT_CB)
+                if isinstance(ev.callback, native_event_counter):
+                    return ctypes.cast(lib.hy_event_counter_t, _lib.T_EVENT_CB)
 
                 def tramp(handle, d_sgn, idx, _user):
                     ta = _TAB_REGISTRY.get(int(handle))
@@ -938,11 +957,13 @@ class taylor_adaptive_batch:
             for k, ev in enumerate(t_events):
                 cb = make_t(ev)
                 cbs.append(cb)
-                te_arr[k] = _lib.TEvent(ev.eq._h, cb, None, int(ev.direction), ev.cooldown)
+                user = ctypes.cast(ctypes.byref(ev.callback._c), ctypes.c_void_p) if isinstance(ev.callback, native_event_counter) else None
+                te_arr[k] = _lib.TEvent(ev.eq._h, cb, user, int(ev.direction), ev.cooldown)
             for k, ev in enumerate(nt_events):
                 cb = make_nt(ev)
                 cbs.append(cb)
-                nte_arr[k] = _lib.NtEvent(ev.eq._h, cb, None, int(ev.direction))
+                user = ctypes.cast(ctypes.byref(ev.callback._c), ctypes.c_void_p) if isinstance(ev.callback, native_event_counter) else None
+                nte_arr[k] = _lib.NtEvent(ev.eq._h, cb, user, int(ev.direction))
             self._events = (t_events, nt_events, cbs)
             self._h = check_handle(
                 lib.hy_tab_create_with_events(self._sys._h, st.ctypes.data if st.size else None, st.size,
@@ -964,6 +985,18 @@ class taylor_adaptive_batch:
     @property
     def with_events(self):
         return bool(lib.hy_tab_with_events(self._h))
+
+    def set_event_timing(self, on=True):
+        """Phase timing of the steps with events (one stream synchronisation per phase while it is on)."""
+        raise_for(lib.hy_tab_set_event_timing(self._h, 1 if on else 0))
+
+    @property
+    def event_stats(self):
+        out = np.zeros(8)
+        raise_for(lib.hy_tab_get_event_stats(self._h, out.ctypes.data))
+        keys = ("steps", "ms_upload", "ms_stepper", "ms_detection", "ms_bookkeeping_flags", "ms_update_records",
+                "tc_regeneration_launches", "systems_with_events")
+        return dict(zip(keys, [float(x) for x in out]))
 
     def reset_cooldowns(self, batch_idx=None):
         raise_for(lib.hy_tab_reset_cooldowns(self._h, -1 if batch_idx is None else int(batch_idx)))
@@ -1329,10 +1362,34 @@ class taylor_adaptive_batch:
         k = int(lib.hy_tab_get_kernel_ms_history(self._h, out.ctypes.data, int(n)))
         return out[:k]
 
-    def raw_step(self, d_state, d_pars, d_time, d_h, d_tc, n_systems):
-        """Stepper function-pointer ABI on caller-owned device buffers (integers = device addresses)."""
-        raise_for(lib.hy_tab_raw_step(self._h, int(d_state), int(d_pars) if d_pars else None, int(d_time), int(d_h),
-                                      int(d_tc) if d_tc else None, int(n_systems)))
+    def raw_step(self, d_state, d_pars, d_time, d_h, d_tc, n_systems, d_tape=None):
+        """Stepper function-pointer ABI on caller-owned device buffers (integers = device addresses); d_tape: the tape in
+        caller-owned memory of raw_tape_size_align() bytes (c_step_f_t)."""
+        if d_tape is None:
+            raise_for(lib.hy_tab_raw_step(self._h, int(d_state), int(d_pars) if d_pars else None, int(d_time), int(d_h),
+                                          int(d_tc) if d_tc else None, int(n_systems)))
+        else:
+            raise_for(lib.hy_tab_raw_step_tape(self._h, int(d_state), int(d_pars) if d_pars else None, int(d_time), int(d_h),
+                                               int(d_tc) if d_tc else None, int(d_tape), int(n_systems)))
+
+    def raw_step_e(self, d_jet, d_state, d_pars, d_time, d_h, d_max_abs_state, n_systems, d_tape=None):
+        """step_f_e_t: jets of the state variables and of the event equations, step size, max |x_i|; no state update."""
+        if d_tape is None:
+            raise_for(lib.hy_tab_raw_step_e(self._h, int(d_jet), int(d_state), int(d_pars) if d_pars else None, int(d_time),
+                                            int(d_h), int(d_max_abs_state), int(n_systems)))
+        else:
+            raise_for(lib.hy_tab_raw_step_e_tape(self._h, int(d_jet), int(d_state), int(d_pars) if d_pars else None, int(d_time),
+                                                 int(d_h), int(d_max_abs_state), int(d_tape), int(n_systems)))
+
+    def raw_d_out_f(self, d_out, d_tc, d_h, n_systems):
+        """d_out_f_t: the Taylor polynomials d_tc evaluated at d_h."""
+        raise_for(lib.hy_tab_raw_d_out_f(self._h, int(d_out), int(d_tc), int(d_h), int(n_systems)))
+
+    def raw_tape_size_align(self, n_systems):
+        """(bytes, alignment) of the tape of the compact-mode steppers for n_systems systems (0 bytes: none needed)."""
+        sz, al = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        raise_for(lib.hy_tab_tape_size_align(self._h, int(n_systems), ctypes.byref(sz), ctypes.byref(al)))
+        return int(sz.value), int(al.value)
 
 
 def _ensemble(fn, ta, t, n_iter, gen, max_steps, n_devices):

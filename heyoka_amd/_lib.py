@@ -135,6 +135,10 @@ SIGNATURES = [
     ("hy_tab_create_with_events", c_void_p,
      [c_void_p, c_void_p, c_size_t, c_uint32, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t]),
     ("hy_tab_with_events", c_int, [c_void_p]),
+    ("hy_event_counter_nt", None, [c_void_p, ctypes.c_double, c_int, ctypes.c_uint32, c_void_p]),
+    ("hy_event_counter_t", c_int, [c_void_p, c_int, ctypes.c_uint32, c_void_p]),
+    ("hy_tab_set_event_timing", c_int, [c_void_p, c_int]),
+    ("hy_tab_get_event_stats", c_int, [c_void_p, c_void_p]),
     ("hy_tab_reset_cooldowns", c_int, [c_void_p, ctypes.c_int64]),
     ("hy_tab_get_te_cooldowns", c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     ("hy_tab_copy", c_void_p, [c_void_p]),
@@ -252,6 +256,11 @@ SIGNATURES = [
     ("hy_tab_get_last_total_steps", c_uint64, [c_void_p]),
     ("hy_tab_get_kernel_ms_history", c_size_t, [c_void_p, c_void_p, c_size_t]),
     ("hy_tab_raw_step", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64]),
+    ("hy_tab_raw_step_tape", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64]),
+    ("hy_tab_raw_step_e", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64]),
+    ("hy_tab_raw_step_e_tape", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64]),
+    ("hy_tab_raw_d_out_f", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint64]),
+    ("hy_tab_tape_size_align", c_int, [c_void_p, c_uint64, c_void_p, c_void_p]),
     (
         "hy_ensemble_propagate_until_batch",
         c_int,

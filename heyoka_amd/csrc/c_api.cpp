@@ -810,6 +810,39 @@ hy_tab hy_tab_create_with_events(hy_sys sys, const double *state, size_t n_state
         return nullptr;
     }
 }
+int hy_tab_set_event_timing(hy_tab t, int on)
+{
+    try {
+        t->core.set_event_timing(on != 0);
+        return HY_OK;
+    } catch (...) {
+        return handle_exception();
+    }
+}
+
+int hy_tab_get_event_stats(hy_tab t, double *out8)
+{
+    try {
+        const auto st = t->core.get_event_stats();
+        std::copy(st.begin(), st.end(), out8);
+        return HY_OK;
+    } catch (...) {
+        return handle_exception();
+    }
+}
+
+// Native callbacks which count their invocations in the 64-bit integer behind `user` (the callbacks of an integrator run
+// serially on the host).
+void hy_event_counter_nt(hy_tab, double, int, uint32_t, void *user)
+{
+    ++*static_cast<std::uint64_t *>(user);
+}
+int hy_event_counter_t(hy_tab, int, uint32_t, void *user)
+{
+    ++*static_cast<std::uint64_t *>(user);
+    return 1;
+}
+
 int hy_tab_with_events(hy_tab t)
 {
     return t->core.with_events() ? 1 : 0;
@@ -1364,6 +1397,42 @@ int hy_tab_raw_step(hy_tab t, double *d_state, const double *d_pars, const doubl
                     uint64_t n)
 {
     return guarded([&] { t->core.raw_step(d_state, d_pars, d_time, d_h, d_tc, n); });
+}
+
+int hy_tab_raw_step_tape(hy_tab t, double *d_state, const double *d_pars, const double *d_time, double *d_h, double *d_tc,
+                         void *d_tape, uint64_t n)
+{
+    return guarded([&] { t->core.raw_step(d_state, d_pars, d_time, d_h, d_tc, n, d_tape); });
+}
+
+int hy_tab_raw_step_e(hy_tab t, double *d_jet, const double *d_state, const double *d_pars, const double *d_time, double *d_h,
+                      double *d_max_abs_state, uint64_t n)
+{
+    return guarded([&] { t->core.raw_step_e(d_jet, d_state, d_pars, d_time, d_h, d_max_abs_state, n, nullptr); });
+}
+
+int hy_tab_raw_step_e_tape(hy_tab t, double *d_jet, const double *d_state, const double *d_pars, const double *d_time,
+                           double *d_h, double *d_max_abs_state, void *d_tape, uint64_t n)
+{
+    return guarded([&] { t->core.raw_step_e(d_jet, d_state, d_pars, d_time, d_h, d_max_abs_state, n, d_tape); });
+}
+
+int hy_tab_raw_d_out_f(hy_tab t, double *d_out, const double *d_tc, const double *d_h, uint64_t n)
+{
+    return guarded([&] { t->core.raw_d_out_f(d_out, d_tc, d_h, n); });
+}
+
+int hy_tab_tape_size_align(hy_tab t, uint64_t n, size_t *size, size_t *align)
+{
+    return guarded([&] {
+        const auto sa = t->core.raw_tape_size_align(n);
+        if (size != nullptr) {
+            *size = sa.first;
+        }
+        if (align != nullptr) {
+            *align = sa.second;
+        }
+    });
 }
 
 static int ensemble_impl(hy_tab ta, double tm, size_t n_iter, hy_ensemble_gen gen, void *gen_data, uint64_t max_steps,

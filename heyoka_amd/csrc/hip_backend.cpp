@@ -242,7 +242,18 @@ void *device_module::stream() const
     return m_impl->stream;
 }
 
-void device_module::launch_taylor(const hy_kargs &args)
+std::size_t device_module::tape_bytes(std::uint64_t n_systems) const
+{
+    const auto &meta = m_impl->cm->meta;
+    if (!meta.persistent || meta.scratch_per_wave == 0u || n_systems == 0u) {
+        return 0;
+    }
+    const auto bs = static_cast<std::uint64_t>(meta.block_size);
+    const auto grid = std::min<std::uint64_t>((n_systems * meta.lanes_per_system + bs - 1u) / bs, m_impl->max_grid);
+    return static_cast<std::size_t>(grid) * (bs / 64u) * meta.scratch_per_wave * sizeof(double);
+}
+
+void device_module::launch_taylor(const hy_kargs &args, void *user_tape)
 {
     if (args.N == 0u) {
         return;
@@ -261,7 +272,10 @@ void device_module::launch_taylor(const hy_kargs &args)
         // Persistent blocks pulling work from a device-side queue: the grid covers the machine once,
         // and the jet scratch is sized by the number of resident waves.
         grid = std::min<std::uint64_t>(grid, m_impl->max_grid);
-        if (meta.scratch_per_wave != 0u) {
+        if (meta.scratch_per_wave != 0u && user_tape != nullptr) {
+            // (The caller's tape: tape_bytes() of this many systems, the stepper function-pointer ABI with the tape argument.)
+            a.scratch = static_cast<double *>(user_tape);
+        } else if (meta.scratch_per_wave != 0u) {
             // Bound the scratch (table mode keeps the whole tape of every resident thread in HBM):
             // 48 GiB by default out of the 288 GB of an MI355X.
             double budget_gib = 48.;
@@ -280,15 +294,17 @@ void device_module::launch_taylor(const hy_kargs &args)
             grid = std::max<std::uint64_t>(1u, std::min<std::uint64_t>(grid, max_blocks));
         }
         const auto need = static_cast<std::size_t>(grid) * (bs / 64u) * meta.scratch_per_wave * sizeof(double);
-        if (need > m_impl->scratch_bytes && need != 0u) {
-            if (m_impl->scratch != nullptr) {
-                hip_check(hipFree(m_impl->scratch), "hipFree");
-                m_impl->scratch = nullptr;
+        if (user_tape == nullptr || meta.scratch_per_wave == 0u) {
+            if (need > m_impl->scratch_bytes && need != 0u) {
+                if (m_impl->scratch != nullptr) {
+                    hip_check(hipFree(m_impl->scratch), "hipFree");
+                    m_impl->scratch = nullptr;
+                }
+                hip_check(hipMalloc(&m_impl->scratch, need), "hipMalloc(scratch)");
+                m_impl->scratch_bytes = need;
             }
-            hip_check(hipMalloc(&m_impl->scratch, need), "hipMalloc(scratch)");
-            m_impl->scratch_bytes = need;
+            a.scratch = static_cast<double *>(m_impl->scratch);
         }
-        a.scratch = static_cast<double *>(m_impl->scratch);
     }
     std::size_t sz = sizeof(a);
     void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};

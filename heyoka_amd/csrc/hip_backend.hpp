@@ -47,7 +47,10 @@ public:
     [[nodiscard]] void *stream() const;
 
     // Launch the stepper over N systems.
-    void launch_taylor(const hy_kargs &args);
+    // (user_tape: the tape / scratch of the launch in caller-owned device memory of tape_bytes(args.N) bytes instead of the
+    // module's own allocation - the c_step(..., void *tape) flavour of the reference's stepper ABI.)
+    void launch_taylor(const hy_kargs &args, void *user_tape = nullptr);
+    [[nodiscard]] std::size_t tape_bytes(std::uint64_t n_systems) const;
     // Durations (ms) of the last n stepper kernels, oldest first, from HIP events recorded on the launch
     // stream right around each launch (at most 64 are kept); synchronises on their completion.
     std::vector<double> kernel_ms_history(std::size_t n);

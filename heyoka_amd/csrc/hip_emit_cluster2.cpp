@@ -2937,7 +2937,8 @@ const bool hy_tc_only = HY_M4 && ((a.pad & 2) != 0);
         }
         src << "nv = hy_nmax(nv, hy_q0 ? evm0 : (hy_q1 ? evmo : evmom1));\n";
         // (max |x_i| over the state variables and the event equations: the scale of the root finder's tolerance.)
-        src << "a.max_abs_state[s] = hy_dpp<0x00>(nv);\n";
+        // (Not in the regeneration launch - hy_tc_only: it gets null pointers for everything but the coefficients.)
+        src << "if (!hy_tc_only) a.max_abs_state[s] = hy_dpp<0x00>(nv);\n";
     }
     src << "#define HY_EV_INLINE " << (ev_inline ? 1 : 0) << "\n";
     src << "const bool nostate = " << ((m4 && !ev_inline) ? "true" : "false") << ";\n";
@@ -3068,8 +3069,8 @@ lim = fin ? 0.0 : lim;
         src << "ev_possible = (maybe & maybe0) | " << sys_any("pe_m") << ";\nneed_tc = need_tc | ev_possible;\n}\n";
         // (For the detection kernel: systems in which no event is possible are skipped without reading their event jets -
         // which are stored only by the wavefronts that hold such a system.)
-        src << "a.sel_norms[s] = ev_possible ? 1.0 : 0.0;\n";
-        src << "if (__builtin_amdgcn_ballot_w64(ev_possible) != 0ull) {\n";
+        src << "if (!hy_tc_only) a.sel_norms[s] = ev_possible ? 1.0 : 0.0;\n";
+        src << "if (!hy_tc_only && __builtin_amdgcn_ballot_w64(ev_possible) != 0ull) {\n";
         for (std::size_t ev = 0; ev < ev_coeffs.size(); ++ev) {
             for (std::uint32_t k = 0; !ev_coeffs[ev].empty() && k <= order; ++k) {
                 src << "a.ev_tc[(u64)" << static_cast<std::uint64_t>(ev) * (order + 1u) + k << "u * N + s] = " << ev_coeffs[ev][k] << ";\n";
@@ -3081,7 +3082,7 @@ lim = fin ? 0.0 : lim;
         }
         src << "}\n";
     } else if (ev_inline) {
-        src << "a.sel_norms[s] = 1.0;\n";
+        src << "if (!hy_tc_only) a.sel_norms[s] = 1.0;\n";
     }
 
     src << "asm volatile(\"\" ::: \"memory\");\n";

@@ -2,6 +2,7 @@
 #include "taylor_adaptive_batch.hpp"
 
 #include <algorithm>
+#include <array>
 #include <cassert>
 #include <charconv>
 #include <chrono>
@@ -129,7 +130,14 @@ struct tab_core::impl {
     // continuous output, propagate_grid()) triggers a second launch of the stepper on the snapshot which stores nothing
     // but them (bit-identical: the same kernel on the same input). ev_all_tc: store them in every step (lock-step loops
     // which consume them step by step).
-    device_buffer evs_state, evs_thi, evs_tlo;
+    device_buffer evs_state, evs_thi, evs_tlo, evs_pars;
+    // Accounting of the steps with events (tab_core::set_event_timing() / get_event_stats(); bench.py's events leg): number
+    // of steps, wall-clock ms of the five phases (only with the timing switched on: a stream synchronisation after each
+    // phase), regeneration launches of the Taylor coefficients, systems which reported events.
+    bool ev_timing = false;
+    double ev_ms[5] = {0, 0, 0, 0, 0};
+    std::uint64_t ev_steps = 0, ev_systems = 0;
+    mutable std::uint64_t tc_regens = 0;
     mutable bool tc_partial = false;
     bool ev_all_tc = false;
     // (A caller who read the coefficients of the previous step - a step callback with dense output, say - will probably read
@@ -972,15 +980,22 @@ void tab_core::impl::ensure_tc_complete() const
     }
     tc_partial = false;
     tc_regenerated = true;
+    ++tc_regens;
     auto &self = const_cast<impl &>(*this);
     auto a = self.base_args();
     a.state = evs_state.as<double>();
     a.time_hi = evs_thi.as<double>();
     a.time_lo = evs_tlo.as<double>();
     a.tc = d_tc.as<double>();
-    a.ev_tc = d_ev_tc.as<double>();
-    a.max_abs_state = d_mas.as<double>();
-    a.sel_norms = d_selnorms.as<double>();
+    // (The regeneration launch stores the Taylor coefficients and NOTHING else: the outputs of the step proper - event
+    // jets, selector norms, max |x| - get null pointers, so that a generator regression faults instead of silently
+    // rewriting them; the parameters are the ones the step ran with, snapshot below.)
+    a.ev_tc = nullptr;
+    a.max_abs_state = nullptr;
+    a.sel_norms = nullptr;
+    if (evs_pars.bytes() != 0u) {
+        a.pars = evs_pars.as<double>();
+    }
     a.mode = 4;
     a.pad = 3; // every workgroup stores its coefficients, nothing else is stored
     self.d_counters.zero(stream);
@@ -1285,6 +1300,13 @@ void tab_core::impl::launch_event_stepper(const std::vector<double> *lims)
                 evs_tlo = device_buffer(d_tlo.bytes(), device);
             }
             device_copy(evs_state.get(), d_state.get(), d_state.bytes(), device, stream);
+            // (Runtime parameters: a callback of this step may change them before somebody asks for the coefficients.)
+            if (prog.n_par != 0u && d_pars.bytes() != 0u) {
+                if (evs_pars.bytes() != d_pars.bytes()) {
+                    evs_pars = device_buffer(d_pars.bytes(), device);
+                }
+                device_copy(evs_pars.get(), d_pars.get(), d_pars.bytes(), device, stream);
+            }
             device_copy(evs_thi.get(), d_thi.get(), d_thi.bytes(), device, stream);
             device_copy(evs_tlo.get(), d_tlo.get(), d_tlo.bytes(), device, stream);
             a.pad = 0;
@@ -1385,16 +1407,26 @@ void tab_core::impl::step_with_events_device(const std::vector<double> *lims)
     const auto n_te = static_cast<std::uint32_t>(tes.size()), n_nte = static_cast<std::uint32_t>(ntes.size());
 
     // HEYOKA_AMD_EVENTS_TIMING=1: wall-clock time of the phases (with a stream synchronisation after each of them).
-    static const bool timing = std::getenv("HEYOKA_AMD_EVENTS_TIMING") != nullptr;
+    static const bool timing_env = std::getenv("HEYOKA_AMD_EVENTS_TIMING") != nullptr;
+    const bool timing = timing_env || ev_timing;
     auto t_last = std::chrono::steady_clock::now();
+    int lap_idx = 0;
     const auto lap = [&](const char *what) {
         if (timing) {
             stream_synchronize(device, stream);
             const auto now = std::chrono::steady_clock::now();
-            std::fprintf(stderr, "[events] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+            const auto ms = std::chrono::duration<double, std::milli>(now - t_last).count();
+            if (timing_env) {
+                std::fprintf(stderr, "[events] %-28s %8.3f ms\n", what, ms);
+            }
+            if (lap_idx < 5) {
+                ev_ms[lap_idx] += ms;
+            }
+            ++lap_idx;
             t_last = now;
         }
     };
+    ++ev_steps;
     before_kernel();
     ensure_event_buffers();
     cooldowns_to_device();
@@ -1507,6 +1539,7 @@ void tab_core::impl::step_with_events_device(const std::vector<double> *lims)
         }
         p += 8u + 4u * (c_te + c_nte);
         recs.push_back(std::move(lr));
+        ++ev_systems;
     }
     std::sort(recs.begin(), recs.end(), [](const auto &x, const auto &y) { return x.lane < y.lane; });
 
@@ -2538,6 +2571,18 @@ void tab_core::pack_results(double *dst)
     cp(d.dim + 5u, d.d_maxh.get(), 1);
 }
 
+void tab_core::set_event_timing(bool on)
+{
+    m_impl->ev_timing = on;
+}
+
+std::array<double, 8> tab_core::get_event_stats() const
+{
+    const auto &d = *m_impl;
+    return {static_cast<double>(d.ev_steps), d.ev_ms[0], d.ev_ms[1], d.ev_ms[2], d.ev_ms[3], d.ev_ms[4],
+            static_cast<double>(d.tc_regens), static_cast<double>(d.ev_systems)};
+}
+
 void tab_core::mark_device_modified()
 {
     m_impl->to_device();
@@ -2602,6 +2647,7 @@ void tab_core::set_device(int device)
     d.tc_expand_pending = false;
     d.tc_partial = false;
     d.evs_state = {};
+    d.evs_pars = {};
     d.evs_thi = {};
     d.evs_tlo = {};
     d.d_selnorms = {};
@@ -2655,7 +2701,7 @@ std::vector<double> tab_core::get_kernel_ms_history(std::size_t n) const
 }
 
 void tab_core::raw_step(double *d_state, const double *d_pars, const double *d_time, double *d_h, double *d_tc,
-                        std::uint64_t n_systems)
+                        std::uint64_t n_systems, void *d_tape)
 {
     auto &d = *m_impl;
     d.ensure_device();
@@ -2684,7 +2730,83 @@ void tab_core::raw_step(double *d_state, const double *d_pars, const double *d_t
     a.N = n_systems;
     a.mode = 2;
     a.counters = d.d_counters.as<unsigned>();
-    d.dmod->launch_taylor(a);
+    d.dmod->launch_taylor(a, d_tape);
+    d.dmod->synchronize();
+}
+
+std::pair<std::size_t, std::size_t> tab_core::raw_tape_size_align(std::uint64_t n_systems)
+{
+    auto &d = *m_impl;
+    d.ensure_device();
+    // (0 bytes: this stepper keeps its Taylor coefficients on chip. 256: the alignment of a device allocation.)
+    return {d.dmod->tape_bytes(n_systems), 256u};
+}
+
+void tab_core::raw_d_out_f(double *d_out, const double *d_tc, const double *d_h, std::uint64_t n_systems)
+{
+    auto &d = *m_impl;
+    d.ensure_device();
+    d.dmod->launch_dout(d_out, d_tc, d_h, n_systems);
+    d.dmod->synchronize();
+}
+
+void tab_core::raw_step_e(double *d_jet, const double *d_state, const double *d_pars, const double *d_time, double *d_h,
+                          double *d_max_abs_state, std::uint64_t n_systems, void *d_tape)
+{
+    auto &d = *m_impl;
+    if (!with_events()) {
+        throw std::invalid_argument("raw_step_e(): the stepper with events exists only in an integrator constructed with events");
+    }
+    d.ensure_device();
+    d.ensure_event_buffers();
+    const auto n = static_cast<std::size_t>(n_systems), w = sizeof(double);
+    const auto n_ev = d.tes.size() + d.ntes.size();
+    const auto tc_words = static_cast<std::size_t>(d.dim) * (d.order + 1u) * n;
+    // Scratch for what the ABI does not expose. The stepper which evaluates the event equations itself also updates the
+    // state it is given: it works on a copy (step_e leaves the state alone).
+    device_buffer st(static_cast<std::size_t>(d.dim) * n * w, d.device), tlo(n * w, d.device), oc(n * sizeof(long long), d.device),
+        lh(n * w, d.device), seln(3u * n * w, d.device), cnt(16u * sizeof(unsigned), d.device);
+    device_copy(st.get(), d_state, st.bytes(), d.device, d.stream);
+    tlo.zero(d.stream);
+    cnt.zero(d.stream);
+    hy_kargs a{};
+    a.state = st.as<double>();
+    a.pars = d_pars;
+    a.time_hi = const_cast<double *>(d_time);
+    a.time_lo = tlo.as<double>();
+    a.lim = d_h;
+    a.last_h = lh.as<double>();
+    a.outcome = oc.as<long long>();
+    a.tc = d_jet;
+    a.ev_tc = d_jet + tc_words;
+    a.max_abs_state = d_max_abs_state;
+    a.sel_norms = seln.as<double>();
+    a.N = n_systems;
+    a.mode = 4;
+    a.pad = 1; // the Taylor coefficients of every system
+    a.counters = cnt.as<unsigned>();
+    (void)n_ev;
+    d.dmod->launch_taylor(a, d_tape);
+    if (d.cluster_events && !d.emitted.events_in_stepper) {
+        // (Jets of the event equations, extended norms and the step size from the jets of the state variables.)
+        if (!d.evj_mod) {
+            d.evj_mod = std::make_unique<aux_module>(d.ev_cmod, d.device);
+        }
+        d.evj_mod->launch("hy_ev_jets", n_systems, 256, &a, sizeof(a), d.stream);
+    }
+    if (d.emitted.compact_tc && d.evj_mod) {
+        // (The stepper left the rows of the variables defined by another state variable to be derived: x^[k] = v^[k-1] / k.)
+        const struct {
+            double *out;
+            const double *tc;
+            const double *hs;
+            unsigned long long N;
+            const double *hfull;
+        } ea{d_jet, d_jet, nullptr, n_systems, nullptr};
+        d.evj_mod->launch("hy_tc_expand", n_systems, 256, &ea, sizeof(ea), d.stream);
+    }
+    // The step size which was taken.
+    device_copy(d_h, lh.get(), n * w, d.device, d.stream);
     d.dmod->synchronize();
 }
 

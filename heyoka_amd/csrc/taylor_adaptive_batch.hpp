@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstddef>
+#include <array>
 #include <cstdint>
 #include <functional>
 #include <initializer_list>
@@ -236,6 +237,11 @@ public:
     // (reference: ensemble_propagate_*() returns whole integrators, src/ensemble_propagate.cpp:193-297).
     static constexpr std::size_t n_result_rows = 6;
     void pack_results(double *d_dst);
+    // Accounting of the steps with events: {steps, ms upload / buffers, ms stepper (+ event jets), ms detection, ms
+    // bookkeeping + flags to the host, ms state update + records, regeneration launches of the Taylor coefficients,
+    // systems which reported events}. The phase times are taken only with the timing on (a synchronisation per phase).
+    void set_event_timing(bool on);
+    [[nodiscard]] std::array<double, 8> get_event_stats() const;
     // Mark the device copies as modified by the caller (e.g. initial conditions written by a kernel).
     void mark_device_modified();
     void set_stream(void *hip_stream);
@@ -249,7 +255,15 @@ public:
     // Stepper function-pointer ABI of the reference (include/heyoka/detail/ta_jit_data.hpp:35-44)
     // on caller-provided device buffers: state rw, h in = signed max step, out = step taken.
     void raw_step(double *d_state, const double *d_pars, const double *d_time, double *d_h, double *d_tc,
-                  std::uint64_t n_systems);
+                  std::uint64_t n_systems, void *d_tape = nullptr);
+    // The other pointer types of that ABI (ta_jit_data.hpp:34-43): the stepper with events - jets of the state variables
+    // and of the event equations, step size and max |x_i|, NO state update (taylor_add_adaptive_step_with_events(),
+    // src/taylor_00.cpp:592-710) -, the dense output (taylor_add_d_out_function(), src/taylor_01.cpp:1015-1185) and the
+    // size / alignment of the tape of the compact-mode steppers (c_step_f_t: the caller owns the tape).
+    void raw_step_e(double *d_jet, const double *d_state, const double *d_pars, const double *d_time, double *d_h,
+                    double *d_max_abs_state, std::uint64_t n_systems, void *d_tape = nullptr);
+    void raw_d_out_f(double *d_out, const double *d_tc, const double *d_h, std::uint64_t n_systems);
+    [[nodiscard]] std::pair<std::size_t, std::size_t> raw_tape_size_align(std::uint64_t n_systems);
 
 private:
     struct impl;

@@ -253,6 +253,15 @@ hy_tab hy_tab_create_with_events(hy_sys sys, const double *state, size_t n_state
                                  const hy_tab_config *cfg, const hy_t_event *t_events, size_t n_t_events,
                                  const hy_nt_event *nt_events, size_t n_nt_events);
 int hy_tab_with_events(hy_tab);
+/* Accounting of the steps with events (bench.py's events leg). out8 = {steps with events, ms upload / buffers, ms stepper
+ * (+ event jets), ms detection kernel, ms bookkeeping kernel + flags to the host, ms state update + records, regeneration
+ * launches of the Taylor coefficients, systems which reported events}; the five phase times accumulate only while the
+ * timing is on (hy_tab_set_event_timing(): one stream synchronisation per phase). */
+int hy_tab_set_event_timing(hy_tab, int on);
+int hy_tab_get_event_stats(hy_tab, double *out8);
+/* Ready-made callbacks which count their invocations in the uint64_t `user` points to (the terminal one continues). */
+void hy_event_counter_nt(hy_tab, double time, int d_sgn, uint32_t batch_idx, void *user);
+int hy_event_counter_t(hy_tab, int d_sgn, uint32_t batch_idx, void *user);
 /* reset_cooldowns(): batch_idx < 0 -> all the lanes. */
 int hy_tab_reset_cooldowns(hy_tab, int64_t batch_idx);
 /* get_te_cooldowns(): [batch_size * n_t_events] arrays indexed [lane * n_t_events + event]; active != 0 where a
@@ -430,6 +439,27 @@ size_t hy_tab_get_kernel_ms_history(hy_tab, double *out, size_t n);
  * No error channel for numerical failures (non-finite results are the caller's to detect). */
 int hy_tab_raw_step(hy_tab, double *d_state, const double *d_pars, const double *d_time, double *d_h, double *d_tc,
                     uint64_t n_systems);
+/* The other pointer types of the reference's stepper ABI (include/heyoka/detail/ta_jit_data.hpp:34-43), same argument
+ * order, on caller-owned device buffers of n_systems systems:
+ *   step_f_e_t   (jet, state, pars, time, h, max_abs_state): the stepper with events of an integrator constructed with
+ *                events (taylor_add_adaptive_step_with_events(), src/taylor_00.cpp:592-710) - d_jet receives the Taylor
+ *                coefficients of the state variables, [n_eq * (order + 1) * n], followed by those of the event equations,
+ *                [(n_t_events + n_nt_events) * (order + 1) * n] (terminal events first), d_h in: signed max step, out: the
+ *                step size of the selector, d_max_abs_state [n]: max |x_i| over the state; the state is NOT updated;
+ *   d_out_f_t    (d_out, tc, h): dense output (taylor_add_d_out_function(), src/taylor_01.cpp:1015-1185) - d_out [n_eq * n]
+ *                = the Taylor polynomials d_tc [n_eq * (order + 1) * n] evaluated at d_h [n] (compensated in high-accuracy
+ *                mode, Horner otherwise);
+ *   c_step_f_t / c_step_f_e_t (... , void *tape): the same two steppers with the tape in caller-owned device memory of
+ *                hy_tab_tape_size_align() bytes (0: this stepper keeps its coefficients on chip and ignores the argument;
+ *                src/taylor_02.cpp:1194-1260 for the reference's tape). */
+int hy_tab_raw_step_e(hy_tab, double *d_jet, const double *d_state, const double *d_pars, const double *d_time, double *d_h,
+                      double *d_max_abs_state, uint64_t n_systems);
+int hy_tab_raw_d_out_f(hy_tab, double *d_out, const double *d_tc, const double *d_h, uint64_t n_systems);
+int hy_tab_raw_step_tape(hy_tab, double *d_state, const double *d_pars, const double *d_time, double *d_h, double *d_tc,
+                         void *d_tape, uint64_t n_systems);
+int hy_tab_raw_step_e_tape(hy_tab, double *d_jet, const double *d_state, const double *d_pars, const double *d_time,
+                           double *d_h, double *d_max_abs_state, void *d_tape, uint64_t n_systems);
+int hy_tab_tape_size_align(hy_tab, uint64_t n_systems, size_t *size, size_t *align);
 
 /* Build-time check: hiprtc-compiles for gfx950 the auxiliary kernels that are otherwise compiled at first use on a
  * GPU (continuous output, propagate_grid post-step, event detection) for the given order / dimension; does not need

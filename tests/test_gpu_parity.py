@@ -301,6 +301,118 @@ def test_raw_step_abi():
     assert np.array_equal(d_tc[:, 0, :].cpu().numpy(), st)
 
 
+def test_raw_stepper_abi_step_e_d_out_f_and_caller_owned_tape(golden):
+    """The other pointer types of the reference's stepper ABI (include/heyoka/detail/ta_jit_data.hpp:34-43) through the C
+    ABI on caller-owned device buffers. step_f_e_t: jets of the state and of the event equations, step size and max |x_i|
+    against the oracle's hy_oracle_step_e (the reference's stepper with events, src/taylor_00.cpp:592-710), the state left
+    untouched - for the unrolled stepper (pendulum with one terminal and one non-terminal event) and for the wave-cluster
+    stepper which evaluates the event equations itself (outer Solar System). d_out_f_t: the dense output of the batch-mode
+    tutorial (doc/tut_batch_mode.rst golden values) and the compensated evaluation of the oracle. c_step_f_t: a
+    compact-mode stepper on a caller-owned tape of hy_tab_tape_size_align() bytes gives the results of the integrator's own
+    tape bit for bit."""
+    import ctypes
+
+    import torch
+
+    dev = torch.device("cuda:0")
+
+    def dt(a):
+        return torch.tensor(np.ascontiguousarray(a), device=dev, dtype=torch.float64)
+
+    def oracle_step_e(ora, n):
+        h = np.full(n, np.inf)
+        n_ev = len(ora.t_events) + len(ora.nt_events)
+        ho._lib().hy_oracle_step_e(ctypes.byref(ora._prog), n, ho._p(ora.state), ho._p(ora.pars), ho._p(ora.time_hi), ho._p(h),
+                                   ho._p(ora.tc), ho._p(ora._ev_u), n_ev, ho._p(ora._ev_tc), ho._p(ora._mas), ho._p(ora._scratch))
+        return h, ora.tc.copy(), ora._ev_tc.copy(), ora._mas.copy()
+
+    # ---- step_e, unrolled stepper: pendulum, events v = 0 (terminal) and x = 0 (non-terminal).
+    n = 200
+    rng = np.random.RandomState(8)
+    st = np.stack([rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)])
+    x, v = hy.make_vars("x", "v")
+    ox, ov = ho.var("x"), ho.var("v")
+    ta = hy.taylor_adaptive_batch([(x, v), (v, -9.8 * hy.sin(x))], st, n, t_events=[hy.t_event(v)],
+                                  nt_events=[hy.nt_event(x, lambda *a: None)])
+    ora = ho.OracleIntegrator([(ox, ov), (ov, -9.8 * ho.sin(ox))], st, n, t_events=[ho.t_event(ov)],
+                              nt_events=[ho.nt_event(ox, lambda *a: None)])
+    p = ta.order
+    h_o, tc_o, evtc_o, mas_o = oracle_step_e(ora, n)
+    d_state, d_time, d_h = dt(st), dt(np.zeros(n)), dt(np.full(n, np.inf))
+    d_jet = torch.zeros((2 + 2) * (p + 1) * n, device=dev, dtype=torch.float64)
+    d_mas = torch.zeros(n, device=dev, dtype=torch.float64)
+    ta.raw_step_e(d_jet.data_ptr(), d_state.data_ptr(), 0, d_time.data_ptr(), d_h.data_ptr(), d_mas.data_ptr(), n)
+    jet = d_jet.cpu().numpy()
+    assert np.array_equal(d_state.cpu().numpy(), st)  # no state update
+    assert np.max(np.abs(d_h.cpu().numpy() - h_o) / np.abs(h_o)) <= 1e4 * EPS
+    assert np.array_equal(d_mas.cpu().numpy(), mas_o)
+    tc_ref = tc_o.reshape(2, p + 1, n)
+    scale = np.max(np.abs(tc_ref), axis=2, keepdims=True) + 1e-300
+    assert np.max(np.abs(jet[: 2 * (p + 1) * n].reshape(2, p + 1, n) - tc_ref) / scale) <= 1e5 * EPS
+    ev_ref = evtc_o.reshape(2, p + 1, n)
+    scale = np.max(np.abs(ev_ref), axis=2, keepdims=True) + 1e-300
+    assert np.max(np.abs(jet[2 * (p + 1) * n:].reshape(2, p + 1, n) - ev_ref) / scale) <= 1e5 * EPS
+
+    # ---- step_e, the stepper which evaluates the event equations itself (outer Solar System, v5 with events inside).
+    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    n = 48
+    st = configs.outer_ss_state(n, perturb=1e-6, seed=9)
+    x1, x2 = hy.make_vars("x_1", "x_2")
+    o1, o2 = ho.var("x_1"), ho.var("x_2")
+    ta = hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True,
+                                  nt_events=[hy.nt_event(x1 - x2, lambda *a: None)])
+    ora = ho.OracleIntegrator(ho.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True, nt_events=[ho.nt_event(o1 - o2, lambda *a: None)])
+    p = ta.order
+    h_o, tc_o, evtc_o, mas_o = oracle_step_e(ora, n)
+    d_state, d_time, d_h = dt(st), dt(np.zeros(n)), dt(np.full(n, np.inf))
+    d_jet = torch.zeros((36 + 1) * (p + 1) * n, device=dev, dtype=torch.float64)
+    d_mas = torch.zeros(n, device=dev, dtype=torch.float64)
+    ta.raw_step_e(d_jet.data_ptr(), d_state.data_ptr(), 0, d_time.data_ptr(), d_h.data_ptr(), d_mas.data_ptr(), n)
+    jet = d_jet.cpu().numpy()
+    assert np.array_equal(d_state.cpu().numpy(), st)
+    assert np.max(np.abs(d_h.cpu().numpy() - h_o) / np.abs(h_o)) <= 1e6 * EPS
+    assert np.max(np.abs(d_mas.cpu().numpy() - mas_o) / mas_o) <= 4 * EPS
+    tc_ref = tc_o.reshape(36, p + 1, n)
+    scale = np.max(np.abs(tc_ref), axis=2, keepdims=True) + 1e-300
+    assert np.max(np.abs(jet[: 36 * (p + 1) * n].reshape(36, p + 1, n) - tc_ref) / scale) <= 1e6 * EPS
+    ev_ref = evtc_o.reshape(1, p + 1, n)
+    scale = np.max(np.abs(ev_ref), axis=2, keepdims=True) + 1e-300
+    assert np.max(np.abs(jet[36 * (p + 1) * n:].reshape(1, p + 1, n) - ev_ref) / scale) <= 1e6 * EPS
+
+    # ---- d_out_f: the oracle's compensated / Horner evaluation of its own Taylor coefficients at fractions of the step.
+    for ha in (False, True):
+        n = 64
+        st = configs.two_body_state(n, perturb=1e-2, seed=12)
+        ta = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), st, n, high_accuracy=ha)
+        ora = ho.OracleIntegrator(ho.nbody(2, masses=[1.0, 0.0]), st, n, high_accuracy=ha)
+        ora.step(wtc=True)
+        hs = np.array([h for _, h in ora.step_res]) * np.linspace(0.1, 1.0, n)
+        d_out = torch.zeros(12 * n, device=dev, dtype=torch.float64)
+        ta.raw_d_out_f(d_out.data_ptr(), dt(ora.tc).data_ptr(), dt(hs).data_ptr(), n)
+        exp = np.stack([ora._dense(i, hs[i]) for i in range(n)], axis=1)
+        assert rel_err(d_out.cpu().numpy().reshape(12, n), exp) <= 4 * EPS
+
+    # ---- c_step_f_t: a compact-mode stepper (tape in HBM) on a caller-owned tape.
+    n = 4096
+    st = configs.plummer_nbody_state(4, n, seed=5)
+    ta = hy.taylor_adaptive_batch(hy.model.nbody(4), st, n, compact_mode=True)
+    assert "tape in HBM" in ta.hip_source_mode, ta.hip_source_mode
+    size, align = ta.raw_tape_size_align(n)
+    assert size > 0 and align >= 8
+    tape = torch.empty(size // 8 + align // 8, device=dev, dtype=torch.float64)
+    tptr = (tape.data_ptr() + align - 1) // align * align
+    res = []
+    for use_tape in (False, True):
+        d_state, d_time, d_h = dt(st), dt(np.zeros(n)), dt(np.full(n, np.inf))
+        d_tc = torch.zeros(24 * (ta.order + 1) * n, device=dev, dtype=torch.float64)
+        ta.raw_step(d_state.data_ptr(), 0, d_time.data_ptr(), d_h.data_ptr(), d_tc.data_ptr(), n, d_tape=tptr if use_tape else None)
+        res.append((d_state.cpu().numpy(), d_h.cpu().numpy(), d_tc.cpu().numpy()))
+    for a_, b_ in zip(res[0], res[1]):
+        assert np.array_equal(a_, b_)
+    # (A stepper which keeps its coefficients on chip needs no tape.)
+    assert hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), None, 64).raw_tape_size_align(64)[0] == 0
+
+
 def test_device_array_views_and_ensemble():
     import torch
 
