@@ -202,9 +202,6 @@ device_module::device_module(std::shared_ptr<const compiled_module> cm, int devi
             (void)hipGetLastError();
             per_cu = 1;
         }
-        if (const char *env = std::getenv("HEYOKA_AMD_BLOCKS_PER_CU")) {
-            per_cu = std::max(1, std::atoi(env));
-        }
         m_impl->max_grid = static_cast<unsigned>(std::max(1, n_cu) * std::max(1, per_cu));
     }
     for (int i = 0; i < impl::n_ev; ++i) {

@@ -725,8 +725,7 @@ emitted_module emit_unrolled(const taylor_program &p, const emit_options &opts)
     emitted_module ret;
     // Register-resident jets when they fit comfortably in the 512 VGPR+AGPR of a lane.
     // NOTE: the stepper with events needs the Taylor coefficients in memory (event detection, dense output).
-    const bool reg_jets = p.ev_u.empty() && reg_jet_estimate(p, opts.order) <= 200u
-                          && std::getenv("HEYOKA_AMD_NO_REG_JETS") == nullptr;
+    const bool reg_jets = p.ev_u.empty() && reg_jet_estimate(p, opts.order) <= 200u;
     if (reg_jets) {
         src << emit_unrolled_kernel(p, opts, "hy_taylor", true, ret.n_statements);
         // NOTE: the variant serving write_tc streams the coefficients out of the same register-resident code (round 1
@@ -791,10 +790,7 @@ emitted_module emit_event_jets(const taylor_program &p, const emit_options &opts
         }
     }
     // NOTE: straight-line code with the histories in registers, like the unrolled stepper.
-    std::uint32_t max_nodes = 40;
-    if (const char *ev = std::getenv("HEYOKA_AMD_EV_JETS_MAX_NODES")) {
-        max_nodes = static_cast<std::uint32_t>(std::max(0, std::atoi(ev)));
-    }
+    const std::uint32_t max_nodes = 40;
     if (n_nodes > max_nodes && !opts.ev_helpers_only) {
         why_not = "the event equations depend on " + std::to_string(n_nodes) + " nodes of the decomposition (limit: "
                   + std::to_string(max_nodes) + ")";
@@ -1155,11 +1151,6 @@ bool emit_event_jets_inline(const taylor_program &p, const emit_options &opts,
                     has_conv = has_conv || !linear_node(p.nodes[u - n_eq]);
                 }
             }
-            if (std::getenv("HEYOKA_AMD_EV_DEBUG") != nullptr) {
-                std::fprintf(stderr, "[event lanes] sum u_%u: %zu new term(s)%s: %s (%s)\n", S, cand_pos.size(),
-                             ext >= 0 ? " added to an earlier sum" : "", (ok && has_conv) ? "side by side" : "no",
-                             sigs.empty() ? "" : sigs.back().c_str());
-            }
             if (!ok || !has_conv) {
                 continue;
             }
@@ -1204,8 +1195,8 @@ bool emit_event_jets_inline(const taylor_program &p, const emit_options &opts,
         n_nonlin += linear ? 0u : (n.kind == func_kind::sum_sq ? static_cast<std::uint32_t>((n.args.size() + 1u) / 2u) : 1u);
     }
     std::uint32_t max_nonlin = 3, max_nodes = 40;
-    if (const char *ev = std::getenv("HEYOKA_AMD_EV_INLINE_MAX_NONLINEAR")) {
-        max_nonlin = static_cast<std::uint32_t>(std::max(0, std::atoi(ev)));
+    if (opts.dev.ev_inline_max_nonlinear >= 0) {
+        max_nonlin = static_cast<std::uint32_t>(opts.dev.ev_inline_max_nonlinear);
         max_nodes = std::max(max_nodes, 12u * max_nonlin);
     }
     if (n_nonlin > max_nonlin || n_nodes > max_nodes) {
@@ -1440,6 +1431,38 @@ std::string program_to_string(const taylor_program &p)
     return oss.str();
 }
 
+dev_switches dev_switches::from_env()
+{
+    dev_switches d;
+    const auto off = [](const char *name) {
+        const char *e = std::getenv(name);
+        return e != nullptr && std::atoi(e) == 0;
+    };
+    const auto set = [](const char *name) { return std::getenv(name) != nullptr; };
+    const auto num = [](const char *name, int dflt) {
+        const char *e = std::getenv(name);
+        return e != nullptr ? std::atoi(e) : dflt;
+    };
+    const auto str = [](const char *name) {
+        const char *e = std::getenv(name);
+        return e != nullptr ? std::string(e) : std::string{};
+    };
+    d.v5_events = !off("HEYOKA_AMD_V5_EVENTS");
+    d.compact_tc = !off("HEYOKA_AMD_COMPACT_TC");
+    d.events_in_stepper = !set("HEYOKA_AMD_NO_EVENTS_IN_STEPPER");
+    d.pair_events = !set("HEYOKA_AMD_NO_PAIR_EVENTS");
+    d.refill = !set("HEYOKA_AMD_NO_REFILL");
+    d.block_v2 = !off("HEYOKA_AMD_BLOCK_V2");
+    d.state_aliases = !set("HEYOKA_AMD_NO_STATE_ALIASES");
+    d.cluster_v1 = set("HEYOKA_AMD_CLUSTER_V1");
+    d.table_lds = num("HEYOKA_AMD_TABLE_LDS", -1);
+    d.ev_inline_max_nonlinear = num("HEYOKA_AMD_EV_INLINE_MAX_NONLINEAR", -1);
+    d.v5_prio = num("HEYOKA_AMD_V5_PRIO", 2);
+    d.v5_opts = str("HEYOKA_AMD_V5_OPTS");
+    d.v5_pad = str("HEYOKA_AMD_V5_PAD");
+    return d;
+}
+
 emitted_module emit_hip_module(const taylor_program &prog, const emit_options &opts)
 {
     if (opts.order < 2u) {
@@ -1452,7 +1475,7 @@ emitted_module emit_hip_module(const taylor_program &prog, const emit_options &o
             std::string why;
             auto m = emit_cluster_or_empty(prog, opts, why);
             if (m.source.empty() && why.rfind("a state variable is a history operand", 0) == 0
-                && std::getenv("HEYOKA_AMD_NO_STATE_ALIASES") == nullptr) {
+                && opts.dev.state_aliases) {
                 // Retry with alias u variables for those state variables (see add_state_aliases()).
                 taylor_program aliased;
                 if (add_state_aliases(prog, aliased)) {
@@ -1471,8 +1494,7 @@ emitted_module emit_hip_module(const taylor_program &prog, const emit_options &o
                     why += "; with state-variable aliases: " + why2;
                 }
             }
-            if (m.source.empty() && why.rfind("clusters are not isomorphic", 0) == 0
-                && std::getenv("HEYOKA_AMD_NO_CLUSTER_PADDING") == nullptr) {
+            if (m.source.empty() && why.rfind("clusters are not isomorphic", 0) == 0) {
                 // Clusters which are sub-shapes of the largest one (test particles next to massive bodies): pad them
                 // in the internal program (see pad_clusters()).
                 taylor_program padded;
@@ -1513,9 +1535,6 @@ emitted_module emit_hip_module(const taylor_program &prog, const emit_options &o
             // (see privatise_cluster_inputs()), then - if needed - the unit scalings and the padding on top of it; wave-cluster
             // kernels, or block mode beyond 64 clusters.
             const auto try_private_inputs = [&](emitted_module &res) {
-                if (std::getenv("HEYOKA_AMD_NO_PRIVATE_INPUTS") != nullptr) {
-                    return false;
-                }
                 taylor_program priv;
                 if (!privatise_cluster_inputs(prog, priv)) {
                     return false;
@@ -1566,12 +1585,8 @@ emitted_module emit_hip_module(const taylor_program &prog, const emit_options &o
                 std::string why_b;
                 // Measured on an MI355X: block mode beats the table-driven one-lane-per-system kernels by 5x
                 // (nbody(12), 66 clusters) to 44x (nbody(64)) - it is used whenever it is applicable.
-                std::uint32_t block_min_clusters = 0;
-                if (const char *ev = std::getenv("HEYOKA_AMD_BLOCK_MIN_CLUSTERS")) {
-                    block_min_clusters = static_cast<std::uint32_t>(std::max(0, std::atoi(ev)));
-                }
                 auto b = emit_block(prog, opts, why_b);
-                if (!b.source.empty() && b.n_clusters >= block_min_clusters) {
+                if (!b.source.empty()) {
                     return b;
                 }
                 why += why_b.empty() ? "; block mode: too few clusters" : ("; block mode: " + why_b);

@@ -57,7 +57,33 @@ struct hy_kargs {
 
 enum class emit_mode { unrolled, cluster, table, block };
 
+// Developer switches of the generators: experiments and the test matrix. ALL of them are read from the environment in ONE
+// place, dev_switches::from_env() (hip_emit.cpp), when an integrator is constructed; the generators only see this struct.
+//   HEYOKA_AMD_V5_EVENTS=0            stepper with events: not on the one-lane-per-pair kernel (lane-pair kernel instead)
+//   HEYOKA_AMD_COMPACT_TC=0           stepper with events: full instead of compact Taylor coefficients
+//   HEYOKA_AMD_NO_EVENTS_IN_STEPPER   event equations in a kernel of their own (hy_ev_jets) instead of inside the stepper
+//   HEYOKA_AMD_NO_PAIR_EVENTS         close-encounter events through the generic statements, not on the lanes of their pairs
+//   HEYOKA_AMD_NO_REFILL              one-lane-per-pair kernel: whole groups of systems from the queue, no per-system refill
+//   HEYOKA_AMD_BLOCK_V2=0             block mode: generic cluster phase
+//   HEYOKA_AMD_NO_STATE_ALIASES       planner: no alias u variables for state variables in history position
+//   HEYOKA_AMD_CLUSTER_V1             first-generation cluster generator
+//   HEYOKA_AMD_TABLE_LDS=0|1          table stepper: tape in HBM / in LDS (default: by size)
+//   HEYOKA_AMD_EV_INLINE_MAX_NONLINEAR  budget of nonlinear nodes of the event equations inside the stepper
+//   HEYOKA_AMD_V5_PRIO, HEYOKA_AMD_V5_OPTS, HEYOKA_AMD_V5_PAD   one-lane-per-pair kernel: issue priorities, round-5 items
+//                                     switched off one by one (A/B harness), sensitivity padding (see hip_emit_cluster2.cpp)
+// (HEYOKA_AMD_EMIT_MODE, HEYOKA_AMD_ONE_LANE, HEYOKA_AMD_PAIR_SPLIT, HEYOKA_AMD_EVENTS_ON_CLUSTER map onto kwargs of the
+// integrator - taylor_adaptive_batch.cpp -; HEYOKA_AMD_HIPRTC_FLAGS, HEYOKA_AMD_SCRATCH_GIB, HEYOKA_AMD_GATHER_RCCL and
+// HEYOKA_AMD_EVENTS_TIMING belong to the runtime, not to code generation.)
+struct dev_switches {
+    bool v5_events = true, compact_tc = true, events_in_stepper = true, pair_events = true, refill = true, block_v2 = true,
+         state_aliases = true, cluster_v1 = false;
+    int table_lds = -1, ev_inline_max_nonlinear = -1, v5_prio = 2;
+    std::string v5_opts, v5_pad;
+    static dev_switches from_env();
+};
+
 struct emit_options {
+    dev_switches dev;
     std::uint32_t order = 20;
     bool high_accuracy = false;
     emit_mode mode = emit_mode::unrolled;

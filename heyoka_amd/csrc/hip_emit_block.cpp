@@ -68,12 +68,6 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
             bs = 128;
         }
     }
-    if (const char *ev = std::getenv("HEYOKA_AMD_BLOCK_SIZE")) {
-        const auto v = std::atoi(ev);
-        if (v == 128 || v == 256 || v == 512 || v == 1024) {
-            bs = static_cast<std::uint32_t>(v);
-        }
-    }
     const auto nc = static_cast<std::uint32_t>(pl.clusters.size());
     const auto ncp = (nc + 63u) / 64u * 64u;
     const auto &t0 = pl.clusters[0];
@@ -96,7 +90,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
     std::vector<char> ext_used(n_ext, 0);
     std::vector<std::uint32_t> ej_slots; // distinct slab slots of the external inputs with LDS jets
     std::vector<std::uint32_t> ej_index; // [x * nc + c] -> index into ej_slots
-    if (std::getenv("HEYOKA_AMD_BLOCK_NO_RECOMPUTE") == nullptr) {
+    {
         std::map<std::uint32_t, std::uint32_t> ext_pos;
         for (std::uint32_t x = 0; x < n_ext; ++x) {
             ext_pos[pl.ext_u[0][x]] = x;
@@ -273,7 +267,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
     const std::uint32_t v2_T = (order - 1u) / 2u + 1u; // index pairs (slots) of the highest order
     std::uint32_t v2_M = 0;
     bool v2 = [&]() {
-        if (const char *ev = std::getenv("HEYOKA_AMD_BLOCK_V2"); ev != nullptr && std::atoi(ev) == 0) {
+        if (!opts.dev.block_v2) {
             return false;
         }
         if (!pp.ok || pp.sc != -1 || pp.rx[0] != -1 || pp.rx[1] != -1 || pp.rx[2] != -1 || n_cst != 0u
@@ -336,17 +330,9 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         if (n_iter <= 1u) {
             return 0;
         }
-        if (const char *ev = std::getenv("HEYOKA_AMD_BLOCK_PREFETCH")) {
-            return std::max(0, std::min(2, std::atoi(ev)));
-        }
         return 0;
     }();
-    const std::uint32_t sched_every = [&]() -> std::uint32_t {
-        if (const char *ev = std::getenv("HEYOKA_AMD_BLOCK_SCHED")) {
-            return static_cast<std::uint32_t>(std::max(1, std::atoi(ev)));
-        }
-        return 4u;
-    }();
+    const std::uint32_t sched_every = 4;
     const auto emit_cluster = [&](std::uint32_t k) {
         if (n_ej != 0u && k + 1u < order) {
             // Record the order-k coefficients of the external inputs (read back from order k + 1 on).
@@ -549,11 +535,8 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         const auto T = v2_T;
         // Developer experiments (timing only, wrong results): 1 = no slots beyond slot 0, 2 = no glue arithmetic, 3 = no LDS
         // reads in the slots, 4 = no tape loads in the slots.
-        const int exp_mode = std::getenv("HEYOKA_AMD_BLOCK_EXP") != nullptr ? std::atoi(std::getenv("HEYOKA_AMD_BLOCK_EXP")) : 0;
+        const int exp_mode = 0;
         std::uint32_t M = 160u / (4u * R);
-        if (const char *ev = std::getenv("HEYOKA_AMD_BLOCK_CACHE_ROWS")) {
-            M = static_cast<std::uint32_t>(std::max(0, std::atoi(ev)));
-        }
         M = std::min(T, std::max(2u, M));
         v2_M = M;
         int s_sq = -1, s_pw = -1;
@@ -627,7 +610,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         const auto oslot_of = [&](std::uint32_t c, int x) {
             return static_cast<std::uint32_t>(pl.slot_of[pl.clusters[c][pl.out_pos[static_cast<std::uint32_t>(x)]]]);
         };
-        bool compact = n_ext == 6u && std::getenv("HEYOKA_AMD_BLOCK_FULL_DESC") == nullptr;
+        bool compact = n_ext == 6u;
         if (compact) {
             for (std::uint32_t side = 0; side < 2u && compact; ++side) {
                 const auto xb = pp.de[0][side];
@@ -721,7 +704,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         };
         std::map<std::uint32_t, merged_sums> merged;
         std::vector<char> group_merged(pl.groups.size(), 0);
-        if (std::getenv("HEYOKA_AMD_BLOCK_NO_MERGE") == nullptr) {
+        {
             for (std::size_t g = 0; g < pl.groups.size(); ++g) {
                 const auto &n0 = p.nodes[pl.groups[g].nodes[0] - n_eq];
                 bool all_var = n0.kind == func_kind::sum && n0.args.size() <= 8u;
@@ -779,7 +762,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                    << "[i_];\n";
                 defs << "#define " << name << " l_" << name << "\n";
             };
-            if (std::getenv("HEYOKA_AMD_BLOCK_NO_LDS_TABLES") == nullptr) {
+            {
                 mirror("hy_dsc", static_cast<std::size_t>(n_dw) * nc, "unsigned", 4u);
                 for (const auto &[name, n] : utbl_list) {
                     bool unused = false;
@@ -1071,9 +1054,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         // Rounds per pipeline group (the accumulators, descriptors and tape registers of a group are live at the same
         // time: R rounds at once do not fit the register file next to the register copies of the low orders).
         std::uint32_t G = R;
-        if (const char *ev = std::getenv("HEYOKA_AMD_BLOCK_GROUP")) {
-            G = static_cast<std::uint32_t>(std::max(1, std::atoi(ev)));
-        } else if (R > 4u) {
+        if (R > 4u) {
             G = 4;
         }
         G = std::min(G, R);
@@ -1082,10 +1063,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         // (Measured on nbody(64), 65 536 systems, rows < 5 in registers: depth 1 / 2 / 3 / 4 with groups of two rounds =
         // 9.8e5 / 9.7e5 / 8.8e5 / 8.6e5 system-steps/s - the registers of a deeper pipeline cost more than the latency they
         // hide; the kernel is bound by the instruction issue of its single wavefront per SIMD.)
-        std::uint32_t D = 1;
-        if (const char *ev = std::getenv("HEYOKA_AMD_BLOCK_DEPTH")) {
-            D = static_cast<std::uint32_t>(std::max(1, std::atoi(ev)));
-        }
+        const std::uint32_t D = 1;
         // The tape loads of slot i (rounds r0 .. r1 - 1) into the set i % 2.
         const auto gname = [&](const char *b, std::uint32_t i, std::uint32_t r) {
             return std::string(b) + S(i % (D + 1u)) + "_" + S(r);

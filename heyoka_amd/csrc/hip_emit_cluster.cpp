@@ -1746,7 +1746,7 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
 // Returns a module with an empty source (and the reason in why_not) if cluster mode is not applicable.
 emitted_module emit_cluster_or_empty(const taylor_program &p, const emit_options &opts, std::string &why_not)
 {
-    if (std::getenv("HEYOKA_AMD_CLUSTER_V1") == nullptr && opts.cluster_kernel != 1) {
+    if (!opts.dev.cluster_v1 && opts.cluster_kernel != 1) {
         std::string why2;
         auto m = emit_cluster_v2(p, opts, why2);
         if (!m.source.empty()) {

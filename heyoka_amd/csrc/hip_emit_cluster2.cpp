@@ -44,12 +44,11 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     // (profiles/experiments/ab.py compares variants inside one process). Every flag switches OFF one of the round-5 items:
     //   nomsq     three accumulators for the half sums of squares (one per coordinate) instead of one;
     //   nopack2   the final evaluation of a partially filled owner slot as a full two-series pass;
-    const auto v5_flag = [](const char *name) {
-        const char *ev = std::getenv("HEYOKA_AMD_V5_OPTS");
-        if (ev == nullptr) {
+    const auto v5_flag = [&opts](const char *name) {
+        if (opts.dev.v5_opts.empty()) {
             return false;
         }
-        std::string s = std::string(",") + ev + ",";
+        std::string s = std::string(",") + opts.dev.v5_opts + ",";
         std::replace(s.begin(), s.end(), '+', ','); // ('+' separates flags where ',' separates variables: ab.py)
         return s.find(std::string(",") + name + ",") != std::string::npos;
     };
@@ -81,14 +80,10 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     const bool pp_shape_ok = pp.ok;
     {
         const bool ok = pp.ok;
-        const char *ev = std::getenv("HEYOKA_AMD_PAIR_SPLIT");
         // NOTE: up to 32 pairs. With 17 .. 32 pairs there is one system per wavefront (64 lanes per system); in round 2
         // that variant did not terminate on the hardware: a finished system kept taking steps whose length was only
         // clamped to zero (a nan from the selector of a non-finite state survives the clamp), fixed by forcing h = 0.
-        const char *evm = std::getenv("HEYOKA_AMD_PAIR_SPLIT_MAX_LANES");
-        const auto max_lanes = evm != nullptr ? static_cast<std::uint32_t>(std::atoi(evm)) : 64u;
-        pp.ok = ok && 2u * nc <= max_lanes && p.n_par == 0u && !(ev != nullptr && std::atoi(ev) == 0)
-                && (opts.cluster_kernel == 0 || opts.cluster_kernel >= 3);
+        pp.ok = ok && 2u * nc <= 64u && p.n_par == 0u && (opts.cluster_kernel == 0 || opts.cluster_kernel >= 3);
     }
     const bool m4 = opts.event_stepper;
     // ---- 0b. One lane per pair, two wavefronts per SIMD ("v5"): the lane-pair split halves the histories a lane keeps
@@ -103,21 +98,15 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     // defined by a glue node) are stored, the coefficients of the position-type ones (x' = v) are re-derived in the final
     // evaluation as x^[k] = v^[k-1] * RN(1 / k) - the very operation which produced them.
     const bool one_lane = [&]() {
-        const char *ev = std::getenv("HEYOKA_AMD_ONE_LANE");
-        if (!allow_one_lane || (ev != nullptr && std::atoi(ev) == 0)) {
+        if (!allow_one_lane) {
             return false;
         }
         // (The derived position jets rely on the reciprocal form of the division by the order.)
         // (Stepper with events: this kernel keeps exactly the COMPACT set of Taylor coefficients - velocity-type jets and
         // the current values of the position-type variables -, see emitted_module::compact_tc; HEYOKA_AMD_V5_EVENTS=0 and
         // HEYOKA_AMD_COMPACT_TC=0 keep the stepper with events on the lane-pair kernel.)
-        const auto env_off = [](const char *name) {
-            const char *e = std::getenv(name);
-            return e != nullptr && std::atoi(e) == 0;
-        };
-        const bool m4_ok = !m4 || (!env_off("HEYOKA_AMD_V5_EVENTS") && !env_off("HEYOKA_AMD_COMPACT_TC"));
-        return pp_shape_ok && p.n_par == 0u && m4_ok && nc <= 64u && !opts.exact_division
-               && std::getenv("HEYOKA_AMD_V3_EXACT_DIV") == nullptr && std::getenv("HEYOKA_AMD_V3_POW_DIV") == nullptr;
+        const bool m4_ok = !m4 || (opts.dev.v5_events && opts.dev.compact_tc);
+        return pp_shape_ok && p.n_par == 0u && m4_ok && nc <= 64u && !opts.exact_division;
     }();
     if (one_lane) {
         pp.ok = false;
@@ -185,10 +174,8 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
         pl.n_slots = ns;
     }
     const auto L = pl.L, spw = pl.spw;
-    // NOTE: HEYOKA_AMD_V2_BS overrides the block size (experiments). Lane pairs: 512 threads = two wavefronts per SIMD.
-    const std::uint32_t bs = std::getenv("HEYOKA_AMD_V2_BS") != nullptr
-                                 ? static_cast<std::uint32_t>(std::atoi(std::getenv("HEYOKA_AMD_V2_BS")))
-                                 : (pairk ? 512u : 256u);
+    // (Lane pairs / one lane per pair: 512 threads = two wavefronts per SIMD.)
+    const std::uint32_t bs = pairk ? 512u : 256u;
     const std::uint32_t wpb = bs / 64u;
     const auto n_ext = static_cast<std::uint32_t>(pl.ext_u[0].size());
     const auto n_out = static_cast<std::uint32_t>(pl.out_pos.size());
@@ -293,10 +280,9 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     std::vector<std::uint32_t> rx_src(p.n_u, 0);
     bool fuse_rx = false;
     if (pairk && pp.rx[0] >= 0) {
-        const char *ev = std::getenv("HEYOKA_AMD_V3_FUSE_RX");
         // (One-lane pair kernel: the reactions are computed and exported by the pair lane - the slab of a system is
         // single-buffered there and has room for them - so that the sums need no per-lane coefficients: 20 registers.)
-        fuse_rx = !(ev != nullptr && std::atoi(ev) == 0) && !one_lane;
+        fuse_rx = !one_lane;
         for (std::size_t c = 0; c < nc; ++c) {
             for (std::uint32_t i = 0; i < 3u; ++i) {
                 const auto u = pl.clusters[c][static_cast<std::uint32_t>(pp.rx[i])];
@@ -494,7 +480,7 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
                 slab_stride_opt = st_;
             }
         }
-        if (std::getenv("HEYOKA_AMD_V5_NO_BANK_SEARCH") == nullptr) {
+        {
             std::uint64_t rng = 0x9E3779B97F4A7C15ull;
             const auto next = [&]() {
                 rng ^= rng << 13;
@@ -1029,7 +1015,7 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     // Lane-pair kernel: x^[k+1] = f^[k] * RN(1 / (k + 1)) - one multiplication, within 1 ulp of the quotient - instead of
     // the exact 3-operation sequence (60 VALU instructions per step, +2.1 % system-steps/s; the strict-contraction parity
     // test passes its 1e4 / 1e5 eps bounds with it). HEYOKA_AMD_V3_EXACT_DIV=1 restores the correctly-rounded quotient.
-    e.recip_div = pairk && !opts.exact_division && std::getenv("HEYOKA_AMD_V3_EXACT_DIV") == nullptr;
+    e.recip_div = pairk && !opts.exact_division;
     e.enable_pow_rcp(!opts.exact_division);
 
     // Lane-pair variant: lane l = 2 * pair + role (role 0 = A: d_0, d_1; role 1 = B: d_2 and the pow); the lanes
@@ -1350,8 +1336,7 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     const auto lds_doubles_slab = static_cast<std::uint64_t>(wpb) * spw * slab_stride;
     // (Mode 4: plus the source table of the cooperative store of the Taylor coefficients, 4 bytes per row.)
     const auto lds_tc_table_bytes = m4 ? static_cast<std::uint64_t>(n_eq) * (order + 1u) * 8u : 0u;
-    const bool jet_lds = (lds_doubles_slab + wpb * jet_doubles_per_wave) * 8u + lds_tc_table_bytes <= 160u * 1024u
-                         && std::getenv("HEYOKA_AMD_JET_GLOBAL") == nullptr;
+    const bool jet_lds = (lds_doubles_slab + wpb * jet_doubles_per_wave) * 8u + lds_tc_table_bytes <= 160u * 1024u;
     if (vexch && (!jet_lds || n_dcol != n_col)) {
         why_not = "one-lane pair kernel: the velocity exchange needs the jets in LDS and one position per velocity";
         return ret;
@@ -1366,10 +1351,8 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
         if (one_lane) {
             return true;
         }
-        if (const char *ev = std::getenv("HEYOKA_AMD_COMPACT_TC")) {
-            if (std::atoi(ev) == 0) {
-                return false;
-            }
+        if (!opts.dev.compact_tc) {
+            return false;
         }
         // (Chains x' = v, v' = a only: the parent of a derived variable is not derived itself.)
         const auto derived = [&](std::uint32_t var) {
@@ -1431,8 +1414,7 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
                 return false;
             }
         }
-        const char *ev = std::getenv("HEYOKA_AMD_V3_MERGED");
-        return !(ev != nullptr && std::atoi(ev) == 0);
+        return true;
     }();
     if (one_lane && !merged) {
         why_not = "one-lane pair kernel: the merged schedule does not apply";
@@ -1605,12 +1587,7 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     // order k. Measured on gfx950 (outer-SS, 1 048 576 systems): 18.11 ms per launch for 1, 2 and 3 parts
     // - the chains only touch registers, so the compiler's scheduler already moves them across the
     // compiler-only HY_WSYNC barrier. Hence the default of a single part.
-    const std::uint32_t n_parts = [&]() -> std::uint32_t {
-        if (const char *ev = std::getenv("HEYOKA_AMD_PARTIAL_SPLIT")) {
-            return std::max(1, std::atoi(ev));
-        }
-        return 1u;
-    }();
+    const std::uint32_t n_parts = 1;
     std::vector<std::uint32_t> t0_ids;
     for (const auto u : t0) {
         t0_ids.push_back(u - n_eq);
@@ -1621,23 +1598,8 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     // scheduling barriers - a chunk of history-chain FMAs which do not depend on them, then the dependent
     // computation. The chunks are (ssa_emitter::emit_partials_sel): in the cluster region of order k the second
     // half of the early terms of order k + 1; in the last glue region of order k the late terms of order k + 1
-    // and the first half of the early terms of order k + 2. HEYOKA_AMD_V2_OVERLAP=0 restores the previous
-    // schedule (whole history chain of order k + 1 at the end of order k, placement left to the compiler).
-    const bool overlap = [&]() {
-        if (const char *ev = std::getenv("HEYOKA_AMD_V2_OVERLAP")) {
-            return std::atoi(ev) != 0;
-        }
-        return true;
-    }();
-    if (const char *ev = std::getenv("HEYOKA_AMD_V2_EARLY_A_PCT")) {
-        e.early_a_pct = static_cast<std::size_t>(std::max(0, std::min(100, std::atoi(ev))));
-    }
-    const bool fence2 = [&]() {
-        if (const char *ev = std::getenv("HEYOKA_AMD_V2_FENCE2")) {
-            return std::atoi(ev) != 0;
-        }
-        return true;
-    }();
+    // and the first half of the early terms of order k + 2.
+    const bool overlap = true, fence2 = true;
     const auto sched_fence = [&]() { os << "__builtin_amdgcn_sched_barrier(0);\n"; };
     using psel = ssa_emitter::part_sel;
 
@@ -1657,20 +1619,12 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     std::string hc1, hc2, hc3, hc4, hmid;
     const bool has_rx = pp.rx[0] >= 0;
     std::string rb1;   // 1 / b_0 (lane B)
-    // (Experiment switch: the previous formulation, q = num / (k b_0) with r = RN(1 / b_0) RN(1 / k).)
-    const bool div_by_kb0 = [&]() {
-        const char *ev = std::getenv("HEYOKA_AMD_V3_DIV_KB0");
-        return ev != nullptr && std::atoi(ev) != 0;
-    }();
     // Normalised pow recurrence (default): lane B keeps b_k / b_0 (k >= 1) instead of b_k, one multiplication by
     // RN(1 / b_0) folded into the FMA which forms the lane's aP[k]; the recurrence k b_0 a_k = sum(...) then needs no
     // division: a_k = alpha S1 - (alpha + 1) S2 / k on the normalised sums. The new coefficient goes to both lanes of
-    // the pair with one DPP broadcast from the odd lane. HEYOKA_AMD_V3_POW_DIV=1: the previous formulation (quotient by
-    // b_0 with a Markstein correction, within 1.5 ulp of the reference's single division).
-    const bool pow_norm = [&]() {
-        const char *ev = std::getenv("HEYOKA_AMD_V3_POW_DIV");
-        return !(ev != nullptr && std::atoi(ev) != 0) && !div_by_kb0 && !opts.exact_division;
-    }();
+    // the pair with one DPP broadcast from the odd lane. kw::exact_division: the quotient by b_0 with a Markstein
+    // correction, within 1.5 ulp of the reference's single division.
+    const bool pow_norm = !opts.exact_division;
     std::string ap0x2; // 2 aP[0]
     const auto emit_pair_reads = [&](std::uint32_t k) {
         const auto rd = [&](std::size_t t) { return e.def(slabk(k, utname(t))); };
@@ -1734,19 +1688,10 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
             // q = q0 + rem * r (Markstein: the correctly-rounded n / b_0 unless r is off by more than an ulp in a
             // halfway case; n itself carries the rounding of the scaling by 1 / k, so q is within 1.5 ulp of the
             // quotient num / (k b_0) the reference rounds once).
-            std::string sab;
-            if (div_by_kb0) {
-                const auto dv = e.def(ssa_emitter::mul(fp_literal(static_cast<double>(k)), aP[0]));
-                const auto rk = (k == 1u) ? rb1 : e.def(ssa_emitter::mul(rb1, fp_literal(1. / static_cast<double>(k))));
-                const auto q0 = e.def(ssa_emitter::mul(num, rk));
-                const auto rem = e.def("__builtin_fma(-" + dv + ", " + q0 + ", " + num + ")");
-                sab = e.def("__builtin_fma(" + rem + ", " + rk + ", " + q0 + ")");
-            } else {
-                const auto nk = (k == 1u) ? num : e.def(ssa_emitter::mul(num, fp_literal(1. / static_cast<double>(k))));
-                const auto q0 = e.def(ssa_emitter::mul(nk, rb1));
-                const auto rem = e.def("__builtin_fma(-" + aP[0] + ", " + q0 + ", " + nk + ")");
-                sab = e.def("__builtin_fma(" + rem + ", " + rb1 + ", " + q0 + ")");
-            }
+            const auto nk = (k == 1u) ? num : e.def(ssa_emitter::mul(num, fp_literal(1. / static_cast<double>(k))));
+            const auto q0 = e.def(ssa_emitter::mul(nk, rb1));
+            const auto rem = e.def("__builtin_fma(-" + aP[0] + ", " + q0 + ", " + nk + ")");
+            const auto sab = e.def("__builtin_fma(" + rem + ", " + rb1 + ", " + q0 + ")");
             const auto sao = e.def("hy_swap1(" + sab + ")");
             aR[k] = e.def(sab + " + " + sao);
             }
@@ -1821,8 +1766,8 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     // and LDS reads in the dependent section, scalar no-ops - without touching the results: the slope of the step time
     // against each count says which resource the kernel is bound by.
     unsigned pad_chain = 0, pad_dep = 0, pad_st = 0, pad_ld = 0, pad_salu = 0;
-    if (const char *ev = std::getenv("HEYOKA_AMD_V5_PAD")) {
-        std::sscanf(ev, "%u:%u:%u:%u:%u", &pad_chain, &pad_dep, &pad_st, &pad_ld, &pad_salu);
+    if (!opts.dev.v5_pad.empty()) {
+        std::sscanf(opts.dev.v5_pad.c_str(), "%u:%u:%u:%u:%u", &pad_chain, &pad_dep, &pad_st, &pad_ld, &pad_salu);
     }
     const bool any_pad = (pad_chain | pad_dep | pad_st | pad_ld | pad_salu) != 0u;
     // One accumulator for the half sum of squares bh_k = sum_i (sum_j d_i[k-j] d_i[j] + 1/2 d_i[k/2]^2): the three chains
@@ -1837,7 +1782,7 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     // that the wavefront which is in its critical section wins the VALU over the one streaming FMAs.
     // Measured (outer Solar System, 1 048 576 systems, A/B harness): 7.02e8 -> 7.15e8 system-steps/s; on by default,
     // HEYOKA_AMD_V5_PRIO=0 switches it off, =2 also keeps the serial tail of the step at the high priority.
-    const int prio_mode = std::getenv("HEYOKA_AMD_V5_PRIO") != nullptr ? std::atoi(std::getenv("HEYOKA_AMD_V5_PRIO")) : 2;
+    const int prio_mode = opts.dev.v5_prio;
     const bool prio_switch = prio_mode != 0;
     const auto emit_single_reads = [&](std::uint32_t k) {
         std::vector<std::string> r(6);
@@ -2060,7 +2005,7 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
 
     // ===================== step body =====================
     os << "double m0 = 0.0, mo = 0.0, mom1 = 0.0;\n";
-    if (one_lane && std::getenv("HEYOKA_AMD_V5_PAD") != nullptr) {
+    if (one_lane && !opts.dev.v5_pad.empty()) {
         os << "double hy_pad0 = 1.0, hy_pad1 = 1.0, hy_pad2 = 1.0, hy_pad3 = 1.0, hy_pad4 = 1.0;\n";
     }
     for (auto &rg : rounds) {
@@ -2114,7 +2059,6 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
             // Round k of the one-lane kernel: LDS reads | early chains of order k + 1 (independent of the reads) | glue of
             // order k - 1 (consumes its ten operands right away: 20 registers which would otherwise stay live across
             // the finishing operations of the pairs) | finishing of order k, stores, late chains.
-            static const bool glue_first = std::getenv("HEYOKA_AMD_V5_GLUE_LAST") == nullptr;
             if (prio_switch) {
                 os << "__builtin_amdgcn_s_setprio(3);\n";
             }
@@ -2123,17 +2067,10 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
                 sched_fence();
             }
             for (const auto &[g, r, names] : pend) {
-                if (glue_first) {
-                    emit_glue_compute(g, r, k - 1u, names);
-                }
+                emit_glue_compute(g, r, k - 1u, names);
             }
             if (k < order) {
                 emit_single_compute(k, prd);
-            }
-            for (const auto &[g, r, names] : pend) {
-                if (!glue_first) {
-                    emit_glue_compute(g, r, k - 1u, names);
-                }
             }
             if (k < order) {
                 emit_single_history(k);
@@ -2195,7 +2132,7 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
             sync();
         }
     }
-    if (one_lane && std::getenv("HEYOKA_AMD_V5_PAD") != nullptr) {
+    if (one_lane && !opts.dev.v5_pad.empty()) {
         os << "asm volatile(\"\" ::\"v\"(hy_pad4));\n";
     }
     const auto body = os.str();
@@ -2216,10 +2153,7 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     // bookkeeping of the propagation mode, ~900 instructions per group of systems around a single step, is not generated.)
     src << "#define HY_MODE " << (m4 ? "4" : "a.mode") << "\n";
     // (The stepper with events always uses the static schedule: its cooperative store has workgroup barriers.)
-    src << "#define HY_NO_STATIC " << ((!m4 && std::getenv("HEYOKA_AMD_NO_STATIC_SCHEDULE") != nullptr) ? 1 : 0) << "\n";
-    if (std::getenv("HEYOKA_AMD_NO_NMAX") != nullptr) {
-        src << "#define HY_NO_NMAX 1\n";
-    }
+    src << "#define HY_NO_STATIC 0\n";
     src << prelude;
     emit_detail::emit_dout(src, p, opts);
     src << emit_detail::wsync_macro;
@@ -2477,7 +2411,7 @@ __device__ __forceinline__ double hy_swap1(double x)
     // the pickup of a group and ahead of every store of its results is a vector load, and gfx9 counts loads and stores in
     // ONE in-order counter (vmcnt) - the address of each group of stores then waits for the acknowledgement of all the
     // stores before it (four owner slots: four round trips per group of systems; with the table in LDS: none).
-    if (std::getenv("HEYOKA_AMD_NO_LDS_UTBL") == nullptr) {
+    {
         const auto n_ut = std::max<std::size_t>(utbl.size(), 1u) * L;
         src << "__shared__ unsigned short lds_utbl[" << n_ut << "];\n";
         src << "for (unsigned i = threadIdx.x; i < " << n_ut << "u; i += " << bs << "u) lds_utbl[i] = hy_utbl[i];\n";
@@ -2552,9 +2486,9 @@ __device__ __forceinline__ double hy_swap1(double x)
     std::map<std::uint32_t, double> pe_lane_sign; // (-1: the event equation is c - |r_i - r_j|^2)
     std::string ev_code;
     std::vector<std::vector<std::string>> ev_coeffs;
-    const bool packed_tail_ev = L >= 4u && std::getenv("HEYOKA_AMD_NO_PACKED_TAIL") == nullptr;
+    const bool packed_tail_ev = L >= 4u;
     if (m4 && one_lane && jet_lds && packed_tail_ev && opts.ev_prog != nullptr && !opts.exact_division && slab_stride >= n_own * L
-        && std::getenv("HEYOKA_AMD_NO_EVENTS_IN_STEPPER") == nullptr) {
+        && opts.dev.events_in_stepper) {
         struct sv_loc {
             bool derived = false;
             std::uint64_t off = 0;
@@ -2600,7 +2534,7 @@ __device__ __forceinline__ double hy_swap1(double x)
         };
         // (With the exclusion test below the jets of the event equations are stored behind it, and only by wavefronts in which
         // an event is possible: the detection kernel does not read the jets of the systems the test has ruled out.)
-        const bool ev_store_late = std::getenv("HEYOKA_AMD_EVENTS_ALL_TC") == nullptr;
+        const bool ev_store_late = true;
         const std::function<std::string(std::uint32_t, std::uint32_t, const std::string &)> ev_store
             = [&](std::uint32_t ev, std::uint32_t k, const std::string &v) {
                   if (ev_store_late) {
@@ -2628,24 +2562,17 @@ __device__ __forceinline__ double hy_swap1(double x)
             return "__shfl(" + v + ", (int)((threadIdx.x & " + std::to_string(64u - L) + "u) + " + std::to_string(c) + "u), 64)";
         };
         std::string why_ev;
-        const bool use_lanes = std::getenv("HEYOKA_AMD_NO_EVENT_LANES") == nullptr;
+        const bool use_lanes = true;
         // Close encounters: an event equation |r_i - r_j|^2 + c is, up to the constant, the squared distance whose Taylor
         // coefficients the lane of the pair (i, j) holds as the history of its pow recurrence (sB: b_k / b_0). Such events are
         // not evaluated at all: the lane of the pair contributes its history - one event per lane, every lane at the same
         // time (one exclusion test, one set of stores for ALL of them); order p, which the recursion of the state does not
         // need, costs one more convolution from the order-p coefficients of the positions.
         std::vector<char> ev_on_lane(opts.ev_prog->ev_u.size(), 0);
-        if (pairk && ev_store_late && std::getenv("HEYOKA_AMD_NO_PAIR_EVENTS") == nullptr) {
+        if (pairk && ev_store_late && opts.dev.pair_events) {
             for (std::size_t ev = 0; ev < opts.ev_prog->ev_u.size(); ++ev) {
                 pair_distance_event pe;
                 const bool pe_ok = match_pair_distance_event(*opts.ev_prog, opts.ev_prog->ev_u[ev], pe);
-                if (std::getenv("HEYOKA_AMD_EV_DEBUG") != nullptr) {
-                    std::fprintf(stderr, "[pair events] event %zu: %s", ev, pe_ok ? "squared distance" : "other\n");
-                    if (pe_ok) {
-                        std::fprintf(stderr, " (%u,%u) (%u,%u) (%u,%u) + %g\n", pe.diffs[0].first, pe.diffs[0].second, pe.diffs[1].first,
-                                     pe.diffs[1].second, pe.diffs[2].first, pe.diffs[2].second, pe.c);
-                    }
-                }
                 if (!pe_ok) {
                     continue;
                 }
@@ -2676,10 +2603,6 @@ __device__ __forceinline__ double hy_swap1(double x)
                                                   use_lanes ? &hooks : nullptr, &ev_on_lane);
         if (!ev_ok) {
             pe_lane_ev.clear();
-        }
-        if (std::getenv("HEYOKA_AMD_EV_DEBUG") != nullptr) {
-            std::fprintf(stderr, "[events in the stepper] %s%s; %zu leaf positions on the lanes\n", ev_ok ? "yes" : "no: ", why_ev.c_str(),
-                         hooks.leaf_vars.size());
         }
         if (ev_ok) {
             ev_inline = true;
@@ -2804,7 +2727,7 @@ const bool hy_tc_only = HY_M4 && ((a.pad & 2) != 0);
     // a tail, read back at the beginning of the next one - instead of being spilled to scratch by the register
     // allocator, whose reloads are scattered over the tail and each wait for a round trip through the vector memory
     // path. Every lane of a system holds the same values and stores them to the same address.
-    const bool bk_lds = one_lane && std::getenv("HEYOKA_AMD_NO_BK_LDS") == nullptr;
+    const bool bk_lds = one_lane;
     const char *bk_fields_d[] = {"t_hi", "t_lo", "tfin.hi", "tfin.lo", "rem.hi", "rem.lo", "mdt", "step_lim", "min_h", "max_h", "last_h"};
     // (which = 0: every field; 1: the fields a step changes; 2: the others - final time and limits, which only change when a
     // system is picked up: an LDS store is the most expensive instruction of the kernel.)
@@ -2887,9 +2810,9 @@ const bool hy_tc_only = HY_M4 && ((a.pad & 2) != 0);
     // Packed tail (L >= 4): after the two stages inside the quads the three norms move to three lanes of every quad
     // (lane & 3 = 0: |x|, 1: |x^[p]|, 2 and 3: |x^[p-1]|) and the remaining stages reduce ONE value instead of three;
     // the logarithm of the selector is then evaluated once, on the packed lanes (hy_sel_log above).
-    const bool packed_tail = L >= 4u && std::getenv("HEYOKA_AMD_NO_PACKED_TAIL") == nullptr;
+    const bool packed_tail = L >= 4u;
     const auto red_ex = [&](std::uint32_t m, const char *v) -> std::string {
-        const bool dpp_ok = std::getenv("HEYOKA_AMD_NO_DPP_REDUCE") == nullptr;
+        const bool dpp_ok = true;
         if (dpp_ok && m == 1u) {
             return std::string("hy_dpp<0xB1>(") + v + ")";
         }
@@ -2964,16 +2887,9 @@ const bool hy_tc_only = HY_M4 && ((a.pad & 2) != 0);
         src << "const double rho_m = " << (sel_scalar ? "hy_sel_exp_s" : "exp") << "(hy_min(lr_o, lr_om1));\n";
     } else {
         src << "const double num_rho = (m0 <= 1.0) ? 1.0 : m0;\n";
-        if (std::getenv("HEYOKA_AMD_RHO_2EXP") != nullptr) {
-            src << "const double rho_o = hy_root(num_rho / mo, " << fp_literal(1. / static_cast<double>(order)) << ");\n";
-            src << "const double rho_om1 = hy_root(num_rho / mom1, " << fp_literal(1. / static_cast<double>(order - 1u))
-                << ");\n";
-            src << "const double rho_m = hy_min(rho_o, rho_om1);\n";
-        } else {
-            src << "const double lr_o = log(num_rho / mo) * " << fp_literal(1. / static_cast<double>(order)) << ";\n";
-            src << "const double lr_om1 = log(num_rho / mom1) * " << fp_literal(1. / static_cast<double>(order - 1u)) << ";\n";
-            src << "const double rho_m = exp(hy_min(lr_o, lr_om1));\n";
-        }
+        src << "const double lr_o = log(num_rho / mo) * " << fp_literal(1. / static_cast<double>(order)) << ";\n";
+        src << "const double lr_om1 = log(num_rho / mom1) * " << fp_literal(1. / static_cast<double>(order - 1u)) << ";\n";
+        src << "const double rho_m = exp(hy_min(lr_o, lr_om1));\n";
     }
     if (bk_lds) {
         bk_load();
@@ -3000,7 +2916,7 @@ lim = fin ? 0.0 : lim;
     // the double-length time, the remaining time, the state and the step counters then reproduce themselves bit by bit,
     // and only the values which a zero-length step would overwrite need a select below (last_h, outcome).
     src << "h = fin ? 0.0 : h;\n";
-    if (ev_inline && std::getenv("HEYOKA_AMD_EVENTS_ALL_TC") == nullptr) {
+    if (ev_inline) {
         // On-demand Taylor coefficients. Behind a step with events nothing reads the coefficients of the state variables
         // unless an event is detected (its callback may ask for dense output) or the caller asks for them. The stepper
         // runs the fast exclusion test of the detection (interval Horner enclosure of the event polynomial over the
@@ -3329,7 +3245,7 @@ int nfi = !(hy_finite(nt_hi) && hy_finite(nt_lo)) ? 1 : 0;
     // that some system of the wavefront has just finished. (The reference's lanes idle like the old loop:
     // src/taylor_adaptive_batch.cpp:1378-1460.)
     const bool refill = one_lane && !m4 && jet_lds && p.n_par == 0u && lane_par_tbls.empty() && L < 64u
-                        && std::getenv("HEYOKA_AMD_NO_REFILL") == nullptr;
+                        && opts.dev.refill;
     if (refill) {
         src << "if (!hy_static && !hy_queue_empty && __builtin_amdgcn_ballot_w64(fin) != 0ull) {\n";
         // 1. Retire.

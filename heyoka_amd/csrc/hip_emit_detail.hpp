@@ -1153,7 +1153,7 @@ struct ssa_emitter {
     bool pow_rcp = false;
     void enable_pow_rcp(bool on = true)
     {
-        pow_rcp = on && std::getenv("HEYOKA_AMD_EXACT_POW_DIV") == nullptr;
+        pow_rcp = on;
     }
     std::map<std::uint32_t, std::string> pow_r0;
     std::string pow_quotient(std::uint32_t u, std::uint32_t b, const std::string &acc, std::uint32_t k)

@@ -998,8 +998,8 @@ emitted_module emit_table(const taylor_program &p, const emit_options &opts)
     // Measured with model::np1body(6) (234 nodes): 3.4e6 vs 4.1e6 system-steps/s at 65 536 systems - the wave-level
     // variant wins below that. HEYOKA_AMD_TABLE_LDS=0 / 1 overrides the choice.
     bool wave_level = tape_bytes <= 64u * 1024u && opts.batch_size != 0u && opts.batch_size <= 32768u;
-    if (const char *ev = std::getenv("HEYOKA_AMD_TABLE_LDS")) {
-        wave_level = tape_bytes <= 64u * 1024u && std::atoi(ev) != 0;
+    if (opts.dev.table_lds >= 0) {
+        wave_level = tape_bytes <= 64u * 1024u && opts.dev.table_lds != 0;
     }
 
     std::ostringstream src;

@@ -526,9 +526,6 @@ tab_core::tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_siz
     if (const char *ev = std::getenv("HEYOKA_AMD_EVENTS_ON_CLUSTER"); ev != nullptr && std::atoi(ev) == 0) {
         d.events_on_cluster = 1;
     }
-    if (const char *ev = std::getenv("HEYOKA_AMD_REFERENCE_BATCH_SEMANTICS"); ev != nullptr && std::atoi(ev) != 0) {
-        d.batch_semantics = 1;
-    }
 
     if (d.N == 0u) {
         throw std::invalid_argument("The batch size in an adaptive Taylor integrator cannot be zero");
@@ -641,6 +638,7 @@ tab_core::tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_siz
 
     // Code generation + hiprtc compilation (works without a GPU).
     emit_options eo;
+    eo.dev = dev_switches::from_env();
     eo.order = d.order;
     eo.high_accuracy = d.high_accuracy;
     eo.batch_size = d.N;

@@ -334,8 +334,8 @@ def test_raw_stepper_abi_step_e_d_out_f_and_caller_owned_tape(golden):
     ox, ov = ho.var("x"), ho.var("v")
     ta = hy.taylor_adaptive_batch([(x, v), (v, -9.8 * hy.sin(x))], st, n, t_events=[hy.t_event(v)],
                                   nt_events=[hy.nt_event(x, lambda *a: None)])
-    ora = ho.OracleIntegrator([(ox, ov), (ov, -9.8 * ho.sin(ox))], st, n, t_events=[ho.t_event(ov)],
-                              nt_events=[ho.nt_event(ox, lambda *a: None)])
+    ora = ho.OracleEventIntegrator([(ox, ov), (ov, -9.8 * ho.sin(ox))], st, n, t_events=[ho.t_event(ov)],
+                                   nt_events=[ho.nt_event(ox, lambda *a: None)])
     p = ta.order
     h_o, tc_o, evtc_o, mas_o = oracle_step_e(ora, n)
     d_state, d_time, d_h = dt(st), dt(np.zeros(n)), dt(np.full(n, np.inf))
@@ -361,7 +361,8 @@ def test_raw_stepper_abi_step_e_d_out_f_and_caller_owned_tape(golden):
     o1, o2 = ho.var("x_1"), ho.var("x_2")
     ta = hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True,
                                   nt_events=[hy.nt_event(x1 - x2, lambda *a: None)])
-    ora = ho.OracleIntegrator(ho.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True, nt_events=[ho.nt_event(o1 - o2, lambda *a: None)])
+    ora = ho.OracleEventIntegrator(ho.nbody(6, masses=M, Gconst=G), st, n, nt_events=[ho.nt_event(o1 - o2, lambda *a: None)],
+                                   high_accuracy=True)
     p = ta.order
     h_o, tc_o, evtc_o, mas_o = oracle_step_e(ora, n)
     d_state, d_time, d_h = dt(st), dt(np.zeros(n)), dt(np.full(n, np.inf))
