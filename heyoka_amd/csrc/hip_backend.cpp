@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <limits>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -112,6 +113,12 @@ std::shared_ptr<const compiled_module> hiprtc_compile(const emitted_module &m)
     ret->compile_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
     std::lock_guard lock(cache_mutex);
+    // (Bounded: beyond 1024 entries the compiled modules which only the cache still refers to are dropped.)
+    if (module_cache.size() >= 1024u) {
+        for (auto it = module_cache.begin(); it != module_cache.end();) {
+            it = it->second.use_count() == 1 ? module_cache.erase(it) : std::next(it);
+        }
+    }
     module_cache.emplace(cache_key, ret);
     return ret;
 }
@@ -128,27 +135,90 @@ int hip_device_count()
 namespace
 {
 
-// Loaded code objects, per (device, compiled module), kept for the lifetime of the process. Integrators built from the
-// same system share the hipModule_t (construction does not reload it), and nothing is ever unloaded: with this toolchain
-// (ROCm 7.2) a process that loads and unloads many run-time modules and then runs the first kernels of another HIP
-// client (PyTorch's lazily-loaded kernels) intermittently took a GPU memory fault inside that client's kernel; keeping
-// the modules resident removes the unloads from the picture. The code objects are a few tens of KB each.
+// Loaded code objects, per (device, compiled module), reference counted: integrators built from the same system share
+// the hipModule_t (construction does not reload it). A module nobody uses any more is NOT unloaded at once: with this
+// toolchain (ROCm 7.x) a process which loads and unloads many run-time modules and then runs the first kernels of
+// another HIP client (PyTorch's lazily-loaded kernels) intermittently took a GPU memory fault inside that client's
+// kernel. Idle modules stay resident as a cache - a later integrator of the same system gets them back without a reload -
+// up to a bound (256 by default; HEYOKA_AMD_KEEP_MODULES = number, or "all" for the unbounded behaviour of the earlier
+// rounds): beyond it the longest-idle one is unloaded, so that a long-lived process which builds many distinct
+// integrators holds a bounded number of code objects (a few tens of KB each, plus their LDS / scratch descriptors).
+struct loaded_entry {
+    hipModule_t mod = nullptr;
+    std::shared_ptr<const compiled_module> cm;
+    std::uint64_t users = 0, idle_since = 0;
+};
 std::mutex loaded_mutex;
-std::map<std::pair<int, const compiled_module *>, std::pair<hipModule_t, std::shared_ptr<const compiled_module>>>
-    loaded_modules;
+std::map<std::pair<int, const compiled_module *>, loaded_entry> loaded_modules;
+std::uint64_t loaded_tick = 0;
+
+std::size_t idle_module_bound()
+{
+    static const std::size_t bound = [] {
+        const char *ev = std::getenv("HEYOKA_AMD_KEEP_MODULES");
+        if (ev == nullptr) {
+            return std::size_t(256);
+        }
+        if (std::string(ev) == "all") {
+            return std::numeric_limits<std::size_t>::max();
+        }
+        return static_cast<std::size_t>(std::max(0, std::atoi(ev)));
+    }();
+    return bound;
+}
 
 hipModule_t load_module_cached(const std::shared_ptr<const compiled_module> &cm, int device)
 {
     std::lock_guard lock(loaded_mutex);
     const auto key = std::make_pair(device, cm.get());
     if (const auto it = loaded_modules.find(key); it != loaded_modules.end()) {
-        return it->second.first;
+        ++it->second.users;
+        return it->second.mod;
     }
     hip_check(hipSetDevice(device), "hipSetDevice");
     hipModule_t mod = nullptr;
     hip_check(hipModuleLoadData(&mod, cm->code.data()), "hipModuleLoadData");
-    loaded_modules.emplace(key, std::make_pair(mod, cm));
+    loaded_modules.emplace(key, loaded_entry{mod, cm, 1, 0});
     return mod;
+}
+
+// One user less; unloads the longest-idle modules beyond the bound. Never throws (called from destructors, possibly
+// while the process winds down).
+void release_module(const std::shared_ptr<const compiled_module> &cm, int device) noexcept
+{
+    try {
+        std::lock_guard lock(loaded_mutex);
+        const auto it = loaded_modules.find(std::make_pair(device, cm.get()));
+        if (it == loaded_modules.end() || it->second.users == 0u) {
+            return;
+        }
+        if (--it->second.users != 0u) {
+            return;
+        }
+        it->second.idle_since = ++loaded_tick;
+        std::size_t n_idle = 0;
+        for (const auto &[k, e] : loaded_modules) {
+            (void)k;
+            n_idle += e.users == 0u ? 1u : 0u;
+        }
+        while (n_idle > idle_module_bound()) {
+            auto victim = loaded_modules.end();
+            for (auto jt = loaded_modules.begin(); jt != loaded_modules.end(); ++jt) {
+                if (jt->second.users == 0u && (victim == loaded_modules.end() || jt->second.idle_since < victim->second.idle_since)) {
+                    victim = jt;
+                }
+            }
+            if (victim == loaded_modules.end()) {
+                break;
+            }
+            if (hipSetDevice(victim->first.first) == hipSuccess) {
+                (void)hipModuleUnload(victim->second.mod);
+            }
+            loaded_modules.erase(victim);
+            --n_idle;
+        }
+    } catch (...) {
+    }
 }
 
 } // namespace
@@ -220,7 +290,7 @@ device_module::~device_module()
         if (m_impl->scratch != nullptr) {
             (void)hipFree(m_impl->scratch);
         }
-        // NOTE: the module stays loaded (see load_module_cached()).
+        release_module(m_impl->cm, m_impl->device);
     }
 }
 
@@ -373,8 +443,12 @@ aux_module::aux_module(std::shared_ptr<const compiled_module> cm, int device) : 
     m_impl->mod = load_module_cached(m_impl->cm, device);
 }
 
-// NOTE: the module stays loaded (see load_module_cached()).
-aux_module::~aux_module() = default;
+aux_module::~aux_module()
+{
+    if (m_impl && m_impl->mod != nullptr) {
+        release_module(m_impl->cm, m_impl->device);
+    }
+}
 
 int aux_module::device() const
 {

@@ -2340,3 +2340,34 @@ def test_python_exceptions_in_pre_hook_and_in_a_callback_set_stop_the_propagatio
     ref_tc = np.array(tb2.tc).copy()
     tb.step()          # no write_tc: must not disturb what get_tc() returns
     assert np.array_equal(np.asarray(tb.tc), ref_tc)
+
+
+@pytest.mark.gpu
+def test_code_objects_are_reference_counted_and_unloaded_beyond_the_bound():
+    """Code objects are shared between integrators of the same system, reference counted and - once idle - kept as a bounded
+    cache (HEYOKA_AMD_KEEP_MODULES, default 256; earlier rounds never unloaded anything). With a bound of 2 a process which
+    builds and drops ten distinct integrators unloads eight code objects on the way; every integrator steps correctly, an
+    integrator of a system seen before works again (reload), and the kernels of another HIP client (torch) run afterwards."""
+    import subprocess
+    import sys
+
+    code = r"""
+import numpy as np, torch
+import heyoka_amd as hy
+x, v = hy.make_vars("x", "v")
+res = []
+for k in list(range(10)) + [0, 3]:
+    ta = hy.taylor_adaptive_batch([(x, v), (v, -(1.0 + 0.1 * k) * hy.sin(x))], np.array([[0.3] * 64, [0.0] * 64]), 64)
+    ta.propagate_until(1.0)
+    res.append((k, float(ta.state[0, 0])))
+    del ta
+assert res[10][1] == res[0][1] and res[11][1] == res[3][1]
+assert len({r[1] for r in res[:10]}) == 10
+t = torch.arange(1024, device="cuda", dtype=torch.float64)
+assert float((t * 2).sum()) == 1023 * 1024.0
+print("OK")
+"""
+    env = dict(os.environ, HEYOKA_AMD_KEEP_MODULES="2")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and "OK" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
