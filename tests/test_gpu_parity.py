@@ -3,6 +3,8 @@
 Tolerances follow the reference's own tests: single step from identical
 state - h within 1e4 eps, state within 1e5 eps (test/two_body_batch.cpp:118-150); after a
 propagation - 1e3..1e5 eps depending on the number of steps (test/taylor_adaptive_batch.cpp:105-146)."""
+import os
+
 import numpy as np
 import pytest
 
