@@ -396,7 +396,11 @@ std::string emit_unrolled_kernel(const taylor_program &p, const emit_options &op
     // the two-body problem.
     e.recip_div = !opts.exact_division;
 
-    os << "extern \"C\" __global__ void __launch_bounds__(" << bs << ") " << kname << "(const hy_kargs a)\n{\n";
+    os << "extern \"C\" __global__ void __launch_bounds__(" << bs << ") ";
+    if (opts.dev.unrolled_waves > 0) {
+        os << "__attribute__((amdgpu_waves_per_eu(" << opts.dev.unrolled_waves << ", " << opts.dev.unrolled_waves << "))) ";
+    }
+    os << kname << "(const hy_kargs a)\n{\n";
     os << "const u64 s = (u64)blockIdx.x * " << bs << "u + threadIdx.x;\n";
     os << "if (s >= a.N) return;\n";
     os << "const u64 N = a.N;\n";
@@ -1458,6 +1462,7 @@ dev_switches dev_switches::from_env()
     d.table_lds = num("HEYOKA_AMD_TABLE_LDS", -1);
     d.ev_inline_max_nonlinear = num("HEYOKA_AMD_EV_INLINE_MAX_NONLINEAR", -1);
     d.v5_prio = num("HEYOKA_AMD_V5_PRIO", 2);
+    d.unrolled_waves = num("HEYOKA_AMD_UNROLLED_WAVES", 0);
     d.v5_opts = str("HEYOKA_AMD_V5_OPTS");
     d.v5_pad = str("HEYOKA_AMD_V5_PAD");
     return d;

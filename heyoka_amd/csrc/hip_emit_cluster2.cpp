@@ -685,8 +685,18 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
             // (Velocity exchange: no position slots.)
             const auto pos_sz = vexch ? 0u : 4u * nb;
             std::uint32_t Dd = W * n_rank, pos_base = 0, op_base = pos_sz;
+            // Position of operand a of the sums of rank r inside a coordinate block: arr_pos[r][a]. Default: arrays of W slots
+            // one after the other; replaced below by a placement without store conflicts where one exists.
+            std::vector<std::vector<std::uint32_t>> arr_pos(n_rank, std::vector<std::uint32_t>(n_args));
+            for (std::uint32_t r = 0; r < n_rank; ++r) {
+                for (std::uint32_t a = 0; a < n_args; ++a) {
+                    arr_pos[r][a] = W * r + a;
+                }
+            }
+            std::uint32_t dummy_pos[2] = {W - 1u, 2u * W - 1u}; // (spare slots of the arrays of rank 0 / rank 1)
+            std::uint32_t blk_used = W * n_rank;                 // (slots of a coordinate block)
             const auto op_slot = [&](std::uint32_t coord, std::uint32_t rank, std::uint32_t a) {
-                return op_base + Dd * coord + W * perm[rank] + a;
+                return op_base + Dd * coord + arr_pos[rank][a];
             };
             const auto out_slot = [&](std::uint32_t u) {
                 // (u: an exported cluster output: the slot of the operand position which reads it.)
@@ -701,8 +711,8 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
                 return 0u;
             };
             // (Dummy slots of the idle lanes: the spare slot of the arrays of rank 0 (products) and rank 1 (reactions).)
-            const auto dummy_pr = [&](std::uint32_t i) { return op_slot(i, 0, W - 1u); };
-            const auto dummy_rx = [&](std::uint32_t i) { return op_slot(i, 1, W - 1u); };
+            const auto dummy_pr = [&](std::uint32_t i) { return op_base + Dd * i + dummy_pos[0]; };
+            const auto dummy_rx = [&](std::uint32_t i) { return op_base + Dd * i + dummy_pos[1]; };
             // Which operand position reads the outputs of every cluster (independent of the layout parameters).
             std::vector<std::array<std::uint32_t, 3>> pr_ref(nc), rx_ref(nc); // (node index j, argument) packed: j * 8 + a
             for (std::uint32_t c = 0; c < nc; ++c) {
@@ -773,7 +783,7 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
                     lds_op ow{-8, std::vector<std::uint32_t>(pl.L)};
                     for (std::uint32_t l = 0; l < pl.L; ++l) {
                         if (r * pl.L + l >= n_nodes) {
-                            ow.addr[l] = pos_sz + 2u * Dd + W * n_rank; // (the dummy area)
+                            ow.addr[l] = pos_sz + 2u * Dd + blk_used; // (the dummy area)
                             continue;
                         }
                         const auto j = r * pl.L + l;
@@ -864,40 +874,132 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
                 return tot;
             };
             if (wide_rd) {
-                // Exhaustive over the order of the bodies inside a coordinate block (n_rank! <= 720), a few block distances
-                // and the even slab strides of one bank period.
-                std::uint64_t best_c = ~std::uint64_t(0);
-                auto best_perm = perm;
-                std::uint32_t best_D = Dd, best_stride = 0;
-                std::vector<std::uint32_t> pm(n_rank);
-                for (std::uint32_t r = 0; r < n_rank; ++r) {
-                    pm[r] = r;
-                }
-                // (+ 2: the dummy area behind the arrays - idle lanes of a partially filled glue round publish there.)
-                const auto total_for = [&](std::uint32_t D_) { return pos_sz + 2u * D_ + W * n_rank + 2u; };
-                // (An exhaustive search over the order of the bodies inside a block and a few block distances - 720 x 5 x 16 layouts,
-                // 6.5 s per integrator - found nothing the slab stride alone does not give: every layout keeps one two-way
-                // conflict per store, and the kernel time does not move, profiles/r05_ab_velocity_exchange.log, "nobanksearch".
-                // The LDS time of this kernel follows the BYTES it moves. Only the stride is scanned.)
-                const bool full = false;
-                do {
-                    perm = pm;
-                    for (std::uint32_t D_ = W * n_rank; D_ <= W * n_rank + (full ? 8u : 0u); D_ += 2u) {
-                        Dd = D_;
-                        const auto ops = addr_lists();
-                        const auto tot = total_for(D_);
-                        for (std::uint32_t st_ = (tot + 1u) & ~1u; st_ < ((tot + 1u) & ~1u) + 32u; st_ += 2u) {
-                            // (The dead slab also parks the new state of the stepper with events: >= n_own * L slots.)
-                            const auto c = wcost(ops, st_);
-                            if (c < best_c) {
-                                best_c = c;
-                                best_perm = pm;
-                                best_D = D_;
-                                best_stride = st_;
+                // Placement of the operand arrays inside a coordinate block. A ds_write_b64 is serviced in four groups of 16
+                // lanes - one system each - over 16 pairs of banks: the 15 pair lanes + 1 idle lane of a system write 16
+                // slots, and the store is conflict free iff those slots are distinct modulo 16. With arrays [t0 .. t4, -] back
+                // to back no order of the bodies achieves that for the products AND the reactions (the operand positions a
+                // sum reads as reactions are the first ones, as products the last ones), and 34 % of the LDS cycles of the
+                // kernel were bank conflicts (profiles/r05_outer_ss_sq_counters.json, first collection). The arrays keep
+                // the two 16-byte pairs (t0, t1), (t2, t3) adjacent - read with two ds_read_b128 from ONE table register - and
+                // let the fifth operand sit anywhere (a second table register): a depth-first search over (array base, place
+                // of the fifth operand) per rank finds a placement in which the slots of every product store and of every
+                // reaction store are distinct modulo 16 (outer Solar System: a block of 34 slots).
+                const auto BLK = 8u * n_rank;
+                bool placed = false;
+                if (!v5_flag("nostoreplace") && n_args >= 2u && n_args <= 5u) {
+                    // Which operand positions of a rank are written by the product store / the reaction store.
+                    std::vector<std::vector<char>> is_rx(n_rank, std::vector<char>(n_args, 0));
+                    std::vector<std::vector<char>> is_wr(n_rank, std::vector<char>(n_args, 0));
+                    for (std::uint32_t c = 0; c < nc; ++c) {
+                        for (int kind = 0; kind < 2; ++kind) {
+                            const auto ref = (kind == 0 ? pr_ref : rx_ref)[c][0];
+                            if (ref != ~0u) {
+                                is_rx[node_rank[ref / 8u]][ref % 8u] = static_cast<char>(kind);
+                                is_wr[node_rank[ref / 8u]][ref % 8u] = 1;
                             }
                         }
                     }
-                } while (full && std::next_permutation(pm.begin(), pm.end()) && best_c != 0u);
+                    std::vector<std::vector<std::uint32_t>> cur(n_rank, std::vector<std::uint32_t>(n_args));
+                    std::vector<char> used(BLK, 0);
+                    std::uint64_t n_visit = 0;
+                    const std::function<bool(std::uint32_t, std::uint32_t, std::uint32_t)> dfs = [&](std::uint32_t r, std::uint32_t pm,
+                                                                                                 std::uint32_t rm) -> bool {
+                        if (r == n_rank) {
+                            // The stores of the idle lanes: a free slot on the one residue each store leaves free.
+                            std::uint32_t dz[2] = {~0u, ~0u};
+                            for (std::uint32_t z = 0; z < BLK; ++z) {
+                                if (used[z] != 0) {
+                                    continue;
+                                }
+                                if (dz[0] == ~0u && (pm & (1u << (z % 16u))) == 0u) {
+                                    dz[0] = z;
+                                } else if (dz[1] == ~0u && (rm & (1u << (z % 16u))) == 0u) {
+                                    dz[1] = z;
+                                }
+                            }
+                            if (dz[0] == ~0u || dz[1] == ~0u) {
+                                return false;
+                            }
+                            dummy_pos[0] = dz[0];
+                            dummy_pos[1] = dz[1];
+                            return true;
+                        }
+                        const auto n_pair = n_args & ~1u; // operands read in 16-byte pairs
+                        for (std::uint32_t e_ = 0; e_ + n_pair <= BLK; e_ += 2u) {
+                            for (std::uint32_t f_ = 0; f_ < (n_args % 2u == 1u ? BLK : 1u); ++f_) {
+                                if (++n_visit > 4000000u) {
+                                    return false;
+                                }
+                                std::vector<std::uint32_t> ps(n_args);
+                                bool ok = true;
+                                for (std::uint32_t a_ = 0; a_ < n_args; ++a_) {
+                                    ps[a_] = a_ < n_pair ? e_ + a_ : f_;
+                                    ok = ok && used[ps[a_]] == 0 && !(a_ >= n_pair && f_ >= e_ && f_ < e_ + n_pair);
+                                }
+                                if (!ok) {
+                                    continue;
+                                }
+                                std::uint32_t pm2 = pm, rm2 = rm;
+                                for (std::uint32_t a_ = 0; a_ < n_args && ok; ++a_) {
+                                    if (is_wr[r][a_] == 0) {
+                                        continue;
+                                    }
+                                    auto &m_ = is_rx[r][a_] != 0 ? rm2 : pm2;
+                                    const auto bit = 1u << (ps[a_] % 16u);
+                                    ok = (m_ & bit) == 0u;
+                                    m_ |= bit;
+                                }
+                                if (!ok) {
+                                    continue;
+                                }
+                                for (const auto x : ps) {
+                                    used[x] = 1;
+                                }
+                                cur[r] = ps;
+                                if (dfs(r + 1u, pm2, rm2)) {
+                                    return true;
+                                }
+                                for (const auto x : ps) {
+                                    used[x] = 0;
+                                }
+                            }
+                        }
+                        return false;
+                    };
+                    if (pl.L == 16u && dfs(0, 0, 0)) {
+                        arr_pos = cur;
+                        placed = true;
+                    }
+                }
+                if (placed) {
+                    blk_used = std::max(dummy_pos[0], dummy_pos[1]) + 1u;
+                    for (const auto &v : arr_pos) {
+                        for (const auto x : v) {
+                            blk_used = std::max(blk_used, x + 1u);
+                        }
+                    }
+                    blk_used = (blk_used + 1u) & ~1u;
+                }
+                std::uint64_t best_c = ~std::uint64_t(0);
+                auto best_perm = perm;
+                std::uint32_t best_D = Dd, best_stride = 0;
+                // (+ 2: the dummy area behind the arrays - idle lanes of a partially filled glue round publish there.)
+                const auto total_for = [&](std::uint32_t D_) { return pos_sz + 2u * D_ + blk_used + 2u; };
+                // The distance between the coordinate blocks and between the slabs of two systems: scanned with the bank model
+                // (reads in the lane groups of each instruction width; the stores are settled by the placement above).
+                for (std::uint32_t D_ = blk_used; D_ <= blk_used + 6u; D_ += 2u) {
+                    Dd = D_;
+                    const auto ops = addr_lists();
+                    const auto tot = total_for(D_);
+                    for (std::uint32_t st_ = (tot + 1u) & ~1u; st_ < ((tot + 1u) & ~1u) + 32u; st_ += 2u) {
+                        const auto c = wcost(ops, st_);
+                        if (c < best_c) {
+                            best_c = c;
+                            best_D = D_;
+                            best_stride = st_;
+                        }
+                    }
+                }
                 perm = best_perm;
                 Dd = best_D;
                 slab_stride_opt = best_stride;

@@ -2785,11 +2785,11 @@ void tab_core::raw_step_e(double *d_jet, const double *d_state, const double *d_
     a.counters = cnt.as<unsigned>();
     (void)n_ev;
     d.dmod->launch_taylor(a, d_tape);
+    if (d.cluster_events && !d.evj_mod && d.ev_cmod) {
+        d.evj_mod = std::make_unique<aux_module>(d.ev_cmod, d.device);
+    }
     if (d.cluster_events && !d.emitted.events_in_stepper) {
         // (Jets of the event equations, extended norms and the step size from the jets of the state variables.)
-        if (!d.evj_mod) {
-            d.evj_mod = std::make_unique<aux_module>(d.ev_cmod, d.device);
-        }
         d.evj_mod->launch("hy_ev_jets", n_systems, 256, &a, sizeof(a), d.stream);
     }
     if (d.emitted.compact_tc && d.evj_mod) {
