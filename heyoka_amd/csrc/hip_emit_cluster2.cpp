@@ -1867,11 +1867,15 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     // dummy instructions of each kind to every order - independent FMAs in the chain section, dependent FMAs, LDS stores
     // and LDS reads in the dependent section, scalar no-ops - without touching the results: the slope of the step time
     // against each count says which resource the kernel is bound by.
-    unsigned pad_chain = 0, pad_dep = 0, pad_st = 0, pad_ld = 0, pad_salu = 0;
+    // (A sixth field: that many per-lane doubles kept live through the step, each used by one dependent FMA per order - what
+    // per-lane coefficients of the acceleration sums would cost in registers; "norx" among HEYOKA_AMD_V5_OPTS drops the
+    // reaction products and their stores - WRONG results, timing only: what fusing them into the sums could gain.)
+    unsigned pad_chain = 0, pad_dep = 0, pad_st = 0, pad_ld = 0, pad_salu = 0, pad_regs = 0;
     if (!opts.dev.v5_pad.empty()) {
-        std::sscanf(opts.dev.v5_pad.c_str(), "%u:%u:%u:%u:%u", &pad_chain, &pad_dep, &pad_st, &pad_ld, &pad_salu);
+        std::sscanf(opts.dev.v5_pad.c_str(), "%u:%u:%u:%u:%u:%u", &pad_chain, &pad_dep, &pad_st, &pad_ld, &pad_salu, &pad_regs);
     }
-    const bool any_pad = (pad_chain | pad_dep | pad_st | pad_ld | pad_salu) != 0u;
+    const bool any_pad = (pad_chain | pad_dep | pad_st | pad_ld | pad_salu | pad_regs) != 0u;
+    const bool exp_norx = v5_flag("norx");
     // One accumulator for the half sum of squares bh_k = sum_i (sum_j d_i[k-j] d_i[j] + 1/2 d_i[k/2]^2): the three chains
     // of the coordinates run into each other - two additions per order and two multiply-adds per even order less, two
     // accumulators less. (The reference adds the three squares pairwise, src/detail/sum_sq.cpp:120-245: same terms, other
@@ -1974,7 +1978,7 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
         for (std::uint32_t i = 0; i < 3u; ++i) {
             emit_store(slabk(k, utname(st1.o[i])) + " = " + pr[i] + ";\n");
         }
-        for (std::uint32_t i = 0; pp.rx[0] >= 0 && i < 3u; ++i) {
+        for (std::uint32_t i = 0; pp.rx[0] >= 0 && i < 3u && !exp_norx; ++i) {
             // (The reaction on the second body of the pair: c * (d_i * sa), src/model/nbody.cpp:113-130.)
             const auto rxv = e.def(ssa_emitter::mul("crs_r", pr[i]));
             emit_store(slabk(k, utname(st1.r[i])) + " = " + rxv + ";\n");
@@ -1982,6 +1986,9 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
         if (any_pad && k >= 1u) {
             for (unsigned i = 0; i < pad_dep; ++i) {
                 os << "asm volatile(\"v_fma_f64 %0, %0, %0, %0\" : \"+v\"(hy_pad0));\n";
+            }
+            for (unsigned i = 0; i < pad_regs; ++i) {
+                os << "asm volatile(\"v_fma_f64 %0, %1, %0, %0\" : \"+v\"(hy_pad0) : \"v\"(hy_rp" << i << "));\n";
             }
             // (Written-out LDS stores of the first product to its own slot once more: same value, same address. The
             // compiler's lgkmcnt bookkeeping stays conservative: LDS operations complete in order.)
@@ -2109,6 +2116,11 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     os << "double m0 = 0.0, mo = 0.0, mom1 = 0.0;\n";
     if (one_lane && !opts.dev.v5_pad.empty()) {
         os << "double hy_pad0 = 1.0, hy_pad1 = 1.0, hy_pad2 = 1.0, hy_pad3 = 1.0, hy_pad4 = 1.0;\n";
+        unsigned n_rp = 0;
+        std::sscanf(opts.dev.v5_pad.c_str(), "%*u:%*u:%*u:%*u:%*u:%u", &n_rp);
+        for (unsigned i = 0; i < n_rp; ++i) {
+            os << "double hy_rp" << i << " = lds_fac[(threadIdx.x + " << i << "u) % 40u];\n";
+        }
     }
     for (auto &rg : rounds) {
         for (auto &gr : rg) {
@@ -3088,7 +3100,9 @@ lim = fin ? 0.0 : lim;
         // (For the detection kernel: systems in which no event is possible are skipped without reading their event jets -
         // which are stored only by the wavefronts that hold such a system.)
         src << "if (!hy_tc_only) a.sel_norms[s] = ev_possible ? 1.0 : 0.0;\n";
-        src << "if (!hy_tc_only && __builtin_amdgcn_ballot_w64(ev_possible) != 0ull) {\n";
+        // (A caller who asked for the coefficients of every system - the raw stepper ABI, loops with dense output - gets the
+        // event jets of every system as well.)
+        src << "if (!hy_tc_only && (((a.pad & 1) != 0) | (__builtin_amdgcn_ballot_w64(ev_possible) != 0ull))) {\n";
         for (std::size_t ev = 0; ev < ev_coeffs.size(); ++ev) {
             for (std::uint32_t k = 0; !ev_coeffs[ev].empty() && k <= order; ++k) {
                 src << "a.ev_tc[(u64)" << static_cast<std::uint64_t>(ev) * (order + 1u) + k << "u * N + s] = " << ev_coeffs[ev][k] << ";\n";
