@@ -181,6 +181,55 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     const auto n_out = static_cast<std::uint32_t>(pl.out_pos.size());
     const auto n_cst = static_cast<std::uint32_t>(pl.cst_pos.size());
 
+    // ---- 0c. One lane per pair: reactions fused into the acceleration sums ("frx", round 5). The sensitivity experiment
+    // (profiles/r05_sensitivity_marginal_costs.log) prices an LDS store at ~30 cycles of the issuing wavefront's time, five
+    // FMAs; 3 of the 8 stores of an order are the reactions c * (d_i * sa), values which differ from the direct products
+    // by a per-pair factor. Dropping them (timing experiment "norx", profiles/r05_ab_fused_reactions_estimate.log) is worth
+    // +7.8 %. Here the sums of the first glue round read the direct product wherever they read a reaction and apply the
+    // factor themselves, t_a = c_a * p_a with per-lane coefficients (c, or 1.0 for a direct product: exact, so that without
+    // FMA contraction every term is rounded like the separate node); the additions keep the reference's pairwise order.
+    // Registers are what this costs (five coefficient doubles per lane through the orders), so the coefficients exist only
+    // once: the nodes of the sum group are reordered so that the sums made of direct products alone (the first body of every
+    // pair it takes part in) come last - the rounds after the first are then plain sums without coefficients.
+    bool frx = false;
+    if (one_lane && !m4 && pp.rx[0] >= 0 && pl.groups.size() == 1u && !v5_flag("nofrx")) {
+        auto &nodes = pl.groups[0].nodes;
+        std::map<std::uint32_t, bool> is_rx_out; // cluster output -> is it a reaction?
+        for (std::uint32_t c = 0; c < nc; ++c) {
+            for (std::uint32_t i = 0; i < 3u; ++i) {
+                is_rx_out[pl.clusters[c][pp.pr[i]]] = false;
+                is_rx_out[pl.clusters[c][static_cast<std::uint32_t>(pp.rx[i])]] = true;
+            }
+        }
+        const auto &n0 = p.nodes[nodes[0] - n_eq];
+        frx = n0.kind == func_kind::sum && n0.args.size() >= 2u;
+        std::vector<char> plain(nodes.size(), 1);
+        for (std::size_t j = 0; j < nodes.size() && frx; ++j) {
+            const auto &nd = p.nodes[nodes[j] - n_eq];
+            frx = nd.kind == func_kind::sum && nd.args.size() == n0.args.size();
+            for (const auto &o : nd.args) {
+                const auto it = is_var(o) ? is_rx_out.find(o.idx) : is_rx_out.end();
+                frx = frx && it != is_rx_out.end();
+                if (frx && it->second) {
+                    plain[j] = 0;
+                }
+            }
+        }
+        if (frx) {
+            // (Stable: the three coordinates of a body stay adjacent and in order, which the velocity exchange relies on.)
+            std::vector<std::uint32_t> first, last;
+            for (std::size_t j = 0; j < nodes.size(); ++j) {
+                (plain[j] != 0 ? last : first).push_back(nodes[j]);
+            }
+            // Every round after the first must consist of plain sums.
+            frx = first.size() <= pl.L && !last.empty();
+            if (frx) {
+                first.insert(first.end(), last.begin(), last.end());
+                nodes = std::move(first);
+            }
+        }
+    }
+
     // ---- 1. Anchor every state variable to the glue node at the root of its rhs chain. ----
     // anchor[i] = glue u variable, depth[i] >= 1.
     std::vector<int> anchor(n_eq, -1);
@@ -282,7 +331,7 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     if (pairk && pp.rx[0] >= 0) {
         // (One-lane pair kernel: the reactions are computed and exported by the pair lane - the slab of a system is
         // single-buffered there and has room for them - so that the sums need no per-lane coefficients: 20 registers.)
-        fuse_rx = !one_lane;
+        fuse_rx = !one_lane || frx;
         for (std::size_t c = 0; c < nc; ++c) {
             for (std::uint32_t i = 0; i < 3u; ++i) {
                 const auto u = pl.clusters[c][static_cast<std::uint32_t>(pp.rx[i])];
@@ -316,6 +365,7 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
             std::fill(rx_fused.begin(), rx_fused.end(), 0);
         }
     }
+    frx = frx && fuse_rx;
     // A glue node / state variable needs a slab slot only if somebody reads it through the slab.
     std::vector<char> glue_read(p.n_u, 0);
     for (const auto &n : p.nodes) {
@@ -343,181 +393,6 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
                 return ret;
             }
         }
-        std::vector<int> remap(pl.n_slots, -1);
-        std::uint32_t ns = 0;
-        const auto keep = [&](std::uint32_t u) {
-            if (pl.slot_of[u] < 0) {
-                return false;
-            }
-            if (pl.cluster_of[u] != -1) {
-                // Cluster outputs: the direct products, or - when only the reaction was exported - that one.
-                if (fuse_rx && rx_fused[u] != 0) {
-                    return pl.slot_of[rx_src[u]] < 0;
-                }
-                return true;
-            }
-            return glue_read[u] != 0;
-        };
-        // (The kept slots keep their relative order.)
-        std::vector<char> kept(p.n_u, 0);
-        std::vector<std::pair<int, std::uint32_t>> order_v;
-        for (std::uint32_t u = 0; u < p.n_u; ++u) {
-            kept[u] = keep(u) ? 1 : 0;
-            if (kept[u] != 0) {
-                order_v.emplace_back(pl.slot_of[u], u);
-            }
-        }
-        std::sort(order_v.begin(), order_v.end());
-        for (std::uint32_t u = 0; u < p.n_u; ++u) {
-            if (kept[u] == 0) {
-                pl.slot_of[u] = -1;
-            }
-        }
-        for (const auto &[old_slot, u] : order_v) {
-            (void)old_slot;
-            if (pl.cluster_of[u] == -1) {
-                pl.slot_of[u] = static_cast<int>(ns++);
-            }
-        }
-        // Cluster outputs: every lane (the idle ones too) owns 3 + 3 slots, read or not: lane l keeps its products in the
-        // slots out_base + 3 * lane_pr[l] + i and its reactions in rx_base + 3 * lane_rx[l] + i, where lane_pr / lane_rx are
-        // permutations of the lanes. The kernel is within 25 % of the LDS throughput, so the permutations and the
-        // distance between the slabs of two systems are chosen to minimise the bank conflicts of the exchange (a small
-        // deterministic local search over the access patterns of a step; the model is the one of the microarchitecture
-        // guide: a ds_read_b64 services the lanes 0-31 / 32-63 together, bank pair = double index mod 32, every further
-        // distinct address on a bank pair costs a cycle; a ds_write_b64 services 16 consecutive lanes, double index mod 16).
-        const auto out_base = ns;
-        const auto rx_base = out_base + 3u * pl.L;
-        lane_pr.resize(pl.L);
-        lane_rx.resize(pl.L);
-        for (std::uint32_t l = 0; l < pl.L; ++l) {
-            lane_pr[l] = lane_rx[l] = l;
-        }
-        ns = out_base + 3u * pl.L * (pp.rx[0] >= 0 ? 2u : 1u);
-        const auto assign = [&]() {
-            for (std::uint32_t c = 0; c < nc; ++c) {
-                for (std::uint32_t i = 0; i < 3u; ++i) {
-                    pl.slot_of[pl.clusters[c][pp.pr[i]]] = static_cast<int>(out_base + 3u * lane_pr[c] + i);
-                    if (pp.rx[0] >= 0) {
-                        pl.slot_of[pl.clusters[c][static_cast<std::uint32_t>(pp.rx[i])]] = static_cast<int>(rx_base + 3u * lane_rx[c] + i);
-                    }
-                }
-            }
-        };
-        // Read patterns of a step: per LDS read instruction, the u variable every lane of a group reads.
-        std::vector<std::vector<std::uint32_t>> rd_pat;
-        for (std::uint32_t i = 0; i < 3u; ++i) {
-            for (std::uint32_t sd = 0; sd < 2u; ++sd) {
-                std::vector<std::uint32_t> v(pl.L);
-                for (std::uint32_t l = 0; l < pl.L; ++l) {
-                    v[l] = pl.ext_u[l < nc ? l : 0u][pp.de[i][sd]];
-                }
-                rd_pat.push_back(std::move(v));
-            }
-        }
-        for (const auto &grp : pl.groups) {
-            const auto n_nodes = static_cast<std::uint32_t>(grp.nodes.size());
-            const auto &n0 = p.nodes[grp.nodes[0] - n_eq];
-            for (std::uint32_t r = 0; r * pl.L < n_nodes; ++r) {
-                for (std::size_t a = 0; a < n0.args.size(); ++a) {
-                    if (!is_var(n0.args[a])) {
-                        continue;
-                    }
-                    std::vector<std::uint32_t> v(pl.L);
-                    for (std::uint32_t l = 0; l < pl.L; ++l) {
-                        const auto j = r * pl.L + l;
-                        v[l] = p.nodes[grp.nodes[j < n_nodes ? j : r * pl.L] - n_eq].args[a].idx;
-                    }
-                    rd_pat.push_back(std::move(v));
-                }
-            }
-        }
-        const auto cost = [&](std::uint32_t stride) {
-            std::uint64_t tot = 0;
-            const auto spw_ = 64u / pl.L;
-            // Reads: two groups of 32 lanes.
-            for (const auto &v : rd_pat) {
-                for (std::uint32_t g = 0; g < 2u; ++g) {
-                    std::map<std::uint32_t, std::set<std::uint32_t>> banks;
-                    for (std::uint32_t lane = 32u * g; lane < 32u * g + 32u; ++lane) {
-                        const auto q = (lane / pl.L) % spw_, l = lane % pl.L;
-                        const auto a = q * stride + static_cast<std::uint32_t>(std::max(0, pl.slot_of[v[l]]));
-                        banks[a % 32u].insert(a);
-                    }
-                    std::size_t mx = 1;
-                    for (const auto &[b, st_] : banks) {
-                        mx = std::max(mx, st_.size());
-                    }
-                    tot += mx - 1u;
-                }
-            }
-            // Writes of the outputs: four groups of 16 lanes, three coordinates, two kinds.
-            for (std::uint32_t kind = 0; kind < (pp.rx[0] >= 0 ? 2u : 1u); ++kind) {
-                for (std::uint32_t g = 0; g < 4u; ++g) {
-                    std::map<std::uint32_t, std::set<std::uint32_t>> banks;
-                    for (std::uint32_t lane = 16u * g; lane < 16u * g + 16u; ++lane) {
-                        const auto q = (lane / pl.L) % spw_, l = lane % pl.L;
-                        const auto a = q * stride + (kind == 0u ? out_base + 3u * lane_pr[l] : rx_base + 3u * lane_rx[l]);
-                        banks[a % 16u].insert(a);
-                    }
-                    std::size_t mx = 1;
-                    for (const auto &[b, st_] : banks) {
-                        mx = std::max(mx, st_.size());
-                    }
-                    tot += 3u * 2u * (mx - 1u); // (a conflicting store costs two LDS cycles more, three coordinates)
-                }
-            }
-            return tot;
-        };
-        // Total slots incl. the dummy area (as computed below).
-        const auto n_tot_est = ns + std::max<std::uint32_t>(static_cast<std::uint32_t>(pl.out_pos.size()), 6u);
-        assign();
-        slab_stride_opt = n_tot_est;
-        auto best = cost(slab_stride_opt);
-        for (std::uint32_t st_ = n_tot_est; st_ < n_tot_est + 32u; ++st_) {
-            if (const auto c = cost(st_); c < best) {
-                best = c;
-                slab_stride_opt = st_;
-            }
-        }
-        {
-            std::uint64_t rng = 0x9E3779B97F4A7C15ull;
-            const auto next = [&]() {
-                rng ^= rng << 13;
-                rng ^= rng >> 7;
-                rng ^= rng << 17;
-                return rng;
-            };
-            for (int it = 0; it < 4000 && best != 0u; ++it) {
-                auto &perm = (pp.rx[0] >= 0 && (next() & 1u) != 0u) ? lane_rx : lane_pr;
-                const auto i1 = static_cast<std::uint32_t>(next() % pl.L), i2 = static_cast<std::uint32_t>(next() % pl.L);
-                if (i1 == i2) {
-                    continue;
-                }
-                std::swap(perm[i1], perm[i2]);
-                assign();
-                auto c = cost(slab_stride_opt);
-                auto cs = slab_stride_opt;
-                if (it % 16 == 0) {
-                    for (std::uint32_t st_ = n_tot_est; st_ < n_tot_est + 32u; ++st_) {
-                        if (const auto c2 = cost(st_); c2 < c) {
-                            c = c2;
-                            cs = st_;
-                        }
-                    }
-                }
-                if (c <= best) {
-                    best = c;
-                    slab_stride_opt = cs;
-                } else {
-                    std::swap(perm[i1], perm[i2]);
-                }
-            }
-            assign();
-        }
-        bank_cost = best;
-        pl.n_slots = ns;
-
         // ---- Wide-read layout (round 5). A wavefront pays ~7 cycles of its own time for every LDS instruction it issues
         // (profiles/README.md, issue-rate table), and a round of the step reads 6 positions + 2 x 5 sum operands with 16
         // ds_read_b64. Slots arranged BY CONSUMER make them 10 reads: the three coordinates of a body are adjacent
@@ -668,6 +543,195 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
                 }
             }
         }
+        // (The consumer-arranged slots exclude the fused reactions - a product then has two readers -; the analysis above still
+        // serves the velocity exchange.)
+        const bool wide_an = wide_rd;
+        wide_rd = wide_rd && !frx;
+        vexch = vexch && wide_an;
+        std::vector<int> remap(pl.n_slots, -1);
+        std::uint32_t ns = 0;
+        const auto keep = [&](std::uint32_t u) {
+            if (pl.slot_of[u] < 0) {
+                return false;
+            }
+            if (pl.cluster_of[u] != -1) {
+                // Cluster outputs: the direct products, or - when only the reaction was exported - that one.
+                if (fuse_rx && rx_fused[u] != 0) {
+                    return pl.slot_of[rx_src[u]] < 0;
+                }
+                return true;
+            }
+            // (Velocity exchange: nobody reads a position coefficient through the slab.)
+            if (vexch && u < n_eq) {
+                return false;
+            }
+            return glue_read[u] != 0;
+        };
+        // (The kept slots keep their relative order.)
+        std::vector<char> kept(p.n_u, 0);
+        std::vector<std::pair<int, std::uint32_t>> order_v;
+        for (std::uint32_t u = 0; u < p.n_u; ++u) {
+            kept[u] = keep(u) ? 1 : 0;
+            if (kept[u] != 0) {
+                order_v.emplace_back(pl.slot_of[u], u);
+            }
+        }
+        std::sort(order_v.begin(), order_v.end());
+        for (std::uint32_t u = 0; u < p.n_u; ++u) {
+            if (kept[u] == 0) {
+                pl.slot_of[u] = -1;
+            }
+        }
+        for (const auto &[old_slot, u] : order_v) {
+            (void)old_slot;
+            if (pl.cluster_of[u] == -1) {
+                pl.slot_of[u] = static_cast<int>(ns++);
+            }
+        }
+        // Cluster outputs: every lane (the idle ones too) owns 3 + 3 slots, read or not: lane l keeps its products in the
+        // slots out_base + 3 * lane_pr[l] + i and its reactions in rx_base + 3 * lane_rx[l] + i, where lane_pr / lane_rx are
+        // permutations of the lanes. The kernel is within 25 % of the LDS throughput, so the permutations and the
+        // distance between the slabs of two systems are chosen to minimise the bank conflicts of the exchange (a small
+        // deterministic local search over the access patterns of a step; the model is the one of the microarchitecture
+        // guide: a ds_read_b64 services the lanes 0-31 / 32-63 together, bank pair = double index mod 32, every further
+        // distinct address on a bank pair costs a cycle; a ds_write_b64 services 16 consecutive lanes, double index mod 16).
+        const auto out_base = ns;
+        const auto rx_base = out_base + 3u * pl.L;
+        lane_pr.resize(pl.L);
+        lane_rx.resize(pl.L);
+        for (std::uint32_t l = 0; l < pl.L; ++l) {
+            lane_pr[l] = lane_rx[l] = l;
+        }
+        // (Fused reactions: the sums read the products; no second region.)
+        const bool rx_region = pp.rx[0] >= 0 && !fuse_rx;
+        ns = out_base + 3u * pl.L * (rx_region ? 2u : 1u);
+        const auto assign = [&]() {
+            for (std::uint32_t c = 0; c < nc; ++c) {
+                for (std::uint32_t i = 0; i < 3u; ++i) {
+                    pl.slot_of[pl.clusters[c][pp.pr[i]]] = static_cast<int>(out_base + 3u * lane_pr[c] + i);
+                    if (rx_region) {
+                        pl.slot_of[pl.clusters[c][static_cast<std::uint32_t>(pp.rx[i])]] = static_cast<int>(rx_base + 3u * lane_rx[c] + i);
+                    }
+                }
+            }
+        };
+        // Read patterns of a step: per LDS read instruction, the u variable every lane of a group reads.
+        std::vector<std::vector<std::uint32_t>> rd_pat;
+        for (std::uint32_t i = 0; i < 3u; ++i) {
+            for (std::uint32_t sd = 0; sd < 2u; ++sd) {
+                std::vector<std::uint32_t> v(pl.L);
+                for (std::uint32_t l = 0; l < pl.L; ++l) {
+                    v[l] = pl.ext_u[l < nc ? l : 0u][pp.de[i][sd]];
+                }
+                rd_pat.push_back(std::move(v));
+            }
+        }
+        for (const auto &grp : pl.groups) {
+            const auto n_nodes = static_cast<std::uint32_t>(grp.nodes.size());
+            const auto &n0 = p.nodes[grp.nodes[0] - n_eq];
+            for (std::uint32_t r = 0; r * pl.L < n_nodes; ++r) {
+                for (std::size_t a = 0; a < n0.args.size(); ++a) {
+                    if (!is_var(n0.args[a])) {
+                        continue;
+                    }
+                    std::vector<std::uint32_t> v(pl.L);
+                    for (std::uint32_t l = 0; l < pl.L; ++l) {
+                        const auto j = r * pl.L + l;
+                        v[l] = p.nodes[grp.nodes[j < n_nodes ? j : r * pl.L] - n_eq].args[a].idx;
+                        if (fuse_rx && rx_fused[v[l]] != 0) {
+                            v[l] = rx_src[v[l]];
+                        }
+                    }
+                    rd_pat.push_back(std::move(v));
+                }
+            }
+        }
+        const auto cost = [&](std::uint32_t stride) {
+            std::uint64_t tot = 0;
+            const auto spw_ = 64u / pl.L;
+            // Reads: two groups of 32 lanes.
+            for (const auto &v : rd_pat) {
+                for (std::uint32_t g = 0; g < 2u; ++g) {
+                    std::map<std::uint32_t, std::set<std::uint32_t>> banks;
+                    for (std::uint32_t lane = 32u * g; lane < 32u * g + 32u; ++lane) {
+                        const auto q = (lane / pl.L) % spw_, l = lane % pl.L;
+                        const auto a = q * stride + static_cast<std::uint32_t>(std::max(0, pl.slot_of[v[l]]));
+                        banks[a % 32u].insert(a);
+                    }
+                    std::size_t mx = 1;
+                    for (const auto &[b, st_] : banks) {
+                        mx = std::max(mx, st_.size());
+                    }
+                    tot += mx - 1u;
+                }
+            }
+            // Writes of the outputs: four groups of 16 lanes, three coordinates, two kinds.
+            for (std::uint32_t kind = 0; kind < (rx_region ? 2u : 1u); ++kind) {
+                for (std::uint32_t g = 0; g < 4u; ++g) {
+                    std::map<std::uint32_t, std::set<std::uint32_t>> banks;
+                    for (std::uint32_t lane = 16u * g; lane < 16u * g + 16u; ++lane) {
+                        const auto q = (lane / pl.L) % spw_, l = lane % pl.L;
+                        const auto a = q * stride + (kind == 0u ? out_base + 3u * lane_pr[l] : rx_base + 3u * lane_rx[l]);
+                        banks[a % 16u].insert(a);
+                    }
+                    std::size_t mx = 1;
+                    for (const auto &[b, st_] : banks) {
+                        mx = std::max(mx, st_.size());
+                    }
+                    tot += 3u * 2u * (mx - 1u); // (a conflicting store costs two LDS cycles more, three coordinates)
+                }
+            }
+            return tot;
+        };
+        // Total slots incl. the dummy area (as computed below).
+        const auto n_tot_est = ns + std::max<std::uint32_t>(static_cast<std::uint32_t>(pl.out_pos.size()), 6u);
+        assign();
+        slab_stride_opt = n_tot_est;
+        auto best = cost(slab_stride_opt);
+        for (std::uint32_t st_ = n_tot_est; st_ < n_tot_est + 32u; ++st_) {
+            if (const auto c = cost(st_); c < best) {
+                best = c;
+                slab_stride_opt = st_;
+            }
+        }
+        {
+            std::uint64_t rng = 0x9E3779B97F4A7C15ull;
+            const auto next = [&]() {
+                rng ^= rng << 13;
+                rng ^= rng >> 7;
+                rng ^= rng << 17;
+                return rng;
+            };
+            for (int it = 0; it < 4000 && best != 0u; ++it) {
+                auto &perm = (rx_region && (next() & 1u) != 0u) ? lane_rx : lane_pr;
+                const auto i1 = static_cast<std::uint32_t>(next() % pl.L), i2 = static_cast<std::uint32_t>(next() % pl.L);
+                if (i1 == i2) {
+                    continue;
+                }
+                std::swap(perm[i1], perm[i2]);
+                assign();
+                auto c = cost(slab_stride_opt);
+                auto cs = slab_stride_opt;
+                if (it % 16 == 0) {
+                    for (std::uint32_t st_ = n_tot_est; st_ < n_tot_est + 32u; ++st_) {
+                        if (const auto c2 = cost(st_); c2 < c) {
+                            c = c2;
+                            cs = st_;
+                        }
+                    }
+                }
+                if (c <= best) {
+                    best = c;
+                    slab_stride_opt = cs;
+                } else {
+                    std::swap(perm[i1], perm[i2]);
+                }
+            }
+            assign();
+        }
+        bank_cost = best;
+        pl.n_slots = ns;
+
         if (wide_rd) {
             const auto W = (n_args + 2u) & ~1u; // slots of an operand array (>= one spare slot, even)
             const auto nb = static_cast<std::uint32_t>(bodies.size());
@@ -1047,7 +1111,6 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
                 (void)out_slot;
             }
         }
-        vexch = vexch && wide_rd;
     }
 
     // ---- 2. LDS layout: every slot double-buffered by order parity. ----
@@ -1111,6 +1174,10 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     const auto dtname = [&](std::size_t t) {
         return one_lane ? ("dtl[" + std::to_string(t * L) + "]") : ("dt" + std::to_string(t));
     };
+    // (One-lane pair kernel, fused reactions: the coefficients of the sums are loaded once per step - registers through the
+    // orders, free again in the tail of the step; "frxlds" among HEYOKA_AMD_V5_OPTS reads them from LDS at every use.)
+    const bool frx_regs = frx && !v5_flag("frxlds");
+    const auto coefname = [&](std::size_t t) { return frx_regs ? ("frc" + std::to_string(t)) : dtname(t); };
 
     ssa_emitter e(p, order);
     auto &os = e.os;
@@ -1208,7 +1275,7 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
                 // (Every lane owns its output slots, the idle ones too: slot = first slot of pair 0 + 3 * lane + i.)
                 o[l] = wide_rd ? wide_pr[l][i]
                                : static_cast<std::uint32_t>(pl.slot_of[pl.clusters[0][pp.pr[i]]]) - 3u * lane_pr[0] + 3u * lane_pr[l];
-                if (pp.rx[0] >= 0) {
+                if (pp.rx[0] >= 0 && !fuse_rx) {
                     const auto ru = cl[static_cast<std::uint32_t>(pp.rx[i])];
                     r[l] = wide_rd ? wide_rx[l][i]
                                    : static_cast<std::uint32_t>(pl.slot_of[pl.clusters[0][static_cast<std::uint32_t>(pp.rx[i])]])
@@ -1227,14 +1294,14 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
             st1.s[i][0] = add_utbl(std::move(s0));
             st1.s[i][1] = add_utbl(std::move(s1));
             st1.o[i] = add_utbl(std::move(o));
-            if (pp.rx[0] >= 0) {
+            if (pp.rx[0] >= 0 && !fuse_rx) {
                 st1.r[i] = add_utbl(std::move(r));
             }
         }
         if (pp.sc >= 0) {
             st1.csc = add_dtbl(std::move(csc));
         }
-        if (pp.rx[0] >= 0) {
+        if (pp.rx[0] >= 0 && !fuse_rx) {
             st1.crs = add_dtbl(std::move(crs));
         }
     }
@@ -1603,8 +1670,8 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
             // first product of every pair fused into the addition.
             std::vector<std::string> terms;
             for (std::size_t a = 0; a + 1u < names.size(); a += 2u) {
-                const auto m = e.def(ssa_emitter::mul(dtname(gr.coef_tbl[a + 1u]), names[a + 1u]));
-                terms.push_back(e.def("__builtin_fma(" + dtname(gr.coef_tbl[a]) + ", " + names[a] + ", " + m + ")"));
+                const auto m = e.def(ssa_emitter::mul(coefname(gr.coef_tbl[a + 1u]), names[a + 1u]));
+                terms.push_back(e.def("__builtin_fma(" + coefname(gr.coef_tbl[a]) + ", " + names[a] + ", " + m + ")"));
             }
             const bool odd = names.size() % 2u == 1u;
             while (terms.size() > 1u) {
@@ -1619,8 +1686,8 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
             }
             if (odd) {
                 const auto a = names.size() - 1u;
-                fused_val = terms.empty() ? e.def(ssa_emitter::mul(dtname(gr.coef_tbl[a]), names[a]))
-                                          : e.def("__builtin_fma(" + dtname(gr.coef_tbl[a]) + ", " + names[a] + ", " + terms[0] + ")");
+                fused_val = terms.empty() ? e.def(ssa_emitter::mul(coefname(gr.coef_tbl[a]), names[a]))
+                                          : e.def("__builtin_fma(" + coefname(gr.coef_tbl[a]) + ", " + names[a] + ", " + terms[0] + ")");
             } else {
                 fused_val = terms[0];
             }
@@ -1978,7 +2045,7 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
         for (std::uint32_t i = 0; i < 3u; ++i) {
             emit_store(slabk(k, utname(st1.o[i])) + " = " + pr[i] + ";\n");
         }
-        for (std::uint32_t i = 0; pp.rx[0] >= 0 && i < 3u && !exp_norx; ++i) {
+        for (std::uint32_t i = 0; pp.rx[0] >= 0 && !fuse_rx && i < 3u && !exp_norx; ++i) {
             // (The reaction on the second body of the pair: c * (d_i * sa), src/model/nbody.cpp:113-130.)
             const auto rxv = e.def(ssa_emitter::mul("crs_r", pr[i]));
             emit_store(slabk(k, utname(st1.r[i])) + " = " + rxv + ";\n");
@@ -2114,6 +2181,15 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
 
     // ===================== step body =====================
     os << "double m0 = 0.0, mo = 0.0, mom1 = 0.0;\n";
+    if (frx_regs) {
+        for (const auto &rg : rounds) {
+            for (const auto &gr : rg) {
+                for (const auto t : gr.coef_tbl) {
+                    os << "const double frc" << t << " = " << dtname(t) << ";\n";
+                }
+            }
+        }
+    }
     if (one_lane && !opts.dev.v5_pad.empty()) {
         os << "double hy_pad0 = 1.0, hy_pad1 = 1.0, hy_pad2 = 1.0, hy_pad3 = 1.0, hy_pad4 = 1.0;\n";
         unsigned n_rp = 0;
@@ -2540,7 +2616,7 @@ __device__ __forceinline__ double hy_swap1(double x)
         src << "__shared__ double lds_dt[" << std::max<std::size_t>(dtbl.size(), 1u) * L << "];\n";
         src << "for (unsigned i = threadIdx.x; i < " << dtbl.size() * L << "u; i += " << bs << "u) lds_dt[i] = hy_dtbl[i];\n";
         src << "__syncthreads();\nconst double *const dtl = lds_dt + l;\n";
-        if (pp.rx[0] >= 0) {
+        if (pp.rx[0] >= 0 && !fuse_rx) {
             src << "const double crs_r = hy_dtbl[" << st1.crs * L << "u + l];\n";
         }
     }

@@ -391,7 +391,8 @@ def test_raw_stepper_abi_step_e_d_out_f_and_caller_owned_tape(golden):
         ora.step(wtc=True)
         hs = np.array([h for _, h in ora.step_res]) * np.linspace(0.1, 1.0, n)
         d_out = torch.zeros(12 * n, device=dev, dtype=torch.float64)
-        ta.raw_d_out_f(d_out.data_ptr(), dt(ora.tc).data_ptr(), dt(hs).data_ptr(), n)
+        d_tc, d_hs = dt(ora.tc), dt(hs)  # (kept alive across the call)
+        ta.raw_d_out_f(d_out.data_ptr(), d_tc.data_ptr(), d_hs.data_ptr(), n)
         exp = np.stack([ho.OracleEventIntegrator._dense(ora, i, hs[i]) for i in range(n)], axis=1)  # (the oracle's evaluation of its own coefficients)
         assert rel_err(d_out.cpu().numpy().reshape(12, n), exp) <= 4 * EPS
 
