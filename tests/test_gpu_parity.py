@@ -397,9 +397,19 @@ def test_raw_stepper_abi_step_e_d_out_f_and_caller_owned_tape(golden):
         assert rel_err(d_out.cpu().numpy().reshape(12, n), exp) <= 4 * EPS
 
     # ---- c_step_f_t: a compact-mode stepper (tape in HBM) on a caller-owned tape.
+    # (Small ensembles get the wave-level variant with its tape in LDS; HEYOKA_AMD_TABLE_LDS=0 is the developer switch for
+    # the lane-per-system variant at any size.)
     n = 4096
     st = configs.plummer_nbody_state(4, n, seed=5)
-    ta = hy.taylor_adaptive_batch(hy.model.nbody(4), st, n, compact_mode=True)
+    old_env = os.environ.get("HEYOKA_AMD_TABLE_LDS")
+    os.environ["HEYOKA_AMD_TABLE_LDS"] = "0"
+    try:
+        ta = hy.taylor_adaptive_batch(hy.model.nbody(4), st, n, compact_mode=True)
+    finally:
+        if old_env is None:
+            del os.environ["HEYOKA_AMD_TABLE_LDS"]
+        else:
+            os.environ["HEYOKA_AMD_TABLE_LDS"] = old_env
     assert "tape in HBM" in ta.hip_source_mode, ta.hip_source_mode
     size, align = ta.raw_tape_size_align(n)
     assert size > 0 and align >= 8
