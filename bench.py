@@ -25,6 +25,10 @@ import time
 # ask the OpenMP runtime to place the workers on distinct cores before anything loads it.
 os.environ.setdefault("OMP_PLACES", "cores")
 os.environ.setdefault("OMP_PROC_BIND", "spread")
+# (With OMP_PROC_BIND the OpenMP runtime pins the calling thread - this process's main thread, which also drives the GPU -
+# to ONE core for the rest of the process, and every thread the HIP runtime creates afterwards inherits that mask: legs
+# with many small launches per step then read 5x too slow. The CPU baseline restores the mask it found.)
+AFFINITY_AT_START = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
 
 import numpy as np
 
@@ -126,6 +130,14 @@ if CPU_QUOTA is not None:
 def cpu_baseline(workload, dt, target_seconds=15.0):
     """The oracle (C restatement, OpenMP over SIMD-width batches like the reference's
     TBB-over-batches ensemble) timed on this host on a bounded sample of the same workload."""
+    try:
+        return _cpu_baseline(workload, dt, target_seconds)
+    finally:
+        if AFFINITY_AT_START is not None:
+            os.sched_setaffinity(0, AFFINITY_AT_START)
+
+
+def _cpu_baseline(workload, dt, target_seconds):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import heyoka_oracle as ho
     from heyoka_amd import configs
@@ -548,6 +560,9 @@ def events_leg(ctx, n, n_steps=6):
             r["tc_regeneration_launches"] = s1["tc_regeneration_launches"]
             r["systems_with_events_per_step"] = (s1["systems_with_events"] - s0["systems_with_events"]) / n_steps
             r["outcomes_ok"] = bool(np.all(np.isfinite(np.asarray(ta.time))))
+            # (HIP-event durations of the stepper launches of the phase-timed steps: the kernel itself, whatever the wall
+            # clock of the phase says.)
+            r["stepper_kernel_ms"] = [round(x, 3) for x in ta.kernel_ms_history(n_steps)]
         res[name] = r
         del ta
         torch.cuda.empty_cache()
@@ -561,10 +576,12 @@ def events_leg(ctx, n, n_steps=6):
         "event_free_ms_per_step": fr * 1e3, "with_events_over_event_free_time": ev["s_per_step"] / fr,
         "events_detected_per_step": ev["nt_events_per_step"], "fraction_of_systems_with_an_event_per_step":
         ev.get("systems_with_events_per_step", 0.0) / n, "phase_ms_per_step": ev.get("phase_ms_per_step"),
+        "stepper_kernel_ms": ev.get("stepper_kernel_ms"),
         "tc_regeneration_launches": ev.get("tc_regeneration_launches"),
         "terminal_variant": {"ms_per_step": tv["s_per_step"] * 1e3, "over_event_free_time": tv["s_per_step"] / fr,
                              "terminal_events_per_step": tv["t_events_per_step"], "nt_events_per_step": tv["nt_events_per_step"],
-                             "phase_ms_per_step": tv.get("phase_ms_per_step"), "tc_regeneration_launches": tv.get("tc_regeneration_launches"),
+                             "phase_ms_per_step": tv.get("phase_ms_per_step"), "stepper_kernel_ms": tv.get("stepper_kernel_ms"),
+                             "tc_regeneration_launches": tv.get("tc_regeneration_launches"),
                              "stepper": tv["mode"]},
     }
 

@@ -584,6 +584,25 @@ extern "C" __global__ void __launch_bounds__(256) hy_ev_scatter(const hy_ep_args
         a.outcome[(u64)u[0]] = (i64)u[1];
     }
 }
+
+// Copies of up to four arrays of doubles in one launch (the snapshot of state / times / parameters in front of a step whose
+// Taylor coefficients are stored on demand). One launch instead of three or four asynchronous copies (0.12 ms for
+// 300 MB).
+struct hy_copy_args {
+    double *dst[4];
+    const double *src[4];
+    u64 n[4];
+};
+extern "C" __global__ void __launch_bounds__(256) hy_copy_arrays(const hy_copy_args a)
+{
+    const u64 stride = (u64)gridDim.x * 256u;
+    for (unsigned q = 0; q < 4u; ++q) {
+        double *d = a.dst[q];
+        const double *s = a.src[q];
+        const u64 n = a.n[q];
+        for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < n; i += stride) d[i] = s[i];
+    }
+}
 )HIP";
     return src.str();
 }

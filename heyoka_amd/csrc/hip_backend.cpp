@@ -567,6 +567,28 @@ void device_buffer::download(void *dst, std::size_t bytes, void *stream) const
     hip_check(hipStreamSynchronize(static_cast<hipStream_t>(stream)), "hipStreamSynchronize");
 }
 
+pinned_buffer::~pinned_buffer()
+{
+    if (m_ptr != nullptr) {
+        (void)hipHostFree(m_ptr);
+    }
+}
+
+void *pinned_buffer::reserve(std::size_t bytes)
+{
+    if (bytes > m_bytes) {
+        if (m_ptr != nullptr) {
+            (void)hipHostFree(m_ptr);
+            m_ptr = nullptr;
+            m_bytes = 0;
+        }
+        const auto want = bytes + bytes / 2u + 4096u;
+        hip_check(hipHostMalloc(&m_ptr, want, hipHostMallocDefault), "hipHostMalloc");
+        m_bytes = want;
+    }
+    return m_ptr;
+}
+
 void device_buffer::zero(void *stream)
 {
     if (m_bytes == 0u) {

@@ -120,4 +120,26 @@ public:
     void zero(void *stream);
 };
 
+// Page-locked host memory (hipHostMalloc): the target of the per-step downloads of a loop. A device-to-host copy into
+// pageable memory makes the runtime pin and unpin the destination around the transfer; with a fresh 20 MB vector per step
+// (the event records of 10^5 systems) the next submission to the device waited 15 ... 25 ms for it
+// (profiles/r05_events_leg_laps.log).
+class pinned_buffer
+{
+    void *m_ptr = nullptr;
+    std::size_t m_bytes = 0;
+
+public:
+    pinned_buffer() = default;
+    ~pinned_buffer();
+    pinned_buffer(const pinned_buffer &) = delete;
+    pinned_buffer &operator=(const pinned_buffer &) = delete;
+    // Grows (never shrinks) to at least 'bytes'; the contents are not preserved.
+    void *reserve(std::size_t bytes);
+    [[nodiscard]] std::size_t bytes() const
+    {
+        return m_bytes;
+    }
+};
+
 } // namespace heyoka_amd

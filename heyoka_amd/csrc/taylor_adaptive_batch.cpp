@@ -234,6 +234,8 @@ struct tab_core::impl {
     void cooldowns_to_host() const;
     void cooldowns_to_device();
     mutable device_buffer d_ev_cursor, d_ev_rec, d_ev_upd;
+    // (Page-locked landing area of the event records of a step: see pinned_buffer.)
+    mutable pinned_buffer h_ev_rec;
     [[nodiscard]] bool is_cluster() const
     {
         // NOTE: true whenever the stepper does not need the tc buffer as its jet scratch (cluster / table
@@ -1297,19 +1299,28 @@ void tab_core::impl::launch_event_stepper(const std::vector<double> *lims)
                 evs_thi = device_buffer(d_thi.bytes(), device);
                 evs_tlo = device_buffer(d_tlo.bytes(), device);
             }
-            device_copy(evs_state.get(), d_state.get(), d_state.bytes(), device, stream);
+            // (One copy kernel of the event-detection module: see hy_copy_arrays in event_detection.cpp.)
+            struct {
+                double *dst[4];
+                const double *src[4];
+                unsigned long long n[4];
+            } ca{{evs_state.as<double>(), evs_thi.as<double>(), evs_tlo.as<double>(), nullptr},
+                 {d_state.as<double>(), d_thi.as<double>(), d_tlo.as<double>(), nullptr},
+                 {d_state.bytes() / dsz, d_thi.bytes() / dsz, d_tlo.bytes() / dsz, 0u}};
             // (Runtime parameters: a callback of this step may change them before somebody asks for the coefficients.)
             if (prog.n_par != 0u && d_pars.bytes() != 0u) {
                 if (evs_pars.bytes() != d_pars.bytes()) {
                     evs_pars = device_buffer(d_pars.bytes(), device);
                 }
-                device_copy(evs_pars.get(), d_pars.get(), d_pars.bytes(), device, stream);
+                ca.dst[3] = evs_pars.as<double>();
+                ca.src[3] = d_pars.as<double>();
+                ca.n[3] = d_pars.bytes() / dsz;
             }
-            device_copy(evs_thi.get(), d_thi.get(), d_thi.bytes(), device, stream);
-            device_copy(evs_tlo.get(), d_tlo.get(), d_tlo.bytes(), device, stream);
+            ed_mod->launch("hy_copy_arrays", std::min<std::uint64_t>(ca.n[0], std::uint64_t(256) * 256u * 16u), 256, &ca, sizeof(ca), stream);
             a.pad = 0;
         }
     }
+
     if (cluster_events) {
         if (d_selnorms.bytes() == 0u) {
             d_selnorms = device_buffer(3u * n * dsz, device);
@@ -1504,12 +1515,15 @@ void tab_core::impl::step_with_events_device(const std::vector<double> *lims)
         dmod->launch_dout(d_state.as<double>(), d_tc.as<double>(), d_douth.as<double>(), N);
     }
     ed_mod->launch("hy_ev_post", N, 256, &pa, sizeof(pa), stream);
-    std::vector<double> rec;
+    const double *rec = nullptr;
+    std::size_t rec_size = 0;
     if (cur[0] != 0u) {
         d_ev_cursor.download(cur, sizeof(cur), stream);
-        rec.resize(cur[1]);
+        rec_size = static_cast<std::size_t>(cur[1]);
         if (cur[1] != 0u) {
-            d_ev_rec.download(rec.data(), rec.size() * dsz, stream);
+            auto *dst = static_cast<double *>(h_ev_rec.reserve(rec_size * dsz));
+            d_ev_rec.download(dst, rec_size * dsz, stream);
+            rec = dst;
         }
     } else {
         stream_synchronize(device, stream);
@@ -1520,36 +1534,63 @@ void tab_core::impl::step_with_events_device(const std::vector<double> *lims)
     step_res_dev_newer = true;
     cd_dev_newer = n_te != 0u;
 
-    // Records -> per-lane lists, in the order of the batch index.
-    struct lane_rec {
+    // Records in the order of the batch index (the compaction kernel appends them in the order its lanes get there): an
+    // index of (lane, offset) pairs, sorted; the events of a record are unpacked into two scratch lists which are reused
+    // from record to record - with 10^5 systems reporting events per step a pair of heap-allocated lists per record was
+    // most of the host time of a step.
+    struct rec_ref {
         std::uint32_t lane;
-        double g_eps, h, thi, tlo;
-        std::vector<detected_event> tes, ntes;
+        std::size_t off;
     };
-    std::vector<lane_rec> recs;
-    for (std::size_t p = 0; p < rec.size();) {
-        const auto *r = rec.data() + p;
-        lane_rec lr{static_cast<std::uint32_t>(r[0]), r[3], r[4], r[5], r[6], {}, {}};
-        const auto c_te = static_cast<unsigned>(r[1]), c_nte = static_cast<unsigned>(r[2]);
-        const auto *e = r + 8;
-        for (unsigned c = 0; c < c_te + c_nte; ++c, e += 4) {
-            (c < c_te ? lr.tes : lr.ntes).push_back({static_cast<std::uint32_t>(e[0]), e[1], static_cast<int>(e[2]), e[3]});
-        }
-        p += 8u + 4u * (c_te + c_nte);
-        recs.push_back(std::move(lr));
+    std::vector<rec_ref> refs;
+    for (std::size_t p = 0; p < rec_size;) {
+        const auto *r = rec + p;
+        refs.push_back({static_cast<std::uint32_t>(r[0]), p});
+        p += 8u + 4u * (static_cast<std::size_t>(r[1]) + static_cast<std::size_t>(r[2]));
         ++ev_systems;
     }
-    std::sort(recs.begin(), recs.end(), [](const auto &x, const auto &y) { return x.lane < y.lane; });
+    std::sort(refs.begin(), refs.end(), [](const auto &x, const auto &y) { return x.lane < y.lane; });
+    struct lane_rec {
+        std::uint32_t lane = 0;
+        double g_eps = 0, h = 0, thi = 0, tlo = 0;
+        std::vector<detected_event> tes, ntes;
+    } lr;
 
     std::vector<std::pair<std::uint32_t, std::exception_ptr>> cb_eptrs;
     auto &upd_cd = pending_cd;
     upd_cd.clear();
     std::vector<double> upd_oc;
     const auto gen = time_gen;
-    for (auto &lr : recs) {
-        const auto by_root = [](const auto &x, const auto &y) { return std::abs(x.root) < std::abs(y.root); };
-        std::stable_sort(lr.tes.begin(), lr.tes.end(), by_root);
-        std::stable_sort(lr.ntes.begin(), lr.ntes.end(), by_root);
+    for (const auto &ref : refs) {
+        {
+            const auto *r = rec + ref.off;
+            lr.lane = ref.lane;
+            lr.g_eps = r[3];
+            lr.h = r[4];
+            lr.thi = r[5];
+            lr.tlo = r[6];
+            lr.tes.clear();
+            lr.ntes.clear();
+            const auto c_te = static_cast<unsigned>(r[1]), c_nte = static_cast<unsigned>(r[2]);
+            const auto *e = r + 8;
+            for (unsigned c = 0; c < c_te + c_nte; ++c, e += 4) {
+                (c < c_te ? lr.tes : lr.ntes).push_back({static_cast<std::uint32_t>(e[0]), e[1], static_cast<int>(e[2]), e[3]});
+            }
+        }
+        // (Stable, by |root|: src/detail/event_detection.cpp:771-781. Insertion sort: the lists hold one or two events and
+        // std::stable_sort() asks the allocator for a buffer every time.)
+        const auto sort_by_root = [](std::vector<detected_event> &v) {
+            for (std::size_t a_ = 1; a_ < v.size(); ++a_) {
+                const auto x = v[a_];
+                auto b_ = a_;
+                for (; b_ > 0u && std::abs(x.root) < std::abs(v[b_ - 1u].root); --b_) {
+                    v[b_] = v[b_ - 1u];
+                }
+                v[b_] = x;
+            }
+        };
+        sort_by_root(lr.tes);
+        sort_by_root(lr.ntes);
         const auto i = lr.lane;
         const auto h = lr.h;
         const auto new_time = dfloat(lr.thi, lr.tlo);

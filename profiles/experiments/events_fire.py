@@ -14,11 +14,12 @@ sp = hy.taylor_adaptive_batch(sys_, st0, n, high_accuracy=True)
 sp.propagate_until(np.random.RandomState(4244).uniform(0.0, 30.0, n))
 st = np.array(sp.state)
 del sp
-y1, y2 = hy.make_vars("y_1", "y_2")
-c = hy.native_event_counter()
-ta = hy.taylor_adaptive_batch(sys_, st, n, high_accuracy=True, nt_events=[hy.nt_event(y1, c), hy.nt_event(y2, c)])
+y1, y2, y3 = hy.make_vars("y_1", "y_2", "y_3")
+c, ct = hy.native_event_counter(), hy.native_event_counter()
+kw = {"t_events": [hy.t_event(y3, ct)]} if len(sys.argv) > 2 and sys.argv[2] == "terminal" else {}
+ta = hy.taylor_adaptive_batch(sys_, st, n, high_accuracy=True, nt_events=[hy.nt_event(y1, c), hy.nt_event(y2, c)], **kw)
 print(ta.hip_source_mode[-150:])
-for _ in range(2):
+for _ in range(8):
     ta.step()
 _ = ta.time
 t0 = time.perf_counter()

@@ -11,6 +11,7 @@ from heyoka_amd import configs
 ap = argparse.ArgumentParser()
 ap.add_argument("--systems", type=int, default=1048576)
 ap.add_argument("--kernels", default="5,3")
+ap.add_argument("--steps-last", action="store_true", help="end with single-step launches (counter passes read the LAST dispatch)")
 args = ap.parse_args()
 n = args.systems
 sys_ = hy.model.nbody(6, masses=configs.OUTER_SS_MASSES, Gconst=configs.OUTER_SS_G)
@@ -31,6 +32,10 @@ for ck in [int(x) for x in args.kernels.split(",")]:
     ta.propagate_until(float(ta.time[0]) + 40.0)
     ns = ta.propagate_res_arrays()[3]
     pms = list(ta.kernel_ms_history(1))[-1]
+    if args.steps_last:
+        for _ in range(3):
+            ta.step()
+        _ = ta.time
     print(json.dumps({"cluster_kernel": ck, "systems": n, "step_kernel_ms": ["%.3f" % x for x in ms], "step_wall_ms": "%.3f" % (wall * 1e3),
                       "single_step_rate": "%.4g" % (n / (np.mean(ms) * 1e-3)),
                       "propagate_rate": "%.4g" % (float(ns.sum()) / (pms * 1e-3)), "mode": ta.hip_source_mode[:90]}))
