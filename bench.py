@@ -26,8 +26,8 @@ import time
 os.environ.setdefault("OMP_PLACES", "cores")
 os.environ.setdefault("OMP_PROC_BIND", "spread")
 # (With OMP_PROC_BIND the OpenMP runtime pins the calling thread - this process's main thread, which also drives the GPU -
-# to ONE core for the rest of the process, and every thread the HIP runtime creates afterwards inherits that mask: legs
-# with many small launches per step then read 5x too slow. The CPU baseline restores the mask it found.)
+# to ONE core for the rest of the process, and every thread created afterwards inherits that mask. The CPU baseline
+# restores the mask it found, so that the legs which follow it run like the ones before it.)
 AFFINITY_AT_START = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
 
 import numpy as np
