@@ -85,7 +85,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
     // Stored members which are linear functions of external inputs only (e.g. the coordinate differences of
     // an N-body pair) are not written to the tape: their lower-order coefficients are recomputed from the
     // jets of the external inputs, which are kept in LDS (ejet[m * n_ej + e]). This removes 3 of the 5 tape
-    // streams of the N-body clusters (HEYOKA_AMD_BLOCK_NO_RECOMPUTE=1 disables it, for A/B measurements).
+    // streams of the N-body clusters.
     std::vector<char> recomp(n_sto, 0);
     std::vector<char> ext_used(n_ext, 0);
     std::vector<std::uint32_t> ej_slots; // distinct slab slots of the external inputs with LDS jets

@@ -1183,7 +1183,7 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     auto &os = e.os;
     // Lane-pair kernel: x^[k+1] = f^[k] * RN(1 / (k + 1)) - one multiplication, within 1 ulp of the quotient - instead of
     // the exact 3-operation sequence (60 VALU instructions per step, +2.1 % system-steps/s; the strict-contraction parity
-    // test passes its 1e4 / 1e5 eps bounds with it). HEYOKA_AMD_V3_EXACT_DIV=1 restores the correctly-rounded quotient.
+    // test passes its 1e4 / 1e5 eps bounds with it). kw::exact_division restores the correctly-rounded quotient.
     e.recip_div = pairk && !opts.exact_division;
     e.enable_pow_rcp(!opts.exact_division);
 

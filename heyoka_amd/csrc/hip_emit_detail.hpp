@@ -1148,7 +1148,7 @@ struct ssa_emitter {
     // (~13 instructions on gfx950): r = RN(1 / b_0) once per step and node, then q0 = acc * r_k with r_k = r * RN(1 / k),
     // the exact residual rem = acc - (k b_0) q0 (FMA) and q = q0 + rem * r_k (Markstein: the correctly-rounded quotient
     // unless r_k is off by more than an ulp in a halfway case). Opt-in of the emitters whose step body is ONE scope (the
-    // reciprocal is defined at the first use and read at every later order): enable_pow_rcp(); HEYOKA_AMD_EXACT_POW_DIV=1
+    // reciprocal is defined at the first use and read at every later order): enable_pow_rcp(); kw::exact_division
     // keeps the plain division.
     bool pow_rcp = false;
     void enable_pow_rcp(bool on = true)

@@ -1918,11 +1918,12 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
     d.prop_res_override.reset();
     d.fix_step_limit = false;
 
-    // Opt-in: the reference's batch-wide semantics (src/taylor_adaptive_batch.cpp:1404-1407, :1462-1467, :1516): a
-    // non-finite lane stops the whole batch at that iteration, max_steps counts lock-step iterations of the batch and
-    // the lanes which are done keep taking zero-length steps. HEYOKA_AMD_REFERENCE_BATCH_SEMANTICS=1 routes
-    // propagate_until() / propagate_for() through the lock-step loop (one step of every lane per sweep), which
-    // implements exactly that; by default every lane runs its own loop on the device (known deviations).
+    // The reference's batch-wide semantics (src/taylor_adaptive_batch.cpp:1404-1407, :1462-1467, :1516): a non-finite lane
+    // stops the whole batch at that iteration, max_steps counts lock-step iterations of the batch and the lanes which are
+    // done keep taking zero-length steps. batch_semantics = 1 routes propagate_until() / propagate_for() through the
+    // lock-step loop (one step of every lane per sweep), which implements exactly that; the default (0) runs every lane's
+    // own loop on the device and falls back to the lock-step loop only where the outcomes would differ (DESIGN.md,
+    // "Outcome semantics").
     const bool ref_semantics = d.batch_semantics == 1 || d.force_lockstep;
 
     if (!cb && !c_out && !d.has_events() && !ref_semantics) {
