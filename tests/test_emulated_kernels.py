@@ -25,12 +25,29 @@ def rel_err(a, b):
 
 
 def _outer_ss(kernel, monkeypatch=None, **kw):
-    ta = hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), None, 64, high_accuracy=True, cluster_kernel=kernel, **kw)
+    # ("v5-nofrx": the one-lane-per-pair kernel with the reactions exported by the pair lanes and the consumer-arranged
+    # operand arrays read with 128-bit loads - the layout the stepper with events keeps.)
+    opts = None
+    if kernel.endswith("-nofrx"):
+        kernel, opts = kernel[:-6], "nofrx"
+    old = os.environ.get("HEYOKA_AMD_V5_OPTS")
+    if opts is not None:
+        os.environ["HEYOKA_AMD_V5_OPTS"] = opts
+    try:
+        ta = hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), None, 64, high_accuracy=True, cluster_kernel=kernel, **kw)
+    finally:
+        if opts is not None:
+            if old is None:
+                del os.environ["HEYOKA_AMD_V5_OPTS"]
+            else:
+                os.environ["HEYOKA_AMD_V5_OPTS"] = old
     assert kernel in ta.hip_source_mode, ta.hip_source_mode
+    if kernel == "v5":
+        assert ("const hy_d2 w" in ta.hip_source) == (opts == "nofrx")  # (128-bit operand reads: only in the nofrx layout)
     return ta
 
 
-@pytest.mark.parametrize("kernel", ["v5", "v3", "v2"])
+@pytest.mark.parametrize("kernel", ["v5", "v5-nofrx", "v3", "v2"])
 def test_emulated_cluster_kernels_single_step_vs_oracle(kernel):
     """One Taylor step of 11 perturbed outer Solar Systems (ragged: the last wavefront holds replicas) with the strict
     (no contraction) host build of the generated source: step sizes to 1e4 eps, states and Taylor coefficients to 1e5 eps
