@@ -149,6 +149,11 @@ struct emitted_module {
     bool compact_tc = false;
     // Mode 4 also evaluates the event equations, takes the final step size and updates the state (emit_options::ev_prog).
     bool events_in_stepper = false;
+    // Single-step launches (mode 0) understand hy_kargs::pad bit 2: a.tfin_hi[] holds a time per system, and the Taylor
+    // coefficients of a step are stored only if the step reaches it (or has length zero). The lock-step loop of
+    // propagate_grid() passes the next grid time of every system: 6 GB of coefficients per sweep of 1 048 576 outer Solar
+    // Systems otherwise, for dense output which a handful of steps need.
+    bool tc_by_threshold = false;
     // When the code was generated from a rewritten INTERNAL program (state-variable aliases, padded clusters, restored unit
     // scalings - the user-visible decomposition is never touched): its text, one node per line in the format of the
     // decomposition strings, then the definitions of the state derivatives. Lets the tests run the oracle's interpreter

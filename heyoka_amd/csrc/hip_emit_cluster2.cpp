@@ -2894,6 +2894,10 @@ if (HY_MODE == 1) {
     if (a.lim != nullptr) mdt = a.lim[s];
 } else {
     step_lim = a.lim[s];
+    // (Taylor coefficients of a lock-step sweep on demand - hy_kargs::pad bit 2, the loop of propagate_grid() without a
+    // callback: a.tfin_hi holds the NEXT GRID TIME of every system, and only the steps which reach it store their
+    // coefficients - see emitted_module::tc_by_threshold.)
+    if ((a.pad & 4) != 0) tfin.hi = a.tfin_hi[s];
 }
 u64 n_steps = 0, iter = 0;
 double min_h = __builtin_inf(), max_h = 0.0, last_h = 0.0;
@@ -3368,7 +3372,14 @@ int nfi = !(hy_finite(nt_hi) && hy_finite(nt_lo)) ? 1 : 0;
     // loop (see the toolchain notes in DESIGN.md). A rolled loop with a running pointer: unrolled, the (order + 1)
     // store addresses per owner slot are invariants of the step loop and get hoisted into registers (84 x 64 bit for
     // the outer Solar System) for a path that only runs when the caller asks for the coefficients.
-    src << (jet_lds ? "if (a.tc != nullptr && !HY_M4) {\n" : "if (a.tc != nullptr) {\n");
+    if (one_lane && jet_lds && !m4) {
+        // (A zero-length step - a system which has reached its last grid point - stores like the reference's lock-step
+        // loop does; a non-finite new time compares false and stores nothing: nobody reads those coefficients.)
+        src << "const bool tc_sys = ((a.pad & 4) == 0) | (h == 0.0) | ((h > 0.0) ? (nt_hi >= tfin.hi) : (nt_hi <= tfin.hi));\n";
+        src << "if (a.tc != nullptr && tc_sys) {\n";
+    } else {
+        src << (jet_lds ? "if (a.tc != nullptr && !HY_M4) {\n" : "if (a.tc != nullptr) {\n");
+    }
     for (const auto &rg : rounds) {
         for (const auto &gr : rg) {
             for (const auto &ow : gr.owners) {
@@ -3604,6 +3615,7 @@ if (l == 0u && live && !hy_tc_only) {
     ret.cluster_mode4 = m4;
     ret.events_in_stepper = ev_inline;
     ret.compact_tc = compact_tc;
+    ret.tc_by_threshold = one_lane && jet_lds && !m4;
     one_lane_jets_in_lds = one_lane && jet_lds;
     ret.notes = std::string(one_lane ? "cluster mode v5 (one lane per pair, 2 wavefronts per SIMD): "
                                      : (pair_split ? "cluster mode v3 (lane pairs, 2 wavefronts per SIMD): " : "cluster mode v2 (pipelined): "))

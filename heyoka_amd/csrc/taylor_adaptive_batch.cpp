@@ -55,6 +55,8 @@ struct grid_kargs {
     unsigned *counters;
     unsigned long long N;
     unsigned n_grid;
+    // (Next grid time of every lane, +-inf once the lane is through its grid: hy_kargs::pad bit 2 of the next sweep.)
+    double *next_tg;
 };
 
 // Code generator from the configuration field (0 automatic: the wave-cluster generator is tried first and falls back
@@ -410,6 +412,9 @@ struct tab_core::impl {
     {
         run_step_impl(&lims, wtc);
     }
+    // (Set by the lock-step loop of propagate_grid(): per-lane times below which a step does not store its Taylor
+    // coefficients - emitted_module::tc_by_threshold.)
+    const double *tc_threshold = nullptr;
     void run_step_impl(const std::vector<double> *lims, bool wtc)
     {
         before_kernel();
@@ -426,6 +431,10 @@ struct tab_core::impl {
             a.tc = d_tc.as<double>();
         }
         a.mode = 0;
+        if (tc_threshold != nullptr && wtc) {
+            a.tfin_hi = tc_threshold;
+            a.pad = 4;
+        }
         dmod->launch_taylor(a);
         after_kernel(wtc);
         step_res_dev_newer = true;
@@ -2050,7 +2059,7 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
                                d.d_tlo.as<double>(), d.d_lasth.as<double>(), d.d_outcome.as<long long>(),
                                b_rem_hi.as<double>(), b_rem_lo.as<double>(), b_mdt.as<double>(), b_tdir.as<int>(),
                                d.d_lim.as<double>(), nullptr, d.d_minh.as<double>(), d.d_maxh.as<double>(),
-                               d.d_nsteps.as<unsigned long long>(), b_cnt.as<unsigned>(), N, 0u};
+                               d.d_nsteps.as<unsigned long long>(), b_cnt.as<unsigned>(), N, 0u, nullptr};
             d.grid_mod->launch("hy_until_post", N, 256, &a, sizeof(a), d.stream);
             unsigned cnt[3] = {0, 0, 0};
             b_cnt.download(cnt, sizeof(cnt), d.stream);
@@ -2139,12 +2148,22 @@ struct hy_grid_args {
     unsigned *counters;
     u64 N;
     unsigned n_grid;
+    double *next_tg;
 };
 
 // Post-step kernel of the device-driven propagate_until() lock-step loop (callbacks / continuous output): the
 // per-lane bookkeeping of src/taylor_adaptive_batch.cpp:1395-1440 (step counters, min/max |h|, remaining time, limit of
 // the next step). counters[0] = lanes done in this sweep, counters[1] = lanes with a non-finite state. The final
 // times are in the (double-length) grid row 0: grid[i] = hi, out[i] = lo.
+// One atomic per wavefront instead of one per lane: the lanes which reach a call site with pred set elect the lowest of
+// them, which adds their number. (hy_grid_post counts the lanes which are NOT through their grid - every lane of every
+// sweep: 262 144 atomics on one address were 6 ms of a 6.5-ms sweep, profiles/r05_grid_sweeps.log.)
+__device__ __forceinline__ void hy_count(unsigned *p, bool pred)
+{
+    const u64 m = __builtin_amdgcn_ballot_w64(pred);
+    if (pred && (unsigned)__builtin_ctzll(m) == (threadIdx.x & 63u)) atomicAdd(p, (unsigned)__builtin_popcountll(m));
+}
+
 extern "C" __global__ void __launch_bounds__(256) hy_until_post(const hy_grid_args a)
 {
     const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
@@ -2153,7 +2172,7 @@ extern "C" __global__ void __launch_bounds__(256) hy_until_post(const hy_grid_ar
     const i64 oc = a.outcome[i];
     const double h = a.last_h[i];
     if (oc == HY_OC_ERR_NF_STATE) {
-        atomicAdd(a.counters + 1, 1u);
+        hy_count(a.counters + 1, true);
         return;
     }
     a.n_steps[i] += (h != 0.0) ? 1u : 0u;
@@ -2163,10 +2182,10 @@ extern "C" __global__ void __launch_bounds__(256) hy_until_post(const hy_grid_ar
         a.max_h[i] = hy_max(a.max_h[i], ah);
     }
     // Stopping terminal event: outcome -index - 1 (src/taylor_adaptive_batch.cpp:1411).
-    if (oc > HY_OC_SUCCESS && oc < 0) atomicAdd(a.counters + 2, 1u);
+    hy_count(a.counters + 2, oc > HY_OC_SUCCESS && oc < 0);
     hy_df rem; rem.hi = a.rem_hi[i]; rem.lo = a.rem_lo[i];
+    hy_count(a.counters, h == rem.hi);
     if (h == rem.hi) {
-        atomicAdd(a.counters, 1u);
         rem.hi = 0.0; rem.lo = 0.0;
     } else {
         hy_df tcur; tcur.hi = a.thi[i]; tcur.lo = a.tlo[i];
@@ -2189,7 +2208,7 @@ extern "C" __global__ void __launch_bounds__(256) hy_grid_post(const hy_grid_arg
     const i64 oc = a.outcome[i];
     const double h = a.last_h[i];
     if (oc == HY_OC_ERR_NF_STATE) {
-        atomicAdd(a.counters + 1, 1u);
+        hy_count(a.counters + 1, true);
         return;
     }
     a.n_steps[i] += (h != 0.0) ? 1u : 0u;
@@ -2199,7 +2218,7 @@ extern "C" __global__ void __launch_bounds__(256) hy_grid_post(const hy_grid_arg
         a.max_h[i] = hy_max(a.max_h[i], ah);
     }
     // Stopping terminal event: outcome -index - 1 (:1903-1908).
-    if (oc > HY_OC_SUCCESS && oc < 0) atomicAdd(a.counters + 2, 1u);
+    hy_count(a.counters + 2, oc > HY_OC_SUCCESS && oc < 0);
     hy_df tcur; tcur.hi = a.thi[i]; tcur.lo = a.tlo[i];
     hy_df rem; rem.hi = a.rem_hi[i]; rem.lo = a.rem_lo[i];
     const unsigned ng = a.n_grid;
@@ -2245,13 +2264,17 @@ extern "C" __global__ void __launch_bounds__(256) hy_grid_post(const hy_grid_arg
         ++g;
     }
     a.gidx[i] = g;
+    // (The next grid time of the lane: the steps which do not reach it need not store their Taylor coefficients.)
+    if (a.next_tg != nullptr) {
+        a.next_tg[i] = (g < ng) ? a.grid[(u64)g * N + i] : ((a.t_dir[i] != 0) ? __builtin_inf() : -__builtin_inf());
+    }
     // Limit of the next step.
     hy_df m; m.lo = 0.0;
     double lim;
     if (a.t_dir[i] != 0) { m.hi = a.mdt[i]; lim = hy_df_lt(rem, m) ? rem.hi : m.hi; }
     else { m.hi = -a.mdt[i]; lim = hy_df_lt(m, rem) ? rem.hi : m.hi; }
     a.lim[i] = lim;
-    if (g < ng) atomicAdd(a.counters, 1u);
+    hy_count(a.counters, g < ng);
 }
 )HIP";
     return src.str();
@@ -2316,6 +2339,26 @@ void tab_core::propagate_grid_device_loop(const std::vector<double> &grid, std::
     d.fix_step_limit = false;
     std::size_t iter_counter = 0;
     bool any_step = false;
+    // Taylor coefficients on demand: dense output is evaluated only in the steps which reach a grid point, so a stepper
+    // which can tell (emitted_module::tc_by_threshold) stores the coefficients of those steps only - unless a step callback
+    // may look at them, or the stepper with events is in charge (its own on-demand logic is switched off below).
+    const bool tc_on_demand = !cb && !d.has_events() && d.emitted.tc_by_threshold && n_grid > 1u;
+    device_buffer b_next_tg(tc_on_demand ? N * dsz : 0u, d.device);
+    if (tc_on_demand) {
+        std::vector<double> tg(N);
+        for (std::uint32_t i = 0; i < N; ++i) {
+            tg[i] = grid[static_cast<std::size_t>(N) + i];
+        }
+        b_next_tg.upload(tg.data(), N * dsz, d.stream);
+        d.tc_threshold = b_next_tg.as<double>();
+    }
+    const struct thr_reset {
+        const double *&p;
+        ~thr_reset()
+        {
+            p = nullptr;
+        }
+    } thr_guard{d.tc_threshold};
     // (The dense output over the grid consumes the Taylor coefficients of every step.)
     d.ev_all_tc = true;
     const struct all_tc_reset {
@@ -2338,7 +2381,8 @@ void tab_core::propagate_grid_device_loop(const std::vector<double> &grid, std::
                            d.d_tlo.as<double>(),   d.d_lasth.as<double>(), d.d_outcome.as<long long>(),
                            b_rem_hi.as<double>(),  b_rem_lo.as<double>(),  b_mdt.as<double>(),    b_tdir.as<int>(),
                            d.d_lim.as<double>(),   b_gidx.as<unsigned>(),  d.d_minh.as<double>(), d.d_maxh.as<double>(),
-                           d.d_nsteps.as<unsigned long long>(), b_cnt.as<unsigned>(), N, n_grid};
+                           d.d_nsteps.as<unsigned long long>(), b_cnt.as<unsigned>(), N, n_grid,
+                           tc_on_demand ? b_next_tg.as<double>() : nullptr};
         d.grid_mod->launch("hy_grid_post", N, 256, &a, sizeof(a), d.stream);
         unsigned cnt[3] = {0, 0, 0};
         b_cnt.download(cnt, sizeof(cnt), d.stream);

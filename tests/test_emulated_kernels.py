@@ -86,3 +86,28 @@ def test_emulated_v5_propagation_through_the_work_queue_with_refill():
     ns_o = np.array([int(p[3]) for p in ora.prop_res])
     assert np.abs(r["n_steps"].astype(np.int64) - ns_o).max() <= 1
     assert rel_err(r["state"], ora.state.reshape(36, n)) <= 1e5 * EPS
+
+
+def test_emulated_v5_taylor_coefficients_by_threshold():
+    """Single-step launch with hy_kargs::pad bit 2 (the lock-step loop of propagate_grid() without a callback): a.tfin_hi holds a
+    time per system, and only the systems whose step reaches it store their Taylor coefficients - bit for bit the
+    coefficients of the launch which stores them all; state, step sizes and times do not depend on it."""
+    n = 11
+    st = configs.outer_ss_state(n, perturb=1e-6, seed=5)
+    ta = _outer_ss("v5")
+    k = emu.EmulatedKernel(ta.hip_source)
+    rows = 36 * (ta.order + 1)
+    full = k.run(st, np.zeros(n), np.zeros(n), mode=0, lim=np.full(n, np.inf), want_tc_rows=rows)
+    thr = np.where(np.arange(n) % 2 == 0, 0.01, 1e9)  # (a step of the outer Solar System is ~0.4 yr)
+    part = k.run(st, np.zeros(n), np.zeros(n), mode=0, lim=np.full(n, np.inf), want_tc_rows=rows, tfin=thr, pad=4)
+    for key in ("state", "last_h", "time_hi", "time_lo"):
+        assert np.array_equal(full[key], part[key]), key
+    reached = full["time_hi"] >= thr
+    assert reached.any() and not reached.all()
+    assert np.array_equal(part["tc"][:, reached], full["tc"][:, reached])
+    assert np.all(part["tc"][:, ~reached] == 0.0)
+    # Backward in time: the comparison turns around.
+    fullb = k.run(st, np.zeros(n), np.zeros(n), mode=0, lim=np.full(n, -np.inf), want_tc_rows=rows)
+    partb = k.run(st, np.zeros(n), np.zeros(n), mode=0, lim=np.full(n, -np.inf), want_tc_rows=rows, tfin=-thr, pad=4)
+    assert np.array_equal(partb["tc"][:, reached], fullb["tc"][:, reached])
+    assert np.all(partb["tc"][:, ~reached] == 0.0)
