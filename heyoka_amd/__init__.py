@@ -1111,6 +1111,18 @@ class taylor_adaptive_batch:
             raise ValueError("invalid state size")
         raise_for(lib.hy_tab_set_state(self._h, a.ctypes.data))
 
+    def state_data(self):
+        """get_state_data(): a WRITABLE (dim, batch_size) view of the host mirror of the state, valid while the integrator
+        lives. Like in the reference, what is written through it is what the next step starts from - which makes the
+        integrator refresh the mirror after every launch from now on (eager synchronisation); ``ta.state = ...`` and the
+        device views do not."""
+        p = lib.hy_tab_get_state_data(self._h)
+        if not p:
+            raise RuntimeError(_lib.last_error())
+        n = self.dim * self.batch_size
+        arr = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_double)), shape=(n,))
+        return arr.reshape(self.dim, self.batch_size)
+
     @property
     def pars(self):
         out = np.empty((self.n_pars, self.batch_size))

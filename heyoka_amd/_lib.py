@@ -161,6 +161,8 @@ SIGNATURES = [
     ("hy_hiprtc_compile", c_int, [c_char_p, c_void_p, c_void_p]),
     ("hy_tab_get_state", c_int, [c_void_p, c_void_p]),
     ("hy_tab_set_state", c_int, [c_void_p, c_void_p]),
+    ("hy_tab_get_state_data", c_void_p, [c_void_p]),
+    ("hy_tab_get_pars_data", c_void_p, [c_void_p]),
     ("hy_tab_get_pars", c_int, [c_void_p, c_void_p]),
     ("hy_tab_set_pars", c_int, [c_void_p, c_void_p]),
     ("hy_tab_get_dtime", c_int, [c_void_p, c_void_p, c_void_p]),

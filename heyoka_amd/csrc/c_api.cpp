@@ -981,10 +981,20 @@ int hy_tab_get_state(hy_tab t, double *out)
 int hy_tab_set_state(hy_tab t, const double *in)
 {
     return guarded([&] {
-        const auto n = static_cast<std::size_t>(t->core.get_dim()) * t->core.get_batch_size();
-        auto *p = t->core.get_state_data();
-        std::memcpy(p, in, n * sizeof(double));
+        t->core.set_state_values(in);
     });
+}
+double *hy_tab_get_state_data(hy_tab t)
+{
+    double *ret = nullptr;
+    (void)guarded([&] { ret = t->core.get_state_data(); });
+    return ret;
+}
+double *hy_tab_get_pars_data(hy_tab t)
+{
+    double *ret = nullptr;
+    (void)guarded([&] { ret = t->core.get_pars_data(); });
+    return ret;
 }
 int hy_tab_get_pars(hy_tab t, double *out)
 {
@@ -996,9 +1006,7 @@ int hy_tab_get_pars(hy_tab t, double *out)
 int hy_tab_set_pars(hy_tab t, const double *in)
 {
     return guarded([&] {
-        const auto n = t->core.get_pars().size();
-        auto *p = t->core.get_pars_data();
-        std::memcpy(p, in, n * sizeof(double));
+        t->core.set_pars_values(in);
     });
 }
 int hy_tab_get_dtime(hy_tab t, double *hi, double *lo)

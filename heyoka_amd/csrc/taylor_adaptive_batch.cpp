@@ -982,6 +982,22 @@ double *tab_core::get_pars_data()
     return d.pars.data();
 }
 
+void tab_core::set_state_values(const double *in)
+{
+    auto &d = *m_impl;
+    d.to_host();
+    std::copy(in, in + d.state.size(), d.state.begin());
+    d.host_newer = true;
+}
+
+void tab_core::set_pars_values(const double *in)
+{
+    auto &d = *m_impl;
+    d.to_host();
+    std::copy(in, in + d.pars.size(), d.pars.begin());
+    d.host_newer = true;
+}
+
 void tab_core::impl::ensure_tc_complete() const
 {
     if (!tc_partial) {

@@ -173,6 +173,11 @@ public:
     [[nodiscard]] double *get_state_data();
     [[nodiscard]] const std::vector<double> &get_pars() const;
     [[nodiscard]] double *get_pars_data();
+    // Setters by value (the C ABI's hy_tab_set_state() / hy_tab_set_pars()): the mirrors are brought up to date, overwritten
+    // and marked newer than the device - no pointer leaves the object, so it does NOT switch to the eager synchronisation
+    // which a handed-out mutable pointer requires (a download of the state after every launch).
+    void set_state_values(const double *in);
+    void set_pars_values(const double *in);
     [[nodiscard]] const std::vector<double> &get_tc() const;
     [[nodiscard]] const std::vector<double> &get_last_h() const;
     [[nodiscard]] const std::vector<double> &get_d_output() const;

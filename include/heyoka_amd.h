@@ -301,9 +301,17 @@ int hy_tab_get_code_object(hy_tab, void *out, size_t *size);
 int hy_hiprtc_compile(const char *source, void *out, size_t *size);
 
 int hy_tab_get_state(hy_tab, double *out);                 /* get_state()        n_eq * batch_size */
-int hy_tab_set_state(hy_tab, const double *in);            /* writes through get_state_data() */
+int hy_tab_set_state(hy_tab, const double *in);            /* the values of get_state_data()[...] = in[...]; by value: the
+                                                            * integrator stays lazily synchronised */
 int hy_tab_get_pars(hy_tab, double *out);                  /* get_pars() */
-int hy_tab_set_pars(hy_tab, const double *in);             /* writes through get_pars_data() */
+int hy_tab_set_pars(hy_tab, const double *in);             /* like hy_tab_set_state() for get_pars_data() */
+/* get_state_data() / get_pars_data() (include/heyoka/taylor.hpp:984-990): MUTABLE pointers to the host mirrors, valid for
+ * the lifetime of the integrator. Reference call sites write through them between steps (ta.get_state_data()[i] = ...), so
+ * handing one out switches the integrator to eager synchronisation: the mirrors are refreshed after every launch and
+ * uploaded before the next one (a download of the whole state per step: use the setters above, or the device views of
+ * hy_tab_device_ptr(), where that matters). NULL + hy_last_error() on failure. */
+double *hy_tab_get_state_data(hy_tab);
+double *hy_tab_get_pars_data(hy_tab);
 int hy_tab_get_dtime(hy_tab, double *hi, double *lo);      /* get_dtime()        batch_size each; lo may be NULL */
 int hy_tab_set_time(hy_tab, const double *t, size_t n);    /* set_time(): n == 1 scalar, else batch_size */
 int hy_tab_set_dtime(hy_tab, const double *hi, const double *lo, size_t n); /* set_dtime() */

@@ -1572,8 +1572,8 @@ def test_reference_batch_semantics(semantics):
 
 @pytest.mark.gpu
 def test_rollback_of_a_batch_with_a_nonfinite_lane_when_the_state_was_set_through_the_setter():
-    """Advisor finding (round 3): with the state written through the setter (hy_tab_set_state / ta.state = ..., which keeps
-    the host mirrors in step with the device after every launch) the rollback of a batch with a diverging lane restored
+    """Advisor finding (round 3): with the state written through the mutable host pointer (get_state_data() /
+    ta.state_data(), which keeps the host mirrors in step with the device after every launch) the rollback of a batch with a diverging lane restored
     the device buffers only - the forced lock-step re-run then uploaded the END state of the rolled-back propagation over
     the snapshot. The healthy lanes must come out as in the oracle's lock-step loop, exactly like with the state passed to
     the constructor."""
@@ -1583,8 +1583,13 @@ def test_rollback_of_a_batch_with_a_nonfinite_lane_when_the_state_was_set_throug
     ref = hy.taylor_adaptive_batch([(x, x * x), (v, -v)], st, 4)
     ref.propagate_until(3.0)
     ta = hy.taylor_adaptive_batch([(x, x * x), (v, -v)], np.zeros((2, 4)), 4)
-    ta.state = st  # the setter: sticky host pointer
+    ta.state_data()[:] = st  # get_state_data(): a handed-out host pointer, eager synchronisation from here on
     ta.propagate_until(3.0)
+    # (The setter by value does not switch the integrator to eager synchronisation - and gives the same results.)
+    tv = hy.taylor_adaptive_batch([(x, x * x), (v, -v)], np.zeros((2, 4)), 4)
+    tv.state = st
+    tv.propagate_until(3.0)
+    assert tv.propagate_res == ta.propagate_res and np.array_equal(np.nan_to_num(tv.state), np.nan_to_num(ta.state))
     ora = ho.OracleIntegrator([(ox, ox * ox), (ov, -1.0 * ov)], st, 4)
     ora.propagate_until(3.0)
     assert [int(r[0]) for r in ta.propagate_res] == [int(r[0]) for r in ora.prop_res]
