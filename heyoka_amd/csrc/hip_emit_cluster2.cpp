@@ -384,6 +384,11 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     std::vector<std::array<std::uint32_t, 3>> wide_pr, wide_rx; // ... its output slots, per lane and coordinate
     std::uint32_t slab_stride_opt = 0;
     std::uint64_t bank_cost = 0;
+    // One-lane pair kernel: the bookkeeping block of a system (16 doubles parked between the tails of two steps) sits at the
+    // end of its slab instead of in an array of its own - its address is the slab pointer + a constant, and the register
+    // which held it (spilled: two scratch reloads per step) is gone: +0.7 %, profiles/r05_ab_bookkeeping_in_slab.log (a
+    // laundered system index in the retire block, against hoisted address arithmetic, measured nothing).
+    const bool bk_in_slab = one_lane && !v5_flag("nobkslab");
     if (one_lane) {
         // 32 systems per CU: the slab only keeps the slots which are read through it (positions, products, glue nodes
         // with readers): 63 instead of 144 for the outer Solar System.
@@ -683,8 +688,9 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
             }
             return tot;
         };
-        // Total slots incl. the dummy area (as computed below).
-        const auto n_tot_est = ns + std::max<std::uint32_t>(static_cast<std::uint32_t>(pl.out_pos.size()), 6u);
+        // Total slots incl. the dummy area (as computed below) and the 16 bookkeeping doubles of the system, which sit at the
+        // end of its slab (one address register for both: see bk_in_slab).
+        const auto n_tot_est = ns + std::max<std::uint32_t>(static_cast<std::uint32_t>(pl.out_pos.size()), 6u) + (bk_in_slab ? 16u : 0u);
         assign();
         slab_stride_opt = n_tot_est;
         auto best = cost(slab_stride_opt);
@@ -1048,7 +1054,7 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
                 auto best_perm = perm;
                 std::uint32_t best_D = Dd, best_stride = 0;
                 // (+ 2: the dummy area behind the arrays - idle lanes of a partially filled glue round publish there.)
-                const auto total_for = [&](std::uint32_t D_) { return pos_sz + 2u * D_ + blk_used + 2u; };
+                const auto total_for = [&](std::uint32_t D_) { return pos_sz + 2u * D_ + blk_used + 2u + (bk_in_slab ? 16u : 0u); };
                 // The distance between the coordinate blocks and between the slabs of two systems: scanned with the bank model
                 // (reads in the lane groups of each instruction width; the stores are settled by the placement above).
                 for (std::uint32_t D_ = blk_used; D_ <= blk_used + 6u; D_ += 2u) {
@@ -1107,7 +1113,7 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
                         }
                     }
                 }
-                pl.n_slots = total_for(Dd) - 2u;
+                pl.n_slots = total_for(Dd) - 2u - (bk_in_slab ? 16u : 0u);
                 (void)out_slot;
             }
         }
@@ -1124,7 +1130,8 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     // their order).
     const auto buf_stride = one_lane ? 0u : n_slots_tot; // doubles between the two parity buffers
     // (One buffer; the stride comes out of the bank-conflict search above.)
-    const auto slab_stride = one_lane ? std::max(slab_stride_opt, n_slots_tot) : ((2u * n_slots_tot) | 1u); // doubles per system
+    const auto slab_stride = one_lane ? std::max(slab_stride_opt, n_slots_tot + (bk_in_slab ? 16u : 0u))
+                                      : ((2u * n_slots_tot) | 1u); // doubles per system
 
     // ---- 3. Tables. ----
     std::vector<std::vector<std::uint32_t>> utbl;
@@ -2577,7 +2584,11 @@ __device__ __forceinline__ double hy_swap1(double x)
     }
     src << "double *const slab = lds_slab + (wib * " << spw << "u + q) * " << slab_stride << "u;\n";
     if (one_lane) {
-        src << "__shared__ double lds_bk[" << wpb * spw * 16u << "];\ndouble *const bk = lds_bk + (wib * " << spw << "u + q) * 16u;\n";
+        if (bk_in_slab) {
+            src << "double *const bk = slab + " << (slab_stride - 16u) << "u;\n";
+        } else {
+            src << "__shared__ double lds_bk[" << wpb * spw * 16u << "];\ndouble *const bk = lds_bk + (wib * " << spw << "u + q) * 16u;\n";
+        }
     }
     const bool vexch_decl = vexch;
     src << "const u64 gwave = (u64)blockIdx.x * " << wpb << "u + wib;\n";
