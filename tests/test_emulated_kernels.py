@@ -111,3 +111,32 @@ def test_emulated_v5_taylor_coefficients_by_threshold():
     partb = k.run(st, np.zeros(n), np.zeros(n), mode=0, lim=np.full(n, -np.inf), want_tc_rows=rows, tfin=-thr, pad=4)
     assert np.array_equal(partb["tc"][:, reached], fullb["tc"][:, reached])
     assert np.all(partb["tc"][:, ~reached] == 0.0)
+
+
+@pytest.mark.parametrize("nb,masses", [(5, None), (6, None), (6, [3.0, 1e-3, 0.7, 2.0, 4e-3, 0.5])])
+def test_emulated_v5_other_systems_single_step_vs_oracle(nb, masses):
+    """The one-lane-per-pair kernel with the reactions fused into the sums on other pair-interaction systems: 5 bodies (10
+    pairs on 16 lanes, 15 sums: ONE glue round) and 6 bodies with other mass ratios than the outer Solar System's (comparable
+    masses: reaction coefficients of order one). (Equal masses take model::nbody() to its grouped branch, whose clusters
+    have another shape: those systems run on the lane-pair / first-generation kernels.)"""
+    rng = np.random.RandomState(40 + nb)
+    if masses is None:
+        masses = list(1.0 / (1.0 + np.arange(nb)) ** 2)
+    n = 13
+    pos = rng.uniform(-3.0, 3.0, (nb, 3, n)) + 6.0 * np.arange(nb)[:, None, None] * np.array([1.0, 0.3, -0.2])[None, :, None]
+    vel = rng.uniform(-0.3, 0.3, (nb, 3, n))
+    st = np.concatenate([np.concatenate([pos[b], vel[b]], axis=0) for b in range(nb)], axis=0)
+    ta = hy.taylor_adaptive_batch(hy.model.nbody(nb, masses=masses), None, 64, high_accuracy=True, cluster_kernel="v5")
+    assert "v5" in ta.hip_source_mode, ta.hip_source_mode
+    assert "frc" in ta.hip_source  # (coefficient registers of the fused sums)
+    k = emu.EmulatedKernel(ta.hip_source)
+    rows = 6 * nb * (ta.order + 1)
+    r = k.run(st, np.zeros(n), np.zeros(n), mode=0, lim=np.full(n, np.inf), want_tc_rows=rows)
+    ora = ho.OracleIntegrator(ho.nbody(nb, masses=masses), st, n, high_accuracy=True)
+    ora.step(wtc=True)
+    h_o = np.array([h for _, h in ora.step_res])
+    assert rel_err(r["last_h"], h_o) <= 1e4 * EPS
+    assert rel_err(r["state"], ora.state.reshape(6 * nb, n)) <= 1e5 * EPS
+    tc_o = ora.tc.reshape(6 * nb, ta.order + 1, n)
+    scale = np.max(np.abs(tc_o), axis=2, keepdims=True) + 1e-300
+    assert np.max(np.abs(r["tc"].reshape(tc_o.shape) - tc_o) / scale) <= 1e5 * EPS
