@@ -1396,6 +1396,7 @@ bool add_state_aliases(const taylor_program &, taylor_program &);
 bool pad_clusters(const taylor_program &, std::uint32_t, taylor_program &);
 bool insert_unit_scalings(const taylor_program &, taylor_program &);
 bool privatise_cluster_inputs(const taylor_program &, taylor_program &);
+bool linearise_accelerations(const taylor_program &, taylor_program &);
 
 std::string program_to_string(const taylor_program &p)
 {
@@ -1459,6 +1460,7 @@ dev_switches dev_switches::from_env()
     d.block_v2 = !off("HEYOKA_AMD_BLOCK_V2");
     d.state_aliases = !set("HEYOKA_AMD_NO_STATE_ALIASES");
     d.cluster_v1 = set("HEYOKA_AMD_CLUSTER_V1");
+    d.linearise = !set("HEYOKA_AMD_NO_LINEARISED_SUMS");
     d.table_lds = num("HEYOKA_AMD_TABLE_LDS", -1);
     d.ev_inline_max_nonlinear = num("HEYOKA_AMD_EV_INLINE_MAX_NONLINEAR", -1);
     d.v5_prio = num("HEYOKA_AMD_V5_PRIO", 2);
@@ -1479,6 +1481,40 @@ emitted_module emit_hip_module(const taylor_program &prog, const emit_options &o
         case emit_mode::cluster: {
             std::string why;
             auto m = emit_cluster_or_empty(prog, opts, why);
+            // Pair-interaction systems whose accelerations are not plain sums over the partners (equal or repeated masses:
+            // sum / sub / negation trees, reactions as glue nodes of their own) miss the one-lane-per-pair kernel only
+            // because of that: retry on the internal program with the accelerations flattened (linearise_accelerations()).
+            // (Generations of the wave-cluster kernels, best first: one lane per pair, lane pairs, pipelined, first one.)
+            const auto kernel_rank = [](const emitted_module &em) {
+                if (em.source.empty()) {
+                    return 0;
+                }
+                for (const auto &[tag, r] : {std::pair{"cluster mode v5", 4}, std::pair{"cluster mode v3", 3}, std::pair{"cluster mode v2", 2}}) {
+                    if (em.notes.find(tag) != std::string::npos) {
+                        return r;
+                    }
+                }
+                return 1;
+            };
+            if (opts.dev.linearise && !opts.dev.cluster_v1 && !opts.event_stepper && opts.cluster_kernel != 1 && kernel_rank(m) < 4) {
+                taylor_program lin;
+                if (linearise_accelerations(prog, lin)) {
+                    std::string w2;
+                    auto m2 = emit_cluster_or_empty(lin, opts, w2);
+                    // (Unit masses next to other masses: the elided unit factors of the scaled powers, like below.)
+                    taylor_program lin_scaled;
+                    if (m2.source.empty() && w2.rfind("clusters are not isomorphic", 0) == 0 && insert_unit_scalings(lin, lin_scaled)) {
+                        m2 = emit_cluster_or_empty(lin_scaled, opts, w2);
+                        lin = std::move(lin_scaled);
+                    }
+                    if (kernel_rank(m2) > kernel_rank(m)) {
+                        m2.notes += "; accelerations rewritten as flat sums of scaled pair products in the internal program "
+                                    "(re-associated additions: equal to the decomposition to rounding)";
+                        m2.internal_program = program_to_string(lin);
+                        return m2;
+                    }
+                }
+            }
             if (m.source.empty() && why.rfind("a state variable is a history operand", 0) == 0
                 && opts.dev.state_aliases) {
                 // Retry with alias u variables for those state variables (see add_state_aliases()).

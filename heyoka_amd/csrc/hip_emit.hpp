@@ -76,7 +76,7 @@ enum class emit_mode { unrolled, cluster, table, block };
 // HEYOKA_AMD_EVENTS_TIMING belong to the runtime, not to code generation.)
 struct dev_switches {
     bool v5_events = true, compact_tc = true, events_in_stepper = true, pair_events = true, refill = true, block_v2 = true,
-         state_aliases = true, cluster_v1 = false;
+         state_aliases = true, cluster_v1 = false, linearise = true;
     int table_lds = -1, ev_inline_max_nonlinear = -1, v5_prio = 2;
     // HEYOKA_AMD_UNROLLED_WAVES=n: the straight-line stepper is compiled for n wavefronts per SIMD (amdgpu_waves_per_eu: the
     // register allocator gets 512 / n registers per lane and spills the rest - the two-wavefront experiment of round 5).

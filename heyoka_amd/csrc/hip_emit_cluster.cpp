@@ -375,6 +375,229 @@ bool insert_unit_scalings(const taylor_program &p, taylor_program &out)
     return true;
 }
 
+// Accelerations as flat sums of scaled pair products. model::nbody() writes the acceleration of a body as whatever its
+// masses let the expression system fold: with distinct numerical masses a plain sum over the partners, each term a product
+// d * (G m r^-3) or its "reaction" c * (d * (G m r^-3)) - the shape the one-lane-per-pair kernel is built for -, but with
+// EQUAL masses the reactions become negations and the sums of a body turn into sum / sub / -1 * sum trees whose kind differs
+// from body to body (default masses: src/model/nbody.cpp:95-130, the grouped branch), and with REPEATED masses the reactions
+// are glue nodes of their own in front of the sums: two glue levels. The lanes of a glue round execute one instruction
+// stream, so those systems fell to the lane-pair / first-generation kernels (1.5e8 ... 5.5e8 system-steps/s against 7.9e8).
+// This pass rewrites the INTERNAL program (the user-visible decomposition is untouched): the definition of every state
+// variable which is a linear tree - sum, sub, prod(number, .) - over products of two variables is flattened into
+// sum_j c_j p_j; every product keeps the appearance with coefficient +1 as the direct one, the other one becomes a node
+// prod(c, p) right behind it (the reaction), and the acceleration becomes ONE sum node over its terms in the order of the
+// flattened tree. The result has the shape of the distinct-mass decomposition. NOTE: the additions of an acceleration are
+// re-associated (one pairwise sum over all the terms instead of the tree of the expression) and nested constant factors are
+// multiplied on the host: the jets of the rewritten program agree with the decomposition to rounding, not bit for bit -
+// the one rewrite of this family with that property (tests: 1e3 eps on the jets of the internal program).
+// Returns false if the program does not have that form or nothing would change.
+bool linearise_accelerations(const taylor_program &p, taylor_program &out)
+{
+    const auto n_eq = p.n_eq;
+    constexpr auto none = std::numeric_limits<std::uint32_t>::max();
+    if (!p.ev_u.empty() || p.n_par != 0u) {
+        return false;
+    }
+    const auto node_of = [&](std::uint32_t u) -> const dc_node & { return p.nodes[u - n_eq]; };
+    const auto is_num = [](const operand &o) { return o.type == operand::kind::num; };
+    // Linear glue: sum over variables, sub of two variables, prod(number, variable).
+    const auto linear = [&](std::uint32_t u) {
+        if (u < n_eq) {
+            return false;
+        }
+        const auto &n = node_of(u);
+        if (!n.deps.empty()) {
+            return false;
+        }
+        if (n.kind == func_kind::sum) {
+            return !n.args.empty() && std::all_of(n.args.begin(), n.args.end(), [](const operand &o) { return is_var(o); });
+        }
+        if (n.kind == func_kind::sub) {
+            return n.args.size() == 2u && is_var(n.args[0]) && is_var(n.args[1]);
+        }
+        return n.kind == func_kind::prod && n.args.size() == 2u && is_num(n.args[0]) && is_var(n.args[1]);
+    };
+    const auto leaf_ok = [&](std::uint32_t u) {
+        if (u < n_eq) {
+            return false;
+        }
+        const auto &n = node_of(u);
+        return n.kind == func_kind::prod && n.args.size() == 2u && is_var(n.args[0]) && is_var(n.args[1]) && n.deps.empty();
+    };
+    // Flattened definitions.
+    struct term {
+        double c;
+        std::uint32_t leaf;
+    };
+    std::vector<std::vector<term>> flat(n_eq);
+    std::vector<char> removed(p.n_u, 0);
+    bool ok = true, any_tree = false;
+    const std::function<void(std::uint32_t, double, std::vector<term> &)> walk = [&](std::uint32_t u, double c, std::vector<term> &dst) {
+        if (!ok) {
+            return;
+        }
+        if (linear(u)) {
+            removed[u] = 1;
+            const auto &n = node_of(u);
+            if (n.kind == func_kind::sum) {
+                for (const auto &o : n.args) {
+                    walk(o.idx, c, dst);
+                }
+            } else if (n.kind == func_kind::sub) {
+                walk(n.args[0].idx, c, dst);
+                walk(n.args[1].idx, -c, dst);
+            } else {
+                walk(n.args[1].idx, c * n.args[0].value, dst);
+            }
+            return;
+        }
+        if (!leaf_ok(u)) {
+            ok = false;
+            return;
+        }
+        dst.push_back({c, u});
+    };
+    std::vector<std::uint32_t> acc_vars;
+    for (std::uint32_t i = 0; i < n_eq && ok; ++i) {
+        const auto &d = p.sv_defs[i];
+        if (d.type != operand::kind::uvar) {
+            return false;
+        }
+        if (d.idx < n_eq) {
+            continue; // (x' = v)
+        }
+        walk(d.idx, 1., flat[i]);
+        acc_vars.push_back(i);
+        const auto &root = node_of(d.idx);
+        // (Already one sum over leaves and reactions: nothing to do for this variable.)
+        any_tree = any_tree || !(root.kind == func_kind::sum && std::all_of(root.args.begin(), root.args.end(), [&](const operand &o) {
+                                     return leaf_ok(o.idx);
+                                 }));
+    }
+    if (!ok || acc_vars.size() < 2u || !any_tree) {
+        return false;
+    }
+    const auto n_terms = flat[acc_vars[0]].size();
+    if (n_terms < 2u) {
+        return false;
+    }
+    // Appearances of every leaf: at most two, one of them with coefficient +1 (the direct product).
+    std::map<std::uint32_t, std::vector<std::pair<std::uint32_t, double>>> app;
+    for (const auto i : acc_vars) {
+        if (flat[i].size() != n_terms) {
+            return false;
+        }
+        for (const auto &t : flat[i]) {
+            if (!std::isfinite(t.c) || t.c == 0.) {
+                return false;
+            }
+            app[t.leaf].emplace_back(i, t.c);
+        }
+    }
+    std::map<std::pair<std::uint32_t, std::uint32_t>, bool> is_reaction; // (variable, leaf) -> reads the reaction node
+    std::map<std::uint32_t, double> rx_coef;                            // leaf -> coefficient of its reaction node
+    for (const auto &[leaf, v] : app) {
+        if (v.size() > 2u || (v.size() == 2u && v[0].first == v[1].first)) {
+            return false;
+        }
+        std::size_t direct = v.size();
+        for (std::size_t a = 0; a < v.size(); ++a) {
+            if (v[a].second == 1.) {
+                direct = a;
+                break;
+            }
+        }
+        if (direct == v.size()) {
+            return false;
+        }
+        for (std::size_t a = 0; a < v.size(); ++a) {
+            is_reaction[{v[a].first, leaf}] = a != direct;
+            if (a != direct) {
+                rx_coef[leaf] = v[a].second;
+            }
+        }
+    }
+    // The removed linear nodes must have no reader outside the trees.
+    for (std::uint32_t u = n_eq; u < p.n_u; ++u) {
+        if (removed[u] != 0) {
+            continue;
+        }
+        for (const auto &o : node_of(u).args) {
+            if (is_var(o) && removed[o.idx] != 0) {
+                return false;
+            }
+        }
+        for (const auto dd : node_of(u).deps) {
+            if (removed[dd] != 0) {
+                return false;
+            }
+        }
+    }
+    // New numbering: the kept nodes in their order, a reaction node right behind its product, the sums at the end.
+    std::vector<std::uint32_t> new_idx(p.n_u, none), rx_idx(p.n_u, none);
+    std::uint32_t next = n_eq;
+    for (std::uint32_t i = 0; i < n_eq; ++i) {
+        new_idx[i] = i;
+    }
+    for (std::uint32_t u = n_eq; u < p.n_u; ++u) {
+        if (removed[u] != 0) {
+            continue;
+        }
+        new_idx[u] = next++;
+        if (rx_coef.count(u) != 0u) {
+            rx_idx[u] = next++;
+        }
+    }
+    out = p;
+    out.nodes.clear();
+    const auto uvar = [](std::uint32_t idx) {
+        operand o;
+        o.type = operand::kind::uvar;
+        o.idx = idx;
+        return o;
+    };
+    for (std::uint32_t u = n_eq; u < p.n_u; ++u) {
+        if (removed[u] != 0) {
+            continue;
+        }
+        auto nn = node_of(u);
+        for (auto &o : nn.args) {
+            if (o.type == operand::kind::uvar) {
+                o.idx = new_idx[o.idx];
+            }
+        }
+        for (auto &d : nn.deps) {
+            d = new_idx[d];
+        }
+        out.nodes.push_back(std::move(nn));
+        if (rx_idx[u] != none) {
+            dc_node rx;
+            rx.kind = func_kind::prod;
+            operand c;
+            c.type = operand::kind::num;
+            c.value = rx_coef.at(u);
+            rx.args = {c, uvar(new_idx[u])};
+            out.nodes.push_back(std::move(rx));
+        }
+    }
+    for (const auto i : acc_vars) {
+        dc_node sm;
+        sm.kind = func_kind::sum;
+        for (const auto &t : flat[i]) {
+            sm.args.push_back(uvar(is_reaction.at({i, t.leaf}) ? rx_idx[t.leaf] : new_idx[t.leaf]));
+        }
+        out.nodes.push_back(std::move(sm));
+        out.sv_defs[i] = uvar(next++);
+    }
+    for (std::uint32_t i = 0; i < n_eq; ++i) {
+        if (p.sv_defs[i].idx < n_eq) {
+            out.sv_defs[i] = p.sv_defs[i];
+        }
+    }
+    out.n_u = next;
+    return true;
+}
+
 namespace
 {
 

@@ -170,8 +170,8 @@ inline void detect_pair_pattern(const taylor_program &p, const cluster_plan &pl,
                 continue;
             }
             bool hit = false;
-            if (n.kind == func_kind::prod && n.args.size() == 2u && n.args[0].type == operand::kind::num
-                && !(n.args[0].value == -1.) && member(n.args[1])) {
+            // (A reaction may well be a negation - equal masses -: its factor is a per-lane table value like any other.)
+            if (n.kind == func_kind::prod && n.args.size() == 2u && n.args[0].type == operand::kind::num && member(n.args[1])) {
                 for (std::uint32_t c = 0; c < 3u; ++c) {
                     if (pos_of.at(n.args[1].idx) == pp.pr[c] && pp.rx[c] == -1) {
                         pp.rx[c] = static_cast<int>(q);

@@ -113,7 +113,8 @@ def test_emulated_v5_taylor_coefficients_by_threshold():
     assert np.all(partb["tc"][:, ~reached] == 0.0)
 
 
-@pytest.mark.parametrize("nb,masses", [(5, None), (6, None), (6, [3.0, 1e-3, 0.7, 2.0, 4e-3, 0.5])])
+@pytest.mark.parametrize("nb,masses", [(5, None), (6, None), (6, [3.0, 1e-3, 0.7, 2.0, 4e-3, 0.5]), (6, "default"),
+                                       (6, [1.0, 1e-3, 1.0, 2.0, 1e-3, 0.5]), (7, "default")])
 def test_emulated_v5_other_systems_single_step_vs_oracle(nb, masses):
     """The one-lane-per-pair kernel with the reactions fused into the sums on other pair-interaction systems: 5 bodies (10
     pairs on 16 lanes, 15 sums: ONE glue round) and 6 bodies with other mass ratios than the outer Solar System's (comparable
@@ -122,17 +123,18 @@ def test_emulated_v5_other_systems_single_step_vs_oracle(nb, masses):
     rng = np.random.RandomState(40 + nb)
     if masses is None:
         masses = list(1.0 / (1.0 + np.arange(nb)) ** 2)
+    kw_g = {} if masses == "default" else {"masses": masses}
     n = 13
     pos = rng.uniform(-3.0, 3.0, (nb, 3, n)) + 6.0 * np.arange(nb)[:, None, None] * np.array([1.0, 0.3, -0.2])[None, :, None]
     vel = rng.uniform(-0.3, 0.3, (nb, 3, n))
     st = np.concatenate([np.concatenate([pos[b], vel[b]], axis=0) for b in range(nb)], axis=0)
-    ta = hy.taylor_adaptive_batch(hy.model.nbody(nb, masses=masses), None, 64, high_accuracy=True, cluster_kernel="v5")
+    ta = hy.taylor_adaptive_batch(hy.model.nbody(nb, **kw_g), None, 64, high_accuracy=True, cluster_kernel="v5")
     assert "v5" in ta.hip_source_mode, ta.hip_source_mode
     assert "frc" in ta.hip_source  # (coefficient registers of the fused sums)
     k = emu.EmulatedKernel(ta.hip_source)
     rows = 6 * nb * (ta.order + 1)
     r = k.run(st, np.zeros(n), np.zeros(n), mode=0, lim=np.full(n, np.inf), want_tc_rows=rows)
-    ora = ho.OracleIntegrator(ho.nbody(nb, masses=masses), st, n, high_accuracy=True)
+    ora = ho.OracleIntegrator(ho.nbody(nb, **kw_g), st, n, high_accuracy=True)
     ora.step(wtc=True)
     h_o = np.array([h for _, h in ora.step_res])
     assert rel_err(r["last_h"], h_o) <= 1e4 * EPS

@@ -653,3 +653,47 @@ def test_events_on_a_program_with_private_cluster_inputs():
         assert rel_err(ta.state, ora.state.reshape(6, n)) <= 1e6 * EPS
     assert len(log_p) >= n and [(a[0], a[1], a[3]) for a in log_p] == [(a[0], a[1], a[3]) for a in log_o]
     assert np.max(np.abs(np.array([a[2] for a in log_p]) - np.array([a[2] for a in log_o]))) <= 1e-10
+
+
+@pytest.mark.parametrize("case", ["default_masses_6", "default_masses_8", "repeated_masses_6", "equal_masses_G_5"])
+def test_linearised_accelerations_of_the_internal_program(case, monkeypatch):
+    """linearise_accelerations(): with equal (default) or repeated masses model::nbody() writes the accelerations as sum / sub
+    / negation trees, or with the reactions as glue nodes in front of the sums - shapes which kept those systems off the
+    one-lane-per-pair kernel. The planner flattens them in the INTERNAL program into plain sums of scaled pair products (the
+    shape of the distinct-mass decomposition; unit scalings restored on top where unit masses sit next to others). Unlike the
+    other rewrites this one RE-ASSOCIATES additions: the oracle's interpreter on the rewritten program agrees with the
+    decomposition to rounding (1e3 eps on the Taylor coefficients, 1e4 eps on the step size), not bit for bit."""
+    if case == "default_masses_6":
+        sys_g, sys_o = hy.model.nbody(6), ho.nbody(6)
+    elif case == "default_masses_8":
+        sys_g, sys_o = hy.model.nbody(8), ho.nbody(8)
+    elif case == "repeated_masses_6":
+        m = [1.0, 1e-3, 1.0, 2.0, 1e-3, 0.5]
+        sys_g, sys_o = hy.model.nbody(6, masses=m), ho.nbody(6, masses=m)
+    else:
+        sys_g, sys_o = hy.model.nbody(5, masses=[0.3] * 5, Gconst=2.5), ho.nbody(5, masses=[0.3] * 5, Gconst=2.5)
+    n_eq, n = len(sys_o), 6
+    rng = np.random.default_rng(11)
+    nb = n_eq // 6
+    st = rng.uniform(-1.0, 1.0, (n_eq, n)) * 0.3
+    st[0::6] += 5.0 * np.arange(nb)[:, None]
+    st[1::6] += 2.0 * np.arange(nb)[:, None] ** 2 % 7
+    ta = hy.taylor_adaptive_batch(sys_g, st, n, high_accuracy=True)
+    mode, prog = ta.hip_source_mode, ta.internal_program
+    assert "cluster mode v5" in mode and "accelerations rewritten as flat sums" in mode, mode
+    # The shape of the distinct-mass decomposition: one sum of N - 1 terms per acceleration, reactions as prod(c, product).
+    sums = [ln for ln in prog if ln.startswith("sum(")]
+    assert len(sums) == n_eq // 2 and all(ln.count("u_") == nb - 1 for ln in sums)
+    assert not any(ln.startswith("sub(u_") and int(ln[6:].split(",")[0].rstrip(")")) >= n_eq for ln in prog)  # (no sub over u variables)
+    plain = ho.OracleIntegrator(sys_o, st, n, high_accuracy=True)
+    rewritten = _oracle_on_program(monkeypatch, prog, n_eq, st, n, high_accuracy=True)
+    plain.step(wtc=True)
+    rewritten.step(wtc=True)
+    h_p, h_r = np.array([h for _, h in plain.step_res]), np.array([h for _, h in rewritten.step_res])
+    assert np.max(np.abs(h_p - h_r) / np.abs(h_p)) <= 1e4 * 2.220446049250313e-16
+    tc_p, tc_r = plain.tc.reshape(n_eq, -1, n), rewritten.tc.reshape(n_eq, -1, n)
+    scale = np.max(np.abs(tc_p), axis=2, keepdims=True) + 1e-300
+    assert np.max(np.abs(tc_p - tc_r) / scale) <= 1e3 * 2.220446049250313e-16
+    # (Re-associated sums: default masses differ in the last bits; with repeated masses only the reactions moved - same bits.)
+    if case == "repeated_masses_6":
+        assert np.array_equal(tc_p, tc_r)
