@@ -42,9 +42,12 @@ WORKLOADS = {
     "outer_ss": 5.7e4,
     "two_body": 4.1e3,
     "nbody64": 6.9e6,
+    # (Not a BASELINE.json configuration: model::nbody(6) with its DEFAULT masses - the accelerations are sum / sub /
+    # negation trees which the planner flattens in the internal program to reach the kernel of the headline system.)
+    "nbody6_default_masses": 5.7e4,
 }
 # Default ensemble sizes of the BASELINE.json configurations (systems per GPU).
-DEFAULT_SYSTEMS = {"outer_ss": 1048576, "two_body": 4194304, "nbody64": 65536}
+DEFAULT_SYSTEMS = {"outer_ss": 1048576, "two_body": 4194304, "nbody64": 65536, "nbody6_default_masses": 1048576}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_PEAK_TFLOPS = 78.6  # vector FP64
 
@@ -62,6 +65,11 @@ def make_integrator(hy, configs, workload, n_systems, seed, device=0):
         st = configs.plummer_nbody_state(64, n_systems, seed=1234 + seed)
         ta = hy.taylor_adaptive_batch(sys_, None, n_systems, high_accuracy=False, device=device)
         dt = 0.03
+    elif workload == "nbody6_default_masses":
+        sys_ = hy.model.nbody(6)
+        st = configs.plummer_nbody_state(6, n_systems, seed=1234 + seed)
+        ta = hy.taylor_adaptive_batch(sys_, None, n_systems, high_accuracy=False, device=device)
+        dt = 0.5
     else:
         sys_ = hy.model.nbody(2, masses=[1.0, 0.0])
         st = configs.two_body_state(n_systems, perturb=1e-12, seed=seed)
@@ -130,6 +138,8 @@ if CPU_QUOTA is not None:
 def cpu_baseline(workload, dt, target_seconds=15.0):
     """The oracle (C restatement, OpenMP over SIMD-width batches like the reference's
     TBB-over-batches ensemble) timed on this host on a bounded sample of the same workload."""
+    if workload not in ("outer_ss", "two_body", "nbody64"):
+        return None  # (auxiliary workloads carry no CPU baseline)
     try:
         return _cpu_baseline(workload, dt, target_seconds)
     finally:
@@ -716,6 +726,12 @@ def main():
                     extra.append(leg)
                 except Exception as e:  # an auxiliary leg must never cost the headline line
                     extra.append({"config": {"workload": wl}, "error": "%s: %s" % (type(e).__name__, e)})
+            try:
+                # A system off the headline shape: equal (default) masses. No CPU baseline of its own.
+                r = run_workload(ctx, "nbody6_default_masses", DEFAULT_SYSTEMS["nbody6_default_masses"], 3, 1)
+                extra.append({k: r[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline")})
+            except Exception as e:
+                extra.append({"config": {"workload": "nbody6_default_masses"}, "error": "%s: %s" % (type(e).__name__, e)})
             try:
                 extra.append(divergence_leg(ctx, DEFAULT_SYSTEMS["outer_ss"]))
             except Exception as e:
