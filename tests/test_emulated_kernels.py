@@ -114,7 +114,7 @@ def test_emulated_v5_taylor_coefficients_by_threshold():
 
 
 @pytest.mark.parametrize("nb,masses", [(5, None), (6, None), (6, [3.0, 1e-3, 0.7, 2.0, 4e-3, 0.5]), (6, "default"),
-                                       (6, [1.0, 1e-3, 1.0, 2.0, 1e-3, 0.5]), (7, "default")])
+                                       (6, [1.0, 1e-3, 1.0, 2.0, 1e-3, 0.5]), (7, "default"), (9, "default")])
 def test_emulated_v5_other_systems_single_step_vs_oracle(nb, masses):
     """The one-lane-per-pair kernel with the reactions fused into the sums on other pair-interaction systems: 5 bodies (10
     pairs on 16 lanes, 15 sums: ONE glue round) and 6 bodies with other mass ratios than the outer Solar System's (comparable
