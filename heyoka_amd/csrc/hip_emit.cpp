@@ -1496,7 +1496,7 @@ emitted_module emit_hip_module(const taylor_program &prog, const emit_options &o
                 }
                 return 1;
             };
-            if (opts.dev.linearise && !opts.dev.cluster_v1 && !opts.event_stepper && opts.cluster_kernel != 1 && kernel_rank(m) < 4) {
+            if (opts.dev.linearise && !opts.dev.cluster_v1 && opts.cluster_kernel != 1 && kernel_rank(m) < 4) {
                 taylor_program lin;
                 if (linearise_accelerations(prog, lin)) {
                     std::string w2;

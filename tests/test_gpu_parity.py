@@ -2314,6 +2314,63 @@ def test_events_on_the_cluster_stepper_vs_oracle(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_events_on_systems_with_default_masses_reach_the_cluster_stepper(monkeypatch):
+    """model::nbody(6) with its DEFAULT masses and events: until round 5 such an integrator fell to the table stepper (the
+    accelerations of equal masses are sum / sub / negation trees which no stepper with events of the wave-cluster family
+    took). With the accelerations flattened in the internal program (linearise_accelerations()) it runs on the
+    one-lane-per-pair stepper with the event equations inside. Step by step against the oracle's stepper with events and
+    against the one-system-per-lane stepper with events: outcomes, step sizes, states, events in order; then a lock-step
+    propagation."""
+    n = 70
+    st = configs.plummer_nbody_state(6, n, seed=21, jitter=1e-3)
+    logs = {"p": [], "o": [], "q": []}
+    tes = {"p": [], "o": [], "q": []}
+
+    def events(m, key):
+        mk = (lambda s_: m.var(s_)) if m is ho else (lambda s_: m.make_vars(s_))
+        x1, y1, z1, vx1, vy1, vz1 = [mk(s_ + "_1") for s_ in ("x", "y", "z", "vx", "vy", "vz")]
+        x2, y2, z2 = [mk(s_ + "_2") for s_ in ("x", "y", "z")]
+        nt = [m.nt_event(y1, lambda ta, t, d, i: logs[key].append((i, 0, t, d))),
+              m.nt_event(x1 * vx1 + y1 * vy1 + z1 * vz1, lambda ta, t, d, i: logs[key].append((i, 1, t, d)))]
+        # (Bodies 1 and 2 start 2.5 apart and approach: the squared distance falls through 6.2 within the first steps.)
+        d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2) - 6.2
+        te = [m.t_event(d2, lambda ta, d, i: tes[key].append((i, d)) or True)]
+        return nt, te
+
+    nt_p, te_p = events(hy, "p")
+    ta = hy.taylor_adaptive_batch(hy.model.nbody(6), st, n, nt_events=nt_p, t_events=te_p)
+    mode = ta.hip_source_mode
+    assert mode.startswith("cluster") and "v5" in mode and "accelerations rewritten as flat sums" in mode, mode
+    nt_o, te_o = events(ho, "o")
+    ora = ho.OracleEventIntegrator(ho.nbody(6), st, n, nt_events=nt_o, t_events=te_o)
+    monkeypatch.setenv("HEYOKA_AMD_EVENTS_ON_CLUSTER", "0")
+    nt_q, te_q = events(hy, "q")
+    tq = hy.taylor_adaptive_batch(hy.model.nbody(6), st, n, nt_events=nt_q, t_events=te_q)
+    assert not tq.hip_source_mode.startswith("cluster")
+    for _ in range(40):
+        ta.step()
+        ora.step()
+        tq.step()
+        assert [int(oc) for oc, _ in ta.step_res] == [oc for oc, _ in ora.step_res]
+        assert [int(oc) for oc, _ in ta.step_res] == [int(oc) for oc, _ in tq.step_res]
+        h_p = np.array([h for _, h in ta.step_res])
+        h_o = np.array([h for _, h in ora.step_res])
+        assert np.max(np.abs(h_p - h_o) / np.abs(h_o)) <= 1e6 * EPS
+        assert rel_err(ta.state, ora.state.reshape(36, n)) <= 1e6 * EPS
+        assert rel_err(ta.state, tq.state) <= 1e6 * EPS
+    assert len(logs["p"]) >= n // 2 and len(tes["p"]) >= n // 2
+    assert [(a[0], a[1], a[3]) for a in logs["p"]] == [(a[0], a[1], a[3]) for a in logs["o"]]
+    assert np.max(np.abs(np.array([a[2] for a in logs["p"]]) - np.array([a[2] for a in logs["o"]]))) <= 1e-10
+    assert tes["p"] == tes["o"] and tes["p"] == tes["q"]
+    t_end = float(np.max(ora.time_hi)) + 0.3
+    ta.propagate_until(t_end)
+    ora.propagate_until(t_end)
+    assert [int(r[0]) for r in ta.propagate_res] == [r[0] for r in ora.prop_res]
+    assert rel_err(ta.state, ora.state.reshape(36, n)) <= 1e7 * EPS
+    assert [(a[0], a[1], a[3]) for a in logs["p"]] == [(a[0], a[1], a[3]) for a in logs["o"]]
+
+
+@pytest.mark.gpu
 def test_python_exceptions_in_pre_hook_and_in_a_callback_set_stop_the_propagation():
     """Advisor findings (round 3): an exception raised by pre_hook() must stop propagate_*() BEFORE the first step (the
     reference lets it out of propagate_*(), src/taylor_adaptive_batch.cpp:1356-1365) - state and time untouched -, and after
