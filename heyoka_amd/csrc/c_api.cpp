@@ -833,13 +833,14 @@ int hy_tab_get_event_stats(hy_tab t, double *out8)
 
 // Native callbacks which count their invocations in the 64-bit integer behind `user` (the callbacks of an integrator run
 // serially on the host).
+// (Copies of an integrator made by ensemble_propagate_*() share `user` and run on one host thread per device: atomic.)
 void hy_event_counter_nt(hy_tab, double, int, uint32_t, void *user)
 {
-    ++*static_cast<std::uint64_t *>(user);
+    __atomic_fetch_add(static_cast<std::uint64_t *>(user), std::uint64_t(1), __ATOMIC_RELAXED);
 }
 int hy_event_counter_t(hy_tab, int, uint32_t, void *user)
 {
-    ++*static_cast<std::uint64_t *>(user);
+    __atomic_fetch_add(static_cast<std::uint64_t *>(user), std::uint64_t(1), __ATOMIC_RELAXED);
     return 1;
 }
 

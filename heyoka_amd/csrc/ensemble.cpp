@@ -199,6 +199,9 @@ namespace
 // lifetime of the process.
 struct comm_cache {
     std::mutex mtx;
+    // Held for the whole group of sends / receives of a gather: concurrent gathers would otherwise interleave their
+    // operations on the same (cached) communicators.
+    std::mutex use_mtx;
     std::map<std::vector<int>, std::vector<rccl_api::comm_t>> comms;
 };
 comm_cache &comm_store()
@@ -280,6 +283,7 @@ ensemble_gathered detail_gather(const std::vector<detail::tab_core *> &tabs, int
     bool done = false;
     if (want_rccl && rccl().ok) {
         const auto &a = rccl();
+        const std::lock_guard<std::mutex> comm_use(comm_store().use_mtx);
         const auto comms = comms_for(devs);
         std::vector<hipStream_t> streams(devs.size(), nullptr);
         std::vector<device_buffer> staging; // contiguous landing blocks on the destination, one per integrator

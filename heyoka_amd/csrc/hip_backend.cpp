@@ -212,6 +212,8 @@ void release_module(const std::shared_ptr<const compiled_module> &cm, int device
                 break;
             }
             if (hipSetDevice(victim->first.first) == hipSuccess) {
+                // (Kernels of the module may still be in flight on a stream of its last owner: drain the device first.)
+                (void)hipDeviceSynchronize();
                 (void)hipModuleUnload(victim->second.mod);
             }
             loaded_modules.erase(victim);
@@ -251,6 +253,21 @@ device_module::device_module(std::shared_ptr<const compiled_module> cm, int devi
     m_impl->device = device;
     hip_check(hipSetDevice(device), "hipSetDevice");
     m_impl->mod = load_module_cached(m_impl->cm, device);
+    // (If anything below throws the destructor does not run: give the user count of the module back.)
+    struct load_guard {
+        impl *p;
+        ~load_guard()
+        {
+            if (p != nullptr) {
+                for (int i = 0; i < impl::n_ev; ++i) {
+                    if (p->ev_start[i] != nullptr) (void)hipEventDestroy(p->ev_start[i]);
+                    if (p->ev_stop[i] != nullptr) (void)hipEventDestroy(p->ev_stop[i]);
+                }
+                release_module(p->cm, p->device);
+                p->mod = nullptr;
+            }
+        }
+    } guard{m_impl.get()};
     hip_check(hipModuleGetFunction(&m_impl->fn_taylor, m_impl->mod, m_impl->cm->meta.kernel_name.c_str()),
               "hipModuleGetFunction(taylor)");
     hip_check(hipModuleGetFunction(&m_impl->fn_dout, m_impl->mod, m_impl->cm->meta.dout_name.c_str()),
@@ -278,6 +295,7 @@ device_module::device_module(std::shared_ptr<const compiled_module> cm, int devi
         hip_check(hipEventCreate(&m_impl->ev_start[i]), "hipEventCreate");
         hip_check(hipEventCreate(&m_impl->ev_stop[i]), "hipEventCreate");
     }
+    guard.p = nullptr;
 }
 
 device_module::~device_module()

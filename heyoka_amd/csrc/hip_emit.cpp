@@ -1642,7 +1642,7 @@ emitted_module emit_hip_module(const taylor_program &prog, const emit_options &o
                 // Not applicable to this DAG: fall back to the generic one-system-per-lane code, unrolled
                 // for small decompositions (registers), table-driven for large ones (bounded code size, the
                 // reason compact mode exists in the reference).
-                auto u = (prog.nodes.size() > 150u) ? emit_table(prog, opts) : emit_detail::emit_unrolled(prog, opts);
+                auto u = (prog.nodes.size() > opts.unroll_max_nodes) ? emit_table(prog, opts) : emit_detail::emit_unrolled(prog, opts);
                 u.notes += (u.notes.empty() ? "" : "; ") + ("cluster mode not applicable: " + why);
                 return u;
             }

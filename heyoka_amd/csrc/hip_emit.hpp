@@ -108,6 +108,9 @@ struct emit_options {
     // (running sum from 0: src/math/prod.cpp:686-698; one FMA per term). kw::sum_order. The table stepper always uses the
     // running sums, the cluster kernels their own FMA chains.
     int sum_order = 0;
+    // Decompositions the wave-cluster / block planners cannot shape: straight-line code up to this many nodes, the
+    // table-driven steppers beyond (kw::compact_mode lowers it: short compile times).
+    std::uint32_t unroll_max_nodes = 150;
     // emit_event_jets(): the stepper it accompanies leaves out the Taylor coefficients of order >= 1 of the state variables
     // defined by another state variable (emitted_module::compact_tc): read them as parent^[k-1] / k.
     bool compact_tc = false;

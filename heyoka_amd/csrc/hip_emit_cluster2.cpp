@@ -3386,7 +3386,11 @@ int nfi = !(hy_finite(nt_hi) && hy_finite(nt_lo)) ? 1 : 0;
     if (one_lane && jet_lds && !m4) {
         // (A zero-length step - a system which has reached its last grid point - stores like the reference's lock-step
         // loop does; a non-finite new time compares false and stores nothing: nobody reads those coefficients.)
-        src << "const bool tc_sys = ((a.pad & 4) == 0) | (h == 0.0) | ((h > 0.0) ? (nt_hi >= tfin.hi) : (nt_hi <= tfin.hi));\n";
+        // A step clamped to its limit stores as well: the last step of a lane ends at tlast - rem.lo, whose high part can
+        // land on either side of the last grid time (grids ending at 0, crossing 0, backward runs to 0) while hy_grid_post
+        // (h == rem.hi) evaluates every remaining grid point from these coefficients. (Steps clamped by max_delta_t store
+        // needlessly: harmless.)
+        src << "const bool tc_sys = ((a.pad & 4) == 0) | (h == 0.0) | (h == lim) | ((h > 0.0) ? (nt_hi >= tfin.hi) : (nt_hi <= tfin.hi));\n";
         src << "if (a.tc != nullptr && tc_sys) {\n";
     } else {
         src << (jet_lds ? "if (a.tc != nullptr && !HY_M4) {\n" : "if (a.tc != nullptr) {\n");

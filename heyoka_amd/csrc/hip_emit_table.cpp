@@ -82,13 +82,16 @@ struct hy_tctx {
     double t_hi;
 };
 
-#if defined(HY_LEVEL)
-// Wave-level variant: one system per wavefront, its whole tape in LDS (u-major, odd row length: the lanes of a level
-// hit different banks).
-__shared__ double hy_lds_tape[HY_N_U * (HY_ORDER + 1u)];
+#if defined(HY_STAGED)
+// Staged variant (hip_emit_staged.cpp): one system per workgroup, its whole tape in LDS, u-major with an odd row length
+// HY_P >= order + 1 (the lanes of a group hit different banks), one row per u variable whose history is read, a dummy
+// row for idle lanes and one cell per u variable which is only read at the current order.
+__shared__ double hy_lds_tape[HY_TAPE_DOUBLES];
 __device__ __forceinline__ double &hy_tp(const hy_tctx &, unsigned k, unsigned u)
 {
-    return hy_lds_tape[u * (HY_ORDER + 1u) + k];
+    // (hy_row_of[u]: the row of a u variable with a history - state variable i has row i -; the specialised code of the
+    // groups carries its offsets in registers, this accessor serves the interpreter and the tail of a step.)
+    return hy_lds_tape[hy_row_of[u] + k];
 }
 #else
 __device__ __forceinline__ double &hy_tp(const hy_tctx &c, unsigned k, unsigned u)
@@ -548,7 +551,10 @@ __device__ double hy_sv_value(const hy_tctx &c, unsigned i, unsigned k)
     }
 }
 
-#if !defined(HY_LEVEL)
+)HIP";
+
+// The stepper with one system per lane and the tape in HBM.
+const char *table_hbm_kernel_code = R"HIP(
 // Order-k coefficients of all the u variables that are not state variables / of the state variables.
 __device__ void hy_nodes_order(const hy_tctx &c, unsigned k)
 {
@@ -713,193 +719,6 @@ extern "C" __global__ void __launch_bounds__(256, 4) hy_taylor(const hy_kargs a)
         }
     }
 }
-#else // HY_LEVEL
-// ---- Wave-level interpreter: one system per wavefront, tape in LDS. ----
-// The u variables are grouped in dependency levels (hy_lvl_*): within an order, the nodes of a level only read
-// same-order values of earlier levels (and lower orders of anything), so they are evaluated by different lanes at the same
-// time; the lanes then serve the state variables (recursion, Horner / compensated update, infinity norms). The per-system
-// scalars (time, step, counters) are computed redundantly by all the lanes. LDS operations of a wavefront complete in
-// order: between levels a compiler barrier is enough.
-__device__ __forceinline__ double hy_wave_max(double v)
-{
-    for (int m = 32; m >= 1; m >>= 1) v = hy_max(v, __shfl_xor(v, m, 64));
-    return v;
-}
-
-__device__ __forceinline__ void hy_level_nodes(const hy_tctx &c, unsigned k, unsigned lane)
-{
-    for (unsigned L = 0; L < HY_N_LEVELS; ++L) {
-        const unsigned b = hy_lvl_off[L], e = hy_lvl_off[L + 1u];
-        for (unsigned q = b + lane; q < e; q += 64u) {
-            const unsigned i = hy_lvl_node[q];
-            hy_tp(c, k, HY_N_EQ + i) = hy_node_value(c, i, k);
-        }
-        HY_WSYNC();
-    }
-}
-
-__device__ __forceinline__ void hy_level_sv(const hy_tctx &c, unsigned k, unsigned lane)
-{
-    for (unsigned i = lane; i < HY_N_EQ; i += 64u) hy_tp(c, k, i) = hy_sv_value(c, i, k);
-    HY_WSYNC();
-}
-
-extern "C" __global__ void __launch_bounds__(64) hy_taylor(const hy_kargs a)
-{
-    const unsigned lane = threadIdx.x;
-    const u64 N = a.N;
-    hy_tctx c;
-    c.tape = nullptr;
-    c.T = 0;
-    c.pars = a.pars;
-    c.N = N;
-    for (u64 s = blockIdx.x; s < N; s += gridDim.x) {
-        c.s = s;
-        double t_hi = a.time_hi[s], t_lo = a.time_lo[s];
-        hy_df tfin, rem;
-        tfin.hi = 0.0; tfin.lo = 0.0; rem.hi = 0.0; rem.lo = 0.0;
-        bool t_dir = true;
-        double mdt = __builtin_inf();
-        double step_lim = 0.0;
-        if (a.mode == 1) {
-            tfin.hi = (a.tfin_hi != nullptr) ? a.tfin_hi[s] : a.tfin_s_hi;
-            tfin.lo = (a.tfin_hi != nullptr) ? a.tfin_lo[s] : a.tfin_s_lo;
-            hy_df tcur; tcur.hi = t_hi; tcur.lo = t_lo;
-            rem = hy_df_sub(tfin, tcur);
-            t_dir = (rem.hi > 0.0) | ((rem.hi == 0.0) & (rem.lo >= 0.0));
-            if (a.lim != nullptr) mdt = a.lim[s];
-        } else {
-            step_lim = a.lim[s];
-        }
-        HY_WSYNC();
-        for (unsigned i = lane; i < HY_N_EQ; i += 64u) hy_tp(c, 0, i) = a.state[(u64)i * N + s];
-        HY_WSYNC();
-        u64 n_steps = 0, iter = 0;
-        double min_h = __builtin_inf(), max_h = 0.0, last_h = 0.0;
-        i64 outcome = HY_OC_SUCCESS;
-        for (;;) {
-            double lim;
-            if (a.mode == 1) {
-                hy_df m; m.lo = 0.0;
-                m.hi = t_dir ? mdt : -mdt;
-                const bool lt_fwd = hy_df_lt(rem, m), lt_bwd = hy_df_lt(m, rem);
-                const bool rem_first = (t_dir & lt_fwd) | (!t_dir & lt_bwd);
-                lim = rem_first ? rem.hi : m.hi;
-            } else {
-                lim = step_lim;
-            }
-            c.t_hi = t_hi;
-            hy_level_nodes(c, 0, lane);
-            for (unsigned k = 1; k < HY_ORDER; ++k) {
-                hy_level_sv(c, k, lane);
-                hy_level_nodes(c, k, lane);
-            }
-            hy_level_sv(c, HY_ORDER, lane);
-#if HY_N_EV > 0
-            hy_level_nodes(c, HY_ORDER, lane);
-#endif
-
-            // Step size (taylor_determine_h(), src/taylor_00.cpp:102-273): infinity norms over the state variables.
-            double m0 = 0.0, mo = 0.0, mom1 = 0.0;
-            for (unsigned i = lane; i < HY_N_EQ; i += 64u) {
-                m0 = hy_max(m0, fabs(hy_tp(c, 0, i)));
-                mo = hy_max(mo, fabs(hy_tp(c, HY_ORDER, i)));
-                mom1 = hy_max(mom1, fabs(hy_tp(c, HY_ORDER - 1u, i)));
-            }
-#if HY_N_EV > 0
-            // (The event equations take part in the norms, src/taylor_00.cpp:209-219.)
-            for (unsigned e = lane; e < HY_N_EV; e += 64u) {
-                m0 = hy_max(m0, fabs(hy_tp(c, 0, hy_ev_u[e])));
-                mo = hy_max(mo, fabs(hy_tp(c, HY_ORDER, hy_ev_u[e])));
-                mom1 = hy_max(mom1, fabs(hy_tp(c, HY_ORDER - 1u, hy_ev_u[e])));
-            }
-#endif
-            m0 = hy_wave_max(m0);
-            mo = hy_wave_max(mo);
-            mom1 = hy_wave_max(mom1);
-            const double num_rho = (m0 <= 1.0) ? 1.0 : m0;
-            const double rho_o = hy_root(num_rho / mo, 1.0 / (double)HY_ORDER);
-            const double rho_om1 = hy_root(num_rho / mom1, 1.0 / (double)(HY_ORDER - 1u));
-            const double rho_m = hy_min(rho_o, rho_om1);
-            double h = rho_m * HY_RHOFAC;
-            h = hy_min(h, fabs(lim));
-            h = (lim < 0.0) ? -h : h;
-
-            if (a.tc != nullptr) {
-                for (unsigned q = lane; q < HY_N_EQ * (HY_ORDER + 1u); q += 64u) {
-                    const unsigned i = q / (HY_ORDER + 1u), k = q % (HY_ORDER + 1u);
-                    a.tc[((u64)i * (HY_ORDER + 1u) + k) * N + s] = hy_tp(c, k, i);
-                }
-            }
-
-            if (a.mode == 4) {
-#if HY_N_EV > 0
-                for (unsigned q = lane; q < HY_N_EV * (HY_ORDER + 1u); q += 64u) {
-                    const unsigned e = q / (HY_ORDER + 1u), k = q % (HY_ORDER + 1u);
-                    a.ev_tc[((u64)e * (HY_ORDER + 1u) + k) * N + s] = hy_tp(c, k, hy_ev_u[e]);
-                }
-#endif
-                if (lane == 0u) a.max_abs_state[s] = m0;
-                last_h = h;
-                break;
-            }
-
-            bool nf = false;
-            for (unsigned i = lane; i < HY_N_EQ; i += 64u) {
-                double res;
-#if HY_HIGH_ACCURACY
-                res = hy_tp(c, 0, i);
-                double comp = 0.0, cur_h = h;
-                for (unsigned k = 1; k <= HY_ORDER; ++k) {
-                    const double tmp = hy_tp(c, k, i) * cur_h;
-                    const double y = tmp - comp;
-                    const double t = res + y;
-                    comp = (t - res) - y;
-                    res = t;
-                    cur_h = cur_h * h;
-                }
-#else
-                res = hy_tp(c, HY_ORDER, i);
-                for (unsigned k = 1; k <= HY_ORDER; ++k) res = hy_tp(c, HY_ORDER - k, i) + res * h;
-#endif
-                hy_tp(c, 0, i) = res;
-                nf = nf | !hy_finite(res);
-            }
-            nf = __builtin_amdgcn_ballot_w64(nf) != 0ull;
-            HY_WSYNC();
-            {
-                hy_df tcur; tcur.hi = t_hi; tcur.lo = t_lo;
-                hy_df hh; hh.hi = h; hh.lo = 0.0;
-                const hy_df nt = hy_df_add(tcur, hh);
-                t_hi = nt.hi; t_lo = nt.lo;
-            }
-            last_h = h;
-            nf = nf | !(hy_finite(t_hi) & hy_finite(t_lo));
-            HY_STEP_TAIL(nf, lane == 0u)
-        }
-        if (a.mode == 4) {
-            if (lane == 0u) a.last_h[s] = last_h;
-            continue;
-        }
-        for (unsigned i = lane; i < HY_N_EQ; i += 64u) a.state[(u64)i * N + s] = hy_tp(c, 0, i);
-        if (lane == 0u) {
-            if (a.mode != 2) {
-                a.time_hi[s] = t_hi;
-                a.time_lo[s] = t_lo;
-            } else {
-                const_cast<double *>(a.lim)[s] = last_h;
-            }
-            a.last_h[s] = last_h;
-            a.outcome[s] = outcome;
-            if (a.mode == 1) {
-                a.min_h[s] = min_h;
-                a.max_h[s] = max_h;
-                a.n_steps[s] = n_steps;
-            }
-        }
-    }
-}
-#endif // HY_LEVEL
 )HIP";
 
 int kind_id(func_kind k)
@@ -986,66 +805,25 @@ int kind_id(func_kind k)
 
 } // namespace
 
-emitted_module emit_table(const taylor_program &p, const emit_options &opts)
+namespace table_detail
 {
-    // Variant: one system per lane with the tape in HBM (throughput), or - when the tape of one system fits in a static
-    // LDS allocation and the batch is small - one system per wavefront with the tape in LDS and the lanes spread over
-    // the nodes of a dependency level (latency; see the device code).
-    const auto tape_bytes = static_cast<std::uint64_t>(p.n_u) * (opts.order + 1u) * sizeof(double);
-    // The lane-per-system variant needs ~260 000 systems to fill the chip and is bound by the latency of the HBM tape
-    // for a single lane; the wave-level variant keeps ~3 wavefronts per CU busy with 768+ systems but only a fraction
-    // of the lanes of a wavefront work at any time (different node kinds in a level run one after the other).
-    // Measured with model::np1body(6) (234 nodes): 3.4e6 vs 4.1e6 system-steps/s at 65 536 systems - the wave-level
-    // variant wins below that. HEYOKA_AMD_TABLE_LDS=0 / 1 overrides the choice.
-    bool wave_level = tape_bytes <= 64u * 1024u && opts.batch_size != 0u && opts.batch_size <= 32768u;
-    if (opts.dev.table_lds >= 0) {
-        wave_level = tape_bytes <= 64u * 1024u && opts.dev.table_lds != 0;
-    }
 
-    std::ostringstream src;
-    src << emit_detail::prelude << emit_detail::rules_source(p);
-    emit_detail::emit_dout(src, p, opts);
-    std::uint32_t n_levels = 0;
-    if (wave_level) {
-        // Dependency levels of the nodes with respect to their same-order operands (state variables: level 0 inputs).
-        std::vector<std::uint32_t> level(p.nodes.size(), 0u);
-        for (std::size_t i = 0; i < p.nodes.size(); ++i) {
-            std::uint32_t l = 0;
-            for (const auto &o : p.nodes[i].args) {
-                if (o.type == operand::kind::uvar && o.idx >= p.n_eq) {
-                    l = std::max(l, level[o.idx - p.n_eq] + 1u);
-                }
-            }
-            level[i] = l;
-            n_levels = std::max(n_levels, l + 1u);
-        }
-        // Nodes of a level sorted by kind (then by index): lanes running the same rule sit next to each other.
-        std::vector<std::vector<std::uint32_t>> by_level(n_levels);
-        for (std::size_t i = 0; i < p.nodes.size(); ++i) {
-            by_level[level[i]].push_back(static_cast<std::uint32_t>(i));
-        }
-        src << emit_detail::wsync_macro << "#define HY_LEVEL 1\n#define HY_N_LEVELS " << n_levels << "u\n";
-        std::ostringstream lo, ln;
-        std::size_t tot = 0;
-        lo << "0,";
-        for (auto &v : by_level) {
-            std::stable_sort(v.begin(), v.end(), [&](std::uint32_t x, std::uint32_t y) {
-                return kind_id(p.nodes[x].kind) < kind_id(p.nodes[y].kind);
-            });
-            for (const auto i : v) {
-                ln << i << ",";
-            }
-            tot += v.size();
-            lo << tot << ",";
-        }
-        src << "__device__ const unsigned hy_lvl_off[] = {" << lo.str() << "0};\n";
-        src << "__device__ const unsigned hy_lvl_node[] = {" << ln.str() << "0};\n";
-    }
+int kind_id(func_kind k)
+{
+    return heyoka_amd::kind_id(k);
+}
 
+// Everything the rule functions need in front of a stepper kernel: size macros, node tables, the rule functions
+// themselves and the dispatcher of the functions defined through node rules. `pre_defs` goes in front of the rule
+// functions (variant macros); `stride` is the distance between two orders of a u variable on the tape, in doubles.
+void emit_tables_and_rules(std::ostream &src, const taylor_program &p, const emit_options &opts, const std::string &pre_defs,
+                           const char *stride)
+{
     src << "#define HY_N_EQ " << p.n_eq << "u\n#define HY_N_U " << p.n_u << "u\n#define HY_N_NODES " << p.nodes.size()
         << "u\n#define HY_ORDER " << opts.order << "u\n#define HY_HIGH_ACCURACY " << (opts.high_accuracy ? 1 : 0)
         << "\n#define HY_RHOFAC " << fp_literal(emit_detail::rhofac(opts.order)) << "\n#define HY_N_EV " << p.ev_u.size()
         << "\n";
+    src << pre_defs;
     src << "__device__ const unsigned hy_ev_u[] = {";
     for (const auto u : p.ev_u) {
         src << u << ",";
@@ -1101,56 +879,79 @@ emitted_module emit_table(const taylor_program &p, const emit_options &opts)
     for (const auto &n : p.nodes) {
         has_custom = has_custom || n.kind == func_kind::custom;
     }
-    if (has_custom) {
-        std::ostringstream doff, dlist, rof;
-        std::size_t nd = 0;
-        doff << "0,";
-        std::vector<std::uint32_t> used;
-        for (const auto &n : p.nodes) {
-            if (n.kind == func_kind::custom) {
-                for (const auto d : n.deps) {
-                    dlist << d << ",";
-                    ++nd;
-                }
-                if (std::find(used.begin(), used.end(), n.rule) == used.end()) {
-                    used.push_back(n.rule);
-                }
-            }
-            doff << nd << ",";
-            rof << n.rule << ",";
-        }
-        src << "#define HY_HAS_CUSTOM 1\n";
-        src << "__device__ const unsigned hy_cdep_off[] = {" << doff.str() << "0};\n";
-        src << "__device__ const unsigned hy_cdep[] = {" << dlist.str() << "0};\n";
-        src << "__device__ const unsigned hy_rule_of[] = {" << rof.str() << "0};\n";
+    if (!has_custom) {
         src << table_device_code;
-        const char *stride = wave_level ? "1u" : "64u";
-        src << "__device__ double hy_custom_value(const hy_tctx &c, unsigned i, unsigned a0, unsigned nargs, unsigned u, "
-               "unsigned k)\n{\n";
-        src << "double xv[8];\nhy_jet xj[8], hj[8];\n";
-        src << "for (unsigned a = 0; a < nargs && a < 8u; ++a) {\n"
-               "    if (hy_arg_type[a0 + a] == A_UVAR) {\n"
-               "        xj[a].p = &hy_tp(c, 0, hy_arg_idx[a0 + a]); xj[a].s = " << stride << "; xj[a].n = k + 1u; xv[a] = xj[a].p[0];\n"
-               "    } else {\n"
-               "        xv[a] = hy_numpar(c, a0 + a); xj[a].p = &xv[a]; xj[a].s = 1u; xj[a].n = 1u;\n"
-               "    }\n}\n";
-        src << "const unsigned d0 = hy_cdep_off[i], ndep = hy_cdep_off[i + 1u] - d0;\n";
-        src << "for (unsigned j = 0; j < ndep && j < 8u; ++j) { hj[j].p = &hy_tp(c, 0, hy_cdep[d0 + j]); hj[j].s = " << stride
-            << "; hj[j].n = k; }\n";
-        src << "hy_jet self; self.p = &hy_tp(c, 0, u); self.s = " << stride << "; self.n = k;\n";
-        src << "switch (hy_rule_of[i]) {\n";
-        for (const auto id : used) {
-            const auto &nm = get_node_rule(id).name;
-            src << "case " << id << "u: return (k == 0u) ? hy_rule_" << nm << "_value(";
-            for (std::uint32_t q = 0; q < get_node_rule(id).n_args; ++q) {
-                src << (q == 0u ? "" : ", ") << "xv[" << q << "]";
-            }
-            src << ") : hy_rule_" << nm << "_orderk(k, self, xj, hj);\n";
-        }
-        src << "default: return 0.0;\n}\n}\n";
-    } else {
-        src << table_device_code;
+        return;
     }
+    std::ostringstream doff, dlist, rof;
+    std::size_t nd = 0;
+    doff << "0,";
+    std::vector<std::uint32_t> used;
+    for (const auto &n : p.nodes) {
+        if (n.kind == func_kind::custom) {
+            for (const auto d : n.deps) {
+                dlist << d << ",";
+                ++nd;
+            }
+            if (std::find(used.begin(), used.end(), n.rule) == used.end()) {
+                used.push_back(n.rule);
+            }
+        }
+        doff << nd << ",";
+        rof << n.rule << ",";
+    }
+    src << "#define HY_HAS_CUSTOM 1\n";
+    src << "__device__ const unsigned hy_cdep_off[] = {" << doff.str() << "0};\n";
+    src << "__device__ const unsigned hy_cdep[] = {" << dlist.str() << "0};\n";
+    src << "__device__ const unsigned hy_rule_of[] = {" << rof.str() << "0};\n";
+    src << table_device_code;
+    src << "__device__ double hy_custom_value(const hy_tctx &c, unsigned i, unsigned a0, unsigned nargs, unsigned u, "
+           "unsigned k)\n{\n";
+    src << "double xv[8];\nhy_jet xj[8], hj[8];\n";
+    src << "for (unsigned a = 0; a < nargs && a < 8u; ++a) {\n"
+           "    if (hy_arg_type[a0 + a] == A_UVAR) {\n"
+           "        xj[a].p = &hy_tp(c, 0, hy_arg_idx[a0 + a]); xj[a].s = " << stride << "; xj[a].n = k + 1u; xv[a] = xj[a].p[0];\n"
+           "    } else {\n"
+           "        xv[a] = hy_numpar(c, a0 + a); xj[a].p = &xv[a]; xj[a].s = 1u; xj[a].n = 1u;\n"
+           "    }\n}\n";
+    src << "const unsigned d0 = hy_cdep_off[i], ndep = hy_cdep_off[i + 1u] - d0;\n";
+    src << "for (unsigned j = 0; j < ndep && j < 8u; ++j) { hj[j].p = &hy_tp(c, 0, hy_cdep[d0 + j]); hj[j].s = " << stride
+        << "; hj[j].n = k; }\n";
+    src << "hy_jet self; self.p = &hy_tp(c, 0, u); self.s = " << stride << "; self.n = k;\n";
+    src << "switch (hy_rule_of[i]) {\n";
+    for (const auto id : used) {
+        const auto &nm = get_node_rule(id).name;
+        src << "case " << id << "u: return (k == 0u) ? hy_rule_" << nm << "_value(";
+        for (std::uint32_t q = 0; q < get_node_rule(id).n_args; ++q) {
+            src << (q == 0u ? "" : ", ") << "xv[" << q << "]";
+        }
+        src << ") : hy_rule_" << nm << "_orderk(k, self, xj, hj);\n";
+    }
+    src << "default: return 0.0;\n}\n}\n";
+}
+
+} // namespace table_detail
+
+emitted_module emit_staged(const taylor_program &, const emit_options &, std::string &why_not);
+
+emitted_module emit_table(const taylor_program &p, const emit_options &opts)
+{
+    // Variant: the staged stepper (hip_emit_staged.cpp: one system per workgroup, the tape in LDS, code specialised per
+    // group of nodes) whenever the tape of one system fits in LDS; otherwise one system per lane with the tape in HBM.
+    // HEYOKA_AMD_TABLE_LDS=0 forces the latter.
+    std::string why_staged = "switched off (HEYOKA_AMD_TABLE_LDS=0)";
+    if (opts.dev.table_lds != 0) {
+        auto m = emit_staged(p, opts, why_staged);
+        if (!m.source.empty()) {
+            return m;
+        }
+    }
+
+    std::ostringstream src;
+    src << emit_detail::prelude << emit_detail::rules_source(p);
+    emit_detail::emit_dout(src, p, opts);
+    table_detail::emit_tables_and_rules(src, p, opts, "", "64u");
+    src << table_hbm_kernel_code;
 
     emitted_module ret;
     ret.source = src.str();
@@ -1159,20 +960,12 @@ emitted_module emit_table(const taylor_program &p, const emit_options &opts)
     ret.mode = emit_mode::table;
     ret.persistent = true;
     ret.tc_optional = true;
-    if (wave_level) {
-        ret.block_size = 64;
-        ret.lanes_per_system = 64;
-        ret.scratch_per_wave = 0;
-        ret.notes = "table mode (wave-level): " + std::to_string(p.nodes.size()) + " nodes in " + std::to_string(n_levels)
-                    + " dependency levels interpreted from tables, one system per wavefront, tape in LDS ("
-                    + std::to_string(tape_bytes) + " B)";
-    } else {
-        ret.block_size = 256;
-        ret.lanes_per_system = 1;
-        // One tape tile per resident wave: n_u * (order + 1) rows of 64 doubles.
-        ret.scratch_per_wave = static_cast<std::uint64_t>(p.n_u) * (opts.order + 1u) * 64u;
-        ret.notes = "table mode: " + std::to_string(p.nodes.size()) + " nodes interpreted from tables, tape in HBM";
-    }
+    ret.block_size = 256;
+    ret.lanes_per_system = 1;
+    // One tape tile per resident wave: n_u * (order + 1) rows of 64 doubles.
+    ret.scratch_per_wave = static_cast<std::uint64_t>(p.n_u) * (opts.order + 1u) * 64u;
+    ret.notes = "table mode: " + std::to_string(p.nodes.size()) + " nodes interpreted from tables, tape in HBM (staged stepper: "
+                + why_staged + ")";
     return ret;
 }
 

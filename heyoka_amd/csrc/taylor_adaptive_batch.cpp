@@ -141,6 +141,16 @@ struct tab_core::impl {
     std::uint64_t ev_steps = 0, ev_systems = 0;
     mutable std::uint64_t tc_regens = 0;
     mutable bool tc_partial = false;
+    // propagate_grid() with Taylor coefficients on demand (emitted_module::tc_by_threshold) which was interrupted by a
+    // non-finite state: d_tc mixes the coefficients of different steps. Cleared by the next step which stores them.
+    mutable bool tc_stale = false;
+    void check_tc_not_stale() const
+    {
+        if (tc_stale) {
+            throw std::runtime_error("The Taylor coefficients of the last step are not available: the last propagate_grid() "
+                                     "stored them on demand and was interrupted by a non-finite state");
+        }
+    }
     bool ev_all_tc = false;
     // (A caller who read the coefficients of the previous step - a step callback with dense output, say - will probably read
     // those of the next one: that step stores them all instead of paying for a second launch again.)
@@ -327,6 +337,10 @@ struct tab_core::impl {
         times_fresh = false;
         if (tc_written) {
             tc_dev_newer = true;
+            // (A launch which stored the coefficients of every lane ends the "mixed steps" state of tc_stale.)
+            if (tc_threshold == nullptr) {
+                tc_stale = false;
+            }
         }
         lasth_dev_newer = true;
         if (sticky_host_ptr || sticky_const_refs) {
@@ -692,14 +706,21 @@ tab_core::tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_siz
         }
     } else {
         eo.mode = choose_mode(d.emitter);
-        // kw::compact_mode = true selects the analogue of the reference's compact mode (src/taylor_02.cpp:1194-1260):
-        // the table-driven stepper - one device function per elementary function, rolled loops, running sums like
-        // src/math/prod.cpp:686-698 - instead of unrolled / clustered straight-line code (code size and compile time
-        // independent of the order). Decompositions beyond 2000 nodes keep the automatic choice (block / table: both
-        // tape-based), and HEYOKA_AMD_EMIT_MODE still overrides.
-        if (d.compact_mode && d.emitter == 0 && d.prog.nodes.size() <= 2000u) {
-            eo.mode = emit_mode::table;
+        // kw::compact_mode = true. In the reference it is a code-size / compile-time knob which also changes the order of
+        // the additions inside the convolutions (running sums, src/math/prod.cpp:686-698, instead of products + pairwise
+        // sum, :386-395) and costs little at run time. Here: the on-chip kernels stay whenever the planner can shape the
+        // decomposition (their convolutions are FMA chains - running sums - already; code size does not grow with the
+        // number of bodies); the straight-line generator adds in the compact order (sum_order = 2) and is kept only for
+        // small decompositions; everything else runs on the rolled, table-driven steppers (one device function per
+        // elementary function: the analogue of src/taylor_02.cpp:1194-1260). HEYOKA_AMD_EMIT_MODE / kw::emitter override.
+        if (d.compact_mode && d.emitter == 0) {
+            eo.unroll_max_nodes = 40;
         }
+    }
+    // (The order of the additions of compact mode, whatever generator is in charge - the staged table stepper deals the
+    // terms of a convolution to several lanes otherwise.)
+    if (d.compact_mode && eo.sum_order == 0) {
+        eo.sum_order = 2;
     }
     if (!d.cluster_events) {
         d.emitted = emit_hip_module(d.prog, eo);
@@ -1048,6 +1069,7 @@ void tab_core::impl::ensure_tc_expanded() const
 const std::vector<double> &tab_core::get_tc() const
 {
     auto &d = *m_impl;
+    d.check_tc_not_stale();
     d.ensure_tc_expanded();
     const auto sz = static_cast<std::size_t>(d.dim) * (d.order + 1u) * d.N;
     if (d.tc.size() != sz) {
@@ -1087,6 +1109,7 @@ const std::vector<double> &tab_core::update_d_output(const std::vector<double> &
     }
     d.ensure_device();
     d.ensure_tc();
+    d.check_tc_not_stale();
     std::vector<double> hs(d.N);
     if (rel_time) {
         hs = t;
@@ -2384,7 +2407,13 @@ void tab_core::propagate_grid_device_loop(const std::vector<double> &grid, std::
             flag = false;
         }
     } tc_reset{d.ev_all_tc};
+    d.tc_stale = false;
     while (n_grid > 1u) {
+        // (The sweep after which max_steps ends the loop stores the coefficients of EVERY lane: the reference leaves the
+        // Taylor coefficients of the last step behind, src/taylor_adaptive_batch.cpp:1546-2055.)
+        if (tc_on_demand && max_steps != 0u && iter_counter + 1u == max_steps) {
+            d.tc_threshold = nullptr;
+        }
         if (d.has_events()) {
             d.step_with_events_device(nullptr);
         } else {
@@ -2403,7 +2432,10 @@ void tab_core::propagate_grid_device_loop(const std::vector<double> &grid, std::
         unsigned cnt[3] = {0, 0, 0};
         b_cnt.download(cnt, sizeof(cnt), d.stream);
         if (cnt[1] != 0u) {
-            // A non-finite state was detected: stop (the outcomes of the last step are reported).
+            // A non-finite state was detected: stop (the outcomes of the last step are reported). With coefficients on
+            // demand the lanes which did not reach a grid point in this sweep hold the coefficients of OLDER steps:
+            // get_tc() / update_d_output() refuse to hand those out as the last step's (tc_stale).
+            d.tc_stale = tc_on_demand && d.tc_threshold != nullptr;
             break;
         }
         ++iter_counter;
@@ -2640,8 +2672,16 @@ void tab_core::pack_results(double *dst)
     const auto n = static_cast<std::size_t>(d.N), w = sizeof(double);
     // The results of the last propagation: on the device after a device-resident propagation (a step-limited batch first
     // gets the reference's batch-wide outcome, see fetch_prop_res()), otherwise uploaded from the host records.
-    if (d.prop_res_dev_newer && d.fix_step_limit) {
+    if (d.prop_res_dev_newer && (d.fix_step_limit || d.prop_res_override)) {
         d.fetch_prop_res();
+    }
+    if (d.prop_res_override) {
+        // (A lock-step propagation which ended with step_limit / cb_stop: the batch-wide outcome get_propagate_res()
+        // reports, src/taylor_adaptive_batch.cpp:1516.)
+        for (auto &r : d.prop_res) {
+            std::get<0>(r) = *d.prop_res_override;
+        }
+        d.prop_res_override.reset();
     }
     if (!d.prop_res_dev_newer) {
         std::vector<long long> oc(n);

@@ -191,6 +191,16 @@ inline int shfl(int v, int src)
         wave_exchange(static_cast<std::uint32_t>(v), [src](unsigned) { return static_cast<unsigned>(src) & 63u; })));
 }
 
+inline double shfl(double v, int src)
+{
+    std::uint64_t bits;
+    std::memcpy(&bits, &v, 8);
+    bits = wave_exchange(bits, [src](unsigned) { return static_cast<unsigned>(src) & 63u; });
+    double r;
+    std::memcpy(&r, &bits, 8);
+    return r;
+}
+
 inline double shfl_xor(double v, int m)
 {
     std::uint64_t bits;

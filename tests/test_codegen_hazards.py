@@ -70,13 +70,13 @@ def _cases():
         "tan_3500_statements": (tan_system, {}, {}, "unrolled"),
         "cr3bp_unrolled": (lambda: hy.model.cr3bp(), {}, {}, "unrolled"),
         "functions_unrolled": (lambda: pw, {}, {}, "unrolled"),
-        "functions_table_wave_level": (lambda: pw, {}, {"HEYOKA_AMD_EMIT_MODE": "table", "HEYOKA_AMD_TABLE_LDS": "1"}, "wave-level"),
+        "functions_table_wave_level": (lambda: pw, {}, {"HEYOKA_AMD_EMIT_MODE": "table", "HEYOKA_AMD_TABLE_LDS": "1"}, "staged"),
         "functions_table_hbm": (lambda: pw, {}, {"HEYOKA_AMD_EMIT_MODE": "table", "HEYOKA_AMD_TABLE_LDS": "0"}, "tape in HBM"),
         # Functions defined through the registry of node rules: their order-0 functions (Newton iterations, library calls)
         # sit behind out-of-line frames (node_rule.cpp).
         "node_rules_unrolled": (lambda: kep, {}, {}, "unrolled"),
         "node_rules_table_hbm": (lambda: kep, {}, {"HEYOKA_AMD_EMIT_MODE": "table", "HEYOKA_AMD_TABLE_LDS": "0"}, "tape in HBM"),
-        "node_rules_table_wave_level": (lambda: kep, {}, {"HEYOKA_AMD_EMIT_MODE": "table", "HEYOKA_AMD_TABLE_LDS": "1"}, "wave-level"),
+        "node_rules_table_wave_level": (lambda: kep, {}, {"HEYOKA_AMD_EMIT_MODE": "table", "HEYOKA_AMD_TABLE_LDS": "1"}, "staged"),
         "events_unrolled": (lambda: pw, {"nt_events": ev}, {}, "unrolled"),
         "events_table": (lambda: pw, {"nt_events": ev}, {"HEYOKA_AMD_EMIT_MODE": "table"}, "table"),
     }

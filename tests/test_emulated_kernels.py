@@ -111,6 +111,17 @@ def test_emulated_v5_taylor_coefficients_by_threshold():
     partb = k.run(st, np.zeros(n), np.zeros(n), mode=0, lim=np.full(n, -np.inf), want_tc_rows=rows, tfin=-thr, pad=4)
     assert np.array_equal(partb["tc"][:, reached], fullb["tc"][:, reached])
     assert np.all(partb["tc"][:, ~reached] == 0.0)
+    # The LAST step of a lane is clamped to the remaining time rem.hi and ends at tlast - rem.lo: with a grid ending at 0
+    # (or crossing 0) the high part of the new time lands on either side of the last grid time, while hy_grid_post treats
+    # the lane as done (h == rem.hi) and evaluates every remaining grid point from these coefficients - a clamped step
+    # always stores (round-5 advisor finding: t = (-0.05, -+3e-18), limit 0.05, last grid time 0).
+    for lo in (-3e-18, 3e-18):
+        t_hi, t_lo = np.full(n, -0.05), np.full(n, lo)
+        fullc = k.run(st, t_hi, t_lo, mode=0, lim=np.full(n, 0.05), want_tc_rows=rows)
+        partc = k.run(st, t_hi, t_lo, mode=0, lim=np.full(n, 0.05), want_tc_rows=rows, tfin=np.zeros(n), pad=4)
+        assert np.all(fullc["last_h"] == 0.05)
+        assert np.all(np.sign(fullc["time_hi"]) == np.sign(lo))  # (the new time is -+3e-18: both sides of the grid time)
+        assert np.array_equal(partc["tc"], fullc["tc"]), lo
 
 
 @pytest.mark.parametrize("nb,masses", [(5, None), (6, None), (6, [3.0, 1e-3, 0.7, 2.0, 4e-3, 0.5]), (6, "default"),

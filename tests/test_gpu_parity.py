@@ -23,6 +23,31 @@ def rel_err(a, b):
     return np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))
 
 
+def row_rel_err(a, b, per_row=False):
+    """State comparison with a PER-ROW scale: rows = state variables, columns = systems of the ensemble; the error of a row
+    is max |a - b| over the ensemble divided by max |b| over the ensemble (no floor at 1: the Sun's coordinates in the outer
+    Solar System are 4e-3 AU / 2e-3 AU/yr and every z component is below 0.25 - with rel_err() '1e6 eps' is an ABSOLUTE
+    2e-10 for those rows, 250 times looser than it reads). The Taylor-coefficient comparisons scale the same way."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    a, b = a.reshape(b.shape[0], -1), b.reshape(b.shape[0], -1)
+    scale = np.max(np.abs(b), axis=1) + 1e-300
+    rows = np.max(np.abs(a - b), axis=1) / scale
+    return rows if per_row else float(np.max(rows))
+
+
+def nbody_row_classes(a, b, label=""):
+    """Measured error in eps per row class of an N-body state (body-major rows x, y, z, vx, vy, vz): the first body (the
+    Sun of the outer Solar System), the other bodies' x / y components, the z components. Printed (pytest -s / the
+    captured output of a failing test) and returned."""
+    rows = row_rel_err(a, b, per_row=True) / EPS
+    nb = rows.size // 6
+    r = rows.reshape(nb, 6)
+    cls = {"first body": float(np.max(r[0])), "others x, y, vx, vy": float(np.max(r[1:][:, [0, 1, 3, 4]])) if nb > 1 else 0.0,
+           "others z, vz": float(np.max(r[1:][:, [2, 5]])) if nb > 1 else 0.0}
+    print("[row-scaled state error, eps]%s %s" % (" " + label if label else "", ", ".join("%s: %.3g" % kv for kv in cls.items())))
+    return cls
+
+
 def pendulum_p():
     x, v = hy.make_vars("x", "v")
     return [(x, v), (v, -9.8 * hy.sin(x))]
@@ -554,20 +579,23 @@ def test_pair_kernels_with_17_to_32_pairs(n_bodies, kernel, monkeypatch):
     assert rel_err(ta.state, ora.state.reshape(6 * n_bodies, n)) <= 1e6 * EPS
 
 
-@pytest.mark.parametrize("variant", ["wave-level", "tape in HBM"])
+@pytest.mark.parametrize("variant", ["staged", "tape in HBM"])
 def test_table_mode_small_dag_forced(variant, monkeypatch):
-    """Table (compact-mode analogue) kernels on a DAG that would normally be unrolled, in both variants: one system per
-    wavefront with the tape in LDS (the default for batches of up to 32 768 systems) and one system per lane with the
-    tape in HBM (HEYOKA_AMD_TABLE_LDS=0, the default for larger batches)."""
-    monkeypatch.setenv("HEYOKA_AMD_TABLE_LDS", "1" if variant == "wave-level" else "0")
+    """Table (compact-mode analogue) kernels on a DAG that would normally be unrolled, in both variants: the staged
+    stepper - one system per workgroup, tape in LDS, code specialised per group of nodes: the default whenever the tape of
+    a system fits in LDS - and one system per lane with the tape in HBM (HEYOKA_AMD_TABLE_LDS=0, and the automatic choice
+    for decompositions whose tape is larger than the LDS of a CU)."""
+    monkeypatch.setenv("HEYOKA_AMD_TABLE_LDS", "1" if variant == "staged" else "0")
     ta = _nbody_parity(3, 200, 3, "table", t_final=0.1, env_mode="table")
     assert variant in ta.hip_source_mode
-    if variant == "wave-level":
-        # The default choice depends on the batch size.
+    if variant == "staged":
+        # The default choice does not depend on the batch size; a tape beyond the LDS of a CU goes to HBM.
         monkeypatch.delenv("HEYOKA_AMD_TABLE_LDS")
         monkeypatch.setenv("HEYOKA_AMD_EMIT_MODE", "table")
-        assert "wave-level" in hy.taylor_adaptive_batch(hy.model.nbody(3), None, 32768).hip_source_mode
-        assert "tape in HBM" in hy.taylor_adaptive_batch(hy.model.nbody(3), None, 32832).hip_source_mode
+        assert "staged" in hy.taylor_adaptive_batch(hy.model.nbody(3), None, 32768).hip_source_mode
+        assert "staged" in hy.taylor_adaptive_batch(hy.model.nbody(3), None, 1 << 20).hip_source_mode
+        big = hy.taylor_adaptive_batch(hy.model.nbody(16), None, 64).hip_source_mode
+        assert "tape in HBM" in big and "does not fit in the LDS" in big, big
 
 
 def test_nbody12_block_automatic_and_table_forced():
@@ -1625,7 +1653,7 @@ def test_unrolled_kernel_is_bit_identical_to_the_oracle_without_contraction(sum_
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["wave-level", "tape in HBM"])
+@pytest.mark.parametrize("variant", ["staged", "tape in HBM"])
 def test_compact_mode_has_the_arithmetic_of_the_reference_compact_mode(variant, monkeypatch):
     """kw::compact_mode = true is a flavour of the ARITHMETIC too: running sums inside the convolutions
     (src/math/prod.cpp:686-698, src/math/pow.cpp:905-925, src/detail/sum_sq.cpp:330-345), pairwise sums over the arguments
@@ -1634,7 +1662,10 @@ def test_compact_mode_has_the_arithmetic_of_the_reference_compact_mode(variant, 
     N-body right-hand side contains no library function: sqrt and the divisions are correctly rounded on both sides),
     and differs from the default-mode flavour in the last bits - for both variants of the table kernel."""
     monkeypatch.setenv("HEYOKA_AMD_HIPRTC_FLAGS", "-ffp-contract=off")
-    monkeypatch.setenv("HEYOKA_AMD_TABLE_LDS", "1" if variant == "wave-level" else "0")
+    monkeypatch.setenv("HEYOKA_AMD_TABLE_LDS", "1" if variant == "staged" else "0")
+    # (kw::compact_mode keeps the on-chip kernels where the planner can shape the decomposition - see
+    # test_compact_mode_keeps_the_on_chip_kernels -: the table steppers are selected explicitly here.)
+    monkeypatch.setenv("HEYOKA_AMD_EMIT_MODE", "table")
     M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
     n = 64
     for sys_g, sys_o, st, ha in (
@@ -1664,22 +1695,62 @@ def test_compact_mode_has_the_arithmetic_of_the_reference_compact_mode(variant, 
 
 
 @pytest.mark.gpu
-def test_compact_mode_kwarg_selects_the_table_stepper():
-    """kw::compact_mode = true (include/heyoka/kw.hpp) is honoured: the table-driven stepper (the analogue of
-    src/taylor_02.cpp:1194-1260) instead of straight-line code, same results as the default mode and as the oracle."""
+def test_compact_mode_keeps_the_on_chip_kernels():
+    """kw::compact_mode = true (include/heyoka/kw.hpp; benchmark/outer_ss_long_term_batch.cpp:113 exposes it on the headline
+    workload) is a code-size knob in the reference which changes the order of the additions inside the convolutions
+    (running sums, src/math/prod.cpp:686-698) and costs little at run time. Here it keeps the wave-cluster kernel of the
+    outer Solar System (its convolutions are FMA chains - running sums - already), keeps straight-line code only for small
+    decompositions - with the compact order of the additions -, and sends everything else to the table steppers. Parity
+    against the COMPACT-mode oracle: one step (h 1e6 eps, Taylor coefficients 1e6 eps of the row maximum over the
+    ensemble) and a propagation of ~80 steps (identical outcomes / end times, step counts within one step, states
+    1e6 eps of the row maximum)."""
+    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    n = 256
+    st = configs.outer_ss_state(n, perturb=1e-6, seed=9)
+    sys_g, sys_o = hy.model.nbody(6, masses=M, Gconst=G), ho.nbody(6, masses=M, Gconst=G)
+    a = hy.taylor_adaptive_batch(sys_g, st, n, high_accuracy=True, compact_mode=True)
+    b = hy.taylor_adaptive_batch(sys_g, st, n, high_accuracy=True)
+    assert a.compact_mode and not b.compact_mode
+    assert a.hip_source_mode.startswith("cluster") and "v5" in a.hip_source_mode, a.hip_source_mode
+    oc = ho.OracleIntegrator(sys_o, st, n, high_accuracy=True, compact_mode=True)
+    a.step(write_tc=True)
+    oc.step(wtc=True)
+    h_g, h_o = np.array([h for _, h in a.step_res]), np.array([h for _, h in oc.step_res])
+    assert np.max(np.abs(h_g - h_o) / np.abs(h_o)) <= 1e6 * EPS
+    tc_o = oc.tc.reshape(36, a.order + 1, n)
+    scale = np.max(np.abs(tc_o), axis=2, keepdims=True) + 1e-300
+    assert np.max(np.abs(np.asarray(a.tc).reshape(tc_o.shape) - tc_o) / scale) <= 1e6 * EPS
+    a.propagate_until(35.0)
+    oc.propagate_until(35.0)
+    assert all(r[0] == OC.time_limit for r in a.propagate_res)
+    assert max(abs(x[3] - y[3]) for x, y in zip(a.propagate_res, oc.prop_res)) <= 1
+    assert np.array_equal(np.asarray(a.time), oc.time_hi)
+    assert row_rel_err(a.state, oc.state.reshape(36, n)) <= 1e6 * EPS
+
+    # A small decomposition: straight-line code with the compact order of the additions (kw::sum_order = running), bit
+    # for bit the kernel the default mode builds with that order - and the oracle's compact flavour to the usual
+    # tolerances after a propagation.
     n = 32
     st = configs.two_body_state(n, perturb=1e-3, seed=5)
     sys_g = hy.model.nbody(2, masses=[1.0, 0.0])
     a = hy.taylor_adaptive_batch(sys_g, st, n, compact_mode=True)
-    b = hy.taylor_adaptive_batch(sys_g, st, n)
-    assert a.compact_mode and not b.compact_mode
-    assert a.hip_source_mode.startswith("table") and not b.hip_source_mode.startswith("table")
-    ora = ho.OracleIntegrator(ho.nbody(2, masses=[1.0, 0.0]), st, n)
-    for ta in (a, b):
-        ta.propagate_until(7.0)
+    b = hy.taylor_adaptive_batch(sys_g, st, n, sum_order="running")
+    assert a.hip_source_mode.startswith("unrolled") and a.hip_source == b.hip_source
+    ora = ho.OracleIntegrator(ho.nbody(2, masses=[1.0, 0.0]), st, n, compact_mode=True)
+    a.propagate_until(7.0)
     ora.propagate_until(7.0)
-    assert rel_err(a.state, ora.state.reshape(12, n)) <= 1e5 * EPS
-    assert rel_err(a.state, b.state) <= 1e5 * EPS
+    assert row_rel_err(a.state, ora.state.reshape(12, n)) <= 1e5 * EPS
+
+    # A decomposition the planners cannot shape and which is not small: the table steppers (staged: tape in LDS).
+    x, y, z = hy.make_vars("x", "y", "z")
+    big = [(x, y * z + hy.sin(x) * hy.cos(y) + hy.exp(-x * x) * z + hy.log(1.5 + y * y) - x),
+           (y, z * hy.sin(x * y) - y * hy.cos(z) + hy.pow(1.2 + x * x + y * y, -1.5) * x),
+           (z, x * y - z * hy.sqrt(1.0 + z * z) + hy.sin(z) * hy.exp(-y * y))]
+    assert len(hy.taylor_decompose_sys(big)) - 6 > 40
+    c = hy.taylor_adaptive_batch(big, None, 64, compact_mode=True)
+    d = hy.taylor_adaptive_batch(big, None, 64)
+    assert c.hip_source_mode.startswith("table") and "staged" in c.hip_source_mode, c.hip_source_mode
+    assert d.hip_source_mode.startswith("unrolled"), d.hip_source_mode
 
 
 @pytest.mark.gpu
