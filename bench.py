@@ -45,9 +45,22 @@ WORKLOADS = {
     # (Not a BASELINE.json configuration: model::nbody(6) with its DEFAULT masses - the accelerations are sum / sub /
     # negation trees which the planner flattens in the internal program to reach the kernel of the headline system.)
     "nbody6_default_masses": 5.7e4,
+    # Round 6: the general-DAG paths. No SURVEY estimate: the derived count (heyoka_amd/roofline.py) is the only figure.
+    # - the headline configuration with kw::compact_mode = true (benchmark/outer_ss_long_term_batch.cpp:113 exposes the
+    #   flag): the on-chip kernel stays, the arithmetic is checked against the compact-mode oracle in the tests;
+    # - the headline DAG FORCED onto the table stepper (kw::emitter = table): the staged variant, tape in LDS;
+    # - a mixed model the cluster planners cannot shape (point masses + the oblateness of the first body: the histories of
+    #   one cluster of every class exceed the register file): the staged table stepper picked AUTOMATICALLY;
+    # - a mixed model on the multi-class wave-cluster stepper (pendulum chain with cubic bonds: two classes of clusters).
+    "outer_ss_compact_mode": None,
+    "outer_ss_forced_table": None,
+    "nbody6_j2_mixed": None,
+    "sine_lattice16_mixed": None,
 }
 # Default ensemble sizes of the BASELINE.json configurations (systems per GPU).
-DEFAULT_SYSTEMS = {"outer_ss": 1048576, "two_body": 4194304, "nbody64": 65536, "nbody6_default_masses": 1048576}
+DEFAULT_SYSTEMS = {"outer_ss": 1048576, "two_body": 4194304, "nbody64": 65536, "nbody6_default_masses": 1048576,
+                   "outer_ss_compact_mode": 1048576, "outer_ss_forced_table": 262144, "nbody6_j2_mixed": 262144,
+                   "sine_lattice16_mixed": 262144}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_PEAK_TFLOPS = 78.6  # vector FP64
 
@@ -60,6 +73,29 @@ def make_integrator(hy, configs, workload, n_systems, seed, device=0):
         # Years per bench step: ~82 Taylor steps per system and call, i.e. ~0.17 s of kernel per step - the timed region
         # of the driver's `--steps 20 --warmup 5` is > 3 s (clock / thermal steady state, visible to the SMI sampler).
         dt = 60.0
+    elif workload in ("outer_ss_compact_mode", "outer_ss_forced_table"):
+        sys_ = hy.model.nbody(6, masses=configs.OUTER_SS_MASSES, Gconst=configs.OUTER_SS_G)
+        st = configs.outer_ss_state(n_systems, perturb=1e-12, seed=seed)
+        if workload == "outer_ss_compact_mode":
+            ta = hy.taylor_adaptive_batch(sys_, None, n_systems, high_accuracy=True, compact_mode=True, device=device)
+            dt = 60.0
+        else:
+            ta = hy.taylor_adaptive_batch(sys_, None, n_systems, high_accuracy=True, emitter="table", device=device)
+            dt = 10.0
+    elif workload == "nbody6_j2_mixed":
+        from heyoka_amd import mixed_models as mm
+
+        sys_ = mm.nbody_j2(hy, 6, configs.OUTER_SS_MASSES, configs.OUTER_SS_G, 1e-7)
+        st = configs.outer_ss_state(n_systems, perturb=1e-12, seed=seed)
+        ta = hy.taylor_adaptive_batch(sys_, None, n_systems, device=device)
+        dt = 10.0
+    elif workload == "sine_lattice16_mixed":
+        from heyoka_amd import mixed_models as mm
+
+        sys_ = mm.sine_lattice(hy, 16)
+        st = mm.sine_lattice_state(16, n_systems, seed=seed)
+        ta = hy.taylor_adaptive_batch(sys_, None, n_systems, device=device)
+        dt = 4.0
     elif workload == "nbody64":
         sys_ = hy.model.nbody(64)
         st = configs.plummer_nbody_state(64, n_systems, seed=1234 + seed)
@@ -329,6 +365,11 @@ def run_workload(ctx, workload, n, steps, warmup):
 
     local_steps = float(steps_per_call_all.sum())
     local = torch.tensor([elapsed, local_steps, float(np.mean(kern_ms))], dtype=torch.float64, device=dev)
+    # What every rank actually ran on and measured (a slow or misplaced rank is invisible in the one aggregate): device
+    # ordinal, PCI location, own elapsed time / system-steps / mean kernel time.
+    props = torch.cuda.get_device_properties(dev)
+    pci = [float(getattr(props, "pci_domain_id", -1)), float(getattr(props, "pci_bus_id", -1)), float(getattr(props, "pci_device_id", -1))]
+    rank_rec = torch.tensor([elapsed, local_steps, float(np.mean(kern_ms)), float(dev_index)] + pci, dtype=torch.float64, device=dev)
     if distributed:
         mx_t = local.clone()
         dist.all_reduce(mx_t, op=dist.ReduceOp.MAX)
@@ -336,9 +377,15 @@ def run_workload(ctx, workload, n, steps, warmup):
         dist.all_reduce(sm_t, op=dist.ReduceOp.SUM)
         elapsed_max = float(mx_t[0])
         total_steps = float(sm_t[1])
+        recs = [torch.zeros_like(rank_rec) for _ in range(world)]
+        dist.all_gather(recs, rank_rec)
+        rank_recs = [r.cpu().numpy() for r in recs]
+        ranks_seen = int(dist.get_world_size())
     else:
         elapsed_max = elapsed
         total_steps = local_steps
+        rank_recs = [rank_rec.cpu().numpy()]
+        ranks_seen = 1
 
     if rank == 0:
         from heyoka_amd import codegen_check, roofline
@@ -366,6 +413,9 @@ def run_workload(ctx, workload, n, steps, warmup):
         # (Block mode v2 keeps the low rows of the cluster histories in registers and recomputes three of five members:
         # the B_tape model counts bytes which it does not move.)
         partly_on_chip = (not on_chip) and "v2 cluster phase" in mode_str
+        # (The staged table stepper keeps the tape of a system in LDS: the B_tape figure is the ALGORITHMIC traffic of the
+        # one-lane-per-system formulation - SURVEY 8d's official scale for this path -, not bytes which reach HBM.)
+        staged = mode_str.startswith("table") and "staged" in mode_str
         hbm_util = (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else (0.0 if on_chip else min(1.0, achieved_gbs / HBM_PEAK_GBS))
         compute_bound = achieved_tflops / FP64_PEAK_TFLOPS > hbm_util
         # (How the binding ceiling was decided: from counter traffic of this very kernel, or - without a matching summary
@@ -391,7 +441,10 @@ def run_workload(ctx, workload, n, steps, warmup):
                     "frac": min(1.0, achieved_gbs / HBM_PEAK_GBS) if partly_on_chip else achieved_gbs / HBM_PEAK_GBS,
                     "achieved_basis": "algorithmic tape bytes (B_tape, SURVEY 8d) / kernel time"
                     + ("; capped at 1: part of the tape stays on chip and no counter summary of this kernel is under profiles/"
-                       if partly_on_chip else "")}
+                       if partly_on_chip else "")
+                    + ("; the tape of this stepper lives in LDS (one system per workgroup): the figure is the algorithmic traffic "
+                       "of the one-lane-per-system formulation on the 8 TB/s scale, what binds is the LDS latency of the "
+                       "dependency chain of an order" if staged else "")}
         out = {
             "metric": "ODE systems x steps/sec (fp64)",
             "value": value,
@@ -418,8 +471,21 @@ def run_workload(ctx, workload, n, steps, warmup):
                 "integrator_build_s": build_s,
                 "hiprtc_compile_s": ta.compile_seconds,
                 "kernel_sha256": kernel_sha(ta),
+                # Build id of libheyoka_amd.so = hash of the sources it was built from; the import refuses a library which
+                # does not match the tree (heyoka_amd/_lib.py), so this is also the hash of heyoka_amd/csrc of this run.
+                "library_build_id": hy.build_id(),
                 # (The kernels are compiled on THIS box at construction: which hiprtc / HIP runtime did it.)
                 "toolchain": hy.version(),
+                # Rank by rank (index = rank): throughput from the rank's own clock, its mean kernel time, the device it
+                # bound (ordinal in its process, PCI domain:bus:device), and the size of the communicator as the collective
+                # library reports it.
+                "per_rank_value": [float(r[1] / r[0]) for r in rank_recs],
+                "per_rank_kernel_ms": [float(r[2]) for r in rank_recs],
+                "per_rank_device": [{"ordinal": int(r[3]), "pci": "%04x:%02x:%02x" % (int(r[4]) & 0xFFFF, int(r[5]) & 0xFF, int(r[6]) & 0xFF)}
+                                    for r in rank_recs],
+                "rccl_ranks_seen": ranks_seen,
+                "collective_backend": (ctx.get("backend") if distributed else None),
+                "collective_timeout_s": (ctx.get("collective_timeout") if distributed else None),
                 "untimed_final_state_all_gather_ms": gather_ms,
                 "gathered_systems": (int(gathered.shape[1]) if gathered is not None else None),
                 "gathered_bytes_per_rank": (int(gathered.numel()) * 8 if gathered is not None else None),
@@ -444,18 +510,19 @@ def run_workload(ctx, workload, n, steps, warmup):
                 "algorithmic_counts_source": "heyoka_amd/roofline.py on the decomposition of this integrator "
                 "(%d u variables, order %d)" % (n_u, ta.order),
                 # Round-1 basis (SURVEY 8d estimate of F_alg), for continuity only.
-                "fp64_valu_frac_survey_falg": f_survey * per_launch_steps / (k_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                "fp64_valu_frac_survey_falg": (f_survey * per_launch_steps / (k_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if f_survey else None,
                 "kernel_resources": codegen_check.kernel_resources(ta.code_object),
                 "kernel_mode": ta.hip_source_mode,
                 # Both views, whichever binds.
                 "fp64_valu_frac": achieved_tflops / FP64_PEAK_TFLOPS,
                 "hbm_tape_model_frac": achieved_gbs / HBM_PEAK_GBS,
                 # (> 1 in the tape model means the jets never travel: they live in registers / LDS - not skipped work.)
-                "tape_on_chip": bool(on_chip or partly_on_chip),
+                "tape_on_chip": bool(on_chip or partly_on_chip or staged),
                 "tape_on_chip_note": ("all of the jets in LDS / registers" if on_chip else
                                       ("part of the tape never travels: " + mode_str[mode_str.find("v2 cluster phase"):]
                                        + " - see hbm_measured_frac for the bytes which do") if partly_on_chip else
-                                      "the tape streams through HBM"),
+                                      ("the tape of a system lives in LDS for the whole step (staged table stepper)" if staged else
+                                       "the tape streams through HBM")),
                 "hbm_measured_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
             },
         }
@@ -667,6 +734,8 @@ def main():
     ap.add_argument("--no-long-horizon", action="store_true", help="skip the long-horizon leg of the extra workloads (~30 s)")
     ap.add_argument("--long-horizon-years", type=float, default=1.0e4)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI)")
+    ap.add_argument("--collective-timeout", type=float, default=180.0,
+                    help="seconds after which a collective that does not complete fails the run instead of hanging it")
     ap.add_argument("--single-device", action="store_true",
                     help="debug: all ranks share GPU 0 (use with --backend gloo to exercise the N > 1 path on one GPU)")
     args = ap.parse_args()
@@ -685,17 +754,23 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dev_index = 0 if args.single_device else local_rank
         torch.cuda.set_device(dev_index)
+        import datetime
+
+        # Every collective is bounded: a rank which never arrives fails the run after the timeout (the process-group
+        # watchdog aborts the communicator) instead of eating the driver's whole time budget.
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        tmo = datetime.timedelta(seconds=args.collective_timeout)
         if args.backend == "nccl":
             # Binding the communicator to this rank's device up front: barrier() and the first collective do not have to
             # guess the device (and RCCL initialises eagerly, before the timed region).
             try:
-                dist.init_process_group(backend=args.backend, device_id=torch.device("cuda", dev_index))
+                dist.init_process_group(backend=args.backend, device_id=torch.device("cuda", dev_index), timeout=tmo)
             except Exception:  # (eager initialisation not available / failed: fall back to the lazy one)
                 if dist.is_initialized():
                     dist.destroy_process_group()
-                dist.init_process_group(backend=args.backend)
+                dist.init_process_group(backend=args.backend, timeout=tmo)
         else:
-            dist.init_process_group(backend=args.backend)
+            dist.init_process_group(backend=args.backend, timeout=tmo)
     else:
         dev_index = 0
         torch.cuda.set_device(0)
@@ -706,7 +781,8 @@ def main():
     from heyoka_amd import ensemble as hens
 
     ctx = dict(torch=torch, hy=hy, configs=configs, hens=hens, dist=(dist if distributed else None), rank=rank, world=world,
-               distributed=distributed, dev=dev, dev_index=dev_index)
+               distributed=distributed, dev=dev, dev_index=dev_index, backend=args.backend,
+               collective_timeout=args.collective_timeout)
     n = args.systems if args.systems > 0 else DEFAULT_SYSTEMS[args.workload]
     out = run_workload(ctx, args.workload, n, args.steps, args.warmup)
     gather_failed = bool(out.pop("_gather_failed", False)) if out is not None else False
@@ -732,6 +808,13 @@ def main():
                 extra.append({k: r[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline")})
             except Exception as e:
                 extra.append({"config": {"workload": "nbody6_default_masses"}, "error": "%s: %s" % (type(e).__name__, e)})
+            # Round 6: the general-DAG paths (see WORKLOADS), each with its own roofline.
+            for wl in ("outer_ss_compact_mode", "outer_ss_forced_table", "nbody6_j2_mixed", "sine_lattice16_mixed"):
+                try:
+                    r = run_workload(ctx, wl, DEFAULT_SYSTEMS[wl], 3, 1)
+                    extra.append({k: r[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline")})
+                except Exception as e:
+                    extra.append({"config": {"workload": wl}, "error": "%s: %s" % (type(e).__name__, e)})
             try:
                 extra.append(divergence_leg(ctx, DEFAULT_SYSTEMS["outer_ss"]))
             except Exception as e:

@@ -69,6 +69,55 @@ def version():
     return take_str(lib.hy_version())
 
 
+_LOG_LEVELS = {"trace": 0, "debug": 1, "info": 2, "warn": 3, "err": 4, "critical": 5, "off": 6}
+_log_keep = []
+
+
+def set_logger_level(level):
+    """include/heyoka/logging.hpp:19-24 (set_logger_level_trace() ... set_logger_level_critical()): a name or 0 ... 6."""
+    raise_for(lib.hy_set_logger_level(int(_LOG_LEVELS.get(level, level))))
+
+
+def set_logger_level_trace():
+    set_logger_level("trace")
+
+
+def set_logger_level_debug():
+    set_logger_level("debug")
+
+
+def set_logger_level_info():
+    set_logger_level("info")
+
+
+def set_logger_level_warn():
+    set_logger_level("warn")
+
+
+def set_logger_level_err():
+    set_logger_level("err")
+
+
+def set_logger_level_critical():
+    set_logger_level("critical")
+
+
+def set_log_callback(fn):
+    """fn(level, message) receives the log messages instead of stderr (None restores stderr)."""
+    if fn is None:
+        lib.hy_set_log_callback(None, None)
+        del _log_keep[:]
+        return
+    cb = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_char_p, ctypes.c_void_p)(lambda lvl, msg, _u: fn(int(lvl), msg.decode()))
+    _log_keep.append(cb)
+    lib.hy_set_log_callback(ctypes.cast(cb, ctypes.c_void_p), None)
+
+
+def build_id():
+    """Build id of the loaded library (checked against the sources of this tree at import, heyoka_amd/_lib.py)."""
+    return lib.hy_build_id().decode()
+
+
 def device_count():
     return int(lib.hy_device_count())
 

@@ -18,6 +18,43 @@ if not os.path.exists(LIB_PATH):
 
 lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
 
+
+def tree_build_id():
+    """Build id of the SOURCES next to this file: first 16 hex digits of the SHA-256 over heyoka_amd/csrc/*.{cpp,hpp} (sorted)
+    and include/heyoka_amd.h - what the Makefile bakes into the library (hy_build_id())."""
+    import glob
+    import hashlib
+
+    csrc = os.path.join(_HERE, "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.cpp")) + glob.glob(os.path.join(csrc, "*.hpp")), key=os.path.basename)
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "heyoka_amd.h"))
+    h = hashlib.sha256()
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def _check_build_id():
+    """A prebuilt library which does not match the sources it ships with is a stale build: hard error (the GPU box never
+    rebuilds the library - it travels with the snapshot -, so nothing else would notice).
+    HEYOKA_AMD_SKIP_BUILD_ID_CHECK=1 switches the check off (installed copies without the sources skip it by themselves)."""
+    if os.environ.get("HEYOKA_AMD_SKIP_BUILD_ID_CHECK") == "1" or not os.path.isdir(os.path.join(_HERE, "csrc")):
+        return
+    try:
+        lib.hy_build_id.restype = ctypes.c_char_p
+        have = lib.hy_build_id().decode()
+    except AttributeError:
+        have = "(no build id: a library built before round 6)"
+    want = tree_build_id()
+    if have != want:
+        raise ImportError(
+            "heyoka_amd: %s was built from other sources than the ones in this tree (library build id %s, tree %s). Rebuild it "
+            "with `make -C heyoka_amd/csrc` (or `python -c 'import __graft_entry__ as g; g.build()'`)." % (LIB_PATH, have, want))
+
+
+_check_build_id()
+
 c_void_p = ctypes.c_void_p
 c_char_p = ctypes.c_char_p
 c_double = ctypes.c_double
@@ -80,6 +117,10 @@ SIGNATURES = [
     ("hy_last_error_code", c_int, []),
     ("hy_free_str", None, [c_void_p]),
     ("hy_version", c_void_p, []),
+    ("hy_build_id", c_char_p, []),
+    ("hy_set_logger_level", c_int, [c_int]),
+    ("hy_get_logger_level", c_int, []),
+    ("hy_set_log_callback", None, [c_void_p, c_void_p]),
     ("hy_device_count", c_int, []),
     ("hy_expr_var", c_void_p, [c_char_p]),
     ("hy_expr_num", c_void_p, [c_double]),

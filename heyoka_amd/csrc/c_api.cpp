@@ -1,4 +1,6 @@
 // C ABI of the MI355X batch Taylor integrator. See include/heyoka_amd.h.
+#include "logging.hpp"
+#include "_build/build_id.h"
 #include "../../include/heyoka_amd.h"
 
 #include <cstdlib>
@@ -842,6 +844,32 @@ int hy_event_counter_t(hy_tab, int, uint32_t, void *user)
 {
     __atomic_fetch_add(static_cast<std::uint64_t *>(user), std::uint64_t(1), __ATOMIC_RELAXED);
     return 1;
+}
+
+// Logger (include/heyoka/logging.hpp:19-24): level 0 trace ... 5 critical, 6 off; default 3 (warn). A sink of the caller's
+// receives (level, message) instead of stderr.
+int hy_set_logger_level(int level)
+{
+    return guarded([&] {
+        if (level < 0 || level > 6) {
+            throw std::invalid_argument("Invalid logger level: " + std::to_string(level) + " (0 trace ... 5 critical, 6 off)");
+        }
+        heyoka_amd::set_logger_level(static_cast<heyoka_amd::log_level>(level));
+    });
+}
+int hy_get_logger_level(void)
+{
+    return static_cast<int>(heyoka_amd::get_logger_level());
+}
+void hy_set_log_callback(hy_log_callback_t cb, void *user)
+{
+    heyoka_amd::set_log_sink(cb, user);
+}
+
+// Build id of the library: the first 16 hex digits of the SHA-256 of its sources (Makefile, _build/build_id.h).
+const char *hy_build_id(void)
+{
+    return HY_BUILD_ID;
 }
 
 int hy_tab_with_events(hy_tab t)

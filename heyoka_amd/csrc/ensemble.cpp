@@ -181,6 +181,24 @@ void nccl_ok(int rc, const char *what)
     }
 }
 
+// The device which owns a buffer must be the one the plan says: a block packed on the wrong device (or a stale pointer)
+// would otherwise be read over xGMI from somewhere else - or fault inside a collective, where nothing names the culprit.
+void assert_owner(const void *ptr, int device, const char *what)
+{
+    if (ptr == nullptr) {
+        return;
+    }
+    hipPointerAttribute_t attr{};
+    if (hipPointerGetAttributes(&attr, ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        throw std::runtime_error(std::string("heyoka_amd: the gather cannot identify the owner of the ") + what);
+    }
+    if (attr.device != device) {
+        throw std::runtime_error(std::string("heyoka_amd: the ") + what + " lives on device " + std::to_string(attr.device)
+                                 + ", expected device " + std::to_string(device));
+    }
+}
+
 // A 2D copy (dim rows of n doubles) into the columns [off, off + n) of the result.
 void place_block(double *dst, std::size_t n_total, std::size_t off, const double *src, std::size_t n, std::size_t dim,
                  hipStream_t stream)
@@ -270,6 +288,13 @@ ensemble_gathered detail_gather(const std::vector<detail::tab_core *> &tabs, int
     }
     g.m_buf = device_buffer(n_rows * g.m_total * sizeof(double), dst_device);
     auto *const out = g.m_buf.as<double>();
+    // (First contact with a multi-GPU node: every buffer is checked against the device it is supposed to live on before
+    // anything is sent or copied between devices.)
+    assert_owner(out, dst_device, "gathered result");
+    for (std::size_t i = 0; i < tabs.size(); ++i) {
+        assert_owner(packs[i].get(), tabs[i]->get_device(), "packed results of an integrator");
+        assert_owner(tabs[i]->device_state(), tabs[i]->get_device(), "state of an integrator");
+    }
 
     // Which devices take part (the destination is rank 0).
     std::vector<int> devs{dst_device};
@@ -305,6 +330,7 @@ ensemble_gathered detail_gather(const std::vector<detail::tab_core *> &tabs, int
             };
             for (auto *t : tabs) {
                 staging.emplace_back(n_rows * t->get_batch_size() * sizeof(double), dst_device);
+                assert_owner(staging.back().get(), dst_device, "staging block of the gather");
             }
             constexpr int nccl_f64 = 8; // ncclFloat64 (ncclDataType_t, nccl.h)
             nccl_ok(a.GroupStart(), "ncclGroupStart");

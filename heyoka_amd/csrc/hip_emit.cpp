@@ -1390,6 +1390,7 @@ bool match_pair_distance_event(const taylor_program &p, std::uint32_t u, pair_di
 }
 
 emitted_module emit_cluster_or_empty(const taylor_program &, const emit_options &, std::string &why_not);
+emitted_module emit_cluster_multi_or_empty(const taylor_program &, const emit_options &, std::string &why_not);
 emitted_module emit_table(const taylor_program &, const emit_options &);
 emitted_module emit_block(const taylor_program &, const emit_options &, std::string &why_not);
 bool add_state_aliases(const taylor_program &, taylor_program &);
@@ -1460,6 +1461,7 @@ dev_switches dev_switches::from_env()
     d.block_v2 = !off("HEYOKA_AMD_BLOCK_V2");
     d.state_aliases = !set("HEYOKA_AMD_NO_STATE_ALIASES");
     d.cluster_v1 = set("HEYOKA_AMD_CLUSTER_V1");
+    d.multi_class = !(std::getenv("HEYOKA_AMD_MULTI_CLASS") != nullptr && std::string(std::getenv("HEYOKA_AMD_MULTI_CLASS")) == "0");
     d.linearise = !set("HEYOKA_AMD_NO_LINEARISED_SUMS");
     d.table_lds = num("HEYOKA_AMD_TABLE_LDS", -1);
     d.ev_inline_max_nonlinear = num("HEYOKA_AMD_EV_INLINE_MAX_NONLINEAR", -1);
@@ -1637,6 +1639,33 @@ emitted_module emit_hip_module(const taylor_program &prog, const emit_options &o
                         return mp;
                     }
                 }
+            }
+            // (Decompositions small enough for straight-line code on ONE lane stay there: a handful of clusters spread
+            // over two or four lanes with an LDS exchange is not faster than the registers of a single lane.)
+            if (m.source.empty() && opts.dev.multi_class && !opts.event_stepper && prog.nodes.size() > opts.unroll_max_nodes) {
+                // Clusters of several shapes (point-mass pairs next to oblateness / drag / relativistic terms, mixed
+                // models) or at several dependency levels: one section of straight-line code per CLASS of clusters, cluster
+                // i of a class on lane i of the system (emit_cluster_v1() on a multi-class plan); with alias u variables
+                // for state variables in history position where needed.
+                std::string why_m;
+                auto mm = emit_cluster_multi_or_empty(prog, opts, why_m);
+                if (mm.source.empty() && why_m.rfind("a state variable is a history operand", 0) == 0 && opts.dev.state_aliases) {
+                    taylor_program aliased;
+                    if (add_state_aliases(prog, aliased)) {
+                        std::string why_a;
+                        mm = emit_cluster_multi_or_empty(aliased, opts, why_a);
+                        if (!mm.source.empty()) {
+                            mm.notes += "; state variables in history-operand position aliased by u variables";
+                            mm.internal_program = program_to_string(aliased);
+                        }
+                        why_m += "; with state-variable aliases: " + why_a;
+                    }
+                }
+                if (!mm.source.empty()) {
+                    mm.notes += " (single-class planners: " + why + ")";
+                    return mm;
+                }
+                why += "; multi-class plan: " + why_m;
             }
             if (m.source.empty()) {
                 // Not applicable to this DAG: fall back to the generic one-system-per-lane code, unrolled

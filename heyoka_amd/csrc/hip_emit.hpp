@@ -67,6 +67,7 @@ enum class emit_mode { unrolled, cluster, table, block };
 //   HEYOKA_AMD_BLOCK_V2=0             block mode: generic cluster phase
 //   HEYOKA_AMD_NO_STATE_ALIASES       planner: no alias u variables for state variables in history position
 //   HEYOKA_AMD_CLUSTER_V1             first-generation cluster generator
+//   HEYOKA_AMD_MULTI_CLASS=0          planner: no multi-class plans (clusters of several shapes / levels)
 //   HEYOKA_AMD_TABLE_LDS=0|1          table stepper: tape in HBM / in LDS (default: by size)
 //   HEYOKA_AMD_EV_INLINE_MAX_NONLINEAR  budget of nonlinear nodes of the event equations inside the stepper
 //   HEYOKA_AMD_V5_PRIO, HEYOKA_AMD_V5_OPTS, HEYOKA_AMD_V5_PAD   one-lane-per-pair kernel: issue priorities, round-5 items
@@ -76,7 +77,7 @@ enum class emit_mode { unrolled, cluster, table, block };
 // HEYOKA_AMD_EVENTS_TIMING belong to the runtime, not to code generation.)
 struct dev_switches {
     bool v5_events = true, compact_tc = true, events_in_stepper = true, pair_events = true, refill = true, block_v2 = true,
-         state_aliases = true, cluster_v1 = false, linearise = true;
+         state_aliases = true, cluster_v1 = false, linearise = true, multi_class = true;
     int table_lds = -1, ev_inline_max_nonlinear = -1, v5_prio = 2;
     // HEYOKA_AMD_UNROLLED_WAVES=n: the straight-line stepper is compiled for n wavefronts per SIMD (amdgpu_waves_per_eu: the
     // register allocator gets 512 / n registers per lane and spills the rest - the two-wavefront experiment of round 5).

@@ -1066,6 +1066,174 @@ std::string cluster_detail::make_plan(const taylor_program &p, std::uint32_t ord
 namespace
 {
 
+// Second half of make_plan_impl() for multi-class plans: the clusters are grouped into classes of identical shape and
+// dependency level; constants, exported members and histories are per class; LDS slots and glue groups as usual.
+std::string finish_multi_class_plan(const taylor_program &p, std::uint32_t order, cluster_plan &pl, const std::vector<char> *cu,
+                                    const std::vector<std::uint32_t> &clvl, const std::vector<std::string> &sigs,
+                                    const std::vector<std::vector<std::pair<std::uint32_t, std::uint32_t>>> &num_pos,
+                                    const std::vector<std::vector<double>> &num_val, const std::vector<char> &exported)
+{
+    using cluster_detail::cluster_class;
+    using cluster_detail::glue_group;
+    const auto n_eq = p.n_eq, n_u = p.n_u;
+    const auto nc = pl.clusters.size();
+    // Classes, in the order of their first cluster.
+    std::map<std::pair<std::uint32_t, std::string>, std::size_t> cidx;
+    for (std::size_t c = 0; c < nc; ++c) {
+        const auto key = std::make_pair(clvl[c], sigs[c]);
+        auto it = cidx.find(key);
+        if (it == cidx.end()) {
+            it = cidx.emplace(key, pl.classes.size()).first;
+            pl.classes.emplace_back();
+            pl.classes.back().level = clvl[c];
+        }
+        pl.classes[it->second].members.push_back(static_cast<std::uint32_t>(c));
+    }
+    std::size_t max_members = 0, stored_total = 0;
+    for (auto &cls : pl.classes) {
+        const auto c0 = cls.members[0];
+        const auto &t0 = pl.clusters[c0];
+        max_members = std::max(max_members, cls.members.size());
+        // Constants: literal if identical across the class, otherwise a per-lane table entry.
+        cls.cst_val.assign(cls.members.size(), {});
+        for (std::size_t j = 0; j < num_pos[c0].size(); ++j) {
+            bool same = true;
+            for (const auto c : cls.members) {
+                const auto a = num_val[c][j], b = num_val[c0][j];
+                if (!(a == b || (std::isnan(a) && std::isnan(b))) || std::signbit(a) != std::signbit(b)) {
+                    same = false;
+                }
+            }
+            if (!same) {
+                cls.cst_pos.push_back(num_pos[c0][j]);
+                for (std::size_t m = 0; m < cls.members.size(); ++m) {
+                    cls.cst_val[m].push_back(num_val[cls.members[m]][j]);
+                }
+            }
+        }
+        for (std::uint32_t q = 0; q < t0.size(); ++q) {
+            bool any = false;
+            for (const auto c : cls.members) {
+                any = any || exported[pl.clusters[c][q]] != 0;
+            }
+            if (any) {
+                cls.out_pos.push_back(q);
+            }
+        }
+        // Histories of the template.
+        std::set<std::uint32_t> stored;
+        for (const auto u : t0) {
+            const auto &n = p.nodes[u - n_eq];
+            const auto hs = history_operands(n, cu);
+            for (const auto h : hs) {
+                stored.insert(h);
+            }
+            switch (n.kind) {
+                case func_kind::pow:
+                case func_kind::div:
+                case func_kind::sin:
+                case func_kind::cos:
+                case func_kind::exp:
+                case func_kind::log:
+                case func_kind::sigmoid:
+                case func_kind::asin:
+                case func_kind::acos:
+                case func_kind::atan:
+                case func_kind::asinh:
+                case func_kind::acosh:
+                case func_kind::atanh:
+                    if (!hs.empty()) {
+                        stored.insert(u);
+                    }
+                    break;
+                default:
+                    break;
+            }
+        }
+        for (std::uint32_t q = 0; q < t0.size(); ++q) {
+            if (stored.count(t0[q]) != 0u) {
+                cls.stored_pos.push_back(q);
+            }
+        }
+        stored_total += stored.size();
+    }
+    if (max_members > 64u) {
+        return "more than 64 clusters in a class";
+    }
+    // (Every lane carries the histories of one cluster of EVERY class.)
+    if (stored_total * order * 2u > 420u) {
+        return "the jets of the cluster classes do not fit in the register file (" + std::to_string(stored_total) + " histories)";
+    }
+    pl.L = 2;
+    while (pl.L < max_members && pl.L < 64u) {
+        pl.L *= 2u;
+    }
+    pl.spw = 64u / pl.L;
+    pl.max_level = *std::max_element(pl.lvl.begin(), pl.lvl.end());
+
+    // LDS slots: state variables, exported cluster members (output-major inside a class), glue nodes.
+    pl.slot_of.assign(n_u, -1);
+    std::uint32_t ns = 0;
+    for (std::uint32_t i = 0; i < n_eq; ++i) {
+        pl.slot_of[i] = static_cast<int>(ns++);
+    }
+    for (const auto &cls : pl.classes) {
+        for (const auto q : cls.out_pos) {
+            for (const auto c : cls.members) {
+                pl.slot_of[pl.clusters[c][q]] = static_cast<int>(ns++);
+            }
+        }
+    }
+    for (std::uint32_t u = n_eq; u < n_u; ++u) {
+        if (pl.cluster_of[u] == -1) {
+            pl.slot_of[u] = static_cast<int>(ns++);
+        }
+    }
+    pl.n_slots = ns;
+
+    // Glue groups: per level, per shape.
+    const auto structural_number = [](const dc_node &n, std::size_t a) {
+        if (n.kind == func_kind::pow && a == 1u) {
+            return true;
+        }
+        return n.kind == func_kind::prod && a == 0u && n.args[0].type == operand::kind::num && n.args[0].value == -1.;
+    };
+    std::map<std::pair<std::uint32_t, std::string>, std::size_t> gidx;
+    for (std::uint32_t i = 0; i < p.nodes.size(); ++i) {
+        const auto u = n_eq + i;
+        if (pl.cluster_of[u] != -1) {
+            continue;
+        }
+        const auto &n = p.nodes[i];
+        std::ostringstream key;
+        key << func_kind_name(n.kind);
+        for (std::size_t a = 0; a < n.args.size(); ++a) {
+            const auto &o = n.args[a];
+            if (is_var(o)) {
+                key << ((cu != nullptr && n.kind == func_kind::prod && (*cu)[o.idx] != 0) ? "k" : "v");
+            } else if (o.type == operand::kind::par) {
+                key << "p" << o.idx;
+            } else if (structural_number(n, a)) {
+                key << "n" << fp_literal(o.value);
+            } else {
+                key << "c";
+            }
+        }
+        const auto k = std::make_pair(pl.lvl[u], key.str());
+        auto it = gidx.find(k);
+        if (it == gidx.end()) {
+            it = gidx.emplace(k, pl.groups.size()).first;
+            pl.groups.emplace_back();
+            pl.groups.back().level = pl.lvl[u];
+            pl.groups.back().key = key.str();
+        }
+        pl.groups[it->second].nodes.push_back(u);
+    }
+    std::stable_sort(pl.groups.begin(), pl.groups.end(),
+                     [](const glue_group &a, const glue_group &b) { return a.level < b.level; });
+    return {};
+}
+
 std::string make_plan_impl(const taylor_program &p, std::uint32_t order, cluster_plan &pl,
                            const cluster_detail::plan_limits &lim)
 {
@@ -1119,7 +1287,7 @@ std::string make_plan_impl(const taylor_program &p, std::uint32_t order, cluster
     if (pl.clusters.size() < 2u) {
         return "fewer than 2 clusters";
     }
-    if (pl.clusters.size() > lim.max_clusters) {
+    if (pl.clusters.size() > lim.max_clusters && !lim.multi_class) {
         return "more than " + std::to_string(lim.max_clusters) + " clusters";
     }
 
@@ -1197,7 +1365,7 @@ std::string make_plan_impl(const taylor_program &p, std::uint32_t order, cluster
             }
         }
     }
-    for (std::size_t c = 1; c < nc; ++c) {
+    for (std::size_t c = 1; c < nc && !lim.multi_class; ++c) {
         if (clvl[c] != clvl[0]) {
             return "clusters at different dependency levels";
         }
@@ -1205,7 +1373,7 @@ std::string make_plan_impl(const taylor_program &p, std::uint32_t order, cluster
     pl.cluster_level = clvl[0];
     for (std::uint32_t u = n_eq; u < n_u; ++u) {
         if (pl.cluster_of[u] >= 0) {
-            pl.lvl[u] = pl.cluster_level;
+            pl.lvl[u] = clvl[static_cast<std::size_t>(pl.cluster_of[u])];
         }
     }
     pl.max_level = *std::max_element(pl.lvl.begin(), pl.lvl.end());
@@ -1246,7 +1414,7 @@ std::string make_plan_impl(const taylor_program &p, std::uint32_t order, cluster
     std::vector<std::vector<std::uint32_t>> par_idx(nc);
     for (std::size_t c = 0; c < nc; ++c) {
         const auto &mem = pl.clusters[c];
-        if (mem.size() != t0.size()) {
+        if (mem.size() != t0.size() && !lim.multi_class) {
             return "clusters are not isomorphic (different sizes)";
         }
         std::map<std::uint32_t, std::uint32_t> pos_of, ext_of;
@@ -1305,9 +1473,12 @@ std::string make_plan_impl(const taylor_program &p, std::uint32_t order, cluster
             sig << ']';
         }
         sigs[c] = sig.str();
-        if (sigs[c] != sigs[0]) {
+        if (sigs[c] != sigs[0] && !lim.multi_class) {
             return "clusters are not isomorphic";
         }
+    }
+    if (lim.multi_class) {
+        return finish_multi_class_plan(p, order, pl, cu, clvl, sigs, num_pos, num_val, exported);
     }
     // Constants: literal if identical across clusters, otherwise a per-lane table entry.
     for (std::size_t j = 0; j < num_pos[0].size(); ++j) {
@@ -1463,14 +1634,17 @@ std::string make_plan_impl(const taylor_program &p, std::uint32_t order, cluster
 
 // Version 1 of the cluster kernel: separate state-variable phase, 4 LDS synchronisations per order.
 // Returns a module with an empty source (and the reason in why_not) if cluster mode is not applicable.
-emitted_module emit_cluster_v1(const taylor_program &p, const emit_options &opts, std::string &why_not)
+emitted_module emit_cluster_v1(const taylor_program &p, const emit_options &opts, std::string &why_not, bool multi_class)
 {
     using emit_detail::prelude;
     using emit_detail::rhofac;
+    using cluster_detail::cluster_class;
 
     emitted_module ret;
     cluster_plan pl;
-    why_not = cluster_detail::make_plan(p, opts.order, pl);
+    cluster_detail::plan_limits lim;
+    lim.multi_class = multi_class;
+    why_not = cluster_detail::make_plan(p, opts.order, pl, lim);
     if (!why_not.empty()) {
         return ret;
     }
@@ -1478,15 +1652,27 @@ emitted_module emit_cluster_v1(const taylor_program &p, const emit_options &opts
     const auto n_eq = p.n_eq, order = opts.order, L = pl.L, spw = pl.spw;
     const std::uint32_t bs = 256, wpb = bs / 64u;
     const auto nc = static_cast<std::uint32_t>(pl.clusters.size());
-    const auto &t0 = pl.clusters[0];
-    const auto n_ext = static_cast<std::uint32_t>(pl.ext_u[0].size());
-    const auto n_out = static_cast<std::uint32_t>(pl.out_pos.size());
-    const auto n_cst = static_cast<std::uint32_t>(pl.cst_pos.size());
+    // The classes of clusters: one section of code each (a single-class plan is the class of all the clusters).
+    std::vector<cluster_class> classes = pl.classes;
+    if (classes.empty()) {
+        cluster_class c;
+        c.members.resize(nc);
+        std::iota(c.members.begin(), c.members.end(), 0u);
+        c.level = pl.cluster_level;
+        c.cst_pos = pl.cst_pos;
+        c.cst_val = pl.cst_val;
+        c.out_pos = pl.out_pos;
+        c.stored_pos = pl.stored_pos;
+        classes.push_back(std::move(c));
+    }
     const auto sv_rounds = (n_eq + L - 1u) / L;
     const auto n_col = sv_rounds * L;
 
     // Dummy slots for idle lanes (they replicate real work and write to slots nobody reads).
-    std::uint32_t max_round_outputs = std::max<std::uint32_t>(n_out, 1u);
+    std::uint32_t max_round_outputs = 1u;
+    for (const auto &cls : classes) {
+        max_round_outputs = std::max<std::uint32_t>(max_round_outputs, static_cast<std::uint32_t>(cls.out_pos.size()));
+    }
     const auto dummy_base = pl.n_slots;
     const auto n_slots_tot = pl.n_slots + max_round_outputs;
     // Pad the per-system slab to an odd number of doubles (bank spreading between the systems of a wave).
@@ -1510,31 +1696,44 @@ emitted_module emit_cluster_v1(const taylor_program &p, const emit_options &opts
     // once the whole body has been generated.
     std::ostringstream body;
 
-    // Cluster tables.
-    std::vector<std::size_t> ext_tbl(n_ext), out_tbl(n_out), cst_tbl(n_cst);
-    for (std::uint32_t x = 0; x < n_ext; ++x) {
-        std::vector<std::uint32_t> v(L);
-        for (std::uint32_t l = 0; l < L; ++l) {
-            const auto c = l < nc ? l : 0u;
-            v[l] = static_cast<std::uint32_t>(pl.slot_of[pl.ext_u[c][x]]);
+    // Cluster tables, per class: lane l of a system holds cluster l of the class (idle lanes replicate its first one).
+    struct class_tbls {
+        std::vector<std::size_t> ext_tbl, out_tbl, cst_tbl;
+    };
+    std::vector<class_tbls> ctb(classes.size());
+    std::vector<std::pair<std::string, std::size_t>> cst_names; // (name of the per-lane constant, its double table)
+    for (std::size_t ci = 0; ci < classes.size(); ++ci) {
+        const auto &cls = classes[ci];
+        const auto ncl = static_cast<std::uint32_t>(cls.members.size());
+        const auto c0 = cls.members[0];
+        const auto &t0 = pl.clusters[c0];
+        const auto n_ext = static_cast<std::uint32_t>(pl.ext_u[c0].size());
+        const auto cluster_at = [&](std::uint32_t l) { return cls.members[l < ncl ? l : 0u]; };
+        for (std::uint32_t x = 0; x < n_ext; ++x) {
+            std::vector<std::uint32_t> v(L);
+            for (std::uint32_t l = 0; l < L; ++l) {
+                v[l] = static_cast<std::uint32_t>(pl.slot_of[pl.ext_u[cluster_at(l)][x]]);
+            }
+            ctb[ci].ext_tbl.push_back(add_utbl(std::move(v)));
         }
-        ext_tbl[x] = add_utbl(std::move(v));
-    }
-    for (std::uint32_t x = 0; x < n_out; ++x) {
-        std::vector<std::uint32_t> v(L);
-        for (std::uint32_t l = 0; l < L; ++l) {
-            v[l] = l < nc ? static_cast<std::uint32_t>(pl.slot_of[pl.clusters[l][pl.out_pos[x]]]) : dummy_base + x;
+        for (std::uint32_t x = 0; x < cls.out_pos.size(); ++x) {
+            std::vector<std::uint32_t> v(L);
+            for (std::uint32_t l = 0; l < L; ++l) {
+                v[l] = l < ncl ? static_cast<std::uint32_t>(pl.slot_of[pl.clusters[cls.members[l]][cls.out_pos[x]]]) : dummy_base + x;
+            }
+            ctb[ci].out_tbl.push_back(add_utbl(std::move(v)));
         }
-        out_tbl[x] = add_utbl(std::move(v));
-    }
-    for (std::uint32_t x = 0; x < n_cst; ++x) {
-        std::vector<double> v(L);
-        for (std::uint32_t l = 0; l < L; ++l) {
-            v[l] = pl.cst_val[l < nc ? l : 0u][x];
+        for (std::uint32_t x = 0; x < cls.cst_pos.size(); ++x) {
+            std::vector<double> v(L);
+            for (std::uint32_t l = 0; l < L; ++l) {
+                v[l] = cls.cst_val[l < ncl ? l : 0u][x];
+            }
+            ctb[ci].cst_tbl.push_back(add_dtbl(std::move(v)));
+            const auto [q, a] = cls.cst_pos[x];
+            const auto nm = "ccst" + std::to_string(ci) + "_" + std::to_string(x);
+            e.numpar_override[&p.nodes[t0[q] - n_eq].args[a]] = nm;
+            cst_names.emplace_back(nm, ctb[ci].cst_tbl.back());
         }
-        cst_tbl[x] = add_dtbl(std::move(v));
-        const auto [q, a] = pl.cst_pos[x];
-        e.numpar_override[&p.nodes[t0[q] - n_eq].args[a]] = "ccst" + std::to_string(x);
     }
 
     // State-variable rounds: variable index of lane l in round r is r * L + l (clamped for padding lanes).
@@ -1672,24 +1871,29 @@ emitted_module emit_cluster_v1(const taylor_program &p, const emit_options &opts
         }
     };
 
-    // Cluster code at order k.
-    const auto emit_cluster = [&](std::uint32_t k) {
-        for (std::uint32_t x = 0; x < n_ext; ++x) {
-            e.val(pl.ext_u[0][x], k) = e.def("slab[" + utname(ext_tbl[x]) + "]");
+    // Code of class ci at order k (the template cluster of the class; the lanes differ by their slot tables / constants).
+    const auto emit_cluster = [&](std::size_t ci, std::uint32_t k) {
+        const auto &cls = classes[ci];
+        const auto c0 = cls.members[0];
+        const auto &t0 = pl.clusters[c0];
+        for (std::size_t x = 0; x < ctb[ci].ext_tbl.size(); ++x) {
+            e.val(pl.ext_u[c0][x], k) = e.def("slab[" + utname(ctb[ci].ext_tbl[x]) + "]");
         }
         for (const auto u : t0) {
             e.node(u - n_eq, k);
         }
-        for (std::uint32_t x = 0; x < n_out; ++x) {
-            os << "slab[" << utname(out_tbl[x]) << "] = " << e.val(t0[pl.out_pos[x]], k) << ";\n";
+        for (std::size_t x = 0; x < cls.out_pos.size(); ++x) {
+            os << "slab[" << utname(ctb[ci].out_tbl[x]) << "] = " << e.val(t0[cls.out_pos[x]], k) << ";\n";
         }
     };
 
     // All the levels of order k (k < order).
     const auto emit_levels = [&](std::uint32_t k) {
         for (std::uint32_t lev = 1; lev <= pl.max_level; ++lev) {
-            if (lev == pl.cluster_level) {
-                emit_cluster(k);
+            for (std::size_t ci = 0; ci < classes.size(); ++ci) {
+                if (classes[ci].level == lev) {
+                    emit_cluster(ci, k);
+                }
             }
             for (std::size_t g = 0; g < pl.groups.size(); ++g) {
                 if (pl.groups[g].level == lev) {
@@ -1797,8 +2001,8 @@ emitted_module emit_cluster_v1(const taylor_program &p, const emit_options &opts
     for (std::size_t t = 0; t < dtbl.size(); ++t) {
         src << "const double dt" << t << " = hy_dtbl[" << t * L << "u + l];\n";
     }
-    for (std::uint32_t x = 0; x < n_cst; ++x) {
-        src << "const double ccst" << x << " = dt" << cst_tbl[x] << ";\n";
+    for (const auto &[nm, t] : cst_names) {
+        src << "const double " << nm << " = dt" << t << ";\n";
     }
     for (std::uint32_t r = 0; r < sv_rounds; ++r) {
         src << "const bool svalid" << r << " = (" << r * L << "u + l) < " << n_eq << "u;\n";
@@ -1954,10 +2158,19 @@ if (l == 0u && live) {
     ret.scratch_per_wave = static_cast<std::uint64_t>(order + 1u) * spw * n_col;
     ret.persistent = true;
     ret.tc_optional = true;
-    ret.notes = "cluster mode: " + std::to_string(nc) + " clusters of " + std::to_string(t0.size())
-                + " nodes, L=" + std::to_string(L) + ", " + std::to_string(pl.n_slots) + " LDS slots, "
-                + std::to_string(pl.groups.size()) + " glue groups, " + std::to_string(utbl.size())
-                + " slot tables";
+    if (classes.size() == 1u) {
+        ret.notes = "cluster mode: " + std::to_string(nc) + " clusters of " + std::to_string(pl.clusters[0].size()) + " nodes";
+    } else {
+        ret.notes = "cluster mode (" + std::to_string(classes.size()) + " classes of clusters:";
+        for (const auto &cls : classes) {
+            ret.notes += " " + std::to_string(cls.members.size()) + " x " + std::to_string(pl.clusters[cls.members[0]].size())
+                         + " nodes at level " + std::to_string(cls.level) + ",";
+        }
+        ret.notes.back() = ')';
+        ret.notes += ": " + std::to_string(nc) + " clusters";
+    }
+    ret.notes += ", L=" + std::to_string(L) + ", " + std::to_string(pl.n_slots) + " LDS slots, "
+                 + std::to_string(pl.groups.size()) + " glue groups, " + std::to_string(utbl.size()) + " slot tables";
     (void)n_slots_tot;
     return ret;
 }
@@ -1975,13 +2188,19 @@ emitted_module emit_cluster_or_empty(const taylor_program &p, const emit_options
         if (!m.source.empty()) {
             return m;
         }
-        auto m1 = emit_cluster_v1(p, opts, why_not);
+        auto m1 = emit_cluster_v1(p, opts, why_not, false);
         if (!m1.source.empty()) {
             m1.notes += " (pipelined cluster kernel not applicable: " + why2 + ")";
         }
         return m1;
     }
-    return emit_cluster_v1(p, opts, why_not);
+    return emit_cluster_v1(p, opts, why_not, false);
+}
+
+// Clusters of several shapes / at several dependency levels: one section of code per class (see cluster_class).
+emitted_module emit_cluster_multi_or_empty(const taylor_program &p, const emit_options &opts, std::string &why_not)
+{
+    return emit_cluster_v1(p, opts, why_not, true);
 }
 
 } // namespace heyoka_amd

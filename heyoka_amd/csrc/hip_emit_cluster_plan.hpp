@@ -18,6 +18,18 @@ struct glue_group {
     std::vector<std::uint32_t> nodes; // u indices
 };
 
+// A class of isomorphic clusters at one dependency level (multi-class plans: systems whose nonlinear sub-DAGs come in
+// several shapes - point-mass pairs next to oblateness or drag terms, ... - run every class as its own section of
+// straight-line code, cluster i of a class on lane i of the system's lane group).
+struct cluster_class {
+    std::vector<std::uint32_t> members; // cluster ids (indices into cluster_plan::clusters), the first one is the template
+    std::uint32_t level = 1;
+    std::vector<std::pair<std::uint32_t, std::uint32_t>> cst_pos; // (template position, arg index) of per-lane constants
+    std::vector<std::vector<double>> cst_val;                     // [member][slot]
+    std::vector<std::uint32_t> out_pos;                           // template positions whose value is exported
+    std::vector<std::uint32_t> stored_pos;                        // template positions with a history
+};
+
 struct cluster_plan {
     std::uint32_t n_eq = 0, n_u = 0, L = 1, spw = 64;
     std::vector<std::vector<std::uint32_t>> clusters; // member u indices (ascending), all isomorphic
@@ -42,6 +54,8 @@ struct cluster_plan {
     // Template positions of the members whose lower-order coefficients are read by a recurrence
     // (they must be kept for the whole step: in registers, or on a tape).
     std::vector<std::uint32_t> stored_pos;
+    // Multi-class plans (plan_limits::multi_class): the classes; the single-class fields above then describe class 0.
+    std::vector<cluster_class> classes;
 };
 
 // Limits of the target kernel shape: wave mode (one system per group of <= 64 lanes, jets in registers) or
@@ -55,6 +69,8 @@ struct plan_limits {
     // Parameter operands as per-lane values (the index may differ between isomorphic clusters / the nodes of a glue
     // group: cluster_plan::par_pos / par_idx, glue_has_par). Off: the index is part of the shape.
     bool generic_pars = false;
+    // Several classes of clusters: isomorphic within a class, any shapes and dependency levels between the classes.
+    bool multi_class = false;
 };
 
 // Build the plan; returns an empty string on success, otherwise the reason why cluster mode is not applicable.

@@ -1,4 +1,5 @@
 // Host driver of the MI355X batch Taylor integrator. See taylor_adaptive_batch.hpp.
+#include "logging.hpp"
 #include "taylor_adaptive_batch.hpp"
 
 #include <algorithm>
@@ -607,6 +608,7 @@ tab_core::tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_siz
 
     // Decomposition + flattened program (with the event equations as extra functions, terminal events first,
     // reference: src/taylor_adaptive_batch.cpp:280-330).
+    const detail::stopwatch sw_dc;
     d.tes = std::move(cfg.t_events);
     d.ntes = std::move(cfg.nt_events);
     if (d.has_events()) {
@@ -636,6 +638,12 @@ tab_core::tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_siz
         d.dc = taylor_decompose_sys(sys);
         d.prog = make_program(d.dc, d.dim);
     }
+
+    // (Stage log, in the reference's wording: src/taylor_01.cpp:439-440, :968.)
+    detail::log_message(log_level::debug, "Taylor decomposition of " + std::to_string(d.dim) + " equations: " + std::to_string(d.dc.size())
+                                              + " entries (" + std::to_string(d.prog.n_u) + " u variables, "
+                                              + std::to_string(d.prog.nodes.size()) + " elementary functions)");
+    detail::log_message(log_level::trace, "Taylor decomposition construction runtime: " + sw_dc.str());
 
     // Parameters.
     const auto tot_n_pars = d.prog.n_par;
@@ -722,10 +730,25 @@ tab_core::tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_siz
     if (d.compact_mode && eo.sum_order == 0) {
         eo.sum_order = 2;
     }
+    const detail::stopwatch sw_gen;
     if (!d.cluster_events) {
         d.emitted = emit_hip_module(d.prog, eo);
     }
+    // The planner's verdict: which generator, and - in its notes - why the others did not apply (the reasons of every
+    // planner which was tried travel in emitted_module::notes; get_codegen_info() shows the same text).
+    detail::log_message(log_level::info, "Taylor batch code generation: " + get_codegen_info());
+    if (d.emitted.mode == emit_mode::table || d.emitted.notes.find("cluster mode not applicable") != std::string::npos) {
+        // A decomposition which left the on-chip steppers for a generic one is worth a line at the default level only
+        // when it is big enough to matter.
+        detail::log_message(d.prog.nodes.size() > 150u && !d.compact_mode && d.emitter == 0 ? log_level::warn : log_level::debug,
+                            "the decomposition (" + std::to_string(d.prog.nodes.size())
+                                + " elementary functions) runs on a generic stepper instead of a wave-cluster kernel: " + d.emitted.notes);
+    }
+    detail::log_message(log_level::trace, "Taylor batch code generation runtime: " + sw_gen.str());
+    const detail::stopwatch sw_jit;
     d.cmod = hiprtc_compile(d.emitted);
+    detail::log_message(log_level::trace, "Taylor batch hiprtc compilation runtime: " + sw_jit.str() + " ("
+                                              + std::to_string(d.emitted.source.size()) + " bytes of HIP source)");
 
     d.sys = std::move(sys);
     d.last_h.assign(d.N, 0.);

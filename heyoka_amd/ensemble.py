@@ -55,6 +55,9 @@ def ensemble_propagate_until_sharded(make_integrator, global_state, t_final, gro
     everything the reference's returned integrators hold (src/ensemble_propagate.cpp:193-297).
     make_integrator(n_local) -> taylor_adaptive_batch.
 
+    Returns the 4-tuple (integrator of this rank, states, meta, rec) - rounds 1 to 4 returned the first three; callers
+    which only want those index [:3].
+
     device: the torch device of the collective. With a CUDA device (backend "nccl" = RCCL over xGMI) the final state,
     outcomes and step counters are gathered straight from the integrator's device arrays (zero-copy views, no host
     staging); with None / CPU (backend "gloo", the tests) they go through the host mirrors."""

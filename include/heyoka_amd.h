@@ -44,6 +44,19 @@ int hy_last_error_code(void);
 void hy_free_str(char *);
 /* Library/toolchain information: "heyoka_amd <version>; gfx950; hiprtc <ver>". Caller frees. */
 char *hy_version(void);
+/* Build id of the library: the first 16 hex digits of the SHA-256 over its sources (the .cpp and .hpp files of heyoka_amd/csrc in sorted
+ * order, then this header). The Python host layer recomputes it from the tree at import and refuses a library which does
+ * not match (a stale prebuilt .so); bench.py prints it next to the sha of the generated kernel. Static string. */
+const char *hy_build_id(void);
+/* Stage logger (include/heyoka/logging.hpp:19-24: set_logger_level_trace() ... _critical(); src/logging.cpp:20-48): level
+ * 0 trace, 1 debug, 2 info, 3 warn (default), 4 err, 5 critical, 6 off. Logged at construction: the size of the Taylor
+ * decomposition (debug), the generator the planner chose with the reasons the others did not apply (info; warn when a large
+ * decomposition falls to a generic stepper), and the decomposition / code generation / hiprtc times (trace). Messages go to
+ * stderr unless a callback is installed. */
+typedef void (*hy_log_callback_t)(int level, const char *msg, void *user);
+int hy_set_logger_level(int level);
+int hy_get_logger_level(void);
+void hy_set_log_callback(hy_log_callback_t cb, void *user);
 /* Number of visible HIP devices (0 without a GPU). */
 int hy_device_count(void);
 

@@ -20,12 +20,24 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session", autouse=True)
 def _build_product():
-    """Make sure libheyoka_amd.so exists (built in-tree, travels to the GPU box with the snapshot)."""
+    """Make sure libheyoka_amd.so exists (built in-tree, travels to the GPU box with the snapshot) and matches the sources:
+    the import of heyoka_amd refuses a library whose build id differs from the hash of heyoka_amd/csrc (a stale prebuilt
+    .so), in which case it is rebuilt here."""
     lib = os.path.join(ROOT, "heyoka_amd", "libheyoka_amd.so")
-    if not os.path.exists(lib):
-        import __graft_entry__
+    stale = False
+    if os.path.exists(lib):
+        try:
+            import heyoka_amd  # noqa: F401
+        except ImportError as e:
+            if "other sources" not in str(e):
+                raise
+            stale = True
+    if stale or not os.path.exists(lib):
+        import subprocess
 
-        __graft_entry__.build()
+        for m in [k for k in sys.modules if k == "heyoka_amd" or k.startswith("heyoka_amd.")]:
+            del sys.modules[m]
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "heyoka_amd", "csrc"), "-j8"])
 
 
 @pytest.fixture(scope="session")

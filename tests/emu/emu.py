@@ -110,7 +110,8 @@ class EmulatedKernel:
         threads = n * self.lanes_per_system
         return max(1, min((threads + self.block - 1) // self.block, max_grid))
 
-    def run(self, state, time_hi, time_lo, *, mode, lim=None, tfin=None, max_steps=0, pars=None, want_tc_rows=0, max_grid=2, pad=0):
+    def run(self, state, time_hi, time_lo, *, mode, lim=None, tfin=None, max_steps=0, pars=None, want_tc_rows=0, max_grid=2, pad=0,
+            scratch_per_wave=0):
         """One launch of hy_taylor. state: (n_eq, n) array, modified in place like the device buffer. Returns a dict of the
         per-system outputs."""
         n = state.shape[1]
@@ -144,6 +145,11 @@ class EmulatedKernel:
         if want_tc_rows:
             tc = np.zeros((want_tc_rows, n))
             a.tc = ptr(tc)
+        if scratch_per_wave:
+            # (Jet scratch of the steppers which keep the jets of the state variables in global memory: per resident wave.)
+            sc = np.zeros(self._grid(n, max_grid) * (self.block // 64) * int(scratch_per_wave))
+            keep.append(sc)
+            a.scratch = ptr(sc)
         a.N, a.max_steps, a.mode, a.pad = n, max_steps, mode, pad
         self.lib.emu_run(ctypes.byref(a), self._grid(n, max_grid), self.block)
         out.update(state=st, time_hi=thi, time_lo=tlo, outcome=outcome, n_steps=n_steps, counters=counters, tc=tc)

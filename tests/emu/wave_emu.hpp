@@ -185,30 +185,27 @@ inline unsigned readfirstlane(unsigned v)
     return static_cast<unsigned>(wave_exchange(v, [](unsigned) { return 0u; }));
 }
 
-inline int shfl(int v, int src)
+// Wave shuffles of any trivially copyable value of up to 8 bytes (int, unsigned long long, double).
+template <typename T, typename F>
+inline T shfl_any(T v, F src_of)
 {
-    return static_cast<int>(static_cast<std::uint32_t>(
-        wave_exchange(static_cast<std::uint32_t>(v), [src](unsigned) { return static_cast<unsigned>(src) & 63u; })));
-}
-
-inline double shfl(double v, int src)
-{
-    std::uint64_t bits;
-    std::memcpy(&bits, &v, 8);
-    bits = wave_exchange(bits, [src](unsigned) { return static_cast<unsigned>(src) & 63u; });
-    double r;
-    std::memcpy(&r, &bits, 8);
+    static_assert(sizeof(T) <= 8u, "wave_emu: shuffle of a value wider than 64 bits");
+    std::uint64_t bits = 0;
+    std::memcpy(&bits, &v, sizeof(T));
+    bits = wave_exchange(bits, src_of);
+    T r;
+    std::memcpy(&r, &bits, sizeof(T));
     return r;
 }
-
-inline double shfl_xor(double v, int m)
+template <typename T>
+inline T shfl(T v, int src)
 {
-    std::uint64_t bits;
-    std::memcpy(&bits, &v, 8);
-    bits = wave_exchange(bits, [m](unsigned lane) { return (lane ^ static_cast<unsigned>(m)) & 63u; });
-    double r;
-    std::memcpy(&r, &bits, 8);
-    return r;
+    return shfl_any(v, [src](unsigned) { return static_cast<unsigned>(src) & 63u; });
+}
+template <typename T>
+inline T shfl_xor(T v, int m)
+{
+    return shfl_any(v, [m](unsigned lane) { return (lane ^ static_cast<unsigned>(m)) & 63u; });
 }
 
 inline int bpermute(int byte_addr, int v)

@@ -295,3 +295,34 @@ def test_time_setters_follow_the_reference_checks_without_a_gpu():
     hi, lo = ta.dtime
     assert list(hi) == [4.0, 6.0] and list(lo) == [0.0, 0.0]
     assert not np.any(ta.tc)
+
+
+def test_stage_logger_levels_callback_and_build_id():
+    """The minimal stage logger (include/heyoka/logging.hpp:19-24): levels, a callback sink, and what a
+    construction logs - the size of the decomposition (debug), the planner's verdict with the reasons the other generators
+    did not apply (info), the stage times (trace) - plus the build id which ties the library to the sources of the tree."""
+    import heyoka_amd as hy
+    from heyoka_amd import _lib
+
+    assert hy.build_id() == _lib.tree_build_id() and len(hy.build_id()) == 16
+    msgs = []
+    hy.set_log_callback(lambda lvl, m: msgs.append((lvl, m)))
+    try:
+        old = _lib.lib.hy_get_logger_level()
+        assert old == 3  # warn, the reference's default
+        hy.set_logger_level_trace()
+        x, v = hy.make_vars("x", "v")
+        hy.taylor_adaptive_batch([(x, v), (v, -9.8 * hy.sin(x))], None, 8)
+        text = "\n".join(m for _, m in msgs)
+        assert "Taylor decomposition of 2 equations: 7 entries" in text
+        assert "Taylor decomposition construction runtime:" in text and "hiprtc compilation runtime:" in text
+        assert any(lvl == 2 and "Taylor batch code generation: unrolled" in m and "fewer than 2 clusters" in m for lvl, m in msgs)
+        del msgs[:]
+        hy.set_logger_level("err")
+        hy.taylor_adaptive_batch([(x, v), (v, -9.8 * hy.sin(x))], None, 8)
+        assert msgs == []
+        with pytest.raises(ValueError):
+            hy.set_logger_level(9)
+    finally:
+        hy.set_logger_level("warn")
+        hy.set_log_callback(None)

@@ -194,6 +194,18 @@ def test_bench_py_two_ranks_on_one_gpu_prints_the_contract_line():
     assert abs(per_step_total / (2 * d["config"]["system_steps_per_launch"]) - 1) < 0.05
     if d["config"]["untimed_final_state_all_gather_error"] is None:
         assert d["config"]["gathered_systems"] == 2 * n
+    # Round 6, first-contact fields: what every rank measured on its own clock and the device it bound, the size of the
+    # communicator as the backend reports it, the timeout which bounds every collective, and the build id of the library.
+    c = d["config"]
+    assert c["rccl_ranks_seen"] == 2 and c["collective_backend"] == "gloo" and c["collective_timeout_s"] > 0
+    assert len(c["per_rank_value"]) == 2 and all(v > 0 for v in c["per_rank_value"])
+    assert len(c["per_rank_kernel_ms"]) == 2 and all(v > 0 for v in c["per_rank_kernel_ms"])
+    assert abs(sum(c["per_rank_value"]) / d["value"] - 1) < 0.25  # (the aggregate uses the slowest rank's clock)
+    assert [r["ordinal"] for r in c["per_rank_device"]] == [0, 0]  # (--single-device: both ranks on GPU 0)
+    assert all(len(r["pci"].split(":")) == 3 for r in c["per_rank_device"])
+    import heyoka_amd as hy
+
+    assert c["library_build_id"] == hy.build_id() and len(c["library_build_id"]) == 16
 
 
 @pytest.mark.gpu
@@ -240,6 +252,8 @@ print("RCCL_ONE_RANK_OK")
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 1 and d["config"]["untimed_final_state_all_gather_error"] is None
     assert d["config"]["gathered_systems"] == 8192 and d["config"]["untimed_final_state_all_gather_ms"] is not None
+    assert d["config"]["rccl_ranks_seen"] == 1 and d["config"]["collective_backend"] == "nccl"
+    assert d["config"]["per_rank_device"][0]["ordinal"] == 0 and len(d["config"]["per_rank_value"]) == 1
 
 
 @pytest.mark.gpu

@@ -153,3 +153,53 @@ def test_emulated_v5_other_systems_single_step_vs_oracle(nb, masses):
     tc_o = ora.tc.reshape(6 * nb, ta.order + 1, n)
     scale = np.max(np.abs(tc_o), axis=2, keepdims=True) + 1e-300
     assert np.max(np.abs(r["tc"].reshape(tc_o.shape) - tc_o) / scale) <= 1e5 * EPS
+
+
+def test_emulated_multi_class_cluster_stepper_and_staged_table_stepper_vs_oracle():
+    """Round 6. (a) A system whose clusters come in two shapes - a chain of pendula with cubic bonds: 16 sin / cos pairs of
+    state variables, 15 cubes of differences - on the multi-class wave-cluster stepper (one section of code per class of
+    clusters): built without contraction it keeps the reference's operation order, the Taylor coefficients, the step size
+    and the state of one step are the default-mode oracle's BIT FOR BIT. (b) The staged table stepper (tape in LDS, lanes
+    over the nodes of a group) on the outer Solar System: with the strict order of the additions (kw::compact_mode) the
+    COMPACT-mode oracle's coefficients bit for bit, with the terms of the convolutions dealt to several lanes 1e5 eps; a
+    propagation through the device-side queue against the oracle."""
+    from heyoka_amd import mixed_models as mm
+
+    n, ns = 9, 16
+    st = mm.sine_lattice_state(ns, n)
+    ta = hy.taylor_adaptive_batch(mm.sine_lattice(hy, ns), None, 64)
+    assert "2 classes of clusters" in ta.hip_source_mode, ta.hip_source_mode
+    p = ta.order
+    k = emu.EmulatedKernel(ta.hip_source)
+    r = k.run(st, np.zeros(n), np.zeros(n), mode=0, lim=np.full(n, np.inf), want_tc_rows=2 * ns * (p + 1),
+              scratch_per_wave=(p + 1) * 4 * 64)
+    ora = ho.OracleIntegrator(mm.sine_lattice(ho, ns), st, n)
+    ora.step(wtc=True)
+    assert np.array_equal(r["last_h"], np.array([h for _, h in ora.step_res]))
+    assert np.array_equal(r["tc"].reshape(2 * ns, p + 1, n), ora.tc.reshape(2 * ns, p + 1, n))
+    assert np.array_equal(r["state"], ora.state.reshape(2 * ns, n))
+
+    n = 7
+    st = configs.outer_ss_state(n, perturb=1e-6, seed=5)
+    for compact in (True, False):
+        ta = hy.taylor_adaptive_batch(hy.model.nbody(6, masses=M, Gconst=G), None, 64, high_accuracy=True, compact_mode=compact,
+                                      emitter="table")
+        assert "table mode (staged)" in ta.hip_source_mode and ("strict order" in ta.hip_source_mode) == compact
+        k = emu.EmulatedKernel(ta.hip_source)
+        r = k.run(st, np.zeros(n), np.zeros(n), mode=0, lim=np.full(n, np.inf), want_tc_rows=36 * 21)
+        ora = ho.OracleIntegrator(ho.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True, compact_mode=True)
+        ora.step(wtc=True)
+        tc_o = ora.tc.reshape(36, 21, n)
+        if compact:
+            assert np.array_equal(r["tc"].reshape(tc_o.shape), tc_o)
+        else:
+            scale = np.max(np.abs(tc_o), axis=2, keepdims=True) + 1e-300
+            assert np.max(np.abs(r["tc"].reshape(tc_o.shape) - tc_o) / scale) <= 1e5 * EPS
+        tf = np.linspace(1.0, 3.0, n)
+        r = k.run(st, np.zeros(n), np.zeros(n), mode=1, tfin=tf, max_grid=2)
+        ora = ho.OracleIntegrator(ho.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True, compact_mode=True)
+        ora.propagate_until(tf)
+        assert np.array_equal(r["outcome"], np.array([int(q[0]) for q in ora.prop_res]))
+        assert np.array_equal(r["n_steps"].astype(np.int64), np.array([int(q[3]) for q in ora.prop_res]))
+        assert np.array_equal(r["time_hi"], tf)
+        assert rel_err(r["state"], ora.state.reshape(36, n)) <= 1e5 * EPS

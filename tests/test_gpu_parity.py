@@ -334,9 +334,10 @@ def test_raw_stepper_abi_step_e_d_out_f_and_caller_owned_tape(golden):
     against the oracle's hy_oracle_step_e (the reference's stepper with events, src/taylor_00.cpp:592-710), the state left
     untouched - for the unrolled stepper (pendulum with one terminal and one non-terminal event) and for the wave-cluster
     stepper which evaluates the event equations itself (outer Solar System). d_out_f_t: the dense output of the batch-mode
-    tutorial (doc/tut_batch_mode.rst golden values) and the compensated evaluation of the oracle. c_step_f_t: a
-    compact-mode stepper on a caller-owned tape of hy_tab_tape_size_align() bytes gives the results of the integrator's own
-    tape bit for bit."""
+    tutorial (doc/tut_batch_mode.rst golden values) and the compensated evaluation of the oracle. c_step_f_t / c_step_f_e_t:
+    the compact-mode steppers (without / with events) on a caller-owned tape of hy_tab_tape_size_align() bytes give the
+    results of the integrator's own tape bit for bit AND the compact-mode oracle's (hy_oracle_step_e for the stepper with
+    events) to the reference's tolerances."""
     import ctypes
 
     import torch
@@ -421,20 +422,27 @@ def test_raw_stepper_abi_step_e_d_out_f_and_caller_owned_tape(golden):
         exp = np.stack([ho.OracleEventIntegrator._dense(ora, i, hs[i]) for i in range(n)], axis=1)  # (the oracle's evaluation of its own coefficients)
         assert rel_err(d_out.cpu().numpy().reshape(12, n), exp) <= 4 * EPS
 
-    # ---- c_step_f_t: a compact-mode stepper (tape in HBM) on a caller-owned tape.
-    # (Small ensembles get the wave-level variant with its tape in LDS; HEYOKA_AMD_TABLE_LDS=0 is the developer switch for
-    # the lane-per-system variant at any size.)
+    # ---- c_step_f_t: the compact-mode stepper with its tape in HBM (kw::emitter = table; HEYOKA_AMD_TABLE_LDS=0 is the
+    # developer switch for the lane-per-system variant where the tape of a system would fit in LDS) on a CALLER-OWNED tape
+    # of hy_tab_tape_size_align() bytes: the results of the integrator's own tape bit for bit, and the COMPACT-MODE oracle
+    # (running sums inside the convolutions, src/math/prod.cpp:686-698) to the tolerances of the reference
+    # (test/two_body_batch.cpp:118-150: h 1e4 eps, coefficients 1e5 eps of the row maximum; the default build contracts
+    # multiply-adds, the strict build is bit-identical: test_compact_mode_has_the_arithmetic_of_the_reference_compact_mode).
     n = 4096
     st = configs.plummer_nbody_state(4, n, seed=5)
-    old_env = os.environ.get("HEYOKA_AMD_TABLE_LDS")
-    os.environ["HEYOKA_AMD_TABLE_LDS"] = "0"
-    try:
-        ta = hy.taylor_adaptive_batch(hy.model.nbody(4), st, n, compact_mode=True)
-    finally:
-        if old_env is None:
-            del os.environ["HEYOKA_AMD_TABLE_LDS"]
-        else:
-            os.environ["HEYOKA_AMD_TABLE_LDS"] = old_env
+
+    def hbm_table(**kw):
+        old_env = os.environ.get("HEYOKA_AMD_TABLE_LDS")
+        os.environ["HEYOKA_AMD_TABLE_LDS"] = "0"
+        try:
+            return hy.taylor_adaptive_batch(hy.model.nbody(4), st, n, compact_mode=True, emitter="table", **kw)
+        finally:
+            if old_env is None:
+                del os.environ["HEYOKA_AMD_TABLE_LDS"]
+            else:
+                os.environ["HEYOKA_AMD_TABLE_LDS"] = old_env
+
+    ta = hbm_table()
     assert "tape in HBM" in ta.hip_source_mode, ta.hip_source_mode
     size, align = ta.raw_tape_size_align(n)
     assert size > 0 and align >= 8
@@ -448,6 +456,49 @@ def test_raw_stepper_abi_step_e_d_out_f_and_caller_owned_tape(golden):
         res.append((d_state.cpu().numpy(), d_h.cpu().numpy(), d_tc.cpu().numpy()))
     for a_, b_ in zip(res[0], res[1]):
         assert np.array_equal(a_, b_)
+    oc = ho.OracleIntegrator(ho.nbody(4), st, n, compact_mode=True)
+    oc.step(wtc=True)
+    h_o = np.array([h for _, h in oc.step_res])
+    assert np.max(np.abs(res[1][1] - h_o) / np.abs(h_o)) <= 1e4 * EPS
+    tc_ref = oc.tc.reshape(24, ta.order + 1, n)
+    scale = np.max(np.abs(tc_ref), axis=2, keepdims=True) + 1e-300
+    assert np.max(np.abs(res[1][2].reshape(tc_ref.shape) - tc_ref) / scale) <= 1e5 * EPS
+    assert row_rel_err(res[1][0].reshape(24, n), oc.state.reshape(24, n)) <= 1e5 * EPS
+
+    # ---- c_step_f_e_t: the compact-mode stepper WITH EVENTS on a caller-owned tape (hy_tab_raw_step_e_tape(),
+    # include/heyoka/detail/ta_jit_data.hpp:40-43) against hy_oracle_step_e: jets of the state variables and of the event
+    # equations, step size, max |x_i|; the state stays untouched; identical to the integrator's own tape.
+    xa, xb = hy.make_vars("x_0", "x_1")
+    oa, ob = ho.var("x_0"), ho.var("x_1")
+    te = hbm_table(nt_events=[hy.nt_event(xa - xb, lambda *a: None)])
+    assert "tape in HBM" in te.hip_source_mode, te.hip_source_mode
+    ore = ho.OracleEventIntegrator(ho.nbody(4), st, n, nt_events=[ho.nt_event(oa - ob, lambda *a: None)])
+    p = te.order
+    h_o, tc_o, evtc_o, mas_o = oracle_step_e(ore, n)
+    size_e, align_e = te.raw_tape_size_align(n)
+    assert size_e > 0
+    tape_e = torch.empty(size_e // 8 + align_e // 8, device=dev, dtype=torch.float64)
+    tptr_e = (tape_e.data_ptr() + align_e - 1) // align_e * align_e
+    jets = []
+    for use_tape in (False, True):
+        d_state, d_time, d_h = dt(st), dt(np.zeros(n)), dt(np.full(n, np.inf))
+        d_jet = torch.zeros((24 + 1) * (p + 1) * n, device=dev, dtype=torch.float64)
+        d_mas = torch.zeros(n, device=dev, dtype=torch.float64)
+        te.raw_step_e(d_jet.data_ptr(), d_state.data_ptr(), 0, d_time.data_ptr(), d_h.data_ptr(), d_mas.data_ptr(), n,
+                      d_tape=tptr_e if use_tape else None)
+        assert np.array_equal(d_state.cpu().numpy(), st)
+        jets.append((d_jet.cpu().numpy(), d_h.cpu().numpy(), d_mas.cpu().numpy()))
+    for a_, b_ in zip(jets[0], jets[1]):
+        assert np.array_equal(a_, b_)
+    jet, h_g, mas_g = jets[1]
+    assert np.max(np.abs(h_g - h_o) / np.abs(h_o)) <= 1e4 * EPS
+    assert np.array_equal(mas_g, mas_o)
+    tc_ref = tc_o.reshape(24, p + 1, n)
+    scale = np.max(np.abs(tc_ref), axis=2, keepdims=True) + 1e-300
+    assert np.max(np.abs(jet[: 24 * (p + 1) * n].reshape(24, p + 1, n) - tc_ref) / scale) <= 1e5 * EPS
+    ev_ref = evtc_o.reshape(1, p + 1, n)
+    scale = np.max(np.abs(ev_ref), axis=2, keepdims=True) + 1e-300
+    assert np.max(np.abs(jet[24 * (p + 1) * n:].reshape(1, p + 1, n) - ev_ref) / scale) <= 1e5 * EPS
     # (A stepper which keeps its coefficients on chip needs no tape.)
     assert hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), None, 64).raw_tape_size_align(64)[0] == 0
 

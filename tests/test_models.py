@@ -697,3 +697,85 @@ def test_linearised_accelerations_of_the_internal_program(case, monkeypatch):
     # (Re-associated sums: default masses differ in the last bits; with repeated masses only the reactions moved - same bits.)
     if case == "repeated_masses_6":
         assert np.array_equal(tc_p, tc_r)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Mixed models (round 6): nonlinear sub-DAGs of SEVERAL shapes in one system. The planner groups the clusters into
+# classes of identical shape and dependency level and runs every class as its own section of straight-line code, cluster i
+# of a class on lane i of the system's lane group (heyoka_amd/csrc/hip_emit_cluster.cpp, cluster_class); what does not fit
+# the register file goes to the staged table stepper (tape in LDS, hip_emit_staged.cpp). The reference runs any
+# decomposition through its segment / block tables at full SIMD rate (src/taylor_02.cpp:105-207, :983-1189).
+# ------------------------------------------------------------------------------------------------------------------
+from heyoka_amd import mixed_models as mm  # noqa: E402
+
+
+def _mixed_cases():
+    from heyoka_amd import configs
+
+    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    cen, ch = mm.lattice_centres_setup()
+    return {
+        # name: (system builder over an expression module, state builder, horizon, expected stepper)
+        "sine_lattice16": (lambda m: mm.sine_lattice(m, 16), lambda n: mm.sine_lattice_state(16, n), 6.0, "classes of clusters"),
+        "lattice_centres12": (lambda m: mm.lattice_centres(m, cen, ch), mm.lattice_centres_state, 6.0, "classes of clusters"),
+        # (17 histories per lane: beyond the register file - the staged table stepper.)
+        "nbody6_j2": (lambda m: mm.nbody_j2(m, 6, M, G, 1e-7), lambda n: configs.outer_ss_state(n, perturb=1e-6, seed=3), 15.0,
+                      "table mode (staged)"),
+    }
+
+
+@pytest.mark.parametrize("name", sorted(_mixed_cases()))
+def test_mixed_models_decomposition_and_planner(name, monkeypatch):
+    """Decomposition identical to the oracle's, and the stepper the planner picks: the multi-class wave-cluster stepper where
+    the histories of one cluster of every class fit the register file of a lane, the staged table stepper otherwise (and
+    with HEYOKA_AMD_MULTI_CLASS=0)."""
+    build, _, _, expect = _mixed_cases()[name]
+    sg = build(hy)
+    assert hy.taylor_decompose_sys(sg) == ho.dc_to_strings(ho.taylor_decompose_sys(build(ho)))
+    mode = hy.taylor_adaptive_batch(sg, None, 1 << 18).hip_source_mode
+    assert expect in mode, mode
+    if expect == "classes of clusters":
+        assert mode.startswith("cluster")
+        monkeypatch.setenv("HEYOKA_AMD_MULTI_CLASS", "0")
+        assert "table mode (staged)" in hy.taylor_adaptive_batch(sg, None, 1 << 18).hip_source_mode
+    else:
+        assert "multi-class plan: the jets of the cluster classes do not fit in the register file" in mode
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(_mixed_cases()))
+@pytest.mark.parametrize("contract", [True, False])
+def test_mixed_models_step_and_propagate_vs_oracle(name, contract, monkeypatch):
+    """One full-order step (h, Taylor coefficients, state) and a propagation of the mixed models against the oracle, at the
+    tolerances of test_models_step_and_propagate_vs_oracle (default build: h 1e6 eps, coefficients 1e6 eps of the row
+    maximum, states 1e5 eps of the row maximum after one step and 1e7 eps after the propagation; without FMA contraction
+    the reference's own tolerances, test/two_body_batch.cpp:118-150)."""
+    build, state, T, expect = _mixed_cases()[name]
+    n = 48
+    st = state(n)
+    if not contract:
+        monkeypatch.setenv("HEYOKA_AMD_HIPRTC_FLAGS", "-ffp-contract=off")
+    h_tol, tc_tol = (1e6, 1e6) if contract else (1e4, 1e5)
+    ta = hy.taylor_adaptive_batch(build(hy), st, n)
+    assert expect in ta.hip_source_mode, ta.hip_source_mode
+    oi = ho.OracleIntegrator(build(ho), st, n)
+    n_eq = st.shape[0]
+    ta.step(write_tc=True)
+    oi.step(wtc=True)
+    h_g = np.array([h for _, h in ta.step_res])
+    h_o = np.array([h for _, h in oi.step_res])
+    assert all(o == hy.taylor_outcome.success for o, _ in ta.step_res)
+    assert np.max(np.abs(h_g - h_o) / np.abs(h_o)) <= h_tol * EPS
+    tc_o = oi.tc.reshape(n_eq, oi.order + 1, n)
+    scale = np.max(np.abs(tc_o), axis=2, keepdims=True) + 1e-300
+    assert np.max(np.abs(np.asarray(ta.tc).reshape(n_eq, oi.order + 1, n) - tc_o) / scale) <= tc_tol * EPS
+
+    def row_err(a, b):
+        return np.max(np.max(np.abs(a - b), axis=1) / (np.max(np.abs(b), axis=1) + 1e-300))
+
+    assert row_err(np.asarray(ta.state), oi.state.reshape(n_eq, n)) <= 1e5 * EPS
+    ta.propagate_until(T)
+    oi.propagate_until(T)
+    assert all(r[0] == hy.taylor_outcome.time_limit for r in ta.propagate_res)
+    assert max(abs(a[3] - b[3]) for a, b in zip(ta.propagate_res, oi.prop_res)) <= 1
+    assert row_err(np.asarray(ta.state), oi.state.reshape(n_eq, n)) <= 1e7 * EPS
