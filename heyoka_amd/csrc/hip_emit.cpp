@@ -67,6 +67,8 @@ struct hy_kargs {
     double *ev_tc;
     double *max_abs_state;
     double *sel_norms;
+    const double *tc_thr;
+    double *grid_done;
 };
 
 #define HY_OC_SUCCESS (-4294967296LL - 1)

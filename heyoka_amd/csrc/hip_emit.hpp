@@ -53,6 +53,14 @@ struct hy_kargs {
     // (With the event equations inside the stepper the first N entries carry its verdict per system for the detection
     // kernel instead: 0.0 = no event possible in this step.)
     double *sel_norms;
+    // Taylor coefficients on demand (hy_kargs::pad bit 2, emitted_module::tc_by_threshold / grid_multi_step): a time per
+    // system - the next grid point of propagate_grid() -; a step stores its coefficients only if it reaches that time, and in
+    // propagate mode (mode 1) the system leaves the step loop after that step: one launch takes every system from one grid
+    // point to the next instead of one step further.
+    const double *tc_thr;
+    // ... and, out, per system: 1.0 if its last step was clamped to the remaining time (h == rem.hi: the system has reached
+    // its final time - the post-step kernel of propagate_grid() then treats it as done), 0.0 otherwise.
+    double *grid_done;
 };
 
 enum class emit_mode { unrolled, cluster, table, block };
@@ -158,6 +166,8 @@ struct emitted_module {
     // propagate_grid() passes the next grid time of every system: 6 GB of coefficients per sweep of 1 048 576 outer Solar
     // Systems otherwise, for dense output which a handful of steps need.
     bool tc_by_threshold = false;
+    // Propagate-mode launches (mode 1) understand hy_kargs::pad bit 2 as well: see hy_kargs::tc_thr.
+    bool grid_multi_step = false;
     // When the code was generated from a rewritten INTERNAL program (state-variable aliases, padded clusters, restored unit
     // scalings - the user-visible decomposition is never touched): its text, one node per line in the format of the
     // decomposition strings, then the definitions of the state derivatives. Lets the tests run the oracle's interpreter

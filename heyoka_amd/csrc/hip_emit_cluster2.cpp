@@ -2349,6 +2349,9 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
     // (The stepper with events is a specialisation of its own and always runs in mode 4: a compile-time constant there - the
     // bookkeeping of the propagation mode, ~900 instructions per group of systems around a single step, is not generated.)
     src << "#define HY_MODE " << (m4 ? "4" : "a.mode") << "\n";
+    // (Propagation from grid point to grid point: see hy_kargs::tc_thr.)
+    src << "#define HY_GRID_STOP " << ((one_lane && jet_lds && !m4) ? "((HY_MODE == 1) & ((a.pad & 4) != 0) & hy_reach)" : "false") << "\n";
+    src << "#define HY_GRID_FLAGS " << ((one_lane && jet_lds && !m4) ? "((HY_MODE == 1) & ((a.pad & 4) != 0))" : "false") << "\n";
     // (The stepper with events always uses the static schedule: its cooperative store has workgroup barriers.)
     src << "#define HY_NO_STATIC 0\n";
     src << prelude;
@@ -2896,6 +2899,7 @@ tfin.hi = 0.0; tfin.lo = 0.0; rem.hi = 0.0; rem.lo = 0.0;
 bool t_dir = true;
 double mdt = __builtin_inf();
 double step_lim = 0.0;
+double thr = 0.0;
 if (HY_MODE == 1) {
     tfin.hi = (a.tfin_hi != nullptr) ? a.tfin_hi[s] : a.tfin_s_hi;
     tfin.lo = (a.tfin_hi != nullptr) ? a.tfin_lo[s] : a.tfin_s_lo;
@@ -2903,12 +2907,15 @@ if (HY_MODE == 1) {
     rem = hy_df_sub(tfin, tcur);
     t_dir = (rem.hi > 0.0) || (rem.hi == 0.0 && rem.lo >= 0.0);
     if (a.lim != nullptr) mdt = a.lim[s];
+    // (Propagation from grid point to grid point - hy_kargs::pad bit 2 in mode 1, emitted_module::grid_multi_step: the
+    // system leaves the step loop after the first step which reaches a.tc_thr[s], with the coefficients of that step stored.)
+    if ((a.pad & 4) != 0) thr = a.tc_thr[s];
 } else {
     step_lim = a.lim[s];
     // (Taylor coefficients of a lock-step sweep on demand - hy_kargs::pad bit 2, the loop of propagate_grid() without a
-    // callback: a.tfin_hi holds the NEXT GRID TIME of every system, and only the steps which reach it store their
-    // coefficients - see emitted_module::tc_by_threshold.)
-    if ((a.pad & 4) != 0) tfin.hi = a.tfin_hi[s];
+    // callback: the NEXT GRID TIME of every system - a.tc_thr, or a.tfin_hi for callers of before round 6 -, and only the
+    // steps which reach it store their coefficients - see emitted_module::tc_by_threshold.)
+    if ((a.pad & 4) != 0) thr = (a.tc_thr != nullptr) ? a.tc_thr[s] : a.tfin_hi[s];
 }
 u64 n_steps = 0, iter = 0;
 double min_h = __builtin_inf(), max_h = 0.0, last_h = 0.0;
@@ -2920,6 +2927,8 @@ i64 outcome = HY_OC_SUCCESS;
 // hundred live registers of the remaining ones, which is where this toolchain's live-range splitting goes
 // wrong (DESIGN.md, toolchain notes).
 bool fin = false;
+// (Did the system leave the step loop through a step clamped to its remaining time? hy_kargs::grid_done.)
+bool gfin = false;
 int nf_seen = 0;
 // (Stepper with events which evaluates the event equations itself: does this system need its Taylor coefficients in
 // memory? See "On-demand Taylor coefficients" below. hy_kargs::pad: bit 0 = store them for every system, bit 1 = store
@@ -2933,14 +2942,14 @@ const bool hy_tc_only = HY_M4 && ((a.pad & 2) != 0);
     // allocator, whose reloads are scattered over the tail and each wait for a round trip through the vector memory
     // path. Every lane of a system holds the same values and stores them to the same address.
     const bool bk_lds = one_lane;
-    const char *bk_fields_d[] = {"t_hi", "t_lo", "tfin.hi", "tfin.lo", "rem.hi", "rem.lo", "mdt", "step_lim", "min_h", "max_h", "last_h"};
+    const char *bk_fields_d[] = {"t_hi", "t_lo", "tfin.hi", "tfin.lo", "rem.hi", "rem.lo", "mdt", "step_lim", "min_h", "max_h", "last_h", "thr"};
     // (which = 0: every field; 1: the fields a step changes; 2: the others - final time and limits, which only change when a
     // system is picked up: an LDS store is the most expensive instruction of the kernel.)
     const auto bk_store = [&](int which = 0) {
         std::uint32_t f = 0;
         for (const auto *nm : bk_fields_d) {
             const std::string n_ = nm;
-            const bool constant = n_ == "tfin.hi" || n_ == "tfin.lo" || n_ == "mdt" || n_ == "step_lim";
+            const bool constant = n_ == "tfin.hi" || n_ == "tfin.lo" || n_ == "mdt" || n_ == "step_lim" || n_ == "thr";
             if (which == 0 || (which == 1) != constant) {
                 src << "bk[" << f << "] = " << nm << ";\n";
             }
@@ -2952,7 +2961,7 @@ const bool hy_tc_only = HY_M4 && ((a.pad & 2) != 0);
         src << "bk[" << f++ << "] = __longlong_as_double((long long)n_steps);\n";
         src << "bk[" << f++ << "] = __longlong_as_double((long long)iter);\n";
         src << "bk[" << f++ << "] = __longlong_as_double((long long)outcome);\n";
-        src << "bk[" << f++ << "] = __longlong_as_double((long long)((t_dir ? 1 : 0) | (nf_seen != 0 ? 2 : 0)));\n";
+        src << "bk[" << f++ << "] = __longlong_as_double((long long)((t_dir ? 1 : 0) | (nf_seen != 0 ? 2 : 0) | (gfin ? 4 : 0)));\n";
     };
     const auto bk_load = [&]() {
         std::uint32_t f = 0;
@@ -2962,7 +2971,7 @@ const bool hy_tc_only = HY_M4 && ((a.pad & 2) != 0);
         src << "n_steps = (u64)__double_as_longlong(bk[" << f++ << "]);\n";
         src << "iter = (u64)__double_as_longlong(bk[" << f++ << "]);\n";
         src << "outcome = (i64)__double_as_longlong(bk[" << f++ << "]);\n";
-        src << "{\nconst long long fl = __double_as_longlong(bk[" << f++ << "]);\nt_dir = (fl & 1) != 0;\nnf_seen = (fl & 2) != 0 ? 1 : 0;\n}\n";
+        src << "{\nconst long long fl = __double_as_longlong(bk[" << f++ << "]);\nt_dir = (fl & 1) != 0;\nnf_seen = (fl & 2) != 0 ? 1 : 0;\ngfin = (fl & 4) != 0;\n}\n";
     };
     if (bk_lds) {
         bk_store();
@@ -3390,7 +3399,11 @@ int nfi = !(hy_finite(nt_hi) && hy_finite(nt_lo)) ? 1 : 0;
         // land on either side of the last grid time (grids ending at 0, crossing 0, backward runs to 0) while hy_grid_post
         // (h == rem.hi) evaluates every remaining grid point from these coefficients. (Steps clamped by max_delta_t store
         // needlessly: harmless.)
-        src << "const bool tc_sys = ((a.pad & 4) == 0) | (h == 0.0) | (h == lim) | ((h > 0.0) ? (nt_hi >= tfin.hi) : (nt_hi <= tfin.hi));\n";
+        src << "const bool hy_reach = (h > 0.0) ? (nt_hi >= thr) : (nt_hi <= thr);\n";
+        // (fin: a system which left the step loop in an EARLIER iteration idles with zero-length steps until its wavefront is
+        // done or its slot is refilled - in a launch from grid point to grid point those must not overwrite the coefficients
+        // of its exit step.)
+        src << "const bool tc_sys = ((a.pad & 4) == 0) | (!fin & ((h == 0.0) | (h == lim) | hy_reach));\n";
         src << "if (a.tc != nullptr && tc_sys) {\n";
     } else {
         src << (jet_lds ? "if (a.tc != nullptr && !HY_M4) {\n" : "if (a.tc != nullptr) {\n");
@@ -3433,6 +3446,8 @@ int nfi = !(hy_finite(nt_hi) && hy_finite(nt_lo)) ? 1 : 0;
     const double mn_new = upd ? hy_min(min_h, ah) : min_h;
     const double mx_new = upd ? hy_max(max_h, ah) : max_h;
     done |= (h == rem.hi);
+    gfin = fin ? gfin : (h == rem.hi);
+    done |= HY_GRID_STOP;
     hy_df tnew; tnew.hi = nt_hi; tnew.lo = nt_lo;
     const hy_df rem_new = hy_df_sub(tfin, tnew);
     const u64 it_new = iter + 1u;
@@ -3484,6 +3499,7 @@ if (fin && l == 0u && live) {
     a.min_h[s] = min_h;
     a.max_h[s] = max_h;
     a.n_steps[s] = n_steps;
+    if (HY_GRID_FLAGS) a.grid_done[s] = gfin ? 1.0 : 0.0;
     if (nf_seen != 0) atomicAdd(a.counters, 1u);
 }
 // 2. The next system of the queue, for every finished system of the wavefront (its lane 0 asks, the others listen).
@@ -3520,6 +3536,7 @@ if (got) {
     rem = hy_df_sub(tfin, tcur);
     t_dir = (rem.hi > 0.0) || (rem.hi == 0.0 && rem.lo >= 0.0);
     mdt = (a.lim != nullptr) ? a.lim[s] : __builtin_inf();
+    thr = ((a.pad & 4) != 0) ? a.tc_thr[s] : 0.0;
     n_steps = 0;
     iter = 0;
     min_h = __builtin_inf();
@@ -3527,6 +3544,7 @@ if (got) {
     last_h = 0.0;
     outcome = HY_OC_SUCCESS;
     fin = false;
+    gfin = false;
 }
 HY_WSYNC();
 )HIP";
@@ -3598,6 +3616,7 @@ if (l == 0u && live && !hy_tc_only) {
         a.min_h[s] = min_h;
         a.max_h[s] = max_h;
         a.n_steps[s] = n_steps;
+        if (HY_GRID_FLAGS) a.grid_done[s] = gfin ? 1.0 : 0.0;
     }
 }
 }
@@ -3631,6 +3650,7 @@ if (l == 0u && live && !hy_tc_only) {
     ret.events_in_stepper = ev_inline;
     ret.compact_tc = compact_tc;
     ret.tc_by_threshold = one_lane && jet_lds && !m4;
+    ret.grid_multi_step = ret.tc_by_threshold;
     one_lane_jets_in_lds = one_lane && jet_lds;
     ret.notes = std::string(one_lane ? "cluster mode v5 (one lane per pair, 2 wavefronts per SIMD): "
                                      : (pair_split ? "cluster mode v3 (lane pairs, 2 wavefronts per SIMD): " : "cluster mode v2 (pipelined): "))

@@ -58,6 +58,13 @@ struct grid_kargs {
     unsigned n_grid;
     // (Next grid time of every lane, +-inf once the lane is through its grid: hy_kargs::pad bit 2 of the next sweep.)
     double *next_tg;
+    // Launches which take every lane from one grid point to the next (emitted_module::grid_multi_step): the stepper leaves
+    // the counters / extrema of ITS launch in n_steps / min_h / max_h, which are accumulated here (null: single-step sweeps).
+    unsigned long long *acc_n_steps;
+    double *acc_min_h;
+    double *acc_max_h;
+    // (... and whether the lane's last step was clamped to its remaining time: hy_kargs::grid_done.)
+    const double *grid_done;
 };
 
 // Code generator from the configuration field (0 automatic: the wave-cluster generator is tried first and falls back
@@ -2121,7 +2128,7 @@ void tab_core::propagate_until(const std::vector<double> &ts_, std::size_t max_s
                                d.d_tlo.as<double>(), d.d_lasth.as<double>(), d.d_outcome.as<long long>(),
                                b_rem_hi.as<double>(), b_rem_lo.as<double>(), b_mdt.as<double>(), b_tdir.as<int>(),
                                d.d_lim.as<double>(), nullptr, d.d_minh.as<double>(), d.d_maxh.as<double>(),
-                               d.d_nsteps.as<unsigned long long>(), b_cnt.as<unsigned>(), N, 0u, nullptr};
+                               d.d_nsteps.as<unsigned long long>(), b_cnt.as<unsigned>(), N, 0u, nullptr, nullptr, nullptr, nullptr, nullptr};
             d.grid_mod->launch("hy_until_post", N, 256, &a, sizeof(a), d.stream);
             unsigned cnt[3] = {0, 0, 0};
             b_cnt.download(cnt, sizeof(cnt), d.stream);
@@ -2211,6 +2218,10 @@ struct hy_grid_args {
     u64 N;
     unsigned n_grid;
     double *next_tg;
+    u64 *acc_n_steps;
+    double *acc_min_h;
+    double *acc_max_h;
+    const double *grid_done;
 };
 
 // Post-step kernel of the device-driven propagate_until() lock-step loop (callbacks / continuous output): the
@@ -2273,18 +2284,28 @@ extern "C" __global__ void __launch_bounds__(256) hy_grid_post(const hy_grid_arg
         hy_count(a.counters + 1, true);
         return;
     }
-    a.n_steps[i] += (h != 0.0) ? 1u : 0u;
-    if (oc == HY_OC_SUCCESS) {
-        const double ah = fabs(h);
-        a.min_h[i] = hy_min(a.min_h[i], ah);
-        a.max_h[i] = hy_max(a.max_h[i], ah);
+    if (a.acc_n_steps != nullptr) {
+        // (A launch of several steps per lane: its own counters and extrema.)
+        a.acc_n_steps[i] += a.n_steps[i];
+        a.acc_min_h[i] = hy_min(a.acc_min_h[i], a.min_h[i]);
+        a.acc_max_h[i] = hy_max(a.acc_max_h[i], a.max_h[i]);
+    } else {
+        a.n_steps[i] += (h != 0.0) ? 1u : 0u;
+        if (oc == HY_OC_SUCCESS) {
+            const double ah = fabs(h);
+            a.min_h[i] = hy_min(a.min_h[i], ah);
+            a.max_h[i] = hy_max(a.max_h[i], ah);
+        }
     }
     // Stopping terminal event: outcome -index - 1 (:1903-1908).
     hy_count(a.counters + 2, oc > HY_OC_SUCCESS && oc < 0);
     hy_df tcur; tcur.hi = a.thi[i]; tcur.lo = a.tlo[i];
     hy_df rem; rem.hi = a.rem_hi[i]; rem.lo = a.rem_lo[i];
     const unsigned ng = a.n_grid;
-    if (h == rem.hi) {
+    // (A launch of several steps per lane: the stored remaining time is the one before its FIRST step - the stepper says
+    // whether its last step was the one clamped to the remaining time.)
+    const bool clamped_to_rem = (a.grid_done != nullptr) ? (a.grid_done[i] != 0.0) : (h == rem.hi);
+    if (clamped_to_rem) {
         rem.hi = 0.0; rem.lo = 0.0;
     } else {
         hy_df tl; tl.hi = a.grid[(u64)(ng - 1u) * N + i]; tl.lo = 0.0;
@@ -2405,6 +2426,26 @@ void tab_core::propagate_grid_device_loop(const std::vector<double> &grid, std::
     // which can tell (emitted_module::tc_by_threshold) stores the coefficients of those steps only - unless a step callback
     // may look at them, or the stepper with events is in charge (its own on-demand logic is switched off below).
     const bool tc_on_demand = !cb && !d.has_events() && d.emitted.tc_by_threshold && n_grid > 1u;
+    // From grid point to grid point in ONE launch per lane (emitted_module::grid_multi_step, hy_kargs::tc_thr): without a
+    // callback and without events nothing happens on the host between two sweeps, and the lanes are independent - every lane
+    // runs its own steps inside a propagate-mode launch until the step which reaches its next grid time, whose coefficients
+    // it stores; hy_grid_post then evaluates the dense output of that step. A launch per grid interval instead of a launch
+    // per step: the lock-step loop was at 0.7 of the rate of the propagation loop (ramp-up / drain and clock of 2-ms
+    // launches). max_steps counts lock-step iterations of the batch: with a step limit the single-step sweeps stay.
+    const bool multi_step = tc_on_demand && d.emitted.grid_multi_step && max_steps == 0u && d.batch_semantics != 1;
+    device_buffer b_acc_ns(multi_step ? N * sizeof(unsigned long long) : 0u, d.device), b_acc_min(multi_step ? N * dsz : 0u, d.device),
+        b_acc_max(multi_step ? N * dsz : 0u, d.device), b_grid_done(multi_step ? N * dsz : 0u, d.device);
+    if (multi_step) {
+        std::vector<double> tl(N), zero(N, 0.);
+        for (std::uint32_t i = 0; i < N; ++i) {
+            tl[i] = grid[static_cast<std::size_t>(n_grid - 1u) * N + i];
+        }
+        d.d_tfhi.upload(tl.data(), N * dsz, d.stream);
+        d.d_tflo.upload(zero.data(), N * dsz, d.stream);
+        b_acc_ns.upload(ns.data(), N * sizeof(unsigned long long), d.stream);
+        b_acc_min.upload(mn.data(), N * dsz, d.stream);
+        b_acc_max.upload(mx.data(), N * dsz, d.stream);
+    }
     device_buffer b_next_tg(tc_on_demand ? N * dsz : 0u, d.device);
     if (tc_on_demand) {
         std::vector<double> tg(N);
@@ -2439,6 +2480,22 @@ void tab_core::propagate_grid_device_loop(const std::vector<double> &grid, std::
         }
         if (d.has_events()) {
             d.step_with_events_device(nullptr);
+        } else if (multi_step) {
+            d.before_kernel();
+            d.d_counters.zero(d.stream);
+            auto ka = d.base_args();
+            ka.tfin_hi = d.d_tfhi.as<double>();
+            ka.tfin_lo = d.d_tflo.as<double>();
+            ka.lim = b_mdt.as<double>();
+            ka.tc = d.d_tc.as<double>();
+            ka.tc_thr = b_next_tg.as<double>();
+            ka.grid_done = b_grid_done.as<double>();
+            ka.mode = 1;
+            ka.pad = 4;
+            ka.max_steps = 0;
+            d.dmod->launch_taylor(ka);
+            d.after_kernel(true);
+            d.step_res_dev_newer = true;
         } else {
             d.run_step_impl(nullptr, true);
         }
@@ -2450,7 +2507,9 @@ void tab_core::propagate_grid_device_loop(const std::vector<double> &grid, std::
                            b_rem_hi.as<double>(),  b_rem_lo.as<double>(),  b_mdt.as<double>(),    b_tdir.as<int>(),
                            d.d_lim.as<double>(),   b_gidx.as<unsigned>(),  d.d_minh.as<double>(), d.d_maxh.as<double>(),
                            d.d_nsteps.as<unsigned long long>(), b_cnt.as<unsigned>(), N, n_grid,
-                           tc_on_demand ? b_next_tg.as<double>() : nullptr};
+                           tc_on_demand ? b_next_tg.as<double>() : nullptr,
+                           multi_step ? b_acc_ns.as<unsigned long long>() : nullptr, multi_step ? b_acc_min.as<double>() : nullptr,
+                           multi_step ? b_acc_max.as<double>() : nullptr, multi_step ? b_grid_done.as<double>() : nullptr};
         d.grid_mod->launch("hy_grid_post", N, 256, &a, sizeof(a), d.stream);
         unsigned cnt[3] = {0, 0, 0};
         b_cnt.download(cnt, sizeof(cnt), d.stream);
@@ -2486,6 +2545,12 @@ void tab_core::propagate_grid_device_loop(const std::vector<double> &grid, std::
             d.prop_res_override = taylor_outcome::step_limit;
             break;
         }
+    }
+    if (multi_step && any_step) {
+        // (The accumulated counters / extrema take the place of the last launch's own.)
+        device_copy(d.d_nsteps.get(), b_acc_ns.get(), N * sizeof(unsigned long long), d.device, d.stream);
+        device_copy(d.d_minh.get(), b_acc_min.get(), N * dsz, d.device, d.stream);
+        device_copy(d.d_maxh.get(), b_acc_max.get(), N * dsz, d.device, d.stream);
     }
     if (any_step) {
         // Outcomes of the last sweep + the accumulated statistics live on the device.

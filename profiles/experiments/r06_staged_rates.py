@@ -78,3 +78,21 @@ st1 = np.ascontiguousarray(st1 - 0.0)
 leg("np1body6 default", np1_g, np1_o, st1, 20.0, {})
 leg("np1body6 table staged", np1_g, np1_o, st1, 5.0, {"HEYOKA_AMD_EMIT_MODE": "table"})
 leg("np1body6 table HBM tape", np1_g, np1_o, st1, 5.0, {"HEYOKA_AMD_EMIT_MODE": "table", "HEYOKA_AMD_TABLE_LDS": "0"}, reps=1)
+
+# Mixed models: the multi-class wave-cluster stepper against the two table steppers on the same system.
+from heyoka_amd import mixed_models as mm
+
+sl_g, sl_o = mm.sine_lattice(hy, 16), mm.sine_lattice(ho, 16)
+st2 = mm.sine_lattice_state(16, N, seed=42)
+leg("sine_lattice16 multi-class", sl_g, sl_o, st2, 2.0, {})
+leg("sine_lattice16 table staged", sl_g, sl_o, st2, 1.0, {"HEYOKA_AMD_MULTI_CLASS": "0"})
+leg("sine_lattice16 table HBM", sl_g, sl_o, st2, 1.0, {"HEYOKA_AMD_MULTI_CLASS": "0", "HEYOKA_AMD_TABLE_LDS": "0"}, reps=1)
+cen, ch = mm.lattice_centres_setup()
+lc_g, lc_o = mm.lattice_centres(hy, cen, ch), mm.lattice_centres(ho, cen, ch)
+st3 = mm.lattice_centres_state(N, seed=42)
+leg("lattice_centres12 multi-class", lc_g, lc_o, st3, 2.0, {})
+leg("lattice_centres12 table staged", lc_g, lc_o, st3, 1.0, {"HEYOKA_AMD_MULTI_CLASS": "0"})
+leg("lattice_centres12 table HBM", lc_g, lc_o, st3, 1.0, {"HEYOKA_AMD_MULTI_CLASS": "0", "HEYOKA_AMD_TABLE_LDS": "0"}, reps=1)
+j2_g, j2_o = mm.nbody_j2(hy, 6, M, G, 1e-7), mm.nbody_j2(ho, 6, M, G, 1e-7)
+leg("nbody6_j2 table staged", j2_g, j2_o, st, 5.0, {})
+leg("nbody6_j2 table HBM", j2_g, j2_o, st, 5.0, {"HEYOKA_AMD_TABLE_LDS": "0"}, reps=1)

@@ -21,7 +21,7 @@ class KArgs(ctypes.Structure):
         ("tc", ctypes.c_void_p), ("N", ctypes.c_uint64), ("max_steps", ctypes.c_uint64), ("mode", ctypes.c_int),
         ("pad", ctypes.c_int), ("counters", ctypes.c_void_p), ("scratch", ctypes.c_void_p), ("tfin_s_hi", ctypes.c_double),
         ("tfin_s_lo", ctypes.c_double), ("ev_tc", ctypes.c_void_p), ("max_abs_state", ctypes.c_void_p),
-        ("sel_norms", ctypes.c_void_p),
+        ("sel_norms", ctypes.c_void_p), ("tc_thr", ctypes.c_void_p), ("grid_done", ctypes.c_void_p),
     ]
 
 
@@ -111,7 +111,7 @@ class EmulatedKernel:
         return max(1, min((threads + self.block - 1) // self.block, max_grid))
 
     def run(self, state, time_hi, time_lo, *, mode, lim=None, tfin=None, max_steps=0, pars=None, want_tc_rows=0, max_grid=2, pad=0,
-            scratch_per_wave=0):
+            scratch_per_wave=0, tc_thr=None):
         """One launch of hy_taylor. state: (n_eq, n) array, modified in place like the device buffer. Returns a dict of the
         per-system outputs."""
         n = state.shape[1]
@@ -145,6 +145,11 @@ class EmulatedKernel:
         if want_tc_rows:
             tc = np.zeros((want_tc_rows, n))
             a.tc = ptr(tc)
+        if tc_thr is not None:
+            th = f8(np.broadcast_to(tc_thr, (n,))).copy()
+            out["grid_done"] = np.full(n, -1.0)
+            keep.append(th)
+            a.tc_thr, a.grid_done = ptr(th), ptr(out["grid_done"])
         if scratch_per_wave:
             # (Jet scratch of the steppers which keep the jets of the state variables in global memory: per resident wave.)
             sc = np.zeros(self._grid(n, max_grid) * (self.block // 64) * int(scratch_per_wave))

@@ -203,3 +203,39 @@ def test_emulated_multi_class_cluster_stepper_and_staged_table_stepper_vs_oracle
         assert np.array_equal(r["n_steps"].astype(np.int64), np.array([int(q[3]) for q in ora.prop_res]))
         assert np.array_equal(r["time_hi"], tf)
         assert rel_err(r["state"], ora.state.reshape(36, n)) <= 1e5 * EPS
+
+
+def test_emulated_v5_propagation_from_grid_point_to_grid_point():
+    """Round 6: propagate-mode launches with hy_kargs::pad bit 2 (emitted_module::grid_multi_step) - the lock-step loop of
+    propagate_grid() without a callback takes every system from one grid point to the next in ONE launch: the system leaves
+    the step loop after the first step which reaches a.tc_thr[s] (not clamped there: only the last grid time a.tfin clamps),
+    with the Taylor coefficients of THAT step stored. Checked: the exit step brackets the threshold, counters and outcomes,
+    and the dense output of the stored coefficients at the threshold against the oracle propagated to that time; through the
+    retire / refill path of the work queue (37 systems on one workgroup) with per-system thresholds."""
+    n = 37
+    rng = np.random.RandomState(11)
+    st = configs.outer_ss_state(n, perturb=1e-6, seed=21)
+    thr = rng.uniform(0.3, 2.5, n)
+    ta = _outer_ss("v5")
+    k = emu.EmulatedKernel(ta.hip_source)
+    p = ta.order
+    r = k.run(st, np.zeros(n), np.zeros(n), mode=1, tfin=np.full(n, 100.0), pad=4, tc_thr=thr, want_tc_rows=36 * (p + 1), max_grid=1)
+    t1, h = r["time_hi"], r["last_h"]
+    assert np.all(r["outcome"] == int(hy.taylor_outcome.success))
+    assert np.all(t1 >= thr) and np.all(t1 - h < thr)  # the exit step is the first one which reaches the threshold
+    assert np.all(r["n_steps"] >= 1) and np.all(r["n_steps"] == np.ceil(np.round(r["n_steps"])))
+    # Dense output at the threshold from the stored coefficients (Horner in extended precision is not needed at 1e-13).
+    tc = r["tc"].reshape(36, p + 1, n)
+    hd = thr - (t1 - h)
+    dense = np.zeros((36, n))
+    for kk in range(p, -1, -1):
+        dense = dense * hd + tc[:, kk, :]
+    ora = ho.OracleIntegrator(ho.nbody(6, masses=M, Gconst=G), st, n, high_accuracy=True)
+    ora.propagate_until(thr)
+    ref = ora.state.reshape(36, n)
+    assert np.max(np.abs(dense - ref) / (np.max(np.abs(ref), axis=1, keepdims=True))) <= 1e5 * EPS
+    # The clamp at the last grid time still holds: a threshold beyond it ends with time_limit exactly there.
+    r2 = k.run(st[:, :4], np.zeros(4), np.zeros(4), mode=1, tfin=np.full(4, 1.0), pad=4, tc_thr=np.full(4, np.inf), want_tc_rows=36 * (p + 1))
+    assert np.all(r2["time_hi"] == 1.0) and np.all(r2["outcome"] == int(hy.taylor_outcome.time_limit))
+    # hy_kargs::grid_done: 1 for the systems whose last step was clamped to the remaining time, 0 for a grid-point exit.
+    assert np.all(r2["grid_done"] == 1.0) and np.all(r["grid_done"] == 0.0)

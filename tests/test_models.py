@@ -184,6 +184,15 @@ def rel_err(a, b):
     return np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))
 
 
+def row_rel_err(a, b):
+    """State comparison with a per-row scale (rows = state variables, columns = systems): max |a - b| over the ensemble
+    divided by max |b| over the ensemble, no floor at 1 (round 6: rows well below 1 - velocities of massive bodies,
+    out-of-plane components - were compared at an ABSOLUTE tolerance otherwise)."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    a = a.reshape(b.shape)
+    return float(np.max(np.max(np.abs(a - b), axis=1) / (np.max(np.abs(b), axis=1) + 1e-300)))
+
+
 def _lanes(base, n, rel, seed):
     """(len(base), n) initial conditions: lane 0 is the reference test's state, the others are perturbed copies."""
     rng = np.random.RandomState(seed)
@@ -293,12 +302,12 @@ def test_models_step_and_propagate_vs_oracle(name, pins, contract, monkeypatch):
     tc_o = oi.tc.reshape(n_eq, oi.order + 1, n)
     scale = np.max(np.abs(tc_o), axis=2, keepdims=True) + 1e-300
     assert np.max(np.abs(np.asarray(ta.tc).reshape(n_eq, oi.order + 1, n) - tc_o) / scale) <= tc_tol * EPS
-    assert rel_err(ta.state, oi.state.reshape(n_eq, n)) <= 1e5 * EPS
+    assert row_rel_err(ta.state, oi.state.reshape(n_eq, n)) <= 1e5 * EPS
     ta.propagate_until(T)
     oi.propagate_until(T)
     assert all(r[0] == hy.taylor_outcome.time_limit for r in ta.propagate_res)
     assert max(abs(a[3] - b[3]) for a, b in zip(ta.propagate_res, oi.prop_res)) <= (0 if contract else 1)
-    assert rel_err(ta.state, oi.state.reshape(n_eq, n)) <= 1e7 * EPS
+    assert row_rel_err(ta.state, oi.state.reshape(n_eq, n)) <= 1e7 * EPS
 
 
 def _invariant_drift(sys_, inv_ex, st, T, pars=None, high_accuracy=False):
@@ -716,7 +725,7 @@ def _mixed_cases():
     cen, ch = mm.lattice_centres_setup()
     return {
         # name: (system builder over an expression module, state builder, horizon, expected stepper)
-        "sine_lattice16": (lambda m: mm.sine_lattice(m, 16), lambda n: mm.sine_lattice_state(16, n), 6.0, "classes of clusters"),
+        "sine_lattice16": (lambda m: mm.sine_lattice(m, 16), lambda n: mm.sine_lattice_state(16, n), 2.0, "classes of clusters"),
         "lattice_centres12": (lambda m: mm.lattice_centres(m, cen, ch), mm.lattice_centres_state, 6.0, "classes of clusters"),
         # (17 histories per lane: beyond the register file - the staged table stepper.)
         "nbody6_j2": (lambda m: mm.nbody_j2(m, 6, M, G, 1e-7), lambda n: configs.outer_ss_state(n, perturb=1e-6, seed=3), 15.0,
