@@ -769,6 +769,9 @@ hy_tab hy_tab_create_with_events(hy_sys sys, const double *state, size_t n_state
                 e.callback = [cb, user](void *ctx, int d_sgn, std::uint32_t idx) {
                     return cb(static_cast<hy_tab>(ctx), d_sgn, idx, user) != 0;
                 };
+                if (cb == &hy_event_counter_t && user != nullptr) {
+                    e.native_counter = static_cast<std::uint64_t *>(user);
+                }
             }
             c.t_events.push_back(std::move(e));
         }
@@ -782,6 +785,9 @@ hy_tab hy_tab_create_with_events(hy_sys sys, const double *state, size_t n_state
                 e.callback = [cb, user](void *ctx, double tm, int d_sgn, std::uint32_t idx) {
                     cb(static_cast<hy_tab>(ctx), tm, d_sgn, idx, user);
                 };
+                if (cb == &hy_event_counter_nt && user != nullptr) {
+                    e.native_counter = static_cast<std::uint64_t *>(user);
+                }
             }
             c.nt_events.push_back(std::move(e));
         }

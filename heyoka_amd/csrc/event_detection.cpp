@@ -88,6 +88,9 @@ struct hy_ep_args {
     const double *upd;
     u64 N;
     unsigned n_te, n_nte, dim, n_cd, n_oc, pad;
+    int native;
+    u64 *ev_counts;
+    const double *te_cd;
 };
 
 __device__ __forceinline__ int hy_sgn(double x)
@@ -551,6 +554,8 @@ extern "C" __global__ void __launch_bounds__(256) hy_ev_post(const hy_ep_args a)
     a.outcome[j] = (h == a.lim[j]) ? HY_OC_TIME_LIMIT : HY_OC_SUCCESS;
     const unsigned c_te = a.counts[j], c_nte = a.counts[N + j];
     if (c_te + c_nte == 0u) return;
+    // (Library-side counting callbacks only: hy_ev_native applies the events, no records.)
+    if (a.native != 0) return;
     const u64 off = atomicAdd(a.cursor + 1, (u64)(8u + 4u * (c_te + c_nte)));
     double *r = a.rec + off;
     r[0] = (double)j;
@@ -567,6 +572,62 @@ extern "C" __global__ void __launch_bounds__(256) hy_ev_post(const hy_ep_args a)
         const double *src = a.ed_out + (((u64)cls * N + j) * HY_MAXD) * 4u;
         for (unsigned c = 0; c < cnt * 4u; ++c) r[c] = src[c];
         r += cnt * 4u;
+    }
+}
+
+// Every callback is the library's counting callback (hy_ep_args::native): what the host loop of step_impl() does for a
+// lane with events (src/taylor_adaptive_batch.cpp:837-1030), without the round trip - the non-terminal events which
+// trigger before the first terminal event are counted, the first terminal event (smallest |root|, the first one detected
+// among equals: the stable sort of src/detail/event_detection.cpp:771-781) gets its cooldown, its count and the outcome
+// "continuing" (the counting callback returns true). Runs behind hy_ev_post (times, non-finite check, cooldown ageing).
+// The counts are summed over the wavefront before they touch memory: 10^5 lanes with events per step on two addresses
+// would serialise otherwise.
+extern "C" __global__ void __launch_bounds__(256) hy_ev_native(const hy_ep_args a)
+{
+    const u64 N = a.N;
+    const u64 j0 = (u64)blockIdx.x * 256u + threadIdx.x;
+    const bool in = j0 < N;
+    const u64 j = in ? j0 : (N - 1u);
+    const unsigned c_te = in ? a.counts[j] : 0u, c_nte = in ? a.counts[N + j] : 0u;
+    const bool act = in && (c_te + c_nte != 0u) && (a.outcome[j] != HY_OC_ERR_NF_STATE);
+    const double h = a.dout_h[j];
+    const double *te = a.ed_out + ((u64)j * HY_MAXD) * 4u;
+    const double *nte = a.ed_out + (((u64)N + j) * HY_MAXD) * 4u;
+    unsigned first = 0;
+    for (unsigned c = 1; act && c < c_te; ++c) {
+        if (fabs(te[c * 4u + 1u]) < fabs(te[first * 4u + 1u])) first = c;
+    }
+    const unsigned te_idx = (act && c_te != 0u) ? (unsigned)te[first * 4u] : 0xffffffffu;
+    if (te_idx != 0xffffffffu) {
+        double cd = a.te_cd[te_idx];
+        if (!(cd >= 0.0)) {
+            // taylor_deduce_cooldown(), src/detail/event_detection.cpp:519-550.
+            cd = a.g_eps[j] / te[first * 4u + 3u] * 10.0;
+            if (!hy_finite(cd)) cd = 0.0;
+        }
+        const u64 p = (u64)te_idx * N + j;
+        a.cd_first[p] = 0.0;
+        a.cd_second[p] = cd;
+        a.cd_active[p] = 1;
+        a.outcome[j] = (i64)te_idx;
+    }
+    // Counts per event, one atomic per wavefront and event.
+    for (unsigned e = 0; e < a.n_te + a.n_nte; ++e) {
+        unsigned mine = 0;
+        if (e < a.n_te) {
+            mine = (te_idx == e) ? 1u : 0u;
+        } else {
+            for (unsigned c = 0; act && c < c_nte; ++c) {
+                if ((unsigned)nte[c * 4u] == e - a.n_te && (c_te == 0u || fabs(nte[c * 4u + 1u]) < fabs(h))) ++mine;
+            }
+        }
+        for (int m = 32; m >= 1; m >>= 1) mine += __shfl_xor(mine, m, 64);
+        if ((threadIdx.x & 63u) == 0u && mine != 0u) atomicAdd(a.ev_counts + e, (u64)mine);
+    }
+    {
+        // (Lanes with events, for the statistics: ballot + population count, one atomic per wavefront.)
+        const u64 m = __builtin_amdgcn_ballot_w64(act);
+        if ((threadIdx.x & 63u) == 0u && m != 0ull) atomicAdd(a.cursor + 2, (u64)__builtin_popcountll(m));
     }
 }
 

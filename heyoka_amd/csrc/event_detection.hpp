@@ -50,6 +50,8 @@ struct core_nt_event {
     expression eq;
     std::function<void(void *ctx, double time, int d_sgn, std::uint32_t batch_idx)> callback;
     event_direction dir = event_direction::any;
+    // (See core_t_event::native_counter: hy_event_counter_nt.)
+    std::uint64_t *native_counter = nullptr;
 };
 
 struct core_t_event {
@@ -57,6 +59,9 @@ struct core_t_event {
     std::function<bool(void *ctx, int d_sgn, std::uint32_t batch_idx)> callback; // empty -> always stop
     event_direction dir = event_direction::any;
     double cooldown = -1; // < 0: deduced automatically (taylor_deduce_cooldown())
+    // The callback is the library's own counting callback (hy_event_counter_t of the C ABI: increments *counter and lets
+    // the integration continue): nothing of the caller's runs, so the step applies it on the device.
+    std::uint64_t *native_counter = nullptr;
 };
 
 // One detected event of a lane: (event index, root (time from the beginning of the step), sign of the time
@@ -132,6 +137,12 @@ struct ep_kargs {
     const double *upd;          // hy_ev_scatter: n_cd x (position, first, second) then n_oc x (lane, outcome)
     unsigned long long N;
     unsigned n_te, n_nte, dim, n_cd, n_oc, pad;
+    // Every callback is the library's counting callback (core_*_event::native_counter): hy_ev_post applies the events of
+    // a lane itself - counts per event in ev_counts[n_te + n_nte] (terminal events first), cooldown and outcome of the
+    // first terminal event, cooldown settings in te_cd[n_te] (< 0: deduced) - and writes no records.
+    int native;
+    unsigned long long *ev_counts;
+    const double *te_cd;
 };
 
 } // namespace detail

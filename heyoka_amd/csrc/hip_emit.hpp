@@ -129,6 +129,10 @@ struct emit_options {
     // size and updates the state (emitted_module::events_in_stepper): hy_ev_jets and the dense-output pass over the Taylor
     // coefficients drop out of a step.
     const taylor_program *ev_prog = nullptr;
+    // Number of TERMINAL events among the event equations of ev_prog (they come first). Without terminal events no step is
+    // ever truncated, so nothing behind the stepper reads the Taylor coefficients of the state variables: they are stored
+    // on request only (hy_kargs::pad bit 0; a later get_tc() regenerates them from the snapshot of the step).
+    std::uint32_t n_t_events = 0;
     // emit_event_jets(): only the kernels which serve the compact Taylor coefficients (hy_dout_c, hy_tc_expand) - the
     // stepper evaluates the event equations itself (emitted_module::events_in_stepper).
     bool ev_helpers_only = false;

@@ -3169,8 +3169,9 @@ lim = fin ? 0.0 : lim;
                    + std::to_string((std::uint64_t(1) << L) - 1u) + "ull) != 0ull)";
         };
         src << "if (__builtin_amdgcn_ballot_w64(maybe0 | pe_m0) != 0ull) {\n";
-        src << "bool maybe = false;\nconst double lo_h = (h < 0.0) ? h : 0.0, hi_h = (h < 0.0) ? 0.0 : h;\n";
-        for (const auto &c : ev_coeffs) {
+        src << "bool maybe = false, maybe_te = false;\nconst double lo_h = (h < 0.0) ? h : 0.0, hi_h = (h < 0.0) ? 0.0 : h;\n";
+        for (std::size_t ci = 0; ci < ev_coeffs.size(); ++ci) {
+            const auto &c = ev_coeffs[ci];
             if (c.empty()) {
                 continue;
             }
@@ -3182,7 +3183,7 @@ lim = fin ? 0.0 : lim;
                     << "mm = fmax(mm, fmax(fabs(lo), fabs(hi)));\n}\n";
             }
             src << "const bool excl = (((lo > 0.0) & (hi > 0.0)) | ((lo < 0.0) & (hi < 0.0))) & (fmin(fabs(lo), fabs(hi)) > 1e-8 * mm);\n"
-                << "maybe = maybe | !excl;\n}\n";
+                << "maybe = maybe | !excl;\n" << (ci < opts.n_t_events ? "maybe_te = maybe_te | !excl;\n" : "") << "}\n";
         }
         src << "bool pe_m = false;\n";
         if (!pe_g.empty()) {
@@ -3196,7 +3197,13 @@ lim = fin ? 0.0 : lim;
             src << "const bool excl = (((lo > 0.0) & (hi > 0.0)) | ((lo < 0.0) & (hi < 0.0))) & (fmin(fabs(lo), fabs(hi)) > 1e-8 * mm);\n"
                 << "pe_m = pe_m0 & !excl;\n}\n";
         }
-        src << "ev_possible = (maybe & maybe0) | " << sys_any("pe_m") << ";\nneed_tc = need_tc | ev_possible;\n}\n";
+        // (The coefficients of the state variables are read behind the stepper only where a step may be TRUNCATED: at a
+        // TERMINAL event: the events on the lanes of their pairs count as terminal whenever the integrator has one.)
+        src << "ev_possible = (maybe & maybe0) | " << sys_any("pe_m") << ";\n";
+        if (opts.n_t_events != 0u) {
+            src << "need_tc = need_tc | (maybe_te & maybe0) | " << sys_any("pe_m") << ";\n";
+        }
+        src << "}\n";
         // (For the detection kernel: systems in which no event is possible are skipped without reading their event jets -
         // which are stored only by the wavefronts that hold such a system.)
         src << "if (!hy_tc_only) a.sel_norms[s] = ev_possible ? 1.0 : 0.0;\n";

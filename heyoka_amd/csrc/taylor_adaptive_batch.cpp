@@ -253,7 +253,9 @@ struct tab_core::impl {
     mutable std::vector<double> pending_cd;
     void cooldowns_to_host() const;
     void cooldowns_to_device();
-    mutable device_buffer d_ev_cursor, d_ev_rec, d_ev_upd;
+    mutable device_buffer d_ev_cursor, d_ev_rec, d_ev_upd, d_ev_counts, d_te_cd;
+    // Every event callback is the library's counting callback: hy_ev_post applies the events itself (ep_kargs::native).
+    mutable bool ev_native = false;
     // (Page-locked landing area of the event records of a step: see pinned_buffer.)
     mutable pinned_buffer h_ev_rec;
     [[nodiscard]] bool is_cluster() const
@@ -702,6 +704,7 @@ tab_core::tab_core(sys_t sys, std::vector<double> state, std::uint32_t batch_siz
             // (emit_options::ev_prog); lanes whose step is truncated at a terminal event are redone from the Taylor
             // coefficients afterwards.
             eo2.ev_prog = &d.prog;
+            eo2.n_t_events = static_cast<std::uint32_t>(d.tes.size());
             auto m = emit_hip_module(prog0, eo2);
             std::string why;
             if (m.cluster_mode4) {
@@ -1332,7 +1335,24 @@ void tab_core::impl::ensure_event_buffers()
         const std::uint64_t max_slots = std::clamp<std::uint64_t>((std::uint64_t(1) << 30) / per_slot / 64u * 64u, 64u * 256u, 64u * 256u * 8u);
         ed_slots = std::min<std::uint64_t>((static_cast<std::uint64_t>(n) + 63u) / 64u * 64u, max_slots);
         d_ed_wl = device_buffer(static_cast<std::size_t>(ed_slots) * per_slot, device);
-        d_ev_cursor = device_buffer(2u * sizeof(unsigned long long), device);
+        d_ev_cursor = device_buffer(4u * sizeof(unsigned long long), device);
+        // Library-side counting callbacks only (core_*_event::native_counter): the events are applied on the device.
+        ev_native = true;
+        std::vector<double> te_cd;
+        for (const auto &ev : tes) {
+            ev_native = ev_native && ev.native_counter != nullptr;
+            te_cd.push_back(ev.cooldown);
+        }
+        for (const auto &ev : ntes) {
+            ev_native = ev_native && ev.native_counter != nullptr;
+        }
+        if (ev_native) {
+            d_ev_counts = device_buffer((tes.size() + ntes.size()) * sizeof(unsigned long long), device);
+            d_te_cd = device_buffer(std::max<std::size_t>(te_cd.size(), 1u) * sizeof(double), device);
+            if (!te_cd.empty()) {
+                d_te_cd.upload(te_cd.data(), te_cd.size() * sizeof(double), stream);
+            }
+        }
         std::vector<int> dirs;
         for (const auto &ev : tes) {
             dirs.push_back(static_cast<int>(ev.dir));
@@ -1547,7 +1567,13 @@ void tab_core::impl::step_with_events_device(const std::vector<double> *lims)
     d_ev_cursor.zero(stream);
     ed_mod->launch("hy_ev_pre", N, 256, &pa, sizeof(pa), stream);
     unsigned flags[3] = {0, 0, 0};
-    unsigned long long cur[2] = {0, 0};
+    unsigned long long cur[4] = {0, 0, 0, 0};
+    if (ev_native) {
+        pa.native = 1;
+        pa.ev_counts = d_ev_counts.as<unsigned long long>();
+        pa.te_cd = d_te_cd.as<double>();
+        d_ev_counts.zero(stream);
+    }
     d_ed_flags.download(flags, sizeof(flags), stream);
     if (cluster_events && emitted.events_in_stepper) {
         // (Workgroups of the stepper which did not store their Taylor coefficients: none if it was asked to store all.)
@@ -1555,10 +1581,10 @@ void tab_core::impl::step_with_events_device(const std::vector<double> *lims)
         d_counters.download(cnt, sizeof(cnt), stream);
         tc_partial = cnt[4] != 0u;
     }
-    d_ev_cursor.download(cur, sizeof(cur), stream);
+    d_ev_cursor.download(cur, 2u * sizeof(unsigned long long), stream);
     report_ed_failures(ed_failures, flags);
     lap("pre + flags to host");
-    if (cur[0] * dsz > d_ev_rec.bytes()) {
+    if (!ev_native && cur[0] * dsz > d_ev_rec.bytes()) {
         d_ev_rec = device_buffer(static_cast<std::size_t>(cur[0] + cur[0] / 2u + 1024u) * dsz, device);
     }
     pa.rec = d_ev_rec.as<double>();
@@ -1593,10 +1619,37 @@ void tab_core::impl::step_with_events_device(const std::vector<double> *lims)
         dmod->launch_dout(d_state.as<double>(), d_tc.as<double>(), d_douth.as<double>(), N);
     }
     ed_mod->launch("hy_ev_post", N, 256, &pa, sizeof(pa), stream);
+    if (ev_native && cur[0] != 0u) {
+        ed_mod->launch("hy_ev_native", N, 256, &pa, sizeof(pa), stream);
+    }
     const double *rec = nullptr;
     std::size_t rec_size = 0;
+    if (ev_native) {
+        // The events were applied by hy_ev_post (counts per event, cooldown and outcome of the first terminal event of a
+        // lane): what is left of the host loop of src/taylor_adaptive_batch.cpp:837-1030 is adding the counts to the
+        // callbacks' counters - no records, no per-event work. (The reference runs the callbacks one by one in batch
+        // order; a counter does not see the order.)
+        std::vector<unsigned long long> cnts(tes.size() + ntes.size(), 0u);
+        if (cur[0] != 0u) {
+            d_ev_counts.download(cnts.data(), cnts.size() * sizeof(unsigned long long), stream);
+            d_ev_cursor.download(cur, sizeof(cur), stream);
+            ev_systems += cur[2];
+        } else {
+            stream_synchronize(device, stream);
+        }
+        for (std::size_t e = 0; e < cnts.size(); ++e) {
+            auto *ctr = e < tes.size() ? tes[e].native_counter : ntes[e - tes.size()].native_counter;
+            __atomic_fetch_add(ctr, static_cast<std::uint64_t>(cnts[e]), __ATOMIC_RELAXED);
+        }
+        lap("dout + post + records");
+        host_newer = false;
+        after_kernel();
+        step_res_dev_newer = true;
+        cd_dev_newer = n_te != 0u;
+        return;
+    }
     if (cur[0] != 0u) {
-        d_ev_cursor.download(cur, sizeof(cur), stream);
+        d_ev_cursor.download(cur, 2u * sizeof(unsigned long long), stream);
         rec_size = static_cast<std::size_t>(cur[1]);
         if (cur[1] != 0u) {
             auto *dst = static_cast<double *>(h_ev_rec.reserve(rec_size * dsz));

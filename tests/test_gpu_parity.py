@@ -2579,3 +2579,61 @@ print("OK")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.returncode == 0 and "OK" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
+
+
+@pytest.mark.gpu
+def test_library_side_counting_callbacks_are_applied_on_the_device():
+    """Events whose callbacks are ALL the library's counting callbacks (hy_event_counter_nt / hy_event_counter_t: nothing
+    of the caller's runs) are applied by the post-step kernel itself - counts per event, cooldown and "continuing" outcome
+    of the first terminal event of a lane - instead of the host loop over the records of the step
+    (src/taylor_adaptive_batch.cpp:837-1030). Against the same integrator with Python callbacks which count (the host
+    loop): identical counts per event, outcomes, step sizes, states, times and cooldowns after every step, on an ensemble
+    in which events fire in most steps."""
+    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    n = 1024
+    rng = np.random.RandomState(5)
+    sysd = hy.model.nbody(6, masses=M, Gconst=G)
+    spread = hy.taylor_adaptive_batch(sysd, configs.outer_ss_state(n, perturb=1e-6, seed=31), n, high_accuracy=True)
+    spread.propagate_until(rng.uniform(0.0, 30.0, n))
+    st = np.array(spread.state)
+    y1, y2, y3 = hy.make_vars("y_1", "y_2", "y_3")
+    c_nt = [hy.native_event_counter(), hy.native_event_counter()]
+    c_t = hy.native_event_counter()
+    a = hy.taylor_adaptive_batch(sysd, st, n, high_accuracy=True, nt_events=[hy.nt_event(y1, c_nt[0]), hy.nt_event(y2, c_nt[1])],
+                                 t_events=[hy.t_event(y3, c_t, cooldown=0.05)])
+    p_nt, p_t = [0, 0], [0]
+
+    def mk_nt(k):
+        def cb(ta, t, d_sgn, idx):
+            p_nt[k] += 1
+        return cb
+
+    def cb_t(ta, d_sgn, idx):
+        p_t[0] += 1
+        return True
+
+    b = hy.taylor_adaptive_batch(sysd, st, n, high_accuracy=True, nt_events=[hy.nt_event(y1, mk_nt(0)), hy.nt_event(y2, mk_nt(1))],
+                                 t_events=[hy.t_event(y3, cb_t, cooldown=0.05)])
+    for _ in range(12):
+        a.step()
+        b.step()
+        assert a.step_res == b.step_res
+        assert np.array_equal(a.state, b.state) and np.array_equal(np.asarray(a.time), np.asarray(b.time))
+        assert [c.value for c in c_nt] == p_nt and c_t.value == p_t[0]
+    assert sum(p_nt) > 100 and p_t[0] > 10
+    assert any(int(o) >= 0 for o, _ in a.step_res) or p_t[0] > 0
+    assert a.te_cooldowns == b.te_cooldowns
+    # With an automatic cooldown as well (taylor_deduce_cooldown(), src/detail/event_detection.cpp:519-550).
+    c2, cnt = hy.native_event_counter(), [0]
+
+    def cb2(ta, d_sgn, idx):
+        cnt[0] += 1
+        return True
+
+    a2 = hy.taylor_adaptive_batch(sysd, st, n, high_accuracy=True, t_events=[hy.t_event(y3, c2)])
+    b2 = hy.taylor_adaptive_batch(sysd, st, n, high_accuracy=True, t_events=[hy.t_event(y3, cb2)])
+    for _ in range(6):
+        a2.step()
+        b2.step()
+        assert a2.step_res == b2.step_res and np.array_equal(a2.state, b2.state)
+    assert c2.value == cnt[0] > 0 and a2.te_cooldowns == b2.te_cooldowns
