@@ -174,7 +174,7 @@ if CPU_QUOTA is not None:
 def cpu_baseline(workload, dt, target_seconds=15.0):
     """The oracle (C restatement, OpenMP over SIMD-width batches like the reference's
     TBB-over-batches ensemble) timed on this host on a bounded sample of the same workload."""
-    if workload not in ("outer_ss", "two_body", "nbody64"):
+    if workload not in ("outer_ss", "two_body", "nbody64", "outer_ss_compact_mode", "outer_ss_forced_table"):
         return None  # (auxiliary workloads carry no CPU baseline)
     try:
         return _cpu_baseline(workload, dt, target_seconds)
@@ -191,7 +191,8 @@ def _cpu_baseline(workload, dt, target_seconds):
     width = 8
     hw_threads = max(ho.max_threads(), HW_THREADS_AT_START)
     threads = min(PHYSICAL_CORES_AT_START, hw_threads)
-    if workload == "outer_ss":
+    compact = workload in ("outer_ss_compact_mode", "outer_ss_forced_table")
+    if workload == "outer_ss" or compact:
         osys = ho.nbody(6, masses=configs.OUTER_SS_MASSES, Gconst=configs.OUTER_SS_G)
         gen = lambda n: configs.outer_ss_state(n, perturb=1e-12, seed=42)
         ha = True
@@ -205,15 +206,19 @@ def _cpu_baseline(workload, dt, target_seconds):
         ha = False
     # Bounded sample: a fixed set of systems propagated further and further (t += dt per call, exactly
     # like the GPU bench steps) until ~target_seconds of CPU work have been spent.
-    n = width * threads * (1 if workload == "nbody64" else 256)
+    n = width * threads * (1 if workload == "nbody64" else (32 if compact else 256))
     st = gen(n)
-    tmpl = ho.OracleIntegrator(osys, np.zeros(len(osys) * width), width, high_accuracy=ha)
+    # (The compact-mode legs: the oracle's interpreter with the arithmetic of the reference's compact mode - rolled loops
+    # over the decomposition, running sums: the CPU analogue of src/taylor_02.cpp:1194-1260.)
+    tmpl = ho.OracleIntegrator(osys, np.zeros(len(osys) * width), width, high_accuracy=ha, compact_mode=compact)
     # Outer Solar System / two-body: the jet is a compiled, fully unrolled, 8-wide vectorised function generated from
     # the oracle's decomposition (oracle/compiled_baseline.py - the CPU analogue of the reference's default-mode SIMD
     # JIT, checked bit by bit against the interpreter in tests/test_oracle_golden.py); N = 64 (18 663 u variables x
     # 20 orders) stays on the interpreter.
     how, compile_s = "oracle C interpreter, gcc -O2 -march=native -ffp-contract=off", 0.0
-    if workload != "nbody64":
+    if compact:
+        how = "oracle C interpreter with the compact-mode arithmetic (running sums), gcc -O2 -march=native -ffp-contract=off"
+    elif workload != "nbody64":
         import compiled_baseline as cb
 
         compile_s = cb.install(tmpl, fast=True)
@@ -278,6 +283,52 @@ def pmc_traffic(sha, n_systems):
             if steps:
                 return d["per_launch_avg"]["traffic_bytes_fetch_x2"] / steps, os.path.basename(path)
     return None, None
+
+
+def measure_traffic(workload, n):
+    """HBM traffic of the stepper kernel from PMC passes taken NOW, on this box and this very library (`--measure-traffic`):
+    two child runs of this script under rocprofv3 - `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes, counters
+    only (never combined with tracing domains, as the guide's HBM section prescribes) -, the per-dispatch values of
+    hy_taylor summed as 2 x FETCH_SIZE + WRITE_SIZE (the gfx950 correction calibrated in profiles/*_pmc_calibration.json)
+    and divided by the system-steps of the same launches (the child prints them). Returns (bytes per system-step, source)
+    or (None, reason)."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+
+    rp = shutil.which("rocprofv3")
+    if rp is None:
+        return None, "rocprofv3 is not on this box"
+    vals, steps_per_launch = {}, None
+    tmp = tempfile.mkdtemp(prefix="hy_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(tmp, ctr)
+            cmd = [rp, "--pmc", ctr, "-d", out_dir, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--workload", workload,
+                   "--systems", str(n), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra-workloads"]
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd="/tmp", env=env)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                return None, "the %s pass failed (rc %d): %s" % (ctr, r.returncode, r.stderr[-300:])
+            steps_per_launch = json.loads(line[-1])["config"]["system_steps_per_launch"]
+            dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(out_dir) for f in fs if f.endswith(".db")]
+            if not dbs:
+                return None, "no rocpd database from the %s pass" % ctr
+            cur = sqlite3.connect(dbs[0]).cursor()
+            per = [row[0] for row in cur.execute("select value from counters_collection where kernel_name = 'hy_taylor' and "
+                                                 "counter_name = ? order by dispatch_id", (ctr,))]
+            if len(per) < 2:
+                return None, "no hy_taylor dispatches in the %s pass" % ctr
+            timed = per[1:]  # (the first launch is the warmup)
+            vals[ctr] = sum(timed) / len(timed) * 1024.0  # KiB as reported -> bytes per launch
+    except Exception as e:  # a measurement aid must never cost the line
+        return None, "%s: %s" % (type(e).__name__, e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    traffic = 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]
+    return traffic / steps_per_launch, "same-run rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this command (2 x FETCH + WRITE)"
 
 
 def run_workload(ctx, workload, n, steps, warmup):
@@ -399,6 +450,13 @@ def run_workload(ctx, workload, n, steps, warmup):
         achieved_gbs = b_tape * per_launch_steps / (k_ms * 1e-3) / 1e9
         achieved_tflops = f_alg * per_launch_steps / (k_ms * 1e-3) / 1e12
         traffic_per_step, traffic_src = pmc_traffic(kernel_sha(ta), n)
+        if ctx.get("measure_traffic"):
+            # (A same-run counter pass beats a committed summary matched by sha.)
+            m_tps, m_src = measure_traffic(workload, n)
+            if m_tps is not None:
+                traffic_per_step, traffic_src = m_tps, m_src
+            elif traffic_per_step is None:
+                traffic_src = "not measured: " + str(m_src)
         traffic = traffic_per_step * per_launch_steps if traffic_per_step else None
         # Which ceiling binds. The tape model B_tape describes a stepper that streams its jets through HBM
         # (block / table modes). The cluster and register-resident steppers keep the jets on chip: their measured HBM
@@ -734,6 +792,9 @@ def main():
     ap.add_argument("--no-long-horizon", action="store_true", help="skip the long-horizon leg of the extra workloads (~30 s)")
     ap.add_argument("--long-horizon-years", type=float, default=1.0e4)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI)")
+    ap.add_argument("--measure-traffic", action="store_true",
+                    help="fill roofline.traffic from rocprofv3 PMC passes taken now (two child runs per workload, ~1 min each) "
+                    "instead of the committed summary under profiles/ matched by the sha of the kernel")
     ap.add_argument("--collective-timeout", type=float, default=180.0,
                     help="seconds after which a collective that does not complete fails the run instead of hanging it")
     ap.add_argument("--single-device", action="store_true",
@@ -782,7 +843,7 @@ def main():
 
     ctx = dict(torch=torch, hy=hy, configs=configs, hens=hens, dist=(dist if distributed else None), rank=rank, world=world,
                distributed=distributed, dev=dev, dev_index=dev_index, backend=args.backend,
-               collective_timeout=args.collective_timeout)
+               collective_timeout=args.collective_timeout, measure_traffic=bool(args.measure_traffic) and world == 1)
     n = args.systems if args.systems > 0 else DEFAULT_SYSTEMS[args.workload]
     out = run_workload(ctx, args.workload, n, args.steps, args.warmup)
     gather_failed = bool(out.pop("_gather_failed", False)) if out is not None else False
@@ -812,7 +873,10 @@ def main():
             for wl in ("outer_ss_compact_mode", "outer_ss_forced_table", "nbody6_j2_mixed", "sine_lattice16_mixed"):
                 try:
                     r = run_workload(ctx, wl, DEFAULT_SYSTEMS[wl], 3, 1)
-                    extra.append({k: r[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline")})
+                    leg = {k: r[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline")}
+                    if wl == "outer_ss_forced_table" and not args.no_cpu_baseline:
+                        leg["cpu_baseline"] = cpu_baseline(wl, r["_dt"], 4.0)
+                    extra.append(leg)
                 except Exception as e:
                     extra.append({"config": {"workload": wl}, "error": "%s: %s" % (type(e).__name__, e)})
             try:

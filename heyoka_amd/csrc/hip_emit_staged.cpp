@@ -30,6 +30,7 @@
 // per-system variant is bound by the latency of its HBM tape: every coefficient is re-read O(order) times).
 #include <algorithm>
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <sstream>
 #include <string>
@@ -270,6 +271,90 @@ emitted_module emit_staged(const taylor_program &p, const emit_options &opts, st
                 break;
         }
     }
+    // Fusion of the dependency chain of an order. Every level costs a store - barrier - load round trip through LDS, and an
+    // order is a CHAIN of levels (its latency, not its work, bounds the step). Two kinds of u variable need no level of
+    // their own:
+    //   * followers: a linear function of ONE u variable and numbers / parameters (c * u, -u, u - c, c - u, u / c: the
+    //     scalings G m r^-3 and the reactions c (d r^-3) of an N-body system) is computed by the lane(s) which have just
+    //     computed that variable, from the value in their register;
+    //   * the state-variable recursion x^[k+1] = rhs^[k] / (k + 1) (taylor_compute_sv_diff(), src/taylor_02.cpp:245-287):
+    //     written by the lane which computes rhs^[k]; a state variable defined by another state variable (x' = v) follows one
+    //     order later, x^[k+2] = v^[k+1] / (k + 2), from the same lane.
+    // Same operations on the same operands as the separate nodes: bit for bit the same results.
+    std::vector<int> parent(n_nodes, -1);
+    std::vector<std::vector<std::uint32_t>> followers(n_nodes), sv_of(n_nodes);
+    std::vector<std::vector<std::uint32_t>> chain_of(n_eq); // state variables defined by state variable i
+    std::vector<char> sv_fused(n_eq, 0);
+    // Measured (profiles/r06_staged_fusion_ab.log, 262 144 systems): followers + 12 % on the outer Solar System (8 -> 5
+    // levels), + 0 ... 3 % elsewhere; the fused recursion of the state variables - 2 ... - 12 % on everything but the outer
+    // Solar System (+ 1 %): two divisions in sequence on every lane of the last level cost more than the level they save.
+    // Default: followers only. (HEYOKA_AMD_TABLE_LDS=3: no fusion, 5: both - A/B switches.)
+    const bool fuse = opts.dev.table_lds != 3;
+    const bool fuse_sv = opts.dev.table_lds == 5;
+    for (std::uint32_t i = 0; i < n_nodes && fuse; ++i) {
+        const auto &n = p.nodes[i];
+        if (spec_of[i] != spec::prod && spec_of[i] != spec::sub && spec_of[i] != spec::div) {
+            continue;
+        }
+        if (n.args.size() != 2u || is_uvar(n.args[0]) == is_uvar(n.args[1])) {
+            continue;
+        }
+        const auto &ov = is_uvar(n.args[0]) ? n.args[0] : n.args[1];
+        if (ov.idx < n_eq || spec_of[ov.idx - n_eq] == spec::generic) {
+            continue;
+        }
+        if (spec_of[i] == spec::div && !is_uvar(n.args[0])) {
+            continue; // (c / u is a recurrence, not a linear function of u)
+        }
+        parent[i] = static_cast<int>(ov.idx - n_eq);
+        followers[ov.idx - n_eq].push_back(i);
+    }
+    for (std::uint32_t i = 0; i < n_eq && fuse_sv; ++i) {
+        const auto &d = p.sv_defs[i];
+        if (is_uvar(d) && d.idx >= n_eq && spec_of[d.idx - n_eq] != spec::generic) {
+            sv_of[d.idx - n_eq].push_back(i);
+            sv_fused[i] = 1;
+        }
+    }
+    for (std::uint32_t i = 0; i < n_eq && fuse_sv; ++i) {
+        const auto &d = p.sv_defs[i];
+        // (One link: x' = v with v' a node. Longer chains of state variables keep the separate recursion.)
+        if (is_uvar(d) && d.idx < n_eq && sv_fused[d.idx] != 0 && !(is_uvar(p.sv_defs[d.idx]) && p.sv_defs[d.idx].idx < n_eq)) {
+            chain_of[d.idx].push_back(i);
+            sv_fused[i] = 1;
+        }
+    }
+    // Levels again: a follower sits at the level of the variable it follows.
+    n_levels = 0;
+    for (std::uint32_t i = 0; i < n_nodes; ++i) {
+        std::uint32_t l = 0;
+        if (parent[i] >= 0) {
+            l = level[static_cast<std::uint32_t>(parent[i])];
+        } else {
+            for (const auto &o : p.nodes[i].args) {
+                if (is_uvar(o) && o.idx >= n_eq) {
+                    l = std::max(l, level[o.idx - n_eq] + 1u);
+                }
+            }
+        }
+        level[i] = l;
+        n_levels = std::max(n_levels, l + 1u);
+    }
+    // Shape of what hangs off a node: part of the key of its group (the lanes of a group run one instruction stream).
+    std::function<std::string(std::uint32_t)> tail_sig = [&](std::uint32_t i) {
+        std::string sg;
+        for (const auto f : followers[i]) {
+            sg += "{" + key_of[f] + (hist[n_eq + f] != 0 ? "H" : "S") + tail_sig(f) + "}";
+        }
+        if (!sv_of[i].empty()) {
+            sg += "|sv" + std::to_string(sv_of[i].size());
+            for (const auto v : sv_of[i]) {
+                sg += "c" + std::to_string(chain_of[v].size());
+            }
+        }
+        return sg;
+    };
+
     // Layout: rows of the history variables (state variables first: row i = state variable i), the dummy row, the slab.
     std::vector<std::uint32_t> base(n_u, 0u);
     std::uint32_t n_hist = 0, n_slab = 0;
@@ -305,6 +390,9 @@ emitted_module emit_staged(const taylor_program &p, const emit_options &opts, st
     {
         std::map<std::pair<std::uint32_t, std::string>, std::size_t> gidx;
         for (std::uint32_t i = 0; i < n_nodes; ++i) {
+            if (parent[i] >= 0) {
+                continue; // (computed by the lanes of the variable it follows)
+            }
             // (Whether the result and the arguments sit in a row or in a slab cell is part of the shape of the code.)
             std::string key = key_of[i];
             if (spec_of[i] != spec::generic) {
@@ -312,6 +400,7 @@ emitted_module emit_staged(const taylor_program &p, const emit_options &opts, st
                 for (const auto &o : p.nodes[i].args) {
                     key += !is_uvar(o) ? '-' : (hist[o.idx] != 0 ? 'h' : 's');
                 }
+                key += tail_sig(i);
             }
             const auto s = spec_of[i];
             const auto kk = std::make_pair(level[i], key);
@@ -492,6 +581,7 @@ emitted_module emit_staged(const taylor_program &p, const emit_options &opts, st
                 }
                 return h.str();
             };
+            std::ostringstream r0, rk;
             switch (grp.sp) {
                 case spec::sum: {
                     // hy_diff_sum(): numbers / parameters contribute at order 0 only; pairwise over all the arguments.
@@ -500,101 +590,101 @@ emitted_module emit_staged(const taylor_program &p, const emit_options &opts, st
                         t0.push_back(is_uvar(n0.args[a]) ? T(A[a], "0u") : C[a]);
                         tk.push_back(is_uvar(n0.args[a]) ? T(A[a], "k") : std::string("0.0"));
                     }
-                    o0 << T(O, "0u") << " = " << pairwise(t0) << ";\n";
-                    ok << T(O, "k") << " = " << pairwise(tk) << ";\n";
+                    r0 << T(O, "0u") << " = " << pairwise(t0) << ";\n";
+                    rk << T(O, "k") << " = " << pairwise(tk) << ";\n";
                     break;
                 }
                 case spec::sub:
                     if (v0 && v1) {
-                        o0 << T(O, "0u") << " = " << T(A[0], "0u") << " - " << T(A[1], "0u") << ";\n";
-                        ok << T(O, "k") << " = " << T(A[0], "k") << " - " << T(A[1], "k") << ";\n";
+                        r0 << T(O, "0u") << " = " << T(A[0], "0u") << " - " << T(A[1], "0u") << ";\n";
+                        rk << T(O, "k") << " = " << T(A[0], "k") << " - " << T(A[1], "k") << ";\n";
                     } else if (v0) {
-                        o0 << T(O, "0u") << " = " << T(A[0], "0u") << " - " << C[1] << ";\n";
-                        ok << T(O, "k") << " = " << T(A[0], "k") << ";\n";
+                        r0 << T(O, "0u") << " = " << T(A[0], "0u") << " - " << C[1] << ";\n";
+                        rk << T(O, "k") << " = " << T(A[0], "k") << ";\n";
                     } else if (v1) {
-                        o0 << T(O, "0u") << " = " << C[0] << " - " << T(A[1], "0u") << ";\n";
-                        ok << T(O, "k") << " = -" << T(A[1], "k") << ";\n";
+                        r0 << T(O, "0u") << " = " << C[0] << " - " << T(A[1], "0u") << ";\n";
+                        rk << T(O, "k") << " = -" << T(A[1], "k") << ";\n";
                     } else {
-                        o0 << T(O, "0u") << " = " << C[0] << " - " << C[1] << ";\n";
-                        ok << T(O, "k") << " = 0.0;\n";
+                        r0 << T(O, "0u") << " = " << C[0] << " - " << C[1] << ";\n";
+                        rk << T(O, "k") << " = 0.0;\n";
                     }
                     break;
                 case spec::prod: {
                     const bool neg = n0.args[0].type == operand::kind::num && n0.args[0].value == -1.;
                     if (v0 && v1) {
-                        o0 << T(O, "0u") << " = " << T(A[0], "0u") << " * " << T(A[1], "0u") << ";\n";
-                        ok << "{\nconst double *pa = hy_lds_tape + " << A[0] << " + k, *pb = hy_lds_tape + " << A[1]
+                        r0 << T(O, "0u") << " = " << T(A[0], "0u") << " * " << T(A[1], "0u") << ";\n";
+                        rk << "{\nconst double *pa = hy_lds_tape + " << A[0] << " + k, *pb = hy_lds_tape + " << A[1]
                            << ";\ndouble acc = 0.0;\n" << jloop("0u", "j <= k") << " acc += pa[-(int)j] * pb[j];\n"
                            << reduce("acc") << T(O, "k") << " = acc;\n}\n";
                     } else if (!v0 && !v1) {
-                        o0 << T(O, "0u") << " = " << (neg ? "-" + C[1] : C[0] + " * " + C[1]) << ";\n";
-                        ok << T(O, "k") << " = 0.0;\n";
+                        r0 << T(O, "0u") << " = " << (neg ? "-" + C[1] : C[0] + " * " + C[1]) << ";\n";
+                        rk << T(O, "k") << " = 0.0;\n";
                     } else {
                         const auto av = v0 ? 0u : 1u, an = v0 ? 1u : 0u;
                         const std::string f = (neg && an == 0u) ? std::string("-") : (C[an] + " * ");
-                        o0 << T(O, "0u") << " = " << f << T(A[av], "0u") << ";\n";
-                        ok << T(O, "k") << " = " << f << T(A[av], "k") << ";\n";
+                        r0 << T(O, "0u") << " = " << f << T(A[av], "0u") << ";\n";
+                        rk << T(O, "k") << " = " << f << T(A[av], "k") << ";\n";
                     }
                     break;
                 }
                 case spec::div:
                     if (v1) {
                         const auto U = own_row();
-                        o0 << T(O, "0u") << " = " << (v0 ? T(A[0], "0u") : C[0]) << " / " << T(A[1], "0u") << ";\n";
-                        ok << "{\nconst double *pu = hy_lds_tape + " << U << " + k, *pd = hy_lds_tape + " << A[1]
+                        r0 << T(O, "0u") << " = " << (v0 ? T(A[0], "0u") : C[0]) << " / " << T(A[1], "0u") << ";\n";
+                        rk << "{\nconst double *pu = hy_lds_tape + " << U << " + k, *pd = hy_lds_tape + " << A[1]
                            << ";\ndouble acc = 0.0;\n" << jloop("1u", "j <= k") << " acc += pu[-(int)j] * pd[j];\n" << reduce("acc")
                            << T(O, "k") << " = " << (v0 ? "(" + T(A[0], "k") + " - acc)" : std::string("(-acc)")) << " / pd[0];\n}\n";
                     } else if (v0) {
-                        o0 << T(O, "0u") << " = " << T(A[0], "0u") << " / " << C[1] << ";\n";
-                        ok << T(O, "k") << " = " << T(A[0], "k") << " / " << C[1] << ";\n";
+                        r0 << T(O, "0u") << " = " << T(A[0], "0u") << " / " << C[1] << ";\n";
+                        rk << T(O, "k") << " = " << T(A[0], "k") << " / " << C[1] << ";\n";
                     } else {
-                        o0 << T(O, "0u") << " = " << C[0] << " / " << C[1] << ";\n";
-                        ok << T(O, "k") << " = 0.0;\n";
+                        r0 << T(O, "0u") << " = " << C[0] << " / " << C[1] << ";\n";
+                        rk << T(O, "k") << " = 0.0;\n";
                     }
                     break;
                 case spec::sum_sq: {
                     // hy_diff_sum_sq(): per-argument running sums, pairwise sum over the arguments, doubled at odd orders.
-                    ok << "{\nconst unsigned odd = k & 1u, jn = odd ? (k + 1u) / 2u : k / 2u;\n";
+                    rk << "{\nconst unsigned odd = k & 1u, jn = odd ? (k + 1u) / 2u : k / 2u;\n";
                     if (nu == 1u) {
                         std::vector<std::string> t0, tk;
                         for (std::size_t a = 0; a < nargs; ++a) {
                             t0.push_back("(" + T(A[a], "0u") + " * " + T(A[a], "0u") + ")");
                             const auto s_ = std::to_string(a);
-                            ok << "double t" << s_ << ";\n{\nconst double *pa = hy_lds_tape + " << A[a] << ";\ndouble acc = 0.0;\n"
+                            rk << "double t" << s_ << ";\n{\nconst double *pa = hy_lds_tape + " << A[a] << ";\ndouble acc = 0.0;\n"
                                << jloop("0u", "j < jn") << " acc += pa[k - j] * pa[j];\n" << reduce("acc")
                                << "const double hv = pa[k / 2u];\nt" << s_ << " = odd ? acc : (acc + acc) + hv * hv;\n}\n";
                             tk.push_back("t" + s_);
                         }
-                        o0 << T(O, "0u") << " = " << pairwise(t0) << ";\n";
-                        ok << "const double tot = " << pairwise(tk) << ";\n" << T(O, "k") << " = odd ? tot + tot : tot;\n}\n";
+                        r0 << T(O, "0u") << " = " << pairwise(t0) << ";\n";
+                        rk << "const double tot = " << pairwise(tk) << ";\n" << T(O, "k") << " = odd ? tot + tot : tot;\n}\n";
                     } else {
                         // One unit of `sp` lanes per argument: the terms of the arguments are collected by wave shuffles
                         // from the first lane of every unit (lane L0 + a * sp), then added pairwise like above.
                         const std::string L0 = urow([&](std::uint32_t l) { return (l % 64u) - ((l % 64u) % lpn); });
-                        o0 << "{\nconst double x0 = " << T(A[0], "0u") << ";\nconst double q0 = x0 * x0;\n";
-                        ok << "const double *pa = hy_lds_tape + " << A[0] << ";\ndouble acc = 0.0;\n" << jloop("0u", "j < jn")
+                        r0 << "{\nconst double x0 = " << T(A[0], "0u") << ";\nconst double q0 = x0 * x0;\n";
+                        rk << "const double *pa = hy_lds_tape + " << A[0] << ";\ndouble acc = 0.0;\n" << jloop("0u", "j < jn")
                            << " acc += pa[k - j] * pa[j];\n" << reduce("acc")
                            << "const double hv = pa[k / 2u];\nconst double tu = odd ? acc : (acc + acc) + hv * hv;\n";
                         std::vector<std::string> t0, tk;
                         for (std::size_t a = 0; a < nargs; ++a) {
                             const auto s_ = std::to_string(a);
-                            o0 << "const double q0_" << s_ << " = __shfl(q0, (int)(" << L0 << " + " << a * sp << "u), 64);\n";
-                            ok << "const double t" << s_ << " = __shfl(tu, (int)(" << L0 << " + " << a * sp << "u), 64);\n";
+                            r0 << "const double q0_" << s_ << " = __shfl(q0, (int)(" << L0 << " + " << a * sp << "u), 64);\n";
+                            rk << "const double t" << s_ << " = __shfl(tu, (int)(" << L0 << " + " << a * sp << "u), 64);\n";
                             t0.push_back("q0_" + s_);
                             tk.push_back("t" + s_);
                         }
-                        o0 << T(O, "0u") << " = " << pairwise(t0) << ";\n}\n";
-                        ok << "const double tot = " << pairwise(tk) << ";\n" << T(O, "k") << " = odd ? tot + tot : tot;\n}\n";
+                        r0 << T(O, "0u") << " = " << pairwise(t0) << ";\n}\n";
+                        rk << "const double tot = " << pairwise(tk) << ";\n" << T(O, "k") << " = odd ? tot + tot : tot;\n}\n";
                     }
                     break;
                 }
                 case spec::pow: {
                     const auto ex = n0.args[1].value;
                     const auto U = own_row();
-                    o0 << T(O, "0u") << " = hy_pow_eval(" << T(A[0], "0u") << ", " << fp_literal(ex) << ");\n";
+                    r0 << T(O, "0u") << " = hy_pow_eval(" << T(A[0], "0u") << ", " << fp_literal(ex) << ");\n";
                     if (ex == 0.5) {
                         // sqrt (src/math/pow.cpp:432-474).
-                        ok << "{\nconst double *pu = hy_lds_tape + " << U << ";\nconst double a_0 = pu[0];\ndouble fac = "
+                        rk << "{\nconst double *pu = hy_lds_tape + " << U << ";\nconst double a_0 = pu[0];\ndouble fac = "
                            << T(A[0], "k") << ", acc = 0.0;\nconst unsigned jmax = (k & 1u) ? (k - 1u) / 2u : (k - 2u) / 2u;\n"
                            << jloop("1u", "j <= jmax") << " acc += pu[k - j] * pu[j];\n" << reduce("acc")
                            << "if ((k & 1u) == 0u) { const double hv = pu[k / 2u]; fac = fac - hv * hv; }\n"
@@ -602,13 +692,13 @@ emitted_module emit_staged(const taylor_program &p, const emit_options &opts, st
                            << T(O, "k") << " = fac / (a_0 + a_0);\n}\n";
                     } else if (ex == 2.) {
                         // square (src/math/pow.cpp:395-430).
-                        ok << "{\nconst double *pa = hy_lds_tape + " << A[0]
+                        rk << "{\nconst double *pa = hy_lds_tape + " << A[0]
                            << ";\nconst unsigned odd = k & 1u, jn = odd ? (k + 1u) / 2u : k / 2u;\ndouble acc = 0.0;\n"
                            << jloop("0u", "j < jn") << " acc += pa[k - j] * pa[j];\n" << reduce("acc")
                            << "const double hv = pa[k / 2u];\n"
                            << T(O, "k") << " = odd ? acc + acc : (acc + acc) + hv * hv;\n}\n";
                     } else {
-                        ok << "{\nconst double *pb = hy_lds_tape + " << A[0] << " + k, *pu = hy_lds_tape + " << U
+                        rk << "{\nconst double *pb = hy_lds_tape + " << A[0] << " + k, *pu = hy_lds_tape + " << U
                            << ";\nconst double ex = " << fp_literal(ex) << ", kex = (double)k * ex;\ndouble acc = 0.0;\n"
                            << jloop("0u", "j < k") << " {\nconst double sf = kex - (double)j * (ex + 1.0);\n"
                            << "acc += sf * (pb[-(int)j] * pu[j]);\n}\n" << reduce("acc")
@@ -619,48 +709,149 @@ emitted_module emit_staged(const taylor_program &p, const emit_options &opts, st
                 case spec::sin:
                 case spec::cos: {
                     const bool is_sin = grp.sp == spec::sin;
-                    o0 << T(O, "0u") << " = " << (is_sin ? "hy_sin(" : "hy_cos(") << T(A[0], "0u") << ");\n";
-                    ok << "{\nconst double *pd = hy_lds_tape + " << D << " + k, *pb = hy_lds_tape + " << A[0]
+                    r0 << T(O, "0u") << " = " << (is_sin ? "hy_sin(" : "hy_cos(") << T(A[0], "0u") << ");\n";
+                    rk << "{\nconst double *pd = hy_lds_tape + " << D << " + k, *pb = hy_lds_tape + " << A[0]
                        << ";\ndouble acc = 0.0;\n" << jloop("1u", "j <= k") << " acc += (double)j * (pd[-(int)j] * pb[j]);\n"
                        << reduce("acc") << T(O, "k") << " = acc / " << (is_sin ? "(double)k" : "-(double)k") << ";\n}\n";
                     break;
                 }
                 case spec::exp: {
                     const auto U = own_row();
-                    o0 << T(O, "0u") << " = exp(" << T(A[0], "0u") << ");\n";
-                    ok << "{\nconst double *pu = hy_lds_tape + " << U << " + k, *pb = hy_lds_tape + " << A[0]
+                    r0 << T(O, "0u") << " = exp(" << T(A[0], "0u") << ");\n";
+                    rk << "{\nconst double *pu = hy_lds_tape + " << U << " + k, *pb = hy_lds_tape + " << A[0]
                        << ";\ndouble acc = 0.0;\n" << jloop("1u", "j <= k") << " acc += (double)j * (pu[-(int)j] * pb[j]);\n"
                        << reduce("acc") << T(O, "k") << " = acc / (double)k;\n}\n";
                     break;
                 }
                 case spec::log: {
                     const auto U = own_row();
-                    o0 << T(O, "0u") << " = log(" << T(A[0], "0u") << ");\n";
-                    ok << "{\nconst double *pb = hy_lds_tape + " << A[0] << " + k, *pu = hy_lds_tape + " << U
+                    r0 << T(O, "0u") << " = log(" << T(A[0], "0u") << ");\n";
+                    rk << "{\nconst double *pb = hy_lds_tape + " << A[0] << " + k, *pu = hy_lds_tape + " << U
                        << ";\ndouble ret = (double)k * pb[0];\ndouble acc = 0.0;\n" << jloop("1u", "j < k")
                        << " acc += (double)j * (pb[-(int)j] * pu[j]);\n" << reduce("acc") << "if (k > 1u) ret = ret - acc;\n"
                        << T(O, "k") << " = ret / ((double)k * " << T(A[0], "0u") << ");\n}\n";
                     break;
                 }
                 case spec::time:
-                    o0 << T(O, "0u") << " = t_hi;\n";
-                    ok << T(O, "k") << " = (k == 1u) ? 1.0 : 0.0;\n";
+                    r0 << T(O, "0u") << " = t_hi;\n";
+                    rk << T(O, "k") << " = (k == 1u) ? 1.0 : 0.0;\n";
                     break;
                 case spec::number:
-                    o0 << T(O, "0u") << " = " << C[0] << ";\n";
-                    ok << T(O, "k") << " = 0.0;\n";
+                    r0 << T(O, "0u") << " = " << C[0] << ";\n";
+                    rk << T(O, "k") << " = 0.0;\n";
                     break;
                 default:
                     break;
             }
+            // The value of the node stays in a register (hy_v): its row / cell, then what follows it - linear functions of it
+            // and the recursion of the state variables it defines - without another trip through LDS (see `followers`).
+            const auto finish = [&](std::ostringstream &dst, const std::string &body, const std::string &kk) {
+                const auto tgt = T(O, kk) + " = ";
+                std::string b = body;
+                for (std::size_t pos = b.find(tgt); pos != std::string::npos; pos = b.find(tgt, pos)) {
+                    b.replace(pos, tgt.size(), "hy_v = ");
+                    pos += 7u;
+                }
+                dst << "{\ndouble hy_v;\n" << b << tgt << "hy_v;\n";
+                std::uint32_t depth = 0;
+                // f_of(l): the node whose value sits in `var` on lane l.
+                std::function<void(const std::function<std::uint32_t(std::uint32_t)> &, const std::string &)> tail
+                    = [&](const std::function<std::uint32_t(std::uint32_t)> &f_of, const std::string &var) {
+                          const auto rep = f_of(0);
+                          // Followers.
+                          for (std::size_t fi = 0; fi < followers[rep].size(); ++fi) {
+                              const auto sel = [&, fi](std::uint32_t l) { return followers[f_of(l)][fi]; };
+                              const auto &nf = p.nodes[sel(0)];
+                              const auto an = is_uvar(nf.args[0]) ? 1u : 0u; // position of the number / parameter
+                              std::string cst;
+                              if (nf.args[an].type == operand::kind::par) {
+                                  std::vector<std::uint32_t> v(LANES);
+                                  for (std::uint32_t l = 0; l < LANES; ++l) {
+                                      v[l] = p.nodes[sel(l)].args[an].idx;
+                                  }
+                                  cst = lt.add_p(std::move(v));
+                              } else {
+                                  bool same = true;
+                                  for (std::uint32_t l = 0; l < LANES; ++l) {
+                                      const auto x = p.nodes[sel(l)].args[an].value, y = nf.args[an].value;
+                                      same = same && (x == y || (x != x && y != y)) && std::signbit(x) == std::signbit(y);
+                                  }
+                                  if (same) {
+                                      cst = fp_literal(nf.args[an].value);
+                                  } else {
+                                      std::vector<double> v(LANES);
+                                      for (std::uint32_t l = 0; l < LANES; ++l) {
+                                          v[l] = p.nodes[sel(l)].args[an].value;
+                                      }
+                                      cst = lt.add_d(std::move(v));
+                                  }
+                              }
+                              std::string ex;
+                              const bool k0 = kk == "0u";
+                              switch (spec_of[sel(0)]) {
+                                  case spec::prod:
+                                      // (hy_diff_prod(): a leading number -1 negates.)
+                                      ex = (an == 0u && nf.args[0].type == operand::kind::num && nf.args[0].value == -1.) ? "-" + var
+                                                                                                                           : cst + " * " + var;
+                                      break;
+                                  case spec::sub:
+                                      ex = an == 1u ? (k0 ? var + " - " + cst : var) : (k0 ? cst + " - " + var : "-" + var);
+                                      break;
+                                  default: // div: u / c
+                                      ex = var + " / " + cst;
+                                      break;
+                              }
+                              const auto nv = "hy_w" + std::to_string(depth++);
+                              const auto OF = urow([&](std::uint32_t l) { return leader[l] != 0 ? row_of(n_eq + sel(l)) : dummy_row; });
+                              reg_hist[OF] = hist[n_eq + sel(0)] != 0;
+                              dst << "const double " << nv << " = " << ex << ";\n" << T(OF, kk) << " = " << nv << ";\n";
+                              tail(sel, nv);
+                          }
+                          // State variables defined by this u variable: x^[k+1] = u^[k] / (k + 1), and the state variables
+                          // defined by THOSE one order further.
+                          for (std::size_t si = 0; si < sv_of[rep].size(); ++si) {
+                              const auto sv_sel = [&, si](std::uint32_t l) { return sv_of[f_of(l)][si]; };
+                              const auto SV = urow([&](std::uint32_t l) { return leader[l] != 0 ? row_of(sv_sel(l)) : dummy_row; });
+                              const bool k0 = kk == "0u";
+                              const auto sv1 = "hy_x" + std::to_string(depth++);
+                              dst << "const double " << sv1 << " = " << var << " / " << (k0 ? "1.0" : "(double)(k + 1u)") << ";\n";
+                              dst << (k0 ? "" : "if (k + 1u <= HY_ORDER) ") << "hy_lds_tape[" << SV << " + " << (k0 ? "1u" : "k + 1u") << "] = " << sv1
+                                  << ";\n";
+                              for (std::size_t ci = 0; ci < chain_of[sv_sel(0)].size(); ++ci) {
+                                  const auto CH = urow([&](std::uint32_t l) {
+                                      return leader[l] != 0 ? row_of(chain_of[sv_sel(l)][ci]) : dummy_row;
+                                  });
+                                  if (k0) {
+                                      // x^[1] = v^[0] / 1 (the state), x^[2] = v^[1] / 2.
+                                      dst << "hy_lds_tape[" << CH << " + 1u] = hy_lds_tape[" << SV << "] / 1.0;\n";
+                                      dst << "hy_lds_tape[" << CH << " + 2u] = " << sv1 << " / 2.0;\n";
+                                  } else {
+                                      dst << "if (k + 2u <= HY_ORDER) hy_lds_tape[" << CH << " + k + 2u] = " << sv1 << " / (double)(k + 2u);\n";
+                                  }
+                              }
+                          }
+                      };
+                tail([&](std::uint32_t l) { return node_of[l]; }, "hy_v");
+                dst << "}\n";
+            };
+            finish(o0, r0.str(), "0u");
+            finish(ok, rk.str(), "k");
         }
     }
     o0 << sync;
     ok << sync;
 
     // ---- state variables: recursion x^[k] = rhs^[k-1] / k (taylor_compute_sv_diff(), src/taylor_02.cpp:245-287) ----
+    // (Only the state variables whose recursion is not fused into the lanes of their right-hand sides - see `followers`.)
     std::ostringstream svk;
-    const auto sv_rounds = (n_eq + LANES - 1u) / LANES;
+    std::vector<std::uint32_t> sv_rest;
+    for (std::uint32_t i = 0; i < n_eq; ++i) {
+        if (sv_fused[i] == 0) {
+            sv_rest.push_back(i);
+        }
+    }
+    const auto n_rest = static_cast<std::uint32_t>(sv_rest.size());
+    const auto sv_rounds = (n_rest + LANES - 1u) / LANES;
     bool sv_any_par = false;
     for (std::uint32_t r = 0; r < sv_rounds; ++r) {
         std::vector<std::uint32_t> own(LANES), def(LANES), isv(LANES), pidx(LANES, 0u), dstr(LANES, 1u);
@@ -668,9 +859,9 @@ emitted_module emit_staged(const taylor_program &p, const emit_options &opts, st
         bool any_var = false, any_num = false, any_par = false;
         for (std::uint32_t l = 0; l < LANES; ++l) {
             const auto i = r * LANES + l;
-            const auto ii = i < n_eq ? i : r * LANES;
+            const auto ii = sv_rest[i < n_rest ? i : r * LANES];
             const auto &d = p.sv_defs[ii];
-            own[l] = i < n_eq ? row_of(i) : dummy_row;
+            own[l] = i < n_rest ? row_of(ii) : dummy_row;
             isv[l] = is_uvar(d) ? 1u : 0u;
             def[l] = is_uvar(d) ? row_of(d.idx) : dummy_row;
             if (is_uvar(d)) {
@@ -689,7 +880,7 @@ emitted_module emit_staged(const taylor_program &p, const emit_options &opts, st
         bool any_slab = false;
         for (std::uint32_t l = 0; l < LANES; ++l) {
             const auto i = r * LANES + l;
-            const auto &d = p.sv_defs[i < n_eq ? i : r * LANES];
+            const auto &d = p.sv_defs[sv_rest[i < n_rest ? i : r * LANES]];
             dstr[l] = (is_uvar(d) && hist[d.idx] == 0) ? 0u : 1u;
             any_slab = any_slab || dstr[l] == 0u;
         }
@@ -709,7 +900,9 @@ emitted_module emit_staged(const taylor_program &p, const emit_options &opts, st
         }
         svk << "HY_T(" << O << ", k) = " << val << ";\n";
     }
-    svk << sync;
+    if (n_rest != 0u) {
+        svk << sync;
+    }
     (void)sv_any_par;
 
     // ---- module text ----
@@ -997,7 +1190,7 @@ for (;;) {
                 + " rounds, " + std::to_string(n_generic) + " through the interpreter), one system per workgroup of "
                 + std::to_string(LANES) + " lanes, tape in LDS (" + std::to_string(tape_bytes) + " B, "
                 + std::to_string(std::min<std::uint64_t>(per_cu, 32u / wps)) + " systems per CU), "
-                + std::to_string(lt.urows.size() + 2u * lt.drows.size() + 2u * lt.prows.size()) + " table registers per lane, " + std::to_string(n_hist) + " rows + " + std::to_string(n_slab) + " cells, " + (strict ? std::string("strict order of the additions") : std::to_string(n_split) + " groups with split convolutions");
+                + std::to_string(lt.urows.size() + 2u * lt.drows.size() + 2u * lt.prows.size()) + " table registers per lane, " + std::to_string(n_hist) + " rows + " + std::to_string(n_slab) + " cells, " + std::to_string(std::count_if(parent.begin(), parent.end(), [](int x) { return x >= 0; })) + " followers and " + std::to_string(n_eq - n_rest) + " state-variable recursions fused, " + (strict ? std::string("strict order of the additions") : std::to_string(n_split) + " groups with split convolutions");
     return ret;
 }
 

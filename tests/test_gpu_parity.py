@@ -1784,7 +1784,7 @@ def test_compact_mode_keeps_the_on_chip_kernels():
     assert all(r[0] == OC.time_limit for r in a.propagate_res)
     assert max(abs(x[3] - y[3]) for x, y in zip(a.propagate_res, oc.prop_res)) <= 1
     assert np.array_equal(np.asarray(a.time), oc.time_hi)
-    assert row_nbody_err(a.state, oc.state.reshape(36, n)) <= 1e6 * EPS
+    assert row_rel_err(a.state, oc.state.reshape(36, n)) <= 1e6 * EPS
 
     # A small decomposition: straight-line code with the compact order of the additions (kw::sum_order = running), bit
     # for bit the kernel the default mode builds with that order - and the oracle's compact flavour to the usual
