@@ -30,6 +30,7 @@
 // per-system variant is bound by the latency of its HBM tape: every coefficient is re-read O(order) times).
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <functional>
 #include <map>
 #include <sstream>
@@ -380,10 +381,21 @@ emitted_module emit_staged(const taylor_program &p, const emit_options &opts, st
         return ret;
     }
     // Systems per CU by LDS, and the lanes of a workgroup. The tapes limit a CU to a few systems (7 for the outer Solar
-    // System): every system gets two or four wavefronts - lanes are spread over the nodes of a group AND over the terms of
-    // their convolutions (below) - so that a CU holds 12 ... 16 wavefronts which hide each other's LDS latency.
+    // System); the lanes of a system are spread over the nodes of a group AND - where a group is small - over the terms of
+    // their convolutions (below).
     const auto per_cu = std::min<std::uint64_t>(lds_per_cu / (tape_bytes + lds_reserve), 32u);
-    const std::uint32_t wps = per_cu <= 4u ? 4u : (per_cu <= 8u ? 2u : 1u);
+    // Measured (profiles/r06_staged_wps.log, 262 144 systems): ONE wavefront per system wins on every decomposition - 7.2e7
+    // against 5.5e7 (two) and 3.5e7 (four wavefronts) on the outer Solar System, 2.5e7 / 1.9e7 / 5.9e6 on 511 u variables:
+    // a level then ends with a wave-level synchronisation (LDS operations of a wavefront complete in order: no s_barrier),
+    // and the 5 ... 10 systems of a CU hide each other's latency. Four wavefronts only where ONE tape fills the LDS of a CU.
+    std::uint32_t wps = per_cu >= 2u ? 1u : 4u;
+    if (const char *e = std::getenv("HEYOKA_AMD_STAGED_WPS")) {
+        // (Experiment switch: wavefronts per system.)
+        const auto w = static_cast<std::uint32_t>(std::atoi(e));
+        if (w == 1u || w == 2u || w == 4u) {
+            wps = w;
+        }
+    }
     const std::uint32_t LANES = 64u * wps;
 
     std::vector<group> groups;
