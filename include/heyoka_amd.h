@@ -272,7 +272,10 @@ int hy_tab_with_events(hy_tab);
  * timing is on (hy_tab_set_event_timing(): one stream synchronisation per phase). */
 int hy_tab_set_event_timing(hy_tab, int on);
 int hy_tab_get_event_stats(hy_tab, double *out8);
-/* Ready-made callbacks which count their invocations in the uint64_t `user` points to (the terminal one continues). */
+/* Ready-made callbacks which count their invocations in the uint64_t `user` points to (the terminal one continues).
+ * When EVERY event of an integrator has one of them as its callback, the step applies the events on the device (counts per
+ * event, cooldown and "continuing" outcome of the first terminal event of a lane: what the host loop of
+ * src/taylor_adaptive_batch.cpp:837-1030 does) and adds the counts to the counters once per step: no per-event host work. */
 void hy_event_counter_nt(hy_tab, double time, int d_sgn, uint32_t batch_idx, void *user);
 int hy_event_counter_t(hy_tab, int d_sgn, uint32_t batch_idx, void *user);
 /* reset_cooldowns(): batch_idx < 0 -> all the lanes. */

@@ -8,7 +8,7 @@
 set -u
 TAG=${1:-r02}
 shift || true
-WLS=${@:-outer_ss two_body nbody64}
+WLS=${@:-outer_ss two_body nbody64 outer_ss_forced_table nbody6_j2_mixed sine_lattice16_mixed}
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 R=$(pwd)
 export TMPDIR=/tmp
