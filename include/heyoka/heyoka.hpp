@@ -6,6 +6,7 @@
 #include "../../heyoka_amd/csrc/ensemble.hpp"
 #include "../../heyoka_amd/csrc/model.hpp"
 #include "../../heyoka_amd/csrc/cfunc.hpp"
+#include "../../heyoka_amd/csrc/logging.hpp"
 #include "math/constants.hpp"
 #include "math/kepDE.hpp"
 #include "math/kepF.hpp"

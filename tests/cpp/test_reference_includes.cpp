@@ -11,6 +11,7 @@
 #include <heyoka/func.hpp>
 #include <heyoka/heyoka.hpp>
 #include <heyoka/kw.hpp>
+#include <heyoka/logging.hpp>
 #include <heyoka/model/nbody.hpp>
 #include <heyoka/math.hpp>
 #include <heyoka/models.hpp>
@@ -25,6 +26,9 @@ namespace hy = heyoka;
 
 int main(int argc, char **)
 {
+    // include/heyoka/logging.hpp:19-24 (the reference's default level is warn: restored right away).
+    heyoka::set_logger_level_err();
+    heyoka::set_logger_level_warn();
     // tutorial/batch_mode.cpp
     auto [x, v] = make_vars("x", "v");
     const auto batch_size = 4u;
