@@ -11,7 +11,7 @@ cd "$R/heyoka_amd/csrc"
 for f in *.cpp; do echo "g++ $FLAGS -c $f -o $O/${f%.cpp}.o"; done | xargs -P "$(nproc)" -I{} sh -c "{}"
 g++ "$O"/*.o -shared -fsanitize=address,undefined -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib -lamdhip64 -lhiprtc -pthread -o "$O/libheyoka_amd.so"
 cd "$R"
-for t in test_reference_cases test_reference_event_cases test_reference_includes; do
+for t in test_reference_cases test_reference_event_cases test_reference_includes test_round6_generators; do
     g++ -std=c++20 -O1 -g -fsanitize=address,undefined -Iinclude tests/cpp/$t.cpp -o "$O/$t" -L"$O" -lheyoka_amd -Wl,-rpath,"$O" -Wl,-rpath,/opt/rocm/lib
     ASAN_OPTIONS=detect_leaks=0 "$O/$t"
 done

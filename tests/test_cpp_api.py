@@ -131,3 +131,26 @@ def test_reference_event_detection_cases_on_gpu():
     out = subprocess.run([EXE4, "gpu"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr + out.stdout
     assert "GPU cases OK" in out.stdout
+
+
+EXE5 = os.path.join(ROOT, "heyoka_amd", "csrc", "_build", "test_round6_generators")
+
+
+def test_round6_generators_through_the_cpp_api():
+    """tests/cpp/test_round6_generators.cpp: a system with two classes of clusters on the multi-class wave-cluster stepper,
+    the same on the staged / HBM-tape table steppers (developer switches), the outer Solar System forced onto the staged
+    stepper with and without kw::compact_mode - constructed through the C++ drop-in class (also the program which
+    tests/run_sanitized_host_tests.sh runs under ASan / UBSan)."""
+    src = os.path.join(ROOT, "tests", "cpp", "test_round6_generators.cpp")
+    lib = os.path.join(ROOT, "heyoka_amd", "libheyoka_amd.so")
+    if not (os.path.exists(EXE5) and os.path.getmtime(EXE5) > max(os.path.getmtime(src), os.path.getmtime(lib))):
+        os.makedirs(os.path.dirname(EXE5), exist_ok=True)
+        subprocess.check_call(
+            ["g++", "-std=c++20", "-O1", "-I" + os.path.join(ROOT, "include"), src, "-o", EXE5,
+             "-L" + os.path.join(ROOT, "heyoka_amd"), "-lheyoka_amd", "-Wl,-rpath," + os.path.join(ROOT, "heyoka_amd"),
+             "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([EXE5], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.splitlines()
+    assert "2 classes of clusters" in lines[0] and "table mode (staged)" in lines[1] and "tape in HBM" in out.stdout
+    assert lines[-1] == "round-6 generators under the sanitizers OK"
