@@ -214,6 +214,86 @@ emitted_module emit_staged(const taylor_program &p, const emit_options &opts, st
     // 22 KB instead of 39 KB per system, 7 systems per CU instead of 4.
     std::vector<spec> spec_of(n_nodes);
     std::vector<std::string> key_of(n_nodes);
+    for (std::uint32_t i = 0; i < n_nodes; ++i) {
+        spec_of[i] = classify(p.nodes[i], key_of[i]);
+    }
+    // Virtual differences. A difference d = a - b of two u variables which is read ONLY by convolutions (the coordinate
+    // differences of an N-body system: operands of a sum of squares and of the products d r^-3) needs no row of its own:
+    // its consumers subtract on the fly, d^[j] = a^[j] - b^[j] - the same operation on the same operands, the same value bit
+    // for bit. 45 of the 126 rows of the outer Solar System go (10 systems per CU instead of 7: the throughput of this
+    // stepper is systems in flight over the latency of a step) and the level of the differences with them.
+    // (HEYOKA_AMD_TABLE_LDS=6 switches it off - A/B.)
+    std::vector<char> virt(n_nodes, 0);
+    if (opts.dev.table_lds != 6 && opts.dev.table_lds != 3) {
+        std::vector<char> ok_virt(n_nodes, 0);
+        for (std::uint32_t i = 0; i < n_nodes; ++i) {
+            const auto &n = p.nodes[i];
+            ok_virt[i] = spec_of[i] == spec::sub && n.args.size() == 2u && is_uvar(n.args[0]) && is_uvar(n.args[1]);
+        }
+        for (const auto u : p.ev_u) {
+            if (u >= n_eq) {
+                ok_virt[u - n_eq] = 0;
+            }
+        }
+        for (const auto &d : p.sv_defs) {
+            if (is_uvar(d) && d.idx >= n_eq) {
+                ok_virt[d.idx - n_eq] = 0;
+            }
+        }
+        std::vector<char> used(n_nodes, 0);
+        for (std::uint32_t i = 0; i < n_nodes; ++i) {
+            const auto &n = p.nodes[i];
+            const bool conv_reader = (spec_of[i] == spec::sum_sq)
+                                     || (spec_of[i] == spec::prod && n.args.size() == 2u && is_uvar(n.args[0]) && is_uvar(n.args[1]));
+            for (const auto &o : n.args) {
+                if (is_uvar(o) && o.idx >= n_eq) {
+                    used[o.idx - n_eq] = 1;
+                    if (!conv_reader) {
+                        ok_virt[o.idx - n_eq] = 0;
+                    }
+                }
+            }
+            for (const auto d : n.deps) {
+                if (d >= n_eq) {
+                    ok_virt[d - n_eq] = 0;
+                }
+            }
+            // (A product of two virtual differences, or a sum of squares with a mix of virtual and stored arguments, keeps
+            // the code simple by storing: decided below, once the flags of all the arguments are known.)
+        }
+        for (std::uint32_t i = 0; i < n_nodes; ++i) {
+            virt[i] = (ok_virt[i] != 0 && used[i] != 0) ? 1 : 0;
+        }
+        // Consumers want uniform shapes: a sum of squares all of whose arguments are virtual (or none), a product with at
+        // most one virtual factor; and a virtual difference must not read another one.
+        bool changed = true;
+        while (changed) {
+            changed = false;
+            const auto is_virt = [&](const operand &o) { return is_uvar(o) && o.idx >= n_eq && virt[o.idx - n_eq] != 0; };
+            const auto drop = [&](const operand &o) {
+                if (is_virt(o)) {
+                    virt[o.idx - n_eq] = 0;
+                    changed = true;
+                }
+            };
+            for (std::uint32_t i = 0; i < n_nodes; ++i) {
+                const auto &n = p.nodes[i];
+                if (spec_of[i] == spec::sum_sq) {
+                    const auto nv = std::count_if(n.args.begin(), n.args.end(), is_virt);
+                    if (nv != 0 && static_cast<std::size_t>(nv) != n.args.size()) {
+                        for (const auto &o : n.args) {
+                            drop(o);
+                        }
+                    }
+                } else if (spec_of[i] == spec::prod && n.args.size() == 2u && is_virt(n.args[0]) && is_virt(n.args[1])) {
+                    drop(n.args[1]);
+                } else if (virt[i] != 0 && (is_virt(n.args[0]) || is_virt(n.args[1]))) {
+                    virt[i] = 0;
+                    changed = true;
+                }
+            }
+        }
+    }
     std::vector<char> hist(n_u, 0);
     for (std::uint32_t i = 0; i < n_eq; ++i) {
         hist[i] = 1;
@@ -223,10 +303,15 @@ emitted_module emit_staged(const taylor_program &p, const emit_options &opts, st
     }
     for (std::uint32_t i = 0; i < n_nodes; ++i) {
         const auto &n = p.nodes[i];
-        spec_of[i] = classify(n, key_of[i]);
         const auto mark_arg = [&](std::size_t a) {
             if (a < n.args.size() && is_uvar(n.args[a])) {
                 hist[n.args[a].idx] = 1;
+                // (A virtual difference is read through the rows of ITS operands.)
+                if (n.args[a].idx >= n_eq && virt[n.args[a].idx - n_eq] != 0) {
+                    for (const auto &o2 : p.nodes[n.args[a].idx - n_eq].args) {
+                        hist[o2.idx] = 1;
+                    }
+                }
             }
         };
         const auto self = n_eq + i;
@@ -334,7 +419,16 @@ emitted_module emit_staged(const taylor_program &p, const emit_options &opts, st
         } else {
             for (const auto &o : p.nodes[i].args) {
                 if (is_uvar(o) && o.idx >= n_eq) {
-                    l = std::max(l, level[o.idx - n_eq] + 1u);
+                    if (virt[o.idx - n_eq] != 0) {
+                        // (Read through the rows of its operands: no level of its own.)
+                        for (const auto &o2 : p.nodes[o.idx - n_eq].args) {
+                            if (o2.idx >= n_eq) {
+                                l = std::max(l, level[o2.idx - n_eq] + 1u);
+                            }
+                        }
+                    } else {
+                        l = std::max(l, level[o.idx - n_eq] + 1u);
+                    }
                 }
             }
         }
@@ -359,14 +453,15 @@ emitted_module emit_staged(const taylor_program &p, const emit_options &opts, st
     // Layout: rows of the history variables (state variables first: row i = state variable i), the dummy row, the slab.
     std::vector<std::uint32_t> base(n_u, 0u);
     std::uint32_t n_hist = 0, n_slab = 0;
+    const auto is_virt_u = [&](std::uint32_t u) { return u >= n_eq && virt[u - n_eq] != 0; };
     for (std::uint32_t u = 0; u < n_u; ++u) {
-        if (hist[u] != 0) {
+        if (hist[u] != 0 && !is_virt_u(u)) {
             base[u] = (n_hist++) * P;
         }
     }
     const std::uint32_t dummy_row = n_hist * P;
     for (std::uint32_t u = 0; u < n_u; ++u) {
-        if (hist[u] == 0) {
+        if (hist[u] == 0 && !is_virt_u(u)) {
             base[u] = (n_hist + 1u) * P + (n_slab++);
         }
     }
@@ -402,15 +497,15 @@ emitted_module emit_staged(const taylor_program &p, const emit_options &opts, st
     {
         std::map<std::pair<std::uint32_t, std::string>, std::size_t> gidx;
         for (std::uint32_t i = 0; i < n_nodes; ++i) {
-            if (parent[i] >= 0) {
-                continue; // (computed by the lanes of the variable it follows)
+            if (parent[i] >= 0 || virt[i] != 0) {
+                continue; // (computed by the lanes of the variable it follows / never stored)
             }
             // (Whether the result and the arguments sit in a row or in a slab cell is part of the shape of the code.)
             std::string key = key_of[i];
             if (spec_of[i] != spec::generic) {
                 key += hist[n_eq + i] != 0 ? ":H" : ":S";
                 for (const auto &o : p.nodes[i].args) {
-                    key += !is_uvar(o) ? '-' : (hist[o.idx] != 0 ? 'h' : 's');
+                    key += !is_uvar(o) ? '-' : (is_virt_u(o.idx) ? 'V' : (hist[o.idx] != 0 ? 'h' : 's'));
                 }
                 key += tail_sig(i);
             }
@@ -525,7 +620,19 @@ emitted_module emit_staged(const taylor_program &p, const emit_options &opts, st
             }
             // Arguments: tape rows of the u variables; numbers as literals when every node of the group has the same
             // value, per-lane registers otherwise; parameters as per-lane values loaded with the system.
-            std::vector<std::string> A(nargs), C(nargs);
+            // (A2[a]: the row of the subtrahend when argument a is a virtual difference - A[a] then holds the minuend's.)
+            std::vector<std::string> A(nargs), A2(nargs), C(nargs);
+            const auto arg_rows = [&](const std::function<const operand &(std::uint32_t)> &arg_of, std::string &r1, std::string &r2) {
+                if (is_virt_u(arg_of(0).idx)) {
+                    r1 = urow([&](std::uint32_t l) { return row_of(p.nodes[arg_of(l).idx - n_eq].args[0].idx); });
+                    r2 = urow([&](std::uint32_t l) { return row_of(p.nodes[arg_of(l).idx - n_eq].args[1].idx); });
+                    reg_hist[r1] = true;
+                    reg_hist[r2] = true;
+                } else {
+                    r1 = urow([&](std::uint32_t l) { return row_of(arg_of(l).idx); });
+                    reg_hist[r1] = hist[arg_of(0).idx] != 0;
+                }
+            };
             for (std::size_t a = 0; a < nargs; ++a) {
                 const auto &o = n0.args[a];
                 if (is_uvar(o)) {
@@ -533,8 +640,7 @@ emitted_module emit_staged(const taylor_program &p, const emit_options &opts, st
                         // (Sum of squares over units: every lane holds the row of ITS argument, in A[0].)
                         continue;
                     }
-                    A[a] = urow([&](std::uint32_t l) { return row_of(p.nodes[node_of[l]].args[a].idx); });
-                    reg_hist[A[a]] = hist[o.idx] != 0;
+                    arg_rows([&, a](std::uint32_t l) -> const operand & { return p.nodes[node_of[l]].args[a]; }, A[a], A2[a]);
                 } else if (o.type == operand::kind::par) {
                     std::vector<std::uint32_t> v(LANES);
                     for (std::uint32_t l = 0; l < LANES; ++l) {
@@ -559,7 +665,7 @@ emitted_module emit_staged(const taylor_program &p, const emit_options &opts, st
                 }
             }
             if (nu > 1u) {
-                A[0] = urow([&](std::uint32_t l) { return row_of(p.nodes[node_of[l]].args[unit_of[l]].idx); });
+                arg_rows([&](std::uint32_t l) -> const operand & { return p.nodes[node_of[l]].args[unit_of[l]]; }, A[0], A2[0]);
                 reg_hist[A[0]] = true;
             }
             std::string D;
@@ -624,10 +730,23 @@ emitted_module emit_staged(const taylor_program &p, const emit_options &opts, st
                 case spec::prod: {
                     const bool neg = n0.args[0].type == operand::kind::num && n0.args[0].value == -1.;
                     if (v0 && v1) {
-                        r0 << T(O, "0u") << " = " << T(A[0], "0u") << " * " << T(A[1], "0u") << ";\n";
-                        rk << "{\nconst double *pa = hy_lds_tape + " << A[0] << " + k, *pb = hy_lds_tape + " << A[1]
-                           << ";\ndouble acc = 0.0;\n" << jloop("0u", "j <= k") << " acc += pa[-(int)j] * pb[j];\n"
-                           << reduce("acc") << T(O, "k") << " = acc;\n}\n";
+                        // (A virtual factor is read as the difference of the rows of its operands.)
+                        const auto op0 = [&](const std::string &ptr, const std::string &idx, std::size_t a) {
+                            return A2[a].empty() ? ptr + "[" + idx + "]" : "(" + ptr + "[" + idx + "] - " + ptr + "2[" + idx + "])";
+                        };
+                        const auto val0 = [&](std::size_t a) {
+                            return A2[a].empty() ? T(A[a], "0u") : "(" + T(A[a], "0u") + " - " + T(A2[a], "0u") + ")";
+                        };
+                        r0 << T(O, "0u") << " = " << val0(0) << " * " << val0(1) << ";\n";
+                        rk << "{\nconst double *pa = hy_lds_tape + " << A[0] << " + k, *pb = hy_lds_tape + " << A[1] << ";\n";
+                        if (!A2[0].empty()) {
+                            rk << "const double *pa2 = hy_lds_tape + " << A2[0] << " + k;\n";
+                        }
+                        if (!A2[1].empty()) {
+                            rk << "const double *pb2 = hy_lds_tape + " << A2[1] << ";\n";
+                        }
+                        rk << "double acc = 0.0;\n" << jloop("0u", "j <= k") << " acc += " << op0("pa", "-(int)j", 0) << " * " << op0("pb", "j", 1)
+                           << ";\n" << reduce("acc") << T(O, "k") << " = acc;\n}\n";
                     } else if (!v0 && !v1) {
                         r0 << T(O, "0u") << " = " << (neg ? "-" + C[1] : C[0] + " * " + C[1]) << ";\n";
                         rk << T(O, "k") << " = 0.0;\n";
@@ -660,11 +779,18 @@ emitted_module emit_staged(const taylor_program &p, const emit_options &opts, st
                     if (nu == 1u) {
                         std::vector<std::string> t0, tk;
                         for (std::size_t a = 0; a < nargs; ++a) {
-                            t0.push_back("(" + T(A[a], "0u") + " * " + T(A[a], "0u") + ")");
+                            const bool va = !A2[a].empty();
+                            const auto x0 = va ? "(" + T(A[a], "0u") + " - " + T(A2[a], "0u") + ")" : T(A[a], "0u");
+                            t0.push_back("(" + x0 + " * " + x0 + ")");
                             const auto s_ = std::to_string(a);
-                            rk << "double t" << s_ << ";\n{\nconst double *pa = hy_lds_tape + " << A[a] << ";\ndouble acc = 0.0;\n"
-                               << jloop("0u", "j < jn") << " acc += pa[k - j] * pa[j];\n" << reduce("acc")
-                               << "const double hv = pa[k / 2u];\nt" << s_ << " = odd ? acc : (acc + acc) + hv * hv;\n}\n";
+                            const auto op = [&](const std::string &idx) { return va ? "(pa[" + idx + "] - pa2[" + idx + "])" : "pa[" + idx + "]"; };
+                            rk << "double t" << s_ << ";\n{\nconst double *pa = hy_lds_tape + " << A[a] << ";\n";
+                            if (va) {
+                                rk << "const double *pa2 = hy_lds_tape + " << A2[a] << ";\n";
+                            }
+                            rk << "double acc = 0.0;\n" << jloop("0u", "j < jn") << " acc += " << op("k - j") << " * " << op("j") << ";\n"
+                               << reduce("acc") << "const double hv = " << op("k / 2u") << ";\nt" << s_
+                               << " = odd ? acc : (acc + acc) + hv * hv;\n}\n";
                             tk.push_back("t" + s_);
                         }
                         r0 << T(O, "0u") << " = " << pairwise(t0) << ";\n";
@@ -673,10 +799,16 @@ emitted_module emit_staged(const taylor_program &p, const emit_options &opts, st
                         // One unit of `sp` lanes per argument: the terms of the arguments are collected by wave shuffles
                         // from the first lane of every unit (lane L0 + a * sp), then added pairwise like above.
                         const std::string L0 = urow([&](std::uint32_t l) { return (l % 64u) - ((l % 64u) % lpn); });
-                        r0 << "{\nconst double x0 = " << T(A[0], "0u") << ";\nconst double q0 = x0 * x0;\n";
-                        rk << "const double *pa = hy_lds_tape + " << A[0] << ";\ndouble acc = 0.0;\n" << jloop("0u", "j < jn")
-                           << " acc += pa[k - j] * pa[j];\n" << reduce("acc")
-                           << "const double hv = pa[k / 2u];\nconst double tu = odd ? acc : (acc + acc) + hv * hv;\n";
+                        const bool va = !A2[0].empty();
+                        const auto op = [&](const std::string &idx) { return va ? "(pa[" + idx + "] - pa2[" + idx + "])" : "pa[" + idx + "]"; };
+                        r0 << "{\nconst double x0 = " << (va ? T(A[0], "0u") + " - " + T(A2[0], "0u") : T(A[0], "0u"))
+                           << ";\nconst double q0 = x0 * x0;\n";
+                        rk << "const double *pa = hy_lds_tape + " << A[0] << ";\n";
+                        if (va) {
+                            rk << "const double *pa2 = hy_lds_tape + " << A2[0] << ";\n";
+                        }
+                        rk << "double acc = 0.0;\n" << jloop("0u", "j < jn") << " acc += " << op("k - j") << " * " << op("j") << ";\n"
+                           << reduce("acc") << "const double hv = " << op("k / 2u") << ";\nconst double tu = odd ? acc : (acc + acc) + hv * hv;\n";
                         std::vector<std::string> t0, tk;
                         for (std::size_t a = 0; a < nargs; ++a) {
                             const auto s_ = std::to_string(a);
@@ -1202,7 +1334,7 @@ for (;;) {
                 + " rounds, " + std::to_string(n_generic) + " through the interpreter), one system per workgroup of "
                 + std::to_string(LANES) + " lanes, tape in LDS (" + std::to_string(tape_bytes) + " B, "
                 + std::to_string(std::min<std::uint64_t>(per_cu, 32u / wps)) + " systems per CU), "
-                + std::to_string(lt.urows.size() + 2u * lt.drows.size() + 2u * lt.prows.size()) + " table registers per lane, " + std::to_string(n_hist) + " rows + " + std::to_string(n_slab) + " cells, " + std::to_string(std::count_if(parent.begin(), parent.end(), [](int x) { return x >= 0; })) + " followers and " + std::to_string(n_eq - n_rest) + " state-variable recursions fused, " + (strict ? std::string("strict order of the additions") : std::to_string(n_split) + " groups with split convolutions");
+                + std::to_string(lt.urows.size() + 2u * lt.drows.size() + 2u * lt.prows.size()) + " table registers per lane, " + std::to_string(n_hist) + " rows + " + std::to_string(n_slab) + " cells, " + std::to_string(std::count_if(parent.begin(), parent.end(), [](int x) { return x >= 0; })) + " followers and " + std::to_string(n_eq - n_rest) + " state-variable recursions fused, " + std::to_string(std::count(virt.begin(), virt.end(), char(1))) + " differences never stored, " + (strict ? std::string("strict order of the additions") : std::to_string(n_split) + " groups with split convolutions");
     return ret;
 }
 

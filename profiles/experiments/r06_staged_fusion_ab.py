@@ -16,7 +16,7 @@ cases = {
 }
 hy.set_logger_level("err")
 for name, (mk, st, T, kw) in cases.items():
-    for sw in ("2", "3", "4", "5", "2", "3"):
+    for sw in (os.environ.get("AB_SWITCHES", "2,3,4,5,2,3").split(",")):
         os.environ["HEYOKA_AMD_TABLE_LDS"] = sw
         os.environ["HEYOKA_AMD_EMIT_MODE"] = "table"
         os.environ["HEYOKA_AMD_MULTI_CLASS"] = "0"

@@ -653,7 +653,7 @@ def test_table_mode_small_dag_forced(variant, monkeypatch):
         monkeypatch.setenv("HEYOKA_AMD_EMIT_MODE", "table")
         assert "staged" in hy.taylor_adaptive_batch(hy.model.nbody(3), None, 32768).hip_source_mode
         assert "staged" in hy.taylor_adaptive_batch(hy.model.nbody(3), None, 1 << 20).hip_source_mode
-        big = hy.taylor_adaptive_batch(hy.model.nbody(24), None, 64).hip_source_mode
+        big = hy.taylor_adaptive_batch(hy.model.nbody(32), None, 64).hip_source_mode
         assert "tape in HBM" in big and "does not fit in the LDS" in big, big
 
 
