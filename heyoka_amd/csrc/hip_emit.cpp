@@ -1471,6 +1471,7 @@ dev_switches dev_switches::from_env()
     d.unrolled_waves = num("HEYOKA_AMD_UNROLLED_WAVES", 0);
     d.v5_opts = str("HEYOKA_AMD_V5_OPTS");
     d.v5_pad = str("HEYOKA_AMD_V5_PAD");
+    d.block_opts = str("HEYOKA_AMD_BLOCK_OPTS");
     return d;
 }
 

@@ -73,6 +73,7 @@ enum class emit_mode { unrolled, cluster, table, block };
 //   HEYOKA_AMD_NO_PAIR_EVENTS         close-encounter events through the generic statements, not on the lanes of their pairs
 //   HEYOKA_AMD_NO_REFILL              one-lane-per-pair kernel: whole groups of systems from the queue, no per-system refill
 //   HEYOKA_AMD_BLOCK_V2=0             block mode: generic cluster phase
+//   HEYOKA_AMD_BLOCK_OPTS             block mode, v2 cluster phase: items switched one by one (see hip_emit_block.cpp)
 //   HEYOKA_AMD_NO_STATE_ALIASES       planner: no alias u variables for state variables in history position
 //   HEYOKA_AMD_CLUSTER_V1             first-generation cluster generator
 //   HEYOKA_AMD_MULTI_CLASS=0          planner: no multi-class plans (clusters of several shapes / levels)
@@ -91,6 +92,9 @@ struct dev_switches {
     // register allocator gets 512 / n registers per lane and spills the rest - the two-wavefront experiment of round 5).
     int unrolled_waves = 0;
     std::string v5_opts, v5_pad;
+    // HEYOKA_AMD_BLOCK_OPTS: comma-separated items of the v2 cluster phase of block mode switched one by one (A/B harness,
+    // timing experiments - see hip_emit_block.cpp).
+    std::string block_opts;
     static dev_switches from_env();
 };
 

@@ -67,6 +67,12 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         if (nc0 <= 128u) {
             bs = 128;
         }
+        // (HEYOKA_AMD_BLOCK_OPTS=bs=N: A/B harness.)
+        std::string s = "," + opts.dev.block_opts + ",";
+        std::replace(s.begin(), s.end(), ':', ',');
+        if (const auto pos = s.find(",bs="); pos != std::string::npos) {
+            bs = static_cast<std::uint32_t>(std::atoi(s.c_str() + pos + 4u));
+        }
     }
     const auto nc = static_cast<std::uint32_t>(pl.clusters.size());
     const auto ncp = (nc + 63u) / 64u * 64u;
@@ -308,6 +314,17 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         }
         return true;
     }();
+    // Two wavefronts per SIMD for the v2 cluster phase with more than four rounds per lane (round 6): 512 lanes with 256
+    // registers each. With eight rounds on one wavefront per SIMD the kernel was bound by the ISSUE of its single
+    // wavefront (8.5 cycles per instruction by the counters: 30 % VALU, 13 % LDS, 5 % memory, the rest waiting); HBM bytes,
+    // LDS reads and tape loads of the slots each removed in turn gained 11 ... 13 % only (profiles/r06_nbody64_experiments.log).
+    // With a second wavefront the ping-pong of the LDS operands is not needed (the other wavefront covers the latency; its
+    // registers go to the rows in registers), groups of two rounds, tape loads two slots ahead: nbody(64) 1.42e6 -> 1.52e6.
+    bool v2_two_waves = false, v2_recip = false;
+    if (v2 && bs == 256u && nc > 1024u && opts.dev.block_opts.find("bs=") == std::string::npos) {
+        bs = 512;
+        v2_two_waves = true;
+    }
     // ---- body ----
     ssa_emitter e(p, order);
     auto &os = e.os;
@@ -535,10 +552,29 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         const auto T = v2_T;
         // Developer experiments (timing only, wrong results): 1 = no slots beyond slot 0, 2 = no glue arithmetic, 3 = no LDS
         // reads in the slots, 4 = no tape loads in the slots.
-        const int exp_mode = 0;
-        std::uint32_t M = 160u / (4u * R);
+        // HEYOKA_AMD_BLOCK_OPTS (A/B harness): "exp=N" (the experiments above), "M=N" (rows in registers), "tape_low" (round-5
+        // behaviour: the high member of a slot always comes from the tape, every row is stored).
+        const auto bopt = [&](const std::string &name, int dflt) {
+            std::string s = "," + opts.dev.block_opts + ",";
+            std::replace(s.begin(), s.end(), ':', ',');
+            if (const auto pos = s.find("," + name + "="); pos != std::string::npos) {
+                return std::atoi(s.c_str() + pos + name.size() + 2u);
+            }
+            return s.find("," + name + ",") != std::string::npos ? 1 : dflt;
+        };
+        const int exp_mode = bopt("exp", 0);
+        std::uint32_t M = (bs >= 512u ? 80u : 160u) / (4u * R);
+        M = static_cast<std::uint32_t>(bopt("M", static_cast<int>(M)));
         M = std::min(T, std::max(2u, M));
         v2_M = M;
+        // The high member p = k - i of slot i is one of the rows in registers while k < i + M (slots 2 ... M - 1 of the orders
+        // 2 i ... i + M - 1): selected from the register copies by the (wave-uniform) order, not loaded. The rows < M are
+        // then never read from the tape and not stored; neither is the row of order P - 2, which only order P - 1 reads -
+        // from the hand-over registers. 11 of the 120 row transfers of a step of nbody(64) (rows < 5 in registers).
+        const bool reg_high = bopt("reg_high", 0) != 0 && exp_mode == 0;
+        // Quotients as products with reciprocals + one exact-residual correction unless kw::exact_division ("div": A/B).
+        const bool recip = !opts.exact_division && bopt("div", 0) == 0;
+        v2_recip = recip;
         int s_sq = -1, s_pw = -1;
         for (std::uint32_t s = 0; s < n_sto; ++s) {
             if (recomp[s] == 0 && pl.stored_pos[s] == pp.sq) {
@@ -823,6 +859,9 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
             for (std::uint32_t m = 0; m < M; ++m) {
                 os << "double " << nm2("ca", m, r) << " = 0.0, " << nm2("cb", m, r) << " = 0.0;\n";
             }
+            if (recip) {
+                os << "double rca_" << r << " = 0.0;\n";
+            }
         }
 
         // ---- order 0: the node rules of the other modes ----
@@ -839,6 +878,9 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
             }
             os << nm2("ca", 0, r) << " = " << e.val(t0[pp.sq], 0) << ";\n";
             os << nm2("cb", 0, r) << " = " << e.val(t0[pp.pw], 0) << ";\n";
+            if (recip) {
+                os << "rca_" << r << " = 1.0 / " << nm2("ca", 0, r) << ";\n";
+            }
             const std::string v[3] = {e.val(t0[pp.pr[0]], 0), e.val(t0[pp.pr[1]], 0), e.val(t0[pp.pr[2]], 0)};
             if (!is_full(r)) {
                 os << "if (live_" << r << ") {\n";
@@ -967,7 +1009,12 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                 os << "{ const unsigned i = tid + " << r * bs << "u; if (i < " << n_eq << "u) {\n";
                 os << "const unsigned kd_ = hy_sv_kind[i];\n";
                 if (dyn) {
-                    os << "if (kd_ == 0u) xn" << r << " = slab[hy_sv_idx[i]] / (kd + 1.0);\n";
+                    if (v2_recip) {
+                        os << "if (kd_ == 0u) { const double xv = slab[hy_sv_idx[i]], xq = xv * rkd1; xn" << r
+                           << " = __builtin_fma(__builtin_fma(-xq, kd + 1.0, xv), rkd1, xq); }\n";
+                    } else {
+                        os << "if (kd_ == 0u) xn" << r << " = slab[hy_sv_idx[i]] / (kd + 1.0);\n";
+                    }
                 } else {
                     os << "if (kd_ == 0u) xn" << r << " = slab[hy_sv_idx[i]];\n";
                     os << "else if (kd_ == 1u) xn" << r << " = hy_sv_val[i];\n";
@@ -1010,6 +1057,9 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         os << "#pragma nounroll\nfor (unsigned k = 1; k < " << P << "u; ++k) {\n";
         os << "const double kd = (double)k;\n";
         os << "const double c0k = kd * " << fp_literal(ex) << ";\n";
+        if (recip) {
+            os << "const double rkd = 1.0 / kd, rkd1 = 1.0 / (kd + 1.0);\n";
+        }
         os << "const unsigned nm1 = k >> 1;\nconst bool even = (k & 1u) == 0u;\n";
         os << "const unsigned kbr = (" << P - 1u << "u - k) * " << U(ejrow) << ";\n";
         os << "const unsigned tpa = (" << arow0 << "u + k) * " << rowb << "u;\n";
@@ -1057,13 +1107,17 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         if (R > 4u) {
             G = 4;
         }
-        G = std::min(G, R);
+        if (v2_two_waves) {
+            G = 2;
+        }
+        G = static_cast<std::uint32_t>(bopt("G", static_cast<int>(G)));
+        G = std::max(1u, std::min(G, R));
         // Depth of the tape-load pipeline, in slots: the loads of slot i + D are issued at the head of slot i. One slot of a
         // group is G * ~80 instructions, i.e. a fraction of a microsecond, against 1 - 2 us for a load which misses L2.
         // (Measured on nbody(64), 65 536 systems, rows < 5 in registers: depth 1 / 2 / 3 / 4 with groups of two rounds =
         // 9.8e5 / 9.7e5 / 8.8e5 / 8.6e5 system-steps/s - the registers of a deeper pipeline cost more than the latency they
         // hide; the kernel is bound by the instruction issue of its single wavefront per SIMD.)
-        const std::uint32_t D = 1;
+        const std::uint32_t D = static_cast<std::uint32_t>(std::max(1, bopt("D", v2_two_waves ? 2 : 1)));
         // The tape loads of slot i (rounds r0 .. r1 - 1) into the set i % 2.
         const auto gname = [&](const char *b, std::uint32_t i, std::uint32_t r) {
             return std::string(b) + S(i % (D + 1u)) + "_" + S(r);
@@ -1080,7 +1134,9 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                 }
                 return;
             }
-            os << "{\nconst unsigned sa = tpa - " << back << ", sb = tpb - " << back << ";\n";
+            // (reg_high: no request while the high member of the slot is a row in registers.)
+            os << (reg_high && i < M ? "if (k >= " + S(i + M) + "u) {\n" : std::string("{\n"));
+            os << "const unsigned sa = tpa - " << back << ", sb = tpb - " << back << ";\n";
             if (i >= M) {
                 os << "const unsigned oa = " << arow0 * rowb << "u + " << own << ", ob = " << brow0 * rowb << "u + " << own << ";\n";
             }
@@ -1096,7 +1152,9 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         };
         const auto emit_group = [&](std::uint32_t r0, std::uint32_t r1, std::uint32_t gi) {
             const auto Rg = r1 - r0;
-            const auto step_set = [&](std::uint32_t i, std::uint32_t r) { return ((i - 1u) * Rg + (r - r0)) % 2u; };
+            // ("nopp", A/B harness: no ping-pong - the LDS reads of a step right in front of its arithmetic, one register set.)
+            const bool nopp = bopt("nopp", v2_two_waves ? 1 : 0) != 0;
+            const auto step_set = [&](std::uint32_t i, std::uint32_t r) { return nopp ? 0u : ((i - 1u) * Rg + (r - r0)) % 2u; };
             os << "{\n";
             // Declarations of the pipeline registers.
             for (std::uint32_t set = 0; set <= D; ++set) {
@@ -1151,8 +1209,10 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                 os << "}\n";
             }
             if (T > 1u) {
-                lds_step(1, r0, step_set(1, r0));
-                os << "__builtin_amdgcn_sched_barrier(0);\n";
+                if (!nopp) {
+                    lds_step(1, r0, step_set(1, r0));
+                    os << "__builtin_amdgcn_sched_barrier(0);\n";
+                }
                 os << (exp_mode == 1 ? "if (nm1 > 1000u) {\n" : "if (nm1 != 0u) {\n");
                 for (std::uint32_t i = 1; i < T; ++i) {
                     os << "{\n";
@@ -1169,22 +1229,37 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                     for (std::uint32_t r = r0; r < r1; ++r) {
                         const auto set = step_set(i, r);
                         os << "{\n";
-                        if (r + 1u < r1) {
-                            lds_step(i, r + 1u, 1u - set);
-                        } else if (i + 1u < T) {
-                            lds_step(i + 1u, r0, 1u - set);
+                        if (nopp) {
+                            lds_step(i, r, 0u);
+                        } else {
+                            if (r + 1u < r1) {
+                                lds_step(i, r + 1u, 1u - set);
+                            } else if (i + 1u < T) {
+                                lds_step(i + 1u, r0, 1u - set);
+                            }
+                            os << "__builtin_amdgcn_sched_barrier(0);\n";
                         }
-                        os << "__builtin_amdgcn_sched_barrier(0);\n";
                         for (std::uint32_t c = 0; c < 3u; ++c) {
                             os << "const double pi" << c << " = " << raw(set, 0, c, 0) << " - " << raw(set, 0, c, 1) << ";\n";
                             os << "const double pp" << c << " = " << raw(set, 1, c, 0) << " - " << raw(set, 1, c, 1) << ";\n";
                         }
                         const auto ai = i < M ? nm2("ca", i, r) : gname("al", i, r);
                         const auto bi = i < M ? nm2("cb", i, r) : gname("bl", i, r);
-                        os << "const double bpw = " << gname("bp", i, r) << " * w2;\n";
+                        auto aph = gname("ap", i, r), bph = gname("bp", i, r);
+                        if (reg_high && i >= 2u && i < M) {
+                            // (k - i = m < M: the register copy of row m.)
+                            for (std::uint32_t m = i; m < M; ++m) {
+                                aph = "(k == " + S(i + m) + "u ? " + nm2("ca", m, r) + " : " + aph + ")";
+                                bph = "(k == " + S(i + m) + "u ? " + nm2("cb", m, r) + " : " + bph + ")";
+                            }
+                            os << "const double aph = " << aph << ", bph = " << bph << ";\n";
+                            aph = "aph";
+                            bph = "bph";
+                        }
+                        os << "const double bpw = " << bph << " * w2;\n";
                         os << "double sqt = pi0 * pp0;\nsqt = __builtin_fma(pi1, pp1, sqt);\nsqt = __builtin_fma(pi2, pp2, sqt);\n";
                         os << "ssq_" << r << " = __builtin_fma(wq, sqt, ssq_" << r << ");\n";
-                        os << "spw_" << r << " = __builtin_fma(ci, " << gname("ap", i, r) << " * " << bi << ", spw_" << r << ");\n";
+                        os << "spw_" << r << " = __builtin_fma(ci, " << aph << " * " << bi << ", spw_" << r << ");\n";
                         os << "spw_" << r << " = __builtin_fma(cp, " << ai << " * bpw, spw_" << r << ");\n";
                         for (std::uint32_t c = 0; c < 3u; ++c) {
                             os << "sf" << c << "_" << r << " = __builtin_fma(pp" << c << ", " << bi << ", sf" << c << "_" << r
@@ -1212,14 +1287,22 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                 }
                 os << "const double ak = ssq_" << r << " + ssq_" << r << ";\n";
                 os << "const double spw = __builtin_fma(c0k, ak * " << nm2("cb", 0, r) << ", spw_" << r << ");\n";
-                os << "const double bk = spw / (kd * " << nm2("ca", 0, r) << ");\n";
+                if (recip) {
+                    // (The quotient of the recurrence as a product with RN(1 / r2^[0]) RN(1 / k) and one correction with the
+                    // exact residual: 5 operations instead of the ~13 of a division, correctly rounded but for rare ties.)
+                    os << "const double rinv = rca_" << r << " * rkd, den = kd * " << nm2("ca", 0, r) << ";\n";
+                    os << "const double bq = spw * rinv;\n";
+                    os << "const double bk = __builtin_fma(__builtin_fma(-bq, den, spw), rinv, bq);\n";
+                } else {
+                    os << "const double bk = spw / (kd * " << nm2("ca", 0, r) << ");\n";
+                }
                 for (std::uint32_t c = 0; c < 3u; ++c) {
                     os << "const double sf" << c << " = __builtin_fma(dz" << c << ", bk, sf" << c << "_" << r << ");\n";
                 }
                 if (!is_full(r)) {
                     os << "if (live_" << r << ") {\n";
                 }
-                os << "if (k + 1u < " << P << "u) {\n";
+                os << (reg_high ? "if (k >= " + S(M) + "u && k + 2u < " + S(P) + "u) {\n" : "if (k + 1u < " + S(P) + "u) {\n");
                 os << "HY_TST(ak, lo_" << r << ", tpa);\nHY_TST(bk, lo_" << r << ", tpb);\n";
                 os << "}\n";
                 const std::string v[3] = {"sf0", "sf1", "sf2"};
