@@ -30,6 +30,8 @@
 #include <cstdlib>
 #include <map>
 #include <sstream>
+#include <set>
+#include <numeric>
 #include <string>
 #include <vector>
 
@@ -121,21 +123,108 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                 }
             }
         }
+        // (Jets in the order of the external inputs of the template, within one input by ascending slot: the layout does not
+        // depend on the order of the clusters.)
         std::map<std::uint32_t, std::uint32_t> slot_to_ej;
         ej_index.assign(static_cast<std::size_t>(n_ext) * nc, 0u);
         for (std::uint32_t x = 0; x < n_ext; ++x) {
             if (ext_used[x] == 0) {
                 continue;
             }
+            std::set<std::uint32_t> fresh;
             for (std::uint32_t c = 0; c < nc; ++c) {
                 const auto slot = static_cast<std::uint32_t>(pl.slot_of[pl.ext_u[c][x]]);
-                auto it = slot_to_ej.find(slot);
-                if (it == slot_to_ej.end()) {
-                    it = slot_to_ej.emplace(slot, static_cast<std::uint32_t>(ej_slots.size())).first;
-                    ej_slots.push_back(slot);
+                if (slot_to_ej.count(slot) == 0u) {
+                    fresh.insert(slot);
                 }
-                ej_index[static_cast<std::size_t>(x) * nc + c] = it->second;
             }
+            for (const auto slot : fresh) {
+                slot_to_ej.emplace(slot, static_cast<std::uint32_t>(ej_slots.size()));
+                ej_slots.push_back(slot);
+            }
+            for (std::uint32_t c = 0; c < nc; ++c) {
+                ej_index[static_cast<std::size_t>(x) * nc + c] = slot_to_ej[static_cast<std::uint32_t>(pl.slot_of[pl.ext_u[c][x]])];
+            }
+        }
+        // Order of the clusters (round 6): lane l of a wavefront reads the jets of the inputs of ITS cluster from LDS - 64-bit
+        // reads, served 32 lanes at a time, one cycle when the addresses of a group of 32 lanes fall into distinct banks
+        // (or coincide). In the order of the decomposition (pairs of an N-body system: body-major) a group of 32 straddles
+        // the boundary between two bodies and its partners collide: 1.24 cycles per group on nbody(64), a quarter of the
+        // LDS cycles of the kernel. HEYOKA_AMD_BLOCK_OPTS=perm deals the clusters greedily into groups of 32 whose inputs are
+        // conflict-free input by input (1.01 on nbody(64)) - MEASURED: 1.506e6 against 1.525e6 system-steps/s in the order
+        // of the decomposition (profiles/r06_nbody64_experiments.log): the conflicts of these reads are not what binds;
+        // the order of the decomposition stays the default.
+        if (!ej_slots.empty() && nc >= 64u && ("," + opts.dev.block_opts + ",").find(",perm,") != std::string::npos) {
+            std::vector<std::uint32_t> rem(nc), order_;
+            std::iota(rem.begin(), rem.end(), 0u);
+            order_.reserve(nc);
+            while (!rem.empty()) {
+                std::vector<std::uint32_t> grp, keep;
+                std::vector<std::map<std::uint32_t, std::uint32_t>> bank(n_ext);
+                for (const auto c : rem) {
+                    bool ok = grp.size() < 32u;
+                    for (std::uint32_t x = 0; x < n_ext && ok; ++x) {
+                        if (ext_used[x] != 0) {
+                            const auto a = ej_index[static_cast<std::size_t>(x) * nc + c];
+                            const auto it = bank[x].find(a % 32u);
+                            ok = it == bank[x].end() || it->second == a;
+                        }
+                    }
+                    if (ok) {
+                        grp.push_back(c);
+                        for (std::uint32_t x = 0; x < n_ext; ++x) {
+                            if (ext_used[x] != 0) {
+                                const auto a = ej_index[static_cast<std::size_t>(x) * nc + c];
+                                bank[x][a % 32u] = a;
+                            }
+                        }
+                    } else {
+                        keep.push_back(c);
+                    }
+                }
+                std::size_t taken = 0;
+                while (grp.size() < 32u && taken < keep.size()) {
+                    grp.push_back(keep[taken++]);
+                }
+                keep.erase(keep.begin(), keep.begin() + static_cast<std::ptrdiff_t>(taken));
+                order_.insert(order_.end(), grp.begin(), grp.end());
+                rem.swap(keep);
+            }
+            // new position -> old cluster: apply to everything indexed by the cluster.
+            std::vector<std::uint32_t> new_of(nc);
+            for (std::uint32_t i = 0; i < nc; ++i) {
+                new_of[order_[i]] = i;
+            }
+            const auto permute = [&](auto &v) {
+                if (v.size() == nc) {
+                    // (Element by element: references to the elements - the template cluster - stay valid.)
+                    const auto w = v;
+                    for (std::uint32_t i = 0; i < nc; ++i) {
+                        v[i] = w[order_[i]];
+                    }
+                }
+            };
+            permute(pl.clusters);
+            permute(pl.ext_u);
+            permute(pl.cst_val);
+            permute(pl.par_idx);
+            for (auto &c : pl.cluster_of) {
+                if (c >= 0) {
+                    c = static_cast<int>(new_of[static_cast<std::uint32_t>(c)]);
+                }
+            }
+            for (auto &cls : pl.classes) {
+                for (auto &m : cls.members) {
+                    m = new_of[m];
+                }
+            }
+            auto ej2 = ej_index;
+            for (std::uint32_t x = 0; x < n_ext; ++x) {
+                for (std::uint32_t i = 0; i < nc; ++i) {
+                    ej2[static_cast<std::size_t>(x) * nc + i] = ej_index[static_cast<std::size_t>(x) * nc + order_[i]];
+                }
+            }
+            ej_index.swap(ej2);
         }
     }
     auto n_ej = static_cast<std::uint32_t>(ej_slots.size());
@@ -828,6 +917,10 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
             }
         };
 
+        const auto cl_expr = [&](std::uint32_t r) {
+            const bool full = static_cast<std::uint64_t>(r + 1u) * bs <= nc;
+            return full ? "tid + " + U(r * bs) : "(live_" + S(r) + " ? tid + " + U(r * bs) + " : " + U(nc - 1u) + ")";
+        };
         const auto unpack = [&](std::uint32_t r) {
             for (std::uint32_t x = 0; x < n_ext; ++x) {
                 os << "const unsigned ex" << x << " = " << ex_expr(x, r) << ";\n";
@@ -1051,6 +1144,37 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         // computed itself one order earlier - they are handed over in registers (no load: the head of a group does not
         // wait for the memory system). NOTE: loading them back right behind their stores is NOT an option: under load
         // such a load was observed to overtake the store (stale values, runaway step sizes).
+        // Rounds per pipeline group (the accumulators, descriptors and tape registers of a group are live at the same
+        // time: R rounds at once do not fit the register file next to the register copies of the low orders).
+        std::uint32_t G = R;
+        if (R > 4u) {
+            G = 4;
+        }
+        if (v2_two_waves) {
+            G = 2;
+        }
+        G = static_cast<std::uint32_t>(bopt("G", static_cast<int>(G)));
+        G = std::max(1u, std::min(G, R));
+        // Depth of the tape-load pipeline, in slots: the loads of slot i + D are issued at the head of slot i. One slot of a
+        // group is G * ~80 instructions, i.e. a fraction of a microsecond, against 1 - 2 us for a load which misses L2.
+        // (Measured on nbody(64), 65 536 systems, rows < 5 in registers: depth 1 / 2 / 3 / 4 with groups of two rounds =
+        // 9.8e5 / 9.7e5 / 8.8e5 / 8.6e5 system-steps/s - the registers of a deeper pipeline cost more than the latency they
+        // hide; the kernel is bound by the instruction issue of its single wavefront per SIMD.)
+        const std::uint32_t D = static_cast<std::uint32_t>(std::max(1, bopt("D", v2_two_waves ? 2 : 1)));
+        // Cross-group prefetch ("xpf"): the high rows of the slots 2 .. D + 1 of a group - rows of order <= k - 2, stored long
+        // ago - are requested while the PREVIOUS group finishes (for the first group of an order: behind the last group of
+        // the order before, across the glue phases), so that a group does not start with the latency of the memory system
+        // exposed (D slots of two rounds are ~0.5 us of work against 1 - 2 us): registers xa<i>_<q> / xb<i>_<q>, q the
+        // position of the round in its group, live from the end of a group to the slots of the next one.
+        const bool xpf = bopt("xpf", 0) != 0 && D + 1u < M && D + 1u < T && !reg_high && exp_mode == 0 && R % G == 0u;
+        const auto xname = [&](const char *b, std::uint32_t i, std::uint32_t q) { return std::string(b) + S(i) + "_" + S(q); };
+        if (xpf) {
+            for (std::uint32_t i = 2; i <= D + 1u; ++i) {
+                for (std::uint32_t q = 0; q < G; ++q) {
+                    os << "double " << xname("xa", i, q) << " = 0.0, " << xname("xb", i, q) << " = 0.0;\n";
+                }
+            }
+        }
         for (std::uint32_t r = 0; r < R; ++r) {
             os << "double ap1_" << r << " = 0.0, bp1_" << r << " = 0.0;\n";
         }
@@ -1082,7 +1206,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         };
         // The LDS reads of step (i, r) into set `set` (inside their own scope: the unpacked offsets are temporaries).
         const auto lds_step = [&](std::uint32_t i, std::uint32_t r, std::uint32_t set) {
-            if (exp_mode == 3) {
+            if (exp_mode == 3 || exp_mode == 34) {
                 for (std::uint32_t c = 0; c < 3u; ++c) {
                     for (std::uint32_t side = 0; side < 2u; ++side) {
                         os << raw(set, 0, c, side) << " = kd;\n" << raw(set, 1, c, side) << " = c0k;\n";
@@ -1101,23 +1225,6 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                 }
             }
         };
-        // Rounds per pipeline group (the accumulators, descriptors and tape registers of a group are live at the same
-        // time: R rounds at once do not fit the register file next to the register copies of the low orders).
-        std::uint32_t G = R;
-        if (R > 4u) {
-            G = 4;
-        }
-        if (v2_two_waves) {
-            G = 2;
-        }
-        G = static_cast<std::uint32_t>(bopt("G", static_cast<int>(G)));
-        G = std::max(1u, std::min(G, R));
-        // Depth of the tape-load pipeline, in slots: the loads of slot i + D are issued at the head of slot i. One slot of a
-        // group is G * ~80 instructions, i.e. a fraction of a microsecond, against 1 - 2 us for a load which misses L2.
-        // (Measured on nbody(64), 65 536 systems, rows < 5 in registers: depth 1 / 2 / 3 / 4 with groups of two rounds =
-        // 9.8e5 / 9.7e5 / 8.8e5 / 8.6e5 system-steps/s - the registers of a deeper pipeline cost more than the latency they
-        // hide; the kernel is bound by the instruction issue of its single wavefront per SIMD.)
-        const std::uint32_t D = static_cast<std::uint32_t>(std::max(1, bopt("D", v2_two_waves ? 2 : 1)));
         // The tape loads of slot i (rounds r0 .. r1 - 1) into the set i % 2.
         const auto gname = [&](const char *b, std::uint32_t i, std::uint32_t r) {
             return std::string(b) + S(i % (D + 1u)) + "_" + S(r);
@@ -1125,7 +1232,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         const auto tape_loads = [&](std::uint32_t i, std::uint32_t r0, std::uint32_t r1) {
             const auto back = "(nm1 < " + S(i) + "u ? nm1 : " + S(i) + "u) * " + std::to_string(rowb) + "u";
             const auto own = "(k < " + S(i) + "u ? k : " + S(i) + "u) * " + std::to_string(rowb) + "u";
-            if (exp_mode == 4) {
+            if (exp_mode == 4 || exp_mode == 34) {
                 for (std::uint32_t r = r0; r < r1; ++r) {
                     os << gname("ap", i, r) << " = kd;\n" << gname("bp", i, r) << " = c0k;\n";
                     if (i >= M) {
@@ -1190,8 +1297,10 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                     os << "const unsigned kx" << x << "_" << r << " = kbr + eo" << x << "_" << r << ";\n";
                 }
             }
-            for (std::uint32_t i = 2; i <= D && i < T; ++i) {
-                tape_loads(i, r0, r1);
+            if (!xpf) {
+                for (std::uint32_t i = 2; i <= D && i < T; ++i) {
+                    tape_loads(i, r0, r1);
+                }
             }
             for (std::uint32_t r = r0; r < r1; ++r) {
                 os << "double ssq_" << r << ", spw_" << r << " = 0.0, sf0_" << r << ", sf1_" << r << ", sf2_" << r << ";\n";
@@ -1216,7 +1325,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                 os << (exp_mode == 1 ? "if (nm1 > 1000u) {\n" : "if (nm1 != 0u) {\n");
                 for (std::uint32_t i = 1; i < T; ++i) {
                     os << "{\n";
-                    if (i + D < T) {
+                    if (i + D < T && !(xpf && i + D <= D + 1u)) {
                         tape_loads(i + D, r0, r1);
                     }
                     // Weights of the last slot of an even order (middle term): 1/2 on the squares, 0 on the mirrored
@@ -1246,6 +1355,10 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                         const auto ai = i < M ? nm2("ca", i, r) : gname("al", i, r);
                         const auto bi = i < M ? nm2("cb", i, r) : gname("bl", i, r);
                         auto aph = gname("ap", i, r), bph = gname("bp", i, r);
+                        if (xpf && i >= 2u && i <= D + 1u) {
+                            aph = xname("xa", i, r - r0);
+                            bph = xname("xb", i, r - r0);
+                        }
                         if (reg_high && i >= 2u && i < M) {
                             // (k - i = m < M: the register copy of row m.)
                             for (std::uint32_t m = i; m < M; ++m) {
@@ -1274,6 +1387,27 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                     os << "}\n";
                 }
                 os << "}\nhy_done_" << gi << ":;\n";
+                if (xpf) {
+                    const bool last = r1 >= R;
+                    const auto n0 = last ? 0u : r1;
+                    // (Next group of this order, or the first group of the next order: rows k' - min(floor(k' / 2), i).)
+                    os << (last ? "if (k + 1u < " + S(P) + "u) {\nconst unsigned kn = k + 1u, tan = tpa + " + U(rowb) + ", tbn = tpb + " + U(rowb) + ";\n"
+                                : std::string("{\nconst unsigned kn = k, tan = tpa, tbn = tpb;\n"));
+                    os << "const unsigned nmn = kn >> 1;\n";
+                    for (std::uint32_t q = 0; q < G; ++q) {
+                        os << "unsigned xcl" << q << " = " << cl_expr(n0 + q) << ";\nasm volatile(\"\" : \"+v\"(xcl" << q << "));\n";
+                        os << "const unsigned xlo" << q << " = xcl" << q << " * 8u;\n";
+                    }
+                    for (std::uint32_t i = 2; i <= D + 1u; ++i) {
+                        os << "{\nconst unsigned bk_ = (nmn < " << i << "u ? nmn : " << i << "u) * " << U(rowb) << ";\n";
+                        for (std::uint32_t q = 0; q < G; ++q) {
+                            os << xname("xa", i, q) << " = HY_TLD(xlo" << q << ", tan - bk_);\n";
+                            os << xname("xb", i, q) << " = HY_TLD(xlo" << q << ", tbn - bk_);\n";
+                        }
+                        os << "}\n";
+                    }
+                    os << "}\n";
+                }
             }
             // Slot 0, second half, and the quotient of the pow recurrence (src/math/pow.cpp:546-549); stores; the register
             // copies of the coefficients of order < M.
