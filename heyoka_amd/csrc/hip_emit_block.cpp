@@ -1178,6 +1178,35 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         for (std::uint32_t r = 0; r < R; ++r) {
             os << "double ap1_" << r << " = 0.0, bp1_" << r << " = 0.0;\n";
         }
+        // ("hoist", A/B harness: the descriptors of the clusters of a lane loaded once per step, in registers through the orders.)
+        const bool hoist = bopt("hoist", 0) != 0;
+        // ("keepdz": the order-0 differences of the clusters of a lane in registers through the orders - they are read
+        // twice per order and round otherwise.)
+        const bool keepdz = bopt("keepdz", v2_two_waves ? 1 : 0) != 0;
+        if (hoist) {
+            for (std::uint32_t r = 0; r < R; ++r) {
+                desc_loads(r);
+            }
+        }
+        if (keepdz) {
+            for (std::uint32_t r = 0; r < R; ++r) {
+                for (std::uint32_t c = 0; c < 3u; ++c) {
+                    os << "double hdz" << c << "_" << r << ";\n";
+                }
+                os << "{\n";
+                if (!hoist) {
+                    desc_loads(r);
+                }
+                for (std::uint32_t x = 0; x < n_ext; ++x) {
+                    os << "const unsigned ex" << x << " = " << ex_expr(x, r) << ";\n";
+                }
+                for (std::uint32_t c = 0; c < 3u; ++c) {
+                    os << "hdz" << c << "_" << r << " = HY_EJ(" << U(ej0b) << " + ex" << pp.de[c][0] << ") - HY_EJ(" << U(ej0b) << " + ex"
+                       << pp.de[c][1] << ");\n";
+                }
+                os << "}\n";
+            }
+        }
         os << "#pragma nounroll\nfor (unsigned k = 1; k < " << P << "u; ++k) {\n";
         os << "const double kd = (double)k;\n";
         os << "const double c0k = kd * " << fp_literal(ex) << ";\n";
@@ -1288,7 +1317,9 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
             }
             // Head: descriptors, the tape loads of slot 1, slot 0 (order-k differences x order-0 ones).
             for (std::uint32_t r = r0; r < r1; ++r) {
-                desc_loads(r);
+                if (!hoist) {
+                    desc_loads(r);
+                }
                 for (std::uint32_t x = 0; x < n_ext; ++x) {
                     // (The optimiser re-derives these from the packed word where they are used - one SDWA addition per read
                     // of a dynamic row; pinning them in registers was measured: they end up in AGPRs and every read pays a
@@ -1308,7 +1339,11 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                 unpack_ex(r);
                 for (std::uint32_t c = 0; c < 3u; ++c) {
                     diff("dk" + S(c), c, "kbr");
-                    diff("dz" + S(c), c, U(ej0b));
+                    if (keepdz) {
+                        os << "const double dz" << c << " = hdz" << c << "_" << r << ";\n";
+                    } else {
+                        diff("dz" + S(c), c, U(ej0b));
+                    }
                 }
                 os << "ssq_" << r << " = dz0 * dk0;\nssq_" << r << " = __builtin_fma(dz1, dk1, ssq_" << r << ");\nssq_" << r
                    << " = __builtin_fma(dz2, dk2, ssq_" << r << ");\n";
@@ -1417,7 +1452,11 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                 os << "const unsigned dvo0 = " << out_expr(0, r) << ", dvo1 = " << out_expr(1, r) << ", dvo2 = " << out_expr(2, r)
                    << ";\n";
                 for (std::uint32_t c = 0; c < 3u; ++c) {
-                    diff("dz" + S(c), c, U(ej0b));
+                    if (keepdz) {
+                        os << "const double dz" << c << " = hdz" << c << "_" << r << ";\n";
+                    } else {
+                        diff("dz" + S(c), c, U(ej0b));
+                    }
                 }
                 os << "const double ak = ssq_" << r << " + ssq_" << r << ";\n";
                 os << "const double spw = __builtin_fma(c0k, ak * " << nm2("cb", 0, r) << ", spw_" << r << ");\n";
