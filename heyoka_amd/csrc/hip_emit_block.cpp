@@ -661,6 +661,9 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         // then never read from the tape and not stored; neither is the row of order P - 2, which only order P - 1 reads -
         // from the hand-over registers. 11 of the 120 row transfers of a step of nbody(64) (rows < 5 in registers).
         const bool reg_high = bopt("reg_high", 0) != 0 && exp_mode == 0;
+        // (reg_high=2: the selection behind a wave-uniform branch at the head of the slot - no instruction at the orders
+        // whose high member comes from the tape.)
+        const bool reg_high_br = bopt("reg_high", 0) == 2;
         // Quotients as products with reciprocals + one exact-residual correction unless kw::exact_division ("div": A/B).
         const bool recip = !opts.exact_division && bopt("div", 0) == 0;
         v2_recip = recip;
@@ -1370,6 +1373,18 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                     os << "const double ci = c0k - " << fp_literal(static_cast<double>(i) * e1) << ";\n";
                     os << "const double cp = c0k - (kd - " << fp_literal(static_cast<double>(i)) << ") * " << fp_literal(e1)
                        << ";\n";
+                    if (reg_high_br && i >= 2u && i < M) {
+                        os << "if (k < " << S(i + M) << "u) {\n";
+                        for (std::uint32_t r = r0; r < r1; ++r) {
+                            std::string a = nm2("ca", M - 1u, r), b = nm2("cb", M - 1u, r);
+                            for (std::uint32_t m = M - 1u; m-- > i;) {
+                                a = "(k == " + S(i + m) + "u ? " + nm2("ca", m, r) + " : " + a + ")";
+                                b = "(k == " + S(i + m) + "u ? " + nm2("cb", m, r) + " : " + b + ")";
+                            }
+                            os << gname("ap", i, r) << " = " << a << ";\n" << gname("bp", i, r) << " = " << b << ";\n";
+                        }
+                        os << "}\n";
+                    }
                     for (std::uint32_t r = r0; r < r1; ++r) {
                         const auto set = step_set(i, r);
                         os << "{\n";
@@ -1394,7 +1409,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                             aph = xname("xa", i, r - r0);
                             bph = xname("xb", i, r - r0);
                         }
-                        if (reg_high && i >= 2u && i < M) {
+                        if (reg_high && !reg_high_br && i >= 2u && i < M) {
                             // (k - i = m < M: the register copy of row m.)
                             for (std::uint32_t m = i; m < M; ++m) {
                                 aph = "(k == " + S(i + m) + "u ? " + nm2("ca", m, r) + " : " + aph + ")";
