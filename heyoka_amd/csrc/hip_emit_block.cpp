@@ -264,7 +264,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
     std::vector<std::pair<std::string, std::size_t>> utbl_list; // (name, entries) of the index tables
     const auto emit_utbl = [&](const std::string &name, const std::vector<std::uint32_t> &v) {
         utbl_list.emplace_back(name, std::max<std::size_t>(v.size(), 1u));
-        tbl << "__device__ const " << ut << " " << name << "[" << std::max<std::size_t>(v.size(), 1u) << "] = {";
+        tbl << "__device__ const " << ut << " __attribute__((aligned(16))) " << name << "[" << std::max<std::size_t>(v.size(), 1u) << "] = {";
         for (const auto x : v) {
             tbl << x << ",";
         }
@@ -409,7 +409,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
     // LDS reads and tape loads of the slots each removed in turn gained 11 ... 13 % only (profiles/r06_nbody64_experiments.log).
     // With a second wavefront the ping-pong of the LDS operands is not needed (the other wavefront covers the latency; its
     // registers go to the rows in registers), groups of two rounds, tape loads two slots ahead: nbody(64) 1.42e6 -> 1.52e6.
-    bool v2_two_waves = false, v2_recip = false;
+    bool v2_two_waves = false, v2_recip = false, v2_fuse_last = false, v2_dbuf = false;
     if (v2 && bs == 256u && nc > 1024u && opts.dev.block_opts.find("bs=") == std::string::npos) {
         bs = 512;
         v2_two_waves = true;
@@ -694,6 +694,8 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         }
         const auto arow0 = static_cast<std::uint64_t>(tape_row[static_cast<std::uint32_t>(s_sq)]) * order;
         const auto brow0 = static_cast<std::uint64_t>(tape_row[static_cast<std::uint32_t>(s_pw)]) * order;
+        // ("split": A/B harness - the two tape members in separate halves of the tape, two 8-byte accesses.)
+        const bool il_tape = bopt("split", 0) == 0 && bopt("xpf", 0) == 0 && n_tape == 2u;
         const auto rowb = static_cast<std::uint64_t>(ncp) * 8u;
         const auto P = order;
         const auto ejrow = static_cast<std::uint64_t>(n_ej) * 8u;         // bytes per row of the input jets
@@ -724,10 +726,16 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         // Tape accesses as raw buffer instructions: lane offset in a VGPR, row offset in an SGPR - one instruction per access
         // (the flat form costs a 64-bit VALU addition per access and two SALU instructions per row).
         dc << "typedef unsigned hy_u2 __attribute__((ext_vector_type(2)));\n";
+        dc << "typedef unsigned hy_u4 __attribute__((ext_vector_type(4)));\n";
         dc << "const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void *)tape, 0, "
            << static_cast<std::uint64_t>(n_tape) * order * ncp * 8u << ", 0x00020000);\n";
         dc << "#define HY_TLD(lo, so) __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(trs, (lo), (so), 0))\n";
         dc << "#define HY_TST(v, lo, so) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(hy_u2, (v)), trs, (lo), (so), 0)\n";
+        // Interleaved tape (round 6): the coefficients of the two tape members of a cluster side by side,
+        // tape[(row * n_clusters + cluster) * 2 + member] - ONE 16-byte load / store per cluster and row instead of two 8-byte ones.
+        dc << "typedef double hy_dd2 __attribute__((ext_vector_type(2)));\n";
+        dc << "#define HY_TLD2(lo, so) __builtin_bit_cast(hy_dd2, __builtin_amdgcn_raw_buffer_load_b128(trs, (lo), (so), 0))\n";
+        dc << "#define HY_TST2(va, vb, lo, so) { hy_dd2 t2_; t2_[0] = (va); t2_[1] = (vb); __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(hy_u4, t2_), trs, (lo), (so), 0); }\n";
         // Compact form (2 words per cluster instead of n_ext / 2 + 2) when the tables are affine: the inputs of a cluster are
         // the coordinates of two bodies whose jets sit at a constant distance from one another ([component][body] layout of
         // the input jets) and its outputs sit at constant distances too - then one offset per body and one output slot
@@ -832,6 +840,9 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         };
         std::map<std::uint32_t, merged_sums> merged;
         std::vector<char> group_merged(pl.groups.size(), 0);
+        // ("unpacked": A/B harness - one table per operand position, eight 2-byte reads per node.)
+        const bool packed_idx = !wide && bopt("unpacked", 0) == 0;
+        std::set<std::uint32_t> packed_levels;
         {
             for (std::size_t g = 0; g < pl.groups.size(); ++g) {
                 const auto &n0 = p.nodes[pl.groups[g].nodes[0] - n_eq];
@@ -854,6 +865,18 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                         group_merged[g] = 1;
                     }
                     const auto base = "hy_gm" + std::to_string(it->first);
+                    if (packed_idx && it->second.nargs == 8u) {
+                        // (The eight operand slots of a node side by side: ONE 16-byte table read per node instead of eight.)
+                        std::vector<std::uint32_t> v;
+                        for (const auto u : it->second.nodes) {
+                            const auto &args = p.nodes[u - n_eq].args;
+                            for (std::uint32_t a2 = 0; a2 < 8u; ++a2) {
+                                v.push_back(a2 < args.size() ? static_cast<std::uint32_t>(pl.slot_of[args[a2].idx]) : n_slots + 1u);
+                            }
+                        }
+                        emit_utbl(base + "_p", v);
+                        packed_levels.insert(it->first);
+                    } else {
                     for (std::uint32_t a2 = 0; a2 < it->second.nargs; ++a2) {
                         std::vector<std::uint32_t> v;
                         for (const auto u : it->second.nodes) {
@@ -861,6 +884,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                             v.push_back(a2 < args.size() ? static_cast<std::uint32_t>(pl.slot_of[args[a2].idx]) : n_slots + 1u);
                         }
                         emit_utbl(base + "_a" + std::to_string(a2), v);
+                    }
                     }
                     std::vector<std::uint32_t> v;
                     for (const auto u : it->second.nodes) {
@@ -871,12 +895,141 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                 }
             }
         }
+        // The same for the groups which stay on their own (<= 3 variable operands: operands and result in one 8-byte
+        // record) and for the state-variable definitions (kind, slot, index of the input jet).
+        std::set<std::size_t> q_groups;
+        if (packed_idx) {
+            for (std::size_t g = 0; g < pl.groups.size(); ++g) {
+                if (group_merged[g] != 0) {
+                    continue;
+                }
+                const auto &n0 = p.nodes[pl.groups[g].nodes[0] - n_eq];
+                std::vector<std::size_t> va;
+                for (std::size_t a = 0; a < n0.args.size(); ++a) {
+                    if (is_var(n0.args[a])) {
+                        va.push_back(a);
+                    }
+                }
+                if (va.empty() || va.size() > 3u) {
+                    continue;
+                }
+                std::vector<std::uint32_t> v;
+                for (const auto u : pl.groups[g].nodes) {
+                    for (std::size_t q = 0; q < 3u; ++q) {
+                        v.push_back(q < va.size() ? static_cast<std::uint32_t>(pl.slot_of[p.nodes[u - n_eq].args[va[q]].idx]) : 0u);
+                    }
+                    v.push_back(static_cast<std::uint32_t>(pl.slot_of[u]));
+                }
+                emit_utbl("hy_g" + std::to_string(g) + "_q", v);
+                q_groups.insert(g);
+            }
+            std::vector<std::uint32_t> v;
+            for (std::uint32_t i = 0; i < n_eq; ++i) {
+                const auto &d = p.sv_defs[i];
+                v.push_back(d.type == operand::kind::uvar ? 0u : (d.type == operand::kind::num ? 1u : 2u));
+                v.push_back(d.type == operand::kind::uvar ? static_cast<std::uint32_t>(pl.slot_of[d.idx])
+                                                          : (d.type == operand::kind::num ? 0u : d.idx));
+                std::uint32_t ee = 0xffffu;
+                for (std::uint32_t e2 = 0; e2 < n_ej; ++e2) {
+                    if (ej_slots[e2] == i) {
+                        ee = e2;
+                    }
+                }
+                v.push_back(ee);
+                v.push_back(0u);
+            }
+            emit_utbl("hy_sv_q", v);
+        }
+        // The LAST glue level fused into the state recursion (orders >= 1): when every node of the level is a difference of
+        // two variables or a negation which only a state-variable definition reads (the accelerations of an N-body system
+        // with equal masses: sum over the later partners minus sum over the earlier ones), the lane of the state variable
+        // reads the two operands and subtracts itself - one barrier-separated phase per order less. Record per state
+        // variable: operand slots a, b (b: the zero slot when unused), operation (0 a - 0.0, 2 nothing: constant
+        // definition, 4 -a), index of the input jet. ("nofuse": A/B harness.)
+        bool fuse_last = packed_idx && bopt("nofuse", 0) == 0 && pl.max_level >= 2u;
+        std::vector<std::uint32_t> sv_f;
+        if (fuse_last) {
+            std::vector<char> read_elsewhere(p.nodes.size() + n_eq, 0);
+            for (const auto &n : p.nodes) {
+                for (const auto &o : n.args) {
+                    if (is_var(o)) {
+                        read_elsewhere[o.idx] = 1;
+                    }
+                }
+            }
+            for (const auto u : p.ev_u) {
+                read_elsewhere[u] = 1;
+            }
+            std::map<std::uint32_t, std::uint32_t> n_defs;
+            for (const auto &d : p.sv_defs) {
+                if (d.type == operand::kind::uvar) {
+                    ++n_defs[d.idx];
+                }
+            }
+            for (std::size_t g = 0; g < pl.groups.size() && fuse_last; ++g) {
+                if (pl.groups[g].level != pl.max_level) {
+                    continue;
+                }
+                for (const auto u : pl.groups[g].nodes) {
+                    const auto &n = p.nodes[u - n_eq];
+                    const bool sub2 = n.kind == func_kind::sub && n.args.size() == 2u && is_var(n.args[0]) && is_var(n.args[1]);
+                    const bool neg = n.kind == func_kind::prod && n.args.size() == 2u && n.args[0].type == operand::kind::num
+                                     && n.args[0].value == -1. && is_var(n.args[1]);
+                    fuse_last = fuse_last && (sub2 || neg) && read_elsewhere[u] == 0 && n_defs[u] == 1u;
+                }
+            }
+        }
+        if (fuse_last) {
+            for (std::uint32_t i = 0; i < n_eq; ++i) {
+                const auto &d = p.sv_defs[i];
+                std::uint32_t a = n_slots + 1u, b = n_slots + 1u, op = 2u, ee = 0xffffu;
+                if (d.type == operand::kind::uvar) {
+                    op = 0u;
+                    a = static_cast<std::uint32_t>(pl.slot_of[d.idx]);
+                    if (d.idx >= n_eq && pl.lvl[d.idx] == pl.max_level && pl.cluster_of[d.idx] < 0) {
+                        const auto &n = p.nodes[d.idx - n_eq];
+                        if (n.kind == func_kind::sub) {
+                            a = static_cast<std::uint32_t>(pl.slot_of[n.args[0].idx]);
+                            b = static_cast<std::uint32_t>(pl.slot_of[n.args[1].idx]);
+                        } else {
+                            op = 4u;
+                            a = static_cast<std::uint32_t>(pl.slot_of[n.args[1].idx]);
+                        }
+                    }
+                }
+                for (std::uint32_t e2 = 0; e2 < n_ej; ++e2) {
+                    if (ej_slots[e2] == i) {
+                        ee = e2;
+                    }
+                }
+                sv_f.insert(sv_f.end(), {a, b, op, ee});
+            }
+            emit_utbl("hy_sv_f", sv_f);
+        }
+        v2_fuse_last = fuse_last;
+        // One phase for the state recursion (with the fused level): a lane reads the operands of ITS definition - possibly
+        // the slot of another state variable (x' = v) - and writes the next coefficient of its own variable; with the slots
+        // of the state variables double-buffered by the parity of the order (bank 1 behind the slab) the write cannot
+        // overtake another lane's read and the barrier between the two halves goes. Only when nothing but the state
+        // recursion reads state-variable slots from the slab. MEASURED: nothing (1.647e6 with, 1.649e6 without): off; "dbuf" switches it on.
+        bool dbuf = fuse_last && bopt("dbuf", 0) != 0;
+        for (std::uint32_t x = 0; x < n_ext; ++x) {
+            dbuf = dbuf && ext_used[x] != 0;
+        }
+        for (std::size_t i = 0; i < p.nodes.size() && dbuf; ++i) {
+            if (pl.cluster_of[n_eq + i] < 0) {
+                for (const auto &o : p.nodes[i].args) {
+                    dbuf = dbuf && !(is_var(o) && o.idx < n_eq);
+                }
+            }
+        }
+        v2_dbuf = dbuf;
         // LDS copies of the index tables read at every order (cluster descriptors, glue operands / results, state-variable
         // definitions), as far as they fit next to the slab and the input jets: a table lookup in front of every LDS access
         // of the glue phases and of the head of a round is a ~1 us round trip to L2 per dependency level when it is a
         // global load, ~0.1 us from LDS. Filled once per workgroup (the workgroups are persistent).
         {
-            std::uint64_t lds_used = (static_cast<std::uint64_t>(n_slots) + 1u) * 8u + static_cast<std::uint64_t>(n_ej) * order * 8u
+            std::uint64_t lds_used = (static_cast<std::uint64_t>(n_slots) + 2u + (v2_dbuf ? n_eq : 0u)) * 8u + static_cast<std::uint64_t>(n_ej) * order * 8u
                                      + 3u * 8u * (bs / 64u) + 64u;
             const std::uint64_t lds_cap = 160u * 1024u - 256u;
             std::ostringstream cp, defs;
@@ -884,8 +1037,8 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                 if (lds_used + n * esz + 8u > lds_cap) {
                     return;
                 }
-                lds_used += (n * esz + 7u) / 8u * 8u;
-                dc << "__shared__ " << type << " l_" << name << "[" << n << "];\n";
+                lds_used += (n * esz + 15u) / 16u * 16u;
+                dc << "__shared__ " << type << " __attribute__((aligned(16))) l_" << name << "[" << n << "];\n";
                 cp << "for (unsigned i_ = tid; i_ < " << n << "u; i_ += " << bs << "u) l_" << name << "[i_] = " << name
                    << "[i_];\n";
                 defs << "#define " << name << " l_" << name << "\n";
@@ -896,7 +1049,10 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                     bool unused = false;
                     for (std::size_t g = 0; g < pl.groups.size(); ++g) {
                         unused = unused || (group_merged[g] != 0 && name.rfind("hy_g" + std::to_string(g) + "_", 0) == 0);
+                        unused = unused || (q_groups.count(g) != 0u && name.rfind("hy_g" + std::to_string(g) + "_", 0) == 0
+                                            && name != "hy_g" + std::to_string(g) + "_q");
                     }
+                    unused = unused || (packed_idx && (name == "hy_sv_kind" || name == "hy_sv_idx" || name == "hy_sv_ej"));
                     if (!unused && (name.rfind("hy_g", 0) == 0 || name.rfind("hy_sv_", 0) == 0)) {
                         mirror(name, n, "unsigned short", 2u);
                     }
@@ -1013,8 +1169,17 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                        << (partial ? inside + " ? tid + " + std::to_string(r * bs) + "u : " + std::to_string(ng - 1u) + "u"
                                    : "tid + " + std::to_string(r * bs) + "u")
                        << ";\n";
+                    if (packed_levels.count(lev) != 0u) {
+                        os << "const hy_u4 iw" << tag << " = *(const hy_u4 *)(" << gn << "_p + 8u * j" << tag << ");\n";
+                        for (std::uint32_t a2 = 0; a2 < 8u; ++a2) {
+                            os << "const unsigned ia" << a2 << tag << " = " << ((a2 & 1u) != 0u ? "(iw" + tag + "[" + std::to_string(a2 / 2u) + "] >> 16)"
+                                                                                           : "(iw" + tag + "[" + std::to_string(a2 / 2u) + "] & 0xffffu)")
+                               << ";\n";
+                        }
+                    } else {
                     for (std::uint32_t a2 = 0; a2 < m.nargs; ++a2) {
                         os << "const unsigned ia" << a2 << tag << " = " << gn << "_a" << a2 << "[j" << tag << "];\n";
+                    }
                     }
                     os << "const unsigned io" << tag << " = "
                        << (partial ? inside + " ? (unsigned)" + gn + "_o[j" + tag + "] : " + std::to_string(n_slots) + "u"
@@ -1049,6 +1214,23 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                     } else {
                         os << "tid + " << r * bs << "u;\n";
                     }
+                    if (q_groups.count(g) != 0u) {
+                        os << "const hy_u2 iq" << tag << " = *(const hy_u2 *)(" << gn << "_q + 4u * j" << tag << ");\n";
+                        std::uint32_t q = 0;
+                        for (std::size_t a = 0; a < n0.args.size(); ++a) {
+                            if (is_var(n0.args[a])) {
+                                os << "const unsigned ia" << a << tag << " = "
+                                   << (q == 0u ? "(iq" + tag + "[0] & 0xffffu)" : (q == 1u ? "(iq" + tag + "[0] >> 16)" : "(iq" + tag + "[1] & 0xffffu)"))
+                                   << ";\n";
+                                ++q;
+                            }
+                        }
+                        os << "const unsigned io" << tag << " = "
+                           << (partial ? "(tid + " + std::to_string(r * bs) + "u < " + std::to_string(ng) + "u) ? (iq" + tag + "[1] >> 16) : "
+                                             + std::to_string(n_slots) + "u"
+                                       : "(iq" + tag + "[1] >> 16)")
+                           << ";\n";
+                    } else {
                     for (std::size_t a = 0; a < n0.args.size(); ++a) {
                         if (is_var(n0.args[a])) {
                             os << "const unsigned ia" << a << tag << " = " << gn << "_a" << a << "[j" << tag << "];\n";
@@ -1059,6 +1241,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                                          + "_o[j" + tag + "] : " + std::to_string(n_slots) + "u"
                                    : "(unsigned)" + gn + "_o[j" + tag + "]")
                        << ";\n";
+                    }
                     st_idx += take();
                     const auto saved = e.numpar_override;
                     std::vector<std::pair<std::uint32_t, std::string>> saved_vals;
@@ -1091,6 +1274,9 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         };
         const auto glue_levels = [&](std::uint32_t k) {
             for (std::uint32_t lev = 1; lev <= pl.max_level; ++lev) {
+                if (k != 0u && v2_fuse_last && lev == pl.max_level) {
+                    continue; // (computed by the lanes of the state variables, below)
+                }
                 glue_level_staged(lev, k);
                 sync();
             }
@@ -1101,37 +1287,72 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         const auto recursion = [&](bool dyn) {
             os << "{\n";
             for (std::uint32_t r = 0; r < sv_rounds; ++r) {
-                os << "double xn" << r << " = 0.0;\n";
+                os << "double xn" << r << " = 0.0;\nunsigned svej" << r << " = 0xffffu;\n";
                 os << "{ const unsigned i = tid + " << r * bs << "u; if (i < " << n_eq << "u) {\n";
-                os << "const unsigned kd_ = hy_sv_kind[i];\n";
+                if (dyn && v2_fuse_last) {
+                    os << "const hy_u2 svf = *(const hy_u2 *)(hy_sv_f + 4u * i);\n";
+                    os << "svej" << r << " = svf[1] >> 16;\n";
+                    os << "const unsigned op_ = svf[1] & 0xffffu;\n";
+                    if (v2_dbuf) {
+                        // (Order-k coefficients of the state variables: bank (k - 1) & 1; the new ones go to bank k & 1.)
+                        os << "const unsigned rbo = ((k - 1u) & 1u) * " << U(n_slots + 2u) << ";\n";
+                        os << "const unsigned sa_ = svf[0] & 0xffffu, sb_ = svf[0] >> 16;\n";
+                        os << "const double xa_ = slab[sa_ + (sa_ < " << n_eq << "u ? rbo : 0u)], xb_ = slab[sb_ + (sb_ < " << n_eq
+                           << "u ? rbo : 0u)];\n";
+                    } else {
+                        os << "const double xa_ = slab[svf[0] & 0xffffu], xb_ = slab[svf[0] >> 16];\n";
+                    }
+                    os << "const double xv = op_ == 4u ? -xa_ : xa_ - xb_;\n";
+                    if (v2_recip) {
+                        os << "const double xq = xv * rkd1;\n";
+                        os << "xn" << r << " = op_ == 2u ? 0.0 : __builtin_fma(__builtin_fma(-xq, kd + 1.0, xv), rkd1, xq);\n";
+                    } else {
+                        os << "xn" << r << " = op_ == 2u ? 0.0 : xv / (kd + 1.0);\n";
+                    }
+                    os << "} }\n";
+                    continue;
+                }
+                if (packed_idx) {
+                    os << "const hy_u2 svq = *(const hy_u2 *)(hy_sv_q + 4u * i);\n";
+                    os << "svej" << r << " = svq[1] & 0xffffu;\n";
+                    os << "const unsigned kd_ = svq[0] & 0xffffu, svi_ = svq[0] >> 16;\n";
+                } else {
+                    os << "const unsigned kd_ = hy_sv_kind[i], svi_ = hy_sv_idx[i];\n";
+                }
                 if (dyn) {
                     if (v2_recip) {
-                        os << "if (kd_ == 0u) { const double xv = slab[hy_sv_idx[i]], xq = xv * rkd1; xn" << r
+                        os << "if (kd_ == 0u) { const double xv = slab[svi_], xq = xv * rkd1; xn" << r
                            << " = __builtin_fma(__builtin_fma(-xq, kd + 1.0, xv), rkd1, xq); }\n";
                     } else {
-                        os << "if (kd_ == 0u) xn" << r << " = slab[hy_sv_idx[i]] / (kd + 1.0);\n";
+                        os << "if (kd_ == 0u) xn" << r << " = slab[svi_] / (kd + 1.0);\n";
                     }
                 } else {
-                    os << "if (kd_ == 0u) xn" << r << " = slab[hy_sv_idx[i]];\n";
+                    os << "if (kd_ == 0u) xn" << r << " = slab[svi_];\n";
                     os << "else if (kd_ == 1u) xn" << r << " = hy_sv_val[i];\n";
-                    os << "else xn" << r << " = a.pars[(u64)hy_sv_idx[i] * N + s];\n";
+                    os << "else xn" << r << " = a.pars[(u64)svi_ * N + s];\n";
                 }
                 os << "} }\n";
             }
-            sync();
+            if (!(dyn && v2_dbuf)) {
+                sync();
+            }
             for (std::uint32_t r = 0; r < sv_rounds; ++r) {
                 os << "{ const unsigned i = tid + " << r * bs << "u; if (i < " << n_eq << "u) {\n";
-                os << "slab[i] = xn" << r << ";\n";
+                if (dyn && v2_dbuf) {
+                    os << "slab[i + (k & 1u) * " << U(n_slots + 2u) << "] = xn" << r << ";\n";
+                } else {
+                    os << "slab[i] = xn" << r << ";\n";
+                }
                 if (dyn) {
                     os << "sjet[(k + 1u) * " << n_eq << "u + i] = xn" << r << ";\n";
-                    os << "const unsigned ee = hy_sv_ej[i];\n";
+                    os << "const unsigned ee = " << (packed_idx ? "svej" + std::to_string(r) : std::string("hy_sv_ej[i]")) << ";\n";
                     os << "if (ee != 0xffffu && k + 1u < " << P << "u) HY_EJW((" << P - 2u << "u - k) * " << U(ejrow)
                        << " + ee * 8u) = xn" << r << ";\n";
                     os << "if (k + 1u == " << P << "u) mo = hy_max(mo, fabs(xn" << r << "));\n";
                     os << "else if (k + 2u == " << P << "u) mom1 = hy_max(mom1, fabs(xn" << r << "));\n";
                 } else {
                     os << "sjet[" << n_eq << "u + i] = xn" << r << ";\n";
-                    os << "const unsigned ee = hy_sv_ej[i];\n";
+                    os << "const unsigned ee = " << (packed_idx ? "svej" + std::to_string(r) : std::string("hy_sv_ej[i]")) << ";\n";
                     os << "if (ee != 0xffffu) HY_EJW(" << U(static_cast<std::uint64_t>(P - 2u) * ejrow) << " + ee * 8u) = xn" << r
                        << ";\n";
                 }
@@ -1182,7 +1403,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
             os << "double ap1_" << r << " = 0.0, bp1_" << r << " = 0.0;\n";
         }
         // ("hoist", A/B harness: the descriptors of the clusters of a lane loaded once per step, in registers through the orders.)
-        const bool hoist = bopt("hoist", 0) != 0;
+        const bool hoist = bopt("hoist", v2_two_waves ? 1 : 0) != 0;
         // ("keepdz": the order-0 differences of the clusters of a lane in registers through the orders - they are read
         // twice per order and round otherwise.)
         const bool keepdz = bopt("keepdz", v2_two_waves ? 1 : 0) != 0;
@@ -1218,8 +1439,12 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         }
         os << "const unsigned nm1 = k >> 1;\nconst bool even = (k & 1u) == 0u;\n";
         os << "const unsigned kbr = (" << P - 1u << "u - k) * " << U(ejrow) << ";\n";
-        os << "const unsigned tpa = (" << arow0 << "u + k) * " << rowb << "u;\n";
-        os << "const unsigned tpb = (" << brow0 << "u + k) * " << rowb << "u;\n";
+        if (il_tape) {
+            os << "const unsigned tpa = k * " << 2u * rowb << "u;\n";
+        } else {
+            os << "const unsigned tpa = (" << arow0 << "u + k) * " << rowb << "u;\n";
+            os << "const unsigned tpb = (" << brow0 << "u + k) * " << rowb << "u;\n";
+        }
         // The cluster phase of order k, SLOT-major: for slot i = 1 .. floor(k / 2) (early exit after the last one) the
         // rounds 0 .. R - 1 of the lane, with the five accumulators of every round in registers. One software pipeline runs
         // through the whole (slot, round) sequence of an order:
@@ -1275,6 +1500,22 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
             }
             // (reg_high: no request while the high member of the slot is a row in registers.)
             os << (reg_high && i < M ? "if (k >= " + S(i + M) + "u) {\n" : std::string("{\n"));
+            if (il_tape) {
+                os << "const unsigned sa = tpa - 2u * " << back << ";\n";
+                if (i >= M) {
+                    os << "const unsigned oa = 2u * " << own << ";\n";
+                }
+                for (std::uint32_t r = r0; r < r1; ++r) {
+                    os << "{ const hy_dd2 t_ = HY_TLD2(2u * lo_" << r << ", sa); " << gname("ap", i, r) << " = t_[0]; " << gname("bp", i, r)
+                       << " = t_[1]; }\n";
+                    if (i >= M) {
+                        os << "{ const hy_dd2 t_ = HY_TLD2(2u * lo_" << r << ", oa); " << gname("al", i, r) << " = t_[0]; "
+                           << gname("bl", i, r) << " = t_[1]; }\n";
+                    }
+                }
+                os << "}\n";
+                return;
+            }
             os << "const unsigned sa = tpa - " << back << ", sb = tpb - " << back << ";\n";
             if (i >= M) {
                 os << "const unsigned oa = " << arow0 * rowb << "u + " << own << ", ob = " << brow0 * rowb << "u + " << own << ";\n";
@@ -1491,7 +1732,11 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                     os << "if (live_" << r << ") {\n";
                 }
                 os << (reg_high ? "if (k >= " + S(M) + "u && k + 2u < " + S(P) + "u) {\n" : "if (k + 1u < " + S(P) + "u) {\n");
-                os << "HY_TST(ak, lo_" << r << ", tpa);\nHY_TST(bk, lo_" << r << ", tpb);\n";
+                if (il_tape) {
+                    os << "HY_TST2(ak, bk, 2u * lo_" << r << ", tpa);\n";
+                } else {
+                    os << "HY_TST(ak, lo_" << r << ", tpa);\nHY_TST(bk, lo_" << r << ", tpb);\n";
+                }
                 os << "}\n";
                 const std::string v[3] = {"sf0", "sf1", "sf2"};
                 store_out(r, v);
@@ -1596,7 +1841,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
     src << "extern \"C\" __global__ void __launch_bounds__(" << bs << ") hy_taylor(const hy_kargs a)\n{\n";
     // (slab[n_slots]: the slot idle lanes write to; slab[n_slots + 1]: a constant 0.0 - the missing operands of the merged
     // sums of the v2 glue.)
-    src << "__shared__ double slab[" << n_slots + 2u << "];\n";
+    src << "__shared__ double slab[" << n_slots + 2u + (v2_dbuf ? n_eq : 0u) << "];\n";
     if (n_ej != 0u) {
         src << "__shared__ double ejet[" << static_cast<std::uint64_t>(n_ej) * (v2 ? order : order - 1u) << "];\n";
     }
