@@ -865,6 +865,82 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                         group_merged[g] = 1;
                     }
                     const auto base = "hy_gm" + std::to_string(it->first);
+                    // Order of the nodes of the level = lane assignment: lane l of a round gathers ITS operands from the slab
+                    // with 64-bit reads, 32 lanes at a time, one cycle per distinct address sharing a bank. In the order of the
+                    // decomposition (the three coordinates of a sum on adjacent lanes, 2016 slots = 0 mod 32 apart; partners in
+                    // triangular order) a gather of the widest level of nbody(64) takes 4.9 cycles per 32 lanes; dealing the
+                    // nodes greedily into groups of 32 with at most `tol` addresses per bank and operand position brings that
+                    // to 2.3 (tol = 2). ("noglueperm": A/B harness.)
+                    if (bopt("noglueperm", 0) == 0 && it->second.nodes.size() > 64u) {
+                        auto &nodes = it->second.nodes;
+                        const auto nargs = it->second.nargs;
+                        const auto slots_of = [&](std::uint32_t u) {
+                            std::vector<std::uint32_t> v(nargs, n_slots + 1u);
+                            const auto &args = p.nodes[u - n_eq].args;
+                            for (std::uint32_t a2 = 0; a2 < nargs && a2 < args.size(); ++a2) {
+                                v[a2] = static_cast<std::uint32_t>(pl.slot_of[args[a2].idx]);
+                            }
+                            return v;
+                        };
+                        const auto score = [&](const std::vector<std::uint32_t> &ord) {
+                            std::uint64_t tot = 0;
+                            for (std::size_t g0 = 0; g0 < ord.size(); g0 += 32u) {
+                                for (std::uint32_t a2 = 0; a2 < nargs; ++a2) {
+                                    std::map<std::uint32_t, std::set<std::uint32_t>> bank;
+                                    for (std::size_t j = g0; j < std::min(ord.size(), g0 + 32u); ++j) {
+                                        const auto sl = slots_of(ord[j])[a2];
+                                        bank[sl % 32u].insert(sl);
+                                    }
+                                    std::size_t mx = 0;
+                                    for (const auto &[b_, st] : bank) {
+                                        mx = std::max(mx, st.size());
+                                    }
+                                    tot += mx;
+                                }
+                            }
+                            return tot;
+                        };
+                        auto best = nodes;
+                        auto best_score = score(nodes);
+                        for (std::uint32_t tol = 1; tol <= 3u; ++tol) {
+                            std::vector<std::uint32_t> rem = nodes, ord;
+                            while (!rem.empty()) {
+                                std::vector<std::uint32_t> grp, keep;
+                                std::vector<std::map<std::uint32_t, std::set<std::uint32_t>>> bank(nargs);
+                                for (const auto u : rem) {
+                                    bool ok = grp.size() < 32u;
+                                    std::vector<std::uint32_t> sl;
+                                    if (ok) {
+                                        sl = slots_of(u);
+                                        for (std::uint32_t a2 = 0; a2 < nargs && ok; ++a2) {
+                                            const auto bi = bank[a2].find(sl[a2] % 32u);
+                                            ok = bi == bank[a2].end() || bi->second.count(sl[a2]) != 0u || bi->second.size() < tol;
+                                        }
+                                    }
+                                    if (ok) {
+                                        grp.push_back(u);
+                                        for (std::uint32_t a2 = 0; a2 < nargs; ++a2) {
+                                            bank[a2][sl[a2] % 32u].insert(sl[a2]);
+                                        }
+                                    } else {
+                                        keep.push_back(u);
+                                    }
+                                }
+                                std::size_t taken = 0;
+                                while (grp.size() < 32u && taken < keep.size()) {
+                                    grp.push_back(keep[taken++]);
+                                }
+                                keep.erase(keep.begin(), keep.begin() + static_cast<std::ptrdiff_t>(taken));
+                                ord.insert(ord.end(), grp.begin(), grp.end());
+                                rem.swap(keep);
+                            }
+                            if (const auto sc = score(ord); sc < best_score) {
+                                best_score = sc;
+                                best = ord;
+                            }
+                        }
+                        nodes = best;
+                    }
                     if (packed_idx && it->second.nargs == 8u) {
                         // (The eight operand slots of a node side by side: ONE 16-byte table read per node instead of eight.)
                         std::vector<std::uint32_t> v;
