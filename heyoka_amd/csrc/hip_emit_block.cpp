@@ -60,6 +60,31 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
     }
 
     const auto n_eq = p.n_eq, order = opts.order;
+    // Slots of the exported cluster members: output-major blocks of n_clusters slots each. When the number of clusters is a
+    // multiple of the 32 bank pairs of LDS (2016 for nbody(64)), the three products of a pair sit in ONE bank, and so do
+    // the operands of the sums of the three coordinates of a body, which the glue gathers on adjacent lanes: one slot of
+    // padding between the blocks (an odd distance). ("nopad": A/B harness.)
+    if (pl.classes.size() <= 1u && pl.clusters.size() % 2u == 0u && pl.out_pos.size() > 1u
+        && ("," + opts.dev.block_opts + ",").find(",nopad,") == std::string::npos) {
+        const auto ncl = static_cast<int>(pl.clusters.size()), nout = static_cast<int>(pl.out_pos.size());
+        const auto first = static_cast<int>(n_eq), last = first + ncl * nout;
+        bool layout_ok = true;
+        for (int c = 0; c < ncl && layout_ok; ++c) {
+            for (int q = 0; q < nout; ++q) {
+                layout_ok = layout_ok && pl.slot_of[pl.clusters[static_cast<std::size_t>(c)][pl.out_pos[static_cast<std::size_t>(q)]]] == first + q * ncl + c;
+            }
+        }
+        if (layout_ok) {
+            for (auto &sl : pl.slot_of) {
+                if (sl >= last) {
+                    sl += nout - 1;
+                } else if (sl >= first) {
+                    sl += (sl - first) / ncl;
+                }
+            }
+            pl.n_slots += static_cast<std::uint32_t>(nout - 1);
+        }
+    }
     // Workgroup size: 256 lanes = one wavefront per SIMD with the whole register file (512 VGPRs) for the
     // history of the cluster being processed.
     std::uint32_t bs = 256;
