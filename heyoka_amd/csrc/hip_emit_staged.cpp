@@ -680,11 +680,12 @@ emitted_module emit_staged(const taylor_program &p, const emit_options &opts, st
             // Loop header of a convolution whose index j runs from j0 to jend (inclusive if incl): this lane's share.
             const auto jloop = [&](const std::string &j0, const std::string &cond) {
                 std::ostringstream h;
+                const bool full = opts.dev.table_lds == 7 || opts.dev.table_lds == 8;
                 if (sp == 1u) {
-                    h << "#pragma unroll 4\nfor (unsigned j = " << j0 << "; " << cond << "; ++j)";
+                    h << (full ? "#pragma unroll\n" : "#pragma unroll 4\n") << "for (unsigned j = " << j0 << "; " << cond << "; ++j)";
                 } else {
-                    h << "#pragma unroll 2\nfor (unsigned j = " << j0 << " + (lane & " << (sp - 1u) << "u); " << cond << "; j += " << sp
-                      << "u)";
+                    h << (full ? "#pragma unroll\n" : "#pragma unroll 2\n") << "for (unsigned j = " << j0 << " + (lane & " << (sp - 1u)
+                      << "u); " << cond << "; j += " << sp << "u)";
                 }
                 return h.str();
             };
@@ -1107,7 +1108,12 @@ __device__ __forceinline__ double hy_dpp(double x)
 }
 )HIP";
     // (Registers: what lets `per_cu` workgroups of `wps` wavefronts share the four SIMDs of a CU.)
-    const auto waves_per_simd = std::max<std::uint64_t>(1u, std::min<std::uint64_t>(8u, (per_cu * wps + 3u) / 4u));
+    // (HEYOKA_AMD_TABLE_LDS=7 / 8, A/B harness: the order loop unrolled - the terms of the convolutions become straight-line
+    // code with constant LDS offsets -, 8: compiled for two wavefronts per SIMD, 256 registers.)
+    const bool unroll_orders = opts.dev.table_lds == 7 || opts.dev.table_lds == 8;
+    const auto waves_per_simd = opts.dev.table_lds == 8
+                                    ? std::uint64_t(2)
+                                    : std::max<std::uint64_t>(1u, std::min<std::uint64_t>(8u, (per_cu * wps + 3u) / 4u));
     src << "extern \"C\" __global__ __attribute__((amdgpu_waves_per_eu(" << waves_per_simd << "))) void __launch_bounds__(" << LANES
         << ") hy_taylor(const hy_kargs a)\n{\n";
     src << "const unsigned lane = threadIdx.x;\nconst u64 N = a.N;\n";
@@ -1185,7 +1191,7 @@ for (;;) {
 )HIP";
     src << o0.str();
     src << "#if HY_N_EV > 0\nconst unsigned k_end = HY_ORDER + 1u;\n#else\nconst unsigned k_end = HY_ORDER;\n#endif\n";
-    src << "#pragma nounroll\nfor (unsigned k = 1; k <= HY_ORDER; ++k) {\n";
+    src << (unroll_orders ? "#pragma unroll\n" : "#pragma nounroll\n") << "for (unsigned k = 1; k <= HY_ORDER; ++k) {\n";
     src << svk.str();
     src << "if (k == k_end) break;\n";
     src << ok.str();
