@@ -385,7 +385,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
     pair_pattern pp;
     detect_pair_pattern(p, pl, pp);
     const std::uint32_t v2_T = (order - 1u) / 2u + 1u; // index pairs (slots) of the highest order
-    std::uint32_t v2_M = 0;
+    std::uint32_t v2_M = 0, v2_hand = 1;
     bool v2 = [&]() {
         if (!opts.dev.block_v2) {
             return false;
@@ -434,7 +434,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
     // LDS reads and tape loads of the slots each removed in turn gained 11 ... 13 % only (profiles/r06_nbody64_experiments.log).
     // With a second wavefront the ping-pong of the LDS operands is not needed (the other wavefront covers the latency; its
     // registers go to the rows in registers), groups of two rounds, tape loads two slots ahead: nbody(64) 1.42e6 -> 1.52e6.
-    bool v2_two_waves = false, v2_recip = false, v2_fuse_last = false, v2_dbuf = false;
+    bool v2_two_waves = false, v2_recip = false, v2_fuse_last = false, v2_dbuf = false, v2_lean = false;
     if (v2 && bs == 256u && nc > 1024u && opts.dev.block_opts.find("bs=") == std::string::npos) {
         bs = 512;
         v2_two_waves = true;
@@ -677,7 +677,27 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
             return s.find("," + name + ",") != std::string::npos ? 1 : dflt;
         };
         const int exp_mode = bopt("exp", 0);
-        std::uint32_t M = (bs >= 512u ? 80u : 160u) / (4u * R);
+        std::uint32_t M = 160u / (4u * R);
+        // Two wavefronts per SIMD: 96 registers for rows which stay in registers - the low rows 0 ... M - 1 for the whole step
+        // and the `hand` most recent ones, handed over from order to order (below). A low row m saves 20 - 2 m tape reads per
+        // step, a handed-over row h 21 - 2 h: dealt in turn (row 0, m = 1, h = 2, m = 2, h = 3, ...).
+        std::uint32_t hand_dflt = 1;
+        // (More than four rounds per lane - nbody(80): seven -: per-round registers cost too much, measured: spills inside
+        // the order loop halve the rate; two rows, one hand-over, no differences / descriptors kept.)
+        v2_lean = v2_two_waves && R > 4u;
+        if (v2_lean) {
+            M = std::max(2u, 80u / (4u * R));
+        } else if (v2_two_waves) {
+            const auto rows = std::max(3u, 96u / (4u * R));
+            M = 1;
+            for (std::uint32_t e = 0; e + 1u < rows; ++e) {
+                if (e % 2u == 0u) {
+                    ++M;
+                } else {
+                    ++hand_dflt;
+                }
+            }
+        }
         M = static_cast<std::uint32_t>(bopt("M", static_cast<int>(M)));
         M = std::min(T, std::max(2u, M));
         v2_M = M;
@@ -1493,6 +1513,11 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         // position of the round in its group, live from the end of a group to the slots of the next one.
         const bool xpf = bopt("xpf", 0) != 0 && D + 1u < M && D + 1u < T && !reg_high && exp_mode == 0 && R % G == 0u;
         const auto xname = [&](const char *b, std::uint32_t i, std::uint32_t q) { return std::string(b) + S(i) + "_" + S(q); };
+        const std::uint32_t hand = (!xpf && !reg_high && exp_mode == 0)
+                                       ? std::min<std::uint32_t>(static_cast<std::uint32_t>(std::max(1, bopt("hand", static_cast<int>(hand_dflt)))), std::min(T - 1u, il_tape ? T - 1u : M - 1u))
+                                       : 1u;
+        const bool hand2 = hand >= 2u;
+        v2_hand = hand;
         if (xpf) {
             for (std::uint32_t i = 2; i <= D + 1u; ++i) {
                 for (std::uint32_t q = 0; q < G; ++q) {
@@ -1502,12 +1527,17 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         }
         for (std::uint32_t r = 0; r < R; ++r) {
             os << "double ap1_" << r << " = 0.0, bp1_" << r << " = 0.0;\n";
+            // ("hand=H": the coefficients of the orders k - 2 ... k - H handed over in registers too: the slots 2 ... H need no
+            // tape load for their high member.)
+            for (std::uint32_t h = 2; h <= hand; ++h) {
+                os << "double ah" << h << "_" << r << " = 0.0, bh" << h << "_" << r << " = 0.0;\n";
+            }
         }
         // ("hoist", A/B harness: the descriptors of the clusters of a lane loaded once per step, in registers through the orders.)
-        const bool hoist = bopt("hoist", v2_two_waves ? 1 : 0) != 0;
+        const bool hoist = bopt("hoist", v2_two_waves && !v2_lean ? 1 : 0) != 0;
         // ("keepdz": the order-0 differences of the clusters of a lane in registers through the orders - they are read
         // twice per order and round otherwise.)
-        const bool keepdz = bopt("keepdz", v2_two_waves ? 1 : 0) != 0;
+        const bool keepdz = bopt("keepdz", v2_two_waves && !v2_lean ? 1 : 0) != 0;
         if (hoist) {
             for (std::uint32_t r = 0; r < R; ++r) {
                 desc_loads(r);
@@ -1588,6 +1618,10 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
             return std::string(b) + S(i % (D + 1u)) + "_" + S(r);
         };
         const auto tape_loads = [&](std::uint32_t i, std::uint32_t r0, std::uint32_t r1) {
+            const bool skip_high = i >= 2u && i <= hand;
+            if (skip_high && i < M) {
+                return;
+            }
             const auto back = "(nm1 < " + S(i) + "u ? nm1 : " + S(i) + "u) * " + std::to_string(rowb) + "u";
             const auto own = "(k < " + S(i) + "u ? k : " + S(i) + "u) * " + std::to_string(rowb) + "u";
             if (exp_mode == 4 || exp_mode == 34) {
@@ -1607,8 +1641,10 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                     os << "const unsigned oa = 2u * " << own << ";\n";
                 }
                 for (std::uint32_t r = r0; r < r1; ++r) {
-                    os << "{ const hy_dd2 t_ = HY_TLD2(2u * lo_" << r << ", sa); " << gname("ap", i, r) << " = t_[0]; " << gname("bp", i, r)
-                       << " = t_[1]; }\n";
+                    if (!skip_high) {
+                        os << "{ const hy_dd2 t_ = HY_TLD2(2u * lo_" << r << ", sa); " << gname("ap", i, r) << " = t_[0]; "
+                           << gname("bp", i, r) << " = t_[1]; }\n";
+                    }
                     if (i >= M) {
                         os << "{ const hy_dd2 t_ = HY_TLD2(2u * lo_" << r << ", oa); " << gname("al", i, r) << " = t_[0]; "
                            << gname("bl", i, r) << " = t_[1]; }\n";
@@ -1676,6 +1712,11 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
             if (!xpf) {
                 for (std::uint32_t i = 2; i <= D && i < T; ++i) {
                     tape_loads(i, r0, r1);
+                }
+            }
+            if (hand2) {
+                for (std::uint32_t r = r0; r < r1; ++r) {
+                    os << "const double ah1s_" << r << " = ap1_" << r << ", bh1s_" << r << " = bp1_" << r << ";\n";
                 }
             }
             for (std::uint32_t r = r0; r < r1; ++r) {
@@ -1750,6 +1791,10 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                         if (xpf && i >= 2u && i <= D + 1u) {
                             aph = xname("xa", i, r - r0);
                             bph = xname("xb", i, r - r0);
+                        }
+                        if (i >= 2u && i <= hand) {
+                            aph = "ah" + S(i) + "_" + S(r);
+                            bph = "bh" + S(i) + "_" + S(r);
                         }
                         if (reg_high && !reg_high_br && i >= 2u && i < M) {
                             // (k - i = m < M: the register copy of row m.)
@@ -1832,7 +1877,9 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                 if (!is_full(r)) {
                     os << "if (live_" << r << ") {\n";
                 }
-                os << (reg_high ? "if (k >= " + S(M) + "u && k + 2u < " + S(P) + "u) {\n" : "if (k + 1u < " + S(P) + "u) {\n");
+                // (Row k is read from the tape by a slot i > hand of an order k + i <= P - 1 with i <= k: rows beyond P - 2 - hand
+                // are only ever handed over in registers.)
+                os << (reg_high ? "if (k >= " + S(M) + "u && k + 2u < " + S(P) + "u) {\n" : "if (k + " + S(hand + 1u) + "u < " + S(P) + "u) {\n");
                 if (il_tape) {
                     os << "HY_TST2(ak, bk, 2u * lo_" << r << ", tpa);\n";
                 } else {
@@ -1843,6 +1890,13 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                 store_out(r, v);
                 if (!is_full(r)) {
                     os << "}\n";
+                }
+                for (std::uint32_t h = hand; h >= 3u; --h) {
+                    os << "ah" << h << "_" << r << " = ah" << h - 1u << "_" << r << ";\nbh" << h << "_" << r << " = bh" << h - 1u << "_" << r
+                       << ";\n";
+                }
+                if (hand2) {
+                    os << "ah2_" << r << " = ah1s_" << r << ";\nbh2_" << r << " = bh1s_" << r << ";\n";
                 }
                 os << "ap1_" << r << " = ak;\nbp1_" << r << " = bk;\n";
                 if (M > 1u) {
@@ -2123,7 +2177,8 @@ if (tid == 0u) {
                 + " KiB per workgroup";
     if (v2) {
         ret.notes += "; v2 cluster phase: rolled order loop, " + std::to_string(n_iter) + " rounds per lane, rows < "
-                     + std::to_string(v2_M) + " of the tape members in registers";
+                     + std::to_string(v2_M) + " of the tape members in registers, the " + std::to_string(v2_hand)
+                     + " most recent rows handed over in registers";
     }
     return ret;
 }
