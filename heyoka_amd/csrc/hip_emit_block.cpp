@@ -1878,8 +1878,9 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
                     os << "if (live_" << r << ") {\n";
                 }
                 // (Row k is read from the tape by a slot i > hand of an order k + i <= P - 1 with i <= k: rows beyond P - 2 - hand
-                // are only ever handed over in registers.)
-                os << (reg_high ? "if (k >= " + S(M) + "u && k + 2u < " + S(P) + "u) {\n" : "if (k + " + S(hand + 1u) + "u < " + S(P) + "u) {\n");
+                // are only ever handed over in registers; a row below min(M, hand + 1) is never read from the tape either - as a
+                // low member it is in registers, as a high member it belongs to a slot i <= hand.)
+                os << (reg_high ? "if (k >= " + S(M) + "u && k + 2u < " + S(P) + "u) {\n" : "if (k >= " + S(std::min(M, hand + 1u)) + "u && k + " + S(hand + 1u) + "u < " + S(P) + "u) {\n");
                 if (il_tape) {
                     os << "HY_TST2(ak, bk, 2u * lo_" << r << ", tpa);\n";
                 } else {
