@@ -2091,11 +2091,13 @@ if (a.mode == 1) {
     // variable in its last round evaluates a copy of the last variable and the result is ignored.
     for (std::uint32_t r = 0; r < sv_rounds; ++r) {
         const bool partial = static_cast<std::uint64_t>(r + 1u) * bs > n_eq;
-        src << "const unsigned hi" << r << " = " << (partial ? "(tid + " + std::to_string(r * bs) + "u < " + std::to_string(n_eq)
-                                                                      + "u) ? tid + " + std::to_string(r * bs) + "u : "
-                                                                      + std::to_string(n_eq - 1u) + "u"
-                                                                : "tid + " + std::to_string(r * bs) + "u")
-            << ";\n";
+        // (Opaque to the optimiser: as invariants of the step loop the order + 1 addresses of a round are computed once per
+        // kernel and spilled - 42 registers reloaded from scratch at every step.)
+        src << "unsigned hi" << r << " = " << (partial ? "(tid + " + std::to_string(r * bs) + "u < " + std::to_string(n_eq)
+                                                                + "u) ? tid + " + std::to_string(r * bs) + "u : "
+                                                                + std::to_string(n_eq - 1u) + "u"
+                                                          : "tid + " + std::to_string(r * bs) + "u")
+            << ";\nasm volatile(\"\" : \"+v\"(hi" << r << "));\n";
         for (std::uint32_t k = 0; k <= order; ++k) {
             src << "const double hc" << r << "_" << k << " = sjet[" << static_cast<std::uint64_t>(k) * n_eq << "u + hi" << r
                 << "];\n";
@@ -2176,6 +2178,11 @@ if (tid == 0u) {
                 + " LDS-resident input jets), " + std::to_string(pl.groups.size()) + " glue groups, "
                 + std::to_string(n_slots) + " LDS slots, tape " + std::to_string(per_block * 8u / 1024u)
                 + " KiB per workgroup";
+    // Machine-level loop-invariant code motion off for the v2 kernel: invariants of the step loop hoisted in front of it
+    // are what the register allocator spills (nbody(64): 54 -> 41 spilled registers, +1.3 %; "licm": A/B harness).
+    if (v2 && ("," + opts.dev.block_opts + ",").find(",licm,") == std::string::npos) {
+        ret.compile_flags = "-mllvm -disable-machine-licm";
+    }
     if (v2) {
         ret.notes += "; v2 cluster phase: rolled order loop, " + std::to_string(n_iter) + " rounds per lane, rows < "
                      + std::to_string(v2_M) + " of the tape members in registers, the " + std::to_string(v2_hand)
