@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <functional>
 #include <map>
+#include <set>
 #include <sstream>
 #include <stdexcept>
 
@@ -397,12 +398,51 @@ std::string emit_unrolled_kernel(const taylor_program &p, const emit_options &op
     // kernels), unless kw::exact_division asks for the correctly rounded 3-operation sequence - 120 of them per step of
     // the two-body problem.
     e.recip_div = !opts.exact_division;
+    e.fold_zeros = opts.dev.unrolled_trim;
+    e.merge_sum_sq = opts.sum_order == 0 && opts.dev.unrolled_merge_ssq;
+
+    // ---- Cold coefficients parked in LDS (register-resident jets). ----
+    // A state variable which no elementary function reads (a velocity: it only defines x' = v) has coefficients with two
+    // uses - the next coefficient of the variable it defines, right away, and the evaluation of the series at the very end
+    // of the step. Held in registers through the orders they are what pushes the kernel beyond 256 architectural registers
+    // (two-body problem: 8 histories of 21 doubles, 3 of them cold; the compiler moves ~80 doubles to the accumulation
+    // registers and back, v_accvgpr_write / _read: 13 % of the VALU instructions of a step). One workgroup per CU runs
+    // anyway (one wavefront per SIMD), so its LDS is free: the cold coefficients of orders 1 ... order - 2 go there
+    // ([slot][lane], 8-byte stride over the lanes: no bank conflicts) and come back for the final evaluation - LDS
+    // instructions are not VALU instructions. Bit-identical. HEYOKA_AMD_UNROLLED_PARK=0 switches it off, =n limits the slots.
+    std::vector<char> cold(n_eq, 0);
+    std::map<std::pair<std::uint32_t, std::uint32_t>, std::uint32_t> park_slot;
+    std::uint32_t park_max = 0;
+    if (reg_jets && !stream_tc && opts.dev.unrolled_park != 0 && order >= 4u) {
+        std::fill(cold.begin(), cold.end(), 1);
+        for (const auto &nd : p.nodes) {
+            for (const auto &o : nd.args) {
+                if (o.type == operand::kind::uvar && o.idx < n_eq) {
+                    cold[o.idx] = 0;
+                }
+            }
+        }
+        for (const auto u : p.ev_u) {
+            if (u < n_eq) {
+                cold[u] = 0;
+            }
+        }
+        // (144 KB of the 160 KB of a CU.)
+        park_max = static_cast<std::uint32_t>((144u * 1024u) / (8u * bs));
+        if (opts.dev.unrolled_park > 0) {
+            park_max = std::min<std::uint32_t>(park_max, static_cast<std::uint32_t>(opts.dev.unrolled_park));
+        }
+    }
+    const auto is_ssa_name = [](const std::string &v) { return !v.empty() && v[0] == 't'; };
 
     os << "extern \"C\" __global__ void __launch_bounds__(" << bs << ") ";
     if (opts.dev.unrolled_waves > 0) {
         os << "__attribute__((amdgpu_waves_per_eu(" << opts.dev.unrolled_waves << ", " << opts.dev.unrolled_waves << "))) ";
     }
     os << kname << "(const hy_kargs a)\n{\n";
+    if (park_max != 0u) {
+        os << "@HY_PARK_DECL@";
+    }
     os << "const u64 s = (u64)blockIdx.x * " << bs << "u + threadIdx.x;\n";
     os << "if (s >= a.N) return;\n";
     os << "const u64 N = a.N;\n";
@@ -466,6 +506,12 @@ if (a.mode == 1) {
     }
     const auto store_sv = [&](std::uint32_t i, std::uint32_t k) {
         if (reg_jets && !stream_tc) {
+            if (park_max != 0u && cold[i] != 0 && k >= 1u && k + 2u <= order && is_ssa_name(e.val(i, k))
+                && park_slot.size() < park_max) {
+                const auto slot = static_cast<std::uint32_t>(park_slot.size());
+                park_slot[{i, k}] = slot;
+                os << "hy_park[" << (static_cast<std::uint64_t>(slot) * bs) << "u + threadIdx.x] = " << e.val(i, k) << ";\n";
+            }
             return;
         }
         os << "jet[(u64)" << (static_cast<std::uint64_t>(i) * (order + 1u) + k) << "u * N] = " << e.val(i, k)
@@ -555,9 +601,36 @@ if (a.mode == 1) {
     if (reg_jets) {
         // ---- State update straight from the SSA coefficients. ----
         // Coefficient k of state variable i: re-derived from the defining state variable when x' = v.
+        // (Parked coefficients: read back once, after a compiler barrier - the compiler would otherwise forward the stored
+        // values, i.e. keep them in registers. A coefficient of a defined variable which is also the coefficient of a u
+        // variable with a history - x^[k] = d^[k] where the partner of the difference d has vanishing derivatives - is live
+        // anyway and used as it is.)
+        std::set<std::string> hist_names;
+        std::map<std::pair<std::uint32_t, std::uint32_t>, std::string> unparked;
+        if (!park_slot.empty()) {
+            os << "asm volatile(\"\" ::: \"memory\");\n";
+            for (const auto &[ik, slot] : park_slot) {
+                unparked[ik] = e.def("hy_park[" + std::to_string(static_cast<std::uint64_t>(slot) * bs) + "u + threadIdx.x]");
+            }
+            for (const auto &nd : p.nodes) {
+                for (const auto &o : nd.args) {
+                    if (o.type == operand::kind::uvar) {
+                        for (std::uint32_t k = 0; k <= order; ++k) {
+                            hist_names.insert(e.val(o.idx, k));
+                        }
+                    }
+                }
+            }
+        }
         std::function<std::string(std::uint32_t, std::uint32_t)> coef = [&](std::uint32_t i, std::uint32_t k) {
             const auto &d = p.sv_defs[i];
+            if (const auto it = unparked.find({i, k}); it != unparked.end()) {
+                return it->second;
+            }
             if (k > 0u && d.type == operand::kind::uvar && d.idx < n_eq) {
+                if (!park_slot.empty() && hist_names.count(e.val(i, k)) != 0u) {
+                    return e.val(i, k);
+                }
                 return e.div_const(coef(d.idx, k - 1u), k);
             }
             return e.val(i, k);
@@ -577,8 +650,17 @@ if (a.mode == 1) {
                 for (std::uint32_t k = 0; k <= order; ++k) {
                     cs.push_back(coef(i, k));
                 }
-                os << "{\ndouble res = " << cs[order] << ";\n";
-                for (std::uint32_t k = 1; k <= order; ++k) {
+                // Leading coefficients which are the literal +0 (derivatives which vanish identically): the steps
+                // res = 0 + res * h over them yield +0 for a finite h and a NaN otherwise from the first one on - ONE of them
+                // is all of them (the compiler cannot drop any: no fast-math flags).
+                std::uint32_t top = order;
+                if (opts.dev.unrolled_trim) {
+                    while (top >= 1u && ssa_emitter::is_zero_lit(cs[top]) && ssa_emitter::is_zero_lit(cs[top - 1u])) {
+                        --top;
+                    }
+                }
+                os << "{\ndouble res = " << cs[top] << ";\n";
+                for (std::uint32_t k = order - top + 1u; k <= order; ++k) {
                     os << "res = " << cs[order - k] << " + res * h;\n";
                 }
                 os << "x" << i << "n = res;\n}\n";
@@ -661,7 +743,16 @@ if (a.mode == 1) {
 )HIP";
 
     n_stmt += e.n_stmt;
-    return os.str();
+    auto text = os.str();
+    if (park_max != 0u) {
+        const std::string tag = "@HY_PARK_DECL@";
+        const auto pos = text.find(tag);
+        assert(pos != std::string::npos);
+        text.replace(pos, tag.size(),
+                     park_slot.empty() ? std::string{}
+                                       : "__shared__ double hy_park[" + std::to_string(park_slot.size() * bs) + "];\n");
+    }
+    return text;
 }
 
 // Estimate (in doubles) of what a lane must keep alive in register-jet mode: the jets of the state variables
@@ -740,6 +831,13 @@ emitted_module emit_unrolled(const taylor_program &p, const emit_options &opts)
         ret.tc_kernel_name = "hy_taylor_tc";
         ret.tc_optional = true;
         ret.notes = "register-resident state jets (+ variant streaming the Taylor coefficients out)";
+        // Machine LICM off: the kernel body is ONE loop (the steps) around straight-line code; what LICM hoists out of it
+        // (literals of the recurrences, the polynomial constants of the selector's log / exp, store addresses) occupies
+        // registers through the whole step and ends up in accumulation registers, read back at every use (two-body: 37
+        // v_accvgpr_read per step instead of 116, no spills). HEYOKA_AMD_UNROLLED_LICM=1 switches it back on (A/B).
+        if (!opts.dev.unrolled_licm) {
+            ret.compile_flags = "-mllvm -disable-machine-licm";
+        }
     } else {
         src << emit_unrolled_kernel(p, opts, "hy_taylor", false, ret.n_statements);
     }
@@ -1469,6 +1567,10 @@ dev_switches dev_switches::from_env()
     d.ev_inline_max_nonlinear = num("HEYOKA_AMD_EV_INLINE_MAX_NONLINEAR", -1);
     d.v5_prio = num("HEYOKA_AMD_V5_PRIO", 2);
     d.unrolled_waves = num("HEYOKA_AMD_UNROLLED_WAVES", 0);
+    d.unrolled_park = num("HEYOKA_AMD_UNROLLED_PARK", 0);
+    d.unrolled_trim = !off("HEYOKA_AMD_UNROLLED_TRIM");
+    d.unrolled_merge_ssq = !off("HEYOKA_AMD_UNROLLED_MERGE_SSQ");
+    d.unrolled_licm = !off("HEYOKA_AMD_UNROLLED_LICM");
     d.v5_opts = str("HEYOKA_AMD_V5_OPTS");
     d.v5_pad = str("HEYOKA_AMD_V5_PAD");
     d.block_opts = str("HEYOKA_AMD_BLOCK_OPTS");

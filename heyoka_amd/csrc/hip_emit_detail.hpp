@@ -1,6 +1,7 @@
 // Internal pieces shared by the HIP code generators (hip_emit.cpp, hip_emit_cluster.cpp).
 #pragma once
 
+#include <algorithm>
 #include <cassert>
 #include <cmath>
 #include <cstdint>
@@ -111,6 +112,9 @@ struct ssa_emitter {
     // ~1.5 (k + 1) (half of the products cannot be fused into an addition). emit_options::sum_order selects
     // (hip_emit.hpp); the sums over the ARGUMENTS of sum() / sum_sq() are pairwise in both modes.
     bool running_sums = false;
+    // sum_sq(): one running sum over the half convolutions of ALL the arguments (not an order of the additions of the
+    // reference: only with the automatic sum_order of the straight-line generator).
+    bool merge_sum_sq = false;
     std::string conv_sum(std::vector<std::string> v)
     {
         if (!running_sums) {
@@ -148,6 +152,17 @@ struct ssa_emitter {
     {
         return a + " * " + b;
     }
+
+    // A coefficient which is the literal +0 (state variables and u variables whose derivatives vanish identically from some
+    // order on: x' = number, x' = v with a constant v). NOTE: not (-0x0p+0).
+    static bool is_zero_lit(const std::string &s)
+    {
+        return s == "0.0" || s == "0x0p+0";
+    }
+    // Folding of those literals in the generator (the compiler does the same on the products; what it cannot remove without
+    // fast-math flags are the chains built on top: 0 * h + 0 is a NaN for a non-finite h): x - (+0) = x for every x, signed
+    // zeros and NaNs included; (+0) * RN(1 / d) = +0. HEYOKA_AMD_UNROLLED_TRIM=0 switches it off (A/B).
+    bool fold_zeros = false;
 
     // Exponentiation by squaring (reference: pow_ebs(), src/math/pow.cpp:136-152).
     std::string pow_ebs(const std::string &base, std::uint32_t e)
@@ -222,6 +237,10 @@ struct ssa_emitter {
             case func_kind::sub: {
                 // Reference: src/detail/sub.cpp:60-124.
                 if (is_var(a[0]) && is_var(a[1])) {
+                    if (fold_zeros && is_zero_lit(val(a[1].idx, k))) {
+                        out = val(a[0].idx, k);
+                        break;
+                    }
                     out = def(val(a[0].idx, k) + " - " + val(a[1].idx, k));
                 } else if (is_var(a[0])) {
                     out = (k == 0u) ? def(val(a[0].idx, 0) + " - " + numpar(a[1])) : val(a[0].idx, k);
@@ -301,6 +320,25 @@ struct ssa_emitter {
             case func_kind::sum_sq: {
                 // Reference: src/detail/sum_sq.cpp:100-245.
                 std::vector<std::string> tmp;
+                if (merge_sum_sq && k > 0u && std::all_of(a.begin(), a.end(), [](const operand &o) { return is_var(o); })) {
+                    // ONE accumulator for the half sums of all the arguments (like the pair kernels): the doubling and the
+                    // additions between the arguments are paid once per order instead of once per argument.
+                    std::string acc;
+                    const auto jend = (k % 2u == 1u) ? (k - 1u) / 2u + 1u : k / 2u;
+                    for (const auto &o : a) {
+                        for (std::uint32_t j = 0; j < jend; ++j) {
+                            acc = chain(acc, val(o.idx, k - j), val(o.idx, j));
+                        }
+                    }
+                    out = def(acc + " + " + acc);
+                    if (k % 2u == 0u) {
+                        for (const auto &o : a) {
+                            const auto &hv = val(o.idx, k / 2u);
+                            out = def(mul(hv, hv) + " + " + out);
+                        }
+                    }
+                    break;
+                }
                 if (k % 2u == 1u) {
                     for (const auto &o : a) {
                         if (is_var(o)) {
@@ -1181,6 +1219,9 @@ struct ssa_emitter {
     {
         if (d == 1u) {
             return x;
+        }
+        if (fold_zeros && is_zero_lit(x)) {
+            return "0.0";
         }
         if ((d & (d - 1u)) == 0u || recip_div) {
             // Power of two: the multiplication by the reciprocal is exact.
