@@ -383,8 +383,11 @@ void emit_dout(std::ostringstream &os, const taylor_program &p, const emit_optio
 // defined by other state variables (x' = v) are re-derived in the final evaluation instead of being stored.
 // stream_tc (with reg_jets): the Taylor coefficients are additionally streamed to a.tc as they are produced (stores
 // only, nothing is read back): the write_tc / continuous-output / propagate_grid variant of a register-resident stepper.
+// (waves: amdgpu_waves_per_eu of the kernel, 0 = the compiler's choice; n_derived: the number of state variables whose
+// coefficient histories are not kept because they are re-derived at the end of the step - see "The other way round" below.)
 std::string emit_unrolled_kernel(const taylor_program &p, const emit_options &opts, const std::string &kname,
-                                 bool reg_jets, std::uint64_t &n_stmt, bool stream_tc = false)
+                                 bool reg_jets, std::uint64_t &n_stmt, bool stream_tc = false, int waves = 0,
+                                 std::uint32_t *n_derived = nullptr)
 {
     const auto n_eq = p.n_eq;
     const auto order = opts.order;
@@ -401,48 +404,11 @@ std::string emit_unrolled_kernel(const taylor_program &p, const emit_options &op
     e.fold_zeros = opts.dev.unrolled_trim;
     e.merge_sum_sq = opts.sum_order == 0 && opts.dev.unrolled_merge_ssq;
 
-    // ---- Cold coefficients parked in LDS (register-resident jets). ----
-    // A state variable which no elementary function reads (a velocity: it only defines x' = v) has coefficients with two
-    // uses - the next coefficient of the variable it defines, right away, and the evaluation of the series at the very end
-    // of the step. Held in registers through the orders they are what pushes the kernel beyond 256 architectural registers
-    // (two-body problem: 8 histories of 21 doubles, 3 of them cold; the compiler moves ~80 doubles to the accumulation
-    // registers and back, v_accvgpr_write / _read: 13 % of the VALU instructions of a step). One workgroup per CU runs
-    // anyway (one wavefront per SIMD), so its LDS is free: the cold coefficients of orders 1 ... order - 2 go there
-    // ([slot][lane], 8-byte stride over the lanes: no bank conflicts) and come back for the final evaluation - LDS
-    // instructions are not VALU instructions. Bit-identical. HEYOKA_AMD_UNROLLED_PARK=0 switches it off, =n limits the slots.
-    std::vector<char> cold(n_eq, 0);
-    std::map<std::pair<std::uint32_t, std::uint32_t>, std::uint32_t> park_slot;
-    std::uint32_t park_max = 0;
-    if (reg_jets && !stream_tc && opts.dev.unrolled_park != 0 && order >= 4u) {
-        std::fill(cold.begin(), cold.end(), 1);
-        for (const auto &nd : p.nodes) {
-            for (const auto &o : nd.args) {
-                if (o.type == operand::kind::uvar && o.idx < n_eq) {
-                    cold[o.idx] = 0;
-                }
-            }
-        }
-        for (const auto u : p.ev_u) {
-            if (u < n_eq) {
-                cold[u] = 0;
-            }
-        }
-        // (144 KB of the 160 KB of a CU.)
-        park_max = static_cast<std::uint32_t>((144u * 1024u) / (8u * bs));
-        if (opts.dev.unrolled_park > 0) {
-            park_max = std::min<std::uint32_t>(park_max, static_cast<std::uint32_t>(opts.dev.unrolled_park));
-        }
-    }
-    const auto is_ssa_name = [](const std::string &v) { return !v.empty() && v[0] == 't'; };
-
     os << "extern \"C\" __global__ void __launch_bounds__(" << bs << ") ";
-    if (opts.dev.unrolled_waves > 0) {
-        os << "__attribute__((amdgpu_waves_per_eu(" << opts.dev.unrolled_waves << ", " << opts.dev.unrolled_waves << "))) ";
+    if (waves > 0) {
+        os << "__attribute__((amdgpu_waves_per_eu(" << waves << ", " << waves << "))) ";
     }
     os << kname << "(const hy_kargs a)\n{\n";
-    if (park_max != 0u) {
-        os << "@HY_PARK_DECL@";
-    }
     os << "const u64 s = (u64)blockIdx.x * " << bs << "u + threadIdx.x;\n";
     os << "if (s >= a.N) return;\n";
     os << "const u64 N = a.N;\n";
@@ -506,12 +472,6 @@ if (a.mode == 1) {
     }
     const auto store_sv = [&](std::uint32_t i, std::uint32_t k) {
         if (reg_jets && !stream_tc) {
-            if (park_max != 0u && cold[i] != 0 && k >= 1u && k + 2u <= order && is_ssa_name(e.val(i, k))
-                && park_slot.size() < park_max) {
-                const auto slot = static_cast<std::uint32_t>(park_slot.size());
-                park_slot[{i, k}] = slot;
-                os << "hy_park[" << (static_cast<std::uint64_t>(slot) * bs) << "u + threadIdx.x] = " << e.val(i, k) << ";\n";
-            }
             return;
         }
         os << "jet[(u64)" << (static_cast<std::uint64_t>(i) * (order + 1u) + k) << "u * N] = " << e.val(i, k)
@@ -601,37 +561,50 @@ if (a.mode == 1) {
     if (reg_jets) {
         // ---- State update straight from the SSA coefficients. ----
         // Coefficient k of state variable i: re-derived from the defining state variable when x' = v.
-        // (Parked coefficients: read back once, after a compiler barrier - the compiler would otherwise forward the stored
-        // values, i.e. keep them in registers. A coefficient of a defined variable which is also the coefficient of a u
-        // variable with a history - x^[k] = d^[k] where the partner of the difference d has vanishing derivatives - is live
-        // anyway and used as it is.)
+        // The other way round for a variable v which only DEFINES another one (x' = v, no elementary function reads v) when
+        // the coefficients of x are live anyway (they are the coefficients of a u variable with a history: x^[k] = d^[k]
+        // where the partner of the difference d has vanishing derivatives - a test particle): v^[k] = (k + 1) x^[k+1], one
+        // multiplication at the end of the step instead of a coefficient history through the orders (two-body problem:
+        // 3 of 8 histories). Within 1.5 ulp of the coefficient (x^[k+1] = RN(v^[k] RN(1 / (k + 1)))): not under
+        // kw::exact_division.
         std::set<std::string> hist_names;
-        std::map<std::pair<std::uint32_t, std::uint32_t>, std::string> unparked;
-        if (!park_slot.empty()) {
-            os << "asm volatile(\"\" ::: \"memory\");\n";
-            for (const auto &[ik, slot] : park_slot) {
-                unparked[ik] = e.def("hy_park[" + std::to_string(static_cast<std::uint64_t>(slot) * bs) + "u + threadIdx.x]");
-            }
+        std::vector<std::int64_t> defines(n_eq, -1);
+        if (opts.dev.unrolled_derive && !opts.exact_division) {
+            std::vector<char> read_by_node(n_eq, 0);
             for (const auto &nd : p.nodes) {
                 for (const auto &o : nd.args) {
                     if (o.type == operand::kind::uvar) {
+                        if (o.idx < n_eq) {
+                            read_by_node[o.idx] = 1;
+                        }
                         for (std::uint32_t k = 0; k <= order; ++k) {
                             hist_names.insert(e.val(o.idx, k));
                         }
                     }
                 }
             }
+            for (std::uint32_t j = 0; j < n_eq; ++j) {
+                const auto &d = p.sv_defs[j];
+                if (d.type == operand::kind::uvar && d.idx < n_eq && read_by_node[d.idx] == 0) {
+                    defines[d.idx] = (defines[d.idx] == -1) ? static_cast<std::int64_t>(j) : -2;
+                }
+            }
         }
+        std::vector<std::uint32_t> derived_count(n_eq, 0);
         std::function<std::string(std::uint32_t, std::uint32_t)> coef = [&](std::uint32_t i, std::uint32_t k) {
             const auto &d = p.sv_defs[i];
-            if (const auto it = unparked.find({i, k}); it != unparked.end()) {
-                return it->second;
-            }
             if (k > 0u && d.type == operand::kind::uvar && d.idx < n_eq) {
-                if (!park_slot.empty() && hist_names.count(e.val(i, k)) != 0u) {
+                if (defines[d.idx] >= 0 && hist_names.count(e.val(i, k)) != 0u) {
                     return e.val(i, k);
                 }
                 return e.div_const(coef(d.idx, k - 1u), k);
+            }
+            if (k > 0u && k < order && defines[i] >= 0) {
+                const auto &xk = e.val(static_cast<std::uint32_t>(defines[i]), k + 1u);
+                if (hist_names.count(xk) != 0u && !ssa_emitter::is_zero_lit(xk)) {
+                    ++derived_count[i];
+                    return e.def(ssa_emitter::mul(fp_literal(static_cast<double>(k + 1u)), xk));
+                }
             }
             return e.val(i, k);
         };
@@ -668,6 +641,10 @@ if (a.mode == 1) {
         }
         for (std::uint32_t i = 0; i < n_eq; ++i) {
             os << "x" << i << " = x" << i << "n;\n";
+        }
+        if (n_derived != nullptr) {
+            *n_derived = static_cast<std::uint32_t>(
+                std::count_if(derived_count.begin(), derived_count.end(), [&](std::uint32_t c) { return c + 1u == order; }));
         }
     } else {
         // ---- State update: reload the coefficients from the jet buffer. ----
@@ -743,16 +720,7 @@ if (a.mode == 1) {
 )HIP";
 
     n_stmt += e.n_stmt;
-    auto text = os.str();
-    if (park_max != 0u) {
-        const std::string tag = "@HY_PARK_DECL@";
-        const auto pos = text.find(tag);
-        assert(pos != std::string::npos);
-        text.replace(pos, tag.size(),
-                     park_slot.empty() ? std::string{}
-                                       : "__shared__ double hy_park[" + std::to_string(park_slot.size() * bs) + "];\n");
-    }
-    return text;
+    return os.str();
 }
 
 // Estimate (in doubles) of what a lane must keep alive in register-jet mode: the jets of the state variables
@@ -824,22 +792,35 @@ emitted_module emit_unrolled(const taylor_program &p, const emit_options &opts)
     // NOTE: the stepper with events needs the Taylor coefficients in memory (event detection, dense output).
     const bool reg_jets = p.ev_u.empty() && reg_jet_estimate(p, opts.order) <= 200u;
     if (reg_jets) {
-        src << emit_unrolled_kernel(p, opts, "hy_taylor", true, ret.n_statements);
+        // Two wavefronts per SIMD (256 registers per lane) when what a lane keeps through the orders leaves room for the
+        // working set: measured on the two-body problem with a test particle, where the histories of the velocities are
+        // re-derived (5 histories instead of 8: 1.26e10 -> 1.38e10 system-steps/s with 50 spilled registers; with all 8
+        // histories the same attribute costs 2.3x, profiles/r05_ab_two_body_one_vs_two_wavefronts.log). Only there: a
+        // decomposition which keeps that little WITHOUT the re-derivation is compiled as before (not measured).
+        // HEYOKA_AMD_UNROLLED_WAVES=n forces n.
+        int waves = opts.dev.unrolled_waves;
+        if (waves == 0) {
+            std::uint64_t n_tmp = 0;
+            std::uint32_t n_derived = 0;
+            emit_unrolled_kernel(p, opts, "hy_taylor", true, n_tmp, false, 0, &n_derived);
+            const auto est = reg_jet_estimate(p, opts.order);
+            if (n_derived > 0u && est >= static_cast<std::uint64_t>(n_derived) * (opts.order + 1u)
+                && est - static_cast<std::uint64_t>(n_derived) * (opts.order + 1u) <= 126u) {
+                waves = 2;
+            }
+        }
+        src << emit_unrolled_kernel(p, opts, "hy_taylor", true, ret.n_statements, false, waves);
         // NOTE: the variant serving write_tc streams the coefficients out of the same register-resident code (round 1
         // went through the jets-in-memory kernel: 512 registers, 790 spilled dwords for the two-body problem).
-        src << emit_unrolled_kernel(p, opts, "hy_taylor_tc", true, ret.n_statements, true);
+        src << emit_unrolled_kernel(p, opts, "hy_taylor_tc", true, ret.n_statements, true, waves);
         ret.tc_kernel_name = "hy_taylor_tc";
         ret.tc_optional = true;
         ret.notes = "register-resident state jets (+ variant streaming the Taylor coefficients out)";
-        // Machine LICM off: the kernel body is ONE loop (the steps) around straight-line code; what LICM hoists out of it
-        // (literals of the recurrences, the polynomial constants of the selector's log / exp, store addresses) occupies
-        // registers through the whole step and ends up in accumulation registers, read back at every use (two-body: 37
-        // v_accvgpr_read per step instead of 116, no spills). HEYOKA_AMD_UNROLLED_LICM=1 switches it back on (A/B).
-        if (!opts.dev.unrolled_licm) {
-            ret.compile_flags = "-mllvm -disable-machine-licm";
+        if (waves == 2 && opts.dev.unrolled_waves == 0) {
+            ret.notes += ", two wavefronts per SIMD (coefficient histories of the variables which only define x' = v re-derived)";
         }
     } else {
-        src << emit_unrolled_kernel(p, opts, "hy_taylor", false, ret.n_statements);
+        src << emit_unrolled_kernel(p, opts, "hy_taylor", false, ret.n_statements, false, opts.dev.unrolled_waves);
     }
     ret.source = src.str();
     ret.kernel_name = "hy_taylor";
@@ -1567,10 +1548,9 @@ dev_switches dev_switches::from_env()
     d.ev_inline_max_nonlinear = num("HEYOKA_AMD_EV_INLINE_MAX_NONLINEAR", -1);
     d.v5_prio = num("HEYOKA_AMD_V5_PRIO", 2);
     d.unrolled_waves = num("HEYOKA_AMD_UNROLLED_WAVES", 0);
-    d.unrolled_park = num("HEYOKA_AMD_UNROLLED_PARK", 0);
     d.unrolled_trim = !off("HEYOKA_AMD_UNROLLED_TRIM");
     d.unrolled_merge_ssq = !off("HEYOKA_AMD_UNROLLED_MERGE_SSQ");
-    d.unrolled_licm = !off("HEYOKA_AMD_UNROLLED_LICM");
+    d.unrolled_derive = !off("HEYOKA_AMD_UNROLLED_DERIVE");
     d.v5_opts = str("HEYOKA_AMD_V5_OPTS");
     d.v5_pad = str("HEYOKA_AMD_V5_PAD");
     d.block_opts = str("HEYOKA_AMD_BLOCK_OPTS");

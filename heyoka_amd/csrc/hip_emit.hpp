@@ -91,11 +91,11 @@ struct dev_switches {
     // HEYOKA_AMD_UNROLLED_WAVES=n: the straight-line stepper is compiled for n wavefronts per SIMD (amdgpu_waves_per_eu: the
     // register allocator gets 512 / n registers per lane and spills the rest - the two-wavefront experiment of round 5).
     int unrolled_waves = 0;
-    // Straight-line stepper with register-resident jets: cold coefficients parked in LDS (HEYOKA_AMD_UNROLLED_PARK: -1
-    // automatic, 0 off, n = at most n slots), literal-zero coefficients folded in the generator and the Horner steps over
-    // leading zeros collapsed into one (HEYOKA_AMD_UNROLLED_TRIM=0: off) - see emit_unrolled_kernel().
-    int unrolled_park = 0;
-    bool unrolled_trim = true, unrolled_licm = true, unrolled_merge_ssq = true;
+    // Straight-line stepper with register-resident jets (see emit_unrolled_kernel(); A/B: profiles/r06_two_body_unrolled_ab.log):
+    // literal-zero coefficients folded in the generator and the Horner steps over leading zeros collapsed into one
+    // (HEYOKA_AMD_UNROLLED_TRIM=0: off), one running sum for the sum of squares (HEYOKA_AMD_UNROLLED_MERGE_SSQ=0: off), the
+    // coefficients of a variable which only defines x' = v re-derived from those of x (HEYOKA_AMD_UNROLLED_DERIVE=0: off).
+    bool unrolled_trim = true, unrolled_merge_ssq = true, unrolled_derive = true;
     std::string v5_opts, v5_pad;
     // HEYOKA_AMD_BLOCK_OPTS: comma-separated items of the v2 cluster phase of block mode switched one by one (A/B harness,
     // timing experiments - see hip_emit_block.cpp).

@@ -1111,9 +1111,17 @@ __device__ __forceinline__ double hy_dpp(double x)
     // (HEYOKA_AMD_TABLE_LDS=7 / 8, A/B harness: the order loop unrolled - the terms of the convolutions become straight-line
     // code with constant LDS offsets -, 8: compiled for two wavefronts per SIMD, 256 registers.)
     const bool unroll_orders = opts.dev.table_lds == 7 || opts.dev.table_lds == 8;
-    const auto waves_per_simd = opts.dev.table_lds == 8
-                                    ? std::uint64_t(2)
-                                    : std::max<std::uint64_t>(1u, std::min<std::uint64_t>(8u, (per_cu * wps + 3u) / 4u));
+    // NOTE: not more wavefronts than the registers of a lane allow WITHOUT spilling its table registers (offsets and constants
+    // of its nodes, loaded once per kernel) - 512 / (table registers + ~56 of working set). The attribute is a demand on the
+    // register allocator: a decomposition with 117 table registers compiled for the 7 wavefronts its LDS tapes allow spilled
+    // 637 registers (1 560 B of scratch per lane) - and returned results which differed from run to run on the GPU
+    // (profiles/r06_staged_spill_nondeterminism.log; the same source is exact under the emulator).
+    const std::uint64_t n_table_regs = lt.urows.size() + 2u * lt.drows.size() + 2u * lt.prows.size();
+    const auto waves_by_regs = std::max<std::uint64_t>(1u, 512u / (((n_table_regs + 56u) + 7u) / 8u * 8u));
+    const auto waves_per_simd
+        = opts.dev.table_lds == 8
+              ? std::uint64_t(2)
+              : std::max<std::uint64_t>(1u, std::min<std::uint64_t>({std::uint64_t(8), (per_cu * wps + 3u) / 4u, waves_by_regs}));
     src << "extern \"C\" __global__ __attribute__((amdgpu_waves_per_eu(" << waves_per_simd << "))) void __launch_bounds__(" << LANES
         << ") hy_taylor(const hy_kargs a)\n{\n";
     src << "const unsigned lane = threadIdx.x;\nconst u64 N = a.N;\n";
