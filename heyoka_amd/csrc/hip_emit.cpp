@@ -402,7 +402,7 @@ std::string emit_unrolled_kernel(const taylor_program &p, const emit_options &op
     // the two-body problem.
     e.recip_div = !opts.exact_division;
     e.fold_zeros = opts.dev.unrolled_trim;
-    e.merge_sum_sq = opts.sum_order == 0 && opts.dev.unrolled_merge_ssq;
+    e.merge_sum_sq = opts.sum_order == 0 && !opts.exact_division && opts.dev.unrolled_merge_ssq;
 
     os << "extern \"C\" __global__ void __launch_bounds__(" << bs << ") ";
     if (waves > 0) {
@@ -483,18 +483,50 @@ if (a.mode == 1) {
     for (std::uint32_t i = 0; i < p.nodes.size(); ++i) {
         e.node(i, 0);
     }
+    // x' = v, v' = u with a v which no elementary function reads (register-resident jets, not under kw::exact_division):
+    // x^[k] = u^[k-2] RN(1 / (k (k - 1))) - one multiplication instead of the two through v^[k-1], whose only other use is
+    // the final evaluation (where it is re-derived from x, see below; the compiler drops the unused ones).
+    std::vector<std::int64_t> second_order(n_eq, -1);
+    if (reg_jets && !stream_tc && opts.dev.unrolled_derive && !opts.exact_division) {
+        std::vector<char> read_by_node(n_eq, 0);
+        for (const auto &nd : p.nodes) {
+            for (const auto &o : nd.args) {
+                if (o.type == operand::kind::uvar && o.idx < n_eq) {
+                    read_by_node[o.idx] = 1;
+                }
+            }
+        }
+        for (std::uint32_t i = 0; i < n_eq; ++i) {
+            const auto &d = p.sv_defs[i];
+            if (d.type == operand::kind::uvar && d.idx < n_eq && read_by_node[d.idx] == 0) {
+                const auto &dd = p.sv_defs[d.idx];
+                if (dd.type == operand::kind::uvar && dd.idx >= n_eq) {
+                    second_order[i] = dd.idx;
+                }
+            }
+        }
+    }
+    const auto emit_sv = [&](std::uint32_t i, std::uint32_t k) {
+        if (k >= 2u && second_order[i] >= 0) {
+            const auto &src = e.val(static_cast<std::uint32_t>(second_order[i]), k - 2u);
+            e.val(i, k) = ssa_emitter::is_zero_lit(src)
+                              ? std::string("0.0")
+                              : e.def(ssa_emitter::mul(src, fp_literal(1. / (static_cast<double>(k) * static_cast<double>(k - 1u)))));
+        } else {
+            e.sv(i, k);
+        }
+        store_sv(i, k);
+    };
     for (std::uint32_t k = 1; k < order; ++k) {
         for (std::uint32_t i = 0; i < n_eq; ++i) {
-            e.sv(i, k);
-            store_sv(i, k);
+            emit_sv(i, k);
         }
         for (std::uint32_t i = 0; i < p.nodes.size(); ++i) {
             e.node(i, k);
         }
     }
     for (std::uint32_t i = 0; i < n_eq; ++i) {
-        e.sv(i, order);
-        store_sv(i, order);
+        emit_sv(i, order);
     }
 
     // Integrators with events: every step is a step with events (mode 4), which needs the order-p coefficients of the u

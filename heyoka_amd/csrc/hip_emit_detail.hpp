@@ -113,7 +113,7 @@ struct ssa_emitter {
     // (hip_emit.hpp); the sums over the ARGUMENTS of sum() / sum_sq() are pairwise in both modes.
     bool running_sums = false;
     // sum_sq(): one running sum over the half convolutions of ALL the arguments (not an order of the additions of the
-    // reference: only with the automatic sum_order of the straight-line generator).
+    // reference: only with the automatic sum_order of the straight-line generator and not under kw::exact_division).
     bool merge_sum_sq = false;
     std::string conv_sum(std::vector<std::string> v)
     {
