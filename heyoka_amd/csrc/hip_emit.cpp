@@ -487,7 +487,7 @@ if (a.mode == 1) {
     // x^[k] = u^[k-2] RN(1 / (k (k - 1))) - one multiplication instead of the two through v^[k-1], whose only other use is
     // the final evaluation (where it is re-derived from x, see below; the compiler drops the unused ones).
     std::vector<std::int64_t> second_order(n_eq, -1);
-    if (reg_jets && !stream_tc && opts.dev.unrolled_derive && !opts.exact_division) {
+    if (reg_jets && opts.dev.unrolled_derive && !opts.exact_division) {
         std::vector<char> read_by_node(n_eq, 0);
         for (const auto &nd : p.nodes) {
             for (const auto &o : nd.args) {

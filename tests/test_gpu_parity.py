@@ -1353,6 +1353,26 @@ EXT_SEEDS = [1000 + i for i in range(12)]
 
 
 @pytest.mark.gpu
+def test_unrolled_kernel_and_its_tc_variant_take_the_same_steps():
+    """The straight-line stepper with register-resident jets and its variant which streams the Taylor coefficients out
+    (write_tc) share their arithmetic - the re-derived velocity histories and the one-multiplication x'' = u recursion of
+    round 6 included: the same states and step sizes bit for bit; two wavefronts per SIMD on the test-particle system."""
+    n = 256
+    st = configs.two_body_state(n, perturb=1e-3, seed=5)
+    sys_ = hy.model.nbody(2, masses=[1.0, 0.0])
+    ta, tb = hy.taylor_adaptive_batch(sys_, st, n), hy.taylor_adaptive_batch(sys_, st, n)
+    assert "two wavefronts per SIMD" in ta.hip_source_mode
+    for _ in range(5):
+        ta.step()
+        tb.step(write_tc=True)
+        assert [h for _, h in ta.step_res] == [h for _, h in tb.step_res]
+        assert np.array_equal(np.asarray(ta.state), np.asarray(tb.state))
+    # The coefficients written are those of the step: order 0 = the state before it, order 1 of a position = the velocity.
+    tc = np.asarray(tb.tc).reshape(12, tb.order + 1, n)
+    assert np.array_equal(tc[6:9, 1, :], tc[9:12, 0, :])
+
+
+@pytest.mark.gpu
 def test_staged_table_stepper_is_deterministic_run_to_run():
     """The staged table stepper on the pseudo-random system which exposed run-to-run differences on the GPU (a kernel
     compiled for the occupancy of its LDS tapes with 637 spilled registers: profiles/r06_staged_spill_nondeterminism.log):
