@@ -54,6 +54,10 @@ WORKLOADS = {
     # - a mixed model on the multi-class wave-cluster stepper (pendulum chain with cubic bonds: two classes of clusters).
     "outer_ss_compact_mode": None,
     "outer_ss_forced_table": None,
+    # - the same DAG on the OTHER table stepper: one system per lane, the rule functions interpreted from node tables, the
+    #   tape in HBM - the north star's literal formulation and the fallback for decompositions whose tape exceeds the LDS of
+    #   a CU (HEYOKA_AMD_TABLE_LDS=0 switches the staged variant off while the integrator is built);
+    "outer_ss_forced_table_hbm_tape": None,
     "nbody6_j2_mixed": None,
     "sine_lattice16_mixed": None,
 }
@@ -63,12 +67,13 @@ WORKLOAD_ICS = {
     "nbody6_default_masses": "Plummer spheres of 6 bodies (seeded)",
     "outer_ss_compact_mode": "perturbed ICs (perturb 1e-12, seed 42+rank), kw::compact_mode = true",
     "outer_ss_forced_table": "perturbed ICs (perturb 1e-12, seed 42+rank), kw::emitter = table (the staged table stepper)",
+    "outer_ss_forced_table_hbm_tape": "perturbed ICs (perturb 1e-12, seed 42+rank), kw::emitter = table with the staged variant switched off (one system per lane, tape in HBM)",
     "nbody6_j2_mixed": "perturbed outer-SS ICs, point masses + oblateness of the first body (heyoka_amd/mixed_models.py)",
     "sine_lattice16_mixed": "random ICs of a chain of 16 pendula with cubic bonds (heyoka_amd/mixed_models.py, seeded)",
 }
 # Default ensemble sizes of the BASELINE.json configurations (systems per GPU).
 DEFAULT_SYSTEMS = {"outer_ss": 1048576, "two_body": 4194304, "nbody64": 65536, "nbody6_default_masses": 1048576,
-                   "outer_ss_compact_mode": 1048576, "outer_ss_forced_table": 262144, "nbody6_j2_mixed": 262144,
+                   "outer_ss_compact_mode": 1048576, "outer_ss_forced_table": 262144, "outer_ss_forced_table_hbm_tape": 262144, "nbody6_j2_mixed": 262144,
                    "sine_lattice16_mixed": 262144}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_PEAK_TFLOPS = 78.6  # vector FP64
@@ -82,12 +87,23 @@ def make_integrator(hy, configs, workload, n_systems, seed, device=0):
         # Years per bench step: ~82 Taylor steps per system and call, i.e. ~0.17 s of kernel per step - the timed region
         # of the driver's `--steps 20 --warmup 5` is > 3 s (clock / thermal steady state, visible to the SMI sampler).
         dt = 60.0
-    elif workload in ("outer_ss_compact_mode", "outer_ss_forced_table"):
+    elif workload in ("outer_ss_compact_mode", "outer_ss_forced_table", "outer_ss_forced_table_hbm_tape"):
         sys_ = hy.model.nbody(6, masses=configs.OUTER_SS_MASSES, Gconst=configs.OUTER_SS_G)
         st = configs.outer_ss_state(n_systems, perturb=1e-12, seed=seed)
         if workload == "outer_ss_compact_mode":
             ta = hy.taylor_adaptive_batch(sys_, None, n_systems, high_accuracy=True, compact_mode=True, device=device)
             dt = 60.0
+        elif workload == "outer_ss_forced_table_hbm_tape":
+            old = os.environ.get("HEYOKA_AMD_TABLE_LDS")
+            os.environ["HEYOKA_AMD_TABLE_LDS"] = "0"
+            try:
+                ta = hy.taylor_adaptive_batch(sys_, None, n_systems, high_accuracy=True, emitter="table", device=device)
+            finally:
+                if old is None:
+                    del os.environ["HEYOKA_AMD_TABLE_LDS"]
+                else:
+                    os.environ["HEYOKA_AMD_TABLE_LDS"] = old
+            dt = 10.0
         else:
             ta = hy.taylor_adaptive_batch(sys_, None, n_systems, high_accuracy=True, emitter="table", device=device)
             dt = 10.0
@@ -879,7 +895,8 @@ def main():
             except Exception as e:
                 extra.append({"config": {"workload": "nbody6_default_masses"}, "error": "%s: %s" % (type(e).__name__, e)})
             # Round 6: the general-DAG paths (see WORKLOADS), each with its own roofline.
-            for wl in ("outer_ss_compact_mode", "outer_ss_forced_table", "nbody6_j2_mixed", "sine_lattice16_mixed"):
+            for wl in ("outer_ss_compact_mode", "outer_ss_forced_table", "outer_ss_forced_table_hbm_tape", "nbody6_j2_mixed",
+                       "sine_lattice16_mixed"):
                 try:
                     r = run_workload(ctx, wl, DEFAULT_SYSTEMS[wl], 3, 1)
                     leg = {k: r[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline")}
