@@ -1117,7 +1117,9 @@ __device__ __forceinline__ double hy_dpp(double x)
     // 637 registers (1 560 B of scratch per lane) - and returned results which differed from run to run on the GPU
     // (profiles/r06_staged_spill_nondeterminism.log; the same source is exact under the emulator).
     const std::uint64_t n_table_regs = lt.urows.size() + 2u * lt.drows.size() + 2u * lt.prows.size();
-    const auto waves_by_regs = std::max<std::uint64_t>(1u, 512u / (((n_table_regs + 56u) + 7u) / 8u * 8u));
+    // (Rounds through the interpreter are non-inlined calls: room for the callee's registers as well.)
+    const std::uint64_t n_work_regs = 56u + (n_generic != 0u ? 64u : 0u);
+    const auto waves_by_regs = std::max<std::uint64_t>(1u, 512u / (((n_table_regs + n_work_regs) + 7u) / 8u * 8u));
     const auto waves_per_simd
         = opts.dev.table_lds == 8
               ? std::uint64_t(2)

@@ -1373,6 +1373,49 @@ def test_unrolled_kernel_and_its_tc_variant_take_the_same_steps():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("path", ["v5", "unrolled_two_waves", "staged", "table_hbm", "multi_class", "block_v2"])
+def test_every_stepper_is_deterministic_run_to_run(path, monkeypatch):
+    """The same propagation twice on fresh integrators, one per code path, through the device-side work queue (which hands
+    the systems to the lanes in an order which differs from run to run): states, times, step counts and extreme step
+    sizes are identical bit for bit - no result depends on which lane, workgroup or neighbour a system happened to get."""
+    from heyoka_amd import mixed_models as mm
+
+    M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+    kw, t_end = {}, 30.0
+    if path in ("v5", "staged", "table_hbm"):
+        n = 8192 if path == "v5" else 2048
+        sys_, st = hy.model.nbody(6, masses=M, Gconst=G), configs.outer_ss_state(n, perturb=1e-3, seed=3)
+        kw = dict(high_accuracy=True)
+        if path != "v5":
+            kw["emitter"] = "table"
+            t_end = 5.0
+        if path == "table_hbm":
+            monkeypatch.setenv("HEYOKA_AMD_TABLE_LDS", "0")
+    elif path == "unrolled_two_waves":
+        n = 16384
+        sys_, st = hy.model.nbody(2, masses=[1.0, 0.0]), configs.two_body_state(n, perturb=1e-3, seed=3)
+    elif path == "multi_class":
+        n, t_end = 4096, 2.0
+        sys_, st = mm.sine_lattice(hy, 16), mm.sine_lattice_state(16, n, seed=3)
+    else:
+        n, t_end = 128, 0.02
+        sys_, st = hy.model.nbody(64), configs.plummer_nbody_state(64, n, seed=3)
+    # (Final times which differ from system to system: the lanes of a wavefront finish at different moments.)
+    tf = t_end * np.random.RandomState(1).uniform(0.5, 1.5, n)
+    res = []
+    for _ in range(2):
+        ta = hy.taylor_adaptive_batch(sys_, st, n, **kw)
+        want = {"v5": "v5", "unrolled_two_waves": "two wavefronts per SIMD", "staged": "staged", "table_hbm": "tape in HBM",
+                "multi_class": "classes of clusters", "block_v2": "v2 cluster phase"}[path]
+        assert want in ta.hip_source_mode, ta.hip_source_mode
+        ta.propagate_until(tf)
+        arr = ta.propagate_res_arrays()
+        res.append([np.asarray(ta.state).copy(), np.asarray(ta.time).copy()] + [np.asarray(a).copy() for a in arr])
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
 def test_staged_table_stepper_is_deterministic_run_to_run():
     """The staged table stepper on the pseudo-random system which exposed run-to-run differences on the GPU (a kernel
     compiled for the occupancy of its LDS tapes with 637 spilled registers: profiles/r06_staged_spill_nondeterminism.log):
