@@ -1373,7 +1373,8 @@ def test_unrolled_kernel_and_its_tc_variant_take_the_same_steps():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("path", ["v5", "unrolled_two_waves", "staged", "table_hbm", "multi_class", "block_v2"])
+@pytest.mark.parametrize("path", ["v5", "v3", "v2", "v2_aliased", "unrolled_two_waves", "staged", "table_hbm", "multi_class",
+                                  "block_v2", "block_centres"])
 def test_every_stepper_is_deterministic_run_to_run(path, monkeypatch):
     """The same propagation twice on fresh integrators, one per code path, through the device-side work queue (which hands
     the systems to the lanes in an order which differs from run to run): states, times, step counts and extreme step
@@ -1382,11 +1383,13 @@ def test_every_stepper_is_deterministic_run_to_run(path, monkeypatch):
 
     M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
     kw, t_end = {}, 30.0
-    if path in ("v5", "staged", "table_hbm"):
-        n = 8192 if path == "v5" else 2048
+    if path in ("v3", "v2"):
+        _select_cluster_kernel(monkeypatch, path)
+    if path in ("v5", "v3", "v2", "staged", "table_hbm"):
+        n = 2048 if path in ("staged", "table_hbm") else 8192
         sys_, st = hy.model.nbody(6, masses=M, Gconst=G), configs.outer_ss_state(n, perturb=1e-3, seed=3)
         kw = dict(high_accuracy=True)
-        if path != "v5":
+        if path in ("staged", "table_hbm"):
             kw["emitter"] = "table"
             t_end = 5.0
         if path == "table_hbm":
@@ -1394,6 +1397,16 @@ def test_every_stepper_is_deterministic_run_to_run(path, monkeypatch):
     elif path == "unrolled_two_waves":
         n = 16384
         sys_, st = hy.model.nbody(2, masses=[1.0, 0.0]), configs.two_body_state(n, perturb=1e-3, seed=3)
+    elif path == "v2_aliased":
+        n = 4096
+        sys_ = hy.model.np1body(6, masses=M, Gconst=G)
+        full = configs.outer_ss_state(n, perturb=1e-3, seed=3).reshape(6, 6, n)
+        st = (full[1:] - full[:1]).reshape(30, n)
+    elif path == "block_centres":
+        n, t_end = 512, 0.5
+        rs = np.random.RandomState(11)
+        sys_ = hy.model.fixed_centres(masses=list(rs.uniform(0.5, 1.5, 100) / 100.0), positions=list(rs.uniform(-1.0, 1.0, 300)))
+        st = np.concatenate([rs.uniform(1.5, 2.0, (3, n)), rs.uniform(-0.3, 0.3, (3, n))])
     elif path == "multi_class":
         n, t_end = 4096, 2.0
         sys_, st = mm.sine_lattice(hy, 16), mm.sine_lattice_state(16, n, seed=3)
@@ -1405,7 +1418,7 @@ def test_every_stepper_is_deterministic_run_to_run(path, monkeypatch):
     res = []
     for _ in range(2):
         ta = hy.taylor_adaptive_batch(sys_, st, n, **kw)
-        want = {"v5": "v5", "unrolled_two_waves": "two wavefronts per SIMD", "staged": "staged", "table_hbm": "tape in HBM",
+        want = {"v5": "v5", "v3": "v3", "v2": "v2", "v2_aliased": "aliased", "block_centres": "block", "unrolled_two_waves": "two wavefronts per SIMD", "staged": "staged", "table_hbm": "tape in HBM",
                 "multi_class": "classes of clusters", "block_v2": "v2 cluster phase"}[path]
         assert want in ta.hip_source_mode, ta.hip_source_mode
         ta.propagate_until(tf)
