@@ -512,9 +512,10 @@ def run_workload(ctx, workload, n, steps, warmup):
             # MFMA itself is unused: the recurrences are elementwise).
             roof = {"bound": "fp64_valu", "bound_contract_class": "mfma", "achieved": achieved_tflops,
                     "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / FP64_PEAK_TFLOPS}
-        elif partly_on_chip and traffic:
-            # The tape model counts bytes this stepper no longer moves (rows cached in registers, members recomputed): a
-            # fraction above 1 is not a roofline fraction. The bytes it DOES move are the counter traffic of this very
+        elif traffic and (partly_on_chip or achieved_gbs > HBM_PEAK_GBS):
+            # The tape model counts bytes this stepper no longer moves (rows cached in registers, members recomputed; or a
+            # wave-cluster stepper which keeps the histories in registers and only the jets of the state variables in global
+            # scratch): a fraction above 1 is not a roofline fraction. The bytes it DOES move are the counter traffic of this very
             # kernel: achieved = measured HBM bytes per second; the tape-model figure stays as hbm_tape_model_frac.
             meas_gbs = traffic / (k_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": meas_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": meas_gbs / HBM_PEAK_GBS,
