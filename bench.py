@@ -498,7 +498,7 @@ def run_workload(ctx, workload, n, steps, warmup):
         partly_on_chip = (not on_chip) and "v2 cluster phase" in mode_str
         # (The staged table stepper keeps the tape of a system in LDS: the B_tape figure is the ALGORITHMIC traffic of the
         # one-lane-per-system formulation - SURVEY 8d's official scale for this path -, not bytes which reach HBM.)
-        staged = mode_str.startswith("table") and "staged" in mode_str
+        staged = mode_str.startswith("table") and "table mode (staged)" in mode_str
         hbm_util = (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else (0.0 if on_chip else min(1.0, achieved_gbs / HBM_PEAK_GBS))
         compute_bound = achieved_tflops / FP64_PEAK_TFLOPS > hbm_util
         # (How the binding ceiling was decided: from counter traffic of this very kernel, or - without a matching summary
