@@ -402,6 +402,7 @@ std::string emit_unrolled_kernel(const taylor_program &p, const emit_options &op
     // the two-body problem.
     e.recip_div = !opts.exact_division;
     e.fold_zeros = opts.dev.unrolled_trim;
+    e.fold_scaled = opts.dev.unrolled_trim && !opts.exact_division && opts.sum_order == 0;
     e.merge_sum_sq = opts.sum_order == 0 && !opts.exact_division && opts.dev.unrolled_merge_ssq;
 
     os << "extern \"C\" __global__ void __launch_bounds__(" << bs << ") ";
@@ -425,7 +426,7 @@ std::string emit_unrolled_kernel(const taylor_program &p, const emit_options &op
     if (stream_tc) {
         os << "double *jet = a.tc + s;\n";
     } else if (!reg_jets) {
-        os << "double *const jet = a.tc + s;\n";
+        os << "double *jet = a.tc + s;\n";
     }
     os << R"HIP(
 hy_df tfin, rem;
@@ -460,9 +461,11 @@ if (a.mode == 1) {
     lim = step_lim;
 }
 )HIP";
-    if (stream_tc) {
+    if (stream_tc || !reg_jets) {
         // NOTE: the (order + 1) * n_eq store addresses are invariants of the step loop: left alone, the compiler hoists
         // all of them into registers (2 per address). Laundering the base pointer once per step makes them per-step values.
+        // (Round 6: also in the kernel which keeps the jets of the state variables in memory - cr3bp: 526 -> 0 spilled
+        // registers together with the folded histories, see ssa_emitter::fold_scaled.)
         os << "asm volatile(\"\" : \"+v\"(jet));\n";
     }
 

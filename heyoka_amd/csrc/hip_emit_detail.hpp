@@ -163,6 +163,27 @@ struct ssa_emitter {
     // fast-math flags are the chains built on top: 0 * h + 0 is a NaN for a non-finite h): x - (+0) = x for every x, signed
     // zeros and NaNs included; (+0) * RN(1 / d) = +0. HEYOKA_AMD_UNROLLED_TRIM=0 switches it off (A/B).
     bool fold_zeros = false;
+    // Products whose factor is a scaled copy of another u variable (prod(number, u): the masses and couplings of a model):
+    // the convolution runs over u and the number multiplies its sum, within 1 ulp of the reference's order of the
+    // operations - not under kw::exact_division. Returns u (and the number, "-" for -1) or the variable itself.
+    bool fold_scaled = false;
+    std::uint32_t scaled_parent(std::uint32_t u, std::string &c) const
+    {
+        if (u < p.n_eq) {
+            return u;
+        }
+        const auto &n = p.nodes[u - p.n_eq];
+        if (n.kind != func_kind::prod || n.args.size() != 2u || is_var(n.args[0]) == is_var(n.args[1])) {
+            return u;
+        }
+        const auto &cv = is_var(n.args[0]) ? n.args[1] : n.args[0];
+        const auto &v = is_var(n.args[0]) ? n.args[0] : n.args[1];
+        if (numpar_override.count(&cv) != 0u) {
+            return u;
+        }
+        c = (cv.type == operand::kind::num && cv.value == -1.) ? std::string("-") : numpar(cv);
+        return v.idx;
+    }
 
     // Exponentiation by squaring (reference: pow_ebs(), src/math/pow.cpp:136-152).
     std::string pow_ebs(const std::string &base, std::uint32_t e)
@@ -231,6 +252,21 @@ struct ssa_emitter {
                         terms.push_back(k == 0u ? numpar(o) : "0.0");
                     }
                 }
+                if (fold_zeros && k > 0u) {
+                    // x + (+0) = x (up to the sign of a zero result): the coefficients of order >= 1 of u + number ARE those
+                    // of u - no second history for the compiler to keep (x + 0.0 is not foldable without fast-math flags).
+                    std::vector<std::string> nz;
+                    for (auto &t : terms) {
+                        if (!is_zero_lit(t)) {
+                            nz.push_back(std::move(t));
+                        }
+                    }
+                    if (nz.empty()) {
+                        out = "0.0";
+                        break;
+                    }
+                    terms.swap(nz);
+                }
                 out = pairwise_sum(std::move(terms));
                 break;
             }
@@ -268,11 +304,23 @@ struct ssa_emitter {
                         out = def(mul(val(c.idx, 0), val(v.idx, k)));
                     }
                 } else if (is_var(a[0]) && is_var(a[1])) {
+                    // (fold_scaled: a factor which is itself number * u is read as u, the number multiplies the sum - the
+                    // scaled copy of u's coefficient history is never kept.)
+                    std::string c0, c1;
+                    const auto i0 = fold_scaled ? scaled_parent(a[0].idx, c0) : a[0].idx;
+                    const auto i1 = fold_scaled ? scaled_parent(a[1].idx, c1) : a[1].idx;
                     std::vector<std::string> terms;
                     for (std::uint32_t j = 0; j <= k; ++j) {
-                        terms.push_back(def(mul(val(a[0].idx, k - j), val(a[1].idx, j))));
+                        terms.push_back(def(mul(val(i0, k - j), val(i1, j))));
                     }
                     out = conv_sum(std::move(terms));
+                    for (const auto *c : {&c0, &c1}) {
+                        if (*c == "-") {
+                            out = def("-" + out);
+                        } else if (!c->empty()) {
+                            out = def(mul(*c, out));
+                        }
+                    }
                 } else if (!is_var(a[0]) && !is_var(a[1])) {
                     if (k != 0u) {
                         out = "0.0";

@@ -1,0 +1,64 @@
+#!/usr/bin/env python
+"""Rates of the models beside the BASELINE.json configurations on the current kernels: system-steps / kernel time of the
+second of two propagate_until() launches. usage: model_rates.py [--systems N]"""
+import argparse, json, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import heyoka_amd as hy
+from heyoka_amd import configs, codegen_check
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--systems", type=int, default=262144)
+args = ap.parse_args()
+n = args.systems
+M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
+rs = np.random.RandomState(7)
+
+
+def np1body_case():
+    full = configs.outer_ss_state(n, perturb=1e-6, seed=3).reshape(6, 6, n)
+    return hy.model.np1body(6, masses=M, Gconst=G), (full[1:] - full[:1]).reshape(30, n), None, 30.0
+
+
+def cr3bp_case():
+    st = np.array([[-0.45], [0.80], [0.0], [-0.80], [-0.45], [0.58]]) + 1e-3 * rs.uniform(-1, 1, (6, n))
+    return hy.model.cr3bp(mu=0.01), st, None, 20.0
+
+
+def centres_case(mascon):
+    m = list(rs.uniform(0.5, 1.5, 100) / 100.0)
+    pos = list(rs.uniform(-1.0, 1.0, 300))
+    s = hy.model.mascon(masses=m, positions=pos, Gconst=1.0, omega=[0.0, 0.0, 0.3]) if mascon else hy.model.fixed_centres(masses=m, positions=pos)
+    st = np.concatenate([rs.uniform(1.5, 2.0, (3, n)), rs.uniform(-0.3, 0.3, (3, n))])
+    return s, st, None, 1.0
+
+
+def par_masses_case():
+    s = hy.model.nbody(6, masses=[hy.par[i] for i in range(6)], Gconst=G)
+    return s, configs.outer_ss_state(n, perturb=1e-6, seed=3), np.tile(np.array(M)[:, None], (1, n)), 30.0
+
+
+def pendulum_case():
+    return hy.model.pendulum(), np.stack([rs.uniform(-1.5, 1.5, n), rs.uniform(-0.5, 0.5, n)]), None, 50.0
+
+
+cases = {"np1body(6)": np1body_case, "cr3bp": cr3bp_case, "fixed_centres(100)": lambda: centres_case(False),
+         "mascon(100)": lambda: centres_case(True), "nbody(6), par[] masses": par_masses_case, "pendulum": pendulum_case}
+for name, mk in cases.items():
+    try:
+        s, st, pars, dt = mk()
+        kw = {} if pars is None else {"pars": pars}
+        ta = hy.taylor_adaptive_batch(s, st, n, **kw)
+        rates = []
+        for r in range(3):
+            ta.propagate_until(dt * (r + 1))
+            ns = ta.propagate_res_arrays()[3]
+            ms = list(ta.kernel_ms_history(1))[-1]
+            rates.append(float(ns.sum()) / (ms * 1e-3))
+        res = codegen_check.kernel_resources(ta.code_object)
+        print("%-24s %s system-steps/s (launches: %s) steps/system %.1f | vgpr %s spills %s waves %s | %s" % (
+            name, "%.3g" % rates[-1], ", ".join("%.3g" % x for x in rates), float(ns.mean()), res["vgpr_total"], res["vgpr_spill"],
+            res["waves_per_simd_by_registers"], ta.hip_source_mode[:110]), flush=True)
+    except Exception as e:
+        print(name, "ERROR", type(e).__name__, e, flush=True)
