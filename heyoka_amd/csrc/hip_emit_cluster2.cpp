@@ -23,6 +23,7 @@
 
 #include "hip_emit_cluster_plan.hpp"
 #include "hip_emit_detail.hpp"
+#include "logging.hpp"
 
 namespace heyoka_amd
 {
@@ -30,8 +31,9 @@ namespace heyoka_amd
 namespace
 {
 
+// (min_lanes: the smallest number of lanes per system of the one-lane-per-pair kernel - see emit_cluster_v2().)
 emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options &opts, std::string &why_not, bool allow_one_lane,
-                                    bool &one_lane_jets_in_lds)
+                                    bool &one_lane_jets_in_lds, std::uint32_t min_lanes = 4)
 {
     using cluster_detail::cluster_plan;
     using cluster_detail::is_var;
@@ -145,7 +147,7 @@ emitted_module emit_cluster_v2_impl(const taylor_program &p, const emit_options 
         pl.n_slots = ns;
     }
     if (one_lane) {
-        pl.L = 4;
+        pl.L = min_lanes;
         while (pl.L < nc) {
             pl.L *= 2u;
         }
@@ -3676,13 +3678,30 @@ emitted_module emit_cluster_v2(const taylor_program &p, const emit_options &opts
 {
     // The one-lane pair kernel first (pair-pattern systems without runtime parameters, not the stepper with events); if
     // its shape requirements fail or the jets of its systems do not fit in LDS, the lane-pair / pipelined kernels.
+    // Few pairs (3 or 6: model::nbody(3), (4)): with 4 / 8 lanes per system a CU holds 128 / 64 systems, whose jets do not
+    // fit in its LDS - and the lane-pair kernel with the jets in global scratch which used to serve them spills 176 / 116
+    // registers. More lanes per system than pairs (idle lanes replicate pair 0 and write to dummy slots, like the 16th lane
+    // of the outer Solar System) bring the systems per CU down to what fits: the second and third attempts.
     bool in_lds = false;
     std::string why1;
     const bool try_one_lane = opts.cluster_kernel == 0 || opts.cluster_kernel == 5;
-    auto ret = emit_cluster_v2_impl(p, opts, why1, try_one_lane, in_lds);
-    if (why1.empty() && (in_lds || ret.notes.find("cluster mode v5") == std::string::npos)) {
-        why_not.clear();
-        return ret;
+    for (const std::uint32_t min_lanes : {4u, 8u, 16u}) {
+        why1.clear();
+        auto ret = emit_cluster_v2_impl(p, opts, why1, try_one_lane, in_lds, min_lanes);
+        const bool is_v5 = ret.notes.find("cluster mode v5") != std::string::npos;
+        if (try_one_lane) {
+            detail::log_message(log_level::debug, "one-lane-per-pair kernel, at least " + std::to_string(min_lanes) + " lanes per system: "
+                                              + (!why1.empty() ? why1 : (!is_v5 ? "not applicable" : (in_lds ? "accepted" : "the jets of the systems of a CU do not fit in its LDS"))));
+        }
+        if (why1.empty() && (in_lds || !is_v5)) {
+            why_not.clear();
+            return ret;
+        }
+        // (Another attempt only for the reasons which more lanes per system cure.)
+        const bool lds_reason = why1.find("needs the jets in LDS") != std::string::npos;
+        if (!try_one_lane || (!why1.empty() && !lds_reason) || (why1.empty() && !is_v5)) {
+            break;
+        }
     }
     return emit_cluster_v2_impl(p, opts, why_not, false, in_lds);
 }

@@ -43,12 +43,23 @@ def pendulum_case():
     return hy.model.pendulum(), np.stack([rs.uniform(-1.5, 1.5, n), rs.uniform(-0.5, 0.5, n)]), None, 50.0
 
 
-cases = {"np1body(6)": np1body_case, "cr3bp": cr3bp_case, "fixed_centres(100)": lambda: centres_case(False),
+def small_nbody_case(nb, kernel):
+    m = [1.0, 1e-3, 3e-4, 2e-4][:nb]
+    pos = rs.uniform(-0.3, 0.3, (nb, 3, n)) + 5.0 * np.arange(nb)[:, None, None] * np.array([1.0, 0.3, -0.2])[None, :, None]
+    vel = rs.uniform(-0.05, 0.05, (nb, 3, n)) + (0.4 / np.sqrt(1.0 + 5.0 * np.arange(nb)))[:, None, None] * np.array([-0.3, 1.0, 0.1])[None, :, None]
+    st = np.concatenate([np.concatenate([pos[b], vel[b]], axis=0) for b in range(nb)], axis=0)
+    return hy.model.nbody(nb, masses=m), st, None, 20.0, dict(high_accuracy=True, cluster_kernel=kernel)
+
+
+cases = {"nbody(3) on v5": lambda: small_nbody_case(3, "v5"), "nbody(3) on v3": lambda: small_nbody_case(3, "v3"),
+         "nbody(4) on v5": lambda: small_nbody_case(4, "v5"), "nbody(4) on v3": lambda: small_nbody_case(4, "v3"),
+         "np1body(6)": np1body_case, "cr3bp": cr3bp_case, "fixed_centres(100)": lambda: centres_case(False),
          "mascon(100)": lambda: centres_case(True), "nbody(6), par[] masses": par_masses_case, "pendulum": pendulum_case}
 for name, mk in cases.items():
     try:
-        s, st, pars, dt = mk()
+        s, st, pars, dt, *extra = mk()
         kw = {} if pars is None else {"pars": pars}
+        kw.update(extra[0] if extra else {})
         ta = hy.taylor_adaptive_batch(s, st, n, **kw)
         rates = []
         for r in range(3):

@@ -124,11 +124,12 @@ def test_emulated_v5_taylor_coefficients_by_threshold():
         assert np.array_equal(partc["tc"], fullc["tc"]), lo
 
 
-@pytest.mark.parametrize("nb,masses", [(5, None), (6, None), (6, [3.0, 1e-3, 0.7, 2.0, 4e-3, 0.5]), (6, "default"),
+@pytest.mark.parametrize("nb,masses", [(3, None), (4, None), (3, [1.0, 1e-3, 3e-4]), (5, None), (6, None), (6, [3.0, 1e-3, 0.7, 2.0, 4e-3, 0.5]), (6, "default"),
                                        (6, [1.0, 1e-3, 1.0, 2.0, 1e-3, 0.5]), (7, "default"), (9, "default")])
 def test_emulated_v5_other_systems_single_step_vs_oracle(nb, masses):
     """The one-lane-per-pair kernel with the reactions fused into the sums on other pair-interaction systems: 5 bodies (10
-    pairs on 16 lanes, 15 sums: ONE glue round) and 6 bodies with other mass ratios than the outer Solar System's (comparable
+    pairs on 16 lanes, 15 sums: ONE glue round; 3 and 4 bodies - round 6: 3 pairs on 8 lanes, 6 pairs on 16, more lanes per
+    system than pairs so that the jets of the systems of a CU fit in its LDS) and 6 bodies with other mass ratios than the outer Solar System's (comparable
     masses: reaction coefficients of order one). (Equal masses take model::nbody() to its grouped branch, whose clusters
     have another shape: those systems run on the lane-pair / first-generation kernels.)"""
     rng = np.random.RandomState(40 + nb)
