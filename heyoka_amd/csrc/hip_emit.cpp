@@ -5,6 +5,7 @@
 // heyoka's CPU path up to FMA contraction and the <= 1 ulp elementary functions.
 #include "hip_emit.hpp"
 #include "hip_emit_detail.hpp"
+#include "logging.hpp"
 
 #include <algorithm>
 #include <cassert>
@@ -383,6 +384,81 @@ void emit_dout(std::ostringstream &os, const taylor_program &p, const emit_optio
 // defined by other state variables (x' = v) are re-derived in the final evaluation instead of being stored.
 // stream_tc (with reg_jets): the Taylor coefficients are additionally streamed to a.tc as they are produced (stores
 // only, nothing is read back): the write_tc / continuous-output / propagate_grid variant of a register-resident stepper.
+// The u variables whose coefficient HISTORY is read (operands of convolutions and of recurrences, functions with a
+// recurrence on themselves): what a lane of the straight-line stepper keeps through the orders.
+// (folded: with ssa_emitter::fold_scaled / fold_zeros a history which is a scaled copy of another one - prod(number, u) -, or
+// its coefficients beyond order 0 - u + number, u - number -, is not kept: the mark moves to u.)
+std::vector<char> history_operands(const taylor_program &p, bool folded = false)
+{
+    std::vector<char> hist(p.n_u, 0);
+    for (std::uint32_t i = 0; i < p.nodes.size(); ++i) {
+        const auto &nd = p.nodes[i];
+        const auto &a = nd.args;
+        const auto mark = [&](const operand &o) {
+            if (o.type == operand::kind::uvar) {
+                hist[o.idx] = 1;
+            }
+        };
+        switch (nd.kind) {
+            case func_kind::prod:
+                if (a.size() == 2u && a[0].type == operand::kind::uvar && a[1].type == operand::kind::uvar) {
+                    mark(a[0]);
+                    mark(a[1]);
+                }
+                break;
+            case func_kind::sum_sq:
+                for (const auto &o : a) {
+                    mark(o);
+                }
+                break;
+            case func_kind::pow:
+            case func_kind::exp:
+            case func_kind::log:
+            case func_kind::sin:
+            case func_kind::cos:
+                if (a[0].type == operand::kind::uvar) {
+                    mark(a[0]);
+                    // (The square is a convolution of its argument with itself: no recurrence on its own coefficients.)
+                    const bool square = nd.kind == func_kind::pow && a.size() == 2u && a[1].type == operand::kind::num && a[1].value == 2.;
+                    if (!(folded && square)) {
+                        hist[p.n_eq + i] = 1;
+                    }
+                }
+                break;
+            case func_kind::div:
+                if (a[1].type == operand::kind::uvar) {
+                    mark(a[1]);
+                    hist[p.n_eq + i] = 1;
+                }
+                break;
+            default:
+                break;
+        }
+    }
+    for (std::uint32_t i = static_cast<std::uint32_t>(p.nodes.size()); folded && i-- > 0u;) {
+        const auto &nd = p.nodes[i];
+        const auto &a = nd.args;
+        if (hist[p.n_eq + i] == 0) {
+            continue;
+        }
+        std::uint32_t n_var = 0, parent = 0;
+        for (const auto &o : a) {
+            if (o.type == operand::kind::uvar) {
+                ++n_var;
+                parent = o.idx;
+            }
+        }
+        const bool copy = n_var == 1u
+                          && ((nd.kind == func_kind::prod && a.size() == 2u) || nd.kind == func_kind::sum
+                              || (nd.kind == func_kind::sub && a[0].type == operand::kind::uvar));
+        if (copy) {
+            hist[p.n_eq + i] = 0;
+            hist[parent] = 1;
+        }
+    }
+    return hist;
+}
+
 // (waves: amdgpu_waves_per_eu of the kernel, 0 = the compiler's choice; n_derived: the number of state variables whose
 // coefficient histories are not kept because they are re-derived at the end of the step - see "The other way round" below.)
 std::string emit_unrolled_kernel(const taylor_program &p, const emit_options &opts, const std::string &kname,
@@ -467,6 +543,10 @@ if (a.mode == 1) {
         // (Round 6: also in the kernel which keeps the jets of the state variables in memory - cr3bp: 526 -> 0 spilled
         // registers together with the folded histories, see ssa_emitter::fold_scaled.)
         os << "asm volatile(\"\" : \"+v\"(jet));\n";
+        // (The same for the scalar halves of the addresses, index * N: hoisted, they are 2 SGPRs each - 651 spilled SGPRs in the
+        // stepper of two massive bodies.)
+        os << "u64 hy_Ns = N;\n#if defined(HY_HOST_EMU)\nasm volatile(\"\" : \"+r\"(hy_Ns));\n#else\nasm volatile(\"\" : "
+              "\"+s\"(hy_Ns));\n#endif\n";
     }
 
     // ---- Jet of normalised derivatives. ----
@@ -477,7 +557,7 @@ if (a.mode == 1) {
         if (reg_jets && !stream_tc) {
             return;
         }
-        os << "jet[(u64)" << (static_cast<std::uint64_t>(i) * (order + 1u) + k) << "u * N] = " << e.val(i, k)
+        os << "jet[(u64)" << (static_cast<std::uint64_t>(i) * (order + 1u) + k) << "u * hy_Ns] = " << e.val(i, k)
            << ";\n";
     };
     for (std::uint32_t i = 0; i < n_eq; ++i) {
@@ -608,14 +688,16 @@ if (a.mode == 1) {
             std::vector<char> read_by_node(n_eq, 0);
             for (const auto &nd : p.nodes) {
                 for (const auto &o : nd.args) {
-                    if (o.type == operand::kind::uvar) {
-                        if (o.idx < n_eq) {
-                            read_by_node[o.idx] = 1;
-                        }
-                        for (std::uint32_t k = 0; k <= order; ++k) {
-                            hist_names.insert(e.val(o.idx, k));
-                        }
+                    if (o.type == operand::kind::uvar && o.idx < n_eq) {
+                        read_by_node[o.idx] = 1;
                     }
+                }
+            }
+            // (Names of the coefficients which are kept anyway: the histories.)
+            const auto hist = history_operands(p);
+            for (std::uint32_t u = 0; u < p.n_u; ++u) {
+                for (std::uint32_t k = 0; hist[u] != 0 && k <= order; ++k) {
+                    hist_names.insert(e.val(u, k));
                 }
             }
             for (std::uint32_t j = 0; j < n_eq; ++j) {
@@ -626,17 +708,23 @@ if (a.mode == 1) {
             }
         }
         std::vector<std::uint32_t> derived_count(n_eq, 0);
+        // (v is re-derived from x when x is the one variable it defines and the coefficients of x are those of a history -
+        // checked on order 2, the first one which is not a plain copy of another state variable.)
+        const auto derive_v = [&](std::uint32_t v) {
+            return order >= 3u && defines[v] >= 0 && hist_names.count(e.val(static_cast<std::uint32_t>(defines[v]), 2u)) != 0u;
+        };
         std::function<std::string(std::uint32_t, std::uint32_t)> coef = [&](std::uint32_t i, std::uint32_t k) {
             const auto &d = p.sv_defs[i];
             if (k > 0u && d.type == operand::kind::uvar && d.idx < n_eq) {
-                if (defines[d.idx] >= 0 && hist_names.count(e.val(i, k)) != 0u) {
+                if (derive_v(d.idx)) {
+                    // (Never back from the re-derived v.)
                     return e.val(i, k);
                 }
                 return e.div_const(coef(d.idx, k - 1u), k);
             }
-            if (k > 0u && k < order && defines[i] >= 0) {
+            if (k > 0u && k < order && derive_v(i)) {
                 const auto &xk = e.val(static_cast<std::uint32_t>(defines[i]), k + 1u);
-                if (hist_names.count(xk) != 0u && !ssa_emitter::is_zero_lit(xk)) {
+                if (!ssa_emitter::is_zero_lit(xk)) {
                     ++derived_count[i];
                     return e.def(ssa_emitter::mul(fp_literal(static_cast<double>(k + 1u)), xk));
                 }
@@ -690,10 +778,10 @@ if (a.mode == 1) {
             // Compensated summation (reference: taylor_run_ceval(), src/taylor_00.cpp:355-460).
             for (std::uint32_t i = 0; i < n_eq; ++i) {
                 os << "{\nconst double *c = jet + (u64)" << (static_cast<std::uint64_t>(i) * (order + 1u))
-                   << "u * N;\n";
+                   << "u * hy_Ns;\n";
                 os << "double res = c[0], comp = 0.0, cur_h = h;\n";
                 os << "#pragma unroll\nfor (unsigned k = 1; k <= " << order << "u; ++k) {\n";
-                os << "const double tmp = c[(u64)k * N] * cur_h;\nconst double y = tmp - comp;\nconst double t = res + "
+                os << "const double tmp = c[(u64)k * hy_Ns] * cur_h;\nconst double y = tmp - comp;\nconst double t = res + "
                       "y;\n";
                 os << "comp = (t - res) - y;\nres = t;\ncur_h = cur_h * h;\n}\n";
                 os << "x" << i << " = res;\n}\n";
@@ -702,10 +790,10 @@ if (a.mode == 1) {
             // Horner (reference: taylor_run_multihorner(), src/taylor_00.cpp:279-351).
             for (std::uint32_t i = 0; i < n_eq; ++i) {
                 os << "{\nconst double *c = jet + (u64)" << (static_cast<std::uint64_t>(i) * (order + 1u))
-                   << "u * N;\n";
-                os << "double res = c[(u64)" << order << "u * N];\n";
+                   << "u * hy_Ns;\n";
+                os << "double res = c[(u64)" << order << "u * hy_Ns];\n";
                 os << "#pragma unroll\nfor (unsigned k = 1; k <= " << order << "u; ++k) {\n";
-                os << "res = c[(u64)(" << order << "u - k) * N] + res * h;\n}\n";
+                os << "res = c[(u64)(" << order << "u - k) * hy_Ns] + res * h;\n}\n";
                 os << "x" << i << " = res;\n}\n";
             }
         }
@@ -761,7 +849,7 @@ if (a.mode == 1) {
 // Estimate (in doubles) of what a lane must keep alive in register-jet mode: the jets of the state variables
 // that are neither constant nor defined by another state variable, plus the history of the operands of the
 // nonlinear nodes.
-std::uint64_t reg_jet_estimate(const taylor_program &p, std::uint32_t order)
+std::uint64_t reg_jet_estimate(const taylor_program &p, std::uint32_t order, bool folded = false)
 {
     std::uint64_t n = 0;
     for (const auto &d : p.sv_defs) {
@@ -769,48 +857,7 @@ std::uint64_t reg_jet_estimate(const taylor_program &p, std::uint32_t order)
             n += order + 1u;
         }
     }
-    std::vector<char> hist(p.n_u, 0);
-    for (std::uint32_t i = 0; i < p.nodes.size(); ++i) {
-        const auto &nd = p.nodes[i];
-        const auto &a = nd.args;
-        const auto mark = [&](const operand &o) {
-            if (o.type == operand::kind::uvar) {
-                hist[o.idx] = 1;
-            }
-        };
-        switch (nd.kind) {
-            case func_kind::prod:
-                if (a.size() == 2u && a[0].type == operand::kind::uvar && a[1].type == operand::kind::uvar) {
-                    mark(a[0]);
-                    mark(a[1]);
-                }
-                break;
-            case func_kind::sum_sq:
-                for (const auto &o : a) {
-                    mark(o);
-                }
-                break;
-            case func_kind::pow:
-            case func_kind::exp:
-            case func_kind::log:
-            case func_kind::sin:
-            case func_kind::cos:
-                if (a[0].type == operand::kind::uvar) {
-                    mark(a[0]);
-                    hist[p.n_eq + i] = 1;
-                }
-                break;
-            case func_kind::div:
-                if (a[1].type == operand::kind::uvar) {
-                    mark(a[1]);
-                    hist[p.n_eq + i] = 1;
-                }
-                break;
-            default:
-                break;
-        }
-    }
-    for (const auto h : hist) {
+    for (const auto h : history_operands(p, folded)) {
         n += (h != 0) ? order : 0u;
     }
     return n;
@@ -825,7 +872,15 @@ emitted_module emit_unrolled(const taylor_program &p, const emit_options &opts)
     emitted_module ret;
     // Register-resident jets when they fit comfortably in the 512 VGPR+AGPR of a lane.
     // NOTE: the stepper with events needs the Taylor coefficients in memory (event detection, dense output).
-    const bool reg_jets = p.ev_u.empty() && reg_jet_estimate(p, opts.order) <= 200u;
+    // (Round 6: the estimate counts what the generator really keeps when it folds scaled copies and u + number into their
+    // parents - default arithmetic only -, and the limit went from 200 to 270 doubles: two massive bodies 226, 1.24e9 -> 8.7e9
+    // system-steps/s, cr3bp 265, 3.0e9 -> 6.6e9, both with 10 ... 16 spilled registers of 512 - against jets which travel
+    // through HBM at every step; profiles/r06_model_rates.log. HEYOKA_AMD_REG_JETS_MAX overrides the limit.)
+    const bool folds = opts.dev.unrolled_trim && !opts.exact_division && opts.sum_order == 0;
+    const bool reg_jets
+        = p.ev_u.empty()
+          && reg_jet_estimate(p, opts.order, folds)
+                 <= static_cast<std::uint64_t>(opts.dev.reg_jets_max >= 0 ? opts.dev.reg_jets_max : (folds ? 270 : 200));
     if (reg_jets) {
         // Two wavefronts per SIMD (256 registers per lane) when what a lane keeps through the orders leaves room for the
         // working set: measured on the two-body problem with a test particle, where the histories of the velocities are
@@ -839,6 +894,8 @@ emitted_module emit_unrolled(const taylor_program &p, const emit_options &opts)
             std::uint32_t n_derived = 0;
             emit_unrolled_kernel(p, opts, "hy_taylor", true, n_tmp, false, 0, &n_derived);
             const auto est = reg_jet_estimate(p, opts.order);
+            detail::log_message(log_level::debug, "straight-line stepper: " + std::to_string(est) + " doubles kept per lane (estimate), the histories of "
+                                                      + std::to_string(n_derived) + " state variables re-derived at the end of the step");
             if (n_derived > 0u && est >= static_cast<std::uint64_t>(n_derived) * (opts.order + 1u)
                 && est - static_cast<std::uint64_t>(n_derived) * (opts.order + 1u) <= 126u) {
                 waves = 2;
@@ -1586,6 +1643,7 @@ dev_switches dev_switches::from_env()
     d.unrolled_trim = !off("HEYOKA_AMD_UNROLLED_TRIM");
     d.unrolled_merge_ssq = !off("HEYOKA_AMD_UNROLLED_MERGE_SSQ");
     d.unrolled_derive = !off("HEYOKA_AMD_UNROLLED_DERIVE");
+    d.reg_jets_max = num("HEYOKA_AMD_REG_JETS_MAX", -1);
     d.v5_opts = str("HEYOKA_AMD_V5_OPTS");
     d.v5_pad = str("HEYOKA_AMD_V5_PAD");
     d.block_opts = str("HEYOKA_AMD_BLOCK_OPTS");

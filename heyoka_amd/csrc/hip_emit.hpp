@@ -96,6 +96,9 @@ struct dev_switches {
     // (HEYOKA_AMD_UNROLLED_TRIM=0: off), one running sum for the sum of squares (HEYOKA_AMD_UNROLLED_MERGE_SSQ=0: off), the
     // coefficients of a variable which only defines x' = v re-derived from those of x (HEYOKA_AMD_UNROLLED_DERIVE=0: off).
     bool unrolled_trim = true, unrolled_merge_ssq = true, unrolled_derive = true;
+    // Register-resident jets of the state variables up to this estimate of the doubles a lane keeps (reg_jet_estimate()).
+    // (-1: automatic - 270 with the folded histories of the default arithmetic, 200 otherwise.)
+    int reg_jets_max = -1;
     std::string v5_opts, v5_pad;
     // HEYOKA_AMD_BLOCK_OPTS: comma-separated items of the v2 cluster phase of block mode switched one by one (A/B harness,
     // timing experiments - see hip_emit_block.cpp).

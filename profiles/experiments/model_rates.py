@@ -10,6 +10,7 @@ from heyoka_amd import configs, codegen_check
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--systems", type=int, default=262144)
+ap.add_argument("--only", default="", help="substring of the case names to run")
 args = ap.parse_args()
 n = args.systems
 M, G = configs.OUTER_SS_MASSES, configs.OUTER_SS_G
@@ -51,11 +52,18 @@ def small_nbody_case(nb, kernel):
     return hy.model.nbody(nb, masses=m), st, None, 20.0, dict(high_accuracy=True, cluster_kernel=kernel)
 
 
-cases = {"nbody(3) on v5": lambda: small_nbody_case(3, "v5"), "nbody(3) on v3": lambda: small_nbody_case(3, "v3"),
+def two_massive_case():
+    st = configs.two_body_state(n, perturb=1e-3, seed=3)
+    return hy.model.nbody(2, masses=[1.0, 0.5]), st, None, 20.0
+
+
+cases = {"nbody(2), both massive": two_massive_case, "nbody(3) on v5": lambda: small_nbody_case(3, "v5"), "nbody(3) on v3": lambda: small_nbody_case(3, "v3"),
          "nbody(4) on v5": lambda: small_nbody_case(4, "v5"), "nbody(4) on v3": lambda: small_nbody_case(4, "v3"),
          "np1body(6)": np1body_case, "cr3bp": cr3bp_case, "fixed_centres(100)": lambda: centres_case(False),
          "mascon(100)": lambda: centres_case(True), "nbody(6), par[] masses": par_masses_case, "pendulum": pendulum_case}
 for name, mk in cases.items():
+    if args.only and args.only not in name:
+        continue
     try:
         s, st, pars, dt, *extra = mk()
         kw = {} if pars is None else {"pars": pars}
