@@ -731,7 +731,41 @@ if (a.mode == 1) {
             }
             return e.val(i, k);
         };
+        // A pair x' = v with a re-derived v, plain Horner evaluation: sum_k (k + 1) x^[k+1] h^k is the DERIVATIVE of the series
+        // of x - both come out of one pass (res' = res' h + res, res = res h + x^[k]: two FMAs per coefficient, like the two
+        // chains) without the multiplications by k + 1; the term v^[p] h^p, which the series of x knows nothing of, is added at
+        // the end (h^p by squaring, once per step).
+        std::vector<char> paired(n_eq, 0);
+        std::string h_to_p;
+        for (std::uint32_t v = 0; v < n_eq && !opts.high_accuracy && opts.dev.unrolled_derive; ++v) {
+            if (!derive_v(v)) {
+                continue;
+            }
+            const auto x = static_cast<std::uint32_t>(defines[v]);
+            bool ok = true;
+            for (std::uint32_t k = 2; k <= order; ++k) {
+                ok = ok && !ssa_emitter::is_zero_lit(e.val(x, k)) && !e.val(x, k).empty();
+            }
+            if (!ok) {
+                continue;
+            }
+            if (h_to_p.empty()) {
+                h_to_p = e.pow_ebs("h", order);
+            }
+            // (x^[1] = v^[0] / 1 = the current v; x^[0] = the current x.)
+            os << "{\ndouble res = " << e.val(x, order) << ", der = " << e.val(x, order) << ";\n";
+            os << "res = " << e.val(x, order - 1u) << " + res * h;\n";
+            for (std::uint32_t k = order - 1u; k-- > 0u;) {
+                os << "der = res + der * h;\nres = " << coef(x, k) << " + res * h;\n";
+            }
+            os << "x" << x << "n = res;\nx" << v << "n = " << e.val(v, order) << " * " << h_to_p << " + der;\n}\n";
+            paired[x] = paired[v] = 1;
+            derived_count[v] = order - 1u;
+        }
         for (std::uint32_t i = 0; i < n_eq; ++i) {
+            if (paired[i] != 0) {
+                continue;
+            }
             if (opts.high_accuracy) {
                 os << "{\ndouble res = " << coef(i, 0) << ", comp = 0.0, cur_h = h;\n";
                 for (std::uint32_t k = 1; k <= order; ++k) {
