@@ -150,3 +150,46 @@ def test_detector_on_synthetic_disassembly():
     assert codegen_check.scan_disassembly(after) == []
     outlined = bad.replace("s_cbranch_execz 3", "s_cbranch_execnz 3")
     assert codegen_check.scan_disassembly(outlined) == []
+
+
+def test_round6_generator_choices_and_register_budgets():
+    """The choices of the code generators which round 6 changed, checked on the compiled code objects (no GPU needed):
+    - the test-particle two-body problem (config 3): histories of the velocities re-derived, two wavefronts per SIMD, the series
+      of a pair x' = v evaluated in one pass;
+    - cr3bp and two massive bodies: jets of the state variables in registers (scaled copies of coefficient histories folded into
+      their consumers), no mass spilling - before: 526 spilled VGPRs / 651 spilled SGPRs;
+    - model::nbody(3) / (4): the one-lane-per-pair kernel with more lanes per system than pairs, jets in LDS, no spills - before:
+      the lane-pair kernel with the jets in global scratch, 176 / 116 spilled registers;
+    - the staged table stepper never asks for more wavefronts per SIMD than its table registers leave room for."""
+    import re
+
+    ta = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), None, 64)
+    res = codegen_check.kernel_resources(ta.code_object)
+    assert "two wavefronts per SIMD" in ta.hip_source_mode and res["waves_per_simd_by_registers"] == 2
+    assert res["vgpr_spill"] <= 64 and "der = res + der * h;" in ta.hip_source
+    # (Strict arithmetic: none of the re-derivations.)
+    ts = hy.taylor_adaptive_batch(hy.model.nbody(2, masses=[1.0, 0.0]), None, 64, exact_division=True)
+    assert "two wavefronts per SIMD" not in ts.hip_source_mode and "der = res + der * h;" not in ts.hip_source
+
+    for sys_ in (hy.model.cr3bp(mu=0.01), hy.model.nbody(2, masses=[1.0, 0.5])):
+        ta = hy.taylor_adaptive_batch(sys_, None, 64)
+        res = codegen_check.kernel_resources(ta.code_object)
+        assert "register-resident state jets" in ta.hip_source_mode, ta.hip_source_mode
+        assert res["vgpr_spill"] <= 32 and res["sgpr_spill"] <= 128, res
+
+    for nb, lanes in ((3, 8), (4, 16)):
+        ta = hy.taylor_adaptive_batch(hy.model.nbody(nb, masses=[1.0, 1e-3, 3e-4, 2e-4][:nb]), None, 64, high_accuracy=True)
+        res = codegen_check.kernel_resources(ta.code_object)
+        assert "cluster mode v5" in ta.hip_source_mode and "jets in LDS" in ta.hip_source_mode, ta.hip_source_mode
+        assert ("lanes per system: %d" % lanes) in ta.hip_source_mode and res["vgpr_spill"] == 0, (ta.hip_source_mode, res)
+
+    os.environ["HEYOKA_AMD_EMIT_MODE"] = "table"
+    try:
+        x, y, z = hy.make_vars("x", "y", "z")
+        ta = hy.taylor_adaptive_batch([(x, hy.erf(y) - 0.2 * x + hy.atan2(0.7, y)), (y, x * z), (z, 0.3 - hy.tanh(y))], None, 64)
+    finally:
+        os.environ.pop("HEYOKA_AMD_EMIT_MODE", None)
+    assert "staged" in ta.hip_source_mode
+    w = int(re.search(r"amdgpu_waves_per_eu\((\d+)\)", ta.hip_source).group(1))
+    t_regs = int(re.search(r"(\d+) table registers per lane", ta.hip_source_mode).group(1))
+    assert w == 1 or w * (t_regs + 56 + 64) <= 512 + 7 * w
