@@ -1605,6 +1605,7 @@ bool pad_clusters(const taylor_program &, std::uint32_t, taylor_program &);
 bool insert_unit_scalings(const taylor_program &, taylor_program &);
 bool privatise_cluster_inputs(const taylor_program &, taylor_program &);
 bool linearise_accelerations(const taylor_program &, taylor_program &);
+bool externalise_scalings(const taylor_program &, taylor_program &);
 
 std::string program_to_string(const taylor_program &p)
 {
@@ -1841,6 +1842,24 @@ emitted_module emit_hip_module(const taylor_program &prog, const emit_options &o
                 // Measured on an MI355X: block mode beats the table-driven one-lane-per-system kernels by 5x
                 // (nbody(12), 66 clusters) to 44x (nbody(64)) - it is used whenever it is applicable.
                 auto b = emit_block(prog, opts, why_b);
+                // (Distinct masses: the scalings of the pair products sit inside the clusters, which keeps the decomposition off
+                // the v2 cluster phase - rolled order loop, rows in registers, index-pair convolutions. externalise_scalings()
+                // gives the internal program the clusters of the equal-mass system, the scalings become glue nodes.)
+                if (opts.dev.linearise && b.notes.find("v2 cluster phase") == std::string::npos && !opts.exact_division) {
+                    taylor_program ext;
+                    if (externalise_scalings(prog, ext)) {
+                        std::string wl;
+                        auto o2 = opts;
+                        o2.block_no_absorb = true;
+                        auto b2 = emit_block(ext, o2, wl);
+                        if (!b2.source.empty() && b2.notes.find("v2 cluster phase") != std::string::npos) {
+                            b2.notes += "; scalings of the pair products moved out of the clusters in the internal program (c (d "
+                                        "r^-3) for d (c r^-3): equal to the decomposition to rounding)";
+                            b2.internal_program = program_to_string(ext);
+                            return b2;
+                        }
+                    }
+                }
                 if (!b.source.empty()) {
                     return b;
                 }

@@ -132,6 +132,9 @@ struct emit_options {
     // Decompositions the wave-cluster / block planners cannot shape: straight-line code up to this many nodes, the
     // table-driven steppers beyond (kw::compact_mode lowers it: short compile times).
     std::uint32_t unroll_max_nodes = 150;
+    // Block mode: linear nodes fed by one cluster stay glue nodes (plan_limits::absorb_linear off) - the internal program whose
+    // scalings were moved out of the clusters for the v2 cluster phase (externalise_scalings()).
+    bool block_no_absorb = false;
     // emit_event_jets(): the stepper it accompanies leaves out the Taylor coefficients of order >= 1 of the state variables
     // defined by another state variable (emitted_module::compact_tc): read them as parent^[k-1] / k.
     bool compact_tc = false;

@@ -37,6 +37,7 @@
 
 #include "hip_emit_cluster_plan.hpp"
 #include "hip_emit_detail.hpp"
+#include "logging.hpp"
 
 namespace heyoka_amd
 {
@@ -54,6 +55,7 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
     plan_limits lim;
     lim.max_clusters = 1u << 20;
     lim.jets_in_registers = false;
+    lim.absorb_linear = !opts.block_no_absorb;
     why_not = make_plan(p, opts.order, pl, lim);
     if (!why_not.empty()) {
         return ret;
@@ -393,6 +395,12 @@ emitted_module emit_block(const taylor_program &p, const emit_options &opts, std
         if (!pp.ok || pp.sc != -1 || pp.rx[0] != -1 || pp.rx[1] != -1 || pp.rx[2] != -1 || n_cst != 0u
             || !pl.par_pos.empty() || pl.glue_has_par || wide || pl.cluster_level != 1u || n_ej == 0u || n_tape != 2u
             || n_out != 3u || order < 6u || p.n_par != 0u) {
+            detail::log_message(log_level::debug,
+                                "block mode, v2 cluster phase not applicable: pair pattern " + std::to_string(pp.ok) + ", scaling "
+                                    + std::to_string(pp.sc) + ", reactions " + std::to_string(pp.rx[0]) + ", constants "
+                                    + std::to_string(n_cst) + ", wide " + std::to_string(wide) + ", cluster level "
+                                    + std::to_string(pl.cluster_level) + ", external jets " + std::to_string(n_ej) + ", tape members "
+                                    + std::to_string(n_tape) + ", outputs " + std::to_string(n_out));
             return false;
         }
         if (static_cast<std::uint64_t>(n_ej) * order * 8u >= 65536u || (nc + bs - 1u) / bs > 16u) {

@@ -598,6 +598,156 @@ bool linearise_accelerations(const taylor_program &p, taylor_program &out)
     return true;
 }
 
+// Distinct masses in a pair-interaction system: model::nbody() scales the power of the distance ONCE per pair
+// (s = c * r^-3), multiplies the coordinate differences by it and derives the reactions from those products - scaling,
+// scaled products and reactions are members of the pair's cluster. The v2 cluster phase of block mode (rolled order loop,
+// rows in registers, index-pair convolutions: the kernel of model::nbody(64) with its equal masses) wants the clusters of the
+// EQUAL-mass system: differences, sum of squares, power, three unit products. This pass rewrites the INTERNAL program (the
+// user-visible decomposition is untouched): every product d * s reads r^-3 directly, a node c * (d * r^-3) placed right
+// behind it takes its place for the sums which read it, a reaction c' * (d * s) becomes (c' c) * (d * r^-3), the scaling node
+// goes. Equal to the decomposition to rounding (c (d r^-3) against d (c r^-3); the product of the two constants is formed in
+// double precision). Returns false if nothing has that shape.
+bool externalise_scalings(const taylor_program &p, taylor_program &out)
+{
+    const auto n_eq = p.n_eq;
+    constexpr auto none = std::numeric_limits<std::uint32_t>::max();
+    if (!p.ev_u.empty() || p.n_par != 0u) {
+        return false;
+    }
+    const auto node_of = [&](std::uint32_t u) -> const dc_node & { return p.nodes[u - n_eq]; };
+    const auto is_num = [](const operand &o) { return o.type == operand::kind::num; };
+    const auto scaled = [&](const dc_node &n) {
+        return n.kind == func_kind::prod && n.args.size() == 2u && is_num(n.args[0]) && is_var(n.args[1]) && n.deps.empty();
+    };
+    const auto product = [&](const dc_node &n) {
+        return n.kind == func_kind::prod && n.args.size() == 2u && is_var(n.args[0]) && is_var(n.args[1]) && n.deps.empty();
+    };
+    std::vector<std::vector<std::uint32_t>> readers(p.n_u);
+    std::vector<char> dep_read(p.n_u, 0);
+    for (std::uint32_t u = n_eq; u < p.n_u; ++u) {
+        for (const auto &o : node_of(u).args) {
+            if (is_var(o)) {
+                readers[o.idx].push_back(u);
+            }
+        }
+        for (const auto d : node_of(u).deps) {
+            dep_read[d] = 1;
+        }
+    }
+    std::vector<char> sv_read(p.n_u, 0);
+    for (const auto &d : p.sv_defs) {
+        if (d.type == operand::kind::uvar) {
+            sv_read[d.idx] = 1;
+        }
+    }
+    // Scaling nodes: number * pow, read by products only.
+    std::map<std::uint32_t, std::pair<double, std::uint32_t>> scal;
+    for (std::uint32_t u = n_eq; u < p.n_u; ++u) {
+        const auto &n = node_of(u);
+        if (!scaled(n) || n.args[1].idx < n_eq || node_of(n.args[1].idx).kind != func_kind::pow || dep_read[u] != 0 || sv_read[u] != 0
+            || readers[u].empty()) {
+            continue;
+        }
+        if (std::all_of(readers[u].begin(), readers[u].end(), [&](std::uint32_t r) {
+                const auto &rn = node_of(r);
+                return product(rn) && (rn.args[0].idx == u) != (rn.args[1].idx == u);
+            })) {
+            scal[u] = {n.args[0].value, n.args[1].idx};
+        }
+    }
+    if (scal.empty()) {
+        return false;
+    }
+    // The products which read them; their readers: sums / differences, or reactions number * product.
+    std::map<std::uint32_t, double> scaled_prod;
+    for (const auto &[s_u, cw] : scal) {
+        for (const auto pr : readers[s_u]) {
+            if (dep_read[pr] != 0) {
+                return false;
+            }
+            for (const auto r : readers[pr]) {
+                const auto &rn = node_of(r);
+                const bool lin = rn.deps.empty() && (rn.kind == func_kind::sum || rn.kind == func_kind::sub || scaled(rn));
+                if (!lin) {
+                    return false;
+                }
+            }
+            scaled_prod[pr] = cw.first;
+        }
+    }
+    // New numbering: the scalings go, number * product right behind every product.
+    std::vector<std::uint32_t> new_idx(p.n_u, none), a_idx(p.n_u, none);
+    std::uint32_t next = n_eq;
+    for (std::uint32_t i = 0; i < n_eq; ++i) {
+        new_idx[i] = i;
+    }
+    for (std::uint32_t u = n_eq; u < p.n_u; ++u) {
+        if (scal.count(u) != 0u) {
+            continue;
+        }
+        new_idx[u] = next++;
+        if (scaled_prod.count(u) != 0u) {
+            a_idx[u] = next++;
+        }
+    }
+    const auto uvar = [](std::uint32_t idx) {
+        operand o;
+        o.type = operand::kind::uvar;
+        o.idx = idx;
+        return o;
+    };
+    const auto num = [](double v) {
+        operand o;
+        o.type = operand::kind::num;
+        o.value = v;
+        return o;
+    };
+    // (What a reader of u reads now.)
+    const auto reads = [&](std::uint32_t u) { return a_idx[u] != none ? a_idx[u] : new_idx[u]; };
+    out = p;
+    out.nodes.clear();
+    for (std::uint32_t u = n_eq; u < p.n_u; ++u) {
+        if (scal.count(u) != 0u) {
+            continue;
+        }
+        auto nn = node_of(u);
+        if (scaled_prod.count(u) != 0u) {
+            for (auto &o : nn.args) {
+                o.idx = (scal.count(o.idx) != 0u) ? new_idx[scal.at(o.idx).second] : reads(o.idx);
+            }
+            out.nodes.push_back(std::move(nn));
+            dc_node a;
+            a.kind = func_kind::prod;
+            a.args = {num(scaled_prod.at(u)), uvar(new_idx[u])};
+            out.nodes.push_back(std::move(a));
+            continue;
+        }
+        if (scaled(nn) && scaled_prod.count(nn.args[1].idx) != 0u) {
+            // Reaction: (c' c) * unit product.
+            const auto pr = nn.args[1].idx;
+            nn.args = {num(nn.args[0].value * scaled_prod.at(pr)), uvar(new_idx[pr])};
+            out.nodes.push_back(std::move(nn));
+            continue;
+        }
+        for (auto &o : nn.args) {
+            if (o.type == operand::kind::uvar) {
+                o.idx = reads(o.idx);
+            }
+        }
+        for (auto &d : nn.deps) {
+            d = new_idx[d];
+        }
+        out.nodes.push_back(std::move(nn));
+    }
+    for (auto &d : out.sv_defs) {
+        if (d.type == operand::kind::uvar) {
+            d.idx = reads(d.idx);
+        }
+    }
+    out.n_u = next;
+    return true;
+}
+
 namespace
 {
 

@@ -52,12 +52,20 @@ def small_nbody_case(nb, kernel):
     return hy.model.nbody(nb, masses=m), st, None, 20.0, dict(high_accuracy=True, cluster_kernel=kernel)
 
 
+def nbody_plummer_case(nb, default_masses):
+    st = configs.plummer_nbody_state(nb, n, seed=5)
+    kw = {} if default_masses else {"masses": list(1.0 / (1.0 + np.arange(nb)) ** 2 * nb / 4.0)}
+    return hy.model.nbody(nb, **kw), st, None, 0.05
+
+
 def two_massive_case():
     st = configs.two_body_state(n, perturb=1e-3, seed=3)
     return hy.model.nbody(2, masses=[1.0, 0.5]), st, None, 20.0
 
 
-cases = {"nbody(2), both massive": two_massive_case, "nbody(3) on v5": lambda: small_nbody_case(3, "v5"), "nbody(3) on v3": lambda: small_nbody_case(3, "v3"),
+cases = {"nbody(12), default masses": lambda: nbody_plummer_case(12, True), "nbody(12), distinct masses": lambda: nbody_plummer_case(12, False),
+         "nbody(16), default masses": lambda: nbody_plummer_case(16, True), "nbody(16), distinct masses": lambda: nbody_plummer_case(16, False),
+         "nbody(2), both massive": two_massive_case, "nbody(3) on v5": lambda: small_nbody_case(3, "v5"), "nbody(3) on v3": lambda: small_nbody_case(3, "v3"),
          "nbody(4) on v5": lambda: small_nbody_case(4, "v5"), "nbody(4) on v3": lambda: small_nbody_case(4, "v3"),
          "np1body(6)": np1body_case, "cr3bp": cr3bp_case, "fixed_centres(100)": lambda: centres_case(False),
          "mascon(100)": lambda: centres_case(True), "nbody(6), par[] masses": par_masses_case, "pendulum": pendulum_case}

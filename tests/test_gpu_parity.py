@@ -1301,6 +1301,34 @@ def test_block_mode_nonuniform_masses_and_massless_bodies():
     assert nbody_err(tb.state, ob.state.reshape(6 * nb2, 16)) <= 1e5 * EPS
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("nb", [12, 16])
+def test_block_v2_with_distinct_masses_vs_oracle(nb):
+    """model::nbody() with DISTINCT masses and more than 64 pairs: the scalings of the pair products are moved out of the
+    clusters in the internal program (externalise_scalings()), which takes the system to the v2 cluster phase of block mode
+    like its equal-mass sibling (before round 6: the first-generation cluster phase with 150 ... 186 spilled registers, 2.7x
+    slower). One step with Taylor coefficients and a short propagation against the oracle on the USER's decomposition."""
+    n = 24
+    masses = list(1.0 / (1.0 + np.arange(nb)) ** 2 * nb / 4.0)
+    st = configs.plummer_nbody_state(nb, n, seed=31, jitter=1e-6)
+    ta = hy.taylor_adaptive_batch(hy.model.nbody(nb, masses=masses), st, n)
+    assert "v2 cluster phase" in ta.hip_source_mode and "scalings of the pair products moved out" in ta.hip_source_mode
+    ora = ho.OracleIntegrator(ho.nbody(nb, masses=masses), st, n)
+    ta.step(write_tc=True)
+    ora.step(wtc=True)
+    h_g = np.array([h for _, h in ta.step_res])
+    h_o = np.array([h for _, h in ora.step_res])
+    assert np.max(np.abs(h_g - h_o) / np.abs(h_o)) <= 1e6 * EPS
+    tc_o = ora.tc.reshape(6 * nb, ora.order + 1, n)
+    scale = np.max(np.abs(tc_o), axis=2, keepdims=True) + 1e-300
+    assert np.max(np.abs(np.asarray(ta.tc).reshape(tc_o.shape) - tc_o) / scale) <= 1e6 * EPS
+    assert nbody_err(ta.state, ora.state.reshape(6 * nb, n)) <= 1e5 * EPS
+    ta.propagate_until(0.02)
+    ora.propagate_until(0.02)
+    assert max(abs(a[3] - b[3]) for a, b in zip(ta.propagate_res, ora.prop_res)) <= 1
+    assert nbody_err(ta.state, ora.state.reshape(6 * nb, n)) <= 1e7 * EPS
+
+
 def _random_system(m, rng, n_var=3, extended=False):
     """The same pseudo-random ODE system through expression module m (product or oracle)."""
     if m is ho:
