@@ -2141,8 +2141,19 @@ emitted_module emit_cluster_v1(const taylor_program &p, const emit_options &opts
     src << "const u64 N = a.N;\n";
     src << "double *const slab = lds_slab + (wib * " << spw << "u + q) * " << slab_stride << "u;\n";
     src << "const u64 gwave = (u64)blockIdx.x * " << wpb << "u + wib;\n";
-    src << "double *const jetw = a.scratch + gwave * " << static_cast<std::uint64_t>(order + 1u) * spw * n_col
-        << "ull;\n";
+    // The jets of the state variables of the systems of a wavefront ([order][system][variable]): in LDS when they fit next to
+    // the slab (round 6: one workgroup per CU runs anyway - one wavefront per SIMD -, and through global scratch they cost
+    // the chain of 16 pendula 44 GB of HBM traffic per launch, 1.2 TB/s), otherwise in a per-wavefront global scratch.
+    const std::uint64_t jet_doubles_per_wave = static_cast<std::uint64_t>(order + 1u) * spw * n_col;
+    const bool jets_in_lds
+        = (static_cast<std::uint64_t>(wpb) * spw * slab_stride + static_cast<std::uint64_t>(wpb) * jet_doubles_per_wave) * 8u + 2048u
+          <= 160u * 1024u;
+    if (jets_in_lds) {
+        src << "__shared__ double lds_jets[" << static_cast<std::uint64_t>(wpb) * jet_doubles_per_wave << "];\n";
+        src << "double *const jetw = lds_jets + wib * " << jet_doubles_per_wave << "u;\n";
+    } else {
+        src << "double *const jetw = a.scratch + gwave * " << jet_doubles_per_wave << "ull;\n";
+    }
     src << "double *const jetl = jetw + q * " << n_col << "u + l;\n";
     // Per-lane table entries (loop invariant).
     for (std::size_t t = 0; t < utbl.size(); ++t) {
@@ -2305,7 +2316,7 @@ if (l == 0u && live) {
     ret.lds_bytes = 0;
     ret.mode = emit_mode::cluster;
     ret.n_statements = e.n_stmt;
-    ret.scratch_per_wave = static_cast<std::uint64_t>(order + 1u) * spw * n_col;
+    ret.scratch_per_wave = jets_in_lds ? 0u : jet_doubles_per_wave;
     ret.persistent = true;
     ret.tc_optional = true;
     if (classes.size() == 1u) {
@@ -2320,7 +2331,8 @@ if (l == 0u && live) {
         ret.notes += ": " + std::to_string(nc) + " clusters";
     }
     ret.notes += ", L=" + std::to_string(L) + ", " + std::to_string(pl.n_slots) + " LDS slots, "
-                 + std::to_string(pl.groups.size()) + " glue groups, " + std::to_string(utbl.size()) + " slot tables";
+                 + std::to_string(pl.groups.size()) + " glue groups, " + std::to_string(utbl.size()) + " slot tables, jets in "
+                 + (jets_in_lds ? "LDS" : "global scratch");
     (void)n_slots_tot;
     return ret;
 }
