@@ -708,6 +708,42 @@ def test_linearised_accelerations_of_the_internal_program(case, monkeypatch):
         assert np.array_equal(tc_p, tc_r)
 
 
+def test_externalised_scalings_of_the_internal_program(monkeypatch):
+    """externalise_scalings(): model::nbody() with DISTINCT masses and more than 64 pairs keeps scaling, scaled products and
+    reactions inside the pair clusters - not the shape of block mode's v2 cluster phase. The planner moves them out in the
+    INTERNAL program (every product reads r^-3 directly, c * (d * r^-3) for d * (c * r^-3), reactions (c' c) * (d * r^-3)): the
+    clusters are those of the equal-mass system. The oracle's interpreter on the rewritten program agrees with the
+    decomposition to rounding (1e3 eps on the Taylor coefficients, 1e4 eps on the step size)."""
+    nb, n = 12, 5
+    masses = list(1.0 / (1.0 + np.arange(nb)) ** 2 * nb / 4.0)
+    sys_g, sys_o = hy.model.nbody(nb, masses=masses), ho.nbody(nb, masses=masses)
+    n_eq = 6 * nb
+    rng = np.random.default_rng(12)
+    st = rng.uniform(-1.0, 1.0, (n_eq, n)) * 0.3
+    st[0::6] += 5.0 * np.arange(nb)[:, None]
+    st[1::6] += 2.0 * np.arange(nb)[:, None] ** 2 % 7
+    ta = hy.taylor_adaptive_batch(sys_g, st, n)
+    mode, prog = ta.hip_source_mode, ta.internal_program
+    assert "v2 cluster phase" in mode and "scalings of the pair products moved out of the clusters" in mode, mode
+    n_pairs = nb * (nb - 1) // 2
+    # No scaled power any more (number * pow), six scaled unit products per pair.
+    u_of = {n_eq + i: ln for i, ln in enumerate(prog[: len(prog) - n_eq])}
+    scaled = [ln for ln in prog if ln.startswith("prod(") and not ln.startswith("prod(u_")]
+    assert len(scaled) == 6 * n_pairs
+    for ln in scaled:
+        src = int(ln.split("u_")[1].rstrip(")"))
+        assert u_of[src].startswith("prod(u_"), (ln, u_of[src])
+    plain = ho.OracleIntegrator(sys_o, st, n)
+    rewritten = _oracle_on_program(monkeypatch, prog, n_eq, st, n)
+    plain.step(wtc=True)
+    rewritten.step(wtc=True)
+    h_p, h_r = np.array([h for _, h in plain.step_res]), np.array([h for _, h in rewritten.step_res])
+    assert np.max(np.abs(h_p - h_r) / np.abs(h_p)) <= 1e4 * 2.220446049250313e-16
+    tc_p, tc_r = plain.tc.reshape(n_eq, -1, n), rewritten.tc.reshape(n_eq, -1, n)
+    scale = np.max(np.abs(tc_p), axis=2, keepdims=True) + 1e-300
+    assert np.max(np.abs(tc_p - tc_r) / scale) <= 1e3 * 2.220446049250313e-16
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # Mixed models (round 6): nonlinear sub-DAGs of SEVERAL shapes in one system. The planner groups the clusters into
 # classes of identical shape and dependency level and runs every class as its own section of straight-line code, cluster i
