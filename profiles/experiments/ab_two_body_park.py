@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Interleaved A/B of the round-6 items of the straight-line stepper on the two-body workload (BASELINE.json configs[2]) in one
-process: cold coefficients parked in LDS (HEYOKA_AMD_UNROLLED_PARK), literal zeros folded / Horner steps over leading zeros
-collapsed (HEYOKA_AMD_UNROLLED_TRIM), machine LICM (HEYOKA_AMD_UNROLLED_LICM), one accumulator for the sum of squares
-(HEYOKA_AMD_UNROLLED_MERGE_SSQ). The switches are read when an integrator is built.
+process: literal zeros and scaled copies folded / Horner steps over leading zeros collapsed (HEYOKA_AMD_UNROLLED_TRIM), one
+accumulator for the sum of squares (HEYOKA_AMD_UNROLLED_MERGE_SSQ), velocity histories re-derived + one-pass evaluation
+(HEYOKA_AMD_UNROLLED_DERIVE), wavefronts per SIMD (HEYOKA_AMD_UNROLLED_WAVES). The switches are read when an integrator is built.
 usage: ab_two_body_park.py [--systems N] [--rounds R]"""
 import argparse, json, os, sys
 import numpy as np
@@ -21,14 +21,14 @@ args = ap.parse_args()
 n = args.systems
 sys_ = hy.model.nbody(2, masses=[1.0, 0.0])
 st = configs.two_body_state(n, perturb=1e-12, seed=42)
-OFF = {"HEYOKA_AMD_UNROLLED_PARK": "0", "HEYOKA_AMD_UNROLLED_TRIM": "0", "HEYOKA_AMD_UNROLLED_LICM": "1", "HEYOKA_AMD_UNROLLED_MERGE_SSQ": "0"}
+OFF = {"HEYOKA_AMD_UNROLLED_TRIM": "0", "HEYOKA_AMD_UNROLLED_MERGE_SSQ": "0", "HEYOKA_AMD_UNROLLED_DERIVE": "0"}
+# (HEYOKA_AMD_UNROLLED_PARK / _LICM: switches of the first runs of profiles/r06_two_body_unrolled_ab.log, removed with the code they switched.)
 variants = [
-    ("round 5 kernel (all four off)", dict(OFF)),
-    ("+ zeros folded / trimmed Horner", {**OFF, "HEYOKA_AMD_UNROLLED_TRIM": "1"}),
-    ("+ cold coefficients parked in LDS", {**OFF, "HEYOKA_AMD_UNROLLED_TRIM": "1", "HEYOKA_AMD_UNROLLED_PARK": "-1"}),
-    ("+ machine LICM off", {**OFF, "HEYOKA_AMD_UNROLLED_TRIM": "1", "HEYOKA_AMD_UNROLLED_PARK": "-1", "HEYOKA_AMD_UNROLLED_LICM": "0"}),
-    ("+ one accumulator for the sum of squares (default)", {}),
-    ("default without parking", {"HEYOKA_AMD_UNROLLED_PARK": "0"}),
+    ("round 5 kernel (all three off)", dict(OFF)),
+    ("+ zeros and scaled copies folded, trimmed Horner", {**OFF, "HEYOKA_AMD_UNROLLED_TRIM": "1"}),
+    ("+ one accumulator for the sum of squares", {**OFF, "HEYOKA_AMD_UNROLLED_TRIM": "1", "HEYOKA_AMD_UNROLLED_MERGE_SSQ": "1"}),
+    ("+ velocity histories re-derived, one wavefront per SIMD", {"HEYOKA_AMD_UNROLLED_WAVES": "1"}),
+    ("default: + two wavefronts per SIMD", {}),
 ]
 if args.only_extra:
     variants = variants[:1]
